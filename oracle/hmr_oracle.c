@@ -1,0 +1,648 @@
+/*
+ * TEST INFRASTRUCTURE - CPU oracle, see hmr_oracle.h.
+ *
+ * Plain-C restatement of the reference's hot-path kernels.  Arithmetic follows
+ * the reference's scalar sources (the readable spec) with the
+ * two SSE4.2-path deviations that are part of the contract:
+ *   Q1  quant rounding offset 85 on non-I slices (hmr_sse42_functions_quant.c:47)
+ *   Q2  byte-widened modified_variance (hmr_sse42_functions_pixel.c:953-1103)
+ * and signed-saturating packs (_mm_packs_epi32) where the SSE path packs to i16.
+ * Each function cites the reference file:line it restates.
+ */
+#include "hmr_oracle.h"
+
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline int clip3(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline int16_t sat16(int32_t v) { return (int16_t)clip3(v, -32768, 32767); }
+static inline int ilog2(int n) { int s = 0; while ((1 << s) < n) s++; return s; }
+
+/* ------------------------------------------------------------------ tables */
+
+/* HEVC transform basis: T32[k][n] = c[(k*(2n+1)) mod 128] with the 33 integer
+ * cosine samples of the standard; smaller sizes are sub-sampled rows.  Equals
+ * g_aiT4..g_aiT32 of hmr_transform.c:54-128. */
+static const int16_t k_cos64[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+				    61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9,  4,  0};
+static int16_t g_dct[4][32 * 32];
+/* DST-VII 4x4, hmr_transform.c:133-152 written as a matrix (coeff[k] = sum_n M[k][n] x[n]) */
+static const int16_t k_dst4[16] = {29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29};
+
+/* default scaling lists, hmr_tables.h:53-82 (HEVC spec Table 7-6) */
+static const int16_t k_sl_intra8[64] = {16, 16, 16, 16, 17, 18, 21, 24, 16, 16, 16, 16, 17, 19, 22, 25, 16, 16, 17, 18, 20, 22,
+					25, 29, 16, 16, 18, 21, 24, 27, 31, 36, 17, 17, 20, 24, 30, 35, 41, 47, 18, 19, 22, 27,
+					35, 44, 54, 65, 21, 22, 25, 31, 41, 54, 70, 88, 24, 25, 29, 36, 47, 65, 88, 115};
+static const int16_t k_sl_inter8[64] = {16, 16, 16, 16, 17, 18, 20, 24, 16, 16, 16, 17, 18, 20, 24, 25, 16, 16, 17, 18, 20, 24,
+					25, 28, 16, 17, 18, 20, 24, 25, 28, 33, 17, 18, 20, 24, 25, 28, 33, 41, 18, 20, 24, 25,
+					28, 33, 41, 54, 20, 24, 25, 28, 33, 41, 54, 71, 24, 25, 28, 33, 41, 54, 71, 91};
+
+static uint32_t g_scan[4][6][32 * 32];           /* [mode][log2 size] */
+static int32_t g_quant[4][6][6][32 * 32];        /* [log2 size - 2][list][rem] */
+static int32_t g_dequant[4][6][6][32 * 32];
+static int g_tables_ready;
+
+static int cos_sample(int m)
+{
+	m &= 127;
+	if (m > 64) m = 128 - m;
+	return m <= 32 ? k_cos64[m] : -k_cos64[64 - m];
+}
+
+/* up-right diagonal scan of a w x w block, hmr_tables.c:67-90 */
+static void diag_scan(uint32_t *out, int w)
+{
+	int pos = 0, line, n = w * w;
+	for (line = 0; pos < n; line++) {
+		int prim = line, scnd = 0;
+		while (prim >= w) { scnd++; prim--; }
+		while (prim >= 0 && scnd < w) { out[pos++] = (uint32_t)(prim * w + scnd); scnd++; prim--; }
+	}
+}
+
+static void build_tables(void)
+{
+	int l, k, n, mode, list, rem;
+	uint32_t cg8[64];
+	if (g_tables_ready) return;
+	for (l = 2; l <= 5; l++) {
+		int N = 1 << l, step = 32 / N;
+		for (k = 0; k < N; k++)
+			for (n = 0; n < N; n++)
+				g_dct[l - 2][k * N + n] = (int16_t)cos_sample(k * step * (2 * n + 1));
+	}
+	/* scan pyramid, hmr_tables.c:62-188 (sizes 2..32; mode 0 "zigzag" is never filled by the reference) */
+	diag_scan(cg8, 8);
+	for (l = 1; l <= 5; l++) {
+		int w = 1 << l;
+		uint32_t *H = g_scan[ORA_SCAN_HOR][l], *V = g_scan[ORA_SCAN_VER][l], *D = g_scan[ORA_SCAN_DIAG][l];
+		if (w == 2 || w == 4)
+			diag_scan(D, w);
+		if (w > 4) {
+			int side = w >> 2, blks = side * side, b;
+			uint32_t inner[16];
+			const uint32_t *cg = (w == 32) ? cg8 : g_scan[ORA_SCAN_DIAG][l - 2];
+			diag_scan(inner, 4);
+			for (b = 0; b < blks; b++) {
+				int oy = (int)cg[b] / side, ox = (int)cg[b] - oy * side, i;
+				for (i = 0; i < 16; i++) {
+					int py = (int)inner[i] >> 2, px = (int)inner[i] & 3;
+					D[16 * b + i] = (uint32_t)(py * w + px + 4 * (ox + oy * w));
+				}
+			}
+		}
+		if (w > 2) {
+			int side = w >> 2, by, bx, x, y, cnt = 0;
+			for (by = 0; by < side; by++)
+				for (bx = 0; bx < side; bx++)
+					for (y = 0; y < 4; y++)
+						for (x = 0; x < 4; x++)
+							H[cnt++] = (uint32_t)(y * w + x + by * 4 * w + bx * 4);
+			cnt = 0;
+			for (bx = 0; bx < side; bx++)
+				for (by = 0; by < side; by++)
+					for (x = 0; x < 4; x++)
+						for (y = 0; y < 4; y++)
+							V[cnt++] = (uint32_t)(y * w + x + by * 4 * w + bx * 4);
+		} else {
+			H[0] = 0; H[1] = 1; H[2] = 2; H[3] = 3;
+			V[0] = 0; V[1] = 2; V[2] = 1; V[3] = 3;
+		}
+	}
+	/* quant / dequant pyramids, hmr_tables.c:221-250 + hmr_encoder_lib.c:112-140 */
+	{
+		static const int qs[6] = {26214, 23302, 20560, 18396, 16384, 14564};
+		static const int iqs[6] = {40, 45, 51, 57, 64, 72};
+		for (l = 2; l <= 5; l++) {
+			int size = 1 << l, ms = size < 8 ? size : 8, ratio = size / ms, nlist = (l == 5) ? 2 : 6;
+			for (list = 0; list < 6; list++) {
+				int src_list = list;
+				const int16_t *tab;
+				if (l == 5) src_list = (list == 0) ? 0 : 1; /* [3][3] aliases [3][1]; other 32x32 lists are unused */
+				(void)nlist;
+				if (l == 2) tab = NULL;
+				else if (l == 5) tab = src_list < 1 ? k_sl_intra8 : k_sl_inter8;
+				else tab = src_list < 3 ? k_sl_intra8 : k_sl_inter8;
+				for (rem = 0; rem < 6; rem++) {
+					int i, j;
+					for (j = 0; j < size; j++)
+						for (i = 0; i < size; i++) {
+							int t = tab ? tab[ms * (j / ratio) + i / ratio] : 16;
+							g_quant[l - 2][list][rem][j * size + i] = (qs[rem] << 4) / t;
+							g_dequant[l - 2][list][rem][j * size + i] = iqs[rem] * t;
+						}
+					if (ratio > 1) {
+						g_quant[l - 2][list][rem][0] = (qs[rem] << 4) / 16;
+						g_dequant[l - 2][list][rem][0] = iqs[rem] * 16;
+					}
+				}
+			}
+		}
+	}
+	(void)mode; (void)n;
+	g_tables_ready = 1;
+}
+
+const uint32_t *ora_scan_table(int scan_mode, int log2_size) { build_tables(); return g_scan[scan_mode][log2_size]; }
+const int32_t *ora_quant_table(int log2_size, int list, int rem) { build_tables(); return g_quant[log2_size - 2][list][rem]; }
+const int32_t *ora_dequant_table(int log2_size, int list, int rem) { build_tables(); return g_dequant[log2_size - 2][list][rem]; }
+const int16_t *ora_dct_matrix(int log2_size) { build_tables(); return g_dct[log2_size - 2]; }
+const int16_t *ora_dst_matrix(void) { return k_dst4; }
+
+/* ------------------------------------------------------------------ K6 copies */
+
+/* hmr_sse42_functions_pixel.c:152 - width 4, 8 or a multiple of 16 at the call sites;
+ * the SSE code rounds other widths up to 16, the contract is the [0,width) region. */
+void ora_copy_16_16(const int16_t *src, uint32_t src_stride, int16_t *dst, uint32_t dst_stride, int height, int width)
+{
+	int j;
+	for (j = 0; j < height; j++)
+		memcpy(dst + (size_t)j * dst_stride, src + (size_t)j * src_stride, (size_t)width * sizeof(int16_t));
+}
+
+/* hmr_sse42_functions_pixel.c:236 - u8 -> i16 zero extension */
+void ora_copy_8_16(const uint8_t *src, uint32_t src_stride, int16_t *dst, uint32_t dst_stride, int height, int width)
+{
+	int i, j;
+	for (j = 0; j < height; j++)
+		for (i = 0; i < width; i++)
+			dst[(size_t)j * dst_stride + i] = (int16_t)src[(size_t)j * src_stride + i];
+}
+
+/* hmr_sse42_functions_pixel.c:319 - i16 -> u8 with unsigned saturation (_mm_packus_epi16) */
+void ora_copy_16_8(const int16_t *src, uint32_t src_stride, uint8_t *dst, uint32_t dst_stride, int height, int width)
+{
+	int i, j;
+	for (j = 0; j < height; j++)
+		for (i = 0; i < width; i++)
+			dst[(size_t)j * dst_stride + i] = (uint8_t)clip3(src[(size_t)j * src_stride + i], 0, 255);
+}
+
+/* ------------------------------------------------------------------ K1-K5 */
+
+/* hmr_sse42_functions_pixel.c:462 (scalar hmr_motion_intra.c:51).  The SSE lanes accumulate
+ * |a-b| in u16; exact for 8-bit samples, which is the only domain the encoder feeds it
+ * (SURVEY.md §8 Q10).  Any size other than 4/8/16/32 takes the 64x64 path in the reference. */
+uint32_t ora_sad(const int16_t *src, uint32_t src_stride, const int16_t *pred, uint32_t pred_stride, int size)
+{
+	uint32_t acc = 0;
+	int x, y;
+	if (size != 4 && size != 8 && size != 16 && size != 32) size = 64;
+	for (y = 0; y < size; y++)
+		for (x = 0; x < size; x++)
+			acc += (uint32_t)abs((int16_t)(src[(size_t)y * src_stride + x] - pred[(size_t)y * pred_stride + x]));
+	return acc;
+}
+
+/* hmr_sse42_functions_pixel.c:728: (a-b) in i16, squared and summed in 32 bits; pred_stride may be 0 */
+uint32_t ora_ssd16b(const int16_t *src, uint32_t src_stride, const int16_t *pred, uint32_t pred_stride, int size)
+{
+	uint32_t acc = 0;
+	int x, y;
+	if (size != 4 && size != 8 && size != 16 && size != 32) size = 64;
+	for (y = 0; y < size; y++)
+		for (x = 0; x < size; x++) {
+			int32_t d = (int16_t)(src[(size_t)y * src_stride + x] - pred[(size_t)y * pred_stride + x]);
+			acc += (uint32_t)(d * d);
+		}
+	return acc;
+}
+
+/* hmr_sse42_functions_pixel.c:817 (scalar hmr_motion_intra.c:152) */
+void ora_predict(const int16_t *orig, int orig_stride, const int16_t *pred, int pred_stride, int16_t *residual, int residual_stride, int size)
+{
+	int x, y;
+	for (y = 0; y < size; y++)
+		for (x = 0; x < size; x++)
+			residual[y * residual_stride + x] = (int16_t)(orig[y * orig_stride + x] - pred[y * pred_stride + x]);
+}
+
+/* hmr_sse42_functions_pixel.c:919: saturating i16 add, then clip to 0..255; residual_stride may be 0 */
+void ora_reconst(const int16_t *pred, int pred_stride, const int16_t *residual, int residual_stride, int16_t *decoded, int decoded_stride, int size)
+{
+	int x, y;
+	for (y = 0; y < size; y++)
+		for (x = 0; x < size; x++)
+			decoded[y * decoded_stride + x] = (int16_t)clip3(sat16(pred[y * pred_stride + x] + residual[y * residual_stride + x]), 0, 255);
+}
+
+/* hmr_sse42_functions_pixel.c:1123 (Q2).  The SSE code loads int16 rows and zero-extends their
+ * BYTES: per row it consumes `size` bytes (for size >= 16: bytes [32g,32g+8) and [32g+16,32g+24)
+ * of every 16-sample group g), i.e. the low and high bytes of half of the samples. */
+uint32_t ora_modified_variance(const int16_t *p, int size, int stride, int modif)
+{
+	uint32_t sum = 0, var = 0;
+	int pass, j, k, avg = 0;
+	for (pass = 0; pass < 2; pass++) {
+		for (j = 0; j < size; j++) {
+			const uint8_t *row = (const uint8_t *)(p + (size_t)j * stride);
+			for (k = 0; k < size; k++) {
+				int off = size < 16 ? k : (k >> 4) * 32 + ((k >> 3) & 1) * 16 + (k & 7);
+				int v = row[off];
+				if (!pass) sum += (uint32_t)v;
+				else {
+					int16_t d = (int16_t)(1 + (int16_t)((int16_t)(v - avg) * (int16_t)modif));
+					var += (uint32_t)((int32_t)d * d);
+				}
+			}
+		}
+		if (!pass) avg = (int)(sum / (uint32_t)(size * size));
+	}
+	return var;
+}
+
+/* ------------------------------------------------------------------ K7/K8 intra prediction */
+
+/* hmr_motion_intra.c:408-439 (SSE: hmr_sse42_functions_prediction.c:199; full-width write) */
+void ora_intra_planar(int16_t *pred, int pred_stride, const int16_t *adi, int adi_size, int cu_size)
+{
+	const int16_t *mid = adi + (adi_size >> 1);
+	int shift = ilog2(cu_size), i, j;
+	int top_row[64], bottom_row[64], right_col[64], left_col[64];
+	int bl = mid[-(cu_size + 1)], tr = mid[cu_size + 1];
+	for (i = 0; i < cu_size; i++) {
+		int left = mid[-(i + 1)], top = mid[i + 1];
+		bottom_row[i] = bl - top;
+		right_col[i] = tr - left;
+		top_row[i] = top << shift;
+		left_col[i] = left << shift;
+	}
+	for (j = 0; j < cu_size; j++) {
+		int hor = left_col[j] + cu_size;
+		for (i = 0; i < cu_size; i++) {
+			hor += right_col[j];
+			top_row[i] += bottom_row[i];
+			pred[j * pred_stride + i] = (int16_t)((hor + top_row[i]) >> (shift + 1));
+		}
+	}
+}
+
+/* hmr_motion_intra.c:482-625 (SSE: hmr_sse42_functions_prediction.c:926); ctu->top/left are always 1 */
+void ora_intra_angular(int16_t *pred, int pred_stride, const int16_t *adi, int adi_size, int cu_size, int cu_mode, int is_luma)
+{
+	static const int ang_table[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};            /* hmr_encoder_lib.c:35 */
+	static const int inv_ang_table[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256}; /* :36 */
+	const int16_t *mid = adi + (adi_size >> 1);
+	int is_dc = cu_mode < 2, is_hor = !is_dc && cu_mode < 18, is_ver = !is_dc && !is_hor;
+	int pred_angle = is_ver ? cu_mode - 26 : is_hor ? -(cu_mode - 10) : 0;
+	int abs_angle = abs(pred_angle), sign = pred_angle < 0 ? -1 : (pred_angle > 0 ? 1 : 0);
+	int inv_angle = inv_ang_table[abs_angle];
+	int i, j;
+	abs_angle = ang_table[abs_angle];
+	pred_angle = sign * abs_angle;
+	if (is_dc) {
+		int acc = 0, dc;
+		for (i = 1; i <= cu_size; i++) acc += mid[i];
+		for (i = 1; i <= cu_size; i++) acc += mid[-i];
+		dc = (uint16_t)((acc + cu_size) / (2 * cu_size));
+		for (j = 0; j < cu_size; j++)
+			for (i = 0; i < cu_size; i++)
+				pred[j * pred_stride + i] = (uint8_t)dc;
+		if (cu_size <= 16 && cu_mode == 1 && is_luma) {
+			pred[0] = (int16_t)((mid[-1] + mid[1] + 2 * pred[0] + 2) >> 2);
+			for (i = 1; i < cu_size; i++) pred[i] = (int16_t)((mid[1 + i] + 3 * pred[i] + 2) >> 2);
+			for (j = 1; j < cu_size; j++) pred[j * pred_stride] = (int16_t)((mid[-1 - j] + 3 * pred[j * pred_stride] + 2) >> 2);
+		}
+		return;
+	}
+	{
+		int16_t above[2 * 64 + 1 + 64], left[2 * 64 + 1 + 64];
+		int16_t *ref_main, *ref_side;
+		int filter = is_luma ? (cu_size <= 16) : 0;
+		int s1 = is_hor ? 1 : pred_stride, s2 = is_hor ? pred_stride : 1;
+		memset(above, 0, sizeof above);
+		memset(left, 0, sizeof left);
+		if (pred_angle < 0) {
+			int inv_sum = 128;
+			for (i = 0; i < cu_size + 1; i++) { above[i + cu_size - 1] = mid[i]; left[i + cu_size - 1] = mid[-i]; }
+			ref_main = (is_ver ? above : left) + (cu_size - 1);
+			ref_side = (is_ver ? left : above) + (cu_size - 1);
+			for (i = -1; i > ((cu_size * pred_angle) >> 5); i--) {
+				inv_sum += inv_angle;
+				ref_main[i] = ref_side[inv_sum >> 8];
+			}
+		} else {
+			for (i = 0; i < 2 * cu_size + 1; i++) { above[i] = mid[i]; left[i] = mid[-i]; }
+			ref_main = is_ver ? above : left;
+			ref_side = is_ver ? left : above;
+		}
+		if (pred_angle == 0) {
+			for (j = 0; j < cu_size; j++)
+				for (i = 0; i < cu_size; i++)
+					pred[j * s1 + i * s2] = (uint8_t)ref_main[i + 1];
+			if (filter)
+				for (i = 0; i < cu_size; i++)
+					pred[i * s1] = (int16_t)clip3(pred[i * s1] + ((ref_side[i + 1] - ref_side[0]) >> 1), 0, 255);
+		} else {
+			int pos = 0;
+			for (j = 0; j < cu_size; j++) {
+				int delta, fract;
+				pos += pred_angle;
+				delta = pos >> 5;
+				fract = pos & 31;
+				for (i = 0; i < cu_size; i++) {
+					int idx = i + delta + 1;
+					pred[j * s1 + i * s2] = fract ? (uint8_t)(((32 - fract) * ref_main[idx] + fract * ref_main[idx + 1] + 16) >> 5)
+								      : (uint8_t)ref_main[idx];
+				}
+			}
+		}
+	}
+}
+
+/* ------------------------------------------------------------------ K19 intra reference build */
+
+/* hmr_motion_intra.c:246-390 with the partition node flattened: left/top/bottom_left/top_right are the
+ * node's neighbour flags, bl_size / tr_size the reference's left_bottom_size / top_right_size
+ * (min(n, rows/cols left inside the picture), :289,335).  `decoded` points at the top-left corner
+ * sample (-1,-1).  adi[0] is the bottom-most bottom-left sample, adi[2n] the corner, adi[4n] the
+ * right-most top-right sample. */
+void ora_fill_reference_samples(const int16_t *decoded, int stride, int n, int left, int top, int bottom_left, int top_right,
+				int bl_size, int tr_size, int16_t *adi)
+{
+	int adi_size = 4 * n + 1, i;
+	int16_t first_sample = 0, last_sample = 0;
+	int16_t *pad_left = adi, *pad_top = adi;
+	int pad_left_size = 0, pad_top_size = 0;
+	int16_t *ptr;
+	const int16_t *ref;
+	if (!left && !top) {
+		for (i = 0; i < adi_size; i++) adi[i] = 128;
+		return;
+	}
+	ref = decoded + n * stride;
+	ptr = adi + n;
+	if (left) {
+		for (i = 0; i < n; i++) *ptr++ = ref[-i * stride];
+		first_sample = ptr[-n];
+		last_sample = ptr[-1];
+	} else {
+		pad_left = ptr;
+		pad_left_size = n;
+	}
+	ref = decoded + (n + 1) * stride;
+	ptr = adi + n - 1;
+	if (bottom_left) {
+		for (i = 0; i < bl_size; i++) *ptr-- = ref[i * stride];
+		first_sample = ptr[1];
+		if (bl_size != n) { pad_left = adi; pad_left_size = n - bl_size; }
+	} else {
+		pad_left = adi;
+		if (left) pad_left_size = n;
+		else pad_left_size += n;
+	}
+	ptr = adi + 2 * n + 1;
+	ref = decoded + 1;
+	if (top) {
+		for (i = 0; i < n; i++) *ptr++ = *ref++;
+		if (!left) first_sample = ptr[-n];
+		last_sample = ptr[-1];
+	} else {
+		pad_top = ptr;
+		pad_top_size = n;
+	}
+	if (top_right) {
+		for (i = 0; i < tr_size; i++) *ptr++ = *ref++;
+		last_sample = ptr[-1];
+		if (tr_size != n) { pad_top = ptr; pad_top_size = n - tr_size; }
+	} else {
+		if (top) { pad_top = ptr; pad_top_size = n; }
+		else pad_top_size += n;
+	}
+	if (left && top) adi[2 * n] = decoded[0];
+	else if (left) { pad_top--; pad_top_size++; }
+	else pad_left_size++;
+	for (i = 0; i < pad_left_size; i++) *pad_left++ = first_sample;
+	for (i = 0; i < pad_top_size; i++) *pad_top++ = last_sample;
+}
+
+/* hmr_motion_intra.c:189-243: [1 2 1]/4 smoothing, or the strong bilinear filter for n >= 32 when
+ * both edges are nearly linear.  size_shift = log2(2n) for the luma sizes that reach the strong
+ * branch (max_cu_size_shift - depth + 1, :206). */
+void ora_adi_filter(const int16_t *adi, int16_t *out, int adi_size, int n, int strong_enabled)
+{
+	int i;
+	if (strong_enabled) {
+		int bl = adi[0], tl = adi[2 * n], tr = adi[adi_size - 1];
+		int lin_left = abs(bl + tl - 2 * adi[n]) < 8;
+		int lin_top = abs(tl + tr - 2 * adi[3 * n]) < 8;
+		if (n >= 32 && lin_left && lin_top) {
+			int shift = ilog2(2 * n);
+			out[0] = adi[0];
+			out[2 * n] = adi[2 * n];
+			out[adi_size - 1] = adi[adi_size - 1];
+			for (i = 1; i < 2 * n; i++) out[i] = (int16_t)(((2 * n - i) * bl + i * tl + n) >> shift);
+			for (i = 1; i < 2 * n; i++) out[2 * n + i] = (int16_t)(((2 * n - i) * tl + i * tr + n) >> shift);
+			return;
+		}
+	}
+	out[0] = adi[0];
+	for (i = 1; i < adi_size - 1; i++) out[i] = (int16_t)((adi[i - 1] + 2 * adi[i] + adi[i + 1] + 2) >> 2);
+	out[adi_size - 1] = adi[adi_size - 1];
+}
+
+/* ------------------------------------------------------------------ K9-K11 interpolation */
+
+static const int16_t k_luma_taps[4][8] = {   /* hmr_motion_inter.c:240-246 */
+	{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}};
+static const int16_t k_chroma_taps[8][4] = { /* hmr_motion_inter.c:248-258 */
+	{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4}, {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
+
+/* hmr_motion_inter.c:262-311 (filter_copy) */
+static void filter_copy(const int16_t *src, int ss, int16_t *dst, int ds, int w, int h, int first, int last)
+{
+	int r, c;
+	for (r = 0; r < h; r++)
+		for (c = 0; c < w; c++) {
+			int v = src[r * ss + c];
+			if (first == last) dst[r * ds + c] = (int16_t)v;
+			else if (first) dst[r * ds + c] = (int16_t)((int16_t)(v << 6) - 8192);
+			else dst[r * ds + c] = (int16_t)clip3((v + 8192 + 32) >> 6, 0, 255);
+		}
+}
+
+/* hmr_motion_inter.c:314-377 / :878-936: separable FIR with the HM stage rules */
+static void fir(const int16_t *src, int ss, int16_t *dst, int ds, const int16_t *taps, int ntaps, int w, int h, int vert, int first, int last)
+{
+	int rs = vert ? ss : 1, shift = 6, offset, r, c, t;
+	src -= (ntaps / 2 - 1) * rs;
+	if (last) {
+		shift += first ? 0 : 6;
+		offset = 1 << (shift - 1);
+		offset += first ? 0 : 8192 << 6;
+	} else {
+		shift -= first ? 6 : 0;
+		offset = first ? -(8192 << shift) : 0;
+	}
+	for (r = 0; r < h; r++)
+		for (c = 0; c < w; c++) {
+			int sum = 0;
+			int16_t v;
+			for (t = 0; t < ntaps; t++) sum += src[r * ss + c + t * rs] * taps[t];
+			v = sat16((sum + offset) >> shift);   /* _mm_packs_epi32 */
+			if (last) v = (int16_t)clip3(v, 0, 255);
+			dst[r * ds + c] = v;
+		}
+}
+
+void ora_interpolate_luma(const int16_t *src, int ss, int16_t *dst, int ds, int fraction, int w, int h, int vert, int first, int last)
+{
+	if (fraction == 0) filter_copy(src, ss, dst, ds, w, h, first, last);
+	else fir(src, ss, dst, ds, k_luma_taps[fraction], 8, w, h, vert, first, last);
+}
+
+/* hmr_sse42_functions_inter_prediction.c:818: fraction 0 with width < 4 is a silent no-op */
+void ora_interpolate_chroma(const int16_t *src, int ss, int16_t *dst, int ds, int fraction, int w, int h, int vert, int first, int last)
+{
+	if (fraction == 0) {
+		if (w < 4) return;
+		filter_copy(src, ss, dst, ds, w, h, first, last);
+	} else
+		fir(src, ss, dst, ds, k_chroma_taps[fraction], 4, w, h, vert, first, last);
+}
+
+/* hmr_sse42_functions_inter_prediction.c:944: clip((a + b + 64 + 2*8192) >> 7) */
+void ora_weighted_average(const int16_t *a, int as, const int16_t *b, int bs, int16_t *d, int ds, int h, int w)
+{
+	int r, c;
+	for (r = 0; r < h; r++)
+		for (c = 0; c < w; c++)
+			d[r * ds + c] = (int16_t)clip3(sat16((a[r * as + c] + b[r * bs + c] + 64 + 16384) >> 7), 0, 255);
+}
+
+/* ------------------------------------------------------------------ K12/K13 transforms */
+
+/* One 1-D stage written as a matrix product: out[k*n + j] = sat16((sum_i M[k][i] * in[j][i] + rnd) >> shift).
+ * The butterflies of hmr_transform.c:154-500 are an exact factorisation of this product (no
+ * intermediate rounding), and the SSE kernels pack with signed saturation (Q3). */
+static void fwd_stage(const int16_t *in, int in_stride, int16_t *out, const int16_t *M, int n, int shift)
+{
+	int j, k, i, rnd = 1 << (shift - 1);
+	for (j = 0; j < n; j++)
+		for (k = 0; k < n; k++) {
+			int32_t s = 0;
+			for (i = 0; i < n; i++) s += M[k * n + i] * in[j * in_stride + i];
+			out[k * n + j] = sat16((s + rnd) >> shift);
+		}
+}
+
+/* out[j][k] = sat16((sum_i M[i][k] * in[i*n + j] + rnd) >> shift) */
+static void inv_stage(const int16_t *in, int16_t *out, int out_stride, const int16_t *M, int n, int shift)
+{
+	int j, k, i, rnd = 1 << (shift - 1);
+	for (j = 0; j < n; j++)
+		for (k = 0; k < n; k++) {
+			int32_t s = 0;
+			for (i = 0; i < n; i++) s += M[i * n + k] * in[i * n + j];
+			out[j * out_stride + k] = sat16((s + rnd) >> shift);
+		}
+}
+
+/* hmr_sse42_functions_transform.c:1670: shifts {log2N-1, log2N+6} for 8-bit video; DST-VII for 4x4 intra luma */
+void ora_transform(const int16_t *block, int16_t *coeff, int block_stride, int n, int is_dst)
+{
+	int16_t tmp[32 * 32];
+	int l = ilog2(n);
+	const int16_t *M = (n == 4 && is_dst) ? k_dst4 : ora_dct_matrix(l);
+	if (n != 4 && n != 8 && n != 16 && n != 32) return; /* unsupported sizes fall through silently, :1672-1694 */
+	fwd_stage(block, block_stride, tmp, M, n, l - 1);
+	fwd_stage(tmp, n, coeff, M, n, l + 6);
+}
+
+/* hmr_sse42_functions_transform.c:1700: shifts {7, 12} */
+void ora_itransform(int16_t *block, const int16_t *coeff, int block_stride, int n, int is_dst)
+{
+	int16_t tmp[32 * 32];
+	int l = ilog2(n);
+	const int16_t *M = (n == 4 && is_dst) ? k_dst4 : ora_dct_matrix(l);
+	if (n != 4 && n != 8 && n != 16 && n != 32) return;
+	inv_stage(coeff, tmp, n, M, n, 7);
+	inv_stage(tmp, block, block_stride, M, n, 12);
+}
+
+/* ------------------------------------------------------------------ K14/K15 quant */
+
+/* hmr_quant.c:61-169, shared by the scalar and SSE quantisers */
+void ora_sign_bit_hiding(int16_t *dst, const int16_t *src, const uint32_t *scan, const int16_t *delta_u, int n_coeffs)
+{
+	int last_cg = -1, subset, n;
+	for (subset = (n_coeffs - 1) >> 4; subset >= 0; subset--) {
+		int sub_pos = subset << 4, first_nz = 16, last_nz = -1, abs_sum = 0;
+		for (n = 15; n >= 0; --n)
+			if (dst[scan[n + sub_pos]]) { last_nz = n; break; }
+		for (n = 0; n < 16; n++)
+			if (dst[scan[n + sub_pos]]) { first_nz = n; break; }
+		for (n = first_nz; n <= last_nz; n++) abs_sum += dst[scan[n + sub_pos]];
+		if (last_nz >= 0 && last_cg == -1) last_cg = 1;
+		if (last_nz - first_nz >= 4) {
+			unsigned signbit = dst[scan[sub_pos + first_nz]] > 0 ? 0 : 1;
+			if (signbit != (unsigned)(abs_sum & 1)) {
+				int min_cost = INT_MAX, min_pos = -1, final_change = 0, cur_cost = INT_MAX, cur_change = 0;
+				for (n = (last_cg == 1 ? last_nz : 15); n >= 0; --n) {
+					unsigned pos = scan[n + sub_pos];
+					if (dst[pos] != 0) {
+						if (delta_u[pos] > 0) { cur_cost = -delta_u[pos]; cur_change = 1; }
+						else if (n == first_nz && abs(dst[pos]) == 1) cur_cost = INT_MAX;
+						else { cur_cost = delta_u[pos]; cur_change = -1; }
+					} else if (n < first_nz) {
+						unsigned this_sign = src[pos] >= 0 ? 0 : 1;
+						if (this_sign != signbit) cur_cost = INT_MAX;
+						else { cur_cost = -delta_u[pos]; cur_change = 1; }
+					} else { cur_cost = -delta_u[pos]; cur_change = 1; }
+					if (cur_cost < min_cost) { min_cost = cur_cost; final_change = cur_change; min_pos = (int)pos; }
+				}
+				if (dst[min_pos] == 32767 || dst[min_pos] == -32768) final_change = -1;
+				if (src[min_pos] >= 0) dst[min_pos] = (int16_t)(dst[min_pos] + final_change);
+				else dst[min_pos] = (int16_t)(dst[min_pos] - final_change);
+			}
+		}
+		if (last_cg == 1) last_cg = 0;
+	}
+}
+
+/* hmr_sse42_functions_quant.c:34-131.  32-bit wrapping arithmetic (_mm_mullo_epi32), arithmetic shifts,
+ * signed-saturating packs, sign re-applied with a 16-bit multiply. */
+void ora_quant(const int16_t *src, int16_t *dst, int16_t *delta_u, int scan_mode, int depth, int comp, int is_intra,
+	       int slice_is_intra, int sign_hiding, int *ac_sum, int cu_size, int per, int rem)
+{
+	int inv_depth = 6 - (depth + (comp != 0));
+	const uint32_t *scan = ora_scan_table(scan_mode, inv_depth);
+	const int32_t *q = ora_quant_table(inv_depth, (is_intra ? 0 : 3) + comp, rem);
+	int qbits = 14 + per + (15 - 8 - inv_depth), qbits8 = qbits - 8;
+	int32_t add = (int32_t)((uint32_t)(slice_is_intra ? 171 : 85) << (qbits - 9));
+	int16_t scratch[32 * 32];
+	int n, total = cu_size * cu_size;
+	uint32_t sum = 0;
+	if (!delta_u) delta_u = scratch;
+	for (n = 0; n < total; n++) {
+		uint32_t a = (uint16_t)(src[n] < 0 ? -src[n] : src[n]);      /* _mm_abs_epi16 then zero-extend */
+		int32_t aux = (int32_t)(a * (uint32_t)q[n]);
+		int32_t c = (int32_t)((uint32_t)aux + (uint32_t)add) >> qbits;
+		int32_t d = (int32_t)((uint32_t)aux - ((uint32_t)c << qbits)) >> qbits8;
+		int sgn = src[n] > 0 ? 1 : (src[n] < 0 ? -1 : 0);
+		sum += (uint32_t)c;
+		dst[n] = (int16_t)(sgn * sat16(c));
+		delta_u[n] = sat16(d);
+	}
+	*ac_sum = (int)sum;
+	if (sign_hiding && *ac_sum >= 2) ora_sign_bit_hiding(dst, src, scan, delta_u, total);
+}
+
+/* hmr_sse42_functions_quant.c:135-246; list index keeps the reference's precedence slip (:138) */
+void ora_inv_quant(const int16_t *src, int16_t *dst, int depth, int comp, int is_intra, int cu_size, int per, int rem)
+{
+	int inv_depth = 6 - (depth + (comp != 0));
+	const int32_t *iq = ora_dequant_table(inv_depth, is_intra ? 0 : 3 + comp, rem);
+	int iq_shift = 20 - 14 - (15 - 8 - inv_depth) + 4, n, total = cu_size * cu_size;
+	if (iq_shift > per) {
+		int32_t add = 1 << (iq_shift - per - 1);
+		int sh = iq_shift - per;
+		for (n = 0; n < total; n++)
+			dst[n] = sat16((int32_t)((uint32_t)(int32_t)src[n] * (uint32_t)iq[n] + (uint32_t)add) >> sh);
+	} else {
+		int sh = per - iq_shift;
+		for (n = 0; n < total; n++)
+			dst[n] = sat16((int32_t)(((uint32_t)(int32_t)src[n] * (uint32_t)iq[n]) << sh));
+	}
+}

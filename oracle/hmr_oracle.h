@@ -1,0 +1,81 @@
+/*
+ * TEST INFRASTRUCTURE - CPU oracle for the HomerHEVC per-block encode hot path.
+ *
+ * A plain-C restatement of the reference's low_level_funcs_t kernels
+ * (hmr_private.h:1063-1092) and of the in-loop kernels that live outside the
+ * table (deblock, SAO offset, intra reference build, border padding), with the
+ * henc_thread_t* arguments flattened to scalars.  Only tests/, smoke() and
+ * bench.py's cpu_baseline leg may load this library; the product path
+ * (homerhevc_amd/, libhomer_gpu.so) never does.
+ *
+ * Pinning: every function here is diffed against the compiled reference's
+ * SSE4.2 symbols (oracle/_ref/libhomer_ref.so, "oracle B" flags) by
+ * tests/test_oracle_vs_ref.py in the build container, and against the golden
+ * vectors minted from that build (tests/golden/) everywhere else.
+ *
+ * All samples are int16_t, strides are in elements.
+ */
+#ifndef HMR_ORACLE_H
+#define HMR_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORA_SCAN_ZIGZAG 0
+#define ORA_SCAN_HOR 1
+#define ORA_SCAN_VER 2
+#define ORA_SCAN_DIAG 3
+
+/* tables (hmr_tables.c:62,221; hmr_encoder_lib.c:93-140) */
+const uint32_t *ora_scan_table(int scan_mode, int log2_size);          /* log2_size 1..5 */
+const int32_t *ora_quant_table(int log2_size, int list, int rem);      /* log2_size 2..5 */
+const int32_t *ora_dequant_table(int log2_size, int list, int rem);
+const int16_t *ora_dct_matrix(int log2_size);                          /* N x N row-major, log2 2..5 */
+const int16_t *ora_dst_matrix(void);                                   /* 4 x 4 */
+
+/* K6 copies (hmr_sse42_functions_pixel.c:152,236,319): arg order (src,sstride,dst,dstride,height,width) */
+void ora_copy_16_16(const int16_t *src, uint32_t src_stride, int16_t *dst, uint32_t dst_stride, int height, int width);
+void ora_copy_8_16(const uint8_t *src, uint32_t src_stride, int16_t *dst, uint32_t dst_stride, int height, int width);
+void ora_copy_16_8(const int16_t *src, uint32_t src_stride, uint8_t *dst, uint32_t dst_stride, int height, int width);
+
+/* K1-K5 (hmr_sse42_functions_pixel.c:462,728,817,919,1123) */
+uint32_t ora_sad(const int16_t *src, uint32_t src_stride, const int16_t *pred, uint32_t pred_stride, int size);
+uint32_t ora_ssd16b(const int16_t *src, uint32_t src_stride, const int16_t *pred, uint32_t pred_stride, int size);
+void ora_predict(const int16_t *orig, int orig_stride, const int16_t *pred, int pred_stride, int16_t *residual, int residual_stride, int size);
+void ora_reconst(const int16_t *pred, int pred_stride, const int16_t *residual, int residual_stride, int16_t *decoded, int decoded_stride, int size);
+uint32_t ora_modified_variance(const int16_t *p, int size, int stride, int modif);
+
+/* K7/K8 intra prediction (hmr_sse42_functions_prediction.c:199,926; scalar spec hmr_motion_intra.c:408,482) */
+void ora_intra_planar(int16_t *pred, int pred_stride, const int16_t *adi, int adi_size, int cu_size);
+void ora_intra_angular(int16_t *pred, int pred_stride, const int16_t *adi, int adi_size, int cu_size, int cu_mode, int is_luma);
+
+/* K19 intra reference build (hmr_motion_intra.c:246,189) */
+void ora_fill_reference_samples(const int16_t *decoded, int stride, int n, int left, int top, int bottom_left, int top_right,
+				int bl_size, int tr_size, int16_t *adi);
+void ora_adi_filter(const int16_t *adi, int16_t *out, int adi_size, int n, int strong_enabled);
+
+/* K9-K11 (hmr_sse42_functions_inter_prediction.c:796,818,944; scalar spec hmr_motion_inter.c:262-391,878) */
+void ora_interpolate_luma(const int16_t *src, int src_stride, int16_t *dst, int dst_stride, int fraction, int width, int height,
+			  int is_vertical, int is_first, int is_last);
+void ora_interpolate_chroma(const int16_t *src, int src_stride, int16_t *dst, int dst_stride, int fraction, int width, int height,
+			    int is_vertical, int is_first, int is_last);
+void ora_weighted_average(const int16_t *src0, int s0_stride, const int16_t *src1, int s1_stride, int16_t *dst, int dst_stride,
+			  int height, int width);
+
+/* K12/K13 (hmr_sse42_functions_transform.c:1670,1700; scalar spec hmr_transform.c:514,553) */
+void ora_transform(const int16_t *block, int16_t *coeff, int block_stride, int n, int is_dst);
+void ora_itransform(int16_t *block, const int16_t *coeff, int block_stride, int n, int is_dst);
+
+/* K14/K15 (hmr_sse42_functions_quant.c:34,135; hmr_quant.c:61) */
+void ora_quant(const int16_t *src, int16_t *dst, int16_t *delta_u, int scan_mode, int depth, int comp, int is_intra,
+	       int slice_is_intra, int sign_hiding, int *ac_sum, int cu_size, int per, int rem);
+void ora_inv_quant(const int16_t *src, int16_t *dst, int depth, int comp, int is_intra, int cu_size, int per, int rem);
+void ora_sign_bit_hiding(int16_t *dst, const int16_t *src, const uint32_t *scan, const int16_t *delta_u, int n_coeffs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import libs
+    return libs.load_oracle()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    import libs
+    lib = libs.load_ref()
+    if lib is None:
+        pytest.skip("oracle/_ref not built (reference sources are only present in the build container)")
+    return lib

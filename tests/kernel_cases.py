@@ -1,0 +1,343 @@
+"""Shared case generator / caller for the table kernels (K1-K15, K19).
+
+One flat C signature per kernel is exported three times:
+  ora_*      oracle/liboracle.so        (this repo's CPU restatement, test infrastructure)
+  refh_*     oracle/_ref/libhomer_ref.so (the compiled reference's SSE4.2 symbols; build container only)
+  hmr_gpu_*  homerhevc_amd/libhomer_gpu.so (the product: HIP kernels behind the C ABI)
+so one case description drives oracle-vs-reference pinning, golden minting and GPU parity.
+
+A case is (kernel, params dict, seed).  `run(lib, prefix, case)` returns a dict of numpy outputs.
+Inputs are rebuilt from the seed (numpy default_rng), so golden files hold params + outputs only.
+"""
+import ctypes as C
+
+import numpy as np
+
+VP = C.c_void_p
+
+
+def aligned(shape, dtype, align=64):
+    """Zero-filled array whose first element is `align`-byte aligned (SSE aligned loads)."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape))
+    raw = np.zeros(n * dtype.itemsize + align, dtype=np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + n * dtype.itemsize].view(dtype).reshape(shape)
+
+
+def aligned_copy(a, align=64):
+    out = aligned(a.shape, a.dtype, align)
+    out[...] = a
+    return out
+
+
+def ptr(a, off=0):
+    return VP(a.ctypes.data + off * a.dtype.itemsize)
+
+
+def fn(lib, prefix, name, restype=None):
+    f = getattr(lib, prefix + name)
+    f.restype = restype
+    return f
+
+
+PLANE_H, PLANE_W = 160, 192  # scratch plane: room for 64x64 blocks at any offset + filter margins
+
+
+def pix_plane(rng, lo=0, hi=256):
+    p = aligned((PLANE_H, PLANE_W), np.int16)
+    p[...] = rng.integers(lo, hi, (PLANE_H, PLANE_W))
+    return p
+
+
+# ------------------------------------------------------------------ kernels
+
+def k_sad(lib, prefix, p, rng, which="sad"):
+    n = p["n"]
+    src = pix_plane(rng, *p.get("src_range", (0, 256)))
+    pred = pix_plane(rng, *p.get("pred_range", (0, 256)))
+    so = 16 * PLANE_W + 16                       # aligned source block
+    po = (8 + p.get("dy", 0)) * PLANE_W + 8 + p.get("dx", 0)  # unaligned candidate (ME walks +-1 px)
+    ps = 0 if p.get("pred_stride0") else PLANE_W
+    f = fn(lib, prefix, which, C.c_uint32)
+    r = f(ptr(src, so), C.c_uint32(PLANE_W), ptr(pred, po), C.c_uint32(ps), C.c_int(n))
+    return {"value": np.array([r], dtype=np.uint32)}
+
+
+def k_ssd16b(lib, prefix, p, rng):
+    return k_sad(lib, prefix, p, rng, which="ssd16b")
+
+
+def k_predict(lib, prefix, p, rng):
+    n = p["n"]
+    orig, pred = pix_plane(rng), pix_plane(rng)
+    res = aligned((64, 64), np.int16)
+    fn(lib, prefix, "predict")(ptr(orig, 16 * PLANE_W + 16), C.c_int(PLANE_W), ptr(pred, 8 * PLANE_W + 32), C.c_int(PLANE_W),
+                               ptr(res), C.c_int(64), C.c_int(n))
+    return {"residual": res[:n, :n].copy()}
+
+
+def k_reconst(lib, prefix, p, rng):
+    n = p["n"]
+    lo, hi = p.get("res_range", (-300, 301))
+    pred = pix_plane(rng)
+    res = aligned((64, 64), np.int16)
+    res[...] = rng.integers(lo, hi, (64, 64))
+    if p.get("extreme"):
+        res[::3, ::5] = 32767
+        res[1::4, 2::3] = -32768
+    dec = aligned((64, 64), np.int16)
+    rs = 0 if p.get("res_stride0") else 64
+    if rs == 0:
+        res[0, :] = 0
+    fn(lib, prefix, "reconst")(ptr(pred, 16 * PLANE_W + 16), C.c_int(PLANE_W), ptr(res), C.c_int(rs), ptr(dec), C.c_int(64), C.c_int(n))
+    return {"decoded": dec[:n, :n].copy()}
+
+
+def k_modified_variance(lib, prefix, p, rng):
+    src = pix_plane(rng)
+    r = fn(lib, prefix, "modified_variance", C.c_uint32)(ptr(src, 16 * PLANE_W + 16), C.c_int(p["n"]), C.c_int(PLANE_W), C.c_int(p["modif"]))
+    return {"value": np.array([r], dtype=np.uint32)}
+
+
+def k_copy(lib, prefix, p, rng):
+    kind, h, w = p["kind"], p["h"], p["w"]
+    wpad = (w + 15) // 16 * 16
+    if kind == "8_16":
+        src = aligned((PLANE_H, PLANE_W), np.uint8)
+        src[...] = rng.integers(0, 256, src.shape)
+        dst = aligned((h, wpad + 16), np.int16)
+    elif kind == "16_8":
+        src = pix_plane(rng, -64, 400)
+        dst = aligned((h, wpad + 16), np.uint8)
+    else:
+        src = pix_plane(rng, -32768, 32768)
+        dst = aligned((h, wpad + 16), np.int16)
+    fn(lib, prefix, "copy_" + kind)(ptr(src, 8 * PLANE_W + 16), C.c_uint32(PLANE_W), ptr(dst), C.c_uint32(dst.shape[1]), C.c_int(h), C.c_int(w))
+    return {"dst": dst[:, :w].copy()}
+
+
+def adi_buffer(rng, n, smooth=False):
+    adi = aligned((4 * 64 + 1 + 15,), np.int16)
+    if smooth:
+        base = rng.integers(40, 200)
+        adi[:4 * n + 1] = base + (np.arange(4 * n + 1) * rng.integers(-2, 3)) // 8
+    else:
+        adi[:4 * n + 1] = rng.integers(0, 256, 4 * n + 1)
+    return adi
+
+
+def k_intra_planar(lib, prefix, p, rng):
+    n = p["n"]
+    adi = adi_buffer(rng, n)
+    pred = aligned((64, 64), np.int16)
+    pred[...] = 0x1234  # poison: a partial write must show
+    fn(lib, prefix, "intra_planar")(ptr(pred), C.c_int(64), ptr(adi), C.c_int(4 * n + 1), C.c_int(n))
+    return {"pred": pred[:n, :n].copy()}
+
+
+def k_intra_angular(lib, prefix, p, rng):
+    n = p["n"]
+    adi = adi_buffer(rng, n)
+    if p.get("flat") is not None:
+        adi[:4 * n + 1] = p["flat"]
+    pred = aligned((64, 64), np.int16)
+    pred[...] = 0x1234
+    fn(lib, prefix, "intra_angular")(ptr(pred), C.c_int(64), ptr(adi), C.c_int(4 * n + 1), C.c_int(n), C.c_int(p["mode"]), C.c_int(p["luma"]))
+    return {"pred": pred[:n, :n].copy()}
+
+
+def k_fill_reference_samples(lib, prefix, p, rng):
+    n = p["n"]
+    dec = pix_plane(rng)
+    adi = aligned((4 * 64 + 1 + 15,), np.int16)
+    adi[...] = 0x1234
+    fn(lib, prefix, "fill_reference_samples")(ptr(dec, 15 * PLANE_W + 15), C.c_int(PLANE_W), C.c_int(n), C.c_int(p["left"]), C.c_int(p["top"]),
+                                              C.c_int(p["bl"]), C.c_int(p["tr"]), C.c_int(p["bl_size"]), C.c_int(p["tr_size"]), ptr(adi))
+    return {"adi": adi[:4 * n + 1].copy()}
+
+
+def k_adi_filter(lib, prefix, p, rng):
+    n = p["n"]
+    adi = adi_buffer(rng, n, smooth=p.get("smooth", False))
+    out = aligned((4 * 64 + 1 + 15,), np.int16)
+    fn(lib, prefix, "adi_filter")(ptr(adi), ptr(out), C.c_int(4 * n + 1), C.c_int(n), C.c_int(p["strong"]))
+    return {"out": out[:4 * n + 1].copy()}
+
+
+def k_interpolate(lib, prefix, p, rng):
+    w, h, first = p["w"], p["h"], p["first"]
+    src = pix_plane(rng, 0, 256) if first else pix_plane(rng, -8192, 8129)
+    dst = aligned((80, 96), np.int16)
+    dst[...] = 0x1234
+    name = "interpolate_luma" if p["luma"] else "interpolate_chroma"
+    fn(lib, prefix, name)(ptr(src, 16 * PLANE_W + 16 + p.get("dx", 0)), C.c_int(PLANE_W), ptr(dst), C.c_int(96), C.c_int(p["frac"]),
+                          C.c_int(w), C.c_int(h), C.c_int(p["vert"]), C.c_int(first), C.c_int(p["last"]))
+    return {"dst": dst[:h, :w].copy()}
+
+
+def k_weighted_average(lib, prefix, p, rng):
+    w, h = p["w"], p["h"]
+    a, b = pix_plane(rng, -8192, 8129), pix_plane(rng, -8192, 8129)
+    dst = aligned((64, 64), np.int16)
+    fn(lib, prefix, "weighted_average")(ptr(a, 16 * PLANE_W + 16), C.c_int(PLANE_W), ptr(b, 8 * PLANE_W + 8), C.c_int(PLANE_W), ptr(dst), C.c_int(64),
+                                        C.c_int(h), C.c_int(w))
+    return {"dst": dst[:h, :w].copy()}
+
+
+def k_transform(lib, prefix, p, rng):
+    n, amp = p["n"], p.get("amp", 255)
+    blk = aligned((64, 64), np.int16)
+    blk[...] = rng.integers(-amp, amp + 1, (64, 64))
+    if p.get("const") is not None:
+        blk[...] = p["const"]
+    coeff = aligned((32 * 32,), np.int16)
+    fn(lib, prefix, "transform")(ptr(blk), ptr(coeff), C.c_int(64), C.c_int(n), C.c_int(p.get("dst", 0)))
+    return {"coeff": coeff[:n * n].copy()}
+
+
+def k_itransform(lib, prefix, p, rng):
+    n, amp = p["n"], p.get("amp", 1500)
+    coeff = aligned((32 * 32,), np.int16)
+    c = rng.integers(-amp, amp + 1, n * n)
+    if p.get("sparse", True):
+        c = np.where(rng.random(n * n) < 0.25, c, 0)
+    coeff[:n * n] = c
+    blk = aligned((64, 64), np.int16)
+    fn(lib, prefix, "itransform")(ptr(blk), ptr(coeff), C.c_int(64), C.c_int(n), C.c_int(p.get("dst", 0)))
+    return {"block": blk[:n, :n].copy()}
+
+
+def quant_depth(n, comp):
+    """`depth` argument such that inv_depth = 6-(depth+(comp!=0)) equals log2(n) (hmr_sse42_functions_quant.c:39)."""
+    return 6 - int(np.log2(n)) - (1 if comp else 0)
+
+
+def k_quant(lib, prefix, p, rng):
+    n, comp = p["n"], p["comp"]
+    amp = p.get("amp", 3000)
+    src = aligned((32 * 32,), np.int16)
+    decay = 1.0 / (1.0 + 0.35 * (np.add.outer(np.arange(n), np.arange(n))).ravel())
+    src[:n * n] = (rng.integers(-amp, amp + 1, n * n) * decay).astype(np.int64)
+    if p.get("extreme"):
+        src[0] = -32768
+        src[1] = 32767
+    dst = aligned((32 * 32,), np.int16)
+    du = aligned((32 * 32,), np.int16)
+    ac = C.c_int(0)
+    fn(lib, prefix, "quant")(ptr(src), ptr(dst), ptr(du), C.c_int(p["scan"]), C.c_int(quant_depth(n, comp)), C.c_int(comp), C.c_int(p["intra"]),
+                             C.c_int(p["slice_i"]), C.c_int(p["sbh"]), C.byref(ac), C.c_int(n), C.c_int(p["per"]), C.c_int(p["rem"]))
+    return {"dst": dst[:n * n].copy(), "delta_u": du[:n * n].copy(), "ac_sum": np.array([ac.value], dtype=np.int32)}
+
+
+def k_inv_quant(lib, prefix, p, rng):
+    n, comp = p["n"], p["comp"]
+    amp = p.get("amp", 200)
+    src = aligned((32 * 32,), np.int16)
+    src[:n * n] = np.where(rng.random(n * n) < 0.3, rng.integers(-amp, amp + 1, n * n), 0)
+    dst = aligned((32 * 32,), np.int16)
+    fn(lib, prefix, "inv_quant")(ptr(src), ptr(dst), C.c_int(quant_depth(n, comp)), C.c_int(comp), C.c_int(p["intra"]), C.c_int(n), C.c_int(p["per"]),
+                                 C.c_int(p["rem"]))
+    return {"dst": dst[:n * n].copy()}
+
+
+KERNELS = {
+    "sad": k_sad, "ssd16b": k_ssd16b, "predict": k_predict, "reconst": k_reconst, "modified_variance": k_modified_variance,
+    "copy": k_copy, "intra_planar": k_intra_planar, "intra_angular": k_intra_angular,
+    "fill_reference_samples": k_fill_reference_samples, "adi_filter": k_adi_filter, "interpolate": k_interpolate,
+    "weighted_average": k_weighted_average, "transform": k_transform, "itransform": k_itransform, "quant": k_quant,
+    "inv_quant": k_inv_quant,
+}
+
+
+def run(lib, prefix, case):
+    kernel, params, seed = case
+    return KERNELS[kernel](lib, prefix, params, np.random.default_rng(seed))
+
+
+# ------------------------------------------------------------------ case lists
+
+def all_cases(level="full"):
+    """level 'golden' = the committed fixture set (small), 'full' = the sweep used for pinning/parity."""
+    full = level == "full"
+    cases = []
+    seed = [1000]
+
+    def add(kernel, **p):
+        seed[0] += 1
+        cases.append((kernel, p, seed[0]))
+
+    sizes = [4, 8, 16, 32, 64]
+    for n in sizes:
+        for dx, dy in ([(0, 0), (1, 0), (3, -1), (-1, 1), (7, 5)] if full else [(0, 0), (3, -1)]):
+            add("sad", n=n, dx=dx, dy=dy)
+            add("ssd16b", n=n, dx=dx, dy=dy)
+        add("ssd16b", n=n, dx=0, dy=0, pred_stride0=1, src_range=(-255, 256), pred_range=(0, 1))
+        add("ssd16b", n=n, dx=2, dy=0, src_range=(-255, 256), pred_range=(-255, 256))
+        add("predict", n=n)
+        add("reconst", n=n)
+        add("reconst", n=n, res_stride0=1)
+        add("reconst", n=n, extreme=1)
+    for n in [2, 4, 8, 16, 32, 64]:
+        for modif in (1, 2):
+            add("modified_variance", n=n, modif=modif)
+    for kind in ("16_16", "8_16", "16_8"):
+        for h, w in [(4, 4), (8, 8), (16, 16), (7, 32), (33, 48), (64, 64)]:
+            add("copy", kind=kind, h=h, w=w)
+    for n in sizes:
+        for _ in range(3 if full else 1):
+            add("intra_planar", n=n)
+        for mode in range(1, 35):
+            for luma in (1, 0):
+                if full or mode in (1, 2, 6, 10, 14, 18, 22, 26, 30, 34) or n == 8:
+                    add("intra_angular", n=n, mode=mode, luma=luma)
+        add("intra_angular", n=n, mode=1, luma=1, flat=255)
+        add("intra_angular", n=n, mode=10, luma=1, flat=0)
+        add("intra_angular", n=n, mode=26, luma=1, flat=255)
+        for left, top, bl, tr in [(0, 0, 0, 0), (1, 0, 0, 0), (0, 1, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (1, 1, 0, 1), (1, 1, 1, 1), (1, 0, 1, 0), (0, 1, 0, 1)]:
+            add("fill_reference_samples", n=n, left=left, top=top, bl=bl, tr=tr, bl_size=n if bl else 0, tr_size=n if tr else 0)
+        if n >= 8:
+            add("fill_reference_samples", n=n, left=1, top=1, bl=1, tr=1, bl_size=n // 2, tr_size=n // 4)
+            add("fill_reference_samples", n=n, left=1, top=1, bl=1, tr=1, bl_size=n, tr_size=n // 2)
+        for strong in (0, 1):
+            add("adi_filter", n=n, strong=strong)
+            add("adi_filter", n=n, strong=strong, smooth=True)
+    stage_modes = [(1, 0), (0, 1), (1, 1), (0, 0)]
+    for frac in range(4):
+        for first, last in stage_modes:
+            for vert in (0, 1):
+                for w, h in ([(8, 8), (16, 16), (9, 16), (17, 24), (32, 40), (64, 64), (65, 72)] if full else [(8, 8), (17, 24), (64, 64)]):
+                    add("interpolate", luma=1, frac=frac, first=first, last=last, vert=vert, w=w, h=h, dx=(frac + w) % 3)
+    for frac in range(8):
+        for first, last in stage_modes:
+            for vert in (0, 1):
+                for w, h in ([(4, 4), (4, 9), (8, 8), (8, 13), (16, 16), (32, 32), (32, 37)] if full else [(4, 4), (8, 13), (32, 32)]):
+                    add("interpolate", luma=0, frac=frac, first=first, last=last, vert=vert, w=w, h=h, dx=frac % 2)
+    add("interpolate", luma=0, frac=0, first=1, last=1, vert=0, w=2, h=2)
+    for w, h in [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (8, 4)]:
+        add("weighted_average", w=w, h=h)
+    for n in (4, 8, 16, 32):
+        for dst in ((0, 1) if n == 4 else (0,)):
+            for _ in range(4 if full else 2):
+                add("transform", n=n, dst=dst)
+                add("itransform", n=n, dst=dst)
+            add("transform", n=n, dst=dst, const=255)
+            add("transform", n=n, dst=dst, const=-255)
+            add("transform", n=n, dst=dst, amp=1)
+            add("itransform", n=n, dst=dst, amp=20000, sparse=False)
+            add("itransform", n=n, dst=dst, amp=60)
+    for n in (4, 8, 16, 32):
+        for comp in ((0, 1, 2) if n < 32 else (0,)):
+            for intra in (1, 0):
+                for slice_i in ((1,) if intra and not full else (1, 0)):
+                    for sbh in (1, 0):
+                        for per, rem in ([(5, 2), (3, 0), (0, 5), (8, 3), (4, 4), (6, 1)] if full else [(5, 2), (3, 0)]):
+                            for scan in ((1, 2, 3) if (full and intra) else (3,)):
+                                add("quant", n=n, comp=comp, intra=intra, slice_i=slice_i, sbh=sbh, per=per, rem=rem, scan=scan)
+            add("quant", n=n, comp=comp, intra=1, slice_i=1, sbh=1, per=5, rem=2, scan=3, extreme=1)
+            add("quant", n=n, comp=comp, intra=0, slice_i=0, sbh=1, per=4, rem=1, scan=3, amp=40)
+            for intra in (1, 0):
+                for per, rem in [(5, 2), (3, 0), (0, 5), (8, 3), (1, 1)]:
+                    add("inv_quant", n=n, comp=comp, intra=intra, per=per, rem=rem)
+            add("inv_quant", n=n, comp=comp, intra=1, per=8, rem=5, amp=32000)
+    return cases

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Synthetic planar I420 clip generator.
+
+Sinusoid base + seeded +-12 texture, global pan (3,2) px/frame and a moving
+240x160 ramp box, so motion estimation, sub-pel refinement and the intra
+fallback all have work to do.  `default_rng(1234)` makes clips reproducible;
+the md5 of the 1080p x 8 clip is feb867ccc9a69dc281ee193445ab234f.
+"""
+import argparse
+import hashlib
+import sys
+
+import numpy as np
+
+
+def gen_frames(width, height, frames, seed=1234):
+    """Yield (Y, U, V) uint8 planes for `frames` frames."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:height, 0:width]
+    base = (128 + 60 * np.sin(xx / 53.0) * np.cos(yy / 41.0) + 40 * np.sin((xx + yy) / 17.0)).astype(np.float32)
+    tex = rng.integers(-12, 13, size=(height + 64, width + 64)).astype(np.float32)
+    for n in range(frames):
+        dx, dy = 3 * n, 2 * n
+        Y = np.roll(np.roll(base, dx, axis=1), dy, axis=0) + tex[dy:dy + height, dx:dx + width]
+        bx, by = 200 + 11 * n, 300 + 7 * n
+        if by < height and bx < width:
+            bh, bw = min(160, height - by), min(240, width - bx)
+            Y[by:by + bh, bx:bx + bw] = (200 - 0.2 * np.arange(240))[None, :bw]
+        Y = np.clip(Y, 0, 255).astype(np.uint8)
+        # chroma is sampled on the even luma grid (x2 = 0, 2, 4, ...)
+        U = np.clip(128 + 30 * np.sin((xx[::2, ::2] + dx) / 97.0), 0, 255).astype(np.uint8)
+        V = np.clip(128 + 30 * np.cos((yy[::2, ::2] + dy) / 89.0), 0, 255).astype(np.uint8)
+        yield Y, U, V
+
+
+def write_clip(path, width, height, frames, seed=1234):
+    md5 = hashlib.md5()
+    with open(path, "wb") as f:
+        for planes in gen_frames(width, height, frames, seed):
+            for p in planes:
+                b = p.tobytes()
+                md5.update(b)
+                f.write(b)
+    return md5.hexdigest()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("out")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=1234)
+    a = ap.parse_args(argv)
+    print(write_clip(a.out, a.width, a.height, a.frames, a.seed))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
