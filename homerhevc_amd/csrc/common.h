@@ -1,0 +1,78 @@
+// Shared declarations for the gfx950 backend (context, device tables, wave helpers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/homer_gpu.h"
+
+#define HMR_WAVE 64
+#define HMR_BLOCK 256               // 4 waves per workgroup
+#define HMR_WAVES_PER_BLOCK (HMR_BLOCK / HMR_WAVE)
+#define HMR_MAX_GRID 4096           // >> 256 CUs; every batched kernel grid-strides over its jobs
+
+// Constant tables, device resident, built once per context (tables.cpp).
+struct DevTables {
+	int16_t dct[4][32 * 32];        // [log2N-2] N x N row-major HEVC core transform
+	int16_t dst4[16];               // DST-VII 4x4
+	uint32_t scan[4][6][32 * 32];   // [scan_mode][log2N] coefficient scan order (mode 0 unused)
+	int32_t quant[4][6][6][32 * 32];   // [log2N-2][list][qp%6]
+	int32_t dequant[4][6][6][32 * 32];
+};
+
+struct hmr_gpu_ctx {
+	int device;
+	hipStream_t stream;
+	bool owns_stream;
+	DevTables *tables;              // device
+	hipEvent_t ev0, ev1;
+	// staging for the host-pointer (drop-in) entries
+	uint8_t *h_stage;               // pinned
+	uint8_t *d_stage;
+	size_t stage_bytes;
+	int num_cus;
+};
+
+void hmr_set_error(const char *fmt, ...);
+const DevTables *hmr_host_tables();      // host copy (tables.cpp)
+
+#define HIP_TRY(expr)                                                                          \
+	do {                                                                                       \
+		hipError_t e_ = (expr);                                                                \
+		if (e_ != hipSuccess) {                                                                \
+			hmr_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+			return HMR_GPU_ERR_HIP;                                                            \
+		}                                                                                      \
+	} while (0)
+
+static inline int hmr_grid_for_waves(long njobs_waves)
+{
+	long blocks = (njobs_waves + HMR_WAVES_PER_BLOCK - 1) / HMR_WAVES_PER_BLOCK;
+	if (blocks < 1) blocks = 1;
+	if (blocks > HMR_MAX_GRID) blocks = HMR_MAX_GRID;
+	return (int)blocks;
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (HMR_WAVE - 1); }
+__device__ __forceinline__ int wave_in_block() { return threadIdx.x >> 6; }
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, HMR_WAVE);
+	return v;
+}
+// sum over aligned groups of G lanes (G power of two <= 64)
+template <int G, typename T>
+__device__ __forceinline__ T group_sum(T v)
+{
+#pragma unroll
+	for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, HMR_WAVE);
+	return v;
+}
+__device__ __forceinline__ int clip3i(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int sat16i(int v) { return clip3i(v, -32768, 32767); }
+#endif

@@ -1,0 +1,124 @@
+// Context: device selection, stream, constant-table upload, device memory helpers, HIP-event timer.
+#include "common.h"
+
+static hmr_gpu_ctx *g_default = nullptr;
+
+extern "C" int hmr_gpu_create(hmr_gpu_ctx **out, int device, void *stream)
+{
+	if (!out) return HMR_GPU_ERR_ARG;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+		hmr_set_error("no HIP device visible: the MI355X backend has no CPU fallback");
+		return HMR_GPU_ERR_NO_DEVICE;
+	}
+	if (device < 0 || device >= count) {
+		hmr_set_error("device %d out of range (%d visible)", device, count);
+		return HMR_GPU_ERR_ARG;
+	}
+	HIP_TRY(hipSetDevice(device));
+	hmr_gpu_ctx *c = new hmr_gpu_ctx();
+	memset(c, 0, sizeof *c);
+	c->device = device;
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	c->num_cus = prop.multiProcessorCount;
+	if (stream) {
+		c->stream = (hipStream_t)stream;
+		c->owns_stream = false;
+	} else {
+		HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+		c->owns_stream = true;
+	}
+	HIP_TRY(hipEventCreate(&c->ev0));
+	HIP_TRY(hipEventCreate(&c->ev1));
+	HIP_TRY(hipMalloc((void **)&c->tables, sizeof(DevTables)));
+	HIP_TRY(hipMemcpy(c->tables, hmr_host_tables(), sizeof(DevTables), hipMemcpyHostToDevice));
+	c->stage_bytes = 4u << 20;
+	HIP_TRY(hipHostMalloc((void **)&c->h_stage, c->stage_bytes, hipHostMallocDefault));
+	HIP_TRY(hipMalloc((void **)&c->d_stage, c->stage_bytes));
+	*out = c;
+	return HMR_GPU_OK;
+}
+
+extern "C" void hmr_gpu_destroy(hmr_gpu_ctx *c)
+{
+	if (!c) return;
+	if (g_default == c) g_default = nullptr;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	(void)hipFree(c->tables);
+	(void)hipFree(c->d_stage);
+	(void)hipHostFree(c->h_stage);
+	(void)hipEventDestroy(c->ev0);
+	(void)hipEventDestroy(c->ev1);
+	if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+extern "C" int hmr_gpu_set_default(hmr_gpu_ctx *ctx)
+{
+	g_default = ctx;
+	return HMR_GPU_OK;
+}
+
+// default context for the drop-in entries: created on first use on device 0
+hmr_gpu_ctx *hmr_default_ctx()
+{
+	if (!g_default) {
+		hmr_gpu_ctx *c = nullptr;
+		if (hmr_gpu_create(&c, 0, nullptr) != HMR_GPU_OK) {
+			fprintf(stderr, "homer_gpu: cannot create the default context: %s\n", hmr_gpu_last_error());
+			abort();   // the table has no error channel (SURVEY.md §8-b "Errors"); never fall back silently
+		}
+		g_default = c;
+	}
+	return g_default;
+}
+
+extern "C" int hmr_gpu_sync(hmr_gpu_ctx *c)
+{
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return HMR_GPU_OK;
+}
+extern "C" void *hmr_gpu_stream(hmr_gpu_ctx *c) { return (void *)c->stream; }
+
+extern "C" int hmr_gpu_malloc(hmr_gpu_ctx *c, void **p, size_t bytes)
+{
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipMalloc(p, bytes));
+	return HMR_GPU_OK;
+}
+extern "C" int hmr_gpu_free(hmr_gpu_ctx *c, void *p)
+{
+	HIP_TRY(hipFree(p));
+	return HMR_GPU_OK;
+}
+extern "C" int hmr_gpu_upload(hmr_gpu_ctx *c, void *d, const void *h, size_t bytes)
+{
+	HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return HMR_GPU_OK;
+}
+extern "C" int hmr_gpu_download(hmr_gpu_ctx *c, void *h, const void *d, size_t bytes)
+{
+	HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return HMR_GPU_OK;
+}
+extern "C" int hmr_gpu_memset(hmr_gpu_ctx *c, void *d, int value, size_t bytes)
+{
+	HIP_TRY(hipMemsetAsync(d, value, bytes, c->stream));
+	return HMR_GPU_OK;
+}
+extern "C" int hmr_gpu_timer_start(hmr_gpu_ctx *c)
+{
+	HIP_TRY(hipEventRecord(c->ev0, c->stream));
+	return HMR_GPU_OK;
+}
+extern "C" int hmr_gpu_timer_stop(hmr_gpu_ctx *c, float *ms)
+{
+	HIP_TRY(hipEventRecord(c->ev1, c->stream));
+	HIP_TRY(hipEventSynchronize(c->ev1));
+	HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+	return HMR_GPU_OK;
+}

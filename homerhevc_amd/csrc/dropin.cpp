@@ -1,0 +1,387 @@
+// Drop-in entries: the low_level_funcs_t signatures (hmr_private.h:1066-1091) on HOST pointers.
+// Each call packs its operands into the context's pinned staging buffer, does one H2D copy, launches the
+// same batched kernel the performance path uses with a one-job batch, copies the result back and waits.
+// This is the compatibility surface (a maintainer can store these pointers in hvenc_enc_t.funcs, see
+// INTEGRATION.md); it is launch- and PCIe-bound by construction and is not what bench.py measures.
+#include "common.h"
+
+hmr_gpu_ctx *hmr_default_ctx();
+
+namespace {
+
+struct Stager {
+	hmr_gpu_ctx *c;
+	size_t in_end = 0, out_begin = 0, out_end = 0;
+	explicit Stager(hmr_gpu_ctx *ctx) : c(ctx) { in_end = align(sizeof(hmr_gpu_job)); }
+	static size_t align(size_t v) { return (v + 63) & ~(size_t)63; }
+	hmr_gpu_job *job() { return (hmr_gpu_job *)c->h_stage; }
+	void check(size_t end)
+	{
+		if (end > c->stage_bytes) {
+			fprintf(stderr, "homer_gpu: drop-in operand exceeds the %zu-byte staging buffer\n", c->stage_bytes);
+			abort();
+		}
+	}
+	// copy an h x w region (elements of `es` bytes, host stride in elements) densely; returns the byte offset
+	size_t put2d(const void *host, size_t stride, int h, int w, size_t es)
+	{
+		size_t off = in_end;
+		check(off + (size_t)h * w * es);
+		for (int y = 0; y < h; y++) memcpy(c->h_stage + off + (size_t)y * w * es, (const uint8_t *)host + (size_t)y * stride * es, (size_t)w * es);
+		in_end = align(off + (size_t)h * w * es);
+		return off;
+	}
+	size_t zeros(size_t bytes)
+	{
+		size_t off = in_end;
+		check(off + bytes);
+		memset(c->h_stage + off, 0, bytes);
+		in_end = align(off + bytes);
+		return off;
+	}
+	void begin_outputs() { out_begin = out_end = in_end; }
+	size_t out(size_t bytes)
+	{
+		size_t off = out_end;
+		check(off + bytes);
+		out_end = align(off + bytes);
+		return off;
+	}
+	hmr_gpu_job *djob() { return (hmr_gpu_job *)c->d_stage; }
+	template <typename T> T *dev(size_t off = 0) { return (T *)(c->d_stage + off); }
+	template <typename T> T *host(size_t off) { return (T *)(c->h_stage + off); }
+	void upload()
+	{
+		if (hipMemcpyAsync(c->d_stage, c->h_stage, in_end, hipMemcpyHostToDevice, c->stream) != hipSuccess) die("H2D");
+	}
+	void finish()
+	{
+		if (out_end > out_begin &&
+		    hipMemcpyAsync(c->h_stage + out_begin, c->d_stage + out_begin, out_end - out_begin, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+			die("D2H");
+		if (hipStreamSynchronize(c->stream) != hipSuccess) die("sync");
+	}
+	// scatter a dense h x w result back to the caller's strided buffer
+	void get2d(size_t off, void *host_dst, size_t stride, int h, int w, size_t es)
+	{
+		for (int y = 0; y < h; y++) memcpy((uint8_t *)host_dst + (size_t)y * stride * es, c->h_stage + off + (size_t)y * w * es, (size_t)w * es);
+	}
+	[[noreturn]] static void die(const char *what)
+	{
+		fprintf(stderr, "homer_gpu: %s failed in a drop-in entry: %s\n", what, hipGetErrorString(hipGetLastError()));
+		abort();
+	}
+};
+
+void must(int rc, const char *what)
+{
+	if (rc != HMR_GPU_OK) {
+		fprintf(stderr, "homer_gpu: %s failed: %s\n", what, hmr_gpu_last_error());
+		abort();
+	}
+}
+
+int norm_size(int size) { return (size == 4 || size == 8 || size == 16 || size == 32) ? size : 64; }
+
+uint32_t sad_like(bool ssd, int16_t *src, uint32_t ss, int16_t *pred, uint32_t ps, int size)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	const int n = norm_size(size);
+	Stager st(c);
+	hmr_gpu_job jb = {};
+	jb.a_off = (uint32_t)(st.put2d(src, ss, n, n, 2) / 2);
+	jb.a_stride = n;
+	jb.b_off = (uint32_t)(st.put2d(pred, ps, ps ? n : 1, n, 2) / 2);
+	jb.b_stride = ps ? n : 0;
+	*st.job() = jb;
+	st.begin_outputs();
+	size_t o = st.out(4);
+	st.upload();
+	must(ssd ? hmr_gpu_ssd16b_batch(c, st.djob(), 1, n, st.dev<int16_t>(), st.dev<int16_t>(), st.dev<uint32_t>(o))
+		 : hmr_gpu_sad_batch(c, st.djob(), 1, n, st.dev<int16_t>(), st.dev<int16_t>(), st.dev<uint32_t>(o)),
+	     "sad/ssd");
+	st.finish();
+	return *st.host<uint32_t>(o);
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t hmr_gpu_sad(int16_t *src, uint32_t ss, int16_t *pred, uint32_t ps, int size) { return sad_like(false, src, ss, pred, ps, size); }
+uint32_t hmr_gpu_ssd16b(int16_t *src, uint32_t ss, int16_t *pred, uint32_t ps, int size) { return sad_like(true, src, ss, pred, ps, size); }
+
+void hmr_gpu_predict(int16_t *orig, int os, int16_t *pred, int ps, int16_t *res, int rs, int n)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	hmr_gpu_job jb = {};
+	jb.a_off = (uint32_t)(st.put2d(orig, os, n, n, 2) / 2); jb.a_stride = n;
+	jb.b_off = (uint32_t)(st.put2d(pred, ps, n, n, 2) / 2); jb.b_stride = n;
+	st.begin_outputs();
+	size_t o = st.out((size_t)n * n * 2);
+	jb.c_off = (uint32_t)(o / 2); jb.c_stride = n;
+	*st.job() = jb;
+	st.upload();
+	must(hmr_gpu_predict_batch(c, st.djob(), 1, n, st.dev<int16_t>(), st.dev<int16_t>(), st.dev<int16_t>()), "predict");
+	st.finish();
+	st.get2d(o, res, rs, n, n, 2);
+}
+
+void hmr_gpu_reconst(int16_t *pred, int ps, int16_t *res, int rs, int16_t *dec, int ds, int n)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	hmr_gpu_job jb = {};
+	jb.a_off = (uint32_t)(st.put2d(pred, ps, n, n, 2) / 2); jb.a_stride = n;
+	jb.b_off = (uint32_t)(st.put2d(res, rs, rs ? n : 1, n, 2) / 2); jb.b_stride = rs ? n : 0;
+	st.begin_outputs();
+	size_t o = st.out((size_t)n * n * 2);
+	jb.c_off = (uint32_t)(o / 2); jb.c_stride = n;
+	*st.job() = jb;
+	st.upload();
+	must(hmr_gpu_reconst_batch(c, st.djob(), 1, n, st.dev<int16_t>(), st.dev<int16_t>(), st.dev<int16_t>()), "reconst");
+	st.finish();
+	st.get2d(o, dec, ds, n, n, 2);
+}
+
+static void copy_any(int kind, void *src, uint32_t ss, void *dst, uint32_t ds, int h, int w)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	const size_t es = kind == 1 ? 1 : 2, ed = kind == 2 ? 1 : 2;
+	Stager st(c);
+	hmr_gpu_job jb = {};
+	jb.a_off = (uint32_t)(st.put2d(src, ss, h, w, es) / es); jb.a_stride = w;
+	jb.w = (uint16_t)w; jb.h = (uint16_t)h;
+	st.begin_outputs();
+	size_t o = st.out((size_t)h * w * ed);
+	jb.c_off = (uint32_t)(o / ed); jb.c_stride = w;
+	*st.job() = jb;
+	st.upload();
+	must(hmr_gpu_copy_batch(c, st.djob(), 1, kind, st.dev<void>(), st.dev<void>()), "copy");
+	st.finish();
+	st.get2d(o, dst, ds, h, w, ed);
+}
+void hmr_gpu_copy_16_16(void *s, uint32_t ss, void *d, uint32_t ds, int h, int w) { copy_any(0, s, ss, d, ds, h, w); }
+void hmr_gpu_copy_8_16(void *s, uint32_t ss, void *d, uint32_t ds, int h, int w) { copy_any(1, s, ss, d, ds, h, w); }
+void hmr_gpu_copy_16_8(void *s, uint32_t ss, void *d, uint32_t ds, int h, int w) { copy_any(2, s, ss, d, ds, h, w); }
+
+uint32_t hmr_gpu_modified_variance(int16_t *p, int size, int stride, int modif)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	hmr_gpu_job jb = {};
+	// the SSE code reads whole 16-byte vectors: size x max(size,8) samples cover every byte it uses
+	const int wcopy = size < 8 ? 8 : size;
+	jb.a_off = (uint32_t)(st.put2d(p, stride, size, wcopy, 2) / 2); jb.a_stride = wcopy;
+	jb.p0 = (uint32_t)modif;
+	*st.job() = jb;
+	st.begin_outputs();
+	size_t o = st.out(4);
+	st.upload();
+	must(hmr_gpu_modified_variance_batch(c, st.djob(), 1, size, st.dev<int16_t>(), st.dev<uint32_t>(o)), "modified_variance");
+	st.finish();
+	return *st.host<uint32_t>(o);
+}
+
+static void intra_pred(int16_t *pred, int ps, int16_t *adi, int adi_size, int n, int mode, int luma)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	hmr_gpu_job jb = {};
+	(void)adi_size;
+	jb.a_off = (uint32_t)(st.put2d(adi, 0, 1, 4 * n + 1, 2) / 2);
+	jb.p0 = (uint32_t)mode; jb.p1 = (uint32_t)luma;
+	st.begin_outputs();
+	size_t o = st.out((size_t)n * n * 2);
+	jb.c_off = (uint32_t)(o / 2); jb.c_stride = n;
+	*st.job() = jb;
+	st.upload();
+	must(hmr_gpu_intra_pred_batch(c, st.djob(), 1, n, st.dev<int16_t>(), st.dev<int16_t>()), "intra_pred");
+	st.finish();
+	st.get2d(o, pred, ps, n, n, 2);
+}
+void hmr_gpu_intra_planar(int16_t *pred, int ps, int16_t *adi, int adi_size, int n) { intra_pred(pred, ps, adi, adi_size, n, 0, 1); }
+void hmr_gpu_intra_angular(int16_t *pred, int ps, int16_t *adi, int adi_size, int n, int mode, int luma) { intra_pred(pred, ps, adi, adi_size, n, mode, luma); }
+
+void hmr_gpu_fill_reference_samples(int16_t *corner, int stride, int n, int left, int top, int bl, int tr, int bl_size, int tr_size, int16_t *adi_out)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	hmr_gpu_job jb = {};
+	// stage only the L-shaped neighbourhood the kernel reads: row 0 and column 0 of a (2n+1)^2 tile
+	const int S = 2 * n + 1;
+	size_t off = st.zeros((size_t)S * S * 2);
+	int16_t *tile = st.host<int16_t>(off);
+	const int rows = left ? n + (bl ? bl_size : 0) : 0, cols = top ? n + (tr ? tr_size : 0) : 0;
+	if (left || top) tile[0] = corner[0];
+	for (int y = 1; y <= rows; y++) tile[y * S] = corner[(size_t)y * stride];
+	for (int x = 1; x <= cols; x++) tile[x] = corner[x];
+	jb.a_off = (uint32_t)(off / 2); jb.a_stride = S;
+	jb.p0 = (left ? 1u : 0u) | (top ? 2u : 0u) | (bl ? 4u : 0u) | (tr ? 8u : 0u);
+	jb.p1 = (uint32_t)bl_size | ((uint32_t)tr_size << 16);
+	st.begin_outputs();
+	size_t o = st.out((size_t)(4 * n + 1) * 2);
+	jb.c_off = (uint32_t)(o / 2);
+	*st.job() = jb;
+	st.upload();
+	must(hmr_gpu_intra_refs_batch(c, st.djob(), 1, n, st.dev<int16_t>(), st.dev<int16_t>()), "intra_refs");
+	st.finish();
+	memcpy(adi_out, st.host<int16_t>(o), (size_t)(4 * n + 1) * 2);
+}
+
+// adi_filter alone: rebuild the adi array from a synthetic neighbourhood is not possible, so this entry runs the
+// filter stage of the same kernel on an already-built array placed as the top row/left column of a tile.
+void hmr_gpu_adi_filter(int16_t *adi, int16_t *out, int adi_size, int n, int strong)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	hmr_gpu_job jb = {};
+	(void)adi_size;
+	const int S = 2 * n + 1;
+	size_t off = st.zeros((size_t)S * S * 2);
+	int16_t *tile = st.host<int16_t>(off);
+	// inverse of the gather: adi[2n] corner, adi[2n-r] = row r (r = 1..2n), adi[2n+x] = column x
+	tile[0] = adi[2 * n];
+	for (int r = 1; r <= 2 * n; r++) tile[r * S] = adi[2 * n - r];
+	for (int x = 1; x <= 2 * n; x++) tile[x] = adi[2 * n + x];
+	jb.a_off = (uint32_t)(off / 2); jb.a_stride = S;
+	jb.p0 = 1u | 2u | 4u | 8u | 16u | (strong ? 32u : 0u);
+	jb.p1 = (uint32_t)n | ((uint32_t)n << 16);
+	st.begin_outputs();
+	size_t o = st.out((size_t)(4 * n + 1) * 2);
+	size_t f = st.out((size_t)(4 * n + 1) * 2);
+	jb.c_off = (uint32_t)(o / 2);
+	jb.b_off = (uint32_t)(f / 2);
+	*st.job() = jb;
+	st.upload();
+	must(hmr_gpu_intra_refs_batch(c, st.djob(), 1, n, st.dev<int16_t>(), st.dev<int16_t>()), "adi_filter");
+	st.finish();
+	memcpy(out, st.host<int16_t>(f), (size_t)(4 * n + 1) * 2);
+}
+
+static void interp(int is_luma, int16_t *src, int ss, int16_t *dst, int ds, int frac, int w, int h, int vert, int first, int last)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	if (!is_luma && frac == 0 && w < 4) return;
+	Stager st(c);
+	hmr_gpu_job jb = {};
+	const int taps = is_luma ? 8 : 4, before = frac ? taps / 2 - 1 : 0, after = frac ? taps / 2 : 0;
+	const int mx0 = vert ? 0 : before, mx1 = vert ? 0 : after, my0 = vert ? before : 0, my1 = vert ? after : 0;
+	const int tw = w + mx0 + mx1, th = h + my0 + my1;
+	size_t off = st.put2d(src - (ptrdiff_t)my0 * ss - mx0, ss, th, tw, 2);
+	jb.a_off = (uint32_t)(off / 2 + (size_t)my0 * tw + mx0); jb.a_stride = tw;
+	jb.w = (uint16_t)w; jb.h = (uint16_t)h;
+	jb.p0 = (uint32_t)frac; jb.p1 = (vert ? 1u : 0u) | (first ? 2u : 0u) | (last ? 4u : 0u);
+	st.begin_outputs();
+	size_t o = st.out((size_t)w * h * 2);
+	jb.c_off = (uint32_t)(o / 2); jb.c_stride = w;
+	*st.job() = jb;
+	st.upload();
+	must(hmr_gpu_interpolate_batch(c, st.djob(), 1, is_luma, st.dev<int16_t>(), st.dev<int16_t>()), "interpolate");
+	st.finish();
+	st.get2d(o, dst, ds, h, w, 2);
+}
+void hmr_gpu_interpolate_luma(int16_t *s, int ss, int16_t *d, int ds, int frac, int w, int h, int v, int f, int l) { interp(1, s, ss, d, ds, frac, w, h, v, f, l); }
+void hmr_gpu_interpolate_chroma(int16_t *s, int ss, int16_t *d, int ds, int frac, int w, int h, int v, int f, int l) { interp(0, s, ss, d, ds, frac, w, h, v, f, l); }
+
+void hmr_gpu_weighted_average(int16_t *a, int as, int16_t *b, int bs, int16_t *d, int ds, int h, int w)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	hmr_gpu_job jb = {};
+	jb.a_off = (uint32_t)(st.put2d(a, as, h, w, 2) / 2); jb.a_stride = w;
+	jb.b_off = (uint32_t)(st.put2d(b, bs, h, w, 2) / 2); jb.b_stride = w;
+	jb.w = (uint16_t)w; jb.h = (uint16_t)h;
+	st.begin_outputs();
+	size_t o = st.out((size_t)w * h * 2);
+	jb.c_off = (uint32_t)(o / 2); jb.c_stride = w;
+	*st.job() = jb;
+	st.upload();
+	must(hmr_gpu_weighted_average_batch(c, st.djob(), 1, st.dev<int16_t>(), st.dev<int16_t>(), st.dev<int16_t>()), "weighted_average");
+	st.finish();
+	st.get2d(o, d, ds, h, w, 2);
+}
+
+void hmr_gpu_transform(int16_t *block, int16_t *coeff, int stride, int n, int is_dst)
+{
+	if (n != 4 && n != 8 && n != 16 && n != 32) return;
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	hmr_gpu_job jb = {};
+	jb.a_off = (uint32_t)(st.put2d(block, stride, n, n, 2) / 2); jb.a_stride = n;
+	jb.p0 = (uint32_t)is_dst;
+	st.begin_outputs();
+	size_t o = st.out((size_t)n * n * 2);
+	jb.c_off = (uint32_t)(o / 2);
+	*st.job() = jb;
+	st.upload();
+	must(hmr_gpu_transform_batch(c, st.djob(), 1, n, st.dev<int16_t>(), st.dev<int16_t>()), "transform");
+	st.finish();
+	memcpy(coeff, st.host<int16_t>(o), (size_t)n * n * 2);
+}
+
+void hmr_gpu_itransform(int16_t *block, int16_t *coeff, int stride, int n, int is_dst)
+{
+	if (n != 4 && n != 8 && n != 16 && n != 32) return;
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	hmr_gpu_job jb = {};
+	jb.a_off = (uint32_t)(st.put2d(coeff, 0, 1, n * n, 2) / 2);
+	jb.p0 = (uint32_t)is_dst;
+	st.begin_outputs();
+	size_t o = st.out((size_t)n * n * 2);
+	jb.c_off = (uint32_t)(o / 2); jb.c_stride = n;
+	*st.job() = jb;
+	st.upload();
+	must(hmr_gpu_itransform_batch(c, st.djob(), 1, n, st.dev<int16_t>(), st.dev<int16_t>()), "itransform");
+	st.finish();
+	st.get2d(o, block, stride, n, n, 2);
+}
+
+void hmr_gpu_quant(int16_t *src, int16_t *dst, int16_t *delta_u, int scan_mode, int depth, int comp, int is_intra, int slice_is_intra, int sign_hiding,
+		   int *ac_sum, int cu_size, int per, int rem)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	const int n = 1 << (6 - (depth + (comp != 0)));   // inv_depth, hmr_sse42_functions_quant.c:39
+	(void)cu_size;
+	Stager st(c);
+	hmr_gpu_job jb = {};
+	jb.a_off = (uint32_t)(st.put2d(src, 0, 1, n * n, 2) / 2);
+	jb.p0 = (uint32_t)(scan_mode & 3) | ((uint32_t)comp << 2) | ((uint32_t)(is_intra != 0) << 4) | ((uint32_t)(slice_is_intra != 0) << 5) |
+		((uint32_t)(sign_hiding != 0) << 6);
+	jb.p1 = (uint32_t)per | ((uint32_t)rem << 8);
+	st.begin_outputs();
+	size_t o = st.out((size_t)n * n * 2), du = st.out((size_t)n * n * 2), ac = st.out(4);
+	jb.c_off = (uint32_t)(o / 2);
+	jb.b_off = (uint32_t)(du / 2);
+	*st.job() = jb;
+	st.upload();
+	must(hmr_gpu_quant_batch(c, st.djob(), 1, n, st.dev<int16_t>(), st.dev<int16_t>(), st.dev<int16_t>(), st.dev<int32_t>(ac)), "quant");
+	st.finish();
+	memcpy(dst, st.host<int16_t>(o), (size_t)n * n * 2);
+	if (delta_u) memcpy(delta_u, st.host<int16_t>(du), (size_t)n * n * 2);
+	*ac_sum = *st.host<int32_t>(ac);
+}
+
+void hmr_gpu_inv_quant(int16_t *src, int16_t *dst, int depth, int comp, int is_intra, int cu_size, int per, int rem)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	const int n = 1 << (6 - (depth + (comp != 0)));
+	(void)cu_size;
+	Stager st(c);
+	hmr_gpu_job jb = {};
+	jb.a_off = (uint32_t)(st.put2d(src, 0, 1, n * n, 2) / 2);
+	jb.p0 = ((uint32_t)comp << 2) | ((uint32_t)(is_intra != 0) << 4);
+	jb.p1 = (uint32_t)per | ((uint32_t)rem << 8);
+	st.begin_outputs();
+	size_t o = st.out((size_t)n * n * 2);
+	jb.c_off = (uint32_t)(o / 2);
+	*st.job() = jb;
+	st.upload();
+	must(hmr_gpu_inv_quant_batch(c, st.djob(), 1, n, st.dev<int16_t>(), st.dev<int16_t>()), "inv_quant");
+	st.finish();
+	memcpy(dst, st.host<int16_t>(o), (size_t)n * n * 2);
+}
+
+}  // extern "C"

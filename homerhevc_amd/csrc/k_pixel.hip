@@ -1,0 +1,194 @@
+// Batched pixel kernels: SAD, SSD, residual, reconstruction, copies, modified variance, bi-pred average.
+// Reference semantics: hmr_sse42_functions_pixel.c:152-1136, hmr_sse42_functions_inter_prediction.c:944.
+//
+// Mapping: a job (one N x N block) is owned by a group of G = min(64, N*N) lanes of one wave, so a wave
+// carries 4 4x4 blocks or one larger block; lanes walk the block row-major, i.e. consecutive lanes read
+// consecutive samples of a row (coalesced 2-byte accesses into 128-byte row segments), and the per-job
+// result is reduced with cross-lane shuffles - no LDS, no atomics.  HBM/L2-bound integer work: no MFMA.
+#include "common.h"
+
+namespace {
+
+enum { OP_SAD = 0, OP_SSD = 1 };
+
+template <int N, int OP>
+__global__ __launch_bounds__(HMR_BLOCK) void k_sad_ssd(const hmr_gpu_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ A,
+							  const int16_t *__restrict__ B, uint32_t *__restrict__ out)
+{
+	constexpr int E = N * N;
+	constexpr int G = E < HMR_WAVE ? E : HMR_WAVE;
+	constexpr int JPW = HMR_WAVE / G;
+	const int lane = lane_id(), sub = lane / G, l = lane % G;
+	const long wave = (long)blockIdx.x * HMR_WAVES_PER_BLOCK + wave_in_block();
+	const long nwaves = (long)gridDim.x * HMR_WAVES_PER_BLOCK;
+	for (long j0 = wave * JPW; j0 < njobs; j0 += nwaves * JPW) {
+		const long j = j0 + sub;
+		uint32_t acc = 0;
+		if (j < njobs) {
+			const hmr_gpu_job jb = jobs[j];
+			const int16_t *a = A + jb.a_off;
+			const int16_t *b = B + jb.b_off;
+#pragma unroll 4
+			for (int e = l; e < E; e += G) {
+				const int y = e / N, x = e % N;
+				const int d = (int16_t)(a[(size_t)y * jb.a_stride + x] - b[(size_t)y * jb.b_stride + x]);
+				acc += OP == OP_SAD ? (uint32_t)(d < 0 ? -d : d) : (uint32_t)(d * d);
+			}
+		}
+		acc = group_sum<G>(acc);
+		if (j < njobs && l == 0) out[j] = acc;
+	}
+}
+
+enum { EW_PREDICT = 0, EW_RECONST = 1, EW_WAVG = 2 };
+
+// c = f(a, b) over a w x h region (square kernels pass w = h = N through the job)
+template <int OP>
+__global__ __launch_bounds__(HMR_BLOCK) void k_elementwise(const hmr_gpu_job *__restrict__ jobs, int njobs, int size, const int16_t *__restrict__ A,
+							      const int16_t *__restrict__ B, int16_t *__restrict__ Cc)
+{
+	const int lane = lane_id();
+	const long wave = (long)blockIdx.x * HMR_WAVES_PER_BLOCK + wave_in_block();
+	const long nwaves = (long)gridDim.x * HMR_WAVES_PER_BLOCK;
+	for (long j = wave; j < njobs; j += nwaves) {
+		const hmr_gpu_job jb = jobs[j];
+		const int w = size ? size : jb.w, h = size ? size : jb.h;
+		const int16_t *a = A + jb.a_off;
+		const int16_t *b = B + jb.b_off;
+		int16_t *c = Cc + jb.c_off;
+		for (int e = lane; e < w * h; e += HMR_WAVE) {
+			const int y = e / w, x = e - y * w;
+			const int va = a[(size_t)y * jb.a_stride + x], vb = b[(size_t)y * jb.b_stride + x];
+			int r;
+			if (OP == EW_PREDICT) r = (int16_t)(va - vb);
+			else if (OP == EW_RECONST) r = clip3i(sat16i(va + vb), 0, 255);
+			else r = clip3i(sat16i((va + vb + 64 + 16384) >> 7), 0, 255);
+			c[(size_t)y * jb.c_stride + x] = (int16_t)r;
+		}
+	}
+}
+
+template <typename TS, typename TD, int CLAMP>
+__global__ __launch_bounds__(HMR_BLOCK) void k_copy(const hmr_gpu_job *__restrict__ jobs, int njobs, const TS *__restrict__ A, TD *__restrict__ Cc)
+{
+	const int lane = lane_id();
+	const long wave = (long)blockIdx.x * HMR_WAVES_PER_BLOCK + wave_in_block();
+	const long nwaves = (long)gridDim.x * HMR_WAVES_PER_BLOCK;
+	for (long j = wave; j < njobs; j += nwaves) {
+		const hmr_gpu_job jb = jobs[j];
+		const TS *a = A + jb.a_off;
+		TD *c = Cc + jb.c_off;
+		const int w = jb.w, h = jb.h;
+		for (int e = lane; e < w * h; e += HMR_WAVE) {
+			const int y = e / w, x = e - y * w;
+			int v = a[(size_t)y * jb.a_stride + x];
+			if (CLAMP) v = clip3i(v, 0, 255);
+			c[(size_t)y * jb.c_stride + x] = (TD)v;
+		}
+	}
+}
+
+// hmr_sse42_functions_pixel.c:1123 - statistics over the BYTES the SSE code zero-extends:
+// `size` bytes per row; for size >= 16 bytes [32g, 32g+8) and [32g+16, 32g+24) of each 16-sample group g.
+__global__ __launch_bounds__(HMR_BLOCK) void k_modified_variance(const hmr_gpu_job *__restrict__ jobs, int njobs, int size, const int16_t *__restrict__ A,
+								    uint32_t *__restrict__ out)
+{
+	const int lane = lane_id();
+	const long wave = (long)blockIdx.x * HMR_WAVES_PER_BLOCK + wave_in_block();
+	const long nwaves = (long)gridDim.x * HMR_WAVES_PER_BLOCK;
+	for (long j = wave; j < njobs; j += nwaves) {
+		const hmr_gpu_job jb = jobs[j];
+		const uint8_t *base = (const uint8_t *)(A + jb.a_off);
+		const int modif = (int)jb.p0, total = size * size;
+		uint32_t sum = 0;
+		for (int e = lane; e < total; e += HMR_WAVE) {
+			const int y = e / size, k = e - y * size;
+			const int off = size < 16 ? k : (k >> 4) * 32 + ((k >> 3) & 1) * 16 + (k & 7);
+			sum += base[(size_t)y * jb.a_stride * 2 + off];
+		}
+		sum = wave_sum(sum);
+		const int avg = (int)(sum / (uint32_t)total);
+		uint32_t var = 0;
+		for (int e = lane; e < total; e += HMR_WAVE) {
+			const int y = e / size, k = e - y * size;
+			const int off = size < 16 ? k : (k >> 4) * 32 + ((k >> 3) & 1) * 16 + (k & 7);
+			const int v = base[(size_t)y * jb.a_stride * 2 + off];
+			const int d = (int16_t)(1 + (int16_t)((int16_t)(v - avg) * (int16_t)modif));
+			var += (uint32_t)(d * d);
+		}
+		var = wave_sum(var);
+		if (lane == 0) out[j] = var;
+	}
+}
+
+template <int OP>
+int launch_sad_ssd(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *A, const int16_t *B, uint32_t *out)
+{
+	if (njobs <= 0) return HMR_GPU_OK;
+	// any size other than 4/8/16/32 takes the 64x64 path in the reference (hmr_sse42_functions_pixel.c:462-475)
+	const int n = (size == 4 || size == 8 || size == 16 || size == 32) ? size : 64;
+	const long waves = n == 4 ? (njobs + 3) / 4 : njobs;
+	dim3 grid(hmr_grid_for_waves(waves)), block(HMR_BLOCK);
+	switch (n) {
+	case 4: hipLaunchKernelGGL((k_sad_ssd<4, OP>), grid, block, 0, ctx->stream, jobs, njobs, A, B, out); break;
+	case 8: hipLaunchKernelGGL((k_sad_ssd<8, OP>), grid, block, 0, ctx->stream, jobs, njobs, A, B, out); break;
+	case 16: hipLaunchKernelGGL((k_sad_ssd<16, OP>), grid, block, 0, ctx->stream, jobs, njobs, A, B, out); break;
+	case 32: hipLaunchKernelGGL((k_sad_ssd<32, OP>), grid, block, 0, ctx->stream, jobs, njobs, A, B, out); break;
+	default: hipLaunchKernelGGL((k_sad_ssd<64, OP>), grid, block, 0, ctx->stream, jobs, njobs, A, B, out); break;
+	}
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
+
+}  // namespace
+
+extern "C" int hmr_gpu_sad_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a, const int16_t *b, uint32_t *out)
+{
+	return launch_sad_ssd<OP_SAD>(ctx, jobs, njobs, size, a, b, out);
+}
+extern "C" int hmr_gpu_ssd16b_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a, const int16_t *b, uint32_t *out)
+{
+	return launch_sad_ssd<OP_SSD>(ctx, jobs, njobs, size, a, b, out);
+}
+extern "C" int hmr_gpu_predict_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a, const int16_t *b, int16_t *c)
+{
+	if (njobs <= 0) return HMR_GPU_OK;
+	if (size <= 0 || size > 64) return HMR_GPU_ERR_ARG;
+	hipLaunchKernelGGL((k_elementwise<EW_PREDICT>), dim3(hmr_grid_for_waves(njobs)), dim3(HMR_BLOCK), 0, ctx->stream, jobs, njobs, size, a, b, c);
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
+extern "C" int hmr_gpu_reconst_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a, const int16_t *b, int16_t *c)
+{
+	if (njobs <= 0) return HMR_GPU_OK;
+	if (size <= 0 || size > 64) return HMR_GPU_ERR_ARG;
+	hipLaunchKernelGGL((k_elementwise<EW_RECONST>), dim3(hmr_grid_for_waves(njobs)), dim3(HMR_BLOCK), 0, ctx->stream, jobs, njobs, size, a, b, c);
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
+extern "C" int hmr_gpu_weighted_average_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, const int16_t *a, const int16_t *b, int16_t *c)
+{
+	if (njobs <= 0) return HMR_GPU_OK;
+	hipLaunchKernelGGL((k_elementwise<EW_WAVG>), dim3(hmr_grid_for_waves(njobs)), dim3(HMR_BLOCK), 0, ctx->stream, jobs, njobs, 0, a, b, c);
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
+extern "C" int hmr_gpu_copy_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int kind, const void *a, void *c)
+{
+	if (njobs <= 0) return HMR_GPU_OK;
+	dim3 grid(hmr_grid_for_waves(njobs)), block(HMR_BLOCK);
+	if (kind == 0) hipLaunchKernelGGL((k_copy<int16_t, int16_t, 0>), grid, block, 0, ctx->stream, jobs, njobs, (const int16_t *)a, (int16_t *)c);
+	else if (kind == 1) hipLaunchKernelGGL((k_copy<uint8_t, int16_t, 0>), grid, block, 0, ctx->stream, jobs, njobs, (const uint8_t *)a, (int16_t *)c);
+	else if (kind == 2) hipLaunchKernelGGL((k_copy<int16_t, uint8_t, 1>), grid, block, 0, ctx->stream, jobs, njobs, (const int16_t *)a, (uint8_t *)c);
+	else return HMR_GPU_ERR_ARG;
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
+extern "C" int hmr_gpu_modified_variance_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a, uint32_t *out)
+{
+	if (njobs <= 0) return HMR_GPU_OK;
+	if (size < 2 || size > 64) return HMR_GPU_ERR_ARG;
+	hipLaunchKernelGGL(k_modified_variance, dim3(hmr_grid_for_waves(njobs)), dim3(HMR_BLOCK), 0, ctx->stream, jobs, njobs, size, a, out);
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}

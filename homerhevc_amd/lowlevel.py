@@ -1,0 +1,58 @@
+"""ctypes mirror of the reference's plug-in surface, `struct low_level_funcs_t` (hmr_private.h:1063-1092).
+
+`LowLevelFuncs` exposes the table's member names (sad, ssd16b, predict, reconst, transform, quant, ...) bound
+to the drop-in entries of libhomer_gpu.so, which take HOST pointers and are synchronous exactly like the
+SSE4.2 functions the reference stores there (hmr_encoder_lib.c:159-187).  Members whose reference signature
+starts with `henc_thread_t*` take the scalars that struct is read for instead (see include/homer_gpu.h).
+"""
+import ctypes as C
+import os
+
+from .build import LIB_PATH
+
+_I16P = C.c_void_p
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def load_library():
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(f"{LIB_PATH} not built: run __graft_entry__.build() (there is no CPU fallback)")
+    return C.CDLL(LIB_PATH)
+
+
+# member name in low_level_funcs_t -> (exported symbol, restype, argtypes)
+TABLE = {
+    "sse_copy_16_16": ("hmr_gpu_copy_16_16", None, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
+    "sse_copy_16_8": ("hmr_gpu_copy_16_8", None, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
+    "sse_copy_8_16": ("hmr_gpu_copy_8_16", None, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
+    "sad": ("hmr_gpu_sad", C.c_uint32, [_I16P, C.c_uint32, _I16P, C.c_uint32, C.c_int]),
+    "ssd16b": ("hmr_gpu_ssd16b", C.c_uint32, [_I16P, C.c_uint32, _I16P, C.c_uint32, C.c_int]),
+    "predict": ("hmr_gpu_predict", None, [_I16P, C.c_int, _I16P, C.c_int, _I16P, C.c_int, C.c_int]),
+    "reconst": ("hmr_gpu_reconst", None, [_I16P, C.c_int, _I16P, C.c_int, _I16P, C.c_int, C.c_int]),
+    "modified_variance": ("hmr_gpu_modified_variance", C.c_uint32, [_I16P, C.c_int, C.c_int, C.c_int]),
+    "create_intra_planar_prediction": ("hmr_gpu_intra_planar", None, [_I16P, C.c_int, _I16P, C.c_int, C.c_int]),
+    "create_intra_angular_prediction": ("hmr_gpu_intra_angular", None, [_I16P, C.c_int, _I16P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "interpolate_luma_m_compensation": ("hmr_gpu_interpolate_luma", None, [_I16P, C.c_int, _I16P, C.c_int] + [C.c_int] * 6),
+    "interpolate_chroma_m_compensation": ("hmr_gpu_interpolate_chroma", None, [_I16P, C.c_int, _I16P, C.c_int] + [C.c_int] * 6),
+    "interpolate_luma_m_estimation": ("hmr_gpu_interpolate_luma", None, [_I16P, C.c_int, _I16P, C.c_int] + [C.c_int] * 6),
+    "weighted_average_motion": ("hmr_gpu_weighted_average", None, [_I16P, C.c_int, _I16P, C.c_int, _I16P, C.c_int, C.c_int, C.c_int]),
+    "quant": ("hmr_gpu_quant", None, [_I16P, _I16P, _I16P] + [C.c_int] * 6 + [C.POINTER(C.c_int)] + [C.c_int] * 3),
+    "inv_quant": ("hmr_gpu_inv_quant", None, [_I16P, _I16P] + [C.c_int] * 6),
+    "transform": ("hmr_gpu_transform", None, [_I16P, _I16P, C.c_int, C.c_int, C.c_int]),
+    "itransform": ("hmr_gpu_itransform", None, [_I16P, _I16P, C.c_int, C.c_int, C.c_int]),
+}
+
+
+class LowLevelFuncs:
+    """The function table, populated the way HOMER_enc_init populates hvenc->funcs."""
+
+    def __init__(self, lib=None):
+        self.lib = lib or load_library()
+        for member, (sym, restype, argtypes) in TABLE.items():
+            f = getattr(self.lib, sym)
+            f.restype = restype
+            f.argtypes = argtypes
+            setattr(self, member, f)

@@ -1,0 +1,155 @@
+/*
+ * homer_gpu.h - C ABI of the MI355X (gfx950) backend for HomerHEVC's per-block encode hot path.
+ *
+ * The reference's plug-in surface is `struct low_level_funcs_t` (hmr_private.h:1063-1092), a table of
+ * 19 function pointers filled once in HOMER_enc_init (hmr_encoder_lib.c:155-214).  This library
+ * replaces what is behind that table, plus the in-loop kernels the reference keeps outside it
+ * (deblock, SAO offset, intra reference build, border padding), with hand-written HIP
+ * kernels.  Three layers, all `extern "C"`, plain pointers and sizes:
+ *
+ *   1. context / device memory          hmr_gpu_create ... hmr_gpu_timer_stop
+ *   2. drop-in entries                   hmr_gpu_sad(...) etc.: HOST pointers, synchronous, the exact
+ *                                        low_level_funcs_t signatures (henc_thread_t* arguments flattened
+ *                                        to the scalars they carry); one launch per call - correct, not fast
+ *   3. batched entries                   hmr_gpu_*_batch(ctx, jobs, n, ...): DEVICE-resident planes addressed by
+ *                                        job descriptors; one launch per batch - the performance path
+ *      frame-level in-loop passes        hmr_gpu_deblock_frame / sao_* / pad_frame
+ *
+ * All samples are int16_t and strides are in elements, as in the reference.
+ * Every entry returns 0 on success or a negative hmr_gpu_status; nothing falls back to the CPU.
+ */
+#ifndef HOMER_GPU_H
+#define HOMER_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hmr_gpu_ctx hmr_gpu_ctx;
+
+enum hmr_gpu_status {
+	HMR_GPU_OK = 0,
+	HMR_GPU_ERR_NO_DEVICE = -1,   /* no HIP device / wrong architecture */
+	HMR_GPU_ERR_HIP = -2,         /* a HIP call failed, see hmr_gpu_last_error */
+	HMR_GPU_ERR_ARG = -3,         /* unsupported size or malformed argument */
+	HMR_GPU_ERR_NOMEM = -4
+};
+
+/* ------------------------------------------------------------------------------------------------
+ * 1. context, device memory, timing
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Create a context on `device` (HIP ordinal).  `stream` may be an existing hipStream_t (e.g. the
+ * torch current stream, passed as void*) or NULL to let the context own one. */
+int hmr_gpu_create(hmr_gpu_ctx **out, int device, void *stream);
+void hmr_gpu_destroy(hmr_gpu_ctx *ctx);
+const char *hmr_gpu_last_error(void);
+int hmr_gpu_sync(hmr_gpu_ctx *ctx);
+void *hmr_gpu_stream(hmr_gpu_ctx *ctx);   /* the hipStream_t every launch of this context goes to */
+
+int hmr_gpu_malloc(hmr_gpu_ctx *ctx, void **dev_ptr, size_t bytes);
+int hmr_gpu_free(hmr_gpu_ctx *ctx, void *dev_ptr);
+int hmr_gpu_upload(hmr_gpu_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);     /* sync */
+int hmr_gpu_download(hmr_gpu_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);   /* sync */
+int hmr_gpu_memset(hmr_gpu_ctx *ctx, void *dev_dst, int value, size_t bytes);
+
+/* HIP-event timer on the context's stream (bench.py brackets the timed region with it). */
+int hmr_gpu_timer_start(hmr_gpu_ctx *ctx);
+int hmr_gpu_timer_stop(hmr_gpu_ctx *ctx, float *elapsed_ms);   /* records, synchronises, returns ms */
+
+/* Constant tables the kernels use, built at context creation (defaults of hmr_tables.c:62,221 and
+ * hmr_encoder_lib.c:93-140); exposed so the host can check them against its own. */
+int hmr_gpu_get_scan_table(int scan_mode, int log2_size, uint32_t *out);          /* (1<<log2)^2 entries */
+int hmr_gpu_get_quant_table(int log2_size, int list, int rem, int32_t *quant, int32_t *dequant);
+
+/* ------------------------------------------------------------------------------------------------
+ * 2. drop-in entries: host pointers, synchronous.  Signatures = low_level_funcs_t members
+ *    (hmr_private.h:1066-1091); they run on the process-wide default context (device 0, created on
+ *    first use, or the one set with hmr_gpu_set_default).
+ * ------------------------------------------------------------------------------------------------ */
+int hmr_gpu_set_default(hmr_gpu_ctx *ctx);
+
+/* hmr_private.h:1066-1068 (sse_copy_16_16 / sse_copy_16_8 / sse_copy_8_16), SSE impl hmr_sse42_functions_pixel.c:152,319,236 */
+void hmr_gpu_copy_16_16(void *src, uint32_t src_stride, void *dst, uint32_t dst_stride, int height, int width);
+void hmr_gpu_copy_16_8(void *src, uint32_t src_stride, void *dst, uint32_t dst_stride, int height, int width);
+void hmr_gpu_copy_8_16(void *src, uint32_t src_stride, void *dst, uint32_t dst_stride, int height, int width);
+/* :1069 sad, :1071 ssd16b, :1072 predict, :1073 reconst, :1074 modified_variance */
+uint32_t hmr_gpu_sad(int16_t *src, uint32_t src_stride, int16_t *pred, uint32_t pred_stride, int size);
+uint32_t hmr_gpu_ssd16b(int16_t *src, uint32_t src_stride, int16_t *pred, uint32_t pred_stride, int size);
+void hmr_gpu_predict(int16_t *orig, int orig_stride, int16_t *pred, int pred_stride, int16_t *residual, int residual_stride, int size);
+void hmr_gpu_reconst(int16_t *pred, int pred_stride, int16_t *residual, int residual_stride, int16_t *decoded, int decoded_stride, int size);
+uint32_t hmr_gpu_modified_variance(int16_t *p, int size, int stride, int modif);
+/* :1076 create_intra_planar_prediction, :1077 create_intra_angular_prediction (henc_thread_t*, ctu_info_t* dropped:
+ * they only carry scratch buffers, the angle tables and ctu->top/left which are always 1, hmr_motion_intra.c:257) */
+void hmr_gpu_intra_planar(int16_t *prediction, int pred_stride, int16_t *adi_pred_buff, int adi_size, int cu_size);
+void hmr_gpu_intra_angular(int16_t *prediction, int pred_stride, int16_t *adi_pred_buff, int adi_size, int cu_size, int cu_mode, int is_luma);
+/* not in the table: fill_reference_samples hmr_motion_intra.c:246 and adi_filter :189, partition node flattened to flags */
+void hmr_gpu_fill_reference_samples(int16_t *decoded_corner, int stride, int n, int left, int top, int bottom_left, int top_right,
+				    int bl_size, int tr_size, int16_t *adi_out);
+void hmr_gpu_adi_filter(int16_t *adi, int16_t *out, int adi_size, int n, int strong_enabled);
+/* :1079-1081 interpolate_luma_m_compensation/_m_estimation, interpolate_chroma_m_compensation, :1083 weighted_average_motion */
+void hmr_gpu_interpolate_luma(int16_t *reference_buff, int reference_buff_stride, int16_t *pred_buff, int pred_buff_stride, int fraction,
+			      int width, int height, int is_vertical, int is_first, int is_last);
+void hmr_gpu_interpolate_chroma(int16_t *reference_buff, int reference_buff_stride, int16_t *pred_buff, int pred_buff_stride, int fraction,
+				int width, int height, int is_vertical, int is_first, int is_last);
+void hmr_gpu_weighted_average(int16_t *src0, int src0_stride, int16_t *src1, int src1_stride, int16_t *dst, int dst_stride, int height, int width);
+/* :1088 transform, :1089 itransform (bit depth fixed at 8, uiMode reduced to "DST-VII for 4x4 intra luma") */
+void hmr_gpu_transform(int16_t *block, int16_t *coeff, int block_stride, int n, int is_dst);
+void hmr_gpu_itransform(int16_t *block, int16_t *coeff, int block_stride, int n, int is_dst);
+/* :1085 quant, :1086 inv_quant.  henc_thread_t* replaced by what it is read for: slice type (hmr_sse42_functions_quant.c:47),
+ * pps->sign_data_hiding_flag (:121) and the aux_buff scratch that receives deltaU (:48; NULL = do not return it). */
+void hmr_gpu_quant(int16_t *src, int16_t *dst, int16_t *delta_u, int scan_mode, int depth, int comp, int is_intra, int slice_is_intra,
+		   int sign_hiding, int *ac_sum, int cu_size, int per, int rem);
+void hmr_gpu_inv_quant(int16_t *src, int16_t *dst, int depth, int comp, int is_intra, int cu_size, int per, int rem);
+
+/* ------------------------------------------------------------------------------------------------
+ * 3. batched entries: device-resident operands, one launch per call, asynchronous on the context's
+ *    stream.  A job addresses up to three operands by ELEMENT offset from the base pointer passed to
+ *    the call; all jobs of one call share `size` (the host groups work by block size, the way it
+ *    groups CUs by depth).  `jobs` is a DEVICE pointer (upload with hmr_gpu_upload).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct hmr_gpu_job {
+	uint32_t a_off, a_stride;   /* first operand  (src / orig / pred / reference / adi / coeff-in)  */
+	uint32_t b_off, b_stride;   /* second operand (pred / residual / ...)                            */
+	uint32_t c_off, c_stride;   /* output                                                            */
+	uint16_t w, h;              /* extent where the kernel is not square (copies, interpolation)    */
+	uint32_t p0, p1;            /* kernel-specific parameters, see each entry                        */
+} hmr_gpu_job;
+
+/* out[i] = SAD / SSD of job i.  a = src, b = pred (b_stride may be 0 for ssd) */
+int hmr_gpu_sad_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, const int16_t *b_base, uint32_t *out);
+int hmr_gpu_ssd16b_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, const int16_t *b_base, uint32_t *out);
+/* c = a - b */
+int hmr_gpu_predict_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, const int16_t *b_base, int16_t *c_base);
+/* c = clip(a (pred) + b (residual, stride may be 0)) */
+int hmr_gpu_reconst_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, const int16_t *b_base, int16_t *c_base);
+/* c[h x w] = a[h x w]; kind 0: i16->i16, 1: u8->i16, 2: i16->u8 (offsets/strides in elements of each side's type) */
+int hmr_gpu_copy_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int kind, const void *a_base, void *c_base);
+/* out[i] = modified variance of the size x size block at a; p0 = modif */
+int hmr_gpu_modified_variance_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, uint32_t *out);
+/* a = adi array (4*size+1 entries at a_off), c = prediction; p0 = cu_mode (0 planar, 1 DC, 2..34), p1 = is_luma */
+int hmr_gpu_intra_pred_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, int16_t *c_base);
+/* a = reconstructed plane, a_off addresses the corner sample (-1,-1), c = adi out (4*size+1), b_off = filtered adi out;
+ * p0 bits: 0 left, 1 top, 2 bottom_left, 3 top_right, 4 write filtered copy, 5 strong filter enabled; p1 = bl_size | tr_size << 16 */
+int hmr_gpu_intra_refs_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, int16_t *c_base);
+/* a = reference/intermediate, c = out, w/h = extent; p0 = fraction, p1 bits: 0 vertical, 1 first, 2 last; is_luma picks taps */
+int hmr_gpu_interpolate_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int is_luma, const int16_t *a_base, int16_t *c_base);
+int hmr_gpu_weighted_average_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, const int16_t *a_base, const int16_t *b_base, int16_t *c_base);
+/* a = residual block (strided), c = coefficients (linear size*size at c_off); p0 = is_dst */
+int hmr_gpu_transform_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, int16_t *c_base);
+/* a = coefficients (linear), c = residual block (strided); p0 = is_dst */
+int hmr_gpu_itransform_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, int16_t *c_base);
+/* a = coefficients in, c = levels out (both linear), b_off = deltaU out when delta_u_base != NULL;
+ * p0 bits 0-1 scan_mode, 2-3 comp, 4 is_intra, 5 slice_is_intra, 6 sign_hiding; p1 = per | rem << 8; ac_sum[i] out */
+int hmr_gpu_quant_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, int16_t *c_base,
+			int16_t *delta_u_base, int32_t *ac_sum);
+/* a = levels, c = coefficients; p0 bits 2-3 comp, 4 is_intra; p1 = per | rem << 8 */
+int hmr_gpu_inv_quant_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, int16_t *c_base);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOMER_GPU_H */
