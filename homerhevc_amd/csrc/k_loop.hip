@@ -1,0 +1,413 @@
+// Frame-level in-loop filters: deblocking (two passes), SAO statistics, SAO offset, reference border padding.
+// Reference semantics: hmr_deblocking_filter.c:737 (+:138,287,478), hmr_sse42_sao.c:35, hmr_sao.c:960,1210,
+// hmr_encoder_lib.c:1723.  The reference runs these CTU by CTU in a lagged pipeline (hmr_encoder_lib.c:2386);
+// every sample it reads is final when read, so whole-picture passes give identical results and expose the
+// picture's full parallelism: these are the HBM-streaming kernels of the path.
+//
+// Deblock: one thread per 4-sample edge segment.  For vertical edges consecutive lanes own consecutive edges of
+// one 4-row band, so each row is read as 16-byte pieces at a 16-byte pitch - a fully coalesced 1 KiB row segment
+// per wave; for horizontal edges one lane owns one column and the per-segment decisions are exchanged inside
+// 4-lane groups with shuffles.  SAO statistics: one workgroup per (CTU, component), the (w+2) x (h+2) deblocked
+// tile staged in LDS, per-lane class counters reduced with wave shuffles, then one LDS atomic per wave.
+#include "common.h"
+
+namespace {
+
+constexpr int F_INTRA = 1, F_CBF = 2, F_EDGE_VER = 4, F_EDGE_HOR = 8;
+
+__constant__ uint8_t cTc[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+				2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
+__constant__ uint8_t cBeta[52] = {0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15,
+				  16, 17, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
+__constant__ uint8_t cChromaMid[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37};
+
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int chroma_qp(int q)
+{
+	q = clip3i(q, 0, 57);
+	return q < 30 ? q : (q < 44 ? cChromaMid[q - 30] : q - 6);
+}
+
+struct UnitInfo {
+	int units_stride;
+	const int16_t *mvx, *mvy;
+	const int8_t *ref_idx;
+	const uint8_t *qp;
+	const uint8_t *flags;
+};
+
+__device__ __forceinline__ int boundary_strength(const UnitInfo &ui, int q, int p)
+{
+	const int fq = ui.flags[q], fp = ui.flags[p];
+	if ((fq | fp) & F_INTRA) return 2;
+	if ((fq | fp) & F_CBF) return 1;
+	const int rq = ui.ref_idx[q], rp = ui.ref_idx[p];
+	const int mqx = rq < 0 ? 0 : ui.mvx[q], mqy = rq < 0 ? 0 : ui.mvy[q];
+	const int mpx = rp < 0 ? 0 : ui.mvx[p], mpy = rp < 0 ? 0 : ui.mvy[p];
+	if ((rp < 0 ? -1 : rp) != (rq < 0 ? -1 : rq)) return 1;
+	return (iabs(mqx - mpx) >= 4 || iabs(mqy - mpy) >= 4) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(HMR_BLOCK) void k_edge_flags(const uint8_t *__restrict__ pred_depth, const uint8_t *__restrict__ tr_idx, int w4, int h4,
+							     int units_stride, uint8_t *__restrict__ flags)
+{
+	const int i = blockIdx.x * HMR_BLOCK + threadIdx.x;
+	if (i >= w4 * h4) return;
+	const int uy = i / w4, ux = i - uy * w4, o = uy * units_stride + ux;
+	int leaf = 64 >> (pred_depth[o] + tr_idx[o]);
+	if (leaf < 8) leaf = 8;
+	int f = flags[o] & ~(F_EDGE_VER | F_EDGE_HOR);
+	if (ux && (ux * 4) % leaf == 0) f |= F_EDGE_VER;
+	if (uy && (uy * 4) % leaf == 0) f |= F_EDGE_HOR;
+	flags[o] = (uint8_t)f;
+}
+
+// luma filter of one line m[0..7] = p3 p2 p1 p0 q0 q1 q2 q3 (filter_luma, hmr_deblocking_filter.c:287)
+__device__ __forceinline__ void luma_line(int (&m)[8], int tc, bool strong, int thr_cut, bool fp, bool fq)
+{
+	const int m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7];
+	if (strong) {
+		m[3] = clip3i((m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3, m3 - 2 * tc, m3 + 2 * tc);
+		m[4] = clip3i((m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3, m4 - 2 * tc, m4 + 2 * tc);
+		m[2] = clip3i((m1 + m2 + m3 + m4 + 2) >> 2, m2 - 2 * tc, m2 + 2 * tc);
+		m[5] = clip3i((m3 + m4 + m5 + m6 + 2) >> 2, m5 - 2 * tc, m5 + 2 * tc);
+		m[1] = clip3i((2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3, m1 - 2 * tc, m1 + 2 * tc);
+		m[6] = clip3i((m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3, m6 - 2 * tc, m6 + 2 * tc);
+	} else {
+		int delta = (9 * (m4 - m3) - 3 * (m5 - m2) + 8) >> 4;
+		if (iabs(delta) < thr_cut) {
+			const int tc2 = tc >> 1;
+			delta = clip3i(delta, -tc, tc);
+			m[3] = clip3i(m3 + delta, 0, 255);
+			m[4] = clip3i(m4 - delta, 0, 255);
+			if (fp) m[2] = clip3i(m2 + clip3i((((m1 + m3 + 1) >> 1) - m2 + delta) >> 1, -tc2, tc2), 0, 255);
+			if (fq) m[5] = clip3i(m5 + clip3i((((m6 + m4 + 1) >> 1) - m5 - delta) >> 1, -tc2, tc2), 0, 255);
+		}
+	}
+}
+
+__device__ __forceinline__ bool strong_decision(const int (&m)[8], int d, int beta, int tc)
+{
+	return (iabs(m[0] - m[3]) + iabs(m[7] - m[4]) < (beta >> 3)) && (d < (beta >> 2)) && (iabs(m[3] - m[4]) < ((tc * 5 + 1) >> 1));
+}
+
+__device__ __forceinline__ void chroma_edge(int16_t *e, int s, int t, int tc)
+{
+#pragma unroll
+	for (int i = 0; i < 2; i++) {
+		int16_t *x = e + i * t;
+		const int m4 = x[0], m3 = x[-s], m5 = x[s], m2 = x[-2 * s];
+		const int delta = clip3i((((m4 - m3) << 2) + m2 - m5 + 4) >> 3, -tc, tc);
+		x[-s] = (int16_t)clip3i(m3 + delta, 0, 255);
+		x[0] = (int16_t)clip3i(m4 - delta, 0, 255);
+	}
+}
+
+struct DeblockArgs {
+	int16_t *y, *u, *v;
+	int ys, cs, w4, h4;
+	UnitInfo ui;
+	int cb_off, cr_off, beta_off, tc_off;
+	uint8_t *bs_out;
+};
+
+// vertical edges: thread = (unit row uy, even unit column ux)
+__global__ __launch_bounds__(HMR_BLOCK) void k_deblock_ver(DeblockArgs a)
+{
+	const int ew = (a.w4 + 1) / 2;                 // edges per unit row (even ux)
+	const int i = blockIdx.x * HMR_BLOCK + threadIdx.x;
+	if (i >= ew * a.h4) return;
+	const int uy = i / ew, ux = (i - uy * ew) * 2;
+	const int q = uy * a.ui.units_stride + ux;
+	if (a.bs_out) { a.bs_out[q] = 0; if (ux + 1 < a.w4) a.bs_out[q + 1] = 0; }
+	if (!(a.ui.flags[q] & F_EDGE_VER)) return;
+	const int p = q - 1;
+	const int bs = boundary_strength(a.ui, q, p);
+	if (a.bs_out) a.bs_out[q] = (uint8_t)(0x80 | bs);
+	if (!bs) return;
+	const int qpa = (a.ui.qp[p] + a.ui.qp[q] + 1) >> 1;
+	const int tc = cTc[clip3i(qpa + 2 * (bs - 1) + (a.tc_off << 1), 0, 53)];
+	const int beta = cBeta[clip3i(qpa + (a.beta_off << 1), 0, 51)];
+	int16_t *e = a.y + (size_t)uy * 4 * a.ys + ux * 4;
+	int m[4][8];
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		// 8 samples p3..q3 start 8-byte aligned (edge on the 8-sample grid, strides are multiples of 8 samples)
+		const short4 lo = *reinterpret_cast<const short4 *>(e + (size_t)r * a.ys - 4);
+		const short4 hi = *reinterpret_cast<const short4 *>(e + (size_t)r * a.ys);
+		m[r][0] = lo.x; m[r][1] = lo.y; m[r][2] = lo.z; m[r][3] = lo.w;
+		m[r][4] = hi.x; m[r][5] = hi.y; m[r][6] = hi.z; m[r][7] = hi.w;
+	}
+	const int dp0 = iabs(m[0][1] - 2 * m[0][2] + m[0][3]), dq0 = iabs(m[0][4] - 2 * m[0][5] + m[0][6]);
+	const int dp3 = iabs(m[3][1] - 2 * m[3][2] + m[3][3]), dq3 = iabs(m[3][4] - 2 * m[3][5] + m[3][6]);
+	const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+	if (d0 + d3 < beta) {
+		const int side = (beta + (beta >> 1)) >> 3;
+		const bool fp = (dp0 + dp3) < side, fq = (dq0 + dq3) < side;
+		const bool sw = strong_decision(m[0], 2 * d0, beta, tc) && strong_decision(m[3], 2 * d3, beta, tc);
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			luma_line(m[r], tc, sw, tc * 10, fp, fq);
+			short4 lo, hi;
+			lo.x = (short)m[r][0]; lo.y = (short)m[r][1]; lo.z = (short)m[r][2]; lo.w = (short)m[r][3];
+			hi.x = (short)m[r][4]; hi.y = (short)m[r][5]; hi.z = (short)m[r][6]; hi.w = (short)m[r][7];
+			*reinterpret_cast<short4 *>(e + (size_t)r * a.ys - 4) = lo;
+			*reinterpret_cast<short4 *>(e + (size_t)r * a.ys) = hi;
+		}
+	}
+	if (bs > 1 && (ux & 3) == 0) {
+		const size_t co = (size_t)uy * 2 * a.cs + ux * 2;
+		chroma_edge(a.u + co, 1, a.cs, cTc[clip3i(chroma_qp(qpa + a.cb_off) + 2 * (bs - 1) + (a.tc_off << 1), 0, 53)]);
+		chroma_edge(a.v + co, 1, a.cs, cTc[clip3i(chroma_qp(qpa + a.cr_off) + 2 * (bs - 1) + (a.tc_off << 1), 0, 53)]);
+	}
+}
+
+// horizontal edges: thread = one luma column of one even unit row; 4-lane groups share the segment decision
+__global__ __launch_bounds__(HMR_BLOCK) void k_deblock_hor(DeblockArgs a)
+{
+	const int width = a.w4 * 4, eh = (a.h4 + 1) / 2;
+	const int i = blockIdx.x * HMR_BLOCK + threadIdx.x;
+	const bool in = i < width * eh;
+	const int er = in ? i / width : 0, x = in ? i - er * width : 0;
+	const int uy = er * 2, ux = x >> 2, col = x & 3;
+	const int q = uy * a.ui.units_stride + ux;
+	if (in && a.bs_out && col == 0) { a.bs_out[q] = 0; if (uy + 1 < a.h4) a.bs_out[q + a.ui.units_stride] = 0; }
+	const bool edge = in && (a.ui.flags[q] & F_EDGE_HOR);
+	int bs = 0, qpa = 0;
+	if (edge) {
+		const int p = q - a.ui.units_stride;
+		bs = boundary_strength(a.ui, q, p);
+		qpa = (a.ui.qp[p] + a.ui.qp[q] + 1) >> 1;
+		if (a.bs_out && col == 0) a.bs_out[q] = (uint8_t)(0x80 | bs);
+	}
+	int m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	int16_t *e = a.y + (size_t)uy * 4 * a.ys + x;
+	if (bs) {
+#pragma unroll
+		for (int k = 0; k < 8; k++) m[k] = e[(ptrdiff_t)(k - 4) * a.ys];
+	}
+	// width is a multiple of 8, so 4-lane groups never straddle rows or the `in` boundary: whole groups share bs
+	const int dp = iabs(m[1] - 2 * m[2] + m[3]), dq = iabs(m[4] - 2 * m[5] + m[6]);
+	const int lane = threadIdx.x & 63, g0 = lane & ~3;
+	const int dp0 = __shfl(dp, g0, 64), dq0 = __shfl(dq, g0, 64), dp3 = __shfl(dp, g0 + 3, 64), dq3 = __shfl(dq, g0 + 3, 64);
+	const int tc = cTc[clip3i(qpa + 2 * (bs ? bs - 1 : 0) + (a.tc_off << 1), 0, 53)];
+	const int beta = cBeta[clip3i(qpa + (a.beta_off << 1), 0, 51)];
+	const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+	const bool my_strong = strong_decision(m, 2 * (col == 0 ? d0 : d3), beta, tc);
+	const bool s0 = __shfl((int)my_strong, g0, 64), s3 = __shfl((int)my_strong, g0 + 3, 64);
+	if (bs && d0 + d3 < beta) {
+		const int side = (beta + (beta >> 1)) >> 3;
+		luma_line(m, tc, s0 && s3, tc * 10, (dp0 + dp3) < side, (dq0 + dq3) < side);
+#pragma unroll
+		for (int k = 1; k < 7; k++) e[(ptrdiff_t)(k - 4) * a.ys] = (int16_t)m[k];
+	}
+	if (bs > 1 && (uy & 3) == 0 && col < 2) {
+		// two chroma columns per unit: lanes col 0 and 1 take one each
+		const size_t co = (size_t)uy * 2 * a.cs + ux * 2 + col;
+		const int tcb = cTc[clip3i(chroma_qp(qpa + a.cb_off) + 2 * (bs - 1) + (a.tc_off << 1), 0, 53)];
+		const int tcr = cTc[clip3i(chroma_qp(qpa + a.cr_off) + 2 * (bs - 1) + (a.tc_off << 1), 0, 53)];
+		for (int pl = 0; pl < 2; pl++) {
+			int16_t *xp = (pl ? a.v : a.u) + co;
+			const int tcc = pl ? tcr : tcb, s = a.cs;
+			const int m4 = xp[0], m3 = xp[-s], m5 = xp[s], m2 = xp[-2 * s];
+			const int delta = clip3i((((m4 - m3) << 2) + m2 - m5 + 4) >> 3, -tcc, tcc);
+			xp[-s] = (int16_t)clip3i(m3 + delta, 0, 255);
+			xp[0] = (int16_t)clip3i(m4 - delta, 0, 255);
+		}
+	}
+}
+
+struct Planes {
+	const int16_t *p[3];
+	int stride[2];   // luma, chroma
+};
+
+__device__ __forceinline__ int sgn(int v) { return v > 0 ? 1 : (v < 0 ? -1 : 0); }
+
+// grid = (ctus, 3).  stats[ctu][comp][type][diff|count][32]
+__global__ __launch_bounds__(HMR_BLOCK) void k_sao_stats(Planes org, Planes rec, int width, int height, int ctus_x, int32_t *__restrict__ stats)
+{
+	__shared__ int16_t tile[66 * 66];
+	__shared__ int sAcc[5][2][32];
+	const int ctu = blockIdx.x, comp = blockIdx.y, cx = ctu % ctus_x, cy = ctu / ctus_x;
+	const int sh = comp ? 1 : 0;
+	const int hl = (cy * 64 + 64 > height) ? height - cy * 64 : 64, wl = (cx * 64 + 64 > width) ? width - cx * 64 : 64;
+	const int h = hl >> sh, w = wl >> sh;
+	const bool la = cx > 0, ta = cy > 0, ra = cx * 64 + 64 < width, ba = cy * 64 + 64 < height;
+	const int rs = rec.stride[sh], os = org.stride[sh];
+	const int16_t *r0 = rec.p[comp] + (size_t)(cy * 64 >> sh) * rs + (cx * 64 >> sh);
+	const int16_t *o0 = org.p[comp] + (size_t)(cy * 64 >> sh) * os + (cx * 64 >> sh);
+	const int tw = w + 2;
+	for (int i = threadIdx.x; i < 5 * 2 * 32; i += HMR_BLOCK) (&sAcc[0][0][0])[i] = 0;
+	// stage the tile with a 1-sample ring; ring samples outside the picture are never used by the regions below
+	for (int i = threadIdx.x; i < tw * (h + 2); i += HMR_BLOCK) {
+		const int ty = i / tw, tx = i - ty * tw, y = ty - 1, x = tx - 1;
+		const bool ok = (x >= 0 || la) && (x < w || ra) && (y >= 0 || ta) && (y < h || ba);
+		tile[ty * 66 + tx] = ok ? r0[(ptrdiff_t)y * rs + x] : (int16_t)0;
+	}
+	__syncthreads();
+	const int skr = comp ? 3 : 5, skb = comp ? 2 : 4;
+	int dsum[4][5], csum[4][5];
+#pragma unroll
+	for (int t = 0; t < 4; t++)
+#pragma unroll
+		for (int k = 0; k < 5; k++) dsum[t][k] = csum[t][k] = 0;
+	const int ex_eo = ra ? w - skr : w - 1, ex_full = ra ? w - skr : w, sx_eo = la ? 0 : 1;
+	const int ey_eo = ba ? h - skb : h - 1, ey_full = ba ? h - skb : h, sy_eo = ta ? 0 : 1;
+	for (int i = threadIdx.x; i < w * h; i += HMR_BLOCK) {
+		const int y = i / w, x = i - y * w;
+		const int16_t *c = &tile[(y + 1) * 66 + x + 1];
+		const int v = c[0], d = o0[(size_t)y * os + x] - v;
+		const int sl = sgn(v - c[-1]), sr = sgn(v - c[1]), su = sgn(v - c[-66]), sd = sgn(v - c[66]);
+		const int sul = sgn(v - c[-67]), sdr = sgn(v - c[67]), sur = sgn(v - c[-65]), sdl = sgn(v - c[65]);
+		const bool in_x_eo = x >= sx_eo && x < ex_eo, in_y_eo = y >= sy_eo && y < ey_eo;
+		const bool in0 = in_x_eo && y < ey_full;                 // EO 0: all rows (bottom skip only)
+		const bool in1 = x < ex_full && in_y_eo;                 // EO 90
+		const bool in2 = in_x_eo && in_y_eo;                     // EO 135 / 45
+		const int k0 = 2 + sl + sr, k1 = 2 + su + sd, k2 = 2 + sul + sdr, k3 = 2 + sur + sdl;
+#pragma unroll
+		for (int k = 0; k < 5; k++) {
+			dsum[0][k] += (in0 && k0 == k) ? d : 0; csum[0][k] += (in0 && k0 == k) ? 1 : 0;
+			dsum[1][k] += (in1 && k1 == k) ? d : 0; csum[1][k] += (in1 && k1 == k) ? 1 : 0;
+			dsum[2][k] += (in2 && k2 == k) ? d : 0; csum[2][k] += (in2 && k2 == k) ? 1 : 0;
+			dsum[3][k] += (in2 && k3 == k) ? d : 0; csum[3][k] += (in2 && k3 == k) ? 1 : 0;
+		}
+		if (x < ex_full && y < ey_full) {                        // BO
+			atomicAdd(&sAcc[4][0][v >> 3], d);
+			atomicAdd(&sAcc[4][1][v >> 3], 1);
+		}
+	}
+#pragma unroll
+	for (int t = 0; t < 4; t++)
+#pragma unroll
+		for (int k = 0; k < 5; k++) {
+			const int ds = wave_sum(dsum[t][k]), cs = wave_sum(csum[t][k]);
+			if ((threadIdx.x & 63) == 0) {
+				atomicAdd(&sAcc[t][0][k], ds);
+				atomicAdd(&sAcc[t][1][k], cs);
+			}
+		}
+	__syncthreads();
+	int32_t *out = stats + ((size_t)ctu * 3 + comp) * 5 * 2 * 32;
+	for (int i = threadIdx.x; i < 5 * 2 * 32; i += HMR_BLOCK) out[i] = (&sAcc[0][0][0])[i];
+}
+
+// grid = (ctus, 3).  dst must already hold a copy of src.
+__global__ __launch_bounds__(HMR_BLOCK) void k_sao_apply(Planes src, int16_t *dy, int16_t *du, int16_t *dv, int width, int height, int ctus_x,
+							    const int32_t *__restrict__ params)
+{
+	const int ctu = blockIdx.x, comp = blockIdx.y, cx = ctu % ctus_x, cy = ctu / ctus_x;
+	const int32_t *pc = params + (size_t)ctu * 3 * 34, *p = pc + comp * 34;
+	if (!p[0]) return;
+	const int type = p[1], sh = comp ? 1 : 0;
+	const int hl = (cy * 64 + 64 > height) ? height - cy * 64 : 64, wl = (cx * 64 + 64 > width) ? width - cx * 64 : 64;
+	const int h = hl >> sh, w = wl >> sh, st = src.stride[sh];
+	const bool la = cx > 0, ta = cy > 0, ra = cx * 64 + 64 < width, ba = cy * 64 + 64 < height;
+	const size_t base = (size_t)(cy * 64 >> sh) * st + (cx * 64 >> sh);
+	const int16_t *s0 = src.p[comp] + base;
+	int16_t *d0 = (comp == 0 ? dy : comp == 1 ? du : dv) + base;
+	__shared__ int off[32];
+	if (threadIdx.x < 32) off[threadIdx.x] = p[2 + threadIdx.x];
+	__syncthreads();
+	const int dx0 = type == 1 ? 0 : (type == 3 ? 1 : -1), dy0 = type == 0 ? 0 : -1;   // second neighbour is the mirror image
+	for (int i = threadIdx.x; i < w * h; i += HMR_BLOCK) {
+		const int y = i / w, x = i - y * w;
+		const int c = s0[(size_t)y * st + x];
+		int k;
+		if (type == 4) k = c >> 3;
+		else {
+			if (type != 1 && ((x == 0 && !la) || (x == w - 1 && !ra))) continue;
+			if (type != 0 && ((y == 0 && !ta) || (y == h - 1 && !ba))) continue;
+			k = 2 + sgn(c - s0[(ptrdiff_t)(y + dy0) * st + x + dx0]) + sgn(c - s0[(ptrdiff_t)(y - dy0) * st + x - dx0]);
+		}
+		d0[(size_t)y * st + x] = (int16_t)clip3i(c + off[k], 0, 255);
+	}
+}
+
+// replicate the picture edge into the margins; pic = sample (0,0); one thread per margin-or-picture sample of the padded window
+__global__ __launch_bounds__(HMR_BLOCK) void k_pad(int16_t *pic, int stride, int width, int height, int pad_x, int pad_y)
+{
+	const int pw = width + 2 * pad_x;
+	const long i = (long)blockIdx.x * HMR_BLOCK + threadIdx.x;
+	if (i >= (long)pw * (height + 2 * pad_y)) return;
+	const int y = (int)(i / pw) - pad_y, x = (int)(i % pw) - pad_x;
+	if (x >= 0 && x < width && y >= 0 && y < height) return;
+	pic[(ptrdiff_t)y * stride + x] = pic[(ptrdiff_t)clip3i(y, 0, height - 1) * stride + clip3i(x, 0, width - 1)];
+}
+
+}  // namespace
+
+extern "C" int hmr_gpu_edge_flags_frame(hmr_gpu_ctx *ctx, const uint8_t *pred_depth, const uint8_t *tr_idx, int width, int height, int units_stride,
+					uint8_t *flags)
+{
+	const int n = (width / 4) * (height / 4);
+	hipLaunchKernelGGL(k_edge_flags, dim3((n + HMR_BLOCK - 1) / HMR_BLOCK), dim3(HMR_BLOCK), 0, ctx->stream, pred_depth, tr_idx, width / 4, height / 4,
+			   units_stride, flags);
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
+
+extern "C" int hmr_gpu_deblock_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *f, const hmr_gpu_units *info, int cb_qp_offset, int cr_qp_offset,
+				     int beta_offset_div2, int tc_offset_div2, uint8_t *bs_ver, uint8_t *bs_hor)
+{
+	if (!f || !info || (f->width & 7) || (f->height & 7) || (f->stride_y & 3) || (f->stride_c & 1) || ((uintptr_t)f->y & 7)) {
+		hmr_set_error("deblock_frame: width/height must be multiples of 8, luma stride a multiple of 4 and the luma plane 8-byte aligned");
+		return HMR_GPU_ERR_ARG;
+	}
+	DeblockArgs a;
+	a.y = f->y; a.u = f->u; a.v = f->v; a.ys = f->stride_y; a.cs = f->stride_c;
+	a.w4 = f->width / 4; a.h4 = f->height / 4;
+	a.ui.units_stride = info->units_stride; a.ui.mvx = info->mvx; a.ui.mvy = info->mvy; a.ui.ref_idx = info->ref_idx; a.ui.qp = info->qp; a.ui.flags = info->flags;
+	a.cb_off = cb_qp_offset; a.cr_off = cr_qp_offset; a.beta_off = beta_offset_div2; a.tc_off = tc_offset_div2;
+	a.bs_out = bs_ver;
+	const int nver = ((a.w4 + 1) / 2) * a.h4;
+	hipLaunchKernelGGL(k_deblock_ver, dim3((nver + HMR_BLOCK - 1) / HMR_BLOCK), dim3(HMR_BLOCK), 0, ctx->stream, a);
+	a.bs_out = bs_hor;
+	const int nhor = f->width * ((a.h4 + 1) / 2);
+	hipLaunchKernelGGL(k_deblock_hor, dim3((nhor + HMR_BLOCK - 1) / HMR_BLOCK), dim3(HMR_BLOCK), 0, ctx->stream, a);
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
+
+static Planes planes_of(const hmr_gpu_frame *f)
+{
+	Planes p;
+	p.p[0] = f->y; p.p[1] = f->u; p.p[2] = f->v;
+	p.stride[0] = f->stride_y; p.stride[1] = f->stride_c;
+	return p;
+}
+
+extern "C" int hmr_gpu_sao_stats_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *orig, const hmr_gpu_frame *recon, int32_t *stats)
+{
+	if (!orig || !recon || orig->width != recon->width || orig->height != recon->height) return HMR_GPU_ERR_ARG;
+	const int ctus_x = (recon->width + 63) / 64, ctus_y = (recon->height + 63) / 64;
+	hipLaunchKernelGGL(k_sao_stats, dim3(ctus_x * ctus_y, 3), dim3(HMR_BLOCK), 0, ctx->stream, planes_of(orig), planes_of(recon), recon->width, recon->height,
+			   ctus_x, stats);
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
+
+extern "C" int hmr_gpu_sao_apply_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *src, const hmr_gpu_frame *dst, const int32_t *params)
+{
+	if (!src || !dst || src->width != dst->width || src->height != dst->height || src->stride_y != dst->stride_y || src->stride_c != dst->stride_c)
+		return HMR_GPU_ERR_ARG;
+	const int ctus_x = (src->width + 63) / 64, ctus_y = (src->height + 63) / 64;
+	hipLaunchKernelGGL(k_sao_apply, dim3(ctus_x * ctus_y, 3), dim3(HMR_BLOCK), 0, ctx->stream, planes_of(src), dst->y, dst->u, dst->v, src->width, src->height,
+			   ctus_x, params);
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
+
+extern "C" int hmr_gpu_pad_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *f, int pad_x, int pad_y)
+{
+	if (!f) return HMR_GPU_ERR_ARG;
+	int16_t *pl[3] = {f->y, f->u, f->v};
+	for (int c = 0; c < 3; c++) {
+		const int w = c ? f->width / 2 : f->width, h = c ? f->height / 2 : f->height, px = c ? pad_x / 2 : pad_x, py = c ? pad_y / 2 : pad_y;
+		const long n = (long)(w + 2 * px) * (h + 2 * py);
+		hipLaunchKernelGGL(k_pad, dim3((unsigned)((n + HMR_BLOCK - 1) / HMR_BLOCK)), dim3(HMR_BLOCK), 0, ctx->stream, pl[c], c ? f->stride_c : f->stride_y, w, h,
+				   px, py);
+	}
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}

@@ -149,6 +149,47 @@ int hmr_gpu_quant_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, in
 /* a = levels, c = coefficients; p0 bits 2-3 comp, 4 is_intra; p1 = per | rem << 8 */
 int hmr_gpu_inv_quant_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, int16_t *c_base);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * 4. frame-level in-loop passes (the reference keeps these outside the table and runs them CTU by CTU in a
+ *    lagged pipeline, hmr_encoder_lib.c:2386 hmr_deblock_sao_pad_sync_ctu; whole-picture passes are
+ *    equivalent).  All pointers are DEVICE pointers; launches are asynchronous on the context's stream.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct hmr_gpu_frame {
+	int width, height;          /* luma size, multiples of 8 (hmr_encoder_lib.c:1001) */
+	int16_t *y, *u, *v;         /* sample (0,0) of each plane; margins, if any, lie before/after */
+	int stride_y, stride_c;     /* elements */
+} hmr_gpu_frame;
+
+/* side-info the encoder decided, one entry per 4x4 luma unit in raster order (ctu_info_t arrays of
+ * hmr_private.h:792-843 are the same data in z-order per CTU) */
+#define HMR_GPU_UNIT_INTRA 1     /* pred_mode == INTRA_MODE */
+#define HMR_GPU_UNIT_CBF_Y 2     /* CBF(ctu, idx, Y_COMP, tr_idx) */
+#define HMR_GPU_UNIT_EDGE_VER 4  /* left edge of the unit is a transform/CU edge (set by hmr_gpu_edge_flags_frame) */
+#define HMR_GPU_UNIT_EDGE_HOR 8  /* top edge */
+typedef struct hmr_gpu_units {
+	int units_stride;           /* units per row of the arrays below */
+	const int16_t *mvx, *mvy;   /* mv_ref[REF_PIC_LIST_0], quarter-sample units */
+	const int8_t *ref_idx;      /* mv_ref_idx[REF_PIC_LIST_0], < 0 = none */
+	const uint8_t *qp;
+	uint8_t *flags;
+} hmr_gpu_units;
+
+/* derive the EDGE bits of flags[] from the coding tree: pred_depth + tr_idx per unit (hmr_deblocking_filter.c:737-825) */
+int hmr_gpu_edge_flags_frame(hmr_gpu_ctx *ctx, const uint8_t *pred_depth, const uint8_t *tr_idx, int width, int height, int units_stride, uint8_t *flags);
+/* hmr_deblock_filter_cu over the picture (hmr_deblocking_filter.c:737): boundary strength, luma strong/weak, chroma; in place.
+ * bs_ver / bs_hor (optional, units_stride x height/4) receive 0x80|bs for every evaluated edge segment. P/I slices. */
+int hmr_gpu_deblock_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *frame, const hmr_gpu_units *info, int cb_qp_offset, int cr_qp_offset,
+			  int beta_offset_div2, int tc_offset_div2, uint8_t *bs_ver, uint8_t *bs_hor);
+/* low_level_funcs_t.get_sao_stats (hmr_private.h:1091, hmr_sse42_sao.c:35) for every CTU:
+ * stats[ctu][comp][type EO0,EO90,EO135,EO45,BO][0 = diff, 1 = count][32] as int32 */
+int hmr_gpu_sao_stats_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *orig, const hmr_gpu_frame *recon, int32_t *stats);
+/* sao_offset_ctu (hmr_sao.c:1210) for every CTU: src = pre-SAO picture, dst = output (must hold a copy of src);
+ * params[ctu][comp][34] = {modeIdc, typeIdc, offset[32]} */
+int hmr_gpu_sao_apply_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *src, const hmr_gpu_frame *dst, const int32_t *params);
+/* reference_picture_border_padding_ctu (hmr_encoder_lib.c:1723) for every CTU: replicate edges into pad_x/pad_y (luma; chroma half) */
+int hmr_gpu_pad_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *frame, int pad_x, int pad_y);
+
 #ifdef __cplusplus
 }
 #endif

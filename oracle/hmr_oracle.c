@@ -12,6 +12,7 @@
 #include "hmr_oracle.h"
 
 #include <limits.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -644,5 +645,253 @@ void ora_inv_quant(const int16_t *src, int16_t *dst, int depth, int comp, int is
 		int sh = per - iq_shift;
 		for (n = 0; n < total; n++)
 			dst[n] = sat16((int32_t)(((uint32_t)(int32_t)src[n] * (uint32_t)iq[n]) << sh));
+	}
+}
+
+/* ====================================================================================================
+ * Frame-level in-loop kernels (not in the reference's table): deblocking, SAO
+ * statistics, SAO offset, border padding.  The reference runs them CTU by CTU in a lagged software
+ * pipeline (hmr_encoder_lib.c:2386); every sample they read is final by the time it is read, so the
+ * result equals two frame passes (all vertical edges, then all horizontal edges), one statistics pass
+ * on the deblocked picture and one offset pass from a pre-SAO copy - which is what is restated here.
+ * Side-info is a structure-of-arrays over the picture's 4x4 units in raster order.
+ * ==================================================================================================== */
+
+#define UNIT_INTRA 1
+#define UNIT_CBF_Y 2
+#define UNIT_EDGE_VER 4
+#define UNIT_EDGE_HOR 8
+
+static const uint8_t k_tc_table[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+				       2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
+static const uint8_t k_beta_table[52] = {0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15,
+					 16, 17, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
+static int chroma_qp(int qpi)   /* chroma_scale_conversion_table, hmr_encoder_lib.c:2245 */
+{
+	static const uint8_t mid[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37};
+	qpi = clip3(qpi, 0, 57);
+	return qpi < 30 ? qpi : (qpi < 44 ? mid[qpi - 30] : qpi - 6);
+}
+
+/* Transform/CU edge flags from the coding tree (hmr_deblocking_filter.c:737-825): a unit's left/top edge is an
+ * edge when it lies on the boundary of the leaf of size max(8, 64 >> (pred_depth + tr_idx)); picture borders are not. */
+void ora_make_edge_flags(const uint8_t *pred_depth, const uint8_t *tr_idx, int width, int height, int units_stride, uint8_t *flags)
+{
+	int ux, uy;
+	for (uy = 0; uy < height / 4; uy++)
+		for (ux = 0; ux < width / 4; ux++) {
+			int o = uy * units_stride + ux, total = pred_depth[o] + tr_idx[o];
+			int leaf = 64 >> total;
+			if (leaf < 8) leaf = 8;
+			flags[o] &= (uint8_t)~(UNIT_EDGE_VER | UNIT_EDGE_HOR);
+			if (ux && (ux * 4) % leaf == 0) flags[o] |= UNIT_EDGE_VER;
+			if (uy && (uy * 4) % leaf == 0) flags[o] |= UNIT_EDGE_HOR;
+		}
+}
+
+/* get_boundary_strength_single, hmr_deblocking_filter.c:138-268, P slices (single reference list) */
+static int boundary_strength(int q, int p, const int16_t *mvx, const int16_t *mvy, const int8_t *ref_idx, const uint8_t *flags)
+{
+	int mqx, mqy, mpx, mpy;
+	if ((flags[p] & UNIT_INTRA) || (flags[q] & UNIT_INTRA)) return 2;
+	if ((flags[p] & UNIT_CBF_Y) || (flags[q] & UNIT_CBF_Y)) return 1;
+	mqx = ref_idx[q] < 0 ? 0 : mvx[q]; mqy = ref_idx[q] < 0 ? 0 : mvy[q];
+	mpx = ref_idx[p] < 0 ? 0 : mvx[p]; mpy = ref_idx[p] < 0 ? 0 : mvy[p];
+	if ((ref_idx[p] < 0 ? -1 : ref_idx[p]) != (ref_idx[q] < 0 ? -1 : ref_idx[q])) return 1;
+	return (abs(mqx - mpx) >= 4 || abs(mqy - mpy) >= 4) ? 1 : 0;
+}
+
+/* filter_luma :287-349 on one line; s = step across the edge */
+static void luma_line(int16_t *src, int s, int tc, int strong, int thr_cut, int filt_p, int filt_q)
+{
+	int m4 = src[0], m3 = src[-s], m5 = src[s], m2 = src[-2 * s], m6 = src[2 * s], m1 = src[-3 * s], m7 = src[3 * s], m0 = src[-4 * s];
+	if (strong) {
+		src[-s] = (int16_t)clip3((m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3, m3 - 2 * tc, m3 + 2 * tc);
+		src[0] = (int16_t)clip3((m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3, m4 - 2 * tc, m4 + 2 * tc);
+		src[-2 * s] = (int16_t)clip3((m1 + m2 + m3 + m4 + 2) >> 2, m2 - 2 * tc, m2 + 2 * tc);
+		src[s] = (int16_t)clip3((m3 + m4 + m5 + m6 + 2) >> 2, m5 - 2 * tc, m5 + 2 * tc);
+		src[-3 * s] = (int16_t)clip3((2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3, m1 - 2 * tc, m1 + 2 * tc);
+		src[2 * s] = (int16_t)clip3((m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3, m6 - 2 * tc, m6 + 2 * tc);
+	} else {
+		int delta = (9 * (m4 - m3) - 3 * (m5 - m2) + 8) >> 4;
+		if (abs(delta) < thr_cut) {
+			int tc2 = tc >> 1;
+			delta = clip3(delta, -tc, tc);
+			src[-s] = (int16_t)clip3(m3 + delta, 0, 255);
+			src[0] = (int16_t)clip3(m4 - delta, 0, 255);
+			if (filt_p) src[-2 * s] = (int16_t)clip3(m2 + clip3((((m1 + m3 + 1) >> 1) - m2 + delta) >> 1, -tc2, tc2), 0, 255);
+			if (filt_q) src[s] = (int16_t)clip3(m5 + clip3((((m6 + m4 + 1) >> 1) - m5 - delta) >> 1, -tc2, tc2), 0, 255);
+		}
+	}
+}
+
+static int strong_decision(const int16_t *src, int s, int d, int beta, int tc)   /* use_strong_filter :275 */
+{
+	int m4 = src[0], m3 = src[-s], m7 = src[3 * s], m0 = src[-4 * s];
+	return (abs(m0 - m3) + abs(m7 - m4) < (beta >> 3)) && (d < (beta >> 2)) && (abs(m3 - m4) < ((tc * 5 + 1) >> 1));
+}
+
+/* One direction over the whole picture: deblock_filter_luma :353-458 and deblock_filter_chroma :504-634 */
+static void deblock_pass(int dir, int16_t *y, int ys, int16_t *u, int16_t *v, int cs, int width, int height, int units_stride, const int16_t *mvx,
+			 const int16_t *mvy, const int8_t *ref_idx, const uint8_t *qp, const uint8_t *flags, int cb_off, int cr_off, int beta_off,
+			 int tc_off, uint8_t *bs_out)
+{
+	int ux, uy, i, comp;
+	for (uy = 0; uy < height / 4; uy++)
+		for (ux = 0; ux < width / 4; ux++) {
+			int q = uy * units_stride + ux, p, bs, qpa, tc, beta;
+			int on_grid = dir == 0 ? (ux & 1) == 0 : (uy & 1) == 0;   /* edges on the 8x8 luma grid only, :667,689 */
+			if (bs_out) bs_out[q] = 0;
+			if (!(flags[q] & (dir == 0 ? UNIT_EDGE_VER : UNIT_EDGE_HOR)) || !on_grid) continue;
+			p = dir == 0 ? q - 1 : q - units_stride;
+			bs = boundary_strength(q, p, mvx, mvy, ref_idx, flags);
+			if (bs_out) bs_out[q] = (uint8_t)(0x80 | bs);
+			if (!bs) continue;
+			qpa = (qp[p] + qp[q] + 1) >> 1;
+			{
+				int16_t *e = y + (size_t)uy * 4 * ys + ux * 4;
+				int s = dir == 0 ? 1 : ys, t = dir == 0 ? ys : 1;   /* s across the edge, t along it */
+				int dp0, dq0, dp3, dq3, d0, d3, d, side;
+				tc = k_tc_table[clip3(qpa + 2 * (bs - 1) + (tc_off << 1), 0, 53)];
+				beta = k_beta_table[clip3(qpa + (beta_off << 1), 0, 51)];
+				side = (beta + (beta >> 1)) >> 3;
+				dp0 = abs(e[-3 * s] - 2 * e[-2 * s] + e[-s]);
+				dq0 = abs(e[0] - 2 * e[s] + e[2 * s]);
+				dp3 = abs(e[3 * t - 3 * s] - 2 * e[3 * t - 2 * s] + e[3 * t - s]);
+				dq3 = abs(e[3 * t] - 2 * e[3 * t + s] + e[3 * t + 2 * s]);
+				d0 = dp0 + dq0; d3 = dp3 + dq3; d = d0 + d3;
+				if (d < beta) {
+					int fp = (dp0 + dp3) < side, fq = (dq0 + dq3) < side;
+					int sw = strong_decision(e, s, 2 * d0, beta, tc) && strong_decision(e + 3 * t, s, 2 * d3, beta, tc);
+					for (i = 0; i < 4; i++) luma_line(e + i * t, s, tc, sw, tc * 10, fp, fq);
+				}
+			}
+			/* chroma: only bs == 2, only edges on the 8x8 chroma grid (16 luma samples), :533,545 */
+			if (bs > 1 && (dir == 0 ? (ux & 3) == 0 : (uy & 3) == 0))
+				for (comp = 1; comp <= 2; comp++) {
+					int16_t *pl = comp == 1 ? u : v;
+					int16_t *e = pl + (size_t)uy * 2 * cs + ux * 2;
+					int s = dir == 0 ? 1 : cs, t = dir == 0 ? cs : 1;
+					int cq = chroma_qp(qpa + (comp == 1 ? cb_off : cr_off));
+					int tcc = k_tc_table[clip3(cq + 2 * (bs - 1) + (tc_off << 1), 0, 53)];
+					for (i = 0; i < 2; i++) {
+						int16_t *x = e + i * t;
+						int m4 = x[0], m3 = x[-s], m5 = x[s], m2 = x[-2 * s];
+						int delta = clip3((((m4 - m3) << 2) + m2 - m5 + 4) >> 3, -tcc, tcc);
+						x[-s] = (int16_t)clip3(m3 + delta, 0, 255);
+						x[0] = (int16_t)clip3(m4 - delta, 0, 255);
+					}
+				}
+		}
+}
+
+void ora_deblock_frame(int16_t *y, int ys, int16_t *u, int16_t *v, int cs, int width, int height, int units_stride, const int16_t *mvx,
+		       const int16_t *mvy, const int8_t *ref_idx, const uint8_t *qp, const uint8_t *flags, int cb_qp_offset, int cr_qp_offset,
+		       int beta_offset_div2, int tc_offset_div2, uint8_t *bs_ver, uint8_t *bs_hor)
+{
+	deblock_pass(0, y, ys, u, v, cs, width, height, units_stride, mvx, mvy, ref_idx, qp, flags, cb_qp_offset, cr_qp_offset, beta_offset_div2, tc_offset_div2, bs_ver);
+	deblock_pass(1, y, ys, u, v, cs, width, height, units_stride, mvx, mvy, ref_idx, qp, flags, cb_qp_offset, cr_qp_offset, beta_offset_div2, tc_offset_div2, bs_hor);
+}
+
+static inline int sgn(int v) { return v > 0 ? 1 : (v < 0 ? -1 : 0); }
+
+/* SAO statistics per CTU and component, hmr_sse42_sao.c:35 (scalar spec hmr_sao.c:75-348), written per sample:
+ * class = sign(c - a) + sign(c - b) for the two neighbours of the edge type, regions as derived from the loops
+ * (right 5/3 columns and bottom 4/2 rows skipped when a neighbour CTU exists, hmr_sao.c:60-61).
+ * stats layout: [ctu][comp][type][0 = diff, 1 = count][32] int32; EO classes -2..2 at index 0..4, BO bands 0..31. */
+void ora_sao_stats_frame(const int16_t *oy, const int16_t *ou, const int16_t *ov, int os_y, int os_c, const int16_t *ry, const int16_t *ru,
+			 const int16_t *rv, int rs_y, int rs_c, int width, int height, int32_t *stats)
+{
+	static const int skip_r[3] = {5, 3, 3}, skip_b[3] = {4, 2, 2};
+	static const int dx[4][2] = {{-1, 1}, {0, 0}, {-1, 1}, {1, -1}}, dy[4][2] = {{0, 0}, {-1, 1}, {-1, 1}, {-1, 1}};
+	int ctus_x = (width + 63) / 64, ctus_y = (height + 63) / 64, cx, cy, comp, type, x, y;
+	memset(stats, 0, (size_t)ctus_x * ctus_y * 3 * 5 * 2 * 32 * sizeof(int32_t));
+	for (cy = 0; cy < ctus_y; cy++)
+		for (cx = 0; cx < ctus_x; cx++) {
+			int hl = (cy * 64 + 64 > height) ? height - cy * 64 : 64, wl = (cx * 64 + 64 > width) ? width - cx * 64 : 64;
+			int la = cx > 0, ta = cy > 0, ra = cx * 64 + 64 < width, ba = cy * 64 + 64 < height;
+			for (comp = 0; comp < 3; comp++) {
+				int sh = comp ? 1 : 0, h = hl >> sh, w = wl >> sh, rs = comp ? rs_c : rs_y, os = comp ? os_c : os_y;
+				const int16_t *rec = (comp == 0 ? ry : comp == 1 ? ru : rv) + (size_t)(cy * 64 >> sh) * rs + (cx * 64 >> sh);
+				const int16_t *org = (comp == 0 ? oy : comp == 1 ? ou : ov) + (size_t)(cy * 64 >> sh) * os + (cx * 64 >> sh);
+				for (type = 0; type < 5; type++) {
+					int32_t *diff = stats + (((((size_t)cy * ctus_x + cx) * 3 + comp) * 5 + type) * 2) * 32, *count = diff + 32;
+					int sx = (type == 1 || type == 4) ? 0 : (la ? 0 : 1);
+					int ex = ra ? w - skip_r[comp] : ((type == 1 || type == 4) ? w : w - 1);
+					int sy = (type == 0 || type == 4) ? 0 : (ta ? 0 : 1);
+					int ey = ba ? h - skip_b[comp] : ((type == 0 || type == 4) ? h : h - 1);
+					for (y = sy; y < ey; y++)
+						for (x = sx; x < ex; x++) {
+							int c = rec[(size_t)y * rs + x], k;
+							if (type == 4) k = c >> 3;
+							else {
+								/* first row of the diagonal types: the above-left (135) sample of column 0 needs the
+								 * above-left CTU, i.e. both neighbours (first_line_start_x, hmr_sao.c:214) */
+								if (type == 2 && y == 0 && x == 0 && !(ta && la)) continue;
+								k = 2 + sgn(c - rec[(size_t)(y + dy[type][0]) * rs + x + dx[type][0]]) +
+								    sgn(c - rec[(size_t)(y + dy[type][1]) * rs + x + dx[type][1]]);
+							}
+							diff[k] += org[(size_t)y * os + x] - c;
+							count[k]++;
+						}
+				}
+			}
+		}
+}
+
+/* SAO offset, sao_offset_ctu hmr_sao.c:1210 + offset_block :960, per sample.  src = pre-SAO (deblocked) picture,
+ * dst = output picture, which must already hold a copy of src (samples outside the per-type regions stay as they are).
+ * params[ctu][comp][34] = {modeIdc (0 = off), typeIdc, offset[32]}; EO offsets at [0..4] for classes -2..2. */
+void ora_sao_apply_frame(const int16_t *sy_, const int16_t *su, const int16_t *sv, int16_t *dy_, int16_t *du, int16_t *dv, int stride_y, int stride_c,
+			 int width, int height, const int32_t *params)
+{
+	static const int dx[4][2] = {{-1, 1}, {0, 0}, {-1, 1}, {1, -1}}, dyy[4][2] = {{0, 0}, {-1, 1}, {-1, 1}, {-1, 1}};
+	int ctus_x = (width + 63) / 64, ctus_y = (height + 63) / 64, cx, cy, comp, x, y;
+	for (cy = 0; cy < ctus_y; cy++)
+		for (cx = 0; cx < ctus_x; cx++) {
+			int hl = (cy * 64 + 64 > height) ? height - cy * 64 : 64, wl = (cx * 64 + 64 > width) ? width - cx * 64 : 64;
+			int la = cx > 0, ta = cy > 0, ra = cx * 64 + 64 < width, ba = cy * 64 + 64 < height;
+			const int32_t *pc = params + ((size_t)cy * ctus_x + cx) * 3 * 34;
+			if (!pc[0] && !pc[34] && !pc[68]) continue;
+			for (comp = 0; comp < 3; comp++) {
+				const int32_t *p = pc + comp * 34, *off = p + 2;
+				int sh = comp ? 1 : 0, h = hl >> sh, w = wl >> sh, st = comp ? stride_c : stride_y, type = p[1];
+				const int16_t *src = (comp == 0 ? sy_ : comp == 1 ? su : sv) + (size_t)(cy * 64 >> sh) * st + (cx * 64 >> sh);
+				int16_t *dst = (comp == 0 ? dy_ : comp == 1 ? du : dv) + (size_t)(cy * 64 >> sh) * st + (cx * 64 >> sh);
+				if (!p[0]) continue;
+				for (y = 0; y < h; y++)
+					for (x = 0; x < w; x++) {
+						int c = src[(size_t)y * st + x], k;
+						if (type == 4) k = c >> 3;
+						else {
+							/* availability of the two neighbours this type reads */
+							int x0 = x + dx[type][0], y0 = y + dyy[type][0], x1 = x + dx[type][1], y1 = y + dyy[type][1];
+							int ok0 = (x0 >= 0 || la) && (x0 < w || ra) && (y0 >= 0 || ta) && (y0 < h || ba);
+							int ok1 = (x1 >= 0 || la) && (x1 < w || ra) && (y1 >= 0 || ta) && (y1 < h || ba);
+							if (!ok0 || !ok1) continue;
+							/* the reference also skips column 0 / w-1 rows it cannot start from, see the per-type loops */
+							if (type != 1 && ((x == 0 && !la) || (x == w - 1 && !ra))) continue;
+							if (type != 0 && ((y == 0 && !ta) || (y == h - 1 && !ba))) continue;
+							k = 2 + sgn(c - src[(size_t)y0 * st + x0]) + sgn(c - src[(size_t)y1 * st + x1]);
+						}
+						dst[(size_t)y * st + x] = (int16_t)clip3(c + off[k], 0, 255);
+					}
+			}
+		}
+}
+
+/* reference_picture_border_padding_ctu over every CTU, hmr_encoder_lib.c:1723 == replicate the picture edge
+ * into the pad_x / pad_y margins (corners from the corner sample).  `pic` points at sample (0,0). */
+void ora_pad_plane(int16_t *pic, int stride, int width, int height, int pad_x, int pad_y)
+{
+	int x, y;
+	for (y = 0; y < height; y++)
+		for (x = 0; x < pad_x; x++) {
+			pic[(size_t)y * stride - 1 - x] = pic[(size_t)y * stride];
+			pic[(size_t)y * stride + width + x] = pic[(size_t)y * stride + width - 1];
+		}
+	for (y = 0; y < pad_y; y++) {
+		memcpy(pic + (ptrdiff_t)(-1 - y) * stride - pad_x, pic - pad_x, (size_t)(width + 2 * pad_x) * 2);
+		memcpy(pic + (size_t)(height + y) * stride - pad_x, pic + (size_t)(height - 1) * stride - pad_x, (size_t)(width + 2 * pad_x) * 2);
 	}
 }

@@ -75,6 +75,26 @@ void ora_quant(const int16_t *src, int16_t *dst, int16_t *delta_u, int scan_mode
 void ora_inv_quant(const int16_t *src, int16_t *dst, int depth, int comp, int is_intra, int cu_size, int per, int rem);
 void ora_sign_bit_hiding(int16_t *dst, const int16_t *src, const uint32_t *scan, const int16_t *delta_u, int n_coeffs);
 
+
+/* ---- frame-level in-loop kernels (K16-K18, K20); side-info = SoA over 4x4 units, raster order ---- */
+#define ORA_UNIT_INTRA 1
+#define ORA_UNIT_CBF_Y 2
+#define ORA_UNIT_EDGE_VER 4
+#define ORA_UNIT_EDGE_HOR 8
+void ora_make_edge_flags(const uint8_t *pred_depth, const uint8_t *tr_idx, int width, int height, int units_stride, uint8_t *flags);
+/* hmr_deblocking_filter.c:737 over the picture: all vertical edges, then all horizontal edges (in place) */
+void ora_deblock_frame(int16_t *y, int ys, int16_t *u, int16_t *v, int cs, int width, int height, int units_stride, const int16_t *mvx,
+		       const int16_t *mvy, const int8_t *ref_idx, const uint8_t *qp, const uint8_t *flags, int cb_qp_offset, int cr_qp_offset,
+		       int beta_offset_div2, int tc_offset_div2, uint8_t *bs_ver, uint8_t *bs_hor);
+/* hmr_sse42_sao.c:35; stats[ctu][comp][type][diff|count][32] int32 */
+void ora_sao_stats_frame(const int16_t *oy, const int16_t *ou, const int16_t *ov, int os_y, int os_c, const int16_t *ry, const int16_t *ru,
+			 const int16_t *rv, int rs_y, int rs_c, int width, int height, int32_t *stats);
+/* hmr_sao.c:1210,960; params[ctu][comp][34] = {modeIdc, typeIdc, offset[32]} */
+void ora_sao_apply_frame(const int16_t *sy, const int16_t *su, const int16_t *sv, int16_t *dy, int16_t *du, int16_t *dv, int stride_y, int stride_c,
+			 int width, int height, const int32_t *params);
+/* hmr_encoder_lib.c:1723 over every CTU */
+void ora_pad_plane(int16_t *pic, int stride, int width, int height, int pad_x, int pad_y);
+
 #ifdef __cplusplus
 }
 #endif

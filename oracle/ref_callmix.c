@@ -1,0 +1,153 @@
+/*
+ * TEST INFRASTRUCTURE - not part of the product path.
+ *
+ * Records WHICH hot-path calls the reference makes per frame (function, block size, stage flags - no
+ * sample data): the "call mix" that bench.py replays as batched GPU launches and that DESIGN.md uses to
+ * turn per-kernel bytes into per-frame bytes.  It overwrites hvenc_enc_t.funcs (hmr_private.h:1443) with
+ * counting wrappers after HOMER_enc_init - the registration route verified in SURVEY.md §8-b - and wraps
+ * the scalar sad() the sub-pel refinement calls directly (hmr_motion_inter.c:1712,1757) at link time
+ * (-Wl,--wrap=sad).  Built by oracle/Makefile into oracle/_ref/ref_callmix; includes ref_lockstep.c.
+ *
+ * usage: ref_callmix in.yuv out.json W H frames [key=value ...]     (same keys as ref_lockstep)
+ */
+#define main lockstep_main_unused
+#include "ref_lockstep.c"
+#undef main
+#include "hmr_private.h"
+#include "hmr_common.h"
+#include "hmr_sse42_functions.h"
+
+#define MAXKEYS 4096
+static struct { char key[48]; long n; } g_cnt[MAXKEYS];
+static int g_nkeys;
+static low_level_funcs_t g_orig;
+
+static void bump(const char *fmt, int a, int b, int c, int d)
+{
+	char key[48];
+	int i;
+	snprintf(key, sizeof key, fmt, a, b, c, d);
+	for (i = 0; i < g_nkeys; i++)
+		if (!strcmp(g_cnt[i].key, key)) { g_cnt[i].n++; return; }
+	if (g_nkeys < MAXKEYS) { strcpy(g_cnt[g_nkeys].key, key); g_cnt[g_nkeys++].n = 1; }
+}
+
+static void w_c1616(void *s, uint32_t ss, void *d, uint32_t ds, int h, int w) { bump("copy_16_16:%d:%d", h, w, 0, 0); g_orig.sse_copy_16_16(s, ss, d, ds, h, w); }
+static void w_c168(void *s, uint32_t ss, void *d, uint32_t ds, int h, int w) { bump("copy_16_8:%d:%d", h, w, 0, 0); g_orig.sse_copy_16_8(s, ss, d, ds, h, w); }
+static void w_c816(void *s, uint32_t ss, void *d, uint32_t ds, int h, int w) { bump("copy_8_16:%d:%d", h, w, 0, 0); g_orig.sse_copy_8_16(s, ss, d, ds, h, w); }
+static uint32_t w_sad(int16_t *s, uint32_t ss, int16_t *p, uint32_t ps, int n) { bump("sad:%d", n, 0, 0, 0); return g_orig.sad(s, ss, p, ps, n); }
+static uint32_t w_ssd(int16_t *s, uint32_t ss, int16_t *p, uint32_t ps, int n) { bump("ssd16b:%d:%d", n, ps == 0, 0, 0); return g_orig.ssd16b(s, ss, p, ps, n); }
+static void w_predict(int16_t *o, int os, int16_t *p, int ps, int16_t *r, int rs, int n) { bump("predict:%d", n, 0, 0, 0); g_orig.predict(o, os, p, ps, r, rs, n); }
+static void w_reconst(int16_t *p, int ps, int16_t *r, int rs, int16_t *d, int ds, int n) { bump("reconst:%d:%d", n, rs == 0, 0, 0); g_orig.reconst(p, ps, r, rs, d, ds, n); }
+static uint32_t w_var(int16_t *p, int size, int stride, int modif) { bump("modified_variance:%d:%d", size, modif, 0, 0); return g_orig.modified_variance(p, size, stride, modif); }
+static void w_planar(henc_thread_t *et, int16_t *pr, int ps, int16_t *adi, int as, int n, int sh) { bump("intra_planar:%d", n, 0, 0, 0); g_orig.create_intra_planar_prediction(et, pr, ps, adi, as, n, sh); }
+static void w_ang(henc_thread_t *et, ctu_info_t *ctu, int16_t *pr, int ps, int16_t *adi, int as, int n, int mode, int luma)
+{
+	bump("intra_angular:%d:%d:%d", n, mode, luma, 0);
+	g_orig.create_intra_angular_prediction(et, ctu, pr, ps, adi, as, n, mode, luma);
+}
+static void w_il(int16_t *s, int ss, int16_t *d, int ds, int fr, int w, int h, int v, int f, int l)
+{
+	bump("interp_luma:%d:%d:%d:%d", w, h, (fr != 0) | (v << 1) | (f << 2) | (l << 3), 0);
+	g_orig.interpolate_luma_m_compensation(s, ss, d, ds, fr, w, h, v, f, l);
+}
+static void w_ic(int16_t *s, int ss, int16_t *d, int ds, int fr, int w, int h, int v, int f, int l)
+{
+	bump("interp_chroma:%d:%d:%d:%d", w, h, (fr != 0) | (v << 1) | (f << 2) | (l << 3), 0);
+	g_orig.interpolate_chroma_m_compensation(s, ss, d, ds, fr, w, h, v, f, l);
+}
+static void w_wavg(int16_t *a, int as, int16_t *b, int bs, int16_t *d, int ds, int h, int w, int bd) { bump("weighted_average:%d:%d", w, h, 0, 0); g_orig.weighted_average_motion(a, as, b, bs, d, ds, h, w, bd); }
+static void w_quant(henc_thread_t *et, int16_t *s, int16_t *d, int scan, int depth, int comp, int mode, int intra, int *ac, int n, int per, int rem)
+{
+	bump("quant:%d:%d:%d", n, comp, intra, 0);
+	g_orig.quant(et, s, d, scan, depth, comp, mode, intra, ac, n, per, rem);
+}
+static void w_iquant(henc_thread_t *et, short *s, short *d, int depth, int comp, int intra, int n, int per, int rem)
+{
+	bump("inv_quant:%d:%d:%d", n, comp, intra, 0);
+	g_orig.inv_quant(et, s, d, depth, comp, intra, n, per, rem);
+}
+static void w_tr(int bd, int16_t *b, int16_t *c, int bs, int w, int h, int ws, int hs, uint16_t mode, int16_t *aux)
+{
+	bump("transform:%d:%d", w, w == 4 && mode != REG_DCT, 0, 0);
+	g_orig.transform(bd, b, c, bs, w, h, ws, hs, mode, aux);
+}
+static void w_itr(int bd, int16_t *b, int16_t *c, int bs, int w, int h, unsigned mode, int16_t *aux)
+{
+	bump("itransform:%d:%d", w, w == 4 && mode != REG_DCT, 0, 0);
+	g_orig.itransform(bd, b, c, bs, w, h, mode, aux);
+}
+static void w_sao(henc_thread_t *t, slice_t *s, ctu_info_t *c, sao_stat_data_t st[][NUM_SAO_NEW_TYPES]) { bump("sao_stats_ctu", 0, 0, 0, 0); g_orig.get_sao_stats(t, s, c, st); }
+
+uint32_t __real_sad(int16_t *s, uint32_t ss, int16_t *p, uint32_t ps, int n);
+uint32_t __wrap_sad(int16_t *s, uint32_t ss, int16_t *p, uint32_t ps, int n) { bump("sad_direct:%d", n, 0, 0, 0); return __real_sad(s, ss, p, ps, n); }
+
+static void dump_frame(FILE *fo, int frame, int first)
+{
+	int i;
+	fprintf(fo, "%s\n {\"frame\": %d, \"calls\": {", first ? "" : ",", frame);
+	for (i = 0; i < g_nkeys; i++) fprintf(fo, "%s\"%s\": %ld", i ? ", " : "", g_cnt[i].key, g_cnt[i].n);
+	fprintf(fo, "}}");
+	g_nkeys = 0;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 6) { fprintf(stderr, "usage: %s in.yuv out.json W H frames [key=value ...]\n", argv[0]); return 2; }
+	const char *in = argv[1], *out = argv[2];
+	int W = atoi(argv[3]), H = atoi(argv[4]), N = atoi(argv[5]), i, force_intra = 0;
+	HVENC_Cfg c;
+	memset(&c, 0, sizeof c);
+	c.size = sizeof c; c.width = W; c.height = H; c.profile = PROFILE_MAIN;
+	c.gop_size = 1; c.num_b = 0; c.intra_period = 100; c.qp = 32; c.bitrate_mode = BR_FIXED_QP; c.bitrate = 20000;
+	c.wfpp_num_threads = 1; c.wfpp_enable = 1; c.num_enc_engines = 1; c.sample_adaptive_offset = 1; c.performance_mode = 2; c.rd_mode = 2;
+	c.max_intra_tr_depth = 2; c.max_inter_tr_depth = 1; c.motion_estimation_precision = QUARTER_PEL; c.frame_rate = 25;
+	c.num_ref_frames = 1; c.cu_size = 64; c.max_pred_partition_depth = 4; c.sign_hiding = 1; c.chroma_qp_offset = 2; c.reinit_gop_on_scene_change = 1;
+	for (i = 6; i < argc; i++) {
+		char *eq = strchr(argv[i], '=');
+		if (!eq) continue;
+		*eq = 0;
+		const char *k = argv[i], *v = eq + 1;
+		if (!strcmp(k, "qp")) c.qp = atoi(v);
+		else if (!strcmp(k, "perf")) c.performance_mode = atoi(v);
+		else if (!strcmp(k, "rd")) c.rd_mode = atoi(v);
+		else if (!strcmp(k, "sao")) c.sample_adaptive_offset = atoi(v);
+		else if (!strcmp(k, "force_intra")) force_intra = atoi(v);
+		else if (!strcmp(k, "intra_tr")) c.max_intra_tr_depth = atoi(v);
+		else { fprintf(stderr, "unknown key %s\n", k); return 2; }
+	}
+	c.vbv_size = c.bitrate; c.vbv_init = (int)(c.bitrate * 0.35);
+	void *h = HOMER_enc_init();
+	hvenc_enc_t *hv = (hvenc_enc_t *)h;
+	g_orig = hv->funcs;
+	hv->funcs.sse_copy_16_16 = w_c1616; hv->funcs.sse_copy_16_8 = w_c168; hv->funcs.sse_copy_8_16 = w_c816;
+	hv->funcs.sad = w_sad; hv->funcs.ssd16b = w_ssd; hv->funcs.predict = w_predict; hv->funcs.reconst = w_reconst;
+	hv->funcs.modified_variance = w_var; hv->funcs.create_intra_planar_prediction = w_planar; hv->funcs.create_intra_angular_prediction = w_ang;
+	hv->funcs.interpolate_luma_m_compensation = w_il; hv->funcs.interpolate_luma_m_estimation = w_il; hv->funcs.interpolate_chroma_m_compensation = w_ic;
+	hv->funcs.weighted_average_motion = w_wavg; hv->funcs.quant = w_quant; hv->funcs.inv_quant = w_iquant;
+	hv->funcs.transform = w_tr; hv->funcs.itransform = w_itr; hv->funcs.get_sao_stats = w_sao;
+	FILE *fi = fopen(in, "rb"), *fo = fopen(out, "w");
+	if (!fi || !fo) { fprintf(stderr, "cannot open files\n"); return 1; }
+	if (!HOMER_enc_control(h, HOMER_SETCFG, &c)) { fprintf(stderr, "SETCFG failed\n"); return 1; }
+	unsigned char *y = malloc((size_t)W * H), *u = malloc((size_t)W * H / 4), *v = malloc((size_t)W * H / 4);
+	encoder_in_out_t inf, os, rec;
+	memset(&inf, 0, sizeof inf); memset(&os, 0, sizeof os); memset(&rec, 0, sizeof rec);
+	os.stream.streams[0] = malloc(0x4000000);
+	long bytes = 0;
+	int fed = 0;
+	fprintf(fo, "{\"width\": %d, \"height\": %d, \"qp\": %d, \"perf\": %d, \"rd\": %d, \"force_intra\": %d, \"frames\": [", W, H, c.qp, c.performance_mode, c.rd_mode, force_intra);
+	while (fed < N && fread(y, 1, (size_t)W * H, fi) == (size_t)W * H && fread(u, 1, (size_t)W * H / 4, fi) == (size_t)W * H / 4 &&
+	       fread(v, 1, (size_t)W * H / 4, fi) == (size_t)W * H / 4) {
+		inf.stream.streams[0] = y; inf.stream.streams[1] = u; inf.stream.streams[2] = v;
+		inf.stream.data_stride[0] = W; inf.stream.data_stride[1] = inf.stream.data_stride[2] = W / 2;
+		inf.pts = fed;
+		inf.image_type = force_intra ? IMAGE_I : IMAGE_AUTO;
+		HOMER_enc_encode(h, &inf);
+		while (!drain_one(h, &rec, &os, NULL, NULL, W, H, &bytes)) usleep(100);
+		dump_frame(fo, fed, fed == 0);
+		fed++;
+	}
+	fprintf(fo, "\n]}\n");
+	fclose(fo);
+	_exit(0);
+}

@@ -168,3 +168,237 @@ void refh_weighted_average(int16_t *a, int as, int16_t *b, int bs, int16_t *d, i
 {
 	sse_weighted_average_motion(a, as, b, bs, d, ds, h, w, 8);
 }
+
+/* =====================================================================================================
+ * In-loop filters at frame level, driven by REAL side-info: a clip is encoded with the reference
+ * encoder (lockstep), after which engine->ctu_info[] holds every decision of the last frame.  The
+ * functions below export that side-info as flat per-4x4-unit raster arrays and run the reference's own
+ * deblock / SAO / padding code (hmr_deblocking_filter.c:737, hmr_sse42_sao.c:35, hmr_sao.c:1210,
+ * hmr_encoder_lib.c:1723) over caller-supplied sample planes, CTU by CTU in the order of the unused
+ * frame-level driver hmr_deblock_filter (hmr_deblocking_filter.c:829).
+ * ===================================================================================================== */
+
+static int g_w, g_h;
+
+/* (re)open with an explicit configuration; several encoders may be created in one process (the old one leaks) */
+int refh_open_cfg(int width, int height, int qp, int sao, int perf, int rd)
+{
+	HVENC_Cfg c;
+	int fd_out, fd_null, ok;
+	fflush(stdout);
+	fd_out = dup(1);
+	fd_null = open("/dev/null", 1);
+	dup2(fd_null, 1);
+	memset(&c, 0, sizeof c);
+	c.size = sizeof c;
+	c.width = width; c.height = height; c.profile = PROFILE_MAIN;
+	c.gop_size = 1; c.num_b = 0; c.intra_period = 100; c.qp = qp;
+	c.bitrate_mode = BR_FIXED_QP; c.bitrate = 1000; c.vbv_size = 1000; c.vbv_init = 350;
+	c.wfpp_num_threads = 1; c.wfpp_enable = 1; c.num_enc_engines = 1;
+	c.sample_adaptive_offset = sao; c.performance_mode = perf; c.rd_mode = rd;
+	c.max_intra_tr_depth = 2; c.max_inter_tr_depth = 1;
+	c.motion_estimation_precision = QUARTER_PEL; c.frame_rate = 25;
+	c.num_ref_frames = 1; c.cu_size = 64; c.max_pred_partition_depth = 4;
+	c.sign_hiding = 1; c.chroma_qp_offset = 2; c.reinit_gop_on_scene_change = 1;
+	g_handle = HOMER_enc_init();
+	g_enc = (hvenc_enc_t *)g_handle;
+	ok = HOMER_enc_control(g_handle, HOMER_SETCFG, &c);
+	fflush(stdout);
+	dup2(fd_out, 1);
+	close(fd_out);
+	close(fd_null);
+	if (!ok) return -1;
+	g_eng = g_enc->encoder_engines[0];
+	g_et = g_eng->thread[0];
+	g_w = width; g_h = height;
+	memset(&g_ctu, 0, sizeof g_ctu);
+	g_ctu.top = g_ctu.left = 1;
+	return 0;
+}
+
+/* feed one frame, wait for its NALs; returns the Annex-B byte count (stream copied to out if it fits) */
+int refh_encode_frame(uint8_t *y, uint8_t *u, uint8_t *v, int force_intra, uint8_t *out, int out_cap, int *frame_type)
+{
+	static uint8_t *buf;
+	encoder_in_out_t inf, os, rec;
+	nalu_t *nal[8];
+	unsigned nn = 0;
+	int fd_out, fd_null;
+	if (!buf) buf = malloc(0x2000000);
+	memset(&inf, 0, sizeof inf); memset(&os, 0, sizeof os); memset(&rec, 0, sizeof rec);
+	os.stream.streams[0] = buf;
+	inf.stream.streams[0] = y; inf.stream.streams[1] = u; inf.stream.streams[2] = v;
+	inf.stream.data_stride[0] = g_w; inf.stream.data_stride[1] = inf.stream.data_stride[2] = g_w / 2;
+	inf.image_type = force_intra ? IMAGE_I : IMAGE_AUTO;
+	fflush(stdout);
+	fd_out = dup(1); fd_null = open("/dev/null", 1); dup2(fd_null, 1);
+	HOMER_enc_encode(g_handle, &inf);
+	for (;;) {
+		HOMER_enc_get_coded_frame(g_handle, &rec, nal, &nn);
+		if (nn) break;
+		usleep(100);
+	}
+	HOMER_enc_write_annex_b_output(nal, nn, &os);
+	fflush(stdout);
+	dup2(fd_out, 1); close(fd_out); close(fd_null);
+	if (frame_type) *frame_type = rec.image_type;
+	if (out && os.stream.data_size[0] <= out_cap) memcpy(out, buf, os.stream.data_size[0]);
+	return os.stream.data_size[0];
+}
+
+void refh_pict_geometry(int *geo)
+{
+	geo[0] = g_eng->pict_width_in_ctu; geo[1] = g_eng->pict_height_in_ctu;
+	geo[2] = g_eng->curr_reference_frame->img.window_size_x[0]; geo[3] = g_eng->curr_reference_frame->img.window_size_x[1];
+	geo[4] = g_eng->curr_reference_frame->img.data_padding_x[0]; geo[5] = g_eng->curr_reference_frame->img.data_padding_y[0];
+	geo[6] = g_eng->curr_reference_frame->img.data_padding_x[1]; geo[7] = g_eng->curr_reference_frame->img.data_padding_y[1];
+	geo[8] = g_eng->current_pict.slice.slice_type == I_SLICE;
+	geo[9] = g_eng->current_pict.slice.pps->cb_qp_offset; geo[10] = g_eng->current_pict.slice.pps->cr_qp_offset;
+	geo[11] = g_eng->current_pict.slice.slice_beta_offset_div2; geo[12] = g_eng->current_pict.slice.slice_tc_offset_div2;
+	geo[13] = g_eng->current_pict.slice.deblocking_filter_disabled_flag;
+}
+
+/* per-4x4-unit side info of the last encoded frame, raster order over (ctus_x*16) x (ctus_y*16) units */
+void refh_get_unit_info(int16_t *mvx, int16_t *mvy, int8_t *ref_idx, uint8_t *qp, uint8_t *pred_mode, uint8_t *cbf_y, uint8_t *pred_depth,
+			uint8_t *tr_idx, uint8_t *part_size, uint8_t *skipped)
+{
+	int W4 = g_eng->pict_width_in_ctu * 16, c, a;
+	for (c = 0; c < g_eng->pict_total_ctu; c++) {
+		ctu_info_t *ctu = &g_eng->ctu_info[c];
+		int cx = c % g_eng->pict_width_in_ctu, cy = c / g_eng->pict_width_in_ctu;
+		for (a = 0; a < 256; a++) {
+			int r = g_enc->abs2raster_table[a];
+			size_t o = (size_t)(cy * 16 + r / 16) * W4 + cx * 16 + r % 16;
+			mvx[o] = (int16_t)ctu->mv_ref[0][a].hor_vector;
+			mvy[o] = (int16_t)ctu->mv_ref[0][a].ver_vector;
+			ref_idx[o] = ctu->mv_ref_idx[0][a];
+			qp[o] = ctu->qp[a];
+			pred_mode[o] = ctu->pred_mode[a];
+			cbf_y[o] = CBF(ctu, a, Y_COMP, ctu->tr_idx[a]);
+			pred_depth[o] = ctu->pred_depth[a];
+			tr_idx[o] = ctu->tr_idx[a];
+			part_size[o] = ctu->part_size_type[a];
+			skipped[o] = ctu->skipped[a];
+		}
+	}
+}
+
+static void planes_in(wnd_t *w, int16_t *y, int16_t *u, int16_t *v)
+{
+	int16_t *src[3] = {y, u, v};
+	int comp, j;
+	for (comp = 0; comp < 3; comp++) {
+		int pw = comp ? g_w / 2 : g_w, ph = comp ? g_h / 2 : g_h;
+		for (j = 0; j < ph; j++) memcpy((int16_t *)w->pwnd[comp] + (size_t)j * w->window_size_x[comp], src[comp] + (size_t)j * pw, (size_t)pw * 2);
+	}
+}
+static void planes_out(wnd_t *w, int16_t *y, int16_t *u, int16_t *v)
+{
+	int16_t *dst[3] = {y, u, v};
+	int comp, j;
+	for (comp = 0; comp < 3; comp++) {
+		int pw = comp ? g_w / 2 : g_w, ph = comp ? g_h / 2 : g_h;
+		for (j = 0; j < ph; j++) memcpy(dst[comp] + (size_t)j * pw, (int16_t *)w->pwnd[comp] + (size_t)j * w->window_size_x[comp], (size_t)pw * 2);
+	}
+}
+
+/* planes are dense picture-size int16 arrays (in/out); bs_ver/bs_hor receive the boundary strengths the reference derived */
+void refh_deblock_frame(int16_t *y, int16_t *u, int16_t *v, uint8_t *bs_ver, uint8_t *bs_hor)
+{
+	slice_t *slice = &g_eng->current_pict.slice;
+	wnd_t *img = &g_eng->curr_reference_frame->img;
+	int W4 = g_eng->pict_width_in_ctu * 16, dir, c, a;
+	planes_in(img, y, u, v);
+	for (dir = EDGE_VER; dir <= EDGE_HOR; dir++)
+		for (c = 0; c < g_eng->pict_total_ctu; c++) {
+			ctu_info_t *ctu = &g_eng->ctu_info[c];
+			uint8_t *bs = dir == EDGE_VER ? bs_ver : bs_hor;
+			int cx = c % g_eng->pict_width_in_ctu, cy = c / g_eng->pict_width_in_ctu;
+			create_partition_ctu_neighbours(g_et, ctu, ctu->partition_list);
+			hmr_deblock_filter_cu(g_et, slice, ctu, dir);
+			if (bs)
+				for (a = 0; a < 256; a++) {
+					int r = g_enc->abs2raster_table[a];
+					bs[(size_t)(cy * 16 + r / 16) * W4 + cx * 16 + r % 16] =
+						g_et->deblock_edge_filter[dir][a] ? (uint8_t)(0x80 | g_et->deblock_filter_strength_bs[dir][a]) : 0;
+				}
+		}
+	planes_out(img, y, u, v);
+}
+
+/* stats[ctu][comp][type][0=diff,1=count][32] as int64 */
+void refh_sao_stats_frame(int16_t *oy, int16_t *ou, int16_t *ov, int16_t *ry, int16_t *ru, int16_t *rv, int64_t *stats)
+{
+	slice_t *slice = &g_eng->current_pict.slice;
+	int c, comp, t;
+	planes_in(&g_eng->current_pict.img2encode->img, oy, ou, ov);
+	planes_in(&g_eng->curr_reference_frame->img, ry, ru, rv);
+	for (c = 0; c < g_eng->pict_total_ctu; c++) {
+		ctu_info_t *ctu = &g_eng->ctu_info[c];
+		memset(&ctu->stat_data[0][0], 0, sizeof(ctu->stat_data));
+		sse_sao_get_ctu_stats(g_et, slice, ctu, ctu->stat_data);
+		for (comp = 0; comp < 3; comp++)
+			for (t = 0; t < NUM_SAO_NEW_TYPES; t++) {
+				int64_t *o = stats + ((((size_t)c * 3 + comp) * NUM_SAO_NEW_TYPES + t) * 2) * 32;
+				memcpy(o, ctu->stat_data[comp][t].diff, 32 * 8);
+				memcpy(o + 32, ctu->stat_data[comp][t].count, 32 * 8);
+			}
+	}
+}
+
+/* params[ctu][comp][34] = {modeIdc, typeIdc, offset[32]}; planes in/out.  Source = pre-SAO copy (sao_aux_wnd), hmr_sao.c:1435 */
+void refh_sao_apply_frame(int16_t *y, int16_t *u, int16_t *v, int32_t *params)
+{
+	int c, comp, k;
+	planes_in(&g_eng->curr_reference_frame->img, y, u, v);
+	for (c = 0; c < g_eng->pict_total_ctu; c++) {
+		ctu_info_t *ctu = &g_eng->ctu_info[c];
+		wnd_copy_ctu(sse_copy_16_16, &g_eng->curr_reference_frame->img, &g_eng->sao_aux_wnd, ctu);
+		reference_picture_border_padding_ctu(&g_eng->sao_aux_wnd, ctu);
+	}
+	for (c = 0; c < g_eng->pict_total_ctu; c++) {
+		ctu_info_t *ctu = &g_eng->ctu_info[c];
+		sao_blk_param_t p;
+		memset(&p, 0, sizeof p);
+		for (comp = 0; comp < 3; comp++) {
+			int32_t *src = params + ((size_t)c * 3 + comp) * 34;
+			p.offsetParam[comp].modeIdc = src[0];
+			p.offsetParam[comp].typeIdc = src[1];
+			for (k = 0; k < 32; k++) p.offsetParam[comp].offset[k] = src[2 + k];
+		}
+		sao_offset_ctu(g_et, ctu, &p);
+	}
+	planes_out(&g_eng->curr_reference_frame->img, y, u, v);
+}
+
+/* the SAO parameters the encoder decided for the last frame, same layout as above */
+void refh_get_sao_params(int32_t *params)
+{
+	int c, comp, k;
+	for (c = 0; c < g_eng->pict_total_ctu; c++)
+		for (comp = 0; comp < 3; comp++) {
+			sao_offset_t *o = &g_eng->ctu_info[c].recon_params.offsetParam[comp];
+			int32_t *dst = params + ((size_t)c * 3 + comp) * 34;
+			dst[0] = o->modeIdc; dst[1] = o->typeIdc;
+			for (k = 0; k < 32; k++) dst[2 + k] = o->offset[k];
+		}
+}
+
+/* picture planes in; padded planes out (full allocated window incl. margins: stride x (h + 2*pad_y) per component) */
+void refh_pad_frame(int16_t *y, int16_t *u, int16_t *v, int16_t *py, int16_t *pu, int16_t *pv)
+{
+	wnd_t *img = &g_eng->curr_reference_frame->img;
+	int16_t *out[3] = {py, pu, pv};
+	int c, comp, j;
+	for (comp = 0; comp < 3; comp++) {   /* poison the margins so that missing writes show */
+		int16_t *base = (int16_t *)img->palloc[comp];
+		for (j = 0; j < img->window_size_y[comp] * img->window_size_x[comp]; j++) base[j] = 0x1234;
+	}
+	planes_in(img, y, u, v);
+	for (c = 0; c < g_eng->pict_total_ctu; c++) reference_picture_border_padding_ctu(img, &g_eng->ctu_info[c]);
+	for (comp = 0; comp < 3; comp++) {
+		memcpy(out[comp], img->palloc[comp], (size_t)img->window_size_y[comp] * img->window_size_x[comp] * 2);
+	}
+}
+/* reconstruction of the last encoded frame as the encoder left it (deblocked, SAO'd), dense int16 planes */
+void refh_get_recon(int16_t *y, int16_t *u, int16_t *v) { planes_out(&g_eng->curr_reference_frame->img, y, u, v); }
