@@ -122,3 +122,28 @@ extern "C" int hmr_gpu_timer_stop(hmr_gpu_ctx *c, float *ms)
 	HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
 	return HMR_GPU_OK;
 }
+
+// Event pairs for per-kernel timing on the context's stream (bench.py, roofline accounting)
+extern "C" int hmr_gpu_event_create(hmr_gpu_ctx *c, void **ev)
+{
+	hipEvent_t e;
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipEventCreate(&e));
+	*ev = (void *)e;
+	return HMR_GPU_OK;
+}
+extern "C" int hmr_gpu_event_record(hmr_gpu_ctx *c, void *ev)
+{
+	HIP_TRY(hipEventRecord((hipEvent_t)ev, c->stream));
+	return HMR_GPU_OK;
+}
+extern "C" int hmr_gpu_event_elapsed(void *ev0, void *ev1, float *ms)
+{
+	HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)ev0, (hipEvent_t)ev1));
+	return HMR_GPU_OK;
+}
+extern "C" int hmr_gpu_event_destroy(void *ev)
+{
+	HIP_TRY(hipEventDestroy((hipEvent_t)ev));
+	return HMR_GPU_OK;
+}

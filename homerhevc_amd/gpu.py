@@ -1,0 +1,74 @@
+"""Host-side driver over the batched / frame-level C ABI (include/homer_gpu.h layers 1, 3, 4).
+
+Device memory is owned by the caller (torch tensors in bench.py, hmr_gpu_malloc in tests); this module only
+marshals pointers.  Everything here fails loudly when the native library or the GPU is missing.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .lowlevel import load_library
+
+JOB_DTYPE = np.dtype([("a_off", "<u4"), ("a_stride", "<u4"), ("b_off", "<u4"), ("b_stride", "<u4"), ("c_off", "<u4"), ("c_stride", "<u4"),
+                      ("w", "<u2"), ("h", "<u2"), ("p0", "<u4"), ("p1", "<u4")])
+assert JOB_DTYPE.itemsize == 36
+
+
+class Frame(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("stride_y", C.c_int), ("stride_c", C.c_int)]
+
+
+class Units(C.Structure):
+    _fields_ = [("units_stride", C.c_int), ("mvx", C.c_void_p), ("mvy", C.c_void_p), ("ref_idx", C.c_void_p), ("qp", C.c_void_p), ("flags", C.c_void_p)]
+
+
+class GpuError(RuntimeError):
+    pass
+
+
+class Context:
+    """One context per GPU (one process per GPU in multi-GPU runs)."""
+
+    def __init__(self, device=0, stream=None, lib=None):
+        self.lib = lib or load_library()
+        self.lib.hmr_gpu_last_error.restype = C.c_char_p
+        self.ctx = C.c_void_p()
+        rc = self.lib.hmr_gpu_create(C.byref(self.ctx), int(device), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise GpuError(f"hmr_gpu_create failed ({rc}): {self.lib.hmr_gpu_last_error().decode()}")
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise GpuError(f"{what} failed ({rc}): {self.lib.hmr_gpu_last_error().decode()}")
+
+    def call(self, name, *args):
+        self.check(getattr(self.lib, name)(self.ctx, *args), name)
+
+    def sync(self):
+        self.call("hmr_gpu_sync")
+
+    def timer_start(self):
+        self.call("hmr_gpu_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self.call("hmr_gpu_timer_stop", C.byref(ms))
+        return ms.value
+
+    def event(self):
+        ev = C.c_void_p()
+        self.call("hmr_gpu_event_create", C.byref(ev))
+        return ev
+
+    def record(self, ev):
+        self.call("hmr_gpu_event_record", ev)
+
+    def elapsed(self, ev0, ev1):
+        ms = C.c_float()
+        self.check(self.lib.hmr_gpu_event_elapsed(ev0, ev1, C.byref(ms)), "hmr_gpu_event_elapsed")
+        return ms.value
+
+    def close(self):
+        if self.ctx:
+            self.lib.hmr_gpu_destroy(self.ctx)
+            self.ctx = None

@@ -59,6 +59,11 @@ int hmr_gpu_memset(hmr_gpu_ctx *ctx, void *dev_dst, int value, size_t bytes);
 /* HIP-event timer on the context's stream (bench.py brackets the timed region with it). */
 int hmr_gpu_timer_start(hmr_gpu_ctx *ctx);
 int hmr_gpu_timer_stop(hmr_gpu_ctx *ctx, float *elapsed_ms);   /* records, synchronises, returns ms */
+/* explicit event pairs on the same stream, for per-kernel durations (elapsed() is valid once ev1 has completed) */
+int hmr_gpu_event_create(hmr_gpu_ctx *ctx, void **ev);
+int hmr_gpu_event_record(hmr_gpu_ctx *ctx, void *ev);
+int hmr_gpu_event_elapsed(void *ev0, void *ev1, float *elapsed_ms);
+int hmr_gpu_event_destroy(void *ev);
 
 /* Constant tables the kernels use, built at context creation (defaults of hmr_tables.c:62,221 and
  * hmr_encoder_lib.c:93-140); exposed so the host can check them against its own. */

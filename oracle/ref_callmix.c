@@ -5,11 +5,13 @@
  * sample data): the "call mix" that bench.py replays as batched GPU launches and that DESIGN.md uses to
  * turn per-kernel bytes into per-frame bytes.  It overwrites hvenc_enc_t.funcs (hmr_private.h:1443) with
  * counting wrappers after HOMER_enc_init - the registration route verified in SURVEY.md §8-b - and wraps
- * the scalar sad() the sub-pel refinement calls directly (hmr_motion_inter.c:1712,1757) at link time
- * (-Wl,--wrap=sad).  Built by oracle/Makefile into oracle/_ref/ref_callmix; includes ref_lockstep.c.
+ * the kernels that bypass the table - the scalar sad() of the sub-pel refinement (hmr_motion_inter.c:1712,1757),
+ * fill_reference_samples, the sub-pel plane builders, deblock, SAO offset, padding - by ELF symbol interposition
+ * (it links the shared oracle/_ref/libhomer_ref.so with -rdynamic).  Built by oracle/Makefile into oracle/_ref/ref_callmix; includes ref_lockstep.c.
  *
  * usage: ref_callmix in.yuv out.json W H frames [key=value ...]     (same keys as ref_lockstep)
  */
+#define _GNU_SOURCE
 #define main lockstep_main_unused
 #include "ref_lockstep.c"
 #undef main
@@ -79,8 +81,45 @@ static void w_itr(int bd, int16_t *b, int16_t *c, int bs, int w, int h, unsigned
 }
 static void w_sao(henc_thread_t *t, slice_t *s, ctu_info_t *c, sao_stat_data_t st[][NUM_SAO_NEW_TYPES]) { bump("sao_stats_ctu", 0, 0, 0, 0); g_orig.get_sao_stats(t, s, c, st); }
 
-uint32_t __real_sad(int16_t *s, uint32_t ss, int16_t *p, uint32_t ps, int n);
-uint32_t __wrap_sad(int16_t *s, uint32_t ss, int16_t *p, uint32_t ps, int n) { bump("sad_direct:%d", n, 0, 0, 0); return __real_sad(s, ss, p, ps, n); }
+/* Kernels outside the table are reached through the shared library's PLT, so defining the symbol in this
+ * executable (linked -rdynamic) interposes it - the same route INTEGRATION.md uses to swap them. */
+#include <dlfcn.h>
+#define REAL(name) ({ static void *p_; if (!p_) p_ = dlsym(RTLD_NEXT, #name); p_; })
+uint32_t sad(int16_t *s, uint32_t ss, int16_t *p, uint32_t ps, int n)
+{
+	bump("sad_direct:%d", n, 0, 0, 0);
+	return ((uint32_t(*)(int16_t *, uint32_t, int16_t *, uint32_t, int))REAL(sad))(s, ss, p, ps, n);
+}
+void fill_reference_samples(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *pi, int adi_size, int16_t *dec, int stride, int n, int comp, int filt)
+{
+	bump("fill_reference_samples:%d:%d:%d", n, comp != 0, filt, 0);
+	((void (*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int, int16_t *, int, int, int, int))REAL(fill_reference_samples))(et, ctu, pi, adi_size, dec, stride, n, comp, filt);
+}
+void hmr_half_pixel_estimation_luma_hm(henc_thread_t *et, int16_t *r, int rs, cu_partition_info_t *cu, int w, int h, int sh, motion_vector_t *mv)
+{
+	bump("half_pel_planes:%d", w, 0, 0, 0);
+	((void (*)(henc_thread_t *, int16_t *, int, cu_partition_info_t *, int, int, int, motion_vector_t *))REAL(hmr_half_pixel_estimation_luma_hm))(et, r, rs, cu, w, h, sh, mv);
+}
+void hmr_quarter_pixel_estimation_luma_hm(henc_thread_t *et, int16_t *r, int rs, cu_partition_info_t *cu, int w, int h, int sh, motion_vector_t *mv)
+{
+	bump("quarter_pel_planes:%d", w, 0, 0, 0);
+	((void (*)(henc_thread_t *, int16_t *, int, cu_partition_info_t *, int, int, int, motion_vector_t *))REAL(hmr_quarter_pixel_estimation_luma_hm))(et, r, rs, cu, w, h, sh, mv);
+}
+void hmr_deblock_filter_cu(henc_thread_t *et, slice_t *s, ctu_info_t *ctu, int dir)
+{
+	bump("deblock_ctu:%d", dir, 0, 0, 0);
+	((void (*)(henc_thread_t *, slice_t *, ctu_info_t *, int))REAL(hmr_deblock_filter_cu))(et, s, ctu, dir);
+}
+void sao_offset_ctu(henc_thread_t *et, ctu_info_t *ctu, sao_blk_param_t *p)
+{
+	bump("sao_offset_ctu", 0, 0, 0, 0);
+	((void (*)(henc_thread_t *, ctu_info_t *, sao_blk_param_t *))REAL(sao_offset_ctu))(et, ctu, p);
+}
+void reference_picture_border_padding_ctu(wnd_t *w, ctu_info_t *ctu)
+{
+	bump("pad_ctu", 0, 0, 0, 0);
+	((void (*)(wnd_t *, ctu_info_t *))REAL(reference_picture_border_padding_ctu))(w, ctu);
+}
 
 static void dump_frame(FILE *fo, int frame, int first)
 {
