@@ -269,6 +269,7 @@ def main():
 
     import torch
     import torch.distributed as dist
+    from homerhevc_amd.engines import exchange_reference
     from homerhevc_amd.gpu import Context, Frame, Units
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -367,14 +368,8 @@ def main():
         def rec(name, which):
             if timed:
                 ctx.record(events[(idx, name)][which])
-        reqs = []
-        if world > 1:   # reconstructed reference picture: engine r -> engine r+1, point-to-point over RCCL/xGMI
-            nxt, prv = (rank + 1) % world, (rank - 1) % world
-            ops = []
-            for t_send, t_recv in zip(dst_pl, nxt_pl):
-                ops.append(dist.P2POp(dist.isend, t_send, nxt))
-                ops.append(dist.P2POp(dist.irecv, t_recv, prv))
-            reqs = dist.batch_isend_irecv(ops)
+        # reconstructed reference picture: engine r -> engine r+1, point-to-point over RCCL/xGMI
+        reqs = exchange_reference(dst_pl, nxt_pl, rank, world)
         for g in groups:
             name = f"{g['name']}:{g['size']}"
             rec(name, 0)
