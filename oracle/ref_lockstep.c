@@ -22,6 +22,9 @@
 #include <sys/time.h>
 #include "homer_hevc_enc_api.h"
 
+/* hook for oracle/ref_swap.c: called right after HOMER_enc_init, before HOMER_SETCFG */
+__attribute__((weak)) void lockstep_post_init(void *handle) { (void)handle; }
+
 static double now(void)
 {
 	struct timeval tv;
@@ -99,6 +102,7 @@ int main(int argc, char **argv)
 
 	/* the library prints a banner and per-frame traces on stdout: keep ours on stderr+last line */
 	void *h = HOMER_enc_init();
+	lockstep_post_init(h);
 	FILE *fi = fopen(in, "rb");
 	FILE *fo = strcmp(out, "-") ? fopen(out, "wb") : NULL;
 	FILE *frec = recpath ? fopen(recpath, "wb") : NULL;

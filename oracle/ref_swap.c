@@ -1,0 +1,95 @@
+/*
+ * TEST INFRASTRUCTURE - the "swap test" (SURVEY.md §8-V): the reference's own L3 code (quadtree walk, mode
+ * decisions, CABAC, all unmodified, from oracle/_ref/libhomer_ref.so) drives the GPU kernels through the
+ * drop-in C ABI, and the emitted .265 must be byte-identical to the unswapped run.
+ *
+ * It is the binding of INTEGRATION.md §1 compiled for real: low_level_funcs_t entries are overwritten after
+ * HOMER_enc_init with the hmr_gpu_* entries (adapters for the henc_thread_t* members), and the kernels the
+ * reference calls directly are interposed through the PLT (sad, fill_reference_samples).
+ * HOMER_SWAP selects what is swapped: "all" (default), "none", or a comma list of member names.
+ *
+ * Built by oracle/Makefile into oracle/_ref/ref_swap (needs hmr_private.h -> build container only; runs on the
+ * GPU box).  Same command line as ref_lockstep.
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "hmr_private.h"
+#include "hmr_common.h"
+#include "homer_gpu.h"
+
+static int want(const char *name)
+{
+	const char *s = getenv("HOMER_SWAP");
+	if (!s || !strcmp(s, "all")) return 1;
+	if (!strcmp(s, "none")) return 0;
+	{
+		size_t n = strlen(name);
+		const char *p = s;
+		while ((p = strstr(p, name))) {
+			if ((p == s || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return 1;
+			p += n;
+		}
+	}
+	return 0;
+}
+
+static void gpu_planar(henc_thread_t *et, int16_t *pred, int ps, int16_t *adi, int adi_size, int n, int shift)
+{ (void)et; (void)shift; hmr_gpu_intra_planar(pred, ps, adi, adi_size, n); }
+static void gpu_angular(henc_thread_t *et, ctu_info_t *ctu, int16_t *pred, int ps, int16_t *adi, int adi_size, int n, int mode, int luma)
+{ (void)et; (void)ctu; hmr_gpu_intra_angular(pred, ps, adi, adi_size, n, mode, luma); }
+static void gpu_quant(henc_thread_t *et, int16_t *src, int16_t *dst, int scan, int depth, int comp, int cu_mode, int is_intra, int *ac_sum, int cu_size, int per, int rem)
+{
+	(void)cu_mode;
+	hmr_gpu_quant(src, dst, et->aux_buff, scan, depth, comp, is_intra, et->enc_engine->current_pict.slice.slice_type == I_SLICE,
+		      et->pps->sign_data_hiding_flag, ac_sum, cu_size, per, rem);
+}
+static void gpu_iquant(henc_thread_t *et, short *src, short *dst, int depth, int comp, int is_intra, int cu_size, int per, int rem)
+{ (void)et; hmr_gpu_inv_quant(src, dst, depth, comp, is_intra, cu_size, per, rem); }
+static void gpu_transform(int bd, int16_t *block, int16_t *coeff, int stride, int w, int h, int ws, int hs, uint16_t mode, int16_t *aux)
+{ (void)bd; (void)h; (void)ws; (void)hs; (void)aux; hmr_gpu_transform(block, coeff, stride, w, mode != REG_DCT); }
+static void gpu_itransform(int bd, int16_t *block, int16_t *coeff, int stride, int w, int h, unsigned mode, int16_t *aux)
+{ (void)bd; (void)h; (void)aux; hmr_gpu_itransform(block, coeff, stride, w, mode != REG_DCT); }
+static void gpu_wavg(int16_t *a, int as, int16_t *b, int bs, int16_t *d, int ds, int h, int w, int bit_depth)
+{ (void)bit_depth; hmr_gpu_weighted_average(a, as, b, bs, d, ds, h, w); }
+
+void lockstep_post_init(void *handle)
+{
+	low_level_funcs_t *f = &((hvenc_enc_t *)handle)->funcs;
+	int n = 0;
+#define SWAP(member, fn) if (want(#member)) { f->member = fn; n++; }
+	SWAP(sse_copy_16_16, hmr_gpu_copy_16_16) SWAP(sse_copy_16_8, hmr_gpu_copy_16_8) SWAP(sse_copy_8_16, hmr_gpu_copy_8_16)
+	SWAP(sad, hmr_gpu_sad) SWAP(ssd16b, hmr_gpu_ssd16b) SWAP(predict, hmr_gpu_predict) SWAP(reconst, hmr_gpu_reconst)
+	SWAP(modified_variance, hmr_gpu_modified_variance)
+	SWAP(create_intra_planar_prediction, gpu_planar) SWAP(create_intra_angular_prediction, gpu_angular)
+	SWAP(interpolate_luma_m_compensation, hmr_gpu_interpolate_luma) SWAP(interpolate_luma_m_estimation, hmr_gpu_interpolate_luma)
+	SWAP(interpolate_chroma_m_compensation, hmr_gpu_interpolate_chroma) SWAP(weighted_average_motion, gpu_wavg)
+	SWAP(quant, gpu_quant) SWAP(inv_quant, gpu_iquant) SWAP(transform, gpu_transform) SWAP(itransform, gpu_itransform)
+	fprintf(stderr, "ref_swap: %d table entries routed to libhomer_gpu.so\n", n);
+}
+
+/* ---- off-table kernels, interposed through the PLT ---- */
+#define REAL(name) ({ static void *p_; if (!p_) p_ = dlsym(RTLD_NEXT, #name); p_; })
+
+uint32_t sad(int16_t *s, uint32_t ss, int16_t *p, uint32_t ps, int n)   /* hmr_motion_inter.c:1712,1757 call this directly */
+{
+	if (want("sad_direct")) return hmr_gpu_sad(s, ss, p, ps, n);
+	return ((uint32_t(*)(int16_t *, uint32_t, int16_t *, uint32_t, int))REAL(sad))(s, ss, p, ps, n);
+}
+
+void fill_reference_samples(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *pi, int adi_size, int16_t *decoded, int stride, int n, int comp, int is_filtered)
+{
+	if (!want("fill_reference_samples")) {
+		((void (*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int, int16_t *, int, int, int, int))REAL(fill_reference_samples))(et, ctu, pi, adi_size, decoded, stride, n, comp, is_filtered);
+		return;
+	}
+	/* the sizes the reference derives at hmr_motion_intra.c:289,335 */
+	int bl = min(n, et->pict_height[comp] - (ctu->y[comp] + (comp == Y_COMP ? pi->y_position : pi->y_position_chroma) + n));
+	int tr = min(n, et->pict_width[comp] - (ctu->x[comp] + (comp == Y_COMP ? pi->x_position : pi->x_position_chroma) + n));
+	ctu->top = 1;
+	ctu->left = 1;
+	hmr_gpu_fill_reference_samples(decoded, stride, n, pi->left_neighbour, pi->top_neighbour, pi->left_bottom_neighbour, pi->top_right_neighbour, bl, tr, et->adi_pred_buff);
+	if (is_filtered) hmr_gpu_adi_filter(et->adi_pred_buff, et->adi_filtered_pred_buff, adi_size, n, et->sps->strong_intra_smooth_enabled_flag);
+}

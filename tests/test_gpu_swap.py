@@ -1,0 +1,42 @@
+"""Swap test (SURVEY.md §8-V acceptance harness): the reference's own decision code + CABAC, compiled in the build
+container into oracle/_ref, encodes a clip with every low_level_funcs_t entry (and the directly-called sad /
+fill_reference_samples) routed to the HIP kernels through the drop-in C ABI.  The .265 must be byte-identical to
+the unswapped run of the same binary build."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import libs
+
+pytestmark = pytest.mark.gpu
+
+SWAP = os.path.join(libs.ORACLE_DIR, "_ref", "ref_swap")
+
+
+def _encode(exe, clip, out, w, h, frames, env=None, extra=()):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([exe, clip, out, str(w), str(h), str(frames), *extra], capture_output=True, text=True, env=e, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    with open(out, "rb") as f:
+        return f.read(), r.stderr
+
+
+@pytest.mark.parametrize("extra", [(), ("force_intra=1",)], ids=["ippp", "all_intra"])
+def test_stream_identical_with_gpu_kernels(tmp_path, extra):
+    if not (os.path.exists(SWAP) and os.path.exists(libs.REF_LOCKSTEP)):
+        pytest.skip("oracle/_ref not shipped (built only where the reference sources exist)")
+    sys.path.insert(0, os.path.join(libs.ROOT, "tools"))
+    import gen_yuv
+    w, h, frames = 200, 136, 3 if not extra else 2
+    clip = str(tmp_path / "clip.yuv")
+    gen_yuv.write_clip(clip, w, h, frames)
+    ref, _ = _encode(libs.REF_LOCKSTEP, clip, str(tmp_path / "ref.265"), w, h, frames, extra=extra)
+    same, _ = _encode(SWAP, clip, str(tmp_path / "none.265"), w, h, frames, env={"HOMER_SWAP": "none"}, extra=extra)
+    assert same == ref, "harness itself changes the stream"
+    gpu, log = _encode(SWAP, clip, str(tmp_path / "gpu.265"), w, h, frames, env={"HOMER_SWAP": "all"}, extra=extra)
+    assert "table entries routed" in log
+    assert len(ref) > 300
+    assert gpu == ref, f"stream differs: {len(gpu)} vs {len(ref)} bytes"
