@@ -79,9 +79,23 @@ def build_groups(calls, rng, arena):
     out2 = arena.alloc(plane + 16 * W)
     zero_row = arena.alloc(64, np.zeros(64, np.int16))
 
+    NCX, NCY = W // 64, HA // 64
+    cur_ctu = [None]
+
     def pos(n, bw, bh, stride, align=1, x_lo=0, y_lo=0, x_hi=W, y_hi=HA):
-        x = rng.integers(x_lo // align, (x_hi - bw) // align + 1, n) * align
-        y = rng.integers(y_lo // align, (y_hi - bh) // align + 1, n) * align
+        """Job i works inside CTU (i * n_ctus) // n - the reference walks the picture CTU by CTU, so consecutive jobs of a
+        batch touch the same 64x64 neighbourhood.  A non-zero x_lo/y_lo widens the window (motion search / filter taps)."""
+        ctu = (np.arange(n, dtype=np.int64) * (NCX * NCY)) // max(n, 1)
+        cur_ctu[0] = ctu
+        cx, cy = ctu % NCX, ctu // NCX
+        rx, ry = max(64 - bw, 0) - 2 * x_lo, max(64 - bh, 0) - 2 * y_lo      # x_lo/y_lo <= 0
+        x = cx * 64 + x_lo + rng.integers(0, rx // align + 1, n) * align
+        y = cy * 64 + y_lo + rng.integers(0, ry // align + 1, n) * align
+        x = np.clip(x, x_lo, x_hi - bw)
+        y = np.clip(y, y_lo, y_hi - bh)
+        if align > 1:
+            x -= x % align
+            y -= y % align
         return (y * stride + x).astype(np.int64)
 
     def jobs(n):
@@ -91,12 +105,14 @@ def build_groups(calls, rng, arena):
 
     def add(name, fn, size, jb, nbytes, extra=()):
         key = (name, size)
+        ctu = cur_ctu[0] if cur_ctu[0] is not None and len(cur_ctu[0]) == len(jb) else np.zeros(len(jb), np.int64)
         if key in merged:
             g = merged[key]
             g["jobs"] = np.concatenate([g["jobs"], jb])
+            g["ctu"] = np.concatenate([g["ctu"], ctu])
             g["bytes"] += nbytes
         else:
-            merged[key] = {"name": name, "fn": fn, "size": size, "jobs": jb, "bytes": nbytes, "extra": extra}
+            merged[key] = {"name": name, "fn": fn, "size": size, "jobs": jb, "ctu": ctu, "bytes": nbytes, "extra": extra}
 
     for key, n in sorted(calls.items()):
         parts = key.split(":")
@@ -105,7 +121,7 @@ def build_groups(calls, rng, arena):
             N = a[0]
             jb = jobs(n)
             jb["a_off"] = src + pos(n, N, N, W, align=min(N, 8)); jb["a_stride"] = W
-            jb["b_off"] = ref0 + pos(n, N, N, REF_STRIDE, 1, -64, -32, W + 64, HA + 32); jb["b_stride"] = REF_STRIDE
+            jb["b_off"] = ref0 + pos(n, N, N, REF_STRIDE, 1, -32, -16, W + 64, HA + 32); jb["b_stride"] = REF_STRIDE
             add("sad", "hmr_gpu_sad_batch", N, jb, n * (4 * N * N + 4))
         elif kind == "ssd16b":
             N, z = a
@@ -141,7 +157,7 @@ def build_groups(calls, rng, arena):
             jb["a_off"] = rec + pos(n, w, h, W, align=min(w, 8)); jb["a_stride"] = W
             jb["c_off"] = out2 + pos(n, w, h, W, align=min(w, 8)); jb["c_stride"] = W
             jb["w"] = w; jb["h"] = h
-            add("copy_16_16", "hmr_gpu_copy_batch", 0, jb, n * 4 * h * w)
+            add("copy_16_16", "hmr_gpu_copy_batch", w if (h == w and w in (4, 8, 16, 32, 64)) else 0, jb, n * 4 * h * w)
         elif kind in ("intra_planar", "intra_angular"):
             N = a[0]
             mode, luma = (0, 1) if kind == "intra_planar" else (a[1], a[2])
@@ -170,7 +186,7 @@ def build_groups(calls, rng, arena):
             taps = 8 if luma else 4
             jb = jobs(n)
             if first:
-                jb["a_off"] = ref0 + pos(n, w + 8, h + 8, REF_STRIDE, 1, -56, -24, W + 56, HA + 24); jb["a_stride"] = REF_STRIDE
+                jb["a_off"] = ref0 + pos(n, w + 8, h + 8, REF_STRIDE, 1, -24, -12, W + 56, HA + 24); jb["a_stride"] = REF_STRIDE
             else:
                 jb["a_off"] = tmp + 4 * W + pos(n, w + 8, h + 8, W, 1); jb["a_stride"] = W
             jb["c_off"] = out2 + pos(n, w, h, W, align=1); jb["c_stride"] = W
@@ -178,7 +194,9 @@ def build_groups(calls, rng, arena):
             jb["p0"] = rng.integers(1, 4 if luma else 8, n) if frac_nz else 0
             jb["p1"] = vert | (first << 1) | (last << 2)
             rd = (w * (h + taps - 1) if vert else (w + taps - 1) * h) if frac_nz else w * h
-            add(kind, "hmr_gpu_interpolate_batch", 1 if luma else 0, jb, n * 2 * (rd + w * h))
+            chunks = ((w + 3) // 4) * h
+            lanes = 16 if chunks <= 16 else (32 if chunks <= 32 else 64)
+            add(kind, "hmr_gpu_interpolate_batch", (1 if luma else 0) | (lanes << 8), jb, n * 2 * (rd + w * h))
         elif kind in ("transform", "itransform"):
             N, is_dst = a
             pool = arena.alloc(n * N * N, rng.integers(-200, 201, n * N * N).astype(np.int16) if kind == "itransform" else None)
@@ -204,6 +222,9 @@ def build_groups(calls, rng, arena):
             add(kind, "hmr_gpu_%s_batch" % kind, N, jb, n * 4 * N * N)
         # half_pel_planes / quarter_pel_planes are drivers whose interpolation calls are already counted;
         # deblock_ctu / sao_* / pad_ctu are issued as the frame-level passes below.
+    for g in merged.values():      # a batch is issued in CTU order, like the host would enumerate it
+        order = np.argsort(g["ctu"], kind="stable")
+        g["jobs"] = np.ascontiguousarray(g["jobs"][order])
     return list(merged.values()), {"src": src, "ref0": ref0, "rec": rec}
 
 
@@ -332,7 +353,7 @@ def main():
         elif fn in ("hmr_gpu_predict_batch", "hmr_gpu_reconst_batch"):
             rc = getattr(lib, fn)(c, jp, n, s, b, b, b)
         elif fn == "hmr_gpu_copy_batch":
-            rc = lib.hmr_gpu_copy_batch(c, jp, n, 0, b, b)
+            rc = lib.hmr_gpu_copy_batch(c, jp, n, s << 8, b, b)   # kind 0 (int16) | uniform square size hint
         elif fn == "hmr_gpu_interpolate_batch":
             rc = lib.hmr_gpu_interpolate_batch(c, jp, n, s, b, b)
         elif fn == "hmr_gpu_quant_batch":
@@ -426,7 +447,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "bytes_per_launch": int(nbytes[dom]), "ms_per_launch": round(per[dom], 5),
                          "frame_level_frac": round(10.5 * W * H * fps / world / 1e9 / HBM_PEAK_GBS, 6)},
-            "kernels_ms": {k: round(v, 4) for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:12]},
+            "kernels_ms": {k: round(v, 4) for k, v in sorted(per.items(), key=lambda kv: -kv[1])},
+            "kernels_gbs": {k: round(nbytes[k] / (v * 1e-3) / 1e9, 1) for k, v in sorted(per.items(), key=lambda kv: -kv[1]) if v > 0},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline()

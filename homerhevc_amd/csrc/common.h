@@ -46,15 +46,41 @@ const DevTables *hmr_host_tables();      // host copy (tables.cpp)
 		}                                                                                      \
 	} while (0)
 
+#define HMR_XCDS 8                  // MI355X: 8 XCDs, each with a private 4 MiB L2; block b is dispatched to XCD b % 8
+
+// grid for `units` block-iterations of work: capped, and a multiple of the XCD count so that xcd_job_range() can give
+// every XCD a contiguous share of the batch
+static inline int hmr_grid_for_units(long units)
+{
+	long blocks = units < 1 ? 1 : units;
+	if (blocks > HMR_MAX_GRID) blocks = HMR_MAX_GRID;
+	if (blocks >= HMR_XCDS) blocks = (blocks + HMR_XCDS - 1) / HMR_XCDS * HMR_XCDS;
+	return (int)blocks;
+}
 static inline int hmr_grid_for_waves(long njobs_waves)
 {
-	long blocks = (njobs_waves + HMR_WAVES_PER_BLOCK - 1) / HMR_WAVES_PER_BLOCK;
-	if (blocks < 1) blocks = 1;
-	if (blocks > HMR_MAX_GRID) blocks = HMR_MAX_GRID;
-	return (int)blocks;
+	return hmr_grid_for_units((njobs_waves + HMR_WAVES_PER_BLOCK - 1) / HMR_WAVES_PER_BLOCK);
 }
 
 #ifdef __HIPCC__
+// XCD-aware batch partition.  Hosts enumerate jobs in CTU order, so neighbouring jobs touch neighbouring samples;
+// giving XCD x the contiguous job range [x*per, (x+1)*per) keeps each picture region in ONE XCD's L2 instead of
+// spreading it over all eight (placement b % 8 is only used for speed: any placement computes the same result).
+struct JobRange { long begin, end, stride; };
+__device__ __forceinline__ JobRange xcd_job_range(long njobs, int jobs_per_block)
+{
+	JobRange r;
+	if (gridDim.x % HMR_XCDS) {   // tiny grids: plain grid-stride
+		r.begin = (long)blockIdx.x * jobs_per_block; r.end = njobs; r.stride = (long)gridDim.x * jobs_per_block;
+		return r;
+	}
+	const int xcd = blockIdx.x % HMR_XCDS, bi = blockIdx.x / HMR_XCDS, bpx = gridDim.x / HMR_XCDS;
+	const long per = ((njobs + (long)HMR_XCDS * jobs_per_block - 1) / ((long)HMR_XCDS * jobs_per_block)) * jobs_per_block;
+	r.begin = xcd * per + (long)bi * jobs_per_block;
+	r.end = (xcd + 1) * per < njobs ? (xcd + 1) * per : njobs;
+	r.stride = (long)bpx * jobs_per_block;
+	return r;
+}
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (HMR_WAVE - 1); }
 __device__ __forceinline__ int wave_in_block() { return threadIdx.x >> 6; }
 

@@ -6,37 +6,45 @@
 // consecutive samples of a row (coalesced 2-byte accesses into 128-byte row segments), and the per-job
 // result is reduced with cross-lane shuffles - no LDS, no atomics.  HBM/L2-bound integer work: no MFMA.
 #include "common.h"
+#include "vec.h"
 
 namespace {
 
 enum { OP_SAD = 0, OP_SSD = 1 };
 
+// One lane owns 4 consecutive samples of a row (one 8-byte load per operand; the candidate block of a motion
+// search is only 2-byte aligned), G = min(64, N*N/4) lanes own a block: 16 4x4 blocks, four 8x8 blocks or one larger
+// block per wave.
 template <int N, int OP>
 __global__ __launch_bounds__(HMR_BLOCK) void k_sad_ssd(const hmr_gpu_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ A,
 							  const int16_t *__restrict__ B, uint32_t *__restrict__ out)
 {
-	constexpr int E = N * N;
-	constexpr int G = E < HMR_WAVE ? E : HMR_WAVE;
+	constexpr int CH = N * N / 4;                      // 4-sample chunks per block
+	constexpr int CPR = N / 4;                         // chunks per row
+	constexpr int G = CH < HMR_WAVE ? CH : HMR_WAVE;
 	constexpr int JPW = HMR_WAVE / G;
 	const int lane = lane_id(), sub = lane / G, l = lane % G;
-	const long wave = (long)blockIdx.x * HMR_WAVES_PER_BLOCK + wave_in_block();
-	const long nwaves = (long)gridDim.x * HMR_WAVES_PER_BLOCK;
-	for (long j0 = wave * JPW; j0 < njobs; j0 += nwaves * JPW) {
+	const JobRange jr = xcd_job_range(njobs, JPW * HMR_WAVES_PER_BLOCK);
+	for (long j0 = jr.begin + wave_in_block() * JPW; j0 < jr.end; j0 += jr.stride) {
 		const long j = j0 + sub;
 		uint32_t acc = 0;
-		if (j < njobs) {
-			const hmr_gpu_job jb = jobs[j];
+		if (j < jr.end) {
+			const hmr_gpu_job jb = JPW == 1 ? load_job_uniform(jobs, j) : jobs[j];
 			const int16_t *a = A + jb.a_off;
 			const int16_t *b = B + jb.b_off;
 #pragma unroll 4
-			for (int e = l; e < E; e += G) {
-				const int y = e / N, x = e % N;
-				const int d = (int16_t)(a[(size_t)y * jb.a_stride + x] - b[(size_t)y * jb.b_stride + x]);
-				acc += OP == OP_SAD ? (uint32_t)(d < 0 ? -d : d) : (uint32_t)(d * d);
+			for (int e = l; e < CH; e += G) {
+				const int y = e / CPR, x = (e % CPR) * 4;
+				const i16x4 va = ld4(a + (size_t)y * jb.a_stride + x), vb = ld4(b + (size_t)y * jb.b_stride + x);
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const int d = (int16_t)(va.v[k] - vb.v[k]);
+					acc += OP == OP_SAD ? (uint32_t)(d < 0 ? -d : d) : (uint32_t)(d * d);
+				}
 			}
 		}
 		acc = group_sum<G>(acc);
-		if (j < njobs && l == 0) out[j] = acc;
+		if (j < jr.end && l == 0) out[j] = acc;
 	}
 }
 
@@ -48,9 +56,8 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_elementwise(const hmr_gpu_job *__
 							      const int16_t *__restrict__ B, int16_t *__restrict__ Cc)
 {
 	const int lane = lane_id();
-	const long wave = (long)blockIdx.x * HMR_WAVES_PER_BLOCK + wave_in_block();
-	const long nwaves = (long)gridDim.x * HMR_WAVES_PER_BLOCK;
-	for (long j = wave; j < njobs; j += nwaves) {
+	const JobRange jr = xcd_job_range(njobs, HMR_WAVES_PER_BLOCK);
+	for (long j = jr.begin + wave_in_block(); j < jr.end; j += jr.stride) {
 		const hmr_gpu_job jb = jobs[j];
 		const int w = size ? size : jb.w, h = size ? size : jb.h;
 		const int16_t *a = A + jb.a_off;
@@ -68,14 +75,48 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_elementwise(const hmr_gpu_job *__
 	}
 }
 
+// Uniform-size N x N variant of the element-wise kernels and of the int16 copy: same 4-samples-per-lane geometry as SAD.
+// OP 3 = plain copy (a -> c).
+template <int N, int OP>
+__global__ __launch_bounds__(HMR_BLOCK) void k_square(const hmr_gpu_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ A,
+							 const int16_t *__restrict__ B, int16_t *__restrict__ Cc)
+{
+	constexpr int CH = N * N / 4, CPR = N / 4;
+	constexpr int G = CH < HMR_WAVE ? CH : HMR_WAVE;
+	constexpr int JPW = HMR_WAVE / G;
+	const int lane = lane_id(), sub = lane / G, l = lane % G;
+	const JobRange jr = xcd_job_range(njobs, JPW * HMR_WAVES_PER_BLOCK);
+	for (long j0 = jr.begin + wave_in_block() * JPW; j0 < jr.end; j0 += jr.stride) {
+		const long j = j0 + sub;
+		if (j >= jr.end) continue;
+		const hmr_gpu_job jb = JPW == 1 ? load_job_uniform(jobs, j) : jobs[j];
+		const int16_t *a = A + jb.a_off;
+		const int16_t *b = B + jb.b_off;
+		int16_t *c = Cc + jb.c_off;
+#pragma unroll 4
+		for (int e = l; e < CH; e += G) {
+			const int y = e / CPR, x = (e % CPR) * 4;
+			const i16x4 va = ld4(a + (size_t)y * jb.a_stride + x);
+			i16x4 r;
+			if (OP == 3) r = va;
+			else {
+				const i16x4 vb = ld4(b + (size_t)y * jb.b_stride + x);
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					r.v[k] = OP == EW_PREDICT ? (int16_t)(va.v[k] - vb.v[k]) : (int16_t)clip3i(sat16i(va.v[k] + vb.v[k]), 0, 255);
+			}
+			st4(c + (size_t)y * jb.c_stride + x, r);
+		}
+	}
+}
+
 template <typename TS, typename TD, int CLAMP>
 __global__ __launch_bounds__(HMR_BLOCK) void k_copy(const hmr_gpu_job *__restrict__ jobs, int njobs, const TS *__restrict__ A, TD *__restrict__ Cc)
 {
 	const int lane = lane_id();
-	const long wave = (long)blockIdx.x * HMR_WAVES_PER_BLOCK + wave_in_block();
-	const long nwaves = (long)gridDim.x * HMR_WAVES_PER_BLOCK;
-	for (long j = wave; j < njobs; j += nwaves) {
-		const hmr_gpu_job jb = jobs[j];
+	const JobRange jr = xcd_job_range(njobs, HMR_WAVES_PER_BLOCK);
+	for (long j = jr.begin + wave_in_block(); j < jr.end; j += jr.stride) {
+		const hmr_gpu_job jb = load_job_uniform(jobs, j);
 		const TS *a = A + jb.a_off;
 		TD *c = Cc + jb.c_off;
 		const int w = jb.w, h = jb.h;
@@ -88,15 +129,31 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_copy(const hmr_gpu_job *__restric
 	}
 }
 
+template <int OP>
+int launch_square(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int n, const int16_t *A, const int16_t *B, int16_t *Cc)
+{
+	const int ch = n * n / 4, g = ch < HMR_WAVE ? ch : HMR_WAVE, jpw = HMR_WAVE / g;
+	dim3 grid(hmr_grid_for_waves(((long)njobs + jpw - 1) / jpw)), block(HMR_BLOCK);
+	switch (n) {
+	case 4: hipLaunchKernelGGL((k_square<4, OP>), grid, block, 0, ctx->stream, jobs, njobs, A, B, Cc); break;
+	case 8: hipLaunchKernelGGL((k_square<8, OP>), grid, block, 0, ctx->stream, jobs, njobs, A, B, Cc); break;
+	case 16: hipLaunchKernelGGL((k_square<16, OP>), grid, block, 0, ctx->stream, jobs, njobs, A, B, Cc); break;
+	case 32: hipLaunchKernelGGL((k_square<32, OP>), grid, block, 0, ctx->stream, jobs, njobs, A, B, Cc); break;
+	case 64: hipLaunchKernelGGL((k_square<64, OP>), grid, block, 0, ctx->stream, jobs, njobs, A, B, Cc); break;
+	default: return HMR_GPU_ERR_ARG;
+	}
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
+
 // hmr_sse42_functions_pixel.c:1123 - statistics over the BYTES the SSE code zero-extends:
 // `size` bytes per row; for size >= 16 bytes [32g, 32g+8) and [32g+16, 32g+24) of each 16-sample group g.
 __global__ __launch_bounds__(HMR_BLOCK) void k_modified_variance(const hmr_gpu_job *__restrict__ jobs, int njobs, int size, const int16_t *__restrict__ A,
 								    uint32_t *__restrict__ out)
 {
 	const int lane = lane_id();
-	const long wave = (long)blockIdx.x * HMR_WAVES_PER_BLOCK + wave_in_block();
-	const long nwaves = (long)gridDim.x * HMR_WAVES_PER_BLOCK;
-	for (long j = wave; j < njobs; j += nwaves) {
+	const JobRange jr = xcd_job_range(njobs, HMR_WAVES_PER_BLOCK);
+	for (long j = jr.begin + wave_in_block(); j < jr.end; j += jr.stride) {
 		const hmr_gpu_job jb = jobs[j];
 		const uint8_t *base = (const uint8_t *)(A + jb.a_off);
 		const int modif = (int)jb.p0, total = size * size;
@@ -127,7 +184,8 @@ int launch_sad_ssd(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int siz
 	if (njobs <= 0) return HMR_GPU_OK;
 	// any size other than 4/8/16/32 takes the 64x64 path in the reference (hmr_sse42_functions_pixel.c:462-475)
 	const int n = (size == 4 || size == 8 || size == 16 || size == 32) ? size : 64;
-	const long waves = n == 4 ? (njobs + 3) / 4 : njobs;
+	const int ch = n * n / 4, jpw = ch < HMR_WAVE ? HMR_WAVE / ch : 1;
+	const long waves = ((long)njobs + jpw - 1) / jpw;
 	dim3 grid(hmr_grid_for_waves(waves)), block(HMR_BLOCK);
 	switch (n) {
 	case 4: hipLaunchKernelGGL((k_sad_ssd<4, OP>), grid, block, 0, ctx->stream, jobs, njobs, A, B, out); break;
@@ -154,6 +212,7 @@ extern "C" int hmr_gpu_predict_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, 
 {
 	if (njobs <= 0) return HMR_GPU_OK;
 	if (size <= 0 || size > 64) return HMR_GPU_ERR_ARG;
+	if (size == 4 || size == 8 || size == 16 || size == 32 || size == 64) return launch_square<EW_PREDICT>(ctx, jobs, njobs, size, a, b, c);
 	hipLaunchKernelGGL((k_elementwise<EW_PREDICT>), dim3(hmr_grid_for_waves(njobs)), dim3(HMR_BLOCK), 0, ctx->stream, jobs, njobs, size, a, b, c);
 	HIP_TRY(hipGetLastError());
 	return HMR_GPU_OK;
@@ -162,6 +221,7 @@ extern "C" int hmr_gpu_reconst_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, 
 {
 	if (njobs <= 0) return HMR_GPU_OK;
 	if (size <= 0 || size > 64) return HMR_GPU_ERR_ARG;
+	if (size == 4 || size == 8 || size == 16 || size == 32 || size == 64) return launch_square<EW_RECONST>(ctx, jobs, njobs, size, a, b, c);
 	hipLaunchKernelGGL((k_elementwise<EW_RECONST>), dim3(hmr_grid_for_waves(njobs)), dim3(HMR_BLOCK), 0, ctx->stream, jobs, njobs, size, a, b, c);
 	HIP_TRY(hipGetLastError());
 	return HMR_GPU_OK;
@@ -176,6 +236,10 @@ extern "C" int hmr_gpu_weighted_average_batch(hmr_gpu_ctx *ctx, const hmr_gpu_jo
 extern "C" int hmr_gpu_copy_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int kind, const void *a, void *c)
 {
 	if (njobs <= 0) return HMR_GPU_OK;
+	// kind bits 8..15: optional hint that every job is the same N x N int16 square (fast path, N in 4/8/16/32/64)
+	const int square = (kind >> 8) & 0xff;
+	kind &= 0xff;
+	if (kind == 0 && square) return launch_square<3>(ctx, jobs, njobs, square, (const int16_t *)a, (const int16_t *)a, (int16_t *)c);
 	dim3 grid(hmr_grid_for_waves(njobs)), block(HMR_BLOCK);
 	if (kind == 0) hipLaunchKernelGGL((k_copy<int16_t, int16_t, 0>), grid, block, 0, ctx->stream, jobs, njobs, (const int16_t *)a, (int16_t *)c);
 	else if (kind == 1) hipLaunchKernelGGL((k_copy<uint8_t, int16_t, 0>), grid, block, 0, ctx->stream, jobs, njobs, (const uint8_t *)a, (int16_t *)c);

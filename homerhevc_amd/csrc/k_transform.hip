@@ -41,9 +41,10 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_transform(const hmr_gpu_job *__re
 	load_basis<N>(sM, tab);
 	__syncthreads();
 	constexpr int sh1 = g::L2 - 1, sh2 = g::L2 + 6;
-	for (long base = (long)blockIdx.x * g::JPB; base < njobs; base += (long)gridDim.x * g::JPB) {
+	const JobRange jr = xcd_job_range(njobs, g::JPB);
+	for (long base = jr.begin; base < jr.end; base += jr.stride) {
 		const long j = base + w * g::JPW + sub;
-		const bool ok = j < njobs;
+		const bool ok = j < jr.end;
 		hmr_gpu_job jb;
 		if (ok) {
 			jb = jobs[j];
@@ -91,9 +92,10 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_itransform(const hmr_gpu_job *__r
 	const int lane = lane_id(), w = wave_in_block(), sub = lane / g::G, l = lane % g::G;
 	load_basis<N>(sM, tab);
 	__syncthreads();
-	for (long base = (long)blockIdx.x * g::JPB; base < njobs; base += (long)gridDim.x * g::JPB) {
+	const JobRange jr = xcd_job_range(njobs, g::JPB);
+	for (long base = jr.begin; base < jr.end; base += jr.stride) {
 		const long j = base + w * g::JPW + sub;
-		const bool ok = j < njobs;
+		const bool ok = j < jr.end;
 		hmr_gpu_job jb;
 		if (ok) {
 			jb = jobs[j];
@@ -127,36 +129,44 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_itransform(const hmr_gpu_job *__r
 	}
 }
 
-// One lane runs the reference's per-coefficient-group sign-hiding decision (hmr_quant.c:61-169) for one
-// group of 16 scan positions; groups are independent once it is known which is the last one holding a level.
-__device__ void sbh_group(int16_t *dst, const int16_t *src, const int16_t *du, const uint32_t *scan, int sub_pos, bool is_last_cg)
+// Sign-data hiding (hmr_quant.c:61-169) with 16 lanes per coefficient group: lane n owns scan position n of the group.
+// The serial "walk n downwards, keep the strictly smallest cost" becomes a min-reduction over the key (cost, 15 - n);
+// the only cross-group dependency - which group is the last one holding a level - is resolved beforehand.
+// Must be called by all 64 lanes (it shuffles); `active` predicates the update.
+__device__ __forceinline__ void sbh_group16(int16_t *dst, const int16_t *src, const int16_t *du, const uint32_t *scan, int cg, bool is_last_cg, bool active)
 {
-	int first_nz = 16, last_nz = -1, abs_sum = 0;
-	for (int n = 15; n >= 0; --n)
-		if (dst[scan[n + sub_pos]]) { last_nz = n; break; }
-	for (int n = 0; n < 16; n++)
-		if (dst[scan[n + sub_pos]]) { first_nz = n; break; }
-	for (int n = first_nz; n <= last_nz; n++) abs_sum += dst[scan[n + sub_pos]];
-	if (last_nz - first_nz < 4) return;
-	const unsigned signbit = dst[scan[sub_pos + first_nz]] > 0 ? 0u : 1u;
-	if (signbit == (unsigned)(abs_sum & 1)) return;
-	int min_cost = 0x7fffffff, min_pos = -1, final_change = 0, cur_cost = 0x7fffffff, cur_change = 0;
-	for (int n = is_last_cg ? last_nz : 15; n >= 0; --n) {
-		const unsigned pos = scan[n + sub_pos];
-		const int lv = dst[pos], d = du[pos];
+	const int lane = lane_id(), n = lane & 15, gbase = lane & 48;
+	const unsigned pos = scan[cg * 16 + n];
+	const int lv = active ? dst[pos] : 0, d = active ? du[pos] : 0, sv = active ? src[pos] : 0;
+	const unsigned mask = (unsigned)((__ballot(lv != 0) >> gbase) & 0xffffu);
+	const int last_nz = mask ? 31 - __clz((int)mask) : -1, first_nz = mask ? __ffs((int)mask) - 1 : 16;
+	const int abs_sum = group_sum<16>(lv);
+	const int first_val = __shfl(lv, gbase + (first_nz & 15), HMR_WAVE);
+	const unsigned signbit = first_val > 0 ? 0u : 1u;
+	const bool hide = active && (last_nz - first_nz >= 4) && (signbit != (unsigned)(abs_sum & 1));
+	const int start = is_last_cg ? last_nz : 15;
+	int cost = 0x7fffffff, change = 0;
+	if (n <= start) {
 		if (lv != 0) {
-			if (d > 0) { cur_cost = -d; cur_change = 1; }
-			else if (n == first_nz && (lv == 1 || lv == -1)) cur_cost = 0x7fffffff;
-			else { cur_cost = d; cur_change = -1; }
+			if (d > 0) { cost = -d; change = 1; }
+			else if (!(n == first_nz && (lv == 1 || lv == -1))) { cost = d; change = -1; }
 		} else if (n < first_nz) {
-			const unsigned this_sign = src[pos] >= 0 ? 0u : 1u;
-			if (this_sign != signbit) cur_cost = 0x7fffffff;
-			else { cur_cost = -d; cur_change = 1; }
-		} else { cur_cost = -d; cur_change = 1; }
-		if (cur_cost < min_cost) { min_cost = cur_cost; final_change = cur_change; min_pos = (int)pos; }
+			if ((sv >= 0 ? 0u : 1u) == signbit) { cost = -d; change = 1; }
+		} else { cost = -d; change = 1; }
 	}
-	if (dst[min_pos] == 32767 || dst[min_pos] == -32768) final_change = -1;
-	dst[min_pos] = (int16_t)(src[min_pos] >= 0 ? dst[min_pos] + final_change : dst[min_pos] - final_change);
+	// smallest cost wins, ties go to the larger n (the reference meets it first)
+	unsigned long long key = ((unsigned long long)(unsigned)(cost ^ 0x80000000) << 8) | (unsigned)(15 - n);
+#pragma unroll
+	for (int m = 8; m >= 1; m >>= 1) {
+		const unsigned lo = __shfl_xor((unsigned)key, m, HMR_WAVE), hi = __shfl_xor((unsigned)(key >> 32), m, HMR_WAVE);
+		const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+		key = other < key ? other : key;
+	}
+	const int win_n = 15 - (int)(key & 0xff);
+	if (hide && n == win_n && cost != 0x7fffffff) {
+		if (lv == 32767 || lv == -32768) change = -1;
+		dst[pos] = (int16_t)(sv >= 0 ? lv + change : lv - change);
+	}
 }
 
 template <int N>
@@ -170,14 +180,15 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_quant(const hmr_gpu_job *__restri
 	__shared__ int16_t sDu[HMR_WAVES_PER_BLOCK][g::JPW][g::E];
 	__shared__ int sLastCg[HMR_WAVES_PER_BLOCK][g::JPW];
 	const int lane = lane_id(), w = wave_in_block(), sub = lane / g::G, l = lane % g::G;
-	constexpr int NCG = g::E / 16;
-	for (long base = (long)blockIdx.x * g::JPB; base < njobs; base += (long)gridDim.x * g::JPB) {
+	constexpr int NCG = g::E / 16, CG_PER_IT = g::G / 16, ITERS = NCG / CG_PER_IT;
+	const JobRange jr = xcd_job_range(njobs, g::JPB);
+	for (long base = jr.begin; base < jr.end; base += jr.stride) {
 		const long j = base + w * g::JPW + sub;
-		const bool ok = j < njobs;
-		hmr_gpu_job jb;
+		const bool ok = j < jr.end;
+		hmr_gpu_job jb = {};
 		int ac = 0;
 		bool sbh = false;
-		const uint32_t *scan = nullptr;
+		const uint32_t *scan = tab->scan[3][g::L2];
 		if (ok) {
 			jb = jobs[j];
 			const int scan_mode = jb.p0 & 3, comp = (jb.p0 >> 2) & 3, is_intra = (jb.p0 >> 4) & 1, slice_i = (jb.p0 >> 5) & 1;
@@ -203,21 +214,23 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_quant(const hmr_gpu_job *__restri
 				sDu[w][sub][e] = (int16_t)sat16i(d);
 			}
 			ac = (int)group_sum<g::G>(sum);
-		} else {
-			(void)group_sum<g::G>(0u);
 		}
 		__syncthreads();
 		const bool run_sbh = ok && sbh && ac >= 2;
-		if (run_sbh)
-			for (int cg = l; cg < NCG; cg += g::G) {
-				bool nz = false;
-				for (int n = 0; n < 16; n++) nz |= sDst[w][sub][scan[cg * 16 + n]] != 0;
-				if (nz) atomicMax(&sLastCg[w][sub], cg);
-			}
+		// which coefficient group is the last one (in scan order) that holds a level
+		for (int it = 0; it < ITERS; it++) {
+			const int cg = it * CG_PER_IT + (l >> 4);
+			const bool nz = run_sbh && sDst[w][sub][scan[cg * 16 + (l & 15)]] != 0;
+			const unsigned long long m = __ballot(nz);
+			if (run_sbh && (l & 15) == 0 && ((m >> (lane & 48)) & 0xffffull)) atomicMax(&sLastCg[w][sub], cg);
+		}
 		__syncthreads();
-		if (run_sbh) {
-			const int last = sLastCg[w][sub];
-			for (int cg = l; cg < NCG; cg += g::G) sbh_group(sDst[w][sub], sSrc[w][sub], sDu[w][sub], scan, cg * 16, cg == last);
+		{
+			const int last = ok ? sLastCg[w][sub] : -1;
+			for (int it = 0; it < ITERS; it++) {
+				const int cg = it * CG_PER_IT + (l >> 4);
+				sbh_group16(sDst[w][sub], sSrc[w][sub], sDu[w][sub], scan, cg, cg == last, run_sbh);
+			}
 		}
 		__syncthreads();
 		if (ok) {
@@ -237,11 +250,10 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_inv_quant(const hmr_gpu_job *__re
 							    int16_t *__restrict__ Cc, const DevTables *__restrict__ tab)
 {
 	const int lane = lane_id();
-	const long wave = (long)blockIdx.x * HMR_WAVES_PER_BLOCK + wave_in_block();
-	const long nwaves = (long)gridDim.x * HMR_WAVES_PER_BLOCK;
+	const JobRange jr = xcd_job_range(njobs, HMR_WAVES_PER_BLOCK);
 	const int l2 = size == 4 ? 2 : size == 8 ? 3 : size == 16 ? 4 : 5;
 	const int iq_shift = 3 + l2;   // 20 - 14 - (15 - 8 - log2N) + 4
-	for (long j = wave; j < njobs; j += nwaves) {
+	for (long j = jr.begin + wave_in_block(); j < jr.end; j += jr.stride) {
 		const hmr_gpu_job jb = jobs[j];
 		const int comp = (jb.p0 >> 2) & 3, is_intra = (jb.p0 >> 4) & 1;
 		const int per = jb.p1 & 0xff, rem = (jb.p1 >> 8) & 0xff;
@@ -259,7 +271,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_inv_quant(const hmr_gpu_job *__re
 	}
 }
 
-template <int N> int grid_for(int njobs) { long it = ((long)njobs + Geo<N>::JPB - 1) / Geo<N>::JPB; return (int)(it < 1 ? 1 : (it > HMR_MAX_GRID ? HMR_MAX_GRID : it)); }
+template <int N> int grid_for(int njobs) { return hmr_grid_for_units(((long)njobs + Geo<N>::JPB - 1) / Geo<N>::JPB); }
 
 }  // namespace
 

@@ -131,7 +131,8 @@ int hmr_gpu_ssd16b_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, i
 int hmr_gpu_predict_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, const int16_t *b_base, int16_t *c_base);
 /* c = clip(a (pred) + b (residual, stride may be 0)) */
 int hmr_gpu_reconst_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, const int16_t *b_base, int16_t *c_base);
-/* c[h x w] = a[h x w]; kind 0: i16->i16, 1: u8->i16, 2: i16->u8 (offsets/strides in elements of each side's type) */
+/* c[h x w] = a[h x w]; kind 0: i16->i16, 1: u8->i16, 2: i16->u8 (offsets/strides in elements of each side's type).
+ * kind | N << 8 promises that every job is an N x N int16 square (N = 4, 8, 16, 32, 64): vectorised fast path. */
 int hmr_gpu_copy_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int kind, const void *a_base, void *c_base);
 /* out[i] = modified variance of the size x size block at a; p0 = modif */
 int hmr_gpu_modified_variance_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, uint32_t *out);
@@ -140,8 +141,10 @@ int hmr_gpu_intra_pred_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njob
 /* a = reconstructed plane, a_off addresses the corner sample (-1,-1), c = adi out (4*size+1), b_off = filtered adi out;
  * p0 bits: 0 left, 1 top, 2 bottom_left, 3 top_right, 4 write filtered copy, 5 strong filter enabled; p1 = bl_size | tr_size << 16 */
 int hmr_gpu_intra_refs_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, int16_t *c_base);
-/* a = reference/intermediate, c = out, w/h = extent; p0 = fraction, p1 bits: 0 vertical, 1 first, 2 last; is_luma picks taps */
-int hmr_gpu_interpolate_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int is_luma, const int16_t *a_base, int16_t *c_base);
+/* a = reference/intermediate, c = out, w/h = extent; p0 = fraction, p1 bits: 0 vertical, 1 first, 2 last.
+ * flags bit 0: luma (8 taps) / chroma (4 taps); bits 8..15: lanes-per-job hint 16 / 32 / 64 (0 = 64) - a job of
+ * ceil(w/4)*h four-sample chunks is walked by that many lanes, so batches of small blocks should pass 16 or 32. */
+int hmr_gpu_interpolate_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int flags, const int16_t *a_base, int16_t *c_base);
 int hmr_gpu_weighted_average_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, const int16_t *a_base, const int16_t *b_base, int16_t *c_base);
 /* a = residual block (strided), c = coefficients (linear size*size at c_off); p0 = is_dst */
 int hmr_gpu_transform_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, int16_t *c_base);
