@@ -384,4 +384,62 @@ void hmr_gpu_inv_quant(int16_t *src, int16_t *dst, int depth, int comp, int is_i
 	memcpy(dst, st.host<int16_t>(o), (size_t)n * n * 2);
 }
 
+uint32_t hmr_gpu_motion_estimation(int16_t *orig, int orig_stride, int16_t *ref, int ref_stride, int gx, int gy, int init_x, int init_y, int size, int range_x,
+				   int range_y, int frame_w, int frame_h, const int32_t *amvp, int n_amvp, const int32_t *search, int n_search, double corr,
+				   int action, int32_t *out_mv4)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	// the search window the kernel can touch: integer candidates inside [low, high], sub-pel taps 4 further
+	const int xlow = (gx - range_x) < 0 ? -gx : -range_x, xhigh = (gx + range_x) > (frame_w - size) ? frame_w - gx - size : range_x;
+	const int ylow = (gy - range_y) < 0 ? -gy : -range_y, yhigh = (gy + range_y) > (frame_h - size) ? frame_h - gy - size : range_y;
+	const int x0 = xlow - 5, y0 = ylow - 5, ww = xhigh - xlow + size + 10, wh = yhigh - ylow + size + 10;
+	hmr_gpu_me_job jb = {};
+	jb.corr = corr;
+	jb.orig_off = (uint32_t)(st.put2d(orig, orig_stride, size, size, 2) / 2); jb.orig_stride = size;
+	const size_t woff = st.put2d(ref + (ptrdiff_t)y0 * ref_stride + x0, ref_stride, wh, ww, 2);
+	jb.ref_off = (uint32_t)(woff / 2 + (size_t)(-y0) * ww + (-x0)); jb.ref_stride = ww;
+	jb.gx = (int16_t)gx; jb.gy = (int16_t)gy; jb.init_x = (int16_t)init_x; jb.init_y = (int16_t)init_y;
+	jb.n_amvp = (int16_t)n_amvp; jb.n_search = (int16_t)n_search;
+	for (int i = 0; i < n_amvp && i < 2; i++) { jb.amvp[i][0] = (int16_t)amvp[2 * i]; jb.amvp[i][1] = (int16_t)amvp[2 * i + 1]; }
+	for (int i = 0; i < n_search && i < 5; i++) { jb.search[i][0] = (int16_t)search[2 * i]; jb.search[i][1] = (int16_t)search[2 * i + 1]; }
+	jb.action = (uint32_t)action;
+	const size_t joff = st.zeros(sizeof jb);
+	memcpy(st.host<uint8_t>(joff), &jb, sizeof jb);
+	st.begin_outputs();
+	const size_t o = st.out(sizeof(hmr_gpu_me_result));
+	st.upload();
+	must(hmr_gpu_motion_estimation_batch(c, st.dev<hmr_gpu_me_job>(joff), 1, size, st.dev<int16_t>(), st.dev<int16_t>(), range_x, range_y, frame_w, frame_h,
+					     st.dev<hmr_gpu_me_result>(o)),
+	     "motion_estimation");
+	st.finish();
+	const hmr_gpu_me_result *r = st.host<hmr_gpu_me_result>(o);
+	out_mv4[0] = r->mvx; out_mv4[1] = r->mvy; out_mv4[2] = r->subx; out_mv4[3] = r->suby;
+	return r->sad;
+}
+
+static void mc_any(int is_luma, int16_t *ref, int ref_stride, int16_t *pred, int pred_stride, int w, int h, int mvx, int mvy, int is_bi)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	hmr_gpu_job jb = {};
+	const int fs = is_luma ? 2 : 3, m = is_luma ? 4 : 2;   // taps reach m-1 before / m after the block
+	const int ix = mvx >> fs, iy = mvy >> fs;
+	const int tw = w + 2 * m, th = h + 2 * m;
+	const size_t off = st.put2d(ref + (ptrdiff_t)(iy - m) * ref_stride + ix - m, ref_stride, th, tw, 2);
+	// the staged tile already starts at the integer vector: pass only the fractional part on
+	jb.a_off = (uint32_t)(off / 2 + (size_t)m * tw + m); jb.a_stride = tw;
+	jb.w = (uint16_t)w; jb.h = (uint16_t)h; jb.p0 = (uint32_t)(mvx & (is_luma ? 3 : 7)); jb.p1 = (uint32_t)(mvy & (is_luma ? 3 : 7));
+	st.begin_outputs();
+	const size_t o = st.out((size_t)w * h * 2);
+	jb.c_off = (uint32_t)(o / 2); jb.c_stride = w;
+	*st.job() = jb;
+	st.upload();
+	must(hmr_gpu_mc_batch(c, st.djob(), 1, is_luma, is_bi, st.dev<int16_t>(), st.dev<int16_t>()), "mc");
+	st.finish();
+	st.get2d(o, pred, pred_stride, h, w, 2);
+}
+void hmr_gpu_mc_luma(int16_t *ref, int rs, int16_t *pred, int ps, int w, int h, int mvx, int mvy, int bi) { mc_any(1, ref, rs, pred, ps, w, h, mvx, mvy, bi); }
+void hmr_gpu_mc_chroma(int16_t *ref, int rs, int16_t *pred, int ps, int size, int mvx, int mvy, int bi) { mc_any(0, ref, rs, pred, ps, size, size, mvx, mvy, bi); }
+
 }  // extern "C"

@@ -1,0 +1,353 @@
+// Motion search driver and motion compensation.
+// Reference semantics: hmr_motion_estimation hmr_motion_inter.c:1404-1775 (integer diamond search with AMVP-relative
+// vector cost, 9-point half- and 9-point quarter-sample refinement on SAD), the sub-pel plane recipes
+// hmr_half/quarter_pixel_estimation_luma_hm :395,442, and hmr_motion_compensation_luma/chroma :1779,1860.
+//
+// One wave runs the whole search of one PU: the source block is staged in LDS once, every candidate SAD is a
+// wave-wide reduction, and the search state (best vector, restart arc, ring radius) is wave-uniform scalar code, so the
+// strict-'<' tie-breaking order of the reference is reproduced exactly.  The reference materialises 16 sub-pel planes
+// per PU in memory (18 interpolation calls); here the horizontal first stage of the (at most three) candidate
+// columns is kept in LDS tiles and each candidate's vertical stage feeds the SAD directly - the planes never exist
+// in HBM.  The vector cost is the reference's double arithmetic with the host-supplied factor
+// calc_mv_correction(qp, avg_dist) (hmr_common.h:53); the build uses -ffp-contract=off so no FMA is formed.
+#include "common.h"
+#include "vec.h"
+
+namespace {
+
+// order LDS traffic between the lanes of one wave (the compiler sees only per-lane dependences)
+__device__ __forceinline__ void wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__constant__ int16_t cLumaTaps[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}};
+__constant__ int16_t cChromaTaps[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4},
+					  {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
+__constant__ int cDs[4][2] = {{-1, 0}, {0, -1}, {1, 0}, {0, 1}};
+__constant__ int cDb[8][2] = {{-2, 0}, {-1, -1}, {0, -2}, {1, -1}, {2, 0}, {1, 1}, {0, 2}, {-1, 1}};
+__constant__ int cRefH[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
+__constant__ int cRefQ[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
+
+template <int N> struct MeGeo {
+	static constexpr int WPB = N == 64 ? 1 : 4;          // waves per workgroup (LDS budget: 36 KB per wave at N = 64)
+	static constexpr int TR = N + 8;                     // tile rows: reference rows best_y-4 .. best_y+N+3
+};
+
+// wave-uniform vector cost (select_mv_candidate_fast, hmr_motion_inter.c:1004)
+__device__ __forceinline__ uint32_t mv_cost(const hmr_gpu_me_job &jb, int mvx, int mvy)
+{
+	uint32_t best = 0x7fffffffu;
+	for (int i = 0; i < jb.n_amvp; i++) {
+		const int dx = jb.amvp[i][0] - mvx, dy = jb.amvp[i][1] - mvy;
+		const double cx = jb.corr * (double)(float)(dx < 0 ? -dx : dx), cy = jb.corr * (double)(float)(dy < 0 ? -dy : dy);
+		const uint32_t c = (uint32_t)(cx + cy + .5);
+		if (best > c) best = c;
+	}
+	return best;
+}
+
+template <int N>
+__global__ __launch_bounds__(MeGeo<N>::WPB * 64) void k_motion_estimation(const hmr_gpu_me_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ O,
+									     const int16_t *__restrict__ R, int range_x, int range_y, int frame_w, int frame_h,
+									     hmr_gpu_me_result *__restrict__ out)
+{
+	using g = MeGeo<N>;
+	constexpr int CH = N * N / 4, CPR = N / 4;
+	__shared__ int16_t sOrig[g::WPB][N * N];
+	__shared__ int16_t sTile[g::WPB][3][g::TR * N];
+	const int lane = lane_id(), w = threadIdx.x >> 6;
+	int16_t *orig = sOrig[w];
+	const JobRange jr = xcd_job_range(njobs, g::WPB);
+	for (long base = jr.begin; base < jr.end; base += jr.stride) {
+		const long j = base + w;
+		if (j >= jr.end) continue;       // whole wave leaves together; no block-level barrier is used below
+		const hmr_gpu_me_job jb = jobs[j];
+		const int16_t *ref = R + jb.ref_off;
+		const int rs = (int)jb.ref_stride;
+		{
+			const int16_t *o = O + jb.orig_off;
+			for (int e = lane; e < CH; e += 64) {
+				const int y = e / CPR, x = (e % CPR) * 4;
+				st4(orig + y * N + x, ld4(o + (size_t)y * jb.orig_stride + x));
+			}
+		}
+		wave_sync();
+		const int gx = jb.gx, gy = jb.gy;
+		const int xlow = (gx - range_x) < 0 ? -gx : -range_x, xhigh = (gx + range_x) > (frame_w - N) ? frame_w - gx - N : range_x;
+		const int ylow = (gy - range_y) < 0 ? -gy : -range_y, yhigh = (gy + range_y) > (frame_h - N) ? frame_h - gy - N : range_y;
+
+		auto sad_at = [&](int x, int y) -> uint32_t {
+			const int16_t *p = ref + (ptrdiff_t)y * rs + x;
+			uint32_t acc = 0;
+#pragma unroll 4
+			for (int e = lane; e < CH; e += 64) {
+				const int yy = e / CPR, xx = (e % CPR) * 4;
+				const i16x4 a = ld4(orig + yy * N + xx), b = ld4(p + (size_t)yy * rs + xx);
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const int d = a.v[k] - b.v[k];
+					acc += (uint32_t)(d < 0 ? -d : d);
+				}
+			}
+			return wave_sum(acc);
+		};
+
+		uint32_t cur_sad = 0, cur_rd = 0;
+		int cur_x = 0, cur_y = 0, best_x = 0, best_y = 0, mvx, mvy, subx = 0, suby = 0;
+		const unsigned action = jb.action;
+		if (action & 1) {
+			int next_start, search_size;
+			bool better;
+#define TRY(x_, y_)                                                                                          \
+	better = false;                                                                                      \
+	if ((x_) >= xlow && (x_) <= xhigh && (y_) >= ylow && (y_) <= yhigh) {                                \
+		const uint32_t s_ = sad_at((x_), (y_));                                                      \
+		const uint32_t rd_ = s_ + mv_cost(jb, (x_) << 2, (y_) << 2);                                 \
+		if (rd_ < cur_rd) { cur_sad = s_; cur_rd = rd_; cur_x = (x_); cur_y = (y_); better = true; } \
+	}
+			cur_x = clip3i(jb.init_x, xlow, xhigh);
+			cur_y = clip3i(jb.init_y, ylow, yhigh);
+			cur_sad = sad_at(cur_x, cur_y);
+			cur_rd = cur_sad + mv_cost(jb, cur_x << 2, cur_y << 2);
+			uint32_t best_sad = cur_sad;
+			best_x = cur_x; best_y = cur_y;
+			bool skip = best_sad == 0;
+			if (!skip) {
+				for (int i = 0; i < jb.n_search; i++) {
+					const int x = jb.search[i][0] >> 2, y = jb.search[i][1] >> 2;
+					if (x == 0 && y == 0) continue;
+					TRY(x, y)
+				}
+				best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
+				skip = best_sad == 0;
+			}
+			if (!skip) {
+				for (int i = 0; i < 4; i++) {
+					const int x = best_x + cDs[i][0], y = best_y + cDs[i][1];
+					TRY(x, y)
+				}
+				skip = best_sad == 0;   // (best_sad is not refreshed after the small diamond, as in the reference)
+			}
+			if (!skip) {
+				int dist = 2;
+				const int end = (best_x != 0 && best_y != 0) ? 4 : 8;
+				next_start = 0; search_size = 8;
+				best_x = cur_x; best_y = cur_y;
+				while (dist < end) {
+					for (int i = next_start; i < next_start + search_size; i++) {
+						const int idx = i % 8, x = best_x + cDb[idx][0] * dist, y = best_y + cDb[idx][1] * dist;
+						TRY(x, y)
+						if (better) { next_start = (idx - 2 + 8) % 8; search_size = 5; }
+					}
+					dist *= 2;
+				}
+			}
+			best_x = cur_x; best_y = cur_y;
+			next_start = 0; search_size = 4;
+			for (;;) {
+				for (int i = next_start; i < next_start + search_size; i++) {
+					const int idx = i % 4, x = best_x + cDs[idx][0], y = best_y + cDs[idx][1];
+					TRY(x, y)
+					if (better) { next_start = (idx - 1 + 4) % 4; search_size = 3; }
+				}
+				if (best_x == cur_x && best_y == cur_y) break;
+				best_x = cur_x; best_y = cur_y;
+			}
+#undef TRY
+			mvx = best_x << 2; mvy = best_y << 2;
+		} else {
+			mvx = jb.init_x << 2; mvy = jb.init_y << 2;
+		}
+		uint32_t best_sad = cur_sad;
+		if (action & 2) {
+			best_x = mvx >> 2; best_y = mvy >> 2;
+			if (!(action & 1)) cur_sad = sad_at(best_x, best_y);
+			// first-stage tile t holds column offset cxs[t] (quarter samples): rows best_y-4 .. best_y+N+3
+			auto build_tiles = [&](int cx0, int cx1, int cx2) {
+				const int cxs[3] = {cx0, cx1, cx2};
+				for (int t = 0; t < 3; t++) {
+					const int qx = (best_x << 2) + cxs[t], ix = qx >> 2, fx = qx & 3;
+					const int16_t *p0 = ref + (ptrdiff_t)(best_y - 4) * rs + ix - 3;
+					int c[8];
+#pragma unroll
+					for (int k = 0; k < 8; k++) c[k] = cLumaTaps[fx][k];
+					for (int e = lane; e < g::TR * CPR; e += 64) {
+						const int r = e / CPR, x = (e % CPR) * 4;
+						const int16_t *p = p0 + (size_t)r * rs + x;
+						int in[11];
+						const i16x4 v0 = ld4(p), v1 = ld4(p + 4);
+#pragma unroll
+						for (int k = 0; k < 4; k++) { in[k] = v0.v[k]; in[4 + k] = v1.v[k]; }
+						in[8] = p[8]; in[9] = p[9]; in[10] = p[10];
+						i16x4 o;
+#pragma unroll
+						for (int k = 0; k < 4; k++) {
+							int s = 0;
+#pragma unroll
+							for (int tp = 0; tp < 8; tp++) s += in[k + tp] * c[tp];
+							o.v[k] = (int16_t)(s - 8192);   // first, not last: shift 0, offset -8192 (for fx = 0: 64*x - 8192)
+						}
+						st4(&sTile[w][t][r * N + x], o);
+					}
+				}
+				wave_sync();
+			};
+			// SAD of candidate (tile t, vertical quarter offset cy)
+			auto sad_sub = [&](int t, int cy) -> uint32_t {
+				const int qy = (best_y << 2) + cy, iy = (qy >> 2) - best_y, fy = qy & 3;   // iy in {-1, 0}
+				int c[8];
+#pragma unroll
+				for (int k = 0; k < 8; k++) c[k] = cLumaTaps[fy][k];
+				const int16_t *tile = &sTile[w][t][(4 + iy - 3) * N];
+				uint32_t acc = 0;
+				for (int e = lane; e < CH; e += 64) {
+					const int y = e / CPR, x = (e % CPR) * 4;
+					int s[4] = {0, 0, 0, 0};
+#pragma unroll
+					for (int tp = 0; tp < 8; tp++) {
+						const i16x4 r = ld4(tile + (y + tp) * N + x);
+#pragma unroll
+						for (int k = 0; k < 4; k++) s[k] += r.v[k] * c[tp];
+					}
+					const i16x4 a = ld4(orig + y * N + x);
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						const int pv = clip3i(sat16i((s[k] + 2048 + (8192 << 6)) >> 12), 0, 255);   // not first, last
+						const int d = a.v[k] - pv;
+						acc += (uint32_t)(d < 0 ? -d : d);
+					}
+				}
+				return wave_sum(acc);
+			};
+			int bidx = 0, bx = 0, by = 0;
+			build_tiles(-2, 0, 2);
+			for (int i = 0; i < 9; i++) {
+				const int cx = cRefH[i][0] * 2, cy = cRefH[i][1] * 2;
+				const uint32_t s = sad_sub(cRefH[i][0] + 1, cy);
+				if (s < cur_sad) { cur_sad = s; bx = cx; by = cy; bidx = i; }
+			}
+			mvx = (best_x << 2) + bx; mvy = (best_y << 2) + by; subx = bx; suby = by;
+			best_sad = cur_sad;
+			if (action & 4) {
+				const int hx = cRefH[bidx][0], hy = cRefH[bidx][1];
+				wave_sync();
+				build_tiles(hx * 2 - 1, hx * 2, hx * 2 + 1);
+				bx = hx * 2; by = hy * 2;
+				for (int i = 0; i < 9; i++) {
+					const int cx = hx * 2 + cRefQ[i][0], cy = hy * 2 + cRefQ[i][1];
+					const uint32_t s = sad_sub(cRefQ[i][0] + 1, cy);
+					if (s < cur_sad) { cur_sad = s; bx = cx; by = cy; }
+				}
+				best_sad = cur_sad;
+				mvx = (best_x << 2) + bx; mvy = (best_y << 2) + by; subx = bx; suby = by;
+			}
+		} else {
+			best_sad = cur_sad;
+		}
+		if (lane == 0) {
+			hmr_gpu_me_result r;
+			r.mvx = mvx; r.mvy = mvy; r.subx = subx; r.suby = suby; r.sad = best_sad;
+			out[j] = r;
+		}
+		wave_sync();
+	}
+}
+
+// Motion compensation: p0 = mv.x, p1 = mv.y (quarter samples for luma, eighth samples for chroma), w/h extent,
+// a = co-located block in the reference, c = prediction.  Two-stage vectors keep the first stage in an LDS tile.
+template <int TAPS>
+__global__ __launch_bounds__(HMR_BLOCK) void k_mc(const hmr_gpu_job *__restrict__ jobs, int njobs, int is_bi, const int16_t *__restrict__ A, int16_t *__restrict__ Cc)
+{
+	constexpr int FM = TAPS == 8 ? 3 : 7, FS = TAPS == 8 ? 2 : 3, MAXW = TAPS == 8 ? 64 : 32;
+	__shared__ int16_t sTile[HMR_WAVES_PER_BLOCK][(MAXW + TAPS - 1) * MAXW];
+	const int lane = lane_id(), w = wave_in_block();
+	const bool last = !is_bi;
+	const JobRange jr = xcd_job_range(njobs, HMR_WAVES_PER_BLOCK);
+	for (long j = jr.begin + w; j < jr.end; j += jr.stride) {
+		const hmr_gpu_job jb = load_job_uniform(jobs, j);
+		const int bw = jb.w, bh = jb.h, mvx = (int)jb.p0, mvy = (int)jb.p1;
+		const int xf = mvx & FM, yf = mvy & FM, rs = (int)jb.a_stride, ds = (int)jb.c_stride;
+		const int16_t *src = A + jb.a_off + (ptrdiff_t)(mvy >> FS) * rs + (mvx >> FS);
+		int16_t *dst = Cc + jb.c_off;
+		int cx[TAPS], cy[TAPS];
+#pragma unroll
+		for (int k = 0; k < TAPS; k++) {
+			cx[k] = TAPS == 8 ? cLumaTaps[xf][k] : cChromaTaps[xf][k];
+			cy[k] = TAPS == 8 ? cLumaTaps[yf][k] : cChromaTaps[yf][k];
+		}
+		if (xf == 0 || yf == 0) {
+			// one stage, first: (sum + 32) >> 6 clipped when last, sum - 8192 when feeding a bi-prediction average
+			const bool vert = xf == 0;
+			const int step = vert ? rs : 1, f = vert ? yf : xf;
+			const int16_t *s0 = src - (TAPS / 2 - 1) * step;
+			if (TAPS == 4 && f == 0 && bw < 4) continue;   // hmr_sse42_functions_inter_prediction.c:822
+			for (int e = lane; e < bw * bh; e += 64) {
+				const int y = e / bw, x = e - y * bw;
+				int v;
+				if (f == 0) {
+					const int p = src[(size_t)y * rs + x];
+					v = last ? p : (int16_t)((int16_t)(p << 6) - 8192);
+				} else {
+					int s = 0;
+#pragma unroll
+					for (int k = 0; k < TAPS; k++) s += s0[(size_t)y * rs + x + k * step] * (vert ? cy[k] : cx[k]);
+					v = last ? clip3i(sat16i((s + 32) >> 6), 0, 255) : sat16i(s - 8192);
+				}
+				dst[(size_t)y * ds + x] = (int16_t)v;
+			}
+			continue;
+		}
+		const int th = bh + TAPS - 1;
+		for (int e = lane; e < bw * th; e += 64) {
+			const int y = e / bw, x = e - y * bw;
+			const int16_t *p = src + (ptrdiff_t)(y - (TAPS / 2 - 1)) * rs + x - (TAPS / 2 - 1);
+			int s = 0;
+#pragma unroll
+			for (int k = 0; k < TAPS; k++) s += p[k] * cx[k];
+			sTile[w][y * bw + x] = (int16_t)sat16i(s - 8192);
+		}
+		wave_sync();
+		for (int e = lane; e < bw * bh; e += 64) {
+			const int y = e / bw, x = e - y * bw;
+			int s = 0;
+#pragma unroll
+			for (int k = 0; k < TAPS; k++) s += sTile[w][(y + k) * bw + x] * cy[k];
+			const int v = last ? clip3i(sat16i((s + 2048 + (8192 << 6)) >> 12), 0, 255) : sat16i(s >> 6);
+			dst[(size_t)y * ds + x] = (int16_t)v;
+		}
+		wave_sync();
+	}
+}
+
+}  // namespace
+
+extern "C" int hmr_gpu_motion_estimation_batch(hmr_gpu_ctx *ctx, const hmr_gpu_me_job *jobs, int njobs, int size, const int16_t *orig_base,
+						const int16_t *ref_base, int range_x, int range_y, int frame_w, int frame_h, hmr_gpu_me_result *out)
+{
+	if (njobs <= 0) return HMR_GPU_OK;
+#define ME_LAUNCH(N)                                                                                                                       \
+	hipLaunchKernelGGL((k_motion_estimation<N>), dim3(hmr_grid_for_units(((long)njobs + MeGeo<N>::WPB - 1) / MeGeo<N>::WPB)), dim3(MeGeo<N>::WPB * 64), 0, \
+			   ctx->stream, jobs, njobs, orig_base, ref_base, range_x, range_y, frame_w, frame_h, out)
+	switch (size) {
+	case 8: ME_LAUNCH(8); break;
+	case 16: ME_LAUNCH(16); break;
+	case 32: ME_LAUNCH(32); break;
+	case 64: ME_LAUNCH(64); break;
+	default: hmr_set_error("motion_estimation_batch: PU size must be 8, 16, 32 or 64"); return HMR_GPU_ERR_ARG;
+	}
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
+
+extern "C" int hmr_gpu_mc_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int is_luma, int is_bi, const int16_t *a, int16_t *c)
+{
+	if (njobs <= 0) return HMR_GPU_OK;
+	dim3 grid(hmr_grid_for_waves(njobs)), block(HMR_BLOCK);
+	if (is_luma) hipLaunchKernelGGL((k_mc<8>), grid, block, 0, ctx->stream, jobs, njobs, is_bi, a, c);
+	else hipLaunchKernelGGL((k_mc<4>), grid, block, 0, ctx->stream, jobs, njobs, is_bi, a, c);
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}

@@ -198,6 +198,42 @@ int hmr_gpu_sao_apply_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *src, const hm
 /* reference_picture_border_padding_ctu (hmr_encoder_lib.c:1723) for every CTU: replicate edges into pad_x/pad_y (luma; chroma half) */
 int hmr_gpu_pad_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *frame, int pad_x, int pad_y);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * 5. motion: search driver and compensation (the reference's L3 helpers that sit directly on the kernels)
+ * ------------------------------------------------------------------------------------------------ */
+/* One PU of hmr_motion_estimation (hmr_motion_inter.c:1404).  Vectors are in quarter samples. */
+typedef struct hmr_gpu_me_job {
+	double corr;                 /* calc_mv_correction(qp, avg_dist) = qp * clip(avg_dist / 2000., .15, 1.4), hmr_common.h:53 (host-side double) */
+	uint32_t orig_off, orig_stride;   /* source block */
+	uint32_t ref_off, ref_stride;     /* co-located block (mv = 0) in the padded reference picture */
+	int16_t gx, gy;              /* curr_part_global_x / _y */
+	int16_t init_x, init_y;      /* start vector, integer samples */
+	int16_t n_amvp, n_search;    /* candidate counts: AMVP list (vector cost, 1..2), search list et->mv_search_candidates (0..5) */
+	int16_t amvp[2][2];
+	int16_t search[5][2];
+	uint32_t action;             /* MOTION_PEL_MASK 1 | MOTION_HALF_PEL_MASK 2 | MOTION_QUARTER_PEL_MASK 4, hmr_common.h:77-79 */
+	uint32_t reserved;
+} hmr_gpu_me_job;
+typedef struct hmr_gpu_me_result {
+	int32_t mvx, mvy;            /* *mv */
+	int32_t subx, suby;          /* *subpix_mv */
+	uint32_t sad;                /* return value */
+} hmr_gpu_me_result;
+/* jobs / out are DEVICE arrays; all PUs of a call share `size` (8, 16, 32, 64); range = MOTION_SEARCH_RANGE_X/Y (128/64, hmr_private.h:76-77).
+ * The 16 sub-pel planes of hmr_half/quarter_pixel_estimation_luma_hm (hmr_motion_inter.c:395,442) are produced and consumed on chip. */
+int hmr_gpu_motion_estimation_batch(hmr_gpu_ctx *ctx, const hmr_gpu_me_job *jobs, int njobs, int size, const int16_t *orig_base, const int16_t *ref_base,
+				    int range_x, int range_y, int frame_w, int frame_h, hmr_gpu_me_result *out);
+/* hmr_motion_compensation_luma / _chroma (hmr_motion_inter.c:1779,1860): a = co-located block, c = prediction, w/h extent,
+ * p0 = mv.x, p1 = mv.y (as int32; quarter samples for luma, eighth samples for chroma) */
+int hmr_gpu_mc_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int is_luma, int is_bi_predict, const int16_t *a_base, int16_t *c_base);
+/* host-pointer (drop-in) forms */
+uint32_t hmr_gpu_motion_estimation(int16_t *orig, int orig_stride, int16_t *ref, int ref_stride, int gx, int gy, int init_x, int init_y, int size,
+				   int range_x, int range_y, int frame_w, int frame_h, const int32_t *amvp, int n_amvp, const int32_t *search, int n_search,
+				   double corr, int action, int32_t *out_mv4);
+void hmr_gpu_mc_luma(int16_t *ref, int ref_stride, int16_t *pred, int pred_stride, int width, int height, int mvx, int mvy, int is_bi);
+void hmr_gpu_mc_chroma(int16_t *ref, int ref_stride, int16_t *pred, int pred_stride, int size, int mvx, int mvy, int is_bi);
+
 #ifdef __cplusplus
 }
 #endif

@@ -895,3 +895,159 @@ void ora_pad_plane(int16_t *pic, int stride, int width, int height, int pad_x, i
 		memcpy(pic + (size_t)(height + y) * stride - pad_x, pic + (size_t)(height - 1) * stride - pad_x, (size_t)(width + 2 * pad_x) * 2);
 	}
 }
+
+/* ====================================================================================================
+ * Motion: compensation (a17), and the integer + sub-pel motion search driver (a15/a16).
+ * ==================================================================================================== */
+
+/* hmr_motion_compensation_luma, hmr_motion_inter.c:1779-1812.  `ref` points at the co-located block (mv = 0). */
+void ora_mc_luma(const int16_t *ref, int ref_stride, int16_t *pred, int pred_stride, int width, int height, int mvx, int mvy, int is_bi)
+{
+	int xf = mvx & 3, yf = mvy & 3;
+	const int16_t *src = ref + (mvy >> 2) * ref_stride + (mvx >> 2);
+	if (xf == 0) ora_interpolate_luma(src, ref_stride, pred, pred_stride, yf, width, height, 1, 1, !is_bi);
+	else if (yf == 0) ora_interpolate_luma(src, ref_stride, pred, pred_stride, xf, width, height, 0, 1, !is_bi);
+	else {
+		int16_t tmp[(64 + 8) * 80];
+		ora_interpolate_luma(src - 3 * ref_stride, ref_stride, tmp, 80, xf, width, height + 7, 0, 1, 0);
+		ora_interpolate_luma(tmp + 3 * 80, 80, pred, pred_stride, yf, width, height, 1, 0, !is_bi);
+	}
+}
+
+/* hmr_motion_compensation_chroma, hmr_motion_inter.c:1860-1907 (eighth-sample vectors) */
+void ora_mc_chroma(const int16_t *ref, int ref_stride, int16_t *pred, int pred_stride, int size, int mvx, int mvy, int is_bi)
+{
+	int xf = mvx & 7, yf = mvy & 7;
+	const int16_t *src = ref + (mvy >> 3) * ref_stride + (mvx >> 3);
+	if (xf == 0) ora_interpolate_chroma(src, ref_stride, pred, pred_stride, yf, size, size, 1, 1, !is_bi);
+	else if (yf == 0) ora_interpolate_chroma(src, ref_stride, pred, pred_stride, xf, size, size, 0, 1, !is_bi);
+	else {
+		int16_t tmp[(32 + 8) * 40];
+		ora_interpolate_chroma(src - ref_stride, ref_stride, tmp, 40, xf, size, size + 3, 0, 1, 0);
+		ora_interpolate_chroma(tmp + 40, 40, pred, pred_stride, yf, size, size, 1, 0, !is_bi);
+	}
+}
+
+/* select_mv_candidate_fast, hmr_motion_inter.c:1004-1031; `corr` = calc_mv_correction(qp, avg_dist) (hmr_common.h:53) is a
+ * host-side double.  cands = (x, y) pairs in quarter samples. */
+static uint32_t mv_cost(const int32_t *cands, int n, double corr, int mvx, int mvy)
+{
+	uint32_t best = INT_MAX;
+	int i;
+	for (i = 0; i < n; i++) {
+		double cx = corr * ((float)abs(cands[2 * i] - mvx)), cy = corr * ((float)abs(cands[2 * i + 1] - mvy));
+		uint32_t c = (uint32_t)(cx + cy + .5);
+		if (best > c) best = c;
+	}
+	return best;
+}
+
+/* SAD of the source block against the prediction at quarter-sample vector (qx, qy): the planes the reference builds
+ * with hmr_half/quarter_pixel_estimation_luma_hm (hmr_motion_inter.c:395,442) hold exactly these samples. */
+static uint32_t subpel_sad(const int16_t *orig, int orig_stride, const int16_t *ref, int ref_stride, int size, int qx, int qy)
+{
+	int16_t pred[64 * 64];
+	ora_mc_luma(ref, ref_stride, pred, 64, size, size, qx, qy, 0);
+	return ora_sad(orig, (uint32_t)orig_stride, pred, 64, size);
+}
+
+/* hmr_motion_estimation, hmr_motion_inter.c:1404-1775.  out = {mv.x, mv.y, subpix.x, subpix.y}; returns best SAD.
+ * action bits: 1 integer search, 2 half-sample, 4 quarter-sample refinement. */
+uint32_t ora_motion_estimation(const int16_t *orig, int orig_stride, const int16_t *ref, int ref_stride, int gx, int gy, int init_x, int init_y,
+			       int size, int range_x, int range_y, int frame_w, int frame_h, const int32_t *amvp, int n_amvp,
+			       const int32_t *search, int n_search, double corr, int action, int32_t *out)
+{
+	static const int ds[4][2] = {{-1, 0}, {0, -1}, {1, 0}, {0, 1}};
+	static const int db[8][2] = {{-2, 0}, {-1, -1}, {0, -2}, {1, -1}, {2, 0}, {1, 1}, {0, 2}, {-1, 1}};
+	static const int ref_h[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
+	static const int ref_q[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
+	int xlow = (gx - range_x) < 0 ? -gx : -range_x, xhigh = (gx + range_x) > (frame_w - size) ? frame_w - gx - size : range_x;
+	int ylow = (gy - range_y) < 0 ? -gy : -range_y, yhigh = (gy + range_y) > (frame_h - size) ? frame_h - gy - size : range_y;
+	uint32_t cur_sad = 0, cur_rd = 0, best_sad = 0xffffffffu;
+	int cur_x = 0, cur_y = 0, best_x = 0, best_y = 0, mvx = 0, mvy = 0, subx = 0, suby = 0, i, dist, end, next_start, search_size;
+#define IN_WIN(x, y) ((x) >= xlow && (x) <= xhigh && (y) >= ylow && (y) <= yhigh)
+#define SAD_AT(x, y) ora_sad(orig, (uint32_t)orig_stride, ref + (y) * ref_stride + (x), (uint32_t)ref_stride, size)
+#define TRY(x, y, on_better)                                                          \
+	do {                                                                          \
+		if (IN_WIN(x, y)) {                                                   \
+			uint32_t s_ = SAD_AT(x, y);                                   \
+			uint32_t rd_ = s_ + mv_cost(amvp, n_amvp, corr, (x) << 2, (y) << 2); \
+			if (rd_ < cur_rd) { on_better; cur_sad = s_; cur_rd = rd_; cur_x = (x); cur_y = (y); } \
+		}                                                                     \
+	} while (0)
+	if (action & 1) {
+		cur_x = clip3(init_x, xlow, xhigh);
+		cur_y = clip3(init_y, ylow, yhigh);
+		cur_sad = SAD_AT(cur_x, cur_y);
+		cur_rd = cur_sad + mv_cost(amvp, n_amvp, corr, cur_x << 2, cur_y << 2);
+		best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
+		if (best_sad <= 0) goto last_search;
+		for (i = 0; i < n_search; i++) {
+			int x = search[2 * i] >> 2, y = search[2 * i + 1] >> 2;
+			if (x == 0 && y == 0) continue;
+			TRY(x, y, (void)0);
+		}
+		best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
+		if (best_sad <= 0) goto last_search;
+		for (i = 0; i < 4; i++) {
+			int x = best_x + ds[i][0], y = best_y + ds[i][1];
+			TRY(x, y, (void)0);
+		}
+		if (best_sad <= 0) goto last_search;
+		dist = 2;
+		end = (best_x != 0 && best_y != 0) ? 4 : 8;
+		next_start = 0; search_size = 8;
+		best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
+		while (dist < end) {
+			for (i = next_start; i < next_start + search_size; i++) {
+				int idx = i % 8, x = best_x + db[idx][0] * dist, y = best_y + db[idx][1] * dist;
+				TRY(x, y, (next_start = (idx - 2 + 8) % 8, search_size = 5));
+			}
+			dist *= 2;
+		}
+	last_search:
+		best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
+		next_start = 0; search_size = 4;   /* (the reference also tracks a runner-up here; it is never read) */
+		for (;;) {
+			for (i = next_start; i < next_start + search_size; i++) {
+				int idx = i % 4, x = best_x + ds[idx][0], y = best_y + ds[idx][1];
+				TRY(x, y, (next_start = (idx - 1 + 4) % 4, search_size = 3));
+			}
+			if (best_x == cur_x && best_y == cur_y) break;
+			best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
+		}
+		best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
+		mvx = best_x << 2; mvy = best_y << 2;
+	} else {
+		mvx = init_x << 2; mvy = init_y << 2;   /* caller-supplied integer vector */
+	}
+	if (action & 2) {
+		int bidx = 0, bx, by;
+		best_x = mvx >> 2; best_y = mvy >> 2;
+		if (!(action & 1)) cur_sad = SAD_AT(best_x, best_y);
+		bx = 0; by = 0;
+		for (i = 0; i < 9; i++) {
+			int cx = ref_h[i][0] * 2, cy = ref_h[i][1] * 2;
+			uint32_t s = subpel_sad(orig, orig_stride, ref, ref_stride, size, (best_x << 2) + cx, (best_y << 2) + cy);
+			if (s < cur_sad) { cur_sad = s; bx = cx; by = cy; bidx = i; }
+		}
+		mvx = (best_x << 2) + bx; mvy = (best_y << 2) + by; subx = bx; suby = by;
+		best_sad = cur_sad;
+		if (action & 4) {
+			int hx = ref_h[bidx][0], hy = ref_h[bidx][1];
+			bx = hx * 2; by = hy * 2;
+			for (i = 0; i < 9; i++) {
+				int cx = hx * 2 + ref_q[i][0], cy = hy * 2 + ref_q[i][1];
+				uint32_t s = subpel_sad(orig, orig_stride, ref, ref_stride, size, (best_x << 2) + cx, (best_y << 2) + cy);
+				if (s < cur_sad) { cur_sad = s; bx = cx; by = cy; }
+			}
+			best_sad = cur_sad;
+			mvx = (best_x << 2) + bx; mvy = (best_y << 2) + by; subx = bx; suby = by;
+		}
+	}
+	out[0] = mvx; out[1] = mvy; out[2] = subx; out[3] = suby;
+	return best_sad;
+#undef IN_WIN
+#undef SAD_AT
+#undef TRY
+}

@@ -95,6 +95,14 @@ void ora_sao_apply_frame(const int16_t *sy, const int16_t *su, const int16_t *sv
 /* hmr_encoder_lib.c:1723 over every CTU */
 void ora_pad_plane(int16_t *pic, int stride, int width, int height, int pad_x, int pad_y);
 
+
+/* ---- motion (a15-a17) ---- */
+void ora_mc_luma(const int16_t *ref, int ref_stride, int16_t *pred, int pred_stride, int width, int height, int mvx, int mvy, int is_bi);
+void ora_mc_chroma(const int16_t *ref, int ref_stride, int16_t *pred, int pred_stride, int size, int mvx, int mvy, int is_bi);
+uint32_t ora_motion_estimation(const int16_t *orig, int orig_stride, const int16_t *ref, int ref_stride, int gx, int gy, int init_x, int init_y,
+			       int size, int range_x, int range_y, int frame_w, int frame_h, const int32_t *amvp, int n_amvp,
+			       const int32_t *search, int n_search, double corr, int action, int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -402,3 +402,59 @@ void refh_pad_frame(int16_t *y, int16_t *u, int16_t *v, int16_t *py, int16_t *pu
 }
 /* reconstruction of the last encoded frame as the encoder left it (deblocked, SAO'd), dense int16 planes */
 void refh_get_recon(int16_t *y, int16_t *u, int16_t *v) { planes_out(&g_eng->curr_reference_frame->img, y, u, v); }
+
+/* =====================================================================================================
+ * Motion: hmr_motion_compensation_luma/chroma (hmr_motion_inter.c:1779,1860) and the search driver
+ * hmr_motion_estimation (:1404) with its sub-pel plane builders (:395,442), called with a synthetic
+ * partition node at window position (0,0).
+ * ===================================================================================================== */
+uint32_t hmr_motion_estimation(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *curr_cu_info, int16_t *orig_buff, int orig_buff_stride,
+			       int16_t *reference_buff, int reference_buff_stride, int curr_part_global_x, int curr_part_global_y, int init_x, int init_y,
+			       int curr_part_size, int curr_part_size_shift, int search_range_x, int search_range_y, int frame_size_x, int frame_size_y,
+			       motion_vector_t *mv, motion_vector_t *subpix_mv, mv_candiate_list_t *amvp_candidate_list, uint32_t threshold, unsigned int action);
+void hmr_motion_compensation_luma(henc_thread_t *et, cu_partition_info_t *curr_cu_info, int16_t *reference_buff, int reference_buff_stride, int16_t *pred_buff,
+				  int pred_buff_stride, int width, int height, int curr_part_size_shift, motion_vector_t *mv, int is_bi_predict);
+void hmr_motion_compensation_chroma(henc_thread_t *et, int16_t *reference_buff, int reference_buff_stride, int16_t *pred_buff, int pred_buff_stride,
+				    int curr_part_size, int curr_part_size_shift, motion_vector_t *mv, int is_bi_predict);
+
+static int log2i(int n) { int s = 0; while ((1 << s) < n) s++; return s; }
+
+void refh_mc_luma(int16_t *ref, int ref_stride, int16_t *pred, int pred_stride, int width, int height, int mvx, int mvy, int is_bi)
+{
+	cu_partition_info_t cu;
+	motion_vector_t mv = {mvx, mvy};
+	memset(&cu, 0, sizeof cu);
+	hmr_motion_compensation_luma(g_et, &cu, ref, ref_stride, pred, pred_stride, width, height, log2i(width), &mv, is_bi);
+}
+void refh_mc_chroma(int16_t *ref, int ref_stride, int16_t *pred, int pred_stride, int size, int mvx, int mvy, int is_bi)
+{
+	motion_vector_t mv = {mvx, mvy};
+	hmr_motion_compensation_chroma(g_et, ref, ref_stride, pred, pred_stride, size, log2i(size), &mv, is_bi);
+}
+uint32_t refh_motion_estimation(int16_t *orig, int orig_stride, int16_t *ref, int ref_stride, int gx, int gy, int init_x, int init_y, int size, int range_x,
+				int range_y, int frame_w, int frame_h, int32_t *amvp, int n_amvp, int32_t *search, int n_search, int qp, double avg_dist,
+				int action, int32_t *out)
+{
+	cu_partition_info_t cu;
+	ctu_info_t ctu;
+	mv_candiate_list_t al;
+	motion_vector_t mv = {init_x << 2, init_y << 2}, sub = {0, 0};
+	uint32_t r;
+	int i;
+	memset(&cu, 0, sizeof cu);
+	memset(&ctu, 0, sizeof ctu);
+	memset(&al, 0, sizeof al);
+	cu.size = size; cu.qp = qp;
+	al.num_mv_candidates = n_amvp;
+	for (i = 0; i < n_amvp; i++) { al.mv_candidates[i].mv.hor_vector = amvp[2 * i]; al.mv_candidates[i].mv.ver_vector = amvp[2 * i + 1]; }
+	g_et->mv_search_candidates.num_mv_candidates = n_search;
+	for (i = 0; i < n_search; i++) {
+		g_et->mv_search_candidates.mv_candidates[i].mv.hor_vector = search[2 * i];
+		g_et->mv_search_candidates.mv_candidates[i].mv.ver_vector = search[2 * i + 1];
+	}
+	g_eng->avg_dist = avg_dist;
+	r = hmr_motion_estimation(g_et, &ctu, &cu, orig, orig_stride, ref, ref_stride, gx, gy, init_x, init_y, size, log2i(size), range_x, range_y, frame_w,
+				  frame_h, &mv, &sub, &al, 0, (unsigned)action);
+	out[0] = mv.hor_vector; out[1] = mv.ver_vector; out[2] = sub.hor_vector; out[3] = sub.ver_vector;
+	return r;
+}

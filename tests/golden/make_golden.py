@@ -42,6 +42,18 @@ def main():
     with open(os.path.join(HERE, "table_kernels.json"), "w") as f:
         json.dump(meta, f, indent=0, separators=(",", ":"))
     print(len(cases), "cases written")
+    # motion search driver / motion compensation (tests/motion_cases.py)
+    import motion_cases as mc
+    arrays, index = {}, []
+    for i, case in enumerate(mc.all_cases("golden")):
+        out = mc.run(ref, "refh_", case)
+        index.append({"kernel": case[0], "params": case[1], "seed": case[2], "outputs": sorted(out)})
+        for k, v in out.items():
+            arrays[f"c{i}_{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "motion.npz"), **arrays)
+    with open(os.path.join(HERE, "motion.json"), "w") as f:
+        json.dump({"generator": "tests/golden/make_golden.py", "reference_flags": meta["reference_flags"], "cases": index}, f, indent=0, separators=(",", ":"))
+    print(len(index), "motion cases written")
 
 
 if __name__ == "__main__":
