@@ -393,7 +393,10 @@ uint32_t hmr_gpu_motion_estimation(int16_t *orig, int orig_stride, int16_t *ref,
 	// the search window the kernel can touch: integer candidates inside [low, high], sub-pel taps 4 further
 	const int xlow = (gx - range_x) < 0 ? -gx : -range_x, xhigh = (gx + range_x) > (frame_w - size) ? frame_w - gx - size : range_x;
 	const int ylow = (gy - range_y) < 0 ? -gy : -range_y, yhigh = (gy + range_y) > (frame_h - size) ? frame_h - gy - size : range_y;
-	const int x0 = xlow - 5, y0 = ylow - 5, ww = xhigh - xlow + size + 10, wh = yhigh - ylow + size + 10;
+	// without the integer stage the caller's vector is used unclamped (hmr_motion_inter.c:1668): keep it inside the staged window
+	const int xl = init_x < xlow ? init_x : xlow, xh = init_x > xhigh ? init_x : xhigh;
+	const int yl = init_y < ylow ? init_y : ylow, yh = init_y > yhigh ? init_y : yhigh;
+	const int x0 = xl - 5, y0 = yl - 5, ww = xh - xl + size + 10, wh = yh - yl + size + 10;
 	hmr_gpu_me_job jb = {};
 	jb.corr = corr;
 	jb.orig_off = (uint32_t)(st.put2d(orig, orig_stride, size, size, 2) / 2); jb.orig_stride = size;
