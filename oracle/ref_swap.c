@@ -93,3 +93,48 @@ void fill_reference_samples(henc_thread_t *et, ctu_info_t *ctu, cu_partition_inf
 	hmr_gpu_fill_reference_samples(decoded, stride, n, pi->left_neighbour, pi->top_neighbour, pi->left_bottom_neighbour, pi->top_right_neighbour, bl, tr, et->adi_pred_buff);
 	if (is_filtered) hmr_gpu_adi_filter(et->adi_pred_buff, et->adi_filtered_pred_buff, adi_size, n, et->sps->strong_intra_smooth_enabled_flag);
 }
+
+/* ---- L3 helpers that sit directly on the kernels: motion search driver and motion compensation ---- */
+uint32_t hmr_motion_estimation(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *cu, int16_t *orig, int orig_stride, int16_t *ref, int ref_stride,
+			       int gx, int gy, int init_x, int init_y, int size, int size_shift, int range_x, int range_y, int frame_w, int frame_h,
+			       motion_vector_t *mv, motion_vector_t *subpix_mv, mv_candiate_list_t *amvp, uint32_t threshold, unsigned int action)
+{
+	if (!want("motion_estimation"))
+		return ((uint32_t(*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int16_t *, int, int16_t *, int, int, int, int, int, int, int, int, int, int, int,
+				     motion_vector_t *, motion_vector_t *, mv_candiate_list_t *, uint32_t, unsigned int))REAL(hmr_motion_estimation))(
+			et, ctu, cu, orig, orig_stride, ref, ref_stride, gx, gy, init_x, init_y, size, size_shift, range_x, range_y, frame_w, frame_h, mv, subpix_mv, amvp,
+			threshold, action);
+	int32_t a[4] = {0, 0, 0, 0}, s[10], out[4];
+	int i, na = amvp->num_mv_candidates, ns = et->mv_search_candidates.num_mv_candidates;
+	for (i = 0; i < na && i < 2; i++) { a[2 * i] = amvp->mv_candidates[i].mv.hor_vector; a[2 * i + 1] = amvp->mv_candidates[i].mv.ver_vector; }
+	for (i = 0; i < ns && i < 5; i++) { s[2 * i] = et->mv_search_candidates.mv_candidates[i].mv.hor_vector; s[2 * i + 1] = et->mv_search_candidates.mv_candidates[i].mv.ver_vector; }
+	/* without the integer stage the reference starts from *mv (hmr_motion_inter.c:1668) */
+	if (!(action & MOTION_PEL_MASK)) { init_x = mv->hor_vector >> 2; init_y = mv->ver_vector >> 2; }
+	double corr = calc_mv_correction(cu->qp, et->enc_engine->avg_dist);
+	uint32_t r = hmr_gpu_motion_estimation(orig, orig_stride, ref, ref_stride, gx, gy, init_x, init_y, cu->size, range_x, range_y, frame_w, frame_h, a, na, s, ns, corr,
+					       (int)action, out);
+	mv->hor_vector = out[0]; mv->ver_vector = out[1];
+	subpix_mv->hor_vector = out[2]; subpix_mv->ver_vector = out[3];
+	return r;
+}
+
+void hmr_motion_compensation_luma(henc_thread_t *et, cu_partition_info_t *cu, int16_t *ref, int ref_stride, int16_t *pred, int pred_stride, int width, int height,
+				  int size_shift, motion_vector_t *mv, int is_bi)
+{
+	if (!want("motion_compensation")) {
+		((void (*)(henc_thread_t *, cu_partition_info_t *, int16_t *, int, int16_t *, int, int, int, int, motion_vector_t *, int))REAL(hmr_motion_compensation_luma))(
+			et, cu, ref, ref_stride, pred, pred_stride, width, height, size_shift, mv, is_bi);
+		return;
+	}
+	hmr_gpu_mc_luma(ref, ref_stride, pred, pred_stride, width, height, mv->hor_vector, mv->ver_vector, is_bi);
+}
+
+void hmr_motion_compensation_chroma(henc_thread_t *et, int16_t *ref, int ref_stride, int16_t *pred, int pred_stride, int size, int size_shift, motion_vector_t *mv, int is_bi)
+{
+	if (!want("motion_compensation")) {
+		((void (*)(henc_thread_t *, int16_t *, int, int16_t *, int, int, int, motion_vector_t *, int))REAL(hmr_motion_compensation_chroma))(et, ref, ref_stride, pred,
+																		   pred_stride, size, size_shift, mv, is_bi);
+		return;
+	}
+	hmr_gpu_mc_chroma(ref, ref_stride, pred, pred_stride, size, mv->hor_vector, mv->ver_vector, is_bi);
+}
