@@ -445,4 +445,39 @@ static void mc_any(int is_luma, int16_t *ref, int ref_stride, int16_t *pred, int
 void hmr_gpu_mc_luma(int16_t *ref, int rs, int16_t *pred, int ps, int w, int h, int mvx, int mvy, int bi) { mc_any(1, ref, rs, pred, ps, w, h, mvx, mvy, bi); }
 void hmr_gpu_mc_chroma(int16_t *ref, int rs, int16_t *pred, int ps, int size, int mvx, int mvy, int bi) { mc_any(0, ref, rs, pred, ps, size, size, mvx, mvy, bi); }
 
+void hmr_gpu_get_sao_stats(const int16_t *const orig[3], const int orig_stride[3], const int16_t *const recon[3], const int recon_stride[3], int pict_width,
+			   int pict_height, int ctu_x, int ctu_y, int64_t *stats)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	hmr_gpu_frame fo = {}, fr = {};
+	fo.width = fr.width = pict_width; fo.height = fr.height = pict_height;
+	int16_t **po[3] = {&fo.y, &fo.u, &fo.v}, **pr[3] = {&fr.y, &fr.u, &fr.v};
+	int tw_l = 0, tw_c = 0;
+	for (int comp = 0; comp < 3; comp++) {
+		const int sh = comp ? 1 : 0, pw = pict_width >> sh, ph = pict_height >> sh, x = ctu_x >> sh, y = ctu_y >> sh, n = 64 >> sh;
+		// the CTU plus a one-sample ring, clipped to the picture
+		const int x0 = x > 0 ? x - 1 : 0, y0 = y > 0 ? y - 1 : 0, x1 = x + n + 1 < pw ? x + n + 1 : pw, y1 = y + n + 1 < ph ? y + n + 1 : ph;
+		const int w = comp ? 34 : 66;   // common tile pitch per plane type, so that one stride serves U and V
+		if (comp == 0) tw_l = w; else tw_c = w;
+		const size_t or_off = st.zeros((size_t)w * w * 2), re_off = st.zeros((size_t)w * w * 2);
+		for (int yy = y0; yy < y1; yy++) {
+			memcpy(st.host<int16_t>(or_off) + (size_t)(yy - y0) * w, orig[comp] + (size_t)yy * orig_stride[comp] + x0, (size_t)(x1 - x0) * 2);
+			memcpy(st.host<int16_t>(re_off) + (size_t)(yy - y0) * w, recon[comp] + (size_t)yy * recon_stride[comp] + x0, (size_t)(x1 - x0) * 2);
+		}
+		// virtual picture origin: the kernel indexes with picture coordinates, only the tile is ever dereferenced
+		*po[comp] = st.dev<int16_t>(or_off) - ((ptrdiff_t)y0 * w + x0);
+		*pr[comp] = st.dev<int16_t>(re_off) - ((ptrdiff_t)y0 * w + x0);
+	}
+	fo.stride_y = fr.stride_y = tw_l; fo.stride_c = fr.stride_c = tw_c;
+	st.begin_outputs();
+	const size_t o = st.out(3 * 5 * 2 * 32 * 4);
+	st.upload();
+	const int ctus_x = (pict_width + 63) / 64;
+	must(hmr_gpu_sao_stats_ctu(c, &fo, &fr, (ctu_y / 64) * ctus_x + ctu_x / 64, st.dev<int32_t>(o)), "get_sao_stats");
+	st.finish();
+	const int32_t *r = st.host<int32_t>(o);
+	for (int i = 0; i < 3 * 5 * 2 * 32; i++) stats[i] = r[i];
+}
+
 }  // extern "C"

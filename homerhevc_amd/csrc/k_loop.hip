@@ -225,11 +225,12 @@ struct Planes {
 __device__ __forceinline__ int sgn(int v) { return v > 0 ? 1 : (v < 0 ? -1 : 0); }
 
 // grid = (ctus, 3).  stats[ctu][comp][type][diff|count][32]
-__global__ __launch_bounds__(HMR_BLOCK) void k_sao_stats(Planes org, Planes rec, int width, int height, int ctus_x, int32_t *__restrict__ stats)
+__global__ __launch_bounds__(HMR_BLOCK) void k_sao_stats(Planes org, Planes rec, int width, int height, int ctus_x, int ctu_first, int32_t *__restrict__ stats)
 {
 	__shared__ int16_t tile[66 * 66];
 	__shared__ int sAcc[5][2][32];
-	const int ctu = blockIdx.x, comp = blockIdx.y, cx = ctu % ctus_x, cy = ctu / ctus_x;
+	// ctu_first lets the drop-in entry run a single CTU of the picture (stats then holds that CTU only)
+	const int ctu = blockIdx.x + ctu_first, comp = blockIdx.y, cx = ctu % ctus_x, cy = ctu / ctus_x;
 	const int sh = comp ? 1 : 0;
 	const int hl = (cy * 64 + 64 > height) ? height - cy * 64 : 64, wl = (cx * 64 + 64 > width) ? width - cx * 64 : 64;
 	const int h = hl >> sh, w = wl >> sh;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_sao_stats(Planes org, Planes rec,
 			}
 		}
 	__syncthreads();
-	int32_t *out = stats + ((size_t)ctu * 3 + comp) * 5 * 2 * 32;
+	int32_t *out = stats + ((size_t)blockIdx.x * 3 + comp) * 5 * 2 * 32;
 	for (int i = threadIdx.x; i < 5 * 2 * 32; i += HMR_BLOCK) out[i] = (&sAcc[0][0][0])[i];
 }
 
@@ -382,7 +383,18 @@ extern "C" int hmr_gpu_sao_stats_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *or
 	if (!orig || !recon || orig->width != recon->width || orig->height != recon->height) return HMR_GPU_ERR_ARG;
 	const int ctus_x = (recon->width + 63) / 64, ctus_y = (recon->height + 63) / 64;
 	hipLaunchKernelGGL(k_sao_stats, dim3(ctus_x * ctus_y, 3), dim3(HMR_BLOCK), 0, ctx->stream, planes_of(orig), planes_of(recon), recon->width, recon->height,
-			   ctus_x, stats);
+			   ctus_x, 0, stats);
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
+
+// one CTU of the picture (the granularity of low_level_funcs_t.get_sao_stats): stats[3][5][2][32]
+extern "C" int hmr_gpu_sao_stats_ctu(hmr_gpu_ctx *ctx, const hmr_gpu_frame *orig, const hmr_gpu_frame *recon, int ctu_index, int32_t *stats)
+{
+	if (!orig || !recon || orig->width != recon->width || orig->height != recon->height) return HMR_GPU_ERR_ARG;
+	const int ctus_x = (recon->width + 63) / 64;
+	hipLaunchKernelGGL(k_sao_stats, dim3(1, 3), dim3(HMR_BLOCK), 0, ctx->stream, planes_of(orig), planes_of(recon), recon->width, recon->height, ctus_x, ctu_index,
+			   stats);
 	HIP_TRY(hipGetLastError());
 	return HMR_GPU_OK;
 }

@@ -43,6 +43,7 @@ TABLE = {
     "inv_quant": ("hmr_gpu_inv_quant", None, [_I16P, _I16P] + [C.c_int] * 6),
     "transform": ("hmr_gpu_transform", None, [_I16P, _I16P, C.c_int, C.c_int, C.c_int]),
     "itransform": ("hmr_gpu_itransform", None, [_I16P, _I16P, C.c_int, C.c_int, C.c_int]),
+    "get_sao_stats": ("hmr_gpu_get_sao_stats", None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
 

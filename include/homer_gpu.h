@@ -109,6 +109,11 @@ void hmr_gpu_itransform(int16_t *block, int16_t *coeff, int block_stride, int n,
 void hmr_gpu_quant(int16_t *src, int16_t *dst, int16_t *delta_u, int scan_mode, int depth, int comp, int is_intra, int slice_is_intra,
 		   int sign_hiding, int *ac_sum, int cu_size, int per, int rem);
 void hmr_gpu_inv_quant(int16_t *src, int16_t *dst, int depth, int comp, int is_intra, int cu_size, int per, int rem);
+/* :1091 get_sao_stats.  The henc_thread_t, slice_t and ctu_info_t pointers are replaced by what they are read for: the picture planes (HOST pointers to
+ * sample (0,0), strides in elements), the picture size and the CTU's luma position; stats[comp][type][diff|count][32] as int64 like
+ * sao_stat_data_t (hmr_private.h:455).  Only the CTU and its one-sample ring are transferred. */
+void hmr_gpu_get_sao_stats(const int16_t *const orig[3], const int orig_stride[3], const int16_t *const recon[3], const int recon_stride[3], int pict_width,
+			   int pict_height, int ctu_x, int ctu_y, int64_t *stats);
 
 /* ------------------------------------------------------------------------------------------------
  * 3. batched entries: device-resident operands, one launch per call, asynchronous on the context's
@@ -192,6 +197,8 @@ int hmr_gpu_deblock_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *frame, const hm
 /* low_level_funcs_t.get_sao_stats (hmr_private.h:1091, hmr_sse42_sao.c:35) for every CTU:
  * stats[ctu][comp][type EO0,EO90,EO135,EO45,BO][0 = diff, 1 = count][32] as int32 */
 int hmr_gpu_sao_stats_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *orig, const hmr_gpu_frame *recon, int32_t *stats);
+/* the same for one CTU (the table's call granularity); stats[comp][type][diff|count][32] */
+int hmr_gpu_sao_stats_ctu(hmr_gpu_ctx *ctx, const hmr_gpu_frame *orig, const hmr_gpu_frame *recon, int ctu_index, int32_t *stats);
 /* sao_offset_ctu (hmr_sao.c:1210) for every CTU: src = pre-SAO picture, dst = output (must hold a copy of src);
  * params[ctu][comp][34] = {modeIdc, typeIdc, offset[32]} */
 int hmr_gpu_sao_apply_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *src, const hmr_gpu_frame *dst, const int32_t *params);

@@ -55,6 +55,22 @@ static void gpu_itransform(int bd, int16_t *block, int16_t *coeff, int stride, i
 static void gpu_wavg(int16_t *a, int as, int16_t *b, int bs, int16_t *d, int ds, int h, int w, int bit_depth)
 { (void)bit_depth; hmr_gpu_weighted_average(a, as, b, bs, d, ds, h, w); }
 
+static void gpu_sao_stats(henc_thread_t *et, slice_t *slice, ctu_info_t *ctu, sao_stat_data_t stats[][NUM_SAO_NEW_TYPES])
+{
+	wnd_t *ow = &et->enc_engine->current_pict.img2encode->img, *rw = &et->enc_engine->curr_reference_frame->img;
+	const int16_t *o[3] = {ow->pwnd[0], ow->pwnd[1], ow->pwnd[2]}, *r[3] = {rw->pwnd[0], rw->pwnd[1], rw->pwnd[2]};
+	int os[3] = {ow->window_size_x[0], ow->window_size_x[1], ow->window_size_x[2]}, rs[3] = {rw->window_size_x[0], rw->window_size_x[1], rw->window_size_x[2]};
+	int64_t flat[3][NUM_SAO_NEW_TYPES][2][32];
+	int c, t;
+	(void)slice;
+	hmr_gpu_get_sao_stats(o, os, r, rs, et->pict_width[0], et->pict_height[0], ctu->x[0], ctu->y[0], &flat[0][0][0][0]);
+	for (c = 0; c < 3; c++)
+		for (t = 0; t < NUM_SAO_NEW_TYPES; t++) {
+			memcpy(stats[c][t].diff, flat[c][t][0], sizeof flat[c][t][0]);
+			memcpy(stats[c][t].count, flat[c][t][1], sizeof flat[c][t][1]);
+		}
+}
+
 void lockstep_post_init(void *handle)
 {
 	low_level_funcs_t *f = &((hvenc_enc_t *)handle)->funcs;
@@ -67,6 +83,7 @@ void lockstep_post_init(void *handle)
 	SWAP(interpolate_luma_m_compensation, hmr_gpu_interpolate_luma) SWAP(interpolate_luma_m_estimation, hmr_gpu_interpolate_luma)
 	SWAP(interpolate_chroma_m_compensation, hmr_gpu_interpolate_chroma) SWAP(weighted_average_motion, gpu_wavg)
 	SWAP(quant, gpu_quant) SWAP(inv_quant, gpu_iquant) SWAP(transform, gpu_transform) SWAP(itransform, gpu_itransform)
+	SWAP(get_sao_stats, gpu_sao_stats)
 	fprintf(stderr, "ref_swap: %d table entries routed to libhomer_gpu.so\n", n);
 }
 

@@ -39,3 +39,20 @@ def test_deblock_rejects_unaligned_geometry(gpu):
         assert gpu.hmr_gpu_deblock_frame(s.ctx, C.byref(f), C.byref(u), 0, 0, 0, 0, None, None) != 0
     finally:
         s.close()
+
+
+def test_get_sao_stats_dropin_per_ctu(gpu, oracle):
+    """The table's own granularity: one CTU per call, host pointers (low_level_funcs_t.get_sao_stats)."""
+    case, exp, meta = golden_io.load_frame_goldens()[2]
+    ora = fc.run_oracle(oracle, case)
+    W, H = case["width"], case["height"]
+    org = [np.ascontiguousarray(p) for p in case["orig"]]
+    rec = [np.ascontiguousarray(p) for p in ora["deblocked"]]
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
+    strides = I3(W, W // 2, W // 2)
+    ctus_x = (W + 63) // 64
+    for ctu in range(ctus_x * ((H + 63) // 64)):
+        out = np.zeros((3, 5, 2, 32), np.int64)
+        gpu.hmr_gpu_get_sao_stats(P3(*[p.ctypes.data for p in org]), strides, P3(*[p.ctypes.data for p in rec]), strides, W, H,
+                                  (ctu % ctus_x) * 64, (ctu // ctus_x) * 64, out.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(out, ora["stats"][ctu].astype(np.int64)), ctu

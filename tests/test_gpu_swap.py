@@ -24,13 +24,13 @@ def _encode(exe, clip, out, w, h, frames, env=None, extra=()):
         return f.read(), r.stderr
 
 
-@pytest.mark.parametrize("extra", [(), ("force_intra=1",)], ids=["ippp", "all_intra"])
-def test_stream_identical_with_gpu_kernels(tmp_path, extra):
+@pytest.mark.parametrize("extra,w,h,frames", [((), 200, 136, 3), (("force_intra=1",), 200, 136, 2), ((), 416, 240, 3)],
+                         ids=["ippp_200x136", "all_intra_200x136", "ippp_416x240"])
+def test_stream_identical_with_gpu_kernels(tmp_path, extra, w, h, frames):
     if not (os.path.exists(SWAP) and os.path.exists(libs.REF_LOCKSTEP)):
         pytest.skip("oracle/_ref not shipped (built only where the reference sources exist)")
     sys.path.insert(0, os.path.join(libs.ROOT, "tools"))
     import gen_yuv
-    w, h, frames = 200, 136, 3 if not extra else 2
     clip = str(tmp_path / "clip.yuv")
     gen_yuv.write_clip(clip, w, h, frames)
     ref, _ = _encode(libs.REF_LOCKSTEP, clip, str(tmp_path / "ref.265"), w, h, frames, extra=extra)
