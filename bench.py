@@ -286,6 +286,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--callmix-frame", type=int, default=2, help="which recorded P frame to replay")
+    ap.add_argument("--launch-order", default=None, help="write the per-step kernel launch order (JSON) for tools/pmc_summary.py")
     args = ap.parse_args()
 
     import torch
@@ -400,6 +401,11 @@ def main():
         for r in reqs:
             r.wait()
 
+    if args.launch_order and rank == 0:
+        order = [f"{g['name']}:{g['size']}" for g in groups] + ["edge_flags", "deblock", "deblock", "sao_stats", "sao_apply", "pad", "pad", "pad"]
+        with open(args.launch_order, "w") as f:
+            json.dump(order, f)
+
     with torch.cuda.stream(stream):
         for i in range(args.warmup):
             step(-1 - i, False)
@@ -430,6 +436,12 @@ def main():
     nbytes.update(frame_bytes)
     dom = max(per, key=per.get)
     achieved = nbytes[dom] / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0
+    # HBM traffic of the dominant kernel from the committed PMC passes of this same command (tools/pmc_summary.py), if present
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get("groups", {}).get(dom, {}).get("hbm_bytes")
     total_alg = sum(nbytes.values())
 
     if rank == 0:
@@ -444,7 +456,7 @@ def main():
                        "callmix_frame": args.callmix_frame, "parallelism": f"engine-per-gpu x{world}",
                        "algorithmic_MB_per_frame_abi_width": round(total_alg / 1e6, 2), "compulsory_MB_per_frame": round(10.5 * W * H / 1e6, 2)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "bytes_per_launch": int(nbytes[dom]), "ms_per_launch": round(per[dom], 5),
                          "frame_level_frac": round(10.5 * W * H * fps / world / 1e9 / HBM_PEAK_GBS, 6)},
             "kernels_ms": {k: round(v, 4) for k, v in sorted(per.items(), key=lambda kv: -kv[1])},
