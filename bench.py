@@ -211,7 +211,11 @@ def build_groups(calls, rng, arena):
             add(kind, "hmr_gpu_%s_batch" % kind, N, jb, n * 4 * N * N)
         elif kind in ("quant", "inv_quant"):
             N, comp, intra = a
-            init = (rng.integers(-3000, 3001, n * N * N) // (1 + rng.integers(0, 40, n * N * N))).astype(np.int16)
+            # transform-coefficient statistics: energy falls off with frequency and most blocks are weak (two thirds of the
+            # reference's quant calls produce an all-zero block: inv_quant / quant call ratio of the recorded mix)
+            fall = (1.0 / (1.0 + 0.6 * np.add.outer(np.arange(N), np.arange(N))) ** 1.5).ravel()
+            scale = 1500.0 * rng.random(n) ** 3
+            init = (rng.standard_normal((n, N * N)) * scale[:, None] * fall[None, :]).astype(np.int16).ravel()
             pin = arena.alloc(n * N * N, init if kind == "quant" else (init // 64).astype(np.int16))
             pout = arena.alloc(n * N * N)
             jb = jobs(n)

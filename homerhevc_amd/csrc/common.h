@@ -19,6 +19,7 @@ struct DevTables {
 	uint32_t scan[4][6][32 * 32];   // [scan_mode][log2N] coefficient scan order (mode 0 unused)
 	int32_t quant[4][6][6][32 * 32];   // [log2N-2][list][qp%6]
 	int32_t dequant[4][6][6][32 * 32];
+	uint8_t blk2cg[4][6][64];       // [scan_mode][log2N][4x4 block in raster order] -> index of its coefficient group in scan order
 };
 
 struct hmr_gpu_ctx {
@@ -98,6 +99,14 @@ __device__ __forceinline__ T group_sum(T v)
 #pragma unroll
 	for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, HMR_WAVE);
 	return v;
+}
+// Order LDS traffic between the lanes of ONE wave (the compiler only sees per-lane dependences).  Kernels whose waves own
+// private LDS regions use this instead of __syncthreads(), so waves of a workgroup never wait for each other.
+__device__ __forceinline__ void wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 __device__ __forceinline__ int clip3i(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int sat16i(int v) { return clip3i(v, -32768, 32767); }

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_intra_pred(const hmr_gpu_job *__r
 			const int16_t *a = A + jb.a_off;
 			for (int i = l; i < 4 * N + 1; i += G) adi[i] = a[i];
 		}
-		__syncthreads();
+		wave_sync();
 		const int mode = ok ? (int)jb.p0 : 0;
 		const bool luma = ok && jb.p1 != 0;
 		const bool is_hor = mode >= 2 && mode < 18, is_ver = mode >= 18;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_intra_pred(const hmr_gpu_job *__r
 			for (int i = 1 + l; i <= N; i += G) s += mid[i] + mid[-i];
 		s = group_sum<G>(s);
 		const int dc = ((s + N) / (2 * N)) & 0xff;
-		__syncthreads();
+		wave_sync();
 		if (ok) {
 			int16_t *c = Cc + jb.c_off;
 			const int cs = (int)jb.c_stride;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_intra_pred(const hmr_gpu_job *__r
 				c[(size_t)y * cs + x] = (int16_t)v;
 			}
 		}
-		__syncthreads();
+		wave_sync();
 	}
 }
 
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_intra_refs(const hmr_gpu_job *__r
 				adi[i] = (int16_t)v;
 			}
 		}
-		__syncthreads();
+		wave_sync();
 		if (ok) {
 			int16_t *o = Cc + jb.c_off;
 			for (int i = l; i < total; i += G) o[i] = adi[i];
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_intra_refs(const hmr_gpu_job *__r
 				}
 			}
 		}
-		__syncthreads();
+		wave_sync();
 	}
 }
 

@@ -15,14 +15,6 @@
 
 namespace {
 
-// order LDS traffic between the lanes of one wave (the compiler sees only per-lane dependences)
-__device__ __forceinline__ void wave_sync()
-{
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 __constant__ int16_t cLumaTaps[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}};
 __constant__ int16_t cChromaTaps[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4},
 					  {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};

@@ -2,7 +2,8 @@
 // Reference semantics: hmr_sse42_functions_transform.c:1670,1700 (scalar spec hmr_transform.c:133-587),
 // hmr_sse42_functions_quant.c:34,135 and sign_bit_hidding hmr_quant.c:61.
 //
-// A TU is owned by G = min(64, N*N) lanes of a wave (four 4x4 TUs per wave, one larger TU per wave).  The
+// A TU is owned by G = clamp(N*N/4, 16, 64) lanes of a wave (four 4x4 or 8x8 TUs per wave, one larger TU per wave); waves own
+// private LDS regions and synchronise only with themselves.  The
 // two separable stages go through LDS tiles with a row pitch of N+2 samples (17 dwords for N = 32) so that
 // the "lanes walk rows" reads of stage 1 and the transposed writes are bank-conflict free; the basis
 // matrix sits in LDS once per workgroup.  Integer multiply-accumulate on 16-bit data: VALU, not MFMA
@@ -13,7 +14,8 @@ namespace {
 
 template <int N> struct Geo {
 	static constexpr int E = N * N;
-	static constexpr int G = E < HMR_WAVE ? E : HMR_WAVE;   // lanes per TU
+	// lanes per TU: at least 16 (sign hiding walks 16-coefficient groups with 16 lanes), about 4 coefficients per lane
+	static constexpr int G = E / 4 < 16 ? 16 : (E / 4 < HMR_WAVE ? E / 4 : HMR_WAVE);
 	static constexpr int JPW = HMR_WAVE / G;                 // TUs per wave
 	static constexpr int JPB = JPW * HMR_WAVES_PER_BLOCK;    // TUs per workgroup iteration
 	static constexpr int P = N + 2;                          // LDS row pitch (samples)
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_transform(const hmr_gpu_job *__re
 				sIn[w][sub][y * g::P + x] = a[(size_t)y * jb.a_stride + x];
 			}
 		}
-		__syncthreads();
+		wave_sync();
 		if (ok) {
 			const int16_t *M = sM[(N == 4 && jb.p0) ? 1 : 0];
 			for (int o = l; o < g::E; o += g::G) {     // tmp[k][row] = sum_i M[k][i] * in[row][i]
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_transform(const hmr_gpu_job *__re
 				sTmp[w][sub][k * g::P + row] = (int16_t)sat16i((s + (1 << (sh1 - 1))) >> sh1);
 			}
 		}
-		__syncthreads();
+		wave_sync();
 		if (ok) {
 			const int16_t *M = sM[(N == 4 && jb.p0) ? 1 : 0];
 			int16_t *c = Cc + jb.c_off;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_transform(const hmr_gpu_job *__re
 				c[o] = (int16_t)sat16i((s + (1 << (sh2 - 1))) >> sh2);
 			}
 		}
-		__syncthreads();
+		wave_sync();
 	}
 }
 
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_itransform(const hmr_gpu_job *__r
 			const int16_t *a = A + jb.a_off;
 			for (int e = l; e < g::E; e += g::G) sIn[w][sub][(e / N) * g::P + (e % N)] = a[e];
 		}
-		__syncthreads();
+		wave_sync();
 		if (ok) {
 			const int16_t *M = sM[(N == 4 && jb.p0) ? 1 : 0];
 			for (int o = l; o < g::E; o += g::G) {     // tmp[col][k] = sum_i M[i][k] * coeff[i][col]
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_itransform(const hmr_gpu_job *__r
 				sTmp[w][sub][col * g::P + k] = (int16_t)sat16i((s + 64) >> 7);
 			}
 		}
-		__syncthreads();
+		wave_sync();
 		if (ok) {
 			const int16_t *M = sM[(N == 4 && jb.p0) ? 1 : 0];
 			int16_t *c = Cc + jb.c_off;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_itransform(const hmr_gpu_job *__r
 				c[(size_t)y * jb.c_stride + x] = (int16_t)sat16i((s + 2048) >> 12);
 			}
 		}
-		__syncthreads();
+		wave_sync();
 	}
 }
 
@@ -178,9 +180,9 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_quant(const hmr_gpu_job *__restri
 	__shared__ int16_t sSrc[HMR_WAVES_PER_BLOCK][g::JPW][g::E];
 	__shared__ int16_t sDst[HMR_WAVES_PER_BLOCK][g::JPW][g::E];
 	__shared__ int16_t sDu[HMR_WAVES_PER_BLOCK][g::JPW][g::E];
-	__shared__ int sLastCg[HMR_WAVES_PER_BLOCK][g::JPW];
+	__shared__ unsigned long long sNzMask[HMR_WAVES_PER_BLOCK][g::JPW];   // coefficient groups (scan order) that hold a level
 	const int lane = lane_id(), w = wave_in_block(), sub = lane / g::G, l = lane % g::G;
-	constexpr int NCG = g::E / 16, CG_PER_IT = g::G / 16, ITERS = NCG / CG_PER_IT;
+	constexpr int CG_PER_IT = g::G / 16, SIDE = N / 4;
 	const JobRange jr = xcd_job_range(njobs, g::JPB);
 	for (long base = jr.begin; base < jr.end; base += jr.stride) {
 		const long j = base + w * g::JPW + sub;
@@ -189,18 +191,21 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_quant(const hmr_gpu_job *__restri
 		int ac = 0;
 		bool sbh = false;
 		const uint32_t *scan = tab->scan[3][g::L2];
+		if (l == 0) sNzMask[w][sub] = 0;
+		wave_sync();
 		if (ok) {
 			jb = jobs[j];
 			const int scan_mode = jb.p0 & 3, comp = (jb.p0 >> 2) & 3, is_intra = (jb.p0 >> 4) & 1, slice_i = (jb.p0 >> 5) & 1;
 			const int per = jb.p1 & 0xff, rem = (jb.p1 >> 8) & 0xff;
 			sbh = (jb.p0 >> 6) & 1;
 			const int32_t *q = tab->quant[g::L2 - 2][(is_intra ? 0 : 3) + comp][rem];
+			const uint8_t *b2c = tab->blk2cg[scan_mode][g::L2];
 			scan = tab->scan[scan_mode][g::L2];
 			const int qbits = 14 + per + (7 - g::L2), qbits8 = qbits - 8;
 			const uint32_t add = (uint32_t)(slice_i ? 171 : 85) << (qbits - 9);
 			const int16_t *a = A + jb.a_off;
 			uint32_t sum = 0;
-			if (l == 0) sLastCg[w][sub] = -1;
+			unsigned long long nz = 0;
 			for (int e = l; e < g::E; e += g::G) {
 				const int s = a[e];
 				const uint32_t mag = (uint16_t)(s < 0 ? -s : s);
@@ -209,30 +214,34 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_quant(const hmr_gpu_job *__restri
 				const int d = (int)(aux - ((uint32_t)c << qbits)) >> qbits8;
 				sum += (uint32_t)c;
 				const int sgn = s > 0 ? 1 : (s < 0 ? -1 : 0);
+				const int lv = (int16_t)(sgn * sat16i(c));
 				sSrc[w][sub][e] = (int16_t)s;
-				sDst[w][sub][e] = (int16_t)(sgn * sat16i(c));
+				sDst[w][sub][e] = (int16_t)lv;
 				sDu[w][sub][e] = (int16_t)sat16i(d);
+				if (lv) nz |= 1ull << b2c[((e / N) >> 2) * SIDE + ((e % N) >> 2)];
 			}
 			ac = (int)group_sum<g::G>(sum);
+			if (nz) atomicOr(&sNzMask[w][sub], nz);
 		}
-		__syncthreads();
+		wave_sync();
+		// sign hiding only visits groups that hold a level; CG_PER_IT groups per pass (16 lanes each)
 		const bool run_sbh = ok && sbh && ac >= 2;
-		// which coefficient group is the last one (in scan order) that holds a level
-		for (int it = 0; it < ITERS; it++) {
-			const int cg = it * CG_PER_IT + (l >> 4);
-			const bool nz = run_sbh && sDst[w][sub][scan[cg * 16 + (l & 15)]] != 0;
-			const unsigned long long m = __ballot(nz);
-			if (run_sbh && (l & 15) == 0 && ((m >> (lane & 48)) & 0xffffull)) atomicMax(&sLastCg[w][sub], cg);
-		}
-		__syncthreads();
-		{
-			const int last = ok ? sLastCg[w][sub] : -1;
-			for (int it = 0; it < ITERS; it++) {
-				const int cg = it * CG_PER_IT + (l >> 4);
-				sbh_group16(sDst[w][sub], sSrc[w][sub], sDu[w][sub], scan, cg, cg == last, run_sbh);
+		unsigned long long m = run_sbh ? sNzMask[w][sub] : 0ull;
+		const int last = m ? 63 - __clzll((long long)m) : -1;
+		const int grp = l >> 4;
+		while (__any(m != 0)) {
+			unsigned long long t = m;
+			int cg = -1;
+#pragma unroll
+			for (int k = 0; k < CG_PER_IT; k++) {
+				const int b = t ? __ffsll((long long)t) - 1 : -1;
+				if (k == grp) cg = b;
+				t &= t - 1;
 			}
+			m = t;
+			sbh_group16(sDst[w][sub], sSrc[w][sub], sDu[w][sub], scan, cg < 0 ? 0 : cg, cg == last, run_sbh && cg >= 0);
 		}
-		__syncthreads();
+		wave_sync();
 		if (ok) {
 			int16_t *c = Cc + jb.c_off;
 			for (int e = l; e < g::E; e += g::G) c[e] = sDst[w][sub][e];
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_quant(const hmr_gpu_job *__restri
 			}
 			if (l == 0) ac_out[j] = ac;
 		}
-		__syncthreads();
+		wave_sync();
 	}
 }
 

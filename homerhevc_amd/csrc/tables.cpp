@@ -93,6 +93,15 @@ void build()
 						for (int y = 0; y < 4; y++) V[k++] = (gy * 4 + y) * w + gx * 4 + x;
 		}
 	}
+	// inverse of the scans at coefficient-group granularity (every scan visits whole 4x4 groups)
+	for (int mode = 1; mode <= 3; mode++)
+		for (int l = 2; l <= 5; l++) {
+			const int w = 1 << l, side = w >> 2;
+			for (int cg = 0; cg < side * side; cg++) {
+				const uint32_t pos = t->scan[mode][l][cg * 16];
+				t->blk2cg[mode][l][((pos / w) >> 2) * side + ((pos % w) >> 2)] = (uint8_t)cg;
+			}
+		}
 	// quantiser pyramids: 8x8 lists are up-sampled for 16/32, DC forced to 16 when up-sampled
 	for (int l = 2; l <= 5; l++) {
 		int n = 1 << l, ms = n < 8 ? n : 8, ratio = n / ms;
