@@ -290,6 +290,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--callmix-frame", type=int, default=2, help="which recorded P frame to replay")
+    ap.add_argument("--mode", choices=["eager", "graph"], default="graph",
+                    help="eager: C command list with an event pair around every launch inside the timed region (per-kernel roofline numbers are live); "
+                         "graph: the same command list captured once into a hipGraph and replayed (no per-launch host cost), per-kernel numbers from an eager pass after the timed region")
     ap.add_argument("--launch-order", default=None, help="write the per-step kernel launch order (JSON) for tools/pmc_summary.py")
     args = ap.parse_args()
 
@@ -350,63 +353,51 @@ def main():
     lib, c = ctx.lib, ctx.ctx
     P = C.c_void_p
 
-    def launch(g):
-        jp, n, s, out = P(g["d_jobs"].data_ptr()), len(g["jobs"]), g["size"], P(g["d_out"].data_ptr())
-        fn, b = g["fn"], P(base)
-        if fn in ("hmr_gpu_sad_batch", "hmr_gpu_ssd16b_batch"):
-            rc = getattr(lib, fn)(c, jp, n, s, b, b, out)
-        elif fn in ("hmr_gpu_predict_batch", "hmr_gpu_reconst_batch"):
-            rc = getattr(lib, fn)(c, jp, n, s, b, b, b)
-        elif fn == "hmr_gpu_copy_batch":
-            rc = lib.hmr_gpu_copy_batch(c, jp, n, s << 8, b, b)   # kind 0 (int16) | uniform square size hint
-        elif fn == "hmr_gpu_interpolate_batch":
-            rc = lib.hmr_gpu_interpolate_batch(c, jp, n, s, b, b)
-        elif fn == "hmr_gpu_quant_batch":
-            rc = lib.hmr_gpu_quant_batch(c, jp, n, s, b, b, None, out)
-        else:   # intra_pred, intra_refs, transform, itransform, inv_quant
-            rc = getattr(lib, fn)(c, jp, n, s, b, b)
-        ctx.check(rc, fn)
+    class Cmd(C.Structure):
+        _fields_ = [("op", C.c_int), ("njobs", C.c_int), ("size", C.c_int), ("p", C.c_int * 4), ("jobs", P), ("a", P), ("b", P), ("c", P), ("out", P)]
 
+    OPS = {"hmr_gpu_sad_batch": 1, "hmr_gpu_ssd16b_batch": 2, "hmr_gpu_predict_batch": 3, "hmr_gpu_reconst_batch": 4, "hmr_gpu_copy_batch": 5,
+           "hmr_gpu_intra_pred_batch": 7, "hmr_gpu_intra_refs_batch": 8, "hmr_gpu_interpolate_batch": 9, "hmr_gpu_transform_batch": 11,
+           "hmr_gpu_itransform_batch": 12, "hmr_gpu_quant_batch": 13, "hmr_gpu_inv_quant_batch": 14}
+    OP_EDGE, OP_DEBLOCK, OP_STATS, OP_APPLY, OP_PAD = 17, 18, 19, 20, 21
+    cmds, names = [], []
+    for g in groups:
+        cm = Cmd(op=OPS[g["fn"]], njobs=len(g["jobs"]), size=g["size"], jobs=g["d_jobs"].data_ptr(), a=base, b=base, c=base, out=g["d_out"].data_ptr())
+        if g["fn"] == "hmr_gpu_copy_batch":
+            cm.size = g["size"] << 8            # kind 0 (int16) | uniform square size hint
+        if g["fn"] == "hmr_gpu_quant_batch":
+            cm.b = None                          # deltaU is scratch in the reference; not returned
+        cmds.append(cm)
+        names.append(f"{g['name']}:{g['size']}")
     frame_bytes = {
         "deblock": 2 * 2 * 6144 * n_ctu, "sao_stats": (2 * 2 * 6144 + 5 * 3 * 512) * n_ctu, "sao_apply": 2 * 2 * 6144 * n_ctu,
-        "pad": 2 * 2 * ((W + 2 * PAD) * (H + 2 * PAD) - W * H) * 3 // 2,
+        "pad": 2 * 2 * ((W + 2 * PAD) * (H + 2 * PAD) - W * H) * 3 // 2, "edge_flags": 3 * (W // 4) * (H // 4),
     }
-
-    def frame_passes(rec):
-        ctx.call("hmr_gpu_edge_flags_frame", P(d_info["pred_depth"].data_ptr()), P(d_info["tr_idx"].data_ptr()), W, H, W // 4, P(d_info["flags"].data_ptr()))
-        rec("deblock", 0)
-        ctx.call("hmr_gpu_deblock_frame", C.byref(f_rec), C.byref(units), 2, 2, 0, 0, None, None)
-        rec("deblock", 1)
-        rec("sao_stats", 0)
-        ctx.call("hmr_gpu_sao_stats_frame", C.byref(f_org), C.byref(f_rec), P(d_stats.data_ptr()))
-        rec("sao_stats", 1)
-        rec("sao_apply", 0)
-        ctx.call("hmr_gpu_sao_apply_frame", C.byref(f_rec), C.byref(f_dst), P(d_info["sao_params"].data_ptr()))
-        rec("sao_apply", 1)
-        rec("pad", 0)
-        ctx.call("hmr_gpu_pad_frame", C.byref(f_dst), PAD, PAD)
-        rec("pad", 1)
-
-    names = [f"{g['name']}:{g['size']}" for g in groups] + list(frame_bytes)
-    events = {(i, n): (ctx.event(), ctx.event()) for i in range(args.steps) for n in names}
+    cmds.append(Cmd(op=OP_EDGE, p=(C.c_int * 4)(W, H, W // 4, 0), a=d_info["pred_depth"].data_ptr(), b=d_info["tr_idx"].data_ptr(), c=d_info["flags"].data_ptr()))
+    cmds.append(Cmd(op=OP_DEBLOCK, p=(C.c_int * 4)(2, 2, 0, 0), a=C.addressof(f_rec), b=C.addressof(units)))
+    cmds.append(Cmd(op=OP_STATS, a=C.addressof(f_org), b=C.addressof(f_rec), out=d_stats.data_ptr()))
+    cmds.append(Cmd(op=OP_APPLY, a=C.addressof(f_rec), b=C.addressof(f_dst), c=d_info["sao_params"].data_ptr()))
+    cmds.append(Cmd(op=OP_PAD, p=(C.c_int * 4)(PAD, PAD, 0, 0), a=C.addressof(f_dst)))
+    names += ["edge_flags", "deblock", "sao_stats", "sao_apply", "pad"]
+    cmd_arr = (Cmd * len(cmds))(*cmds)
+    clist = P()
+    ctx.call("hmr_gpu_cmdlist_create", cmd_arr, len(cmds), C.byref(clist))
+    n_cmd = len(cmds)
+    # one event pair per command and timed step
+    ev = [(P * (2 * n_cmd))(*[ctx.event().value for _ in range(2 * n_cmd)]) for _ in range(args.steps)]
 
     def step(idx, timed):
-        def rec(name, which):
-            if timed:
-                ctx.record(events[(idx, name)][which])
         # reconstructed reference picture: engine r -> engine r+1, point-to-point over RCCL/xGMI
         reqs = exchange_reference(dst_pl, nxt_pl, rank, world)
-        for g in groups:
-            name = f"{g['name']}:{g['size']}"
-            rec(name, 0)
-            launch(g)
-            rec(name, 1)
-        frame_passes(rec)
+        if args.mode == "graph":
+            ctx.call("hmr_gpu_cmdlist_replay", clist)
+        else:
+            ctx.call("hmr_gpu_cmdlist_run", clist, ev[idx] if timed else None)
         for r in reqs:
             r.wait()
 
     if args.launch_order and rank == 0:
-        order = [f"{g['name']}:{g['size']}" for g in groups] + ["edge_flags", "deblock", "deblock", "sao_stats", "sao_apply", "pad", "pad", "pad"]
+        order = [f"{g['name']}:{g['size']}" for g in groups] + ["edge_flags", "deblock", "deblock", "sao_stats", "sao_apply", "pad", "pad", "pad"]   # kernels, not commands
         with open(args.launch_order, "w") as f:
             json.dump(order, f)
 
@@ -431,10 +422,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel durations from the events recorded inside the timed region
+    # per-kernel durations from the event pairs around every command
+    if args.mode == "graph":      # the graph has no event nodes: one eager pass of the same steps right after the timed region
+        with torch.cuda.stream(stream):
+            for i in range(args.steps):
+                ctx.call("hmr_gpu_cmdlist_run", clist, ev[i])
+            torch.cuda.synchronize()
     per = {n: 0.0 for n in names}
-    for (idx, name), (e0, e1) in events.items():
-        per[name] += ctx.elapsed(e0, e1)
+    for i in range(args.steps):
+        for k, n in enumerate(names):
+            per[n] += ctx.elapsed(P(ev[i][2 * k]), P(ev[i][2 * k + 1]))
     per = {k: v / args.steps for k, v in per.items()}
     nbytes = {f"{g['name']}:{g['size']}": g["bytes"] for g in groups}
     nbytes.update(frame_bytes)
@@ -457,10 +454,13 @@ def main():
             "dtype": "int16", "data": "synthetic",
             "config": {"workload": "cfg2-1080p-P-frame-replay", "width": W, "height": H, "qp": 32, "gop": "IPPP gop_size=1", "me": "quarter-pel", "sao": 1,
                        "calls_per_frame": int(sum(len(g["jobs"]) for g in groups)), "launches_per_frame": len(groups) + 8,
-                       "callmix_frame": args.callmix_frame, "parallelism": f"engine-per-gpu x{world}",
+                       "callmix_frame": args.callmix_frame, "parallelism": f"engine-per-gpu x{world}", "launch_mode": args.mode,
                        "algorithmic_MB_per_frame_abi_width": round(total_alg / 1e6, 2), "compulsory_MB_per_frame": round(10.5 * W * H / 1e6, 2)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "timing": ("HIP event pairs around every launch inside the timed region" if args.mode == "eager" else
+                                    "HIP event pairs around every launch, eager replay of the same K steps right after the timed graph replays "
+                                    "(event nodes inside a hipGraph cannot be read back on ROCm 7.2)"),
                          "bytes_per_launch": int(nbytes[dom]), "ms_per_launch": round(per[dom], 5),
                          "frame_level_frac": round(10.5 * W * H * fps / world / 1e9 / HBM_PEAK_GBS, 6)},
             "kernels_ms": {k: round(v, 4) for k, v in sorted(per.items(), key=lambda kv: -kv[1])},

@@ -1,0 +1,98 @@
+// Command lists: the host describes one frame's launches once (kernel, job array, bases) and replays them from C, optionally
+// bracketing every command with an event pair (per-kernel timing) or capturing the whole list into a hipGraph - a frame is a
+// fixed launch sequence, so graph replay removes the per-launch host cost and the inter-kernel gaps.
+#include <vector>
+
+#include "common.h"
+
+struct hmr_gpu_cmdlist {
+	std::vector<hmr_gpu_cmd> cmds;
+	hipGraph_t graph = nullptr;
+	hipGraphExec_t exec = nullptr;
+};
+
+static int run_one(hmr_gpu_ctx *ctx, const hmr_gpu_cmd &c)
+{
+	const hmr_gpu_job *jobs = (const hmr_gpu_job *)c.jobs;
+	const int16_t *a = (const int16_t *)c.a, *b = (const int16_t *)c.b;
+	int16_t *o = (int16_t *)c.c;
+	switch (c.op) {
+	case HMR_GPU_OP_SAD: return hmr_gpu_sad_batch(ctx, jobs, c.njobs, c.size, a, b, (uint32_t *)c.out);
+	case HMR_GPU_OP_SSD16B: return hmr_gpu_ssd16b_batch(ctx, jobs, c.njobs, c.size, a, b, (uint32_t *)c.out);
+	case HMR_GPU_OP_PREDICT: return hmr_gpu_predict_batch(ctx, jobs, c.njobs, c.size, a, b, o);
+	case HMR_GPU_OP_RECONST: return hmr_gpu_reconst_batch(ctx, jobs, c.njobs, c.size, a, b, o);
+	case HMR_GPU_OP_COPY: return hmr_gpu_copy_batch(ctx, jobs, c.njobs, c.size, c.a, c.c);
+	case HMR_GPU_OP_VARIANCE: return hmr_gpu_modified_variance_batch(ctx, jobs, c.njobs, c.size, a, (uint32_t *)c.out);
+	case HMR_GPU_OP_INTRA_PRED: return hmr_gpu_intra_pred_batch(ctx, jobs, c.njobs, c.size, a, o);
+	case HMR_GPU_OP_INTRA_REFS: return hmr_gpu_intra_refs_batch(ctx, jobs, c.njobs, c.size, a, o);
+	case HMR_GPU_OP_INTERPOLATE: return hmr_gpu_interpolate_batch(ctx, jobs, c.njobs, c.size, a, o);
+	case HMR_GPU_OP_WAVG: return hmr_gpu_weighted_average_batch(ctx, jobs, c.njobs, a, b, o);
+	case HMR_GPU_OP_TRANSFORM: return hmr_gpu_transform_batch(ctx, jobs, c.njobs, c.size, a, o);
+	case HMR_GPU_OP_ITRANSFORM: return hmr_gpu_itransform_batch(ctx, jobs, c.njobs, c.size, a, o);
+	case HMR_GPU_OP_QUANT: return hmr_gpu_quant_batch(ctx, jobs, c.njobs, c.size, a, o, (int16_t *)c.b, (int32_t *)c.out);
+	case HMR_GPU_OP_INV_QUANT: return hmr_gpu_inv_quant_batch(ctx, jobs, c.njobs, c.size, a, o);
+	case HMR_GPU_OP_MC: return hmr_gpu_mc_batch(ctx, jobs, c.njobs, c.size & 1, (c.size >> 1) & 1, a, o);
+	case HMR_GPU_OP_ME:
+		return hmr_gpu_motion_estimation_batch(ctx, (const hmr_gpu_me_job *)c.jobs, c.njobs, c.size, a, b, c.p[0], c.p[1], c.p[2], c.p[3], (hmr_gpu_me_result *)c.out);
+	case HMR_GPU_OP_EDGE_FLAGS: return hmr_gpu_edge_flags_frame(ctx, (const uint8_t *)c.a, (const uint8_t *)c.b, c.p[0], c.p[1], c.p[2], (uint8_t *)c.c);
+	case HMR_GPU_OP_DEBLOCK: return hmr_gpu_deblock_frame(ctx, (const hmr_gpu_frame *)c.a, (const hmr_gpu_units *)c.b, c.p[0], c.p[1], c.p[2], c.p[3], nullptr, nullptr);
+	case HMR_GPU_OP_SAO_STATS: return hmr_gpu_sao_stats_frame(ctx, (const hmr_gpu_frame *)c.a, (const hmr_gpu_frame *)c.b, (int32_t *)c.out);
+	case HMR_GPU_OP_SAO_APPLY: return hmr_gpu_sao_apply_frame(ctx, (const hmr_gpu_frame *)c.a, (const hmr_gpu_frame *)c.b, (const int32_t *)c.c);
+	case HMR_GPU_OP_PAD: return hmr_gpu_pad_frame(ctx, (const hmr_gpu_frame *)c.a, c.p[0], c.p[1]);
+	default: hmr_set_error("command list: unknown op %d", c.op); return HMR_GPU_ERR_ARG;
+	}
+}
+
+extern "C" int hmr_gpu_cmdlist_create(hmr_gpu_ctx *ctx, const hmr_gpu_cmd *cmds, int n, hmr_gpu_cmdlist **out)
+{
+	(void)ctx;
+	if (!cmds || n <= 0 || !out) return HMR_GPU_ERR_ARG;
+	hmr_gpu_cmdlist *l = new hmr_gpu_cmdlist;
+	l->cmds.assign(cmds, cmds + n);
+	*out = l;
+	return HMR_GPU_OK;
+}
+
+extern "C" int hmr_gpu_cmdlist_run(hmr_gpu_ctx *ctx, hmr_gpu_cmdlist *l, void **event_pairs)
+{
+	for (size_t i = 0; i < l->cmds.size(); i++) {
+		if (event_pairs) HIP_TRY(hipEventRecord((hipEvent_t)event_pairs[2 * i], ctx->stream));
+		const int rc = run_one(ctx, l->cmds[i]);
+		if (rc != HMR_GPU_OK) return rc;
+		if (event_pairs) HIP_TRY(hipEventRecord((hipEvent_t)event_pairs[2 * i + 1], ctx->stream));
+	}
+	return HMR_GPU_OK;
+}
+
+// (event-record nodes inside a captured graph cannot be read back with hipEventElapsedTime on ROCm 7.2 - "invalid resource
+// handle" - so per-kernel timing uses hmr_gpu_cmdlist_run with event pairs instead)
+extern "C" int hmr_gpu_cmdlist_capture(hmr_gpu_ctx *ctx, hmr_gpu_cmdlist *l)
+{
+	if (l->exec) return HMR_GPU_OK;
+	HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+	int rc = HMR_GPU_OK;
+	for (size_t i = 0; i < l->cmds.size() && rc == HMR_GPU_OK; i++) rc = run_one(ctx, l->cmds[i]);
+	hipError_t e = hipStreamEndCapture(ctx->stream, &l->graph);
+	if (rc != HMR_GPU_OK) return rc;
+	if (e != hipSuccess) { hmr_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return HMR_GPU_ERR_HIP; }
+	HIP_TRY(hipGraphInstantiate(&l->exec, l->graph, nullptr, nullptr, 0));
+	return HMR_GPU_OK;
+}
+
+extern "C" int hmr_gpu_cmdlist_replay(hmr_gpu_ctx *ctx, hmr_gpu_cmdlist *l)
+{
+	if (!l->exec) {
+		const int rc = hmr_gpu_cmdlist_capture(ctx, l);
+		if (rc != HMR_GPU_OK) return rc;
+	}
+	HIP_TRY(hipGraphLaunch(l->exec, ctx->stream));
+	return HMR_GPU_OK;
+}
+
+extern "C" void hmr_gpu_cmdlist_destroy(hmr_gpu_cmdlist *l)
+{
+	if (!l) return;
+	if (l->exec) (void)hipGraphExecDestroy(l->exec);
+	if (l->graph) (void)hipGraphDestroy(l->graph);
+	delete l;
+}

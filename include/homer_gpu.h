@@ -241,6 +241,34 @@ uint32_t hmr_gpu_motion_estimation(int16_t *orig, int orig_stride, int16_t *ref,
 void hmr_gpu_mc_luma(int16_t *ref, int ref_stride, int16_t *pred, int pred_stride, int width, int height, int mvx, int mvy, int is_bi);
 void hmr_gpu_mc_chroma(int16_t *ref, int ref_stride, int16_t *pred, int pred_stride, int size, int mvx, int mvy, int is_bi);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * 6. command lists: one frame's launches described once, replayed from C (optionally as a hipGraph)
+ * ------------------------------------------------------------------------------------------------ */
+enum hmr_gpu_op {
+	HMR_GPU_OP_SAD = 1, HMR_GPU_OP_SSD16B, HMR_GPU_OP_PREDICT, HMR_GPU_OP_RECONST, HMR_GPU_OP_COPY, HMR_GPU_OP_VARIANCE, HMR_GPU_OP_INTRA_PRED,
+	HMR_GPU_OP_INTRA_REFS, HMR_GPU_OP_INTERPOLATE, HMR_GPU_OP_WAVG, HMR_GPU_OP_TRANSFORM, HMR_GPU_OP_ITRANSFORM, HMR_GPU_OP_QUANT,
+	HMR_GPU_OP_INV_QUANT, HMR_GPU_OP_MC, HMR_GPU_OP_ME, HMR_GPU_OP_EDGE_FLAGS, HMR_GPU_OP_DEBLOCK, HMR_GPU_OP_SAO_STATS, HMR_GPU_OP_SAO_APPLY, HMR_GPU_OP_PAD
+};
+/* One call of the batched / frame-level API: `size` is that entry's size/kind/flags argument, a/b/c/out its pointer arguments in
+ * declaration order (frame-level ops take host pointers to hmr_gpu_frame / hmr_gpu_units that must outlive the list), p[] its
+ * scalar arguments (deblock: cb, cr, beta, tc offsets; pad: pad_x, pad_y; edge flags: width, height, units_stride; ME: range_x,
+ * range_y, frame_w, frame_h).  QUANT: b = deltaU base (may be NULL), out = ac_sum. */
+typedef struct hmr_gpu_cmd {
+	int op, njobs, size;
+	int p[4];
+	const void *jobs, *a, *b;
+	void *c, *out;
+} hmr_gpu_cmd;
+typedef struct hmr_gpu_cmdlist hmr_gpu_cmdlist;
+int hmr_gpu_cmdlist_create(hmr_gpu_ctx *ctx, const hmr_gpu_cmd *cmds, int n, hmr_gpu_cmdlist **out);
+/* eager replay; event_pairs (optional, 2*n events from hmr_gpu_event_create) brackets every command for per-kernel timing */
+int hmr_gpu_cmdlist_run(hmr_gpu_ctx *ctx, hmr_gpu_cmdlist *list, void **event_pairs);
+/* capture the list into a hipGraph once, then launch the graph (a frame is a fixed launch sequence) */
+int hmr_gpu_cmdlist_capture(hmr_gpu_ctx *ctx, hmr_gpu_cmdlist *list);
+int hmr_gpu_cmdlist_replay(hmr_gpu_ctx *ctx, hmr_gpu_cmdlist *list);
+void hmr_gpu_cmdlist_destroy(hmr_gpu_cmdlist *list);
+
 #ifdef __cplusplus
 }
 #endif
