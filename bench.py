@@ -67,36 +67,49 @@ def build_groups(calls, rng, arena):
     """Turn the recorded call mix into batched launches.  Returns list of dict(name, fn, size, jobs, args, bytes)."""
     from homerhevc_amd.gpu import JOB_DTYPE
 
-    plane = W * HA
+    # Data layout follows the reference (SURVEY.md §8 header, hmr_encoder_lib.c:1343-1395): per-CTU working windows - source CTU
+    # (curr_mbs_wnd), prediction, residual, reconstruction at pitch 64, sub-pel / intermediate windows at pitch 80 - plus the
+    # picture-sized padded reference frame.  Every job of CTU k works inside CTU k's windows, so the working set of a batch
+    # walks the picture exactly like the encoder does.
+    NCX, NCY = W // 64, HA // 64
+    NCTU = NCX * NCY
     pix = lambda n: rng.integers(0, 256, n).astype(np.int16)   # noqa: E731
-    src = arena.alloc(plane, pix(plane))
     ref = arena.alloc(REF_STRIDE * (HA + 2 * PAD), pix(REF_STRIDE * (HA + 2 * PAD)))
     ref0 = ref + PAD * REF_STRIDE + PAD
-    pred = arena.alloc(plane, pix(plane))
-    res = arena.alloc(plane, rng.integers(-255, 256, plane).astype(np.int16))
-    rec = arena.alloc(plane, pix(plane))
-    tmp = arena.alloc(plane + 16 * W, rng.integers(-8192, 8129, plane + 16 * W).astype(np.int16))   # first-stage interpolation output
-    out2 = arena.alloc(plane + 16 * W)
+    recf = arena.alloc(REF_STRIDE * (HA + 2 * PAD), pix(REF_STRIDE * (HA + 2 * PAD)))   # frame being reconstructed (intra neighbours)
+    recf0 = recf + PAD * REF_STRIDE + PAD
+    P64, P80 = 64 * 64, 80 * 80
+    srcw = arena.alloc(NCTU * P64, pix(NCTU * P64))
+    predw = arena.alloc(NCTU * P64, pix(NCTU * P64))
+    resw = arena.alloc(NCTU * P64, rng.integers(-255, 256, NCTU * P64).astype(np.int16))
+    recw = arena.alloc(NCTU * P64, pix(NCTU * P64))
+    tmpw = arena.alloc(NCTU * P80, rng.integers(-8192, 8129, NCTU * P80).astype(np.int16))   # first-stage interpolation output
+    outw = arena.alloc(NCTU * P80)
     zero_row = arena.alloc(64, np.zeros(64, np.int16))
-
-    NCX, NCY = W // 64, HA // 64
     cur_ctu = [None]
 
-    def pos(n, bw, bh, stride, align=1, x_lo=0, y_lo=0, x_hi=W, y_hi=HA):
-        """Job i works inside CTU (i * n_ctus) // n - the reference walks the picture CTU by CTU, so consecutive jobs of a
-        batch touch the same 64x64 neighbourhood.  A non-zero x_lo/y_lo widens the window (motion search / filter taps)."""
-        ctu = (np.arange(n, dtype=np.int64) * (NCX * NCY)) // max(n, 1)
-        cur_ctu[0] = ctu
-        cx, cy = ctu % NCX, ctu // NCX
-        rx, ry = max(64 - bw, 0) - 2 * x_lo, max(64 - bh, 0) - 2 * y_lo      # x_lo/y_lo <= 0
-        x = cx * 64 + x_lo + rng.integers(0, rx // align + 1, n) * align
-        y = cy * 64 + y_lo + rng.integers(0, ry // align + 1, n) * align
-        x = np.clip(x, x_lo, x_hi - bw)
-        y = np.clip(y, y_lo, y_hi - bh)
-        if align > 1:
-            x -= x % align
-            y -= y % align
-        return (y * stride + x).astype(np.int64)
+    def ctus(n):
+        c = (np.arange(n, dtype=np.int64) * NCTU) // max(n, 1)
+        cur_ctu[0] = c
+        return c
+
+    def wnd(n, base, pitch, bw, bh, align=1, ctu=None):
+        """element offsets of an aligned bw x bh block inside the job's CTU window"""
+        c = ctus(n) if ctu is None else ctu
+        span = pitch                                   # windows are pitch x pitch
+        x = rng.integers(0, max(span - bw, 0) // align + 1, n) * align
+        y = rng.integers(0, max(span - bh, 0) // align + 1, n) * align
+        return (base + c * (pitch * pitch) + y * pitch + x).astype(np.int64)
+
+    def frame(n, base0, bw, bh, lo_x, lo_y, ctu=None):
+        """element offsets inside a picture-sized padded frame, within [lo, 64 - lo) of the job's CTU (search window / neighbours)"""
+        c = ctus(n) if ctu is None else ctu
+        cx, cy = c % NCX, c // NCX
+        x = cx * 64 + lo_x + rng.integers(0, max(64 - bw, 0) - 2 * lo_x + 1, n)
+        y = cy * 64 + lo_y + rng.integers(0, max(64 - bh, 0) - 2 * lo_y + 1, n)
+        x = np.clip(x, -64, W + 64 - bw)
+        y = np.clip(y, -64, HA + 64 - bh)
+        return (base0 + y * REF_STRIDE + x).astype(np.int64)
 
     def jobs(n):
         return np.zeros(n, JOB_DTYPE)
@@ -120,42 +133,48 @@ def build_groups(calls, rng, arena):
         if kind in ("sad", "sad_direct"):
             N = a[0]
             jb = jobs(n)
-            jb["a_off"] = src + pos(n, N, N, W, align=min(N, 8)); jb["a_stride"] = W
-            jb["b_off"] = ref0 + pos(n, N, N, REF_STRIDE, 1, -32, -16, W + 64, HA + 32); jb["b_stride"] = REF_STRIDE
+            c = ctus(n)
+            jb["a_off"] = wnd(n, srcw, 64, N, N, align=min(N, 8), ctu=c); jb["a_stride"] = 64
+            if kind == "sad" or True:
+                jb["b_off"] = frame(n, ref0, N, N, -32, -16, ctu=c); jb["b_stride"] = REF_STRIDE   # candidate block in the search window
             add("sad", "hmr_gpu_sad_batch", N, jb, n * (4 * N * N + 4))
         elif kind == "ssd16b":
             N, z = a
             jb = jobs(n)
-            jb["a_off"] = src + pos(n, N, N, W, align=min(N, 8)); jb["a_stride"] = W
+            c = ctus(n)
+            jb["a_off"] = wnd(n, srcw, 64, N, N, align=min(N, 8), ctu=c); jb["a_stride"] = 64
             if z:
                 jb["b_off"] = zero_row; jb["b_stride"] = 0
             else:
-                jb["b_off"] = rec + pos(n, N, N, W, align=min(N, 8)); jb["b_stride"] = W
+                jb["b_off"] = wnd(n, recw, 64, N, N, align=min(N, 8), ctu=c); jb["b_stride"] = 64
             add("ssd16b", "hmr_gpu_ssd16b_batch", N, jb, n * (4 * N * N + 4))
         elif kind == "predict":
             N = a[0]
             jb = jobs(n)
-            jb["a_off"] = src + pos(n, N, N, W, align=N); jb["a_stride"] = W
-            jb["b_off"] = pred + pos(n, N, N, W, align=N); jb["b_stride"] = W
-            jb["c_off"] = res + pos(n, N, N, W, align=N); jb["c_stride"] = W
+            c = ctus(n)
+            jb["a_off"] = wnd(n, srcw, 64, N, N, align=N, ctu=c); jb["a_stride"] = 64
+            jb["b_off"] = wnd(n, predw, 64, N, N, align=N, ctu=c); jb["b_stride"] = 64
+            jb["c_off"] = wnd(n, resw, 64, N, N, align=N, ctu=c); jb["c_stride"] = 64
             add("predict", "hmr_gpu_predict_batch", N, jb, n * 6 * N * N)
         elif kind == "reconst":
             N, z = a
             jb = jobs(n)
-            jb["a_off"] = pred + pos(n, N, N, W, align=N); jb["a_stride"] = W
+            c = ctus(n)
+            jb["a_off"] = wnd(n, predw, 64, N, N, align=N, ctu=c); jb["a_stride"] = 64
             if z:
                 jb["b_off"] = zero_row; jb["b_stride"] = 0
             else:
-                jb["b_off"] = res + pos(n, N, N, W, align=N); jb["b_stride"] = W
-            jb["c_off"] = rec + pos(n, N, N, W, align=N); jb["c_stride"] = W
+                jb["b_off"] = wnd(n, resw, 64, N, N, align=N, ctu=c); jb["b_stride"] = 64
+            jb["c_off"] = wnd(n, recw, 64, N, N, align=N, ctu=c); jb["c_stride"] = 64
             add("reconst", "hmr_gpu_reconst_batch", N, jb, n * 6 * N * N)
         elif kind == "copy_16_16":
             h, w = a
             if w > W:
                 continue   # whole-picture copies of the input path (3 per frame) are host-side I/O
             jb = jobs(n)
-            jb["a_off"] = rec + pos(n, w, h, W, align=min(w, 8)); jb["a_stride"] = W
-            jb["c_off"] = out2 + pos(n, w, h, W, align=min(w, 8)); jb["c_stride"] = W
+            c = ctus(n)
+            jb["a_off"] = wnd(n, recw, 64, w, h, align=min(w, 8), ctu=c); jb["a_stride"] = 64
+            jb["c_off"] = wnd(n, outw, 80, w, h, align=min(w, 8), ctu=c); jb["c_stride"] = 80
             jb["w"] = w; jb["h"] = h
             add("copy_16_16", "hmr_gpu_copy_batch", w if (h == w and w in (4, 8, 16, 32, 64)) else 0, jb, n * 4 * h * w)
         elif kind in ("intra_planar", "intra_angular"):
@@ -164,14 +183,14 @@ def build_groups(calls, rng, arena):
             pool = arena.alloc(n * (4 * N + 1), pix(n * (4 * N + 1)))
             jb = jobs(n)
             jb["a_off"] = pool + np.arange(n, dtype=np.int64) * (4 * N + 1)
-            jb["c_off"] = pred + pos(n, N, N, W, align=N); jb["c_stride"] = W
+            jb["c_off"] = wnd(n, predw, 64, N, N, align=N); jb["c_stride"] = 64
             jb["p0"] = mode; jb["p1"] = luma
             add("intra_pred", "hmr_gpu_intra_pred_batch", N, jb, n * (2 * (4 * N + 1) + 2 * N * N))
         elif kind == "fill_reference_samples":
             N, chroma, filt = a
             pool = arena.alloc(2 * n * (4 * N + 1))
             jb = jobs(n)
-            jb["a_off"] = rec + pos(n, 2 * N + 1, 2 * N + 1, W, align=1); jb["a_stride"] = W
+            jb["a_off"] = frame(n, recf0, 2 * N + 1, 2 * N + 1, -1, -1); jb["a_stride"] = REF_STRIDE   # neighbours in the frame under reconstruction
             jb["c_off"] = pool + np.arange(n, dtype=np.int64) * 2 * (4 * N + 1)
             jb["b_off"] = jb["c_off"] + (4 * N + 1)
             avail = rng.integers(0, 16, n)     # left/top/bl/tr mix; bl implies left, tr implies top
@@ -185,11 +204,12 @@ def build_groups(calls, rng, arena):
             luma = kind == "interp_luma"
             taps = 8 if luma else 4
             jb = jobs(n)
+            c = ctus(n)
             if first:
-                jb["a_off"] = ref0 + pos(n, w + 8, h + 8, REF_STRIDE, 1, -24, -12, W + 56, HA + 24); jb["a_stride"] = REF_STRIDE
+                jb["a_off"] = frame(n, ref0, w + 8, h + 8, -24, -12, ctu=c); jb["a_stride"] = REF_STRIDE
             else:
-                jb["a_off"] = tmp + 4 * W + pos(n, w + 8, h + 8, W, 1); jb["a_stride"] = W
-            jb["c_off"] = out2 + pos(n, w, h, W, align=1); jb["c_stride"] = W
+                jb["a_off"] = wnd(n, tmpw, 80, min(w + 8, 80), min(h + 8, 76), ctu=c) + 4 * 80 + 4; jb["a_stride"] = 80
+            jb["c_off"] = wnd(n, outw, 80, w, h, ctu=c); jb["c_stride"] = 80
             jb["w"] = w; jb["h"] = h
             jb["p0"] = rng.integers(1, 4 if luma else 8, n) if frac_nz else 0
             jb["p1"] = vert | (first << 1) | (last << 2)
@@ -202,11 +222,11 @@ def build_groups(calls, rng, arena):
             pool = arena.alloc(n * N * N, rng.integers(-200, 201, n * N * N).astype(np.int16) if kind == "itransform" else None)
             jb = jobs(n)
             lin = pool + np.arange(n, dtype=np.int64) * N * N
-            blk = res + pos(n, N, N, W, align=N)
+            blk = wnd(n, resw, 64, N, N, align=N)
             if kind == "transform":
-                jb["a_off"] = blk; jb["a_stride"] = W; jb["c_off"] = lin
+                jb["a_off"] = blk; jb["a_stride"] = 64; jb["c_off"] = lin
             else:
-                jb["a_off"] = lin; jb["c_off"] = blk; jb["c_stride"] = W
+                jb["a_off"] = lin; jb["c_off"] = blk; jb["c_stride"] = 64
             jb["p0"] = is_dst
             add(kind, "hmr_gpu_%s_batch" % kind, N, jb, n * 4 * N * N)
         elif kind in ("quant", "inv_quant"):
@@ -218,6 +238,7 @@ def build_groups(calls, rng, arena):
             init = (rng.standard_normal((n, N * N)) * scale[:, None] * fall[None, :]).astype(np.int16).ravel()
             pin = arena.alloc(n * N * N, init if kind == "quant" else (init // 64).astype(np.int16))
             pout = arena.alloc(n * N * N)
+            ctus(n)
             jb = jobs(n)
             jb["a_off"] = pin + np.arange(n, dtype=np.int64) * N * N
             jb["c_off"] = pout + np.arange(n, dtype=np.int64) * N * N
@@ -229,7 +250,7 @@ def build_groups(calls, rng, arena):
     for g in merged.values():      # a batch is issued in CTU order, like the host would enumerate it
         order = np.argsort(g["ctu"], kind="stable")
         g["jobs"] = np.ascontiguousarray(g["jobs"][order])
-    return list(merged.values()), {"src": src, "ref0": ref0, "rec": rec}
+    return list(merged.values()), {"ref0": ref0}
 
 
 def frame_side_info(rng):
