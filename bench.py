@@ -214,8 +214,8 @@ def build_groups(calls, rng, arena):
             jb["p0"] = rng.integers(1, 4 if luma else 8, n) if frac_nz else 0
             jb["p1"] = vert | (first << 1) | (last << 2)
             rd = (w * (h + taps - 1) if vert else (w + taps - 1) * h) if frac_nz else w * h
-            chunks = ((w + 3) // 4) * h
-            lanes = 16 if chunks <= 16 else (32 if chunks <= 32 else 64)
+            items = ((w + 3) // 4) * ((h + 3) // 4) if (vert and frac_nz) else (((w + 7) // 8) * h if frac_nz else ((w + 3) // 4) * h)
+            lanes = next(g for g in (4, 8, 16, 32, 64) if items <= g or g == 64)
             add(kind, "hmr_gpu_interpolate_batch", (1 if luma else 0) | (lanes << 8), jb, n * 2 * (rd + w * h))
         elif kind in ("transform", "itransform"):
             N, is_dst = a

@@ -147,8 +147,9 @@ int hmr_gpu_intra_pred_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njob
  * p0 bits: 0 left, 1 top, 2 bottom_left, 3 top_right, 4 write filtered copy, 5 strong filter enabled; p1 = bl_size | tr_size << 16 */
 int hmr_gpu_intra_refs_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a_base, int16_t *c_base);
 /* a = reference/intermediate, c = out, w/h = extent; p0 = fraction, p1 bits: 0 vertical, 1 first, 2 last.
- * flags bit 0: luma (8 taps) / chroma (4 taps); bits 8..15: lanes-per-job hint 16 / 32 / 64 (0 = 64) - a job of
- * ceil(w/4)*h four-sample chunks is walked by that many lanes, so batches of small blocks should pass 16 or 32. */
+ * flags bit 0: luma (8 taps) / chroma (4 taps); bits 8..15: lanes-per-job hint 4 / 8 / 16 / 32 / 64 (0 = 64).  A job is
+ * ceil(w/4)*ceil(h/4) work items when vertical (4x4 outputs from a register window of rows) or ceil(w/8)*h when
+ * horizontal (8 outputs per item); that many lanes share it, so batches of small blocks should pass a small hint. */
 int hmr_gpu_interpolate_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int flags, const int16_t *a_base, int16_t *c_base);
 int hmr_gpu_weighted_average_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, const int16_t *a_base, const int16_t *b_base, int16_t *c_base);
 /* a = residual block (strided), c = coefficients (linear size*size at c_off); p0 = is_dst */
