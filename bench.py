@@ -63,7 +63,7 @@ class Arena:
         return off
 
 
-def build_groups(calls, rng, arena):
+def build_groups(calls, rng, arena, fused=True):
     """Turn the recorded call mix into batched launches.  Returns list of dict(name, fn, size, jobs, args, bytes)."""
     from homerhevc_amd.gpu import JOB_DTYPE
 
@@ -247,6 +247,63 @@ def build_groups(calls, rng, arena):
             add(kind, "hmr_gpu_%s_batch" % kind, N, jb, n * 4 * N * N)
         # half_pel_planes / quarter_pel_planes are drivers whose interpolation calls are already counted;
         # deblock_ctu / sao_* / pad_ctu are issued as the frame-level passes below.
+    if fused:
+        # The per-TU sequence predict -> transform -> quant -> [inv_quant -> itransform] -> reconst -> ssd16b (encode_intra_cu /
+        # encode_inter_cu) is issued as ONE fused launch per TU size.  Counts come from the recorded mix: one chain per quant call;
+        # the share of coded TUs is the recorded inv_quant / quant ratio; ssd16b calls beyond the chains stay separate jobs.
+        TU_DTYPE = np.dtype([("orig_off", "<u4"), ("orig_stride", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("rec_off", "<u4"),
+                             ("rec_stride", "<u4"), ("lev_off", "<u4"), ("p0", "<u4"), ("p1", "<u4")])
+        tot = lambda prefix, N: sum(v for k, v in calls.items() if k.split(":")[0] == prefix and int(k.split(":")[1]) == N)   # noqa: E731
+        # prediction window = source window, plus strong noise in its lower half: TUs placed there are coded, TUs in the upper half are not
+        noise = np.zeros((NCTU, 64, 64), np.int64)
+        noise[:, 32:, :] = rng.integers(-40, 41, (NCTU, 32, 64))
+        src_init = next(d for o, d in arena.init if o == srcw)
+        pred_fused = arena.alloc(NCTU * P64, np.clip(src_init.reshape(NCTU, 64, 64) + noise, 0, 255).astype(np.int16).ravel())
+        for N in (4, 8, 16, 32):
+            nq = tot("quant", N)
+            if not nq:
+                continue
+            assert nq == tot("predict", N) == tot("transform", N) == tot("reconst", N), (N, nq, tot("predict", N), tot("transform", N), tot("reconst", N))
+            coded_frac = tot("inv_quant", N) / nq
+            parts = []
+            for key, n in sorted(calls.items()):
+                kp = key.split(":")
+                if kp[0] != "quant" or int(kp[1]) != N:
+                    continue
+                comp, intra = int(kp[2]), int(kp[3])
+                jb = np.zeros(n, TU_DTYPE)
+                c = ctus(n)
+                coded = rng.random(n) < coded_frac
+                half = max(32 - N, 0) // N + 1
+                x = rng.integers(0, (64 - N) // N + 1, n) * N
+                y = rng.integers(0, half, n) * N + np.where(coded, 32 if N < 64 else 0, 0)
+                y = np.minimum(y, 64 - N)
+                pos_in = c * P64 + y * 64 + x
+                jb["orig_off"] = srcw + pos_in; jb["orig_stride"] = 64
+                jb["pred_off"] = pred_fused + pos_in; jb["pred_stride"] = 64
+                jb["rec_off"] = recw + pos_in; jb["rec_stride"] = 64
+                jb["p0"] = 3 | (comp << 2) | (intra << 4) | (0 << 5) | (1 << 6) | ((1 if (N == 4 and comp == 0 and intra) else 0) << 7)
+                jb["p1"] = 5 | (2 << 8)
+                parts.append((jb, c))
+            jobs_all = np.concatenate([p[0] for p in parts])
+            ctu_all = np.concatenate([p[1] for p in parts])
+            lev_pool = arena.alloc(len(jobs_all) * N * N)
+            jobs_all["lev_off"] = lev_pool + np.arange(len(jobs_all), dtype=np.int64) * N * N
+            # algorithmic bytes of the seven calls the chain stands for (ABI width)
+            n_coded = tot("inv_quant", N)
+            nbytes = nq * (6 + 4 + 4 + 6 + 4) * N * N + n_coded * (4 + 4) * N * N
+            merged[("tu_chain", N)] = {"name": "tu_chain", "fn": "hmr_gpu_tu_chain_batch", "size": N, "jobs": jobs_all, "ctu": ctu_all, "bytes": nbytes, "extra": ()}
+            # stand-alone ssd16b calls that are not the tail of a chain
+            extra_ssd = tot("ssd16b", N) - nq
+            g = merged.get(("ssd16b", N))
+            if g is not None:
+                keep = max(extra_ssd, 0)
+                g["jobs"], g["ctu"] = g["jobs"][:keep], g["ctu"][:keep]
+                g["bytes"] = keep * (4 * N * N + 4)
+                if keep == 0:
+                    del merged[("ssd16b", N)]
+            for name in ("predict", "transform", "quant", "inv_quant", "itransform", "reconst"):
+                merged.pop((name, N), None)
     for g in merged.values():      # a batch is issued in CTU order, like the host would enumerate it
         order = np.argsort(g["ctu"], kind="stable")
         g["jobs"] = np.ascontiguousarray(g["jobs"][order])
@@ -314,6 +371,8 @@ def main():
     ap.add_argument("--mode", choices=["eager", "graph"], default="graph",
                     help="eager: C command list with an event pair around every launch inside the timed region (per-kernel roofline numbers are live); "
                          "graph: the same command list captured once into a hipGraph and replayed (no per-launch host cost), per-kernel numbers from an eager pass after the timed region")
+    ap.add_argument("--unfused", action="store_true",
+                    help="replay predict/transform/quant/inv_quant/itransform/reconst/ssd16b as seven separate batches per TU size instead of the fused TU-chain kernel")
     ap.add_argument("--launch-order", default=None, help="write the per-step kernel launch order (JSON) for tools/pmc_summary.py")
     args = ap.parse_args()
 
@@ -336,7 +395,7 @@ def main():
 
     rng = np.random.default_rng(1234 + rank)
     arena = Arena()
-    groups, planes = build_groups(load_callmix(args.callmix_frame), rng, arena)
+    groups, planes = build_groups(load_callmix(args.callmix_frame), rng, arena, fused=not args.unfused)
     info = frame_side_info(rng)
 
     with torch.cuda.stream(stream):
@@ -375,11 +434,11 @@ def main():
     P = C.c_void_p
 
     class Cmd(C.Structure):
-        _fields_ = [("op", C.c_int), ("njobs", C.c_int), ("size", C.c_int), ("p", C.c_int * 4), ("jobs", P), ("a", P), ("b", P), ("c", P), ("out", P)]
+        _fields_ = [("op", C.c_int), ("njobs", C.c_int), ("size", C.c_int), ("p", C.c_int * 4), ("jobs", P), ("a", P), ("b", P), ("c", P), ("out", P), ("p64", P * 2)]
 
     OPS = {"hmr_gpu_sad_batch": 1, "hmr_gpu_ssd16b_batch": 2, "hmr_gpu_predict_batch": 3, "hmr_gpu_reconst_batch": 4, "hmr_gpu_copy_batch": 5,
            "hmr_gpu_intra_pred_batch": 7, "hmr_gpu_intra_refs_batch": 8, "hmr_gpu_interpolate_batch": 9, "hmr_gpu_transform_batch": 11,
-           "hmr_gpu_itransform_batch": 12, "hmr_gpu_quant_batch": 13, "hmr_gpu_inv_quant_batch": 14}
+           "hmr_gpu_itransform_batch": 12, "hmr_gpu_quant_batch": 13, "hmr_gpu_inv_quant_batch": 14, "hmr_gpu_tu_chain_batch": 22}
     OP_EDGE, OP_DEBLOCK, OP_STATS, OP_APPLY, OP_PAD = 17, 18, 19, 20, 21
     cmds, names = [], []
     for g in groups:
@@ -388,6 +447,9 @@ def main():
             cm.size = g["size"] << 8            # kind 0 (int16) | uniform square size hint
         if g["fn"] == "hmr_gpu_quant_batch":
             cm.b = None                          # deltaU is scratch in the reference; not returned
+        if g["fn"] == "hmr_gpu_tu_chain_batch":
+            g["d_ac"] = torch.zeros(len(g["jobs"]), dtype=torch.int32, device=dev)
+            cm.p64 = (P * 2)(base, g["d_ac"].data_ptr())   # reconstruction base, ac_sum
         cmds.append(cm)
         names.append(f"{g['name']}:{g['size']}")
     frame_bytes = {
@@ -475,7 +537,7 @@ def main():
             "dtype": "int16", "data": "synthetic",
             "config": {"workload": "cfg2-1080p-P-frame-replay", "width": W, "height": H, "qp": 32, "gop": "IPPP gop_size=1", "me": "quarter-pel", "sao": 1,
                        "calls_per_frame": int(sum(len(g["jobs"]) for g in groups)), "launches_per_frame": len(groups) + 8,
-                       "callmix_frame": args.callmix_frame, "parallelism": f"engine-per-gpu x{world}", "launch_mode": args.mode,
+                       "callmix_frame": args.callmix_frame, "parallelism": f"engine-per-gpu x{world}", "launch_mode": args.mode, "tu_chain": "7 separate batches" if args.unfused else "fused kernel",
                        "algorithmic_MB_per_frame_abi_width": round(total_alg / 1e6, 2), "compulsory_MB_per_frame": round(10.5 * W * H / 1e6, 2)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

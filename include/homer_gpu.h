@@ -249,7 +249,8 @@ void hmr_gpu_mc_chroma(int16_t *ref, int ref_stride, int16_t *pred, int pred_str
 enum hmr_gpu_op {
 	HMR_GPU_OP_SAD = 1, HMR_GPU_OP_SSD16B, HMR_GPU_OP_PREDICT, HMR_GPU_OP_RECONST, HMR_GPU_OP_COPY, HMR_GPU_OP_VARIANCE, HMR_GPU_OP_INTRA_PRED,
 	HMR_GPU_OP_INTRA_REFS, HMR_GPU_OP_INTERPOLATE, HMR_GPU_OP_WAVG, HMR_GPU_OP_TRANSFORM, HMR_GPU_OP_ITRANSFORM, HMR_GPU_OP_QUANT,
-	HMR_GPU_OP_INV_QUANT, HMR_GPU_OP_MC, HMR_GPU_OP_ME, HMR_GPU_OP_EDGE_FLAGS, HMR_GPU_OP_DEBLOCK, HMR_GPU_OP_SAO_STATS, HMR_GPU_OP_SAO_APPLY, HMR_GPU_OP_PAD
+	HMR_GPU_OP_INV_QUANT, HMR_GPU_OP_MC, HMR_GPU_OP_ME, HMR_GPU_OP_EDGE_FLAGS, HMR_GPU_OP_DEBLOCK, HMR_GPU_OP_SAO_STATS, HMR_GPU_OP_SAO_APPLY, HMR_GPU_OP_PAD,
+	HMR_GPU_OP_TU_CHAIN   /* jobs = hmr_gpu_tu_job*, a = orig base, b = pred base, c = level base, out = ssd; the reconstruction base and ac_sum follow in p64[0..1] */
 };
 /* One call of the batched / frame-level API: `size` is that entry's size/kind/flags argument, a/b/c/out its pointer arguments in
  * declaration order (frame-level ops take host pointers to hmr_gpu_frame / hmr_gpu_units that must outlive the list), p[] its
@@ -260,6 +261,7 @@ typedef struct hmr_gpu_cmd {
 	int p[4];
 	const void *jobs, *a, *b;
 	void *c, *out;
+	void *p64[2];               /* extra pointer arguments (TU_CHAIN: recon base, ac_sum) */
 } hmr_gpu_cmd;
 typedef struct hmr_gpu_cmdlist hmr_gpu_cmdlist;
 int hmr_gpu_cmdlist_create(hmr_gpu_ctx *ctx, const hmr_gpu_cmd *cmds, int n, hmr_gpu_cmdlist **out);
@@ -269,6 +271,26 @@ int hmr_gpu_cmdlist_run(hmr_gpu_ctx *ctx, hmr_gpu_cmdlist *list, void **event_pa
 int hmr_gpu_cmdlist_capture(hmr_gpu_ctx *ctx, hmr_gpu_cmdlist *list);
 int hmr_gpu_cmdlist_replay(hmr_gpu_ctx *ctx, hmr_gpu_cmdlist *list);
 void hmr_gpu_cmdlist_destroy(hmr_gpu_cmdlist *list);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * 7. fused transform-unit chain: predict -> transform -> quant(+SBH) -> [inv_quant -> itransform] -> reconst -> ssd16b
+ *    for a batch of TUs in one launch (the sequence of encode_intra_cu hmr_motion_intra.c:1014-1069 and
+ *    encode_inter_cu hmr_motion_inter.c:40-230); bit-identical to the seven calls issued one after the other.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct hmr_gpu_tu_job {
+	uint32_t orig_off, orig_stride;   /* source block */
+	uint32_t pred_off, pred_stride;   /* prediction block */
+	uint32_t rec_off, rec_stride;     /* reconstruction out */
+	uint32_t lev_off;                 /* quantised levels out, linear size*size */
+	uint32_t p0;                      /* bits 0-1 scan_mode, 2-3 comp, 4 is_intra, 5 slice_is_intra, 6 sign_hiding, 7 is_dst (4x4 intra luma) */
+	uint32_t p1;                      /* per | rem << 8 */
+} hmr_gpu_tu_job;
+int hmr_gpu_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_tu_job *jobs, int njobs, int size, const int16_t *orig_base, const int16_t *pred_base,
+			   int16_t *level_base, int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum);
+/* host-pointer (drop-in) form; returns the SSD between source and reconstruction */
+uint32_t hmr_gpu_tu_chain(int16_t *orig, int orig_stride, int16_t *pred, int pred_stride, int16_t *levels, int16_t *recon, int recon_stride, int size,
+			  int is_dst, int scan_mode, int comp, int is_intra, int slice_is_intra, int sign_hiding, int per, int rem, int *ac_sum);
 
 #ifdef __cplusplus
 }

@@ -1051,3 +1051,25 @@ uint32_t ora_motion_estimation(const int16_t *orig, int orig_stride, const int16
 #undef SAD_AT
 #undef TRY
 }
+
+/* ====================================================================================================
+ * TU chain: the per-TU call sequence of encode_intra_cu (hmr_motion_intra.c:1030-1068) / encode_inter_cu
+ * (hmr_motion_inter.c:40-230) as one function - the composition the fused GPU kernel must reproduce.
+ * ==================================================================================================== */
+uint32_t ora_tu_chain(const int16_t *orig, int orig_stride, const int16_t *pred, int pred_stride, int16_t *levels, int16_t *recon, int recon_stride,
+		      int size, int is_dst, int scan_mode, int comp, int is_intra, int slice_is_intra, int sign_hiding, int per, int rem, int *ac_sum)
+{
+	int16_t res[64 * 64], coef[32 * 32], deq[32 * 32], zero_row[64];
+	int depth = 6 - ilog2(size) - (comp != 0);
+	memset(zero_row, 0, sizeof zero_row);
+	ora_predict(orig, orig_stride, pred, pred_stride, res, 64, size);
+	ora_transform(res, coef, 64, size, is_dst);
+	ora_quant(coef, levels, NULL, scan_mode, depth, comp, is_intra, slice_is_intra, sign_hiding, ac_sum, size, per, rem);
+	if (*ac_sum) {
+		ora_inv_quant(levels, deq, depth, comp, is_intra, size, per, rem);
+		ora_itransform(res, deq, 64, size, is_dst);
+		ora_reconst(pred, pred_stride, res, 64, recon, recon_stride, size);
+	} else
+		ora_reconst(pred, pred_stride, zero_row, 0, recon, recon_stride, size);   /* "quant buff is full of zeros", :1065 */
+	return ora_ssd16b(orig, (uint32_t)orig_stride, recon, (uint32_t)recon_stride, size);
+}

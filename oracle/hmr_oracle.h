@@ -103,6 +103,11 @@ uint32_t ora_motion_estimation(const int16_t *orig, int orig_stride, const int16
 			       int size, int range_x, int range_y, int frame_w, int frame_h, const int32_t *amvp, int n_amvp,
 			       const int32_t *search, int n_search, double corr, int action, int32_t *out);
 
+
+/* ---- per-TU call sequence (encode_intra_cu hmr_motion_intra.c:1030-1068), returns the SSD ---- */
+uint32_t ora_tu_chain(const int16_t *orig, int orig_stride, const int16_t *pred, int pred_stride, int16_t *levels, int16_t *recon, int recon_stride,
+		      int size, int is_dst, int scan_mode, int comp, int is_intra, int slice_is_intra, int sign_hiding, int per, int rem, int *ac_sum);
+
 #ifdef __cplusplus
 }
 #endif

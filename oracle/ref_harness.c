@@ -458,3 +458,28 @@ uint32_t refh_motion_estimation(int16_t *orig, int orig_stride, int16_t *ref, in
 	out[0] = mv.hor_vector; out[1] = mv.ver_vector; out[2] = sub.hor_vector; out[3] = sub.ver_vector;
 	return r;
 }
+
+/* the per-TU call sequence of encode_intra_cu (hmr_motion_intra.c:1030-1068) issued through the reference's own table */
+uint32_t refh_tu_chain(int16_t *orig, int orig_stride, int16_t *pred, int pred_stride, int16_t *levels, int16_t *recon, int recon_stride, int size, int is_dst,
+		       int scan_mode, int comp, int is_intra, int slice_is_intra, int sign_hiding, int per, int rem, int *ac_sum)
+{
+	static int16_t *res, *coef, *deq, *zeros;
+	low_level_funcs_t *f = &g_enc->funcs;
+	int sh = log2i(size), depth = 6 - sh - (comp != 0);
+	if (!res) {
+		res = hmr_aligned_alloc(64 * 64, 2); coef = hmr_aligned_alloc(32 * 32, 2); deq = hmr_aligned_alloc(32 * 32, 2); zeros = hmr_aligned_alloc(64 * 64, 2);
+		memset(zeros, 0, 64 * 64 * 2);
+	}
+	g_eng->current_pict.slice.slice_type = slice_is_intra ? I_SLICE : P_SLICE;
+	g_et->pps->sign_data_hiding_flag = sign_hiding;
+	f->predict(orig, orig_stride, pred, pred_stride, res, 64, size);
+	f->transform(8, res, coef, 64, size, size, sh, sh, is_dst ? 0 : REG_DCT, g_et->pred_aux_buff);
+	f->quant(g_et, coef, levels, scan_mode, depth, comp, 0, is_intra, ac_sum, size, per, rem);
+	if (*ac_sum) {
+		f->inv_quant(g_et, levels, deq, depth, comp, is_intra, size, per, rem);
+		f->itransform(8, res, deq, 64, size, size, is_dst ? 0 : REG_DCT, g_et->pred_aux_buff);
+		f->reconst(pred, pred_stride, res, 64, recon, recon_stride, size);
+	} else
+		f->reconst(pred, pred_stride, zeros, 0, recon, recon_stride, size);
+	return f->ssd16b(orig, orig_stride, recon, recon_stride, size);
+}

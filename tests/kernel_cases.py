@@ -241,12 +241,27 @@ def k_inv_quant(lib, prefix, p, rng):
     return {"dst": dst[:n * n].copy()}
 
 
+def k_tu_chain(lib, prefix, p, rng):
+    n, comp = p["n"], p["comp"]
+    orig = aligned((64, 64), np.int16)
+    orig[...] = rng.integers(0, 256, (64, 64))
+    pred = aligned((64, 64), np.int16)
+    pred[...] = np.clip(orig + rng.integers(-p["noise"], p["noise"] + 1, (64, 64)), 0, 255)
+    levels = aligned((32 * 32,), np.int16)
+    recon = aligned((64, 64), np.int16)
+    ac = C.c_int(0)
+    r = fn(lib, prefix, "tu_chain", C.c_uint32)(ptr(orig), C.c_int(64), ptr(pred), C.c_int(64), ptr(levels), ptr(recon), C.c_int(64), C.c_int(n),
+                                                C.c_int(p.get("dst", 0)), C.c_int(p["scan"]), C.c_int(comp), C.c_int(p["intra"]), C.c_int(p["slice_i"]),
+                                                C.c_int(p["sbh"]), C.c_int(p["per"]), C.c_int(p["rem"]), C.byref(ac))
+    return {"levels": levels[:n * n].copy(), "recon": recon[:n, :n].copy(), "ssd": np.array([r], np.uint32), "ac_sum": np.array([ac.value], np.int32)}
+
+
 KERNELS = {
     "sad": k_sad, "ssd16b": k_ssd16b, "predict": k_predict, "reconst": k_reconst, "modified_variance": k_modified_variance,
     "copy": k_copy, "intra_planar": k_intra_planar, "intra_angular": k_intra_angular,
     "fill_reference_samples": k_fill_reference_samples, "adi_filter": k_adi_filter, "interpolate": k_interpolate,
     "weighted_average": k_weighted_average, "transform": k_transform, "itransform": k_itransform, "quant": k_quant,
-    "inv_quant": k_inv_quant,
+    "inv_quant": k_inv_quant, "tu_chain": k_tu_chain,
 }
 
 
@@ -340,4 +355,11 @@ def all_cases(level="full"):
                 for per, rem in [(5, 2), (3, 0), (0, 5), (8, 3), (1, 1)]:
                     add("inv_quant", n=n, comp=comp, intra=intra, per=per, rem=rem)
             add("inv_quant", n=n, comp=comp, intra=1, per=8, rem=5, amp=32000)
+    for n in (4, 8, 16, 32):
+        for comp in ((0, 1, 2) if n < 32 else (0,)):
+            for intra in (1, 0):
+                for noise in ((1, 6, 40, 255) if full else (2, 40)):
+                    for per, rem in ([(5, 2), (3, 4)] if full else [(5, 2)]):
+                        add("tu_chain", n=n, comp=comp, intra=intra, slice_i=intra, sbh=1, per=per, rem=rem, scan=3, noise=noise,
+                            dst=1 if (n == 4 and intra and comp == 0) else 0)
     return cases
