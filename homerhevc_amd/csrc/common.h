@@ -16,6 +16,8 @@
 struct DevTables {
 	int16_t dct[4][32 * 32];        // [log2N-2] N x N row-major HEVC core transform
 	int16_t dst4[16];               // DST-VII 4x4
+	int16_t dct_t[4][32 * 32];      // the same bases transposed (rows = basis columns), for the inverse stages
+	int16_t dst4_t[16];
 	uint32_t scan[4][6][32 * 32];   // [scan_mode][log2N] coefficient scan order (mode 0 unused)
 	int32_t quant[4][6][6][32 * 32];   // [log2N-2][list][qp%6]
 	int32_t dequant[4][6][6][32 * 32];

@@ -2,174 +2,215 @@
 // inverse transform] -> reconstruction -> SSD, one launch for a batch of TUs.
 // This is the per-TU sequence of the reference's encode_intra_cu (hmr_motion_intra.c:1014-1069) and encode_inter_cu
 // (hmr_motion_inter.c:40-230): seven table calls (predict, transform, quant, inv_quant, itransform, reconst, ssd16b) whose
-// intermediates the CPU keeps in scratch windows.  Here a TU lives in the LDS region of G lanes from the first load to the
-// last store: source and prediction are read once, levels, reconstruction, SSD and ac_sum are written once, and the residual,
-// coefficient and de-quantised planes never reach HBM.  Each stage is the same arithmetic as the stand-alone kernels
-// (k_transform.hip), so the outputs are bit-identical to the seven calls in sequence.
+// intermediates the CPU keeps in scratch windows.  Here a TU stays on chip from the first load to the last store: source and
+// prediction are read once, levels, reconstruction, SSD and ac_sum are written once; residual, coefficients and de-quantised
+// planes never reach HBM.  The arithmetic of every stage is that of the stand-alone kernels, so outputs are bit-identical to the
+// seven calls in sequence.
+//
+// Transform mapping ("lane = row"): N lanes own one TU (64/N TUs per wave) and each lane holds one row of its TU packed two
+// 16-bit samples per register.  A 1-D stage is then, for every basis row k, N/2 v_dot2_i32_i16 per lane against basis words
+// that are wave-uniform (all TUs of a wave walk the same k), i.e. scalar loads from the constant tables - no LDS traffic in the
+// inner loop.  Only the transposes between stages go through LDS (pitch N+2: conflict-free column writes).  The integer dot
+// products are exact (|sum| < 2^31), MFMA is not applicable: the stages need exact 32-bit sums with a saturating 16-bit pack
+// in between.  Quantisation / sign hiding run on the LDS image with the 16-lanes-per-coefficient-group mapping of k_quant.
 #include "common.h"
 #include "tq_device.h"
+#include "vec.h"
 
 namespace {
+
+typedef short short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot2(int a, int b, int c) { return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), c, false); }
+__device__ __forceinline__ int pack2(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
+
+// out[k] = sat16((sum_i row[i] * basis[k][i] + rnd) >> shift) for k = 0..N-1, written to dst[k * pitch] (column walk)
+template <int N>
+__device__ __forceinline__ void stage_to_lds(const int (&row)[N / 2], const int *__restrict__ basis, int shift, int16_t *dst, int pitch)
+{
+	const int rnd = 1 << (shift - 1);
+#pragma unroll 4
+	for (int k = 0; k < N; k++) {
+		int s = 0;
+#pragma unroll
+		for (int i = 0; i < N / 2; i++) s = dot2(row[i], basis[k * (N / 2) + i], s);
+		dst[k * pitch] = (int16_t)sat16i((s + rnd) >> shift);
+	}
+}
+
+template <int N>
+__device__ __forceinline__ void load_row_lds(int (&row)[N / 2], const int16_t *src)
+{
+#pragma unroll
+	for (int i = 0; i < N / 2; i++) row[i] = *reinterpret_cast<const int *>(src + 2 * i);
+}
 
 template <int N>
 __global__ __launch_bounds__(HMR_BLOCK) void k_tu_chain(const hmr_gpu_tu_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ O,
 							   const int16_t *__restrict__ Pp, int16_t *__restrict__ L, int16_t *__restrict__ Rr,
 							   uint32_t *__restrict__ ssd_out, int32_t *__restrict__ ac_out, const DevTables *__restrict__ tab)
 {
-	using g = Geo<N>;
-	__shared__ int16_t sM[2][N * N];
-	__shared__ int16_t sA[HMR_WAVES_PER_BLOCK][g::JPW][N * g::P];      // residual, later de-quantised coefficients
-	__shared__ int16_t sT[HMR_WAVES_PER_BLOCK][g::JPW][N * g::P];      // stage intermediates
-	__shared__ int16_t sOrig[HMR_WAVES_PER_BLOCK][g::JPW][g::E];
-	__shared__ int16_t sPred[HMR_WAVES_PER_BLOCK][g::JPW][g::E];
-	__shared__ int16_t sCoef[HMR_WAVES_PER_BLOCK][g::JPW][g::E];
-	__shared__ int16_t sLev[HMR_WAVES_PER_BLOCK][g::JPW][g::E];
-	__shared__ int16_t sDu[HMR_WAVES_PER_BLOCK][g::JPW][g::E];
-	__shared__ unsigned long long sNzMask[HMR_WAVES_PER_BLOCK][g::JPW];
-	const int lane = lane_id(), w = wave_in_block(), sub = lane / g::G, l = lane % g::G;
-	constexpr int CG_PER_IT = g::G / 16, SIDE = N / 4;
-	constexpr int sh1 = g::L2 - 1, sh2 = g::L2 + 6;
-	for (int i = threadIdx.x; i < N * N; i += HMR_BLOCK) {
-		sM[0][i] = tab->dct[g::L2 - 2][i];
-		sM[1][i] = N == 4 ? tab->dst4[i] : (int16_t)0;
-	}
-	__syncthreads();
-	int16_t *tA = sA[w][sub], *tT = sT[w][sub], *orig = sOrig[w][sub], *pred = sPred[w][sub], *coef = sCoef[w][sub], *lev = sLev[w][sub], *du = sDu[w][sub];
-	const JobRange jr = xcd_job_range(njobs, g::JPB);
+	constexpr int L2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+	constexpr int E = N * N, P = N + 2;
+	constexpr int TW = HMR_WAVE / N;                       // TUs per wave in the transform mapping (lane = row)
+	constexpr int GQ = N == 32 ? 64 : 16;                  // lanes per TU in the quant mapping (sign hiding needs 16-lane groups); measured best
+	constexpr int TQ = HMR_WAVE / GQ, QPASSES = TW / TQ;   // TUs per quant pass, passes per wave
+	constexpr int JPB = TW * HMR_WAVES_PER_BLOCK;
+	constexpr int sh1 = L2 - 1, sh2 = L2 + 6, SIDE = N / 4;
+	__shared__ int16_t sA[HMR_WAVES_PER_BLOCK][TW][N * P];    // coefficients (linear) -> de-quantised coefficients (transposed, pitched)
+	__shared__ int16_t sT[HMR_WAVES_PER_BLOCK][TW][N * P];    // stage intermediates (pitched) / deltaU (linear) during quantisation
+	__shared__ int16_t sLev[HMR_WAVES_PER_BLOCK][TW][E];
+	__shared__ unsigned long long sNz[HMR_WAVES_PER_BLOCK][TW];
+	__shared__ int sAc[HMR_WAVES_PER_BLOCK][TW];
+	const int lane = lane_id(), w = wave_in_block(), tu = lane / N, row = lane % N;
+	const JobRange jr = xcd_job_range(njobs, JPB);
 	for (long base = jr.begin; base < jr.end; base += jr.stride) {
-		const long j = base + w * g::JPW + sub;
+		const long j = base + w * TW + tu;
 		const bool ok = j < jr.end;
 		hmr_gpu_tu_job jb = {};
-		if (l == 0) sNzMask[w][sub] = 0;
+		int orow[N / 2], prow[N / 2], r[N / 2];
+#pragma unroll
+		for (int i = 0; i < N / 2; i++) orow[i] = prow[i] = 0;
 		if (ok) {
 			jb = jobs[j];
-			const int16_t *o = O + jb.orig_off, *p = Pp + jb.pred_off;
-			for (int e = l; e < g::E; e += g::G) {      // K3 predict: res = orig - pred
-				const int y = e / N, x = e % N;
-				const int vo = o[(size_t)y * jb.orig_stride + x], vp = p[(size_t)y * jb.pred_stride + x];
-				orig[e] = (int16_t)vo;
-				pred[e] = (int16_t)vp;
-				tA[y * g::P + x] = (int16_t)(vo - vp);
+			const int16_t *o = O + jb.orig_off + (size_t)row * jb.orig_stride, *p = Pp + jb.pred_off + (size_t)row * jb.pred_stride;
+#pragma unroll
+			for (int i = 0; i < N / 4; i++) {
+				const i16x4 vo = ld4(o + 4 * i), vp = ld4(p + 4 * i);
+				orow[2 * i] = pack2(vo.v[0], vo.v[1]); orow[2 * i + 1] = pack2(vo.v[2], vo.v[3]);
+				prow[2 * i] = pack2(vp.v[0], vp.v[1]); prow[2 * i + 1] = pack2(vp.v[2], vp.v[3]);
 			}
 		}
-		wave_sync();
-		const int16_t *M = sM[(N == 4 && ((jb.p0 >> 7) & 1)) ? 1 : 0];
-		if (ok)                                             // K12 stage 1
-			for (int o = l; o < g::E; o += g::G) {
-				const int k = o / N, row = o % N;
-				int s = 0;
+		// K3 predict: residual row (16-bit wrap per sample)
 #pragma unroll
-				for (int i = 0; i < N; i++) s += M[k * N + i] * tA[row * g::P + i];
-				tT[k * g::P + row] = (int16_t)sat16i((s + (1 << (sh1 - 1))) >> sh1);
-			}
+		for (int i = 0; i < N / 2; i++)
+			r[i] = pack2((int16_t)((int16_t)orow[i] - (int16_t)prow[i]), (int16_t)((orow[i] >> 16) - (prow[i] >> 16)));
+		const bool is_dst = N == 4 && ((jb.p0 >> 7) & 1);
+		// basis words: DST only exists for N = 4, where a lane group may need a different basis than its neighbours -> per-lane pointer
+		const int *Mf = reinterpret_cast<const int *>(is_dst ? tab->dst4 : tab->dct[L2 - 2]);
+		const int *Mt = reinterpret_cast<const int *>(is_dst ? tab->dst4_t : tab->dct_t[L2 - 2]);
+		int16_t *tA = sA[w][tu], *tT = sT[w][tu], *lev = sLev[w][tu];
+		if (lane % N == 0) { sNz[w][tu] = 0; sAc[w][tu] = 0; }
+		// K12 stage 1: tmp[k][row] = sum_i M[k][i] * res[row][i]
+		stage_to_lds<N>(r, Mf, sh1, tT + row, P);
 		wave_sync();
-		if (ok)                                             // K12 stage 2
-			for (int o = l; o < g::E; o += g::G) {
-				const int k2 = o / N, k1 = o % N;
-				int s = 0;
-#pragma unroll
-				for (int i = 0; i < N; i++) s += M[k2 * N + i] * tT[k1 * g::P + i];
-				coef[o] = (int16_t)sat16i((s + (1 << (sh2 - 1))) >> sh2);
-			}
+		// K12 stage 2: coeff[k2][k1 = row] = sum_j M[k2][j] * tmp[k1][j]; stored linear for the quantiser
+		load_row_lds<N>(r, tT + row * P);
 		wave_sync();
-		// K14 quant
-		int ac = 0;
-		bool sbh = false;
-		const uint32_t *scan = tab->scan[3][g::L2];
-		const int comp = (jb.p0 >> 2) & 3, is_intra = (jb.p0 >> 4) & 1, per = jb.p1 & 0xff, rem = (jb.p1 >> 8) & 0xff;
-		if (ok) {
-			const int scan_mode = jb.p0 & 3, slice_i = (jb.p0 >> 5) & 1;
-			sbh = (jb.p0 >> 6) & 1;
-			const int32_t *q = tab->quant[g::L2 - 2][(is_intra ? 0 : 3) + comp][rem];
-			const uint8_t *b2c = tab->blk2cg[scan_mode][g::L2];
-			scan = tab->scan[scan_mode][g::L2];
-			const int qbits = 14 + per + (7 - g::L2), qbits8 = qbits - 8;
-			const uint32_t add = (uint32_t)(slice_i ? 171 : 85) << (qbits - 9);
-			uint32_t sum = 0;
-			unsigned long long nz = 0;
-			for (int e = l; e < g::E; e += g::G) {
-				const int s = coef[e];
-				const uint32_t mag = (uint16_t)(s < 0 ? -s : s);
-				const uint32_t aux = mag * (uint32_t)q[e];
-				const int c = (int)(aux + add) >> qbits;
-				const int d = (int)(aux - ((uint32_t)c << qbits)) >> qbits8;
-				sum += (uint32_t)c;
-				const int sgn = s > 0 ? 1 : (s < 0 ? -1 : 0);
-				const int lv = (int16_t)(sgn * sat16i(c));
-				lev[e] = (int16_t)lv;
-				du[e] = (int16_t)sat16i(d);
-				if (lv) nz |= 1ull << b2c[((e / N) >> 2) * SIDE + ((e % N) >> 2)];
-			}
-			ac = (int)group_sum<g::G>(sum);
-			if (nz) atomicOr(&sNzMask[w][sub], nz);
-		}
+		stage_to_lds<N>(r, Mf, sh2, tA + row, N);
 		wave_sync();
-		{
-			const bool run_sbh = ok && sbh && ac >= 2;
-			unsigned long long m = run_sbh ? sNzMask[w][sub] : 0ull;
+		// K14 quant + sign hiding on the LDS image, TQ TUs per pass with GQ lanes each
+		for (int pass = 0; pass < QPASSES; pass++) {
+			const int qt = pass * TQ + lane / GQ, l = lane % GQ;          // TU handled by this lane in this pass
+			const long qj = base + w * TW + qt;
+			const bool qok = qj < jr.end;
+			// the TU's parameters live with its transform lanes: fetch them from lane qt * N
+			const unsigned p0 = __shfl((int)jb.p0, qt * N, HMR_WAVE), p1 = __shfl((int)jb.p1, qt * N, HMR_WAVE);
+			const int scan_mode = p0 & 3, comp = (p0 >> 2) & 3, is_intra = (p0 >> 4) & 1, slice_i = (p0 >> 5) & 1, sbh = (p0 >> 6) & 1;
+			const int per = p1 & 0xff, rem = (p1 >> 8) & 0xff;
+			int16_t *qc = sA[w][qt], *qd = sT[w][qt], *ql = sLev[w][qt];
+			const uint32_t *scan = tab->scan[scan_mode][L2];
+			int ac = 0;
+			if (qok) {
+				const int32_t *q = tab->quant[L2 - 2][(is_intra ? 0 : 3) + comp][rem];
+				const uint8_t *b2c = tab->blk2cg[scan_mode][L2];
+				const int qbits = 14 + per + (7 - L2), qbits8 = qbits - 8;
+				const uint32_t add = (uint32_t)(slice_i ? 171 : 85) << (qbits - 9);
+				uint32_t sum = 0;
+				unsigned long long nz = 0;
+				for (int e = l; e < E; e += GQ) {
+					const int s = qc[e];
+					const uint32_t mag = (uint16_t)(s < 0 ? -s : s);
+					const uint32_t aux = mag * (uint32_t)q[e];
+					const int c = (int)(aux + add) >> qbits;
+					const int d = (int)(aux - ((uint32_t)c << qbits)) >> qbits8;
+					sum += (uint32_t)c;
+					const int sgn = s > 0 ? 1 : (s < 0 ? -1 : 0);
+					const int lv = (int16_t)(sgn * sat16i(c));
+					ql[e] = (int16_t)lv;
+					qd[e] = (int16_t)sat16i(d);
+					if (lv) nz |= 1ull << b2c[((e / N) >> 2) * SIDE + ((e % N) >> 2)];
+				}
+				ac = (int)group_sum<GQ>(sum);
+				if (nz) atomicOr(&sNz[w][qt], nz);
+				if (l == 0) sAc[w][qt] = ac;
+			}
+			wave_sync();
+			const bool run_sbh = qok && sbh && ac >= 2;
+			unsigned long long m = run_sbh ? sNz[w][qt] : 0ull;
 			const int last = m ? 63 - __clzll((long long)m) : -1;
 			const int grp = l >> 4;
 			while (__any(m != 0)) {
 				unsigned long long t = m;
 				int cg = -1;
 #pragma unroll
-				for (int k = 0; k < CG_PER_IT; k++) {
+				for (int k = 0; k < GQ / 16; k++) {
 					const int b = t ? __ffsll((long long)t) - 1 : -1;
 					if (k == grp) cg = b;
 					t &= t - 1;
 				}
 				m = t;
-				sbh_group16(lev, coef, du, scan, cg < 0 ? 0 : cg, cg == last, run_sbh && cg >= 0);
+				sbh_group16(ql, qc, qd, scan, cg < 0 ? 0 : cg, cg == last, run_sbh && cg >= 0);
+			}
+			wave_sync();
+			if (qok) {                                              // levels out (coalesced) + K15 inv_quant into the transposed tile
+				int16_t *lo = L + __shfl((int)jb.lev_off, qt * N, HMR_WAVE);
+				for (int e = l; e < E; e += GQ) lo[e] = ql[e];
+				if (l == 0) ac_out[qj] = ac;
 			}
 		}
 		wave_sync();
-		const bool coded = ok && ac != 0;                   // the reference skips dequant / inverse transform for all-zero TUs
-		if (ok) {
-			int16_t *lo = L + jb.lev_off;
-			for (int e = l; e < g::E; e += g::G) lo[e] = lev[e];
-			if (l == 0) ac_out[j] = ac;
-		}
-		if (coded) {                                        // K15 inv_quant into the pitched tile
-			const int32_t *iq = tab->dequant[g::L2 - 2][is_intra ? 0 : 3 + comp][rem];
-			const int iq_shift = 3 + g::L2;
-			for (int e = l; e < g::E; e += g::G) {
-				const uint32_t prod = (uint32_t)(int)lev[e] * (uint32_t)iq[e];
-				int r;
-				if (iq_shift > per) r = (int)(prod + (1u << (iq_shift - per - 1))) >> (iq_shift - per);
-				else r = (int)(prod << (per - iq_shift));
-				tA[(e / N) * g::P + (e % N)] = (int16_t)sat16i(r);
-			}
-		}
-		wave_sync();
-		if (coded)                                          // K13 stage 1
-			for (int o = l; o < g::E; o += g::G) {
-				const int k = o / N, col = o % N;
-				int s = 0;
-#pragma unroll
-				for (int i = 0; i < N; i++) s += M[i * N + k] * tA[i * g::P + col];
-				tT[col * g::P + k] = (int16_t)sat16i((s + 64) >> 7);
-			}
-		wave_sync();
-		uint32_t ssd = 0;
-		if (ok) {                                           // K13 stage 2 + K4 reconst + K2 ssd
-			int16_t *ro = Rr + jb.rec_off;
-			for (int o = l; o < g::E; o += g::G) {
-				const int y = o / N, x = o % N;
-				int res = 0;
-				if (coded) {
-					int s = 0;
-#pragma unroll
-					for (int i = 0; i < N; i++) s += M[i * N + x] * tT[i * g::P + y];
-					res = sat16i((s + 2048) >> 12);
+		const int ac = sAc[w][tu];
+		const bool coded = ok && ac != 0;                               // the reference skips dequant / inverse transform for all-zero TUs
+		{
+			const int comp = (jb.p0 >> 2) & 3, is_intra = (jb.p0 >> 4) & 1, per = jb.p1 & 0xff, rem = (jb.p1 >> 8) & 0xff;
+			const int32_t *iq = tab->dequant[L2 - 2][is_intra ? 0 : 3 + comp][rem];
+			const int iq_shift = 3 + L2;
+			if (coded)                                              // lane = coefficient ROW i here: deqT[col][i] = deq[i][col]
+				for (int col = 0; col < N; col++) {
+					const int e = row * N + col;
+					const uint32_t prod = (uint32_t)(int)lev[e] * (uint32_t)iq[e];
+					int v;
+					if (iq_shift > per) v = (int)(prod + (1u << (iq_shift - per - 1))) >> (iq_shift - per);
+					else v = (int)(prod << (per - iq_shift));
+					tA[col * P + row] = (int16_t)sat16i(v);
 				}
-				const int rec = clip3i(sat16i(pred[o] + res), 0, 255);
-				ro[(size_t)y * jb.rec_stride + x] = (int16_t)rec;
-				const int d = (int16_t)(orig[o] - rec);
-				ssd += (uint32_t)(d * d);
+		}
+		wave_sync();
+		// K13 stage 1: tmp[col = row][k] = sum_i M[i][k] * coeff[i][col]; written transposed (tmpT[k][col]) for stage 2
+		load_row_lds<N>(r, tA + row * P);
+		wave_sync();
+		stage_to_lds<N>(r, Mt, 7, tT + row, P);
+		wave_sync();
+		// K13 stage 2 + K4 reconst + K2 ssd: out[y = row][x] = sum_i M[i][x] * tmp[i][y]
+		load_row_lds<N>(r, tT + row * P);
+		uint32_t ssd = 0;
+		if (ok) {
+			int16_t *ro = Rr + jb.rec_off + (size_t)row * jb.rec_stride;
+#pragma unroll 2
+			for (int x4 = 0; x4 < N; x4 += 4) {
+				i16x4 outv;
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					const int x = x4 + q;
+					int res = 0;
+					if (coded) {
+						int s = 0;
+#pragma unroll
+						for (int i = 0; i < N / 2; i++) s = dot2(r[i], Mt[x * (N / 2) + i], s);
+						res = sat16i((s + 2048) >> 12);
+					}
+					const int pw = prow[x >> 1], ow = orow[x >> 1];
+					const int pv = (x & 1) ? (pw >> 16) : (int16_t)pw, ov = (x & 1) ? (ow >> 16) : (int16_t)ow;
+					const int rec = clip3i(sat16i(pv + res), 0, 255);
+					outv.v[q] = (int16_t)rec;
+					const int d = (int16_t)(ov - rec);
+					ssd += (uint32_t)(d * d);
+				}
+				st4(ro + x4, outv);
 			}
 		}
-		ssd = group_sum<g::G>(ssd);
-		if (ok && l == 0) ssd_out[j] = ssd;
+		ssd = group_sum<N>(ssd);
+		if (ok && row == 0) ssd_out[j] = ssd;
 		wave_sync();
 	}
 }
@@ -180,9 +221,9 @@ extern "C" int hmr_gpu_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_tu_job *jo
 				      int16_t *level_base, int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum)
 {
 	if (njobs <= 0) return HMR_GPU_OK;
-#define TU_LAUNCH(N)                                                                                                              \
-	hipLaunchKernelGGL((k_tu_chain<N>), dim3(hmr_grid_for_units(((long)njobs + Geo<N>::JPB - 1) / Geo<N>::JPB)), dim3(HMR_BLOCK), 0, ctx->stream, jobs, \
-			   njobs, orig_base, pred_base, level_base, recon_base, ssd, ac_sum, ctx->tables)
+#define TU_LAUNCH(N)                                                                                                                               \
+	hipLaunchKernelGGL((k_tu_chain<N>), dim3(hmr_grid_for_units(((long)njobs + (HMR_WAVE / N) * HMR_WAVES_PER_BLOCK - 1) / ((HMR_WAVE / N) * HMR_WAVES_PER_BLOCK))), \
+			   dim3(HMR_BLOCK), 0, ctx->stream, jobs, njobs, orig_base, pred_base, level_base, recon_base, ssd, ac_sum, ctx->tables)
 	switch (size) {
 	case 4: TU_LAUNCH(4); break;
 	case 8: TU_LAUNCH(8); break;

@@ -61,6 +61,13 @@ void build()
 	}
 	const int16_t dst[16] = {29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29};
 	memcpy(t->dst4, dst, sizeof dst);
+	for (int l = 2; l <= 5; l++) {
+		const int n = 1 << l;
+		for (int k = 0; k < n; k++)
+			for (int x = 0; x < n; x++) t->dct_t[l - 2][x * n + k] = t->dct[l - 2][k * n + x];
+	}
+	for (int k = 0; k < 4; k++)
+		for (int x = 0; x < 4; x++) t->dst4_t[x * 4 + k] = dst[k * 4 + x];
 
 	// scans: sizes 2..32.  Diagonal: 4x4 coefficient groups visited up-right, each scanned up-right.
 	uint32_t cg_order[64];
