@@ -39,6 +39,7 @@ W, H = 1920, 1080
 HA = 1088                      # CTU-aligned height
 PAD = 80                       # reference-frame margin (hmr_encoder_lib.c:1514)
 REF_STRIDE = W + 2 * PAD
+CREF_STRIDE = W // 2 + PAD
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -61,6 +62,12 @@ class Arena:
         if fill is not None:
             self.init.append((off, fill))
         return off
+
+
+ME_JOB_DTYPE = np.dtype([("corr", "<f8"), ("orig_off", "<u4"), ("orig_stride", "<u4"), ("ref_off", "<u4"), ("ref_stride", "<u4"), ("gx", "<i2"), ("gy", "<i2"),
+                         ("init_x", "<i2"), ("init_y", "<i2"), ("n_amvp", "<i2"), ("n_search", "<i2"), ("amvp", "<i2", (2, 2)), ("search", "<i2", (5, 2)),
+                         ("action", "<u4"), ("reserved", "<u4")])    # hmr_gpu_me_job, include/homer_gpu.h
+assert ME_JOB_DTYPE.itemsize == 72
 
 
 def build_groups(calls, rng, arena, fused=True):
@@ -130,6 +137,11 @@ def build_groups(calls, rng, arena, fused=True):
     for key, n in sorted(calls.items()):
         parts = key.split(":")
         kind, a = parts[0], [int(p) for p in parts[1:]]
+        kind, _, origin = kind.partition("@")     # interpolation calls carry their caller: @planes (sub-pel plane builders) / @mc
+        if fused and (origin or kind == "sad_direct"):
+            continue                               # issued as fused sub-pel refinement / motion compensation jobs below
+        if kind in ("mc_luma", "mc_chroma", "half_pel_planes", "quarter_pel_planes"):
+            continue
         if kind in ("sad", "sad_direct"):
             N = a[0]
             jb = jobs(n)
@@ -248,6 +260,80 @@ def build_groups(calls, rng, arena, fused=True):
         # half_pel_planes / quarter_pel_planes are drivers whose interpolation calls are already counted;
         # deblock_ctu / sao_* / pad_ctu are issued as the frame-level passes below.
     if fused:
+        # Sub-pel refinement (hmr_half/quarter_pixel_estimation_luma_hm + the direct sad calls of hmr_motion_estimation) is ONE job per
+        # PU of the motion-estimation kernel (action = half | quarter): the 16 sub-pel planes never leave the chip.  Algorithmic bytes
+        # = those of the interpolation and sad calls it stands for.
+        def interp_bytes(origin, pred):
+            tot_b = 0
+            for key, n in calls.items():
+                kp = key.split(":")
+                if "@" not in kp[0] or kp[0].split("@")[1] != origin:
+                    continue
+                luma = kp[0].startswith("interp_luma")
+                w, h, fl = int(kp[1]), int(kp[2]), int(kp[3])
+                if not pred(luma, w, h):
+                    continue
+                taps = 8 if luma else 4
+                rd = (w * (h + taps - 1) if (fl >> 1) & 1 else (w + taps - 1) * h) if fl & 1 else w * h
+                tot_b += n * 2 * (rd + w * h)
+            return tot_b
+
+        for key, n in sorted(calls.items()):
+            kp = key.split(":")
+            if kp[0] != "half_pel_planes":
+                continue
+            N = int(kp[1])
+            jb = np.zeros(n, ME_JOB_DTYPE)
+            c = ctus(n)
+            jb["corr"] = 32 * 0.5
+            jb["orig_off"] = wnd(n, srcw, 64, N, N, align=min(N, 8), ctu=c); jb["orig_stride"] = 64
+            blk = frame(n, ref0, N, N, 0, 0, ctu=c)
+            jb["ref_off"] = blk; jb["ref_stride"] = REF_STRIDE
+            rel = blk - ref0
+            jb["gx"] = rel % REF_STRIDE; jb["gy"] = rel // REF_STRIDE
+            jb["init_x"] = rng.integers(-24, 25, n); jb["init_y"] = rng.integers(-12, 13, n)
+            jb["n_amvp"] = 1
+            jb["amvp"][:, 0, 0] = rng.integers(-64, 65, n); jb["amvp"][:, 0, 1] = rng.integers(-32, 33, n)
+            jb["action"] = 6
+            nb = interp_bytes("planes", lambda luma, w, h, N=N: luma and w in (N, N + 1) and h in (N, N + 1, N + 7, N + 8))
+            nb += sum(v for k, v in calls.items() if k == "sad_direct:%d" % N) * (4 * N * N + 4)
+            merged[("me_subpel", N)] = {"name": "me_subpel", "fn": "hmr_gpu_motion_estimation_batch", "size": N, "jobs": jb, "ctu": c, "bytes": nb, "extra": ()}
+        # Motion compensation (hmr_motion_compensation_luma / _chroma): one job per PU and component instead of one or two
+        # interpolation calls through the 80-pitch intermediate window.
+        refc = arena.alloc(2 * CREF_STRIDE * (HA // 2 + PAD), pix(2 * CREF_STRIDE * (HA // 2 + PAD)))
+        for key, n in sorted(calls.items()):
+            kp = key.split(":")
+            if kp[0] not in ("mc_luma", "mc_chroma"):
+                continue
+            luma = kp[0] == "mc_luma"
+            if luma:
+                w, h, fx, fy = (int(v) for v in kp[1:5])
+            else:
+                w = h = int(kp[1]); fx, fy = int(kp[2]), int(kp[3])
+            taps, fbits = (8, 2) if luma else (4, 3)
+            jb = jobs(n)
+            c = ctus(n)
+            if luma:
+                jb["a_off"] = frame(n, ref0, w, h, 0, 0, ctu=c); jb["a_stride"] = REF_STRIDE
+            else:
+                cx, cy = c % NCX, c // NCX
+                plane = rng.integers(0, 2, n)
+                x = cx * 32 + rng.integers(0, 32 - w + 1, n); y = cy * 32 + rng.integers(0, 32 - h + 1, n)
+                jb["a_off"] = refc + plane * (CREF_STRIDE * (HA // 2 + PAD)) + (y + PAD // 2) * CREF_STRIDE + PAD // 2 + x; jb["a_stride"] = CREF_STRIDE
+            jb["c_off"] = wnd(n, predw, 64, w, h, align=min(w, 8), ctu=c); jb["c_stride"] = 64
+            jb["w"] = w; jb["h"] = h
+            mvx = (rng.integers(-10, 11, n) << fbits) + (rng.integers(1, 1 << fbits, n) if fx else 0)
+            mvy = (rng.integers(-6, 7, n) << fbits) + (rng.integers(1, 1 << fbits, n) if fy else 0)
+            jb["p0"] = mvx.astype(np.int32).view(np.uint32); jb["p1"] = mvy.astype(np.int32).view(np.uint32)
+            lanes = min(max(w * h // 4, 16), 64)
+            lanes = 16 if lanes < 32 else (32 if lanes < 64 else 64)
+            if fx and fy:
+                nb = 2 * ((w + taps - 1) * (h + taps - 1) + w * (h + taps - 1)) + 2 * (w * (h + taps - 1) + w * h)
+            elif fx or fy:
+                nb = 2 * (w * (h + taps - 1) + w * h)
+            else:
+                nb = 4 * w * h
+            add("mc_luma" if luma else "mc_chroma", "hmr_gpu_mc_batch", (1 if luma else 0) | (lanes << 8), jb, n * nb)
         # The per-TU sequence predict -> transform -> quant -> [inv_quant -> itransform] -> reconst -> ssd16b (encode_intra_cu /
         # encode_inter_cu) is issued as ONE fused launch per TU size.  Counts come from the recorded mix: one chain per quant call;
         # the share of coded TUs is the recorded inv_quant / quant ratio; ssd16b calls beyond the chains stay separate jobs.
@@ -438,7 +524,8 @@ def main():
 
     OPS = {"hmr_gpu_sad_batch": 1, "hmr_gpu_ssd16b_batch": 2, "hmr_gpu_predict_batch": 3, "hmr_gpu_reconst_batch": 4, "hmr_gpu_copy_batch": 5,
            "hmr_gpu_intra_pred_batch": 7, "hmr_gpu_intra_refs_batch": 8, "hmr_gpu_interpolate_batch": 9, "hmr_gpu_transform_batch": 11,
-           "hmr_gpu_itransform_batch": 12, "hmr_gpu_quant_batch": 13, "hmr_gpu_inv_quant_batch": 14, "hmr_gpu_tu_chain_batch": 22}
+           "hmr_gpu_itransform_batch": 12, "hmr_gpu_quant_batch": 13, "hmr_gpu_inv_quant_batch": 14, "hmr_gpu_mc_batch": 15,
+           "hmr_gpu_motion_estimation_batch": 16, "hmr_gpu_tu_chain_batch": 22}
     OP_EDGE, OP_DEBLOCK, OP_STATS, OP_APPLY, OP_PAD = 17, 18, 19, 20, 21
     cmds, names = [], []
     for g in groups:
@@ -447,6 +534,10 @@ def main():
             cm.size = g["size"] << 8            # kind 0 (int16) | uniform square size hint
         if g["fn"] == "hmr_gpu_quant_batch":
             cm.b = None                          # deltaU is scratch in the reference; not returned
+        if g["fn"] == "hmr_gpu_motion_estimation_batch":
+            g["d_out"] = torch.zeros(5 * len(g["jobs"]), dtype=torch.int32, device=dev)     # hmr_gpu_me_result per PU
+            cm.out = g["d_out"].data_ptr()
+            cm.p = (C.c_int * 4)(128, 64, W, HA)     # MOTION_SEARCH_RANGE_X/Y, picture size
         if g["fn"] == "hmr_gpu_tu_chain_batch":
             g["d_ac"] = torch.zeros(len(g["jobs"]), dtype=torch.int32, device=dev)
             cm.p64 = (P * 2)(base, g["d_ac"].data_ptr())   # reconstruction base, ac_sum

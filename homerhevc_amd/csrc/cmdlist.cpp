@@ -31,7 +31,7 @@ static int run_one(hmr_gpu_ctx *ctx, const hmr_gpu_cmd &c)
 	case HMR_GPU_OP_ITRANSFORM: return hmr_gpu_itransform_batch(ctx, jobs, c.njobs, c.size, a, o);
 	case HMR_GPU_OP_QUANT: return hmr_gpu_quant_batch(ctx, jobs, c.njobs, c.size, a, o, (int16_t *)c.b, (int32_t *)c.out);
 	case HMR_GPU_OP_INV_QUANT: return hmr_gpu_inv_quant_batch(ctx, jobs, c.njobs, c.size, a, o);
-	case HMR_GPU_OP_MC: return hmr_gpu_mc_batch(ctx, jobs, c.njobs, c.size & 1, (c.size >> 1) & 1, a, o);
+	case HMR_GPU_OP_MC: return hmr_gpu_mc_batch(ctx, jobs, c.njobs, c.size, c.p[0], a, o);   /* size = flags, p[0] = is_bi */
 	case HMR_GPU_OP_ME:
 		return hmr_gpu_motion_estimation_batch(ctx, (const hmr_gpu_me_job *)c.jobs, c.njobs, c.size, a, b, c.p[0], c.p[1], c.p[2], c.p[3], (hmr_gpu_me_result *)c.out);
 	case HMR_GPU_OP_EDGE_FLAGS: return hmr_gpu_edge_flags_frame(ctx, (const uint8_t *)c.a, (const uint8_t *)c.b, c.p[0], c.p[1], c.p[2], (uint8_t *)c.c);

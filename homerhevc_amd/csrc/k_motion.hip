@@ -249,17 +249,24 @@ __global__ __launch_bounds__(MeGeo<N>::WPB * 64) void k_motion_estimation(const 
 }
 
 // Motion compensation: p0 = mv.x, p1 = mv.y (quarter samples for luma, eighth samples for chroma), w/h extent,
-// a = co-located block in the reference, c = prediction.  Two-stage vectors keep the first stage in an LDS tile.
+// a = co-located block in the reference, c = prediction.  `lanes_per_job` lanes share a job (small chroma blocks fill a
+// wave together); two-stage vectors keep the first stage in the job's share of an LDS tile.
 template <int TAPS>
-__global__ __launch_bounds__(HMR_BLOCK) void k_mc(const hmr_gpu_job *__restrict__ jobs, int njobs, int is_bi, const int16_t *__restrict__ A, int16_t *__restrict__ Cc)
+__global__ __launch_bounds__(HMR_BLOCK) void k_mc(const hmr_gpu_job *__restrict__ jobs, int njobs, int is_bi, int lanes_per_job, const int16_t *__restrict__ A,
+						     int16_t *__restrict__ Cc)
 {
 	constexpr int FM = TAPS == 8 ? 3 : 7, FS = TAPS == 8 ? 2 : 3, MAXW = TAPS == 8 ? 64 : 32;
-	__shared__ int16_t sTile[HMR_WAVES_PER_BLOCK][(MAXW + TAPS - 1) * MAXW];
-	const int lane = lane_id(), w = wave_in_block();
+	constexpr int TILE = (MAXW + TAPS - 1) * MAXW;
+	__shared__ int16_t sTile[HMR_WAVES_PER_BLOCK][TILE];
+	const int G = lanes_per_job, JPW = HMR_WAVE / G, share = TILE / JPW;
+	const int sub = lane_id() / G, lane = lane_id() % G, w = wave_in_block();
 	const bool last = !is_bi;
-	const JobRange jr = xcd_job_range(njobs, HMR_WAVES_PER_BLOCK);
-	for (long j = jr.begin + w; j < jr.end; j += jr.stride) {
-		const hmr_gpu_job jb = load_job_uniform(jobs, j);
+	int16_t *tile = sTile[w] + sub * share;
+	const JobRange jr = xcd_job_range(njobs, JPW * HMR_WAVES_PER_BLOCK);
+	for (long j0 = jr.begin + w * JPW; j0 < jr.end; j0 += jr.stride) {
+		const long j = j0 + sub;
+		if (j >= jr.end) continue;
+		const hmr_gpu_job jb = JPW == 1 ? load_job_uniform(jobs, j) : jobs[j];
 		const int bw = jb.w, bh = jb.h, mvx = (int)jb.p0, mvy = (int)jb.p1;
 		const int xf = mvx & FM, yf = mvy & FM, rs = (int)jb.a_stride, ds = (int)jb.c_stride;
 		const int16_t *src = A + jb.a_off + (ptrdiff_t)(mvy >> FS) * rs + (mvx >> FS);
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_mc(const hmr_gpu_job *__restrict_
 			const int step = vert ? rs : 1, f = vert ? yf : xf;
 			const int16_t *s0 = src - (TAPS / 2 - 1) * step;
 			if (TAPS == 4 && f == 0 && bw < 4) continue;   // hmr_sse42_functions_inter_prediction.c:822
-			for (int e = lane; e < bw * bh; e += 64) {
+			for (int e = lane; e < bw * bh; e += G) {
 				const int y = e / bw, x = e - y * bw;
 				int v;
 				if (f == 0) {
@@ -293,24 +300,41 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_mc(const hmr_gpu_job *__restrict_
 			continue;
 		}
 		const int th = bh + TAPS - 1;
-		for (int e = lane; e < bw * th; e += 64) {
-			const int y = e / bw, x = e - y * bw;
-			const int16_t *p = src + (ptrdiff_t)(y - (TAPS / 2 - 1)) * rs + x - (TAPS / 2 - 1);
-			int s = 0;
+		if (bw * th <= share) {
+			for (int e = lane; e < bw * th; e += G) {
+				const int y = e / bw, x = e - y * bw;
+				const int16_t *p = src + (ptrdiff_t)(y - (TAPS / 2 - 1)) * rs + x - (TAPS / 2 - 1);
+				int s = 0;
 #pragma unroll
-			for (int k = 0; k < TAPS; k++) s += p[k] * cx[k];
-			sTile[w][y * bw + x] = (int16_t)sat16i(s - 8192);
-		}
-		wave_sync();
-		for (int e = lane; e < bw * bh; e += 64) {
-			const int y = e / bw, x = e - y * bw;
-			int s = 0;
+				for (int k = 0; k < TAPS; k++) s += p[k] * cx[k];
+				tile[y * bw + x] = (int16_t)sat16i(s - 8192);
+			}
+			wave_sync();
+			for (int e = lane; e < bw * bh; e += G) {
+				const int y = e / bw, x = e - y * bw;
+				int s = 0;
 #pragma unroll
-			for (int k = 0; k < TAPS; k++) s += sTile[w][(y + k) * bw + x] * cy[k];
-			const int v = last ? clip3i(sat16i((s + 2048 + (8192 << 6)) >> 12), 0, 255) : sat16i(s >> 6);
-			dst[(size_t)y * ds + x] = (int16_t)v;
+				for (int k = 0; k < TAPS; k++) s += tile[(y + k) * bw + x] * cy[k];
+				const int v = last ? clip3i(sat16i((s + 2048 + (8192 << 6)) >> 12), 0, 255) : sat16i(s >> 6);
+				dst[(size_t)y * ds + x] = (int16_t)v;
+			}
+			wave_sync();
+		} else {
+			// the job does not fit its LDS share (hint too small for this block): recompute the first stage per output row
+			for (int e = lane; e < bw * bh; e += G) {
+				const int y = e / bw, x = e - y * bw;
+				int s2 = 0;
+				for (int r = 0; r < TAPS; r++) {
+					const int16_t *p = src + (ptrdiff_t)(y + r - (TAPS / 2 - 1)) * rs + x - (TAPS / 2 - 1);
+					int s = 0;
+#pragma unroll
+					for (int k = 0; k < TAPS; k++) s += p[k] * cx[k];
+					s2 += sat16i(s - 8192) * cy[r];
+				}
+				const int v = last ? clip3i(sat16i((s2 + 2048 + (8192 << 6)) >> 12), 0, 255) : sat16i(s2 >> 6);
+				dst[(size_t)y * ds + x] = (int16_t)v;
+			}
 		}
-		wave_sync();
 	}
 }
 
@@ -334,12 +358,16 @@ extern "C" int hmr_gpu_motion_estimation_batch(hmr_gpu_ctx *ctx, const hmr_gpu_m
 	return HMR_GPU_OK;
 }
 
-extern "C" int hmr_gpu_mc_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int is_luma, int is_bi, const int16_t *a, int16_t *c)
+extern "C" int hmr_gpu_mc_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int flags, int is_bi, const int16_t *a, int16_t *c)
 {
 	if (njobs <= 0) return HMR_GPU_OK;
-	dim3 grid(hmr_grid_for_waves(njobs)), block(HMR_BLOCK);
-	if (is_luma) hipLaunchKernelGGL((k_mc<8>), grid, block, 0, ctx->stream, jobs, njobs, is_bi, a, c);
-	else hipLaunchKernelGGL((k_mc<4>), grid, block, 0, ctx->stream, jobs, njobs, is_bi, a, c);
+	const int is_luma = flags & 1;
+	int g = (flags >> 8) & 0xff;   // lanes per job hint: 16 / 32 / 64 (0 = 64)
+	if (g != 16 && g != 32) g = 64;
+	const int jpw = HMR_WAVE / g;
+	dim3 grid(hmr_grid_for_waves(((long)njobs + jpw - 1) / jpw)), block(HMR_BLOCK);
+	if (is_luma) hipLaunchKernelGGL((k_mc<8>), grid, block, 0, ctx->stream, jobs, njobs, is_bi, g, a, c);
+	else hipLaunchKernelGGL((k_mc<4>), grid, block, 0, ctx->stream, jobs, njobs, is_bi, g, a, c);
 	HIP_TRY(hipGetLastError());
 	return HMR_GPU_OK;
 }

@@ -233,8 +233,9 @@ typedef struct hmr_gpu_me_result {
 int hmr_gpu_motion_estimation_batch(hmr_gpu_ctx *ctx, const hmr_gpu_me_job *jobs, int njobs, int size, const int16_t *orig_base, const int16_t *ref_base,
 				    int range_x, int range_y, int frame_w, int frame_h, hmr_gpu_me_result *out);
 /* hmr_motion_compensation_luma / _chroma (hmr_motion_inter.c:1779,1860): a = co-located block, c = prediction, w/h extent,
- * p0 = mv.x, p1 = mv.y (as int32; quarter samples for luma, eighth samples for chroma) */
-int hmr_gpu_mc_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int is_luma, int is_bi_predict, const int16_t *a_base, int16_t *c_base);
+ * p0 = mv.x, p1 = mv.y (as int32; quarter samples for luma, eighth samples for chroma).
+ * flags bit 0: luma / chroma; bits 8..15: lanes-per-job hint 16 / 32 / 64 (0 = 64): that many lanes share a block of w*h samples */
+int hmr_gpu_mc_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int flags, int is_bi_predict, const int16_t *a_base, int16_t *c_base);
 /* host-pointer (drop-in) forms */
 uint32_t hmr_gpu_motion_estimation(int16_t *orig, int orig_stride, int16_t *ref, int ref_stride, int gx, int gy, int init_x, int init_y, int size,
 				   int range_x, int range_y, int frame_w, int frame_h, const int32_t *amvp, int n_amvp, const int32_t *search, int n_search,
@@ -255,7 +256,7 @@ enum hmr_gpu_op {
 /* One call of the batched / frame-level API: `size` is that entry's size/kind/flags argument, a/b/c/out its pointer arguments in
  * declaration order (frame-level ops take host pointers to hmr_gpu_frame / hmr_gpu_units that must outlive the list), p[] its
  * scalar arguments (deblock: cb, cr, beta, tc offsets; pad: pad_x, pad_y; edge flags: width, height, units_stride; ME: range_x,
- * range_y, frame_w, frame_h).  QUANT: b = deltaU base (may be NULL), out = ac_sum. */
+ * range_y, frame_w, frame_h; MC: size = flags, p[0] = is_bi_predict).  QUANT: b = deltaU base (may be NULL), out = ac_sum. */
 typedef struct hmr_gpu_cmd {
 	int op, njobs, size;
 	int p[4];

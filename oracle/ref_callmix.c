@@ -20,13 +20,13 @@
 #include "hmr_sse42_functions.h"
 
 #define MAXKEYS 4096
-static struct { char key[48]; long n; } g_cnt[MAXKEYS];
+static struct { char key[64]; long n; } g_cnt[MAXKEYS];
 static int g_nkeys;
 static low_level_funcs_t g_orig;
 
 static void bump(const char *fmt, int a, int b, int c, int d)
 {
-	char key[48];
+	char key[64];
 	int i;
 	snprintf(key, sizeof key, fmt, a, b, c, d);
 	for (i = 0; i < g_nkeys; i++)
@@ -48,14 +48,18 @@ static void w_ang(henc_thread_t *et, ctu_info_t *ctu, int16_t *pr, int ps, int16
 	bump("intra_angular:%d:%d:%d", n, mode, luma, 0);
 	g_orig.create_intra_angular_prediction(et, ctu, pr, ps, adi, as, n, mode, luma);
 }
+/* where an interpolation call comes from: 0 = direct, 1 = sub-pel plane builders, 2 = motion compensation */
+static __thread int g_origin;
+static const char *k_il[3] = {"interp_luma:%d:%d:%d:%d", "interp_luma@planes:%d:%d:%d:%d", "interp_luma@mc:%d:%d:%d:%d"};
+static const char *k_ic[3] = {"interp_chroma:%d:%d:%d:%d", "interp_chroma@planes:%d:%d:%d:%d", "interp_chroma@mc:%d:%d:%d:%d"};
 static void w_il(int16_t *s, int ss, int16_t *d, int ds, int fr, int w, int h, int v, int f, int l)
 {
-	bump("interp_luma:%d:%d:%d:%d", w, h, (fr != 0) | (v << 1) | (f << 2) | (l << 3), 0);
+	bump(k_il[g_origin], w, h, (fr != 0) | (v << 1) | (f << 2) | (l << 3), 0);
 	g_orig.interpolate_luma_m_compensation(s, ss, d, ds, fr, w, h, v, f, l);
 }
 static void w_ic(int16_t *s, int ss, int16_t *d, int ds, int fr, int w, int h, int v, int f, int l)
 {
-	bump("interp_chroma:%d:%d:%d:%d", w, h, (fr != 0) | (v << 1) | (f << 2) | (l << 3), 0);
+	bump(k_ic[g_origin], w, h, (fr != 0) | (v << 1) | (f << 2) | (l << 3), 0);
 	g_orig.interpolate_chroma_m_compensation(s, ss, d, ds, fr, w, h, v, f, l);
 }
 static void w_wavg(int16_t *a, int as, int16_t *b, int bs, int16_t *d, int ds, int h, int w, int bd) { bump("weighted_average:%d:%d", w, h, 0, 0); g_orig.weighted_average_motion(a, as, b, bs, d, ds, h, w, bd); }
@@ -98,12 +102,30 @@ void fill_reference_samples(henc_thread_t *et, ctu_info_t *ctu, cu_partition_inf
 void hmr_half_pixel_estimation_luma_hm(henc_thread_t *et, int16_t *r, int rs, cu_partition_info_t *cu, int w, int h, int sh, motion_vector_t *mv)
 {
 	bump("half_pel_planes:%d", w, 0, 0, 0);
+	g_origin = 1;
 	((void (*)(henc_thread_t *, int16_t *, int, cu_partition_info_t *, int, int, int, motion_vector_t *))REAL(hmr_half_pixel_estimation_luma_hm))(et, r, rs, cu, w, h, sh, mv);
+	g_origin = 0;
 }
 void hmr_quarter_pixel_estimation_luma_hm(henc_thread_t *et, int16_t *r, int rs, cu_partition_info_t *cu, int w, int h, int sh, motion_vector_t *mv)
 {
 	bump("quarter_pel_planes:%d", w, 0, 0, 0);
+	g_origin = 1;
 	((void (*)(henc_thread_t *, int16_t *, int, cu_partition_info_t *, int, int, int, motion_vector_t *))REAL(hmr_quarter_pixel_estimation_luma_hm))(et, r, rs, cu, w, h, sh, mv);
+	g_origin = 0;
+}
+void hmr_motion_compensation_luma(henc_thread_t *et, cu_partition_info_t *cu, int16_t *ref, int rs, int16_t *pred, int ps, int w, int h, int sh, motion_vector_t *mv, int bi)
+{
+	bump("mc_luma:%d:%d:%d:%d", w, h, (mv->hor_vector & 3) != 0, (mv->ver_vector & 3) != 0);
+	g_origin = 2;
+	((void (*)(henc_thread_t *, cu_partition_info_t *, int16_t *, int, int16_t *, int, int, int, int, motion_vector_t *, int))REAL(hmr_motion_compensation_luma))(et, cu, ref, rs, pred, ps, w, h, sh, mv, bi);
+	g_origin = 0;
+}
+void hmr_motion_compensation_chroma(henc_thread_t *et, int16_t *ref, int rs, int16_t *pred, int ps, int size, int sh, motion_vector_t *mv, int bi)
+{
+	bump("mc_chroma:%d:%d:%d", size, (mv->hor_vector & 7) != 0, (mv->ver_vector & 7) != 0, 0);
+	g_origin = 2;
+	((void (*)(henc_thread_t *, int16_t *, int, int16_t *, int, int, int, motion_vector_t *, int))REAL(hmr_motion_compensation_chroma))(et, ref, rs, pred, ps, size, sh, mv, bi);
+	g_origin = 0;
 }
 void hmr_deblock_filter_cu(henc_thread_t *et, slice_t *s, ctu_info_t *ctu, int dir)
 {

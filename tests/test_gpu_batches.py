@@ -1,0 +1,411 @@
+"""GPU parity of the BATCHED entries (include/homer_gpu.h section 3, 5, 7): hundreds of jobs per launch on one device arena, so
+lane packing (several jobs per wavefront), the XCD job partition and the unaligned vector paths are exercised the way bench.py
+uses them.  Every job is replayed through the CPU oracle on a host copy of the same arena and the WHOLE arena is compared, so a
+stray write outside a job's output block fails too."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import libs
+from kernel_cases import quant_depth
+
+pytestmark = pytest.mark.gpu
+
+JOB = np.dtype([("a_off", "<u4"), ("a_stride", "<u4"), ("b_off", "<u4"), ("b_stride", "<u4"), ("c_off", "<u4"), ("c_stride", "<u4"),
+                ("w", "<u2"), ("h", "<u2"), ("p0", "<u4"), ("p1", "<u4")])
+TU_JOB = np.dtype([("orig_off", "<u4"), ("orig_stride", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("rec_off", "<u4"),
+                   ("rec_stride", "<u4"), ("lev_off", "<u4"), ("p0", "<u4"), ("p1", "<u4")])
+ME_JOB = np.dtype([("corr", "<f8"), ("orig_off", "<u4"), ("orig_stride", "<u4"), ("ref_off", "<u4"), ("ref_stride", "<u4"), ("gx", "<i2"), ("gy", "<i2"),
+                   ("init_x", "<i2"), ("init_y", "<i2"), ("n_amvp", "<i2"), ("n_search", "<i2"), ("amvp", "<i2", (2, 2)), ("search", "<i2", (5, 2)),
+                   ("action", "<u4"), ("reserved", "<u4")])
+VP = C.c_void_p
+NJ = 611                      # odd on purpose: ragged last wavefront / last XCD chunk
+PW, PH = 512, 320             # input planes
+SLOT = 80 * 80                # one output slot per job
+
+
+class Rig:
+    """Host arena (int16) mirrored on the device: [pixels | residuals | 14-bit intermediates | out1 slots | out2 slots]."""
+
+    def __init__(self, gpu, rng, nj=NJ):
+        self.gpu, self.nj = gpu, nj
+        self.ctx = VP()
+        assert gpu.hmr_gpu_create(C.byref(self.ctx), 0, None) == 0, gpu.hmr_gpu_last_error()
+        self.pix, self.res, self.mid = 0, PW * PH, 2 * PW * PH
+        self.out1, self.out2 = 3 * PW * PH, 3 * PW * PH + nj * SLOT
+        self.size = 3 * PW * PH + 2 * nj * SLOT
+        h = np.full(self.size, 0x1234, np.int16)
+        h[self.pix:self.res] = rng.integers(0, 256, PW * PH)
+        h[self.res:self.mid] = rng.integers(-300, 301, PW * PH)
+        h[self.mid:self.out1] = rng.integers(-8192, 8129, PW * PH)
+        self.host = h
+        self.dev = self.malloc(self.size * 2)
+        self.bufs = [self.dev]
+
+    def malloc(self, nbytes):
+        p = VP()
+        assert self.gpu.hmr_gpu_malloc(self.ctx, C.byref(p), C.c_size_t(max(nbytes, 4))) == 0
+        return p
+
+    def up(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.malloc(arr.nbytes)
+        self.bufs.append(p)
+        assert self.gpu.hmr_gpu_upload(self.ctx, p, VP(arr.ctypes.data), C.c_size_t(arr.nbytes)) == 0
+        return p
+
+    def down(self, p, shape, dtype):
+        out = np.zeros(shape, dtype)
+        assert self.gpu.hmr_gpu_download(self.ctx, VP(out.ctypes.data), p, C.c_size_t(out.nbytes)) == 0
+        return out
+
+    def launch(self, name, *args):
+        """upload the arena, run one batched call, return the device arena afterwards"""
+        assert self.gpu.hmr_gpu_upload(self.ctx, self.dev, VP(self.host.ctypes.data), C.c_size_t(self.size * 2)) == 0
+        rc = getattr(self.gpu, name)(self.ctx, *args)
+        assert rc == 0, (name, self.gpu.hmr_gpu_last_error())
+        assert self.gpu.hmr_gpu_sync(self.ctx) == 0, (name, self.gpu.hmr_gpu_last_error())
+        return self.down(self.dev, self.size, np.int16)
+
+    def block(self, rng, base, bw, bh, margin=0):
+        """random element offsets of bw x bh blocks inside an input plane, `margin` samples away from its border"""
+        x = rng.integers(margin, PW - bw - margin + 1, self.nj)
+        y = rng.integers(margin, PH - bh - margin + 1, self.nj)
+        return (base + y * PW + x).astype(np.uint32)
+
+    def slots(self, base):
+        return (base + np.arange(self.nj, dtype=np.int64) * SLOT).astype(np.uint32)
+
+    def close(self):
+        for p in self.bufs:
+            self.gpu.hmr_gpu_free(self.ctx, p)
+        self.gpu.hmr_gpu_destroy(self.ctx)
+
+
+@pytest.fixture()
+def rig():
+    gpu = libs.load_gpu()
+    r = Rig(gpu, np.random.default_rng(77))
+    yield r
+    r.close()
+
+
+def at(arr, off):
+    return VP(arr.ctypes.data + int(off) * arr.itemsize)
+
+
+def same(got, exp, what):
+    if not np.array_equal(got, exp):
+        bad = np.flatnonzero(got != exp)
+        raise AssertionError(f"{what}: {bad.size} elements differ, first at {bad[0]} (got {got[bad[0]]}, expected {exp[bad[0]]})")
+
+
+@pytest.mark.parametrize("which", ["sad", "ssd16b"])
+@pytest.mark.parametrize("n", [4, 8, 16, 32, 64])
+def test_sad_ssd(rig, oracle, which, n):
+    rng = np.random.default_rng(n)
+    jb = np.zeros(rig.nj, JOB)
+    jb["a_off"] = rig.block(rng, rig.pix, n, n); jb["a_stride"] = PW
+    jb["b_off"] = rig.block(rng, rig.res if which == "ssd16b" else rig.pix, n, n); jb["b_stride"] = PW
+    if which == "ssd16b":
+        jb["b_stride"][::3] = 0
+    d_out = rig.malloc(4 * rig.nj); rig.bufs.append(d_out)
+    g = rig.launch(f"hmr_gpu_{which}_batch", rig.up(jb), rig.nj, n, rig.dev, rig.dev, d_out)
+    same(g, rig.host, "arena untouched")
+    f = getattr(oracle, "ora_" + which); f.restype = C.c_uint32
+    exp = np.array([f(at(rig.host, j["a_off"]), int(j["a_stride"]), at(rig.host, j["b_off"]), int(j["b_stride"]), n) for j in jb], np.uint32)
+    same(rig.down(d_out, rig.nj, np.uint32), exp, which)
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32, 64])
+def test_predict_reconst(rig, oracle, n):
+    rng = np.random.default_rng(n)
+    jb = np.zeros(rig.nj, JOB)
+    jb["a_off"] = rig.block(rng, rig.pix, n, n); jb["a_stride"] = PW
+    jb["b_off"] = rig.block(rng, rig.pix, n, n); jb["b_stride"] = PW
+    jb["c_off"] = rig.slots(rig.out1); jb["c_stride"] = np.where(np.arange(rig.nj) % 2, n, 80)
+    g = rig.launch("hmr_gpu_predict_batch", rig.up(jb), rig.nj, n, rig.dev, rig.dev, rig.dev)
+    o = rig.host.copy()
+    for j in jb:
+        oracle.ora_predict(at(o, j["a_off"]), int(j["a_stride"]), at(o, j["b_off"]), int(j["b_stride"]), at(o, j["c_off"]), int(j["c_stride"]), n)
+    same(g, o, "predict")
+    jb["b_off"] = rig.block(rng, rig.res, n, n)
+    jb["b_stride"][::4] = 0
+    g = rig.launch("hmr_gpu_reconst_batch", rig.up(jb), rig.nj, n, rig.dev, rig.dev, rig.dev)
+    o = rig.host.copy()
+    for j in jb:
+        oracle.ora_reconst(at(o, j["a_off"]), int(j["a_stride"]), at(o, j["b_off"]), int(j["b_stride"]), at(o, j["c_off"]), int(j["c_stride"]), n)
+    same(g, o, "reconst")
+
+
+@pytest.mark.parametrize("square", [0, 4, 8, 16, 32, 64])
+def test_copy(rig, oracle, square):
+    rng = np.random.default_rng(square)
+    jb = np.zeros(rig.nj, JOB)
+    if square:
+        jb["w"] = jb["h"] = square
+    else:
+        jb["w"] = rng.integers(1, 17, rig.nj) * 4; jb["h"] = rng.integers(1, 65, rig.nj)
+    x = rng.integers(0, PW - 64, rig.nj); y = rng.integers(0, PH - 64, rig.nj)
+    jb["a_off"] = rig.res + y * PW + x; jb["a_stride"] = PW
+    jb["c_off"] = rig.slots(rig.out1); jb["c_stride"] = 80
+    g = rig.launch("hmr_gpu_copy_batch", rig.up(jb), rig.nj, square << 8, rig.dev, rig.dev)
+    o = rig.host.copy()
+    for j in jb:     # the SSE copy rounds the width up to its vector; the contract is the h x w block
+        src = o[j["a_off"]:j["a_off"] + (j["h"] - 1) * PW + j["w"]]
+        for r in range(j["h"]):
+            o[j["c_off"] + r * 80:j["c_off"] + r * 80 + j["w"]] = src[r * PW:r * PW + j["w"]]
+    same(g, o, "copy_16_16")
+    # the oracle's copy agrees on the block itself
+    j = jb[0]
+    blk = np.zeros((int(j["h"]), 96), np.int16)
+    oracle.ora_copy_16_16(at(rig.host, j["a_off"]), PW, at(blk, 0), 96, int(j["h"]), int(j["w"]))
+    same(blk[:, :j["w"]].ravel(), g[j["c_off"]:j["c_off"] + 80 * j["h"]].reshape(-1, 80)[:, :j["w"]].ravel(), "copy vs oracle")
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64])
+def test_modified_variance(rig, oracle, n):
+    rng = np.random.default_rng(n)
+    jb = np.zeros(rig.nj, JOB)
+    jb["a_off"] = rig.block(rng, rig.pix, n, n); jb["a_stride"] = PW
+    jb["p0"] = rng.integers(1, 3, rig.nj)
+    d_out = rig.malloc(4 * rig.nj); rig.bufs.append(d_out)
+    g = rig.launch("hmr_gpu_modified_variance_batch", rig.up(jb), rig.nj, n, rig.dev, d_out)
+    same(g, rig.host, "arena untouched")
+    oracle.ora_modified_variance.restype = C.c_uint32
+    exp = np.array([oracle.ora_modified_variance(at(rig.host, j["a_off"]), n, PW, int(j["p0"])) for j in jb], np.uint32)
+    same(rig.down(d_out, rig.nj, np.uint32), exp, "modified_variance")
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32, 64])
+def test_intra_pred_and_refs(rig, oracle, n):
+    rng = np.random.default_rng(n)
+    jb = np.zeros(rig.nj, JOB)
+    jb["a_off"] = rig.pix + rng.integers(0, PW * PH - 4 * n - 1, rig.nj)
+    jb["c_off"] = rig.slots(rig.out1); jb["c_stride"] = 80
+    jb["p0"] = rng.integers(0, 35, rig.nj); jb["p1"] = rng.integers(0, 2, rig.nj)
+    g = rig.launch("hmr_gpu_intra_pred_batch", rig.up(jb), rig.nj, n, rig.dev, rig.dev)
+    o = rig.host.copy()
+    for j in jb:
+        if j["p0"] == 0:
+            oracle.ora_intra_planar(at(o, j["c_off"]), 80, at(o, j["a_off"]), 4 * n + 1, n)
+        else:
+            oracle.ora_intra_angular(at(o, j["c_off"]), 80, at(o, j["a_off"]), 4 * n + 1, n, int(j["p0"]), int(j["p1"]))
+    same(g, o, "intra_pred")
+
+    jb = np.zeros(rig.nj, JOB)
+    jb["a_off"] = rig.block(rng, rig.pix, 2 * n + 1, 2 * n + 1); jb["a_stride"] = PW
+    jb["c_off"] = rig.slots(rig.out1); jb["b_off"] = rig.slots(rig.out2)
+    avail = rng.integers(0, 16, rig.nj)
+    left, top = (avail & 1) | ((avail >> 2) & 1), ((avail >> 1) & 1) | ((avail >> 3) & 1)
+    bl, tr = (avail >> 2) & 1, (avail >> 3) & 1
+    filt, strong = rng.integers(0, 2, rig.nj), rng.integers(0, 2, rig.nj)
+    bl_size = np.where(bl, np.where(rng.random(rig.nj) < 0.5, n, max(n // 2, 4)), 0)
+    tr_size = np.where(tr, np.where(rng.random(rig.nj) < 0.5, n, max(n // 2, 4)), 0)
+    jb["p0"] = left | (top << 1) | (bl << 2) | (tr << 3) | (filt << 4) | (strong << 5)
+    jb["p1"] = bl_size | (tr_size << 16)
+    g = rig.launch("hmr_gpu_intra_refs_batch", rig.up(jb), rig.nj, n, rig.dev, rig.dev)
+    o = rig.host.copy()
+    for i, j in enumerate(jb):
+        oracle.ora_fill_reference_samples(at(o, j["a_off"]), PW, n, int(left[i]), int(top[i]), int(bl[i]), int(tr[i]), int(bl_size[i]), int(tr_size[i]),
+                                          at(o, j["c_off"]))
+        if filt[i]:
+            oracle.ora_adi_filter(at(o, j["c_off"]), at(o, j["b_off"]), 4 * n + 1, n, int(strong[i]))
+    same(g, o, "intra_refs")
+
+
+@pytest.mark.parametrize("luma", [1, 0])
+@pytest.mark.parametrize("lanes", [4, 8, 16, 32, 64])
+def test_interpolate(rig, oracle, luma, lanes):
+    rng = np.random.default_rng(luma * 100 + lanes)
+    taps = 8 if luma else 4
+    for first in (1, 0):
+        jb = np.zeros(rig.nj, JOB)
+        wmax = {4: 8, 8: 12, 16: 17, 32: 33, 64: 65}[lanes]
+        jb["w"] = rng.integers(2 if not luma else 4, wmax + 1, rig.nj); jb["h"] = rng.integers(2, wmax + 8, rig.nj)
+        jb["a_off"] = rig.block(rng, rig.pix if first else rig.mid, 80, 80, margin=4) ; jb["a_stride"] = PW
+        jb["c_off"] = rig.slots(rig.out1); jb["c_stride"] = 80
+        jb["p0"] = rng.integers(0, 4 if luma else 8, rig.nj)
+        vert, last = rng.integers(0, 2, rig.nj), rng.integers(0, 2, rig.nj)
+        jb["p1"] = vert | (first << 1) | (last << 2)
+        g = rig.launch("hmr_gpu_interpolate_batch", rig.up(jb), rig.nj, luma | (lanes << 8), rig.dev, rig.dev)
+        o = rig.host.copy()
+        f = oracle.ora_interpolate_luma if luma else oracle.ora_interpolate_chroma
+        for i, j in enumerate(jb):
+            f(at(o, j["a_off"]), PW, at(o, j["c_off"]), 80, int(j["p0"]), int(j["w"]), int(j["h"]), int(vert[i]), first, int(last[i]))
+        same(g, o, f"interpolate taps={taps} first={first}")
+
+
+def test_weighted_average(rig, oracle):
+    rng = np.random.default_rng(5)
+    jb = np.zeros(rig.nj, JOB)
+    n = 1 << rng.integers(2, 7, rig.nj)
+    jb["w"] = n; jb["h"] = np.where(rng.random(rig.nj) < 0.2, np.maximum(n // 2, 4), n)
+    jb["a_off"] = rig.block(rng, rig.mid, 64, 64); jb["a_stride"] = PW
+    jb["b_off"] = rig.block(rng, rig.mid, 64, 64); jb["b_stride"] = PW
+    jb["c_off"] = rig.slots(rig.out1); jb["c_stride"] = 80
+    g = rig.launch("hmr_gpu_weighted_average_batch", rig.up(jb), rig.nj, rig.dev, rig.dev, rig.dev)
+    o = rig.host.copy()
+    for j in jb:
+        oracle.ora_weighted_average(at(o, j["a_off"]), PW, at(o, j["b_off"]), PW, at(o, j["c_off"]), 80, int(j["h"]), int(j["w"]))
+    same(g, o, "weighted_average")
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_transform_quant(rig, oracle, n):
+    rng = np.random.default_rng(n)
+    is_dst = rng.integers(0, 2, rig.nj) if n == 4 else np.zeros(rig.nj, np.int64)
+    jb = np.zeros(rig.nj, JOB)
+    jb["a_off"] = rig.block(rng, rig.res, n, n); jb["a_stride"] = PW
+    jb["c_off"] = rig.slots(rig.out1); jb["p0"] = is_dst
+    g = rig.launch("hmr_gpu_transform_batch", rig.up(jb), rig.nj, n, rig.dev, rig.dev)
+    o = rig.host.copy()
+    for j in jb:
+        oracle.ora_transform(at(o, j["a_off"]), at(o, j["c_off"]), PW, n, int(j["p0"]))
+    same(g, o, "transform")
+
+    rig.host[:] = o            # the coefficients just produced feed quant; weaken two thirds of the blocks so sparse paths run
+    coef = rig.host[rig.out1:rig.out1 + rig.nj * SLOT].reshape(rig.nj, SLOT)
+    coef[1::3, :n * n] //= 16
+    coef[2::3, :n * n] //= 64
+    q = np.zeros(rig.nj, JOB)
+    q["a_off"] = rig.slots(rig.out1); q["c_off"] = rig.slots(rig.out2); q["b_off"] = q["c_off"] + n * n
+    comp = rng.integers(0, 3 if n < 32 else 1, rig.nj); intra = rng.integers(0, 2, rig.nj); slice_i = intra | rng.integers(0, 2, rig.nj)
+    sbh = rng.integers(0, 2, rig.nj); scan = np.where(intra == 1, rng.integers(1, 4, rig.nj), 3)
+    per, rem = rng.integers(0, 9, rig.nj), rng.integers(0, 6, rig.nj)
+    q["p0"] = scan | (comp << 2) | (intra << 4) | (slice_i << 5) | (sbh << 6); q["p1"] = per | (rem << 8)
+    d_ac = rig.malloc(4 * rig.nj); rig.bufs.append(d_ac)
+    g = rig.launch("hmr_gpu_quant_batch", rig.up(q), rig.nj, n, rig.dev, rig.dev, rig.dev, d_ac)
+    o = rig.host.copy()
+    ac = np.zeros(rig.nj, np.int32)
+    for i, j in enumerate(q):
+        v = C.c_int(0)
+        oracle.ora_quant(at(o, j["a_off"]), at(o, j["c_off"]), at(o, j["b_off"]), int(scan[i]), quant_depth(n, int(comp[i])), int(comp[i]), int(intra[i]),
+                         int(slice_i[i]), int(sbh[i]), C.byref(v), n, int(per[i]), int(rem[i]))
+        ac[i] = v.value
+    same(g, o, "quant levels + deltaU")
+    same(rig.down(d_ac, rig.nj, np.int32), ac, "ac_sum")
+    # without the deltaU scratch
+    g2 = rig.launch("hmr_gpu_quant_batch", rig.up(q), rig.nj, n, rig.dev, rig.dev, None, d_ac)
+    lev = lambda a: a[rig.out2:rig.out2 + rig.nj * SLOT].reshape(rig.nj, SLOT)[:, :n * n]   # noqa: E731
+    same(lev(g2), lev(o), "quant levels (no deltaU)")
+
+    rig.host[:] = o            # levels -> inv_quant -> itransform
+    iq = np.zeros(rig.nj, JOB)
+    iq["a_off"] = rig.slots(rig.out2); iq["c_off"] = rig.slots(rig.out1)
+    iq["p0"] = (comp << 2) | (intra << 4); iq["p1"] = per | (rem << 8)
+    g = rig.launch("hmr_gpu_inv_quant_batch", rig.up(iq), rig.nj, n, rig.dev, rig.dev)
+    o = rig.host.copy()
+    for i, j in enumerate(iq):
+        oracle.ora_inv_quant(at(o, j["a_off"]), at(o, j["c_off"]), quant_depth(n, int(comp[i])), int(comp[i]), int(intra[i]), n, int(per[i]), int(rem[i]))
+    same(g, o, "inv_quant")
+    rig.host[:] = o
+    it = np.zeros(rig.nj, JOB)
+    it["a_off"] = rig.slots(rig.out1); it["c_off"] = rig.slots(rig.out2); it["c_stride"] = 80; it["p0"] = is_dst
+    g = rig.launch("hmr_gpu_itransform_batch", rig.up(it), rig.nj, n, rig.dev, rig.dev)
+    o = rig.host.copy()
+    for j in it:
+        oracle.ora_itransform(at(o, j["c_off"]), at(o, j["a_off"]), 80, n, int(j["p0"]))
+    same(g, o, "itransform")
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_tu_chain(rig, oracle, n):
+    rng = np.random.default_rng(n)
+    # prediction = source + noise of a per-job strength, so coded and all-zero TUs mix inside one wavefront
+    src = rig.host[rig.pix:rig.res].reshape(PH, PW)
+    noise = rng.integers(-1, 2, (PH, PW)) * np.repeat(np.repeat(rng.choice([0, 2, 12, 60], (PH // 32, PW // 32)), 32, 0), 32, 1)
+    rig.host[rig.res:rig.mid] = np.clip(src + noise, 0, 255).ravel()
+    jb = np.zeros(rig.nj, TU_JOB)
+    pos = rig.block(rng, 0, n, n)
+    jb["orig_off"] = rig.pix + pos; jb["pred_off"] = rig.res + pos; jb["orig_stride"] = jb["pred_stride"] = PW
+    jb["rec_off"] = rig.slots(rig.out1); jb["rec_stride"] = 80
+    jb["lev_off"] = rig.slots(rig.out2)
+    comp = rng.integers(0, 3 if n < 32 else 1, rig.nj); intra = rng.integers(0, 2, rig.nj); sbh = rng.integers(0, 2, rig.nj)
+    per, rem = rng.integers(2, 7, rig.nj), rng.integers(0, 6, rig.nj)
+    is_dst = ((n == 4) & (intra == 1) & (comp == 0)).astype(np.int64)
+    jb["p0"] = 3 | (comp << 2) | (intra << 4) | (intra << 5) | (sbh << 6) | (is_dst << 7); jb["p1"] = per | (rem << 8)
+    d_ssd = rig.malloc(4 * rig.nj); d_ac = rig.malloc(4 * rig.nj); rig.bufs += [d_ssd, d_ac]
+    g = rig.launch("hmr_gpu_tu_chain_batch", rig.up(jb), rig.nj, n, rig.dev, rig.dev, rig.dev, rig.dev, d_ssd, d_ac)
+    o = rig.host.copy()
+    ssd, ac = np.zeros(rig.nj, np.uint32), np.zeros(rig.nj, np.int32)
+    oracle.ora_tu_chain.restype = C.c_uint32
+    for i, j in enumerate(jb):
+        v = C.c_int(0)
+        ssd[i] = oracle.ora_tu_chain(at(o, j["orig_off"]), PW, at(o, j["pred_off"]), PW, at(o, j["lev_off"]), at(o, j["rec_off"]), 80, n, int(is_dst[i]), 3,
+                                     int(comp[i]), int(intra[i]), int(intra[i]), int(sbh[i]), int(per[i]), int(rem[i]), C.byref(v))
+        ac[i] = v.value
+    same(g, o, "tu_chain levels + reconstruction")
+    same(rig.down(d_ssd, rig.nj, np.uint32), ssd, "tu_chain ssd")
+    same(rig.down(d_ac, rig.nj, np.int32), ac, "tu_chain ac_sum")
+
+
+@pytest.mark.parametrize("luma", [1, 0])
+@pytest.mark.parametrize("lanes", [16, 32, 64])
+@pytest.mark.parametrize("is_bi", [0, 1])
+def test_motion_compensation(rig, oracle, luma, lanes, is_bi):
+    rng = np.random.default_rng(luma * 10 + lanes + is_bi)
+    jb = np.zeros(rig.nj, JOB)
+    if luma:   # deliberately includes blocks larger than the hint's LDS share (the kernel's recompute path)
+        n = np.array([8, 16, 32, 64])[rng.integers(0, 4, rig.nj)]
+        jb["w"] = n; jb["h"] = np.where(rng.random(rig.nj) < 0.3, n // 2, n)
+    else:
+        n = np.array([2, 4, 8, 16, 32])[rng.integers(0, 5, rig.nj)]
+        jb["w"] = jb["h"] = n
+    jb["a_off"] = rig.block(rng, rig.pix, 64, 64, margin=24); jb["a_stride"] = PW
+    jb["c_off"] = rig.slots(rig.out1); jb["c_stride"] = 80
+    fb = 2 if luma else 3
+    frac = lambda: np.where(rng.random(rig.nj) < 0.35, 0, rng.integers(0, 1 << fb, rig.nj))   # noqa: E731
+    mvx = (rng.integers(-16, 17, rig.nj) << fb) + frac(); mvy = (rng.integers(-16, 17, rig.nj) << fb) + frac()
+    jb["p0"] = mvx.astype(np.int32).view(np.uint32); jb["p1"] = mvy.astype(np.int32).view(np.uint32)
+    g = rig.launch("hmr_gpu_mc_batch", rig.up(jb), rig.nj, luma | (lanes << 8), is_bi, rig.dev, rig.dev)
+    o = rig.host.copy()
+    for i, j in enumerate(jb):
+        if luma:
+            oracle.ora_mc_luma(at(o, j["a_off"]), PW, at(o, j["c_off"]), 80, int(j["w"]), int(j["h"]), int(mvx[i]), int(mvy[i]), is_bi)
+        else:
+            oracle.ora_mc_chroma(at(o, j["a_off"]), PW, at(o, j["c_off"]), 80, int(j["w"]), int(mvx[i]), int(mvy[i]), is_bi)
+    same(g, o, "motion compensation")
+
+
+@pytest.mark.parametrize("n", [8, 16, 32, 64])
+@pytest.mark.parametrize("action", [7, 6, 1, 3])
+def test_motion_estimation(rig, oracle, n, action):
+    rng = np.random.default_rng(n + action)
+    nj = rig.nj if n < 64 else 97
+    # a reference with structure (so the search has something to find): the source plane is the reference shifted + noise
+    ref = rig.host[rig.pix:rig.res].reshape(PH, PW)
+    sm = ref.astype(np.int64)
+    for _ in range(2):
+        sm = (sm + np.roll(sm, 1, 0) + np.roll(sm, 1, 1) + np.roll(sm, (1, 1), (0, 1))) // 4
+    ref[...] = sm
+    src = np.roll(ref, (3, -5), (0, 1)) + rng.integers(-3, 4, (PH, PW))
+    rig.host[rig.res:rig.mid] = np.clip(src, 0, 255).ravel()
+    FW, FH = PW - 160, PH - 160         # picture = the plane minus an 80-sample margin on every side
+    jb = np.zeros(nj, ME_JOB)
+    gx = rng.integers(0, (FW - n) // 4 + 1, nj) * 4; gy = rng.integers(0, (FH - n) // 4 + 1, nj) * 4
+    pos = (gy + 80) * PW + gx + 80
+    jb["orig_off"] = rig.res + pos; jb["ref_off"] = rig.pix + pos; jb["orig_stride"] = jb["ref_stride"] = PW
+    jb["gx"] = gx; jb["gy"] = gy
+    jb["init_x"] = rng.integers(-12, 13, nj); jb["init_y"] = rng.integers(-8, 9, nj)
+    jb["n_amvp"] = rng.integers(1, 3, nj); jb["n_search"] = rng.integers(0, 6, nj)
+    jb["amvp"] = rng.integers(-48, 49, (nj, 2, 2)); jb["search"] = rng.integers(-40, 41, (nj, 5, 2))
+    qp, avg = rng.integers(20, 40, nj), rng.integers(0, 4000, nj)
+    jb["corr"] = qp * np.clip(avg / 2000.0, 0.15, 1.4)
+    jb["action"] = action
+    d_out = rig.malloc(20 * nj); rig.bufs.append(d_out)
+    g = rig.launch("hmr_gpu_motion_estimation_batch", rig.up(jb), nj, n, rig.dev, rig.dev, 128, 64, FW, FH, d_out)
+    same(g, rig.host, "arena untouched")
+    got = rig.down(d_out, (nj, 5), np.int32)
+    oracle.ora_motion_estimation.restype = C.c_uint32
+    exp = np.zeros((nj, 5), np.int32)
+    I32 = C.c_int32
+    for i, j in enumerate(jb):
+        amvp = (I32 * 4)(*[int(v) for v in j["amvp"].ravel()]); search = (I32 * 10)(*[int(v) for v in j["search"].ravel()])
+        out = (I32 * 4)()
+        sad = oracle.ora_motion_estimation(at(rig.host, j["orig_off"]), PW, at(rig.host, j["ref_off"]), PW, int(j["gx"]), int(j["gy"]), int(j["init_x"]),
+                                           int(j["init_y"]), n, 128, 64, FW, FH, amvp, int(j["n_amvp"]), search, int(j["n_search"]),
+                                           C.c_double(float(j["corr"])), action, out)
+        exp[i] = [out[0], out[1], out[2], out[3], sad]
+    same(got.view(np.uint32), exp.view(np.uint32), "motion estimation (mv, sub-pel mv, sad)")
