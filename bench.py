@@ -459,6 +459,7 @@ def main():
                          "graph: the same command list captured once into a hipGraph and replayed (no per-launch host cost), per-kernel numbers from an eager pass after the timed region")
     ap.add_argument("--unfused", action="store_true",
                     help="replay predict/transform/quant/inv_quant/itransform/reconst/ssd16b as seven separate batches per TU size instead of the fused TU-chain kernel")
+    ap.add_argument("--branches", type=int, default=8, help="graph mode: number of parallel graph branches the independent launches are dealt to (1 = one serial chain)")
     ap.add_argument("--launch-order", default=None, help="write the per-step kernel launch order (JSON) for tools/pmc_summary.py")
     args = ap.parse_args()
 
@@ -520,7 +521,7 @@ def main():
     P = C.c_void_p
 
     class Cmd(C.Structure):
-        _fields_ = [("op", C.c_int), ("njobs", C.c_int), ("size", C.c_int), ("p", C.c_int * 4), ("jobs", P), ("a", P), ("b", P), ("c", P), ("out", P), ("p64", P * 2)]
+        _fields_ = [("op", C.c_int), ("njobs", C.c_int), ("size", C.c_int), ("p", C.c_int * 4), ("jobs", P), ("a", P), ("b", P), ("c", P), ("out", P), ("p64", P * 2), ("branch", C.c_int)]
 
     OPS = {"hmr_gpu_sad_batch": 1, "hmr_gpu_ssd16b_batch": 2, "hmr_gpu_predict_batch": 3, "hmr_gpu_reconst_batch": 4, "hmr_gpu_copy_batch": 5,
            "hmr_gpu_intra_pred_batch": 7, "hmr_gpu_intra_refs_batch": 8, "hmr_gpu_interpolate_batch": 9, "hmr_gpu_transform_batch": 11,
@@ -543,6 +544,15 @@ def main():
             cm.p64 = (P * 2)(base, g["d_ac"].data_ptr())   # reconstruction base, ac_sum
         cmds.append(cm)
         names.append(f"{g['name']}:{g['size']}")
+    # The launches of one replayed frame have no data dependencies on each other except the in-loop filter chain (edge flags ->
+    # deblock -> SAO stats -> SAO apply -> pad), which stays on branch 0 in order.  The batched groups are dealt to `--branches`
+    # graph branches (longest first, by algorithmic bytes) so the ramp-up / tail of one kernel overlaps the body of another.
+    load = [0.0] * max(args.branches, 1)
+    load[0] = 2.0e8                                  # the frame-level chain
+    for i in sorted(range(len(groups)), key=lambda i: -groups[i]["bytes"]):
+        b = load.index(min(load))
+        cmds[i].branch = b
+        load[b] += groups[i]["bytes"]
     frame_bytes = {
         "deblock": 2 * 2 * 6144 * n_ctu, "sao_stats": (2 * 2 * 6144 + 5 * 3 * 512) * n_ctu, "sao_apply": 2 * 2 * 6144 * n_ctu,
         "pad": 2 * 2 * ((W + 2 * PAD) * (H + 2 * PAD) - W * H) * 3 // 2, "edge_flags": 3 * (W // 4) * (H // 4),
@@ -596,6 +606,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # device-to-device copy rate of this GPU (confirm the nominal HBM peak on the box): 1 GiB read + 1 GiB written
+    with torch.cuda.stream(stream):
+        src_probe = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        dst_probe = torch.empty_like(src_probe)
+        dst_probe.copy_(src_probe)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(5):
+            dst_probe.copy_(src_probe)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src_probe, dst_probe
+
     # per-kernel durations from the event pairs around every command
     if args.mode == "graph":      # the graph has no event nodes: one eager pass of the same steps right after the timed region
         with torch.cuda.stream(stream):
@@ -628,10 +652,11 @@ def main():
             "dtype": "int16", "data": "synthetic",
             "config": {"workload": "cfg2-1080p-P-frame-replay", "width": W, "height": H, "qp": 32, "gop": "IPPP gop_size=1", "me": "quarter-pel", "sao": 1,
                        "calls_per_frame": int(sum(len(g["jobs"]) for g in groups)), "launches_per_frame": len(groups) + 8,
-                       "callmix_frame": args.callmix_frame, "parallelism": f"engine-per-gpu x{world}", "launch_mode": args.mode, "tu_chain": "7 separate batches" if args.unfused else "fused kernel",
+                       "callmix_frame": args.callmix_frame, "parallelism": f"engine-per-gpu x{world}", "launch_mode": args.mode, "graph_branches": args.branches if args.mode == "graph" else 1, "tu_chain": "7 separate batches" if args.unfused else "fused kernel",
                        "algorithmic_MB_per_frame_abi_width": round(total_alg / 1e6, 2), "compulsory_MB_per_frame": round(10.5 * W * H / 1e6, 2)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "measured_copy_GBps": round(copy_gbs, 1),
                          "timing": ("HIP event pairs around every launch inside the timed region" if args.mode == "eager" else
                                     "HIP event pairs around every launch, eager replay of the same K steps right after the timed graph replays "
                                     "(event nodes inside a hipGraph cannot be read back on ROCm 7.2)"),

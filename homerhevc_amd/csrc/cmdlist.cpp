@@ -9,6 +9,10 @@ struct hmr_gpu_cmdlist {
 	std::vector<hmr_gpu_cmd> cmds;
 	hipGraph_t graph = nullptr;
 	hipGraphExec_t exec = nullptr;
+	// branches > 0 of a captured list run on side streams forked from / joined to the context's stream
+	std::vector<hipStream_t> side;
+	std::vector<hipEvent_t> join;
+	hipEvent_t fork = nullptr;
 };
 
 static int run_one(hmr_gpu_ctx *ctx, const hmr_gpu_cmd &c)
@@ -71,11 +75,40 @@ extern "C" int hmr_gpu_cmdlist_run(hmr_gpu_ctx *ctx, hmr_gpu_cmdlist *l, void **
 extern "C" int hmr_gpu_cmdlist_capture(hmr_gpu_ctx *ctx, hmr_gpu_cmdlist *l)
 {
 	if (l->exec) return HMR_GPU_OK;
-	HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+	int nbranch = 0;
+	for (const hmr_gpu_cmd &c : l->cmds) {
+		if (c.branch < 0 || c.branch > HMR_GPU_MAX_BRANCHES) { hmr_set_error("command list: branch %d out of range", c.branch); return HMR_GPU_ERR_ARG; }
+		nbranch = c.branch > nbranch ? c.branch : nbranch;
+	}
+	while ((int)l->side.size() < nbranch) {
+		hipStream_t s;
+		hipEvent_t e;
+		HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		l->side.push_back(s);
+		l->join.push_back(e);
+	}
+	if (nbranch && !l->fork) HIP_TRY(hipEventCreateWithFlags(&l->fork, hipEventDisableTiming));
+	hipStream_t main_stream = ctx->stream;
+	HIP_TRY(hipStreamBeginCapture(main_stream, hipStreamCaptureModeThreadLocal));
 	int rc = HMR_GPU_OK;
-	for (size_t i = 0; i < l->cmds.size() && rc == HMR_GPU_OK; i++) rc = run_one(ctx, l->cmds[i]);
-	hipError_t e = hipStreamEndCapture(ctx->stream, &l->graph);
+	hipError_t fe = hipSuccess;
+	if (nbranch) {      // fork: every side stream joins the capture by waiting on an event of the origin stream
+		fe = hipEventRecord(l->fork, main_stream);
+		for (int b = 0; b < nbranch && fe == hipSuccess; b++) fe = hipStreamWaitEvent(l->side[b], l->fork, 0);
+	}
+	for (size_t i = 0; i < l->cmds.size() && rc == HMR_GPU_OK && fe == hipSuccess; i++) {
+		ctx->stream = l->cmds[i].branch ? l->side[l->cmds[i].branch - 1] : main_stream;
+		rc = run_one(ctx, l->cmds[i]);
+	}
+	ctx->stream = main_stream;
+	for (int b = 0; b < nbranch && fe == hipSuccess; b++) {   // join
+		fe = hipEventRecord(l->join[b], l->side[b]);
+		if (fe == hipSuccess) fe = hipStreamWaitEvent(main_stream, l->join[b], 0);
+	}
+	hipError_t e = hipStreamEndCapture(main_stream, &l->graph);
 	if (rc != HMR_GPU_OK) return rc;
+	if (fe != hipSuccess) { hmr_set_error("command list fork/join: %s", hipGetErrorString(fe)); return HMR_GPU_ERR_HIP; }
 	if (e != hipSuccess) { hmr_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return HMR_GPU_ERR_HIP; }
 	HIP_TRY(hipGraphInstantiate(&l->exec, l->graph, nullptr, nullptr, 0));
 	return HMR_GPU_OK;
@@ -96,5 +129,8 @@ extern "C" void hmr_gpu_cmdlist_destroy(hmr_gpu_cmdlist *l)
 	if (!l) return;
 	if (l->exec) (void)hipGraphExecDestroy(l->exec);
 	if (l->graph) (void)hipGraphDestroy(l->graph);
+	for (hipStream_t st : l->side) (void)hipStreamDestroy(st);
+	for (hipEvent_t ev : l->join) (void)hipEventDestroy(ev);
+	if (l->fork) (void)hipEventDestroy(l->fork);
 	delete l;
 }

@@ -263,7 +263,11 @@ typedef struct hmr_gpu_cmd {
 	const void *jobs, *a, *b;
 	void *c, *out;
 	void *p64[2];               /* extra pointer arguments (TU_CHAIN: recon base, ac_sum) */
+	int branch;                 /* 0 = the context's stream.  Commands with the same branch run in list order; different branches are
+	                             * declared independent of each other and may overlap when the list is replayed as a graph (fork at the
+	                             * start of the list, join at its end).  hmr_gpu_cmdlist_run ignores it (one stream, list order). */
 } hmr_gpu_cmd;
+#define HMR_GPU_MAX_BRANCHES 64
 typedef struct hmr_gpu_cmdlist hmr_gpu_cmdlist;
 int hmr_gpu_cmdlist_create(hmr_gpu_ctx *ctx, const hmr_gpu_cmd *cmds, int n, hmr_gpu_cmdlist **out);
 /* eager replay; event_pairs (optional, 2*n events from hmr_gpu_event_create) brackets every command for per-kernel timing */
