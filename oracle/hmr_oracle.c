@@ -1073,3 +1073,61 @@ uint32_t ora_tu_chain(const int16_t *orig, int orig_stride, const int16_t *pred,
 		ora_reconst(pred, pred_stride, zero_row, 0, recon, recon_stride, size);   /* "quant buff is full of zeros", :1065 */
 	return ora_ssd16b(orig, (uint32_t)orig_stride, recon, (uint32_t)recon_stride, size);
 }
+
+/* ====================================================================================================
+ * Intra mode search of one PU: homer_loop1_motion_intra (hmr_motion_intra.c:1084-1179).  The reference builds the raw and
+ * the smoothed neighbour arrays once, then walks four rounds of candidate modes (search_points, :1076-1080): planar/DC,
+ * five coarse angles, +-4/+-2 around the best so far, +-1 around that; each candidate is predicted, its SAD against the
+ * source taken, and cost = SAD + bits * sqrt_lambda compared with strict <.  The most-probable-mode list and the bit
+ * counts are host-side inputs here: `preds` (3 entries, -1 = none) with `pred_bits` for a candidate equal to one of
+ * them, `other_bits` for any other candidate (RD_FAST: 1 / 12, RD_FULL: CABAC estimate / 6, RD_DIST_ONLY: 0 / 0).
+ * Leaves behind what the reference leaves behind: both neighbour arrays and, in `pred`, the prediction of the LAST
+ * candidate evaluated (not the best one).  out[0] = best mode, out[1] = bit count of the best, *best_cost its cost.
+ * ==================================================================================================== */
+void ora_intra_search(const int16_t *orig, int orig_stride, const int16_t *decoded_corner, int decoded_stride, int n, int left, int top, int bottom_left,
+		      int top_right, int bl_size, int tr_size, int strong_enabled, const int32_t *preds, const int32_t *pred_bits, int other_bits,
+		      double sqrt_lambda, int16_t *adi, int16_t *adi_filtered, int16_t *pred, int pred_stride, int32_t *out, double *best_cost_out)
+{
+	static const int points[4][5] = {{0, 1, 0, 8, 16}, {2, 10, 16, 22, 30}, {-4, -2, 2, 4, 0}, {-1, 1, 0, 0, 0}};   /* :1076 */
+	static const int num_points[4] = {2, 5, 4, 2};                                                                /* :1080 */
+	static const int filter_thr[5] = {10, 7, 1, 0, 10};                                                           /* intra_filter, :148 */
+	const int adi_size = 4 * n + 1, l2 = ilog2(n);
+	int best = 0, new_best = 0, best_bits = 0, min_mode = 0, max_mode = 1, loop, k;
+	double best_cost = (double)(UINT32_MAX / 8);   /* MAX_COST, hmr_private.h:54 */
+	ora_fill_reference_samples(decoded_corner, decoded_stride, n, left, top, bottom_left, top_right, bl_size, tr_size, adi);
+	ora_adi_filter(adi, adi_filtered, adi_size, n, strong_enabled);
+	for (loop = 0; loop < 4; loop++) {
+		unsigned bits = 0;
+		if (loop == 1) {
+			best = 2;
+			min_mode = 2;
+			max_mode = 34;
+		}
+		for (k = 0; k < num_points[loop]; k++) {
+			const int mode = best + points[loop][k];
+			int diff, filtered;
+			double cost;
+			if (mode < min_mode || mode > max_mode) continue;
+			diff = abs(mode - 10) < abs(mode - 26) ? abs(mode - 10) : abs(mode - 26);
+			filtered = mode != 1 && diff > filter_thr[l2 - 2];
+			if (mode == 0) ora_intra_planar(pred, pred_stride, filtered ? adi_filtered : adi, adi_size, n);
+			else ora_intra_angular(pred, pred_stride, filtered ? adi_filtered : adi, adi_size, n, mode, 1);
+			cost = (double)ora_sad(orig, (uint32_t)orig_stride, pred, (uint32_t)pred_stride, n);
+			if (preds[0] == mode) bits = (unsigned)pred_bits[0];
+			else if (preds[1] == mode) bits = (unsigned)pred_bits[1];
+			else if (preds[2] == mode) bits = (unsigned)pred_bits[2];
+			else bits = (unsigned)other_bits;
+			cost += bits * sqrt_lambda;
+			if (cost < best_cost) {
+				best_cost = cost;
+				new_best = mode;
+				best_bits = (int)bits;
+			}
+		}
+		best = new_best;
+	}
+	out[0] = best;
+	out[1] = best_bits;
+	*best_cost_out = best_cost;
+}
+

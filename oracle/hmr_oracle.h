@@ -108,6 +108,11 @@ uint32_t ora_motion_estimation(const int16_t *orig, int orig_stride, const int16
 uint32_t ora_tu_chain(const int16_t *orig, int orig_stride, const int16_t *pred, int pred_stride, int16_t *levels, int16_t *recon, int recon_stride,
 		      int size, int is_dst, int scan_mode, int comp, int is_intra, int slice_is_intra, int sign_hiding, int per, int rem, int *ac_sum);
 
+/* ---- intra mode search of one PU (homer_loop1_motion_intra, hmr_motion_intra.c:1084) ---- */
+void ora_intra_search(const int16_t *orig, int orig_stride, const int16_t *decoded_corner, int decoded_stride, int n, int left, int top, int bottom_left,
+		      int top_right, int bl_size, int tr_size, int strong_enabled, const int32_t *preds, const int32_t *pred_bits, int other_bits,
+		      double sqrt_lambda, int16_t *adi, int16_t *adi_filtered, int16_t *pred, int pred_stride, int32_t *out, double *best_cost);
+
 #ifdef __cplusplus
 }
 #endif

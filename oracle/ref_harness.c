@@ -483,3 +483,57 @@ uint32_t refh_tu_chain(int16_t *orig, int orig_stride, int16_t *pred, int pred_s
 		f->reconst(pred, pred_stride, zeros, 0, recon, recon_stride, size);
 	return f->ssd16b(orig, orig_stride, recon, recon_stride, size);
 }
+
+/* homer_loop1_motion_intra (hmr_motion_intra.c:1084) on flat arguments.  The most-probable-mode list is derived by the reference
+ * itself from the neighbour modes given here (left_mode / top_mode, -1 = neighbour not intra): the PU is placed at 4x4-unit
+ * (1,1) of the CTU so that both neighbours are read from ctu_rd (hmr_arithmetic_encoding.c:229,282).  rd_mode 0 (RD_DIST_ONLY)
+ * or 2 (RD_FAST).  out = {best mode, bit cost, num_preds, preds[3]}. */
+int homer_loop1_motion_intra(henc_thread_t *et, ctu_info_t *ctu, ctu_info_t *ctu_rd, cu_partition_info_t *curr_partition_info, int16_t *pred_buff,
+			     int pred_buff_stride, int16_t *orig_buff, int orig_buff_stride, int16_t *decoded_buff, int decoded_buff_stride, int depth,
+			     int curr_depth, int curr_part_size, int curr_part_size_shift, int part_size_type, int curr_adi_size, int best_pred_modes[3],
+			     double best_pred_cost[3]);
+int get_intra_dir_luma_predictor(ctu_info_t *ctu, cu_partition_info_t *curr_partition_info, int *arr_intra_dir, int *piMode);
+void refh_intra_search(int16_t *orig, int orig_stride, int16_t *decoded_corner, int decoded_stride, int n, int left, int top, int bottom_left, int top_right,
+		       int bl_size, int tr_size, int strong_enabled, int left_mode, int top_mode, int rd_mode, double sqrt_lambda, int16_t *adi_out,
+		       int16_t *adi_filtered_out, int16_t *pred_out, int pred_stride, int32_t *out, double *best_cost)
+{
+	static uint8_t pred_mode[MAX_NUM_PARTITIONS];
+	cu_partition_info_t pi;
+	ctu_info_t ctu, ctu_rd;
+	const int sh = log2i(n), curr_depth = 6 - sh, adi_size = 4 * n + 1;
+	int save_w = g_et->pict_width[0], save_h = g_et->pict_height[0], save_rd = g_et->rd_mode, save_strong = g_et->sps->strong_intra_smooth_enabled_flag;
+	double save_lambda = g_et->rd.sqrt_lambda;
+	int modes[3], preds[3] = {-1, -1, -1}, np;
+	double costs[3];
+	memset(&pi, 0, sizeof pi);
+	memset(&ctu, 0, sizeof ctu);
+	memset(&ctu_rd, 0, sizeof ctu_rd);
+	pi.left_neighbour = left; pi.top_neighbour = top;
+	pi.left_bottom_neighbour = bottom_left; pi.top_right_neighbour = top_right;
+	pi.depth = curr_depth;
+	pi.size = n;
+	pi.raster_index = 17;                   /* unit (1,1): left and top neighbours lie inside this CTU */
+	pi.abs_index_left_partition = 1;
+	pi.abs_index_top_partition = 2;
+	ctu.size = ctu_rd.size = 64;
+	ctu_rd.pred_mode = pred_mode;
+	pred_mode[1] = left_mode >= 0 ? INTRA_MODE : INTER_MODE;
+	pred_mode[2] = top_mode >= 0 ? INTRA_MODE : INTER_MODE;
+	g_et->intra_mode_buffs[Y_COMP][curr_depth][1] = (uint8_t)(left_mode >= 0 ? left_mode : 0);
+	g_et->intra_mode_buffs[Y_COMP][curr_depth][2] = (uint8_t)(top_mode >= 0 ? top_mode : 0);
+	g_et->pict_width[0] = n + tr_size; g_et->pict_height[0] = n + bl_size;
+	g_et->rd_mode = rd_mode;
+	g_et->rd.sqrt_lambda = sqrt_lambda;
+	g_et->sps->strong_intra_smooth_enabled_flag = strong_enabled;
+	out[1] = homer_loop1_motion_intra(g_et, &ctu, &ctu_rd, &pi, pred_out, pred_stride, orig, orig_stride, decoded_corner + decoded_stride + 1, decoded_stride,
+					  curr_depth, curr_depth, n, sh, SIZE_2Nx2N, adi_size, modes, costs);
+	out[0] = modes[0];
+	*best_cost = costs[0];
+	np = get_intra_dir_luma_predictor(&ctu_rd, &pi, preds, NULL);
+	out[2] = np; out[3] = preds[0]; out[4] = preds[1]; out[5] = preds[2];
+	memcpy(adi_out, g_et->adi_pred_buff, (size_t)adi_size * 2);
+	memcpy(adi_filtered_out, g_et->adi_filtered_pred_buff, (size_t)adi_size * 2);
+	g_et->pict_width[0] = save_w; g_et->pict_height[0] = save_h;
+	g_et->rd_mode = save_rd; g_et->rd.sqrt_lambda = save_lambda;
+	g_et->sps->strong_intra_smooth_enabled_flag = save_strong;
+}

@@ -256,12 +256,56 @@ def k_tu_chain(lib, prefix, p, rng):
     return {"levels": levels[:n * n].copy(), "recon": recon[:n, :n].copy(), "ssd": np.array([r], np.uint32), "ac_sum": np.array([ac.value], np.int32)}
 
 
+def mpm_list(left_mode, top_mode):
+    """Most-probable-mode list from the neighbours' modes (get_intra_dir_luma_predictor, hmr_arithmetic_encoding.c:545); -1 = not intra -> DC."""
+    a = left_mode if left_mode >= 0 else 1
+    b = top_mode if top_mode >= 0 else 1
+    if a == b:
+        return [a, ((a + 29) % 32) + 2, ((a - 1) % 32) + 2] if a > 1 else [0, 1, 26]
+    return [a, b, 0 if (a and b) else (26 if a + b < 2 else 1)]
+
+
+def k_intra_search(lib, prefix, p, rng):
+    """homer_loop1_motion_intra: the reference derives the MPM list from neighbour modes, the oracle / GPU take it as input."""
+    n = p["n"]
+    H = W = 160
+    yy, xx = np.mgrid[0:H, 0:W]
+    th = p["theta"]
+    base = 128 + p["amp"] * np.sin((xx * np.cos(th) + yy * np.sin(th)) / p["period"]) + p["tilt"] * (xx - yy) / 8.0
+    dec = aligned((H, W), np.int16)
+    dec[...] = np.clip(base + rng.integers(-p["noise"], p["noise"] + 1, (H, W)), 0, 255)
+    orig = aligned((64, 64), np.int16)
+    orig[...] = np.clip(base[16:80, 16:80] + rng.integers(-p["noise"], p["noise"] + 1, (64, 64)), 0, 255)
+    adi = aligned((4 * 64 + 1 + 15,), np.int16)
+    adif = aligned((4 * 64 + 1 + 15,), np.int16)
+    pred = aligned((64, 64), np.int16)
+    pred[...] = 0x1234
+    cost = C.c_double(0)
+    preds = mpm_list(p["left_mode"], p["top_mode"])
+    corner = 15 * W + 15
+    common = [ptr(orig), C.c_int(64), ptr(dec, corner), C.c_int(W), C.c_int(n), C.c_int(p["left"]), C.c_int(p["top"]), C.c_int(p["bl"]), C.c_int(p["tr"]),
+              C.c_int(p["bl_size"]), C.c_int(p["tr_size"]), C.c_int(p["strong"])]
+    if prefix == "refh_":
+        out = np.zeros(6, np.int32)
+        fn(lib, prefix, "intra_search")(*common, C.c_int(p["left_mode"]), C.c_int(p["top_mode"]), C.c_int(p["rd_mode"]), C.c_double(p["sqrt_lambda"]),
+                                        ptr(adi), ptr(adif), ptr(pred), C.c_int(64), ptr(out), C.byref(cost))
+        assert out[2] == 3 and list(out[3:6]) == preds, (list(out), preds)
+    else:
+        out = np.zeros(2, np.int32)
+        bits = {0: ([0, 0, 0], 0), 2: ([1, 1, 1], 12)}[p["rd_mode"]]
+        pa, ba = np.array(preds, np.int32), np.array(bits[0], np.int32)
+        fn(lib, prefix, "intra_search")(*common, ptr(pa), ptr(ba), C.c_int(bits[1]), C.c_double(p["sqrt_lambda"]), ptr(adi), ptr(adif), ptr(pred), C.c_int(64),
+                                        ptr(out), C.byref(cost))
+    return {"best": out[:2].copy(), "cost": np.array([cost.value], np.float64), "adi": adi[:4 * n + 1].copy(), "adi_filtered": adif[:4 * n + 1].copy(),
+            "last_pred": pred[:n, :n].copy()}
+
+
 KERNELS = {
     "sad": k_sad, "ssd16b": k_ssd16b, "predict": k_predict, "reconst": k_reconst, "modified_variance": k_modified_variance,
     "copy": k_copy, "intra_planar": k_intra_planar, "intra_angular": k_intra_angular,
     "fill_reference_samples": k_fill_reference_samples, "adi_filter": k_adi_filter, "interpolate": k_interpolate,
     "weighted_average": k_weighted_average, "transform": k_transform, "itransform": k_itransform, "quant": k_quant,
-    "inv_quant": k_inv_quant, "tu_chain": k_tu_chain,
+    "inv_quant": k_inv_quant, "tu_chain": k_tu_chain, "intra_search": k_intra_search,
 }
 
 
@@ -362,4 +406,14 @@ def all_cases(level="full"):
                     for per, rem in ([(5, 2), (3, 4)] if full else [(5, 2)]):
                         add("tu_chain", n=n, comp=comp, intra=intra, slice_i=intra, sbh=1, per=per, rem=rem, scan=3, noise=noise,
                             dst=1 if (n == 4 and intra and comp == 0) else 0)
+    r = np.random.default_rng(4242)
+    for n in sizes:
+        for i in range(40 if full else 8):
+            left, top = (int(r.integers(0, 2)), int(r.integers(0, 2))) if i % 5 == 0 else (1, 1)
+            bl, tr = int(r.integers(0, 2)) & left, int(r.integers(0, 2)) & top
+            add("intra_search", n=n, left=left, top=top, bl=bl, tr=tr, bl_size=(n if r.random() < 0.7 else max(n // 2, 4)) if bl else 0,
+                tr_size=(n if r.random() < 0.7 else max(n // 2, 4)) if tr else 0, strong=int(r.integers(0, 2)),
+                left_mode=int(r.integers(-1, 35)), top_mode=int(r.integers(-1, 35)), rd_mode=int(r.choice([2, 2, 0])),
+                sqrt_lambda=float(r.uniform(2.0, 60.0)), theta=float(r.uniform(0, np.pi)), period=float(r.uniform(3.0, 25.0)),
+                amp=float(r.uniform(5, 90)), tilt=float(r.uniform(-6, 6)), noise=int(r.integers(0, 9)))
     return cases
