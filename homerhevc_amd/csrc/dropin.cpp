@@ -509,4 +509,46 @@ uint32_t hmr_gpu_tu_chain(int16_t *orig, int orig_stride, int16_t *pred, int pre
 	return *st.host<uint32_t>(so);
 }
 
+void hmr_gpu_intra_search(int16_t *orig, int orig_stride, int16_t *decoded_corner, int decoded_stride, int n, int left, int top, int bottom_left, int top_right,
+			  int bl_size, int tr_size, int strong_enabled, const int32_t *preds, const int32_t *pred_bits, int other_bits, double sqrt_lambda,
+			  int16_t *adi, int16_t *adi_filtered, int16_t *pred, int pred_stride, int32_t *out, double *best_cost)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	hmr_gpu_intra_job jb = {};
+	const int total = 4 * n + 1, ring = 2 * n + 1;
+	jb.sqrt_lambda = sqrt_lambda;
+	jb.orig_off = (uint32_t)(st.put2d(orig, orig_stride, n, n, 2) / 2); jb.orig_stride = n;
+	// stage only the L-shaped neighbourhood the build reads: row 0 and column 0 of a (2n+1)^2 tile
+	const size_t doff = st.zeros((size_t)ring * ring * 2);
+	int16_t *tile = st.host<int16_t>(doff);
+	const int rows = left ? n + (bottom_left ? bl_size : 0) : 0, cols = top ? n + (top_right ? tr_size : 0) : 0;
+	if (left || top) tile[0] = decoded_corner[0];
+	for (int y = 1; y <= rows; y++) tile[(size_t)y * ring] = decoded_corner[(size_t)y * decoded_stride];
+	for (int x = 1; x <= cols; x++) tile[x] = decoded_corner[x];
+	jb.dec_off = (uint32_t)(doff / 2); jb.dec_stride = ring;
+	jb.flags = (uint32_t)(left != 0) | ((uint32_t)(top != 0) << 1) | ((uint32_t)(bottom_left != 0) << 2) | ((uint32_t)(top_right != 0) << 3) |
+		   ((uint32_t)(strong_enabled != 0) << 5);
+	jb.sizes = (uint32_t)bl_size | ((uint32_t)tr_size << 16);
+	for (int i = 0; i < 3; i++) { jb.preds[i] = preds[i]; jb.pred_bits[i] = (uint32_t)pred_bits[i]; }
+	jb.other_bits = (uint32_t)other_bits;
+	const size_t joff = st.zeros(sizeof jb);
+	st.begin_outputs();
+	const size_t ao = st.out((size_t)total * 2), fo = st.out((size_t)total * 2), po = st.out((size_t)n * n * 2), ro = st.out(sizeof(hmr_gpu_intra_result));
+	jb.adi_off = (uint32_t)(ao / 2); jb.adif_off = (uint32_t)(fo / 2);
+	jb.pred_off = (uint32_t)(po / 2); jb.pred_stride = n;
+	memcpy(st.host<uint8_t>(joff), &jb, sizeof jb);
+	st.upload();
+	must(hmr_gpu_intra_search_batch(c, st.dev<hmr_gpu_intra_job>(joff), 1, n, st.dev<int16_t>(), st.dev<int16_t>(), st.dev<int16_t>(), st.dev<hmr_gpu_intra_result>(ro)),
+	     "intra_search");
+	st.finish();
+	memcpy(adi, st.host<int16_t>(ao), (size_t)total * 2);
+	memcpy(adi_filtered, st.host<int16_t>(fo), (size_t)total * 2);
+	st.get2d(po, pred, pred_stride, n, n, 2);
+	const hmr_gpu_intra_result *r = st.host<hmr_gpu_intra_result>(ro);
+	out[0] = r->best_mode;
+	out[1] = r->bits;
+	*best_cost = r->cost;
+}
+
 }  // extern "C"

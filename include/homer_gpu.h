@@ -251,7 +251,8 @@ enum hmr_gpu_op {
 	HMR_GPU_OP_SAD = 1, HMR_GPU_OP_SSD16B, HMR_GPU_OP_PREDICT, HMR_GPU_OP_RECONST, HMR_GPU_OP_COPY, HMR_GPU_OP_VARIANCE, HMR_GPU_OP_INTRA_PRED,
 	HMR_GPU_OP_INTRA_REFS, HMR_GPU_OP_INTERPOLATE, HMR_GPU_OP_WAVG, HMR_GPU_OP_TRANSFORM, HMR_GPU_OP_ITRANSFORM, HMR_GPU_OP_QUANT,
 	HMR_GPU_OP_INV_QUANT, HMR_GPU_OP_MC, HMR_GPU_OP_ME, HMR_GPU_OP_EDGE_FLAGS, HMR_GPU_OP_DEBLOCK, HMR_GPU_OP_SAO_STATS, HMR_GPU_OP_SAO_APPLY, HMR_GPU_OP_PAD,
-	HMR_GPU_OP_TU_CHAIN   /* jobs = hmr_gpu_tu_job*, a = orig base, b = pred base, c = level base, out = ssd; the reconstruction base and ac_sum follow in p64[0..1] */
+	HMR_GPU_OP_TU_CHAIN,  /* jobs = hmr_gpu_tu_job*, a = orig base, b = pred base, c = level base, out = ssd; the reconstruction base and ac_sum follow in p64[0..1] */
+	HMR_GPU_OP_INTRA_SEARCH   /* jobs = hmr_gpu_intra_job*, a = orig base, b = decoded base, c = output base, out = hmr_gpu_intra_result* */
 };
 /* One call of the batched / frame-level API: `size` is that entry's size/kind/flags argument, a/b/c/out its pointer arguments in
  * declaration order (frame-level ops take host pointers to hmr_gpu_frame / hmr_gpu_units that must outlive the list), p[] its
@@ -296,6 +297,40 @@ int hmr_gpu_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_tu_job *jobs, int njo
 /* host-pointer (drop-in) form; returns the SSD between source and reconstruction */
 uint32_t hmr_gpu_tu_chain(int16_t *orig, int orig_stride, int16_t *pred, int pred_stride, int16_t *levels, int16_t *recon, int recon_stride, int size,
 			  int is_dst, int scan_mode, int comp, int is_intra, int slice_is_intra, int sign_hiding, int per, int rem, int *ac_sum);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * 8. intra mode search of one PU: homer_loop1_motion_intra (hmr_motion_intra.c:1084-1179) - reference build, smoothing,
+ *    up to 13 {prediction, SAD} rounds over the search_points schedule (:1076) and the strict-< cost comparison
+ *    SAD + bits * sqrt_lambda (double) in one launch.  The most-probable-mode list (get_intra_dir_luma_predictor,
+ *    hmr_arithmetic_encoding.c:545) and the bit counts are host inputs: RD_FAST 1 / 12 (:1153-1157), RD_FULL the CABAC
+ *    estimate of each list entry / 6 (:1141-1150), RD_DIST_ONLY 0 / 0.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct hmr_gpu_intra_job {
+	double sqrt_lambda;               /* et->rd.sqrt_lambda */
+	uint32_t orig_off, orig_stride;   /* source block */
+	uint32_t dec_off, dec_stride;     /* corner sample (-1,-1) of the block in the plane under reconstruction */
+	uint32_t adi_off, adif_off;       /* out: raw and smoothed neighbour arrays, 4*size+1 each (et->adi_pred_buff / adi_filtered_pred_buff) */
+	uint32_t pred_off, pred_stride;   /* out: prediction of the LAST candidate evaluated (what the reference leaves in prediction_wnd) */
+	uint32_t flags;                   /* bits 0 left, 1 top, 2 bottom_left, 3 top_right, 5 strong_intra_smooth_enabled */
+	uint32_t sizes;                   /* bl_size | tr_size << 16 (hmr_motion_intra.c:289,335) */
+	int32_t preds[3];                 /* most probable modes, -1 = none */
+	uint32_t pred_bits[3];            /* bit count when the candidate equals preds[i] */
+	uint32_t other_bits;              /* bit count of any other candidate */
+	uint32_t reserved;
+} hmr_gpu_intra_job;
+typedef struct hmr_gpu_intra_result {
+	int32_t best_mode;                /* best_pred_modes[0] */
+	int32_t bits;                     /* return value: bit count of the best mode */
+	double cost;                      /* best_pred_cost[0] */
+} hmr_gpu_intra_result;
+/* jobs / out are DEVICE arrays; all PUs of a call share `size` (4, 8, 16, 32, 64) */
+int hmr_gpu_intra_search_batch(hmr_gpu_ctx *ctx, const hmr_gpu_intra_job *jobs, int njobs, int size, const int16_t *orig_base,
+			       const int16_t *decoded_base, int16_t *out_base, hmr_gpu_intra_result *out);
+/* host-pointer (drop-in) form; out = {best mode, bit count} */
+void hmr_gpu_intra_search(int16_t *orig, int orig_stride, int16_t *decoded_corner, int decoded_stride, int n, int left, int top, int bottom_left,
+			  int top_right, int bl_size, int tr_size, int strong_enabled, const int32_t *preds, const int32_t *pred_bits, int other_bits,
+			  double sqrt_lambda, int16_t *adi, int16_t *adi_filtered, int16_t *pred, int pred_stride, int32_t *out, double *best_cost);
 
 #ifdef __cplusplus
 }

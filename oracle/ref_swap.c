@@ -155,3 +155,47 @@ void hmr_motion_compensation_chroma(henc_thread_t *et, int16_t *ref, int ref_str
 	}
 	hmr_gpu_mc_chroma(ref, ref_stride, pred, pred_stride, size, mv->hor_vector, mv->ver_vector, is_bi);
 }
+
+/* ---- intra mode search driver (hmr_motion_intra.c:1084): neighbour arrays, the candidate schedule and its cost comparison in one GPU call.
+ * Host side keeps what is control plane: the most-probable-mode list and (RD_FULL) the CABAC bit estimate of its three entries. ---- */
+int get_intra_dir_luma_predictor(ctu_info_t *ctu, cu_partition_info_t *curr_partition_info, int *arr_intra_dir, int *piMode);
+uint fast_rd_estimate_bits_intra_luma_mode(henc_thread_t *et, cu_partition_info_t *partition_info, uint pred_depth, int dir, int *preds, int num_preds);
+static unsigned long g_intra_searches;
+int homer_loop1_motion_intra(henc_thread_t *et, ctu_info_t *ctu, ctu_info_t *ctu_rd, cu_partition_info_t *pi, int16_t *pred_buff, int pred_buff_stride,
+			     int16_t *orig_buff, int orig_buff_stride, int16_t *decoded_buff, int decoded_buff_stride, int depth, int curr_depth, int size,
+			     int size_shift, int part_size_type, int adi_size, int best_pred_modes[3], double best_pred_cost[3])
+{
+	if (!want("intra_search"))
+		return ((int (*)(henc_thread_t *, ctu_info_t *, ctu_info_t *, cu_partition_info_t *, int16_t *, int, int16_t *, int, int16_t *, int, int, int, int, int, int,
+				 int, int *, double *))REAL(homer_loop1_motion_intra))(et, ctu, ctu_rd, pi, pred_buff, pred_buff_stride, orig_buff, orig_buff_stride,
+										      decoded_buff, decoded_buff_stride, depth, curr_depth, size, size_shift,
+										      part_size_type, adi_size, best_pred_modes, best_pred_cost);
+	int32_t preds[3] = {-1, -1, -1}, bits[3] = {0, 0, 0}, out[2];
+	int other = 0, np, i;
+	double cost;
+	int bl = min(size, et->pict_height[Y_COMP] - (ctu->y[Y_COMP] + pi->y_position + size));
+	int tr = min(size, et->pict_width[Y_COMP] - (ctu->x[Y_COMP] + pi->x_position + size));
+	ctu->top = 1;                                                            /* fill_reference_samples, :256-257 */
+	ctu->left = 1;
+	ctu_rd->intra_mode[Y_COMP] = et->intra_mode_buffs[Y_COMP][curr_depth];   /* :1102 */
+	np = get_intra_dir_luma_predictor(ctu_rd, pi, (int *)preds, NULL);
+	if (et->rd_mode == RD_FULL) {
+		for (i = 0; i < np; i++) {
+			int aux[3] = {preds[0], preds[1], preds[2]};
+			bits[i] = (int32_t)fast_rd_estimate_bits_intra_luma_mode(et, pi, depth - (part_size_type == SIZE_NxN), preds[i], aux, np);
+		}
+		other = 6;
+	} else if (et->rd_mode == RD_FAST) {
+		bits[0] = bits[1] = bits[2] = 1;
+		other = 12;
+	}
+	hmr_gpu_intra_search(orig_buff, orig_buff_stride, decoded_buff - decoded_buff_stride - 1, decoded_buff_stride, size, pi->left_neighbour, pi->top_neighbour,
+			     pi->left_bottom_neighbour, pi->top_right_neighbour, bl, tr, et->sps->strong_intra_smooth_enabled_flag, preds, bits, other,
+			     et->rd.sqrt_lambda, et->adi_pred_buff, et->adi_filtered_pred_buff, pred_buff, pred_buff_stride, out, &cost);
+	best_pred_modes[0] = out[0];
+	best_pred_modes[1] = best_pred_modes[2] = 100;                          /* PRED_MODE_INVALID, :1082 */
+	best_pred_cost[0] = cost;
+	(void)adi_size; (void)size_shift;
+	if (!g_intra_searches++) fprintf(stderr, "ref_swap: intra mode search routed to libhomer_gpu.so\n");
+	return out[1];
+}

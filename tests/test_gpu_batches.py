@@ -409,3 +409,59 @@ def test_motion_estimation(rig, oracle, n, action):
                                            C.c_double(float(j["corr"])), action, out)
         exp[i] = [out[0], out[1], out[2], out[3], sad]
     same(got.view(np.uint32), exp.view(np.uint32), "motion estimation (mv, sub-pel mv, sad)")
+
+
+INTRA_JOB = np.dtype([("sqrt_lambda", "<f8"), ("orig_off", "<u4"), ("orig_stride", "<u4"), ("dec_off", "<u4"), ("dec_stride", "<u4"), ("adi_off", "<u4"),
+                      ("adif_off", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("flags", "<u4"), ("sizes", "<u4"), ("preds", "<i4", (3,)),
+                      ("pred_bits", "<u4", (3,)), ("other_bits", "<u4"), ("reserved", "<u4")])
+INTRA_RES = np.dtype([("best_mode", "<i4"), ("bits", "<i4"), ("cost", "<f8")])
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32, 64])
+def test_intra_search(rig, oracle, n):
+    from kernel_cases import mpm_list
+    assert INTRA_JOB.itemsize == 80 and INTRA_RES.itemsize == 16
+    rng = np.random.default_rng(n)
+    nj = rig.nj if n < 64 else 151
+    # directional texture so that different modes win; the source is the same texture plus noise
+    yy, xx = np.mgrid[0:PH, 0:PW]
+    th = np.repeat(np.repeat(rng.uniform(0, np.pi, (PH // 64, PW // 64)), 64, 0), 64, 1)
+    tex = 128 + 70 * np.sin((xx * np.cos(th) + yy * np.sin(th)) / 6.0)
+    rig.host[rig.pix:rig.res] = np.clip(tex + rng.integers(-4, 5, (PH, PW)), 0, 255).ravel()
+    rig.host[rig.res:rig.mid] = np.clip(tex + rng.integers(-4, 5, (PH, PW)), 0, 255).ravel()
+    jb = np.zeros(nj, INTRA_JOB)
+    x = rng.integers(1, PW - 2 * n - 1, nj); y = rng.integers(1, PH - 2 * n - 1, nj)
+    jb["orig_off"] = rig.res + y * PW + x; jb["orig_stride"] = PW
+    jb["dec_off"] = rig.pix + (y - 1) * PW + x - 1; jb["dec_stride"] = PW
+    slot = rig.slots(rig.out1)[:nj]
+    jb["adi_off"] = slot; jb["adif_off"] = slot + 4 * n + 4; jb["pred_off"] = rig.slots(rig.out2)[:nj]; jb["pred_stride"] = 80
+    avail = np.where(rng.random(nj) < 0.7, 15, rng.integers(0, 16, nj))
+    left, top = (avail & 1) | ((avail >> 2) & 1), ((avail >> 1) & 1) | ((avail >> 3) & 1)
+    bl, tr = (avail >> 2) & 1, (avail >> 3) & 1
+    strong = rng.integers(0, 2, nj)
+    bl_size = np.where(bl, np.where(rng.random(nj) < 0.6, n, max(n // 2, 4)), 0); tr_size = np.where(tr, np.where(rng.random(nj) < 0.6, n, max(n // 2, 4)), 0)
+    jb["flags"] = left | (top << 1) | (bl << 2) | (tr << 3) | (strong << 5); jb["sizes"] = bl_size | (tr_size << 16)
+    fast = rng.random(nj) < 0.7
+    for i in range(nj):
+        jb["preds"][i] = mpm_list(int(rng.integers(-1, 35)), int(rng.integers(-1, 35)))
+        jb["pred_bits"][i] = [1, 1, 1] if fast[i] else rng.integers(0, 9, 3)
+    jb["other_bits"] = np.where(fast, 12, 6)
+    jb["sqrt_lambda"] = rng.uniform(1.0, 50.0, nj)
+    d_out = rig.malloc(16 * nj); rig.bufs.append(d_out)
+    g = rig.launch("hmr_gpu_intra_search_batch", rig.up(jb), nj, n, rig.dev, rig.dev, rig.dev, d_out)
+    o = rig.host.copy()
+    exp = np.zeros(nj, INTRA_RES)
+    I32 = C.c_int32
+    for i, j in enumerate(jb):
+        out = (I32 * 2)(); cost = C.c_double(0)
+        oracle.ora_intra_search(at(o, j["orig_off"]), PW, at(o, j["dec_off"]), PW, n, int(left[i]), int(top[i]), int(bl[i]), int(tr[i]), int(bl_size[i]),
+                                int(tr_size[i]), int(strong[i]), (I32 * 3)(*[int(v) for v in j["preds"]]), (I32 * 3)(*[int(v) for v in j["pred_bits"]]),
+                                int(j["other_bits"]), C.c_double(float(j["sqrt_lambda"])), at(o, j["adi_off"]), at(o, j["adif_off"]), at(o, j["pred_off"]), 80,
+                                out, C.byref(cost))
+        exp[i] = (out[0], out[1], cost.value)
+    same(g, o, "intra search: neighbour arrays + last prediction")
+    got = rig.down(d_out, nj, INTRA_RES)
+    same(got["best_mode"], exp["best_mode"], "best mode")
+    same(got["bits"], exp["bits"], "bits")
+    same(got["cost"].view(np.uint64), exp["cost"].view(np.uint64), "cost (bit pattern)")
+    assert len(set(exp["best_mode"].tolist())) > 8

@@ -24,8 +24,8 @@ def _encode(exe, clip, out, w, h, frames, env=None, extra=()):
         return f.read(), r.stderr
 
 
-@pytest.mark.parametrize("extra,w,h,frames", [((), 200, 136, 3), (("force_intra=1",), 200, 136, 2), ((), 416, 240, 3)],
-                         ids=["ippp_200x136", "all_intra_200x136", "ippp_416x240"])
+@pytest.mark.parametrize("extra,w,h,frames", [((), 200, 136, 3), (("force_intra=1",), 200, 136, 2), ((), 416, 240, 3), (("rd=1",), 200, 136, 2)],
+                         ids=["ippp_200x136", "all_intra_200x136", "ippp_416x240", "ippp_rdfull_200x136"])
 def test_stream_identical_with_gpu_kernels(tmp_path, extra, w, h, frames):
     if not (os.path.exists(SWAP) and os.path.exists(libs.REF_LOCKSTEP)):
         pytest.skip("oracle/_ref not shipped (built only where the reference sources exist)")
@@ -37,6 +37,6 @@ def test_stream_identical_with_gpu_kernels(tmp_path, extra, w, h, frames):
     same, _ = _encode(SWAP, clip, str(tmp_path / "none.265"), w, h, frames, env={"HOMER_SWAP": "none"}, extra=extra)
     assert same == ref, "harness itself changes the stream"
     gpu, log = _encode(SWAP, clip, str(tmp_path / "gpu.265"), w, h, frames, env={"HOMER_SWAP": "all"}, extra=extra)
-    assert "table entries routed" in log
+    assert "table entries routed" in log and "intra mode search routed" in log
     assert len(ref) > 300
     assert gpu == ref, f"stream differs: {len(gpu)} vs {len(ref)} bytes"
