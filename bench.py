@@ -68,6 +68,10 @@ ME_JOB_DTYPE = np.dtype([("corr", "<f8"), ("orig_off", "<u4"), ("orig_stride", "
                          ("init_x", "<i2"), ("init_y", "<i2"), ("n_amvp", "<i2"), ("n_search", "<i2"), ("amvp", "<i2", (2, 2)), ("search", "<i2", (5, 2)),
                          ("action", "<u4"), ("reserved", "<u4")])    # hmr_gpu_me_job, include/homer_gpu.h
 assert ME_JOB_DTYPE.itemsize == 72
+INTRA_JOB_DTYPE = np.dtype([("sqrt_lambda", "<f8"), ("orig_off", "<u4"), ("orig_stride", "<u4"), ("dec_off", "<u4"), ("dec_stride", "<u4"), ("adi_off", "<u4"),
+                            ("adif_off", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("flags", "<u4"), ("sizes", "<u4"), ("preds", "<i4", (3,)),
+                            ("pred_bits", "<u4", (3,)), ("other_bits", "<u4"), ("reserved", "<u4")])   # hmr_gpu_intra_job
+assert INTRA_JOB_DTYPE.itemsize == 80
 
 
 def build_groups(calls, rng, arena, fused=True):
@@ -140,7 +144,7 @@ def build_groups(calls, rng, arena, fused=True):
         kind, _, origin = kind.partition("@")     # interpolation calls carry their caller: @planes (sub-pel plane builders) / @mc
         if fused and (origin or kind == "sad_direct"):
             continue                               # issued as fused sub-pel refinement / motion compensation jobs below
-        if kind in ("mc_luma", "mc_chroma", "half_pel_planes", "quarter_pel_planes"):
+        if kind in ("mc_luma", "mc_chroma", "half_pel_planes", "quarter_pel_planes", "intra_search"):
             continue
         if kind in ("sad", "sad_direct"):
             N = a[0]
@@ -298,6 +302,32 @@ def build_groups(calls, rng, arena, fused=True):
             nb = interp_bytes("planes", lambda luma, w, h, N=N: luma and w in (N, N + 1) and h in (N, N + 1, N + 7, N + 8))
             nb += sum(v for k, v in calls.items() if k == "sad_direct:%d" % N) * (4 * N * N + 4)
             merged[("me_subpel", N)] = {"name": "me_subpel", "fn": "hmr_gpu_motion_estimation_batch", "size": N, "jobs": jb, "ctu": c, "bytes": nb, "extra": ()}
+        # Intra mode search (homer_loop1_motion_intra): one job per PU instead of one reference build + up to 13 {prediction, SAD} pairs
+        for key, n in sorted(calls.items()):
+            kp = key.split(":")
+            if kp[0] != "intra_search":
+                continue
+            N = int(kp[1])
+            jb = np.zeros(n, INTRA_JOB_DTYPE)
+            c = ctus(n)
+            jb["sqrt_lambda"] = 7.5
+            jb["orig_off"] = wnd(n, srcw, 64, N, N, align=N, ctu=c); jb["orig_stride"] = 64
+            jb["dec_off"] = frame(n, recf0, 2 * N + 1, 2 * N + 1, -1, -1, ctu=c); jb["dec_stride"] = REF_STRIDE
+            pool = arena.alloc(n * 2 * (4 * N + 4))
+            jb["adi_off"] = pool + np.arange(n, dtype=np.int64) * 2 * (4 * N + 4); jb["adif_off"] = jb["adi_off"] + 4 * N + 4
+            jb["pred_off"] = wnd(n, predw, 64, N, N, align=N, ctu=c); jb["pred_stride"] = 64
+            avail = np.where(rng.random(n) < 0.8, 15, rng.integers(0, 16, n))
+            left, top = (avail & 1) | ((avail >> 2) & 1), ((avail >> 1) & 1) | ((avail >> 3) & 1)
+            jb["flags"] = left | (top << 1) | (((avail >> 2) & 1) << 2) | (((avail >> 3) & 1) << 3) | 32
+            jb["sizes"] = N | (N << 16)
+            jb["preds"] = np.stack([rng.integers(2, 35, n), np.zeros(n, np.int64), np.ones(n, np.int64)], 1)
+            jb["pred_bits"] = 1; jb["other_bits"] = 12       # RD_FAST
+            nb = 0
+            for k2, v in calls.items():
+                q = k2.split(":")
+                if "@search" in q[0] and int(q[1]) == N:
+                    nb += v * {"fill_reference_samples@search": (4 * N + 1) * 2 * 3, "sad@search": 4 * N * N + 4}.get(q[0], 2 * (4 * N + 1) + 2 * N * N)
+            merged[("intra_search", N)] = {"name": "intra_search", "fn": "hmr_gpu_intra_search_batch", "size": N, "jobs": jb, "ctu": c, "bytes": nb, "extra": ()}
         # Motion compensation (hmr_motion_compensation_luma / _chroma): one job per PU and component instead of one or two
         # interpolation calls through the 80-pitch intermediate window.
         refc = arena.alloc(2 * CREF_STRIDE * (HA // 2 + PAD), pix(2 * CREF_STRIDE * (HA // 2 + PAD)))
@@ -526,7 +556,7 @@ def main():
     OPS = {"hmr_gpu_sad_batch": 1, "hmr_gpu_ssd16b_batch": 2, "hmr_gpu_predict_batch": 3, "hmr_gpu_reconst_batch": 4, "hmr_gpu_copy_batch": 5,
            "hmr_gpu_intra_pred_batch": 7, "hmr_gpu_intra_refs_batch": 8, "hmr_gpu_interpolate_batch": 9, "hmr_gpu_transform_batch": 11,
            "hmr_gpu_itransform_batch": 12, "hmr_gpu_quant_batch": 13, "hmr_gpu_inv_quant_batch": 14, "hmr_gpu_mc_batch": 15,
-           "hmr_gpu_motion_estimation_batch": 16, "hmr_gpu_tu_chain_batch": 22}
+           "hmr_gpu_motion_estimation_batch": 16, "hmr_gpu_tu_chain_batch": 22, "hmr_gpu_intra_search_batch": 23}
     OP_EDGE, OP_DEBLOCK, OP_STATS, OP_APPLY, OP_PAD = 17, 18, 19, 20, 21
     cmds, names = [], []
     for g in groups:
@@ -539,6 +569,9 @@ def main():
             g["d_out"] = torch.zeros(5 * len(g["jobs"]), dtype=torch.int32, device=dev)     # hmr_gpu_me_result per PU
             cm.out = g["d_out"].data_ptr()
             cm.p = (C.c_int * 4)(128, 64, W, HA)     # MOTION_SEARCH_RANGE_X/Y, picture size
+        if g["fn"] == "hmr_gpu_intra_search_batch":
+            g["d_out"] = torch.zeros(4 * len(g["jobs"]), dtype=torch.int32, device=dev)     # hmr_gpu_intra_result per PU
+            cm.out = g["d_out"].data_ptr()
         if g["fn"] == "hmr_gpu_tu_chain_batch":
             g["d_ac"] = torch.zeros(len(g["jobs"]), dtype=torch.int32, device=dev)
             cm.p64 = (P * 2)(base, g["d_ac"].data_ptr())   # reconstruction base, ac_sum
