@@ -455,7 +455,7 @@ def frame_side_info(rng):
     return {"pred_depth": depth, "tr_idx": tr, "flags": flags, "mvx": mvx, "mvy": mvy, "ref_idx": ref_idx, "qp": qp, "sao_params": params}
 
 
-def cpu_baseline(frames=12):
+def cpu_baseline(frames=64):
     """Reference encoder (compiled by oracle/Makefile in the build container, shipped in oracle/_ref) on this host's cores."""
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_lockstep")
     if not os.path.exists(exe):
@@ -490,6 +490,9 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="replay predict/transform/quant/inv_quant/itransform/reconst/ssd16b as seven separate batches per TU size instead of the fused TU-chain kernel")
     ap.add_argument("--branches", type=int, default=8, help="graph mode: number of parallel graph branches the independent launches are dealt to (1 = one serial chain)")
+    ap.add_argument("--engines-per-gpu", type=int, default=1,
+                    help="encoder engines (frames in flight) per GPU, each with its own stream, planes and command list; a step encodes that many frames. "
+                         "The reference runs up to 8 engines on consecutive frames (num_enc_engines); an IPPP chain keeps about 3 usefully in flight at 1080p (SURVEY.md 8-e)")
     ap.add_argument("--launch-order", default=None, help="write the per-step kernel launch order (JSON) for tools/pmc_summary.py")
     args = ap.parse_args()
 
@@ -507,109 +510,119 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
-    stream = torch.cuda.Stream(device=dev)
-    ctx = Context(device=local_rank, stream=stream.cuda_stream)
-
-    rng = np.random.default_rng(1234 + rank)
-    arena = Arena()
-    groups, planes = build_groups(load_callmix(args.callmix_frame), rng, arena, fused=not args.unfused)
-    info = frame_side_info(rng)
-
-    with torch.cuda.stream(stream):
-        host = np.zeros(arena.size, np.int16)
-        for off, data in arena.init:
-            host[off:off + data.size] = data
-        d_arena = torch.from_numpy(host).to(dev)
-        base = d_arena.data_ptr()
-        for g in groups:
-            g["d_jobs"] = torch.from_numpy(g["jobs"].view(np.uint8)).to(dev)
-            g["d_out"] = torch.zeros(len(g["jobs"]), dtype=torch.int32, device=dev)
-        # frame-level state: original + reconstruction (padded) + SAO destination, side-info
-        def padded_plane(w, h, pad):
-            return torch.from_numpy(rng.integers(0, 256, ((h + 2 * pad), (w + 2 * pad))).astype(np.int16)).to(dev)
-        rec_pl = [padded_plane(W, H, PAD), padded_plane(W // 2, H // 2, PAD // 2), padded_plane(W // 2, H // 2, PAD // 2)]
-        org_pl = [padded_plane(W, H, PAD), padded_plane(W // 2, H // 2, PAD // 2), padded_plane(W // 2, H // 2, PAD // 2)]
-        dst_pl = [t.clone() for t in rec_pl]
-        nxt_pl = [torch.empty_like(t) for t in rec_pl]    # reference picture received from the previous engine
-        d_info = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in info.items()}
-        n_ctu = info["sao_params"].shape[0]
-        d_stats = torch.zeros(n_ctu * 3 * 5 * 2 * 32, dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
-
-    def frame_of(pl):
-        f = Frame()
-        f.width, f.height = W, H
-        f.y = pl[0].data_ptr() + 2 * (PAD * (W + 2 * PAD) + PAD)
-        f.u = pl[1].data_ptr() + 2 * ((PAD // 2) * (W // 2 + PAD) + PAD // 2)
-        f.v = pl[2].data_ptr() + 2 * ((PAD // 2) * (W // 2 + PAD) + PAD // 2)
-        f.stride_y, f.stride_c = W + 2 * PAD, W // 2 + PAD
-        return f
-
-    f_rec, f_org, f_dst = frame_of(rec_pl), frame_of(org_pl), frame_of(dst_pl)
-    units = Units(W // 4, d_info["mvx"].data_ptr(), d_info["mvy"].data_ptr(), d_info["ref_idx"].data_ptr(), d_info["qp"].data_ptr(), d_info["flags"].data_ptr())
-    lib, c = ctx.lib, ctx.ctx
     P = C.c_void_p
 
     class Cmd(C.Structure):
         _fields_ = [("op", C.c_int), ("njobs", C.c_int), ("size", C.c_int), ("p", C.c_int * 4), ("jobs", P), ("a", P), ("b", P), ("c", P), ("out", P), ("p64", P * 2), ("branch", C.c_int)]
 
-    OPS = {"hmr_gpu_sad_batch": 1, "hmr_gpu_ssd16b_batch": 2, "hmr_gpu_predict_batch": 3, "hmr_gpu_reconst_batch": 4, "hmr_gpu_copy_batch": 5,
-           "hmr_gpu_intra_pred_batch": 7, "hmr_gpu_intra_refs_batch": 8, "hmr_gpu_interpolate_batch": 9, "hmr_gpu_transform_batch": 11,
-           "hmr_gpu_itransform_batch": 12, "hmr_gpu_quant_batch": 13, "hmr_gpu_inv_quant_batch": 14, "hmr_gpu_mc_batch": 15,
-           "hmr_gpu_motion_estimation_batch": 16, "hmr_gpu_tu_chain_batch": 22, "hmr_gpu_intra_search_batch": 23}
-    OP_EDGE, OP_DEBLOCK, OP_STATS, OP_APPLY, OP_PAD = 17, 18, 19, 20, 21
-    cmds, names = [], []
-    for g in groups:
-        cm = Cmd(op=OPS[g["fn"]], njobs=len(g["jobs"]), size=g["size"], jobs=g["d_jobs"].data_ptr(), a=base, b=base, c=base, out=g["d_out"].data_ptr())
-        if g["fn"] == "hmr_gpu_copy_batch":
-            cm.size = g["size"] << 8            # kind 0 (int16) | uniform square size hint
-        if g["fn"] == "hmr_gpu_quant_batch":
-            cm.b = None                          # deltaU is scratch in the reference; not returned
-        if g["fn"] == "hmr_gpu_motion_estimation_batch":
-            g["d_out"] = torch.zeros(5 * len(g["jobs"]), dtype=torch.int32, device=dev)     # hmr_gpu_me_result per PU
-            cm.out = g["d_out"].data_ptr()
-            cm.p = (C.c_int * 4)(128, 64, W, HA)     # MOTION_SEARCH_RANGE_X/Y, picture size
-        if g["fn"] == "hmr_gpu_intra_search_batch":
-            g["d_out"] = torch.zeros(4 * len(g["jobs"]), dtype=torch.int32, device=dev)     # hmr_gpu_intra_result per PU
-            cm.out = g["d_out"].data_ptr()
-        if g["fn"] == "hmr_gpu_tu_chain_batch":
-            g["d_ac"] = torch.zeros(len(g["jobs"]), dtype=torch.int32, device=dev)
-            cm.p64 = (P * 2)(base, g["d_ac"].data_ptr())   # reconstruction base, ac_sum
-        cmds.append(cm)
-        names.append(f"{g['name']}:{g['size']}")
-    # The launches of one replayed frame have no data dependencies on each other except the in-loop filter chain (edge flags ->
-    # deblock -> SAO stats -> SAO apply -> pad), which stays on branch 0 in order.  The batched groups are dealt to `--branches`
-    # graph branches (longest first, by algorithmic bytes) so the ramp-up / tail of one kernel overlaps the body of another.
-    load = [0.0] * max(args.branches, 1)
-    load[0] = 2.0e8                                  # the frame-level chain
-    for i in sorted(range(len(groups)), key=lambda i: -groups[i]["bytes"]):
-        b = load.index(min(load))
-        cmds[i].branch = b
-        load[b] += groups[i]["bytes"]
-    frame_bytes = {
-        "deblock": 2 * 2 * 6144 * n_ctu, "sao_stats": (2 * 2 * 6144 + 5 * 3 * 512) * n_ctu, "sao_apply": 2 * 2 * 6144 * n_ctu,
-        "pad": 2 * 2 * ((W + 2 * PAD) * (H + 2 * PAD) - W * H) * 3 // 2, "edge_flags": 3 * (W // 4) * (H // 4),
-    }
-    cmds.append(Cmd(op=OP_EDGE, p=(C.c_int * 4)(W, H, W // 4, 0), a=d_info["pred_depth"].data_ptr(), b=d_info["tr_idx"].data_ptr(), c=d_info["flags"].data_ptr()))
-    cmds.append(Cmd(op=OP_DEBLOCK, p=(C.c_int * 4)(2, 2, 0, 0), a=C.addressof(f_rec), b=C.addressof(units)))
-    cmds.append(Cmd(op=OP_STATS, a=C.addressof(f_org), b=C.addressof(f_rec), out=d_stats.data_ptr()))
-    cmds.append(Cmd(op=OP_APPLY, a=C.addressof(f_rec), b=C.addressof(f_dst), c=d_info["sao_params"].data_ptr()))
-    cmds.append(Cmd(op=OP_PAD, p=(C.c_int * 4)(PAD, PAD, 0, 0), a=C.addressof(f_dst)))
-    names += ["edge_flags", "deblock", "sao_stats", "sao_apply", "pad"]
-    cmd_arr = (Cmd * len(cmds))(*cmds)
-    clist = P()
-    ctx.call("hmr_gpu_cmdlist_create", cmd_arr, len(cmds), C.byref(clist))
-    n_cmd = len(cmds)
-    # one event pair per command and timed step
+    calls = load_callmix(args.callmix_frame)
+
+    def make_engine(e):
+        """One encoder engine = one frame in flight: its own stream, context, planes, job arrays and command list."""
+        stream = torch.cuda.Stream(device=dev)
+        ctx = Context(device=local_rank, stream=stream.cuda_stream)
+
+        rng = np.random.default_rng(1234 + rank + 1000 * e)
+        arena = Arena()
+        groups, planes = build_groups(calls, rng, arena, fused=not args.unfused)
+        info = frame_side_info(rng)
+
+        with torch.cuda.stream(stream):
+            host = np.zeros(arena.size, np.int16)
+            for off, data in arena.init:
+                host[off:off + data.size] = data
+            d_arena = torch.from_numpy(host).to(dev)
+            base = d_arena.data_ptr()
+            for g in groups:
+                g["d_jobs"] = torch.from_numpy(g["jobs"].view(np.uint8)).to(dev)
+                g["d_out"] = torch.zeros(len(g["jobs"]), dtype=torch.int32, device=dev)
+            # frame-level state: original + reconstruction (padded) + SAO destination, side-info
+            def padded_plane(w, h, pad):
+                return torch.from_numpy(rng.integers(0, 256, ((h + 2 * pad), (w + 2 * pad))).astype(np.int16)).to(dev)
+            rec_pl = [padded_plane(W, H, PAD), padded_plane(W // 2, H // 2, PAD // 2), padded_plane(W // 2, H // 2, PAD // 2)]
+            org_pl = [padded_plane(W, H, PAD), padded_plane(W // 2, H // 2, PAD // 2), padded_plane(W // 2, H // 2, PAD // 2)]
+            dst_pl = [t.clone() for t in rec_pl]
+            nxt_pl = [torch.empty_like(t) for t in rec_pl]    # reference picture received from the previous engine
+            d_info = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in info.items()}
+            n_ctu = info["sao_params"].shape[0]
+            d_stats = torch.zeros(n_ctu * 3 * 5 * 2 * 32, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+
+        def frame_of(pl):
+            f = Frame()
+            f.width, f.height = W, H
+            f.y = pl[0].data_ptr() + 2 * (PAD * (W + 2 * PAD) + PAD)
+            f.u = pl[1].data_ptr() + 2 * ((PAD // 2) * (W // 2 + PAD) + PAD // 2)
+            f.v = pl[2].data_ptr() + 2 * ((PAD // 2) * (W // 2 + PAD) + PAD // 2)
+            f.stride_y, f.stride_c = W + 2 * PAD, W // 2 + PAD
+            return f
+
+        f_rec, f_org, f_dst = frame_of(rec_pl), frame_of(org_pl), frame_of(dst_pl)
+        units = Units(W // 4, d_info["mvx"].data_ptr(), d_info["mvy"].data_ptr(), d_info["ref_idx"].data_ptr(), d_info["qp"].data_ptr(), d_info["flags"].data_ptr())
+        OPS = {"hmr_gpu_sad_batch": 1, "hmr_gpu_ssd16b_batch": 2, "hmr_gpu_predict_batch": 3, "hmr_gpu_reconst_batch": 4, "hmr_gpu_copy_batch": 5,
+               "hmr_gpu_intra_pred_batch": 7, "hmr_gpu_intra_refs_batch": 8, "hmr_gpu_interpolate_batch": 9, "hmr_gpu_transform_batch": 11,
+               "hmr_gpu_itransform_batch": 12, "hmr_gpu_quant_batch": 13, "hmr_gpu_inv_quant_batch": 14, "hmr_gpu_mc_batch": 15,
+               "hmr_gpu_motion_estimation_batch": 16, "hmr_gpu_tu_chain_batch": 22, "hmr_gpu_intra_search_batch": 23}
+        OP_EDGE, OP_DEBLOCK, OP_STATS, OP_APPLY, OP_PAD = 17, 18, 19, 20, 21
+        cmds, names = [], []
+        for g in groups:
+            cm = Cmd(op=OPS[g["fn"]], njobs=len(g["jobs"]), size=g["size"], jobs=g["d_jobs"].data_ptr(), a=base, b=base, c=base, out=g["d_out"].data_ptr())
+            if g["fn"] == "hmr_gpu_copy_batch":
+                cm.size = g["size"] << 8            # kind 0 (int16) | uniform square size hint
+            if g["fn"] == "hmr_gpu_quant_batch":
+                cm.b = None                          # deltaU is scratch in the reference; not returned
+            if g["fn"] == "hmr_gpu_motion_estimation_batch":
+                g["d_out"] = torch.zeros(5 * len(g["jobs"]), dtype=torch.int32, device=dev)     # hmr_gpu_me_result per PU
+                cm.out = g["d_out"].data_ptr()
+                cm.p = (C.c_int * 4)(128, 64, W, HA)     # MOTION_SEARCH_RANGE_X/Y, picture size
+            if g["fn"] == "hmr_gpu_intra_search_batch":
+                g["d_out"] = torch.zeros(4 * len(g["jobs"]), dtype=torch.int32, device=dev)     # hmr_gpu_intra_result per PU
+                cm.out = g["d_out"].data_ptr()
+            if g["fn"] == "hmr_gpu_tu_chain_batch":
+                g["d_ac"] = torch.zeros(len(g["jobs"]), dtype=torch.int32, device=dev)
+                cm.p64 = (P * 2)(base, g["d_ac"].data_ptr())   # reconstruction base, ac_sum
+            cmds.append(cm)
+            names.append(f"{g['name']}:{g['size']}")
+        # The launches of one replayed frame have no data dependencies on each other except the in-loop filter chain (edge flags ->
+        # deblock -> SAO stats -> SAO apply -> pad), which stays on branch 0 in order.  The batched groups are dealt to `--branches`
+        # graph branches (longest first, by algorithmic bytes) so the ramp-up / tail of one kernel overlaps the body of another.
+        load = [0.0] * max(args.branches, 1)
+        load[0] = 2.0e8                                  # the frame-level chain
+        for i in sorted(range(len(groups)), key=lambda i: -groups[i]["bytes"]):
+            b = load.index(min(load))
+            cmds[i].branch = b
+            load[b] += groups[i]["bytes"]
+        frame_bytes = {
+            "deblock": 2 * 2 * 6144 * n_ctu, "sao_stats": (2 * 2 * 6144 + 5 * 3 * 512) * n_ctu, "sao_apply": 2 * 2 * 6144 * n_ctu,
+            "pad": 2 * 2 * ((W + 2 * PAD) * (H + 2 * PAD) - W * H) * 3 // 2, "edge_flags": 3 * (W // 4) * (H // 4),
+        }
+        cmds.append(Cmd(op=OP_EDGE, p=(C.c_int * 4)(W, H, W // 4, 0), a=d_info["pred_depth"].data_ptr(), b=d_info["tr_idx"].data_ptr(), c=d_info["flags"].data_ptr()))
+        cmds.append(Cmd(op=OP_DEBLOCK, p=(C.c_int * 4)(2, 2, 0, 0), a=C.addressof(f_rec), b=C.addressof(units)))
+        cmds.append(Cmd(op=OP_STATS, a=C.addressof(f_org), b=C.addressof(f_rec), out=d_stats.data_ptr()))
+        cmds.append(Cmd(op=OP_APPLY, a=C.addressof(f_rec), b=C.addressof(f_dst), c=d_info["sao_params"].data_ptr()))
+        cmds.append(Cmd(op=OP_PAD, p=(C.c_int * 4)(PAD, PAD, 0, 0), a=C.addressof(f_dst)))
+        names += ["edge_flags", "deblock", "sao_stats", "sao_apply", "pad"]
+        cmd_arr = (Cmd * len(cmds))(*cmds)
+        clist = P()
+        ctx.call("hmr_gpu_cmdlist_create", cmd_arr, len(cmds), C.byref(clist))
+        n_cmd = len(cmds)
+        return {"ctx": ctx, "stream": stream, "clist": clist, "groups": groups, "names": names, "frame_bytes": frame_bytes, "dst_pl": dst_pl, "nxt_pl": nxt_pl,
+                "n_cmd": n_cmd, "keep": [d_arena, rec_pl, org_pl, d_info, d_stats, f_rec, f_org, f_dst, units, cmd_arr, cmds]}
+
+    engines = [make_engine(e) for e in range(max(args.engines_per_gpu, 1))]
+    E0 = engines[0]
+    ctx, stream, clist, groups, names, frame_bytes, n_cmd = E0["ctx"], E0["stream"], E0["clist"], E0["groups"], E0["names"], E0["frame_bytes"], E0["n_cmd"]
+    # one event pair per command and timed step (engine 0)
     ev = [(P * (2 * n_cmd))(*[ctx.event().value for _ in range(2 * n_cmd)]) for _ in range(args.steps)]
 
     def step(idx, timed):
-        # reconstructed reference picture: engine r -> engine r+1, point-to-point over RCCL/xGMI
-        reqs = exchange_reference(dst_pl, nxt_pl, rank, world)
-        if args.mode == "graph":
-            ctx.call("hmr_gpu_cmdlist_replay", clist)
-        else:
-            ctx.call("hmr_gpu_cmdlist_run", clist, ev[idx] if timed else None)
+        # reconstructed reference picture: engine r -> engine r+1, point-to-point over RCCL/xGMI (engines sharing a GPU share its memory)
+        reqs = exchange_reference(E0["dst_pl"], E0["nxt_pl"], rank, world)
+        for k, eng in enumerate(engines):
+            if args.mode == "graph":
+                eng["ctx"].call("hmr_gpu_cmdlist_replay", eng["clist"])
+            else:
+                eng["ctx"].call("hmr_gpu_cmdlist_run", eng["clist"], ev[idx] if (timed and k == 0) else None)
         for r in reqs:
             r.wait()
 
@@ -674,10 +687,24 @@ def main():
     if os.path.exists(tpath):
         with open(tpath) as f:
             traffic = json.load(f).get("groups", {}).get(dom, {}).get("hbm_bytes")
+    # VALU issue floor of the dominant kernel from the committed SQ counter passes (tools/pmc_sq.sh): a wave64 VALU instruction holds
+    # its SIMD16 for 4 cycles, the chip has 256 CUs x 4 SIMDs at 2.4 GHz
+    valu = None
+    spath = os.path.join(ROOT, "profiles", "sq_summary.csv")
+    if os.path.exists(spath) and os.path.exists(tpath):
+        import csv
+        with open(tpath) as f:
+            kname = json.load(f).get("groups", {}).get(dom, {}).get("kernel", "").replace("void ", "")
+        for r in csv.DictReader(open(spath)):
+            if r["kernel"] == kname and r.get("SQ_INSTS_VALU") and r.get("SQ_WAVES"):
+                insts = float(r["SQ_INSTS_VALU"])
+                floor_ms = insts * 4 / (256 * 4) / 2.4e9 * 1e3
+                valu = {"valu_insts_per_launch": int(insts), "waves_per_launch": int(float(r["SQ_WAVES"])), "issue_floor_ms": round(floor_ms, 5),
+                        "frac_of_issue_peak": round(floor_ms / per[dom], 4) if per[dom] > 0 else None}
     total_alg = sum(nbytes.values())
 
     if rank == 0:
-        fps = args.steps * world / elapsed
+        fps = args.steps * world * len(engines) / elapsed
         line = {
             "metric": "encoded frames/sec, 1080p YUV420 fixed-QP IPPP (hot-path replay of the reference's per-frame call mix)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -685,11 +712,11 @@ def main():
             "dtype": "int16", "data": "synthetic",
             "config": {"workload": "cfg2-1080p-P-frame-replay", "width": W, "height": H, "qp": 32, "gop": "IPPP gop_size=1", "me": "quarter-pel", "sao": 1,
                        "calls_per_frame": int(sum(len(g["jobs"]) for g in groups)), "launches_per_frame": len(groups) + 8,
-                       "callmix_frame": args.callmix_frame, "parallelism": f"engine-per-gpu x{world}", "launch_mode": args.mode, "graph_branches": args.branches if args.mode == "graph" else 1, "tu_chain": "7 separate batches" if args.unfused else "fused kernel",
+                       "callmix_frame": args.callmix_frame, "parallelism": f"{len(engines)} engine(s) per gpu x{world}", "frames_per_step": len(engines) * world, "launch_mode": args.mode, "graph_branches": args.branches if args.mode == "graph" else 1, "tu_chain": "7 separate batches" if args.unfused else "fused kernel",
                        "algorithmic_MB_per_frame_abi_width": round(total_alg / 1e6, 2), "compulsory_MB_per_frame": round(10.5 * W * H / 1e6, 2)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "measured_copy_GBps": round(copy_gbs, 1),
+                         "measured_copy_GBps": round(copy_gbs, 1), "valu_issue": valu,
                          "timing": ("HIP event pairs around every launch inside the timed region" if args.mode == "eager" else
                                     "HIP event pairs around every launch, eager replay of the same K steps right after the timed graph replays "
                                     "(event nodes inside a hipGraph cannot be read back on ROCm 7.2)"),

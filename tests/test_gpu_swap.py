@@ -24,8 +24,10 @@ def _encode(exe, clip, out, w, h, frames, env=None, extra=()):
         return f.read(), r.stderr
 
 
-@pytest.mark.parametrize("extra,w,h,frames", [((), 200, 136, 3), (("force_intra=1",), 200, 136, 2), ((), 416, 240, 3), (("rd=1",), 200, 136, 2)],
-                         ids=["ippp_200x136", "all_intra_200x136", "ippp_416x240", "ippp_rdfull_200x136"])
+@pytest.mark.parametrize("extra,w,h,frames", [((), 200, 136, 3), (("force_intra=1",), 200, 136, 2), ((), 416, 240, 3), (("rd=1",), 200, 136, 2),
+                          (("bitrate_mode=1", "bitrate=400", "perf=1"), 416, 240, 3),                       # BASELINE configs[2] shape: CBR, performance_mode 1
+                          (("force_intra=1", "rd=1", "intra_tr=4", "perf=0"), 200, 136, 2)],               # BASELINE configs[4] shape: all-intra, full RDO, TU depth 4
+                         ids=["ippp_200x136", "all_intra_200x136", "ippp_416x240", "ippp_rdfull_200x136", "cbr_perf1_416x240", "all_intra_rdfull_tr4_200x136"])
 def test_stream_identical_with_gpu_kernels(tmp_path, extra, w, h, frames):
     if not (os.path.exists(SWAP) and os.path.exists(libs.REF_LOCKSTEP)):
         pytest.skip("oracle/_ref not shipped (built only where the reference sources exist)")
