@@ -54,6 +54,12 @@ struct Stager {
 	{
 		if (hipMemcpyAsync(c->d_stage, c->h_stage, in_end, hipMemcpyHostToDevice, c->stream) != hipSuccess) die("H2D");
 	}
+	// in/out operands (in-place kernels): allocate with out(), fill the host side, then upload_all()
+	void upload_all()
+	{
+		const size_t end = out_end > in_end ? out_end : in_end;
+		if (hipMemcpyAsync(c->d_stage, c->h_stage, end, hipMemcpyHostToDevice, c->stream) != hipSuccess) die("H2D");
+	}
 	void finish()
 	{
 		if (out_end > out_begin &&
@@ -549,6 +555,139 @@ void hmr_gpu_intra_search(int16_t *orig, int orig_stride, int16_t *decoded_corne
 	out[0] = r->best_mode;
 	out[1] = r->bits;
 	*best_cost = r->cost;
+}
+
+/* ---- in-loop filters at the reference's own call granularity (one CTU per call).  Only the CTU's neighbourhood travels: the tile is addressed
+ * through a virtual picture origin, the kernels index with picture coordinates and touch nothing outside the region of interest. ---- */
+void hmr_gpu_deblock_filter_ctu(int16_t *const planes[3], const int strides[3], int width, int height, int units_stride, const int16_t *mvx, const int16_t *mvy,
+				const int8_t *ref_idx, const uint8_t *qp, const uint8_t *unit_flags, const uint8_t *pred_depth, const uint8_t *tr_idx, int ctu_x,
+				int ctu_y, int ctu_size, int dir, int cb_qp_offset, int cr_qp_offset, int beta_offset_div2, int tc_offset_div2)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	// luma tile: the CTU grown by 8 samples to the left / top (edges on the CTU boundary modify 3 samples of the neighbour and read 4)
+	const int x0 = ctu_x >= 8 ? ctu_x - 8 : 0, y0 = ctu_y >= 8 ? ctu_y - 8 : 0;
+	const int x1 = ctu_x + ctu_size < width ? ctu_x + ctu_size : width, y1 = ctu_y + ctu_size < height ? ctu_y + ctu_size : height;
+	const int tw = x1 - x0, th = y1 - y0, uw = tw / 4, uh = th / 4, ux0 = x0 / 4, uy0 = y0 / 4;
+	// side-info tiles (inputs)
+	size_t o_mvx = st.zeros((size_t)uw * uh * 2), o_mvy = st.zeros((size_t)uw * uh * 2), o_ref = st.zeros((size_t)uw * uh), o_qp = st.zeros((size_t)uw * uh),
+	       o_fl = st.zeros((size_t)uw * uh), o_pd = st.zeros((size_t)uw * uh), o_tr = st.zeros((size_t)uw * uh);
+	for (int y = 0; y < uh; y++) {
+		const size_t src = (size_t)(uy0 + y) * units_stride + ux0, dst = (size_t)y * uw;
+		memcpy(st.host<int16_t>(o_mvx) + dst, mvx + src, (size_t)uw * 2);
+		memcpy(st.host<int16_t>(o_mvy) + dst, mvy + src, (size_t)uw * 2);
+		memcpy(st.host<int8_t>(o_ref) + dst, ref_idx + src, (size_t)uw);
+		memcpy(st.host<uint8_t>(o_qp) + dst, qp + src, (size_t)uw);
+		for (int x = 0; x < uw; x++) st.host<uint8_t>(o_fl)[dst + x] = unit_flags[src + x] & (HMR_GPU_UNIT_INTRA | HMR_GPU_UNIT_CBF_Y);
+		memcpy(st.host<uint8_t>(o_pd) + dst, pred_depth + src, (size_t)uw);
+		memcpy(st.host<uint8_t>(o_tr) + dst, tr_idx + src, (size_t)uw);
+	}
+	// sample tiles (in place)
+	st.begin_outputs();
+	size_t o_pl[3];
+	for (int comp = 0; comp < 3; comp++) {
+		const int sh = comp ? 1 : 0, w = tw >> sh, h = th >> sh;
+		o_pl[comp] = st.out((size_t)w * h * 2);
+		for (int y = 0; y < h; y++)
+			memcpy(st.host<int16_t>(o_pl[comp]) + (size_t)y * w, planes[comp] + (size_t)((y0 >> sh) + y) * strides[comp] + (x0 >> sh), (size_t)w * 2);
+	}
+	st.upload_all();
+	hmr_gpu_frame f = {};
+	f.width = width; f.height = height; f.stride_y = tw; f.stride_c = tw / 2;
+	f.y = st.dev<int16_t>(o_pl[0]) - ((ptrdiff_t)y0 * tw + x0);
+	f.u = st.dev<int16_t>(o_pl[1]) - ((ptrdiff_t)(y0 / 2) * (tw / 2) + x0 / 2);
+	f.v = st.dev<int16_t>(o_pl[2]) - ((ptrdiff_t)(y0 / 2) * (tw / 2) + x0 / 2);
+	hmr_gpu_units u = {};
+	const ptrdiff_t uo = (ptrdiff_t)uy0 * uw + ux0;
+	u.units_stride = uw;
+	u.mvx = st.dev<int16_t>(o_mvx) - uo; u.mvy = st.dev<int16_t>(o_mvy) - uo; u.ref_idx = st.dev<int8_t>(o_ref) - uo;
+	u.qp = st.dev<uint8_t>(o_qp) - uo; u.flags = st.dev<uint8_t>(o_fl) - uo;
+	must(hmr_gpu_deblock_ctu(c, &f, &u, st.dev<uint8_t>(o_pd) - uo, st.dev<uint8_t>(o_tr) - uo, cb_qp_offset, cr_qp_offset, beta_offset_div2, tc_offset_div2, ctu_x,
+				 ctu_y, ctu_size, dir),
+	     "deblock_ctu");
+	st.finish();
+	for (int comp = 0; comp < 3; comp++) {
+		const int sh = comp ? 1 : 0, w = tw >> sh, h = th >> sh;
+		st.get2d(o_pl[comp], planes[comp] + (size_t)(y0 >> sh) * strides[comp] + (x0 >> sh), strides[comp], h, w, 2);
+	}
+}
+
+void hmr_gpu_sao_offset_ctu(const int16_t *const src[3], const int src_stride[3], int16_t *const dst[3], const int dst_stride[3], int width, int height, int ctu_x,
+			    int ctu_y, const int32_t *params)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	hmr_gpu_frame fs = {}, fd = {};
+	fs.width = fd.width = width; fs.height = fd.height = height;
+	int16_t **ps[3] = {&fs.y, &fs.u, &fs.v}, **pd[3] = {&fd.y, &fd.u, &fd.v};
+	const size_t o_par = st.put2d(params, 3 * 34, 1, 3 * 34, 4);
+	size_t o_src[3], o_dst[3];
+	int x0[3], y0[3], x1[3], y1[3], pitch[3];
+	for (int comp = 0; comp < 3; comp++) {
+		const int sh = comp ? 1 : 0, pw = width >> sh, ph = height >> sh, x = ctu_x >> sh, y = ctu_y >> sh, n = 64 >> sh;
+		x0[comp] = x > 0 ? x - 1 : 0; y0[comp] = y > 0 ? y - 1 : 0;
+		x1[comp] = x + n + 1 < pw ? x + n + 1 : pw; y1[comp] = y + n + 1 < ph ? y + n + 1 : ph;
+		pitch[comp] = comp ? 34 : 66;     // one pitch per plane type, so that one stride serves U and V
+		o_src[comp] = st.zeros((size_t)pitch[comp] * pitch[comp] * 2);
+		for (int yy = y0[comp]; yy < y1[comp]; yy++)
+			memcpy(st.host<int16_t>(o_src[comp]) + (size_t)(yy - y0[comp]) * pitch[comp], src[comp] + (size_t)yy * src_stride[comp] + x0[comp],
+			       (size_t)(x1[comp] - x0[comp]) * 2);
+	}
+	st.begin_outputs();
+	for (int comp = 0; comp < 3; comp++) {
+		o_dst[comp] = st.out((size_t)pitch[comp] * pitch[comp] * 2);
+		for (int yy = y0[comp]; yy < y1[comp]; yy++)    // the samples a class does not touch keep the destination's own value
+			memcpy(st.host<int16_t>(o_dst[comp]) + (size_t)(yy - y0[comp]) * pitch[comp], dst[comp] + (size_t)yy * dst_stride[comp] + x0[comp],
+			       (size_t)(x1[comp] - x0[comp]) * 2);
+		*ps[comp] = st.dev<int16_t>(o_src[comp]) - ((ptrdiff_t)y0[comp] * pitch[comp] + x0[comp]);
+		*pd[comp] = st.dev<int16_t>(o_dst[comp]) - ((ptrdiff_t)y0[comp] * pitch[comp] + x0[comp]);
+	}
+	fs.stride_y = fd.stride_y = pitch[0]; fs.stride_c = fd.stride_c = pitch[1];
+	st.upload_all();
+	const int ctus_x = (width + 63) / 64;
+	must(hmr_gpu_sao_apply_ctu(c, &fs, &fd, (ctu_y / 64) * ctus_x + ctu_x / 64, st.dev<int32_t>(o_par)), "sao_offset_ctu");
+	st.finish();
+	for (int comp = 0; comp < 3; comp++) {
+		if (!params[comp * 34]) continue;       // SAO_MODE_OFF: the reference does not touch the component
+		const int sh = comp ? 1 : 0, pw = width >> sh, ph = height >> sh, x = ctu_x >> sh, y = ctu_y >> sh, n = 64 >> sh;
+		const int xe = x + n < pw ? x + n : pw, ye = y + n < ph ? y + n : ph;
+		for (int yy = y; yy < ye; yy++)
+			memcpy(dst[comp] + (size_t)yy * dst_stride[comp] + x, st.host<int16_t>(o_dst[comp]) + (size_t)(yy - y0[comp]) * pitch[comp] + (x - x0[comp]),
+			       (size_t)(xe - x) * 2);
+	}
+}
+
+void hmr_gpu_pad_ctu(int16_t *const planes[3], const int strides[3], int width, int height, int pad_x, int pad_y, int ctu_x, int ctu_y, int ctu_size)
+{
+	const bool left = ctu_x == 0, top = ctu_y == 0, right = ctu_x + ctu_size >= width, bottom = ctu_y + ctu_size >= height;
+	if (!(left || top || right || bottom)) return;     // interior CTU: nothing to replicate (hmr_encoder_lib.c:1730-1740)
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	const int bw = (right ? width : ctu_x + ctu_size) - ctu_x, bh = (bottom ? height : ctu_y + ctu_size) - ctu_y;
+	st.begin_outputs();
+	size_t off[3];
+	for (int comp = 0; comp < 3; comp++) {
+		const int sh = comp ? 1 : 0, w = bw >> sh, h = bh >> sh, px = pad_x >> sh, py = pad_y >> sh, pitch = w + 2 * px;
+		off[comp] = st.out((size_t)pitch * (h + 2 * py) * 2);
+		for (int y = 0; y < h; y++)
+			memcpy(st.host<int16_t>(off[comp]) + (size_t)(y + py) * pitch + px, planes[comp] + (size_t)((ctu_y >> sh) + y) * strides[comp] + (ctu_x >> sh), (size_t)w * 2);
+	}
+	st.upload_all();
+	// the CTU's block as a picture of its own: replicating ITS edges equals replicating the picture's edges on the sides where they coincide
+	hmr_gpu_frame f = {};
+	f.width = bw; f.height = bh; f.stride_y = bw + 2 * pad_x; f.stride_c = bw / 2 + 2 * (pad_x / 2);
+	f.y = st.dev<int16_t>(off[0]) + (size_t)pad_y * f.stride_y + pad_x;
+	f.u = st.dev<int16_t>(off[1]) + (size_t)(pad_y / 2) * f.stride_c + pad_x / 2;
+	f.v = st.dev<int16_t>(off[2]) + (size_t)(pad_y / 2) * f.stride_c + pad_x / 2;
+	must(hmr_gpu_pad_frame(c, &f, pad_x, pad_y), "pad_ctu");
+	st.finish();
+	for (int comp = 0; comp < 3; comp++) {
+		const int sh = comp ? 1 : 0, w = bw >> sh, h = bh >> sh, px = pad_x >> sh, py = pad_y >> sh, pitch = w + 2 * px;
+		const int xa = left ? -px : 0, xb = right ? w + px : w, ya = top ? -py : 0, yb = bottom ? h + py : h;
+		for (int y = ya; y < yb; y++)
+			memcpy(planes[comp] + ((ptrdiff_t)((ctu_y >> sh) + y)) * strides[comp] + (ctu_x >> sh) + xa,
+			       st.host<int16_t>(off[comp]) + (size_t)(y + py) * pitch + px + xa, (size_t)(xb - xa) * 2);
+	}
 }
 
 }  // extern "C"

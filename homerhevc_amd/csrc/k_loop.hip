@@ -48,12 +48,13 @@ __device__ __forceinline__ int boundary_strength(const UnitInfo &ui, int q, int 
 	return (iabs(mqx - mpx) >= 4 || iabs(mqy - mpy) >= 4) ? 1 : 0;
 }
 
-__global__ __launch_bounds__(HMR_BLOCK) void k_edge_flags(const uint8_t *__restrict__ pred_depth, const uint8_t *__restrict__ tr_idx, int w4, int h4,
+// units [ux0, ux0 + w4) x [uy0, uy0 + h4) of the picture (the whole picture, or one CTU)
+__global__ __launch_bounds__(HMR_BLOCK) void k_edge_flags(const uint8_t *__restrict__ pred_depth, const uint8_t *__restrict__ tr_idx, int ux0, int uy0, int w4, int h4,
 							     int units_stride, uint8_t *__restrict__ flags)
 {
 	const int i = blockIdx.x * HMR_BLOCK + threadIdx.x;
 	if (i >= w4 * h4) return;
-	const int uy = i / w4, ux = i - uy * w4, o = uy * units_stride + ux;
+	const int uy = uy0 + i / w4, ux = ux0 + i % w4, o = uy * units_stride + ux;
 	int leaf = 64 >> (pred_depth[o] + tr_idx[o]);
 	if (leaf < 8) leaf = 8;
 	int f = flags[o] & ~(F_EDGE_VER | F_EDGE_HOR);
@@ -106,6 +107,7 @@ __device__ __forceinline__ void chroma_edge(int16_t *e, int s, int t, int tc)
 struct DeblockArgs {
 	int16_t *y, *u, *v;
 	int ys, cs, w4, h4;
+	int ux0, uy0;        // region of interest in 4x4 units: [ux0, ux0 + w4) x [uy0, uy0 + h4); ux0 / uy0 even (CTU aligned)
 	UnitInfo ui;
 	int cb_off, cr_off, beta_off, tc_off;
 	uint8_t *bs_out;
@@ -117,9 +119,9 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_deblock_ver(DeblockArgs a)
 	const int ew = (a.w4 + 1) / 2;                 // edges per unit row (even ux)
 	const int i = blockIdx.x * HMR_BLOCK + threadIdx.x;
 	if (i >= ew * a.h4) return;
-	const int uy = i / ew, ux = (i - uy * ew) * 2;
+	const int uy = a.uy0 + i / ew, ux = a.ux0 + (i % ew) * 2;
 	const int q = uy * a.ui.units_stride + ux;
-	if (a.bs_out) { a.bs_out[q] = 0; if (ux + 1 < a.w4) a.bs_out[q + 1] = 0; }
+	if (a.bs_out) { a.bs_out[q] = 0; if (ux + 1 < a.ux0 + a.w4) a.bs_out[q + 1] = 0; }
 	if (!(a.ui.flags[q] & F_EDGE_VER)) return;
 	const int p = q - 1;
 	const int bs = boundary_strength(a.ui, q, p);
@@ -168,10 +170,10 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_deblock_hor(DeblockArgs a)
 	const int width = a.w4 * 4, eh = (a.h4 + 1) / 2;
 	const int i = blockIdx.x * HMR_BLOCK + threadIdx.x;
 	const bool in = i < width * eh;
-	const int er = in ? i / width : 0, x = in ? i - er * width : 0;
-	const int uy = er * 2, ux = x >> 2, col = x & 3;
+	const int er = in ? i / width : 0, x = a.ux0 * 4 + (in ? i - er * width : 0);
+	const int uy = a.uy0 + er * 2, ux = x >> 2, col = x & 3;
 	const int q = uy * a.ui.units_stride + ux;
-	if (in && a.bs_out && col == 0) { a.bs_out[q] = 0; if (uy + 1 < a.h4) a.bs_out[q + a.ui.units_stride] = 0; }
+	if (in && a.bs_out && col == 0) { a.bs_out[q] = 0; if (uy + 1 < a.uy0 + a.h4) a.bs_out[q + a.ui.units_stride] = 0; }
 	const bool edge = in && (a.ui.flags[q] & F_EDGE_HOR);
 	int bs = 0, qpa = 0;
 	if (edge) {
@@ -294,11 +296,11 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_sao_stats(Planes org, Planes rec,
 }
 
 // grid = (ctus, 3).  dst must already hold a copy of src.
-__global__ __launch_bounds__(HMR_BLOCK) void k_sao_apply(Planes src, int16_t *dy, int16_t *du, int16_t *dv, int width, int height, int ctus_x,
+__global__ __launch_bounds__(HMR_BLOCK) void k_sao_apply(Planes src, int16_t *dy, int16_t *du, int16_t *dv, int width, int height, int ctus_x, int ctu_first,
 							    const int32_t *__restrict__ params)
 {
-	const int ctu = blockIdx.x, comp = blockIdx.y, cx = ctu % ctus_x, cy = ctu / ctus_x;
-	const int32_t *pc = params + (size_t)ctu * 3 * 34, *p = pc + comp * 34;
+	const int ctu = ctu_first + blockIdx.x, comp = blockIdx.y, cx = ctu % ctus_x, cy = ctu / ctus_x;
+	const int32_t *pc = params + (size_t)blockIdx.x * 3 * 34, *p = pc + comp * 34;   // params[0] belongs to CTU ctu_first
 	if (!p[0]) return;
 	const int type = p[1], sh = comp ? 1 : 0;
 	const int hl = (cy * 64 + 64 > height) ? height - cy * 64 : 64, wl = (cx * 64 + 64 > width) ? width - cx * 64 : 64;
@@ -342,30 +344,74 @@ extern "C" int hmr_gpu_edge_flags_frame(hmr_gpu_ctx *ctx, const uint8_t *pred_de
 					uint8_t *flags)
 {
 	const int n = (width / 4) * (height / 4);
-	hipLaunchKernelGGL(k_edge_flags, dim3((n + HMR_BLOCK - 1) / HMR_BLOCK), dim3(HMR_BLOCK), 0, ctx->stream, pred_depth, tr_idx, width / 4, height / 4,
+	hipLaunchKernelGGL(k_edge_flags, dim3((n + HMR_BLOCK - 1) / HMR_BLOCK), dim3(HMR_BLOCK), 0, ctx->stream, pred_depth, tr_idx, 0, 0, width / 4, height / 4,
 			   units_stride, flags);
 	HIP_TRY(hipGetLastError());
 	return HMR_GPU_OK;
 }
 
-extern "C" int hmr_gpu_deblock_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *f, const hmr_gpu_units *info, int cb_qp_offset, int cr_qp_offset,
-				     int beta_offset_div2, int tc_offset_div2, uint8_t *bs_ver, uint8_t *bs_hor)
+static int deblock_args(DeblockArgs &a, const hmr_gpu_frame *f, const hmr_gpu_units *info, int cb_qp_offset, int cr_qp_offset, int beta_offset_div2,
+			int tc_offset_div2)
 {
 	if (!f || !info || (f->width & 7) || (f->height & 7) || (f->stride_y & 3) || (f->stride_c & 1) || ((uintptr_t)f->y & 7)) {
-		hmr_set_error("deblock_frame: width/height must be multiples of 8, luma stride a multiple of 4 and the luma plane 8-byte aligned");
+		hmr_set_error("deblock: width/height must be multiples of 8, luma stride a multiple of 4 and the luma plane 8-byte aligned");
 		return HMR_GPU_ERR_ARG;
 	}
-	DeblockArgs a;
 	a.y = f->y; a.u = f->u; a.v = f->v; a.ys = f->stride_y; a.cs = f->stride_c;
+	a.ux0 = a.uy0 = 0;
 	a.w4 = f->width / 4; a.h4 = f->height / 4;
 	a.ui.units_stride = info->units_stride; a.ui.mvx = info->mvx; a.ui.mvy = info->mvy; a.ui.ref_idx = info->ref_idx; a.ui.qp = info->qp; a.ui.flags = info->flags;
 	a.cb_off = cb_qp_offset; a.cr_off = cr_qp_offset; a.beta_off = beta_offset_div2; a.tc_off = tc_offset_div2;
+	a.bs_out = nullptr;
+	return HMR_GPU_OK;
+}
+
+static void deblock_launch(hmr_gpu_ctx *ctx, const DeblockArgs &a, int dir)
+{
+	if (dir == 0) {
+		const int nver = ((a.w4 + 1) / 2) * a.h4;
+		hipLaunchKernelGGL(k_deblock_ver, dim3((nver + HMR_BLOCK - 1) / HMR_BLOCK), dim3(HMR_BLOCK), 0, ctx->stream, a);
+	} else {
+		const int nhor = a.w4 * 4 * ((a.h4 + 1) / 2);
+		hipLaunchKernelGGL(k_deblock_hor, dim3((nhor + HMR_BLOCK - 1) / HMR_BLOCK), dim3(HMR_BLOCK), 0, ctx->stream, a);
+	}
+}
+
+extern "C" int hmr_gpu_deblock_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *f, const hmr_gpu_units *info, int cb_qp_offset, int cr_qp_offset,
+				     int beta_offset_div2, int tc_offset_div2, uint8_t *bs_ver, uint8_t *bs_hor)
+{
+	DeblockArgs a;
+	const int rc = deblock_args(a, f, info, cb_qp_offset, cr_qp_offset, beta_offset_div2, tc_offset_div2);
+	if (rc != HMR_GPU_OK) return rc;
 	a.bs_out = bs_ver;
-	const int nver = ((a.w4 + 1) / 2) * a.h4;
-	hipLaunchKernelGGL(k_deblock_ver, dim3((nver + HMR_BLOCK - 1) / HMR_BLOCK), dim3(HMR_BLOCK), 0, ctx->stream, a);
+	deblock_launch(ctx, a, 0);
 	a.bs_out = bs_hor;
-	const int nhor = f->width * ((a.h4 + 1) / 2);
-	hipLaunchKernelGGL(k_deblock_hor, dim3((nhor + HMR_BLOCK - 1) / HMR_BLOCK), dim3(HMR_BLOCK), 0, ctx->stream, a);
+	deblock_launch(ctx, a, 1);
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
+
+// the reference's own call granularity (hmr_deblock_filter_cu, hmr_deblocking_filter.c:737): the edges of one direction inside one CTU; the EDGE bits
+// of the CTU's units are derived first when the coding-tree arrays are given
+extern "C" int hmr_gpu_deblock_ctu(hmr_gpu_ctx *ctx, const hmr_gpu_frame *f, const hmr_gpu_units *info, const uint8_t *pred_depth, const uint8_t *tr_idx,
+				   int cb_qp_offset, int cr_qp_offset, int beta_offset_div2, int tc_offset_div2, int ctu_x, int ctu_y, int ctu_size, int dir)
+{
+	DeblockArgs a;
+	const int rc = deblock_args(a, f, info, cb_qp_offset, cr_qp_offset, beta_offset_div2, tc_offset_div2);
+	if (rc != HMR_GPU_OK) return rc;
+	if ((ctu_x & 7) || (ctu_y & 7) || ctu_x < 0 || ctu_y < 0 || ctu_x >= f->width || ctu_y >= f->height || (dir != 0 && dir != 1)) {
+		hmr_set_error("deblock_ctu: bad CTU position / direction");
+		return HMR_GPU_ERR_ARG;
+	}
+	const int x1 = ctu_x + ctu_size < f->width ? ctu_x + ctu_size : f->width, y1 = ctu_y + ctu_size < f->height ? ctu_y + ctu_size : f->height;
+	a.ux0 = ctu_x / 4; a.uy0 = ctu_y / 4;
+	a.w4 = (x1 - ctu_x) / 4; a.h4 = (y1 - ctu_y) / 4;
+	if (pred_depth && tr_idx) {
+		const int n = a.w4 * a.h4;
+		hipLaunchKernelGGL(k_edge_flags, dim3((n + HMR_BLOCK - 1) / HMR_BLOCK), dim3(HMR_BLOCK), 0, ctx->stream, pred_depth, tr_idx, a.ux0, a.uy0, a.w4, a.h4,
+				   info->units_stride, info->flags);
+	}
+	deblock_launch(ctx, a, dir);
 	HIP_TRY(hipGetLastError());
 	return HMR_GPU_OK;
 }
@@ -405,7 +451,19 @@ extern "C" int hmr_gpu_sao_apply_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *sr
 		return HMR_GPU_ERR_ARG;
 	const int ctus_x = (src->width + 63) / 64, ctus_y = (src->height + 63) / 64;
 	hipLaunchKernelGGL(k_sao_apply, dim3(ctus_x * ctus_y, 3), dim3(HMR_BLOCK), 0, ctx->stream, planes_of(src), dst->y, dst->u, dst->v, src->width, src->height,
-			   ctus_x, params);
+			   ctus_x, 0, params);
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
+
+// one CTU (sao_offset_ctu's own granularity); params = this CTU's [3][34]
+extern "C" int hmr_gpu_sao_apply_ctu(hmr_gpu_ctx *ctx, const hmr_gpu_frame *src, const hmr_gpu_frame *dst, int ctu_index, const int32_t *params)
+{
+	if (!src || !dst || src->width != dst->width || src->height != dst->height || src->stride_y != dst->stride_y || src->stride_c != dst->stride_c)
+		return HMR_GPU_ERR_ARG;
+	const int ctus_x = (src->width + 63) / 64;
+	hipLaunchKernelGGL(k_sao_apply, dim3(1, 3), dim3(HMR_BLOCK), 0, ctx->stream, planes_of(src), dst->y, dst->u, dst->v, src->width, src->height, ctus_x, ctu_index,
+			   params);
 	HIP_TRY(hipGetLastError());
 	return HMR_GPU_OK;
 }

@@ -115,6 +115,16 @@ void hmr_gpu_inv_quant(int16_t *src, int16_t *dst, int depth, int comp, int is_i
 void hmr_gpu_get_sao_stats(const int16_t *const orig[3], const int orig_stride[3], const int16_t *const recon[3], const int recon_stride[3], int pict_width,
 			   int pict_height, int ctu_x, int ctu_y, int64_t *stats);
 
+/* In-loop filters at the reference's own call granularity, HOST pointers (planes address sample (0,0), strides in elements; unit arrays are raster over
+ * the picture's 4x4 units like hmr_gpu_units; unit_flags = HMR_GPU_UNIT_INTRA | HMR_GPU_UNIT_CBF_Y).  Only the CTU's neighbourhood is transferred.
+ * hmr_deblock_filter_cu (hmr_deblocking_filter.c:737), sao_offset_ctu (hmr_sao.c:1210), reference_picture_border_padding_ctu (hmr_encoder_lib.c:1723). */
+void hmr_gpu_deblock_filter_ctu(int16_t *const planes[3], const int strides[3], int width, int height, int units_stride, const int16_t *mvx, const int16_t *mvy,
+				const int8_t *ref_idx, const uint8_t *qp, const uint8_t *unit_flags, const uint8_t *pred_depth, const uint8_t *tr_idx, int ctu_x,
+				int ctu_y, int ctu_size, int dir, int cb_qp_offset, int cr_qp_offset, int beta_offset_div2, int tc_offset_div2);
+void hmr_gpu_sao_offset_ctu(const int16_t *const src[3], const int src_stride[3], int16_t *const dst[3], const int dst_stride[3], int width, int height, int ctu_x,
+			    int ctu_y, const int32_t *params /* [3][34] = {modeIdc, typeIdc, offset[32]} per component */);
+void hmr_gpu_pad_ctu(int16_t *const planes[3], const int strides[3], int width, int height, int pad_x, int pad_y, int ctu_x, int ctu_y, int ctu_size);
+
 /* ------------------------------------------------------------------------------------------------
  * 3. batched entries: device-resident operands, one launch per call, asynchronous on the context's
  *    stream.  A job addresses up to three operands by ELEMENT offset from the base pointer passed to
@@ -195,6 +205,11 @@ int hmr_gpu_edge_flags_frame(hmr_gpu_ctx *ctx, const uint8_t *pred_depth, const 
  * bs_ver / bs_hor (optional, units_stride x height/4) receive 0x80|bs for every evaluated edge segment. P/I slices. */
 int hmr_gpu_deblock_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *frame, const hmr_gpu_units *info, int cb_qp_offset, int cr_qp_offset,
 			  int beta_offset_div2, int tc_offset_div2, uint8_t *bs_ver, uint8_t *bs_hor);
+/* hmr_deblock_filter_cu's own granularity (hmr_deblocking_filter.c:737): the edges of one direction (0 = EDGE_VER, 1 = EDGE_HOR, hmr_private.h:122)
+ * inside the CTU at luma position (ctu_x, ctu_y).  pred_depth / tr_idx (optional, DEVICE, raster like the unit arrays): when given, the EDGE bits of
+ * the CTU's units are derived first. */
+int hmr_gpu_deblock_ctu(hmr_gpu_ctx *ctx, const hmr_gpu_frame *frame, const hmr_gpu_units *info, const uint8_t *pred_depth, const uint8_t *tr_idx,
+			int cb_qp_offset, int cr_qp_offset, int beta_offset_div2, int tc_offset_div2, int ctu_x, int ctu_y, int ctu_size, int dir);
 /* low_level_funcs_t.get_sao_stats (hmr_private.h:1091, hmr_sse42_sao.c:35) for every CTU:
  * stats[ctu][comp][type EO0,EO90,EO135,EO45,BO][0 = diff, 1 = count][32] as int32 */
 int hmr_gpu_sao_stats_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *orig, const hmr_gpu_frame *recon, int32_t *stats);
@@ -203,6 +218,8 @@ int hmr_gpu_sao_stats_ctu(hmr_gpu_ctx *ctx, const hmr_gpu_frame *orig, const hmr
 /* sao_offset_ctu (hmr_sao.c:1210) for every CTU: src = pre-SAO picture, dst = output (must hold a copy of src);
  * params[ctu][comp][34] = {modeIdc, typeIdc, offset[32]} */
 int hmr_gpu_sao_apply_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *src, const hmr_gpu_frame *dst, const int32_t *params);
+/* the same for one CTU (sao_offset_ctu's own granularity); params = that CTU's [3][34] */
+int hmr_gpu_sao_apply_ctu(hmr_gpu_ctx *ctx, const hmr_gpu_frame *src, const hmr_gpu_frame *dst, int ctu_index, const int32_t *params);
 /* reference_picture_border_padding_ctu (hmr_encoder_lib.c:1723) for every CTU: replicate edges into pad_x/pad_y (luma; chroma half) */
 int hmr_gpu_pad_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *frame, int pad_x, int pad_y);
 

@@ -199,3 +199,86 @@ int homer_loop1_motion_intra(henc_thread_t *et, ctu_info_t *ctu, ctu_info_t *ctu
 	if (!g_intra_searches++) fprintf(stderr, "ref_swap: intra mode search routed to libhomer_gpu.so\n");
 	return out[1];
 }
+
+/* ---- in-loop filters at the reference's own call granularity (hmr_deblock_sao_pad_sync_ctu, hmr_encoder_lib.c:2386, drives them CTU by CTU) ---- */
+static int16_t *g_mvx, *g_mvy;
+static int8_t *g_ref;
+static uint8_t *g_qp, *g_fl, *g_pd, *g_tr;
+static int g_us;
+/* ctu_info_t keeps its side-info in z-order per CTU (hmr_private.h:792-843); the GPU side takes raster arrays over the picture */
+static void export_units(hvenc_engine_t *eng, int n)
+{
+	ctu_info_t *ctu = &eng->ctu_info[n];
+	int cx = n % eng->pict_width_in_ctu, cy = n / eng->pict_width_in_ctu, a;
+	for (a = 0; a < 256; a++) {
+		int r = eng->abs2raster_table[a];
+		size_t o = (size_t)(cy * 16 + r / 16) * g_us + cx * 16 + r % 16;
+		g_mvx[o] = (int16_t)ctu->mv_ref[0][a].hor_vector;
+		g_mvy[o] = (int16_t)ctu->mv_ref[0][a].ver_vector;
+		g_ref[o] = ctu->mv_ref_idx[0][a];
+		g_qp[o] = ctu->qp[a];
+		g_fl[o] = (uint8_t)((ctu->pred_mode[a] == INTRA_MODE ? HMR_GPU_UNIT_INTRA : 0) | (CBF(ctu, a, Y_COMP, ctu->tr_idx[a]) ? HMR_GPU_UNIT_CBF_Y : 0));
+		g_pd[o] = ctu->pred_depth[a];
+		g_tr[o] = ctu->tr_idx[a];
+	}
+}
+void hmr_deblock_filter_cu(henc_thread_t *et, slice_t *slice, ctu_info_t *ctu, int dir)
+{
+	hvenc_engine_t *eng = et->enc_engine;
+	if (!want("deblock") || slice->deblocking_filter_disabled_flag) {
+		((void (*)(henc_thread_t *, slice_t *, ctu_info_t *, int))REAL(hmr_deblock_filter_cu))(et, slice, ctu, dir);
+		return;
+	}
+	if (!g_mvx) {
+		size_t n = (size_t)eng->pict_width_in_ctu * 16 * eng->pict_height_in_ctu * 16;
+		g_us = eng->pict_width_in_ctu * 16;
+		g_mvx = calloc(n, 2); g_mvy = calloc(n, 2); g_ref = calloc(n, 1); g_qp = calloc(n, 1); g_fl = calloc(n, 1); g_pd = calloc(n, 1); g_tr = calloc(n, 1);
+		fprintf(stderr, "ref_swap: deblocking routed to libhomer_gpu.so\n");
+	}
+	{
+		int n = ctu->ctu_number, w = eng->pict_width_in_ctu;
+		wnd_t *img = &eng->curr_reference_frame->img;
+		int16_t *planes[3] = {(int16_t *)img->pwnd[0], (int16_t *)img->pwnd[1], (int16_t *)img->pwnd[2]};
+		int strides[3] = {img->window_size_x[0], img->window_size_x[1], img->window_size_x[2]};
+		export_units(eng, n);
+		if (n % w) export_units(eng, n - 1);
+		if (n >= w) export_units(eng, n - w);
+		hmr_gpu_deblock_filter_ctu(planes, strides, et->pict_width[Y_COMP], et->pict_height[Y_COMP], g_us, g_mvx, g_mvy, g_ref, g_qp, g_fl, g_pd, g_tr, ctu->x[Y_COMP],
+					   ctu->y[Y_COMP], ctu->size, dir, slice->pps->cb_qp_offset, slice->pps->cr_qp_offset, slice->slice_beta_offset_div2,
+					   slice->slice_tc_offset_div2);
+	}
+}
+void sao_offset_ctu(henc_thread_t *et, ctu_info_t *ctu, sao_blk_param_t *p)
+{
+	static int said;
+	if (!want("sao_offset")) {
+		((void (*)(henc_thread_t *, ctu_info_t *, sao_blk_param_t *))REAL(sao_offset_ctu))(et, ctu, p);
+		return;
+	}
+	wnd_t *sw = &et->enc_engine->sao_aux_wnd, *dw = &et->enc_engine->curr_reference_frame->img;
+	const int16_t *src[3] = {(int16_t *)sw->pwnd[0], (int16_t *)sw->pwnd[1], (int16_t *)sw->pwnd[2]};
+	int16_t *dst[3] = {(int16_t *)dw->pwnd[0], (int16_t *)dw->pwnd[1], (int16_t *)dw->pwnd[2]};
+	int ss[3] = {sw->window_size_x[0], sw->window_size_x[1], sw->window_size_x[2]}, ds[3] = {dw->window_size_x[0], dw->window_size_x[1], dw->window_size_x[2]};
+	int32_t params[3][34];
+	int c, k;
+	for (c = 0; c < 3; c++) {
+		params[c][0] = p->offsetParam[c].modeIdc;
+		params[c][1] = p->offsetParam[c].typeIdc;
+		for (k = 0; k < 32; k++) params[c][2 + k] = p->offsetParam[c].offset[k];
+	}
+	hmr_gpu_sao_offset_ctu(src, ss, dst, ds, et->pict_width[Y_COMP], et->pict_height[Y_COMP], ctu->x[Y_COMP], ctu->y[Y_COMP], &params[0][0]);
+	if (!said++) fprintf(stderr, "ref_swap: SAO offset routed to libhomer_gpu.so\n");
+}
+void reference_picture_border_padding_ctu(wnd_t *wnd, ctu_info_t *ctu)
+{
+	static int said;
+	if (!want("pad")) {
+		((void (*)(wnd_t *, ctu_info_t *))REAL(reference_picture_border_padding_ctu))(wnd, ctu);
+		return;
+	}
+	int16_t *planes[3] = {(int16_t *)wnd->pwnd[0], (int16_t *)wnd->pwnd[1], (int16_t *)wnd->pwnd[2]};
+	int strides[3] = {wnd->window_size_x[0], wnd->window_size_x[1], wnd->window_size_x[2]};
+	hmr_gpu_pad_ctu(planes, strides, wnd->data_width[Y_COMP], wnd->data_height[Y_COMP], wnd->data_padding_x[Y_COMP], wnd->data_padding_y[Y_COMP], ctu->x[Y_COMP],
+			ctu->y[Y_COMP], ctu->size);
+	if (!said++) fprintf(stderr, "ref_swap: border padding routed to libhomer_gpu.so\n");
+}
