@@ -56,3 +56,53 @@ def test_get_sao_stats_dropin_per_ctu(gpu, oracle):
         gpu.hmr_gpu_get_sao_stats(P3(*[p.ctypes.data for p in org]), strides, P3(*[p.ctypes.data for p in rec]), strides, W, H,
                                   (ctu % ctus_x) * 64, (ctu // ctus_x) * 64, out.ctypes.data_as(C.c_void_p))
         assert np.array_equal(out, ora["stats"][ctu].astype(np.int64)), ctu
+
+
+def test_loop_filters_ctu_by_ctu_dropins(gpu, oracle):
+    """The reference's own call granularity (one CTU per call, host pointers): deblocking direction by direction, SAO offset and border
+    padding issued CTU by CTU must give the frame-level (oracle / reference golden) result."""
+    for case, exp, meta in golden_io.load_frame_goldens():
+        ora = fc.run_oracle(oracle, case)
+        W, H = case["width"], case["height"]
+        info = {k: np.ascontiguousarray(v) for k, v in case["info"].items()}
+        W4 = info["qp"].shape[1]
+        flags = np.ascontiguousarray(((info["pred_mode"] != 0) * 1 + (info["cbf_y"] != 0) * 2).astype(np.uint8))
+        ctus = [(x, y) for y in range(0, H, 64) for x in range(0, W, 64)]
+        P3, I3 = C.c_void_p * 3, C.c_int * 3
+        # deblocking in padded windows, like the encoder's reference frame
+        pl = []
+        for p, pad in zip(case["pre"], (fc.PAD_X, fc.PAD_X // 2, fc.PAD_X // 2)):
+            h, w = p.shape
+            win = np.full((h + 2 * pad, w + 2 * pad), 0x1234, np.int16)
+            win[pad:pad + h, pad:pad + w] = p
+            pl.append(win)
+        def origin(win, pad):
+            return win.ctypes.data + 2 * (pad * win.shape[1] + pad)
+        planes = P3(origin(pl[0], fc.PAD_X), origin(pl[1], fc.PAD_X // 2), origin(pl[2], fc.PAD_X // 2))
+        strides = I3(pl[0].shape[1], pl[1].shape[1], pl[2].shape[1])
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+        for d in (0, 1):
+            for x, y in ctus:
+                gpu.hmr_gpu_deblock_filter_ctu(planes, strides, W, H, W4, vp(info["mvx"]), vp(info["mvy"]), vp(info["ref_idx"]), vp(info["qp"]), vp(flags),
+                                               vp(info["pred_depth"]), vp(info["tr_idx"]), x, y, 64, d, *[int(v) for v in case["dbk"]])
+        inner = lambda win, pad: win[pad:win.shape[0] - pad, pad:win.shape[1] - pad]   # noqa: E731
+        for i, pad in enumerate((fc.PAD_X, fc.PAD_X // 2, fc.PAD_X // 2)):
+            assert np.array_equal(inner(pl[i], pad), ora["deblocked"][i]), (meta["tag"], "deblock", i)
+            assert np.array_equal(inner(pl[i], pad), exp["deblocked"][i]), (meta["tag"], "deblock golden", i)
+            outside = pl[i].copy()
+            inner(outside, pad)[...] = 0x1234
+            assert np.all(outside == 0x1234), (meta["tag"], "deblock wrote outside the picture", i)
+        # SAO offset: source = deblocked copy, destination = the frame
+        src = [w.copy() for w in pl]
+        sp = P3(origin(src[0], fc.PAD_X), origin(src[1], fc.PAD_X // 2), origin(src[2], fc.PAD_X // 2))
+        params = np.ascontiguousarray(case["sao_params"])
+        for k, (x, y) in enumerate(ctus):
+            gpu.hmr_gpu_sao_offset_ctu(sp, strides, planes, strides, W, H, x, y, vp(params[k]))
+        for i, pad in enumerate((fc.PAD_X, fc.PAD_X // 2, fc.PAD_X // 2)):
+            assert np.array_equal(inner(pl[i], pad), ora["sao"][i]), (meta["tag"], "sao", i)
+            assert np.array_equal(inner(pl[i], pad), exp["sao"][i]), (meta["tag"], "sao golden", i)
+        # border padding
+        for x, y in ctus:
+            gpu.hmr_gpu_pad_ctu(planes, strides, W, H, fc.PAD_X, fc.PAD_Y, x, y, 64)
+        for i in range(3):
+            assert np.array_equal(pl[i], ora["padded"][i]), (meta["tag"], "pad", i)
