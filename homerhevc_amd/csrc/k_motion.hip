@@ -251,13 +251,75 @@ __global__ __launch_bounds__(MeGeo<N>::WPB * 64) void k_motion_estimation(const 
 // Motion compensation: p0 = mv.x, p1 = mv.y (quarter samples for luma, eighth samples for chroma), w/h extent,
 // a = co-located block in the reference, c = prediction.  `lanes_per_job` lanes share a job (small chroma blocks fill a
 // wave together); two-stage vectors keep the first stage in the job's share of an LDS tile.
+//
+// A work item is four horizontally adjacent outputs.  Samples stay packed two per register as they are loaded (8-byte
+// loads at 2-byte alignment) and every multiply-accumulate is a v_dot2_i32_i16 against a packed coefficient pair:
+//   horizontal: the TAPS+3 samples of the footprint in 2 / 3 loads; even outputs pair (c[k], c[k+1]) with aligned sample
+//               pairs, odd outputs use the same registers with the pairs (0, c0), (c1, c2), ... - no unpacking, no shuffles
+//               beyond one v_alignbit for the pair that straddles the overlapped last load;
+//   vertical  : one 8-byte load per tap row; each register (two columns) is hit with (c, 0) and (0, c).
+// The sums are exact in 32 bits, so the result is that of the scalar definition (hmr_motion_inter.c:262-391).
+typedef short mc_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int mc_dot2(int a, int b, int c) { return __builtin_amdgcn_sdot2(__builtin_bit_cast(mc_short2, a), __builtin_bit_cast(mc_short2, b), c, false); }
+__device__ __forceinline__ int mc_pair(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
+struct i32x2 { int v[2]; };
+__device__ __forceinline__ i32x2 ld2w(const int16_t *p)
+{
+	i32x2 r;
+	__builtin_memcpy(&r, p, 8);
+	return r;
+}
+
+// four horizontal outputs at p[TAPS/2-1 ...]: p addresses the first sample of the footprint
+template <int TAPS>
+__device__ __forceinline__ void mc_hor4(const int16_t *p, const int (&c)[TAPS], int (&out)[4])
+{
+	if constexpr (TAPS == 8) {
+		const i32x2 a = ld2w(p), b = ld2w(p + 4), d = ld2w(p + 7);          // s0..s3, s4..s7, s7..s10 (no sample beyond the footprint)
+		const int r0 = a.v[0], r1 = a.v[1], r2 = b.v[0], r3 = b.v[1], q78 = d.v[0], q9a = d.v[1];
+		const int r89 = (int)__builtin_amdgcn_alignbit((unsigned)q9a, (unsigned)q78, 16);   // (s8, s9)
+		const int c01 = mc_pair(c[0], c[1]), c23 = mc_pair(c[2], c[3]), c45 = mc_pair(c[4], c[5]), c67 = mc_pair(c[6], c[7]);
+		const int c12 = mc_pair(c[1], c[2]), c34 = mc_pair(c[3], c[4]), c56 = mc_pair(c[5], c[6]), z0 = c[0] << 16, z7 = c[7] << 16, c7l = c[7] & 0xffff;
+		out[0] = mc_dot2(r3, c67, mc_dot2(r2, c45, mc_dot2(r1, c23, mc_dot2(r0, c01, 0))));
+		out[1] = mc_dot2(q78, z7, mc_dot2(r3, c56, mc_dot2(r2, c34, mc_dot2(r1, c12, mc_dot2(r0, z0, 0)))));
+		out[2] = mc_dot2(r89, c67, mc_dot2(r3, c45, mc_dot2(r2, c23, mc_dot2(r1, c01, 0))));
+		out[3] = mc_dot2(q9a, z7, mc_dot2(r89, c56, mc_dot2(r3, c34, mc_dot2(r2, c12, mc_dot2(r1, z0, 0)))));
+		(void)c7l;
+	} else {
+		const i32x2 a = ld2w(p), d = ld2w(p + 3);                           // s0..s3, s3..s6
+		const int r0 = a.v[0], r1 = a.v[1], q34 = d.v[0], q56 = d.v[1];
+		const int r45 = (int)__builtin_amdgcn_alignbit((unsigned)q56, (unsigned)q34, 16);   // (s4, s5)
+		const int c01 = mc_pair(c[0], c[1]), c23 = mc_pair(c[2], c[3]), c12 = mc_pair(c[1], c[2]), z0 = c[0] << 16, z3 = c[3] << 16;
+		out[0] = mc_dot2(r1, c23, mc_dot2(r0, c01, 0));
+		out[1] = mc_dot2(q34, z3, mc_dot2(r1, c12, mc_dot2(r0, z0, 0)));
+		out[2] = mc_dot2(r45, c23, mc_dot2(r1, c01, 0));
+		out[3] = mc_dot2(q56, c23, mc_dot2(q34, c01, 0));
+	}
+}
+
+// four vertical outputs of one row: p addresses the first tap row, `step` elements between rows
+template <int TAPS>
+__device__ __forceinline__ void mc_ver4(const int16_t *p, int step, const int (&c)[TAPS], int (&out)[4])
+{
+	out[0] = out[1] = out[2] = out[3] = 0;
+#pragma unroll
+	for (int k = 0; k < TAPS; k++) {
+		const i32x2 v = ld2w(p + (ptrdiff_t)k * step);
+		const int lo = c[k] & 0xffff, hi = c[k] << 16;
+		out[0] = mc_dot2(v.v[0], lo, out[0]);
+		out[1] = mc_dot2(v.v[0], hi, out[1]);
+		out[2] = mc_dot2(v.v[1], lo, out[2]);
+		out[3] = mc_dot2(v.v[1], hi, out[3]);
+	}
+}
+
 template <int TAPS>
 __global__ __launch_bounds__(HMR_BLOCK) void k_mc(const hmr_gpu_job *__restrict__ jobs, int njobs, int is_bi, int lanes_per_job, const int16_t *__restrict__ A,
 						     int16_t *__restrict__ Cc)
 {
-	constexpr int FM = TAPS == 8 ? 3 : 7, FS = TAPS == 8 ? 2 : 3, MAXW = TAPS == 8 ? 64 : 32;
+	constexpr int FM = TAPS == 8 ? 3 : 7, FS = TAPS == 8 ? 2 : 3, MAXW = TAPS == 8 ? 64 : 32, HT = TAPS / 2 - 1;
 	constexpr int TILE = (MAXW + TAPS - 1) * MAXW;
-	__shared__ int16_t sTile[HMR_WAVES_PER_BLOCK][TILE];
+	__shared__ __attribute__((aligned(16))) int16_t sTile[HMR_WAVES_PER_BLOCK][TILE];
 	const int G = lanes_per_job, JPW = HMR_WAVE / G, share = TILE / JPW;
 	const int sub = lane_id() / G, lane = lane_id() % G, w = wave_in_block();
 	const bool last = !is_bi;
@@ -277,59 +339,85 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_mc(const hmr_gpu_job *__restrict_
 			cx[k] = TAPS == 8 ? cLumaTaps[xf][k] : cChromaTaps[xf][k];
 			cy[k] = TAPS == 8 ? cLumaTaps[yf][k] : cChromaTaps[yf][k];
 		}
+		const bool vec = (bw & 3) == 0;       // every HEVC PU except 2-wide chroma
+		const int cpr = bw >> 2;              // four-output items per row
 		if (xf == 0 || yf == 0) {
 			// one stage, first: (sum + 32) >> 6 clipped when last, sum - 8192 when feeding a bi-prediction average
 			const bool vert = xf == 0;
-			const int step = vert ? rs : 1, f = vert ? yf : xf;
-			const int16_t *s0 = src - (TAPS / 2 - 1) * step;
+			const int f = vert ? yf : xf;
 			if (TAPS == 4 && f == 0 && bw < 4) continue;   // hmr_sse42_functions_inter_prediction.c:822
-			for (int e = lane; e < bw * bh; e += G) {
-				const int y = e / bw, x = e - y * bw;
-				int v;
-				if (f == 0) {
-					const int p = src[(size_t)y * rs + x];
-					v = last ? p : (int16_t)((int16_t)(p << 6) - 8192);
-				} else {
-					int s = 0;
+			if (vec) {
+				for (int e = lane; e < cpr * bh; e += G) {
+					const int y = e / cpr, x = (e - y * cpr) * 4;
+					int o[4];
+					if (f == 0) {
+						const i16x4 v = ld4(src + (size_t)y * rs + x);
 #pragma unroll
-					for (int k = 0; k < TAPS; k++) s += s0[(size_t)y * rs + x + k * step] * (vert ? cy[k] : cx[k]);
-					v = last ? clip3i(sat16i((s + 32) >> 6), 0, 255) : sat16i(s - 8192);
+						for (int q = 0; q < 4; q++) o[q] = last ? v.v[q] : (int16_t)((int16_t)(v.v[q] << 6) - 8192);
+					} else {
+						if (vert) mc_ver4<TAPS>(src + (ptrdiff_t)(y - HT) * rs + x, rs, cy, o);
+						else mc_hor4<TAPS>(src + (size_t)y * rs + x - HT, cx, o);
+#pragma unroll
+						for (int q = 0; q < 4; q++) o[q] = last ? clip3i(sat16i((o[q] + 32) >> 6), 0, 255) : sat16i(o[q] - 8192);
+					}
+					i16x4 r;
+#pragma unroll
+					for (int q = 0; q < 4; q++) r.v[q] = (int16_t)o[q];
+					st4(dst + (size_t)y * ds + x, r);
 				}
-				dst[(size_t)y * ds + x] = (int16_t)v;
+			} else {
+				const int step = vert ? rs : 1;
+				const int16_t *s0 = src - HT * step;
+				for (int e = lane; e < bw * bh; e += G) {
+					const int y = e / bw, x = e - y * bw;
+					int v;
+					if (f == 0) {
+						const int p = src[(size_t)y * rs + x];
+						v = last ? p : (int16_t)((int16_t)(p << 6) - 8192);
+					} else {
+						int sm = 0;
+#pragma unroll
+						for (int k = 0; k < TAPS; k++) sm += s0[(size_t)y * rs + x + k * step] * (vert ? cy[k] : cx[k]);
+						v = last ? clip3i(sat16i((sm + 32) >> 6), 0, 255) : sat16i(sm - 8192);
+					}
+					dst[(size_t)y * ds + x] = (int16_t)v;
+				}
 			}
 			continue;
 		}
 		const int th = bh + TAPS - 1;
-		if (bw * th <= share) {
-			for (int e = lane; e < bw * th; e += G) {
-				const int y = e / bw, x = e - y * bw;
-				const int16_t *p = src + (ptrdiff_t)(y - (TAPS / 2 - 1)) * rs + x - (TAPS / 2 - 1);
-				int s = 0;
+		if (vec && bw * th <= share) {
+			for (int e = lane; e < cpr * th; e += G) {
+				const int y = e / cpr, x = (e - y * cpr) * 4;
+				int o[4];
+				mc_hor4<TAPS>(src + (ptrdiff_t)(y - HT) * rs + x - HT, cx, o);
+				i16x4 r;
 #pragma unroll
-				for (int k = 0; k < TAPS; k++) s += p[k] * cx[k];
-				tile[y * bw + x] = (int16_t)sat16i(s - 8192);
+				for (int q = 0; q < 4; q++) r.v[q] = (int16_t)sat16i(o[q] - 8192);
+				st4(tile + y * bw + x, r);
 			}
 			wave_sync();
-			for (int e = lane; e < bw * bh; e += G) {
-				const int y = e / bw, x = e - y * bw;
-				int s = 0;
+			for (int e = lane; e < cpr * bh; e += G) {
+				const int y = e / cpr, x = (e - y * cpr) * 4;
+				int o[4];
+				mc_ver4<TAPS>(tile + y * bw + x, bw, cy, o);
+				i16x4 r;
 #pragma unroll
-				for (int k = 0; k < TAPS; k++) s += tile[(y + k) * bw + x] * cy[k];
-				const int v = last ? clip3i(sat16i((s + 2048 + (8192 << 6)) >> 12), 0, 255) : sat16i(s >> 6);
-				dst[(size_t)y * ds + x] = (int16_t)v;
+				for (int q = 0; q < 4; q++) r.v[q] = (int16_t)(last ? clip3i(sat16i((o[q] + 2048 + (8192 << 6)) >> 12), 0, 255) : sat16i(o[q] >> 6));
+				st4(dst + (size_t)y * ds + x, r);
 			}
 			wave_sync();
 		} else {
-			// the job does not fit its LDS share (hint too small for this block): recompute the first stage per output row
+			// 2-wide chroma, or the job does not fit its LDS share (hint too small for this block): first stage recomputed per output
 			for (int e = lane; e < bw * bh; e += G) {
 				const int y = e / bw, x = e - y * bw;
 				int s2 = 0;
 				for (int r = 0; r < TAPS; r++) {
-					const int16_t *p = src + (ptrdiff_t)(y + r - (TAPS / 2 - 1)) * rs + x - (TAPS / 2 - 1);
-					int s = 0;
+					const int16_t *p = src + (ptrdiff_t)(y + r - HT) * rs + x - HT;
+					int sm = 0;
 #pragma unroll
-					for (int k = 0; k < TAPS; k++) s += p[k] * cx[k];
-					s2 += sat16i(s - 8192) * cy[r];
+					for (int k = 0; k < TAPS; k++) sm += p[k] * cx[k];
+					s2 += sat16i(sm - 8192) * cy[r];
 				}
 				const int v = last ? clip3i(sat16i((s2 + 2048 + (8192 << 6)) >> 12), 0, 255) : sat16i(s2 >> 6);
 				dst[(size_t)y * ds + x] = (int16_t)v;
