@@ -23,6 +23,65 @@ __constant__ int cDb[8][2] = {{-2, 0}, {-1, -1}, {0, -2}, {1, -1}, {2, 0}, {1, 1
 __constant__ int cRefH[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
 __constant__ int cRefQ[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
 
+// Packed-sample arithmetic shared by the search driver and motion compensation: samples stay two per register as loaded and
+// every multiply-accumulate is a v_dot2_i32_i16 against a coefficient pair; sums are exact in 32 bits.
+typedef short mc_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int mc_dot2(int a, int b, int c) { return __builtin_amdgcn_sdot2(__builtin_bit_cast(mc_short2, a), __builtin_bit_cast(mc_short2, b), c, false); }
+__device__ __forceinline__ int mc_pair(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
+struct i32x2 { int v[2]; };
+__device__ __forceinline__ i32x2 ld2w(const int16_t *p)
+{
+	i32x2 r;
+	__builtin_memcpy(&r, p, 8);
+	return r;
+}
+
+// four horizontal outputs at p[TAPS/2-1 ...]: p addresses the first sample of the footprint
+template <int TAPS>
+__device__ __forceinline__ void mc_hor4(const int16_t *p, const int (&c)[TAPS], int (&out)[4])
+{
+	if constexpr (TAPS == 8) {
+		const i32x2 a = ld2w(p), b = ld2w(p + 4), d = ld2w(p + 7);          // s0..s3, s4..s7, s7..s10 (no sample beyond the footprint)
+		const int r0 = a.v[0], r1 = a.v[1], r2 = b.v[0], r3 = b.v[1], q78 = d.v[0], q9a = d.v[1];
+		const int r89 = (int)__builtin_amdgcn_alignbit((unsigned)q9a, (unsigned)q78, 16);   // (s8, s9)
+		const int c01 = mc_pair(c[0], c[1]), c23 = mc_pair(c[2], c[3]), c45 = mc_pair(c[4], c[5]), c67 = mc_pair(c[6], c[7]);
+		const int c12 = mc_pair(c[1], c[2]), c34 = mc_pair(c[3], c[4]), c56 = mc_pair(c[5], c[6]), z0 = c[0] << 16, z7 = c[7] << 16, c7l = c[7] & 0xffff;
+		out[0] = mc_dot2(r3, c67, mc_dot2(r2, c45, mc_dot2(r1, c23, mc_dot2(r0, c01, 0))));
+		out[1] = mc_dot2(q78, z7, mc_dot2(r3, c56, mc_dot2(r2, c34, mc_dot2(r1, c12, mc_dot2(r0, z0, 0)))));
+		out[2] = mc_dot2(r89, c67, mc_dot2(r3, c45, mc_dot2(r2, c23, mc_dot2(r1, c01, 0))));
+		out[3] = mc_dot2(q9a, z7, mc_dot2(r89, c56, mc_dot2(r3, c34, mc_dot2(r2, c12, mc_dot2(r1, z0, 0)))));
+		(void)c7l;
+	} else {
+		const i32x2 a = ld2w(p), d = ld2w(p + 3);                           // s0..s3, s3..s6
+		const int r0 = a.v[0], r1 = a.v[1], q34 = d.v[0], q56 = d.v[1];
+		const int r45 = (int)__builtin_amdgcn_alignbit((unsigned)q56, (unsigned)q34, 16);   // (s4, s5)
+		const int c01 = mc_pair(c[0], c[1]), c23 = mc_pair(c[2], c[3]), c12 = mc_pair(c[1], c[2]), z0 = c[0] << 16, z3 = c[3] << 16;
+		out[0] = mc_dot2(r1, c23, mc_dot2(r0, c01, 0));
+		out[1] = mc_dot2(q34, z3, mc_dot2(r1, c12, mc_dot2(r0, z0, 0)));
+		out[2] = mc_dot2(r45, c23, mc_dot2(r1, c01, 0));
+		out[3] = mc_dot2(q56, c23, mc_dot2(q34, c01, 0));
+	}
+}
+
+// four vertical outputs of one row: p addresses the first tap row, `step` elements between rows
+template <int TAPS>
+__device__ __forceinline__ void mc_ver4(const int16_t *p, int step, const int (&c)[TAPS], int (&out)[4])
+{
+	out[0] = out[1] = out[2] = out[3] = 0;
+#pragma unroll
+	for (int k = 0; k < TAPS; k++) {
+		const i32x2 v = ld2w(p + (ptrdiff_t)k * step);
+		const int lo = c[k] & 0xffff, hi = c[k] << 16;
+		out[0] = mc_dot2(v.v[0], lo, out[0]);
+		out[1] = mc_dot2(v.v[0], hi, out[1]);
+		out[2] = mc_dot2(v.v[1], lo, out[2]);
+		out[3] = mc_dot2(v.v[1], hi, out[3]);
+	}
+}
+
+// |a0 - b0| + |a1 - b1| + acc on packed unsigned 16-bit pairs (picture samples are 0..255)
+__device__ __forceinline__ uint32_t sad2(int a, int b, uint32_t acc) { return __builtin_amdgcn_sad_u16((unsigned)a, (unsigned)b, acc); }
+
 template <int N> struct MeGeo {
 	static constexpr int WPB = N == 64 ? 1 : 4;          // waves per workgroup (LDS budget: 36 KB per wave at N = 64)
 	static constexpr int TR = N + 8;                     // tile rows: reference rows best_y-4 .. best_y+N+3
@@ -48,8 +107,8 @@ __global__ __launch_bounds__(MeGeo<N>::WPB * 64) void k_motion_estimation(const 
 {
 	using g = MeGeo<N>;
 	constexpr int CH = N * N / 4, CPR = N / 4;
-	__shared__ int16_t sOrig[g::WPB][N * N];
-	__shared__ int16_t sTile[g::WPB][3][g::TR * N];
+	__shared__ __attribute__((aligned(16))) int16_t sOrig[g::WPB][N * N];
+	__shared__ __attribute__((aligned(16))) int16_t sTile[g::WPB][3][g::TR * N];
 	const int lane = lane_id(), w = threadIdx.x >> 6;
 	int16_t *orig = sOrig[w];
 	const JobRange jr = xcd_job_range(njobs, g::WPB);
@@ -77,12 +136,8 @@ __global__ __launch_bounds__(MeGeo<N>::WPB * 64) void k_motion_estimation(const 
 #pragma unroll 4
 			for (int e = lane; e < CH; e += 64) {
 				const int yy = e / CPR, xx = (e % CPR) * 4;
-				const i16x4 a = ld4(orig + yy * N + xx), b = ld4(p + (size_t)yy * rs + xx);
-#pragma unroll
-				for (int k = 0; k < 4; k++) {
-					const int d = a.v[k] - b.v[k];
-					acc += (uint32_t)(d < 0 ? -d : d);
-				}
+				const i32x2 a = ld2w(orig + yy * N + xx), b = ld2w(p + (size_t)yy * rs + xx);
+				acc = sad2(a.v[1], b.v[1], sad2(a.v[0], b.v[0], acc));
 			}
 			return wave_sum(acc);
 		};
@@ -168,20 +223,11 @@ __global__ __launch_bounds__(MeGeo<N>::WPB * 64) void k_motion_estimation(const 
 					for (int k = 0; k < 8; k++) c[k] = cLumaTaps[fx][k];
 					for (int e = lane; e < g::TR * CPR; e += 64) {
 						const int r = e / CPR, x = (e % CPR) * 4;
-						const int16_t *p = p0 + (size_t)r * rs + x;
-						int in[11];
-						const i16x4 v0 = ld4(p), v1 = ld4(p + 4);
-#pragma unroll
-						for (int k = 0; k < 4; k++) { in[k] = v0.v[k]; in[4 + k] = v1.v[k]; }
-						in[8] = p[8]; in[9] = p[9]; in[10] = p[10];
+						int sm[4];
+						mc_hor4<8>(p0 + (size_t)r * rs + x, c, sm);
 						i16x4 o;
 #pragma unroll
-						for (int k = 0; k < 4; k++) {
-							int s = 0;
-#pragma unroll
-							for (int tp = 0; tp < 8; tp++) s += in[k + tp] * c[tp];
-							o.v[k] = (int16_t)(s - 8192);   // first, not last: shift 0, offset -8192 (for fx = 0: 64*x - 8192)
-						}
+						for (int k = 0; k < 4; k++) o.v[k] = (int16_t)(sm[k] - 8192);   // first, not last: shift 0, offset -8192 (for fx = 0: 64*x - 8192)
 						st4(&sTile[w][t][r * N + x], o);
 					}
 				}
@@ -197,20 +243,13 @@ __global__ __launch_bounds__(MeGeo<N>::WPB * 64) void k_motion_estimation(const 
 				uint32_t acc = 0;
 				for (int e = lane; e < CH; e += 64) {
 					const int y = e / CPR, x = (e % CPR) * 4;
-					int s[4] = {0, 0, 0, 0};
+					int sm[4];
+					mc_ver4<8>(tile + y * N + x, N, c, sm);
+					int pv[4];
 #pragma unroll
-					for (int tp = 0; tp < 8; tp++) {
-						const i16x4 r = ld4(tile + (y + tp) * N + x);
-#pragma unroll
-						for (int k = 0; k < 4; k++) s[k] += r.v[k] * c[tp];
-					}
-					const i16x4 a = ld4(orig + y * N + x);
-#pragma unroll
-					for (int k = 0; k < 4; k++) {
-						const int pv = clip3i(sat16i((s[k] + 2048 + (8192 << 6)) >> 12), 0, 255);   // not first, last
-						const int d = a.v[k] - pv;
-						acc += (uint32_t)(d < 0 ? -d : d);
-					}
+					for (int k = 0; k < 4; k++) pv[k] = clip3i(sat16i((sm[k] + 2048 + (8192 << 6)) >> 12), 0, 255);   // not first, last
+					const i32x2 a = ld2w(orig + y * N + x);
+					acc = sad2(a.v[1], pv[2] | (pv[3] << 16), sad2(a.v[0], pv[0] | (pv[1] << 16), acc));
 				}
 				return wave_sum(acc);
 			};
@@ -259,60 +298,6 @@ __global__ __launch_bounds__(MeGeo<N>::WPB * 64) void k_motion_estimation(const 
 //               beyond one v_alignbit for the pair that straddles the overlapped last load;
 //   vertical  : one 8-byte load per tap row; each register (two columns) is hit with (c, 0) and (0, c).
 // The sums are exact in 32 bits, so the result is that of the scalar definition (hmr_motion_inter.c:262-391).
-typedef short mc_short2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int mc_dot2(int a, int b, int c) { return __builtin_amdgcn_sdot2(__builtin_bit_cast(mc_short2, a), __builtin_bit_cast(mc_short2, b), c, false); }
-__device__ __forceinline__ int mc_pair(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
-struct i32x2 { int v[2]; };
-__device__ __forceinline__ i32x2 ld2w(const int16_t *p)
-{
-	i32x2 r;
-	__builtin_memcpy(&r, p, 8);
-	return r;
-}
-
-// four horizontal outputs at p[TAPS/2-1 ...]: p addresses the first sample of the footprint
-template <int TAPS>
-__device__ __forceinline__ void mc_hor4(const int16_t *p, const int (&c)[TAPS], int (&out)[4])
-{
-	if constexpr (TAPS == 8) {
-		const i32x2 a = ld2w(p), b = ld2w(p + 4), d = ld2w(p + 7);          // s0..s3, s4..s7, s7..s10 (no sample beyond the footprint)
-		const int r0 = a.v[0], r1 = a.v[1], r2 = b.v[0], r3 = b.v[1], q78 = d.v[0], q9a = d.v[1];
-		const int r89 = (int)__builtin_amdgcn_alignbit((unsigned)q9a, (unsigned)q78, 16);   // (s8, s9)
-		const int c01 = mc_pair(c[0], c[1]), c23 = mc_pair(c[2], c[3]), c45 = mc_pair(c[4], c[5]), c67 = mc_pair(c[6], c[7]);
-		const int c12 = mc_pair(c[1], c[2]), c34 = mc_pair(c[3], c[4]), c56 = mc_pair(c[5], c[6]), z0 = c[0] << 16, z7 = c[7] << 16, c7l = c[7] & 0xffff;
-		out[0] = mc_dot2(r3, c67, mc_dot2(r2, c45, mc_dot2(r1, c23, mc_dot2(r0, c01, 0))));
-		out[1] = mc_dot2(q78, z7, mc_dot2(r3, c56, mc_dot2(r2, c34, mc_dot2(r1, c12, mc_dot2(r0, z0, 0)))));
-		out[2] = mc_dot2(r89, c67, mc_dot2(r3, c45, mc_dot2(r2, c23, mc_dot2(r1, c01, 0))));
-		out[3] = mc_dot2(q9a, z7, mc_dot2(r89, c56, mc_dot2(r3, c34, mc_dot2(r2, c12, mc_dot2(r1, z0, 0)))));
-		(void)c7l;
-	} else {
-		const i32x2 a = ld2w(p), d = ld2w(p + 3);                           // s0..s3, s3..s6
-		const int r0 = a.v[0], r1 = a.v[1], q34 = d.v[0], q56 = d.v[1];
-		const int r45 = (int)__builtin_amdgcn_alignbit((unsigned)q56, (unsigned)q34, 16);   // (s4, s5)
-		const int c01 = mc_pair(c[0], c[1]), c23 = mc_pair(c[2], c[3]), c12 = mc_pair(c[1], c[2]), z0 = c[0] << 16, z3 = c[3] << 16;
-		out[0] = mc_dot2(r1, c23, mc_dot2(r0, c01, 0));
-		out[1] = mc_dot2(q34, z3, mc_dot2(r1, c12, mc_dot2(r0, z0, 0)));
-		out[2] = mc_dot2(r45, c23, mc_dot2(r1, c01, 0));
-		out[3] = mc_dot2(q56, c23, mc_dot2(q34, c01, 0));
-	}
-}
-
-// four vertical outputs of one row: p addresses the first tap row, `step` elements between rows
-template <int TAPS>
-__device__ __forceinline__ void mc_ver4(const int16_t *p, int step, const int (&c)[TAPS], int (&out)[4])
-{
-	out[0] = out[1] = out[2] = out[3] = 0;
-#pragma unroll
-	for (int k = 0; k < TAPS; k++) {
-		const i32x2 v = ld2w(p + (ptrdiff_t)k * step);
-		const int lo = c[k] & 0xffff, hi = c[k] << 16;
-		out[0] = mc_dot2(v.v[0], lo, out[0]);
-		out[1] = mc_dot2(v.v[0], hi, out[1]);
-		out[2] = mc_dot2(v.v[1], lo, out[2]);
-		out[3] = mc_dot2(v.v[1], hi, out[3]);
-	}
-}
-
 template <int TAPS>
 __global__ __launch_bounds__(HMR_BLOCK) void k_mc(const hmr_gpu_job *__restrict__ jobs, int njobs, int is_bi, int lanes_per_job, const int16_t *__restrict__ A,
 						     int16_t *__restrict__ Cc)

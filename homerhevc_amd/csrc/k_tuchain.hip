@@ -134,28 +134,30 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_tu_chain(const hmr_gpu_tu_job *__
 				if (nz) atomicOr(&sNz[w][qt], nz);
 				if (l == 0) sAc[w][qt] = ac;
 			}
-			wave_sync();
-			const bool run_sbh = qok && sbh && ac >= 2;
-			unsigned long long m = run_sbh ? sNz[w][qt] : 0ull;
-			const int last = m ? 63 - __clzll((long long)m) : -1;
-			const int grp = l >> 4;
-			while (__any(m != 0)) {
-				unsigned long long t = m;
-				int cg = -1;
-#pragma unroll
-				for (int k = 0; k < GQ / 16; k++) {
-					const int b = t ? __ffsll((long long)t) - 1 : -1;
-					if (k == grp) cg = b;
-					t &= t - 1;
-				}
-				m = t;
-				sbh_group16(ql, qc, qd, scan, cg < 0 ? 0 : cg, cg == last, run_sbh && cg >= 0);
+		}
+		wave_sync();
+		// sign hiding: one lane per 16-coefficient group over all TUs of the wave (4N groups)
+		{
+			constexpr int CGS = E / 16, TOTAL = TW * CGS;
+			for (int c0 = 0; c0 < TOTAL; c0 += HMR_WAVE) {
+				const int c = c0 + lane, t = c < TOTAL ? c / CGS : 0, cg = c % CGS;
+				const unsigned p0 = __shfl((int)jb.p0, t * N, HMR_WAVE);
+				const unsigned long long m = sNz[w][t];
+				const bool run = c < TOTAL && base + w * TW + t < jr.end && ((p0 >> 6) & 1) && sAc[w][t] >= 2 && ((m >> cg) & 1);
+				if (run) sbh_group_serial(sLev[w][t], sA[w][t], sT[w][t], tab->scan[p0 & 3][L2], cg, cg == 63 - __clzll((long long)m));
 			}
-			wave_sync();
-			if (qok) {                                              // levels out (coalesced) + K15 inv_quant into the transposed tile
-				int16_t *lo = L + __shfl((int)jb.lev_off, qt * N, HMR_WAVE);
+		}
+		wave_sync();
+		// levels out (coalesced)
+		for (int pass = 0; pass < QPASSES; pass++) {
+			const int qt = pass * TQ + lane / GQ, l = lane % GQ;
+			const long qj = base + w * TW + qt;
+			const unsigned lev_off = __shfl((int)jb.lev_off, qt * N, HMR_WAVE);
+			if (qj < jr.end) {
+				int16_t *lo = L + lev_off;
+				const int16_t *ql = sLev[w][qt];
 				for (int e = l; e < E; e += GQ) lo[e] = ql[e];
-				if (l == 0) ac_out[qj] = ac;
+				if (l == 0) ac_out[qj] = sAc[w][qt];
 			}
 		}
 		wave_sync();

@@ -63,4 +63,55 @@ __device__ __forceinline__ void sbh_group16(int16_t *dst, const int16_t *src, co
 	}
 }
 
+// The same decision with ONE lane per coefficient group (the fused TU chain: a wave holds 4N groups, so every group of every TU
+// of the wave is decided at once instead of group after group).  The reference's walk "n from start down to 0, keep the strictly
+// smallest cost" (hmr_quant.c:101-160) is taken literally; levels are read once into registers, deltaU and the source signs only
+// by the lanes whose group actually has to change a level.
+__device__ __forceinline__ void sbh_group_serial(int16_t *dst, const int16_t *src, const int16_t *du, const uint32_t *scan, int cg, bool is_last_cg)
+{
+	unsigned pos[16];
+	int lv[16];
+#pragma unroll
+	for (int n = 0; n < 16; n++) pos[n] = scan[cg * 16 + n];
+	unsigned mask = 0;
+	int sum = 0;
+#pragma unroll
+	for (int n = 0; n < 16; n++) {
+		lv[n] = dst[pos[n]];
+		mask |= (lv[n] != 0 ? 1u : 0u) << n;
+		sum += lv[n];
+	}
+	if (!mask) return;
+	const int last_nz = 31 - __clz((int)mask), first_nz = __ffs((int)mask) - 1;
+	int first_val = 0;
+#pragma unroll
+	for (int n = 0; n < 16; n++) first_val = n == first_nz ? lv[n] : first_val;
+	const unsigned signbit = first_val > 0 ? 0u : 1u;
+	if (last_nz - first_nz < 4 || signbit == (unsigned)(sum & 1)) return;
+	const int start = is_last_cg ? last_nz : 15;
+	int min_cost = 0x7fffffff, win_change = 0, win_lv = 0, win_sv = 0;
+	unsigned win_pos = 0;
+	bool found = false;
+#pragma unroll
+	for (int n = 15; n >= 0; n--) {
+		if (n > start) continue;
+		const int d = du[pos[n]], sv = src[pos[n]];
+		int cost = 0x7fffffff, change = 0;
+		if (lv[n] != 0) {
+			if (d > 0) { cost = -d; change = 1; }
+			else if (!(n == first_nz && (lv[n] == 1 || lv[n] == -1))) { cost = d; change = -1; }
+		} else if (n < first_nz) {
+			if ((sv >= 0 ? 0u : 1u) == signbit) { cost = -d; change = 1; }
+		} else { cost = -d; change = 1; }
+		if (cost < min_cost) {
+			min_cost = cost; win_change = change; win_lv = lv[n]; win_sv = sv; win_pos = pos[n];
+			found = true;
+		}
+	}
+	if (found) {
+		if (win_lv == 32767 || win_lv == -32768) win_change = -1;
+		dst[win_pos] = (int16_t)(win_sv >= 0 ? win_lv + win_change : win_lv - win_change);
+	}
+}
+
 }  // namespace
