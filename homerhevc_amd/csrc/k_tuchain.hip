@@ -45,7 +45,7 @@ __device__ __forceinline__ void load_row_lds(int (&row)[N / 2], const int16_t *s
 }
 
 template <int N>
-__global__ __launch_bounds__(HMR_BLOCK) void k_tu_chain(const hmr_gpu_tu_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ O,
+__global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const hmr_gpu_tu_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ O,
 							   const int16_t *__restrict__ Pp, int16_t *__restrict__ L, int16_t *__restrict__ Rr,
 							   uint32_t *__restrict__ ssd_out, int32_t *__restrict__ ac_out, const DevTables *__restrict__ tab)
 {
@@ -56,9 +56,9 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_tu_chain(const hmr_gpu_tu_job *__
 	constexpr int TQ = HMR_WAVE / GQ, QPASSES = TW / TQ;   // TUs per quant pass, passes per wave
 	constexpr int JPB = TW * HMR_WAVES_PER_BLOCK;
 	constexpr int sh1 = L2 - 1, sh2 = L2 + 6, SIDE = N / 4;
-	__shared__ int16_t sA[HMR_WAVES_PER_BLOCK][TW][N * P];    // coefficients (linear) -> de-quantised coefficients (transposed, pitched)
-	__shared__ int16_t sT[HMR_WAVES_PER_BLOCK][TW][N * P];    // stage intermediates (pitched) / deltaU (linear) during quantisation
-	__shared__ int16_t sLev[HMR_WAVES_PER_BLOCK][TW][E];
+	__shared__ __attribute__((aligned(16))) int16_t sA[HMR_WAVES_PER_BLOCK][TW][N * P];    // coefficients (linear) -> de-quantised coefficients (transposed, pitched)
+	__shared__ __attribute__((aligned(16))) int16_t sT[HMR_WAVES_PER_BLOCK][TW][N * P];    // stage intermediates (pitched) / deltaU (linear) during quantisation
+	__shared__ __attribute__((aligned(16))) int16_t sLev[HMR_WAVES_PER_BLOCK][TW][E];
 	__shared__ unsigned long long sNz[HMR_WAVES_PER_BLOCK][TW];
 	__shared__ int sAc[HMR_WAVES_PER_BLOCK][TW];
 	const int lane = lane_id(), w = wave_in_block(), tu = lane / N, row = lane % N;
@@ -67,23 +67,23 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_tu_chain(const hmr_gpu_tu_job *__
 		const long j = base + w * TW + tu;
 		const bool ok = j < jr.end;
 		hmr_gpu_tu_job jb = {};
-		int orow[N / 2], prow[N / 2], r[N / 2];
+		int r[N / 2];
 #pragma unroll
-		for (int i = 0; i < N / 2; i++) orow[i] = prow[i] = 0;
+		for (int i = 0; i < N / 2; i++) r[i] = 0;
+		const int16_t *orow_p = O, *prow_p = Pp;
 		if (ok) {
 			jb = jobs[j];
-			const int16_t *o = O + jb.orig_off + (size_t)row * jb.orig_stride, *p = Pp + jb.pred_off + (size_t)row * jb.pred_stride;
+			orow_p = O + jb.orig_off + (size_t)row * jb.orig_stride;
+			prow_p = Pp + jb.pred_off + (size_t)row * jb.pred_stride;
+			// K3 predict: residual row (16-bit wrap per sample).  Source and prediction rows are read again for the reconstruction at the
+			// end of the chain (L2-resident) instead of being held in registers across it: the chain is register-bound.
 #pragma unroll
 			for (int i = 0; i < N / 4; i++) {
-				const i16x4 vo = ld4(o + 4 * i), vp = ld4(p + 4 * i);
-				orow[2 * i] = pack2(vo.v[0], vo.v[1]); orow[2 * i + 1] = pack2(vo.v[2], vo.v[3]);
-				prow[2 * i] = pack2(vp.v[0], vp.v[1]); prow[2 * i + 1] = pack2(vp.v[2], vp.v[3]);
+				const i16x4 vo = ld4(orow_p + 4 * i), vp = ld4(prow_p + 4 * i);
+				r[2 * i] = pack2((int16_t)(vo.v[0] - vp.v[0]), (int16_t)(vo.v[1] - vp.v[1]));
+				r[2 * i + 1] = pack2((int16_t)(vo.v[2] - vp.v[2]), (int16_t)(vo.v[3] - vp.v[3]));
 			}
 		}
-		// K3 predict: residual row (16-bit wrap per sample)
-#pragma unroll
-		for (int i = 0; i < N / 2; i++)
-			r[i] = pack2((int16_t)((int16_t)orow[i] - (int16_t)prow[i]), (int16_t)((orow[i] >> 16) - (prow[i] >> 16)));
 		const bool is_dst = N == 4 && ((jb.p0 >> 7) & 1);
 		// basis words: DST only exists for N = 4, where a lane group may need a different basis than its neighbours -> per-lane pointer
 		const int *Mf = reinterpret_cast<const int *>(is_dst ? tab->dst4 : tab->dct[L2 - 2]);
@@ -108,7 +108,6 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_tu_chain(const hmr_gpu_tu_job *__
 			const int scan_mode = p0 & 3, comp = (p0 >> 2) & 3, is_intra = (p0 >> 4) & 1, slice_i = (p0 >> 5) & 1, sbh = (p0 >> 6) & 1;
 			const int per = p1 & 0xff, rem = (p1 >> 8) & 0xff;
 			int16_t *qc = sA[w][qt], *qd = sT[w][qt], *ql = sLev[w][qt];
-			const uint32_t *scan = tab->scan[scan_mode][L2];
 			int ac = 0;
 			if (qok) {
 				const int32_t *q = tab->quant[L2 - 2][(is_intra ? 0 : 3) + comp][rem];
@@ -144,7 +143,16 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_tu_chain(const hmr_gpu_tu_job *__
 				const unsigned p0 = __shfl((int)jb.p0, t * N, HMR_WAVE);
 				const unsigned long long m = sNz[w][t];
 				const bool run = c < TOTAL && base + w * TW + t < jr.end && ((p0 >> 6) & 1) && sAc[w][t] >= 2 && ((m >> cg) & 1);
-				if (run) sbh_group_serial(sLev[w][t], sA[w][t], sT[w][t], tab->scan[p0 & 3][L2], cg, cg == 63 - __clzll((long long)m));
+				if (run) {
+					const uint32_t *scan = tab->scan[p0 & 3][L2];
+					const bool is_last = cg == 63 - __clzll((long long)m);
+					switch (p0 & 3) {
+					case 3: sbh_group_block<3, N>(sLev[w][t], sA[w][t], sT[w][t], scan, cg, is_last); break;
+					case 1: sbh_group_block<1, N>(sLev[w][t], sA[w][t], sT[w][t], scan, cg, is_last); break;
+					case 2: sbh_group_block<2, N>(sLev[w][t], sA[w][t], sT[w][t], scan, cg, is_last); break;
+					default: sbh_group_serial(sLev[w][t], sA[w][t], sT[w][t], scan, cg, is_last); break;
+					}
+				}
 			}
 		}
 		wave_sync();
@@ -191,6 +199,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_tu_chain(const hmr_gpu_tu_job *__
 #pragma unroll 2
 			for (int x4 = 0; x4 < N; x4 += 4) {
 				i16x4 outv;
+				const i16x4 vo = ld4(orow_p + x4), vp = ld4(prow_p + x4);
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
 					const int x = x4 + q;
@@ -201,8 +210,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_tu_chain(const hmr_gpu_tu_job *__
 						for (int i = 0; i < N / 2; i++) s = dot2(r[i], Mt[x * (N / 2) + i], s);
 						res = sat16i((s + 2048) >> 12);
 					}
-					const int pw = prow[x >> 1], ow = orow[x >> 1];
-					const int pv = (x & 1) ? (pw >> 16) : (int16_t)pw, ov = (x & 1) ? (ow >> 16) : (int16_t)ow;
+					const int pv = vp.v[q], ov = vo.v[q];
 					const int rec = clip3i(sat16i(pv + res), 0, 255);
 					outv.v[q] = (int16_t)rec;
 					const int d = (int16_t)(ov - rec);

@@ -114,4 +114,78 @@ __device__ __forceinline__ void sbh_group_serial(int16_t *dst, const int16_t *sr
 	}
 }
 
+// Same decision, reading the group as the 4x4 block it is.  Inside a group the three scans the encoder uses are fixed 4x4 patterns
+// (hmr_tables.c scan construction: horizontal = raster, vertical = column-major, diagonal = up-right); only the group's origin comes
+// from the scan table (its first entry).  Four 8-byte LDS reads fetch the levels; deltaU and the source coefficients are fetched
+// the same way only when a level has to change.  PAT[n] = 4 * y + x of scan position n.
+template <int MODE> struct CgPattern;
+template <> struct CgPattern<1> { static constexpr int at(int n) { return n; } };
+template <> struct CgPattern<2> { static constexpr int at(int n) { return (n & 3) * 4 + (n >> 2); } };
+template <> struct CgPattern<3> {
+	static constexpr int at(int n)
+	{
+		constexpr int t[16] = {0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15};
+		return t[n];
+	}
+};
+
+// sample k (0..15, raster inside the group) of four packed rows
+__device__ __forceinline__ int cg_get(const int (&w)[8], int k) { return (w[k >> 1] << (16 * (1 - (k & 1)))) >> 16; }
+__device__ __forceinline__ void cg_load(int (&w)[8], const int16_t *p, int pitch)
+{
+#pragma unroll
+	for (int r = 0; r < 4; r++) __builtin_memcpy(&w[2 * r], p + r * pitch, 8);
+}
+
+template <int MODE, int N>
+__device__ __forceinline__ void sbh_group_block(int16_t *dst, const int16_t *src, const int16_t *du, const uint32_t *scan, int cg, bool is_last_cg)
+{
+	using PT = CgPattern<MODE>;
+	const unsigned org = scan[cg * 16];
+	int lw[8];           // levels, two per register, raster inside the group
+	cg_load(lw, dst + org, N);
+	unsigned mask = 0;
+	int sum = 0;
+#pragma unroll
+	for (int n = 0; n < 16; n++) {
+		const int lv = cg_get(lw, PT::at(n));
+		mask |= (lv != 0 ? 1u : 0u) << n;
+		sum += lv;
+	}
+	if (!mask) return;
+	const int last_nz = 31 - __clz((int)mask), first_nz = __ffs((int)mask) - 1;
+	int first_val = 0;
+#pragma unroll
+	for (int n = 0; n < 16; n++) first_val = n == first_nz ? cg_get(lw, PT::at(n)) : first_val;
+	const unsigned signbit = first_val > 0 ? 0u : 1u;
+	if (last_nz - first_nz < 4 || signbit == (unsigned)(sum & 1)) return;
+	int dw[8], sw[8];
+	cg_load(dw, du + org, N);
+	cg_load(sw, src + org, N);
+	const int start = is_last_cg ? last_nz : 15;
+	int min_cost = 0x7fffffff, win_change = 0, win_lv = 0, win_sv = 0, win_off = 0;
+	bool found = false;
+#pragma unroll
+	for (int n = 15; n >= 0; n--) {
+		if (n > start) continue;
+		const int ri = PT::at(n);
+		const int lv = cg_get(lw, ri), d = cg_get(dw, ri), sv = cg_get(sw, ri);
+		int cost = 0x7fffffff, change = 0;
+		if (lv != 0) {
+			if (d > 0) { cost = -d; change = 1; }
+			else if (!(n == first_nz && (lv == 1 || lv == -1))) { cost = d; change = -1; }
+		} else if (n < first_nz) {
+			if ((sv >= 0 ? 0u : 1u) == signbit) { cost = -d; change = 1; }
+		} else { cost = -d; change = 1; }
+		if (cost < min_cost) {
+			min_cost = cost; win_change = change; win_lv = lv; win_sv = sv; win_off = (ri >> 2) * N + (ri & 3);
+			found = true;
+		}
+	}
+	if (found) {
+		if (win_lv == 32767 || win_lv == -32768) win_change = -1;
+		dst[org + win_off] = (int16_t)(win_sv >= 0 ? win_lv + win_change : win_lv - win_change);
+	}
+}
+
 }  // namespace
