@@ -15,14 +15,16 @@ __constant__ int cPoints[4][5] = {{0, 1, 0, 8, 16}, {2, 10, 16, 22, 30}, {-4, -2
 __constant__ int cNumPoints[4] = {2, 5, 4, 2};                                                                 // :1080
 __constant__ int cFilterThr[5] = {10, 7, 1, 0, 10};                                                            // intra_filter, :148
 
-// WPJ wavefronts cooperate on one PU (1 for N <= 16, 2 for N = 32, 4 for N = 64: a 64x64 PU is 13 x 4096 predicted samples, too
-// long a dependent chain for one wave).  A lane owns PPL samples of one column, so the source samples stay in registers for all
+// WPJ wavefronts cooperate on one PU (2 for N = 32, 4 for N = 64: a 64x64 PU is 13 x 4096 predicted samples, too long a
+// dependent chain for one wave; 1 otherwise).  A lane owns PPL samples of one column, so the source samples stay in registers for all
 // candidates.
 template <int N, int WPJ>
 __global__ __launch_bounds__(HMR_BLOCK) void k_intra_search(const hmr_gpu_intra_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ O,
 							       const int16_t *__restrict__ D, int16_t *__restrict__ Cc, hmr_gpu_intra_result *__restrict__ out)
 {
-	constexpr int E = N * N, G = WPJ > 1 ? HMR_WAVE * WPJ : (E < HMR_WAVE ? E : HMR_WAVE);
+	// lanes per PU: 4 / 16 / 32 for N = 4 / 8 / 16 (16 / 4 / 2 PUs share a wavefront: the per-candidate set-up, synchronisation,
+	// reduction and cost arithmetic are paid once per wavefront, so packing PUs divides them), a wavefront or more above
+	constexpr int E = N * N, G = WPJ > 1 ? HMR_WAVE * WPJ : (N == 4 ? 4 : N == 8 ? 16 : N == 16 ? 32 : HMR_WAVE);
 	constexpr int JPB = HMR_BLOCK / G;                     // jobs per workgroup
 	constexpr int PPL = E / G, YSTEP = G / N;              // samples per lane, row distance between a lane's samples
 	constexpr int l2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : N == 32 ? 5 : 6, total = 4 * N + 1;
@@ -159,9 +161,9 @@ extern "C" int hmr_gpu_intra_search_batch(hmr_gpu_ctx *ctx, const hmr_gpu_intra_
 	hipLaunchKernelGGL((k_intra_search<NN, WPJ>), dim3(hmr_grid_for_units(((long)njobs + JPB - 1) / JPB)), dim3(HMR_BLOCK), 0, ctx->stream, jobs, njobs, orig_base, \
 			   decoded_base, out_base, out)
 	switch (size) {
-	case 4: LAUNCH(4, 1, 16); break;
-	case 8: LAUNCH(8, 1, 4); break;
-	case 16: LAUNCH(16, 1, 4); break;
+	case 4: LAUNCH(4, 1, 64); break;
+	case 8: LAUNCH(8, 1, 16); break;
+	case 16: LAUNCH(16, 1, 8); break;
 	case 32: LAUNCH(32, 2, 2); break;
 	case 64: LAUNCH(64, 4, 1); break;
 	default: hmr_set_error("intra search: unsupported size %d", size); return HMR_GPU_ERR_ARG;
