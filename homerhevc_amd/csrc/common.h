@@ -87,20 +87,38 @@ __device__ __forceinline__ JobRange xcd_job_range(long njobs, int jobs_per_block
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (HMR_WAVE - 1); }
 __device__ __forceinline__ int wave_in_block() { return threadIdx.x >> 6; }
 
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v)
+// Butterfly sums.  Inside a row of 16 lanes the exchange is a DPP operand modifier (quad_perm for xor 1 / 2, row_half_mirror and
+// row_mirror for the 8- and 16-lane steps: after the quad steps every lane of a quad holds the quad's sum, so mirroring pairs it with
+// a lane of the other half) - one VALU instruction per step instead of a ds_bpermute round trip; only the 32- and 64-lane steps go
+// through the LDS crossbar.  Every lane of the group ends up with the group's sum.
+__device__ __forceinline__ int dpp_xor_sum_row(int v, int steps)
 {
-#pragma unroll
-	for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, HMR_WAVE);
+	v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);                     // quad_perm [1,0,3,2]
+	if (steps >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
+	if (steps >= 3) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);    // row_half_mirror
+	if (steps >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);    // row_mirror
 	return v;
 }
 // sum over aligned groups of G lanes (G power of two <= 64)
 template <int G, typename T>
 __device__ __forceinline__ T group_sum(T v)
 {
+	if constexpr (sizeof(T) == 4 && __is_integral(T) && G >= 2) {
+		constexpr int steps = G >= 16 ? 4 : G == 8 ? 3 : G == 4 ? 2 : 1;
+		int x = dpp_xor_sum_row((int)v, steps);
+		if constexpr (G >= 32) x += __shfl_xor(x, 16, HMR_WAVE);
+		if constexpr (G >= 64) x += __shfl_xor(x, 32, HMR_WAVE);
+		return (T)x;
+	} else {
 #pragma unroll
-	for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, HMR_WAVE);
-	return v;
+		for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, HMR_WAVE);
+		return v;
+	}
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+	return group_sum<HMR_WAVE, T>(v);
 }
 // Order LDS traffic between the lanes of ONE wave (the compiler only sees per-lane dependences).  Kernels whose waves own
 // private LDS regions use this instead of __syncthreads(), so waves of a workgroup never wait for each other.
