@@ -9,8 +9,18 @@
 
 namespace {
 
-__constant__ int cAng[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};                  // hmr_encoder_lib.c:35
-__constant__ int cInvAng[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};  // hmr_encoder_lib.c:36
+// ang_table {0, 2, 5, 9, 13, 17, 21, 26, 32} and inv_ang_table {0, 4096, 1638, 910, 630, 482, 390, 315, 256} (hmr_encoder_lib.c:35-36) as
+// immediates: a table in memory would put a dependent load in front of every prediction
+__device__ __forceinline__ int intra_ang(int aa)
+{
+	const unsigned long long t = 0ull | (2ull << 6) | (5ull << 12) | (9ull << 18) | (13ull << 24) | (17ull << 30) | (21ull << 36) | (26ull << 42) | (32ull << 48);
+	return (int)((t >> (6 * aa)) & 63);
+}
+__device__ __forceinline__ int intra_inv_ang(int aa)
+{
+	const unsigned long long lo = 0ull | (4096ull << 16) | (1638ull << 32) | (910ull << 48), hi = 630ull | (482ull << 16) | (390ull << 32) | (315ull << 48);
+	return aa >= 8 ? 256 : (int)(((aa < 4 ? lo : hi) >> (16 * (aa & 3))) & 0xffff);
+}
 
 struct IntraMode {
 	int mode, angle, inv_angle, sm;   // sm: main[idx] = mid[sm*idx], side[k] = mid[-sm*k]; +1 for vertical modes
@@ -27,8 +37,8 @@ __device__ __forceinline__ IntraMode intra_mode_setup(int mode)
 	m.inv_angle = 0;
 	if (mode >= 2) {
 		const int aa = m.angle < 0 ? -m.angle : m.angle;
-		m.inv_angle = cInvAng[aa];
-		m.angle = m.angle < 0 ? -cAng[aa] : cAng[aa];
+		m.inv_angle = intra_inv_ang(aa);
+		m.angle = m.angle < 0 ? -intra_ang(aa) : intra_ang(aa);
 	}
 	m.sm = m.is_ver ? 1 : -1;
 	return m;

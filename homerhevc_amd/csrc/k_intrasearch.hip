@@ -11,9 +11,25 @@
 
 namespace {
 
-__constant__ int cPoints[4][5] = {{0, 1, 0, 8, 16}, {2, 10, 16, 22, 30}, {-4, -2, 2, 4, 0}, {-1, 1, 0, 0, 0}};   // search_points, hmr_motion_intra.c:1076
-__constant__ int cNumPoints[4] = {2, 5, 4, 2};                                                                 // :1080
-__constant__ int cFilterThr[5] = {10, 7, 1, 0, 10};                                                            // intra_filter, :148
+// search_points / num_search_points (hmr_motion_intra.c:1076-1080) and intra_filter (:148) as compile-time constants: the 13-candidate
+// schedule unrolls and no table load sits in the dependent chain of a candidate
+struct SearchPlan {
+	static constexpr int point(int loop, int k)
+	{
+		constexpr int p[4][5] = {{0, 1, 0, 8, 16}, {2, 10, 16, 22, 30}, {-4, -2, 2, 4, 0}, {-1, 1, 0, 0, 0}};
+		return p[loop][k];
+	}
+	static constexpr int count(int loop)
+	{
+		constexpr int n[4] = {2, 5, 4, 2};
+		return n[loop];
+	}
+	static constexpr int filter_thr(int l2)
+	{
+		constexpr int t[5] = {10, 7, 1, 0, 10};
+		return t[l2 - 2];
+	}
+};
 
 // WPJ wavefronts cooperate on one PU (2 for N = 32, 4 for N = 64: a 64x64 PU is 13 x 4096 predicted samples, too long a
 // dependent chain for one wave; 1 otherwise).  A lane owns PPL samples of one column, so the source samples stay in registers for all
@@ -87,18 +103,21 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_intra_search(const hmr_gpu_intra_
 		}
 		int best = 0, new_best = 0, best_bits = 0, min_mode = 0, max_mode = 1, last_mode = 0;
 		double best_cost = (double)(0xffffffffu / 8);   // MAX_COST, hmr_private.h:54
+#pragma unroll
 		for (int loop = 0; loop < 4; loop++) {
 			if (loop == 1) {
 				best = 2;
 				min_mode = 2;
 				max_mode = 34;
 			}
-			for (int k = 0; k < cNumPoints[loop]; k++) {
-				const int mode = best + cPoints[loop][k];
+#pragma unroll
+			for (int k = 0; k < 5; k++) {
+				if (k >= SearchPlan::count(loop)) continue;
+				const int mode = best + SearchPlan::point(loop, k);
 				const bool valid = ok && mode >= min_mode && mode <= max_mode;
 				const IntraMode m = intra_mode_setup(valid ? mode : 0);
 				const int d10 = mode > 10 ? mode - 10 : 10 - mode, d26 = mode > 26 ? mode - 26 : 26 - mode;
-				const bool filtered = mode != 1 && (d10 < d26 ? d10 : d26) > cFilterThr[l2 - 2];
+				const bool filtered = mode != 1 && (d10 < d26 ? d10 : d26) > SearchPlan::filter_thr(l2);
 				const int16_t *mid = (filtered ? adif : adi) + 2 * N;
 				if (valid) intra_fill_main<N, G>(m, mid, mainr, l);
 				sync();
@@ -129,7 +148,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_intra_search(const hmr_gpu_intra_
 		{
 			const IntraMode m = intra_mode_setup(last_mode);
 			const int d10 = last_mode > 10 ? last_mode - 10 : 10 - last_mode, d26 = last_mode > 26 ? last_mode - 26 : 26 - last_mode;
-			const bool filtered = last_mode != 1 && (d10 < d26 ? d10 : d26) > cFilterThr[l2 - 2];
+			const bool filtered = last_mode != 1 && (d10 < d26 ? d10 : d26) > SearchPlan::filter_thr(l2);
 			const int16_t *mid = (filtered ? adif : adi) + 2 * N;
 			if (ok) intra_fill_main<N, G>(m, mid, mainr, l);
 			sync();
