@@ -10,12 +10,13 @@
 
 namespace {
 
-// G = min(64, N*N) lanes own one prediction block: four 4x4 blocks per wave, one larger block per wave.
+// G = 4 / 16 / 32 / 64 lanes own one N = 4 / 8 / 16 / larger prediction block (16 / 4 / 2 / 1 blocks per wave): the per-block set-up
+// (neighbour staging, mode decode, main reference) is wave-wide work, so packing blocks divides it.
 template <int N>
 __global__ __launch_bounds__(HMR_BLOCK) void k_intra_pred(const hmr_gpu_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ A,
 							     int16_t *__restrict__ Cc)
 {
-	constexpr int E = N * N, G = E < HMR_WAVE ? E : HMR_WAVE, JPW = HMR_WAVE / G, JPB = JPW * HMR_WAVES_PER_BLOCK;
+	constexpr int E = N * N, G = N == 4 ? 4 : N == 8 ? 16 : N == 16 ? 32 : HMR_WAVE, JPW = HMR_WAVE / G, JPB = JPW * HMR_WAVES_PER_BLOCK;
 	constexpr int l2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : N == 32 ? 5 : 6;
 	__shared__ int16_t sAdi[HMR_WAVES_PER_BLOCK][JPW][4 * N + 1 + 3];
 	__shared__ int16_t sMainBuf[HMR_WAVES_PER_BLOCK][JPW][3 * N + 2];   // main reference, index -N+1 .. 2N, origin at N
@@ -53,12 +54,12 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_intra_pred(const hmr_gpu_job *__r
 }
 
 // Intra reference build.  Flags must come from the partition tree (bottom_left implies left, top_right implies top).
-// G lanes (32 for N = 4, else 64) own one 4N+1 array.
+// G = 8 / 16 / 32 / 64 lanes own one 4N+1 array for N = 4 / 8 / 16 / larger.
 template <int N>
 __global__ __launch_bounds__(HMR_BLOCK) void k_intra_refs(const hmr_gpu_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ A,
 							     int16_t *__restrict__ Cc)
 {
-	constexpr int total = 4 * N + 1, G = N == 4 ? 32 : HMR_WAVE, JPW = HMR_WAVE / G, JPB = JPW * HMR_WAVES_PER_BLOCK;
+	constexpr int total = 4 * N + 1, G = N == 4 ? 8 : N == 8 ? 16 : N == 16 ? 32 : HMR_WAVE, JPW = HMR_WAVE / G, JPB = JPW * HMR_WAVES_PER_BLOCK;
 	__shared__ int16_t sAdi[HMR_WAVES_PER_BLOCK][JPW][total + 3];
 	const int lane = lane_id(), w = wave_in_block(), sub = lane / G, l = lane % G;
 	int16_t *adi = sAdi[w][sub];
@@ -101,8 +102,8 @@ template <int N> int intra_grid(int njobs, int jpw)
 	case 64: hipLaunchKernelGGL((KERNEL<64>), dim3(intra_grid<64>(njobs, JPW_OF(64))), dim3(HMR_BLOCK), 0, ctx->stream, jobs, njobs, a, c); break; \
 	default: return HMR_GPU_ERR_ARG;                                                                                            \
 	}
-#define PRED_JPW(n) ((n) == 4 ? 4 : 1)
-#define REFS_JPW(n) ((n) == 4 ? 2 : 1)
+#define PRED_JPW(n) ((n) == 4 ? 16 : (n) == 8 ? 4 : (n) == 16 ? 2 : 1)
+#define REFS_JPW(n) ((n) == 4 ? 8 : (n) == 8 ? 4 : (n) == 16 ? 2 : 1)
 
 extern "C" int hmr_gpu_intra_pred_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int size, const int16_t *a, int16_t *c)
 {
