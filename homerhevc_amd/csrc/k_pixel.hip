@@ -12,6 +12,11 @@ namespace {
 
 enum { OP_SAD = 0, OP_SSD = 1 };
 
+// lanes per N x N block: 4 / 4 / 16 / 64 / 64 for N = 4 / 8 / 16 / 32 / 64, i.e. 16 / 16 / 4 / 1 / 1 blocks per wavefront and 1 / 4 / 4 / 4 / 16
+// four-sample chunks per lane.  Descriptor fetch, address set-up, reduction and the result store are per-wavefront work: packing
+// blocks divides them.
+template <int N> struct PixelLanes { static constexpr int value = N <= 8 ? 4 : N == 16 ? 16 : HMR_WAVE; };
+
 // One lane owns 4 consecutive samples of a row (one 8-byte load per operand; the candidate block of a motion
 // search is only 2-byte aligned), G = min(64, N*N/4) lanes own a block: 16 4x4 blocks, four 8x8 blocks or one larger
 // block per wave.
@@ -21,7 +26,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_sad_ssd(const hmr_gpu_job *__rest
 {
 	constexpr int CH = N * N / 4;                      // 4-sample chunks per block
 	constexpr int CPR = N / 4;                         // chunks per row
-	constexpr int G = CH < HMR_WAVE ? CH : HMR_WAVE;
+	constexpr int G = PixelLanes<N>::value;
 	constexpr int JPW = HMR_WAVE / G;
 	const int lane = lane_id(), sub = lane / G, l = lane % G;
 	const JobRange jr = xcd_job_range(njobs, JPW * HMR_WAVES_PER_BLOCK);
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_square(const hmr_gpu_job *__restr
 							 const int16_t *__restrict__ B, int16_t *__restrict__ Cc)
 {
 	constexpr int CH = N * N / 4, CPR = N / 4;
-	constexpr int G = CH < HMR_WAVE ? CH : HMR_WAVE;
+	constexpr int G = PixelLanes<N>::value;
 	constexpr int JPW = HMR_WAVE / G;
 	const int lane = lane_id(), sub = lane / G, l = lane % G;
 	const JobRange jr = xcd_job_range(njobs, JPW * HMR_WAVES_PER_BLOCK);
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_copy(const hmr_gpu_job *__restric
 template <int OP>
 int launch_square(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int n, const int16_t *A, const int16_t *B, int16_t *Cc)
 {
-	const int ch = n * n / 4, g = ch < HMR_WAVE ? ch : HMR_WAVE, jpw = HMR_WAVE / g;
+	const int jpw = HMR_WAVE / (n <= 8 ? 4 : n == 16 ? 16 : HMR_WAVE);      // PixelLanes<n>
 	dim3 grid(hmr_grid_for_waves(((long)njobs + jpw - 1) / jpw)), block(HMR_BLOCK);
 	switch (n) {
 	case 4: hipLaunchKernelGGL((k_square<4, OP>), grid, block, 0, ctx->stream, jobs, njobs, A, B, Cc); break;
@@ -184,7 +189,7 @@ int launch_sad_ssd(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int siz
 	if (njobs <= 0) return HMR_GPU_OK;
 	// any size other than 4/8/16/32 takes the 64x64 path in the reference (hmr_sse42_functions_pixel.c:462-475)
 	const int n = (size == 4 || size == 8 || size == 16 || size == 32) ? size : 64;
-	const int ch = n * n / 4, jpw = ch < HMR_WAVE ? HMR_WAVE / ch : 1;
+	const int jpw = HMR_WAVE / (n <= 8 ? 4 : n == 16 ? 16 : HMR_WAVE);      // PixelLanes<n>
 	const long waves = ((long)njobs + jpw - 1) / jpw;
 	dim3 grid(hmr_grid_for_waves(waves)), block(HMR_BLOCK);
 	switch (n) {
