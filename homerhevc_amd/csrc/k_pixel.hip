@@ -11,6 +11,7 @@
 namespace {
 
 enum { OP_SAD = 0, OP_SSD = 1 };
+typedef short px_short2 __attribute__((ext_vector_type(2)));
 
 // lanes per N x N block: 4 / 4 / 16 / 64 / 64 for N = 4 / 8 / 16 / 32 / 64, i.e. 16 / 16 / 4 / 1 / 1 blocks per wavefront and 1 / 4 / 4 / 4 / 16
 // four-sample chunks per lane.  Descriptor fetch, address set-up, reduction and the result store are per-wavefront work: packing
@@ -33,18 +34,48 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_sad_ssd(const hmr_gpu_job *__rest
 	for (long j0 = jr.begin + wave_in_block() * JPW; j0 < jr.end; j0 += jr.stride) {
 		const long j = j0 + sub;
 		uint32_t acc = 0;
+		bool slow = false;
 		if (j < jr.end) {
 			const hmr_gpu_job jb = JPW == 1 ? load_job_uniform(jobs, j) : jobs[j];
 			const int16_t *a = A + jb.a_off;
 			const int16_t *b = B + jb.b_off;
+			// samples stay packed two per register: SSD = v_pk_sub_i16 + v_dot2_i32_i16 (the 16-bit wrap of the difference and the
+			// 32-bit wrap of the sum are the reference's pmaddwd arithmetic); SAD = v_sad_u16, exact whenever both operands are
+			// non-negative (picture samples) - a negative operand anywhere sends the wavefront through the general form below
+			unsigned neg = 0;
 #pragma unroll 4
 			for (int e = l; e < CH; e += G) {
 				const int y = e / CPR, x = (e % CPR) * 4;
-				const i16x4 va = ld4(a + (size_t)y * jb.a_stride + x), vb = ld4(b + (size_t)y * jb.b_stride + x);
+				int wa[2], wb[2];
+				__builtin_memcpy(wa, a + (size_t)y * jb.a_stride + x, 8);
+				__builtin_memcpy(wb, b + (size_t)y * jb.b_stride + x, 8);
 #pragma unroll
-				for (int k = 0; k < 4; k++) {
-					const int d = (int16_t)(va.v[k] - vb.v[k]);
-					acc += OP == OP_SAD ? (uint32_t)(d < 0 ? -d : d) : (uint32_t)(d * d);
+				for (int k = 0; k < 2; k++) {
+					if (OP == OP_SAD) {
+						acc = __builtin_amdgcn_sad_u16((unsigned)wa[k], (unsigned)wb[k], acc);
+						neg |= (unsigned)(wa[k] | wb[k]);
+					} else {
+						const px_short2 d = __builtin_bit_cast(px_short2, wa[k]) - __builtin_bit_cast(px_short2, wb[k]);
+						acc = (uint32_t)__builtin_amdgcn_sdot2(d, d, (int)acc, false);
+					}
+				}
+			}
+			slow = OP == OP_SAD && (neg & 0x80008000u) != 0;
+		}
+		if (OP == OP_SAD && __any(slow)) {
+			acc = 0;
+			if (j < jr.end) {
+				const hmr_gpu_job jb = jobs[j];
+				const int16_t *a = A + jb.a_off;
+				const int16_t *b = B + jb.b_off;
+				for (int e = l; e < CH; e += G) {
+					const int y = e / CPR, x = (e % CPR) * 4;
+					const i16x4 va = ld4(a + (size_t)y * jb.a_stride + x), vb = ld4(b + (size_t)y * jb.b_stride + x);
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						const int d = (int16_t)(va.v[k] - vb.v[k]);
+						acc += (uint32_t)(d < 0 ? -d : d);
+					}
 				}
 			}
 		}

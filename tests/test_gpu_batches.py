@@ -110,6 +110,9 @@ def test_sad_ssd(rig, oracle, which, n):
     jb["b_off"] = rig.block(rng, rig.res if which == "ssd16b" else rig.pix, n, n); jb["b_stride"] = PW
     if which == "ssd16b":
         jb["b_stride"][::3] = 0
+    else:   # a few candidates with negative samples: the packed-unsigned fast path must hand over to the general form
+        neg = rng.random(rig.nj) < 0.1
+        jb["b_off"] = np.where(neg, rig.block(rng, rig.res, n, n), jb["b_off"])
     d_out = rig.malloc(4 * rig.nj); rig.bufs.append(d_out)
     g = rig.launch(f"hmr_gpu_{which}_batch", rig.up(jb), rig.nj, n, rig.dev, rig.dev, d_out)
     same(g, rig.host, "arena untouched")
