@@ -52,7 +52,7 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 	constexpr int L2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
 	constexpr int E = N * N, P = N + 2;
 	constexpr int TW = HMR_WAVE / N;                       // TUs per wave in the transform mapping (lane = row)
-	constexpr int GQ = N == 32 ? 64 : 16;                  // lanes per TU in the quant mapping (sign hiding needs 16-lane groups); measured best
+	constexpr int GQ = N == 4 ? 4 : N == 32 ? 64 : 16;     // lanes per TU in the quant mapping (four coefficients per lane and step); measured best
 	constexpr int TQ = HMR_WAVE / GQ, QPASSES = TW / TQ;   // TUs per quant pass, passes per wave
 	constexpr int JPB = TW * HMR_WAVES_PER_BLOCK;
 	constexpr int sh1 = L2 - 1, sh2 = L2 + 6, SIDE = N / 4;
@@ -116,18 +116,31 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 				const uint32_t add = (uint32_t)(slice_i ? 171 : 85) << (qbits - 9);
 				uint32_t sum = 0;
 				unsigned long long nz = 0;
-				for (int e = l; e < E; e += GQ) {
-					const int s = qc[e];
-					const uint32_t mag = (uint16_t)(s < 0 ? -s : s);
-					const uint32_t aux = mag * (uint32_t)q[e];
-					const int c = (int)(aux + add) >> qbits;
-					const int d = (int)(aux - ((uint32_t)c << qbits)) >> qbits8;
-					sum += (uint32_t)c;
-					const int sgn = s > 0 ? 1 : (s < 0 ? -1 : 0);
-					const int lv = (int16_t)(sgn * sat16i(c));
-					ql[e] = (int16_t)lv;
-					qd[e] = (int16_t)sat16i(d);
-					if (lv) nz |= 1ull << b2c[((e / N) >> 2) * SIDE + ((e % N) >> 2)];
+				// four consecutive coefficients of a row per step (they share a coefficient group): 8-byte LDS accesses, one 16-byte
+				// load of the quantiser entries, one group-table lookup
+				for (int e0 = 4 * l; e0 < E; e0 += 4 * GQ) {
+					int16_t cs[4], lv4[4], du4[4];
+					int32_t qv[4];
+					__builtin_memcpy(cs, qc + e0, 8);
+					__builtin_memcpy(qv, q + e0, 16);
+					bool any = false;
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						const int s = cs[k];
+						const uint32_t mag = (uint16_t)(s < 0 ? -s : s);
+						const uint32_t aux = mag * (uint32_t)qv[k];
+						const int c = (int)(aux + add) >> qbits;
+						const int d = (int)(aux - ((uint32_t)c << qbits)) >> qbits8;
+						sum += (uint32_t)c;
+						const int m16 = sat16i(c);
+						const int lv = (int16_t)(s > 0 ? m16 : (s < 0 ? -m16 : 0));
+						lv4[k] = (int16_t)lv;
+						du4[k] = (int16_t)sat16i(d);
+						any |= lv != 0;
+					}
+					__builtin_memcpy(ql + e0, lv4, 8);
+					__builtin_memcpy(qd + e0, du4, 8);
+					if (any) nz |= 1ull << b2c[((e0 / N) >> 2) * SIDE + ((e0 % N) >> 2)];
 				}
 				ac = (int)group_sum<GQ>(sum);
 				if (nz) atomicOr(&sNz[w][qt], nz);
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 			if (qj < jr.end) {
 				int16_t *lo = L + lev_off;
 				const int16_t *ql = sLev[w][qt];
-				for (int e = l; e < E; e += GQ) lo[e] = ql[e];
+				for (int e0 = 4 * l; e0 < E; e0 += 4 * GQ) st4(lo + e0, ld4(ql + e0));
 				if (l == 0) ac_out[qj] = sAc[w][qt];
 			}
 		}
@@ -176,13 +189,19 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 			const int32_t *iq = tab->dequant[L2 - 2][is_intra ? 0 : 3 + comp][rem];
 			const int iq_shift = 3 + L2;
 			if (coded)                                              // lane = coefficient ROW i here: deqT[col][i] = deq[i][col]
-				for (int col = 0; col < N; col++) {
-					const int e = row * N + col;
-					const uint32_t prod = (uint32_t)(int)lev[e] * (uint32_t)iq[e];
-					int v;
-					if (iq_shift > per) v = (int)(prod + (1u << (iq_shift - per - 1))) >> (iq_shift - per);
-					else v = (int)(prod << (per - iq_shift));
-					tA[col * P + row] = (int16_t)sat16i(v);
+				for (int c0 = 0; c0 < N; c0 += 4) {
+					int16_t l4[4];
+					int32_t q4[4];
+					__builtin_memcpy(l4, lev + row * N + c0, 8);
+					__builtin_memcpy(q4, iq + row * N + c0, 16);
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						const uint32_t prod = (uint32_t)(int)l4[k] * (uint32_t)q4[k];
+						int v;
+						if (iq_shift > per) v = (int)(prod + (1u << (iq_shift - per - 1))) >> (iq_shift - per);
+						else v = (int)(prod << (per - iq_shift));
+						tA[(c0 + k) * P + row] = (int16_t)sat16i(v);
+					}
 				}
 		}
 		wave_sync();
