@@ -41,10 +41,25 @@ PAD = 80                       # reference-frame margin (hmr_encoder_lib.c:1514)
 REF_STRIDE = W + 2 * PAD
 CREF_STRIDE = W // 2 + PAD
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+WORKLOADS = {   # name -> (width, height, recorded call mix); the metric is quoted on the first (BASELINE.json configs[1])
+    "cfg2-1080p-P-frame-replay": (1920, 1080, "callmix_1080p_cfg2.json"),
+    "cfg4-2160p-P-frame-replay": (3840, 2160, "callmix_2160p_cfg4.json"),   # configs[3] per engine: the same encode at 2160p
+}
+CALLMIX = "callmix_1080p_cfg2.json"
+WORKLOAD = "cfg2-1080p-P-frame-replay"
+
+
+def set_workload(name):
+    global W, H, HA, REF_STRIDE, CREF_STRIDE, CALLMIX, WORKLOAD
+    W, H, CALLMIX = WORKLOADS[name]
+    WORKLOAD = name
+    HA = (H + 63) // 64 * 64
+    REF_STRIDE = W + 2 * PAD
+    CREF_STRIDE = W // 2 + PAD
 
 
 def load_callmix(frame_index):
-    with open(os.path.join(ROOT, "tests", "golden", "callmix_1080p_cfg2.json")) as f:
+    with open(os.path.join(ROOT, "tests", "golden", CALLMIX)) as f:
         d = json.load(f)
     return d["frames"][frame_index]["calls"]
 
@@ -455,11 +470,13 @@ def frame_side_info(rng):
     return {"pred_depth": depth, "tr_idx": tr, "flags": flags, "mvx": mvx, "mvy": mvy, "ref_idx": ref_idx, "qp": qp, "sao_params": params}
 
 
-def cpu_baseline(frames=64):
+def cpu_baseline(frames=None):
     """Reference encoder (compiled by oracle/Makefile in the build container, shipped in oracle/_ref) on this host's cores."""
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_lockstep")
     if not os.path.exists(exe):
         return None
+    if frames is None:
+        frames = 64 if W <= 1920 else 16      # about 10-15 s of single-core encoding either way
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gen_yuv
     with tempfile.TemporaryDirectory() as td:
@@ -473,7 +490,7 @@ def cpu_baseline(frames=64):
         if line.startswith("LOCKSTEP"):
             kv = dict(p.split("=") for p in line.split()[1:])
             return {"value": float(kv["fps"]), "unit": "frames/s", "cores": 1, "kind": "reference",
-                    "sample": f"{kv['frames']} frames 1920x1080 cfg2 (IPPP QP32 qpel SAO, wpp=1 engines=1), {kv['seconds']} s, oracle/_ref/ref_lockstep"}
+                    "sample": f"{kv['frames']} frames {W}x{H} cfg2 (IPPP QP32 qpel SAO, wpp=1 engines=1), {kv['seconds']} s, oracle/_ref/ref_lockstep"}
     return None
 
 
@@ -484,6 +501,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--callmix-frame", type=int, default=2, help="which recorded P frame to replay")
+    ap.add_argument("--workload", choices=list(WORKLOADS), default="cfg2-1080p-P-frame-replay")
     ap.add_argument("--mode", choices=["eager", "graph"], default="graph",
                     help="eager: C command list with an event pair around every launch inside the timed region (per-kernel roofline numbers are live); "
                          "graph: the same command list captured once into a hipGraph and replayed (no per-launch host cost), per-kernel numbers from an eager pass after the timed region")
@@ -495,6 +513,7 @@ def main():
                          "The reference runs up to 8 engines on consecutive frames (num_enc_engines); an IPPP chain keeps about 3 usefully in flight at 1080p (SURVEY.md 8-e)")
     ap.add_argument("--launch-order", default=None, help="write the per-step kernel launch order (JSON) for tools/pmc_summary.py")
     args = ap.parse_args()
+    set_workload(args.workload)
 
     import torch
     import torch.distributed as dist
@@ -706,11 +725,11 @@ def main():
     if rank == 0:
         fps = args.steps * world * len(engines) / elapsed
         line = {
-            "metric": "encoded frames/sec, 1080p YUV420 fixed-QP IPPP (hot-path replay of the reference's per-frame call mix)",
+            "metric": f"encoded frames/sec, {H}p YUV420 fixed-QP IPPP (hot-path replay of the reference's per-frame call mix)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
-            "config": {"workload": "cfg2-1080p-P-frame-replay", "width": W, "height": H, "qp": 32, "gop": "IPPP gop_size=1", "me": "quarter-pel", "sao": 1,
+            "config": {"workload": WORKLOAD, "width": W, "height": H, "qp": 32, "gop": "IPPP gop_size=1", "me": "quarter-pel", "sao": 1,
                        "calls_per_frame": int(sum(len(g["jobs"]) for g in groups)), "launches_per_frame": len(groups) + 8,
                        "callmix_frame": args.callmix_frame, "parallelism": f"{len(engines)} engine(s) per gpu x{world}", "frames_per_step": len(engines) * world, "launch_mode": args.mode, "graph_branches": args.branches if args.mode == "graph" else 1, "tu_chain": "7 separate batches" if args.unfused else "fused kernel",
                        "algorithmic_MB_per_frame_abi_width": round(total_alg / 1e6, 2), "compulsory_MB_per_frame": round(10.5 * W * H / 1e6, 2)},
