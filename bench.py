@@ -703,14 +703,15 @@ def main():
     # HBM traffic of the dominant kernel from the committed PMC passes of this same command (tools/pmc_summary.py), if present
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
+    profiled = WORKLOAD == "cfg2-1080p-P-frame-replay" and args.callmix_frame == 2 and not args.unfused   # what the committed counter passes ran
+    if os.path.exists(tpath) and profiled:
         with open(tpath) as f:
             traffic = json.load(f).get("groups", {}).get(dom, {}).get("hbm_bytes")
     # VALU issue floor of the dominant kernel from the committed SQ counter passes (tools/pmc_sq.sh): a wave64 VALU instruction holds
     # its SIMD16 for 4 cycles, the chip has 256 CUs x 4 SIMDs at 2.4 GHz
     valu = None
     spath = os.path.join(ROOT, "profiles", "sq_summary.csv")
-    if os.path.exists(spath) and os.path.exists(tpath):
+    if os.path.exists(spath) and os.path.exists(tpath) and profiled:
         import csv
         with open(tpath) as f:
             kname = json.load(f).get("groups", {}).get(dom, {}).get("kernel", "").replace("void ", "")

@@ -21,7 +21,8 @@ def gen_frames(width, height, frames, seed=1234):
     tex = rng.integers(-12, 13, size=(height + 64, width + 64)).astype(np.float32)
     for n in range(frames):
         dx, dy = 3 * n, 2 * n
-        Y = np.roll(np.roll(base, dx, axis=1), dy, axis=0) + tex[dy:dy + height, dx:dx + width]
+        tx, ty = dx % 64, dy % 64      # the texture window wraps after 21 frames (identical to the published definition before that)
+        Y = np.roll(np.roll(base, dx, axis=1), dy, axis=0) + tex[ty:ty + height, tx:tx + width]
         bx, by = 200 + 11 * n, 300 + 7 * n
         if by < height and bx < width:
             bh, bw = min(160, height - by), min(240, width - bx)
