@@ -38,9 +38,9 @@ template <int N, int WPJ>
 __global__ __launch_bounds__(HMR_BLOCK) void k_intra_search(const hmr_gpu_intra_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ O,
 							       const int16_t *__restrict__ D, int16_t *__restrict__ Cc, hmr_gpu_intra_result *__restrict__ out)
 {
-	// lanes per PU: 4 / 16 / 32 for N = 4 / 8 / 16 (16 / 4 / 2 PUs share a wavefront: the per-candidate set-up, synchronisation,
+	// lanes per PU: 4 / 16 for N = 4 / 8 (16 / 4 PUs share a wavefront: the per-candidate set-up, synchronisation,
 	// reduction and cost arithmetic are paid once per wavefront, so packing PUs divides them), a wavefront or more above
-	constexpr int E = N * N, G = WPJ > 1 ? HMR_WAVE * WPJ : (N == 4 ? 4 : N == 8 ? 16 : N == 16 ? 32 : HMR_WAVE);
+	constexpr int E = N * N, G = WPJ > 1 ? HMR_WAVE * WPJ : (N == 4 ? 4 : N == 8 ? 16 : HMR_WAVE);
 	constexpr int JPB = HMR_BLOCK / G;                     // jobs per workgroup
 	constexpr int PPL = E / G, YSTEP = G / N;              // samples per lane, row distance between a lane's samples
 	constexpr int l2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : N == 32 ? 5 : 6, total = 4 * N + 1;
@@ -182,7 +182,7 @@ extern "C" int hmr_gpu_intra_search_batch(hmr_gpu_ctx *ctx, const hmr_gpu_intra_
 	switch (size) {
 	case 4: LAUNCH(4, 1, 64); break;
 	case 8: LAUNCH(8, 1, 16); break;
-	case 16: LAUNCH(16, 1, 8); break;
+	case 16: LAUNCH(16, 1, 4); break;
 	case 32: LAUNCH(32, 2, 2); break;
 	case 64: LAUNCH(64, 4, 1); break;
 	default: hmr_set_error("intra search: unsupported size %d", size); return HMR_GPU_ERR_ARG;
