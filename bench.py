@@ -370,8 +370,11 @@ def build_groups(calls, rng, arena, fused=True):
             mvx = (rng.integers(-10, 11, n) << fbits) + (rng.integers(1, 1 << fbits, n) if fx else 0)
             mvy = (rng.integers(-6, 7, n) << fbits) + (rng.integers(1, 1 << fbits, n) if fy else 0)
             jb["p0"] = mvx.astype(np.int32).view(np.uint32); jb["p1"] = mvy.astype(np.int32).view(np.uint32)
-            lanes = min(max(w * h // 4, 16), 64)
-            lanes = 16 if lanes < 32 else (32 if lanes < 64 else 64)
+            # lanes per block: about two first-stage work items (four outputs each) per lane, and the first stage must fit the block's
+            # share of the wave's LDS tile
+            items = (w // 4) * (h + taps - 1) if w >= 4 else w * h
+            tile = (64 + 7) * 64 if luma else (32 + 3) * 32
+            lanes = next(g for g in (4, 8, 16, 32, 64) if (2 * g >= items and w * (h + taps - 1) <= tile * g // 64) or g == 64)
             if fx and fy:
                 nb = 2 * ((w + taps - 1) * (h + taps - 1) + w * (h + taps - 1)) + 2 * (w * (h + taps - 1) + w * h)
             elif fx or fy:

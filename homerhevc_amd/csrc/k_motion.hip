@@ -435,8 +435,8 @@ extern "C" int hmr_gpu_mc_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int n
 {
 	if (njobs <= 0) return HMR_GPU_OK;
 	const int is_luma = flags & 1;
-	int g = (flags >> 8) & 0xff;   // lanes per job hint: 16 / 32 / 64 (0 = 64)
-	if (g != 16 && g != 32) g = 64;
+	int g = (flags >> 8) & 0xff;   // lanes per job hint: 4 / 8 / 16 / 32 / 64 (0 = 64)
+	if (g != 4 && g != 8 && g != 16 && g != 32) g = 64;
 	const int jpw = HMR_WAVE / g;
 	dim3 grid(hmr_grid_for_waves(((long)njobs + jpw - 1) / jpw)), block(HMR_BLOCK);
 	if (is_luma) hipLaunchKernelGGL((k_mc<8>), grid, block, 0, ctx->stream, jobs, njobs, is_bi, g, a, c);

@@ -251,7 +251,8 @@ int hmr_gpu_motion_estimation_batch(hmr_gpu_ctx *ctx, const hmr_gpu_me_job *jobs
 				    int range_x, int range_y, int frame_w, int frame_h, hmr_gpu_me_result *out);
 /* hmr_motion_compensation_luma / _chroma (hmr_motion_inter.c:1779,1860): a = co-located block, c = prediction, w/h extent,
  * p0 = mv.x, p1 = mv.y (as int32; quarter samples for luma, eighth samples for chroma).
- * flags bit 0: luma / chroma; bits 8..15: lanes-per-job hint 16 / 32 / 64 (0 = 64): that many lanes share a block of w*h samples */
+ * flags bit 0: luma / chroma; bits 8..15: lanes-per-job hint 4 / 8 / 16 / 32 / 64 (0 = 64): that many lanes share a block of w*h samples (a work item is
+ * four adjacent outputs; a two-stage block whose (h + taps - 1) x w first stage does not fit lanes/64 of the wave's LDS tile falls back to a slower form) */
 int hmr_gpu_mc_batch(hmr_gpu_ctx *ctx, const hmr_gpu_job *jobs, int njobs, int flags, int is_bi_predict, const int16_t *a_base, int16_t *c_base);
 /* host-pointer (drop-in) forms */
 uint32_t hmr_gpu_motion_estimation(int16_t *orig, int orig_stride, int16_t *ref, int ref_stride, int gx, int gy, int init_x, int init_y, int size,

@@ -345,7 +345,7 @@ def test_tu_chain(rig, oracle, n):
 
 
 @pytest.mark.parametrize("luma", [1, 0])
-@pytest.mark.parametrize("lanes", [16, 32, 64])
+@pytest.mark.parametrize("lanes", [4, 8, 16, 32, 64])
 @pytest.mark.parametrize("is_bi", [0, 1])
 def test_motion_compensation(rig, oracle, luma, lanes, is_bi):
     rng = np.random.default_rng(luma * 10 + lanes + is_bi)
