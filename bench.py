@@ -373,8 +373,8 @@ def build_groups(calls, rng, arena, fused=True):
             # lanes per block: about two first-stage work items (four outputs each) per lane, and the first stage must fit the block's
             # share of the wave's LDS tile
             items = (w // 4) * (h + taps - 1) if w >= 4 else w * h
-            tile = (64 + 7) * 64 if luma else (32 + 3) * 32
-            lanes = next(g for g in (4, 8, 16, 32, 64) if (2 * g >= items and w * (h + taps - 1) <= tile * g // 64) or g == 64)
+            tile = (32 + taps - 1) * 32
+            lanes = next(g for g in (4, 8, 16, 32, 64) if (2 * g >= items and min(w, 32) * (min(h, 32) + taps - 1) <= tile * g // 64) or g == 64)
             if fx and fy:
                 nb = 2 * ((w + taps - 1) * (h + taps - 1) + w * (h + taps - 1)) + 2 * (w * (h + taps - 1) + w * h)
             elif fx or fy:

@@ -302,8 +302,10 @@ template <int TAPS>
 __global__ __launch_bounds__(HMR_BLOCK) void k_mc(const hmr_gpu_job *__restrict__ jobs, int njobs, int is_bi, int lanes_per_job, const int16_t *__restrict__ A,
 						     int16_t *__restrict__ Cc)
 {
-	constexpr int FM = TAPS == 8 ? 3 : 7, FS = TAPS == 8 ? 2 : 3, MAXW = TAPS == 8 ? 64 : 32, HT = TAPS / 2 - 1;
-	constexpr int TILE = (MAXW + TAPS - 1) * MAXW;
+	constexpr int FM = TAPS == 8 ? 3 : 7, FS = TAPS == 8 ? 2 : 3, HT = TAPS / 2 - 1;
+	// first-stage tile: outputs are produced in tiles of at most 32 x 32, so a wave needs (32 + TAPS - 1) x 32 intermediates however
+	// large the block is - a small tile keeps eight waves per SIMD resident
+	constexpr int TS = 32, TILE = (TS + TAPS - 1) * TS;
 	__shared__ __attribute__((aligned(16))) int16_t sTile[HMR_WAVES_PER_BLOCK][TILE];
 	const int G = lanes_per_job, JPW = HMR_WAVE / G, share = TILE / JPW;
 	const int sub = lane_id() / G, lane = lane_id() % G, w = wave_in_block();
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_mc(const hmr_gpu_job *__restrict_
 			cy[k] = TAPS == 8 ? cLumaTaps[yf][k] : cChromaTaps[yf][k];
 		}
 		const bool vec = (bw & 3) == 0;       // every HEVC PU except 2-wide chroma
-		const int cpr = bw >> 2;              // four-output items per row
+		const int cpr = bw >> 2, lcpr = __ffs(cpr) - 1;   // four-output items per row (a power of two: PU widths are)
 		if (xf == 0 || yf == 0) {
 			// one stage, first: (sum + 32) >> 6 clipped when last, sum - 8192 when feeding a bi-prediction average
 			const bool vert = xf == 0;
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_mc(const hmr_gpu_job *__restrict_
 			if (TAPS == 4 && f == 0 && bw < 4) continue;   // hmr_sse42_functions_inter_prediction.c:822
 			if (vec) {
 				for (int e = lane; e < cpr * bh; e += G) {
-					const int y = e / cpr, x = (e - y * cpr) * 4;
+					const int y = e >> lcpr, x = (e & (cpr - 1)) * 4;
 					int o[4];
 					if (f == 0) {
 						const i16x4 v = ld4(src + (size_t)y * rs + x);
@@ -370,28 +372,33 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_mc(const hmr_gpu_job *__restrict_
 			}
 			continue;
 		}
-		const int th = bh + TAPS - 1;
-		if (vec && bw * th <= share) {
-			for (int e = lane; e < cpr * th; e += G) {
-				const int y = e / cpr, x = (e - y * cpr) * 4;
-				int o[4];
-				mc_hor4<TAPS>(src + (ptrdiff_t)(y - HT) * rs + x - HT, cx, o);
-				i16x4 r;
+		const int tw = bw < TS ? bw : TS, tb = bh < TS ? bh : TS;      // output tile
+		if (vec && tw * (tb + TAPS - 1) <= share) {
+			const int tcpr = tw >> 2, ltcpr = __ffs(tcpr) - 1;
+			for (int ty = 0; ty < bh; ty += tb)
+				for (int tx = 0; tx < bw; tx += tw) {
+					const int16_t *ts = src + (ptrdiff_t)ty * rs + tx;
+					for (int e = lane; e < tcpr * (tb + TAPS - 1); e += G) {
+						const int y = e >> ltcpr, x = (e & (tcpr - 1)) * 4;
+						int o[4];
+						mc_hor4<TAPS>(ts + (ptrdiff_t)(y - HT) * rs + x - HT, cx, o);
+						i16x4 r;
 #pragma unroll
-				for (int q = 0; q < 4; q++) r.v[q] = (int16_t)sat16i(o[q] - 8192);
-				st4(tile + y * bw + x, r);
-			}
-			wave_sync();
-			for (int e = lane; e < cpr * bh; e += G) {
-				const int y = e / cpr, x = (e - y * cpr) * 4;
-				int o[4];
-				mc_ver4<TAPS>(tile + y * bw + x, bw, cy, o);
-				i16x4 r;
+						for (int q = 0; q < 4; q++) r.v[q] = (int16_t)sat16i(o[q] - 8192);
+						st4(tile + y * tw + x, r);
+					}
+					wave_sync();
+					for (int e = lane; e < tcpr * tb; e += G) {
+						const int y = e >> ltcpr, x = (e & (tcpr - 1)) * 4;
+						int o[4];
+						mc_ver4<TAPS>(tile + y * tw + x, tw, cy, o);
+						i16x4 r;
 #pragma unroll
-				for (int q = 0; q < 4; q++) r.v[q] = (int16_t)(last ? clip3i(sat16i((o[q] + 2048 + (8192 << 6)) >> 12), 0, 255) : sat16i(o[q] >> 6));
-				st4(dst + (size_t)y * ds + x, r);
-			}
-			wave_sync();
+						for (int q = 0; q < 4; q++) r.v[q] = (int16_t)(last ? clip3i(sat16i((o[q] + 2048 + (8192 << 6)) >> 12), 0, 255) : sat16i(o[q] >> 6));
+						st4(dst + (size_t)(ty + y) * ds + tx + x, r);
+					}
+					wave_sync();
+				}
 		} else {
 			// 2-wide chroma, or the job does not fit its LDS share (hint too small for this block): first stage recomputed per output
 			for (int e = lane; e < bw * bh; e += G) {
