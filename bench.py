@@ -485,16 +485,26 @@ def cpu_baseline(frames=None):
     with tempfile.TemporaryDirectory() as td:
         clip = os.path.join(td, "clip.yuv")
         gen_yuv.write_clip(clip, W, H, frames)
-        try:
-            out = subprocess.run([exe, clip, "-", str(W), str(H), str(frames)], capture_output=True, text=True, timeout=600).stdout
-        except Exception:
+        def run(extra):
+            try:
+                out = subprocess.run([exe, clip, "-", str(W), str(H), str(frames), *extra], capture_output=True, text=True, timeout=600).stdout
+            except Exception:
+                return None
+            for line in out.splitlines():
+                if line.startswith("LOCKSTEP"):
+                    return dict(p.split("=") for p in line.split()[1:])
             return None
-    for line in out.splitlines():
-        if line.startswith("LOCKSTEP"):
-            kv = dict(p.split("=") for p in line.split()[1:])
-            return {"value": float(kv["fps"]), "unit": "frames/s", "cores": 1, "kind": "reference",
-                    "sample": f"{kv['frames']} frames {W}x{H} cfg2 (IPPP QP32 qpel SAO, wpp=1 engines=1), {kv['seconds']} s, oracle/_ref/ref_lockstep"}
-    return None
+        kv = run(())
+        # the reference's throughput mode inside one engine: one WPP thread per CTU row, as many as the host has cores for (not deterministic)
+        threads = max(1, min((H + 63) // 64, os.cpu_count() or 1))
+        kv_mt = run((f"wpp={threads}",)) if threads > 1 else None
+    if not kv:
+        return None
+    res = {"value": float(kv["fps"]), "unit": "frames/s", "cores": 1, "kind": "reference",
+           "sample": f"{kv['frames']} frames {W}x{H} cfg2 (IPPP QP32 qpel SAO, wpp=1 engines=1), {kv['seconds']} s, oracle/_ref/ref_lockstep"}
+    if kv_mt:
+        res["wpp_threads"] = {"value": float(kv_mt["fps"]), "cores": threads, "seconds": float(kv_mt["seconds"])}
+    return res
 
 
 def main():
@@ -739,6 +749,7 @@ def main():
                        "algorithmic_MB_per_frame_abi_width": round(total_alg / 1e6, 2), "compulsory_MB_per_frame": round(10.5 * W * H / 1e6, 2)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_frac": round(traffic / (per[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if (traffic and per[dom] > 0) else None,
                          "measured_copy_GBps": round(copy_gbs, 1), "valu_issue": valu,
                          "timing": ("HIP event pairs around every launch inside the timed region" if args.mode == "eager" else
                                     "HIP event pairs around every launch, eager replay of the same K steps right after the timed graph replays "
