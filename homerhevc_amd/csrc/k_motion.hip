@@ -20,8 +20,6 @@ __constant__ int16_t cChromaTaps[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 
 					  {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
 __constant__ int cDs[4][2] = {{-1, 0}, {0, -1}, {1, 0}, {0, 1}};
 __constant__ int cDb[8][2] = {{-2, 0}, {-1, -1}, {0, -2}, {1, -1}, {2, 0}, {1, 1}, {0, 2}, {-1, 1}};
-__constant__ int cRefH[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
-__constant__ int cRefQ[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
 
 // Packed-sample arithmetic shared by the search driver and motion compensation: samples stay two per register as loaded and
 // every multiply-accumulate is a v_dot2_i32_i16 against a coefficient pair; sums are exact in 32 bits.
@@ -81,6 +79,25 @@ __device__ __forceinline__ void mc_ver4(const int16_t *p, int step, const int (&
 
 // |a0 - b0| + |a1 - b1| + acc on packed unsigned 16-bit pairs (picture samples are 0..255)
 __device__ __forceinline__ uint32_t sad2(int a, int b, uint32_t acc) { return __builtin_amdgcn_sad_u16((unsigned)a, (unsigned)b, acc); }
+
+// luma_filter_coeffs (hmr_motion_inter.c:240-246) and the nine-point refinement patterns as immediates, for lanes that work on
+// different candidates at the same time (a table in memory would be a divergent load)
+__device__ __forceinline__ void luma_taps(int f, int (&c)[8])
+{
+	// one byte per tap, taps 0..3 in the low word
+	const unsigned lo = f == 0 ? 0x40000000u : f == 1 ? 0x3af604ffu : f == 2 ? 0x28f504ffu : 0x11fb0100u;
+	const unsigned hi = f == 0 ? 0x00000000u : f == 1 ? 0x0001fb11u : f == 2 ? 0xff04f528u : 0xff04f63au;
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		c[k] = (int)(lo << (24 - 8 * k)) >> 24;
+		c[4 + k] = (int)(hi << (24 - 8 * k)) >> 24;
+	}
+}
+// i-th refinement point (x, y) in -1..1: half-pel order (hmr_motion_inter.c:1693) and quarter-pel order (:1738)
+__device__ __forceinline__ int ref_pt(unsigned packed, int i) { return (int)((packed >> (2 * i)) & 3u) - 1; }
+constexpr unsigned kRefX = 1u | (1u << 2) | (1u << 4) | (0u << 6) | (2u << 8) | (0u << 10) | (2u << 12) | (0u << 14) | (2u << 16);    // 0 0 0 -1 1 -1 1 -1 1
+constexpr unsigned kRefHY = 1u | (0u << 2) | (2u << 4) | (1u << 6) | (1u << 8) | (0u << 10) | (0u << 12) | (2u << 14) | (2u << 16);   // 0 -1 1 0 0 -1 -1 1 1
+constexpr unsigned kRefQY = 1u | (0u << 2) | (2u << 4) | (0u << 6) | (0u << 8) | (1u << 10) | (1u << 12) | (2u << 14) | (2u << 16);   // 0 -1 1 -1 -1 0 0 1 1
 
 template <int N> struct MeGeo {
 	static constexpr int WPB = N == 64 ? 1 : 4;          // waves per workgroup (LDS budget: 36 KB per wave at N = 64)
@@ -233,45 +250,62 @@ __global__ __launch_bounds__(MeGeo<N>::WPB * 64) void k_motion_estimation(const 
 				}
 				wave_sync();
 			};
-			// SAD of candidate (tile t, vertical quarter offset cy)
-			auto sad_sub = [&](int t, int cy) -> uint32_t {
+			// one four-sample item of candidate (tile t, vertical quarter offset cy)
+			auto item_sub = [&](int t, int cy, int e) -> uint32_t {
 				const int qy = (best_y << 2) + cy, iy = (qy >> 2) - best_y, fy = qy & 3;   // iy in {-1, 0}
 				int c[8];
-#pragma unroll
-				for (int k = 0; k < 8; k++) c[k] = cLumaTaps[fy][k];
+				luma_taps(fy, c);
 				const int16_t *tile = &sTile[w][t][(4 + iy - 3) * N];
-				uint32_t acc = 0;
-				for (int e = lane; e < CH; e += 64) {
-					const int y = e / CPR, x = (e % CPR) * 4;
-					int sm[4];
-					mc_ver4<8>(tile + y * N + x, N, c, sm);
-					int pv[4];
+				const int y = e / CPR, x = (e % CPR) * 4;
+				int sm[4];
+				mc_ver4<8>(tile + y * N + x, N, c, sm);
+				int pv[4];
 #pragma unroll
-					for (int k = 0; k < 4; k++) pv[k] = clip3i(sat16i((sm[k] + 2048 + (8192 << 6)) >> 12), 0, 255);   // not first, last
-					const i32x2 a = ld2w(orig + y * N + x);
-					acc = sad2(a.v[1], pv[2] | (pv[3] << 16), sad2(a.v[0], pv[0] | (pv[1] << 16), acc));
-				}
-				return wave_sum(acc);
+				for (int k = 0; k < 4; k++) pv[k] = clip3i(sat16i((sm[k] + 2048 + (8192 << 6)) >> 12), 0, 255);   // not first, last
+				const i32x2 a = ld2w(orig + y * N + x);
+				return sad2(a.v[1], pv[2] | (pv[3] << 16), sad2(a.v[0], pv[0] | (pv[1] << 16), 0));
 			};
+			// SADs of the nine candidates of a refinement round; candidate i = (tile px(i) + 1, vertical offset oy + sy * py(i)).
+			// A block of fewer than 64 items (8x8) is evaluated 64 / CH candidates at a time, each by its own lane group.
+			auto round9 = [&](unsigned ypat, int oy, int sy, uint32_t (&sd)[9]) {
+				if constexpr (CH >= HMR_WAVE) {
+#pragma unroll
+					for (int i = 0; i < 9; i++) {
+						uint32_t acc = 0;
+						for (int e = lane; e < CH; e += HMR_WAVE) acc += item_sub(ref_pt(kRefX, i) + 1, oy + sy * ref_pt(ypat, i), e);
+						sd[i] = wave_sum(acc);
+					}
+				} else {
+					constexpr int PAR = HMR_WAVE / CH;
+#pragma unroll
+					for (int b = 0; b < (9 + PAR - 1) / PAR; b++) {
+						const int i = b * PAR + lane / CH, ii = i < 9 ? i : 8;
+						uint32_t acc = i < 9 ? item_sub(ref_pt(kRefX, ii) + 1, oy + sy * ref_pt(ypat, ii), lane % CH) : 0u;
+						acc = group_sum<CH>(acc);
+#pragma unroll
+						for (int q = 0; q < PAR; q++)
+							if (b * PAR + q < 9) sd[b * PAR + q] = (uint32_t)__builtin_amdgcn_readlane((int)acc, q * CH);
+					}
+				}
+			};
+			uint32_t sd[9];
 			int bidx = 0, bx = 0, by = 0;
 			build_tiles(-2, 0, 2);
-			for (int i = 0; i < 9; i++) {
-				const int cx = cRefH[i][0] * 2, cy = cRefH[i][1] * 2;
-				const uint32_t s = sad_sub(cRefH[i][0] + 1, cy);
-				if (s < cur_sad) { cur_sad = s; bx = cx; by = cy; bidx = i; }
-			}
+			round9(kRefHY, 0, 2, sd);
+#pragma unroll
+			for (int i = 0; i < 9; i++)
+				if (sd[i] < cur_sad) { cur_sad = sd[i]; bx = ref_pt(kRefX, i) * 2; by = ref_pt(kRefHY, i) * 2; bidx = i; }
 			mvx = (best_x << 2) + bx; mvy = (best_y << 2) + by; subx = bx; suby = by;
 			best_sad = cur_sad;
 			if (action & 4) {
-				const int hx = cRefH[bidx][0], hy = cRefH[bidx][1];
+				const int hx = ref_pt(kRefX, bidx), hy = ref_pt(kRefHY, bidx);
 				wave_sync();
 				build_tiles(hx * 2 - 1, hx * 2, hx * 2 + 1);
 				bx = hx * 2; by = hy * 2;
-				for (int i = 0; i < 9; i++) {
-					const int cx = hx * 2 + cRefQ[i][0], cy = hy * 2 + cRefQ[i][1];
-					const uint32_t s = sad_sub(cRefQ[i][0] + 1, cy);
-					if (s < cur_sad) { cur_sad = s; bx = cx; by = cy; }
-				}
+				round9(kRefQY, hy * 2, 1, sd);
+#pragma unroll
+				for (int i = 0; i < 9; i++)
+					if (sd[i] < cur_sad) { cur_sad = sd[i]; bx = hx * 2 + ref_pt(kRefX, i); by = hy * 2 + ref_pt(kRefQY, i); }
 				best_sad = cur_sad;
 				mvx = (best_x << 2) + bx; mvy = (best_y << 2) + by; subx = bx; suby = by;
 			}
