@@ -106,3 +106,41 @@ def test_loop_filters_ctu_by_ctu_dropins(gpu, oracle):
             gpu.hmr_gpu_pad_ctu(planes, strides, W, H, fc.PAD_X, fc.PAD_Y, x, y, 64)
         for i in range(3):
             assert np.array_equal(pl[i], ora["padded"][i]), (meta["tag"], "pad", i)
+
+
+def synthetic_case(width, height, seed):
+    """Full-size picture with a synthetic coding tree / motion field (the shape bench.py uses) - no reference run is needed, the C
+    oracle is fast enough to be the checker at BASELINE.json's picture sizes."""
+    rng = np.random.default_rng(seed)
+    ctus_x, ctus_y = (width + 63) // 64, (height + 63) // 64
+    W4, H4 = ctus_x * 16, ctus_y * 16
+    blk = lambda a, n: np.kron(a, np.ones((n, n), a.dtype))   # noqa: E731
+    depth = blk(rng.integers(0, 4, (ctus_y * 2, ctus_x * 2)).astype(np.uint8), 8)            # per 32x32
+    tr = blk((rng.random((H4 // 2, W4 // 2)) < 0.3).astype(np.uint8), 2)
+    intra = blk((rng.random((H4 // 4, W4 // 4)) < 0.1).astype(np.uint8), 4)
+    info = {
+        "mvx": blk(rng.integers(-40, 41, (H4 // 2, W4 // 2)).astype(np.int16), 2), "mvy": blk(rng.integers(-24, 25, (H4 // 2, W4 // 2)).astype(np.int16), 2),
+        "ref_idx": np.where(intra, -1, 0).astype(np.int8), "qp": blk(rng.integers(26, 38, (H4 // 4, W4 // 4)).astype(np.uint8), 4),
+        "pred_mode": intra, "cbf_y": blk((rng.random((H4 // 2, W4 // 2)) < 0.5).astype(np.uint8), 2), "pred_depth": depth, "tr_idx": tr,
+    }
+    info = {k: np.ascontiguousarray(v) for k, v in info.items()}
+    yy, xx = np.mgrid[0:height, 0:width]
+    y = np.clip(128 + 60 * np.sin(xx / 53.0) * np.cos(yy / 41.0) + rng.integers(-12, 13, (height, width)), 0, 255).astype(np.int16)
+    u = np.clip(128 + 30 * np.sin(xx[::2, ::2] / 97.0) + rng.integers(-3, 4, (height // 2, width // 2)), 0, 255).astype(np.int16)
+    v = np.clip(128 + 30 * np.cos(yy[::2, ::2] / 89.0) + rng.integers(-3, 4, (height // 2, width // 2)), 0, 255).astype(np.int16)
+    return {"width": width, "height": height, "info": info, "pre": fc.blocky_planes(y, u, v, seed + 1), "orig": [y, u, v],
+            "sao_params": fc.random_sao_params(ctus_x * ctus_y, seed + 2), "dbk": [2, 2, int(rng.integers(-2, 3)), int(rng.integers(-2, 3))]}
+
+
+@pytest.mark.parametrize("width,height", [(1920, 1080), (3840, 2160)], ids=["1080p", "2160p"])
+def test_full_size_pictures_match_oracle(gpu, oracle, width, height):
+    """BASELINE.json's picture sizes: edge flags, boundary strengths, deblocking, SAO statistics, SAO offset and border padding of a whole
+    picture (incl. the partial last CTU row) bit-exact against the CPU oracle."""
+    case = synthetic_case(width, height, 5 + width)
+    got = fc.run_gpu(gpu, case)
+    ora = fc.run_oracle(oracle, case)
+    fc.compare(got, ora, width, height)
+    # size-independent property: padding is edge replication of the SAO output
+    for pl, pad in zip(got["padded"], (fc.PAD_X, fc.PAD_X // 2, fc.PAD_X // 2)):
+        inner = pl[pad:-pad, pad:-pad]
+        assert np.array_equal(pl, np.pad(inner, pad, mode="edge"))
