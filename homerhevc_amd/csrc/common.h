@@ -10,7 +10,8 @@
 #define HMR_WAVE 64
 #define HMR_BLOCK 256               // 4 waves per workgroup
 #define HMR_WAVES_PER_BLOCK (HMR_BLOCK / HMR_WAVE)
-#define HMR_MAX_GRID 4096           // >> 256 CUs; every batched kernel grid-strides over its jobs
+#define HMR_MAX_GRID 4096           // default cap, >> 256 CUs; every batched kernel grid-strides over its jobs
+extern int g_hmr_max_grid;          // run-time cap (hmr_gpu_set_max_grid), context.cpp
 
 // Constant tables, device resident, built once per context (tables.cpp).
 struct DevTables {
@@ -56,7 +57,7 @@ const DevTables *hmr_host_tables();      // host copy (tables.cpp)
 static inline int hmr_grid_for_units(long units)
 {
 	long blocks = units < 1 ? 1 : units;
-	if (blocks > HMR_MAX_GRID) blocks = HMR_MAX_GRID;
+	if (blocks > g_hmr_max_grid) blocks = g_hmr_max_grid;
 	if (blocks >= HMR_XCDS) blocks = (blocks + HMR_XCDS - 1) / HMR_XCDS * HMR_XCDS;
 	return (int)blocks;
 }

@@ -147,3 +147,14 @@ extern "C" int hmr_gpu_event_destroy(void *ev)
 	HIP_TRY(hipEventDestroy((hipEvent_t)ev));
 	return HMR_GPU_OK;
 }
+
+// Cap on the workgroups of one batched launch (default HMR_MAX_GRID): the kernels grid-stride over their jobs, so any cap computes the
+// same results; a host may lower it to leave CUs to concurrent streams, the tests lower it to force many iterations per workgroup.
+int g_hmr_max_grid = HMR_MAX_GRID;
+extern "C" int hmr_gpu_set_max_grid(int blocks)
+{
+	if (blocks < 1) { hmr_set_error("hmr_gpu_set_max_grid: need at least one workgroup"); return HMR_GPU_ERR_ARG; }
+	g_hmr_max_grid = blocks;
+	return HMR_GPU_OK;
+}
+

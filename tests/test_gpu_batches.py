@@ -83,12 +83,17 @@ class Rig:
         self.gpu.hmr_gpu_destroy(self.ctx)
 
 
-@pytest.fixture()
-def rig():
+@pytest.fixture(params=[4096, 8, 3], ids=["grid4096", "grid8", "grid3"])
+def rig(request):
+    """Every test runs with the default launch cap and with caps of 8 and 3 workgroups: the same 611 jobs then take many grid-stride
+    iterations per workgroup (8 = one workgroup per XCD chunk, 3 = the plain grid-stride form), which is how the kernels run on
+    frame-sized batches."""
     gpu = libs.load_gpu()
+    assert gpu.hmr_gpu_set_max_grid(request.param) == 0
     r = Rig(gpu, np.random.default_rng(77))
     yield r
     r.close()
+    gpu.hmr_gpu_set_max_grid(4096)
 
 
 def at(arr, off):
