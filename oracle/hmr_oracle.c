@@ -1131,3 +1131,23 @@ void ora_intra_search(const int16_t *orig, int orig_stride, const int16_t *decod
 	*best_cost_out = best_cost;
 }
 
+/* ====================================================================================================
+ * Intra TU chain: the whole of encode_intra_cu's data path (hmr_motion_intra.c:1011-1068) - neighbour array (smoothed when the
+ * host's is_filtered rule :1011-1012 says so), planar / DC / angular prediction into `pred`, then the TU chain of ora_tu_chain.
+ * `recon` may be the block inside the plane the neighbours were read from (the reference reconstructs in place).
+ * ==================================================================================================== */
+uint32_t ora_intra_tu_chain(const int16_t *orig, int orig_stride, const int16_t *decoded_corner, int decoded_stride, int left, int top, int bottom_left,
+			    int top_right, int bl_size, int tr_size, int strong_enabled, int is_filtered, int mode, int is_luma, int16_t *pred, int pred_stride,
+			    int16_t *levels, int16_t *recon, int recon_stride, int size, int is_dst, int scan_mode, int comp, int slice_is_intra, int sign_hiding,
+			    int per, int rem, int *ac_sum)
+{
+	int16_t adi[4 * 64 + 1], adif[4 * 64 + 1];
+	const int adi_size = 4 * size + 1;
+	ora_fill_reference_samples(decoded_corner, decoded_stride, size, left, top, bottom_left, top_right, bl_size, tr_size, adi);
+	if (is_filtered) ora_adi_filter(adi, adif, adi_size, size, strong_enabled);
+	if (mode == 0) ora_intra_planar(pred, pred_stride, is_filtered ? adif : adi, adi_size, size);
+	else ora_intra_angular(pred, pred_stride, is_filtered ? adif : adi, adi_size, size, mode, is_luma);
+	return ora_tu_chain(orig, orig_stride, pred, pred_stride, levels, recon, recon_stride, size, is_dst, scan_mode, comp, 1, slice_is_intra, sign_hiding, per, rem,
+			    ac_sum);
+}
+

@@ -113,6 +113,12 @@ void ora_intra_search(const int16_t *orig, int orig_stride, const int16_t *decod
 		      int top_right, int bl_size, int tr_size, int strong_enabled, const int32_t *preds, const int32_t *pred_bits, int other_bits,
 		      double sqrt_lambda, int16_t *adi, int16_t *adi_filtered, int16_t *pred, int pred_stride, int32_t *out, double *best_cost);
 
+/* ---- intra TU: neighbour array + prediction + TU chain (encode_intra_cu, hmr_motion_intra.c:1011-1068), returns the SSD ---- */
+uint32_t ora_intra_tu_chain(const int16_t *orig, int orig_stride, const int16_t *decoded_corner, int decoded_stride, int left, int top, int bottom_left,
+			    int top_right, int bl_size, int tr_size, int strong_enabled, int is_filtered, int mode, int is_luma, int16_t *pred, int pred_stride,
+			    int16_t *levels, int16_t *recon, int recon_stride, int size, int is_dst, int scan_mode, int comp, int slice_is_intra, int sign_hiding,
+			    int per, int rem, int *ac_sum);
+
 #ifdef __cplusplus
 }
 #endif

@@ -537,3 +537,30 @@ void refh_intra_search(int16_t *orig, int orig_stride, int16_t *decoded_corner, 
 	g_et->rd_mode = save_rd; g_et->rd.sqrt_lambda = save_lambda;
 	g_et->sps->strong_intra_smooth_enabled_flag = save_strong;
 }
+
+/* encode_intra_cu's data path (hmr_motion_intra.c:1011-1068) issued through the reference's own fill_reference_samples and table */
+uint32_t refh_intra_tu_chain(int16_t *orig, int orig_stride, int16_t *decoded_corner, int decoded_stride, int left, int top, int bottom_left, int top_right,
+			     int bl_size, int tr_size, int strong_enabled, int is_filtered, int mode, int is_luma, int16_t *pred, int pred_stride, int16_t *levels,
+			     int16_t *recon, int recon_stride, int size, int is_dst, int scan_mode, int comp, int slice_is_intra, int sign_hiding, int per, int rem,
+			     int *ac_sum)
+{
+	cu_partition_info_t pi;
+	ctu_info_t ctu;
+	const int sh = log2i(size), adi_size = 4 * size + 1;
+	int save_w = g_et->pict_width[0], save_h = g_et->pict_height[0], save_strong = g_et->sps->strong_intra_smooth_enabled_flag;
+	int16_t *adi;
+	memset(&pi, 0, sizeof pi);
+	memset(&ctu, 0, sizeof ctu);
+	pi.left_neighbour = left; pi.top_neighbour = top;
+	pi.left_bottom_neighbour = bottom_left; pi.top_right_neighbour = top_right;
+	pi.depth = 6 - sh;
+	g_et->pict_width[0] = size + tr_size; g_et->pict_height[0] = size + bl_size;
+	g_et->sps->strong_intra_smooth_enabled_flag = strong_enabled;
+	fill_reference_samples(g_et, &ctu, &pi, adi_size, decoded_corner, decoded_stride, size, Y_COMP, is_filtered);
+	g_et->pict_width[0] = save_w; g_et->pict_height[0] = save_h;
+	g_et->sps->strong_intra_smooth_enabled_flag = save_strong;
+	adi = is_filtered ? g_et->adi_filtered_pred_buff : g_et->adi_pred_buff;
+	if (mode == PLANAR_IDX) g_enc->funcs.create_intra_planar_prediction(g_et, pred, pred_stride, adi, adi_size, size, sh);
+	else g_enc->funcs.create_intra_angular_prediction(g_et, &ctu, pred, pred_stride, adi, adi_size, size, mode, is_luma);
+	return refh_tu_chain(orig, orig_stride, pred, pred_stride, levels, recon, recon_stride, size, is_dst, scan_mode, comp, 1, slice_is_intra, sign_hiding, per, rem, ac_sum);
+}

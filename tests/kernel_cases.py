@@ -300,12 +300,43 @@ def k_intra_search(lib, prefix, p, rng):
             "last_pred": pred[:n, :n].copy()}
 
 
+def intra_is_filtered(n, mode):
+    """The host-side rule of encode_intra_cu (hmr_motion_intra.c:1011-1012, intra_filter :148)."""
+    thr = {4: 10, 8: 7, 16: 1, 32: 0, 64: 10}[n]
+    return int(mode != 1 and min(abs(mode - 10), abs(mode - 26)) > thr)
+
+
+def k_intra_tu_chain(lib, prefix, p, rng):
+    """encode_intra_cu's data path; the reconstruction goes back into the plane the neighbours come from, like in the reference."""
+    n, comp = p["n"], p["comp"]
+    H = W = 160
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = 128 + p["amp"] * np.sin((xx * np.cos(p["theta"]) + yy * np.sin(p["theta"])) / p["period"])
+    dec = aligned((H, W), np.int16)
+    dec[...] = np.clip(base + rng.integers(-p["noise"], p["noise"] + 1, (H, W)), 0, 255)
+    orig = aligned((64, 64), np.int16)
+    orig[...] = np.clip(base[16:80, 16:80] + rng.integers(-p["noise"], p["noise"] + 1, (64, 64)), 0, 255)
+    pred = aligned((64, 64), np.int16)
+    pred[...] = 0x1234
+    levels = aligned((32 * 32,), np.int16)
+    ac = C.c_int(0)
+    luma = 1 if comp == 0 else 0
+    filt = intra_is_filtered(n, p["mode"]) if luma else 0
+    r = fn(lib, prefix, "intra_tu_chain", C.c_uint32)(
+        ptr(orig), C.c_int(64), ptr(dec, 15 * W + 15), C.c_int(W), C.c_int(p["left"]), C.c_int(p["top"]), C.c_int(p["bl"]), C.c_int(p["tr"]), C.c_int(p["bl_size"]),
+        C.c_int(p["tr_size"]), C.c_int(p["strong"]), C.c_int(filt), C.c_int(p["mode"]), C.c_int(luma), ptr(pred), C.c_int(64), ptr(levels), ptr(dec, 16 * W + 16),
+        C.c_int(W), C.c_int(n), C.c_int(1 if (n == 4 and luma) else 0), C.c_int(p["scan"]), C.c_int(comp), C.c_int(p["slice_i"]), C.c_int(p["sbh"]),
+        C.c_int(p["per"]), C.c_int(p["rem"]), C.byref(ac))
+    return {"pred": pred[:n, :n].copy(), "levels": levels[:n * n].copy(), "plane": dec.copy(), "ssd": np.array([r], np.uint32),
+            "ac_sum": np.array([ac.value], np.int32)}
+
+
 KERNELS = {
     "sad": k_sad, "ssd16b": k_ssd16b, "predict": k_predict, "reconst": k_reconst, "modified_variance": k_modified_variance,
     "copy": k_copy, "intra_planar": k_intra_planar, "intra_angular": k_intra_angular,
     "fill_reference_samples": k_fill_reference_samples, "adi_filter": k_adi_filter, "interpolate": k_interpolate,
     "weighted_average": k_weighted_average, "transform": k_transform, "itransform": k_itransform, "quant": k_quant,
-    "inv_quant": k_inv_quant, "tu_chain": k_tu_chain, "intra_search": k_intra_search,
+    "inv_quant": k_inv_quant, "tu_chain": k_tu_chain, "intra_search": k_intra_search, "intra_tu_chain": k_intra_tu_chain,
 }
 
 
@@ -416,4 +447,14 @@ def all_cases(level="full"):
                 left_mode=int(r.integers(-1, 35)), top_mode=int(r.integers(-1, 35)), rd_mode=int(r.choice([2, 2, 0])),
                 sqrt_lambda=float(r.uniform(2.0, 60.0)), theta=float(r.uniform(0, np.pi)), period=float(r.uniform(3.0, 25.0)),
                 amp=float(r.uniform(5, 90)), tilt=float(r.uniform(-6, 6)), noise=int(r.integers(0, 9)))
+    r = np.random.default_rng(777)
+    for n in (4, 8, 16, 32):
+        for i in range(24 if full else 6):
+            left, top = (int(r.integers(0, 2)), int(r.integers(0, 2))) if i % 6 == 0 else (1, 1)
+            bl, tr = int(r.integers(0, 2)) & left, int(r.integers(0, 2)) & top
+            add("intra_tu_chain", n=n, comp=int(r.choice([0, 0, 1, 2])) if n < 32 else 0, left=left, top=top, bl=bl, tr=tr,
+                bl_size=(n if r.random() < 0.7 else max(n // 2, 4)) if bl else 0, tr_size=(n if r.random() < 0.7 else max(n // 2, 4)) if tr else 0,
+                strong=int(r.integers(0, 2)), mode=int(r.integers(0, 35)), scan=int(r.integers(1, 4)), slice_i=int(r.integers(0, 2)), sbh=int(r.integers(0, 2)),
+                per=int(r.integers(2, 7)), rem=int(r.integers(0, 6)), theta=float(r.uniform(0, np.pi)), period=float(r.uniform(3.0, 25.0)),
+                amp=float(r.uniform(5, 90)), noise=int(r.choice([0, 2, 8, 30])))
     return cases
