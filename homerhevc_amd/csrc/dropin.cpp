@@ -690,4 +690,48 @@ void hmr_gpu_pad_ctu(int16_t *const planes[3], const int strides[3], int width, 
 	}
 }
 
+uint32_t hmr_gpu_intra_tu_chain(int16_t *orig, int orig_stride, int16_t *decoded_corner, int decoded_stride, int left, int top, int bottom_left, int top_right,
+				int bl_size, int tr_size, int strong_enabled, int is_filtered, int mode, int is_luma, int16_t *pred, int pred_stride, int16_t *levels,
+				int16_t *recon, int recon_stride, int size, int is_dst, int scan_mode, int comp, int slice_is_intra, int sign_hiding, int per, int rem,
+				int *ac_sum)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	hmr_gpu_itu_job jb = {};
+	const int n = size, ring = 2 * n + 1;
+	jb.orig_off = (uint32_t)(st.put2d(orig, orig_stride, n, n, 2) / 2); jb.orig_stride = n;
+	// the L-shaped neighbourhood: row 0 and column 0 of a (2n+1)^2 tile
+	const size_t doff = st.zeros((size_t)ring * ring * 2);
+	int16_t *tile = st.host<int16_t>(doff);
+	const int rows = left ? n + (bottom_left ? bl_size : 0) : 0, cols = top ? n + (top_right ? tr_size : 0) : 0;
+	if (left || top) tile[0] = decoded_corner[0];
+	for (int y = 1; y <= rows; y++) tile[(size_t)y * ring] = decoded_corner[(size_t)y * decoded_stride];
+	for (int x = 1; x <= cols; x++) tile[x] = decoded_corner[x];
+	jb.dec_off = (uint32_t)(doff / 2); jb.dec_stride = ring;
+	jb.flags = (uint32_t)(left != 0) | ((uint32_t)(top != 0) << 1) | ((uint32_t)(bottom_left != 0) << 2) | ((uint32_t)(top_right != 0) << 3) |
+		   ((uint32_t)(strong_enabled != 0) << 5) | ((uint32_t)(is_filtered != 0) << 6) | ((uint32_t)(is_luma != 0) << 7);
+	jb.sizes = (uint32_t)bl_size | ((uint32_t)tr_size << 16);
+	jb.mode = (uint32_t)mode;
+	jb.p0 = (uint32_t)(scan_mode & 3) | ((uint32_t)comp << 2) | (1u << 4) | ((uint32_t)(slice_is_intra != 0) << 5) | ((uint32_t)(sign_hiding != 0) << 6) |
+		((uint32_t)(is_dst != 0) << 7);
+	jb.p1 = (uint32_t)per | ((uint32_t)rem << 8);
+	const size_t joff = st.zeros(sizeof jb);
+	st.begin_outputs();
+	const size_t po = st.out((size_t)n * n * 2), lo = st.out((size_t)n * n * 2), ro = st.out((size_t)n * n * 2), so = st.out(4), ao = st.out(4);
+	jb.pred_off = (uint32_t)(po / 2); jb.pred_stride = n;
+	jb.lev_off = (uint32_t)(lo / 2);
+	jb.rec_off = (uint32_t)(ro / 2); jb.rec_stride = n;
+	memcpy(st.host<uint8_t>(joff), &jb, sizeof jb);
+	st.upload();
+	must(hmr_gpu_intra_tu_chain_batch(c, st.dev<hmr_gpu_itu_job>(joff), 1, n, st.dev<int16_t>(), st.dev<int16_t>(), st.dev<int16_t>(), st.dev<int16_t>(),
+					  st.dev<int16_t>(), st.dev<uint32_t>(so), st.dev<int32_t>(ao)),
+	     "intra_tu_chain");
+	st.finish();
+	st.get2d(po, pred, pred_stride, n, n, 2);
+	memcpy(levels, st.host<int16_t>(lo), (size_t)n * n * 2);
+	st.get2d(ro, recon, recon_stride, n, n, 2);
+	*ac_sum = *st.host<int32_t>(ao);
+	return *st.host<uint32_t>(so);
+}
+
 }  // extern "C"

@@ -14,6 +14,7 @@
 // products are exact (|sum| < 2^31), MFMA is not applicable: the stages need exact 32-bit sums with a saturating 16-bit pack
 // in between.  Quantisation / sign hiding run on the LDS image with the 16-lanes-per-coefficient-group mapping of k_quant.
 #include "common.h"
+#include "intra_device.h"
 #include "tq_device.h"
 #include "vec.h"
 
@@ -44,11 +45,17 @@ __device__ __forceinline__ void load_row_lds(int (&row)[N / 2], const int16_t *s
 	for (int i = 0; i < N / 2; i++) row[i] = *reinterpret_cast<const int *>(src + 2 * i);
 }
 
-template <int N>
-__global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const hmr_gpu_tu_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ O,
-							   const int16_t *__restrict__ Pp, int16_t *__restrict__ L, int16_t *__restrict__ Rr,
-							   uint32_t *__restrict__ ssd_out, int32_t *__restrict__ ac_out, const DevTables *__restrict__ tab)
+// INTRA: the job also carries the neighbourhood and the mode; the prediction is generated first (neighbour array, smoothing, planar / DC /
+// angular, lane = row: each lane predicts its row) into the prediction plane and the chain continues as for a given prediction -
+// encode_intra_cu's data path (hmr_motion_intra.c:1011-1068) in one launch.  D = plane under reconstruction (neighbours), Pp = prediction out.
+template <int N, bool INTRA>
+__global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const void *__restrict__ jobs_v, int njobs, const int16_t *__restrict__ O,
+							   int16_t *__restrict__ Pp, int16_t *__restrict__ L, int16_t *__restrict__ Rr,
+							   uint32_t *__restrict__ ssd_out, int32_t *__restrict__ ac_out, const DevTables *__restrict__ tab,
+							   const int16_t *__restrict__ D)
 {
+	using JobT = typename std::conditional<INTRA, hmr_gpu_itu_job, hmr_gpu_tu_job>::type;
+	const JobT *__restrict__ jobs = static_cast<const JobT *>(jobs_v);
 	constexpr int L2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
 	constexpr int E = N * N, P = N + 2;
 	constexpr int TW = HMR_WAVE / N;                       // TUs per wave in the transform mapping (lane = row)
@@ -66,7 +73,7 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 	for (long base = jr.begin; base < jr.end; base += jr.stride) {
 		const long j = base + w * TW + tu;
 		const bool ok = j < jr.end;
-		hmr_gpu_tu_job jb = {};
+		JobT jb = {};
 		int r[N / 2];
 #pragma unroll
 		for (int i = 0; i < N / 2; i++) r[i] = 0;
@@ -75,6 +82,39 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 			jb = jobs[j];
 			orow_p = O + jb.orig_off + (size_t)row * jb.orig_stride;
 			prow_p = Pp + jb.pred_off + (size_t)row * jb.pred_stride;
+		}
+		if constexpr (INTRA) {
+			// N lanes per TU build the 4N+1 neighbours, smooth them when asked, and predict one row each
+			__shared__ int16_t sAdi[HMR_WAVES_PER_BLOCK][TW][2][4 * N + 4];
+			__shared__ int16_t sMain[HMR_WAVES_PER_BLOCK][TW][3 * N + 2];
+			int16_t *adi = sAdi[w][tu][0], *adif = sAdi[w][tu][1], *mainr = sMain[w][tu] + N;
+			const unsigned fl = ok ? jb.flags : 0u;
+			if (ok)
+				intra_build_refs<N, N>(adi, D + jb.dec_off, (int)jb.dec_stride, fl & 1, fl & 2, (fl & 4) ? (int)(jb.sizes & 0xffff) : 0,
+						       (fl & 8) ? (int)(jb.sizes >> 16) : 0, row);
+			wave_sync();
+			const bool filt = (fl >> 6) & 1;
+			if (ok && filt) intra_filter_refs<N, N>(adi, adif, (fl & 32) != 0, row);
+			wave_sync();
+			const IntraMode m = intra_mode_setup(ok ? (int)jb.mode : 0);
+			const int16_t *mid = (filt ? adif : adi) + 2 * N;
+			if (ok) intra_fill_main<N, N>(m, mid, mainr, row);
+			const int dc = intra_dc<N, N>(mid, row, ok && m.mode == 1);
+			wave_sync();
+			if (ok) {
+				const bool edge = ((fl >> 7) & 1) && N <= 16;      // luma edge filters (DC, pure horizontal / vertical)
+				int16_t *pw = Pp + jb.pred_off + (size_t)row * jb.pred_stride;
+#pragma unroll 2
+				for (int x4 = 0; x4 < N; x4 += 4) {
+					i16x4 pv;
+#pragma unroll
+					for (int q = 0; q < 4; q++) pv.v[q] = (int16_t)intra_pixel<N>(m, mid, mainr, dc, edge, x4 + q, row);
+					st4(pw + x4, pv);
+				}
+			}
+			wave_sync();
+		}
+		if (ok) {
 			// K3 predict: residual row (16-bit wrap per sample).  Source and prediction rows are read again for the reconstruction at the
 			// end of the chain (L2-resident) instead of being held in registers across it: the chain is register-bound.
 #pragma unroll
@@ -246,13 +286,14 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 
 }  // namespace
 
-extern "C" int hmr_gpu_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_tu_job *jobs, int njobs, int size, const int16_t *orig_base, const int16_t *pred_base,
-				      int16_t *level_base, int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum)
+template <bool INTRA>
+static int launch_tu_chain(hmr_gpu_ctx *ctx, const void *jobs, int njobs, int size, const int16_t *orig_base, int16_t *pred_base, int16_t *level_base,
+			   int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum, const int16_t *decoded_base)
 {
 	if (njobs <= 0) return HMR_GPU_OK;
 #define TU_LAUNCH(N)                                                                                                                               \
-	hipLaunchKernelGGL((k_tu_chain<N>), dim3(hmr_grid_for_units(((long)njobs + (HMR_WAVE / N) * HMR_WAVES_PER_BLOCK - 1) / ((HMR_WAVE / N) * HMR_WAVES_PER_BLOCK))), \
-			   dim3(HMR_BLOCK), 0, ctx->stream, jobs, njobs, orig_base, pred_base, level_base, recon_base, ssd, ac_sum, ctx->tables)
+	hipLaunchKernelGGL((k_tu_chain<N, INTRA>), dim3(hmr_grid_for_units(((long)njobs + (HMR_WAVE / N) * HMR_WAVES_PER_BLOCK - 1) / ((HMR_WAVE / N) * HMR_WAVES_PER_BLOCK))), \
+			   dim3(HMR_BLOCK), 0, ctx->stream, jobs, njobs, orig_base, pred_base, level_base, recon_base, ssd, ac_sum, ctx->tables, decoded_base)
 	switch (size) {
 	case 4: TU_LAUNCH(4); break;
 	case 8: TU_LAUNCH(8); break;
@@ -260,6 +301,20 @@ extern "C" int hmr_gpu_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_tu_job *jo
 	case 32: TU_LAUNCH(32); break;
 	default: hmr_set_error("tu_chain_batch: TU size must be 4, 8, 16 or 32"); return HMR_GPU_ERR_ARG;
 	}
+#undef TU_LAUNCH
 	HIP_TRY(hipGetLastError());
 	return HMR_GPU_OK;
+}
+
+extern "C" int hmr_gpu_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_tu_job *jobs, int njobs, int size, const int16_t *orig_base, const int16_t *pred_base,
+				      int16_t *level_base, int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum)
+{
+	return launch_tu_chain<false>(ctx, jobs, njobs, size, orig_base, const_cast<int16_t *>(pred_base), level_base, recon_base, ssd, ac_sum, nullptr);
+}
+
+extern "C" int hmr_gpu_intra_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_itu_job *jobs, int njobs, int size, const int16_t *orig_base,
+					    const int16_t *decoded_base, int16_t *pred_base, int16_t *level_base, int16_t *recon_base, uint32_t *ssd,
+					    int32_t *ac_sum)
+{
+	return launch_tu_chain<true>(ctx, jobs, njobs, size, orig_base, pred_base, level_base, recon_base, ssd, ac_sum, decoded_base);
 }

@@ -274,7 +274,9 @@ enum hmr_gpu_op {
 	HMR_GPU_OP_INTRA_REFS, HMR_GPU_OP_INTERPOLATE, HMR_GPU_OP_WAVG, HMR_GPU_OP_TRANSFORM, HMR_GPU_OP_ITRANSFORM, HMR_GPU_OP_QUANT,
 	HMR_GPU_OP_INV_QUANT, HMR_GPU_OP_MC, HMR_GPU_OP_ME, HMR_GPU_OP_EDGE_FLAGS, HMR_GPU_OP_DEBLOCK, HMR_GPU_OP_SAO_STATS, HMR_GPU_OP_SAO_APPLY, HMR_GPU_OP_PAD,
 	HMR_GPU_OP_TU_CHAIN,  /* jobs = hmr_gpu_tu_job*, a = orig base, b = pred base, c = level base, out = ssd; the reconstruction base and ac_sum follow in p64[0..1] */
-	HMR_GPU_OP_INTRA_SEARCH   /* jobs = hmr_gpu_intra_job*, a = orig base, b = decoded base, c = output base, out = hmr_gpu_intra_result* */
+	HMR_GPU_OP_INTRA_SEARCH,  /* jobs = hmr_gpu_intra_job*, a = orig base, b = decoded base, c = output base, out = hmr_gpu_intra_result* */
+	HMR_GPU_OP_INTRA_TU_CHAIN /* jobs = hmr_gpu_itu_job*, a = orig base, b = decoded base, c = level base, out = ssd; p64 = {recon base, ac_sum}; the prediction
+	                           * plane shares the recon base */
 };
 /* One call of the batched / frame-level API: `size` is that entry's size/kind/flags argument, a/b/c/out its pointer arguments in
  * declaration order (frame-level ops take host pointers to hmr_gpu_frame / hmr_gpu_units that must outlive the list), p[] its
@@ -320,6 +322,28 @@ int hmr_gpu_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_tu_job *jobs, int njo
 uint32_t hmr_gpu_tu_chain(int16_t *orig, int orig_stride, int16_t *pred, int pred_stride, int16_t *levels, int16_t *recon, int recon_stride, int size,
 			  int is_dst, int scan_mode, int comp, int is_intra, int slice_is_intra, int sign_hiding, int per, int rem, int *ac_sum);
 
+/* The same chain for an intra TU, prediction included: encode_intra_cu's data path (hmr_motion_intra.c:1011-1068) - neighbour array from the plane
+ * under reconstruction (smoothed when the host's is_filtered rule :1011-1012 says so), planar / DC / angular prediction, then the chain above.
+ * The reconstruction may go back into the plane the neighbours are read from (the reference works in place); jobs of one call must not depend
+ * on each other's reconstruction. */
+typedef struct hmr_gpu_itu_job {
+	uint32_t orig_off, orig_stride;   /* source block */
+	uint32_t pred_off, pred_stride;   /* prediction out (prediction_wnd) */
+	uint32_t rec_off, rec_stride;     /* reconstruction out */
+	uint32_t lev_off;                 /* quantised levels out, linear size*size */
+	uint32_t p0, p1;                  /* as hmr_gpu_tu_job (is_intra is implied) */
+	uint32_t dec_off, dec_stride;     /* corner sample (-1,-1) of the block in the plane under reconstruction */
+	uint32_t flags;                   /* bits 0 left, 1 top, 2 bottom_left, 3 top_right, 5 strong_intra_smooth_enabled, 6 is_filtered, 7 is_luma */
+	uint32_t sizes;                   /* bl_size | tr_size << 16 */
+	uint32_t mode;                    /* 0 planar, 1 DC, 2..34 angular */
+} hmr_gpu_itu_job;
+int hmr_gpu_intra_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_itu_job *jobs, int njobs, int size, const int16_t *orig_base, const int16_t *decoded_base,
+				 int16_t *pred_base, int16_t *level_base, int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum);
+/* host-pointer (drop-in) form; returns the SSD between source and reconstruction.  `recon` may point into the plane `decoded_corner` belongs to. */
+uint32_t hmr_gpu_intra_tu_chain(int16_t *orig, int orig_stride, int16_t *decoded_corner, int decoded_stride, int left, int top, int bottom_left, int top_right,
+				int bl_size, int tr_size, int strong_enabled, int is_filtered, int mode, int is_luma, int16_t *pred, int pred_stride, int16_t *levels,
+				int16_t *recon, int recon_stride, int size, int is_dst, int scan_mode, int comp, int slice_is_intra, int sign_hiding, int per, int rem,
+				int *ac_sum);
 
 /* ------------------------------------------------------------------------------------------------
  * 8. intra mode search of one PU: homer_loop1_motion_intra (hmr_motion_intra.c:1084-1179) - reference build, smoothing,

@@ -282,3 +282,47 @@ void reference_picture_border_padding_ctu(wnd_t *wnd, ctu_info_t *ctu)
 			ctu->y[Y_COMP], ctu->size);
 	if (!said++) fprintf(stderr, "ref_swap: border padding routed to libhomer_gpu.so\n");
 }
+
+/* ---- encode_intra_cu (hmr_motion_intra.c:970): the luma intra TU - neighbour array, prediction and the whole TU chain in one GPU call; the
+ * bookkeeping on the partition node (:1040-1049) stays on the host ---- */
+int find_scan_mode(int is_intra, int is_luma, int width, int dir_mode, int up_left_luma_dir_mode);
+uint encode_intra_cu(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *pi, int depth, int cu_mode, PartSize part_size_type, int *curr_sum, int gcnt)
+{
+	static int said;
+	if (!want("intra_tu_chain"))
+		return ((uint (*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int, int, PartSize, int *, int))REAL(encode_intra_cu))(et, ctu, pi, depth, cu_mode,
+															       part_size_type, curr_sum, gcnt);
+	static const uint8_t filter_thr[5] = {10, 7, 1, 0, 10};                 /* intra_filter, :148 */
+	int curr_depth = pi->depth, x = pi->x_position, y = pi->y_position, size = pi->size;
+	int scan_mode = find_scan_mode(TRUE, TRUE, size, cu_mode, 0);
+	int per = pi->qp / 6, rem = pi->qp % 6;
+	wnd_t *quant_wnd = et->transform_quant_wnd[curr_depth + 1], *decoded_wnd = et->decoded_mbs_wnd[curr_depth + 1];
+	int pred_stride = WND_STRIDE_2D(et->prediction_wnd[0], Y_COMP), orig_stride = WND_STRIDE_2D(et->curr_mbs_wnd, Y_COMP), dec_stride = WND_STRIDE_2D(*decoded_wnd, Y_COMP);
+	int16_t *pred = WND_POSITION_2D(int16_t *, et->prediction_wnd[0], Y_COMP, x, y, gcnt, et->ctu_width);
+	int16_t *orig = WND_POSITION_2D(int16_t *, et->curr_mbs_wnd, Y_COMP, x, y, gcnt, et->ctu_width);
+	int16_t *dec = WND_POSITION_2D(int16_t *, *decoded_wnd, Y_COMP, x, y, gcnt, et->ctu_width);
+	int16_t *quant = WND_POSITION_1D(int16_t *, *quant_wnd, Y_COMP, gcnt, et->ctu_width, (pi->abs_index << et->num_partitions_in_cu_shift));
+	int inv_depth = et->max_cu_size_shift - curr_depth;
+	int diff = min(abs(cu_mode - HOR_IDX), abs(cu_mode - VER_IDX));
+	int is_filtered = (cu_mode != DC_IDX) && (diff > filter_thr[inv_depth - 2]);
+	int bl = min(size, et->pict_height[Y_COMP] - (ctu->y[Y_COMP] + y + size)), tr = min(size, et->pict_width[Y_COMP] - (ctu->x[Y_COMP] + x + size));
+	int shift = curr_depth - depth + (part_size_type == SIZE_NxN);
+	uint32_t ssd;
+	ctu->top = 1;
+	ctu->left = 1;
+	ssd = hmr_gpu_intra_tu_chain(orig, orig_stride, dec - dec_stride - 1, dec_stride, pi->left_neighbour, pi->top_neighbour, pi->left_bottom_neighbour,
+				     pi->top_right_neighbour, bl, tr, et->sps->strong_intra_smooth_enabled_flag, is_filtered, cu_mode, 1, pred, pred_stride, quant, dec,
+				     dec_stride, size, size == 4, scan_mode, Y_COMP, et->enc_engine->current_pict.slice.slice_type == I_SLICE,
+				     et->pps->sign_data_hiding_flag, per, rem, curr_sum);
+	pi->sum = *curr_sum;
+	pi->intra_cbf[Y_COMP] = ((*curr_sum ? 1 : 0) << shift);
+	pi->intra_tr_idx = shift;
+	pi->intra_mode[Y_COMP] = cu_mode;
+	if (et->rd_mode == RD_FULL) {
+		memset(&et->cbf_buffs[Y_COMP][curr_depth][pi->abs_index], ((pi->sum ? 1 : 0) << shift), pi->num_part_in_cu * sizeof(et->cbf_buffs[0][0][0]));
+		memset(&et->tr_idx_buffs[curr_depth][pi->abs_index], shift, pi->num_part_in_cu * sizeof(et->tr_idx_buffs[0][0]));
+		memset(&et->intra_mode_buffs[Y_COMP][curr_depth][pi->abs_index], cu_mode, pi->num_part_in_cu * sizeof(et->intra_mode_buffs[Y_COMP][0][0]));
+	}
+	if (!said++) fprintf(stderr, "ref_swap: intra TU chain routed to libhomer_gpu.so\n");
+	return ssd;
+}

@@ -473,3 +473,58 @@ def test_intra_search(rig, oracle, n):
     same(got["bits"], exp["bits"], "bits")
     same(got["cost"].view(np.uint64), exp["cost"].view(np.uint64), "cost (bit pattern)")
     assert len(set(exp["best_mode"].tolist())) > 8
+
+
+ITU_JOB = np.dtype([("orig_off", "<u4"), ("orig_stride", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("rec_off", "<u4"), ("rec_stride", "<u4"),
+                    ("lev_off", "<u4"), ("p0", "<u4"), ("p1", "<u4"), ("dec_off", "<u4"), ("dec_stride", "<u4"), ("flags", "<u4"), ("sizes", "<u4"), ("mode", "<u4")])
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_intra_tu_chain(rig, oracle, n):
+    from kernel_cases import intra_is_filtered
+    assert ITU_JOB.itemsize == 56
+    rng = np.random.default_rng(n)
+    nj = rig.nj
+    yy, xx = np.mgrid[0:PH, 0:PW]
+    th = np.repeat(np.repeat(rng.uniform(0, np.pi, (PH // 64, PW // 64)), 64, 0), 64, 1)
+    amp = np.repeat(np.repeat(rng.choice([0, 3, 20, 70], (PH // 64, PW // 64)), 64, 0), 64, 1)     # flat areas give all-zero TUs
+    tex = 128 + amp * np.sin((xx * np.cos(th) + yy * np.sin(th)) / 6.0)
+    rig.host[rig.pix:rig.res] = np.clip(tex + rng.integers(-2, 3, (PH, PW)), 0, 255).ravel()
+    rig.host[rig.res:rig.mid] = np.clip(tex + rng.integers(-2, 3, (PH, PW)), 0, 255).ravel()
+    jb = np.zeros(nj, ITU_JOB)
+    x = rng.integers(1, PW - 2 * n - 1, nj); y = rng.integers(1, PH - 2 * n - 1, nj)
+    jb["orig_off"] = rig.res + y * PW + x; jb["orig_stride"] = PW
+    jb["dec_off"] = rig.pix + (y - 1) * PW + x - 1; jb["dec_stride"] = PW
+    s1, s2 = rig.slots(rig.out1), rig.slots(rig.out2)
+    jb["pred_off"] = s1; jb["pred_stride"] = n
+    jb["lev_off"] = s2; jb["rec_off"] = s2 + 2048; jb["rec_stride"] = 80
+    avail = np.where(rng.random(nj) < 0.7, 15, rng.integers(0, 16, nj))
+    left, top = (avail & 1) | ((avail >> 2) & 1), ((avail >> 1) & 1) | ((avail >> 3) & 1)
+    bl, tr = (avail >> 2) & 1, (avail >> 3) & 1
+    strong = rng.integers(0, 2, nj)
+    bl_size = np.where(bl, np.where(rng.random(nj) < 0.6, n, max(n // 2, 4)), 0); tr_size = np.where(tr, np.where(rng.random(nj) < 0.6, n, max(n // 2, 4)), 0)
+    comp = rng.integers(0, 3 if n < 32 else 1, nj); luma = (comp == 0).astype(np.int64)
+    mode = rng.integers(0, 35, nj)
+    filt = np.array([intra_is_filtered(n, int(m)) for m in mode]) * luma
+    jb["flags"] = left | (top << 1) | (bl << 2) | (tr << 3) | (strong << 5) | (filt << 6) | (luma << 7); jb["sizes"] = bl_size | (tr_size << 16)
+    jb["mode"] = mode
+    scan, slice_i, sbh = rng.integers(1, 4, nj), rng.integers(0, 2, nj), rng.integers(0, 2, nj)
+    per, rem = rng.integers(2, 7, nj), rng.integers(0, 6, nj)
+    is_dst = ((n == 4) & (luma == 1)).astype(np.int64)
+    jb["p0"] = scan | (comp << 2) | (1 << 4) | (slice_i << 5) | (sbh << 6) | (is_dst << 7); jb["p1"] = per | (rem << 8)
+    d_ssd = rig.malloc(4 * nj); d_ac = rig.malloc(4 * nj); rig.bufs += [d_ssd, d_ac]
+    g = rig.launch("hmr_gpu_intra_tu_chain_batch", rig.up(jb), nj, n, rig.dev, rig.dev, rig.dev, rig.dev, rig.dev, d_ssd, d_ac)
+    o = rig.host.copy()
+    ssd, ac = np.zeros(nj, np.uint32), np.zeros(nj, np.int32)
+    oracle.ora_intra_tu_chain.restype = C.c_uint32
+    for i, j in enumerate(jb):
+        v = C.c_int(0)
+        ssd[i] = oracle.ora_intra_tu_chain(at(o, j["orig_off"]), PW, at(o, j["dec_off"]), PW, int(left[i]), int(top[i]), int(bl[i]), int(tr[i]), int(bl_size[i]),
+                                           int(tr_size[i]), int(strong[i]), int(filt[i]), int(mode[i]), int(luma[i]), at(o, j["pred_off"]), n, at(o, j["lev_off"]),
+                                           at(o, j["rec_off"]), 80, n, int(is_dst[i]), int(scan[i]), int(comp[i]), int(slice_i[i]), int(sbh[i]), int(per[i]),
+                                           int(rem[i]), C.byref(v))
+        ac[i] = v.value
+    same(g, o, "intra TU chain: prediction, levels, reconstruction")
+    same(rig.down(d_ssd, nj, np.uint32), ssd, "ssd")
+    same(rig.down(d_ac, nj, np.int32), ac, "ac_sum")
+    assert 0.1 < (ac != 0).mean() < 0.98

@@ -39,7 +39,7 @@ def test_stream_identical_with_gpu_kernels(tmp_path, extra, w, h, frames):
     same, _ = _encode(SWAP, clip, str(tmp_path / "none.265"), w, h, frames, env={"HOMER_SWAP": "none"}, extra=extra)
     assert same == ref, "harness itself changes the stream"
     gpu, log = _encode(SWAP, clip, str(tmp_path / "gpu.265"), w, h, frames, env={"HOMER_SWAP": "all"}, extra=extra)
-    for what in ("table entries routed", "intra mode search routed", "deblocking routed", "border padding routed"):
+    for what in ("table entries routed", "intra mode search routed", "intra TU chain routed", "deblocking routed", "border padding routed"):
         assert what in log, (what, log[-600:])
     assert len(ref) > 300
     assert gpu == ref, f"stream differs: {len(gpu)} vs {len(ref)} bytes"
