@@ -87,6 +87,10 @@ INTRA_JOB_DTYPE = np.dtype([("sqrt_lambda", "<f8"), ("orig_off", "<u4"), ("orig_
                             ("adif_off", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("flags", "<u4"), ("sizes", "<u4"), ("preds", "<i4", (3,)),
                             ("pred_bits", "<u4", (3,)), ("other_bits", "<u4"), ("reserved", "<u4")])   # hmr_gpu_intra_job
 assert INTRA_JOB_DTYPE.itemsize == 80
+ITU_JOB_DTYPE = np.dtype([("orig_off", "<u4"), ("orig_stride", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("rec_off", "<u4"), ("rec_stride", "<u4"),
+                          ("lev_off", "<u4"), ("p0", "<u4"), ("p1", "<u4"), ("dec_off", "<u4"), ("dec_stride", "<u4"), ("flags", "<u4"), ("sizes", "<u4"),
+                          ("mode", "<u4")])   # hmr_gpu_itu_job
+assert ITU_JOB_DTYPE.itemsize == 56
 
 
 def build_groups(calls, rng, arena, fused=True):
@@ -105,6 +109,16 @@ def build_groups(calls, rng, arena, fused=True):
     recf = arena.alloc(REF_STRIDE * (HA + 2 * PAD), pix(REF_STRIDE * (HA + 2 * PAD)))   # frame being reconstructed (intra neighbours)
     recf0 = recf + PAD * REF_STRIDE + PAD
     P64, P80 = 64 * 64, 80 * 80
+    # intra TU chains predict from a SMOOTH picture (recs) and code a source that equals it in the upper half of every CTU window and carries
+    # strong noise in the lower half, so that the recorded share of TUs comes out coded
+    yy, xx = np.mgrid[0:HA + 2 * PAD, 0:REF_STRIDE]
+    smooth = np.clip(128 + 60 * np.sin(xx / 53.0) * np.cos(yy / 41.0), 0, 255).astype(np.int16)
+    recs = arena.alloc(smooth.size, smooth.ravel())
+    recs0 = recs + PAD * REF_STRIDE + PAD
+    core = smooth[PAD:PAD + HA, PAD:PAD + W].reshape(HA // 64, 64, W // 64, 64).transpose(0, 2, 1, 3).reshape(-1, 64, 64).astype(np.int64)
+    inoise = np.zeros_like(core)
+    inoise[:, 32:, :] = rng.integers(-40, 41, (core.shape[0], 32, 64))
+    isrc = arena.alloc(core.size, np.clip(core + inoise, 0, 255).astype(np.int16).ravel())
     srcw = arena.alloc(NCTU * P64, pix(NCTU * P64))
     predw = arena.alloc(NCTU * P64, pix(NCTU * P64))
     resw = arena.alloc(NCTU * P64, rng.integers(-255, 256, NCTU * P64).astype(np.int16))
@@ -159,7 +173,7 @@ def build_groups(calls, rng, arena, fused=True):
         kind, _, origin = kind.partition("@")     # interpolation calls carry their caller: @planes (sub-pel plane builders) / @mc
         if fused and (origin or kind == "sad_direct"):
             continue                               # issued as fused sub-pel refinement / motion compensation jobs below
-        if kind in ("mc_luma", "mc_chroma", "half_pel_planes", "quarter_pel_planes", "intra_search"):
+        if kind in ("mc_luma", "mc_chroma", "half_pel_planes", "quarter_pel_planes", "intra_search", "intra_tu"):
             continue
         if kind in ("sad", "sad_direct"):
             N = a[0]
@@ -343,6 +357,44 @@ def build_groups(calls, rng, arena, fused=True):
                 if "@search" in q[0] and int(q[1]) == N:
                     nb += v * {"fill_reference_samples@search": (4 * N + 1) * 2 * 3, "sad@search": 4 * N * N + 4}.get(q[0], 2 * (4 * N + 1) + 2 * N * N)
             merged[("intra_search", N)] = {"name": "intra_search", "fn": "hmr_gpu_intra_search_batch", "size": N, "jobs": jb, "ctu": c, "bytes": nb, "extra": ()}
+        # Intra TU chain (encode_intra_cu): neighbour array + prediction + the seven-call TU chain as one job per luma intra TU
+        for key, n in sorted(calls.items()):
+            kp = key.split(":")
+            if kp[0] != "intra_tu":
+                continue
+            N = int(kp[1])
+            inner = {k2.split(":")[0]: 0 for k2 in calls if "@itu" in k2}
+            nb = 0
+            for k2, v in calls.items():
+                q = k2.split(":")
+                if "@itu" in q[0] and int(q[1]) == N:
+                    inner[q[0]] += v
+                    nb += v * {"fill_reference_samples@itu": (4 * N + 1) * 2 * (3 if int(q[3]) else 2) if q[0].startswith("fill") else 0,
+                               "intra_planar@itu": 2 * (4 * N + 1) + 2 * N * N, "intra_angular@itu": 2 * (4 * N + 1) + 2 * N * N,
+                               "predict@itu": 6 * N * N, "reconst@itu": 6 * N * N, "ssd16b@itu": 4 * N * N + 4}.get(q[0], 4 * N * N)
+            coded_frac = inner.get("inv_quant@itu", 0) / max(inner.get("quant@itu", 1), 1)
+            jb = np.zeros(n, ITU_JOB_DTYPE)
+            c = ctus(n)
+            coded = rng.random(n) < coded_frac
+            # source = the frame under reconstruction's texture at the TU (+ strong noise in the lower half of the CTU window for coded TUs)
+            half = max(32 - N, 0) // N + 1
+            x = rng.integers(0, (64 - N) // N + 1, n) * N
+            y = np.minimum(rng.integers(0, half, n) * N + np.where(coded, 32, 0), 64 - N)
+            pos_in = c * P64 + y * 64 + x
+            jb["orig_off"] = isrc + pos_in; jb["orig_stride"] = 64
+            jb["pred_off"] = predw + pos_in; jb["pred_stride"] = 64
+            jb["rec_off"] = recw + pos_in; jb["rec_stride"] = 64
+            cx, cy = c % NCX, c // NCX
+            jb["dec_off"] = recs0 + (cy * 64 + y - 1) * REF_STRIDE + cx * 64 + x - 1; jb["dec_stride"] = REF_STRIDE
+            lev_pool = arena.alloc(n * N * N)
+            jb["lev_off"] = lev_pool + np.arange(n, dtype=np.int64) * N * N
+            mode = rng.integers(0, 35, n)
+            thr = {4: 10, 8: 7, 16: 1, 32: 0}[N]
+            filt = ((mode != 1) & (np.minimum(np.abs(mode - 10), np.abs(mode - 26)) > thr)).astype(np.int64)
+            jb["flags"] = 15 | 32 | (filt << 6) | (1 << 7); jb["sizes"] = N | (N << 16); jb["mode"] = mode
+            jb["p0"] = 3 | (0 << 2) | (1 << 4) | (0 << 5) | (1 << 6) | ((1 if N == 4 else 0) << 7)     # diagonal scan, luma, P slice, sign hiding on, DST for 4x4
+            jb["p1"] = 5 | (2 << 8)
+            merged[("intra_tu", N)] = {"name": "intra_tu", "fn": "hmr_gpu_intra_tu_chain_batch", "size": N, "jobs": jb, "ctu": c, "bytes": nb, "extra": ()}
         # Motion compensation (hmr_motion_compensation_luma / _chroma): one job per PU and component instead of one or two
         # interpolation calls through the 80-pitch intermediate window.
         refc = arena.alloc(2 * CREF_STRIDE * (HA // 2 + PAD), pix(2 * CREF_STRIDE * (HA // 2 + PAD)))
@@ -594,7 +646,7 @@ def main():
         OPS = {"hmr_gpu_sad_batch": 1, "hmr_gpu_ssd16b_batch": 2, "hmr_gpu_predict_batch": 3, "hmr_gpu_reconst_batch": 4, "hmr_gpu_copy_batch": 5,
                "hmr_gpu_intra_pred_batch": 7, "hmr_gpu_intra_refs_batch": 8, "hmr_gpu_interpolate_batch": 9, "hmr_gpu_transform_batch": 11,
                "hmr_gpu_itransform_batch": 12, "hmr_gpu_quant_batch": 13, "hmr_gpu_inv_quant_batch": 14, "hmr_gpu_mc_batch": 15,
-               "hmr_gpu_motion_estimation_batch": 16, "hmr_gpu_tu_chain_batch": 22, "hmr_gpu_intra_search_batch": 23}
+               "hmr_gpu_motion_estimation_batch": 16, "hmr_gpu_tu_chain_batch": 22, "hmr_gpu_intra_search_batch": 23, "hmr_gpu_intra_tu_chain_batch": 24}
         OP_EDGE, OP_DEBLOCK, OP_STATS, OP_APPLY, OP_PAD = 17, 18, 19, 20, 21
         cmds, names = [], []
         for g in groups:
@@ -610,6 +662,9 @@ def main():
             if g["fn"] == "hmr_gpu_intra_search_batch":
                 g["d_out"] = torch.zeros(4 * len(g["jobs"]), dtype=torch.int32, device=dev)     # hmr_gpu_intra_result per PU
                 cm.out = g["d_out"].data_ptr()
+            if g["fn"] == "hmr_gpu_intra_tu_chain_batch":
+                g["d_ac"] = torch.zeros(len(g["jobs"]), dtype=torch.int32, device=dev)
+                cm.p64 = (P * 2)(base, g["d_ac"].data_ptr())   # reconstruction / prediction base, ac_sum
             if g["fn"] == "hmr_gpu_tu_chain_batch":
                 g["d_ac"] = torch.zeros(len(g["jobs"]), dtype=torch.int32, device=dev)
                 cm.p64 = (P * 2)(base, g["d_ac"].data_ptr())   # reconstruction base, ac_sum

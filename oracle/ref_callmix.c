@@ -24,11 +24,19 @@ static struct { char key[64]; long n; } g_cnt[MAXKEYS];
 static int g_nkeys;
 static low_level_funcs_t g_orig;
 
+/* calls made from inside a driver that the GPU side replaces as a whole are keyed name@driver:... */
+static __thread const char *g_sfx = "";
 static void bump(const char *fmt, int a, int b, int c, int d)
 {
-	char key[64];
+	char key[64], raw[64];
 	int i;
-	snprintf(key, sizeof key, fmt, a, b, c, d);
+	snprintf(raw, sizeof raw, fmt, a, b, c, d);
+	if (*g_sfx && !strchr(raw, '@')) {
+		const char *colon = strchr(raw, ':');
+		size_t n = colon ? (size_t)(colon - raw) : strlen(raw);
+		snprintf(key, sizeof key, "%.*s%s%s", (int)n, raw, g_sfx, colon ? colon : "");
+	} else
+		snprintf(key, sizeof key, "%s", raw);
 	for (i = 0; i < g_nkeys; i++)
 		if (!strcmp(g_cnt[i].key, key)) { g_cnt[i].n++; return; }
 	if (g_nkeys < MAXKEYS) { strcpy(g_cnt[g_nkeys].key, key); g_cnt[g_nkeys++].n = 1; }
@@ -37,17 +45,15 @@ static void bump(const char *fmt, int a, int b, int c, int d)
 static void w_c1616(void *s, uint32_t ss, void *d, uint32_t ds, int h, int w) { bump("copy_16_16:%d:%d", h, w, 0, 0); g_orig.sse_copy_16_16(s, ss, d, ds, h, w); }
 static void w_c168(void *s, uint32_t ss, void *d, uint32_t ds, int h, int w) { bump("copy_16_8:%d:%d", h, w, 0, 0); g_orig.sse_copy_16_8(s, ss, d, ds, h, w); }
 static void w_c816(void *s, uint32_t ss, void *d, uint32_t ds, int h, int w) { bump("copy_8_16:%d:%d", h, w, 0, 0); g_orig.sse_copy_8_16(s, ss, d, ds, h, w); }
-/* calls made from inside the intra mode search driver (homer_loop1_motion_intra) are keyed @search */
-static __thread int g_in_search;
-static uint32_t w_sad(int16_t *s, uint32_t ss, int16_t *p, uint32_t ps, int n) { bump(g_in_search ? "sad@search:%d" : "sad:%d", n, 0, 0, 0); return g_orig.sad(s, ss, p, ps, n); }
+static uint32_t w_sad(int16_t *s, uint32_t ss, int16_t *p, uint32_t ps, int n) { bump("sad:%d", n, 0, 0, 0); return g_orig.sad(s, ss, p, ps, n); }
 static uint32_t w_ssd(int16_t *s, uint32_t ss, int16_t *p, uint32_t ps, int n) { bump("ssd16b:%d:%d", n, ps == 0, 0, 0); return g_orig.ssd16b(s, ss, p, ps, n); }
 static void w_predict(int16_t *o, int os, int16_t *p, int ps, int16_t *r, int rs, int n) { bump("predict:%d", n, 0, 0, 0); g_orig.predict(o, os, p, ps, r, rs, n); }
 static void w_reconst(int16_t *p, int ps, int16_t *r, int rs, int16_t *d, int ds, int n) { bump("reconst:%d:%d", n, rs == 0, 0, 0); g_orig.reconst(p, ps, r, rs, d, ds, n); }
 static uint32_t w_var(int16_t *p, int size, int stride, int modif) { bump("modified_variance:%d:%d", size, modif, 0, 0); return g_orig.modified_variance(p, size, stride, modif); }
-static void w_planar(henc_thread_t *et, int16_t *pr, int ps, int16_t *adi, int as, int n, int sh) { bump(g_in_search ? "intra_planar@search:%d" : "intra_planar:%d", n, 0, 0, 0); g_orig.create_intra_planar_prediction(et, pr, ps, adi, as, n, sh); }
+static void w_planar(henc_thread_t *et, int16_t *pr, int ps, int16_t *adi, int as, int n, int sh) { bump("intra_planar:%d", n, 0, 0, 0); g_orig.create_intra_planar_prediction(et, pr, ps, adi, as, n, sh); }
 static void w_ang(henc_thread_t *et, ctu_info_t *ctu, int16_t *pr, int ps, int16_t *adi, int as, int n, int mode, int luma)
 {
-	bump(g_in_search ? "intra_angular@search:%d:%d:%d" : "intra_angular:%d:%d:%d", n, mode, luma, 0);
+	bump("intra_angular:%d:%d:%d", n, mode, luma, 0);
 	g_orig.create_intra_angular_prediction(et, ctu, pr, ps, adi, as, n, mode, luma);
 }
 /* where an interpolation call comes from: 0 = direct, 1 = sub-pel plane builders, 2 = motion compensation */
@@ -98,7 +104,7 @@ uint32_t sad(int16_t *s, uint32_t ss, int16_t *p, uint32_t ps, int n)
 }
 void fill_reference_samples(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *pi, int adi_size, int16_t *dec, int stride, int n, int comp, int filt)
 {
-	bump(g_in_search ? "fill_reference_samples@search:%d:%d:%d" : "fill_reference_samples:%d:%d:%d", n, comp != 0, filt, 0);
+	bump("fill_reference_samples:%d:%d:%d", n, comp != 0, filt, 0);
 	((void (*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int, int16_t *, int, int, int, int))REAL(fill_reference_samples))(et, ctu, pi, adi_size, dec, stride, n, comp, filt);
 }
 int homer_loop1_motion_intra(henc_thread_t *et, ctu_info_t *ctu, ctu_info_t *ctu_rd, cu_partition_info_t *pi, int16_t *pred_buff, int pred_buff_stride,
@@ -107,12 +113,22 @@ int homer_loop1_motion_intra(henc_thread_t *et, ctu_info_t *ctu, ctu_info_t *ctu
 {
 	int r;
 	bump("intra_search:%d", size, 0, 0, 0);
-	g_in_search = 1;
+	g_sfx = "@search";
 	r = ((int (*)(henc_thread_t *, ctu_info_t *, ctu_info_t *, cu_partition_info_t *, int16_t *, int, int16_t *, int, int16_t *, int, int, int, int, int, int, int,
 		      int *, double *))REAL(homer_loop1_motion_intra))(et, ctu, ctu_rd, pi, pred_buff, pred_buff_stride, orig_buff, orig_buff_stride, decoded_buff,
 								       decoded_buff_stride, depth, curr_depth, size, size_shift, part_size_type, adi_size,
 								       best_pred_modes, best_pred_cost);
-	g_in_search = 0;
+	g_sfx = "";
+	return r;
+}
+uint encode_intra_cu(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *pi, int depth, int cu_mode, PartSize part_size_type, int *curr_sum, int gcnt)
+{
+	uint r;
+	bump("intra_tu:%d", pi->size, 0, 0, 0);
+	g_sfx = "@itu";
+	r = ((uint (*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int, int, PartSize, int *, int))REAL(encode_intra_cu))(et, ctu, pi, depth, cu_mode, part_size_type,
+														    curr_sum, gcnt);
+	g_sfx = "";
 	return r;
 }
 void hmr_half_pixel_estimation_luma_hm(henc_thread_t *et, int16_t *r, int rs, cu_partition_info_t *cu, int w, int h, int sh, motion_vector_t *mv)
