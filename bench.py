@@ -548,7 +548,7 @@ def cpu_baseline(frames=None):
             return None
         kv = run(())
         # the reference's throughput mode inside one engine: one WPP thread per CTU row, as many as the host has cores for (not deterministic)
-        threads = max(1, min((H + 63) // 64, os.cpu_count() or 1))
+        threads = max(1, min((H + 63) // 64, os.cpu_count() or 1, 32))      # the reference caps WPP threads at 32 (hmr_private.h:1232)
         kv_mt = run((f"wpp={threads}",)) if threads > 1 else None
     if not kv:
         return None
