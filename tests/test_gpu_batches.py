@@ -20,6 +20,7 @@ ME_JOB = np.dtype([("corr", "<f8"), ("orig_off", "<u4"), ("orig_stride", "<u4"),
                    ("init_x", "<i2"), ("init_y", "<i2"), ("n_amvp", "<i2"), ("n_search", "<i2"), ("amvp", "<i2", (2, 2)), ("search", "<i2", (5, 2)),
                    ("action", "<u4"), ("reserved", "<u4")])
 VP = C.c_void_p
+SEED = int(__import__("os").environ.get("HOMER_TEST_SEED", "0"))     # fuzzing: HOMER_TEST_SEED=k reseeds every case
 NJ = 611                      # odd on purpose: ragged last wavefront / last XCD chunk
 PW, PH = 512, 320             # input planes
 SLOT = 80 * 80                # one output slot per job
@@ -90,7 +91,7 @@ def rig(request):
     frame-sized batches."""
     gpu = libs.load_gpu()
     assert gpu.hmr_gpu_set_max_grid(request.param) == 0
-    r = Rig(gpu, np.random.default_rng(77))
+    r = Rig(gpu, np.random.default_rng(77 + SEED))
     yield r
     r.close()
     gpu.hmr_gpu_set_max_grid(4096)
@@ -109,7 +110,7 @@ def same(got, exp, what):
 @pytest.mark.parametrize("which", ["sad", "ssd16b"])
 @pytest.mark.parametrize("n", [4, 8, 16, 32, 64])
 def test_sad_ssd(rig, oracle, which, n):
-    rng = np.random.default_rng(n)
+    rng = np.random.default_rng(n + 1000 * SEED)
     jb = np.zeros(rig.nj, JOB)
     jb["a_off"] = rig.block(rng, rig.pix, n, n); jb["a_stride"] = PW
     jb["b_off"] = rig.block(rng, rig.res if which == "ssd16b" else rig.pix, n, n); jb["b_stride"] = PW
@@ -128,7 +129,7 @@ def test_sad_ssd(rig, oracle, which, n):
 
 @pytest.mark.parametrize("n", [4, 8, 16, 32, 64])
 def test_predict_reconst(rig, oracle, n):
-    rng = np.random.default_rng(n)
+    rng = np.random.default_rng(n + 1000 * SEED)
     jb = np.zeros(rig.nj, JOB)
     jb["a_off"] = rig.block(rng, rig.pix, n, n); jb["a_stride"] = PW
     jb["b_off"] = rig.block(rng, rig.pix, n, n); jb["b_stride"] = PW
@@ -149,7 +150,7 @@ def test_predict_reconst(rig, oracle, n):
 
 @pytest.mark.parametrize("square", [0, 4, 8, 16, 32, 64])
 def test_copy(rig, oracle, square):
-    rng = np.random.default_rng(square)
+    rng = np.random.default_rng(square + 1000 * SEED)
     jb = np.zeros(rig.nj, JOB)
     if square:
         jb["w"] = jb["h"] = square
@@ -174,7 +175,7 @@ def test_copy(rig, oracle, square):
 
 @pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64])
 def test_modified_variance(rig, oracle, n):
-    rng = np.random.default_rng(n)
+    rng = np.random.default_rng(n + 1000 * SEED)
     jb = np.zeros(rig.nj, JOB)
     jb["a_off"] = rig.block(rng, rig.pix, n, n); jb["a_stride"] = PW
     jb["p0"] = rng.integers(1, 3, rig.nj)
@@ -188,7 +189,7 @@ def test_modified_variance(rig, oracle, n):
 
 @pytest.mark.parametrize("n", [4, 8, 16, 32, 64])
 def test_intra_pred_and_refs(rig, oracle, n):
-    rng = np.random.default_rng(n)
+    rng = np.random.default_rng(n + 1000 * SEED)
     jb = np.zeros(rig.nj, JOB)
     jb["a_off"] = rig.pix + rng.integers(0, PW * PH - 4 * n - 1, rig.nj)
     jb["c_off"] = rig.slots(rig.out1); jb["c_stride"] = 80
@@ -226,7 +227,7 @@ def test_intra_pred_and_refs(rig, oracle, n):
 @pytest.mark.parametrize("luma", [1, 0])
 @pytest.mark.parametrize("lanes", [4, 8, 16, 32, 64])
 def test_interpolate(rig, oracle, luma, lanes):
-    rng = np.random.default_rng(luma * 100 + lanes)
+    rng = np.random.default_rng(luma * 100 + lanes + 1000 * SEED)
     taps = 8 if luma else 4
     for first in (1, 0):
         jb = np.zeros(rig.nj, JOB)
@@ -246,7 +247,7 @@ def test_interpolate(rig, oracle, luma, lanes):
 
 
 def test_weighted_average(rig, oracle):
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(5 + 1000 * SEED)
     jb = np.zeros(rig.nj, JOB)
     n = 1 << rng.integers(2, 7, rig.nj)
     jb["w"] = n; jb["h"] = np.where(rng.random(rig.nj) < 0.2, np.maximum(n // 2, 4), n)
@@ -262,7 +263,7 @@ def test_weighted_average(rig, oracle):
 
 @pytest.mark.parametrize("n", [4, 8, 16, 32])
 def test_transform_quant(rig, oracle, n):
-    rng = np.random.default_rng(n)
+    rng = np.random.default_rng(n + 1000 * SEED)
     is_dst = rng.integers(0, 2, rig.nj) if n == 4 else np.zeros(rig.nj, np.int64)
     jb = np.zeros(rig.nj, JOB)
     jb["a_off"] = rig.block(rng, rig.res, n, n); jb["a_stride"] = PW
@@ -320,7 +321,7 @@ def test_transform_quant(rig, oracle, n):
 
 @pytest.mark.parametrize("n", [4, 8, 16, 32])
 def test_tu_chain(rig, oracle, n):
-    rng = np.random.default_rng(n)
+    rng = np.random.default_rng(n + 1000 * SEED)
     # prediction = source + noise of a per-job strength, so coded and all-zero TUs mix inside one wavefront
     src = rig.host[rig.pix:rig.res].reshape(PH, PW)
     noise = rng.integers(-1, 2, (PH, PW)) * np.repeat(np.repeat(rng.choice([0, 2, 12, 60], (PH // 32, PW // 32)), 32, 0), 32, 1)
@@ -353,7 +354,7 @@ def test_tu_chain(rig, oracle, n):
 @pytest.mark.parametrize("lanes", [4, 8, 16, 32, 64])
 @pytest.mark.parametrize("is_bi", [0, 1])
 def test_motion_compensation(rig, oracle, luma, lanes, is_bi):
-    rng = np.random.default_rng(luma * 10 + lanes + is_bi)
+    rng = np.random.default_rng(luma * 10 + lanes + is_bi + 1000 * SEED)
     jb = np.zeros(rig.nj, JOB)
     if luma:   # deliberately includes blocks larger than the hint's LDS share (the kernel's recompute path)
         n = np.array([8, 16, 32, 64])[rng.integers(0, 4, rig.nj)]
@@ -380,7 +381,7 @@ def test_motion_compensation(rig, oracle, luma, lanes, is_bi):
 @pytest.mark.parametrize("n", [8, 16, 32, 64])
 @pytest.mark.parametrize("action", [7, 6, 1, 3])
 def test_motion_estimation(rig, oracle, n, action):
-    rng = np.random.default_rng(n + action)
+    rng = np.random.default_rng(n + action + 1000 * SEED)
     nj = rig.nj if n < 64 else 97
     # a reference with structure (so the search has something to find): the source plane is the reference shifted + noise
     ref = rig.host[rig.pix:rig.res].reshape(PH, PW)
@@ -429,7 +430,7 @@ INTRA_RES = np.dtype([("best_mode", "<i4"), ("bits", "<i4"), ("cost", "<f8")])
 def test_intra_search(rig, oracle, n):
     from kernel_cases import mpm_list
     assert INTRA_JOB.itemsize == 80 and INTRA_RES.itemsize == 16
-    rng = np.random.default_rng(n)
+    rng = np.random.default_rng(n + 1000 * SEED)
     nj = rig.nj if n < 64 else 151
     # directional texture so that different modes win; the source is the same texture plus noise
     yy, xx = np.mgrid[0:PH, 0:PW]
@@ -483,7 +484,7 @@ ITU_JOB = np.dtype([("orig_off", "<u4"), ("orig_stride", "<u4"), ("pred_off", "<
 def test_intra_tu_chain(rig, oracle, n):
     from kernel_cases import intra_is_filtered
     assert ITU_JOB.itemsize == 56
-    rng = np.random.default_rng(n)
+    rng = np.random.default_rng(n + 1000 * SEED)
     nj = rig.nj
     yy, xx = np.mgrid[0:PH, 0:PW]
     th = np.repeat(np.repeat(rng.uniform(0, np.pi, (PH // 64, PW // 64)), 64, 0), 64, 1)
