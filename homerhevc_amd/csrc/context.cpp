@@ -33,7 +33,7 @@ extern "C" int hmr_gpu_create(hmr_gpu_ctx **out, int device, void *stream)
 	HIP_TRY(hipEventCreate(&c->ev1));
 	HIP_TRY(hipMalloc((void **)&c->tables, sizeof(DevTables)));
 	HIP_TRY(hipMemcpy(c->tables, hmr_host_tables(), sizeof(DevTables), hipMemcpyHostToDevice));
-	c->stage_bytes = 4u << 20;
+	c->stage_bytes = 64u << 20;   // largest drop-in operand: a whole 2160p picture going through sse_copy_8_16 (8 MB in, 17 MB out)
 	HIP_TRY(hipHostMalloc((void **)&c->h_stage, c->stage_bytes, hipHostMallocDefault));
 	HIP_TRY(hipMalloc((void **)&c->d_stage, c->stage_bytes));
 	*out = c;

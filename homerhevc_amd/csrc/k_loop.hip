@@ -338,7 +338,42 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_pad(int16_t *pic, int stride, int
 	pic[(ptrdiff_t)y * stride + x] = pic[(ptrdiff_t)clip3i(y, 0, height - 1) * stride + clip3i(x, 0, width - 1)];
 }
 
+// per-CTU z-order side-info (ctu_info_t, hmr_private.h:792-843) -> raster arrays over the picture; abs2raster_table
+// (hmr_encoder_lib.c:95-100) is the Morton de-interleave of the unit index.  One thread per unit.
+__global__ __launch_bounds__(HMR_BLOCK) void k_units_from_ctus(hmr_gpu_ctu_units src, int ctus_x, int n_units, int units_stride, int16_t *__restrict__ mvx,
+								  int16_t *__restrict__ mvy, int8_t *__restrict__ ref_idx, uint8_t *__restrict__ qp,
+								  uint8_t *__restrict__ flags, uint8_t *__restrict__ pred_depth, uint8_t *__restrict__ tr_idx)
+{
+	const int s = blockIdx.x * HMR_BLOCK + threadIdx.x;
+	if (s >= n_units) return;
+	const int c = s >> 8, a = s & 255;
+	int x = 0, y = 0;
+#pragma unroll
+	for (int b = 0; b < 4; b++) {
+		x |= ((a >> (2 * b)) & 1) << b;
+		y |= ((a >> (2 * b + 1)) & 1) << b;
+	}
+	const size_t o = (size_t)((c / ctus_x) * 16 + y) * units_stride + (c % ctus_x) * 16 + x;
+	mvx[o] = src.mvx[s]; mvy[o] = src.mvy[s]; ref_idx[o] = src.ref_idx[s]; qp[o] = src.qp[s];
+	const int tr = src.tr_idx[s];
+	flags[o] = (uint8_t)((src.pred_mode[s] == 1 ? F_INTRA : 0) | (((src.cbf_y[s] >> tr) & 1) ? F_CBF : 0));   // INTRA_MODE = 1 (hmr_private.h:221), CBF() hmr_common.h:73
+	if (pred_depth) pred_depth[o] = src.pred_depth[s];
+	if (tr_idx) tr_idx[o] = (uint8_t)tr;
+}
+
 }  // namespace
+
+extern "C" int hmr_gpu_units_from_ctus(hmr_gpu_ctx *ctx, const hmr_gpu_ctu_units *src, int ctus_x, int ctus_y, const hmr_gpu_units *dst, uint8_t *pred_depth,
+				       uint8_t *tr_idx)
+{
+	if (!src || !dst || ctus_x <= 0 || ctus_y <= 0 || dst->units_stride < ctus_x * 16) return HMR_GPU_ERR_ARG;
+	const int n = ctus_x * ctus_y * 256;
+	hipLaunchKernelGGL(k_units_from_ctus, dim3((n + HMR_BLOCK - 1) / HMR_BLOCK), dim3(HMR_BLOCK), 0, ctx->stream, *src, ctus_x, n, dst->units_stride,
+			   const_cast<int16_t *>(dst->mvx), const_cast<int16_t *>(dst->mvy), const_cast<int8_t *>(dst->ref_idx), const_cast<uint8_t *>(dst->qp), dst->flags,
+			   pred_depth, tr_idx);
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
 
 extern "C" int hmr_gpu_edge_flags_frame(hmr_gpu_ctx *ctx, const uint8_t *pred_depth, const uint8_t *tr_idx, int width, int height, int units_stride,
 					uint8_t *flags)

@@ -203,6 +203,17 @@ typedef struct hmr_gpu_units {
 	uint8_t *flags;
 } hmr_gpu_units;
 
+/* The same side-info as the encoder keeps it: per CTU, 256 entries in z-order (ctu_info_t: mv_ref[0], mv_ref_idx[0], qp, pred_mode, cbf[Y_COMP],
+ * pred_depth, tr_idx), CTU-major.  hmr_gpu_units_from_ctus re-orders it on the device into the raster arrays above (abs2raster_table,
+ * hmr_encoder_lib.c:95-100; flags = INTRA | CBF_Y at the unit's tr_idx) plus raster pred_depth / tr_idx for hmr_gpu_edge_flags_frame. */
+typedef struct hmr_gpu_ctu_units {
+	const int16_t *mvx, *mvy;
+	const int8_t *ref_idx;
+	const uint8_t *qp, *pred_mode, *cbf_y, *pred_depth, *tr_idx;
+} hmr_gpu_ctu_units;
+int hmr_gpu_units_from_ctus(hmr_gpu_ctx *ctx, const hmr_gpu_ctu_units *src, int ctus_x, int ctus_y, const hmr_gpu_units *dst, uint8_t *pred_depth_raster,
+			    uint8_t *tr_idx_raster);
+
 /* derive the EDGE bits of flags[] from the coding tree: pred_depth + tr_idx per unit (hmr_deblocking_filter.c:737-825) */
 int hmr_gpu_edge_flags_frame(hmr_gpu_ctx *ctx, const uint8_t *pred_depth, const uint8_t *tr_idx, int width, int height, int units_stride, uint8_t *flags);
 /* hmr_deblock_filter_cu over the picture (hmr_deblocking_filter.c:737): boundary strength, luma strong/weak, chroma; in place.

@@ -1151,3 +1151,33 @@ uint32_t ora_intra_tu_chain(const int16_t *orig, int orig_stride, const int16_t 
 			    ac_sum);
 }
 
+/* ====================================================================================================
+ * Side-info layout (a3): ctu_info_t keeps its per-unit arrays in z-order inside each CTU (hmr_private.h:792-843); the in-loop
+ * kernels take raster arrays over the picture.  abs2raster_table (hmr_encoder_lib.c:95-100) is the Morton de-interleave:
+ * x from the even bits, y from the odd bits of the z-order index.
+ * ==================================================================================================== */
+int ora_zscan_to_raster(int a)
+{
+	int x = 0, y = 0, b;
+	for (b = 0; b < 4; b++) {
+		x |= ((a >> (2 * b)) & 1) << b;
+		y |= ((a >> (2 * b + 1)) & 1) << b;
+	}
+	return y * 16 + x;
+}
+/* src arrays: ctus * 256 entries each (CTU-major, z-order inside); dst arrays: raster, units_stride per row */
+void ora_units_from_ctus(const int16_t *mvx, const int16_t *mvy, const int8_t *ref_idx, const uint8_t *qp, const uint8_t *pred_mode, const uint8_t *cbf_y,
+			 const uint8_t *pred_depth, const uint8_t *tr_idx, int ctus_x, int ctus_y, int units_stride, int16_t *o_mvx, int16_t *o_mvy,
+			 int8_t *o_ref, uint8_t *o_qp, uint8_t *o_flags, uint8_t *o_pred_depth, uint8_t *o_tr_idx)
+{
+	int c, a;
+	for (c = 0; c < ctus_x * ctus_y; c++)
+		for (a = 0; a < 256; a++) {
+			const int r = ora_zscan_to_raster(a), s = c * 256 + a;
+			const size_t o = (size_t)((c / ctus_x) * 16 + r / 16) * units_stride + (c % ctus_x) * 16 + r % 16;
+			o_mvx[o] = mvx[s]; o_mvy[o] = mvy[s]; o_ref[o] = ref_idx[s]; o_qp[o] = qp[s];
+			o_flags[o] = (uint8_t)((pred_mode[s] == 1 ? ORA_UNIT_INTRA : 0) | (((cbf_y[s] >> tr_idx[s]) & 1) ? 2 : 0));   /* INTRA_MODE = 1; CBF() hmr_common.h:73 */
+			o_pred_depth[o] = pred_depth[s]; o_tr_idx[o] = tr_idx[s];
+		}
+}
+

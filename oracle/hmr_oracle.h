@@ -113,6 +113,12 @@ void ora_intra_search(const int16_t *orig, int orig_stride, const int16_t *decod
 		      int top_right, int bl_size, int tr_size, int strong_enabled, const int32_t *preds, const int32_t *pred_bits, int other_bits,
 		      double sqrt_lambda, int16_t *adi, int16_t *adi_filtered, int16_t *pred, int pred_stride, int32_t *out, double *best_cost);
 
+/* ---- side-info layout: per-CTU z-order -> picture raster (abs2raster_table, hmr_encoder_lib.c:95-100) ---- */
+int ora_zscan_to_raster(int a);
+void ora_units_from_ctus(const int16_t *mvx, const int16_t *mvy, const int8_t *ref_idx, const uint8_t *qp, const uint8_t *pred_mode, const uint8_t *cbf_y,
+			 const uint8_t *pred_depth, const uint8_t *tr_idx, int ctus_x, int ctus_y, int units_stride, int16_t *o_mvx, int16_t *o_mvy,
+			 int8_t *o_ref, uint8_t *o_qp, uint8_t *o_flags, uint8_t *o_pred_depth, uint8_t *o_tr_idx);
+
 /* ---- intra TU: neighbour array + prediction + TU chain (encode_intra_cu, hmr_motion_intra.c:1011-1068), returns the SSD ---- */
 uint32_t ora_intra_tu_chain(const int16_t *orig, int orig_stride, const int16_t *decoded_corner, int decoded_stride, int left, int top, int bottom_left,
 			    int top_right, int bl_size, int tr_size, int strong_enabled, int is_filtered, int mode, int is_luma, int16_t *pred, int pred_stride,

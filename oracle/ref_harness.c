@@ -564,3 +564,10 @@ uint32_t refh_intra_tu_chain(int16_t *orig, int orig_stride, int16_t *decoded_co
 	else g_enc->funcs.create_intra_angular_prediction(g_et, &ctu, pred, pred_stride, adi, adi_size, size, mode, is_luma);
 	return refh_tu_chain(orig, orig_stride, pred, pred_stride, levels, recon, recon_stride, size, is_dst, scan_mode, comp, 1, slice_is_intra, sign_hiding, per, rem, ac_sum);
 }
+
+/* abs2raster_table (hmr_encoder_lib.c:95-100, g_auiZscanToRaster): z-order index of a 4x4 unit inside a 64x64 CTU -> raster index (16 per row) */
+void refh_abs2raster(int32_t *out256)
+{
+	int a;
+	for (a = 0; a < 256; a++) out256[a] = g_enc->abs2raster_table[a];
+}

@@ -144,3 +144,32 @@ def test_full_size_pictures_match_oracle(gpu, oracle, width, height):
     for pl, pad in zip(got["padded"], (fc.PAD_X, fc.PAD_X // 2, fc.PAD_X // 2)):
         inner = pl[pad:-pad, pad:-pad]
         assert np.array_equal(pl, np.pad(inner, pad, mode="edge"))
+
+
+def test_units_from_ctus(gpu, oracle):
+    """a3 on the device: the encoder's per-CTU z-order side-info re-ordered into the raster arrays the in-loop kernels take."""
+    rng = np.random.default_rng(3)
+    ctus_x, ctus_y = 7, 3
+    n = ctus_x * ctus_y * 256
+    src = {"mvx": rng.integers(-200, 201, n).astype(np.int16), "mvy": rng.integers(-200, 201, n).astype(np.int16), "ref_idx": rng.integers(-1, 2, n).astype(np.int8),
+           "qp": rng.integers(10, 50, n).astype(np.uint8), "pred_mode": rng.integers(0, 3, n).astype(np.uint8), "cbf_y": rng.integers(0, 8, n).astype(np.uint8),
+           "pred_depth": rng.integers(0, 4, n).astype(np.uint8), "tr_idx": rng.integers(0, 3, n).astype(np.uint8)}
+    us = ctus_x * 16 + 5
+    shape = (ctus_y * 16, us)
+    exp = {k: np.full(shape, 77, d) for k, d in (("mvx", np.int16), ("mvy", np.int16), ("ref", np.int8), ("qp", np.uint8), ("flags", np.uint8), ("pd", np.uint8), ("tr", np.uint8))}
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    oracle.ora_units_from_ctus(*[vp(src[k]) for k in ("mvx", "mvy", "ref_idx", "qp", "pred_mode", "cbf_y", "pred_depth", "tr_idx")], ctus_x, ctus_y, us,
+                               *[vp(exp[k]) for k in ("mvx", "mvy", "ref", "qp", "flags", "pd", "tr")])
+    s = fc.GpuSession(gpu)
+    try:
+        class CtuUnits(C.Structure):
+            _fields_ = [(k, C.c_void_p) for k in ("mvx", "mvy", "ref_idx", "qp", "pred_mode", "cbf_y", "pred_depth", "tr_idx")]
+        cu = CtuUnits(*[s.up(src[k]) for k in ("mvx", "mvy", "ref_idx", "qp", "pred_mode", "cbf_y", "pred_depth", "tr_idx")])
+        dev = {k: s.up(np.full(shape, 77, v.dtype)) for k, v in exp.items()}
+        units = fc.Units(us, dev["mvx"], dev["mvy"], dev["ref"], dev["qp"], dev["flags"])
+        assert gpu.hmr_gpu_units_from_ctus(s.ctx, C.byref(cu), ctus_x, ctus_y, C.byref(units), dev["pd"], dev["tr"]) == 0
+        assert gpu.hmr_gpu_sync(s.ctx) == 0
+        for k in exp:
+            assert np.array_equal(s.down(dev[k], exp[k]), exp[k]), k
+    finally:
+        s.close()

@@ -29,3 +29,15 @@ def test_oracle_frames_match_reference_goldens(oracle):
         # the fixture must exercise the filters, not just pass through
         assert (got["deblocked"][0] != case["pre"][0]).sum() > 2000
         assert (got["sao"][0] != got["deblocked"][0]).sum() > 500
+
+
+def test_zscan_to_raster_matches_reference_table(oracle, ref):
+    """a3: per-CTU z-order <-> raster (abs2raster_table, hmr_encoder_lib.c:95-100)."""
+    import ctypes as C
+    import numpy as np
+    import pytest
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    t = np.zeros(256, np.int32)
+    ref.refh_abs2raster(t.ctypes.data_as(C.c_void_p))
+    assert [oracle.ora_zscan_to_raster(a) for a in range(256)] == t.tolist()
