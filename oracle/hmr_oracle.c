@@ -1181,3 +1181,37 @@ void ora_units_from_ctus(const int16_t *mvx, const int16_t *mvy, const int8_t *r
 		}
 }
 
+/* ====================================================================================================
+ * Inter TU chain: encode_inter_cu / encode_inter_cu_chroma (hmr_motion_inter.c:40-131, 133-230).  The residual of the CU is already
+ * there (predict ran on the whole CU); per TU: DCT, quantisation as non-intra, and for a coded TU the reference weighs keeping the
+ * levels against dropping them: ssd_zero = SSD(residual, 0), ssd = SSD(residual, de-quantised residual), both scaled by the chroma
+ * weight and truncated to uint32; the levels are zeroed when ssd_zero <= ssd + zero_thr * sum (doubles), zero_thr being the host's
+ * clip(avg_dist / 2.5 - 5, 1, 20000).  Returns ssd (of the coded candidate even when it was dropped, as the reference does).
+ * ==================================================================================================== */
+uint32_t ora_inter_tu_chain(const int16_t *residual, int residual_stride, const int16_t *pred, int pred_stride, int16_t *levels, int16_t *recon, int recon_stride,
+			    int size, int scan_mode, int comp, int slice_is_intra, int sign_hiding, int per, int rem, double weight, double zero_thr, int *ac_sum)
+{
+	int16_t coef[32 * 32], deq[32 * 32], res_dec[32 * 32], zero_row[64];
+	const int depth = 6 - ilog2(size) - (comp != 0);
+	uint32_t ssd;
+	memset(zero_row, 0, sizeof zero_row);
+	ora_transform(residual, coef, residual_stride, size, 0);
+	ora_quant(coef, levels, NULL, scan_mode, depth, comp, 0, slice_is_intra, sign_hiding, ac_sum, size, per, rem);
+	if (*ac_sum > 0) {
+		const uint32_t ssd_zero = (uint32_t)(weight * ora_ssd16b(residual, (uint32_t)residual_stride, zero_row, 0, size));
+		ora_inv_quant(levels, deq, depth, comp, 0, size, per, rem);
+		ora_itransform(res_dec, deq, size, size, 0);
+		ssd = (uint32_t)(weight * ora_ssd16b(residual, (uint32_t)residual_stride, res_dec, (uint32_t)size, size));
+		if ((double)ssd_zero <= (comp == 0 ? (double)(int)ssd : (double)ssd) + zero_thr * *ac_sum) {   /* luma keeps ssd in an int (:42), chroma in a uint32 (:135) */
+			memset(levels, 0, (size_t)size * size * sizeof levels[0]);
+			*ac_sum = 0;
+			ora_reconst(pred, pred_stride, zero_row, 0, recon, recon_stride, size);
+		} else
+			ora_reconst(pred, pred_stride, res_dec, size, recon, recon_stride, size);
+	} else {
+		ssd = (uint32_t)(weight * ora_ssd16b(residual, (uint32_t)residual_stride, zero_row, 0, size));
+		ora_reconst(pred, pred_stride, zero_row, 0, recon, recon_stride, size);
+	}
+	return ssd;
+}
+

@@ -125,6 +125,10 @@ uint32_t ora_intra_tu_chain(const int16_t *orig, int orig_stride, const int16_t 
 			    int16_t *levels, int16_t *recon, int recon_stride, int size, int is_dst, int scan_mode, int comp, int slice_is_intra, int sign_hiding,
 			    int per, int rem, int *ac_sum);
 
+/* ---- inter TU: DCT + quant + keep-or-drop decision + reconstruction (encode_inter_cu / _chroma, hmr_motion_inter.c:40,133) ---- */
+uint32_t ora_inter_tu_chain(const int16_t *residual, int residual_stride, const int16_t *pred, int pred_stride, int16_t *levels, int16_t *recon, int recon_stride,
+			    int size, int scan_mode, int comp, int slice_is_intra, int sign_hiding, int per, int rem, double weight, double zero_thr, int *ac_sum);
+
 #ifdef __cplusplus
 }
 #endif

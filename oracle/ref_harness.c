@@ -571,3 +571,58 @@ void refh_abs2raster(int32_t *out256)
 	int a;
 	for (a = 0; a < 256; a++) out256[a] = g_enc->abs2raster_table[a];
 }
+
+/* encode_inter_cu / encode_inter_cu_chroma's per-TU sequence (hmr_motion_inter.c:82-128, 185-227) issued through the reference's own table, with the
+ * reference's own expressions for the keep-or-drop decision */
+uint32_t refh_inter_tu_chain(int16_t *residual, int residual_stride, int16_t *pred, int pred_stride, int16_t *levels, int16_t *recon, int recon_stride, int size,
+			     int scan_mode, int comp, int slice_is_intra, int sign_hiding, int per, int rem, double weight, double zero_thr, int *ac_sum)
+{
+	static int16_t *coef, *deq, *res_dec, *zeros;
+	low_level_funcs_t *f = &g_enc->funcs;
+	int sh = log2i(size), depth = 6 - sh - (comp != 0);
+	if (!coef) {
+		coef = hmr_aligned_alloc(32 * 32, 2); deq = hmr_aligned_alloc(32 * 32, 2); res_dec = hmr_aligned_alloc(64 * 64, 2); zeros = hmr_aligned_alloc(64 * 64, 2);
+		memset(zeros, 0, 64 * 64 * 2);
+	}
+	g_eng->current_pict.slice.slice_type = slice_is_intra ? I_SLICE : P_SLICE;
+	g_et->pps->sign_data_hiding_flag = sign_hiding;
+	f->transform(8, residual, coef, residual_stride, size, size, sh, sh, REG_DCT, g_et->pred_aux_buff);
+	f->quant(g_et, coef, levels, scan_mode, depth, comp, REG_DCT, 0, ac_sum, size, per, rem);
+	if (comp == 0) {                    /* :93-127, `int ssd_` */
+		int ssd_;
+		if (*ac_sum > 0) {
+			uint32_t ssd_zero = f->ssd16b(residual, residual_stride, zeros, 0, size);
+			f->inv_quant(g_et, levels, deq, depth, comp, 0, size, per, rem);
+			f->itransform(8, res_dec, deq, residual_stride, size, size, REG_DCT, g_et->pred_aux_buff);
+			ssd_ = f->ssd16b(residual, residual_stride, res_dec, residual_stride, size);
+			if (ssd_zero <= ssd_ + zero_thr * (*ac_sum)) {
+				memset(levels, 0, size * size * sizeof(levels[0]));
+				*ac_sum = 0;
+				f->reconst(pred, pred_stride, levels, 0, recon, recon_stride, size);
+			} else
+				f->reconst(pred, pred_stride, res_dec, residual_stride, recon, recon_stride, size);
+		} else {
+			ssd_ = f->ssd16b(residual, residual_stride, levels, 0, size);
+			f->reconst(pred, pred_stride, levels, 0, recon, recon_stride, size);
+		}
+		return (uint32_t)ssd_;
+	} else {                            /* :195-226, `uint32_t ssd_`, weighted */
+		uint32_t ssd_;
+		if (*ac_sum > 0) {
+			uint32_t ssd_zero = (uint32_t)(weight * f->ssd16b(residual, residual_stride, zeros, 0, size));
+			f->inv_quant(g_et, levels, deq, depth, comp, 0, size, per, rem);
+			f->itransform(8, res_dec, deq, residual_stride, size, size, REG_DCT, g_et->pred_aux_buff);
+			ssd_ = (uint32_t)(weight * f->ssd16b(residual, residual_stride, res_dec, residual_stride, size));
+			if (ssd_zero <= ssd_ + zero_thr * (*ac_sum)) {
+				memset(levels, 0, size * size * sizeof(levels[0]));
+				*ac_sum = 0;
+				f->reconst(pred, pred_stride, levels, 0, recon, recon_stride, size);
+			} else
+				f->reconst(pred, pred_stride, res_dec, residual_stride, recon, recon_stride, size);
+		} else {
+			ssd_ = (uint32_t)(weight * f->ssd16b(residual, residual_stride, levels, 0, size));
+			f->reconst(pred, pred_stride, levels, 0, recon, recon_stride, size);
+		}
+		return ssd_;
+	}
+}

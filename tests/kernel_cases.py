@@ -331,12 +331,29 @@ def k_intra_tu_chain(lib, prefix, p, rng):
             "ac_sum": np.array([ac.value], np.int32)}
 
 
+def k_inter_tu_chain(lib, prefix, p, rng):
+    """encode_inter_cu / _chroma per-TU sequence: the residual of a motion-compensated CU, keep-or-drop decision included."""
+    n, comp = p["n"], p["comp"]
+    res = aligned((64, 64), np.int16)
+    yy, xx = np.mgrid[0:64, 0:64]
+    res[...] = (p["amp"] * np.sin((xx * np.cos(p["theta"]) + yy * np.sin(p["theta"])) / p["period"]) + rng.integers(-p["noise"], p["noise"] + 1, (64, 64))).astype(np.int64)
+    pred = pix_plane(rng)
+    levels = aligned((32 * 32,), np.int16)
+    levels[...] = 0x1234
+    recon = aligned((64, 64), np.int16)
+    ac = C.c_int(0)
+    r = fn(lib, prefix, "inter_tu_chain", C.c_uint32)(ptr(res), C.c_int(64), ptr(pred, 16 * PLANE_W + 16), C.c_int(PLANE_W), ptr(levels), ptr(recon), C.c_int(64),
+                                                     C.c_int(n), C.c_int(p["scan"]), C.c_int(comp), C.c_int(p["slice_i"]), C.c_int(p["sbh"]), C.c_int(p["per"]),
+                                                     C.c_int(p["rem"]), C.c_double(p["weight"] if comp else 1.0), C.c_double(p["thr"]), C.byref(ac))
+    return {"levels": levels[:n * n].copy(), "recon": recon[:n, :n].copy(), "ssd": np.array([r], np.uint32), "ac_sum": np.array([ac.value], np.int32)}
+
+
 KERNELS = {
     "sad": k_sad, "ssd16b": k_ssd16b, "predict": k_predict, "reconst": k_reconst, "modified_variance": k_modified_variance,
     "copy": k_copy, "intra_planar": k_intra_planar, "intra_angular": k_intra_angular,
     "fill_reference_samples": k_fill_reference_samples, "adi_filter": k_adi_filter, "interpolate": k_interpolate,
     "weighted_average": k_weighted_average, "transform": k_transform, "itransform": k_itransform, "quant": k_quant,
-    "inv_quant": k_inv_quant, "tu_chain": k_tu_chain, "intra_search": k_intra_search, "intra_tu_chain": k_intra_tu_chain,
+    "inv_quant": k_inv_quant, "tu_chain": k_tu_chain, "intra_search": k_intra_search, "intra_tu_chain": k_intra_tu_chain, "inter_tu_chain": k_inter_tu_chain,
 }
 
 
@@ -457,4 +474,11 @@ def all_cases(level="full"):
                 strong=int(r.integers(0, 2)), mode=int(r.integers(0, 35)), scan=int(r.integers(1, 4)), slice_i=int(r.integers(0, 2)), sbh=int(r.integers(0, 2)),
                 per=int(r.integers(2, 7)), rem=int(r.integers(0, 6)), theta=float(r.uniform(0, np.pi)), period=float(r.uniform(3.0, 25.0)),
                 amp=float(r.uniform(5, 90)), noise=int(r.choice([0, 2, 8, 30])))
+    r = np.random.default_rng(991)
+    for n in (4, 8, 16, 32):
+        for i in range(30 if full else 8):
+            comp = int(r.choice([0, 0, 1, 2])) if n < 32 else 0
+            add("inter_tu_chain", n=n, comp=comp, scan=3, slice_i=0, sbh=int(r.integers(0, 2)), per=int(r.integers(2, 7)), rem=int(r.integers(0, 6)),
+                weight=float(2.0 ** (r.integers(-2, 5) / 3.0)), thr=float(np.clip(r.uniform(0, 3000) / 2.5 - 5.0, 1.0, 20000.0)),
+                theta=float(r.uniform(0, np.pi)), period=float(r.uniform(2.0, 20.0)), amp=float(r.choice([0, 2, 6, 20, 60])), noise=int(r.choice([0, 1, 3, 10])))
     return cases

@@ -36,7 +36,8 @@ def main():
             gpu = encode(SWAP, clip, os.path.join(td, "g.265"), w, h, frames, extra, {"HOMER_SWAP": "all"})
         ok = ref == gpu
         bad += not ok
-        print(spec, len(ref), "bytes", "IDENTICAL" if ok else "DIFFERENT", flush=True)
+        import hashlib
+        print(spec, len(ref), "bytes", "md5", hashlib.md5(gpu).hexdigest(), "IDENTICAL" if ok else "DIFFERENT", flush=True)
     sys.exit(1 if bad else 0)
 
 
