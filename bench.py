@@ -91,6 +91,9 @@ ITU_JOB_DTYPE = np.dtype([("orig_off", "<u4"), ("orig_stride", "<u4"), ("pred_of
                           ("lev_off", "<u4"), ("p0", "<u4"), ("p1", "<u4"), ("dec_off", "<u4"), ("dec_stride", "<u4"), ("flags", "<u4"), ("sizes", "<u4"),
                           ("mode", "<u4")])   # hmr_gpu_itu_job
 assert ITU_JOB_DTYPE.itemsize == 56
+INTER_TU_JOB_DTYPE = np.dtype([("orig_off", "<u4"), ("orig_stride", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("rec_off", "<u4"), ("rec_stride", "<u4"),
+                               ("lev_off", "<u4"), ("p0", "<u4"), ("p1", "<u4"), ("reserved", "<u4"), ("weight", "<f8"), ("zero_thr", "<f8")])   # hmr_gpu_inter_tu_job
+assert INTER_TU_JOB_DTYPE.itemsize == 56
 
 
 def build_groups(calls, rng, arena, fused=True):
@@ -173,7 +176,7 @@ def build_groups(calls, rng, arena, fused=True):
         kind, _, origin = kind.partition("@")     # interpolation calls carry their caller: @planes (sub-pel plane builders) / @mc
         if fused and (origin or kind == "sad_direct"):
             continue                               # issued as fused sub-pel refinement / motion compensation jobs below
-        if kind in ("mc_luma", "mc_chroma", "half_pel_planes", "quarter_pel_planes", "intra_search", "intra_tu"):
+        if kind in ("mc_luma", "mc_chroma", "half_pel_planes", "quarter_pel_planes", "intra_search", "intra_tu", "inter_tu"):
             continue
         if kind in ("sad", "sad_direct"):
             N = a[0]
@@ -395,6 +398,47 @@ def build_groups(calls, rng, arena, fused=True):
             jb["p0"] = 3 | (0 << 2) | (1 << 4) | (0 << 5) | (1 << 6) | ((1 if N == 4 else 0) << 7)     # diagonal scan, luma, P slice, sign hiding on, DST for 4x4
             jb["p1"] = 5 | (2 << 8)
             merged[("intra_tu", N)] = {"name": "intra_tu", "fn": "hmr_gpu_intra_tu_chain_batch", "size": N, "jobs": jb, "ctu": c, "bytes": nb, "extra": ()}
+        # Inter TU chain (encode_inter_cu / _chroma): DCT + quant + keep-or-drop decision + reconstruction as one job per inter TU.  The recorded
+        # mix gives the shares: coded = inv_quant / quant, kept = reconst with a residual / coded.
+        eres = np.zeros((NCTU, 64, 64), np.int64)
+        eres[:, 32:, :] = rng.integers(-40, 41, (NCTU, 32, 64))
+        eresw = arena.alloc(NCTU * P64, eres.astype(np.int16).ravel())
+        for N in (4, 8, 16, 32):
+            keys = {k2: v for k2, v in calls.items() if k2.split(":")[0] == "inter_tu" and int(k2.split(":")[1]) == N}
+            if not keys:
+                continue
+            inner, nb = {}, 0
+            for k2, v in calls.items():
+                q = k2.split(":")
+                if "@etu" in q[0] and int(q[1]) == N:
+                    inner[q[0]] = inner.get(q[0], 0) + v
+                    nb += v * {"reconst@etu": 6 * N * N, "ssd16b@etu": 4 * N * N + 4}.get(q[0], 4 * N * N)
+            n_coded = inner.get("inv_quant@etu", 0)
+            n_kept = calls.get("reconst@etu:%d:0" % N, 0)
+            parts = []
+            for k2, n in sorted(keys.items()):
+                comp = int(k2.split(":")[2])
+                jb = np.zeros(n, INTER_TU_JOB_DTYPE)
+                c = ctus(n)
+                coded = rng.random(n) < n_coded / max(inner.get("quant@etu", 1), 1)
+                kept = rng.random(n) < n_kept / max(n_coded, 1)
+                half = max(32 - N, 0) // N + 1
+                x = rng.integers(0, (64 - N) // N + 1, n) * N
+                y = np.minimum(rng.integers(0, half, n) * N + np.where(coded, 32, 0), 64 - N)
+                pos_in = c * P64 + y * 64 + x
+                jb["orig_off"] = eresw + pos_in; jb["orig_stride"] = 64
+                jb["pred_off"] = predw + pos_in; jb["pred_stride"] = 64
+                jb["rec_off"] = recw + pos_in; jb["rec_stride"] = 64
+                jb["p0"] = 3 | (comp << 2) | (0 << 4) | (0 << 5) | (1 << 6)
+                jb["p1"] = 5 | (2 << 8)
+                jb["weight"] = 1.0 if comp == 0 else 2.0 ** (2 / 3.0)
+                jb["zero_thr"] = np.where(kept, 1.0, 20000.0)
+                parts.append((jb, c))
+            jobs_all = np.concatenate([q[0] for q in parts])
+            lev_pool = arena.alloc(len(jobs_all) * N * N)
+            jobs_all["lev_off"] = lev_pool + np.arange(len(jobs_all), dtype=np.int64) * N * N
+            merged[("inter_tu", N)] = {"name": "inter_tu", "fn": "hmr_gpu_inter_tu_chain_batch", "size": N, "jobs": jobs_all,
+                                       "ctu": np.concatenate([q[1] for q in parts]), "bytes": nb, "extra": ()}
         # Motion compensation (hmr_motion_compensation_luma / _chroma): one job per PU and component instead of one or two
         # interpolation calls through the 80-pitch intermediate window.
         refc = arena.alloc(2 * CREF_STRIDE * (HA // 2 + PAD), pix(2 * CREF_STRIDE * (HA // 2 + PAD)))
@@ -449,7 +493,8 @@ def build_groups(calls, rng, arena, fused=True):
             nq = tot("quant", N)
             if not nq:
                 continue
-            assert nq == tot("predict", N) == tot("transform", N) == tot("reconst", N), (N, nq, tot("predict", N), tot("transform", N), tot("reconst", N))
+            assert nq == tot("transform", N) == tot("reconst", N), (N, nq, tot("transform", N), tot("reconst", N))
+            assert tot("predict", N) == nq + sum(v for k2, v in calls.items() if k2.split(":")[0] == "inter_tu" and int(k2.split(":")[1]) == N), N
             coded_frac = tot("inv_quant", N) / nq
             parts = []
             for key, n in sorted(calls.items()):
@@ -488,8 +533,16 @@ def build_groups(calls, rng, arena, fused=True):
                 g["bytes"] = keep * (4 * N * N + 4)
                 if keep == 0:
                     del merged[("ssd16b", N)]
-            for name in ("predict", "transform", "quant", "inv_quant", "itransform", "reconst"):
+            for name in ("transform", "quant", "inv_quant", "itransform", "reconst"):
                 merged.pop((name, N), None)
+            # predict also runs once per inter TU ahead of encode_inter_cu (the inter chain starts from the residual): those stay predict jobs
+            g = merged.get(("predict", N))
+            if g is not None:
+                keep = tot("predict", N) - nq
+                g["jobs"], g["ctu"] = g["jobs"][:keep], g["ctu"][:keep]
+                g["bytes"] = keep * 6 * N * N
+                if keep == 0:
+                    del merged[("predict", N)]
     for g in merged.values():      # a batch is issued in CTU order, like the host would enumerate it
         order = np.argsort(g["ctu"], kind="stable")
         g["jobs"] = np.ascontiguousarray(g["jobs"][order])
@@ -646,7 +699,7 @@ def main():
         OPS = {"hmr_gpu_sad_batch": 1, "hmr_gpu_ssd16b_batch": 2, "hmr_gpu_predict_batch": 3, "hmr_gpu_reconst_batch": 4, "hmr_gpu_copy_batch": 5,
                "hmr_gpu_intra_pred_batch": 7, "hmr_gpu_intra_refs_batch": 8, "hmr_gpu_interpolate_batch": 9, "hmr_gpu_transform_batch": 11,
                "hmr_gpu_itransform_batch": 12, "hmr_gpu_quant_batch": 13, "hmr_gpu_inv_quant_batch": 14, "hmr_gpu_mc_batch": 15,
-               "hmr_gpu_motion_estimation_batch": 16, "hmr_gpu_tu_chain_batch": 22, "hmr_gpu_intra_search_batch": 23, "hmr_gpu_intra_tu_chain_batch": 24}
+               "hmr_gpu_motion_estimation_batch": 16, "hmr_gpu_tu_chain_batch": 22, "hmr_gpu_intra_search_batch": 23, "hmr_gpu_intra_tu_chain_batch": 24, "hmr_gpu_inter_tu_chain_batch": 25}
         OP_EDGE, OP_DEBLOCK, OP_STATS, OP_APPLY, OP_PAD = 17, 18, 19, 20, 21
         cmds, names = [], []
         for g in groups:
@@ -662,7 +715,7 @@ def main():
             if g["fn"] == "hmr_gpu_intra_search_batch":
                 g["d_out"] = torch.zeros(4 * len(g["jobs"]), dtype=torch.int32, device=dev)     # hmr_gpu_intra_result per PU
                 cm.out = g["d_out"].data_ptr()
-            if g["fn"] == "hmr_gpu_intra_tu_chain_batch":
+            if g["fn"] in ("hmr_gpu_intra_tu_chain_batch", "hmr_gpu_inter_tu_chain_batch"):
                 g["d_ac"] = torch.zeros(len(g["jobs"]), dtype=torch.int32, device=dev)
                 cm.p64 = (P * 2)(base, g["d_ac"].data_ptr())   # reconstruction / prediction base, ac_sum
             if g["fn"] == "hmr_gpu_tu_chain_batch":

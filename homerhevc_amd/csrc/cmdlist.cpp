@@ -50,6 +50,8 @@ static int run_one(hmr_gpu_ctx *ctx, const hmr_gpu_cmd &c)
 	case HMR_GPU_OP_INTRA_TU_CHAIN:
 		return hmr_gpu_intra_tu_chain_batch(ctx, (const hmr_gpu_itu_job *)c.jobs, c.njobs, c.size, a, b, (int16_t *)c.p64[0], o, (int16_t *)c.p64[0], (uint32_t *)c.out,
 						    (int32_t *)c.p64[1]);
+	case HMR_GPU_OP_INTER_TU_CHAIN:
+		return hmr_gpu_inter_tu_chain_batch(ctx, (const hmr_gpu_inter_tu_job *)c.jobs, c.njobs, c.size, a, b, o, (int16_t *)c.p64[0], (uint32_t *)c.out, (int32_t *)c.p64[1]);
 	default: hmr_set_error("command list: unknown op %d", c.op); return HMR_GPU_ERR_ARG;
 	}
 }

@@ -734,4 +734,33 @@ uint32_t hmr_gpu_intra_tu_chain(int16_t *orig, int orig_stride, int16_t *decoded
 	return *st.host<uint32_t>(so);
 }
 
+uint32_t hmr_gpu_inter_tu_chain(int16_t *residual, int residual_stride, int16_t *pred, int pred_stride, int16_t *levels, int16_t *recon, int recon_stride, int size,
+				int scan_mode, int comp, int slice_is_intra, int sign_hiding, int per, int rem, double weight, double zero_thr, int *ac_sum)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	hmr_gpu_inter_tu_job jb = {};
+	const int n = size;
+	jb.orig_off = (uint32_t)(st.put2d(residual, residual_stride, n, n, 2) / 2); jb.orig_stride = n;
+	jb.pred_off = (uint32_t)(st.put2d(pred, pred_stride, n, n, 2) / 2); jb.pred_stride = n;
+	jb.p0 = (uint32_t)(scan_mode & 3) | ((uint32_t)comp << 2) | ((uint32_t)(slice_is_intra != 0) << 5) | ((uint32_t)(sign_hiding != 0) << 6);
+	jb.p1 = (uint32_t)per | ((uint32_t)rem << 8);
+	jb.weight = weight; jb.zero_thr = zero_thr;
+	const size_t joff = st.zeros(sizeof jb);
+	st.begin_outputs();
+	const size_t lo = st.out((size_t)n * n * 2), ro = st.out((size_t)n * n * 2), so = st.out(4), ao = st.out(4);
+	jb.lev_off = (uint32_t)(lo / 2);
+	jb.rec_off = (uint32_t)(ro / 2); jb.rec_stride = n;
+	memcpy(st.host<uint8_t>(joff), &jb, sizeof jb);
+	st.upload();
+	must(hmr_gpu_inter_tu_chain_batch(c, st.dev<hmr_gpu_inter_tu_job>(joff), 1, n, st.dev<int16_t>(), st.dev<int16_t>(), st.dev<int16_t>(), st.dev<int16_t>(),
+					  st.dev<uint32_t>(so), st.dev<int32_t>(ao)),
+	     "inter_tu_chain");
+	st.finish();
+	memcpy(levels, st.host<int16_t>(lo), (size_t)n * n * 2);
+	st.get2d(ro, recon, recon_stride, n, n, 2);
+	*ac_sum = *st.host<int32_t>(ao);
+	return *st.host<uint32_t>(so);
+}
+
 }  // extern "C"

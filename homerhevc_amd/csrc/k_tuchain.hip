@@ -48,13 +48,20 @@ __device__ __forceinline__ void load_row_lds(int (&row)[N / 2], const int16_t *s
 // INTRA: the job also carries the neighbourhood and the mode; the prediction is generated first (neighbour array, smoothing, planar / DC /
 // angular, lane = row: each lane predicts its row) into the prediction plane and the chain continues as for a given prediction -
 // encode_intra_cu's data path (hmr_motion_intra.c:1011-1068) in one launch.  D = plane under reconstruction (neighbours), Pp = prediction out.
-template <int N, bool INTRA>
+//
+// MODE 2 (inter): encode_inter_cu / encode_inter_cu_chroma (hmr_motion_inter.c:40-230).  O addresses the RESIDUAL of the CU (predict ran on
+// the whole CU), the transform is always the DCT, and a coded TU is weighed against dropping its levels: ssd_zero = SSD(residual, 0) and
+// ssd = SSD(residual, reconstructed residual), both scaled by the job's chroma weight and truncated to uint32, levels dropped when
+// ssd_zero <= ssd + zero_thr * sum (doubles).  The returned SSD is the residual-domain one, as in the reference.
+enum { TU_GIVEN_PRED = 0, TU_INTRA = 1, TU_INTER = 2 };
+template <int N, int MODE>
 __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const void *__restrict__ jobs_v, int njobs, const int16_t *__restrict__ O,
 							   int16_t *__restrict__ Pp, int16_t *__restrict__ L, int16_t *__restrict__ Rr,
 							   uint32_t *__restrict__ ssd_out, int32_t *__restrict__ ac_out, const DevTables *__restrict__ tab,
 							   const int16_t *__restrict__ D)
 {
-	using JobT = typename std::conditional<INTRA, hmr_gpu_itu_job, hmr_gpu_tu_job>::type;
+	constexpr bool INTRA = MODE == TU_INTRA, INTER = MODE == TU_INTER;
+	using JobT = typename std::conditional<INTRA, hmr_gpu_itu_job, typename std::conditional<INTER, hmr_gpu_inter_tu_job, hmr_gpu_tu_job>::type>::type;
 	const JobT *__restrict__ jobs = static_cast<const JobT *>(jobs_v);
 	constexpr int L2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
 	constexpr int E = N * N, P = N + 2;
@@ -119,9 +126,15 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 			// end of the chain (L2-resident) instead of being held in registers across it: the chain is register-bound.
 #pragma unroll
 			for (int i = 0; i < N / 4; i++) {
-				const i16x4 vo = ld4(orow_p + 4 * i), vp = ld4(prow_p + 4 * i);
-				r[2 * i] = pack2((int16_t)(vo.v[0] - vp.v[0]), (int16_t)(vo.v[1] - vp.v[1]));
-				r[2 * i + 1] = pack2((int16_t)(vo.v[2] - vp.v[2]), (int16_t)(vo.v[3] - vp.v[3]));
+				const i16x4 vo = ld4(orow_p + 4 * i);
+				if constexpr (INTER) {     // O is the residual plane
+					r[2 * i] = pack2(vo.v[0], vo.v[1]);
+					r[2 * i + 1] = pack2(vo.v[2], vo.v[3]);
+				} else {
+					const i16x4 vp = ld4(prow_p + 4 * i);
+					r[2 * i] = pack2((int16_t)(vo.v[0] - vp.v[0]), (int16_t)(vo.v[1] - vp.v[1]));
+					r[2 * i + 1] = pack2((int16_t)(vo.v[2] - vp.v[2]), (int16_t)(vo.v[3] - vp.v[3]));
+				}
 			}
 		}
 		const bool is_dst = N == 4 && ((jb.p0 >> 7) & 1);
@@ -209,19 +222,6 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 			}
 		}
 		wave_sync();
-		// levels out (coalesced)
-		for (int pass = 0; pass < QPASSES; pass++) {
-			const int qt = pass * TQ + lane / GQ, l = lane % GQ;
-			const long qj = base + w * TW + qt;
-			const unsigned lev_off = __shfl((int)jb.lev_off, qt * N, HMR_WAVE);
-			if (qj < jr.end) {
-				int16_t *lo = L + lev_off;
-				const int16_t *ql = sLev[w][qt];
-				for (int e0 = 4 * l; e0 < E; e0 += 4 * GQ) st4(lo + e0, ld4(ql + e0));
-				if (l == 0) ac_out[qj] = sAc[w][qt];
-			}
-		}
-		wave_sync();
 		const int ac = sAc[w][tu];
 		const bool coded = ok && ac != 0;                               // the reference skips dequant / inverse transform for all-zero TUs
 		{
@@ -253,46 +253,118 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 		// K13 stage 2 + K4 reconst + K2 ssd: out[y = row][x] = sum_i M[i][x] * tmp[i][y]
 		load_row_lds<N>(r, tT + row * P);
 		uint32_t ssd = 0;
-		if (ok) {
-			int16_t *ro = Rr + jb.rec_off + (size_t)row * jb.rec_stride;
+		bool drop = false;
+		if constexpr (!INTER) {
+			if (ok) {
+				int16_t *ro = Rr + jb.rec_off + (size_t)row * jb.rec_stride;
 #pragma unroll 2
-			for (int x4 = 0; x4 < N; x4 += 4) {
-				i16x4 outv;
-				const i16x4 vo = ld4(orow_p + x4), vp = ld4(prow_p + x4);
+				for (int x4 = 0; x4 < N; x4 += 4) {
+					i16x4 outv;
+					const i16x4 vo = ld4(orow_p + x4), vp = ld4(prow_p + x4);
 #pragma unroll
-				for (int q = 0; q < 4; q++) {
-					const int x = x4 + q;
-					int res = 0;
-					if (coded) {
-						int s = 0;
+					for (int q = 0; q < 4; q++) {
+						const int x = x4 + q;
+						int res = 0;
+						if (coded) {
+							int s = 0;
 #pragma unroll
-						for (int i = 0; i < N / 2; i++) s = dot2(r[i], Mt[x * (N / 2) + i], s);
-						res = sat16i((s + 2048) >> 12);
+							for (int i = 0; i < N / 2; i++) s = dot2(r[i], Mt[x * (N / 2) + i], s);
+							res = sat16i((s + 2048) >> 12);
+						}
+						const int pv = vp.v[q], ov = vo.v[q];
+						const int rec = clip3i(sat16i(pv + res), 0, 255);
+						outv.v[q] = (int16_t)rec;
+						const int d = (int16_t)(ov - rec);
+						ssd += (uint32_t)(d * d);
 					}
-					const int pv = vp.v[q], ov = vo.v[q];
-					const int rec = clip3i(sat16i(pv + res), 0, 255);
-					outv.v[q] = (int16_t)rec;
-					const int d = (int16_t)(ov - rec);
-					ssd += (uint32_t)(d * d);
+					st4(ro + x4, outv);
 				}
-				st4(ro + x4, outv);
+			}
+			ssd = group_sum<N>(ssd);
+			if (ok && row == 0) ssd_out[j] = ssd;
+		} else {
+			// reconstructed residual of the row (kept packed), SSD against the residual with and without it, then the keep-or-drop decision
+			int rd[N / 2];
+			uint32_t ssd_zero = 0;
+#pragma unroll
+			for (int i = 0; i < N / 2; i++) rd[i] = 0;
+			if (ok) {
+#pragma unroll 2
+				for (int x4 = 0; x4 < N; x4 += 4) {
+					const i16x4 vr = ld4(orow_p + x4);
+					int res[4];
+#pragma unroll
+					for (int q = 0; q < 4; q++) {
+						res[q] = 0;
+						if (coded) {
+							int s = 0;
+#pragma unroll
+							for (int i = 0; i < N / 2; i++) s = dot2(r[i], Mt[(x4 + q) * (N / 2) + i], s);
+							res[q] = sat16i((s + 2048) >> 12);
+						}
+						const int d = (int16_t)(vr.v[q] - res[q]);
+						ssd += (uint32_t)(d * d);
+						ssd_zero += (uint32_t)((int)vr.v[q] * (int)vr.v[q]);
+					}
+					rd[x4 / 2] = pack2(res[0], res[1]);
+					rd[x4 / 2 + 1] = pack2(res[2], res[3]);
+				}
+			}
+			ssd = group_sum<N>(ssd);
+			ssd_zero = group_sum<N>(ssd_zero);
+			const uint32_t w_ssd = (uint32_t)(jb.weight * ssd), w_zero = (uint32_t)(jb.weight * ssd_zero);
+			const int comp = (jb.p0 >> 2) & 3;
+			// luma keeps ssd in an int (hmr_motion_inter.c:42), chroma in a uint32 (:135)
+			drop = coded && (double)w_zero <= (comp == 0 ? (double)(int)w_ssd : (double)w_ssd) + jb.zero_thr * ac;
+			if (ok) {
+				int16_t *ro = Rr + jb.rec_off + (size_t)row * jb.rec_stride;
+#pragma unroll 2
+				for (int x4 = 0; x4 < N; x4 += 4) {
+					const i16x4 vp = ld4(prow_p + x4);
+					i16x4 outv;
+#pragma unroll
+					for (int q = 0; q < 4; q++) {
+						const int w2 = rd[(x4 + q) >> 1], res = drop ? 0 : (((x4 + q) & 1) ? (w2 >> 16) : (int16_t)w2);
+						outv.v[q] = (int16_t)clip3i(sat16i(vp.v[q] + res), 0, 255);
+					}
+					st4(ro + x4, outv);
+				}
+				if (row == 0) {
+					ssd_out[j] = coded ? w_ssd : w_zero;
+					if (drop) sAc[w][tu] = 0;
+				}
 			}
 		}
-		ssd = group_sum<N>(ssd);
-		if (ok && row == 0) ssd_out[j] = ssd;
+		if (lane % N == 0) sNz[w][tu] = drop ? 1ull : 0ull;     // reused as the "levels dropped" flag of the TU for the store below
+		wave_sync();
+		// levels out (coalesced)
+		for (int pass = 0; pass < QPASSES; pass++) {
+			const int qt = pass * TQ + lane / GQ, l = lane % GQ;
+			const long qj = base + w * TW + qt;
+			const unsigned lev_off = __shfl((int)jb.lev_off, qt * N, HMR_WAVE);
+			if (qj < jr.end) {
+				int16_t *lo = L + lev_off;
+				const int16_t *ql = sLev[w][qt];
+				const bool zero = INTER && sNz[w][qt] != 0;
+				const i16x4 z4 = {{0, 0, 0, 0}};
+				for (int e0 = 4 * l; e0 < E; e0 += 4 * GQ) st4(lo + e0, zero ? z4 : ld4(ql + e0));
+				if (l == 0) ac_out[qj] = sAc[w][qt];
+			}
+		}
+		wave_sync();
 		wave_sync();
 	}
 }
 
 }  // namespace
 
-template <bool INTRA>
+template <int MODE>
 static int launch_tu_chain(hmr_gpu_ctx *ctx, const void *jobs, int njobs, int size, const int16_t *orig_base, int16_t *pred_base, int16_t *level_base,
 			   int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum, const int16_t *decoded_base)
 {
 	if (njobs <= 0) return HMR_GPU_OK;
 #define TU_LAUNCH(N)                                                                                                                               \
-	hipLaunchKernelGGL((k_tu_chain<N, INTRA>), dim3(hmr_grid_for_units(((long)njobs + (HMR_WAVE / N) * HMR_WAVES_PER_BLOCK - 1) / ((HMR_WAVE / N) * HMR_WAVES_PER_BLOCK))), \
+	hipLaunchKernelGGL((k_tu_chain<N, MODE>), dim3(hmr_grid_for_units(((long)njobs + (HMR_WAVE / N) * HMR_WAVES_PER_BLOCK - 1) / ((HMR_WAVE / N) * HMR_WAVES_PER_BLOCK))), \
 			   dim3(HMR_BLOCK), 0, ctx->stream, jobs, njobs, orig_base, pred_base, level_base, recon_base, ssd, ac_sum, ctx->tables, decoded_base)
 	switch (size) {
 	case 4: TU_LAUNCH(4); break;
@@ -309,12 +381,19 @@ static int launch_tu_chain(hmr_gpu_ctx *ctx, const void *jobs, int njobs, int si
 extern "C" int hmr_gpu_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_tu_job *jobs, int njobs, int size, const int16_t *orig_base, const int16_t *pred_base,
 				      int16_t *level_base, int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum)
 {
-	return launch_tu_chain<false>(ctx, jobs, njobs, size, orig_base, const_cast<int16_t *>(pred_base), level_base, recon_base, ssd, ac_sum, nullptr);
+	return launch_tu_chain<TU_GIVEN_PRED>(ctx, jobs, njobs, size, orig_base, const_cast<int16_t *>(pred_base), level_base, recon_base, ssd, ac_sum, nullptr);
 }
 
 extern "C" int hmr_gpu_intra_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_itu_job *jobs, int njobs, int size, const int16_t *orig_base,
 					    const int16_t *decoded_base, int16_t *pred_base, int16_t *level_base, int16_t *recon_base, uint32_t *ssd,
 					    int32_t *ac_sum)
 {
-	return launch_tu_chain<true>(ctx, jobs, njobs, size, orig_base, pred_base, level_base, recon_base, ssd, ac_sum, decoded_base);
+	return launch_tu_chain<TU_INTRA>(ctx, jobs, njobs, size, orig_base, pred_base, level_base, recon_base, ssd, ac_sum, decoded_base);
 }
+
+extern "C" int hmr_gpu_inter_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_inter_tu_job *jobs, int njobs, int size, const int16_t *residual_base,
+					    const int16_t *pred_base, int16_t *level_base, int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum)
+{
+	return launch_tu_chain<TU_INTER>(ctx, jobs, njobs, size, residual_base, const_cast<int16_t *>(pred_base), level_base, recon_base, ssd, ac_sum, nullptr);
+}
+

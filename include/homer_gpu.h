@@ -286,7 +286,8 @@ enum hmr_gpu_op {
 	HMR_GPU_OP_INV_QUANT, HMR_GPU_OP_MC, HMR_GPU_OP_ME, HMR_GPU_OP_EDGE_FLAGS, HMR_GPU_OP_DEBLOCK, HMR_GPU_OP_SAO_STATS, HMR_GPU_OP_SAO_APPLY, HMR_GPU_OP_PAD,
 	HMR_GPU_OP_TU_CHAIN,  /* jobs = hmr_gpu_tu_job*, a = orig base, b = pred base, c = level base, out = ssd; the reconstruction base and ac_sum follow in p64[0..1] */
 	HMR_GPU_OP_INTRA_SEARCH,  /* jobs = hmr_gpu_intra_job*, a = orig base, b = decoded base, c = output base, out = hmr_gpu_intra_result* */
-	HMR_GPU_OP_INTRA_TU_CHAIN /* jobs = hmr_gpu_itu_job*, a = orig base, b = decoded base, c = level base, out = ssd; p64 = {recon base, ac_sum}; the prediction
+	HMR_GPU_OP_INTER_TU_CHAIN = 25, /* jobs = hmr_gpu_inter_tu_job*, a = residual base, b = pred base, c = level base, out = ssd; p64 = {recon base, ac_sum} */
+	HMR_GPU_OP_INTRA_TU_CHAIN = 24 /* jobs = hmr_gpu_itu_job*, a = orig base, b = decoded base, c = level base, out = ssd; p64 = {recon base, ac_sum}; the prediction
 	                           * plane shares the recon base */
 };
 /* One call of the batched / frame-level API: `size` is that entry's size/kind/flags argument, a/b/c/out its pointer arguments in
@@ -355,6 +356,23 @@ uint32_t hmr_gpu_intra_tu_chain(int16_t *orig, int orig_stride, int16_t *decoded
 				int bl_size, int tr_size, int strong_enabled, int is_filtered, int mode, int is_luma, int16_t *pred, int pred_stride, int16_t *levels,
 				int16_t *recon, int recon_stride, int size, int is_dst, int scan_mode, int comp, int slice_is_intra, int sign_hiding, int per, int rem,
 				int *ac_sum);
+/* The inter TU: encode_inter_cu / encode_inter_cu_chroma (hmr_motion_inter.c:40-230).  The residual of the motion-compensated CU is given; per TU: DCT,
+ * quantisation as non-intra, and for a coded TU the keep-or-drop decision ssd_zero <= ssd + zero_thr * sum on SSDs in the residual domain, scaled by
+ * `weight` and truncated to uint32 like the reference (luma: weight 1.0).  zero_thr = clip(avg_dist / 2.5 - 5, 1, 20000) (:59-60,108; host double).
+ * Outputs: levels (zeros when dropped), reconstruction, ac_sum (0 when dropped), ssd = the residual-domain SSD of the coded candidate. */
+typedef struct hmr_gpu_inter_tu_job {
+	uint32_t orig_off, orig_stride;   /* RESIDUAL block (residual_wnd) */
+	uint32_t pred_off, pred_stride;   /* prediction block */
+	uint32_t rec_off, rec_stride;     /* reconstruction out */
+	uint32_t lev_off;                 /* quantised levels out, linear size*size */
+	uint32_t p0, p1;                  /* as hmr_gpu_tu_job (is_intra = 0, is_dst = 0) */
+	uint32_t reserved;
+	double weight, zero_thr;
+} hmr_gpu_inter_tu_job;
+int hmr_gpu_inter_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_inter_tu_job *jobs, int njobs, int size, const int16_t *residual_base, const int16_t *pred_base,
+				 int16_t *level_base, int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum);
+uint32_t hmr_gpu_inter_tu_chain(int16_t *residual, int residual_stride, int16_t *pred, int pred_stride, int16_t *levels, int16_t *recon, int recon_stride, int size,
+				int scan_mode, int comp, int slice_is_intra, int sign_hiding, int per, int rem, double weight, double zero_thr, int *ac_sum);
 
 /* ------------------------------------------------------------------------------------------------
  * 8. intra mode search of one PU: homer_loop1_motion_intra (hmr_motion_intra.c:1084-1179) - reference build, smoothing,

@@ -131,6 +131,25 @@ uint encode_intra_cu(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *pi
 	g_sfx = "";
 	return r;
 }
+int encode_inter_cu(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *cu, int depth, PartSize part_size_type, int *curr_sum, int gcnt)
+{
+	int r;
+	bump("inter_tu:%d:%d", cu->size, 0, 0, 0);
+	g_sfx = "@etu";
+	r = ((int (*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int, PartSize, int *, int))REAL(encode_inter_cu))(et, ctu, cu, depth, part_size_type, curr_sum, gcnt);
+	g_sfx = "";
+	return r;
+}
+int encode_inter_cu_chroma(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *cu, int component, int depth, PartSize part_size_type, int *curr_sum, int gcnt)
+{
+	int r;
+	bump("inter_tu:%d:%d", ((cu->size_chroma != 2) ? cu : cu->parent)->size_chroma, component, 0, 0);
+	g_sfx = "@etu";
+	r = ((int (*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int, int, PartSize, int *, int))REAL(encode_inter_cu_chroma))(et, ctu, cu, component, depth, part_size_type,
+															   curr_sum, gcnt);
+	g_sfx = "";
+	return r;
+}
 void hmr_half_pixel_estimation_luma_hm(henc_thread_t *et, int16_t *r, int rs, cu_partition_info_t *cu, int w, int h, int sh, motion_vector_t *mv)
 {
 	bump("half_pel_planes:%d", w, 0, 0, 0);

@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 #include "hmr_private.h"
 #include "hmr_common.h"
 #include "homer_gpu.h"
@@ -325,4 +326,58 @@ uint encode_intra_cu(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *pi
 	}
 	if (!said++) fprintf(stderr, "ref_swap: intra TU chain routed to libhomer_gpu.so\n");
 	return ssd;
+}
+
+/* ---- encode_inter_cu / encode_inter_cu_chroma (hmr_motion_inter.c:40,133): the inter TU - DCT, quantisation, keep-or-drop decision, reconstruction in
+ * one GPU call; window addressing and the bookkeeping on the partition node stay on the host ---- */
+extern const uint8_t chroma_scale_conversion_table[];
+int encode_inter_cu(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *cu, int depth, PartSize part_size_type, int *curr_sum, int gcnt)
+{
+	static int said;
+	if (!want("inter_tu_chain"))
+		return ((int (*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int, PartSize, int *, int))REAL(encode_inter_cu))(et, ctu, cu, depth, part_size_type, curr_sum, gcnt);
+	int curr_depth = cu->depth, x = cu->x_position, y = cu->y_position, size = cu->size;
+	int scan_mode = find_scan_mode(TRUE, TRUE, size, REG_DCT, 0);
+	wnd_t *quant_wnd = et->transform_quant_wnd[curr_depth + 1 + (part_size_type != SIZE_2Nx2N)], *decoded_wnd = et->decoded_mbs_wnd[curr_depth + 1 + (part_size_type != SIZE_2Nx2N)];
+	int16_t *pred = WND_POSITION_2D(int16_t *, et->prediction_wnd[0], Y_COMP, x, y, gcnt, et->ctu_width);
+	int16_t *res = WND_POSITION_2D(int16_t *, et->residual_wnd, Y_COMP, x, y, gcnt, et->ctu_width);
+	int16_t *quant = WND_POSITION_1D(int16_t *, *quant_wnd, Y_COMP, gcnt, et->ctu_width, (cu->abs_index << et->num_partitions_in_cu_shift));
+	int16_t *dec = WND_POSITION_2D(int16_t *, *decoded_wnd, Y_COMP, x, y, gcnt, et->ctu_width);
+	double thr = clip(et->enc_engine->avg_dist / 2.5 - 5., 1., 20000.);
+	int ssd = (int)hmr_gpu_inter_tu_chain(res, WND_STRIDE_2D(et->residual_wnd, Y_COMP), pred, WND_STRIDE_2D(et->prediction_wnd[0], Y_COMP), quant, dec,
+					      WND_STRIDE_2D(*decoded_wnd, Y_COMP), size, scan_mode, Y_COMP, et->enc_engine->current_pict.slice.slice_type == I_SLICE,
+					      et->pps->sign_data_hiding_flag, cu->qp / 6, cu->qp % 6, 1.0, thr, curr_sum);
+	cu->inter_cbf[Y_COMP] = ((*curr_sum ? 1 : 0) << (curr_depth - depth));
+	cu->inter_tr_idx = (curr_depth - depth);
+	cu->sum = *curr_sum;
+	(void)ctu;
+	if (!said++) fprintf(stderr, "ref_swap: inter TU chain routed to libhomer_gpu.so\n");
+	return ssd;
+}
+int encode_inter_cu_chroma(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *cu, int component, int depth, PartSize part_size_type, int *curr_sum, int gcnt)
+{
+	if (!want("inter_tu_chain"))
+		return ((int (*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int, int, PartSize, int *, int))REAL(encode_inter_cu_chroma))(et, ctu, cu, component, depth,
+																	 part_size_type, curr_sum, gcnt);
+	slice_t *currslice = &et->enc_engine->current_pict.slice;
+	int original_depth = cu->depth;
+	cu_partition_info_t *pp = (cu->size_chroma != 2) ? cu : cu->parent;
+	int x = pp->x_position_chroma, y = pp->y_position_chroma, size = pp->size_chroma;
+	int scan_mode = find_scan_mode(TRUE, TRUE, size, REG_DCT, 0);
+	int chr_qp_offset = et->enc_engine->chroma_qp_offset;
+	int qp_chroma = chroma_scale_conversion_table[clip(cu->qp + chr_qp_offset, 0, 57)];
+	double weight = pow(2.0, (currslice->qp - chroma_scale_conversion_table[clip(currslice->qp + chr_qp_offset, 0, 57)]) / 3.0);
+	wnd_t *quant_wnd = et->transform_quant_wnd[original_depth + 1 + (part_size_type != SIZE_2Nx2N)], *decoded_wnd = et->decoded_mbs_wnd[original_depth + 1 + (part_size_type != SIZE_2Nx2N)];
+	int16_t *pred = WND_POSITION_2D(int16_t *, et->prediction_wnd[0], component, x, y, gcnt, et->ctu_width);
+	int16_t *res = WND_POSITION_2D(int16_t *, et->residual_wnd, component, x, y, gcnt, et->ctu_width);
+	int16_t *quant = WND_POSITION_1D(int16_t *, *quant_wnd, component, gcnt, et->ctu_width, (pp->abs_index << et->num_partitions_in_cu_shift) >> 2);
+	int16_t *dec = WND_POSITION_2D(int16_t *, *decoded_wnd, component, x, y, gcnt, et->ctu_width);
+	double thr = clip(et->enc_engine->avg_dist / 2.5 - 5., 1., 20000.);
+	uint32_t ssd = hmr_gpu_inter_tu_chain(res, WND_STRIDE_2D(et->residual_wnd, component), pred, WND_STRIDE_2D(et->prediction_wnd[0], component), quant, dec,
+					      WND_STRIDE_2D(*decoded_wnd, component), size, scan_mode, component, currslice->slice_type == I_SLICE,
+					      et->pps->sign_data_hiding_flag, qp_chroma / 6, qp_chroma % 6, weight, thr, curr_sum);
+	cu->inter_cbf[component] = ((*curr_sum ? 1 : 0) << (original_depth - depth));
+	cu->sum += *curr_sum;
+	(void)ctu;
+	return (int)ssd;
 }

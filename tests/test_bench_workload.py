@@ -38,8 +38,14 @@ def test_callmix_fixture_is_consistent(workload):
         c = fr["calls"]
         tot = lambda k: sum(v for key, v in c.items() if key.split(":")[0] == k)   # noqa: E731
         # the per-TU chain: one predict / transform / quant / reconst per TU, inverse path only for coded TUs
-        assert tot("predict") == tot("transform") == tot("quant") == tot("reconst")
+        assert tot("transform") == tot("quant") == tot("reconst") and tot("predict") == tot("quant") + tot("inter_tu")
         assert tot("inv_quant") == tot("itransform") <= tot("quant")
+        # inter TUs (encode_inter_cu / _chroma): one DCT / quant / reconst each, two SSDs when coded, one otherwise
+        assert tot("transform@etu") == tot("quant@etu") == tot("reconst@etu") == tot("inter_tu")
+        assert tot("ssd16b@etu") == tot("inter_tu") + tot("inv_quant@etu") and tot("inv_quant@etu") == tot("itransform@etu")
+        # luma intra TUs (encode_intra_cu)
+        assert tot("fill_reference_samples@itu") == tot("predict@itu") == tot("quant@itu") == tot("ssd16b@itu") == tot("intra_tu")
+        assert tot("intra_planar@itu") + tot("intra_angular@itu") == tot("intra_tu")
         # drivers and the calls they make
         assert tot("half_pel_planes") == tot("quarter_pel_planes")
         assert tot("interp_luma@planes") == 16 * tot("half_pel_planes") and tot("sad_direct") == 18 * tot("half_pel_planes")
@@ -62,8 +68,8 @@ def test_fused_and_unfused_replays_account_for_the_same_work():
     assert res[False][1] == sum(v for k, v in calls.items() if k.split(":")[0].split("@")[0] in (
         "sad", "sad_direct", "ssd16b", "predict", "reconst", "copy_16_16", "intra_planar", "intra_angular", "fill_reference_samples", "interp_luma",
         "interp_chroma", "transform", "itransform", "quant", "inv_quant") and not (k.startswith("copy_16_16") and int(k.split(":")[2]) > bench.W))
-    assert {"tu_chain", "me_subpel", "mc_luma", "mc_chroma", "intra_search"} <= res[True][2]
-    assert not ({"tu_chain", "me_subpel", "mc_luma", "intra_search"} & res[False][2])
+    assert {"tu_chain", "inter_tu", "intra_tu", "me_subpel", "mc_luma", "mc_chroma", "intra_search"} <= res[True][2]
+    assert not ({"tu_chain", "inter_tu", "intra_tu", "me_subpel", "mc_luma", "intra_search"} & res[False][2])
     # every job's operands stay inside the arena
     arena = bench.Arena()
     groups, _ = bench.build_groups(calls, np.random.default_rng(7), arena, fused=True)

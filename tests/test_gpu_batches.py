@@ -529,3 +529,43 @@ def test_intra_tu_chain(rig, oracle, n):
     same(rig.down(d_ssd, nj, np.uint32), ssd, "ssd")
     same(rig.down(d_ac, nj, np.int32), ac, "ac_sum")
     assert 0.1 < (ac != 0).mean() < 0.98
+
+
+INTER_TU_JOB = np.dtype([("orig_off", "<u4"), ("orig_stride", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("rec_off", "<u4"), ("rec_stride", "<u4"),
+                         ("lev_off", "<u4"), ("p0", "<u4"), ("p1", "<u4"), ("reserved", "<u4"), ("weight", "<f8"), ("zero_thr", "<f8")])
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_inter_tu_chain(rig, oracle, n):
+    assert INTER_TU_JOB.itemsize == 56
+    rng = np.random.default_rng(n + 1000 * SEED)
+    nj = rig.nj
+    # residual plane: smooth texture of per-region strength (kept / dropped / all-zero TUs all occur)
+    yy, xx = np.mgrid[0:PH, 0:PW]
+    amp = np.repeat(np.repeat(rng.choice([0, 2, 5, 15, 60], (PH // 32, PW // 32)), 32, 0), 32, 1)
+    rig.host[rig.res:rig.mid] = (amp * np.sin(xx / 5.0 + yy / 7.0) + rng.integers(-2, 3, (PH, PW)) * (amp > 0)).astype(np.int16).ravel()
+    jb = np.zeros(nj, INTER_TU_JOB)
+    jb["orig_off"] = rig.block(rng, rig.res, n, n); jb["orig_stride"] = PW
+    jb["pred_off"] = rig.block(rng, rig.pix, n, n); jb["pred_stride"] = PW
+    jb["rec_off"] = rig.slots(rig.out1); jb["rec_stride"] = 80
+    jb["lev_off"] = rig.slots(rig.out2)
+    comp = rng.integers(0, 3 if n < 32 else 1, nj); sbh = rng.integers(0, 2, nj)
+    per, rem = rng.integers(2, 7, nj), rng.integers(0, 6, nj)
+    jb["p0"] = 3 | (comp << 2) | (sbh << 6); jb["p1"] = per | (rem << 8)
+    jb["weight"] = np.where(comp == 0, 1.0, 2.0 ** (rng.integers(-2, 5, nj) / 3.0))
+    jb["zero_thr"] = np.clip(rng.uniform(0, 3000, nj) / 2.5 - 5.0, 1.0, 20000.0)
+    d_ssd = rig.malloc(4 * nj); d_ac = rig.malloc(4 * nj); rig.bufs += [d_ssd, d_ac]
+    g = rig.launch("hmr_gpu_inter_tu_chain_batch", rig.up(jb), nj, n, rig.dev, rig.dev, rig.dev, rig.dev, d_ssd, d_ac)
+    o = rig.host.copy()
+    ssd, ac = np.zeros(nj, np.uint32), np.zeros(nj, np.int32)
+    oracle.ora_inter_tu_chain.restype = C.c_uint32
+    for i, j in enumerate(jb):
+        v = C.c_int(0)
+        ssd[i] = oracle.ora_inter_tu_chain(at(o, j["orig_off"]), PW, at(o, j["pred_off"]), PW, at(o, j["lev_off"]), at(o, j["rec_off"]), 80, n, 3, int(comp[i]), 0,
+                                           int(sbh[i]), int(per[i]), int(rem[i]), C.c_double(float(j["weight"])), C.c_double(float(j["zero_thr"])), C.byref(v))
+        ac[i] = v.value
+    same(g, o, "inter TU chain: levels, reconstruction")
+    same(rig.down(d_ssd, nj, np.uint32), ssd, "ssd")
+    same(rig.down(d_ac, nj, np.int32), ac, "ac_sum")
+    dropped = (ac == 0) & (ssd != 0)
+    assert (ac != 0).sum() > 20 and dropped.sum() > 20
