@@ -283,31 +283,30 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 			ssd = group_sum<N>(ssd);
 			if (ok && row == 0) ssd_out[j] = ssd;
 		} else {
-			// reconstructed residual of the row (kept packed), SSD against the residual with and without it, then the keep-or-drop decision
-			int rd[N / 2];
+			// the reconstruction is written as if the levels were kept while both SSDs are accumulated; the (rare) dropped TU is rewritten
+			// from the prediction alone once the decision is known
 			uint32_t ssd_zero = 0;
-#pragma unroll
-			for (int i = 0; i < N / 2; i++) rd[i] = 0;
+			int16_t *ro = ok ? Rr + jb.rec_off + (size_t)row * jb.rec_stride : nullptr;
 			if (ok) {
 #pragma unroll 2
 				for (int x4 = 0; x4 < N; x4 += 4) {
-					const i16x4 vr = ld4(orow_p + x4);
-					int res[4];
+					const i16x4 vr = ld4(orow_p + x4), vp = ld4(prow_p + x4);
+					i16x4 outv;
 #pragma unroll
 					for (int q = 0; q < 4; q++) {
-						res[q] = 0;
+						int res = 0;
 						if (coded) {
 							int s = 0;
 #pragma unroll
 							for (int i = 0; i < N / 2; i++) s = dot2(r[i], Mt[(x4 + q) * (N / 2) + i], s);
-							res[q] = sat16i((s + 2048) >> 12);
+							res = sat16i((s + 2048) >> 12);
 						}
-						const int d = (int16_t)(vr.v[q] - res[q]);
+						const int d = (int16_t)(vr.v[q] - res);
 						ssd += (uint32_t)(d * d);
 						ssd_zero += (uint32_t)((int)vr.v[q] * (int)vr.v[q]);
+						outv.v[q] = (int16_t)clip3i(sat16i(vp.v[q] + res), 0, 255);
 					}
-					rd[x4 / 2] = pack2(res[0], res[1]);
-					rd[x4 / 2 + 1] = pack2(res[2], res[3]);
+					st4(ro + x4, outv);
 				}
 			}
 			ssd = group_sum<N>(ssd);
@@ -316,19 +315,19 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 			const int comp = (jb.p0 >> 2) & 3;
 			// luma keeps ssd in an int (hmr_motion_inter.c:42), chroma in a uint32 (:135)
 			drop = coded && (double)w_zero <= (comp == 0 ? (double)(int)w_ssd : (double)w_ssd) + jb.zero_thr * ac;
-			if (ok) {
-				int16_t *ro = Rr + jb.rec_off + (size_t)row * jb.rec_stride;
+			if (__any(drop)) {
+				if (drop) {
 #pragma unroll 2
-				for (int x4 = 0; x4 < N; x4 += 4) {
-					const i16x4 vp = ld4(prow_p + x4);
-					i16x4 outv;
+					for (int x4 = 0; x4 < N; x4 += 4) {
+						const i16x4 vp = ld4(prow_p + x4);
+						i16x4 outv;
 #pragma unroll
-					for (int q = 0; q < 4; q++) {
-						const int w2 = rd[(x4 + q) >> 1], res = drop ? 0 : (((x4 + q) & 1) ? (w2 >> 16) : (int16_t)w2);
-						outv.v[q] = (int16_t)clip3i(sat16i(vp.v[q] + res), 0, 255);
+						for (int q = 0; q < 4; q++) outv.v[q] = (int16_t)clip3i((int)vp.v[q], 0, 255);
+						st4(ro + x4, outv);
 					}
-					st4(ro + x4, outv);
 				}
+			}
+			if (ok) {
 				if (row == 0) {
 					ssd_out[j] = coded ? w_ssd : w_zero;
 					if (drop) sAc[w][tu] = 0;
