@@ -1,8 +1,12 @@
 // Fused transform-unit chain: residual -> forward transform -> quantisation (+ sign hiding) -> [dequantisation ->
 // inverse transform] -> reconstruction -> SSD, one launch for a batch of TUs.
-// This is the per-TU sequence of the reference's encode_intra_cu (hmr_motion_intra.c:1014-1069) and encode_inter_cu
-// (hmr_motion_inter.c:40-230): seven table calls (predict, transform, quant, inv_quant, itransform, reconst, ssd16b) whose
-// intermediates the CPU keeps in scratch windows.  Here a TU stays on chip from the first load to the last store: source and
+// Three compositions of the same stages, selected by the kernel's MODE:
+//   given prediction - predict, transform, quant, [inv_quant, itransform], reconst, ssd16b: the per-TU sequence of the reference's
+//                      intra paths once the prediction exists (hmr_motion_intra.c:1030-1068, hmr_motion_intra_chroma.c:345-365);
+//   intra            - the same with the neighbour array and the prediction generated first: encode_intra_cu (hmr_motion_intra.c:970-1069);
+//   inter            - encode_inter_cu / encode_inter_cu_chroma (hmr_motion_inter.c:40-230): starts from the CU's residual, SSDs in the
+//                      residual domain, keep-or-drop decision on the coded levels.
+// The CPU keeps the intermediates of these table calls in scratch windows.  Here a TU stays on chip from the first load to the last store: source and
 // prediction are read once, levels, reconstruction, SSD and ac_sum are written once; residual, coefficients and de-quantised
 // planes never reach HBM.  The arithmetic of every stage is that of the stand-alone kernels, so outputs are bit-identical to the
 // seven calls in sequence.
@@ -12,7 +16,7 @@
 // that are wave-uniform (all TUs of a wave walk the same k), i.e. scalar loads from the constant tables - no LDS traffic in the
 // inner loop.  Only the transposes between stages go through LDS (pitch N+2: conflict-free column writes).  The integer dot
 // products are exact (|sum| < 2^31), MFMA is not applicable: the stages need exact 32-bit sums with a saturating 16-bit pack
-// in between.  Quantisation / sign hiding run on the LDS image with the 16-lanes-per-coefficient-group mapping of k_quant.
+// in between.  Quantisation runs on the LDS image four coefficients per lane and step; sign hiding with one lane per coefficient group.
 #include "common.h"
 #include "intra_device.h"
 #include "tq_device.h"
