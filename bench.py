@@ -79,21 +79,7 @@ class Arena:
         return off
 
 
-ME_JOB_DTYPE = np.dtype([("corr", "<f8"), ("orig_off", "<u4"), ("orig_stride", "<u4"), ("ref_off", "<u4"), ("ref_stride", "<u4"), ("gx", "<i2"), ("gy", "<i2"),
-                         ("init_x", "<i2"), ("init_y", "<i2"), ("n_amvp", "<i2"), ("n_search", "<i2"), ("amvp", "<i2", (2, 2)), ("search", "<i2", (5, 2)),
-                         ("action", "<u4"), ("reserved", "<u4")])    # hmr_gpu_me_job, include/homer_gpu.h
-assert ME_JOB_DTYPE.itemsize == 72
-INTRA_JOB_DTYPE = np.dtype([("sqrt_lambda", "<f8"), ("orig_off", "<u4"), ("orig_stride", "<u4"), ("dec_off", "<u4"), ("dec_stride", "<u4"), ("adi_off", "<u4"),
-                            ("adif_off", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("flags", "<u4"), ("sizes", "<u4"), ("preds", "<i4", (3,)),
-                            ("pred_bits", "<u4", (3,)), ("other_bits", "<u4"), ("reserved", "<u4")])   # hmr_gpu_intra_job
-assert INTRA_JOB_DTYPE.itemsize == 80
-ITU_JOB_DTYPE = np.dtype([("orig_off", "<u4"), ("orig_stride", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("rec_off", "<u4"), ("rec_stride", "<u4"),
-                          ("lev_off", "<u4"), ("p0", "<u4"), ("p1", "<u4"), ("dec_off", "<u4"), ("dec_stride", "<u4"), ("flags", "<u4"), ("sizes", "<u4"),
-                          ("mode", "<u4")])   # hmr_gpu_itu_job
-assert ITU_JOB_DTYPE.itemsize == 56
-INTER_TU_JOB_DTYPE = np.dtype([("orig_off", "<u4"), ("orig_stride", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("rec_off", "<u4"), ("rec_stride", "<u4"),
-                               ("lev_off", "<u4"), ("p0", "<u4"), ("p1", "<u4"), ("reserved", "<u4"), ("weight", "<f8"), ("zero_thr", "<f8")])   # hmr_gpu_inter_tu_job
-assert INTER_TU_JOB_DTYPE.itemsize == 56
+from homerhevc_amd.gpu import INTER_TU_JOB_DTYPE, INTRA_JOB_DTYPE, ITU_JOB_DTYPE, ME_JOB_DTYPE, TU_JOB_DTYPE  # noqa: E402
 
 
 def build_groups(calls, rng, arena, fused=True):
@@ -481,8 +467,7 @@ def build_groups(calls, rng, arena, fused=True):
         # The per-TU sequence predict -> transform -> quant -> [inv_quant -> itransform] -> reconst -> ssd16b (encode_intra_cu /
         # encode_inter_cu) is issued as ONE fused launch per TU size.  Counts come from the recorded mix: one chain per quant call;
         # the share of coded TUs is the recorded inv_quant / quant ratio; ssd16b calls beyond the chains stay separate jobs.
-        TU_DTYPE = np.dtype([("orig_off", "<u4"), ("orig_stride", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("rec_off", "<u4"),
-                             ("rec_stride", "<u4"), ("lev_off", "<u4"), ("p0", "<u4"), ("p1", "<u4")])
+        TU_DTYPE = TU_JOB_DTYPE
         tot = lambda prefix, N: sum(v for k, v in calls.items() if k.split(":")[0] == prefix and int(k.split(":")[1]) == N)   # noqa: E731
         # prediction window = source window, plus strong noise in its lower half: TUs placed there are coded, TUs in the upper half are not
         noise = np.zeros((NCTU, 64, 64), np.int64)

@@ -12,6 +12,18 @@ from .lowlevel import load_library
 JOB_DTYPE = np.dtype([("a_off", "<u4"), ("a_stride", "<u4"), ("b_off", "<u4"), ("b_stride", "<u4"), ("c_off", "<u4"), ("c_stride", "<u4"),
                       ("w", "<u2"), ("h", "<u2"), ("p0", "<u4"), ("p1", "<u4")])
 assert JOB_DTYPE.itemsize == 36
+# the other descriptors of include/homer_gpu.h
+TU_JOB_DTYPE = np.dtype([("orig_off", "<u4"), ("orig_stride", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("rec_off", "<u4"), ("rec_stride", "<u4"),
+                         ("lev_off", "<u4"), ("p0", "<u4"), ("p1", "<u4")])                                                   # hmr_gpu_tu_job
+ITU_JOB_DTYPE = np.dtype(TU_JOB_DTYPE.descr + [("dec_off", "<u4"), ("dec_stride", "<u4"), ("flags", "<u4"), ("sizes", "<u4"), ("mode", "<u4")])   # hmr_gpu_itu_job
+INTER_TU_JOB_DTYPE = np.dtype(TU_JOB_DTYPE.descr + [("reserved", "<u4"), ("weight", "<f8"), ("zero_thr", "<f8")])             # hmr_gpu_inter_tu_job
+ME_JOB_DTYPE = np.dtype([("corr", "<f8"), ("orig_off", "<u4"), ("orig_stride", "<u4"), ("ref_off", "<u4"), ("ref_stride", "<u4"), ("gx", "<i2"), ("gy", "<i2"),
+                         ("init_x", "<i2"), ("init_y", "<i2"), ("n_amvp", "<i2"), ("n_search", "<i2"), ("amvp", "<i2", (2, 2)), ("search", "<i2", (5, 2)),
+                         ("action", "<u4"), ("reserved", "<u4")])                                                             # hmr_gpu_me_job
+INTRA_JOB_DTYPE = np.dtype([("sqrt_lambda", "<f8"), ("orig_off", "<u4"), ("orig_stride", "<u4"), ("dec_off", "<u4"), ("dec_stride", "<u4"), ("adi_off", "<u4"),
+                            ("adif_off", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("flags", "<u4"), ("sizes", "<u4"), ("preds", "<i4", (3,)),
+                            ("pred_bits", "<u4", (3,)), ("other_bits", "<u4"), ("reserved", "<u4")])                          # hmr_gpu_intra_job
+assert (TU_JOB_DTYPE.itemsize, ITU_JOB_DTYPE.itemsize, INTER_TU_JOB_DTYPE.itemsize, ME_JOB_DTYPE.itemsize, INTRA_JOB_DTYPE.itemsize) == (36, 56, 56, 72, 80)
 
 
 class Frame(C.Structure):

@@ -47,8 +47,26 @@ TABLE = {
 }
 
 
+# functions the reference calls directly (no table slot): reference symbol -> (exported symbol, restype).  A C host interposes them by symbol
+# (INTEGRATION.md); argument lists are in include/homer_gpu.h.
+OFF_TABLE = {
+    "fill_reference_samples": ("hmr_gpu_fill_reference_samples", None),
+    "adi_filter": ("hmr_gpu_adi_filter", None),
+    "homer_loop1_motion_intra": ("hmr_gpu_intra_search", None),
+    "encode_intra_cu": ("hmr_gpu_intra_tu_chain", C.c_uint32),
+    "encode_inter_cu": ("hmr_gpu_inter_tu_chain", C.c_uint32),
+    "hmr_motion_estimation": ("hmr_gpu_motion_estimation", C.c_uint32),
+    "hmr_motion_compensation_luma": ("hmr_gpu_mc_luma", None),
+    "hmr_motion_compensation_chroma": ("hmr_gpu_mc_chroma", None),
+    "hmr_deblock_filter_cu": ("hmr_gpu_deblock_filter_ctu", None),
+    "sao_offset_ctu": ("hmr_gpu_sao_offset_ctu", None),
+    "reference_picture_border_padding_ctu": ("hmr_gpu_pad_ctu", None),
+}
+
+
 class LowLevelFuncs:
-    """The function table, populated the way HOMER_enc_init populates hvenc->funcs."""
+    """The function table, populated the way HOMER_enc_init populates hvenc->funcs; the off-table functions are attributes under the
+    reference's own symbol names."""
 
     def __init__(self, lib=None):
         self.lib = lib or load_library()
@@ -57,3 +75,7 @@ class LowLevelFuncs:
             f.restype = restype
             f.argtypes = argtypes
             setattr(self, member, f)
+        for name, (sym, restype) in OFF_TABLE.items():
+            f = getattr(self.lib, sym)
+            f.restype = restype
+            setattr(self, name, f)

@@ -3,6 +3,7 @@ lane packing (several jobs per wavefront), the XCD job partition and the unalign
 uses them.  Every job is replayed through the CPU oracle on a host copy of the same arena and the WHOLE arena is compared, so a
 stray write outside a job's output block fails too."""
 import ctypes as C
+import sys
 
 import numpy as np
 import pytest
@@ -10,15 +11,14 @@ import pytest
 import libs
 from kernel_cases import quant_depth
 
+sys.path.insert(0, libs.ROOT)
+from homerhevc_amd import gpu as gpu_host  # noqa: E402  (descriptor layouts of include/homer_gpu.h)
+
 pytestmark = pytest.mark.gpu
 
-JOB = np.dtype([("a_off", "<u4"), ("a_stride", "<u4"), ("b_off", "<u4"), ("b_stride", "<u4"), ("c_off", "<u4"), ("c_stride", "<u4"),
-                ("w", "<u2"), ("h", "<u2"), ("p0", "<u4"), ("p1", "<u4")])
-TU_JOB = np.dtype([("orig_off", "<u4"), ("orig_stride", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("rec_off", "<u4"),
-                   ("rec_stride", "<u4"), ("lev_off", "<u4"), ("p0", "<u4"), ("p1", "<u4")])
-ME_JOB = np.dtype([("corr", "<f8"), ("orig_off", "<u4"), ("orig_stride", "<u4"), ("ref_off", "<u4"), ("ref_stride", "<u4"), ("gx", "<i2"), ("gy", "<i2"),
-                   ("init_x", "<i2"), ("init_y", "<i2"), ("n_amvp", "<i2"), ("n_search", "<i2"), ("amvp", "<i2", (2, 2)), ("search", "<i2", (5, 2)),
-                   ("action", "<u4"), ("reserved", "<u4")])
+JOB = gpu_host.JOB_DTYPE
+TU_JOB = gpu_host.TU_JOB_DTYPE
+ME_JOB = gpu_host.ME_JOB_DTYPE
 VP = C.c_void_p
 SEED = int(__import__("os").environ.get("HOMER_TEST_SEED", "0"))     # fuzzing: HOMER_TEST_SEED=k reseeds every case
 NJ = 611                      # odd on purpose: ragged last wavefront / last XCD chunk
@@ -420,9 +420,7 @@ def test_motion_estimation(rig, oracle, n, action):
     same(got.view(np.uint32), exp.view(np.uint32), "motion estimation (mv, sub-pel mv, sad)")
 
 
-INTRA_JOB = np.dtype([("sqrt_lambda", "<f8"), ("orig_off", "<u4"), ("orig_stride", "<u4"), ("dec_off", "<u4"), ("dec_stride", "<u4"), ("adi_off", "<u4"),
-                      ("adif_off", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("flags", "<u4"), ("sizes", "<u4"), ("preds", "<i4", (3,)),
-                      ("pred_bits", "<u4", (3,)), ("other_bits", "<u4"), ("reserved", "<u4")])
+INTRA_JOB = gpu_host.INTRA_JOB_DTYPE
 INTRA_RES = np.dtype([("best_mode", "<i4"), ("bits", "<i4"), ("cost", "<f8")])
 
 
@@ -476,8 +474,7 @@ def test_intra_search(rig, oracle, n):
     assert len(set(exp["best_mode"].tolist())) > 8
 
 
-ITU_JOB = np.dtype([("orig_off", "<u4"), ("orig_stride", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("rec_off", "<u4"), ("rec_stride", "<u4"),
-                    ("lev_off", "<u4"), ("p0", "<u4"), ("p1", "<u4"), ("dec_off", "<u4"), ("dec_stride", "<u4"), ("flags", "<u4"), ("sizes", "<u4"), ("mode", "<u4")])
+ITU_JOB = gpu_host.ITU_JOB_DTYPE
 
 
 @pytest.mark.parametrize("n", [4, 8, 16, 32])
@@ -531,8 +528,7 @@ def test_intra_tu_chain(rig, oracle, n):
     assert 0.1 < (ac != 0).mean() < 0.98
 
 
-INTER_TU_JOB = np.dtype([("orig_off", "<u4"), ("orig_stride", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("rec_off", "<u4"), ("rec_stride", "<u4"),
-                         ("lev_off", "<u4"), ("p0", "<u4"), ("p1", "<u4"), ("reserved", "<u4"), ("weight", "<f8"), ("zero_thr", "<f8")])
+INTER_TU_JOB = gpu_host.INTER_TU_JOB_DTYPE
 
 
 @pytest.mark.parametrize("n", [4, 8, 16, 32])
