@@ -162,7 +162,7 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 			const bool qok = qj < jr.end;
 			// the TU's parameters live with its transform lanes: fetch them from lane qt * N
 			const unsigned p0 = __shfl((int)jb.p0, qt * N, HMR_WAVE), p1 = __shfl((int)jb.p1, qt * N, HMR_WAVE);
-			const int scan_mode = p0 & 3, comp = (p0 >> 2) & 3, is_intra = (p0 >> 4) & 1, slice_i = (p0 >> 5) & 1, sbh = (p0 >> 6) & 1;
+			const int scan_mode = p0 & 3, comp = (p0 >> 2) & 3, is_intra = (p0 >> 4) & 1, slice_i = (p0 >> 5) & 1;
 			const int per = p1 & 0xff, rem = (p1 >> 8) & 0xff;
 			int16_t *qc = sA[w][qt], *qd = sT[w][qt], *ql = sLev[w][qt];
 			int ac = 0;
