@@ -250,11 +250,11 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_sao_stats(Planes org, Planes rec,
 	}
 	__syncthreads();
 	const int skr = comp ? 3 : 5, skb = comp ? 2 : 4;
-	int dsum[4][5], csum[4][5];
-#pragma unroll
-	for (int t = 0; t < 4; t++)
-#pragma unroll
-		for (int k = 0; k < 5; k++) dsum[t][k] = csum[t][k] = 0;
+	// per-lane class accumulators as bit fields (a lane sees at most 16 samples): counts 5 x 6 bits in one register per edge type;
+	// differences biased by +256 (9 bits, sums < 2^13) in 16-bit fields - classes 0..3 in a 64-bit pair, class 4 on its own -
+	// so a sample costs one shift-add per type instead of five select-accumulates
+	unsigned cnt[4] = {0, 0, 0, 0}, d4[4] = {0, 0, 0, 0};
+	unsigned long long d03[4] = {0, 0, 0, 0};
 	const int ex_eo = ra ? w - skr : w - 1, ex_full = ra ? w - skr : w, sx_eo = la ? 0 : 1;
 	const int ey_eo = ba ? h - skb : h - 1, ey_full = ba ? h - skb : h, sy_eo = ta ? 0 : 1;
 	for (int i = threadIdx.x; i < w * h; i += HMR_BLOCK) {
@@ -264,16 +264,16 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_sao_stats(Planes org, Planes rec,
 		const int sl = sgn(v - c[-1]), sr = sgn(v - c[1]), su = sgn(v - c[-66]), sd = sgn(v - c[66]);
 		const int sul = sgn(v - c[-67]), sdr = sgn(v - c[67]), sur = sgn(v - c[-65]), sdl = sgn(v - c[65]);
 		const bool in_x_eo = x >= sx_eo && x < ex_eo, in_y_eo = y >= sy_eo && y < ey_eo;
-		const bool in0 = in_x_eo && y < ey_full;                 // EO 0: all rows (bottom skip only)
-		const bool in1 = x < ex_full && in_y_eo;                 // EO 90
-		const bool in2 = in_x_eo && in_y_eo;                     // EO 135 / 45
-		const int k0 = 2 + sl + sr, k1 = 2 + su + sd, k2 = 2 + sul + sdr, k3 = 2 + sur + sdl;
+		const bool in[4] = {in_x_eo && y < ey_full,                // EO 0: all rows (bottom skip only)
+				    x < ex_full && in_y_eo,                 // EO 90
+				    in_x_eo && in_y_eo, in_x_eo && in_y_eo}; // EO 135 / 45
+		const int k[4] = {2 + sl + sr, 2 + su + sd, 2 + sul + sdr, 2 + sur + sdl};
+		const unsigned e = (unsigned)(d + 256);
 #pragma unroll
-		for (int k = 0; k < 5; k++) {
-			dsum[0][k] += (in0 && k0 == k) ? d : 0; csum[0][k] += (in0 && k0 == k) ? 1 : 0;
-			dsum[1][k] += (in1 && k1 == k) ? d : 0; csum[1][k] += (in1 && k1 == k) ? 1 : 0;
-			dsum[2][k] += (in2 && k2 == k) ? d : 0; csum[2][k] += (in2 && k2 == k) ? 1 : 0;
-			dsum[3][k] += (in2 && k3 == k) ? d : 0; csum[3][k] += (in2 && k3 == k) ? 1 : 0;
+		for (int t = 0; t < 4; t++) {
+			cnt[t] += in[t] ? 1u << (6 * k[t]) : 0u;
+			d03[t] += (in[t] && k[t] < 4) ? (unsigned long long)e << (16 * k[t]) : 0ull;
+			d4[t] += (in[t] && k[t] == 4) ? e : 0u;
 		}
 		if (x < ex_full && y < ey_full) {                        // BO
 			atomicAdd(&sAcc[4][0][v >> 3], d);
@@ -283,11 +283,13 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_sao_stats(Planes org, Planes rec,
 #pragma unroll
 	for (int t = 0; t < 4; t++)
 #pragma unroll
-		for (int k = 0; k < 5; k++) {
-			const int ds = wave_sum(dsum[t][k]), cs = wave_sum(csum[t][k]);
+		for (int kk = 0; kk < 5; kk++) {
+			const int cl = (int)((cnt[t] >> (6 * kk)) & 63u);
+			const int el = kk < 4 ? (int)((d03[t] >> (16 * kk)) & 0xffffu) : (int)d4[t];
+			const int ds = wave_sum(el - 256 * cl), cs = wave_sum(cl);
 			if ((threadIdx.x & 63) == 0) {
-				atomicAdd(&sAcc[t][0][k], ds);
-				atomicAdd(&sAcc[t][1][k], cs);
+				atomicAdd(&sAcc[t][0][kk], ds);
+				atomicAdd(&sAcc[t][1][kk], cs);
 			}
 		}
 	__syncthreads();
