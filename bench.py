@@ -590,7 +590,12 @@ def cpu_baseline(frames=None):
         kv_mt = run((f"wpp={threads}",)) if threads > 1 else None
     if not kv:
         return None
-    res = {"value": float(kv["fps"]), "unit": "frames/s", "cores": 1, "kind": "reference",
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        cpu = "unknown"
+    res = {"value": float(kv["fps"]), "unit": "frames/s", "cores": 1, "kind": "reference", "host_cpu": cpu,
            "sample": f"{kv['frames']} frames {W}x{H} cfg2 (IPPP QP32 qpel SAO, wpp=1 engines=1), {kv['seconds']} s, oracle/_ref/ref_lockstep"}
     if kv_mt:
         res["wpp_threads"] = {"value": float(kv_mt["fps"]), "cores": threads, "seconds": float(kv_mt["seconds"])}
