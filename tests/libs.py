@@ -9,7 +9,6 @@ ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libhomer_ref.so")
 REF_LOCKSTEP = os.path.join(ORACLE_DIR, "_ref", "ref_lockstep")
 GPU_SO = os.path.join(ROOT, "homerhevc_amd", "libhomer_gpu.so")
-REFERENCE_SRC = "/root/reference/src/homer_lib"
 
 _cache = {}
 
