@@ -305,6 +305,8 @@ typedef struct hmr_gpu_cmd {
 	                             * start of the list, join at its end).  hmr_gpu_cmdlist_run ignores it (one stream, list order). */
 } hmr_gpu_cmd;
 #define HMR_GPU_MAX_BRANCHES 64
+/* A context and its command lists belong to one host thread at a time (capture temporarily redirects the context's stream to the branch
+ * streams); use one context per thread / per encoder engine. */
 typedef struct hmr_gpu_cmdlist hmr_gpu_cmdlist;
 int hmr_gpu_cmdlist_create(hmr_gpu_ctx *ctx, const hmr_gpu_cmd *cmds, int n, hmr_gpu_cmdlist **out);
 /* eager replay; event_pairs (optional, 2*n events from hmr_gpu_event_create) brackets every command for per-kernel timing */
