@@ -1,4 +1,6 @@
 // Context: device selection, stream, constant-table upload, device memory helpers, HIP-event timer.
+#include <mutex>
+
 #include "common.h"
 
 static hmr_gpu_ctx *g_default = nullptr;
@@ -64,6 +66,8 @@ extern "C" int hmr_gpu_set_default(hmr_gpu_ctx *ctx)
 // default context for the drop-in entries: created on first use on device 0
 hmr_gpu_ctx *hmr_default_ctx()
 {
+	static std::mutex m;
+	std::lock_guard<std::mutex> guard(m);
 	if (!g_default) {
 		hmr_gpu_ctx *c = nullptr;
 		if (hmr_gpu_create(&c, 0, nullptr) != HMR_GPU_OK) {

@@ -3,13 +3,20 @@
 // same batched kernel the performance path uses with a one-job batch, copies the result back and waits.
 // This is the compatibility surface (a maintainer can store these pointers in hvenc_enc_t.funcs, see
 // INTEGRATION.md); it is launch- and PCIe-bound by construction and is not what bench.py measures.
+#include <mutex>
+
 #include "common.h"
 
 hmr_gpu_ctx *hmr_default_ctx();
 
+// The reference calls its table from up to num_enc_engines x wfpp_num_threads host threads at once (hmr_private.h:1232-1234).  The drop-in
+// entries share one default context and its staging buffer, so a call holds this lock from staging to the final copy back.
+static std::recursive_mutex g_dropin_mutex;
+
 namespace {
 
 struct Stager {
+	std::unique_lock<std::recursive_mutex> lock{g_dropin_mutex};
 	hmr_gpu_ctx *c;
 	size_t in_end = 0, out_begin = 0, out_end = 0;
 	explicit Stager(hmr_gpu_ctx *ctx) : c(ctx) { in_end = align(sizeof(hmr_gpu_job)); }

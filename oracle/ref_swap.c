@@ -13,6 +13,7 @@
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -223,6 +224,7 @@ static void export_units(hvenc_engine_t *eng, int n)
 		g_tr[o] = ctu->tr_idx[a];
 	}
 }
+static pthread_mutex_t g_units_lock = PTHREAD_MUTEX_INITIALIZER;   /* WPP threads filter different CTU rows at the same time; the raster copy is shared */
 void hmr_deblock_filter_cu(henc_thread_t *et, slice_t *slice, ctu_info_t *ctu, int dir)
 {
 	hvenc_engine_t *eng = et->enc_engine;
@@ -230,6 +232,7 @@ void hmr_deblock_filter_cu(henc_thread_t *et, slice_t *slice, ctu_info_t *ctu, i
 		((void (*)(henc_thread_t *, slice_t *, ctu_info_t *, int))REAL(hmr_deblock_filter_cu))(et, slice, ctu, dir);
 		return;
 	}
+	pthread_mutex_lock(&g_units_lock);
 	if (!g_mvx) {
 		size_t n = (size_t)eng->pict_width_in_ctu * 16 * eng->pict_height_in_ctu * 16;
 		g_us = eng->pict_width_in_ctu * 16;
@@ -248,6 +251,7 @@ void hmr_deblock_filter_cu(henc_thread_t *et, slice_t *slice, ctu_info_t *ctu, i
 					   ctu->y[Y_COMP], ctu->size, dir, slice->pps->cb_qp_offset, slice->pps->cr_qp_offset, slice->slice_beta_offset_div2,
 					   slice->slice_tc_offset_div2);
 	}
+	pthread_mutex_unlock(&g_units_lock);
 }
 void sao_offset_ctu(henc_thread_t *et, ctu_info_t *ctu, sao_blk_param_t *p)
 {

@@ -43,3 +43,20 @@ def test_stream_identical_with_gpu_kernels(tmp_path, extra, w, h, frames):
         assert what in log, (what, log[-600:])
     assert len(ref) > 300
     assert gpu == ref, f"stream differs: {len(gpu)} vs {len(ref)} bytes"
+
+
+def test_wpp_threads_share_the_gpu(tmp_path):
+    """The reference calls its table from several WPP threads at once; the drop-in entries must serialise on the shared context.  Forced-intra
+    streams do not depend on the thread count, so 4 threads driving the GPU kernels must reproduce the 1-thread reference."""
+    if not (os.path.exists(SWAP) and os.path.exists(libs.REF_LOCKSTEP)):
+        pytest.skip("oracle/_ref not shipped (built only where the reference sources exist)")
+    sys.path.insert(0, os.path.join(libs.ROOT, "tools"))
+    import gen_yuv
+    w, h, frames = 416, 240, 2
+    clip = str(tmp_path / "clip.yuv")
+    gen_yuv.write_clip(clip, w, h, frames)
+    ref1, _ = _encode(libs.REF_LOCKSTEP, clip, str(tmp_path / "r1.265"), w, h, frames, extra=("force_intra=1",))
+    ref4, _ = _encode(libs.REF_LOCKSTEP, clip, str(tmp_path / "r4.265"), w, h, frames, extra=("force_intra=1", "wpp=4"))
+    assert ref4 == ref1, "reference itself depends on the thread count"
+    gpu4, _ = _encode(SWAP, clip, str(tmp_path / "g4.265"), w, h, frames, env={"HOMER_SWAP": "all"}, extra=("force_intra=1", "wpp=4"))
+    assert gpu4 == ref1
