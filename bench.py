@@ -44,7 +44,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 WORKLOADS = {   # name -> (width, height, recorded call mix); the metric is quoted on the first (BASELINE.json configs[1])
     "cfg2-1080p-P-frame-replay": (1920, 1080, "callmix_1080p_cfg2.json"),
     "cfg4-2160p-P-frame-replay": (3840, 2160, "callmix_2160p_cfg4.json"),   # configs[3] per engine: the same encode at 2160p
+    "cfg5-2160p-all-intra-replay": (3840, 2160, "callmix_2160p_cfg5_intra.json"),   # configs[4]: all-intra, full RDO, intra TU depth 4 (use --callmix-frame 1)
 }
+REF_ARGS = {"cfg5-2160p-all-intra-replay": ("force_intra=1", "rd=1", "intra_tr=4", "perf=0")}     # lockstep-driver keys of the CPU baseline
 CALLMIX = "callmix_1080p_cfg2.json"
 WORKLOAD = "cfg2-1080p-P-frame-replay"
 
@@ -568,8 +570,9 @@ def cpu_baseline(frames=None):
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_lockstep")
     if not os.path.exists(exe):
         return None
+    extra_cfg = REF_ARGS.get(WORKLOAD, ())
     if frames is None:
-        frames = 64 if W <= 1920 else 16      # about 10-15 s of single-core encoding either way
+        frames = 1 if extra_cfg else (64 if W <= 1920 else 16)      # about 10-35 s of single-core encoding
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gen_yuv
     with tempfile.TemporaryDirectory() as td:
@@ -577,7 +580,7 @@ def cpu_baseline(frames=None):
         gen_yuv.write_clip(clip, W, H, frames)
         def run(extra):
             try:
-                out = subprocess.run([exe, clip, "-", str(W), str(H), str(frames), *extra], capture_output=True, text=True, timeout=600).stdout
+                out = subprocess.run([exe, clip, "-", str(W), str(H), str(frames), *extra_cfg, *extra], capture_output=True, text=True, timeout=900).stdout
             except Exception:
                 return None
             for line in out.splitlines():
@@ -596,7 +599,7 @@ def cpu_baseline(frames=None):
     except OSError:
         cpu = "unknown"
     res = {"value": float(kv["fps"]), "unit": "frames/s", "cores": 1, "kind": "reference", "host_cpu": cpu,
-           "sample": f"{kv['frames']} frames {W}x{H} cfg2 (IPPP QP32 qpel SAO, wpp=1 engines=1), {kv['seconds']} s, oracle/_ref/ref_lockstep"}
+           "sample": f"{kv['frames']} frames {W}x{H} " + (" ".join(extra_cfg) if extra_cfg else "cfg2 (IPPP QP32 qpel SAO)") + f", wpp=1 engines=1, {kv['seconds']} s, oracle/_ref/ref_lockstep"}
     if kv_mt:
         res["wpp_threads"] = {"value": float(kv_mt["fps"]), "cores": threads, "seconds": float(kv_mt["seconds"])}
     return res
