@@ -799,6 +799,14 @@ def main():
         copy_gbs = 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src_probe, dst_probe
 
+    # what an event pair around a launch measures beyond the kernel: empty launches timed the same way
+    with torch.cuda.stream(stream):
+        evn = [ctx.event() for _ in range(42)]
+        for i in range(0, 42, 2):
+            ctx.record(evn[i]); ctx.call("hmr_gpu_nop"); ctx.record(evn[i + 1])
+        torch.cuda.synchronize()
+    nop_ms = sorted(ctx.elapsed(evn[i], evn[i + 1]) for i in range(2, 42, 2))[10]     # median of 20
+
     # per-kernel durations from the event pairs around every command
     if args.mode == "graph":      # the graph has no event nodes: one eager pass of the same steps right after the timed region
         with torch.cuda.stream(stream):
@@ -855,7 +863,7 @@ def main():
                          "timing": ("HIP event pairs around every launch inside the timed region" if args.mode == "eager" else
                                     "HIP event pairs around every launch, eager replay of the same K steps right after the timed graph replays "
                                     "(event nodes inside a hipGraph cannot be read back on ROCm 7.2)"),
-                         "bytes_per_launch": int(nbytes[dom]), "ms_per_launch": round(per[dom], 5),
+                         "bytes_per_launch": int(nbytes[dom]), "ms_per_launch": round(per[dom], 5), "ms_event_pair_empty_launch": round(nop_ms, 5),
                          "frame_level_frac": round(10.5 * W * H * fps / world / 1e9 / HBM_PEAK_GBS, 6)},
             "kernels_ms": {k: round(v, 4) for k, v in sorted(per.items(), key=lambda kv: -kv[1])},
             "kernels_gbs": {k: round(nbytes[k] / (v * 1e-3) / 1e9, 1) for k, v in sorted(per.items(), key=lambda kv: -kv[1]) if v > 0},

@@ -56,6 +56,8 @@ int hmr_gpu_upload(hmr_gpu_ctx *ctx, void *dev_dst, const void *host_src, size_t
 int hmr_gpu_download(hmr_gpu_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);   /* sync */
 int hmr_gpu_memset(hmr_gpu_ctx *ctx, void *dev_dst, int value, size_t bytes);
 
+/* An empty launch on the context's stream (timing calibration: what an event pair around a launch costs besides the kernel). */
+int hmr_gpu_nop(hmr_gpu_ctx *ctx);
 /* Cap on the workgroups of one batched launch (process-wide, default 4096).  Batched kernels grid-stride over their jobs, so results do not
  * depend on it; lower it to leave compute units to concurrent streams. */
 int hmr_gpu_set_max_grid(int blocks);

@@ -8,11 +8,15 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 20 --warmup 3 --no-cpu-baseline"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o kt -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err"
+# kernel durations: the eager replay (one launch at a time - these are the durations bench.py's roofline uses) and the default graph replay
+# (launches of different graph branches overlap, so individual durations stretch)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o kt -- python3 "$ROOT/bench.py" $ARGS --mode eager > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o ktg -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_under_rocprof_graph.json" 2> "$OUT/ktg.err"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT" -o f -- python3 "$ROOT/bench.py" $ARGS --mode eager --launch-order "$OUT/order.json" > "$OUT/bench_pmc_f.json" 2> "$OUT/f.err"
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT" -o w -- python3 "$ROOT/bench.py" $ARGS --mode eager > "$OUT/bench_pmc_w.json" 2> "$OUT/w.err"
 cd "$ROOT"
-find "$OUT" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
+cp "$(find "$OUT" -name 'kt_kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
+cp "$(find "$OUT" -name 'ktg_kernel_stats.csv' | head -1)" "$OUT/kernel_stats_graph.csv"
 F=$(find "$OUT" -name 'f_counter_collection.csv' | head -1); W=$(find "$OUT" -name 'w_counter_collection.csv' | head -1)
 python3 tools/pmc_summary.py "$F" "$W" "$OUT/order.json" > "$OUT/hbm_traffic.json" 2> "$OUT/pmc_summary.err"
 # keep only the small summaries (the raw traces exceed the merge limit)
