@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Random differential run of the CPU oracle against the compiled reference (build container only: needs oracle/_ref) for the composite
+functions - intra mode search, intra / inter / plain TU chains - beyond the fixed case lists of tests/kernel_cases.py.
+usage: python tools/oracle_fuzz.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import kernel_cases as kc  # noqa: E402
+import libs  # noqa: E402
+
+
+def neighbours(r, n):
+    left, top = (int(r.integers(0, 2)), int(r.integers(0, 2))) if r.random() < 0.3 else (1, 1)
+    bl, tr = int(r.integers(0, 2)) & left, int(r.integers(0, 2)) & top
+    return dict(left=left, top=top, bl=bl, tr=tr, bl_size=(n if r.random() < 0.7 else max(n // 2, 4)) if bl else 0,
+                tr_size=(n if r.random() < 0.7 else max(n // 2, 4)) if tr else 0, strong=int(r.integers(0, 2)))
+
+
+def random_case(r):
+    kind = r.choice(["intra_search", "intra_tu_chain", "inter_tu_chain", "tu_chain"])
+    if kind == "intra_search":
+        n = int(r.choice([4, 8, 16, 32, 64]))
+        p = dict(n=n, **neighbours(r, n), left_mode=int(r.integers(-1, 35)), top_mode=int(r.integers(-1, 35)), rd_mode=int(r.choice([2, 0])),
+                 sqrt_lambda=float(r.uniform(0.5, 80)), theta=float(r.uniform(0, np.pi)), period=float(r.uniform(2, 30)), amp=float(r.uniform(0, 100)),
+                 tilt=float(r.uniform(-8, 8)), noise=int(r.integers(0, 12)))
+    elif kind == "intra_tu_chain":
+        n = int(r.choice([4, 8, 16, 32]))
+        p = dict(n=n, comp=int(r.choice([0, 0, 1, 2])) if n < 32 else 0, **neighbours(r, n), mode=int(r.integers(0, 35)), scan=int(r.integers(1, 4)),
+                 slice_i=int(r.integers(0, 2)), sbh=int(r.integers(0, 2)), per=int(r.integers(0, 9)), rem=int(r.integers(0, 6)), theta=float(r.uniform(0, np.pi)),
+                 period=float(r.uniform(2, 25)), amp=float(r.uniform(0, 100)), noise=int(r.choice([0, 1, 4, 12, 40])))
+    elif kind == "inter_tu_chain":
+        n = int(r.choice([4, 8, 16, 32]))
+        p = dict(n=n, comp=int(r.choice([0, 0, 1, 2])) if n < 32 else 0, scan=3, slice_i=0, sbh=int(r.integers(0, 2)), per=int(r.integers(0, 9)),
+                 rem=int(r.integers(0, 6)), weight=float(2.0 ** (r.integers(-3, 6) / 3.0)), thr=float(np.clip(r.uniform(0, 8000) / 2.5 - 5.0, 1.0, 20000.0)),
+                 theta=float(r.uniform(0, np.pi)), period=float(r.uniform(2, 20)), amp=float(r.choice([0, 1, 3, 8, 25, 80, 250])), noise=int(r.choice([0, 1, 3, 10, 30])))
+    else:
+        n = int(r.choice([4, 8, 16, 32]))
+        comp, intra = (int(r.choice([0, 1, 2])) if n < 32 else 0), int(r.integers(0, 2))
+        p = dict(n=n, comp=comp, intra=intra, slice_i=intra | int(r.integers(0, 2)), sbh=int(r.integers(0, 2)), per=int(r.integers(0, 9)), rem=int(r.integers(0, 6)),
+                 scan=int(r.integers(1, 4)), noise=int(r.choice([1, 3, 10, 40, 255])), dst=1 if (n == 4 and intra and comp == 0) else 0)
+    return (str(kind), p, int(r.integers(1, 1 << 30)))
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    r = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261002)
+    ora, ref = libs.load_oracle(), libs.load_ref()
+    if ref is None:
+        sys.exit("oracle/_ref/libhomer_ref.so is not built here")
+    t0, n, bad = time.time(), 0, 0
+    while time.time() - t0 < seconds:
+        case = random_case(r)
+        a, b = kc.run(ora, "ora_", case), kc.run(ref, "refh_", case)
+        n += 1
+        for k in a:
+            if not np.array_equal(a[k], b[k]):
+                bad += 1
+                print("MISMATCH", case, k)
+                break
+    print(f"{n} cases, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
+main()
