@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Random differential run of the CPU oracle against the compiled reference (build container only: needs oracle/_ref) for the composite
-functions - intra mode search, intra / inter / plain TU chains - beyond the fixed case lists of tests/kernel_cases.py.
-usage: python tools/oracle_fuzz.py [seconds] [seed]"""
+"""Random differential runs for the composite functions - intra mode search, intra / inter / plain TU chains - beyond the fixed case lists
+of tests/kernel_cases.py: the CPU oracle against the compiled reference (build container: needs oracle/_ref), or, with --gpu, the drop-in
+entries of libhomer_gpu.so against the oracle (GPU box).
+usage: python tools/oracle_fuzz.py [--gpu] [seconds] [seed]"""
 import os
 import sys
 import time
@@ -47,15 +48,18 @@ def random_case(r):
 
 
 def main():
-    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    r = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261002)
-    ora, ref = libs.load_oracle(), libs.load_ref()
+    args = [a for a in sys.argv[1:] if a != "--gpu"]
+    gpu = "--gpu" in sys.argv[1:]
+    seconds = float(args[0]) if args else 60.0
+    r = np.random.default_rng(int(args[1]) if len(args) > 1 else 20261002)
+    ora = libs.load_oracle()
+    ref, prefix = (libs.load_gpu(), "hmr_gpu_") if gpu else (libs.load_ref(), "refh_")
     if ref is None:
         sys.exit("oracle/_ref/libhomer_ref.so is not built here")
     t0, n, bad = time.time(), 0, 0
     while time.time() - t0 < seconds:
         case = random_case(r)
-        a, b = kc.run(ora, "ora_", case), kc.run(ref, "refh_", case)
+        a, b = kc.run(ora, "ora_", case), kc.run(ref, prefix, case)
         n += 1
         for k in a:
             if not np.array_equal(a[k], b[k]):
