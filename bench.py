@@ -4,22 +4,29 @@
 Workload ("cfg2-1080p-P-frame-replay"): one step = the complete hot-path work of one 1920x1080 P frame of the
 reference's cfg-2 encode (IPPP gop_size=1, QP 32, quarter-pel ME, SAO on, wpp=1, engines=1):
   * every call the reference makes through low_level_funcs_t and to the off-table kernels during that frame -
-    function, block size and stage flags exactly as recorded from the compiled reference by oracle/ref_callmix.c
-    (fixture tests/golden/callmix_1080p_cfg2.json, ~4.4 M calls per P frame) - issued as ~45 batched launches
-    over device-resident synthetic planes of the frame's shape (seeded positions), and
-  * the four frame-level in-loop passes (deblock V+H, SAO statistics, SAO offset, border padding) over the whole
+    function, block size, stage flags and calling driver exactly as recorded from the compiled reference by
+    oracle/ref_callmix.c (fixture tests/golden/callmix_1080p_cfg2.json, 4.5 M table-level calls per P frame) - issued as
+    batched launches over device-resident synthetic planes laid out like the encoder's windows (seeded positions).  Call
+    sequences that the reference issues from one per-block driver are replayed by that driver's fused kernel (sub-pel
+    refinement, motion compensation, intra mode search, intra / inter / plain TU chains); --unfused replays every table
+    call as its own job;
+  * the frame-level in-loop passes (edge flags, deblock V+H, SAO statistics, SAO offset, border padding) over the whole
     picture with synthetic side-info.
-Inputs are resident in HBM before the timed region; decisions, CABAC and bitstream packing stay on the host
- and are not part of the step.  value = frames/s = steps / wall time (max over ranks, all GPUs).
+The launches of a frame are described once as a C command list, captured into a hipGraph (independent launches on
+parallel branches) and replayed per step.  Inputs are resident in HBM before the timed region; decisions, CABAC and
+bitstream packing stay on the host and are not part of the step.  value = frames/s = steps / wall time
+(max over ranks, all GPUs).  Other workloads (--workload): the same encode at 2160p, and the all-intra full-RDO 2160p
+configuration of BASELINE configs[4].
 
 Multi-GPU (--gpus N under torch.distributed.run): one encoder engine per GPU (num_enc_engines <-> GPUs, weak
 scaling: every rank replays its own frames).  The only data-path exchange is the one the reference's engines
 have: the reconstructed, padded reference picture goes from engine r to engine r+1 (mod N) once per frame, as
 point-to-point send/recv over RCCL.
 
-Extra objects on the JSON line: `roofline` for the dominant kernel (HIP-event durations measured inside the timed
-region, algorithmic bytes at ABI width per SURVEY.md §8-d) and `cpu_baseline` (the compiled reference encoder,
-oracle/_ref/ref_lockstep, timed on this host on a bounded sample of the same configuration; rank 0, N=1 only).
+Extra objects on the JSON line: `roofline` for the launch with the largest HIP-event time (algorithmic bytes at ABI width per
+SURVEY.md 8-d, counter-measured HBM traffic and VALU issue share from the committed profiles) and `cpu_baseline` (the
+compiled reference encoder, oracle/_ref/ref_lockstep, timed on this host on a bounded sample of the same configuration;
+rank 0, N=1 only).
 """
 import argparse
 import ctypes as C
