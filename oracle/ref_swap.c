@@ -22,9 +22,11 @@
 #include "hmr_common.h"
 #include "homer_gpu.h"
 
+static FILE *g_trace;
 static int want(const char *name)
 {
 	const char *s = getenv("HOMER_SWAP");
+	if (g_trace) return 0;             /* trace mode: everything that is not traced runs the reference's own code */
 	if (!s || !strcmp(s, "all")) return 1;
 	if (!strcmp(s, "none")) return 0;
 	{
@@ -37,6 +39,44 @@ static int want(const char *name)
 	}
 	return 0;
 }
+
+
+/* ---- trace mode (HOMER_TRACE=file [HOMER_TRACE_STRIDE=k]): the interposers of the block drivers run the REFERENCE's own function and log the
+ * flat inputs and the outputs it produced, every k-th call - real-encode vectors for the batched GPU entries (tests/golden/make_trace.py).
+ * record = int32 kind, nh, h[nh], nd, double d[nd], nb, then nb x {int32 count, int16 data[count]} ---- */
+static int g_trace_stride = 1;
+static unsigned long g_trace_calls;
+typedef struct { int32_t kind, nh, h[40], nd; double d[4]; int32_t nb, cnt[8]; int16_t *data[8]; } trec;
+static int tr_pick(void) { return g_trace && (g_trace_calls++ % g_trace_stride) == 0; }
+static void tr_blob(trec *t, const int16_t *p, int stride, int w, int h)
+{
+	int y;
+	int16_t *d = malloc((size_t)w * h * 2);
+	for (y = 0; y < h; y++) memcpy(d + (size_t)y * w, p + (size_t)y * stride, (size_t)w * 2);
+	t->cnt[t->nb] = w * h;
+	t->data[t->nb++] = d;
+}
+/* the neighbours an intra block may read: row 0 (corner + 2n) and column 0 (2n below the corner) of the (2n+1)^2 square, what is not available as 0 */
+static void tr_lshape(trec *t, const int16_t *corner, int stride, int n, int left, int top, int bl, int tr, int bl_size, int tr_size)
+{
+	int16_t *d = calloc((size_t)(4 * n + 1), 2);
+	int rows = left ? n + (bl ? bl_size : 0) : 0, cols = top ? n + (tr ? tr_size : 0) : 0, i;
+	if (left || top) d[0] = corner[0];
+	for (i = 1; i <= cols; i++) d[i] = corner[i];
+	for (i = 1; i <= rows; i++) d[2 * n + i] = corner[(size_t)i * stride];
+	t->cnt[t->nb] = 4 * n + 1;
+	t->data[t->nb++] = d;
+}
+static void tr_write(trec *t)
+{
+	int i;
+	fwrite(&t->kind, 4, 1, g_trace); fwrite(&t->nh, 4, 1, g_trace); fwrite(t->h, 4, t->nh, g_trace);
+	fwrite(&t->nd, 4, 1, g_trace); fwrite(t->d, 8, t->nd, g_trace); fwrite(&t->nb, 4, 1, g_trace);
+	for (i = 0; i < t->nb; i++) { fwrite(&t->cnt[i], 4, 1, g_trace); fwrite(t->data[i], 2, t->cnt[i], g_trace); free(t->data[i]); }
+	fflush(g_trace);
+}
+#define TR_H(t, ...) do { int32_t v_[] = {__VA_ARGS__}; memcpy((t)->h + (t)->nh, v_, sizeof v_); (t)->nh += sizeof v_ / 4; } while (0)
+enum { TR_INTER_TU = 1, TR_INTRA_TU = 2, TR_INTRA_SEARCH = 3, TR_MC = 4 };
 
 static void gpu_planar(henc_thread_t *et, int16_t *pred, int ps, int16_t *adi, int adi_size, int n, int shift)
 { (void)et; (void)shift; hmr_gpu_intra_planar(pred, ps, adi, adi_size, n); }
@@ -77,6 +117,12 @@ void lockstep_post_init(void *handle)
 {
 	low_level_funcs_t *f = &((hvenc_enc_t *)handle)->funcs;
 	int n = 0;
+	if (getenv("HOMER_TRACE")) {
+		g_trace = fopen(getenv("HOMER_TRACE"), "wb");
+		if (getenv("HOMER_TRACE_STRIDE")) g_trace_stride = atoi(getenv("HOMER_TRACE_STRIDE"));
+		fprintf(stderr, "ref_swap: trace mode, table untouched\n");
+		return;
+	}
 #define SWAP(member, fn) if (want(#member)) { f->member = fn; n++; }
 	SWAP(sse_copy_16_16, hmr_gpu_copy_16_16) SWAP(sse_copy_16_8, hmr_gpu_copy_16_8) SWAP(sse_copy_8_16, hmr_gpu_copy_8_16)
 	SWAP(sad, hmr_gpu_sad) SWAP(ssd16b, hmr_gpu_ssd16b) SWAP(predict, hmr_gpu_predict) SWAP(reconst, hmr_gpu_reconst)
@@ -140,6 +186,16 @@ uint32_t hmr_motion_estimation(henc_thread_t *et, ctu_info_t *ctu, cu_partition_
 void hmr_motion_compensation_luma(henc_thread_t *et, cu_partition_info_t *cu, int16_t *ref, int ref_stride, int16_t *pred, int pred_stride, int width, int height,
 				  int size_shift, motion_vector_t *mv, int is_bi)
 {
+	if (tr_pick()) {
+		trec t = {TR_MC};
+		TR_H(&t, 1, width, height, mv->hor_vector & 3, mv->ver_vector & 3, is_bi);
+		tr_blob(&t, ref + (ptrdiff_t)((mv->ver_vector >> 2) - 4) * ref_stride + (mv->hor_vector >> 2) - 4, ref_stride, width + 8, height + 8);
+		((void (*)(henc_thread_t *, cu_partition_info_t *, int16_t *, int, int16_t *, int, int, int, int, motion_vector_t *, int))REAL(hmr_motion_compensation_luma))(
+			et, cu, ref, ref_stride, pred, pred_stride, width, height, size_shift, mv, is_bi);
+		tr_blob(&t, pred, pred_stride, width, height);
+		tr_write(&t);
+		return;
+	}
 	if (!want("motion_compensation")) {
 		((void (*)(henc_thread_t *, cu_partition_info_t *, int16_t *, int, int16_t *, int, int, int, int, motion_vector_t *, int))REAL(hmr_motion_compensation_luma))(
 			et, cu, ref, ref_stride, pred, pred_stride, width, height, size_shift, mv, is_bi);
@@ -150,6 +206,16 @@ void hmr_motion_compensation_luma(henc_thread_t *et, cu_partition_info_t *cu, in
 
 void hmr_motion_compensation_chroma(henc_thread_t *et, int16_t *ref, int ref_stride, int16_t *pred, int pred_stride, int size, int size_shift, motion_vector_t *mv, int is_bi)
 {
+	if (tr_pick()) {
+		trec t = {TR_MC};
+		TR_H(&t, 0, size, size, mv->hor_vector & 7, mv->ver_vector & 7, is_bi);
+		tr_blob(&t, ref + (ptrdiff_t)((mv->ver_vector >> 3) - 4) * ref_stride + (mv->hor_vector >> 3) - 4, ref_stride, size + 8, size + 8);
+		((void (*)(henc_thread_t *, int16_t *, int, int16_t *, int, int, int, motion_vector_t *, int))REAL(hmr_motion_compensation_chroma))(et, ref, ref_stride, pred,
+																		   pred_stride, size, size_shift, mv, is_bi);
+		tr_blob(&t, pred, pred_stride, size, size);
+		tr_write(&t);
+		return;
+	}
 	if (!want("motion_compensation")) {
 		((void (*)(henc_thread_t *, int16_t *, int, int16_t *, int, int, int, motion_vector_t *, int))REAL(hmr_motion_compensation_chroma))(et, ref, ref_stride, pred,
 																		   pred_stride, size, size_shift, mv, is_bi);
@@ -167,6 +233,31 @@ int homer_loop1_motion_intra(henc_thread_t *et, ctu_info_t *ctu, ctu_info_t *ctu
 			     int16_t *orig_buff, int orig_buff_stride, int16_t *decoded_buff, int decoded_buff_stride, int depth, int curr_depth, int size,
 			     int size_shift, int part_size_type, int adi_size, int best_pred_modes[3], double best_pred_cost[3])
 {
+	if (et->rd_mode == RD_FAST && tr_pick()) {
+		trec t = {TR_INTRA_SEARCH};
+		int32_t tp[3] = {-1, -1, -1};
+		int tbl = min(size, et->pict_height[Y_COMP] - (ctu->y[Y_COMP] + pi->y_position + size)), ttr = min(size, et->pict_width[Y_COMP] - (ctu->x[Y_COMP] + pi->x_position + size));
+		int r_;
+		ctu_rd->intra_mode[Y_COMP] = et->intra_mode_buffs[Y_COMP][curr_depth];
+		get_intra_dir_luma_predictor(ctu_rd, pi, (int *)tp, NULL);
+		TR_H(&t, size, pi->left_neighbour, pi->top_neighbour, pi->left_bottom_neighbour, pi->top_right_neighbour, tbl, ttr, et->sps->strong_intra_smooth_enabled_flag,
+		     tp[0], tp[1], tp[2], 1, 1, 1, 12);
+		t.nd = 1; t.d[0] = et->rd.sqrt_lambda;
+		tr_blob(&t, orig_buff, orig_buff_stride, size, size);
+		tr_lshape(&t, decoded_buff - decoded_buff_stride - 1, decoded_buff_stride, size, pi->left_neighbour, pi->top_neighbour, pi->left_bottom_neighbour,
+			  pi->top_right_neighbour, tbl, ttr);
+		r_ = ((int (*)(henc_thread_t *, ctu_info_t *, ctu_info_t *, cu_partition_info_t *, int16_t *, int, int16_t *, int, int16_t *, int, int, int, int, int, int, int, int *,
+			       double *))REAL(homer_loop1_motion_intra))(et, ctu, ctu_rd, pi, pred_buff, pred_buff_stride, orig_buff, orig_buff_stride, decoded_buff,
+									   decoded_buff_stride, depth, curr_depth, size, size_shift, part_size_type, adi_size, best_pred_modes,
+									   best_pred_cost);
+		TR_H(&t, best_pred_modes[0], r_);
+		t.nd = 2; t.d[1] = best_pred_cost[0];
+		tr_blob(&t, et->adi_pred_buff, 0, 4 * size + 1, 1);
+		tr_blob(&t, et->adi_filtered_pred_buff, 0, 4 * size + 1, 1);
+		tr_blob(&t, pred_buff, pred_buff_stride, size, size);
+		tr_write(&t);
+		return r_;
+	}
 	if (!want("intra_search"))
 		return ((int (*)(henc_thread_t *, ctu_info_t *, ctu_info_t *, cu_partition_info_t *, int16_t *, int, int16_t *, int, int16_t *, int, int, int, int, int, int,
 				 int, int *, double *))REAL(homer_loop1_motion_intra))(et, ctu, ctu_rd, pi, pred_buff, pred_buff_stride, orig_buff, orig_buff_stride,
@@ -294,7 +385,8 @@ int find_scan_mode(int is_intra, int is_luma, int width, int dir_mode, int up_le
 uint encode_intra_cu(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *pi, int depth, int cu_mode, PartSize part_size_type, int *curr_sum, int gcnt)
 {
 	static int said;
-	if (!want("intra_tu_chain"))
+	const int traced = tr_pick();
+	if (!traced && !want("intra_tu_chain"))
 		return ((uint (*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int, int, PartSize, int *, int))REAL(encode_intra_cu))(et, ctu, pi, depth, cu_mode,
 															       part_size_type, curr_sum, gcnt);
 	static const uint8_t filter_thr[5] = {10, 7, 1, 0, 10};                 /* intra_filter, :148 */
@@ -313,6 +405,21 @@ uint encode_intra_cu(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *pi
 	int bl = min(size, et->pict_height[Y_COMP] - (ctu->y[Y_COMP] + y + size)), tr = min(size, et->pict_width[Y_COMP] - (ctu->x[Y_COMP] + x + size));
 	int shift = curr_depth - depth + (part_size_type == SIZE_NxN);
 	uint32_t ssd;
+	if (traced) {
+		trec t = {TR_INTRA_TU};
+		TR_H(&t, size, pi->left_neighbour, pi->top_neighbour, pi->left_bottom_neighbour, pi->top_right_neighbour, bl, tr, et->sps->strong_intra_smooth_enabled_flag,
+		     is_filtered, cu_mode, scan_mode, et->enc_engine->current_pict.slice.slice_type == I_SLICE, et->pps->sign_data_hiding_flag, per, rem);
+		tr_blob(&t, orig, orig_stride, size, size);
+		tr_lshape(&t, dec - dec_stride - 1, dec_stride, size, pi->left_neighbour, pi->top_neighbour, pi->left_bottom_neighbour, pi->top_right_neighbour, bl, tr);
+		ssd = ((uint (*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int, int, PartSize, int *, int))REAL(encode_intra_cu))(et, ctu, pi, depth, cu_mode,
+															      part_size_type, curr_sum, gcnt);
+		TR_H(&t, *curr_sum, (int32_t)ssd);
+		tr_blob(&t, pred, pred_stride, size, size);
+		tr_blob(&t, quant, size, size, size);
+		tr_blob(&t, dec, dec_stride, size, size);
+		tr_write(&t);
+		return ssd;
+	}
 	ctu->top = 1;
 	ctu->left = 1;
 	ssd = hmr_gpu_intra_tu_chain(orig, orig_stride, dec - dec_stride - 1, dec_stride, pi->left_neighbour, pi->top_neighbour, pi->left_bottom_neighbour,
@@ -338,7 +445,8 @@ extern const uint8_t chroma_scale_conversion_table[];
 int encode_inter_cu(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *cu, int depth, PartSize part_size_type, int *curr_sum, int gcnt)
 {
 	static int said;
-	if (!want("inter_tu_chain"))
+	const int traced = tr_pick();
+	if (!traced && !want("inter_tu_chain"))
 		return ((int (*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int, PartSize, int *, int))REAL(encode_inter_cu))(et, ctu, cu, depth, part_size_type, curr_sum, gcnt);
 	int curr_depth = cu->depth, x = cu->x_position, y = cu->y_position, size = cu->size;
 	int scan_mode = find_scan_mode(TRUE, TRUE, size, REG_DCT, 0);
@@ -348,6 +456,20 @@ int encode_inter_cu(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *cu,
 	int16_t *quant = WND_POSITION_1D(int16_t *, *quant_wnd, Y_COMP, gcnt, et->ctu_width, (cu->abs_index << et->num_partitions_in_cu_shift));
 	int16_t *dec = WND_POSITION_2D(int16_t *, *decoded_wnd, Y_COMP, x, y, gcnt, et->ctu_width);
 	double thr = clip(et->enc_engine->avg_dist / 2.5 - 5., 1., 20000.);
+	if (traced) {
+		trec t = {TR_INTER_TU};
+		int r_;
+		TR_H(&t, size, Y_COMP, scan_mode, et->enc_engine->current_pict.slice.slice_type == I_SLICE, et->pps->sign_data_hiding_flag, cu->qp / 6, cu->qp % 6);
+		t.nd = 2; t.d[0] = 1.0; t.d[1] = thr;
+		tr_blob(&t, res, WND_STRIDE_2D(et->residual_wnd, Y_COMP), size, size);
+		tr_blob(&t, pred, WND_STRIDE_2D(et->prediction_wnd[0], Y_COMP), size, size);
+		r_ = ((int (*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int, PartSize, int *, int))REAL(encode_inter_cu))(et, ctu, cu, depth, part_size_type, curr_sum, gcnt);
+		TR_H(&t, *curr_sum, r_);
+		tr_blob(&t, quant, size, size, size);
+		tr_blob(&t, dec, WND_STRIDE_2D(*decoded_wnd, Y_COMP), size, size);
+		tr_write(&t);
+		return r_;
+	}
 	int ssd = (int)hmr_gpu_inter_tu_chain(res, WND_STRIDE_2D(et->residual_wnd, Y_COMP), pred, WND_STRIDE_2D(et->prediction_wnd[0], Y_COMP), quant, dec,
 					      WND_STRIDE_2D(*decoded_wnd, Y_COMP), size, scan_mode, Y_COMP, et->enc_engine->current_pict.slice.slice_type == I_SLICE,
 					      et->pps->sign_data_hiding_flag, cu->qp / 6, cu->qp % 6, 1.0, thr, curr_sum);
@@ -360,7 +482,8 @@ int encode_inter_cu(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *cu,
 }
 int encode_inter_cu_chroma(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *cu, int component, int depth, PartSize part_size_type, int *curr_sum, int gcnt)
 {
-	if (!want("inter_tu_chain"))
+	const int traced = tr_pick();
+	if (!traced && !want("inter_tu_chain"))
 		return ((int (*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int, int, PartSize, int *, int))REAL(encode_inter_cu_chroma))(et, ctu, cu, component, depth,
 																	 part_size_type, curr_sum, gcnt);
 	slice_t *currslice = &et->enc_engine->current_pict.slice;
@@ -377,6 +500,21 @@ int encode_inter_cu_chroma(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info
 	int16_t *quant = WND_POSITION_1D(int16_t *, *quant_wnd, component, gcnt, et->ctu_width, (pp->abs_index << et->num_partitions_in_cu_shift) >> 2);
 	int16_t *dec = WND_POSITION_2D(int16_t *, *decoded_wnd, component, x, y, gcnt, et->ctu_width);
 	double thr = clip(et->enc_engine->avg_dist / 2.5 - 5., 1., 20000.);
+	if (traced) {
+		trec t = {TR_INTER_TU};
+		int r_;
+		TR_H(&t, size, component, scan_mode, currslice->slice_type == I_SLICE, et->pps->sign_data_hiding_flag, qp_chroma / 6, qp_chroma % 6);
+		t.nd = 2; t.d[0] = weight; t.d[1] = thr;
+		tr_blob(&t, res, WND_STRIDE_2D(et->residual_wnd, component), size, size);
+		tr_blob(&t, pred, WND_STRIDE_2D(et->prediction_wnd[0], component), size, size);
+		r_ = ((int (*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int, int, PartSize, int *, int))REAL(encode_inter_cu_chroma))(et, ctu, cu, component, depth,
+																       part_size_type, curr_sum, gcnt);
+		TR_H(&t, *curr_sum, r_);
+		tr_blob(&t, quant, size, size, size);
+		tr_blob(&t, dec, WND_STRIDE_2D(*decoded_wnd, component), size, size);
+		tr_write(&t);
+		return r_;
+	}
 	uint32_t ssd = hmr_gpu_inter_tu_chain(res, WND_STRIDE_2D(et->residual_wnd, component), pred, WND_STRIDE_2D(et->prediction_wnd[0], component), quant, dec,
 					      WND_STRIDE_2D(*decoded_wnd, component), size, scan_mode, component, currslice->slice_type == I_SLICE,
 					      et->pps->sign_data_hiding_flag, qp_chroma / 6, qp_chroma % 6, weight, thr, curr_sum);
