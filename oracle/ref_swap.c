@@ -76,7 +76,7 @@ static void tr_write(trec *t)
 	fflush(g_trace);
 }
 #define TR_H(t, ...) do { int32_t v_[] = {__VA_ARGS__}; memcpy((t)->h + (t)->nh, v_, sizeof v_); (t)->nh += sizeof v_ / 4; } while (0)
-enum { TR_INTER_TU = 1, TR_INTRA_TU = 2, TR_INTRA_SEARCH = 3, TR_MC = 4 };
+enum { TR_INTER_TU = 1, TR_INTRA_TU = 2, TR_INTRA_SEARCH = 3, TR_MC = 4, TR_REF_PLANE = 5, TR_ME = 6 };
 
 static void gpu_planar(henc_thread_t *et, int16_t *pred, int ps, int16_t *adi, int adi_size, int n, int shift)
 { (void)et; (void)shift; hmr_gpu_intra_planar(pred, ps, adi, adi_size, n); }
@@ -164,6 +164,39 @@ uint32_t hmr_motion_estimation(henc_thread_t *et, ctu_info_t *ctu, cu_partition_
 			       int gx, int gy, int init_x, int init_y, int size, int size_shift, int range_x, int range_y, int frame_w, int frame_h,
 			       motion_vector_t *mv, motion_vector_t *subpix_mv, mv_candiate_list_t *amvp, uint32_t threshold, unsigned int action)
 {
+	if (tr_pick()) {
+		/* the padded reference picture is logged once per picture, a search record then names it and the PU position */
+		static const int16_t *last_plane;
+		static int plane_id = -1;
+		const int16_t *plane = ref - (ptrdiff_t)gy * ref_stride - gx;
+		trec t = {TR_ME};
+		int i, na = amvp->num_mv_candidates, ns = et->mv_search_candidates.num_mv_candidates;
+		int ix = init_x, iy = init_y;
+		uint32_t r_;
+		static uint32_t last_poc = 0xffffffffu;
+		if (plane != last_plane || et->enc_engine->current_pict.slice.poc != last_poc) {
+			trec p = {TR_REF_PLANE};
+			plane_id++;
+			last_plane = plane; last_poc = et->enc_engine->current_pict.slice.poc;
+			TR_H(&p, plane_id, frame_w, frame_h, 80);
+			tr_blob(&p, plane - (ptrdiff_t)80 * ref_stride - 80, ref_stride, frame_w + 160, frame_h + 160);
+			tr_write(&p);
+		}
+		if (!(action & MOTION_PEL_MASK)) { ix = mv->hor_vector >> 2; iy = mv->ver_vector >> 2; }
+		TR_H(&t, cu->size, plane_id, gx, gy, ix, iy, range_x, range_y, frame_w, frame_h, (int)action, na, ns);
+		for (i = 0; i < 2; i++) TR_H(&t, i < na ? amvp->mv_candidates[i].mv.hor_vector : 0, i < na ? amvp->mv_candidates[i].mv.ver_vector : 0);
+		for (i = 0; i < 5; i++)
+			TR_H(&t, i < ns ? et->mv_search_candidates.mv_candidates[i].mv.hor_vector : 0, i < ns ? et->mv_search_candidates.mv_candidates[i].mv.ver_vector : 0);
+		t.nd = 1; t.d[0] = calc_mv_correction(cu->qp, et->enc_engine->avg_dist);
+		tr_blob(&t, orig, orig_stride, cu->size, cu->size);
+		r_ = ((uint32_t(*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int16_t *, int, int16_t *, int, int, int, int, int, int, int, int, int, int, int,
+				   motion_vector_t *, motion_vector_t *, mv_candiate_list_t *, uint32_t, unsigned int))REAL(hmr_motion_estimation))(
+			et, ctu, cu, orig, orig_stride, ref, ref_stride, gx, gy, init_x, init_y, size, size_shift, range_x, range_y, frame_w, frame_h, mv, subpix_mv, amvp,
+			threshold, action);
+		TR_H(&t, mv->hor_vector, mv->ver_vector, subpix_mv->hor_vector, subpix_mv->ver_vector, (int32_t)r_);
+		tr_write(&t);
+		return r_;
+	}
 	if (!want("motion_estimation"))
 		return ((uint32_t(*)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, int16_t *, int, int16_t *, int, int, int, int, int, int, int, int, int, int, int,
 				     motion_vector_t *, motion_vector_t *, mv_candiate_list_t *, uint32_t, unsigned int))REAL(hmr_motion_estimation))(

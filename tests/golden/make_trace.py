@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gen_yuv  # noqa: E402
 
-KINDS = {1: "inter_tu", 2: "intra_tu", 3: "intra_search", 4: "mc"}
+KINDS = {1: "inter_tu", 2: "intra_tu", 3: "intra_search", 4: "mc", 5: "ref_plane", 6: "me"}
 W, H, FRAMES, STRIDE = 200, 136, 3, 4
 
 
@@ -51,7 +51,7 @@ def main():
     groups = {}
     for kind, hdr, dbl, blobs in recs:
         # group by (kind, block geometry) so that every group stacks into rectangular arrays
-        key = (KINDS[kind], hdr[1], hdr[2]) if kind == 4 else (KINDS[kind], hdr[0], hdr[0])
+        key = (KINDS[kind], hdr[1], hdr[2]) if kind in (4, 5) else (KINDS[kind], hdr[0], hdr[0])
         groups.setdefault(key, []).append((hdr, dbl, blobs))
     out, meta = {}, {"width": W, "height": H, "frames": FRAMES, "stride": STRIDE, "groups": []}
     for (name, a, b), items in sorted(groups.items()):

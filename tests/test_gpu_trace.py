@@ -50,8 +50,12 @@ def dev():
 def test_trace_groups_as_single_launches(dev):
     gpu = dev.gpu
     seen = set()
-    for g in tc.load():
+    groups = tc.load()
+    planes = tc.ref_planes(groups)
+    for g in groups:
         cnt, kind, hdr, dbl, b = g["count"], g["kind"], g["hdr"], g["dbl"], g["blobs"]
+        if kind == "ref_plane":
+            continue
         seen.add(kind)
         idx = np.arange(cnt, dtype=np.int64)
         if kind == "inter_tu":
@@ -107,6 +111,23 @@ def test_trace_groups_as_single_launches(dev):
                 assert np.array_equal(out[2 * cnt * a1:].reshape(cnt, e), b[4]), (g["tag"], "last prediction")
                 res = dev.down(d_res, cnt, np.dtype([("best", "<i4"), ("bits", "<i4"), ("cost", "<f8")]))
                 assert np.array_equal(res["best"], hdr[:, 15]) and np.array_equal(res["bits"], hdr[:, 16]) and np.array_equal(res["cost"], dbl[:, 1]), g["tag"]
+        elif kind == "me":
+            n = g["w"]; e = n * n
+            ids = sorted(planes)
+            psize = planes[ids[0]].size
+            arena = np.concatenate([planes[k] for k in ids] + [b[0].ravel()])
+            fw, fh = int(hdr[0, 8]), int(hdr[0, 9]); st = fw + 160
+            assert (hdr[:, 8] == fw).all() and (hdr[:, 9] == fh).all() and (hdr[:, 6] == hdr[0, 6]).all() and (hdr[:, 7] == hdr[0, 7]).all()
+            jb = np.zeros(cnt, gh.ME_JOB_DTYPE)
+            jb["corr"] = dbl[:, 0]
+            jb["orig_off"] = len(ids) * psize + idx * e; jb["orig_stride"] = n
+            jb["ref_off"] = np.array([ids.index(int(p)) for p in hdr[:, 1]]) * psize + (80 + hdr[:, 3]) * st + 80 + hdr[:, 2]; jb["ref_stride"] = st
+            jb["gx"] = hdr[:, 2]; jb["gy"] = hdr[:, 3]; jb["init_x"] = hdr[:, 4]; jb["init_y"] = hdr[:, 5]
+            jb["n_amvp"] = hdr[:, 11]; jb["n_search"] = hdr[:, 12]
+            jb["amvp"] = hdr[:, 13:17].reshape(cnt, 2, 2); jb["search"] = hdr[:, 17:27].reshape(cnt, 5, 2); jb["action"] = hdr[:, 10]
+            d_a, d_out = dev.up(arena), dev.up(np.zeros((cnt, 5), np.int32))
+            assert gpu.hmr_gpu_motion_estimation_batch(dev.ctx, dev.up(jb), cnt, n, d_a, d_a, int(hdr[0, 6]), int(hdr[0, 7]), fw, fh, d_out) == 0
+            assert np.array_equal(dev.down(d_out, (cnt, 5), np.int32), hdr[:, 27:32]), g["tag"]
         else:
             w, h = g["w"], g["h"]; ws = (h + 8) * (w + 8)
             arena = np.concatenate([b[0].ravel(), np.full(cnt * w * h, 0x1234, np.int16)])
@@ -124,4 +145,4 @@ def test_trace_groups_as_single_launches(dev):
                     assert gpu.hmr_gpu_mc_batch(dev.ctx, dev.up(jb), int(sel.size), luma | (lanes << 8), bi, d_a, d_a) == 0
                     out = dev.down(d_a, arena.shape, np.int16)[cnt * ws:].reshape(cnt, w * h)
                     assert np.array_equal(out[sel], b[1][sel]), (g["tag"], luma, bi)
-    assert seen == {"inter_tu", "intra_tu", "intra_search", "mc"}
+    assert seen == {"inter_tu", "intra_tu", "intra_search", "mc", "me"}

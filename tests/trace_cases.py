@@ -36,7 +36,17 @@ def vp(a, off=0):
     return C.c_void_p(a.ctypes.data + off * a.itemsize)
 
 
-def oracle_outputs(ora, g, i):
+def ref_planes(groups):
+    """padded reference pictures logged by the trace, by id"""
+    out = {}
+    for g in groups:
+        if g["kind"] == "ref_plane":
+            for i in range(g["count"]):
+                out[int(g["hdr"][i][0])] = np.ascontiguousarray(g["blobs"][0][i])
+    return out
+
+
+def oracle_outputs(ora, g, i, planes=None):
     """-> dict of outputs for record i of group g, same keys as `expected(g, i)`."""
     h, d, b = g["hdr"][i], g["dbl"][i], g["blobs"]
     kind = g["kind"]
@@ -65,6 +75,16 @@ def oracle_outputs(ora, g, i):
         ora.ora_intra_search(vp(orig), n, vp(tile), 2 * n + 1, n, *[int(v) for v in h[1:8]], vp(preds), vp(bits), int(h[14]), C.c_double(d[0]), vp(adi), vp(adif),
                              vp(pred), n, vp(out), C.byref(cost))
         return {"adi": adi, "adif": adif, "pred": pred, "best": int(out[0]), "bits": int(out[1]), "cost": cost.value}
+    if kind == "me":
+        n, pid, gx, gy, ix, iy, rx, ry, fw, fh, action, na, ns = (int(v) for v in h[:13])
+        plane = planes[pid]
+        st = fw + 160
+        orig = np.ascontiguousarray(b[0][i])
+        amvp, search, out = np.ascontiguousarray(h[13:17], np.int32), np.ascontiguousarray(h[17:27], np.int32), np.zeros(4, np.int32)
+        ora.ora_motion_estimation.restype = C.c_uint32
+        r = ora.ora_motion_estimation(vp(orig), n, vp(plane, (80 + gy) * st + 80 + gx), st, gx, gy, ix, iy, n, rx, ry, fw, fh, vp(amvp), na, vp(search), ns,
+                                      C.c_double(d[0]), action, vp(out))
+        return {"mv": out.copy(), "ret": int(np.int32(np.uint32(r)))}
     luma, w, hh, fx, fy, bi = (int(v) for v in h[:6])
     win = np.ascontiguousarray(b[0][i]).reshape(hh + 8, w + 8)
     pred = np.zeros(hh * w, np.int16)
@@ -84,4 +104,6 @@ def expected(g, i):
         return {"pred": b[2][i], "levels": b[3][i], "recon": b[4][i], "sum": int(h[15]), "ret": int(h[16])}
     if kind == "intra_search":
         return {"adi": b[2][i], "adif": b[3][i], "pred": b[4][i], "best": int(h[15]), "bits": int(h[16]), "cost": float(d[1])}
+    if kind == "me":
+        return {"mv": h[27:31], "ret": int(h[31])}
     return {"pred": b[1][i]}
