@@ -678,8 +678,12 @@ def main():
                 return torch.from_numpy(rng.integers(0, 256, ((h + 2 * pad), (w + 2 * pad))).astype(np.int16)).to(dev)
             rec_pl = [padded_plane(W, H, PAD), padded_plane(W // 2, H // 2, PAD // 2), padded_plane(W // 2, H // 2, PAD // 2)]
             org_pl = [padded_plane(W, H, PAD), padded_plane(W // 2, H // 2, PAD // 2), padded_plane(W // 2, H // 2, PAD // 2)]
-            dst_pl = [t.clone() for t in rec_pl]
-            nxt_pl = [torch.empty_like(t) for t in rec_pl]    # reference picture received from the previous engine
+            # the SAO output / next reference picture: its three padded planes live in ONE buffer, so the engine-to-engine exchange is a single
+            # send and a single receive per picture
+            sizes = [t.numel() for t in rec_pl]
+            dst_flat = torch.cat([t.reshape(-1) for t in rec_pl])
+            nxt_flat = torch.empty_like(dst_flat)              # reference picture received from the previous engine
+            dst_pl = [v.view_as(t) for v, t in zip(torch.split(dst_flat, sizes), rec_pl)]
             d_info = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in info.items()}
             n_ctu = info["sao_params"].shape[0]
             d_stats = torch.zeros(n_ctu * 3 * 5 * 2 * 32, dtype=torch.int32, device=dev)
@@ -746,7 +750,7 @@ def main():
         clist = P()
         ctx.call("hmr_gpu_cmdlist_create", cmd_arr, len(cmds), C.byref(clist))
         n_cmd = len(cmds)
-        return {"ctx": ctx, "stream": stream, "clist": clist, "groups": groups, "names": names, "frame_bytes": frame_bytes, "dst_pl": dst_pl, "nxt_pl": nxt_pl,
+        return {"ctx": ctx, "stream": stream, "clist": clist, "groups": groups, "names": names, "frame_bytes": frame_bytes, "dst_pl": [dst_flat], "nxt_pl": [nxt_flat],
                 "n_cmd": n_cmd, "keep": [d_arena, rec_pl, org_pl, d_info, d_stats, f_rec, f_org, f_dst, units, cmd_arr, cmds]}
 
     engines = [make_engine(e) for e in range(max(args.engines_per_gpu, 1))]
