@@ -1215,3 +1215,90 @@ uint32_t ora_inter_tu_chain(const int16_t *residual, int residual_stride, const 
 	return ssd;
 }
 
+
+/* ====================================================================================================
+ * Intra luma transform tree of one 2Nx2N CU, one level deep (the walk of encode_intra_luma, hmr_motion_intra.c:1441-1566, for the default
+ * max_intra_tr_depth = 2 and rd_mode != RD_FULL): the CU is coded as one TU of `size` in the parent level's windows, then as four TUs of
+ * size/2 in z-order in the child level's windows (each child predicted from its own level's plane, which already holds its siblings'
+ * reconstruction), all with the same prediction mode; smoothing (:1011-1012), scan (find_scan_mode, hmr_tables.c:376) and DST follow from
+ * mode and TU size.  Then the consolidation (:1479-1557): distortion / sum of the four children against the parent's,
+ *     rule 0 (RD_DIST_ONLY)  dist < parent dist
+ *     rule 1 (RD_FAST)       1.25 * (dist + 45 * sum) < parent dist + 45 * parent sum        (uint32 products, double comparison, :1496)
+ * children win  -> their levels and reconstruction are copied up (synchronize_motion_buffers_luma, :866), cbf of child k = nz_k << 1 | any nz,
+ *                  tr_idx 1 (:1510-1522);
+ * parent wins   -> the parent's bottom row and right column go down into the child plane (synchronize_reference_buffs, :844), cbf = nz, tr_idx 0.
+ * A 64x64 CU has no parent TU (its cost is preset to INT_MAX, :1402): size 64 codes the four 32x32 TUs and always consolidates them.
+ * nb: 5 x {left, top, bottom_left, top_right, bl_size, tr_size} for parent, child 0..3 (cu_partition_info_t's neighbour fields + picture bounds).
+ * dec_par / dec_chl: the CU's first sample in decoded_mbs_wnd[depth + 1] / [depth + 2]; lev_par / lev_chl: size*size linear each, child k at k*(size/2)^2
+ * (abs_index order).  out: {split, cost, distortion, sum, cbf[0..3], tr_idx, ssd[5], sum[5]} (19 words).
+ * ==================================================================================================== */
+int ora_intra_is_filtered(int mode, int size)
+{
+	static const int filter_thr[5] = {10, 7, 1, 0, 10};                                                           /* intra_filter, :148 */
+	const int diff = abs(mode - 10) < abs(mode - 26) ? abs(mode - 10) : abs(mode - 26);
+	return mode != 1 && diff > filter_thr[ilog2(size) - 2];
+}
+int ora_intra_scan_mode(int mode, int size)     /* find_scan_mode(is_intra, is_luma, ...), hmr_tables.c:398-402: 1 horizontal, 2 vertical, 3 diagonal (hmr_private.h:91-94) */
+{
+	if (size != 4 && size != 8) return 3;
+	return abs(mode - 26) < 5 ? 1 : abs(mode - 10) < 5 ? 2 : 3;
+}
+void ora_intra_cu_tree(const int16_t *orig, int orig_stride, int16_t *dec_par, int dec_par_stride, int16_t *dec_chl, int dec_chl_stride, const int32_t *nb,
+		       int strong_enabled, int mode, int16_t *pred, int pred_stride, int16_t *lev_par, int16_t *lev_chl, int size, int slice_is_intra,
+		       int sign_hiding, int per, int rem, int rule, int32_t *out)
+{
+	const int h = size / 2;
+	uint32_t ssd[5] = {0, 0, 0, 0, 0}, dist, sum, par_cost, par_sum;
+	int ac[5] = {0, 0, 0, 0, 0}, k, y, split;
+	if (size <= 32)
+		ssd[0] = ora_intra_tu_chain(orig, orig_stride, dec_par - dec_par_stride - 1, dec_par_stride, nb[0], nb[1], nb[2], nb[3], nb[4], nb[5], strong_enabled,
+					    ora_intra_is_filtered(mode, size), mode, 1, pred, pred_stride, lev_par, dec_par, dec_par_stride, size, size == 4,
+					    ora_intra_scan_mode(mode, size), 0, slice_is_intra, sign_hiding, per, rem, &ac[0]);
+	for (k = 0; k < 4; k++) {
+		const int x0 = (k & 1) * h, y0 = (k >> 1) * h;
+		const int32_t *n = nb + 6 * (k + 1);
+		int16_t *d = dec_chl + y0 * dec_chl_stride + x0;
+		ssd[k + 1] = ora_intra_tu_chain(orig + y0 * orig_stride + x0, orig_stride, d - dec_chl_stride - 1, dec_chl_stride, n[0], n[1], n[2], n[3], n[4], n[5],
+						strong_enabled, ora_intra_is_filtered(mode, h), mode, 1, pred + y0 * pred_stride + x0, pred_stride, lev_chl + k * h * h, d,
+						dec_chl_stride, h, h == 4, ora_intra_scan_mode(mode, h), 0, slice_is_intra, sign_hiding, per, rem, &ac[k + 1]);
+	}
+	dist = ssd[1] + ssd[2] + ssd[3] + ssd[4];
+	sum = (uint32_t)ac[1] + (uint32_t)ac[2] + (uint32_t)ac[3] + (uint32_t)ac[4];
+	par_cost = size <= 32 ? ssd[0] : (uint32_t)INT32_MAX;
+	par_sum = (uint32_t)ac[0];
+	if (size > 32) split = 1;
+	else if (rule == 1) split = 1.25 * ((double)dist + 45 * sum) < (double)(uint32_t)(par_cost + 45 * par_sum);
+	else split = (double)dist < (double)par_cost;
+	if (split) {
+		const int any = (ac[1] || ac[2] || ac[3] || ac[4]) ? 1 : 0;
+		for (y = 0; y < size; y++) memcpy(dec_par + y * dec_par_stride, dec_chl + y * dec_chl_stride, (size_t)size * sizeof dec_par[0]);
+		memcpy(lev_par, lev_chl, (size_t)size * size * sizeof lev_par[0]);
+		for (k = 0; k < 4; k++) out[4 + k] = ((ac[k + 1] ? 1 : 0) << 1) | any;
+	} else {
+		memcpy(dec_chl + (size - 1) * dec_chl_stride, dec_par + (size - 1) * dec_par_stride, (size_t)size * sizeof dec_par[0]);
+		for (y = 0; y < size - 1; y++) dec_chl[y * dec_chl_stride + size - 1] = dec_par[y * dec_par_stride + size - 1];
+		for (k = 0; k < 4; k++) out[4 + k] = ac[0] ? 1 : 0;
+	}
+	out[0] = split;
+	out[1] = out[2] = (int32_t)(split ? dist : par_cost);
+	out[3] = (int32_t)(split ? sum : par_sum);
+	out[8] = split;
+	for (k = 0; k < 5; k++) { out[9 + k] = (int32_t)ssd[k]; out[14 + k] = ac[k]; }
+	if (split) { out[9] = (int32_t)dist; out[14] = (int32_t)sum; }     /* the parent node carries the consolidated figures from here on (:1499-1501) */
+}
+
+/* encode_intra_luma's data path for one 2Nx2N CU (hmr_motion_intra.c:1226-1632): the mode search on the parent level's plane (ora_intra_search), then
+ * the transform tree above with the mode it found.  out as ora_intra_cu_tree, then out[19] = mode, out[20] = its bit count; *best_cost its search cost. */
+void ora_intra_luma_cu(const int16_t *orig, int orig_stride, int16_t *dec_par, int dec_par_stride, int16_t *dec_chl, int dec_chl_stride, const int32_t *nb,
+		       int strong_enabled, const int32_t *preds, const int32_t *pred_bits, int other_bits, double sqrt_lambda, int16_t *adi, int16_t *adi_filtered,
+		       int16_t *pred, int pred_stride, int16_t *lev_par, int16_t *lev_chl, int size, int slice_is_intra, int sign_hiding, int per, int rem, int rule,
+		       int32_t *out, double *best_cost)
+{
+	int32_t found[2];
+	ora_intra_search(orig, orig_stride, dec_par - dec_par_stride - 1, dec_par_stride, size, nb[0], nb[1], nb[2], nb[3], nb[4], nb[5], strong_enabled, preds, pred_bits,
+			 other_bits, sqrt_lambda, adi, adi_filtered, pred, pred_stride, found, best_cost);
+	ora_intra_cu_tree(orig, orig_stride, dec_par, dec_par_stride, dec_chl, dec_chl_stride, nb, strong_enabled, found[0], pred, pred_stride, lev_par, lev_chl, size,
+			  slice_is_intra, sign_hiding, per, rem, rule, out);
+	out[19] = found[0];
+	out[20] = found[1];
+}

@@ -129,6 +129,17 @@ uint32_t ora_intra_tu_chain(const int16_t *orig, int orig_stride, const int16_t 
 uint32_t ora_inter_tu_chain(const int16_t *residual, int residual_stride, const int16_t *pred, int pred_stride, int16_t *levels, int16_t *recon, int recon_stride,
 			    int size, int scan_mode, int comp, int slice_is_intra, int sign_hiding, int per, int rem, double weight, double zero_thr, int *ac_sum);
 
+/* ---- intra luma transform tree of one CU and the whole luma CU driver (encode_intra_luma, hmr_motion_intra.c:1226-1632) ---- */
+int ora_intra_is_filtered(int mode, int size);
+int ora_intra_scan_mode(int mode, int size);
+void ora_intra_cu_tree(const int16_t *orig, int orig_stride, int16_t *dec_par, int dec_par_stride, int16_t *dec_chl, int dec_chl_stride, const int32_t *nb,
+		       int strong_enabled, int mode, int16_t *pred, int pred_stride, int16_t *lev_par, int16_t *lev_chl, int size, int slice_is_intra,
+		       int sign_hiding, int per, int rem, int rule, int32_t *out);
+void ora_intra_luma_cu(const int16_t *orig, int orig_stride, int16_t *dec_par, int dec_par_stride, int16_t *dec_chl, int dec_chl_stride, const int32_t *nb,
+		       int strong_enabled, const int32_t *preds, const int32_t *pred_bits, int other_bits, double sqrt_lambda, int16_t *adi, int16_t *adi_filtered,
+		       int16_t *pred, int pred_stride, int16_t *lev_par, int16_t *lev_chl, int size, int slice_is_intra, int sign_hiding, int per, int rem, int rule,
+		       int32_t *out, double *best_cost);
+
 #ifdef __cplusplus
 }
 #endif

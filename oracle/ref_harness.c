@@ -626,3 +626,69 @@ uint32_t refh_inter_tu_chain(int16_t *residual, int residual_stride, int16_t *pr
 		return ssd_;
 	}
 }
+
+/* encode_intra_luma (hmr_motion_intra.c:1226-1632) itself, on the encoder instance's own thread context: the luma of one 2Nx2N CU at the origin of CTU 0 -
+ * mode search, transform tree (one level with the harness configuration max_intra_tr_depth = 2) and consolidation.  Inputs are written where the
+ * encoder keeps them (curr_mbs_wnd, the neighbour L-shape in decoded_mbs_wnd[depth+1] and [depth+2], the neighbour flags on the five partition nodes);
+ * outputs are read back from where it leaves them.  nbflags: 5 x {left, top, bottom_left, top_right}; pict_w / pict_h: picture extent measured from
+ * the CU's origin (bounds the below-left / above-right runs, :289,335).
+ * out: {return value, cost, distortion, sum, cbf of the 4 quadrants (first unit), tr_idx (first unit), ssd[5], sum[5], mode, 0, preds[3]} */
+uint32_t encode_intra_luma(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int depth, int part_position, PartSize part_size_type);
+int refh_intra_luma_cu(int16_t *orig, int16_t *top, int16_t *left, const int32_t *nbflags, int pict_w, int pict_h, int size, int qp, double sqrt_lambda, int rd_mode,
+		       int slice_is_intra, int sign_hiding, int strong_enabled, int32_t *out, int16_t *dec_par, int16_t *dec_chl, int16_t *lev_par, int16_t *lev_chl)
+{
+	henc_thread_t *et = g_et;
+	ctu_info_t *ctu = &g_eng->ctu_info[0];
+	const int depth = 6 - log2i(size), h = size / 2;
+	cu_partition_info_t *pi = &ctu->partition_list[et->partition_depth_start[depth]], *node[5];
+	const int save_w = et->pict_width[0], save_h = et->pict_height[0], save_rd = et->rd_mode, save_strong = et->sps->strong_intra_smooth_enabled_flag;
+	const double save_lambda = et->rd.sqrt_lambda;
+	wnd_t *dp = et->decoded_mbs_wnd[depth + 1], *dc = et->decoded_mbs_wnd[depth + 2], *qp_ = et->transform_quant_wnd[depth + 1], *qc = et->transform_quant_wnd[depth + 2];
+	int16_t *o = WND_POSITION_2D(int16_t *, et->curr_mbs_wnd, Y_COMP, 0, 0, 0, et->ctu_width);
+	const int os = WND_STRIDE_2D(et->curr_mbs_wnd, Y_COMP);
+	int k, x, y, w;
+	uint32_t ret;
+	node[0] = pi;
+	for (k = 0; k < 4; k++) node[k + 1] = pi->children[k];
+	for (k = 0; k < 5; k++) {
+		node[k]->left_neighbour = (uint16_t)nbflags[4 * k]; node[k]->top_neighbour = (uint16_t)nbflags[4 * k + 1];
+		node[k]->left_bottom_neighbour = (uint16_t)nbflags[4 * k + 2]; node[k]->top_right_neighbour = (uint16_t)nbflags[4 * k + 3];
+		node[k]->cost = node[k]->distortion = node[k]->sum = 0;
+	}
+	pi->qp = (uint32_t)qp;
+	ctu->x[Y_COMP] = ctu->y[Y_COMP] = 0;
+	ctu->ctu_left = ctu->ctu_top = NULL;
+	et->ctu_rd->ctu_left = et->ctu_rd->ctu_top = NULL;
+	et->pict_width[0] = pict_w; et->pict_height[0] = pict_h;
+	et->rd_mode = rd_mode; et->rd.sqrt_lambda = sqrt_lambda;
+	et->sps->strong_intra_smooth_enabled_flag = strong_enabled;
+	g_eng->current_pict.slice.slice_type = slice_is_intra ? I_SLICE : P_SLICE;
+	et->pps->sign_data_hiding_flag = sign_hiding;
+	for (y = 0; y < size; y++) memcpy(o + y * os, orig + y * size, (size_t)size * 2);
+	for (w = 0; w < 2; w++) {
+		wnd_t *d = w ? dc : dp;
+		int16_t *p = WND_POSITION_2D(int16_t *, *d, Y_COMP, 0, 0, 0, et->ctu_width);
+		const int s = WND_STRIDE_2D(*d, Y_COMP);
+		for (x = 0; x < 2 * size + 1; x++) p[-s - 1 + x] = top[x];
+		for (y = 0; y < 2 * size; y++) p[y * s - 1] = left[y];
+		for (y = 0; y < size; y++) for (x = 0; x < size; x++) p[y * s + x] = 0x0101;
+	}
+	ret = encode_intra_luma(et, ctu, 0, depth, 0, SIZE_2Nx2N);
+	{
+		int16_t *p = WND_POSITION_2D(int16_t *, *dp, Y_COMP, 0, 0, 0, et->ctu_width), *c = WND_POSITION_2D(int16_t *, *dc, Y_COMP, 0, 0, 0, et->ctu_width);
+		const int sp = WND_STRIDE_2D(*dp, Y_COMP), sc = WND_STRIDE_2D(*dc, Y_COMP);
+		for (y = 0; y < size; y++) { memcpy(dec_par + y * size, p + y * sp, (size_t)size * 2); memcpy(dec_chl + y * size, c + y * sc, (size_t)size * 2); }
+		memcpy(lev_par, WND_POSITION_1D(int16_t *, *qp_, Y_COMP, 0, et->ctu_width, (pi->abs_index << et->num_partitions_in_cu_shift)), (size_t)size * size * 2);
+		memcpy(lev_chl, WND_POSITION_1D(int16_t *, *qc, Y_COMP, 0, et->ctu_width, (pi->abs_index << et->num_partitions_in_cu_shift)), (size_t)size * size * 2);
+	}
+	out[0] = (int32_t)ret; out[1] = (int32_t)pi->cost; out[2] = (int32_t)pi->distortion; out[3] = (int32_t)pi->sum;
+	for (k = 0; k < 4; k++) out[4 + k] = et->cbf_buffs[Y_COMP][depth][node[k + 1]->abs_index];
+	out[8] = et->tr_idx_buffs[depth][pi->abs_index];
+	for (k = 0; k < 5; k++) { out[9 + k] = (int32_t)node[k]->distortion; out[14 + k] = (int32_t)node[k]->sum; }
+	out[19] = et->intra_mode_buffs[Y_COMP][depth][pi->abs_index];
+	out[20] = h;
+	et->pict_width[0] = save_w; et->pict_height[0] = save_h;
+	et->rd_mode = save_rd; et->rd.sqrt_lambda = save_lambda;
+	et->sps->strong_intra_smooth_enabled_flag = save_strong;
+	return 0;
+}

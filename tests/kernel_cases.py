@@ -348,12 +348,85 @@ def k_inter_tu_chain(lib, prefix, p, rng):
     return {"levels": levels[:n * n].copy(), "recon": recon[:n, :n].copy(), "ssd": np.array([r], np.uint32), "ac_sum": np.array([ac.value], np.int32)}
 
 
+def cu_tree_neighbours(n, flags, pict_w, pict_h):
+    """5 x {left, top, bottom_left, top_right, bl_size, tr_size} for a CU of size n at the origin and its four quadrants: the flags are the partition
+    nodes' neighbour fields, the run lengths follow from the picture extent (hmr_motion_intra.c:289,335)."""
+    h = n // 2
+    geo = [(0, 0, n)] + [((k & 1) * h, (k >> 1) * h, h) for k in range(4)]
+    nb = []
+    for (x, y, sz), f in zip(geo, flags):
+        nb += list(f) + [min(sz, pict_h - (y + sz)), min(sz, pict_w - (x + sz))]
+    return np.array(nb, np.int32)
+
+
+def k_intra_luma_cu(lib, prefix, p, rng):
+    """encode_intra_luma for one 2Nx2N CU: mode search + one-level transform tree + consolidation.  The reference runs its real function on its own thread
+    context (CU at the origin of CTU 0, no neighbouring CTUs: MPM list planar / DC / vertical); oracle and GPU take the flat form."""
+    n = p["n"]
+    W = 192
+    yy, xx = np.mgrid[0:W, 0:W]
+    th = p["theta"]
+    base = 128 + p["amp"] * np.sin((xx * np.cos(th) + yy * np.sin(th)) / p["period"]) + p["tilt"] * (xx - yy) / 8.0
+    img = np.clip(base + rng.integers(-p["noise"], p["noise"] + 1, (W, W)), 0, 255).astype(np.int16)
+    rec = np.clip(img + rng.integers(-3, 4, (W, W)), 0, 255).astype(np.int16)     # "already coded" neighbourhood
+    orig = aligned((n, n), np.int16)
+    orig[...] = img[16:16 + n, 16:16 + n]
+    top = np.ascontiguousarray(rec[15, 15:16 + 2 * n])
+    left = np.ascontiguousarray(rec[16:16 + 2 * n, 15])
+    flags = p["flags"]
+    nb = cu_tree_neighbours(n, flags, p["pict_w"], p["pict_h"])
+    out = np.zeros(24, np.int32)
+    dec_par, dec_chl = aligned((n, n), np.int16), aligned((n, n), np.int16)
+    lev_par, lev_chl = aligned((n * n,), np.int16), aligned((n * n,), np.int16)
+    if prefix == "refh_":
+        fl = np.array([f for node in flags for f in node], np.int32)
+        rc = fn(lib, prefix, "intra_luma_cu", C.c_int)(ptr(orig), ptr(top), ptr(left), ptr(fl), C.c_int(p["pict_w"]), C.c_int(p["pict_h"]), C.c_int(n), C.c_int(p["qp"]),
+                                                       C.c_double(p["sqrt_lambda"]), C.c_int(p["rd_mode"]), C.c_int(p["slice_i"]), C.c_int(p["sbh"]),
+                                                       C.c_int(p["strong"]), ptr(out), ptr(dec_par), ptr(dec_chl), ptr(lev_par), ptr(lev_chl))
+        assert rc == 0
+        res = {}
+    else:
+        S = 2 * n + 16
+        planes = []
+        for _ in range(2):
+            pl = aligned((S, S), np.int16)
+            pl[...] = 0x0101
+            pl[7, 7:8 + 2 * n] = top
+            pl[8:8 + 2 * n, 7] = left
+            planes.append(pl)
+        pred = aligned((n, n), np.int16)
+        adi, adif = aligned((4 * 64 + 16,), np.int16), aligned((4 * 64 + 16,), np.int16)
+        bits = {0: ([0, 0, 0], 0), 2: ([1, 1, 1], 12)}[p["rd_mode"]]
+        pa, ba = np.array([0, 1, 26], np.int32), np.array(bits[0], np.int32)
+        cost = C.c_double(0)
+        fn(lib, prefix, "intra_luma_cu")(ptr(orig), C.c_int(n), ptr(planes[0], 8 * S + 8), C.c_int(S), ptr(planes[1], 8 * S + 8), C.c_int(S), ptr(nb), C.c_int(p["strong"]),
+                                         ptr(pa), ptr(ba), C.c_int(bits[1]), C.c_double(p["sqrt_lambda"]), ptr(adi), ptr(adif), ptr(pred), C.c_int(n), ptr(lev_par),
+                                         ptr(lev_chl), C.c_int(n), C.c_int(p["slice_i"]), C.c_int(p["sbh"]), C.c_int(p["qp"] // 6), C.c_int(p["qp"] % 6),
+                                         C.c_int(1 if p["rd_mode"] == 2 else 0), ptr(out), C.byref(cost))
+        dec_par[...] = planes[0][8:8 + n, 8:8 + n]
+        dec_chl[...] = planes[1][8:8 + n, 8:8 + n]
+        # nothing outside the CU may change in either plane
+        for pl in planes:
+            chk = pl.copy()
+            chk[8:8 + n, 8:8 + n] = 0x0101
+            chk[7, 7:8 + 2 * n] = 0x0101
+            chk[8:8 + 2 * n, 7] = 0x0101
+            assert (chk == 0x0101).all(), "write outside the CU"
+        res = {"pred": pred.copy(), "bits_cost": np.array([out[20], cost.value], np.float64)}
+    info = out[1:20].copy()
+    if n == 64:
+        info[8] = info[13] = 0            # no parent TU: its ssd / sum slots are not defined
+    res.update({"info": info, "dec_par": dec_par.copy(), "dec_chl": dec_chl.copy(), "lev_par": lev_par.copy(), "lev_chl": lev_chl.copy()})
+    return res
+
+
 KERNELS = {
     "sad": k_sad, "ssd16b": k_ssd16b, "predict": k_predict, "reconst": k_reconst, "modified_variance": k_modified_variance,
     "copy": k_copy, "intra_planar": k_intra_planar, "intra_angular": k_intra_angular,
     "fill_reference_samples": k_fill_reference_samples, "adi_filter": k_adi_filter, "interpolate": k_interpolate,
     "weighted_average": k_weighted_average, "transform": k_transform, "itransform": k_itransform, "quant": k_quant,
     "inv_quant": k_inv_quant, "tu_chain": k_tu_chain, "intra_search": k_intra_search, "intra_tu_chain": k_intra_tu_chain, "inter_tu_chain": k_inter_tu_chain,
+    "intra_luma_cu": k_intra_luma_cu,
 }
 
 
@@ -481,4 +554,20 @@ def all_cases(level="full"):
             add("inter_tu_chain", n=n, comp=comp, scan=3, slice_i=0, sbh=int(r.integers(0, 2)), per=int(r.integers(2, 7)), rem=int(r.integers(0, 6)),
                 weight=float(2.0 ** (r.integers(-2, 5) / 3.0)), thr=float(np.clip(r.uniform(0, 3000) / 2.5 - 5.0, 1.0, 20000.0)),
                 theta=float(r.uniform(0, np.pi)), period=float(r.uniform(2.0, 20.0)), amp=float(r.choice([0, 2, 6, 20, 60])), noise=int(r.choice([0, 1, 3, 10])))
+    r = np.random.default_rng(1213)
+    for n in (8, 16, 32, 64):
+        for i in range(30 if full else 6):
+            left, top = (int(r.integers(0, 2)), int(r.integers(0, 2))) if i % 5 == 0 else (1, 1)
+            bl, tr = int(r.integers(0, 2)) & left, int(r.integers(0, 2)) & top
+            # the quadrants' flags as cu_partition_get_neighbours derives them, with an occasional arbitrary combination
+            flags = [(left, top, bl, tr), (left, top, left, top), (1, top, 0, tr), (left, 1, bl, 1), (1, 1, 0, 0)]
+            if i % 7 == 3:        # any combination a frame can produce: below-left needs left, above-right needs above, the last quadrant has neither
+                flags = []
+                for node in range(5):
+                    fl, ft = int(r.integers(0, 2)), int(r.integers(0, 2))
+                    flags.append((fl, ft, int(r.integers(0, 2)) & fl & (node != 4), int(r.integers(0, 2)) & ft & (node != 4)))
+            add("intra_luma_cu", n=n, flags=flags, pict_w=int(r.choice([n, n + n // 2, 2 * n, 4 * n])), pict_h=int(r.choice([n, n + n // 2, 2 * n, 4 * n])),
+                qp=int(r.integers(18, 45)), sqrt_lambda=float(r.uniform(2.0, 60.0)), rd_mode=int(r.choice([2, 2, 0])), slice_i=int(r.integers(0, 2)),
+                sbh=int(r.integers(0, 2)), strong=int(r.integers(0, 2)), theta=float(r.uniform(0, np.pi)), period=float(r.uniform(3.0, 25.0)),
+                amp=float(r.uniform(5, 90)), tilt=float(r.uniform(-6, 6)), noise=int(r.choice([0, 1, 3, 8, 20])))
     return cases
