@@ -650,7 +650,7 @@ def main():
     P = C.c_void_p
 
     class Cmd(C.Structure):
-        _fields_ = [("op", C.c_int), ("njobs", C.c_int), ("size", C.c_int), ("p", C.c_int * 4), ("jobs", P), ("a", P), ("b", P), ("c", P), ("out", P), ("p64", P * 2), ("branch", C.c_int)]
+        _fields_ = [("op", C.c_int), ("njobs", C.c_int), ("size", C.c_int), ("p", C.c_int * 4), ("jobs", P), ("a", P), ("b", P), ("c", P), ("out", P), ("p64", P * 3), ("branch", C.c_int)]
 
     calls = load_callmix(args.callmix_frame)
 
@@ -721,10 +721,10 @@ def main():
                 cm.out = g["d_out"].data_ptr()
             if g["fn"] in ("hmr_gpu_intra_tu_chain_batch", "hmr_gpu_inter_tu_chain_batch"):
                 g["d_ac"] = torch.zeros(len(g["jobs"]), dtype=torch.int32, device=dev)
-                cm.p64 = (P * 2)(base, g["d_ac"].data_ptr())   # reconstruction / prediction base, ac_sum
+                cm.p64 = (P * 3)(base, g["d_ac"].data_ptr(), None)   # reconstruction / prediction base, ac_sum
             if g["fn"] == "hmr_gpu_tu_chain_batch":
                 g["d_ac"] = torch.zeros(len(g["jobs"]), dtype=torch.int32, device=dev)
-                cm.p64 = (P * 2)(base, g["d_ac"].data_ptr())   # reconstruction base, ac_sum
+                cm.p64 = (P * 3)(base, g["d_ac"].data_ptr(), None)   # reconstruction base, ac_sum
             cmds.append(cm)
             names.append(f"{g['name']}:{g['size']}")
         # The launches of one replayed frame have no data dependencies on each other except the in-loop filter chain (edge flags ->

@@ -771,3 +771,118 @@ uint32_t hmr_gpu_inter_tu_chain(int16_t *residual, int residual_stride, int16_t 
 }
 
 }  // extern "C"
+
+/* ---- encode_intra_luma's data path for one 2Nx2N CU (hmr_motion_intra.c:1226-1632): search -> parent TU -> four child TUs -> consolidation, seven
+ * launches in stream order on one staged image; the mode never leaves the device between them. ---- */
+void hmr_gpu_intra_luma_cu(int16_t *orig, int orig_stride, int16_t *dec_par, int dec_par_stride, int16_t *dec_chl, int dec_chl_stride, const int32_t *nb,
+			   int strong_enabled, const int32_t *preds, const int32_t *pred_bits, int other_bits, double sqrt_lambda, int16_t *adi, int16_t *adi_filtered,
+			   int16_t *pred, int pred_stride, int16_t *lev_par, int16_t *lev_chl, int size, int slice_is_intra, int sign_hiding, int per, int rem, int rule,
+			   int32_t *out, double *best_cost)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	const int n = size, h = n / 2, ring = 2 * n + 1, total = 4 * n + 1;
+	const bool has_parent = n <= 32;
+	const size_t oo = st.put2d(orig, orig_stride, n, n, 2);
+	// node geometry inside the CU and how far the L-shaped neighbourhood is read
+	const int gx[5] = {0, 0, h, 0, h}, gy[5] = {0, 0, 0, h, h}, gs[5] = {n, h, h, h, h};
+	int rows = 0, cols = 0;
+	for (int k = 0; k < 5; k++) {
+		const int32_t *f = nb + 6 * k;
+		if (gx[k] == 0 && f[0]) { const int r = gy[k] + gs[k] + (f[2] ? f[4] : 0); rows = r > rows ? r : rows; }
+		if (gy[k] == 0 && f[1]) { const int q = gx[k] + gs[k] + (f[3] ? f[5] : 0); cols = q > cols ? q : cols; }
+	}
+	hmr_gpu_intra_job sj = {};
+	hmr_gpu_itu_job tj[5] = {};
+	hmr_gpu_tree_job dj = {};
+	const size_t so = st.zeros(sizeof sj), to = st.zeros(sizeof tj), d_o = st.zeros(sizeof dj);
+	st.begin_outputs();
+	// in/out: the two planes (neighbourhood + CU interior)
+	const size_t pp = st.out((size_t)ring * ring * 2), pc = st.out((size_t)ring * ring * 2);
+	for (int w = 0; w < 2; w++) {
+		int16_t *tile = st.host<int16_t>(w ? pc : pp);
+		const int16_t *src = w ? dec_chl : dec_par;
+		const int ss = w ? dec_chl_stride : dec_par_stride;
+		memset(tile, 0, (size_t)ring * ring * 2);
+		if (rows || cols) tile[0] = src[-ss - 1];
+		for (int y = 0; y < rows; y++) tile[(size_t)(y + 1) * ring] = src[(ptrdiff_t)y * ss - 1];
+		for (int x = 0; x < cols; x++) tile[x + 1] = src[-ss + x];
+		for (int y = 0; y < n; y++) memcpy(tile + (size_t)(y + 1) * ring + 1, src + (ptrdiff_t)y * ss, (size_t)n * 2);
+	}
+	const size_t ao = st.out((size_t)total * 2), fo = st.out((size_t)total * 2), po = st.out((size_t)n * n * 2), ro = st.out(sizeof(hmr_gpu_intra_result));
+	const size_t lp = st.out((size_t)n * n * 2), lc = st.out((size_t)n * n * 2), sso = st.out(5 * 4), aco = st.out(5 * 4), tro = st.out(sizeof(hmr_gpu_tree_result));
+	memset(st.host<uint8_t>(sso), 0, 20);
+	memset(st.host<uint8_t>(aco), 0, 20);
+	auto flags_of = [&](const int32_t *f) {
+		return (uint32_t)(f[0] != 0) | ((uint32_t)(f[1] != 0) << 1) | ((uint32_t)(f[2] != 0) << 2) | ((uint32_t)(f[3] != 0) << 3) | ((uint32_t)(strong_enabled != 0) << 5);
+	};
+	sj.sqrt_lambda = sqrt_lambda;
+	sj.orig_off = (uint32_t)(oo / 2); sj.orig_stride = n;
+	sj.dec_off = (uint32_t)(pp / 2); sj.dec_stride = ring;
+	sj.flags = flags_of(nb);
+	sj.sizes = (uint32_t)nb[4] | ((uint32_t)nb[5] << 16);
+	for (int i = 0; i < 3; i++) { sj.preds[i] = preds[i]; sj.pred_bits[i] = (uint32_t)pred_bits[i]; }
+	sj.other_bits = (uint32_t)other_bits;
+	sj.adi_off = (uint32_t)(ao / 2); sj.adif_off = (uint32_t)(fo / 2);
+	sj.pred_off = (uint32_t)(po / 2); sj.pred_stride = n;
+	for (int k = 0; k < 5; k++) {
+		const int32_t *f = nb + 6 * k;
+		const size_t plane = k ? pc : pp;
+		hmr_gpu_itu_job &j = tj[k];
+		j.orig_off = (uint32_t)(oo / 2 + (size_t)gy[k] * n + gx[k]); j.orig_stride = n;
+		j.pred_off = (uint32_t)(po / 2 + (size_t)gy[k] * n + gx[k]); j.pred_stride = n;
+		j.dec_off = (uint32_t)(plane / 2 + (size_t)gy[k] * ring + gx[k]); j.dec_stride = ring;
+		j.rec_off = j.dec_off + ring + 1; j.rec_stride = ring;
+		j.lev_off = (uint32_t)(k ? lc / 2 + (size_t)(k - 1) * h * h : lp / 2);
+		j.flags = flags_of(f) | (1u << 7) | HMR_GPU_ITU_MODE_FROM_SEARCH;
+		j.sizes = (uint32_t)f[4] | ((uint32_t)f[5] << 16);
+		j.mode = 0;
+		j.p0 = (1u << 4) | ((uint32_t)(slice_is_intra != 0) << 5) | ((uint32_t)(sign_hiding != 0) << 6) | ((uint32_t)(gs[k] == 4) << 7);
+		j.p1 = (uint32_t)per | ((uint32_t)rem << 8);
+	}
+	dj.parent = has_parent ? 0u : HMR_GPU_TREE_NO_PARENT;
+	for (int k = 0; k < 4; k++) dj.child[k] = (uint32_t)(k + 1);
+	dj.par_rec_off = (uint32_t)(pp / 2 + ring + 1); dj.par_rec_stride = ring;
+	dj.chl_rec_off = (uint32_t)(pc / 2 + ring + 1); dj.chl_rec_stride = ring;
+	dj.par_lev_off = (uint32_t)(lp / 2); dj.chl_lev_off = (uint32_t)(lc / 2);
+	dj.size = (uint32_t)n; dj.rule = (uint32_t)rule;
+	memcpy(st.host<uint8_t>(so), &sj, sizeof sj);
+	memcpy(st.host<uint8_t>(to), tj, sizeof tj);
+	memcpy(st.host<uint8_t>(d_o), &dj, sizeof dj);
+	st.upload_all();
+	int16_t *base = st.dev<int16_t>();
+	hmr_gpu_intra_result *modes = st.dev<hmr_gpu_intra_result>(ro);
+	must(hmr_gpu_intra_search_batch(c, st.dev<hmr_gpu_intra_job>(so), 1, n, base, base, base, modes), "intra_luma_cu: search");
+	for (int k = has_parent ? 0 : 1; k < 5; k++)
+		must(hmr_gpu_intra_tu_chain_modes_batch(c, st.dev<hmr_gpu_itu_job>(to) + k, 1, gs[k], base, base, base, base, base, st.dev<uint32_t>(sso) + k,
+							st.dev<int32_t>(aco) + k, modes),
+		     "intra_luma_cu: TU");
+	must(hmr_gpu_tree_decide_batch(c, st.dev<hmr_gpu_tree_job>(d_o), 1, st.dev<uint32_t>(sso), st.dev<int32_t>(aco), base, base, st.dev<hmr_gpu_tree_result>(tro)),
+	     "intra_luma_cu: consolidation");
+	st.finish();
+	for (int w = 0; w < 2; w++) {
+		const int16_t *tile = st.host<int16_t>(w ? pc : pp);
+		int16_t *dst = w ? dec_chl : dec_par;
+		const int ds = w ? dec_chl_stride : dec_par_stride;
+		for (int y = 0; y < n; y++) memcpy(dst + (ptrdiff_t)y * ds, tile + (size_t)(y + 1) * ring + 1, (size_t)n * 2);
+	}
+	memcpy(adi, st.host<int16_t>(ao), (size_t)total * 2);
+	memcpy(adi_filtered, st.host<int16_t>(fo), (size_t)total * 2);
+	st.get2d(po, pred, pred_stride, n, n, 2);
+	memcpy(lev_par, st.host<int16_t>(lp), (size_t)n * n * 2);
+	memcpy(lev_chl, st.host<int16_t>(lc), (size_t)n * n * 2);
+	const hmr_gpu_intra_result *sr = st.host<hmr_gpu_intra_result>(ro);
+	const hmr_gpu_tree_result *tr = st.host<hmr_gpu_tree_result>(tro);
+	const uint32_t *ssd = st.host<uint32_t>(sso);
+	const int32_t *ac = st.host<int32_t>(aco);
+	out[0] = (int32_t)tr->split;
+	out[1] = out[2] = (int32_t)tr->cost;
+	out[3] = (int32_t)tr->sum;
+	for (int k = 0; k < 4; k++) out[4 + k] = tr->cbf[k];
+	out[8] = (int32_t)tr->split;
+	for (int k = 0; k < 5; k++) { out[9 + k] = (int32_t)ssd[k]; out[14 + k] = ac[k]; }
+	if (tr->split) { out[9] = (int32_t)tr->cost; out[14] = (int32_t)tr->sum; }
+	out[19] = sr->best_mode;
+	out[20] = sr->bits;
+	*best_cost = sr->cost;
+}

@@ -62,7 +62,7 @@ template <int N, int MODE>
 __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const void *__restrict__ jobs_v, int njobs, const int16_t *__restrict__ O,
 							   int16_t *__restrict__ Pp, int16_t *__restrict__ L, int16_t *__restrict__ Rr,
 							   uint32_t *__restrict__ ssd_out, int32_t *__restrict__ ac_out, const DevTables *__restrict__ tab,
-							   const int16_t *__restrict__ D)
+							   const int16_t *__restrict__ D, const hmr_gpu_intra_result *__restrict__ modes)
 {
 	constexpr bool INTRA = MODE == TU_INTRA, INTER = MODE == TU_INTER;
 	using JobT = typename std::conditional<INTRA, hmr_gpu_itu_job, typename std::conditional<INTER, hmr_gpu_inter_tu_job, hmr_gpu_tu_job>::type>::type;
@@ -91,6 +91,20 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 		const int16_t *orow_p = O, *prow_p = Pp;
 		if (ok) {
 			jb = jobs[j];
+			if constexpr (INTRA) {
+				// mode handed over on the device by the search that ran before this launch: smoothing (hmr_motion_intra.c:1011-1012) and
+				// scan (find_scan_mode, hmr_tables.c:398-402) follow from mode and TU size
+				if ((jb.flags & 0x100u) && modes) {
+					const int m = modes[jb.mode].best_mode;
+					const int d10 = m > 10 ? m - 10 : 10 - m, d26 = m > 26 ? m - 26 : 26 - m, dmin = d10 < d26 ? d10 : d26;
+					constexpr int thr = N == 4 ? 10 : N == 8 ? 7 : N == 16 ? 1 : 0;
+					const unsigned filt = (m != 1 && dmin > thr) ? 0x40u : 0u;
+					const unsigned scan = N <= 8 ? (d26 < 5 ? 1u : d10 < 5 ? 2u : 3u) : 3u;
+					jb.mode = (uint32_t)m;
+					jb.flags = (jb.flags & ~0x40u) | filt;
+					jb.p0 = (jb.p0 & ~3u) | scan;
+				}
+			}
 			orow_p = O + jb.orig_off + (size_t)row * jb.orig_stride;
 			prow_p = Pp + jb.pred_off + (size_t)row * jb.pred_stride;
 		}
@@ -363,12 +377,12 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 
 template <int MODE>
 static int launch_tu_chain(hmr_gpu_ctx *ctx, const void *jobs, int njobs, int size, const int16_t *orig_base, int16_t *pred_base, int16_t *level_base,
-			   int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum, const int16_t *decoded_base)
+			   int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum, const int16_t *decoded_base, const hmr_gpu_intra_result *modes = nullptr)
 {
 	if (njobs <= 0) return HMR_GPU_OK;
 #define TU_LAUNCH(N)                                                                                                                               \
 	hipLaunchKernelGGL((k_tu_chain<N, MODE>), dim3(hmr_grid_for_units(((long)njobs + (HMR_WAVE / N) * HMR_WAVES_PER_BLOCK - 1) / ((HMR_WAVE / N) * HMR_WAVES_PER_BLOCK))), \
-			   dim3(HMR_BLOCK), 0, ctx->stream, jobs, njobs, orig_base, pred_base, level_base, recon_base, ssd, ac_sum, ctx->tables, decoded_base)
+			   dim3(HMR_BLOCK), 0, ctx->stream, jobs, njobs, orig_base, pred_base, level_base, recon_base, ssd, ac_sum, ctx->tables, decoded_base, modes)
 	switch (size) {
 	case 4: TU_LAUNCH(4); break;
 	case 8: TU_LAUNCH(8); break;
@@ -392,6 +406,14 @@ extern "C" int hmr_gpu_intra_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_itu_
 					    int32_t *ac_sum)
 {
 	return launch_tu_chain<TU_INTRA>(ctx, jobs, njobs, size, orig_base, pred_base, level_base, recon_base, ssd, ac_sum, decoded_base);
+}
+
+extern "C" int hmr_gpu_intra_tu_chain_modes_batch(hmr_gpu_ctx *ctx, const hmr_gpu_itu_job *jobs, int njobs, int size, const int16_t *orig_base,
+						  const int16_t *decoded_base, int16_t *pred_base, int16_t *level_base, int16_t *recon_base, uint32_t *ssd,
+						  int32_t *ac_sum, const hmr_gpu_intra_result *modes)
+{
+	if (!modes) { hmr_set_error("intra_tu_chain_modes_batch: modes is NULL"); return HMR_GPU_ERR_ARG; }
+	return launch_tu_chain<TU_INTRA>(ctx, jobs, njobs, size, orig_base, pred_base, level_base, recon_base, ssd, ac_sum, decoded_base, modes);
 }
 
 extern "C" int hmr_gpu_inter_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_inter_tu_job *jobs, int njobs, int size, const int16_t *residual_base,

@@ -23,6 +23,13 @@ ME_JOB_DTYPE = np.dtype([("corr", "<f8"), ("orig_off", "<u4"), ("orig_stride", "
 INTRA_JOB_DTYPE = np.dtype([("sqrt_lambda", "<f8"), ("orig_off", "<u4"), ("orig_stride", "<u4"), ("dec_off", "<u4"), ("dec_stride", "<u4"), ("adi_off", "<u4"),
                             ("adif_off", "<u4"), ("pred_off", "<u4"), ("pred_stride", "<u4"), ("flags", "<u4"), ("sizes", "<u4"), ("preds", "<i4", (3,)),
                             ("pred_bits", "<u4", (3,)), ("other_bits", "<u4"), ("reserved", "<u4")])                          # hmr_gpu_intra_job
+TREE_JOB_DTYPE = np.dtype([("parent", "<u4"), ("child", "<u4", (4,)), ("par_rec_off", "<u4"), ("par_rec_stride", "<u4"), ("chl_rec_off", "<u4"),
+                           ("chl_rec_stride", "<u4"), ("par_lev_off", "<u4"), ("chl_lev_off", "<u4"), ("size", "<u4"), ("rule", "<u4")])   # hmr_gpu_tree_job
+TREE_RESULT_DTYPE = np.dtype([("split", "<u4"), ("cost", "<u4"), ("sum", "<u4"), ("cbf", "u1", (4,))])                            # hmr_gpu_tree_result
+INTRA_RESULT_DTYPE = np.dtype([("best_mode", "<i4"), ("bits", "<i4"), ("cost", "<f8")])                                          # hmr_gpu_intra_result
+ITU_MODE_FROM_SEARCH = 0x100
+TREE_NO_PARENT = 0xFFFFFFFF
+assert (TREE_JOB_DTYPE.itemsize, TREE_RESULT_DTYPE.itemsize, INTRA_RESULT_DTYPE.itemsize) == (52, 16, 16)
 assert (TU_JOB_DTYPE.itemsize, ITU_JOB_DTYPE.itemsize, INTER_TU_JOB_DTYPE.itemsize, ME_JOB_DTYPE.itemsize, INTRA_JOB_DTYPE.itemsize) == (36, 56, 56, 72, 80)
 
 

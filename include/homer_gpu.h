@@ -289,8 +289,9 @@ enum hmr_gpu_op {
 	HMR_GPU_OP_TU_CHAIN,  /* jobs = hmr_gpu_tu_job*, a = orig base, b = pred base, c = level base, out = ssd; the reconstruction base and ac_sum follow in p64[0..1] */
 	HMR_GPU_OP_INTRA_SEARCH,  /* jobs = hmr_gpu_intra_job*, a = orig base, b = decoded base, c = output base, out = hmr_gpu_intra_result* */
 	HMR_GPU_OP_INTER_TU_CHAIN = 25, /* jobs = hmr_gpu_inter_tu_job*, a = residual base, b = pred base, c = level base, out = ssd; p64 = {recon base, ac_sum} */
-	HMR_GPU_OP_INTRA_TU_CHAIN = 24 /* jobs = hmr_gpu_itu_job*, a = orig base, b = decoded base, c = level base, out = ssd; p64 = {recon base, ac_sum}; the prediction
-	                           * plane shares the recon base */
+	HMR_GPU_OP_TREE_DECIDE = 26,    /* jobs = hmr_gpu_tree_job*, a = ssd, b = ac_sum, c = recon base, out = hmr_gpu_tree_result*; p64[0] = level base */
+	HMR_GPU_OP_INTRA_TU_CHAIN = 24 /* jobs = hmr_gpu_itu_job*, a = orig base, b = decoded base, c = level base, out = ssd; p64 = {recon base, ac_sum, hmr_gpu_intra_result* or NULL};
+	                           * the prediction plane shares the recon base */
 };
 /* One call of the batched / frame-level API: `size` is that entry's size/kind/flags argument, a/b/c/out its pointer arguments in
  * declaration order (frame-level ops take host pointers to hmr_gpu_frame / hmr_gpu_units that must outlive the list), p[] its
@@ -301,7 +302,7 @@ typedef struct hmr_gpu_cmd {
 	int p[4];
 	const void *jobs, *a, *b;
 	void *c, *out;
-	void *p64[2];               /* extra pointer arguments (TU_CHAIN: recon base, ac_sum) */
+	void *p64[3];               /* extra pointer arguments (TU_CHAIN: recon base, ac_sum; INTRA_TU_CHAIN: + the search results when jobs take their mode from them) */
 	int branch;                 /* 0 = the context's stream.  Commands with the same branch run in list order; different branches are
 	                             * declared independent of each other and may overlap when the list is replayed as a graph (fork at the
 	                             * start of the list, join at its end).  hmr_gpu_cmdlist_run ignores it (one stream, list order). */
@@ -360,6 +361,14 @@ uint32_t hmr_gpu_intra_tu_chain(int16_t *orig, int orig_stride, int16_t *decoded
 				int bl_size, int tr_size, int strong_enabled, int is_filtered, int mode, int is_luma, int16_t *pred, int pred_stride, int16_t *levels,
 				int16_t *recon, int recon_stride, int size, int is_dst, int scan_mode, int comp, int slice_is_intra, int sign_hiding, int per, int rem,
 				int *ac_sum);
+/* As above with the prediction mode handed over ON THE DEVICE: a job whose flags carry bit 8 takes its mode from modes[job.mode].best_mode (the result
+ * array of an intra search launched before it) and derives the smoothing rule (hmr_motion_intra.c:1011-1012) and the scan (find_scan_mode,
+ * hmr_tables.c:398-402) from mode and TU size itself; is_filtered / scan_mode / mode of such a job are ignored. */
+#define HMR_GPU_ITU_MODE_FROM_SEARCH 0x100u
+struct hmr_gpu_intra_result;   /* section 8 */
+int hmr_gpu_intra_tu_chain_modes_batch(hmr_gpu_ctx *ctx, const hmr_gpu_itu_job *jobs, int njobs, int size, const int16_t *orig_base, const int16_t *decoded_base,
+				       int16_t *pred_base, int16_t *level_base, int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum,
+				       const struct hmr_gpu_intra_result *modes);
 /* The inter TU: encode_inter_cu / encode_inter_cu_chroma (hmr_motion_inter.c:40-230).  The residual of the motion-compensated CU is given; per TU: DCT,
  * quantisation as non-intra, and for a coded TU the keep-or-drop decision ssd_zero <= ssd + zero_thr * sum on SSDs in the residual domain, scaled by
  * `weight` and truncated to uint32 like the reference (luma: weight 1.0).  zero_thr = clip(avg_dist / 2.5 - 5, 1, 20000) (:59-60,108; host double).
@@ -410,6 +419,44 @@ int hmr_gpu_intra_search_batch(hmr_gpu_ctx *ctx, const hmr_gpu_intra_job *jobs, 
 void hmr_gpu_intra_search(int16_t *orig, int orig_stride, int16_t *decoded_corner, int decoded_stride, int n, int left, int top, int bottom_left,
 			  int top_right, int bl_size, int tr_size, int strong_enabled, const int32_t *preds, const int32_t *pred_bits, int other_bits,
 			  double sqrt_lambda, int16_t *adi, int16_t *adi_filtered, int16_t *pred, int pred_stride, int32_t *out, double *best_cost);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * 9. transform-tree consolidation and the luma intra CU driver: the walk of encode_intra_luma (hmr_motion_intra.c:1441-1566) for a
+ *    one-level tree (max_intra_tr_depth = 2, rd_mode != RD_FULL).  The TUs themselves are launches of section 7 - the parent TUs of
+ *    all CUs in one launch on the parent level's plane, then child 0, 1, 2, 3 of all CUs in four launches on the child level's plane
+ *    (a child reads its siblings' reconstruction) - and this kernel is the comparison and the buffer consolidation (:1479-1557):
+ *       rule 0 (RD_DIST_ONLY)  dist < parent dist            rule 1 (RD_FAST)  1.25 * (dist + 45 * sum) < parent dist + 45 * parent sum
+ *    children win -> levels and reconstruction copied up (synchronize_motion_buffers_luma, :866), cbf of quadrant k = nz_k << 1 | any nz;
+ *    parent wins  -> its bottom row and right column copied down (synchronize_reference_buffs, :844), cbf = nz.
+ *    No host round trip between search, TUs and decision: a CU's whole luma decision is one ordered chain of launches.
+ * ------------------------------------------------------------------------------------------------ */
+#define HMR_GPU_TREE_NO_PARENT 0xffffffffu      /* a 64x64 CU has no parent TU (cost preset to INT_MAX, :1402): always consolidated */
+typedef struct hmr_gpu_tree_job {
+	uint32_t parent;                          /* index of the parent TU in ssd[] / ac_sum[] */
+	uint32_t child[4];                        /* indices of the four child TUs, z-order */
+	uint32_t par_rec_off, par_rec_stride;     /* the CU in the parent level's plane (decoded_mbs_wnd[depth + 1]) */
+	uint32_t chl_rec_off, chl_rec_stride;     /* the CU in the child level's plane (decoded_mbs_wnd[depth + 2]) */
+	uint32_t par_lev_off, chl_lev_off;        /* size * size levels each, linear; the children's blocks are consecutive (abs_index order) */
+	uint32_t size;                            /* CU size: 8, 16, 32, 64 */
+	uint32_t rule;                            /* 0 / 1 above */
+} hmr_gpu_tree_job;
+typedef struct hmr_gpu_tree_result {
+	uint32_t split;                           /* 1 = the four children were kept */
+	uint32_t cost, sum;                       /* what the partition node carries afterwards (cost = distortion) */
+	uint8_t cbf[4];                           /* cbf byte of the four quadrants (tr_idx = split) */
+} hmr_gpu_tree_result;
+int hmr_gpu_tree_decide_batch(hmr_gpu_ctx *ctx, const hmr_gpu_tree_job *jobs, int njobs, const uint32_t *ssd, const int32_t *ac_sum, int16_t *recon_base,
+			      int16_t *level_base, hmr_gpu_tree_result *out);
+/* host-pointer (drop-in) form of the whole luma CU: mode search, parent TU, four child TUs and the consolidation in one submission.
+ * nb: 5 x {left, top, bottom_left, top_right, bl_size, tr_size} for the CU and its four quadrants; dec_par / dec_chl: the CU's first sample in the
+ * two planes (both hold the neighbours); lev_par / lev_chl: size * size each.
+ * out[0] split, [1] = [2] cost, [3] sum, [4..7] cbf, [8] tr_idx, [9..13] ssd of parent + children, [14..18] their sums (slot 0 carries the consolidated
+ * figures after a split), [19] mode, [20] its bit count. */
+void hmr_gpu_intra_luma_cu(int16_t *orig, int orig_stride, int16_t *dec_par, int dec_par_stride, int16_t *dec_chl, int dec_chl_stride, const int32_t *nb,
+			   int strong_enabled, const int32_t *preds, const int32_t *pred_bits, int other_bits, double sqrt_lambda, int16_t *adi, int16_t *adi_filtered,
+			   int16_t *pred, int pred_stride, int16_t *lev_par, int16_t *lev_chl, int size, int slice_is_intra, int sign_hiding, int per, int rem, int rule,
+			   int32_t *out, double *best_cost);
 
 #ifdef __cplusplus
 }

@@ -565,3 +565,103 @@ def test_inter_tu_chain(rig, oracle, n):
     same(rig.down(d_ac, nj, np.int32), ac, "ac_sum")
     dropped = (ac == 0) & (ssd != 0)
     assert (ac != 0).sum() > 20 and dropped.sum() > 20
+
+
+TREE_JOB, TREE_RES = gpu_host.TREE_JOB_DTYPE, gpu_host.TREE_RESULT_DTYPE
+
+
+@pytest.mark.parametrize("n", [8, 16, 32, 64])
+def test_intra_luma_cu_tree(rig, oracle, n):
+    """The luma intra CU as a chain of launches with no host step in between (include/homer_gpu.h section 9): mode search -> parent TUs -> children 0..3 ->
+    consolidation, the mode handed from the search to the TU launches on the device.  Every CU has its own pair of planes (parent / child level) in one
+    device arena; the oracle's ora_intra_luma_cu runs on a host copy and the whole arena is compared."""
+    from kernel_cases import cu_tree_neighbours, mpm_list
+    rng = np.random.default_rng(n + 1000 * SEED)
+    nj = 301 if n <= 16 else 151 if n == 32 else 61
+    h, ring, adi = n // 2, 2 * n + 1, 4 * n + 4
+    per_cu = 2 * ring * ring + 4 * n * n + 2 * adi
+    host = np.zeros(nj * per_cu, np.int16)
+    o_pp = np.arange(nj) * per_cu; o_pc = o_pp + ring * ring; o_orig = o_pc + ring * ring; o_pred = o_orig + n * n
+    o_lp = o_pred + n * n; o_lc = o_lp + n * n; o_adi = o_lc + n * n; o_adif = o_adi + adi
+    yy, xx = np.mgrid[0:ring, 0:ring]
+    nbs, rules = [], rng.integers(0, 2, nj)
+    for i in range(nj):
+        th, amp, noise = rng.uniform(0, np.pi), rng.choice([3, 15, 40, 80]), int(rng.choice([0, 1, 3, 8, 20]))
+        tex = 128 + amp * np.sin((xx * np.cos(th) + yy * np.sin(th)) / rng.uniform(3, 20))
+        img = np.clip(tex + rng.integers(-noise, noise + 1, (ring, ring)), 0, 255).astype(np.int16)
+        for o in (o_pp[i], o_pc[i]):
+            host[o:o + ring * ring] = np.clip(img + rng.integers(-2, 3, (ring, ring)), 0, 255).ravel()
+        host[o_orig[i]:o_orig[i] + n * n] = img[1:n + 1, 1:n + 1].ravel()
+        left, top = (int(rng.integers(0, 2)), int(rng.integers(0, 2))) if i % 5 == 0 else (1, 1)
+        bl, tr = int(rng.integers(0, 2)) & left, int(rng.integers(0, 2)) & top
+        flags = [(left, top, bl, tr), (left, top, left, top), (1, top, 0, tr), (left, 1, bl, 1), (1, 1, 0, 0)]
+        nbs.append(cu_tree_neighbours(n, flags, int(rng.choice([n, n + h, 2 * n, 4 * n])), int(rng.choice([n, n + h, 2 * n, 4 * n]))))
+    nbs = np.array(nbs, np.int32).reshape(nj, 5, 6)
+    strong, slice_i, sbh = rng.integers(0, 2, nj), rng.integers(0, 2, nj), rng.integers(0, 2, nj)
+    qp = rng.integers(18, 45, nj)
+    sj = np.zeros(nj, INTRA_JOB)
+    sj["sqrt_lambda"] = rng.uniform(2.0, 60.0, nj)
+    sj["orig_off"] = o_orig; sj["orig_stride"] = n; sj["dec_off"] = o_pp; sj["dec_stride"] = ring
+    sj["adi_off"] = o_adi; sj["adif_off"] = o_adif; sj["pred_off"] = o_pred; sj["pred_stride"] = n
+    fl = lambda f: f[:, 0] | (f[:, 1] << 1) | (f[:, 2] << 2) | (f[:, 3] << 3) | (strong << 5)
+    sj["flags"] = fl(nbs[:, 0]); sj["sizes"] = nbs[:, 0, 4] | (nbs[:, 0, 5] << 16)
+    for i in range(nj):
+        sj["preds"][i] = mpm_list(int(rng.integers(-1, 35)), int(rng.integers(-1, 35)))
+    sj["pred_bits"] = np.where(rules[:, None] == 1, 1, 0); sj["other_bits"] = np.where(rules == 1, 12, 0)
+    gx, gy, gs = [0, 0, h, 0, h], [0, 0, 0, h, h], [n, h, h, h, h]
+    tj = np.zeros((5, nj), ITU_JOB)
+    for k in range(5):
+        plane = o_pc if k else o_pp
+        t = tj[k]
+        t["orig_off"] = o_orig + gy[k] * n + gx[k]; t["orig_stride"] = n
+        t["pred_off"] = o_pred + gy[k] * n + gx[k]; t["pred_stride"] = n
+        t["dec_off"] = plane + gy[k] * ring + gx[k]; t["dec_stride"] = ring
+        t["rec_off"] = t["dec_off"] + ring + 1; t["rec_stride"] = ring
+        t["lev_off"] = (o_lc + (k - 1) * h * h) if k else o_lp
+        t["flags"] = fl(nbs[:, k]) | (1 << 7) | gpu_host.ITU_MODE_FROM_SEARCH; t["sizes"] = nbs[:, k, 4] | (nbs[:, k, 5] << 16)
+        t["mode"] = np.arange(nj)
+        t["p0"] = (1 << 4) | (slice_i << 5) | (sbh << 6) | (int(gs[k] == 4) << 7); t["p1"] = (qp // 6) | ((qp % 6) << 8)
+    dj = np.zeros(nj, TREE_JOB)
+    dj["parent"] = np.arange(nj) if n <= 32 else gpu_host.TREE_NO_PARENT
+    for k in range(4):
+        dj["child"][:, k] = (k + 1) * nj + np.arange(nj)
+    dj["par_rec_off"] = o_pp + ring + 1; dj["par_rec_stride"] = ring; dj["chl_rec_off"] = o_pc + ring + 1; dj["chl_rec_stride"] = ring
+    dj["par_lev_off"] = o_lp; dj["chl_lev_off"] = o_lc; dj["size"] = n; dj["rule"] = rules
+    gpu, ctx = rig.gpu, rig.ctx
+    d_arena = rig.up(host)
+    d_modes = rig.malloc(16 * nj); d_ssd = rig.malloc(4 * 5 * nj); d_ac = rig.malloc(4 * 5 * nj); d_res = rig.malloc(16 * nj)
+    rig.bufs += [d_modes, d_ssd, d_ac, d_res]
+    zero = np.zeros(5 * nj, np.uint32)
+    for d in (d_ssd, d_ac):
+        assert gpu.hmr_gpu_upload(ctx, d, VP(zero.ctypes.data), C.c_size_t(zero.nbytes)) == 0
+    ok = lambda rc, what: (_ for _ in ()).throw(AssertionError((what, gpu.hmr_gpu_last_error()))) if rc else None
+    ok(gpu.hmr_gpu_intra_search_batch(ctx, rig.up(sj), nj, n, d_arena, d_arena, d_arena, d_modes), "search")
+    for k in range(0 if n <= 32 else 1, 5):
+        ok(gpu.hmr_gpu_intra_tu_chain_modes_batch(ctx, rig.up(tj[k]), nj, gs[k], d_arena, d_arena, d_arena, d_arena, d_arena, VP(d_ssd.value + 4 * k * nj),
+                                                  VP(d_ac.value + 4 * k * nj), d_modes), f"TU level {k}")
+    ok(gpu.hmr_gpu_tree_decide_batch(ctx, rig.up(dj), nj, d_ssd, d_ac, d_arena, d_arena, d_res), "consolidation")
+    assert gpu.hmr_gpu_sync(ctx) == 0, gpu.hmr_gpu_last_error()
+    got = rig.down(d_arena, host.size, np.int16)
+    res = rig.down(d_res, nj, TREE_RES); modes = rig.down(d_modes, nj, gpu_host.INTRA_RESULT_DTYPE)
+    ssd = rig.down(d_ssd, 5 * nj, np.uint32).reshape(5, nj); ac = rig.down(d_ac, 5 * nj, np.int32).reshape(5, nj)
+    o = host.copy()
+    I32 = C.c_int32
+    splits = 0
+    for i in range(nj):
+        out = (I32 * 24)(); cost = C.c_double(0)
+        nb = np.ascontiguousarray(nbs[i].ravel())
+        oracle.ora_intra_luma_cu(at(o, o_orig[i]), n, at(o, o_pp[i] + ring + 1), ring, at(o, o_pc[i] + ring + 1), ring, VP(nb.ctypes.data), int(strong[i]),
+                                 (I32 * 3)(*[int(v) for v in sj["preds"][i]]), (I32 * 3)(*[int(v) for v in sj["pred_bits"][i]]), int(sj["other_bits"][i]),
+                                 C.c_double(float(sj["sqrt_lambda"][i])), at(o, o_adi[i]), at(o, o_adif[i]), at(o, o_pred[i]), n, at(o, o_lp[i]), at(o, o_lc[i]), n,
+                                 int(slice_i[i]), int(sbh[i]), int(qp[i]) // 6, int(qp[i]) % 6, int(rules[i]), out, C.byref(cost))
+        exp = list(out)
+        assert (int(res["split"][i]), int(res["cost"][i]), int(res["sum"][i])) == (exp[0], exp[1] & 0xFFFFFFFF, exp[3]), (i, res[i], exp[:9])
+        assert list(res["cbf"][i]) == exp[4:8], (i, res[i], exp[:9])
+        assert int(modes["best_mode"][i]) == exp[19] and int(modes["bits"][i]) == exp[20]
+        assert modes["cost"][i:i + 1].view(np.uint64)[0] == np.array([cost.value]).view(np.uint64)[0]
+        for k in range(1, 5):
+            assert (int(ssd[k, i]), int(ac[k, i])) == (exp[9 + k] & 0xFFFFFFFF, exp[14 + k]), (i, k)
+        splits += exp[0]
+    same(got, o, "luma CU tree: planes, prediction, levels, neighbour arrays")
+    if n <= 32:
+        assert 0.1 < splits / nj < 0.9, splits
