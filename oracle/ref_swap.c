@@ -29,6 +29,15 @@ static int want(const char *name)
 	if (g_trace) return 0;             /* trace mode: everything that is not traced runs the reference's own code */
 	if (!s || !strcmp(s, "all")) return 1;
 	if (!strcmp(s, "none")) return 0;
+	if (!strncmp(s, "all,", 4)) {      /* "all,-name,-name": everything except the names listed */
+		size_t n = strlen(name);
+		const char *p = s;
+		while ((p = strstr(p, name))) {
+			if (p > s + 1 && p[-1] == '-' && p[-2] == ',' && (p[n] == 0 || p[n] == ',')) return 0;
+			p += n;
+		}
+		return 1;
+	}
 	{
 		size_t n = strlen(name);
 		const char *p = s;
@@ -470,6 +479,92 @@ uint encode_intra_cu(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *pi
 	}
 	if (!said++) fprintf(stderr, "ref_swap: intra TU chain routed to libhomer_gpu.so\n");
 	return ssd;
+}
+
+/* ---- encode_intra_luma (hmr_motion_intra.c:1226): the luma decision of one 2Nx2N intra CU - mode search, parent TU, four child TUs and the tree
+ * consolidation - as ONE GPU submission when the transform tree is one level deep and no CABAC bit estimate enters the comparison (rd_mode != RD_FULL;
+ * the default configuration).  The host keeps the control plane: most-probable modes, neighbour flags, the bookkeeping on the partition nodes and the
+ * side-info buffers (:1040-1049, :1499-1545).  Every other shape of call runs the reference's own function (whose inner calls are still interposed). ---- */
+uint32_t encode_intra_luma(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int depth, int part_position, PartSize part_size_type)
+{
+	static int said;
+	int log2cu = et->max_cu_size_shift - depth, cu_min, mtp, routed = 0;
+	if (log2cu < et->min_tu_size_shift + et->max_intra_tr_depth - 1)                        /* :1418-1432, part_size_type == SIZE_2Nx2N */
+		cu_min = et->min_tu_size_shift;
+	else {
+		cu_min = log2cu - (et->max_intra_tr_depth - 1);
+		if (cu_min > MAX_TU_SIZE_SHIFT) cu_min = MAX_TU_SIZE_SHIFT;
+	}
+	mtp = et->max_cu_size_shift - cu_min;
+	if (et->performance_mode >= PERF_FAST_COMPUTATION) mtp = (depth + 2 <= mtp) ? depth + 2 : ((depth + 1 <= mtp) ? depth + 1 : mtp);
+	if (want("intra_luma_cu") && part_size_type == SIZE_2Nx2N && et->rd_mode != RD_FULL && mtp == depth + 1 && (depth > 0 || et->max_cu_size == MAX_CU_SIZE))
+		routed = 1;
+	if (!routed)
+		return ((uint32_t (*)(henc_thread_t *, ctu_info_t *, int, int, int, PartSize))REAL(encode_intra_luma))(et, ctu, gcnt, depth, part_position, part_size_type);
+	{
+		cu_partition_info_t *pi = &ctu->partition_list[et->partition_depth_start[depth]] + part_position, *node[5];
+		ctu_info_t *ctu_rd = et->ctu_rd;
+		const int size = pi->size, x = pi->x_position, y = pi->y_position, qp = (int)pi->qp, has_parent = depth > 0;
+		wnd_t *dp = et->decoded_mbs_wnd[depth + 1], *dc = et->decoded_mbs_wnd[depth + 2], *qpw = et->transform_quant_wnd[depth + 1], *qcw = et->transform_quant_wnd[depth + 2];
+		int16_t *pred = WND_POSITION_2D(int16_t *, et->prediction_wnd[0], Y_COMP, x, y, gcnt, et->ctu_width);
+		int16_t *orig = WND_POSITION_2D(int16_t *, et->curr_mbs_wnd, Y_COMP, x, y, gcnt, et->ctu_width);
+		int16_t *dec_par = WND_POSITION_2D(int16_t *, *dp, Y_COMP, x, y, gcnt, et->ctu_width), *dec_chl = WND_POSITION_2D(int16_t *, *dc, Y_COMP, x, y, gcnt, et->ctu_width);
+		int16_t *lev_par = WND_POSITION_1D(int16_t *, *qpw, Y_COMP, gcnt, et->ctu_width, (pi->abs_index << et->num_partitions_in_cu_shift));
+		int16_t *lev_chl = WND_POSITION_1D(int16_t *, *qcw, Y_COMP, gcnt, et->ctu_width, (pi->abs_index << et->num_partitions_in_cu_shift));
+		int32_t nb[30], preds[3] = {-1, -1, -1}, bits[3] = {0, 0, 0}, out[24];
+		int other = 0, k, mode, split;
+		double cost;
+		node[0] = pi;
+		for (k = 0; k < 4; k++) node[k + 1] = pi->children[k];
+		for (k = 0; k < 5; k++) {
+			cu_partition_info_t *q = node[k];
+			nb[6 * k] = q->left_neighbour; nb[6 * k + 1] = q->top_neighbour; nb[6 * k + 2] = q->left_bottom_neighbour; nb[6 * k + 3] = q->top_right_neighbour;
+			nb[6 * k + 4] = min(q->size, et->pict_height[Y_COMP] - (ctu->y[Y_COMP] + q->y_position + q->size));
+			nb[6 * k + 5] = min(q->size, et->pict_width[Y_COMP] - (ctu->x[Y_COMP] + q->x_position + q->size));
+		}
+		ctu->top = 1;                                                            /* fill_reference_samples, :256-257 */
+		ctu->left = 1;
+		ctu_rd->intra_mode[Y_COMP] = et->intra_mode_buffs[Y_COMP][depth];        /* homer_loop1_motion_intra, :1102 */
+		get_intra_dir_luma_predictor(ctu_rd, pi, (int *)preds, NULL);
+		if (et->rd_mode == RD_FAST) {
+			bits[0] = bits[1] = bits[2] = 1;
+			other = 12;
+		}
+		hmr_gpu_intra_luma_cu(orig, WND_STRIDE_2D(et->curr_mbs_wnd, Y_COMP), dec_par, WND_STRIDE_2D(*dp, Y_COMP), dec_chl, WND_STRIDE_2D(*dc, Y_COMP), nb,
+				      et->sps->strong_intra_smooth_enabled_flag, preds, bits, other, et->rd.sqrt_lambda, et->adi_pred_buff, et->adi_filtered_pred_buff, pred,
+				      WND_STRIDE_2D(et->prediction_wnd[0], Y_COMP), lev_par, lev_chl, size, et->enc_engine->current_pict.slice.slice_type == I_SLICE,
+				      et->pps->sign_data_hiding_flag, qp / 6, qp % 6, et->rd_mode == RD_FAST, out, &cost);
+		mode = out[19];
+		split = out[0];
+		/* what encode_intra_cu leaves on the nodes (:1040-1049) */
+		for (k = has_parent ? 0 : 1; k < 5; k++) {
+			cu_partition_info_t *q = node[k];
+			const int shift = k ? 1 : 0;
+			q->qp = (uint32_t)qp;
+			q->distortion = q->cost = (uint32_t)out[9 + k];
+			q->sum = (uint32_t)out[14 + k];
+			q->intra_cbf[Y_COMP] = (out[14 + k] ? 1 : 0) << shift;
+			q->intra_tr_idx = shift;
+			q->intra_mode[Y_COMP] = mode;
+		}
+		if (split) {                                                             /* :1497-1522 */
+			pi->cost = pi->distortion = (uint32_t)out[1];
+			pi->sum = (uint32_t)out[3];
+			for (k = 1; k < 5; k++) {
+				cu_partition_info_t *q = node[k];
+				q->intra_cbf[Y_COMP] = out[3 + k];
+				memset(&et->cbf_buffs[Y_COMP][depth][q->abs_index], q->intra_cbf[Y_COMP], q->num_part_in_cu * sizeof(et->cbf_buffs[0][0][0]));
+				memset(&et->tr_idx_buffs[depth][q->abs_index], q->intra_tr_idx, q->num_part_in_cu * sizeof(et->tr_idx_buffs[0][0]));
+				memset(&et->intra_mode_buffs[Y_COMP][depth][q->abs_index], q->intra_mode[Y_COMP], q->num_part_in_cu * sizeof(et->intra_mode_buffs[0][0][0]));
+			}
+		} else {                                                                 /* :1549-1553 */
+			memset(&et->cbf_buffs[Y_COMP][depth][pi->abs_index], pi->intra_cbf[Y_COMP], pi->num_part_in_cu * sizeof(et->cbf_buffs[0][0][0]));
+			memset(&et->tr_idx_buffs[depth][pi->abs_index], pi->intra_tr_idx, pi->num_part_in_cu * sizeof(et->tr_idx_buffs[0][0]));
+			memset(&et->intra_mode_buffs[Y_COMP][depth][pi->abs_index], pi->intra_mode[Y_COMP], pi->num_part_in_cu * sizeof(et->intra_mode_buffs[0][0][0]));
+		}
+		if (!said++) fprintf(stderr, "ref_swap: luma intra CU driver routed to libhomer_gpu.so\n");
+		return (uint32_t)(pi->cost + out[20] * calc_mv_correction(pi->qp, et->enc_engine->avg_dist) + .5);   /* :1621-1624 */
+	}
 }
 
 /* ---- encode_inter_cu / encode_inter_cu_chroma (hmr_motion_inter.c:40,133): the inter TU - DCT, quantisation, keep-or-drop decision, reconstruction in
