@@ -88,10 +88,11 @@ class Arena:
         return off
 
 
-from homerhevc_amd.gpu import INTER_TU_JOB_DTYPE, INTRA_JOB_DTYPE, ITU_JOB_DTYPE, ME_JOB_DTYPE, TU_JOB_DTYPE  # noqa: E402
+from homerhevc_amd.gpu import (INTER_TU_JOB_DTYPE, INTRA_JOB_DTYPE, ITU_JOB_DTYPE, ITU_MODE_FROM_SEARCH, ME_JOB_DTYPE, TREE_JOB_DTYPE, TREE_NO_PARENT,  # noqa: E402
+                               TU_JOB_DTYPE)
 
 
-def build_groups(calls, rng, arena, fused=True):
+def build_groups(calls, rng, arena, fused=True, cu_driver=True):
     """Turn the recorded call mix into batched launches.  Returns list of dict(name, fn, size, jobs, args, bytes)."""
     from homerhevc_amd.gpu import JOB_DTYPE
 
@@ -330,11 +331,18 @@ def build_groups(calls, rng, arena, fused=True):
             nb += sum(v for k, v in calls.items() if k == "sad_direct:%d" % N) * (4 * N * N + 4)
             merged[("me_subpel", N)] = {"name": "me_subpel", "fn": "hmr_gpu_motion_estimation_batch", "size": N, "jobs": jb, "ctu": c, "bytes": nb, "extra": ()}
         # Intra mode search (homer_loop1_motion_intra): one job per PU instead of one reference build + up to 13 {prediction, SAD} pairs
-        for key, n in sorted(calls.items()):
+        # calls made inside a luma CU driver (intra_cu:N = encode_intra_luma with a one-level tree) are issued as that driver's chain further down:
+        # per CU one search at N, one parent TU at N (none for N = 64) and four child TUs at N / 2
+        cu_n = {int(k2.split(":")[1]): v for k2, v in calls.items() if k2.split(":")[0] == "intra_cu"} if cu_driver else {}
+        search_total = {int(k2.split(":")[1]): v for k2, v in calls.items() if k2.split(":")[0] == "intra_search"}
+        itu_total = {int(k2.split(":")[1]): v for k2, v in calls.items() if k2.split(":")[0] == "intra_tu"}
+        cu_bytes = {}
+        for key, n_all in sorted(calls.items()):
             kp = key.split(":")
             if kp[0] != "intra_search":
                 continue
             N = int(kp[1])
+            n = n_all - cu_n.get(N, 0)
             jb = np.zeros(n, INTRA_JOB_DTYPE)
             c = ctus(n)
             jb["sqrt_lambda"] = 7.5
@@ -354,13 +362,19 @@ def build_groups(calls, rng, arena, fused=True):
                 q = k2.split(":")
                 if "@search" in q[0] and int(q[1]) == N:
                     nb += v * {"fill_reference_samples@search": (4 * N + 1) * 2 * 3, "sad@search": 4 * N * N + 4}.get(q[0], 2 * (4 * N + 1) + 2 * N * N)
-            merged[("intra_search", N)] = {"name": "intra_search", "fn": "hmr_gpu_intra_search_batch", "size": N, "jobs": jb, "ctu": c, "bytes": nb, "extra": ()}
+            cu_bytes[("search", N)] = nb / n_all
+            if n:
+                merged[("intra_search", N)] = {"name": "intra_search", "fn": "hmr_gpu_intra_search_batch", "size": N, "jobs": jb, "ctu": c, "bytes": nb * n // n_all,
+                                               "extra": ()}
         # Intra TU chain (encode_intra_cu): neighbour array + prediction + the seven-call TU chain as one job per luma intra TU
-        for key, n in sorted(calls.items()):
+        itu_coded = {}
+        for key, n_all in sorted(calls.items()):
             kp = key.split(":")
             if kp[0] != "intra_tu":
                 continue
             N = int(kp[1])
+            n = n_all - (cu_n.get(N, 0) if N <= 32 else 0) - 4 * cu_n.get(2 * N, 0)
+            assert n >= 0, (key, n)
             inner = {k2.split(":")[0]: 0 for k2 in calls if "@itu" in k2}
             nb = 0
             for k2, v in calls.items():
@@ -371,6 +385,11 @@ def build_groups(calls, rng, arena, fused=True):
                                "intra_planar@itu": 2 * (4 * N + 1) + 2 * N * N, "intra_angular@itu": 2 * (4 * N + 1) + 2 * N * N,
                                "predict@itu": 6 * N * N, "reconst@itu": 6 * N * N, "ssd16b@itu": 4 * N * N + 4}.get(q[0], 4 * N * N)
             coded_frac = inner.get("inv_quant@itu", 0) / max(inner.get("quant@itu", 1), 1)
+            itu_coded[N] = coded_frac
+            cu_bytes[("tu", N)] = nb / n_all
+            if not n:
+                continue
+            nb = nb * n // n_all
             jb = np.zeros(n, ITU_JOB_DTYPE)
             c = ctus(n)
             coded = rng.random(n) < coded_frac
@@ -393,6 +412,61 @@ def build_groups(calls, rng, arena, fused=True):
             jb["p0"] = 3 | (0 << 2) | (1 << 4) | (0 << 5) | (1 << 6) | ((1 if N == 4 else 0) << 7)     # diagonal scan, luma, P slice, sign hiding on, DST for 4x4
             jb["p1"] = 5 | (2 << 8)
             merged[("intra_tu", N)] = {"name": "intra_tu", "fn": "hmr_gpu_intra_tu_chain_batch", "size": N, "jobs": jb, "ctu": c, "bytes": nb, "extra": ()}
+        # Luma intra CU driver (encode_intra_luma, one-level tree): search -> parent TUs -> children 0..3 -> consolidation as seven ordered launches per
+        # CU size, the mode handed from the search to the TU launches on the device.  Every CU owns a pair of (2N+1)^2 planes (parent / child level) cut
+        # from the smooth picture - its neighbourhood - and a source block equal to it, plus noise where the recorded share of TUs is coded.
+        for N, m in sorted(cu_n.items()):
+            h, ring = N // 2, 2 * N + 1
+            c = ctus(m)
+            ty = rng.integers(0, HA + 2 * PAD - ring, m); tx = rng.integers(0, REF_STRIDE - ring, m)
+            yy, xx = np.mgrid[0:ring, 0:ring]
+            tiles = smooth[ty[:, None, None] + yy, tx[:, None, None] + xx]                       # m x ring x ring
+            planes_pool = arena.alloc(2 * m * ring * ring, np.repeat(tiles.reshape(m, 1, -1), 2, 1).ravel())
+            coded = rng.random(m) < itu_coded.get(N if N <= 32 else h, 0.5)
+            src = tiles[:, 1:N + 1, 1:N + 1].astype(np.int64) + np.where(coded[:, None, None], rng.integers(-40, 41, (m, N, N)), 0)
+            src_pool = arena.alloc(m * N * N, np.clip(src, 0, 255).astype(np.int16).ravel())
+            o_pp = planes_pool + np.arange(m, dtype=np.int64) * 2 * ring * ring; o_pc = o_pp + ring * ring
+            o_src = src_pool + np.arange(m, dtype=np.int64) * N * N
+            o_pred = arena.alloc(m * N * N) + np.arange(m, dtype=np.int64) * N * N
+            lev_pool = arena.alloc(2 * m * N * N)
+            o_lp = lev_pool + np.arange(m, dtype=np.int64) * 2 * N * N; o_lc = o_lp + N * N
+            adi_pool = arena.alloc(m * 2 * (4 * N + 4))
+            sj = np.zeros(m, INTRA_JOB_DTYPE)
+            sj["sqrt_lambda"] = 7.5
+            sj["orig_off"] = o_src; sj["orig_stride"] = N; sj["dec_off"] = o_pp; sj["dec_stride"] = ring
+            sj["adi_off"] = adi_pool + np.arange(m, dtype=np.int64) * 2 * (4 * N + 4); sj["adif_off"] = sj["adi_off"] + 4 * N + 4
+            sj["pred_off"] = o_pred; sj["pred_stride"] = N
+            sj["flags"] = 15 | 32; sj["sizes"] = N | (N << 16)
+            sj["preds"] = np.stack([rng.integers(2, 35, m), np.zeros(m, np.int64), np.ones(m, np.int64)], 1)
+            sj["pred_bits"] = 1; sj["other_bits"] = 12       # RD_FAST
+            chain = "cu%d" % N
+            merged[("cu_search", N)] = {"name": "cu_search", "fn": "hmr_gpu_intra_search_batch", "size": N, "jobs": sj, "ctu": c, "bytes": int(cu_bytes[("search", N)] * m),
+                                        "extra": (), "chain": chain, "level": -1}
+            gx, gy, gs = [0, 0, h, 0, h], [0, 0, 0, h, h], [N, h, h, h, h]
+            nbf = [15, 15, 3 | 8, 3 | 8 | 4, 3]      # neighbour flags of the CU and of its quadrants in an interior position
+            for k in range(0 if N <= 32 else 1, 5):
+                t = np.zeros(m, ITU_JOB_DTYPE)
+                plane = o_pc if k else o_pp
+                t["orig_off"] = o_src + gy[k] * N + gx[k]; t["orig_stride"] = N
+                t["pred_off"] = o_pred + gy[k] * N + gx[k]; t["pred_stride"] = N
+                t["dec_off"] = plane + gy[k] * ring + gx[k]; t["dec_stride"] = ring
+                t["rec_off"] = t["dec_off"] + ring + 1; t["rec_stride"] = ring
+                t["lev_off"] = (o_lc + (k - 1) * h * h) if k else o_lp
+                t["flags"] = nbf[k] | 32 | (1 << 7) | ITU_MODE_FROM_SEARCH; t["sizes"] = gs[k] | (gs[k] << 16)
+                t["mode"] = np.arange(m)
+                t["p0"] = (1 << 4) | (1 << 6) | ((1 if gs[k] == 4 else 0) << 7); t["p1"] = 5 | (2 << 8)
+                merged[("cu_tu%d" % k, gs[k])] = {"name": "cu_tu%d" % k, "fn": "hmr_gpu_intra_tu_chain_modes_batch", "size": gs[k], "jobs": t, "ctu": c,
+                                                  "bytes": int(cu_bytes[("tu", gs[k])] * m), "extra": (), "chain": chain, "level": k}
+            dj = np.zeros(m, TREE_JOB_DTYPE)
+            dj["parent"] = np.arange(m) if N <= 32 else TREE_NO_PARENT
+            for k in range(4):
+                dj["child"][:, k] = (k + 1) * m + np.arange(m)
+            dj["par_rec_off"] = o_pp + ring + 1; dj["par_rec_stride"] = ring; dj["chl_rec_off"] = o_pc + ring + 1; dj["chl_rec_stride"] = ring
+            dj["par_lev_off"] = o_lp; dj["chl_lev_off"] = o_lc; dj["size"] = N; dj["rule"] = 1
+            # the consolidation's copies are the copy_16_16 calls of synchronize_motion_buffers_luma / wnd_copy, which the mix already replays as copy
+            # jobs: priced there, not twice
+            merged[("cu_decide", N)] = {"name": "cu_decide", "fn": "hmr_gpu_tree_decide_batch", "size": N, "jobs": dj, "ctu": c, "bytes": 0, "extra": (),
+                                        "chain": chain, "level": 5}
         # Inter TU chain (encode_inter_cu / _chroma): DCT + quant + keep-or-drop decision + reconstruction as one job per inter TU.  The recorded
         # mix gives the shares: coded = inv_quant / quant, kept = reconst with a residual / coded.
         eres = np.zeros((NCTU, 64, 64), np.int64)
@@ -625,6 +699,8 @@ def main():
                          "graph: the same command list captured once into a hipGraph and replayed (no per-launch host cost), per-kernel numbers from an eager pass after the timed region")
     ap.add_argument("--unfused", action="store_true",
                     help="replay predict/transform/quant/inv_quant/itransform/reconst/ssd16b as seven separate batches per TU size instead of the fused TU-chain kernel")
+    ap.add_argument("--no-cu-driver", action="store_true",
+                    help="issue the luma intra CU drivers (search + transform tree + consolidation chains) as independent search / TU batches instead")
     ap.add_argument("--branches", type=int, default=8, help="graph mode: number of parallel graph branches the independent launches are dealt to (1 = one serial chain)")
     ap.add_argument("--engines-per-gpu", type=int, default=1,
                     help="encoder engines (frames in flight) per GPU, each with its own stream, planes and command list; a step encodes that many frames. "
@@ -661,7 +737,7 @@ def main():
 
         rng = np.random.default_rng(1234 + rank + 1000 * e)
         arena = Arena()
-        groups, planes = build_groups(calls, rng, arena, fused=not args.unfused)
+        groups, planes = build_groups(calls, rng, arena, fused=not args.unfused, cu_driver=not args.no_cu_driver)
         info = frame_side_info(rng)
 
         with torch.cuda.stream(stream):
@@ -703,9 +779,17 @@ def main():
         OPS = {"hmr_gpu_sad_batch": 1, "hmr_gpu_ssd16b_batch": 2, "hmr_gpu_predict_batch": 3, "hmr_gpu_reconst_batch": 4, "hmr_gpu_copy_batch": 5,
                "hmr_gpu_intra_pred_batch": 7, "hmr_gpu_intra_refs_batch": 8, "hmr_gpu_interpolate_batch": 9, "hmr_gpu_transform_batch": 11,
                "hmr_gpu_itransform_batch": 12, "hmr_gpu_quant_batch": 13, "hmr_gpu_inv_quant_batch": 14, "hmr_gpu_mc_batch": 15,
-               "hmr_gpu_motion_estimation_batch": 16, "hmr_gpu_tu_chain_batch": 22, "hmr_gpu_intra_search_batch": 23, "hmr_gpu_intra_tu_chain_batch": 24, "hmr_gpu_inter_tu_chain_batch": 25}
+               "hmr_gpu_motion_estimation_batch": 16, "hmr_gpu_tu_chain_batch": 22, "hmr_gpu_intra_search_batch": 23, "hmr_gpu_intra_tu_chain_batch": 24, "hmr_gpu_inter_tu_chain_batch": 25,
+               "hmr_gpu_intra_tu_chain_modes_batch": 24, "hmr_gpu_tree_decide_batch": 26}
         OP_EDGE, OP_DEBLOCK, OP_STATS, OP_APPLY, OP_PAD = 17, 18, 19, 20, 21
         cmds, names = [], []
+        # a luma CU driver chain shares its search results (the modes), the SSD / sum arrays of its five TU levels and the consolidation results
+        chains = {}
+        for g in groups:
+            if g.get("chain") and g["chain"] not in chains:
+                m = len(g["jobs"])
+                chains[g["chain"]] = {"m": m, "modes": torch.zeros(4 * m, dtype=torch.int32, device=dev), "ssd": torch.zeros(5 * m, dtype=torch.int32, device=dev),
+                                      "ac": torch.zeros(5 * m, dtype=torch.int32, device=dev), "res": torch.zeros(4 * m, dtype=torch.int32, device=dev)}
         for g in groups:
             cm = Cmd(op=OPS[g["fn"]], njobs=len(g["jobs"]), size=g["size"], jobs=g["d_jobs"].data_ptr(), a=base, b=base, c=base, out=g["d_out"].data_ptr())
             if g["fn"] == "hmr_gpu_copy_batch":
@@ -717,8 +801,16 @@ def main():
                 cm.out = g["d_out"].data_ptr()
                 cm.p = (C.c_int * 4)(128, 64, W, HA)     # MOTION_SEARCH_RANGE_X/Y, picture size
             if g["fn"] == "hmr_gpu_intra_search_batch":
-                g["d_out"] = torch.zeros(4 * len(g["jobs"]), dtype=torch.int32, device=dev)     # hmr_gpu_intra_result per PU
+                g["d_out"] = chains[g["chain"]]["modes"] if g.get("chain") else torch.zeros(4 * len(g["jobs"]), dtype=torch.int32, device=dev)   # hmr_gpu_intra_result per PU
                 cm.out = g["d_out"].data_ptr()
+            if g["fn"] == "hmr_gpu_intra_tu_chain_modes_batch":
+                ch, k = chains[g["chain"]], g["level"]
+                cm.out = ch["ssd"].data_ptr() + 4 * k * ch["m"]
+                cm.p64 = (P * 3)(base, ch["ac"].data_ptr() + 4 * k * ch["m"], ch["modes"].data_ptr())
+            if g["fn"] == "hmr_gpu_tree_decide_batch":
+                ch = chains[g["chain"]]
+                cm.a, cm.b, cm.c, cm.out = ch["ssd"].data_ptr(), ch["ac"].data_ptr(), base, ch["res"].data_ptr()
+                cm.p64 = (P * 3)(base, None, None)
             if g["fn"] in ("hmr_gpu_intra_tu_chain_batch", "hmr_gpu_inter_tu_chain_batch"):
                 g["d_ac"] = torch.zeros(len(g["jobs"]), dtype=torch.int32, device=dev)
                 cm.p64 = (P * 3)(base, g["d_ac"].data_ptr(), None)   # reconstruction / prediction base, ac_sum
@@ -732,10 +824,14 @@ def main():
         # graph branches (longest first, by algorithmic bytes) so the ramp-up / tail of one kernel overlaps the body of another.
         load = [0.0] * max(args.branches, 1)
         load[0] = 2.0e8                                  # the frame-level chain
-        for i in sorted(range(len(groups)), key=lambda i: -groups[i]["bytes"]):
+        sched = {}
+        for i, g in enumerate(groups):                   # the launches of a CU driver chain depend on each other: one branch, list order
+            sched.setdefault(g.get("chain") or i, []).append(i)
+        for unit in sorted(sched.values(), key=lambda u: -sum(groups[i]["bytes"] for i in u)):
             b = load.index(min(load))
-            cmds[i].branch = b
-            load[b] += groups[i]["bytes"]
+            for i in unit:
+                cmds[i].branch = b
+                load[b] += groups[i]["bytes"]
         frame_bytes = {
             "deblock": 2 * 2 * 6144 * n_ctu, "sao_stats": (2 * 2 * 6144 + 5 * 3 * 512) * n_ctu, "sao_apply": 2 * 2 * 6144 * n_ctu,
             "pad": 2 * 2 * ((W + 2 * PAD) * (H + 2 * PAD) - W * H) * 3 // 2, "edge_flags": 3 * (W // 4) * (H // 4),
@@ -751,7 +847,7 @@ def main():
         ctx.call("hmr_gpu_cmdlist_create", cmd_arr, len(cmds), C.byref(clist))
         n_cmd = len(cmds)
         return {"ctx": ctx, "stream": stream, "clist": clist, "groups": groups, "names": names, "frame_bytes": frame_bytes, "dst_pl": [dst_flat], "nxt_pl": [nxt_flat],
-                "n_cmd": n_cmd, "keep": [d_arena, rec_pl, org_pl, d_info, d_stats, f_rec, f_org, f_dst, units, cmd_arr, cmds]}
+                "n_cmd": n_cmd, "keep": [d_arena, rec_pl, org_pl, d_info, d_stats, f_rec, f_org, f_dst, units, cmd_arr, cmds, chains]}
 
     engines = [make_engine(e) for e in range(max(args.engines_per_gpu, 1))]
     E0 = engines[0]

@@ -121,6 +121,23 @@ int homer_loop1_motion_intra(henc_thread_t *et, ctu_info_t *ctu, ctu_info_t *ctu
 	g_sfx = "";
 	return r;
 }
+/* encode_intra_luma calls whose whole luma decision (search + one-level transform tree + consolidation) is one device-side chain on the GPU side:
+ * 2Nx2N, no CABAC bit estimate in the comparison, tree exactly one level deep (hmr_motion_intra.c:1418-1438) - the condition oracle/ref_swap.c routes on.
+ * Counted on top of the intra_search / intra_tu calls it contains (those keys keep counting every call). */
+uint32_t encode_intra_luma(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int depth, int part_position, PartSize part_size_type)
+{
+	int log2cu = et->max_cu_size_shift - depth, cu_min, mtp;
+	if (log2cu < et->min_tu_size_shift + et->max_intra_tr_depth - 1) cu_min = et->min_tu_size_shift;
+	else {
+		cu_min = log2cu - (et->max_intra_tr_depth - 1);
+		if (cu_min > MAX_TU_SIZE_SHIFT) cu_min = MAX_TU_SIZE_SHIFT;
+	}
+	mtp = et->max_cu_size_shift - cu_min;
+	if (et->performance_mode >= PERF_FAST_COMPUTATION) mtp = (depth + 2 <= mtp) ? depth + 2 : ((depth + 1 <= mtp) ? depth + 1 : mtp);
+	if (part_size_type == SIZE_2Nx2N && et->rd_mode != RD_FULL && mtp == depth + 1 && (depth > 0 || et->max_cu_size == MAX_CU_SIZE))
+		bump("intra_cu:%d", et->max_cu_size >> depth, 0, 0, 0);
+	return ((uint32_t (*)(henc_thread_t *, ctu_info_t *, int, int, int, PartSize))REAL(encode_intra_luma))(et, ctu, gcnt, depth, part_position, part_size_type);
+}
 uint encode_intra_cu(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *pi, int depth, int cu_mode, PartSize part_size_type, int *curr_sum, int gcnt)
 {
 	uint r;
