@@ -92,7 +92,7 @@ from homerhevc_amd.gpu import (INTER_TU_JOB_DTYPE, INTRA_JOB_DTYPE, ITU_JOB_DTYP
                                TU_JOB_DTYPE)
 
 
-def build_groups(calls, rng, arena, fused=True, cu_driver=True):
+def build_groups(calls, rng, arena, fused=True, cu_driver=False, cu_rounds=True):
     """Turn the recorded call mix into batched launches.  Returns list of dict(name, fn, size, jobs, args, bytes)."""
     from homerhevc_amd.gpu import JOB_DTYPE
 
@@ -444,6 +444,7 @@ def build_groups(calls, rng, arena, fused=True, cu_driver=True):
                                         "extra": (), "chain": chain, "level": -1}
             gx, gy, gs = [0, 0, h, 0, h], [0, 0, 0, h, h], [N, h, h, h, h]
             nbf = [15, 15, 3 | 8, 3 | 8 | 4, 3]      # neighbour flags of the CU and of its quadrants in an interior position
+            children = []
             for k in range(0 if N <= 32 else 1, 5):
                 t = np.zeros(m, ITU_JOB_DTYPE)
                 plane = o_pc if k else o_pp
@@ -455,8 +456,15 @@ def build_groups(calls, rng, arena, fused=True, cu_driver=True):
                 t["flags"] = nbf[k] | 32 | (1 << 7) | ITU_MODE_FROM_SEARCH; t["sizes"] = gs[k] | (gs[k] << 16)
                 t["mode"] = np.arange(m)
                 t["p0"] = (1 << 4) | (1 << 6) | ((1 if gs[k] == 4 else 0) << 7); t["p1"] = 5 | (2 << 8)
+                if k and cu_rounds:
+                    children.append(t)
+                    continue
                 merged[("cu_tu%d" % k, gs[k])] = {"name": "cu_tu%d" % k, "fn": "hmr_gpu_intra_tu_chain_modes_batch", "size": gs[k], "jobs": t, "ctu": c,
                                                   "bytes": int(cu_bytes[("tu", gs[k])] * m), "extra": (), "chain": chain, "level": k}
+            if children:      # the four children of every CU back to back in one launch (four rounds over the same lanes)
+                merged[("cu_children", h)] = {"name": "cu_children", "fn": "hmr_gpu_intra_tu_chain_modes_batch", "size": h, "jobs": np.concatenate(children),
+                                              "ctu": np.arange(4 * m), "bytes": int(cu_bytes[("tu", h)] * 4 * m), "extra": (), "chain": chain, "level": 1,
+                                              "njobs": m, "rounds": 4}
             dj = np.zeros(m, TREE_JOB_DTYPE)
             dj["parent"] = np.arange(m) if N <= 32 else TREE_NO_PARENT
             for k in range(4):
@@ -699,8 +707,11 @@ def main():
                          "graph: the same command list captured once into a hipGraph and replayed (no per-launch host cost), per-kernel numbers from an eager pass after the timed region")
     ap.add_argument("--unfused", action="store_true",
                     help="replay predict/transform/quant/inv_quant/itransform/reconst/ssd16b as seven separate batches per TU size instead of the fused TU-chain kernel")
-    ap.add_argument("--no-cu-driver", action="store_true",
-                    help="issue the luma intra CU drivers (search + transform tree + consolidation chains) as independent search / TU batches instead")
+    ap.add_argument("--cu-driver", action="store_true",
+                    help="issue the luma intra CU drivers (encode_intra_luma: search + transform tree + consolidation) as ordered device-side chains - search -> parent TUs -> "
+                         "the four children in one launch -> consolidation, the mode handed over on the device - instead of independent search / TU batches")
+    ap.add_argument("--cu-child-launches", action="store_true", help="issue the four children of the luma CU drivers as four launches instead of one launch with four rounds")
+    ap.add_argument("--chain-branches", type=int, default=1, help="1: every luma CU driver chain runs on a graph branch of its own; 0: chains are balanced like the other launches")
     ap.add_argument("--branches", type=int, default=8, help="graph mode: number of parallel graph branches the independent launches are dealt to (1 = one serial chain)")
     ap.add_argument("--engines-per-gpu", type=int, default=1,
                     help="encoder engines (frames in flight) per GPU, each with its own stream, planes and command list; a step encodes that many frames. "
@@ -737,7 +748,7 @@ def main():
 
         rng = np.random.default_rng(1234 + rank + 1000 * e)
         arena = Arena()
-        groups, planes = build_groups(calls, rng, arena, fused=not args.unfused, cu_driver=not args.no_cu_driver)
+        groups, planes = build_groups(calls, rng, arena, fused=not args.unfused, cu_driver=args.cu_driver, cu_rounds=not args.cu_child_launches)
         info = frame_side_info(rng)
 
         with torch.cuda.stream(stream):
@@ -791,7 +802,7 @@ def main():
                 chains[g["chain"]] = {"m": m, "modes": torch.zeros(4 * m, dtype=torch.int32, device=dev), "ssd": torch.zeros(5 * m, dtype=torch.int32, device=dev),
                                       "ac": torch.zeros(5 * m, dtype=torch.int32, device=dev), "res": torch.zeros(4 * m, dtype=torch.int32, device=dev)}
         for g in groups:
-            cm = Cmd(op=OPS[g["fn"]], njobs=len(g["jobs"]), size=g["size"], jobs=g["d_jobs"].data_ptr(), a=base, b=base, c=base, out=g["d_out"].data_ptr())
+            cm = Cmd(op=OPS[g["fn"]], njobs=g.get("njobs", len(g["jobs"])), size=g["size"], jobs=g["d_jobs"].data_ptr(), a=base, b=base, c=base, out=g["d_out"].data_ptr())
             if g["fn"] == "hmr_gpu_copy_batch":
                 cm.size = g["size"] << 8            # kind 0 (int16) | uniform square size hint
             if g["fn"] == "hmr_gpu_quant_batch":
@@ -807,6 +818,7 @@ def main():
                 ch, k = chains[g["chain"]], g["level"]
                 cm.out = ch["ssd"].data_ptr() + 4 * k * ch["m"]
                 cm.p64 = (P * 3)(base, ch["ac"].data_ptr() + 4 * k * ch["m"], ch["modes"].data_ptr())
+                cm.p = (C.c_int * 4)(g.get("rounds", 1), 0, 0, 0)
             if g["fn"] == "hmr_gpu_tree_decide_batch":
                 ch = chains[g["chain"]]
                 cm.a, cm.b, cm.c, cm.out = ch["ssd"].data_ptr(), ch["ac"].data_ptr(), base, ch["res"].data_ptr()
@@ -827,11 +839,16 @@ def main():
         sched = {}
         for i, g in enumerate(groups):                   # the launches of a CU driver chain depend on each other: one branch, list order
             sched.setdefault(g.get("chain") or i, []).append(i)
+        extra_branch = len(load)
         for unit in sorted(sched.values(), key=lambda u: -sum(groups[i]["bytes"] for i in u)):
-            b = load.index(min(load))
+            if len(unit) > 1 and args.chain_branches:    # a chain is seven short dependent launches: latency, not bytes - it gets a branch of its own
+                b = extra_branch
+                extra_branch += 1
+            else:
+                b = load.index(min(load))
+                load[b] += sum(groups[i]["bytes"] for i in unit)
             for i in unit:
                 cmds[i].branch = b
-                load[b] += groups[i]["bytes"]
         frame_bytes = {
             "deblock": 2 * 2 * 6144 * n_ctu, "sao_stats": (2 * 2 * 6144 + 5 * 3 * 512) * n_ctu, "sao_apply": 2 * 2 * 6144 * n_ctu,
             "pad": 2 * 2 * ((W + 2 * PAD) * (H + 2 * PAD) - W * H) * 3 // 2, "edge_flags": 3 * (W // 4) * (H // 4),

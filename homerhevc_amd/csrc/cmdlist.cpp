@@ -51,6 +51,9 @@ static int run_one(hmr_gpu_ctx *ctx, const hmr_gpu_cmd &c)
 		return hmr_gpu_tree_decide_batch(ctx, (const hmr_gpu_tree_job *)c.jobs, c.njobs, (const uint32_t *)c.a, (const int32_t *)c.b, o, (int16_t *)c.p64[0],
 						 (hmr_gpu_tree_result *)c.out);
 	case HMR_GPU_OP_INTRA_TU_CHAIN:
+		if (c.p[0] > 1)
+			return hmr_gpu_intra_tu_chain_rounds_batch(ctx, (const hmr_gpu_itu_job *)c.jobs, c.njobs, c.p[0], c.size, a, b, (int16_t *)c.p64[0], o, (int16_t *)c.p64[0],
+								   (uint32_t *)c.out, (int32_t *)c.p64[1], (const hmr_gpu_intra_result *)c.p64[2]);
 		if (c.p64[2])
 			return hmr_gpu_intra_tu_chain_modes_batch(ctx, (const hmr_gpu_itu_job *)c.jobs, c.njobs, c.size, a, b, (int16_t *)c.p64[0], o, (int16_t *)c.p64[0],
 								  (uint32_t *)c.out, (int32_t *)c.p64[1], (const hmr_gpu_intra_result *)c.p64[2]);

@@ -772,7 +772,7 @@ uint32_t hmr_gpu_inter_tu_chain(int16_t *residual, int residual_stride, int16_t 
 
 }  // extern "C"
 
-/* ---- encode_intra_luma's data path for one 2Nx2N CU (hmr_motion_intra.c:1226-1632): search -> parent TU -> four child TUs -> consolidation, seven
+/* ---- encode_intra_luma's data path for one 2Nx2N CU (hmr_motion_intra.c:1226-1632): search -> parent TU -> four child TUs (one launch, four rounds) -> consolidation, four
  * launches in stream order on one staged image; the mode never leaves the device between them. ---- */
 void hmr_gpu_intra_luma_cu(int16_t *orig, int orig_stride, int16_t *dec_par, int dec_par_stride, int16_t *dec_chl, int dec_chl_stride, const int32_t *nb,
 			   int strong_enabled, const int32_t *preds, const int32_t *pred_bits, int other_bits, double sqrt_lambda, int16_t *adi, int16_t *adi_filtered,
@@ -853,10 +853,13 @@ void hmr_gpu_intra_luma_cu(int16_t *orig, int orig_stride, int16_t *dec_par, int
 	int16_t *base = st.dev<int16_t>();
 	hmr_gpu_intra_result *modes = st.dev<hmr_gpu_intra_result>(ro);
 	must(hmr_gpu_intra_search_batch(c, st.dev<hmr_gpu_intra_job>(so), 1, n, base, base, base, modes), "intra_luma_cu: search");
-	for (int k = has_parent ? 0 : 1; k < 5; k++)
-		must(hmr_gpu_intra_tu_chain_modes_batch(c, st.dev<hmr_gpu_itu_job>(to) + k, 1, gs[k], base, base, base, base, base, st.dev<uint32_t>(sso) + k,
-							st.dev<int32_t>(aco) + k, modes),
-		     "intra_luma_cu: TU");
+	if (has_parent)
+		must(hmr_gpu_intra_tu_chain_modes_batch(c, st.dev<hmr_gpu_itu_job>(to), 1, n, base, base, base, base, base, st.dev<uint32_t>(sso), st.dev<int32_t>(aco), modes),
+		     "intra_luma_cu: parent TU");
+	// the four children back to back in one launch (each reads its siblings' reconstruction)
+	must(hmr_gpu_intra_tu_chain_rounds_batch(c, st.dev<hmr_gpu_itu_job>(to) + 1, 1, 4, h, base, base, base, base, base, st.dev<uint32_t>(sso) + 1,
+						 st.dev<int32_t>(aco) + 1, modes),
+	     "intra_luma_cu: child TUs");
 	must(hmr_gpu_tree_decide_batch(c, st.dev<hmr_gpu_tree_job>(d_o), 1, st.dev<uint32_t>(sso), st.dev<int32_t>(aco), base, base, st.dev<hmr_gpu_tree_result>(tro)),
 	     "intra_luma_cu: consolidation");
 	st.finish();

@@ -62,7 +62,7 @@ template <int N, int MODE>
 __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const void *__restrict__ jobs_v, int njobs, const int16_t *__restrict__ O,
 							   int16_t *__restrict__ Pp, int16_t *__restrict__ L, int16_t *__restrict__ Rr,
 							   uint32_t *__restrict__ ssd_out, int32_t *__restrict__ ac_out, const DevTables *__restrict__ tab,
-							   const int16_t *__restrict__ D, const hmr_gpu_intra_result *__restrict__ modes)
+							   const int16_t *D, const hmr_gpu_intra_result *__restrict__ modes, int rounds)   // D may alias Rr (in-place reconstruction)
 {
 	constexpr bool INTRA = MODE == TU_INTRA, INTER = MODE == TU_INTER;
 	using JobT = typename std::conditional<INTRA, hmr_gpu_itu_job, typename std::conditional<INTER, hmr_gpu_inter_tu_job, hmr_gpu_tu_job>::type>::type;
@@ -81,7 +81,19 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 	__shared__ int sAc[HMR_WAVES_PER_BLOCK][TW];
 	const int lane = lane_id(), w = wave_in_block(), tu = lane / N, row = lane % N;
 	const JobRange jr = xcd_job_range(njobs, JPB);
-	for (long base = jr.begin; base < jr.end; base += jr.stride) {
+	for (long base = jr.begin; base < jr.end; base += jr.stride)
+	// rounds > 1: the job array holds `rounds` sets of njobs jobs; job j of set r + 1 may read what job j of set r reconstructed (the four
+	// children of a CU, hmr_motion_intra.c:1441-1477) - the same lanes run them back to back, with the stores of one round made visible
+	// to the loads of the next
+	for (int rnd = 0; rnd < rounds; rnd++) {
+		const JobT *__restrict__ jobs_r = jobs + (long)rnd * njobs;
+		uint32_t *__restrict__ ssd_r = ssd_out + (long)rnd * njobs;
+		int32_t *__restrict__ ac_r = ac_out + (long)rnd * njobs;
+		if (rnd) {      // producer and consumer lanes are in the same wave, hence on the same CU and behind the same vector L1: workgroup scope is enough
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		}
 		const long j = base + w * TW + tu;
 		const bool ok = j < jr.end;
 		JobT jb = {};
@@ -90,7 +102,7 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 		for (int i = 0; i < N / 2; i++) r[i] = 0;
 		const int16_t *orow_p = O, *prow_p = Pp;
 		if (ok) {
-			jb = jobs[j];
+			jb = jobs_r[j];
 			if constexpr (INTRA) {
 				// mode handed over on the device by the search that ran before this launch: smoothing (hmr_motion_intra.c:1011-1012) and
 				// scan (find_scan_mode, hmr_tables.c:398-402) follow from mode and TU size
@@ -299,7 +311,7 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 				}
 			}
 			ssd = group_sum<N>(ssd);
-			if (ok && row == 0) ssd_out[j] = ssd;
+			if (ok && row == 0) ssd_r[j] = ssd;
 		} else {
 			// the reconstruction is written as if the levels were kept while both SSDs are accumulated; the (rare) dropped TU is rewritten
 			// from the prediction alone once the decision is known
@@ -347,7 +359,7 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 			}
 			if (ok) {
 				if (row == 0) {
-					ssd_out[j] = coded ? w_ssd : w_zero;
+					ssd_r[j] = coded ? w_ssd : w_zero;
 					if (drop) sAc[w][tu] = 0;
 				}
 			}
@@ -365,7 +377,7 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 				const bool zero = INTER && sNz[w][qt] != 0;
 				const i16x4 z4 = {{0, 0, 0, 0}};
 				for (int e0 = 4 * l; e0 < E; e0 += 4 * GQ) st4(lo + e0, zero ? z4 : ld4(ql + e0));
-				if (l == 0) ac_out[qj] = sAc[w][qt];
+				if (l == 0) ac_r[qj] = sAc[w][qt];
 			}
 		}
 		wave_sync();
@@ -377,12 +389,12 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 
 template <int MODE>
 static int launch_tu_chain(hmr_gpu_ctx *ctx, const void *jobs, int njobs, int size, const int16_t *orig_base, int16_t *pred_base, int16_t *level_base,
-			   int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum, const int16_t *decoded_base, const hmr_gpu_intra_result *modes = nullptr)
+			   int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum, const int16_t *decoded_base, const hmr_gpu_intra_result *modes = nullptr, int rounds = 1)
 {
 	if (njobs <= 0) return HMR_GPU_OK;
 #define TU_LAUNCH(N)                                                                                                                               \
 	hipLaunchKernelGGL((k_tu_chain<N, MODE>), dim3(hmr_grid_for_units(((long)njobs + (HMR_WAVE / N) * HMR_WAVES_PER_BLOCK - 1) / ((HMR_WAVE / N) * HMR_WAVES_PER_BLOCK))), \
-			   dim3(HMR_BLOCK), 0, ctx->stream, jobs, njobs, orig_base, pred_base, level_base, recon_base, ssd, ac_sum, ctx->tables, decoded_base, modes)
+			   dim3(HMR_BLOCK), 0, ctx->stream, jobs, njobs, orig_base, pred_base, level_base, recon_base, ssd, ac_sum, ctx->tables, decoded_base, modes, rounds)
 	switch (size) {
 	case 4: TU_LAUNCH(4); break;
 	case 8: TU_LAUNCH(8); break;
@@ -414,6 +426,14 @@ extern "C" int hmr_gpu_intra_tu_chain_modes_batch(hmr_gpu_ctx *ctx, const hmr_gp
 {
 	if (!modes) { hmr_set_error("intra_tu_chain_modes_batch: modes is NULL"); return HMR_GPU_ERR_ARG; }
 	return launch_tu_chain<TU_INTRA>(ctx, jobs, njobs, size, orig_base, pred_base, level_base, recon_base, ssd, ac_sum, decoded_base, modes);
+}
+
+extern "C" int hmr_gpu_intra_tu_chain_rounds_batch(hmr_gpu_ctx *ctx, const hmr_gpu_itu_job *jobs, int njobs, int rounds, int size, const int16_t *orig_base,
+						   const int16_t *decoded_base, int16_t *pred_base, int16_t *level_base, int16_t *recon_base, uint32_t *ssd,
+						   int32_t *ac_sum, const hmr_gpu_intra_result *modes)
+{
+	if (rounds < 1 || rounds > 16) { hmr_set_error("intra_tu_chain_rounds_batch: rounds must be 1..16"); return HMR_GPU_ERR_ARG; }
+	return launch_tu_chain<TU_INTRA>(ctx, jobs, njobs, size, orig_base, pred_base, level_base, recon_base, ssd, ac_sum, decoded_base, modes, rounds);
 }
 
 extern "C" int hmr_gpu_inter_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_inter_tu_job *jobs, int njobs, int size, const int16_t *residual_base,

@@ -291,7 +291,7 @@ enum hmr_gpu_op {
 	HMR_GPU_OP_INTER_TU_CHAIN = 25, /* jobs = hmr_gpu_inter_tu_job*, a = residual base, b = pred base, c = level base, out = ssd; p64 = {recon base, ac_sum} */
 	HMR_GPU_OP_TREE_DECIDE = 26,    /* jobs = hmr_gpu_tree_job*, a = ssd, b = ac_sum, c = recon base, out = hmr_gpu_tree_result*; p64[0] = level base */
 	HMR_GPU_OP_INTRA_TU_CHAIN = 24 /* jobs = hmr_gpu_itu_job*, a = orig base, b = decoded base, c = level base, out = ssd; p64 = {recon base, ac_sum, hmr_gpu_intra_result* or NULL};
-	                           * the prediction plane shares the recon base */
+	                           * the prediction plane shares the recon base; p[0] = rounds (0 / 1 = one set of jobs) */
 };
 /* One call of the batched / frame-level API: `size` is that entry's size/kind/flags argument, a/b/c/out its pointer arguments in
  * declaration order (frame-level ops take host pointers to hmr_gpu_frame / hmr_gpu_units that must outlive the list), p[] its
@@ -369,6 +369,12 @@ struct hmr_gpu_intra_result;   /* section 8 */
 int hmr_gpu_intra_tu_chain_modes_batch(hmr_gpu_ctx *ctx, const hmr_gpu_itu_job *jobs, int njobs, int size, const int16_t *orig_base, const int16_t *decoded_base,
 				       int16_t *pred_base, int16_t *level_base, int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum,
 				       const struct hmr_gpu_intra_result *modes);
+/* `rounds` sets of njobs jobs in one launch (jobs[r * njobs + j], ssd / ac_sum indexed the same way): job j of set r + 1 may read what job j of set r
+ * reconstructed - the four children of a CU in z-order (hmr_motion_intra.c:1441-1477) run back to back on the same lanes instead of as four launches.
+ * modes may be NULL when no job carries HMR_GPU_ITU_MODE_FROM_SEARCH. */
+int hmr_gpu_intra_tu_chain_rounds_batch(hmr_gpu_ctx *ctx, const hmr_gpu_itu_job *jobs, int njobs, int rounds, int size, const int16_t *orig_base,
+					const int16_t *decoded_base, int16_t *pred_base, int16_t *level_base, int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum,
+					const struct hmr_gpu_intra_result *modes);
 /* The inter TU: encode_inter_cu / encode_inter_cu_chroma (hmr_motion_inter.c:40-230).  The residual of the motion-compensated CU is given; per TU: DCT,
  * quantisation as non-intra, and for a coded TU the keep-or-drop decision ssd_zero <= ssd + zero_thr * sum on SSDs in the residual domain, scaled by
  * `weight` and truncated to uint32 like the reference (luma: weight 1.0).  zero_thr = clip(avg_dist / 2.5 - 5, 1, 20000) (:59-60,108; host double).

@@ -68,27 +68,25 @@ def test_fused_and_unfused_replays_account_for_the_same_work():
     assert res[False][1] == sum(v for k, v in calls.items() if k.split(":")[0].split("@")[0] in (
         "sad", "sad_direct", "ssd16b", "predict", "reconst", "copy_16_16", "intra_planar", "intra_angular", "fill_reference_samples", "interp_luma",
         "interp_chroma", "transform", "itransform", "quant", "inv_quant") and not (k.startswith("copy_16_16") and int(k.split(":")[2]) > bench.W))
-    # in this P frame every intra CU goes through the one-level tree: its searches and TUs are issued as the luma CU driver chains
-    assert {"tu_chain", "inter_tu", "me_subpel", "mc_luma", "mc_chroma", "cu_search", "cu_tu0", "cu_tu1", "cu_tu2", "cu_tu3", "cu_tu4", "cu_decide"} <= res[True][2]
-    assert not ({"tu_chain", "inter_tu", "intra_tu", "me_subpel", "mc_luma", "intra_search", "cu_search", "cu_decide"} & res[False][2])
-    groups, _ = bench.build_groups(calls, np.random.default_rng(7), bench.Arena(), fused=True)
+    assert {"tu_chain", "inter_tu", "intra_tu", "me_subpel", "mc_luma", "mc_chroma", "intra_search"} <= res[True][2]
+    assert not ({"tu_chain", "inter_tu", "intra_tu", "me_subpel", "mc_luma", "intra_search"} & res[False][2])
+    # --cu-driver: in this P frame every intra CU goes through the one-level tree, so all its searches and TUs become luma CU driver chains
+    groups, _ = bench.build_groups(calls, np.random.default_rng(7), bench.Arena(), fused=True, cu_driver=True)
+    assert {"cu_search", "cu_tu0", "cu_children", "cu_decide"} <= {g["name"] for g in groups} and not ({"intra_search", "intra_tu"} & {g["name"] for g in groups})
+    assert abs(sum(g["bytes"] for g in groups) - res[True][0]) / res[True][0] < 0.001
     by = {(g["name"], g["size"]): len(g["jobs"]) for g in groups}
     n_cu = {int(k.split(":")[1]): v for k, v in calls.items() if k.startswith("intra_cu:")}
     tot = lambda kind, n: sum(v for k, v in calls.items() if k.split(":")[0] == kind and int(k.split(":")[1]) == n)   # noqa: E731
     for n, m in n_cu.items():
-        assert by[("cu_search", n)] == by[("cu_tu0", n)] == by[("cu_decide", n)] == m and all(by[("cu_tu%d" % k, n // 2)] == m for k in (1, 2, 3, 4))
+        assert by[("cu_search", n)] == by[("cu_tu0", n)] == by[("cu_decide", n)] == m and by[("cu_children", n // 2)] == 4 * m
     for n in (4, 8, 16, 32, 64):      # chains + what is left of the plain batches = the recorded calls
         assert by.get(("intra_search", n), 0) + n_cu.get(n, 0) == tot("intra_search", n)
         assert by.get(("intra_tu", n), 0) + (n_cu.get(n, 0) if n <= 32 else 0) + 4 * n_cu.get(2 * n, 0) == tot("intra_tu", n)
-    # without the driver chains the same calls are independent search / TU batches
-    groups, _ = bench.build_groups(calls, np.random.default_rng(7), bench.Arena(), fused=True, cu_driver=False)
-    names = {g["name"] for g in groups}
-    assert {"intra_tu", "intra_search"} <= names and not ({"cu_search", "cu_decide"} & names)
-    assert abs(sum(g["bytes"] for g in groups) - res[True][0]) / res[True][0] < 0.001
     # every job's operands stay inside the arena
-    arena = bench.Arena()
-    groups, _ = bench.build_groups(calls, np.random.default_rng(7), arena, fused=True)
-    for g in groups:
-        for field in g["jobs"].dtype.names:
-            if field.endswith("_off"):
-                assert int(g["jobs"][field].max()) < arena.size, (g["name"], field)
+    for cu in (False, True):
+        arena = bench.Arena()
+        groups, _ = bench.build_groups(calls, np.random.default_rng(7), arena, fused=True, cu_driver=cu)
+        for g in groups:
+            for field in g["jobs"].dtype.names:
+                if field.endswith("_off"):
+                    assert int(g["jobs"][field].max()) < arena.size, (g["name"], field)

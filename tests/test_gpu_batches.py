@@ -570,8 +570,9 @@ def test_inter_tu_chain(rig, oracle, n):
 TREE_JOB, TREE_RES = gpu_host.TREE_JOB_DTYPE, gpu_host.TREE_RESULT_DTYPE
 
 
+@pytest.mark.parametrize("rounds", [1, 4], ids=["children_4_launches", "children_1_launch"])
 @pytest.mark.parametrize("n", [8, 16, 32, 64])
-def test_intra_luma_cu_tree(rig, oracle, n):
+def test_intra_luma_cu_tree(rig, oracle, n, rounds):
     """The luma intra CU as a chain of launches with no host step in between (include/homer_gpu.h section 9): mode search -> parent TUs -> children 0..3 ->
     consolidation, the mode handed from the search to the TU launches on the device.  Every CU has its own pair of planes (parent / child level) in one
     device arena; the oracle's ora_intra_luma_cu runs on a host copy and the whole arena is compared."""
@@ -636,9 +637,12 @@ def test_intra_luma_cu_tree(rig, oracle, n):
         assert gpu.hmr_gpu_upload(ctx, d, VP(zero.ctypes.data), C.c_size_t(zero.nbytes)) == 0
     ok = lambda rc, what: (_ for _ in ()).throw(AssertionError((what, gpu.hmr_gpu_last_error()))) if rc else None
     ok(gpu.hmr_gpu_intra_search_batch(ctx, rig.up(sj), nj, n, d_arena, d_arena, d_arena, d_modes), "search")
-    for k in range(0 if n <= 32 else 1, 5):
+    for k in range(0 if n <= 32 else 1, 5 if rounds == 1 else 1):
         ok(gpu.hmr_gpu_intra_tu_chain_modes_batch(ctx, rig.up(tj[k]), nj, gs[k], d_arena, d_arena, d_arena, d_arena, d_arena, VP(d_ssd.value + 4 * k * nj),
                                                   VP(d_ac.value + 4 * k * nj), d_modes), f"TU level {k}")
+    if rounds == 4:     # the four children of every CU back to back in ONE launch
+        ok(gpu.hmr_gpu_intra_tu_chain_rounds_batch(ctx, rig.up(np.concatenate([tj[1], tj[2], tj[3], tj[4]])), nj, 4, h, d_arena, d_arena, d_arena, d_arena, d_arena,
+                                                   VP(d_ssd.value + 4 * nj), VP(d_ac.value + 4 * nj), d_modes), "children")
     ok(gpu.hmr_gpu_tree_decide_batch(ctx, rig.up(dj), nj, d_ssd, d_ac, d_arena, d_arena, d_res), "consolidation")
     assert gpu.hmr_gpu_sync(ctx) == 0, gpu.hmr_gpu_last_error()
     got = rig.down(d_arena, host.size, np.int16)
