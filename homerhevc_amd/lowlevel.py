@@ -54,6 +54,7 @@ OFF_TABLE = {
     "adi_filter": ("hmr_gpu_adi_filter", None),
     "homer_loop1_motion_intra": ("hmr_gpu_intra_search", None),
     "encode_intra_cu": ("hmr_gpu_intra_tu_chain", C.c_uint32),
+    "encode_intra_luma": ("hmr_gpu_intra_luma_cu", None),
     "encode_inter_cu": ("hmr_gpu_inter_tu_chain", C.c_uint32),
     "hmr_motion_estimation": ("hmr_gpu_motion_estimation", C.c_uint32),
     "hmr_motion_compensation_luma": ("hmr_gpu_mc_luma", None),
