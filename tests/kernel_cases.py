@@ -561,11 +561,11 @@ def all_cases(level="full"):
             bl, tr = int(r.integers(0, 2)) & left, int(r.integers(0, 2)) & top
             # the quadrants' flags as cu_partition_get_neighbours derives them, with an occasional arbitrary combination
             flags = [(left, top, bl, tr), (left, top, left, top), (1, top, 0, tr), (left, 1, bl, 1), (1, 1, 0, 0)]
-            if i % 7 == 3:        # any combination a frame can produce: below-left needs left, above-right needs above, the last quadrant has neither
+            if i % 7 == 3:        # any combination a frame can produce: below-left needs left, above-right needs above, quadrant 1 has no below-left, the last quadrant neither
                 flags = []
                 for node in range(5):
                     fl, ft = int(r.integers(0, 2)), int(r.integers(0, 2))
-                    flags.append((fl, ft, int(r.integers(0, 2)) & fl & (node != 4), int(r.integers(0, 2)) & ft & (node != 4)))
+                    flags.append((fl, ft, int(r.integers(0, 2)) & fl & (node not in (2, 4)), int(r.integers(0, 2)) & ft & (node != 4)))
             add("intra_luma_cu", n=n, flags=flags, pict_w=int(r.choice([n, n + n // 2, 2 * n, 4 * n])), pict_h=int(r.choice([n, n + n // 2, 2 * n, 4 * n])),
                 qp=int(r.integers(18, 45)), sqrt_lambda=float(r.uniform(2.0, 60.0)), rd_mode=int(r.choice([2, 2, 0])), slice_i=int(r.integers(0, 2)),
                 sbh=int(r.integers(0, 2)), strong=int(r.integers(0, 2)), theta=float(r.uniform(0, np.pi)), period=float(r.uniform(3.0, 25.0)),

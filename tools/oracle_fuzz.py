@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random differential runs for the composite functions - intra mode search, intra / inter / plain TU chains - beyond the fixed case lists
+"""Random differential runs for the composite functions - intra mode search, intra / inter / plain TU chains, the luma intra CU driver - beyond the fixed case lists
 of tests/kernel_cases.py: the CPU oracle against the compiled reference (build container: needs oracle/_ref), or, with --gpu, the drop-in
 entries of libhomer_gpu.so against the oracle (GPU box).
 usage: python tools/oracle_fuzz.py [--gpu] [seconds] [seed]"""
@@ -23,12 +23,22 @@ def neighbours(r, n):
 
 
 def random_case(r):
-    kind = r.choice(["intra_search", "intra_tu_chain", "inter_tu_chain", "tu_chain"])
+    kind = r.choice(["intra_search", "intra_tu_chain", "inter_tu_chain", "tu_chain", "intra_luma_cu"])
     if kind == "intra_search":
         n = int(r.choice([4, 8, 16, 32, 64]))
         p = dict(n=n, **neighbours(r, n), left_mode=int(r.integers(-1, 35)), top_mode=int(r.integers(-1, 35)), rd_mode=int(r.choice([2, 0])),
                  sqrt_lambda=float(r.uniform(0.5, 80)), theta=float(r.uniform(0, np.pi)), period=float(r.uniform(2, 30)), amp=float(r.uniform(0, 100)),
                  tilt=float(r.uniform(-8, 8)), noise=int(r.integers(0, 12)))
+    elif kind == "intra_luma_cu":
+        n = int(r.choice([8, 16, 32, 64]))
+        flags = []
+        for node in range(5):     # what a frame can produce: below-left needs left, above-right needs above; quadrant 1 has no below-left (quadrant 2 is coded
+            fl, ft = (int(r.integers(0, 2)), int(r.integers(0, 2))) if r.random() < 0.3 else (1, 1)     # after it), quadrant 3 has neither
+            flags.append((fl, ft, int(r.integers(0, 2)) & fl & (node not in (2, 4)), int(r.integers(0, 2)) & ft & (node != 4)))
+        p = dict(n=n, flags=flags, pict_w=int(r.choice([n, n + n // 2, 2 * n, 4 * n])), pict_h=int(r.choice([n, n + n // 2, 2 * n, 4 * n])), qp=int(r.integers(10, 50)),
+                 sqrt_lambda=float(r.uniform(0.5, 80)), rd_mode=int(r.choice([2, 2, 0])), slice_i=int(r.integers(0, 2)), sbh=int(r.integers(0, 2)),
+                 strong=int(r.integers(0, 2)), theta=float(r.uniform(0, np.pi)), period=float(r.uniform(2, 30)), amp=float(r.uniform(0, 100)),
+                 tilt=float(r.uniform(-8, 8)), noise=int(r.choice([0, 1, 3, 8, 20, 40])))
     elif kind == "intra_tu_chain":
         n = int(r.choice([4, 8, 16, 32]))
         p = dict(n=n, comp=int(r.choice([0, 0, 1, 2])) if n < 32 else 0, **neighbours(r, n), mode=int(r.integers(0, 35)), scan=int(r.integers(1, 4)),
@@ -61,7 +71,7 @@ def main():
         case = random_case(r)
         a, b = kc.run(ora, "ora_", case), kc.run(ref, prefix, case)
         n += 1
-        for k in a:
+        for k in (k for k in a if k in b):
             if not np.array_equal(a[k], b[k]):
                 bad += 1
                 print("MISMATCH", case, k)
