@@ -707,6 +707,7 @@ def main():
                          "graph: the same command list captured once into a hipGraph and replayed (no per-launch host cost), per-kernel numbers from an eager pass after the timed region")
     ap.add_argument("--unfused", action="store_true",
                     help="replay predict/transform/quant/inv_quant/itransform/reconst/ssd16b as seven separate batches per TU size instead of the fused TU-chain kernel")
+    ap.add_argument("--no-multi", action="store_true", help="one launch per (pixel kernel, block size) instead of one multi-segment launch per pixel kernel")
     ap.add_argument("--cu-driver", action="store_true",
                     help="issue the luma intra CU drivers (encode_intra_luma: search + transform tree + consolidation) as ordered device-side chains - search -> parent TUs -> "
                          "the four children in one launch -> consolidation, the mode handed over on the device - instead of independent search / TU batches")
@@ -736,6 +737,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     P = C.c_void_p
 
+    class Segment(C.Structure):      # hmr_gpu_segment
+        _fields_ = [("jobs", P), ("out", P), ("njobs", C.c_int), ("size", C.c_int)]
+
     class Cmd(C.Structure):
         _fields_ = [("op", C.c_int), ("njobs", C.c_int), ("size", C.c_int), ("p", C.c_int * 4), ("jobs", P), ("a", P), ("b", P), ("c", P), ("out", P), ("p64", P * 3), ("branch", C.c_int)]
 
@@ -749,6 +753,9 @@ def main():
         rng = np.random.default_rng(1234 + rank + 1000 * e)
         arena = Arena()
         groups, planes = build_groups(calls, rng, arena, fused=not args.unfused, cu_driver=args.cu_driver, cu_rounds=not args.cu_child_launches)
+        if os.environ.get("HOMER_BENCH_DROP"):      # experiments only (what would a launch cost if it were free?): the record is marked
+            drop = set(os.environ["HOMER_BENCH_DROP"].split(","))
+            groups = [g for g in groups if g["name"] not in drop and f"{g['name']}:{g['size']}" not in drop]
         info = frame_side_info(rng)
 
         with torch.cuda.stream(stream):
@@ -760,6 +767,24 @@ def main():
             for g in groups:
                 g["d_jobs"] = torch.from_numpy(g["jobs"].view(np.uint8)).to(dev)
                 g["d_out"] = torch.zeros(len(g["jobs"]), dtype=torch.int32, device=dev)
+            if not args.no_multi:
+                # batches of one pixel kernel that differ only in the block size go out as segments of ONE launch (hmr_gpu_pixel_multi): each is a
+                # short launch that cannot fill the GPU on its own
+                PIXEL_OPS = {"hmr_gpu_sad_batch": 1, "hmr_gpu_ssd16b_batch": 2, "hmr_gpu_predict_batch": 3, "hmr_gpu_reconst_batch": 4, "hmr_gpu_copy_batch": 5}
+                fam = {}
+                for g in groups:
+                    if g["fn"] in PIXEL_OPS and g["size"] in (4, 8, 16, 32, 64) and not g.get("chain"):
+                        fam.setdefault(g["fn"], []).append(g)
+                for fn, members in fam.items():
+                    if len(members) < 2:
+                        continue
+                    segs = (Segment * len(members))(*[Segment(m["d_jobs"].data_ptr(), m["d_out"].data_ptr(), len(m["jobs"]), m["size"]) for m in members])
+                    merged_g = {"name": members[0]["name"], "fn": "hmr_gpu_pixel_multi", "size": "multi", "pixel_op": PIXEL_OPS[fn], "segs": segs, "members": members,
+                                "jobs": np.concatenate([m["jobs"] for m in members]), "bytes": sum(m["bytes"] for m in members), "extra": (),
+                                "d_jobs": None, "d_out": members[0]["d_out"]}
+                    groups[groups.index(members[0])] = merged_g
+                    for m in members[1:]:
+                        groups.remove(m)
             # frame-level state: original + reconstruction (padded) + SAO destination, side-info
             def padded_plane(w, h, pad):
                 return torch.from_numpy(rng.integers(0, 256, ((h + 2 * pad), (w + 2 * pad))).astype(np.int16)).to(dev)
@@ -802,6 +827,10 @@ def main():
                 chains[g["chain"]] = {"m": m, "modes": torch.zeros(4 * m, dtype=torch.int32, device=dev), "ssd": torch.zeros(5 * m, dtype=torch.int32, device=dev),
                                       "ac": torch.zeros(5 * m, dtype=torch.int32, device=dev), "res": torch.zeros(4 * m, dtype=torch.int32, device=dev)}
         for g in groups:
+            if g["fn"] == "hmr_gpu_pixel_multi":
+                cmds.append(Cmd(op=27, njobs=len(g["segs"]), size=g["pixel_op"], jobs=C.addressof(g["segs"]), a=base, b=base, c=base))
+                names.append(f"{g['name']}:multi")
+                continue
             cm = Cmd(op=OPS[g["fn"]], njobs=g.get("njobs", len(g["jobs"])), size=g["size"], jobs=g["d_jobs"].data_ptr(), a=base, b=base, c=base, out=g["d_out"].data_ptr())
             if g["fn"] == "hmr_gpu_copy_batch":
                 cm.size = g["size"] << 8            # kind 0 (int16) | uniform square size hint
@@ -977,7 +1006,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
             "config": {"workload": WORKLOAD, "width": W, "height": H, "qp": 32, "gop": "IPPP gop_size=1", "me": "quarter-pel", "sao": 1,
-                       "calls_per_frame": int(sum(len(g["jobs"]) for g in groups)), "launches_per_frame": len(groups) + 8,
+                       "calls_per_frame": int(sum(len(g["jobs"]) for g in groups)), "launches_per_frame": len(groups) + 8, **({"EXPERIMENT_dropped_groups": os.environ["HOMER_BENCH_DROP"]} if os.environ.get("HOMER_BENCH_DROP") else {}),
                        "callmix_frame": args.callmix_frame, "parallelism": f"{len(engines)} engine(s) per gpu x{world}", "frames_per_step": len(engines) * world, "launch_mode": args.mode, "graph_branches": args.branches if args.mode == "graph" else 1, "tu_chain": "7 separate batches" if args.unfused else "fused kernel",
                        "algorithmic_MB_per_frame_abi_width": round(total_alg / 1e6, 2), "compulsory_MB_per_frame": round(10.5 * W * H / 1e6, 2)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

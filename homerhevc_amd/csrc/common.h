@@ -71,20 +71,23 @@ static inline int hmr_grid_for_waves(long njobs_waves)
 // giving XCD x the contiguous job range [x*per, (x+1)*per) keeps each picture region in ONE XCD's L2 instead of
 // spreading it over all eight (placement b % 8 is only used for speed: any placement computes the same result).
 struct JobRange { long begin, end, stride; };
-__device__ __forceinline__ JobRange xcd_job_range(long njobs, int jobs_per_block)
+// (block, grid) are the launch's blockIdx.x / gridDim.x, or a segment's block index and block count inside a multi-segment launch
+// (segments start at multiples of 8 blocks, so block % 8 is still the XCD)
+__device__ __forceinline__ JobRange xcd_job_range(long njobs, int jobs_per_block, unsigned block, unsigned grid)
 {
 	JobRange r;
-	if (gridDim.x % HMR_XCDS) {   // tiny grids: plain grid-stride
-		r.begin = (long)blockIdx.x * jobs_per_block; r.end = njobs; r.stride = (long)gridDim.x * jobs_per_block;
+	if (grid % HMR_XCDS) {   // tiny grids: plain grid-stride
+		r.begin = (long)block * jobs_per_block; r.end = njobs; r.stride = (long)grid * jobs_per_block;
 		return r;
 	}
-	const int xcd = blockIdx.x % HMR_XCDS, bi = blockIdx.x / HMR_XCDS, bpx = gridDim.x / HMR_XCDS;
+	const int xcd = block % HMR_XCDS, bi = block / HMR_XCDS, bpx = grid / HMR_XCDS;
 	const long per = ((njobs + (long)HMR_XCDS * jobs_per_block - 1) / ((long)HMR_XCDS * jobs_per_block)) * jobs_per_block;
 	r.begin = xcd * per + (long)bi * jobs_per_block;
 	r.end = (xcd + 1) * per < njobs ? (xcd + 1) * per : njobs;
 	r.stride = (long)bpx * jobs_per_block;
 	return r;
 }
+__device__ __forceinline__ JobRange xcd_job_range(long njobs, int jobs_per_block) { return xcd_job_range(njobs, jobs_per_block, blockIdx.x, gridDim.x); }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (HMR_WAVE - 1); }
 __device__ __forceinline__ int wave_in_block() { return threadIdx.x >> 6; }
 

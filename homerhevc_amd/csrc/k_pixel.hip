@@ -22,15 +22,15 @@ template <int N> struct PixelLanes { static constexpr int value = N <= 8 ? 4 : N
 // search is only 2-byte aligned), G = min(64, N*N/4) lanes own a block: 16 4x4 blocks, four 8x8 blocks or one larger
 // block per wave.
 template <int N, int OP>
-__global__ __launch_bounds__(HMR_BLOCK) void k_sad_ssd(const hmr_gpu_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ A,
-							  const int16_t *__restrict__ B, uint32_t *__restrict__ out)
+__device__ __forceinline__ void sad_ssd_body(const hmr_gpu_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ A, const int16_t *__restrict__ B,
+					     uint32_t *__restrict__ out, unsigned block, unsigned grid)
 {
 	constexpr int CH = N * N / 4;                      // 4-sample chunks per block
 	constexpr int CPR = N / 4;                         // chunks per row
 	constexpr int G = PixelLanes<N>::value;
 	constexpr int JPW = HMR_WAVE / G;
 	const int lane = lane_id(), sub = lane / G, l = lane % G;
-	const JobRange jr = xcd_job_range(njobs, JPW * HMR_WAVES_PER_BLOCK);
+	const JobRange jr = xcd_job_range(njobs, JPW * HMR_WAVES_PER_BLOCK, block, grid);
 	for (long j0 = jr.begin + wave_in_block() * JPW; j0 < jr.end; j0 += jr.stride) {
 		const long j = j0 + sub;
 		uint32_t acc = 0;
@@ -84,6 +84,13 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_sad_ssd(const hmr_gpu_job *__rest
 	}
 }
 
+template <int N, int OP>
+__global__ __launch_bounds__(HMR_BLOCK) void k_sad_ssd(const hmr_gpu_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ A,
+							  const int16_t *__restrict__ B, uint32_t *__restrict__ out)
+{
+	sad_ssd_body<N, OP>(jobs, njobs, A, B, out, blockIdx.x, gridDim.x);
+}
+
 enum { EW_PREDICT = 0, EW_RECONST = 1, EW_WAVG = 2 };
 
 // c = f(a, b) over a w x h region (square kernels pass w = h = N through the job)
@@ -114,14 +121,14 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_elementwise(const hmr_gpu_job *__
 // Uniform-size N x N variant of the element-wise kernels and of the int16 copy: same 4-samples-per-lane geometry as SAD.
 // OP 3 = plain copy (a -> c).
 template <int N, int OP>
-__global__ __launch_bounds__(HMR_BLOCK) void k_square(const hmr_gpu_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ A,
-							 const int16_t *__restrict__ B, int16_t *__restrict__ Cc)
+__device__ __forceinline__ void square_body(const hmr_gpu_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ A, const int16_t *__restrict__ B,
+					    int16_t *__restrict__ Cc, unsigned block, unsigned grid)
 {
 	constexpr int CH = N * N / 4, CPR = N / 4;
 	constexpr int G = PixelLanes<N>::value;
 	constexpr int JPW = HMR_WAVE / G;
 	const int lane = lane_id(), sub = lane / G, l = lane % G;
-	const JobRange jr = xcd_job_range(njobs, JPW * HMR_WAVES_PER_BLOCK);
+	const JobRange jr = xcd_job_range(njobs, JPW * HMR_WAVES_PER_BLOCK, block, grid);
 	for (long j0 = jr.begin + wave_in_block() * JPW; j0 < jr.end; j0 += jr.stride) {
 		const long j = j0 + sub;
 		if (j >= jr.end) continue;
@@ -142,6 +149,56 @@ __global__ __launch_bounds__(HMR_BLOCK) void k_square(const hmr_gpu_job *__restr
 					r.v[k] = OP == EW_PREDICT ? (int16_t)(va.v[k] - vb.v[k]) : (int16_t)clip3i(sat16i(va.v[k] + vb.v[k]), 0, 255);
 			}
 			st4(c + (size_t)y * jb.c_stride + x, r);
+		}
+	}
+}
+
+template <int N, int OP>
+__global__ __launch_bounds__(HMR_BLOCK) void k_square(const hmr_gpu_job *__restrict__ jobs, int njobs, const int16_t *__restrict__ A,
+							 const int16_t *__restrict__ B, int16_t *__restrict__ Cc)
+{
+	square_body<N, OP>(jobs, njobs, A, B, Cc, blockIdx.x, gridDim.x);
+}
+
+// Several (block size, job array) segments of one kernel family in ONE launch: a frame's SAD / SSD / residual / copy batches differ only in the
+// block size, and each is a short launch that cannot fill the GPU on its own.  Block b belongs to the segment whose block range contains it and
+// runs that segment's body with its position inside the range; ranges start at multiples of 8 blocks so that b % 8 stays the XCD.
+struct SegTab {
+	const hmr_gpu_job *jobs[HMR_GPU_MAX_SEGMENTS];
+	uint32_t *out[HMR_GPU_MAX_SEGMENTS];
+	int njobs[HMR_GPU_MAX_SEGMENTS], size[HMR_GPU_MAX_SEGMENTS], first[HMR_GPU_MAX_SEGMENTS], blocks[HMR_GPU_MAX_SEGMENTS];
+	int n;
+};
+enum { MULTI_SAD = 0, MULTI_SSD = 1, MULTI_PREDICT = 2, MULTI_RECONST = 3, MULTI_COPY = 4 };
+template <int KIND>
+__global__ __launch_bounds__(HMR_BLOCK) void k_pixel_multi(SegTab t, const int16_t *__restrict__ A, const int16_t *__restrict__ B, int16_t *__restrict__ Cc)
+{
+	int s = 0;
+#pragma unroll
+	for (int i = 1; i < HMR_GPU_MAX_SEGMENTS; i++)
+		if (i < t.n && (int)blockIdx.x >= t.first[i]) s = i;
+	const unsigned vb = blockIdx.x - (unsigned)t.first[s], vg = (unsigned)t.blocks[s];
+	if (vb >= vg) return;
+	const hmr_gpu_job *jobs = t.jobs[s];
+	const int njobs = t.njobs[s];
+	if constexpr (KIND == MULTI_SAD || KIND == MULTI_SSD) {
+		constexpr int OP = KIND == MULTI_SAD ? OP_SAD : OP_SSD;
+		uint32_t *out = t.out[s];
+		switch (t.size[s]) {
+		case 4: sad_ssd_body<4, OP>(jobs, njobs, A, B, out, vb, vg); break;
+		case 8: sad_ssd_body<8, OP>(jobs, njobs, A, B, out, vb, vg); break;
+		case 16: sad_ssd_body<16, OP>(jobs, njobs, A, B, out, vb, vg); break;
+		case 32: sad_ssd_body<32, OP>(jobs, njobs, A, B, out, vb, vg); break;
+		default: sad_ssd_body<64, OP>(jobs, njobs, A, B, out, vb, vg); break;
+		}
+	} else {
+		constexpr int OP = KIND == MULTI_PREDICT ? EW_PREDICT : KIND == MULTI_RECONST ? EW_RECONST : 3;
+		switch (t.size[s]) {
+		case 4: square_body<4, OP>(jobs, njobs, A, B, Cc, vb, vg); break;
+		case 8: square_body<8, OP>(jobs, njobs, A, B, Cc, vb, vg); break;
+		case 16: square_body<16, OP>(jobs, njobs, A, B, Cc, vb, vg); break;
+		case 32: square_body<32, OP>(jobs, njobs, A, B, Cc, vb, vg); break;
+		default: square_body<64, OP>(jobs, njobs, A, B, Cc, vb, vg); break;
 		}
 	}
 }
@@ -289,6 +346,39 @@ extern "C" int hmr_gpu_modified_variance_batch(hmr_gpu_ctx *ctx, const hmr_gpu_j
 	if (njobs <= 0) return HMR_GPU_OK;
 	if (size < 2 || size > 64) return HMR_GPU_ERR_ARG;
 	hipLaunchKernelGGL(k_modified_variance, dim3(hmr_grid_for_waves(njobs)), dim3(HMR_BLOCK), 0, ctx->stream, jobs, njobs, size, a, out);
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
+
+extern "C" int hmr_gpu_pixel_multi(hmr_gpu_ctx *ctx, int op, const hmr_gpu_segment *segs, int nseg, const int16_t *a, const int16_t *b, int16_t *c)
+{
+	if (nseg <= 0) return HMR_GPU_OK;
+	if (nseg > HMR_GPU_MAX_SEGMENTS) { hmr_set_error("pixel_multi: at most %d segments", HMR_GPU_MAX_SEGMENTS); return HMR_GPU_ERR_ARG; }
+	SegTab t = {};
+	int next = 0;
+	for (int i = 0; i < nseg; i++) {
+		const int n = segs[i].size;
+		const bool sized = n == 4 || n == 8 || n == 16 || n == 32 || n == 64;
+		if (segs[i].njobs <= 0) continue;
+		if (!sized && op != HMR_GPU_OP_SAD && op != HMR_GPU_OP_SSD16B) { hmr_set_error("pixel_multi: block size must be 4, 8, 16, 32 or 64"); return HMR_GPU_ERR_ARG; }
+		const int nn = sized ? n : 64;          // any other size takes the 64x64 path in the reference's SAD / SSD (hmr_sse42_functions_pixel.c:462-475)
+		const int jpw = HMR_WAVE / (nn <= 8 ? 4 : nn == 16 ? 16 : HMR_WAVE);      // PixelLanes<nn>
+		const int blocks = hmr_grid_for_waves(((long)segs[i].njobs + jpw - 1) / jpw);
+		t.jobs[t.n] = segs[i].jobs; t.out[t.n] = (uint32_t *)segs[i].out; t.njobs[t.n] = segs[i].njobs; t.size[t.n] = nn;
+		t.first[t.n] = next; t.blocks[t.n] = blocks;
+		next = (next + blocks + HMR_XCDS - 1) / HMR_XCDS * HMR_XCDS;
+		t.n++;
+	}
+	if (!t.n) return HMR_GPU_OK;
+	const dim3 grid(t.first[t.n - 1] + t.blocks[t.n - 1]), block(HMR_BLOCK);
+	switch (op) {
+	case HMR_GPU_OP_SAD: hipLaunchKernelGGL((k_pixel_multi<MULTI_SAD>), grid, block, 0, ctx->stream, t, a, b, c); break;
+	case HMR_GPU_OP_SSD16B: hipLaunchKernelGGL((k_pixel_multi<MULTI_SSD>), grid, block, 0, ctx->stream, t, a, b, c); break;
+	case HMR_GPU_OP_PREDICT: hipLaunchKernelGGL((k_pixel_multi<MULTI_PREDICT>), grid, block, 0, ctx->stream, t, a, b, c); break;
+	case HMR_GPU_OP_RECONST: hipLaunchKernelGGL((k_pixel_multi<MULTI_RECONST>), grid, block, 0, ctx->stream, t, a, b, c); break;
+	case HMR_GPU_OP_COPY: hipLaunchKernelGGL((k_pixel_multi<MULTI_COPY>), grid, block, 0, ctx->stream, t, a, a, c); break;
+	default: hmr_set_error("pixel_multi: op must be SAD, SSD16B, PREDICT, RECONST or COPY"); return HMR_GPU_ERR_ARG;
+	}
 	HIP_TRY(hipGetLastError());
 	return HMR_GPU_OK;
 }

@@ -289,6 +289,7 @@ enum hmr_gpu_op {
 	HMR_GPU_OP_TU_CHAIN,  /* jobs = hmr_gpu_tu_job*, a = orig base, b = pred base, c = level base, out = ssd; the reconstruction base and ac_sum follow in p64[0..1] */
 	HMR_GPU_OP_INTRA_SEARCH,  /* jobs = hmr_gpu_intra_job*, a = orig base, b = decoded base, c = output base, out = hmr_gpu_intra_result* */
 	HMR_GPU_OP_INTER_TU_CHAIN = 25, /* jobs = hmr_gpu_inter_tu_job*, a = residual base, b = pred base, c = level base, out = ssd; p64 = {recon base, ac_sum} */
+	HMR_GPU_OP_PIXEL_MULTI = 27,    /* jobs = hmr_gpu_segment* (host), njobs = segments, size = HMR_GPU_OP_SAD / SSD16B / PREDICT / RECONST / COPY */
 	HMR_GPU_OP_TREE_DECIDE = 26,    /* jobs = hmr_gpu_tree_job*, a = ssd, b = ac_sum, c = recon base, out = hmr_gpu_tree_result*; p64[0] = level base */
 	HMR_GPU_OP_INTRA_TU_CHAIN = 24 /* jobs = hmr_gpu_itu_job*, a = orig base, b = decoded base, c = level base, out = ssd; p64 = {recon base, ac_sum, hmr_gpu_intra_result* or NULL};
 	                           * the prediction plane shares the recon base; p[0] = rounds (0 / 1 = one set of jobs) */
@@ -310,6 +311,18 @@ typedef struct hmr_gpu_cmd {
 #define HMR_GPU_MAX_BRANCHES 64
 /* A context and its command lists belong to one host thread at a time (capture temporarily redirects the context's stream to the branch
  * streams); use one context per thread / per encoder engine. */
+/* Several batches of ONE pixel kernel that differ only in the block size, in one launch: a frame's SAD (or SSD, residual, reconstruction, square int16
+ * copy) batches are short launches that cannot fill the GPU one at a time.  op = HMR_GPU_OP_SAD / SSD16B / PREDICT / RECONST / COPY; every segment is what
+ * the corresponding hmr_gpu_*_batch call takes (jobs = device array, size = block size, out = that batch's result array for SAD / SSD, ignored otherwise);
+ * a, b, c as in the single-batch entries (COPY: a -> c).  Command lists: op HMR_GPU_OP_PIXEL_MULTI, size = the pixel op, jobs = host array of segments
+ * (must outlive the list), njobs = number of segments. */
+#define HMR_GPU_MAX_SEGMENTS 8
+typedef struct hmr_gpu_segment {
+	const hmr_gpu_job *jobs;
+	void *out;
+	int njobs, size;
+} hmr_gpu_segment;
+int hmr_gpu_pixel_multi(hmr_gpu_ctx *ctx, int op, const hmr_gpu_segment *segs, int nseg, const int16_t *a, const int16_t *b, int16_t *c);
 typedef struct hmr_gpu_cmdlist hmr_gpu_cmdlist;
 int hmr_gpu_cmdlist_create(hmr_gpu_ctx *ctx, const hmr_gpu_cmd *cmds, int n, hmr_gpu_cmdlist **out);
 /* eager replay; event_pairs (optional, 2*n events from hmr_gpu_event_create) brackets every command for per-kernel timing */

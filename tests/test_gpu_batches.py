@@ -669,3 +669,47 @@ def test_intra_luma_cu_tree(rig, oracle, n, rounds):
     same(got, o, "luma CU tree: planes, prediction, levels, neighbour arrays")
     if n <= 32:
         assert 0.1 < splits / nj < 0.9, splits
+
+
+class Segment(C.Structure):
+    _fields_ = [("jobs", VP), ("out", VP), ("njobs", C.c_int), ("size", C.c_int)]
+
+
+@pytest.mark.parametrize("op", ["sad", "ssd16b", "predict", "reconst", "copy"])
+def test_pixel_multi(rig, oracle, op):
+    """hmr_gpu_pixel_multi: the five block sizes of one pixel kernel as segments of ONE launch (segment block ranges, XCD partition inside a segment,
+    ragged and tiny segments) against the oracle, whole arena compared."""
+    rng = np.random.default_rng(91 + 1000 * SEED)
+    opcode = {"sad": 1, "ssd16b": 2, "predict": 3, "reconst": 4, "copy": 5}[op]
+    sizes, counts = [4, 8, 16, 32, 64], [rig.nj, 3, 200, 77, 41]
+    segs, jobs, outs = (Segment * 5)(), [], []
+    slot0 = 0
+    for i, (n, cnt) in enumerate(zip(sizes, counts)):
+        jb = np.zeros(cnt, JOB)
+        x = rng.integers(0, PW - n + 1, cnt); y = rng.integers(0, PH - n + 1, cnt)
+        jb["a_off"] = rig.pix + y * PW + x; jb["a_stride"] = PW
+        x = rng.integers(0, PW - n + 1, cnt); y = rng.integers(0, PH - n + 1, cnt)
+        jb["b_off"] = (rig.res if op in ("ssd16b", "reconst") else rig.pix) + y * PW + x; jb["b_stride"] = PW
+        jb["c_off"] = rig.out1 + (slot0 + np.arange(cnt)) * SLOT; jb["c_stride"] = 80
+        jb["w"] = jb["h"] = n
+        slot0 += cnt
+        d_out = rig.malloc(4 * cnt); rig.bufs.append(d_out)
+        segs[i] = Segment(rig.up(jb), d_out, cnt, n)
+        jobs.append(jb); outs.append(d_out)
+    assert slot0 <= 2 * rig.nj
+    g = rig.launch("hmr_gpu_pixel_multi", opcode, segs, 5, rig.dev, rig.dev, rig.dev)
+    o = rig.host.copy()
+    for n, jb, d_out in zip(sizes, jobs, outs):
+        if op in ("sad", "ssd16b"):
+            f = getattr(oracle, "ora_" + op); f.restype = C.c_uint32
+            exp = np.array([f(at(o, j["a_off"]), PW, at(o, j["b_off"]), PW, n) for j in jb], np.uint32)
+            same(rig.down(d_out, len(jb), np.uint32), exp, f"{op} {n}")
+        else:
+            for j in jb:
+                if op == "copy":
+                    for r in range(n):
+                        dst = int(j["c_off"]) + r * 80; src = int(j["a_off"]) + r * PW
+                        o[dst:dst + n] = o[src:src + n]
+                else:
+                    getattr(oracle, "ora_" + op)(at(o, j["a_off"]), PW, at(o, j["b_off"]), PW, at(o, j["c_off"]), 80, n)
+    same(g, o, f"{op} multi: arena")
