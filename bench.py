@@ -707,6 +707,11 @@ def main():
                          "graph: the same command list captured once into a hipGraph and replayed (no per-launch host cost), per-kernel numbers from an eager pass after the timed region")
     ap.add_argument("--unfused", action="store_true",
                     help="replay predict/transform/quant/inv_quant/itransform/reconst/ssd16b as seven separate batches per TU size instead of the fused TU-chain kernel")
+    ap.add_argument("--schedule", choices=["time", "bytes"], default="bytes",
+                    help="how the independent launches are dealt to the graph branches: by their measured isolated duration (one eager pass while the frame is set up) or by algorithmic bytes")
+    ap.add_argument("--tu-multi", choices=["all", "upto16", "small", "off"], default="off",
+                    help="fused TU chain batches (given prediction / intra / inter, all TU sizes) as segments of one launch: every size, sizes 4-16 (a launch with a "
+                         "32x32 segment reserves that body's 52 KB of LDS for all), or one launch per batch")
     ap.add_argument("--no-multi", action="store_true", help="one launch per (pixel kernel, block size) instead of one multi-segment launch per pixel kernel")
     ap.add_argument("--cu-driver", action="store_true",
                     help="issue the luma intra CU drivers (encode_intra_luma: search + transform tree + consolidation) as ordered device-side chains - search -> parent TUs -> "
@@ -739,6 +744,9 @@ def main():
 
     class Segment(C.Structure):      # hmr_gpu_segment
         _fields_ = [("jobs", P), ("out", P), ("njobs", C.c_int), ("size", C.c_int)]
+
+    class TuSegment(C.Structure):    # hmr_gpu_tu_segment
+        _fields_ = [("jobs", P), ("ssd", P), ("ac_sum", P), ("modes", P), ("njobs", C.c_int), ("size", C.c_int), ("kind", C.c_int), ("rounds", C.c_int)]
 
     class Cmd(C.Structure):
         _fields_ = [("op", C.c_int), ("njobs", C.c_int), ("size", C.c_int), ("p", C.c_int * 4), ("jobs", P), ("a", P), ("b", P), ("c", P), ("out", P), ("p64", P * 3), ("branch", C.c_int)]
@@ -775,6 +783,22 @@ def main():
                 for g in groups:
                     if g["fn"] in PIXEL_OPS and g["size"] in (4, 8, 16, 32, 64) and not g.get("chain"):
                         fam.setdefault(g["fn"], []).append(g)
+                # ... and the fused TU chains (given prediction / intra / inter, every TU size) as segments of one launch (hmr_gpu_tu_chain_multi)
+                TU_KIND = {"hmr_gpu_tu_chain_batch": 0, "hmr_gpu_intra_tu_chain_batch": 1, "hmr_gpu_inter_tu_chain_batch": 2}
+                tus = [g for g in groups if g["fn"] in TU_KIND and not g.get("chain") and (g["size"] < 32 or args.tu_multi == "all") and
+                       (args.tu_multi != "small" or g["size"] == 4 or g["fn"] == "hmr_gpu_tu_chain_batch")]
+                if args.tu_multi != "off" and 2 <= len(tus) <= 8:
+                    tus.sort(key=lambda g: -g["bytes"])          # blocks are dispatched in segment order: the long batches first, the short ones fill the tail
+                    for g in tus:
+                        g["d_ac"] = torch.zeros(len(g["jobs"]), dtype=torch.int32, device=dev)
+                    tsegs = (TuSegment * len(tus))(*[TuSegment(m["d_jobs"].data_ptr(), m["d_out"].data_ptr(), m["d_ac"].data_ptr(), None, len(m["jobs"]), m["size"],
+                                                                 TU_KIND[m["fn"]], 0) for m in tus])
+                    merged_g = {"name": "tu_chains", "fn": "hmr_gpu_tu_chain_multi", "size": "multi", "segs": tsegs, "members": tus,
+                                "jobs": np.zeros(sum(len(m["jobs"]) for m in tus), np.uint8), "bytes": sum(m["bytes"] for m in tus), "extra": (), "d_jobs": None,
+                                "d_out": tus[0]["d_out"]}
+                    groups[groups.index(tus[0])] = merged_g
+                    for m in tus[1:]:
+                        groups.remove(m)
                 for fn, members in fam.items():
                     if len(members) < 2:
                         continue
@@ -827,6 +851,12 @@ def main():
                 chains[g["chain"]] = {"m": m, "modes": torch.zeros(4 * m, dtype=torch.int32, device=dev), "ssd": torch.zeros(5 * m, dtype=torch.int32, device=dev),
                                       "ac": torch.zeros(5 * m, dtype=torch.int32, device=dev), "res": torch.zeros(4 * m, dtype=torch.int32, device=dev)}
         for g in groups:
+            if g["fn"] == "hmr_gpu_tu_chain_multi":
+                cm = Cmd(op=28, njobs=len(g["segs"]), jobs=C.addressof(g["segs"]), a=base, b=base, c=base)
+                cm.p64 = (P * 3)(base, None, None)
+                cmds.append(cm)
+                names.append(f"{g['name']}:multi")
+                continue
             if g["fn"] == "hmr_gpu_pixel_multi":
                 cmds.append(Cmd(op=27, njobs=len(g["segs"]), size=g["pixel_op"], jobs=C.addressof(g["segs"]), a=base, b=base, c=base))
                 names.append(f"{g['name']}:multi")
@@ -888,6 +918,31 @@ def main():
         cmds.append(Cmd(op=OP_APPLY, a=C.addressof(f_rec), b=C.addressof(f_dst), c=d_info["sao_params"].data_ptr()))
         cmds.append(Cmd(op=OP_PAD, p=(C.c_int * 4)(PAD, PAD, 0, 0), a=C.addressof(f_dst)))
         names += ["edge_flags", "deblock", "sao_stats", "sao_apply", "pad"]
+        if args.schedule == "time" and args.mode == "graph" and args.branches > 1:
+            # measured schedule: one eager pass with an event pair per command gives each launch's isolated duration; the launches are then dealt to the
+            # branches longest first by TIME (the runtime runs about four kernels at once, so what shares a queue matters more than bytes).
+            # Part of setting the frame up - it happens once, before the warm-up.
+            tmp_arr = (Cmd * len(cmds))(*cmds)
+            for c_ in tmp_arr:
+                c_.branch = 0
+            tmp = P()
+            ctx.call("hmr_gpu_cmdlist_create", tmp_arr, len(cmds), C.byref(tmp))
+            n_c = len(cmds)
+            with torch.cuda.stream(stream):
+                evs = [(P * (2 * n_c))(*[ctx.event().value for _ in range(2 * n_c)]) for _ in range(4)]
+                for r_ in range(4):
+                    ctx.call("hmr_gpu_cmdlist_run", tmp, evs[r_])
+                torch.cuda.synchronize()
+            t_ms = [sorted(ctx.elapsed(P(evs[r_][2 * k]), P(evs[r_][2 * k + 1])) for r_ in range(1, 4))[1] for k in range(n_c)]
+            ctx.lib.hmr_gpu_cmdlist_destroy.restype = None
+            ctx.lib.hmr_gpu_cmdlist_destroy(tmp)
+            tload = [0.0] * args.branches
+            tload[0] = sum(t_ms[len(groups):])               # the frame-level chain stays on branch 0
+            for unit in sorted(sched.values(), key=lambda u: -sum(t_ms[i] for i in u)):
+                b = tload.index(min(tload))
+                tload[b] += sum(t_ms[i] for i in unit)
+                for i in unit:
+                    cmds[i].branch = b
         cmd_arr = (Cmd * len(cmds))(*cmds)
         clist = P()
         ctx.call("hmr_gpu_cmdlist_create", cmd_arr, len(cmds), C.byref(clist))

@@ -58,11 +58,29 @@ __device__ __forceinline__ void load_row_lds(int (&row)[N / 2], const int16_t *s
 // ssd = SSD(residual, reconstructed residual), both scaled by the job's chroma weight and truncated to uint32, levels dropped when
 // ssd_zero <= ssd + zero_thr * sum (doubles).  The returned SSD is the residual-domain one, as in the reference.
 enum { TU_GIVEN_PRED = 0, TU_INTRA = 1, TU_INTER = 2 };
+// LDS image of one workgroup: carved from one raw buffer so that several (N, MODE) bodies can share a launch (k_tu_chain_multi)
+template <int N>
+struct alignas(16) TuLds {
+	static constexpr int TW = HMR_WAVE / N, P = N + 2, E = N * N;
+	int16_t sA[HMR_WAVES_PER_BLOCK][TW][N * P];    // coefficients (linear) -> de-quantised coefficients (transposed, pitched)
+	int16_t sT[HMR_WAVES_PER_BLOCK][TW][N * P];    // stage intermediates (pitched) / deltaU (linear) during quantisation
+	int16_t sLev[HMR_WAVES_PER_BLOCK][TW][E];
+	unsigned long long sNz[HMR_WAVES_PER_BLOCK][TW];
+	int sAc[HMR_WAVES_PER_BLOCK][TW];
+};
+template <int N>
+struct alignas(16) TuLdsIntra {
+	static constexpr int TW = HMR_WAVE / N;
+	int16_t sAdi[HMR_WAVES_PER_BLOCK][TW][2][4 * N + 4];
+	int16_t sMain[HMR_WAVES_PER_BLOCK][TW][3 * N + 2];
+};
+template <int N, int MODE> constexpr int tu_lds_bytes() { return (int)sizeof(TuLds<N>) + (MODE == TU_INTRA ? (int)sizeof(TuLdsIntra<N>) : 0); }
+
 template <int N, int MODE>
-__global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const void *__restrict__ jobs_v, int njobs, const int16_t *__restrict__ O,
-							   int16_t *__restrict__ Pp, int16_t *__restrict__ L, int16_t *__restrict__ Rr,
-							   uint32_t *__restrict__ ssd_out, int32_t *__restrict__ ac_out, const DevTables *__restrict__ tab,
-							   const int16_t *D, const hmr_gpu_intra_result *__restrict__ modes, int rounds)   // D may alias Rr (in-place reconstruction)
+__device__ __forceinline__ void tu_chain_body(const void *__restrict__ jobs_v, int njobs, const int16_t *__restrict__ O, int16_t *__restrict__ Pp,
+					      int16_t *__restrict__ L, int16_t *__restrict__ Rr, uint32_t *__restrict__ ssd_out, int32_t *__restrict__ ac_out,
+					      const DevTables *__restrict__ tab, const int16_t *D, const hmr_gpu_intra_result *__restrict__ modes, int rounds,
+					      char *lds, unsigned block, unsigned grid)   // D may alias Rr (in-place reconstruction)
 {
 	constexpr bool INTRA = MODE == TU_INTRA, INTER = MODE == TU_INTER;
 	using JobT = typename std::conditional<INTRA, hmr_gpu_itu_job, typename std::conditional<INTER, hmr_gpu_inter_tu_job, hmr_gpu_tu_job>::type>::type;
@@ -74,13 +92,10 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 	constexpr int TQ = HMR_WAVE / GQ, QPASSES = TW / TQ;   // TUs per quant pass, passes per wave
 	constexpr int JPB = TW * HMR_WAVES_PER_BLOCK;
 	constexpr int sh1 = L2 - 1, sh2 = L2 + 6, SIDE = N / 4;
-	__shared__ __attribute__((aligned(16))) int16_t sA[HMR_WAVES_PER_BLOCK][TW][N * P];    // coefficients (linear) -> de-quantised coefficients (transposed, pitched)
-	__shared__ __attribute__((aligned(16))) int16_t sT[HMR_WAVES_PER_BLOCK][TW][N * P];    // stage intermediates (pitched) / deltaU (linear) during quantisation
-	__shared__ __attribute__((aligned(16))) int16_t sLev[HMR_WAVES_PER_BLOCK][TW][E];
-	__shared__ unsigned long long sNz[HMR_WAVES_PER_BLOCK][TW];
-	__shared__ int sAc[HMR_WAVES_PER_BLOCK][TW];
+	TuLds<N> &S = *reinterpret_cast<TuLds<N> *>(lds);
+	[[maybe_unused]] TuLdsIntra<N> &SI = *reinterpret_cast<TuLdsIntra<N> *>(lds + sizeof(TuLds<N>));
 	const int lane = lane_id(), w = wave_in_block(), tu = lane / N, row = lane % N;
-	const JobRange jr = xcd_job_range(njobs, JPB);
+	const JobRange jr = xcd_job_range(njobs, JPB, block, grid);
 	for (long base = jr.begin; base < jr.end; base += jr.stride)
 	// rounds > 1: the job array holds `rounds` sets of njobs jobs; job j of set r + 1 may read what job j of set r reconstructed (the four
 	// children of a CU, hmr_motion_intra.c:1441-1477) - the same lanes run them back to back, with the stores of one round made visible
@@ -122,9 +137,7 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 		}
 		if constexpr (INTRA) {
 			// N lanes per TU build the 4N+1 neighbours, smooth them when asked, and predict one row each
-			__shared__ int16_t sAdi[HMR_WAVES_PER_BLOCK][TW][2][4 * N + 4];
-			__shared__ int16_t sMain[HMR_WAVES_PER_BLOCK][TW][3 * N + 2];
-			int16_t *adi = sAdi[w][tu][0], *adif = sAdi[w][tu][1], *mainr = sMain[w][tu] + N;
+			int16_t *adi = SI.sAdi[w][tu][0], *adif = SI.sAdi[w][tu][1], *mainr = SI.sMain[w][tu] + N;
 			const unsigned fl = ok ? jb.flags : 0u;
 			if (ok)
 				intra_build_refs<N, N>(adi, D + jb.dec_off, (int)jb.dec_stride, fl & 1, fl & 2, (fl & 4) ? (int)(jb.sizes & 0xffff) : 0,
@@ -171,8 +184,8 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 		// basis words: DST only exists for N = 4, where a lane group may need a different basis than its neighbours -> per-lane pointer
 		const int *Mf = reinterpret_cast<const int *>(is_dst ? tab->dst4 : tab->dct[L2 - 2]);
 		const int *Mt = reinterpret_cast<const int *>(is_dst ? tab->dst4_t : tab->dct_t[L2 - 2]);
-		int16_t *tA = sA[w][tu], *tT = sT[w][tu], *lev = sLev[w][tu];
-		if (lane % N == 0) { sNz[w][tu] = 0; sAc[w][tu] = 0; }
+		int16_t *tA = S.sA[w][tu], *tT = S.sT[w][tu], *lev = S.sLev[w][tu];
+		if (lane % N == 0) { S.sNz[w][tu] = 0; S.sAc[w][tu] = 0; }
 		// K12 stage 1: tmp[k][row] = sum_i M[k][i] * res[row][i]
 		stage_to_lds<N>(r, Mf, sh1, tT + row, P);
 		wave_sync();
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 			const unsigned p0 = __shfl((int)jb.p0, qt * N, HMR_WAVE), p1 = __shfl((int)jb.p1, qt * N, HMR_WAVE);
 			const int scan_mode = p0 & 3, comp = (p0 >> 2) & 3, is_intra = (p0 >> 4) & 1, slice_i = (p0 >> 5) & 1;
 			const int per = p1 & 0xff, rem = (p1 >> 8) & 0xff;
-			int16_t *qc = sA[w][qt], *qd = sT[w][qt], *ql = sLev[w][qt];
+			int16_t *qc = S.sA[w][qt], *qd = S.sT[w][qt], *ql = S.sLev[w][qt];
 			int ac = 0;
 			if (qok) {
 				const int32_t *q = tab->quant[L2 - 2][(is_intra ? 0 : 3) + comp][rem];
@@ -226,8 +239,8 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 					if (any) nz |= 1ull << b2c[((e0 / N) >> 2) * SIDE + ((e0 % N) >> 2)];
 				}
 				ac = (int)group_sum<GQ>(sum);
-				if (nz) atomicOr(&sNz[w][qt], nz);
-				if (l == 0) sAc[w][qt] = ac;
+				if (nz) atomicOr(&S.sNz[w][qt], nz);
+				if (l == 0) S.sAc[w][qt] = ac;
 			}
 		}
 		wave_sync();
@@ -237,22 +250,22 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 			for (int c0 = 0; c0 < TOTAL; c0 += HMR_WAVE) {
 				const int c = c0 + lane, t = c < TOTAL ? c / CGS : 0, cg = c % CGS;
 				const unsigned p0 = __shfl((int)jb.p0, t * N, HMR_WAVE);
-				const unsigned long long m = sNz[w][t];
-				const bool run = c < TOTAL && base + w * TW + t < jr.end && ((p0 >> 6) & 1) && sAc[w][t] >= 2 && ((m >> cg) & 1);
+				const unsigned long long m = S.sNz[w][t];
+				const bool run = c < TOTAL && base + w * TW + t < jr.end && ((p0 >> 6) & 1) && S.sAc[w][t] >= 2 && ((m >> cg) & 1);
 				if (run) {
 					const uint32_t *scan = tab->scan[p0 & 3][L2];
 					const bool is_last = cg == 63 - __clzll((long long)m);
 					switch (p0 & 3) {
-					case 3: sbh_group_block<3, N>(sLev[w][t], sA[w][t], sT[w][t], scan, cg, is_last); break;
-					case 1: sbh_group_block<1, N>(sLev[w][t], sA[w][t], sT[w][t], scan, cg, is_last); break;
-					case 2: sbh_group_block<2, N>(sLev[w][t], sA[w][t], sT[w][t], scan, cg, is_last); break;
-					default: sbh_group_serial(sLev[w][t], sA[w][t], sT[w][t], scan, cg, is_last); break;
+					case 3: sbh_group_block<3, N>(S.sLev[w][t], S.sA[w][t], S.sT[w][t], scan, cg, is_last); break;
+					case 1: sbh_group_block<1, N>(S.sLev[w][t], S.sA[w][t], S.sT[w][t], scan, cg, is_last); break;
+					case 2: sbh_group_block<2, N>(S.sLev[w][t], S.sA[w][t], S.sT[w][t], scan, cg, is_last); break;
+					default: sbh_group_serial(S.sLev[w][t], S.sA[w][t], S.sT[w][t], scan, cg, is_last); break;
 					}
 				}
 			}
 		}
 		wave_sync();
-		const int ac = sAc[w][tu];
+		const int ac = S.sAc[w][tu];
 		const bool coded = ok && ac != 0;                               // the reference skips dequant / inverse transform for all-zero TUs
 		{
 			const int comp = (jb.p0 >> 2) & 3, is_intra = (jb.p0 >> 4) & 1, per = jb.p1 & 0xff, rem = (jb.p1 >> 8) & 0xff;
@@ -360,11 +373,11 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 			if (ok) {
 				if (row == 0) {
 					ssd_r[j] = coded ? w_ssd : w_zero;
-					if (drop) sAc[w][tu] = 0;
+					if (drop) S.sAc[w][tu] = 0;
 				}
 			}
 		}
-		if (lane % N == 0) sNz[w][tu] = drop ? 1ull : 0ull;     // reused as the "levels dropped" flag of the TU for the store below
+		if (lane % N == 0) S.sNz[w][tu] = drop ? 1ull : 0ull;     // reused as the "levels dropped" flag of the TU for the store below
 		wave_sync();
 		// levels out (coalesced)
 		for (int pass = 0; pass < QPASSES; pass++) {
@@ -373,11 +386,11 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 			const unsigned lev_off = __shfl((int)jb.lev_off, qt * N, HMR_WAVE);
 			if (qj < jr.end) {
 				int16_t *lo = L + lev_off;
-				const int16_t *ql = sLev[w][qt];
-				const bool zero = INTER && sNz[w][qt] != 0;
+				const int16_t *ql = S.sLev[w][qt];
+				const bool zero = INTER && S.sNz[w][qt] != 0;
 				const i16x4 z4 = {{0, 0, 0, 0}};
 				for (int e0 = 4 * l; e0 < E; e0 += 4 * GQ) st4(lo + e0, zero ? z4 : ld4(ql + e0));
-				if (l == 0) ac_r[qj] = sAc[w][qt];
+				if (l == 0) ac_r[qj] = S.sAc[w][qt];
 			}
 		}
 		wave_sync();
@@ -385,7 +398,104 @@ __global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const
 	}
 }
 
+template <int N, int MODE>
+__global__ __launch_bounds__(HMR_BLOCK, (N == 32 ? 1 : 4)) void k_tu_chain(const void *__restrict__ jobs_v, int njobs, const int16_t *__restrict__ O,
+							   int16_t *__restrict__ Pp, int16_t *__restrict__ L, int16_t *__restrict__ Rr,
+							   uint32_t *__restrict__ ssd_out, int32_t *__restrict__ ac_out, const DevTables *__restrict__ tab,
+							   const int16_t *D, const hmr_gpu_intra_result *__restrict__ modes, int rounds)
+{
+	__shared__ __attribute__((aligned(16))) char lds[tu_lds_bytes<N, MODE>()];
+	tu_chain_body<N, MODE>(jobs_v, njobs, O, Pp, L, Rr, ssd_out, ac_out, tab, D, modes, rounds, lds, blockIdx.x, gridDim.x);
+}
+
+// Several TU batches - any mix of block size and kind (given prediction / intra / inter) - as segments of ONE launch: block b runs the body of the
+// segment whose block range contains it (ranges start at multiples of 8 blocks, so b % 8 is still the XCD).  The LDS image is the largest body's.
+struct TuSegTab {
+	const void *jobs[HMR_GPU_MAX_SEGMENTS];
+	uint32_t *ssd[HMR_GPU_MAX_SEGMENTS];
+	int32_t *ac[HMR_GPU_MAX_SEGMENTS];
+	const hmr_gpu_intra_result *modes[HMR_GPU_MAX_SEGMENTS];
+	int njobs[HMR_GPU_MAX_SEGMENTS], size[HMR_GPU_MAX_SEGMENTS], kind[HMR_GPU_MAX_SEGMENTS], rounds[HMR_GPU_MAX_SEGMENTS], first[HMR_GPU_MAX_SEGMENTS],
+		blocks[HMR_GPU_MAX_SEGMENTS];
+	int n;
+};
+template <int MAXN>
+__global__ __launch_bounds__(HMR_BLOCK, (MAXN == 32 ? 1 : 4)) void k_tu_chain_multi(TuSegTab t, const int16_t *__restrict__ O, int16_t *__restrict__ Pp,
+									       int16_t *__restrict__ L, int16_t *__restrict__ Rr, const DevTables *__restrict__ tab,
+									       const int16_t *D)
+{
+	constexpr int b4 = tu_lds_bytes<4, TU_INTRA>(), b8 = tu_lds_bytes<8, TU_INTRA>(), b16 = tu_lds_bytes<16, TU_INTRA>(), bmax = tu_lds_bytes<MAXN, TU_INTRA>();
+	constexpr int bytes = (b4 > b8 ? b4 : b8) > (b16 > bmax ? b16 : bmax) ? (b4 > b8 ? b4 : b8) : (b16 > bmax ? b16 : bmax);
+	__shared__ __attribute__((aligned(16))) char lds[bytes];                              // the largest body's image
+	int s = 0;
+#pragma unroll
+	for (int i = 1; i < HMR_GPU_MAX_SEGMENTS; i++)
+		if (i < t.n && (int)blockIdx.x >= t.first[i]) s = i;
+	const unsigned vb = blockIdx.x - (unsigned)t.first[s], vg = (unsigned)t.blocks[s];
+	if (vb >= vg) return;
+	const void *jobs = t.jobs[s];
+	const int njobs = t.njobs[s], rounds = t.rounds[s];
+	uint32_t *ssd = t.ssd[s];
+	int32_t *ac = t.ac[s];
+	const hmr_gpu_intra_result *modes = t.modes[s];
+#define TU_BODY(N, MODE) tu_chain_body<N, MODE>(jobs, njobs, O, Pp, L, Rr, ssd, ac, tab, D, modes, rounds, lds, vb, vg)
+	switch (t.size[s] * 4 + t.kind[s]) {
+	case 4 * 4 + 0: TU_BODY(4, TU_GIVEN_PRED); break;
+	case 4 * 4 + 1: TU_BODY(4, TU_INTRA); break;
+	case 4 * 4 + 2: TU_BODY(4, TU_INTER); break;
+	case 8 * 4 + 0: TU_BODY(8, TU_GIVEN_PRED); break;
+	case 8 * 4 + 1: TU_BODY(8, TU_INTRA); break;
+	case 8 * 4 + 2: TU_BODY(8, TU_INTER); break;
+	case 16 * 4 + 0: TU_BODY(16, TU_GIVEN_PRED); break;
+	case 16 * 4 + 1: TU_BODY(16, TU_INTRA); break;
+	case 16 * 4 + 2: TU_BODY(16, TU_INTER); break;
+	default:
+		if constexpr (MAXN == 32) {
+			switch (t.kind[s]) {
+			case 0: TU_BODY(32, TU_GIVEN_PRED); break;
+			case 1: TU_BODY(32, TU_INTRA); break;
+			default: TU_BODY(32, TU_INTER); break;
+			}
+		}
+		break;
+	}
+#undef TU_BODY
+}
+
 }  // namespace
+
+extern "C" int hmr_gpu_tu_chain_multi(hmr_gpu_ctx *ctx, const hmr_gpu_tu_segment *segs, int nseg, const int16_t *orig_base, const int16_t *decoded_base,
+				      int16_t *pred_base, int16_t *level_base, int16_t *recon_base)
+{
+	if (nseg <= 0) return HMR_GPU_OK;
+	if (nseg > HMR_GPU_MAX_SEGMENTS) { hmr_set_error("tu_chain_multi: at most %d segments", HMR_GPU_MAX_SEGMENTS); return HMR_GPU_ERR_ARG; }
+	TuSegTab t = {};
+	int next = 0, maxn = 0;
+	for (int i = 0; i < nseg; i++) {
+		const int n = segs[i].size;
+		if (segs[i].njobs <= 0) continue;
+		if ((n != 4 && n != 8 && n != 16 && n != 32) || segs[i].kind < 0 || segs[i].kind > 2) {
+			hmr_set_error("tu_chain_multi: TU size must be 4, 8, 16 or 32 and kind 0 (given prediction), 1 (intra) or 2 (inter)");
+			return HMR_GPU_ERR_ARG;
+		}
+		const int jpb = (HMR_WAVE / n) * HMR_WAVES_PER_BLOCK;
+		const int blocks = hmr_grid_for_units(((long)segs[i].njobs + jpb - 1) / jpb);
+		t.jobs[t.n] = segs[i].jobs; t.ssd[t.n] = segs[i].ssd; t.ac[t.n] = segs[i].ac_sum; t.modes[t.n] = segs[i].modes;
+		t.njobs[t.n] = segs[i].njobs; t.size[t.n] = n; t.kind[t.n] = segs[i].kind; t.rounds[t.n] = segs[i].rounds > 1 ? segs[i].rounds : 1;
+		t.first[t.n] = next; t.blocks[t.n] = blocks;
+		next = (next + blocks + HMR_XCDS - 1) / HMR_XCDS * HMR_XCDS;
+		maxn = n > maxn ? n : maxn;
+		t.n++;
+	}
+	if (!t.n) return HMR_GPU_OK;
+	const dim3 grid(t.first[t.n - 1] + t.blocks[t.n - 1]), block(HMR_BLOCK);
+	if (maxn == 32)
+		hipLaunchKernelGGL((k_tu_chain_multi<32>), grid, block, 0, ctx->stream, t, orig_base, pred_base, level_base, recon_base, ctx->tables, decoded_base);
+	else
+		hipLaunchKernelGGL((k_tu_chain_multi<16>), grid, block, 0, ctx->stream, t, orig_base, pred_base, level_base, recon_base, ctx->tables, decoded_base);
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
 
 template <int MODE>
 static int launch_tu_chain(hmr_gpu_ctx *ctx, const void *jobs, int njobs, int size, const int16_t *orig_base, int16_t *pred_base, int16_t *level_base,

@@ -289,6 +289,7 @@ enum hmr_gpu_op {
 	HMR_GPU_OP_TU_CHAIN,  /* jobs = hmr_gpu_tu_job*, a = orig base, b = pred base, c = level base, out = ssd; the reconstruction base and ac_sum follow in p64[0..1] */
 	HMR_GPU_OP_INTRA_SEARCH,  /* jobs = hmr_gpu_intra_job*, a = orig base, b = decoded base, c = output base, out = hmr_gpu_intra_result* */
 	HMR_GPU_OP_INTER_TU_CHAIN = 25, /* jobs = hmr_gpu_inter_tu_job*, a = residual base, b = pred base, c = level base, out = ssd; p64 = {recon base, ac_sum} */
+	HMR_GPU_OP_TU_MULTI = 28,       /* jobs = hmr_gpu_tu_segment* (host), njobs = segments, a = orig base, b = decoded base, c = level base, p64[0] = recon / prediction base */
 	HMR_GPU_OP_PIXEL_MULTI = 27,    /* jobs = hmr_gpu_segment* (host), njobs = segments, size = HMR_GPU_OP_SAD / SSD16B / PREDICT / RECONST / COPY */
 	HMR_GPU_OP_TREE_DECIDE = 26,    /* jobs = hmr_gpu_tree_job*, a = ssd, b = ac_sum, c = recon base, out = hmr_gpu_tree_result*; p64[0] = level base */
 	HMR_GPU_OP_INTRA_TU_CHAIN = 24 /* jobs = hmr_gpu_itu_job*, a = orig base, b = decoded base, c = level base, out = ssd; p64 = {recon base, ac_sum, hmr_gpu_intra_result* or NULL};
@@ -323,6 +324,21 @@ typedef struct hmr_gpu_segment {
 	int njobs, size;
 } hmr_gpu_segment;
 int hmr_gpu_pixel_multi(hmr_gpu_ctx *ctx, int op, const hmr_gpu_segment *segs, int nseg, const int16_t *a, const int16_t *b, int16_t *c);
+/* The same for the fused TU chains of section 7: any mix of TU size (4, 8, 16, 32) and kind - 0 given prediction (hmr_gpu_tu_job), 1 intra (hmr_gpu_itu_job),
+ * 2 inter (hmr_gpu_inter_tu_job) - as segments of one launch; all segments address the same five bases.  rounds / modes as in
+ * hmr_gpu_intra_tu_chain_rounds_batch (0 / NULL when unused).  A launch that contains a 32x32 segment reserves that body's LDS image (52 KB per workgroup)
+ * for every segment.  Command lists: op HMR_GPU_OP_TU_MULTI, jobs = host array of segments, njobs = number of segments, a = orig, b = decoded, c = level base,
+ * p64[0] = recon / prediction base. */
+struct hmr_gpu_intra_result;
+typedef struct hmr_gpu_tu_segment {
+	const void *jobs;
+	uint32_t *ssd;
+	int32_t *ac_sum;
+	const struct hmr_gpu_intra_result *modes;
+	int njobs, size, kind, rounds;
+} hmr_gpu_tu_segment;
+int hmr_gpu_tu_chain_multi(hmr_gpu_ctx *ctx, const hmr_gpu_tu_segment *segs, int nseg, const int16_t *orig_base, const int16_t *decoded_base, int16_t *pred_base,
+			   int16_t *level_base, int16_t *recon_base);
 typedef struct hmr_gpu_cmdlist hmr_gpu_cmdlist;
 int hmr_gpu_cmdlist_create(hmr_gpu_ctx *ctx, const hmr_gpu_cmd *cmds, int n, hmr_gpu_cmdlist **out);
 /* eager replay; event_pairs (optional, 2*n events from hmr_gpu_event_create) brackets every command for per-kernel timing */

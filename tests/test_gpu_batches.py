@@ -713,3 +713,66 @@ def test_pixel_multi(rig, oracle, op):
                 else:
                     getattr(oracle, "ora_" + op)(at(o, j["a_off"]), PW, at(o, j["b_off"]), PW, at(o, j["c_off"]), 80, n)
     same(g, o, f"{op} multi: arena")
+
+
+class TuSegment(C.Structure):
+    _fields_ = [("jobs", VP), ("ssd", VP), ("ac_sum", VP), ("modes", VP), ("njobs", C.c_int), ("size", C.c_int), ("kind", C.c_int), ("rounds", C.c_int)]
+
+
+@pytest.mark.parametrize("with32", [0, 1], ids=["upto16", "with32"])
+def test_tu_chain_multi(rig, oracle, with32):
+    """hmr_gpu_tu_chain_multi: given-prediction, intra and inter TU batches of different sizes as segments of ONE launch must leave exactly what the
+    single-batch entries leave (those are checked against the oracle above): same arena, same SSD / sum arrays."""
+    rng = np.random.default_rng(5 + 1000 * SEED + with32)
+    yy, xx = np.mgrid[0:PH, 0:PW]
+    amp = np.repeat(np.repeat(rng.choice([0, 3, 20, 70], (PH // 64, PW // 64)), 64, 0), 64, 1)
+    tex = 128 + amp * np.sin((xx * 0.7 + yy * 0.4) / 6.0)
+    rig.host[rig.pix:rig.res] = np.clip(tex + rng.integers(-2, 3, (PH, PW)), 0, 255).ravel()
+    rig.host[rig.res:rig.mid] = (amp * np.sin(xx / 5.0 + yy / 7.0) / 3 + rng.integers(-2, 3, (PH, PW))).astype(np.int16).ravel()
+    plan = [(4, 0, 300), (8, 1, 157), (16, 2, 90), (8, 2, 33), (4, 1, 5), (16, 0, 64)] + ([(32, 2, 40), (32, 1, 17)] if with32 else [])
+    segs, singles, slot = [], [], 0
+    for n, kind, cnt in plan:
+        dt = {0: TU_JOB, 1: ITU_JOB, 2: INTER_TU_JOB}[kind]
+        jb = np.zeros(cnt, dt)
+        x = rng.integers(1, PW - 2 * n - 1, cnt); y = rng.integers(1, PH - 2 * n - 1, cnt)
+        jb["orig_off"] = (rig.res if kind == 2 else rig.pix) + y * PW + x; jb["orig_stride"] = PW
+        sl = rig.out1 + (slot + np.arange(cnt)) * SLOT
+        slot += cnt
+        jb["rec_off"] = sl; jb["rec_stride"] = 80; jb["lev_off"] = sl + 40 * 80
+        if kind == 1:
+            jb["pred_off"] = sl + 40; jb["pred_stride"] = 80
+            jb["dec_off"] = rig.pix + (y - 1) * PW + x - 1; jb["dec_stride"] = PW
+            mode = rng.integers(0, 35, cnt)
+            jb["flags"] = 15 | 32 | (rng.integers(0, 2, cnt) << 6) | (1 << 7); jb["sizes"] = n | (n << 16); jb["mode"] = mode
+            jb["p0"] = rng.integers(1, 4, cnt) | (1 << 4) | (rng.integers(0, 2, cnt) << 5) | (1 << 6) | (int(n == 4) << 7)
+        else:
+            x2 = rng.integers(0, PW - n, cnt); y2 = rng.integers(0, PH - n, cnt)
+            jb["pred_off"] = rig.pix + y2 * PW + x2; jb["pred_stride"] = PW
+            jb["p0"] = 3 | ((1 << 4) if kind == 0 else 0) | (1 << 6)
+            if kind == 2:
+                jb["weight"] = 1.0; jb["zero_thr"] = np.clip(rng.uniform(0, 3000, cnt) / 2.5 - 5.0, 1.0, 20000.0)
+        jb["p1"] = rng.integers(2, 7, cnt) | (rng.integers(0, 6, cnt) << 8)
+        d_jobs = rig.up(jb)
+        bufs = [rig.malloc(4 * cnt) for _ in range(4)]; rig.bufs += bufs
+        segs.append(TuSegment(d_jobs, bufs[0], bufs[1], None, cnt, n, kind, 0))
+        singles.append((kind, n, d_jobs, cnt, bufs[2], bufs[3]))
+    assert slot <= 2 * rig.nj
+    arr = (TuSegment * len(segs))(*segs)
+    g_multi = rig.launch("hmr_gpu_tu_chain_multi", arr, len(segs), rig.dev, rig.dev, rig.dev, rig.dev, rig.dev)
+    # the same batches one launch each
+    assert rig.gpu.hmr_gpu_upload(rig.ctx, rig.dev, VP(rig.host.ctypes.data), C.c_size_t(rig.size * 2)) == 0
+    for kind, n, d_jobs, cnt, d_ssd, d_ac in singles:
+        if kind == 0:
+            rc = rig.gpu.hmr_gpu_tu_chain_batch(rig.ctx, d_jobs, cnt, n, rig.dev, rig.dev, rig.dev, rig.dev, d_ssd, d_ac)
+        elif kind == 1:
+            rc = rig.gpu.hmr_gpu_intra_tu_chain_batch(rig.ctx, d_jobs, cnt, n, rig.dev, rig.dev, rig.dev, rig.dev, rig.dev, d_ssd, d_ac)
+        else:
+            rc = rig.gpu.hmr_gpu_inter_tu_chain_batch(rig.ctx, d_jobs, cnt, n, rig.dev, rig.dev, rig.dev, rig.dev, d_ssd, d_ac)
+        assert rc == 0, rig.gpu.hmr_gpu_last_error()
+    assert rig.gpu.hmr_gpu_sync(rig.ctx) == 0
+    g_single = rig.down(rig.dev, rig.size, np.int16)
+    same(g_multi, g_single, "arena after the multi launch vs after the single launches")
+    assert not np.array_equal(g_single, rig.host)
+    for seg, (kind, n, d_jobs, cnt, d_ssd, d_ac) in zip(segs, singles):
+        same(rig.down(VP(seg.ssd), cnt, np.uint32), rig.down(d_ssd, cnt, np.uint32), f"ssd {n}/{kind}")
+        same(rig.down(VP(seg.ac_sum), cnt, np.int32), rig.down(d_ac, cnt, np.int32), f"ac_sum {n}/{kind}")
