@@ -1007,6 +1007,20 @@ def main():
         copy_gbs = 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src_probe, dst_probe
 
+    # VALU issue rate of this GPU, measured: 16 wavefronts per SIMD issuing nothing but independent packed dot products (hmr_gpu_valu_probe)
+    with torch.cuda.stream(stream):
+        probe_out = torch.zeros(4, dtype=torch.int32, device=dev)
+        blocks, iters = 4096, 4096
+        rates = {}
+        for kind, nm in ((0, "v_dot2_i32_i16"), (1, "v_sad_u16")):
+            ctx.call("hmr_gpu_valu_probe", kind, blocks, 64, probe_out.data_ptr())
+            pe = [ctx.event() for _ in range(2)]
+            ctx.record(pe[0]); ctx.call("hmr_gpu_valu_probe", kind, blocks, iters, probe_out.data_ptr()); ctx.record(pe[1])
+            torch.cuda.synchronize()
+            rates[nm] = blocks * 4 * iters * 8 / (ctx.elapsed(pe[0], pe[1]) * 1e-3) / 1e9       # G wavefront-instructions / s
+    valu_probe = {"Ginst_per_s": {k: round(v, 1) for k, v in rates.items()}, "nominal_Ginst_per_s": 1024 * 2.4 / 4,
+                  "note": "wave64 VALU instructions per second over the whole GPU; nominal = 1024 SIMDs x 2.4 GHz / 4 cycles"}
+
     # what an event pair around a launch measures beyond the kernel: empty launches timed the same way
     with torch.cuda.stream(stream):
         evn = [ctx.event() for _ in range(42)]
@@ -1067,7 +1081,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_frac": round(traffic / (per[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if (traffic and per[dom] > 0) else None,
-                         "measured_copy_GBps": round(copy_gbs, 1), "valu_issue": valu,
+                         "measured_copy_GBps": round(copy_gbs, 1), "valu_issue": valu, "valu_probe": valu_probe,
                          "timing": ("HIP event pairs around every launch inside the timed region" if args.mode == "eager" else
                                     "HIP event pairs around every launch, eager replay of the same K steps right after the timed graph replays "
                                     "(event nodes inside a hipGraph cannot be read back on ROCm 7.2)"),

@@ -387,6 +387,36 @@ extern "C" int hmr_gpu_pixel_multi(hmr_gpu_ctx *ctx, int op, const hmr_gpu_segme
 namespace {
 __global__ void k_nop() {}
 }  // namespace
+// VALU issue probe: every lane runs `iters` rounds of eight independent packed dot products (no memory traffic, no dependent chain shorter than eight
+// instructions), so the launch issues blocks * 4 waves * iters * 8 wave-level VALU instructions: what the integer kernels' issue rate is priced against.
+namespace {
+typedef short probe_short2 __attribute__((ext_vector_type(2)));
+template <int KIND>
+__global__ __launch_bounds__(HMR_BLOCK) void k_valu_probe(int iters, uint32_t *__restrict__ out)
+{
+	int acc[8];
+	probe_short2 a = __builtin_bit_cast(probe_short2, (int)(threadIdx.x * 2654435761u)), b = __builtin_bit_cast(probe_short2, (int)(blockIdx.x * 40503u + 77u));
+#pragma unroll
+	for (int k = 0; k < 8; k++) acc[k] = k;
+	for (int i = 0; i < iters; i++) {
+#pragma unroll
+		for (int k = 0; k < 8; k++)
+			acc[k] = KIND == 0 ? __builtin_amdgcn_sdot2(a, b, acc[k], false)
+					   : (int)__builtin_amdgcn_sad_u16(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), (unsigned)acc[k]);
+	}
+	int r = 0;
+#pragma unroll
+	for (int k = 0; k < 8; k++) r ^= acc[k];
+	if (r == 0x7fffffff) out[0] = (uint32_t)r;      // never true in practice: keeps the loop alive
+}
+}  // namespace
+extern "C" int hmr_gpu_valu_probe(hmr_gpu_ctx *ctx, int kind, int blocks, int iters, uint32_t *out)
+{
+	if (kind == 0) hipLaunchKernelGGL(k_valu_probe<0>, dim3(blocks), dim3(HMR_BLOCK), 0, ctx->stream, iters, out);
+	else hipLaunchKernelGGL(k_valu_probe<1>, dim3(blocks), dim3(HMR_BLOCK), 0, ctx->stream, iters, out);
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
 extern "C" int hmr_gpu_nop(hmr_gpu_ctx *ctx)
 {
 	hipLaunchKernelGGL(k_nop, dim3(1), dim3(HMR_WAVE), 0, ctx->stream);

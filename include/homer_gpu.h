@@ -58,6 +58,9 @@ int hmr_gpu_memset(hmr_gpu_ctx *ctx, void *dev_dst, int value, size_t bytes);
 
 /* An empty launch on the context's stream (timing calibration: what an event pair around a launch costs besides the kernel). */
 int hmr_gpu_nop(hmr_gpu_ctx *ctx);
+/* VALU issue probe: blocks * 4 wavefronts, each issuing iters * 8 independent packed dot products and nothing else (out: any device word, never written in
+ * practice).  bench.py times it to state the integer issue rate the kernels are priced against as measured on the box, next to the nominal one. */
+int hmr_gpu_valu_probe(hmr_gpu_ctx *ctx, int kind, int blocks, int iters, uint32_t *out);   /* kind 0: v_dot2_i32_i16, 1: v_sad_u16 */
 /* Cap on the workgroups of one batched launch (process-wide, default 4096).  Batched kernels grid-stride over their jobs, so results do not
  * depend on it; lower it to leave compute units to concurrent streams. */
 int hmr_gpu_set_max_grid(int blocks);
