@@ -1064,7 +1064,8 @@ def main():
                 insts = float(r["SQ_INSTS_VALU"])
                 floor_ms = insts * 4 / (256 * 4) / 2.4e9 * 1e3
                 valu = {"valu_insts_per_launch": int(insts), "waves_per_launch": int(float(r["SQ_WAVES"])), "issue_floor_ms": round(floor_ms, 5),
-                        "frac_of_issue_peak": round(floor_ms / per[dom], 4) if per[dom] > 0 else None}
+                        "frac_of_issue_peak": round(floor_ms / per[dom], 4) if per[dom] > 0 else None,
+                        "frac_of_measured_issue_rate": round(insts / (rates["v_dot2_i32_i16"] * 1e9) * 1e3 / per[dom], 4) if per[dom] > 0 else None}
     total_alg = sum(nbytes.values())
 
     if rank == 0:
