@@ -712,6 +712,9 @@ def main():
     ap.add_argument("--tu-multi", choices=["all", "upto16", "small", "off"], default="off",
                     help="fused TU chain batches (given prediction / intra / inter, all TU sizes) as segments of one launch: every size, sizes 4-16 (a launch with a "
                          "32x32 segment reserves that body's 52 KB of LDS for all), or one launch per batch")
+    ap.add_argument("--multi-max-mb", type=float, default=100.0,
+                    help="only batches of at most this many algorithmic MB become segments of a multi launch: merging pays for short launches (they cost queue slots, "
+                         "not arithmetic); a batch that fills the GPU on its own is better off alone")
     ap.add_argument("--no-multi", action="store_true", help="one launch per (pixel kernel, block size) instead of one multi-segment launch per pixel kernel")
     ap.add_argument("--cu-driver", action="store_true",
                     help="issue the luma intra CU drivers (encode_intra_luma: search + transform tree + consolidation) as ordered device-side chains - search -> parent TUs -> "
@@ -781,7 +784,7 @@ def main():
                 PIXEL_OPS = {"hmr_gpu_sad_batch": 1, "hmr_gpu_ssd16b_batch": 2, "hmr_gpu_predict_batch": 3, "hmr_gpu_reconst_batch": 4, "hmr_gpu_copy_batch": 5}
                 fam = {}
                 for g in groups:
-                    if g["fn"] in PIXEL_OPS and g["size"] in (4, 8, 16, 32, 64) and not g.get("chain"):
+                    if g["fn"] in PIXEL_OPS and g["size"] in (4, 8, 16, 32, 64) and not g.get("chain") and g["bytes"] <= args.multi_max_mb * 1e6:
                         fam.setdefault(g["fn"], []).append(g)
                 # ... and the fused TU chains (given prediction / intra / inter, every TU size) as segments of one launch (hmr_gpu_tu_chain_multi)
                 TU_KIND = {"hmr_gpu_tu_chain_batch": 0, "hmr_gpu_intra_tu_chain_batch": 1, "hmr_gpu_inter_tu_chain_batch": 2}
