@@ -889,3 +889,108 @@ void hmr_gpu_intra_luma_cu(int16_t *orig, int orig_stride, int16_t *dec_par, int
 	out[20] = sr->bits;
 	*best_cost = sr->cost;
 }
+
+/* ---- encode_intra_chroma's data path for one 2Nx2N CU (hmr_motion_intra_chroma.c:114-471): chroma search -> the U / V TUs of the winner, two launches in
+ * stream order on one staged image; the mode never leaves the device between them. ---- */
+void hmr_gpu_intra_chroma_cu(int16_t *orig_u, int16_t *orig_v, int orig_stride, int16_t *dec_u, int16_t *dec_v, int dec_stride, const int32_t *nb, int luma_mode,
+			     int split, double sqrt_lambda, double weight, int16_t *pred_u, int16_t *pred_v, int pred_stride, int16_t *lev_u, int16_t *lev_v, int size,
+			     int slice_is_intra, int sign_hiding, int per, int rem, int32_t *out)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	const int n = size, ring = 2 * n + 1;
+	const bool do_split = split && n > 4;
+	const int tn = do_split ? n / 2 : n, ntu = do_split ? 4 : 1;
+	const int ss = n == 32 ? 16 : n;                        // a 64x64 CU is searched on its first quadrant only (:165-169)
+	const int32_t *snb = n == 32 ? nb + 6 : nb;
+	int16_t *orig[2] = {orig_u, orig_v}, *dec[2] = {dec_u, dec_v}, *pred[2] = {pred_u, pred_v}, *lev[2] = {lev_u, lev_v};
+	size_t oo[2];
+	for (int k = 0; k < 2; k++) oo[k] = st.put2d(orig[k], orig_stride, n, n, 2);
+	// how far the L-shaped neighbourhood is read (CU node and quadrants, as in hmr_gpu_intra_luma_cu)
+	const int h = n / 2;
+	const int gx[5] = {0, 0, h, 0, h}, gy[5] = {0, 0, 0, h, h}, gs[5] = {n, h, h, h, h};
+	int rows = 0, cols = 0;
+	for (int k = 0; k < 5; k++) {
+		const int32_t *f = nb + 6 * k;
+		if (gx[k] == 0 && f[0]) { const int r = gy[k] + gs[k] + (f[2] ? f[4] : 0); rows = r > rows ? r : rows; }
+		if (gy[k] == 0 && f[1]) { const int q = gx[k] + gs[k] + (f[3] ? f[5] : 0); cols = q > cols ? q : cols; }
+	}
+	hmr_gpu_chroma_job sj = {};
+	hmr_gpu_itu_job tj[8] = {};
+	const size_t so = st.zeros(sizeof sj), to = st.zeros(sizeof tj);
+	st.begin_outputs();
+	size_t pl[2];
+	for (int k = 0; k < 2; k++) {
+		pl[k] = st.out((size_t)ring * ring * 2);
+		int16_t *tile = st.host<int16_t>(pl[k]);
+		const int16_t *src = dec[k];
+		memset(tile, 0, (size_t)ring * ring * 2);
+		if (rows || cols) tile[0] = src[-dec_stride - 1];
+		for (int y = 0; y < rows; y++) tile[(size_t)(y + 1) * ring] = src[(ptrdiff_t)y * dec_stride - 1];
+		for (int x = 0; x < cols; x++) tile[x + 1] = src[-dec_stride + x];
+		for (int y = 0; y < n; y++) memcpy(tile + (size_t)(y + 1) * ring + 1, src + (ptrdiff_t)y * dec_stride, (size_t)n * 2);
+	}
+	size_t po[2], lo[2];
+	for (int k = 0; k < 2; k++) { po[k] = st.out((size_t)n * n * 2); lo[k] = st.out((size_t)n * n * 2); }
+	const size_t ro = st.out(sizeof(hmr_gpu_intra_result)), sso = st.out(8 * 4), aco = st.out(8 * 4);
+	memset(st.host<uint8_t>(sso), 0, 32);
+	memset(st.host<uint8_t>(aco), 0, 32);
+	auto flags_of = [&](const int32_t *f) { return (uint32_t)(f[0] != 0) | ((uint32_t)(f[1] != 0) << 1) | ((uint32_t)(f[2] != 0) << 2) | ((uint32_t)(f[3] != 0) << 3); };
+	sj.sqrt_lambda = sqrt_lambda;
+	sj.orig_u_off = (uint32_t)(oo[0] / 2); sj.orig_v_off = (uint32_t)(oo[1] / 2); sj.orig_stride = n;
+	sj.dec_u_off = (uint32_t)(pl[0] / 2); sj.dec_v_off = (uint32_t)(pl[1] / 2); sj.dec_stride = ring;
+	sj.flags = flags_of(snb); sj.sizes = (uint32_t)snb[4] | ((uint32_t)snb[5] << 16);
+	sj.luma_mode = (uint32_t)luma_mode;
+	// TU jobs: round r (= quadrant when split) holds the U and the V job
+	for (int r = 0; r < ntu; r++)
+		for (int k = 0; k < 2; k++) {
+			const int x0 = do_split ? (r & 1) * tn : 0, y0 = do_split ? (r >> 1) * tn : 0;
+			const int32_t *f = nb + (do_split ? 6 * (r + 1) : 0);
+			hmr_gpu_itu_job &j = tj[2 * r + k];
+			j.orig_off = (uint32_t)(oo[k] / 2 + (size_t)y0 * n + x0); j.orig_stride = n;
+			j.pred_off = (uint32_t)(po[k] / 2 + (size_t)y0 * n + x0); j.pred_stride = n;
+			j.dec_off = (uint32_t)(pl[k] / 2 + (size_t)y0 * ring + x0); j.dec_stride = ring;
+			j.rec_off = j.dec_off + ring + 1; j.rec_stride = ring;
+			j.lev_off = (uint32_t)(lo[k] / 2 + (size_t)r * tn * tn);
+			j.flags = flags_of(f) | HMR_GPU_ITU_MODE_FROM_SEARCH;           /* is_luma = 0 */
+			j.sizes = (uint32_t)f[4] | ((uint32_t)f[5] << 16);
+			j.mode = 0;
+			j.p0 = ((uint32_t)(k + 1) << 2) | (1u << 4) | ((uint32_t)(slice_is_intra != 0) << 5) | ((uint32_t)(sign_hiding != 0) << 6);
+			j.p1 = (uint32_t)per | ((uint32_t)rem << 8);
+		}
+	memcpy(st.host<uint8_t>(so), &sj, sizeof sj);
+	memcpy(st.host<uint8_t>(to), tj, sizeof tj);
+	st.upload_all();
+	int16_t *base = st.dev<int16_t>();
+	hmr_gpu_intra_result *modes = st.dev<hmr_gpu_intra_result>(ro);
+	must(hmr_gpu_chroma_search_batch(c, st.dev<hmr_gpu_chroma_job>(so), 1, ss, base, base, nullptr, modes), "intra_chroma_cu: search");
+	must(hmr_gpu_intra_tu_chain_rounds_batch(c, st.dev<hmr_gpu_itu_job>(to), 2, ntu, tn, base, base, base, base, base, st.dev<uint32_t>(sso), st.dev<int32_t>(aco), modes),
+	     "intra_chroma_cu: TUs");
+	st.finish();
+	for (int k = 0; k < 2; k++) {
+		const int16_t *tile = st.host<int16_t>(pl[k]);
+		for (int y = 0; y < n; y++) memcpy(dec[k] + (ptrdiff_t)y * dec_stride, tile + (size_t)(y + 1) * ring + 1, (size_t)n * 2);
+		st.get2d(po[k], pred[k], pred_stride, n, n, 2);
+		memcpy(lev[k], st.host<int16_t>(lo[k]), (size_t)n * n * 2);
+	}
+	const hmr_gpu_intra_result *sr = st.host<hmr_gpu_intra_result>(ro);
+	const uint32_t *ssd = st.host<uint32_t>(sso);
+	const int32_t *ac = st.host<int32_t>(aco);
+	uint32_t distortion = 0, sum = 0;
+	for (int k = 0; k < 8; k++) out[6 + k] = 0;
+	for (int r = 0; r < ntu; r++) {
+		int part = 0;
+		for (int k = 0; k < 2; k++) {
+			part += (int)(weight * ssd[2 * r + k]);                 /* :331 */
+			sum += (uint32_t)ac[2 * r + k];
+			out[6 + 4 * k + r] = ac[2 * r + k];
+		}
+		distortion += (uint32_t)part;
+	}
+	out[0] = sr->best_mode >> 8;
+	out[1] = sr->best_mode & 0xff;
+	out[2] = sr->bits;
+	out[3] = (int32_t)(uint32_t)sr->cost;
+	out[4] = (int32_t)distortion;
+	out[5] = (int32_t)sum;
+}

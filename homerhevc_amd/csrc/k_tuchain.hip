@@ -122,11 +122,12 @@ __device__ __forceinline__ void tu_chain_body(const void *__restrict__ jobs_v, i
 				// mode handed over on the device by the search that ran before this launch: smoothing (hmr_motion_intra.c:1011-1012) and
 				// scan (find_scan_mode, hmr_tables.c:398-402) follow from mode and TU size
 				if ((jb.flags & 0x100u) && modes) {
-					const int m = modes[jb.mode].best_mode;
+					const int m = modes[jb.mode].best_mode & 0xff;
+					const bool luma = (jb.flags >> 7) & 1;         // chroma TUs: never smoothed, mode-dependent scan for 4x4 only (hmr_tables.c:403-411)
 					const int d10 = m > 10 ? m - 10 : 10 - m, d26 = m > 26 ? m - 26 : 26 - m, dmin = d10 < d26 ? d10 : d26;
 					constexpr int thr = N == 4 ? 10 : N == 8 ? 7 : N == 16 ? 1 : 0;
-					const unsigned filt = (m != 1 && dmin > thr) ? 0x40u : 0u;
-					const unsigned scan = N <= 8 ? (d26 < 5 ? 1u : d10 < 5 ? 2u : 3u) : 3u;
+					const unsigned filt = (luma && m != 1 && dmin > thr) ? 0x40u : 0u;
+					const unsigned scan = (luma ? N <= 8 : N == 4) ? (d26 < 5 ? 1u : d10 < 5 ? 2u : 3u) : 3u;
 					jb.mode = (uint32_t)m;
 					jb.flags = (jb.flags & ~0x40u) | filt;
 					jb.p0 = (jb.p0 & ~3u) | scan;

@@ -27,6 +27,9 @@ TREE_JOB_DTYPE = np.dtype([("parent", "<u4"), ("child", "<u4", (4,)), ("par_rec_
                            ("chl_rec_stride", "<u4"), ("par_lev_off", "<u4"), ("chl_lev_off", "<u4"), ("size", "<u4"), ("rule", "<u4")])   # hmr_gpu_tree_job
 TREE_RESULT_DTYPE = np.dtype([("split", "<u4"), ("cost", "<u4"), ("sum", "<u4"), ("cbf", "u1", (4,))])                            # hmr_gpu_tree_result
 INTRA_RESULT_DTYPE = np.dtype([("best_mode", "<i4"), ("bits", "<i4"), ("cost", "<f8")])                                          # hmr_gpu_intra_result
+CHROMA_JOB_DTYPE = np.dtype([("sqrt_lambda", "<f8"), ("orig_u_off", "<u4"), ("orig_v_off", "<u4"), ("orig_stride", "<u4"), ("dec_u_off", "<u4"), ("dec_v_off", "<u4"),
+                             ("dec_stride", "<u4"), ("flags", "<u4"), ("sizes", "<u4"), ("luma_mode", "<u4"), ("reserved", "<u4")])   # hmr_gpu_chroma_job
+assert CHROMA_JOB_DTYPE.itemsize == 48
 ITU_MODE_FROM_SEARCH = 0x100
 TREE_NO_PARENT = 0xFFFFFFFF
 assert (TREE_JOB_DTYPE.itemsize, TREE_RESULT_DTYPE.itemsize, INTRA_RESULT_DTYPE.itemsize) == (52, 16, 16)

@@ -395,7 +395,9 @@ uint32_t hmr_gpu_intra_tu_chain(int16_t *orig, int orig_stride, int16_t *decoded
 				int *ac_sum);
 /* As above with the prediction mode handed over ON THE DEVICE: a job whose flags carry bit 8 takes its mode from modes[job.mode].best_mode (the result
  * array of an intra search launched before it) and derives the smoothing rule (hmr_motion_intra.c:1011-1012) and the scan (find_scan_mode,
- * hmr_tables.c:398-402) from mode and TU size itself; is_filtered / scan_mode / mode of such a job are ignored. */
+ * hmr_tables.c:398-402) from mode and TU size itself; is_filtered / scan_mode / mode of such a job are ignored.  A job with is_luma = 0 (chroma TU: its mode
+ * comes from a chroma search, section 10) is never smoothed and takes the chroma scan rule (mode dependent for 4x4 only, hmr_tables.c:403-411); only the
+ * low 8 bits of best_mode are the prediction mode. */
 #define HMR_GPU_ITU_MODE_FROM_SEARCH 0x100u
 struct hmr_gpu_intra_result;   /* section 8 */
 int hmr_gpu_intra_tu_chain_modes_batch(hmr_gpu_ctx *ctx, const hmr_gpu_itu_job *jobs, int njobs, int size, const int16_t *orig_base, const int16_t *decoded_base,
@@ -495,6 +497,35 @@ void hmr_gpu_intra_luma_cu(int16_t *orig, int orig_stride, int16_t *dec_par, int
 			   int strong_enabled, const int32_t *preds, const int32_t *pred_bits, int other_bits, double sqrt_lambda, int16_t *adi, int16_t *adi_filtered,
 			   int16_t *pred, int pred_stride, int16_t *lev_par, int16_t *lev_chl, int size, int slice_is_intra, int sign_hiding, int per, int rem, int rule,
 			   int32_t *out, double *best_cost);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * 10. chroma half of an intra CU: encode_intra_chroma (hmr_motion_intra_chroma.c:114-471, rd_mode != RD_FULL).
+ *     Search: five candidates (planar, vertical, horizontal, DC, DM = the luma mode; an entry equal to the luma mode becomes 34) predicted for U and V
+ *     from unfiltered neighbours, cost = dU + (dU + dV) + (uint32)(bits * sqrt_lambda + .5) with bits 1 for DM and 12 otherwise, first minimum wins.
+ *     The TUs of the winner are hmr_gpu_itu_job launches of section 7 with is_luma = 0 whose mode comes from this search's result array.
+ *     Result: best_mode = prediction mode | coded chroma mode << 8 (36 = DM), bits, cost.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct hmr_gpu_chroma_job {
+	double sqrt_lambda;                       /* et->rd.sqrt_lambda */
+	uint32_t orig_u_off, orig_v_off, orig_stride;
+	uint32_t dec_u_off, dec_v_off, dec_stride;   /* corner sample (-1,-1) of the CU in the two planes under reconstruction */
+	uint32_t flags;                           /* bits 0 left, 1 top, 2 bottom_left, 3 top_right; bit 8: luma_mode is an index into the luma search results */
+	uint32_t sizes;                           /* bl_size | tr_size << 16, in chroma samples */
+	uint32_t luma_mode;
+	uint32_t reserved;
+} hmr_gpu_chroma_job;
+/* size = chroma size of the searched block: 4, 8, 16 (a 64x64 CU is searched on its first 32x32 quadrant only, hmr_motion_intra_chroma.c:165-169) */
+int hmr_gpu_chroma_search_batch(hmr_gpu_ctx *ctx, const hmr_gpu_chroma_job *jobs, int njobs, int size, const int16_t *orig_base, const int16_t *decoded_base,
+				const hmr_gpu_intra_result *luma_modes, hmr_gpu_intra_result *out);
+/* host-pointer (drop-in) form of the whole function: search + the U / V TUs of the winner along the luma tree (split = 0: one TU of `size` per component,
+ * split = 1: four of size / 2 in z-order; a 4x4 chroma CU is always one TU) in one submission.  size: chroma CU size 4 ... 32; nb: 5 x {left, top,
+ * bottom_left, top_right, bl_size, tr_size} in chroma samples for the CU and its quadrants; weight: the chroma distortion weight (:149).
+ * out: [0] coded mode, [1] prediction mode, [2] bits, [3] search cost, [4] distortion = sum of (int)(weight * SSD), [5] sum, [6..9] / [10..13] ac sums of
+ * the U / V TUs. */
+void hmr_gpu_intra_chroma_cu(int16_t *orig_u, int16_t *orig_v, int orig_stride, int16_t *dec_u, int16_t *dec_v, int dec_stride, const int32_t *nb, int luma_mode,
+			     int split, double sqrt_lambda, double weight, int16_t *pred_u, int16_t *pred_v, int pred_stride, int16_t *lev_u, int16_t *lev_v, int size,
+			     int slice_is_intra, int sign_hiding, int per, int rem, int32_t *out);
 
 #ifdef __cplusplus
 }

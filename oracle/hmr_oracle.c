@@ -1302,3 +1302,84 @@ void ora_intra_luma_cu(const int16_t *orig, int orig_stride, int16_t *dec_par, i
 	out[19] = found[0];
 	out[20] = found[1];
 }
+
+/* ====================================================================================================
+ * Chroma half of an intra CU: encode_intra_chroma (hmr_motion_intra_chroma.c:114-471, the non-HM path, rd_mode != RD_FULL).
+ *  1. mode list (create_chroma_dir_list, :92): planar, vertical, horizontal, DC, DM (= the luma mode); a list entry equal to the luma mode becomes 34.
+ *  2. search (:176-233): every candidate is predicted for U and V from UNFILTERED neighbours of the CU (of its first quadrant only for a 64x64 CU) (is_luma = 0: no edge filters) and compared by SAD;
+ *     cost = dU + (dU + dV) (the running distortion is added once per component, :211-213) + (uint32)(bits * sqrt_lambda + .5), bits = 1 for DM, 12 otherwise;
+ *     the three best are kept by homer_update_cand_list (hmr_motion_intra.c:893, strict >) and only the best is coded.
+ *  3. TUs (:262-352) following the luma transform tree: split = 0 -> one TU of `size` per component, split = 1 -> four TUs of size / 2 in z-order (a 4x4
+ *     chroma CU is always one TU: 2x2 TUs do not exist, :289-293); per TU and component: neighbours from the plane under reconstruction, prediction, DCT,
+ *     quantisation as intra, reconstruction in place; distortion += (int)(weight * SSD).  Scan: find_scan_mode(intra, chroma): mode dependent for 4x4 only.
+ * size: chroma CU size (4 ... 32).  nb: 5 x {left, top, bottom_left, top_right, bl_size, tr_size} in chroma samples: the CU, then its four quadrants.
+ * lev_u / lev_v: size * size each, TU k at k * (size / 2)^2 when split.
+ * out: [0] coded chroma mode (36 = DM), [1] prediction mode used, [2] bits, [3] search cost of the winner, [4] distortion, [5] sum of the TUs' ac sums,
+ *      [6..9] ac sum of the U TUs, [10..13] of the V TUs (slot 0 only when not split).
+ * ==================================================================================================== */
+void ora_intra_chroma_cu(const int16_t *orig_u, const int16_t *orig_v, int orig_stride, int16_t *dec_u, int16_t *dec_v, int dec_stride, const int32_t *nb, int luma_mode,
+			 int split, double sqrt_lambda, double weight, int16_t *pred_u, int16_t *pred_v, int pred_stride, int16_t *lev_u, int16_t *lev_v, int size,
+			 int slice_is_intra, int sign_hiding, int per, int rem, int32_t *out)
+{
+	int list[5] = {0, 26, 10, 1, 36}, cand_mode[3] = {0, 0, 0}, i, c, k;
+	double cand_cost[3] = {1.7e+308, 1.7e+308, 1.7e+308};
+	unsigned cand_bits[3] = {0, 0, 0};
+	const int16_t *orig[2] = {orig_u, orig_v};
+	int16_t *dec[2] = {dec_u, dec_v}, *pred[2] = {pred_u, pred_v}, *lev[2] = {lev_u, lev_v};
+	int16_t adi[4 * 64 + 1];
+	const int do_split = split && size > 4, n = do_split ? size / 2 : size, ntu = do_split ? 4 : 1;
+	/* a 64x64 CU (chroma 32) is walked as its four 32x32 children from the start (:165-169): the SEARCH sees only the first of them */
+	const int ss = size == 32 ? 16 : size;
+	const int32_t *snb = size == 32 ? nb + 6 : nb;
+	uint32_t distortion = 0, sum = 0;
+	int mode;
+	for (i = 0; i < 4; i++)
+		if (luma_mode == list[i]) { list[i] = 34; break; }
+	for (i = 0; i < 5; i++) {
+		const int m = list[i] == 36 ? luma_mode : list[i];
+		uint32_t dist = 0, cost = 0;
+		unsigned bits = list[i] == 36 ? 1 : 12;
+		double dcost;
+		int mm = list[i];
+		for (c = 0; c < 2; c++) {
+			ora_fill_reference_samples(dec[c] - dec_stride - 1, dec_stride, ss, snb[0], snb[1], snb[2], snb[3], snb[4], snb[5], adi);
+			if (m == 0) ora_intra_planar(pred[c], pred_stride, adi, 4 * ss + 1, ss);
+			else ora_intra_angular(pred[c], pred_stride, adi, 4 * ss + 1, ss, m, 0);
+			dist += ora_sad(orig[c], (uint32_t)orig_stride, pred[c], (uint32_t)pred_stride, ss);
+			cost += dist;
+		}
+		cost += (uint32_t)(bits * sqrt_lambda + .5);
+		dcost = (double)cost;
+		for (k = 0; k < 3; k++)                     /* homer_update_cand_list */
+			if (cand_cost[k] > dcost) {
+				const int am = cand_mode[k]; const double ac = cand_cost[k]; const unsigned ab = cand_bits[k];
+				cand_cost[k] = dcost; cand_mode[k] = mm; cand_bits[k] = bits;
+				dcost = ac; mm = am; bits = ab;
+			}
+	}
+	mode = cand_mode[0] == 36 ? luma_mode : cand_mode[0];
+	for (k = 0; k < 8; k++) out[6 + k] = 0;
+	for (k = 0; k < ntu; k++) {
+		const int x0 = do_split ? (k & 1) * n : 0, y0 = do_split ? (k >> 1) * n : 0;
+		const int32_t *f = nb + (do_split ? 6 * (k + 1) : 0);
+		const int scan = n == 4 ? (abs(mode - 26) < 5 ? 1 : abs(mode - 10) < 5 ? 2 : 3) : 3;     /* find_scan_mode, hmr_tables.c:403-411 */
+		int part = 0;
+		for (c = 0; c < 2; c++) {
+			int16_t *d = dec[c] + y0 * dec_stride + x0;
+			int ac = 0;
+			const uint32_t ssd = ora_intra_tu_chain(orig[c] + y0 * orig_stride + x0, orig_stride, d - dec_stride - 1, dec_stride, f[0], f[1], f[2], f[3], f[4], f[5], 0, 0,
+								mode, 0, pred[c] + y0 * pred_stride + x0, pred_stride, lev[c] + k * n * n, d, dec_stride, n, 0, scan, c + 1,
+								slice_is_intra, sign_hiding, per, rem, &ac);
+			sum += (uint32_t)ac;
+			out[6 + 4 * c + k] = ac;
+			part += (int)(weight * ssd);
+		}
+		distortion += (uint32_t)part;
+	}
+	out[0] = cand_mode[0];
+	out[1] = mode;
+	out[2] = (int32_t)cand_bits[0];
+	out[3] = (int32_t)(uint32_t)cand_cost[0];
+	out[4] = (int32_t)distortion;
+	out[5] = (int32_t)sum;
+}

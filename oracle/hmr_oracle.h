@@ -140,6 +140,11 @@ void ora_intra_luma_cu(const int16_t *orig, int orig_stride, int16_t *dec_par, i
 		       int16_t *pred, int pred_stride, int16_t *lev_par, int16_t *lev_chl, int size, int slice_is_intra, int sign_hiding, int per, int rem, int rule,
 		       int32_t *out, double *best_cost);
 
+/* ---- chroma half of an intra CU (encode_intra_chroma, hmr_motion_intra_chroma.c:114-471): five-candidate mode search on U and V, then the TUs of the winner ---- */
+void ora_intra_chroma_cu(const int16_t *orig_u, const int16_t *orig_v, int orig_stride, int16_t *dec_u, int16_t *dec_v, int dec_stride, const int32_t *nb, int luma_mode,
+			 int split, double sqrt_lambda, double weight, int16_t *pred_u, int16_t *pred_v, int pred_stride, int16_t *lev_u, int16_t *lev_v, int size,
+			 int slice_is_intra, int sign_hiding, int per, int rem, int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -692,3 +692,71 @@ int refh_intra_luma_cu(int16_t *orig, int16_t *top, int16_t *left, const int32_t
 	et->sps->strong_intra_smooth_enabled_flag = save_strong;
 	return 0;
 }
+
+/* encode_intra_chroma (hmr_motion_intra_chroma.c:114) itself on the encoder instance's thread context: the chroma of one 2Nx2N CU at the origin of CTU 0.
+ * The luma decisions it reads are planted where it looks for them (intra_mode_buffs[Y], tr_idx_buffs), the neighbour L-shapes go into the chroma planes of
+ * the last decoded window, the neighbour flags onto the partition nodes.  size = chroma CU size; pict_w / pict_h = chroma picture extent from the CU origin.
+ * out: {coded mode, -, bits, -, distortion, sum}; dec_u / dec_v: size x size from the work window (and checked equal to the consolidated one). */
+uint32_t encode_intra_chroma(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int depth, int part_position, int part_size_type);
+int refh_intra_chroma_cu(int16_t *orig_u, int16_t *orig_v, int16_t *top_u, int16_t *left_u, int16_t *top_v, int16_t *left_v, const int32_t *nbflags, int pict_w,
+			 int pict_h, int size, int luma_mode, int split, int qp, int slice_qp, double sqrt_lambda, int rd_mode, int slice_is_intra, int sign_hiding,
+			 int32_t *out, int16_t *dec_u, int16_t *dec_v, int16_t *lev_u, int16_t *lev_v)
+{
+	henc_thread_t *et = g_et;
+	ctu_info_t *ctu = &g_eng->ctu_info[0];
+	const int depth = 6 - log2i(2 * size);
+	cu_partition_info_t *pi = &ctu->partition_list[et->partition_depth_start[depth]], *node[5];
+	const int save_w = et->pict_width[1], save_h = et->pict_height[1], save_rd = et->rd_mode, save_qp = g_eng->current_pict.slice.qp;
+	const double save_lambda = et->rd.sqrt_lambda, save_avg = g_eng->avg_dist;
+	wnd_t *dw = et->decoded_mbs_wnd[NUM_DECODED_WNDS - 1], *dd = et->decoded_mbs_wnd[depth + 1], *qw = et->transform_quant_wnd[NUM_QUANT_WNDS - 1];
+	int16_t *orig[2] = {orig_u, orig_v}, *top[2] = {top_u, top_v}, *left[2] = {left_u, left_v}, *dec[2] = {dec_u, dec_v}, *lev[2] = {lev_u, lev_v};
+	int k, x, y, c, bits;
+	uint32_t ret;
+	node[0] = pi;
+	for (k = 0; k < 4; k++) node[k + 1] = pi->children[k];
+	for (k = 0; k < 5; k++) {
+		node[k]->left_neighbour = (uint16_t)nbflags[4 * k]; node[k]->top_neighbour = (uint16_t)nbflags[4 * k + 1];
+		node[k]->left_bottom_neighbour = (uint16_t)nbflags[4 * k + 2]; node[k]->top_right_neighbour = (uint16_t)nbflags[4 * k + 3];
+		node[k]->sum = 0;
+	}
+	pi->qp = (uint32_t)qp;
+	for (k = 0; k < 3; k++) ctu->x[k] = ctu->y[k] = 0;
+	et->pict_width[1] = et->pict_width[2] = pict_w; et->pict_height[1] = et->pict_height[2] = pict_h;
+	et->rd_mode = rd_mode; et->rd.sqrt_lambda = sqrt_lambda;
+	g_eng->avg_dist = 0;                                    /* calc_mv_correction = qp * .15 */
+	g_eng->current_pict.slice.qp = slice_qp;
+	g_eng->current_pict.slice.slice_type = slice_is_intra ? I_SLICE : P_SLICE;
+	et->pps->sign_data_hiding_flag = sign_hiding;
+	memset(&et->intra_mode_buffs[Y_COMP][depth][pi->abs_index], luma_mode, pi->num_part_in_cu);
+	memset(&et->tr_idx_buffs[depth][pi->abs_index], split, pi->num_part_in_cu);
+	for (c = 0; c < 2; c++) {
+		const int comp = U_COMP + c;
+		int16_t *o = WND_POSITION_2D(int16_t *, et->curr_mbs_wnd, comp, 0, 0, 0, et->ctu_width);
+		int16_t *p = WND_POSITION_2D(int16_t *, *dw, comp, 0, 0, 0, et->ctu_width);
+		const int os = WND_STRIDE_2D(et->curr_mbs_wnd, comp), s = WND_STRIDE_2D(*dw, comp);
+		for (y = 0; y < size; y++) memcpy(o + y * os, orig[c] + y * size, (size_t)size * 2);
+		for (x = 0; x < 2 * size + 1; x++) p[-s - 1 + x] = top[c][x];
+		for (y = 0; y < 2 * size; y++) p[y * s - 1] = left[c][y];
+		for (y = 0; y < size; y++) for (x = 0; x < size; x++) p[y * s + x] = 0x0101;
+	}
+	ret = encode_intra_chroma(et, ctu, 0, depth, 0, SIZE_2Nx2N);
+	out[0] = et->intra_mode_buffs[CHR_COMP][depth][pi->abs_index];
+	bits = out[0] == DM_CHROMA_IDX ? 1 : 12;
+	out[2] = bits;
+	out[4] = (int32_t)(ret - (uint32_t)(bits * calc_mv_correction(pi->qp, g_eng->avg_dist) + .5));
+	out[5] = (int32_t)((split && size > 4) ? pi->sum : pi->sum / 2);
+	for (c = 0; c < 2; c++) {
+		const int comp = U_COMP + c;
+		int16_t *p = WND_POSITION_2D(int16_t *, *dw, comp, 0, 0, 0, et->ctu_width), *q = WND_POSITION_2D(int16_t *, *dd, comp, 0, 0, 0, et->ctu_width);
+		const int s = WND_STRIDE_2D(*dw, comp), s2 = WND_STRIDE_2D(*dd, comp);
+		for (y = 0; y < size; y++) {
+			memcpy(dec[c] + y * size, p + y * s, (size_t)size * 2);
+			if (memcmp(p + y * s, q + y * s2, (size_t)size * 2)) return -1;            /* synchronize_motion_buffers_chroma, :453 */
+		}
+		memcpy(lev[c], WND_POSITION_1D(int16_t *, *qw, comp, 0, et->ctu_width, (pi->abs_index << et->num_partitions_in_cu_shift) >> 2), (size_t)size * size * 2);
+	}
+	et->pict_width[1] = et->pict_width[2] = save_w; et->pict_height[1] = et->pict_height[2] = save_h;
+	et->rd_mode = save_rd; et->rd.sqrt_lambda = save_lambda;
+	g_eng->avg_dist = save_avg; g_eng->current_pict.slice.qp = save_qp;
+	return 0;
+}

@@ -420,13 +420,73 @@ def k_intra_luma_cu(lib, prefix, p, rng):
     return res
 
 
+# chroma QP mapping of the standard (chroma_scale_conversion_table, hmr_tables.c) - checked against the compiled reference in test_oracle_vs_ref.py
+CHROMA_QP = list(range(30)) + [29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37] + [q - 6 for q in range(44, 58)]
+
+
+def k_intra_chroma_cu(lib, prefix, p, rng):
+    """encode_intra_chroma for one 2Nx2N CU (n = chroma size): five-candidate search on U and V, then the TUs of the winner along the luma tree.  The reference
+    runs its real function on its own thread context (chroma_qp_offset 2 as configured in refh_open); oracle and GPU take the flat form."""
+    n = p["n"]
+    W = 96
+    yy, xx = np.mgrid[0:W, 0:W]
+    orig, top, left, planes = [], [], [], []
+    for c in range(2):
+        th = p["theta"] + 0.4 * c
+        base = 128 + p["amp"] * np.sin((xx * np.cos(th) + yy * np.sin(th)) / p["period"]) + p["tilt"] * (xx - yy) / 8.0
+        img = np.clip(base + rng.integers(-p["noise"], p["noise"] + 1, (W, W)), 0, 255).astype(np.int16)
+        rec = np.clip(img + rng.integers(-3, 4, (W, W)), 0, 255).astype(np.int16)
+        o = aligned((n, n), np.int16)
+        o[...] = img[16:16 + n, 16:16 + n]
+        orig.append(o)
+        top.append(np.ascontiguousarray(rec[15, 15:16 + 2 * n])); left.append(np.ascontiguousarray(rec[16:16 + 2 * n, 15]))
+    flags = p["flags"]
+    nb = cu_tree_neighbours(n, flags, p["pict_w"], p["pict_h"])
+    out = np.zeros(16, np.int32)
+    dec = [aligned((n, n), np.int16), aligned((n, n), np.int16)]
+    lev = [aligned((n * n,), np.int16), aligned((n * n,), np.int16)]
+    qpc = CHROMA_QP[min(max(p["qp"] + 2, 0), 57)]
+    weight = 2.0 ** ((p["slice_qp"] - CHROMA_QP[min(max(p["slice_qp"] + 2, 0), 57)]) / 3.0)
+    if prefix == "refh_":
+        fl = np.array([f for node in flags for f in node], np.int32)
+        rc = fn(lib, prefix, "intra_chroma_cu", C.c_int)(ptr(orig[0]), ptr(orig[1]), ptr(top[0]), ptr(left[0]), ptr(top[1]), ptr(left[1]), ptr(fl), C.c_int(p["pict_w"]),
+                                                         C.c_int(p["pict_h"]), C.c_int(n), C.c_int(p["luma_mode"]), C.c_int(p["split"]), C.c_int(p["qp"]),
+                                                         C.c_int(p["slice_qp"]), C.c_double(p["sqrt_lambda"]), C.c_int(p["rd_mode"]), C.c_int(p["slice_i"]),
+                                                         C.c_int(p["sbh"]), ptr(out), ptr(dec[0]), ptr(dec[1]), ptr(lev[0]), ptr(lev[1]))
+        assert rc == 0, "work window and consolidated window differ"
+        res = {}
+    else:
+        S = 2 * n + 16
+        for c in range(2):
+            pl = aligned((S, S), np.int16)
+            pl[...] = 0x0101
+            pl[7, 7:8 + 2 * n] = top[c]
+            pl[8:8 + 2 * n, 7] = left[c]
+            planes.append(pl)
+        pred = [aligned((n, n), np.int16), aligned((n, n), np.int16)]
+        fn(lib, prefix, "intra_chroma_cu")(ptr(orig[0]), ptr(orig[1]), C.c_int(n), ptr(planes[0], 8 * S + 8), ptr(planes[1], 8 * S + 8), C.c_int(S), ptr(nb),
+                                           C.c_int(p["luma_mode"]), C.c_int(p["split"]), C.c_double(p["sqrt_lambda"]), C.c_double(weight), ptr(pred[0]), ptr(pred[1]),
+                                           C.c_int(n), ptr(lev[0]), ptr(lev[1]), C.c_int(n), C.c_int(p["slice_i"]), C.c_int(p["sbh"]), C.c_int(qpc // 6),
+                                           C.c_int(qpc % 6), ptr(out))
+        for c in range(2):
+            dec[c][...] = planes[c][8:8 + n, 8:8 + n]
+            chk = planes[c].copy()
+            chk[8:8 + n, 8:8 + n] = 0x0101
+            chk[7, 7:8 + 2 * n] = 0x0101
+            chk[8:8 + 2 * n, 7] = 0x0101
+            assert (chk == 0x0101).all(), "write outside the CU"
+        res = {"pred_u": pred[0].copy(), "pred_v": pred[1].copy(), "search": out[[1, 3]].copy(), "ac": out[6:14].copy()}
+    res.update({"info": out[[0, 2, 4, 5]].copy(), "dec_u": dec[0].copy(), "dec_v": dec[1].copy(), "lev_u": lev[0].copy(), "lev_v": lev[1].copy()})
+    return res
+
+
 KERNELS = {
     "sad": k_sad, "ssd16b": k_ssd16b, "predict": k_predict, "reconst": k_reconst, "modified_variance": k_modified_variance,
     "copy": k_copy, "intra_planar": k_intra_planar, "intra_angular": k_intra_angular,
     "fill_reference_samples": k_fill_reference_samples, "adi_filter": k_adi_filter, "interpolate": k_interpolate,
     "weighted_average": k_weighted_average, "transform": k_transform, "itransform": k_itransform, "quant": k_quant,
     "inv_quant": k_inv_quant, "tu_chain": k_tu_chain, "intra_search": k_intra_search, "intra_tu_chain": k_intra_tu_chain, "inter_tu_chain": k_inter_tu_chain,
-    "intra_luma_cu": k_intra_luma_cu,
+    "intra_luma_cu": k_intra_luma_cu, "intra_chroma_cu": k_intra_chroma_cu,
 }
 
 
@@ -570,4 +630,15 @@ def all_cases(level="full"):
                 qp=int(r.integers(18, 45)), sqrt_lambda=float(r.uniform(2.0, 60.0)), rd_mode=int(r.choice([2, 2, 0])), slice_i=int(r.integers(0, 2)),
                 sbh=int(r.integers(0, 2)), strong=int(r.integers(0, 2)), theta=float(r.uniform(0, np.pi)), period=float(r.uniform(3.0, 25.0)),
                 amp=float(r.uniform(5, 90)), tilt=float(r.uniform(-6, 6)), noise=int(r.choice([0, 1, 3, 8, 20])))
+    r = np.random.default_rng(1415)
+    for n in (4, 8, 16, 32):        # chroma sizes: CUs of 8 ... 64 luma samples
+        for i in range(30 if full else 6):
+            left, top = (int(r.integers(0, 2)), int(r.integers(0, 2))) if i % 5 == 0 else (1, 1)
+            bl, tr = int(r.integers(0, 2)) & left, int(r.integers(0, 2)) & top
+            flags = [(left, top, bl, tr), (left, top, left, top), (1, top, 0, tr), (left, 1, bl, 1), (1, 1, 0, 0)]
+            add("intra_chroma_cu", n=n, flags=flags, pict_w=int(r.choice([n, n + n // 2, 2 * n, 4 * n])), pict_h=int(r.choice([n, n + n // 2, 2 * n, 4 * n])),
+                luma_mode=int(r.choice([0, 1, 10, 26, int(r.integers(2, 35))])), split=int(r.integers(0, 2)) if n < 32 else 1, qp=int(r.integers(18, 45)),
+                slice_qp=int(r.integers(22, 40)), sqrt_lambda=float(r.uniform(2.0, 60.0)), rd_mode=int(r.choice([2, 2, 0])), slice_i=int(r.integers(0, 2)),
+                sbh=int(r.integers(0, 2)), theta=float(r.uniform(0, np.pi)), period=float(r.uniform(3.0, 25.0)), amp=float(r.uniform(5, 90)),
+                tilt=float(r.uniform(-6, 6)), noise=int(r.choice([0, 1, 3, 8, 20])))
     return cases

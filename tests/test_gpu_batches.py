@@ -776,3 +776,101 @@ def test_tu_chain_multi(rig, oracle, with32):
     for seg, (kind, n, d_jobs, cnt, d_ssd, d_ac) in zip(segs, singles):
         same(rig.down(VP(seg.ssd), cnt, np.uint32), rig.down(d_ssd, cnt, np.uint32), f"ssd {n}/{kind}")
         same(rig.down(VP(seg.ac_sum), cnt, np.int32), rig.down(d_ac, cnt, np.int32), f"ac_sum {n}/{kind}")
+
+
+@pytest.mark.parametrize("n", [4, 8, 16])
+def test_chroma_search_and_tus(rig, oracle, n):
+    """The chroma half of intra CUs as two launches: hmr_gpu_chroma_search_batch (luma mode read from a luma search result array on the device), then the U / V
+    TUs of every CU in one rounds launch with their mode taken from the chroma search; every CU owns a pair of planes.  Oracle: ora_intra_chroma_cu."""
+    from kernel_cases import cu_tree_neighbours
+    CH = gpu_host.CHROMA_JOB_DTYPE
+    rng = np.random.default_rng(n + 17 + 1000 * SEED)
+    nj = 301
+    h, ring = n // 2, 2 * n + 1
+    split = (rng.integers(0, 2, nj) if n > 4 else np.zeros(nj, np.int64))
+    per_cu = 2 * ring * ring + 6 * n * n
+    host = np.zeros(nj * per_cu, np.int16)
+    o_pl = [np.arange(nj) * per_cu, np.arange(nj) * per_cu + ring * ring]
+    o_org = [o_pl[1] + ring * ring, o_pl[1] + ring * ring + n * n]
+    o_prd = [o_org[1] + n * n, o_org[1] + 2 * n * n]
+    o_lev = [o_prd[1] + n * n, o_prd[1] + 2 * n * n]
+    yy, xx = np.mgrid[0:ring, 0:ring]
+    nbs = []
+    for i in range(nj):
+        for c in range(2):
+            th, amp, noise = rng.uniform(0, np.pi), rng.choice([3, 15, 40, 80]), int(rng.choice([0, 1, 3, 8, 20]))
+            img = np.clip(128 + amp * np.sin((xx * np.cos(th) + yy * np.sin(th)) / rng.uniform(3, 20)) + rng.integers(-noise, noise + 1, (ring, ring)), 0, 255).astype(np.int16)
+            host[o_pl[c][i]:o_pl[c][i] + ring * ring] = np.clip(img + rng.integers(-2, 3, (ring, ring)), 0, 255).ravel()
+            host[o_org[c][i]:o_org[c][i] + n * n] = img[1:n + 1, 1:n + 1].ravel()
+        left, top = (int(rng.integers(0, 2)), int(rng.integers(0, 2))) if i % 5 == 0 else (1, 1)
+        bl, tr = int(rng.integers(0, 2)) & left, int(rng.integers(0, 2)) & top
+        flags = [(left, top, bl, tr), (left, top, left, top), (1, top, 0, tr), (left, 1, bl, 1), (1, 1, 0, 0)]
+        nbs.append(cu_tree_neighbours(n, flags, int(rng.choice([n, n + h, 2 * n, 4 * n])), int(rng.choice([n, n + h, 2 * n, 4 * n]))))
+    nbs = np.array(nbs, np.int32).reshape(nj, 5, 6)
+    luma = np.zeros(nj, gpu_host.INTRA_RESULT_DTYPE)
+    luma["best_mode"] = rng.choice([0, 1, 10, 26, 2, 7, 18, 33, 34], nj)
+    slice_i, sbh, per, rem = rng.integers(0, 2, nj), rng.integers(0, 2, nj), rng.integers(2, 7, nj), rng.integers(0, 6, nj)
+    sj = np.zeros(nj, CH)
+    sj["sqrt_lambda"] = rng.uniform(2.0, 60.0, nj)
+    sj["orig_u_off"] = o_org[0]; sj["orig_v_off"] = o_org[1]; sj["orig_stride"] = n
+    sj["dec_u_off"] = o_pl[0]; sj["dec_v_off"] = o_pl[1]; sj["dec_stride"] = ring
+    fl = lambda f: f[:, 0] | (f[:, 1] << 1) | (f[:, 2] << 2) | (f[:, 3] << 3)
+    sj["flags"] = fl(nbs[:, 0]) | 0x100; sj["sizes"] = nbs[:, 0, 4] | (nbs[:, 0, 5] << 16)
+    sj["luma_mode"] = np.arange(nj)
+    # TU jobs: unsplit CUs go out as one launch of size n, split ones as four rounds of size n / 2; [round][cu * 2 + comp]
+    def tu_jobs(sel, rounds, tn):
+        idx = np.flatnonzero(sel)
+        t = np.zeros((rounds, 2 * len(idx)), ITU_JOB)
+        for r in range(rounds):
+            x0, y0 = ((r & 1) * tn, (r >> 1) * tn) if rounds == 4 else (0, 0)
+            f = nbs[idx, r + 1 if rounds == 4 else 0]
+            for c in range(2):
+                q = t[r, c::2]
+                q["orig_off"] = o_org[c][idx] + y0 * n + x0; q["orig_stride"] = n
+                q["pred_off"] = o_prd[c][idx] + y0 * n + x0; q["pred_stride"] = n
+                q["dec_off"] = o_pl[c][idx] + y0 * ring + x0; q["dec_stride"] = ring
+                q["rec_off"] = q["dec_off"] + ring + 1; q["rec_stride"] = ring
+                q["lev_off"] = o_lev[c][idx] + r * tn * tn
+                q["flags"] = fl(f) | gpu_host.ITU_MODE_FROM_SEARCH; q["sizes"] = f[:, 4] | (f[:, 5] << 16)
+                q["mode"] = idx
+                q["p0"] = ((c + 1) << 2) | (1 << 4) | (slice_i[idx] << 5) | (sbh[idx] << 6); q["p1"] = per[idx] | (rem[idx] << 8)
+        return idx, t
+    gpu, ctx = rig.gpu, rig.ctx
+    d_arena = rig.up(host)
+    d_luma = rig.up(luma)
+    d_modes = rig.malloc(16 * nj); rig.bufs.append(d_modes)
+    ok = lambda rc, what: (_ for _ in ()).throw(AssertionError((what, gpu.hmr_gpu_last_error()))) if rc else None
+    ok(gpu.hmr_gpu_chroma_search_batch(ctx, rig.up(sj), nj, n, d_arena, d_arena, d_luma, d_modes), "chroma search")
+    outs = []
+    for sel, rounds, tn in ((split == 0, 1, n), (split == 1, 4, h)):
+        idx, t = tu_jobs(sel, rounds, tn)
+        if not len(idx):
+            continue
+        m = 2 * len(idx)
+        d_ssd = rig.malloc(4 * rounds * m); d_ac = rig.malloc(4 * rounds * m); rig.bufs += [d_ssd, d_ac]
+        ok(gpu.hmr_gpu_intra_tu_chain_rounds_batch(ctx, rig.up(t.reshape(-1)), m, rounds, tn, d_arena, d_arena, d_arena, d_arena, d_arena, d_ssd, d_ac, d_modes), "chroma TUs")
+        outs.append((idx, rounds, m, d_ssd, d_ac))
+    assert gpu.hmr_gpu_sync(ctx) == 0, gpu.hmr_gpu_last_error()
+    got = rig.down(d_arena, host.size, np.int16)
+    modes = rig.down(d_modes, nj, gpu_host.INTRA_RESULT_DTYPE)
+    ssd_ac = {}
+    for idx, rounds, m, d_ssd, d_ac in outs:
+        s_ = rig.down(d_ssd, rounds * m, np.uint32).reshape(rounds, len(idx), 2); a_ = rig.down(d_ac, rounds * m, np.int32).reshape(rounds, len(idx), 2)
+        for k, i in enumerate(idx):
+            ssd_ac[int(i)] = (s_[:, k, :], a_[:, k, :])
+    o = host.copy()
+    I32 = C.c_int32
+    coded = set()
+    for i in range(nj):
+        out = (I32 * 16)()
+        nb = np.ascontiguousarray(nbs[i].ravel())
+        oracle.ora_intra_chroma_cu(at(o, o_org[0][i]), at(o, o_org[1][i]), n, at(o, o_pl[0][i] + ring + 1), at(o, o_pl[1][i] + ring + 1), ring, VP(nb.ctypes.data),
+                                   int(luma["best_mode"][i]), int(split[i]), C.c_double(float(sj["sqrt_lambda"][i])), C.c_double(1.0), at(o, o_prd[0][i]), at(o, o_prd[1][i]),
+                                   n, at(o, o_lev[0][i]), at(o, o_lev[1][i]), n, int(slice_i[i]), int(sbh[i]), int(per[i]), int(rem[i]), out)
+        exp = list(out)
+        assert (int(modes["best_mode"][i]) >> 8, int(modes["best_mode"][i]) & 0xff, int(modes["bits"][i]), int(modes["cost"][i])) == tuple(exp[0:4]), (i, modes[i], exp[:6])
+        s_, a_ = ssd_ac[i]
+        assert int(s_.sum()) == exp[4] & 0xFFFFFFFF and int(a_.sum()) == exp[5], (i, s_, a_, exp[:6])      # weight 1.0: distortion = sum of the SSDs
+        coded.add(exp[0])
+    same(got, o, "chroma CUs: planes, predictions, levels")
+    assert len(coded) >= 4

@@ -29,6 +29,11 @@ def test_kernel_matches_reference(kernel, oracle, ref):
     assert n > 0
 
 
+def test_chroma_qp_table_matches_reference(ref):
+    tab = (C.c_uint8 * 58).in_dll(ref, "chroma_scale_conversion_table")
+    assert list(tab) == kc.CHROMA_QP
+
+
 def test_tables_match_reference(oracle, ref):
     oracle.ora_scan_table.restype = C.POINTER(C.c_uint32)
     oracle.ora_quant_table.restype = C.POINTER(C.c_int32)
