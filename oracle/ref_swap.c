@@ -567,6 +567,96 @@ uint32_t encode_intra_luma(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int dep
 	}
 }
 
+/* ---- encode_intra_chroma (hmr_motion_intra_chroma.c:114): the chroma half of a 2Nx2N intra CU - five-candidate search on U and V, then the TUs of the winner
+ * along the luma transform tree - as ONE GPU submission when the luma tree is at most one level deep and rd_mode != RD_FULL.  Host side: the neighbour flags /
+ * run lengths in chroma samples, the chroma QP and weight, and afterwards the cbf buffers, the node sums, the mode buffer and the reference's own
+ * synchronize_motion_buffers_chroma (:426-455). ---- */
+extern const uint8_t chroma_scale_conversion_table[];
+void synchronize_motion_buffers_chroma(henc_thread_t *et, cu_partition_info_t *curr_cu_info, wnd_t *quant_src, wnd_t *quant_dst, wnd_t *decoded_src, wnd_t *decoded_dst, int gcnt);
+uint32_t encode_intra_chroma(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int depth, int part_position, int part_size_type)
+{
+	static int said;
+	cu_partition_info_t *pi = &ctu->partition_list[et->partition_depth_start[depth]] + part_position, *node[5];
+	int routed = want("intra_chroma_cu") && part_size_type == SIZE_2Nx2N && et->rd_mode != RD_FULL && pi->size_chroma >= 4 && (depth > 0 || et->max_cu_size == MAX_CU_SIZE);
+	int split = 0, k;
+	if (routed) {
+		split = et->tr_idx_buffs[depth][pi->abs_index];
+		for (k = 0; k < pi->num_part_in_cu; k++)
+			if (et->tr_idx_buffs[depth][pi->abs_index + k] != split) routed = 0;
+		if (split > 1 || (depth == 0 && split != 1)) routed = 0;
+	}
+	if (!routed)
+		return ((uint32_t (*)(henc_thread_t *, ctu_info_t *, int, int, int, int))REAL(encode_intra_chroma))(et, ctu, gcnt, depth, part_position, part_size_type);
+	{
+		slice_t *currslice = &et->enc_engine->current_pict.slice;
+		const int off = et->enc_engine->chroma_qp_offset, sc = pi->size_chroma, x = pi->x_position_chroma, y = pi->y_position_chroma;
+		const double weight = pow(2.0, (currslice->qp - chroma_scale_conversion_table[clip(currslice->qp + off, 0, 57)]) / 3.0);
+		const int qp_chroma = chroma_scale_conversion_table[clip(pi->qp + off, 0, 57)];
+		const int luma_mode = et->intra_mode_buffs[Y_COMP][depth][pi->abs_index];
+		wnd_t *dw = et->decoded_mbs_wnd[NUM_DECODED_WNDS - 1], *qw = et->transform_quant_wnd[NUM_QUANT_WNDS - 1];
+		const int do_split = split && sc > 4;
+		int32_t nb[30], out[16];
+		int16_t *orig[2], *dec[2], *pred[2], *lev[2];
+		uint8_t *cbf_buff[2] = {et->cbf_buffs_chroma[U_COMP], et->cbf_buffs_chroma[V_COMP]};
+		int c, bits, any[2] = {0, 0};
+		uint32_t cost, running = 0;
+		node[0] = pi;
+		for (k = 0; k < 4; k++) node[k + 1] = pi->children[k];
+		for (k = 0; k < 5; k++) {
+			cu_partition_info_t *q = (k && !do_split) ? pi : node[k];        /* the quadrants only matter when the TUs are split */
+			nb[6 * k] = q->left_neighbour; nb[6 * k + 1] = q->top_neighbour; nb[6 * k + 2] = q->left_bottom_neighbour; nb[6 * k + 3] = q->top_right_neighbour;
+			nb[6 * k + 4] = min(q->size_chroma, et->pict_height[CHR_COMP] - (ctu->y[CHR_COMP] + q->y_position_chroma + q->size_chroma));
+			nb[6 * k + 5] = min(q->size_chroma, et->pict_width[CHR_COMP] - (ctu->x[CHR_COMP] + q->x_position_chroma + q->size_chroma));
+		}
+		for (c = 0; c < 2; c++) {
+			const int comp = U_COMP + c;
+			orig[c] = WND_POSITION_2D(int16_t *, et->curr_mbs_wnd, comp, x, y, gcnt, et->ctu_width);
+			dec[c] = WND_POSITION_2D(int16_t *, *dw, comp, x, y, gcnt, et->ctu_width);
+			pred[c] = WND_POSITION_2D(int16_t *, et->prediction_wnd[0], comp, x, y, gcnt, et->ctu_width);
+			lev[c] = WND_POSITION_1D(int16_t *, *qw, comp, gcnt, et->ctu_width, (pi->abs_index << et->num_partitions_in_cu_shift) >> 2);
+		}
+		ctu->top = 1;
+		ctu->left = 1;
+		hmr_gpu_intra_chroma_cu(orig[0], orig[1], WND_STRIDE_2D(et->curr_mbs_wnd, U_COMP), dec[0], dec[1], WND_STRIDE_2D(*dw, U_COMP), nb, luma_mode, split,
+					et->rd.sqrt_lambda, weight, pred[0], pred[1], WND_STRIDE_2D(et->prediction_wnd[0], U_COMP), lev[0], lev[1], sc,
+					currslice->slice_type == I_SLICE, et->pps->sign_data_hiding_flag, qp_chroma / 6, qp_chroma % 6, out);
+		bits = out[2];
+		/* cbf bytes and node sums as the TU loop leaves them (:318-320, :334, :346-361) */
+		if (do_split) {
+			for (k = 0; k < 4; k++) {
+				cu_partition_info_t *q = node[k + 1];
+				for (c = 0; c < 2; c++) {
+					const int nz = out[6 + 4 * c + k] ? 1 : 0;
+					memset(&cbf_buff[c][q->abs_index], (nz << 1) | (nz << 1), q->num_part_in_cu);
+					any[c] |= nz;
+					running += (uint32_t)out[6 + 4 * c + k];
+				}
+				q->sum += running;
+			}
+			for (k = pi->abs_index; k < pi->abs_index + pi->num_part_in_cu; k++) {
+				cbf_buff[0][k] |= any[0];
+				cbf_buff[1][k] |= any[1];
+			}
+		} else {
+			const int sh = split ? 1 : 0;       /* an 8x8 CU whose luma is split: one 4x4 chroma TU that stands for four 2x2 ones (:289-293, :319) */
+			for (c = 0; c < 2; c++) {
+				const int nz = out[6 + 4 * c] ? 1 : 0;
+				memset(&cbf_buff[c][pi->abs_index], (nz << sh) | nz, pi->num_part_in_cu);
+				running += (uint32_t)out[6 + 4 * c];
+			}
+			pi->sum += running;
+		}
+		cost = (uint32_t)out[4] + (uint32_t)(bits * calc_mv_correction(pi->qp, et->enc_engine->avg_dist) + .5);       /* :406-411 */
+		synchronize_motion_buffers_chroma(et, pi, qw, et->transform_quant_wnd[depth + 1], dw, et->decoded_mbs_wnd[depth + 1], gcnt);
+		memcpy(&et->cbf_buffs[U_COMP][depth][pi->abs_index], &cbf_buff[0][pi->abs_index], pi->num_part_in_cu);
+		memcpy(&et->cbf_buffs[V_COMP][depth][pi->abs_index], &cbf_buff[1][pi->abs_index], pi->num_part_in_cu);
+		memset(&et->intra_mode_buffs[CHR_COMP][depth][pi->abs_index], out[0], pi->num_part_in_cu);
+		pi->sum += (uint32_t)out[5];
+		if (!said++) fprintf(stderr, "ref_swap: chroma intra CU driver routed to libhomer_gpu.so\n");
+		return cost;
+	}
+}
+
 /* ---- encode_inter_cu / encode_inter_cu_chroma (hmr_motion_inter.c:40,133): the inter TU - DCT, quantisation, keep-or-drop decision, reconstruction in
  * one GPU call; window addressing and the bookkeeping on the partition node stay on the host ---- */
 extern const uint8_t chroma_scale_conversion_table[];
