@@ -88,11 +88,11 @@ class Arena:
         return off
 
 
-from homerhevc_amd.gpu import (INTER_TU_JOB_DTYPE, INTRA_JOB_DTYPE, ITU_JOB_DTYPE, ITU_MODE_FROM_SEARCH, ME_JOB_DTYPE, TREE_JOB_DTYPE, TREE_NO_PARENT,  # noqa: E402
+from homerhevc_amd.gpu import (CHROMA_JOB_DTYPE, INTER_TU_JOB_DTYPE, INTRA_JOB_DTYPE, ITU_JOB_DTYPE, ITU_MODE_FROM_SEARCH, ME_JOB_DTYPE, TREE_JOB_DTYPE, TREE_NO_PARENT,  # noqa: E402
                                TU_JOB_DTYPE)
 
 
-def build_groups(calls, rng, arena, fused=True, cu_driver=False, cu_rounds=True):
+def build_groups(calls, rng, arena, fused=True, cu_driver=False, cu_rounds=True, chroma_driver=True):
     """Turn the recorded call mix into batched launches.  Returns list of dict(name, fn, size, jobs, args, bytes)."""
     from homerhevc_amd.gpu import JOB_DTYPE
 
@@ -153,6 +153,19 @@ def build_groups(calls, rng, arena, fused=True, cu_driver=False, cu_rounds=True)
     def jobs(n):
         return np.zeros(n, JOB_DTYPE)
 
+    # table calls made inside a chroma CU driver (encode_intra_chroma, keyed ...@chroma by the recorder): replayed as that driver's two launches when fused,
+    # as plain table calls otherwise.  Its window copies (synchronize_motion_buffers_chroma) are replayed as copy jobs either way.
+    chroma_leaf = {}
+    plain = {}
+    for key, n in calls.items():
+        head, _, rest = key.partition(":")
+        kind, _, origin = head.partition("@")
+        if origin == "chroma" and (not (fused and chroma_driver) or kind.startswith("copy")):
+            key = kind + (":" + rest if rest else "")
+        elif origin == "chroma":
+            chroma_leaf[key] = n
+        plain[key] = plain.get(key, 0) + n
+    calls = plain
     merged = {}
 
     def add(name, fn, size, jb, nbytes, extra=()):
@@ -412,6 +425,83 @@ def build_groups(calls, rng, arena, fused=True, cu_driver=False, cu_rounds=True)
             jb["p0"] = 3 | (0 << 2) | (1 << 4) | (0 << 5) | (1 << 6) | ((1 if N == 4 else 0) << 7)     # diagonal scan, luma, P slice, sign hiding on, DST for 4x4
             jb["p1"] = 5 | (2 << 8)
             merged[("intra_tu", N)] = {"name": "intra_tu", "fn": "hmr_gpu_intra_tu_chain_batch", "size": N, "jobs": jb, "ctu": c, "bytes": nb, "extra": ()}
+        # Chroma CU driver (encode_intra_chroma): per chroma CU size one search launch (five candidates on U and V; a 64x64 CU is searched on its first
+        # quadrant) and the TUs of the winner - unsplit CUs one launch of TUs of that size, split CUs one launch of four rounds at half the size - with the
+        # mode handed over on the device.  Every CU owns a pair of (2S+1)^2 planes cut from the smooth picture and a source pair equal to it plus noise.
+        leaf_bytes = {"fill_reference_samples": lambda q: (4 * q[0] + 1) * 2 * 2, "intra_planar": lambda q: 2 * (4 * q[0] + 1) + 2 * q[0] * q[0],
+                      "intra_angular": lambda q: 2 * (4 * q[0] + 1) + 2 * q[0] * q[0], "sad": lambda q: 4 * q[0] * q[0] + 4, "predict": lambda q: 6 * q[0] * q[0],
+                      "reconst": lambda q: 6 * q[0] * q[0], "ssd16b": lambda q: 4 * q[0] * q[0] + 4}
+        cb = {}                                       # (phase, block size) -> algorithmic bytes of the table calls
+        cnt = {}
+        for key, v in chroma_leaf.items():
+            head, _, rest = key.partition(":")
+            kind = head.partition("@")[0]
+            q = [int(t) for t in rest.split(":")] if rest else [0]
+            cnt[(kind, q[0])] = cnt.get((kind, q[0]), 0) + v
+        for (kind, n_), v in cnt.items():
+            per_call = leaf_bytes.get(kind, lambda q: 4 * q[0] * q[0])([n_])
+            if kind in ("fill_reference_samples", "intra_planar", "intra_angular"):      # one per candidate and component in the search, one per TU and component after
+                tu_share = cnt.get(("predict", n_), 0) / max(cnt.get(("predict", n_), 0) + cnt.get(("sad", n_), 0), 1)
+                cb[("tu", n_)] = cb.get(("tu", n_), 0) + v * per_call * tu_share
+                cb[("search", n_)] = cb.get(("search", n_), 0) + v * per_call * (1 - tu_share)
+            else:
+                ph = "search" if kind == "sad" else "tu"
+                cb[(ph, n_)] = cb.get((ph, n_), 0) + v * per_call
+        ccu = {}
+        for key, v in calls.items():
+            kp = key.split(":")
+            if kp[0] == "intra_chroma_cu" and chroma_driver:
+                ccu[(int(kp[1]), int(kp[2]))] = v
+        coded_c = cnt.get(("inv_quant", 4), 0) + cnt.get(("inv_quant", 8), 0) + cnt.get(("inv_quant", 16), 0)
+        coded_c = coded_c / max(cnt.get(("quant", 4), 0) + cnt.get(("quant", 8), 0) + cnt.get(("quant", 16), 0), 1)
+        n_search = {}
+        n_tu = {}
+        for (S, sp), m in ccu.items():
+            n_search[min(S, 16)] = n_search.get(min(S, 16), 0) + m
+            tn = S // 2 if sp else S
+            n_tu[tn] = n_tu.get(tn, 0) + m * (8 if sp else 2)
+        for (S, sp), m in sorted(ccu.items()):
+            ss, ring = min(S, 16), 2 * S + 1
+            c = ctus(m)
+            yy, xx = np.mgrid[0:ring, 0:ring]
+            pools = []
+            srcs = []
+            for comp in range(2):
+                ty = rng.integers(0, HA + 2 * PAD - ring, m); tx = rng.integers(0, REF_STRIDE - ring, m)
+                tiles = smooth[ty[:, None, None] + yy, tx[:, None, None] + xx]
+                pools.append(arena.alloc(m * ring * ring, tiles.ravel()) + np.arange(m, dtype=np.int64) * ring * ring)
+                coded = rng.random(m) < coded_c
+                src = tiles[:, 1:S + 1, 1:S + 1].astype(np.int64) + np.where(coded[:, None, None], rng.integers(-40, 41, (m, S, S)), 0)
+                srcs.append(arena.alloc(m * S * S, np.clip(src, 0, 255).astype(np.int16).ravel()) + np.arange(m, dtype=np.int64) * S * S)
+            o_pred = [arena.alloc(m * S * S) + np.arange(m, dtype=np.int64) * S * S for _ in range(2)]
+            o_lev = [arena.alloc(m * S * S) + np.arange(m, dtype=np.int64) * S * S for _ in range(2)]
+            sj = np.zeros(m, CHROMA_JOB_DTYPE)
+            sj["sqrt_lambda"] = 7.5
+            sj["orig_u_off"] = srcs[0]; sj["orig_v_off"] = srcs[1]; sj["orig_stride"] = S
+            sj["dec_u_off"] = pools[0]; sj["dec_v_off"] = pools[1]; sj["dec_stride"] = ring
+            sj["flags"] = 15; sj["sizes"] = ss | (ss << 16)
+            sj["luma_mode"] = rng.integers(0, 35, m)
+            chain = "chroma%d_%d" % (S, sp)
+            merged[("chroma_search%ds%d" % (S, sp), S)] = {"name": "chroma_search%ds%d" % (S, sp), "fn": "hmr_gpu_chroma_search_batch", "size": ss, "jobs": sj, "ctu": c,
+                                                  "bytes": int(cb.get(("search", ss), 0) * m / max(n_search[ss], 1)), "extra": (), "chain": chain, "level": -1}
+            tn, rounds = (S // 2, 4) if sp else (S, 1)
+            nbf = [15, 3 | 8, 3 | 8 | 4, 3] if sp else [15]
+            t = np.zeros((rounds, 2 * m), ITU_JOB_DTYPE)
+            for r_ in range(rounds):
+                x0, y0 = ((r_ & 1) * tn, (r_ >> 1) * tn) if sp else (0, 0)
+                for comp in range(2):
+                    q = t[r_, comp::2]
+                    q["orig_off"] = srcs[comp] + y0 * S + x0; q["orig_stride"] = S
+                    q["pred_off"] = o_pred[comp] + y0 * S + x0; q["pred_stride"] = S
+                    q["dec_off"] = pools[comp] + y0 * ring + x0; q["dec_stride"] = ring
+                    q["rec_off"] = q["dec_off"] + ring + 1; q["rec_stride"] = ring
+                    q["lev_off"] = o_lev[comp] + r_ * tn * tn
+                    q["flags"] = nbf[r_] | ITU_MODE_FROM_SEARCH; q["sizes"] = tn | (tn << 16)
+                    q["mode"] = np.arange(m)
+                    q["p0"] = ((comp + 1) << 2) | (1 << 4) | (1 << 6); q["p1"] = 5 | (2 << 8)
+            merged[("chroma_tus%ds%d" % (S, sp), S)] = {"name": "chroma_tus%ds%d" % (S, sp), "fn": "hmr_gpu_intra_tu_chain_modes_batch", "size": tn, "jobs": t.reshape(-1),
+                                                "ctu": np.arange(rounds * 2 * m), "bytes": int(cb.get(("tu", tn), 0) * m * (8 if sp else 2) / max(n_tu[tn], 1)),
+                                                "extra": (), "chain": chain, "level": 0, "njobs": 2 * m, "rounds": rounds, "label_size": S}
         # Luma intra CU driver (encode_intra_luma, one-level tree): search -> parent TUs -> children 0..3 -> consolidation as seven ordered launches per
         # CU size, the mode handed from the search to the TU launches on the device.  Every CU owns a pair of (2N+1)^2 planes (parent / child level) cut
         # from the smooth picture - its neighbourhood - and a source block equal to it, plus noise where the recorded share of TUs is coded.
@@ -716,6 +806,8 @@ def main():
                     help="only batches of at most this many algorithmic MB become segments of a multi launch: merging pays for short launches (they cost queue slots, "
                          "not arithmetic); a batch that fills the GPU on its own is better off alone")
     ap.add_argument("--no-multi", action="store_true", help="one launch per (pixel kernel, block size) instead of one multi-segment launch per pixel kernel")
+    ap.add_argument("--no-chroma-driver", action="store_true",
+                    help="replay the table calls of the chroma CU drivers (encode_intra_chroma) one by one instead of as search + TU launches per chroma CU size")
     ap.add_argument("--cu-driver", action="store_true",
                     help="issue the luma intra CU drivers (encode_intra_luma: search + transform tree + consolidation) as ordered device-side chains - search -> parent TUs -> "
                          "the four children in one launch -> consolidation, the mode handed over on the device - instead of independent search / TU batches")
@@ -763,7 +855,7 @@ def main():
 
         rng = np.random.default_rng(1234 + rank + 1000 * e)
         arena = Arena()
-        groups, planes = build_groups(calls, rng, arena, fused=not args.unfused, cu_driver=args.cu_driver, cu_rounds=not args.cu_child_launches)
+        groups, planes = build_groups(calls, rng, arena, fused=not args.unfused, cu_driver=args.cu_driver, cu_rounds=not args.cu_child_launches, chroma_driver=not args.no_chroma_driver)
         if os.environ.get("HOMER_BENCH_DROP"):      # experiments only (what would a launch cost if it were free?): the record is marked
             drop = set(os.environ["HOMER_BENCH_DROP"].split(","))
             groups = [g for g in groups if g["name"] not in drop and f"{g['name']}:{g['size']}" not in drop]
@@ -843,7 +935,7 @@ def main():
                "hmr_gpu_intra_pred_batch": 7, "hmr_gpu_intra_refs_batch": 8, "hmr_gpu_interpolate_batch": 9, "hmr_gpu_transform_batch": 11,
                "hmr_gpu_itransform_batch": 12, "hmr_gpu_quant_batch": 13, "hmr_gpu_inv_quant_batch": 14, "hmr_gpu_mc_batch": 15,
                "hmr_gpu_motion_estimation_batch": 16, "hmr_gpu_tu_chain_batch": 22, "hmr_gpu_intra_search_batch": 23, "hmr_gpu_intra_tu_chain_batch": 24, "hmr_gpu_inter_tu_chain_batch": 25,
-               "hmr_gpu_intra_tu_chain_modes_batch": 24, "hmr_gpu_tree_decide_batch": 26}
+               "hmr_gpu_intra_tu_chain_modes_batch": 24, "hmr_gpu_tree_decide_batch": 26, "hmr_gpu_chroma_search_batch": 29}
         OP_EDGE, OP_DEBLOCK, OP_STATS, OP_APPLY, OP_PAD = 17, 18, 19, 20, 21
         cmds, names = [], []
         # a luma CU driver chain shares its search results (the modes), the SSD / sum arrays of its five TU levels and the consolidation results
@@ -851,8 +943,8 @@ def main():
         for g in groups:
             if g.get("chain") and g["chain"] not in chains:
                 m = len(g["jobs"])
-                chains[g["chain"]] = {"m": m, "modes": torch.zeros(4 * m, dtype=torch.int32, device=dev), "ssd": torch.zeros(5 * m, dtype=torch.int32, device=dev),
-                                      "ac": torch.zeros(5 * m, dtype=torch.int32, device=dev), "res": torch.zeros(4 * m, dtype=torch.int32, device=dev)}
+                chains[g["chain"]] = {"m": m, "modes": torch.zeros(4 * m, dtype=torch.int32, device=dev), "ssd": torch.zeros(8 * m, dtype=torch.int32, device=dev),
+                                      "ac": torch.zeros(8 * m, dtype=torch.int32, device=dev), "res": torch.zeros(4 * m, dtype=torch.int32, device=dev)}
         for g in groups:
             if g["fn"] == "hmr_gpu_tu_chain_multi":
                 cm = Cmd(op=28, njobs=len(g["segs"]), jobs=C.addressof(g["segs"]), a=base, b=base, c=base)
@@ -876,6 +968,9 @@ def main():
             if g["fn"] == "hmr_gpu_intra_search_batch":
                 g["d_out"] = chains[g["chain"]]["modes"] if g.get("chain") else torch.zeros(4 * len(g["jobs"]), dtype=torch.int32, device=dev)   # hmr_gpu_intra_result per PU
                 cm.out = g["d_out"].data_ptr()
+            if g["fn"] == "hmr_gpu_chroma_search_batch":
+                cm.out = chains[g["chain"]]["modes"].data_ptr()
+                cm.p64 = (P * 3)(None, None, None)       # luma modes: given in the jobs here
             if g["fn"] == "hmr_gpu_intra_tu_chain_modes_batch":
                 ch, k = chains[g["chain"]], g["level"]
                 cm.out = ch["ssd"].data_ptr() + 4 * k * ch["m"]

@@ -55,6 +55,7 @@ OFF_TABLE = {
     "homer_loop1_motion_intra": ("hmr_gpu_intra_search", None),
     "encode_intra_cu": ("hmr_gpu_intra_tu_chain", C.c_uint32),
     "encode_intra_luma": ("hmr_gpu_intra_luma_cu", None),
+    "encode_intra_chroma": ("hmr_gpu_intra_chroma_cu", None),
     "encode_inter_cu": ("hmr_gpu_inter_tu_chain", C.c_uint32),
     "hmr_motion_estimation": ("hmr_gpu_motion_estimation", C.c_uint32),
     "hmr_motion_compensation_luma": ("hmr_gpu_mc_luma", None),

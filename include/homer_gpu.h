@@ -292,6 +292,7 @@ enum hmr_gpu_op {
 	HMR_GPU_OP_TU_CHAIN,  /* jobs = hmr_gpu_tu_job*, a = orig base, b = pred base, c = level base, out = ssd; the reconstruction base and ac_sum follow in p64[0..1] */
 	HMR_GPU_OP_INTRA_SEARCH,  /* jobs = hmr_gpu_intra_job*, a = orig base, b = decoded base, c = output base, out = hmr_gpu_intra_result* */
 	HMR_GPU_OP_INTER_TU_CHAIN = 25, /* jobs = hmr_gpu_inter_tu_job*, a = residual base, b = pred base, c = level base, out = ssd; p64 = {recon base, ac_sum} */
+	HMR_GPU_OP_CHROMA_SEARCH = 29,  /* jobs = hmr_gpu_chroma_job*, a = orig base, b = decoded base, p64[0] = luma search results or NULL, out = hmr_gpu_intra_result* */
 	HMR_GPU_OP_TU_MULTI = 28,       /* jobs = hmr_gpu_tu_segment* (host), njobs = segments, a = orig base, b = decoded base, c = level base, p64[0] = recon / prediction base */
 	HMR_GPU_OP_PIXEL_MULTI = 27,    /* jobs = hmr_gpu_segment* (host), njobs = segments, size = HMR_GPU_OP_SAD / SSD16B / PREDICT / RECONST / COPY */
 	HMR_GPU_OP_TREE_DECIDE = 26,    /* jobs = hmr_gpu_tree_job*, a = ssd, b = ac_sum, c = recon base, out = hmr_gpu_tree_result*; p64[0] = level base */

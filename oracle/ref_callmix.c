@@ -138,6 +138,27 @@ uint32_t encode_intra_luma(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int dep
 		bump("intra_cu:%d", et->max_cu_size >> depth, 0, 0, 0);
 	return ((uint32_t (*)(henc_thread_t *, ctu_info_t *, int, int, int, PartSize))REAL(encode_intra_luma))(et, ctu, gcnt, depth, part_position, part_size_type);
 }
+/* encode_intra_chroma calls that the GPU side takes as one chroma CU driver (search + the U / V TUs along a luma tree of at most one level; the condition
+ * oracle/ref_swap.c routes on): keyed intra_chroma_cu:<chroma size>:<TUs split>, and every table call made inside carries @chroma. */
+uint32_t encode_intra_chroma(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int depth, int part_position, int part_size_type)
+{
+	cu_partition_info_t *pi = &ctu->partition_list[et->partition_depth_start[depth]] + part_position;
+	int routed = part_size_type == SIZE_2Nx2N && et->rd_mode != RD_FULL && pi->size_chroma >= 4 && (depth > 0 || et->max_cu_size == MAX_CU_SIZE), split = 0, k;
+	uint32_t r;
+	if (routed) {
+		split = et->tr_idx_buffs[depth][pi->abs_index];
+		for (k = 0; k < pi->num_part_in_cu; k++)
+			if (et->tr_idx_buffs[depth][pi->abs_index + k] != split) routed = 0;
+		if (split > 1 || (depth == 0 && split != 1)) routed = 0;
+	}
+	if (routed) {
+		bump("intra_chroma_cu:%d:%d", pi->size_chroma, split && pi->size_chroma > 4, 0, 0);
+		g_sfx = "@chroma";
+	}
+	r = ((uint32_t (*)(henc_thread_t *, ctu_info_t *, int, int, int, int))REAL(encode_intra_chroma))(et, ctu, gcnt, depth, part_position, part_size_type);
+	g_sfx = "";
+	return r;
+}
 uint encode_intra_cu(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *pi, int depth, int cu_mode, PartSize part_size_type, int *curr_sum, int gcnt)
 {
 	uint r;

@@ -52,6 +52,11 @@ def test_callmix_fixture_is_consistent(workload):
         assert tot("mc_chroma") == 2 * tot("mc_luma")
         assert tot("fill_reference_samples@search") == tot("intra_search") == tot("intra_planar@search")
         assert tot("sad@search") == tot("intra_planar@search") + tot("intra_angular@search")
+        # chroma CU drivers (encode_intra_chroma): ten {reference build, prediction, SAD} per CU in the search, then one TU per component (eight when split)
+        n_cu = sum(v for key, v in c.items() if key.startswith("intra_chroma_cu:"))
+        n_tu = sum(v * (8 if key.endswith(":1") else 2) for key, v in c.items() if key.startswith("intra_chroma_cu:"))
+        assert tot("sad@chroma") == 10 * n_cu and tot("predict@chroma") == tot("quant@chroma") == tot("reconst@chroma") == tot("ssd16b@chroma") == n_tu
+        assert tot("fill_reference_samples@chroma") == tot("intra_planar@chroma") + tot("intra_angular@chroma") == 10 * n_cu + n_tu
         assert tot("sao_stats_ctu") == tot("sao_offset_ctu") == n_ctu and tot("deblock_ctu") == tot("pad_ctu") == 2 * n_ctu
     bench.set_workload("cfg2-1080p-P-frame-replay")
 
@@ -68,7 +73,12 @@ def test_fused_and_unfused_replays_account_for_the_same_work():
     assert res[False][1] == sum(v for k, v in calls.items() if k.split(":")[0].split("@")[0] in (
         "sad", "sad_direct", "ssd16b", "predict", "reconst", "copy_16_16", "intra_planar", "intra_angular", "fill_reference_samples", "interp_luma",
         "interp_chroma", "transform", "itransform", "quant", "inv_quant") and not (k.startswith("copy_16_16") and int(k.split(":")[2]) > bench.W))
-    assert {"tu_chain", "inter_tu", "intra_tu", "me_subpel", "mc_luma", "mc_chroma", "intra_search"} <= res[True][2]
+    # in this P frame every table-level TU chain and every loose reference build / prediction comes from the chroma CU drivers, which go out as search + TU launches
+    assert {"inter_tu", "intra_tu", "me_subpel", "mc_luma", "mc_chroma", "intra_search", "chroma_search8s0", "chroma_tus8s0", "chroma_search4s0", "chroma_tus4s0"} <= res[True][2]
+    assert not ({"tu_chain", "intra_refs", "intra_pred"} & res[True][2])
+    groups, _ = bench.build_groups(calls, np.random.default_rng(7), bench.Arena(), fused=True, chroma_driver=False)
+    assert {"tu_chain", "intra_refs", "intra_pred"} <= {g["name"] for g in groups} and not any(g["name"].startswith("chroma_") for g in groups)
+    assert abs(sum(g["bytes"] for g in groups) - res[True][0]) / res[True][0] < 0.005
     assert not ({"tu_chain", "inter_tu", "intra_tu", "me_subpel", "mc_luma", "intra_search"} & res[False][2])
     # --cu-driver: in this P frame every intra CU goes through the one-level tree, so all its searches and TUs become luma CU driver chains
     groups, _ = bench.build_groups(calls, np.random.default_rng(7), bench.Arena(), fused=True, cu_driver=True)
