@@ -460,48 +460,58 @@ def build_groups(calls, rng, arena, fused=True, cu_driver=False, cu_rounds=True,
             n_search[min(S, 16)] = n_search.get(min(S, 16), 0) + m
             tn = S // 2 if sp else S
             n_tu[tn] = n_tu.get(tn, 0) + m * (8 if sp else 2)
-        for (S, sp), m in sorted(ccu.items()):
-            ss, ring = min(S, 16), 2 * S + 1
-            c = ctus(m)
-            yy, xx = np.mgrid[0:ring, 0:ring]
-            pools = []
-            srcs = []
-            for comp in range(2):
-                ty = rng.integers(0, HA + 2 * PAD - ring, m); tx = rng.integers(0, REF_STRIDE - ring, m)
-                tiles = smooth[ty[:, None, None] + yy, tx[:, None, None] + xx]
-                pools.append(arena.alloc(m * ring * ring, tiles.ravel()) + np.arange(m, dtype=np.int64) * ring * ring)
-                coded = rng.random(m) < coded_c
-                src = tiles[:, 1:S + 1, 1:S + 1].astype(np.int64) + np.where(coded[:, None, None], rng.integers(-40, 41, (m, S, S)), 0)
-                srcs.append(arena.alloc(m * S * S, np.clip(src, 0, 255).astype(np.int16).ravel()) + np.arange(m, dtype=np.int64) * S * S)
-            o_pred = [arena.alloc(m * S * S) + np.arange(m, dtype=np.int64) * S * S for _ in range(2)]
-            o_lev = [arena.alloc(m * S * S) + np.arange(m, dtype=np.int64) * S * S for _ in range(2)]
-            sj = np.zeros(m, CHROMA_JOB_DTYPE)
-            sj["sqrt_lambda"] = 7.5
-            sj["orig_u_off"] = srcs[0]; sj["orig_v_off"] = srcs[1]; sj["orig_stride"] = S
-            sj["dec_u_off"] = pools[0]; sj["dec_v_off"] = pools[1]; sj["dec_stride"] = ring
-            sj["flags"] = 15; sj["sizes"] = ss | (ss << 16)
-            sj["luma_mode"] = rng.integers(0, 35, m)
-            chain = "chroma%d_%d" % (S, sp)
-            merged[("chroma_search%ds%d" % (S, sp), S)] = {"name": "chroma_search%ds%d" % (S, sp), "fn": "hmr_gpu_chroma_search_batch", "size": ss, "jobs": sj, "ctu": c,
-                                                  "bytes": int(cb.get(("search", ss), 0) * m / max(n_search[ss], 1)), "extra": (), "chain": chain, "level": -1}
-            tn, rounds = (S // 2, 4) if sp else (S, 1)
-            nbf = [15, 3 | 8, 3 | 8 | 4, 3] if sp else [15]
-            t = np.zeros((rounds, 2 * m), ITU_JOB_DTYPE)
-            for r_ in range(rounds):
-                x0, y0 = ((r_ & 1) * tn, (r_ >> 1) * tn) if sp else (0, 0)
+        for ss in sorted({min(S, 16) for S, _ in ccu}):
+            # one search launch per kernel size (the CUs of both TU shapes, and the 64x64 CUs searched at 16), then one TU launch per (CU size, shape)
+            entries = [(S, sp, m) for (S, sp), m in sorted(ccu.items()) if min(S, 16) == ss]
+            chain = "chroma%d" % ss
+            sjs, off, ssd_off = [], 0, 0
+            for S, sp, m in entries:
+                ring = 2 * S + 1
+                c = ctus(m)
+                yy, xx = np.mgrid[0:ring, 0:ring]
+                pools, srcs = [], []
                 for comp in range(2):
-                    q = t[r_, comp::2]
-                    q["orig_off"] = srcs[comp] + y0 * S + x0; q["orig_stride"] = S
-                    q["pred_off"] = o_pred[comp] + y0 * S + x0; q["pred_stride"] = S
-                    q["dec_off"] = pools[comp] + y0 * ring + x0; q["dec_stride"] = ring
-                    q["rec_off"] = q["dec_off"] + ring + 1; q["rec_stride"] = ring
-                    q["lev_off"] = o_lev[comp] + r_ * tn * tn
-                    q["flags"] = nbf[r_] | ITU_MODE_FROM_SEARCH; q["sizes"] = tn | (tn << 16)
-                    q["mode"] = np.arange(m)
-                    q["p0"] = ((comp + 1) << 2) | (1 << 4) | (1 << 6); q["p1"] = 5 | (2 << 8)
-            merged[("chroma_tus%ds%d" % (S, sp), S)] = {"name": "chroma_tus%ds%d" % (S, sp), "fn": "hmr_gpu_intra_tu_chain_modes_batch", "size": tn, "jobs": t.reshape(-1),
-                                                "ctu": np.arange(rounds * 2 * m), "bytes": int(cb.get(("tu", tn), 0) * m * (8 if sp else 2) / max(n_tu[tn], 1)),
-                                                "extra": (), "chain": chain, "level": 0, "njobs": 2 * m, "rounds": rounds, "label_size": S}
+                    ty = rng.integers(0, HA + 2 * PAD - ring, m); tx = rng.integers(0, REF_STRIDE - ring, m)
+                    tiles = smooth[ty[:, None, None] + yy, tx[:, None, None] + xx]
+                    pools.append(arena.alloc(m * ring * ring, tiles.ravel()) + np.arange(m, dtype=np.int64) * ring * ring)
+                    coded = rng.random(m) < coded_c
+                    src = tiles[:, 1:S + 1, 1:S + 1].astype(np.int64) + np.where(coded[:, None, None], rng.integers(-40, 41, (m, S, S)), 0)
+                    srcs.append(arena.alloc(m * S * S, np.clip(src, 0, 255).astype(np.int16).ravel()) + np.arange(m, dtype=np.int64) * S * S)
+                o_pred = [arena.alloc(m * S * S) + np.arange(m, dtype=np.int64) * S * S for _ in range(2)]
+                o_lev = [arena.alloc(m * S * S) + np.arange(m, dtype=np.int64) * S * S for _ in range(2)]
+                sj = np.zeros(m, CHROMA_JOB_DTYPE)
+                sj["sqrt_lambda"] = 7.5
+                sj["orig_u_off"] = srcs[0]; sj["orig_v_off"] = srcs[1]; sj["orig_stride"] = S
+                sj["dec_u_off"] = pools[0]; sj["dec_v_off"] = pools[1]; sj["dec_stride"] = ring
+                sj["flags"] = 15; sj["sizes"] = ss | (ss << 16)
+                sj["luma_mode"] = rng.integers(0, 35, m)
+                sjs.append(sj)
+                tn, rounds = (S // 2, 4) if sp else (S, 1)
+                nbf = [15, 3 | 8, 3 | 8 | 4, 3] if sp else [15]
+                t = np.zeros((rounds, 2 * m), ITU_JOB_DTYPE)
+                for r_ in range(rounds):
+                    x0, y0 = ((r_ & 1) * tn, (r_ >> 1) * tn) if sp else (0, 0)
+                    for comp in range(2):
+                        q = t[r_, comp::2]
+                        q["orig_off"] = srcs[comp] + y0 * S + x0; q["orig_stride"] = S
+                        q["pred_off"] = o_pred[comp] + y0 * S + x0; q["pred_stride"] = S
+                        q["dec_off"] = pools[comp] + y0 * ring + x0; q["dec_stride"] = ring
+                        q["rec_off"] = q["dec_off"] + ring + 1; q["rec_stride"] = ring
+                        q["lev_off"] = o_lev[comp] + r_ * tn * tn
+                        q["flags"] = nbf[r_] | ITU_MODE_FROM_SEARCH; q["sizes"] = tn | (tn << 16)
+                        q["mode"] = off + np.arange(m)
+                        q["p0"] = ((comp + 1) << 2) | (1 << 4) | (1 << 6); q["p1"] = 5 | (2 << 8)
+                merged[("chroma_tus%ds%d" % (S, sp), S)] = {"name": "chroma_tus%ds%d" % (S, sp), "fn": "hmr_gpu_intra_tu_chain_modes_batch", "size": tn, "jobs": t.reshape(-1),
+                                                            "ctu": np.arange(rounds * 2 * m), "bytes": int(cb.get(("tu", tn), 0) * m * (8 if sp else 2) / max(n_tu[tn], 1)),
+                                                            "extra": (), "chain": chain, "level": 0, "njobs": 2 * m, "rounds": rounds, "ssd_off": ssd_off}
+                off += m
+                ssd_off += rounds * 2 * m
+            sj = np.concatenate(sjs)
+            # the search goes first in the chain: re-insert the TU groups after it
+            tus = {k_: merged.pop(k_) for k_ in [k2 for k2, g2 in merged.items() if g2.get("chain") == chain]}
+            merged[("chroma_search", ss)] = {"name": "chroma_search", "fn": "hmr_gpu_chroma_search_batch", "size": ss, "jobs": sj, "ctu": np.arange(len(sj)),
+                                             "bytes": int(cb.get(("search", ss), 0)), "extra": (), "chain": chain, "level": -1}
+            merged.update(tus)
         # Luma intra CU driver (encode_intra_luma, one-level tree): search -> parent TUs -> children 0..3 -> consolidation as seven ordered launches per
         # CU size, the mode handed from the search to the TU launches on the device.  Every CU owns a pair of (2N+1)^2 planes (parent / child level) cut
         # from the smooth picture - its neighbourhood - and a source block equal to it, plus noise where the recorded share of TUs is coded.
@@ -973,8 +983,9 @@ def main():
                 cm.p64 = (P * 3)(None, None, None)       # luma modes: given in the jobs here
             if g["fn"] == "hmr_gpu_intra_tu_chain_modes_batch":
                 ch, k = chains[g["chain"]], g["level"]
-                cm.out = ch["ssd"].data_ptr() + 4 * k * ch["m"]
-                cm.p64 = (P * 3)(base, ch["ac"].data_ptr() + 4 * k * ch["m"], ch["modes"].data_ptr())
+                so_ = 4 * g.get("ssd_off", k * ch["m"])
+                cm.out = ch["ssd"].data_ptr() + so_
+                cm.p64 = (P * 3)(base, ch["ac"].data_ptr() + so_, ch["modes"].data_ptr())
                 cm.p = (C.c_int * 4)(g.get("rounds", 1), 0, 0, 0)
             if g["fn"] == "hmr_gpu_tree_decide_batch":
                 ch = chains[g["chain"]]

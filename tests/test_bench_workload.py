@@ -74,7 +74,7 @@ def test_fused_and_unfused_replays_account_for_the_same_work():
         "sad", "sad_direct", "ssd16b", "predict", "reconst", "copy_16_16", "intra_planar", "intra_angular", "fill_reference_samples", "interp_luma",
         "interp_chroma", "transform", "itransform", "quant", "inv_quant") and not (k.startswith("copy_16_16") and int(k.split(":")[2]) > bench.W))
     # in this P frame every table-level TU chain and every loose reference build / prediction comes from the chroma CU drivers, which go out as search + TU launches
-    assert {"inter_tu", "intra_tu", "me_subpel", "mc_luma", "mc_chroma", "intra_search", "chroma_search8s0", "chroma_tus8s0", "chroma_search4s0", "chroma_tus4s0"} <= res[True][2]
+    assert {"inter_tu", "intra_tu", "me_subpel", "mc_luma", "mc_chroma", "intra_search", "chroma_search", "chroma_tus8s0", "chroma_tus4s0"} <= res[True][2]
     assert not ({"tu_chain", "intra_refs", "intra_pred"} & res[True][2])
     groups, _ = bench.build_groups(calls, np.random.default_rng(7), bench.Arena(), fused=True, chroma_driver=False)
     assert {"tu_chain", "intra_refs", "intra_pred"} <= {g["name"] for g in groups} and not any(g["name"].startswith("chroma_") for g in groups)

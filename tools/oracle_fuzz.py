@@ -23,7 +23,7 @@ def neighbours(r, n):
 
 
 def random_case(r):
-    kind = r.choice(["intra_search", "intra_tu_chain", "inter_tu_chain", "tu_chain", "intra_luma_cu"])
+    kind = r.choice(["intra_search", "intra_tu_chain", "inter_tu_chain", "tu_chain", "intra_luma_cu", "intra_chroma_cu"])
     if kind == "intra_search":
         n = int(r.choice([4, 8, 16, 32, 64]))
         p = dict(n=n, **neighbours(r, n), left_mode=int(r.integers(-1, 35)), top_mode=int(r.integers(-1, 35)), rd_mode=int(r.choice([2, 0])),
@@ -39,6 +39,17 @@ def random_case(r):
                  sqrt_lambda=float(r.uniform(0.5, 80)), rd_mode=int(r.choice([2, 2, 0])), slice_i=int(r.integers(0, 2)), sbh=int(r.integers(0, 2)),
                  strong=int(r.integers(0, 2)), theta=float(r.uniform(0, np.pi)), period=float(r.uniform(2, 30)), amp=float(r.uniform(0, 100)),
                  tilt=float(r.uniform(-8, 8)), noise=int(r.choice([0, 1, 3, 8, 20, 40])))
+    elif kind == "intra_chroma_cu":
+        n = int(r.choice([4, 8, 16, 32]))
+        flags = []
+        for node in range(5):
+            fl, ft = (int(r.integers(0, 2)), int(r.integers(0, 2))) if r.random() < 0.3 else (1, 1)
+            flags.append((fl, ft, int(r.integers(0, 2)) & fl & (node not in (2, 4)), int(r.integers(0, 2)) & ft & (node != 4)))
+        p = dict(n=n, flags=flags, pict_w=int(r.choice([n, n + n // 2, 2 * n, 4 * n])), pict_h=int(r.choice([n, n + n // 2, 2 * n, 4 * n])),
+                 luma_mode=int(r.integers(0, 35)), split=int(r.integers(0, 2)) if n < 32 else 1, qp=int(r.integers(10, 50)), slice_qp=int(r.integers(10, 50)),
+                 sqrt_lambda=float(r.uniform(0.5, 80)), rd_mode=int(r.choice([2, 0])), slice_i=int(r.integers(0, 2)), sbh=int(r.integers(0, 2)),
+                 theta=float(r.uniform(0, np.pi)), period=float(r.uniform(2, 30)), amp=float(r.uniform(0, 100)), tilt=float(r.uniform(-8, 8)),
+                 noise=int(r.choice([0, 1, 3, 8, 20, 40])))
     elif kind == "intra_tu_chain":
         n = int(r.choice([4, 8, 16, 32]))
         p = dict(n=n, comp=int(r.choice([0, 0, 1, 2])) if n < 32 else 0, **neighbours(r, n), mode=int(r.integers(0, 35)), scan=int(r.integers(1, 4)),
