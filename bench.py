@@ -815,6 +815,9 @@ def main():
     ap.add_argument("--multi-max-mb", type=float, default=100.0,
                     help="only batches of at most this many algorithmic MB become segments of a multi launch: merging pays for short launches (they cost queue slots, "
                          "not arithmetic); a batch that fills the GPU on its own is better off alone")
+    ap.add_argument("--sao-offsets", action="store_true",
+                    help="add the SAO offset derivation (hmr_gpu_sao_offsets_frame, a launch between SAO statistics and SAO apply) to the frame: not a table call of the "
+                         "recorded mix, the device-side part of the SAO decision")
     ap.add_argument("--no-multi", action="store_true", help="one launch per (pixel kernel, block size) instead of one multi-segment launch per pixel kernel")
     ap.add_argument("--no-chroma-driver", action="store_true",
                     help="replay the table calls of the chroma CU drivers (encode_intra_chroma) one by one instead of as search + TU launches per chroma CU size")
@@ -1019,14 +1022,24 @@ def main():
                 cmds[i].branch = b
         frame_bytes = {
             "deblock": 2 * 2 * 6144 * n_ctu, "sao_stats": (2 * 2 * 6144 + 5 * 3 * 512) * n_ctu, "sao_apply": 2 * 2 * 6144 * n_ctu,
-            "pad": 2 * 2 * ((W + 2 * PAD) * (H + 2 * PAD) - W * H) * 3 // 2, "edge_flags": 3 * (W // 4) * (H // 4),
+            "pad": 2 * 2 * ((W + 2 * PAD) * (H + 2 * PAD) - W * H) * 3 // 2, "edge_flags": 3 * (W // 4) * (H // 4), "sao_offsets": (960 * 4 + 3 * 8 + 15 * (128 + 4 + 8)) * n_ctu,
         }
         cmds.append(Cmd(op=OP_EDGE, p=(C.c_int * 4)(W, H, W // 4, 0), a=d_info["pred_depth"].data_ptr(), b=d_info["tr_idx"].data_ptr(), c=d_info["flags"].data_ptr()))
         cmds.append(Cmd(op=OP_DEBLOCK, p=(C.c_int * 4)(2, 2, 0, 0), a=C.addressof(f_rec), b=C.addressof(units)))
         cmds.append(Cmd(op=OP_STATS, a=C.addressof(f_org), b=C.addressof(f_rec), out=d_stats.data_ptr()))
+        if not (not args.sao_offsets):
+            # SAO offset derivation of every (CTU, component, type) from the statistics just produced (hmr_sao.c:480-659): the device-side part of the SAO decision
+            sao_lambdas = torch.full((n_ctu, 3), 56.0, dtype=torch.float64, device=dev)       # 0.4624 * 1.4^((32 - 12) / 1.4), hmr_wpp_sao_ctu
+            sao_off = torch.zeros(n_ctu * 15 * 32, dtype=torch.int32, device=dev); sao_aux = torch.zeros(n_ctu * 15, dtype=torch.int32, device=dev)
+            sao_dist = torch.zeros(n_ctu * 15, dtype=torch.int64, device=dev)
+            cm = Cmd(op=30, njobs=n_ctu, a=d_stats.data_ptr(), b=sao_lambdas.data_ptr(), c=sao_off.data_ptr(), out=sao_aux.data_ptr())
+            cm.p64 = (P * 3)(sao_dist.data_ptr(), None, None)
+            cmds.append(cm)
+            chains["sao_offsets_buffers"] = [sao_lambdas, sao_off, sao_aux, sao_dist]
         cmds.append(Cmd(op=OP_APPLY, a=C.addressof(f_rec), b=C.addressof(f_dst), c=d_info["sao_params"].data_ptr()))
         cmds.append(Cmd(op=OP_PAD, p=(C.c_int * 4)(PAD, PAD, 0, 0), a=C.addressof(f_dst)))
-        names += ["edge_flags", "deblock", "sao_stats", "sao_apply", "pad"]
+        names_tail = ["edge_flags", "deblock", "sao_stats"] + ([] if (not args.sao_offsets) else ["sao_offsets"]) + ["sao_apply", "pad"]
+        names += names_tail
         if args.schedule == "time" and args.mode == "graph" and args.branches > 1:
             # measured schedule: one eager pass with an event pair per command gives each launch's isolated duration; the launches are then dealt to the
             # branches longest first by TIME (the runtime runs about four kernels at once, so what shares a queue matters more than bytes).
@@ -1077,7 +1090,7 @@ def main():
             r.wait()
 
     if args.launch_order and rank == 0:
-        order = [f"{g['name']}:{g['size']}" for g in groups] + ["edge_flags", "deblock", "deblock", "sao_stats", "sao_apply", "pad", "pad", "pad"]   # kernels, not commands
+        order = [f"{g['name']}:{g['size']}" for g in groups] + ["edge_flags", "deblock", "deblock", "sao_stats"] + ([] if (not args.sao_offsets) else ["sao_offsets"]) + ["sao_apply", "pad", "pad", "pad"]   # kernels, not commands
         with open(args.launch_order, "w") as f:
             json.dump(order, f)
 
@@ -1185,7 +1198,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
             "config": {"workload": WORKLOAD, "width": W, "height": H, "qp": 32, "gop": "IPPP gop_size=1", "me": "quarter-pel", "sao": 1,
-                       "calls_per_frame": int(sum(len(g["jobs"]) for g in groups)), "launches_per_frame": len(groups) + 8, **({"EXPERIMENT_dropped_groups": os.environ["HOMER_BENCH_DROP"]} if os.environ.get("HOMER_BENCH_DROP") else {}),
+                       "calls_per_frame": int(sum(len(g["jobs"]) for g in groups)), "launches_per_frame": len(groups) + 8 + (0 if (not args.sao_offsets) else 1), **({"EXPERIMENT_dropped_groups": os.environ["HOMER_BENCH_DROP"]} if os.environ.get("HOMER_BENCH_DROP") else {}),
                        "callmix_frame": args.callmix_frame, "parallelism": f"{len(engines)} engine(s) per gpu x{world}", "frames_per_step": len(engines) * world, "launch_mode": args.mode, "graph_branches": args.branches if args.mode == "graph" else 1, "tu_chain": "7 separate batches" if args.unfused else "fused kernel",
                        "algorithmic_MB_per_frame_abi_width": round(total_alg / 1e6, 2), "compulsory_MB_per_frame": round(10.5 * W * H / 1e6, 2)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -48,6 +48,8 @@ static int run_one(hmr_gpu_ctx *ctx, const hmr_gpu_cmd &c)
 	case HMR_GPU_OP_INTRA_SEARCH:
 		return hmr_gpu_intra_search_batch(ctx, (const hmr_gpu_intra_job *)c.jobs, c.njobs, c.size, a, b, o, (hmr_gpu_intra_result *)c.out);
 	case HMR_GPU_OP_PIXEL_MULTI: return hmr_gpu_pixel_multi(ctx, c.size, (const hmr_gpu_segment *)c.jobs, c.njobs, a, b, o);
+	case HMR_GPU_OP_SAO_OFFSETS:
+		return hmr_gpu_sao_offsets_frame(ctx, (const int32_t *)c.a, c.njobs, (const double *)c.b, (int32_t *)c.c, (int32_t *)c.out, (int64_t *)c.p64[0]);
 	case HMR_GPU_OP_CHROMA_SEARCH:
 		return hmr_gpu_chroma_search_batch(ctx, (const hmr_gpu_chroma_job *)c.jobs, c.njobs, c.size, a, b, (const hmr_gpu_intra_result *)c.p64[0],
 						   (hmr_gpu_intra_result *)c.out);

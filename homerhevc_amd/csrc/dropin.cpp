@@ -994,3 +994,19 @@ void hmr_gpu_intra_chroma_cu(int16_t *orig_u, int16_t *orig_v, int orig_stride, 
 	out[4] = (int32_t)distortion;
 	out[5] = (int32_t)sum;
 }
+
+/* ---- sao_derive_offsets + sao_invert_quant_offsets + sao_get_distortion for the 15 (component, type) pairs of one CTU (hmr_sao.c:480-659) ---- */
+void hmr_gpu_sao_offsets_ctu(const int32_t *stats, const double *lambdas, int32_t *offsets, int32_t *aux, int64_t *dist)
+{
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	const size_t so = st.put2d(stats, 960, 1, 960, 4), lo = st.put2d(lambdas, 3, 1, 3, 8);
+	st.begin_outputs();
+	const size_t oo = st.out(3 * 5 * 32 * 4), ao = st.out(15 * 4), dd = st.out(15 * 8);
+	st.upload();
+	must(hmr_gpu_sao_offsets_frame(c, st.dev<int32_t>(so), 1, st.dev<double>(lo), st.dev<int32_t>(oo), st.dev<int32_t>(ao), st.dev<int64_t>(dd)), "sao_offsets");
+	st.finish();
+	memcpy(offsets, st.host<int32_t>(oo), 3 * 5 * 32 * 4);
+	memcpy(aux, st.host<int32_t>(ao), 15 * 4);
+	memcpy(dist, st.host<int64_t>(dd), 15 * 8);
+}

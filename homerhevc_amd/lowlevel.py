@@ -62,6 +62,7 @@ OFF_TABLE = {
     "hmr_motion_compensation_chroma": ("hmr_gpu_mc_chroma", None),
     "hmr_deblock_filter_cu": ("hmr_gpu_deblock_filter_ctu", None),
     "sao_offset_ctu": ("hmr_gpu_sao_offset_ctu", None),
+    "sao_derive_offsets": ("hmr_gpu_sao_offsets_ctu", None),
     "reference_picture_border_padding_ctu": ("hmr_gpu_pad_ctu", None),
 }
 

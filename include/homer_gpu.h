@@ -292,6 +292,7 @@ enum hmr_gpu_op {
 	HMR_GPU_OP_TU_CHAIN,  /* jobs = hmr_gpu_tu_job*, a = orig base, b = pred base, c = level base, out = ssd; the reconstruction base and ac_sum follow in p64[0..1] */
 	HMR_GPU_OP_INTRA_SEARCH,  /* jobs = hmr_gpu_intra_job*, a = orig base, b = decoded base, c = output base, out = hmr_gpu_intra_result* */
 	HMR_GPU_OP_INTER_TU_CHAIN = 25, /* jobs = hmr_gpu_inter_tu_job*, a = residual base, b = pred base, c = level base, out = ssd; p64 = {recon base, ac_sum} */
+	HMR_GPU_OP_SAO_OFFSETS = 30,    /* a = stats, njobs = CTUs, b = lambdas, c = offsets, out = aux, p64[0] = dist */
 	HMR_GPU_OP_CHROMA_SEARCH = 29,  /* jobs = hmr_gpu_chroma_job*, a = orig base, b = decoded base, p64[0] = luma search results or NULL, out = hmr_gpu_intra_result* */
 	HMR_GPU_OP_TU_MULTI = 28,       /* jobs = hmr_gpu_tu_segment* (host), njobs = segments, a = orig base, b = decoded base, c = level base, p64[0] = recon / prediction base */
 	HMR_GPU_OP_PIXEL_MULTI = 27,    /* jobs = hmr_gpu_segment* (host), njobs = segments, size = HMR_GPU_OP_SAD / SSD16B / PREDICT / RECONST / COPY */
@@ -527,6 +528,18 @@ int hmr_gpu_chroma_search_batch(hmr_gpu_ctx *ctx, const hmr_gpu_chroma_job *jobs
 void hmr_gpu_intra_chroma_cu(int16_t *orig_u, int16_t *orig_v, int orig_stride, int16_t *dec_u, int16_t *dec_v, int dec_stride, const int32_t *nb, int luma_mode,
 			     int split, double sqrt_lambda, double weight, int16_t *pred_u, int16_t *pred_v, int pred_stride, int16_t *lev_u, int16_t *lev_v, int size,
 			     int slice_is_intra, int sign_hiding, int per, int rem, int32_t *out);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * 11. SAO offset derivation (8-bit): sao_derive_offsets + sao_invert_quant_offsets + sao_get_distortion (hmr_sao.c:480-659) for the five types of the
+ *     three components of every CTU, straight from the statistics array of hmr_gpu_sao_stats_frame - the part of the SAO decision (sao_derive_mode_new_rdo,
+ *     :663) that is a pure function of the statistics.  The rate terms and the off / new / merge comparison read the CABAC state and stay on the host.
+ *     stats [ctu][3][5][2][32] int32, lambdas [ctu][3] double (hmr_wpp_sao_ctu, :1415), offsets [ctu][3][5][32], aux [ctu][3][5] (band position; 0 for the
+ *     edge types), dist [ctu][3][5] int64; all device pointers.
+ * ------------------------------------------------------------------------------------------------ */
+int hmr_gpu_sao_offsets_frame(hmr_gpu_ctx *ctx, const int32_t *stats, int n_ctu, const double *lambdas, int32_t *offsets, int32_t *aux, int64_t *dist);
+/* host-pointer (drop-in) form for one CTU; lambdas[3] */
+void hmr_gpu_sao_offsets_ctu(const int32_t *stats, const double *lambdas, int32_t *offsets, int32_t *aux, int64_t *dist);
 
 #ifdef __cplusplus
 }

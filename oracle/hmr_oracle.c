@@ -1383,3 +1383,87 @@ void ora_intra_chroma_cu(const int16_t *orig_u, const int16_t *orig_v, int orig_
 	out[4] = (int32_t)distortion;
 	out[5] = (int32_t)sum;
 }
+
+/* ====================================================================================================
+ * SAO offset derivation of one CTU (8-bit): sao_derive_offsets + sao_invert_quant_offsets + sao_get_distortion (hmr_sao.c:480-659) for the five types of
+ * the three components - the part of the SAO decision (sao_derive_mode_new_rdo, :663) that is a pure function of the statistics; the rate terms and the
+ * merge / off comparison need the CABAC state and stay on the host.
+ *   initial offset  = round-half-away(diff / count) in double (x_round_ibdi, :432), clipped to +-7; edge classes keep only the sign their shape allows (:522-525)
+ *   refinement      = est_iter_offset (:445): walk the offset towards 0, keep the one with the least dist + lambda * rate (double), dist = count*o*o - 2*diff*o,
+ *                     rate = |o| + 1 (edge) / |o| + 2 (band), one less at |o| = 7; an offset that never beats lambda alone becomes 0
+ *   band position   = first minimum of the sum of four consecutive band costs (:555-567), the other 28 bands are cleared
+ * stats: [3][5][2][32] int32 (diff, count) as ora_sao_stats_frame leaves them; lambdas[3]; offsets [3][5][32], aux [3][5] (band position, 0 for edge types),
+ * dist [3][5] int64 = sao_get_distortion of the derived offsets.
+ * ==================================================================================================== */
+static int sao_iter_offset(int is_bo, double lambda, int offset_input, int64_t count, int64_t diff, int64_t *best_dist, double *best_cost)
+{
+	int iter = offset_input, out = 0;
+	double min_cost = lambda;
+	while (iter != 0) {
+		int64_t rate = is_bo ? abs(iter) + 2 : abs(iter) + 1, d;
+		double cost;
+		if (abs(iter) == 7) rate--;
+		d = count * iter * iter - diff * iter * 2;
+		cost = (double)d + lambda * (double)rate;
+		if (cost < min_cost) {
+			min_cost = cost;
+			out = iter;
+			*best_dist = d;
+			*best_cost = cost;
+		}
+		iter = iter > 0 ? iter - 1 : iter + 1;
+	}
+	return out;
+}
+void ora_sao_offsets_ctu(const int32_t *stats, const double *lambdas, int32_t *offsets, int32_t *aux, int64_t *dist)
+{
+	int comp, type, c, i;
+	for (comp = 0; comp < 3; comp++)
+		for (type = 0; type < 5; type++) {
+			const int32_t *df = stats + ((comp * 5 + type) * 2) * 32, *cn = df + 32;
+			int32_t *q = offsets + (comp * 5 + type) * 32;
+			const int is_bo = type == 4, n = is_bo ? 32 : 5;
+			const double lambda = lambdas[comp];
+			int64_t d = 0;
+			memset(q, 0, 32 * sizeof q[0]);
+			for (c = 0; c < n; c++) {
+				double x;
+				int v;
+				if ((!is_bo && c == 2) || cn[c] == 0) continue;
+				x = (double)(int64_t)df[c] / (double)(int64_t)cn[c];
+				v = x >= 0 ? (int)(x + 0.5) : (int)(x - 0.5);
+				q[c] = v < -7 ? -7 : v > 7 ? 7 : v;
+			}
+			if (!is_bo) {
+				for (c = 0; c < 5; c++) {
+					int64_t cd;
+					double cc;
+					if (c < 2 && q[c] < 0) q[c] = 0;
+					if (c > 2 && q[c] > 0) q[c] = 0;
+					if (q[c] != 0) q[c] = sao_iter_offset(0, lambda, q[c], cn[c], df[c], &cd, &cc);
+				}
+				aux[comp * 5 + type] = 0;
+				for (c = 0; c < 5; c++) d += (int64_t)cn[c] * q[c] * q[c] - (int64_t)df[c] * q[c] * 2;
+			} else {
+				double cost[32], min_cost = (double)(UINT32_MAX / 8);
+				int64_t dd[32];
+				int band = 0, keep[32];
+				for (c = 0; c < 32; c++) {
+					cost[c] = lambda;
+					dd[c] = 0;
+					if (q[c] != 0) q[c] = sao_iter_offset(1, lambda, q[c], cn[c], df[c], &dd[c], &cost[c]);
+				}
+				for (i = 0; i < 29; i++) {
+					double s = cost[i];
+					s += cost[i + 1]; s += cost[i + 2]; s += cost[i + 3];
+					if (s < min_cost) { min_cost = s; band = i; }
+				}
+				memset(keep, 0, sizeof keep);
+				for (i = 0; i < 4; i++) keep[(band + i) % 32] = q[(band + i) % 32];
+				for (c = 0; c < 32; c++) q[c] = keep[c];
+				aux[comp * 5 + type] = band;
+				for (i = band; i < band + 4; i++) d += (int64_t)cn[i % 32] * q[i % 32] * q[i % 32] - (int64_t)df[i % 32] * q[i % 32] * 2;
+			}
+			dist[comp * 5 + type] = d;
+		}
+}

@@ -145,6 +145,9 @@ void ora_intra_chroma_cu(const int16_t *orig_u, const int16_t *orig_v, int orig_
 			 int split, double sqrt_lambda, double weight, int16_t *pred_u, int16_t *pred_v, int pred_stride, int16_t *lev_u, int16_t *lev_v, int size,
 			 int slice_is_intra, int sign_hiding, int per, int rem, int32_t *out);
 
+/* ---- SAO offset derivation of one CTU from its statistics (sao_derive_offsets + sao_invert_quant_offsets + sao_get_distortion, hmr_sao.c:480-659) ---- */
+void ora_sao_offsets_ctu(const int32_t *stats, const double *lambdas, int32_t *offsets, int32_t *aux, int64_t *dist);
+
 #ifdef __cplusplus
 }
 #endif

@@ -760,3 +760,28 @@ int refh_intra_chroma_cu(int16_t *orig_u, int16_t *orig_v, int16_t *top_u, int16
 	g_eng->avg_dist = save_avg; g_eng->current_pict.slice.qp = save_qp;
 	return 0;
 }
+
+/* sao_derive_offsets / sao_invert_quant_offsets / sao_get_distortion (hmr_sao.c:480,592,620) themselves, for the 15 (component, type) pairs of one CTU;
+ * stats in the frame array layout [3][5][2][32] int32 */
+void sao_derive_offsets(henc_thread_t *wpp_thread, int component, int type_idc, sao_stat_data_t *stats, int *quant_offsets, int *type_aux_info);
+void sao_invert_quant_offsets(int component, int type_idc, int typeAuxInfo, int *dstOffsets, int *srcOffsets);
+int64_t sao_get_distortion(int typeIdc, int typeAuxInfo, int *invQuantOffset, sao_stat_data_t *stats, int bit_depth);
+void refh_sao_offsets_ctu(const int32_t *stats, const double *lambdas, int32_t *offsets, int32_t *aux, int64_t *dist)
+{
+	double save[3];
+	int comp, type, c;
+	for (c = 0; c < 3; c++) { save[c] = g_eng->sao_lambdas[c]; g_eng->sao_lambdas[c] = lambdas[c]; }
+	for (comp = 0; comp < 3; comp++)
+		for (type = 0; type < 5; type++) {
+			sao_stat_data_t st;
+			int q[MAX_NUM_SAO_CLASSES], inv[MAX_NUM_SAO_CLASSES], a = 0;
+			const int32_t *df = stats + ((comp * 5 + type) * 2) * 32;
+			for (c = 0; c < 32; c++) { st.diff[c] = df[c]; st.count[c] = df[32 + c]; }
+			sao_derive_offsets(g_et, comp, type, &st, q, &a);
+			sao_invert_quant_offsets(comp, type, a, inv, q);
+			dist[comp * 5 + type] = sao_get_distortion(type, a, inv, &st, g_et->bit_depth);
+			aux[comp * 5 + type] = a;
+			for (c = 0; c < 32; c++) offsets[(comp * 5 + type) * 32 + c] = inv[c];
+		}
+	for (c = 0; c < 3; c++) g_eng->sao_lambdas[c] = save[c];
+}

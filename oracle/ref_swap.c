@@ -386,6 +386,28 @@ void hmr_deblock_filter_cu(henc_thread_t *et, slice_t *slice, ctu_info_t *ctu, i
 	}
 	pthread_mutex_unlock(&g_units_lock);
 }
+/* sao_derive_offsets (hmr_sao.c:480): the offsets of one (component, type) from its statistics on the GPU; the rate terms around it (sao_derive_mode_new_rdo)
+ * read the CABAC state and stay the reference's */
+void sao_derive_offsets(henc_thread_t *et, int component, int type_idc, sao_stat_data_t *stats, int *quant_offsets, int *type_aux_info)
+{
+	static int said;
+	if (!want("sao_offsets") || et->bit_depth != 8) {
+		((void (*)(henc_thread_t *, int, int, sao_stat_data_t *, int *, int *))REAL(sao_derive_offsets))(et, component, type_idc, stats, quant_offsets, type_aux_info);
+		return;
+	}
+	int32_t st[3][5][2][32], off[3][5][32], aux[3][5];
+	int64_t dist[3][5];
+	int c;
+	memset(st, 0, sizeof st);
+	for (c = 0; c < 32; c++) {
+		st[component][type_idc][0][c] = (int32_t)stats->diff[c];
+		st[component][type_idc][1][c] = (int32_t)stats->count[c];
+	}
+	hmr_gpu_sao_offsets_ctu(&st[0][0][0][0], et->enc_engine->sao_lambdas, &off[0][0][0], &aux[0][0], &dist[0][0]);
+	for (c = 0; c < MAX_NUM_SAO_CLASSES; c++) quant_offsets[c] = off[component][type_idc][c];
+	*type_aux_info = aux[component][type_idc];
+	if (!said++) fprintf(stderr, "ref_swap: SAO offset derivation routed to libhomer_gpu.so\n");
+}
 void sao_offset_ctu(henc_thread_t *et, ctu_info_t *ctu, sao_blk_param_t *p)
 {
 	static int said;

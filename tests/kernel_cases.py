@@ -480,13 +480,31 @@ def k_intra_chroma_cu(lib, prefix, p, rng):
     return res
 
 
+def k_sao_offsets(lib, prefix, p, rng):
+    """sao_derive_offsets + sao_invert_quant_offsets + sao_get_distortion for the 15 (component, type) pairs of a CTU."""
+    stats = np.zeros((3, 5, 2, 32), np.int32)
+    for comp in range(3):
+        area = 4096 if comp == 0 else 1024
+        for t in range(5):
+            ncls = 32 if t == 4 else 5
+            cnt = rng.multinomial(int(area * rng.uniform(0.2, 1.0)), rng.dirichlet(np.full(ncls, p["conc"])))
+            cnt[rng.random(ncls) < p["empty"]] = 0
+            sign = rng.choice([-1, 1], ncls) if t == 4 else np.array([1, 1, 0, -1, -1]) * rng.choice([1, 1, 1, -1], ncls)   # valleys are mostly lifted, peaks lowered
+            stats[comp, t, 1, :ncls] = cnt
+            stats[comp, t, 0, :ncls] = np.round(cnt * sign * rng.gamma(1.0, p["bias"], ncls)).astype(np.int64)
+    lambdas = np.array([p["lambda"], p["lambda"] * p["chroma_ratio"], p["lambda"] * p["chroma_ratio"]], np.float64)
+    offsets, aux, dist = np.zeros((3, 5, 32), np.int32), np.zeros((3, 5), np.int32), np.zeros((3, 5), np.int64)
+    fn(lib, prefix, "sao_offsets_ctu")(ptr(stats), ptr(lambdas), ptr(offsets), ptr(aux), ptr(dist))
+    return {"offsets": offsets, "aux": aux, "dist": dist}
+
+
 KERNELS = {
     "sad": k_sad, "ssd16b": k_ssd16b, "predict": k_predict, "reconst": k_reconst, "modified_variance": k_modified_variance,
     "copy": k_copy, "intra_planar": k_intra_planar, "intra_angular": k_intra_angular,
     "fill_reference_samples": k_fill_reference_samples, "adi_filter": k_adi_filter, "interpolate": k_interpolate,
     "weighted_average": k_weighted_average, "transform": k_transform, "itransform": k_itransform, "quant": k_quant,
     "inv_quant": k_inv_quant, "tu_chain": k_tu_chain, "intra_search": k_intra_search, "intra_tu_chain": k_intra_tu_chain, "inter_tu_chain": k_inter_tu_chain,
-    "intra_luma_cu": k_intra_luma_cu, "intra_chroma_cu": k_intra_chroma_cu,
+    "intra_luma_cu": k_intra_luma_cu, "intra_chroma_cu": k_intra_chroma_cu, "sao_offsets": k_sao_offsets,
 }
 
 
@@ -641,4 +659,8 @@ def all_cases(level="full"):
                 slice_qp=int(r.integers(22, 40)), sqrt_lambda=float(r.uniform(2.0, 60.0)), rd_mode=int(r.choice([2, 2, 0])), slice_i=int(r.integers(0, 2)),
                 sbh=int(r.integers(0, 2)), theta=float(r.uniform(0, np.pi)), period=float(r.uniform(3.0, 25.0)), amp=float(r.uniform(5, 90)),
                 tilt=float(r.uniform(-6, 6)), noise=int(r.choice([0, 1, 3, 8, 20])))
+    r = np.random.default_rng(1617)
+    for i in range(120 if full else 16):
+        add("sao_offsets", conc=float(r.choice([0.2, 1.0, 5.0])), empty=float(r.choice([0.0, 0.2, 0.6])), bias=float(r.choice([0.1, 0.5, 1.5, 4.0, 9.0])),
+            chroma_ratio=float(r.uniform(0.5, 1.2)), **{"lambda": float(r.choice([0.5, 4.0, 20.0, 56.0, 150.0, 600.0]) * r.uniform(0.7, 1.4))})
     return cases

@@ -874,3 +874,28 @@ def test_chroma_search_and_tus(rig, oracle, n):
         coded.add(exp[0])
     same(got, o, "chroma CUs: planes, predictions, levels")
     assert len(coded) >= 4
+
+
+def test_sao_offsets_frame(rig, oracle):
+    """hmr_gpu_sao_offsets_frame: the offsets, band positions and distortions of every (CTU, component, type) of a 1080p frame's worth of statistics against
+    ora_sao_offsets_ctu."""
+    rng = np.random.default_rng(31 + 1000 * SEED)
+    n_ctu = 510
+    stats = np.zeros((n_ctu, 3, 5, 2, 32), np.int32)
+    for t in range(5):
+        ncls = 32 if t == 4 else 5
+        cnt = rng.integers(0, 600, (n_ctu, 3, ncls)) * (rng.random((n_ctu, 3, ncls)) > 0.25)
+        sign = rng.choice([-1, 1], (n_ctu, 3, ncls)) if t == 4 else np.array([1, 1, 0, -1, -1]) * rng.choice([1, 1, 1, -1], (n_ctu, 3, ncls))
+        stats[:, :, t, 1, :ncls] = cnt
+        stats[:, :, t, 0, :ncls] = np.round(cnt * sign * rng.gamma(1.0, rng.choice([0.2, 1.0, 4.0], (n_ctu, 3, 1)), (n_ctu, 3, ncls)))
+    lambdas = np.ascontiguousarray(rng.choice([1.0, 8.0, 56.0, 300.0], (n_ctu, 1)) * rng.uniform(0.6, 1.5, (n_ctu, 3)))
+    d_off = rig.malloc(n_ctu * 15 * 32 * 4); d_aux = rig.malloc(n_ctu * 15 * 4); d_dist = rig.malloc(n_ctu * 15 * 8); rig.bufs += [d_off, d_aux, d_dist]
+    rc = rig.gpu.hmr_gpu_sao_offsets_frame(rig.ctx, rig.up(stats), n_ctu, rig.up(lambdas), d_off, d_aux, d_dist)
+    assert rc == 0 and rig.gpu.hmr_gpu_sync(rig.ctx) == 0, rig.gpu.hmr_gpu_last_error()
+    e_off, e_aux, e_dist = np.zeros((n_ctu, 3, 5, 32), np.int32), np.zeros((n_ctu, 3, 5), np.int32), np.zeros((n_ctu, 3, 5), np.int64)
+    for c in range(n_ctu):
+        oracle.ora_sao_offsets_ctu(at(stats, c * 960), at(lambdas, c * 3), at(e_off, c * 480), at(e_aux, c * 15), at(e_dist, c * 15))
+    same(rig.down(d_off, (n_ctu, 3, 5, 32), np.int32), e_off, "offsets")
+    same(rig.down(d_aux, (n_ctu, 3, 5), np.int32), e_aux, "band positions")
+    same(rig.down(d_dist, (n_ctu, 3, 5), np.int64), e_dist, "distortions")
+    assert (e_off != 0).sum() > 1000 and len(set(e_aux[:, :, 4].ravel().tolist())) > 20

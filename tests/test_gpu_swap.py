@@ -42,7 +42,7 @@ def test_stream_identical_with_gpu_kernels(tmp_path, extra, w, h, frames):
     rd_full = "rd=1" in extra
     # with full RDO the CABAC bit estimate enters the tree comparison, so the luma CU driver stays on the host and its two halves are routed instead
     drivers = ("intra mode search routed", "intra TU chain routed") if rd_full else ("luma intra CU driver routed", "chroma intra CU driver routed")
-    for what in ("table entries routed", "deblocking routed", "border padding routed") + drivers:
+    for what in ("table entries routed", "deblocking routed", "border padding routed", "SAO offset derivation routed") + drivers:
         assert what in log, (what, log[-600:])
     assert len(ref) > 300
     assert gpu == ref, f"stream differs: {len(gpu)} vs {len(ref)} bytes"
