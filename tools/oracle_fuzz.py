@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random differential runs for the composite functions - intra mode search, intra / inter / plain TU chains, the luma intra CU driver - beyond the fixed case lists
+"""Random differential runs for the composite functions - intra mode search, intra / inter / plain TU chains, the luma / chroma intra CU drivers, the SAO offset derivation - beyond the fixed case lists
 of tests/kernel_cases.py: the CPU oracle against the compiled reference (build container: needs oracle/_ref), or, with --gpu, the drop-in
 entries of libhomer_gpu.so against the oracle (GPU box).
 usage: python tools/oracle_fuzz.py [--gpu] [seconds] [seed]"""
@@ -23,7 +23,7 @@ def neighbours(r, n):
 
 
 def random_case(r):
-    kind = r.choice(["intra_search", "intra_tu_chain", "inter_tu_chain", "tu_chain", "intra_luma_cu", "intra_chroma_cu"])
+    kind = r.choice(["intra_search", "intra_tu_chain", "inter_tu_chain", "tu_chain", "intra_luma_cu", "intra_chroma_cu", "sao_offsets"])
     if kind == "intra_search":
         n = int(r.choice([4, 8, 16, 32, 64]))
         p = dict(n=n, **neighbours(r, n), left_mode=int(r.integers(-1, 35)), top_mode=int(r.integers(-1, 35)), rd_mode=int(r.choice([2, 0])),
@@ -50,6 +50,9 @@ def random_case(r):
                  sqrt_lambda=float(r.uniform(0.5, 80)), rd_mode=int(r.choice([2, 0])), slice_i=int(r.integers(0, 2)), sbh=int(r.integers(0, 2)),
                  theta=float(r.uniform(0, np.pi)), period=float(r.uniform(2, 30)), amp=float(r.uniform(0, 100)), tilt=float(r.uniform(-8, 8)),
                  noise=int(r.choice([0, 1, 3, 8, 20, 40])))
+    elif kind == "sao_offsets":
+        p = dict(conc=float(r.choice([0.1, 0.5, 2.0, 10.0])), empty=float(r.choice([0.0, 0.3, 0.8])), bias=float(r.choice([0.05, 0.3, 1.0, 3.0, 8.0, 20.0])),
+                 chroma_ratio=float(r.uniform(0.3, 1.5)), **{"lambda": float(10 ** r.uniform(-1, 3.2))})
     elif kind == "intra_tu_chain":
         n = int(r.choice([4, 8, 16, 32]))
         p = dict(n=n, comp=int(r.choice([0, 0, 1, 2])) if n < 32 else 0, **neighbours(r, n), mode=int(r.integers(0, 35)), scan=int(r.integers(1, 4)),
