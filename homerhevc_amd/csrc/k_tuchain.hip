@@ -42,6 +42,45 @@ __device__ __forceinline__ void stage_to_lds(const int (&row)[N / 2], const int 
 	}
 }
 
+// Inverse DCT stage by even / odd input index (N >= 8): the basis column k and its mirror N-1-k share magnitudes - equal for even input indices, opposite for
+// odd ones - so out[k] = E + O and out[N-1-k] = E - O with E, O two half-length dot products: N*N/4 v_dot2 per row instead of N*N/2, plus N/2 v_perm to
+// split the packed row into its even and odd samples.  Exact: E + O is the same 32-bit sum in another order.
+template <int N>
+__device__ __forceinline__ void split_even_odd(const int (&row)[N / 2], int (&ev)[N / 4], int (&od)[N / 4])
+{
+#pragma unroll
+	for (int i = 0; i < N / 4; i++) {
+		ev[i] = (int)__builtin_amdgcn_perm((unsigned)row[2 * i + 1], (unsigned)row[2 * i], 0x05040100u);
+		od[i] = (int)__builtin_amdgcn_perm((unsigned)row[2 * i + 1], (unsigned)row[2 * i], 0x07060302u);
+	}
+}
+template <int N>
+__device__ __forceinline__ void eo_pair(const int (&ev)[N / 4], const int (&od)[N / 4], const int *__restrict__ beo, int k, int &sum, int &dif)
+{
+	int e = 0, o = 0;
+#pragma unroll
+	for (int i = 0; i < N / 4; i++) {
+		e = dot2(ev[i], beo[k * (N / 2) + i], e);
+		o = dot2(od[i], beo[k * (N / 2) + N / 4 + i], o);
+	}
+	sum = e + o;
+	dif = e - o;
+}
+// out[k] = sat16((sum_i row[i] * M[i][k] + rnd) >> shift), written to dst[k * pitch]
+template <int N>
+__device__ __forceinline__ void istage_eo_to_lds(const int (&row)[N / 2], const int *__restrict__ beo, int shift, int16_t *dst, int pitch)
+{
+	const int rnd = 1 << (shift - 1);
+	int ev[N / 4], od[N / 4];
+	split_even_odd<N>(row, ev, od);
+#pragma unroll 4
+	for (int k = 0; k < N / 2; k++) {
+		int s, d;
+		eo_pair<N>(ev, od, beo, k, s, d);
+		dst[k * pitch] = (int16_t)sat16i((s + rnd) >> shift);
+		dst[(N - 1 - k) * pitch] = (int16_t)sat16i((d + rnd) >> shift);
+	}
+}
 template <int N>
 __device__ __forceinline__ void load_row_lds(int (&row)[N / 2], const int16_t *src)
 {
@@ -290,10 +329,15 @@ __device__ __forceinline__ void tu_chain_body(const void *__restrict__ jobs_v, i
 		}
 		wave_sync();
 		// K13 stage 1: tmp[col = row][k] = sum_i M[i][k] * coeff[i][col]; written transposed (tmpT[k][col]) for stage 2
-		load_row_lds<N>(r, tA + row * P);
-		wave_sync();
-		stage_to_lds<N>(r, Mt, 7, tT + row, P);
-		wave_sync();
+		const int *Meo = reinterpret_cast<const int *>(tab->dct_eo[L2 - 2]);
+		const bool any_coded = __any(coded);                            // a wavefront whose TUs are all uncoded skips the inverse path like the reference does per TU
+		if (any_coded) {
+			load_row_lds<N>(r, tA + row * P);
+			wave_sync();
+			if constexpr (N >= 8) istage_eo_to_lds<N>(r, Meo, 7, tT + row, P);
+			else stage_to_lds<N>(r, Mt, 7, tT + row, P);
+			wave_sync();
+		}
 		// K13 stage 2 + K4 reconst + K2 ssd: out[y = row][x] = sum_i M[i][x] * tmp[i][y]
 		load_row_lds<N>(r, tT + row * P);
 		uint32_t ssd = 0;
@@ -301,27 +345,50 @@ __device__ __forceinline__ void tu_chain_body(const void *__restrict__ jobs_v, i
 		if constexpr (!INTER) {
 			if (ok) {
 				int16_t *ro = Rr + jb.rec_off + (size_t)row * jb.rec_stride;
-#pragma unroll 2
-				for (int x4 = 0; x4 < N; x4 += 4) {
+				auto emit4 = [&](int xb, const int (&res)[4]) {
 					i16x4 outv;
-					const i16x4 vo = ld4(orow_p + x4), vp = ld4(prow_p + x4);
+					const i16x4 vo = ld4(orow_p + xb), vp = ld4(prow_p + xb);
 #pragma unroll
 					for (int q = 0; q < 4; q++) {
-						const int x = x4 + q;
-						int res = 0;
-						if (coded) {
-							int s = 0;
-#pragma unroll
-							for (int i = 0; i < N / 2; i++) s = dot2(r[i], Mt[x * (N / 2) + i], s);
-							res = sat16i((s + 2048) >> 12);
-						}
-						const int pv = vp.v[q], ov = vo.v[q];
-						const int rec = clip3i(sat16i(pv + res), 0, 255);
+						const int rec = clip3i(sat16i((int)vp.v[q] + res[q]), 0, 255);
 						outv.v[q] = (int16_t)rec;
-						const int d = (int16_t)(ov - rec);
+						const int d = (int16_t)((int)vo.v[q] - rec);
 						ssd += (uint32_t)(d * d);
 					}
-					st4(ro + x4, outv);
+					st4(ro + xb, outv);
+				};
+				if (N >= 8 && coded) {
+					// even / odd: four outputs from the left half and their four mirrors per step
+					int ev[N / 4 > 0 ? N / 4 : 1], od[N / 4 > 0 ? N / 4 : 1];
+					if constexpr (N >= 8) split_even_odd<N>(r, ev, od);
+#pragma unroll 2
+					for (int x4 = 0; x4 < N / 2; x4 += 4) {
+						int a[4], b[4];
+#pragma unroll
+						for (int q = 0; q < 4; q++) {
+							int sm = 0, df = 0;
+							if constexpr (N >= 8) eo_pair<N>(ev, od, Meo, x4 + q, sm, df);
+							a[q] = sat16i((sm + 2048) >> 12);
+							b[3 - q] = sat16i((df + 2048) >> 12);
+						}
+						emit4(x4, a);
+						emit4(N - 4 - x4, b);
+					}
+				} else {
+#pragma unroll 2
+					for (int x4 = 0; x4 < N; x4 += 4) {
+						int res[4] = {0, 0, 0, 0};
+						if (coded) {
+#pragma unroll
+							for (int q = 0; q < 4; q++) {
+								int s = 0;
+#pragma unroll
+								for (int i = 0; i < N / 2; i++) s = dot2(r[i], Mt[(x4 + q) * (N / 2) + i], s);
+								res[q] = sat16i((s + 2048) >> 12);
+							}
+						}
+						emit4(x4, res);
+					}
 				}
 			}
 			ssd = group_sum<N>(ssd);
@@ -332,25 +399,49 @@ __device__ __forceinline__ void tu_chain_body(const void *__restrict__ jobs_v, i
 			uint32_t ssd_zero = 0;
 			int16_t *ro = ok ? Rr + jb.rec_off + (size_t)row * jb.rec_stride : nullptr;
 			if (ok) {
-#pragma unroll 2
-				for (int x4 = 0; x4 < N; x4 += 4) {
-					const i16x4 vr = ld4(orow_p + x4), vp = ld4(prow_p + x4);
+				auto emit4 = [&](int xb, const int (&res)[4]) {
+					const i16x4 vr = ld4(orow_p + xb), vp = ld4(prow_p + xb);
 					i16x4 outv;
 #pragma unroll
 					for (int q = 0; q < 4; q++) {
-						int res = 0;
-						if (coded) {
-							int s = 0;
-#pragma unroll
-							for (int i = 0; i < N / 2; i++) s = dot2(r[i], Mt[(x4 + q) * (N / 2) + i], s);
-							res = sat16i((s + 2048) >> 12);
-						}
-						const int d = (int16_t)(vr.v[q] - res);
+						const int d = (int16_t)((int)vr.v[q] - res[q]);
 						ssd += (uint32_t)(d * d);
 						ssd_zero += (uint32_t)((int)vr.v[q] * (int)vr.v[q]);
-						outv.v[q] = (int16_t)clip3i(sat16i(vp.v[q] + res), 0, 255);
+						outv.v[q] = (int16_t)clip3i(sat16i((int)vp.v[q] + res[q]), 0, 255);
 					}
-					st4(ro + x4, outv);
+					st4(ro + xb, outv);
+				};
+				if (N >= 8 && coded) {
+					int ev[N / 4 > 0 ? N / 4 : 1], od[N / 4 > 0 ? N / 4 : 1];
+					if constexpr (N >= 8) split_even_odd<N>(r, ev, od);
+#pragma unroll 2
+					for (int x4 = 0; x4 < N / 2; x4 += 4) {
+						int a[4], b[4];
+#pragma unroll
+						for (int q = 0; q < 4; q++) {
+							int sm = 0, df = 0;
+							if constexpr (N >= 8) eo_pair<N>(ev, od, Meo, x4 + q, sm, df);
+							a[q] = sat16i((sm + 2048) >> 12);
+							b[3 - q] = sat16i((df + 2048) >> 12);
+						}
+						emit4(x4, a);
+						emit4(N - 4 - x4, b);
+					}
+				} else {
+#pragma unroll 2
+					for (int x4 = 0; x4 < N; x4 += 4) {
+						int res[4] = {0, 0, 0, 0};
+						if (coded) {
+#pragma unroll
+							for (int q = 0; q < 4; q++) {
+								int s = 0;
+#pragma unroll
+								for (int i = 0; i < N / 2; i++) s = dot2(r[i], Mt[(x4 + q) * (N / 2) + i], s);
+								res[q] = sat16i((s + 2048) >> 12);
+							}
+						}
+						emit4(x4, res);
+					}
 				}
 			}
 			ssd = group_sum<N>(ssd);

@@ -68,6 +68,18 @@ void build()
 	}
 	for (int k = 0; k < 4; k++)
 		for (int x = 0; x < 4; x++) t->dst4_t[x * 4 + k] = dst[k * 4 + x];
+	// even / odd split of the inverse DCT: out[k] = E[k] + O[k], out[N-1-k] = E[k] - O[k] with E over the even, O over the odd input indices
+	for (int l = 3; l <= 5; l++) {
+		const int n = 1 << l;
+		for (int k = 0; k < n / 2; k++)
+			for (int i = 0; i < n / 4; i++) {
+				int16_t *row = t->dct_eo[l - 2] + k * n;
+				row[2 * i] = t->dct[l - 2][(4 * i) * n + k];
+				row[2 * i + 1] = t->dct[l - 2][(4 * i + 2) * n + k];
+				row[n / 2 + 2 * i] = t->dct[l - 2][(4 * i + 1) * n + k];
+				row[n / 2 + 2 * i + 1] = t->dct[l - 2][(4 * i + 3) * n + k];
+			}
+	}
 
 	// scans: sizes 2..32.  Diagonal: 4x4 coefficient groups visited up-right, each scanned up-right.
 	uint32_t cg_order[64];
