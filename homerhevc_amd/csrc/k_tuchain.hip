@@ -97,6 +97,7 @@ __device__ __forceinline__ void load_row_lds(int (&row)[N / 2], const int16_t *s
 // ssd = SSD(residual, reconstructed residual), both scaled by the job's chroma weight and truncated to uint32, levels dropped when
 // ssd_zero <= ssd + zero_thr * sum (doubles).  The returned SSD is the residual-domain one, as in the reference.
 enum { TU_GIVEN_PRED = 0, TU_INTRA = 1, TU_INTER = 2 };
+constexpr int EO_MIN = 16;      // smallest TU whose inverse stages use the even / odd split (8x8: the split costs registers and saves 16 dot products per row)
 // LDS image of one workgroup: carved from one raw buffer so that several (N, MODE) bodies can share a launch (k_tu_chain_multi)
 template <int N>
 struct alignas(16) TuLds {
@@ -334,7 +335,7 @@ __device__ __forceinline__ void tu_chain_body(const void *__restrict__ jobs_v, i
 		if (any_coded) {
 			load_row_lds<N>(r, tA + row * P);
 			wave_sync();
-			if constexpr (N >= 8) istage_eo_to_lds<N>(r, Meo, 7, tT + row, P);
+			if constexpr (N >= EO_MIN) istage_eo_to_lds<N>(r, Meo, 7, tT + row, P);
 			else stage_to_lds<N>(r, Mt, 7, tT + row, P);
 			wave_sync();
 		}
@@ -357,17 +358,17 @@ __device__ __forceinline__ void tu_chain_body(const void *__restrict__ jobs_v, i
 					}
 					st4(ro + xb, outv);
 				};
-				if (N >= 8 && coded) {
+				if (N >= EO_MIN && coded) {
 					// even / odd: four outputs from the left half and their four mirrors per step
 					int ev[N / 4 > 0 ? N / 4 : 1], od[N / 4 > 0 ? N / 4 : 1];
-					if constexpr (N >= 8) split_even_odd<N>(r, ev, od);
+					if constexpr (N >= EO_MIN) split_even_odd<N>(r, ev, od);
 #pragma unroll 2
 					for (int x4 = 0; x4 < N / 2; x4 += 4) {
 						int a[4], b[4];
 #pragma unroll
 						for (int q = 0; q < 4; q++) {
 							int sm = 0, df = 0;
-							if constexpr (N >= 8) eo_pair<N>(ev, od, Meo, x4 + q, sm, df);
+							if constexpr (N >= EO_MIN) eo_pair<N>(ev, od, Meo, x4 + q, sm, df);
 							a[q] = sat16i((sm + 2048) >> 12);
 							b[3 - q] = sat16i((df + 2048) >> 12);
 						}
@@ -411,16 +412,16 @@ __device__ __forceinline__ void tu_chain_body(const void *__restrict__ jobs_v, i
 					}
 					st4(ro + xb, outv);
 				};
-				if (N >= 8 && coded) {
+				if (N >= EO_MIN && coded) {
 					int ev[N / 4 > 0 ? N / 4 : 1], od[N / 4 > 0 ? N / 4 : 1];
-					if constexpr (N >= 8) split_even_odd<N>(r, ev, od);
+					if constexpr (N >= EO_MIN) split_even_odd<N>(r, ev, od);
 #pragma unroll 2
 					for (int x4 = 0; x4 < N / 2; x4 += 4) {
 						int a[4], b[4];
 #pragma unroll
 						for (int q = 0; q < 4; q++) {
 							int sm = 0, df = 0;
-							if constexpr (N >= 8) eo_pair<N>(ev, od, Meo, x4 + q, sm, df);
+							if constexpr (N >= EO_MIN) eo_pair<N>(ev, od, Meo, x4 + q, sm, df);
 							a[q] = sat16i((sm + 2048) >> 12);
 							b[3 - q] = sat16i((df + 2048) >> 12);
 						}

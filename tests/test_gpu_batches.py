@@ -899,3 +899,33 @@ def test_sao_offsets_frame(rig, oracle):
     same(rig.down(d_aux, (n_ctu, 3, 5), np.int32), e_aux, "band positions")
     same(rig.down(d_dist, (n_ctu, 3, 5), np.int64), e_dist, "distortions")
     assert (e_off != 0).sum() > 1000 and len(set(e_aux[:, :, 4].ravel().tolist())) > 20
+
+
+@pytest.mark.parametrize("n", [16, 32])
+def test_inter_tu_chain_wide_residuals(rig, oracle, n):
+    """Residuals beyond what 8-bit pictures produce (up to +-32767 in some regions): the contract is the full int16 range, saturating packs included."""
+    rng = np.random.default_rng(n + 7 + 1000 * SEED)
+    nj = rig.nj
+    amp = np.repeat(np.repeat(rng.choice([3, 300, 16383, 16384, 20000, 32767], (PH // 32, PW // 32)), 32, 0), 32, 1)
+    rig.host[rig.res:rig.mid] = np.clip(rng.integers(-32768, 32768, (PH, PW)) * amp // 32768, -32768, 32767).astype(np.int16).ravel()
+    jb = np.zeros(nj, INTER_TU_JOB)
+    jb["orig_off"] = rig.block(rng, rig.res, n, n); jb["orig_stride"] = PW
+    jb["pred_off"] = rig.block(rng, rig.pix, n, n); jb["pred_stride"] = PW
+    jb["rec_off"] = rig.slots(rig.out1); jb["rec_stride"] = 80
+    jb["lev_off"] = rig.slots(rig.out2)
+    per, rem = rng.integers(2, 9, nj), rng.integers(0, 6, nj)
+    jb["p0"] = 3 | (1 << 6); jb["p1"] = per | (rem << 8)
+    jb["weight"] = 1.0; jb["zero_thr"] = 1.0
+    d_ssd = rig.malloc(4 * nj); d_ac = rig.malloc(4 * nj); rig.bufs += [d_ssd, d_ac]
+    g = rig.launch("hmr_gpu_inter_tu_chain_batch", rig.up(jb), nj, n, rig.dev, rig.dev, rig.dev, rig.dev, d_ssd, d_ac)
+    o = rig.host.copy()
+    ssd, ac = np.zeros(nj, np.uint32), np.zeros(nj, np.int32)
+    oracle.ora_inter_tu_chain.restype = C.c_uint32
+    for i, j in enumerate(jb):
+        v = C.c_int(0)
+        ssd[i] = oracle.ora_inter_tu_chain(at(o, j["orig_off"]), PW, at(o, j["pred_off"]), PW, at(o, j["lev_off"]), at(o, j["rec_off"]), 80, n, 3, 0, 0, 1, int(per[i]),
+                                           int(rem[i]), C.c_double(1.0), C.c_double(1.0), C.byref(v))
+        ac[i] = v.value
+    same(g, o, "levels, reconstruction")
+    same(rig.down(d_ssd, nj, np.uint32), ssd, "ssd")
+    same(rig.down(d_ac, nj, np.int32), ac, "ac_sum")
