@@ -807,6 +807,8 @@ def main():
                          "graph: the same command list captured once into a hipGraph and replayed (no per-launch host cost), per-kernel numbers from an eager pass after the timed region")
     ap.add_argument("--unfused", action="store_true",
                     help="replay predict/transform/quant/inv_quant/itransform/reconst/ssd16b as seven separate batches per TU size instead of the fused TU-chain kernel")
+    ap.add_argument("--issue-order", choices=["heavy-first", "recorded"], default="recorded",
+                    help="order of the launches in the command list (issue order inside a graph branch): by descending algorithmic bytes, or in the order the groups were built")
     ap.add_argument("--schedule", choices=["time", "bytes"], default="bytes",
                     help="how the independent launches are dealt to the graph branches: by their measured isolated duration (one eager pass while the frame is set up) or by algorithmic bytes")
     ap.add_argument("--tu-multi", choices=["all", "upto16", "small", "off"], default="off",
@@ -951,6 +953,15 @@ def main():
                "hmr_gpu_intra_tu_chain_modes_batch": 24, "hmr_gpu_tree_decide_batch": 26, "hmr_gpu_chroma_search_batch": 29}
         OP_EDGE, OP_DEBLOCK, OP_STATS, OP_APPLY, OP_PAD = 17, 18, 19, 20, 21
         cmds, names = [], []
+        if args.issue_order == "heavy-first":
+            # list order is issue order inside a branch and the order the graph's root nodes go out: the long launches first, so that the GPU is full
+            # while the short ones ramp up and the tail of the frame is made of short launches.  Chains keep their internal order.
+            unit_bytes = {}
+            for g in groups:
+                key = g.get("chain") or id(g)
+                unit_bytes[key] = unit_bytes.get(key, 0) + g["bytes"]
+            order_ = sorted(range(len(groups)), key=lambda i: (-unit_bytes[groups[i].get("chain") or id(groups[i])], i))
+            groups[:] = [groups[i] for i in order_]
         # a luma CU driver chain shares its search results (the modes), the SSD / sum arrays of its five TU levels and the consolidation results
         chains = {}
         for g in groups:
