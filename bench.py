@@ -1168,11 +1168,12 @@ def main():
             for i in range(args.steps):
                 ctx.call("hmr_gpu_cmdlist_run", clist, ev[i])
             torch.cuda.synchronize()
-    per = {n: 0.0 for n in names}
+    # median over the steps: one disturbed pass (a host hiccup between two launches) must not pick the launch the roofline object describes
+    samples = {n: [] for n in names}
     for i in range(args.steps):
         for k, n in enumerate(names):
-            per[n] += ctx.elapsed(P(ev[i][2 * k]), P(ev[i][2 * k + 1]))
-    per = {k: v / args.steps for k, v in per.items()}
+            samples[n].append(ctx.elapsed(P(ev[i][2 * k]), P(ev[i][2 * k + 1])))
+    per = {k: sorted(v)[len(v) // 2] for k, v in samples.items()}
     nbytes = {f"{g['name']}:{g['size']}": g["bytes"] for g in groups}
     nbytes.update(frame_bytes)
     dom = max(per, key=per.get)
