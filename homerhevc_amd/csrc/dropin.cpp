@@ -1010,3 +1010,63 @@ void hmr_gpu_sao_offsets_ctu(const int32_t *stats, const double *lambdas, int32_
 	memcpy(aux, st.host<int32_t>(ao), 15 * 4);
 	memcpy(dist, st.host<int64_t>(dd), 15 * 8);
 }
+
+/* ---- the inter TUs of one CU's transform tree (encode_inter, hmr_motion_inter.c:3069: encode_inter_cu + encode_inter_cu_chroma per node) in ONE submission:
+ * they only read the CU's residual and prediction, so the whole tree can be computed ahead of the walk that compares and consolidates it. ---- */
+void hmr_gpu_inter_tu_chain_n(hmr_gpu_inter_tu_host *tus, int n)
+{
+	if (n <= 0) return;
+	if (n > 32) { fprintf(stderr, "homer_gpu: inter_tu_chain_n takes at most 32 TUs\n"); abort(); }
+	hmr_gpu_ctx *c = hmr_default_ctx();
+	Stager st(c);
+	hmr_gpu_inter_tu_job jb[32] = {};
+	int order[32], cnt = 0;
+	const int sizes[4] = {32, 16, 8, 4};
+	int seg_first[4], seg_n[4];
+	for (int s = 0; s < 4; s++) {            // jobs grouped by TU size: one segment of the multi launch each
+		seg_first[s] = cnt;
+		for (int i = 0; i < n; i++)
+			if (tus[i].size == sizes[s]) order[cnt++] = i;
+		seg_n[s] = cnt - seg_first[s];
+	}
+	if (cnt != n) { fprintf(stderr, "homer_gpu: inter_tu_chain_n: TU size must be 4, 8, 16 or 32\n"); abort(); }
+	for (int k = 0; k < n; k++) {
+		const hmr_gpu_inter_tu_host &t = tus[order[k]];
+		hmr_gpu_inter_tu_job &j = jb[k];
+		j.orig_off = (uint32_t)(st.put2d(t.residual, t.residual_stride, t.size, t.size, 2) / 2); j.orig_stride = t.size;
+		j.pred_off = (uint32_t)(st.put2d(t.pred, t.pred_stride, t.size, t.size, 2) / 2); j.pred_stride = t.size;
+		j.p0 = (uint32_t)(t.scan_mode & 3) | ((uint32_t)t.comp << 2) | ((uint32_t)(t.slice_is_intra != 0) << 5) | ((uint32_t)(t.sign_hiding != 0) << 6);
+		j.p1 = (uint32_t)t.per | ((uint32_t)t.rem << 8);
+		j.weight = t.weight; j.zero_thr = t.zero_thr;
+	}
+	const size_t joff = st.zeros(sizeof jb);
+	st.begin_outputs();
+	size_t lo[32], ro[32];
+	for (int k = 0; k < n; k++) {
+		const int sz = tus[order[k]].size;
+		lo[k] = st.out((size_t)sz * sz * 2); ro[k] = st.out((size_t)sz * sz * 2);
+		jb[k].lev_off = (uint32_t)(lo[k] / 2);
+		jb[k].rec_off = (uint32_t)(ro[k] / 2); jb[k].rec_stride = sz;
+	}
+	const size_t so = st.out(32 * 4), ao = st.out(32 * 4);
+	memcpy(st.host<uint8_t>(joff), jb, sizeof jb);
+	st.upload();
+	hmr_gpu_tu_segment segs[4];
+	int nseg = 0;
+	for (int s = 0; s < 4; s++)
+		if (seg_n[s]) {
+			hmr_gpu_tu_segment &g = segs[nseg++];
+			g.jobs = st.dev<hmr_gpu_inter_tu_job>(joff) + seg_first[s];
+			g.ssd = st.dev<uint32_t>(so) + seg_first[s]; g.ac_sum = st.dev<int32_t>(ao) + seg_first[s]; g.modes = nullptr;
+			g.njobs = seg_n[s]; g.size = sizes[s]; g.kind = 2; g.rounds = 0;
+		}
+	must(hmr_gpu_tu_chain_multi(c, segs, nseg, st.dev<int16_t>(), st.dev<int16_t>(), st.dev<int16_t>(), st.dev<int16_t>(), st.dev<int16_t>()), "inter_tu_chain_n");
+	st.finish();
+	for (int k = 0; k < n; k++) {
+		hmr_gpu_inter_tu_host &t = tus[order[k]];
+		memcpy(t.levels, st.host<int16_t>(lo[k]), (size_t)t.size * t.size * 2);
+		st.get2d(ro[k], t.recon, t.recon_stride, t.size, t.size, 2);
+		t.ssd = st.host<uint32_t>(so)[k];
+		t.ac_sum = st.host<int32_t>(ao)[k];
+	}
+}

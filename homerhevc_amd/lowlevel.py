@@ -57,6 +57,7 @@ OFF_TABLE = {
     "encode_intra_luma": ("hmr_gpu_intra_luma_cu", None),
     "encode_intra_chroma": ("hmr_gpu_intra_chroma_cu", None),
     "encode_inter_cu": ("hmr_gpu_inter_tu_chain", C.c_uint32),
+    "encode_inter": ("hmr_gpu_inter_tu_chain_n", None),
     "hmr_motion_estimation": ("hmr_gpu_motion_estimation", C.c_uint32),
     "hmr_motion_compensation_luma": ("hmr_gpu_mc_luma", None),
     "hmr_motion_compensation_chroma": ("hmr_gpu_mc_chroma", None),

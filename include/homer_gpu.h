@@ -429,6 +429,21 @@ int hmr_gpu_inter_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_inter_tu_job *j
 uint32_t hmr_gpu_inter_tu_chain(int16_t *residual, int residual_stride, int16_t *pred, int pred_stride, int16_t *levels, int16_t *recon, int recon_stride, int size,
 				int scan_mode, int comp, int slice_is_intra, int sign_hiding, int per, int rem, double weight, double zero_thr, int *ac_sum);
 
+/* All inter TUs of one CU's transform tree (encode_inter, hmr_motion_inter.c:3069-3290: encode_inter_cu + encode_inter_cu_chroma per node, luma and both chroma
+ * planes, parent and child level) in one submission, host pointers: inter TUs read only the CU's residual and prediction, so the tree can be computed ahead of
+ * the walk that compares (cost < parent cost, :3211) and consolidates it.  In: the pointer / parameter fields; out: levels, recon, ssd, ac_sum of every entry. */
+typedef struct hmr_gpu_inter_tu_host {
+	int16_t *residual; int residual_stride;
+	int16_t *pred; int pred_stride;
+	int16_t *levels;
+	int16_t *recon; int recon_stride;
+	int size, scan_mode, comp, slice_is_intra, sign_hiding, per, rem;
+	double weight, zero_thr;
+	uint32_t ssd;
+	int ac_sum;
+} hmr_gpu_inter_tu_host;
+void hmr_gpu_inter_tu_chain_n(hmr_gpu_inter_tu_host *tus, int n);
+
 /* ------------------------------------------------------------------------------------------------
  * 8. intra mode search of one PU: homer_loop1_motion_intra (hmr_motion_intra.c:1084-1179) - reference build, smoothing,
  *    up to 13 {prediction, SAD} rounds over the search_points schedule (:1076) and the strict-< cost comparison

@@ -682,6 +682,96 @@ uint32_t encode_intra_chroma(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int d
 /* ---- encode_inter_cu / encode_inter_cu_chroma (hmr_motion_inter.c:40,133): the inter TU - DCT, quantisation, keep-or-drop decision, reconstruction in
  * one GPU call; window addressing and the bookkeeping on the partition node stay on the host ---- */
 extern const uint8_t chroma_scale_conversion_table[];
+/* ---- encode_inter (hmr_motion_inter.c:3069): the transform tree of an inter CU.  Its TUs (encode_inter_cu / _chroma per node, luma and both chroma planes, up
+ * to two levels) only read the CU's residual and prediction, so they are all computed in ONE GPU submission before the reference's own walk runs; the walk -
+ * comparison cost < parent cost (:3211), cbf consolidation, window copies - stays the reference's code and finds every TU result already in place (the two
+ * interposers below answer from this cache; a node the prediction missed is computed call by call as before). ---- */
+static __thread struct { cu_partition_info_t *cu; int comp; uint32_t ssd; int sum; } g_pre[40];
+static __thread int g_pre_n;
+static int pre_lookup(cu_partition_info_t *cu, int comp, uint32_t *ssd, int *sum)
+{
+	int i;
+	for (i = 0; i < g_pre_n; i++)
+		if (g_pre[i].cu == cu && g_pre[i].comp == comp) { *ssd = g_pre[i].ssd; *sum = g_pre[i].sum; return 1; }
+	return 0;
+}
+static void inter_tu_entry(henc_thread_t *et, cu_partition_info_t *cu, int comp, PartSize pst, int gcnt, hmr_gpu_inter_tu_host *t)
+{
+	slice_t *currslice = &et->enc_engine->current_pict.slice;
+	cu_partition_info_t *pp = (comp == Y_COMP || cu->size_chroma != 2) ? cu : cu->parent;
+	const int x = comp == Y_COMP ? cu->x_position : pp->x_position_chroma, y = comp == Y_COMP ? cu->y_position : pp->y_position_chroma;
+	const int off = et->enc_engine->chroma_qp_offset;
+	const int qp = comp == Y_COMP ? (int)cu->qp : chroma_scale_conversion_table[clip(cu->qp + off, 0, 57)];
+	wnd_t *qw = et->transform_quant_wnd[cu->depth + 1 + (pst != SIZE_2Nx2N)], *dw = et->decoded_mbs_wnd[cu->depth + 1 + (pst != SIZE_2Nx2N)];
+	memset(t, 0, sizeof *t);
+	t->size = comp == Y_COMP ? cu->size : pp->size_chroma;
+	t->residual = WND_POSITION_2D(int16_t *, et->residual_wnd, comp, x, y, gcnt, et->ctu_width); t->residual_stride = WND_STRIDE_2D(et->residual_wnd, comp);
+	t->pred = WND_POSITION_2D(int16_t *, et->prediction_wnd[0], comp, x, y, gcnt, et->ctu_width); t->pred_stride = WND_STRIDE_2D(et->prediction_wnd[0], comp);
+	t->levels = WND_POSITION_1D(int16_t *, *qw, comp, gcnt, et->ctu_width,
+				    comp == Y_COMP ? (cu->abs_index << et->num_partitions_in_cu_shift) : ((pp->abs_index << et->num_partitions_in_cu_shift) >> 2));
+	t->recon = WND_POSITION_2D(int16_t *, *dw, comp, x, y, gcnt, et->ctu_width); t->recon_stride = WND_STRIDE_2D(*dw, comp);
+	t->scan_mode = find_scan_mode(TRUE, TRUE, t->size, REG_DCT, 0);
+	t->comp = comp;
+	t->slice_is_intra = currslice->slice_type == I_SLICE;
+	t->sign_hiding = et->pps->sign_data_hiding_flag;
+	t->per = qp / 6; t->rem = qp % 6;
+	t->weight = comp == Y_COMP ? 1.0 : pow(2.0, (currslice->qp - chroma_scale_conversion_table[clip(currslice->qp + off, 0, 57)]) / 3.0);
+	t->zero_thr = clip(et->enc_engine->avg_dist / 2.5 - 5., 1., 20000.);
+}
+int encode_inter(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int depth, int part_position, PartSize part_size_type)
+{
+	static int said;
+	int r;
+	if (want("inter_cu") && want("inter_tu_chain") && !g_trace) {
+		/* which nodes the walk will code (:3094-3148) */
+		cu_partition_info_t *first[4], *nodes[20], *curr, *qnode;
+		hmr_gpu_inter_tu_host tus[40];
+		cu_partition_info_t *owner[40];
+		int nfirst = 0, nn = 0, n = 0, i, k, mtp, cu_min, log2cu = et->max_cu_size_shift - depth, qp;
+		if (log2cu < et->min_tu_size_shift + et->max_inter_tr_depth - 1 + (et->max_inter_tr_depth == 1 && part_size_type != SIZE_2Nx2N)) cu_min = et->min_tu_size_shift;
+		else {
+			cu_min = log2cu - (et->max_inter_tr_depth - 1 + (et->max_inter_tr_depth == 1 && part_size_type != SIZE_2Nx2N));
+			if (cu_min > et->max_tu_size_shift) cu_min = et->max_tu_size_shift;
+		}
+		mtp = et->max_cu_size_shift - cu_min;
+		if (et->performance_mode >= PERF_FAST_COMPUTATION) mtp = depth == 0 ? 1 : (depth + ((part_size_type != SIZE_2Nx2N) ? 1 : 0));
+		if (depth == 0 && et->max_cu_size == MAX_CU_SIZE) {
+			qnode = &ctu->partition_list[et->partition_depth_start[depth]];
+			for (k = 0; k < 4; k++) first[nfirst++] = qnode->children[k];
+		} else {
+			qnode = curr = &ctu->partition_list[et->partition_depth_start[depth]] + part_position;
+			if (et->max_inter_tr_depth == 1 && part_size_type != SIZE_2Nx2N && log2cu > mtp)
+				for (k = 0; k < 4; k++) first[nfirst++] = curr->children[k];
+			else
+				first[nfirst++] = curr;
+		}
+		qp = (int)qnode->qp;                       /* the walk stamps this QP on every node it codes (:3162) */
+		for (i = 0; i < nfirst; i++) {
+			nodes[nn++] = first[i];
+			if (first[i]->depth < mtp && nfirst == 1 && first[i]->size > 8)
+				for (k = 0; k < 4; k++) nodes[nn++] = first[i]->children[k];
+		}
+		for (i = 0; i < nn; i++) {
+			cu_partition_info_t *q = nodes[i];
+			const int is_first_child = q->parent && q->parent->children[0] == q;
+			q->qp = (uint32_t)qp;
+			owner[n] = q; inter_tu_entry(et, q, Y_COMP, part_size_type, gcnt, &tus[n++]);
+			if (q->size_chroma != 2 || is_first_child) {
+				owner[n] = q; inter_tu_entry(et, q, U_COMP, part_size_type, gcnt, &tus[n++]);
+				owner[n] = q; inter_tu_entry(et, q, V_COMP, part_size_type, gcnt, &tus[n++]);
+			}
+		}
+		if (n <= 32) {
+			hmr_gpu_inter_tu_chain_n(tus, n);
+			for (i = 0; i < n; i++) { g_pre[i].cu = owner[i]; g_pre[i].comp = tus[i].comp; g_pre[i].ssd = tus[i].ssd; g_pre[i].sum = tus[i].ac_sum; }
+			g_pre_n = n;
+			if (!said++) fprintf(stderr, "ref_swap: inter CU transform tree routed to libhomer_gpu.so\n");
+		}
+	}
+	r = ((int (*)(henc_thread_t *, ctu_info_t *, int, int, int, PartSize))REAL(encode_inter))(et, ctu, gcnt, depth, part_position, part_size_type);
+	g_pre_n = 0;
+	return r;
+}
 int encode_inter_cu(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *cu, int depth, PartSize part_size_type, int *curr_sum, int gcnt)
 {
 	static int said;
@@ -710,9 +800,13 @@ int encode_inter_cu(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *cu,
 		tr_write(&t);
 		return r_;
 	}
-	int ssd = (int)hmr_gpu_inter_tu_chain(res, WND_STRIDE_2D(et->residual_wnd, Y_COMP), pred, WND_STRIDE_2D(et->prediction_wnd[0], Y_COMP), quant, dec,
-					      WND_STRIDE_2D(*decoded_wnd, Y_COMP), size, scan_mode, Y_COMP, et->enc_engine->current_pict.slice.slice_type == I_SLICE,
-					      et->pps->sign_data_hiding_flag, cu->qp / 6, cu->qp % 6, 1.0, thr, curr_sum);
+	uint32_t pre_ssd;
+	int ssd;
+	if (pre_lookup(cu, Y_COMP, &pre_ssd, curr_sum)) ssd = (int)pre_ssd;      /* computed ahead with the rest of the CU's tree (encode_inter above) */
+	else
+		ssd = (int)hmr_gpu_inter_tu_chain(res, WND_STRIDE_2D(et->residual_wnd, Y_COMP), pred, WND_STRIDE_2D(et->prediction_wnd[0], Y_COMP), quant, dec,
+						  WND_STRIDE_2D(*decoded_wnd, Y_COMP), size, scan_mode, Y_COMP, et->enc_engine->current_pict.slice.slice_type == I_SLICE,
+						  et->pps->sign_data_hiding_flag, cu->qp / 6, cu->qp % 6, 1.0, thr, curr_sum);
 	cu->inter_cbf[Y_COMP] = ((*curr_sum ? 1 : 0) << (curr_depth - depth));
 	cu->inter_tr_idx = (curr_depth - depth);
 	cu->sum = *curr_sum;
@@ -755,9 +849,11 @@ int encode_inter_cu_chroma(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info
 		tr_write(&t);
 		return r_;
 	}
-	uint32_t ssd = hmr_gpu_inter_tu_chain(res, WND_STRIDE_2D(et->residual_wnd, component), pred, WND_STRIDE_2D(et->prediction_wnd[0], component), quant, dec,
-					      WND_STRIDE_2D(*decoded_wnd, component), size, scan_mode, component, currslice->slice_type == I_SLICE,
-					      et->pps->sign_data_hiding_flag, qp_chroma / 6, qp_chroma % 6, weight, thr, curr_sum);
+	uint32_t ssd;
+	if (!pre_lookup(cu, component, &ssd, curr_sum))
+		ssd = hmr_gpu_inter_tu_chain(res, WND_STRIDE_2D(et->residual_wnd, component), pred, WND_STRIDE_2D(et->prediction_wnd[0], component), quant, dec,
+					     WND_STRIDE_2D(*decoded_wnd, component), size, scan_mode, component, currslice->slice_type == I_SLICE,
+					     et->pps->sign_data_hiding_flag, qp_chroma / 6, qp_chroma % 6, weight, thr, curr_sum);
 	cu->inter_cbf[component] = ((*curr_sum ? 1 : 0) << (original_depth - depth));
 	cu->sum += *curr_sum;
 	(void)ctu;

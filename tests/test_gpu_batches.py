@@ -929,3 +929,38 @@ def test_inter_tu_chain_wide_residuals(rig, oracle, n):
     same(g, o, "levels, reconstruction")
     same(rig.down(d_ssd, nj, np.uint32), ssd, "ssd")
     same(rig.down(d_ac, nj, np.int32), ac, "ac_sum")
+
+
+class InterTuHost(C.Structure):
+    _fields_ = [("residual", VP), ("residual_stride", C.c_int), ("pred", VP), ("pred_stride", C.c_int), ("levels", VP), ("recon", VP), ("recon_stride", C.c_int),
+                ("size", C.c_int), ("scan_mode", C.c_int), ("comp", C.c_int), ("slice_is_intra", C.c_int), ("sign_hiding", C.c_int), ("per", C.c_int), ("rem", C.c_int),
+                ("weight", C.c_double), ("zero_thr", C.c_double), ("ssd", C.c_uint32), ("ac_sum", C.c_int)]
+
+
+def test_inter_tu_chain_n(oracle):
+    """hmr_gpu_inter_tu_chain_n: the inter TUs of a CU's transform tree (luma 16 + chroma 8 parent level, luma 8 + chroma 4 child level: 15 TUs of three sizes) in one
+    submission against the oracle TU by TU."""
+    gpu = libs.load_gpu()
+    rng = np.random.default_rng(77 + SEED)
+    oracle.ora_inter_tu_chain.restype = C.c_uint32
+    for trial in range(6):
+        plan = [(16, 0), (8, 1), (8, 2)] + [(8, 0)] * 4 + [(4, 1)] * 4 + [(4, 2)] * 4 + ([(32, 0)] if trial % 2 else [])
+        amp = [0, 2, 8, 30, 90, 250][trial]
+        tus = (InterTuHost * len(plan))()
+        keep, exp = [], []
+        for i, (n, comp) in enumerate(plan):
+            res = np.ascontiguousarray((amp * np.sin(np.arange(n * 40).reshape(n, 40) / 5.0) + rng.integers(-3, 4, (n, 40))).astype(np.int16))
+            pred = np.ascontiguousarray(rng.integers(0, 256, (n, 48)).astype(np.int16))
+            lev, rec = np.zeros(n * n, np.int16), np.zeros((n, 36), np.int16)
+            per, rem, sbh = int(rng.integers(2, 7)), int(rng.integers(0, 6)), int(rng.integers(0, 2))
+            w, thr = (1.0 if comp == 0 else 2.0 ** (int(rng.integers(-2, 5)) / 3.0)), float(np.clip(rng.uniform(0, 3000) / 2.5 - 5.0, 1.0, 20000.0))
+            tus[i] = InterTuHost(VP(res.ctypes.data), 40, VP(pred.ctypes.data), 48, VP(lev.ctypes.data), VP(rec.ctypes.data), 36, n, 3, comp, 0, sbh, per, rem, w, thr, 0, 0)
+            elev, erec, v = np.zeros(n * n, np.int16), np.zeros((n, 36), np.int16), C.c_int(0)
+            essd = oracle.ora_inter_tu_chain(VP(res.ctypes.data), 40, VP(pred.ctypes.data), 48, VP(elev.ctypes.data), VP(erec.ctypes.data), 36, n, 3, comp, 0, sbh, per, rem,
+                                             C.c_double(w), C.c_double(thr), C.byref(v))
+            keep.append((res, pred, lev, rec)); exp.append((elev, erec, essd, v.value))
+        gpu.hmr_gpu_inter_tu_chain_n.restype = None
+        gpu.hmr_gpu_inter_tu_chain_n(tus, len(plan))
+        for i, ((res, pred, lev, rec), (elev, erec, essd, eac)) in enumerate(zip(keep, exp)):
+            same(lev, elev, f"levels of TU {i}"); same(rec, erec, f"reconstruction of TU {i}")
+            assert (tus[i].ssd, tus[i].ac_sum) == (essd, eac), (trial, i, tus[i].ssd, tus[i].ac_sum, essd, eac)

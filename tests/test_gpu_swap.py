@@ -42,13 +42,15 @@ def test_stream_identical_with_gpu_kernels(tmp_path, extra, w, h, frames):
     rd_full = "rd=1" in extra
     # with full RDO the CABAC bit estimate enters the tree comparison, so the luma CU driver stays on the host and its two halves are routed instead
     drivers = ("intra mode search routed", "intra TU chain routed") if rd_full else ("luma intra CU driver routed", "chroma intra CU driver routed")
+    if not any(e.startswith("force_intra") for e in extra):
+        drivers += ("inter CU transform tree routed",)
     for what in ("table entries routed", "deblocking routed", "border padding routed", "SAO offset derivation routed") + drivers:
         assert what in log, (what, log[-600:])
     assert len(ref) > 300
     assert gpu == ref, f"stream differs: {len(gpu)} vs {len(ref)} bytes"
     if not rd_full:    # the same encode with the CU driver left to the host: search and TU chain are then routed call by call
-        low, log = _encode(SWAP, clip, str(tmp_path / "low.265"), w, h, frames, env={"HOMER_SWAP": "all,-intra_luma_cu,-intra_chroma_cu"}, extra=extra)
-        assert "luma intra CU driver routed" not in log and "chroma intra CU driver routed" not in log
+        low, log = _encode(SWAP, clip, str(tmp_path / "low.265"), w, h, frames, env={"HOMER_SWAP": "all,-intra_luma_cu,-intra_chroma_cu,-inter_cu"}, extra=extra)
+        assert "luma intra CU driver routed" not in log and "chroma intra CU driver routed" not in log and "inter CU transform tree routed" not in log
         for what in ("intra mode search routed", "intra TU chain routed"):
             assert what in log, (what, log[-600:])
         assert low == ref

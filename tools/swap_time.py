@@ -19,7 +19,7 @@ with tempfile.TemporaryDirectory() as td:
     clip = os.path.join(td, "c.yuv")
     gen_yuv.write_clip(clip, w, h, frames)
     out = {}
-    for mode in ("all", "all,-intra_luma_cu,-intra_chroma_cu", "none"):
+    for mode in ("all", "all,-intra_luma_cu,-intra_chroma_cu,-inter_cu", "none"):
         e = dict(os.environ, HOMER_SWAP=mode)
         t0 = time.perf_counter()
         r = subprocess.run([SWAP, clip, os.path.join(td, "o.265"), str(w), str(h), str(frames), *extra], capture_output=True, text=True, env=e, timeout=3000)
@@ -27,5 +27,5 @@ with tempfile.TemporaryDirectory() as td:
         assert r.returncode == 0, r.stderr[-500:]
         out[mode] = (dt, open(os.path.join(td, "o.265"), "rb").read())
         print(f"HOMER_SWAP={mode:36s} {dt:8.2f} s", flush=True)
-    assert out["all"][1] == out["none"][1] == out["all,-intra_luma_cu,-intra_chroma_cu"][1], "streams differ"
+    assert out["all"][1] == out["none"][1] == out["all,-intra_luma_cu,-intra_chroma_cu,-inter_cu"][1], "streams differ"
     print("streams identical")
