@@ -92,7 +92,7 @@ from homerhevc_amd.gpu import (CHROMA_JOB_DTYPE, INTER_TU_JOB_DTYPE, INTRA_JOB_D
                                TU_JOB_DTYPE)
 
 
-def build_groups(calls, rng, arena, fused=True, cu_driver=False, cu_rounds=True, chroma_driver=True):
+def build_groups(calls, rng, arena, fused=True, cu_driver=False, cu_rounds=True, chroma_driver=True, inter_source=True):
     """Turn the recorded call mix into batched launches.  Returns list of dict(name, fn, size, jobs, args, bytes)."""
     from homerhevc_amd.gpu import JOB_DTYPE
 
@@ -580,6 +580,11 @@ def build_groups(calls, rng, arena, fused=True, cu_driver=False, cu_rounds=True,
         eres = np.zeros((NCTU, 64, 64), np.int64)
         eres[:, 32:, :] = rng.integers(-40, 41, (NCTU, 32, 64))
         eresw = arena.alloc(NCTU * P64, eres.astype(np.int16).ravel())
+        # inter_source: the TU jobs address the source block and form the residual themselves (what the CU-level `predict` calls ahead of encode_inter write
+        # out in the reference): prediction window in 40..215, source = prediction + the residual above, so the same residuals reach the transform
+        epred = rng.integers(40, 216, (NCTU, 64, 64))
+        epredw = arena.alloc(NCTU * P64, epred.astype(np.int16).ravel()) if inter_source else predw
+        esrcw = arena.alloc(NCTU * P64, (epred + eres).astype(np.int16).ravel()) if inter_source else eresw
         for N in (4, 8, 16, 32):
             keys = {k2: v for k2, v in calls.items() if k2.split(":")[0] == "inter_tu" and int(k2.split(":")[1]) == N}
             if not keys:
@@ -603,8 +608,9 @@ def build_groups(calls, rng, arena, fused=True, cu_driver=False, cu_rounds=True,
                 x = rng.integers(0, (64 - N) // N + 1, n) * N
                 y = np.minimum(rng.integers(0, half, n) * N + np.where(coded, 32, 0), 64 - N)
                 pos_in = c * P64 + y * 64 + x
-                jb["orig_off"] = eresw + pos_in; jb["orig_stride"] = 64
-                jb["pred_off"] = predw + pos_in; jb["pred_stride"] = 64
+                jb["orig_off"] = esrcw + pos_in; jb["orig_stride"] = 64
+                jb["pred_off"] = epredw + pos_in; jb["pred_stride"] = 64
+                jb["reserved"] = 1 if inter_source else 0
                 jb["rec_off"] = recw + pos_in; jb["rec_stride"] = 64
                 jb["p0"] = 3 | (comp << 2) | (0 << 4) | (0 << 5) | (1 << 6)
                 jb["p1"] = 5 | (2 << 8)
@@ -719,6 +725,17 @@ def build_groups(calls, rng, arena, fused=True, cu_driver=False, cu_rounds=True,
                 g["bytes"] = keep * 6 * N * N
                 if keep == 0:
                     del merged[("predict", N)]
+    if fused and inter_source:
+        # the predict calls left over are the CU-level residuals ahead of encode_inter: the inter TU jobs form them themselves and are priced with their bytes
+        left = [k for k in merged if k[0] == "predict"]
+        pred_bytes = sum(merged[k]["bytes"] for k in left)
+        tus_ = [g for k, g in merged.items() if k[0] == "inter_tu"]
+        if tus_ and left:
+            total = sum(g["bytes"] for g in tus_)
+            for g in tus_:
+                g["bytes"] += int(pred_bytes * g["bytes"] / total)
+            for k in left:
+                del merged[k]
     for g in merged.values():      # a batch is issued in CTU order, like the host would enumerate it
         order = np.argsort(g["ctu"], kind="stable")
         g["jobs"] = np.ascontiguousarray(g["jobs"][order])
@@ -821,6 +838,9 @@ def main():
                     help="add the SAO offset derivation (hmr_gpu_sao_offsets_frame, a launch between SAO statistics and SAO apply) to the frame: not a table call of the "
                          "recorded mix, the device-side part of the SAO decision")
     ap.add_argument("--no-multi", action="store_true", help="one launch per (pixel kernel, block size) instead of one multi-segment launch per pixel kernel")
+    ap.add_argument("--no-inter-source", action="store_true",
+                    help="replay the CU-level `predict` calls ahead of encode_inter as their own jobs and feed the inter TU chains from the residual plane, instead of "
+                         "letting the inter TU jobs form the residual from source and prediction")
     ap.add_argument("--no-chroma-driver", action="store_true",
                     help="replay the table calls of the chroma CU drivers (encode_intra_chroma) one by one instead of as search + TU launches per chroma CU size")
     ap.add_argument("--cu-driver", action="store_true",
@@ -870,7 +890,7 @@ def main():
 
         rng = np.random.default_rng(1234 + rank + 1000 * e)
         arena = Arena()
-        groups, planes = build_groups(calls, rng, arena, fused=not args.unfused, cu_driver=args.cu_driver, cu_rounds=not args.cu_child_launches, chroma_driver=not args.no_chroma_driver)
+        groups, planes = build_groups(calls, rng, arena, fused=not args.unfused, cu_driver=args.cu_driver, cu_rounds=not args.cu_child_launches, chroma_driver=not args.no_chroma_driver, inter_source=not args.no_inter_source)
         if os.environ.get("HOMER_BENCH_DROP"):      # experiments only (what would a launch cost if it were free?): the record is marked
             drop = set(os.environ["HOMER_BENCH_DROP"].split(","))
             groups = [g for g in groups if g["name"] not in drop and f"{g['name']}:{g['size']}" not in drop]

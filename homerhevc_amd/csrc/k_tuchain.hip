@@ -116,6 +116,12 @@ struct alignas(16) TuLdsIntra {
 };
 template <int N, int MODE> constexpr int tu_lds_bytes() { return (int)sizeof(TuLds<N>) + (MODE == TU_INTRA ? (int)sizeof(TuLdsIntra<N>) : 0); }
 
+// inter TU jobs whose `reserved` word carries bit 0 address the SOURCE picture: the residual (source - prediction, 16-bit wrap: the `predict` call the
+// reference issues per CU ahead of encode_inter) is formed in the kernel and never written out
+__device__ __forceinline__ bool inter_from_source(const hmr_gpu_inter_tu_job &jb) { return (jb.reserved & 1u) != 0; }
+__device__ __forceinline__ bool inter_from_source(const hmr_gpu_tu_job &) { return false; }
+__device__ __forceinline__ bool inter_from_source(const hmr_gpu_itu_job &) { return false; }
+
 template <int N, int MODE>
 __device__ __forceinline__ void tu_chain_body(const void *__restrict__ jobs_v, int njobs, const int16_t *__restrict__ O, int16_t *__restrict__ Pp,
 					      int16_t *__restrict__ L, int16_t *__restrict__ Rr, uint32_t *__restrict__ ssd_out, int32_t *__restrict__ ac_out,
@@ -211,9 +217,15 @@ __device__ __forceinline__ void tu_chain_body(const void *__restrict__ jobs_v, i
 #pragma unroll
 			for (int i = 0; i < N / 4; i++) {
 				const i16x4 vo = ld4(orow_p + 4 * i);
-				if constexpr (INTER) {     // O is the residual plane
-					r[2 * i] = pack2(vo.v[0], vo.v[1]);
-					r[2 * i + 1] = pack2(vo.v[2], vo.v[3]);
+				if constexpr (INTER) {     // O is the residual plane - or the source picture, the residual then formed here like `predict` forms it
+					if (inter_from_source(jb)) {
+						const i16x4 vp = ld4(prow_p + 4 * i);
+						r[2 * i] = pack2((int16_t)(vo.v[0] - vp.v[0]), (int16_t)(vo.v[1] - vp.v[1]));
+						r[2 * i + 1] = pack2((int16_t)(vo.v[2] - vp.v[2]), (int16_t)(vo.v[3] - vp.v[3]));
+					} else {
+						r[2 * i] = pack2(vo.v[0], vo.v[1]);
+						r[2 * i + 1] = pack2(vo.v[2], vo.v[3]);
+					}
 				} else {
 					const i16x4 vp = ld4(prow_p + 4 * i);
 					r[2 * i] = pack2((int16_t)(vo.v[0] - vp.v[0]), (int16_t)(vo.v[1] - vp.v[1]));
@@ -401,7 +413,12 @@ __device__ __forceinline__ void tu_chain_body(const void *__restrict__ jobs_v, i
 			int16_t *ro = ok ? Rr + jb.rec_off + (size_t)row * jb.rec_stride : nullptr;
 			if (ok) {
 				auto emit4 = [&](int xb, const int (&res)[4]) {
-					const i16x4 vr = ld4(orow_p + xb), vp = ld4(prow_p + xb);
+					i16x4 vr = ld4(orow_p + xb);
+					const i16x4 vp = ld4(prow_p + xb);
+					if (inter_from_source(jb)) {
+#pragma unroll
+						for (int q = 0; q < 4; q++) vr.v[q] = (int16_t)(vr.v[q] - vp.v[q]);
+					}
 					i16x4 outv;
 #pragma unroll
 					for (int q = 0; q < 4; q++) {

@@ -421,9 +421,11 @@ typedef struct hmr_gpu_inter_tu_job {
 	uint32_t rec_off, rec_stride;     /* reconstruction out */
 	uint32_t lev_off;                 /* quantised levels out, linear size*size */
 	uint32_t p0, p1;                  /* as hmr_gpu_tu_job (is_intra = 0, is_dst = 0) */
-	uint32_t reserved;
+	uint32_t reserved;                /* bit 0 (HMR_GPU_INTER_TU_FROM_SOURCE): orig_off addresses the SOURCE block and the residual = source - prediction (16-bit wrap, the
+	                                   * `predict` call the reference issues per CU ahead of encode_inter, hmr_motion_inter.c:3054-3056) is formed in the kernel */
 	double weight, zero_thr;
 } hmr_gpu_inter_tu_job;
+#define HMR_GPU_INTER_TU_FROM_SOURCE 1u
 int hmr_gpu_inter_tu_chain_batch(hmr_gpu_ctx *ctx, const hmr_gpu_inter_tu_job *jobs, int njobs, int size, const int16_t *residual_base, const int16_t *pred_base,
 				 int16_t *level_base, int16_t *recon_base, uint32_t *ssd, int32_t *ac_sum);
 uint32_t hmr_gpu_inter_tu_chain(int16_t *residual, int residual_stride, int16_t *pred, int pred_stride, int16_t *levels, int16_t *recon, int recon_stride, int size,

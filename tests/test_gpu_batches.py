@@ -964,3 +964,44 @@ def test_inter_tu_chain_n(oracle):
         for i, ((res, pred, lev, rec), (elev, erec, essd, eac)) in enumerate(zip(keep, exp)):
             same(lev, elev, f"levels of TU {i}"); same(rec, erec, f"reconstruction of TU {i}")
             assert (tus[i].ssd, tus[i].ac_sum) == (essd, eac), (trial, i, tus[i].ssd, tus[i].ac_sum, essd, eac)
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_inter_tu_chain_from_source(rig, oracle, n):
+    """Inter TU jobs that address the SOURCE block (HMR_GPU_INTER_TU_FROM_SOURCE): the kernel forms the residual the reference's `predict` call would have
+    written (source - prediction, 16-bit wrap) and must leave what predict + the inter TU chain leave."""
+    rng = np.random.default_rng(n + 23 + 1000 * SEED)
+    nj = rig.nj
+    yy, xx = np.mgrid[0:PH, 0:PW]
+    amp = np.repeat(np.repeat(rng.choice([0, 2, 5, 15, 60], (PH // 32, PW // 32)), 32, 0), 32, 1)
+    src = np.clip(128 + 50 * np.sin(xx / 9.0 + yy / 13.0), 0, 255)
+    rig.host[rig.pix:rig.res] = src.astype(np.int16).ravel()                                                              # source picture
+    rig.host[rig.res:rig.mid] = np.clip(src - amp * np.sin(xx / 5.0 + yy / 7.0) - rng.integers(-2, 3, (PH, PW)) * (amp > 0), 0, 255).astype(np.int16).ravel()   # prediction
+    jb = np.zeros(nj, INTER_TU_JOB)
+    x = rng.integers(0, PW - n + 1, nj); y = rng.integers(0, PH - n + 1, nj)
+    jb["orig_off"] = rig.pix + y * PW + x; jb["orig_stride"] = PW
+    jb["pred_off"] = rig.res + y * PW + x; jb["pred_stride"] = PW
+    jb["rec_off"] = rig.slots(rig.out1); jb["rec_stride"] = 80
+    jb["lev_off"] = rig.slots(rig.out2)
+    jb["reserved"] = 1
+    comp = rng.integers(0, 3 if n < 32 else 1, nj); sbh = rng.integers(0, 2, nj)
+    per, rem = rng.integers(2, 7, nj), rng.integers(0, 6, nj)
+    jb["p0"] = 3 | (comp << 2) | (sbh << 6); jb["p1"] = per | (rem << 8)
+    jb["weight"] = np.where(comp == 0, 1.0, 2.0 ** (rng.integers(-2, 5, nj) / 3.0))
+    jb["zero_thr"] = np.clip(rng.uniform(0, 3000, nj) / 2.5 - 5.0, 1.0, 20000.0)
+    d_ssd = rig.malloc(4 * nj); d_ac = rig.malloc(4 * nj); rig.bufs += [d_ssd, d_ac]
+    g = rig.launch("hmr_gpu_inter_tu_chain_batch", rig.up(jb), nj, n, rig.dev, rig.dev, rig.dev, rig.dev, d_ssd, d_ac)
+    o = rig.host.copy()
+    ssd, ac = np.zeros(nj, np.uint32), np.zeros(nj, np.int32)
+    oracle.ora_inter_tu_chain.restype = C.c_uint32
+    res = np.zeros((n, n), np.int16)
+    for i, j in enumerate(jb):
+        v = C.c_int(0)
+        oracle.ora_predict(at(o, j["orig_off"]), PW, at(o, j["pred_off"]), PW, VP(res.ctypes.data), n, n)
+        ssd[i] = oracle.ora_inter_tu_chain(VP(res.ctypes.data), n, at(o, j["pred_off"]), PW, at(o, j["lev_off"]), at(o, j["rec_off"]), 80, n, 3, int(comp[i]), 0,
+                                           int(sbh[i]), int(per[i]), int(rem[i]), C.c_double(float(j["weight"])), C.c_double(float(j["zero_thr"])), C.byref(v))
+        ac[i] = v.value
+    same(g, o, "levels, reconstruction")
+    same(rig.down(d_ssd, nj, np.uint32), ssd, "ssd")
+    same(rig.down(d_ac, nj, np.int32), ac, "ac_sum")
+    assert (ac != 0).sum() > 20 and ((ac == 0) & (ssd != 0)).sum() > 5
