@@ -1230,7 +1230,10 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
             "config": {"workload": WORKLOAD, "width": W, "height": H, "qp": 32, "gop": "IPPP gop_size=1", "me": "quarter-pel", "sao": 1,
-                       "calls_per_frame": int(sum(len(g["jobs"]) for g in groups)), "launches_per_frame": len(groups) + 8 + (0 if (not args.sao_offsets) else 1), **({"EXPERIMENT_dropped_groups": os.environ["HOMER_BENCH_DROP"]} if os.environ.get("HOMER_BENCH_DROP") else {}),
+                       "calls_per_frame": int(sum(len(g["jobs"]) for g in groups)), "launches_per_frame": len(groups) + 8 + (0 if (not args.sao_offsets) else 1),
+                       "replay": {"fused_call_sequences": not args.unfused, "chroma_cu_drivers": not args.no_chroma_driver and not args.unfused,
+                                  "inter_residual_in_kernel": not args.no_inter_source and not args.unfused, "luma_cu_driver_chains": bool(args.cu_driver),
+                                  "multi_segment_launches_up_to_MB": None if args.no_multi else args.multi_max_mb, "sao_offsets_launch": bool(args.sao_offsets)}, **({"EXPERIMENT_dropped_groups": os.environ["HOMER_BENCH_DROP"]} if os.environ.get("HOMER_BENCH_DROP") else {}),
                        "callmix_frame": args.callmix_frame, "parallelism": f"{len(engines)} engine(s) per gpu x{world}", "frames_per_step": len(engines) * world, "launch_mode": args.mode, "graph_branches": args.branches if args.mode == "graph" else 1, "tu_chain": "7 separate batches" if args.unfused else "fused kernel",
                        "algorithmic_MB_per_frame_abi_width": round(total_alg / 1e6, 2), "compulsory_MB_per_frame": round(10.5 * W * H / 1e6, 2)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
