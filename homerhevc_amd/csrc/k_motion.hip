@@ -238,6 +238,17 @@ __global__ __launch_bounds__(MeGeo<N>::WPB * 64) void k_motion_estimation(const 
 					int c[8];
 #pragma unroll
 					for (int k = 0; k < 8; k++) c[k] = cLumaTaps[fx][k];
+					if (fx == 0) {       // integer column: the filter is the single tap 64 on the centre sample - 64 * x - 8192 without the seven zero products
+						for (int e = lane; e < g::TR * CPR; e += 64) {
+							const int r = e / CPR, x = (e % CPR) * 4;
+							const i16x4 v = ld4(p0 + (size_t)r * rs + x + 3);
+							i16x4 o;
+#pragma unroll
+							for (int k = 0; k < 4; k++) o.v[k] = (int16_t)(64 * v.v[k] - 8192);
+							st4(&sTile[w][t][r * N + x], o);
+						}
+						continue;
+					}
 					for (int e = lane; e < g::TR * CPR; e += 64) {
 						const int r = e / CPR, x = (e % CPR) * 4;
 						int sm[4];
@@ -258,7 +269,12 @@ __global__ __launch_bounds__(MeGeo<N>::WPB * 64) void k_motion_estimation(const 
 				const int16_t *tile = &sTile[w][t][(4 + iy - 3) * N];
 				const int y = e / CPR, x = (e % CPR) * 4;
 				int sm[4];
-				mc_ver4<8>(tile + y * N + x, N, c, sm);
+				if (fy == 0) {          // integer row: single tap 64 on the centre row
+					const i16x4 v = ld4(tile + (y + 3) * N + x);
+#pragma unroll
+					for (int k = 0; k < 4; k++) sm[k] = 64 * v.v[k];
+				} else
+					mc_ver4<8>(tile + y * N + x, N, c, sm);
 				int pv[4];
 #pragma unroll
 				for (int k = 0; k < 4; k++) pv[k] = clip3i(sat16i((sm[k] + 2048 + (8192 << 6)) >> 12), 0, 255);   // not first, last
