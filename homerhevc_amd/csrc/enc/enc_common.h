@@ -1,0 +1,149 @@
+// Context of one CTU worker and the helpers shared by the intra and inter decision code:
+// neighbour lookup over the partition tree and the window consolidation copies.
+#pragma once
+#include "enc_prims.h"
+
+#if !defined(__HIPCC__) && defined(HENC_TRACE_ENABLE)
+#include <stdio.h>
+extern "C" FILE *henc_trace_file;
+#define HENC_TRACE(...) do { if (henc_trace_file) fprintf(henc_trace_file, __VA_ARGS__); } while (0)
+#else
+#define HENC_TRACE(...) do { } while (0)
+#endif
+
+namespace henc {
+
+struct Enc {
+	const Seq *seq;
+	const FrameCtx *f;
+	const DevTables *T;
+	const Geo *geo;
+	CtuInfo *ctus;         // all CTUs of the picture (persistent across frames)
+	CtuInfo *ctu;          // the CTU being encoded
+	Work *w;
+	int16_t *coeff;        // the CTU's coefficient output: 4096 luma + 2 x 1024 chroma, linear per TU in z-order
+	// speculative inputs of a P-frame CTU (enc_ctu.h)
+	uint32_t total_intra_partitions, total_partitions;
+};
+
+HENC_INLINE Node &node_of(Enc &e, int idx) { return e.ctu->nodes[idx]; }
+HENC_INLINE int node_at(const Enc &e, int depth, int position) { return e.seq->depth_start[depth] + position; }
+
+// ---- neighbour partitions (hmr_arithmetic_encoding.c:229-355).  Return the CTU that holds the neighbour (nullptr when not
+// available) and its z-order unit index. -------------------------------------------------------------------------------
+HENC_INLINE CtuInfo *ctu_left_of(Enc &e) { return e.ctu->has_left ? e.ctu - 1 : nullptr; }
+HENC_INLINE CtuInfo *ctu_top_of(Enc &e) { return e.ctu->has_top ? e.ctu - e.seq->wctu : nullptr; }
+HENC_INLINE CtuInfo *ctu_top_right_of(Enc &e) { return e.ctu->has_top_right ? e.ctu - e.seq->wctu + 1 : nullptr; }
+HENC_INLINE CtuInfo *ctu_top_left_of(Enc &e) { return e.ctu->has_top_left ? e.ctu - e.seq->wctu - 1 : nullptr; }
+
+HENC_INLINE CtuInfo *pu_left(Enc &e, int ni, uint32_t *idx)
+{
+	const Geo &gq = e.geo[ni];
+	*idx = gq.abs_left;
+	return (gq.raster_index & 15) == 0 ? ctu_left_of(e) : e.ctu;
+}
+HENC_INLINE CtuInfo *pu_left_bottom(Enc &e, int ni, uint32_t *idx)
+{
+	const Geo &gq = e.geo[ni];
+	if (!node_of(e, ni).left_bottom_nb) return nullptr;
+	*idx = gq.abs_left_bottom;
+	if (gq.raster_index == NPART - 16) return nullptr;                     // ctu_left_bottom never exists in raster / wavefront order
+	if ((gq.raster_index & 15) == 0) return ctu_left_of(e);
+	if (gq.raster_index >= NPART - 16) return nullptr;
+	if (gq.abs_index > gq.abs_left_bottom) return e.ctu;
+	return nullptr;
+}
+HENC_INLINE CtuInfo *pu_top(Enc &e, int ni, uint32_t *idx, int planar_at_ctu_boundary)
+{
+	const Geo &gq = e.geo[ni];
+	*idx = gq.abs_top;
+	if (gq.raster_index < 16) return planar_at_ctu_boundary ? nullptr : ctu_top_of(e);
+	return e.ctu;
+}
+HENC_INLINE CtuInfo *pu_top_right(Enc &e, int ni, uint32_t *idx)
+{
+	const Geo &gq = e.geo[ni];
+	if (!node_of(e, ni).top_right_nb) return nullptr;
+	*idx = gq.abs_top_right;
+	if (gq.raster_index == 15) return ctu_top_right_of(e);
+	if (gq.raster_index < 16) return ctu_top_of(e);
+	if ((gq.raster_index & 15) == 15) return nullptr;
+	if (gq.abs_index > gq.abs_top_right) return e.ctu;
+	return nullptr;
+}
+HENC_INLINE CtuInfo *pu_top_left(Enc &e, int ni, uint32_t *idx)
+{
+	const Geo &gq = e.geo[ni];
+	*idx = gq.abs_top_left;
+	if (gq.raster_index == 0) return ctu_top_left_of(e);
+	if (gq.raster_index < 16) return ctu_top_of(e);
+	if ((gq.raster_index & 15) == 0) return ctu_left_of(e);
+	return e.ctu;
+}
+
+// ---- window consolidation (hmr_motion_intra.c:844-890, hmr_motion_intra_chroma.c:29-90, hmr_mem_transfer.c:125-176) -------
+// bottom row and right column of a CU, luma: what later blocks of a deeper window need as neighbours
+template <class G>
+HENC_HD void sync_reference_buffs(const G &g, Enc &e, int ni, int src_wnd, int dst_wnd)
+{
+	const Geo &q = e.geo[ni];
+	const int16_t *s = dec_ptr(*e.w, src_wnd, COMP_Y) + q.y * DEC_STRIDE_Y + q.x;
+	int16_t *d = dec_ptr(*e.w, dst_wnd, COMP_Y) + q.y * DEC_STRIDE_Y + q.x;
+	const int n = q.size;
+	for (int i = g.tid; i < 2 * n - 1; i += g.n) {
+		const int off = i < n ? (n - 1) * DEC_STRIDE_Y + i : (i - n) * DEC_STRIDE_Y + n - 1;
+		d[off] = s[off];
+	}
+	g.sync();
+}
+template <class G>
+HENC_HD void sync_reference_buffs_chroma(const G &g, Enc &e, int ni, int src_wnd, int dst_wnd)
+{
+	const Geo &q = e.geo[ni];
+	const int n = q.size_chroma;
+	for (int c = COMP_U; c <= COMP_V; c++) {
+		const int16_t *s = dec_ptr(*e.w, src_wnd, c) + q.yc * DEC_STRIDE_C + q.xc;
+		int16_t *d = dec_ptr(*e.w, dst_wnd, c) + q.yc * DEC_STRIDE_C + q.xc;
+		for (int i = g.tid; i < 2 * n - 1; i += g.n) {
+			const int off = i < n ? (n - 1) * DEC_STRIDE_C + i : (i - n) * DEC_STRIDE_C + n - 1;
+			d[off] = s[off];
+		}
+	}
+	g.sync();
+}
+// whole CU: reconstruction (2-D) and levels (linear), one component
+template <class G>
+HENC_HD void sync_cu_comp(const G &g, Enc &e, int ni, int q_src, int q_dst, int d_src, int d_dst, int comp)
+{
+	const Geo &q = e.geo[ni];
+	const int n = comp == COMP_Y ? q.size : q.size_chroma, x = comp == COMP_Y ? q.x : q.xc, y = comp == COMP_Y ? q.y : q.yc;
+	const int st = dec_stride(comp), off = comp == COMP_Y ? (q.abs_index << 4) : ((q.abs_index << 4) >> 2);
+	const int16_t *ds = dec_ptr(*e.w, d_src, comp) + y * st + x;
+	int16_t *dd = dec_ptr(*e.w, d_dst, comp) + y * st + x;
+	const int16_t *qs = tq_ptr(*e.w, q_src, comp) + off;
+	int16_t *qd = tq_ptr(*e.w, q_dst, comp) + off;
+	for (int i = g.tid; i < n * n; i += g.n) {
+		const int r = i / n, c = i - r * n;
+		dd[r * st + c] = ds[r * st + c];
+		qd[i] = qs[i];
+	}
+	g.sync();
+}
+template <class G>
+HENC_HD void sync_motion_buffers_luma(const G &g, Enc &e, int ni, int q_src, int q_dst, int d_src, int d_dst)
+{
+	sync_cu_comp(g, e, ni, q_src, q_dst, d_src, d_dst, COMP_Y);
+}
+template <class G>
+HENC_HD void sync_motion_buffers_chroma(const G &g, Enc &e, int ni, int q_src, int q_dst, int d_src, int d_dst)
+{
+	sync_cu_comp(g, e, ni, q_src, q_dst, d_src, d_dst, COMP_U);
+	sync_cu_comp(g, e, ni, q_src, q_dst, d_src, d_dst, COMP_V);
+}
+
+// cost helpers (hmr_common.h:53-59): the reference's macros with their operand types
+HENC_INLINE double calc_mv_correction(uint32_t qp, double avg_dist) { return qp * hclip(avg_dist / 2000., .15, 1.4); }
+HENC_INLINE double depth_term(double avg_dist, int depth) { return (hclip(avg_dist - 400, 40., avg_dist) / 1.75) * depth; }
+HENC_INLINE double cost_rd(double avg_dist, uint32_t sum) { return hclip(avg_dist / 1.75, 0., 20000.) * sum; }
+
+}  // namespace henc

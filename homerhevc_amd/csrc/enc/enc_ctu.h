@@ -1,0 +1,651 @@
+// The CTU decision drivers: the depth-first walk over the coding quadtree for P slices (motion_inter_full,
+// hmr_motion_inter.c:3746-4263) and I slices (motion_intra_cu, hmr_motion_intra.c:1759-1990), the merge evaluation
+// (check_rd_cost_merge_2nx2n :3493-3742), the buffer consolidation between depths (:3298-3487), and the CTU set-up /
+// tear-down the WPP thread does around them (wfpp_encoder_thread hmr_encoder_lib.c:2897-2945, init_ctu :2254,
+// create_partition_ctu_neighbours hmr_motion_intra.c:658, hmr_mem_transfer.c:284-419).
+#pragma once
+#include "enc_intra.h"
+#include "enc_inter.h"
+
+namespace henc {
+
+// ---- info-buffer shuffles ----------------------------------------------------------------------------------------------
+// CONSOLIDATE_ENC_INFO_BUFFS :3298 (dir = 0: CTU arrays <- worker buffers of `depth`) and its inverse (get_back :3461-3466,
+// consolidate_info_buffers_for_rd hmr_motion_intra.c:1632)
+template <class G>
+HENC_HD void info_buffs_copy(const G &g, Enc &e, int depth, int abs_idx, int num, int to_ctu)
+{
+	Work &w = *e.w;
+	CtuInfo &c = *e.ctu;
+	for (int i = g.tid; i < num; i += g.n) {
+		const int k = abs_idx + i;
+		if (to_ctu) {
+			c.cbf[0][k] = w.cbf_buffs[0][depth][k];
+			c.cbf[1][k] = w.cbf_buffs[1][depth][k];
+			c.cbf[2][k] = w.cbf_buffs[2][depth][k];
+			c.tr_idx[k] = w.tr_idx_buffs[depth][k];
+			c.intra_mode[0][k] = w.intra_mode_buffs[0][depth][k];
+			c.intra_mode[1][k] = w.intra_mode_buffs[1][depth][k];
+		} else {
+			w.cbf_buffs[0][depth][k] = c.cbf[0][k];
+			w.cbf_buffs[1][depth][k] = c.cbf[1][k];
+			w.cbf_buffs[2][depth][k] = c.cbf[2][k];
+			w.tr_idx_buffs[depth][k] = c.tr_idx[k];
+			w.intra_mode_buffs[0][depth][k] = c.intra_mode[0][k];
+			w.intra_mode_buffs[1][depth][k] = c.intra_mode[1][k];
+		}
+	}
+	g.sync();
+}
+
+// SET_INTER_INFO_BUFFS :3309
+template <class G>
+HENC_HD void set_inter_info_buffs(const G &g, Enc &e, int ni)
+{
+	const Geo &q = e.geo[ni];
+	const Node &nd = node_of(e, ni);
+	CtuInfo &c = *e.ctu;
+	const int a = q.abs_index, n = q.num_part;
+	if (nd.prediction_mode == PM_INTER) {
+		for (int i = g.tid; i < n; i += g.n) {
+			c.inter_mode[a + i] = (uint8_t)nd.inter_mode;
+			c.skipped[a + i] = (uint8_t)nd.skipped;
+			c.merge[a + i] = (uint8_t)nd.merge_flag;
+			c.merge_idx[a + i] = (uint8_t)nd.merge_idx;
+			c.mv_ref_idx[a + i] = (int8_t)nd.inter_ref_index;
+			if (nd.inter_mode & 1) c.mv_ref[a + i] = nd.inter_mv;
+		}
+		if (nd.inter_mode & 1) {
+			c.mv_diff_ref_idx[a] = (uint8_t)nd.best_candidate_idx;
+			c.mv_diff[a] = nd.best_dif_mv;
+		}
+	} else {
+		for (int i = g.tid; i < n; i += g.n) {
+			c.mv_ref_idx[a + i] = -1;
+			c.skipped[a + i] = 0;
+			c.merge[a + i] = 0;
+		}
+	}
+	for (int i = g.tid; i < n; i += g.n) c.pred_mode[a + i] = (uint8_t)nd.prediction_mode;
+	g.sync();
+}
+
+// get_back_consolidated_info :3456 / put_consolidated_info :3472
+template <class G>
+HENC_HD void get_back_consolidated_info(const G &g, Enc &e, int ni, int depth)
+{
+	info_buffs_copy(g, e, depth, e.geo[ni].abs_index, e.geo[ni].num_part, 0);
+	sync_motion_buffers_luma(g, e, ni, 0, depth + 1, 0, depth + 1);
+	sync_motion_buffers_chroma(g, e, ni, 0, depth + 1, 0, depth + 1);
+}
+template <class G>
+HENC_HD void put_consolidated_info(const G &g, Enc &e, int ni, int depth)
+{
+	info_buffs_copy(g, e, depth, e.geo[ni].abs_index, e.geo[ni].num_part, 1);
+	sync_motion_buffers_luma(g, e, ni, depth + 1, 0, depth + 1, 0);
+	sync_motion_buffers_chroma(g, e, ni, depth + 1, 0, depth + 1, 0);
+}
+
+// consolidate_prediction_info :3372
+template <class G>
+HENC_HD void consolidate_prediction_info(const G &g, Enc &e, int pi, uint32_t parent_cost, uint32_t children_cost, int is_max_depth, uint32_t *cost_sum)
+{
+	const Geo &pq = e.geo[pi];
+	Node &pn = node_of(e, pi);
+	CtuInfo &c = *e.ctu;
+	const int abs_index = pq.abs_index, num = pq.num_part, curr_depth = pq.depth + 1;
+	uint32_t children_sum = 0;
+	if (pq.child[0] >= 0)
+		children_sum = node_of(e, pq.child[0]).sum + node_of(e, pq.child[1]).sum + node_of(e, pq.child[2]).sum + node_of(e, pq.child[3]).sum;
+	if (children_cost < parent_cost || !(pn.b_inside && pn.r_inside)) {
+		const int part2 = curr_depth < e.seq->max_pred_depth ? PART_2Nx2N : PART_NxN;
+		if (cost_sum) {
+			cost_sum[pq.depth] -= parent_cost;
+			cost_sum[pq.depth] += children_cost;
+		}
+		pn.cost = children_cost;
+		pn.distortion = node_of(e, pq.child[0]).distortion + node_of(e, pq.child[1]).distortion + node_of(e, pq.child[2]).distortion + node_of(e, pq.child[3]).distortion;
+		pn.sum = children_sum;
+		if (is_max_depth) {
+			sync_motion_buffers_luma(g, e, pi, curr_depth + 1, 0, curr_depth + 1, 0);
+			sync_motion_buffers_chroma(g, e, pi, curr_depth + 1, 0, curr_depth + 1, 0);
+			info_buffs_copy(g, e, curr_depth, abs_index, num, 1);
+			for (int k = 0; k < 4; k++) {
+				const int ci = pq.child[k];
+				set_inter_info_buffs(g, e, ci);
+				const Geo &cq = e.geo[ci];
+				const uint8_t qp = (uint8_t)node_of(e, ci).qp;
+				for (int i = g.tid; i < cq.num_part; i += g.n) c.qp[cq.abs_index + i] = qp;
+			}
+			for (int i = g.tid; i < num; i += g.n) {
+				c.pred_depth[abs_index + i] = (uint8_t)(curr_depth - (part2 == PART_NxN));
+				c.part_size_type[abs_index + i] = (uint8_t)part2;
+			}
+			g.sync();
+		}
+	} else {
+		const int part2 = pq.depth < e.seq->max_pred_depth ? PART_2Nx2N : PART_NxN;
+		const int parent_depth = pq.depth;
+		sync_motion_buffers_luma(g, e, pi, parent_depth + 1, 0, parent_depth + 1, 0);
+		sync_motion_buffers_chroma(g, e, pi, parent_depth + 1, 0, parent_depth + 1, 0);
+		info_buffs_copy(g, e, parent_depth, abs_index, num, 1);
+		set_inter_info_buffs(g, e, pi);
+		const uint8_t qp = (uint8_t)pn.qp;
+		for (int i = g.tid; i < num; i += g.n) {
+			c.qp[abs_index + i] = qp;
+			c.pred_depth[abs_index + i] = (uint8_t)(pq.depth - (part2 == PART_NxN));
+			c.part_size_type[abs_index + i] = (uint8_t)part2;
+		}
+		g.sync();
+	}
+}
+
+// the reference-sample refresh after a CU (sub)tree is final: bottom row / right column of the consolidated reconstruction
+// into the deeper windows (hmr_motion_inter.c:3985-4001 and :4222-4230, hmr_motion_intra.c:1899-1916, 1956-1974)
+template <class G>
+HENC_HD void refresh_deeper_windows(const G &g, Enc &e, int aux_ni, int from_depth, int with_info)
+{
+	const int max_processing_depth = hmin(e.seq->max_pred_depth + e.seq->max_intra_tr_depth - 1, NDEPTH - 1);
+	if (from_depth > max_processing_depth) return;
+	const Geo &q = e.geo[aux_ni];
+	for (int aux_depth = from_depth; aux_depth <= max_processing_depth; aux_depth++) {
+		sync_reference_buffs(g, e, aux_ni, 0, aux_depth + 1);
+		if (with_info && e.seq->rd_mode != RDM_DIST_ONLY) info_buffs_copy(g, e, aux_depth, q.abs_index, q.num_part, 0);
+	}
+	sync_reference_buffs_chroma(g, e, aux_ni, 0, NWND - 1);
+}
+
+// encode_intra, hmr_motion_intra.c:1731
+template <class G>
+HENC_HD uint32_t encode_intra(const G &g, Enc &e, int curr_depth, int position, int part_size_type)
+{
+	uint32_t cost = 0;
+	if (part_size_type == PART_2Nx2N) {
+		const uint32_t cl = encode_intra_luma(g, e, curr_depth, position, part_size_type);
+		const uint32_t cc = encode_intra_chroma(g, e, curr_depth, position, part_size_type);
+		cost = cl + cc;
+	} else {
+		for (int n = 0; n < 4; n++) {
+			node_of(e, node_at(e, curr_depth, position) + n).qp = (uint32_t)e.f->qp;
+			cost += encode_intra_luma(g, e, curr_depth, position + n, part_size_type);
+		}
+		cost += encode_intra_chroma(g, e, curr_depth, position, part_size_type);
+	}
+	return cost;
+}
+
+// check_rd_cost_merge_2nx2n :3493 (P slice)
+template <class G>
+HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &e, int depth, int position)
+{
+	Work &w = *e.w;
+	const Seq &S = *e.seq;
+	const int ni = node_at(e, depth, position);
+	const Geo &q = e.geo[ni];
+	Node &nd = node_of(e, ni);
+	CtuInfo &c = *e.ctu;
+	const int abs_index = q.abs_index, curr_depth = q.depth, n = q.size, nc = q.size_chroma;
+	const int gx = c.x + q.x, gy = c.y + q.y;
+	int merge_cand_buffer[5] = {0, 0, 0, 0, 0};
+	int best_is_skip = 0, best_candidate = 0;
+	uint32_t dist, best_dist = MAX_COST, cost, best_cost = MAX_COST, best_sum = 0;
+	MV best_mv = {0, 0};
+	int best_ref_idx = 0;
+	uint8_t inter_modes[5] = {255, 255, 255, 255, 255};
+	const double weight = e.f->chroma_weight;
+	get_merge_candidates(e, ni, w.merge_cands, inter_modes);
+	for (int cand = 0; cand < S.num_merge_cand; cand++) {
+		int mc_done = 0;
+		for (int no_res = 0; no_res < 2; no_res++) {
+			if (no_res == 1 && merge_cand_buffer[cand] == 1) continue;
+			if (best_is_skip && no_res == 0) continue;
+			if (!mc_done) {
+				const MV mv = w.merge_cands.mv[cand];
+				const int xlow = -S.margin_y, xhigh = S.width + S.margin_y, ylow = -S.margin_y, yhigh = S.height + S.margin_y;
+				const int spx = gx + mv.x / 4, spy = gy + mv.y / 4;
+				if (!(spx < xlow || spx + n > xhigh || spy < ylow || spy + n > yhigh)) motion_compensate_cu(g, e, ni, mv);
+				mc_done = 1;
+			}
+			if (no_res == 0) {
+				predict_all_comps(g, e, ni);
+				cost = dist = encode_inter(g, e, curr_depth, position, PART_2Nx2N);
+				cost = (uint32_t)((double)cost + cost_rd(e.f->avg_dist, nd.sum));
+			} else {
+				dist = blk_ssd(g, w.curr_y + q.y * 64 + q.x, 64, w.pred_y + q.y * 64 + q.x, 64, n);
+				dist += (uint32_t)(weight * blk_ssd(g, w.curr_c[0] + q.yc * 32 + q.xc, 32, w.pred_c[0] + q.yc * 32 + q.xc, 32, nc));
+				dist += (uint32_t)(weight * blk_ssd(g, w.curr_c[1] + q.yc * 32 + q.xc, 32, w.pred_c[1] + q.yc * 32 + q.xc, 32, nc));
+				nd.inter_cbf[0] = nd.inter_cbf[1] = nd.inter_cbf[2] = 0;
+				nd.inter_tr_idx = 0;
+				nd.sum = 0;
+				cost = dist;
+			}
+			if (cost < best_cost) {
+				best_mv = w.merge_cands.mv[cand];
+				best_ref_idx = w.merge_cands.ref_idx[cand];
+				best_candidate = cand;
+				best_dist = dist;
+				best_cost = cost;
+				best_sum = nd.sum;
+				if (no_res == 1) {
+					// skipped: the prediction is the reconstruction, the levels are zero
+					blk_copy(g, w.pred_y + q.y * 64 + q.x, 64, dec_ptr(w, curr_depth + 1, COMP_Y) + q.y * DEC_STRIDE_Y + q.x, DEC_STRIDE_Y, n, n);
+					for (int k = 0; k < 2; k++)
+						blk_copy(g, w.pred_c[k] + q.yc * 32 + q.xc, 32, dec_ptr(w, curr_depth + 1, COMP_U + k) + q.yc * DEC_STRIDE_C + q.xc, DEC_STRIDE_C, nc, nc);
+					lin_zero(g, w.tq_y[curr_depth + 1] + (abs_index << 4), n * n);
+					lin_zero(g, w.tq_c[curr_depth + 1][0] + ((abs_index << 4) >> 2), nc * nc);
+					lin_zero(g, w.tq_c[curr_depth + 1][1] + ((abs_index << 4) >> 2), nc * nc);
+					set_enc_info_buffs(g, e, ni, curr_depth);
+				}
+				put_consolidated_info(g, e, ni, curr_depth);
+				best_is_skip = (((c.cbf[0][abs_index]) | (c.cbf[1][abs_index]) | (c.cbf[2][abs_index])) & 1) == 0;
+			}
+			if (no_res == 0 && ((((c.cbf[0][abs_index] >> curr_depth) | (c.cbf[1][abs_index] >> curr_depth) | (c.cbf[2][abs_index] >> curr_depth)) & 1) == 0))
+				merge_cand_buffer[cand] = 1;
+		}
+	}
+	nd.skipped = best_is_skip;
+	nd.inter_mv = best_mv;
+	nd.inter_ref_index = best_ref_idx;
+	nd.cost = nd.distortion = best_dist;
+	nd.merge_flag = 1;
+	nd.merge_idx = best_candidate;
+	nd.inter_mode = inter_modes[best_candidate];
+	nd.sum = best_sum;
+	return best_dist;
+}
+
+// one speculated comparison of the P-slice walk: intra against inter with the running intra ratio (:4018-4021)
+HENC_INLINE double intra_ratio(const Enc &e)
+{
+	const uint32_t tp = e.total_partitions == 0 ? 1 : e.total_partitions;
+	return hclip((double)e.total_intra_partitions / (double)tp, .0, .15);
+}
+
+// motion_inter_full :3746
+template <class G>
+HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &e)
+{
+	const Seq &S = *e.seq;
+	CtuInfo &c = *e.ctu;
+	const double avg_distortion = e.f->avg_dist;
+	const int perf_min_depth = S.perf_min_depth, perf_fast_skip = S.perf_fast_skip;
+	int depth_state[NDEPTH] = {0, 0, 0, 0, 0};
+	uint32_t cost_sum[NDEPTH] = {0, 0, 0, 0, 0};
+	int curr_depth = 0, parent = -1, curr = 0;
+	double dist = 0, best_cost;
+	const int root = 0;
+	while (curr_depth != 0 || depth_state[curr_depth] != 1) {
+		double cost = 0, intra_cost = 0;
+		int stop_recursion = 0, is_skipped = 0;
+		const Geo &q = e.geo[curr];
+		Node &nd = node_of(e, curr);
+		curr_depth = q.depth;
+		const int part_size_type = curr_depth < S.max_pred_depth ? PART_2Nx2N : PART_NxN;
+		const int num_part_in_cu = q.num_part;
+		const int position = q.list_index - S.depth_start[curr_depth];
+		nd.qp = (uint32_t)e.f->qp;   // hmr_rc_get_cu_qp, fixed QP (hmr_rate_control.c:366)
+		if (nd.b_inside && nd.r_inside) {
+			int mv_cost = 0;
+			if (part_size_type == PART_2Nx2N) {
+				uint32_t sad = 0, merge_dist = MAX_COST, merge_cost = MAX_COST, merge_sum = 0;
+				MV merge_mv = {0, 0};
+				int merge_ref_idx = 0, merge_inter_mode = 0;
+				const int action = S.me_precision * 2 - 1;
+				nd.prediction_mode = PM_INTER;
+				if (curr_depth >= perf_min_depth) {
+					merge_dist = check_rd_cost_merge(g, e, curr_depth, position);
+					merge_mv = nd.inter_mv;
+					merge_ref_idx = nd.inter_ref_index;
+					merge_inter_mode = nd.inter_mode;
+					merge_sum = nd.sum;
+					merge_cost = merge_dist;
+					merge_cost += (uint32_t)nd.merge_idx;
+					merge_cost = (uint32_t)(merge_cost * 1.1 + depth_term(avg_distortion, curr_depth));
+					merge_cost = (uint32_t)((double)merge_cost + cost_rd(e.f->avg_dist, nd.sum));
+					cost = merge_cost;
+					dist = merge_dist;
+					if (nd.skipped) merge_cost = (uint32_t)(merge_cost * .95);
+					if (nd.skipped && (double)merge_cost < avg_distortion * NPART / 2.5) is_skipped = 1;
+				} else {
+					nd.inter_mv.x = nd.inter_mv.y = 0;
+					nd.merge_flag = 0;
+					nd.skipped = 0;
+					cost = nd.cost = merge_cost = MAX_COST;
+					dist = nd.distortion = merge_dist = MAX_COST;
+					is_skipped = 0;
+				}
+				if (curr_depth >= perf_min_depth) {
+					if (!is_skipped) sad = (uint32_t)cu_motion_estimation(g, e, curr_depth, position, PART_2Nx2N, action);
+					if (!is_skipped && (q.size < 64 || sad < 100u * num_part_in_cu)) {
+						mv_cost = predict_inter(g, e, curr_depth, position, PART_2Nx2N);
+						dist = (double)(int)encode_inter(g, e, curr_depth, position, PART_2Nx2N);
+					} else {
+						mv_cost = 0;
+						dist = MAX_COST;
+						nd.sum = 0;
+						nd.inter_mv.x = nd.inter_mv.y = 0;
+					}
+					cost = dist;
+					cost += 2 * mv_cost;
+					cost = cost * 1.1 + depth_term(avg_distortion, curr_depth);
+					cost += cost_rd(e.f->avg_dist, nd.sum);
+					if (cost < merge_cost) {
+						nd.merge_flag = 0;
+						nd.skipped = 0;
+					} else {
+						nd.inter_mv = merge_mv;
+						nd.inter_ref_index = merge_ref_idx;
+						nd.inter_mode = merge_inter_mode;
+						nd.sum = merge_sum;
+						cost = merge_cost;
+						dist = merge_dist;
+					}
+				}
+				nd.cost = (uint32_t)cost;
+				nd.distortion = (uint32_t)dist;
+				HENC_TRACE("CU ctu=%d d=%d abs=%d inter: merge=%d idx=%d skip=%d mv=(%d,%d) cost=%u dist=%u sum=%u\n", c.ctu_number, curr_depth, q.abs_index,
+					   nd.merge_flag, nd.merge_idx, nd.skipped, nd.inter_mv.x, nd.inter_mv.y, nd.cost, nd.distortion, nd.sum);
+				if (perf_fast_skip && (dist == 0 || (nd.sum < (uint32_t)num_part_in_cu && dist < .25 * avg_distortion * num_part_in_cu) ||
+						       (nd.sum == 0 && dist < avg_distortion * num_part_in_cu))) {
+					if (nd.merge_flag) get_back_consolidated_info(g, e, curr, curr_depth);
+					stop_recursion = 1;
+					consolidate_prediction_info(g, e, curr, nd.cost, MAX_COST, 0, (uint32_t *)nullptr);
+					refresh_deeper_windows(g, e, curr, curr_depth, 1);
+				}
+				if (perf_fast_skip && (curr_depth >= perf_min_depth && !stop_recursion && !is_skipped && (q.size < 32 || sad > 400u * num_part_in_cu))) {
+					const uint32_t inter_sum = nd.sum;
+					if (!nd.merge_flag) put_consolidated_info(g, e, curr, curr_depth);
+					const uint32_t intra_dist = encode_intra(g, e, curr_depth, position, PART_2Nx2N);
+					const double ratio = intra_ratio(e);
+					const double add = hclip(avg_distortion - 400, 40., avg_distortion) / 1.75 * curr_depth;
+					intra_cost = intra_dist * (1.275 - ratio) + add;
+					intra_cost += cost_rd(e.f->avg_dist, nd.sum);
+					const int take_intra = intra_cost < cost;
+					if (c.n_ratio_cmp < 96) {
+						c.ratio_cmp[3 * c.n_ratio_cmp] = (double)intra_dist;
+						c.ratio_cmp[3 * c.n_ratio_cmp + 1] = add + cost_rd(e.f->avg_dist, nd.sum);
+						c.ratio_cmp[3 * c.n_ratio_cmp + 2] = cost;
+						c.ratio_out[c.n_ratio_cmp] = (uint8_t)take_intra;
+					}
+					c.n_ratio_cmp++;
+					HENC_TRACE("CU ctu=%d d=%d abs=%d intra: dist=%u cost=%.3f vs %.3f\n", c.ctu_number, curr_depth, q.abs_index, intra_dist, intra_cost, cost);
+					if (take_intra) {
+						nd.cost = (uint32_t)intra_cost;
+						nd.distortion = intra_dist;
+						nd.prediction_mode = PM_INTRA;
+						nd.merge_flag = 0;
+						nd.skipped = 0;
+					} else {
+						get_back_consolidated_info(g, e, curr, curr_depth);
+						nd.cost = (uint32_t)cost;
+						nd.distortion = (uint32_t)dist;
+						nd.sum = inter_sum;
+						nd.prediction_mode = PM_INTER;
+					}
+				} else if (curr_depth >= perf_min_depth && !stop_recursion) {
+					if (nd.merge_flag) get_back_consolidated_info(g, e, curr, curr_depth);
+				}
+			} else {
+				// NxN level.  Inter NxN needs a parent larger than 8x8 (:4061), which the 8x8 minimum CU of the built configurations excludes.
+				cost = dist = nd.cost = nd.distortion = MAX_COST;
+				depth_state[curr_depth] = 3;
+			}
+		} else {
+			nd.cost = MAX_COST;
+		}
+		cost_sum[curr_depth] += nd.cost;
+		depth_state[curr_depth]++;
+		if (curr_depth < S.max_pred_depth && nd.tl_inside && !stop_recursion) {
+			curr_depth++;
+			parent = curr;
+		} else if (depth_state[curr_depth] == 4) {
+			while (depth_state[curr_depth] == 4 && curr_depth > 0) {
+				const int is_max_depth = curr_depth == S.max_pred_depth;
+				const Geo &pq = e.geo[parent];
+				const uint32_t ccost = node_of(e, pq.child[0]).cost + node_of(e, pq.child[1]).cost + node_of(e, pq.child[2]).cost + node_of(e, pq.child[3]).cost;
+				cost = ccost;
+				depth_state[curr_depth] = 0;
+				best_cost = node_of(e, parent).cost;
+				consolidate_prediction_info(g, e, parent, (uint32_t)best_cost, (uint32_t)cost, is_max_depth, cost_sum);
+				cost_sum[curr_depth] = 0;
+				curr_depth--;
+				parent = e.geo[parent].parent;
+				if (curr_depth > perf_min_depth && cost_sum[curr_depth] > node_of(e, parent).cost && depth_state[curr_depth] < 4 && node_of(e, root).b_inside &&
+				    node_of(e, root).r_inside)
+					depth_state[curr_depth] = 4;
+			}
+			const int aux = parent >= 0 ? e.geo[parent].child[(depth_state[curr_depth] + 3) & 3] : root;
+			refresh_deeper_windows(g, e, aux, curr_depth, 0);
+		}
+		if (parent >= 0) curr = e.geo[parent].child[depth_state[curr_depth]];
+	}
+	return node_of(e, root).cost;
+}
+
+// motion_intra_cu, hmr_motion_intra.c:1759 (performance_mode <= 2: no variance pre-analysis)
+template <class G>
+HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &e)
+{
+	const Seq &S = *e.seq;
+	CtuInfo &c = *e.ctu;
+	int depth_state[NDEPTH] = {0, 0, 0, 0, 0};
+	uint32_t cost_sum[NDEPTH] = {0, 0, 0, 0, 0};
+	int curr_depth = 0, parent = 0, curr = 0;
+	const int initial_depth = 0, initial_position = 0;
+	depth_state[0] = initial_position;
+	while (curr_depth != initial_depth || depth_state[curr_depth] != initial_position + 1) {
+		const Geo &q = e.geo[curr];
+		Node *nd = &node_of(e, curr);
+		curr_depth = q.depth;
+		const int part_size_type = curr_depth < S.max_pred_depth ? PART_2Nx2N : PART_NxN;
+		int position = q.list_index - S.depth_start[curr_depth];
+		double cost_luma = 0, cost_chroma = 0;
+		nd->qp = (uint32_t)e.f->qp;
+		if (nd->b_inside && nd->r_inside) {
+			if (part_size_type == PART_2Nx2N) {
+				cost_luma = encode_intra_luma(g, e, curr_depth, position, part_size_type);
+				cost_chroma = encode_intra_chroma(g, e, curr_depth, position, part_size_type);
+				nd->cost = (uint32_t)(cost_luma + cost_chroma);
+				cost_sum[curr_depth] += nd->cost;
+				nd->prediction_mode = PM_INTRA;
+				HENC_TRACE("ICU ctu=%d d=%d abs=%d cost=%u (l %.0f c %.0f) mode=%d\n", c.ctu_number, curr_depth, q.abs_index, nd->cost, cost_luma, cost_chroma, nd->intra_mode[0]);
+			} else {
+				cost_luma = 0;
+				for (int n = 0; n < 4; n++) {
+					Node &sn = node_of(e, curr + n);
+					sn.qp = (uint32_t)e.f->qp;
+					sn.cost = encode_intra_luma(g, e, curr_depth, position + n, part_size_type);
+					cost_luma += sn.cost;
+					cost_sum[curr_depth] += sn.cost;
+					sn.prediction_mode = PM_INTRA;
+				}
+				if (cost_luma < node_of(e, parent).cost && (nd->b_inside && nd->r_inside)) {
+					position = e.geo[e.geo[parent].child[0]].list_index - S.depth_start[curr_depth];
+					cost_chroma = encode_intra_chroma(g, e, curr_depth, position, part_size_type);
+					nd->cost += (uint32_t)cost_chroma;
+					cost_sum[curr_depth] += (uint32_t)cost_chroma;
+				}
+				HENC_TRACE("ICU ctu=%d d=%d abs=%d NxN luma=%.0f chroma=%.0f\n", c.ctu_number, curr_depth, q.abs_index, cost_luma, cost_chroma);
+				depth_state[curr_depth] = 3;
+			}
+		}
+		depth_state[curr_depth]++;
+		if (curr_depth < S.max_pred_depth && nd->tl_inside) {
+			curr_depth++;
+			parent = curr;
+		} else if (depth_state[curr_depth] == 4) {
+			while (depth_state[curr_depth] == 4 && curr_depth > initial_depth) {
+				const Geo &pq = e.geo[parent];
+				const uint32_t ccost = node_of(e, pq.child[0]).cost + node_of(e, pq.child[1]).cost + node_of(e, pq.child[2]).cost + node_of(e, pq.child[3]).cost;
+				const double cost = ccost;
+				depth_state[curr_depth] = 0;
+				const double best_cost = node_of(e, parent).cost;
+				consolidate_prediction_info(g, e, parent, (uint32_t)best_cost, (uint32_t)cost, curr_depth == S.max_pred_depth, cost_sum);
+				cost_sum[curr_depth] = 0;
+				curr_depth--;
+				parent = e.geo[parent].parent;
+				if (S.perf_mode <= 2 && curr_depth > 0 && curr_depth < S.max_pred_depth && depth_state[curr_depth] < 4 && node_of(e, 0).b_inside && node_of(e, 0).r_inside) {
+					double totalcost = 0;
+					for (int h = 0; h < depth_state[curr_depth]; h++) totalcost += node_of(e, e.geo[parent].child[h]).cost;
+					if (totalcost > node_of(e, parent).cost) depth_state[curr_depth] = 4;
+				}
+			}
+			const int aux = parent >= 0 ? e.geo[parent].child[(depth_state[curr_depth] + 3) & 3] : 0;
+			refresh_deeper_windows(g, e, aux, curr_depth, 1);
+		}
+		if (parent >= 0) curr = e.geo[parent].child[depth_state[curr_depth]];
+	}
+	for (int i = g.tid; i < NPART; i += g.n) {
+		c.mv_ref_idx[i] = -1;
+		c.pred_mode[i] = PM_INTRA;
+		c.skipped[i] = 0;
+	}
+	g.sync();
+	return node_of(e, 0).cost;
+}
+
+// ---- CTU set-up and tear-down ---------------------------------------------------------------------------------------------
+// create_partition_ctu_neighbours, hmr_motion_intra.c:658 + cu_partition_get_neighbours :629
+HENC_INLINE void create_partition_neighbours(Enc &e)
+{
+	const Seq &S = *e.seq;
+	CtuInfo &c = *e.ctu;
+	const int cu_min_tu_size_shift = hmax(S.max_cu_size_shift - (S.max_pred_depth + hmax(S.max_intra_tr_depth, S.max_inter_tr_depth) - 1), 2);
+	const int max_processing_depth = S.max_cu_size_shift - cu_min_tu_size_shift;
+	const int valid_lines = (c.y + 64) > S.height ? S.height - c.y : 64, valid_cols = (c.x + 64) > S.width ? S.width - c.x : 64;
+	int depth_state[NDEPTH] = {0, 0, 0, 0, 0};
+	int curr_depth = 0, parent = -1, curr = 0;
+	while (curr_depth != 0 || depth_state[curr_depth] != 1) {
+		const Geo &q = e.geo[curr];
+		Node &nd = node_of(e, curr);
+		curr_depth = q.depth;
+		nd.tl_inside = (c.y + q.y < S.height) && (c.x + q.x < S.width);
+		nd.b_inside = (c.y + q.y + q.size <= S.height);
+		nd.r_inside = (c.x + q.x + q.size <= S.width);
+		if (nd.tl_inside) {
+			if (parent < 0) {
+				nd.left_nb = c.has_left;
+				nd.top_nb = c.has_top;
+				nd.left_bottom_nb = 0;
+				nd.top_right_nb = c.has_top_right;
+			} else {
+				const Geo &pq = e.geo[q.parent];
+				const Node &pn = node_of(e, q.parent);
+				nd.left_nb = (pn.left_nb || q.x) ? 1 : 0;
+				nd.top_nb = (pn.top_nb || q.y) ? 1 : 0;
+				nd.left_bottom_nb = ((pn.left_bottom_nb && q.x == pq.x) || (pn.left_nb && q.x == pq.x && q.y == pq.y && valid_lines > q.y + q.size)) ? 1 : 0;
+				nd.top_right_nb = ((pn.top_right_nb && q.y == pq.y) || (pn.top_nb && q.x == pq.x && q.y == pq.y && valid_cols > q.x + q.size) ||
+						   (q.x == pq.x && q.y != pq.y && valid_cols > q.x + q.size))
+							  ? 1
+							  : 0;
+			}
+		}
+		depth_state[curr_depth]++;
+		if (curr_depth < max_processing_depth && nd.tl_inside) {
+			curr_depth++;
+			parent = curr;
+		} else if (depth_state[curr_depth] == 4) {
+			while (depth_state[curr_depth] == 4) {
+				depth_state[curr_depth] = 0;
+				curr_depth--;
+				parent = e.geo[parent].parent;
+			}
+		}
+		if (parent >= 0) curr = e.geo[parent].child[depth_state[curr_depth]];
+	}
+}
+
+// init_ctu :2254 + CuGetNeighbors :2160, mem_transfer_move_curr_ctu_group / mem_transfer_intra_refs (hmr_mem_transfer.c:284,351)
+template <class G>
+HENC_HD void ctu_begin(const G &g, Enc &e, int ctu_num)
+{
+	const Seq &S = *e.seq;
+	Work &w = *e.w;
+	e.ctu = e.ctus + ctu_num;
+	CtuInfo &c = *e.ctu;
+	const int cx = ctu_num % S.wctu, cy = ctu_num / S.wctu;
+	c.ctu_number = ctu_num;
+	c.x = cx * 64;
+	c.y = cy * 64;
+	const int ctu_w = (c.x + 64) < S.width ? 64 : S.width - c.x, ctu_h = (c.y + 64) < S.height ? 64 : S.height - c.y;
+	if (ctu_w != 64 || ctu_h != 64) c.last_valid_partition = raster2abs(((ctu_h >> 2) - 1) * 16 + (ctu_w >> 2) - 1);
+	else c.last_valid_partition = NPART - 1;
+	c.has_left = cx > 0;
+	c.has_top = cy > 0;
+	c.has_top_left = cx > 0 && cy > 0;
+	c.has_top_right = cy > 0 && cx != S.wctu - 1;
+	c.n_spec_reads = c.n_ratio_cmp = 0;
+	// source CTU
+	for (int comp = 0; comp < 3; comp++) {
+		const int sz = comp ? 32 : 64, px = comp ? c.x >> 1 : c.x, py = comp ? c.y >> 1 : c.y;
+		const int pw = comp ? S.width >> 1 : S.width, ph = comp ? S.height >> 1 : S.height;
+		const int ss = comp ? S.src_stride_c : S.src_stride_y;
+		const int ww = (px + sz) < pw ? sz : pw - px, hh = (py + sz) < ph ? sz : ph - py;
+		blk_copy(g, e.f->src[comp] + py * ss + px, ss, curr_ptr(w, comp), sz, hh, ww);
+	}
+	// neighbour samples of the picture under reconstruction into every decoded window
+	if (c.has_left || c.has_top) {
+		for (int comp = 0; comp < 3; comp++) {
+			const int sz = comp ? 32 : 64, px = comp ? c.x >> 1 : c.x, py = comp ? c.y >> 1 : c.y;
+			const int pw = comp ? S.width >> 1 : S.width, ph = comp ? S.height >> 1 : S.height;
+			const int rs = comp ? S.stride_c : S.stride_y, ds = dec_stride(comp);
+			int left_copy = 0, top_copy = 0;
+			if (c.has_left) left_copy += sz;
+			if (c.has_top) top_copy += sz;
+			if (c.has_top_right) top_copy += sz;
+			if (left_copy > ph - py) left_copy = ph - py;
+			if (top_copy > pw - px) top_copy = pw - px;
+			const int16_t *src = e.f->rec[comp] + py * rs + px;
+			for (int l = 0; l < NWND; l++) {
+				int16_t *dst = dec_ptr(w, l, comp);
+				for (int i = g.tid; i < 1 + top_copy + left_copy; i += g.n) {
+					if (i == 0) {
+						if (c.has_left && c.has_top) dst[-ds - 1] = src[-rs - 1];
+					} else if (i <= top_copy) dst[-ds + (i - 1)] = src[-rs + (i - 1)];
+					else {
+						const int j = i - 1 - top_copy;
+						dst[j * ds - 1] = src[j * rs - 1];
+					}
+				}
+			}
+		}
+		g.sync();
+	}
+	create_partition_neighbours(e);
+}
+
+// mem_transfer_decoded_blocks :312 + the coefficient copy (hmr_encoder_lib.c:2942-2945) + the thread counters (:2924-2940)
+template <class G>
+HENC_HD void ctu_end(const G &g, Enc &e)
+{
+	const Seq &S = *e.seq;
+	Work &w = *e.w;
+	CtuInfo &c = *e.ctu;
+	for (int comp = 0; comp < 3; comp++) {
+		const int sz = comp ? 32 : 64, px = comp ? c.x >> 1 : c.x, py = comp ? c.y >> 1 : c.y;
+		const int pw = comp ? S.width >> 1 : S.width, ph = comp ? S.height >> 1 : S.height;
+		const int rs = comp ? S.stride_c : S.stride_y;
+		const int ww = (px + sz) < pw ? sz : pw - px, hh = (py + sz) < ph ? sz : ph - py;
+		blk_copy(g, dec_ptr(w, 0, comp), dec_stride(comp), e.f->rec[comp] + py * rs + px, rs, hh, ww);
+	}
+	lin_copy(g, w.tq_y[0], e.coeff, 4096);
+	lin_copy(g, w.tq_c[0][0], e.coeff + 4096, 1024);
+	lin_copy(g, w.tq_c[0][1], e.coeff + 5120, 1024);
+	uint32_t cnt = 0;
+	for (int i = g.tid; i < NPART; i += g.n) cnt += c.pred_mode[i] == PM_INTRA;
+	cnt = g.sum(cnt);
+	c.intra_parts = e.f->slice_type != SLICE_I && !e.f->is_scene_change ? cnt : NPART;
+	c.distortion = node_of(e, 0).distortion;
+	g.sync();
+}
+
+template <class G>
+HENC_HD void encode_ctu(const G &g, Enc &e, int ctu_num)
+{
+	ctu_begin(g, e, ctu_num);
+	if (e.f->slice_type != SLICE_I && !e.f->is_scene_change) motion_inter_ctu(g, e);
+	else motion_intra_ctu(g, e);
+	ctu_end(g, e);
+}
+
+}  // namespace henc

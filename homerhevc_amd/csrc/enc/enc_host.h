@@ -1,0 +1,205 @@
+// Host-side control of the frame encoder: configuration clamps, the static partition geometry, frame typing and the
+// per-frame scalars the device code takes as inputs (doubles that come out of pow / sqrt stay on the host).
+// Restates HOMER_enc_control(HOMER_SETCFG) hmr_encoder_lib.c:704-1650 (the fields the hot path reads), init_partition_info
+// hmr_motion_intra.c:758, put_frame_to_encode :262 (frame typing), hmr_rd_init hmr_tables.c:315 and the per-frame
+// statistics of encoder_engine_thread :3217-3238.
+#pragma once
+#include <math.h>
+#include <stdlib.h>
+#include <vector>
+#include "enc_types.h"
+
+namespace henc {
+
+// mirrors HVENC_Cfg (homer_hevc_enc_api.h:138-167), same field names
+struct HostCfg {
+	int32_t size, profile, width, height;
+	float frame_rate;
+	int32_t cu_size, max_pred_partition_depth, max_intra_tr_depth, max_inter_tr_depth, intra_period, gop_size, num_b, num_ref_frames;
+	int32_t motion_estimation_precision, qp, chroma_qp_offset, num_enc_engines, wfpp_enable, wfpp_num_threads, sign_hiding, sample_adaptive_offset;
+	int32_t bitrate_mode, bitrate, vbv_size, vbv_init, reinit_gop_on_scene_change, rd_mode, performance_mode;
+};
+
+inline int host_raster2abs(int r)
+{
+	const int x = r & 15, y = r >> 4;
+	int a = 0;
+	for (int b = 0; b < 4; b++) a |= (((x >> b) & 1) << (2 * b)) | (((y >> b) & 1) << (2 * b + 1));
+	return a;
+}
+inline int host_abs2raster(int a)
+{
+	int x = 0, y = 0;
+	for (int b = 0; b < 4; b++) {
+		x |= ((a >> (2 * b)) & 1) << b;
+		y |= ((a >> (2 * b + 1)) & 1) << b;
+	}
+	return y * 16 + x;
+}
+
+inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// returns false for configurations outside the rows built so far
+inline bool make_seq(HostCfg cfg, Seq &s, const char **why)
+{
+	memset(&s, 0, sizeof s);
+	*why = "";
+	cfg.num_b = clampi(cfg.num_b, 0, 1);
+	cfg.gop_size = clampi(cfg.gop_size, 1, cfg.num_b + 1);
+	cfg.intra_period = clampi(cfg.intra_period, cfg.gop_size + 1, ((cfg.intra_period - 1) / cfg.gop_size) * cfg.gop_size + 1);
+	cfg.num_ref_frames = (cfg.gop_size == cfg.num_b) ? 1 : clampi(cfg.num_ref_frames, 0, 16);
+	if (cfg.cu_size != 64) { *why = "cu_size != 64"; return false; }
+	if (cfg.num_b != 0 || cfg.gop_size != 1) { *why = "B frames"; return false; }
+	if (cfg.num_ref_frames != 1) { *why = "num_ref_frames != 1"; return false; }
+	if (cfg.bitrate_mode != 0) { *why = "rate control (fixed QP only)"; return false; }
+	if (cfg.rd_mode == RDM_FULL) { *why = "rd_mode RD_FULL"; return false; }
+	if (cfg.performance_mode > 2) { *why = "performance_mode 3"; return false; }
+	s.max_cu_size = 64;
+	s.max_cu_size_shift = 6;
+	s.max_pred_depth = cfg.max_pred_partition_depth > 4 ? 4 : cfg.max_pred_partition_depth;
+	if (s.max_pred_depth != 4) { *why = "max_pred_partition_depth != 4"; return false; }
+	if (cfg.width % (64 >> (s.max_pred_depth - 1)) || cfg.height % (64 >> (s.max_pred_depth - 1))) { *why = "size not a multiple of the minimum CU"; return false; }
+	s.max_intra_tr_depth = cfg.max_intra_tr_depth > 5 ? 5 : cfg.max_intra_tr_depth;
+	s.max_inter_tr_depth = cfg.max_inter_tr_depth > 5 ? 5 : cfg.max_inter_tr_depth;
+	s.min_tu_size_shift = 2;
+	s.max_tu_size_shift = 5;
+	s.mincu_mintr_shift_diff = (6 - s.max_pred_depth) - 2;
+	s.max_cu_depth = s.max_pred_depth + s.mincu_mintr_shift_diff;
+	s.mincu_mintr_shift_diff++;
+	s.perf_mode = clampi(cfg.performance_mode, 0, 3);
+	s.perf_fast_skip = s.perf_mode >= 1;
+	s.perf_min_depth = s.perf_mode == 2 ? 1 : (s.perf_mode == 3 ? 2 : 0);
+	s.rd_mode = clampi(cfg.rd_mode, 0, 2);
+	s.me_precision = cfg.motion_estimation_precision == 0 ? ME_PEL : (cfg.motion_estimation_precision == 1 ? ME_HALF : ME_QUARTER);
+	s.num_merge_cand = 2;
+	s.sign_hiding = cfg.sign_hiding;
+	s.strong_intra = 1;
+	s.chroma_qp_offset = cfg.chroma_qp_offset;
+	s.sao = cfg.sample_adaptive_offset;
+	s.wpp = cfg.wfpp_enable;
+	s.bitrate_mode = cfg.bitrate_mode;
+	s.qp = cfg.qp;
+	s.intra_period = cfg.intra_period;
+	s.gop_size = cfg.gop_size;
+	s.num_ref_frames = cfg.num_ref_frames;
+	s.reinit_gop = cfg.reinit_gop_on_scene_change;
+	s.width = cfg.width;
+	s.height = cfg.height;
+	s.wctu = (s.width + 63) >> 6;
+	s.hctu = (s.height + 63) >> 6;
+	s.nctu = s.wctu * s.hctu;
+	s.depth_start[0] = 0; s.depth_start[1] = 1; s.depth_start[2] = 5; s.depth_start[3] = 21; s.depth_start[4] = 85;
+	// wnd_alloc(width, height, 64 + 16, 64 + 16), hmr_mem_transfer.c:48: strides are rounded to 16 bytes
+	s.margin_y = 80;
+	s.margin_c = 40;
+	s.stride_y = ((s.width * 2 + 15) / 16 * 16) / 2 + 2 * s.margin_y;
+	s.stride_c = (((s.width / 2) * 2 + 15) / 16 * 16) / 2 + 2 * s.margin_c;
+	s.src_stride_y = ((s.width * 2 + 15) / 16 * 16) / 2;
+	s.src_stride_c = (((s.width / 2) * 2 + 15) / 16 * 16) / 2;
+	return true;
+}
+
+// init_partition_info + get_partition_neigbours
+inline void make_geo(Geo *geo)
+{
+	memset(geo, 0, sizeof(Geo) * NNODES);
+	geo[0].size = 64; geo[0].size_chroma = 32; geo[0].num_part = 256; geo[0].parent = -1;
+	for (int k = 0; k < 4; k++) geo[0].child[k] = -1;
+	int next = 1;
+	for (int p = 0; p < 85; p++) {
+		Geo &par = geo[p];
+		const int depth = par.depth + 1, size = 64 >> depth, np = (size * size) >> 4;
+		for (int k = 0; k < 4; k++, next++) {
+			Geo &c = geo[next];
+			par.child[k] = (int16_t)next;
+			c.parent = (int16_t)p;
+			c.list_index = (uint16_t)next;
+			c.depth = (uint16_t)depth;
+			c.size = (uint16_t)size;
+			c.size_chroma = (uint16_t)(size >> 1);
+			c.x = (uint16_t)(par.x + (k & 1) * size);
+			c.y = (uint16_t)(par.y + (k >> 1) * size);
+			c.xc = c.x >> 1;
+			c.yc = c.y >> 1;
+			c.abs_index = (uint16_t)(par.abs_index + k * np);
+			c.num_part = (uint16_t)np;
+			for (int j = 0; j < 4; j++) c.child[j] = -1;
+		}
+	}
+	for (int i = 0; i < NNODES; i++) {
+		Geo &c = geo[i];
+		c.raster_index = (uint16_t)host_abs2raster(c.abs_index);
+		const int r = c.raster_index;
+		const int left = (r & 15) == 0 ? r + 15 : r - 1;
+		const int left_bottom = (left + 16) & 255, top = (r + 240) & 255;
+		const int top_right = (top & 15) == 15 ? top - 15 : top + 1;
+		const int top_left = (left + 240) & 255;
+		c.abs_left = (uint16_t)host_raster2abs(left);
+		c.abs_left_bottom = (uint16_t)host_raster2abs(left_bottom);
+		c.abs_top = (uint16_t)host_raster2abs(top);
+		c.abs_top_right = (uint16_t)host_raster2abs(top_right);
+		c.abs_top_left = (uint16_t)host_raster2abs(top_left);
+	}
+}
+
+inline int host_chroma_qp(int qpi)
+{
+	static const uint8_t t[58] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28,
+				      29, 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51};
+	return t[clampi(qpi, 0, 57)];
+}
+
+// sequence-level state the engine thread carries from frame to frame
+struct HostState {
+	int poc = 0, last_intra = 0, last_gop_reinit = 0, num_encoded_frames = 0;
+	double avg_dist = 0.0;          // hvenc->avg_dist: calloc'ed, so the first frame runs with 0 (hmr_encoder_lib.c:3191)
+};
+
+enum { IMG_AUTO = 0, IMG_B = 1, IMG_P = 2, IMG_I = 3 };
+
+// frame typing (put_frame_to_encode :311-331) and the per-frame scalars (hmr_slice_init :1986, hmr_rd_init hmr_tables.c:315)
+inline void begin_frame(const Seq &s, HostState &st, int image_type, FrameCtx &f)
+{
+	memset(&f, 0, sizeof f);
+	const int poc = st.poc++;
+	const bool intra = poc == 0 || (s.intra_period != 0 && poc == st.last_intra + s.intra_period && image_type == IMG_AUTO) || image_type == IMG_I;
+	if (intra) {
+		st.last_intra = poc;
+		st.last_gop_reinit = poc;
+	}
+	f.slice_type = intra ? SLICE_I : SLICE_P;
+	f.poc = poc;
+	f.qp = s.qp;
+	f.num_encoded_frames = st.num_encoded_frames;
+	f.is_scene_change = 0;
+	f.ref_poc = poc - 1;
+	f.avg_dist = st.avg_dist;
+	const double qp_temp = (double)s.qp - 12;
+	const double lambda_scale = 1.0 - fmin(fmax(0.05 * (double)(s.gop_size - 1), 0.0), 0.5);
+	double qp_factor = 0.4624;
+	if (f.slice_type == SLICE_I) qp_factor = 0.57 * lambda_scale;
+	double lambda = qp_factor * pow(2.0, qp_temp / 3.0);
+	if (f.slice_type != SLICE_I) lambda *= .95;
+	const double weight = pow(2.0, (f.qp - host_chroma_qp(f.qp + s.chroma_qp_offset)) / 3.0);
+	f.lambda = lambda;
+	f.sqrt_lambda = sqrt(lambda);
+	f.chroma_weight = weight;
+	f.sao_lambda[0] = lambda;
+	f.sao_lambda[1] = f.sao_lambda[2] = lambda / weight;
+}
+
+// :3217-3238 after the CTUs of a frame: acc_dist = sum of the CTUs' root distortions (uint32 accumulation)
+inline void end_frame(const Seq &s, HostState &st, const FrameCtx &f, uint32_t acc_dist)
+{
+	if (st.num_encoded_frames == 0 || f.slice_type != SLICE_I || s.intra_period == 1) {
+		double a = acc_dist;
+		a /= s.nctu * NPART;
+		a = a < .1 ? .1 : a;
+		if (f.slice_type == SLICE_I) a *= 1.5;
+		else if (f.is_scene_change) a *= 1.375;
+		st.avg_dist = a;
+	}
+	st.num_encoded_frames++;
+}
+
+}  // namespace henc

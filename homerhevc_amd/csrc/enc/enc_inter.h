@@ -1,0 +1,670 @@
+// Inter coding of a CU for P slices with one reference picture (BASELINE configs 2-4; B slices are outside the built rows):
+// motion search, compensation, vector prediction, merge evaluation, the inter transform tree.
+// Restates hmr_motion_inter.c: encode_inter_cu / _chroma :40-230, select_mv_candidate :975-1031, hmr_motion_estimation :1404-1775,
+// hmr_motion_compensation_luma / _chroma :1779-1907, get_merge_mvp_candidates :1937-2180, get_amvp_candidates :2342-2448,
+// hmr_cu_motion_estimation :2471-2880, predict_inter :2924-3067, encode_inter :3071-3294, check_rd_cost_merge_2nx2n :3493-3742.
+#pragma once
+#include "enc_common.h"
+
+namespace henc {
+
+// ---- motion compensation ------------------------------------------------------------------------------------------
+// `ref` points at the co-located block (mv = 0) in the padded reference plane
+template <class G>
+HENC_HD void mc_luma(const G &g, Enc &e, const int16_t *ref, int rs, int16_t *pred, int ps, int n, int mvx, int mvy)
+{
+	const int xf = mvx & 3, yf = mvy & 3;
+	const int16_t *src = ref + (mvy >> 2) * rs + (mvx >> 2);
+	if (xf == 0) interp_stage<8>(g, src, rs, pred, ps, yf, n, n, 1, 1, 1);
+	else if (yf == 0) interp_stage<8>(g, src, rs, pred, ps, xf, n, n, 0, 1, 1);
+	else {
+		int16_t *tmp = e.w->sub_tmp;
+		interp_stage<8>(g, src - 3 * rs, rs, tmp, 72, xf, n, n + 7, 0, 1, 0);
+		interp_stage<8>(g, tmp + 3 * 72, 72, pred, ps, yf, n, n, 1, 0, 1);
+	}
+}
+template <class G>
+HENC_HD void mc_chroma(const G &g, Enc &e, const int16_t *ref, int rs, int16_t *pred, int ps, int n, int mvx, int mvy)
+{
+	const int xf = mvx & 7, yf = mvy & 7;
+	const int16_t *src = ref + (mvy >> 3) * rs + (mvx >> 3);
+	if (xf == 0) interp_stage<4>(g, src, rs, pred, ps, yf, n, n, 1, 1, 1);
+	else if (yf == 0) interp_stage<4>(g, src, rs, pred, ps, xf, n, n, 0, 1, 1);
+	else {
+		int16_t *tmp = e.w->sub_tmp;
+		interp_stage<4>(g, src - rs, rs, tmp, 40, xf, n, n + 3, 0, 1, 0);
+		interp_stage<4>(g, tmp + 40, 40, pred, ps, yf, n, n, 1, 0, 1);
+	}
+}
+
+// ---- vector cost ----------------------------------------------------------------------------------------------------
+// select_mv_candidate_fast :1004
+HENC_INLINE uint32_t mv_cost_fast(const MvCandList &l, double corr, int mvx, int mvy, int *best_idx)
+{
+	uint32_t best = 0x7fffffff;
+	int bi = 0;
+	for (int i = 0; i < l.num; i++) {
+		const double cx = corr * ((float)habs(l.mv[i].x - mvx)), cy = corr * ((float)habs(l.mv[i].y - mvy));
+		const uint32_t c = (uint32_t)(cx + cy + .5);
+		if (best > c) { best = c; bi = i; }
+	}
+	*best_idx = bi;
+	return best;
+}
+// squareRoot :938: the reference's exponent-halving approximation on the float's bits
+HENC_INLINE float bit_sqrt(float x)
+{
+	union { float f; uint32_t u; } v;
+	v.f = x;
+	v.u += 127u << 23;
+	v.u >>= 1;
+	return v.f;
+}
+// select_mv_candidate :975 (xCheckBestMVP)
+HENC_INLINE uint32_t mv_cost_sqrt(const MvCandList &l, uint32_t qp, int mvx, int mvy, int *best_idx)
+{
+	uint32_t best = 0x7fffffff;
+	int bi = 0;
+	for (int i = 0; i < l.num; i++) {
+		const double cx = (float)qp * bit_sqrt((float)habs(l.mv[i].x - mvx));
+		const double cy = (float)qp * bit_sqrt((float)habs(l.mv[i].y - mvy));
+		const uint32_t c = (uint32_t)(3. + cx + cy + .5);
+		if (best > c) { best = c; bi = i; }
+	}
+	*best_idx = bi;
+	return best;
+}
+
+// ---- hmr_motion_estimation :1404-1775 --------------------------------------------------------------------------------
+// orig: source block (CTU window); ref: co-located block in the padded reference.  Returns the best SAD.
+template <class G>
+HENC_HD uint32_t motion_estimation(const G &g, Enc &e, const int16_t *orig, const int16_t *ref, int rs, int gx, int gy, int size,
+				   const MvCandList &amvp, const MvCandList &search, double corr, int action, MV *mv_io, MV *subpix_out)
+{
+	const int ds[4][2] = {{-1, 0}, {0, -1}, {1, 0}, {0, 1}};
+	const int db[8][2] = {{-2, 0}, {-1, -1}, {0, -2}, {1, -1}, {2, 0}, {1, 1}, {0, 2}, {-1, 1}};
+	const int ref_h[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
+	const int ref_q[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
+	const int fw = e.seq->width, fh = e.seq->height;
+	const int xlow = (gx - SEARCH_RANGE_X) < 0 ? -gx : -SEARCH_RANGE_X, xhigh = (gx + SEARCH_RANGE_X) > (fw - size) ? fw - gx - size : SEARCH_RANGE_X;
+	const int ylow = (gy - SEARCH_RANGE_Y) < 0 ? -gy : -SEARCH_RANGE_Y, yhigh = (gy + SEARCH_RANGE_Y) > (fh - size) ? fh - gy - size : SEARCH_RANGE_Y;
+	uint32_t cur_sad = 0, cur_rd = 0, best_sad = 0xffffffffu;
+	int cur_x = 0, cur_y = 0, best_x = 0, best_y = 0, mvx = 0, mvy = 0, subx = 0, suby = 0, dummy;
+#define HENC_IN_WIN(x, y) ((x) >= xlow && (x) <= xhigh && (y) >= ylow && (y) <= yhigh)
+#define HENC_SAD_AT(x, y) blk_sad(g, orig, CTU_STRIDE_Y, ref + (y) * rs + (x), rs, size)
+#define HENC_TRY(x, y, on_better)                                                                  \
+	do {                                                                                       \
+		if (HENC_IN_WIN(x, y)) {                                                           \
+			const uint32_t s_ = HENC_SAD_AT(x, y);                                     \
+			const uint32_t rd_ = s_ + mv_cost_fast(amvp, corr, (x) << 2, (y) << 2, &dummy); \
+			if (rd_ < cur_rd) { on_better; cur_sad = s_; cur_rd = rd_; cur_x = (x); cur_y = (y); } \
+		}                                                                                  \
+	} while (0)
+	if (action & ME_PEL) {
+		bool early = false;
+		cur_x = hclip(0, xlow, xhigh);
+		cur_y = hclip(0, ylow, yhigh);
+		cur_sad = HENC_SAD_AT(cur_x, cur_y);
+		cur_rd = cur_sad + mv_cost_fast(amvp, corr, cur_x << 2, cur_y << 2, &dummy);
+		best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
+		if (best_sad <= 0) early = true;
+		if (!early) {
+			for (int i = 0; i < search.num; i++) {
+				const int x = search.mv[i].x >> 2, y = search.mv[i].y >> 2;
+				if (x == 0 && y == 0) continue;
+				HENC_TRY(x, y, (void)0);
+			}
+			best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
+			if (best_sad <= 0) early = true;
+		}
+		if (!early) {
+			for (int i = 0; i < 4; i++) {
+				const int x = best_x + ds[i][0], y = best_y + ds[i][1];
+				HENC_TRY(x, y, (void)0);
+			}
+			if (best_sad <= 0) early = true;
+		}
+		if (!early) {
+			int dist = 2;
+			const int end = (best_x != 0 && best_y != 0) ? 4 : 8;
+			int next_start = 0, search_size = 8;
+			best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
+			while (dist < end) {
+				for (int i = next_start; i < next_start + search_size; i++) {
+					const int idx = i % 8, x = best_x + db[idx][0] * dist, y = best_y + db[idx][1] * dist;
+					HENC_TRY(x, y, (next_start = (idx - 2 + 8) % 8, search_size = 5));
+				}
+				dist *= 2;
+			}
+		}
+		// last search: small-diamond descent
+		best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
+		{
+			int next_start = 0, search_size = 4;
+			for (;;) {
+				for (int i = next_start; i < next_start + search_size; i++) {
+					const int idx = i % 4, x = best_x + ds[idx][0], y = best_y + ds[idx][1];
+					HENC_TRY(x, y, (next_start = (idx - 1 + 4) % 4, search_size = 3));
+				}
+				if (best_x == cur_x && best_y == cur_y) break;
+				best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
+			}
+		}
+		best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
+		mvx = best_x << 2; mvy = best_y << 2;
+	} else {
+		mvx = mv_io->x; mvy = mv_io->y;
+	}
+	if (action & ME_HALF) {
+		int bidx = 0, bx = 0, by = 0;
+		best_x = mvx >> 2; best_y = mvy >> 2;
+		if (!(action & ME_PEL)) cur_sad = HENC_SAD_AT(best_x, best_y);
+		int16_t *sp = e.w->sub_out;
+		for (int i = 0; i < 9; i++) {
+			const int cx = ref_h[i][0] * 2, cy = ref_h[i][1] * 2;
+			mc_luma(g, e, ref, rs, sp, 64, size, (best_x << 2) + cx, (best_y << 2) + cy);
+			const uint32_t s = blk_sad(g, orig, CTU_STRIDE_Y, sp, 64, size);
+			g.sync();
+			if (s < cur_sad) { cur_sad = s; bx = cx; by = cy; bidx = i; }
+		}
+		mvx = (best_x << 2) + bx; mvy = (best_y << 2) + by; subx = bx; suby = by;
+		best_sad = cur_sad;
+		if (action & ME_QUARTER) {
+			const int hx = ref_h[bidx][0], hy = ref_h[bidx][1];
+			bx = hx * 2; by = hy * 2;
+			for (int i = 0; i < 9; i++) {
+				const int cx = hx * 2 + ref_q[i][0], cy = hy * 2 + ref_q[i][1];
+				mc_luma(g, e, ref, rs, sp, 64, size, (best_x << 2) + cx, (best_y << 2) + cy);
+				const uint32_t s = blk_sad(g, orig, CTU_STRIDE_Y, sp, 64, size);
+				g.sync();
+				if (s < cur_sad) { cur_sad = s; bx = cx; by = cy; }
+			}
+			best_sad = cur_sad;
+			mvx = (best_x << 2) + bx; mvy = (best_y << 2) + by; subx = bx; suby = by;
+		}
+	}
+#undef HENC_IN_WIN
+#undef HENC_SAD_AT
+#undef HENC_TRY
+	mv_io->x = mvx; mv_io->y = mvy;
+	subpix_out->x = subx; subpix_out->y = suby;
+	return best_sad;
+}
+
+// ---- candidate derivation ---------------------------------------------------------------------------------------------
+HENC_INLINE int raster2abs(int r)   // raster2abs_table for the 16 x 16 unit grid (hmr_encoder_lib.c:95-100)
+{
+	const int x = r & 15, y = r >> 4;
+	int a = 0;
+	for (int b = 0; b < 4; b++) a |= (((x >> b) & 1) << (2 * b)) | (((y >> b) & 1) << (2 * b + 1));
+	return a;
+}
+struct CornerNodes { int lb, tl, tr; };
+HENC_INLINE CornerNodes corner_nodes(Enc &e, int ni)
+{
+	const Geo &q = e.geo[ni];
+	const int np = q.size >> 2, base = e.seq->depth_start[e.seq->max_cu_depth];
+	CornerNodes c;
+	c.lb = base + raster2abs(q.raster_index + 16 * (np - 1));
+	c.tl = base + raster2abs(q.raster_index);
+	c.tr = base + raster2abs(q.raster_index + np - 1);
+	return c;
+}
+// add_amvp_cand :2182 (one reference picture: list 0 index 0 is the only picture a neighbour can point to; the scaled variant
+// add_amvp_cand_order :2229 then adds the same unscaled vector under the same condition)
+HENC_INLINE int add_amvp_cand(MvCandList &l, CtuInfo *c, uint32_t idx)
+{
+	if (c && c->mv_ref_idx[idx] >= 0) {
+		l.mv[l.num++] = c->mv_ref[idx];
+		return 1;
+	}
+	return 0;
+}
+// get_amvp_candidates :2342
+HENC_INLINE void get_amvp_candidates(Enc &e, int ni, MvCandList &l)
+{
+	const CornerNodes cn = corner_nodes(e, ni);
+	uint32_t idx_lb = 0, idx_l = 0, idx_aux = 0;
+	CtuInfo *c_lb, *c_l = nullptr, *c_tr, *c_t, *c_tl;
+	l.num = 0;
+	node_of(e, cn.lb).left_bottom_nb = node_of(e, ni).left_bottom_nb;
+	c_lb = pu_left_bottom(e, cn.lb, &idx_lb);
+	int added_smvp = c_lb && c_lb->pred_mode[idx_lb] != PM_INTRA;
+	if (!added_smvp) {
+		c_l = pu_left(e, cn.lb, &idx_l);
+		added_smvp = c_l && c_l->pred_mode[idx_l] != PM_INTRA;
+	}
+	int added = add_amvp_cand(l, c_lb, idx_lb);
+	if (!added) {
+		c_l = pu_left(e, cn.lb, &idx_l);
+		added = add_amvp_cand(l, c_l, idx_l);
+	}
+	if (!added) {
+		added = add_amvp_cand(l, c_lb, idx_lb);
+		if (!added) added = add_amvp_cand(l, c_l, idx_l);
+	}
+	node_of(e, cn.tr).top_right_nb = node_of(e, ni).top_right_nb;
+	c_tr = pu_top_right(e, cn.tr, &idx_aux);
+	added = add_amvp_cand(l, c_tr, idx_aux);
+	if (!added) {
+		c_t = pu_top(e, cn.tr, &idx_aux, 0);
+		added = add_amvp_cand(l, c_t, idx_aux);
+	}
+	if (!added) {
+		c_tl = pu_top_left(e, cn.tl, &idx_aux);
+		added = add_amvp_cand(l, c_tl, idx_aux);
+	}
+	if (!added_smvp) {
+		c_tr = pu_top_right(e, cn.tr, &idx_aux);
+		added = add_amvp_cand(l, c_tr, idx_aux);
+		if (!added) {
+			c_t = pu_top(e, cn.tr, &idx_aux, 0);
+			added = add_amvp_cand(l, c_t, idx_aux);
+		}
+		if (!added) {
+			c_tl = pu_top_left(e, cn.tl, &idx_aux);
+			added = add_amvp_cand(l, c_tl, idx_aux);
+		}
+	}
+	if (l.num == 2 && l.mv[0].x == l.mv[1].x && l.mv[0].y == l.mv[1].y) l.num = 1;
+	if (l.num > 2) l.num = 2;
+	while (l.num < 2) {
+		l.mv[l.num].x = 0;
+		l.mv[l.num].y = 0;
+		l.num++;
+	}
+}
+
+// equal_motion :1913 (list 0 only carries vectors in P slices)
+HENC_INLINE int equal_motion(const CtuInfo *a, uint32_t ia, const CtuInfo *b, uint32_t ib)
+{
+	if (a->inter_mode[ia] != b->inter_mode[ib]) return 0;
+	if (a->inter_mode[ia] & 1) {
+		if (a->mv_ref[ia].x != b->mv_ref[ib].x || a->mv_ref[ia].y != b->mv_ref[ib].y || a->mv_ref_idx[ia] != b->mv_ref_idx[ib]) return 0;
+	}
+	return 1;
+}
+// get_merge_mvp_candidates :1937, P slice.  inter_modes[k] = inter_mode of candidate k's source unit.
+HENC_INLINE void get_merge_candidates(Enc &e, int ni, MvCandList &l, uint8_t *inter_modes)
+{
+	const int max_cand = e.seq->num_merge_cand;
+	const CornerNodes cn = corner_nodes(e, ni);
+	uint32_t i_l = 0, i_t = 0, i_tr = 0, i_lb = 0, i_tl = 0;
+	int cnt = 0;
+	for (int k = 0; k < max_cand; k++) l.ref_idx[k] = -1;
+	l.num = 0;
+	CtuInfo *c_l = pu_left(e, cn.lb, &i_l);
+	const int a1 = c_l && c_l->pred_mode[i_l] != PM_INTRA;
+	if (a1) {
+		inter_modes[cnt] = c_l->inter_mode[i_l];
+		l.mv[cnt] = c_l->mv_ref[i_l];
+		l.ref_idx[cnt] = c_l->mv_ref_idx[i_l];
+		cnt++;
+	}
+	if (cnt >= max_cand) { l.num = cnt; return; }
+	CtuInfo *c_t = pu_top(e, cn.tr, &i_t, 0);
+	const int b1 = c_t && c_t->pred_mode[i_t] != PM_INTRA;
+	if (b1 && (!a1 || !equal_motion(c_l, i_l, c_t, i_t))) {
+		inter_modes[cnt] = c_t->inter_mode[i_t];
+		l.mv[cnt] = c_t->mv_ref[i_t];
+		l.ref_idx[cnt] = c_t->mv_ref_idx[i_t];
+		cnt++;
+	}
+	if (cnt >= max_cand) { l.num = cnt; return; }
+	node_of(e, cn.tr).top_right_nb = node_of(e, ni).top_right_nb;
+	CtuInfo *c_tr = pu_top_right(e, cn.tr, &i_tr);
+	const int b0 = c_tr && c_tr->pred_mode[i_tr] != PM_INTRA;
+	if (b0 && (!b1 || !equal_motion(c_t, i_t, c_tr, i_tr))) {
+		inter_modes[cnt] = c_tr->inter_mode[i_tr];
+		l.mv[cnt] = c_tr->mv_ref[i_tr];
+		l.ref_idx[cnt] = c_tr->mv_ref_idx[i_tr];
+		cnt++;
+	}
+	if (cnt >= max_cand) { l.num = cnt; return; }
+	node_of(e, cn.lb).left_bottom_nb = node_of(e, ni).left_bottom_nb;
+	CtuInfo *c_lb = pu_left_bottom(e, cn.lb, &i_lb);
+	const int a0 = c_lb && c_lb->pred_mode[i_lb] != PM_INTRA;
+	if (a0 && (!a1 || !equal_motion(c_l, i_l, c_lb, i_lb))) {
+		inter_modes[cnt] = c_lb->inter_mode[i_lb];
+		l.mv[cnt] = c_lb->mv_ref[i_lb];
+		l.ref_idx[cnt] = c_lb->mv_ref_idx[i_lb];
+		cnt++;
+	}
+	if (cnt >= max_cand) { l.num = cnt; return; }
+	if (cnt < 4) {
+		CtuInfo *c_tl = pu_top_left(e, cn.tl, &i_tl);
+		const int b2 = c_tl && c_tl->pred_mode[i_tl] != PM_INTRA;
+		if (b2 && (!a1 || !equal_motion(c_l, i_l, c_tl, i_tl)) && (!b1 || !equal_motion(c_t, i_t, c_tl, i_tl))) {
+			inter_modes[cnt] = c_tl->inter_mode[i_tl];
+			l.mv[cnt] = c_tl->mv_ref[i_tl];
+			l.ref_idx[cnt] = c_tl->mv_ref_idx[i_tl];
+			cnt++;
+		}
+	}
+	if (cnt >= max_cand) { l.num = cnt; return; }
+	int addr = cnt;
+	while (addr < max_cand) {       // zero candidates (one reference picture: index 0)
+		inter_modes[addr] = 1;
+		l.mv[addr].x = 0;
+		l.mv[addr].y = 0;
+		l.ref_idx[addr] = 0;
+		addr++;
+	}
+	l.num = addr;
+}
+
+// ---- inter TUs ---------------------------------------------------------------------------------------------------------
+// encode_inter_cu :40 (comp 0) / encode_inter_cu_chroma :133: DCT + quant, keep-or-drop decision in the residual domain, reconstruction
+template <class G>
+HENC_HD uint32_t encode_inter_tu(const G &g, Enc &e, int ni, int comp, int depth, int part_size_type, int *curr_sum)
+{
+	Work &w = *e.w;
+	Node &nd = node_of(e, ni);
+	const int original_depth = e.geo[ni].depth;
+	const int pi = (comp == COMP_Y || e.geo[ni].size_chroma != 2) ? ni : e.geo[ni].parent;     // 2x2 chroma: coded as the parent's 4x4
+	const Geo &q = e.geo[pi];
+	const int is_y = comp == COMP_Y;
+	const int curr_depth = q.depth, n = is_y ? q.size : q.size_chroma, x = is_y ? q.x : q.xc, y = is_y ? q.y : q.yc;
+	const int cs = ctu_stride(comp), ds = dec_stride(comp);
+	const int wnd = original_depth + 1 + (part_size_type != PART_2Nx2N);
+	const int qp = is_y ? (int)nd.qp : chroma_qp_table((int)nd.qp + e.seq->chroma_qp_offset);
+	const int per = qp / 6, rem = qp % 6;
+	const double weight = is_y ? 1.0 : e.f->chroma_weight;
+	const int off = is_y ? (q.abs_index << 4) : ((q.abs_index << 4) >> 2);
+	const int16_t *pred = pred_ptr(w, comp) + y * cs + x;
+	int16_t *resid = resid_ptr(w, comp) + y * cs + x, *rdec = rdec_ptr(w, comp) + y * cs + x;
+	int16_t *quant = tq_ptr(w, wnd, comp) + off, *iquant = iq_ptr(w, comp) + off;
+	int16_t *dec = dec_ptr(w, wnd, comp) + y * ds + x;
+	tr_forward(g, e.T, resid, cs, w.pred_aux, quant, n, 0);
+	int sum = quantize(g, e.T, w.pred_aux, quant, w.delta_u, SCAN_DIAG, curr_depth, comp, 0, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
+	nd.inter_cbf[comp] = (sum ? 1 : 0) << (original_depth - depth);
+	if (is_y) nd.inter_tr_idx = original_depth - depth;
+	uint32_t ssd;
+	if (sum > 0) {
+		const uint32_t raw_zero = blk_ssq(g, resid, cs, n);
+		dequantize(g, e.T, quant, iquant, curr_depth, comp, 0, n, per, rem);
+		tr_inverse(g, e.T, rdec, cs, iquant, w.pred_aux, n, 0);
+		const uint32_t raw = blk_ssd(g, resid, cs, rdec, cs, n);
+		uint32_t ssd_zero;
+		if (is_y) { ssd_zero = raw_zero; ssd = raw; }
+		else { ssd_zero = (uint32_t)(weight * raw_zero); ssd = (uint32_t)(weight * raw); }
+		const double thr = hclip(e.f->avg_dist / 2.5 - 5., 1., 20000.);
+		if (is_y ? ((double)ssd_zero <= (double)(int)ssd + thr * sum) : ((double)ssd_zero <= (double)ssd + thr * sum)) {
+			lin_zero(g, quant, n * n);
+			sum = 0;
+			nd.inter_cbf[comp] = 0;
+			blk_reconst(g, pred, cs, (const int16_t *)nullptr, 0, dec, ds, n);
+		} else {
+			blk_reconst(g, pred, cs, rdec, cs, dec, ds, n);
+		}
+	} else {
+		const uint32_t raw = blk_ssq(g, resid, cs, n);
+		ssd = is_y ? raw : (uint32_t)(weight * raw);
+		blk_reconst(g, pred, cs, (const int16_t *)nullptr, 0, dec, ds, n);
+	}
+	*curr_sum = sum;
+	if (is_y) nd.sum = (uint32_t)sum;
+	else nd.sum += (uint32_t)sum;
+	return ssd;
+}
+
+// SET_ENC_INFO_BUFFS :2451
+template <class G>
+HENC_HD void set_enc_info_buffs(const G &g, Enc &e, int ni, int depth)
+{
+	const Geo &q = e.geo[ni];
+	const Node &nd = node_of(e, ni);
+	Work &w = *e.w;
+	for (int i = g.tid; i < q.num_part; i += g.n) {
+		w.cbf_buffs[COMP_Y][depth][q.abs_index + i] = (uint8_t)nd.inter_cbf[COMP_Y];
+		w.cbf_buffs[COMP_U][depth][q.abs_index + i] = (uint8_t)nd.inter_cbf[COMP_U];
+		w.cbf_buffs[COMP_V][depth][q.abs_index + i] = (uint8_t)nd.inter_cbf[COMP_V];
+		w.tr_idx_buffs[depth][q.abs_index + i] = (uint8_t)nd.inter_tr_idx;
+	}
+	g.sync();
+}
+
+// encode_inter :3071 - the transform tree of an inter CU; referenced by the prediction depth
+template <class G>
+HENC_HD uint32_t encode_inter(const G &g, Enc &e, int depth, int part_position, int part_size_type)
+{
+	const Seq &S = *e.seq;
+	Work &w = *e.w;
+	const int nxn = part_size_type != PART_2Nx2N;
+	int parent, curr, initial_state, end_state;
+	uint32_t qp;
+	if (depth == 0 && S.max_cu_size == 64) {
+		parent = S.depth_start[0];
+		curr = e.geo[parent].child[0];
+		node_of(e, parent).cost = 0x7fffffff;
+		initial_state = part_position & 3;
+		end_state = initial_state;
+		qp = node_of(e, parent).qp;
+	} else {
+		curr = node_at(e, depth, part_position);
+		parent = e.geo[curr].parent;
+		initial_state = part_position & 3;
+		end_state = initial_state + 1;
+		qp = node_of(e, curr).qp;
+	}
+	int curr_depth = e.geo[curr].depth;
+	const int log2cu_size = S.max_cu_size_shift - depth;
+	const int one_level_nxn = (S.max_inter_tr_depth == 1 && nxn);
+	int cu_min_tu_size_shift;
+	if (log2cu_size < S.min_tu_size_shift + S.max_inter_tr_depth - 1 + one_level_nxn) cu_min_tu_size_shift = S.min_tu_size_shift;
+	else {
+		cu_min_tu_size_shift = log2cu_size - (S.max_inter_tr_depth - 1 + one_level_nxn);
+		if (cu_min_tu_size_shift > S.max_tu_size_shift) cu_min_tu_size_shift = S.max_tu_size_shift;
+	}
+	int max_tr_processing_depth = S.max_cu_size_shift - cu_min_tu_size_shift;
+	if (S.perf_mode >= 1) max_tr_processing_depth = depth == 0 ? 1 : (depth + (nxn ? 1 : 0));
+	if (S.max_inter_tr_depth == 1 && nxn && curr_depth == depth && log2cu_size > max_tr_processing_depth) {
+		parent = curr;
+		curr = e.geo[parent].child[0];
+		node_of(e, parent).distortion = node_of(e, parent).cost = MAX_COST;
+		initial_state = part_position & 3;
+		end_state = initial_state;
+	}
+	int depth_state[NDEPTH] = {0, 0, 0, 0, 0};
+	depth_state[curr_depth] = initial_state;
+	curr_depth = e.geo[curr].depth;
+	int curr_sum_y = 0, curr_sum_u = 0, curr_sum_v = 0;
+	while (curr_depth != depth || depth_state[curr_depth] != end_state) {
+		curr = parent < 0 ? curr : e.geo[parent].child[depth_state[curr_depth]];
+		Node &cn = node_of(e, curr);
+		cn.qp = qp;
+		curr_depth = e.geo[curr].depth;
+		uint32_t dist_y = encode_inter_tu(g, e, curr, COMP_Y, depth, part_size_type, &curr_sum_y), dist_u, dist_v;
+		if (e.geo[curr].size_chroma != 2 || depth_state[curr_depth] == 0) {
+			dist_u = encode_inter_tu(g, e, curr, COMP_U, depth, part_size_type, &curr_sum_u);
+			dist_v = encode_inter_tu(g, e, curr, COMP_V, depth, part_size_type, &curr_sum_v);
+		} else {
+			dist_u = dist_v = 0;
+			cn.inter_cbf[COMP_U] = node_of(e, curr - 1).inter_cbf[COMP_U];
+			cn.inter_cbf[COMP_V] = node_of(e, curr - 1).inter_cbf[COMP_V];
+		}
+		cn.distortion = dist_y + dist_u + dist_v;
+		cn.cost = cn.distortion;
+		cn.sum = (uint32_t)(curr_sum_y + curr_sum_u + curr_sum_v);
+		depth_state[curr_depth]++;
+		if (curr_depth < max_tr_processing_depth) {
+			curr_depth++;
+			parent = curr;
+		} else if (depth_state[curr_depth] == 4) {
+			while (depth_state[curr_depth] == 4 && curr_depth > depth) {
+				const Geo &pq = e.geo[parent];
+				Node &pn = node_of(e, parent);
+				Node &c0 = node_of(e, pq.child[0]), &c1 = node_of(e, pq.child[1]), &c2 = node_of(e, pq.child[2]), &c3 = node_of(e, pq.child[3]);
+				const double distortion = (double)c0.distortion + c1.distortion + c2.distortion + c3.distortion;
+				const uint32_t sum = c0.sum + c1.sum + c2.sum + c3.sum;
+				const double cost = distortion;
+				const int buff_depth = depth + nxn;
+				depth_state[curr_depth] = 0;
+				if (cost < pn.cost) {
+					pn.cost = (uint32_t)cost;
+					pn.distortion = (uint32_t)distortion;
+					pn.sum = sum;
+					const int tr_mask = 1 << (curr_depth - depth);
+					if (curr_depth == max_tr_processing_depth) {
+						uint32_t sp[3];
+						for (int c = 0; c < 3; c++)
+							sp[c] = ((c0.inter_cbf[c] & tr_mask) | (c1.inter_cbf[c] & tr_mask) | (c2.inter_cbf[c] & tr_mask) | (c3.inter_cbf[c] & tr_mask)) >> 1;
+						for (int k = 0; k < 4; k++) {
+							Node &ck = node_of(e, pq.child[k]);
+							ck.inter_cbf[0] |= (int32_t)sp[0];
+							ck.inter_cbf[1] |= (int32_t)sp[1];
+							ck.inter_cbf[2] |= (int32_t)sp[2];
+							set_enc_info_buffs(g, e, pq.child[k], buff_depth);
+						}
+					} else {
+						uint32_t cb[3];
+						for (int c = 0; c < 3; c++) {
+							const uint8_t *b = w.cbf_buffs[c][buff_depth];
+							cb[c] = ((b[e.geo[pq.child[0]].abs_index] & tr_mask) | (b[e.geo[pq.child[1]].abs_index] & tr_mask) | (b[e.geo[pq.child[2]].abs_index] & tr_mask) |
+								 (b[e.geo[pq.child[3]].abs_index] & tr_mask)) >> 1;
+						}
+						g.sync();
+						for (int i = g.tid; i < pq.num_part; i += g.n)
+							for (int c = 0; c < 3; c++) w.cbf_buffs[c][buff_depth][pq.abs_index + i] |= (uint8_t)cb[c];
+						g.sync();
+					}
+					sync_motion_buffers_luma(g, e, parent, curr_depth + 1 + nxn, curr_depth + nxn, curr_depth + 1 + nxn, curr_depth + nxn);
+					sync_motion_buffers_chroma(g, e, parent, curr_depth + 1 + nxn, curr_depth + nxn, curr_depth + 1 + nxn, curr_depth + nxn);
+				} else {
+					set_enc_info_buffs(g, e, parent, buff_depth);
+				}
+				curr_depth--;
+				parent = e.geo[parent].parent;
+			}
+		}
+	}
+	const int top = node_at(e, depth, part_position);
+	if (depth == max_tr_processing_depth) set_enc_info_buffs(g, e, top, depth + nxn);
+	{
+		const Geo &tq = e.geo[top];
+		const int8_t ri = (int8_t)node_of(e, top).inter_ref_index;
+		for (int i = g.tid; i < tq.num_part; i += g.n) e.ctu->mv_ref_idx[tq.abs_index + i] = ri;
+		g.sync();
+	}
+	return node_of(e, top).cost;
+}
+
+// SET_INTER_MV_BUFFS :2460 + the reference-index memsets that follow it in predict_inter :3042-3044
+template <class G>
+HENC_HD void set_inter_mv_buffs(const G &g, Enc &e, int ni)
+{
+	const Geo &q = e.geo[ni];
+	const Node &nd = node_of(e, ni);
+	for (int i = g.tid; i < q.num_part; i += g.n) {
+		e.ctu->mv_ref[q.abs_index + i] = nd.inter_mv;
+		e.ctu->mv_ref_idx[q.abs_index + i] = (int8_t)nd.inter_ref_index;
+	}
+	g.sync();
+}
+
+template <class G>
+HENC_HD void predict_all_comps(const G &g, Enc &e, int ni)
+{
+	Work &w = *e.w;
+	const Geo &q = e.geo[ni];
+	blk_predict(g, w.curr_y + q.y * 64 + q.x, 64, w.pred_y + q.y * 64 + q.x, 64, w.resid_y + q.y * 64 + q.x, 64, q.size);
+	for (int c = 0; c < 2; c++)
+		blk_predict(g, w.curr_c[c] + q.yc * 32 + q.xc, 32, w.pred_c[c] + q.yc * 32 + q.xc, 32, w.resid_c[c] + q.yc * 32 + q.xc, 32, q.size_chroma);
+}
+
+template <class G>
+HENC_HD void motion_compensate_cu(const G &g, Enc &e, int ni, MV mv)
+{
+	Work &w = *e.w;
+	const Geo &q = e.geo[ni];
+	const Seq &S = *e.seq;
+	const int gx = e.ctu->x + q.x, gy = e.ctu->y + q.y, gxc = (e.ctu->x >> 1) + q.xc, gyc = (e.ctu->y >> 1) + q.yc;
+	mc_luma(g, e, e.f->ref[0] + gy * S.stride_y + gx, S.stride_y, w.pred_y + q.y * 64 + q.x, 64, q.size, mv.x, mv.y);
+	mc_chroma(g, e, e.f->ref[1] + gyc * S.stride_c + gxc, S.stride_c, w.pred_c[0] + q.yc * 32 + q.xc, 32, q.size_chroma, mv.x, mv.y);
+	mc_chroma(g, e, e.f->ref[2] + gyc * S.stride_c + gxc, S.stride_c, w.pred_c[1] + q.yc * 32 + q.xc, 32, q.size_chroma, mv.x, mv.y);
+}
+
+// predict_inter :2924 (uni-directional): vector predictor choice, motion compensation, residual.  Returns the vector cost.
+template <class G>
+HENC_HD int predict_inter(const G &g, Enc &e, int depth, int part_position, int part_size_type)
+{
+	int curr = node_at(e, depth, part_position), num_partitions = 1;
+	if (part_size_type == PART_NxN) {
+		curr = e.geo[e.geo[curr].parent].child[0];
+		num_partitions = 4;
+	}
+	int mv_cost = 0;
+	for (int np = 0; np < num_partitions; np++, curr++) {
+		Node &nd = node_of(e, curr);
+		const MV mv = nd.inter_mv;
+		get_amvp_candidates(e, curr, e.w->amvp);
+		mv_cost += (int)mv_cost_sqrt(e.w->amvp, nd.qp, mv.x, mv.y, &nd.best_candidate_idx);
+		nd.best_dif_mv.x = mv.x - e.w->amvp.mv[nd.best_candidate_idx].x;
+		nd.best_dif_mv.y = mv.y - e.w->amvp.mv[nd.best_candidate_idx].y;
+		set_inter_mv_buffs(g, e, curr);
+		motion_compensate_cu(g, e, curr, mv);
+		predict_all_comps(g, e, curr);
+	}
+	return mv_cost;
+}
+
+// hmr_cu_motion_estimation :2471 (list 0, one reference).  Returns SAD + vector cost.
+template <class G>
+HENC_HD int cu_motion_estimation(const G &g, Enc &e, int depth, int part_position, int part_size_type, int action)
+{
+	Work &w = *e.w;
+	const Seq &S = *e.seq;
+	int curr = node_at(e, depth, part_position), num_partitions = 1;
+	if (part_size_type == PART_NxN) {
+		curr = e.geo[e.geo[curr].parent].child[0];
+		num_partitions = 4;
+	}
+	uint32_t sad = 0, mv_total_cost = 0;
+	for (int np = 0; np < num_partitions; np++, curr++) {
+		const Geo &q = e.geo[curr];
+		Node &nd = node_of(e, curr);
+		const int gx = e.ctu->x + q.x, gy = e.ctu->y + q.y;
+		MvCandList amvp;
+		get_amvp_candidates(e, curr, amvp);
+		w.search_cands.num = 0;
+		for (int i = 0; i < amvp.num; i++)
+			if (amvp.mv[i].x != 0 && amvp.mv[i].y != 0) w.search_cands.mv[w.search_cands.num++] = amvp.mv[i];
+		if (q.parent >= 0) {
+			const MV pm = node_of(e, q.parent).inter_mv;
+			if (pm.x != 0 && pm.y != 0) w.search_cands.mv[w.search_cands.num++] = pm;
+		}
+		MV mv = {0, 0}, subpix = {0, 0};
+		if ((action & (ME_HALF | ME_QUARTER)) && !(action & ME_PEL)) {
+			mv = nd.inter_mv;
+			subpix = nd.subpix_mv;
+		}
+		const double corr = calc_mv_correction(nd.qp, e.f->avg_dist);
+		const uint32_t cost = motion_estimation(g, e, w.curr_y + q.y * 64 + q.x, e.f->ref[0] + gy * S.stride_y + gx, S.stride_y, gx, gy, q.size, amvp,
+							w.search_cands, corr, action, &mv, &subpix);
+		int mvp_idx = 0;
+		const uint32_t mv_cost = mv_cost_fast(amvp, corr, mv.x, mv.y, &mvp_idx);
+		nd.subpix_mv = subpix;
+		// best_cost starts at MAX_COST with a zero vector cost, so the single reference always wins (:2652)
+		nd.inter_mv = mv;
+		nd.inter_ref_index = 0;
+		nd.inter_mode = 1;
+		w.amvp = amvp;
+		nd.best_candidate_idx = mvp_idx;
+		nd.best_dif_mv.x = mv.x - amvp.mv[mvp_idx].x;
+		nd.best_dif_mv.y = mv.y - amvp.mv[mvp_idx].y;
+		sad += cost;
+		mv_total_cost += mv_cost;
+		nd.inter_mode = 1;
+		if (part_size_type == PART_NxN) {
+			set_inter_mv_buffs(g, e, curr);
+			for (int i = g.tid; i < q.num_part; i += g.n) {
+				e.ctu->inter_mode[q.abs_index + i] = (uint8_t)nd.inter_mode;
+				e.ctu->pred_mode[q.abs_index + i] = PM_INTER;
+			}
+			g.sync();
+		}
+	}
+	return (int)(sad + mv_total_cost);
+}
+
+}  // namespace henc

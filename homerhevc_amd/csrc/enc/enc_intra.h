@@ -1,0 +1,463 @@
+// Intra coding of a CU: mode search, transform tree, chroma.
+// Restates hmr_motion_intra.c:970-1630 (encode_intra_cu, homer_loop1_motion_intra, encode_intra_luma),
+// hmr_motion_intra_chroma.c:92-469 (encode_intra_chroma) and hmr_motion_intra.c:1731-1757 (encode_intra)
+// for rd_mode != RD_FULL (BASELINE configs 1-4; the full-RDO bit estimators are a later row).
+#pragma once
+#include "enc_common.h"
+
+namespace henc {
+
+HENC_INLINE int intra_is_filtered(int mode, int inv_depth)
+{
+	const int intra_filter[5] = {10, 7, 1, 0, 10};   // hmr_motion_intra.c:148
+	const int diff = hmin(habs(mode - HOR_IDX), habs(mode - VER_IDX));
+	return (mode != DC_IDX) && (diff > intra_filter[inv_depth - 2]);
+}
+
+// fill_reference_samples for the node's block of component class `comp` in decoded window `wnd` (+ smoothing when asked)
+template <class G>
+HENC_HD void node_fill_refs(const G &g, Enc &e, int ni, int wnd, int comp, int want_filtered)
+{
+	const Geo &q = e.geo[ni];
+	const Node &nd = node_of(e, ni);
+	const int is_y = comp == COMP_Y;
+	const int n = is_y ? q.size : q.size_chroma, x = is_y ? q.x : q.xc, y = is_y ? q.y : q.yc;
+	const int pw = is_y ? e.seq->width : e.seq->width >> 1, ph = is_y ? e.seq->height : e.seq->height >> 1;
+	const int cx = is_y ? e.ctu->x : e.ctu->x >> 1, cy = is_y ? e.ctu->y : e.ctu->y >> 1;
+	const int bl_size = hmin(n, ph - (cy + y + n)), tr_size = hmin(n, pw - (cx + x + n));
+	const int st = dec_stride(comp);
+	const int16_t *corner = dec_ptr(*e.w, wnd, comp) + (y - 1) * st + (x - 1);
+	intra_fill_refs(g, corner, st, n, nd.left_nb, nd.top_nb, nd.left_bottom_nb, nd.top_right_nb, bl_size, tr_size, e.w->adi);
+	if (want_filtered) intra_adi_filter(g, e.w->adi, e.w->adi_f, n, e.seq->strong_intra);
+}
+
+// most probable modes as the DECISION code sees them (homer_loop1_motion_intra, hmr_motion_intra.c:1102-1104 through
+// get_intra_dir_luma_predictor, hmr_arithmetic_encoding.c:545): the left / top unit inside the CTU is looked up in the
+// worker's mode buffer of the PU's depth and always counts as intra (the worker's shadow CTU keeps pred_mode == INTRA
+// from the first frame on); units of other CTUs use those CTUs' final arrays.  The worker's buffer is NOT reset between
+// CTUs: for a neighbour that ended up inter-coded it holds whatever earlier CUs left there, which is part of the
+// reference's single-thread behaviour and therefore of the bitstream.
+HENC_INLINE int read_mode_buff(Enc &e, int depth, uint32_t idx)
+{
+	return e.w->intra_mode_buffs[COMP_Y][depth][idx];
+}
+HENC_INLINE void intra_dir_predictor(Enc &e, int ni, int depth, int *preds)
+{
+	uint32_t idx = 0;
+	CtuInfo *cl = pu_left(e, ni, &idx);
+	int left_dir = DC_IDX, top_dir = DC_IDX;
+	if (cl == e.ctu) left_dir = read_mode_buff(e, depth, idx);
+	else if (cl) left_dir = cl->pred_mode[idx] == PM_INTRA ? cl->intra_mode[COMP_Y][idx] : DC_IDX;
+	CtuInfo *ct = pu_top(e, ni, &idx, 1);
+	if (ct == e.ctu) top_dir = read_mode_buff(e, depth, idx);
+	else if (ct) top_dir = ct->pred_mode[idx] == PM_INTRA ? ct->intra_mode[COMP_Y][idx] : DC_IDX;
+	if (left_dir == top_dir) {
+		if (left_dir > 1) {
+			preds[0] = left_dir;
+			preds[1] = ((left_dir + 29) % 32) + 2;
+			preds[2] = ((left_dir - 1) % 32) + 2;
+		} else {
+			preds[0] = PLANAR_IDX; preds[1] = DC_IDX; preds[2] = VER_IDX;
+		}
+	} else {
+		preds[0] = left_dir;
+		preds[1] = top_dir;
+		if (left_dir && top_dir) preds[2] = PLANAR_IDX;
+		else preds[2] = (left_dir + top_dir) < 2 ? VER_IDX : DC_IDX;
+	}
+}
+
+// homer_loop1_motion_intra, hmr_motion_intra.c:1084-1180.  Returns the bit cost of the winner; *best_mode / *best_cost out.
+template <class G>
+HENC_HD int intra_mode_search(const G &g, Enc &e, int ni, int depth, int *best_mode_out, double *best_cost_out)
+{
+	const Geo &q = e.geo[ni];
+	Work &w = *e.w;
+	const int n = q.size, curr_depth = q.depth, inv_depth = e.seq->max_cu_size_shift - curr_depth;
+	node_fill_refs(g, e, ni, depth + 1, COMP_Y, 1);
+	int preds[3];
+	intra_dir_predictor(e, ni, curr_depth, preds);
+	const int search_points[4][5] = {{0, 1, 0, 8, 16}, {2, 10, 16, 22, 30}, {-4, -2, 2, 4, 0}, {-1, 1, 0, 0, 0}};
+	const int num_search_points[4] = {2, 5, 4, 2};
+	int best_cu_mode = 0, new_best = 0, min_mode = 0, max_mode = 1, best_bit_cost = 0;
+	double best_cost = MAX_COST;
+	int16_t *pred = w.pred_y + q.y * CTU_STRIDE_Y + q.x;
+	const int16_t *orig = w.curr_y + q.y * CTU_STRIDE_Y + q.x;
+	for (int loop = 0; loop < 4; loop++) {
+		if (loop == 1) { best_cu_mode = 2; min_mode = 2; max_mode = 34; }
+		for (int k = 0; k < num_search_points[loop]; k++) {
+			const int mode = best_cu_mode + search_points[loop][k];
+			if (mode < min_mode || mode > max_mode) continue;
+			const int filt = intra_is_filtered(mode, inv_depth);
+			const uint32_t sad = intra_predict_sad(g, pred, CTU_STRIDE_Y, orig, CTU_STRIDE_Y, filt ? w.adi_f : w.adi, n, mode, 1);
+			double cost = (double)sad;
+			int bit_cost = 0;
+			if (e.seq->rd_mode == RDM_FAST) {
+				bit_cost = (preds[0] == mode || preds[1] == mode || preds[2] == mode) ? 1 : 12;
+				cost += bit_cost * e.f->sqrt_lambda;
+			}
+			if (cost < best_cost) { best_cost = cost; new_best = mode; best_bit_cost = bit_cost; }
+		}
+		best_cu_mode = new_best;
+	}
+	*best_mode_out = best_cu_mode;
+	*best_cost_out = best_cost;
+	return best_bit_cost;
+}
+
+// encode_intra_cu, hmr_motion_intra.c:973-1071: one luma TU.  depth = prediction depth.  Returns the SSD, *curr_sum the level sum.
+template <class G>
+HENC_HD uint32_t encode_intra_tu(const G &g, Enc &e, int ni, int depth, int cu_mode, int part_size_type, int *curr_sum)
+{
+	const Geo &q = e.geo[ni];
+	Node &nd = node_of(e, ni);
+	Work &w = *e.w;
+	const int curr_depth = q.depth, n = q.size;
+	const int scan_mode = find_scan_mode(1, 1, n, cu_mode, 0);
+	const int per = nd.qp / 6, rem = nd.qp % 6;
+	const int wnd = curr_depth + 1;
+	int16_t *pred = w.pred_y + q.y * CTU_STRIDE_Y + q.x, *resid = w.resid_y + q.y * CTU_STRIDE_Y + q.x;
+	const int16_t *orig = w.curr_y + q.y * CTU_STRIDE_Y + q.x;
+	int16_t *quant = w.tq_y[wnd] + (q.abs_index << 4), *iquant = w.iq_y + (q.abs_index << 4);
+	int16_t *dec = dec_ptr(w, wnd, COMP_Y) + q.y * DEC_STRIDE_Y + q.x;
+	const int inv_depth = e.seq->max_cu_size_shift - curr_depth;
+	const int filt = intra_is_filtered(cu_mode, inv_depth);
+	node_fill_refs(g, e, ni, wnd, COMP_Y, filt);
+	intra_predict(g, pred, CTU_STRIDE_Y, filt ? w.adi_f : w.adi, n, cu_mode, 1);
+	blk_predict(g, orig, CTU_STRIDE_Y, pred, CTU_STRIDE_Y, resid, CTU_STRIDE_Y, n);
+	tr_forward(g, e.T, resid, CTU_STRIDE_Y, w.pred_aux, quant, n, cu_mode != REG_DCT);   // `quant` doubles as the stage buffer (the reference passes it as aux)
+	const int sum = quantize(g, e.T, w.pred_aux, quant, w.delta_u, scan_mode, curr_depth, COMP_Y, 1, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
+	*curr_sum = sum;
+	const int tr = curr_depth - depth + (part_size_type == PART_NxN);
+	nd.sum = (uint32_t)sum;
+	nd.intra_cbf[COMP_Y] = (sum ? 1 : 0) << tr;
+	nd.intra_tr_idx = tr;
+	nd.intra_mode[COMP_Y] = cu_mode;
+	if (sum) {
+		dequantize(g, e.T, quant, iquant, curr_depth, COMP_Y, 1, n, per, rem);
+		tr_inverse(g, e.T, resid, CTU_STRIDE_Y, iquant, w.pred_aux, n, cu_mode != REG_DCT);
+		blk_reconst(g, pred, CTU_STRIDE_Y, resid, CTU_STRIDE_Y, dec, DEC_STRIDE_Y, n);
+	} else {
+		blk_reconst(g, pred, CTU_STRIDE_Y, (const int16_t *)nullptr, 0, dec, DEC_STRIDE_Y, n);
+	}
+	return blk_ssd(g, orig, CTU_STRIDE_Y, dec, DEC_STRIDE_Y, n);
+}
+
+template <class G>
+HENC_HD void set_intra_info_buffs(const G &g, Enc &e, int depth, int ni)
+{
+	const Geo &q = e.geo[ni];
+	const Node &nd = node_of(e, ni);
+	Work &w = *e.w;
+	for (int i = g.tid; i < q.num_part; i += g.n) {
+		w.cbf_buffs[COMP_Y][depth][q.abs_index + i] = (uint8_t)nd.intra_cbf[COMP_Y];
+		w.tr_idx_buffs[depth][q.abs_index + i] = (uint8_t)nd.intra_tr_idx;
+		w.intra_mode_buffs[COMP_Y][depth][q.abs_index + i] = (uint8_t)nd.intra_mode[COMP_Y];
+	}
+	g.sync();
+}
+
+// encode_intra_luma, hmr_motion_intra.c:1229-1630 (non-HM path): search, then the transform tree of the winner.
+template <class G>
+HENC_HD uint32_t encode_intra_luma(const G &g, Enc &e, int depth, int part_position, int part_size_type)
+{
+	const Seq &S = *e.seq;
+	Work &w = *e.w;
+	const int top_ni = node_at(e, depth, part_position);
+	const uint32_t qp = node_of(e, top_ni).qp;
+	int cu_mode;
+	double search_cost;
+	const int bitcost_cu_mode = intra_mode_search(g, e, top_ni, depth, &cu_mode, &search_cost);
+
+	int parent, curr, initial_state, end_state;
+	if (depth == 0 && S.max_cu_size == 64) {
+		parent = S.depth_start[0];
+		curr = e.geo[parent].child[0];
+		node_of(e, parent).cost = 0x7fffffff;
+		initial_state = part_position & 3;
+		end_state = initial_state;
+	} else {
+		curr = top_ni;
+		parent = e.geo[curr].parent;
+		initial_state = part_position & 3;
+		end_state = initial_state + 1;
+	}
+	int curr_depth = e.geo[curr].depth;
+	const int log2cu_size = S.max_cu_size_shift - (depth - (part_size_type == PART_NxN));
+	int cu_min_tu_size_shift;
+	if (log2cu_size < S.min_tu_size_shift + S.max_intra_tr_depth - 1 + (part_size_type == PART_NxN)) cu_min_tu_size_shift = S.min_tu_size_shift;
+	else {
+		cu_min_tu_size_shift = log2cu_size - (S.max_intra_tr_depth - 1 + (part_size_type == PART_NxN));
+		if (cu_min_tu_size_shift > 5) cu_min_tu_size_shift = 5;
+	}
+	int max_tr_processing_depth = S.max_cu_size_shift - cu_min_tu_size_shift;
+	if (S.perf_mode >= 1)
+		max_tr_processing_depth = (depth + 2 <= max_tr_processing_depth) ? depth + 2 : ((depth + 1 <= max_tr_processing_depth) ? depth + 1 : max_tr_processing_depth);
+
+	int depth_state[NDEPTH] = {0, 0, 0, 0, 0};
+	depth_state[curr_depth] = initial_state;
+	while (curr_depth != depth || depth_state[curr_depth] != end_state) {
+		curr = parent < 0 ? curr : e.geo[parent].child[depth_state[curr_depth]];
+		Node &cn = node_of(e, curr);
+		cn.qp = qp;
+		curr_depth = e.geo[curr].depth;
+		int curr_sum = 0;
+		cn.distortion = encode_intra_tu(g, e, curr, depth, cu_mode, part_size_type, &curr_sum);
+		cn.sum = (uint32_t)curr_sum;
+		cn.cost = cn.distortion;
+		depth_state[curr_depth]++;
+		if (curr_depth < max_tr_processing_depth) {
+			curr_depth++;
+			parent = curr;
+		} else if (depth_state[curr_depth] == 4) {
+			while (depth_state[curr_depth] == 4 && curr_depth > depth) {
+				const Geo &pq = e.geo[parent];
+				Node &pn = node_of(e, parent);
+				Node &c0 = node_of(e, pq.child[0]), &c1 = node_of(e, pq.child[1]), &c2 = node_of(e, pq.child[2]), &c3 = node_of(e, pq.child[3]);
+				const uint32_t sum = c0.sum + c1.sum + c2.sum + c3.sum;
+				const double distortion = (double)c0.distortion + c1.distortion + c2.distortion + c3.distortion;
+				const double cost = distortion;
+				depth_state[curr_depth] = 0;
+				bool take_children;
+				if (S.rd_mode != RDM_FAST) take_children = cost < pn.cost;
+				else take_children = 1.25 * (cost + (double)(uint32_t)(45u * sum)) < (double)(uint32_t)(pn.cost + 45u * pn.sum);
+				if (take_children) {
+					pn.cost = (uint32_t)cost;
+					pn.distortion = (uint32_t)distortion;
+					pn.sum = sum;
+					if (curr_depth == max_tr_processing_depth) {
+						const int tr_mask = 1 << (curr_depth - depth + (part_size_type == PART_NxN));
+						uint32_t cbf_split = (c0.intra_cbf[0] & tr_mask) | (c1.intra_cbf[0] & tr_mask) | (c2.intra_cbf[0] & tr_mask) | (c3.intra_cbf[0] & tr_mask);
+						cbf_split >>= 1;
+						for (int k = 0; k < 4; k++) {
+							node_of(e, pq.child[k]).intra_cbf[0] |= (int32_t)cbf_split;
+							set_intra_info_buffs(g, e, depth, pq.child[k]);
+						}
+					} else {
+						const int tr_mask = 1 << (curr_depth - depth + (part_size_type == PART_NxN));
+						uint8_t *cb = w.cbf_buffs[COMP_Y][depth];
+						uint32_t cbf_y = (cb[e.geo[pq.child[0]].abs_index] & tr_mask) | (cb[e.geo[pq.child[1]].abs_index] & tr_mask) |
+								 (cb[e.geo[pq.child[2]].abs_index] & tr_mask) | (cb[e.geo[pq.child[3]].abs_index] & tr_mask);
+						cbf_y >>= 1;
+						g.sync();
+						for (int i = g.tid; i < pq.num_part; i += g.n) cb[pq.abs_index + i] |= (uint8_t)cbf_y;
+						g.sync();
+					}
+					sync_motion_buffers_luma(g, e, parent, curr_depth + 1, curr_depth, curr_depth + 1, curr_depth);
+				} else {
+					set_intra_info_buffs(g, e, depth, parent);
+					sync_reference_buffs(g, e, parent, curr_depth, curr_depth + 1);
+				}
+				curr_depth--;
+				parent = e.geo[parent].parent;
+			}
+			if (curr_depth + 2 <= max_tr_processing_depth) {
+				const int aux = parent >= 0 ? e.geo[parent].child[(depth_state[curr_depth] + 3) & 3] : 0;
+				for (int aux_depth = curr_depth + 2; aux_depth <= max_tr_processing_depth; aux_depth++)
+					sync_reference_buffs(g, e, aux, curr_depth + 1, aux_depth + 1);
+			}
+		}
+	}
+	Node &tn = node_of(e, top_ni);
+	if (depth == max_tr_processing_depth) set_intra_info_buffs(g, e, depth, top_ni);
+	if (part_size_type == PART_NxN && (part_position & 3) == 3) {
+		const int par = e.geo[top_ni].parent;
+		const int nsub = e.geo[e.geo[par].child[0]].num_part, abs_index = e.geo[par].abs_index;
+		uint8_t *cb = w.cbf_buffs[COMP_Y][curr_depth];
+		uint32_t split = (cb[abs_index] & 2) | (cb[abs_index + nsub] & 2) | (cb[abs_index + 2 * nsub] & 2) | (cb[abs_index + 3 * nsub] & 2);
+		if (split) {
+			split >>= 1;
+			g.sync();
+			for (int i = g.tid; i < 4 * nsub; i += g.n) cb[abs_index + i] |= (uint8_t)split;
+			g.sync();
+		}
+	}
+	if (S.rd_mode != RDM_FULL) {
+		const double correction = calc_mv_correction(tn.qp, e.f->avg_dist);
+		return (uint32_t)(tn.cost + bitcost_cu_mode * correction + .5);
+	}
+	return tn.cost;
+}
+
+HENC_INLINE void chroma_dir_list(int *list, int luma_mode)
+{
+	list[0] = PLANAR_IDX; list[1] = VER_IDX; list[2] = HOR_IDX; list[3] = DC_IDX; list[4] = DM_CHROMA_IDX;
+	for (int i = 0; i < 4; i++)
+		if (luma_mode == list[i]) { list[i] = 34; break; }
+}
+
+// encode_intra_chroma, hmr_motion_intra_chroma.c:114-469 (non-HM path, rd_mode != RD_FULL)
+template <class G>
+HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &e, int depth, int part_position, int part_size_type)
+{
+	const Seq &S = *e.seq;
+	Work &w = *e.w;
+	const int nxn = part_size_type == PART_NxN;
+	int curr = node_at(e, depth, part_position), parent;
+	const double weight = e.f->chroma_weight;
+	const int qp_chroma = chroma_qp_table((int)node_of(e, curr).qp + S.chroma_qp_offset);
+	const int per = qp_chroma / 6, rem = qp_chroma % 6;
+	if (depth == 0 && S.max_cu_size == 64) {
+		parent = S.depth_start[0];
+		curr = e.geo[parent].child[0];
+	} else parent = e.geo[curr].parent;
+	const int luma_mode = w.intra_mode_buffs[COMP_Y][depth][e.geo[curr].abs_index];
+	int mode_list[5];
+	chroma_dir_list(mode_list, luma_mode);
+	if (e.geo[curr].size_chroma == 2) {
+		curr = parent;
+		parent = e.geo[curr].parent;
+	}
+	// candidate search on the unfiltered neighbours of the last decoded window
+	int best_modes[3] = {0, 0, 0};
+	double best_costs[3] = {1.7e+308, 1.7e+308, 1.7e+308};
+	uint32_t best_bits[3] = {0, 0, 0};
+	{
+		const Geo &q = e.geo[curr];
+		const int n = q.size_chroma;
+		for (int mi = 0; mi < 5; mi++) {
+			uint32_t distortion = 0, cost = 0;
+			int cu_mode = mode_list[mi];
+			if (cu_mode == DM_CHROMA_IDX) cu_mode = luma_mode;
+			for (int c = COMP_U; c <= COMP_V; c++) {
+				node_fill_refs(g, e, curr, NWND - 1, c, 0);
+				int16_t *pred = pred_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
+				const int16_t *orig = curr_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
+				distortion += intra_predict_sad(g, pred, CTU_STRIDE_C, orig, CTU_STRIDE_C, w.adi, n, cu_mode, 0);
+				cost += distortion;
+			}
+			uint32_t bit_cost = mode_list[mi] == DM_CHROMA_IDX ? 1 : 12;
+			cost += (uint32_t)(bit_cost * e.f->sqrt_lambda + .5);
+			// homer_update_cand_list, hmr_motion_intra.c:893
+			int um = mode_list[mi];
+			double uc = cost;
+			uint32_t ub = bit_cost;
+			for (int i = 0; i < 3; i++)
+				if (best_costs[i] > uc) {
+					const int am = best_modes[i]; const double ac = best_costs[i]; const uint32_t ab = best_bits[i];
+					best_costs[i] = uc; best_modes[i] = um; best_bits[i] = ub;
+					uc = ac; um = am; ub = ab;
+				}
+		}
+	}
+	uint32_t best_cost = MAX_COST, best_sum = 0, sum = 0, distortion = 0, cost;
+	int best_mode = 0;
+	int top;
+	{
+		int cu_mode = best_modes[0];
+		const uint32_t bit_cost = best_bits[0];
+		int depth_state[NDEPTH] = {0, 0, 0, 0, 0};
+		int cbf_split[2][NDEPTH] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+		int partition_cost[4];
+		if (cu_mode == DM_CHROMA_IDX) cu_mode = luma_mode;
+		if (depth == 0 && S.max_cu_size == 64) {
+			parent = S.depth_start[0];
+			curr = e.geo[parent].child[0];
+		} else {
+			curr = node_at(e, depth, part_position);
+			parent = e.geo[curr].parent;
+		}
+		int curr_depth = e.geo[curr].depth;
+		depth_state[curr_depth] = part_position & 3;
+		const int qwnd = NWND - 1, dwnd = NWND - 1;
+		bool broke = false;
+		while (!(curr_depth == (depth - nxn) && depth_state[curr_depth] == (part_position & 3) + 1)) {
+			curr = parent < 0 ? curr : e.geo[parent].child[depth_state[curr_depth]];
+			const int tr_depth_luma = w.tr_idx_buffs[depth][e.geo[curr].abs_index] + depth - nxn;
+			while (curr_depth < tr_depth_luma) {
+				parent = curr;
+				curr_depth++;
+				curr = e.geo[parent].child[depth_state[curr_depth]];
+			}
+			const int scan_mode = find_scan_mode(1, 0, e.geo[curr].size_chroma, cu_mode, 0);
+			const int original_depth = e.geo[curr].depth;
+			if (e.geo[curr].size_chroma == 2) {
+				curr = parent;
+				parent = e.geo[curr].parent;
+			}
+			const Geo &q = e.geo[curr];
+			curr_depth = q.depth;
+			const int n = q.size_chroma;
+			partition_cost[depth_state[curr_depth]] = 0;
+			for (int c = COMP_U; c <= COMP_V; c++) {
+				int16_t *pred = pred_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc, *resid = resid_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
+				const int16_t *orig = curr_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
+				int16_t *quant = tq_ptr(w, qwnd, c) + ((q.abs_index << 4) >> 2), *iquant = iq_ptr(w, c) + ((q.abs_index << 4) >> 2);
+				int16_t *dec = dec_ptr(w, dwnd, c) + q.yc * DEC_STRIDE_C + q.xc;
+				node_fill_refs(g, e, curr, dwnd, c, 0);
+				intra_predict(g, pred, CTU_STRIDE_C, w.adi, n, cu_mode, 0);
+				blk_predict(g, orig, CTU_STRIDE_C, pred, CTU_STRIDE_C, resid, CTU_STRIDE_C, n);
+				tr_forward(g, e.T, resid, CTU_STRIDE_C, w.pred_aux, quant, n, 0);
+				const int curr_sum = quantize(g, e.T, w.pred_aux, quant, w.delta_u, scan_mode, curr_depth, c, 1, e.f->slice_type == SLICE_I, S.sign_hiding, n, per, rem);
+				sum += (uint32_t)curr_sum;
+				const int cbfv = ((curr_sum ? 1 : 0) << (original_depth - depth + nxn)) | ((curr_sum ? 1 : 0) << (curr_depth - depth + nxn));
+				bytes_set(g, &w.cbf_chroma[c - 1][q.abs_index], cbfv, q.num_part);
+				cbf_split[c - 1][curr_depth] |= (curr_sum ? 1 : 0);
+				if (curr_sum) {
+					dequantize(g, e.T, quant, iquant, curr_depth, c, 1, n, per, rem);
+					tr_inverse(g, e.T, resid, CTU_STRIDE_C, iquant, w.pred_aux, n, 0);
+					blk_reconst(g, pred, CTU_STRIDE_C, resid, CTU_STRIDE_C, dec, DEC_STRIDE_C, n);
+				} else {
+					blk_reconst(g, pred, CTU_STRIDE_C, (const int16_t *)nullptr, 0, dec, DEC_STRIDE_C, n);
+				}
+				partition_cost[depth_state[curr_depth]] += (int)(weight * blk_ssd(g, orig, CTU_STRIDE_C, dec, DEC_STRIDE_C, n));
+			}
+			node_of(e, curr).sum += sum;
+			distortion += (uint32_t)partition_cost[depth_state[curr_depth]];
+			if (distortion > best_cost) {
+				distortion = best_cost + 1;
+				broke = true;
+				break;
+			}
+			depth_state[curr_depth]++;
+			if (depth_state[curr_depth] == 4) {
+				while (depth_state[curr_depth] == 4 && curr_depth > (depth - nxn)) {
+					const Geo &pq = e.geo[parent];
+					const int sh = curr_depth - 1 - depth + nxn;
+					g.sync();
+					for (int i = g.tid; i < pq.num_part; i += g.n) {
+						w.cbf_chroma[0][pq.abs_index + i] |= (uint8_t)(cbf_split[0][curr_depth] << sh);
+						w.cbf_chroma[1][pq.abs_index + i] |= (uint8_t)(cbf_split[1][curr_depth] << sh);
+					}
+					g.sync();
+					cbf_split[0][curr_depth - 1] |= cbf_split[0][curr_depth];
+					cbf_split[1][curr_depth - 1] |= cbf_split[1][curr_depth];
+					cbf_split[0][curr_depth] = cbf_split[1][curr_depth] = 0;
+					depth_state[curr_depth] = 0;
+					curr_depth--;
+					depth_state[curr_depth]++;
+					if (curr_depth != 0) parent = e.geo[parent].parent;
+				}
+			}
+		}
+		(void)broke;
+		if (depth == 0) top = S.depth_start[0];
+		else {
+			top = node_at(e, depth, part_position);
+			if (nxn) top = e.geo[top].parent;
+		}
+		cost = distortion;
+		if (cost < best_cost) {
+			const double correction = calc_mv_correction(node_of(e, top).qp, e.f->avg_dist);
+			cost += (uint32_t)(bit_cost * correction + .5);
+		}
+		if (cost < best_cost) {
+			best_cost = cost;
+			best_sum = sum;
+			best_mode = best_modes[0];
+			sync_motion_buffers_chroma(g, e, top, qwnd, depth + 1, dwnd, depth + 1);
+			const Geo &tq = e.geo[top];
+			bytes_copy(g, &w.cbf_chroma[0][tq.abs_index], &w.cbf_buffs[COMP_U][depth][tq.abs_index], tq.num_part);
+			bytes_copy(g, &w.cbf_chroma[1][tq.abs_index], &w.cbf_buffs[COMP_V][depth][tq.abs_index], tq.num_part);
+		}
+	}
+	const Geo &tq = e.geo[top];
+	bytes_set(g, &w.intra_mode_buffs[COMP_CHR][depth][tq.abs_index], best_mode, tq.num_part);
+	node_of(e, top).sum += best_sum;
+	return best_cost;
+}
+
+template <class G>
+HENC_HD uint32_t encode_intra(const G &g, Enc &e, int curr_depth, int position, int part_size_type);
+
+}  // namespace henc

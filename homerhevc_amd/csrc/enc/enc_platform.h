@@ -1,0 +1,73 @@
+// Execution-group abstraction of the CTU encoder.
+//
+// The encoder core (enc_*.h) is written once as SPMD code: every function is executed by all lanes of a group with
+// group-uniform control flow; pixel loops are strided by the lane index and reductions go through the group.
+//   * product: hipcc, HENC_HD = __device__, group = one 64-lane wavefront that owns a CTU (k_encode.hip);
+//   * checker: g++ (oracle/enc_cpu.cpp, test infrastructure only), group = one lane - the same decision logic runs
+//     serially there so that it can be diffed against the compiled reference in the build container, where there is no GPU.
+// The product library never contains the one-lane instantiation: there is no CPU fallback.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HENC_HD __device__
+#define HENC_INLINE __device__ __forceinline__
+#else
+#define HENC_HD
+#define HENC_INLINE inline
+#endif
+
+namespace henc {
+
+#if defined(__HIPCC__)
+// One wavefront.  Scalar state is computed redundantly by all lanes (uniform), so stores of uniform values by every
+// lane are benign; sync() orders the data-parallel producer / consumer phases that go through memory.
+struct WaveGrp {
+	int tid;
+	static constexpr int n = 64;
+	__device__ __forceinline__ void sync() const { __syncthreads(); }
+	__device__ __forceinline__ uint32_t sum(uint32_t v) const
+	{
+#pragma unroll
+		for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+		return v;
+	}
+	__device__ __forceinline__ int64_t sum64(int64_t v) const
+	{
+#pragma unroll
+		for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+		return v;
+	}
+	__device__ __forceinline__ uint32_t any(bool p) const { return __ballot(p) != 0; }
+	// smallest key over the lanes (ties: the key itself breaks them)
+	__device__ __forceinline__ uint64_t min64(uint64_t v) const
+	{
+#pragma unroll
+		for (int m = 32; m >= 1; m >>= 1) {
+			const uint64_t o = __shfl_xor(v, m, 64);
+			v = o < v ? o : v;
+		}
+		return v;
+	}
+};
+#endif
+
+struct CpuGrp {
+	static constexpr int tid = 0;
+	static constexpr int n = 1;
+	void sync() const {}
+	uint32_t sum(uint32_t v) const { return v; }
+	int64_t sum64(int64_t v) const { return v; }
+	uint32_t any(bool p) const { return p; }
+	uint64_t min64(uint64_t v) const { return v; }
+};
+
+template <class T> HENC_INLINE T hmin(T a, T b) { return a < b ? a : b; }
+template <class T> HENC_INLINE T hmax(T a, T b) { return a > b ? a : b; }
+template <class T> HENC_INLINE T hclip(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
+HENC_INLINE int habs(int v) { return v < 0 ? -v : v; }
+HENC_INLINE int16_t sat16(int v) { return (int16_t)hclip(v, -32768, 32767); }
+
+}  // namespace henc

@@ -1,0 +1,548 @@
+// Block primitives of the CTU encoder in SPMD form: the lanes of the group share one block.
+// Each primitive cites the reference kernel it restates; the arithmetic is the one pinned in round 1
+// (oracle/hmr_oracle.c against the compiled reference, tests/test_oracle_vs_ref.py).
+// Convention: inputs must be visible to the group on entry (caller synced), outputs are visible on return.
+#pragma once
+#include "enc_types.h"
+#include "../tables_layout.h"
+
+namespace henc {
+
+HENC_INLINE int ilog2i(int n)
+{
+	int s = 0;
+	while ((1 << s) < n) s++;
+	return s;
+}
+
+// ---- pixel kernels (hmr_sse42_functions_pixel.c:462,728,817,919) -------------------------------------------------
+template <class G>
+HENC_HD uint32_t blk_sad(const G &g, const int16_t *a, int as, const int16_t *b, int bs, int n)
+{
+	const int l = ilog2i(n);
+	uint32_t acc = 0;
+	for (int i = g.tid; i < n * n; i += g.n) {
+		const int y = i >> l, x = i & (n - 1);
+		acc += (uint32_t)habs((int16_t)(a[y * as + x] - b[y * bs + x]));
+	}
+	return g.sum(acc);
+}
+
+template <class G>
+HENC_HD uint32_t blk_ssd(const G &g, const int16_t *a, int as, const int16_t *b, int bs, int n)
+{
+	const int l = ilog2i(n);
+	uint32_t acc = 0;
+	for (int i = g.tid; i < n * n; i += g.n) {
+		const int y = i >> l, x = i & (n - 1);
+		const int32_t d = (int16_t)(a[y * as + x] - b[y * bs + x]);
+		acc += (uint32_t)(d * d);
+	}
+	return g.sum(acc);
+}
+
+// sum of squares of a block (ssd16b against the reference's zero row, hmr_motion_inter.c:94)
+template <class G>
+HENC_HD uint32_t blk_ssq(const G &g, const int16_t *a, int as, int n)
+{
+	const int l = ilog2i(n);
+	uint32_t acc = 0;
+	for (int i = g.tid; i < n * n; i += g.n) {
+		const int32_t d = a[(i >> l) * as + (i & (n - 1))];
+		acc += (uint32_t)(d * d);
+	}
+	return g.sum(acc);
+}
+
+template <class G>
+HENC_HD void blk_predict(const G &g, const int16_t *o, int os, const int16_t *p, int ps, int16_t *r, int rs, int n)
+{
+	const int l = ilog2i(n);
+	for (int i = g.tid; i < n * n; i += g.n) {
+		const int y = i >> l, x = i & (n - 1);
+		r[y * rs + x] = (int16_t)(o[y * os + x] - p[y * ps + x]);
+	}
+	g.sync();
+}
+
+// res == nullptr: the all-zero residual (the reference passes a zeroed row with stride 0, hmr_motion_intra.c:1065)
+template <class G>
+HENC_HD void blk_reconst(const G &g, const int16_t *p, int ps, const int16_t *res, int rs, int16_t *d, int ds, int n)
+{
+	const int l = ilog2i(n);
+	for (int i = g.tid; i < n * n; i += g.n) {
+		const int y = i >> l, x = i & (n - 1);
+		const int r = res ? res[y * rs + x] : 0;
+		d[y * ds + x] = (int16_t)hclip((int)sat16(p[y * ps + x] + r), 0, 255);
+	}
+	g.sync();
+}
+
+template <class G>
+HENC_HD void blk_copy(const G &g, const int16_t *s, int ss, int16_t *d, int ds, int h, int w)
+{
+	for (int i = g.tid; i < h * w; i += g.n) {
+		const int y = i / w, x = i - y * w;
+		d[y * ds + x] = s[y * ss + x];
+	}
+	g.sync();
+}
+
+template <class G>
+HENC_HD void lin_copy(const G &g, const int16_t *s, int16_t *d, int count)
+{
+	for (int i = g.tid; i < count; i += g.n) d[i] = s[i];
+	g.sync();
+}
+
+template <class G>
+HENC_HD void lin_zero(const G &g, int16_t *d, int count)
+{
+	for (int i = g.tid; i < count; i += g.n) d[i] = 0;
+	g.sync();
+}
+
+template <class G>
+HENC_HD void bytes_set(const G &g, uint8_t *d, int v, int count)
+{
+	for (int i = g.tid; i < count; i += g.n) d[i] = (uint8_t)v;
+	g.sync();
+}
+
+template <class G>
+HENC_HD void bytes_copy(const G &g, const uint8_t *s, uint8_t *d, int count)
+{
+	for (int i = g.tid; i < count; i += g.n) d[i] = s[i];
+	g.sync();
+}
+
+// ---- intra reference samples (fill_reference_samples hmr_motion_intra.c:246-404, adi_filter :189-244) --------------
+// `corner` points at sample (-1,-1) of the block in the window under reconstruction.
+template <class G>
+HENC_HD void intra_fill_refs(const G &g, const int16_t *corner, int stride, int n, int left, int top, int bottom_left, int top_right,
+			     int bl_size, int tr_size, int16_t *adi)
+{
+	const int adi_size = 4 * n + 1;
+	if (!left && !top) {
+		for (int i = g.tid; i < adi_size; i += g.n) adi[i] = 128;
+		g.sync();
+		return;
+	}
+	int pl_ptr = 0, pl_size = 0, pt_ptr = 0, pt_size = 0, first_idx = 0, last_idx = 0;
+	if (left) { first_idx = n; last_idx = 2 * n - 1; }
+	else { pl_ptr = n; pl_size = n; }
+	if (bottom_left) {
+		first_idx = n - bl_size;
+		if (bl_size != n) { pl_ptr = 0; pl_size = n - bl_size; }
+	} else {
+		pl_ptr = 0;
+		if (left) pl_size = n;
+		else pl_size += n;
+	}
+	if (top) {
+		if (!left) first_idx = 2 * n + 1;
+		last_idx = 3 * n;
+	} else { pt_ptr = 2 * n + 1; pt_size = n; }
+	if (top_right) {
+		last_idx = 3 * n + tr_size;
+		if (tr_size != n) { pt_ptr = 3 * n + 1 + tr_size; pt_size = n - tr_size; }
+	} else {
+		if (top) { pt_ptr = 3 * n + 1; pt_size = n; }
+		else pt_size += n;
+	}
+	const bool corner_copy = left && top;
+	if (!corner_copy) {
+		if (left) { pt_ptr--; pt_size++; }
+		else pl_size++;
+	}
+	// available samples
+	for (int k = g.tid; k < adi_size; k += g.n) {
+		if (k < n) {                       // bottom-left: adi[n-1-i] = row n+1+i
+			const int i = n - 1 - k;
+			if (bottom_left && i < bl_size) adi[k] = corner[(n + 1 + i) * stride];
+		} else if (k < 2 * n) {            // left: adi[n+i] = row n-i
+			if (left) adi[k] = corner[(n - (k - n)) * stride];
+		} else if (k == 2 * n) {
+			if (corner_copy) adi[k] = corner[0];
+		} else if (k <= 3 * n) {           // top
+			if (top) adi[k] = corner[k - 2 * n];
+		} else {                           // top-right
+			const int i = k - 3 * n - 1;
+			if (top_right && i < tr_size) adi[k] = corner[1 + n + i];
+		}
+	}
+	g.sync();
+	const int16_t first_sample = adi[first_idx], last_sample = adi[last_idx];
+	g.sync();
+	for (int i = g.tid; i < pl_size; i += g.n) adi[pl_ptr + i] = first_sample;
+	for (int i = g.tid; i < pt_size; i += g.n) adi[pt_ptr + i] = last_sample;
+	g.sync();
+}
+
+template <class G>
+HENC_HD void intra_adi_filter(const G &g, const int16_t *adi, int16_t *out, int n, int strong_enabled)
+{
+	const int adi_size = 4 * n + 1;
+	bool strong = false;
+	int bl = 0, tl = 0, tr = 0;
+	if (strong_enabled) {
+		bl = adi[0]; tl = adi[2 * n]; tr = adi[adi_size - 1];
+		const bool lin_left = habs(bl + tl - 2 * adi[n]) < 8, lin_top = habs(tl + tr - 2 * adi[3 * n]) < 8;
+		strong = n >= 32 && lin_left && lin_top;
+	}
+	if (strong) {
+		const int shift = ilog2i(2 * n);
+		for (int i = g.tid; i < adi_size; i += g.n) {
+			int v;
+			if (i == 0 || i == 2 * n || i == adi_size - 1) v = adi[i];
+			else if (i < 2 * n) v = ((2 * n - i) * bl + i * tl + n) >> shift;
+			else { const int k = i - 2 * n; v = ((2 * n - k) * tl + k * tr + n) >> shift; }
+			out[i] = (int16_t)v;
+		}
+	} else {
+		for (int i = g.tid; i < adi_size; i += g.n)
+			out[i] = (i == 0 || i == adi_size - 1) ? adi[i] : (int16_t)((adi[i - 1] + 2 * adi[i] + adi[i + 1] + 2) >> 2);
+	}
+	g.sync();
+}
+
+// ---- intra prediction (planar hmr_motion_intra.c:408-439; DC / angular :482-625; SSE twins prediction.c:199,926) -------
+// The value of one prediction sample in closed form, so that a search can compare it against the source without storing it.
+struct IntraPredictor {
+	const int16_t *mid;
+	int n, shift, mode, is_luma;
+	int kind;                // 0 planar, 1 dc, 2 angular
+	int dc, bl, tr;
+	int is_ver, angle, inv_angle, edge_filter;
+};
+
+HENC_INLINE IntraPredictor intra_setup(const int16_t *adi, int n, int mode, int is_luma)
+{
+	IntraPredictor p;
+	p.mid = adi + 2 * n;
+	p.n = n; p.shift = ilog2i(n); p.mode = mode; p.is_luma = is_luma;
+	p.dc = p.bl = p.tr = p.is_ver = p.angle = p.inv_angle = p.edge_filter = 0;
+	if (mode == PLANAR_IDX) {
+		p.kind = 0;
+		p.bl = p.mid[-(n + 1)];
+		p.tr = p.mid[n + 1];
+	} else if (mode == DC_IDX) {
+		p.kind = 1;
+		int acc = 0;
+		for (int i = 1; i <= n; i++) acc += p.mid[i] + p.mid[-i];
+		p.dc = (uint8_t)(uint16_t)((acc + n) / (2 * n));
+		p.edge_filter = n <= 16 && is_luma;
+	} else {
+		p.kind = 2;
+		const int ang_table[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};
+		const int inv_ang_table[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};
+		const int is_hor = mode < 18;
+		p.is_ver = !is_hor;
+		int pa = p.is_ver ? mode - 26 : -(mode - 10);
+		const int aa = habs(pa), sign = pa < 0 ? -1 : (pa > 0 ? 1 : 0);
+		p.inv_angle = inv_ang_table[aa];
+		p.angle = sign * ang_table[aa];
+		p.edge_filter = is_luma ? (n <= 16) : 0;
+	}
+	return p;
+}
+
+HENC_INLINE int intra_ref_main(const IntraPredictor &p, int idx)
+{
+	if (idx >= 0) return p.is_ver ? p.mid[idx] : p.mid[-idx];
+	const int k = (128 + (-idx) * p.inv_angle) >> 8;
+	return p.is_ver ? p.mid[-k] : p.mid[k];
+}
+
+// sample at row j, column i of the prediction block
+HENC_INLINE int intra_sample(const IntraPredictor &p, int j, int i)
+{
+	const int n = p.n;
+	if (p.kind == 0) {
+		const int left = p.mid[-(j + 1)], top = p.mid[i + 1];
+		const int hor = (left << p.shift) + n + (i + 1) * (p.tr - left);
+		const int ver = (top << p.shift) + (j + 1) * (p.bl - top);
+		return (int16_t)((hor + ver) >> (p.shift + 1));
+	}
+	if (p.kind == 1) {
+		if (p.edge_filter) {
+			if (j == 0 && i == 0) return (int16_t)((p.mid[-1] + p.mid[1] + 2 * p.dc + 2) >> 2);
+			if (j == 0) return (int16_t)((p.mid[1 + i] + 3 * p.dc + 2) >> 2);
+			if (i == 0) return (int16_t)((p.mid[-1 - j] + 3 * p.dc + 2) >> 2);
+		}
+		return p.dc;
+	}
+	// angular: horizontal modes are the vertical construction transposed (a = index along the main reference, b = line)
+	const int a = p.is_ver ? i : j, b = p.is_ver ? j : i;
+	if (p.angle == 0) {
+		int v = (uint8_t)intra_ref_main(p, a + 1);
+		if (p.edge_filter && a == 0) {
+			const int side_b = p.is_ver ? p.mid[-(b + 1)] : p.mid[b + 1], side_0 = p.mid[0];
+			v = hclip(v + ((side_b - side_0) >> 1), 0, 255);
+		}
+		return v;
+	}
+	const int pos = (b + 1) * p.angle, delta = pos >> 5, fract = pos & 31, idx = a + delta + 1;
+	if (fract) return (uint8_t)(((32 - fract) * intra_ref_main(p, idx) + fract * intra_ref_main(p, idx + 1) + 16) >> 5);
+	return (uint8_t)intra_ref_main(p, idx);
+}
+
+template <class G>
+HENC_HD void intra_predict(const G &g, int16_t *pred, int ps, const int16_t *adi, int n, int mode, int is_luma)
+{
+	const IntraPredictor p = intra_setup(adi, n, mode, is_luma);
+	const int l = p.shift;
+	for (int k = g.tid; k < n * n; k += g.n) {
+		const int j = k >> l, i = k & (n - 1);
+		pred[j * ps + i] = (int16_t)intra_sample(p, j, i);
+	}
+	g.sync();
+}
+
+// prediction + SAD against the source in one pass; the prediction is also stored (later stages of the reference read it)
+template <class G>
+HENC_HD uint32_t intra_predict_sad(const G &g, int16_t *pred, int ps, const int16_t *orig, int os, const int16_t *adi, int n, int mode, int is_luma)
+{
+	const IntraPredictor p = intra_setup(adi, n, mode, is_luma);
+	const int l = p.shift;
+	uint32_t acc = 0;
+	for (int k = g.tid; k < n * n; k += g.n) {
+		const int j = k >> l, i = k & (n - 1);
+		const int v = intra_sample(p, j, i);
+		pred[j * ps + i] = (int16_t)v;
+		acc += (uint32_t)habs((int16_t)(orig[j * os + i] - (int16_t)v));
+	}
+	const uint32_t s = g.sum(acc);
+	g.sync();
+	return s;
+}
+
+// ---- interpolation (hmr_motion_inter.c:240-391,878-936; SSE twins inter_prediction.c:796,818) -----------------------
+HENC_INLINE void luma_tap_row(int f, int *c)
+{
+	const int t[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}};
+	for (int k = 0; k < 8; k++) c[k] = t[f][k];
+}
+HENC_INLINE void chroma_tap_row(int f, int *c)
+{
+	const int t[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4}, {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
+	for (int k = 0; k < 4; k++) c[k] = t[f][k];
+}
+
+// one separable stage; NT = 8 (luma) / 4 (chroma).  fraction 0 = the reference's filter_copy variants.
+template <int NT, class G>
+HENC_HD void interp_stage(const G &g, const int16_t *src, int ss, int16_t *dst, int ds, int fraction, int w, int h, int vert, int first, int last)
+{
+	if (fraction == 0) {
+		if (NT == 4 && w < 4) { g.sync(); return; }    // chroma no-op (inter_prediction.c:822-825)
+		for (int k = g.tid; k < w * h; k += g.n) {
+			const int r = k / w, c = k - r * w;
+			const int v = src[r * ss + c];
+			int16_t o;
+			if (first == last) o = (int16_t)v;
+			else if (first) o = (int16_t)((int16_t)(v << 6) - 8192);
+			else o = (int16_t)hclip((v + 8192 + 32) >> 6, 0, 255);
+			dst[r * ds + c] = o;
+		}
+		g.sync();
+		return;
+	}
+	int c8[8];
+	if (NT == 8) luma_tap_row(fraction, c8);
+	else chroma_tap_row(fraction, c8);
+	const int rs = vert ? ss : 1;
+	int shift = 6, offset;
+	if (last) {
+		shift += first ? 0 : 6;
+		offset = 1 << (shift - 1);
+		offset += first ? 0 : 8192 << 6;
+	} else {
+		shift -= first ? 6 : 0;
+		offset = first ? -(8192 << shift) : 0;
+	}
+	const int16_t *s0 = src - (NT / 2 - 1) * rs;
+	for (int k = g.tid; k < w * h; k += g.n) {
+		const int r = k / w, c = k - r * w;
+		int sum = 0;
+#pragma unroll
+		for (int t = 0; t < NT; t++) sum += s0[r * ss + c + t * rs] * c8[t];
+		int16_t v = sat16((sum + offset) >> shift);
+		if (last) v = (int16_t)hclip((int)v, 0, 255);
+		dst[r * ds + c] = v;
+	}
+	g.sync();
+}
+
+// ---- transforms (hmr_sse42_functions_transform.c:1670,1700; spec hmr_transform.c:133-549) ---------------------------
+template <class G>
+HENC_HD void tr_forward(const G &g, const DevTables *T, const int16_t *block, int bs, int16_t *coeff, int16_t *tmp, int n, int is_dst)
+{
+	const int l = ilog2i(n);
+	const int16_t *M = (n == 4 && is_dst) ? T->dst4 : T->dct[l - 2];
+	{
+		const int shift = l - 1, rnd = shift > 0 ? 1 << (shift - 1) : 0;
+		for (int o = g.tid; o < n * n; o += g.n) {
+			const int k = o >> l, j = o & (n - 1);
+			int32_t s = 0;
+			for (int i = 0; i < n; i++) s += M[k * n + i] * block[j * bs + i];
+			tmp[k * n + j] = sat16((s + rnd) >> shift);
+		}
+	}
+	g.sync();
+	{
+		const int shift = l + 6, rnd = 1 << (shift - 1);
+		for (int o = g.tid; o < n * n; o += g.n) {
+			const int k = o >> l, j = o & (n - 1);
+			int32_t s = 0;
+			for (int i = 0; i < n; i++) s += M[k * n + i] * tmp[j * n + i];
+			coeff[k * n + j] = sat16((s + rnd) >> shift);
+		}
+	}
+	g.sync();
+}
+
+template <class G>
+HENC_HD void tr_inverse(const G &g, const DevTables *T, int16_t *block, int bs, const int16_t *coeff, int16_t *tmp, int n, int is_dst)
+{
+	const int l = ilog2i(n);
+	const int16_t *M = (n == 4 && is_dst) ? T->dst4 : T->dct[l - 2];
+	for (int o = g.tid; o < n * n; o += g.n) {
+		const int j = o >> l, k = o & (n - 1);
+		int32_t s = 0;
+		for (int i = 0; i < n; i++) s += M[i * n + k] * coeff[i * n + j];
+		tmp[j * n + k] = sat16((s + 64) >> 7);
+	}
+	g.sync();
+	for (int o = g.tid; o < n * n; o += g.n) {
+		const int j = o >> l, k = o & (n - 1);
+		int32_t s = 0;
+		for (int i = 0; i < n; i++) s += M[i * n + k] * tmp[i * n + j];
+		block[j * bs + k] = sat16((s + 2048) >> 12);
+	}
+	g.sync();
+}
+
+// ---- quantisation (hmr_sse42_functions_quant.c:34-131 + sign_bit_hidding hmr_quant.c:61-169; inverse :135-246) -------
+// sign hiding of one 16-coefficient group, the reference's walk taken literally
+HENC_INLINE void sbh_group(int16_t *dst, const int16_t *src, const int16_t *du, const uint32_t *scan, int cg, bool is_last_cg)
+{
+	const int sub_pos = cg << 4;
+	int first_nz = 16, last_nz = -1, abs_sum = 0;
+	for (int n = 15; n >= 0; --n)
+		if (dst[scan[n + sub_pos]]) { last_nz = n; break; }
+	for (int n = 0; n < 16; n++)
+		if (dst[scan[n + sub_pos]]) { first_nz = n; break; }
+	if (last_nz - first_nz < 4) return;
+	for (int n = first_nz; n <= last_nz; n++) abs_sum += dst[scan[n + sub_pos]];
+	const unsigned signbit = dst[scan[sub_pos + first_nz]] > 0 ? 0 : 1;
+	if (signbit == (unsigned)(abs_sum & 1)) return;
+	int min_cost = 0x7fffffff, min_pos = -1, final_change = 0, cur_cost = 0x7fffffff, cur_change = 0;
+	for (int n = (is_last_cg ? last_nz : 15); n >= 0; --n) {
+		const unsigned pos = scan[n + sub_pos];
+		if (dst[pos] != 0) {
+			if (du[pos] > 0) { cur_cost = -du[pos]; cur_change = 1; }
+			else if (n == first_nz && habs(dst[pos]) == 1) cur_cost = 0x7fffffff;
+			else { cur_cost = du[pos]; cur_change = -1; }
+		} else if (n < first_nz) {
+			const unsigned this_sign = src[pos] >= 0 ? 0 : 1;
+			if (this_sign != signbit) cur_cost = 0x7fffffff;
+			else { cur_cost = -du[pos]; cur_change = 1; }
+		} else { cur_cost = -du[pos]; cur_change = 1; }
+		if (cur_cost < min_cost) { min_cost = cur_cost; final_change = cur_change; min_pos = (int)pos; }
+	}
+	if (dst[min_pos] == 32767 || dst[min_pos] == -32768) final_change = -1;
+	if (src[min_pos] >= 0) dst[min_pos] = (int16_t)(dst[min_pos] + final_change);
+	else dst[min_pos] = (int16_t)(dst[min_pos] - final_change);
+}
+
+// returns ac_sum (the sum of the levels BEFORE sign hiding, as the reference reports it)
+template <class G>
+HENC_HD int quantize(const G &g, const DevTables *T, const int16_t *src, int16_t *dst, int16_t *delta_u, int scan_mode, int depth, int comp,
+		     int is_intra, int slice_is_intra, int sign_hiding, int n, int per, int rem)
+{
+	const int inv_depth = 6 - (depth + (comp != 0));
+	const int32_t *q = T->quant[inv_depth - 2][(is_intra ? 0 : 3) + comp][rem];
+	const int qbits = 14 + per + (15 - 8 - inv_depth), qbits8 = qbits - 8;
+	const int32_t add = (int32_t)((uint32_t)(slice_is_intra ? 171 : 85) << (qbits - 9));
+	const int total = n * n;
+	uint32_t sum = 0;
+	for (int i = g.tid; i < total; i += g.n) {
+		const int sv = src[i];
+		const uint32_t a = (uint16_t)(sv < 0 ? -sv : sv);
+		const int32_t aux = (int32_t)(a * (uint32_t)q[i]);
+		const int32_t c = (int32_t)((uint32_t)aux + (uint32_t)add) >> qbits;
+		const int32_t d = (int32_t)((uint32_t)aux - ((uint32_t)c << qbits)) >> qbits8;
+		const int sgn = sv > 0 ? 1 : (sv < 0 ? -1 : 0);
+		sum += (uint32_t)c;
+		dst[i] = (int16_t)(sgn * sat16(c));
+		delta_u[i] = sat16(d);
+	}
+	const int ac_sum = (int)g.sum(sum);
+	g.sync();
+	if (sign_hiding && ac_sum >= 2) {
+		const uint32_t *scan = T->scan[scan_mode][inv_depth];
+		const int ngroups = total >> 4;
+		// the last group holding a level (in scan order) starts its walk at its last level
+		uint64_t key = ~0ull;
+		for (int cg = g.tid; cg < ngroups; cg += g.n) {
+			bool nz = false;
+			for (int k = 0; k < 16; k++) nz |= dst[scan[cg * 16 + k]] != 0;
+			if (nz) key = hmin(key, (uint64_t)(ngroups - 1 - cg));
+		}
+		key = g.min64(key);
+		const int last_cg = key == ~0ull ? -1 : ngroups - 1 - (int)key;
+		for (int cg = g.tid; cg < ngroups; cg += g.n) sbh_group(dst, src, delta_u, scan, cg, cg == last_cg);
+		g.sync();
+	}
+	return ac_sum;
+}
+
+template <class G>
+HENC_HD void dequantize(const G &g, const DevTables *T, const int16_t *src, int16_t *dst, int depth, int comp, int is_intra, int n, int per, int rem)
+{
+	const int inv_depth = 6 - (depth + (comp != 0));
+	const int32_t *iq = T->dequant[inv_depth - 2][is_intra ? 0 : 3 + comp][rem];
+	const int iq_shift = 20 - 14 - (15 - 8 - inv_depth) + 4, total = n * n;
+	if (iq_shift > per) {
+		const int32_t add = 1 << (iq_shift - per - 1);
+		const int sh = iq_shift - per;
+		for (int i = g.tid; i < total; i += g.n) dst[i] = sat16((int32_t)((uint32_t)(int32_t)src[i] * (uint32_t)iq[i] + (uint32_t)add) >> sh);
+	} else {
+		const int sh = per - iq_shift;
+		for (int i = g.tid; i < total; i += g.n) dst[i] = sat16((int32_t)(((uint32_t)(int32_t)src[i] * (uint32_t)iq[i]) << sh));
+	}
+	g.sync();
+}
+
+HENC_INLINE int chroma_qp_table(int qpi)   // chroma_scale_conversion_table, hmr_encoder_lib.c:2245
+{
+	const uint8_t mid[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37};
+	qpi = hclip(qpi, 0, 57);
+	return qpi < 30 ? qpi : (qpi < 44 ? mid[qpi - 30] : qpi - 6);
+}
+
+// find_scan_mode, hmr_tables.c:376
+HENC_INLINE int find_scan_mode(int is_intra, int is_luma, int width, int dir_mode, int up_left_luma_dir_mode)
+{
+	if (!is_intra) return SCAN_DIAG;
+	int ctx_idx;
+	switch (width) {
+	case 2: ctx_idx = 6; break;
+	case 4: ctx_idx = 5; break;
+	case 8: ctx_idx = 4; break;
+	case 16: ctx_idx = 3; break;
+	case 32: ctx_idx = 2; break;
+	case 64: ctx_idx = 1; break;
+	default: ctx_idx = 0; break;
+	}
+	int scan_idx = SCAN_DIAG;
+	if (is_luma) {
+		if (ctx_idx > 3 && ctx_idx < 6) scan_idx = habs(dir_mode - VER_IDX) < 5 ? SCAN_HOR : (habs(dir_mode - HOR_IDX) < 5 ? SCAN_VER : SCAN_DIAG);
+	} else {
+		if (dir_mode == DM_CHROMA_IDX) dir_mode = up_left_luma_dir_mode;
+		if (ctx_idx > 4 && ctx_idx < 7) scan_idx = habs(dir_mode - VER_IDX) < 5 ? SCAN_HOR : (habs(dir_mode - HOR_IDX) < 5 ? SCAN_VER : SCAN_DIAG);
+	}
+	return scan_idx;
+}
+
+}  // namespace henc

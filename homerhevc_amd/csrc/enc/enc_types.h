@@ -1,0 +1,157 @@
+// Data model of the device-resident CTU encoder.
+//
+// The layout follows what the reference keeps per encoder instance, per WPP thread and per CTU, because the decision
+// code reads and writes that state in ways that are part of the bitstream (which buffer a candidate's result is left in,
+// what a later candidate finds there):
+//   Seq       <- hvenc_engine_t configuration (hmr_private.h:1238-1367, set in HOMER_enc_control, hmr_encoder_lib.c:704-1650)
+//   FrameCtx  <- slice_t / picture_t / rate_distortion_t of the frame being encoded (hmr_private.h:1012-1060, 983-990)
+//   CtuInfo   <- ctu_info_t + its cu_partition_info_t list (hmr_private.h:792-843, 738-790); persistent across frames
+//   Work      <- the windows and scratch buffers of henc_thread_t (hmr_private.h:1102-1228, allocated hmr_encoder_lib.c:1334-1441)
+#pragma once
+#include "enc_platform.h"
+
+namespace henc {
+
+enum { COMP_Y = 0, COMP_U = 1, COMP_V = 2, COMP_CHR = 1 };
+enum { PM_INTER = 0, PM_INTRA = 1 };
+enum { PART_2Nx2N = 0, PART_NxN = 3 };
+enum { SLICE_B = 0, SLICE_P = 1, SLICE_I = 2 };
+enum { RDM_DIST_ONLY = 0, RDM_FULL = 1, RDM_FAST = 2 };
+enum { ME_PEL = 1, ME_HALF = 2, ME_QUARTER = 4 };
+enum { PLANAR_IDX = 0, DC_IDX = 1, HOR_IDX = 10, VER_IDX = 26, DM_CHROMA_IDX = 36, REG_DCT = 65535 };
+enum { SCAN_ZIGZAG = 0, SCAN_HOR = 1, SCAN_VER = 2, SCAN_DIAG = 3 };
+
+constexpr int NPART = 256;                 // 4x4 units of a 64x64 CTU (z-order)
+constexpr int NNODES = 341;                // 1 + 4 + 16 + 64 + 256 partition nodes
+constexpr int NDEPTH = 5;                  // MAX_PARTITION_DEPTH
+constexpr int NWND = 7;                    // NUM_QUANT_WNDS / NUM_DECODED_WNDS
+constexpr uint32_t MAX_COST = 0xffffffffu / 8;   // hmr_private.h:55
+
+constexpr int SEARCH_RANGE_X = 128, SEARCH_RANGE_Y = 64;   // hmr_private.h:76-77
+
+// windows of a CTU worker.  Decoded windows hold a 128 x 128 (64 x 64 chroma) area with a one-sample frame around it
+// (hmr_encoder_lib.c:1363): the CTU sits at the origin, row -1 / column -1 carry the neighbours.
+constexpr int DEC_STRIDE_Y = 144, DEC_ROWS_Y = 130, DEC_ORG_Y = 1 * DEC_STRIDE_Y + 8;
+constexpr int DEC_STRIDE_C = 80, DEC_ROWS_C = 66, DEC_ORG_C = 1 * DEC_STRIDE_C + 8;
+constexpr int CTU_STRIDE_Y = 64, CTU_STRIDE_C = 32;
+
+struct MV {
+	int32_t x, y;
+};
+
+// static geometry of the partition tree (init_partition_info, hmr_motion_intra.c:758; get_partition_neigbours :710)
+struct Geo {
+	uint16_t list_index, depth, abs_index, size, size_chroma, x, y, xc, yc, num_part, raster_index;
+	uint16_t abs_left, abs_left_bottom, abs_top, abs_top_right, abs_top_left;
+	int16_t parent;
+	int16_t child[4];
+};
+
+// dynamic part of cu_partition_info_t
+struct Node {
+	uint8_t left_nb, top_nb, left_bottom_nb, top_right_nb;
+	uint8_t tl_inside, b_inside, r_inside, pad_;
+	uint32_t qp, sum, distortion, cost;
+	int32_t prediction_mode, inter_mode, merge_flag, merge_idx, skipped;
+	int32_t intra_cbf[3], intra_tr_idx, intra_mode[3];
+	int32_t inter_cbf[3], inter_tr_idx;
+	MV inter_mv, subpix_mv, best_dif_mv;     // list 0 (P slices; B slices are outside the built configurations)
+	int32_t best_candidate_idx, inter_ref_index;
+};
+
+struct SaoOffset {                         // sao_offset_t, hmr_private.h:463-476
+	int32_t mode_idc, type_idc, type_aux;
+	int32_t offset[32];
+};
+
+struct CtuInfo {
+	uint8_t cbf[3][NPART];
+	uint8_t intra_mode[2][NPART];
+	uint8_t inter_mode[NPART], tr_idx[NPART], pred_depth[NPART], part_size_type[NPART], pred_mode[NPART];
+	uint8_t skipped[NPART], merge[NPART], merge_idx[NPART], qp[NPART];
+	int8_t mv_ref_idx[NPART];
+	uint8_t mv_diff_ref_idx[NPART];
+	MV mv_ref[NPART], mv_diff[NPART];
+	int32_t ctu_number, x, y, last_valid_partition;
+	uint32_t distortion;
+	uint8_t has_left, has_top, has_top_right, has_top_left;
+	// speculation record of a P-frame CTU (enc_ctu.h): reads of inherited intra modes and the intra / inter comparisons that used the running ratio
+	int32_t n_spec_reads, n_ratio_cmp;
+	uint16_t spec_read[96];                // (unit index << 8) | value used
+	double ratio_cmp[3 * 96];              // intra_dist, additive term, inter cost
+	uint8_t ratio_out[96];                 // outcome taken
+	double ratio_used;
+	uint32_t intra_parts;                  // partitions with pred_mode == INTRA after the CTU (hmr_encoder_lib.c:2924-2928)
+	SaoOffset sao_recon[3], sao_coded[3];
+	Node nodes[NNODES];
+};
+
+struct Seq {
+	int32_t width, height;                 // luma picture size (multiple of the minimum CU)
+	int32_t wctu, hctu, nctu;
+	int32_t max_cu_size, max_cu_size_shift;
+	int32_t max_pred_depth, max_intra_tr_depth, max_inter_tr_depth, max_cu_depth, mincu_mintr_shift_diff;
+	int32_t min_tu_size_shift, max_tu_size_shift;
+	int32_t perf_mode, perf_min_depth, perf_fast_skip, rd_mode;
+	int32_t me_precision, num_merge_cand;
+	int32_t sign_hiding, strong_intra, chroma_qp_offset, sao, wpp, bitrate_mode, qp;
+	int32_t intra_period, gop_size, num_ref_frames, reinit_gop;
+	int32_t depth_start[NDEPTH];
+	// padded picture planes (reference / reconstruction): element strides and margins (hmr_encoder_lib.c:1514)
+	int32_t stride_y, stride_c, margin_y, margin_c;
+	// source planes (no margin)
+	int32_t src_stride_y, src_stride_c;
+};
+
+struct FrameCtx {
+	int32_t slice_type, poc, qp, num_encoded_frames, is_scene_change, ref_poc;
+	double avg_dist, lambda, sqrt_lambda, chroma_weight;
+	double sao_lambda[3];
+	const int16_t *src[3];                 // source picture, first sample
+	const int16_t *ref[3];                 // reference picture (list 0, index 0), first valid sample
+	int16_t *rec[3];                       // picture under reconstruction, first valid sample
+};
+
+struct MvCandList {
+	int32_t num;
+	MV mv[5];
+	int32_t ref_idx[5];
+};
+
+struct Work {
+	int16_t curr_y[64 * 64], curr_c[2][32 * 32];
+	int16_t pred_y[64 * 64], pred_c[2][32 * 32];
+	int16_t resid_y[64 * 64], resid_c[2][32 * 32];
+	int16_t rdec_y[64 * 64], rdec_c[2][32 * 32];
+	int16_t tq_y[NWND][64 * 64], tq_c[NWND][2][32 * 32];
+	int16_t iq_y[64 * 64], iq_c[2][32 * 32];
+	int16_t dec_y[NWND][DEC_ROWS_Y * DEC_STRIDE_Y], dec_c[NWND][2][DEC_ROWS_C * DEC_STRIDE_C];
+	uint8_t cbf_buffs[3][NDEPTH][NPART];
+	uint8_t intra_mode_buffs[2][NDEPTH][NPART];
+	uint8_t tr_idx_buffs[NDEPTH][NPART];
+	uint8_t cbf_chroma[2][NPART];
+	int16_t adi[264], adi_f[264];
+	int16_t pred_aux[64 * 64];
+	int16_t delta_u[64 * 64];
+	int16_t sub_tmp[(64 + 8) * 72];        // first interpolation stage of a sub-pel candidate / two-stage motion compensation
+	int16_t sub_out[64 * 64];
+	MvCandList amvp, merge_cands, search_cands;
+};
+
+HENC_INLINE int16_t *wnd_y(int16_t *base) { return base; }
+
+// accessors ------------------------------------------------------------------------------------------------------
+HENC_INLINE int16_t *dec_ptr(Work &w, int wnd, int comp)
+{
+	return comp == COMP_Y ? w.dec_y[wnd] + DEC_ORG_Y : w.dec_c[wnd][comp - 1] + DEC_ORG_C;
+}
+HENC_INLINE int dec_stride(int comp) { return comp == COMP_Y ? DEC_STRIDE_Y : DEC_STRIDE_C; }
+HENC_INLINE int ctu_stride(int comp) { return comp == COMP_Y ? CTU_STRIDE_Y : CTU_STRIDE_C; }
+HENC_INLINE int16_t *tq_ptr(Work &w, int wnd, int comp) { return comp == COMP_Y ? w.tq_y[wnd] : w.tq_c[wnd][comp - 1]; }
+HENC_INLINE int16_t *curr_ptr(Work &w, int comp) { return comp == COMP_Y ? w.curr_y : w.curr_c[comp - 1]; }
+HENC_INLINE int16_t *pred_ptr(Work &w, int comp) { return comp == COMP_Y ? w.pred_y : w.pred_c[comp - 1]; }
+HENC_INLINE int16_t *resid_ptr(Work &w, int comp) { return comp == COMP_Y ? w.resid_y : w.resid_c[comp - 1]; }
+HENC_INLINE int16_t *rdec_ptr(Work &w, int comp) { return comp == COMP_Y ? w.rdec_y : w.rdec_c[comp - 1]; }
+HENC_INLINE int16_t *iq_ptr(Work &w, int comp) { return comp == COMP_Y ? w.iq_y : w.iq_c[comp - 1]; }
+
+}  // namespace henc

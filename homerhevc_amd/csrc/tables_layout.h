@@ -1,0 +1,17 @@
+// Layout of the constant tables the kernels index (built on the host by tables.cpp, uploaded once per context).
+#pragma once
+#include <stdint.h>
+
+// Constant tables, device resident, built once per context (tables.cpp).
+struct DevTables {
+	int16_t dct[4][32 * 32];        // [log2N-2] N x N row-major HEVC core transform
+	int16_t dst4[16];               // DST-VII 4x4
+	int16_t dct_t[4][32 * 32];      // the same bases transposed (rows = basis columns), for the inverse stages
+	int16_t dst4_t[16];
+	int16_t dct_eo[4][32 * 32];     // inverse stages by even / odd input index (k_tu_chain): output k < N/2 has N/4 words (M[4i][k], M[4i+2][k]) then N/4 words (M[4i+1][k], M[4i+3][k])
+	uint32_t scan[4][6][32 * 32];   // [scan_mode][log2N] coefficient scan order (mode 0 unused)
+	int32_t quant[4][6][6][32 * 32];   // [log2N-2][list][qp%6]
+	int32_t dequant[4][6][6][32 * 32];
+	uint8_t blk2cg[4][6][64];       // [scan_mode][log2N][4x4 block in raster order] -> index of its coefficient group in scan order
+};
+

@@ -1,0 +1,158 @@
+/*
+ * TEST INFRASTRUCTURE - not part of the product path.
+ *
+ * The reference encoder (oracle/_ref/libhomer_ref.so, compiled from /root/reference where it lies) run in lockstep with
+ * an interposer on hmr_deblock_sao_pad_sync_ctu (hmr_encoder_lib.c:2386), the first call after a CTU's decisions are
+ * final (wfpp_encoder_thread :2942-2948): the CTU's side-info arrays, its levels, its reconstruction before the loop
+ * filters and the worker thread's mode buffers are appended to $HOMER_CTUDUMP.  tests/golden/make_ctu_golden.py turns
+ * that into the fixtures the device-resident CTU encoder is compared with; tools/ctu_diff.py uses it for drill-down.
+ * With HOMER_CUTRACE=file the block drivers are interposed as well and log one text line per call.
+ *
+ * Same command line as ref_lockstep.  Built by oracle/Makefile (needs hmr_private.h -> build container only).
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "hmr_private.h"
+#include "hmr_common.h"
+
+static FILE *g_dump, *g_trace;
+static void *next(const char *name)
+{
+	void *p = dlsym(RTLD_NEXT, name);
+	if (!p) { fprintf(stderr, "ref_ctudump: %s not found\n", name); abort(); }
+	return p;
+}
+
+static void put(const void *p, size_t n) { fwrite(p, 1, n, g_dump); }
+
+void hmr_deblock_sao_pad_sync_ctu(henc_thread_t *et, slice_t *currslice, ctu_info_t *ctu)
+{
+	static void (*real)(henc_thread_t *, slice_t *, ctu_info_t *);
+	if (!real) {
+		real = next("hmr_deblock_sao_pad_sync_ctu");
+		if (getenv("HOMER_CTUDUMP")) g_dump = fopen(getenv("HOMER_CTUDUMP"), "wb");
+	}
+	if (g_dump) {
+		int32_t hdr[8] = {0x43545544, et->enc_engine->num_encoded_frames, ctu->ctu_number, (int32_t)currslice->slice_type,
+				  (int32_t)ctu->partition_list[0].cost, (int32_t)ctu->partition_list[0].distortion, (int32_t)ctu->partition_list[0].sum,
+				  et->enc_engine->is_scene_change};
+		int c, y, d;
+		put(hdr, sizeof hdr);
+		for (c = 0; c < 3; c++) put(ctu->cbf[c], 256);
+		put(ctu->intra_mode[0], 256); put(ctu->intra_mode[1], 256);
+		put(ctu->inter_mode, 256); put(ctu->tr_idx, 256); put(ctu->pred_depth, 256); put(ctu->part_size_type, 256); put(ctu->pred_mode, 256);
+		put(ctu->skipped, 256); put(ctu->merge, 256); put(ctu->merge_idx, 256); put(ctu->qp, 256);
+		put(ctu->mv_ref_idx[0], 256); put(ctu->mv_diff_ref_idx[0], 256);
+		put(ctu->mv_ref[0], 256 * sizeof(motion_vector_t)); put(ctu->mv_diff[0], 256 * sizeof(motion_vector_t));
+		for (c = 0; c < 3; c++) put(et->transform_quant_wnd[0]->pwnd[c], (c ? 1024 : 4096) * 2);
+		for (c = 0; c < 3; c++) {
+			int n = c ? 32 : 64, s = et->decoded_mbs_wnd[0]->window_size_x[c];
+			for (y = 0; y < n; y++) put((int16_t *)et->decoded_mbs_wnd[0]->pwnd[c] + y * s, n * 2);
+		}
+		for (c = 0; c < 2; c++)
+			for (d = 0; d < 5; d++) put(et->intra_mode_buffs[c][d], 256);
+		fflush(g_dump);
+	}
+	real(et, currslice, ctu);
+}
+
+/* ---- optional per-call text trace of the block drivers ---- */
+static FILE *trace(void)
+{
+	static int init;
+	if (!init) { init = 1; if (getenv("HOMER_CUTRACE")) g_trace = fopen(getenv("HOMER_CUTRACE"), "w"); }
+	return g_trace;
+}
+
+uint32_t check_rd_cost_merge_2nx2n(henc_thread_t *et, ctu_info_t *ctu, int depth, int position)
+{
+	static uint32_t (*real)(henc_thread_t *, ctu_info_t *, int, int);
+	if (!real) real = next("check_rd_cost_merge_2nx2n");
+	uint32_t r = real(et, ctu, depth, position);
+	if (trace()) {
+		cu_partition_info_t *cu = &ctu->partition_list[et->partition_depth_start[depth]] + position;
+		fprintf(g_trace, "MERGE ctu=%d d=%d abs=%d dist=%u idx=%d skip=%d mv=(%d,%d) sum=%u cands=(%d,%d)(%d,%d)\n", ctu->ctu_number, depth, cu->abs_index, r, cu->merge_idx,
+			cu->skipped, cu->inter_mv[0].hor_vector, cu->inter_mv[0].ver_vector, cu->sum, et->merge_mvp_candidates[0].mv_candidates[0].mv.hor_vector,
+			et->merge_mvp_candidates[0].mv_candidates[0].mv.ver_vector, et->merge_mvp_candidates[0].mv_candidates[1].mv.hor_vector,
+			et->merge_mvp_candidates[0].mv_candidates[1].mv.ver_vector);
+	}
+	return r;
+}
+
+int hmr_cu_motion_estimation(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int depth, int part_position, PartSize pst, uint threshold, unsigned int action)
+{
+	static int (*real)(henc_thread_t *, ctu_info_t *, int, int, int, PartSize, uint, unsigned int);
+	if (!real) real = next("hmr_cu_motion_estimation");
+	int r = real(et, ctu, gcnt, depth, part_position, pst, threshold, action);
+	if (trace()) {
+		cu_partition_info_t *cu = &ctu->partition_list[et->partition_depth_start[depth]] + part_position;
+		fprintf(g_trace, "ME ctu=%d d=%d abs=%d ret=%d mv=(%d,%d) amvp=(%d,%d)(%d,%d)\n", ctu->ctu_number, depth, cu->abs_index, r, cu->inter_mv[0].hor_vector,
+			cu->inter_mv[0].ver_vector, et->amvp_candidates[0].mv_candidates[0].mv.hor_vector, et->amvp_candidates[0].mv_candidates[0].mv.ver_vector,
+			et->amvp_candidates[0].mv_candidates[1].mv.hor_vector, et->amvp_candidates[0].mv_candidates[1].mv.ver_vector);
+	}
+	return r;
+}
+
+int predict_inter(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int depth, int part_position, PartSize pst)
+{
+	static int (*real)(henc_thread_t *, ctu_info_t *, int, int, int, PartSize);
+	if (!real) real = next("predict_inter");
+	int r = real(et, ctu, gcnt, depth, part_position, pst);
+	if (trace()) {
+		cu_partition_info_t *cu = &ctu->partition_list[et->partition_depth_start[depth]] + part_position;
+		fprintf(g_trace, "PRED ctu=%d d=%d abs=%d mvcost=%d\n", ctu->ctu_number, depth, cu->abs_index, r);
+	}
+	return r;
+}
+
+int encode_inter(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int depth, int part_position, PartSize pst)
+{
+	static int (*real)(henc_thread_t *, ctu_info_t *, int, int, int, PartSize);
+	if (!real) real = next("encode_inter");
+	int r = real(et, ctu, gcnt, depth, part_position, pst);
+	if (trace()) {
+		cu_partition_info_t *cu = &ctu->partition_list[et->partition_depth_start[depth]] + part_position;
+		fprintf(g_trace, "EINTER ctu=%d d=%d abs=%d ret=%d sum=%u cbf=%d,%d,%d\n", ctu->ctu_number, depth, cu->abs_index, r, cu->sum, cu->inter_cbf[0], cu->inter_cbf[1],
+			cu->inter_cbf[2]);
+	}
+	return r;
+}
+
+uint32_t encode_intra_luma(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int depth, int part_position, PartSize pst)
+{
+	static uint32_t (*real)(henc_thread_t *, ctu_info_t *, int, int, int, PartSize);
+	if (!real) real = next("encode_intra_luma");
+	uint32_t r = real(et, ctu, gcnt, depth, part_position, pst);
+	if (trace()) {
+		cu_partition_info_t *cu = &ctu->partition_list[et->partition_depth_start[depth]] + part_position;
+		fprintf(g_trace, "ILUMA ctu=%d d=%d abs=%d ret=%u mode=%d sum=%u cost=%u\n", ctu->ctu_number, depth, cu->abs_index, r, cu->intra_mode[0], cu->sum, cu->cost);
+	}
+	return r;
+}
+
+uint32_t encode_intra_chroma(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int depth, int part_position, int pst)
+{
+	static uint32_t (*real)(henc_thread_t *, ctu_info_t *, int, int, int, int);
+	if (!real) real = next("encode_intra_chroma");
+	uint32_t r = real(et, ctu, gcnt, depth, part_position, pst);
+	if (trace()) {
+		cu_partition_info_t *cu = &ctu->partition_list[et->partition_depth_start[depth]] + part_position;
+		fprintf(g_trace, "ICHROMA ctu=%d d=%d abs=%d ret=%u mode=%d\n", ctu->ctu_number, depth, cu->abs_index, r,
+			et->intra_mode_buffs[1][depth][depth == 0 ? 0 : (pst == SIZE_NxN ? cu->parent->abs_index : cu->abs_index)]);
+	}
+	return r;
+}
+
+void consolidate_prediction_info(henc_thread_t *et, ctu_info_t *ctu, ctu_info_t *ctu_rd, cu_partition_info_t *parent, uint32_t parent_cost, uint32_t children_cost,
+				 int is_max_depth, uint32_t *cost_sum)
+{
+	static void (*real)(henc_thread_t *, ctu_info_t *, ctu_info_t *, cu_partition_info_t *, uint32_t, uint32_t, int, uint32_t *);
+	if (!real) real = next("consolidate_prediction_info");
+	if (trace())
+		fprintf(g_trace, "CONS ctu=%d d=%d abs=%d parent=%u children=%u max=%d mode=%d\n", ctu->ctu_number, parent->depth, parent->abs_index, parent_cost, children_cost,
+			is_max_depth, parent->prediction_mode);
+	real(et, ctu, ctu_rd, parent, parent_cost, children_cost, is_max_depth, cost_sum);
+}
