@@ -6,7 +6,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libhomer_gpu.so")
-SOURCES = ["tables.cpp", "context.cpp", "dropin.cpp", "cmdlist.cpp", "k_pixel.hip", "k_transform.hip", "k_intra.hip", "k_interp.hip", "k_loop.hip", "k_motion.hip", "k_tuchain.hip", "k_intrasearch.hip", "k_tree.hip", "k_chromasearch.hip", "k_saooffsets.hip"]
+SOURCES = ["tables.cpp", "context.cpp", "dropin.cpp", "cmdlist.cpp", "k_pixel.hip", "k_transform.hip", "k_intra.hip", "k_interp.hip", "k_loop.hip", "k_motion.hip", "k_tuchain.hip", "k_intrasearch.hip", "k_tree.hip", "k_chromasearch.hip", "k_saooffsets.hip", "k_encode.hip"]
 # -ffp-contract=off: the few double-precision cost terms must round exactly like the reference's x87-free SSE2 code
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip"]
 
@@ -15,7 +15,7 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(PKG_DIR, "..", "include", "homer_gpu.h")]
+    deps = [os.path.join(dp, f) for dp, _, fs in os.walk(CSRC) for f in fs] + [os.path.join(PKG_DIR, "..", "include", "homer_gpu.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

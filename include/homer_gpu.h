@@ -558,6 +558,42 @@ int hmr_gpu_sao_offsets_frame(hmr_gpu_ctx *ctx, const int32_t *stats, int n_ctu,
 /* host-pointer (drop-in) form for one CTU; lambdas[3] */
 void hmr_gpu_sao_offsets_ctu(const int32_t *stats, const double *lambdas, int32_t *offsets, int32_t *aux, int64_t *dist);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * 12. frame encoder: the reference's public API (homer_hevc_enc_api.h:169-174) with the CTU loop of its WPP thread
+ *     (wfpp_encoder_thread, hmr_encoder_lib.c:2849-2975: stage the CTU, motion_inter / motion_intra, store, in-loop filters,
+ *     entropy coding) running on the device.  One persistent launch walks the picture as the WPP wavefront: a wavefront
+ *     per CTU row, row r+1 two CTUs behind row r (:2885-2898); planes, side-info and levels stay resident in HBM.
+ *     hmr_gpu_enc_cfg has the layout and field names of HVENC_Cfg (homer_hevc_enc_api.h:138-167), so a caller passes
+ *     the struct it already fills for HOMER_enc_control(HOMER_SETCFG).
+ *     Built rows: 8-bit 4:2:0, 64x64 CTUs, I / P slices with one reference picture, fixed QP, rd_mode 0 / 2,
+ *     performance_mode 0-2 (BASELINE configs 1, 2, 4); anything else makes hmr_gpu_enc_create return HMR_GPU_ERR_ARG.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct hmr_gpu_enc_cfg {
+	int32_t size, profile, width, height;
+	float frame_rate;
+	int32_t cu_size, max_pred_partition_depth, max_intra_tr_depth, max_inter_tr_depth, intra_period, gop_size, num_b, num_ref_frames;
+	int32_t motion_estimation_precision, qp, chroma_qp_offset, num_enc_engines, wfpp_enable, wfpp_num_threads, sign_hiding, sample_adaptive_offset;
+	int32_t bitrate_mode, bitrate, vbv_size, vbv_init, reinit_gop_on_scene_change, rd_mode, performance_mode;
+} hmr_gpu_enc_cfg;
+typedef struct hmr_gpu_enc hmr_gpu_enc;
+
+/* HOMER_enc_init + HOMER_enc_control(HOMER_SETCFG) */
+int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, hmr_gpu_enc **out);
+/* HOMER_enc_close */
+void hmr_gpu_enc_destroy(hmr_gpu_enc *enc);
+/* bytes of one per-CTU record of hmr_gpu_enc_frame_ctus (layout of oracle/ref_ctudump.c) */
+int hmr_gpu_enc_record_bytes(void);
+/* The CTU decisions of one frame (the part of HOMER_enc_encode between slice set-up and the in-loop filters): y / u / v are host
+ * 8-bit planes (width x height, width/2 x height/2); image_type as encoder_in_out_t.image_type (0 auto, 3 forced intra);
+ * ref_y / ref_u / ref_v, when not NULL, replace the encoder's reference picture (8-bit, unpadded) - used by the parity tests to
+ * compare frame by frame against the reference's own pictures; avg_dist < 0 keeps the encoder's own running value.
+ * records (host, may be NULL): nctu x hmr_gpu_enc_record_bytes() bytes, one record per CTU. Returns the slice type (1 P, 2 I) or a negative status. */
+int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *enc, const uint8_t *y, const uint8_t *u, const uint8_t *v, int image_type, const uint8_t *ref_y, const uint8_t *ref_u,
+			   const uint8_t *ref_v, double avg_dist, uint8_t *records);
+/* milliseconds the last CTU launch took on the device (HIP events on the context's stream) */
+float hmr_gpu_enc_last_ctu_ms(hmr_gpu_enc *enc);
+
 #ifdef __cplusplus
 }
 #endif
