@@ -11,9 +11,20 @@ extern "C" FILE *henc_trace_file;
 #define HENC_TRACE(...) do { } while (0)
 #endif
 
+// Device-side phase timers (profiling build only, -DHENC_PROFILE): lane 0 accumulates s_memtime ticks per phase into Enc::prof.
+enum { PF_SETUP = 0, PF_MERGE, PF_ME_INT, PF_ME_SUB, PF_PRED_INTER, PF_ENC_INTER, PF_INTRA_SEARCH, PF_INTRA_TU, PF_INTRA_CHROMA, PF_CONSOLIDATE, PF_WAIT, PF_TOTAL, PF_COUNT };
+#if defined(__HIPCC__) && defined(HENC_PROFILE)
+#define HENC_PROF_T0() const unsigned long long prof_t0_ = __builtin_amdgcn_s_memtime()
+#define HENC_PROF_ADD(e, cat) do { if ((e).prof && threadIdx.x == 0) (e).prof[cat] += __builtin_amdgcn_s_memtime() - prof_t0_; } while (0)
+#else
+#define HENC_PROF_T0() do { } while (0)
+#define HENC_PROF_ADD(e, cat) do { } while (0)
+#endif
+
 namespace henc {
 
 struct Enc {
+	unsigned long long *prof;   // PF_COUNT accumulators of this worker (profiling build), else unused
 	const Seq *seq;
 	const FrameCtx *f;
 	const DevTables *T;

@@ -161,8 +161,9 @@ HENC_HD uint32_t encode_intra(const G &g, Enc &e, int curr_depth, int position, 
 {
 	uint32_t cost = 0;
 	if (part_size_type == PART_2Nx2N) {
-		const uint32_t cl = encode_intra_luma(g, e, curr_depth, position, part_size_type);
-		const uint32_t cc = encode_intra_chroma(g, e, curr_depth, position, part_size_type);
+		uint32_t cl, cc;
+		{ HENC_PROF_T0(); cl = encode_intra_luma(g, e, curr_depth, position, part_size_type); HENC_PROF_ADD(e, PF_INTRA_TU); }
+		{ HENC_PROF_T0(); cc = encode_intra_chroma(g, e, curr_depth, position, part_size_type); HENC_PROF_ADD(e, PF_INTRA_CHROMA); }
 		cost = cl + cc;
 	} else {
 		for (int n = 0; n < 4; n++) {
@@ -293,7 +294,7 @@ HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &e)
 				const int action = S.me_precision * 2 - 1;
 				nd.prediction_mode = PM_INTER;
 				if (curr_depth >= perf_min_depth) {
-					merge_dist = check_rd_cost_merge(g, e, curr_depth, position);
+					{ HENC_PROF_T0(); merge_dist = check_rd_cost_merge(g, e, curr_depth, position); HENC_PROF_ADD(e, PF_MERGE); }
 					merge_mv = nd.inter_mv;
 					merge_ref_idx = nd.inter_ref_index;
 					merge_inter_mode = nd.inter_mode;
@@ -315,10 +316,10 @@ HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &e)
 					is_skipped = 0;
 				}
 				if (curr_depth >= perf_min_depth) {
-					if (!is_skipped) sad = (uint32_t)cu_motion_estimation(g, e, curr_depth, position, PART_2Nx2N, action);
+					if (!is_skipped) sad = (uint32_t)cu_motion_estimation(g, e, curr_depth, position, PART_2Nx2N, action);   // timed inside (PF_ME_INT / PF_ME_SUB)
 					if (!is_skipped && (q.size < 64 || sad < 100u * num_part_in_cu)) {
-						mv_cost = predict_inter(g, e, curr_depth, position, PART_2Nx2N);
-						dist = (double)(int)encode_inter(g, e, curr_depth, position, PART_2Nx2N);
+						{ HENC_PROF_T0(); mv_cost = predict_inter(g, e, curr_depth, position, PART_2Nx2N); HENC_PROF_ADD(e, PF_PRED_INTER); }
+						{ HENC_PROF_T0(); dist = (double)(int)encode_inter(g, e, curr_depth, position, PART_2Nx2N); HENC_PROF_ADD(e, PF_ENC_INTER); }
 					} else {
 						mv_cost = 0;
 						dist = MAX_COST;
@@ -443,8 +444,8 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &e)
 		nd->qp = (uint32_t)e.f->qp;
 		if (nd->b_inside && nd->r_inside) {
 			if (part_size_type == PART_2Nx2N) {
-				cost_luma = encode_intra_luma(g, e, curr_depth, position, part_size_type);
-				cost_chroma = encode_intra_chroma(g, e, curr_depth, position, part_size_type);
+				{ HENC_PROF_T0(); cost_luma = encode_intra_luma(g, e, curr_depth, position, part_size_type); HENC_PROF_ADD(e, PF_INTRA_TU); }
+				{ HENC_PROF_T0(); cost_chroma = encode_intra_chroma(g, e, curr_depth, position, part_size_type); HENC_PROF_ADD(e, PF_INTRA_CHROMA); }
 				nd->cost = (uint32_t)(cost_luma + cost_chroma);
 				cost_sum[curr_depth] += nd->cost;
 				nd->prediction_mode = PM_INTRA;
@@ -642,7 +643,7 @@ HENC_HD void ctu_end(const G &g, Enc &e)
 template <class G>
 HENC_HD void encode_ctu(const G &g, Enc &e, int ctu_num)
 {
-	ctu_begin(g, e, ctu_num);
+	{ HENC_PROF_T0(); ctu_begin(g, e, ctu_num); HENC_PROF_ADD(e, PF_SETUP); }
 	if (e.f->slice_type != SLICE_I && !e.f->is_scene_change) motion_inter_ctu(g, e);
 	else motion_intra_ctu(g, e);
 	ctu_end(g, e);

@@ -100,6 +100,7 @@ HENC_HD uint32_t motion_estimation(const G &g, Enc &e, const int16_t *orig, cons
 			if (rd_ < cur_rd) { on_better; cur_sad = s_; cur_rd = rd_; cur_x = (x); cur_y = (y); } \
 		}                                                                                  \
 	} while (0)
+	HENC_PROF_T0();
 	if (action & ME_PEL) {
 		bool early = false;
 		cur_x = hclip(0, xlow, xhigh);
@@ -155,6 +156,7 @@ HENC_HD uint32_t motion_estimation(const G &g, Enc &e, const int16_t *orig, cons
 	} else {
 		mvx = mv_io->x; mvy = mv_io->y;
 	}
+	HENC_PROF_ADD(e, PF_ME_INT);
 	if (action & ME_HALF) {
 		int bidx = 0, bx = 0, by = 0;
 		best_x = mvx >> 2; best_y = mvy >> 2;
@@ -186,6 +188,7 @@ HENC_HD uint32_t motion_estimation(const G &g, Enc &e, const int16_t *orig, cons
 #undef HENC_IN_WIN
 #undef HENC_SAD_AT
 #undef HENC_TRY
+	HENC_PROF_ADD(e, PF_ME_SUB);   // includes the integer part; the report subtracts
 	mv_io->x = mvx; mv_io->y = mvy;
 	subpix_out->x = subx; subpix_out->y = suby;
 	return best_sad;

@@ -167,7 +167,8 @@ HENC_HD uint32_t encode_intra_luma(const G &g, Enc &e, int depth, int part_posit
 	const uint32_t qp = node_of(e, top_ni).qp;
 	int cu_mode;
 	double search_cost;
-	const int bitcost_cu_mode = intra_mode_search(g, e, top_ni, depth, &cu_mode, &search_cost);
+	int bitcost_cu_mode;
+	{ HENC_PROF_T0(); bitcost_cu_mode = intra_mode_search(g, e, top_ni, depth, &cu_mode, &search_cost); HENC_PROF_ADD(e, PF_INTRA_SEARCH); }
 
 	int parent, curr, initial_state, end_state;
 	if (depth == 0 && S.max_cu_size == 64) {

@@ -64,7 +64,8 @@ struct SaoOffset {                         // sao_offset_t, hmr_private.h:463-47
 	int32_t offset[32];
 };
 
-struct CtuInfo {
+// what the stages after the CTU decisions read (in-loop filters, SAO decision, entropy coding): the head of every CtuInfo
+struct CtuPublic {
 	uint8_t cbf[3][NPART];
 	uint8_t intra_mode[2][NPART];
 	uint8_t inter_mode[NPART], tr_idx[NPART], pred_depth[NPART], part_size_type[NPART], pred_mode[NPART];
@@ -75,14 +76,17 @@ struct CtuInfo {
 	int32_t ctu_number, x, y, last_valid_partition;
 	uint32_t distortion;
 	uint8_t has_left, has_top, has_top_right, has_top_left;
+	uint32_t intra_parts;                  // partitions with pred_mode == INTRA after the CTU (hmr_encoder_lib.c:2924-2928)
+	SaoOffset sao_recon[3], sao_coded[3];
+};
+
+struct CtuInfo : CtuPublic {
 	// speculation record of a P-frame CTU (enc_ctu.h): reads of inherited intra modes and the intra / inter comparisons that used the running ratio
 	int32_t n_spec_reads, n_ratio_cmp;
 	uint16_t spec_read[96];                // (unit index << 8) | value used
 	double ratio_cmp[3 * 96];              // intra_dist, additive term, inter cost
 	uint8_t ratio_out[96];                 // outcome taken
 	double ratio_used;
-	uint32_t intra_parts;                  // partitions with pred_mode == INTRA after the CTU (hmr_encoder_lib.c:2924-2928)
-	SaoOffset sao_recon[3], sao_coded[3];
 	Node nodes[NNODES];
 };
 

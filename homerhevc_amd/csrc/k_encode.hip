@@ -23,6 +23,7 @@ struct EncDev {
 	int16_t *coeff;
 	int *progress;         // [hctu] CTUs finished per row
 	uint32_t *intra_prefix;   // [hctu][wctu + 1] running count of intra partitions along each row
+	unsigned long long *prof; // [hctu][PF_COUNT] phase timers (profiling build)
 };
 
 __global__ __launch_bounds__(64) void k_encode_ctus(EncDev d)
@@ -38,14 +39,18 @@ __global__ __launch_bounds__(64) void k_encode_ctus(EncDev d)
 	e.ctus = d.ctus;
 	e.ctu = nullptr;
 	e.w = d.work + row;
+	e.prof = d.prof ? d.prof + (size_t)row * PF_COUNT : nullptr;
 	uint32_t *my_prefix = d.intra_prefix + (size_t)row * (W + 1);
 	uint32_t run = 0;
 	if (g.tid == 0) my_prefix[0] = 0;
 	for (int c = 0; c < W; c++) {
 		if (row > 0) {
+			HENC_PROF_T0();
 			const int need = c + 2 < W ? c + 2 : W;
 			while (__hip_atomic_load(&d.progress[row - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(16);
+			HENC_PROF_ADD(e, PF_WAIT);
 		}
+		HENC_PROF_T0();
 		// running intra statistics (hmr_motion_inter.c:3769-3776) from the CTUs the wavefront order guarantees to be finished:
 		// row r-k has completed at least c + 2k CTUs
 		uint32_t ti = run;
@@ -58,6 +63,7 @@ __global__ __launch_bounds__(64) void k_encode_ctus(EncDev d)
 		const int n = row * W + c;
 		e.coeff = d.coeff + (size_t)n * 6144;
 		encode_ctu(g, e, n);
+		HENC_PROF_ADD(e, PF_TOTAL);
 		run += d.ctus[n].intra_parts;
 		if (g.tid == 0) my_prefix[c + 1] = run;
 		__syncthreads();
@@ -130,6 +136,8 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 	HIP_TRY(hipMemset(e->d.coeff, 0, sizeof(int16_t) * 6144 * s.nctu));
 	HIP_TRY(hipMalloc((void **)&e->d.progress, sizeof(int) * s.hctu));
 	HIP_TRY(hipMalloc((void **)&e->d.intra_prefix, sizeof(uint32_t) * s.hctu * (s.wctu + 1)));
+	HIP_TRY(hipMalloc((void **)&e->d.prof, sizeof(unsigned long long) * s.hctu * PF_COUNT));
+	HIP_TRY(hipMemset(e->d.prof, 0, sizeof(unsigned long long) * s.hctu * PF_COUNT));
 	for (int c = 0; c < 3; c++) {
 		e->src_elems[c] = (size_t)(c ? s.src_stride_c : s.src_stride_y) * (c ? s.height / 2 : s.height);
 		e->pic_elems[c] = (size_t)(c ? s.stride_c : s.stride_y) * ((c ? s.height / 2 : s.height) + 2 * (c ? s.margin_c : s.margin_y));
@@ -165,6 +173,15 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 }
 
 extern "C" float hmr_gpu_enc_last_ctu_ms(hmr_gpu_enc *e) { return e ? e->last_ms : 0.f; }
+
+// profiling build (-DHENC_PROFILE): per-row phase timers in s_memtime ticks (100 MHz), [hctu][12]; all zero otherwise
+extern "C" int hmr_gpu_enc_profile(hmr_gpu_enc *e, unsigned long long *out, int reset)
+{
+	if (!e || !out) return HMR_GPU_ERR_ARG;
+	HIP_TRY(hipMemcpy(out, e->d.prof, sizeof(unsigned long long) * e->seq.hctu * PF_COUNT, hipMemcpyDeviceToHost));
+	if (reset) HIP_TRY(hipMemset(e->d.prof, 0, sizeof(unsigned long long) * e->seq.hctu * PF_COUNT));
+	return HMR_GPU_OK;
+}
 
 // host 8-bit plane -> device int16 plane (sse_copy_8_16 at frame entry, hmr_encoder_lib.c:295-305); pad > 0 also replicates the borders
 static int upload_plane(hmr_gpu_enc *e, const uint8_t *src, int w, int h, int16_t *dst_base, size_t elems, int stride, int margin)

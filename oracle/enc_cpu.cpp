@@ -15,8 +15,13 @@
 #include <vector>
 
 #define HENC_TRACE_ENABLE 1
+#define HENC_SAO_TRACE 1
+#include <stdio.h>
+static FILE *henc_sao_trace_file = nullptr;
 #include "../homerhevc_amd/csrc/enc/enc_ctu.h"
 #include "../homerhevc_amd/csrc/enc/enc_host.h"
+#include "../homerhevc_amd/csrc/enc/enc_entropy.h"
+#include "hmr_oracle.h"
 
 extern "C" FILE *henc_trace_file = nullptr;
 const DevTables *hmr_host_tables();
@@ -35,11 +40,13 @@ struct Cpu {
 	Geo geo[NNODES];
 	std::vector<CtuInfo> ctus;
 	Work *w;
+	std::vector<Work *> row_w;   // wavefront emulation: one worker per CTU row
 	std::vector<int16_t> src[3], pic[2][3], coeff;
 	std::vector<uint8_t> records;
 	int cur = 0;        // picture under reconstruction: pic[cur], reference: pic[cur ^ 1]
 	uint32_t acc_dist = 0;
 	uint32_t intra_parts = 0, total_parts = 0;
+	EntropyState es;
 };
 
 int16_t *plane0(Cpu &c, int which, int comp)
@@ -135,6 +142,12 @@ void henc_cpu_destroy(void *h)
 	delete c;
 }
 
+void henc_cpu_set_sao_trace(const char *path)
+{
+	if (henc_sao_trace_file) fclose(henc_sao_trace_file);
+	henc_sao_trace_file = path && *path ? fopen(path, "w") : nullptr;
+}
+
 void henc_cpu_set_trace(const char *path)
 {
 	if (henc_trace_file) fclose(henc_trace_file);
@@ -195,7 +208,139 @@ int henc_cpu_frame_ctus(void *h, const uint8_t *y, const uint8_t *u, const uint8
 	return c.f.slice_type;
 }
 
+// Debug aid: the same frame in WAVEFRONT order with one worker per CTU row (the device schedule).  `oracle` = the reference's
+// records of this frame and `prev_last` = the last record of the previous frame: every row start takes the serial thread's
+// mode buffers and every CTU the raster-order intra count from them, so that whatever still differs from the serial run is a
+// dependence on worker state that the schedule does not model.
+int henc_cpu_frame_ctus_wavefront(void *h, const uint8_t *y, const uint8_t *u, const uint8_t *v, int image_type, const uint8_t *ref_y, const uint8_t *ref_u,
+				  const uint8_t *ref_v, const uint8_t *oracle, const uint8_t *prev_last)
+{
+	Cpu &c = *(Cpu *)h;
+	const Seq &s = c.seq;
+	const uint8_t *in[3] = {y, u, v}, *rin[3] = {ref_y, ref_u, ref_v};
+	c.cur ^= 1;
+	begin_frame(s, c.st, image_type, c.f);
+	c.acc_dist = 0;
+	for (int comp = 0; comp < 3; comp++) {
+		const int w = comp ? s.width / 2 : s.width, hh = comp ? s.height / 2 : s.height, ss = comp ? s.src_stride_c : s.src_stride_y;
+		for (int r = 0; r < hh; r++)
+			for (int x = 0; x < w; x++) c.src[comp][(size_t)r * ss + x] = in[comp][(size_t)r * w + x];
+		if (rin[comp]) {
+			int16_t *p = plane0(c, c.cur ^ 1, comp);
+			const int rs = comp ? s.stride_c : s.stride_y;
+			for (int r = 0; r < hh; r++)
+				for (int x = 0; x < w; x++) p[(size_t)r * rs + x] = rin[comp][(size_t)r * w + x];
+			pad_plane(p, rs, w, hh, comp ? s.margin_c : s.margin_y);
+		}
+		c.f.src[comp] = c.src[comp].data();
+		c.f.ref[comp] = plane0(c, c.cur ^ 1, comp);
+		c.f.rec[comp] = plane0(c, c.cur, comp);
+	}
+	while ((int)c.row_w.size() < s.hctu) c.row_w.push_back((Work *)calloc(1, sizeof(Work)));
+	Enc e;
+	memset(&e, 0, sizeof e);
+	e.seq = &c.seq; e.f = &c.f; e.T = hmr_host_tables(); e.geo = c.geo; e.ctus = c.ctus.data();
+	CpuGrp g;
+	const int mb_off = REC_BYTES - 2560, pm_off = 32 + 768 + 512 + 256 * 4;
+	std::vector<uint32_t> intra_prefix(s.nctu + 1, 0);
+	for (int n = 0; n < s.nctu; n++) {
+		uint32_t cnt = 0;
+		const uint8_t *pm = oracle + (size_t)n * REC_BYTES + pm_off;
+		for (int i = 0; i < 256; i++) cnt += pm[i] == PM_INTRA;
+		intra_prefix[n + 1] = intra_prefix[n] + (c.f.slice_type == SLICE_I ? 256 : cnt);
+	}
+	std::vector<std::vector<uint8_t>> snap(s.hctu, std::vector<uint8_t>(2560));
+	for (int t = 0; t < s.wctu + 2 * (s.hctu - 1); t++)
+		for (int r = 0; r < s.hctu; r++) {
+			const int col = t - 2 * r;
+			if (col < 0 || col >= s.wctu) continue;
+			const int n = r * s.wctu + col;
+			e.w = c.row_w[r];
+			static const int guess_mode = getenv("HENC_WF_GUESS") ? atoi(getenv("HENC_WF_GUESS")) : 0;   // 0 exact state, 1 snapshot of the row above after its CTU 1, 2 per-row chain
+			if (col == 0) {
+				const uint8_t *src = n == 0 ? prev_last : oracle + (size_t)(n - 1) * REC_BYTES;
+				if (guess_mode == 0 || (guess_mode == 1 && r == 0)) { if (src) memcpy(e.w->intra_mode_buffs, src + mb_off, 2560); }
+				else if (guess_mode == 1) memcpy(e.w->intra_mode_buffs, snap[r - 1].data(), 2560);
+			}
+			e.coeff = c.coeff.data() + (size_t)n * 6144;
+			e.total_intra_partitions = intra_prefix[n];
+			e.total_partitions = (uint32_t)n * NPART;
+			encode_ctu(g, e, n);
+			c.acc_dist += c.ctus[n].distortion;
+			if (col == 1 || s.wctu == 1) memcpy(snap[r].data(), e.w->intra_mode_buffs, 2560);
+			Work *keep = c.w;
+			c.w = e.w;
+			make_record(c, n, e);
+			c.w = keep;
+		}
+	end_frame(s, c.st, c.f, c.acc_dist);
+	return c.f.slice_type;
+}
+
 const uint8_t *henc_cpu_records(void *h) { return ((Cpu *)h)->records.data(); }
 double henc_cpu_avg_dist(void *h) { return ((Cpu *)h)->st.avg_dist; }
+
+// The whole frame, free running: CTU decisions (raster order), in-loop filters (the round-1 oracle functions), SAO decision + entropy
+// coding (homerhevc_amd/csrc/enc/enc_entropy.h, host code of the product) -> Annex-B bytes appended to `stream`; the final picture
+// (8 bit, planar) goes to recon when not NULL.  Returns the number of bytes written or a negative value.
+long henc_cpu_encode_frame(void *h, const uint8_t *y, const uint8_t *u, const uint8_t *v, int image_type, uint8_t *stream, long cap, uint8_t *recon)
+{
+	Cpu &c = *(Cpu *)h;
+	const Seq &s = c.seq;
+	henc_cpu_frame_ctus(h, y, u, v, image_type, nullptr, nullptr, nullptr, -1.0, 0, -1);
+	const int us = s.wctu * 16, uh = s.hctu * 16;
+	std::vector<int16_t> mvx((size_t)us * uh), mvy((size_t)us * uh);
+	std::vector<int8_t> ref((size_t)us * uh);
+	std::vector<uint8_t> qp((size_t)us * uh), flags((size_t)us * uh), pd((size_t)us * uh), ti((size_t)us * uh);
+	for (int n = 0; n < s.nctu; n++) {
+		const CtuInfo &ci = c.ctus[n];
+		for (int a = 0; a < 256; a++) {
+			const int r = host_abs2raster(a);
+			const size_t o = (size_t)((n / s.wctu) * 16 + r / 16) * us + (n % s.wctu) * 16 + r % 16;
+			mvx[o] = (int16_t)ci.mv_ref[a].x; mvy[o] = (int16_t)ci.mv_ref[a].y; ref[o] = ci.mv_ref_idx[a]; qp[o] = ci.qp[a];
+			flags[o] = (uint8_t)((ci.pred_mode[a] == PM_INTRA ? 1 : 0) | (((ci.cbf[0][a] >> ci.tr_idx[a]) & 1) ? 2 : 0));
+			pd[o] = ci.pred_depth[a]; ti[o] = ci.tr_idx[a];
+		}
+	}
+	int16_t *ry = plane0(c, c.cur, 0), *ru = plane0(c, c.cur, 1), *rv = plane0(c, c.cur, 2);
+	ora_make_edge_flags(pd.data(), ti.data(), s.width, s.height, us, flags.data());
+	ora_deblock_frame(ry, s.stride_y, ru, rv, s.stride_c, s.width, s.height, us, mvx.data(), mvy.data(), ref.data(), qp.data(), flags.data(), s.chroma_qp_offset,
+			  s.chroma_qp_offset, 0, 0, nullptr, nullptr);
+	std::vector<int32_t> stats((size_t)s.nctu * 3 * 5 * 2 * 32, 0);
+	if (s.sao) ora_sao_stats_frame(c.src[0].data(), c.src[1].data(), c.src[2].data(), s.src_stride_y, s.src_stride_c, ry, ru, rv, s.stride_y, s.stride_c, s.width, s.height, stats.data());
+	EntropyFrame fr;
+	fr.seq = &c.seq; fr.f = &c.f; fr.T = hmr_host_tables(); fr.geo = c.geo;
+	fr.ctu_base = (const uint8_t *)c.ctus.data(); fr.ctu_pitch = sizeof(CtuInfo); fr.coeff = c.coeff.data();
+	std::vector<uint8_t> out;
+	encode_frame_entropy(c.es, fr, (const SaoStats *)stats.data(), c.cfg.profile, out);
+	if (s.sao) {
+		std::vector<int32_t> params((size_t)s.nctu * 3 * 34, 0);
+		for (int n = 0; n < s.nctu; n++)
+			for (int k = 0; k < 3; k++) {
+				const SaoOffset &o = c.ctus[n].sao_recon[k];
+				int32_t *p = params.data() + ((size_t)n * 3 + k) * 34;
+				p[0] = o.mode_idc; p[1] = o.type_idc;
+				memcpy(p + 2, o.offset, sizeof o.offset);
+			}
+		std::vector<int16_t> pre[3] = {c.pic[c.cur][0], c.pic[c.cur][1], c.pic[c.cur][2]};
+		const size_t oy = (size_t)s.margin_y * s.stride_y + s.margin_y, oc = (size_t)s.margin_c * s.stride_c + s.margin_c;
+		ora_sao_apply_frame(pre[0].data() + oy, pre[1].data() + oc, pre[2].data() + oc, ry, ru, rv, s.stride_y, s.stride_c, s.width, s.height, params.data());
+	}
+	ora_pad_plane(ry, s.stride_y, s.width, s.height, s.margin_y, s.margin_y);
+	ora_pad_plane(ru, s.stride_c, s.width / 2, s.height / 2, s.margin_c, s.margin_c);
+	ora_pad_plane(rv, s.stride_c, s.width / 2, s.height / 2, s.margin_c, s.margin_c);
+	if (recon) {
+		uint8_t *o = recon;
+		for (int k = 0; k < 3; k++) {
+			const int w = k ? s.width / 2 : s.width, hh = k ? s.height / 2 : s.height, st = k ? s.stride_c : s.stride_y;
+			const int16_t *p = plane0(c, c.cur, k);
+			for (int r = 0; r < hh; r++)
+				for (int x = 0; x < w; x++) *o++ = (uint8_t)p[(size_t)r * st + x];
+		}
+	}
+	if ((long)out.size() > cap) return -1;
+	memcpy(stream, out.data(), out.size());
+	return (long)out.size();
+}
 
 }  // extern "C"

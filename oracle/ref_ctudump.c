@@ -59,6 +59,58 @@ void hmr_deblock_sao_pad_sync_ctu(henc_thread_t *et, slice_t *currslice, ctu_inf
 	real(et, currslice, ctu);
 }
 
+/* the SAO decision of every CTU, logged when it is entropy coded (wfpp_encode_ctu, hmr_encoder_lib.c:2347) */
+void wfpp_encode_ctu(henc_thread_t *et, ctu_info_t *ctu)
+{
+	static void (*real)(henc_thread_t *, ctu_info_t *);
+	static FILE *f;
+	static int init;
+	if (!real) real = next("wfpp_encode_ctu");
+	if (!init) { init = 1; if (getenv("HOMER_SAODUMP")) f = fopen(getenv("HOMER_SAODUMP"), "w"); }
+	if (f) {
+		int c, k;
+		fprintf(f, "SAO frame=%d ctu=%d", et->enc_engine->num_encoded_frames, ctu->ctu_number);
+		for (c = 0; c < 3; c++) {
+			sao_offset_t *o = &ctu->coded_params.offsetParam[c];
+			fprintf(f, " | %d", o->modeIdc);
+			if (o->modeIdc != SAO_MODE_OFF) {
+				fprintf(f, " %d %d :", o->typeIdc, o->typeAuxInfo);
+				if (o->modeIdc == SAO_MODE_NEW)
+					for (k = 0; k < (o->typeIdc == SAO_TYPE_BO ? 32 : 5); k++) fprintf(f, " %d", o->offset[k]);
+			}
+		}
+		fprintf(f, " bits=%d\n", hmr_bitstream_bitcount(et->ee->bs));
+		if (getenv("HOMER_SAODUMP_STATS")) {
+			int t;
+			for (c = 0; c < 3; c++)
+				for (t = 0; t < 5; t++) {
+					fprintf(f, "  ST %d %d :", c, t);
+					for (k = 0; k < (t == 4 ? 32 : 5); k++) fprintf(f, " %d/%d", (int)ctu->stat_data[c][t].diff[k], (int)ctu->stat_data[c][t].count[k]);
+					fprintf(f, "\n");
+				}
+		}
+		fflush(f);
+	}
+	real(et, ctu);
+}
+
+
+/* costs of the two SAO mode searches (hmr_sao.c:663, :854) */
+void sao_derive_mode_new_rdo(henc_thread_t *wt, sao_blk_param_t **ml, int mls, sao_stat_data_t stats[][NUM_SAO_NEW_TYPES], sao_blk_param_t *mp, double *mode_cost, int se[])
+{
+	static void (*real)(henc_thread_t *, sao_blk_param_t **, int, sao_stat_data_t [][NUM_SAO_NEW_TYPES], sao_blk_param_t *, double *, int []);
+	if (!real) real = next("sao_derive_mode_new_rdo");
+	real(wt, ml, mls, stats, mp, mode_cost, se);
+	if (getenv("HOMER_SAOCOST")) fprintf(stderr, "NEWCOST %.6f lambdas %.6f %.6f\n", *mode_cost, wt->enc_engine->sao_lambdas[0], wt->enc_engine->sao_lambdas[1]);
+}
+void sao_derive_mode_merge_rdo(henc_thread_t *wt, sao_blk_param_t **ml, int mls, int *se, sao_stat_data_t stats[][NUM_SAO_NEW_TYPES], sao_blk_param_t *mp, double *mode_cost)
+{
+	static void (*real)(henc_thread_t *, sao_blk_param_t **, int, int *, sao_stat_data_t [][NUM_SAO_NEW_TYPES], sao_blk_param_t *, double *);
+	if (!real) real = next("sao_derive_mode_merge_rdo");
+	real(wt, ml, mls, se, stats, mp, mode_cost);
+	if (getenv("HOMER_SAOCOST")) fprintf(stderr, "MERGECOST %.6f type %d\n", *mode_cost, mp->offsetParam[0].typeIdc);
+}
+
 /* ---- optional per-call text trace of the block drivers ---- */
 static FILE *trace(void)
 {
