@@ -35,6 +35,7 @@ struct Enc {
 	int16_t *coeff;        // the CTU's coefficient output: 4096 luma + 2 x 1024 chroma, linear per TU in z-order
 	// speculative inputs of a P-frame CTU (enc_ctu.h)
 	uint32_t total_intra_partitions, total_partitions;
+	int n_spec_reads, n_ratio_cmp, last_slog;
 };
 
 HENC_INLINE Node &node_of(Enc &e, int idx) { return e.ctu->nodes[idx]; }

@@ -255,11 +255,18 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &e, int depth, int position
 	return best_dist;
 }
 
-// one speculated comparison of the P-slice walk: intra against inter with the running intra ratio (:4018-4021)
-HENC_INLINE double intra_ratio(const Enc &e)
+// the comparison of the P-slice walk that uses the running intra ratio (:4018-4021).  The ratio is the one input of a CTU that depends on
+// every CTU before it in raster order; enc_sched.h re-evaluates the logged comparisons with the true value through this same function.
+HENC_INLINE double intra_ratio(uint32_t total_intra_partitions, uint32_t total_partitions)
 {
-	const uint32_t tp = e.total_partitions == 0 ? 1 : e.total_partitions;
-	return hclip((double)e.total_intra_partitions / (double)tp, .0, .15);
+	const uint32_t tp = total_partitions == 0 ? 1 : total_partitions;
+	return hclip((double)total_intra_partitions / (double)tp, .0, .15);
+}
+HENC_INLINE double intra_cost_with_ratio(double intra_dist, double ratio, double add, double rd)
+{
+	double intra_cost = intra_dist * (1.275 - ratio) + add;
+	intra_cost += rd;
+	return intra_cost;
 }
 
 // motion_inter_full :3746
@@ -356,19 +363,21 @@ HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &e)
 				if (perf_fast_skip && (curr_depth >= perf_min_depth && !stop_recursion && !is_skipped && (q.size < 32 || sad > 400u * num_part_in_cu))) {
 					const uint32_t inter_sum = nd.sum;
 					if (!nd.merge_flag) put_consolidated_info(g, e, curr, curr_depth);
+					e.last_slog = -1;
 					const uint32_t intra_dist = encode_intra(g, e, curr_depth, position, PART_2Nx2N);
-					const double ratio = intra_ratio(e);
+					const double ratio = intra_ratio(e.total_intra_partitions, e.total_partitions);
 					const double add = hclip(avg_distortion - 400, 40., avg_distortion) / 1.75 * curr_depth;
-					intra_cost = intra_dist * (1.275 - ratio) + add;
-					intra_cost += cost_rd(e.f->avg_dist, nd.sum);
+					const double rd = cost_rd(e.f->avg_dist, nd.sum);
+					intra_cost = intra_cost_with_ratio((double)intra_dist, ratio, add, rd);
 					const int take_intra = intra_cost < cost;
-					if (c.n_ratio_cmp < 96) {
-						c.ratio_cmp[3 * c.n_ratio_cmp] = (double)intra_dist;
-						c.ratio_cmp[3 * c.n_ratio_cmp + 1] = add + cost_rd(e.f->avg_dist, nd.sum);
-						c.ratio_cmp[3 * c.n_ratio_cmp + 2] = cost;
-						c.ratio_out[c.n_ratio_cmp] = (uint8_t)take_intra;
+					if (e.n_ratio_cmp < MAX_RATIO_CMP) {
+						double *lg = c.ratio_cmp + 4 * e.n_ratio_cmp;
+						lg[0] = (double)intra_dist; lg[1] = add; lg[2] = rd; lg[3] = cost;
+						c.ratio_out[e.n_ratio_cmp] = (uint8_t)take_intra;
+						c.ratio_slog[e.n_ratio_cmp] = (int16_t)e.last_slog;
+						if (e.last_slog >= 0) c.slog[e.last_slog].has_cmp = 1;
 					}
-					c.n_ratio_cmp++;
+					e.n_ratio_cmp++;
 					HENC_TRACE("CU ctu=%d d=%d abs=%d intra: dist=%u cost=%.3f vs %.3f\n", c.ctu_number, curr_depth, q.abs_index, intra_dist, intra_cost, cost);
 					if (take_intra) {
 						nd.cost = (uint32_t)intra_cost;
@@ -575,7 +584,9 @@ HENC_HD void ctu_begin(const G &g, Enc &e, int ctu_num)
 	c.has_top = cy > 0;
 	c.has_top_left = cx > 0 && cy > 0;
 	c.has_top_right = cy > 0 && cx != S.wctu - 1;
-	c.n_spec_reads = c.n_ratio_cmp = 0;
+	e.n_spec_reads = e.n_ratio_cmp = 0;
+	// the worker's mode buffers start as "inherited" everywhere (see read_mode_buff, enc_intra.h)
+	for (int i = g.tid; i < 2 * NDEPTH * NPART; i += g.n) (&w.intra_mode_buffs[0][0][0])[i] = (uint8_t)(MODE_TOKEN | ((i / NPART) % NDEPTH));
 	// source CTU
 	for (int comp = 0; comp < 3; comp++) {
 		const int sz = comp ? 32 : 64, px = comp ? c.x >> 1 : c.x, py = comp ? c.y >> 1 : c.y;
@@ -637,6 +648,23 @@ HENC_HD void ctu_end(const G &g, Enc &e)
 	cnt = g.sum(cnt);
 	c.intra_parts = e.f->slice_type != SLICE_I && !e.f->is_scene_change ? cnt : NPART;
 	c.distortion = node_of(e, 0).distortion;
+	c.n_spec_reads = e.n_spec_reads;
+	c.n_ratio_cmp = e.n_ratio_cmp;
+	g.sync();
+}
+
+// tokens -> values, for the worker buffers and the CTU's mode arrays, once the values behind the tokens (Work::mode_in) are the true ones
+template <class G>
+HENC_HD void resolve_mode_tokens(const G &g, Work &w, CtuInfo &c)
+{
+	for (int i = g.tid; i < 2 * NDEPTH * NPART; i += g.n) {
+		uint8_t &v = (&w.intra_mode_buffs[0][0][0])[i];
+		if (v & MODE_TOKEN) v = w.mode_in[i / (NDEPTH * NPART)][v & 7][i % NPART];
+	}
+	for (int i = g.tid; i < 2 * NPART; i += g.n) {
+		uint8_t &v = (&c.intra_mode[0][0])[i];
+		if (v & MODE_TOKEN) v = w.mode_in[i / NPART][v & 7][i % NPART];
+	}
 	g.sync();
 }
 

@@ -37,20 +37,23 @@ HENC_HD void node_fill_refs(const G &g, Enc &e, int ni, int wnd, int comp, int w
 // from the first frame on); units of other CTUs use those CTUs' final arrays.  The worker's buffer is NOT reset between
 // CTUs: for a neighbour that ended up inter-coded it holds whatever earlier CUs left there, which is part of the
 // reference's single-thread behaviour and therefore of the bitstream.
-HENC_INLINE int read_mode_buff(Enc &e, int depth, uint32_t idx)
+// A worker that runs one CTU row cannot have that state (it comes from the CTU before in raster order, which for a row start is the
+// end of the row above).  ctu_begin therefore fills the buffers with tokens that stand for "the inherited value", the copies between
+// buffers and CTU arrays carry tokens along, and a look-up that lands on a token uses the scheduler's guess (Work::mode_in).  A mode
+// search that used such a guess logs where its two neighbour directions came from and the SAD of every mode it tried
+// (SearchLog); enc_sched.h replays the search walk on that table with the true directions and re-encodes the CTU only when
+// the winner, its cost or its bit cost would have been different.
+HENC_INLINE int read_mode_buff(Enc &e, int depth, uint32_t idx, uint16_t *src)
 {
-	return e.w->intra_mode_buffs[COMP_Y][depth][idx];
+	const int v = e.w->intra_mode_buffs[COMP_Y][depth][idx];
+	if (!(v & MODE_TOKEN)) { *src = (uint16_t)v; return v; }
+	const int d = v & 7;
+	*src = (uint16_t)(0x8000 | (d << 8) | idx);
+	return e.w->mode_in[COMP_Y][d][idx];
 }
-HENC_INLINE void intra_dir_predictor(Enc &e, int ni, int depth, int *preds)
+// get_intra_dir_luma_predictor, hmr_arithmetic_encoding.c:545-590: the candidate list from the two neighbour directions
+HENC_INLINE void mpm_from_dirs(int left_dir, int top_dir, int *preds)
 {
-	uint32_t idx = 0;
-	CtuInfo *cl = pu_left(e, ni, &idx);
-	int left_dir = DC_IDX, top_dir = DC_IDX;
-	if (cl == e.ctu) left_dir = read_mode_buff(e, depth, idx);
-	else if (cl) left_dir = cl->pred_mode[idx] == PM_INTRA ? cl->intra_mode[COMP_Y][idx] : DC_IDX;
-	CtuInfo *ct = pu_top(e, ni, &idx, 1);
-	if (ct == e.ctu) top_dir = read_mode_buff(e, depth, idx);
-	else if (ct) top_dir = ct->pred_mode[idx] == PM_INTRA ? ct->intra_mode[COMP_Y][idx] : DC_IDX;
 	if (left_dir == top_dir) {
 		if (left_dir > 1) {
 			preds[0] = left_dir;
@@ -66,6 +69,53 @@ HENC_INLINE void intra_dir_predictor(Enc &e, int ni, int depth, int *preds)
 		else preds[2] = (left_dir + top_dir) < 2 ? VER_IDX : DC_IDX;
 	}
 }
+HENC_INLINE void intra_neighbour_dirs(Enc &e, int ni, int depth, int *dirs, uint16_t *src)
+{
+	uint32_t idx = 0;
+	CtuInfo *cl = pu_left(e, ni, &idx);
+	dirs[0] = dirs[1] = DC_IDX;
+	src[0] = src[1] = DC_IDX;
+	if (cl == e.ctu) dirs[0] = read_mode_buff(e, depth, idx, &src[0]);
+	else if (cl) src[0] = (uint16_t)(dirs[0] = cl->pred_mode[idx] == PM_INTRA ? cl->intra_mode[COMP_Y][idx] : DC_IDX);
+	CtuInfo *ct = pu_top(e, ni, &idx, 1);
+	if (ct == e.ctu) dirs[1] = read_mode_buff(e, depth, idx, &src[1]);
+	else if (ct) src[1] = (uint16_t)(dirs[1] = ct->pred_mode[idx] == PM_INTRA ? ct->intra_mode[COMP_Y][idx] : DC_IDX);
+}
+
+// The walk of homer_loop1_motion_intra (hmr_motion_intra.c:1084-1180) over the prediction directions: planar / DC, five coarse
+// angles, +-2 / +-4 around the best, +-1 around that.  sad_of(mode) returns the SAD of a direction or a negative value when it is not
+// available (only the replay in enc_sched.h can fail).  Returns the bit cost of the winner, or -1.
+template <class SadFn>
+HENC_INLINE int intra_search_walk(const int *preds, int rd_fast, double sqrt_lambda, SadFn &&sad_of, int *best_mode_out, double *best_cost_out)
+{
+	const int search_points[4][5] = {{0, 1, 0, 8, 16}, {2, 10, 16, 22, 30}, {-4, -2, 2, 4, 0}, {-1, 1, 0, 0, 0}};
+	const int num_search_points[4] = {2, 5, 4, 2};
+	int best_cu_mode = 0, new_best = 0, min_mode = 0, max_mode = 1, best_bit_cost = 0;
+	double best_cost = MAX_COST;
+	for (int loop = 0; loop < 4; loop++) {
+		if (loop == 1) { best_cu_mode = 2; min_mode = 2; max_mode = 34; }
+		for (int k = 0; k < num_search_points[loop]; k++) {
+			const int mode = best_cu_mode + search_points[loop][k];
+			if (mode < min_mode || mode > max_mode) continue;
+			const int64_t sad = sad_of(mode);
+			if (sad < 0) return -1;
+			double cost = (double)(uint32_t)sad;
+			int bit_cost = 0;
+			if (rd_fast) {
+				bit_cost = (preds[0] == mode || preds[1] == mode || preds[2] == mode) ? 1 : 12;
+				cost += bit_cost * sqrt_lambda;
+			}
+			if (cost < best_cost) { best_cost = cost; new_best = mode; best_bit_cost = bit_cost; }
+		}
+		best_cu_mode = new_best;
+	}
+	*best_mode_out = best_cu_mode;
+	*best_cost_out = best_cost;
+	return best_bit_cost;
+}
+
+// what encode_intra_luma returns for rd_mode != RD_FULL: the transform tree's cost plus the mode bits (hmr_motion_intra.c:1625)
+HENC_INLINE uint32_t intra_luma_cost(uint32_t tu_cost, int mode_bits, double correction) { return (uint32_t)(tu_cost + mode_bits * correction + .5); }
 
 // homer_loop1_motion_intra, hmr_motion_intra.c:1084-1180.  Returns the bit cost of the winner; *best_mode / *best_cost out.
 template <class G>
@@ -75,34 +125,38 @@ HENC_HD int intra_mode_search(const G &g, Enc &e, int ni, int depth, int *best_m
 	Work &w = *e.w;
 	const int n = q.size, curr_depth = q.depth, inv_depth = e.seq->max_cu_size_shift - curr_depth;
 	node_fill_refs(g, e, ni, depth + 1, COMP_Y, 1);
-	int preds[3];
-	intra_dir_predictor(e, ni, curr_depth, preds);
-	const int search_points[4][5] = {{0, 1, 0, 8, 16}, {2, 10, 16, 22, 30}, {-4, -2, 2, 4, 0}, {-1, 1, 0, 0, 0}};
-	const int num_search_points[4] = {2, 5, 4, 2};
-	int best_cu_mode = 0, new_best = 0, min_mode = 0, max_mode = 1, best_bit_cost = 0;
-	double best_cost = MAX_COST;
+	int preds[3], dirs[2];
+	uint16_t src[2];
+	intra_neighbour_dirs(e, ni, curr_depth, dirs, src);
+	mpm_from_dirs(dirs[0], dirs[1], preds);
+	const int rd_fast = e.seq->rd_mode == RDM_FAST;
+	// a search whose candidate list rests on a guess is logged (every lane writes the same values)
+	SearchLog *lg = nullptr;
+	e.last_slog = -1;
+	if (rd_fast && ((src[0] | src[1]) & 0x8000)) {
+		if (e.n_spec_reads < MAX_SEARCH_LOGS) {
+			lg = e.ctu->slog + e.n_spec_reads;
+			lg->src[0] = src[0]; lg->src[1] = src[1];
+			lg->used[0] = (uint8_t)dirs[0]; lg->used[1] = (uint8_t)dirs[1];
+			lg->n = 0;
+			lg->has_cmp = 0;
+			lg->tu_cost = 0;
+			e.last_slog = e.n_spec_reads;
+		}
+		e.n_spec_reads++;
+	}
 	int16_t *pred = w.pred_y + q.y * CTU_STRIDE_Y + q.x;
 	const int16_t *orig = w.curr_y + q.y * CTU_STRIDE_Y + q.x;
-	for (int loop = 0; loop < 4; loop++) {
-		if (loop == 1) { best_cu_mode = 2; min_mode = 2; max_mode = 34; }
-		for (int k = 0; k < num_search_points[loop]; k++) {
-			const int mode = best_cu_mode + search_points[loop][k];
-			if (mode < min_mode || mode > max_mode) continue;
-			const int filt = intra_is_filtered(mode, inv_depth);
-			const uint32_t sad = intra_predict_sad(g, pred, CTU_STRIDE_Y, orig, CTU_STRIDE_Y, filt ? w.adi_f : w.adi, n, mode, 1);
-			double cost = (double)sad;
-			int bit_cost = 0;
-			if (e.seq->rd_mode == RDM_FAST) {
-				bit_cost = (preds[0] == mode || preds[1] == mode || preds[2] == mode) ? 1 : 12;
-				cost += bit_cost * e.f->sqrt_lambda;
-			}
-			if (cost < best_cost) { best_cost = cost; new_best = mode; best_bit_cost = bit_cost; }
+	return intra_search_walk(preds, rd_fast, e.f->sqrt_lambda, [&](int mode) -> int64_t {
+		const int filt = intra_is_filtered(mode, inv_depth);
+		const uint32_t sad = intra_predict_sad(g, pred, CTU_STRIDE_Y, orig, CTU_STRIDE_Y, filt ? w.adi_f : w.adi, n, mode, 1);
+		if (lg) {
+			lg->mode[lg->n] = (uint8_t)mode;
+			lg->sad[lg->n] = sad;
+			lg->n++;
 		}
-		best_cu_mode = new_best;
-	}
-	*best_mode_out = best_cu_mode;
-	*best_cost_out = best_cost;
-	return best_bit_cost;
+		return (int64_t)sad;
+	}, best_mode_out, best_cost_out);
 }
 
 // encode_intra_cu, hmr_motion_intra.c:973-1071: one luma TU.  depth = prediction depth.  Returns the SSD, *curr_sum the level sum.
@@ -275,7 +329,8 @@ HENC_HD uint32_t encode_intra_luma(const G &g, Enc &e, int depth, int part_posit
 	}
 	if (S.rd_mode != RDM_FULL) {
 		const double correction = calc_mv_correction(tn.qp, e.f->avg_dist);
-		return (uint32_t)(tn.cost + bitcost_cu_mode * correction + .5);
+		if (e.last_slog >= 0) e.ctu->slog[e.last_slog].tu_cost = tn.cost;
+		return intra_luma_cost(tn.cost, bitcost_cu_mode, correction);
 	}
 	return tn.cost;
 }
@@ -302,7 +357,10 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &e, int depth, int part_pos
 		parent = S.depth_start[0];
 		curr = e.geo[parent].child[0];
 	} else parent = e.geo[curr].parent;
-	const int luma_mode = w.intra_mode_buffs[COMP_Y][depth][e.geo[curr].abs_index];
+	const int luma_mode = w.intra_mode_buffs[COMP_Y][depth][e.geo[curr].abs_index];   // written by the luma pass just before: never a token
+#if !defined(__HIPCC__)
+	if (luma_mode & MODE_TOKEN) { fprintf(stderr, "encode_intra_chroma: inherited luma mode\n"); abort(); }
+#endif
 	int mode_list[5];
 	chroma_dir_list(mode_list, luma_mode);
 	if (e.geo[curr].size_chroma == 2) {

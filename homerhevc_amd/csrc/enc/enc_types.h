@@ -27,6 +27,9 @@ constexpr int NDEPTH = 5;                  // MAX_PARTITION_DEPTH
 constexpr int NWND = 7;                    // NUM_QUANT_WNDS / NUM_DECODED_WNDS
 constexpr uint32_t MAX_COST = 0xffffffffu / 8;   // hmr_private.h:55
 
+constexpr int MAX_SEARCH_LOGS = 192, MAX_RATIO_CMP = 96;
+constexpr int MODE_TOKEN = 0x80;           // worker mode buffers: MODE_TOKEN | depth = "whatever this unit held at depth `depth` when the CTU started"
+
 constexpr int SEARCH_RANGE_X = 128, SEARCH_RANGE_Y = 64;   // hmr_private.h:76-77
 
 // windows of a CTU worker.  Decoded windows hold a 128 x 128 (64 x 64 chroma) area with a one-sample frame around it
@@ -64,6 +67,17 @@ struct SaoOffset {                         // sao_offset_t, hmr_private.h:463-47
 	int32_t offset[32];
 };
 
+// one logged mode search (enc_intra.h): where the left / top directions came from (0x8000 | depth << 8 | unit = inherited, else the
+// direction itself), the values used, and the SAD of every direction tried
+struct SearchLog {
+	uint16_t src[2];
+	uint8_t used[2];
+	uint8_t n, has_cmp;                    // has_cmp: the evaluation ends in one logged intra / inter comparison (P-slice walk)
+	uint8_t mode[14];
+	uint32_t sad[14];
+	uint32_t tu_cost;                      // the luma cost before the mode bits are added (encode_intra_luma)
+};
+
 // what the stages after the CTU decisions read (in-loop filters, SAO decision, entropy coding): the head of every CtuInfo
 struct CtuPublic {
 	uint8_t cbf[3][NPART];
@@ -81,12 +95,13 @@ struct CtuPublic {
 };
 
 struct CtuInfo : CtuPublic {
-	// speculation record of a P-frame CTU (enc_ctu.h): reads of inherited intra modes and the intra / inter comparisons that used the running ratio
+	// speculation record of the CTU (enc_sched.h): the mode searches whose candidate list used an inherited mode, and the intra / inter
+	// comparisons that used the running intra ratio (intra_dist, depth term, rate term, inter cost -> outcome taken)
 	int32_t n_spec_reads, n_ratio_cmp;
-	uint16_t spec_read[96];                // (unit index << 8) | value used
-	double ratio_cmp[3 * 96];              // intra_dist, additive term, inter cost
-	uint8_t ratio_out[96];                 // outcome taken
-	double ratio_used;
+	SearchLog slog[MAX_SEARCH_LOGS];
+	double ratio_cmp[4 * MAX_RATIO_CMP];
+	uint8_t ratio_out[MAX_RATIO_CMP];
+	int16_t ratio_slog[MAX_RATIO_CMP];     // the logged search behind the comparison's intra cost, or -1
 	Node nodes[NNODES];
 };
 
@@ -132,6 +147,7 @@ struct Work {
 	int16_t dec_y[NWND][DEC_ROWS_Y * DEC_STRIDE_Y], dec_c[NWND][2][DEC_ROWS_C * DEC_STRIDE_C];
 	uint8_t cbf_buffs[3][NDEPTH][NPART];
 	uint8_t intra_mode_buffs[2][NDEPTH][NPART];
+	uint8_t mode_in[2][NDEPTH][NPART];     // what intra_mode_buffs held when the CTU started (the values behind the tokens)
 	uint8_t tr_idx_buffs[NDEPTH][NPART];
 	uint8_t cbf_chroma[2][NPART];
 	int16_t adi[264], adi_f[264];

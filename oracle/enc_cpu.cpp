@@ -16,14 +16,17 @@
 
 #define HENC_TRACE_ENABLE 1
 #define HENC_SAO_TRACE 1
+#define HENC_SCHED_CAUSES 1
 #include <stdio.h>
 static FILE *henc_sao_trace_file = nullptr;
-#include "../homerhevc_amd/csrc/enc/enc_ctu.h"
+#include <stddef.h>
+#include "../homerhevc_amd/csrc/enc/enc_sched.h"
 #include "../homerhevc_amd/csrc/enc/enc_host.h"
 #include "../homerhevc_amd/csrc/enc/enc_entropy.h"
 #include "hmr_oracle.h"
 
 extern "C" FILE *henc_trace_file = nullptr;
+extern "C" int henc_sched_causes[8] = {0};
 const DevTables *hmr_host_tables();
 
 using namespace henc;
@@ -47,6 +50,14 @@ struct Cpu {
 	uint32_t acc_dist = 0;
 	uint32_t intra_parts = 0, total_parts = 0;
 	EntropyState es;
+	// speculative row-parallel schedule (enc_sched.h), emulated: sched = 0 raster order, 1 wavefront with guesses + verification
+	int sched = 0, row_guess = 0;          // row_guess: 0 = the truth of the previous frame, 1 = the row above after its second CTU
+	std::vector<CtuInfo> ctus_start;
+	std::vector<uint8_t> guess, truth, outtok, valid, dirty;
+	std::vector<uint32_t> intra_before, used_intra, prefix;
+	std::vector<uint64_t> hash;
+	uint8_t chain_start[MODE_STATE_BYTES] = {0}, chain_end[MODE_STATE_BYTES] = {0};
+	int stat_passes = 0, stat_encodes = 0, stat_invalid_first = 0;
 };
 
 int16_t *plane0(Cpu &c, int which, int comp)
@@ -100,6 +111,175 @@ void make_record(Cpu &c, int n, Enc &e)
 	(void)e;
 }
 
+// ---- the row-parallel schedule of the device (k_encode.hip), emulated with one lane: same passes, same guesses, same checks ----------
+void record_from_outputs(Cpu &c, int n, const uint8_t *state_after)
+{
+	const Seq &s = c.seq;
+	uint8_t *o = c.records.data() + (size_t)n * REC_BYTES;
+	const CtuInfo &ci = c.ctus[n];
+	memset(o, 0, REC_BYTES);
+	int32_t hdr[8] = {0x43545544, c.f.num_encoded_frames, n, c.f.slice_type, (int32_t)ci.nodes[0].cost, (int32_t)ci.nodes[0].distortion, (int32_t)ci.nodes[0].sum,
+			  c.f.is_scene_change};
+	memcpy(o, hdr, 32); o += 32;
+	for (int k = 0; k < 3; k++) { memcpy(o, ci.cbf[k], 256); o += 256; }
+	memcpy(o, ci.intra_mode[0], 256); o += 256;
+	memcpy(o, ci.intra_mode[1], 256); o += 256;
+	const uint8_t *arrs[9] = {ci.inter_mode, ci.tr_idx, ci.pred_depth, ci.part_size_type, ci.pred_mode, ci.skipped, ci.merge, ci.merge_idx, ci.qp};
+	for (int k = 0; k < 9; k++) { memcpy(o, arrs[k], 256); o += 256; }
+	memcpy(o, ci.mv_ref_idx, 256); o += 256;
+	memcpy(o, ci.mv_diff_ref_idx, 256); o += 256;
+	memcpy(o, ci.mv_ref, 2048); o += 2048;
+	memcpy(o, ci.mv_diff, 2048); o += 2048;
+	memcpy(o, c.coeff.data() + (size_t)n * 6144, 12288); o += 12288;
+	for (int comp = 0; comp < 3; comp++) {
+		const int nn = comp ? 32 : 64, px = ci.x >> (comp ? 1 : 0), py = ci.y >> (comp ? 1 : 0);
+		const int pw = comp ? s.width / 2 : s.width, ph = comp ? s.height / 2 : s.height, rs = comp ? s.stride_c : s.stride_y;
+		const int16_t *p = plane0(c, c.cur, comp);
+		for (int yy = 0; yy < nn; yy++) {
+			if (py + yy < ph) memcpy(o, p + (size_t)(py + yy) * rs + px, (px + nn <= pw ? nn : pw - px) * 2);
+			o += nn * 2;
+		}
+	}
+	memcpy(o, state_after, MODE_STATE_BYTES);
+}
+
+void sched_verify(Cpu &c, int *n_invalid)
+{
+	const Seq &s = c.seq;
+	CpuGrp g;
+	uint8_t st[MODE_STATE_BYTES];
+	memcpy(st, c.chain_start, MODE_STATE_BYTES);
+	uint32_t ib = 0;
+	for (int n = 0; n < s.nctu; n++) {
+		memcpy(&c.truth[(size_t)n * MODE_STATE_BYTES], st, MODE_STATE_BYTES);
+		for (int k = 0; k < NPART; k++) {
+			uint8_t col[2][NDEPTH];
+			for (int comp = 0; comp < 2; comp++)
+				for (int d = 0; d < NDEPTH; d++) col[comp][d] = st[(comp * NDEPTH + d) * NPART + k];
+			sched_chain_step(col, &c.outtok[(size_t)n * MODE_STATE_BYTES], k);
+			for (int comp = 0; comp < 2; comp++)
+				for (int d = 0; d < NDEPTH; d++) st[(comp * NDEPTH + d) * NPART + k] = col[comp][d];
+		}
+		c.intra_before[n] = ib;
+		ib += c.ctus[n].intra_parts;
+	}
+	memcpy(c.chain_end, st, MODE_STATE_BYTES);
+	const int uses_ratio = c.f.slice_type != SLICE_I && !c.f.is_scene_change;
+	int bad = 0;
+	for (int n = 0; n < s.nctu; n++) {
+		c.valid[n] = (uint8_t)sched_guesses_hold(g, c.ctus[n], c.f, &c.truth[(size_t)n * MODE_STATE_BYTES], &c.guess[(size_t)n * MODE_STATE_BYTES], c.intra_before[n],
+							 (uint32_t)n * NPART, c.used_intra[n], uses_ratio);
+		bad += !c.valid[n];
+		if (getenv("HENC_SCHED_DEBUG2")) {
+			int dd[NDEPTH] = {0}, tok[NDEPTH] = {0};
+			for (int d = 0; d < NDEPTH; d++)
+				for (int k = 0; k < NPART; k++) {
+					dd[d] += c.truth[(size_t)n * MODE_STATE_BYTES + d * NPART + k] != c.guess[(size_t)n * MODE_STATE_BYTES + d * NPART + k];
+					tok[d] += (c.outtok[(size_t)n * MODE_STATE_BYTES + d * NPART + k] & MODE_TOKEN) != 0;
+				}
+			fprintf(stderr, "  ctu %3d %s guess!=truth by depth: %3d %3d %3d %3d %3d   untouched: %3d %3d %3d %3d %3d  searches %d\n", n, c.valid[n] ? "ok " : "BAD", dd[0], dd[1], dd[2], dd[3], dd[4],
+				tok[0], tok[1], tok[2], tok[3], tok[4], c.ctus[n].n_spec_reads);
+		}
+		if (getenv("HENC_SCHED_DEBUG") && !c.valid[n])
+			fprintf(stderr, "  ctu %d invalid: modes %s (%d looked at), ratio used %u true %u of %u (%d comparisons)\n", n,
+				sched_guesses_hold(g, c.ctus[n], c.f, &c.truth[(size_t)n * MODE_STATE_BYTES], &c.guess[(size_t)n * MODE_STATE_BYTES], 0, 0, 0, 0) ? "ok" : "WRONG",
+				c.ctus[n].n_spec_reads, c.used_intra[n], c.intra_before[n], n * NPART, c.ctus[n].n_ratio_cmp);
+	}
+	*n_invalid = bad;
+	if (getenv("HENC_SCHED_DEBUG")) {
+		fprintf(stderr, " verify: %d invalid; causes: replay %d winner %d bits-flip %d ratio-flip %d intra-bits %d\n", bad, henc_sched_causes[0], henc_sched_causes[1],
+			henc_sched_causes[2], henc_sched_causes[3], henc_sched_causes[4]);
+		memset(henc_sched_causes, 0, sizeof henc_sched_causes);
+	}
+}
+
+void sched_pass(Cpu &c, Enc &e, int pass)
+{
+	const Seq &s = c.seq;
+	const int W = s.wctu, H = s.hctu;
+	CpuGrp g;
+	for (int t = 0; t < W + 2 * (H - 1); t++)
+		for (int r = 0; r < H; r++) {
+			const int col = t - 2 * r;
+			if (col < 0 || col >= W) continue;
+			const int n = r * W + col;
+			if (pass > 0 && c.valid[n] && !c.dirty[n]) continue;
+			e.w = c.row_w[r];
+			uint8_t *gs = &c.guess[(size_t)n * MODE_STATE_BYTES];
+			if (pass > 0) {
+				c.ctus[n] = c.ctus_start[n];
+				memcpy(gs, &c.truth[(size_t)n * MODE_STATE_BYTES], MODE_STATE_BYTES);
+				c.used_intra[n] = c.intra_before[n];
+			} else {
+				if (n == 0) memcpy(gs, c.chain_start, MODE_STATE_BYTES);
+				c.used_intra[n] = sched_known_intra(c.prefix.data(), W, r, col, c.prefix[(size_t)r * (W + 1) + col]);
+			}
+			const uint64_t old_hash = c.hash[n];
+			memcpy(e.w->mode_in, gs, MODE_STATE_BYTES);
+			e.coeff = c.coeff.data() + (size_t)n * 6144;
+			e.total_intra_partitions = c.used_intra[n];
+			e.total_partitions = (uint32_t)n * NPART;
+			encode_ctu(g, e, n);
+			c.stat_encodes++;
+			memcpy(&c.outtok[(size_t)n * MODE_STATE_BYTES], e.w->intra_mode_buffs, MODE_STATE_BYTES);
+			c.hash[n] = sched_output_hash(g, s, c.f, c.ctus[n]);
+			c.dirty[n] = 0;
+			if (pass == 0) {
+				// the guesses further on: what this worker's buffers would hold if its own guesses were right
+				uint8_t res[MODE_STATE_BYTES];
+				for (int i = 0; i < MODE_STATE_BYTES; i++) {
+					const uint8_t v = (&e.w->intra_mode_buffs[0][0][0])[i];
+					res[i] = (v & MODE_TOKEN) ? gs[(i / (NDEPTH * NPART)) * NDEPTH * NPART + (v & 7) * NPART + i % NPART] : v;
+				}
+				if (col + 1 < W) memcpy(gs + MODE_STATE_BYTES, res, MODE_STATE_BYTES);
+				if (c.row_guess == 1 && r + 1 < H && col == (W > 1 ? 1 : 0)) memcpy(&c.guess[(size_t)(r + 1) * W * MODE_STATE_BYTES], res, MODE_STATE_BYTES);
+				c.prefix[(size_t)r * (W + 1) + col + 1] = c.prefix[(size_t)r * (W + 1) + col] + c.ctus[n].intra_parts;
+			} else if (c.hash[n] != old_hash) {
+				if (col + 1 < W) c.dirty[n + 1] = 1;
+				if (r + 1 < H) {
+					if (col > 0) c.dirty[n + W - 1] = 1;
+					c.dirty[n + W] = 1;
+					if (col + 1 < W) c.dirty[n + W + 1] = 1;
+				}
+			}
+		}
+}
+
+void frame_ctus_sched(Cpu &c, Enc &e)
+{
+	const Seq &s = c.seq;
+	const size_t nb = (size_t)s.nctu * MODE_STATE_BYTES;
+	if (c.guess.size() != nb) {
+		c.guess.assign(nb, 0); c.truth.assign(nb, 0); c.outtok.assign(nb, 0);
+		c.valid.assign(s.nctu, 0); c.dirty.assign(s.nctu, 0);
+		c.intra_before.assign(s.nctu, 0); c.used_intra.assign(s.nctu, 0); c.hash.assign(s.nctu, 0);
+		c.prefix.assign((size_t)s.hctu * (s.wctu + 1), 0);
+	}
+	while ((int)c.row_w.size() < s.hctu) c.row_w.push_back((Work *)calloc(1, sizeof(Work)));
+	c.ctus_start = c.ctus;
+	std::fill(c.prefix.begin(), c.prefix.end(), 0);
+	if (c.row_guess == 0)   // row starts: what the previous frame found there
+		for (int r = 1; r < s.hctu; r++) memcpy(&c.guess[(size_t)r * s.wctu * MODE_STATE_BYTES], &c.truth[(size_t)r * s.wctu * MODE_STATE_BYTES], MODE_STATE_BYTES);
+	int bad = 0;
+	for (int pass = 0;; pass++) {
+		sched_pass(c, e, pass);
+		sched_verify(c, &bad);
+		c.stat_passes++;
+		if (pass == 0) c.stat_invalid_first += bad;
+		if (!bad) break;
+		if (pass > s.nctu + 2) { fprintf(stderr, "frame_ctus_sched: no convergence\n"); abort(); }
+	}
+	CpuGrp g;
+	for (int n = 0; n < s.nctu; n++) {
+		Work *w = c.row_w[0];
+		memcpy(w->mode_in, &c.truth[(size_t)n * MODE_STATE_BYTES], MODE_STATE_BYTES);
+		resolve_mode_tokens(g, *w, c.ctus[n]);
+		record_from_outputs(c, n, n + 1 < s.nctu ? &c.truth[(size_t)(n + 1) * MODE_STATE_BYTES] : c.chain_end);
+		c.acc_dist += c.ctus[n].distortion;
+	}
+	memcpy(c.chain_start, c.chain_end, MODE_STATE_BYTES);
+}
+
 }  // namespace
 
 extern "C" {
@@ -140,6 +320,18 @@ void henc_cpu_destroy(void *h)
 	Cpu *c = (Cpu *)h;
 	free(c->w);
 	delete c;
+}
+
+void henc_cpu_set_sched(void *h, int sched, int row_guess)
+{
+	((Cpu *)h)->sched = sched;
+	((Cpu *)h)->row_guess = row_guess;
+}
+void henc_cpu_sched_stats(void *h, int *out3, int reset)
+{
+	Cpu &c = *(Cpu *)h;
+	out3[0] = c.stat_passes; out3[1] = c.stat_encodes; out3[2] = c.stat_invalid_first;
+	if (reset) c.stat_passes = c.stat_encodes = c.stat_invalid_first = 0;
 }
 
 void henc_cpu_set_sao_trace(const char *path)
@@ -194,11 +386,24 @@ int henc_cpu_frame_ctus(void *h, const uint8_t *y, const uint8_t *u, const uint8
 	e.w = c.w;
 	CpuGrp g;
 	if (last_ctu < 0 || last_ctu > s.nctu) last_ctu = s.nctu;
+	if (c.sched) {
+		if (first_ctu != 0 || last_ctu != s.nctu) return -1;
+		frame_ctus_sched(c, e);
+		first_ctu = last_ctu;
+	}
 	for (int n = first_ctu; n < last_ctu; n++) {
 		e.coeff = c.coeff.data() + (size_t)n * 6144;
 		e.total_intra_partitions = c.intra_parts;
 		e.total_partitions = c.total_parts;
+		memcpy(c.w->mode_in, c.w->intra_mode_buffs, MODE_STATE_BYTES);   // one worker in raster order: what the buffers hold IS the inherited state
+		if (getenv("HENC_WIPE_WORK")) {   // experiment: nothing but the mode chain may carry over from CTU to CTU
+			uint8_t keep[MODE_STATE_BYTES];
+			memcpy(keep, c.w->mode_in, MODE_STATE_BYTES);
+			memset(c.w, atoi(getenv("HENC_WIPE_WORK")), sizeof(Work));
+			memcpy(c.w->mode_in, keep, MODE_STATE_BYTES);
+		}
 		encode_ctu(g, e, n);
+		resolve_mode_tokens(g, *c.w, c.ctus[n]);
 		c.intra_parts += c.ctus[n].intra_parts;
 		c.total_parts += NPART;
 		c.acc_dist += c.ctus[n].distortion;
@@ -265,7 +470,9 @@ int henc_cpu_frame_ctus_wavefront(void *h, const uint8_t *y, const uint8_t *u, c
 			e.coeff = c.coeff.data() + (size_t)n * 6144;
 			e.total_intra_partitions = intra_prefix[n];
 			e.total_partitions = (uint32_t)n * NPART;
+			memcpy(e.w->mode_in, e.w->intra_mode_buffs, MODE_STATE_BYTES);
 			encode_ctu(g, e, n);
+			resolve_mode_tokens(g, *e.w, c.ctus[n]);
 			c.acc_dist += c.ctus[n].distortion;
 			if (col == 1 || s.wctu == 1) memcpy(snap[r].data(), e.w->intra_mode_buffs, 2560);
 			Work *keep = c.w;

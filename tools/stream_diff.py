@@ -37,7 +37,7 @@ def split_nals(b):
     return out
 
 
-def encode_cpu(width, height, frames, keys, force_intra=False):
+def encode_cpu(width, height, frames, keys, force_intra=False, sched=0, row_guess=0):
     lib = C.CDLL(os.path.join(ROOT, "oracle", "libenc_cpu.so"))
     lib.henc_cpu_create.restype = C.c_void_p
     lib.henc_cpu_create.argtypes = [C.POINTER(ec.EncCfg)]
@@ -46,6 +46,9 @@ def encode_cpu(width, height, frames, keys, force_intra=False):
     cfg = ec.default_cfg(width, height, **keys)
     h = lib.henc_cpu_create(C.byref(cfg))
     assert h
+    lib.henc_cpu_set_sched.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.henc_cpu_set_sched(h, sched, row_guess)
+    lib.henc_cpu_sched_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
     buf = C.create_string_buffer(8 << 20)
     rec = C.create_string_buffer(width * height * 3 // 2)
     streams, recons = [], []
@@ -53,6 +56,10 @@ def encode_cpu(width, height, frames, keys, force_intra=False):
         n = lib.henc_cpu_encode_frame(h, *planes, 3 if force_intra else 0, buf, len(buf), rec)
         assert n > 0
         streams.append(buf.raw[:n])
+        if sched:
+            st = (C.c_int * 3)()
+            lib.henc_cpu_sched_stats(h, st, 1)
+            print(f"  schedule: {st[0]} passes, {st[1]} CTU encodes, {st[2]} CTUs failed the first check")
         recons.append(rec.raw)
     return streams, recons
 
@@ -63,6 +70,8 @@ def main():
     ap.add_argument("--height", type=int, default=240)
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--force-intra", action="store_true")
+    ap.add_argument("--sched", type=int, default=0, help="1 = the device's row-parallel schedule (guesses + verification), emulated")
+    ap.add_argument("--row-guess", type=int, default=0)
     ap.add_argument("keys", nargs="*")
     a = ap.parse_args()
     keys = dict(k.split("=") for k in a.keys)
@@ -74,7 +83,7 @@ def main():
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
         ref_stream = open(os.path.join(tmp, "out.265"), "rb").read()
         ref_rec = open(os.path.join(tmp, "rec.yuv"), "rb").read()
-    streams, recons = encode_cpu(a.width, a.height, a.frames, keys, a.force_intra)
+    streams, recons = encode_cpu(a.width, a.height, a.frames, keys, a.force_intra, a.sched, a.row_guess)
     mine = b"".join(streams)
     fsz = a.width * a.height * 3 // 2
     ok = True
