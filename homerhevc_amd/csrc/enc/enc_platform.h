@@ -13,7 +13,7 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define HENC_HD __device__
-#define HENC_INLINE __device__ __forceinline__
+#define HENC_INLINE __host__ __device__ __forceinline__   // the small helpers are also used by the host entropy stage
 #else
 #define HENC_HD
 #define HENC_INLINE inline

@@ -66,13 +66,13 @@ HENC_INLINE int sched_replay_search(const SearchLog &lg, const uint8_t *true_in,
 //   * every comparison must keep its outcome under the true ratio, and where intra wins, the cost it leaves behind.
 template <class G>
 HENC_HD int sched_guesses_hold(const G &g, const CtuInfo &c, const FrameCtx &f, const uint8_t *true_in, const uint8_t *used_in, uint32_t intra_before,
-			       uint32_t parts_before, uint32_t used_intra, int uses_ratio)
+			       uint32_t parts_before, uint32_t used_intra, uint32_t used_parts, int uses_ratio)
 {
 	int bad = 0;
 	if (c.n_spec_reads > MAX_SEARCH_LOGS || c.n_ratio_cmp > MAX_RATIO_CMP) {
 		// log overflow: everything the CTU was given has to be right
 		for (int i = g.tid; i < NDEPTH * NPART; i += g.n) bad |= true_in[i] != used_in[i];
-		if (uses_ratio) bad |= intra_ratio(intra_before, parts_before) != intra_ratio(used_intra, parts_before);
+		if (uses_ratio) bad |= intra_ratio(intra_before, parts_before) != intra_ratio(used_intra, used_parts);
 		return !g.any(bad);
 	}
 	for (int i = g.tid; i < c.n_spec_reads; i += g.n) {
@@ -82,7 +82,7 @@ HENC_HD int sched_guesses_hold(const G &g, const CtuInfo &c, const FrameCtx &f, 
 		bad |= !sched_replay_search(lg, true_in, f.sqrt_lambda, &mg, &bg, &mt, &bt) || mg != mt || bg != bt;
 	}
 	if (uses_ratio) {
-		const double ratio = intra_ratio(intra_before, parts_before), used_ratio = intra_ratio(used_intra, parts_before);
+		const double ratio = intra_ratio(intra_before, parts_before), used_ratio = intra_ratio(used_intra, used_parts);
 		const double correction = calc_mv_correction((uint32_t)f.qp, f.avg_dist);
 		for (int i = g.tid; i < c.n_ratio_cmp; i += g.n) {
 			const double *lg = c.ratio_cmp + 4 * i;
@@ -133,16 +133,18 @@ HENC_HD uint64_t sched_output_hash(const G &g, const Seq &S, const FrameCtx &f, 
 	return ((uint64_t)h1 << 32) | h2;
 }
 
-// the intra-partition count the wavefront order guarantees to be known when CTU (row, col) starts: row - k has finished col + 2k CTUs
-// (prefix[r * (W + 1) + i] = intra partitions of the first i CTUs of row r, `run` = those of this row so far)
-HENC_INLINE uint32_t sched_known_intra(const uint32_t *prefix, int W, int row, int col, uint32_t run)
+// the intra statistics the wavefront order guarantees to be known when CTU (row, col) starts: row - k has finished col + 2k CTUs
+// (prefix[r * (W + 1) + i] = intra partitions of the first i CTUs of row r).  The first guess of the ratio is the share among those.
+HENC_INLINE void sched_known_intra(const uint32_t *prefix, int W, int row, int col, uint32_t *intra, uint32_t *parts)
 {
-	uint32_t ti = run;
+	uint32_t ti = prefix[(size_t)row * (W + 1) + col], tp = (uint32_t)col;
 	for (int k = 1; k <= row; k++) {
 		const int have = col + 2 * k < W ? col + 2 * k : W;
 		ti += prefix[(size_t)(row - k) * (W + 1) + have];
+		tp += (uint32_t)have;
 	}
-	return ti;
+	*intra = ti;
+	*parts = tp * NPART;
 }
 
 }  // namespace henc

@@ -1,15 +1,25 @@
 // Frame encoder on the device (include/homer_gpu.h section 12).
 //
-// k_encode_ctus is ONE persistent launch per frame that walks the picture the way the reference's WPP threads do
-// (wfpp_encoder_thread, hmr_encoder_lib.c:2849-2975): workgroup r = one wavefront = the worker of CTU row r; it encodes its row
-// left to right and may start CTU (r, c) once row r-1 has finished CTU c+1 (:2885-2898, two CTUs of lag).  Rows publish their
-// progress with release stores at agent scope and wait with acquire loads, so a row sees the reconstruction, side-info and
-// counters of the rows above it.  The decision code is enc/enc_ctu.h, instantiated for the 64-lane group.
+// k_encode_ctus is a persistent launch that walks the picture the way the reference's WPP threads do (wfpp_encoder_thread,
+// hmr_encoder_lib.c:2849-2975): workgroup r = one wavefront = the worker of CTU row r; it encodes its row left to right and may
+// start CTU (r, c) once row r-1 has finished CTU c+1 (:2885-2898, two CTUs of lag).  Rows publish their progress with release
+// stores at agent scope and wait with acquire loads, so a row sees the reconstruction and side-info of the rows above it.
+// The decision code is enc/enc_ctu.h, instantiated for the 64-lane group.
+//
+// The output has to be what the reference produces with ONE thread in raster order (the deterministic configuration), and two
+// inputs of a CTU depend on every CTU before it in that order; enc/enc_sched.h explains the guess / verify / re-encode scheme.
+// On the device it is: k_encode_ctus (pass 0: all CTUs; later passes: only the CTUs marked wrong or whose neighbours changed),
+// k_sched_scan (the true chains, one thread per 4x4 unit column), k_sched_check (one wavefront per CTU replays its logs against
+// the truth), repeated until nothing is wrong, then k_sched_finish.  The in-loop filters are the frame kernels of round 1
+// (k_deblock.hip, k_sao.hip, k_pad.hip); the entropy stage (enc/enc_entropy.h) is host code fed with the side-info, the levels
+// and the SAO statistics, and hands the SAO parameters back for the offset pass.
+#include <stddef.h>
 #include <vector>
 
 #include "common.h"
-#include "enc/enc_ctu.h"
+#include "enc/enc_sched.h"
 #include "enc/enc_host.h"
+#include "enc/enc_entropy.h"
 
 using namespace henc;
 
@@ -18,18 +28,31 @@ struct EncDev {
 	const FrameCtx *frame;
 	const DevTables *tables;
 	const Geo *geo;
-	CtuInfo *ctus;
-	Work *work;            // one per CTU row
+	CtuInfo *ctus, *ctus_start;   // the CTUs (persistent across frames) and their state when the frame started
+	Work *work;                   // one per CTU row
 	int16_t *coeff;
-	int *progress;         // [hctu] CTUs finished per row
-	uint32_t *intra_prefix;   // [hctu][wctu + 1] running count of intra partitions along each row
-	unsigned long long *prof; // [hctu][PF_COUNT] phase timers (profiling build)
+	int *progress;                // [hctu] CTUs passed per row in the running pass
+	uint32_t *prefix;             // [hctu][wctu + 1] running count of intra partitions along each row (first pass)
+	unsigned long long *prof;     // [hctu][PF_COUNT] phase timers (profiling build)
+	uint8_t *guess, *truth, *outtok;   // [nctu][MODE_STATE_BYTES]: mode state a CTU was given / should have been given / left behind (tokens)
+	uint8_t *chain_start, *chain_end;  // [MODE_STATE_BYTES] the single thread's mode buffers before the first / after the last CTU
+	int *valid, *dirty;           // [nctu]
+	unsigned long long *hash;     // [nctu] digest of what other CTUs can see of a CTU
+	uint32_t *intra_before, *used_intra, *used_parts;   // [nctu] true intra count before the CTU; the counters it was given
+	int *counters;                // [0] CTUs found wrong by the last check, [1] CTU encodes of the frame
 };
 
-__global__ __launch_bounds__(64) void k_encode_ctus(EncDev d)
+__device__ __forceinline__ void wave_copy_words(void *dst, const void *src, int bytes, int tid)
+{
+	uint32_t *d = (uint32_t *)dst;
+	const uint32_t *s = (const uint32_t *)src;
+	for (int i = tid; i < bytes / 4; i += 64) d[i] = s[i];
+}
+
+__global__ __launch_bounds__(64) void k_encode_ctus(EncDev d, int pass)
 {
 	const Seq &S = *d.seq;
-	const int row = blockIdx.x, W = S.wctu;
+	const int row = blockIdx.x, W = S.wctu, H = S.hctu;
 	WaveGrp g{(int)threadIdx.x};
 	Enc e;
 	e.seq = d.seq;
@@ -40,9 +63,9 @@ __global__ __launch_bounds__(64) void k_encode_ctus(EncDev d)
 	e.ctu = nullptr;
 	e.w = d.work + row;
 	e.prof = d.prof ? d.prof + (size_t)row * PF_COUNT : nullptr;
-	uint32_t *my_prefix = d.intra_prefix + (size_t)row * (W + 1);
-	uint32_t run = 0;
-	if (g.tid == 0) my_prefix[0] = 0;
+	uint32_t *my_prefix = d.prefix + (size_t)row * (W + 1);
+	if (pass == 0 && g.tid == 0) my_prefix[0] = 0;
+	int encodes = 0;
 	for (int c = 0; c < W; c++) {
 		if (row > 0) {
 			HENC_PROF_T0();
@@ -50,26 +73,151 @@ __global__ __launch_bounds__(64) void k_encode_ctus(EncDev d)
 			while (__hip_atomic_load(&d.progress[row - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(16);
 			HENC_PROF_ADD(e, PF_WAIT);
 		}
-		HENC_PROF_T0();
-		// running intra statistics (hmr_motion_inter.c:3769-3776) from the CTUs the wavefront order guarantees to be finished:
-		// row r-k has completed at least c + 2k CTUs
-		uint32_t ti = run;
-		for (int k = 1; k <= row; k++) {
-			const int have = c + 2 * k < W ? c + 2 * k : W;
-			ti += d.intra_prefix[(size_t)(row - k) * (W + 1) + have];
-		}
-		e.total_intra_partitions = ti;
-		e.total_partitions = (uint32_t)(row * W + c) * NPART;
 		const int n = row * W + c;
-		e.coeff = d.coeff + (size_t)n * 6144;
-		encode_ctu(g, e, n);
-		HENC_PROF_ADD(e, PF_TOTAL);
-		run += d.ctus[n].intra_parts;
-		if (g.tid == 0) my_prefix[c + 1] = run;
+		const int redo = pass == 0 || !__hip_atomic_load(&d.valid[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+				 __hip_atomic_load(&d.dirty[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (redo) {
+			HENC_PROF_T0();
+			uint8_t *gs = d.guess + (size_t)n * MODE_STATE_BYTES;
+			uint32_t ui, up;
+			if (pass > 0) {
+				// start again from what the CTU looked like when the frame started, with the inputs the last check derived
+				wave_copy_words(&d.ctus[n], &d.ctus_start[n], (int)offsetof(CtuInfo, n_spec_reads), g.tid);
+				wave_copy_words(d.ctus[n].nodes, d.ctus_start[n].nodes, (int)sizeof(d.ctus[n].nodes), g.tid);
+				wave_copy_words(gs, d.truth + (size_t)n * MODE_STATE_BYTES, MODE_STATE_BYTES, g.tid);
+				ui = d.intra_before[n];
+				up = (uint32_t)n * NPART;
+			} else {
+				if (n == 0) wave_copy_words(gs, d.chain_start, MODE_STATE_BYTES, g.tid);
+				sched_known_intra(d.prefix, W, row, c, &ui, &up);
+			}
+			__syncthreads();
+			wave_copy_words(e.w->mode_in, gs, MODE_STATE_BYTES, g.tid);
+			if (g.tid == 0) { d.used_intra[n] = ui; d.used_parts[n] = up; }
+			const unsigned long long old_hash = d.hash[n];
+			e.total_intra_partitions = ui;
+			e.total_partitions = up;
+			e.coeff = d.coeff + (size_t)n * 6144;
+			__syncthreads();
+			encode_ctu(g, e, n);
+			encodes++;
+			wave_copy_words(d.outtok + (size_t)n * MODE_STATE_BYTES, e.w->intra_mode_buffs, MODE_STATE_BYTES, g.tid);
+			const unsigned long long h = sched_output_hash(g, S, *d.frame, d.ctus[n]);
+			if (g.tid == 0) { d.hash[n] = h; d.dirty[n] = 0; }
+			if (pass == 0) {
+				// the guesses further on: what this worker's buffers would hold if its own guesses were right
+				const int snap = row + 1 < H && c == (W > 1 ? 1 : 0);
+				if (c + 1 < W || snap) {
+					const uint8_t *tok = &e.w->intra_mode_buffs[0][0][0];
+					uint8_t *nx = gs + MODE_STATE_BYTES, *rs = d.guess + (size_t)(row + 1) * W * MODE_STATE_BYTES;
+					for (int i = g.tid; i < MODE_STATE_BYTES; i += 64) {
+						const uint8_t v = tok[i];
+						const uint8_t r = (v & MODE_TOKEN) ? gs[(i / (NDEPTH * NPART)) * NDEPTH * NPART + (v & 7) * NPART + i % NPART] : v;
+						if (c + 1 < W) nx[i] = r;
+						if (snap) rs[i] = r;
+					}
+				}
+				if (g.tid == 0) my_prefix[c + 1] = my_prefix[c] + d.ctus[n].intra_parts;
+			} else if (h != old_hash && g.tid == 0) {
+				if (c + 1 < W) d.dirty[n + 1] = 1;
+				if (row + 1 < H) {
+					if (c > 0) d.dirty[n + W - 1] = 1;
+					d.dirty[n + W] = 1;
+					if (c + 1 < W) d.dirty[n + W + 1] = 1;
+				}
+			}
+			HENC_PROF_ADD(e, PF_TOTAL);
+		}
 		__syncthreads();
 		if (g.tid == 0) __hip_atomic_store(&d.progress[row], c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 	}
+	if (g.tid == 0 && encodes) atomicAdd(&d.counters[1], encodes);
 }
+
+// the true chains in raster order: threads 0..255 one unit column of the mode buffers each, thread 256 the intra counter
+__global__ __launch_bounds__(320) void k_sched_scan(EncDev d)
+{
+	const int nctu = d.seq->nctu, k = threadIdx.x;
+	if (k < NPART) {
+		uint8_t st[2][NDEPTH];
+		for (int comp = 0; comp < 2; comp++)
+			for (int dd = 0; dd < NDEPTH; dd++) st[comp][dd] = d.chain_start[(comp * NDEPTH + dd) * NPART + k];
+		for (int n = 0; n < nctu; n++) {
+			uint8_t *t = d.truth + (size_t)n * MODE_STATE_BYTES;
+			for (int comp = 0; comp < 2; comp++)
+				for (int dd = 0; dd < NDEPTH; dd++) t[(comp * NDEPTH + dd) * NPART + k] = st[comp][dd];
+			sched_chain_step(st, d.outtok + (size_t)n * MODE_STATE_BYTES, k);
+		}
+		for (int comp = 0; comp < 2; comp++)
+			for (int dd = 0; dd < NDEPTH; dd++) d.chain_end[(comp * NDEPTH + dd) * NPART + k] = st[comp][dd];
+	} else if (k == NPART) {
+		uint32_t ib = 0;
+		for (int n = 0; n < nctu; n++) {
+			d.intra_before[n] = ib;
+			ib += d.ctus[n].intra_parts;
+		}
+		d.counters[0] = 0;
+	}
+}
+
+__global__ __launch_bounds__(64) void k_sched_check(EncDev d)
+{
+	const int n = blockIdx.x;
+	WaveGrp g{(int)threadIdx.x};
+	const FrameCtx &f = *d.frame;
+	const int uses_ratio = f.slice_type != SLICE_I && !f.is_scene_change;
+	const int ok = sched_guesses_hold(g, d.ctus[n], f, d.truth + (size_t)n * MODE_STATE_BYTES, d.guess + (size_t)n * MODE_STATE_BYTES, d.intra_before[n], (uint32_t)n * NPART,
+					  d.used_intra[n], d.used_parts[n], uses_ratio);
+	if (g.tid == 0) {
+		d.valid[n] = ok;
+		if (!ok) atomicAdd(&d.counters[0], 1);
+	}
+}
+
+// the frame has converged: tokens left in the CTUs' mode arrays become the values they stand for, the chain moves on
+__global__ __launch_bounds__(64) void k_sched_finish(EncDev d)
+{
+	const int n = blockIdx.x, tid = threadIdx.x;
+	CtuInfo &c = d.ctus[n];
+	const uint8_t *t = d.truth + (size_t)n * MODE_STATE_BYTES;
+	for (int i = tid; i < 2 * NPART; i += 64) {
+		uint8_t &v = (&c.intra_mode[0][0])[i];
+		if (v & MODE_TOKEN) v = t[((i / NPART) * NDEPTH + (v & 7)) * NPART + i % NPART];
+	}
+}
+
+// side-info of the CTUs (z-order per CTU) -> the raster unit arrays the frame filters read (hmr_gpu_units, homer_gpu.h section 4)
+__global__ __launch_bounds__(256) void k_units_from_ctuinfo(const CtuInfo *ctus, const Geo *geo, int wctu, int units_stride, int16_t *mvx, int16_t *mvy, int8_t *ref, uint8_t *qp,
+							      uint8_t *flags, uint8_t *pred_depth, uint8_t *tr_idx)
+{
+	const int n = blockIdx.x, a = threadIdx.x;
+	const CtuInfo &c = ctus[n];
+	const int r = geo[NNODES - NPART + a].raster_index;   // the 256 depth-4 nodes are the units in z-order
+	const size_t o = (size_t)((n / wctu) * 16 + r / 16) * units_stride + (n % wctu) * 16 + r % 16;
+	mvx[o] = (int16_t)c.mv_ref[a].x;
+	mvy[o] = (int16_t)c.mv_ref[a].y;
+	ref[o] = c.mv_ref_idx[a];
+	qp[o] = c.qp[a];
+	flags[o] = (uint8_t)((c.pred_mode[a] == PM_INTRA ? HMR_GPU_UNIT_INTRA : 0) | (((c.cbf[0][a] >> c.tr_idx[a]) & 1) ? HMR_GPU_UNIT_CBF_Y : 0));
+	pred_depth[o] = c.pred_depth[a];
+	tr_idx[o] = c.tr_idx[a];
+}
+
+// host 8-bit planes -> int16 device planes (sse_copy_8_16 at frame entry, hmr_encoder_lib.c:295-305)
+__global__ void k_widen_plane(const uint8_t *src, int w, int h, int16_t *dst, int stride)
+{
+	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+	if (x < w && y < h) dst[(size_t)y * stride + x] = src[(size_t)y * w + x];
+}
+__global__ void k_narrow_plane(const int16_t *src, int stride, int w, int h, uint8_t *dst)
+{
+	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+	if (x < w && y < h) dst[(size_t)y * w + x] = (uint8_t)src[(size_t)y * stride + x];
+}
+
+struct SrcSlot {
+	int16_t *p[3];
+};
 
 struct hmr_gpu_enc {
 	hmr_gpu_ctx *ctx;
@@ -81,11 +229,25 @@ struct hmr_gpu_enc {
 	Seq *d_seq;
 	FrameCtx *d_frame;
 	Geo *d_geo;
-	int16_t *d_src[3], *d_pic[2][3];
+	std::vector<Geo> geo;
+	std::vector<SrcSlot> src;
+	int16_t *d_pic[2][3], *d_pre[3];
 	size_t src_elems[3], pic_elems[3];
+	uint8_t *d_bytes;              // staging for 8-bit planes (one 4:2:0 picture)
+	// raster unit arrays of the filters, SAO statistics and parameters
+	int units_stride, units_rows;
+	int16_t *d_mvx, *d_mvy;
+	int8_t *d_ref;
+	uint8_t *d_qp, *d_flags, *d_pd, *d_ti;
+	int32_t *d_stats, *d_params;
+	// host side of the entropy stage
+	std::vector<uint8_t> h_public;
+	std::vector<int16_t> h_coeff;
+	std::vector<int32_t> h_stats, h_params;
+	EntropyState es;
 	int cur;
-	float last_ms;
-	std::vector<int16_t> stage;
+	float last_ms, last_total_ms;
+	int last_passes, last_encodes;
 };
 
 namespace {
@@ -97,6 +259,90 @@ int16_t *plane0(hmr_gpu_enc *e, int which, int comp)
 	const int st = comp ? s.stride_c : s.stride_y, m = comp ? s.margin_c : s.margin_y;
 	return e->d_pic[which][comp] + (size_t)m * st + m;
 }
+
+template <class T>
+int dev_alloc(T **p, size_t n, bool zero = true)
+{
+	HIP_TRY(hipMalloc((void **)p, n * sizeof(T)));
+	if (zero) HIP_TRY(hipMemset(*p, 0, n * sizeof(T)));
+	return HMR_GPU_OK;
+}
+#define DEV_ALLOC(p, n)                           \
+	do {                                      \
+		const int rc_ = dev_alloc(&(p), (n)); \
+		if (rc_) return rc_;              \
+	} while (0)
+
+int load_planes(hmr_gpu_enc *e, const uint8_t *y, const uint8_t *u, const uint8_t *v, int16_t *const dst[3], int stride_y, int stride_c)
+{
+	const Seq &s = e->seq;
+	hipStream_t st = e->ctx->stream;
+	const uint8_t *in[3] = {y, u, v};
+	for (int c = 0; c < 3; c++) {
+		const int w = c ? s.width / 2 : s.width, h = c ? s.height / 2 : s.height;
+		HIP_TRY(hipMemcpyAsync(e->d_bytes, in[c], (size_t)w * h, hipMemcpyHostToDevice, st));
+		hipLaunchKernelGGL(k_widen_plane, dim3((w + 255) / 256, h), dim3(256), 0, st, e->d_bytes, w, h, dst[c], c ? stride_c : stride_y);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(st));   // d_bytes is reused by the next plane
+	}
+	return HMR_GPU_OK;
+}
+
+// the CTU decisions of the frame set up in e->f / e->d_frame: passes until the check finds nothing wrong
+int run_ctu_passes(hmr_gpu_enc *e)
+{
+	const Seq &s = e->seq;
+	hipStream_t st = e->ctx->stream;
+	HIP_TRY(hipMemcpyAsync(e->d.ctus_start, e->d.ctus, sizeof(CtuInfo) * s.nctu, hipMemcpyDeviceToDevice, st));
+	HIP_TRY(hipMemsetAsync(e->d.counters, 0, sizeof(int) * 2, st));
+	HIP_TRY(hipEventRecord(e->ctx->ev0, st));
+	int pass = 0;
+	for (;; pass++) {
+		HIP_TRY(hipMemsetAsync(e->d.progress, 0, sizeof(int) * s.hctu, st));
+		hipLaunchKernelGGL(k_encode_ctus, dim3(s.hctu), dim3(64), 0, st, e->d, pass);
+		hipLaunchKernelGGL(k_sched_scan, dim3(1), dim3(320), 0, st, e->d);
+		hipLaunchKernelGGL(k_sched_check, dim3(s.nctu), dim3(64), 0, st, e->d);
+		HIP_TRY(hipGetLastError());
+		int counters[2];
+		HIP_TRY(hipMemcpyAsync(counters, e->d.counters, sizeof counters, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		e->last_encodes = counters[1];
+		if (counters[0] == 0) break;
+		if (pass > s.nctu + 2) {
+			hmr_set_error("hmr_gpu_enc: the CTU schedule did not converge");
+			return HMR_GPU_ERR_HIP;
+		}
+	}
+	hipLaunchKernelGGL(k_sched_finish, dim3(s.nctu), dim3(64), 0, st, e->d);
+	HIP_TRY(hipMemcpyAsync(e->d.chain_start, e->d.chain_end, MODE_STATE_BYTES, hipMemcpyDeviceToDevice, st));
+	HIP_TRY(hipEventRecord(e->ctx->ev1, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ctx->ev0, e->ctx->ev1));
+	e->last_passes = pass + 1;
+	return HMR_GPU_OK;
+}
+
+int set_frame(hmr_gpu_enc *e, int slot, int image_type, double avg_dist)
+{
+	const Seq &s = e->seq;
+	e->cur ^= 1;
+	begin_frame(s, e->st, image_type, e->f);
+	if (avg_dist >= 0) e->f.avg_dist = avg_dist;
+	for (int c = 0; c < 3; c++) {
+		e->f.src[c] = e->src[slot].p[c];
+		e->f.ref[c] = plane0(e, e->cur ^ 1, c);
+		e->f.rec[c] = plane0(e, e->cur, c);
+	}
+	HIP_TRY(hipMemcpyAsync(e->d_frame, &e->f, sizeof(FrameCtx), hipMemcpyHostToDevice, e->ctx->stream));
+	return HMR_GPU_OK;
+}
+
+int download_public(hmr_gpu_enc *e)
+{
+	const Seq &s = e->seq;
+	HIP_TRY(hipMemcpy2DAsync(e->h_public.data(), sizeof(CtuPublic), e->d.ctus, sizeof(CtuInfo), sizeof(CtuPublic), s.nctu, hipMemcpyDeviceToHost, e->ctx->stream));
+	return HMR_GPU_OK;
+}
 }  // namespace
 
 extern "C" int hmr_gpu_enc_record_bytes(void) { return REC_BYTES; }
@@ -105,6 +351,7 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 {
 	if (!ctx || !cfg || !out) return HMR_GPU_ERR_ARG;
 	static_assert(sizeof(hmr_gpu_enc_cfg) == sizeof(HostCfg), "configuration layouts must match");
+	static_assert(offsetof(CtuInfo, n_spec_reads) % 4 == 0 && sizeof(Node) % 4 == 0 && MODE_STATE_BYTES % 4 == 0, "word copies");
 	hmr_gpu_enc *e = new hmr_gpu_enc();
 	e->ctx = ctx;
 	memcpy(&e->cfg, cfg, sizeof(HostCfg));
@@ -116,43 +363,63 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 	}
 	const Seq &s = e->seq;
 	HIP_TRY(hipSetDevice(ctx->device));
-	std::vector<Geo> geo(NNODES);
-	make_geo(geo.data());
-	HIP_TRY(hipMalloc((void **)&e->d_seq, sizeof(Seq)));
+	e->geo.resize(NNODES);
+	make_geo(e->geo.data());
+	DEV_ALLOC(e->d_seq, 1);
 	HIP_TRY(hipMemcpy(e->d_seq, &s, sizeof(Seq), hipMemcpyHostToDevice));
-	HIP_TRY(hipMalloc((void **)&e->d_frame, sizeof(FrameCtx)));
-	HIP_TRY(hipMalloc((void **)&e->d_geo, sizeof(Geo) * NNODES));
-	HIP_TRY(hipMemcpy(e->d_geo, geo.data(), sizeof(Geo) * NNODES, hipMemcpyHostToDevice));
-	HIP_TRY(hipMalloc((void **)&e->d.ctus, sizeof(CtuInfo) * s.nctu));
+	DEV_ALLOC(e->d_frame, 1);
+	DEV_ALLOC(e->d_geo, NNODES);
+	HIP_TRY(hipMemcpy(e->d_geo, e->geo.data(), sizeof(Geo) * NNODES, hipMemcpyHostToDevice));
+	DEV_ALLOC(e->d.ctus, s.nctu);
+	DEV_ALLOC(e->d.ctus_start, s.nctu);
 	{
 		std::vector<CtuInfo> init(s.nctu);
-		memset(init.data(), 0, sizeof(CtuInfo) * s.nctu);
+		memset((void *)init.data(), 0, sizeof(CtuInfo) * s.nctu);
 		for (auto &c : init) memset(c.mv_ref_idx, -1, sizeof c.mv_ref_idx);
 		HIP_TRY(hipMemcpy(e->d.ctus, init.data(), sizeof(CtuInfo) * s.nctu, hipMemcpyHostToDevice));
 	}
-	HIP_TRY(hipMalloc((void **)&e->d.work, sizeof(Work) * s.hctu));
-	HIP_TRY(hipMemset(e->d.work, 0, sizeof(Work) * s.hctu));
-	HIP_TRY(hipMalloc((void **)&e->d.coeff, sizeof(int16_t) * 6144 * s.nctu));
-	HIP_TRY(hipMemset(e->d.coeff, 0, sizeof(int16_t) * 6144 * s.nctu));
-	HIP_TRY(hipMalloc((void **)&e->d.progress, sizeof(int) * s.hctu));
-	HIP_TRY(hipMalloc((void **)&e->d.intra_prefix, sizeof(uint32_t) * s.hctu * (s.wctu + 1)));
-	HIP_TRY(hipMalloc((void **)&e->d.prof, sizeof(unsigned long long) * s.hctu * PF_COUNT));
-	HIP_TRY(hipMemset(e->d.prof, 0, sizeof(unsigned long long) * s.hctu * PF_COUNT));
+	DEV_ALLOC(e->d.work, s.hctu);
+	DEV_ALLOC(e->d.coeff, (size_t)6144 * s.nctu);
+	DEV_ALLOC(e->d.progress, s.hctu);
+	DEV_ALLOC(e->d.prefix, (size_t)s.hctu * (s.wctu + 1));
+	DEV_ALLOC(e->d.prof, (size_t)s.hctu * PF_COUNT);
+	DEV_ALLOC(e->d.guess, (size_t)s.nctu * MODE_STATE_BYTES);
+	DEV_ALLOC(e->d.truth, (size_t)s.nctu * MODE_STATE_BYTES);
+	DEV_ALLOC(e->d.outtok, (size_t)s.nctu * MODE_STATE_BYTES);
+	DEV_ALLOC(e->d.chain_start, MODE_STATE_BYTES);
+	DEV_ALLOC(e->d.chain_end, MODE_STATE_BYTES);
+	DEV_ALLOC(e->d.valid, s.nctu);
+	DEV_ALLOC(e->d.dirty, s.nctu);
+	DEV_ALLOC(e->d.hash, s.nctu);
+	DEV_ALLOC(e->d.intra_before, s.nctu);
+	DEV_ALLOC(e->d.used_intra, s.nctu);
+	DEV_ALLOC(e->d.used_parts, s.nctu);
+	DEV_ALLOC(e->d.counters, 2);
 	for (int c = 0; c < 3; c++) {
 		e->src_elems[c] = (size_t)(c ? s.src_stride_c : s.src_stride_y) * (c ? s.height / 2 : s.height);
 		e->pic_elems[c] = (size_t)(c ? s.stride_c : s.stride_y) * ((c ? s.height / 2 : s.height) + 2 * (c ? s.margin_c : s.margin_y));
-		HIP_TRY(hipMalloc((void **)&e->d_src[c], e->src_elems[c] * 2));
-		for (int k = 0; k < 2; k++) {
-			HIP_TRY(hipMalloc((void **)&e->d_pic[k][c], e->pic_elems[c] * 2));
-			HIP_TRY(hipMemset(e->d_pic[k][c], 0, e->pic_elems[c] * 2));
-		}
+		for (int k = 0; k < 2; k++) DEV_ALLOC(e->d_pic[k][c], e->pic_elems[c]);
+		DEV_ALLOC(e->d_pre[c], e->pic_elems[c]);
 	}
+	DEV_ALLOC(e->d_bytes, (size_t)s.width * s.height * 3 / 2);
+	e->units_stride = s.wctu * 16;
+	e->units_rows = s.hctu * 16;
+	const size_t nu = (size_t)e->units_stride * e->units_rows;
+	DEV_ALLOC(e->d_mvx, nu); DEV_ALLOC(e->d_mvy, nu); DEV_ALLOC(e->d_ref, nu); DEV_ALLOC(e->d_qp, nu);
+	DEV_ALLOC(e->d_flags, nu); DEV_ALLOC(e->d_pd, nu); DEV_ALLOC(e->d_ti, nu);
+	DEV_ALLOC(e->d_stats, (size_t)s.nctu * 3 * 5 * 2 * 32);
+	DEV_ALLOC(e->d_params, (size_t)s.nctu * 3 * 34);
+	e->h_public.resize(sizeof(CtuPublic) * s.nctu);
+	e->h_coeff.resize((size_t)6144 * s.nctu);
+	e->h_stats.resize((size_t)s.nctu * 3 * 5 * 2 * 32);
+	e->h_params.resize((size_t)s.nctu * 3 * 34);
 	e->d.seq = e->d_seq;
 	e->d.frame = e->d_frame;
 	e->d.tables = ctx->tables;
 	e->d.geo = e->d_geo;
 	e->cur = 0;
-	e->last_ms = 0;
+	e->last_ms = e->last_total_ms = 0;
+	e->last_passes = e->last_encodes = 0;
 	*out = e;
 	return HMR_GPU_OK;
 }
@@ -162,19 +429,33 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	if (!e) return;
 	(void)hipSetDevice(e->ctx->device);
 	(void)hipStreamSynchronize(e->ctx->stream);
-	(void)hipFree(e->d_seq); (void)hipFree(e->d_frame); (void)hipFree(e->d_geo);
-	(void)hipFree(e->d.ctus); (void)hipFree(e->d.work); (void)hipFree(e->d.coeff); (void)hipFree(e->d.progress); (void)hipFree(e->d.intra_prefix);
+	void *p[] = {e->d_seq, e->d_frame, e->d_geo, e->d.ctus, e->d.ctus_start, e->d.work, e->d.coeff, e->d.progress, e->d.prefix, e->d.prof, e->d.guess, e->d.truth, e->d.outtok,
+		     e->d.chain_start, e->d.chain_end, e->d.valid, e->d.dirty, e->d.hash, e->d.intra_before, e->d.used_intra, e->d.used_parts, e->d.counters, e->d_bytes, e->d_mvx,
+		     e->d_mvy, e->d_ref, e->d_qp, e->d_flags, e->d_pd, e->d_ti, e->d_stats, e->d_params};
+	for (void *q : p) (void)hipFree(q);
 	for (int c = 0; c < 3; c++) {
-		(void)hipFree(e->d_src[c]);
 		(void)hipFree(e->d_pic[0][c]);
 		(void)hipFree(e->d_pic[1][c]);
+		(void)hipFree(e->d_pre[c]);
 	}
+	for (auto &sl : e->src)
+		for (int c = 0; c < 3; c++) (void)hipFree(sl.p[c]);
 	delete e;
 }
 
 extern "C" float hmr_gpu_enc_last_ctu_ms(hmr_gpu_enc *e) { return e ? e->last_ms : 0.f; }
 
-// profiling build (-DHENC_PROFILE): per-row phase timers in s_memtime ticks (100 MHz), [hctu][12]; all zero otherwise
+extern "C" int hmr_gpu_enc_last_stats(hmr_gpu_enc *e, int *passes, int *ctu_encodes, float *ctu_ms, float *frame_ms)
+{
+	if (!e) return HMR_GPU_ERR_ARG;
+	if (passes) *passes = e->last_passes;
+	if (ctu_encodes) *ctu_encodes = e->last_encodes;
+	if (ctu_ms) *ctu_ms = e->last_ms;
+	if (frame_ms) *frame_ms = e->last_total_ms;
+	return HMR_GPU_OK;
+}
+
+// profiling build (-DHENC_PROFILE): per-row phase timers in s_memtime ticks, [hctu][PF_COUNT]; all zero otherwise
 extern "C" int hmr_gpu_enc_profile(hmr_gpu_enc *e, unsigned long long *out, int reset)
 {
 	if (!e || !out) return HMR_GPU_ERR_ARG;
@@ -183,27 +464,16 @@ extern "C" int hmr_gpu_enc_profile(hmr_gpu_enc *e, unsigned long long *out, int 
 	return HMR_GPU_OK;
 }
 
-// host 8-bit plane -> device int16 plane (sse_copy_8_16 at frame entry, hmr_encoder_lib.c:295-305); pad > 0 also replicates the borders
-static int upload_plane(hmr_gpu_enc *e, const uint8_t *src, int w, int h, int16_t *dst_base, size_t elems, int stride, int margin)
+extern "C" int hmr_gpu_enc_load_source(hmr_gpu_enc *e, int slot, const uint8_t *y, const uint8_t *u, const uint8_t *v)
 {
-	e->stage.assign(elems, 0);
-	int16_t *p = e->stage.data() + (size_t)margin * stride + margin;
-	for (int y = 0; y < h; y++)
-		for (int x = 0; x < w; x++) p[(size_t)y * stride + x] = src[(size_t)y * w + x];
-	if (margin) {
-		for (int y = 0; y < h; y++)
-			for (int x = 1; x <= margin; x++) {
-				p[(size_t)y * stride - x] = p[(size_t)y * stride];
-				p[(size_t)y * stride + w - 1 + x] = p[(size_t)y * stride + w - 1];
-			}
-		for (int y = 1; y <= margin; y++) {
-			memcpy(p - (size_t)y * stride - margin, p - margin, sizeof(int16_t) * (w + 2 * margin));
-			memcpy(p + (size_t)(h - 1 + y) * stride - margin, p + (size_t)(h - 1) * stride - margin, sizeof(int16_t) * (w + 2 * margin));
-		}
+	if (!e || slot < 0 || slot > 4096 || !y || !u || !v) return HMR_GPU_ERR_ARG;
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	while ((int)e->src.size() <= slot) {
+		SrcSlot sl;
+		for (int c = 0; c < 3; c++) DEV_ALLOC(sl.p[c], e->src_elems[c]);
+		e->src.push_back(sl);
 	}
-	HIP_TRY(hipMemcpyAsync(dst_base, e->stage.data(), elems * 2, hipMemcpyHostToDevice, e->ctx->stream));
-	HIP_TRY(hipStreamSynchronize(e->ctx->stream));
-	return HMR_GPU_OK;
+	return load_planes(e, y, u, v, e->src[slot].p, e->seq.src_stride_y, e->seq.src_stride_c);
 }
 
 extern "C" int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *e, const uint8_t *y, const uint8_t *u, const uint8_t *v, int image_type, const uint8_t *ref_y, const uint8_t *ref_u,
@@ -213,39 +483,39 @@ extern "C" int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *e, const uint8_t *y, const ui
 	const Seq &s = e->seq;
 	hipStream_t st = e->ctx->stream;
 	HIP_TRY(hipSetDevice(e->ctx->device));
-	const uint8_t *in[3] = {y, u, v}, *rin[3] = {ref_y, ref_u, ref_v};
-	e->cur ^= 1;
-	begin_frame(s, e->st, image_type, e->f);
-	if (avg_dist >= 0) e->f.avg_dist = avg_dist;
-	for (int c = 0; c < 3; c++) {
-		const int w = c ? s.width / 2 : s.width, h = c ? s.height / 2 : s.height;
-		int rc = upload_plane(e, in[c], w, h, e->d_src[c], e->src_elems[c], c ? s.src_stride_c : s.src_stride_y, 0);
+	int rc = hmr_gpu_enc_load_source(e, 0, y, u, v);
+	if (rc) return rc;
+	rc = set_frame(e, 0, image_type, avg_dist);
+	if (rc) return rc;
+	if (ref_y && ref_u && ref_v) {
+		int16_t *dst[3] = {plane0(e, e->cur ^ 1, 0), plane0(e, e->cur ^ 1, 1), plane0(e, e->cur ^ 1, 2)};
+		rc = load_planes(e, ref_y, ref_u, ref_v, dst, s.stride_y, s.stride_c);
 		if (rc) return rc;
-		if (rin[c]) {
-			rc = upload_plane(e, rin[c], w, h, e->d_pic[e->cur ^ 1][c], e->pic_elems[c], c ? s.stride_c : s.stride_y, c ? s.margin_c : s.margin_y);
-			if (rc) return rc;
-		}
-		e->f.src[c] = e->d_src[c];
-		e->f.ref[c] = plane0(e, e->cur ^ 1, c);
-		e->f.rec[c] = plane0(e, e->cur, c);
+		hmr_gpu_frame fr = {s.width, s.height, dst[0], dst[1], dst[2], s.stride_y, s.stride_c};
+		rc = hmr_gpu_pad_frame(e->ctx, &fr, s.margin_y, s.margin_y);
+		if (rc) return rc;
 	}
-	HIP_TRY(hipMemcpyAsync(e->d_frame, &e->f, sizeof(FrameCtx), hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemsetAsync(e->d.progress, 0, sizeof(int) * s.hctu, st));
-	HIP_TRY(hipEventRecord(e->ctx->ev0, st));
-	hipLaunchKernelGGL(k_encode_ctus, dim3(s.hctu), dim3(64), 0, st, e->d);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipEventRecord(e->ctx->ev1, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ctx->ev0, e->ctx->ev1));
+	rc = run_ctu_passes(e);
+	if (rc) return rc;
 	// frame statistics (encoder_engine_thread :3217-3238)
-	std::vector<CtuInfo> ctus(s.nctu);
-	HIP_TRY(hipMemcpy(ctus.data(), e->d.ctus, sizeof(CtuInfo) * s.nctu, hipMemcpyDeviceToHost));
+	rc = download_public(e);
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(st));
 	uint32_t acc = 0;
-	for (int n = 0; n < s.nctu; n++) acc += ctus[n].distortion;
+	for (int n = 0; n < s.nctu; n++) acc += ((const CtuPublic *)(e->h_public.data() + sizeof(CtuPublic) * n))->distortion;
 	end_frame(s, e->st, e->f, acc);
 	if (records) {
-		std::vector<int16_t> coeff((size_t)s.nctu * 6144), rec[3];
-		HIP_TRY(hipMemcpy(coeff.data(), e->d.coeff, coeff.size() * 2, hipMemcpyDeviceToHost));
+		std::vector<int16_t> rec[3];
+		std::vector<uint8_t> truth((size_t)s.nctu * MODE_STATE_BYTES), chain_end(MODE_STATE_BYTES);
+		std::vector<uint32_t> node0(3 * s.nctu);
+		HIP_TRY(hipMemcpy(e->h_coeff.data(), e->d.coeff, e->h_coeff.size() * 2, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(truth.data(), e->d.truth, truth.size(), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(chain_end.data(), e->d.chain_end, MODE_STATE_BYTES, hipMemcpyDeviceToHost));
+		for (int n = 0; n < s.nctu; n++) {
+			Node nd;
+			HIP_TRY(hipMemcpy(&nd, &e->d.ctus[n].nodes[0], sizeof(Node), hipMemcpyDeviceToHost));
+			node0[3 * n] = nd.cost; node0[3 * n + 1] = nd.distortion; node0[3 * n + 2] = nd.sum;
+		}
 		for (int c = 0; c < 3; c++) {
 			rec[c].resize(e->pic_elems[c]);
 			HIP_TRY(hipMemcpy(rec[c].data(), e->d_pic[e->cur][c], e->pic_elems[c] * 2, hipMemcpyDeviceToHost));
@@ -253,8 +523,8 @@ extern "C" int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *e, const uint8_t *y, const ui
 		memset(records, 0, (size_t)REC_BYTES * s.nctu);
 		for (int n = 0; n < s.nctu; n++) {
 			uint8_t *o = records + (size_t)n * REC_BYTES;
-			const CtuInfo &ci = ctus[n];
-			int32_t hdr[8] = {0x43545544, e->f.num_encoded_frames, n, e->f.slice_type, (int32_t)ci.nodes[0].cost, (int32_t)ci.nodes[0].distortion, (int32_t)ci.nodes[0].sum,
+			const CtuPublic &ci = *(const CtuPublic *)(e->h_public.data() + sizeof(CtuPublic) * n);
+			int32_t hdr[8] = {0x43545544, e->f.num_encoded_frames, n, e->f.slice_type, (int32_t)node0[3 * n], (int32_t)node0[3 * n + 1], (int32_t)node0[3 * n + 2],
 					  e->f.is_scene_change};
 			memcpy(o, hdr, 32); o += 32;
 			for (int k = 0; k < 3; k++) { memcpy(o, ci.cbf[k], 256); o += 256; }
@@ -266,7 +536,7 @@ extern "C" int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *e, const uint8_t *y, const ui
 			memcpy(o, ci.mv_diff_ref_idx, 256); o += 256;
 			memcpy(o, ci.mv_ref, 2048); o += 2048;
 			memcpy(o, ci.mv_diff, 2048); o += 2048;
-			memcpy(o, coeff.data() + (size_t)n * 6144, 12288); o += 12288;
+			memcpy(o, e->h_coeff.data() + (size_t)n * 6144, 12288); o += 12288;
 			// reconstruction before the loop filters: the part of the CTU inside the picture (the rest stays zero)
 			for (int c = 0; c < 3; c++) {
 				const int nn = c ? 32 : 64, px = (ci.x >> (c ? 1 : 0)), py = (ci.y >> (c ? 1 : 0));
@@ -280,7 +550,98 @@ extern "C" int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *e, const uint8_t *y, const ui
 					o += nn * 2;
 				}
 			}
+			// the single thread's mode buffers after the CTU
+			memcpy(o, n + 1 < s.nctu ? truth.data() + (size_t)(n + 1) * MODE_STATE_BYTES : chain_end.data(), MODE_STATE_BYTES);
 		}
 	}
 	return e->f.slice_type;
+}
+
+// HOMER_enc_encode for one picture already on the device (hmr_gpu_enc_load_source): CTU decisions, deblocking, SAO statistics on the
+// device; SAO decision + entropy coding on the host; SAO offsets and border padding on the device.  The access unit is written to stream.
+extern "C" int hmr_gpu_enc_encode_source(hmr_gpu_enc *e, int slot, int image_type, uint8_t *stream, long cap, long *stream_bytes, uint8_t *recon)
+{
+	if (!e || slot < 0 || slot >= (int)e->src.size() || !stream || !stream_bytes) return HMR_GPU_ERR_ARG;
+	const Seq &s = e->seq;
+	hipStream_t st = e->ctx->stream;
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	hipEvent_t t0, t1;
+	HIP_TRY(hipEventCreate(&t0));
+	HIP_TRY(hipEventCreate(&t1));
+	HIP_TRY(hipEventRecord(t0, st));
+	int rc = set_frame(e, slot, image_type, -1.0);
+	if (rc) return rc;
+	rc = run_ctu_passes(e);
+	if (rc) return rc;
+	// in-loop filters on the picture under reconstruction
+	hmr_gpu_frame pic = {s.width, s.height, plane0(e, e->cur, 0), plane0(e, e->cur, 1), plane0(e, e->cur, 2), s.stride_y, s.stride_c};
+	hmr_gpu_frame org = {s.width, s.height, e->src[slot].p[0], e->src[slot].p[1], e->src[slot].p[2], s.src_stride_y, s.src_stride_c};
+	hmr_gpu_units units = {e->units_stride, e->d_mvx, e->d_mvy, e->d_ref, e->d_qp, e->d_flags};
+	hipLaunchKernelGGL(k_units_from_ctuinfo, dim3(s.nctu), dim3(NPART), 0, st, e->d.ctus, e->d_geo, s.wctu, e->units_stride, e->d_mvx, e->d_mvy, e->d_ref, e->d_qp, e->d_flags, e->d_pd,
+			   e->d_ti);
+	HIP_TRY(hipGetLastError());
+	if ((rc = hmr_gpu_edge_flags_frame(e->ctx, e->d_pd, e->d_ti, s.width, s.height, e->units_stride, e->d_flags))) return rc;
+	if ((rc = hmr_gpu_deblock_frame(e->ctx, &pic, &units, s.chroma_qp_offset, s.chroma_qp_offset, 0, 0, nullptr, nullptr))) return rc;
+	if (s.sao && (rc = hmr_gpu_sao_stats_frame(e->ctx, &org, &pic, e->d_stats))) return rc;
+	// side-info, levels and statistics to the host
+	if ((rc = download_public(e))) return rc;
+	HIP_TRY(hipMemcpyAsync(e->h_coeff.data(), e->d.coeff, e->h_coeff.size() * 2, hipMemcpyDeviceToHost, st));
+	if (s.sao) HIP_TRY(hipMemcpyAsync(e->h_stats.data(), e->d_stats, e->h_stats.size() * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	uint32_t acc = 0;
+	for (int n = 0; n < s.nctu; n++) acc += ((const CtuPublic *)(e->h_public.data() + sizeof(CtuPublic) * n))->distortion;
+	// SAO decision + entropy coding (enc/enc_entropy.h)
+	EntropyFrame fr;
+	fr.seq = &e->seq; fr.f = &e->f; fr.T = hmr_host_tables(); fr.geo = e->geo.data();
+	fr.ctu_base = e->h_public.data(); fr.ctu_pitch = sizeof(CtuPublic); fr.coeff = e->h_coeff.data();
+	std::vector<uint8_t> out;
+	encode_frame_entropy(e->es, fr, s.sao ? (const SaoStats *)e->h_stats.data() : nullptr, e->cfg.profile, out);
+	if (s.sao) {
+		for (int n = 0; n < s.nctu; n++) {
+			const CtuPublic &ci = fr.ctu(n);
+			for (int k = 0; k < 3; k++) {
+				int32_t *p = e->h_params.data() + ((size_t)n * 3 + k) * 34;
+				p[0] = ci.sao_recon[k].mode_idc; p[1] = ci.sao_recon[k].type_idc;
+				memcpy(p + 2, ci.sao_recon[k].offset, sizeof ci.sao_recon[k].offset);
+			}
+		}
+		HIP_TRY(hipMemcpyAsync(e->d_params, e->h_params.data(), e->h_params.size() * 4, hipMemcpyHostToDevice, st));
+		for (int c = 0; c < 3; c++) HIP_TRY(hipMemcpyAsync(e->d_pre[c], e->d_pic[e->cur][c], e->pic_elems[c] * 2, hipMemcpyDeviceToDevice, st));
+		const size_t oy = (size_t)s.margin_y * s.stride_y + s.margin_y, oc = (size_t)s.margin_c * s.stride_c + s.margin_c;
+		hmr_gpu_frame pre = {s.width, s.height, e->d_pre[0] + oy, e->d_pre[1] + oc, e->d_pre[2] + oc, s.stride_y, s.stride_c};
+		if ((rc = hmr_gpu_sao_apply_frame(e->ctx, &pre, &pic, e->d_params))) return rc;
+	}
+	if ((rc = hmr_gpu_pad_frame(e->ctx, &pic, s.margin_y, s.margin_y))) return rc;
+	if (recon) {
+		uint8_t *o = recon;
+		for (int c = 0; c < 3; c++) {
+			const int w = c ? s.width / 2 : s.width, h = c ? s.height / 2 : s.height;
+			hipLaunchKernelGGL(k_narrow_plane, dim3((w + 255) / 256, h), dim3(256), 0, st, plane0(e, e->cur, c), c ? s.stride_c : s.stride_y, w, h, e->d_bytes);
+			HIP_TRY(hipMemcpyAsync(o, e->d_bytes, (size_t)w * h, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			o += (size_t)w * h;
+		}
+	}
+	HIP_TRY(hipEventRecord(t1, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipEventElapsedTime(&e->last_total_ms, t0, t1));
+	(void)hipEventDestroy(t0);
+	(void)hipEventDestroy(t1);
+	end_frame(s, e->st, e->f, acc);
+	*stream_bytes = (long)out.size();
+	if ((long)out.size() > cap) {
+		hmr_set_error("hmr_gpu_enc_encode: the access unit needs %ld bytes, the buffer holds %ld", (long)out.size(), cap);
+		return HMR_GPU_ERR_ARG;
+	}
+	memcpy(stream, out.data(), out.size());
+	return e->f.slice_type;
+}
+
+// HOMER_enc_encode (homer_hevc_enc_api.h:173): host planes in, access unit out
+extern "C" int hmr_gpu_enc_encode(hmr_gpu_enc *e, const uint8_t *y, const uint8_t *u, const uint8_t *v, int image_type, uint8_t *stream, long cap, long *stream_bytes,
+				  uint8_t *recon)
+{
+	const int rc = hmr_gpu_enc_load_source(e, 0, y, u, v);
+	if (rc) return rc;
+	return hmr_gpu_enc_encode_source(e, 0, image_type, stream, cap, stream_bytes, recon);
 }

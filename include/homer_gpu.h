@@ -591,8 +591,24 @@ int hmr_gpu_enc_record_bytes(void);
  * records (host, may be NULL): nctu x hmr_gpu_enc_record_bytes() bytes, one record per CTU. Returns the slice type (1 P, 2 I) or a negative status. */
 int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *enc, const uint8_t *y, const uint8_t *u, const uint8_t *v, int image_type, const uint8_t *ref_y, const uint8_t *ref_u,
 			   const uint8_t *ref_v, double avg_dist, uint8_t *records);
-/* milliseconds the last CTU launch took on the device (HIP events on the context's stream) */
+/* milliseconds the CTU passes of the last frame took on the device (HIP events on the context's stream) */
 float hmr_gpu_enc_last_ctu_ms(hmr_gpu_enc *enc);
+
+/* HOMER_enc_encode (homer_hevc_enc_api.h:173, hmr_encoder_lib.c:1655 + encoder_engine_thread :3043-3260): one picture in, one access unit out.
+ * CTU decisions, deblocking, SAO statistics, SAO offsets and border padding run on the device; the SAO decision and the CABAC / NAL writer
+ * (hmr_arithmetic_encoding.c, hmr_binary_encoding.c, hmr_bitstream.c, hmr_sao.c:1295) run on the host from the side-info, the levels and the
+ * statistics.  y / u / v: host 8-bit planes; image_type as encoder_in_out_t.image_type (0 auto, 3 forced intra).  stream receives the
+ * Annex-B bytes of the access unit (VPS / SPS / PPS in front of an IDR), *stream_bytes their count; recon (optional) the final picture,
+ * 8-bit planar.  Returns the slice type (1 P, 2 I) or a negative status. */
+int hmr_gpu_enc_encode(hmr_gpu_enc *enc, const uint8_t *y, const uint8_t *u, const uint8_t *v, int image_type, uint8_t *stream, long cap, long *stream_bytes,
+		       uint8_t *recon);
+/* the same with the source picture already resident in HBM: load_source converts and keeps a picture in slot `slot`, encode_source encodes it */
+int hmr_gpu_enc_load_source(hmr_gpu_enc *enc, int slot, const uint8_t *y, const uint8_t *u, const uint8_t *v);
+int hmr_gpu_enc_encode_source(hmr_gpu_enc *enc, int slot, int image_type, uint8_t *stream, long cap, long *stream_bytes, uint8_t *recon);
+/* the last frame: passes of the CTU schedule, CTU encodes (>= the number of CTUs), device milliseconds of the CTU passes and of the whole frame */
+int hmr_gpu_enc_last_stats(hmr_gpu_enc *enc, int *passes, int *ctu_encodes, float *ctu_ms, float *frame_ms);
+/* profiling build (-DHENC_PROFILE): per-row phase timers, [ctu rows][12] */
+int hmr_gpu_enc_profile(hmr_gpu_enc *enc, unsigned long long *out, int reset);
 
 #ifdef __cplusplus
 }

@@ -54,7 +54,7 @@ struct Cpu {
 	int sched = 0, row_guess = 0;          // row_guess: 0 = the truth of the previous frame, 1 = the row above after its second CTU
 	std::vector<CtuInfo> ctus_start;
 	std::vector<uint8_t> guess, truth, outtok, valid, dirty;
-	std::vector<uint32_t> intra_before, used_intra, prefix;
+	std::vector<uint32_t> intra_before, used_intra, used_parts, prefix;
 	std::vector<uint64_t> hash;
 	uint8_t chain_start[MODE_STATE_BYTES] = {0}, chain_end[MODE_STATE_BYTES] = {0};
 	int stat_passes = 0, stat_encodes = 0, stat_invalid_first = 0;
@@ -168,7 +168,7 @@ void sched_verify(Cpu &c, int *n_invalid)
 	int bad = 0;
 	for (int n = 0; n < s.nctu; n++) {
 		c.valid[n] = (uint8_t)sched_guesses_hold(g, c.ctus[n], c.f, &c.truth[(size_t)n * MODE_STATE_BYTES], &c.guess[(size_t)n * MODE_STATE_BYTES], c.intra_before[n],
-							 (uint32_t)n * NPART, c.used_intra[n], uses_ratio);
+							 (uint32_t)n * NPART, c.used_intra[n], c.used_parts[n], uses_ratio);
 		bad += !c.valid[n];
 		if (getenv("HENC_SCHED_DEBUG2")) {
 			int dd[NDEPTH] = {0}, tok[NDEPTH] = {0};
@@ -182,7 +182,7 @@ void sched_verify(Cpu &c, int *n_invalid)
 		}
 		if (getenv("HENC_SCHED_DEBUG") && !c.valid[n])
 			fprintf(stderr, "  ctu %d invalid: modes %s (%d looked at), ratio used %u true %u of %u (%d comparisons)\n", n,
-				sched_guesses_hold(g, c.ctus[n], c.f, &c.truth[(size_t)n * MODE_STATE_BYTES], &c.guess[(size_t)n * MODE_STATE_BYTES], 0, 0, 0, 0) ? "ok" : "WRONG",
+				sched_guesses_hold(g, c.ctus[n], c.f, &c.truth[(size_t)n * MODE_STATE_BYTES], &c.guess[(size_t)n * MODE_STATE_BYTES], 0, 0, 0, 0, 0) ? "ok" : "WRONG",
 				c.ctus[n].n_spec_reads, c.used_intra[n], c.intra_before[n], n * NPART, c.ctus[n].n_ratio_cmp);
 	}
 	*n_invalid = bad;
@@ -210,15 +210,16 @@ void sched_pass(Cpu &c, Enc &e, int pass)
 				c.ctus[n] = c.ctus_start[n];
 				memcpy(gs, &c.truth[(size_t)n * MODE_STATE_BYTES], MODE_STATE_BYTES);
 				c.used_intra[n] = c.intra_before[n];
+				c.used_parts[n] = (uint32_t)n * NPART;
 			} else {
 				if (n == 0) memcpy(gs, c.chain_start, MODE_STATE_BYTES);
-				c.used_intra[n] = sched_known_intra(c.prefix.data(), W, r, col, c.prefix[(size_t)r * (W + 1) + col]);
+				sched_known_intra(c.prefix.data(), W, r, col, &c.used_intra[n], &c.used_parts[n]);
 			}
 			const uint64_t old_hash = c.hash[n];
 			memcpy(e.w->mode_in, gs, MODE_STATE_BYTES);
 			e.coeff = c.coeff.data() + (size_t)n * 6144;
 			e.total_intra_partitions = c.used_intra[n];
-			e.total_partitions = (uint32_t)n * NPART;
+			e.total_partitions = c.used_parts[n];
 			encode_ctu(g, e, n);
 			c.stat_encodes++;
 			memcpy(&c.outtok[(size_t)n * MODE_STATE_BYTES], e.w->intra_mode_buffs, MODE_STATE_BYTES);
@@ -232,7 +233,13 @@ void sched_pass(Cpu &c, Enc &e, int pass)
 					res[i] = (v & MODE_TOKEN) ? gs[(i / (NDEPTH * NPART)) * NDEPTH * NPART + (v & 7) * NPART + i % NPART] : v;
 				}
 				if (col + 1 < W) memcpy(gs + MODE_STATE_BYTES, res, MODE_STATE_BYTES);
-				if (c.row_guess == 1 && r + 1 < H && col == (W > 1 ? 1 : 0)) memcpy(&c.guess[(size_t)(r + 1) * W * MODE_STATE_BYTES], res, MODE_STATE_BYTES);
+				if (c.row_guess >= 1 && r + 1 < H && col == (W > 1 ? 1 : 0)) {
+					uint8_t *dst = &c.guess[(size_t)(r + 1) * W * MODE_STATE_BYTES];
+					memcpy(dst, res, MODE_STATE_BYTES);
+					if (c.row_guess == 2 && c.f.num_encoded_frames >= 2)   // the depths P slices write: what the previous frame had at this row start
+						for (int comp = 0; comp < 2; comp++)
+							memcpy(dst + (comp * NDEPTH + 2) * NPART, &c.truth[(size_t)(r + 1) * W * MODE_STATE_BYTES + (comp * NDEPTH + 2) * NPART], 2 * NPART);
+				}
 				c.prefix[(size_t)r * (W + 1) + col + 1] = c.prefix[(size_t)r * (W + 1) + col] + c.ctus[n].intra_parts;
 			} else if (c.hash[n] != old_hash) {
 				if (col + 1 < W) c.dirty[n + 1] = 1;
@@ -252,7 +259,7 @@ void frame_ctus_sched(Cpu &c, Enc &e)
 	if (c.guess.size() != nb) {
 		c.guess.assign(nb, 0); c.truth.assign(nb, 0); c.outtok.assign(nb, 0);
 		c.valid.assign(s.nctu, 0); c.dirty.assign(s.nctu, 0);
-		c.intra_before.assign(s.nctu, 0); c.used_intra.assign(s.nctu, 0); c.hash.assign(s.nctu, 0);
+		c.intra_before.assign(s.nctu, 0); c.used_intra.assign(s.nctu, 0); c.used_parts.assign(s.nctu, 0); c.hash.assign(s.nctu, 0);
 		c.prefix.assign((size_t)s.hctu * (s.wctu + 1), 0);
 	}
 	while ((int)c.row_w.size() < s.hctu) c.row_w.push_back((Work *)calloc(1, sizeof(Work)));
@@ -396,6 +403,8 @@ int henc_cpu_frame_ctus(void *h, const uint8_t *y, const uint8_t *u, const uint8
 		e.total_intra_partitions = c.intra_parts;
 		e.total_partitions = c.total_parts;
 		memcpy(c.w->mode_in, c.w->intra_mode_buffs, MODE_STATE_BYTES);   // one worker in raster order: what the buffers hold IS the inherited state
+		if (getenv("HENC_WIPE_NODES")) memset(c.ctus[n].nodes, atoi(getenv("HENC_WIPE_NODES")), sizeof c.ctus[n].nodes);
+		if (getenv("HENC_WIPE_PUBLIC")) memset((CtuPublic *)&c.ctus[n], atoi(getenv("HENC_WIPE_PUBLIC")), offsetof(CtuPublic, sao_recon));
 		if (getenv("HENC_WIPE_WORK")) {   // experiment: nothing but the mode chain may carry over from CTU to CTU
 			uint8_t keep[MODE_STATE_BYTES];
 			memcpy(keep, c.w->mode_in, MODE_STATE_BYTES);

@@ -16,8 +16,8 @@ FIELDS = [("hdr", 32, np.int32), ("cbf", 768, np.uint8), ("intra_mode", 512, np.
           ("merge_idx", 256, np.uint8), ("qp", 256, np.uint8), ("mv_ref_idx", 256, np.int8), ("mv_diff_ref_idx", 256, np.uint8), ("mv_ref", 2048, np.int32),
           ("mv_diff", 2048, np.int32), ("coeff", 12288, np.int16), ("recon", 12288, np.int16), ("mode_buffs", 2560, np.uint8)]
 REC = sum(f[1] for f in FIELDS)
-# what a wavefront run must reproduce: everything but the serial worker's mode buffers (they exist per row worker on the device)
-COMPARED = [f[0] for f in FIELDS if f[0] != "mode_buffs"]
+# what a run must reproduce: everything, including the single worker thread's mode buffers after each CTU (the device rebuilds that chain, enc_sched.h)
+COMPARED = [f[0] for f in FIELDS]
 
 
 class EncCfg(C.Structure):
@@ -52,11 +52,28 @@ def split(rec):
     return out
 
 
+def _abs2raster():
+    t = np.zeros(256, dtype=np.int32)
+    for a in range(256):
+        x = y = 0
+        for b in range(4):
+            x |= ((a >> (2 * b)) & 1) << b
+            y |= ((a >> (2 * b + 1)) & 1) << b
+        t[a] = y * 16 + x
+    return t
+
+
+ABS2RASTER = _abs2raster()
+
+
 def crop_recon(rec, width, height, nx):
-    """zero the part of each CTU's reconstruction that lies outside the picture (stale window content in the reference's dump)"""
+    """zero what lies outside the picture in each CTU's reconstruction and levels: the reference's dump shows stale window content there
+    (whatever the worker thread's previous CTU left), which is never coded"""
     rec = bytearray(rec)
     nctu = len(rec) // REC
+    off_c = sum(f[1] for f in FIELDS[:16])
     off = sum(f[1] for f in FIELDS[:17])
+    ux, uy = (ABS2RASTER % 16) * 4, (ABS2RASTER // 16) * 4
     for n in range(nctu):
         cx, cy = (n % nx) * 64, (n // nx) * 64
         a = np.frombuffer(rec, dtype=np.int16, count=6144, offset=n * REC + off)
@@ -67,6 +84,12 @@ def crop_recon(rec, width, height, nx):
             c = a[4096 + 1024 * k:5120 + 1024 * k].reshape(32, 32)
             c[max(0, height // 2 - cy // 2):, :] = 0
             c[:, max(0, width // 2 - cx // 2):] = 0
+        outside = (cx + ux >= width) | (cy + uy >= height)
+        if outside.any():
+            q = np.frombuffer(rec, dtype=np.int16, count=6144, offset=n * REC + off_c)
+            q[:4096].reshape(256, 16)[outside] = 0
+            q[4096:5120].reshape(256, 4)[outside] = 0
+            q[5120:].reshape(256, 4)[outside] = 0
     return bytes(rec)
 
 

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Mint the bitstream fixtures from the COMPILED REFERENCE (build container only): oracle/_ref/ref_lockstep encodes the synthetic
+clip of tools/gen_yuv.py (wpp = 1, engines = 1: the deterministic mode) and this script records, per case, the md5 of the .265
+stream, the NAL unit sizes and the md5 of every reconstructed picture.  tests/golden/streams.json is what the free-running encoder
+(checker build on the CPU, the device path under -m gpu) has to reproduce byte for byte."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import gen_yuv  # noqa: E402
+import stream_diff  # noqa: E402
+
+CASES = [
+    ("200x136", 200, 136, 3, {}),
+    ("416x240", 416, 240, 5, {}),
+    ("416x240_nosao", 416, 240, 3, {"sao": 0}),
+    ("416x240_qp22_perf0", 416, 240, 3, {"qp": 22, "perf": 0}),
+    ("328x264_qp38_nosbh", 328, 264, 3, {"qp": 38, "sign_hiding": 0}),
+    ("416x240_intra", 416, 240, 2, {"intra_period": 1}),
+    ("832x480", 832, 480, 3, {}),
+    ("1920x1080_cfg2", 1920, 1080, 8, {}),       # BASELINE.json configs[1]
+]
+
+
+def run(width, height, frames, keys):
+    with tempfile.TemporaryDirectory() as tmp:
+        yuv = os.path.join(tmp, "in.yuv")
+        gen_yuv.write_clip(yuv, width, height, frames)
+        cmd = [os.path.join(ROOT, "oracle", "_ref", "ref_lockstep"), yuv, os.path.join(tmp, "out.265"), str(width), str(height), str(frames),
+               "recon=" + os.path.join(tmp, "rec.yuv")] + [f"{k}={v}" for k, v in keys.items()]
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+        stream = open(os.path.join(tmp, "out.265"), "rb").read()
+        rec = open(os.path.join(tmp, "rec.yuv"), "rb").read()
+    fsz = width * height * 3 // 2
+    return {"width": width, "height": height, "frames": frames, "keys": keys, "stream_md5": hashlib.md5(stream).hexdigest(), "stream_bytes": len(stream),
+            "nal_sizes": [len(x) for x in stream_diff.split_nals(stream)],
+            "recon_md5": [hashlib.md5(rec[f * fsz:(f + 1) * fsz]).hexdigest() for f in range(frames)]}
+
+
+if __name__ == "__main__":
+    out = {name: run(w, h, f, keys) for name, w, h, f, keys in CASES}
+    json.dump(out, open(os.path.join(HERE, "streams.json"), "w"), indent=1)
+    for k, v in out.items():
+        print(k, v["stream_md5"], v["stream_bytes"])

@@ -1,6 +1,7 @@
 """-m gpu: the device-resident CTU encoder (include/homer_gpu.h section 12) through the C ABI against the per-CTU fixtures
-minted from the compiled reference: side-info arrays, motion vectors, levels and the pre-filter reconstruction of every CTU
-of an I frame and the P frames that follow it."""
+minted from the compiled reference: side-info arrays, motion vectors, levels, the pre-filter reconstruction and the single worker
+thread's mode buffers after every CTU of an I frame and the P frames that follow it (outside-picture window content excluded,
+encoder_cases.crop_recon)."""
 import ctypes as C
 
 import numpy as np

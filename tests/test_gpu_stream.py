@@ -1,0 +1,66 @@
+"""-m gpu: HOMER_enc_encode on the device through the C ABI (hmr_gpu_enc_encode, include/homer_gpu.h section 12), free running over
+several frames: CTU decisions on the row-parallel schedule, deblocking, SAO statistics / offsets and padding as kernels, SAO decision
+and CABAC on the host.  The .265 bytes and every reconstructed picture must equal what the compiled reference produced
+(tests/golden/streams.json), including BASELINE.json configs[1] at full size (1920x1080, 8 frames, md5 2f0c3447...)."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import pytest
+
+import encoder_cases as ec
+import libs
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(ec.GOLDEN, "streams.json")))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    lib = libs.load_gpu()
+    lib.hmr_gpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
+    lib.hmr_gpu_enc_create.argtypes = [C.c_void_p, C.POINTER(ec.EncCfg), C.POINTER(C.c_void_p)]
+    lib.hmr_gpu_enc_encode.argtypes = [C.c_void_p] + [C.c_char_p] * 3 + [C.c_int, C.c_char_p, C.c_long, C.POINTER(C.c_long), C.c_char_p]
+    lib.hmr_gpu_enc_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.hmr_gpu_enc_destroy.argtypes = [C.c_void_p]
+    lib.hmr_gpu_last_error.restype = C.c_char_p
+    ctx = C.c_void_p()
+    rc = lib.hmr_gpu_create(C.byref(ctx), 0, None)
+    assert rc == 0, lib.hmr_gpu_last_error()
+    lib._ctx = ctx
+    return lib
+
+
+def encode(lib, case):
+    g = GOLD[case]
+    w, h, frames = g["width"], g["height"], g["frames"]
+    cfg = ec.default_cfg(w, h, **g["keys"])
+    enc = C.c_void_p()
+    rc = lib.hmr_gpu_enc_create(lib._ctx, C.byref(cfg), C.byref(enc))
+    assert rc == 0, lib.hmr_gpu_last_error()
+    buf = C.create_string_buffer(4 << 20)
+    rec = C.create_string_buffer(w * h * 3 // 2)
+    nbytes = C.c_long()
+    stream, recon, log = b"", [], []
+    for f, planes in enumerate(ec.clip_frames(w, h, frames)):
+        st = lib.hmr_gpu_enc_encode(enc, *planes, 0, buf, len(buf), C.byref(nbytes), rec)
+        assert st in (1, 2), lib.hmr_gpu_last_error()
+        stream += buf.raw[:nbytes.value]
+        recon.append(hashlib.md5(rec.raw).hexdigest())
+        p, n, ms, tot = C.c_int(), C.c_int(), C.c_float(), C.c_float()
+        lib.hmr_gpu_enc_last_stats(enc, C.byref(p), C.byref(n), C.byref(ms), C.byref(tot))
+        log.append(f"f{f}: {p.value} passes {n.value} encodes {ms.value:.1f}/{tot.value:.1f} ms")
+    lib.hmr_gpu_enc_destroy(enc)
+    print(case, "; ".join(log))
+    return stream, recon
+
+
+@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra", "832x480", "1920x1080_cfg2"])
+def test_device_stream_is_byte_identical_to_the_reference(gpu, case):
+    stream, recon = encode(gpu, case)
+    g = GOLD[case]
+    first_bad = next((f for f in range(g["frames"]) if recon[f] != g["recon_md5"][f]), None)
+    assert first_bad is None, f"reconstructed picture {first_bad} differs"
+    assert len(stream) == g["stream_bytes"]
+    assert hashlib.md5(stream).hexdigest() == g["stream_md5"]

@@ -1,0 +1,85 @@
+"""CPU tests of the whole frame pipeline as the product runs it, minus the device: the one-lane checker build of the CTU core
+(oracle/libenc_cpu.so), the round-1 oracle's in-loop filters, and the product's host entropy stage (homerhevc_amd/csrc/enc/enc_entropy.h:
+SAO decision, CABAC, parameter sets, Annex-B) free running over several frames.  The .265 bytes and every reconstructed picture must
+equal what the compiled reference produced (tests/golden/streams.json, minted by tests/golden/make_stream_golden.py)."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+import encoder_cases as ec
+import libs
+
+CPU_SO = os.path.join(libs.ORACLE_DIR, "libenc_cpu.so")
+GOLD = json.load(open(os.path.join(ec.GOLDEN, "streams.json")))
+
+
+@pytest.fixture(scope="module")
+def cpu():
+    subprocess.check_call(["make", "-s", "-C", libs.ORACLE_DIR, CPU_SO])
+    lib = C.CDLL(CPU_SO)
+    lib.henc_cpu_create.restype = C.c_void_p
+    lib.henc_cpu_create.argtypes = [C.POINTER(ec.EncCfg)]
+    lib.henc_cpu_encode_frame.restype = C.c_long
+    lib.henc_cpu_encode_frame.argtypes = [C.c_void_p] + [C.c_char_p] * 3 + [C.c_int, C.c_char_p, C.c_long, C.c_char_p]
+    lib.henc_cpu_set_sched.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.henc_cpu_sched_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    lib.henc_cpu_destroy.argtypes = [C.c_void_p]
+    return lib
+
+
+def encode(lib, case, sched=0):
+    g = GOLD[case]
+    w, h, frames = g["width"], g["height"], g["frames"]
+    cfg = ec.default_cfg(w, h, **g["keys"])
+    enc = lib.henc_cpu_create(C.byref(cfg))
+    assert enc
+    lib.henc_cpu_set_sched(enc, sched, 1)
+    buf = C.create_string_buffer(4 << 20)
+    rec = C.create_string_buffer(w * h * 3 // 2)
+    stream, recon = b"", []
+    for planes in ec.clip_frames(w, h, frames):
+        n = lib.henc_cpu_encode_frame(enc, *planes, 0, buf, len(buf), rec)
+        assert n > 0
+        stream += buf.raw[:n]
+        recon.append(hashlib.md5(rec.raw).hexdigest())
+    st = (C.c_int * 3)()
+    lib.henc_cpu_sched_stats(enc, st, 0)
+    lib.henc_cpu_destroy(enc)
+    return stream, recon, list(st)
+
+
+@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra", "832x480"])
+def test_stream_is_byte_identical_to_the_reference(cpu, case):
+    stream, recon, _ = encode(cpu, case)
+    g = GOLD[case]
+    assert len(stream) == g["stream_bytes"]
+    assert hashlib.md5(stream).hexdigest() == g["stream_md5"]
+    assert recon == g["recon_md5"]
+
+
+def test_stream_matches_the_ctu_fixture_stream(cpu):
+    """the same bytes the per-CTU fixture carries (ref_ctudump's own .265)"""
+    fx = ec.load_fixture("ctus_200x136")
+    stream, _, _ = encode(cpu, "200x136")
+    assert stream == fx["stream"].tobytes()
+
+
+@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_qp22_perf0"])
+def test_row_parallel_schedule_reproduces_the_single_thread_stream(cpu, case):
+    """the device's schedule (row workers with guessed inputs, raster-order verification, selective re-encode; enc_sched.h) emulated with one lane"""
+    stream, recon, st = encode(cpu, case, sched=1)
+    g = GOLD[case]
+    assert hashlib.md5(stream).hexdigest() == g["stream_md5"]
+    assert recon == g["recon_md5"]
+    assert st[0] >= g["frames"] and st[1] >= g["frames"]   # at least one pass and nctu encodes per frame
+
+
+def test_1080p_cfg2_stream_md5(cpu):
+    """BASELINE.json configs[1]: 1920x1080 IPPP, QP 32, 8 frames -> the reference's 2f0c3447..."""
+    stream, recon, _ = encode(cpu, "1920x1080_cfg2")
+    assert hashlib.md5(stream).hexdigest() == GOLD["1920x1080_cfg2"]["stream_md5"] == "2f0c3447dabb6fbd87cac9821bb479fd"
+    assert recon == GOLD["1920x1080_cfg2"]["recon_md5"]
