@@ -36,9 +36,11 @@ struct Enc {
 	// speculative inputs of a P-frame CTU (enc_ctu.h)
 	uint32_t total_intra_partitions, total_partitions;
 	int n_spec_reads, n_ratio_cmp, last_slog;
+	Node *nodes;           // the CTU's partition nodes: ctu->nodes, or the worker's fast copy of them (nodes_fast != nullptr) while the CTU is encoded
+	Node *nodes_fast;
 };
 
-HENC_INLINE Node &node_of(Enc &e, int idx) { return e.ctu->nodes[idx]; }
+HENC_INLINE Node &node_of(Enc &e, int idx) { return e.nodes[idx]; }
 HENC_INLINE int node_at(const Enc &e, int depth, int position) { return e.seq->depth_start[depth] + position; }
 
 // ---- neighbour partitions (hmr_arithmetic_encoding.c:229-355).  Return the CTU that holds the neighbour (nullptr when not

@@ -232,9 +232,9 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &e, int depth, int position
 					blk_copy(g, w.pred_y + q.y * 64 + q.x, 64, dec_ptr(w, curr_depth + 1, COMP_Y) + q.y * DEC_STRIDE_Y + q.x, DEC_STRIDE_Y, n, n);
 					for (int k = 0; k < 2; k++)
 						blk_copy(g, w.pred_c[k] + q.yc * 32 + q.xc, 32, dec_ptr(w, curr_depth + 1, COMP_U + k) + q.yc * DEC_STRIDE_C + q.xc, DEC_STRIDE_C, nc, nc);
-					lin_zero(g, w.tq_y[curr_depth + 1] + (abs_index << 4), n * n);
-					lin_zero(g, w.tq_c[curr_depth + 1][0] + ((abs_index << 4) >> 2), nc * nc);
-					lin_zero(g, w.tq_c[curr_depth + 1][1] + ((abs_index << 4) >> 2), nc * nc);
+					lin_zero(g, tq_ptr(w, curr_depth + 1, COMP_Y) + (abs_index << 4), n * n);
+					lin_zero(g, tq_ptr(w, curr_depth + 1, COMP_U) + ((abs_index << 4) >> 2), nc * nc);
+					lin_zero(g, tq_ptr(w, curr_depth + 1, COMP_V) + ((abs_index << 4) >> 2), nc * nc);
 					set_enc_info_buffs(g, e, ni, curr_depth);
 				}
 				put_consolidated_info(g, e, ni, curr_depth);
@@ -573,6 +573,11 @@ HENC_HD void ctu_begin(const G &g, Enc &e, int ctu_num)
 	Work &w = *e.w;
 	e.ctu = e.ctus + ctu_num;
 	CtuInfo &c = *e.ctu;
+	// the partition nodes are read and written all through the walk: a worker with fast memory of its own works on a copy
+	if (e.nodes_fast) {
+		lin_copy_words(g, (const uint32_t *)c.nodes, (uint32_t *)e.nodes_fast, (int)(sizeof(Node) * NNODES / 4));
+		e.nodes = e.nodes_fast;
+	} else e.nodes = c.nodes;
 	const int cx = ctu_num % S.wctu, cy = ctu_num / S.wctu;
 	c.ctu_number = ctu_num;
 	c.x = cx * 64;
@@ -640,9 +645,9 @@ HENC_HD void ctu_end(const G &g, Enc &e)
 		const int ww = (px + sz) < pw ? sz : pw - px, hh = (py + sz) < ph ? sz : ph - py;
 		blk_copy(g, dec_ptr(w, 0, comp), dec_stride(comp), e.f->rec[comp] + py * rs + px, rs, hh, ww);
 	}
-	lin_copy(g, w.tq_y[0], e.coeff, 4096);
-	lin_copy(g, w.tq_c[0][0], e.coeff + 4096, 1024);
-	lin_copy(g, w.tq_c[0][1], e.coeff + 5120, 1024);
+	lin_copy(g, tq_ptr(w, 0, COMP_Y), e.coeff, 4096);
+	lin_copy(g, tq_ptr(w, 0, COMP_U), e.coeff + 4096, 1024);
+	lin_copy(g, tq_ptr(w, 0, COMP_V), e.coeff + 5120, 1024);
 	uint32_t cnt = 0;
 	for (int i = g.tid; i < NPART; i += g.n) cnt += c.pred_mode[i] == PM_INTRA;
 	cnt = g.sum(cnt);
@@ -651,6 +656,7 @@ HENC_HD void ctu_end(const G &g, Enc &e)
 	c.n_spec_reads = e.n_spec_reads;
 	c.n_ratio_cmp = e.n_ratio_cmp;
 	g.sync();
+	if (e.nodes_fast) lin_copy_words(g, (const uint32_t *)e.nodes_fast, (uint32_t *)c.nodes, (int)(sizeof(Node) * NNODES / 4));
 }
 
 // tokens -> values, for the worker buffers and the CTU's mode arrays, once the values behind the tokens (Work::mode_in) are the true ones

@@ -172,7 +172,7 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &e, int ni, int depth, int cu_m
 	const int wnd = curr_depth + 1;
 	int16_t *pred = w.pred_y + q.y * CTU_STRIDE_Y + q.x, *resid = w.resid_y + q.y * CTU_STRIDE_Y + q.x;
 	const int16_t *orig = w.curr_y + q.y * CTU_STRIDE_Y + q.x;
-	int16_t *quant = w.tq_y[wnd] + (q.abs_index << 4), *iquant = w.iq_y + (q.abs_index << 4);
+	int16_t *quant = tq_ptr(w, wnd, COMP_Y) + (q.abs_index << 4), *iquant = w.iq_y + (q.abs_index << 4);
 	int16_t *dec = dec_ptr(w, wnd, COMP_Y) + q.y * DEC_STRIDE_Y + q.x;
 	const int inv_depth = e.seq->max_cu_size_shift - curr_depth;
 	const int filt = intra_is_filtered(cu_mode, inv_depth);

@@ -96,6 +96,13 @@ HENC_HD void lin_copy(const G &g, const int16_t *s, int16_t *d, int count)
 }
 
 template <class G>
+HENC_HD void lin_copy_words(const G &g, const uint32_t *s, uint32_t *d, int count)
+{
+	for (int i = g.tid; i < count; i += g.n) d[i] = s[i];
+	g.sync();
+}
+
+template <class G>
 HENC_HD void lin_zero(const G &g, int16_t *d, int count)
 {
 	for (int i = g.tid; i < count; i += g.n) d[i] = 0;

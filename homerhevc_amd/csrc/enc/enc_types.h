@@ -137,14 +137,19 @@ struct MvCandList {
 	int32_t ref_idx[5];
 };
 
+// the windows a worker touches less often: seven transform / decoded windows (one per depth + the final and the auxiliary one).
+// On the device they stay in HBM (they are 0.5 MB per worker); everything in Work itself is in LDS.
+struct WorkSlow {
+	int16_t rdec_y[64 * 64], rdec_c[2][32 * 32];
+	int16_t tq_y[NWND][64 * 64], tq_c[NWND][2][32 * 32];
+	int16_t dec_y[NWND][DEC_ROWS_Y * DEC_STRIDE_Y], dec_c[NWND][2][DEC_ROWS_C * DEC_STRIDE_C];
+};
+
 struct Work {
 	int16_t curr_y[64 * 64], curr_c[2][32 * 32];
 	int16_t pred_y[64 * 64], pred_c[2][32 * 32];
 	int16_t resid_y[64 * 64], resid_c[2][32 * 32];
-	int16_t rdec_y[64 * 64], rdec_c[2][32 * 32];
-	int16_t tq_y[NWND][64 * 64], tq_c[NWND][2][32 * 32];
 	int16_t iq_y[64 * 64], iq_c[2][32 * 32];
-	int16_t dec_y[NWND][DEC_ROWS_Y * DEC_STRIDE_Y], dec_c[NWND][2][DEC_ROWS_C * DEC_STRIDE_C];
 	uint8_t cbf_buffs[3][NDEPTH][NPART];
 	uint8_t intra_mode_buffs[2][NDEPTH][NPART];
 	uint8_t mode_in[2][NDEPTH][NPART];     // what intra_mode_buffs held when the CTU started (the values behind the tokens)
@@ -156,6 +161,7 @@ struct Work {
 	int16_t sub_tmp[(64 + 8) * 72];        // first interpolation stage of a sub-pel candidate / two-stage motion compensation
 	int16_t sub_out[64 * 64];
 	MvCandList amvp, merge_cands, search_cands;
+	WorkSlow *slow;
 };
 
 HENC_INLINE int16_t *wnd_y(int16_t *base) { return base; }
@@ -163,15 +169,15 @@ HENC_INLINE int16_t *wnd_y(int16_t *base) { return base; }
 // accessors ------------------------------------------------------------------------------------------------------
 HENC_INLINE int16_t *dec_ptr(Work &w, int wnd, int comp)
 {
-	return comp == COMP_Y ? w.dec_y[wnd] + DEC_ORG_Y : w.dec_c[wnd][comp - 1] + DEC_ORG_C;
+	return comp == COMP_Y ? w.slow->dec_y[wnd] + DEC_ORG_Y : w.slow->dec_c[wnd][comp - 1] + DEC_ORG_C;
 }
 HENC_INLINE int dec_stride(int comp) { return comp == COMP_Y ? DEC_STRIDE_Y : DEC_STRIDE_C; }
 HENC_INLINE int ctu_stride(int comp) { return comp == COMP_Y ? CTU_STRIDE_Y : CTU_STRIDE_C; }
-HENC_INLINE int16_t *tq_ptr(Work &w, int wnd, int comp) { return comp == COMP_Y ? w.tq_y[wnd] : w.tq_c[wnd][comp - 1]; }
+HENC_INLINE int16_t *tq_ptr(Work &w, int wnd, int comp) { return comp == COMP_Y ? w.slow->tq_y[wnd] : w.slow->tq_c[wnd][comp - 1]; }
 HENC_INLINE int16_t *curr_ptr(Work &w, int comp) { return comp == COMP_Y ? w.curr_y : w.curr_c[comp - 1]; }
 HENC_INLINE int16_t *pred_ptr(Work &w, int comp) { return comp == COMP_Y ? w.pred_y : w.pred_c[comp - 1]; }
 HENC_INLINE int16_t *resid_ptr(Work &w, int comp) { return comp == COMP_Y ? w.resid_y : w.resid_c[comp - 1]; }
-HENC_INLINE int16_t *rdec_ptr(Work &w, int comp) { return comp == COMP_Y ? w.rdec_y : w.rdec_c[comp - 1]; }
+HENC_INLINE int16_t *rdec_ptr(Work &w, int comp) { return comp == COMP_Y ? w.slow->rdec_y : w.slow->rdec_c[comp - 1]; }
 HENC_INLINE int16_t *iq_ptr(Work &w, int comp) { return comp == COMP_Y ? w.iq_y : w.iq_c[comp - 1]; }
 
 }  // namespace henc

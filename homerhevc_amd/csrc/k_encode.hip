@@ -29,7 +29,7 @@ struct EncDev {
 	const DevTables *tables;
 	const Geo *geo;
 	CtuInfo *ctus, *ctus_start;   // the CTUs (persistent across frames) and their state when the frame started
-	Work *work;                   // one per CTU row
+	WorkSlow *work_slow;          // one per CTU row: the transform / decoded windows (the rest of a worker's state is in LDS)
 	int16_t *coeff;
 	int *progress;                // [hctu] CTUs passed per row in the running pass
 	uint32_t *prefix;             // [hctu][wctu + 1] running count of intra partitions along each row (first pass)
@@ -49,19 +49,34 @@ __device__ __forceinline__ void wave_copy_words(void *dst, const void *src, int 
 	for (int i = tid; i < bytes / 4; i += 64) d[i] = s[i];
 }
 
+// LDS of a row worker: its Work, a copy of the CTU's partition nodes and of the partition geometry
+constexpr size_t LDS_WORK = (sizeof(Work) + 15) & ~(size_t)15, LDS_NODES = (sizeof(Node) * NNODES + 15) & ~(size_t)15, LDS_GEO = (sizeof(Geo) * NNODES + 15) & ~(size_t)15;
+constexpr size_t LDS_BYTES = LDS_WORK + LDS_NODES + LDS_GEO;
+static_assert(LDS_BYTES <= 160 * 1024, "a workgroup has 160 KiB of LDS on gfx950");
+
 __global__ __launch_bounds__(64) void k_encode_ctus(EncDev d, int pass)
 {
+	extern __shared__ __align__(16) uint8_t lds[];
 	const Seq &S = *d.seq;
 	const int row = blockIdx.x, W = S.wctu, H = S.hctu;
 	WaveGrp g{(int)threadIdx.x};
+	Work *lw = (Work *)lds;
+	Geo *lgeo = (Geo *)(lds + LDS_WORK + LDS_NODES);
+	for (int i = g.tid; i < (int)(LDS_WORK / 4); i += 64) ((uint32_t *)lds)[i] = 0;
+	for (int i = g.tid; i < (int)(sizeof(Geo) * NNODES / 2); i += 64) ((uint16_t *)lgeo)[i] = ((const uint16_t *)d.geo)[i];
+	__syncthreads();
+	if (g.tid == 0) lw->slow = d.work_slow + row;
+	__syncthreads();
 	Enc e;
 	e.seq = d.seq;
 	e.f = d.frame;
 	e.T = d.tables;
-	e.geo = d.geo;
+	e.geo = lgeo;
 	e.ctus = d.ctus;
 	e.ctu = nullptr;
-	e.w = d.work + row;
+	e.w = lw;
+	e.nodes = nullptr;
+	e.nodes_fast = (Node *)(lds + LDS_WORK);
 	e.prof = d.prof ? d.prof + (size_t)row * PF_COUNT : nullptr;
 	uint32_t *my_prefix = d.prefix + (size_t)row * (W + 1);
 	if (pass == 0 && g.tid == 0) my_prefix[0] = 0;
@@ -299,7 +314,7 @@ int run_ctu_passes(hmr_gpu_enc *e)
 	int pass = 0;
 	for (;; pass++) {
 		HIP_TRY(hipMemsetAsync(e->d.progress, 0, sizeof(int) * s.hctu, st));
-		hipLaunchKernelGGL(k_encode_ctus, dim3(s.hctu), dim3(64), 0, st, e->d, pass);
+		hipLaunchKernelGGL(k_encode_ctus, dim3(s.hctu), dim3(64), LDS_BYTES, st, e->d, pass);
 		hipLaunchKernelGGL(k_sched_scan, dim3(1), dim3(320), 0, st, e->d);
 		hipLaunchKernelGGL(k_sched_check, dim3(s.nctu), dim3(64), 0, st, e->d);
 		HIP_TRY(hipGetLastError());
@@ -351,7 +366,7 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 {
 	if (!ctx || !cfg || !out) return HMR_GPU_ERR_ARG;
 	static_assert(sizeof(hmr_gpu_enc_cfg) == sizeof(HostCfg), "configuration layouts must match");
-	static_assert(offsetof(CtuInfo, n_spec_reads) % 4 == 0 && sizeof(Node) % 4 == 0 && MODE_STATE_BYTES % 4 == 0, "word copies");
+	static_assert(offsetof(CtuInfo, n_spec_reads) % 4 == 0 && sizeof(Node) % 4 == 0 && sizeof(Geo) % 2 == 0 && MODE_STATE_BYTES % 4 == 0, "word copies");
 	hmr_gpu_enc *e = new hmr_gpu_enc();
 	e->ctx = ctx;
 	memcpy(&e->cfg, cfg, sizeof(HostCfg));
@@ -378,7 +393,8 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 		for (auto &c : init) memset(c.mv_ref_idx, -1, sizeof c.mv_ref_idx);
 		HIP_TRY(hipMemcpy(e->d.ctus, init.data(), sizeof(CtuInfo) * s.nctu, hipMemcpyHostToDevice));
 	}
-	DEV_ALLOC(e->d.work, s.hctu);
+	DEV_ALLOC(e->d.work_slow, s.hctu);
+	HIP_TRY(hipFuncSetAttribute((const void *)k_encode_ctus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
 	DEV_ALLOC(e->d.coeff, (size_t)6144 * s.nctu);
 	DEV_ALLOC(e->d.progress, s.hctu);
 	DEV_ALLOC(e->d.prefix, (size_t)s.hctu * (s.wctu + 1));
@@ -429,7 +445,7 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	if (!e) return;
 	(void)hipSetDevice(e->ctx->device);
 	(void)hipStreamSynchronize(e->ctx->stream);
-	void *p[] = {e->d_seq, e->d_frame, e->d_geo, e->d.ctus, e->d.ctus_start, e->d.work, e->d.coeff, e->d.progress, e->d.prefix, e->d.prof, e->d.guess, e->d.truth, e->d.outtok,
+	void *p[] = {e->d_seq, e->d_frame, e->d_geo, e->d.ctus, e->d.ctus_start, e->d.work_slow, e->d.coeff, e->d.progress, e->d.prefix, e->d.prof, e->d.guess, e->d.truth, e->d.outtok,
 		     e->d.chain_start, e->d.chain_end, e->d.valid, e->d.dirty, e->d.hash, e->d.intra_before, e->d.used_intra, e->d.used_parts, e->d.counters, e->d_bytes, e->d_mvx,
 		     e->d_mvy, e->d_ref, e->d_qp, e->d_flags, e->d_pd, e->d_ti, e->d_stats, e->d_params};
 	for (void *q : p) (void)hipFree(q);

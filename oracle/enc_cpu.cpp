@@ -60,6 +60,13 @@ struct Cpu {
 	int stat_passes = 0, stat_encodes = 0, stat_invalid_first = 0;
 };
 
+Work *new_work()
+{
+	Work *w = (Work *)calloc(1, sizeof(Work));
+	w->slow = (WorkSlow *)calloc(1, sizeof(WorkSlow));
+	return w;
+}
+
 int16_t *plane0(Cpu &c, int which, int comp)
 {
 	const Seq &s = c.seq;
@@ -98,12 +105,12 @@ void make_record(Cpu &c, int n, Enc &e)
 	memcpy(o, ci.mv_diff_ref_idx, 256); o += 256;
 	memcpy(o, ci.mv_ref, 2048); o += 2048;
 	memcpy(o, ci.mv_diff, 2048); o += 2048;
-	memcpy(o, w.tq_y[0], 8192); o += 8192;
-	memcpy(o, w.tq_c[0][0], 2048); o += 2048;
-	memcpy(o, w.tq_c[0][1], 2048); o += 2048;
+	memcpy(o, w.slow->tq_y[0], 8192); o += 8192;
+	memcpy(o, w.slow->tq_c[0][0], 2048); o += 2048;
+	memcpy(o, w.slow->tq_c[0][1], 2048); o += 2048;
 	for (int comp = 0; comp < 3; comp++) {
 		const int nn = comp ? 32 : 64;
-		const int16_t *d = comp ? w.dec_c[0][comp - 1] + DEC_ORG_C : w.dec_y[0] + DEC_ORG_Y;
+		const int16_t *d = comp ? w.slow->dec_c[0][comp - 1] + DEC_ORG_C : w.slow->dec_y[0] + DEC_ORG_Y;
 		for (int y = 0; y < nn; y++) { memcpy(o, d + y * dec_stride(comp), nn * 2); o += nn * 2; }
 	}
 	for (int k = 0; k < 2; k++)
@@ -262,7 +269,7 @@ void frame_ctus_sched(Cpu &c, Enc &e)
 		c.intra_before.assign(s.nctu, 0); c.used_intra.assign(s.nctu, 0); c.used_parts.assign(s.nctu, 0); c.hash.assign(s.nctu, 0);
 		c.prefix.assign((size_t)s.hctu * (s.wctu + 1), 0);
 	}
-	while ((int)c.row_w.size() < s.hctu) c.row_w.push_back((Work *)calloc(1, sizeof(Work)));
+	while ((int)c.row_w.size() < s.hctu) c.row_w.push_back(new_work());
 	c.ctus_start = c.ctus;
 	std::fill(c.prefix.begin(), c.prefix.end(), 0);
 	if (c.row_guess == 0)   // row starts: what the previous frame found there
@@ -308,7 +315,7 @@ void *henc_cpu_create(const HostCfg *cfg)
 	c->ctus.resize(s.nctu);
 	memset(c->ctus.data(), 0, sizeof(CtuInfo) * s.nctu);
 	for (auto &ci : c->ctus) memset(ci.mv_ref_idx, -1, sizeof ci.mv_ref_idx);
-	c->w = (Work *)calloc(1, sizeof(Work));
+	c->w = new_work();
 	c->src[0].assign((size_t)s.src_stride_y * s.height, 0);
 	c->src[1].assign((size_t)s.src_stride_c * s.height / 2, 0);
 	c->src[2].assign((size_t)s.src_stride_c * s.height / 2, 0);
@@ -325,6 +332,7 @@ void *henc_cpu_create(const HostCfg *cfg)
 void henc_cpu_destroy(void *h)
 {
 	Cpu *c = (Cpu *)h;
+	free(c->w->slow);
 	free(c->w);
 	delete c;
 }
@@ -408,7 +416,10 @@ int henc_cpu_frame_ctus(void *h, const uint8_t *y, const uint8_t *u, const uint8
 		if (getenv("HENC_WIPE_WORK")) {   // experiment: nothing but the mode chain may carry over from CTU to CTU
 			uint8_t keep[MODE_STATE_BYTES];
 			memcpy(keep, c.w->mode_in, MODE_STATE_BYTES);
+			WorkSlow *slow = c.w->slow;
 			memset(c.w, atoi(getenv("HENC_WIPE_WORK")), sizeof(Work));
+			memset(slow, atoi(getenv("HENC_WIPE_WORK")), sizeof(WorkSlow));
+			c.w->slow = slow;
 			memcpy(c.w->mode_in, keep, MODE_STATE_BYTES);
 		}
 		encode_ctu(g, e, n);
@@ -450,7 +461,7 @@ int henc_cpu_frame_ctus_wavefront(void *h, const uint8_t *y, const uint8_t *u, c
 		c.f.ref[comp] = plane0(c, c.cur ^ 1, comp);
 		c.f.rec[comp] = plane0(c, c.cur, comp);
 	}
-	while ((int)c.row_w.size() < s.hctu) c.row_w.push_back((Work *)calloc(1, sizeof(Work)));
+	while ((int)c.row_w.size() < s.hctu) c.row_w.push_back(new_work());
 	Enc e;
 	memset(&e, 0, sizeof e);
 	e.seq = &c.seq; e.f = &c.f; e.T = hmr_host_tables(); e.geo = c.geo; e.ctus = c.ctus.data();

@@ -5,7 +5,7 @@ import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench
+import bench_callmix as bench
 from homerhevc_amd.gpu import Context
 import torch
 
