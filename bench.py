@@ -74,6 +74,54 @@ def cpu_baseline(width, height, keys, frames):
             "sample": f"{frames} frames {width}x{height} IPPP QP32 through oracle/_ref/ref_lockstep (SSE4.2 table, wpp=1, engines=1), wall time incl. init and file I/O"}
 
 
+def multi_stream(lib, device, width, height, keys, streams, warmup, steps):
+    """Aggregate throughput of `streams` independent sequences encoded CONCURRENTLY on one GPU (one encoder instance, HIP stream and host thread each).
+    One 1080p encode occupies 17 of the 256 CUs (one workgroup per CTU row), so this is what the device delivers when it is kept busy; it is
+    reported beside `value`, which stays the single-sequence rate of the BASELINE configuration."""
+    import threading
+    import encoder_cases as ec
+    frames = ec.clip_frames(width, height, warmup + steps)
+    gate = threading.Barrier(streams + 1)
+    errors = []
+
+    def worker():
+        try:
+            ctx, enc = C.c_void_p(), C.c_void_p()
+            assert lib.hmr_gpu_create(C.byref(ctx), device, None) == 0
+            cfg = ec.default_cfg(width, height, **keys)
+            assert lib.hmr_gpu_enc_create(ctx, C.byref(cfg), C.byref(enc)) == 0
+            for f, planes in enumerate(frames):
+                assert lib.hmr_gpu_enc_load_source(enc, f, *planes) == 0
+            buf, n = C.create_string_buffer(16 << 20), C.c_long()
+            for f in range(warmup):
+                assert lib.hmr_gpu_enc_encode_source(enc, f, 0, buf, len(buf), C.byref(n), None) in (1, 2)
+            gate.wait()
+            for f in range(warmup, warmup + steps):
+                assert lib.hmr_gpu_enc_encode_source(enc, f, 0, buf, len(buf), C.byref(n), None) in (1, 2)
+            gate.wait()
+            lib.hmr_gpu_enc_destroy(enc)
+        except Exception as ex:   # noqa: BLE001
+            errors.append(repr(ex))
+            gate.abort()
+
+    th = [threading.Thread(target=worker) for _ in range(streams)]
+    for t in th:
+        t.start()
+    try:
+        gate.wait()
+        t0 = time.perf_counter()
+        gate.wait()
+        dt = time.perf_counter() - t0
+    except threading.BrokenBarrierError:
+        dt = None
+    for t in th:
+        t.join()
+    if dt is None or errors:
+        return {"streams": streams, "error": errors[:1]}
+    return {"streams": streams, "frames_per_stream": steps, "value": round(streams * steps / dt, 4), "unit": "frames/s aggregate",
+            "note": f"{streams} independent {width}x{height} sequences concurrently on one GPU, {steps} timed frames each after {warmup} warm-up frames"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +130,7 @@ def main():
     ap.add_argument("--workload", default="cfg2-1080p-encode", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=24)
+    ap.add_argument("--streams", type=int, default=8, help="concurrent sequences of the extra multi_stream measurement (0 = skip)")
     a = ap.parse_args()
 
     import torch
@@ -164,6 +213,8 @@ def main():
                          "note": "one wavefront per CTU row (17 at 1080p) walking a dependent decision chain: bound by instruction issue and memory latency of "
                                  "those few wavefronts, not by HBM bandwidth; the fraction is the honest distance from the bandwidth roof"},
         }
+        if world == 1 and a.streams > 1:
+            out["multi_stream"] = multi_stream(lib, local, width, height, keys, a.streams, 2, 3)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(width, height, keys, a.cpu_frames)
         print(json.dumps(out))

@@ -136,8 +136,9 @@ HENC_HD void sync_cu_comp(const G &g, Enc &e, int ni, int q_src, int q_dst, int 
 	int16_t *dd = dec_ptr(*e.w, d_dst, comp) + y * st + x;
 	const int16_t *qs = tq_ptr(*e.w, q_src, comp) + off;
 	int16_t *qd = tq_ptr(*e.w, q_dst, comp) + off;
+	const int ln = ilog2i(n);
 	for (int i = g.tid; i < n * n; i += g.n) {
-		const int r = i / n, c = i - r * n;
+		const int r = i >> ln, c = i & (n - 1);
 		dd[r * st + c] = ds[r * st + c];
 		qd[i] = qs[i];
 	}

@@ -6,13 +6,30 @@
 #include "enc_types.h"
 #include "../tables_layout.h"
 
+// Primitive-level timers of the profiling build (-DHENC_PROFILE, device only): lane 0 adds s_memtime ticks and a call count per primitive class
+// to a small table at the end of the worker's LDS; k_encode_ctus folds it into the per-row profile.
+enum { PP_SAD = 0, PP_SSD, PP_BLK, PP_FILLREF, PP_ADIFILT, PP_INTRAPRED, PP_INTERP, PP_TRF, PP_TRI, PP_QUANT, PP_DEQUANT, PP_COUNT };
+#if defined(__HIPCC__) && defined(HENC_PROFILE)
+extern __shared__ __align__(16) unsigned char henc_lds[];
+#define HENC_LDS_PROF_OFFSET (159 * 1024)
+#define PRIM_T0() const unsigned long long prim_t0_ = __builtin_amdgcn_s_memtime()
+#define PRIM_END(cat) do { if (threadIdx.x == 0) { unsigned long long *pp_ = (unsigned long long *)(henc_lds + HENC_LDS_PROF_OFFSET); pp_[cat] += __builtin_amdgcn_s_memtime() - prim_t0_; pp_[PP_COUNT + (cat)]++; } } while (0)
+#else
+#define PRIM_T0() do { } while (0)
+#define PRIM_END(cat) do { } while (0)
+#endif
+
 namespace henc {
 
-HENC_INLINE int ilog2i(int n)
+HENC_INLINE int ilog2i(int n)   // smallest s with (1 << s) >= n
 {
-	int s = 0;
-	while ((1 << s) < n) s++;
-	return s;
+	return n <= 1 ? 0 : 32 - __builtin_clz((unsigned)(n - 1));
+}
+// row / column of element k of a block w wide without a division when w is a power of two (it is, except at picture edges)
+HENC_INLINE void split_rc(int k, int w, int lw, int *r, int *c)
+{
+	if ((w & (w - 1)) == 0) { *r = k >> lw; *c = k & (w - 1); }
+	else { *r = k / w; *c = k - *r * w; }
 }
 
 // ---- pixel kernels (hmr_sse42_functions_pixel.c:462,728,817,919) -------------------------------------------------
@@ -81,8 +98,10 @@ HENC_HD void blk_reconst(const G &g, const int16_t *p, int ps, const int16_t *re
 template <class G>
 HENC_HD void blk_copy(const G &g, const int16_t *s, int ss, int16_t *d, int ds, int h, int w)
 {
+	const int lw = ilog2i(w);
 	for (int i = g.tid; i < h * w; i += g.n) {
-		const int y = i / w, x = i - y * w;
+		int y, x;
+		split_rc(i, w, lw, &y, &x);
 		d[y * ds + x] = s[y * ss + x];
 	}
 	g.sync();
@@ -342,8 +361,10 @@ HENC_HD void interp_stage(const G &g, const int16_t *src, int ss, int16_t *dst, 
 {
 	if (fraction == 0) {
 		if (NT == 4 && w < 4) { g.sync(); return; }    // chroma no-op (inter_prediction.c:822-825)
+		const int lw0 = ilog2i(w);
 		for (int k = g.tid; k < w * h; k += g.n) {
-			const int r = k / w, c = k - r * w;
+			int r, c;
+			split_rc(k, w, lw0, &r, &c);
 			const int v = src[r * ss + c];
 			int16_t o;
 			if (first == last) o = (int16_t)v;
@@ -368,8 +389,10 @@ HENC_HD void interp_stage(const G &g, const int16_t *src, int ss, int16_t *dst, 
 		offset = first ? -(8192 << shift) : 0;
 	}
 	const int16_t *s0 = src - (NT / 2 - 1) * rs;
+	const int lw = ilog2i(w);
 	for (int k = g.tid; k < w * h; k += g.n) {
-		const int r = k / w, c = k - r * w;
+		int r, c;
+		split_rc(k, w, lw, &r, &c);
 		int sum = 0;
 #pragma unroll
 		for (int t = 0; t < NT; t++) sum += s0[r * ss + c + t * rs] * c8[t];
