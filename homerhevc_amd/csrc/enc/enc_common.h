@@ -12,7 +12,7 @@ extern "C" FILE *henc_trace_file;
 #endif
 
 // Device-side phase timers (profiling build only, -DHENC_PROFILE): lane 0 accumulates s_memtime ticks per phase into Enc::prof.
-enum { PF_SETUP = 0, PF_MERGE, PF_ME_INT, PF_ME_SUB, PF_PRED_INTER, PF_ENC_INTER, PF_INTRA_SEARCH, PF_INTRA_TU, PF_INTRA_CHROMA, PF_CONSOLIDATE, PF_WAIT, PF_TOTAL, PF_COUNT };
+enum { PF_SETUP = 0, PF_MERGE, PF_ME_INT, PF_ME_SUB, PF_PRED_INTER, PF_ENC_INTER, PF_INTRA_SEARCH, PF_INTRA_TU, PF_INTRA_CHROMA, PF_CONSOLIDATE, PF_WAIT, PF_TOTAL, PF_PRIM0, PF_COUNT = PF_PRIM0 + 2 * PP_COUNT + 2 };   // PF_PRIM0...: ticks, then calls, per primitive class (enc_prims.h)
 #if defined(__HIPCC__) && defined(HENC_PROFILE)
 #define HENC_PROF_T0() const unsigned long long prof_t0_ = __builtin_amdgcn_s_memtime()
 #define HENC_PROF_ADD(e, cat) do { if ((e).prof && threadIdx.x == 0) (e).prof[cat] += __builtin_amdgcn_s_memtime() - prof_t0_; } while (0)

@@ -13,9 +13,11 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define HENC_HD __device__
+#define HENC_PRIM __device__   // block primitives (measured: forcing them out of line does not pay, 1080p P frame +7 %)
 #define HENC_INLINE __host__ __device__ __forceinline__   // the small helpers are also used by the host entropy stage
 #else
 #define HENC_HD
+#define HENC_PRIM
 #define HENC_INLINE inline
 #endif
 
@@ -28,11 +30,15 @@ struct WaveGrp {
 	int tid;
 	static constexpr int n = 64;
 	__device__ __forceinline__ void sync() const { __syncthreads(); }
+	// wave-wide sum without LDS traffic: row shifts (DPP) inside the 16-lane rows, then the four row totals through readlane
 	__device__ __forceinline__ uint32_t sum(uint32_t v) const
 	{
-#pragma unroll
-		for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-		return v;
+		int x = (int)v;
+		x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+		x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+		x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+		x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8 -> lane 15 of every row holds the row total
+		return (uint32_t)(__builtin_amdgcn_readlane(x, 15) + __builtin_amdgcn_readlane(x, 31) + __builtin_amdgcn_readlane(x, 47) + __builtin_amdgcn_readlane(x, 63));
 	}
 	__device__ __forceinline__ int64_t sum64(int64_t v) const
 	{
@@ -41,6 +47,7 @@ struct WaveGrp {
 		return v;
 	}
 	__device__ __forceinline__ uint32_t any(bool p) const { return __ballot(p) != 0; }
+	__device__ __forceinline__ uint64_t ballot(bool p) const { return __ballot(p); }
 	// smallest key over the lanes (ties: the key itself breaks them)
 	__device__ __forceinline__ uint64_t min64(uint64_t v) const
 	{
@@ -61,6 +68,7 @@ struct CpuGrp {
 	uint32_t sum(uint32_t v) const { return v; }
 	int64_t sum64(int64_t v) const { return v; }
 	uint32_t any(bool p) const { return p; }
+	uint64_t ballot(bool p) const { return p ? 1 : 0; }
 	uint64_t min64(uint64_t v) const { return v; }
 };
 

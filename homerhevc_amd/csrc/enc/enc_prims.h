@@ -34,125 +34,151 @@ HENC_INLINE void split_rc(int k, int w, int lw, int *r, int *c)
 
 // ---- pixel kernels (hmr_sse42_functions_pixel.c:462,728,817,919) -------------------------------------------------
 template <class G>
-HENC_HD uint32_t blk_sad(const G &g, const int16_t *a, int as, const int16_t *b, int bs, int n)
+HENC_PRIM uint32_t blk_sad(const G &g, const int16_t *a, int as, const int16_t *b, int bs, int n)
 {
+	PRIM_T0();
 	const int l = ilog2i(n);
 	uint32_t acc = 0;
+	#pragma unroll 4
 	for (int i = g.tid; i < n * n; i += g.n) {
 		const int y = i >> l, x = i & (n - 1);
 		acc += (uint32_t)habs((int16_t)(a[y * as + x] - b[y * bs + x]));
 	}
-	return g.sum(acc);
+	{ const auto prim_ret_ = g.sum(acc); PRIM_END(PP_SAD); return prim_ret_; }
 }
 
 template <class G>
-HENC_HD uint32_t blk_ssd(const G &g, const int16_t *a, int as, const int16_t *b, int bs, int n)
+HENC_PRIM uint32_t blk_ssd(const G &g, const int16_t *a, int as, const int16_t *b, int bs, int n)
 {
+	PRIM_T0();
 	const int l = ilog2i(n);
 	uint32_t acc = 0;
+	#pragma unroll 4
 	for (int i = g.tid; i < n * n; i += g.n) {
 		const int y = i >> l, x = i & (n - 1);
 		const int32_t d = (int16_t)(a[y * as + x] - b[y * bs + x]);
 		acc += (uint32_t)(d * d);
 	}
-	return g.sum(acc);
+	{ const auto prim_ret_ = g.sum(acc); PRIM_END(PP_SSD); return prim_ret_; }
 }
 
 // sum of squares of a block (ssd16b against the reference's zero row, hmr_motion_inter.c:94)
 template <class G>
-HENC_HD uint32_t blk_ssq(const G &g, const int16_t *a, int as, int n)
+HENC_PRIM uint32_t blk_ssq(const G &g, const int16_t *a, int as, int n)
 {
+	PRIM_T0();
 	const int l = ilog2i(n);
 	uint32_t acc = 0;
+	#pragma unroll 4
 	for (int i = g.tid; i < n * n; i += g.n) {
 		const int32_t d = a[(i >> l) * as + (i & (n - 1))];
 		acc += (uint32_t)(d * d);
 	}
-	return g.sum(acc);
+	{ const auto prim_ret_ = g.sum(acc); PRIM_END(PP_SSD); return prim_ret_; }
 }
 
 template <class G>
-HENC_HD void blk_predict(const G &g, const int16_t *o, int os, const int16_t *p, int ps, int16_t *r, int rs, int n)
+HENC_PRIM void blk_predict(const G &g, const int16_t *o, int os, const int16_t *p, int ps, int16_t *r, int rs, int n)
 {
+	PRIM_T0();
 	const int l = ilog2i(n);
+	#pragma unroll 4
 	for (int i = g.tid; i < n * n; i += g.n) {
 		const int y = i >> l, x = i & (n - 1);
 		r[y * rs + x] = (int16_t)(o[y * os + x] - p[y * ps + x]);
 	}
 	g.sync();
+	PRIM_END(PP_BLK);
 }
 
 // res == nullptr: the all-zero residual (the reference passes a zeroed row with stride 0, hmr_motion_intra.c:1065)
 template <class G>
-HENC_HD void blk_reconst(const G &g, const int16_t *p, int ps, const int16_t *res, int rs, int16_t *d, int ds, int n)
+HENC_PRIM void blk_reconst(const G &g, const int16_t *p, int ps, const int16_t *res, int rs, int16_t *d, int ds, int n)
 {
+	PRIM_T0();
 	const int l = ilog2i(n);
+	#pragma unroll 4
 	for (int i = g.tid; i < n * n; i += g.n) {
 		const int y = i >> l, x = i & (n - 1);
 		const int r = res ? res[y * rs + x] : 0;
 		d[y * ds + x] = (int16_t)hclip((int)sat16(p[y * ps + x] + r), 0, 255);
 	}
 	g.sync();
+	PRIM_END(PP_BLK);
 }
 
 template <class G>
-HENC_HD void blk_copy(const G &g, const int16_t *s, int ss, int16_t *d, int ds, int h, int w)
+HENC_PRIM void blk_copy(const G &g, const int16_t *s, int ss, int16_t *d, int ds, int h, int w)
 {
+	PRIM_T0();
 	const int lw = ilog2i(w);
+	#pragma unroll 4
 	for (int i = g.tid; i < h * w; i += g.n) {
 		int y, x;
 		split_rc(i, w, lw, &y, &x);
 		d[y * ds + x] = s[y * ss + x];
 	}
 	g.sync();
+	PRIM_END(PP_BLK);
 }
 
 template <class G>
-HENC_HD void lin_copy(const G &g, const int16_t *s, int16_t *d, int count)
+HENC_PRIM void lin_copy(const G &g, const int16_t *s, int16_t *d, int count)
 {
+	PRIM_T0();
 	for (int i = g.tid; i < count; i += g.n) d[i] = s[i];
 	g.sync();
+	PRIM_END(PP_BLK);
 }
 
 template <class G>
-HENC_HD void lin_copy_words(const G &g, const uint32_t *s, uint32_t *d, int count)
+HENC_PRIM void lin_copy_words(const G &g, const uint32_t *s, uint32_t *d, int count)
 {
+	PRIM_T0();
 	for (int i = g.tid; i < count; i += g.n) d[i] = s[i];
 	g.sync();
+	PRIM_END(PP_BLK);
 }
 
 template <class G>
-HENC_HD void lin_zero(const G &g, int16_t *d, int count)
+HENC_PRIM void lin_zero(const G &g, int16_t *d, int count)
 {
+	PRIM_T0();
 	for (int i = g.tid; i < count; i += g.n) d[i] = 0;
 	g.sync();
+	PRIM_END(PP_BLK);
 }
 
 template <class G>
-HENC_HD void bytes_set(const G &g, uint8_t *d, int v, int count)
+HENC_PRIM void bytes_set(const G &g, uint8_t *d, int v, int count)
 {
+	PRIM_T0();
 	for (int i = g.tid; i < count; i += g.n) d[i] = (uint8_t)v;
 	g.sync();
+	PRIM_END(PP_BLK);
 }
 
 template <class G>
-HENC_HD void bytes_copy(const G &g, const uint8_t *s, uint8_t *d, int count)
+HENC_PRIM void bytes_copy(const G &g, const uint8_t *s, uint8_t *d, int count)
 {
+	PRIM_T0();
 	for (int i = g.tid; i < count; i += g.n) d[i] = s[i];
 	g.sync();
+	PRIM_END(PP_BLK);
 }
 
 // ---- intra reference samples (fill_reference_samples hmr_motion_intra.c:246-404, adi_filter :189-244) --------------
 // `corner` points at sample (-1,-1) of the block in the window under reconstruction.
 template <class G>
-HENC_HD void intra_fill_refs(const G &g, const int16_t *corner, int stride, int n, int left, int top, int bottom_left, int top_right,
+HENC_PRIM void intra_fill_refs(const G &g, const int16_t *corner, int stride, int n, int left, int top, int bottom_left, int top_right,
 			     int bl_size, int tr_size, int16_t *adi)
 {
+	PRIM_T0();
 	const int adi_size = 4 * n + 1;
 	if (!left && !top) {
 		for (int i = g.tid; i < adi_size; i += g.n) adi[i] = 128;
 		g.sync();
-		return;
+		{ PRIM_END(PP_FILLREF); return; }
 	}
 	int pl_ptr = 0, pl_size = 0, pt_ptr = 0, pt_size = 0, first_idx = 0, last_idx = 0;
 	if (left) { first_idx = n; last_idx = 2 * n - 1; }
@@ -182,6 +208,7 @@ HENC_HD void intra_fill_refs(const G &g, const int16_t *corner, int stride, int 
 		else pl_size++;
 	}
 	// available samples
+	#pragma unroll 4
 	for (int k = g.tid; k < adi_size; k += g.n) {
 		if (k < n) {                       // bottom-left: adi[n-1-i] = row n+1+i
 			const int i = n - 1 - k;
@@ -203,11 +230,13 @@ HENC_HD void intra_fill_refs(const G &g, const int16_t *corner, int stride, int 
 	for (int i = g.tid; i < pl_size; i += g.n) adi[pl_ptr + i] = first_sample;
 	for (int i = g.tid; i < pt_size; i += g.n) adi[pt_ptr + i] = last_sample;
 	g.sync();
+	PRIM_END(PP_FILLREF);
 }
 
 template <class G>
-HENC_HD void intra_adi_filter(const G &g, const int16_t *adi, int16_t *out, int n, int strong_enabled)
+HENC_PRIM void intra_adi_filter(const G &g, const int16_t *adi, int16_t *out, int n, int strong_enabled)
 {
+	PRIM_T0();
 	const int adi_size = 4 * n + 1;
 	bool strong = false;
 	int bl = 0, tl = 0, tr = 0;
@@ -218,6 +247,7 @@ HENC_HD void intra_adi_filter(const G &g, const int16_t *adi, int16_t *out, int 
 	}
 	if (strong) {
 		const int shift = ilog2i(2 * n);
+		#pragma unroll 4
 		for (int i = g.tid; i < adi_size; i += g.n) {
 			int v;
 			if (i == 0 || i == 2 * n || i == adi_size - 1) v = adi[i];
@@ -230,6 +260,7 @@ HENC_HD void intra_adi_filter(const G &g, const int16_t *adi, int16_t *out, int 
 			out[i] = (i == 0 || i == adi_size - 1) ? adi[i] : (int16_t)((adi[i - 1] + 2 * adi[i] + adi[i + 1] + 2) >> 2);
 	}
 	g.sync();
+	PRIM_END(PP_ADIFILT);
 }
 
 // ---- intra prediction (planar hmr_motion_intra.c:408-439; DC / angular :482-625; SSE twins prediction.c:199,926) -------
@@ -314,24 +345,29 @@ HENC_INLINE int intra_sample(const IntraPredictor &p, int j, int i)
 }
 
 template <class G>
-HENC_HD void intra_predict(const G &g, int16_t *pred, int ps, const int16_t *adi, int n, int mode, int is_luma)
+HENC_PRIM void intra_predict(const G &g, int16_t *pred, int ps, const int16_t *adi, int n, int mode, int is_luma)
 {
+	PRIM_T0();
 	const IntraPredictor p = intra_setup(adi, n, mode, is_luma);
 	const int l = p.shift;
+	#pragma unroll 4
 	for (int k = g.tid; k < n * n; k += g.n) {
 		const int j = k >> l, i = k & (n - 1);
 		pred[j * ps + i] = (int16_t)intra_sample(p, j, i);
 	}
 	g.sync();
+	PRIM_END(PP_INTRAPRED);
 }
 
 // prediction + SAD against the source in one pass; the prediction is also stored (later stages of the reference read it)
 template <class G>
-HENC_HD uint32_t intra_predict_sad(const G &g, int16_t *pred, int ps, const int16_t *orig, int os, const int16_t *adi, int n, int mode, int is_luma)
+HENC_PRIM uint32_t intra_predict_sad(const G &g, int16_t *pred, int ps, const int16_t *orig, int os, const int16_t *adi, int n, int mode, int is_luma)
 {
+	PRIM_T0();
 	const IntraPredictor p = intra_setup(adi, n, mode, is_luma);
 	const int l = p.shift;
 	uint32_t acc = 0;
+	#pragma unroll 4
 	for (int k = g.tid; k < n * n; k += g.n) {
 		const int j = k >> l, i = k & (n - 1);
 		const int v = intra_sample(p, j, i);
@@ -340,7 +376,7 @@ HENC_HD uint32_t intra_predict_sad(const G &g, int16_t *pred, int ps, const int1
 	}
 	const uint32_t s = g.sum(acc);
 	g.sync();
-	return s;
+	{ const auto prim_ret_ = s; PRIM_END(PP_INTRAPRED); return prim_ret_; }
 }
 
 // ---- interpolation (hmr_motion_inter.c:240-391,878-936; SSE twins inter_prediction.c:796,818) -----------------------
@@ -357,11 +393,13 @@ HENC_INLINE void chroma_tap_row(int f, int *c)
 
 // one separable stage; NT = 8 (luma) / 4 (chroma).  fraction 0 = the reference's filter_copy variants.
 template <int NT, class G>
-HENC_HD void interp_stage(const G &g, const int16_t *src, int ss, int16_t *dst, int ds, int fraction, int w, int h, int vert, int first, int last)
+HENC_PRIM void interp_stage(const G &g, const int16_t *src, int ss, int16_t *dst, int ds, int fraction, int w, int h, int vert, int first, int last)
 {
+	PRIM_T0();
 	if (fraction == 0) {
-		if (NT == 4 && w < 4) { g.sync(); return; }    // chroma no-op (inter_prediction.c:822-825)
+		if (NT == 4 && w < 4) { g.sync(); PRIM_END(PP_INTERP); return; }    // chroma no-op (inter_prediction.c:822-825)
 		const int lw0 = ilog2i(w);
+		#pragma unroll 4
 		for (int k = g.tid; k < w * h; k += g.n) {
 			int r, c;
 			split_rc(k, w, lw0, &r, &c);
@@ -373,7 +411,7 @@ HENC_HD void interp_stage(const G &g, const int16_t *src, int ss, int16_t *dst, 
 			dst[r * ds + c] = o;
 		}
 		g.sync();
-		return;
+		{ PRIM_END(PP_INTERP); return; }
 	}
 	int c8[8];
 	if (NT == 8) luma_tap_row(fraction, c8);
@@ -390,6 +428,7 @@ HENC_HD void interp_stage(const G &g, const int16_t *src, int ss, int16_t *dst, 
 	}
 	const int16_t *s0 = src - (NT / 2 - 1) * rs;
 	const int lw = ilog2i(w);
+	#pragma unroll 4
 	for (int k = g.tid; k < w * h; k += g.n) {
 		int r, c;
 		split_rc(k, w, lw, &r, &c);
@@ -401,101 +440,199 @@ HENC_HD void interp_stage(const G &g, const int16_t *src, int ss, int16_t *dst, 
 		dst[r * ds + c] = v;
 	}
 	g.sync();
+	PRIM_END(PP_INTERP);
 }
 
 // ---- transforms (hmr_sse42_functions_transform.c:1670,1700; spec hmr_transform.c:133-549) ---------------------------
-template <class G>
-HENC_HD void tr_forward(const G &g, const DevTables *T, const int16_t *block, int bs, int16_t *coeff, int16_t *tmp, int n, int is_dst)
+// Every stage is out[k][j] = sat16((sum_i B[k][i] * in[j][i] + rnd) >> shift) with both operand rows contiguous: a lane keeps "its" input
+// row in registers as packed pairs and walks the basis rows with 16-byte loads and two-way dot products (v_dot2_i32_i16 on the device).
+// The sums are exact in 32 bits (<= 32 products of 16-bit values), so the order of accumulation does not matter.
+HENC_INLINE int32_t dot2_acc(int32_t a, int32_t b, int32_t c)
 {
-	const int l = ilog2i(n);
-	const int16_t *M = (n == 4 && is_dst) ? T->dst4 : T->dct[l - 2];
-	{
-		const int shift = l - 1, rnd = shift > 0 ? 1 << (shift - 1) : 0;
-		for (int o = g.tid; o < n * n; o += g.n) {
-			const int k = o >> l, j = o & (n - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+	typedef short short2_t __attribute__((ext_vector_type(2)));
+	return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), c, false);
+#else
+	return c + (int32_t)(int16_t)(a & 0xffff) * (int32_t)(int16_t)(b & 0xffff) + (int32_t)(int16_t)(a >> 16) * (int32_t)(int16_t)(b >> 16);
+#endif
+}
+HENC_INLINE int32_t pack_pair(int lo, int hi) { return (int32_t)(((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16)); }
+// N 16-bit values from an address that is a multiple of 2N bytes (at most 16) -> N / 2 packed pairs
+template <int N>
+HENC_INLINE void load_pairs(const int16_t *p, int32_t (&r)[N / 2])
+{
+	__builtin_memcpy(r, __builtin_assume_aligned(p, N >= 8 ? 16 : 8), N * 2);
+}
+
+// one stage with the input row held by the lane: in[j][0..N) contiguous at in + j * is
+template <int N, class G>
+HENC_HD void tr_stage_rows(const G &g, const int16_t *B, const int16_t *in, int is, int16_t *out, int os_k, int os_j, int shift)
+{
+	constexpr int H = N / 2;
+	const int rnd = shift > 0 ? 1 << (shift - 1) : 0;
+	if (G::n % N == 0) {
+		const int j = g.tid % N;
+		int32_t row[H], m[H];
+		load_pairs<N>(in + j * is, row);
+#pragma unroll 4
+		for (int k = g.tid / N; k < N; k += (G::n / N ? G::n / N : 1)) {
+			load_pairs<N>(B + k * N, m);
 			int32_t s = 0;
-			for (int i = 0; i < n; i++) s += M[k * n + i] * block[j * bs + i];
-			tmp[k * n + j] = sat16((s + rnd) >> shift);
+#pragma unroll
+			for (int h = 0; h < H; h++) s = dot2_acc(m[h], row[h], s);
+			out[k * os_k + j * os_j] = sat16((s + rnd) >> shift);
+		}
+	} else {
+		for (int o = g.tid; o < N * N; o += G::n) {
+			const int j = o % N, k = o / N;
+			int32_t row[H], m[H];
+			load_pairs<N>(in + j * is, row);
+			load_pairs<N>(B + k * N, m);
+			int32_t s = 0;
+			for (int h = 0; h < H; h++) s = dot2_acc(m[h], row[h], s);
+			out[k * os_k + j * os_j] = sat16((s + rnd) >> shift);
 		}
 	}
+}
+// the same with the input COLUMN j of a linear N x N array (first inverse stage: the levels come row-major)
+template <int N, class G>
+HENC_HD void tr_stage_cols(const G &g, const int16_t *B, const int16_t *in, int16_t *out, int shift)
+{
+	constexpr int H = N / 2;
+	const int rnd = 1 << (shift - 1);
+	const int step = G::n % N == 0 ? G::n : 1;                   // lanes keep their column when the group is a multiple of N wide
+	for (int o = g.tid; o < N * N; o += step) {
+		const int j = o % N;
+		int32_t col[H], m[H];
+#pragma unroll
+		for (int h = 0; h < H; h++) col[h] = pack_pair(in[(2 * h) * N + j], in[(2 * h + 1) * N + j]);
+#pragma unroll 4
+		for (int k = o / N; k < N; k += (G::n % N == 0 ? G::n / N : N)) {
+			load_pairs<N>(B + k * N, m);
+			int32_t s = 0;
+#pragma unroll
+			for (int h = 0; h < H; h++) s = dot2_acc(m[h], col[h], s);
+			out[k * N + j] = sat16((s + rnd) >> shift);
+		}
+		if (G::n % N == 0) break;
+	}
+}
+
+template <int N, class G>
+HENC_HD void tr_forward_n(const G &g, const int16_t *M, const int16_t *block, int bs, int16_t *coeff, int16_t *tmp)
+{
+	constexpr int L = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+	tr_stage_rows<N>(g, M, block, bs, tmp, N, 1, L - 1);     // tmp[k][j] = sum_i M[k][i] * block[j][i]
 	g.sync();
-	{
-		const int shift = l + 6, rnd = 1 << (shift - 1);
-		for (int o = g.tid; o < n * n; o += g.n) {
-			const int k = o >> l, j = o & (n - 1);
-			int32_t s = 0;
-			for (int i = 0; i < n; i++) s += M[k * n + i] * tmp[j * n + i];
-			coeff[k * n + j] = sat16((s + rnd) >> shift);
-		}
-	}
+	tr_stage_rows<N>(g, M, tmp, N, coeff, N, 1, L + 6);      // coeff[k][j] = sum_i M[k][i] * tmp[j][i]
+	g.sync();
+}
+template <int N, class G>
+HENC_HD void tr_inverse_n(const G &g, const int16_t *Mt, int16_t *block, int bs, const int16_t *coeff, int16_t *tmp)
+{
+	tr_stage_cols<N>(g, Mt, coeff, tmp, 7);                   // tmp[k][j] = sum_i M[i][k] * coeff[i][j]  (the reference's tmp, transposed)
+	g.sync();
+	tr_stage_rows<N>(g, Mt, tmp, N, block, 1, bs, 12);        // block[j][k] = sum_i M[i][k] * tmp[k'= i][j]
 	g.sync();
 }
 
 template <class G>
-HENC_HD void tr_inverse(const G &g, const DevTables *T, int16_t *block, int bs, const int16_t *coeff, int16_t *tmp, int n, int is_dst)
+HENC_PRIM void tr_forward(const G &g, const DevTables *T, const int16_t *block, int bs, int16_t *coeff, int16_t *tmp, int n, int is_dst)
 {
-	const int l = ilog2i(n);
-	const int16_t *M = (n == 4 && is_dst) ? T->dst4 : T->dct[l - 2];
-	for (int o = g.tid; o < n * n; o += g.n) {
-		const int j = o >> l, k = o & (n - 1);
-		int32_t s = 0;
-		for (int i = 0; i < n; i++) s += M[i * n + k] * coeff[i * n + j];
-		tmp[j * n + k] = sat16((s + 64) >> 7);
+	PRIM_T0();
+	switch (n) {
+	case 4: tr_forward_n<4>(g, is_dst ? T->dst4 : T->dct[0], block, bs, coeff, tmp); break;
+	case 8: tr_forward_n<8>(g, T->dct[1], block, bs, coeff, tmp); break;
+	case 16: tr_forward_n<16>(g, T->dct[2], block, bs, coeff, tmp); break;
+	default: tr_forward_n<32>(g, T->dct[3], block, bs, coeff, tmp); break;
 	}
-	g.sync();
-	for (int o = g.tid; o < n * n; o += g.n) {
-		const int j = o >> l, k = o & (n - 1);
-		int32_t s = 0;
-		for (int i = 0; i < n; i++) s += M[i * n + k] * tmp[i * n + j];
-		block[j * bs + k] = sat16((s + 2048) >> 12);
+	PRIM_END(PP_TRF);
+}
+
+template <class G>
+HENC_PRIM void tr_inverse(const G &g, const DevTables *T, int16_t *block, int bs, const int16_t *coeff, int16_t *tmp, int n, int is_dst)
+{
+	PRIM_T0();
+	switch (n) {
+	case 4: tr_inverse_n<4>(g, is_dst ? T->dst4_t : T->dct_t[0], block, bs, coeff, tmp); break;
+	case 8: tr_inverse_n<8>(g, T->dct_t[1], block, bs, coeff, tmp); break;
+	case 16: tr_inverse_n<16>(g, T->dct_t[2], block, bs, coeff, tmp); break;
+	default: tr_inverse_n<32>(g, T->dct_t[3], block, bs, coeff, tmp); break;
 	}
-	g.sync();
+	PRIM_END(PP_TRI);
 }
 
 // ---- quantisation (hmr_sse42_functions_quant.c:34-131 + sign_bit_hidding hmr_quant.c:61-169; inverse :135-246) -------
-// sign hiding of one 16-coefficient group, the reference's walk taken literally
-HENC_INLINE void sbh_group(int16_t *dst, const int16_t *src, const int16_t *du, const uint32_t *scan, int cg, bool is_last_cg)
+// sign hiding of one 16-coefficient group (sign_bit_hidding, hmr_quant.c:61-169).  The group's positions, levels, source coefficients and
+// rounding remainders are gathered first (independent loads), the reference's walk then runs on them with fixed trip counts:
+//   first / last non-zero level in scan order, the parity test, and the search for the cheapest +-1 change from the start position down
+//   to 0 (strict "<" on a descending walk = the LARGEST position wins ties, hence "<=" on the ascending loop here).
+struct SbhGroup {
+	uint32_t pos[16];
+	int16_t lv[16], sv[16], du[16];
+};
+HENC_INLINE bool sbh_gather(SbhGroup &q, const int16_t *dst, const int16_t *src, const int16_t *du, const uint32_t *scan, int cg)
 {
-	const int sub_pos = cg << 4;
-	int first_nz = 16, last_nz = -1, abs_sum = 0;
-	for (int n = 15; n >= 0; --n)
-		if (dst[scan[n + sub_pos]]) { last_nz = n; break; }
+	int any = 0;
+#pragma unroll
+	for (int n = 0; n < 16; n++) q.pos[n] = scan[(cg << 4) + n];
+#pragma unroll
+	for (int n = 0; n < 16; n++) { q.lv[n] = dst[q.pos[n]]; q.sv[n] = src[q.pos[n]]; q.du[n] = du[q.pos[n]]; any |= q.lv[n]; }
+	return any != 0;
+}
+HENC_INLINE void sbh_apply(const SbhGroup &q, int16_t *dst, bool is_last_cg)
+{
+	int first_nz = 16, last_nz = -1, abs_sum = 0, first_val = 0;
+#pragma unroll
 	for (int n = 0; n < 16; n++)
-		if (dst[scan[n + sub_pos]]) { first_nz = n; break; }
+		if (q.lv[n]) last_nz = n;
+#pragma unroll
+	for (int n = 15; n >= 0; --n)
+		if (q.lv[n]) { first_nz = n; first_val = q.lv[n]; }
 	if (last_nz - first_nz < 4) return;
-	for (int n = first_nz; n <= last_nz; n++) abs_sum += dst[scan[n + sub_pos]];
-	const unsigned signbit = dst[scan[sub_pos + first_nz]] > 0 ? 0 : 1;
+#pragma unroll
+	for (int n = 0; n < 16; n++) abs_sum += q.lv[n];          // zero outside first_nz..last_nz
+	const unsigned signbit = first_val > 0 ? 0 : 1;
 	if (signbit == (unsigned)(abs_sum & 1)) return;
-	int min_cost = 0x7fffffff, min_pos = -1, final_change = 0, cur_cost = 0x7fffffff, cur_change = 0;
-	for (int n = (is_last_cg ? last_nz : 15); n >= 0; --n) {
-		const unsigned pos = scan[n + sub_pos];
-		if (dst[pos] != 0) {
-			if (du[pos] > 0) { cur_cost = -du[pos]; cur_change = 1; }
-			else if (n == first_nz && habs(dst[pos]) == 1) cur_cost = 0x7fffffff;
-			else { cur_cost = du[pos]; cur_change = -1; }
+	const int start = is_last_cg ? last_nz : 15;
+	int min_cost = 0x7fffffff, min_n = -1, final_change = 0;
+	uint32_t min_pos = 0;
+	int min_lv = 0, min_sv = 0;
+#pragma unroll
+	for (int n = 0; n < 16; n++) {
+		if (n > start) continue;
+		int cur_cost, cur_change = 0;
+		if (q.lv[n] != 0) {
+			if (q.du[n] > 0) { cur_cost = -q.du[n]; cur_change = 1; }
+			else if (n == first_nz && habs((int)q.lv[n]) == 1) cur_cost = 0x7fffffff;
+			else { cur_cost = q.du[n]; cur_change = -1; }
 		} else if (n < first_nz) {
-			const unsigned this_sign = src[pos] >= 0 ? 0 : 1;
+			const unsigned this_sign = q.sv[n] >= 0 ? 0 : 1;
 			if (this_sign != signbit) cur_cost = 0x7fffffff;
-			else { cur_cost = -du[pos]; cur_change = 1; }
-		} else { cur_cost = -du[pos]; cur_change = 1; }
-		if (cur_cost < min_cost) { min_cost = cur_cost; final_change = cur_change; min_pos = (int)pos; }
+			else { cur_cost = -q.du[n]; cur_change = 1; }
+		} else { cur_cost = -q.du[n]; cur_change = 1; }
+		// descending walk with "<": a position replaces the running minimum only when strictly cheaper, so among equals the largest n stays;
+		// 0x7fffffff never replaces anything (the initial minimum is 0x7fffffff too)
+		if (cur_cost != 0x7fffffff && cur_cost <= min_cost) { min_cost = cur_cost; final_change = cur_change; min_n = n; min_pos = q.pos[n]; min_lv = q.lv[n]; min_sv = q.sv[n]; }
 	}
-	if (dst[min_pos] == 32767 || dst[min_pos] == -32768) final_change = -1;
-	if (src[min_pos] >= 0) dst[min_pos] = (int16_t)(dst[min_pos] + final_change);
-	else dst[min_pos] = (int16_t)(dst[min_pos] - final_change);
+	if (min_n < 0) return;   // cannot happen after the parity test (the reference would index with -1); kept as a guard
+	if (min_lv == 32767 || min_lv == -32768) final_change = -1;
+	dst[min_pos] = (int16_t)(min_sv >= 0 ? min_lv + final_change : min_lv - final_change);
 }
 
 // returns ac_sum (the sum of the levels BEFORE sign hiding, as the reference reports it)
 template <class G>
-HENC_HD int quantize(const G &g, const DevTables *T, const int16_t *src, int16_t *dst, int16_t *delta_u, int scan_mode, int depth, int comp,
+HENC_PRIM int quantize(const G &g, const DevTables *T, const int16_t *src, int16_t *dst, int16_t *delta_u, int scan_mode, int depth, int comp,
 		     int is_intra, int slice_is_intra, int sign_hiding, int n, int per, int rem)
 {
+	PRIM_T0();
 	const int inv_depth = 6 - (depth + (comp != 0));
 	const int32_t *q = T->quant[inv_depth - 2][(is_intra ? 0 : 3) + comp][rem];
 	const int qbits = 14 + per + (15 - 8 - inv_depth), qbits8 = qbits - 8;
 	const int32_t add = (int32_t)((uint32_t)(slice_is_intra ? 171 : 85) << (qbits - 9));
 	const int total = n * n;
 	uint32_t sum = 0;
+	#pragma unroll 4
 	for (int i = g.tid; i < total; i += g.n) {
 		const int sv = src[i];
 		const uint32_t a = (uint16_t)(sv < 0 ? -sv : sv);
@@ -513,23 +650,31 @@ HENC_HD int quantize(const G &g, const DevTables *T, const int16_t *src, int16_t
 		const uint32_t *scan = T->scan[scan_mode][inv_depth];
 		const int ngroups = total >> 4;
 		// the last group holding a level (in scan order) starts its walk at its last level
-		uint64_t key = ~0ull;
-		for (int cg = g.tid; cg < ngroups; cg += g.n) {
-			bool nz = false;
-			for (int k = 0; k < 16; k++) nz |= dst[scan[cg * 16 + k]] != 0;
-			if (nz) key = hmin(key, (uint64_t)(ngroups - 1 - cg));
+		if (G::n >= 64) {
+			// one group per lane: gather once, find the last non-empty group with a ballot, apply where there is anything to hide a sign in
+			SbhGroup q;
+			const int cg = g.tid;
+			const bool nz = cg < ngroups && sbh_gather(q, dst, src, delta_u, scan, cg);
+			const uint64_t mask = g.ballot(nz);
+			const int last_cg = mask ? 63 - __builtin_clzll(mask) : -1;
+			if (nz) sbh_apply(q, dst, cg == last_cg);
+		} else {
+			SbhGroup q;
+			int last_cg = -1;
+			for (int cg = g.tid; cg < ngroups; cg += g.n)
+				if (sbh_gather(q, dst, src, delta_u, scan, cg)) last_cg = cg;
+			for (int cg = g.tid; cg < ngroups; cg += g.n)
+				if (sbh_gather(q, dst, src, delta_u, scan, cg)) sbh_apply(q, dst, cg == last_cg);
 		}
-		key = g.min64(key);
-		const int last_cg = key == ~0ull ? -1 : ngroups - 1 - (int)key;
-		for (int cg = g.tid; cg < ngroups; cg += g.n) sbh_group(dst, src, delta_u, scan, cg, cg == last_cg);
 		g.sync();
 	}
-	return ac_sum;
+	{ const auto prim_ret_ = ac_sum; PRIM_END(PP_QUANT); return prim_ret_; }
 }
 
 template <class G>
-HENC_HD void dequantize(const G &g, const DevTables *T, const int16_t *src, int16_t *dst, int depth, int comp, int is_intra, int n, int per, int rem)
+HENC_PRIM void dequantize(const G &g, const DevTables *T, const int16_t *src, int16_t *dst, int depth, int comp, int is_intra, int n, int per, int rem)
 {
+	PRIM_T0();
 	const int inv_depth = 6 - (depth + (comp != 0));
 	const int32_t *iq = T->dequant[inv_depth - 2][is_intra ? 0 : 3 + comp][rem];
 	const int iq_shift = 20 - 14 - (15 - 8 - inv_depth) + 4, total = n * n;
@@ -542,6 +687,7 @@ HENC_HD void dequantize(const G &g, const DevTables *T, const int16_t *src, int1
 		for (int i = g.tid; i < total; i += g.n) dst[i] = sat16((int32_t)(((uint32_t)(int32_t)src[i] * (uint32_t)iq[i]) << sh));
 	}
 	g.sync();
+	PRIM_END(PP_DEQUANT);
 }
 
 HENC_INLINE int chroma_qp_table(int qpi)   // chroma_scale_conversion_table, hmr_encoder_lib.c:2245

@@ -51,7 +51,13 @@ __device__ __forceinline__ void wave_copy_words(void *dst, const void *src, int 
 
 // LDS of a row worker: its Work, a copy of the CTU's partition nodes and of the partition geometry
 constexpr size_t LDS_WORK = (sizeof(Work) + 15) & ~(size_t)15, LDS_NODES = (sizeof(Node) * NNODES + 15) & ~(size_t)15, LDS_GEO = (sizeof(Geo) * NNODES + 15) & ~(size_t)15;
-constexpr size_t LDS_BYTES = LDS_WORK + LDS_NODES + LDS_GEO;
+constexpr size_t LDS_SEQ = (sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15;
+#if defined(HENC_PROFILE)
+constexpr size_t LDS_BYTES = 160 * 1024;   // the primitive timers sit at HENC_LDS_PROF_OFFSET
+static_assert(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ <= HENC_LDS_PROF_OFFSET, "profile table overlaps the worker state");
+#else
+constexpr size_t LDS_BYTES = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ;
+#endif
 static_assert(LDS_BYTES <= 160 * 1024, "a workgroup has 160 KiB of LDS on gfx950");
 
 __global__ __launch_bounds__(64) void k_encode_ctus(EncDev d, int pass)
@@ -65,11 +71,19 @@ __global__ __launch_bounds__(64) void k_encode_ctus(EncDev d, int pass)
 	for (int i = g.tid; i < (int)(LDS_WORK / 4); i += 64) ((uint32_t *)lds)[i] = 0;
 	for (int i = g.tid; i < (int)(sizeof(Geo) * NNODES / 2); i += 64) ((uint16_t *)lgeo)[i] = ((const uint16_t *)d.geo)[i];
 	__syncthreads();
+	// the sequence and frame parameters are read all through the control code: a copy next to the worker
+	Seq *lseq = (Seq *)(lds + LDS_WORK + LDS_NODES + LDS_GEO);
+	FrameCtx *lframe = (FrameCtx *)((uint8_t *)lseq + ((sizeof(Seq) + 15) & ~(size_t)15));
+	for (int i = g.tid; i < (int)(sizeof(Seq) / 4); i += 64) ((uint32_t *)lseq)[i] = ((const uint32_t *)d.seq)[i];
+	for (int i = g.tid; i < (int)(sizeof(FrameCtx) / 4); i += 64) ((uint32_t *)lframe)[i] = ((const uint32_t *)d.frame)[i];
 	if (g.tid == 0) lw->slow = d.work_slow + row;
+#if defined(HENC_PROFILE)
+	if (g.tid < 2 * PP_COUNT) ((unsigned long long *)(lds + HENC_LDS_PROF_OFFSET))[g.tid] = 0;
+#endif
 	__syncthreads();
 	Enc e;
-	e.seq = d.seq;
-	e.f = d.frame;
+	e.seq = lseq;
+	e.f = lframe;
 	e.T = d.tables;
 	e.geo = lgeo;
 	e.ctus = d.ctus;
@@ -117,7 +131,7 @@ __global__ __launch_bounds__(64) void k_encode_ctus(EncDev d, int pass)
 			encode_ctu(g, e, n);
 			encodes++;
 			wave_copy_words(d.outtok + (size_t)n * MODE_STATE_BYTES, e.w->intra_mode_buffs, MODE_STATE_BYTES, g.tid);
-			const unsigned long long h = sched_output_hash(g, S, *d.frame, d.ctus[n]);
+			const unsigned long long h = sched_output_hash(g, S, *lframe, d.ctus[n]);
 			if (g.tid == 0) { d.hash[n] = h; d.dirty[n] = 0; }
 			if (pass == 0) {
 				// the guesses further on: what this worker's buffers would hold if its own guesses were right
@@ -147,6 +161,12 @@ __global__ __launch_bounds__(64) void k_encode_ctus(EncDev d, int pass)
 		if (g.tid == 0) __hip_atomic_store(&d.progress[row], c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	if (g.tid == 0 && encodes) atomicAdd(&d.counters[1], encodes);
+#if defined(HENC_PROFILE)
+	if (g.tid == 0 && e.prof) {
+		const unsigned long long *pp = (const unsigned long long *)(lds + HENC_LDS_PROF_OFFSET);
+		for (int k = 0; k < 2 * PP_COUNT; k++) e.prof[PF_PRIM0 + k] += pp[k];
+	}
+#endif
 }
 
 // the true chains in raster order: threads 0..255 one unit column of the mode buffers each, thread 256 the intra counter
@@ -366,7 +386,7 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 {
 	if (!ctx || !cfg || !out) return HMR_GPU_ERR_ARG;
 	static_assert(sizeof(hmr_gpu_enc_cfg) == sizeof(HostCfg), "configuration layouts must match");
-	static_assert(offsetof(CtuInfo, n_spec_reads) % 4 == 0 && sizeof(Node) % 4 == 0 && sizeof(Geo) % 2 == 0 && MODE_STATE_BYTES % 4 == 0, "word copies");
+	static_assert(offsetof(CtuInfo, n_spec_reads) % 4 == 0 && sizeof(Node) % 4 == 0 && sizeof(Geo) % 2 == 0 && sizeof(Seq) % 4 == 0 && sizeof(FrameCtx) % 4 == 0 && MODE_STATE_BYTES % 4 == 0, "word copies");
 	hmr_gpu_enc *e = new hmr_gpu_enc();
 	e->ctx = ctx;
 	memcpy(&e->cfg, cfg, sizeof(HostCfg));

@@ -18,6 +18,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import encoder_cases as ec  # noqa: E402
 
 PHASES = ["setup", "merge", "me_int", "me_sub(+int)", "pred_inter", "enc_inter", "intra_search", "intra_luma(+search)", "intra_chroma", "consolidate", "wait", "total"]
+PRIMS = ["sad", "ssd", "blk(copy/predict/reconst)", "fill_refs", "adi_filter", "intra_pred", "interp", "tr_fwd", "tr_inv", "quant", "dequant"]
+NCOL = 12 + 2 * len(PRIMS) + 2
 
 
 def main():
@@ -46,7 +48,7 @@ def main():
     enc = C.c_void_p()
     assert lib.hmr_gpu_enc_create(ctx, C.byref(cfg), C.byref(enc)) == 0, lib.hmr_gpu_last_error()
     recs = C.create_string_buffer(ec.REC * nx * ny)
-    prof = (C.c_ulonglong * (ny * 12))()
+    prof = (C.c_ulonglong * (ny * NCOL))()
     ysz = w * h
     report = {"width": w, "height": h, "frames": []}
     for f, planes in enumerate(ec.clip_frames(w, h, frames)):
@@ -58,11 +60,17 @@ def main():
         assert st > 0, lib.hmr_gpu_last_error()
         ms = lib.hmr_gpu_enc_last_ctu_ms(enc)
         lib.hmr_gpu_enc_profile(enc, prof, 1)
-        p = np.array(list(prof), dtype=np.float64).reshape(ny, 12) / 100e6 * 1e3   # s_memtime: 100 MHz -> ms
+        raw = np.array(list(prof), dtype=np.float64).reshape(ny, NCOL)
+        p = raw[:, :12] / 100e6 * 1e3   # nominal 100 MHz -> "ms" (the tick is the shader clock on this part: use the shares)
         entry = {"frame": f, "slice": st, "ctu_kernel_ms": round(ms, 3), "ms_per_ctu_step": round(ms / (nx + 2 * (ny - 1)), 3)}
         if p.sum() > 0:
             entry["phase_ms_sum_over_rows"] = {PHASES[k]: round(float(p[:, k].sum()), 2) for k in range(12)}
             entry["busiest_row_ms"] = {PHASES[k]: round(float(p[:, k].max()), 2) for k in range(12)}
+        if raw[:, 12:].sum() > 0:
+            tot = raw[:, 11].sum()
+            entry["primitives"] = {PRIMS[k]: {"share_of_total": round(float(raw[:, 12 + k].sum() / tot), 4), "calls": int(raw[:, 12 + len(PRIMS) + k].sum()),
+                                              "ticks_per_call": round(float(raw[:, 12 + k].sum() / max(raw[:, 12 + len(PRIMS) + k].sum(), 1)), 1)} for k in range(len(PRIMS))}
+            entry["phase_share_of_total"] = {PHASES[k]: round(float(raw[:, k].sum() / tot), 4) for k in range(11)}
         if fx is not None:
             bad = ec.check_frame_against_fixture(fx, f, recs.raw, w, h)
             entry["mismatches"] = len(bad)
