@@ -122,6 +122,33 @@ def multi_stream(lib, device, width, height, keys, streams, warmup, steps):
             "note": f"{streams} independent {width}x{height} sequences concurrently on one GPU, {steps} timed frames each after {warmup} warm-up frames"}
 
 
+def measure(step, warmup, nframes, world, device_sync, device):
+    """The timing contract: `warmup` untimed steps, then steps warmup..nframes-1 bracketed by a barrier + device synchronisation on both sides;
+    returns the wall time, MAX over the ranks.  step(f) encodes frame f.  (tests/test_bench_gloo.py runs this with world 2 on gloo.)"""
+    import torch
+    import torch.distributed as dist
+
+    def fence():
+        device_sync()
+        if world > 1:
+            dist.barrier()
+        device_sync()
+
+    for f in range(warmup):
+        step(f)
+    fence()
+    t0 = time.perf_counter()
+    for f in range(warmup, nframes):
+        step(f)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,24 +193,7 @@ def main():
         lib.hmr_gpu_enc_last_stats(enc, C.byref(p), C.byref(n), C.byref(ms), C.byref(tot))
         stats.append((f, st, nbytes.value, p.value, n.value, ms.value, tot.value))
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for f in range(a.warmup):
-        step(f)
-    fence()
-    t0 = time.perf_counter()
-    for f in range(a.warmup, nframes):
-        step(f)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = measure(step, a.warmup, nframes, world, torch.cuda.synchronize, "cuda")
     lib.hmr_gpu_enc_destroy(enc)
 
     if rank == 0:

@@ -5,6 +5,32 @@
 
 static hmr_gpu_ctx *g_default = nullptr;
 
+static std::recursive_mutex g_default_mutex;   // guards g_default (recursive: a failing create under hmr_default_ctx destroys its context)
+
+static int ctx_init(hmr_gpu_ctx *c, void *stream)
+{
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+	c->num_cus = prop.multiProcessorCount;
+	if (stream) {
+		c->stream = (hipStream_t)stream;
+		c->owns_stream = false;
+	} else {
+		HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+		c->owns_stream = true;
+	}
+	HIP_TRY(hipEventCreate(&c->ev0));
+	HIP_TRY(hipEventCreate(&c->ev1));
+	HIP_TRY(hipMalloc((void **)&c->tables, sizeof(DevTables)));
+	HIP_TRY(hipMemcpy(c->tables, hmr_host_tables(), sizeof(DevTables), hipMemcpyHostToDevice));
+	c->stage_bytes = 64u << 20;   // largest drop-in operand: a whole 2160p picture going through sse_copy_8_16 (8 MB in, 17 MB out)
+	HIP_TRY(hipHostMalloc((void **)&c->h_stage, c->stage_bytes, hipHostMallocDefault));
+	HIP_TRY(hipMalloc((void **)&c->d_stage, c->stage_bytes));
+	return HMR_GPU_OK;
+}
+
+extern "C" void hmr_gpu_destroy(hmr_gpu_ctx *c);
+
 extern "C" int hmr_gpu_create(hmr_gpu_ctx **out, int device, void *stream)
 {
 	if (!out) return HMR_GPU_ERR_ARG;
@@ -21,23 +47,11 @@ extern "C" int hmr_gpu_create(hmr_gpu_ctx **out, int device, void *stream)
 	hmr_gpu_ctx *c = new hmr_gpu_ctx();
 	memset(c, 0, sizeof *c);
 	c->device = device;
-	hipDeviceProp_t prop;
-	HIP_TRY(hipGetDeviceProperties(&prop, device));
-	c->num_cus = prop.multiProcessorCount;
-	if (stream) {
-		c->stream = (hipStream_t)stream;
-		c->owns_stream = false;
-	} else {
-		HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-		c->owns_stream = true;
+	const int rc = ctx_init(c, stream);
+	if (rc != HMR_GPU_OK) {
+		hmr_gpu_destroy(c);   // releases whatever was created before the failing call
+		return rc;
 	}
-	HIP_TRY(hipEventCreate(&c->ev0));
-	HIP_TRY(hipEventCreate(&c->ev1));
-	HIP_TRY(hipMalloc((void **)&c->tables, sizeof(DevTables)));
-	HIP_TRY(hipMemcpy(c->tables, hmr_host_tables(), sizeof(DevTables), hipMemcpyHostToDevice));
-	c->stage_bytes = 64u << 20;   // largest drop-in operand: a whole 2160p picture going through sse_copy_8_16 (8 MB in, 17 MB out)
-	HIP_TRY(hipHostMalloc((void **)&c->h_stage, c->stage_bytes, hipHostMallocDefault));
-	HIP_TRY(hipMalloc((void **)&c->d_stage, c->stage_bytes));
 	*out = c;
 	return HMR_GPU_OK;
 }
@@ -45,20 +59,24 @@ extern "C" int hmr_gpu_create(hmr_gpu_ctx **out, int device, void *stream)
 extern "C" void hmr_gpu_destroy(hmr_gpu_ctx *c)
 {
 	if (!c) return;
-	if (g_default == c) g_default = nullptr;
+	{
+		std::lock_guard<std::recursive_mutex> guard(g_default_mutex);
+		if (g_default == c) g_default = nullptr;
+	}
 	(void)hipSetDevice(c->device);
-	(void)hipStreamSynchronize(c->stream);
-	(void)hipFree(c->tables);
-	(void)hipFree(c->d_stage);
-	(void)hipHostFree(c->h_stage);
-	(void)hipEventDestroy(c->ev0);
-	(void)hipEventDestroy(c->ev1);
-	if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	if (c->tables) (void)hipFree(c->tables);
+	if (c->d_stage) (void)hipFree(c->d_stage);
+	if (c->h_stage) (void)hipHostFree(c->h_stage);
+	if (c->ev0) (void)hipEventDestroy(c->ev0);
+	if (c->ev1) (void)hipEventDestroy(c->ev1);
+	if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
 
 extern "C" int hmr_gpu_set_default(hmr_gpu_ctx *ctx)
 {
+	std::lock_guard<std::recursive_mutex> guard(g_default_mutex);
 	g_default = ctx;
 	return HMR_GPU_OK;
 }
@@ -66,8 +84,7 @@ extern "C" int hmr_gpu_set_default(hmr_gpu_ctx *ctx)
 // default context for the drop-in entries: created on first use on device 0
 hmr_gpu_ctx *hmr_default_ctx()
 {
-	static std::mutex m;
-	std::lock_guard<std::mutex> guard(m);
+	std::lock_guard<std::recursive_mutex> guard(g_default_mutex);
 	if (!g_default) {
 		hmr_gpu_ctx *c = nullptr;
 		if (hmr_gpu_create(&c, 0, nullptr) != HMR_GPU_OK) {

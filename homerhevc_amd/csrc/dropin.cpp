@@ -19,7 +19,12 @@ struct Stager {
 	std::unique_lock<std::recursive_mutex> lock{g_dropin_mutex};
 	hmr_gpu_ctx *c;
 	size_t in_end = 0, out_begin = 0, out_end = 0;
-	explicit Stager(hmr_gpu_ctx *ctx) : c(ctx) { in_end = align(sizeof(hmr_gpu_job)); }
+	explicit Stager(hmr_gpu_ctx *ctx) : c(ctx)
+	{
+		// the reference's WPP / engine threads have device 0 current; the context may live on another GPU (one engine per GPU)
+		(void)hipSetDevice(c->device);
+		in_end = align(sizeof(hmr_gpu_job));
+	}
 	static size_t align(size_t v) { return (v + 63) & ~(size_t)63; }
 	hmr_gpu_job *job() { return (hmr_gpu_job *)c->h_stage; }
 	void check(size_t end)

@@ -68,6 +68,15 @@ OFF_TABLE = {
 }
 
 
+def _pointer_safe(f):
+    """The off-table entries have long mixed argument lists (include/homer_gpu.h) and no argtypes here: without them ctypes passes a bare Python
+    int as a C int, which would cut a 64-bit address to 32 bits.  Addresses given as plain ints are therefore wrapped as pointers."""
+    def call(*args):
+        return f(*[C.c_void_p(a) if isinstance(a, int) and not isinstance(a, bool) and (a > 0x7fffffff or a < -0x80000000) else a for a in args])
+    call.__name__ = getattr(f, "__name__", "off_table_entry")
+    return call
+
+
 class LowLevelFuncs:
     """The function table, populated the way HOMER_enc_init populates hvenc->funcs; the off-table functions are attributes under the
     reference's own symbol names."""
@@ -82,4 +91,4 @@ class LowLevelFuncs:
         for name, (sym, restype) in OFF_TABLE.items():
             f = getattr(self.lib, sym)
             f.restype = restype
-            setattr(self, name, f)
+            setattr(self, name, _pointer_safe(f))
