@@ -30,7 +30,9 @@ struct Enc {
 	const DevTables *T;
 	const Geo *geo;
 	CtuInfo *ctus;         // all CTUs of the picture (persistent across frames)
-	CtuInfo *ctu;          // the CTU being encoded
+	CtuPublic *ctu;        // the side-info record of the CTU being encoded: ctu_g's, or the worker's fast copy of it (ctu_fast != nullptr) while the CTU is encoded
+	CtuInfo *ctu_g;        // its home in the picture array (logs, nodes; neighbours are ctu_g - 1, ctu_g - wctu ...)
+	CtuPublic *ctu_fast;
 	Work *w;
 	int16_t *coeff;        // the CTU's coefficient output: 4096 luma + 2 x 1024 chroma, linear per TU in z-order
 	// speculative inputs of a P-frame CTU (enc_ctu.h)
@@ -45,18 +47,18 @@ HENC_INLINE int node_at(const Enc &e, int depth, int position) { return e.seq->d
 
 // ---- neighbour partitions (hmr_arithmetic_encoding.c:229-355).  Return the CTU that holds the neighbour (nullptr when not
 // available) and its z-order unit index. -------------------------------------------------------------------------------
-HENC_INLINE CtuInfo *ctu_left_of(Enc &e) { return e.ctu->has_left ? e.ctu - 1 : nullptr; }
-HENC_INLINE CtuInfo *ctu_top_of(Enc &e) { return e.ctu->has_top ? e.ctu - e.seq->wctu : nullptr; }
-HENC_INLINE CtuInfo *ctu_top_right_of(Enc &e) { return e.ctu->has_top_right ? e.ctu - e.seq->wctu + 1 : nullptr; }
-HENC_INLINE CtuInfo *ctu_top_left_of(Enc &e) { return e.ctu->has_top_left ? e.ctu - e.seq->wctu - 1 : nullptr; }
+HENC_INLINE CtuPublic *ctu_left_of(Enc &e) { return e.ctu->has_left ? e.ctu_g - 1 : nullptr; }
+HENC_INLINE CtuPublic *ctu_top_of(Enc &e) { return e.ctu->has_top ? e.ctu_g - e.seq->wctu : nullptr; }
+HENC_INLINE CtuPublic *ctu_top_right_of(Enc &e) { return e.ctu->has_top_right ? e.ctu_g - e.seq->wctu + 1 : nullptr; }
+HENC_INLINE CtuPublic *ctu_top_left_of(Enc &e) { return e.ctu->has_top_left ? e.ctu_g - e.seq->wctu - 1 : nullptr; }
 
-HENC_INLINE CtuInfo *pu_left(Enc &e, int ni, uint32_t *idx)
+HENC_INLINE CtuPublic *pu_left(Enc &e, int ni, uint32_t *idx)
 {
 	const Geo &gq = e.geo[ni];
 	*idx = gq.abs_left;
 	return (gq.raster_index & 15) == 0 ? ctu_left_of(e) : e.ctu;
 }
-HENC_INLINE CtuInfo *pu_left_bottom(Enc &e, int ni, uint32_t *idx)
+HENC_INLINE CtuPublic *pu_left_bottom(Enc &e, int ni, uint32_t *idx)
 {
 	const Geo &gq = e.geo[ni];
 	if (!node_of(e, ni).left_bottom_nb) return nullptr;
@@ -67,14 +69,14 @@ HENC_INLINE CtuInfo *pu_left_bottom(Enc &e, int ni, uint32_t *idx)
 	if (gq.abs_index > gq.abs_left_bottom) return e.ctu;
 	return nullptr;
 }
-HENC_INLINE CtuInfo *pu_top(Enc &e, int ni, uint32_t *idx, int planar_at_ctu_boundary)
+HENC_INLINE CtuPublic *pu_top(Enc &e, int ni, uint32_t *idx, int planar_at_ctu_boundary)
 {
 	const Geo &gq = e.geo[ni];
 	*idx = gq.abs_top;
 	if (gq.raster_index < 16) return planar_at_ctu_boundary ? nullptr : ctu_top_of(e);
 	return e.ctu;
 }
-HENC_INLINE CtuInfo *pu_top_right(Enc &e, int ni, uint32_t *idx)
+HENC_INLINE CtuPublic *pu_top_right(Enc &e, int ni, uint32_t *idx)
 {
 	const Geo &gq = e.geo[ni];
 	if (!node_of(e, ni).top_right_nb) return nullptr;
@@ -85,7 +87,7 @@ HENC_INLINE CtuInfo *pu_top_right(Enc &e, int ni, uint32_t *idx)
 	if (gq.abs_index > gq.abs_top_right) return e.ctu;
 	return nullptr;
 }
-HENC_INLINE CtuInfo *pu_top_left(Enc &e, int ni, uint32_t *idx)
+HENC_INLINE CtuPublic *pu_top_left(Enc &e, int ni, uint32_t *idx)
 {
 	const Geo &gq = e.geo[ni];
 	*idx = gq.abs_top_left;
@@ -100,6 +102,7 @@ HENC_INLINE CtuInfo *pu_top_left(Enc &e, int ni, uint32_t *idx)
 template <class G>
 HENC_HD void sync_reference_buffs(const G &g, Enc &e, int ni, int src_wnd, int dst_wnd)
 {
+	PRIM_T0();
 	const Geo &q = e.geo[ni];
 	const int16_t *s = dec_ptr(*e.w, src_wnd, COMP_Y) + q.y * DEC_STRIDE_Y + q.x;
 	int16_t *d = dec_ptr(*e.w, dst_wnd, COMP_Y) + q.y * DEC_STRIDE_Y + q.x;
@@ -109,10 +112,12 @@ HENC_HD void sync_reference_buffs(const G &g, Enc &e, int ni, int src_wnd, int d
 		d[off] = s[off];
 	}
 	g.sync();
+	PRIM_END(PP_SYNC);
 }
 template <class G>
 HENC_HD void sync_reference_buffs_chroma(const G &g, Enc &e, int ni, int src_wnd, int dst_wnd)
 {
+	PRIM_T0();
 	const Geo &q = e.geo[ni];
 	const int n = q.size_chroma;
 	for (int c = COMP_U; c <= COMP_V; c++) {
@@ -124,11 +129,13 @@ HENC_HD void sync_reference_buffs_chroma(const G &g, Enc &e, int ni, int src_wnd
 		}
 	}
 	g.sync();
+	PRIM_END(PP_SYNC);
 }
 // whole CU: reconstruction (2-D) and levels (linear), one component
 template <class G>
 HENC_HD void sync_cu_comp(const G &g, Enc &e, int ni, int q_src, int q_dst, int d_src, int d_dst, int comp)
 {
+	PRIM_T0();
 	const Geo &q = e.geo[ni];
 	const int n = comp == COMP_Y ? q.size : q.size_chroma, x = comp == COMP_Y ? q.x : q.xc, y = comp == COMP_Y ? q.y : q.yc;
 	const int st = dec_stride(comp), off = comp == COMP_Y ? (q.abs_index << 4) : ((q.abs_index << 4) >> 2);
@@ -143,6 +150,7 @@ HENC_HD void sync_cu_comp(const G &g, Enc &e, int ni, int q_src, int q_dst, int 
 		qd[i] = qs[i];
 	}
 	g.sync();
+	PRIM_END(PP_SYNC);
 }
 template <class G>
 HENC_HD void sync_motion_buffers_luma(const G &g, Enc &e, int ni, int q_src, int q_dst, int d_src, int d_dst)

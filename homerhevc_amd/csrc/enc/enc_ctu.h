@@ -15,8 +15,9 @@ namespace henc {
 template <class G>
 HENC_HD void info_buffs_copy(const G &g, Enc &e, int depth, int abs_idx, int num, int to_ctu)
 {
+	PRIM_T0();
 	Work &w = *e.w;
-	CtuInfo &c = *e.ctu;
+	CtuPublic &c = *e.ctu;
 	for (int i = g.tid; i < num; i += g.n) {
 		const int k = abs_idx + i;
 		if (to_ctu) {
@@ -36,15 +37,17 @@ HENC_HD void info_buffs_copy(const G &g, Enc &e, int depth, int abs_idx, int num
 		}
 	}
 	g.sync();
+	PRIM_END(PP_INFO);
 }
 
 // SET_INTER_INFO_BUFFS :3309
 template <class G>
 HENC_HD void set_inter_info_buffs(const G &g, Enc &e, int ni)
 {
+	PRIM_T0();
 	const Geo &q = e.geo[ni];
 	const Node &nd = node_of(e, ni);
-	CtuInfo &c = *e.ctu;
+	CtuPublic &c = *e.ctu;
 	const int a = q.abs_index, n = q.num_part;
 	if (nd.prediction_mode == PM_INTER) {
 		for (int i = g.tid; i < n; i += g.n) {
@@ -68,6 +71,7 @@ HENC_HD void set_inter_info_buffs(const G &g, Enc &e, int ni)
 	}
 	for (int i = g.tid; i < n; i += g.n) c.pred_mode[a + i] = (uint8_t)nd.prediction_mode;
 	g.sync();
+	PRIM_END(PP_INFO);
 }
 
 // get_back_consolidated_info :3456 / put_consolidated_info :3472
@@ -92,7 +96,7 @@ HENC_HD void consolidate_prediction_info(const G &g, Enc &e, int pi, uint32_t pa
 {
 	const Geo &pq = e.geo[pi];
 	Node &pn = node_of(e, pi);
-	CtuInfo &c = *e.ctu;
+	CtuPublic &c = *e.ctu;
 	const int abs_index = pq.abs_index, num = pq.num_part, curr_depth = pq.depth + 1;
 	uint32_t children_sum = 0;
 	if (pq.child[0] >= 0)
@@ -184,7 +188,7 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &e, int depth, int position
 	const int ni = node_at(e, depth, position);
 	const Geo &q = e.geo[ni];
 	Node &nd = node_of(e, ni);
-	CtuInfo &c = *e.ctu;
+	CtuPublic &c = *e.ctu;
 	const int abs_index = q.abs_index, curr_depth = q.depth, n = q.size, nc = q.size_chroma;
 	const int gx = c.x + q.x, gy = c.y + q.y;
 	int merge_cand_buffer[5] = {0, 0, 0, 0, 0};
@@ -194,7 +198,7 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &e, int depth, int position
 	int best_ref_idx = 0;
 	uint8_t inter_modes[5] = {255, 255, 255, 255, 255};
 	const double weight = e.f->chroma_weight;
-	get_merge_candidates(e, ni, w.merge_cands, inter_modes);
+	{ PRIM_T0(); get_merge_candidates(e, ni, w.merge_cands, inter_modes); PRIM_END(PP_CAND); }
 	for (int cand = 0; cand < S.num_merge_cand; cand++) {
 		int mc_done = 0;
 		for (int no_res = 0; no_res < 2; no_res++) {
@@ -274,7 +278,7 @@ template <class G>
 HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &e)
 {
 	const Seq &S = *e.seq;
-	CtuInfo &c = *e.ctu;
+	CtuPublic &c = *e.ctu;
 	const double avg_distortion = e.f->avg_dist;
 	const int perf_min_depth = S.perf_min_depth, perf_fast_skip = S.perf_fast_skip;
 	int depth_state[NDEPTH] = {0, 0, 0, 0, 0};
@@ -371,11 +375,11 @@ HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &e)
 					intra_cost = intra_cost_with_ratio((double)intra_dist, ratio, add, rd);
 					const int take_intra = intra_cost < cost;
 					if (e.n_ratio_cmp < MAX_RATIO_CMP) {
-						double *lg = c.ratio_cmp + 4 * e.n_ratio_cmp;
+						double *lg = e.ctu_g->ratio_cmp + 4 * e.n_ratio_cmp;
 						lg[0] = (double)intra_dist; lg[1] = add; lg[2] = rd; lg[3] = cost;
-						c.ratio_out[e.n_ratio_cmp] = (uint8_t)take_intra;
-						c.ratio_slog[e.n_ratio_cmp] = (int16_t)e.last_slog;
-						if (e.last_slog >= 0) c.slog[e.last_slog].has_cmp = 1;
+						e.ctu_g->ratio_out[e.n_ratio_cmp] = (uint8_t)take_intra;
+						e.ctu_g->ratio_slog[e.n_ratio_cmp] = (int16_t)e.last_slog;
+						if (e.last_slog >= 0) e.ctu_g->slog[e.last_slog].has_cmp = 1;
 					}
 					e.n_ratio_cmp++;
 					HENC_TRACE("CU ctu=%d d=%d abs=%d intra: dist=%u cost=%.3f vs %.3f\n", c.ctu_number, curr_depth, q.abs_index, intra_dist, intra_cost, cost);
@@ -437,7 +441,7 @@ template <class G>
 HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &e)
 {
 	const Seq &S = *e.seq;
-	CtuInfo &c = *e.ctu;
+	CtuPublic &c = *e.ctu;
 	int depth_state[NDEPTH] = {0, 0, 0, 0, 0};
 	uint32_t cost_sum[NDEPTH] = {0, 0, 0, 0, 0};
 	int curr_depth = 0, parent = 0, curr = 0;
@@ -519,7 +523,7 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &e)
 HENC_INLINE void create_partition_neighbours(Enc &e)
 {
 	const Seq &S = *e.seq;
-	CtuInfo &c = *e.ctu;
+	CtuPublic &c = *e.ctu;
 	const int cu_min_tu_size_shift = hmax(S.max_cu_size_shift - (S.max_pred_depth + hmax(S.max_intra_tr_depth, S.max_inter_tr_depth) - 1), 2);
 	const int max_processing_depth = S.max_cu_size_shift - cu_min_tu_size_shift;
 	const int valid_lines = (c.y + 64) > S.height ? S.height - c.y : 64, valid_cols = (c.x + 64) > S.width ? S.width - c.x : 64;
@@ -569,15 +573,20 @@ HENC_INLINE void create_partition_neighbours(Enc &e)
 template <class G>
 HENC_HD void ctu_begin(const G &g, Enc &e, int ctu_num)
 {
+	PRIM_T0();
 	const Seq &S = *e.seq;
 	Work &w = *e.w;
-	e.ctu = e.ctus + ctu_num;
-	CtuInfo &c = *e.ctu;
-	// the partition nodes are read and written all through the walk: a worker with fast memory of its own works on a copy
+	e.ctu_g = e.ctus + ctu_num;
+	// the side-info record and the partition nodes are read and written all through the walk: a worker with fast memory of its own works on copies
+	if (e.ctu_fast) {
+		lin_copy_words(g, (const uint32_t *)(const CtuPublic *)e.ctu_g, (uint32_t *)e.ctu_fast, (int)(sizeof(CtuPublic) / 4));
+		e.ctu = e.ctu_fast;
+	} else e.ctu = e.ctu_g;
 	if (e.nodes_fast) {
-		lin_copy_words(g, (const uint32_t *)c.nodes, (uint32_t *)e.nodes_fast, (int)(sizeof(Node) * NNODES / 4));
+		lin_copy_words(g, (const uint32_t *)e.ctu_g->nodes, (uint32_t *)e.nodes_fast, (int)(sizeof(Node) * NNODES / 4));
 		e.nodes = e.nodes_fast;
-	} else e.nodes = c.nodes;
+	} else e.nodes = e.ctu_g->nodes;
+	CtuPublic &c = *e.ctu;
 	const int cx = ctu_num % S.wctu, cy = ctu_num / S.wctu;
 	c.ctu_number = ctu_num;
 	c.x = cx * 64;
@@ -629,15 +638,17 @@ HENC_HD void ctu_begin(const G &g, Enc &e, int ctu_num)
 		g.sync();
 	}
 	create_partition_neighbours(e);
+	PRIM_END(PP_CTU_IO);
 }
 
 // mem_transfer_decoded_blocks :312 + the coefficient copy (hmr_encoder_lib.c:2942-2945) + the thread counters (:2924-2940)
 template <class G>
 HENC_HD void ctu_end(const G &g, Enc &e)
 {
+	PRIM_T0();
 	const Seq &S = *e.seq;
 	Work &w = *e.w;
-	CtuInfo &c = *e.ctu;
+	CtuPublic &c = *e.ctu;
 	for (int comp = 0; comp < 3; comp++) {
 		const int sz = comp ? 32 : 64, px = comp ? c.x >> 1 : c.x, py = comp ? c.y >> 1 : c.y;
 		const int pw = comp ? S.width >> 1 : S.width, ph = comp ? S.height >> 1 : S.height;
@@ -653,15 +664,17 @@ HENC_HD void ctu_end(const G &g, Enc &e)
 	cnt = g.sum(cnt);
 	c.intra_parts = e.f->slice_type != SLICE_I && !e.f->is_scene_change ? cnt : NPART;
 	c.distortion = node_of(e, 0).distortion;
-	c.n_spec_reads = e.n_spec_reads;
-	c.n_ratio_cmp = e.n_ratio_cmp;
+	e.ctu_g->n_spec_reads = e.n_spec_reads;
+	e.ctu_g->n_ratio_cmp = e.n_ratio_cmp;
 	g.sync();
-	if (e.nodes_fast) lin_copy_words(g, (const uint32_t *)e.nodes_fast, (uint32_t *)c.nodes, (int)(sizeof(Node) * NNODES / 4));
+	if (e.ctu_fast) lin_copy_words(g, (const uint32_t *)e.ctu_fast, (uint32_t *)(CtuPublic *)e.ctu_g, (int)(sizeof(CtuPublic) / 4));
+	if (e.nodes_fast) lin_copy_words(g, (const uint32_t *)e.nodes_fast, (uint32_t *)e.ctu_g->nodes, (int)(sizeof(Node) * NNODES / 4));
+	PRIM_END(PP_CTU_IO);
 }
 
 // tokens -> values, for the worker buffers and the CTU's mode arrays, once the values behind the tokens (Work::mode_in) are the true ones
 template <class G>
-HENC_HD void resolve_mode_tokens(const G &g, Work &w, CtuInfo &c)
+HENC_HD void resolve_mode_tokens(const G &g, Work &w, CtuPublic &c)
 {
 	for (int i = g.tid; i < 2 * NDEPTH * NPART; i += g.n) {
 		uint8_t &v = (&w.intra_mode_buffs[0][0][0])[i];

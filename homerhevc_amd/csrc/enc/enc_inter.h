@@ -161,7 +161,7 @@ HENC_HD uint32_t motion_estimation(const G &g, Enc &e, const int16_t *orig, cons
 		int bidx = 0, bx = 0, by = 0;
 		best_x = mvx >> 2; best_y = mvy >> 2;
 		if (!(action & ME_PEL)) cur_sad = HENC_SAD_AT(best_x, best_y);
-		int16_t *sp = e.w->sub_out;
+		int16_t *sp = e.w->pred_aux;   // scratch: no TU is in flight during the search
 		for (int i = 0; i < 9; i++) {
 			const int cx = ref_h[i][0] * 2, cy = ref_h[i][1] * 2;
 			mc_luma(g, e, ref, rs, sp, 64, size, (best_x << 2) + cx, (best_y << 2) + cy);
@@ -215,7 +215,7 @@ HENC_INLINE CornerNodes corner_nodes(Enc &e, int ni)
 }
 // add_amvp_cand :2182 (one reference picture: list 0 index 0 is the only picture a neighbour can point to; the scaled variant
 // add_amvp_cand_order :2229 then adds the same unscaled vector under the same condition)
-HENC_INLINE int add_amvp_cand(MvCandList &l, CtuInfo *c, uint32_t idx)
+HENC_INLINE int add_amvp_cand(MvCandList &l, CtuPublic *c, uint32_t idx)
 {
 	if (c && c->mv_ref_idx[idx] >= 0) {
 		l.mv[l.num++] = c->mv_ref[idx];
@@ -228,7 +228,7 @@ HENC_INLINE void get_amvp_candidates(Enc &e, int ni, MvCandList &l)
 {
 	const CornerNodes cn = corner_nodes(e, ni);
 	uint32_t idx_lb = 0, idx_l = 0, idx_aux = 0;
-	CtuInfo *c_lb, *c_l = nullptr, *c_tr, *c_t, *c_tl;
+	CtuPublic *c_lb, *c_l = nullptr, *c_tr, *c_t, *c_tl;
 	l.num = 0;
 	node_of(e, cn.lb).left_bottom_nb = node_of(e, ni).left_bottom_nb;
 	c_lb = pu_left_bottom(e, cn.lb, &idx_lb);
@@ -279,7 +279,7 @@ HENC_INLINE void get_amvp_candidates(Enc &e, int ni, MvCandList &l)
 }
 
 // equal_motion :1913 (list 0 only carries vectors in P slices)
-HENC_INLINE int equal_motion(const CtuInfo *a, uint32_t ia, const CtuInfo *b, uint32_t ib)
+HENC_INLINE int equal_motion(const CtuPublic *a, uint32_t ia, const CtuPublic *b, uint32_t ib)
 {
 	if (a->inter_mode[ia] != b->inter_mode[ib]) return 0;
 	if (a->inter_mode[ia] & 1) {
@@ -296,7 +296,7 @@ HENC_INLINE void get_merge_candidates(Enc &e, int ni, MvCandList &l, uint8_t *in
 	int cnt = 0;
 	for (int k = 0; k < max_cand; k++) l.ref_idx[k] = -1;
 	l.num = 0;
-	CtuInfo *c_l = pu_left(e, cn.lb, &i_l);
+	CtuPublic *c_l = pu_left(e, cn.lb, &i_l);
 	const int a1 = c_l && c_l->pred_mode[i_l] != PM_INTRA;
 	if (a1) {
 		inter_modes[cnt] = c_l->inter_mode[i_l];
@@ -305,7 +305,7 @@ HENC_INLINE void get_merge_candidates(Enc &e, int ni, MvCandList &l, uint8_t *in
 		cnt++;
 	}
 	if (cnt >= max_cand) { l.num = cnt; return; }
-	CtuInfo *c_t = pu_top(e, cn.tr, &i_t, 0);
+	CtuPublic *c_t = pu_top(e, cn.tr, &i_t, 0);
 	const int b1 = c_t && c_t->pred_mode[i_t] != PM_INTRA;
 	if (b1 && (!a1 || !equal_motion(c_l, i_l, c_t, i_t))) {
 		inter_modes[cnt] = c_t->inter_mode[i_t];
@@ -315,7 +315,7 @@ HENC_INLINE void get_merge_candidates(Enc &e, int ni, MvCandList &l, uint8_t *in
 	}
 	if (cnt >= max_cand) { l.num = cnt; return; }
 	node_of(e, cn.tr).top_right_nb = node_of(e, ni).top_right_nb;
-	CtuInfo *c_tr = pu_top_right(e, cn.tr, &i_tr);
+	CtuPublic *c_tr = pu_top_right(e, cn.tr, &i_tr);
 	const int b0 = c_tr && c_tr->pred_mode[i_tr] != PM_INTRA;
 	if (b0 && (!b1 || !equal_motion(c_t, i_t, c_tr, i_tr))) {
 		inter_modes[cnt] = c_tr->inter_mode[i_tr];
@@ -325,7 +325,7 @@ HENC_INLINE void get_merge_candidates(Enc &e, int ni, MvCandList &l, uint8_t *in
 	}
 	if (cnt >= max_cand) { l.num = cnt; return; }
 	node_of(e, cn.lb).left_bottom_nb = node_of(e, ni).left_bottom_nb;
-	CtuInfo *c_lb = pu_left_bottom(e, cn.lb, &i_lb);
+	CtuPublic *c_lb = pu_left_bottom(e, cn.lb, &i_lb);
 	const int a0 = c_lb && c_lb->pred_mode[i_lb] != PM_INTRA;
 	if (a0 && (!a1 || !equal_motion(c_l, i_l, c_lb, i_lb))) {
 		inter_modes[cnt] = c_lb->inter_mode[i_lb];
@@ -335,7 +335,7 @@ HENC_INLINE void get_merge_candidates(Enc &e, int ni, MvCandList &l, uint8_t *in
 	}
 	if (cnt >= max_cand) { l.num = cnt; return; }
 	if (cnt < 4) {
-		CtuInfo *c_tl = pu_top_left(e, cn.tl, &i_tl);
+		CtuPublic *c_tl = pu_top_left(e, cn.tl, &i_tl);
 		const int b2 = c_tl && c_tl->pred_mode[i_tl] != PM_INTRA;
 		if (b2 && (!a1 || !equal_motion(c_l, i_l, c_tl, i_tl)) && (!b1 || !equal_motion(c_t, i_t, c_tl, i_tl))) {
 			inter_modes[cnt] = c_tl->inter_mode[i_tl];
@@ -600,7 +600,7 @@ HENC_HD int predict_inter(const G &g, Enc &e, int depth, int part_position, int 
 	for (int np = 0; np < num_partitions; np++, curr++) {
 		Node &nd = node_of(e, curr);
 		const MV mv = nd.inter_mv;
-		get_amvp_candidates(e, curr, e.w->amvp);
+		{ PRIM_T0(); get_amvp_candidates(e, curr, e.w->amvp); PRIM_END(PP_CAND); }
 		mv_cost += (int)mv_cost_sqrt(e.w->amvp, nd.qp, mv.x, mv.y, &nd.best_candidate_idx);
 		nd.best_dif_mv.x = mv.x - e.w->amvp.mv[nd.best_candidate_idx].x;
 		nd.best_dif_mv.y = mv.y - e.w->amvp.mv[nd.best_candidate_idx].y;
@@ -628,7 +628,7 @@ HENC_HD int cu_motion_estimation(const G &g, Enc &e, int depth, int part_positio
 		Node &nd = node_of(e, curr);
 		const int gx = e.ctu->x + q.x, gy = e.ctu->y + q.y;
 		MvCandList amvp;
-		get_amvp_candidates(e, curr, amvp);
+		{ PRIM_T0(); get_amvp_candidates(e, curr, amvp); PRIM_END(PP_CAND); }
 		w.search_cands.num = 0;
 		for (int i = 0; i < amvp.num; i++)
 			if (amvp.mv[i].x != 0 && amvp.mv[i].y != 0) w.search_cands.mv[w.search_cands.num++] = amvp.mv[i];

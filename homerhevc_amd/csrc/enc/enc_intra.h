@@ -72,12 +72,12 @@ HENC_INLINE void mpm_from_dirs(int left_dir, int top_dir, int *preds)
 HENC_INLINE void intra_neighbour_dirs(Enc &e, int ni, int depth, int *dirs, uint16_t *src)
 {
 	uint32_t idx = 0;
-	CtuInfo *cl = pu_left(e, ni, &idx);
+	CtuPublic *cl = pu_left(e, ni, &idx);
 	dirs[0] = dirs[1] = DC_IDX;
 	src[0] = src[1] = DC_IDX;
 	if (cl == e.ctu) dirs[0] = read_mode_buff(e, depth, idx, &src[0]);
 	else if (cl) src[0] = (uint16_t)(dirs[0] = cl->pred_mode[idx] == PM_INTRA ? cl->intra_mode[COMP_Y][idx] : DC_IDX);
-	CtuInfo *ct = pu_top(e, ni, &idx, 1);
+	CtuPublic *ct = pu_top(e, ni, &idx, 1);
 	if (ct == e.ctu) dirs[1] = read_mode_buff(e, depth, idx, &src[1]);
 	else if (ct) src[1] = (uint16_t)(dirs[1] = ct->pred_mode[idx] == PM_INTRA ? ct->intra_mode[COMP_Y][idx] : DC_IDX);
 }
@@ -135,7 +135,7 @@ HENC_HD int intra_mode_search(const G &g, Enc &e, int ni, int depth, int *best_m
 	e.last_slog = -1;
 	if (rd_fast && ((src[0] | src[1]) & 0x8000)) {
 		if (e.n_spec_reads < MAX_SEARCH_LOGS) {
-			lg = e.ctu->slog + e.n_spec_reads;
+			lg = e.ctu_g->slog + e.n_spec_reads;
 			lg->src[0] = src[0]; lg->src[1] = src[1];
 			lg->used[0] = (uint8_t)dirs[0]; lg->used[1] = (uint8_t)dirs[1];
 			lg->n = 0;
@@ -329,7 +329,7 @@ HENC_HD uint32_t encode_intra_luma(const G &g, Enc &e, int depth, int part_posit
 	}
 	if (S.rd_mode != RDM_FULL) {
 		const double correction = calc_mv_correction(tn.qp, e.f->avg_dist);
-		if (e.last_slog >= 0) e.ctu->slog[e.last_slog].tu_cost = tn.cost;
+		if (e.last_slog >= 0) e.ctu_g->slog[e.last_slog].tu_cost = tn.cost;
 		return intra_luma_cost(tn.cost, bitcost_cu_mode, correction);
 	}
 	return tn.cost;

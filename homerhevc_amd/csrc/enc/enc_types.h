@@ -156,10 +156,9 @@ struct Work {
 	uint8_t tr_idx_buffs[NDEPTH][NPART];
 	uint8_t cbf_chroma[2][NPART];
 	int16_t adi[264], adi_f[264];
-	int16_t pred_aux[64 * 64];
+	int16_t pred_aux[64 * 64];             // transform coefficients of the TU in flight; between TUs also the motion search's sub-pel candidate block
 	int16_t delta_u[64 * 64];
 	int16_t sub_tmp[(64 + 8) * 72];        // first interpolation stage of a sub-pel candidate / two-stage motion compensation
-	int16_t sub_out[64 * 64];
 	MvCandList amvp, merge_cands, search_cands;
 	WorkSlow *slow;
 };

@@ -51,12 +51,12 @@ __device__ __forceinline__ void wave_copy_words(void *dst, const void *src, int 
 
 // LDS of a row worker: its Work, a copy of the CTU's partition nodes and of the partition geometry
 constexpr size_t LDS_WORK = (sizeof(Work) + 15) & ~(size_t)15, LDS_NODES = (sizeof(Node) * NNODES + 15) & ~(size_t)15, LDS_GEO = (sizeof(Geo) * NNODES + 15) & ~(size_t)15;
-constexpr size_t LDS_SEQ = (sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15;
+constexpr size_t LDS_SEQ = (sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15, LDS_CTU = (sizeof(CtuPublic) + 15) & ~(size_t)15;
 #if defined(HENC_PROFILE)
 constexpr size_t LDS_BYTES = 160 * 1024;   // the primitive timers sit at HENC_LDS_PROF_OFFSET
-static_assert(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ <= HENC_LDS_PROF_OFFSET, "profile table overlaps the worker state");
+static_assert(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU <= HENC_LDS_PROF_OFFSET, "profile table overlaps the worker state");
 #else
-constexpr size_t LDS_BYTES = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ;
+constexpr size_t LDS_BYTES = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU;
 #endif
 static_assert(LDS_BYTES <= 160 * 1024, "a workgroup has 160 KiB of LDS on gfx950");
 
@@ -91,6 +91,8 @@ __global__ __launch_bounds__(64) void k_encode_ctus(EncDev d, int pass)
 	e.w = lw;
 	e.nodes = nullptr;
 	e.nodes_fast = (Node *)(lds + LDS_WORK);
+	e.ctu_g = nullptr;
+	e.ctu_fast = (CtuPublic *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ);
 	e.prof = d.prof ? d.prof + (size_t)row * PF_COUNT : nullptr;
 	uint32_t *my_prefix = d.prefix + (size_t)row * (W + 1);
 	if (pass == 0 && g.tid == 0) my_prefix[0] = 0;
@@ -386,7 +388,7 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 {
 	if (!ctx || !cfg || !out) return HMR_GPU_ERR_ARG;
 	static_assert(sizeof(hmr_gpu_enc_cfg) == sizeof(HostCfg), "configuration layouts must match");
-	static_assert(offsetof(CtuInfo, n_spec_reads) % 4 == 0 && sizeof(Node) % 4 == 0 && sizeof(Geo) % 2 == 0 && sizeof(Seq) % 4 == 0 && sizeof(FrameCtx) % 4 == 0 && MODE_STATE_BYTES % 4 == 0, "word copies");
+	static_assert(offsetof(CtuInfo, n_spec_reads) % 4 == 0 && sizeof(Node) % 4 == 0 && sizeof(Geo) % 2 == 0 && sizeof(Seq) % 4 == 0 && sizeof(FrameCtx) % 4 == 0 && sizeof(CtuPublic) % 4 == 0 && MODE_STATE_BYTES % 4 == 0, "word copies");
 	hmr_gpu_enc *e = new hmr_gpu_enc();
 	e->ctx = ctx;
 	memcpy(&e->cfg, cfg, sizeof(HostCfg));

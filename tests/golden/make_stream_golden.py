@@ -26,6 +26,8 @@ CASES = [
     ("416x240_intra", 416, 240, 2, {"intra_period": 1}),
     ("832x480", 832, 480, 3, {}),
     ("1920x1080_cfg2", 1920, 1080, 8, {}),       # BASELINE.json configs[1]
+    ("1280x720_intra", 1280, 720, 2, {"intra_period": 1}),   # configs[0]: 720p all-intra, QP 32, one thread
+    ("3840x2160_cfg2", 3840, 2160, 2, {}),       # configs[3], one engine's share: the cfg-2 encode at 2160p (I + P)
 ]
 
 

@@ -52,7 +52,7 @@ def encode(lib, case, sched=0):
     return stream, recon, list(st)
 
 
-@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra", "832x480"])
+@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra", "832x480", "1280x720_intra"])
 def test_stream_is_byte_identical_to_the_reference(cpu, case):
     stream, recon, _ = encode(cpu, case)
     g = GOLD[case]
