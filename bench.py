@@ -30,6 +30,10 @@ import sys
 import tempfile
 import time
 
+# one hardware queue per concurrent encoder instance of the multi_stream measurement (the default of 4 serialises kernels of streams that share a queue);
+# must be set before the HIP runtime starts
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -205,6 +209,12 @@ def main():
         # SURVEY.md 8-d, the CTU stage's share of the frame-level compulsory traffic: source + reference + reconstruction (1 byte samples) + levels (2 bytes)
         algo_bytes_frame = 1.5 * width * height * 3 + 2 * 1.5 * width * height
         achieved = algo_bytes_frame * len(timed) / (ctu_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed counter passes of this same command (TCC_EA0_RDREQ / WRREQ x 64 B, MI355X_MICROARCH.md "HBM"; narrow accesses: uncalibrated)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_k_encode_ctus.json")
+        if os.path.exists(tpath) and a.workload == "cfg2-1080p-encode":
+            k = json.load(open(tpath))["k_encode_ctus"]
+            traffic = int((k["derived"]["hbm_read_bytes_TCC_EA0_RDREQ_x64"] + k["derived"]["hbm_write_bytes_TCC_EA0_WRREQ_x64_upper_bound"]) / k["launches"])
         digest = md5.hexdigest()
         want = REFERENCE_MD5.get((a.workload, nframes))
         out = {
@@ -218,7 +228,7 @@ def main():
             "schedule": {"ctus_per_frame": nctu, "passes_per_frame": [s[3] for s in timed], "ctu_encodes_per_frame": [s[4] for s in timed],
                          "ctu_stage_ms_per_frame": [round(s[5], 1) for s in timed], "device_ms_per_frame": [round(s[6], 1) for s in timed]},
             "roofline": {"bound": "hbm", "kernel": "k_encode_ctus", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 7),
-                         "traffic": None, "launches": launches, "ms_per_launch": round(ctu_ms / max(launches, 1), 2),
+                         "traffic": traffic, "launches": launches, "algorithmic_bytes_per_launch": int(algo_bytes_frame * len(timed) / max(launches, 1)), "ms_per_launch": round(ctu_ms / max(launches, 1), 2),
                          "algorithmic_bytes_per_frame": int(algo_bytes_frame), "share_of_device_time": round(ctu_ms / frame_ms, 3),
                          "note": "one wavefront per CTU row (17 at 1080p) walking a dependent decision chain: bound by instruction issue and memory latency of "
                                  "those few wavefronts, not by HBM bandwidth; the fraction is the honest distance from the bandwidth roof"},
