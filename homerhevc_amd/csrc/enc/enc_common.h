@@ -40,7 +40,51 @@ struct Enc {
 	int n_spec_reads, n_ratio_cmp, last_slog;
 	Node *nodes;           // the CTU's partition nodes: ctu->nodes, or the worker's fast copy of them (nodes_fast != nullptr) while the CTU is encoded
 	Node *nodes_fast;
+	// helper wavefronts of the worker (device only; nullptr = everything runs on the group itself)
+	struct HelperBox *box;
+	int16_t *mc_tmp_c;                // first-stage buffer of a two-stage chroma interpolation: Work::sub_tmp, or a helper's own
+	int16_t *scratch_a, *scratch_b;   // transform coefficients / rounding remainders of the TU in flight: Work::pred_aux / delta_u, or a helper's own
+	int hseq[2];
 };
+
+// Two helper wavefronts per row worker take the chroma components of a step whose three components are independent (motion compensation, the
+// transform chain of a TU) and single candidates of the intra mode search, while the worker itself does luma / the first candidate.  The worker
+// posts a job in LDS and goes on; a helper runs the same SPMD code on its own 64 lanes with its own scratch and reports back.
+enum { HJOB_NONE = 0, HJOB_NEW_CTU, HJOB_MC_CHROMA, HJOB_INTER_TU, HJOB_INTRA_SAD, HJOB_SYNC_CU, HJOB_SSD, HJOB_QUIT };
+struct HelperBox {
+	int cmd[2], done[2];       // sequence numbers: helper h runs its next job when cmd[h] moves on, and sets done[h] = cmd[h] when finished
+	int job[2];
+	int a[2][8];
+	uint32_t r[2][4];
+	Enc enc;                   // the worker's context, refreshed at every CTU start
+};
+
+template <class G>
+HENC_HD void helper_post(const G &g, Enc &e, int h, int job, int a0 = 0, int a1 = 0, int a2 = 0, int a3 = 0, int a4 = 0, int a5 = 0)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	HelperBox *b = e.box;
+	e.hseq[h]++;               // (the release store below orders everything this wavefront has written before it)
+	if (g.tid == 0) {
+		b->job[h] = job;
+		b->a[h][0] = a0; b->a[h][1] = a1; b->a[h][2] = a2; b->a[h][3] = a3; b->a[h][4] = a4; b->a[h][5] = a5;
+		__hip_atomic_store(&b->cmd[h], e.hseq[h], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+#else
+	(void)g; (void)e; (void)h; (void)job; (void)a0; (void)a1; (void)a2; (void)a3; (void)a4; (void)a5;
+#endif
+}
+template <class G>
+HENC_HD void helper_wait(const G &g, Enc &e, int h)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	HelperBox *b = e.box;
+	while (__hip_atomic_load(&b->done[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != e.hseq[h]) __builtin_amdgcn_s_sleep(1);
+	g.sync();
+#else
+	(void)g; (void)e; (void)h;
+#endif
+}
 
 HENC_INLINE Node &node_of(Enc &e, int idx) { return e.nodes[idx]; }
 HENC_INLINE int node_at(const Enc &e, int depth, int position) { return e.seq->depth_start[depth] + position; }
@@ -162,6 +206,22 @@ HENC_HD void sync_motion_buffers_chroma(const G &g, Enc &e, int ni, int q_src, i
 {
 	sync_cu_comp(g, e, ni, q_src, q_dst, d_src, d_dst, COMP_U);
 	sync_cu_comp(g, e, ni, q_src, q_dst, d_src, d_dst, COMP_V);
+}
+
+// both: with helper wavefronts the chroma planes are copied while the worker copies luma
+template <class G>
+HENC_HD void sync_motion_buffers(const G &g, Enc &e, int ni, int q_src, int q_dst, int d_src, int d_dst)
+{
+	if (e.box) {
+		helper_post(g, e, 0, HJOB_SYNC_CU, ni, COMP_U, q_src, q_dst, d_src, d_dst);
+		helper_post(g, e, 1, HJOB_SYNC_CU, ni, COMP_V, q_src, q_dst, d_src, d_dst);
+		sync_cu_comp(g, e, ni, q_src, q_dst, d_src, d_dst, COMP_Y);
+		helper_wait(g, e, 0);
+		helper_wait(g, e, 1);
+		return;
+	}
+	sync_motion_buffers_luma(g, e, ni, q_src, q_dst, d_src, d_dst);
+	sync_motion_buffers_chroma(g, e, ni, q_src, q_dst, d_src, d_dst);
 }
 
 // cost helpers (hmr_common.h:53-59): the reference's macros with their operand types

@@ -79,15 +79,13 @@ template <class G>
 HENC_HD void get_back_consolidated_info(const G &g, Enc &e, int ni, int depth)
 {
 	info_buffs_copy(g, e, depth, e.geo[ni].abs_index, e.geo[ni].num_part, 0);
-	sync_motion_buffers_luma(g, e, ni, 0, depth + 1, 0, depth + 1);
-	sync_motion_buffers_chroma(g, e, ni, 0, depth + 1, 0, depth + 1);
+	sync_motion_buffers(g, e, ni, 0, depth + 1, 0, depth + 1);
 }
 template <class G>
 HENC_HD void put_consolidated_info(const G &g, Enc &e, int ni, int depth)
 {
 	info_buffs_copy(g, e, depth, e.geo[ni].abs_index, e.geo[ni].num_part, 1);
-	sync_motion_buffers_luma(g, e, ni, depth + 1, 0, depth + 1, 0);
-	sync_motion_buffers_chroma(g, e, ni, depth + 1, 0, depth + 1, 0);
+	sync_motion_buffers(g, e, ni, depth + 1, 0, depth + 1, 0);
 }
 
 // consolidate_prediction_info :3372
@@ -111,8 +109,7 @@ HENC_HD void consolidate_prediction_info(const G &g, Enc &e, int pi, uint32_t pa
 		pn.distortion = node_of(e, pq.child[0]).distortion + node_of(e, pq.child[1]).distortion + node_of(e, pq.child[2]).distortion + node_of(e, pq.child[3]).distortion;
 		pn.sum = children_sum;
 		if (is_max_depth) {
-			sync_motion_buffers_luma(g, e, pi, curr_depth + 1, 0, curr_depth + 1, 0);
-			sync_motion_buffers_chroma(g, e, pi, curr_depth + 1, 0, curr_depth + 1, 0);
+			sync_motion_buffers(g, e, pi, curr_depth + 1, 0, curr_depth + 1, 0);
 			info_buffs_copy(g, e, curr_depth, abs_index, num, 1);
 			for (int k = 0; k < 4; k++) {
 				const int ci = pq.child[k];
@@ -130,8 +127,7 @@ HENC_HD void consolidate_prediction_info(const G &g, Enc &e, int pi, uint32_t pa
 	} else {
 		const int part2 = pq.depth < e.seq->max_pred_depth ? PART_2Nx2N : PART_NxN;
 		const int parent_depth = pq.depth;
-		sync_motion_buffers_luma(g, e, pi, parent_depth + 1, 0, parent_depth + 1, 0);
-		sync_motion_buffers_chroma(g, e, pi, parent_depth + 1, 0, parent_depth + 1, 0);
+		sync_motion_buffers(g, e, pi, parent_depth + 1, 0, parent_depth + 1, 0);
 		info_buffs_copy(g, e, parent_depth, abs_index, num, 1);
 		set_inter_info_buffs(g, e, pi);
 		const uint8_t qp = (uint8_t)pn.qp;
@@ -216,9 +212,20 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &e, int depth, int position
 				cost = dist = encode_inter(g, e, curr_depth, position, PART_2Nx2N);
 				cost = (uint32_t)((double)cost + cost_rd(e.f->avg_dist, nd.sum));
 			} else {
+				if (e.box) {
+					helper_post(g, e, 0, HJOB_SSD, ni, COMP_U);
+					helper_post(g, e, 1, HJOB_SSD, ni, COMP_V);
+				}
 				dist = blk_ssd(g, w.curr_y + q.y * 64 + q.x, 64, w.pred_y + q.y * 64 + q.x, 64, n);
-				dist += (uint32_t)(weight * blk_ssd(g, w.curr_c[0] + q.yc * 32 + q.xc, 32, w.pred_c[0] + q.yc * 32 + q.xc, 32, nc));
-				dist += (uint32_t)(weight * blk_ssd(g, w.curr_c[1] + q.yc * 32 + q.xc, 32, w.pred_c[1] + q.yc * 32 + q.xc, 32, nc));
+				if (e.box) {
+					helper_wait(g, e, 0);
+					helper_wait(g, e, 1);
+					dist += (uint32_t)(weight * e.box->r[0][0]);
+					dist += (uint32_t)(weight * e.box->r[1][0]);
+				} else {
+					dist += (uint32_t)(weight * blk_ssd(g, w.curr_c[0] + q.yc * 32 + q.xc, 32, w.pred_c[0] + q.yc * 32 + q.xc, 32, nc));
+					dist += (uint32_t)(weight * blk_ssd(g, w.curr_c[1] + q.yc * 32 + q.xc, 32, w.pred_c[1] + q.yc * 32 + q.xc, 32, nc));
+				}
 				nd.inter_cbf[0] = nd.inter_cbf[1] = nd.inter_cbf[2] = 0;
 				nd.inter_tr_idx = 0;
 				nd.sum = 0;
@@ -587,6 +594,9 @@ HENC_HD void ctu_begin(const G &g, Enc &e, int ctu_num)
 		e.nodes = e.nodes_fast;
 	} else e.nodes = e.ctu_g->nodes;
 	CtuPublic &c = *e.ctu;
+	e.scratch_a = w.pred_aux;
+	e.scratch_b = w.delta_u;
+	e.mc_tmp_c = w.sub_tmp;
 	const int cx = ctu_num % S.wctu, cy = ctu_num / S.wctu;
 	c.ctu_number = ctu_num;
 	c.x = cx * 64;
@@ -638,6 +648,14 @@ HENC_HD void ctu_begin(const G &g, Enc &e, int ctu_num)
 		g.sync();
 	}
 	create_partition_neighbours(e);
+	if (e.box) {               // the helpers work on this CTU from now on
+		g.sync();
+		if (g.tid == 0) e.box->enc = e;
+		helper_post(g, e, 0, HJOB_NEW_CTU);
+		helper_post(g, e, 1, HJOB_NEW_CTU);
+		helper_wait(g, e, 0);
+		helper_wait(g, e, 1);
+	}
 	PRIM_END(PP_CTU_IO);
 }
 

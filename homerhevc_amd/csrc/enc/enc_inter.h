@@ -31,7 +31,7 @@ HENC_HD void mc_chroma(const G &g, Enc &e, const int16_t *ref, int rs, int16_t *
 	if (xf == 0) interp_stage<4>(g, src, rs, pred, ps, yf, n, n, 1, 1, 1);
 	else if (yf == 0) interp_stage<4>(g, src, rs, pred, ps, xf, n, n, 0, 1, 1);
 	else {
-		int16_t *tmp = e.w->sub_tmp;
+		int16_t *tmp = e.mc_tmp_c;
 		interp_stage<4>(g, src - rs, rs, tmp, 40, xf, n, n + 3, 0, 1, 0);
 		interp_stage<4>(g, tmp + 40, 40, pred, ps, yf, n, n, 1, 0, 1);
 	}
@@ -378,15 +378,15 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &e, int ni, int comp, int depth
 	int16_t *resid = resid_ptr(w, comp) + y * cs + x, *rdec = rdec_ptr(w, comp) + y * cs + x;
 	int16_t *quant = tq_ptr(w, wnd, comp) + off, *iquant = iq_ptr(w, comp) + off;
 	int16_t *dec = dec_ptr(w, wnd, comp) + y * ds + x;
-	tr_forward(g, e.T, resid, cs, w.pred_aux, quant, n, 0);
-	int sum = quantize(g, e.T, w.pred_aux, quant, w.delta_u, SCAN_DIAG, curr_depth, comp, 0, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
+	tr_forward(g, e.T, resid, cs, e.scratch_a, quant, n, 0);
+	int sum = quantize(g, e.T, e.scratch_a, quant, e.scratch_b, SCAN_DIAG, curr_depth, comp, 0, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
 	nd.inter_cbf[comp] = (sum ? 1 : 0) << (original_depth - depth);
 	if (is_y) nd.inter_tr_idx = original_depth - depth;
 	uint32_t ssd;
 	if (sum > 0) {
 		const uint32_t raw_zero = blk_ssq(g, resid, cs, n);
 		dequantize(g, e.T, quant, iquant, curr_depth, comp, 0, n, per, rem);
-		tr_inverse(g, e.T, rdec, cs, iquant, w.pred_aux, n, 0);
+		tr_inverse(g, e.T, rdec, cs, iquant, e.scratch_a, n, 0);
 		const uint32_t raw = blk_ssd(g, resid, cs, rdec, cs, n);
 		uint32_t ssd_zero;
 		if (is_y) { ssd_zero = raw_zero; ssd = raw; }
@@ -405,9 +405,7 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &e, int ni, int comp, int depth
 		ssd = is_y ? raw : (uint32_t)(weight * raw);
 		blk_reconst(g, pred, cs, (const int16_t *)nullptr, 0, dec, ds, n);
 	}
-	*curr_sum = sum;
-	if (is_y) nd.sum = (uint32_t)sum;
-	else nd.sum += (uint32_t)sum;
+	*curr_sum = sum;      // the caller adds the three components up (nd.sum; the reference accumulates it here, :128,:222)
 	return ssd;
 }
 
@@ -477,11 +475,25 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &e, int depth, int part_position, 
 		Node &cn = node_of(e, curr);
 		cn.qp = qp;
 		curr_depth = e.geo[curr].depth;
-		uint32_t dist_y = encode_inter_tu(g, e, curr, COMP_Y, depth, part_size_type, &curr_sum_y), dist_u, dist_v;
-		if (e.geo[curr].size_chroma != 2 || depth_state[curr_depth] == 0) {
+		uint32_t dist_y, dist_u, dist_v;
+		const bool has_chroma = e.geo[curr].size_chroma != 2 || depth_state[curr_depth] == 0;
+		if (has_chroma && e.box) {
+			// the three components of a TU are independent: the helpers take U and V
+			helper_post(g, e, 0, HJOB_INTER_TU, curr, COMP_U, depth, part_size_type);
+			helper_post(g, e, 1, HJOB_INTER_TU, curr, COMP_V, depth, part_size_type);
+			dist_y = encode_inter_tu(g, e, curr, COMP_Y, depth, part_size_type, &curr_sum_y);
+			helper_wait(g, e, 0);
+			helper_wait(g, e, 1);
+			dist_u = e.box->r[0][0]; curr_sum_u = (int)e.box->r[0][1];
+			dist_v = e.box->r[1][0]; curr_sum_v = (int)e.box->r[1][1];
+		} else {
+			dist_y = encode_inter_tu(g, e, curr, COMP_Y, depth, part_size_type, &curr_sum_y);
+			dist_u = dist_v = 0;
+		}
+		if (has_chroma && !e.box) {
 			dist_u = encode_inter_tu(g, e, curr, COMP_U, depth, part_size_type, &curr_sum_u);
 			dist_v = encode_inter_tu(g, e, curr, COMP_V, depth, part_size_type, &curr_sum_v);
-		} else {
+		} else if (!has_chroma) {
 			dist_u = dist_v = 0;
 			cn.inter_cbf[COMP_U] = node_of(e, curr - 1).inter_cbf[COMP_U];
 			cn.inter_cbf[COMP_V] = node_of(e, curr - 1).inter_cbf[COMP_V];
@@ -531,8 +543,7 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &e, int depth, int part_position, 
 							for (int c = 0; c < 3; c++) w.cbf_buffs[c][buff_depth][pq.abs_index + i] |= (uint8_t)cb[c];
 						g.sync();
 					}
-					sync_motion_buffers_luma(g, e, parent, curr_depth + 1 + nxn, curr_depth + nxn, curr_depth + 1 + nxn, curr_depth + nxn);
-					sync_motion_buffers_chroma(g, e, parent, curr_depth + 1 + nxn, curr_depth + nxn, curr_depth + 1 + nxn, curr_depth + nxn);
+					sync_motion_buffers(g, e, parent, curr_depth + 1 + nxn, curr_depth + nxn, curr_depth + 1 + nxn, curr_depth + nxn);
 				} else {
 					set_enc_info_buffs(g, e, parent, buff_depth);
 				}
@@ -582,9 +593,28 @@ HENC_HD void motion_compensate_cu(const G &g, Enc &e, int ni, MV mv)
 	const Geo &q = e.geo[ni];
 	const Seq &S = *e.seq;
 	const int gx = e.ctu->x + q.x, gy = e.ctu->y + q.y, gxc = (e.ctu->x >> 1) + q.xc, gyc = (e.ctu->y >> 1) + q.yc;
+	if (e.box) {
+		helper_post(g, e, 0, HJOB_MC_CHROMA, ni, COMP_U, mv.x, mv.y);
+		helper_post(g, e, 1, HJOB_MC_CHROMA, ni, COMP_V, mv.x, mv.y);
+	}
 	mc_luma(g, e, e.f->ref[0] + gy * S.stride_y + gx, S.stride_y, w.pred_y + q.y * 64 + q.x, 64, q.size, mv.x, mv.y);
+	if (e.box) {
+		helper_wait(g, e, 0);
+		helper_wait(g, e, 1);
+		return;
+	}
 	mc_chroma(g, e, e.f->ref[1] + gyc * S.stride_c + gxc, S.stride_c, w.pred_c[0] + q.yc * 32 + q.xc, 32, q.size_chroma, mv.x, mv.y);
 	mc_chroma(g, e, e.f->ref[2] + gyc * S.stride_c + gxc, S.stride_c, w.pred_c[1] + q.yc * 32 + q.xc, 32, q.size_chroma, mv.x, mv.y);
+}
+// one chroma plane of the same (what a helper wavefront runs)
+template <class G>
+HENC_HD void motion_compensate_chroma_comp(const G &g, Enc &e, int ni, int comp, MV mv)
+{
+	Work &w = *e.w;
+	const Geo &q = e.geo[ni];
+	const Seq &S = *e.seq;
+	const int gxc = (e.ctu->x >> 1) + q.xc, gyc = (e.ctu->y >> 1) + q.yc;
+	mc_chroma(g, e, e.f->ref[comp] + gyc * S.stride_c + gxc, S.stride_c, w.pred_c[comp - 1] + q.yc * 32 + q.xc, 32, q.size_chroma, mv.x, mv.y);
 }
 
 // predict_inter :2924 (uni-directional): vector predictor choice, motion compensation, residual.  Returns the vector cost.

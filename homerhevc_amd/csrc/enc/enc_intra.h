@@ -85,8 +85,8 @@ HENC_INLINE void intra_neighbour_dirs(Enc &e, int ni, int depth, int *dirs, uint
 // The walk of homer_loop1_motion_intra (hmr_motion_intra.c:1084-1180) over the prediction directions: planar / DC, five coarse
 // angles, +-2 / +-4 around the best, +-1 around that.  sad_of(mode) returns the SAD of a direction or a negative value when it is not
 // available (only the replay in enc_sched.h can fail).  Returns the bit cost of the winner, or -1.
-template <class SadFn>
-HENC_INLINE int intra_search_walk(const int *preds, int rd_fast, double sqrt_lambda, SadFn &&sad_of, int *best_mode_out, double *best_cost_out)
+template <class SadsFn>
+HENC_INLINE int intra_search_walk_batched(const int *preds, int rd_fast, double sqrt_lambda, SadsFn &&sads_of, int *best_mode_out, double *best_cost_out)
 {
 	const int search_points[4][5] = {{0, 1, 0, 8, 16}, {2, 10, 16, 22, 30}, {-4, -2, 2, 4, 0}, {-1, 1, 0, 0, 0}};
 	const int num_search_points[4] = {2, 5, 4, 2};
@@ -94,12 +94,18 @@ HENC_INLINE int intra_search_walk(const int *preds, int rd_fast, double sqrt_lam
 	double best_cost = MAX_COST;
 	for (int loop = 0; loop < 4; loop++) {
 		if (loop == 1) { best_cu_mode = 2; min_mode = 2; max_mode = 34; }
+		// the candidates of a round do not depend on each other: their SADs may be computed side by side, the comparison below keeps the reference's order
+		int modes[5], cnt = 0;
+		int64_t sads[5];
 		for (int k = 0; k < num_search_points[loop]; k++) {
 			const int mode = best_cu_mode + search_points[loop][k];
 			if (mode < min_mode || mode > max_mode) continue;
-			const int64_t sad = sad_of(mode);
-			if (sad < 0) return -1;
-			double cost = (double)(uint32_t)sad;
+			modes[cnt++] = mode;
+		}
+		if (!sads_of(modes, cnt, sads)) return -1;
+		for (int k = 0; k < cnt; k++) {
+			const int mode = modes[k];
+			double cost = (double)(uint32_t)sads[k];
 			int bit_cost = 0;
 			if (rd_fast) {
 				bit_cost = (preds[0] == mode || preds[1] == mode || preds[2] == mode) ? 1 : 12;
@@ -112,6 +118,17 @@ HENC_INLINE int intra_search_walk(const int *preds, int rd_fast, double sqrt_lam
 	*best_mode_out = best_cu_mode;
 	*best_cost_out = best_cost;
 	return best_bit_cost;
+}
+template <class SadFn>
+HENC_INLINE int intra_search_walk(const int *preds, int rd_fast, double sqrt_lambda, SadFn &&sad_of, int *best_mode_out, double *best_cost_out)
+{
+	return intra_search_walk_batched(preds, rd_fast, sqrt_lambda, [&](const int *modes, int cnt, int64_t *sads) -> bool {
+		for (int k = 0; k < cnt; k++) {
+			sads[k] = sad_of(modes[k]);
+			if (sads[k] < 0) return false;
+		}
+		return true;
+	}, best_mode_out, best_cost_out);
 }
 
 // what encode_intra_luma returns for rd_mode != RD_FULL: the transform tree's cost plus the mode bits (hmr_motion_intra.c:1625)
@@ -147,15 +164,29 @@ HENC_HD int intra_mode_search(const G &g, Enc &e, int ni, int depth, int *best_m
 	}
 	int16_t *pred = w.pred_y + q.y * CTU_STRIDE_Y + q.x;
 	const int16_t *orig = w.curr_y + q.y * CTU_STRIDE_Y + q.x;
-	return intra_search_walk(preds, rd_fast, e.f->sqrt_lambda, [&](int mode) -> int64_t {
-		const int filt = intra_is_filtered(mode, inv_depth);
-		const uint32_t sad = intra_predict_sad(g, pred, CTU_STRIDE_Y, orig, CTU_STRIDE_Y, filt ? w.adi_f : w.adi, n, mode, 1);
-		if (lg) {
-			lg->mode[lg->n] = (uint8_t)mode;
-			lg->sad[lg->n] = sad;
-			lg->n++;
+	return intra_search_walk_batched(preds, rd_fast, e.f->sqrt_lambda, [&](const int *modes, int cnt, int64_t *sads) -> bool {
+		// with helper wavefronts: rounds of three candidates, the worker always taking the last one of the round (so that the prediction
+		// left in the window is the one the serial order leaves there); the helpers only return the SAD
+		for (int k0 = 0; k0 < cnt;) {
+			const int take = e.box ? hmin(3, cnt - k0) : 1, mine = k0 + take - 1;
+			for (int j = 0; j < take - 1; j++) helper_post(g, e, j, HJOB_INTRA_SAD, ni, n, modes[k0 + j], intra_is_filtered(modes[k0 + j], inv_depth));
+			{
+				const int mode = modes[mine], filt = intra_is_filtered(mode, inv_depth);
+				sads[mine] = (int64_t)intra_predict_sad(g, pred, CTU_STRIDE_Y, orig, CTU_STRIDE_Y, filt ? w.adi_f : w.adi, n, mode, 1);
+			}
+			for (int j = 0; j < take - 1; j++) {
+				helper_wait(g, e, j);
+				sads[k0 + j] = (int64_t)e.box->r[j][0];
+			}
+			k0 += take;
 		}
-		return (int64_t)sad;
+		if (lg)
+			for (int k = 0; k < cnt; k++) {
+				lg->mode[lg->n] = (uint8_t)modes[k];
+				lg->sad[lg->n] = (uint32_t)sads[k];
+				lg->n++;
+			}
+		return true;
 	}, best_mode_out, best_cost_out);
 }
 

@@ -29,7 +29,14 @@ namespace henc {
 struct WaveGrp {
 	int tid;
 	static constexpr int n = 64;
-	__device__ __forceinline__ void sync() const { __syncthreads(); }
+	// the group is ONE wavefront: its lanes run in lockstep, so ordering its own memory operations is all a "barrier" has to do (the workgroup may hold
+	// helper wavefronts that are doing something else, see HelperBox in enc_common.h)
+	__device__ __forceinline__ void sync() const
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	}
 	// wave-wide sum without LDS traffic: row shifts (DPP) inside the 16-lane rows, then the four row totals through readlane
 	__device__ __forceinline__ uint32_t sum(uint32_t v) const
 	{

@@ -371,7 +371,7 @@ HENC_PRIM uint32_t intra_predict_sad(const G &g, int16_t *pred, int ps, const in
 	for (int k = g.tid; k < n * n; k += g.n) {
 		const int j = k >> l, i = k & (n - 1);
 		const int v = intra_sample(p, j, i);
-		pred[j * ps + i] = (int16_t)v;
+		if (pred) pred[j * ps + i] = (int16_t)v;          // pred == nullptr: the SAD alone (a helper wavefront's candidate)
 		acc += (uint32_t)habs((int16_t)(orig[j * os + i] - (int16_t)v));
 	}
 	const uint32_t s = g.sum(acc);

@@ -53,24 +53,88 @@ __device__ __forceinline__ void wave_copy_words(void *dst, const void *src, int 
 constexpr size_t LDS_WORK = (sizeof(Work) + 15) & ~(size_t)15, LDS_NODES = (sizeof(Node) * NNODES + 15) & ~(size_t)15, LDS_GEO = (sizeof(Geo) * NNODES + 15) & ~(size_t)15;
 constexpr size_t LDS_SEQ = (sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15, LDS_CTU = (sizeof(CtuPublic) + 15) & ~(size_t)15;
 #if defined(HENC_PROFILE)
+constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = 2 * 4096;
 constexpr size_t LDS_BYTES = 160 * 1024;   // the primitive timers sit at HENC_LDS_PROF_OFFSET
-static_assert(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU <= HENC_LDS_PROF_OFFSET, "profile table overlaps the worker state");
+static_assert(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH <= HENC_LDS_PROF_OFFSET, "profile table overlaps the worker state");
 #else
-constexpr size_t LDS_BYTES = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU;
+constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = 2 * 4096;   // per helper: 2 x 1024 coefficients (a 32 x 32 chroma TU)
+constexpr size_t LDS_BYTES = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH;
 #endif
+constexpr int ENC_THREADS = 192;   // the row worker + two helper wavefronts
 static_assert(LDS_BYTES <= 160 * 1024, "a workgroup has 160 KiB of LDS on gfx950");
 
-__global__ __launch_bounds__(64) void k_encode_ctus(EncDev d, int pass)
+// a helper wavefront: run the jobs the worker posts (HelperBox, enc_common.h) until it says quit
+__device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
+{
+	WaveGrp g{(int)(threadIdx.x & 63)};
+	Enc e = {};   // (a context struct shared in LDS instead of one per lane in private memory was tried: the kernel hangs, cause not found)
+	for (int seq = 1;; seq++) {
+		while (__hip_atomic_load(&box->cmd[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) {}
+		const int job = box->job[h];
+		if (job == HJOB_QUIT) return;
+		if (job == HJOB_NEW_CTU) {
+			e = box->enc;
+			e.box = nullptr;
+			e.scratch_a = scratch;
+			e.scratch_b = scratch + 1024;
+			e.mc_tmp_c = scratch;
+			e.prof = nullptr;
+		}
+		const int *a = box->a[h];
+		uint32_t r0 = 0, r1 = 0;
+		switch (job) {
+		case HJOB_MC_CHROMA: {
+			MV mv = {a[2], a[3]};
+			motion_compensate_chroma_comp(g, e, a[0], a[1], mv);
+			break;
+		}
+		case HJOB_INTER_TU: {
+			int sum = 0;
+			r0 = encode_inter_tu(g, e, a[0], a[1], a[2], a[3], &sum);
+			r1 = (uint32_t)sum;
+			break;
+		}
+		case HJOB_SYNC_CU: sync_cu_comp(g, e, a[0], a[2], a[3], a[4], a[5], a[1]); break;
+		case HJOB_SSD: {
+			const Geo &q = e.geo[a[0]];
+			const int c = a[1] - 1;
+			r0 = blk_ssd(g, e.w->curr_c[c] + q.yc * 32 + q.xc, 32, e.w->pred_c[c] + q.yc * 32 + q.xc, 32, q.size_chroma);
+			break;
+		}
+		case HJOB_INTRA_SAD: {
+			const Geo &q = e.geo[a[0]];
+			r0 = intra_predict_sad(g, (int16_t *)nullptr, 0, e.w->curr_y + q.y * CTU_STRIDE_Y + q.x, CTU_STRIDE_Y, a[3] ? e.w->adi_f : e.w->adi, a[1], a[2], 1);
+			break;
+		}
+		default: break;
+		}
+		g.sync();
+		if (g.tid == 0) {
+			box->r[h][0] = r0; box->r[h][1] = r1;
+			__hip_atomic_store(&box->done[h], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+	}
+}
+
+__global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
 {
 	extern __shared__ __align__(16) uint8_t lds[];
 	const Seq &S = *d.seq;
 	const int row = blockIdx.x, W = S.wctu, H = S.hctu;
-	WaveGrp g{(int)threadIdx.x};
+	WaveGrp g{(int)(threadIdx.x & 63)};
 	Work *lw = (Work *)lds;
 	Geo *lgeo = (Geo *)(lds + LDS_WORK + LDS_NODES);
+	HelperBox *box = (HelperBox *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU);
+	const int wave = (int)(threadIdx.x >> 6);
+	if (threadIdx.x < 2) { box->cmd[threadIdx.x] = 0; box->done[threadIdx.x] = 0; }
+	__syncthreads();
+	if (wave > 0) {
+		helper_loop(box, wave - 1, (int16_t *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX) + (wave - 1) * 2048);
+		return;
+	}
 	for (int i = g.tid; i < (int)(LDS_WORK / 4); i += 64) ((uint32_t *)lds)[i] = 0;
 	for (int i = g.tid; i < (int)(sizeof(Geo) * NNODES / 2); i += 64) ((uint16_t *)lgeo)[i] = ((const uint16_t *)d.geo)[i];
-	__syncthreads();
+	g.sync();
 	// the sequence and frame parameters are read all through the control code: a copy next to the worker
 	Seq *lseq = (Seq *)(lds + LDS_WORK + LDS_NODES + LDS_GEO);
 	FrameCtx *lframe = (FrameCtx *)((uint8_t *)lseq + ((sizeof(Seq) + 15) & ~(size_t)15));
@@ -80,7 +144,7 @@ __global__ __launch_bounds__(64) void k_encode_ctus(EncDev d, int pass)
 #if defined(HENC_PROFILE)
 	if (g.tid < 2 * PP_COUNT) ((unsigned long long *)(lds + HENC_LDS_PROF_OFFSET))[g.tid] = 0;
 #endif
-	__syncthreads();
+	g.sync();
 	Enc e;
 	e.seq = lseq;
 	e.f = lframe;
@@ -93,6 +157,8 @@ __global__ __launch_bounds__(64) void k_encode_ctus(EncDev d, int pass)
 	e.nodes_fast = (Node *)(lds + LDS_WORK);
 	e.ctu_g = nullptr;
 	e.ctu_fast = (CtuPublic *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ);
+	e.box = box;
+	e.hseq[0] = e.hseq[1] = 0;
 	e.prof = d.prof ? d.prof + (size_t)row * PF_COUNT : nullptr;
 	uint32_t *my_prefix = d.prefix + (size_t)row * (W + 1);
 	if (pass == 0 && g.tid == 0) my_prefix[0] = 0;
@@ -122,14 +188,14 @@ __global__ __launch_bounds__(64) void k_encode_ctus(EncDev d, int pass)
 				if (n == 0) wave_copy_words(gs, d.chain_start, MODE_STATE_BYTES, g.tid);
 				sched_known_intra(d.prefix, W, row, c, &ui, &up);
 			}
-			__syncthreads();
+			g.sync();
 			wave_copy_words(e.w->mode_in, gs, MODE_STATE_BYTES, g.tid);
 			if (g.tid == 0) { d.used_intra[n] = ui; d.used_parts[n] = up; }
 			const unsigned long long old_hash = d.hash[n];
 			e.total_intra_partitions = ui;
 			e.total_partitions = up;
 			e.coeff = d.coeff + (size_t)n * 6144;
-			__syncthreads();
+			g.sync();
 			encode_ctu(g, e, n);
 			encodes++;
 			wave_copy_words(d.outtok + (size_t)n * MODE_STATE_BYTES, e.w->intra_mode_buffs, MODE_STATE_BYTES, g.tid);
@@ -159,9 +225,11 @@ __global__ __launch_bounds__(64) void k_encode_ctus(EncDev d, int pass)
 			}
 			HENC_PROF_ADD(e, PF_TOTAL);
 		}
-		__syncthreads();
+		g.sync();
 		if (g.tid == 0) __hip_atomic_store(&d.progress[row], c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 	}
+	helper_post(g, e, 0, HJOB_QUIT);
+	helper_post(g, e, 1, HJOB_QUIT);
 	if (g.tid == 0 && encodes) atomicAdd(&d.counters[1], encodes);
 #if defined(HENC_PROFILE)
 	if (g.tid == 0 && e.prof) {
@@ -336,7 +404,7 @@ int run_ctu_passes(hmr_gpu_enc *e)
 	int pass = 0;
 	for (;; pass++) {
 		HIP_TRY(hipMemsetAsync(e->d.progress, 0, sizeof(int) * s.hctu, st));
-		hipLaunchKernelGGL(k_encode_ctus, dim3(s.hctu), dim3(64), LDS_BYTES, st, e->d, pass);
+		hipLaunchKernelGGL(k_encode_ctus, dim3(s.hctu), dim3(ENC_THREADS), LDS_BYTES, st, e->d, pass);
 		hipLaunchKernelGGL(k_sched_scan, dim3(1), dim3(320), 0, st, e->d);
 		hipLaunchKernelGGL(k_sched_check, dim3(s.nctu), dim3(64), 0, st, e->d);
 		HIP_TRY(hipGetLastError());
