@@ -42,6 +42,7 @@ struct Enc {
 	Node *nodes_fast;
 	// helper wavefronts of the worker (device only; nullptr = everything runs on the group itself)
 	struct HelperBox *box;
+	int16_t *adi_c;                   // neighbour array of a chroma block: Work::adi, or a helper's own
 	int16_t *mc_tmp_c;                // first-stage buffer of a two-stage chroma interpolation: Work::sub_tmp, or a helper's own
 	int16_t *scratch_a, *scratch_b;   // transform coefficients / rounding remainders of the TU in flight: Work::pred_aux / delta_u, or a helper's own
 	int hseq[2];
@@ -50,12 +51,12 @@ struct Enc {
 // Two helper wavefronts per row worker take the chroma components of a step whose three components are independent (motion compensation, the
 // transform chain of a TU) and single candidates of the intra mode search, while the worker itself does luma / the first candidate.  The worker
 // posts a job in LDS and goes on; a helper runs the same SPMD code on its own 64 lanes with its own scratch and reports back.
-enum { HJOB_NONE = 0, HJOB_NEW_CTU, HJOB_MC_CHROMA, HJOB_INTER_TU, HJOB_INTRA_SAD, HJOB_SYNC_CU, HJOB_SSD, HJOB_QUIT };
+enum { HJOB_NONE = 0, HJOB_NEW_CTU, HJOB_MC_CHROMA, HJOB_INTER_TU, HJOB_INTRA_SAD, HJOB_SYNC_CU, HJOB_SSD, HJOB_CHROMA_SEARCH, HJOB_CHROMA_TU, HJOB_QUIT };
 struct HelperBox {
 	int cmd[2], done[2];       // sequence numbers: helper h runs its next job when cmd[h] moves on, and sets done[h] = cmd[h] when finished
 	int job[2];
 	int a[2][8];
-	uint32_t r[2][4];
+	uint32_t r[2][8];
 	Enc enc;                   // the worker's context, refreshed at every CTU start
 };
 

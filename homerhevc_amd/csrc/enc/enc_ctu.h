@@ -597,6 +597,7 @@ HENC_HD void ctu_begin(const G &g, Enc &e, int ctu_num)
 	e.scratch_a = w.pred_aux;
 	e.scratch_b = w.delta_u;
 	e.mc_tmp_c = w.sub_tmp;
+	e.adi_c = w.adi;
 	const int cx = ctu_num % S.wctu, cy = ctu_num / S.wctu;
 	c.ctu_number = ctu_num;
 	c.x = cx * 64;

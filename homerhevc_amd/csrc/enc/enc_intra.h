@@ -27,7 +27,7 @@ HENC_HD void node_fill_refs(const G &g, Enc &e, int ni, int wnd, int comp, int w
 	const int bl_size = hmin(n, ph - (cy + y + n)), tr_size = hmin(n, pw - (cx + x + n));
 	const int st = dec_stride(comp);
 	const int16_t *corner = dec_ptr(*e.w, wnd, comp) + (y - 1) * st + (x - 1);
-	intra_fill_refs(g, corner, st, n, nd.left_nb, nd.top_nb, nd.left_bottom_nb, nd.top_right_nb, bl_size, tr_size, e.w->adi);
+	intra_fill_refs(g, corner, st, n, nd.left_nb, nd.top_nb, nd.left_bottom_nb, nd.top_right_nb, bl_size, tr_size, is_y ? e.w->adi : e.adi_c);
 	if (want_filtered) intra_adi_filter(g, e.w->adi, e.w->adi_f, n, e.seq->strong_intra);
 }
 
@@ -373,6 +373,49 @@ HENC_INLINE void chroma_dir_list(int *list, int luma_mode)
 		if (luma_mode == list[i]) { list[i] = 34; break; }
 }
 
+// one chroma plane of the candidate search of encode_intra_chroma: SAD of the five candidates on the unfiltered neighbours of the auxiliary window
+template <class G>
+HENC_HD void chroma_search_comp(const G &g, Enc &e, int curr, int c, const int *cand, uint32_t *sads)
+{
+	Work &w = *e.w;
+	const Geo &q = e.geo[curr];
+	const int n = q.size_chroma;
+	int16_t *pred = pred_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
+	const int16_t *orig = curr_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
+	for (int mi = 0; mi < 5; mi++) {
+		node_fill_refs(g, e, curr, NWND - 1, c, 0);
+		sads[mi] = intra_predict_sad(g, pred, CTU_STRIDE_C, orig, CTU_STRIDE_C, e.adi_c, n, cand[mi], 0);
+	}
+}
+// one chroma TU of the winner: neighbours, prediction, residual, transform chain, reconstruction into the auxiliary window.  Returns the weighted SSD.
+template <class G>
+HENC_HD int chroma_tu_comp(const G &g, Enc &e, int curr, int c, int cu_mode, int scan_mode, int shifts, int per, int rem, int *curr_sum_out)
+{
+	Work &w = *e.w;
+	const Geo &q = e.geo[curr];
+	const int n = q.size_chroma, curr_depth = q.depth, qwnd = NWND - 1, dwnd = NWND - 1;
+	int16_t *pred = pred_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc, *resid = resid_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
+	const int16_t *orig = curr_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
+	int16_t *quant = tq_ptr(w, qwnd, c) + ((q.abs_index << 4) >> 2), *iquant = iq_ptr(w, c) + ((q.abs_index << 4) >> 2);
+	int16_t *dec = dec_ptr(w, dwnd, c) + q.yc * DEC_STRIDE_C + q.xc;
+	node_fill_refs(g, e, curr, dwnd, c, 0);
+	intra_predict(g, pred, CTU_STRIDE_C, e.adi_c, n, cu_mode, 0);
+	blk_predict(g, orig, CTU_STRIDE_C, pred, CTU_STRIDE_C, resid, CTU_STRIDE_C, n);
+	tr_forward(g, e.T, resid, CTU_STRIDE_C, e.scratch_a, quant, n, 0);
+	const int curr_sum = quantize(g, e.T, e.scratch_a, quant, e.scratch_b, scan_mode, curr_depth, c, 1, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
+	const int cbfv = ((curr_sum ? 1 : 0) << (shifts & 255)) | ((curr_sum ? 1 : 0) << (shifts >> 8));
+	bytes_set(g, &w.cbf_chroma[c - 1][q.abs_index], cbfv, q.num_part);
+	if (curr_sum) {
+		dequantize(g, e.T, quant, iquant, curr_depth, c, 1, n, per, rem);
+		tr_inverse(g, e.T, resid, CTU_STRIDE_C, iquant, e.scratch_a, n, 0);
+		blk_reconst(g, pred, CTU_STRIDE_C, resid, CTU_STRIDE_C, dec, DEC_STRIDE_C, n);
+	} else {
+		blk_reconst(g, pred, CTU_STRIDE_C, (const int16_t *)nullptr, 0, dec, DEC_STRIDE_C, n);
+	}
+	*curr_sum_out = curr_sum;
+	return (int)(e.f->chroma_weight * blk_ssd(g, orig, CTU_STRIDE_C, dec, DEC_STRIDE_C, n));
+}
+
 // encode_intra_chroma, hmr_motion_intra_chroma.c:114-469 (non-HM path, rd_mode != RD_FULL)
 template <class G>
 HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &e, int depth, int part_position, int part_size_type)
@@ -405,17 +448,24 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &e, int depth, int part_pos
 	{
 		const Geo &q = e.geo[curr];
 		const int n = q.size_chroma;
+		// the SADs of the five candidates, U and V side by side when there is a helper wavefront (the reference alternates U and V per candidate;
+		// the neighbour arrays do not change during the search, so the grouping does not matter)
+		uint32_t sad_u[5], sad_v[5];
+		int cand[5];
+		for (int mi = 0; mi < 5; mi++) cand[mi] = mode_list[mi] == DM_CHROMA_IDX ? luma_mode : mode_list[mi];
+		if (e.box) {
+			helper_post(g, e, 0, HJOB_CHROMA_SEARCH, curr, COMP_U, cand[0] | (cand[1] << 8) | (cand[2] << 16) | (cand[3] << 24), cand[4]);
+			chroma_search_comp(g, e, curr, COMP_V, cand, sad_v);
+			helper_wait(g, e, 0);
+			for (int mi = 0; mi < 5; mi++) sad_u[mi] = e.box->r[0][mi];
+		} else {
+			chroma_search_comp(g, e, curr, COMP_U, cand, sad_u);
+			chroma_search_comp(g, e, curr, COMP_V, cand, sad_v);
+		}
 		for (int mi = 0; mi < 5; mi++) {
-			uint32_t distortion = 0, cost = 0;
-			int cu_mode = mode_list[mi];
-			if (cu_mode == DM_CHROMA_IDX) cu_mode = luma_mode;
-			for (int c = COMP_U; c <= COMP_V; c++) {
-				node_fill_refs(g, e, curr, NWND - 1, c, 0);
-				int16_t *pred = pred_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
-				const int16_t *orig = curr_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
-				distortion += intra_predict_sad(g, pred, CTU_STRIDE_C, orig, CTU_STRIDE_C, w.adi, n, cu_mode, 0);
-				cost += distortion;
-			}
+			uint32_t distortion = sad_u[mi], cost = distortion;
+			distortion += sad_v[mi];
+			cost += distortion;
 			uint32_t bit_cost = mode_list[mi] == DM_CHROMA_IDX ? 1 : 12;
 			cost += (uint32_t)(bit_cost * e.f->sqrt_lambda + .5);
 			// homer_update_cand_list, hmr_motion_intra.c:893
@@ -469,28 +519,24 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &e, int depth, int part_pos
 			curr_depth = q.depth;
 			const int n = q.size_chroma;
 			partition_cost[depth_state[curr_depth]] = 0;
-			for (int c = COMP_U; c <= COMP_V; c++) {
-				int16_t *pred = pred_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc, *resid = resid_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
-				const int16_t *orig = curr_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
-				int16_t *quant = tq_ptr(w, qwnd, c) + ((q.abs_index << 4) >> 2), *iquant = iq_ptr(w, c) + ((q.abs_index << 4) >> 2);
-				int16_t *dec = dec_ptr(w, dwnd, c) + q.yc * DEC_STRIDE_C + q.xc;
-				node_fill_refs(g, e, curr, dwnd, c, 0);
-				intra_predict(g, pred, CTU_STRIDE_C, w.adi, n, cu_mode, 0);
-				blk_predict(g, orig, CTU_STRIDE_C, pred, CTU_STRIDE_C, resid, CTU_STRIDE_C, n);
-				tr_forward(g, e.T, resid, CTU_STRIDE_C, w.pred_aux, quant, n, 0);
-				const int curr_sum = quantize(g, e.T, w.pred_aux, quant, w.delta_u, scan_mode, curr_depth, c, 1, e.f->slice_type == SLICE_I, S.sign_hiding, n, per, rem);
-				sum += (uint32_t)curr_sum;
-				const int cbfv = ((curr_sum ? 1 : 0) << (original_depth - depth + nxn)) | ((curr_sum ? 1 : 0) << (curr_depth - depth + nxn));
-				bytes_set(g, &w.cbf_chroma[c - 1][q.abs_index], cbfv, q.num_part);
-				cbf_split[c - 1][curr_depth] |= (curr_sum ? 1 : 0);
-				if (curr_sum) {
-					dequantize(g, e.T, quant, iquant, curr_depth, c, 1, n, per, rem);
-					tr_inverse(g, e.T, resid, CTU_STRIDE_C, iquant, w.pred_aux, n, 0);
-					blk_reconst(g, pred, CTU_STRIDE_C, resid, CTU_STRIDE_C, dec, DEC_STRIDE_C, n);
+			{
+				int cs[2], pc[2];
+				const int shifts = (original_depth - depth + nxn) | ((curr_depth - depth + nxn) << 8);
+				if (e.box) {
+					helper_post(g, e, 0, HJOB_CHROMA_TU, curr, COMP_U, cu_mode, scan_mode, shifts, per | (rem << 8));
+					pc[1] = chroma_tu_comp(g, e, curr, COMP_V, cu_mode, scan_mode, shifts, per, rem, &cs[1]);
+					helper_wait(g, e, 0);
+					pc[0] = (int)e.box->r[0][0];
+					cs[0] = (int)e.box->r[0][1];
 				} else {
-					blk_reconst(g, pred, CTU_STRIDE_C, (const int16_t *)nullptr, 0, dec, DEC_STRIDE_C, n);
+					pc[0] = chroma_tu_comp(g, e, curr, COMP_U, cu_mode, scan_mode, shifts, per, rem, &cs[0]);
+					pc[1] = chroma_tu_comp(g, e, curr, COMP_V, cu_mode, scan_mode, shifts, per, rem, &cs[1]);
 				}
-				partition_cost[depth_state[curr_depth]] += (int)(weight * blk_ssd(g, orig, CTU_STRIDE_C, dec, DEC_STRIDE_C, n));
+				for (int k = 0; k < 2; k++) {
+					sum += (uint32_t)cs[k];
+					cbf_split[k][curr_depth] |= (cs[k] ? 1 : 0);
+					partition_cost[depth_state[curr_depth]] += pc[k];
+				}
 			}
 			node_of(e, curr).sum += sum;
 			distortion += (uint32_t)partition_cost[depth_state[curr_depth]];

@@ -49,15 +49,16 @@ __device__ __forceinline__ void wave_copy_words(void *dst, const void *src, int 
 	for (int i = tid; i < bytes / 4; i += 64) d[i] = s[i];
 }
 
+constexpr int HSCRATCH_ELEMS = 2048 + 144;   // int16 per helper
 // LDS of a row worker: its Work, a copy of the CTU's partition nodes and of the partition geometry
 constexpr size_t LDS_WORK = (sizeof(Work) + 15) & ~(size_t)15, LDS_NODES = (sizeof(Node) * NNODES + 15) & ~(size_t)15, LDS_GEO = (sizeof(Geo) * NNODES + 15) & ~(size_t)15;
 constexpr size_t LDS_SEQ = (sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15, LDS_CTU = (sizeof(CtuPublic) + 15) & ~(size_t)15;
 #if defined(HENC_PROFILE)
-constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = 2 * 4096;
+constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = 2 * HSCRATCH_ELEMS * 2;
 constexpr size_t LDS_BYTES = 160 * 1024;   // the primitive timers sit at HENC_LDS_PROF_OFFSET
 static_assert(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH <= HENC_LDS_PROF_OFFSET, "profile table overlaps the worker state");
 #else
-constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = 2 * 4096;   // per helper: 2 x 1024 coefficients (a 32 x 32 chroma TU)
+constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = 2 * HSCRATCH_ELEMS * 2;   // per helper: 2 x 1024 coefficients (a 32 x 32 chroma TU) + a chroma neighbour array
 constexpr size_t LDS_BYTES = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH;
 #endif
 constexpr int ENC_THREADS = 192;   // the row worker + two helper wavefronts
@@ -78,6 +79,7 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 			e.scratch_a = scratch;
 			e.scratch_b = scratch + 1024;
 			e.mc_tmp_c = scratch;
+			e.adi_c = scratch + 2048;
 			e.prof = nullptr;
 		}
 		const int *a = box->a[h];
@@ -101,6 +103,21 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 			r0 = blk_ssd(g, e.w->curr_c[c] + q.yc * 32 + q.xc, 32, e.w->pred_c[c] + q.yc * 32 + q.xc, 32, q.size_chroma);
 			break;
 		}
+		case HJOB_CHROMA_SEARCH: {
+			const int cand[5] = {a[2] & 255, (a[2] >> 8) & 255, (a[2] >> 16) & 255, (a[2] >> 24) & 255, a[3]};
+			uint32_t sads[5];
+			chroma_search_comp(g, e, a[0], a[1], cand, sads);
+			g.sync();
+			if (g.tid == 0)
+				for (int k = 0; k < 5; k++) box->r[h][k] = sads[k];
+			break;
+		}
+		case HJOB_CHROMA_TU: {
+			int cs = 0;
+			r0 = (uint32_t)chroma_tu_comp(g, e, a[0], a[1], a[2], a[3], a[4], a[5] & 255, a[5] >> 8, &cs);
+			r1 = (uint32_t)cs;
+			break;
+		}
 		case HJOB_INTRA_SAD: {
 			const Geo &q = e.geo[a[0]];
 			r0 = intra_predict_sad(g, (int16_t *)nullptr, 0, e.w->curr_y + q.y * CTU_STRIDE_Y + q.x, CTU_STRIDE_Y, a[3] ? e.w->adi_f : e.w->adi, a[1], a[2], 1);
@@ -110,7 +127,7 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 		}
 		g.sync();
 		if (g.tid == 0) {
-			box->r[h][0] = r0; box->r[h][1] = r1;
+			if (job != HJOB_CHROMA_SEARCH) { box->r[h][0] = r0; box->r[h][1] = r1; }
 			__hip_atomic_store(&box->done[h], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 	}
@@ -129,7 +146,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
 	if (threadIdx.x < 2) { box->cmd[threadIdx.x] = 0; box->done[threadIdx.x] = 0; }
 	__syncthreads();
 	if (wave > 0) {
-		helper_loop(box, wave - 1, (int16_t *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX) + (wave - 1) * 2048);
+		helper_loop(box, wave - 1, (int16_t *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX) + (wave - 1) * HSCRATCH_ELEMS);
 		return;
 	}
 	for (int i = g.tid; i < (int)(LDS_WORK / 4); i += 64) ((uint32_t *)lds)[i] = 0;
