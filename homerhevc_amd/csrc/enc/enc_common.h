@@ -61,7 +61,7 @@ struct HelperBox {
 };
 
 template <class G>
-HENC_HD void helper_post(const G &g, Enc &e, int h, int job, int a0 = 0, int a1 = 0, int a2 = 0, int a3 = 0, int a4 = 0, int a5 = 0)
+HENC_HD void helper_post(const G &g, Enc &__restrict__ e, int h, int job, int a0 = 0, int a1 = 0, int a2 = 0, int a3 = 0, int a4 = 0, int a5 = 0)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 	HelperBox *b = e.box;
@@ -76,34 +76,36 @@ HENC_HD void helper_post(const G &g, Enc &e, int h, int job, int a0 = 0, int a1 
 #endif
 }
 template <class G>
-HENC_HD void helper_wait(const G &g, Enc &e, int h)
+HENC_HD void helper_wait(const G &g, Enc &__restrict__ e, int h)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+	PRIM_T0();
 	HelperBox *b = e.box;
 	while (__hip_atomic_load(&b->done[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != e.hseq[h]) __builtin_amdgcn_s_sleep(1);
 	g.sync();
+	PRIM_END(PP_HWAIT);
 #else
 	(void)g; (void)e; (void)h;
 #endif
 }
 
-HENC_INLINE Node &node_of(Enc &e, int idx) { return e.nodes[idx]; }
-HENC_INLINE int node_at(const Enc &e, int depth, int position) { return e.seq->depth_start[depth] + position; }
+HENC_INLINE Node &node_of(Enc &__restrict__ e, int idx) { return e.nodes[idx]; }
+HENC_INLINE int node_at(const Enc &__restrict__ e, int depth, int position) { return e.seq->depth_start[depth] + position; }
 
 // ---- neighbour partitions (hmr_arithmetic_encoding.c:229-355).  Return the CTU that holds the neighbour (nullptr when not
 // available) and its z-order unit index. -------------------------------------------------------------------------------
-HENC_INLINE CtuPublic *ctu_left_of(Enc &e) { return e.ctu->has_left ? e.ctu_g - 1 : nullptr; }
-HENC_INLINE CtuPublic *ctu_top_of(Enc &e) { return e.ctu->has_top ? e.ctu_g - e.seq->wctu : nullptr; }
-HENC_INLINE CtuPublic *ctu_top_right_of(Enc &e) { return e.ctu->has_top_right ? e.ctu_g - e.seq->wctu + 1 : nullptr; }
-HENC_INLINE CtuPublic *ctu_top_left_of(Enc &e) { return e.ctu->has_top_left ? e.ctu_g - e.seq->wctu - 1 : nullptr; }
+HENC_INLINE CtuPublic *ctu_left_of(Enc &__restrict__ e) { return e.ctu->has_left ? e.ctu_g - 1 : nullptr; }
+HENC_INLINE CtuPublic *ctu_top_of(Enc &__restrict__ e) { return e.ctu->has_top ? e.ctu_g - e.seq->wctu : nullptr; }
+HENC_INLINE CtuPublic *ctu_top_right_of(Enc &__restrict__ e) { return e.ctu->has_top_right ? e.ctu_g - e.seq->wctu + 1 : nullptr; }
+HENC_INLINE CtuPublic *ctu_top_left_of(Enc &__restrict__ e) { return e.ctu->has_top_left ? e.ctu_g - e.seq->wctu - 1 : nullptr; }
 
-HENC_INLINE CtuPublic *pu_left(Enc &e, int ni, uint32_t *idx)
+HENC_INLINE CtuPublic *pu_left(Enc &__restrict__ e, int ni, uint32_t *idx)
 {
 	const Geo &gq = e.geo[ni];
 	*idx = gq.abs_left;
 	return (gq.raster_index & 15) == 0 ? ctu_left_of(e) : e.ctu;
 }
-HENC_INLINE CtuPublic *pu_left_bottom(Enc &e, int ni, uint32_t *idx)
+HENC_INLINE CtuPublic *pu_left_bottom(Enc &__restrict__ e, int ni, uint32_t *idx)
 {
 	const Geo &gq = e.geo[ni];
 	if (!node_of(e, ni).left_bottom_nb) return nullptr;
@@ -114,14 +116,14 @@ HENC_INLINE CtuPublic *pu_left_bottom(Enc &e, int ni, uint32_t *idx)
 	if (gq.abs_index > gq.abs_left_bottom) return e.ctu;
 	return nullptr;
 }
-HENC_INLINE CtuPublic *pu_top(Enc &e, int ni, uint32_t *idx, int planar_at_ctu_boundary)
+HENC_INLINE CtuPublic *pu_top(Enc &__restrict__ e, int ni, uint32_t *idx, int planar_at_ctu_boundary)
 {
 	const Geo &gq = e.geo[ni];
 	*idx = gq.abs_top;
 	if (gq.raster_index < 16) return planar_at_ctu_boundary ? nullptr : ctu_top_of(e);
 	return e.ctu;
 }
-HENC_INLINE CtuPublic *pu_top_right(Enc &e, int ni, uint32_t *idx)
+HENC_INLINE CtuPublic *pu_top_right(Enc &__restrict__ e, int ni, uint32_t *idx)
 {
 	const Geo &gq = e.geo[ni];
 	if (!node_of(e, ni).top_right_nb) return nullptr;
@@ -132,7 +134,7 @@ HENC_INLINE CtuPublic *pu_top_right(Enc &e, int ni, uint32_t *idx)
 	if (gq.abs_index > gq.abs_top_right) return e.ctu;
 	return nullptr;
 }
-HENC_INLINE CtuPublic *pu_top_left(Enc &e, int ni, uint32_t *idx)
+HENC_INLINE CtuPublic *pu_top_left(Enc &__restrict__ e, int ni, uint32_t *idx)
 {
 	const Geo &gq = e.geo[ni];
 	*idx = gq.abs_top_left;
@@ -145,7 +147,7 @@ HENC_INLINE CtuPublic *pu_top_left(Enc &e, int ni, uint32_t *idx)
 // ---- window consolidation (hmr_motion_intra.c:844-890, hmr_motion_intra_chroma.c:29-90, hmr_mem_transfer.c:125-176) -------
 // bottom row and right column of a CU, luma: what later blocks of a deeper window need as neighbours
 template <class G>
-HENC_HD void sync_reference_buffs(const G &g, Enc &e, int ni, int src_wnd, int dst_wnd)
+HENC_HD void sync_reference_buffs(const G &g, Enc &__restrict__ e, int ni, int src_wnd, int dst_wnd)
 {
 	PRIM_T0();
 	const Geo &q = e.geo[ni];
@@ -160,7 +162,7 @@ HENC_HD void sync_reference_buffs(const G &g, Enc &e, int ni, int src_wnd, int d
 	PRIM_END(PP_SYNC);
 }
 template <class G>
-HENC_HD void sync_reference_buffs_chroma(const G &g, Enc &e, int ni, int src_wnd, int dst_wnd)
+HENC_HD void sync_reference_buffs_chroma(const G &g, Enc &__restrict__ e, int ni, int src_wnd, int dst_wnd)
 {
 	PRIM_T0();
 	const Geo &q = e.geo[ni];
@@ -178,7 +180,7 @@ HENC_HD void sync_reference_buffs_chroma(const G &g, Enc &e, int ni, int src_wnd
 }
 // whole CU: reconstruction (2-D) and levels (linear), one component
 template <class G>
-HENC_HD void sync_cu_comp(const G &g, Enc &e, int ni, int q_src, int q_dst, int d_src, int d_dst, int comp)
+HENC_HD void sync_cu_comp(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst, int comp)
 {
 	PRIM_T0();
 	const Geo &q = e.geo[ni];
@@ -198,12 +200,12 @@ HENC_HD void sync_cu_comp(const G &g, Enc &e, int ni, int q_src, int q_dst, int 
 	PRIM_END(PP_SYNC);
 }
 template <class G>
-HENC_HD void sync_motion_buffers_luma(const G &g, Enc &e, int ni, int q_src, int q_dst, int d_src, int d_dst)
+HENC_HD void sync_motion_buffers_luma(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
 {
 	sync_cu_comp(g, e, ni, q_src, q_dst, d_src, d_dst, COMP_Y);
 }
 template <class G>
-HENC_HD void sync_motion_buffers_chroma(const G &g, Enc &e, int ni, int q_src, int q_dst, int d_src, int d_dst)
+HENC_HD void sync_motion_buffers_chroma(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
 {
 	sync_cu_comp(g, e, ni, q_src, q_dst, d_src, d_dst, COMP_U);
 	sync_cu_comp(g, e, ni, q_src, q_dst, d_src, d_dst, COMP_V);
@@ -211,7 +213,7 @@ HENC_HD void sync_motion_buffers_chroma(const G &g, Enc &e, int ni, int q_src, i
 
 // both: with helper wavefronts the chroma planes are copied while the worker copies luma
 template <class G>
-HENC_HD void sync_motion_buffers(const G &g, Enc &e, int ni, int q_src, int q_dst, int d_src, int d_dst)
+HENC_HD void sync_motion_buffers(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
 {
 	if (e.box) {
 		helper_post(g, e, 0, HJOB_SYNC_CU, ni, COMP_U, q_src, q_dst, d_src, d_dst);

@@ -13,7 +13,7 @@ namespace henc {
 // CONSOLIDATE_ENC_INFO_BUFFS :3298 (dir = 0: CTU arrays <- worker buffers of `depth`) and its inverse (get_back :3461-3466,
 // consolidate_info_buffers_for_rd hmr_motion_intra.c:1632)
 template <class G>
-HENC_HD void info_buffs_copy(const G &g, Enc &e, int depth, int abs_idx, int num, int to_ctu)
+HENC_HD void info_buffs_copy(const G &g, Enc &__restrict__ e, int depth, int abs_idx, int num, int to_ctu)
 {
 	PRIM_T0();
 	Work &w = *e.w;
@@ -42,7 +42,7 @@ HENC_HD void info_buffs_copy(const G &g, Enc &e, int depth, int abs_idx, int num
 
 // SET_INTER_INFO_BUFFS :3309
 template <class G>
-HENC_HD void set_inter_info_buffs(const G &g, Enc &e, int ni)
+HENC_HD void set_inter_info_buffs(const G &g, Enc &__restrict__ e, int ni)
 {
 	PRIM_T0();
 	const Geo &q = e.geo[ni];
@@ -76,13 +76,13 @@ HENC_HD void set_inter_info_buffs(const G &g, Enc &e, int ni)
 
 // get_back_consolidated_info :3456 / put_consolidated_info :3472
 template <class G>
-HENC_HD void get_back_consolidated_info(const G &g, Enc &e, int ni, int depth)
+HENC_HD void get_back_consolidated_info(const G &g, Enc &__restrict__ e, int ni, int depth)
 {
 	info_buffs_copy(g, e, depth, e.geo[ni].abs_index, e.geo[ni].num_part, 0);
 	sync_motion_buffers(g, e, ni, 0, depth + 1, 0, depth + 1);
 }
 template <class G>
-HENC_HD void put_consolidated_info(const G &g, Enc &e, int ni, int depth)
+HENC_HD void put_consolidated_info(const G &g, Enc &__restrict__ e, int ni, int depth)
 {
 	info_buffs_copy(g, e, depth, e.geo[ni].abs_index, e.geo[ni].num_part, 1);
 	sync_motion_buffers(g, e, ni, depth + 1, 0, depth + 1, 0);
@@ -90,7 +90,7 @@ HENC_HD void put_consolidated_info(const G &g, Enc &e, int ni, int depth)
 
 // consolidate_prediction_info :3372
 template <class G>
-HENC_HD void consolidate_prediction_info(const G &g, Enc &e, int pi, uint32_t parent_cost, uint32_t children_cost, int is_max_depth, uint32_t *cost_sum)
+HENC_HD void consolidate_prediction_info(const G &g, Enc &__restrict__ e, int pi, uint32_t parent_cost, uint32_t children_cost, int is_max_depth, uint32_t *cost_sum)
 {
 	const Geo &pq = e.geo[pi];
 	Node &pn = node_of(e, pi);
@@ -143,7 +143,7 @@ HENC_HD void consolidate_prediction_info(const G &g, Enc &e, int pi, uint32_t pa
 // the reference-sample refresh after a CU (sub)tree is final: bottom row / right column of the consolidated reconstruction
 // into the deeper windows (hmr_motion_inter.c:3985-4001 and :4222-4230, hmr_motion_intra.c:1899-1916, 1956-1974)
 template <class G>
-HENC_HD void refresh_deeper_windows(const G &g, Enc &e, int aux_ni, int from_depth, int with_info)
+HENC_HD void refresh_deeper_windows(const G &g, Enc &__restrict__ e, int aux_ni, int from_depth, int with_info)
 {
 	const int max_processing_depth = hmin(e.seq->max_pred_depth + e.seq->max_intra_tr_depth - 1, NDEPTH - 1);
 	if (from_depth > max_processing_depth) return;
@@ -157,7 +157,7 @@ HENC_HD void refresh_deeper_windows(const G &g, Enc &e, int aux_ni, int from_dep
 
 // encode_intra, hmr_motion_intra.c:1731
 template <class G>
-HENC_HD uint32_t encode_intra(const G &g, Enc &e, int curr_depth, int position, int part_size_type)
+HENC_HD uint32_t encode_intra(const G &g, Enc &__restrict__ e, int curr_depth, int position, int part_size_type)
 {
 	uint32_t cost = 0;
 	if (part_size_type == PART_2Nx2N) {
@@ -177,7 +177,7 @@ HENC_HD uint32_t encode_intra(const G &g, Enc &e, int curr_depth, int position, 
 
 // check_rd_cost_merge_2nx2n :3493 (P slice)
 template <class G>
-HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &e, int depth, int position)
+HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth, int position)
 {
 	Work &w = *e.w;
 	const Seq &S = *e.seq;
@@ -282,7 +282,7 @@ HENC_INLINE double intra_cost_with_ratio(double intra_dist, double ratio, double
 
 // motion_inter_full :3746
 template <class G>
-HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &e)
+HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &__restrict__ e)
 {
 	const Seq &S = *e.seq;
 	CtuPublic &c = *e.ctu;
@@ -445,7 +445,7 @@ HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &e)
 
 // motion_intra_cu, hmr_motion_intra.c:1759 (performance_mode <= 2: no variance pre-analysis)
 template <class G>
-HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &e)
+HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 {
 	const Seq &S = *e.seq;
 	CtuPublic &c = *e.ctu;
@@ -527,7 +527,7 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &e)
 
 // ---- CTU set-up and tear-down ---------------------------------------------------------------------------------------------
 // create_partition_ctu_neighbours, hmr_motion_intra.c:658 + cu_partition_get_neighbours :629
-HENC_INLINE void create_partition_neighbours(Enc &e)
+HENC_INLINE void create_partition_neighbours(Enc &__restrict__ e)
 {
 	const Seq &S = *e.seq;
 	CtuPublic &c = *e.ctu;
@@ -578,7 +578,7 @@ HENC_INLINE void create_partition_neighbours(Enc &e)
 
 // init_ctu :2254 + CuGetNeighbors :2160, mem_transfer_move_curr_ctu_group / mem_transfer_intra_refs (hmr_mem_transfer.c:284,351)
 template <class G>
-HENC_HD void ctu_begin(const G &g, Enc &e, int ctu_num)
+HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 {
 	PRIM_T0();
 	const Seq &S = *e.seq;
@@ -662,7 +662,7 @@ HENC_HD void ctu_begin(const G &g, Enc &e, int ctu_num)
 
 // mem_transfer_decoded_blocks :312 + the coefficient copy (hmr_encoder_lib.c:2942-2945) + the thread counters (:2924-2940)
 template <class G>
-HENC_HD void ctu_end(const G &g, Enc &e)
+HENC_HD void ctu_end(const G &g, Enc &__restrict__ e)
 {
 	PRIM_T0();
 	const Seq &S = *e.seq;
@@ -707,7 +707,7 @@ HENC_HD void resolve_mode_tokens(const G &g, Work &w, CtuPublic &c)
 }
 
 template <class G>
-HENC_HD void encode_ctu(const G &g, Enc &e, int ctu_num)
+HENC_HD void encode_ctu(const G &g, Enc &__restrict__ e, int ctu_num)
 {
 	{ HENC_PROF_T0(); ctu_begin(g, e, ctu_num); HENC_PROF_ADD(e, PF_SETUP); }
 	if (e.f->slice_type != SLICE_I && !e.f->is_scene_change) motion_inter_ctu(g, e);

@@ -11,7 +11,7 @@ namespace henc {
 // ---- motion compensation ------------------------------------------------------------------------------------------
 // `ref` points at the co-located block (mv = 0) in the padded reference plane
 template <class G>
-HENC_HD void mc_luma(const G &g, Enc &e, const int16_t *ref, int rs, int16_t *pred, int ps, int n, int mvx, int mvy)
+HENC_HD void mc_luma(const G &g, Enc &__restrict__ e, const int16_t *ref, int rs, int16_t *pred, int ps, int n, int mvx, int mvy)
 {
 	const int xf = mvx & 3, yf = mvy & 3;
 	const int16_t *src = ref + (mvy >> 2) * rs + (mvx >> 2);
@@ -24,7 +24,7 @@ HENC_HD void mc_luma(const G &g, Enc &e, const int16_t *ref, int rs, int16_t *pr
 	}
 }
 template <class G>
-HENC_HD void mc_chroma(const G &g, Enc &e, const int16_t *ref, int rs, int16_t *pred, int ps, int n, int mvx, int mvy)
+HENC_HD void mc_chroma(const G &g, Enc &__restrict__ e, const int16_t *ref, int rs, int16_t *pred, int ps, int n, int mvx, int mvy)
 {
 	const int xf = mvx & 7, yf = mvy & 7;
 	const int16_t *src = ref + (mvy >> 3) * rs + (mvx >> 3);
@@ -78,7 +78,7 @@ HENC_INLINE uint32_t mv_cost_sqrt(const MvCandList &l, uint32_t qp, int mvx, int
 // ---- hmr_motion_estimation :1404-1775 --------------------------------------------------------------------------------
 // orig: source block (CTU window); ref: co-located block in the padded reference.  Returns the best SAD.
 template <class G>
-HENC_HD uint32_t motion_estimation(const G &g, Enc &e, const int16_t *orig, const int16_t *ref, int rs, int gx, int gy, int size,
+HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, const int16_t *orig, const int16_t *ref, int rs, int gx, int gy, int size,
 				   const MvCandList &amvp, const MvCandList &search, double corr, int action, MV *mv_io, MV *subpix_out)
 {
 	const int ds[4][2] = {{-1, 0}, {0, -1}, {1, 0}, {0, 1}};
@@ -203,7 +203,7 @@ HENC_INLINE int raster2abs(int r)   // raster2abs_table for the 16 x 16 unit gri
 	return a;
 }
 struct CornerNodes { int lb, tl, tr; };
-HENC_INLINE CornerNodes corner_nodes(Enc &e, int ni)
+HENC_INLINE CornerNodes corner_nodes(Enc &__restrict__ e, int ni)
 {
 	const Geo &q = e.geo[ni];
 	const int np = q.size >> 2, base = e.seq->depth_start[e.seq->max_cu_depth];
@@ -224,7 +224,7 @@ HENC_INLINE int add_amvp_cand(MvCandList &l, CtuPublic *c, uint32_t idx)
 	return 0;
 }
 // get_amvp_candidates :2342
-HENC_INLINE void get_amvp_candidates(Enc &e, int ni, MvCandList &l)
+HENC_INLINE void get_amvp_candidates(Enc &__restrict__ e, int ni, MvCandList &l)
 {
 	const CornerNodes cn = corner_nodes(e, ni);
 	uint32_t idx_lb = 0, idx_l = 0, idx_aux = 0;
@@ -288,7 +288,7 @@ HENC_INLINE int equal_motion(const CtuPublic *a, uint32_t ia, const CtuPublic *b
 	return 1;
 }
 // get_merge_mvp_candidates :1937, P slice.  inter_modes[k] = inter_mode of candidate k's source unit.
-HENC_INLINE void get_merge_candidates(Enc &e, int ni, MvCandList &l, uint8_t *inter_modes)
+HENC_INLINE void get_merge_candidates(Enc &__restrict__ e, int ni, MvCandList &l, uint8_t *inter_modes)
 {
 	const int max_cand = e.seq->num_merge_cand;
 	const CornerNodes cn = corner_nodes(e, ni);
@@ -359,7 +359,7 @@ HENC_INLINE void get_merge_candidates(Enc &e, int ni, MvCandList &l, uint8_t *in
 // ---- inter TUs ---------------------------------------------------------------------------------------------------------
 // encode_inter_cu :40 (comp 0) / encode_inter_cu_chroma :133: DCT + quant, keep-or-drop decision in the residual domain, reconstruction
 template <class G>
-HENC_HD uint32_t encode_inter_tu(const G &g, Enc &e, int ni, int comp, int depth, int part_size_type, int *curr_sum)
+HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int comp, int depth, int part_size_type, int *curr_sum)
 {
 	Work &w = *e.w;
 	Node &nd = node_of(e, ni);
@@ -411,7 +411,7 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &e, int ni, int comp, int depth
 
 // SET_ENC_INFO_BUFFS :2451
 template <class G>
-HENC_HD void set_enc_info_buffs(const G &g, Enc &e, int ni, int depth)
+HENC_HD void set_enc_info_buffs(const G &g, Enc &__restrict__ e, int ni, int depth)
 {
 	const Geo &q = e.geo[ni];
 	const Node &nd = node_of(e, ni);
@@ -427,7 +427,7 @@ HENC_HD void set_enc_info_buffs(const G &g, Enc &e, int ni, int depth)
 
 // encode_inter :3071 - the transform tree of an inter CU; referenced by the prediction depth
 template <class G>
-HENC_HD uint32_t encode_inter(const G &g, Enc &e, int depth, int part_position, int part_size_type)
+HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
 {
 	const Seq &S = *e.seq;
 	Work &w = *e.w;
@@ -565,7 +565,7 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &e, int depth, int part_position, 
 
 // SET_INTER_MV_BUFFS :2460 + the reference-index memsets that follow it in predict_inter :3042-3044
 template <class G>
-HENC_HD void set_inter_mv_buffs(const G &g, Enc &e, int ni)
+HENC_HD void set_inter_mv_buffs(const G &g, Enc &__restrict__ e, int ni)
 {
 	const Geo &q = e.geo[ni];
 	const Node &nd = node_of(e, ni);
@@ -577,7 +577,7 @@ HENC_HD void set_inter_mv_buffs(const G &g, Enc &e, int ni)
 }
 
 template <class G>
-HENC_HD void predict_all_comps(const G &g, Enc &e, int ni)
+HENC_HD void predict_all_comps(const G &g, Enc &__restrict__ e, int ni)
 {
 	Work &w = *e.w;
 	const Geo &q = e.geo[ni];
@@ -587,7 +587,7 @@ HENC_HD void predict_all_comps(const G &g, Enc &e, int ni)
 }
 
 template <class G>
-HENC_HD void motion_compensate_cu(const G &g, Enc &e, int ni, MV mv)
+HENC_HD void motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv)
 {
 	Work &w = *e.w;
 	const Geo &q = e.geo[ni];
@@ -608,7 +608,7 @@ HENC_HD void motion_compensate_cu(const G &g, Enc &e, int ni, MV mv)
 }
 // one chroma plane of the same (what a helper wavefront runs)
 template <class G>
-HENC_HD void motion_compensate_chroma_comp(const G &g, Enc &e, int ni, int comp, MV mv)
+HENC_HD void motion_compensate_chroma_comp(const G &g, Enc &__restrict__ e, int ni, int comp, MV mv)
 {
 	Work &w = *e.w;
 	const Geo &q = e.geo[ni];
@@ -619,7 +619,7 @@ HENC_HD void motion_compensate_chroma_comp(const G &g, Enc &e, int ni, int comp,
 
 // predict_inter :2924 (uni-directional): vector predictor choice, motion compensation, residual.  Returns the vector cost.
 template <class G>
-HENC_HD int predict_inter(const G &g, Enc &e, int depth, int part_position, int part_size_type)
+HENC_HD int predict_inter(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
 {
 	int curr = node_at(e, depth, part_position), num_partitions = 1;
 	if (part_size_type == PART_NxN) {
@@ -643,7 +643,7 @@ HENC_HD int predict_inter(const G &g, Enc &e, int depth, int part_position, int 
 
 // hmr_cu_motion_estimation :2471 (list 0, one reference).  Returns SAD + vector cost.
 template <class G>
-HENC_HD int cu_motion_estimation(const G &g, Enc &e, int depth, int part_position, int part_size_type, int action)
+HENC_HD int cu_motion_estimation(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type, int action)
 {
 	Work &w = *e.w;
 	const Seq &S = *e.seq;

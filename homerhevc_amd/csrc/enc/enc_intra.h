@@ -16,7 +16,7 @@ HENC_INLINE int intra_is_filtered(int mode, int inv_depth)
 
 // fill_reference_samples for the node's block of component class `comp` in decoded window `wnd` (+ smoothing when asked)
 template <class G>
-HENC_HD void node_fill_refs(const G &g, Enc &e, int ni, int wnd, int comp, int want_filtered)
+HENC_HD void node_fill_refs(const G &g, Enc &__restrict__ e, int ni, int wnd, int comp, int want_filtered)
 {
 	const Geo &q = e.geo[ni];
 	const Node &nd = node_of(e, ni);
@@ -43,7 +43,7 @@ HENC_HD void node_fill_refs(const G &g, Enc &e, int ni, int wnd, int comp, int w
 // search that used such a guess logs where its two neighbour directions came from and the SAD of every mode it tried
 // (SearchLog); enc_sched.h replays the search walk on that table with the true directions and re-encodes the CTU only when
 // the winner, its cost or its bit cost would have been different.
-HENC_INLINE int read_mode_buff(Enc &e, int depth, uint32_t idx, uint16_t *src)
+HENC_INLINE int read_mode_buff(Enc &__restrict__ e, int depth, uint32_t idx, uint16_t *src)
 {
 	const int v = e.w->intra_mode_buffs[COMP_Y][depth][idx];
 	if (!(v & MODE_TOKEN)) { *src = (uint16_t)v; return v; }
@@ -69,7 +69,7 @@ HENC_INLINE void mpm_from_dirs(int left_dir, int top_dir, int *preds)
 		else preds[2] = (left_dir + top_dir) < 2 ? VER_IDX : DC_IDX;
 	}
 }
-HENC_INLINE void intra_neighbour_dirs(Enc &e, int ni, int depth, int *dirs, uint16_t *src)
+HENC_INLINE void intra_neighbour_dirs(Enc &__restrict__ e, int ni, int depth, int *dirs, uint16_t *src)
 {
 	uint32_t idx = 0;
 	CtuPublic *cl = pu_left(e, ni, &idx);
@@ -136,7 +136,7 @@ HENC_INLINE uint32_t intra_luma_cost(uint32_t tu_cost, int mode_bits, double cor
 
 // homer_loop1_motion_intra, hmr_motion_intra.c:1084-1180.  Returns the bit cost of the winner; *best_mode / *best_cost out.
 template <class G>
-HENC_HD int intra_mode_search(const G &g, Enc &e, int ni, int depth, int *best_mode_out, double *best_cost_out)
+HENC_HD int intra_mode_search(const G &g, Enc &__restrict__ e, int ni, int depth, int *best_mode_out, double *best_cost_out)
 {
 	const Geo &q = e.geo[ni];
 	Work &w = *e.w;
@@ -192,7 +192,7 @@ HENC_HD int intra_mode_search(const G &g, Enc &e, int ni, int depth, int *best_m
 
 // encode_intra_cu, hmr_motion_intra.c:973-1071: one luma TU.  depth = prediction depth.  Returns the SSD, *curr_sum the level sum.
 template <class G>
-HENC_HD uint32_t encode_intra_tu(const G &g, Enc &e, int ni, int depth, int cu_mode, int part_size_type, int *curr_sum)
+HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int depth, int cu_mode, int part_size_type, int *curr_sum)
 {
 	const Geo &q = e.geo[ni];
 	Node &nd = node_of(e, ni);
@@ -229,7 +229,7 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &e, int ni, int depth, int cu_m
 }
 
 template <class G>
-HENC_HD void set_intra_info_buffs(const G &g, Enc &e, int depth, int ni)
+HENC_HD void set_intra_info_buffs(const G &g, Enc &__restrict__ e, int depth, int ni)
 {
 	const Geo &q = e.geo[ni];
 	const Node &nd = node_of(e, ni);
@@ -244,7 +244,7 @@ HENC_HD void set_intra_info_buffs(const G &g, Enc &e, int depth, int ni)
 
 // encode_intra_luma, hmr_motion_intra.c:1229-1630 (non-HM path): search, then the transform tree of the winner.
 template <class G>
-HENC_HD uint32_t encode_intra_luma(const G &g, Enc &e, int depth, int part_position, int part_size_type)
+HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
 {
 	const Seq &S = *e.seq;
 	Work &w = *e.w;
@@ -375,7 +375,7 @@ HENC_INLINE void chroma_dir_list(int *list, int luma_mode)
 
 // one chroma plane of the candidate search of encode_intra_chroma: SAD of the five candidates on the unfiltered neighbours of the auxiliary window
 template <class G>
-HENC_HD void chroma_search_comp(const G &g, Enc &e, int curr, int c, const int *cand, uint32_t *sads)
+HENC_HD void chroma_search_comp(const G &g, Enc &__restrict__ e, int curr, int c, const int *cand, uint32_t *sads)
 {
 	Work &w = *e.w;
 	const Geo &q = e.geo[curr];
@@ -389,7 +389,7 @@ HENC_HD void chroma_search_comp(const G &g, Enc &e, int curr, int c, const int *
 }
 // one chroma TU of the winner: neighbours, prediction, residual, transform chain, reconstruction into the auxiliary window.  Returns the weighted SSD.
 template <class G>
-HENC_HD int chroma_tu_comp(const G &g, Enc &e, int curr, int c, int cu_mode, int scan_mode, int shifts, int per, int rem, int *curr_sum_out)
+HENC_HD int chroma_tu_comp(const G &g, Enc &__restrict__ e, int curr, int c, int cu_mode, int scan_mode, int shifts, int per, int rem, int *curr_sum_out)
 {
 	Work &w = *e.w;
 	const Geo &q = e.geo[curr];
@@ -418,7 +418,7 @@ HENC_HD int chroma_tu_comp(const G &g, Enc &e, int curr, int c, int cu_mode, int
 
 // encode_intra_chroma, hmr_motion_intra_chroma.c:114-469 (non-HM path, rd_mode != RD_FULL)
 template <class G>
-HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &e, int depth, int part_position, int part_size_type)
+HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
 {
 	const Seq &S = *e.seq;
 	Work &w = *e.w;
@@ -594,6 +594,6 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &e, int depth, int part_pos
 }
 
 template <class G>
-HENC_HD uint32_t encode_intra(const G &g, Enc &e, int curr_depth, int position, int part_size_type);
+HENC_HD uint32_t encode_intra(const G &g, Enc &__restrict__ e, int curr_depth, int position, int part_size_type);
 
 }  // namespace henc

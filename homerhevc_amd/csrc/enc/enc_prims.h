@@ -8,7 +8,7 @@
 
 // Primitive-level timers of the profiling build (-DHENC_PROFILE, device only): lane 0 adds s_memtime ticks and a call count per primitive class
 // to a small table at the end of the worker's LDS; k_encode_ctus folds it into the per-row profile.
-enum { PP_SAD = 0, PP_SSD, PP_BLK, PP_FILLREF, PP_ADIFILT, PP_INTRAPRED, PP_INTERP, PP_TRF, PP_TRI, PP_QUANT, PP_DEQUANT, PP_CAND, PP_SYNC, PP_INFO, PP_CTU_IO, PP_COUNT };
+enum { PP_SAD = 0, PP_SSD, PP_BLK, PP_FILLREF, PP_ADIFILT, PP_INTRAPRED, PP_INTERP, PP_TRF, PP_TRI, PP_QUANT, PP_DEQUANT, PP_CAND, PP_SYNC, PP_INFO, PP_CTU_IO, PP_HWAIT, PP_COUNT };
 #if defined(__HIPCC__) && defined(HENC_PROFILE)
 extern __shared__ __align__(16) unsigned char henc_lds[];
 #define HENC_LDS_PROF_OFFSET (159 * 1024)

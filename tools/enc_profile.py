@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import encoder_cases as ec  # noqa: E402
 
 PHASES = ["setup", "merge", "me_int", "me_sub(+int)", "pred_inter", "enc_inter", "intra_search", "intra_luma(+search)", "intra_chroma", "consolidate", "wait", "total"]
-PRIMS = ["sad", "ssd", "blk(copy/predict/reconst)", "fill_refs", "adi_filter", "intra_pred", "interp", "tr_fwd", "tr_inv", "quant", "dequant", "candidates(merge/amvp)", "sync copies", "info-buffer copies", "ctu begin/end"]
+PRIMS = ["sad", "ssd", "blk(copy/predict/reconst)", "fill_refs", "adi_filter", "intra_pred", "interp", "tr_fwd", "tr_inv", "quant", "dequant", "candidates(merge/amvp)", "sync copies", "info-buffer copies", "ctu begin/end", "waiting for helpers"]
 NCOL = 12 + 2 * len(PRIMS) + 2
 
 
