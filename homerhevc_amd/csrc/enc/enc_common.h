@@ -43,6 +43,8 @@ struct Enc {
 	// helper wavefronts of the worker (device only; nullptr = everything runs on the group itself)
 	struct HelperBox *box;
 	int16_t *adi_c;                   // neighbour array of a chroma block: Work::adi, or a helper's own
+	int16_t *mc_tmp_y;                // first-stage buffer of a two-stage luma interpolation (and its row pitch): Work::sub_tmp / 72, or a helper's own
+	int mc_tmp_y_stride;
 	int16_t *mc_tmp_c;                // first-stage buffer of a two-stage chroma interpolation: Work::sub_tmp, or a helper's own
 	int16_t *scratch_a, *scratch_b;   // transform coefficients / rounding remainders of the TU in flight: Work::pred_aux / delta_u, or a helper's own
 	int hseq[2];
@@ -51,7 +53,7 @@ struct Enc {
 // Two helper wavefronts per row worker take the chroma components of a step whose three components are independent (motion compensation, the
 // transform chain of a TU) and single candidates of the intra mode search, while the worker itself does luma / the first candidate.  The worker
 // posts a job in LDS and goes on; a helper runs the same SPMD code on its own 64 lanes with its own scratch and reports back.
-enum { HJOB_NONE = 0, HJOB_NEW_CTU, HJOB_MC_CHROMA, HJOB_INTER_TU, HJOB_INTRA_SAD, HJOB_SYNC_CU, HJOB_SSD, HJOB_CHROMA_SEARCH, HJOB_CHROMA_TU, HJOB_QUIT };
+enum { HJOB_NONE = 0, HJOB_NEW_CTU, HJOB_MC_CHROMA, HJOB_INTER_TU, HJOB_INTRA_SAD, HJOB_SYNC_CU, HJOB_SSD, HJOB_CHROMA_SEARCH, HJOB_CHROMA_TU, HJOB_SUBPEL, HJOB_QUIT };
 struct HelperBox {
 	int cmd[2], done[2];       // sequence numbers: helper h runs its next job when cmd[h] moves on, and sets done[h] = cmd[h] when finished
 	int job[2];
@@ -191,10 +193,10 @@ HENC_HD void sync_cu_comp(const G &g, Enc &__restrict__ e, int ni, int q_src, in
 	const int16_t *qs = tq_ptr(*e.w, q_src, comp) + off;
 	int16_t *qd = tq_ptr(*e.w, q_dst, comp) + off;
 	const int ln = ilog2i(n);
-	for (int i = g.tid; i < n * n; i += g.n) {
+	for (int i = g.tid * 4; i < n * n; i += g.n * 4) {      // four samples per lane and step (enc_prims.h)
 		const int r = i >> ln, c = i & (n - 1);
-		dd[r * st + c] = ds[r * st + c];
-		qd[i] = qs[i];
+		st4(dd + r * st + c, ld4(ds + r * st + c));
+		st4(qd + i, ld4(qs + i));
 	}
 	g.sync();
 	PRIM_END(PP_SYNC);

@@ -597,6 +597,8 @@ HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 	e.scratch_a = w.pred_aux;
 	e.scratch_b = w.delta_u;
 	e.mc_tmp_c = w.sub_tmp;
+	e.mc_tmp_y = w.sub_tmp;
+	e.mc_tmp_y_stride = 72;
 	e.adi_c = w.adi;
 	const int cx = ctu_num % S.wctu, cy = ctu_num / S.wctu;
 	c.ctu_number = ctu_num;

@@ -18,9 +18,46 @@ HENC_HD void mc_luma(const G &g, Enc &__restrict__ e, const int16_t *ref, int rs
 	if (xf == 0) interp_stage<8>(g, src, rs, pred, ps, yf, n, n, 1, 1, 1);
 	else if (yf == 0) interp_stage<8>(g, src, rs, pred, ps, xf, n, n, 0, 1, 1);
 	else {
-		int16_t *tmp = e.w->sub_tmp;
-		interp_stage<8>(g, src - 3 * rs, rs, tmp, 72, xf, n, n + 7, 0, 1, 0);
-		interp_stage<8>(g, tmp + 3 * 72, 72, pred, ps, yf, n, n, 1, 0, 1);
+		int16_t *tmp = e.mc_tmp_y;
+		const int ts = e.mc_tmp_y_stride;
+		interp_stage<8>(g, src - 3 * rs, rs, tmp, ts, xf, n, n + 7, 0, 1, 0);
+		interp_stage<8>(g, tmp + 3 * ts, ts, pred, ps, yf, n, n, 1, 0, 1);
+	}
+}
+// SAD of one sub-pel candidate of the refinement: interpolate the block at (mvx, mvy) into `out` and compare with the source
+template <class G>
+HENC_HD uint32_t subpel_candidate_sad(const G &g, Enc &__restrict__ e, const int16_t *orig, const int16_t *ref, int rs, int16_t *out, int os, int size, int mvx, int mvy)
+{
+	mc_luma(g, e, ref, rs, out, os, size, mvx, mvy);
+	const uint32_t s = blk_sad(g, orig, CTU_STRIDE_Y, out, os, size);
+	g.sync();
+	return s;
+}
+// the nine candidates of a refinement round around (cx0, cy0) (quarter-sample units relative to the integer vector): with helper wavefronts and blocks
+// up to 16 x 16 three at a time (the helpers interpolate into their own scratch); the comparison afterwards keeps the reference's order
+template <class G>
+HENC_HD void subpel_round_sads(const G &g, Enc &__restrict__ e, const int16_t *orig, int ox, int oy, const int16_t *ref, int rs, int gx, int gy, int size, int base_x, int base_y,
+			       const int (*offs)[2], int scale, int cx0, int cy0, uint32_t *sads)
+{
+	int16_t *sp = e.w->pred_aux;   // scratch: no TU is in flight during the search
+	if (e.box && size <= 16) {
+		for (int i0 = 0; i0 < 9; i0 += 3) {
+			for (int j = 0; j < 2; j++) {
+				const int i = i0 + j, cx = cx0 + offs[i][0] * scale, cy = cy0 + offs[i][1] * scale;
+				helper_post(g, e, j, HJOB_SUBPEL, ox | (oy << 8) | (size << 16), gx, gy, base_x + cx, base_y + cy);
+			}
+			const int i = i0 + 2, cx = cx0 + offs[i][0] * scale, cy = cy0 + offs[i][1] * scale;
+			sads[i] = subpel_candidate_sad(g, e, orig, ref, rs, sp, 64, size, base_x + cx, base_y + cy);
+			for (int j = 0; j < 2; j++) {
+				helper_wait(g, e, j);
+				sads[i0 + j] = e.box->r[j][0];
+			}
+		}
+		return;
+	}
+	for (int i = 0; i < 9; i++) {
+		const int cx = cx0 + offs[i][0] * scale, cy = cy0 + offs[i][1] * scale;
+		sads[i] = subpel_candidate_sad(g, e, orig, ref, rs, sp, 64, size, base_x + cx, base_y + cy);
 	}
 }
 template <class G>
@@ -78,7 +115,7 @@ HENC_INLINE uint32_t mv_cost_sqrt(const MvCandList &l, uint32_t qp, int mvx, int
 // ---- hmr_motion_estimation :1404-1775 --------------------------------------------------------------------------------
 // orig: source block (CTU window); ref: co-located block in the padded reference.  Returns the best SAD.
 template <class G>
-HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, const int16_t *orig, const int16_t *ref, int rs, int gx, int gy, int size,
+HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, const int16_t *orig, int ox, int oy, const int16_t *ref, int rs, int gx, int gy, int size,
 				   const MvCandList &amvp, const MvCandList &search, double corr, int action, MV *mv_io, MV *subpix_out)
 {
 	const int ds[4][2] = {{-1, 0}, {0, -1}, {1, 0}, {0, 1}};
@@ -161,12 +198,11 @@ HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, const int16_
 		int bidx = 0, bx = 0, by = 0;
 		best_x = mvx >> 2; best_y = mvy >> 2;
 		if (!(action & ME_PEL)) cur_sad = HENC_SAD_AT(best_x, best_y);
-		int16_t *sp = e.w->pred_aux;   // scratch: no TU is in flight during the search
+		uint32_t sads[9];
+		subpel_round_sads(g, e, orig, ox, oy, ref, rs, gx, gy, size, best_x << 2, best_y << 2, ref_h, 2, 0, 0, sads);
 		for (int i = 0; i < 9; i++) {
 			const int cx = ref_h[i][0] * 2, cy = ref_h[i][1] * 2;
-			mc_luma(g, e, ref, rs, sp, 64, size, (best_x << 2) + cx, (best_y << 2) + cy);
-			const uint32_t s = blk_sad(g, orig, CTU_STRIDE_Y, sp, 64, size);
-			g.sync();
+			const uint32_t s = sads[i];
 			if (s < cur_sad) { cur_sad = s; bx = cx; by = cy; bidx = i; }
 		}
 		mvx = (best_x << 2) + bx; mvy = (best_y << 2) + by; subx = bx; suby = by;
@@ -174,11 +210,10 @@ HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, const int16_
 		if (action & ME_QUARTER) {
 			const int hx = ref_h[bidx][0], hy = ref_h[bidx][1];
 			bx = hx * 2; by = hy * 2;
+			subpel_round_sads(g, e, orig, ox, oy, ref, rs, gx, gy, size, best_x << 2, best_y << 2, ref_q, 1, hx * 2, hy * 2, sads);
 			for (int i = 0; i < 9; i++) {
 				const int cx = hx * 2 + ref_q[i][0], cy = hy * 2 + ref_q[i][1];
-				mc_luma(g, e, ref, rs, sp, 64, size, (best_x << 2) + cx, (best_y << 2) + cy);
-				const uint32_t s = blk_sad(g, orig, CTU_STRIDE_Y, sp, 64, size);
-				g.sync();
+				const uint32_t s = sads[i];
 				if (s < cur_sad) { cur_sad = s; bx = cx; by = cy; }
 			}
 			best_sad = cur_sad;
@@ -672,7 +707,7 @@ HENC_HD int cu_motion_estimation(const G &g, Enc &__restrict__ e, int depth, int
 			subpix = nd.subpix_mv;
 		}
 		const double corr = calc_mv_correction(nd.qp, e.f->avg_dist);
-		const uint32_t cost = motion_estimation(g, e, w.curr_y + q.y * 64 + q.x, e.f->ref[0] + gy * S.stride_y + gx, S.stride_y, gx, gy, q.size, amvp,
+		const uint32_t cost = motion_estimation(g, e, w.curr_y + q.y * 64 + q.x, q.x, q.y, e.f->ref[0] + gy * S.stride_y + gx, S.stride_y, gx, gy, q.size, amvp,
 							w.search_cands, corr, action, &mv, &subpix);
 		int mvp_idx = 0;
 		const uint32_t mv_cost = mv_cost_fast(amvp, corr, mv.x, mv.y, &mvp_idx);

@@ -33,16 +33,25 @@ HENC_INLINE void split_rc(int k, int w, int lw, int *r, int *c)
 }
 
 // ---- pixel kernels (hmr_sse42_functions_pixel.c:462,728,817,919) -------------------------------------------------
+// A CU's memory pipeline is shared by its wavefronts and a 2-byte-per-lane access costs it as much as an 8-byte one, so every block loop moves
+// FOUR samples per lane and step (one 8-byte access; blocks are at least 4 wide and start at multiples of 4 samples in rows whose pitch is a
+// multiple of 4, except the motion search's reference operand, which may start anywhere: gfx950 runs with unaligned global access enabled).
+struct S4 { int16_t v[4]; };
+HENC_INLINE S4 ld4(const int16_t *p) { S4 r; __builtin_memcpy(&r, p, 8); return r; }
+HENC_INLINE void st4(int16_t *p, const S4 &v) { __builtin_memcpy(p, &v, 8); }
+
 template <class G>
 HENC_PRIM uint32_t blk_sad(const G &g, const int16_t *a, int as, const int16_t *b, int bs, int n)
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
 	uint32_t acc = 0;
-	#pragma unroll 4
-	for (int i = g.tid; i < n * n; i += g.n) {
+#pragma unroll 2
+	for (int i = g.tid * 4; i < n * n; i += g.n * 4) {
 		const int y = i >> l, x = i & (n - 1);
-		acc += (uint32_t)habs((int16_t)(a[y * as + x] - b[y * bs + x]));
+		const S4 va = ld4(a + y * as + x), vb = ld4(b + y * bs + x);
+#pragma unroll
+		for (int k = 0; k < 4; k++) acc += (uint32_t)habs((int16_t)(va.v[k] - vb.v[k]));
 	}
 	{ const auto prim_ret_ = g.sum(acc); PRIM_END(PP_SAD); return prim_ret_; }
 }
@@ -53,11 +62,15 @@ HENC_PRIM uint32_t blk_ssd(const G &g, const int16_t *a, int as, const int16_t *
 	PRIM_T0();
 	const int l = ilog2i(n);
 	uint32_t acc = 0;
-	#pragma unroll 4
-	for (int i = g.tid; i < n * n; i += g.n) {
+#pragma unroll 2
+	for (int i = g.tid * 4; i < n * n; i += g.n * 4) {
 		const int y = i >> l, x = i & (n - 1);
-		const int32_t d = (int16_t)(a[y * as + x] - b[y * bs + x]);
-		acc += (uint32_t)(d * d);
+		const S4 va = ld4(a + y * as + x), vb = ld4(b + y * bs + x);
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const int32_t d = (int16_t)(va.v[k] - vb.v[k]);
+			acc += (uint32_t)(d * d);
+		}
 	}
 	{ const auto prim_ret_ = g.sum(acc); PRIM_END(PP_SSD); return prim_ret_; }
 }
@@ -69,10 +82,11 @@ HENC_PRIM uint32_t blk_ssq(const G &g, const int16_t *a, int as, int n)
 	PRIM_T0();
 	const int l = ilog2i(n);
 	uint32_t acc = 0;
-	#pragma unroll 4
-	for (int i = g.tid; i < n * n; i += g.n) {
-		const int32_t d = a[(i >> l) * as + (i & (n - 1))];
-		acc += (uint32_t)(d * d);
+#pragma unroll 2
+	for (int i = g.tid * 4; i < n * n; i += g.n * 4) {
+		const S4 va = ld4(a + (i >> l) * as + (i & (n - 1)));
+#pragma unroll
+		for (int k = 0; k < 4; k++) acc += (uint32_t)((int32_t)va.v[k] * va.v[k]);
 	}
 	{ const auto prim_ret_ = g.sum(acc); PRIM_END(PP_SSD); return prim_ret_; }
 }
@@ -82,10 +96,14 @@ HENC_PRIM void blk_predict(const G &g, const int16_t *o, int os, const int16_t *
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
-	#pragma unroll 4
-	for (int i = g.tid; i < n * n; i += g.n) {
+#pragma unroll 2
+	for (int i = g.tid * 4; i < n * n; i += g.n * 4) {
 		const int y = i >> l, x = i & (n - 1);
-		r[y * rs + x] = (int16_t)(o[y * os + x] - p[y * ps + x]);
+		const S4 vo = ld4(o + y * os + x), vp = ld4(p + y * ps + x);
+		S4 vr;
+#pragma unroll
+		for (int k = 0; k < 4; k++) vr.v[k] = (int16_t)(vo.v[k] - vp.v[k]);
+		st4(r + y * rs + x, vr);
 	}
 	g.sync();
 	PRIM_END(PP_BLK);
@@ -97,11 +115,15 @@ HENC_PRIM void blk_reconst(const G &g, const int16_t *p, int ps, const int16_t *
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
-	#pragma unroll 4
-	for (int i = g.tid; i < n * n; i += g.n) {
+#pragma unroll 2
+	for (int i = g.tid * 4; i < n * n; i += g.n * 4) {
 		const int y = i >> l, x = i & (n - 1);
-		const int r = res ? res[y * rs + x] : 0;
-		d[y * ds + x] = (int16_t)hclip((int)sat16(p[y * ps + x] + r), 0, 255);
+		const S4 vp = ld4(p + y * ps + x);
+		S4 vr = {{0, 0, 0, 0}}, vd;
+		if (res) vr = ld4(res + y * rs + x);
+#pragma unroll
+		for (int k = 0; k < 4; k++) vd.v[k] = (int16_t)hclip((int)sat16(vp.v[k] + vr.v[k]), 0, 255);
+		st4(d + y * ds + x, vd);
 	}
 	g.sync();
 	PRIM_END(PP_BLK);
@@ -111,12 +133,20 @@ template <class G>
 HENC_PRIM void blk_copy(const G &g, const int16_t *s, int ss, int16_t *d, int ds, int h, int w)
 {
 	PRIM_T0();
-	const int lw = ilog2i(w);
-	#pragma unroll 4
-	for (int i = g.tid; i < h * w; i += g.n) {
-		int y, x;
-		split_rc(i, w, lw, &y, &x);
-		d[y * ds + x] = s[y * ss + x];
+	if ((w & 3) == 0 && (w & (w - 1)) == 0) {
+		const int lw = ilog2i(w);
+#pragma unroll 2
+		for (int i = g.tid * 4; i < h * w; i += g.n * 4) {
+			const int y = i >> lw, x = i & (w - 1);
+			st4(d + y * ds + x, ld4(s + y * ss + x));
+		}
+	} else {
+		const int lw = ilog2i(w);
+		for (int i = g.tid; i < h * w; i += g.n) {
+			int y, x;
+			split_rc(i, w, lw, &y, &x);
+			d[y * ds + x] = s[y * ss + x];
+		}
 	}
 	g.sync();
 	PRIM_END(PP_BLK);

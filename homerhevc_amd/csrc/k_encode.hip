@@ -79,6 +79,8 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 			e.scratch_a = scratch;
 			e.scratch_b = scratch + 1024;
 			e.mc_tmp_c = scratch;
+			e.mc_tmp_y = scratch;
+			e.mc_tmp_y_stride = 16;
 			e.adi_c = scratch + 2048;
 			e.prof = nullptr;
 		}
@@ -101,6 +103,11 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 			const Geo &q = e.geo[a[0]];
 			const int c = a[1] - 1;
 			r0 = blk_ssd(g, e.w->curr_c[c] + q.yc * 32 + q.xc, 32, e.w->pred_c[c] + q.yc * 32 + q.xc, 32, q.size_chroma);
+			break;
+		}
+		case HJOB_SUBPEL: {   // one sub-pel candidate of a block up to 16 x 16: first stage (23 x 16) at scratch, candidate block at scratch + 1024
+			const int ox = a[0] & 255, oy = (a[0] >> 8) & 255, size = a[0] >> 16;
+			r0 = subpel_candidate_sad(g, e, e.w->curr_y + oy * 64 + ox, e.f->ref[0] + a[2] * e.seq->stride_y + a[1], e.seq->stride_y, scratch + 1024, size, size, a[3], a[4]);
 			break;
 		}
 		case HJOB_CHROMA_SEARCH: {
