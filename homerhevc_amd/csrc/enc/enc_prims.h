@@ -421,32 +421,60 @@ HENC_INLINE void chroma_tap_row(int f, int *c)
 	for (int k = 0; k < 4; k++) c[k] = t[f][k];
 }
 
-// one separable stage; NT = 8 (luma) / 4 (chroma).  fraction 0 = the reference's filter_copy variants.
+// one separable stage; NT = 8 (luma) / 4 (chroma).  fraction 0 = the reference's filter_copy variants.  Four outputs per lane and step: a horizontal
+// stage reads its 4 + NT - 1 consecutive samples with 8-byte loads (the source may start at any sample: unaligned global access), a vertical one reads
+// NT rows of four.
 template <int NT, class G>
 HENC_PRIM void interp_stage(const G &g, const int16_t *src, int ss, int16_t *dst, int ds, int fraction, int w, int h, int vert, int first, int last)
 {
 	PRIM_T0();
-	if (fraction == 0) {
-		if (NT == 4 && w < 4) { g.sync(); PRIM_END(PP_INTERP); return; }    // chroma no-op (inter_prediction.c:822-825)
-		const int lw0 = ilog2i(w);
-		#pragma unroll 4
+	if (NT == 4 && w < 4 && fraction == 0) { g.sync(); PRIM_END(PP_INTERP); return; }    // chroma no-op (inter_prediction.c:822-825)
+	const int lw = ilog2i(w);
+	if ((w & 3) != 0 || (fraction != 0 && w * h < 4 * G::n && G::n > 1)) {
+		// blocks too small to give every lane four outputs (and 2-wide chroma blocks): one output per lane
+		int c8[8];
+		if (NT == 8) luma_tap_row(fraction, c8);
+		else chroma_tap_row(fraction, c8);
+		const int rs = vert ? ss : 1;
+		int shift = 6, offset;
+		if (last) { shift += first ? 0 : 6; offset = 1 << (shift - 1); offset += first ? 0 : 8192 << 6; }
+		else { shift -= first ? 6 : 0; offset = first ? -(8192 << shift) : 0; }
+		const int16_t *s0 = src - (NT / 2 - 1) * rs;
 		for (int k = g.tid; k < w * h; k += g.n) {
 			int r, c;
-			split_rc(k, w, lw0, &r, &c);
-			const int v = src[r * ss + c];
-			int16_t o;
-			if (first == last) o = (int16_t)v;
-			else if (first) o = (int16_t)((int16_t)(v << 6) - 8192);
-			else o = (int16_t)hclip((v + 8192 + 32) >> 6, 0, 255);
-			dst[r * ds + c] = o;
+			split_rc(k, w, lw, &r, &c);
+			int sum = 0;
+			for (int t = 0; t < NT; t++) sum += s0[r * ss + c + t * rs] * c8[t];
+			int16_t v = sat16((sum + offset) >> shift);
+			if (last) v = (int16_t)hclip((int)v, 0, 255);
+			dst[r * ds + c] = v;
 		}
 		g.sync();
-		{ PRIM_END(PP_INTERP); return; }
+		PRIM_END(PP_INTERP);
+		return;
+	}
+	if (fraction == 0) {
+#pragma unroll 2
+		for (int k = g.tid * 4; k < w * h; k += g.n * 4) {
+			int r, c;
+			split_rc(k, w, lw, &r, &c);
+			const S4 v = ld4(src + r * ss + c);
+			S4 o;
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				if (first == last) o.v[j] = v.v[j];
+				else if (first) o.v[j] = (int16_t)((int16_t)(v.v[j] << 6) - 8192);
+				else o.v[j] = (int16_t)hclip((v.v[j] + 8192 + 32) >> 6, 0, 255);
+			}
+			st4(dst + r * ds + c, o);
+		}
+		g.sync();
+		PRIM_END(PP_INTERP);
+		return;
 	}
 	int c8[8];
 	if (NT == 8) luma_tap_row(fraction, c8);
 	else chroma_tap_row(fraction, c8);
-	const int rs = vert ? ss : 1;
 	int shift = 6, offset;
 	if (last) {
 		shift += first ? 0 : 6;
@@ -456,18 +484,54 @@ HENC_PRIM void interp_stage(const G &g, const int16_t *src, int ss, int16_t *dst
 		shift -= first ? 6 : 0;
 		offset = first ? -(8192 << shift) : 0;
 	}
-	const int16_t *s0 = src - (NT / 2 - 1) * rs;
-	const int lw = ilog2i(w);
-	#pragma unroll 4
-	for (int k = g.tid; k < w * h; k += g.n) {
-		int r, c;
-		split_rc(k, w, lw, &r, &c);
-		int sum = 0;
+	if (!vert) {
+		constexpr int NS = NT == 8 ? 12 : 8;                  // samples a lane reads: 4 outputs + NT - 1 taps, rounded up to whole loads
+		const int16_t *s0 = src - (NT / 2 - 1);
+#pragma unroll 2
+		for (int k = g.tid * 4; k < w * h; k += g.n * 4) {
+			int r, c;
+			split_rc(k, w, lw, &r, &c);
+			int sv[NS];
 #pragma unroll
-		for (int t = 0; t < NT; t++) sum += s0[r * ss + c + t * rs] * c8[t];
-		int16_t v = sat16((sum + offset) >> shift);
-		if (last) v = (int16_t)hclip((int)v, 0, 255);
-		dst[r * ds + c] = v;
+			for (int q = 0; q < NS / 4; q++) {
+				const S4 v = ld4(s0 + r * ss + c + 4 * q);
+#pragma unroll
+				for (int j = 0; j < 4; j++) sv[4 * q + j] = v.v[j];
+			}
+			S4 o;
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				int sum = 0;
+#pragma unroll
+				for (int t = 0; t < NT; t++) sum += sv[j + t] * c8[t];
+				int16_t v = sat16((sum + offset) >> shift);
+				if (last) v = (int16_t)hclip((int)v, 0, 255);
+				o.v[j] = v;
+			}
+			st4(dst + r * ds + c, o);
+		}
+	} else {
+		const int16_t *s0 = src - (NT / 2 - 1) * ss;
+#pragma unroll 2
+		for (int k = g.tid * 4; k < w * h; k += g.n * 4) {
+			int r, c;
+			split_rc(k, w, lw, &r, &c);
+			int sum[4] = {0, 0, 0, 0};
+#pragma unroll
+			for (int t = 0; t < NT; t++) {
+				const S4 v = ld4(s0 + (r + t) * ss + c);
+#pragma unroll
+				for (int j = 0; j < 4; j++) sum[j] += v.v[j] * c8[t];
+			}
+			S4 o;
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				int16_t v = sat16((sum[j] + offset) >> shift);
+				if (last) v = (int16_t)hclip((int)v, 0, 255);
+				o.v[j] = v;
+			}
+			st4(dst + r * ds + c, o);
+		}
 	}
 	g.sync();
 	PRIM_END(PP_INTERP);
