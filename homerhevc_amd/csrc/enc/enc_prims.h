@@ -237,28 +237,27 @@ HENC_PRIM void intra_fill_refs(const G &g, const int16_t *corner, int stride, in
 		if (left) { pt_ptr--; pt_size++; }
 		else pl_size++;
 	}
-	// available samples
-	#pragma unroll 4
+	// entry k of the array straight from the window, for the entries that are available (first_idx and last_idx always are)
+	auto sample = [&](int k) -> int16_t {
+		if (k < n) return corner[(n + 1 + (n - 1 - k)) * stride];        // bottom-left: adi[n-1-i] = row n+1+i
+		if (k < 2 * n) return corner[(n - (k - n)) * stride];            // left: adi[n+i] = row n-i
+		if (k == 2 * n) return corner[0];
+		if (k <= 3 * n) return corner[k - 2 * n];                        // top
+		return corner[1 + n + (k - 3 * n - 1)];                          // top-right
+	};
+	const int16_t first_sample = sample(first_idx), last_sample = sample(last_idx);
+	// one pass: available samples, and the two substitution runs (the reference copies first, then pads: same result, two barriers fewer)
 	for (int k = g.tid; k < adi_size; k += g.n) {
-		if (k < n) {                       // bottom-left: adi[n-1-i] = row n+1+i
-			const int i = n - 1 - k;
-			if (bottom_left && i < bl_size) adi[k] = corner[(n + 1 + i) * stride];
-		} else if (k < 2 * n) {            // left: adi[n+i] = row n-i
-			if (left) adi[k] = corner[(n - (k - n)) * stride];
-		} else if (k == 2 * n) {
-			if (corner_copy) adi[k] = corner[0];
-		} else if (k <= 3 * n) {           // top
-			if (top) adi[k] = corner[k - 2 * n];
-		} else {                           // top-right
-			const int i = k - 3 * n - 1;
-			if (top_right && i < tr_size) adi[k] = corner[1 + n + i];
-		}
+		bool avail;
+		if (k < n) avail = bottom_left && (n - 1 - k) < bl_size;
+		else if (k < 2 * n) avail = left;
+		else if (k == 2 * n) avail = corner_copy;
+		else if (k <= 3 * n) avail = top;
+		else avail = top_right && (k - 3 * n - 1) < tr_size;
+		if (k >= pl_ptr && k < pl_ptr + pl_size) adi[k] = first_sample;
+		else if (k >= pt_ptr && k < pt_ptr + pt_size) adi[k] = last_sample;
+		else if (avail) adi[k] = sample(k);
 	}
-	g.sync();
-	const int16_t first_sample = adi[first_idx], last_sample = adi[last_idx];
-	g.sync();
-	for (int i = g.tid; i < pl_size; i += g.n) adi[pl_ptr + i] = first_sample;
-	for (int i = g.tid; i < pt_size; i += g.n) adi[pt_ptr + i] = last_sample;
 	g.sync();
 	PRIM_END(PP_FILLREF);
 }
