@@ -280,6 +280,14 @@ HENC_INLINE double intra_cost_with_ratio(double intra_dist, double ratio, double
 	return intra_cost;
 }
 
+// which walk a CTU takes (wfpp_encoder_thread, hmr_encoder_lib.c:2916): intra for I slices and for the CTUs after a scene cut
+HENC_INLINE int ctu_takes_intra_walk(const FrameCtx &f, int ctu_num) { return f.slice_type == SLICE_I || (f.scene_cut_ctu >= 0 && ctu_num > f.scene_cut_ctu); }
+// the detection itself, evaluated when CTU `ctu_num` enters the inter walk with the counters of the CTUs before it (:3791-3793)
+HENC_INLINE int scene_cut_fires(const Seq &S, const FrameCtx &f, uint32_t intra_before, uint32_t parts_before)
+{
+	return f.scene_cut_allowed && parts_before > (uint32_t)(S.nctu * NPART / 10) && (double)intra_before > (double)parts_before * .7;
+}
+
 // motion_inter_full :3746
 template <class G>
 HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &__restrict__ e)
@@ -683,7 +691,7 @@ HENC_HD void ctu_end(const G &g, Enc &__restrict__ e)
 	uint32_t cnt = 0;
 	for (int i = g.tid; i < NPART; i += g.n) cnt += c.pred_mode[i] == PM_INTRA;
 	cnt = g.sum(cnt);
-	c.intra_parts = e.f->slice_type != SLICE_I && !e.f->is_scene_change ? cnt : NPART;
+	c.intra_parts = ctu_takes_intra_walk(*e.f, c.ctu_number) ? NPART : cnt;
 	c.distortion = node_of(e, 0).distortion;
 	e.ctu_g->n_spec_reads = e.n_spec_reads;
 	e.ctu_g->n_ratio_cmp = e.n_ratio_cmp;
@@ -712,7 +720,9 @@ template <class G>
 HENC_HD void encode_ctu(const G &g, Enc &__restrict__ e, int ctu_num)
 {
 	{ HENC_PROF_T0(); ctu_begin(g, e, ctu_num); HENC_PROF_ADD(e, PF_SETUP); }
-	if (e.f->slice_type != SLICE_I && !e.f->is_scene_change) motion_inter_ctu(g, e);
+	const int intra_walk = ctu_takes_intra_walk(*e.f, ctu_num);
+	e.ctu_g->walk_intra = intra_walk;
+	if (!intra_walk) motion_inter_ctu(g, e);
 	else motion_intra_ctu(g, e);
 	ctu_end(g, e);
 }

@@ -172,6 +172,8 @@ inline void begin_frame(const Seq &s, HostState &st, int image_type, FrameCtx &f
 	f.qp = s.qp;
 	f.num_encoded_frames = st.num_encoded_frames;
 	f.is_scene_change = 0;
+	f.scene_cut_ctu = -1;
+	f.scene_cut_allowed = f.slice_type == SLICE_P && st.num_encoded_frames > 1 && 20 < poc - st.last_gop_reinit;
 	f.ref_poc = poc - 1;
 	f.avg_dist = st.avg_dist;
 	const double qp_temp = (double)s.qp - 12;
@@ -191,12 +193,17 @@ inline void begin_frame(const Seq &s, HostState &st, int image_type, FrameCtx &f
 // :3217-3238 after the CTUs of a frame: acc_dist = sum of the CTUs' root distortions (uint32 accumulation)
 inline void end_frame(const Seq &s, HostState &st, const FrameCtx &f, uint32_t acc_dist)
 {
+	const bool scene_change = f.scene_cut_ctu >= 0;     // :3796-3800: the frame was found to be a new scene while it was encoded
+	if (scene_change) {
+		if (s.reinit_gop) st.last_intra = f.poc;
+		st.last_gop_reinit = f.poc;
+	}
 	if (st.num_encoded_frames == 0 || f.slice_type != SLICE_I || s.intra_period == 1) {
 		double a = acc_dist;
 		a /= s.nctu * NPART;
 		a = a < .1 ? .1 : a;
 		if (f.slice_type == SLICE_I) a *= 1.5;
-		else if (f.is_scene_change) a *= 1.375;
+		else if (scene_change) a *= 1.375;
 		st.avg_dist = a;
 	}
 	st.num_encoded_frames++;

@@ -69,6 +69,8 @@ HENC_HD int sched_guesses_hold(const G &g, const CtuInfo &c, const FrameCtx &f, 
 			       uint32_t parts_before, uint32_t used_intra, uint32_t used_parts, int uses_ratio)
 {
 	int bad = 0;
+	if (c.walk_intra != ctu_takes_intra_walk(f, c.ctu_number)) return 0;   // the scene cut moved: the CTU took the wrong walk
+	if (c.walk_intra) uses_ratio = 0;
 	if (c.n_spec_reads > MAX_SEARCH_LOGS || c.n_ratio_cmp > MAX_RATIO_CMP) {
 		// log overflow: everything the CTU was given has to be right
 		for (int i = g.tid; i < NDEPTH * NPART; i += g.n) bad |= true_in[i] != used_in[i];

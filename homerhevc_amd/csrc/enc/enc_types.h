@@ -102,6 +102,7 @@ struct CtuInfo : CtuPublic {
 	double ratio_cmp[4 * MAX_RATIO_CMP];
 	uint8_t ratio_out[MAX_RATIO_CMP];
 	int16_t ratio_slog[MAX_RATIO_CMP];     // the logged search behind the comparison's intra cost, or -1
+	int32_t walk_intra;                    // the CTU took the intra walk (I slice, or after a scene cut)
 	Node nodes[NNODES];
 };
 
@@ -124,6 +125,10 @@ struct Seq {
 
 struct FrameCtx {
 	int32_t slice_type, poc, qp, num_encoded_frames, is_scene_change, ref_poc;
+	// scene-change detection inside a P frame (hmr_motion_inter.c:3791-3806): when the running intra share passes 70 % the remaining CTUs of the frame
+	// take the intra walk.  scene_cut_allowed: the frame-level conditions hold; scene_cut_ctu: the CTU whose inter walk fired the detection (-1 none) -
+	// the CTUs AFTER it are intra.  In raster order it is found on the way, under the row-parallel schedule by the verification (enc_sched.h).
+	int32_t scene_cut_allowed, scene_cut_ctu;
 	double avg_dist, lambda, sqrt_lambda, chroma_weight;
 	double sao_lambda[3];
 	const int16_t *src[3];                 // source picture, first sample

@@ -39,7 +39,7 @@ struct EncDev {
 	int *valid, *dirty;           // [nctu]
 	unsigned long long *hash;     // [nctu] digest of what other CTUs can see of a CTU
 	uint32_t *intra_before, *used_intra, *used_parts;   // [nctu] true intra count before the CTU; the counters it was given
-	int *counters;                // [0] CTUs found wrong by the last check, [1] CTU encodes of the frame
+	int *counters;                // [0] CTUs found wrong by the last check, [1] CTU encodes of the frame, [2] the CTU at which a scene change is detected (-1: none)
 };
 
 __device__ __forceinline__ void wave_copy_words(void *dst, const void *src, int bytes, int tid)
@@ -165,6 +165,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
 	for (int i = g.tid; i < (int)(sizeof(Seq) / 4); i += 64) ((uint32_t *)lseq)[i] = ((const uint32_t *)d.seq)[i];
 	for (int i = g.tid; i < (int)(sizeof(FrameCtx) / 4); i += 64) ((uint32_t *)lframe)[i] = ((const uint32_t *)d.frame)[i];
 	if (g.tid == 0) lw->slow = d.work_slow + row;
+	g.sync();
+	if (g.tid == 0) lframe->scene_cut_ctu = d.counters[2];
 #if defined(HENC_PROFILE)
 	if (g.tid < 2 * PP_COUNT) ((unsigned long long *)(lds + HENC_LDS_PROF_OFFSET))[g.tid] = 0;
 #endif
@@ -281,11 +283,15 @@ __global__ __launch_bounds__(320) void k_sched_scan(EncDev d)
 			for (int dd = 0; dd < NDEPTH; dd++) d.chain_end[(comp * NDEPTH + dd) * NPART + k] = st[comp][dd];
 	} else if (k == NPART) {
 		uint32_t ib = 0;
+		int cut = -1;
+		const FrameCtx &f = *d.frame;
 		for (int n = 0; n < nctu; n++) {
 			d.intra_before[n] = ib;
+			if (cut < 0 && f.slice_type == SLICE_P && scene_cut_fires(*d.seq, f, ib, (uint32_t)n * NPART)) cut = n;
 			ib += d.ctus[n].intra_parts;
 		}
 		d.counters[0] = 0;
+		d.counters[2] = cut;
 	}
 }
 
@@ -293,8 +299,9 @@ __global__ __launch_bounds__(64) void k_sched_check(EncDev d)
 {
 	const int n = blockIdx.x;
 	WaveGrp g{(int)threadIdx.x};
-	const FrameCtx &f = *d.frame;
-	const int uses_ratio = f.slice_type != SLICE_I && !f.is_scene_change;
+	FrameCtx f = *d.frame;
+	f.scene_cut_ctu = d.counters[2];
+	const int uses_ratio = f.slice_type != SLICE_I;
 	const int ok = sched_guesses_hold(g, d.ctus[n], f, d.truth + (size_t)n * MODE_STATE_BYTES, d.guess + (size_t)n * MODE_STATE_BYTES, d.intra_before[n], (uint32_t)n * NPART,
 					  d.used_intra[n], d.used_parts[n], uses_ratio);
 	if (g.tid == 0) {
@@ -423,7 +430,10 @@ int run_ctu_passes(hmr_gpu_enc *e)
 	const Seq &s = e->seq;
 	hipStream_t st = e->ctx->stream;
 	HIP_TRY(hipMemcpyAsync(e->d.ctus_start, e->d.ctus, sizeof(CtuInfo) * s.nctu, hipMemcpyDeviceToDevice, st));
-	HIP_TRY(hipMemsetAsync(e->d.counters, 0, sizeof(int) * 2, st));
+	{
+		static const int zero_counters[3] = {0, 0, -1};
+		HIP_TRY(hipMemcpyAsync(e->d.counters, zero_counters, sizeof zero_counters, hipMemcpyHostToDevice, st));
+	}
 	HIP_TRY(hipEventRecord(e->ctx->ev0, st));
 	int pass = 0;
 	for (;; pass++) {
@@ -432,10 +442,11 @@ int run_ctu_passes(hmr_gpu_enc *e)
 		hipLaunchKernelGGL(k_sched_scan, dim3(1), dim3(320), 0, st, e->d);
 		hipLaunchKernelGGL(k_sched_check, dim3(s.nctu), dim3(64), 0, st, e->d);
 		HIP_TRY(hipGetLastError());
-		int counters[2];
+		int counters[3];
 		HIP_TRY(hipMemcpyAsync(counters, e->d.counters, sizeof counters, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
 		e->last_encodes = counters[1];
+		e->f.scene_cut_ctu = counters[2];
 		if (counters[0] == 0) break;
 		if (pass > s.nctu + 2) {
 			hmr_set_error("hmr_gpu_enc: the CTU schedule did not converge");
@@ -524,7 +535,7 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 	DEV_ALLOC(e->d.intra_before, s.nctu);
 	DEV_ALLOC(e->d.used_intra, s.nctu);
 	DEV_ALLOC(e->d.used_parts, s.nctu);
-	DEV_ALLOC(e->d.counters, 2);
+	DEV_ALLOC(e->d.counters, 4);
 	for (int c = 0; c < 3; c++) {
 		e->src_elems[c] = (size_t)(c ? s.src_stride_c : s.src_stride_y) * (c ? s.height / 2 : s.height);
 		e->pic_elems[c] = (size_t)(c ? s.stride_c : s.stride_y) * ((c ? s.height / 2 : s.height) + 2 * (c ? s.margin_c : s.margin_y));
@@ -655,7 +666,7 @@ extern "C" int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *e, const uint8_t *y, const ui
 			uint8_t *o = records + (size_t)n * REC_BYTES;
 			const CtuPublic &ci = *(const CtuPublic *)(e->h_public.data() + sizeof(CtuPublic) * n);
 			int32_t hdr[8] = {0x43545544, e->f.num_encoded_frames, n, e->f.slice_type, (int32_t)node0[3 * n], (int32_t)node0[3 * n + 1], (int32_t)node0[3 * n + 2],
-					  e->f.is_scene_change};
+					  e->f.scene_cut_ctu >= 0 && n >= e->f.scene_cut_ctu};
 			memcpy(o, hdr, 32); o += 32;
 			for (int k = 0; k < 3; k++) { memcpy(o, ci.cbf[k], 256); o += 256; }
 			memcpy(o, ci.intra_mode[0], 256); o += 256;

@@ -94,7 +94,7 @@ void make_record(Cpu &c, int n, Enc &e)
 	const CtuInfo &ci = c.ctus[n];
 	const Work &w = *c.w;
 	int32_t hdr[8] = {0x43545544, c.f.num_encoded_frames, n, c.f.slice_type, (int32_t)ci.nodes[0].cost, (int32_t)ci.nodes[0].distortion, (int32_t)ci.nodes[0].sum,
-			  c.f.is_scene_change};
+			  c.f.scene_cut_ctu >= 0 && n >= c.f.scene_cut_ctu};
 	memcpy(o, hdr, 32); o += 32;
 	for (int k = 0; k < 3; k++) { memcpy(o, ci.cbf[k], 256); o += 256; }
 	memcpy(o, ci.intra_mode[0], 256); o += 256;
@@ -126,7 +126,7 @@ void record_from_outputs(Cpu &c, int n, const uint8_t *state_after)
 	const CtuInfo &ci = c.ctus[n];
 	memset(o, 0, REC_BYTES);
 	int32_t hdr[8] = {0x43545544, c.f.num_encoded_frames, n, c.f.slice_type, (int32_t)ci.nodes[0].cost, (int32_t)ci.nodes[0].distortion, (int32_t)ci.nodes[0].sum,
-			  c.f.is_scene_change};
+			  c.f.scene_cut_ctu >= 0 && n >= c.f.scene_cut_ctu};
 	memcpy(o, hdr, 32); o += 32;
 	for (int k = 0; k < 3; k++) { memcpy(o, ci.cbf[k], 256); o += 256; }
 	memcpy(o, ci.intra_mode[0], 256); o += 256;
@@ -157,6 +157,7 @@ void sched_verify(Cpu &c, int *n_invalid)
 	uint8_t st[MODE_STATE_BYTES];
 	memcpy(st, c.chain_start, MODE_STATE_BYTES);
 	uint32_t ib = 0;
+	int cut = -1;
 	for (int n = 0; n < s.nctu; n++) {
 		memcpy(&c.truth[(size_t)n * MODE_STATE_BYTES], st, MODE_STATE_BYTES);
 		for (int k = 0; k < NPART; k++) {
@@ -168,10 +169,12 @@ void sched_verify(Cpu &c, int *n_invalid)
 				for (int d = 0; d < NDEPTH; d++) st[(comp * NDEPTH + d) * NPART + k] = col[comp][d];
 		}
 		c.intra_before[n] = ib;
+		if (cut < 0 && c.f.slice_type == SLICE_P && scene_cut_fires(s, c.f, ib, (uint32_t)n * NPART)) cut = n;
 		ib += c.ctus[n].intra_parts;
 	}
+	c.f.scene_cut_ctu = cut;      // where the single thread would have detected a scene change, given what the CTUs before it look like now
 	memcpy(c.chain_end, st, MODE_STATE_BYTES);
-	const int uses_ratio = c.f.slice_type != SLICE_I && !c.f.is_scene_change;
+	const int uses_ratio = c.f.slice_type != SLICE_I;
 	int bad = 0;
 	for (int n = 0; n < s.nctu; n++) {
 		c.valid[n] = (uint8_t)sched_guesses_hold(g, c.ctus[n], c.f, &c.truth[(size_t)n * MODE_STATE_BYTES], &c.guess[(size_t)n * MODE_STATE_BYTES], c.intra_before[n],
@@ -410,6 +413,7 @@ int henc_cpu_frame_ctus(void *h, const uint8_t *y, const uint8_t *u, const uint8
 		e.coeff = c.coeff.data() + (size_t)n * 6144;
 		e.total_intra_partitions = c.intra_parts;
 		e.total_partitions = c.total_parts;
+		if (c.f.scene_cut_ctu < 0 && c.f.slice_type == SLICE_P && scene_cut_fires(s, c.f, c.intra_parts, c.total_parts)) c.f.scene_cut_ctu = n;   // this CTU still takes the inter walk
 		memcpy(c.w->mode_in, c.w->intra_mode_buffs, MODE_STATE_BYTES);   // one worker in raster order: what the buffers hold IS the inherited state
 		if (getenv("HENC_WIPE_NODES")) memset(c.ctus[n].nodes, atoi(getenv("HENC_WIPE_NODES")), sizeof c.ctus[n].nodes);
 		if (getenv("HENC_WIPE_PUBLIC")) memset((CtuPublic *)&c.ctus[n], atoi(getenv("HENC_WIPE_PUBLIC")), offsetof(CtuPublic, sao_recon));

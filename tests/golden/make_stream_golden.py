@@ -28,19 +28,25 @@ CASES = [
     ("1920x1080_cfg2", 1920, 1080, 8, {}),       # BASELINE.json configs[1]
     ("1280x720_intra", 1280, 720, 2, {"intra_period": 1}),   # configs[0]: 720p all-intra, QP 32, one thread
     ("3840x2160_cfg2", 3840, 2160, 2, {}),       # configs[3], one engine's share: the cfg-2 encode at 2160p (I + P)
+    ("200x136_scene_cut", 200, 136, 27, {"cut_at": 24}),     # new scene at frame 24: in-frame scene-change detection (hmr_motion_inter.c:3791), frames 25-26 after it
+    ("416x240_scene_cut", 416, 240, 25, {"cut_at": 23}),
 ]
 
 
 def run(width, height, frames, keys):
+    keys = dict(keys)
+    cut_at = keys.pop("cut_at", None)
     with tempfile.TemporaryDirectory() as tmp:
         yuv = os.path.join(tmp, "in.yuv")
-        gen_yuv.write_clip(yuv, width, height, frames)
+        gen_yuv.write_clip(yuv, width, height, frames, cut_at=cut_at)
         cmd = [os.path.join(ROOT, "oracle", "_ref", "ref_lockstep"), yuv, os.path.join(tmp, "out.265"), str(width), str(height), str(frames),
                "recon=" + os.path.join(tmp, "rec.yuv")] + [f"{k}={v}" for k, v in keys.items()]
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
         stream = open(os.path.join(tmp, "out.265"), "rb").read()
         rec = open(os.path.join(tmp, "rec.yuv"), "rb").read()
     fsz = width * height * 3 // 2
+    if cut_at is not None:
+        keys["cut_at"] = cut_at
     return {"width": width, "height": height, "frames": frames, "keys": keys, "stream_md5": hashlib.md5(stream).hexdigest(), "stream_bytes": len(stream),
             "nal_sizes": [len(x) for x in stream_diff.split_nals(stream)],
             "recon_md5": [hashlib.md5(rec[f * fsz:(f + 1) * fsz]).hexdigest() for f in range(frames)]}

@@ -35,7 +35,9 @@ def gpu():
 def encode(lib, case):
     g = GOLD[case]
     w, h, frames = g["width"], g["height"], g["frames"]
-    cfg = ec.default_cfg(w, h, **g["keys"])
+    keys = dict(g["keys"])
+    cut_at = keys.pop("cut_at", None)
+    cfg = ec.default_cfg(w, h, **keys)
     enc = C.c_void_p()
     rc = lib.hmr_gpu_enc_create(lib._ctx, C.byref(cfg), C.byref(enc))
     assert rc == 0, lib.hmr_gpu_last_error()
@@ -43,7 +45,7 @@ def encode(lib, case):
     rec = C.create_string_buffer(w * h * 3 // 2)
     nbytes = C.c_long()
     stream, recon, log = b"", [], []
-    for f, planes in enumerate(ec.clip_frames(w, h, frames)):
+    for f, planes in enumerate(ec.clip_frames(w, h, frames, cut_at)):
         st = lib.hmr_gpu_enc_encode(enc, *planes, 0, buf, len(buf), C.byref(nbytes), rec)
         assert st in (1, 2), lib.hmr_gpu_last_error()
         stream += buf.raw[:nbytes.value]
@@ -56,7 +58,7 @@ def encode(lib, case):
     return stream, recon
 
 
-@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra", "832x480", "1920x1080_cfg2", "1280x720_intra", "3840x2160_cfg2"])
+@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra", "832x480", "1920x1080_cfg2", "1280x720_intra", "3840x2160_cfg2", "200x136_scene_cut", "416x240_scene_cut"])
 def test_device_stream_is_byte_identical_to_the_reference(gpu, case):
     stream, recon = encode(gpu, case)
     g = GOLD[case]

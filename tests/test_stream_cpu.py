@@ -34,14 +34,16 @@ def cpu():
 def encode(lib, case, sched=0):
     g = GOLD[case]
     w, h, frames = g["width"], g["height"], g["frames"]
-    cfg = ec.default_cfg(w, h, **g["keys"])
+    keys = dict(g["keys"])
+    cut_at = keys.pop("cut_at", None)
+    cfg = ec.default_cfg(w, h, **keys)
     enc = lib.henc_cpu_create(C.byref(cfg))
     assert enc
     lib.henc_cpu_set_sched(enc, sched, 1)
     buf = C.create_string_buffer(4 << 20)
     rec = C.create_string_buffer(w * h * 3 // 2)
     stream, recon = b"", []
-    for planes in ec.clip_frames(w, h, frames):
+    for planes in ec.clip_frames(w, h, frames, cut_at):
         n = lib.henc_cpu_encode_frame(enc, *planes, 0, buf, len(buf), rec)
         assert n > 0
         stream += buf.raw[:n]
@@ -52,7 +54,7 @@ def encode(lib, case, sched=0):
     return stream, recon, list(st)
 
 
-@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra", "832x480", "1280x720_intra"])
+@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra", "832x480", "1280x720_intra", "200x136_scene_cut", "416x240_scene_cut"])
 def test_stream_is_byte_identical_to_the_reference(cpu, case):
     stream, recon, _ = encode(cpu, case)
     g = GOLD[case]
@@ -68,7 +70,7 @@ def test_stream_matches_the_ctu_fixture_stream(cpu):
     assert stream == fx["stream"].tobytes()
 
 
-@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_qp22_perf0"])
+@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_qp22_perf0", "200x136_scene_cut", "416x240_scene_cut"])
 def test_row_parallel_schedule_reproduces_the_single_thread_stream(cpu, case):
     """the device's schedule (row workers with guessed inputs, raster-order verification, selective re-encode; enc_sched.h) emulated with one lane"""
     stream, recon, st = encode(cpu, case, sched=1)

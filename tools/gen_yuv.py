@@ -13,14 +13,21 @@ import sys
 import numpy as np
 
 
-def gen_frames(width, height, frames, seed=1234):
-    """Yield (Y, U, V) uint8 planes for `frames` frames."""
+def gen_frames(width, height, frames, seed=1234, cut_at=None):
+    """Yield (Y, U, V) uint8 planes for `frames` frames.  cut_at = n: from frame n on the content is a different scene (new texture, mirrored and
+    re-scaled base) - what the encoder's scene-change detection reacts to; None (the published clips) = no cut."""
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:height, 0:width]
     base = (128 + 60 * np.sin(xx / 53.0) * np.cos(yy / 41.0) + 40 * np.sin((xx + yy) / 17.0)).astype(np.float32)
     tex = rng.integers(-12, 13, size=(height + 64, width + 64)).astype(np.float32)
+    base2 = tex2 = None
+    if cut_at is not None:
+        base2 = (120 + 70 * np.cos(xx[:, ::-1] / 23.0) * np.sin(yy / 19.0) + 30 * np.sin((2 * xx - yy) / 11.0)).astype(np.float32)
+        tex2 = np.random.default_rng(seed + 1).integers(-40, 41, size=(height + 64, width + 64)).astype(np.float32)
     for n in range(frames):
         dx, dy = 3 * n, 2 * n
+        if cut_at is not None and n >= cut_at:
+            base, tex = base2, tex2
         tx, ty = dx % 64, dy % 64      # the texture window wraps after 21 frames (identical to the published definition before that)
         Y = np.roll(np.roll(base, dx, axis=1), dy, axis=0) + tex[ty:ty + height, tx:tx + width]
         bx, by = 200 + 11 * n, 300 + 7 * n
@@ -34,10 +41,10 @@ def gen_frames(width, height, frames, seed=1234):
         yield Y, U, V
 
 
-def write_clip(path, width, height, frames, seed=1234):
+def write_clip(path, width, height, frames, seed=1234, cut_at=None):
     md5 = hashlib.md5()
     with open(path, "wb") as f:
-        for planes in gen_frames(width, height, frames, seed):
+        for planes in gen_frames(width, height, frames, seed, cut_at):
             for p in planes:
                 b = p.tobytes()
                 md5.update(b)
