@@ -59,6 +59,16 @@ inline bool make_seq(HostCfg cfg, Seq &s, const char **why)
 	s.max_pred_depth = cfg.max_pred_partition_depth > 4 ? 4 : cfg.max_pred_partition_depth;
 	if (s.max_pred_depth != 4) { *why = "max_pred_partition_depth != 4"; return false; }
 	if (cfg.width % (64 >> (s.max_pred_depth - 1)) || cfg.height % (64 >> (s.max_pred_depth - 1))) { *why = "size not a multiple of the minimum CU"; return false; }
+	// Two corners of the reference's CTU-lagged filter pipeline (hmr_encoder_lib.c:2386-2843) that the frame-level passes here do not reproduce
+	// (found by sweeping picture grids against the compiled reference, tools/stream_diff.py): pictures one CTU wide, and - with SAO on - pictures of at
+	// most five CTU columns with at least as many rows as columns (and at least four): the in-row lag conditions (`ctu_num_index >= 3 / 4 / 5`)
+	// then hardly ever hold, the stages run in the row-end flushes instead, and SAO statistics see offsets already applied above them.  Observed:
+	// 3x4, 3x5, 4x4, 5x5, 5x6 differ; 3x3, 4x3, 5x4, 6x5, 6x6, 6x17, 7x4 and everything wider are identical.  Refused rather than approximated.
+	if ((cfg.width + 63) / 64 < 2) { *why = "picture narrower than two CTUs"; return false; }
+	{
+		const int wc = (cfg.width + 63) / 64, hc = (cfg.height + 63) / 64;
+		if (cfg.sample_adaptive_offset && wc <= 5 && hc >= (wc > 4 ? wc : 4)) { *why = "SAO on a picture of at most five CTU columns that has at least as many CTU rows"; return false; }
+	}
 	s.max_intra_tr_depth = cfg.max_intra_tr_depth > 5 ? 5 : cfg.max_intra_tr_depth;
 	s.max_inter_tr_depth = cfg.max_inter_tr_depth > 5 ? 5 : cfg.max_inter_tr_depth;
 	s.min_tu_size_shift = 2;
