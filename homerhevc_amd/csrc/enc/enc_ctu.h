@@ -281,7 +281,14 @@ HENC_INLINE double intra_cost_with_ratio(double intra_dist, double ratio, double
 }
 
 // which walk a CTU takes (wfpp_encoder_thread, hmr_encoder_lib.c:2916): intra for I slices and for the CTUs after a scene cut
-HENC_INLINE int ctu_takes_intra_walk(const FrameCtx &f, int ctu_num) { return f.slice_type == SLICE_I || (f.scene_cut_ctu >= 0 && ctu_num > f.scene_cut_ctu); }
+HENC_INLINE int ctu_takes_intra_walk(const FrameCtx &f, int ctu_num)
+{
+	if (f.slice_type == SLICE_I) return 1;
+	if (f.scene_cut_ctu < 0) return 0;
+	if (!f.lockstep) return ctu_num > f.scene_cut_ctu;
+	// synchronous wavefront: the detecting CTU (thread 0, row 0) decides first in its step; everything else from that step on is intra
+	return ctu_num != f.scene_cut_ctu && ctu_num % f.wctu + 2 * (ctu_num / f.wctu) >= f.scene_cut_ctu % f.wctu + 2 * (f.scene_cut_ctu / f.wctu);
+}
 // the detection itself, evaluated when CTU `ctu_num` enters the inter walk with the counters of the CTUs before it (:3791-3793)
 HENC_INLINE int scene_cut_fires(const Seq &S, const FrameCtx &f, uint32_t intra_before, uint32_t parts_before)
 {

@@ -64,6 +64,9 @@ inline bool make_seq(HostCfg cfg, Seq &s, const char **why)
 	// most five CTU columns with at least as many rows as columns (and at least four): the in-row lag conditions (`ctu_num_index >= 3 / 4 / 5`)
 	// then hardly ever hold, the stages run in the row-end flushes instead, and SAO statistics see offsets already applied above them.  Observed:
 	// 3x4, 3x5, 4x4, 5x5, 5x6 differ; 3x3, 4x3, 5x4, 6x5, 6x6, 6x17, 7x4 and everything wider are identical.  Refused rather than approximated.
+	// WPP threads: 1 = the reference's deterministic single-thread order; one per CTU row = its synchronous-wavefront schedule (enc_sched.h).  Anything in between
+	// makes a thread own several rows, whose order against the other threads' rows is timing in the reference.
+	if (cfg.wfpp_num_threads > 1 && cfg.wfpp_num_threads != (cfg.height + 63) / 64) { *why = "wfpp_num_threads must be 1 or the number of CTU rows"; return false; }
 	if ((cfg.width + 63) / 64 < 2) { *why = "picture narrower than two CTUs"; return false; }
 	{
 		const int wc = (cfg.width + 63) / 64, hc = (cfg.height + 63) / 64;
@@ -183,6 +186,8 @@ inline void begin_frame(const Seq &s, HostState &st, int image_type, FrameCtx &f
 	f.num_encoded_frames = st.num_encoded_frames;
 	f.is_scene_change = 0;
 	f.scene_cut_ctu = -1;
+	f.lockstep = 0;
+	f.wctu = s.wctu;
 	f.scene_cut_allowed = f.slice_type == SLICE_P && st.num_encoded_frames > 1 && 20 < poc - st.last_gop_reinit;
 	f.ref_poc = poc - 1;
 	f.avg_dist = st.avg_dist;

@@ -413,7 +413,7 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 	int16_t *resid = resid_ptr(w, comp) + y * cs + x, *rdec = rdec_ptr(w, comp) + y * cs + x;
 	int16_t *quant = tq_ptr(w, wnd, comp) + off, *iquant = iq_ptr(w, comp) + off;
 	int16_t *dec = dec_ptr(w, wnd, comp) + y * ds + x;
-	tr_forward(g, e.T, resid, cs, e.scratch_a, quant, n, 0);
+	tr_forward(g, e.T, resid, cs, e.scratch_a, e.scratch_b, n, 0);   // stage buffer: the remainder scratch (the reference passes the level window, which the quantiser overwrites anyway; this one is in LDS)
 	int sum = quantize(g, e.T, e.scratch_a, quant, e.scratch_b, SCAN_DIAG, curr_depth, comp, 0, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
 	nd.inter_cbf[comp] = (sum ? 1 : 0) << (original_depth - depth);
 	if (is_y) nd.inter_tr_idx = original_depth - depth;

@@ -210,7 +210,7 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 	node_fill_refs(g, e, ni, wnd, COMP_Y, filt);
 	intra_predict(g, pred, CTU_STRIDE_Y, filt ? w.adi_f : w.adi, n, cu_mode, 1);
 	blk_predict(g, orig, CTU_STRIDE_Y, pred, CTU_STRIDE_Y, resid, CTU_STRIDE_Y, n);
-	tr_forward(g, e.T, resid, CTU_STRIDE_Y, w.pred_aux, quant, n, cu_mode != REG_DCT);   // `quant` doubles as the stage buffer (the reference passes it as aux)
+	tr_forward(g, e.T, resid, CTU_STRIDE_Y, w.pred_aux, w.delta_u, n, cu_mode != REG_DCT);   // stage buffer: the remainder scratch (the reference passes the level window, which the quantiser overwrites anyway)
 	const int sum = quantize(g, e.T, w.pred_aux, quant, w.delta_u, scan_mode, curr_depth, COMP_Y, 1, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
 	*curr_sum = sum;
 	const int tr = curr_depth - depth + (part_size_type == PART_NxN);
@@ -401,7 +401,7 @@ HENC_HD int chroma_tu_comp(const G &g, Enc &__restrict__ e, int curr, int c, int
 	node_fill_refs(g, e, curr, dwnd, c, 0);
 	intra_predict(g, pred, CTU_STRIDE_C, e.adi_c, n, cu_mode, 0);
 	blk_predict(g, orig, CTU_STRIDE_C, pred, CTU_STRIDE_C, resid, CTU_STRIDE_C, n);
-	tr_forward(g, e.T, resid, CTU_STRIDE_C, e.scratch_a, quant, n, 0);
+	tr_forward(g, e.T, resid, CTU_STRIDE_C, e.scratch_a, e.scratch_b, n, 0);
 	const int curr_sum = quantize(g, e.T, e.scratch_a, quant, e.scratch_b, scan_mode, curr_depth, c, 1, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
 	const int cbfv = ((curr_sum ? 1 : 0) << (shifts & 255)) | ((curr_sum ? 1 : 0) << (shifts >> 8));
 	bytes_set(g, &w.cbf_chroma[c - 1][q.abs_index], cbfv, q.num_part);

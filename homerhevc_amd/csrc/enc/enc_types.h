@@ -129,6 +129,8 @@ struct FrameCtx {
 	// take the intra walk.  scene_cut_allowed: the frame-level conditions hold; scene_cut_ctu: the CTU whose inter walk fired the detection (-1 none) -
 	// the CTUs AFTER it are intra.  In raster order it is found on the way, under the row-parallel schedule by the verification (enc_sched.h).
 	int32_t scene_cut_allowed, scene_cut_ctu;
+	// lockstep = 1: the synchronous-wavefront schedule of wfpp_num_threads > 1 (enc_sched.h): "after the cut" then means a later STEP (c + 2r), not a later CTU
+	int32_t lockstep, wctu;
 	double avg_dist, lambda, sqrt_lambda, chroma_weight;
 	double sao_lambda[3];
 	const int16_t *src[3];                 // source picture, first sample

@@ -39,6 +39,8 @@ struct EncDev {
 	int *valid, *dirty;           // [nctu]
 	unsigned long long *hash;     // [nctu] digest of what other CTUs can see of a CTU
 	uint32_t *intra_before, *used_intra, *used_parts;   // [nctu] true intra count before the CTU; the counters it was given
+	uint8_t *rowstate;            // [hctu][MODE_STATE_BYTES] lockstep schedule: the mode buffers of the worker of each CTU row, carried from frame to frame
+	int *row0_checked;            // lockstep schedule: steps for which row 0 has made its scene-change check
 	int *counters;                // [0] CTUs found wrong by the last check, [1] CTU encodes of the frame, [2] the CTU at which a scene change is detected (-1: none)
 };
 
@@ -187,7 +189,74 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
 	e.hseq[0] = e.hseq[1] = 0;
 	e.prof = d.prof ? d.prof + (size_t)row * PF_COUNT : nullptr;
 	uint32_t *my_prefix = d.prefix + (size_t)row * (W + 1);
-	if (pass == 0 && g.tid == 0) my_prefix[0] = 0;
+	if (pass <= 0 && g.tid == 0) my_prefix[0] = 0;
+	if (pass < 0) {
+		// ---- the synchronous wavefront of wfpp_num_threads = CTU rows (enc_sched.h, oracle/ref_ctudump.c HOMER_TURNSTILE): one worker per row with its own mode
+		// buffers, all CTUs of step t = c + 2 * row see the counters as of the end of step t - 1, row 0 alone looks for a scene change and does so first in its step.
+		// No guesses, no verification: one launch per frame.
+		wave_copy_words(&e.w->intra_mode_buffs[0][0][0], d.rowstate + (size_t)row * MODE_STATE_BYTES, MODE_STATE_BYTES, g.tid);
+		g.sync();
+		for (int c = 0; c < W; c++) {
+			const int t = c + 2 * row, n = row * W + c;
+			{
+				HENC_PROF_T0();
+				// every row must have finished its CTUs of the earlier steps
+				for (;;) {
+					int behind = 0;
+					for (int r2 = g.tid; r2 < H; r2 += 64) {
+						const int need = t - 2 * r2 < 0 ? 0 : (t - 2 * r2 < W ? t - 2 * r2 : W);
+						behind |= __hip_atomic_load(&d.progress[r2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need;
+					}
+					if (!g.any(behind)) break;
+					__builtin_amdgcn_s_sleep(8);
+				}
+				HENC_PROF_ADD(e, PF_WAIT);
+			}
+			uint32_t ti = 0, tc = 0;
+			for (int r2 = g.tid; r2 < H; r2 += 64) {
+				const int have = t - 2 * r2 < 0 ? 0 : (t - 2 * r2 < W ? t - 2 * r2 : W);
+				ti += d.prefix[(size_t)r2 * (W + 1) + have];
+				tc += (uint32_t)have;
+			}
+			ti = g.sum(ti);
+			tc = g.sum(tc);
+			if (row == 0) {
+				if (g.tid == 0) {
+					if (d.counters[2] < 0 && lframe->slice_type == SLICE_P && scene_cut_fires(S, *lframe, ti, tc * NPART)) d.counters[2] = n;
+					__hip_atomic_store(d.row0_checked, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			} else if (t < W) {
+				while (__hip_atomic_load(d.row0_checked, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < t + 1) __builtin_amdgcn_s_sleep(4);
+			}
+			g.sync();
+			if (g.tid == 0) lframe->scene_cut_ctu = __hip_atomic_load(&d.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			g.sync();
+			HENC_PROF_T0();
+			wave_copy_words(e.w->mode_in, e.w->intra_mode_buffs, MODE_STATE_BYTES, g.tid);
+			e.total_intra_partitions = ti;
+			e.total_partitions = tc * NPART;
+			e.coeff = d.coeff + (size_t)n * 6144;
+			g.sync();
+			encode_ctu(g, e, n);
+			resolve_mode_tokens(g, *e.w, d.ctus[n]);
+			wave_copy_words(d.outtok + (size_t)n * MODE_STATE_BYTES, e.w->intra_mode_buffs, MODE_STATE_BYTES, g.tid);
+			if (g.tid == 0) my_prefix[c + 1] = my_prefix[c] + d.ctus[n].intra_parts;
+			HENC_PROF_ADD(e, PF_TOTAL);
+			g.sync();
+			if (g.tid == 0) __hip_atomic_store(&d.progress[row], c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		wave_copy_words(d.rowstate + (size_t)row * MODE_STATE_BYTES, &e.w->intra_mode_buffs[0][0][0], MODE_STATE_BYTES, g.tid);
+		helper_post(g, e, 0, HJOB_QUIT);
+		helper_post(g, e, 1, HJOB_QUIT);
+		if (g.tid == 0) atomicAdd(&d.counters[1], W);
+#if defined(HENC_PROFILE)
+		if (g.tid == 0 && e.prof) {
+			const unsigned long long *pp = (const unsigned long long *)(lds + HENC_LDS_PROF_OFFSET);
+			for (int k = 0; k < 2 * PP_COUNT; k++) e.prof[PF_PRIM0 + k] += pp[k];
+		}
+#endif
+		return;
+	}
 	int encodes = 0;
 	for (int c = 0; c < W; c++) {
 		if (row > 0) {
@@ -381,7 +450,7 @@ struct hmr_gpu_enc {
 	std::vector<int16_t> h_coeff;
 	std::vector<int32_t> h_stats, h_params;
 	EntropyState es;
-	int cur;
+	int cur, lockstep;
 	float last_ms, last_total_ms;
 	int last_passes, last_encodes;
 };
@@ -435,6 +504,22 @@ int run_ctu_passes(hmr_gpu_enc *e)
 		HIP_TRY(hipMemcpyAsync(e->d.counters, zero_counters, sizeof zero_counters, hipMemcpyHostToDevice, st));
 	}
 	HIP_TRY(hipEventRecord(e->ctx->ev0, st));
+	if (e->lockstep) {
+		// wfpp_num_threads = CTU rows: the synchronous wavefront, one launch, nothing to verify
+		HIP_TRY(hipMemsetAsync(e->d.progress, 0, sizeof(int) * s.hctu, st));
+		HIP_TRY(hipMemsetAsync(e->d.row0_checked, 0, sizeof(int), st));
+		hipLaunchKernelGGL(k_encode_ctus, dim3(s.hctu), dim3(ENC_THREADS), LDS_BYTES, st, e->d, -1);
+		HIP_TRY(hipGetLastError());
+		int counters[3];
+		HIP_TRY(hipMemcpyAsync(counters, e->d.counters, sizeof counters, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipEventRecord(e->ctx->ev1, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ctx->ev0, e->ctx->ev1));
+		e->last_encodes = counters[1];
+		e->f.scene_cut_ctu = counters[2];
+		e->last_passes = 1;
+		return HMR_GPU_OK;
+	}
 	int pass = 0;
 	for (;; pass++) {
 		HIP_TRY(hipMemsetAsync(e->d.progress, 0, sizeof(int) * s.hctu, st));
@@ -468,6 +553,7 @@ int set_frame(hmr_gpu_enc *e, int slot, int image_type, double avg_dist)
 	e->cur ^= 1;
 	begin_frame(s, e->st, image_type, e->f);
 	if (avg_dist >= 0) e->f.avg_dist = avg_dist;
+	e->f.lockstep = e->lockstep;
 	for (int c = 0; c < 3; c++) {
 		e->f.src[c] = e->src[slot].p[c];
 		e->f.ref[c] = plane0(e, e->cur ^ 1, c);
@@ -536,6 +622,8 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 	DEV_ALLOC(e->d.used_intra, s.nctu);
 	DEV_ALLOC(e->d.used_parts, s.nctu);
 	DEV_ALLOC(e->d.counters, 4);
+	DEV_ALLOC(e->d.rowstate, (size_t)s.hctu * MODE_STATE_BYTES);
+	DEV_ALLOC(e->d.row0_checked, 1);
 	for (int c = 0; c < 3; c++) {
 		e->src_elems[c] = (size_t)(c ? s.src_stride_c : s.src_stride_y) * (c ? s.height / 2 : s.height);
 		e->pic_elems[c] = (size_t)(c ? s.stride_c : s.stride_y) * ((c ? s.height / 2 : s.height) + 2 * (c ? s.margin_c : s.margin_y));
@@ -559,6 +647,7 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 	e->d.tables = ctx->tables;
 	e->d.geo = e->d_geo;
 	e->cur = 0;
+	e->lockstep = e->cfg.wfpp_num_threads > 1;
 	e->last_ms = e->last_total_ms = 0;
 	e->last_passes = e->last_encodes = 0;
 	*out = e;
@@ -571,7 +660,7 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	(void)hipSetDevice(e->ctx->device);
 	(void)hipStreamSynchronize(e->ctx->stream);
 	void *p[] = {e->d_seq, e->d_frame, e->d_geo, e->d.ctus, e->d.ctus_start, e->d.work_slow, e->d.coeff, e->d.progress, e->d.prefix, e->d.prof, e->d.guess, e->d.truth, e->d.outtok,
-		     e->d.chain_start, e->d.chain_end, e->d.valid, e->d.dirty, e->d.hash, e->d.intra_before, e->d.used_intra, e->d.used_parts, e->d.counters, e->d_bytes, e->d_mvx,
+		     e->d.chain_start, e->d.chain_end, e->d.valid, e->d.dirty, e->d.hash, e->d.intra_before, e->d.used_intra, e->d.used_parts, e->d.counters, e->d.rowstate, e->d.row0_checked, e->d_bytes, e->d_mvx,
 		     e->d_mvy, e->d_ref, e->d_qp, e->d_flags, e->d_pd, e->d_ti, e->d_stats, e->d_params};
 	for (void *q : p) (void)hipFree(q);
 	for (int c = 0; c < 3; c++) {

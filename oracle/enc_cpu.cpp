@@ -262,6 +262,45 @@ void sched_pass(Cpu &c, Enc &e, int pass)
 		}
 }
 
+// ---- sched = 2: the synchronous wavefront of wfpp_num_threads = N > 1 (the schedule oracle/ref_ctudump.c's HOMER_TURNSTILE forces on the reference): worker t owns the
+// rows t, t + N, ... with its own mode buffers; the CTUs of step s = c + 2r all see the counters as of the end of step s - 1; thread 0 alone looks for a scene change ----
+void frame_ctus_lockstep(Cpu &c, Enc &e)
+{
+	const Seq &s = c.seq;
+	const int W = s.wctu, H = s.hctu, N = c.cfg.wfpp_num_threads;
+	CpuGrp g;
+	while ((int)c.row_w.size() < N) c.row_w.push_back(new_work());
+	c.f.lockstep = 1;
+	uint32_t done_intra = 0, done_ctus = 0;
+	std::vector<uint8_t> after(s.nctu * MODE_STATE_BYTES);
+	for (int t = 0; t < W + 2 * (H - 1); t++) {
+		uint32_t step_intra = 0, step_ctus = 0;
+		int fired = -1;
+		for (int r = 0; r < H; r++) {
+			const int col = t - 2 * r;
+			if (col < 0 || col >= W) continue;
+			const int n = r * W + col;
+			e.w = c.row_w[r % N];
+			e.coeff = c.coeff.data() + (size_t)n * 6144;
+			e.total_intra_partitions = done_intra;
+			e.total_partitions = done_ctus * NPART;
+			if (r % N == 0 && c.f.scene_cut_ctu < 0 && fired < 0 && c.f.slice_type == SLICE_P && !ctu_takes_intra_walk(c.f, n) &&
+			    scene_cut_fires(s, c.f, done_intra, done_ctus * NPART))
+				c.f.scene_cut_ctu = fired = n;     // thread 0 decides first in its step: the other CTUs of the step already take the intra walk
+			memcpy(e.w->mode_in, e.w->intra_mode_buffs, MODE_STATE_BYTES);
+			encode_ctu(g, e, n);
+			resolve_mode_tokens(g, *e.w, c.ctus[n]);
+			memcpy(&after[(size_t)n * MODE_STATE_BYTES], e.w->intra_mode_buffs, MODE_STATE_BYTES);
+			step_intra += c.ctus[n].intra_parts;
+			step_ctus++;
+			c.acc_dist += c.ctus[n].distortion;
+		}
+		done_intra += step_intra;
+		done_ctus += step_ctus;
+	}
+	for (int n = 0; n < s.nctu; n++) record_from_outputs(c, n, &after[(size_t)n * MODE_STATE_BYTES]);
+}
+
 void frame_ctus_sched(Cpu &c, Enc &e)
 {
 	const Seq &s = c.seq;
@@ -314,6 +353,7 @@ void *henc_cpu_create(const HostCfg *cfg)
 		return nullptr;
 	}
 	make_geo(c->geo);
+	if (cfg->wfpp_num_threads > 1) c->sched = 2;   // one worker per CTU row: the synchronous wavefront
 	const Seq &s = c->seq;
 	c->ctus.resize(s.nctu);
 	memset(c->ctus.data(), 0, sizeof(CtuInfo) * s.nctu);
@@ -342,6 +382,7 @@ void henc_cpu_destroy(void *h)
 
 void henc_cpu_set_sched(void *h, int sched, int row_guess)
 {
+	if (((Cpu *)h)->cfg.wfpp_num_threads > 1) return;   // the schedule follows from the configuration
 	((Cpu *)h)->sched = sched;
 	((Cpu *)h)->row_guess = row_guess;
 }
@@ -406,7 +447,8 @@ int henc_cpu_frame_ctus(void *h, const uint8_t *y, const uint8_t *u, const uint8
 	if (last_ctu < 0 || last_ctu > s.nctu) last_ctu = s.nctu;
 	if (c.sched) {
 		if (first_ctu != 0 || last_ctu != s.nctu) return -1;
-		frame_ctus_sched(c, e);
+		if (c.sched == 2) frame_ctus_lockstep(c, e);
+		else frame_ctus_sched(c, e);
 		first_ctu = last_ctu;
 	}
 	for (int n = first_ctu; n < last_ctu; n++) {

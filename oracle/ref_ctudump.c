@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include "hmr_private.h"
 #include "hmr_common.h"
 
@@ -28,6 +29,101 @@ static void *next(const char *name)
 
 static void put(const void *p, size_t n) { fwrite(p, 1, n, g_dump); }
 
+/* ---- HOMER_TURNSTILE=1: a deterministic schedule for wfpp_num_threads > 1 -------------------------------------------------------------------------
+ * With several WPP threads the reference reads counters that other threads update (hmr_motion_inter.c:3769-3776), so its output depends on timing.
+ * The turnstile forces ONE legal interleaving - the synchronous wavefront: CTU (r, c) belongs to step t = c + 2r; the CTUs of a step start when every
+ * CTU of the steps before has finished completely, none of them leaves its decision function before all of the step have (so that all read the counters
+ * as of the end of step t - 1), and their post-decision sections (counter update is theirs alone; lagged filters / SAO / entropy coding in
+ * hmr_deblock_sao_pad_sync_ctu) run one after the other in row order.  This is the schedule a row-parallel device executes. */
+#define TS_MAX_STEPS 4096
+static pthread_mutex_t ts_m = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t ts_c = PTHREAD_COND_INITIALIZER;
+static int ts_on = -1, ts_frame = -1, ts_W, ts_H, ts_steps_done;
+static int ts_returned[TS_MAX_STEPS], ts_completed[TS_MAX_STEPS], ts_post_done[TS_MAX_STEPS], ts_row0_returned[TS_MAX_STEPS];
+static int ts_enabled(void) { if (ts_on < 0) ts_on = getenv("HOMER_TURNSTILE") ? 1 : 0; return ts_on; }
+static int ts_count(int t)
+{
+	int r, k = 0;
+	for (r = 0; r < ts_H; r++) { const int c = t - 2 * r; if (c >= 0 && c < ts_W) k++; }
+	return k;
+}
+static void ts_enter(henc_thread_t *et, int n)
+{
+	int t;
+	pthread_mutex_lock(&ts_m);
+	if (ts_frame != (int)et->enc_engine->num_encoded_frames) {
+		ts_frame = (int)et->enc_engine->num_encoded_frames;
+		ts_W = et->pict_width_in_ctu; ts_H = et->pict_height_in_ctu;
+		memset(ts_returned, 0, sizeof ts_returned); memset(ts_completed, 0, sizeof ts_completed); memset(ts_post_done, 0, sizeof ts_post_done); memset(ts_row0_returned, 0, sizeof ts_row0_returned);
+		ts_steps_done = 0;
+	}
+	t = n % ts_W + 2 * (n / ts_W);
+	while (ts_steps_done < t) pthread_cond_wait(&ts_c, &ts_m);
+	/* thread 0 is the one that may detect a scene change (et->index == 0, hmr_motion_inter.c:3791): its CTU of the step decides first, so that what the
+	 * other threads read in is_scene_change (:2916) does not depend on timing */
+	if (n >= ts_W && t < ts_W)
+		while (!ts_row0_returned[t]) pthread_cond_wait(&ts_c, &ts_m);
+	pthread_mutex_unlock(&ts_m);
+}
+static void ts_leave_decision(int n)
+{
+	const int t = n % ts_W + 2 * (n / ts_W);
+	pthread_mutex_lock(&ts_m);
+	ts_returned[t]++;
+	if (n < ts_W) ts_row0_returned[t] = 1;
+	pthread_cond_broadcast(&ts_c);
+	while (ts_returned[t] < ts_count(t)) pthread_cond_wait(&ts_c, &ts_m);
+	pthread_mutex_unlock(&ts_m);
+}
+static void ts_post_begin(int n)
+{
+	const int r = n / ts_W, t = n % ts_W + 2 * r;
+	int pos = 0, rr;
+	for (rr = 0; rr < r; rr++) { const int c = t - 2 * rr; if (c >= 0 && c < ts_W) pos++; }
+	pthread_mutex_lock(&ts_m);
+	while (ts_post_done[t] < pos) pthread_cond_wait(&ts_c, &ts_m);
+	pthread_mutex_unlock(&ts_m);
+}
+static void ts_post_end(int n)
+{
+	const int t = n % ts_W + 2 * (n / ts_W);
+	pthread_mutex_lock(&ts_m);
+	ts_post_done[t]++;
+	ts_completed[t]++;
+	while (ts_steps_done < TS_MAX_STEPS && ts_completed[ts_steps_done] == ts_count(ts_steps_done) && ts_steps_done < ts_W + 2 * (ts_H - 1)) ts_steps_done++;
+	pthread_cond_broadcast(&ts_c);
+	pthread_mutex_unlock(&ts_m);
+}
+/* the step starts at init_ctu (hmr_encoder_lib.c:2900), before the thread looks at is_scene_change (:2916) */
+ctu_info_t *init_ctu(henc_thread_t *et)
+{
+	static ctu_info_t *(*real)(henc_thread_t *);
+	if (!real) real = next("init_ctu");
+	if (ts_enabled()) ts_enter(et, et->cu_current);
+	return real(et);
+}
+uint32_t motion_inter(henc_thread_t *et, ctu_info_t *ctu)
+{
+	static uint32_t (*real)(henc_thread_t *, ctu_info_t *);
+	uint32_t r;
+	if (!real) real = next("motion_inter");
+	if (!ts_enabled()) return real(et, ctu);
+	r = real(et, ctu);
+	ts_leave_decision(ctu->ctu_number);
+	return r;
+}
+uint32_t motion_intra(henc_thread_t *et, ctu_info_t *ctu, int gcnt)
+{
+	static uint32_t (*real)(henc_thread_t *, ctu_info_t *, int);
+	uint32_t r;
+	if (!real) real = next("motion_intra");
+	if (!ts_enabled()) return real(et, ctu, gcnt);
+	r = real(et, ctu, gcnt);
+	ts_leave_decision(ctu->ctu_number);
+	return r;
+}
+
+
 void hmr_deblock_sao_pad_sync_ctu(henc_thread_t *et, slice_t *currslice, ctu_info_t *ctu)
 {
 	static void (*real)(henc_thread_t *, slice_t *, ctu_info_t *);
@@ -35,6 +131,7 @@ void hmr_deblock_sao_pad_sync_ctu(henc_thread_t *et, slice_t *currslice, ctu_inf
 		real = next("hmr_deblock_sao_pad_sync_ctu");
 		if (getenv("HOMER_CTUDUMP")) g_dump = fopen(getenv("HOMER_CTUDUMP"), "wb");
 	}
+	if (ts_enabled()) ts_post_begin(ctu->ctu_number);
 	if (g_dump) {
 		int32_t hdr[8] = {0x43545544, et->enc_engine->num_encoded_frames, ctu->ctu_number, (int32_t)currslice->slice_type,
 				  (int32_t)ctu->partition_list[0].cost, (int32_t)ctu->partition_list[0].distortion, (int32_t)ctu->partition_list[0].sum,
@@ -57,6 +154,7 @@ void hmr_deblock_sao_pad_sync_ctu(henc_thread_t *et, slice_t *currslice, ctu_inf
 		fflush(g_dump);
 	}
 	real(et, currslice, ctu);
+	if (ts_enabled()) ts_post_end(ctu->ctu_number);
 }
 
 /* the SAO decision of every CTU, logged when it is entropy coded (wfpp_encode_ctu, hmr_encoder_lib.c:2347) */

@@ -30,6 +30,11 @@ CASES = [
     ("3840x2160_cfg2", 3840, 2160, 2, {}),       # configs[3], one engine's share: the cfg-2 encode at 2160p (I + P)
     ("200x136_scene_cut", 200, 136, 27, {"cut_at": 24}),     # new scene at frame 24: in-frame scene-change detection (hmr_motion_inter.c:3791), frames 25-26 after it
     ("416x240_scene_cut", 416, 240, 25, {"cut_at": 23}),
+    # wfpp_num_threads = CTU rows: the reference is not deterministic with several threads; oracle/ref_ctudump.c's HOMER_TURNSTILE forces the synchronous-wavefront
+    # schedule on it (one legal interleaving, the one a row-parallel device executes) and these fixtures are what it then produces
+    ("416x240_wpp_rows", 416, 240, 5, {"wpp": 4}),
+    ("416x240_scene_cut_wpp_rows", 416, 240, 25, {"cut_at": 23, "wpp": 4}),
+    ("1920x1080_cfg2_wpp_rows", 1920, 1080, 8, {"wpp": 17}),
 ]
 
 
@@ -39,9 +44,10 @@ def run(width, height, frames, keys):
     with tempfile.TemporaryDirectory() as tmp:
         yuv = os.path.join(tmp, "in.yuv")
         gen_yuv.write_clip(yuv, width, height, frames, cut_at=cut_at)
-        cmd = [os.path.join(ROOT, "oracle", "_ref", "ref_lockstep"), yuv, os.path.join(tmp, "out.265"), str(width), str(height), str(frames),
+        turnstile = int(keys.get("wpp", 1)) > 1
+        cmd = [os.path.join(ROOT, "oracle", "_ref", "ref_ctudump" if turnstile else "ref_lockstep"), yuv, os.path.join(tmp, "out.265"), str(width), str(height), str(frames),
                "recon=" + os.path.join(tmp, "rec.yuv")] + [f"{k}={v}" for k, v in keys.items()]
-        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, env=dict(os.environ, HOMER_TURNSTILE="1") if turnstile else None)
         stream = open(os.path.join(tmp, "out.265"), "rb").read()
         rec = open(os.path.join(tmp, "rec.yuv"), "rb").read()
     fsz = width * height * 3 // 2

@@ -58,7 +58,7 @@ def encode(lib, case):
     return stream, recon
 
 
-@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra", "832x480", "1920x1080_cfg2", "1280x720_intra", "3840x2160_cfg2", "200x136_scene_cut", "416x240_scene_cut"])
+@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra", "832x480", "1920x1080_cfg2", "1280x720_intra", "3840x2160_cfg2", "200x136_scene_cut", "416x240_scene_cut", "416x240_wpp_rows", "416x240_scene_cut_wpp_rows", "1920x1080_cfg2_wpp_rows"])
 def test_device_stream_is_byte_identical_to_the_reference(gpu, case):
     stream, recon = encode(gpu, case)
     g = GOLD[case]

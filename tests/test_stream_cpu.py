@@ -54,7 +54,7 @@ def encode(lib, case, sched=0):
     return stream, recon, list(st)
 
 
-@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra", "832x480", "1280x720_intra", "200x136_scene_cut", "416x240_scene_cut"])
+@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra", "832x480", "1280x720_intra", "200x136_scene_cut", "416x240_scene_cut", "416x240_wpp_rows", "416x240_scene_cut_wpp_rows"])
 def test_stream_is_byte_identical_to_the_reference(cpu, case):
     stream, recon, _ = encode(cpu, case)
     g = GOLD[case]
@@ -78,6 +78,13 @@ def test_row_parallel_schedule_reproduces_the_single_thread_stream(cpu, case):
     assert hashlib.md5(stream).hexdigest() == g["stream_md5"]
     assert recon == g["recon_md5"]
     assert st[0] >= g["frames"] and st[1] >= g["frames"]   # at least one pass and nctu encodes per frame
+
+
+def test_1080p_cfg2_one_thread_per_row(cpu):
+    """the same configuration with wfpp_num_threads = 17 (one WPP thread per CTU row) against the reference forced into the synchronous-wavefront schedule"""
+    stream, recon, _ = encode(cpu, "1920x1080_cfg2_wpp_rows")
+    assert hashlib.md5(stream).hexdigest() == GOLD["1920x1080_cfg2_wpp_rows"]["stream_md5"]
+    assert recon == GOLD["1920x1080_cfg2_wpp_rows"]["recon_md5"]
 
 
 def test_1080p_cfg2_stream_md5(cpu):
