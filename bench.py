@@ -41,11 +41,15 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s
 WORKLOADS = {                  # name -> (width, height, configuration keys of tests/encoder_cases.default_cfg)
-    "cfg2-1080p-encode": (1920, 1080, {}),                                   # BASELINE.json configs[1]
-    "cfg2-2160p-encode": (3840, 2160, {}),                                   # the same encode at 2160p (configs[3] per engine)
-    "cfg2-416x240-encode": (416, 240, {}),                                   # quick look
+    # BASELINE.json configs[1] "WPP CTU rows on-GPU": one WPP thread per CTU row (wfpp_num_threads = 17), the reference's synchronous-wavefront schedule
+    "cfg2-1080p-encode": (1920, 1080, {"wpp": 17}),
+    # the same encode in the reference's single-thread order (wfpp_num_threads = 1): guesses + verification passes (enc_sched.h)
+    "cfg2-1080p-encode-single-thread-order": (1920, 1080, {}),
+    "cfg2-2160p-encode": (3840, 2160, {"wpp": 34}),                          # the same encode at 2160p (configs[3] per engine)
+    "cfg2-416x240-encode": (416, 240, {"wpp": 4}),                           # quick look
 }
-REFERENCE_MD5 = {("cfg2-1080p-encode", 8): "2f0c3447dabb6fbd87cac9821bb479fd"}
+# md5 of the reference's stream for (workload, frames): tests/golden/streams.json (ref_lockstep for one thread, ref_ctudump under HOMER_TURNSTILE for one thread per row)
+REFERENCE_MD5 = {("cfg2-1080p-encode", 8): "909750574aea72a30b956a8e91af5b42", ("cfg2-1080p-encode-single-thread-order", 8): "2f0c3447dabb6fbd87cac9821bb479fd"}
 
 
 def load_lib():
@@ -74,8 +78,14 @@ def cpu_baseline(width, height, keys, frames):
         t0 = time.time()
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
         dt = time.time() - t0
+        rows = (height + 63) // 64
+        t0 = time.time()
+        subprocess.run(cmd + [f"wpp={rows}"], check=True, stdout=subprocess.DEVNULL)
+        dt_rows = time.time() - t0
     return {"value": round(frames / dt, 3), "unit": "frames/s", "cores": 1, "kind": "reference",
-            "sample": f"{frames} frames {width}x{height} IPPP QP32 through oracle/_ref/ref_lockstep (SSE4.2 table, wpp=1, engines=1), wall time incl. init and file I/O"}
+            "sample": f"{frames} frames {width}x{height} IPPP QP32 through oracle/_ref/ref_lockstep (SSE4.2 table, wpp=1, engines=1), wall time incl. init and file I/O",
+            "one_thread_per_ctu_row": {"value": round(frames / dt_rows, 3), "threads": rows, "host_cores": os.cpu_count(),
+                                       "note": "the same reference run free with wfpp_num_threads = CTU rows (its multi-thread mode; output depends on timing)"}}
 
 
 def multi_stream(lib, device, width, height, keys, streams, warmup, steps):
@@ -175,9 +185,27 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
 
-    width, height, keys = WORKLOADS[a.workload]
-    nframes = a.warmup + a.steps
     lib = load_lib()
+    out = run_workload(lib, a, a.workload, world, rank, local, torch)
+    if rank == 0:
+        width, height, keys = WORKLOADS[a.workload]
+        if world == 1 and a.workload == "cfg2-1080p-encode":
+            other = run_workload(lib, a, "cfg2-1080p-encode-single-thread-order", world, rank, local, torch)
+            out["single_thread_order"] = {k: other[k] for k in ("value", "unit", "ms_per_step", "stream_md5", "stream_matches_reference", "schedule")}
+            out["single_thread_order"]["note"] = "the same encode with wfpp_num_threads = 1: output identical to the reference's single-thread run (md5 2f0c3447...), which costs guesses, verification and re-encode passes"
+        if world == 1 and a.streams > 1:
+            out["multi_stream"] = multi_stream(lib, local, width, height, keys, a.streams, 2, 3)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(width, height, {k: v for k, v in keys.items() if k != "wpp"}, a.cpu_frames)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_workload(lib, a, workload, world, rank, local, torch):
+    import encoder_cases as ec
+    width, height, keys = WORKLOADS[workload]
+    nframes = a.warmup + a.steps
     ctx, enc = C.c_void_p(), C.c_void_p()
     assert lib.hmr_gpu_create(C.byref(ctx), local, None) == 0, lib.hmr_gpu_last_error()
     cfg = ec.default_cfg(width, height, **keys)
@@ -200,7 +228,7 @@ def main():
     dt = measure(step, a.warmup, nframes, world, torch.cuda.synchronize, "cuda")
     lib.hmr_gpu_enc_destroy(enc)
 
-    if rank == 0:
+    if True:
         timed = stats[a.warmup:]
         nctu = ((width + 63) // 64) * ((height + 63) // 64)
         launches = sum(s[3] for s in timed)                       # one k_encode_ctus launch per pass
@@ -212,16 +240,16 @@ def main():
         # HBM bytes per launch from the committed counter passes of this same command (TCC_EA0_RDREQ / WRREQ x 64 B, MI355X_MICROARCH.md "HBM"; narrow accesses: uncalibrated)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r02_pmc_k_encode_ctus.json")
-        if os.path.exists(tpath) and a.workload == "cfg2-1080p-encode":
+        if os.path.exists(tpath) and workload == "cfg2-1080p-encode":
             k = json.load(open(tpath))["k_encode_ctus"]
             traffic = int((k["derived"]["hbm_read_bytes_TCC_EA0_RDREQ_x64"] + k["derived"]["hbm_write_bytes_TCC_EA0_WRREQ_x64_upper_bound"]) / k["launches"])
         digest = md5.hexdigest()
-        want = REFERENCE_MD5.get((a.workload, nframes))
+        want = REFERENCE_MD5.get((workload, nframes))
         out = {
             "metric": "encoded frames/sec, 1080p & 2160p YUV420 fixed-QP IPPP, 1/2/4/8 MI355X", "value": round(world * a.steps / dt, 4), "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
-            "config": {"workload": a.workload, "width": width, "height": height, "frames_in_sequence": nframes, "gop": "IPPP intra_period=100", "qp": 32,
+            "config": {"workload": workload, "wfpp_num_threads": int(keys.get("wpp", 1)), "width": width, "height": height, "frames_in_sequence": nframes, "gop": "IPPP intra_period=100", "qp": 32,
                        "rd_mode": 2, "performance_mode": 2, "sao": 1, "parallelism": f"replicas x{world}" if world > 1 else "single engine",
                        "timed_region": "CTU decisions + deblock + SAO stats + host SAO decision / CABAC / NAL + SAO offsets + padding per frame; source in HBM"},
             "stream_md5": digest, "stream_matches_reference": (digest == want) if want else None,
@@ -233,13 +261,7 @@ def main():
                          "note": "one wavefront per CTU row (17 at 1080p) walking a dependent decision chain: bound by instruction issue and memory latency of "
                                  "those few wavefronts, not by HBM bandwidth; the fraction is the honest distance from the bandwidth roof"},
         }
-        if world == 1 and a.streams > 1:
-            out["multi_stream"] = multi_stream(lib, local, width, height, keys, a.streams, 2, 3)
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(width, height, keys, a.cpu_frames)
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        return out
 
 
 if __name__ == "__main__":
