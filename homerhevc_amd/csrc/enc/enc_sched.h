@@ -12,6 +12,9 @@
 //   * re-encode the CTUs whose guesses were wrong with the true values, and the CTUs that read a neighbour whose output changed;
 //     repeat until a walk finds nothing wrong.  The first wrong CTU in raster order always gets exact inputs, so this terminates,
 //     and when it does every CTU has seen exactly what the single thread would have shown it.
+// With one WPP thread per CTU row (wfpp_num_threads = CTU rows) none of this runs: each row worker owns its buffers for the whole sequence and
+// the counters of (a) are read as of the end of the previous wavefront step - the synchronous-wavefront schedule (k_encode.hip, lockstep path; the checker:
+// oracle/enc_cpu.cpp frame_ctus_lockstep; the pin: oracle/ref_ctudump.c HOMER_TURNSTILE).
 // The functions are shared by the gfx950 kernels (k_encode.hip) and the one-lane checker build (oracle/enc_cpu.cpp).
 #pragma once
 #include "enc_ctu.h"

@@ -568,6 +568,9 @@ void hmr_gpu_sao_offsets_ctu(const int32_t *stats, const double *lambdas, int32_
  *     the struct it already fills for HOMER_enc_control(HOMER_SETCFG).
  *     Built rows: 8-bit 4:2:0, 64x64 CTUs, I / P slices with one reference picture, fixed QP, rd_mode 0 / 2,
  *     performance_mode 0-2 (BASELINE configs 1, 2, 4); anything else makes hmr_gpu_enc_create return HMR_GPU_ERR_ARG.
+ *     wfpp_num_threads = 1: the stream of the reference's single worker thread.  wfpp_num_threads = CTU rows: the stream of its
+ *     multi-thread mode with the threads advancing as a synchronous wavefront (pinned by oracle/ref_ctudump.c, HOMER_TURNSTILE);
+ *     other thread counts are refused.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct hmr_gpu_enc_cfg {
 	int32_t size, profile, width, height;
