@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--workload", default="cfg2-1080p-encode", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=24)
+    ap.add_argument("--no-single-thread-order", action="store_true", help="skip the second measurement (wfpp_num_threads = 1)")
     ap.add_argument("--streams", type=int, default=8, help="concurrent sequences of the extra multi_stream measurement (0 = skip)")
     a = ap.parse_args()
 
@@ -189,7 +190,7 @@ def main():
     out = run_workload(lib, a, a.workload, world, rank, local, torch)
     if rank == 0:
         width, height, keys = WORKLOADS[a.workload]
-        if world == 1 and a.workload == "cfg2-1080p-encode":
+        if world == 1 and a.workload == "cfg2-1080p-encode" and not a.no_single_thread_order:
             other = run_workload(lib, a, "cfg2-1080p-encode-single-thread-order", world, rank, local, torch)
             out["single_thread_order"] = {k: other[k] for k in ("value", "unit", "ms_per_step", "stream_md5", "stream_matches_reference", "schedule")}
             out["single_thread_order"]["note"] = "the same encode with wfpp_num_threads = 1: output identical to the reference's single-thread run (md5 2f0c3447...), which costs guesses, verification and re-encode passes"

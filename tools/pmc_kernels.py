@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Sum the rocprofv3 --pmc passes written by tools/profile_bench.sh per kernel and derive the shares DESIGN.md quotes.
+
+    tools/pmc_kernels.py gpurun_out r02 "command line" > profiles/r02_pmc_k_encode_ctus.json
+
+Every pass is its own run of the same command (MI355X_MICROARCH.md, HBM / rocprofv3: counter sets that do not fit one pass are collected
+separately, never together with a trace domain).  HBM bytes = TCC_EA0_RDREQ / WRREQ requests x 64 B; the write figure is an upper bound
+(narrow writes are counted as full requests)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    root, tag = sys.argv[1], sys.argv[2]
+    cmd = sys.argv[3] if len(sys.argv) > 3 else ""
+    kernels = {}
+    for path in sorted(glob.glob(os.path.join(root, f"pmc_{tag}_*", "**", "*counter_collection.csv"), recursive=True)):
+        launches = {}
+        for row in csv.DictReader(open(path)):
+            name = row["Kernel_Name"].split("(")[0].split("::")[-1].strip()
+            k = kernels.setdefault(name, {})
+            k[row["Counter_Name"]] = k.get(row["Counter_Name"], 0) + int(float(row["Counter_Value"]))
+            launches.setdefault(name, set()).add(row["Dispatch_Id"])
+        for name, ids in launches.items():
+            kernels[name]["launches"] = len(ids)
+    for name, k in kernels.items():
+        d = {}
+        if "SQ_WAVE_CYCLES" in k and k["SQ_WAVE_CYCLES"]:
+            d["wait_share_of_wave_cycles"] = round(k.get("SQ_WAIT_ANY", 0) / k["SQ_WAVE_CYCLES"], 3)
+            d["issue_share_of_wave_cycles"] = round(k.get("SQ_ACTIVE_INST_ANY", 0) / k["SQ_WAVE_CYCLES"], 3)
+        if "TCC_EA0_RDREQ_sum" in k:
+            d["hbm_read_bytes_TCC_EA0_RDREQ_x64"] = k["TCC_EA0_RDREQ_sum"] * 64
+            d["hbm_write_bytes_TCC_EA0_WRREQ_x64_upper_bound"] = k.get("TCC_EA0_WRREQ_sum", 0) * 64
+            tot = k.get("TCC_HIT_sum", 0) + k.get("TCC_MISS_sum", 0)
+            if tot:
+                d["l2_hit_rate"] = round(k["TCC_HIT_sum"] / tot, 4)
+        if name == "k_encode_ctus":
+            d["note"] = (f"rocprofv3 --pmc passes of `{cmd}`; sums over all launches of the kernel (three wavefronts per workgroup: the row worker and two "
+                         "helpers, whose polling counts as waiting); SQ cycle counters in quad-cycles")
+        k["derived"] = d
+    json.dump(kernels, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
