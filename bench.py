@@ -96,7 +96,7 @@ def multi_stream(lib, device, width, height, keys, streams, warmup, steps):
     import encoder_cases as ec
     frames = ec.clip_frames(width, height, warmup + steps)
     gate = threading.Barrier(streams + 1)
-    errors = []
+    errors, ctu_ms = [], []
 
     def worker():
         try:
@@ -112,6 +112,9 @@ def multi_stream(lib, device, width, height, keys, streams, warmup, steps):
             gate.wait()
             for f in range(warmup, warmup + steps):
                 assert lib.hmr_gpu_enc_encode_source(enc, f, 0, buf, len(buf), C.byref(n), None) in (1, 2)
+                p, k, ms, tot = C.c_int(), C.c_int(), C.c_float(), C.c_float()
+                lib.hmr_gpu_enc_last_stats(enc, C.byref(p), C.byref(k), C.byref(ms), C.byref(tot))
+                ctu_ms.append(ms.value)
             gate.wait()
             lib.hmr_gpu_enc_destroy(enc)
         except Exception as ex:   # noqa: BLE001
@@ -133,6 +136,7 @@ def multi_stream(lib, device, width, height, keys, streams, warmup, steps):
     if dt is None or errors:
         return {"streams": streams, "error": errors[:1]}
     return {"streams": streams, "frames_per_stream": steps, "value": round(streams * steps / dt, 4), "unit": "frames/s aggregate",
+            "ctu_stage_ms_per_frame_mean": round(sum(ctu_ms) / max(len(ctu_ms), 1), 1),
             "note": f"{streams} independent {width}x{height} sequences concurrently on one GPU, {steps} timed frames each after {warmup} warm-up frames"}
 
 

@@ -10,5 +10,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench  # noqa: E402
 
 lib = bench.load_lib()
+keys = {"wpp": int(os.environ["WPP"])} if os.environ.get("WPP") else {}
 for s in [int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]:
-    print(s, bench.multi_stream(lib, 0, 1920, 1080, {}, s, 2, 3), flush=True)
+    print(s, bench.multi_stream(lib, 0, 1920, 1080, keys, s, 2, 3), flush=True)
