@@ -176,7 +176,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=24)
     ap.add_argument("--no-single-thread-order", action="store_true", help="skip the second measurement (wfpp_num_threads = 1)")
-    ap.add_argument("--streams", type=int, default=8, help="concurrent sequences of the extra multi_stream measurement (0 = skip)")
+    ap.add_argument("--streams", type=int, default=10, help="concurrent sequences of the extra multi_stream measurement (0 = skip)")
     a = ap.parse_args()
 
     import torch

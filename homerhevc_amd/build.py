@@ -8,11 +8,14 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libhomer_gpu.so")
 SOURCES = ["tables.cpp", "context.cpp", "dropin.cpp", "cmdlist.cpp", "k_pixel.hip", "k_transform.hip", "k_intra.hip", "k_interp.hip", "k_loop.hip", "k_motion.hip", "k_tuchain.hip", "k_intrasearch.hip", "k_tree.hip", "k_chromasearch.hip", "k_saooffsets.hip", "k_encode.hip"]
 # -ffp-contract=off: the few double-precision cost terms must round exactly like the reference's x87-free SSE2 code
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip"] + (["-DHENC_PROFILE"] if os.environ.get("HENC_PROFILE") else [])
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip"] + (["-DHENC_PROFILE"] if os.environ.get("HENC_PROFILE") else []) + os.environ.get("HENC_EXTRA_FLAGS", "").split()
+
+
+STAMP = LIB_PATH + ".flags"   # the flags the library was built with: a profiling / debug-info build is never mistaken for the product build
 
 
 def _stale():
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP) or open(STAMP).read() != " ".join(FLAGS):
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(dp, f) for dp, _, fs in os.walk(CSRC) for f in fs] + [os.path.join(PKG_DIR, "..", "include", "homer_gpu.h")]
@@ -45,4 +48,6 @@ def build_native(force=False, verbose=False):
             print(" ".join(link))
         subprocess.check_call(link)
         os.replace(LIB_PATH + ".tmp", LIB_PATH)
+        with open(STAMP, "w") as f:
+            f.write(" ".join(FLAGS))
     return LIB_PATH

@@ -391,6 +391,9 @@ HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &__restrict__ e)
 					if (!nd.merge_flag) put_consolidated_info(g, e, curr, curr_depth);
 					e.last_slog = -1;
 					const uint32_t intra_dist = encode_intra(g, e, curr_depth, position, PART_2Nx2N);
+#if defined(__HIPCC__) && defined(HENC_PROFILE)
+					if (g.tid == 0 && e.timeline && e.timeline[2] == 0) e.timeline[2] = wall_clock64();
+#endif
 					const double ratio = intra_ratio(e.total_intra_partitions, e.total_partitions);
 					const double add = hclip(avg_distortion - 400, 40., avg_distortion) / 1.75 * curr_depth;
 					const double rd = cost_rd(e.f->avg_dist, nd.sum);

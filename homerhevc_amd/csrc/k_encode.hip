@@ -188,6 +188,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
 	e.box = box;
 	e.hseq[0] = e.hseq[1] = 0;
 	e.prof = d.prof ? d.prof + (size_t)row * PF_COUNT : nullptr;
+	e.timeline = nullptr;
 	uint32_t *my_prefix = d.prefix + (size_t)row * (W + 1);
 	if (pass <= 0 && g.tid == 0) my_prefix[0] = 0;
 	if (pass < 0) {
@@ -200,18 +201,27 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
 			const int t = c + 2 * row, n = row * W + c;
 			{
 				HENC_PROF_T0();
+#if defined(HENC_PROFILE)
+				if (g.tid == 0 && d.prof) d.prof[(size_t)H * PF_COUNT + 4 * n] = wall_clock64();
+#endif
 				// every row must have finished its CTUs of the earlier steps
 				for (;;) {
 					int behind = 0;
 					for (int r2 = g.tid; r2 < H; r2 += 64) {
 						const int need = t - 2 * r2 < 0 ? 0 : (t - 2 * r2 < W ? t - 2 * r2 : W);
-						behind |= __hip_atomic_load(&d.progress[r2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need;
+						behind |= __hip_atomic_load(&d.progress[r2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need;
 					}
 					if (!g.any(behind)) break;
-					__builtin_amdgcn_s_sleep(8);
+					__builtin_amdgcn_s_sleep(32);
 				}
+				// one acquire once the condition holds: an acquiring load per poll would invalidate the caches this XCD's other row workers are using
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 				HENC_PROF_ADD(e, PF_WAIT);
 			}
+#if defined(HENC_PROFILE)
+			if (g.tid == 0 && d.prof) { d.prof[(size_t)H * PF_COUNT + 4 * n + 1] = wall_clock64(); d.prof[(size_t)H * PF_COUNT + 4 * n + 2] = 0; }
+			e.timeline = d.prof ? d.prof + (size_t)H * PF_COUNT + 4 * n : nullptr;
+#endif
 			uint32_t ti = 0, tc = 0;
 			for (int r2 = g.tid; r2 < H; r2 += 64) {
 				const int have = t - 2 * r2 < 0 ? 0 : (t - 2 * r2 < W ? t - 2 * r2 : W);
@@ -226,7 +236,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
 					__hip_atomic_store(d.row0_checked, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 				}
 			} else if (t < W) {
-				while (__hip_atomic_load(d.row0_checked, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < t + 1) __builtin_amdgcn_s_sleep(4);
+				while (__hip_atomic_load(d.row0_checked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t + 1) __builtin_amdgcn_s_sleep(8);
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 			}
 			g.sync();
 			if (g.tid == 0) lframe->scene_cut_ctu = __hip_atomic_load(&d.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -242,6 +253,9 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
 			wave_copy_words(d.outtok + (size_t)n * MODE_STATE_BYTES, e.w->intra_mode_buffs, MODE_STATE_BYTES, g.tid);
 			if (g.tid == 0) my_prefix[c + 1] = my_prefix[c] + d.ctus[n].intra_parts;
 			HENC_PROF_ADD(e, PF_TOTAL);
+#if defined(HENC_PROFILE)
+			if (g.tid == 0 && d.prof) d.prof[(size_t)H * PF_COUNT + 4 * n + 3] = wall_clock64();
+#endif
 			g.sync();
 			if (g.tid == 0) __hip_atomic_store(&d.progress[row], c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 		}
@@ -262,7 +276,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
 		if (row > 0) {
 			HENC_PROF_T0();
 			const int need = c + 2 < W ? c + 2 : W;
-			while (__hip_atomic_load(&d.progress[row - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(16);
+			while (__hip_atomic_load(&d.progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(32);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 			HENC_PROF_ADD(e, PF_WAIT);
 		}
 		const int n = row * W + c;
@@ -609,7 +624,7 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 	DEV_ALLOC(e->d.coeff, (size_t)6144 * s.nctu);
 	DEV_ALLOC(e->d.progress, s.hctu);
 	DEV_ALLOC(e->d.prefix, (size_t)s.hctu * (s.wctu + 1));
-	DEV_ALLOC(e->d.prof, (size_t)s.hctu * PF_COUNT);
+	DEV_ALLOC(e->d.prof, (size_t)s.hctu * PF_COUNT + (size_t)s.nctu * 4);   // + per CTU: 100 MHz timestamps of wait start, encode start, first use of the intra share, end
 	DEV_ALLOC(e->d.guess, (size_t)s.nctu * MODE_STATE_BYTES);
 	DEV_ALLOC(e->d.truth, (size_t)s.nctu * MODE_STATE_BYTES);
 	DEV_ALLOC(e->d.outtok, (size_t)s.nctu * MODE_STATE_BYTES);
@@ -682,6 +697,14 @@ extern "C" int hmr_gpu_enc_last_stats(hmr_gpu_enc *e, int *passes, int *ctu_enco
 	if (ctu_encodes) *ctu_encodes = e->last_encodes;
 	if (ctu_ms) *ctu_ms = e->last_ms;
 	if (frame_ms) *frame_ms = e->last_total_ms;
+	return HMR_GPU_OK;
+}
+
+// profiling build: per CTU, 100 MHz timestamps of {wait start, encode start, first use of the intra share (0: none), end} in the row-per-thread schedule
+extern "C" int hmr_gpu_enc_timeline(hmr_gpu_enc *e, unsigned long long *out)
+{
+	if (!e || !out) return HMR_GPU_ERR_ARG;
+	HIP_TRY(hipMemcpy(out, e->d.prof + (size_t)e->seq.hctu * PF_COUNT, sizeof(unsigned long long) * e->seq.nctu * 4, hipMemcpyDeviceToHost));
 	return HMR_GPU_OK;
 }
 

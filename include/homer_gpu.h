@@ -612,6 +612,8 @@ int hmr_gpu_enc_encode_source(hmr_gpu_enc *enc, int slot, int image_type, uint8_
 int hmr_gpu_enc_last_stats(hmr_gpu_enc *enc, int *passes, int *ctu_encodes, float *ctu_ms, float *frame_ms);
 /* profiling build (-DHENC_PROFILE): per-row phase timers, [ctu rows][12] */
 int hmr_gpu_enc_profile(hmr_gpu_enc *enc, unsigned long long *out, int reset);
+/* profiling build, row-per-thread schedule: per CTU four 100 MHz timestamps {wait start, encode start, first use of the intra share (0: none), end}, [ctus][4] */
+int hmr_gpu_enc_timeline(hmr_gpu_enc *enc, unsigned long long *out);
 
 #ifdef __cplusplus
 }
