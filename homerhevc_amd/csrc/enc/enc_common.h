@@ -25,29 +25,29 @@ namespace henc {
 
 struct Enc {
 	unsigned long long *prof;   // PF_COUNT accumulators of this worker (profiling build), else unused
-	const Seq *seq;
-	const FrameCtx *f;
+	FastPtr<const Seq> seq;
+	FastPtr<const FrameCtx> f;
 	const DevTables *T;
-	const Geo *geo;
+	FastPtr<const Geo> geo;
 	CtuInfo *ctus;         // all CTUs of the picture (persistent across frames)
-	CtuPublic *ctu;        // the side-info record of the CTU being encoded: ctu_g's, or the worker's fast copy of it (ctu_fast != nullptr) while the CTU is encoded
+	FastPtr<CtuPublic> ctu;   // the side-info record of the CTU being encoded: ctu_g's, or the worker's fast copy of it (ctu_fast != nullptr) while the CTU is encoded
 	CtuInfo *ctu_g;        // its home in the picture array (logs, nodes; neighbours are ctu_g - 1, ctu_g - wctu ...)
 	CtuPublic *ctu_fast;
-	Work *w;
+	FastPtr<Work> w;
 	int16_t *coeff;        // the CTU's coefficient output: 4096 luma + 2 x 1024 chroma, linear per TU in z-order
 	// speculative inputs of a P-frame CTU (enc_ctu.h)
 	uint32_t total_intra_partitions, total_partitions;
 	unsigned long long *timeline;   // profiling build: the CTU's timestamps
 	int n_spec_reads, n_ratio_cmp, last_slog;
-	Node *nodes;           // the CTU's partition nodes: ctu->nodes, or the worker's fast copy of them (nodes_fast != nullptr) while the CTU is encoded
+	FastPtr<Node> nodes;      // the CTU's partition nodes: ctu->nodes, or the worker's fast copy of them (nodes_fast != nullptr) while the CTU is encoded
 	Node *nodes_fast;
 	// helper wavefronts of the worker (device only; nullptr = everything runs on the group itself)
-	struct HelperBox *box;
-	int16_t *adi_c;                   // neighbour array of a chroma block: Work::adi, or a helper's own
-	int16_t *mc_tmp_y;                // first-stage buffer of a two-stage luma interpolation (and its row pitch): Work::sub_tmp / 72, or a helper's own
+	FastPtr<struct HelperBox> box;
+	FastPtr<int16_t> adi_c;              // neighbour array of a chroma block: Work::adi, or a helper's own
+	FastPtr<int16_t> mc_tmp_y;           // first-stage buffer of a two-stage luma interpolation (and its row pitch): Work::sub_tmp / 72, or a helper's own
 	int mc_tmp_y_stride;
-	int16_t *mc_tmp_c;                // first-stage buffer of a two-stage chroma interpolation: Work::sub_tmp, or a helper's own
-	int16_t *scratch_a, *scratch_b;   // transform coefficients / rounding remainders of the TU in flight: Work::pred_aux / delta_u, or a helper's own
+	FastPtr<int16_t> mc_tmp_c;           // first-stage buffer of a two-stage chroma interpolation: Work::sub_tmp, or a helper's own
+	FastPtr<int16_t> scratch_a, scratch_b;   // transform coefficients / rounding remainders of the TU in flight: Work::pred_aux / delta_u, or a helper's own
 	int hseq[2];
 };
 

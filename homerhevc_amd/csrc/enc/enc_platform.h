@@ -68,6 +68,33 @@ struct WaveGrp {
 };
 #endif
 
+// The row worker's state - its Work, the CTU's nodes and record, the geometry, the sequence / frame parameters, the helper mailbox and scratch - lives in
+// LDS on the device (k_encode.hip).  The pointers to it travel through Enc as generic pointers, which the compiler can only serve with flat_* instructions:
+// 64-bit address arithmetic, and a wait on every outstanding store before any load result is used.  FastPtr says where they point (a cast to the LDS address
+// space and back, which address-space inference propagates into everything derived from the pointer), so these accesses become ds_* instructions.
+// On the CPU (checker build, host pass) it is an ordinary pointer.
+template <class T>
+HENC_INLINE T *in_fast_memory(T *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	__builtin_assume(__builtin_amdgcn_is_shared((const void *)p));
+	return p;
+#else
+	return p;
+#endif
+}
+template <class T>
+struct FastPtr {
+	T *p;
+	HENC_INLINE T *get() const { return in_fast_memory(p); }
+	HENC_INLINE T *operator->() const { return get(); }
+	HENC_INLINE T &operator*() const { return *get(); }
+	HENC_INLINE T &operator[](int i) const { return get()[i]; }
+	HENC_INLINE operator T *() const { return get(); }
+	HENC_INLINE explicit operator bool() const { return p != nullptr; }
+	HENC_INLINE FastPtr &operator=(T *q) { p = q; return *this; }
+};
+
 struct CpuGrp {
 	static constexpr int tid = 0;
 	static constexpr int n = 1;
