@@ -45,11 +45,12 @@ WORKLOADS = {                  # name -> (width, height, configuration keys of t
     "cfg2-1080p-encode": (1920, 1080, {"wpp": 17}),
     # the same encode in the reference's single-thread order (wfpp_num_threads = 1): guesses + verification passes (enc_sched.h)
     "cfg2-1080p-encode-single-thread-order": (1920, 1080, {}),
-    "cfg2-2160p-encode": (3840, 2160, {"wpp": 34}),                          # the same encode at 2160p (configs[3] per engine)
+    "cfg2-2160p-encode": (3840, 2160, {"wpp": 32}),                          # the same encode at 2160p (configs[3] per engine): 34 CTU rows on the reference's maximum of 32 threads
     "cfg2-416x240-encode": (416, 240, {"wpp": 4}),                           # quick look
 }
 # md5 of the reference's stream for (workload, frames): tests/golden/streams.json (ref_lockstep for one thread, ref_ctudump under HOMER_TURNSTILE for one thread per row)
-REFERENCE_MD5 = {("cfg2-1080p-encode", 8): "909750574aea72a30b956a8e91af5b42", ("cfg2-1080p-encode-single-thread-order", 8): "2f0c3447dabb6fbd87cac9821bb479fd"}
+REFERENCE_MD5 = {("cfg2-1080p-encode", 8): "909750574aea72a30b956a8e91af5b42", ("cfg2-1080p-encode-single-thread-order", 8): "2f0c3447dabb6fbd87cac9821bb479fd",
+                 ("cfg2-2160p-encode", 3): "a24791eb74514443222b689f247e03d8"}
 
 
 def load_lib():
@@ -263,6 +264,9 @@ def run_workload(lib, a, workload, world, rank, local, torch):
             "roofline": {"bound": "hbm", "kernel": "k_encode_ctus", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 7),
                          "traffic": traffic, "launches": launches, "algorithmic_bytes_per_launch": int(algo_bytes_frame * len(timed) / max(launches, 1)), "ms_per_launch": round(ctu_ms / max(launches, 1), 2),
                          "algorithmic_bytes_per_frame": int(algo_bytes_frame), "share_of_device_time": round(ctu_ms / frame_ms, 3),
+                         # SURVEY 8-d, the whole P frame (CTU stage + the in-loop filters' read / write): 10.5 W H bytes x frames/s against the same peak
+                         "frame_level": {"algorithmic_bytes_per_frame": int(10.5 * width * height), "achieved": round(10.5 * width * height * world * a.steps / dt / 1e9, 4),
+                                         "frac": round(10.5 * width * height * world * a.steps / dt / 1e9 / HBM_PEAK_GBS, 7)},
                          "note": "one wavefront per CTU row (17 at 1080p) walking a dependent decision chain: bound by instruction issue and memory latency of "
                                  "those few wavefronts, not by HBM bandwidth; the fraction is the honest distance from the bandwidth roof"},
         }

@@ -64,9 +64,15 @@ inline bool make_seq(HostCfg cfg, Seq &s, const char **why)
 	// most five CTU columns with at least as many rows as columns (and at least four): the in-row lag conditions (`ctu_num_index >= 3 / 4 / 5`)
 	// then hardly ever hold, the stages run in the row-end flushes instead, and SAO statistics see offsets already applied above them.  Observed:
 	// 3x4, 3x5, 4x4, 5x5, 5x6 differ; 3x3, 4x3, 5x4, 6x5, 6x6, 6x17, 7x4 and everything wider are identical.  Refused rather than approximated.
-	// WPP threads: 1 = the reference's deterministic single-thread order; one per CTU row = its synchronous-wavefront schedule (enc_sched.h).  Anything in between
-	// makes a thread own several rows, whose order against the other threads' rows is timing in the reference.
-	if (cfg.wfpp_num_threads > 1 && cfg.wfpp_num_threads != (cfg.height + 63) / 64) { *why = "wfpp_num_threads must be 1 or the number of CTU rows"; return false; }
+	// WPP threads: 1 = the reference's deterministic single-thread order; N > 1 = its synchronous-wavefront schedule (enc_sched.h), which is one of the
+	// reference's own interleavings only if thread k is free again when its next row (k + N) reaches its first step: 2 N >= CTU columns.  The reference has room
+	// for 32 threads (hmr_private.h:1234), so a 2160p picture (34 rows, 60 columns) runs with 32 and rows 32 / 33 continue threads 0 / 1.
+	{
+		const int wc = (cfg.width + 63) / 64, hc = (cfg.height + 63) / 64, n = cfg.wfpp_num_threads;
+		if (n > 32) { *why = "wfpp_num_threads above the reference's 32"; return false; }
+		if (n > hc) { *why = "more WPP threads than CTU rows"; return false; }
+		if (n > 1 && n < hc && 2 * n < wc) { *why = "wfpp_num_threads between 1 and the number of CTU rows needs 2 x threads >= CTU columns"; return false; }
+	}
 	if ((cfg.width + 63) / 64 < 2) { *why = "picture narrower than two CTUs"; return false; }
 	{
 		const int wc = (cfg.width + 63) / 64, hc = (cfg.height + 63) / 64;

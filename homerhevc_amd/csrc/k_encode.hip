@@ -42,6 +42,7 @@ struct EncDev {
 	uint8_t *rowstate;            // [hctu][MODE_STATE_BYTES] lockstep schedule: the mode buffers of the worker of each CTU row, carried from frame to frame
 	int *row0_checked;            // lockstep schedule: steps for which row 0 has made its scene-change check
 	int *counters;                // [0] CTUs found wrong by the last check, [1] CTU encodes of the frame, [2] the CTU at which a scene change is detected (-1: none)
+	int threads;                  // lockstep schedule: wfpp_num_threads (row r is encoded by thread r % threads)
 };
 
 __device__ __forceinline__ void wave_copy_words(void *dst, const void *src, int bytes, int tid)
@@ -195,8 +196,9 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
 		// ---- the synchronous wavefront of wfpp_num_threads = CTU rows (enc_sched.h, oracle/ref_ctudump.c HOMER_TURNSTILE): one worker per row with its own mode
 		// buffers, all CTUs of step t = c + 2 * row see the counters as of the end of step t - 1, row 0 alone looks for a scene change and does so first in its step.
 		// No guesses, no verification: one launch per frame.
-		wave_copy_words(&e.w->intra_mode_buffs[0][0][0], d.rowstate + (size_t)row * MODE_STATE_BYTES, MODE_STATE_BYTES, g.tid);
-		g.sync();
+		// With fewer threads than rows (allowed when 2 * threads >= CTU columns, so that thread k has left row r - threads before row r's first step) the worker
+		// of row r continues with the buffers row r - threads left behind in this same frame, and thread 0's rows are the ones that look for a scene change.
+		const int T = d.threads, me = row % T;
 		for (int c = 0; c < W; c++) {
 			const int t = c + 2 * row, n = row * W + c;
 			{
@@ -230,12 +232,18 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
 			}
 			ti = g.sum(ti);
 			tc = g.sum(tc);
-			if (row == 0) {
+			if (c == 0) {
+				// (the barrier above has seen the last CTU of row - T, whose worker stored these before it published that CTU)
+				wave_copy_words(&e.w->intra_mode_buffs[0][0][0], d.rowstate + (size_t)me * MODE_STATE_BYTES, MODE_STATE_BYTES, g.tid);
+				g.sync();
+			}
+			const int hrow = t / (2 * T) * T;   // thread 0's row that is inside the picture at this step, if any
+			if (row == hrow) {
 				if (g.tid == 0) {
 					if (d.counters[2] < 0 && lframe->slice_type == SLICE_P && scene_cut_fires(S, *lframe, ti, tc * NPART)) d.counters[2] = n;
 					__hip_atomic_store(d.row0_checked, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 				}
-			} else if (t < W) {
+			} else if (hrow < H && t - 2 * hrow < W) {
 				while (__hip_atomic_load(d.row0_checked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t + 1) __builtin_amdgcn_s_sleep(8);
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 			}
@@ -256,10 +264,10 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
 #if defined(HENC_PROFILE)
 			if (g.tid == 0 && d.prof) d.prof[(size_t)H * PF_COUNT + 4 * n + 3] = wall_clock64();
 #endif
+			if (c == W - 1) wave_copy_words(d.rowstate + (size_t)me * MODE_STATE_BYTES, &e.w->intra_mode_buffs[0][0][0], MODE_STATE_BYTES, g.tid);
 			g.sync();
 			if (g.tid == 0) __hip_atomic_store(&d.progress[row], c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 		}
-		wave_copy_words(d.rowstate + (size_t)row * MODE_STATE_BYTES, &e.w->intra_mode_buffs[0][0][0], MODE_STATE_BYTES, g.tid);
 		helper_post(g, e, 0, HJOB_QUIT);
 		helper_post(g, e, 1, HJOB_QUIT);
 		if (g.tid == 0) atomicAdd(&d.counters[1], W);
@@ -663,6 +671,7 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 	e->d.geo = e->d_geo;
 	e->cur = 0;
 	e->lockstep = e->cfg.wfpp_num_threads > 1;
+	e->d.threads = e->cfg.wfpp_num_threads > 1 ? e->cfg.wfpp_num_threads : 1;
 	e->last_ms = e->last_total_ms = 0;
 	e->last_passes = e->last_encodes = 0;
 	*out = e;

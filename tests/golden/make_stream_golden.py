@@ -35,6 +35,13 @@ CASES = [
     ("416x240_wpp_rows", 416, 240, 5, {"wpp": 4}),
     ("416x240_scene_cut_wpp_rows", 416, 240, 25, {"cut_at": 23, "wpp": 4}),
     ("1920x1080_cfg2_wpp_rows", 1920, 1080, 8, {"wpp": 17}),
+    ("832x480_wpp_rows", 832, 480, 3, {"wpp": 8}),
+    ("416x240_qp22_perf0_wpp_rows", 416, 240, 3, {"qp": 22, "perf": 0, "wpp": 4}),
+    ("416x240_nosao_wpp_rows", 416, 240, 3, {"sao": 0, "wpp": 4}),
+    # fewer threads than rows (2 x threads >= CTU columns keeps the synchronous wavefront one of the reference's own interleavings): threads own rows k, k + N
+    ("328x264_wpp3", 328, 264, 4, {"wpp": 3}),
+    ("200x136_wpp2", 200, 136, 4, {"wpp": 2}),
+    ("3840x2160_cfg2_wpp32", 3840, 2160, 3, {"wpp": 32}),     # the 2160p picture of the metric with the reference's maximum of 32 WPP threads for 34 CTU rows (I + P + P)
 ]
 
 
@@ -47,7 +54,7 @@ def run(width, height, frames, keys):
         turnstile = int(keys.get("wpp", 1)) > 1
         cmd = [os.path.join(ROOT, "oracle", "_ref", "ref_ctudump" if turnstile else "ref_lockstep"), yuv, os.path.join(tmp, "out.265"), str(width), str(height), str(frames),
                "recon=" + os.path.join(tmp, "rec.yuv")] + [f"{k}={v}" for k, v in keys.items()]
-        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, env=dict(os.environ, HOMER_TURNSTILE="1") if turnstile else None)
+        subprocess.run(cmd, check=True, timeout=900, stdout=subprocess.DEVNULL, env=dict(os.environ, HOMER_TURNSTILE="1") if turnstile else None)
         stream = open(os.path.join(tmp, "out.265"), "rb").read()
         rec = open(os.path.join(tmp, "rec.yuv"), "rb").read()
     fsz = width * height * 3 // 2
@@ -59,7 +66,12 @@ def run(width, height, frames, keys):
 
 
 if __name__ == "__main__":
-    out = {name: run(w, h, f, keys) for name, w, h, f, keys in CASES}
+    # no arguments: every case; with case names: only those, merged into the existing file
+    path = os.path.join(HERE, "streams.json")
+    only = set(sys.argv[1:])
+    out = json.load(open(path)) if only and os.path.exists(path) else {}
+    out.update({name: run(w, h, f, keys) for name, w, h, f, keys in CASES if not only or name in only})
+    out = {name: out[name] for name, *_ in CASES if name in out}
     json.dump(out, open(os.path.join(HERE, "streams.json"), "w"), indent=1)
     for k, v in out.items():
         print(k, v["stream_md5"], v["stream_bytes"])
