@@ -11,6 +11,7 @@
 #include <vector>
 #include "enc_cabac_tables.h"
 #include "enc_prims.h"
+#include "enc_sao.h"
 
 namespace henc {
 
@@ -73,14 +74,7 @@ struct Cabac {
 	BitWriter *bs = nullptr;
 
 	static int next_mps(int s) { return s < 124 ? s + 2 : (s < 126 ? s : s); }
-	static int next_lps(int s)
-	{
-		static const uint8_t t[128] = {1,  0,  0,  1,  2,  3,  4,  5,  4,  5,  8,  9,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 18, 19, 22, 23, 22, 23, 24, 25,
-					       26, 27, 26, 27, 30, 31, 30, 31, 32, 33, 32, 33, 36, 37, 36, 37, 38, 39, 38, 39, 42, 43, 42, 43, 44, 45, 44, 45, 46, 47, 48, 49,
-					       48, 49, 50, 51, 52, 53, 52, 53, 54, 55, 54, 55, 56, 57, 58, 59, 58, 59, 60, 61, 60, 61, 60, 61, 62, 63, 64, 65, 64, 65, 66, 67,
-					       66, 67, 66, 67, 68, 69, 68, 69, 70, 71, 70, 71, 70, 71, 72, 73, 72, 73, 72, 73, 74, 75, 74, 75, 74, 75, 76, 77, 76, 77, 126, 127};
-		return t[s];
-	}
+	static int next_lps(int s) { return kNextStateLps[s]; }
 	static int mps_next(int s) { return s >= 124 && s < 126 ? s : (s >= 126 ? s : s + 2); }
 
 	void start() { low = 0; bits_left = 23; num_buffered = 0; buffered_byte = 0xff; range = 510; }
@@ -708,86 +702,7 @@ inline void encode_ctu_syntax(Cabac &ee, const EntropyFrame &fr, int n)
 	}
 }
 
-// ---- SAO syntax and decision -------------------------------------------------------------------------------------------------------
-enum { SAO_OFF = 0, SAO_NEW = 1, SAO_MERGE = 2, SAO_BO = 4 };
-
-// code_sao_offset_param :1839 (8-bit: offsets up to 7)
-inline void code_sao_offset_param(Cabac &ee, int comp, const SaoOffset &p, int enabled)
-{
-	if (!enabled) return;
-	if (comp == COMP_Y || comp == COMP_U) {
-		const uint32_t sym = p.mode_idc == SAO_OFF ? 0 : (p.type_idc == SAO_BO ? 1 : 2);
-		if (sym == 0) ee.encode_bin(CTX_SAO_TYPE, 0);
-		else {
-			ee.encode_bin(CTX_SAO_TYPE, 1);
-			ee.encode_ep(sym == 1 ? 0 : 1);
-		}
-	}
-	if (p.mode_idc == SAO_NEW) {
-		const int num_classes = p.type_idc == SAO_BO ? 4 : 5;
-		int offset[4], k = 0;
-		for (int i = 0; i < num_classes; i++) {
-			if (p.type_idc != SAO_BO && i == 2) continue;
-			const int cls = p.type_idc == SAO_BO ? (p.type_aux + i) % 32 : i;
-			offset[k++] = p.offset[cls];
-		}
-		for (int i = 0; i < 4; i++) {
-			const uint32_t code = (uint32_t)habs(offset[i]), max_symbol = 7;
-			const int code_last = max_symbol > code;
-			if (code == 0) ee.encode_ep(0);
-			else {
-				ee.encode_ep(1);
-				for (uint32_t j = 0; j + 1 < code; j++) ee.encode_ep(1);
-				if (code_last) ee.encode_ep(0);
-			}
-		}
-		if (p.type_idc == SAO_BO) {
-			for (int i = 0; i < 4; i++)
-				if (offset[i] != 0) ee.encode_ep(offset[i] < 0 ? 1 : 0);
-			ee.encode_bins_ep(p.type_aux, 5);
-		} else if (comp == COMP_Y || comp == COMP_U) ee.encode_bins_ep(p.type_idc, 2);
-	}
-}
-
-// code_sao_blk_param :1971
-inline void code_sao_blk_param(Cabac &ee, const SaoOffset *p, int left_avail, int above_avail)
-{
-	int is_left = 0, is_above = 0;
-	if (left_avail) {
-		is_left = p[0].mode_idc == SAO_MERGE && p[0].type_idc == 0;
-		ee.encode_bin(CTX_SAO_MERGE, is_left);
-	}
-	if (above_avail && !is_left) {
-		is_above = p[0].mode_idc == SAO_MERGE && p[0].type_idc == 1;
-		ee.encode_bin(CTX_SAO_MERGE, is_above);
-	}
-	if (!is_left && !is_above)
-		for (int comp = 0; comp < 3; comp++) code_sao_offset_param(ee, comp, p[comp], 1);
-}
-
-struct SaoCoder {
-	Cabac ec, aux;        // the counting coder and the saved state between luma and chroma (henc_thread_t.ec / aux_contexts + aux_bm)
-	SaoCoder() { ec.counter = true; aux.counter = true; }
-	// rd_code_sao_offset_param :2377
-	uint32_t rate_offset(const Cabac &src, int comp, const SaoOffset &p)
-	{
-		ec.load(src);
-		const uint32_t init = ec.bitcnt();
-		code_sao_offset_param(ec, comp, p, 1);
-		return ec.bitcnt() - init;
-	}
-	// rd_code_sao_blk_param :2391
-	uint32_t rate_blk(const Cabac &src, const SaoOffset *p, int left_avail, int above_avail)
-	{
-		ec.load(src);
-		const uint32_t init = ec.bitcnt();
-		code_sao_blk_param(ec, p, left_avail, above_avail);
-		return ec.bitcnt() - init;
-	}
-};
-
-inline int64_t est_sao_dist(int64_t count, int64_t offset, int64_t diff) { return count * offset * offset - diff * offset * 2; }
-
+// ---- SAO decision: the shared part is enc_sao.h; here the candidate derivation from the statistics as the reference does it on the CPU ------------
 // est_iter_offset :445
 inline int sao_iter_offset(int type_idx, double lambda, int offset_input, int64_t count, int64_t diff, int64_t *best_dist, double *best_cost)
 {
@@ -808,9 +723,6 @@ inline int sao_iter_offset(int type_idx, double lambda, int offset_input, int64_
 	}
 	return out;
 }
-
-// statistics of one CTU: [comp][type][0 diff, 1 count][32] as the frame pass writes them
-typedef int32_t SaoStats[3][5][2][32];
 
 // sao_derive_offsets :480
 inline void sao_derive_offsets(const double *lambdas, int comp, int type, const int32_t (*st)[32], int *q, int *aux)
@@ -868,119 +780,28 @@ inline void sao_invert_quant(int type, int aux, int *dst, const int *src)
 	else
 		for (int i = 0; i < 5; i++) dst[i] = coded[i];
 }
-// sao_get_distortion :620
-inline int64_t sao_distortion(int type, int aux, const int *off, const int32_t (*st)[32])
-{
-	int64_t d = 0;
-	if (type != SAO_BO)
-		for (int k = 0; k < 5; k++) d += est_sao_dist(st[1][k], off[k], st[0][k]);
-	else
-		for (int k = aux; k < aux + 4; k++) d += est_sao_dist(st[1][k % 32], off[k % 32], st[0][k % 32]);
-	return d;
-}
-
-// sao_decide_blk_params :1295 (+ sao_derive_mode_new_rdo :663, sao_derive_mode_merge_rdo :854, reconstruct_blk_sao_param :919)
-inline void sao_decide_ctu(SaoCoder &sc, const Cabac &ee, const EntropyFrame &fr, int n, const SaoStats &stats, const double *lambdas)
+// the candidates of SAO_MODE_NEW from the statistics (on the device k_sao_offsets has them ready: k_saooffsets.hip)
+struct SaoCandFromStats {
+	const double *lambdas;
+	const SaoStats *st;
+	int64_t get(int comp, int type, SaoOffset &t) const
+	{
+		int inv[32];
+		sao_derive_offsets(lambdas, comp, type, (*st)[comp][type], t.offset, &t.type_aux);
+		sao_invert_quant(type, t.type_aux, inv, t.offset);
+		return sao_distortion(type, t.type_aux, inv, (*st)[comp][type]);
+	}
+};
+// sao_decide_blk_params :1295 for CTU n with the real coder `ee` standing before the CTU's SAO syntax
+inline void sao_decide_ctu(const Cabac &ee, const EntropyFrame &fr, int n, const SaoStats &stats, const double *lambdas)
 {
 	const Seq &S = *fr.seq;
 	CtuPublic &c = fr.ctu_rw(n);
 	const int cx = n % S.wctu, cy = n / S.wctu;
-	const SaoOffset *merge_list[2] = {cx > 0 ? fr.ctu(n - 1).sao_recon : nullptr, cy > 0 ? fr.ctu(n - S.wctu).sao_recon : nullptr};   // [0] left, [1] above
-	const int left_avail = merge_list[0] != nullptr, above_avail = merge_list[1] != nullptr;
-	SaoOffset mode_param[3], coded[3];
-	memset(mode_param, 0, sizeof mode_param);
-	memset(coded, 0, sizeof coded);
-	double min_cost = MAX_COST, mode_cost;
-	// ---- SAO_MODE_NEW
-	{
-		int64_t dist[3], mode_dist[3] = {0, 0, 0};
-		SaoOffset test[3];
-		int inv[32];
-		double cost, mcost;
-		uint32_t rate;
-		memset(test, 0, sizeof test);
-		mode_param[0].mode_idc = SAO_OFF;
-		rate = sc.rate_offset(ee, 0, mode_param[0]);
-		mcost = lambdas[0] * rate;
-		sc.aux.load(sc.ec);
-		for (int type = 0; type < 5; type++) {
-			test[0].mode_idc = SAO_NEW;
-			test[0].type_idc = type;
-			sao_derive_offsets(lambdas, 0, type, stats[0][type], test[0].offset, &test[0].type_aux);
-			sao_invert_quant(type, test[0].type_aux, inv, test[0].offset);
-			dist[0] = sao_distortion(type, test[0].type_aux, inv, stats[0][type]);
-			cost = (double)dist[0];
-			rate = sc.rate_offset(ee, 0, test[0]);
-			cost += lambdas[0] * rate;
-			if (cost < mcost) {
-				mcost = cost;
-				mode_dist[0] = dist[0];
-				mode_param[0] = test[0];
-				sc.aux.load(sc.ec);
-			}
-		}
-		cost = 0;
-		for (int comp = 1; comp < 3; comp++) {
-			mode_param[comp].mode_idc = SAO_OFF;
-			mode_dist[comp] = 0;
-			rate = comp == 1 ? sc.rate_offset(sc.aux, comp, mode_param[comp]) : sc.rate_offset(sc.ec, comp, mode_param[comp]);
-			cost += lambdas[comp] * rate;
-		}
-		mcost = cost;
-		for (int type = 0; type < 5; type++) {
-			cost = 0;
-			for (int comp = 1; comp < 3; comp++) {
-				test[comp].mode_idc = SAO_NEW;
-				test[comp].type_idc = type;
-				sao_derive_offsets(lambdas, comp, type, stats[comp][type], test[comp].offset, &test[comp].type_aux);
-				sao_invert_quant(type, test[comp].type_aux, inv, test[comp].offset);
-				dist[comp] = sao_distortion(type, test[comp].type_aux, inv, stats[comp][type]);
-				cost += dist[comp];
-				rate = comp == 1 ? sc.rate_offset(sc.aux, comp, test[comp]) : sc.rate_offset(sc.ec, comp, test[comp]);
-				cost += lambdas[comp] * rate;
-			}
-			if (cost < mcost) {
-				mcost = cost;
-				for (int comp = 1; comp < 3; comp++) { mode_dist[comp] = dist[comp]; mode_param[comp] = test[comp]; }
-			}
-		}
-		mode_cost = (double)mode_dist[0] / lambdas[0] + (double)mode_dist[1] / lambdas[1] + (double)mode_dist[2] / lambdas[2];
-		mode_cost += sc.rate_blk(ee, mode_param, left_avail, above_avail);
-		if (mode_cost < min_cost) { min_cost = mode_cost; memcpy(coded, mode_param, sizeof coded); }
-	}
-	// ---- SAO_MODE_MERGE (the reference's test parameters start from a copy of the candidate; the mode decision only reads what is set here)
-	{
-		mode_cost = MAX_COST;
-		SaoOffset best[3];
-		bool have = false;
-		for (int mt = 0; mt < 2; mt++) {
-			if (!merge_list[mt]) continue;
-			SaoOffset test[3];
-			memcpy(test, merge_list[mt], sizeof test);
-			double norm_dist = 0;
-			for (int comp = 0; comp < 3; comp++) {
-				test[comp].mode_idc = SAO_MERGE;
-				test[comp].type_idc = mt;
-				const SaoOffset &m = merge_list[mt][comp];
-				if (m.mode_idc != SAO_OFF) norm_dist += ((double)sao_distortion(m.type_idc, m.type_aux, m.offset, stats[comp][m.type_idc])) / lambdas[comp];
-			}
-			const uint32_t rate = sc.rate_blk(ee, test, left_avail, above_avail);
-			const double cost = norm_dist + (double)rate;
-			if (cost < mode_cost) { mode_cost = cost; memcpy(best, test, sizeof best); have = true; }
-		}
-#if defined(HENC_SAO_TRACE)
-		if (getenv("HOMER_SAOCOST")) fprintf(stderr, "NEWCOST %.6f lambdas %.6f %.6f\nMERGECOST %.6f type %d\n", min_cost, lambdas[0], lambdas[1], mode_cost, have ? best[0].type_idc : -1);
-#endif
-		if (have && mode_cost < min_cost) { min_cost = mode_cost; memcpy(coded, best, sizeof coded); }
-	}
-	memcpy(c.sao_coded, coded, sizeof coded);
-	memcpy(c.sao_recon, coded, sizeof coded);
-	for (int comp = 0; comp < 3; comp++) {
-		SaoOffset &o = c.sao_recon[comp];
-		if (o.mode_idc == SAO_OFF) continue;
-		if (o.mode_idc == SAO_NEW) sao_invert_quant(o.type_idc, o.type_aux, o.offset, o.offset);
-		else o = merge_list[o.type_idc][comp];
-	}
+	const SaoTables T = {kEntropyBits, kNextStateLps};
+	const SaoCandFromStats cand = {lambdas, &stats};
+	sao_decide(T, ee.ctx[CTX_SAO_MERGE], ee.ctx[CTX_SAO_TYPE], cand, stats, cx > 0 ? fr.ctu(n - 1).sao_recon : nullptr, cy > 0 ? fr.ctu(n - S.wctu).sao_recon : nullptr, lambdas,
+		   c.sao_coded, c.sao_recon);
 }
 
 // ---- parameter sets, slice header, access unit ------------------------------------------------------------------------------------
@@ -1097,27 +918,21 @@ inline uint32_t count_escapes(const BitWriter &b)
 struct EntropyState {
 	std::vector<BitWriter> rows;      // one sub-stream per CTU row (aux_bs)
 	Cabac ee, saved;                  // the coding environment and the copy the next row starts from (ee_list pair)
-	SaoCoder sc;
 	int last_idr = 0;
 	bool sets_written = false;
 };
 
 // The entropy stage of one frame: SAO decision + CTU syntax per CTU in raster order, then the access unit in Annex-B form appended to `out`.
-// stats: SAO statistics of every CTU (nullptr when SAO is off); the SAO parameters land in the CTU records (sao_coded / sao_recon).
+// stats: SAO statistics of every CTU: the SAO parameters are decided here and land in the CTU records (sao_coded / sao_recon); nullptr when SAO is off or when
+// the records already carry the parameters (the device path: k_sao_decide).
 inline void encode_frame_entropy(EntropyState &es, const EntropyFrame &fr, const SaoStats *stats, int profile, std::vector<uint8_t> &out)
 {
 	const Seq &S = *fr.seq;
 	const FrameCtx &f = *fr.f;
 	const int W = S.wctu, H = S.hctu;
 	es.rows.resize(H);
-	// SAO lambdas, hmr_wpp_sao_ctu :1415 (fixed QP: the same for every CTU)
 	double sao_lambda[3];
-	{
-		const double qp_temp = (double)f.qp - 12, lambda_scale = 1.0 - hclip(0.05 * (double)(S.gop_size - 1), 0.0, 0.5);
-		const double qp_factor = f.slice_type == SLICE_I ? 0.57 * lambda_scale : 0.4624;
-		sao_lambda[0] = qp_factor * pow(1.4, qp_temp / 1.4);
-		sao_lambda[1] = sao_lambda[2] = qp_factor * pow(1.4, (qp_temp + S.chroma_qp_offset) / 1.4);
-	}
+	sao_lambdas(S, f, sao_lambda);
 	es.ee.counter = false;
 	for (int n = 0; n < S.nctu; n++) {
 		const int cx = n % W, cy = n / W;
@@ -1138,9 +953,9 @@ inline void encode_frame_entropy(EntropyState &es, const EntropyFrame &fr, const
 			}
 		}
 		if (S.sao) {
-			sao_decide_ctu(es.sc, es.ee, fr, n, stats[n], sao_lambda);
+			if (stats) sao_decide_ctu(es.ee, fr, n, stats[n], sao_lambda);   // (no statistics: the records already hold the decision, made on the device)
 #if defined(HENC_SAO_TRACE)
-			if (henc_sao_trace_file) {
+			if (henc_sao_trace_file && stats) {
 				fprintf(henc_sao_trace_file, "SAO frame=%d ctu=%d", f.num_encoded_frames, n);
 				for (int c3 = 0; c3 < 3; c3++) {
 					const SaoOffset &o = fr.ctu(n).sao_coded[c3];

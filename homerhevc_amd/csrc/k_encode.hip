@@ -447,6 +447,68 @@ struct SrcSlot {
 	int16_t *p[3];
 };
 
+// ---- SAO parameter decision on the device (enc/enc_sao.h): what it needs from the entropy coder is the walk of two contexts through the SAO syntax of each
+// sub-stream, so it runs here, behind the statistics and the candidate offsets (k_saooffsets.hip) and in front of the offset pass, with no host in the chain.
+// One wavefront; lane r owns CTU row r and the rows advance as the WPP wavefront (CTU (r, c) at step c + 2 r): a CTU needs the parameters of its left and
+// above neighbours, and a row starts from the contexts the row above had after its second CTU (hmr_encoder_lib.c:2368-2373).  Without WPP lane 0 walks alone.
+struct SaoCandFromDevice {
+	const int32_t *offsets, *aux;   // [3][5][32], [3][5] of the CTU (hmr_gpu_sao_offsets_frame)
+	const long long *dist;          // [3][5]
+	__device__ int64_t get(int comp, int type, SaoOffset &t) const
+	{
+		const int32_t *o = offsets + (comp * 5 + type) * 32;
+		for (int k = 0; k < 32; k++) t.offset[k] = o[k];
+		t.type_aux = aux[comp * 5 + type];
+		return dist[comp * 5 + type];
+	}
+};
+struct SaoDecideArgs {
+	CtuInfo *ctus;
+	const int32_t *stats, *offsets, *aux;
+	const long long *dist;
+	double lambdas[3];
+	int W, H, wpp, st_merge, st_type;
+	const int32_t *entropy_bits;
+	const uint8_t *next_lps;
+	int32_t *params;                // [ctu][3][34] for the offset pass: mode, type, 32 offsets
+	uint8_t *saved;                 // [H][2] scratch: the two contexts after the second CTU of each row
+};
+__device__ void sao_decide_one(const SaoDecideArgs &a, int r, int c, SaoContexts &cur)
+{
+	const int n = r * a.W + c;
+	CtuPublic &ci = a.ctus[n];
+	const SaoTables T = {a.entropy_bits, a.next_lps};
+	const SaoCandFromDevice cand = {a.offsets + (size_t)n * 480, a.aux + (size_t)n * 15, a.dist + (size_t)n * 15};
+	sao_decide(T, cur.st_merge, cur.st_type, cand, *(const SaoStats *)(a.stats + (size_t)n * 960), c > 0 ? a.ctus[n - 1].sao_recon : nullptr,
+		   r > 0 ? a.ctus[n - a.W].sao_recon : nullptr, a.lambdas, ci.sao_coded, ci.sao_recon);
+	code_sao_blk_param(cur, ci.sao_coded, c > 0, r > 0);   // the real coder's two contexts move on through this CTU's SAO syntax
+	for (int k = 0; k < 3; k++) {
+		int32_t *p = a.params + ((size_t)n * 3 + k) * 34;
+		p[0] = ci.sao_recon[k].mode_idc;
+		p[1] = ci.sao_recon[k].type_idc;
+		for (int j = 0; j < 32; j++) p[2 + j] = ci.sao_recon[k].offset[j];
+	}
+}
+__global__ __launch_bounds__(64) void k_sao_decide(SaoDecideArgs a)
+{
+	const int r = (int)threadIdx.x;
+	SaoContexts cur = {(uint8_t)a.st_merge, (uint8_t)a.st_type, a.next_lps};
+	if (!a.wpp) {
+		if (r == 0)
+			for (int n = 0; n < a.W * a.H; n++) sao_decide_one(a, n / a.W, n % a.W, cur);
+		return;
+	}
+	for (int t = 0; t < a.W + 2 * (a.H - 1); t++) {
+		const int c = t - 2 * r;
+		if (r < a.H && c >= 0 && c < a.W) {
+			if (c == 0 && r > 0) { cur.st_merge = a.saved[2 * (r - 1)]; cur.st_type = a.saved[2 * (r - 1) + 1]; }
+			sao_decide_one(a, r, c, cur);
+			if (c == 1) { a.saved[2 * r] = cur.st_merge; a.saved[2 * r + 1] = cur.st_type; }
+		}
+		__syncthreads();   // (one wavefront) the rows' results of this step are in memory before the next step reads them
+	}
+}
+
 struct hmr_gpu_enc {
 	hmr_gpu_ctx *ctx;
 	HostCfg cfg;
@@ -468,10 +530,15 @@ struct hmr_gpu_enc {
 	int8_t *d_ref;
 	uint8_t *d_qp, *d_flags, *d_pd, *d_ti;
 	int32_t *d_stats, *d_params;
+	int32_t *d_sao_offsets, *d_sao_aux, *d_sao_bits;   // candidate offsets [ctu][3][5][32], band positions [ctu][3][5]; kEntropyBits
+	long long *d_sao_dist;                             // [ctu][3][5]
+	double *d_sao_lambdas;                             // [ctu][3]
+	uint8_t *d_sao_lps, *d_sao_saved;                  // kNextStateLps; [ctu rows][2]
 	// host side of the entropy stage
 	std::vector<uint8_t> h_public;
 	std::vector<int16_t> h_coeff;
 	std::vector<int32_t> h_stats, h_params;
+	std::vector<double> h_lambdas;
 	EntropyState es;
 	int cur, lockstep;
 	float last_ms, last_total_ms;
@@ -661,6 +728,15 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 	DEV_ALLOC(e->d_flags, nu); DEV_ALLOC(e->d_pd, nu); DEV_ALLOC(e->d_ti, nu);
 	DEV_ALLOC(e->d_stats, (size_t)s.nctu * 3 * 5 * 2 * 32);
 	DEV_ALLOC(e->d_params, (size_t)s.nctu * 3 * 34);
+	DEV_ALLOC(e->d_sao_offsets, (size_t)s.nctu * 480);
+	DEV_ALLOC(e->d_sao_aux, (size_t)s.nctu * 15);
+	DEV_ALLOC(e->d_sao_dist, (size_t)s.nctu * 15);
+	DEV_ALLOC(e->d_sao_lambdas, (size_t)s.nctu * 3);
+	DEV_ALLOC(e->d_sao_bits, 128);
+	DEV_ALLOC(e->d_sao_lps, 128);
+	DEV_ALLOC(e->d_sao_saved, (size_t)s.hctu * 2);
+	HIP_TRY(hipMemcpy(e->d_sao_bits, kEntropyBits, sizeof kEntropyBits, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(e->d_sao_lps, kNextStateLps, sizeof kNextStateLps, hipMemcpyHostToDevice));
 	e->h_public.resize(sizeof(CtuPublic) * s.nctu);
 	e->h_coeff.resize((size_t)6144 * s.nctu);
 	e->h_stats.resize((size_t)s.nctu * 3 * 5 * 2 * 32);
@@ -685,7 +761,8 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	(void)hipStreamSynchronize(e->ctx->stream);
 	void *p[] = {e->d_seq, e->d_frame, e->d_geo, e->d.ctus, e->d.ctus_start, e->d.work_slow, e->d.coeff, e->d.progress, e->d.prefix, e->d.prof, e->d.guess, e->d.truth, e->d.outtok,
 		     e->d.chain_start, e->d.chain_end, e->d.valid, e->d.dirty, e->d.hash, e->d.intra_before, e->d.used_intra, e->d.used_parts, e->d.counters, e->d.rowstate, e->d.row0_checked, e->d_bytes, e->d_mvx,
-		     e->d_mvy, e->d_ref, e->d_qp, e->d_flags, e->d_pd, e->d_ti, e->d_stats, e->d_params};
+		     e->d_mvy, e->d_ref, e->d_qp, e->d_flags, e->d_pd, e->d_ti, e->d_stats, e->d_params, e->d_sao_offsets, e->d_sao_aux, e->d_sao_dist, e->d_sao_lambdas, e->d_sao_bits,
+		     e->d_sao_lps, e->d_sao_saved};
 	for (void *q : p) (void)hipFree(q);
 	for (int c = 0; c < 3; c++) {
 		(void)hipFree(e->d_pic[0][c]);
@@ -819,8 +896,8 @@ extern "C" int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *e, const uint8_t *y, const ui
 	return e->f.slice_type;
 }
 
-// HOMER_enc_encode for one picture already on the device (hmr_gpu_enc_load_source): CTU decisions, deblocking, SAO statistics on the
-// device; SAO decision + entropy coding on the host; SAO offsets and border padding on the device.  The access unit is written to stream.
+// HOMER_enc_encode for one picture already on the device (hmr_gpu_enc_load_source): CTU decisions, deblocking, SAO statistics, SAO decision, SAO offsets and
+// border padding on the device; entropy coding on the host.  The access unit is written to stream.
 extern "C" int hmr_gpu_enc_encode_source(hmr_gpu_enc *e, int slot, int image_type, uint8_t *stream, long cap, long *stream_bytes, uint8_t *recon)
 {
 	if (!e || slot < 0 || slot >= (int)e->src.size() || !stream || !stream_bytes) return HMR_GPU_ERR_ARG;
@@ -844,36 +921,44 @@ extern "C" int hmr_gpu_enc_encode_source(hmr_gpu_enc *e, int slot, int image_typ
 	HIP_TRY(hipGetLastError());
 	if ((rc = hmr_gpu_edge_flags_frame(e->ctx, e->d_pd, e->d_ti, s.width, s.height, e->units_stride, e->d_flags))) return rc;
 	if ((rc = hmr_gpu_deblock_frame(e->ctx, &pic, &units, s.chroma_qp_offset, s.chroma_qp_offset, 0, 0, nullptr, nullptr))) return rc;
-	if (s.sao && (rc = hmr_gpu_sao_stats_frame(e->ctx, &org, &pic, e->d_stats))) return rc;
-	// side-info, levels and statistics to the host
-	if ((rc = download_public(e))) return rc;
-	HIP_TRY(hipMemcpyAsync(e->h_coeff.data(), e->d.coeff, e->h_coeff.size() * 2, hipMemcpyDeviceToHost, st));
-	if (s.sao) HIP_TRY(hipMemcpyAsync(e->h_stats.data(), e->d_stats, e->h_stats.size() * 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	uint32_t acc = 0;
-	for (int n = 0; n < s.nctu; n++) acc += ((const CtuPublic *)(e->h_public.data() + sizeof(CtuPublic) * n))->distortion;
-	// SAO decision + entropy coding (enc/enc_entropy.h)
-	EntropyFrame fr;
-	fr.seq = &e->seq; fr.f = &e->f; fr.T = hmr_host_tables(); fr.geo = e->geo.data();
-	fr.ctu_base = e->h_public.data(); fr.ctu_pitch = sizeof(CtuPublic); fr.coeff = e->h_coeff.data();
-	std::vector<uint8_t> out;
-	encode_frame_entropy(e->es, fr, s.sao ? (const SaoStats *)e->h_stats.data() : nullptr, e->cfg.profile, out);
 	if (s.sao) {
-		for (int n = 0; n < s.nctu; n++) {
-			const CtuPublic &ci = fr.ctu(n);
-			for (int k = 0; k < 3; k++) {
-				int32_t *p = e->h_params.data() + ((size_t)n * 3 + k) * 34;
-				p[0] = ci.sao_recon[k].mode_idc; p[1] = ci.sao_recon[k].type_idc;
-				memcpy(p + 2, ci.sao_recon[k].offset, sizeof ci.sao_recon[k].offset);
-			}
+		// statistics -> candidate offsets -> decision -> offsets applied to a copy of the deblocked picture: one chain on the encoder's stream
+		if ((rc = hmr_gpu_sao_stats_frame(e->ctx, &org, &pic, e->d_stats))) return rc;
+		SaoDecideArgs a;
+		sao_lambdas(s, e->f, a.lambdas);
+		if (e->h_lambdas.empty() || e->h_lambdas[0] != a.lambdas[0] || e->h_lambdas[1] != a.lambdas[1]) {
+			e->h_lambdas.resize((size_t)s.nctu * 3);
+			for (int n = 0; n < s.nctu; n++)
+				for (int k = 0; k < 3; k++) e->h_lambdas[(size_t)n * 3 + k] = a.lambdas[k];
+			HIP_TRY(hipMemcpyAsync(e->d_sao_lambdas, e->h_lambdas.data(), e->h_lambdas.size() * sizeof(double), hipMemcpyHostToDevice, st));
+			HIP_TRY(hipStreamSynchronize(st));
 		}
-		HIP_TRY(hipMemcpyAsync(e->d_params, e->h_params.data(), e->h_params.size() * 4, hipMemcpyHostToDevice, st));
+		if ((rc = hmr_gpu_sao_offsets_frame(e->ctx, e->d_stats, s.nctu, e->d_sao_lambdas, e->d_sao_offsets, e->d_sao_aux, (int64_t *)e->d_sao_dist))) return rc;
+		Cabac first;
+		first.init_contexts(e->f.slice_type, e->f.qp);
+		a.ctus = e->d.ctus; a.stats = e->d_stats; a.offsets = e->d_sao_offsets; a.aux = e->d_sao_aux; a.dist = e->d_sao_dist;
+		a.W = s.wctu; a.H = s.hctu; a.wpp = s.wpp; a.st_merge = first.ctx[CTX_SAO_MERGE]; a.st_type = first.ctx[CTX_SAO_TYPE];
+		a.entropy_bits = e->d_sao_bits; a.next_lps = e->d_sao_lps; a.params = e->d_params; a.saved = e->d_sao_saved;
+		hipLaunchKernelGGL(k_sao_decide, dim3(1), dim3(64), 0, st, a);
+		HIP_TRY(hipGetLastError());
 		for (int c = 0; c < 3; c++) HIP_TRY(hipMemcpyAsync(e->d_pre[c], e->d_pic[e->cur][c], e->pic_elems[c] * 2, hipMemcpyDeviceToDevice, st));
 		const size_t oy = (size_t)s.margin_y * s.stride_y + s.margin_y, oc = (size_t)s.margin_c * s.stride_c + s.margin_c;
 		hmr_gpu_frame pre = {s.width, s.height, e->d_pre[0] + oy, e->d_pre[1] + oc, e->d_pre[2] + oc, s.stride_y, s.stride_c};
 		if ((rc = hmr_gpu_sao_apply_frame(e->ctx, &pre, &pic, e->d_params))) return rc;
 	}
 	if ((rc = hmr_gpu_pad_frame(e->ctx, &pic, s.margin_y, s.margin_y))) return rc;
+	// side-info (with the SAO parameters) and levels to the host: what the entropy coder reads
+	if ((rc = download_public(e))) return rc;
+	HIP_TRY(hipMemcpyAsync(e->h_coeff.data(), e->d.coeff, e->h_coeff.size() * 2, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	uint32_t acc = 0;
+	for (int n = 0; n < s.nctu; n++) acc += ((const CtuPublic *)(e->h_public.data() + sizeof(CtuPublic) * n))->distortion;
+	// entropy coding (enc/enc_entropy.h)
+	EntropyFrame fr;
+	fr.seq = &e->seq; fr.f = &e->f; fr.T = hmr_host_tables(); fr.geo = e->geo.data();
+	fr.ctu_base = e->h_public.data(); fr.ctu_pitch = sizeof(CtuPublic); fr.coeff = e->h_coeff.data();
+	std::vector<uint8_t> out;
+	encode_frame_entropy(e->es, fr, nullptr, e->cfg.profile, out);
 	if (recon) {
 		uint8_t *o = recon;
 		for (int c = 0; c < 3; c++) {
