@@ -570,7 +570,8 @@ void hmr_gpu_sao_offsets_ctu(const int32_t *stats, const double *lambdas, int32_
  *     performance_mode 0-2 (BASELINE configs 1, 2, 4); anything else makes hmr_gpu_enc_create return HMR_GPU_ERR_ARG.
  *     wfpp_num_threads = 1: the stream of the reference's single worker thread.  wfpp_num_threads = CTU rows: the stream of its
  *     multi-thread mode with the threads advancing as a synchronous wavefront (pinned by oracle/ref_ctudump.c, HOMER_TURNSTILE);
- *     other thread counts are refused.
+ *     fewer threads than rows are accepted when 2 x threads >= CTU columns (2160p: 32 threads, the reference's maximum, for 34 rows), others are refused.
+ *     The SAO parameter decision runs on the device too (k_sao_decide); entropy coding is the host stage.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct hmr_gpu_enc_cfg {
 	int32_t size, profile, width, height;
