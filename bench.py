@@ -141,6 +141,18 @@ def multi_stream(lib, device, width, height, keys, streams, warmup, steps):
             "note": f"{streams} independent {width}x{height} sequences concurrently on one GPU, {steps} timed frames each after {warmup} warm-up frames"}
 
 
+def multi_stream_child(device, workload, streams):
+    """multi_stream in a fresh process (a child, not an exec): the hardware queues of this process are already shared out among torch's and the
+    earlier encoders' streams, and two sequences that land on one queue run one after the other."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--multi-stream-child", str(streams), "--workload", workload, "--device", str(device)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    for line in reversed(r.stdout.splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    return {"streams": streams, "error": (r.stderr or r.stdout)[-300:]}
+
+
 def measure(step, warmup, nframes, world, device_sync, device):
     """The timing contract: `warmup` untimed steps, then steps warmup..nframes-1 bracketed by a barrier + device synchronisation on both sides;
     returns the wall time, MAX over the ranks.  step(f) encodes frame f.  (tests/test_bench_gloo.py runs this with world 2 on gloo.)"""
@@ -178,7 +190,13 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=24)
     ap.add_argument("--no-single-thread-order", action="store_true", help="skip the second measurement (wfpp_num_threads = 1)")
     ap.add_argument("--streams", type=int, default=10, help="concurrent sequences of the extra multi_stream measurement (0 = skip)")
+    ap.add_argument("--multi-stream-child", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.multi_stream_child:
+        width, height, keys = WORKLOADS[a.workload]
+        print(json.dumps(multi_stream(load_lib(), a.device, width, height, keys, a.multi_stream_child, 2, 3)))
+        return
 
     import torch
     import torch.distributed as dist
@@ -200,7 +218,7 @@ def main():
             out["single_thread_order"] = {k: other[k] for k in ("value", "unit", "ms_per_step", "stream_md5", "stream_matches_reference", "schedule")}
             out["single_thread_order"]["note"] = "the same encode with wfpp_num_threads = 1: output identical to the reference's single-thread run (md5 2f0c3447...), which costs guesses, verification and re-encode passes"
         if world == 1 and a.streams > 1:
-            out["multi_stream"] = multi_stream(lib, local, width, height, keys, a.streams, 2, 3)
+            out["multi_stream"] = multi_stream_child(local, a.workload, a.streams)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(width, height, {k: v for k, v in keys.items() if k != "wpp"}, a.cpu_frames)
         print(json.dumps(out))

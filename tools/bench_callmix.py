@@ -1115,13 +1115,14 @@ def main():
     ev = [(P * (2 * n_cmd))(*[ctx.event().value for _ in range(2 * n_cmd)]) for _ in range(args.steps)]
 
     def step(idx, timed):
-        # reconstructed reference picture: engine r -> engine r+1, point-to-point over RCCL/xGMI (engines sharing a GPU share its memory)
-        reqs = exchange_reference(E0["dst_pl"], E0["nxt_pl"], rank, world)
         for k, eng in enumerate(engines):
             if args.mode == "graph":
                 eng["ctx"].call("hmr_gpu_cmdlist_replay", eng["clist"])
             else:
                 eng["ctx"].call("hmr_gpu_cmdlist_run", eng["clist"], ev[idx] if (timed and k == 0) else None)
+        # reconstructed reference picture: engine r -> engine r+1, point-to-point over RCCL/xGMI, posted AFTER the frame's work on this stream (the
+        # transfer is ordered behind what is already on the stream: the offsets and padding that write the picture) and waited for before the next step
+        reqs = exchange_reference(E0["dst_pl"], E0["nxt_pl"], rank, world)
         for r in reqs:
             r.wait()
 
