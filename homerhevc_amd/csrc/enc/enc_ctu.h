@@ -545,52 +545,50 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 
 // ---- CTU set-up and tear-down ---------------------------------------------------------------------------------------------
 // create_partition_ctu_neighbours, hmr_motion_intra.c:658 + cu_partition_get_neighbours :629
-HENC_INLINE void create_partition_neighbours(Enc &__restrict__ e)
+// The reference walks the tree depth-first; a node only reads its parent, so the levels are done one after the other with the nodes of a level side by side.
+// A node is reached when its parent's top-left corner lies inside the picture (then so do the corners of the parent's ancestors).
+template <class G>
+HENC_HD void create_partition_neighbours(const G &g, Enc &__restrict__ e)
 {
 	const Seq &S = *e.seq;
 	CtuPublic &c = *e.ctu;
 	const int cu_min_tu_size_shift = hmax(S.max_cu_size_shift - (S.max_pred_depth + hmax(S.max_intra_tr_depth, S.max_inter_tr_depth) - 1), 2);
 	const int max_processing_depth = S.max_cu_size_shift - cu_min_tu_size_shift;
 	const int valid_lines = (c.y + 64) > S.height ? S.height - c.y : 64, valid_cols = (c.x + 64) > S.width ? S.width - c.x : 64;
-	int depth_state[NDEPTH] = {0, 0, 0, 0, 0};
-	int curr_depth = 0, parent = -1, curr = 0;
-	while (curr_depth != 0 || depth_state[curr_depth] != 1) {
-		const Geo &q = e.geo[curr];
-		Node &nd = node_of(e, curr);
-		curr_depth = q.depth;
-		nd.tl_inside = (c.y + q.y < S.height) && (c.x + q.x < S.width);
-		nd.b_inside = (c.y + q.y + q.size <= S.height);
-		nd.r_inside = (c.x + q.x + q.size <= S.width);
-		if (nd.tl_inside) {
-			if (parent < 0) {
-				nd.left_nb = c.has_left;
-				nd.top_nb = c.has_top;
-				nd.left_bottom_nb = 0;
-				nd.top_right_nb = c.has_top_right;
-			} else {
+	const int cx = c.x, cy = c.y, has_left = c.has_left, has_top = c.has_top, has_top_right = c.has_top_right;
+	for (int depth = 0; depth <= max_processing_depth && depth < NDEPTH; depth++) {
+		const int first = S.depth_start[depth], count = 1 << (2 * depth);
+		for (int k = g.tid; k < count; k += g.n) {
+			const int curr = first + k;
+			const Geo &q = e.geo[curr];
+			if (depth > 0) {
 				const Geo &pq = e.geo[q.parent];
-				const Node &pn = node_of(e, q.parent);
-				nd.left_nb = (pn.left_nb || q.x) ? 1 : 0;
-				nd.top_nb = (pn.top_nb || q.y) ? 1 : 0;
-				nd.left_bottom_nb = ((pn.left_bottom_nb && q.x == pq.x) || (pn.left_nb && q.x == pq.x && q.y == pq.y && valid_lines > q.y + q.size)) ? 1 : 0;
-				nd.top_right_nb = ((pn.top_right_nb && q.y == pq.y) || (pn.top_nb && q.x == pq.x && q.y == pq.y && valid_cols > q.x + q.size) ||
-						   (q.x == pq.x && q.y != pq.y && valid_cols > q.x + q.size))
-							  ? 1
-							  : 0;
+				if (!((cy + pq.y < S.height) && (cx + pq.x < S.width))) continue;
+			}
+			Node &nd = node_of(e, curr);
+			nd.tl_inside = (cy + q.y < S.height) && (cx + q.x < S.width);
+			nd.b_inside = (cy + q.y + q.size <= S.height);
+			nd.r_inside = (cx + q.x + q.size <= S.width);
+			if (nd.tl_inside) {
+				if (depth == 0) {
+					nd.left_nb = has_left;
+					nd.top_nb = has_top;
+					nd.left_bottom_nb = 0;
+					nd.top_right_nb = has_top_right;
+				} else {
+					const Geo &pq = e.geo[q.parent];
+					const Node &pn = node_of(e, q.parent);
+					nd.left_nb = (pn.left_nb || q.x) ? 1 : 0;
+					nd.top_nb = (pn.top_nb || q.y) ? 1 : 0;
+					nd.left_bottom_nb = ((pn.left_bottom_nb && q.x == pq.x) || (pn.left_nb && q.x == pq.x && q.y == pq.y && valid_lines > q.y + q.size)) ? 1 : 0;
+					nd.top_right_nb = ((pn.top_right_nb && q.y == pq.y) || (pn.top_nb && q.x == pq.x && q.y == pq.y && valid_cols > q.x + q.size) ||
+							   (q.x == pq.x && q.y != pq.y && valid_cols > q.x + q.size))
+								  ? 1
+								  : 0;
+				}
 			}
 		}
-		depth_state[curr_depth]++;
-		if (curr_depth < max_processing_depth && nd.tl_inside) {
-			curr_depth++;
-			parent = curr;
-		} else if (depth_state[curr_depth] == 4) {
-			while (depth_state[curr_depth] == 4) {
-				depth_state[curr_depth] = 0;
-				curr_depth--;
-				parent = e.geo[parent].parent;
-			}
-		}
-		if (parent >= 0) curr = e.geo[parent].child[depth_state[curr_depth]];
+		g.sync();
 	}
 }
 
@@ -668,7 +666,7 @@ HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 		}
 		g.sync();
 	}
-	create_partition_neighbours(e);
+	create_partition_neighbours(g, e);
 	if (e.box) {               // the helpers work on this CTU from now on
 		g.sync();
 		if (g.tid == 0) e.box->enc = e;
