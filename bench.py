@@ -217,6 +217,13 @@ def main():
             other = run_workload(lib, a, "cfg2-1080p-encode-single-thread-order", world, rank, local, torch)
             out["single_thread_order"] = {k: other[k] for k in ("value", "unit", "ms_per_step", "stream_md5", "stream_matches_reference", "schedule")}
             out["single_thread_order"]["note"] = "the same encode with wfpp_num_threads = 1: output identical to the reference's single-thread run (md5 2f0c3447...), which costs guesses, verification and re-encode passes"
+            # the metric's other picture size: 2160p, 34 CTU rows on the reference's maximum of 32 WPP threads, I + P + P (the two P frames timed)
+            import copy
+            b = copy.copy(a)
+            b.warmup, b.steps = 1, 2
+            big = run_workload(lib, b, "cfg2-2160p-encode", world, rank, local, torch)
+            out["at_2160p"] = {k: big[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "stream_md5", "stream_matches_reference")}
+            out["at_2160p"]["config"] = big["config"]
         if world == 1 and a.streams > 1:
             out["multi_stream"] = multi_stream_child(local, a.workload, a.streams)
         if world == 1 and not a.no_cpu_baseline:
