@@ -282,7 +282,7 @@ def run_workload(lib, a, workload, world, rank, local, torch):
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": workload, "wfpp_num_threads": int(keys.get("wpp", 1)), "width": width, "height": height, "frames_in_sequence": nframes, "gop": "IPPP intra_period=100", "qp": 32,
                        "rd_mode": 2, "performance_mode": 2, "sao": 1, "parallelism": f"replicas x{world}" if world > 1 else "single engine",
-                       "timed_region": "CTU decisions + deblock + SAO stats + host SAO decision / CABAC / NAL + SAO offsets + padding per frame; source in HBM"},
+                       "timed_region": "CTU decisions + deblock + SAO statistics / decision / offsets + padding on the device, CABAC / NAL on the host, per frame; source in HBM"},
             "stream_md5": digest, "stream_matches_reference": (digest == want) if want else None,
             "schedule": {"ctus_per_frame": nctu, "passes_per_frame": [s[3] for s in timed], "ctu_encodes_per_frame": [s[4] for s in timed],
                          "ctu_stage_ms_per_frame": [round(s[5], 1) for s in timed], "device_ms_per_frame": [round(s[6], 1) for s in timed]},
