@@ -10,4 +10,5 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_IN
   rocprofv3 --pmc $set -d $R/gpurun_out/pmc_${TAG}_$tag -o pmc --output-format csv -- python3 $R/bench.py $ARGS > /dev/null 2> $R/gpurun_out/pmc_${TAG}_$tag.log
 done
 python3 $R/tools/pmc_kernels.py $R/gpurun_out $TAG "python3 bench.py $ARGS" > $R/gpurun_out/${TAG}_pmc_k_encode_ctus.json
+python3 $R/tools/kernel_launches.py $R/gpurun_out/prof_$TAG/bench_kernel_trace.csv $R/gpurun_out/${TAG}_bench_under_rocprof.json > $R/gpurun_out/${TAG}_k_encode_ctus_launches.json
 find $R/gpurun_out/prof_$TAG -name "*stats*" | head
