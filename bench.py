@@ -141,11 +141,51 @@ def multi_stream(lib, device, width, height, keys, streams, warmup, steps):
             "note": f"{streams} independent {width}x{height} sequences concurrently on one GPU, {steps} timed frames each after {warmup} warm-up frames"}
 
 
-def multi_stream_child(device, workload, streams):
+def multi_stream_batched(lib, device, width, height, keys, streams, warmup, steps):
+    """The same measurement through hmr_gpu_enc_encode_batch: one launch per step for the CTU stages of all sequences (no dependence on how streams map
+    to hardware queues); each sequence finishes its frame on its own stream and host thread inside the call."""
+    import encoder_cases as ec
+    lib.hmr_gpu_enc_encode_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    frames = ec.clip_frames(width, height, warmup + steps)
+    encs, bufs = [], []
+    for _ in range(streams):
+        ctx, enc = C.c_void_p(), C.c_void_p()
+        assert lib.hmr_gpu_create(C.byref(ctx), device, None) == 0
+        cfg = ec.default_cfg(width, height, **keys)
+        assert lib.hmr_gpu_enc_create(ctx, C.byref(cfg), C.byref(enc)) == 0, lib.hmr_gpu_last_error()
+        for f, planes in enumerate(frames):
+            assert lib.hmr_gpu_enc_load_source(enc, f, *planes) == 0
+        encs.append(enc)
+        bufs.append(C.create_string_buffer(4 << 20))
+    n = streams
+    e_arr = (C.c_void_p * n)(*encs)
+    ptrs = (C.c_char_p * n)(*[C.cast(b, C.c_char_p) for b in bufs])
+    caps = (C.c_long * n)(*[len(b) for b in bufs])
+    got = (C.c_long * n)()
+    md5 = [hashlib.md5() for _ in range(n)]
+    t0 = None
+    for f in range(warmup + steps):
+        if f == warmup:
+            t0 = time.perf_counter()
+        assert lib.hmr_gpu_enc_encode_batch(e_arr, n, (C.c_int * n)(*([f] * n)), None, ptrs, caps, got) == 0, lib.hmr_gpu_last_error()
+        for i in range(n):
+            md5[i].update(bufs[i].raw[:got[i]])
+    dt = time.perf_counter() - t0
+    p, k, ms, tot = C.c_int(), C.c_int(), C.c_float(), C.c_float()
+    lib.hmr_gpu_enc_last_stats(encs[0], C.byref(p), C.byref(k), C.byref(ms), C.byref(tot))
+    for enc in encs:
+        lib.hmr_gpu_enc_destroy(enc)
+    return {"streams": streams, "frames_per_stream": steps, "value": round(streams * steps / dt, 4), "unit": "frames/s aggregate", "ctu_kernel_ms_last_step": round(ms.value, 1),
+            "all_streams_identical": len({m.hexdigest() for m in md5}) == 1, "stream_md5": md5[0].hexdigest(),
+            "note": f"{streams} independent {width}x{height} sequences, one hmr_gpu_enc_encode_batch call per step ({streams * ((height + 63) // 64)} workgroups in one launch), "
+                    f"{steps} timed steps after {warmup}"}
+
+
+def multi_stream_child(device, workload, streams, batched=False):
     """multi_stream in a fresh process (a child, not an exec): the hardware queues of this process are already shared out among torch's and the
     earlier encoders' streams, and two sequences that land on one queue run one after the other."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--multi-stream-child", str(streams), "--workload", workload, "--device", str(device)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--multi-stream-child", str(streams), "--workload", workload, "--device", str(device)] + (["--batched"] if batched else [])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     for line in reversed(r.stdout.splitlines()):
         if line.startswith("{"):
@@ -189,13 +229,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=24)
     ap.add_argument("--no-single-thread-order", action="store_true", help="skip the second measurement (wfpp_num_threads = 1)")
-    ap.add_argument("--streams", type=int, default=10, help="concurrent sequences of the extra multi_stream measurement (0 = skip)")
+    ap.add_argument("--sequences", type=int, default=15, help="independent sequences per GPU, encoded with one launch per step (hmr_gpu_enc_encode_batch); 1 = a single sequence")
+    ap.add_argument("--streams", type=int, default=0, help="concurrent sequences of the extra multi_stream measurement (0 = skip)")
     ap.add_argument("--multi-stream-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--batched", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--batch", type=int, default=0, help="sequences of the multi_stream_batched measurement (one launch for all CTU stages; 0 = skip)")
     a = ap.parse_args()
     if a.multi_stream_child:
         width, height, keys = WORKLOADS[a.workload]
-        print(json.dumps(multi_stream(load_lib(), a.device, width, height, keys, a.multi_stream_child, 2, 3)))
+        fn = multi_stream_batched if a.batched else multi_stream
+        print(json.dumps(fn(load_lib(), a.device, width, height, keys, a.multi_stream_child, 2, 3)))
         return
 
     import torch
@@ -210,9 +254,13 @@ def main():
     torch.cuda.set_device(local)
 
     lib = load_lib()
-    out = run_workload(lib, a, a.workload, world, rank, local, torch)
+    out = run_workload(lib, a, a.workload, world, rank, local, torch, sequences=a.sequences)
     if rank == 0:
         width, height, keys = WORKLOADS[a.workload]
+        if world == 1 and a.sequences > 1:
+            one = run_workload(lib, a, a.workload, world, rank, local, torch)
+            out["single_sequence"] = {k: one[k] for k in ("value", "unit", "ms_per_step", "stream_md5", "stream_matches_reference", "schedule")}
+            out["single_sequence"]["note"] = "one sequence alone on the GPU (17 of the 256 CUs busy): the latency of the row-parallel CTU chain"
         if world == 1 and a.workload == "cfg2-1080p-encode" and not a.no_single_thread_order:
             other = run_workload(lib, a, "cfg2-1080p-encode-single-thread-order", world, rank, local, torch)
             out["single_thread_order"] = {k: other[k] for k in ("value", "unit", "ms_per_step", "stream_md5", "stream_matches_reference", "schedule")}
@@ -226,6 +274,8 @@ def main():
             out["at_2160p"]["config"] = big["config"]
         if world == 1 and a.streams > 1:
             out["multi_stream"] = multi_stream_child(local, a.workload, a.streams)
+        if world == 1 and a.batch > 1:
+            out["multi_stream_batched"] = multi_stream_child(local, a.workload, a.batch, batched=True)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(width, height, {k: v for k, v in keys.items() if k != "wpp"}, a.cpu_frames)
         print(json.dumps(out))
@@ -233,31 +283,53 @@ def main():
         dist.destroy_process_group()
 
 
-def run_workload(lib, a, workload, world, rank, local, torch):
+def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
+    """`sequences` independent sequences of the workload per GPU: 1 = hmr_gpu_enc_encode_source frame by frame; more = one hmr_gpu_enc_encode_batch call per step
+    (ONE launch for the CTU stages of all of them - a row worker takes a whole CU, fifteen 1080p sequences are 255 workgroups), every stream hashed."""
     import encoder_cases as ec
     width, height, keys = WORKLOADS[workload]
     nframes = a.warmup + a.steps
-    ctx, enc = C.c_void_p(), C.c_void_p()
-    assert lib.hmr_gpu_create(C.byref(ctx), local, None) == 0, lib.hmr_gpu_last_error()
-    cfg = ec.default_cfg(width, height, **keys)
-    assert lib.hmr_gpu_enc_create(ctx, C.byref(cfg), C.byref(enc)) == 0, lib.hmr_gpu_last_error()
-    for f, planes in enumerate(ec.clip_frames(width, height, nframes)):
-        assert lib.hmr_gpu_enc_load_source(enc, f, *planes) == 0, lib.hmr_gpu_last_error()
-    buf = C.create_string_buffer(16 << 20)
+    S = sequences if int(keys.get("wpp", 1)) > 1 else 1
+    frames = ec.clip_frames(width, height, nframes)
+    encs, bufs = [], []
+    for _ in range(S):
+        ctx, enc = C.c_void_p(), C.c_void_p()
+        assert lib.hmr_gpu_create(C.byref(ctx), local, None) == 0, lib.hmr_gpu_last_error()
+        cfg = ec.default_cfg(width, height, **keys)
+        assert lib.hmr_gpu_enc_create(ctx, C.byref(cfg), C.byref(enc)) == 0, lib.hmr_gpu_last_error()
+        for f, planes in enumerate(frames):
+            assert lib.hmr_gpu_enc_load_source(enc, f, *planes) == 0, lib.hmr_gpu_last_error()
+        encs.append(enc)
+        bufs.append(C.create_string_buffer(16 << 20))
+    enc, buf = encs[0], bufs[0]
     nbytes = C.c_long()
-    md5 = hashlib.md5()
+    md5s = [hashlib.md5() for _ in range(S)]
     stats = []
+    lib.hmr_gpu_enc_encode_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    e_arr = (C.c_void_p * S)(*encs)
+    ptrs = (C.c_char_p * S)(*[C.cast(b, C.c_char_p) for b in bufs])
+    caps = (C.c_long * S)(*[len(b) for b in bufs])
+    got = (C.c_long * S)()
 
     def step(f):
-        st = lib.hmr_gpu_enc_encode_source(enc, f, 0, buf, len(buf), C.byref(nbytes), None)
-        assert st in (1, 2), lib.hmr_gpu_last_error()
-        md5.update(buf.raw[:nbytes.value])
+        if S == 1:
+            st = lib.hmr_gpu_enc_encode_source(enc, f, 0, buf, len(buf), C.byref(nbytes), None)
+            assert st in (1, 2), lib.hmr_gpu_last_error()
+            md5s[0].update(buf.raw[:nbytes.value])
+        else:
+            assert lib.hmr_gpu_enc_encode_batch(e_arr, S, (C.c_int * S)(*([f] * S)), None, ptrs, caps, got) == 0, lib.hmr_gpu_last_error()
+            for i in range(S):
+                md5s[i].update(bufs[i].raw[:got[i]])
+            st, nbytes.value = 0, got[0]
         p, n, ms, tot = C.c_int(), C.c_int(), C.c_float(), C.c_float()
         lib.hmr_gpu_enc_last_stats(enc, C.byref(p), C.byref(n), C.byref(ms), C.byref(tot))
         stats.append((f, st, nbytes.value, p.value, n.value, ms.value, tot.value))
 
     dt = measure(step, a.warmup, nframes, world, torch.cuda.synchronize, "cuda")
-    lib.hmr_gpu_enc_destroy(enc)
+    for x in encs:
+        lib.hmr_gpu_enc_destroy(x)
+    md5 = md5s[0]
+    all_same = len({m.hexdigest() for m in md5s}) == 1
 
     if True:
         timed = stats[a.warmup:]
@@ -267,31 +339,32 @@ def run_workload(lib, a, workload, world, rank, local, torch):
         frame_ms = sum(s[6] for s in timed)
         # SURVEY.md 8-d, the CTU stage's share of the frame-level compulsory traffic: source + reference + reconstruction (1 byte samples) + levels (2 bytes)
         algo_bytes_frame = 1.5 * width * height * 3 + 2 * 1.5 * width * height
-        achieved = algo_bytes_frame * len(timed) / (ctu_ms * 1e-3) / 1e9
+        achieved = S * algo_bytes_frame * len(timed) / (ctu_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed counter passes of this same command (TCC_EA0_RDREQ / WRREQ x 64 B, MI355X_MICROARCH.md "HBM"; narrow accesses: uncalibrated)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r02_pmc_k_encode_ctus.json")
-        if os.path.exists(tpath) and workload == "cfg2-1080p-encode":
-            k = json.load(open(tpath))["k_encode_ctus"]
+        kernel_name = "k_encode_ctus_batch" if S > 1 else "k_encode_ctus"
+        if os.path.exists(tpath) and workload == "cfg2-1080p-encode" and kernel_name in json.load(open(tpath)):
+            k = json.load(open(tpath))[kernel_name]
             traffic = int((k["derived"]["hbm_read_bytes_TCC_EA0_RDREQ_x64"] + k["derived"]["hbm_write_bytes_TCC_EA0_WRREQ_x64_upper_bound"]) / k["launches"])
         digest = md5.hexdigest()
         want = REFERENCE_MD5.get((workload, nframes))
         out = {
-            "metric": "encoded frames/sec, 1080p & 2160p YUV420 fixed-QP IPPP, 1/2/4/8 MI355X", "value": round(world * a.steps / dt, 4), "unit": "frames/s",
+            "metric": "encoded frames/sec, 1080p & 2160p YUV420 fixed-QP IPPP, 1/2/4/8 MI355X", "value": round(world * S * a.steps / dt, 4), "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
-            "config": {"workload": workload, "wfpp_num_threads": int(keys.get("wpp", 1)), "width": width, "height": height, "frames_in_sequence": nframes, "gop": "IPPP intra_period=100", "qp": 32,
-                       "rd_mode": 2, "performance_mode": 2, "sao": 1, "parallelism": f"replicas x{world}" if world > 1 else "single engine",
+            "config": {"workload": workload, "sequences_per_gpu": S, "frames_per_step": S, "wfpp_num_threads": int(keys.get("wpp", 1)), "width": width, "height": height, "frames_in_sequence": nframes, "gop": "IPPP intra_period=100", "qp": 32,
+                       "rd_mode": 2, "performance_mode": 2, "sao": 1, "parallelism": (f"{S} independent sequences per GPU, one launch per step for their CTU stages" if S > 1 else "one sequence") + (f"; replicas x{world}" if world > 1 else ""),
                        "timed_region": "CTU decisions + deblock + SAO statistics / decision / offsets + padding on the device, CABAC / NAL on the host, per frame; source in HBM"},
-            "stream_md5": digest, "stream_matches_reference": (digest == want) if want else None,
+            "stream_md5": digest, "stream_matches_reference": (digest == want and all_same) if want else None, "all_streams_identical": all_same,
             "schedule": {"ctus_per_frame": nctu, "passes_per_frame": [s[3] for s in timed], "ctu_encodes_per_frame": [s[4] for s in timed],
                          "ctu_stage_ms_per_frame": [round(s[5], 1) for s in timed], "device_ms_per_frame": [round(s[6], 1) for s in timed]},
-            "roofline": {"bound": "hbm", "kernel": "k_encode_ctus", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 7),
-                         "traffic": traffic, "launches": launches, "algorithmic_bytes_per_launch": int(algo_bytes_frame * len(timed) / max(launches, 1)), "ms_per_launch": round(ctu_ms / max(launches, 1), 2),
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 7),
+                         "traffic": traffic, "launches": launches, "algorithmic_bytes_per_launch": int(S * algo_bytes_frame * len(timed) / max(launches, 1)), "ms_per_launch": round(ctu_ms / max(launches, 1), 2),
                          "algorithmic_bytes_per_frame": int(algo_bytes_frame), "share_of_device_time": round(ctu_ms / frame_ms, 3),
                          # SURVEY 8-d, the whole P frame (CTU stage + the in-loop filters' read / write): 10.5 W H bytes x frames/s against the same peak
-                         "frame_level": {"algorithmic_bytes_per_frame": int(10.5 * width * height), "achieved": round(10.5 * width * height * world * a.steps / dt / 1e9, 4),
-                                         "frac": round(10.5 * width * height * world * a.steps / dt / 1e9 / HBM_PEAK_GBS, 7)},
+                         "frame_level": {"algorithmic_bytes_per_frame": int(10.5 * width * height), "achieved": round(10.5 * width * height * world * S * a.steps / dt / 1e9, 4),
+                                         "frac": round(10.5 * width * height * world * S * a.steps / dt / 1e9 / HBM_PEAK_GBS, 7)},
                          "note": "one wavefront per CTU row (17 at 1080p) walking a dependent decision chain: bound by instruction issue and memory latency of "
                                  "those few wavefronts, not by HBM bandwidth; the fraction is the honest distance from the bandwidth roof"},
         }

@@ -14,6 +14,7 @@
 // (k_deblock.hip, k_sao.hip, k_pad.hip); the entropy stage (enc/enc_entropy.h) is host code fed with the side-info, the levels
 // and the SAO statistics, and hands the SAO parameters back for the offset pass.
 #include <stddef.h>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -143,11 +144,12 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 	}
 }
 
-__global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
+// the work of one row worker (a workgroup): `row` of the picture described by d
+__device__ __forceinline__ void encode_rows_body(const EncDev &d, int pass, int row)
 {
 	extern __shared__ __align__(16) uint8_t lds[];
 	const Seq &S = *d.seq;
-	const int row = blockIdx.x, W = S.wctu, H = S.hctu;
+	const int W = S.wctu, H = S.hctu;
 	WaveGrp g{(int)(threadIdx.x & 63)};
 	Work *lw = (Work *)lds;
 	Geo *lgeo = (Geo *)(lds + LDS_WORK + LDS_NODES);
@@ -447,6 +449,21 @@ struct SrcSlot {
 	int16_t *p[3];
 };
 
+__global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
+{
+	encode_rows_body(d, pass, (int)blockIdx.x);
+}
+// several sequences in ONE launch (row-per-thread schedule): workgroup b works on row b - first_row[q] of sequence q.  Every row worker takes a whole CU (its LDS),
+// so fifteen 1080p sequences (255 workgroups) fill the chip with one dispatch instead of fifteen queues competing for it.  A row only ever waits for rows of its
+// own sequence with smaller indices, which are dispatched before it.
+__global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus_batch(const EncDev *devs, const int *first_row, int nseq)
+{
+	int q = 0;
+	while (q + 1 < nseq && (int)blockIdx.x >= first_row[q + 1]) q++;
+	const EncDev d = devs[q];
+	encode_rows_body(d, -1, (int)blockIdx.x - first_row[q]);
+}
+
 // ---- SAO parameter decision on the device (enc/enc_sao.h): what it needs from the entropy coder is the walk of two contexts through the SAO syntax of each
 // sub-stream, so it runs here, behind the statistics and the candidate offsets (k_saooffsets.hip) and in front of the offset pass, with no host in the chain.
 // One wavefront; lane r owns CTU row r and the rows advance as the WPP wavefront (CTU (r, c) at step c + 2 r): a CTU needs the parameters of its left and
@@ -539,6 +556,8 @@ struct hmr_gpu_enc {
 	std::vector<int16_t> h_coeff;
 	std::vector<int32_t> h_stats, h_params;
 	std::vector<double> h_lambdas;
+	hipEvent_t ev_frame = nullptr, ev_ready = nullptr;   // start of the frame on the encoder's stream; its CTU stage may be launched
+	void *d_batch = nullptr;                             // hmr_gpu_enc_encode_batch (lead encoder): the sequences' EncDev records and first rows
 	EntropyState es;
 	int cur, lockstep;
 	float last_ms, last_total_ms;
@@ -583,8 +602,8 @@ int load_planes(hmr_gpu_enc *e, const uint8_t *y, const uint8_t *u, const uint8_
 	return HMR_GPU_OK;
 }
 
-// the CTU decisions of the frame set up in e->f / e->d_frame: passes until the check finds nothing wrong
-int run_ctu_passes(hmr_gpu_enc *e)
+// what a frame's CTU stage needs on the stream before its first launch
+int ctu_stage_prepare(hmr_gpu_enc *e)
 {
 	const Seq &s = e->seq;
 	hipStream_t st = e->ctx->stream;
@@ -593,21 +612,40 @@ int run_ctu_passes(hmr_gpu_enc *e)
 		static const int zero_counters[3] = {0, 0, -1};
 		HIP_TRY(hipMemcpyAsync(e->d.counters, zero_counters, sizeof zero_counters, hipMemcpyHostToDevice, st));
 	}
+	if (e->lockstep) {
+		HIP_TRY(hipMemsetAsync(e->d.progress, 0, sizeof(int) * s.hctu, st));
+		HIP_TRY(hipMemsetAsync(e->d.row0_checked, 0, sizeof(int), st));
+	}
+	return HMR_GPU_OK;
+}
+// row-per-thread schedule, after the launch: what the frame found
+int lockstep_collect(hmr_gpu_enc *e)
+{
+	hipStream_t st = e->ctx->stream;
+	int counters[3];
+	HIP_TRY(hipMemcpyAsync(counters, e->d.counters, sizeof counters, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	e->last_encodes = counters[1];
+	e->f.scene_cut_ctu = counters[2];
+	e->last_passes = 1;
+	return HMR_GPU_OK;
+}
+
+// the CTU decisions of the frame set up in e->f / e->d_frame: passes until the check finds nothing wrong
+int run_ctu_passes(hmr_gpu_enc *e)
+{
+	const Seq &s = e->seq;
+	hipStream_t st = e->ctx->stream;
+	int rc = ctu_stage_prepare(e);
+	if (rc) return rc;
 	HIP_TRY(hipEventRecord(e->ctx->ev0, st));
 	if (e->lockstep) {
 		// wfpp_num_threads = CTU rows: the synchronous wavefront, one launch, nothing to verify
-		HIP_TRY(hipMemsetAsync(e->d.progress, 0, sizeof(int) * s.hctu, st));
-		HIP_TRY(hipMemsetAsync(e->d.row0_checked, 0, sizeof(int), st));
 		hipLaunchKernelGGL(k_encode_ctus, dim3(s.hctu), dim3(ENC_THREADS), LDS_BYTES, st, e->d, -1);
 		HIP_TRY(hipGetLastError());
-		int counters[3];
-		HIP_TRY(hipMemcpyAsync(counters, e->d.counters, sizeof counters, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipEventRecord(e->ctx->ev1, st));
-		HIP_TRY(hipStreamSynchronize(st));
+		if ((rc = lockstep_collect(e))) return rc;
 		HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ctx->ev0, e->ctx->ev1));
-		e->last_encodes = counters[1];
-		e->f.scene_cut_ctu = counters[2];
-		e->last_passes = 1;
 		return HMR_GPU_OK;
 	}
 	int pass = 0;
@@ -696,6 +734,9 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 	}
 	DEV_ALLOC(e->d.work_slow, s.hctu);
 	HIP_TRY(hipFuncSetAttribute((const void *)k_encode_ctus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+	HIP_TRY(hipFuncSetAttribute((const void *)k_encode_ctus_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+	HIP_TRY(hipEventCreate(&e->ev_frame));
+	HIP_TRY(hipEventCreate(&e->ev_ready));
 	DEV_ALLOC(e->d.coeff, (size_t)6144 * s.nctu);
 	DEV_ALLOC(e->d.progress, s.hctu);
 	DEV_ALLOC(e->d.prefix, (size_t)s.hctu * (s.wctu + 1));
@@ -759,6 +800,9 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	if (!e) return;
 	(void)hipSetDevice(e->ctx->device);
 	(void)hipStreamSynchronize(e->ctx->stream);
+	if (e->ev_frame) (void)hipEventDestroy(e->ev_frame);
+	if (e->ev_ready) (void)hipEventDestroy(e->ev_ready);
+	if (e->d_batch) (void)hipFree(e->d_batch);
 	void *p[] = {e->d_seq, e->d_frame, e->d_geo, e->d.ctus, e->d.ctus_start, e->d.work_slow, e->d.coeff, e->d.progress, e->d.prefix, e->d.prof, e->d.guess, e->d.truth, e->d.outtok,
 		     e->d.chain_start, e->d.chain_end, e->d.valid, e->d.dirty, e->d.hash, e->d.intra_before, e->d.used_intra, e->d.used_parts, e->d.counters, e->d.rowstate, e->d.row0_checked, e->d_bytes, e->d_mvx,
 		     e->d_mvy, e->d_ref, e->d_qp, e->d_flags, e->d_pd, e->d_ti, e->d_stats, e->d_params, e->d_sao_offsets, e->d_sao_aux, e->d_sao_dist, e->d_sao_lambdas, e->d_sao_bits,
@@ -898,20 +942,13 @@ extern "C" int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *e, const uint8_t *y, const ui
 
 // HOMER_enc_encode for one picture already on the device (hmr_gpu_enc_load_source): CTU decisions, deblocking, SAO statistics, SAO decision, SAO offsets and
 // border padding on the device; entropy coding on the host.  The access unit is written to stream.
-extern "C" int hmr_gpu_enc_encode_source(hmr_gpu_enc *e, int slot, int image_type, uint8_t *stream, long cap, long *stream_bytes, uint8_t *recon)
+namespace {
+// the frame behind its CTU stage: in-loop filters and SAO on the device, side-info and levels to the host, entropy coding, the access unit into `stream`
+int frame_finish(hmr_gpu_enc *e, int slot, uint8_t *stream, long cap, long *stream_bytes, uint8_t *recon)
 {
-	if (!e || slot < 0 || slot >= (int)e->src.size() || !stream || !stream_bytes) return HMR_GPU_ERR_ARG;
 	const Seq &s = e->seq;
 	hipStream_t st = e->ctx->stream;
-	HIP_TRY(hipSetDevice(e->ctx->device));
-	hipEvent_t t0, t1;
-	HIP_TRY(hipEventCreate(&t0));
-	HIP_TRY(hipEventCreate(&t1));
-	HIP_TRY(hipEventRecord(t0, st));
-	int rc = set_frame(e, slot, image_type, -1.0);
-	if (rc) return rc;
-	rc = run_ctu_passes(e);
-	if (rc) return rc;
+	int rc;
 	// in-loop filters on the picture under reconstruction
 	hmr_gpu_frame pic = {s.width, s.height, plane0(e, e->cur, 0), plane0(e, e->cur, 1), plane0(e, e->cur, 2), s.stride_y, s.stride_c};
 	hmr_gpu_frame org = {s.width, s.height, e->src[slot].p[0], e->src[slot].p[1], e->src[slot].p[2], s.src_stride_y, s.src_stride_c};
@@ -969,11 +1006,9 @@ extern "C" int hmr_gpu_enc_encode_source(hmr_gpu_enc *e, int slot, int image_typ
 			o += (size_t)w * h;
 		}
 	}
-	HIP_TRY(hipEventRecord(t1, st));
+	HIP_TRY(hipEventRecord(e->ctx->ev1, st));
 	HIP_TRY(hipStreamSynchronize(st));
-	HIP_TRY(hipEventElapsedTime(&e->last_total_ms, t0, t1));
-	(void)hipEventDestroy(t0);
-	(void)hipEventDestroy(t1);
+	HIP_TRY(hipEventElapsedTime(&e->last_total_ms, e->ev_frame, e->ctx->ev1));
 	end_frame(s, e->st, e->f, acc);
 	*stream_bytes = (long)out.size();
 	if ((long)out.size() > cap) {
@@ -982,6 +1017,81 @@ extern "C" int hmr_gpu_enc_encode_source(hmr_gpu_enc *e, int slot, int image_typ
 	}
 	memcpy(stream, out.data(), out.size());
 	return e->f.slice_type;
+}
+}  // namespace
+
+extern "C" int hmr_gpu_enc_encode_source(hmr_gpu_enc *e, int slot, int image_type, uint8_t *stream, long cap, long *stream_bytes, uint8_t *recon)
+{
+	if (!e || slot < 0 || slot >= (int)e->src.size() || !stream || !stream_bytes) return HMR_GPU_ERR_ARG;
+	hipStream_t st = e->ctx->stream;
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	HIP_TRY(hipEventRecord(e->ev_frame, st));
+	int rc = set_frame(e, slot, image_type, -1.0);
+	if (rc) return rc;
+	rc = run_ctu_passes(e);
+	if (rc) return rc;
+	return frame_finish(e, slot, stream, cap, stream_bytes, recon);
+}
+
+// Several sequences, one frame each, with ONE launch for all their CTU stages (k_encode_ctus_batch): encs[i] encodes its picture slots[i] into streams[i].
+// All encoders must use the row-per-thread schedule and live on the same device; each finishes its frame (filters, SAO, download, entropy coding) on its own
+// stream and host thread.  The streams are those hmr_gpu_enc_encode_source would have produced one by one.
+extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes)
+{
+	if (!encs || n <= 0 || n > 64 || !slots || !streams || !caps || !stream_bytes) return HMR_GPU_ERR_ARG;
+	for (int i = 0; i < n; i++) {
+		hmr_gpu_enc *e = encs[i];
+		if (!e || !e->lockstep || e->ctx->device != encs[0]->ctx->device || slots[i] < 0 || slots[i] >= (int)e->src.size() || !streams[i]) {
+			hmr_set_error("hmr_gpu_enc_encode_batch: encoder %d: needs the row-per-thread schedule (wfpp_num_threads > 1), the batch's device and a loaded picture slot", i);
+			return HMR_GPU_ERR_ARG;
+		}
+		for (int j = 0; j < i; j++)
+			if (encs[j] == e) return HMR_GPU_ERR_ARG;
+	}
+	hmr_gpu_enc *lead = encs[0];
+	hipStream_t bst = lead->ctx->stream;
+	HIP_TRY(hipSetDevice(lead->ctx->device));
+	std::vector<EncDev> devs(n);
+	std::vector<int> first(n + 1, 0);
+	int rc;
+	for (int i = 0; i < n; i++) {
+		hmr_gpu_enc *e = encs[i];
+		HIP_TRY(hipEventRecord(e->ev_frame, e->ctx->stream));
+		if ((rc = set_frame(e, slots[i], image_types ? image_types[i] : 0, -1.0))) return rc;
+		if ((rc = ctu_stage_prepare(e))) return rc;
+		HIP_TRY(hipEventRecord(e->ev_ready, e->ctx->stream));
+		if (i) HIP_TRY(hipStreamWaitEvent(bst, e->ev_ready, 0));
+		devs[i] = e->d;
+		first[i + 1] = first[i] + e->seq.hctu;
+	}
+	if (!lead->d_batch) {
+		HIP_TRY(hipMalloc((void **)&lead->d_batch, 64 * sizeof(EncDev) + 65 * sizeof(int)));
+	}
+	int *d_first = (int *)((uint8_t *)lead->d_batch + 64 * sizeof(EncDev));
+	HIP_TRY(hipMemcpyAsync(lead->d_batch, devs.data(), n * sizeof(EncDev), hipMemcpyHostToDevice, bst));
+	HIP_TRY(hipMemcpyAsync(d_first, first.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, bst));
+	HIP_TRY(hipEventRecord(lead->ctx->ev0, bst));
+	hipLaunchKernelGGL(k_encode_ctus_batch, dim3(first[n]), dim3(ENC_THREADS), LDS_BYTES, bst, (const EncDev *)lead->d_batch, (const int *)d_first, n);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(lead->ctx->ev1, bst));
+	HIP_TRY(hipStreamSynchronize(bst));      // (devs / first are host vectors; and the kernel time is read below)
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, lead->ctx->ev0, lead->ctx->ev1));
+	std::vector<int> rcs(n, 0);
+	std::vector<std::thread> th;
+	for (int i = 0; i < n; i++)
+		th.emplace_back([&, i]() {
+			hmr_gpu_enc *e = encs[i];
+			if (hipSetDevice(e->ctx->device) != hipSuccess) { rcs[i] = HMR_GPU_ERR_HIP; return; }
+			e->last_ms = ms;
+			int r = lockstep_collect(e);
+			if (!r) r = frame_finish(e, slots[i], streams[i], caps[i], &stream_bytes[i], nullptr);
+			rcs[i] = r;
+		});
+	for (auto &t : th) t.join();
+	for (int i = 0; i < n; i++)
+		if (rcs[i] < 0) return rcs[i];
+	return HMR_GPU_OK;
 }
 
 // HOMER_enc_encode (homer_hevc_enc_api.h:173): host planes in, access unit out

@@ -66,3 +66,47 @@ def test_device_stream_is_byte_identical_to_the_reference(gpu, case):
     assert first_bad is None, f"reconstructed picture {first_bad} differs"
     assert len(stream) == g["stream_bytes"]
     assert hashlib.md5(stream).hexdigest() == g["stream_md5"]
+
+
+def test_batch_of_sequences_in_one_launch(gpu):
+    """hmr_gpu_enc_encode_batch: four sequences (three 416x240, one 832x480; row-per-thread schedule) advance frame by frame with ONE launch for all their CTU
+    stages; every sequence's stream must be the one it gets when encoded alone, i.e. the turnstile reference's."""
+    lib = gpu
+    lib.hmr_gpu_enc_load_source.argtypes = [C.c_void_p, C.c_int] + [C.c_char_p] * 3
+    lib.hmr_gpu_enc_encode_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    cases = ["416x240_wpp_rows", "832x480_wpp_rows", "416x240_wpp_rows", "416x240_wpp_rows"]
+    encs, ctxs, frames = [], [], []
+    for case in cases:
+        g = GOLD[case]
+        ctx, enc = C.c_void_p(), C.c_void_p()
+        assert lib.hmr_gpu_create(C.byref(ctx), 0, None) == 0, lib.hmr_gpu_last_error()      # a context (stream) of its own per sequence
+        cfg = ec.default_cfg(g["width"], g["height"], **g["keys"])
+        assert lib.hmr_gpu_enc_create(ctx, C.byref(cfg), C.byref(enc)) == 0, lib.hmr_gpu_last_error()
+        for f, planes in enumerate(ec.clip_frames(g["width"], g["height"], g["frames"])):
+            assert lib.hmr_gpu_enc_load_source(enc, f, *planes) == 0, lib.hmr_gpu_last_error()
+        encs.append(enc); ctxs.append(ctx); frames.append(g["frames"])
+    bufs = [C.create_string_buffer(1 << 20) for _ in cases]
+    out = [b"" for _ in cases]
+    for f in range(max(frames)):
+        live = [i for i in range(len(cases)) if f < frames[i]]
+        n = len(live)
+        e_arr = (C.c_void_p * n)(*[encs[i] for i in live])
+        slots = (C.c_int * n)(*([f] * n))
+        ptrs = (C.c_char_p * n)(*[C.cast(bufs[i], C.c_char_p) for i in live])
+        caps = (C.c_long * n)(*[len(bufs[i]) for i in live])
+        got = (C.c_long * n)()
+        assert lib.hmr_gpu_enc_encode_batch(e_arr, n, slots, None, ptrs, caps, got) == 0, lib.hmr_gpu_last_error()
+        for k, i in enumerate(live):
+            out[i] += bufs[i].raw[:got[k]]
+    for i, case in enumerate(cases):
+        assert hashlib.md5(out[i]).hexdigest() == GOLD[case]["stream_md5"], (i, case)
+        lib.hmr_gpu_enc_destroy(encs[i])
+    # the single-thread order is not a batch schedule
+    cfg = ec.default_cfg(416, 240)
+    enc = C.c_void_p()
+    assert lib.hmr_gpu_enc_create(ctxs[0], C.byref(cfg), C.byref(enc)) == 0
+    planes = next(iter(ec.clip_frames(416, 240, 1)))
+    assert lib.hmr_gpu_enc_load_source(enc, 0, *planes) == 0
+    e_arr, slots, ptrs, caps, got = (C.c_void_p * 1)(enc), (C.c_int * 1)(0), (C.c_char_p * 1)(C.cast(bufs[0], C.c_char_p)), (C.c_long * 1)(len(bufs[0])), (C.c_long * 1)()
+    assert lib.hmr_gpu_enc_encode_batch(e_arr, 1, slots, None, ptrs, caps, got) == -3
+    lib.hmr_gpu_enc_destroy(enc)

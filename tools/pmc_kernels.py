@@ -37,7 +37,7 @@ def main():
             tot = k.get("TCC_HIT_sum", 0) + k.get("TCC_MISS_sum", 0)
             if tot:
                 d["l2_hit_rate"] = round(k["TCC_HIT_sum"] / tot, 4)
-        if name == "k_encode_ctus":
+        if name.startswith("k_encode_ctus"):
             d["note"] = (f"rocprofv3 --pmc passes of `{cmd}`; sums over all launches of the kernel (three wavefronts per workgroup: the row worker and two "
                          "helpers, whose polling counts as waiting); SQ cycle counters in quad-cycles")
         k["derived"] = d
