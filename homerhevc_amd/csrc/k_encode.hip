@@ -14,6 +14,7 @@
 // (k_deblock.hip, k_sao.hip, k_pad.hip); the entropy stage (enc/enc_entropy.h) is host code fed with the side-info, the levels
 // and the SAO statistics, and hands the SAO parameters back for the offset pass.
 #include <stddef.h>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -526,6 +527,24 @@ __global__ __launch_bounds__(64) void k_sao_decide(SaoDecideArgs a)
 	}
 }
 
+// page-locked host memory for what comes back from the device every frame (records and levels: 11 MB per 1080p frame; a pageable target is copied through a
+// staging buffer at a fraction of the link's rate)
+template <class T>
+struct PinnedAlloc {
+	typedef T value_type;
+	PinnedAlloc() = default;
+	template <class U> PinnedAlloc(const PinnedAlloc<U> &) {}
+	T *allocate(size_t n)
+	{
+		void *p = nullptr;
+		if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) != hipSuccess) throw std::bad_alloc();
+		return (T *)p;
+	}
+	void deallocate(T *p, size_t) { (void)hipHostFree(p); }
+	template <class U> bool operator==(const PinnedAlloc<U> &) const { return true; }
+	template <class U> bool operator!=(const PinnedAlloc<U> &) const { return false; }
+};
+
 struct hmr_gpu_enc {
 	hmr_gpu_ctx *ctx;
 	HostCfg cfg;
@@ -552,8 +571,8 @@ struct hmr_gpu_enc {
 	double *d_sao_lambdas;                             // [ctu][3]
 	uint8_t *d_sao_lps, *d_sao_saved;                  // kNextStateLps; [ctu rows][2]
 	// host side of the entropy stage
-	std::vector<uint8_t> h_public;
-	std::vector<int16_t> h_coeff;
+	std::vector<uint8_t, PinnedAlloc<uint8_t>> h_public;
+	std::vector<int16_t, PinnedAlloc<int16_t>> h_coeff;
 	std::vector<int32_t> h_stats, h_params;
 	std::vector<double> h_lambdas;
 	hipEvent_t ev_frame = nullptr, ev_ready = nullptr;   // start of the frame on the encoder's stream; its CTU stage may be launched
@@ -607,7 +626,8 @@ int ctu_stage_prepare(hmr_gpu_enc *e)
 {
 	const Seq &s = e->seq;
 	hipStream_t st = e->ctx->stream;
-	HIP_TRY(hipMemcpyAsync(e->d.ctus_start, e->d.ctus, sizeof(CtuInfo) * s.nctu, hipMemcpyDeviceToDevice, st));
+	if (!e->lockstep)   // (the frame-start state CTUs are re-encoded from in the single-thread order)
+		HIP_TRY(hipMemcpyAsync(e->d.ctus_start, e->d.ctus, sizeof(CtuInfo) * s.nctu, hipMemcpyDeviceToDevice, st));
 	{
 		static const int zero_counters[3] = {0, 0, -1};
 		HIP_TRY(hipMemcpyAsync(e->d.counters, zero_counters, sizeof zero_counters, hipMemcpyHostToDevice, st));
