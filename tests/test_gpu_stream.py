@@ -69,20 +69,23 @@ def test_device_stream_is_byte_identical_to_the_reference(gpu, case):
 
 
 def test_batch_of_sequences_in_one_launch(gpu):
-    """hmr_gpu_enc_encode_batch: four sequences (three 416x240, one 832x480; row-per-thread schedule) advance frame by frame with ONE launch for all their CTU
-    stages; every sequence's stream must be the one it gets when encoded alone, i.e. the turnstile reference's."""
+    """hmr_gpu_enc_encode_batch: four sequences of different sizes and lengths (one with a scene cut, one with fewer threads than rows; row-per-thread schedule)
+    advance frame by frame with ONE launch for all their CTU stages; every sequence's stream must be the one it gets when encoded alone, i.e. the turnstile
+    reference's."""
     lib = gpu
     lib.hmr_gpu_enc_load_source.argtypes = [C.c_void_p, C.c_int] + [C.c_char_p] * 3
     lib.hmr_gpu_enc_encode_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_long)]
-    cases = ["416x240_wpp_rows", "832x480_wpp_rows", "416x240_wpp_rows", "416x240_wpp_rows"]
+    cases = ["416x240_wpp_rows", "832x480_wpp_rows", "416x240_scene_cut_wpp_rows", "328x264_wpp3"]
     encs, ctxs, frames = [], [], []
     for case in cases:
         g = GOLD[case]
         ctx, enc = C.c_void_p(), C.c_void_p()
         assert lib.hmr_gpu_create(C.byref(ctx), 0, None) == 0, lib.hmr_gpu_last_error()      # a context (stream) of its own per sequence
-        cfg = ec.default_cfg(g["width"], g["height"], **g["keys"])
+        keys = dict(g["keys"])
+        cut_at = keys.pop("cut_at", None)
+        cfg = ec.default_cfg(g["width"], g["height"], **keys)
         assert lib.hmr_gpu_enc_create(ctx, C.byref(cfg), C.byref(enc)) == 0, lib.hmr_gpu_last_error()
-        for f, planes in enumerate(ec.clip_frames(g["width"], g["height"], g["frames"])):
+        for f, planes in enumerate(ec.clip_frames(g["width"], g["height"], g["frames"], cut_at)):
             assert lib.hmr_gpu_enc_load_source(enc, f, *planes) == 0, lib.hmr_gpu_last_error()
         encs.append(enc); ctxs.append(ctx); frames.append(g["frames"])
     bufs = [C.create_string_buffer(1 << 20) for _ in cases]
