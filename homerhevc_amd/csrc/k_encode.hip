@@ -566,6 +566,7 @@ struct hmr_gpu_enc {
 	int8_t *d_ref;
 	uint8_t *d_qp, *d_flags, *d_pd, *d_ti;
 	int32_t *d_stats, *d_params;
+	uint8_t *d_public;                                 // the CTUs' side-info records, packed for the download
 	int32_t *d_sao_offsets, *d_sao_aux, *d_sao_bits;   // candidate offsets [ctu][3][5][32], band positions [ctu][3][5]; kEntropyBits
 	long long *d_sao_dist;                             // [ctu][3][5]
 	double *d_sao_lambdas;                             // [ctu][3]
@@ -711,10 +712,19 @@ int set_frame(hmr_gpu_enc *e, int slot, int image_type, double avg_dist)
 	return HMR_GPU_OK;
 }
 
+// the side-info records lie 68 KB apart inside the CTU records: packed on the device, then one linear copy to the host
+__global__ void k_pack_public(const CtuInfo *ctus, uint32_t *out)
+{
+	const uint32_t *src = (const uint32_t *)(const CtuPublic *)(ctus + blockIdx.x);
+	uint32_t *dst = out + (size_t)blockIdx.x * (sizeof(CtuPublic) / 4);
+	for (int i = threadIdx.x; i < (int)(sizeof(CtuPublic) / 4); i += blockDim.x) dst[i] = src[i];
+}
 int download_public(hmr_gpu_enc *e)
 {
 	const Seq &s = e->seq;
-	HIP_TRY(hipMemcpy2DAsync(e->h_public.data(), sizeof(CtuPublic), e->d.ctus, sizeof(CtuInfo), sizeof(CtuPublic), s.nctu, hipMemcpyDeviceToHost, e->ctx->stream));
+	hipLaunchKernelGGL(k_pack_public, dim3(s.nctu), dim3(256), 0, e->ctx->stream, e->d.ctus, (uint32_t *)e->d_public);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(e->h_public.data(), e->d_public, sizeof(CtuPublic) * s.nctu, hipMemcpyDeviceToHost, e->ctx->stream));
 	return HMR_GPU_OK;
 }
 }  // namespace
@@ -789,6 +799,7 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 	DEV_ALLOC(e->d_flags, nu); DEV_ALLOC(e->d_pd, nu); DEV_ALLOC(e->d_ti, nu);
 	DEV_ALLOC(e->d_stats, (size_t)s.nctu * 3 * 5 * 2 * 32);
 	DEV_ALLOC(e->d_params, (size_t)s.nctu * 3 * 34);
+	DEV_ALLOC(e->d_public, sizeof(CtuPublic) * s.nctu);
 	DEV_ALLOC(e->d_sao_offsets, (size_t)s.nctu * 480);
 	DEV_ALLOC(e->d_sao_aux, (size_t)s.nctu * 15);
 	DEV_ALLOC(e->d_sao_dist, (size_t)s.nctu * 15);
@@ -826,7 +837,7 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	void *p[] = {e->d_seq, e->d_frame, e->d_geo, e->d.ctus, e->d.ctus_start, e->d.work_slow, e->d.coeff, e->d.progress, e->d.prefix, e->d.prof, e->d.guess, e->d.truth, e->d.outtok,
 		     e->d.chain_start, e->d.chain_end, e->d.valid, e->d.dirty, e->d.hash, e->d.intra_before, e->d.used_intra, e->d.used_parts, e->d.counters, e->d.rowstate, e->d.row0_checked, e->d_bytes, e->d_mvx,
 		     e->d_mvy, e->d_ref, e->d_qp, e->d_flags, e->d_pd, e->d_ti, e->d_stats, e->d_params, e->d_sao_offsets, e->d_sao_aux, e->d_sao_dist, e->d_sao_lambdas, e->d_sao_bits,
-		     e->d_sao_lps, e->d_sao_saved};
+		     e->d_sao_lps, e->d_sao_saved, e->d_public};
 	for (void *q : p) (void)hipFree(q);
 	for (int c = 0; c < 3; c++) {
 		(void)hipFree(e->d_pic[0][c]);
