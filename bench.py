@@ -169,7 +169,7 @@ def multi_stream_batched(lib, device, width, height, keys, streams, warmup, step
             t0 = time.perf_counter()
         assert lib.hmr_gpu_enc_encode_batch(e_arr, n, (C.c_int * n)(*([f] * n)), None, ptrs, caps, got) == 0, lib.hmr_gpu_last_error()
         for i in range(n):
-            md5[i].update(bufs[i].raw[:got[i]])
+            md5[i].update(C.string_at(bufs[i], got[i]))       # (.raw would copy the whole buffer first)
     dt = time.perf_counter() - t0
     p, k, ms, tot = C.c_int(), C.c_int(), C.c_float(), C.c_float()
     lib.hmr_gpu_enc_last_stats(encs[0], C.byref(p), C.byref(k), C.byref(ms), C.byref(tot))
@@ -319,11 +319,11 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
         if S == 1:
             st = lib.hmr_gpu_enc_encode_source(enc, f, 0, buf, len(buf), C.byref(nbytes), None)
             assert st in (1, 2), lib.hmr_gpu_last_error()
-            md5s[0].update(buf.raw[:nbytes.value])
+            md5s[0].update(C.string_at(buf, nbytes.value))
         else:
             assert lib.hmr_gpu_enc_encode_batch(e_arr, S, (C.c_int * S)(*([f] * S)), None, ptrs, caps, got) == 0, lib.hmr_gpu_last_error()
             for i in range(S):
-                md5s[i].update(bufs[i].raw[:got[i]])
+                md5s[i].update(C.string_at(bufs[i], got[i]))
             st, nbytes.value = 0, got[0]
         p, n, ms, tot = C.c_int(), C.c_int(), C.c_float(), C.c_float()
         lib.hmr_gpu_enc_last_stats(enc, C.byref(p), C.byref(n), C.byref(ms), C.byref(tot))

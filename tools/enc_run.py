@@ -45,7 +45,7 @@ def main():
     for f in range(a.frames):
         st = lib.hmr_gpu_enc_encode_source(enc, f, 0, buf, len(buf), C.byref(nbytes), None)
         assert st in (1, 2), lib.hmr_gpu_last_error()
-        md5.update(buf.raw[:nbytes.value])
+        md5.update(C.string_at(buf, nbytes.value))
         p, n, ms, tot = C.c_int(), C.c_int(), C.c_float(), C.c_float()
         lib.hmr_gpu_enc_last_stats(enc, C.byref(p), C.byref(n), C.byref(ms), C.byref(tot))
         print(f"frame {f}: slice {st} {nbytes.value} bytes, {p.value} passes, {n.value} CTU encodes, CTU passes {ms.value:.1f} ms, frame {tot.value:.1f} ms")
