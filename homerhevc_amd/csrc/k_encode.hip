@@ -145,8 +145,34 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 	}
 }
 
-// the work of one row worker (a workgroup): `row` of the picture described by d
-__device__ __forceinline__ void encode_rows_body(const EncDev &d, int pass, int row)
+// A workgroup is a row worker (wavefront 0) and its two helpers.  rows_enter sets the mailbox up and sends the helper wavefronts into their service loop; it
+// returns true on the worker only.  release_helpers lets them go (without it the workgroup never ends).
+__device__ __forceinline__ bool rows_enter()
+{
+	extern __shared__ __align__(16) uint8_t lds[];
+	HelperBox *box = (HelperBox *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU);
+	const int wave = (int)(threadIdx.x >> 6);
+	// LDS keeps what the last workgroup on this CU left in it: everything starts from zero (the helpers' scratch included), whatever ran here before
+	for (int i = (int)threadIdx.x; i < (int)(LDS_BYTES / 4); i += ENC_THREADS) ((uint32_t *)lds)[i] = 0;
+	__syncthreads();
+	if (wave > 0) {
+		helper_loop(box, wave - 1, (int16_t *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX) + (wave - 1) * HSCRATCH_ELEMS);
+		return false;
+	}
+	return true;
+}
+__device__ __forceinline__ void release_helpers(int *hseq)
+{
+	extern __shared__ __align__(16) uint8_t lds[];
+	HelperBox *box = (HelperBox *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU);
+	if ((threadIdx.x & 63) == 0)
+		for (int h = 0; h < 2; h++) {
+			box->job[h] = HJOB_QUIT;
+			__hip_atomic_store(&box->cmd[h], ++hseq[h], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+}
+// the work of one row worker on one picture: `row` of the picture described by d (hseq: the helpers' job counters, which live as long as the workgroup)
+__device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, int *hseq)
 {
 	extern __shared__ __align__(16) uint8_t lds[];
 	const Seq &S = *d.seq;
@@ -155,13 +181,6 @@ __device__ __forceinline__ void encode_rows_body(const EncDev &d, int pass, int 
 	Work *lw = (Work *)lds;
 	Geo *lgeo = (Geo *)(lds + LDS_WORK + LDS_NODES);
 	HelperBox *box = (HelperBox *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU);
-	const int wave = (int)(threadIdx.x >> 6);
-	if (threadIdx.x < 2) { box->cmd[threadIdx.x] = 0; box->done[threadIdx.x] = 0; }
-	__syncthreads();
-	if (wave > 0) {
-		helper_loop(box, wave - 1, (int16_t *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX) + (wave - 1) * HSCRATCH_ELEMS);
-		return;
-	}
 	for (int i = g.tid; i < (int)(LDS_WORK / 4); i += 64) ((uint32_t *)lds)[i] = 0;
 	for (int i = g.tid; i < (int)(sizeof(Geo) * NNODES / 2); i += 64) ((uint16_t *)lgeo)[i] = ((const uint16_t *)d.geo)[i];
 	g.sync();
@@ -190,7 +209,7 @@ __device__ __forceinline__ void encode_rows_body(const EncDev &d, int pass, int 
 	e.ctu_g = nullptr;
 	e.ctu_fast = (CtuPublic *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ);
 	e.box = box;
-	e.hseq[0] = e.hseq[1] = 0;
+	e.hseq[0] = hseq[0]; e.hseq[1] = hseq[1];
 	e.prof = d.prof ? d.prof + (size_t)row * PF_COUNT : nullptr;
 	e.timeline = nullptr;
 	uint32_t *my_prefix = d.prefix + (size_t)row * (W + 1);
@@ -271,8 +290,7 @@ __device__ __forceinline__ void encode_rows_body(const EncDev &d, int pass, int 
 			g.sync();
 			if (g.tid == 0) __hip_atomic_store(&d.progress[row], c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 		}
-		helper_post(g, e, 0, HJOB_QUIT);
-		helper_post(g, e, 1, HJOB_QUIT);
+		hseq[0] = e.hseq[0]; hseq[1] = e.hseq[1];
 		if (g.tid == 0) atomicAdd(&d.counters[1], W);
 #if defined(HENC_PROFILE)
 		if (g.tid == 0 && e.prof) {
@@ -349,8 +367,7 @@ __device__ __forceinline__ void encode_rows_body(const EncDev &d, int pass, int 
 		g.sync();
 		if (g.tid == 0) __hip_atomic_store(&d.progress[row], c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 	}
-	helper_post(g, e, 0, HJOB_QUIT);
-	helper_post(g, e, 1, HJOB_QUIT);
+	hseq[0] = e.hseq[0]; hseq[1] = e.hseq[1];
 	if (g.tid == 0 && encodes) atomicAdd(&d.counters[1], encodes);
 #if defined(HENC_PROFILE)
 	if (g.tid == 0 && e.prof) {
@@ -452,17 +469,26 @@ struct SrcSlot {
 
 __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
 {
-	encode_rows_body(d, pass, (int)blockIdx.x);
+	if (!rows_enter()) return;
+	int hseq[2] = {0, 0};
+	encode_row(d, pass, (int)blockIdx.x, hseq);
+	release_helpers(hseq);
 }
-// several sequences in ONE launch (row-per-thread schedule): workgroup b works on row b - first_row[q] of sequence q.  Every row worker takes a whole CU (its LDS),
-// so fifteen 1080p sequences (255 workgroups) fill the chip with one dispatch instead of fifteen queues competing for it.  A row only ever waits for rows of its
-// own sequence with smaller indices, which are dispatched before it.
-__global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus_batch(const EncDev *devs, const int *first_row, int nseq)
+// Several sequences in ONE launch (row-per-thread schedule).  Every row worker takes a whole CU (its LDS), so the grid is `groups` x hmax workgroups with
+// groups x hmax <= the number of CUs (fifteen groups of 17 rows for 1080p), and the workgroup (g, r) encodes row r of the sequences g, g + groups, g + 2 groups ...
+// one after the other.  Chaining sequences through a workgroup fills the bubbles of the WPP wavefront: row r is idle for 2 r steps while a picture's wavefront
+// builds up and for 2 (H - 1 - r) while it drains, and it spends that time on the next sequence's row r - k chained pictures take k W + 2 (H - 1) steps, not
+// k (W + 2 (H - 1)).  A row only ever waits for rows of its own sequence, all of which are resident.
+__global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus_batch(const EncDev *devs, int nseq, int groups, int hmax)
 {
-	int q = 0;
-	while (q + 1 < nseq && (int)blockIdx.x >= first_row[q + 1]) q++;
-	const EncDev d = devs[q];
-	encode_rows_body(d, -1, (int)blockIdx.x - first_row[q]);
+	if (!rows_enter()) return;
+	const int grp = (int)blockIdx.x / hmax, row = (int)blockIdx.x % hmax;
+	int hseq[2] = {0, 0};
+	for (int q = grp; q < nseq; q += groups) {
+		const EncDev d = devs[q];
+		if (row < d.seq->hctu) encode_row(d, -1, row, hseq);
+	}
+	release_helpers(hseq);
 }
 
 // ---- SAO parameter decision on the device (enc/enc_sao.h): what it needs from the entropy coder is the walk of two contexts through the SAO syntax of each
@@ -577,6 +603,7 @@ struct hmr_gpu_enc {
 	std::vector<int32_t> h_stats, h_params;
 	std::vector<double> h_lambdas;
 	hipEvent_t ev_frame = nullptr, ev_ready = nullptr;   // start of the frame on the encoder's stream; its CTU stage may be launched
+	int n_cus = 0;
 	void *d_batch = nullptr;                             // hmr_gpu_enc_encode_batch (lead encoder): the sequences' EncDev records and first rows
 	EntropyState es;
 	int cur, lockstep;
@@ -822,6 +849,8 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 	e->d.threads = e->cfg.wfpp_num_threads > 1 ? e->cfg.wfpp_num_threads : 1;
 	e->last_ms = e->last_total_ms = 0;
 	e->last_passes = e->last_encodes = 0;
+	// the buffers were cleared on the null stream, which the encoder's (non-blocking) stream does not wait for
+	HIP_TRY(hipDeviceSynchronize());
 	*out = e;
 	return HMR_GPU_OK;
 }
@@ -1069,7 +1098,7 @@ extern "C" int hmr_gpu_enc_encode_source(hmr_gpu_enc *e, int slot, int image_typ
 // stream and host thread.  The streams are those hmr_gpu_enc_encode_source would have produced one by one.
 extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes)
 {
-	if (!encs || n <= 0 || n > 64 || !slots || !streams || !caps || !stream_bytes) return HMR_GPU_ERR_ARG;
+	if (!encs || n <= 0 || n > 256 || !slots || !streams || !caps || !stream_bytes) return HMR_GPU_ERR_ARG;
 	for (int i = 0; i < n; i++) {
 		hmr_gpu_enc *e = encs[i];
 		if (!e || !e->lockstep || e->ctx->device != encs[0]->ctx->device || slots[i] < 0 || slots[i] >= (int)e->src.size() || !streams[i]) {
@@ -1083,7 +1112,6 @@ extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *sl
 	hipStream_t bst = lead->ctx->stream;
 	HIP_TRY(hipSetDevice(lead->ctx->device));
 	std::vector<EncDev> devs(n);
-	std::vector<int> first(n + 1, 0);
 	int rc;
 	for (int i = 0; i < n; i++) {
 		hmr_gpu_enc *e = encs[i];
@@ -1093,19 +1121,21 @@ extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *sl
 		HIP_TRY(hipEventRecord(e->ev_ready, e->ctx->stream));
 		if (i) HIP_TRY(hipStreamWaitEvent(bst, e->ev_ready, 0));
 		devs[i] = e->d;
-		first[i + 1] = first[i] + e->seq.hctu;
 	}
 	if (!lead->d_batch) {
-		HIP_TRY(hipMalloc((void **)&lead->d_batch, 64 * sizeof(EncDev) + 65 * sizeof(int)));
+		HIP_TRY(hipMalloc((void **)&lead->d_batch, 256 * sizeof(EncDev)));
+		HIP_TRY(hipDeviceGetAttribute(&lead->n_cus, hipDeviceAttributeMultiprocessorCount, lead->ctx->device));
 	}
-	int *d_first = (int *)((uint8_t *)lead->d_batch + 64 * sizeof(EncDev));
+	int hmax = 1;
+	for (int i = 0; i < n; i++) hmax = encs[i]->seq.hctu > hmax ? encs[i]->seq.hctu : hmax;
+	int groups = lead->n_cus / hmax;
+	groups = groups < 1 ? 1 : (groups > n ? n : groups);
 	HIP_TRY(hipMemcpyAsync(lead->d_batch, devs.data(), n * sizeof(EncDev), hipMemcpyHostToDevice, bst));
-	HIP_TRY(hipMemcpyAsync(d_first, first.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, bst));
 	HIP_TRY(hipEventRecord(lead->ctx->ev0, bst));
-	hipLaunchKernelGGL(k_encode_ctus_batch, dim3(first[n]), dim3(ENC_THREADS), LDS_BYTES, bst, (const EncDev *)lead->d_batch, (const int *)d_first, n);
+	hipLaunchKernelGGL(k_encode_ctus_batch, dim3(groups * hmax), dim3(ENC_THREADS), LDS_BYTES, bst, (const EncDev *)lead->d_batch, n, groups, hmax);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(lead->ctx->ev1, bst));
-	HIP_TRY(hipStreamSynchronize(bst));      // (devs / first are host vectors; and the kernel time is read below)
+	HIP_TRY(hipStreamSynchronize(bst));      // (devs is a host vector; and the kernel time is read below)
 	float ms = 0;
 	HIP_TRY(hipEventElapsedTime(&ms, lead->ctx->ev0, lead->ctx->ev1));
 	std::vector<int> rcs(n, 0);
