@@ -621,16 +621,19 @@ int16_t *plane0(hmr_gpu_enc *e, int which, int comp)
 	return e->d_pic[which][comp] + (size_t)m * st + m;
 }
 
+// device memory, cleared ON THE ENCODER'S STREAM: the stream is non-blocking, so a hipMemset (null stream) is not ordered against the work that follows on it -
+// a picture slot allocated by hmr_gpu_enc_load_source could be cleared after the picture had been written into it (seen as an occasional different stream)
 template <class T>
-int dev_alloc(T **p, size_t n, bool zero = true)
+int dev_alloc(T **p, size_t n, hipStream_t st)
 {
 	HIP_TRY(hipMalloc((void **)p, n * sizeof(T)));
-	if (zero) HIP_TRY(hipMemset(*p, 0, n * sizeof(T)));
+	HIP_TRY(hipMemsetAsync(*p, 0, n * sizeof(T), st));
+	HIP_TRY(hipStreamSynchronize(st));   // (and a synchronous copy into the buffer, which runs on the null stream, must not overtake the clearing either)
 	return HMR_GPU_OK;
 }
 #define DEV_ALLOC(p, n)                           \
 	do {                                      \
-		const int rc_ = dev_alloc(&(p), (n)); \
+		const int rc_ = dev_alloc(&(p), (n), e->ctx->stream); \
 		if (rc_) return rc_;              \
 	} while (0)
 
@@ -849,8 +852,7 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 	e->d.threads = e->cfg.wfpp_num_threads > 1 ? e->cfg.wfpp_num_threads : 1;
 	e->last_ms = e->last_total_ms = 0;
 	e->last_passes = e->last_encodes = 0;
-	// the buffers were cleared on the null stream, which the encoder's (non-blocking) stream does not wait for
-	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipStreamSynchronize(ctx->stream));   // (the buffers are cleared by now)
 	*out = e;
 	return HMR_GPU_OK;
 }
@@ -903,7 +905,10 @@ extern "C" int hmr_gpu_enc_profile(hmr_gpu_enc *e, unsigned long long *out, int 
 {
 	if (!e || !out) return HMR_GPU_ERR_ARG;
 	HIP_TRY(hipMemcpy(out, e->d.prof, sizeof(unsigned long long) * e->seq.hctu * PF_COUNT, hipMemcpyDeviceToHost));
-	if (reset) HIP_TRY(hipMemset(e->d.prof, 0, sizeof(unsigned long long) * e->seq.hctu * PF_COUNT));
+	if (reset) {
+		HIP_TRY(hipMemsetAsync(e->d.prof, 0, sizeof(unsigned long long) * e->seq.hctu * PF_COUNT, e->ctx->stream));
+		HIP_TRY(hipStreamSynchronize(e->ctx->stream));
+	}
 	return HMR_GPU_OK;
 }
 
