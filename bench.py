@@ -229,7 +229,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=24)
     ap.add_argument("--no-single-thread-order", action="store_true", help="skip the second measurement (wfpp_num_threads = 1)")
-    ap.add_argument("--sequences", type=int, default=15, help="independent sequences per GPU, encoded with one launch per step (hmr_gpu_enc_encode_batch); 1 = a single sequence")
+    ap.add_argument("--sequences", type=int, default=60, help="independent sequences per GPU, encoded with one launch per step (hmr_gpu_enc_encode_batch: 15 groups of 17 row "
+                    "workers at 1080p, each group takes its sequences one after the other); 1 = a single sequence")
     ap.add_argument("--streams", type=int, default=0, help="concurrent sequences of the extra multi_stream measurement (0 = skip)")
     ap.add_argument("--multi-stream-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)
@@ -266,11 +267,11 @@ def main():
             out["single_thread_order"] = {k: other[k] for k in ("value", "unit", "ms_per_step", "stream_md5", "stream_matches_reference", "schedule")}
             out["single_thread_order"]["note"] = "the same encode with wfpp_num_threads = 1: output identical to the reference's single-thread run (md5 2f0c3447...), which costs guesses, verification and re-encode passes"
             # the metric's other picture size: 2160p, 34 CTU rows on the reference's maximum of 32 WPP threads, I + P + P (the two P frames timed):
-            # a batch of 7 sequences (238 workgroups) and one sequence alone
+            # a batch of 21 sequences (7 groups of 34 row workers, three sequences each) and one sequence alone
             import copy
             b = copy.copy(a)
             b.warmup, b.steps = 1, 2
-            big = run_workload(lib, b, "cfg2-2160p-encode", world, rank, local, torch, sequences=7 if a.sequences > 1 else 1)
+            big = run_workload(lib, b, "cfg2-2160p-encode", world, rank, local, torch, sequences=21 if a.sequences > 1 else 1)
             out["at_2160p"] = {k: big[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "stream_md5", "stream_matches_reference", "all_streams_identical")}
             out["at_2160p"]["config"] = big["config"]
             if a.sequences > 1:
@@ -289,7 +290,8 @@ def main():
 
 def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
     """`sequences` independent sequences of the workload per GPU: 1 = hmr_gpu_enc_encode_source frame by frame; more = one hmr_gpu_enc_encode_batch call per step
-    (ONE launch for the CTU stages of all of them - a row worker takes a whole CU, fifteen 1080p sequences are 255 workgroups), every stream hashed."""
+    (ONE launch for the CTU stages of all of them - a row worker takes a whole CU, so the launch is 15 groups of 17 workgroups at 1080p and a group encodes its
+    sequences one after the other, which fills the bubbles of the WPP wavefront), every stream hashed."""
     import encoder_cases as ec
     width, height, keys = WORKLOADS[workload]
     nframes = a.warmup + a.steps
@@ -358,7 +360,7 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": workload, "sequences_per_gpu": S, "frames_per_step": S, "wfpp_num_threads": int(keys.get("wpp", 1)), "width": width, "height": height, "frames_in_sequence": nframes, "gop": "IPPP intra_period=100", "qp": 32,
-                       "rd_mode": 2, "performance_mode": 2, "sao": 1, "parallelism": (f"{S} independent sequences per GPU, one launch per step for their CTU stages" if S > 1 else "one sequence") + (f"; replicas x{world}" if world > 1 else ""),
+                       "rd_mode": 2, "performance_mode": 2, "sao": 1, "parallelism": (f"{S} independent sequences per GPU, one launch per step for their CTU stages (groups of row workers, each chaining its sequences)" if S > 1 else "one sequence") + (f"; replicas x{world}" if world > 1 else ""),
                        "timed_region": "CTU decisions + deblock + SAO statistics / decision / offsets + padding on the device, CABAC / NAL on the host, per frame; source in HBM"},
             "stream_md5": digest, "stream_matches_reference": (digest == want and all_same) if want else None, "all_streams_identical": all_same,
             "schedule": {"ctus_per_frame": nctu, "passes_per_frame": [s[3] for s in timed], "ctu_encodes_per_frame": [s[4] for s in timed],
