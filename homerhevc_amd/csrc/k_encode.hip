@@ -480,20 +480,14 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
 // one after the other.  Chaining sequences through a workgroup fills the bubbles of the WPP wavefront: row r is idle for 2 r steps while a picture's wavefront
 // builds up and for 2 (H - 1 - r) while it drains, and it spends that time on the next sequence's row r - k chained pictures take k W + 2 (H - 1) steps, not
 // k (W + 2 (H - 1)).  A row only ever waits for rows of its own sequence, all of which are resident.
-__global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus_batch(const EncDev *devs, int nseq, int groups, int hmax, int *rows_done)
+__global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus_batch(const EncDev *devs, int nseq, int groups, int hmax)
 {
 	if (!rows_enter()) return;
 	const int grp = (int)blockIdx.x / hmax, row = (int)blockIdx.x % hmax;
 	int hseq[2] = {0, 0};
 	for (int q = grp; q < nseq; q += groups) {
 		const EncDev d = devs[q];
-		if (row < d.seq->hctu) {
-			encode_row(d, -1, row, hseq);
-			// rows_done lives in host memory: the host starts the sequence's filters, download and entropy coding when all its rows have reported,
-			// while this launch goes on with the sequences chained behind it
-			__builtin_amdgcn_wave_barrier();
-			if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&rows_done[q], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-		}
+		if (row < d.seq->hctu) encode_row(d, -1, row, hseq);
 	}
 	release_helpers(hseq);
 }
@@ -611,7 +605,6 @@ struct hmr_gpu_enc {
 	std::vector<double> h_lambdas;
 	hipEvent_t ev_frame = nullptr, ev_ready = nullptr, ev_batch0 = nullptr, ev_batch1 = nullptr;   // (the batch launch has events of its own: frame_finish re-records the context's)   // start of the frame on the encoder's stream; its CTU stage may be launched
 	int n_cus = 0;
-	int *h_rows_done = nullptr;                          // host memory the batch launch reports finished rows in, per sequence
 	void *d_batch = nullptr;                             // hmr_gpu_enc_encode_batch (lead encoder): the sequences' EncDev records and first rows
 	EntropyState es;
 	int cur, lockstep;
@@ -877,7 +870,6 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	if (e->ev_batch0) (void)hipEventDestroy(e->ev_batch0);
 	if (e->ev_batch1) (void)hipEventDestroy(e->ev_batch1);
 	if (e->d_batch) (void)hipFree(e->d_batch);
-	if (e->h_rows_done) (void)hipHostFree(e->h_rows_done);
 	void *p[] = {e->d_seq, e->d_frame, e->d_geo, e->d.ctus, e->d.ctus_start, e->d.work_slow, e->d.coeff, e->d.progress, e->d.prefix, e->d.prof, e->d.guess, e->d.truth, e->d.outtok,
 		     e->d.chain_start, e->d.chain_end, e->d.valid, e->d.dirty, e->d.hash, e->d.intra_before, e->d.used_intra, e->d.used_parts, e->d.counters, e->d.rowstate, e->d.row0_checked, e->d_bytes, e->d_mvx,
 		     e->d_mvy, e->d_ref, e->d_qp, e->d_flags, e->d_pd, e->d_ti, e->d_stats, e->d_params, e->d_sao_offsets, e->d_sao_aux, e->d_sao_dist, e->d_sao_lambdas, e->d_sao_bits,
@@ -1142,42 +1134,35 @@ extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *sl
 	}
 	if (!lead->d_batch) {
 		HIP_TRY(hipMalloc((void **)&lead->d_batch, 256 * sizeof(EncDev)));
-		HIP_TRY(hipHostMalloc((void **)&lead->h_rows_done, 256 * sizeof(int), hipHostMallocDefault));
 		HIP_TRY(hipDeviceGetAttribute(&lead->n_cus, hipDeviceAttributeMultiprocessorCount, lead->ctx->device));
 	}
-	for (int i = 0; i < n; i++) lead->h_rows_done[i] = 0;
+
 	int hmax = 1;
 	for (int i = 0; i < n; i++) hmax = encs[i]->seq.hctu > hmax ? encs[i]->seq.hctu : hmax;
 	int groups = lead->n_cus / hmax;
 	groups = groups < 1 ? 1 : (groups > n ? n : groups);
 	HIP_TRY(hipMemcpyAsync(lead->d_batch, devs.data(), n * sizeof(EncDev), hipMemcpyHostToDevice, bst));
 	HIP_TRY(hipEventRecord(lead->ev_batch0, bst));
-	hipLaunchKernelGGL(k_encode_ctus_batch, dim3(groups * hmax), dim3(ENC_THREADS), LDS_BYTES, bst, (const EncDev *)lead->d_batch, n, groups, hmax, lead->h_rows_done);
+	hipLaunchKernelGGL(k_encode_ctus_batch, dim3(groups * hmax), dim3(ENC_THREADS), LDS_BYTES, bst, (const EncDev *)lead->d_batch, n, groups, hmax);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(lead->ev_batch1, bst));
-	// every sequence finishes its frame on its own stream and host thread as soon as its rows are done (the launch may still be busy with later sequences)
+	HIP_TRY(hipStreamSynchronize(bst));
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, lead->ev_batch0, lead->ev_batch1));
+	// every sequence finishes its frame on its own stream and host thread.  (Starting a sequence's filters while the launch is still busy with the sequences
+	// chained behind it was tried - rows reporting into host memory - and gained 1-2 %, but one run in four of the 2160p batch then produced a wrong stream.)
 	std::vector<int> rcs(n, 0);
 	std::vector<std::thread> th;
-	volatile int *rows_done = lead->h_rows_done;
-	hipEvent_t launch_done = lead->ev_batch1;
 	for (int i = 0; i < n; i++)
 		th.emplace_back([&, i]() {
 			hmr_gpu_enc *e = encs[i];
 			if (hipSetDevice(e->ctx->device) != hipSuccess) { rcs[i] = HMR_GPU_ERR_HIP; return; }
-			for (int spins = 0; rows_done[i] < e->seq.hctu; spins++) {
-				if ((spins & 63) == 63 && hipEventQuery(launch_done) == hipSuccess) break;   // (the launch is over: every row has reported, or the launch failed)
-				std::this_thread::sleep_for(std::chrono::microseconds(50));
-			}
-			__atomic_thread_fence(__ATOMIC_ACQUIRE);
+			e->last_ms = ms;
 			int r = lockstep_collect(e);
 			if (!r) r = frame_finish(e, slots[i], streams[i], caps[i], &stream_bytes[i], nullptr);
 			rcs[i] = r;
 		});
 	for (auto &t : th) t.join();
-	HIP_TRY(hipStreamSynchronize(bst));
-	float ms = 0;
-	HIP_TRY(hipEventElapsedTime(&ms, lead->ev_batch0, lead->ev_batch1));
-	for (int i = 0; i < n; i++) encs[i]->last_ms = ms;
 	for (int i = 0; i < n; i++)
 		if (rcs[i] < 0) return rcs[i];
 	return HMR_GPU_OK;
