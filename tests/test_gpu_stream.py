@@ -1,6 +1,6 @@
 """-m gpu: HOMER_enc_encode on the device through the C ABI (hmr_gpu_enc_encode, include/homer_gpu.h section 12), free running over
-several frames: CTU decisions on the row-parallel schedule, deblocking, SAO statistics / offsets and padding as kernels, SAO decision
-and CABAC on the host.  The .265 bytes and every reconstructed picture must equal what the compiled reference produced
+several frames: CTU decisions on the row-parallel schedule, deblocking, SAO statistics / decision / offsets and padding as kernels, CABAC
+on the host.  The .265 bytes and every reconstructed picture must equal what the compiled reference produced
 (tests/golden/streams.json), including BASELINE.json configs[1] at full size (1920x1080, 8 frames, md5 2f0c3447...)."""
 import ctypes as C
 import hashlib
