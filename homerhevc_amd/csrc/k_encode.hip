@@ -15,6 +15,8 @@
 // and the SAO statistics, and hands the SAO parameters back for the offset pass.
 #include <stddef.h>
 #include <chrono>
+#include <mutex>
+#include <condition_variable>
 #include <new>
 #include <thread>
 #include <vector>
@@ -653,6 +655,34 @@ int load_planes(hmr_gpu_enc *e, const uint8_t *y, const uint8_t *u, const uint8_
 	return HMR_GPU_OK;
 }
 
+// Row workers of the row-per-thread schedule wait for ALL rows of their picture (the synchronous wavefront), so every workgroup of such a launch has to be
+// resident: two launches that together need more CUs than the device has could each get a part of theirs and wait for the rest for ever.  Launches of this
+// process therefore take their workgroups out of a per-device budget of CUs and wait (on the host) until they fit.  (Other processes on the same GPU: not covered.)
+struct CuBudget {
+	std::mutex m;
+	std::condition_variable cv;
+	int total[16] = {0}, used[16] = {0};
+	int acquire(int device, int want)
+	{
+		std::unique_lock<std::mutex> lk(m);
+		device &= 15;
+		if (!total[device] && hipDeviceGetAttribute(&total[device], hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) total[device] = 256;
+		if (want > total[device]) want = total[device];      // (a launch larger than the device alone: it runs by itself)
+		cv.wait(lk, [&] { return used[device] + want <= total[device]; });
+		used[device] += want;
+		return want;
+	}
+	void release(int device, int got)
+	{
+		{
+			std::lock_guard<std::mutex> lk(m);
+			used[device & 15] -= got;
+		}
+		cv.notify_all();
+	}
+};
+CuBudget g_cu_budget;
+
 // what a frame's CTU stage needs on the stream before its first launch
 int ctu_stage_prepare(hmr_gpu_enc *e)
 {
@@ -693,10 +723,14 @@ int run_ctu_passes(hmr_gpu_enc *e)
 	HIP_TRY(hipEventRecord(e->ctx->ev0, st));
 	if (e->lockstep) {
 		// wfpp_num_threads = CTU rows: the synchronous wavefront, one launch, nothing to verify
+		const int cus = g_cu_budget.acquire(e->ctx->device, s.hctu);
 		hipLaunchKernelGGL(k_encode_ctus, dim3(s.hctu), dim3(ENC_THREADS), LDS_BYTES, st, e->d, -1);
-		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipEventRecord(e->ctx->ev1, st));
-		if ((rc = lockstep_collect(e))) return rc;
+		const hipError_t launched = hipGetLastError();
+		if (launched == hipSuccess) (void)hipEventRecord(e->ctx->ev1, st);
+		rc = launched == hipSuccess ? lockstep_collect(e) : HMR_GPU_ERR_HIP;      // (waits for the launch)
+		g_cu_budget.release(e->ctx->device, cus);
+		if (launched != hipSuccess) hmr_set_error("k_encode_ctus: %s", hipGetErrorString(launched));
+		if (rc) return rc;
 		HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ctx->ev0, e->ctx->ev1));
 		return HMR_GPU_OK;
 	}
@@ -1143,10 +1177,16 @@ extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *sl
 	groups = groups < 1 ? 1 : (groups > n ? n : groups);
 	HIP_TRY(hipMemcpyAsync(lead->d_batch, devs.data(), n * sizeof(EncDev), hipMemcpyHostToDevice, bst));
 	HIP_TRY(hipEventRecord(lead->ev_batch0, bst));
+	const int cus = g_cu_budget.acquire(lead->ctx->device, groups * hmax);
 	hipLaunchKernelGGL(k_encode_ctus_batch, dim3(groups * hmax), dim3(ENC_THREADS), LDS_BYTES, bst, (const EncDev *)lead->d_batch, n, groups, hmax);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipEventRecord(lead->ev_batch1, bst));
-	HIP_TRY(hipStreamSynchronize(bst));
+	const hipError_t launched = hipGetLastError();
+	if (launched == hipSuccess) (void)hipEventRecord(lead->ev_batch1, bst);
+	const hipError_t waited = hipStreamSynchronize(bst);
+	g_cu_budget.release(lead->ctx->device, cus);
+	if (launched != hipSuccess || waited != hipSuccess) {
+		hmr_set_error("k_encode_ctus_batch: %s", hipGetErrorString(launched != hipSuccess ? launched : waited));
+		return HMR_GPU_ERR_HIP;
+	}
 	float ms = 0;
 	HIP_TRY(hipEventElapsedTime(&ms, lead->ev_batch0, lead->ev_batch1));
 	// every sequence finishes its frame on its own stream and host thread.  (Starting a sequence's filters while the launch is still busy with the sequences
