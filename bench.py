@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=24)
     ap.add_argument("--no-single-thread-order", action="store_true", help="skip the second measurement (wfpp_num_threads = 1)")
-    ap.add_argument("--sequences", type=int, default=60, help="independent sequences per GPU, encoded with one launch per step (hmr_gpu_enc_encode_batch: 15 groups of 17 row "
+    ap.add_argument("--sequences", type=int, default=120, help="independent sequences per GPU, encoded with one launch per step (hmr_gpu_enc_encode_batch: 15 groups of 17 row "
                     "workers at 1080p, each group takes its sequences one after the other); 1 = a single sequence")
     ap.add_argument("--streams", type=int, default=0, help="concurrent sequences of the extra multi_stream measurement (0 = skip)")
     ap.add_argument("--multi-stream-child", type=int, default=0, help=argparse.SUPPRESS)
