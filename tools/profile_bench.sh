@@ -11,4 +11,7 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_IN
 done
 python3 $R/tools/pmc_kernels.py $R/gpurun_out $TAG "python3 bench.py $ARGS" > $R/gpurun_out/${TAG}_pmc_k_encode_ctus.json
 python3 $R/tools/kernel_launches.py $R/gpurun_out/prof_$TAG/bench_kernel_trace.csv $R/gpurun_out/${TAG}_bench_under_rocprof.json > $R/gpurun_out/${TAG}_k_encode_ctus_launches.json
+# the raw per-dispatch tables of a 120-sequence run exceed what comes back from the GPU box: the summaries above are what is kept
+find $R/gpurun_out/pmc_${TAG}_* -name "*counter_collection.csv" -delete
+find $R/gpurun_out/prof_$TAG -name "*kernel_trace.csv" -delete
 find $R/gpurun_out/prof_$TAG -name "*stats*" | head
