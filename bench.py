@@ -107,7 +107,7 @@ def multi_stream(lib, device, width, height, keys, streams, warmup, steps):
             assert lib.hmr_gpu_enc_create(ctx, C.byref(cfg), C.byref(enc)) == 0
             for f, planes in enumerate(frames):
                 assert lib.hmr_gpu_enc_load_source(enc, f, *planes) == 0
-            buf, n = C.create_string_buffer(16 << 20), C.c_long()
+            buf, n = C.create_string_buffer(4 << 20), C.c_long()
             for f in range(warmup):
                 assert lib.hmr_gpu_enc_encode_source(enc, f, 0, buf, len(buf), C.byref(n), None) in (1, 2)
             gate.wait()
@@ -306,7 +306,7 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
         for f, planes in enumerate(frames):
             assert lib.hmr_gpu_enc_load_source(enc, f, *planes) == 0, lib.hmr_gpu_last_error()
         encs.append(enc)
-        bufs.append(C.create_string_buffer(16 << 20))
+        bufs.append(C.create_string_buffer(4 << 20))
     enc, buf = encs[0], bufs[0]
     nbytes = C.c_long()
     md5s = [hashlib.md5() for _ in range(S)]
