@@ -612,9 +612,11 @@ HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 	CtuPublic &c = *e.ctu;
 	e.scratch_a = w.pred_aux;
 	e.scratch_b = w.delta_u;
+#if !defined(__HIPCC__)
 	e.mc_tmp_c = w.sub_tmp;
 	e.mc_tmp_y = w.sub_tmp;
 	e.mc_tmp_y_stride = 72;
+#endif
 	e.adi_c = w.adi;
 	const int cx = ctu_num % S.wctu, cy = ctu_num / S.wctu;
 	c.ctu_number = ctu_num;
@@ -638,6 +640,14 @@ HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 		const int ww = (px + sz) < pw ? sz : pw - px, hh = (py + sz) < ph ? sz : ph - py;
 		blk_copy(g, e.f->src[comp] + py * ss + px, ss, curr_ptr(w, comp), sz, hh, ww);
 	}
+#if defined(__HIPCC__)
+	// the luma source as bytes, for the motion search against the 8-bit phase planes
+	for (int i = g.tid * 4; i < 64 * 64; i += g.n * 4) {
+		const S4 v = ld4(w.curr_y + i);
+		*(uint32_t *)(w.curr_y8 + i) = (uint32_t)(v.v[0] & 255) | ((uint32_t)(v.v[1] & 255) << 8) | ((uint32_t)(v.v[2] & 255) << 16) | ((uint32_t)(v.v[3] & 255) << 24);
+	}
+	g.sync();
+#endif
 	// neighbour samples of the picture under reconstruction into every decoded window
 	if (c.has_left || c.has_top) {
 		for (int comp = 0; comp < 3; comp++) {

@@ -115,6 +115,8 @@ inline bool make_seq(HostCfg cfg, Seq &s, const char **why)
 	s.stride_c = (((s.width / 2) * 2 + 15) / 16 * 16) / 2 + 2 * s.margin_c;
 	s.src_stride_y = ((s.width * 2 + 15) / 16 * 16) / 2;
 	s.src_stride_c = (((s.width / 2) * 2 + 15) / 16 * 16) / 2;
+	s.plane_elems_y = s.stride_y * (s.height + 2 * s.margin_y);
+	s.plane_elems_c = s.stride_c * (s.height / 2 + 2 * s.margin_c);
 	return true;
 }
 

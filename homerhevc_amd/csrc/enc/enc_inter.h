@@ -9,9 +9,12 @@
 namespace henc {
 
 // ---- motion compensation ------------------------------------------------------------------------------------------
+// Device: the reference picture exists as 8-bit phase planes (FrameCtx::sub_y / sub_c, built once per frame by k_subpel.hip with the stage rules of
+// hmr_motion_inter.c:240-391 / inter_prediction.c:796,818), so the prediction of a block is a copy.  Checker build: the interpolation itself, from ref[].
+#if !defined(__HIPCC__)
 // `ref` points at the co-located block (mv = 0) in the padded reference plane
 template <class G>
-HENC_HD void mc_luma(const G &g, Enc &__restrict__ e, const int16_t *ref, int rs, int16_t *pred, int ps, int n, int mvx, int mvy)
+HENC_HD void mc_luma_interp(const G &g, Enc &__restrict__ e, const int16_t *ref, int rs, int16_t *pred, int ps, int n, int mvx, int mvy)
 {
 	const int xf = mvx & 3, yf = mvy & 3;
 	const int16_t *src = ref + (mvy >> 2) * rs + (mvx >> 2);
@@ -24,44 +27,8 @@ HENC_HD void mc_luma(const G &g, Enc &__restrict__ e, const int16_t *ref, int rs
 		interp_stage<8>(g, tmp + 3 * ts, ts, pred, ps, yf, n, n, 1, 0, 1);
 	}
 }
-// SAD of one sub-pel candidate of the refinement: interpolate the block at (mvx, mvy) into `out` and compare with the source
 template <class G>
-HENC_HD uint32_t subpel_candidate_sad(const G &g, Enc &__restrict__ e, const int16_t *orig, const int16_t *ref, int rs, int16_t *out, int os, int size, int mvx, int mvy)
-{
-	mc_luma(g, e, ref, rs, out, os, size, mvx, mvy);
-	const uint32_t s = blk_sad(g, orig, CTU_STRIDE_Y, out, os, size);
-	g.sync();
-	return s;
-}
-// the nine candidates of a refinement round around (cx0, cy0) (quarter-sample units relative to the integer vector): with helper wavefronts and blocks
-// up to 16 x 16 three at a time (the helpers interpolate into their own scratch); the comparison afterwards keeps the reference's order
-template <class G>
-HENC_HD void subpel_round_sads(const G &g, Enc &__restrict__ e, const int16_t *orig, int ox, int oy, const int16_t *ref, int rs, int gx, int gy, int size, int base_x, int base_y,
-			       const int (*offs)[2], int scale, int cx0, int cy0, uint32_t *sads)
-{
-	int16_t *sp = e.w->pred_aux;   // scratch: no TU is in flight during the search
-	if (e.box && size <= 16) {
-		for (int i0 = 0; i0 < 9; i0 += 3) {
-			for (int j = 0; j < 2; j++) {
-				const int i = i0 + j, cx = cx0 + offs[i][0] * scale, cy = cy0 + offs[i][1] * scale;
-				helper_post(g, e, j, HJOB_SUBPEL, ox | (oy << 8) | (size << 16), gx, gy, base_x + cx, base_y + cy);
-			}
-			const int i = i0 + 2, cx = cx0 + offs[i][0] * scale, cy = cy0 + offs[i][1] * scale;
-			sads[i] = subpel_candidate_sad(g, e, orig, ref, rs, sp, 64, size, base_x + cx, base_y + cy);
-			for (int j = 0; j < 2; j++) {
-				helper_wait(g, e, j);
-				sads[i0 + j] = e.box->r[j][0];
-			}
-		}
-		return;
-	}
-	for (int i = 0; i < 9; i++) {
-		const int cx = cx0 + offs[i][0] * scale, cy = cy0 + offs[i][1] * scale;
-		sads[i] = subpel_candidate_sad(g, e, orig, ref, rs, sp, 64, size, base_x + cx, base_y + cy);
-	}
-}
-template <class G>
-HENC_HD void mc_chroma(const G &g, Enc &__restrict__ e, const int16_t *ref, int rs, int16_t *pred, int ps, int n, int mvx, int mvy)
+HENC_HD void mc_chroma_interp(const G &g, Enc &__restrict__ e, const int16_t *ref, int rs, int16_t *pred, int ps, int n, int mvx, int mvy)
 {
 	const int xf = mvx & 7, yf = mvy & 7;
 	const int16_t *src = ref + (mvy >> 3) * rs + (mvx >> 3);
@@ -72,6 +39,70 @@ HENC_HD void mc_chroma(const G &g, Enc &__restrict__ e, const int16_t *ref, int 
 		interp_stage<4>(g, src - rs, rs, tmp, 40, xf, n, n + 3, 0, 1, 0);
 		interp_stage<4>(g, tmp + 40, 40, pred, ps, yf, n, n, 1, 0, 1);
 	}
+}
+#endif
+
+// prediction of the node's three blocks for the vector mv (hmr_motion_compensation_luma / _chroma :1779-1907, uni-directional)
+template <class G>
+HENC_HD void motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv)
+{
+	Work &w = *e.w;
+	const Geo &q = e.geo[ni];
+	const Seq &S = *e.seq;
+	const int gx = e.ctu->x + q.x, gy = e.ctu->y + q.y, gxc = (e.ctu->x >> 1) + q.xc, gyc = (e.ctu->y >> 1) + q.yc;
+#if defined(__HIPCC__)
+	PRIM_T0();
+	const uint8_t *py = e.f->sub_y + (size_t)(((mv.y & 3) << 2) | (mv.x & 3)) * S.plane_elems_y + (gy + (mv.y >> 2)) * S.stride_y + gx + (mv.x >> 2);
+	const size_t oc = (size_t)(((mv.y & 7) << 3) | (mv.x & 7)) * S.plane_elems_c + (gyc + (mv.y >> 3)) * S.stride_c + gxc + (mv.x >> 3);
+	blk_from_u8(g, e.f->sub_c[0] + oc, S.stride_c, w.pred_c[0] + q.yc * 32 + q.xc, 32, q.size_chroma);
+	blk_from_u8(g, e.f->sub_c[1] + oc, S.stride_c, w.pred_c[1] + q.yc * 32 + q.xc, 32, q.size_chroma);
+	blk_from_u8(g, py, S.stride_y, w.pred_y + q.y * 64 + q.x, 64, q.size);
+	g.sync();
+	PRIM_END(PP_INTERP);
+#else
+	mc_luma_interp(g, e, e.f->ref[0] + gy * S.stride_y + gx, S.stride_y, w.pred_y + q.y * 64 + q.x, 64, q.size, mv.x, mv.y);
+	mc_chroma_interp(g, e, e.f->ref[1] + gyc * S.stride_c + gxc, S.stride_c, w.pred_c[0] + q.yc * 32 + q.xc, 32, q.size_chroma, mv.x, mv.y);
+	mc_chroma_interp(g, e, e.f->ref[2] + gyc * S.stride_c + gxc, S.stride_c, w.pred_c[1] + q.yc * 32 + q.xc, 32, q.size_chroma, mv.x, mv.y);
+#endif
+}
+
+// SADs of the source block at (ox, oy) of the CTU against the reference displaced by (qx[k], qy[k]) quarter samples from the co-located block at picture
+// position (gx, gy), for the candidates with ok[k]: a round of the motion search in one go
+template <int MAXC, class G>
+HENC_HD void cand_sads(const G &g, Enc &__restrict__ e, int ox, int oy, int gx, int gy, int size, const int (&qx)[MAXC], const int (&qy)[MAXC], const bool (&ok)[MAXC],
+		       uint32_t (&out)[MAXC])
+{
+	const Seq &S = *e.seq;
+#if defined(__HIPCC__)
+	const uint8_t *p0 = e.f->sub_y + gy * S.stride_y + gx;
+	const uint8_t *cand[MAXC];
+#pragma unroll
+	for (int k = 0; k < MAXC; k++)
+		cand[k] = ok[k] ? p0 + (size_t)(((qy[k] & 3) << 2) | (qx[k] & 3)) * S.plane_elems_y + (qy[k] >> 2) * S.stride_y + (qx[k] >> 2) : nullptr;
+	multi_sad_u8<MAXC>(g, e.w->curr_y8 + oy * 64 + ox, size, cand, S.stride_y, out);
+#else
+	const int16_t *orig = e.w->curr_y + oy * 64 + ox, *ref = e.f->ref[0] + gy * S.stride_y + gx;
+	for (int k = 0; k < MAXC; k++) {
+		if (!ok[k]) { out[k] = 0; continue; }
+		if (((qx[k] | qy[k]) & 3) == 0) out[k] = blk_sad(g, orig, CTU_STRIDE_Y, ref + (qy[k] >> 2) * S.stride_y + (qx[k] >> 2), S.stride_y, size);
+		else {
+			mc_luma_interp(g, e, ref, S.stride_y, e.w->pred_aux, 64, size, qx[k], qy[k]);   // scratch: no TU is in flight during the search
+			out[k] = blk_sad(g, orig, CTU_STRIDE_Y, e.w->pred_aux, 64, size);
+			g.sync();
+		}
+	}
+#endif
+}
+// a[idx] with the array kept in registers (the indices of the search walk are data dependent)
+template <int N>
+HENC_INLINE uint32_t pick(const uint32_t (&a)[N], int idx)
+{
+	uint32_t r = a[0];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+	for (int k = 1; k < N; k++) r = idx == k ? a[k] : r;
+	return r;
 }
 
 // ---- vector cost ----------------------------------------------------------------------------------------------------
@@ -113,10 +144,12 @@ HENC_INLINE uint32_t mv_cost_sqrt(const MvCandList &l, uint32_t qp, int mvx, int
 }
 
 // ---- hmr_motion_estimation :1404-1775 --------------------------------------------------------------------------------
-// orig: source block (CTU window); ref: co-located block in the padded reference.  Returns the best SAD.
+// The source block sits at (ox, oy) of the CTU, (gx, gy) in the picture.  Returns the best SAD.
+// The candidates of a search round do not depend on each other - only the comparisons do - so every round asks for all its SADs at once (cand_sads) and
+// then walks them in the reference's order, with its loop bounds that move while the loop runs.
 template <class G>
-HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, const int16_t *orig, int ox, int oy, const int16_t *ref, int rs, int gx, int gy, int size,
-				   const MvCandList &amvp, const MvCandList &search, double corr, int action, MV *mv_io, MV *subpix_out)
+HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, int ox, int oy, int gx, int gy, int size, const MvCandList &amvp, const MvCandList &search, double corr,
+				   int action, MV *mv_io, MV *subpix_out)
 {
 	const int ds[4][2] = {{-1, 0}, {0, -1}, {1, 0}, {0, 1}};
 	const int db[8][2] = {{-2, 0}, {-1, -1}, {0, -2}, {1, -1}, {2, 0}, {1, 1}, {0, 2}, {-1, 1}};
@@ -128,11 +161,10 @@ HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, const int16_
 	uint32_t cur_sad = 0, cur_rd = 0, best_sad = 0xffffffffu;
 	int cur_x = 0, cur_y = 0, best_x = 0, best_y = 0, mvx = 0, mvy = 0, subx = 0, suby = 0, dummy;
 #define HENC_IN_WIN(x, y) ((x) >= xlow && (x) <= xhigh && (y) >= ylow && (y) <= yhigh)
-#define HENC_SAD_AT(x, y) blk_sad(g, orig, CTU_STRIDE_Y, ref + (y) * rs + (x), rs, size)
-#define HENC_TRY(x, y, on_better)                                                                  \
+#define HENC_TRY(x, y, sad_, on_better)                                                            \
 	do {                                                                                       \
 		if (HENC_IN_WIN(x, y)) {                                                           \
-			const uint32_t s_ = HENC_SAD_AT(x, y);                                     \
+			const uint32_t s_ = (sad_);                                                \
 			const uint32_t rd_ = s_ + mv_cost_fast(amvp, corr, (x) << 2, (y) << 2, &dummy); \
 			if (rd_ < cur_rd) { on_better; cur_sad = s_; cur_rd = rd_; cur_x = (x); cur_y = (y); } \
 		}                                                                                  \
@@ -142,23 +174,44 @@ HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, const int16_
 		bool early = false;
 		cur_x = hclip(0, xlow, xhigh);
 		cur_y = hclip(0, ylow, yhigh);
-		cur_sad = HENC_SAD_AT(cur_x, cur_y);
-		cur_rd = cur_sad + mv_cost_fast(amvp, corr, cur_x << 2, cur_y << 2, &dummy);
-		best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
-		if (best_sad <= 0) early = true;
-		if (!early) {
-			for (int i = 0; i < search.num; i++) {
-				const int x = search.mv[i].x >> 2, y = search.mv[i].y >> 2;
-				if (x == 0 && y == 0) continue;
-				HENC_TRY(x, y, (void)0);
+		{
+			// the start position and the predictor positions
+			int qx[4], qy[4];
+			bool ok[4];
+			uint32_t s4[4];
+			qx[0] = cur_x << 2; qy[0] = cur_y << 2; ok[0] = true;
+			for (int i = 0; i < 3; i++) {
+				const int x = i < search.num ? search.mv[i].x >> 2 : 0, y = i < search.num ? search.mv[i].y >> 2 : 0;
+				qx[i + 1] = x << 2; qy[i + 1] = y << 2;
+				ok[i + 1] = i < search.num && !(x == 0 && y == 0) && HENC_IN_WIN(x, y);
 			}
+			cand_sads<4>(g, e, ox, oy, gx, gy, size, qx, qy, ok, s4);
+			cur_sad = s4[0];
+			cur_rd = cur_sad + mv_cost_fast(amvp, corr, cur_x << 2, cur_y << 2, &dummy);
 			best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
 			if (best_sad <= 0) early = true;
+			if (!early) {
+				for (int i = 0; i < search.num; i++) {
+					const int x = search.mv[i].x >> 2, y = search.mv[i].y >> 2;
+					if (x == 0 && y == 0) continue;
+					HENC_TRY(x, y, pick(s4, i + 1), (void)0);
+				}
+				best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
+				if (best_sad <= 0) early = true;
+			}
 		}
 		if (!early) {
+			int qx[4], qy[4];
+			bool ok[4];
+			uint32_t s4[4];
 			for (int i = 0; i < 4; i++) {
 				const int x = best_x + ds[i][0], y = best_y + ds[i][1];
-				HENC_TRY(x, y, (void)0);
+				qx[i] = x << 2; qy[i] = y << 2; ok[i] = HENC_IN_WIN(x, y);
+			}
+			cand_sads<4>(g, e, ox, oy, gx, gy, size, qx, qy, ok, s4);
+			for (int i = 0; i < 4; i++) {
+				const int x = best_x + ds[i][0], y = best_y + ds[i][1];
+				HENC_TRY(x, y, pick(s4, i), (void)0);
 			}
 			if (best_sad <= 0) early = true;
 		}
@@ -168,9 +221,18 @@ HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, const int16_
 			int next_start = 0, search_size = 8;
 			best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
 			while (dist < end) {
+				// the eight directions at this distance around the (fixed) centre; the walk below visits a data-dependent subset of them
+				int qx[8], qy[8];
+				bool ok[8];
+				uint32_t s8[8];
+				for (int i = 0; i < 8; i++) {
+					const int x = best_x + db[i][0] * dist, y = best_y + db[i][1] * dist;
+					qx[i] = x << 2; qy[i] = y << 2; ok[i] = HENC_IN_WIN(x, y);
+				}
+				cand_sads<8>(g, e, ox, oy, gx, gy, size, qx, qy, ok, s8);
 				for (int i = next_start; i < next_start + search_size; i++) {
 					const int idx = i % 8, x = best_x + db[idx][0] * dist, y = best_y + db[idx][1] * dist;
-					HENC_TRY(x, y, (next_start = (idx - 2 + 8) % 8, search_size = 5));
+					HENC_TRY(x, y, pick(s8, idx), (next_start = (idx - 2 + 8) % 8, search_size = 5));
 				}
 				dist *= 2;
 			}
@@ -180,9 +242,17 @@ HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, const int16_
 		{
 			int next_start = 0, search_size = 4;
 			for (;;) {
+				int qx[4], qy[4];
+				bool ok[4];
+				uint32_t s4[4];
+				for (int i = 0; i < 4; i++) {
+					const int x = best_x + ds[i][0], y = best_y + ds[i][1];
+					qx[i] = x << 2; qy[i] = y << 2; ok[i] = HENC_IN_WIN(x, y);
+				}
+				cand_sads<4>(g, e, ox, oy, gx, gy, size, qx, qy, ok, s4);
 				for (int i = next_start; i < next_start + search_size; i++) {
 					const int idx = i % 4, x = best_x + ds[idx][0], y = best_y + ds[idx][1];
-					HENC_TRY(x, y, (next_start = (idx - 1 + 4) % 4, search_size = 3));
+					HENC_TRY(x, y, pick(s4, idx), (next_start = (idx - 1 + 4) % 4, search_size = 3));
 				}
 				if (best_x == cur_x && best_y == cur_y) break;
 				best_sad = cur_sad; best_x = cur_x; best_y = cur_y;
@@ -197,12 +267,15 @@ HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, const int16_
 	if (action & ME_HALF) {
 		int bidx = 0, bx = 0, by = 0;
 		best_x = mvx >> 2; best_y = mvy >> 2;
-		if (!(action & ME_PEL)) cur_sad = HENC_SAD_AT(best_x, best_y);
+		int qx[9], qy[9];
+		bool ok[9];
 		uint32_t sads[9];
-		subpel_round_sads(g, e, orig, ox, oy, ref, rs, gx, gy, size, best_x << 2, best_y << 2, ref_h, 2, 0, 0, sads);
+		for (int i = 0; i < 9; i++) { qx[i] = (best_x << 2) + ref_h[i][0] * 2; qy[i] = (best_y << 2) + ref_h[i][1] * 2; ok[i] = true; }
+		cand_sads<9>(g, e, ox, oy, gx, gy, size, qx, qy, ok, sads);
+		if (!(action & ME_PEL)) cur_sad = sads[0];     // candidate 0 of the round is the integer position itself
 		for (int i = 0; i < 9; i++) {
 			const int cx = ref_h[i][0] * 2, cy = ref_h[i][1] * 2;
-			const uint32_t s = sads[i];
+			const uint32_t s = pick(sads, i);
 			if (s < cur_sad) { cur_sad = s; bx = cx; by = cy; bidx = i; }
 		}
 		mvx = (best_x << 2) + bx; mvy = (best_y << 2) + by; subx = bx; suby = by;
@@ -210,10 +283,11 @@ HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, const int16_
 		if (action & ME_QUARTER) {
 			const int hx = ref_h[bidx][0], hy = ref_h[bidx][1];
 			bx = hx * 2; by = hy * 2;
-			subpel_round_sads(g, e, orig, ox, oy, ref, rs, gx, gy, size, best_x << 2, best_y << 2, ref_q, 1, hx * 2, hy * 2, sads);
+			for (int i = 0; i < 9; i++) { qx[i] = (best_x << 2) + hx * 2 + ref_q[i][0]; qy[i] = (best_y << 2) + hy * 2 + ref_q[i][1]; }
+			cand_sads<9>(g, e, ox, oy, gx, gy, size, qx, qy, ok, sads);
 			for (int i = 0; i < 9; i++) {
 				const int cx = hx * 2 + ref_q[i][0], cy = hy * 2 + ref_q[i][1];
-				const uint32_t s = sads[i];
+				const uint32_t s = pick(sads, i);
 				if (s < cur_sad) { cur_sad = s; bx = cx; by = cy; }
 			}
 			best_sad = cur_sad;
@@ -221,7 +295,6 @@ HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, const int16_
 		}
 	}
 #undef HENC_IN_WIN
-#undef HENC_SAD_AT
 #undef HENC_TRY
 	HENC_PROF_ADD(e, PF_ME_SUB);   // includes the integer part; the report subtracts
 	mv_io->x = mvx; mv_io->y = mvy;
@@ -621,37 +694,6 @@ HENC_HD void predict_all_comps(const G &g, Enc &__restrict__ e, int ni)
 		blk_predict(g, w.curr_c[c] + q.yc * 32 + q.xc, 32, w.pred_c[c] + q.yc * 32 + q.xc, 32, w.resid_c[c] + q.yc * 32 + q.xc, 32, q.size_chroma);
 }
 
-template <class G>
-HENC_HD void motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv)
-{
-	Work &w = *e.w;
-	const Geo &q = e.geo[ni];
-	const Seq &S = *e.seq;
-	const int gx = e.ctu->x + q.x, gy = e.ctu->y + q.y, gxc = (e.ctu->x >> 1) + q.xc, gyc = (e.ctu->y >> 1) + q.yc;
-	if (e.box) {
-		helper_post(g, e, 0, HJOB_MC_CHROMA, ni, COMP_U, mv.x, mv.y);
-		helper_post(g, e, 1, HJOB_MC_CHROMA, ni, COMP_V, mv.x, mv.y);
-	}
-	mc_luma(g, e, e.f->ref[0] + gy * S.stride_y + gx, S.stride_y, w.pred_y + q.y * 64 + q.x, 64, q.size, mv.x, mv.y);
-	if (e.box) {
-		helper_wait(g, e, 0);
-		helper_wait(g, e, 1);
-		return;
-	}
-	mc_chroma(g, e, e.f->ref[1] + gyc * S.stride_c + gxc, S.stride_c, w.pred_c[0] + q.yc * 32 + q.xc, 32, q.size_chroma, mv.x, mv.y);
-	mc_chroma(g, e, e.f->ref[2] + gyc * S.stride_c + gxc, S.stride_c, w.pred_c[1] + q.yc * 32 + q.xc, 32, q.size_chroma, mv.x, mv.y);
-}
-// one chroma plane of the same (what a helper wavefront runs)
-template <class G>
-HENC_HD void motion_compensate_chroma_comp(const G &g, Enc &__restrict__ e, int ni, int comp, MV mv)
-{
-	Work &w = *e.w;
-	const Geo &q = e.geo[ni];
-	const Seq &S = *e.seq;
-	const int gxc = (e.ctu->x >> 1) + q.xc, gyc = (e.ctu->y >> 1) + q.yc;
-	mc_chroma(g, e, e.f->ref[comp] + gyc * S.stride_c + gxc, S.stride_c, w.pred_c[comp - 1] + q.yc * 32 + q.xc, 32, q.size_chroma, mv.x, mv.y);
-}
-
 // predict_inter :2924 (uni-directional): vector predictor choice, motion compensation, residual.  Returns the vector cost.
 template <class G>
 HENC_HD int predict_inter(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
@@ -707,8 +749,7 @@ HENC_HD int cu_motion_estimation(const G &g, Enc &__restrict__ e, int depth, int
 			subpix = nd.subpix_mv;
 		}
 		const double corr = calc_mv_correction(nd.qp, e.f->avg_dist);
-		const uint32_t cost = motion_estimation(g, e, w.curr_y + q.y * 64 + q.x, q.x, q.y, e.f->ref[0] + gy * S.stride_y + gx, S.stride_y, gx, gy, q.size, amvp,
-							w.search_cands, corr, action, &mv, &subpix);
+		const uint32_t cost = motion_estimation(g, e, q.x, q.y, gx, gy, q.size, amvp, w.search_cands, corr, action, &mv, &subpix);
 		int mvp_idx = 0;
 		const uint32_t mv_cost = mv_cost_fast(amvp, corr, mv.x, mv.y, &mvp_idx);
 		nd.subpix_mv = subpix;

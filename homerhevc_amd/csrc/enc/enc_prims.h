@@ -56,6 +56,75 @@ HENC_PRIM uint32_t blk_sad(const G &g, const int16_t *a, int as, const int16_t *
 	{ const auto prim_ret_ = g.sum(acc); PRIM_END(PP_SAD); return prim_ret_; }
 }
 
+#if defined(__HIPCC__)
+// ---- 8-bit reference planes (k_subpel.hip) ----------------------------------------------------------------------------
+// The reference picture is kept as sixteen 8-bit luma planes (one per quarter-sample phase) and sixty-four chroma planes per component, built once per
+// frame by a bandwidth-bound kernel: inside the CTU walk a motion-compensated block is a copy and a motion-search candidate is a SAD against a plane -
+// no interpolation on the serial path.  Blocks start at any byte of a plane (gfx950 runs with unaligned global access enabled).
+HENC_INLINE uint32_t ld32u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+
+// SADs of up to MAXC candidate blocks (global, 8 bit, row pitch `stride`) against one source block (8 bit, row pitch 64); cand[k] == nullptr: skipped.
+// Every candidate's loads are issued before the first result is needed, so a round of candidates costs one memory latency.
+template <int MAXC>
+__device__ __forceinline__ void multi_sad_u8(const WaveGrp &g, const uint8_t *orig8, int n, const uint8_t *const (&cand)[MAXC], int stride, uint32_t (&out)[MAXC])
+{
+	PRIM_T0();
+	if (n == 8) {
+		// 16 four-sample chunks per block: four candidates side by side, one per 16-lane row; the row totals are what WaveGrp::sum adds up last
+		const int sub = g.tid >> 4, r = (g.tid & 15) >> 1, c = (g.tid & 1) << 2;
+		const uint32_t a = *(const uint32_t *)(orig8 + r * 64 + c);
+#pragma unroll
+		for (int k0 = 0; k0 < MAXC; k0 += 4) {
+			const uint8_t *p = cand[k0];
+#pragma unroll
+			for (int j = 1; j < 4; j++)
+				if (k0 + j < MAXC) p = sub == j ? cand[k0 + j] : p;
+			if (k0 + 4 > MAXC && sub >= MAXC - k0) p = nullptr;
+			int x = p ? (int)__builtin_amdgcn_sad_u8(a, ld32u(p + r * stride + c), 0u) : 0;
+			x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+			x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+			x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+			x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+				if (k0 + j < MAXC) out[k0 + j] = (uint32_t)__builtin_amdgcn_readlane(x, 16 * j + 15);
+		}
+		PRIM_END(PP_SAD);
+		return;
+	}
+	const int lw = ilog2i(n) - 2, chunks = (n * n) >> 2;       // n >= 16: at least one chunk per lane
+	uint32_t acc[MAXC];
+#pragma unroll
+	for (int k = 0; k < MAXC; k++) acc[k] = 0;
+	for (int i = g.tid; i < chunks; i += 64) {
+		const int r = i >> lw, c = (i & ((1 << lw) - 1)) << 2;
+		const uint32_t a = *(const uint32_t *)(orig8 + r * 64 + c);
+		uint32_t b[MAXC];
+#pragma unroll
+		for (int k = 0; k < MAXC; k++) b[k] = cand[k] ? ld32u(cand[k] + r * stride + c) : a;
+#pragma unroll
+		for (int k = 0; k < MAXC; k++) acc[k] = __builtin_amdgcn_sad_u8(a, b[k], acc[k]);
+	}
+#pragma unroll
+	for (int k = 0; k < MAXC; k++) out[k] = g.sum(acc[k]);
+	PRIM_END(PP_SAD);
+}
+
+// n x n samples of an 8-bit plane into a 16-bit block (motion compensation from the phase planes); the caller syncs
+__device__ __forceinline__ void blk_from_u8(const WaveGrp &g, const uint8_t *s, int ss, int16_t *d, int ds, int n)
+{
+	const int lw = ilog2i(n) - 2, chunks = (n * n) >> 2;
+#pragma unroll 4
+	for (int i = g.tid; i < chunks; i += 64) {
+		const int r = i >> lw, c = (i & ((1 << lw) - 1)) << 2;
+		const uint32_t v = ld32u(s + r * ss + c);
+		S4 o;
+		o.v[0] = (int16_t)(v & 255); o.v[1] = (int16_t)((v >> 8) & 255); o.v[2] = (int16_t)((v >> 16) & 255); o.v[3] = (int16_t)(v >> 24);
+		st4(d + r * ds + c, o);
+	}
+}
+#endif
+
 template <class G>
 HENC_PRIM uint32_t blk_ssd(const G &g, const int16_t *a, int as, const int16_t *b, int bs, int n)
 {

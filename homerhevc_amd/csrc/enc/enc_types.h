@@ -121,6 +121,8 @@ struct Seq {
 	int32_t stride_y, stride_c, margin_y, margin_c;
 	// source planes (no margin)
 	int32_t src_stride_y, src_stride_c;
+	// elements of one padded plane (stride x (rows + 2 margins)): the pitch between the phase planes of the reference (FrameCtx::sub_y / sub_c)
+	int32_t plane_elems_y, plane_elems_c;
 };
 
 struct FrameCtx {
@@ -136,6 +138,10 @@ struct FrameCtx {
 	const int16_t *src[3];                 // source picture, first sample
 	const int16_t *ref[3];                 // reference picture (list 0, index 0), first valid sample
 	int16_t *rec[3];                       // picture under reconstruction, first valid sample
+	// the reference picture as 8-bit phase planes (k_subpel.hip), first valid sample of plane 0: luma plane (mvy & 3) * 4 + (mvx & 3) holds the picture
+	// interpolated at that quarter-sample phase, chroma plane (mvy & 7) * 8 + (mvx & 7) likewise in eighth samples; planes are plane_elems_y / _c apart
+	// and share the reference's strides and margins.  Device only (the checker build interpolates from ref[]).
+	const uint8_t *sub_y, *sub_c[2];
 };
 
 struct MvCandList {
@@ -165,7 +171,11 @@ struct Work {
 	int16_t adi[264], adi_f[264];
 	int16_t pred_aux[64 * 64];             // transform coefficients of the TU in flight; between TUs also the motion search's sub-pel candidate block
 	int16_t delta_u[64 * 64];
-	int16_t sub_tmp[(64 + 8) * 72];        // first interpolation stage of a sub-pel candidate / two-stage motion compensation
+#if defined(__HIPCC__)
+	uint8_t curr_y8[64 * 64];              // the source CTU's luma as bytes: the motion search compares it with the 8-bit phase planes (v_sad_u8)
+#else
+	int16_t sub_tmp[(64 + 8) * 72];        // checker build: first interpolation stage of a sub-pel candidate / two-stage motion compensation
+#endif
 	MvCandList amvp, merge_cands, search_cands;
 	WorkSlow *slow;
 };

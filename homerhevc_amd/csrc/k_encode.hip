@@ -86,20 +86,12 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 			e.box = nullptr;
 			e.scratch_a = scratch;
 			e.scratch_b = scratch + 1024;
-			e.mc_tmp_c = scratch;
-			e.mc_tmp_y = scratch;
-			e.mc_tmp_y_stride = 16;
 			e.adi_c = scratch + 2048;
 			e.prof = nullptr;
 		}
 		const int *a = box->a[h];
 		uint32_t r0 = 0, r1 = 0;
 		switch (job) {
-		case HJOB_MC_CHROMA: {
-			MV mv = {a[2], a[3]};
-			motion_compensate_chroma_comp(g, e, a[0], a[1], mv);
-			break;
-		}
 		case HJOB_INTER_TU: {
 			int sum = 0;
 			r0 = encode_inter_tu(g, e, a[0], a[1], a[2], a[3], &sum);
@@ -111,11 +103,6 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 			const Geo &q = e.geo[a[0]];
 			const int c = a[1] - 1;
 			r0 = blk_ssd(g, e.w->curr_c[c] + q.yc * 32 + q.xc, 32, e.w->pred_c[c] + q.yc * 32 + q.xc, 32, q.size_chroma);
-			break;
-		}
-		case HJOB_SUBPEL: {   // one sub-pel candidate of a block up to 16 x 16: first stage (23 x 16) at scratch, candidate block at scratch + 1024
-			const int ox = a[0] & 255, oy = (a[0] >> 8) & 255, size = a[0] >> 16;
-			r0 = subpel_candidate_sad(g, e, e.w->curr_y + oy * 64 + ox, e.f->ref[0] + a[2] * e.seq->stride_y + a[1], e.seq->stride_y, scratch + 1024, size, size, a[3], a[4]);
 			break;
 		}
 		case HJOB_CHROMA_SEARCH: {
@@ -587,6 +574,7 @@ struct hmr_gpu_enc {
 	std::vector<Geo> geo;
 	std::vector<SrcSlot> src;
 	int16_t *d_pic[2][3], *d_pre[3];
+	uint8_t *d_sub_y = nullptr, *d_sub_c[2] = {nullptr, nullptr};   // phase planes of the reference picture (k_subpel.hip): 16 luma, 2 x 64 chroma
 	size_t src_elems[3], pic_elems[3];
 	uint8_t *d_bytes;              // staging for 8-bit planes (one 4:2:0 picture)
 	// raster unit arrays of the filters, SAO statistics and parameters
@@ -692,6 +680,12 @@ int ctu_stage_prepare(hmr_gpu_enc *e)
 	hipStream_t st = e->ctx->stream;
 	if (!e->lockstep)   // (the frame-start state CTUs are re-encoded from in the single-thread order)
 		HIP_TRY(hipMemcpyAsync(e->d.ctus_start, e->d.ctus, sizeof(CtuInfo) * s.nctu, hipMemcpyDeviceToDevice, st));
+	if (e->f.slice_type != SLICE_I) {
+		// the reference picture, interpolated once at every sub-sample phase: what motion search and compensation read (k_subpel.hip)
+		const int rc = hmr_gpu_subpel_planes(e->ctx, e->d_pic[e->cur ^ 1][0], e->d_pic[e->cur ^ 1][1], e->d_pic[e->cur ^ 1][2], s.stride_y, s.height + 2 * s.margin_y, s.stride_c,
+						     s.height / 2 + 2 * s.margin_c, e->d_sub_y, e->d_sub_c[0], e->d_sub_c[1]);
+		if (rc) return rc;
+	}
 	{
 		static const int zero_counters[3] = {0, 0, -1};
 		HIP_TRY(hipMemcpyAsync(e->d.counters, zero_counters, sizeof zero_counters, hipMemcpyHostToDevice, st));
@@ -775,6 +769,9 @@ int set_frame(hmr_gpu_enc *e, int slot, int image_type, double avg_dist)
 		e->f.ref[c] = plane0(e, e->cur ^ 1, c);
 		e->f.rec[c] = plane0(e, e->cur, c);
 	}
+	e->f.sub_y = e->d_sub_y + (size_t)s.margin_y * s.stride_y + s.margin_y;
+	e->f.sub_c[0] = e->d_sub_c[0] + (size_t)s.margin_c * s.stride_c + s.margin_c;
+	e->f.sub_c[1] = e->d_sub_c[1] + (size_t)s.margin_c * s.stride_c + s.margin_c;
 	HIP_TRY(hipMemcpyAsync(e->d_frame, &e->f, sizeof(FrameCtx), hipMemcpyHostToDevice, e->ctx->stream));
 	return HMR_GPU_OK;
 }
@@ -860,6 +857,9 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 		for (int k = 0; k < 2; k++) DEV_ALLOC(e->d_pic[k][c], e->pic_elems[c]);
 		DEV_ALLOC(e->d_pre[c], e->pic_elems[c]);
 	}
+	DEV_ALLOC(e->d_sub_y, (size_t)16 * s.plane_elems_y);
+	DEV_ALLOC(e->d_sub_c[0], (size_t)64 * s.plane_elems_c);
+	DEV_ALLOC(e->d_sub_c[1], (size_t)64 * s.plane_elems_c);
 	DEV_ALLOC(e->d_bytes, (size_t)s.width * s.height * 3 / 2);
 	e->units_stride = s.wctu * 16;
 	e->units_rows = s.hctu * 16;

@@ -1,0 +1,167 @@
+// Phase planes of a reference picture (include/homer_gpu.h section 13).
+//
+// The reference interpolates a block every time a vector is tried: the 16 planes of hmr_half/quarter_pixel_estimation_luma_hm
+// (hmr_motion_inter.c:395,442) per motion search, hmr_motion_compensation_luma / _chroma (:1779,1860) per merge candidate and
+// per coded vector - all through sse_interpolate_luma / _chroma (inter_prediction.c:796,818; stage rules hmr_motion_inter.c:240-391).
+// The value of a prediction sample depends only on the vector's phase and on the reference samples around it, not on the block it
+// is asked for, so here the whole padded reference is interpolated ONCE per frame for every phase:
+//   luma    16 planes, plane (fy * 4 + fx) = the picture displaced by (fx, fy) quarter samples,
+//   chroma  64 planes per component, plane (fy * 8 + fx) in eighth samples,
+// stored as bytes with the picture's own stride and margins.  Inside the CTU walk (enc/enc_inter.h) motion compensation is then a
+// copy and a motion-search candidate is v_sad_u8 against a plane.
+//
+// These kernels are streaming, store-bound work: a luma sample is read once (2 bytes at the picture's int16 width) and 16 bytes are
+// written; a chroma sample 2 in, 64 out.  One workgroup = a 64 x 16 tile: the tile and its filter margin are staged in LDS, the
+// horizontal first stages (14-bit intermediates, as the reference keeps them) are computed once per row and phase into LDS, the
+// vertical stage reads them back; every thread finishes four adjacent samples of all phases and stores one dword per plane, so a
+// wavefront writes 256 contiguous bytes per plane and row.  Addressing is linear over the allocation (taps that run over a row end
+// read the neighbouring row's memory exactly as the reference's pointer arithmetic does); taps outside the allocation read zero.
+#include "common.h"
+
+namespace {
+
+constexpr int TW = 64, TH = 16;
+
+__device__ __forceinline__ int clip255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+// out = [16][elems] bytes; pic = allocation start; elems = stride * rows
+__global__ __launch_bounds__(256) void k_subpel_luma(const int16_t *__restrict__ pic, int stride, int rows, uint8_t *__restrict__ out)
+{
+	__shared__ int16_t in[TH + 7][TW + 8];          // rows y0-3 .. y0+TH+3, columns x0-3 .. x0+TW+4
+	__shared__ int16_t hs[3][TH + 7][TW];           // horizontal stage (sum - 8192) for fx = 1, 2, 3
+	const int tiles_x = (stride + TW - 1) / TW;
+	const int x0 = (int)(blockIdx.x % tiles_x) * TW, y0 = (int)(blockIdx.x / tiles_x) * TH;
+	const long elems = (long)stride * rows;
+	const int t = (int)threadIdx.x;
+	for (int i = t; i < (TH + 7) * (TW + 8); i += 256) {
+		const int r = i / (TW + 8), c = i - r * (TW + 8);
+		const long li = (long)(y0 - 3 + r) * stride + (x0 - 3 + c);
+		in[r][c] = (li >= 0 && li < elems) ? pic[li] : (int16_t)0;
+	}
+	__syncthreads();
+	const int c1[8] = {-1, 4, -10, 58, 17, -5, 1, 0}, c2[8] = {-1, 4, -11, 40, 40, -11, 4, -1}, c3[8] = {0, 1, -5, 17, 58, -10, 4, -1};
+	for (int i = t; i < (TH + 7) * TW; i += 256) {
+		const int r = i / TW, c = i - r * TW;
+		int s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			const int v = in[r][c + k];
+			s1 += v * c1[k]; s2 += v * c2[k]; s3 += v * c3[k];
+		}
+		hs[0][r][c] = (int16_t)(s1 - 8192); hs[1][r][c] = (int16_t)(s2 - 8192); hs[2][r][c] = (int16_t)(s3 - 8192);
+	}
+	__syncthreads();
+	const int ty = t >> 4, tx = (t & 15) << 2;
+	const int y = y0 + ty, x = x0 + tx;
+	if (y >= rows || x >= stride) return;
+	const long li = (long)y * stride + x;
+	uint32_t pk[16];
+#pragma unroll
+	for (int f = 0; f < 16; f++) pk[f] = 0;
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		const int c = tx + j;
+		// fy = 0: the integer sample and the three horizontal phases (single stage: (sum + 32) >> 6)
+		pk[0] |= (uint32_t)clip255(in[ty + 3][c + 3]) << (8 * j);
+#pragma unroll
+		for (int fx = 1; fx < 4; fx++) pk[fx] |= (uint32_t)clip255((hs[fx - 1][ty + 3][c] + 8192 + 32) >> 6) << (8 * j);
+		// fy = 1..3: vertical filter over the integer column (single stage) and over the horizontal intermediates (second stage: >> 12)
+		int v0[8], v1[8], v2[8], v3[8];
+#pragma unroll
+		for (int k = 0; k < 8; k++) { v0[k] = in[ty + k][c + 3]; v1[k] = hs[0][ty + k][c]; v2[k] = hs[1][ty + k][c]; v3[k] = hs[2][ty + k][c]; }
+#pragma unroll
+		for (int fy = 1; fy < 4; fy++) {
+			const int *cf = fy == 1 ? c1 : (fy == 2 ? c2 : c3);
+			int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+			for (int k = 0; k < 8; k++) { s0 += v0[k] * cf[k]; s1 += v1[k] * cf[k]; s2 += v2[k] * cf[k]; s3 += v3[k] * cf[k]; }
+			pk[fy * 4 + 0] |= (uint32_t)clip255((s0 + 32) >> 6) << (8 * j);
+			pk[fy * 4 + 1] |= (uint32_t)clip255(sat16i((s1 + 2048 + (8192 << 6)) >> 12)) << (8 * j);
+			pk[fy * 4 + 2] |= (uint32_t)clip255(sat16i((s2 + 2048 + (8192 << 6)) >> 12)) << (8 * j);
+			pk[fy * 4 + 3] |= (uint32_t)clip255(sat16i((s3 + 2048 + (8192 << 6)) >> 12)) << (8 * j);
+		}
+	}
+#pragma unroll
+	for (int f = 0; f < 16; f++) *(uint32_t *)(out + (size_t)f * elems + li) = pk[f];
+}
+
+// one chroma component: out = [64][elems]
+__global__ __launch_bounds__(256) void k_subpel_chroma(const int16_t *__restrict__ pic, int stride, int rows, uint8_t *__restrict__ out)
+{
+	__shared__ int16_t in[TH + 3][TW + 4];          // rows y0-1 .. y0+TH+1, columns x0-1 .. x0+TW+2
+	__shared__ int16_t hs[7][TH + 3][TW];           // horizontal stage (sum - 8192) for fx = 1 .. 7
+	const int tiles_x = (stride + TW - 1) / TW;
+	const int x0 = (int)(blockIdx.x % tiles_x) * TW, y0 = (int)(blockIdx.x / tiles_x) * TH;
+	const long elems = (long)stride * rows;
+	const int t = (int)threadIdx.x;
+	for (int i = t; i < (TH + 3) * (TW + 4); i += 256) {
+		const int r = i / (TW + 4), c = i - r * (TW + 4);
+		const long li = (long)(y0 - 1 + r) * stride + (x0 - 1 + c);
+		in[r][c] = (li >= 0 && li < elems) ? pic[li] : (int16_t)0;
+	}
+	__syncthreads();
+	const int cf[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4}, {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
+	for (int i = t; i < (TH + 3) * TW; i += 256) {
+		const int r = i / TW, c = i - r * TW;
+		const int a = in[r][c], b = in[r][c + 1], d = in[r][c + 2], e = in[r][c + 3];
+#pragma unroll
+		for (int fx = 1; fx < 8; fx++) hs[fx - 1][r][c] = (int16_t)(a * cf[fx][0] + b * cf[fx][1] + d * cf[fx][2] + e * cf[fx][3] - 8192);
+	}
+	__syncthreads();
+	const int ty = t >> 4, tx = (t & 15) << 2;
+	const int y = y0 + ty, x = x0 + tx;
+	if (y >= rows || x >= stride) return;
+	const long li = (long)y * stride + x;
+	// fy = 0
+	{
+		uint32_t pk[8];
+#pragma unroll
+		for (int f = 0; f < 8; f++) pk[f] = 0;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const int c = tx + j;
+			pk[0] |= (uint32_t)clip255(in[ty + 1][c + 1]) << (8 * j);
+#pragma unroll
+			for (int fx = 1; fx < 8; fx++) pk[fx] |= (uint32_t)clip255((hs[fx - 1][ty + 1][c] + 8192 + 32) >> 6) << (8 * j);
+		}
+#pragma unroll
+		for (int f = 0; f < 8; f++) *(uint32_t *)(out + (size_t)f * elems + li) = pk[f];
+	}
+	for (int fy = 1; fy < 8; fy++) {
+		const int k0 = cf[fy][0], k1 = cf[fy][1], k2 = cf[fy][2], k3 = cf[fy][3];
+		uint32_t pk[8];
+#pragma unroll
+		for (int f = 0; f < 8; f++) pk[f] = 0;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const int c = tx + j;
+			const int s0 = in[ty][c + 1] * k0 + in[ty + 1][c + 1] * k1 + in[ty + 2][c + 1] * k2 + in[ty + 3][c + 1] * k3;
+			pk[0] |= (uint32_t)clip255((s0 + 32) >> 6) << (8 * j);
+#pragma unroll
+			for (int fx = 1; fx < 8; fx++) {
+				const int s = hs[fx - 1][ty][c] * k0 + hs[fx - 1][ty + 1][c] * k1 + hs[fx - 1][ty + 2][c] * k2 + hs[fx - 1][ty + 3][c] * k3;
+				pk[fx] |= (uint32_t)clip255(sat16i((s + 2048 + (8192 << 6)) >> 12)) << (8 * j);
+			}
+		}
+#pragma unroll
+		for (int f = 0; f < 8; f++) *(uint32_t *)(out + (size_t)(fy * 8 + f) * elems + li) = pk[f];
+	}
+}
+
+}  // namespace
+
+// device pointers; pic_* = start of the padded allocations (stride x rows elements), out_y = 16 planes, out_u / out_v = 64 planes each
+extern "C" int hmr_gpu_subpel_planes(hmr_gpu_ctx *ctx, const int16_t *pic_y, const int16_t *pic_u, const int16_t *pic_v, int stride_y, int rows_y, int stride_c, int rows_c,
+				     uint8_t *out_y, uint8_t *out_u, uint8_t *out_v)
+{
+	if (!ctx || !pic_y || !out_y || (stride_y & 3) || (stride_c & 3) || stride_y <= 0 || rows_y <= 0) return HMR_GPU_ERR_ARG;
+	const int gy = ((stride_y + TW - 1) / TW) * ((rows_y + TH - 1) / TH);
+	hipLaunchKernelGGL(k_subpel_luma, dim3(gy), dim3(256), 0, ctx->stream, pic_y, stride_y, rows_y, out_y);
+	if (pic_u && pic_v && out_u && out_v) {
+		const int gc = ((stride_c + TW - 1) / TW) * ((rows_c + TH - 1) / TH);
+		hipLaunchKernelGGL(k_subpel_chroma, dim3(gc), dim3(256), 0, ctx->stream, pic_u, stride_c, rows_c, out_u);
+		hipLaunchKernelGGL(k_subpel_chroma, dim3(gc), dim3(256), 0, ctx->stream, pic_v, stride_c, rows_c, out_v);
+	}
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}

@@ -599,9 +599,9 @@ int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *enc, const uint8_t *y, const uint8_t *u,
 float hmr_gpu_enc_last_ctu_ms(hmr_gpu_enc *enc);
 
 /* HOMER_enc_encode (homer_hevc_enc_api.h:173, hmr_encoder_lib.c:1655 + encoder_engine_thread :3043-3260): one picture in, one access unit out.
- * CTU decisions, deblocking, SAO statistics, SAO offsets and border padding run on the device; the SAO decision and the CABAC / NAL writer
- * (hmr_arithmetic_encoding.c, hmr_binary_encoding.c, hmr_bitstream.c, hmr_sao.c:1295) run on the host from the side-info, the levels and the
- * statistics.  y / u / v: host 8-bit planes; image_type as encoder_in_out_t.image_type (0 auto, 3 forced intra).  stream receives the
+ * CTU decisions, deblocking, SAO statistics, the SAO parameter decision (hmr_sao.c:663-1410), SAO offsets and border padding run on the
+ * device; the CABAC / NAL writer (hmr_arithmetic_encoding.c, hmr_binary_encoding.c, hmr_bitstream.c) runs on the host from the side-info
+ * records and the levels.  y / u / v: host 8-bit planes; image_type as encoder_in_out_t.image_type (0 auto, 3 forced intra).  stream receives the
  * Annex-B bytes of the access unit (VPS / SPS / PPS in front of an IDR), *stream_bytes their count; recon (optional) the final picture,
  * 8-bit planar.  Returns the slice type (1 P, 2 I) or a negative status. */
 int hmr_gpu_enc_encode(hmr_gpu_enc *enc, const uint8_t *y, const uint8_t *u, const uint8_t *v, int image_type, uint8_t *stream, long cap, long *stream_bytes,
@@ -620,6 +620,21 @@ int hmr_gpu_enc_last_stats(hmr_gpu_enc *enc, int *passes, int *ctu_encodes, floa
 int hmr_gpu_enc_profile(hmr_gpu_enc *enc, unsigned long long *out, int reset);
 /* profiling build, row-per-thread schedule: per CTU four 100 MHz timestamps {wait start, encode start, first use of the intra share (0: none), end}, [ctus][4] */
 int hmr_gpu_enc_timeline(hmr_gpu_enc *enc, unsigned long long *out);
+
+/* ------------------------------------------------------------------------------------------------
+ * 13. Phase planes of a reference picture
+ *     Replaces the per-block interpolation calls of the motion search and of motion compensation - the sixteen planes of
+ *     hmr_half_pixel_estimation_luma_hm / hmr_quarter_pixel_estimation_luma_hm (hmr_motion_inter.c:395,442) and
+ *     hmr_motion_compensation_luma / _chroma (:1779,1860), all through low_level_funcs_t.interpolate_luma / interpolate_chroma
+ *     (hmr_private.h:1077-1078, stage rules hmr_motion_inter.c:240-391) - by ONE bandwidth-bound pass per reference picture.
+ *     All pointers are device memory.  pic_y / pic_u / pic_v: the padded int16 planes from the first element of their allocation,
+ *     stride x rows elements each (strides multiples of 4).  out_y: 16 x stride_y x rows_y bytes, plane fy * 4 + fx = the picture
+ *     displaced by (fx, fy) quarter samples, clipped to 8 bits like the final stage of the interpolation; out_u / out_v: 64 planes
+ *     each, plane fy * 8 + fx in eighth samples (pic_u / pic_v / out_u / out_v may be NULL: luma only).  Taps run over row ends
+ *     linearly, as the reference's pointer arithmetic does; taps outside the allocation read zero.
+ * ------------------------------------------------------------------------------------------------ */
+int hmr_gpu_subpel_planes(hmr_gpu_ctx *ctx, const int16_t *pic_y, const int16_t *pic_u, const int16_t *pic_v, int stride_y, int rows_y, int stride_c, int rows_c,
+			  uint8_t *out_y, uint8_t *out_u, uint8_t *out_v);
 
 #ifdef __cplusplus
 }
