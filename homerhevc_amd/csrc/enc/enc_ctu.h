@@ -643,8 +643,10 @@ HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 #if defined(__HIPCC__)
 	// the luma source as bytes, for the motion search against the 8-bit phase planes
 	for (int i = g.tid * 4; i < 64 * 64; i += g.n * 4) {
-		const S4 v = ld4(w.curr_y + i);
-		*(uint32_t *)(w.curr_y8 + i) = (uint32_t)(v.v[0] & 255) | ((uint32_t)(v.v[1] & 255) << 8) | ((uint32_t)(v.v[2] & 255) << 16) | ((uint32_t)(v.v[3] & 255) << 24);
+		uint32_t lo, hi;   // samples 0, 1 and 2, 3 as 16-bit pairs; their low bytes -> one dword (v_perm_b32: bytes 0-3 come from the second operand, 4-7 from the first)
+		__builtin_memcpy(&lo, w.curr_y + i, 4);
+		__builtin_memcpy(&hi, w.curr_y + i + 2, 4);
+		*(uint32_t *)(w.curr_y8 + i) = __builtin_amdgcn_perm(hi, lo, 0x06040200u);
 	}
 	g.sync();
 #endif
@@ -735,6 +737,9 @@ HENC_HD void resolve_mode_tokens(const G &g, Work &w, CtuPublic &c)
 }
 
 template <class G>
+#if defined(__HIPCC__)
+__attribute__((noinline))   // one compiled body for every kernel that encodes CTUs
+#endif
 HENC_HD void encode_ctu(const G &g, Enc &__restrict__ e, int ctu_num)
 {
 	{ HENC_PROF_T0(); ctu_begin(g, e, ctu_num); HENC_PROF_ADD(e, PF_SETUP); }

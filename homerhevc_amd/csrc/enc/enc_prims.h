@@ -118,9 +118,9 @@ __device__ __forceinline__ void blk_from_u8(const WaveGrp &g, const uint8_t *s, 
 	for (int i = g.tid; i < chunks; i += 64) {
 		const int r = i >> lw, c = (i & ((1 << lw) - 1)) << 2;
 		const uint32_t v = ld32u(s + r * ss + c);
-		S4 o;
-		o.v[0] = (int16_t)(v & 255); o.v[1] = (int16_t)((v >> 8) & 255); o.v[2] = (int16_t)((v >> 16) & 255); o.v[3] = (int16_t)(v >> 24);
-		st4(d + r * ds + c, o);
+		// bytes -> zero-extended 16-bit samples, two per dword (v_perm_b32; selector 0x0c = the constant 0)
+		const uint32_t o[2] = {__builtin_amdgcn_perm(0u, v, 0x0c010c00u), __builtin_amdgcn_perm(0u, v, 0x0c030c02u)};
+		__builtin_memcpy(d + r * ds + c, o, 8);
 	}
 }
 #endif

@@ -14,6 +14,7 @@
 // (k_deblock.hip, k_sao.hip, k_pad.hip); the entropy stage (enc/enc_entropy.h) is host code fed with the side-info, the levels
 // and the SAO statistics, and hands the SAO parameters back for the offset pass.
 #include <stddef.h>
+#include <stdlib.h>
 #include <chrono>
 #include <mutex>
 #include <condition_variable>
@@ -720,7 +721,12 @@ int run_ctu_passes(hmr_gpu_enc *e)
 	if (e->lockstep) {
 		// wfpp_num_threads = CTU rows: the synchronous wavefront, one launch, nothing to verify
 		const int cus = g_cu_budget.acquire(e->ctx->device, s.hctu);
-		hipLaunchKernelGGL(k_encode_ctus, dim3(s.hctu), dim3(ENC_THREADS), LDS_BYTES, st, e->d, -1);
+		if (getenv("HENC_FORCE_BATCH_KERNEL")) {   // debugging aid: the batch launch's kernel for this one sequence (same rows, same result expected)
+			if (!e->d_batch) HIP_TRY(hipMalloc((void **)&e->d_batch, 256 * sizeof(EncDev)));
+			HIP_TRY(hipMemcpyAsync(e->d_batch, &e->d, sizeof(EncDev), hipMemcpyHostToDevice, st));
+			hipLaunchKernelGGL(k_encode_ctus_batch, dim3(s.hctu), dim3(ENC_THREADS), LDS_BYTES, st, (const EncDev *)e->d_batch, 1, 1, s.hctu);
+		} else
+			hipLaunchKernelGGL(k_encode_ctus, dim3(s.hctu), dim3(ENC_THREADS), LDS_BYTES, st, e->d, -1);
 		const hipError_t launched = hipGetLastError();
 		if (launched == hipSuccess) (void)hipEventRecord(e->ctx->ev1, st);
 		rc = launched == hipSuccess ? lockstep_collect(e) : HMR_GPU_ERR_HIP;      // (waits for the launch)

@@ -22,7 +22,15 @@ namespace {
 
 constexpr int TW = 64, TH = 16;
 
-__device__ __forceinline__ int clip255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+// One output byte.  The values clipped here provably fit 16 bits and the compiler clips them with a 16-bit median (v_med3_i16), which leaves the upper half
+// of its destination register as it was; packed with shift-and-or that garbage lands in the neighbouring byte (seen on gfx950, ROCm 7.2: bits of byte 2 set
+// from sample 0's register).  The empty asm hides the value's range, so the mask after it is a real instruction.
+__device__ __forceinline__ uint32_t clip255(int v)
+{
+	v = v < 0 ? 0 : (v > 255 ? 255 : v);
+	asm volatile("" : "+v"(v));
+	return (uint32_t)v & 255u;
+}
 
 // out = [16][elems] bytes; pic = allocation start; elems = stride * rows
 __global__ __launch_bounds__(256) void k_subpel_luma(const int16_t *__restrict__ pic, int stride, int rows, uint8_t *__restrict__ out)
@@ -62,9 +70,9 @@ __global__ __launch_bounds__(256) void k_subpel_luma(const int16_t *__restrict__
 	for (int j = 0; j < 4; j++) {
 		const int c = tx + j;
 		// fy = 0: the integer sample and the three horizontal phases (single stage: (sum + 32) >> 6)
-		pk[0] |= (uint32_t)clip255(in[ty + 3][c + 3]) << (8 * j);
+		pk[0] |= clip255(in[ty + 3][c + 3]) << (8 * j);
 #pragma unroll
-		for (int fx = 1; fx < 4; fx++) pk[fx] |= (uint32_t)clip255((hs[fx - 1][ty + 3][c] + 8192 + 32) >> 6) << (8 * j);
+		for (int fx = 1; fx < 4; fx++) pk[fx] |= clip255((hs[fx - 1][ty + 3][c] + 8192 + 32) >> 6) << (8 * j);
 		// fy = 1..3: vertical filter over the integer column (single stage) and over the horizontal intermediates (second stage: >> 12)
 		int v0[8], v1[8], v2[8], v3[8];
 #pragma unroll
@@ -75,10 +83,10 @@ __global__ __launch_bounds__(256) void k_subpel_luma(const int16_t *__restrict__
 			int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
 			for (int k = 0; k < 8; k++) { s0 += v0[k] * cf[k]; s1 += v1[k] * cf[k]; s2 += v2[k] * cf[k]; s3 += v3[k] * cf[k]; }
-			pk[fy * 4 + 0] |= (uint32_t)clip255((s0 + 32) >> 6) << (8 * j);
-			pk[fy * 4 + 1] |= (uint32_t)clip255(sat16i((s1 + 2048 + (8192 << 6)) >> 12)) << (8 * j);
-			pk[fy * 4 + 2] |= (uint32_t)clip255(sat16i((s2 + 2048 + (8192 << 6)) >> 12)) << (8 * j);
-			pk[fy * 4 + 3] |= (uint32_t)clip255(sat16i((s3 + 2048 + (8192 << 6)) >> 12)) << (8 * j);
+			pk[fy * 4 + 0] |= clip255((s0 + 32) >> 6) << (8 * j);
+			pk[fy * 4 + 1] |= clip255(sat16i((s1 + 2048 + (8192 << 6)) >> 12)) << (8 * j);
+			pk[fy * 4 + 2] |= clip255(sat16i((s2 + 2048 + (8192 << 6)) >> 12)) << (8 * j);
+			pk[fy * 4 + 3] |= clip255(sat16i((s3 + 2048 + (8192 << 6)) >> 12)) << (8 * j);
 		}
 	}
 #pragma unroll
@@ -120,9 +128,9 @@ __global__ __launch_bounds__(256) void k_subpel_chroma(const int16_t *__restrict
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			const int c = tx + j;
-			pk[0] |= (uint32_t)clip255(in[ty + 1][c + 1]) << (8 * j);
+			pk[0] |= clip255(in[ty + 1][c + 1]) << (8 * j);
 #pragma unroll
-			for (int fx = 1; fx < 8; fx++) pk[fx] |= (uint32_t)clip255((hs[fx - 1][ty + 1][c] + 8192 + 32) >> 6) << (8 * j);
+			for (int fx = 1; fx < 8; fx++) pk[fx] |= clip255((hs[fx - 1][ty + 1][c] + 8192 + 32) >> 6) << (8 * j);
 		}
 #pragma unroll
 		for (int f = 0; f < 8; f++) *(uint32_t *)(out + (size_t)f * elems + li) = pk[f];
@@ -136,11 +144,11 @@ __global__ __launch_bounds__(256) void k_subpel_chroma(const int16_t *__restrict
 		for (int j = 0; j < 4; j++) {
 			const int c = tx + j;
 			const int s0 = in[ty][c + 1] * k0 + in[ty + 1][c + 1] * k1 + in[ty + 2][c + 1] * k2 + in[ty + 3][c + 1] * k3;
-			pk[0] |= (uint32_t)clip255((s0 + 32) >> 6) << (8 * j);
+			pk[0] |= clip255((s0 + 32) >> 6) << (8 * j);
 #pragma unroll
 			for (int fx = 1; fx < 8; fx++) {
 				const int s = hs[fx - 1][ty][c] * k0 + hs[fx - 1][ty + 1][c] * k1 + hs[fx - 1][ty + 2][c] * k2 + hs[fx - 1][ty + 3][c] * k3;
-				pk[fx] |= (uint32_t)clip255(sat16i((s + 2048 + (8192 << 6)) >> 12)) << (8 * j);
+				pk[fx] |= clip255(sat16i((s + 2048 + (8192 << 6)) >> 12)) << (8 * j);
 			}
 		}
 #pragma unroll

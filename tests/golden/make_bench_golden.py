@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Mint bench.py's self-check fixture from the COMPILED REFERENCE (build container only).
+
+bench.py hashes every stream it produces; whatever --steps / --warmup it is run with, the digest after frame k has to be the
+reference's digest after frame k.  For each bench workload this script encodes the synthetic clip once with the reference
+(oracle/_ref/ref_lockstep for one thread; oracle/_ref/ref_ctudump under HOMER_TURNSTILE for one thread per CTU row, with
+engines = E its engine turnstile as well) and records the md5 of the stream's first k access units for every k:
+tests/golden/bench_md5.json  {workload: {"frames": N, "cumulative_md5": [md5 after AU 0, after AU 1, ...]}}.
+
+usage: make_bench_golden.py [workload ...]        (no arguments: all)
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import gen_yuv  # noqa: E402
+
+# name -> (width, height, frames, keys)  - the names are bench.py's WORKLOADS
+CASES = {
+    "cfg2-1080p-encode": (1920, 1080, 40, {"wpp": 17}),
+    "cfg2-1080p-encode-single-thread-order": (1920, 1080, 40, {}),
+    "cfg2-2160p-encode": (3840, 2160, 10, {"wpp": 32}),
+    "cfg2-416x240-encode": (416, 240, 40, {"wpp": 4}),
+}
+
+
+def access_unit_ends(stream):
+    """byte offsets at which the access units of an Annex-B stream end (one slice per picture: an access unit ends with its VCL NAL unit)"""
+    starts, i = [], 0
+    while True:
+        i = stream.find(b"\x00\x00\x01", i)
+        if i < 0:
+            break
+        starts.append((i - 1 if i > 0 and stream[i - 1] == 0 else i, stream[i + 3]))   # (first byte of the start code, first header byte)
+        i += 3
+    ends = []
+    for k, (pos, hdr) in enumerate(starts):
+        if ((hdr >> 1) & 0x3f) < 32:                                                       # VCL
+            ends.append(starts[k + 1][0] if k + 1 < len(starts) else len(stream))
+    return ends
+
+
+def run(width, height, frames, keys):
+    with tempfile.TemporaryDirectory() as tmp:
+        yuv = os.path.join(tmp, "in.yuv")
+        gen_yuv.write_clip(yuv, width, height, frames)
+        turnstile = int(keys.get("wpp", 1)) > 1 or int(keys.get("engines", 1)) > 1
+        cmd = [os.path.join(ROOT, "oracle", "_ref", "ref_ctudump" if turnstile else "ref_lockstep"), yuv, os.path.join(tmp, "out.265"), str(width), str(height), str(frames)]
+        cmd += [f"{k}={v}" for k, v in keys.items()]
+        subprocess.run(cmd, check=True, timeout=7200, stdout=subprocess.DEVNULL, env=dict(os.environ, HOMER_TURNSTILE="1") if turnstile else None)
+        stream = open(os.path.join(tmp, "out.265"), "rb").read()
+    ends = access_unit_ends(stream)
+    assert len(ends) == frames, (len(ends), frames)
+    h, out, pos = hashlib.md5(), [], 0
+    for e in ends:
+        h.update(stream[pos:e])
+        pos = e
+        out.append(h.copy().hexdigest())
+    return {"width": width, "height": height, "frames": frames, "keys": keys, "cumulative_md5": out}
+
+
+if __name__ == "__main__":
+    path = os.path.join(HERE, "bench_md5.json")
+    only = set(sys.argv[1:])
+    out = json.load(open(path)) if os.path.exists(path) else {}
+    for name, (w, h, f, keys) in CASES.items():
+        if only and name not in only:
+            continue
+        out[name] = run(w, h, f, keys)
+        print(name, f, out[name]["cumulative_md5"][-1], flush=True)
+        json.dump(out, open(path, "w"), indent=1)

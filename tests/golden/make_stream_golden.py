@@ -23,10 +23,14 @@ CASES = [
     ("416x240_nosao", 416, 240, 3, {"sao": 0}),
     ("416x240_qp22_perf0", 416, 240, 3, {"qp": 22, "perf": 0}),
     ("328x264_qp38_nosbh", 328, 264, 3, {"qp": 38, "sign_hiding": 0}),
-    ("416x240_intra", 416, 240, 2, {"intra_period": 1}),
+    ("416x240_intra_period1", 416, 240, 2, {"intra_period": 1}),   # the reference clamps intra_period to gop_size + 1 = 2 (hmr_encoder_lib.c:743): I, P
     ("832x480", 832, 480, 3, {}),
     ("1920x1080_cfg2", 1920, 1080, 8, {}),       # BASELINE.json configs[1]
-    ("1280x720_intra", 1280, 720, 2, {"intra_period": 1}),   # configs[0]: 720p all-intra, QP 32, one thread
+    ("1280x720_intra_period1", 1280, 720, 2, {"intra_period": 1}),   # I, P at 720p (see above)
+    # forced intra pictures (encoder_in_out_t.image_type = IMAGE_I on every frame, homer_hevc_enc_api.h:112, honoured hmr_encoder_lib.c:311-313): consecutive I frames
+    ("1280x720_force_intra", 1280, 720, 4, {"force_intra": 1}),   # BASELINE.json configs[0]: 720p all-intra, QP 32, one thread
+    ("416x240_force_intra", 416, 240, 4, {"force_intra": 1}),
+    ("416x240_force_intra_wpp_rows", 416, 240, 4, {"force_intra": 1, "wpp": 4}),
     ("3840x2160_cfg2", 3840, 2160, 2, {}),       # configs[3], one engine's share: the cfg-2 encode at 2160p (I + P)
     ("200x136_scene_cut", 200, 136, 27, {"cut_at": 24}),     # new scene at frame 24: in-frame scene-change detection (hmr_motion_inter.c:3791), frames 25-26 after it
     ("416x240_scene_cut", 416, 240, 25, {"cut_at": 23}),

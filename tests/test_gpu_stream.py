@@ -37,6 +37,7 @@ def encode(lib, case):
     w, h, frames = g["width"], g["height"], g["frames"]
     keys = dict(g["keys"])
     cut_at = keys.pop("cut_at", None)
+    image_type = 3 if keys.pop("force_intra", 0) else 0          # encoder_in_out_t.image_type: IMAGE_I on every frame
     cfg = ec.default_cfg(w, h, **keys)
     enc = C.c_void_p()
     rc = lib.hmr_gpu_enc_create(lib._ctx, C.byref(cfg), C.byref(enc))
@@ -46,7 +47,7 @@ def encode(lib, case):
     nbytes = C.c_long()
     stream, recon, log = b"", [], []
     for f, planes in enumerate(ec.clip_frames(w, h, frames, cut_at)):
-        st = lib.hmr_gpu_enc_encode(enc, *planes, 0, buf, len(buf), C.byref(nbytes), rec)
+        st = lib.hmr_gpu_enc_encode(enc, *planes, image_type, buf, len(buf), C.byref(nbytes), rec)
         assert st in (1, 2), lib.hmr_gpu_last_error()
         stream += buf.raw[:nbytes.value]
         recon.append(hashlib.md5(rec.raw).hexdigest())
@@ -58,7 +59,7 @@ def encode(lib, case):
     return stream, recon
 
 
-@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra", "832x480", "1920x1080_cfg2", "1280x720_intra", "3840x2160_cfg2", "200x136_scene_cut", "416x240_scene_cut", "416x240_wpp_rows", "416x240_scene_cut_wpp_rows", "1920x1080_cfg2_wpp_rows", "832x480_wpp_rows", "416x240_qp22_perf0_wpp_rows", "416x240_nosao_wpp_rows", "328x264_wpp3", "200x136_wpp2", "3840x2160_cfg2_wpp32"])
+@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra_period1", "832x480", "1920x1080_cfg2", "1280x720_intra_period1", "1280x720_force_intra", "416x240_force_intra", "416x240_force_intra_wpp_rows", "3840x2160_cfg2", "200x136_scene_cut", "416x240_scene_cut", "416x240_wpp_rows", "416x240_scene_cut_wpp_rows", "1920x1080_cfg2_wpp_rows", "832x480_wpp_rows", "416x240_qp22_perf0_wpp_rows", "416x240_nosao_wpp_rows", "328x264_wpp3", "200x136_wpp2", "3840x2160_cfg2_wpp32"])
 def test_device_stream_is_byte_identical_to_the_reference(gpu, case):
     stream, recon = encode(gpu, case)
     g = GOLD[case]

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--fixture", default=None, help="teacher-force the reference pictures of this fixture and check the records")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--wpp", type=int, default=1, help="wfpp_num_threads (CTU rows = the row-per-thread schedule)")
     a = ap.parse_args()
     lib = C.CDLL(os.path.join(ROOT, "homerhevc_amd", "libhomer_gpu.so"))
     lib.hmr_gpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
@@ -44,7 +45,7 @@ def main():
     w, h = (int(fx["width"]), int(fx["height"])) if fx is not None else (a.width, a.height)
     frames = min(a.frames, int(fx["frames"])) if fx is not None else a.frames
     nx, ny = (w + 63) // 64, (h + 63) // 64
-    cfg = ec.default_cfg(w, h)
+    cfg = ec.default_cfg(w, h, wpp=a.wpp)
     enc = C.c_void_p()
     assert lib.hmr_gpu_enc_create(ctx, C.byref(cfg), C.byref(enc)) == 0, lib.hmr_gpu_last_error()
     recs = C.create_string_buffer(ec.REC * nx * ny)
