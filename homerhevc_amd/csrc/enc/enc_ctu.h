@@ -197,6 +197,21 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth,
 	{ PRIM_T0(); get_merge_candidates(e, ni, w.merge_cands, inter_modes); PRIM_END(PP_CAND); }
 	for (int cand = 0; cand < S.num_merge_cand; cand++) {
 		int mc_done = 0;
+		// A candidate that repeats candidate 0 (same vector, same reference - the usual case under coherent motion, and always for the zero candidates) cannot win:
+		// its two evaluations recompute what candidate 0's did, bit for bit, and "<" keeps the earlier one.  The reference runs them anyway; what they leave behind
+		// is what candidate 0 left, except that the no-residual evaluation, where it runs (the candidate's coded evaluation - candidate 0's - had levels, or was
+		// itself skipped because the best so far is a skip), resets the node's cbf / transform index / level sum.  Do exactly that and nothing else.
+		if (cand == 1 && w.merge_cands.mv[1].x == w.merge_cands.mv[0].x && w.merge_cands.mv[1].y == w.merge_cands.mv[0].y &&
+		    w.merge_cands.ref_idx[1] == w.merge_cands.ref_idx[0]) {
+			const int coded_runs = !best_is_skip;                                   // (then it rewrites candidate 0's coded result over itself)
+			const int nores_runs = !(coded_runs && merge_cand_buffer[0] == 1);      // merge_cand_buffer[1] would become what merge_cand_buffer[0] is
+			if (nores_runs) {
+				nd.inter_cbf[0] = nd.inter_cbf[1] = nd.inter_cbf[2] = 0;
+				nd.inter_tr_idx = 0;
+				nd.sum = 0;
+			}
+			continue;
+		}
 		for (int no_res = 0; no_res < 2; no_res++) {
 			if (no_res == 1 && merge_cand_buffer[cand] == 1) continue;
 			if (best_is_skip && no_res == 0) continue;
@@ -682,10 +697,8 @@ HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 	if (e.box) {               // the helpers work on this CTU from now on
 		g.sync();
 		if (g.tid == 0) e.box->enc = e;
-		helper_post(g, e, 0, HJOB_NEW_CTU);
-		helper_post(g, e, 1, HJOB_NEW_CTU);
-		helper_wait(g, e, 0);
-		helper_wait(g, e, 1);
+		for (int h = 0; h < NHELP; h++) helper_post(g, e, h, HJOB_NEW_CTU);
+		for (int h = 0; h < NHELP; h++) helper_wait(g, e, h);
 	}
 	PRIM_END(PP_CTU_IO);
 }

@@ -483,19 +483,24 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 	const double weight = is_y ? 1.0 : e.f->chroma_weight;
 	const int off = is_y ? (q.abs_index << 4) : ((q.abs_index << 4) >> 2);
 	const int16_t *pred = pred_ptr(w, comp) + y * cs + x;
-	int16_t *resid = resid_ptr(w, comp) + y * cs + x, *rdec = rdec_ptr(w, comp) + y * cs + x;
+	int16_t *resid = resid_ptr(w, comp) + y * cs + x;
 	int16_t *quant = tq_ptr(w, wnd, comp) + off, *iquant = iq_ptr(w, comp) + off;
 	int16_t *dec = dec_ptr(w, wnd, comp) + y * ds + x;
-	tr_forward(g, e.T, resid, cs, e.scratch_a, e.scratch_b, n, 0);   // stage buffer: the remainder scratch (the reference passes the level window, which the quantiser overwrites anyway; this one is in LDS)
-	int sum = quantize(g, e.T, e.scratch_a, quant, e.scratch_b, SCAN_DIAG, curr_depth, comp, 0, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
+	// The chain runs in the worker's fast memory: coefficients in scratch_a, rounding remainders in scratch_b, the levels in the block's slot of the
+	// dequantised-coefficient buffer (dequantised in place afterwards), the reconstructed residual in scratch_b (the reference's separate window, which
+	// nothing else reads); only the final levels and the reconstruction go to the windows in HBM.
+	int16_t *rdec = e.scratch_b;
+	tr_forward(g, e.ft, resid, cs, e.scratch_a, e.scratch_b, n, 0);
+	int sum = quantize(g, e.ft, e.T, e.scratch_a, iquant, e.scratch_b, SCAN_DIAG, curr_depth, comp, 0, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
 	nd.inter_cbf[comp] = (sum ? 1 : 0) << (original_depth - depth);
 	if (is_y) nd.inter_tr_idx = original_depth - depth;
 	uint32_t ssd;
 	if (sum > 0) {
+		lin_copy_nosync(g, iquant, quant, n * n);
 		const uint32_t raw_zero = blk_ssq(g, resid, cs, n);
-		dequantize(g, e.T, quant, iquant, curr_depth, comp, 0, n, per, rem);
-		tr_inverse(g, e.T, rdec, cs, iquant, e.scratch_a, n, 0);
-		const uint32_t raw = blk_ssd(g, resid, cs, rdec, cs, n);
+		dequantize(g, e.ft, e.T, iquant, iquant, curr_depth, comp, 0, n, per, rem);
+		tr_inverse(g, e.ft, rdec, n, iquant, e.scratch_a, n, 0);
+		const uint32_t raw = blk_ssd(g, resid, cs, rdec, n, n);
 		uint32_t ssd_zero;
 		if (is_y) { ssd_zero = raw_zero; ssd = raw; }
 		else { ssd_zero = (uint32_t)(weight * raw_zero); ssd = (uint32_t)(weight * raw); }
@@ -506,15 +511,30 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 			nd.inter_cbf[comp] = 0;
 			blk_reconst(g, pred, cs, (const int16_t *)nullptr, 0, dec, ds, n);
 		} else {
-			blk_reconst(g, pred, cs, rdec, cs, dec, ds, n);
+			blk_reconst(g, pred, cs, rdec, n, dec, ds, n);
 		}
 	} else {
+		lin_zero_nosync(g, quant, n * n);
 		const uint32_t raw = blk_ssq(g, resid, cs, n);
 		ssd = is_y ? raw : (uint32_t)(weight * raw);
 		blk_reconst(g, pred, cs, (const int16_t *)nullptr, 0, dec, ds, n);
 	}
 	*curr_sum = sum;      // the caller adds the three components up (nd.sum; the reference accumulates it here, :128,:222)
 	return ssd;
+}
+
+// the three components of one TU, one after the other, by whatever group runs it (the whole workgroup in a wide job, enc_common.h)
+template <class G>
+HENC_HD void inter_tu_all_comps(const G &g, Enc &__restrict__ e, int curr, int depth, int part_size_type, int has_chroma, uint32_t *dist, int *sums)
+{
+	dist[0] = encode_inter_tu(g, e, curr, COMP_Y, depth, part_size_type, &sums[0]);
+	dist[1] = dist[2] = 0;
+	sums[1] = sums[2] = 0;
+	if (has_chroma) {
+		dist[1] = encode_inter_tu(g, e, curr, COMP_U, depth, part_size_type, &sums[1]);
+		dist[2] = encode_inter_tu(g, e, curr, COMP_V, depth, part_size_type, &sums[2]);
+	}
+	g.sync();
 }
 
 // SET_ENC_INFO_BUFFS :2451
@@ -585,7 +605,22 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 		curr_depth = e.geo[curr].depth;
 		uint32_t dist_y, dist_u, dist_v;
 		const bool has_chroma = e.geo[curr].size_chroma != 2 || depth_state[curr_depth] == 0;
-		if (has_chroma && e.box) {
+		bool done_wide = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (use_wide(e, e.geo[curr].size)) {
+			// the whole workgroup on this TU: luma, then the chroma planes
+			uint32_t d3[3];
+			int s3[3];
+			wide_post(g, e, HJOB_WIDE_INTER_TU, curr, depth, part_size_type, has_chroma);
+			inter_tu_all_comps(wide_group(e), e, curr, depth, part_size_type, has_chroma, d3, s3);
+			dist_y = d3[0]; curr_sum_y = s3[0];
+			dist_u = d3[1]; dist_v = d3[2];
+			if (has_chroma) { curr_sum_u = s3[1]; curr_sum_v = s3[2]; }
+			done_wide = true;
+		}
+#endif
+		if (done_wide) {
+		} else if (has_chroma && e.box) {
 			// the three components of a TU are independent: the helpers take U and V
 			helper_post(g, e, 0, HJOB_INTER_TU, curr, COMP_U, depth, part_size_type);
 			helper_post(g, e, 1, HJOB_INTER_TU, curr, COMP_V, depth, part_size_type);
@@ -694,6 +729,22 @@ HENC_HD void predict_all_comps(const G &g, Enc &__restrict__ e, int ni)
 		blk_predict(g, w.curr_c[c] + q.yc * 32 + q.xc, 32, w.pred_c[c] + q.yc * 32 + q.xc, 32, w.resid_c[c] + q.yc * 32 + q.xc, 32, q.size_chroma);
 }
 
+// the residual of a CU's three blocks, by the whole workgroup when the CU is large
+template <class G>
+HENC_HD void predict_cu_residual(const G &g, Enc &__restrict__ e, int ni)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (use_wide(e, e.geo[ni].size)) {
+		wide_post(g, e, HJOB_WIDE_PREDICT, ni);
+		const WideGrp wg = wide_group(e);
+		predict_all_comps(wg, e, ni);
+		wg.sync();
+		return;
+	}
+#endif
+	predict_all_comps(g, e, ni);
+}
+
 // predict_inter :2924 (uni-directional): vector predictor choice, motion compensation, residual.  Returns the vector cost.
 template <class G>
 HENC_HD int predict_inter(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
@@ -708,12 +759,14 @@ HENC_HD int predict_inter(const G &g, Enc &__restrict__ e, int depth, int part_p
 		Node &nd = node_of(e, curr);
 		const MV mv = nd.inter_mv;
 		{ PRIM_T0(); get_amvp_candidates(e, curr, e.w->amvp); PRIM_END(PP_CAND); }
-		mv_cost += (int)mv_cost_sqrt(e.w->amvp, nd.qp, mv.x, mv.y, &nd.best_candidate_idx);
+		int best_idx = 0;
+		mv_cost += (int)mv_cost_sqrt(e.w->amvp, nd.qp, mv.x, mv.y, &best_idx);
+		nd.best_candidate_idx = (int8_t)best_idx;
 		nd.best_dif_mv.x = mv.x - e.w->amvp.mv[nd.best_candidate_idx].x;
 		nd.best_dif_mv.y = mv.y - e.w->amvp.mv[nd.best_candidate_idx].y;
 		set_inter_mv_buffs(g, e, curr);
 		motion_compensate_cu(g, e, curr, mv);
-		predict_all_comps(g, e, curr);
+		predict_cu_residual(g, e, curr);
 	}
 	return mv_cost;
 }

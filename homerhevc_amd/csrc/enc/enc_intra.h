@@ -165,10 +165,10 @@ HENC_HD int intra_mode_search(const G &g, Enc &__restrict__ e, int ni, int depth
 	int16_t *pred = w.pred_y + q.y * CTU_STRIDE_Y + q.x;
 	const int16_t *orig = w.curr_y + q.y * CTU_STRIDE_Y + q.x;
 	return intra_search_walk_batched(preds, rd_fast, e.f->sqrt_lambda, [&](const int *modes, int cnt, int64_t *sads) -> bool {
-		// with helper wavefronts: rounds of three candidates, the worker always taking the last one of the round (so that the prediction
+		// with helper wavefronts: rounds of 1 + NHELP candidates, the worker always taking the last one of the round (so that the prediction
 		// left in the window is the one the serial order leaves there); the helpers only return the SAD
 		for (int k0 = 0; k0 < cnt;) {
-			const int take = e.box ? hmin(3, cnt - k0) : 1, mine = k0 + take - 1;
+			const int take = e.box ? hmin(1 + NHELP, cnt - k0) : 1, mine = k0 + take - 1;
 			for (int j = 0; j < take - 1; j++) helper_post(g, e, j, HJOB_INTRA_SAD, ni, n, modes[k0 + j], intra_is_filtered(modes[k0 + j], inv_depth));
 			{
 				const int mode = modes[mine], filt = intra_is_filtered(mode, inv_depth);
@@ -210,8 +210,9 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 	node_fill_refs(g, e, ni, wnd, COMP_Y, filt);
 	intra_predict(g, pred, CTU_STRIDE_Y, filt ? w.adi_f : w.adi, n, cu_mode, 1);
 	blk_predict(g, orig, CTU_STRIDE_Y, pred, CTU_STRIDE_Y, resid, CTU_STRIDE_Y, n);
-	tr_forward(g, e.T, resid, CTU_STRIDE_Y, w.pred_aux, w.delta_u, n, cu_mode != REG_DCT);   // stage buffer: the remainder scratch (the reference passes the level window, which the quantiser overwrites anyway)
-	const int sum = quantize(g, e.T, w.pred_aux, quant, w.delta_u, scan_mode, curr_depth, COMP_Y, 1, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
+	// transform chain in fast memory (see encode_inter_tu): levels in the block's slot of the dequantised-coefficient buffer, to the window in HBM when final
+	tr_forward(g, e.ft, resid, CTU_STRIDE_Y, w.pred_aux, w.delta_u, n, cu_mode != REG_DCT);
+	const int sum = quantize(g, e.ft, e.T, w.pred_aux, iquant, w.delta_u, scan_mode, curr_depth, COMP_Y, 1, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
 	*curr_sum = sum;
 	const int tr = curr_depth - depth + (part_size_type == PART_NxN);
 	nd.sum = (uint32_t)sum;
@@ -219,13 +220,13 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 	nd.intra_tr_idx = tr;
 	nd.intra_mode[COMP_Y] = cu_mode;
 	if (sum) {
-		dequantize(g, e.T, quant, iquant, curr_depth, COMP_Y, 1, n, per, rem);
-		tr_inverse(g, e.T, resid, CTU_STRIDE_Y, iquant, w.pred_aux, n, cu_mode != REG_DCT);
-		blk_reconst(g, pred, CTU_STRIDE_Y, resid, CTU_STRIDE_Y, dec, DEC_STRIDE_Y, n);
-	} else {
-		blk_reconst(g, pred, CTU_STRIDE_Y, (const int16_t *)nullptr, 0, dec, DEC_STRIDE_Y, n);
+		lin_copy_nosync(g, iquant, quant, n * n);
+		dequantize(g, e.ft, e.T, iquant, iquant, curr_depth, COMP_Y, 1, n, per, rem);
+		tr_inverse(g, e.ft, resid, CTU_STRIDE_Y, iquant, w.pred_aux, n, cu_mode != REG_DCT);
+		return blk_reconst_ssd(g, pred, CTU_STRIDE_Y, resid, CTU_STRIDE_Y, orig, CTU_STRIDE_Y, dec, DEC_STRIDE_Y, n);
 	}
-	return blk_ssd(g, orig, CTU_STRIDE_Y, dec, DEC_STRIDE_Y, n);
+	lin_zero_nosync(g, quant, n * n);
+	return blk_reconst_ssd(g, pred, CTU_STRIDE_Y, (const int16_t *)nullptr, 0, orig, CTU_STRIDE_Y, dec, DEC_STRIDE_Y, n);
 }
 
 template <class G>
@@ -288,7 +289,17 @@ HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, i
 		cn.qp = qp;
 		curr_depth = e.geo[curr].depth;
 		int curr_sum = 0;
-		cn.distortion = encode_intra_tu(g, e, curr, depth, cu_mode, part_size_type, &curr_sum);
+		bool done_wide = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (use_wide(e, e.geo[curr].size)) {
+			wide_post(g, e, HJOB_WIDE_INTRA_TU, curr, depth, cu_mode, part_size_type);
+			const WideGrp wg = wide_group(e);
+			cn.distortion = encode_intra_tu(wg, e, curr, depth, cu_mode, part_size_type, &curr_sum);
+			wg.sync();
+			done_wide = true;
+		}
+#endif
+		if (!done_wide) cn.distortion = encode_intra_tu(g, e, curr, depth, cu_mode, part_size_type, &curr_sum);
 		cn.sum = (uint32_t)curr_sum;
 		cn.cost = cn.distortion;
 		depth_state[curr_depth]++;
@@ -401,19 +412,31 @@ HENC_HD int chroma_tu_comp(const G &g, Enc &__restrict__ e, int curr, int c, int
 	node_fill_refs(g, e, curr, dwnd, c, 0);
 	intra_predict(g, pred, CTU_STRIDE_C, e.adi_c, n, cu_mode, 0);
 	blk_predict(g, orig, CTU_STRIDE_C, pred, CTU_STRIDE_C, resid, CTU_STRIDE_C, n);
-	tr_forward(g, e.T, resid, CTU_STRIDE_C, e.scratch_a, e.scratch_b, n, 0);
-	const int curr_sum = quantize(g, e.T, e.scratch_a, quant, e.scratch_b, scan_mode, curr_depth, c, 1, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
+	tr_forward(g, e.ft, resid, CTU_STRIDE_C, e.scratch_a, e.scratch_b, n, 0);
+	const int curr_sum = quantize(g, e.ft, e.T, e.scratch_a, iquant, e.scratch_b, scan_mode, curr_depth, c, 1, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
 	const int cbfv = ((curr_sum ? 1 : 0) << (shifts & 255)) | ((curr_sum ? 1 : 0) << (shifts >> 8));
 	bytes_set(g, &w.cbf_chroma[c - 1][q.abs_index], cbfv, q.num_part);
+	uint32_t raw;
 	if (curr_sum) {
-		dequantize(g, e.T, quant, iquant, curr_depth, c, 1, n, per, rem);
-		tr_inverse(g, e.T, resid, CTU_STRIDE_C, iquant, e.scratch_a, n, 0);
-		blk_reconst(g, pred, CTU_STRIDE_C, resid, CTU_STRIDE_C, dec, DEC_STRIDE_C, n);
+		lin_copy_nosync(g, iquant, quant, n * n);
+		dequantize(g, e.ft, e.T, iquant, iquant, curr_depth, c, 1, n, per, rem);
+		tr_inverse(g, e.ft, resid, CTU_STRIDE_C, iquant, e.scratch_a, n, 0);
+		raw = blk_reconst_ssd(g, pred, CTU_STRIDE_C, resid, CTU_STRIDE_C, orig, CTU_STRIDE_C, dec, DEC_STRIDE_C, n);
 	} else {
-		blk_reconst(g, pred, CTU_STRIDE_C, (const int16_t *)nullptr, 0, dec, DEC_STRIDE_C, n);
+		lin_zero_nosync(g, quant, n * n);
+		raw = blk_reconst_ssd(g, pred, CTU_STRIDE_C, (const int16_t *)nullptr, 0, orig, CTU_STRIDE_C, dec, DEC_STRIDE_C, n);
 	}
 	*curr_sum_out = curr_sum;
-	return (int)(e.f->chroma_weight * blk_ssd(g, orig, CTU_STRIDE_C, dec, DEC_STRIDE_C, n));
+	return (int)(e.f->chroma_weight * raw);
+}
+
+// both chroma planes of a TU, one after the other, by whatever group runs it (a wide job: the whole workgroup)
+template <class G>
+HENC_HD void chroma_tu_both(const G &g, Enc &__restrict__ e, int curr, int cu_mode, int scan_mode, int shifts, int per, int rem, int *pc, int *cs)
+{
+	pc[0] = chroma_tu_comp(g, e, curr, COMP_U, cu_mode, scan_mode, shifts, per, rem, &cs[0]);
+	pc[1] = chroma_tu_comp(g, e, curr, COMP_V, cu_mode, scan_mode, shifts, per, rem, &cs[1]);
+	g.sync();
 }
 
 // encode_intra_chroma, hmr_motion_intra_chroma.c:114-469 (non-HM path, rd_mode != RD_FULL)
@@ -522,7 +545,16 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth,
 			{
 				int cs[2], pc[2];
 				const int shifts = (original_depth - depth + nxn) | ((curr_depth - depth + nxn) << 8);
-				if (e.box) {
+				bool done_wide = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+				if (use_wide(e, 2 * n)) {
+					wide_post(g, e, HJOB_WIDE_CHROMA_TU, curr, cu_mode, scan_mode, shifts, per | (rem << 8));
+					chroma_tu_both(wide_group(e), e, curr, cu_mode, scan_mode, shifts, per, rem, pc, cs);
+					done_wide = true;
+				}
+#endif
+				if (done_wide) {
+				} else if (e.box) {
 					helper_post(g, e, 0, HJOB_CHROMA_TU, curr, COMP_U, cu_mode, scan_mode, shifts, per | (rem << 8));
 					pc[1] = chroma_tu_comp(g, e, curr, COMP_V, cu_mode, scan_mode, shifts, per, rem, &cs[1]);
 					helper_wait(g, e, 0);

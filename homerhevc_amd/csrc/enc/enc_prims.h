@@ -198,6 +198,32 @@ HENC_PRIM void blk_reconst(const G &g, const int16_t *p, int ps, const int16_t *
 	PRIM_END(PP_BLK);
 }
 
+// reconstruction and its distance from the source in one pass (the reference reconstructs, then reads the window back for ssd16b, hmr_motion_intra.c:1061-1068)
+template <class G>
+HENC_PRIM uint32_t blk_reconst_ssd(const G &g, const int16_t *p, int ps, const int16_t *res, int rs, const int16_t *o, int os, int16_t *d, int ds, int n)
+{
+	PRIM_T0();
+	const int l = ilog2i(n);
+	uint32_t acc = 0;
+#pragma unroll 2
+	for (int i = g.tid * 4; i < n * n; i += g.n * 4) {
+		const int y = i >> l, x = i & (n - 1);
+		const S4 vp = ld4(p + y * ps + x), vo = ld4(o + y * os + x);
+		S4 vr = {{0, 0, 0, 0}}, vd;
+		if (res) vr = ld4(res + y * rs + x);
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			vd.v[k] = (int16_t)hclip((int)sat16(vp.v[k] + vr.v[k]), 0, 255);
+			const int32_t df = (int16_t)(vo.v[k] - vd.v[k]);
+			acc += (uint32_t)(df * df);
+		}
+		st4(d + y * ds + x, vd);
+	}
+	const uint32_t s = g.sum(acc);
+	g.sync();
+	{ const auto prim_ret_ = s; PRIM_END(PP_BLK); return prim_ret_; }
+}
+
 template <class G>
 HENC_PRIM void blk_copy(const G &g, const int16_t *s, int ss, int16_t *d, int ds, int h, int w)
 {
@@ -261,6 +287,22 @@ HENC_PRIM void lin_copy(const G &g, const int16_t *s, int16_t *d, int count)
 	lin_copy_bytes(g, s, d, count * 2);
 	g.sync();
 	PRIM_END(PP_BLK);
+}
+
+// the same without the closing sync: stores to a window nobody reads before the chain's next sync (the levels of a TU on their way to HBM)
+template <class G>
+HENC_PRIM void lin_copy_nosync(const G &g, const int16_t *s, int16_t *d, int count)
+{
+	lin_copy_bytes(g, s, d, count * 2);
+}
+template <class G>
+HENC_PRIM void lin_zero_nosync(const G &g, int16_t *d, int count)
+{
+	if ((((uintptr_t)d | (uintptr_t)(count * 2)) & 7) == 0) {
+		const S4 z = {{0, 0, 0, 0}};
+		for (int i = g.tid * 4; i < count; i += g.n * 4) st4(d + i, z);
+	} else
+		for (int i = g.tid; i < count; i += g.n) d[i] = 0;
 }
 
 template <class G>
@@ -638,6 +680,67 @@ HENC_PRIM void interp_stage(const G &g, const int16_t *src, int ss, int16_t *dst
 	PRIM_END(PP_INTERP);
 }
 
+// ---- the constant tables a TU needs, next to the worker ------------------------------------------------------------------
+// The transform bases, the coefficient scans and the quantiser lists are read by every TU of every candidate; DevTables keeps them in HBM (1.2 MB with every
+// list at every size and QP remainder), where each use costs an L2 round trip in the middle of a dependent chain.  A row worker keeps what it can use in LDS:
+//   * the four DCT bases + DST, plain and transposed, densely packed;
+//   * the scans as 16-bit positions: horizontal / vertical / diagonal for 4x4 and 8x8, diagonal only for 16x16 and 32x32 (find_scan_mode gives nothing else there);
+//   * the quantiser / dequantiser lists of ONE QP (the frame's, luma and chroma remainder): the default scaling lists are 8x8 matrices replicated over larger
+//     blocks (tables.cpp, HOMER_enc_init), so two 64-entry lists (intra, inter) per remainder class, the flat value of 4x4 blocks / DC of the replicated sizes.
+// A TU whose QP is not the cached one falls back to DevTables.
+struct alignas(16) FastTables {
+	int16_t dct[16 + 64 + 256 + 1024], dct_t[16 + 64 + 256 + 1024];   // [log2N - 2] at offsets 0, 16, 80, 336
+	int16_t dst4[16], dst4_t[16];
+	uint16_t scan4[3][16], scan8[3][64], scan16[256], scan32[1024];    // [scan_mode - 1]
+	uint16_t q8[2][2][64], iq8[2][2][64];                               // [luma / chroma remainder][intra / inter list][8x8 cell]
+	uint16_t q_flat[2], iq_flat[2];
+	int32_t rem[2], valid;
+};
+HENC_INLINE int ft_dct_offset(int log2n) { return log2n == 2 ? 0 : (log2n == 3 ? 16 : (log2n == 4 ? 80 : 336)); }
+HENC_INLINE const uint16_t *ft_scan(const FastTables &F, int scan_mode, int log2n)
+{
+	return log2n == 2 ? F.scan4[scan_mode - 1] : (log2n == 3 ? F.scan8[scan_mode - 1] : (log2n == 4 ? F.scan16 : F.scan32));
+}
+// the list (0 intra, 1 inter) behind DevTables::quant[log2n - 2][list]: tables.cpp, hmr_tables.c default scaling lists (32x32 has its own rule)
+HENC_INLINE int ft_list_kind(int log2n, int list) { return log2n == 5 ? (list != 0) : (list >= 3); }
+// element i of an n x n list from its 8x8 cells (n >= 8; DC of the replicated sizes and every 4x4 entry: the flat value)
+HENC_INLINE uint32_t ft_list_value(const uint16_t *cells, uint32_t flat, int i, int log2n)
+{
+	if (log2n == 2 || (i == 0 && log2n > 3)) return flat;
+	const int s = log2n - 3, y = i >> log2n, x = i & ((1 << log2n) - 1);
+	return cells[((y >> s) << 3) | (x >> s)];
+}
+template <class G>
+HENC_HD void fast_tables_fill(const G &g, FastTables &F, const DevTables *T, int rem_y, int rem_c)
+{
+	for (int l = 2; l <= 5; l++) {
+		const int n = 1 << l, o = ft_dct_offset(l);
+		for (int i = g.tid; i < n * n; i += g.n) { F.dct[o + i] = T->dct[l - 2][i]; F.dct_t[o + i] = T->dct_t[l - 2][i]; }
+	}
+	for (int i = g.tid; i < 16; i += g.n) { F.dst4[i] = T->dst4[i]; F.dst4_t[i] = T->dst4_t[i]; }
+	for (int m = 1; m <= 3; m++) {
+		for (int i = g.tid; i < 16; i += g.n) F.scan4[m - 1][i] = (uint16_t)T->scan[m][2][i];
+		for (int i = g.tid; i < 64; i += g.n) F.scan8[m - 1][i] = (uint16_t)T->scan[m][3][i];
+	}
+	for (int i = g.tid; i < 256; i += g.n) F.scan16[i] = (uint16_t)T->scan[SCAN_DIAG][4][i];
+	for (int i = g.tid; i < 1024; i += g.n) F.scan32[i] = (uint16_t)T->scan[SCAN_DIAG][5][i];
+	for (int c = 0; c < 2; c++) {
+		const int rem = c ? rem_c : rem_y;
+		for (int k = 0; k < 2; k++)
+			for (int i = g.tid; i < 64; i += g.n) {
+				F.q8[c][k][i] = (uint16_t)T->quant[1][k ? 3 : 0][rem][i];       // the 8x8 lists themselves
+				F.iq8[c][k][i] = (uint16_t)T->dequant[1][k ? 3 : 0][rem][i];
+			}
+		if (g.tid == 0) {
+			F.q_flat[c] = (uint16_t)T->quant[0][0][rem][0];
+			F.iq_flat[c] = (uint16_t)T->dequant[0][0][rem][0];
+			F.rem[c] = rem;
+		}
+	}
+	if (g.tid == 0) F.valid = 1;
+	g.sync();
+}
+
 // ---- transforms (hmr_sse42_functions_transform.c:1670,1700; spec hmr_transform.c:133-549) ---------------------------
 // Every stage is out[k][j] = sat16((sum_i B[k][i] * in[j][i] + rnd) >> shift) with both operand rows contiguous: a lane keeps "its" input
 // row in registers as packed pairs and walks the basis rows with 16-byte loads and two-way dot products (v_dot2_i32_i16 on the device).
@@ -732,27 +835,27 @@ HENC_HD void tr_inverse_n(const G &g, const int16_t *Mt, int16_t *block, int bs,
 }
 
 template <class G>
-HENC_PRIM void tr_forward(const G &g, const DevTables *T, const int16_t *block, int bs, int16_t *coeff, int16_t *tmp, int n, int is_dst)
+HENC_PRIM void tr_forward(const G &g, const FastTables *F, const int16_t *block, int bs, int16_t *coeff, int16_t *tmp, int n, int is_dst)
 {
 	PRIM_T0();
 	switch (n) {
-	case 4: tr_forward_n<4>(g, is_dst ? T->dst4 : T->dct[0], block, bs, coeff, tmp); break;
-	case 8: tr_forward_n<8>(g, T->dct[1], block, bs, coeff, tmp); break;
-	case 16: tr_forward_n<16>(g, T->dct[2], block, bs, coeff, tmp); break;
-	default: tr_forward_n<32>(g, T->dct[3], block, bs, coeff, tmp); break;
+	case 4: tr_forward_n<4>(g, is_dst ? F->dst4 : F->dct, block, bs, coeff, tmp); break;
+	case 8: tr_forward_n<8>(g, F->dct + 16, block, bs, coeff, tmp); break;
+	case 16: tr_forward_n<16>(g, F->dct + 80, block, bs, coeff, tmp); break;
+	default: tr_forward_n<32>(g, F->dct + 336, block, bs, coeff, tmp); break;
 	}
 	PRIM_END(PP_TRF);
 }
 
 template <class G>
-HENC_PRIM void tr_inverse(const G &g, const DevTables *T, int16_t *block, int bs, const int16_t *coeff, int16_t *tmp, int n, int is_dst)
+HENC_PRIM void tr_inverse(const G &g, const FastTables *F, int16_t *block, int bs, const int16_t *coeff, int16_t *tmp, int n, int is_dst)
 {
 	PRIM_T0();
 	switch (n) {
-	case 4: tr_inverse_n<4>(g, is_dst ? T->dst4_t : T->dct_t[0], block, bs, coeff, tmp); break;
-	case 8: tr_inverse_n<8>(g, T->dct_t[1], block, bs, coeff, tmp); break;
-	case 16: tr_inverse_n<16>(g, T->dct_t[2], block, bs, coeff, tmp); break;
-	default: tr_inverse_n<32>(g, T->dct_t[3], block, bs, coeff, tmp); break;
+	case 4: tr_inverse_n<4>(g, is_dst ? F->dst4_t : F->dct_t, block, bs, coeff, tmp); break;
+	case 8: tr_inverse_n<8>(g, F->dct_t + 16, block, bs, coeff, tmp); break;
+	case 16: tr_inverse_n<16>(g, F->dct_t + 80, block, bs, coeff, tmp); break;
+	default: tr_inverse_n<32>(g, F->dct_t + 336, block, bs, coeff, tmp); break;
 	}
 	PRIM_END(PP_TRI);
 }
@@ -766,7 +869,8 @@ struct SbhGroup {
 	uint32_t pos[16];
 	int16_t lv[16], sv[16], du[16];
 };
-HENC_INLINE bool sbh_gather(SbhGroup &q, const int16_t *dst, const int16_t *src, const int16_t *du, const uint32_t *scan, int cg)
+template <class ScanT>
+HENC_INLINE bool sbh_gather(SbhGroup &q, const int16_t *dst, const int16_t *src, const int16_t *du, const ScanT *scan, int cg)
 {
 	int any = 0;
 #pragma unroll
@@ -815,23 +919,54 @@ HENC_INLINE void sbh_apply(const SbhGroup &q, int16_t *dst, bool is_last_cg)
 	dst[min_pos] = (int16_t)(min_sv >= 0 ? min_lv + final_change : min_lv - final_change);
 }
 
-// returns ac_sum (the sum of the levels BEFORE sign hiding, as the reference reports it)
+// the sign-hiding pass over the coefficient groups of a block (after the levels are visible to the group)
+template <class G, class ScanT>
+HENC_HD void sbh_pass(const G &g, const int16_t *src, int16_t *dst, const int16_t *delta_u, const ScanT *scan, int total)
+{
+	const int ngroups = total >> 4;
+	// the last group holding a level (in scan order) starts its walk at its last level
+	if (G::n >= 64) {
+		// one group per lane: gather once, find the last non-empty group with a ballot, apply where there is anything to hide a sign in
+		SbhGroup q;
+		const int cg = g.tid;
+		const bool nz = cg < ngroups && sbh_gather(q, dst, src, delta_u, scan, cg);
+		const uint64_t mask = g.ballot(nz);
+		const int last_cg = mask ? 63 - __builtin_clzll(mask) : -1;
+		if (nz) sbh_apply(q, dst, cg == last_cg);
+	} else {
+		SbhGroup q;
+		int last_cg = -1;
+		for (int cg = g.tid; cg < ngroups; cg += g.n)
+			if (sbh_gather(q, dst, src, delta_u, scan, cg)) last_cg = cg;
+		for (int cg = g.tid; cg < ngroups; cg += g.n)
+			if (sbh_gather(q, dst, src, delta_u, scan, cg)) sbh_apply(q, dst, cg == last_cg);
+	}
+	g.sync();
+}
+
+// returns ac_sum (the sum of the levels BEFORE sign hiding, as the reference reports it).  src / dst / delta_u are the worker's (fast memory); the lists and
+// the scan come from F when it caches this QP remainder, else from T.
 template <class G>
-HENC_PRIM int quantize(const G &g, const DevTables *T, const int16_t *src, int16_t *dst, int16_t *delta_u, int scan_mode, int depth, int comp,
+HENC_PRIM int quantize(const G &g, const FastTables *F, const DevTables *T, const int16_t *src, int16_t *dst, int16_t *delta_u, int scan_mode, int depth, int comp,
 		     int is_intra, int slice_is_intra, int sign_hiding, int n, int per, int rem)
 {
 	PRIM_T0();
 	const int inv_depth = 6 - (depth + (comp != 0));
-	const int32_t *q = T->quant[inv_depth - 2][(is_intra ? 0 : 3) + comp][rem];
+	const int list = (is_intra ? 0 : 3) + comp, rc = comp != 0;
+	const bool fast = F && F->valid && F->rem[rc] == rem;
 	const int qbits = 14 + per + (15 - 8 - inv_depth), qbits8 = qbits - 8;
 	const int32_t add = (int32_t)((uint32_t)(slice_is_intra ? 171 : 85) << (qbits - 9));
 	const int total = n * n;
 	uint32_t sum = 0;
+	const int32_t *q = T->quant[inv_depth - 2][list][rem];
+	const uint16_t *cells = fast ? F->q8[rc][ft_list_kind(inv_depth, list)] : nullptr;
+	const uint32_t flat = fast ? F->q_flat[rc] : 0;
 	#pragma unroll 4
 	for (int i = g.tid; i < total; i += g.n) {
 		const int sv = src[i];
 		const uint32_t a = (uint16_t)(sv < 0 ? -sv : sv);
-		const int32_t aux = (int32_t)(a * (uint32_t)q[i]);
+		const uint32_t qv = fast ? ft_list_value(cells, flat, i, inv_depth) : (uint32_t)q[i];
+		const int32_t aux = (int32_t)(a * qv);
 		const int32_t c = (int32_t)((uint32_t)aux + (uint32_t)add) >> qbits;
 		const int32_t d = (int32_t)((uint32_t)aux - ((uint32_t)c << qbits)) >> qbits8;
 		const int sgn = sv > 0 ? 1 : (sv < 0 ? -1 : 0);
@@ -842,44 +977,37 @@ HENC_PRIM int quantize(const G &g, const DevTables *T, const int16_t *src, int16
 	const int ac_sum = (int)g.sum(sum);
 	g.sync();
 	if (sign_hiding && ac_sum >= 2) {
-		const uint32_t *scan = T->scan[scan_mode][inv_depth];
-		const int ngroups = total >> 4;
-		// the last group holding a level (in scan order) starts its walk at its last level
-		if (G::n >= 64) {
-			// one group per lane: gather once, find the last non-empty group with a ballot, apply where there is anything to hide a sign in
-			SbhGroup q;
-			const int cg = g.tid;
-			const bool nz = cg < ngroups && sbh_gather(q, dst, src, delta_u, scan, cg);
-			const uint64_t mask = g.ballot(nz);
-			const int last_cg = mask ? 63 - __builtin_clzll(mask) : -1;
-			if (nz) sbh_apply(q, dst, cg == last_cg);
-		} else {
-			SbhGroup q;
-			int last_cg = -1;
-			for (int cg = g.tid; cg < ngroups; cg += g.n)
-				if (sbh_gather(q, dst, src, delta_u, scan, cg)) last_cg = cg;
-			for (int cg = g.tid; cg < ngroups; cg += g.n)
-				if (sbh_gather(q, dst, src, delta_u, scan, cg)) sbh_apply(q, dst, cg == last_cg);
-		}
-		g.sync();
+		if (fast) sbh_pass(g, src, dst, delta_u, ft_scan(*F, scan_mode, inv_depth), total);
+		else sbh_pass(g, src, dst, delta_u, T->scan[scan_mode][inv_depth], total);
 	}
 	{ const auto prim_ret_ = ac_sum; PRIM_END(PP_QUANT); return prim_ret_; }
 }
 
+// src == dst is allowed (element-wise)
 template <class G>
-HENC_PRIM void dequantize(const G &g, const DevTables *T, const int16_t *src, int16_t *dst, int depth, int comp, int is_intra, int n, int per, int rem)
+HENC_PRIM void dequantize(const G &g, const FastTables *F, const DevTables *T, const int16_t *src, int16_t *dst, int depth, int comp, int is_intra, int n, int per, int rem)
 {
 	PRIM_T0();
 	const int inv_depth = 6 - (depth + (comp != 0));
-	const int32_t *iq = T->dequant[inv_depth - 2][is_intra ? 0 : 3 + comp][rem];
+	const int list = is_intra ? 0 : 3 + comp, rc = comp != 0;      // (the reference's expression: intra blocks of every component use list 0)
+	const bool fast = F && F->valid && F->rem[rc] == rem;
+	const int32_t *iq = T->dequant[inv_depth - 2][list][rem];
+	const uint16_t *cells = fast ? F->iq8[rc][ft_list_kind(inv_depth, list)] : nullptr;
+	const uint32_t flat = fast ? F->iq_flat[rc] : 0;
 	const int iq_shift = 20 - 14 - (15 - 8 - inv_depth) + 4, total = n * n;
 	if (iq_shift > per) {
 		const int32_t add = 1 << (iq_shift - per - 1);
 		const int sh = iq_shift - per;
-		for (int i = g.tid; i < total; i += g.n) dst[i] = sat16((int32_t)((uint32_t)(int32_t)src[i] * (uint32_t)iq[i] + (uint32_t)add) >> sh);
+		for (int i = g.tid; i < total; i += g.n) {
+			const uint32_t v = fast ? ft_list_value(cells, flat, i, inv_depth) : (uint32_t)iq[i];
+			dst[i] = sat16((int32_t)((uint32_t)(int32_t)src[i] * v + (uint32_t)add) >> sh);
+		}
 	} else {
 		const int sh = per - iq_shift;
-		for (int i = g.tid; i < total; i += g.n) dst[i] = sat16((int32_t)(((uint32_t)(int32_t)src[i] * (uint32_t)iq[i]) << sh));
+		for (int i = g.tid; i < total; i += g.n) {
+			const uint32_t v = fast ? ft_list_value(cells, flat, i, inv_depth) : (uint32_t)iq[i];
+			dst[i] = sat16((int32_t)(((uint32_t)(int32_t)src[i] * v) << sh));
+		}
 	}
 	g.sync();
 	PRIM_END(PP_DEQUANT);

@@ -50,17 +50,25 @@ struct Geo {
 	int16_t child[4];
 };
 
-// dynamic part of cu_partition_info_t
+// a motion vector as a partition node keeps it: vectors come out of a search of +-128 x +-64 samples (or are copied from a neighbour), so 16 bits hold them
+struct MV16 {
+	int16_t x, y;
+	HENC_INLINE operator MV() const { MV m = {x, y}; return m; }
+	HENC_INLINE MV16 &operator=(const MV &m) { x = (int16_t)m.x; y = (int16_t)m.y; return *this; }
+};
+
+// dynamic part of cu_partition_info_t (hmr_private.h:738-790), packed: 341 of these per CTU live in the row worker's LDS and travel to HBM and back with every CTU
 struct Node {
 	uint8_t left_nb, top_nb, left_bottom_nb, top_right_nb;
-	uint8_t tl_inside, b_inside, r_inside, pad_;
-	uint32_t qp, sum, distortion, cost;
-	int32_t prediction_mode, inter_mode, merge_flag, merge_idx, skipped;
-	int32_t intra_cbf[3], intra_tr_idx, intra_mode[3];
-	int32_t inter_cbf[3], inter_tr_idx;
-	MV inter_mv, subpix_mv, best_dif_mv;     // list 0 (P slices; B slices are outside the built configurations)
-	int32_t best_candidate_idx, inter_ref_index;
+	uint8_t tl_inside, b_inside, r_inside, qp;
+	uint32_t sum, distortion, cost;
+	uint8_t prediction_mode, inter_mode, merge_flag, merge_idx, skipped;
+	uint8_t intra_cbf[3], intra_tr_idx, intra_mode[3];
+	uint8_t inter_cbf[3], inter_tr_idx;
+	int8_t best_candidate_idx, inter_ref_index;
+	MV16 inter_mv, subpix_mv, best_dif_mv;     // list 0 (P slices; B slices are outside the built configurations)
 };
+static_assert(sizeof(Node) == 52, "Node layout");
 
 struct SaoOffset {                         // sao_offset_t, hmr_private.h:463-476
 	int32_t mode_idc, type_idc, type_aux;
@@ -123,6 +131,8 @@ struct Seq {
 	int32_t src_stride_y, src_stride_c;
 	// elements of one padded plane (stride x (rows + 2 margins)): the pitch between the phase planes of the reference (FrameCtx::sub_y / sub_c)
 	int32_t plane_elems_y, plane_elems_c;
+	int32_t wide_min_n;                    // device: smallest block side the row worker and its helpers work on together (enc_common.h: wide jobs)
+	int32_t pad_;
 };
 
 struct FrameCtx {

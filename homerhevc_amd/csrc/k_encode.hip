@@ -61,16 +61,19 @@ __device__ __forceinline__ void wave_copy_words(void *dst, const void *src, int 
 constexpr int HSCRATCH_ELEMS = 2048 + 144;   // int16 per helper
 // LDS of a row worker: its Work, a copy of the CTU's partition nodes and of the partition geometry
 constexpr size_t LDS_WORK = (sizeof(Work) + 15) & ~(size_t)15, LDS_NODES = (sizeof(Node) * NNODES + 15) & ~(size_t)15, LDS_GEO = (sizeof(Geo) * NNODES + 15) & ~(size_t)15;
-constexpr size_t LDS_SEQ = (sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15, LDS_CTU = (sizeof(CtuPublic) + 15) & ~(size_t)15;
+constexpr size_t LDS_SEQ = (sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15, LDS_CTU = (sizeof(CtuPublic) + 15) & ~(size_t)15, LDS_FT = (sizeof(FastTables) + 15) & ~(size_t)15;
 #if defined(HENC_PROFILE)
-constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = 2 * HSCRATCH_ELEMS * 2;
+constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = NHELP * HSCRATCH_ELEMS * 2;
 constexpr size_t LDS_BYTES = 160 * 1024;   // the primitive timers sit at HENC_LDS_PROF_OFFSET
-static_assert(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH <= HENC_LDS_PROF_OFFSET, "profile table overlaps the worker state");
+constexpr size_t LDS_FT_OFFSET = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH;
+static_assert(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH + LDS_FT <= HENC_LDS_PROF_OFFSET, "profile table overlaps the worker state");
 #else
-constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = 2 * HSCRATCH_ELEMS * 2;   // per helper: 2 x 1024 coefficients (a 32 x 32 chroma TU) + a chroma neighbour array
-constexpr size_t LDS_BYTES = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH;
+constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = NHELP * HSCRATCH_ELEMS * 2;   // per helper: 2 x 1024 coefficients (a 32 x 32 chroma TU) + a chroma neighbour array
+constexpr size_t LDS_BYTES = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH + LDS_FT;
+constexpr size_t LDS_FT_OFFSET = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH;
 #endif
-constexpr int ENC_THREADS = 192;   // the row worker + two helper wavefronts
+constexpr int ENC_THREADS = 64 * (1 + NHELP);   // the row worker + its helper wavefronts: one wavefront per SIMD of the CU
+static_assert(ENC_THREADS == WideGrp::n, "a wide job is the whole workgroup");
 static_assert(LDS_BYTES <= 160 * 1024, "a workgroup has 160 KiB of LDS on gfx950");
 
 // a helper wavefront: run the jobs the worker posts (HelperBox, enc_common.h) until it says quit
@@ -78,12 +81,15 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 {
 	WaveGrp g{(int)(threadIdx.x & 63)};
 	Enc e = {};   // (a context struct shared in LDS instead of one per lane in private memory was tried: the kernel hangs, cause not found)
+	Enc ew = {};  // the worker's own context (its scratch, not this helper's): what a wide job runs on
 	for (int seq = 1;; seq++) {
 		while (__hip_atomic_load(&box->cmd[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) {}
 		const int job = box->job[h];
 		if (job == HJOB_QUIT) return;
 		if (job == HJOB_NEW_CTU) {
 			e = box->enc;
+			ew = e;
+			ew.box = nullptr;
 			e.box = nullptr;
 			e.scratch_a = scratch;
 			e.scratch_b = scratch + 1024;
@@ -93,6 +99,32 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 		const int *a = box->a[h];
 		uint32_t r0 = 0, r1 = 0;
 		switch (job) {
+		case HJOB_WIDE_INTER_TU: {
+			uint32_t dist[3];
+			int sums[3];
+			const WideGrp wg{(int)threadIdx.x, &box->xch[0][0], 0};
+			inter_tu_all_comps(wg, ew, a[0], a[1], a[2], a[3], dist, sums);
+			break;
+		}
+		case HJOB_WIDE_PREDICT: {
+			const WideGrp wg{(int)threadIdx.x, &box->xch[0][0], 0};
+			predict_all_comps(wg, ew, a[0]);
+			wg.sync();
+			break;
+		}
+		case HJOB_WIDE_INTRA_TU: {
+			int cs = 0;
+			const WideGrp wg{(int)threadIdx.x, &box->xch[0][0], 0};
+			(void)encode_intra_tu(wg, ew, a[0], a[1], a[2], a[3], &cs);
+			wg.sync();
+			break;
+		}
+		case HJOB_WIDE_CHROMA_TU: {
+			int cs[2], pc[2];
+			const WideGrp wg{(int)threadIdx.x, &box->xch[0][0], 0};
+			chroma_tu_both(wg, ew, a[0], a[1], a[2], a[3], a[4] & 255, a[4] >> 8, pc, cs);
+			break;
+		}
 		case HJOB_INTER_TU: {
 			int sum = 0;
 			r0 = encode_inter_tu(g, e, a[0], a[1], a[2], a[3], &sum);
@@ -157,7 +189,7 @@ __device__ __forceinline__ void release_helpers(int *hseq)
 	extern __shared__ __align__(16) uint8_t lds[];
 	HelperBox *box = (HelperBox *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU);
 	if ((threadIdx.x & 63) == 0)
-		for (int h = 0; h < 2; h++) {
+		for (int h = 0; h < NHELP; h++) {
 			box->job[h] = HJOB_QUIT;
 			__hip_atomic_store(&box->cmd[h], ++hseq[h], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
@@ -183,6 +215,9 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 	if (g.tid == 0) lw->slow = d.work_slow + row;
 	g.sync();
 	if (g.tid == 0) lframe->scene_cut_ctu = d.counters[2];
+	// the transform bases, scans and this frame's quantiser lists next to the worker (enc_prims.h: FastTables)
+	FastTables *lft = (FastTables *)(lds + LDS_FT_OFFSET);
+	fast_tables_fill(g, *lft, d.tables, lframe->qp % 6, chroma_qp_table(lframe->qp + S.chroma_qp_offset) % 6);
 #if defined(HENC_PROFILE)
 	if (g.tid < 2 * PP_COUNT) ((unsigned long long *)(lds + HENC_LDS_PROF_OFFSET))[g.tid] = 0;
 #endif
@@ -191,6 +226,7 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 	e.seq = lseq;
 	e.f = lframe;
 	e.T = d.tables;
+	e.ft = lft;
 	e.geo = lgeo;
 	e.ctus = d.ctus;
 	e.ctu = nullptr;
@@ -200,7 +236,7 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 	e.ctu_g = nullptr;
 	e.ctu_fast = (CtuPublic *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ);
 	e.box = box;
-	e.hseq[0] = hseq[0]; e.hseq[1] = hseq[1];
+	for (int h = 0; h < NHELP; h++) e.hseq[h] = hseq[h];
 	e.prof = d.prof ? d.prof + (size_t)row * PF_COUNT : nullptr;
 	e.timeline = nullptr;
 	uint32_t *my_prefix = d.prefix + (size_t)row * (W + 1);
@@ -281,7 +317,7 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 			g.sync();
 			if (g.tid == 0) __hip_atomic_store(&d.progress[row], c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 		}
-		hseq[0] = e.hseq[0]; hseq[1] = e.hseq[1];
+		for (int h = 0; h < NHELP; h++) hseq[h] = e.hseq[h];
 		if (g.tid == 0) atomicAdd(&d.counters[1], W);
 #if defined(HENC_PROFILE)
 		if (g.tid == 0 && e.prof) {
@@ -358,7 +394,7 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 		g.sync();
 		if (g.tid == 0) __hip_atomic_store(&d.progress[row], c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 	}
-	hseq[0] = e.hseq[0]; hseq[1] = e.hseq[1];
+	for (int h = 0; h < NHELP; h++) hseq[h] = e.hseq[h];
 	if (g.tid == 0 && encodes) atomicAdd(&d.counters[1], encodes);
 #if defined(HENC_PROFILE)
 	if (g.tid == 0 && e.prof) {
@@ -366,6 +402,194 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 		for (int k = 0; k < 2 * PP_COUNT; k++) e.prof[PF_PRIM0 + k] += pp[k];
 	}
 #endif
+}
+
+// ---- The row-per-thread schedule as a pool of CTU tasks ---------------------------------------------------------------------------------------------------
+// In the synchronous wavefront (enc_sched.h) the CTUs of step t = c + 2 row of a picture may start when all its CTUs of step t - 1 are done, and nothing else
+// orders them.  With one workgroup nailed to each CTU row, a step lasts as long as its slowest CTU and the other rows' CUs wait (46 % of the row workers' time
+// at 1080p, profiles/r03_history.md).  Here the CTUs are tasks instead: a persistent workgroup (row worker + helpers, as before) claims the next CTU of ANY
+// picture of the launch whose step is open, encodes it and closes the step when it was the step's last.  What a CTU needs from "its thread" - the mode buffers
+// the reference's WPP thread carries along its rows - travels through EncDev::rowstate; everything else in Work is scratch (checked by wiping it between CTUs,
+// oracle/enc_cpu.cpp HENC_WIPE_WORK).  No workgroup ever waits for a CTU that is not already running (the one exception - a step's CTUs wait for thread 0's
+// scene-change check - is claimed first in its step), so the launch needs no co-residency: any number of workgroups makes progress.
+struct PoolSeq {
+	int *cur_step;      // the open step of the picture
+	int *ticket;        // [steps] CTUs of the step handed out
+	int *done;          // [steps] CTUs of the step finished
+};
+constexpr int POOL_MAX_STEPS = 192;             // W + 2 (H - 1) for 64 x 34 CTUs and more
+constexpr int POOL_STRIDE = 1 + 2 * POOL_MAX_STEPS;
+
+// rows of step t: r_lo .. r_hi (empty when r_lo > r_hi)
+__device__ __forceinline__ void pool_step_rows(int t, int W, int H, int *r_lo, int *r_hi)
+{
+	const int lo = t - W + 1;
+	*r_lo = lo <= 0 ? 0 : (lo + 1) >> 1;
+	*r_hi = (t >> 1) < H - 1 ? (t >> 1) : H - 1;
+}
+
+__device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const WaveGrp &g, Seq *lseq, FrameCtx *lframe, FastTables *lft, int t, int row, int *cached_rem)
+{
+	const Seq &S = *lseq;
+	const int W = S.wctu, H = S.hctu;
+	const int T = d.threads, me = row % T, c = t - 2 * row, n = row * W + c;
+	// counters as of the end of step t - 1
+	uint32_t ti = 0, tc = 0;
+	for (int r2 = g.tid; r2 < H; r2 += 64) {
+		const int have = t - 2 * r2 < 0 ? 0 : (t - 2 * r2 < W ? t - 2 * r2 : W);
+		ti += d.prefix[(size_t)r2 * (W + 1) + have];
+		tc += (uint32_t)have;
+	}
+	ti = g.sum(ti);
+	tc = g.sum(tc);
+	// the mode buffers of the thread that owns this row, as the CTU before left them (this row's, or the last one of row - T)
+	wave_copy_words(&e.w->intra_mode_buffs[0][0][0], d.rowstate + (size_t)me * MODE_STATE_BYTES, MODE_STATE_BYTES, g.tid);
+	const int rem_y = lframe->qp % 6, rem_c = chroma_qp_table(lframe->qp + S.chroma_qp_offset) % 6;
+	if (cached_rem[0] != rem_y || cached_rem[1] != rem_c) {
+		fast_tables_fill(g, *lft, d.tables, rem_y, rem_c);
+		cached_rem[0] = rem_y; cached_rem[1] = rem_c;
+	}
+	g.sync();
+	const int hrow = t / (2 * T) * T;   // thread 0's row that is inside the picture at this step, if any
+	if (row == hrow) {
+		if (g.tid == 0) {
+			if (d.counters[2] < 0 && lframe->slice_type == SLICE_P && scene_cut_fires(S, *lframe, ti, tc * NPART)) d.counters[2] = n;
+			__hip_atomic_store(d.row0_checked, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	} else if (hrow < H && t - 2 * hrow < W) {
+		while (__hip_atomic_load(d.row0_checked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t + 1) __builtin_amdgcn_s_sleep(8);
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	}
+	g.sync();
+	if (g.tid == 0) lframe->scene_cut_ctu = __hip_atomic_load(&d.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	g.sync();
+	wave_copy_words(e.w->mode_in, e.w->intra_mode_buffs, MODE_STATE_BYTES, g.tid);
+	e.total_intra_partitions = ti;
+	e.total_partitions = tc * NPART;
+	e.coeff = d.coeff + (size_t)n * 6144;
+	g.sync();
+	encode_ctu(g, e, n);
+	resolve_mode_tokens(g, *e.w, d.ctus[n]);
+	wave_copy_words(d.outtok + (size_t)n * MODE_STATE_BYTES, e.w->intra_mode_buffs, MODE_STATE_BYTES, g.tid);
+	wave_copy_words(d.rowstate + (size_t)me * MODE_STATE_BYTES, &e.w->intra_mode_buffs[0][0][0], MODE_STATE_BYTES, g.tid);
+	if (g.tid == 0) {
+		uint32_t *my_prefix = d.prefix + (size_t)row * (W + 1);
+		my_prefix[c + 1] = my_prefix[c] + d.ctus[n].intra_parts;
+		atomicAdd(&d.counters[1], 1);
+	}
+	g.sync();
+}
+
+__global__ __launch_bounds__(ENC_THREADS) void k_encode_pool(const EncDev *devs, int nseq, int *state, int *finished, WorkSlow *slow)
+{
+	if (!rows_enter()) return;
+	extern __shared__ __align__(16) uint8_t lds[];
+	WaveGrp g{(int)(threadIdx.x & 63)};
+	Work *lw = (Work *)lds;
+	Geo *lgeo = (Geo *)(lds + LDS_WORK + LDS_NODES);
+	HelperBox *box = (HelperBox *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU);
+	Seq *lseq = (Seq *)(lds + LDS_WORK + LDS_NODES + LDS_GEO);
+	FrameCtx *lframe = (FrameCtx *)((uint8_t *)lseq + ((sizeof(Seq) + 15) & ~(size_t)15));
+	FastTables *lft = (FastTables *)(lds + LDS_FT_OFFSET);
+	for (int i = g.tid; i < (int)(sizeof(Geo) * NNODES / 2); i += 64) ((uint16_t *)lgeo)[i] = ((const uint16_t *)devs[0].geo)[i];   // (the same tree for every encoder: 64 x 64 CTUs)
+	if (g.tid == 0) lw->slow = slow + blockIdx.x;
+#if defined(HENC_PROFILE)
+	if (g.tid < 2 * PP_COUNT) ((unsigned long long *)(lds + HENC_LDS_PROF_OFFSET))[g.tid] = 0;
+#endif
+	g.sync();
+	Enc e;
+	e.seq = lseq;
+	e.f = lframe;
+	e.ft = lft;
+	e.geo = lgeo;
+	e.ctu = nullptr;
+	e.w = lw;
+	e.nodes = nullptr;
+	e.nodes_fast = (Node *)(lds + LDS_WORK);
+	e.ctu_g = nullptr;
+	e.ctu_fast = (CtuPublic *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ);
+	e.box = box;
+	for (int h = 0; h < NHELP; h++) e.hseq[h] = 0;
+	e.prof = nullptr;
+	e.timeline = nullptr;
+	int cached_rem[2] = {-1, -1}, cached_q = -1;
+	int start = (int)(blockIdx.x % (unsigned)nseq);
+	for (;;) {
+		// look for a picture with an open step that still has CTUs to hand out: 64 pictures at a time, one per lane
+		int q = -1, t = 0, k = 0;
+		bool all_finished = true;
+		for (int base = 0; base < nseq && q < 0; base += 64) {
+			const int i = base + g.tid, cand = i < nseq ? (start + i) % nseq : -1;
+			int ct = -1;
+			bool open = false;
+			if (cand >= 0) {
+				const int *st = state + (size_t)cand * POOL_STRIDE;
+				const EncDev &dd = devs[cand];
+				const int W = dd.seq->wctu, H = dd.seq->hctu, steps = W + 2 * (H - 1);
+				ct = __hip_atomic_load(&st[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (ct < steps) {
+					all_finished = false;
+					int r_lo, r_hi;
+					pool_step_rows(ct, W, H, &r_lo, &r_hi);
+					open = __hip_atomic_load(&st[1 + ct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < r_hi - r_lo + 1;
+				}
+			}
+			if (g.any(!all_finished)) all_finished = false;
+			const uint64_t m = g.ballot(open);
+			if (m) {
+				const int lane = __builtin_ctzll(m);
+				const int qq = __builtin_amdgcn_readlane(cand, lane), tt = __builtin_amdgcn_readlane(ct, lane);
+				int kk = 0;
+				if (g.tid == 0) kk = atomicAdd(&state[(size_t)qq * POOL_STRIDE + 1 + tt], 1);
+				kk = __builtin_amdgcn_readfirstlane(kk);
+				const EncDev &dd = devs[qq];
+				int r_lo, r_hi;
+				pool_step_rows(tt, dd.seq->wctu, dd.seq->hctu, &r_lo, &r_hi);
+				if (kk < r_hi - r_lo + 1) { q = qq; t = tt; k = kk; }
+				else base -= 64;                     // somebody else took the last one: look again from the same place
+			}
+		}
+		if (q < 0) {
+			if (all_finished && __hip_atomic_load(finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nseq) break;
+			__builtin_amdgcn_s_sleep(32);
+			continue;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (the step was opened with a release store after its predecessors' results)
+		const EncDev d = devs[q];
+		if (q != cached_q) {
+			for (int i = g.tid; i < (int)(sizeof(Seq) / 4); i += 64) ((uint32_t *)lseq)[i] = ((const uint32_t *)d.seq)[i];
+			for (int i = g.tid; i < (int)(sizeof(FrameCtx) / 4); i += 64) ((uint32_t *)lframe)[i] = ((const uint32_t *)d.frame)[i];
+			cached_q = q;
+			g.sync();
+		}
+		e.T = d.tables;
+		e.ctus = d.ctus;
+		const int W = lseq->wctu, H = lseq->hctu;
+		// the k-th CTU of the step: the row of thread 0 first (it makes the scene-change check the others of the step wait for), then the rest top down
+		int r_lo, r_hi;
+		pool_step_rows(t, W, H, &r_lo, &r_hi);
+		const int hrow = t / (2 * d.threads) * d.threads;
+		const bool hvalid = hrow >= r_lo && hrow <= r_hi;
+		int row;
+		if (hvalid) row = k == 0 ? hrow : (r_lo + k - 1 < hrow ? r_lo + k - 1 : r_lo + k);
+		else row = r_lo + k;
+		pool_encode_ctu(d, e, g, lseq, lframe, lft, t, row, cached_rem);
+		// close the step when this was its last CTU
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		if (g.tid == 0) {
+			int *st = state + (size_t)q * POOL_STRIDE;
+			const int dn = atomicAdd(&st[1 + POOL_MAX_STEPS + t], 1) + 1;
+			if (dn == r_hi - r_lo + 1) {
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (the other finishers' results happen before the step is declared closed)
+				__hip_atomic_store(&st[0], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+				if (t + 1 == W + 2 * (H - 1)) atomicAdd(finished, 1);
+			}
+		}
+		start = (q + 1) % nseq;
+	}
+	int hseq[NHELP];
+	for (int h = 0; h < NHELP; h++) hseq[h] = e.hseq[h];
+	release_helpers(hseq);
 }
 
 // the true chains in raster order: threads 0..255 one unit column of the mode buffers each, thread 256 the intra counter
@@ -461,7 +685,7 @@ struct SrcSlot {
 __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
 {
 	if (!rows_enter()) return;
-	int hseq[2] = {0, 0};
+	int hseq[NHELP] = {0, 0, 0};
 	encode_row(d, pass, (int)blockIdx.x, hseq);
 	release_helpers(hseq);
 }
@@ -474,7 +698,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus_batch(const EncDev 
 {
 	if (!rows_enter()) return;
 	const int grp = (int)blockIdx.x / hmax, row = (int)blockIdx.x % hmax;
-	int hseq[2] = {0, 0};
+	int hseq[NHELP] = {0, 0, 0};
 	for (int q = grp; q < nseq; q += groups) {
 		const EncDev d = devs[q];
 		if (row < d.seq->hctu) encode_row(d, -1, row, hseq);
@@ -599,6 +823,9 @@ struct hmr_gpu_enc {
 	uint8_t *d_stage = nullptr, *h_stage = nullptr;      // batch: the side-info records and levels of all sequences, on the device and page-locked on the host
 	size_t stage_bytes = 0;
 	void *d_batch = nullptr;                             // hmr_gpu_enc_encode_batch (lead encoder): the sequences' EncDev records and first rows
+	int *d_pool_state = nullptr;                         // k_encode_pool: per picture of the launch the open step and the steps' ticket / done counters, then the finished-pictures counter
+	WorkSlow *d_pool_slow = nullptr;                     // the pool workers' transform / decoded windows
+	int pool_workers = 0;
 	EntropyState es;
 	int cur, lockstep;
 	float last_ms, last_total_ms;
@@ -694,6 +921,7 @@ int ctu_stage_prepare(hmr_gpu_enc *e)
 	if (e->lockstep) {
 		HIP_TRY(hipMemsetAsync(e->d.progress, 0, sizeof(int) * s.hctu, st));
 		HIP_TRY(hipMemsetAsync(e->d.row0_checked, 0, sizeof(int), st));
+		HIP_TRY(hipMemsetAsync(e->d.prefix, 0, sizeof(uint32_t) * s.hctu * (s.wctu + 1), st));
 	}
 	return HMR_GPU_OK;
 }
@@ -710,6 +938,31 @@ int lockstep_collect(hmr_gpu_enc *e)
 	return HMR_GPU_OK;
 }
 
+// the row-per-thread schedule of n pictures (their EncDev records already at lead->d_batch) as ONE pool launch on `st`
+int launch_pool(hmr_gpu_enc *lead, int n, int rows_total, hipStream_t st)
+{
+	if (!lead->n_cus) HIP_TRY(hipDeviceGetAttribute(&lead->n_cus, hipDeviceAttributeMultiprocessorCount, lead->ctx->device));
+	const int workers = rows_total < lead->n_cus ? rows_total : lead->n_cus;     // a worker takes a CU's LDS; a picture never has more CTUs in flight than rows
+	if (!lead->d_pool_state) HIP_TRY(hipMalloc((void **)&lead->d_pool_state, sizeof(int) * (256 * POOL_STRIDE + 4)));
+	if (lead->pool_workers < workers) {
+		if (lead->d_pool_slow) (void)hipFree(lead->d_pool_slow);
+		lead->d_pool_slow = nullptr;
+		lead->pool_workers = 0;
+		HIP_TRY(hipMalloc((void **)&lead->d_pool_slow, sizeof(WorkSlow) * workers));
+		HIP_TRY(hipMemsetAsync(lead->d_pool_slow, 0, sizeof(WorkSlow) * workers, st));
+		lead->pool_workers = workers;
+	}
+	HIP_TRY(hipMemsetAsync(lead->d_pool_state, 0, sizeof(int) * (256 * POOL_STRIDE + 4), st));
+	hipLaunchKernelGGL(k_encode_pool, dim3(workers), dim3(ENC_THREADS), LDS_BYTES, st, (const EncDev *)lead->d_batch, n, lead->d_pool_state, lead->d_pool_state + 256 * POOL_STRIDE,
+			   lead->d_pool_slow);
+	const hipError_t launched = hipGetLastError();
+	if (launched != hipSuccess) {
+		hmr_set_error("k_encode_pool: %s", hipGetErrorString(launched));
+		return HMR_GPU_ERR_HIP;
+	}
+	return HMR_GPU_OK;
+}
+
 // the CTU decisions of the frame set up in e->f / e->d_frame: passes until the check finds nothing wrong
 int run_ctu_passes(hmr_gpu_enc *e)
 {
@@ -719,14 +972,19 @@ int run_ctu_passes(hmr_gpu_enc *e)
 	if (rc) return rc;
 	HIP_TRY(hipEventRecord(e->ctx->ev0, st));
 	if (e->lockstep) {
-		// wfpp_num_threads = CTU rows: the synchronous wavefront, one launch, nothing to verify
-		const int cus = g_cu_budget.acquire(e->ctx->device, s.hctu);
-		if (getenv("HENC_FORCE_BATCH_KERNEL")) {   // debugging aid: the batch launch's kernel for this one sequence (same rows, same result expected)
+		// wfpp_num_threads > 1: the synchronous wavefront, one launch, nothing to verify - the picture's CTUs as a pool of tasks (k_encode_pool)
+		if (!getenv("HENC_ROW_WORKERS")) {
 			if (!e->d_batch) HIP_TRY(hipMalloc((void **)&e->d_batch, 256 * sizeof(EncDev)));
 			HIP_TRY(hipMemcpyAsync(e->d_batch, &e->d, sizeof(EncDev), hipMemcpyHostToDevice, st));
-			hipLaunchKernelGGL(k_encode_ctus_batch, dim3(s.hctu), dim3(ENC_THREADS), LDS_BYTES, st, (const EncDev *)e->d_batch, 1, 1, s.hctu);
-		} else
-			hipLaunchKernelGGL(k_encode_ctus, dim3(s.hctu), dim3(ENC_THREADS), LDS_BYTES, st, e->d, -1);
+			if ((rc = launch_pool(e, 1, s.hctu, st))) return rc;
+			HIP_TRY(hipEventRecord(e->ctx->ev1, st));
+			if ((rc = lockstep_collect(e))) return rc;      // (waits for the launch)
+			HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ctx->ev0, e->ctx->ev1));
+			return HMR_GPU_OK;
+		}
+		// (kept for comparison, HENC_ROW_WORKERS=1: one workgroup per CTU row, rows waiting for each other at every step - needs all of them resident)
+		const int cus = g_cu_budget.acquire(e->ctx->device, s.hctu);
+		hipLaunchKernelGGL(k_encode_ctus, dim3(s.hctu), dim3(ENC_THREADS), LDS_BYTES, st, e->d, -1);
 		const hipError_t launched = hipGetLastError();
 		if (launched == hipSuccess) (void)hipEventRecord(e->ctx->ev1, st);
 		rc = launched == hipSuccess ? lockstep_collect(e) : HMR_GPU_ERR_HIP;      // (waits for the launch)
@@ -815,6 +1073,7 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 		delete e;
 		return HMR_GPU_ERR_ARG;
 	}
+	e->seq.wide_min_n = getenv("HENC_WIDE_MIN") ? atoi(getenv("HENC_WIDE_MIN")) : 0;   // blocks from this size on are worked on by the whole workgroup; measured on MI355X (1080p, one sequence): 32 -> no gain, 16 -> 8 % slower, so off by default (profiles/r03_history.md)
 	const Seq &s = e->seq;
 	HIP_TRY(hipSetDevice(ctx->device));
 	e->geo.resize(NNODES);
@@ -835,6 +1094,7 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 	DEV_ALLOC(e->d.work_slow, s.hctu);
 	HIP_TRY(hipFuncSetAttribute((const void *)k_encode_ctus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
 	HIP_TRY(hipFuncSetAttribute((const void *)k_encode_ctus_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+	HIP_TRY(hipFuncSetAttribute((const void *)k_encode_pool, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
 	HIP_TRY(hipEventCreate(&e->ev_frame));
 	HIP_TRY(hipEventCreate(&e->ev_ready));
 	HIP_TRY(hipEventCreate(&e->ev_batch0));
@@ -912,6 +1172,8 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	if (e->ev_batch0) (void)hipEventDestroy(e->ev_batch0);
 	if (e->ev_batch1) (void)hipEventDestroy(e->ev_batch1);
 	if (e->d_batch) (void)hipFree(e->d_batch);
+	if (e->d_pool_state) (void)hipFree(e->d_pool_state);
+	if (e->d_pool_slow) (void)hipFree(e->d_pool_slow);
 	if (e->d_stage) (void)hipFree(e->d_stage);
 	if (e->h_stage) (void)hipHostFree(e->h_stage);
 	void *p[] = {e->d_seq, e->d_frame, e->d_geo, e->d.ctus, e->d.ctus_start, e->d.work_slow, e->d.coeff, e->d.progress, e->d.prefix, e->d.prof, e->d.guess, e->d.truth, e->d.outtok,
@@ -1197,20 +1459,15 @@ extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *sl
 		HIP_TRY(hipDeviceGetAttribute(&lead->n_cus, hipDeviceAttributeMultiprocessorCount, lead->ctx->device));
 	}
 
-	int hmax = 1;
-	for (int i = 0; i < n; i++) hmax = encs[i]->seq.hctu > hmax ? encs[i]->seq.hctu : hmax;
-	int groups = lead->n_cus / hmax;
-	groups = groups < 1 ? 1 : (groups > n ? n : groups);
+	int rows_total = 0;
+	for (int i = 0; i < n; i++) rows_total += encs[i]->seq.hctu;
 	HIP_TRY(hipMemcpyAsync(lead->d_batch, devs.data(), n * sizeof(EncDev), hipMemcpyHostToDevice, bst));
 	HIP_TRY(hipEventRecord(lead->ev_batch0, bst));
-	const int cus = g_cu_budget.acquire(lead->ctx->device, groups * hmax);
-	hipLaunchKernelGGL(k_encode_ctus_batch, dim3(groups * hmax), dim3(ENC_THREADS), LDS_BYTES, bst, (const EncDev *)lead->d_batch, n, groups, hmax);
-	const hipError_t launched = hipGetLastError();
-	if (launched == hipSuccess) (void)hipEventRecord(lead->ev_batch1, bst);
+	if ((rc = launch_pool(lead, n, rows_total, bst))) return rc;
+	(void)hipEventRecord(lead->ev_batch1, bst);
 	const hipError_t waited = hipStreamSynchronize(bst);
-	g_cu_budget.release(lead->ctx->device, cus);
-	if (launched != hipSuccess || waited != hipSuccess) {
-		hmr_set_error("k_encode_ctus_batch: %s", hipGetErrorString(launched != hipSuccess ? launched : waited));
+	if (waited != hipSuccess) {
+		hmr_set_error("k_encode_pool: %s", hipGetErrorString(waited));
 		return HMR_GPU_ERR_HIP;
 	}
 	float ms = 0;

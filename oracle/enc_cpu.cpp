@@ -50,6 +50,7 @@ struct Cpu {
 	uint32_t acc_dist = 0;
 	uint32_t intra_parts = 0, total_parts = 0;
 	EntropyState es;
+	FastTables ft;      // the worker's copy of the tables a TU reads (enc_prims.h), refreshed per frame
 	// speculative row-parallel schedule (enc_sched.h), emulated: sched = 0 raster order, 1 wavefront with guesses + verification
 	int sched = 0, row_guess = 0;          // row_guess: 0 = the truth of the previous frame, 1 = the row above after its second CTU
 	std::vector<CtuInfo> ctus_start;
@@ -440,6 +441,8 @@ int henc_cpu_frame_ctus(void *h, const uint8_t *y, const uint8_t *u, const uint8
 	e.seq = &c.seq;
 	e.f = &c.f;
 	e.T = hmr_host_tables();
+	fast_tables_fill(CpuGrp(), c.ft, e.T, c.f.qp % 6, chroma_qp_table(c.f.qp + c.seq.chroma_qp_offset) % 6);
+	e.ft = &c.ft;
 	e.geo = c.geo;
 	e.ctus = c.ctus.data();
 	e.w = c.w;
@@ -511,6 +514,8 @@ int henc_cpu_frame_ctus_wavefront(void *h, const uint8_t *y, const uint8_t *u, c
 	Enc e;
 	memset(&e, 0, sizeof e);
 	e.seq = &c.seq; e.f = &c.f; e.T = hmr_host_tables(); e.geo = c.geo; e.ctus = c.ctus.data();
+	fast_tables_fill(CpuGrp(), c.ft, e.T, c.f.qp % 6, chroma_qp_table(c.f.qp + c.seq.chroma_qp_offset) % 6);
+	e.ft = &c.ft;
 	CpuGrp g;
 	const int mb_off = REC_BYTES - 2560, pm_off = 32 + 768 + 512 + 256 * 4;
 	std::vector<uint32_t> intra_prefix(s.nctu + 1, 0);
