@@ -23,6 +23,7 @@ enum { PF_SETUP = 0, PF_MERGE, PF_ME_INT, PF_ME_SUB, PF_PRED_INTER, PF_ENC_INTER
 
 namespace henc {
 
+constexpr int NHELP_MAX = 3;
 struct Enc {
 	unsigned long long *prof;   // PF_COUNT accumulators of this worker (profiling build), else unused
 	FastPtr<const Seq> seq;
@@ -49,7 +50,7 @@ struct Enc {
 	int mc_tmp_y_stride;
 	FastPtr<int16_t> mc_tmp_c;           // first-stage buffer of a two-stage chroma interpolation: Work::sub_tmp, or a helper's own
 	FastPtr<int16_t> scratch_a, scratch_b;   // transform coefficients / rounding remainders of the TU in flight: Work::pred_aux / delta_u, or a helper's own
-	int hseq[3];
+	int hseq[NHELP_MAX];
 };
 
 // Two helper wavefronts per row worker take the chroma components of a step whose three components are independent (motion compensation, the
@@ -59,13 +60,13 @@ struct Enc {
 // then the worker enters the same function; the chain's own barriers keep them together, nothing is waited for afterwards.
 enum { HJOB_NONE = 0, HJOB_NEW_CTU, HJOB_INTER_TU, HJOB_INTRA_SAD, HJOB_SYNC_CU, HJOB_SSD, HJOB_CHROMA_SEARCH, HJOB_CHROMA_TU, HJOB_WIDE_INTER_TU, HJOB_WIDE_INTRA_TU,
        HJOB_WIDE_CHROMA_TU, HJOB_WIDE_PREDICT, HJOB_QUIT };
-constexpr int NHELP = 3;
+constexpr int NHELP = 2;   // (a third helper was measured: 3 % slower - one more wavefront polling its mailbox, nothing for it to do most of the time)
 struct HelperBox {
 	int cmd[NHELP], done[NHELP];   // sequence numbers: helper h runs its next job when cmd[h] moves on, and sets done[h] = cmd[h] when finished
 	int job[NHELP];
 	int a[NHELP][8];
 	uint32_t r[NHELP][8];
-	uint32_t xch[2][4];            // WideGrp's reduction exchange
+	uint32_t xch[2][4];            // WideGrp's reduction exchange ([2][WIDE_WAVES] used)
 	Enc enc;                       // the worker's context, refreshed at every CTU start
 };
 

@@ -487,6 +487,7 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 	int curr_depth = 0, parent = 0, curr = 0;
 	const int initial_depth = 0, initial_position = 0;
 	depth_state[0] = initial_position;
+	e.w->thread_seen_intra = 1;   // (every lane stores the same value) hmr_motion_intra.c:1783: from now on this thread's shadow CTU reads "intra"
 	while (curr_depth != initial_depth || depth_state[curr_depth] != initial_position + 1) {
 		const Geo &q = e.geo[curr];
 		Node *nd = &node_of(e, curr);

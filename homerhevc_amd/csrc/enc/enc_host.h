@@ -171,10 +171,18 @@ inline int host_chroma_qp(int qpi)
 }
 
 // sequence-level state the engine thread carries from frame to frame
+// Engines (num_enc_engines = E > 1, encoder_engine_thread hmr_encoder_lib.c:3043-3330): frames are dealt to E engines that overlap in the reference, with a
+// timing-dependent result; what is built is the interleaving oracle/ref_ctudump.c's engine turnstile pins on it - frame n sees the complete reconstruction
+// of frame n - 1 and the frame-typing state of the single-engine run, starts from the avg_dist frame n - E left behind (zero for the first E frames), and
+// works on the persistent state (CTU records, WPP thread mode buffers) of engine n mod E.  The frames may overlap as far as reference rows allow: none of
+// that changes.  HostState is everything that travels from frame to frame besides the pictures; with one engine per GPU it is sent along with them.
 struct HostState {
 	int poc = 0, last_intra = 0, last_gop_reinit = 0, num_encoded_frames = 0;
 	double avg_dist = 0.0;          // hvenc->avg_dist: calloc'ed, so the first frame runs with 0 (hmr_encoder_lib.c:3191)
+	double avg_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // hvenc->avg_dist after each of the last eight frames
+	int engines = 1, pad_ = 0;
 };
+constexpr int MAX_ENGINES = 8;       // hmr_private.h:1232
 
 enum { IMG_AUTO = 0, IMG_B = 1, IMG_P = 2, IMG_I = 3 };
 
@@ -198,7 +206,7 @@ inline void begin_frame(const Seq &s, HostState &st, int image_type, FrameCtx &f
 	f.wctu = s.wctu;
 	f.scene_cut_allowed = f.slice_type == SLICE_P && st.num_encoded_frames > 1 && 20 < poc - st.last_gop_reinit;
 	f.ref_poc = poc - 1;
-	f.avg_dist = st.avg_dist;
+	f.avg_dist = st.num_encoded_frames >= st.engines ? st.avg_hist[(st.num_encoded_frames - st.engines) & 7] : 0.0;   // one engine: the frame before
 	const double qp_temp = (double)s.qp - 12;
 	const double lambda_scale = 1.0 - fmin(fmax(0.05 * (double)(s.gop_size - 1), 0.0), 0.5);
 	double qp_factor = 0.4624;
@@ -229,6 +237,7 @@ inline void end_frame(const Seq &s, HostState &st, const FrameCtx &f, uint32_t a
 		else if (scene_change) a *= 1.375;
 		st.avg_dist = a;
 	}
+	st.avg_hist[st.num_encoded_frames & 7] = st.avg_dist;    // (an I frame inside the sequence keeps the value pushed by the frame before it, :3268-3279)
 	st.num_encoded_frames++;
 }
 

@@ -75,10 +75,10 @@ HENC_INLINE void intra_neighbour_dirs(Enc &__restrict__ e, int ni, int depth, in
 	CtuPublic *cl = pu_left(e, ni, &idx);
 	dirs[0] = dirs[1] = DC_IDX;
 	src[0] = src[1] = DC_IDX;
-	if (cl == e.ctu) dirs[0] = read_mode_buff(e, depth, idx, &src[0]);
+	if (cl == e.ctu) { if (e.w->thread_seen_intra) dirs[0] = read_mode_buff(e, depth, idx, &src[0]); }   // (else: the shadow CTU says "not intra" -> DC)
 	else if (cl) src[0] = (uint16_t)(dirs[0] = cl->pred_mode[idx] == PM_INTRA ? cl->intra_mode[COMP_Y][idx] : DC_IDX);
 	CtuPublic *ct = pu_top(e, ni, &idx, 1);
-	if (ct == e.ctu) dirs[1] = read_mode_buff(e, depth, idx, &src[1]);
+	if (ct == e.ctu) { if (e.w->thread_seen_intra) dirs[1] = read_mode_buff(e, depth, idx, &src[1]); }
 	else if (ct) src[1] = (uint16_t)(dirs[1] = ct->pred_mode[idx] == PM_INTRA ? ct->intra_mode[COMP_Y][idx] : DC_IDX);
 }
 

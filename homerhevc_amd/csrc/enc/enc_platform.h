@@ -68,10 +68,10 @@ struct WaveGrp {
 };
 
 // The row worker and its helper wavefronts working on ONE block together (k_encode.hip, enc_common.h: wide jobs).  The decision walk is a serial chain, but
-// at 32 x 32 a block primitive is bound by what one wavefront can issue (sixteen samples per lane and pass); spread over the four SIMDs of the CU it is four.
+// at 32 x 32 a block primitive is bound by what one wavefront can issue (sixteen samples per lane and pass); spread over the workgroup's wavefronts (one per SIMD) it is that many times fewer.
 // Same SPMD code: tid runs over the whole workgroup, sync() is the workgroup barrier, reductions combine the wavefronts' totals through a small exchange
 // buffer in LDS (two slots, used alternately: one barrier per reduction).
-constexpr int WIDE_WAVES = 4;
+constexpr int WIDE_WAVES = 3;   // = 1 + NHELP (enc_common.h)
 struct WideGrp {
 	int tid;
 	uint32_t *xch;              // [2][WIDE_WAVES] in LDS (HelperBox)

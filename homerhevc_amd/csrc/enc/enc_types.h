@@ -188,6 +188,11 @@ struct Work {
 #endif
 	MvCandList amvp, merge_cands, search_cands;
 	WorkSlow *slow;
+	// Part of the WPP thread's state next to the mode buffers: has this thread ever taken the intra walk?  The reference's thread keeps a shadow CTU whose
+	// pred_mode array is set to INTRA by motion_intra_cu (hmr_motion_intra.c:1783) and never cleared; the most-probable-mode look-up of the mode search reads
+	// it (homer_loop1_motion_intra :1102-1104).  With one engine every thread has been through the first (intra) frame; the threads of a second engine start
+	// on a P frame and see "not intra" -> DC for neighbours inside the CTU until an intra frame or a scene change comes their way.
+	int32_t thread_seen_intra;
 };
 
 HENC_INLINE int16_t *wnd_y(int16_t *base) { return base; }

@@ -46,6 +46,7 @@ struct EncDev {
 	unsigned long long *hash;     // [nctu] digest of what other CTUs can see of a CTU
 	uint32_t *intra_before, *used_intra, *used_parts;   // [nctu] true intra count before the CTU; the counters it was given
 	uint8_t *rowstate;            // [hctu][MODE_STATE_BYTES] lockstep schedule: the mode buffers of the worker of each CTU row, carried from frame to frame
+	int *thread_seen;             // [threads] lockstep schedule: has the WPP thread ever taken the intra walk (Work::thread_seen_intra)
 	int *row0_checked;            // lockstep schedule: steps for which row 0 has made its scene-change check
 	int *counters;                // [0] CTUs found wrong by the last check, [1] CTU encodes of the frame, [2] the CTU at which a scene change is detected (-1: none)
 	int threads;                  // lockstep schedule: wfpp_num_threads (row r is encoded by thread r % threads)
@@ -284,6 +285,7 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 			if (c == 0) {
 				// (the barrier above has seen the last CTU of row - T, whose worker stored these before it published that CTU)
 				wave_copy_words(&e.w->intra_mode_buffs[0][0][0], d.rowstate + (size_t)me * MODE_STATE_BYTES, MODE_STATE_BYTES, g.tid);
+				if (g.tid == 0) e.w->thread_seen_intra = d.thread_seen[me];
 				g.sync();
 			}
 			const int hrow = t / (2 * T) * T;   // thread 0's row that is inside the picture at this step, if any
@@ -313,7 +315,10 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 #if defined(HENC_PROFILE)
 			if (g.tid == 0 && d.prof) d.prof[(size_t)H * PF_COUNT + 4 * n + 3] = wall_clock64();
 #endif
-			if (c == W - 1) wave_copy_words(d.rowstate + (size_t)me * MODE_STATE_BYTES, &e.w->intra_mode_buffs[0][0][0], MODE_STATE_BYTES, g.tid);
+			if (c == W - 1) {
+				wave_copy_words(d.rowstate + (size_t)me * MODE_STATE_BYTES, &e.w->intra_mode_buffs[0][0][0], MODE_STATE_BYTES, g.tid);
+				if (g.tid == 0) d.thread_seen[me] = e.w->thread_seen_intra;
+			}
 			g.sync();
 			if (g.tid == 0) __hip_atomic_store(&d.progress[row], c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 		}
@@ -328,6 +333,8 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 		return;
 	}
 	int encodes = 0;
+	if (g.tid == 0) lw->thread_seen_intra = 1;   // the single thread has been through the first (intra) frame's CTUs before anything else looks (enc_types.h)
+	g.sync();
 	for (int c = 0; c < W; c++) {
 		if (row > 0) {
 			HENC_PROF_T0();
@@ -444,6 +451,7 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 	tc = g.sum(tc);
 	// the mode buffers of the thread that owns this row, as the CTU before left them (this row's, or the last one of row - T)
 	wave_copy_words(&e.w->intra_mode_buffs[0][0][0], d.rowstate + (size_t)me * MODE_STATE_BYTES, MODE_STATE_BYTES, g.tid);
+	if (g.tid == 0) e.w->thread_seen_intra = d.thread_seen[me];
 	const int rem_y = lframe->qp % 6, rem_c = chroma_qp_table(lframe->qp + S.chroma_qp_offset) % 6;
 	if (cached_rem[0] != rem_y || cached_rem[1] != rem_c) {
 		fast_tables_fill(g, *lft, d.tables, rem_y, rem_c);
@@ -473,6 +481,7 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 	wave_copy_words(d.outtok + (size_t)n * MODE_STATE_BYTES, e.w->intra_mode_buffs, MODE_STATE_BYTES, g.tid);
 	wave_copy_words(d.rowstate + (size_t)me * MODE_STATE_BYTES, &e.w->intra_mode_buffs[0][0][0], MODE_STATE_BYTES, g.tid);
 	if (g.tid == 0) {
+		d.thread_seen[me] = e.w->thread_seen_intra;
 		uint32_t *my_prefix = d.prefix + (size_t)row * (W + 1);
 		my_prefix[c + 1] = my_prefix[c] + d.ctus[n].intra_parts;
 		atomicAdd(&d.counters[1], 1);
@@ -685,7 +694,7 @@ struct SrcSlot {
 __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
 {
 	if (!rows_enter()) return;
-	int hseq[NHELP] = {0, 0, 0};
+	int hseq[NHELP_MAX] = {0, 0, 0};
 	encode_row(d, pass, (int)blockIdx.x, hseq);
 	release_helpers(hseq);
 }
@@ -698,7 +707,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus_batch(const EncDev 
 {
 	if (!rows_enter()) return;
 	const int grp = (int)blockIdx.x / hmax, row = (int)blockIdx.x % hmax;
-	int hseq[NHELP] = {0, 0, 0};
+	int hseq[NHELP_MAX] = {0, 0, 0};
 	for (int q = grp; q < nseq; q += groups) {
 		const EncDev d = devs[q];
 		if (row < d.seq->hctu) encode_row(d, -1, row, hseq);
@@ -827,6 +836,11 @@ struct hmr_gpu_enc {
 	WorkSlow *d_pool_slow = nullptr;                     // the pool workers' transform / decoded windows
 	int pool_workers = 0;
 	EntropyState es;
+	// engines (enc_host.h): the persistent state of each engine this object runs - engine k = frames k, k + E, ... - swapped into d at set_frame
+	CtuInfo *d_ctus_eng[MAX_ENGINES] = {nullptr};
+	uint8_t *d_rowstate_eng[MAX_ENGINES] = {nullptr};
+	int *d_seen_eng[MAX_ENGINES] = {nullptr};
+	int local_engines = 1, engine_index = -1;     // engine_index >= 0: this object is ONE engine of st.engines (the others live elsewhere, hmr_gpu_enc_create_engine)
 	int cur, lockstep;
 	float last_ms, last_total_ms;
 	int last_passes, last_encodes;
@@ -1025,6 +1039,12 @@ int set_frame(hmr_gpu_enc *e, int slot, int image_type, double avg_dist)
 {
 	const Seq &s = e->seq;
 	e->cur ^= 1;
+	{
+		const int k = e->local_engines > 1 ? e->st.num_encoded_frames % e->local_engines : 0;
+		e->d.ctus = e->d_ctus_eng[k];
+		e->d.rowstate = e->d_rowstate_eng[k];
+		e->d.thread_seen = e->d_seen_eng[k];
+	}
 	begin_frame(s, e->st, image_type, e->f);
 	if (avg_dist >= 0) e->f.avg_dist = avg_dist;
 	e->f.lockstep = e->lockstep;
@@ -1059,7 +1079,7 @@ int download_public(hmr_gpu_enc *e)
 
 extern "C" int hmr_gpu_enc_record_bytes(void) { return REC_BYTES; }
 
-extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, hmr_gpu_enc **out)
+static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_index, hmr_gpu_enc **out)
 {
 	if (!ctx || !cfg || !out) return HMR_GPU_ERR_ARG;
 	static_assert(sizeof(hmr_gpu_enc_cfg) == sizeof(HostCfg), "configuration layouts must match");
@@ -1073,6 +1093,15 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 		delete e;
 		return HMR_GPU_ERR_ARG;
 	}
+	e->st.engines = clampi(e->cfg.num_enc_engines, 1, MAX_ENGINES);
+	e->engine_index = engine_index;
+	e->local_engines = engine_index >= 0 ? 1 : e->st.engines;
+	if (e->st.engines > 1 && e->cfg.wfpp_num_threads < 2) {
+		hmr_set_error("hmr_gpu_enc_create: configuration outside the built rows: num_enc_engines > 1 needs the row-per-thread schedule (wfpp_num_threads > 1)");
+		delete e;
+		return HMR_GPU_ERR_ARG;
+	}
+	if (engine_index >= e->st.engines) { delete e; return HMR_GPU_ERR_ARG; }
 	e->seq.wide_min_n = getenv("HENC_WIDE_MIN") ? atoi(getenv("HENC_WIDE_MIN")) : 0;   // blocks from this size on are worked on by the whole workgroup; measured on MI355X (1080p, one sequence): 32 -> no gain, 16 -> 8 % slower, so off by default (profiles/r03_history.md)
 	const Seq &s = e->seq;
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -1090,6 +1119,11 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 		memset((void *)init.data(), 0, sizeof(CtuInfo) * s.nctu);
 		for (auto &c : init) memset(c.mv_ref_idx, -1, sizeof c.mv_ref_idx);
 		HIP_TRY(hipMemcpy(e->d.ctus, init.data(), sizeof(CtuInfo) * s.nctu, hipMemcpyHostToDevice));
+		e->d_ctus_eng[0] = e->d.ctus;
+		for (int k = 1; k < e->local_engines; k++) {
+			DEV_ALLOC(e->d_ctus_eng[k], s.nctu);
+			HIP_TRY(hipMemcpy(e->d_ctus_eng[k], init.data(), sizeof(CtuInfo) * s.nctu, hipMemcpyHostToDevice));
+		}
 	}
 	DEV_ALLOC(e->d.work_slow, s.hctu);
 	HIP_TRY(hipFuncSetAttribute((const void *)k_encode_ctus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
@@ -1116,6 +1150,13 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 	DEV_ALLOC(e->d.used_parts, s.nctu);
 	DEV_ALLOC(e->d.counters, 4);
 	DEV_ALLOC(e->d.rowstate, (size_t)s.hctu * MODE_STATE_BYTES);
+	DEV_ALLOC(e->d.thread_seen, 64);
+	e->d_rowstate_eng[0] = e->d.rowstate;
+	e->d_seen_eng[0] = e->d.thread_seen;
+	for (int k = 1; k < e->local_engines; k++) {
+		DEV_ALLOC(e->d_rowstate_eng[k], (size_t)s.hctu * MODE_STATE_BYTES);
+		DEV_ALLOC(e->d_seen_eng[k], 64);
+	}
 	DEV_ALLOC(e->d.row0_checked, 1);
 	for (int c = 0; c < 3; c++) {
 		e->src_elems[c] = (size_t)(c ? s.src_stride_c : s.src_stride_y) * (c ? s.height / 2 : s.height);
@@ -1162,11 +1203,57 @@ extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, 
 	return HMR_GPU_OK;
 }
 
+extern "C" int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, hmr_gpu_enc **out) { return enc_create(ctx, cfg, -1, out); }
+extern "C" int hmr_gpu_enc_create_engine(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_index, hmr_gpu_enc **out)
+{
+	if (engine_index < 0) return HMR_GPU_ERR_ARG;
+	return enc_create(ctx, cfg, engine_index, out);
+}
+extern "C" int hmr_gpu_enc_state_bytes(void) { return (int)sizeof(HostState); }
+extern "C" long hmr_gpu_enc_reference_elems(hmr_gpu_enc *e, int comp) { return e && comp >= 0 && comp < 3 ? (long)e->pic_elems[comp] : -1; }
+
+// The picture the next frame predicts from (padded planes, from the first element of their allocation) and the frame-to-frame scalars: what one engine hands
+// to the next (encoder_engine_thread keeps both in the shared hvenc_enc_t; with an engine per GPU they travel).  Device buffers of hmr_gpu_enc_reference_elems.
+extern "C" int hmr_gpu_enc_export_reference(hmr_gpu_enc *e, int16_t *dy, int16_t *du, int16_t *dv, void *state)
+{
+	if (!e || !dy || !du || !dv || !state) return HMR_GPU_ERR_ARG;
+	hipStream_t st = e->ctx->stream;
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	int16_t *dst[3] = {dy, du, dv};
+	for (int c = 0; c < 3; c++) HIP_TRY(hipMemcpyAsync(dst[c], e->d_pic[e->cur][c], e->pic_elems[c] * 2, hipMemcpyDeviceToDevice, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	memcpy(state, &e->st, sizeof(HostState));
+	return HMR_GPU_OK;
+}
+extern "C" int hmr_gpu_enc_import_reference(hmr_gpu_enc *e, const int16_t *dy, const int16_t *du, const int16_t *dv, const void *state)
+{
+	if (!e || !dy || !du || !dv || !state) return HMR_GPU_ERR_ARG;
+	HostState in;
+	memcpy(&in, state, sizeof in);
+	if (in.engines != e->st.engines || (e->engine_index >= 0 && in.num_encoded_frames % e->st.engines != e->engine_index)) {
+		hmr_set_error("hmr_gpu_enc_import_reference: state of frame %d does not precede a frame of engine %d of %d", in.num_encoded_frames - 1, e->engine_index, e->st.engines);
+		return HMR_GPU_ERR_ARG;
+	}
+	hipStream_t st = e->ctx->stream;
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	const int16_t *src[3] = {dy, du, dv};
+	for (int c = 0; c < 3; c++) HIP_TRY(hipMemcpyAsync(e->d_pic[e->cur][c], src[c], e->pic_elems[c] * 2, hipMemcpyDeviceToDevice, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	e->st = in;
+	return HMR_GPU_OK;
+}
+
 extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 {
 	if (!e) return;
 	(void)hipSetDevice(e->ctx->device);
 	(void)hipStreamSynchronize(e->ctx->stream);
+	e->d.ctus = e->d_ctus_eng[0]; e->d.rowstate = e->d_rowstate_eng[0]; e->d.thread_seen = e->d_seen_eng[0];
+	for (int k = 1; k < MAX_ENGINES; k++) {
+		if (e->d_ctus_eng[k]) (void)hipFree(e->d_ctus_eng[k]);
+		if (e->d_rowstate_eng[k]) (void)hipFree(e->d_rowstate_eng[k]);
+		if (e->d_seen_eng[k]) (void)hipFree(e->d_seen_eng[k]);
+	}
 	if (e->ev_frame) (void)hipEventDestroy(e->ev_frame);
 	if (e->ev_ready) (void)hipEventDestroy(e->ev_ready);
 	if (e->ev_batch0) (void)hipEventDestroy(e->ev_batch0);
@@ -1177,7 +1264,7 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	if (e->d_stage) (void)hipFree(e->d_stage);
 	if (e->h_stage) (void)hipHostFree(e->h_stage);
 	void *p[] = {e->d_seq, e->d_frame, e->d_geo, e->d.ctus, e->d.ctus_start, e->d.work_slow, e->d.coeff, e->d.progress, e->d.prefix, e->d.prof, e->d.guess, e->d.truth, e->d.outtok,
-		     e->d.chain_start, e->d.chain_end, e->d.valid, e->d.dirty, e->d.hash, e->d.intra_before, e->d.used_intra, e->d.used_parts, e->d.counters, e->d.rowstate, e->d.row0_checked, e->d_bytes, e->d_mvx,
+		     e->d.chain_start, e->d.chain_end, e->d.valid, e->d.dirty, e->d.hash, e->d.intra_before, e->d.used_intra, e->d.used_parts, e->d.counters, e->d.rowstate, e->d.thread_seen, e->d.row0_checked, e->d_bytes, e->d_mvx,
 		     e->d_mvy, e->d_ref, e->d_qp, e->d_flags, e->d_pd, e->d_ti, e->d_stats, e->d_params, e->d_sao_offsets, e->d_sao_aux, e->d_sao_dist, e->d_sao_lambdas, e->d_sao_bits,
 		     e->d_sao_lps, e->d_sao_saved, e->d_public};
 	for (void *q : p) (void)hipFree(q);

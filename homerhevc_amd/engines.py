@@ -1,29 +1,159 @@
-"""Frame-parallel encoder engines across GPUs: one engine (process) per GPU.
+"""Frame-parallel encoder engines, one engine per GPU (process).
 
-The reference deals frames to `num_enc_engines` engines in decode order (`encoder_engine_thread`,
-hmr_encoder_lib.c:3154-3211) and the only data engines share is the reconstructed, padded reference picture
-(`hvenc->ref_wnds`, hmr_private.h:1407): engine e needs engine e-1's reconstruction of the previous frame.
-That is a ring of point-to-point transfers, not a reduction, so it maps to RCCL send/recv over xGMI.
+The reference deals the frames of a sequence to `num_enc_engines` engine threads in decode order (`encoder_engine_thread`,
+hmr_encoder_lib.c:3043-3330): frame n goes to engine n mod E, which owns the persistent per-engine state (CTU records, the
+WPP threads' contexts), and what the engines share lives in the common `hvenc_enc_t`: the reconstructed reference picture
+(`reference_picture_buffer`, filled row by row behind `synchro_sem[1]`, :2393-2445) and a few frame-to-frame scalars
+(`avg_dist`, frame typing state; :3185-3279).  With an engine per GPU those two things travel: after frame n, engine n mod E
+hands the padded reconstruction and the scalars to engine (n + 1) mod E - a ring of point-to-point transfers, RCCL send / recv
+over xGMI (`backend="nccl"`), gloo in the CPU tests.  The stream is the one oracle/ref_ctudump.c's engine turnstile pins on the
+reference (include/homer_gpu.h section 12b, enc/enc_host.h).
+
+`EngineRing` runs S sequences at once so that every rank has work at every step: sequence s's frame t is encoded by rank
+(s + t) mod E - at step t every rank encodes the frames t of the sequences whose turn it is there (one batch launch on the
+GPU), then every rank sends what it produced to the next and receives what the previous produced, in ONE packed transfer.
+
+An `adapter` hides the encoder behind five calls (the product's is `GpuEngines` below: the C ABI of libhomer_gpu.so on torch
+CUDA tensors; the CPU tests bring their own over the checker build):
+    create(seq, engine_index) -> handle          load_source(handle, slot, planes)
+    encode(handles, slot) -> [access unit bytes] export(handle, tensor_row)        import_(handle, tensor_row)
+    row_elems                                     new_buffer(rows) -> torch.int16 tensor [rows, row_elems]
 """
+import ctypes as C
+import os
+
+import torch
 import torch.distributed as dist
 
-
-def frames_for_engine(rank, world, n_frames):
-    """Frame indices (decode order) engine `rank` encodes: round-robin, as the reference hands them out."""
-    return list(range(rank, n_frames, world))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def exchange_reference(send_planes, recv_planes, rank, world):
-    """Post the ring transfer of one reference picture: send ours to engine rank+1, receive engine rank-1's.
+def engine_of(seq, frame, world):
+    """the rank (= engine slot of the ring) that encodes `frame` of sequence `seq`"""
+    return (seq + frame) % world
 
-    Returns the request list (wait on them before the next frame reads `recv_planes`); [] when world == 1.
-    Works on any backend (nccl = RCCL on ROCm, gloo in the CPU tests).
-    """
-    if world <= 1:
-        return []
-    nxt, prv = (rank + 1) % world, (rank - 1) % world
-    ops = []
-    for t_send, t_recv in zip(send_planes, recv_planes):
-        ops.append(dist.P2POp(dist.isend, t_send, nxt))
-        ops.append(dist.P2POp(dist.irecv, t_recv, prv))
-    return dist.batch_isend_irecv(ops)
+
+def engine_index(seq, rank, world):
+    """which of the sequence's E engines lives on `rank`: the one that gets the frames t with (seq + t) mod E == rank"""
+    return (rank - seq) % world
+
+
+class EngineRing:
+    def __init__(self, adapter, n_sequences, rank, world):
+        self.a, self.S, self.rank, self.world = adapter, n_sequences, rank, world
+        self.enc = {s: adapter.create(s, engine_index(s, rank, world)) for s in range(n_sequences)}
+        per_step = (n_sequences + world - 1) // world
+        self.send_buf = adapter.new_buffer(per_step)
+        self.recv_buf = adapter.new_buffer(per_step)
+
+    def sequences_at(self, frame, rank=None):
+        r = self.rank if rank is None else rank
+        return [s for s in range(self.S) if engine_of(s, frame, self.world) == r]
+
+    def load_sources(self, clip):
+        """clip[t] = the planes of frame t (the same clip for every sequence): a rank keeps only the frames it will encode"""
+        for s, h in self.enc.items():
+            for t, planes in enumerate(clip):
+                if engine_of(s, t, self.world) == self.rank:
+                    self.a.load_source(h, t, planes)
+
+    def step(self, frame, last=False):
+        """encode frame `frame` of this rank's sequences; returns {sequence: access unit}.  Unless `last`, the reconstructions go round the ring afterwards."""
+        mine = self.sequences_at(frame)
+        if frame > 0 and self.world > 1:
+            for i, s in enumerate(mine):
+                self.a.import_(self.enc[s], self.recv_buf[i])
+        aus = self.a.encode([self.enc[s] for s in mine], frame)
+        if not last and self.world > 1:
+            for i, s in enumerate(mine):
+                self.a.export(self.enc[s], self.send_buf[i])
+            # rank r's sequences of this step are rank r + 1's of the next, in the same order
+            nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
+            n_out, n_in = len(mine), len(self.sequences_at(frame + 1))
+            ops = []
+            if n_out:
+                ops.append(dist.P2POp(dist.isend, self.send_buf[:n_out], nxt))
+            if n_in:
+                ops.append(dist.P2POp(dist.irecv, self.recv_buf[:n_in], prv))
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        return dict(zip(mine, aus))
+
+
+class GpuEngines:
+    """adapter over libhomer_gpu.so (no fallback: without the HIP library there is nothing to run)"""
+
+    def __init__(self, cfg_of, device):
+        self.lib = C.CDLL(os.path.join(ROOT, "homerhevc_amd", "libhomer_gpu.so"))
+        self.cfg_of, self.device = cfg_of, device
+        lib = self.lib
+        lib.hmr_gpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
+        lib.hmr_gpu_enc_create_engine.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        lib.hmr_gpu_enc_load_source.argtypes = [C.c_void_p, C.c_int] + [C.c_char_p] * 3
+        lib.hmr_gpu_enc_encode_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        lib.hmr_gpu_enc_reference_elems.restype = C.c_long
+        lib.hmr_gpu_enc_reference_elems.argtypes = [C.c_void_p, C.c_int]
+        lib.hmr_gpu_enc_export_reference.argtypes = [C.c_void_p] * 5
+        lib.hmr_gpu_enc_import_reference.argtypes = [C.c_void_p] * 5
+        lib.hmr_gpu_enc_destroy.argtypes = [C.c_void_p]
+        lib.hmr_gpu_last_error.restype = C.c_char_p
+        self.state_bytes = lib.hmr_gpu_enc_state_bytes()
+        self.elems = None
+        self.bufs = {}
+        self.states = {}
+        self.slots = {}
+
+    def create(self, seq, index):
+        ctx, enc = C.c_void_p(), C.c_void_p()
+        assert self.lib.hmr_gpu_create(C.byref(ctx), self.device, None) == 0, self.lib.hmr_gpu_last_error()
+        cfg = self.cfg_of(seq)
+        assert self.lib.hmr_gpu_enc_create_engine(ctx, C.byref(cfg), index, C.byref(enc)) == 0, self.lib.hmr_gpu_last_error()
+        if self.elems is None:
+            self.elems = [self.lib.hmr_gpu_enc_reference_elems(enc, c) for c in range(3)]
+        self.bufs[enc.value] = C.create_string_buffer(4 << 20)
+        self.slots[enc.value] = {}
+        return enc
+
+    @property
+    def row_elems(self):
+        return sum(self.elems) + (self.state_bytes + 1) // 2
+
+    def new_buffer(self, rows):
+        return torch.zeros((max(rows, 1), self.row_elems), dtype=torch.int16, device=f"cuda:{self.device}")
+
+    def load_source(self, h, frame, planes):
+        slot = len(self.slots[h.value])
+        self.slots[h.value][frame] = slot
+        assert self.lib.hmr_gpu_enc_load_source(h, slot, *planes) == 0, self.lib.hmr_gpu_last_error()
+
+    def encode(self, handles, frame):
+        n = len(handles)
+        if n == 0:
+            return []
+        e_arr = (C.c_void_p * n)(*handles)
+        slots = (C.c_int * n)(*[self.slots[h.value][frame] for h in handles])
+        ptrs = (C.c_char_p * n)(*[C.cast(self.bufs[h.value], C.c_char_p) for h in handles])
+        caps = (C.c_long * n)(*[len(self.bufs[h.value]) for h in handles])
+        got = (C.c_long * n)()
+        assert self.lib.hmr_gpu_enc_encode_batch(e_arr, n, slots, None, ptrs, caps, got) == 0, self.lib.hmr_gpu_last_error()
+        return [C.string_at(self.bufs[h.value], got[i]) for i, h in enumerate(handles)]
+
+    def _split(self, row):
+        p = row.data_ptr()
+        y, u, v = p, p + 2 * self.elems[0], p + 2 * (self.elems[0] + self.elems[1])
+        return y, u, v, p + 2 * sum(self.elems)
+
+    def export(self, h, row):
+        y, u, v, st = self._split(row)
+        state = C.create_string_buffer(self.state_bytes)
+        assert self.lib.hmr_gpu_enc_export_reference(h, y, u, v, state) == 0, self.lib.hmr_gpu_last_error()
+        tail = torch.frombuffer(bytearray(state.raw + b"\0" * (self.state_bytes & 1)), dtype=torch.int16)
+        row[sum(self.elems):].copy_(tail)
+
+    def import_(self, h, row):
+        y, u, v, st = self._split(row)
+        state = bytes(row[sum(self.elems):].cpu().numpy().tobytes()[:self.state_bytes])
+        assert self.lib.hmr_gpu_enc_import_reference(h, y, u, v, state) == 0, self.lib.hmr_gpu_last_error()
+
+    def destroy(self, h):
+        self.lib.hmr_gpu_enc_destroy(h)

@@ -622,6 +622,23 @@ int hmr_gpu_enc_profile(hmr_gpu_enc *enc, unsigned long long *out, int reset);
 int hmr_gpu_enc_timeline(hmr_gpu_enc *enc, unsigned long long *out);
 
 /* ------------------------------------------------------------------------------------------------
+ * 12b. Engines: hvenc_enc_t.num_encoder_engines / encoder_engine_thread (hmr_encoder_lib.c:3043-3330; hmr_private.h:1232)
+ *     hmr_gpu_enc_cfg.num_enc_engines = E > 1 (row-per-thread schedule only) gives the stream of the reference's frame pipeline in the
+ *     interleaving oracle/ref_ctudump.c's engine turnstile pins on it: frame n is encoded on the complete reconstruction of frame
+ *     n - 1, starts from the avg_dist frame n - E left behind and works on the persistent state of engine n mod E.
+ *     hmr_gpu_enc_create keeps all E engines in one object.  hmr_gpu_enc_create_engine makes ONE engine (index k of E): it is given
+ *     only the frames k, k + E, ... and, before each of them except frame 0, the hand-over of the engine before it -
+ *     hmr_gpu_enc_export_reference on that engine after its frame, hmr_gpu_enc_import_reference here: the reconstructed picture
+ *     (three padded int16 planes in DEVICE memory, hmr_gpu_enc_reference_elems(enc, comp) elements each, e.g. buffers an RCCL
+ *     send / recv moves between GPUs) and hmr_gpu_enc_state_bytes() bytes of frame-to-frame scalars (host memory).
+ * ------------------------------------------------------------------------------------------------ */
+int hmr_gpu_enc_create_engine(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_index, hmr_gpu_enc **out);
+int hmr_gpu_enc_state_bytes(void);
+long hmr_gpu_enc_reference_elems(hmr_gpu_enc *enc, int comp);
+int hmr_gpu_enc_export_reference(hmr_gpu_enc *enc, int16_t *dev_y, int16_t *dev_u, int16_t *dev_v, void *state);
+int hmr_gpu_enc_import_reference(hmr_gpu_enc *enc, const int16_t *dev_y, const int16_t *dev_u, const int16_t *dev_v, const void *state);
+
+/* ------------------------------------------------------------------------------------------------
  * 13. Phase planes of a reference picture
  *     Replaces the per-block interpolation calls of the motion search and of motion compensation - the sixteen planes of
  *     hmr_half_pixel_estimation_luma_hm / hmr_quarter_pixel_estimation_luma_hm (hmr_motion_inter.c:395,442) and

@@ -44,6 +44,9 @@ struct Cpu {
 	std::vector<CtuInfo> ctus;
 	Work *w;
 	std::vector<Work *> row_w;   // wavefront emulation: one worker per CTU row
+	// engines (enc_host.h): the persistent per-engine state - CTU records, worker(s) - of the engines that are not the active one
+	struct EngState { std::vector<CtuInfo> ctus; Work *w = nullptr; std::vector<Work *> row_w; } eng[MAX_ENGINES];
+	int active = 0, local_engines = 1;
 	std::vector<int16_t> src[3], pic[2][3], coeff;
 	std::vector<uint8_t> records;
 	int cur = 0;        // picture under reconstruction: pic[cur], reference: pic[cur ^ 1]
@@ -66,6 +69,15 @@ Work *new_work()
 	Work *w = (Work *)calloc(1, sizeof(Work));
 	w->slow = (WorkSlow *)calloc(1, sizeof(WorkSlow));
 	return w;
+}
+
+void activate_engine(Cpu &c, int k)
+{
+	if (k == c.active) return;
+	Cpu::EngState &out = c.eng[c.active], &in = c.eng[k];
+	std::swap(c.ctus, out.ctus); std::swap(c.w, out.w); std::swap(c.row_w, out.row_w);      // park the active engine's state
+	std::swap(c.ctus, in.ctus); std::swap(c.w, in.w); std::swap(c.row_w, in.row_w);
+	c.active = k;
 }
 
 int16_t *plane0(Cpu &c, int which, int comp)
@@ -360,6 +372,12 @@ void *henc_cpu_create(const HostCfg *cfg)
 	memset(c->ctus.data(), 0, sizeof(CtuInfo) * s.nctu);
 	for (auto &ci : c->ctus) memset(ci.mv_ref_idx, -1, sizeof ci.mv_ref_idx);
 	c->w = new_work();
+	c->st.engines = clampi(cfg->num_enc_engines, 1, MAX_ENGINES);
+	c->local_engines = c->st.engines;
+	for (int k = 1; k < c->local_engines; k++) {
+		c->eng[k].ctus = c->ctus;
+		c->eng[k].w = new_work();
+	}
 	c->src[0].assign((size_t)s.src_stride_y * s.height, 0);
 	c->src[1].assign((size_t)s.src_stride_c * s.height / 2, 0);
 	c->src[2].assign((size_t)s.src_stride_c * s.height / 2, 0);
@@ -371,6 +389,31 @@ void *henc_cpu_create(const HostCfg *cfg)
 	c->coeff.assign((size_t)s.nctu * 6144, 0);
 	c->records.assign((size_t)s.nctu * REC_BYTES, 0);
 	return c;
+}
+
+// ONE engine of cfg->num_enc_engines (enc_host.h): it is given only its own frames, and the hand-over of the engine before it in front of each of them
+void *henc_cpu_create_engine(const HostCfg *cfg, int engine_index)
+{
+	Cpu *c = (Cpu *)henc_cpu_create(cfg);
+	if (!c || engine_index < 0 || engine_index >= c->st.engines) return nullptr;
+	c->local_engines = 1;
+	return c;
+}
+int henc_cpu_state_bytes(void) { return (int)sizeof(HostState); }
+long henc_cpu_reference_elems(void *h, int comp) { return (long)((Cpu *)h)->pic[0][comp].size(); }
+void henc_cpu_export_reference(void *h, int16_t *y, int16_t *u, int16_t *v, void *state)
+{
+	Cpu &c = *(Cpu *)h;
+	int16_t *dst[3] = {y, u, v};
+	for (int k = 0; k < 3; k++) memcpy(dst[k], c.pic[c.cur][k].data(), c.pic[c.cur][k].size() * 2);
+	memcpy(state, &c.st, sizeof(HostState));
+}
+void henc_cpu_import_reference(void *h, const int16_t *y, const int16_t *u, const int16_t *v, const void *state)
+{
+	Cpu &c = *(Cpu *)h;
+	const int16_t *src[3] = {y, u, v};
+	for (int k = 0; k < 3; k++) memcpy(c.pic[c.cur][k].data(), src[k], c.pic[c.cur][k].size() * 2);
+	memcpy(&c.st, state, sizeof(HostState));
 }
 
 void henc_cpu_destroy(void *h)
@@ -415,6 +458,7 @@ int henc_cpu_frame_ctus(void *h, const uint8_t *y, const uint8_t *u, const uint8
 	const Seq &s = c.seq;
 	const uint8_t *in[3] = {y, u, v}, *rin[3] = {ref_y, ref_u, ref_v};
 	if (first_ctu == 0) {
+		activate_engine(c, c.local_engines > 1 ? c.st.num_encoded_frames % c.local_engines : 0);
 		c.cur ^= 1;
 		begin_frame(s, c.st, image_type, c.f);
 		if (avg_dist >= 0) c.f.avg_dist = avg_dist;

@@ -94,12 +94,59 @@ static void ts_post_end(int n)
 	pthread_cond_broadcast(&ts_c);
 	pthread_mutex_unlock(&ts_m);
 }
+/* ---- HOMER_TURNSTILE=1 with num_enc_engines = E > 1: a deterministic schedule for the frame pipeline ---------------------------------------------------
+ * The reference deals frames to E engine threads (encoder_engine_thread, hmr_encoder_lib.c:3043) that overlap: engine k+1 starts frame n+1 as soon as engine k
+ * has left the input section of frame n, its WPP threads follow frame n's rows at a distance (synchro_sem[1], :2393-2445), and when a frame ends its engine
+ * pushes avg_dist into the engines that are ahead (:3268-3279) - whenever that happens to be.  Its output therefore depends on timing.  The turnstile forces
+ * ONE legal interleaving:
+ *   * the CTU work of frame n+1 starts when the CTU work of frame n is complete (its WPP threads have returned: reconstruction filtered and padded);
+ *   * the end-of-frame section of frame n (avg_dist, the push, output) runs when the CTU work of frame n+E-1 is complete, i.e. as late as the pipeline allows -
+ *     the frames it pushes into have made their decisions by then, so the push has no effect on them, and frame n+E (same engine, next) starts from it.
+ * What a frame then sees: the complete reconstruction of the frame before it, the frame typing state as in the single-engine run (ref_lockstep feeds frame f+1
+ * after frame f+1-E came out, i.e. after frame f's CTU work), avg_dist as of the end of frame n-E (zero for the first E frames), and the persistent per-engine
+ * state (ctu_info arrays, WPP thread contexts) of engine n mod E.  A device can overlap the frames as far as the reference rows it reads allow without changing
+ * any of this.  Inside a frame the synchronous wavefront above applies as before. */
+static pthread_mutex_t eg_m = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t eg_c = PTHREAD_COND_INITIALIZER;
+static int eg_complete, eg_fed = -1, eg_count[1 << 16];
+void lockstep_all_fed(int frames)
+{
+	pthread_mutex_lock(&eg_m);
+	eg_fed = frames;
+	pthread_cond_broadcast(&eg_c);
+	pthread_mutex_unlock(&eg_m);
+}
+THREAD_RETURN_TYPE wfpp_encoder_thread(void *h)
+{
+	static THREAD_RETURN_TYPE (*real)(void *);
+	henc_thread_t *et = (henc_thread_t *)h;
+	const int engines = et->enc_engine->hvenc->num_encoder_engines, n = (int)et->enc_engine->num_encoded_frames, T = et->enc_engine->wfpp_num_threads;
+	if (!real) real = next("wfpp_encoder_thread");
+	if (!ts_enabled() || engines < 2) return real(h);
+	if (getenv("HOMER_TS_DEBUG")) fprintf(stderr, "EG frame %d thread %d: at start gate (complete %d)\n", n, et->index, eg_complete);
+	pthread_mutex_lock(&eg_m);
+	while (eg_complete < n) pthread_cond_wait(&eg_c, &eg_m);
+	pthread_mutex_unlock(&eg_m);
+	if (getenv("HOMER_TS_DEBUG")) fprintf(stderr, "EG frame %d thread %d: runs\n", n, et->index);
+	real(h);
+	if (getenv("HOMER_TS_DEBUG")) fprintf(stderr, "EG frame %d thread %d: CTUs done\n", n, et->index);
+	pthread_mutex_lock(&eg_m);
+	if (++eg_count[n & 0xffff] == T) {
+		eg_count[n & 0xffff] = 0;
+		eg_complete = n + 1;
+		pthread_cond_broadcast(&eg_c);
+	}
+	while (eg_complete < n + engines && !(eg_fed >= 0 && eg_complete >= eg_fed)) pthread_cond_wait(&eg_c, &eg_m);
+	pthread_mutex_unlock(&eg_m);
+	return THREAD_RETURN;
+}
+
 /* the step starts at init_ctu (hmr_encoder_lib.c:2900), before the thread looks at is_scene_change (:2916) */
 ctu_info_t *init_ctu(henc_thread_t *et)
 {
 	static ctu_info_t *(*real)(henc_thread_t *);
 	if (!real) real = next("init_ctu");
-	if (ts_enabled()) ts_enter(et, et->cu_current);
+	if (ts_enabled() && et->wfpp_num_threads > 1) ts_enter(et, et->cu_current);
 	return real(et);
 }
 uint32_t motion_inter(henc_thread_t *et, ctu_info_t *ctu)
@@ -107,7 +154,7 @@ uint32_t motion_inter(henc_thread_t *et, ctu_info_t *ctu)
 	static uint32_t (*real)(henc_thread_t *, ctu_info_t *);
 	uint32_t r;
 	if (!real) real = next("motion_inter");
-	if (!ts_enabled()) return real(et, ctu);
+	if (!ts_enabled() || et->wfpp_num_threads < 2) return real(et, ctu);
 	r = real(et, ctu);
 	ts_leave_decision(ctu->ctu_number);
 	return r;
@@ -117,7 +164,7 @@ uint32_t motion_intra(henc_thread_t *et, ctu_info_t *ctu, int gcnt)
 	static uint32_t (*real)(henc_thread_t *, ctu_info_t *, int);
 	uint32_t r;
 	if (!real) real = next("motion_intra");
-	if (!ts_enabled()) return real(et, ctu, gcnt);
+	if (!ts_enabled() || et->wfpp_num_threads < 2) return real(et, ctu, gcnt);
 	r = real(et, ctu, gcnt);
 	ts_leave_decision(ctu->ctu_number);
 	return r;
@@ -131,7 +178,7 @@ void hmr_deblock_sao_pad_sync_ctu(henc_thread_t *et, slice_t *currslice, ctu_inf
 		real = next("hmr_deblock_sao_pad_sync_ctu");
 		if (getenv("HOMER_CTUDUMP")) g_dump = fopen(getenv("HOMER_CTUDUMP"), "wb");
 	}
-	if (ts_enabled()) ts_post_begin(ctu->ctu_number);
+	if (ts_enabled() && et->wfpp_num_threads > 1) ts_post_begin(ctu->ctu_number);
 	if (g_dump) {
 		int32_t hdr[8] = {0x43545544, et->enc_engine->num_encoded_frames, ctu->ctu_number, (int32_t)currslice->slice_type,
 				  (int32_t)ctu->partition_list[0].cost, (int32_t)ctu->partition_list[0].distortion, (int32_t)ctu->partition_list[0].sum,
@@ -154,7 +201,7 @@ void hmr_deblock_sao_pad_sync_ctu(henc_thread_t *et, slice_t *currslice, ctu_inf
 		fflush(g_dump);
 	}
 	real(et, currslice, ctu);
-	if (ts_enabled()) ts_post_end(ctu->ctu_number);
+	if (ts_enabled() && et->wfpp_num_threads > 1) ts_post_end(ctu->ctu_number);
 }
 
 /* the SAO decision of every CTU, logged when it is entropy coded (wfpp_encode_ctu, hmr_encoder_lib.c:2347) */

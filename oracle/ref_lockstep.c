@@ -24,6 +24,8 @@
 
 /* hook for oracle/ref_swap.c: called right after HOMER_enc_init, before HOMER_SETCFG */
 __attribute__((weak)) void lockstep_post_init(void *handle) { (void)handle; }
+/* hook for oracle/ref_ctudump.c (engine turnstile): every input frame has been handed to the encoder */
+__attribute__((weak)) void lockstep_all_fed(int frames) { (void)frames; }
 
 static double now(void)
 {
@@ -134,6 +136,7 @@ int main(int argc, char **argv)
 			else usleep(100);
 		}
 	}
+	lockstep_all_fed(fed);
 	while (got < fed) {
 		if (drain_one(h, &rec, &os, fo, frec, W, H, &bytes)) got++;
 		else usleep(100);

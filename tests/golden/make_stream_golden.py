@@ -45,7 +45,16 @@ CASES = [
     # fewer threads than rows (2 x threads >= CTU columns keeps the synchronous wavefront one of the reference's own interleavings): threads own rows k, k + N
     ("328x264_wpp3", 328, 264, 4, {"wpp": 3}),
     ("200x136_wpp2", 200, 136, 4, {"wpp": 2}),
-    ("3840x2160_cfg2_wpp32", 3840, 2160, 3, {"wpp": 32}),     # the 2160p picture of the metric with the reference's maximum of 32 WPP threads for 34 CTU rows (I + P + P)
+    ("3840x2160_cfg2_wpp32", 3840, 2160, 3, {"wpp": 32}),
+    # num_enc_engines > 1: the reference's frame pipeline is not deterministic either; oracle/ref_ctudump.c's engine turnstile pins it (frame n starts from the avg_dist frame n - E
+    # left and from engine n mod E's own state, on the complete reconstruction of frame n - 1) - with one WPP thread, and combined with the synchronous wavefront
+    ("416x240_eng2", 416, 240, 10, {"engines": 2}),
+    ("416x240_eng3_wpp_rows", 416, 240, 10, {"engines": 3, "wpp": 4}),
+    ("832x480_eng2_wpp_rows", 832, 480, 6, {"engines": 2, "wpp": 8}),
+    ("416x240_scene_cut_eng2_wpp_rows", 416, 240, 27, {"cut_at": 23, "engines": 2, "wpp": 4}),
+    ("1920x1080_cfg2_eng2", 1920, 1080, 8, {"engines": 2, "wpp": 17}),
+    ("1920x1080_cfg2_eng3", 1920, 1080, 8, {"engines": 3, "wpp": 17}),
+    ("3840x2160_cfg2_eng8", 3840, 2160, 10, {"engines": 8, "wpp": 32}),       # BASELINE.json configs[3]: 2160p, n_enc_engines = 8     # the 2160p picture of the metric with the reference's maximum of 32 WPP threads for 34 CTU rows (I + P + P)
 ]
 
 
@@ -55,7 +64,7 @@ def run(width, height, frames, keys):
     with tempfile.TemporaryDirectory() as tmp:
         yuv = os.path.join(tmp, "in.yuv")
         gen_yuv.write_clip(yuv, width, height, frames, cut_at=cut_at)
-        turnstile = int(keys.get("wpp", 1)) > 1
+        turnstile = int(keys.get("wpp", 1)) > 1 or int(keys.get("engines", 1)) > 1
         cmd = [os.path.join(ROOT, "oracle", "_ref", "ref_ctudump" if turnstile else "ref_lockstep"), yuv, os.path.join(tmp, "out.265"), str(width), str(height), str(frames),
                "recon=" + os.path.join(tmp, "rec.yuv")] + [f"{k}={v}" for k, v in keys.items()]
         subprocess.run(cmd, check=True, timeout=900, stdout=subprocess.DEVNULL, env=dict(os.environ, HOMER_TURNSTILE="1") if turnstile else None)
