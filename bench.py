@@ -11,9 +11,12 @@ timed frames the P frames that follow - every frame depends on the reconstructio
 The stream produced during the run is hashed; for the default workload and --steps + --warmup == 8 it must be the reference's
 2f0c3447dabb6fbd87cac9821bb479fd (reported as `stream_md5`, `stream_matches_reference`).
 
-Multi-GPU (--gpus N under torch.distributed.run): the encode of one sequence is a chain of frames (each frame needs the complete
-reconstruction and the distortion statistic of the one before), so it does not shard; N ranks run N independent encoder instances,
-one sequence per GPU ("replicas only", weak scaling), with the barrier / max-over-ranks timing of the contract.
+Multi-GPU (--gpus N under torch.distributed.run): one engine per GPU, as BASELINE.json's north_star and configs[3] say - the reference's
+num_enc_engines = N frame pipeline (encoder_engine_thread, hmr_encoder_lib.c:3043) with engine k on rank k.  Every rank keeps one engine object of every
+sequence; frame t of sequence s is encoded on rank (s + t) mod N, and after each step the ranks pass the reconstructed pictures (padded int16 planes) and
+the frame-to-frame scalars round the ring in ONE packed RCCL send / recv per rank (homerhevc_amd/engines.py).  N x --sequences sequences are in flight, so
+every rank encodes --sequences frames per step whatever N is (weak scaling); the exchange is inside the timed region.  Every access unit is checked against
+the reference's num_enc_engines = N stream (oracle/ref_ctudump.c's engine turnstile; tests/golden/bench_md5.json).
 
 Extra objects: `roofline` for k_encode_ctus (the launch that takes > 95 % of the frame): algorithmic bytes per SURVEY.md 8-d
 against the 8 TB/s HBM peak - the kernel is bound by dependent-instruction latency of a few wavefronts, not by bandwidth, and the
@@ -258,12 +261,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("HOMER_BENCH_ONE_DEVICE"):     # test aid: all ranks on GPU 0 (a one-GPU box); RCCL wants a GPU per rank, so the ring then goes over gloo
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if os.environ.get("HOMER_BENCH_ONE_DEVICE"):
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
 
     lib = load_lib()
+    if world > 1:
+        out = run_engine_ring(a, world, rank, local, torch)
+        if rank == 0:
+            print(json.dumps(out))
+        dist.destroy_process_group()
+        return
     out = run_workload(lib, a, a.workload, world, rank, local, torch, sequences=a.sequences)
     if rank == 0:
         width, height, keys = WORKLOADS[a.workload]
@@ -295,6 +309,50 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_engine_ring(a, world, rank, local, torch):
+    """--gpus N > 1: the engine ring (module docstring)."""
+    import torch.distributed as dist
+    import encoder_cases as ec
+    from homerhevc_amd.engines import EngineRing, GpuEngines
+    base = a.workload
+    width, height, keys = WORKLOADS[base]
+    name = f"{base}-engines{world}"
+    keys = dict(keys, engines=world)
+    nframes = a.warmup + a.steps
+    S = a.sequences * world
+    adapter = GpuEngines(lambda seq: ec.default_cfg(width, height, **keys), local)
+    ring = EngineRing(adapter, S, rank, world)
+    ring.load_sources(ec.clip_frames(width, height, nframes))
+    gold = REFERENCE_MD5.get(name, {}).get("au_md5", [])
+    bad, checked, produced = [0], [0], [0]
+
+    def step(f):
+        for s, au in ring.step(f, last=f + 1 == nframes).items():
+            produced[0] += 1
+            if f < len(gold):
+                checked[0] += 1
+                bad[0] += hashlib.md5(au).hexdigest() != gold[f]
+
+    dt = measure(step, a.warmup, nframes, world, torch.cuda.synchronize, "cuda")
+    t = torch.tensor([bad[0], checked[0], produced[0]], dtype=torch.int64, device="cuda")
+    dist.all_reduce(t)
+    bad_all, checked_all, produced_all = (int(x) for x in t.tolist())
+    row_bytes = adapter.row_elems * 2
+    return {
+        "metric": "encoded frames/sec, 1080p & 2160p YUV420 fixed-QP IPPP, 1/2/4/8 MI355X", "value": round(S * a.steps / dt, 4), "unit": "frames/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+        "config": {"workload": name, "sequences_per_gpu": a.sequences, "sequences": S, "frames_per_step": S, "num_enc_engines": world, "wfpp_num_threads": int(keys.get("wpp", 1)),
+                   "width": width, "height": height, "frames_in_sequence": nframes, "gop": "IPPP intra_period=100", "qp": 32, "rd_mode": 2, "performance_mode": 2, "sao": 1,
+                   "parallelism": f"engine per GPU: frame t of sequence s on rank (s + t) mod {world}; every rank encodes {a.sequences} frames per step in one launch, "
+                                  "then one packed RCCL send / recv of the reconstructed pictures + frame scalars to the next rank",
+                   "timed_region": "per step: import of the previous rank's pictures, CTU decisions + filters + SAO on the device, CABAC / NAL on the host, export + ring exchange"},
+        "stream_matches_reference": bool(checked_all > 0 and bad_all == 0), "access_units_checked_against_reference": checked_all, "access_units_produced": produced_all,
+        "exchange": {"bytes_per_sequence_and_step": row_bytes, "bytes_per_rank_and_step": row_bytes * a.sequences, "collective": "ring of point-to-point transfers (batch_isend_irecv), no reduction"},
+        "roofline": None, "cpu_baseline": None,
+    }
 
 
 def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):

@@ -795,6 +795,39 @@ struct PinnedAlloc {
 	template <class U> bool operator!=(const PinnedAlloc<U> &) const { return false; }
 };
 
+// The phase planes (124 MB for a 1080p picture) are needed from the start of a P frame's CTU stage to its end.  An encoder object borrows a set for that
+// time from a per-process pool instead of owning one: hundreds of sequences can be resident on a GPU (an engine ring keeps an engine object of EVERY
+// sequence on every GPU) while only the pictures of the running step need planes.
+struct PlaneSet { uint8_t *y = nullptr, *c[2] = {nullptr, nullptr}; size_t bytes_y = 0, bytes_c = 0; int device = 0; };
+struct PlanePool {
+	std::mutex m;
+	std::vector<PlaneSet> free_sets;
+	int acquire(int device, size_t by, size_t bc, PlaneSet *out)
+	{
+		{
+			std::lock_guard<std::mutex> lk(m);
+			for (size_t i = 0; i < free_sets.size(); i++)
+				if (free_sets[i].device == device && free_sets[i].bytes_y == by && free_sets[i].bytes_c == bc) {
+					*out = free_sets[i];
+					free_sets.erase(free_sets.begin() + (long)i);
+					return HMR_GPU_OK;
+				}
+		}
+		PlaneSet p;
+		p.device = device; p.bytes_y = by; p.bytes_c = bc;
+		HIP_TRY(hipMalloc((void **)&p.y, by));
+		HIP_TRY(hipMalloc((void **)&p.c[0], bc));
+		HIP_TRY(hipMalloc((void **)&p.c[1], bc));
+		*out = p;
+		return HMR_GPU_OK;
+	}
+	void release(const PlaneSet &p)
+	{
+		std::lock_guard<std::mutex> lk(m);
+		free_sets.push_back(p);
+	}
+};
+PlanePool g_plane_pool;
 struct hmr_gpu_enc {
 	hmr_gpu_ctx *ctx;
 	HostCfg cfg;
@@ -808,7 +841,7 @@ struct hmr_gpu_enc {
 	std::vector<Geo> geo;
 	std::vector<SrcSlot> src;
 	int16_t *d_pic[2][3], *d_pre[3];
-	uint8_t *d_sub_y = nullptr, *d_sub_c[2] = {nullptr, nullptr};   // phase planes of the reference picture (k_subpel.hip): 16 luma, 2 x 64 chroma
+	PlaneSet planes;                 // phase planes of the reference picture (k_subpel.hip: 16 luma, 2 x 64 chroma), borrowed from g_plane_pool for the CTU stage of a P frame
 	size_t src_elems[3], pic_elems[3];
 	uint8_t *d_bytes;              // staging for 8-bit planes (one 4:2:0 picture)
 	// raster unit arrays of the filters, SAO statistics and parameters
@@ -847,6 +880,7 @@ struct hmr_gpu_enc {
 };
 
 namespace {
+void release_planes(hmr_gpu_enc *e);
 constexpr int REC_BYTES = 32 + 3 * 256 + 2 * 256 + 9 * 256 + 256 + 256 + 2048 + 2048 + 6144 * 2 + 6144 * 2 + 2 * 5 * 256;
 
 int16_t *plane0(hmr_gpu_enc *e, int which, int comp)
@@ -925,7 +959,7 @@ int ctu_stage_prepare(hmr_gpu_enc *e)
 	if (e->f.slice_type != SLICE_I) {
 		// the reference picture, interpolated once at every sub-sample phase: what motion search and compensation read (k_subpel.hip)
 		const int rc = hmr_gpu_subpel_planes(e->ctx, e->d_pic[e->cur ^ 1][0], e->d_pic[e->cur ^ 1][1], e->d_pic[e->cur ^ 1][2], s.stride_y, s.height + 2 * s.margin_y, s.stride_c,
-						     s.height / 2 + 2 * s.margin_c, e->d_sub_y, e->d_sub_c[0], e->d_sub_c[1]);
+						     s.height / 2 + 2 * s.margin_c, e->planes.y, e->planes.c[0], e->planes.c[1]);
 		if (rc) return rc;
 	}
 	{
@@ -949,6 +983,7 @@ int lockstep_collect(hmr_gpu_enc *e)
 	e->last_encodes = counters[1];
 	e->f.scene_cut_ctu = counters[2];
 	e->last_passes = 1;
+	release_planes(e);
 	return HMR_GPU_OK;
 }
 
@@ -1032,6 +1067,7 @@ int run_ctu_passes(hmr_gpu_enc *e)
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ctx->ev0, e->ctx->ev1));
 	e->last_passes = pass + 1;
+	release_planes(e);
 	return HMR_GPU_OK;
 }
 
@@ -1053,11 +1089,24 @@ int set_frame(hmr_gpu_enc *e, int slot, int image_type, double avg_dist)
 		e->f.ref[c] = plane0(e, e->cur ^ 1, c);
 		e->f.rec[c] = plane0(e, e->cur, c);
 	}
-	e->f.sub_y = e->d_sub_y + (size_t)s.margin_y * s.stride_y + s.margin_y;
-	e->f.sub_c[0] = e->d_sub_c[0] + (size_t)s.margin_c * s.stride_c + s.margin_c;
-	e->f.sub_c[1] = e->d_sub_c[1] + (size_t)s.margin_c * s.stride_c + s.margin_c;
+	if (e->f.slice_type != SLICE_I) {
+		if (!e->planes.y) {
+			const int rc = g_plane_pool.acquire(e->ctx->device, (size_t)16 * s.plane_elems_y, (size_t)64 * s.plane_elems_c, &e->planes);
+			if (rc) return rc;
+		}
+		e->f.sub_y = e->planes.y + (size_t)s.margin_y * s.stride_y + s.margin_y;
+		e->f.sub_c[0] = e->planes.c[0] + (size_t)s.margin_c * s.stride_c + s.margin_c;
+		e->f.sub_c[1] = e->planes.c[1] + (size_t)s.margin_c * s.stride_c + s.margin_c;
+	}
 	HIP_TRY(hipMemcpyAsync(e->d_frame, &e->f, sizeof(FrameCtx), hipMemcpyHostToDevice, e->ctx->stream));
 	return HMR_GPU_OK;
+}
+
+// the CTU stage of the frame is over (its launch has been waited for): the planes go back to the pool
+void release_planes(hmr_gpu_enc *e)
+{
+	if (e->planes.y) g_plane_pool.release(e->planes);
+	e->planes = PlaneSet();
 }
 
 // the side-info records lie 68 KB apart inside the CTU records: packed on the device, then one linear copy to the host
@@ -1113,7 +1162,7 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 	DEV_ALLOC(e->d_geo, NNODES);
 	HIP_TRY(hipMemcpy(e->d_geo, e->geo.data(), sizeof(Geo) * NNODES, hipMemcpyHostToDevice));
 	DEV_ALLOC(e->d.ctus, s.nctu);
-	DEV_ALLOC(e->d.ctus_start, s.nctu);
+	if (e->cfg.wfpp_num_threads <= 1) DEV_ALLOC(e->d.ctus_start, s.nctu);   // (the frame-start state CTUs are re-encoded from: single-thread order only)
 	{
 		std::vector<CtuInfo> init(s.nctu);
 		memset((void *)init.data(), 0, sizeof(CtuInfo) * s.nctu);
@@ -1164,9 +1213,6 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 		for (int k = 0; k < 2; k++) DEV_ALLOC(e->d_pic[k][c], e->pic_elems[c]);
 		DEV_ALLOC(e->d_pre[c], e->pic_elems[c]);
 	}
-	DEV_ALLOC(e->d_sub_y, (size_t)16 * s.plane_elems_y);
-	DEV_ALLOC(e->d_sub_c[0], (size_t)64 * s.plane_elems_c);
-	DEV_ALLOC(e->d_sub_c[1], (size_t)64 * s.plane_elems_c);
 	DEV_ALLOC(e->d_bytes, (size_t)s.width * s.height * 3 / 2);
 	e->units_stride = s.wctu * 16;
 	e->units_rows = s.hctu * 16;
@@ -1248,6 +1294,7 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	if (!e) return;
 	(void)hipSetDevice(e->ctx->device);
 	(void)hipStreamSynchronize(e->ctx->stream);
+	release_planes(e);
 	e->d.ctus = e->d_ctus_eng[0]; e->d.rowstate = e->d_rowstate_eng[0]; e->d.thread_seen = e->d_seen_eng[0];
 	for (int k = 1; k < MAX_ENGINES; k++) {
 		if (e->d_ctus_eng[k]) (void)hipFree(e->d_ctus_eng[k]);

@@ -28,6 +28,11 @@ CASES = {
     "cfg2-1080p-encode-single-thread-order": (1920, 1080, 40, {}),
     "cfg2-2160p-encode": (3840, 2160, 10, {"wpp": 32}),
     "cfg2-416x240-encode": (416, 240, 40, {"wpp": 4}),
+    # bench.py --gpus N: the same 1080p encode with one engine per GPU (num_enc_engines = N), the reference pinned by the engine turnstile
+    "cfg2-1080p-encode-engines2": (1920, 1080, 40, {"wpp": 17, "engines": 2}),
+    "cfg2-1080p-encode-engines4": (1920, 1080, 40, {"wpp": 17, "engines": 4}),
+    "cfg2-1080p-encode-engines8": (1920, 1080, 40, {"wpp": 17, "engines": 8}),
+    "cfg2-416x240-encode-engines2": (416, 240, 40, {"wpp": 4, "engines": 2}),
 }
 
 
@@ -58,12 +63,13 @@ def run(width, height, frames, keys):
         stream = open(os.path.join(tmp, "out.265"), "rb").read()
     ends = access_unit_ends(stream)
     assert len(ends) == frames, (len(ends), frames)
-    h, out, pos = hashlib.md5(), [], 0
+    h, out, each, pos = hashlib.md5(), [], [], 0
     for e in ends:
         h.update(stream[pos:e])
+        each.append(hashlib.md5(stream[pos:e]).hexdigest())
         pos = e
         out.append(h.copy().hexdigest())
-    return {"width": width, "height": height, "frames": frames, "keys": keys, "cumulative_md5": out}
+    return {"width": width, "height": height, "frames": frames, "keys": keys, "cumulative_md5": out, "au_md5": each}
 
 
 if __name__ == "__main__":
