@@ -364,7 +364,8 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
     nframes = a.warmup + a.steps
     S = sequences if int(keys.get("wpp", 1)) > 1 else 1
     frames = ec.clip_frames(width, height, nframes)
-    encs, bufs = [], []
+    encs, bufs, ctxs = [], [], []
+    lib.hmr_gpu_destroy.argtypes = [C.c_void_p]
     for _ in range(S):
         ctx, enc = C.c_void_p(), C.c_void_p()
         assert lib.hmr_gpu_create(C.byref(ctx), local, None) == 0, lib.hmr_gpu_last_error()
@@ -373,6 +374,7 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
         for f, planes in enumerate(frames):
             assert lib.hmr_gpu_enc_load_source(enc, f, *planes) == 0, lib.hmr_gpu_last_error()
         encs.append(enc)
+        ctxs.append(ctx)
         bufs.append(C.create_string_buffer(4 << 20))
     enc, buf = encs[0], bufs[0]
     nbytes = C.c_long()
@@ -403,6 +405,8 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
     dt = measure(step, a.warmup, nframes, world, torch.cuda.synchronize, "cuda")
     for x in encs:
         lib.hmr_gpu_enc_destroy(x)
+    for x in ctxs:
+        lib.hmr_gpu_destroy(x)          # (a context holds pinned host memory, HBM staging and a stream)
     md5 = md5s[0]
     all_same = len({m.hexdigest() for m in md5s}) == 1
 

@@ -74,6 +74,8 @@ inline bool make_seq(HostCfg cfg, Seq &s, const char **why)
 		if (n > 1 && n < hc && 2 * n < wc) { *why = "wfpp_num_threads between 1 and the number of CTU rows needs 2 x threads >= CTU columns"; return false; }
 	}
 	if ((cfg.width + 63) / 64 < 2) { *why = "picture narrower than two CTUs"; return false; }
+	// the SAO decision advances one CTU row per lane of a wavefront (k_sao_decide): 64 rows
+	if (cfg.sample_adaptive_offset && cfg.wfpp_enable && (cfg.height + 63) / 64 > 64) { *why = "SAO with wavefront sub-streams on a picture of more than 64 CTU rows"; return false; }
 	{
 		const int wc = (cfg.width + 63) / 64, hc = (cfg.height + 63) / 64;
 		if (cfg.sample_adaptive_offset && wc <= 5 && hc >= (wc > 4 ? wc : 4)) { *why = "SAO on a picture of at most five CTU columns that has at least as many CTU rows"; return false; }
@@ -221,8 +223,24 @@ inline void begin_frame(const Seq &s, HostState &st, int image_type, FrameCtx &f
 	f.sao_lambda[1] = f.sao_lambda[2] = lambda / weight;
 }
 
-// :3217-3238 after the CTUs of a frame: acc_dist = sum of the CTUs' root distortions (uint32 accumulation)
-inline void end_frame(const Seq &s, HostState &st, const FrameCtx &f, uint32_t acc_dist)
+// The frame's distortion total as the reference forms it (:3217-3228, hmr_private.h:1217): every WPP thread adds up the root distortions of the CTUs of
+// its rows (row r belongs to thread r mod T) in a uint32 that may wrap, the engine adds the threads' totals in a double.  dist_of(n) = CTU n's distortion.
+template <class DistFn>
+inline double frame_acc_dist(const Seq &s, int threads, DistFn &&dist_of)
+{
+	const int T = threads < 1 ? 1 : threads;
+	double total = 0;
+	for (int t = 0; t < T && t < s.hctu; t++) {
+		uint32_t acc = 0;
+		for (int r = t; r < s.hctu; r += T)
+			for (int c = 0; c < s.wctu; c++) acc += dist_of(r * s.wctu + c);
+		total += acc;
+	}
+	return total;
+}
+
+// :3217-3238 after the CTUs of a frame: acc_dist = frame_acc_dist
+inline void end_frame(const Seq &s, HostState &st, const FrameCtx &f, double acc_dist)
 {
 	const bool scene_change = f.scene_cut_ctu >= 0;     // :3796-3800: the frame was found to be a new scene while it was encoded
 	if (scene_change) {

@@ -19,6 +19,7 @@
 #include <mutex>
 #include <condition_variable>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -242,96 +243,6 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 	e.timeline = nullptr;
 	uint32_t *my_prefix = d.prefix + (size_t)row * (W + 1);
 	if (pass <= 0 && g.tid == 0) my_prefix[0] = 0;
-	if (pass < 0) {
-		// ---- the synchronous wavefront of wfpp_num_threads = CTU rows (enc_sched.h, oracle/ref_ctudump.c HOMER_TURNSTILE): one worker per row with its own mode
-		// buffers, all CTUs of step t = c + 2 * row see the counters as of the end of step t - 1, row 0 alone looks for a scene change and does so first in its step.
-		// No guesses, no verification: one launch per frame.
-		// With fewer threads than rows (allowed when 2 * threads >= CTU columns, so that thread k has left row r - threads before row r's first step) the worker
-		// of row r continues with the buffers row r - threads left behind in this same frame, and thread 0's rows are the ones that look for a scene change.
-		const int T = d.threads, me = row % T;
-		for (int c = 0; c < W; c++) {
-			const int t = c + 2 * row, n = row * W + c;
-			{
-				HENC_PROF_T0();
-#if defined(HENC_PROFILE)
-				if (g.tid == 0 && d.prof) d.prof[(size_t)H * PF_COUNT + 4 * n] = wall_clock64();
-#endif
-				// every row must have finished its CTUs of the earlier steps
-				for (;;) {
-					int behind = 0;
-					for (int r2 = g.tid; r2 < H; r2 += 64) {
-						const int need = t - 2 * r2 < 0 ? 0 : (t - 2 * r2 < W ? t - 2 * r2 : W);
-						behind |= __hip_atomic_load(&d.progress[r2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need;
-					}
-					if (!g.any(behind)) break;
-					__builtin_amdgcn_s_sleep(32);
-				}
-				// one acquire once the condition holds: an acquiring load per poll would invalidate the caches this XCD's other row workers are using
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-				HENC_PROF_ADD(e, PF_WAIT);
-			}
-#if defined(HENC_PROFILE)
-			if (g.tid == 0 && d.prof) { d.prof[(size_t)H * PF_COUNT + 4 * n + 1] = wall_clock64(); d.prof[(size_t)H * PF_COUNT + 4 * n + 2] = 0; }
-			e.timeline = d.prof ? d.prof + (size_t)H * PF_COUNT + 4 * n : nullptr;
-#endif
-			uint32_t ti = 0, tc = 0;
-			for (int r2 = g.tid; r2 < H; r2 += 64) {
-				const int have = t - 2 * r2 < 0 ? 0 : (t - 2 * r2 < W ? t - 2 * r2 : W);
-				ti += d.prefix[(size_t)r2 * (W + 1) + have];
-				tc += (uint32_t)have;
-			}
-			ti = g.sum(ti);
-			tc = g.sum(tc);
-			if (c == 0) {
-				// (the barrier above has seen the last CTU of row - T, whose worker stored these before it published that CTU)
-				wave_copy_words(&e.w->intra_mode_buffs[0][0][0], d.rowstate + (size_t)me * MODE_STATE_BYTES, MODE_STATE_BYTES, g.tid);
-				if (g.tid == 0) e.w->thread_seen_intra = d.thread_seen[me];
-				g.sync();
-			}
-			const int hrow = t / (2 * T) * T;   // thread 0's row that is inside the picture at this step, if any
-			if (row == hrow) {
-				if (g.tid == 0) {
-					if (d.counters[2] < 0 && lframe->slice_type == SLICE_P && scene_cut_fires(S, *lframe, ti, tc * NPART)) d.counters[2] = n;
-					__hip_atomic_store(d.row0_checked, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-				}
-			} else if (hrow < H && t - 2 * hrow < W) {
-				while (__hip_atomic_load(d.row0_checked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t + 1) __builtin_amdgcn_s_sleep(8);
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-			}
-			g.sync();
-			if (g.tid == 0) lframe->scene_cut_ctu = __hip_atomic_load(&d.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			g.sync();
-			HENC_PROF_T0();
-			wave_copy_words(e.w->mode_in, e.w->intra_mode_buffs, MODE_STATE_BYTES, g.tid);
-			e.total_intra_partitions = ti;
-			e.total_partitions = tc * NPART;
-			e.coeff = d.coeff + (size_t)n * 6144;
-			g.sync();
-			encode_ctu(g, e, n);
-			resolve_mode_tokens(g, *e.w, d.ctus[n]);
-			wave_copy_words(d.outtok + (size_t)n * MODE_STATE_BYTES, e.w->intra_mode_buffs, MODE_STATE_BYTES, g.tid);
-			if (g.tid == 0) my_prefix[c + 1] = my_prefix[c] + d.ctus[n].intra_parts;
-			HENC_PROF_ADD(e, PF_TOTAL);
-#if defined(HENC_PROFILE)
-			if (g.tid == 0 && d.prof) d.prof[(size_t)H * PF_COUNT + 4 * n + 3] = wall_clock64();
-#endif
-			if (c == W - 1) {
-				wave_copy_words(d.rowstate + (size_t)me * MODE_STATE_BYTES, &e.w->intra_mode_buffs[0][0][0], MODE_STATE_BYTES, g.tid);
-				if (g.tid == 0) d.thread_seen[me] = e.w->thread_seen_intra;
-			}
-			g.sync();
-			if (g.tid == 0) __hip_atomic_store(&d.progress[row], c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-		}
-		for (int h = 0; h < NHELP; h++) hseq[h] = e.hseq[h];
-		if (g.tid == 0) atomicAdd(&d.counters[1], W);
-#if defined(HENC_PROFILE)
-		if (g.tid == 0 && e.prof) {
-			const unsigned long long *pp = (const unsigned long long *)(lds + HENC_LDS_PROF_OFFSET);
-			for (int k = 0; k < 2 * PP_COUNT; k++) e.prof[PF_PRIM0 + k] += pp[k];
-		}
-#endif
-		return;
-	}
 	int encodes = 0;
 	if (g.tid == 0) lw->thread_seen_intra = 1;   // the single thread has been through the first (intra) frame's CTUs before anything else looks (enc_types.h)
 	g.sync();
@@ -698,23 +609,6 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
 	encode_row(d, pass, (int)blockIdx.x, hseq);
 	release_helpers(hseq);
 }
-// Several sequences in ONE launch (row-per-thread schedule).  Every row worker takes a whole CU (its LDS), so the grid is `groups` x hmax workgroups with
-// groups x hmax <= the number of CUs (fifteen groups of 17 rows for 1080p), and the workgroup (g, r) encodes row r of the sequences g, g + groups, g + 2 groups ...
-// one after the other.  Chaining sequences through a workgroup fills the bubbles of the WPP wavefront: row r is idle for 2 r steps while a picture's wavefront
-// builds up and for 2 (H - 1 - r) while it drains, and it spends that time on the next sequence's row r - k chained pictures take k W + 2 (H - 1) steps, not
-// k (W + 2 (H - 1)).  A row only ever waits for rows of its own sequence, all of which are resident.
-__global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus_batch(const EncDev *devs, int nseq, int groups, int hmax)
-{
-	if (!rows_enter()) return;
-	const int grp = (int)blockIdx.x / hmax, row = (int)blockIdx.x % hmax;
-	int hseq[NHELP_MAX] = {0, 0, 0};
-	for (int q = grp; q < nseq; q += groups) {
-		const EncDev d = devs[q];
-		if (row < d.seq->hctu) encode_row(d, -1, row, hseq);
-	}
-	release_helpers(hseq);
-}
-
 // ---- SAO parameter decision on the device (enc/enc_sao.h): what it needs from the entropy coder is the walk of two contexts through the SAO syntax of each
 // sub-stream, so it runs here, behind the statistics and the candidate offsets (k_saooffsets.hip) and in front of the offset pass, with no host in the chain.
 // One wavefront; lane r owns CTU row r and the rows advance as the WPP wavefront (CTU (r, c) at step c + 2 r): a CTU needs the parameters of its left and
@@ -921,33 +815,6 @@ int load_planes(hmr_gpu_enc *e, const uint8_t *y, const uint8_t *u, const uint8_
 	return HMR_GPU_OK;
 }
 
-// Row workers of the row-per-thread schedule wait for ALL rows of their picture (the synchronous wavefront), so every workgroup of such a launch has to be
-// resident: two launches that together need more CUs than the device has could each get a part of theirs and wait for the rest for ever.  Launches of this
-// process therefore take their workgroups out of a per-device budget of CUs and wait (on the host) until they fit.  (Other processes on the same GPU: not covered.)
-struct CuBudget {
-	std::mutex m;
-	std::condition_variable cv;
-	int total[16] = {0}, used[16] = {0};
-	int acquire(int device, int want)
-	{
-		std::unique_lock<std::mutex> lk(m);
-		device &= 15;
-		if (!total[device] && hipDeviceGetAttribute(&total[device], hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) total[device] = 256;
-		if (want > total[device]) want = total[device];      // (a launch larger than the device alone: it runs by itself)
-		cv.wait(lk, [&] { return used[device] + want <= total[device]; });
-		used[device] += want;
-		return want;
-	}
-	void release(int device, int got)
-	{
-		{
-			std::lock_guard<std::mutex> lk(m);
-			used[device & 15] -= got;
-		}
-		cv.notify_all();
-	}
-};
-CuBudget g_cu_budget;
 
 // what a frame's CTU stage needs on the stream before its first launch
 int ctu_stage_prepare(hmr_gpu_enc *e)
@@ -1022,31 +889,30 @@ int run_ctu_passes(hmr_gpu_enc *e)
 	HIP_TRY(hipEventRecord(e->ctx->ev0, st));
 	if (e->lockstep) {
 		// wfpp_num_threads > 1: the synchronous wavefront, one launch, nothing to verify - the picture's CTUs as a pool of tasks (k_encode_pool)
-		if (!getenv("HENC_ROW_WORKERS")) {
-			if (!e->d_batch) HIP_TRY(hipMalloc((void **)&e->d_batch, 256 * sizeof(EncDev)));
-			HIP_TRY(hipMemcpyAsync(e->d_batch, &e->d, sizeof(EncDev), hipMemcpyHostToDevice, st));
-			if ((rc = launch_pool(e, 1, s.hctu, st))) return rc;
-			HIP_TRY(hipEventRecord(e->ctx->ev1, st));
-			if ((rc = lockstep_collect(e))) return rc;      // (waits for the launch)
-			HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ctx->ev0, e->ctx->ev1));
-			return HMR_GPU_OK;
-		}
-		// (kept for comparison, HENC_ROW_WORKERS=1: one workgroup per CTU row, rows waiting for each other at every step - needs all of them resident)
-		const int cus = g_cu_budget.acquire(e->ctx->device, s.hctu);
-		hipLaunchKernelGGL(k_encode_ctus, dim3(s.hctu), dim3(ENC_THREADS), LDS_BYTES, st, e->d, -1);
-		const hipError_t launched = hipGetLastError();
-		if (launched == hipSuccess) (void)hipEventRecord(e->ctx->ev1, st);
-		rc = launched == hipSuccess ? lockstep_collect(e) : HMR_GPU_ERR_HIP;      // (waits for the launch)
-		g_cu_budget.release(e->ctx->device, cus);
-		if (launched != hipSuccess) hmr_set_error("k_encode_ctus: %s", hipGetErrorString(launched));
-		if (rc) return rc;
+		if (!e->d_batch) HIP_TRY(hipMalloc((void **)&e->d_batch, 256 * sizeof(EncDev)));
+		HIP_TRY(hipMemcpyAsync(e->d_batch, &e->d, sizeof(EncDev), hipMemcpyHostToDevice, st));
+		if ((rc = launch_pool(e, 1, s.hctu, st))) return rc;
+		HIP_TRY(hipEventRecord(e->ctx->ev1, st));
+		if ((rc = lockstep_collect(e))) return rc;      // (waits for the launch)
 		HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ctx->ev0, e->ctx->ev1));
 		return HMR_GPU_OK;
 	}
+	// wfpp_num_threads = 1: the single thread's order.  Row workers wait for the row above (progress[]), so every workgroup of the launch has to be resident
+	// or the waiting ones spin for ever: a cooperative launch makes the runtime guarantee that - it fails at launch time when the grid does not fit (another
+	// process on the GPU, a partition mode) instead of hanging.
 	int pass = 0;
 	for (;; pass++) {
 		HIP_TRY(hipMemsetAsync(e->d.progress, 0, sizeof(int) * s.hctu, st));
-		hipLaunchKernelGGL(k_encode_ctus, dim3(s.hctu), dim3(ENC_THREADS), LDS_BYTES, st, e->d, pass);
+		{
+			EncDev dd = e->d;
+			int pp = pass;
+			void *args[] = {&dd, &pp};
+			const hipError_t launched = hipLaunchCooperativeKernel((const void *)k_encode_ctus, dim3(s.hctu), dim3(ENC_THREADS), args, (unsigned)LDS_BYTES, st);
+			if (launched != hipSuccess) {
+				hmr_set_error("k_encode_ctus (%d row workers, cooperative): %s", s.hctu, hipGetErrorString(launched));
+				return HMR_GPU_ERR_HIP;
+			}
+		}
 		hipLaunchKernelGGL(k_sched_scan, dim3(1), dim3(320), 0, st, e->d);
 		hipLaunchKernelGGL(k_sched_check, dim3(s.nctu), dim3(64), 0, st, e->d);
 		HIP_TRY(hipGetLastError());
@@ -1151,6 +1017,11 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 		return HMR_GPU_ERR_ARG;
 	}
 	if (engine_index >= e->st.engines) { delete e; return HMR_GPU_ERR_ARG; }
+	struct Guard {               // a failure further down (HIP_TRY / DEV_ALLOC return) frees what has been allocated so far
+		hmr_gpu_enc *e;
+		bool ok = false;
+		~Guard() { if (!ok) hmr_gpu_enc_destroy(e); }
+	} guard{e};
 	e->seq.wide_min_n = getenv("HENC_WIDE_MIN") ? atoi(getenv("HENC_WIDE_MIN")) : 0;   // blocks from this size on are worked on by the whole workgroup; measured on MI355X (1080p, one sequence): 32 -> no gain, 16 -> 8 % slower, so off by default (profiles/r03_history.md)
 	const Seq &s = e->seq;
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -1176,7 +1047,6 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 	}
 	DEV_ALLOC(e->d.work_slow, s.hctu);
 	HIP_TRY(hipFuncSetAttribute((const void *)k_encode_ctus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-	HIP_TRY(hipFuncSetAttribute((const void *)k_encode_ctus_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
 	HIP_TRY(hipFuncSetAttribute((const void *)k_encode_pool, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
 	HIP_TRY(hipEventCreate(&e->ev_frame));
 	HIP_TRY(hipEventCreate(&e->ev_ready));
@@ -1245,6 +1115,7 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 	e->last_ms = e->last_total_ms = 0;
 	e->last_passes = e->last_encodes = 0;
 	HIP_TRY(hipStreamSynchronize(ctx->stream));   // (the buffers are cleared by now)
+	guard.ok = true;
 	*out = e;
 	return HMR_GPU_OK;
 }
@@ -1394,9 +1265,7 @@ extern "C" int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *e, const uint8_t *y, const ui
 	rc = download_public(e);
 	if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(st));
-	uint32_t acc = 0;
-	for (int n = 0; n < s.nctu; n++) acc += ((const CtuPublic *)(e->h_public.data() + sizeof(CtuPublic) * n))->distortion;
-	end_frame(s, e->st, e->f, acc);
+	end_frame(s, e->st, e->f, frame_acc_dist(s, e->cfg.wfpp_num_threads, [&](int n) { return ((const CtuPublic *)(e->h_public.data() + sizeof(CtuPublic) * n))->distortion; }));
 	if (records) {
 		std::vector<int16_t> rec[3];
 		std::vector<uint8_t> truth((size_t)s.nctu * MODE_STATE_BYTES), chain_end(MODE_STATE_BYTES);
@@ -1501,19 +1370,19 @@ int frame_device_part(hmr_gpu_enc *e, int slot)
 int frame_host_part(hmr_gpu_enc *e, const uint8_t *h_public, const int16_t *h_coeff, uint8_t *stream, long cap, long *stream_bytes)
 {
 	const Seq &s = e->seq;
-	uint32_t acc = 0;
-	for (int n = 0; n < s.nctu; n++) acc += ((const CtuPublic *)(h_public + sizeof(CtuPublic) * n))->distortion;
+	const double acc = frame_acc_dist(s, e->cfg.wfpp_num_threads, [&](int n) { return ((const CtuPublic *)(h_public + sizeof(CtuPublic) * n))->distortion; });
 	EntropyFrame fr;
 	fr.seq = &e->seq; fr.f = &e->f; fr.T = hmr_host_tables(); fr.geo = e->geo.data();
 	fr.ctu_base = h_public; fr.ctu_pitch = sizeof(CtuPublic); fr.coeff = h_coeff;
 	std::vector<uint8_t> out;
 	encode_frame_entropy(e->es, fr, nullptr, e->cfg.profile, out);
-	end_frame(s, e->st, e->f, acc);
 	*stream_bytes = (long)out.size();
 	if ((long)out.size() > cap) {
+		// the access unit is lost with this return; the sequence state has not moved on, but the device pictures have: the caller has to start over
 		hmr_set_error("hmr_gpu_enc_encode: the access unit needs %ld bytes, the buffer holds %ld", (long)out.size(), cap);
 		return HMR_GPU_ERR_ARG;
 	}
+	end_frame(s, e->st, e->f, acc);
 	memcpy(stream, out.data(), out.size());
 	return e->f.slice_type;
 }
@@ -1628,12 +1497,13 @@ extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *sl
 		lead->stage_bytes = total;
 	}
 	std::vector<int> rcs(n, 0);
+	std::vector<std::string> errs(n);       // (the error text is per thread: bring the workers' back to the caller's)
 	{
 		std::vector<std::thread> th;
 		for (int i = 0; i < n; i++)
 			th.emplace_back([&, i]() {
 				hmr_gpu_enc *e = encs[i];
-				if (hipSetDevice(e->ctx->device) != hipSuccess) { rcs[i] = HMR_GPU_ERR_HIP; return; }
+				if (hipSetDevice(e->ctx->device) != hipSuccess) { rcs[i] = HMR_GPU_ERR_HIP; errs[i] = "hipSetDevice failed"; return; }
 				e->last_ms = ms;
 				int r = lockstep_collect(e);
 				if (!r) r = frame_device_part(e, slots[i]);
@@ -1645,11 +1515,12 @@ extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *sl
 						r = HMR_GPU_ERR_HIP;
 				}
 				rcs[i] = r;
+				if (r < 0) errs[i] = hmr_gpu_last_error();
 			});
 		for (auto &t : th) t.join();
 	}
 	for (int i = 0; i < n; i++)
-		if (rcs[i] < 0) return rcs[i];
+		if (rcs[i] < 0) { hmr_set_error("hmr_gpu_enc_encode_batch: sequence %d: %s", i, errs[i].c_str()); return rcs[i]; }
 	for (int i = 0; i < n; i++) HIP_TRY(hipStreamWaitEvent(bst, encs[i]->ev_ready, 0));
 	HIP_TRY(hipMemcpyAsync(lead->h_stage, lead->d_stage, total, hipMemcpyDeviceToHost, bst));
 	HIP_TRY(hipStreamSynchronize(bst));
@@ -1659,12 +1530,13 @@ extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *sl
 			th.emplace_back([&, i]() {
 				hmr_gpu_enc *e = encs[i];
 				rcs[i] = frame_host_part(e, lead->h_stage + off_pub[i], (const int16_t *)(lead->h_stage + off_coeff[i]), streams[i], caps[i], &stream_bytes[i]);
+				if (rcs[i] < 0) errs[i] = hmr_gpu_last_error();
 				e->last_total_ms = ms;
 			});
 		for (auto &t : th) t.join();
 	}
 	for (int i = 0; i < n; i++)
-		if (rcs[i] < 0) return rcs[i];
+		if (rcs[i] < 0) { hmr_set_error("hmr_gpu_enc_encode_batch: sequence %d: %s", i, errs[i].c_str()); return rcs[i]; }
 	return HMR_GPU_OK;
 }
 

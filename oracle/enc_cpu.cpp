@@ -522,7 +522,7 @@ int henc_cpu_frame_ctus(void *h, const uint8_t *y, const uint8_t *u, const uint8
 		c.acc_dist += c.ctus[n].distortion;
 		make_record(c, n, e);
 	}
-	if (last_ctu == s.nctu) end_frame(s, c.st, c.f, c.acc_dist);
+	if (last_ctu == s.nctu) end_frame(s, c.st, c.f, frame_acc_dist(s, c.cfg.wfpp_num_threads, [&](int n) { return c.ctus[n].distortion; }));
 	return c.f.slice_type;
 }
 
@@ -595,7 +595,7 @@ int henc_cpu_frame_ctus_wavefront(void *h, const uint8_t *y, const uint8_t *u, c
 			make_record(c, n, e);
 			c.w = keep;
 		}
-	end_frame(s, c.st, c.f, c.acc_dist);
+	end_frame(s, c.st, c.f, frame_acc_dist(s, c.cfg.wfpp_num_threads, [&](int n) { return c.ctus[n].distortion; }));
 	return c.f.slice_type;
 }
 
