@@ -23,6 +23,26 @@ enum { PF_SETUP = 0, PF_MERGE, PF_ME_INT, PF_ME_SUB, PF_PRED_INTER, PF_ENC_INTER
 
 namespace henc {
 
+// The partition geometry is the same table for every CTU of every encoder.  Device: constant memory, indexed with a value the compiler is told is wave-uniform
+// (it is: the walk is group-uniform), so the fields arrive in scalar registers through the scalar cache and block addresses, sizes and loop bounds are scalar
+// arithmetic.  Checker build: a plain array.
+#if defined(__HIPCC__)
+extern __constant__ Geo henc_geo_table[NNODES];      // defined in k_encode.hip, filled by hmr_gpu_enc_create
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+struct GeoTable {
+	const Geo *p;
+	__device__ __forceinline__ const Geo &operator[](int i) const { return henc_geo_table[__builtin_amdgcn_readfirstlane(i)]; }
+	__device__ __forceinline__ const Geo &lane(int i) const { return henc_geo_table[i]; }      // an index of the lane's own (loops over the nodes of a level)
+};
+#else
+struct GeoTable {
+	const Geo *p;
+	HENC_INLINE const Geo &operator[](int i) const { return p[i]; }
+	HENC_INLINE const Geo &lane(int i) const { return p[i]; }
+};
+#endif
+
 constexpr int NHELP_MAX = 3;
 struct Enc {
 	unsigned long long *prof;   // PF_COUNT accumulators of this worker (profiling build), else unused
@@ -30,7 +50,7 @@ struct Enc {
 	FastPtr<const FrameCtx> f;
 	const DevTables *T;
 	FastPtr<const FastTables> ft;   // the tables a TU reads, in the worker's fast memory (enc_prims.h)
-	FastPtr<const Geo> geo;
+	GeoTable geo;
 	CtuInfo *ctus;         // all CTUs of the picture (persistent across frames)
 	FastPtr<CtuPublic> ctu;   // the side-info record of the CTU being encoded: ctu_g's, or the worker's fast copy of it (ctu_fast != nullptr) while the CTU is encoded
 	CtuInfo *ctu_g;        // its home in the picture array (logs, nodes; neighbours are ctu_g - 1, ctu_g - wctu ...)

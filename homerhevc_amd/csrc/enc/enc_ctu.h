@@ -576,9 +576,9 @@ HENC_HD void create_partition_neighbours(const G &g, Enc &__restrict__ e)
 		const int first = S.depth_start[depth], count = 1 << (2 * depth);
 		for (int k = g.tid; k < count; k += g.n) {
 			const int curr = first + k;
-			const Geo &q = e.geo[curr];
+			const Geo &q = e.geo.lane(curr);
 			if (depth > 0) {
-				const Geo &pq = e.geo[q.parent];
+				const Geo &pq = e.geo.lane(q.parent);
 				if (!((cy + pq.y < S.height) && (cx + pq.x < S.width))) continue;
 			}
 			Node &nd = node_of(e, curr);
@@ -592,7 +592,7 @@ HENC_HD void create_partition_neighbours(const G &g, Enc &__restrict__ e)
 					nd.left_bottom_nb = 0;
 					nd.top_right_nb = has_top_right;
 				} else {
-					const Geo &pq = e.geo[q.parent];
+					const Geo &pq = e.geo.lane(q.parent);
 					const Node &pn = node_of(e, q.parent);
 					nd.left_nb = (pn.left_nb || q.x) ? 1 : 0;
 					nd.top_nb = (pn.top_nb || q.y) ? 1 : 0;

@@ -134,34 +134,34 @@ inline void make_geo(Geo *geo)
 		const int depth = par.depth + 1, size = 64 >> depth, np = (size * size) >> 4;
 		for (int k = 0; k < 4; k++, next++) {
 			Geo &c = geo[next];
-			par.child[k] = (int16_t)next;
-			c.parent = (int16_t)p;
-			c.list_index = (uint16_t)next;
-			c.depth = (uint16_t)depth;
-			c.size = (uint16_t)size;
-			c.size_chroma = (uint16_t)(size >> 1);
-			c.x = (uint16_t)(par.x + (k & 1) * size);
-			c.y = (uint16_t)(par.y + (k >> 1) * size);
+			par.child[k] = (int32_t)next;
+			c.parent = (int32_t)p;
+			c.list_index = (int32_t)next;
+			c.depth = (int32_t)depth;
+			c.size = (int32_t)size;
+			c.size_chroma = (int32_t)(size >> 1);
+			c.x = (int32_t)(par.x + (k & 1) * size);
+			c.y = (int32_t)(par.y + (k >> 1) * size);
 			c.xc = c.x >> 1;
 			c.yc = c.y >> 1;
-			c.abs_index = (uint16_t)(par.abs_index + k * np);
-			c.num_part = (uint16_t)np;
+			c.abs_index = (int32_t)(par.abs_index + k * np);
+			c.num_part = (int32_t)np;
 			for (int j = 0; j < 4; j++) c.child[j] = -1;
 		}
 	}
 	for (int i = 0; i < NNODES; i++) {
 		Geo &c = geo[i];
-		c.raster_index = (uint16_t)host_abs2raster(c.abs_index);
+		c.raster_index = (int32_t)host_abs2raster(c.abs_index);
 		const int r = c.raster_index;
 		const int left = (r & 15) == 0 ? r + 15 : r - 1;
 		const int left_bottom = (left + 16) & 255, top = (r + 240) & 255;
 		const int top_right = (top & 15) == 15 ? top - 15 : top + 1;
 		const int top_left = (left + 240) & 255;
-		c.abs_left = (uint16_t)host_raster2abs(left);
-		c.abs_left_bottom = (uint16_t)host_raster2abs(left_bottom);
-		c.abs_top = (uint16_t)host_raster2abs(top);
-		c.abs_top_right = (uint16_t)host_raster2abs(top_right);
-		c.abs_top_left = (uint16_t)host_raster2abs(top_left);
+		c.abs_left = (int32_t)host_raster2abs(left);
+		c.abs_left_bottom = (int32_t)host_raster2abs(left_bottom);
+		c.abs_top = (int32_t)host_raster2abs(top);
+		c.abs_top_right = (int32_t)host_raster2abs(top_right);
+		c.abs_top_left = (int32_t)host_raster2abs(top_left);
 	}
 }
 

@@ -42,12 +42,13 @@ struct MV {
 	int32_t x, y;
 };
 
-// static geometry of the partition tree (init_partition_info, hmr_motion_intra.c:758; get_partition_neigbours :710)
+// static geometry of the partition tree (init_partition_info, hmr_motion_intra.c:758; get_partition_neigbours :710).  Whole words: on the device the table
+// lives in constant memory and is read with scalar loads (GeoTable, enc_common.h) - everything computed from it then stays on the scalar unit.
 struct Geo {
-	uint16_t list_index, depth, abs_index, size, size_chroma, x, y, xc, yc, num_part, raster_index;
-	uint16_t abs_left, abs_left_bottom, abs_top, abs_top_right, abs_top_left;
-	int16_t parent;
-	int16_t child[4];
+	int32_t list_index, depth, abs_index, size, size_chroma, x, y, xc, yc, num_part, raster_index;
+	int32_t abs_left, abs_left_bottom, abs_top, abs_top_right, abs_top_left;
+	int32_t parent;
+	int32_t child[4];
 };
 
 // a motion vector as a partition node keeps it: vectors come out of a search of +-128 x +-64 samples (or are copied from a neighbour), so 16 bits hold them

@@ -62,7 +62,8 @@ __device__ __forceinline__ void wave_copy_words(void *dst, const void *src, int 
 
 constexpr int HSCRATCH_ELEMS = 2048 + 144;   // int16 per helper
 // LDS of a row worker: its Work, a copy of the CTU's partition nodes and of the partition geometry
-constexpr size_t LDS_WORK = (sizeof(Work) + 15) & ~(size_t)15, LDS_NODES = (sizeof(Node) * NNODES + 15) & ~(size_t)15, LDS_GEO = (sizeof(Geo) * NNODES + 15) & ~(size_t)15;
+constexpr size_t LDS_WORK = (sizeof(Work) + 15) & ~(size_t)15, LDS_NODES = (sizeof(Node) * NNODES + 15) & ~(size_t)15, LDS_GEO = 0;   // (the geometry is in constant memory: enc_common.h GeoTable)
+namespace henc { __constant__ Geo henc_geo_table[NNODES]; }
 constexpr size_t LDS_SEQ = (sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15, LDS_CTU = (sizeof(CtuPublic) + 15) & ~(size_t)15, LDS_FT = (sizeof(FastTables) + 15) & ~(size_t)15;
 #if defined(HENC_PROFILE)
 constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = NHELP * HSCRATCH_ELEMS * 2;
@@ -204,10 +205,8 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 	const int W = S.wctu, H = S.hctu;
 	WaveGrp g{(int)(threadIdx.x & 63)};
 	Work *lw = (Work *)lds;
-	Geo *lgeo = (Geo *)(lds + LDS_WORK + LDS_NODES);
 	HelperBox *box = (HelperBox *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU);
 	for (int i = g.tid; i < (int)(LDS_WORK / 4); i += 64) ((uint32_t *)lds)[i] = 0;
-	for (int i = g.tid; i < (int)(sizeof(Geo) * NNODES / 2); i += 64) ((uint16_t *)lgeo)[i] = ((const uint16_t *)d.geo)[i];
 	g.sync();
 	// the sequence and frame parameters are read all through the control code: a copy next to the worker
 	Seq *lseq = (Seq *)(lds + LDS_WORK + LDS_NODES + LDS_GEO);
@@ -229,7 +228,7 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 	e.f = lframe;
 	e.T = d.tables;
 	e.ft = lft;
-	e.geo = lgeo;
+	e.geo.p = nullptr;
 	e.ctus = d.ctus;
 	e.ctu = nullptr;
 	e.w = lw;
@@ -406,12 +405,10 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_pool(const EncDev *devs,
 	extern __shared__ __align__(16) uint8_t lds[];
 	WaveGrp g{(int)(threadIdx.x & 63)};
 	Work *lw = (Work *)lds;
-	Geo *lgeo = (Geo *)(lds + LDS_WORK + LDS_NODES);
 	HelperBox *box = (HelperBox *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU);
 	Seq *lseq = (Seq *)(lds + LDS_WORK + LDS_NODES + LDS_GEO);
 	FrameCtx *lframe = (FrameCtx *)((uint8_t *)lseq + ((sizeof(Seq) + 15) & ~(size_t)15));
 	FastTables *lft = (FastTables *)(lds + LDS_FT_OFFSET);
-	for (int i = g.tid; i < (int)(sizeof(Geo) * NNODES / 2); i += 64) ((uint16_t *)lgeo)[i] = ((const uint16_t *)devs[0].geo)[i];   // (the same tree for every encoder: 64 x 64 CTUs)
 	if (g.tid == 0) lw->slow = slow + blockIdx.x;
 #if defined(HENC_PROFILE)
 	if (g.tid < 2 * PP_COUNT) ((unsigned long long *)(lds + HENC_LDS_PROF_OFFSET))[g.tid] = 0;
@@ -421,7 +418,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_pool(const EncDev *devs,
 	e.seq = lseq;
 	e.f = lframe;
 	e.ft = lft;
-	e.geo = lgeo;
+	e.geo.p = nullptr;
 	e.ctu = nullptr;
 	e.w = lw;
 	e.nodes = nullptr;
@@ -1032,6 +1029,7 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 	DEV_ALLOC(e->d_frame, 1);
 	DEV_ALLOC(e->d_geo, NNODES);
 	HIP_TRY(hipMemcpy(e->d_geo, e->geo.data(), sizeof(Geo) * NNODES, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(henc_geo_table), e->geo.data(), sizeof(Geo) * NNODES));   // (the same tree for every encoder: 64 x 64 CTUs, prediction depth 4)
 	DEV_ALLOC(e->d.ctus, s.nctu);
 	if (e->cfg.wfpp_num_threads <= 1) DEV_ALLOC(e->d.ctus_start, s.nctu);   // (the frame-start state CTUs are re-encoded from: single-thread order only)
 	{

@@ -487,7 +487,7 @@ int henc_cpu_frame_ctus(void *h, const uint8_t *y, const uint8_t *u, const uint8
 	e.T = hmr_host_tables();
 	fast_tables_fill(CpuGrp(), c.ft, e.T, c.f.qp % 6, chroma_qp_table(c.f.qp + c.seq.chroma_qp_offset) % 6);
 	e.ft = &c.ft;
-	e.geo = c.geo;
+	e.geo.p = c.geo;
 	e.ctus = c.ctus.data();
 	e.w = c.w;
 	CpuGrp g;
@@ -557,7 +557,7 @@ int henc_cpu_frame_ctus_wavefront(void *h, const uint8_t *y, const uint8_t *u, c
 	while ((int)c.row_w.size() < s.hctu) c.row_w.push_back(new_work());
 	Enc e;
 	memset(&e, 0, sizeof e);
-	e.seq = &c.seq; e.f = &c.f; e.T = hmr_host_tables(); e.geo = c.geo; e.ctus = c.ctus.data();
+	e.seq = &c.seq; e.f = &c.f; e.T = hmr_host_tables(); e.geo.p = c.geo; e.ctus = c.ctus.data();
 	fast_tables_fill(CpuGrp(), c.ft, e.T, c.f.qp % 6, chroma_qp_table(c.f.qp + c.seq.chroma_qp_offset) % 6);
 	e.ft = &c.ft;
 	CpuGrp g;

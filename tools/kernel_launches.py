@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-launch durations of k_encode_ctus from a rocprofv3 --kernel-trace csv beside the HIP-event times bench.py measured in the same run.
+"""Per-launch durations of k_encode_pool (the CTU stage) from a rocprofv3 --kernel-trace csv beside the HIP-event times bench.py measured in the same run.
 
     tools/kernel_launches.py gpurun_out/prof_r02/bench_kernel_trace.csv gpurun_out/r02_bench_under_rocprof.json > profiles/r02_k_encode_ctus_launches.json
 """
@@ -7,9 +7,12 @@ import csv
 import json
 import sys
 
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_encode_ctus" in r["Kernel_Name"]]
-if any("k_encode_ctus_batch" in r["Kernel_Name"] for r in rows):      # the bench's headline runs the batch kernel; the single-sequence run beside it is not listed here
-    rows = [r for r in rows if "k_encode_ctus_batch" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_encode_pool" in r["Kernel_Name"]]
+# the bench's headline is the batch of sequences (a launch of as many workgroups as the GPU has CUs); the single-sequence run beside it (17 workgroups) is not listed here
+gkey = next((k for k in ("Grid_Size", "Grid_Size_X", "Workgroup_Count") if rows and k in rows[0]), None)
+if gkey:
+    big = max(int(r[gkey]) for r in rows)
+    rows = [r for r in rows if int(r[gkey]) == big]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ms = [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, 2) for r in rows]
 b = json.load(open(sys.argv[2]))

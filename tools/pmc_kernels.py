@@ -37,9 +37,11 @@ def main():
             tot = k.get("TCC_HIT_sum", 0) + k.get("TCC_MISS_sum", 0)
             if tot:
                 d["l2_hit_rate"] = round(k["TCC_HIT_sum"] / tot, 4)
-        if name.startswith("k_encode_ctus"):
+        if name.startswith("k_encode_ctus") or name.startswith("k_encode_pool"):
             d["note"] = (f"rocprofv3 --pmc passes of `{cmd}`; sums over all launches of the kernel (three wavefronts per workgroup: the row worker and two "
                          "helpers, whose polling counts as waiting); SQ cycle counters in quad-cycles")
+            if k.get("SQ_WAVE_CYCLES"):
+                d["valu_share_of_issue"] = round(k.get("SQ_INSTS_VALU", 0) / max(k.get("SQ_INSTS_VALU", 0) + k.get("SQ_INSTS_SALU", 0), 1), 3)
         k["derived"] = d
     json.dump(kernels, sys.stdout, indent=1)
     print()
