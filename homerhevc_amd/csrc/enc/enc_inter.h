@@ -54,9 +54,38 @@ HENC_HD void motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv
 	PRIM_T0();
 	const uint8_t *py = e.f->sub_y + (size_t)(((mv.y & 3) << 2) | (mv.x & 3)) * S.plane_elems_y + (gy + (mv.y >> 2)) * S.stride_y + gx + (mv.x >> 2);
 	const size_t oc = (size_t)(((mv.y & 7) << 3) | (mv.x & 7)) * S.plane_elems_c + (gyc + (mv.y >> 3)) * S.stride_c + gxc + (mv.x >> 3);
-	blk_from_u8(g, e.f->sub_c[0] + oc, S.stride_c, w.pred_c[0] + q.yc * 32 + q.xc, 32, q.size_chroma);
-	blk_from_u8(g, e.f->sub_c[1] + oc, S.stride_c, w.pred_c[1] + q.yc * 32 + q.xc, 32, q.size_chroma);
-	blk_from_u8(g, py, S.stride_y, w.pred_y + q.y * 64 + q.x, 64, q.size);
+	if (q.size <= 32) {
+		// every load of the three blocks is issued before the first store waits for one: the copy costs one trip to the planes, not three
+		const int n = q.size, nc = q.size_chroma, lw = ilog2i(n) - 2, lc = ilog2i(nc) - 2, ychunks = (n * n) >> 2, cchunks = (nc * nc) >> 2;
+		const uint8_t *pu = e.f->sub_c[0] + oc, *pv = e.f->sub_c[1] + oc;
+		int16_t *dy = w.pred_y + q.y * 64 + q.x, *du = w.pred_c[0] + q.yc * 32 + q.xc, *dv = w.pred_c[1] + q.yc * 32 + q.xc;
+		uint32_t vy[4] = {0, 0, 0, 0}, vu = 0, vv = 0;
+		const int ic = g.tid, rc = ic >> lc, cc = (ic & ((1 << lc) - 1)) << 2;
+		if (ic < cchunks) { vu = ld32u(pu + rc * S.stride_c + cc); vv = ld32u(pv + rc * S.stride_c + cc); }
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const int i = g.tid + 64 * k;
+			if (i < ychunks) vy[k] = ld32u(py + (i >> lw) * S.stride_y + ((i & ((1 << lw) - 1)) << 2));
+		}
+		if (ic < cchunks) {
+			const uint32_t ou[2] = {__builtin_amdgcn_perm(0u, vu, 0x0c010c00u), __builtin_amdgcn_perm(0u, vu, 0x0c030c02u)};
+			const uint32_t ov[2] = {__builtin_amdgcn_perm(0u, vv, 0x0c010c00u), __builtin_amdgcn_perm(0u, vv, 0x0c030c02u)};
+			__builtin_memcpy(du + rc * 32 + cc, ou, 8);
+			__builtin_memcpy(dv + rc * 32 + cc, ov, 8);
+		}
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const int i = g.tid + 64 * k;
+			if (i < ychunks) {
+				const uint32_t o[2] = {__builtin_amdgcn_perm(0u, vy[k], 0x0c010c00u), __builtin_amdgcn_perm(0u, vy[k], 0x0c030c02u)};
+				__builtin_memcpy(dy + (i >> lw) * 64 + ((i & ((1 << lw) - 1)) << 2), o, 8);
+			}
+		}
+	} else {
+		blk_from_u8(g, e.f->sub_c[0] + oc, S.stride_c, w.pred_c[0] + q.yc * 32 + q.xc, 32, q.size_chroma);
+		blk_from_u8(g, e.f->sub_c[1] + oc, S.stride_c, w.pred_c[1] + q.yc * 32 + q.xc, 32, q.size_chroma);
+		blk_from_u8(g, py, S.stride_y, w.pred_y + q.y * 64 + q.x, 64, q.size);
+	}
 	g.sync();
 	PRIM_END(PP_INTERP);
 #else

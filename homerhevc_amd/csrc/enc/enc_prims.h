@@ -710,6 +710,17 @@ HENC_INLINE uint32_t ft_list_value(const uint16_t *cells, uint32_t flat, int i, 
 	const int s = log2n - 3, y = i >> log2n, x = i & ((1 << log2n) - 1);
 	return cells[((y >> s) << 3) | (x >> s)];
 }
+// the same for the four elements i0 .. i0 + 3 of a row (i0 a multiple of 4): one, two or four cells
+HENC_INLINE void ft_list_value4(const uint16_t *cells, uint32_t flat, int i0, int log2n, uint32_t *v)
+{
+	if (log2n == 2) { v[0] = v[1] = v[2] = v[3] = flat; return; }
+	const int s = log2n - 3, y = i0 >> log2n, x = i0 & ((1 << log2n) - 1);
+	const uint16_t *c = cells + (((y >> s) << 3) | (x >> s));
+	if (s == 0) { v[0] = c[0]; v[1] = c[1]; v[2] = c[2]; v[3] = c[3]; }
+	else if (s == 1) { v[0] = v[1] = c[0]; v[2] = v[3] = c[1]; }
+	else v[0] = v[1] = v[2] = v[3] = c[0];
+	if (i0 == 0 && log2n > 3) v[0] = flat;
+}
 template <class G>
 HENC_HD void fast_tables_fill(const G &g, FastTables &F, const DevTables *T, int rem_y, int rem_c)
 {
@@ -961,11 +972,35 @@ HENC_PRIM int quantize(const G &g, const FastTables *F, const DevTables *T, cons
 	const int32_t *q = T->quant[inv_depth - 2][list][rem];
 	const uint16_t *cells = fast ? F->q8[rc][ft_list_kind(inv_depth, list)] : nullptr;
 	const uint32_t flat = fast ? F->q_flat[rc] : 0;
+	if (fast) {
+		// four coefficients per lane and step; the list values from the 8 x 8 cells in fast memory
+#pragma unroll 2
+		for (int i = g.tid * 4; i < total; i += g.n * 4) {
+			const S4 sv4 = ld4(src + i);
+			uint32_t qv[4];
+			ft_list_value4(cells, flat, i, inv_depth, qv);
+			S4 lv, du;
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const int sv = sv4.v[k];
+				const uint32_t a = (uint16_t)(sv < 0 ? -sv : sv);
+				const int32_t aux = (int32_t)(a * qv[k]);
+				const int32_t c = (int32_t)((uint32_t)aux + (uint32_t)add) >> qbits;
+				const int32_t d = (int32_t)((uint32_t)aux - ((uint32_t)c << qbits)) >> qbits8;
+				const int sgn = sv > 0 ? 1 : (sv < 0 ? -1 : 0);
+				sum += (uint32_t)c;
+				lv.v[k] = (int16_t)(sgn * sat16(c));
+				du.v[k] = sat16(d);
+			}
+			st4(dst + i, lv);
+			st4(delta_u + i, du);
+		}
+	} else {
 	#pragma unroll 4
 	for (int i = g.tid; i < total; i += g.n) {
 		const int sv = src[i];
 		const uint32_t a = (uint16_t)(sv < 0 ? -sv : sv);
-		const uint32_t qv = fast ? ft_list_value(cells, flat, i, inv_depth) : (uint32_t)q[i];
+		const uint32_t qv = (uint32_t)q[i];
 		const int32_t aux = (int32_t)(a * qv);
 		const int32_t c = (int32_t)((uint32_t)aux + (uint32_t)add) >> qbits;
 		const int32_t d = (int32_t)((uint32_t)aux - ((uint32_t)c << qbits)) >> qbits8;
@@ -973,6 +1008,7 @@ HENC_PRIM int quantize(const G &g, const FastTables *F, const DevTables *T, cons
 		sum += (uint32_t)c;
 		dst[i] = (int16_t)(sgn * sat16(c));
 		delta_u[i] = sat16(d);
+	}
 	}
 	const int ac_sum = (int)g.sum(sum);
 	g.sync();
@@ -995,19 +1031,26 @@ HENC_PRIM void dequantize(const G &g, const FastTables *F, const DevTables *T, c
 	const uint16_t *cells = fast ? F->iq8[rc][ft_list_kind(inv_depth, list)] : nullptr;
 	const uint32_t flat = fast ? F->iq_flat[rc] : 0;
 	const int iq_shift = 20 - 14 - (15 - 8 - inv_depth) + 4, total = n * n;
-	if (iq_shift > per) {
+	if (fast) {
+		const int32_t add = iq_shift > per ? 1 << (iq_shift - per - 1) : 0;
+		const int sh = iq_shift > per ? iq_shift - per : per - iq_shift;
+		for (int i = g.tid * 4; i < total; i += g.n * 4) {
+			const S4 lv = ld4(src + i);
+			uint32_t v[4];
+			ft_list_value4(cells, flat, i, inv_depth, v);
+			S4 o;
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				o.v[k] = iq_shift > per ? sat16((int32_t)((uint32_t)(int32_t)lv.v[k] * v[k] + (uint32_t)add) >> sh) : sat16((int32_t)(((uint32_t)(int32_t)lv.v[k] * v[k]) << sh));
+			st4(dst + i, o);
+		}
+	} else if (iq_shift > per) {
 		const int32_t add = 1 << (iq_shift - per - 1);
 		const int sh = iq_shift - per;
-		for (int i = g.tid; i < total; i += g.n) {
-			const uint32_t v = fast ? ft_list_value(cells, flat, i, inv_depth) : (uint32_t)iq[i];
-			dst[i] = sat16((int32_t)((uint32_t)(int32_t)src[i] * v + (uint32_t)add) >> sh);
-		}
+		for (int i = g.tid; i < total; i += g.n) dst[i] = sat16((int32_t)((uint32_t)(int32_t)src[i] * (uint32_t)iq[i] + (uint32_t)add) >> sh);
 	} else {
 		const int sh = per - iq_shift;
-		for (int i = g.tid; i < total; i += g.n) {
-			const uint32_t v = fast ? ft_list_value(cells, flat, i, inv_depth) : (uint32_t)iq[i];
-			dst[i] = sat16((int32_t)(((uint32_t)(int32_t)src[i] * v) << sh));
-		}
+		for (int i = g.tid; i < total; i += g.n) dst[i] = sat16((int32_t)(((uint32_t)(int32_t)src[i] * (uint32_t)iq[i]) << sh));
 	}
 	g.sync();
 	PRIM_END(PP_DEQUANT);
