@@ -52,7 +52,8 @@ struct Enc {
 	FastPtr<const FastTables> ft;   // the tables a TU reads, in the worker's fast memory (enc_prims.h)
 	GeoTable geo;
 	CtuInfo *ctus;         // all CTUs of the picture (persistent across frames)
-	FastPtr<CtuPublic> ctu;   // the side-info record of the CTU being encoded: ctu_g's, or the worker's fast copy of it (ctu_fast != nullptr) while the CTU is encoded
+	CtuPublic *ctu;           // the side-info record of the CTU being encoded: ctu_g's (HBM), or the worker's fast copy of it (ctu_fast != nullptr) while the CTU is encoded -
+	                          // a plain pointer: FastPtr promises the compiler LDS, which is only true for the copy
 	CtuInfo *ctu_g;        // its home in the picture array (logs, nodes; neighbours are ctu_g - 1, ctu_g - wctu ...)
 	CtuPublic *ctu_fast;
 	FastPtr<Work> w;

@@ -654,18 +654,8 @@ HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 		const int pw = comp ? S.width >> 1 : S.width, ph = comp ? S.height >> 1 : S.height;
 		const int ss = comp ? S.src_stride_c : S.src_stride_y;
 		const int ww = (px + sz) < pw ? sz : pw - px, hh = (py + sz) < ph ? sz : ph - py;
-		blk_copy(g, e.f->src[comp] + py * ss + px, ss, curr_ptr(w, comp), sz, hh, ww);
+		blk_copy_to_src(g, e.f->src[comp] + py * ss + px, ss, curr_ptr(w, comp), sz, hh, ww);
 	}
-#if defined(__HIPCC__)
-	// the luma source as bytes, for the motion search against the 8-bit phase planes
-	for (int i = g.tid * 4; i < 64 * 64; i += g.n * 4) {
-		uint32_t lo, hi;   // samples 0, 1 and 2, 3 as 16-bit pairs; their low bytes -> one dword (v_perm_b32: bytes 0-3 come from the second operand, 4-7 from the first)
-		__builtin_memcpy(&lo, w.curr_y + i, 4);
-		__builtin_memcpy(&hi, w.curr_y + i + 2, 4);
-		*(uint32_t *)(w.curr_y8 + i) = __builtin_amdgcn_perm(hi, lo, 0x06040200u);
-	}
-	g.sync();
-#endif
 	// neighbour samples of the picture under reconstruction into every decoded window
 	if (c.has_left || c.has_top) {
 		for (int comp = 0; comp < 3; comp++) {

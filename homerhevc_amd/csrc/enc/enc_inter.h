@@ -108,7 +108,7 @@ HENC_HD void cand_sads(const G &g, Enc &__restrict__ e, int ox, int oy, int gx, 
 #pragma unroll
 	for (int k = 0; k < MAXC; k++)
 		cand[k] = ok[k] ? p0 + (size_t)(((qy[k] & 3) << 2) | (qx[k] & 3)) * S.plane_elems_y + (qy[k] >> 2) * S.stride_y + (qx[k] >> 2) : nullptr;
-	multi_sad_u8<MAXC>(g, e.w->curr_y8 + oy * 64 + ox, size, cand, S.stride_y, out);
+	multi_sad_u8<MAXC>(g, e.w->curr_y + oy * 64 + ox, size, cand, S.stride_y, out);
 #else
 	const int16_t *orig = e.w->curr_y + oy * 64 + ox, *ref = e.f->ref[0] + gy * S.stride_y + gx;
 	for (int k = 0; k < MAXC; k++) {
@@ -513,13 +513,13 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 	const int off = is_y ? (q.abs_index << 4) : ((q.abs_index << 4) >> 2);
 	const int16_t *pred = pred_ptr(w, comp) + y * cs + x;
 	int16_t *resid = resid_ptr(w, comp) + y * cs + x;
-	int16_t *quant = tq_ptr(w, wnd, comp) + off, *iquant = iq_ptr(w, comp) + off;
+	int16_t *quant = tq_ptr(w, wnd, comp) + off, *iquant = iq_slot(w, comp, off);
 	int16_t *dec = dec_ptr(w, wnd, comp) + y * ds + x;
 	// The chain runs in the worker's fast memory: coefficients in scratch_a, rounding remainders in scratch_b, the levels in the block's slot of the
 	// dequantised-coefficient buffer (dequantised in place afterwards), the reconstructed residual in scratch_b (the reference's separate window, which
 	// nothing else reads); only the final levels and the reconstruction go to the windows in HBM.
 	int16_t *rdec = e.scratch_b;
-	tr_forward(g, e.ft, resid, cs, e.scratch_a, e.scratch_b, n, 0);
+	tr_forward(g, e.ft, e.T, resid, cs, e.scratch_a, e.scratch_b, n, 0);
 	int sum = quantize(g, e.ft, e.T, e.scratch_a, iquant, e.scratch_b, SCAN_DIAG, curr_depth, comp, 0, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
 	nd.inter_cbf[comp] = (sum ? 1 : 0) << (original_depth - depth);
 	if (is_y) nd.inter_tr_idx = original_depth - depth;
@@ -528,7 +528,7 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 		lin_copy_nosync(g, iquant, quant, n * n);
 		const uint32_t raw_zero = blk_ssq(g, resid, cs, n);
 		dequantize(g, e.ft, e.T, iquant, iquant, curr_depth, comp, 0, n, per, rem);
-		tr_inverse(g, e.ft, rdec, n, iquant, e.scratch_a, n, 0);
+		tr_inverse(g, e.ft, e.T, rdec, n, iquant, e.scratch_a, n, 0);
 		const uint32_t raw = blk_ssd(g, resid, cs, rdec, n, n);
 		uint32_t ssd_zero;
 		if (is_y) { ssd_zero = raw_zero; ssd = raw; }

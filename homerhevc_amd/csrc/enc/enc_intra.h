@@ -163,7 +163,7 @@ HENC_HD int intra_mode_search(const G &g, Enc &__restrict__ e, int ni, int depth
 		e.n_spec_reads++;
 	}
 	int16_t *pred = w.pred_y + q.y * CTU_STRIDE_Y + q.x;
-	const int16_t *orig = w.curr_y + q.y * CTU_STRIDE_Y + q.x;
+	const src_t *orig = w.curr_y + q.y * CTU_STRIDE_Y + q.x;
 	return intra_search_walk_batched(preds, rd_fast, e.f->sqrt_lambda, [&](const int *modes, int cnt, int64_t *sads) -> bool {
 		// with helper wavefronts: rounds of 1 + NHELP candidates, the worker always taking the last one of the round (so that the prediction
 		// left in the window is the one the serial order leaves there); the helpers only return the SAD
@@ -202,8 +202,8 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 	const int per = nd.qp / 6, rem = nd.qp % 6;
 	const int wnd = curr_depth + 1;
 	int16_t *pred = w.pred_y + q.y * CTU_STRIDE_Y + q.x, *resid = w.resid_y + q.y * CTU_STRIDE_Y + q.x;
-	const int16_t *orig = w.curr_y + q.y * CTU_STRIDE_Y + q.x;
-	int16_t *quant = tq_ptr(w, wnd, COMP_Y) + (q.abs_index << 4), *iquant = w.iq_y + (q.abs_index << 4);
+	const src_t *orig = w.curr_y + q.y * CTU_STRIDE_Y + q.x;
+	int16_t *quant = tq_ptr(w, wnd, COMP_Y) + (q.abs_index << 4), *iquant = iq_slot(w, COMP_Y, q.abs_index << 4);
 	int16_t *dec = dec_ptr(w, wnd, COMP_Y) + q.y * DEC_STRIDE_Y + q.x;
 	const int inv_depth = e.seq->max_cu_size_shift - curr_depth;
 	const int filt = intra_is_filtered(cu_mode, inv_depth);
@@ -211,7 +211,7 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 	intra_predict(g, pred, CTU_STRIDE_Y, filt ? w.adi_f : w.adi, n, cu_mode, 1);
 	blk_predict(g, orig, CTU_STRIDE_Y, pred, CTU_STRIDE_Y, resid, CTU_STRIDE_Y, n);
 	// transform chain in fast memory (see encode_inter_tu): levels in the block's slot of the dequantised-coefficient buffer, to the window in HBM when final
-	tr_forward(g, e.ft, resid, CTU_STRIDE_Y, w.pred_aux, w.delta_u, n, cu_mode != REG_DCT);
+	tr_forward(g, e.ft, e.T, resid, CTU_STRIDE_Y, w.pred_aux, w.delta_u, n, cu_mode != REG_DCT);
 	const int sum = quantize(g, e.ft, e.T, w.pred_aux, iquant, w.delta_u, scan_mode, curr_depth, COMP_Y, 1, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
 	*curr_sum = sum;
 	const int tr = curr_depth - depth + (part_size_type == PART_NxN);
@@ -222,7 +222,7 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 	if (sum) {
 		lin_copy_nosync(g, iquant, quant, n * n);
 		dequantize(g, e.ft, e.T, iquant, iquant, curr_depth, COMP_Y, 1, n, per, rem);
-		tr_inverse(g, e.ft, resid, CTU_STRIDE_Y, iquant, w.pred_aux, n, cu_mode != REG_DCT);
+		tr_inverse(g, e.ft, e.T, resid, CTU_STRIDE_Y, iquant, w.pred_aux, n, cu_mode != REG_DCT);
 		return blk_reconst_ssd(g, pred, CTU_STRIDE_Y, resid, CTU_STRIDE_Y, orig, CTU_STRIDE_Y, dec, DEC_STRIDE_Y, n);
 	}
 	lin_zero_nosync(g, quant, n * n);
@@ -392,7 +392,7 @@ HENC_HD void chroma_search_comp(const G &g, Enc &__restrict__ e, int curr, int c
 	const Geo &q = e.geo[curr];
 	const int n = q.size_chroma;
 	int16_t *pred = pred_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
-	const int16_t *orig = curr_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
+	const src_t *orig = curr_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
 	for (int mi = 0; mi < 5; mi++) {
 		node_fill_refs(g, e, curr, NWND - 1, c, 0);
 		sads[mi] = intra_predict_sad(g, pred, CTU_STRIDE_C, orig, CTU_STRIDE_C, e.adi_c, n, cand[mi], 0);
@@ -406,13 +406,13 @@ HENC_HD int chroma_tu_comp(const G &g, Enc &__restrict__ e, int curr, int c, int
 	const Geo &q = e.geo[curr];
 	const int n = q.size_chroma, curr_depth = q.depth, qwnd = NWND - 1, dwnd = NWND - 1;
 	int16_t *pred = pred_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc, *resid = resid_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
-	const int16_t *orig = curr_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
-	int16_t *quant = tq_ptr(w, qwnd, c) + ((q.abs_index << 4) >> 2), *iquant = iq_ptr(w, c) + ((q.abs_index << 4) >> 2);
+	const src_t *orig = curr_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
+	int16_t *quant = tq_ptr(w, qwnd, c) + ((q.abs_index << 4) >> 2), *iquant = iq_slot(w, c, (q.abs_index << 4) >> 2);
 	int16_t *dec = dec_ptr(w, dwnd, c) + q.yc * DEC_STRIDE_C + q.xc;
 	node_fill_refs(g, e, curr, dwnd, c, 0);
 	intra_predict(g, pred, CTU_STRIDE_C, e.adi_c, n, cu_mode, 0);
 	blk_predict(g, orig, CTU_STRIDE_C, pred, CTU_STRIDE_C, resid, CTU_STRIDE_C, n);
-	tr_forward(g, e.ft, resid, CTU_STRIDE_C, e.scratch_a, e.scratch_b, n, 0);
+	tr_forward(g, e.ft, e.T, resid, CTU_STRIDE_C, e.scratch_a, e.scratch_b, n, 0);
 	const int curr_sum = quantize(g, e.ft, e.T, e.scratch_a, iquant, e.scratch_b, scan_mode, curr_depth, c, 1, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
 	const int cbfv = ((curr_sum ? 1 : 0) << (shifts & 255)) | ((curr_sum ? 1 : 0) << (shifts >> 8));
 	bytes_set(g, &w.cbf_chroma[c - 1][q.abs_index], cbfv, q.num_part);
@@ -420,7 +420,7 @@ HENC_HD int chroma_tu_comp(const G &g, Enc &__restrict__ e, int curr, int c, int
 	if (curr_sum) {
 		lin_copy_nosync(g, iquant, quant, n * n);
 		dequantize(g, e.ft, e.T, iquant, iquant, curr_depth, c, 1, n, per, rem);
-		tr_inverse(g, e.ft, resid, CTU_STRIDE_C, iquant, e.scratch_a, n, 0);
+		tr_inverse(g, e.ft, e.T, resid, CTU_STRIDE_C, iquant, e.scratch_a, n, 0);
 		raw = blk_reconst_ssd(g, pred, CTU_STRIDE_C, resid, CTU_STRIDE_C, orig, CTU_STRIDE_C, dec, DEC_STRIDE_C, n);
 	} else {
 		lin_zero_nosync(g, quant, n * n);

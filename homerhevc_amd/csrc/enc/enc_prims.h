@@ -39,9 +39,18 @@ HENC_INLINE void split_rc(int k, int w, int lw, int *r, int *c)
 struct S4 { int16_t v[4]; };
 HENC_INLINE S4 ld4(const int16_t *p) { S4 r; __builtin_memcpy(&r, p, 8); return r; }
 HENC_INLINE void st4(int16_t *p, const S4 &v) { __builtin_memcpy(p, &v, 8); }
+// four source samples (enc_types.h src_t: bytes on the device) as 16-bit values
+HENC_INLINE S4 ld4(const uint8_t *p)
+{
+	uint32_t v;
+	__builtin_memcpy(&v, p, 4);
+	S4 r;
+	r.v[0] = (int16_t)(v & 255); r.v[1] = (int16_t)((v >> 8) & 255); r.v[2] = (int16_t)((v >> 16) & 255); r.v[3] = (int16_t)(v >> 24);
+	return r;
+}
 
-template <class G>
-HENC_PRIM uint32_t blk_sad(const G &g, const int16_t *a, int as, const int16_t *b, int bs, int n)
+template <class G, class S>
+HENC_PRIM uint32_t blk_sad(const G &g, const S *a, int as, const int16_t *b, int bs, int n)
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
@@ -125,8 +134,8 @@ __device__ __forceinline__ void blk_from_u8(const WaveGrp &g, const uint8_t *s, 
 }
 #endif
 
-template <class G>
-HENC_PRIM uint32_t blk_ssd(const G &g, const int16_t *a, int as, const int16_t *b, int bs, int n)
+template <class G, class S>
+HENC_PRIM uint32_t blk_ssd(const G &g, const S *a, int as, const int16_t *b, int bs, int n)
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
@@ -160,8 +169,8 @@ HENC_PRIM uint32_t blk_ssq(const G &g, const int16_t *a, int as, int n)
 	{ const auto prim_ret_ = g.sum(acc); PRIM_END(PP_SSD); return prim_ret_; }
 }
 
-template <class G>
-HENC_PRIM void blk_predict(const G &g, const int16_t *o, int os, const int16_t *p, int ps, int16_t *r, int rs, int n)
+template <class G, class S>
+HENC_PRIM void blk_predict(const G &g, const S *o, int os, const int16_t *p, int ps, int16_t *r, int rs, int n)
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
@@ -199,8 +208,8 @@ HENC_PRIM void blk_reconst(const G &g, const int16_t *p, int ps, const int16_t *
 }
 
 // reconstruction and its distance from the source in one pass (the reference reconstructs, then reads the window back for ssd16b, hmr_motion_intra.c:1061-1068)
-template <class G>
-HENC_PRIM uint32_t blk_reconst_ssd(const G &g, const int16_t *p, int ps, const int16_t *res, int rs, const int16_t *o, int os, int16_t *d, int ds, int n)
+template <class G, class S>
+HENC_PRIM uint32_t blk_reconst_ssd(const G &g, const int16_t *p, int ps, const int16_t *res, int rs, const S *o, int os, int16_t *d, int ds, int n)
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
@@ -242,6 +251,25 @@ HENC_PRIM void blk_copy(const G &g, const int16_t *s, int ss, int16_t *d, int ds
 			split_rc(i, w, lw, &y, &x);
 			d[y * ds + x] = s[y * ss + x];
 		}
+	}
+	g.sync();
+	PRIM_END(PP_BLK);
+}
+
+// a block of a 16-bit picture plane into the CTU's source buffer (bytes on the device); w a multiple of 4
+template <class G>
+HENC_PRIM void blk_copy_to_src(const G &g, const int16_t *s, int ss, src_t *d, int ds, int h, int w)
+{
+	PRIM_T0();
+	const int cw = w >> 2;
+	for (int i = g.tid; i < h * cw; i += g.n) {
+		const int y = i / cw, x = (i - y * cw) << 2;
+		const S4 v = ld4(s + y * ss + x);
+#if defined(__HIPCC__)
+		*(uint32_t *)(d + y * ds + x) = (uint32_t)(v.v[0] & 255) | ((uint32_t)(v.v[1] & 255) << 8) | ((uint32_t)(v.v[2] & 255) << 16) | ((uint32_t)(v.v[3] & 255) << 24);
+#else
+		st4(d + y * ds + x, v);
+#endif
 	}
 	g.sync();
 	PRIM_END(PP_BLK);
@@ -533,8 +561,8 @@ HENC_PRIM void intra_predict(const G &g, int16_t *pred, int ps, const int16_t *a
 }
 
 // prediction + SAD against the source in one pass; the prediction is also stored (later stages of the reference read it)
-template <class G>
-HENC_PRIM uint32_t intra_predict_sad(const G &g, int16_t *pred, int ps, const int16_t *orig, int os, const int16_t *adi, int n, int mode, int is_luma)
+template <class G, class S>
+HENC_PRIM uint32_t intra_predict_sad(const G &g, int16_t *pred, int ps, const S *orig, int os, const int16_t *adi, int n, int mode, int is_luma)
 {
 	PRIM_T0();
 	const IntraPredictor p = intra_setup(adi, n, mode, is_luma);
@@ -846,9 +874,19 @@ HENC_HD void tr_inverse_n(const G &g, const int16_t *Mt, int16_t *block, int bs,
 }
 
 template <class G>
-HENC_PRIM void tr_forward(const G &g, const FastTables *F, const int16_t *block, int bs, int16_t *coeff, int16_t *tmp, int n, int is_dst)
+HENC_PRIM void tr_forward(const G &g, const FastTables *F, const DevTables *T, const int16_t *block, int bs, int16_t *coeff, int16_t *tmp, int n, int is_dst)
 {
 	PRIM_T0();
+	if (!F) {
+		switch (n) {
+		case 4: tr_forward_n<4>(g, is_dst ? T->dst4 : T->dct[0], block, bs, coeff, tmp); break;
+		case 8: tr_forward_n<8>(g, T->dct[1], block, bs, coeff, tmp); break;
+		case 16: tr_forward_n<16>(g, T->dct[2], block, bs, coeff, tmp); break;
+		default: tr_forward_n<32>(g, T->dct[3], block, bs, coeff, tmp); break;
+		}
+		PRIM_END(PP_TRF);
+		return;
+	}
 	switch (n) {
 	case 4: tr_forward_n<4>(g, is_dst ? F->dst4 : F->dct, block, bs, coeff, tmp); break;
 	case 8: tr_forward_n<8>(g, F->dct + 16, block, bs, coeff, tmp); break;
@@ -859,9 +897,19 @@ HENC_PRIM void tr_forward(const G &g, const FastTables *F, const int16_t *block,
 }
 
 template <class G>
-HENC_PRIM void tr_inverse(const G &g, const FastTables *F, int16_t *block, int bs, const int16_t *coeff, int16_t *tmp, int n, int is_dst)
+HENC_PRIM void tr_inverse(const G &g, const FastTables *F, const DevTables *T, int16_t *block, int bs, const int16_t *coeff, int16_t *tmp, int n, int is_dst)
 {
 	PRIM_T0();
+	if (!F) {
+		switch (n) {
+		case 4: tr_inverse_n<4>(g, is_dst ? T->dst4_t : T->dct_t[0], block, bs, coeff, tmp); break;
+		case 8: tr_inverse_n<8>(g, T->dct_t[1], block, bs, coeff, tmp); break;
+		case 16: tr_inverse_n<16>(g, T->dct_t[2], block, bs, coeff, tmp); break;
+		default: tr_inverse_n<32>(g, T->dct_t[3], block, bs, coeff, tmp); break;
+		}
+		PRIM_END(PP_TRI);
+		return;
+	}
 	switch (n) {
 	case 4: tr_inverse_n<4>(g, is_dst ? F->dst4_t : F->dct_t, block, bs, coeff, tmp); break;
 	case 8: tr_inverse_n<8>(g, F->dct_t + 16, block, bs, coeff, tmp); break;

@@ -169,22 +169,34 @@ struct WorkSlow {
 	int16_t dec_y[NWND][DEC_ROWS_Y * DEC_STRIDE_Y], dec_c[NWND][2][DEC_ROWS_C * DEC_STRIDE_C];
 };
 
+// Source samples of the CTU: bytes on the device (LDS is what limits how many row workers a CU holds: two fit when a worker's state stays under 80 KB),
+// the reference's 16-bit width in the checker build.  Block primitives take the source operand as a template parameter.
+#if defined(__HIPCC__)
+typedef uint8_t src_t;
+constexpr int TU_SCRATCH = 32 * 32;        // coefficients / remainders / levels of the TU in flight: a TU is at most 32 x 32
+#else
+typedef int16_t src_t;
+constexpr int TU_SCRATCH = 64 * 64;        // (the checker's motion search also interpolates candidate blocks of up to 64 x 64 into pred_aux)
+#endif
+
 struct Work {
-	int16_t curr_y[64 * 64], curr_c[2][32 * 32];
+	src_t curr_y[64 * 64], curr_c[2][32 * 32];
 	int16_t pred_y[64 * 64], pred_c[2][32 * 32];
 	int16_t resid_y[64 * 64], resid_c[2][32 * 32];
+#if defined(__HIPCC__)
+	int16_t iq_y[32 * 32], iq_c[2][32 * 32];   // levels, then dequantised coefficients, of the TU in flight (one slot per component: the helpers run chroma beside luma)
+#else
 	int16_t iq_y[64 * 64], iq_c[2][32 * 32];
+#endif
 	uint8_t cbf_buffs[3][NDEPTH][NPART];
 	uint8_t intra_mode_buffs[2][NDEPTH][NPART];
 	uint8_t mode_in[2][NDEPTH][NPART];     // what intra_mode_buffs held when the CTU started (the values behind the tokens)
 	uint8_t tr_idx_buffs[NDEPTH][NPART];
 	uint8_t cbf_chroma[2][NPART];
 	int16_t adi[264], adi_f[264];
-	int16_t pred_aux[64 * 64];             // transform coefficients of the TU in flight; between TUs also the motion search's sub-pel candidate block
-	int16_t delta_u[64 * 64];
-#if defined(__HIPCC__)
-	uint8_t curr_y8[64 * 64];              // the source CTU's luma as bytes: the motion search compares it with the 8-bit phase planes (v_sad_u8)
-#else
+	int16_t pred_aux[TU_SCRATCH];          // transform coefficients of the TU in flight (checker build: between TUs also the motion search's sub-pel candidate block)
+	int16_t delta_u[TU_SCRATCH];
+#if !defined(__HIPCC__)
 	int16_t sub_tmp[(64 + 8) * 72];        // checker build: first interpolation stage of a sub-pel candidate / two-stage motion compensation
 #endif
 	MvCandList amvp, merge_cands, search_cands;
@@ -206,10 +218,19 @@ HENC_INLINE int16_t *dec_ptr(Work &w, int wnd, int comp)
 HENC_INLINE int dec_stride(int comp) { return comp == COMP_Y ? DEC_STRIDE_Y : DEC_STRIDE_C; }
 HENC_INLINE int ctu_stride(int comp) { return comp == COMP_Y ? CTU_STRIDE_Y : CTU_STRIDE_C; }
 HENC_INLINE int16_t *tq_ptr(Work &w, int wnd, int comp) { return comp == COMP_Y ? w.slow->tq_y[wnd] : w.slow->tq_c[wnd][comp - 1]; }
-HENC_INLINE int16_t *curr_ptr(Work &w, int comp) { return comp == COMP_Y ? w.curr_y : w.curr_c[comp - 1]; }
+HENC_INLINE src_t *curr_ptr(Work &w, int comp) { return comp == COMP_Y ? w.curr_y : w.curr_c[comp - 1]; }
 HENC_INLINE int16_t *pred_ptr(Work &w, int comp) { return comp == COMP_Y ? w.pred_y : w.pred_c[comp - 1]; }
 HENC_INLINE int16_t *resid_ptr(Work &w, int comp) { return comp == COMP_Y ? w.resid_y : w.resid_c[comp - 1]; }
 HENC_INLINE int16_t *rdec_ptr(Work &w, int comp) { return comp == COMP_Y ? w.slow->rdec_y : w.slow->rdec_c[comp - 1]; }
-HENC_INLINE int16_t *iq_ptr(Work &w, int comp) { return comp == COMP_Y ? w.iq_y : w.iq_c[comp - 1]; }
+// the TU's slot of the level / dequantised-coefficient buffer (`off`: its place in a CTU-sized buffer, which only the checker build keeps)
+HENC_INLINE int16_t *iq_slot(Work &w, int comp, int off)
+{
+#if defined(__HIPCC__)
+	(void)off;
+	return comp == COMP_Y ? w.iq_y : w.iq_c[comp - 1];
+#else
+	return (comp == COMP_Y ? w.iq_y : w.iq_c[comp - 1]) + off;
+#endif
+}
 
 }  // namespace henc

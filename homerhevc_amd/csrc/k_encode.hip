@@ -64,7 +64,12 @@ constexpr int HSCRATCH_ELEMS = 2048 + 144;   // int16 per helper
 // LDS of a row worker: its Work, a copy of the CTU's partition nodes and of the partition geometry
 constexpr size_t LDS_WORK = (sizeof(Work) + 15) & ~(size_t)15, LDS_NODES = (sizeof(Node) * NNODES + 15) & ~(size_t)15, LDS_GEO = 0;   // (the geometry is in constant memory: enc_common.h GeoTable)
 namespace henc { __constant__ Geo henc_geo_table[NNODES]; }
-constexpr size_t LDS_SEQ = (sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15, LDS_CTU = (sizeof(CtuPublic) + 15) & ~(size_t)15, LDS_FT = (sizeof(FastTables) + 15) & ~(size_t)15;
+// Two things that used to sit in LDS do not any more, so that TWO row workers fit a CU (80 KB each): the CTU's side-info record (the worker reads and writes
+// it in HBM: measured in round 2 to make no difference) and the TU tables (FastTables: transform bases, scans, quantiser cells - from DevTables through L2
+// instead: 1-2 % per worker, against twice the workers).  Set to true to get them back (one worker per CU).
+constexpr bool LDS_KEEPS_CTU_RECORD = false, LDS_KEEPS_TU_TABLES = false;
+constexpr size_t LDS_SEQ = (sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15, LDS_CTU = LDS_KEEPS_CTU_RECORD ? (sizeof(CtuPublic) + 15) & ~(size_t)15 : 0,
+		 LDS_FT = LDS_KEEPS_TU_TABLES ? (sizeof(FastTables) + 15) & ~(size_t)15 : 0;
 #if defined(HENC_PROFILE)
 constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = NHELP * HSCRATCH_ELEMS * 2;
 constexpr size_t LDS_BYTES = 160 * 1024;   // the primitive timers sit at HENC_LDS_PROF_OFFSET
@@ -78,6 +83,7 @@ constexpr size_t LDS_FT_OFFSET = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_
 constexpr int ENC_THREADS = 64 * (1 + NHELP);   // the row worker + its helper wavefronts: one wavefront per SIMD of the CU
 static_assert(ENC_THREADS == WideGrp::n, "a wide job is the whole workgroup");
 static_assert(LDS_BYTES <= 160 * 1024, "a workgroup has 160 KiB of LDS on gfx950");
+constexpr int WORKERS_PER_CU = LDS_BYTES <= 80 * 1024 ? 2 : 1;
 
 // a helper wavefront: run the jobs the worker posts (HelperBox, enc_common.h) until it says quit
 __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
@@ -217,8 +223,8 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 	g.sync();
 	if (g.tid == 0) lframe->scene_cut_ctu = d.counters[2];
 	// the transform bases, scans and this frame's quantiser lists next to the worker (enc_prims.h: FastTables)
-	FastTables *lft = (FastTables *)(lds + LDS_FT_OFFSET);
-	fast_tables_fill(g, *lft, d.tables, lframe->qp % 6, chroma_qp_table(lframe->qp + S.chroma_qp_offset) % 6);
+	FastTables *lft = LDS_KEEPS_TU_TABLES ? (FastTables *)(lds + LDS_FT_OFFSET) : nullptr;
+	if (lft) fast_tables_fill(g, *lft, d.tables, lframe->qp % 6, chroma_qp_table(lframe->qp + S.chroma_qp_offset) % 6);
 #if defined(HENC_PROFILE)
 	if (g.tid < 2 * PP_COUNT) ((unsigned long long *)(lds + HENC_LDS_PROF_OFFSET))[g.tid] = 0;
 #endif
@@ -235,7 +241,7 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 	e.nodes = nullptr;
 	e.nodes_fast = (Node *)(lds + LDS_WORK);
 	e.ctu_g = nullptr;
-	e.ctu_fast = (CtuPublic *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ);
+	e.ctu_fast = LDS_KEEPS_CTU_RECORD ? (CtuPublic *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ) : nullptr;
 	e.box = box;
 	for (int h = 0; h < NHELP; h++) e.hseq[h] = hseq[h];
 	e.prof = d.prof ? d.prof + (size_t)row * PF_COUNT : nullptr;
@@ -363,7 +369,7 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 	wave_copy_words(&e.w->intra_mode_buffs[0][0][0], d.rowstate + (size_t)me * MODE_STATE_BYTES, MODE_STATE_BYTES, g.tid);
 	if (g.tid == 0) e.w->thread_seen_intra = d.thread_seen[me];
 	const int rem_y = lframe->qp % 6, rem_c = chroma_qp_table(lframe->qp + S.chroma_qp_offset) % 6;
-	if (cached_rem[0] != rem_y || cached_rem[1] != rem_c) {
+	if (lft && (cached_rem[0] != rem_y || cached_rem[1] != rem_c)) {
 		fast_tables_fill(g, *lft, d.tables, rem_y, rem_c);
 		cached_rem[0] = rem_y; cached_rem[1] = rem_c;
 	}
@@ -399,7 +405,7 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 	g.sync();
 }
 
-__global__ __launch_bounds__(ENC_THREADS) void k_encode_pool(const EncDev *devs, int nseq, int *state, int *finished, WorkSlow *slow)
+__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void k_encode_pool(const EncDev *devs, int nseq, int *state, int *finished, WorkSlow *slow)
 {
 	if (!rows_enter()) return;
 	extern __shared__ __align__(16) uint8_t lds[];
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_pool(const EncDev *devs,
 	HelperBox *box = (HelperBox *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU);
 	Seq *lseq = (Seq *)(lds + LDS_WORK + LDS_NODES + LDS_GEO);
 	FrameCtx *lframe = (FrameCtx *)((uint8_t *)lseq + ((sizeof(Seq) + 15) & ~(size_t)15));
-	FastTables *lft = (FastTables *)(lds + LDS_FT_OFFSET);
+	FastTables *lft = LDS_KEEPS_TU_TABLES ? (FastTables *)(lds + LDS_FT_OFFSET) : nullptr;
 	if (g.tid == 0) lw->slow = slow + blockIdx.x;
 #if defined(HENC_PROFILE)
 	if (g.tid < 2 * PP_COUNT) ((unsigned long long *)(lds + HENC_LDS_PROF_OFFSET))[g.tid] = 0;
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode_pool(const EncDev *devs,
 	e.nodes = nullptr;
 	e.nodes_fast = (Node *)(lds + LDS_WORK);
 	e.ctu_g = nullptr;
-	e.ctu_fast = (CtuPublic *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ);
+	e.ctu_fast = LDS_KEEPS_CTU_RECORD ? (CtuPublic *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ) : nullptr;
 	e.box = box;
 	for (int h = 0; h < NHELP; h++) e.hseq[h] = 0;
 	e.prof = nullptr;
@@ -599,7 +605,7 @@ struct SrcSlot {
 	int16_t *p[3];
 };
 
-__global__ __launch_bounds__(ENC_THREADS) void k_encode_ctus(EncDev d, int pass)
+__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void k_encode_ctus(EncDev d, int pass)
 {
 	if (!rows_enter()) return;
 	int hseq[NHELP_MAX] = {0, 0, 0};
@@ -855,7 +861,8 @@ int lockstep_collect(hmr_gpu_enc *e)
 int launch_pool(hmr_gpu_enc *lead, int n, int rows_total, hipStream_t st)
 {
 	if (!lead->n_cus) HIP_TRY(hipDeviceGetAttribute(&lead->n_cus, hipDeviceAttributeMultiprocessorCount, lead->ctx->device));
-	const int workers = rows_total < lead->n_cus ? rows_total : lead->n_cus;     // a worker takes a CU's LDS; a picture never has more CTUs in flight than rows
+	const int cap = lead->n_cus * WORKERS_PER_CU;                             // what the LDS lets be resident; more would only queue behind
+	const int workers = rows_total < cap ? rows_total : cap;                  // (a picture never has more CTUs in flight than rows)
 	if (!lead->d_pool_state) HIP_TRY(hipMalloc((void **)&lead->d_pool_state, sizeof(int) * (256 * POOL_STRIDE + 4)));
 	if (lead->pool_workers < workers) {
 		if (lead->d_pool_slow) (void)hipFree(lead->d_pool_slow);
@@ -866,7 +873,8 @@ int launch_pool(hmr_gpu_enc *lead, int n, int rows_total, hipStream_t st)
 		lead->pool_workers = workers;
 	}
 	HIP_TRY(hipMemsetAsync(lead->d_pool_state, 0, sizeof(int) * (256 * POOL_STRIDE + 4), st));
-	hipLaunchKernelGGL(k_encode_pool, dim3(workers), dim3(ENC_THREADS), LDS_BYTES, st, (const EncDev *)lead->d_batch, n, lead->d_pool_state, lead->d_pool_state + 256 * POOL_STRIDE,
+	const size_t lds_bytes = getenv("HENC_LDS_BYTES") ? (size_t)atoi(getenv("HENC_LDS_BYTES")) : LDS_BYTES;   // (experiment: a larger request keeps a CU to one worker)
+	hipLaunchKernelGGL(k_encode_pool, dim3(workers), dim3(ENC_THREADS), lds_bytes, st, (const EncDev *)lead->d_batch, n, lead->d_pool_state, lead->d_pool_state + 256 * POOL_STRIDE,
 			   lead->d_pool_slow);
 	const hipError_t launched = hipGetLastError();
 	if (launched != hipSuccess) {
@@ -1045,7 +1053,7 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 	}
 	DEV_ALLOC(e->d.work_slow, s.hctu);
 	HIP_TRY(hipFuncSetAttribute((const void *)k_encode_ctus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-	HIP_TRY(hipFuncSetAttribute((const void *)k_encode_pool, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+	HIP_TRY(hipFuncSetAttribute((const void *)k_encode_pool, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipEventCreate(&e->ev_frame));
 	HIP_TRY(hipEventCreate(&e->ev_ready));
 	HIP_TRY(hipEventCreate(&e->ev_batch0));
