@@ -95,10 +95,57 @@ def cpu_baseline(width, height, keys, frames):
         t0 = time.time()
         subprocess.run(cmd + [f"wpp={rows}"], check=True, stdout=subprocess.DEVNULL)
         dt_rows = time.time() - t0
-    return {"value": round(frames / dt, 3), "unit": "frames/s", "cores": 1, "kind": "reference",
+    # the same shape as the batch: K independent sequences at once, one single-thread reference process per host core
+    ncores = os.cpu_count() or 1
+    K = max(1, min(ncores, 64))
+    with tempfile.TemporaryDirectory() as tmp:
+        yuv = os.path.join(tmp, "in.yuv")
+        tf = max(4, frames // 3)
+        gen_yuv.write_clip(yuv, width, height, tf)
+        cmd = [exe, yuv, "-", str(width), str(height), str(tf)] + [f"{k}={v}" for k, v in keys.items()]
+        t0 = time.time()
+        procs = [subprocess.Popen(cmd, stdout=subprocess.DEVNULL) for _ in range(K)]
+        for p in procs:
+            p.wait()
+        dt_k = time.time() - t0
+    throughput = {"value": round(K * tf / dt_k, 3), "unit": "frames/s aggregate", "processes": K, "cores": K, "host_cores": ncores, "frames_per_process": tf,
+                  "note": "K single-thread reference processes side by side, one sequence each: the host's answer to a batch of independent sequences"}
+    return {"value": round(frames / dt, 3), "unit": "frames/s", "cores": 1, "kind": "reference", "throughput": throughput,
             "sample": f"{frames} frames {width}x{height} IPPP QP32 through oracle/_ref/ref_lockstep (SSE4.2 table, wpp=1, engines=1), wall time incl. init and file I/O",
             "one_thread_per_ctu_row": {"value": round(frames / dt_rows, 3), "threads": rows, "host_cores": os.cpu_count(),
                                        "note": "the same reference run free with wfpp_num_threads = CTU rows (its multi-thread mode; output depends on timing)"}}
+
+
+def subpel_planes_roofline(lib, torch, width, height, reps=20):
+    """The frame-level kernels that replace every interpolation of the CTU walk (k_subpel.hip): one pass over the padded reference picture per P frame, 2 bytes in and
+    16 (luma) / 64 (chroma) bytes out per sample - streaming work, timed here with events on the context's stream against the HBM peak."""
+    lib.hmr_gpu_subpel_planes.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 3
+    lib.hmr_gpu_stream.restype = C.c_void_p
+    lib.hmr_gpu_stream.argtypes = [C.c_void_p]
+    lib.hmr_gpu_destroy.argtypes = [C.c_void_p]
+    ctx = C.c_void_p()
+    assert lib.hmr_gpu_create(C.byref(ctx), torch.cuda.current_device(), None) == 0
+    sy, ry = ((width * 2 + 15) // 16 * 16) // 2 + 160, height + 160
+    sc, rc = ((width // 2 * 2 + 15) // 16 * 16) // 2 + 80, height // 2 + 80
+    pic = [torch.randint(0, 256, (r * st,), dtype=torch.int16, device="cuda") for st, r in ((sy, ry), (sc, rc), (sc, rc))]
+    out = [torch.empty(16 * sy * ry, dtype=torch.uint8, device="cuda"), torch.empty(64 * sc * rc, dtype=torch.uint8, device="cuda"), torch.empty(64 * sc * rc, dtype=torch.uint8, device="cuda")]
+    stream = torch.cuda.ExternalStream(lib.hmr_gpu_stream(ctx))
+    args = [ctx] + [C.c_void_p(t.data_ptr()) for t in pic] + [sy, ry, sc, rc] + [C.c_void_p(t.data_ptr()) for t in out]
+    for _ in range(3):
+        assert lib.hmr_gpu_subpel_planes(*args) == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        e0.record(stream)
+        for _ in range(reps):
+            assert lib.hmr_gpu_subpel_planes(*args) == 0
+        e1.record(stream)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    algo = 2 * (sy * ry + 2 * sc * rc) + 16 * sy * ry + 2 * 64 * sc * rc
+    lib.hmr_gpu_destroy(ctx)
+    gbs = algo / (ms * 1e-3) / 1e9
+    return {"kernels": "k_subpel_luma + 2 x k_subpel_chroma (one reference picture)", "bound": "hbm", "algorithmic_bytes_per_picture": int(algo), "ms_per_picture": round(ms, 4),
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "width": width, "height": height}
 
 
 def multi_stream(lib, device, width, height, keys, streams, warmup, steps):
@@ -241,8 +288,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=24)
     ap.add_argument("--no-single-thread-order", action="store_true", help="skip the second measurement (wfpp_num_threads = 1)")
-    ap.add_argument("--sequences", type=int, default=120, help="independent sequences per GPU, encoded with one launch per step (hmr_gpu_enc_encode_batch: 15 groups of 17 row "
-                    "workers at 1080p, each group takes its sequences one after the other); 1 = a single sequence")
+    ap.add_argument("--sequences", type=int, default=180, help="independent sequences per GPU, encoded with one launch per step (hmr_gpu_enc_encode_batch: their CTUs are a pool of tasks for "
+                    "two row workers per CU); 1 = a single sequence")
     ap.add_argument("--streams", type=int, default=0, help="concurrent sequences of the extra multi_stream measurement (0 = skip)")
     ap.add_argument("--multi-stream-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)
@@ -300,6 +347,8 @@ def main():
             if a.sequences > 1:
                 big1 = run_workload(lib, b, "cfg2-2160p-encode", world, rank, local, torch)
                 out["at_2160p"]["single_sequence"] = {k: big1[k] for k in ("value", "ms_per_step", "stream_matches_reference")}
+        if world == 1:
+            out["roofline"]["subpel_planes"] = subpel_planes_roofline(lib, torch, width, height)
         if world == 1 and a.streams > 1:
             out["multi_stream"] = multi_stream_child(local, a.workload, a.streams)
         if world == 1 and a.batch > 1:
@@ -420,12 +469,23 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
         algo_bytes_frame = 1.5 * width * height * 3 + 2 * 1.5 * width * height
         achieved = S * algo_bytes_frame * len(timed) / (ctu_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed counter passes of this same command (TCC_EA0_RDREQ / WRREQ x 64 B, MI355X_MICROARCH.md "HBM"; narrow accesses: uncalibrated)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_k_encode_ctus.json")
-        kernel_name = "k_encode_ctus_batch" if S > 1 else "k_encode_ctus"
-        if os.path.exists(tpath) and workload == "cfg2-1080p-encode" and kernel_name in json.load(open(tpath)):
-            k = json.load(open(tpath))[kernel_name]
-            traffic = int((k["derived"]["hbm_read_bytes_TCC_EA0_RDREQ_x64"] + k["derived"]["hbm_write_bytes_TCC_EA0_WRREQ_x64_upper_bound"]) / k["launches"])
+        traffic, issue = None, None
+        kernel_name = "k_encode_pool"
+        tpath = os.path.join(ROOT, "profiles", "r03_pmc_kernels.json")
+        if os.path.exists(tpath) and workload == "cfg2-1080p-encode":
+            pm = json.load(open(tpath))
+            k, frames_profiled = pm.get(kernel_name), pm.get("frames_encoded_by_k_encode_pool")
+            if k and frames_profiled:
+                per_frame = (k["derived"]["hbm_read_bytes_TCC_EA0_RDREQ_x64"] + k["derived"]["hbm_write_bytes_TCC_EA0_WRREQ_x64_upper_bound"]) / frames_profiled
+                traffic = int(per_frame * S * len(timed) / max(launches, 1))       # per launch, like `achieved`
+                # what actually bounds the kernel: wave-instruction issue (MI355X_MICROARCH.md: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction)
+                valu_per_frame, salu_per_frame = k["SQ_INSTS_VALU"] / frames_profiled, k["SQ_INSTS_SALU"] / frames_profiled
+                fps_kernel = S * len(timed) / (ctu_ms * 1e-3)
+                issue = {"valu_wave_instructions_per_frame": int(valu_per_frame), "salu_wave_instructions_per_frame": int(salu_per_frame),
+                         "valu_issue_peak_per_s": 614.4e9, "valu_issue_frac": round(valu_per_frame * fps_kernel / 614.4e9, 4),
+                         "wait_share_of_wave_cycles": k["derived"].get("wait_share_of_wave_cycles"), "issue_share_of_wave_cycles": k["derived"].get("issue_share_of_wave_cycles"),
+                         "wavefronts_per_simd": round(3 * 2 / 4, 2), "workgroups_per_cu": 2,
+                         "source": "profiles/r03_pmc_kernels.json (rocprofv3 --pmc passes of this command), instruction counts per encoded frame x this run's frames/s of the kernel"}
         digest = md5.hexdigest()
         matches, checked = check_against_reference(workload, cumulative)
         out = {
@@ -433,7 +493,7 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": workload, "sequences_per_gpu": S, "frames_per_step": S, "wfpp_num_threads": int(keys.get("wpp", 1)), "width": width, "height": height, "frames_in_sequence": nframes, "gop": "IPPP intra_period=100", "qp": 32,
-                       "rd_mode": 2, "performance_mode": 2, "sao": 1, "parallelism": (f"{S} independent sequences per GPU, one launch per step for their CTU stages (groups of row workers, each chaining its sequences)" if S > 1 else "one sequence") + (f"; replicas x{world}" if world > 1 else ""),
+                       "rd_mode": 2, "performance_mode": 2, "sao": 1, "parallelism": (f"{S} independent sequences per GPU, one launch per step for their CTU stages (a pool of CTU tasks on two row workers per CU)" if S > 1 else "one sequence"),
                        "timed_region": "CTU decisions + deblock + SAO statistics / decision / offsets + padding on the device, CABAC / NAL on the host, per frame; source in HBM"},
             "stream_md5": digest, "stream_matches_reference": bool(matches and all_same), "frames_checked_against_reference": checked, "all_streams_identical": all_same,
             "schedule": {"ctus_per_frame": nctu, "passes_per_frame": [s[3] for s in timed], "ctu_encodes_per_frame": [s[4] for s in timed],
@@ -444,8 +504,9 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
                          # SURVEY 8-d, the whole P frame (CTU stage + the in-loop filters' read / write): 10.5 W H bytes x frames/s against the same peak
                          "frame_level": {"algorithmic_bytes_per_frame": int(10.5 * width * height), "achieved": round(10.5 * width * height * world * S * a.steps / dt / 1e9, 4),
                                          "frac": round(10.5 * width * height * world * S * a.steps / dt / 1e9 / HBM_PEAK_GBS, 7)},
-                         "note": "one wavefront per CTU row (17 at 1080p) walking a dependent decision chain: bound by instruction issue and memory latency of "
-                                 "those few wavefronts, not by HBM bandwidth; the fraction is the honest distance from the bandwidth roof"},
+                         "issue_bound": issue,
+                         "note": "a pool of CTU tasks on 2 x 256 row workers (one wavefront + two helpers each) walking dependent decision chains: bound by instruction "
+                                 "issue of the workers' wavefronts (issue_bound) and memory latency, not by HBM bandwidth; frac is the honest distance from the bandwidth roof"},
         }
         return out
 

@@ -74,8 +74,6 @@ inline bool make_seq(HostCfg cfg, Seq &s, const char **why)
 		if (n > 1 && n < hc && 2 * n < wc) { *why = "wfpp_num_threads between 1 and the number of CTU rows needs 2 x threads >= CTU columns"; return false; }
 	}
 	if ((cfg.width + 63) / 64 < 2) { *why = "picture narrower than two CTUs"; return false; }
-	// the SAO decision advances one CTU row per lane of a wavefront (k_sao_decide): 64 rows
-	if (cfg.sample_adaptive_offset && cfg.wfpp_enable && (cfg.height + 63) / 64 > 64) { *why = "SAO with wavefront sub-streams on a picture of more than 64 CTU rows"; return false; }
 	{
 		const int wc = (cfg.width + 63) / 64, hc = (cfg.height + 63) / 64;
 		if (cfg.sample_adaptive_offset && wc <= 5 && hc >= (wc > 4 ? wc : 4)) { *why = "SAO on a picture of at most five CTU columns that has at least as many CTU rows"; return false; }

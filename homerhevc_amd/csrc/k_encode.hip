@@ -92,7 +92,7 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 	Enc e = {};   // (a context struct shared in LDS instead of one per lane in private memory was tried: the kernel hangs, cause not found)
 	Enc ew = {};  // the worker's own context (its scratch, not this helper's): what a wide job runs on
 	for (int seq = 1;; seq++) {
-		while (__hip_atomic_load(&box->cmd[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) {}
+		while (__hip_atomic_load(&box->cmd[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) __builtin_amdgcn_s_sleep(1);   // (two workgroups share a CU now: a helper that spins takes issue cycles from the other workgroup's worker on its SIMD)
 		const int job = box->job[h];
 		if (job == HJOB_QUIT) return;
 		if (job == HJOB_NEW_CTU) {
@@ -654,23 +654,31 @@ __device__ void sao_decide_one(const SaoDecideArgs &a, int r, int c, SaoContexts
 		for (int j = 0; j < 32; j++) p[2 + j] = ci.sao_recon[k].offset[j];
 	}
 }
-__global__ __launch_bounds__(64) void k_sao_decide(SaoDecideArgs a)
+// One workgroup (one wavefront, its first lane working) per CTU row: the decision of a CTU is a long scalar computation with data-dependent branches, and rows
+// sharing a wavefront (lane = row, the first version) executed the union of each other's paths.  Rows advance as the WPP wavefront: CTU (r, c) needs the
+// parameters of (r - 1, c) for the merge-up candidate and row r starts from the contexts row r - 1 had after its second CTU - row r waits until row r - 1 has
+// published c + 2 CTUs (or all of them).  Workgroups are dispatched in row order, so the row a workgroup waits for is always running or done.
+__global__ __launch_bounds__(64) void k_sao_decide(SaoDecideArgs a, int *progress)
 {
-	const int r = (int)threadIdx.x;
+	if (threadIdx.x != 0) return;
 	SaoContexts cur = {(uint8_t)a.st_merge, (uint8_t)a.st_type, a.next_lps};
 	if (!a.wpp) {
-		if (r == 0)
+		if (blockIdx.x == 0)
 			for (int n = 0; n < a.W * a.H; n++) sao_decide_one(a, n / a.W, n % a.W, cur);
 		return;
 	}
-	for (int t = 0; t < a.W + 2 * (a.H - 1); t++) {
-		const int c = t - 2 * r;
-		if (r < a.H && c >= 0 && c < a.W) {
-			if (c == 0 && r > 0) { cur.st_merge = a.saved[2 * (r - 1)]; cur.st_type = a.saved[2 * (r - 1) + 1]; }
-			sao_decide_one(a, r, c, cur);
-			if (c == 1) { a.saved[2 * r] = cur.st_merge; a.saved[2 * r + 1] = cur.st_type; }
+	const int r = (int)blockIdx.x;
+	for (int c = 0; c < a.W; c++) {
+		if (r > 0) {
+			const int need = c + 2 < a.W ? c + 2 : a.W;
+			while (__hip_atomic_load(&progress[r - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(4);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			if (c == 0) { cur.st_merge = a.saved[2 * (r - 1)]; cur.st_type = a.saved[2 * (r - 1) + 1]; }
 		}
-		__syncthreads();   // (one wavefront) the rows' results of this step are in memory before the next step reads them
+		sao_decide_one(a, r, c, cur);
+		if (c == 1 || a.W == 1) { a.saved[2 * r] = cur.st_merge; a.saved[2 * r + 1] = cur.st_type; }
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		__hip_atomic_store(&progress[r], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 }
 
@@ -752,6 +760,7 @@ struct hmr_gpu_enc {
 	long long *d_sao_dist;                             // [ctu][3][5]
 	double *d_sao_lambdas;                             // [ctu][3]
 	uint8_t *d_sao_lps, *d_sao_saved;                  // kNextStateLps; [ctu rows][2]
+	int *d_sao_progress = nullptr;                     // [ctu rows] CTUs decided per row (k_sao_decide)
 	// host side of the entropy stage
 	std::vector<uint8_t, PinnedAlloc<uint8_t>> h_public;
 	std::vector<int16_t, PinnedAlloc<int16_t>> h_coeff;
@@ -1105,6 +1114,7 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 	DEV_ALLOC(e->d_sao_bits, 128);
 	DEV_ALLOC(e->d_sao_lps, 128);
 	DEV_ALLOC(e->d_sao_saved, (size_t)s.hctu * 2);
+	DEV_ALLOC(e->d_sao_progress, s.hctu);
 	HIP_TRY(hipMemcpy(e->d_sao_bits, kEntropyBits, sizeof kEntropyBits, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(e->d_sao_lps, kNextStateLps, sizeof kNextStateLps, hipMemcpyHostToDevice));
 	e->h_public.resize(sizeof(CtuPublic) * s.nctu);
@@ -1190,7 +1200,7 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	void *p[] = {e->d_seq, e->d_frame, e->d_geo, e->d.ctus, e->d.ctus_start, e->d.work_slow, e->d.coeff, e->d.progress, e->d.prefix, e->d.prof, e->d.guess, e->d.truth, e->d.outtok,
 		     e->d.chain_start, e->d.chain_end, e->d.valid, e->d.dirty, e->d.hash, e->d.intra_before, e->d.used_intra, e->d.used_parts, e->d.counters, e->d.rowstate, e->d.thread_seen, e->d.row0_checked, e->d_bytes, e->d_mvx,
 		     e->d_mvy, e->d_ref, e->d_qp, e->d_flags, e->d_pd, e->d_ti, e->d_stats, e->d_params, e->d_sao_offsets, e->d_sao_aux, e->d_sao_dist, e->d_sao_lambdas, e->d_sao_bits,
-		     e->d_sao_lps, e->d_sao_saved, e->d_public};
+		     e->d_sao_lps, e->d_sao_saved, e->d_sao_progress, e->d_public};
 	for (void *q : p) (void)hipFree(q);
 	for (int c = 0; c < 3; c++) {
 		(void)hipFree(e->d_pic[0][c]);
@@ -1362,7 +1372,8 @@ int frame_device_part(hmr_gpu_enc *e, int slot)
 		a.ctus = e->d.ctus; a.stats = e->d_stats; a.offsets = e->d_sao_offsets; a.aux = e->d_sao_aux; a.dist = e->d_sao_dist;
 		a.W = s.wctu; a.H = s.hctu; a.wpp = s.wpp; a.st_merge = first.ctx[CTX_SAO_MERGE]; a.st_type = first.ctx[CTX_SAO_TYPE];
 		a.entropy_bits = e->d_sao_bits; a.next_lps = e->d_sao_lps; a.params = e->d_params; a.saved = e->d_sao_saved;
-		hipLaunchKernelGGL(k_sao_decide, dim3(1), dim3(64), 0, st, a);
+		HIP_TRY(hipMemsetAsync(e->d_sao_progress, 0, sizeof(int) * s.hctu, st));
+		hipLaunchKernelGGL(k_sao_decide, dim3(s.wpp ? s.hctu : 1), dim3(64), 0, st, a, e->d_sao_progress);
 		HIP_TRY(hipGetLastError());
 		for (int c = 0; c < 3; c++) HIP_TRY(hipMemcpyAsync(e->d_pre[c], e->d_pic[e->cur][c], e->pic_elems[c] * 2, hipMemcpyDeviceToDevice, st));
 		const size_t oy = (size_t)s.margin_y * s.stride_y + s.margin_y, oc = (size_t)s.margin_c * s.stride_c + s.margin_c;
@@ -1481,6 +1492,7 @@ extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *sl
 	}
 	float ms = 0;
 	HIP_TRY(hipEventElapsedTime(&ms, lead->ev_batch0, lead->ev_batch1));
+	const auto tt0 = std::chrono::steady_clock::now();
 	// Every sequence queues the device part of its frame on its own stream (a host thread each); the side-info records and the levels of ALL sequences are packed
 	// into one staging buffer and come to the host as ONE copy (sixty separate 11 MB downloads reached 9 GB/s between them); then a host thread per sequence codes
 	// its access unit.  (Starting a sequence's filters while the launch is still busy with the sequences chained behind it was tried - rows reporting into host
@@ -1527,9 +1539,14 @@ extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *sl
 	}
 	for (int i = 0; i < n; i++)
 		if (rcs[i] < 0) { hmr_set_error("hmr_gpu_enc_encode_batch: sequence %d: %s", i, errs[i].c_str()); return rcs[i]; }
+	const auto tt1 = std::chrono::steady_clock::now();
 	for (int i = 0; i < n; i++) HIP_TRY(hipStreamWaitEvent(bst, encs[i]->ev_ready, 0));
+	HIP_TRY(hipEventRecord(lead->ev_batch0, bst));
+	HIP_TRY(hipStreamSynchronize(bst));
+	const auto tt2 = std::chrono::steady_clock::now();
 	HIP_TRY(hipMemcpyAsync(lead->h_stage, lead->d_stage, total, hipMemcpyDeviceToHost, bst));
 	HIP_TRY(hipStreamSynchronize(bst));
+	const auto tt3 = std::chrono::steady_clock::now();
 	{
 		std::vector<std::thread> th;
 		for (int i = 0; i < n; i++)
@@ -1543,6 +1560,11 @@ extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *sl
 	}
 	for (int i = 0; i < n; i++)
 		if (rcs[i] < 0) { hmr_set_error("hmr_gpu_enc_encode_batch: sequence %d: %s", i, errs[i].c_str()); return rcs[i]; }
+	if (getenv("HENC_BATCH_TIMING")) {
+		const auto tt4 = std::chrono::steady_clock::now();
+		auto d = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+		fprintf(stderr, "batch tail: queue device parts %.1f ms, device parts done %.1f, download %.1f (%.0f MB), entropy coding %.1f\n", d(tt0, tt1), d(tt1, tt2), d(tt2, tt3), total / 1e6, d(tt3, tt4));
+	}
 	return HMR_GPU_OK;
 }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sum the rocprofv3 --pmc passes written by tools/profile_bench.sh per kernel and derive the shares DESIGN.md quotes.
 
-    tools/pmc_kernels.py gpurun_out r02 "command line" > profiles/r02_pmc_k_encode_ctus.json
+    tools/pmc_kernels.py gpurun_out r03 "command line" frames > profiles/r03_pmc_kernels.json
 
 Every pass is its own run of the same command (MI355X_MICROARCH.md, HBM / rocprofv3: counter sets that do not fit one pass are collected
 separately, never together with a trace domain).  HBM bytes = TCC_EA0_RDREQ / WRREQ requests x 64 B; the write figure is an upper bound
@@ -16,11 +16,12 @@ import sys
 def main():
     root, tag = sys.argv[1], sys.argv[2]
     cmd = sys.argv[3] if len(sys.argv) > 3 else ""
+    frames = int(sys.argv[4]) if len(sys.argv) > 4 else None      # frames the command encodes (all launches of k_encode_pool together)
     kernels = {}
     for path in sorted(glob.glob(os.path.join(root, f"pmc_{tag}_*", "**", "*counter_collection.csv"), recursive=True)):
         launches = {}
         for row in csv.DictReader(open(path)):
-            name = row["Kernel_Name"].split("(")[0].split("::")[-1].strip()
+            name = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].split("::")[-1].strip()
             k = kernels.setdefault(name, {})
             k[row["Counter_Name"]] = k.get(row["Counter_Name"], 0) + int(float(row["Counter_Value"]))
             launches.setdefault(name, set()).add(row["Dispatch_Id"])
@@ -43,6 +44,8 @@ def main():
             if k.get("SQ_WAVE_CYCLES"):
                 d["valu_share_of_issue"] = round(k.get("SQ_INSTS_VALU", 0) / max(k.get("SQ_INSTS_VALU", 0) + k.get("SQ_INSTS_SALU", 0), 1), 3)
         k["derived"] = d
+    if frames:
+        kernels["frames_encoded_by_k_encode_pool"] = frames
     json.dump(kernels, sys.stdout, indent=1)
     print()
 

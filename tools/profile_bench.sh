@@ -3,13 +3,15 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r03}
-ARGS="--steps 3 --warmup 3 --streams 0 --no-cpu-baseline --no-single-thread-order"
+SEQ=${SEQ:-180}
+ARGS="--steps 3 --warmup 3 --streams 0 --no-cpu-baseline --no-single-thread-order --sequences $SEQ"
+FRAMES=$((6 * SEQ + 6))      # six steps of the batch + six frames of the single sequence measured beside it
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o bench --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/${TAG}_rocprof.log
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_INSTS_LDS SQ_INSTS_FLAT SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_FLAT" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $set | cut -d' ' -f1)
   rocprofv3 --pmc $set -d $R/gpurun_out/pmc_${TAG}_$tag -o pmc --output-format csv -- python3 $R/bench.py $ARGS > /dev/null 2> $R/gpurun_out/pmc_${TAG}_$tag.log
 done
-python3 $R/tools/pmc_kernels.py $R/gpurun_out $TAG "python3 bench.py $ARGS" > $R/gpurun_out/${TAG}_pmc_kernels.json
+python3 $R/tools/pmc_kernels.py $R/gpurun_out $TAG "python3 bench.py $ARGS" $FRAMES > $R/gpurun_out/${TAG}_pmc_kernels.json
 python3 $R/tools/kernel_launches.py $R/gpurun_out/prof_$TAG/bench_kernel_trace.csv $R/gpurun_out/${TAG}_bench_under_rocprof.json > $R/gpurun_out/${TAG}_k_encode_pool_launches.json
 # the raw per-dispatch tables of a 120-sequence run exceed what comes back from the GPU box: the summaries above are what is kept
 find $R/gpurun_out/pmc_${TAG}_* -name "*counter_collection.csv" -delete
