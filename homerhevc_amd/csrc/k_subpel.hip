@@ -32,31 +32,45 @@ __device__ __forceinline__ uint32_t clip255(int v)
 	return (uint32_t)v & 255u;
 }
 
+typedef short short4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ short4_t lds4(const int16_t *p) { return *(const short4_t *)p; }      // four samples with one 8-byte LDS read (p 8-byte aligned)
+
+// The tiles keep sample x0 + c at column c + 4 (a left margin of four, of which the filters use three / one): the four samples a thread finishes start on an
+// 8-byte boundary, so every LDS access of the hot loops is a 64-bit one.
+
 // out = [16][elems] bytes; pic = allocation start; elems = stride * rows
 __global__ __launch_bounds__(256) void k_subpel_luma(const int16_t *__restrict__ pic, int stride, int rows, uint8_t *__restrict__ out)
 {
-	__shared__ int16_t in[TH + 7][TW + 8];          // rows y0-3 .. y0+TH+3, columns x0-3 .. x0+TW+4
-	__shared__ int16_t hs[3][TH + 7][TW];           // horizontal stage (sum - 8192) for fx = 1, 2, 3
+	__shared__ __attribute__((aligned(16))) int16_t in[TH + 7][TW + 8];          // rows y0-3 .. y0+TH+3, columns x0-4 .. x0+TW+3
+	__shared__ __attribute__((aligned(16))) int16_t hs[3][TH + 7][TW];           // horizontal stage (sum - 8192) for fx = 1, 2, 3
 	const int tiles_x = (stride + TW - 1) / TW;
 	const int x0 = (int)(blockIdx.x % tiles_x) * TW, y0 = (int)(blockIdx.x / tiles_x) * TH;
 	const long elems = (long)stride * rows;
 	const int t = (int)threadIdx.x;
 	for (int i = t; i < (TH + 7) * (TW + 8); i += 256) {
 		const int r = i / (TW + 8), c = i - r * (TW + 8);
-		const long li = (long)(y0 - 3 + r) * stride + (x0 - 3 + c);
+		const long li = (long)(y0 - 3 + r) * stride + (x0 - 4 + c);
 		in[r][c] = (li >= 0 && li < elems) ? pic[li] : (int16_t)0;
 	}
 	__syncthreads();
 	const int c1[8] = {-1, 4, -10, 58, 17, -5, 1, 0}, c2[8] = {-1, 4, -11, 40, 40, -11, 4, -1}, c3[8] = {0, 1, -5, 17, 58, -10, 4, -1};
-	for (int i = t; i < (TH + 7) * TW; i += 256) {
-		const int r = i / TW, c = i - r * TW;
-		int s1 = 0, s2 = 0, s3 = 0;
+	// horizontal stage: four adjacent outputs per work item from twelve samples (three 64-bit reads)
+	for (int i = t; i < (TH + 7) * (TW / 4); i += 256) {
+		const int r = i / (TW / 4), c = (i - r * (TW / 4)) << 2;
+		const short4_t a = lds4(&in[r][c]), b = lds4(&in[r][c + 4]), d = lds4(&in[r][c + 8]);
+		const int sm[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w};      // columns c .. c + 11 of the tile = samples x0 + c - 4 ...
+		short4_t o1, o2, o3;
 #pragma unroll
-		for (int k = 0; k < 8; k++) {
-			const int v = in[r][c + k];
-			s1 += v * c1[k]; s2 += v * c2[k]; s3 += v * c3[k];
+		for (int j = 0; j < 4; j++) {
+			int s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				const int v = sm[j + 1 + k];                                                        // sample (c + j) - 3 + k
+				s1 += v * c1[k]; s2 += v * c2[k]; s3 += v * c3[k];
+			}
+			o1[j] = (short)(s1 - 8192); o2[j] = (short)(s2 - 8192); o3[j] = (short)(s3 - 8192);
 		}
-		hs[0][r][c] = (int16_t)(s1 - 8192); hs[1][r][c] = (int16_t)(s2 - 8192); hs[2][r][c] = (int16_t)(s3 - 8192);
+		*(short4_t *)&hs[0][r][c] = o1; *(short4_t *)&hs[1][r][c] = o2; *(short4_t *)&hs[2][r][c] = o3;
 	}
 	__syncthreads();
 	const int ty = t >> 4, tx = (t & 15) << 2;
@@ -66,23 +80,23 @@ __global__ __launch_bounds__(256) void k_subpel_luma(const int16_t *__restrict__
 	uint32_t pk[16];
 #pragma unroll
 	for (int f = 0; f < 16; f++) pk[f] = 0;
+	short4_t v0[8], v1[8], v2[8], v3[8];
+#pragma unroll
+	for (int k = 0; k < 8; k++) { v0[k] = lds4(&in[ty + k][tx + 4]); v1[k] = lds4(&hs[0][ty + k][tx]); v2[k] = lds4(&hs[1][ty + k][tx]); v3[k] = lds4(&hs[2][ty + k][tx]); }
 #pragma unroll
 	for (int j = 0; j < 4; j++) {
-		const int c = tx + j;
 		// fy = 0: the integer sample and the three horizontal phases (single stage: (sum + 32) >> 6)
-		pk[0] |= clip255(in[ty + 3][c + 3]) << (8 * j);
-#pragma unroll
-		for (int fx = 1; fx < 4; fx++) pk[fx] |= clip255((hs[fx - 1][ty + 3][c] + 8192 + 32) >> 6) << (8 * j);
+		pk[0] |= clip255(v0[3][j]) << (8 * j);
+		pk[1] |= clip255((v1[3][j] + 8192 + 32) >> 6) << (8 * j);
+		pk[2] |= clip255((v2[3][j] + 8192 + 32) >> 6) << (8 * j);
+		pk[3] |= clip255((v3[3][j] + 8192 + 32) >> 6) << (8 * j);
 		// fy = 1..3: vertical filter over the integer column (single stage) and over the horizontal intermediates (second stage: >> 12)
-		int v0[8], v1[8], v2[8], v3[8];
-#pragma unroll
-		for (int k = 0; k < 8; k++) { v0[k] = in[ty + k][c + 3]; v1[k] = hs[0][ty + k][c]; v2[k] = hs[1][ty + k][c]; v3[k] = hs[2][ty + k][c]; }
 #pragma unroll
 		for (int fy = 1; fy < 4; fy++) {
 			const int *cf = fy == 1 ? c1 : (fy == 2 ? c2 : c3);
 			int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
-			for (int k = 0; k < 8; k++) { s0 += v0[k] * cf[k]; s1 += v1[k] * cf[k]; s2 += v2[k] * cf[k]; s3 += v3[k] * cf[k]; }
+			for (int k = 0; k < 8; k++) { s0 += v0[k][j] * cf[k]; s1 += v1[k][j] * cf[k]; s2 += v2[k][j] * cf[k]; s3 += v3[k][j] * cf[k]; }
 			pk[fy * 4 + 0] |= clip255((s0 + 32) >> 6) << (8 * j);
 			pk[fy * 4 + 1] |= clip255(sat16i((s1 + 2048 + (8192 << 6)) >> 12)) << (8 * j);
 			pk[fy * 4 + 2] |= clip255(sat16i((s2 + 2048 + (8192 << 6)) >> 12)) << (8 * j);
@@ -96,63 +110,70 @@ __global__ __launch_bounds__(256) void k_subpel_luma(const int16_t *__restrict__
 // one chroma component: out = [64][elems]
 __global__ __launch_bounds__(256) void k_subpel_chroma(const int16_t *__restrict__ pic, int stride, int rows, uint8_t *__restrict__ out)
 {
-	__shared__ int16_t in[TH + 3][TW + 4];          // rows y0-1 .. y0+TH+1, columns x0-1 .. x0+TW+2
-	__shared__ int16_t hs[7][TH + 3][TW];           // horizontal stage (sum - 8192) for fx = 1 .. 7
+	__shared__ __attribute__((aligned(16))) int16_t in[TH + 3][TW + 8];          // rows y0-1 .. y0+TH+1, columns x0-4 .. x0+TW+3
+	__shared__ __attribute__((aligned(16))) int16_t hs[7][TH + 3][TW];           // horizontal stage (sum - 8192) for fx = 1 .. 7
 	const int tiles_x = (stride + TW - 1) / TW;
 	const int x0 = (int)(blockIdx.x % tiles_x) * TW, y0 = (int)(blockIdx.x / tiles_x) * TH;
 	const long elems = (long)stride * rows;
 	const int t = (int)threadIdx.x;
-	for (int i = t; i < (TH + 3) * (TW + 4); i += 256) {
-		const int r = i / (TW + 4), c = i - r * (TW + 4);
-		const long li = (long)(y0 - 1 + r) * stride + (x0 - 1 + c);
+	for (int i = t; i < (TH + 3) * (TW + 8); i += 256) {
+		const int r = i / (TW + 8), c = i - r * (TW + 8);
+		const long li = (long)(y0 - 1 + r) * stride + (x0 - 4 + c);
 		in[r][c] = (li >= 0 && li < elems) ? pic[li] : (int16_t)0;
 	}
 	__syncthreads();
 	const int cf[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4}, {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
-	for (int i = t; i < (TH + 3) * TW; i += 256) {
-		const int r = i / TW, c = i - r * TW;
-		const int a = in[r][c], b = in[r][c + 1], d = in[r][c + 2], e = in[r][c + 3];
+	for (int i = t; i < (TH + 3) * (TW / 4); i += 256) {
+		const int r = i / (TW / 4), c = (i - r * (TW / 4)) << 2;
+		const short4_t a = lds4(&in[r][c]), b = lds4(&in[r][c + 4]), d = lds4(&in[r][c + 8]);
+		const int sm[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w};
 #pragma unroll
-		for (int fx = 1; fx < 8; fx++) hs[fx - 1][r][c] = (int16_t)(a * cf[fx][0] + b * cf[fx][1] + d * cf[fx][2] + e * cf[fx][3] - 8192);
+		for (int fx = 1; fx < 8; fx++) {
+			short4_t o;
+#pragma unroll
+			for (int j = 0; j < 4; j++) o[j] = (short)(sm[j + 3] * cf[fx][0] + sm[j + 4] * cf[fx][1] + sm[j + 5] * cf[fx][2] + sm[j + 6] * cf[fx][3] - 8192);   // samples (c + j) - 1 ...
+			*(short4_t *)&hs[fx - 1][r][c] = o;
+		}
 	}
 	__syncthreads();
 	const int ty = t >> 4, tx = (t & 15) << 2;
 	const int y = y0 + ty, x = x0 + tx;
 	if (y >= rows || x >= stride) return;
 	const long li = (long)y * stride + x;
+	short4_t in4[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) in4[k] = lds4(&in[ty + k][tx + 4]);
 	// fy = 0
 	{
 		uint32_t pk[8];
 #pragma unroll
 		for (int f = 0; f < 8; f++) pk[f] = 0;
 #pragma unroll
-		for (int j = 0; j < 4; j++) {
-			const int c = tx + j;
-			pk[0] |= clip255(in[ty + 1][c + 1]) << (8 * j);
+		for (int fx = 1; fx < 8; fx++) {
+			const short4_t h = lds4(&hs[fx - 1][ty + 1][tx]);
 #pragma unroll
-			for (int fx = 1; fx < 8; fx++) pk[fx] |= clip255((hs[fx - 1][ty + 1][c] + 8192 + 32) >> 6) << (8 * j);
+			for (int j = 0; j < 4; j++) pk[fx] |= clip255((h[j] + 8192 + 32) >> 6) << (8 * j);
 		}
+#pragma unroll
+		for (int j = 0; j < 4; j++) pk[0] |= clip255(in4[1][j]) << (8 * j);
 #pragma unroll
 		for (int f = 0; f < 8; f++) *(uint32_t *)(out + (size_t)f * elems + li) = pk[f];
 	}
-	for (int fy = 1; fy < 8; fy++) {
-		const int k0 = cf[fy][0], k1 = cf[fy][1], k2 = cf[fy][2], k3 = cf[fy][3];
-		uint32_t pk[8];
+	for (int fx = 0; fx < 8; fx++) {
+		// the column of intermediates (fx = 0: of integer samples) once, the seven vertical phases from it
+		short4_t h[4];
 #pragma unroll
-		for (int f = 0; f < 8; f++) pk[f] = 0;
+		for (int k = 0; k < 4; k++) h[k] = fx ? lds4(&hs[fx - 1][ty + k][tx]) : in4[k];
 #pragma unroll
-		for (int j = 0; j < 4; j++) {
-			const int c = tx + j;
-			const int s0 = in[ty][c + 1] * k0 + in[ty + 1][c + 1] * k1 + in[ty + 2][c + 1] * k2 + in[ty + 3][c + 1] * k3;
-			pk[0] |= clip255((s0 + 32) >> 6) << (8 * j);
+		for (int fy = 1; fy < 8; fy++) {
+			uint32_t pk = 0;
 #pragma unroll
-			for (int fx = 1; fx < 8; fx++) {
-				const int s = hs[fx - 1][ty][c] * k0 + hs[fx - 1][ty + 1][c] * k1 + hs[fx - 1][ty + 2][c] * k2 + hs[fx - 1][ty + 3][c] * k3;
-				pk[fx] |= clip255(sat16i((s + 2048 + (8192 << 6)) >> 12)) << (8 * j);
+			for (int j = 0; j < 4; j++) {
+				const int sum = h[0][j] * cf[fy][0] + h[1][j] * cf[fy][1] + h[2][j] * cf[fy][2] + h[3][j] * cf[fy][3];
+				pk |= (fx ? clip255(sat16i((sum + 2048 + (8192 << 6)) >> 12)) : clip255((sum + 32) >> 6)) << (8 * j);
 			}
+			*(uint32_t *)(out + (size_t)(fy * 8 + fx) * elems + li) = pk;
 		}
-#pragma unroll
-		for (int f = 0; f < 8; f++) *(uint32_t *)(out + (size_t)(fy * 8 + f) * elems + li) = pk[f];
 	}
 }
 
