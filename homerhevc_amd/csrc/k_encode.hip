@@ -1,18 +1,21 @@
-// Frame encoder on the device (include/homer_gpu.h section 12).
+// Frame encoder on the device (include/homer_gpu.h section 12).  The decision code is enc/enc_ctu.h, instantiated for the 64-lane group.
 //
-// k_encode_ctus is a persistent launch that walks the picture the way the reference's WPP threads do (wfpp_encoder_thread,
-// hmr_encoder_lib.c:2849-2975): workgroup r = one wavefront = the worker of CTU row r; it encodes its row left to right and may
-// start CTU (r, c) once row r-1 has finished CTU c+1 (:2885-2898, two CTUs of lag).  Rows publish their progress with release
-// stores at agent scope and wait with acquire loads, so a row sees the reconstruction and side-info of the rows above it.
-// The decision code is enc/enc_ctu.h, instantiated for the 64-lane group.
+// Row-per-thread schedule (wfpp_num_threads > 1, the product's mode): the reference's WPP threads (wfpp_encoder_thread, hmr_encoder_lib.c:2849-2975)
+// pinned to the synchronous wavefront - CTU (row, c) belongs to step c + 2 row, and a step may start when the step before it is complete.
+// k_encode_pool runs that as a task pool: persistent workgroups (a worker wavefront + NHELP helper wavefronts, two workgroups per CU) claim the next
+// CTU of ANY picture of the launch whose step is open, load the owning WPP thread's state (mode buffers, "seen intra"), encode, store the state and
+// close the step with a release store when they were its last CTU.  No workgroup waits for work that is not already running.
 //
-// The output has to be what the reference produces with ONE thread in raster order (the deterministic configuration), and two
-// inputs of a CTU depend on every CTU before it in that order; enc/enc_sched.h explains the guess / verify / re-encode scheme.
-// On the device it is: k_encode_ctus (pass 0: all CTUs; later passes: only the CTUs marked wrong or whose neighbours changed),
-// k_sched_scan (the true chains, one thread per 4x4 unit column), k_sched_check (one wavefront per CTU replays its logs against
-// the truth), repeated until nothing is wrong, then k_sched_finish.  The in-loop filters are the frame kernels of round 1
-// (k_deblock.hip, k_sao.hip, k_pad.hip); the entropy stage (enc/enc_entropy.h) is host code fed with the side-info, the levels
-// and the SAO statistics, and hands the SAO parameters back for the offset pass.
+// Single-thread order (wfpp_num_threads = 1): the output has to be what the reference produces with ONE thread in raster order, and two inputs
+// of a CTU depend on every CTU before it in that order; enc/enc_sched.h explains the guess / verify / re-encode scheme.  On the device it is:
+// k_encode_ctus (workgroup r = the worker of CTU row r, waits for row r - 1 to be two CTUs ahead - a cooperative launch, so that it fails at launch
+// time when the rows cannot all be resident; pass 0: all CTUs; later passes: only the CTUs marked wrong or whose neighbours changed), k_sched_scan
+// (the true chains, one thread per 4x4 unit column), k_sched_check (one wavefront per CTU replays its logs against the truth), repeated until
+// nothing is wrong, then k_sched_finish.
+//
+// Before the CTU stage of a P frame k_subpel.hip writes the reference picture at every sub-sample phase (planes borrowed from g_plane_pool);
+// after it the in-loop filters are the frame kernels of round 1 (k_deblock.hip, k_sao.hip, k_pad.hip) and k_sao_decide (the SAO parameter decision,
+// one workgroup per CTU row); the entropy stage (enc/enc_entropy.h) is host code fed with the side-info records and the levels.
 #include <stddef.h>
 #include <stdlib.h>
 #include <chrono>
@@ -1445,7 +1448,7 @@ extern "C" int hmr_gpu_enc_encode_source(hmr_gpu_enc *e, int slot, int image_typ
 	return frame_finish(e, slot, stream, cap, stream_bytes, recon);
 }
 
-// Several sequences, one frame each, with ONE launch for all their CTU stages (k_encode_ctus_batch): encs[i] encodes its picture slots[i] into streams[i].
+// Several sequences, one frame each, with ONE launch for all their CTU stages (k_encode_pool): encs[i] encodes its picture slots[i] into streams[i].
 // All encoders must use the row-per-thread schedule and live on the same device; each finishes its frame (filters, SAO, download, entropy coding) on its own
 // stream and host thread.  The streams are those hmr_gpu_enc_encode_source would have produced one by one.
 extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes)

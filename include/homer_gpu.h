@@ -611,8 +611,9 @@ int hmr_gpu_enc_load_source(hmr_gpu_enc *enc, int slot, const uint8_t *y, const 
 int hmr_gpu_enc_encode_source(hmr_gpu_enc *enc, int slot, int image_type, uint8_t *stream, long cap, long *stream_bytes, uint8_t *recon);
 /* one frame of each of n sequences with ONE launch for all their CTU stages: encs[i] encodes its resident picture slots[i] (image_types may be NULL: automatic)
  * into streams[i] (capacity caps[i], size stream_bytes[i]).  The encoders use the row-per-thread schedule (wfpp_num_threads > 1) and the same device; the access
- * units are those hmr_gpu_enc_encode_source gives one by one.  A row worker takes a whole CU: the launch is (CUs / CTU rows) groups of row workers, fifteen for
- * 1080p, and a group encodes its sequences (n may exceed the number of groups, up to 256) one after the other, which fills the bubbles of the WPP wavefront. */
+ * units are those hmr_gpu_enc_encode_source gives one by one.  The launch is a pool of persistent row workers (two per CU) that claim CTUs of any of the n
+ * pictures whose wavefront step is open (k_encode_pool); n is at most 256, a few hundred pictures' worth of CTU rows saturate the pool (120 at 1080p).  A worker
+ * never waits for a CTU that is not already running, so the launch does not depend on all its workgroups being resident. */
 int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes);
 /* the last frame: passes of the CTU schedule, CTU encodes (>= the number of CTUs), device milliseconds of the CTU passes and of the whole frame */
 int hmr_gpu_enc_last_stats(hmr_gpu_enc *enc, int *passes, int *ctu_encodes, float *ctu_ms, float *frame_ms);
