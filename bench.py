@@ -252,9 +252,11 @@ def multi_stream_child(device, workload, streams, batched=False):
     return {"streams": streams, "error": (r.stderr or r.stdout)[-300:]}
 
 
-def measure(step, warmup, nframes, world, device_sync, device):
+def measure(step, warmup, nframes, world, device_sync, device, flush=None):
     """The timing contract: `warmup` untimed steps, then steps warmup..nframes-1 bracketed by a barrier + device synchronisation on both sides;
-    returns the wall time, MAX over the ranks.  step(f) encodes frame f.  (tests/test_bench_gloo.py runs this with world 2 on gloo.)"""
+    returns the wall time, MAX over the ranks.  step(f) encodes frame f.  `flush` (pipelined steps: step f delivers the access units of step f - 1) is called
+    after the warm-up and again at the end of the timed region, so that the region contains all the work of its steps and nothing of the warm-up's.
+    (tests/test_bench_gloo.py runs this with world 2 on gloo.)"""
     import torch
     import torch.distributed as dist
 
@@ -266,10 +268,14 @@ def measure(step, warmup, nframes, world, device_sync, device):
 
     for f in range(warmup):
         step(f)
+    if flush:
+        flush()
     fence()
     t0 = time.perf_counter()
     for f in range(warmup, nframes):
         step(f)
+    if flush:
+        flush()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -290,6 +296,7 @@ def main():
     ap.add_argument("--no-single-thread-order", action="store_true", help="skip the second measurement (wfpp_num_threads = 1)")
     ap.add_argument("--sequences", type=int, default=180, help="independent sequences per GPU, encoded with one launch per step (hmr_gpu_enc_encode_batch: their CTUs are a pool of tasks for "
                     "two row workers per CU); 1 = a single sequence")
+    ap.add_argument("--no-pipeline", action="store_true", help="batch steps through hmr_gpu_enc_encode_batch (access units inside the call) instead of the pipelined call")
     ap.add_argument("--streams", type=int, default=0, help="concurrent sequences of the extra multi_stream measurement (0 = skip)")
     ap.add_argument("--multi-stream-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)
@@ -431,10 +438,25 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
     cumulative = []                # digest of sequence 0's stream after every access unit
     stats = []
     lib.hmr_gpu_enc_encode_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    lib.hmr_gpu_enc_encode_batch_pipelined.argtypes = lib.hmr_gpu_enc_encode_batch.argtypes
+    pipelined = S > 1 and not a.no_pipeline
     e_arr = (C.c_void_p * S)(*encs)
     ptrs = (C.c_char_p * S)(*[C.cast(b, C.c_char_p) for b in bufs])
     caps = (C.c_long * S)(*[len(b) for b in bufs])
     got = (C.c_long * S)()
+
+    def take_units():
+        # (pipelined: the access units of the step before; nothing after the first call of a run)
+        if pipelined and got[0] == 0:
+            return
+        for i in range(S):
+            md5s[i].update(C.string_at(bufs[i], got[i]))
+        if pipelined:
+            cumulative.append(md5s[0].hexdigest())
+
+    def flush():
+        assert lib.hmr_gpu_enc_encode_batch_pipelined(e_arr, S, None, None, ptrs, caps, got) == 0, lib.hmr_gpu_last_error()
+        take_units()
 
     def step(f):
         if S == 1:
@@ -442,16 +464,17 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
             assert st in (1, 2), lib.hmr_gpu_last_error()
             md5s[0].update(C.string_at(buf, nbytes.value))
         else:
-            assert lib.hmr_gpu_enc_encode_batch(e_arr, S, (C.c_int * S)(*([f] * S)), None, ptrs, caps, got) == 0, lib.hmr_gpu_last_error()
-            for i in range(S):
-                md5s[i].update(C.string_at(bufs[i], got[i]))
+            call = lib.hmr_gpu_enc_encode_batch_pipelined if pipelined else lib.hmr_gpu_enc_encode_batch
+            assert call(e_arr, S, (C.c_int * S)(*([f] * S)), None, ptrs, caps, got) == 0, lib.hmr_gpu_last_error()
+            take_units()
             st, nbytes.value = 0, got[0]
-        cumulative.append(md5s[0].hexdigest())
+        if not pipelined:
+            cumulative.append(md5s[0].hexdigest())
         p, n, ms, tot = C.c_int(), C.c_int(), C.c_float(), C.c_float()
         lib.hmr_gpu_enc_last_stats(enc, C.byref(p), C.byref(n), C.byref(ms), C.byref(tot))
         stats.append((f, st, nbytes.value, p.value, n.value, ms.value, tot.value))
 
-    dt = measure(step, a.warmup, nframes, world, torch.cuda.synchronize, "cuda")
+    dt = measure(step, a.warmup, nframes, world, torch.cuda.synchronize, "cuda", flush if pipelined else None)
     for x in encs:
         lib.hmr_gpu_enc_destroy(x)
     for x in ctxs:
@@ -494,7 +517,9 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": workload, "sequences_per_gpu": S, "frames_per_step": S, "wfpp_num_threads": int(keys.get("wpp", 1)), "width": width, "height": height, "frames_in_sequence": nframes, "gop": "IPPP intra_period=100", "qp": 32,
                        "rd_mode": 2, "performance_mode": 2, "sao": 1, "parallelism": (f"{S} independent sequences per GPU, one launch per step for their CTU stages (a pool of CTU tasks on two row workers per CU)" if S > 1 else "one sequence"),
-                       "timed_region": "CTU decisions + deblock + SAO statistics / decision / offsets + padding on the device, CABAC / NAL on the host, per frame; source in HBM"},
+                       "timed_region": "CTU decisions + deblock + SAO statistics / decision / offsets + padding on the device, CABAC / NAL on the host, per frame; source in HBM",
+                       "call": ("hmr_gpu_enc_encode_batch_pipelined: a step's download and entropy coding run under the next step's CTU launch; the pipeline is empty when the timed "
+                                "region starts and flushed inside it" if pipelined else "hmr_gpu_enc_encode_batch" if S > 1 else "hmr_gpu_enc_encode_source")},
             "stream_md5": digest, "stream_matches_reference": bool(matches and all_same), "frames_checked_against_reference": checked, "all_streams_identical": all_same,
             "schedule": {"ctus_per_frame": nctu, "passes_per_frame": [s[3] for s in timed], "ctu_encodes_per_frame": [s[4] for s in timed],
                          "ctu_stage_ms_per_frame": [round(s[5], 1) for s in timed], "device_ms_per_frame": [round(s[6], 1) for s in timed]},

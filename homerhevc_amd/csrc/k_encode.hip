@@ -774,6 +774,19 @@ struct hmr_gpu_enc {
 	uint8_t *d_stage = nullptr, *h_stage = nullptr;      // batch: the side-info records and levels of all sequences, on the device and page-locked on the host
 	size_t stage_bytes = 0;
 	void *d_batch = nullptr;                             // hmr_gpu_enc_encode_batch (lead encoder): the sequences' EncDev records and first rows
+	// pipelined batch (lead encoder): the step whose access units are still to be delivered
+	bool pending = false;
+	std::vector<hmr_gpu_enc *> pend_encs;
+	std::vector<size_t> pend_pub, pend_coeff;
+	size_t pend_total = 0;
+	hipStream_t copy_stream = nullptr;
+	uint32_t *d_gather = nullptr, *h_gather = nullptr;   // per picture of a launch: the frame's counters and the CTUs' distortions
+	size_t gather_words = 0;
+	// (every encoder of the batch)
+	bool awaiting_delivery = false;                      // its last frame's access unit has not been coded yet
+	FrameCtx f_pending;                                  // that frame's parameters (e->f moves on with the next set_frame)
+	double acc_pending = 0;
+	hipEvent_t ev_packed = nullptr;                      // its records and levels are in the staging buffer
 	int *d_pool_state = nullptr;                         // k_encode_pool: per picture of the launch the open step and the steps' ticket / done counters, then the finished-pictures counter
 	WorkSlow *d_pool_slow = nullptr;                     // the pool workers' transform / decoded windows
 	int pool_workers = 0;
@@ -1070,6 +1083,7 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 	HIP_TRY(hipEventCreate(&e->ev_ready));
 	HIP_TRY(hipEventCreate(&e->ev_batch0));
 	HIP_TRY(hipEventCreate(&e->ev_batch1));
+	HIP_TRY(hipEventCreateWithFlags(&e->ev_packed, hipEventDisableTiming));
 	DEV_ALLOC(e->d.coeff, (size_t)6144 * s.nctu);
 	DEV_ALLOC(e->d.progress, s.hctu);
 	DEV_ALLOC(e->d.prefix, (size_t)s.hctu * (s.wctu + 1));
@@ -1195,6 +1209,10 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	if (e->ev_ready) (void)hipEventDestroy(e->ev_ready);
 	if (e->ev_batch0) (void)hipEventDestroy(e->ev_batch0);
 	if (e->ev_batch1) (void)hipEventDestroy(e->ev_batch1);
+	if (e->ev_packed) (void)hipEventDestroy(e->ev_packed);
+	if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
+	if (e->d_gather) (void)hipFree(e->d_gather);
+	if (e->h_gather) (void)hipHostFree(e->h_gather);
 	if (e->d_batch) (void)hipFree(e->d_batch);
 	if (e->d_pool_state) (void)hipFree(e->d_pool_state);
 	if (e->d_pool_slow) (void)hipFree(e->d_pool_slow);
@@ -1386,24 +1404,31 @@ int frame_device_part(hmr_gpu_enc *e, int slot)
 	if ((rc = hmr_gpu_pad_frame(e->ctx, &pic, s.margin_y, s.margin_y))) return rc;
 	return HMR_GPU_OK;
 }
-// host part: entropy coding from the downloaded side-info records and levels, frame bookkeeping, the access unit into `stream`
-int frame_host_part(hmr_gpu_enc *e, const uint8_t *h_public, const int16_t *h_coeff, uint8_t *stream, long cap, long *stream_bytes)
+// host part: entropy coding of the frame `f` from the downloaded side-info records and levels, the access unit into `stream`
+int frame_entropy_part(hmr_gpu_enc *e, const FrameCtx &f, const uint8_t *h_public, const int16_t *h_coeff, uint8_t *stream, long cap, long *stream_bytes)
 {
-	const Seq &s = e->seq;
-	const double acc = frame_acc_dist(s, e->cfg.wfpp_num_threads, [&](int n) { return ((const CtuPublic *)(h_public + sizeof(CtuPublic) * n))->distortion; });
 	EntropyFrame fr;
-	fr.seq = &e->seq; fr.f = &e->f; fr.T = hmr_host_tables(); fr.geo = e->geo.data();
+	fr.seq = &e->seq; fr.f = &f; fr.T = hmr_host_tables(); fr.geo = e->geo.data();
 	fr.ctu_base = h_public; fr.ctu_pitch = sizeof(CtuPublic); fr.coeff = h_coeff;
 	std::vector<uint8_t> out;
 	encode_frame_entropy(e->es, fr, nullptr, e->cfg.profile, out);
 	*stream_bytes = (long)out.size();
 	if ((long)out.size() > cap) {
-		// the access unit is lost with this return; the sequence state has not moved on, but the device pictures have: the caller has to start over
 		hmr_set_error("hmr_gpu_enc_encode: the access unit needs %ld bytes, the buffer holds %ld", (long)out.size(), cap);
 		return HMR_GPU_ERR_ARG;
 	}
-	end_frame(s, e->st, e->f, acc);
 	memcpy(stream, out.data(), out.size());
+	return f.slice_type;
+}
+// host part of one frame: entropy coding, then the frame bookkeeping
+int frame_host_part(hmr_gpu_enc *e, const uint8_t *h_public, const int16_t *h_coeff, uint8_t *stream, long cap, long *stream_bytes)
+{
+	const Seq &s = e->seq;
+	const double acc = frame_acc_dist(s, e->cfg.wfpp_num_threads, [&](int n) { return ((const CtuPublic *)(h_public + sizeof(CtuPublic) * n))->distortion; });
+	// (a buffer that is too small loses the access unit; the sequence state has not moved on, but the device pictures have: the caller has to start over)
+	const int rc = frame_entropy_part(e, e->f, h_public, h_coeff, stream, cap, stream_bytes);
+	if (rc < 0) return rc;
+	end_frame(s, e->st, e->f, acc);
 	return e->f.slice_type;
 }
 // one sequence: device part, download, host part
@@ -1438,6 +1463,10 @@ int frame_finish(hmr_gpu_enc *e, int slot, uint8_t *stream, long cap, long *stre
 extern "C" int hmr_gpu_enc_encode_source(hmr_gpu_enc *e, int slot, int image_type, uint8_t *stream, long cap, long *stream_bytes, uint8_t *recon)
 {
 	if (!e || slot < 0 || slot >= (int)e->src.size() || !stream || !stream_bytes) return HMR_GPU_ERR_ARG;
+	if (e->awaiting_delivery) {
+		hmr_set_error("hmr_gpu_enc_encode_source: the encoder has an access unit outstanding from a pipelined batch call: flush first");
+		return HMR_GPU_ERR_ARG;
+	}
 	hipStream_t st = e->ctx->stream;
 	HIP_TRY(hipSetDevice(e->ctx->device));
 	HIP_TRY(hipEventRecord(e->ev_frame, st));
@@ -1449,25 +1478,51 @@ extern "C" int hmr_gpu_enc_encode_source(hmr_gpu_enc *e, int slot, int image_typ
 }
 
 // Several sequences, one frame each, with ONE launch for all their CTU stages (k_encode_pool): encs[i] encodes its picture slots[i] into streams[i].
-// All encoders must use the row-per-thread schedule and live on the same device; each finishes its frame (filters, SAO, download, entropy coding) on its own
-// stream and host thread.  The streams are those hmr_gpu_enc_encode_source would have produced one by one.
-extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes)
+// All encoders must use the row-per-thread schedule and live on the same device; each finishes its frame (filters, SAO, records and levels into the staging buffer)
+// on its own stream.  The streams are those hmr_gpu_enc_encode_source would have produced one by one.
+//
+// A step has three parts: LAUNCH (frame set-up, phase planes, the pool launch), FINISH (after the launch: the frames' counters and distortions in one small
+// download, frame bookkeeping, a host thread per sequence queues its filter chain and packs its records and levels into the staging buffer, whose download to the
+// host is queued behind them on a copy stream) and DELIVER (wait for that download, a host thread per sequence codes its access unit).  The plain call runs
+// LAUNCH, FINISH, DELIVER; the pipelined call runs LAUNCH(k), DELIVER(k - 1), FINISH(k), so that the download and the entropy coding of a step run while the
+// device is busy with the next step's CTU stage (nothing of step k reads what DELIVER(k - 1) reads: the staging buffers are written again only in FINISH(k)).
+namespace {
+__global__ void k_gather_results(const EncDev *devs, uint32_t *out, int pitch)
 {
-	if (!encs || n <= 0 || n > 256 || !slots || !streams || !caps || !stream_bytes) return HMR_GPU_ERR_ARG;
+	const EncDev &d = devs[blockIdx.x];
+	uint32_t *o = out + (size_t)blockIdx.x * pitch;
+	const int nctu = d.seq->nctu;
+	if (threadIdx.x < 3) o[threadIdx.x] = (uint32_t)d.counters[threadIdx.x];
+	for (int c = threadIdx.x; c < nctu; c += blockDim.x) o[4 + c] = d.ctus[c].distortion;
+}
+
+struct BatchTimes {
+	std::chrono::steady_clock::time_point t[8];
+	double ms(int a, int b) const { return std::chrono::duration<double, std::milli>(t[b] - t[a]).count(); }
+};
+
+int batch_check(hmr_gpu_enc **encs, int n, const int *slots, uint8_t **streams, const long *caps, long *stream_bytes)
+{
+	if (!encs || n <= 0 || n > 256 || !streams || !caps || !stream_bytes) return HMR_GPU_ERR_ARG;
 	for (int i = 0; i < n; i++) {
 		hmr_gpu_enc *e = encs[i];
-		if (!e || !e->lockstep || e->ctx->device != encs[0]->ctx->device || slots[i] < 0 || slots[i] >= (int)e->src.size() || !streams[i]) {
+		if (!e || !e->lockstep || e->ctx->device != encs[0]->ctx->device || (slots && (slots[i] < 0 || slots[i] >= (int)e->src.size())) || !streams[i]) {
 			hmr_set_error("hmr_gpu_enc_encode_batch: encoder %d: needs the row-per-thread schedule (wfpp_num_threads > 1), the batch's device and a loaded picture slot", i);
 			return HMR_GPU_ERR_ARG;
 		}
 		for (int j = 0; j < i; j++)
 			if (encs[j] == e) return HMR_GPU_ERR_ARG;
 	}
+	return HMR_GPU_OK;
+}
+
+// LAUNCH: the frames' CTU stages as one pool launch on the lead encoder's stream, their counters and distortions gathered behind it
+int batch_launch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_types, int *pitch_out)
+{
 	hmr_gpu_enc *lead = encs[0];
 	hipStream_t bst = lead->ctx->stream;
-	HIP_TRY(hipSetDevice(lead->ctx->device));
 	std::vector<EncDev> devs(n);
-	int rc;
+	int rc, rows_total = 0, max_ctus = 0;
 	for (int i = 0; i < n; i++) {
 		hmr_gpu_enc *e = encs[i];
 		HIP_TRY(hipEventRecord(e->ev_frame, e->ctx->stream));
@@ -1476,36 +1531,56 @@ extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *sl
 		HIP_TRY(hipEventRecord(e->ev_ready, e->ctx->stream));
 		if (i) HIP_TRY(hipStreamWaitEvent(bst, e->ev_ready, 0));
 		devs[i] = e->d;
+		rows_total += e->seq.hctu;
+		if (e->seq.nctu > max_ctus) max_ctus = e->seq.nctu;
 	}
 	if (!lead->d_batch) {
 		HIP_TRY(hipMalloc((void **)&lead->d_batch, 256 * sizeof(EncDev)));
 		HIP_TRY(hipDeviceGetAttribute(&lead->n_cus, hipDeviceAttributeMultiprocessorCount, lead->ctx->device));
 	}
-
-	int rows_total = 0;
-	for (int i = 0; i < n; i++) rows_total += encs[i]->seq.hctu;
+	const int pitch = 4 + max_ctus;
+	if ((size_t)pitch * n > lead->gather_words) {
+		if (lead->d_gather) (void)hipFree(lead->d_gather);
+		if (lead->h_gather) (void)hipHostFree(lead->h_gather);
+		lead->d_gather = lead->h_gather = nullptr;
+		lead->gather_words = 0;
+		HIP_TRY(hipMalloc((void **)&lead->d_gather, (size_t)pitch * 256 * 4));
+		HIP_TRY(hipHostMalloc((void **)&lead->h_gather, (size_t)pitch * 256 * 4, hipHostMallocDefault));
+		lead->gather_words = (size_t)pitch * 256;
+	}
 	HIP_TRY(hipMemcpyAsync(lead->d_batch, devs.data(), n * sizeof(EncDev), hipMemcpyHostToDevice, bst));
 	HIP_TRY(hipEventRecord(lead->ev_batch0, bst));
 	if ((rc = launch_pool(lead, n, rows_total, bst))) return rc;
 	(void)hipEventRecord(lead->ev_batch1, bst);
+	hipLaunchKernelGGL(k_gather_results, dim3(n), dim3(256), 0, bst, (const EncDev *)lead->d_batch, lead->d_gather, pitch);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(lead->h_gather, lead->d_gather, (size_t)pitch * n * 4, hipMemcpyDeviceToHost, bst));
+	*pitch_out = pitch;
+	return HMR_GPU_OK;
+}
+
+// FINISH: wait for the launch; frame bookkeeping; every sequence's filter chain, records and levels queued; the download queued behind them
+int batch_finish(hmr_gpu_enc **encs, int n, const int *slots, int pitch, BatchTimes &bt)
+{
+	hmr_gpu_enc *lead = encs[0];
+	hipStream_t bst = lead->ctx->stream;
 	const hipError_t waited = hipStreamSynchronize(bst);
 	if (waited != hipSuccess) {
 		hmr_set_error("k_encode_pool: %s", hipGetErrorString(waited));
 		return HMR_GPU_ERR_HIP;
 	}
+	bt.t[2] = std::chrono::steady_clock::now();
 	float ms = 0;
 	HIP_TRY(hipEventElapsedTime(&ms, lead->ev_batch0, lead->ev_batch1));
-	const auto tt0 = std::chrono::steady_clock::now();
-	// Every sequence queues the device part of its frame on its own stream (a host thread each); the side-info records and the levels of ALL sequences are packed
-	// into one staging buffer and come to the host as ONE copy (sixty separate 11 MB downloads reached 9 GB/s between them); then a host thread per sequence codes
-	// its access unit.  (Starting a sequence's filters while the launch is still busy with the sequences chained behind it was tried - rows reporting into host
-	// memory - and gained 1-2 %, but one run in four of the 2160p batch then produced a wrong stream.)
-	std::vector<size_t> off_pub(n), off_coeff(n);
+	// The side-info records and the levels of ALL sequences are packed into one staging buffer and come to the host as ONE copy (sixty separate 11 MB downloads
+	// reached 9 GB/s between them).
+	lead->pend_pub.resize(n);
+	lead->pend_coeff.resize(n);
 	size_t total = 0;
 	for (int i = 0; i < n; i++) {
-		off_pub[i] = total;
+		lead->pend_pub[i] = total;
 		total += (sizeof(CtuPublic) * encs[i]->seq.nctu + 255) & ~(size_t)255;
-		off_coeff[i] = total;
+		lead->pend_coeff[i] = total;
 		total += ((size_t)12288 * encs[i]->seq.nctu + 255) & ~(size_t)255;
 	}
 	if (total > lead->stage_bytes) {
@@ -1517,6 +1592,7 @@ extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *sl
 		HIP_TRY(hipHostMalloc((void **)&lead->h_stage, total, hipHostMallocDefault));
 		lead->stage_bytes = total;
 	}
+	if (!lead->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&lead->copy_stream, hipStreamNonBlocking));
 	std::vector<int> rcs(n, 0);
 	std::vector<std::string> errs(n);       // (the error text is per thread: bring the workers' back to the caller's)
 	{
@@ -1525,15 +1601,26 @@ extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *sl
 			th.emplace_back([&, i]() {
 				hmr_gpu_enc *e = encs[i];
 				if (hipSetDevice(e->ctx->device) != hipSuccess) { rcs[i] = HMR_GPU_ERR_HIP; errs[i] = "hipSetDevice failed"; return; }
-				e->last_ms = ms;
-				int r = lockstep_collect(e);
-				if (!r) r = frame_device_part(e, slots[i]);
+				const uint32_t *g = lead->h_gather + (size_t)i * pitch;
+				e->last_ms = e->last_total_ms = ms;
+				e->last_encodes = (int)g[1];
+				e->f.scene_cut_ctu = (int)g[2];
+				e->last_passes = 1;
+				release_planes(e);
+				int r = frame_device_part(e, slots[i]);
 				if (!r) {
 					hipStream_t st = e->ctx->stream;
-					hipLaunchKernelGGL(k_pack_public, dim3(e->seq.nctu), dim3(256), 0, st, e->d.ctus, (uint32_t *)(lead->d_stage + off_pub[i]));
-					if (hipGetLastError() != hipSuccess || hipMemcpyAsync(lead->d_stage + off_coeff[i], e->d.coeff, (size_t)12288 * e->seq.nctu, hipMemcpyDeviceToDevice, st) != hipSuccess ||
-					    hipEventRecord(e->ev_ready, st) != hipSuccess)
+					hipLaunchKernelGGL(k_pack_public, dim3(e->seq.nctu), dim3(256), 0, st, e->d.ctus, (uint32_t *)(lead->d_stage + lead->pend_pub[i]));
+					if (hipGetLastError() != hipSuccess ||
+					    hipMemcpyAsync(lead->d_stage + lead->pend_coeff[i], e->d.coeff, (size_t)12288 * e->seq.nctu, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+					    hipEventRecord(e->ev_packed, st) != hipSuccess)
 						r = HMR_GPU_ERR_HIP;
+				}
+				if (!r) {
+					// the frame's statistics (encoder_engine_thread :3217-3238) need the CTUs' distortions only: the sequence can start its next frame
+					e->f_pending = e->f;
+					e->awaiting_delivery = true;
+					end_frame(e->seq, e->st, e->f, frame_acc_dist(e->seq, e->cfg.wfpp_num_threads, [&](int c) { return g[4 + c]; }));
 				}
 				rcs[i] = r;
 				if (r < 0) errs[i] = hmr_gpu_last_error();
@@ -1542,32 +1629,107 @@ extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *sl
 	}
 	for (int i = 0; i < n; i++)
 		if (rcs[i] < 0) { hmr_set_error("hmr_gpu_enc_encode_batch: sequence %d: %s", i, errs[i].c_str()); return rcs[i]; }
-	const auto tt1 = std::chrono::steady_clock::now();
-	for (int i = 0; i < n; i++) HIP_TRY(hipStreamWaitEvent(bst, encs[i]->ev_ready, 0));
-	HIP_TRY(hipEventRecord(lead->ev_batch0, bst));
-	HIP_TRY(hipStreamSynchronize(bst));
-	const auto tt2 = std::chrono::steady_clock::now();
-	HIP_TRY(hipMemcpyAsync(lead->h_stage, lead->d_stage, total, hipMemcpyDeviceToHost, bst));
-	HIP_TRY(hipStreamSynchronize(bst));
-	const auto tt3 = std::chrono::steady_clock::now();
+	bt.t[3] = std::chrono::steady_clock::now();
+	for (int i = 0; i < n; i++) HIP_TRY(hipStreamWaitEvent(lead->copy_stream, encs[i]->ev_packed, 0));
+	HIP_TRY(hipMemcpyAsync(lead->h_stage, lead->d_stage, total, hipMemcpyDeviceToHost, lead->copy_stream));
+	lead->pend_encs.assign(encs, encs + n);
+	lead->pend_total = total;
+	lead->pending = true;
+	return HMR_GPU_OK;
+}
+
+// DELIVER: the outstanding step's access units
+int batch_deliver(hmr_gpu_enc *lead, uint8_t **streams, const long *caps, long *stream_bytes, BatchTimes &bt)
+{
+	const int n = (int)lead->pend_encs.size();
+	bt.t[4] = std::chrono::steady_clock::now();
+	lead->pending = false;
+	for (int i = 0; i < n; i++) lead->pend_encs[i]->awaiting_delivery = false;
+	HIP_TRY(hipStreamSynchronize(lead->copy_stream));
+	bt.t[5] = std::chrono::steady_clock::now();
+	std::vector<int> rcs(n, 0);
+	std::vector<std::string> errs(n);
 	{
 		std::vector<std::thread> th;
 		for (int i = 0; i < n; i++)
 			th.emplace_back([&, i]() {
-				hmr_gpu_enc *e = encs[i];
-				rcs[i] = frame_host_part(e, lead->h_stage + off_pub[i], (const int16_t *)(lead->h_stage + off_coeff[i]), streams[i], caps[i], &stream_bytes[i]);
+				hmr_gpu_enc *e = lead->pend_encs[i];
+				rcs[i] = frame_entropy_part(e, e->f_pending, lead->h_stage + lead->pend_pub[i], (const int16_t *)(lead->h_stage + lead->pend_coeff[i]), streams[i], caps[i],
+							    &stream_bytes[i]);
 				if (rcs[i] < 0) errs[i] = hmr_gpu_last_error();
-				e->last_total_ms = ms;
 			});
 		for (auto &t : th) t.join();
 	}
+	bt.t[6] = std::chrono::steady_clock::now();
 	for (int i = 0; i < n; i++)
 		if (rcs[i] < 0) { hmr_set_error("hmr_gpu_enc_encode_batch: sequence %d: %s", i, errs[i].c_str()); return rcs[i]; }
-	if (getenv("HENC_BATCH_TIMING")) {
-		const auto tt4 = std::chrono::steady_clock::now();
-		auto d = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-		fprintf(stderr, "batch tail: queue device parts %.1f ms, device parts done %.1f, download %.1f (%.0f MB), entropy coding %.1f\n", d(tt0, tt1), d(tt1, tt2), d(tt2, tt3), total / 1e6, d(tt3, tt4));
+	return HMR_GPU_OK;
+}
+
+void batch_report(const BatchTimes &bt, hmr_gpu_enc *lead, bool pipelined)
+{
+	if (!getenv("HENC_BATCH_TIMING")) return;
+	fprintf(stderr, "batch step%s: launch %.1f ms, wait for the pool %.1f, queue device parts %.1f, download wait %.1f (%.0f MB), entropy coding %.1f\n", pipelined ? " (pipelined)" : "",
+		bt.ms(0, 1), pipelined ? bt.ms(6, 2) : bt.ms(1, 2), bt.ms(2, 3), bt.ms(4, 5), lead->pend_total / 1e6, bt.ms(5, 6));
+}
+}  // namespace
+
+extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes)
+{
+	int rc = batch_check(encs, n, slots, streams, caps, stream_bytes);
+	if (rc) return rc;
+	if (!slots) return HMR_GPU_ERR_ARG;
+	for (int i = 0; i < n; i++)
+		if (encs[i]->awaiting_delivery || encs[i]->pending) {
+			hmr_set_error("hmr_gpu_enc_encode_batch: encoder %d has an access unit outstanding from a pipelined call: flush first", i);
+			return HMR_GPU_ERR_ARG;
+		}
+	hmr_gpu_enc *lead = encs[0];
+	HIP_TRY(hipSetDevice(lead->ctx->device));
+	BatchTimes bt;
+	int pitch = 0;
+	bt.t[0] = std::chrono::steady_clock::now();
+	if ((rc = batch_launch(encs, n, slots, image_types, &pitch))) return rc;
+	bt.t[1] = std::chrono::steady_clock::now();
+	if ((rc = batch_finish(encs, n, slots, pitch, bt))) return rc;
+	if ((rc = batch_deliver(lead, streams, caps, stream_bytes, bt))) return rc;
+	batch_report(bt, lead, false);
+	return HMR_GPU_OK;
+}
+
+// The pipelined form: call k launches the frames slots[] and delivers the access units of call k - 1's frames (stream_bytes[i] = 0 on the first call).
+// slots == NULL: deliver the outstanding access units only.  The encoder list stays the same from call to call until the flush.
+extern "C" int hmr_gpu_enc_encode_batch_pipelined(hmr_gpu_enc **encs, int n, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes)
+{
+	int rc = batch_check(encs, n, slots, streams, caps, stream_bytes);
+	if (rc) return rc;
+	hmr_gpu_enc *lead = encs[0];
+	HIP_TRY(hipSetDevice(lead->ctx->device));
+	if (lead->pending) {
+		if ((int)lead->pend_encs.size() != n || memcmp(lead->pend_encs.data(), encs, n * sizeof(hmr_gpu_enc *))) {
+			hmr_set_error("hmr_gpu_enc_encode_batch_pipelined: the encoder list changed while access units are outstanding: flush (slots = NULL) with the previous list first");
+			return HMR_GPU_ERR_ARG;
+		}
+	} else {
+		for (int i = 0; i < n; i++)
+			if (encs[i]->awaiting_delivery) {
+				hmr_set_error("hmr_gpu_enc_encode_batch_pipelined: encoder %d has an access unit outstanding in another batch", i);
+				return HMR_GPU_ERR_ARG;
+			}
 	}
+	BatchTimes bt;
+	for (auto &t : bt.t) t = std::chrono::steady_clock::now();
+	int pitch = 0;
+	if (slots && (rc = batch_launch(encs, n, slots, image_types, &pitch))) return rc;
+	bt.t[1] = std::chrono::steady_clock::now();
+	if (lead->pending) {
+		if ((rc = batch_deliver(lead, streams, caps, stream_bytes, bt))) return rc;
+	} else {
+		for (int i = 0; i < n; i++) stream_bytes[i] = 0;
+		bt.t[6] = bt.t[1];
+	}
+	if (slots && (rc = batch_finish(encs, n, slots, pitch, bt))) return rc;
+	if (slots) batch_report(bt, lead, true);
 	return HMR_GPU_OK;
 }
 

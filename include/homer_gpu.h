@@ -615,6 +615,12 @@ int hmr_gpu_enc_encode_source(hmr_gpu_enc *enc, int slot, int image_type, uint8_
  * pictures whose wavefront step is open (k_encode_pool); n is at most 256, a few hundred pictures' worth of CTU rows saturate the pool (120 at 1080p).  A worker
  * never waits for a CTU that is not already running, so the launch does not depend on all its workgroups being resident. */
 int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes);
+/* the same, pipelined: call k launches the frames slots[] and delivers the access units of call k - 1's frames (stream_bytes[i] = 0 on the first call), whose download
+ * and entropy coding run while the device is busy with call k's CTU stage - a frame's successor needs its reconstruction and its distortion statistic, not its bytes
+ * (the reference's interface is asynchronous in the same way: HOMER_enc_encode queues a picture, HOMER_enc_get_coded_frame, hmr_encoder_lib.c:2997, takes coded frames
+ * from the output queue later).  slots == NULL: deliver the outstanding
+ * access units only (flush).  encs / n stay the same from call to call until the flush; an encoder with an access unit outstanding is refused by the other encode calls. */
+int hmr_gpu_enc_encode_batch_pipelined(hmr_gpu_enc **encs, int n, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes);
 /* the last frame: passes of the CTU schedule, CTU encodes (>= the number of CTUs), device milliseconds of the CTU passes and of the whole frame */
 int hmr_gpu_enc_last_stats(hmr_gpu_enc *enc, int *passes, int *ctu_encodes, float *ctu_ms, float *frame_ms);
 /* profiling build (-DHENC_PROFILE): per-row phase timers, [ctu rows][12] */
