@@ -197,14 +197,17 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth,
 	{ PRIM_T0(); get_merge_candidates(e, ni, w.merge_cands, inter_modes); PRIM_END(PP_CAND); }
 	for (int cand = 0; cand < S.num_merge_cand; cand++) {
 		int mc_done = 0;
-		// A candidate that repeats candidate 0 (same vector, same reference - the usual case under coherent motion, and always for the zero candidates) cannot win:
-		// its two evaluations recompute what candidate 0's did, bit for bit, and "<" keeps the earlier one.  The reference runs them anyway; what they leave behind
-		// is what candidate 0 left, except that the no-residual evaluation, where it runs (the candidate's coded evaluation - candidate 0's - had levels, or was
-		// itself skipped because the best so far is a skip), resets the node's cbf / transform index / level sum.  Do exactly that and nothing else.
-		if (cand == 1 && w.merge_cands.mv[1].x == w.merge_cands.mv[0].x && w.merge_cands.mv[1].y == w.merge_cands.mv[0].y &&
-		    w.merge_cands.ref_idx[1] == w.merge_cands.ref_idx[0]) {
-			const int coded_runs = !best_is_skip;                                   // (then it rewrites candidate 0's coded result over itself)
-			const int nores_runs = !(coded_runs && merge_cand_buffer[0] == 1);      // merge_cand_buffer[1] would become what merge_cand_buffer[0] is
+		// A candidate that repeats the one before it (same vector, same reference - the usual case under coherent motion, and always for the zero candidates that
+		// fill the list: with one reference picture they are all alike) cannot win: its two evaluations recompute what its predecessor's did, bit for bit, into
+		// the same buffers, and "<" keeps the earlier one.  The reference runs them anyway; what they leave behind is what the predecessor left, except that
+		// the no-residual evaluation, where it runs (the candidate's coded evaluation - the predecessor's - had levels, or is itself skipped because the best so
+		// far is a skip), resets the node's cbf / transform index / level sum.  Do exactly that and nothing else.  (best_is_skip only ever goes from 0 to 1, so a
+		// coded evaluation that would run here has run for the predecessor.)
+		if (cand >= 1 && w.merge_cands.mv[cand].x == w.merge_cands.mv[cand - 1].x && w.merge_cands.mv[cand].y == w.merge_cands.mv[cand - 1].y &&
+		    w.merge_cands.ref_idx[cand] == w.merge_cands.ref_idx[cand - 1]) {
+			const int coded_runs = !best_is_skip;                                       // (then it rewrites the predecessor's coded result over itself)
+			if (coded_runs) merge_cand_buffer[cand] = merge_cand_buffer[cand - 1];
+			const int nores_runs = !(coded_runs && merge_cand_buffer[cand] == 1);
 			if (nores_runs) {
 				nd.inter_cbf[0] = nd.inter_cbf[1] = nd.inter_cbf[2] = 0;
 				nd.inter_tr_idx = 0;

@@ -395,7 +395,20 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 	e.total_partitions = tc * NPART;
 	e.coeff = d.coeff + (size_t)n * 6144;
 	g.sync();
+#if defined(HENC_PROFILE)
+	e.prof = d.prof ? d.prof + (size_t)row * PF_COUNT : nullptr;     // (a picture has one CTU per row in flight)
+	{
+		HENC_PROF_T0();
+		encode_ctu(g, e, n);
+		HENC_PROF_ADD(e, PF_TOTAL);
+	}
+	if (g.tid == 0 && e.prof) {
+		unsigned long long *pp = (unsigned long long *)(henc_lds + HENC_LDS_PROF_OFFSET);
+		for (int k = 0; k < 2 * PP_COUNT; k++) { e.prof[PF_PRIM0 + k] += pp[k]; pp[k] = 0; }
+	}
+#else
 	encode_ctu(g, e, n);
+#endif
 	resolve_mode_tokens(g, *e.w, d.ctus[n]);
 	wave_copy_words(d.outtok + (size_t)n * MODE_STATE_BYTES, e.w->intra_mode_buffs, MODE_STATE_BYTES, g.tid);
 	wave_copy_words(d.rowstate + (size_t)me * MODE_STATE_BYTES, &e.w->intra_mode_buffs[0][0][0], MODE_STATE_BYTES, g.tid);

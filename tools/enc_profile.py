@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--wpp", type=int, default=1, help="wfpp_num_threads (CTU rows = the row-per-thread schedule)")
     a = ap.parse_args()
-    lib = C.CDLL(os.path.join(ROOT, "homerhevc_amd", "libhomer_gpu.so"))
+    lib = C.CDLL(os.environ.get("HOMER_GPU_LIB") or os.path.join(ROOT, "homerhevc_amd", "libhomer_gpu.so"))     # (HOMER_GPU_LIB: a profiling build kept beside the product library)
     lib.hmr_gpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
     lib.hmr_gpu_enc_create.argtypes = [C.c_void_p, C.POINTER(ec.EncCfg), C.POINTER(C.c_void_p)]
     lib.hmr_gpu_enc_frame_ctus.argtypes = [C.c_void_p] + [C.c_char_p] * 3 + [C.c_int] + [C.c_char_p] * 3 + [C.c_double, C.c_char_p]
