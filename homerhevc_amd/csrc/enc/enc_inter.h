@@ -52,8 +52,10 @@ HENC_HD void motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv
 	const int gx = e.ctu->x + q.x, gy = e.ctu->y + q.y, gxc = (e.ctu->x >> 1) + q.xc, gyc = (e.ctu->y >> 1) + q.yc;
 #if defined(__HIPCC__)
 	PRIM_T0();
-	const uint8_t *py = e.f->sub_y + (size_t)(((mv.y & 3) << 2) | (mv.x & 3)) * S.plane_elems_y + (gy + (mv.y >> 2)) * S.stride_y + gx + (mv.x >> 2);
-	const size_t oc = (size_t)(((mv.y & 7) << 3) | (mv.x & 7)) * S.plane_elems_c + (gyc + (mv.y >> 3)) * S.stride_c + gxc + (mv.x >> 3);
+	// (row-interleaved planes, k_subpel.hip: row y of phase f starts at (y * phases + f) * stride)
+	const int sy = 16 * S.stride_y, sc = 64 * S.stride_c;
+	const uint8_t *py = e.f->sub_y + (((mv.y & 3) << 2) | (mv.x & 3)) * S.stride_y + (ptrdiff_t)(gy + (mv.y >> 2)) * sy + gx + (mv.x >> 2);
+	const ptrdiff_t oc = (((mv.y & 7) << 3) | (mv.x & 7)) * S.stride_c + (ptrdiff_t)(gyc + (mv.y >> 3)) * sc + gxc + (mv.x >> 3);
 	if (q.size <= 32) {
 		// every load of the three blocks is issued before the first store waits for one: the copy costs one trip to the planes, not three
 		const int n = q.size, nc = q.size_chroma, lw = ilog2i(n) - 2, lc = ilog2i(nc) - 2, ychunks = (n * n) >> 2, cchunks = (nc * nc) >> 2;
@@ -61,11 +63,11 @@ HENC_HD void motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv
 		int16_t *dy = w.pred_y + q.y * 64 + q.x, *du = w.pred_c[0] + q.yc * 32 + q.xc, *dv = w.pred_c[1] + q.yc * 32 + q.xc;
 		uint32_t vy[4] = {0, 0, 0, 0}, vu = 0, vv = 0;
 		const int ic = g.tid, rc = ic >> lc, cc = (ic & ((1 << lc) - 1)) << 2;
-		if (ic < cchunks) { vu = ld32u(pu + rc * S.stride_c + cc); vv = ld32u(pv + rc * S.stride_c + cc); }
+		if (ic < cchunks) { vu = ld32u(pu + rc * sc + cc); vv = ld32u(pv + rc * sc + cc); }
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
 			const int i = g.tid + 64 * k;
-			if (i < ychunks) vy[k] = ld32u(py + (i >> lw) * S.stride_y + ((i & ((1 << lw) - 1)) << 2));
+			if (i < ychunks) vy[k] = ld32u(py + (i >> lw) * sy + ((i & ((1 << lw) - 1)) << 2));
 		}
 		if (ic < cchunks) {
 			const uint32_t ou[2] = {__builtin_amdgcn_perm(0u, vu, 0x0c010c00u), __builtin_amdgcn_perm(0u, vu, 0x0c030c02u)};
@@ -82,9 +84,9 @@ HENC_HD void motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv
 			}
 		}
 	} else {
-		blk_from_u8(g, e.f->sub_c[0] + oc, S.stride_c, w.pred_c[0] + q.yc * 32 + q.xc, 32, q.size_chroma);
-		blk_from_u8(g, e.f->sub_c[1] + oc, S.stride_c, w.pred_c[1] + q.yc * 32 + q.xc, 32, q.size_chroma);
-		blk_from_u8(g, py, S.stride_y, w.pred_y + q.y * 64 + q.x, 64, q.size);
+		blk_from_u8(g, e.f->sub_c[0] + oc, sc, w.pred_c[0] + q.yc * 32 + q.xc, 32, q.size_chroma);
+		blk_from_u8(g, e.f->sub_c[1] + oc, sc, w.pred_c[1] + q.yc * 32 + q.xc, 32, q.size_chroma);
+		blk_from_u8(g, py, sy, w.pred_y + q.y * 64 + q.x, 64, q.size);
 	}
 	g.sync();
 	PRIM_END(PP_INTERP);
@@ -103,12 +105,13 @@ HENC_HD void cand_sads(const G &g, Enc &__restrict__ e, int ox, int oy, int gx, 
 {
 	const Seq &S = *e.seq;
 #if defined(__HIPCC__)
-	const uint8_t *p0 = e.f->sub_y + gy * S.stride_y + gx;
+	const int sy = 16 * S.stride_y;      // (row-interleaved planes)
+	const uint8_t *p0 = e.f->sub_y + (ptrdiff_t)gy * sy + gx;
 	const uint8_t *cand[MAXC];
 #pragma unroll
 	for (int k = 0; k < MAXC; k++)
-		cand[k] = ok[k] ? p0 + (size_t)(((qy[k] & 3) << 2) | (qx[k] & 3)) * S.plane_elems_y + (qy[k] >> 2) * S.stride_y + (qx[k] >> 2) : nullptr;
-	multi_sad_u8<MAXC>(g, e.w->curr_y + oy * 64 + ox, size, cand, S.stride_y, out);
+		cand[k] = ok[k] ? p0 + (((qy[k] & 3) << 2) | (qx[k] & 3)) * S.stride_y + (ptrdiff_t)(qy[k] >> 2) * sy + (qx[k] >> 2) : nullptr;
+	multi_sad_u8<MAXC>(g, e.w->curr_y + oy * 64 + ox, size, cand, sy, out);
 #else
 	const int16_t *orig = e.w->curr_y + oy * 64 + ox, *ref = e.f->ref[0] + gy * S.stride_y + gx;
 	for (int k = 0; k < MAXC; k++) {

@@ -130,7 +130,7 @@ struct Seq {
 	int32_t stride_y, stride_c, margin_y, margin_c;
 	// source planes (no margin)
 	int32_t src_stride_y, src_stride_c;
-	// elements of one padded plane (stride x (rows + 2 margins)): the pitch between the phase planes of the reference (FrameCtx::sub_y / sub_c)
+	// elements of one padded plane (stride x (rows + 2 margins)): the phase planes of the reference (FrameCtx::sub_y / sub_c) take 16 / 64 of them
 	int32_t plane_elems_y, plane_elems_c;
 	int32_t wide_min_n;                    // device: smallest block side the row worker and its helpers work on together (enc_common.h: wide jobs)
 	int32_t pad_;
@@ -150,8 +150,8 @@ struct FrameCtx {
 	const int16_t *ref[3];                 // reference picture (list 0, index 0), first valid sample
 	int16_t *rec[3];                       // picture under reconstruction, first valid sample
 	// the reference picture as 8-bit phase planes (k_subpel.hip), first valid sample of plane 0: luma plane (mvy & 3) * 4 + (mvx & 3) holds the picture
-	// interpolated at that quarter-sample phase, chroma plane (mvy & 7) * 8 + (mvx & 7) likewise in eighth samples; planes are plane_elems_y / _c apart
-	// and share the reference's strides and margins.  Device only (the checker build interpolates from ref[]).
+	// interpolated at that quarter-sample phase, chroma plane (mvy & 7) * 8 + (mvx & 7) likewise in eighth samples; the planes are row-interleaved
+	// (row y of plane f starts at (y * 16 + f) * stride_y, chroma (y * 64 + f) * stride_c) and share the reference's row length and margins.  Device only (the checker build interpolates from ref[]).
 	const uint8_t *sub_y, *sub_c[2];
 };
 

@@ -1003,9 +1003,9 @@ int set_frame(hmr_gpu_enc *e, int slot, int image_type, double avg_dist)
 			const int rc = g_plane_pool.acquire(e->ctx->device, (size_t)16 * s.plane_elems_y, (size_t)64 * s.plane_elems_c, &e->planes);
 			if (rc) return rc;
 		}
-		e->f.sub_y = e->planes.y + (size_t)s.margin_y * s.stride_y + s.margin_y;
-		e->f.sub_c[0] = e->planes.c[0] + (size_t)s.margin_c * s.stride_c + s.margin_c;
-		e->f.sub_c[1] = e->planes.c[1] + (size_t)s.margin_c * s.stride_c + s.margin_c;
+		e->f.sub_y = e->planes.y + (size_t)s.margin_y * 16 * s.stride_y + s.margin_y;       // (row-interleaved: a row of the picture is 16 / 64 rows of phases)
+		e->f.sub_c[0] = e->planes.c[0] + (size_t)s.margin_c * 64 * s.stride_c + s.margin_c;
+		e->f.sub_c[1] = e->planes.c[1] + (size_t)s.margin_c * 64 * s.stride_c + s.margin_c;
 	}
 	HIP_TRY(hipMemcpyAsync(e->d_frame, &e->f, sizeof(FrameCtx), hipMemcpyHostToDevice, e->ctx->stream));
 	return HMR_GPU_OK;

@@ -7,7 +7,8 @@
 // is asked for, so here the whole padded reference is interpolated ONCE per frame for every phase:
 //   luma    16 planes, plane (fy * 4 + fx) = the picture displaced by (fx, fy) quarter samples,
 //   chroma  64 planes per component, plane (fy * 8 + fx) in eighth samples,
-// stored as bytes with the picture's own stride and margins.  Inside the CTU walk (enc/enc_inter.h) motion compensation is then a
+// stored as bytes with the picture's own row length and margins, ROW-INTERLEAVED: row y of plane f starts at byte (y * planes + f) * stride, so that what a
+// CTU reads of all the planes (its search window, a few hundred rows) is one contiguous stretch of memory - a handful of pages instead of one per plane.  Inside the CTU walk (enc/enc_inter.h) motion compensation is then a
 // copy and a motion-search candidate is v_sad_u8 against a plane.
 //
 // These kernels are streaming, store-bound work: a luma sample is read once (2 bytes at the picture's int16 width) and 16 bytes are
@@ -38,7 +39,7 @@ __device__ __forceinline__ short4_t lds4(const int16_t *p) { return *(const shor
 // The tiles keep sample x0 + c at column c + 4 (a left margin of four, of which the filters use three / one): the four samples a thread finishes start on an
 // 8-byte boundary, so every LDS access of the hot loops is a 64-bit one.
 
-// out = [16][elems] bytes; pic = allocation start; elems = stride * rows
+// out = [rows][16][stride] bytes; pic = allocation start; elems = stride * rows
 __global__ __launch_bounds__(256) void k_subpel_luma(const int16_t *__restrict__ pic, int stride, int rows, uint8_t *__restrict__ out)
 {
 	__shared__ __attribute__((aligned(16))) int16_t in[TH + 7][TW + 8];          // rows y0-3 .. y0+TH+3, columns x0-4 .. x0+TW+3
@@ -76,7 +77,6 @@ __global__ __launch_bounds__(256) void k_subpel_luma(const int16_t *__restrict__
 	const int ty = t >> 4, tx = (t & 15) << 2;
 	const int y = y0 + ty, x = x0 + tx;
 	if (y >= rows || x >= stride) return;
-	const long li = (long)y * stride + x;
 	uint32_t pk[16];
 #pragma unroll
 	for (int f = 0; f < 16; f++) pk[f] = 0;
@@ -103,11 +103,12 @@ __global__ __launch_bounds__(256) void k_subpel_luma(const int16_t *__restrict__
 			pk[fy * 4 + 3] |= clip255(sat16i((s3 + 2048 + (8192 << 6)) >> 12)) << (8 * j);
 		}
 	}
+	uint8_t *o = out + ((size_t)y * 16 * stride + x);      // row y of phase f starts at (y * 16 + f) * stride: the phases of a row lie side by side
 #pragma unroll
-	for (int f = 0; f < 16; f++) *(uint32_t *)(out + (size_t)f * elems + li) = pk[f];
+	for (int f = 0; f < 16; f++) *(uint32_t *)(o + (size_t)f * stride) = pk[f];
 }
 
-// one chroma component: out = [64][elems]
+// one chroma component: out = [rows][64][stride]
 __global__ __launch_bounds__(256) void k_subpel_chroma(const int16_t *__restrict__ pic, int stride, int rows, uint8_t *__restrict__ out)
 {
 	__shared__ __attribute__((aligned(16))) int16_t in[TH + 3][TW + 8];          // rows y0-1 .. y0+TH+1, columns x0-4 .. x0+TW+3
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void k_subpel_chroma(const int16_t *__restrict
 	const int ty = t >> 4, tx = (t & 15) << 2;
 	const int y = y0 + ty, x = x0 + tx;
 	if (y >= rows || x >= stride) return;
-	const long li = (long)y * stride + x;
+	uint8_t *o = out + ((size_t)y * 64 * stride + x);      // row y of phase f starts at (y * 64 + f) * stride
 	short4_t in4[4];
 #pragma unroll
 	for (int k = 0; k < 4; k++) in4[k] = lds4(&in[ty + k][tx + 4]);
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void k_subpel_chroma(const int16_t *__restrict
 #pragma unroll
 		for (int j = 0; j < 4; j++) pk[0] |= clip255(in4[1][j]) << (8 * j);
 #pragma unroll
-		for (int f = 0; f < 8; f++) *(uint32_t *)(out + (size_t)f * elems + li) = pk[f];
+		for (int f = 0; f < 8; f++) *(uint32_t *)(o + (size_t)f * stride) = pk[f];
 	}
 	for (int fx = 0; fx < 8; fx++) {
 		// the column of intermediates (fx = 0: of integer samples) once, the seven vertical phases from it
@@ -172,14 +173,14 @@ __global__ __launch_bounds__(256) void k_subpel_chroma(const int16_t *__restrict
 				const int sum = h[0][j] * cf[fy][0] + h[1][j] * cf[fy][1] + h[2][j] * cf[fy][2] + h[3][j] * cf[fy][3];
 				pk |= (fx ? clip255(sat16i((sum + 2048 + (8192 << 6)) >> 12)) : clip255((sum + 32) >> 6)) << (8 * j);
 			}
-			*(uint32_t *)(out + (size_t)(fy * 8 + fx) * elems + li) = pk;
+			*(uint32_t *)(o + (size_t)(fy * 8 + fx) * stride) = pk;
 		}
 	}
 }
 
 }  // namespace
 
-// device pointers; pic_* = start of the padded allocations (stride x rows elements), out_y = 16 planes, out_u / out_v = 64 planes each
+// device pointers; pic_* = start of the padded allocations (stride x rows elements), out_y = [rows][16][stride], out_u / out_v = [rows][64][stride]
 extern "C" int hmr_gpu_subpel_planes(hmr_gpu_ctx *ctx, const int16_t *pic_y, const int16_t *pic_u, const int16_t *pic_v, int stride_y, int rows_y, int stride_c, int rows_c,
 				     uint8_t *out_y, uint8_t *out_u, uint8_t *out_v)
 {

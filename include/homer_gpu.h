@@ -654,7 +654,9 @@ int hmr_gpu_enc_import_reference(hmr_gpu_enc *enc, const int16_t *dev_y, const i
  *     All pointers are device memory.  pic_y / pic_u / pic_v: the padded int16 planes from the first element of their allocation,
  *     stride x rows elements each (strides multiples of 4).  out_y: 16 x stride_y x rows_y bytes, plane fy * 4 + fx = the picture
  *     displaced by (fx, fy) quarter samples, clipped to 8 bits like the final stage of the interpolation; out_u / out_v: 64 planes
- *     each, plane fy * 8 + fx in eighth samples (pic_u / pic_v / out_u / out_v may be NULL: luma only).  Taps run over row ends
+ *     each, plane fy * 8 + fx in eighth samples (pic_u / pic_v / out_u / out_v may be NULL: luma only).  The planes are
+ *     row-interleaved - row y of plane f starts at byte (y * 16 + f) * stride_y (chroma: (y * 64 + f) * stride_c) - so that the
+ *     window a CTU reads of all of them is one stretch of memory.  Taps run over row ends
  *     linearly, as the reference's pointer arithmetic does; taps outside the allocation read zero.
  * ------------------------------------------------------------------------------------------------ */
 int hmr_gpu_subpel_planes(hmr_gpu_ctx *ctx, const int16_t *pic_y, const int16_t *pic_u, const int16_t *pic_v, int stride_y, int rows_y, int stride_c, int rows_c,

@@ -47,7 +47,7 @@ def test_planes_equal_oracle_motion_compensation(rig, stride_y, rows_y, seed):
     pic[0][: rows_y // 2, : stride_y // 2] = 255                      # a flat saturated area and hard edges: the clipping paths
     pic[1][rows_c // 3:, stride_c // 3:] = 0
     d_pic = [dev(gpu, ctx, p) for p in pic]
-    out = [np.zeros((16, rows_y, stride_y), np.uint8), np.zeros((64, rows_c, stride_c), np.uint8), np.zeros((64, rows_c, stride_c), np.uint8)]
+    out = [np.zeros((rows_y, 16, stride_y), np.uint8), np.zeros((rows_c, 64, stride_c), np.uint8), np.zeros((rows_c, 64, stride_c), np.uint8)]      # row-interleaved planes
     d_out = [dev(gpu, ctx, o) for o in out]
     assert gpu.hmr_gpu_subpel_planes(ctx, *d_pic, stride_y, rows_y, stride_c, rows_c, *d_out) == 0, gpu.hmr_gpu_last_error()
     for o, d in zip(out, d_out):
@@ -63,7 +63,7 @@ def test_planes_equal_oracle_motion_compensation(rig, stride_y, rows_y, seed):
         for y0 in range(0, hv, n):
             for x0 in range(0, wv, n):
                 ora.ora_mc_luma(VP(src + 2 * (y0 * stride_y + x0)), stride_y, VP(want.ctypes.data + 2 * (y0 * w + x0)), w, n, n, fx, fy, 0)
-        bad = np.argwhere(out[0][f, 4:4 + hv, 4:4 + wv] != want[:hv, :wv].astype(np.uint8))
+        bad = np.argwhere(out[0][4:4 + hv, f, 4:4 + wv] != want[:hv, :wv].astype(np.uint8))
         assert len(bad) == 0, f"luma plane {f}: {len(bad)} samples differ, first at {bad[:4].tolist()}"
     wc, hc = stride_c - 8, rows_c - 8
     wantc = np.zeros((hc, wc), np.int16)
@@ -76,7 +76,7 @@ def test_planes_equal_oracle_motion_compensation(rig, stride_y, rows_y, seed):
                 for x0 in range(0, wc - n + 1, n):
                     ora.ora_mc_chroma(VP(src + 2 * (y0 * stride_c + x0)), stride_c, VP(wantc.ctypes.data + 2 * (y0 * wc + x0)), wc, n, fx, fy, 0)
             hv, wv = (hc // n) * n, (wc // n) * n
-            bad = np.argwhere(out[comp][f, 4:4 + hv, 4:4 + wv] != wantc[:hv, :wv].astype(np.uint8))
+            bad = np.argwhere(out[comp][4:4 + hv, f, 4:4 + wv] != wantc[:hv, :wv].astype(np.uint8))
             assert len(bad) == 0, f"chroma {comp} plane {f}: {len(bad)} samples differ, first at {bad[:4].tolist()}"
     for d in d_pic + d_out:
         gpu.hmr_gpu_free(ctx, d)

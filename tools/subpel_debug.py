@@ -34,7 +34,7 @@ S, R = 208, 72
 Sc, Rc = 108, 39
 rng = np.random.default_rng(1)
 pic = [rng.integers(0, 256, (R, S)).astype(np.int16), rng.integers(0, 256, (Rc, Sc)).astype(np.int16), rng.integers(0, 256, (Rc, Sc)).astype(np.int16)]
-out = [np.zeros((16, R, S), np.uint8), np.zeros((64, Rc, Sc), np.uint8), np.zeros((64, Rc, Sc), np.uint8)]
+out = [np.zeros((R, 16, S), np.uint8), np.zeros((Rc, 64, Sc), np.uint8), np.zeros((Rc, 64, Sc), np.uint8)]      # row-interleaved planes
 d_pic, d_out = [dev(p) for p in pic], [dev(o) for o in out]
 assert gpu.hmr_gpu_subpel_planes(ctx, *d_pic, S, R, Sc, Rc, *d_out) == 0
 for o, d in zip(out, d_out):
@@ -48,7 +48,7 @@ for f in range(16):
     for y0 in range(0, hv, 8):
         for x0 in range(0, wv, 8):
             ora.ora_mc_luma(VP(src + 2 * (y0 * S + x0)), S, VP(want.ctypes.data + 2 * (y0 * w + x0)), w, 8, 8, fx, fy, 0)
-    a, b = out[0][f, 4:4 + hv, 4:4 + wv], want[:hv, :wv].astype(np.uint8)
+    a, b = out[0][4:4 + hv, f, 4:4 + wv], want[:hv, :wv].astype(np.uint8)
     bad = np.argwhere(a != b)
     print("luma", f, len(bad), [(int(y), int(x), int(a[y, x]), int(b[y, x])) for y, x in bad[:6]])
 wc, hc = Sc - 8, Rc - 8
@@ -62,7 +62,7 @@ for comp in (1, 2):
         for y0 in range(0, hv, 8):
             for x0 in range(0, wv, 8):
                 ora.ora_mc_chroma(VP(src + 2 * (y0 * Sc + x0)), Sc, VP(want.ctypes.data + 2 * (y0 * wc + x0)), wc, 8, fx, fy, 0)
-        a, b = out[comp][f, 4:4 + hv, 4:4 + wv], want[:hv, :wv].astype(np.uint8)
+        a, b = out[comp][4:4 + hv, f, 4:4 + wv], want[:hv, :wv].astype(np.uint8)
         bad = np.argwhere(a != b)
         tot += len(bad)
         if len(bad):
