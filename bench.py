@@ -491,7 +491,8 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
         # SURVEY.md 8-d, the CTU stage's share of the frame-level compulsory traffic: source + reference + reconstruction (1 byte samples) + levels (2 bytes)
         algo_bytes_frame = 1.5 * width * height * 3 + 2 * 1.5 * width * height
         achieved = S * algo_bytes_frame * len(timed) / (ctu_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed counter passes of this same command (TCC_EA0_RDREQ / WRREQ x 64 B, MI355X_MICROARCH.md "HBM"; narrow accesses: uncalibrated)
+        # HBM bytes per launch from the committed counter passes of this same command: TCC_EA0 requests by their width (64 / 128-byte reads, 64-byte full-line and 32-byte
+        # partial-line writes; calibrated on known byte counts, profiles/r03_tcc_calibration.json, as MI355X_MICROARCH.md "HBM" asks for narrow accesses)
         traffic, issue = None, None
         kernel_name = "k_encode_pool"
         tpath = os.path.join(ROOT, "profiles", "r03_pmc_kernels.json")
@@ -499,7 +500,8 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
             pm = json.load(open(tpath))
             k, frames_profiled = pm.get(kernel_name), pm.get("frames_encoded_by_k_encode_pool")
             if k and frames_profiled:
-                per_frame = (k["derived"]["hbm_read_bytes_TCC_EA0_RDREQ_x64"] + k["derived"]["hbm_write_bytes_TCC_EA0_WRREQ_x64_upper_bound"]) / frames_profiled
+                dv = k["derived"]      # (by request width where the passes have it, tools/tcc_calibrate.py; else requests x 64 B)
+                per_frame = (dv.get("hbm_read_bytes", dv["hbm_read_bytes_TCC_EA0_RDREQ_x64"]) + dv.get("hbm_write_bytes", dv["hbm_write_bytes_TCC_EA0_WRREQ_x64_upper_bound"])) / frames_profiled
                 traffic = int(per_frame * S * len(timed) / max(launches, 1))       # per launch, like `achieved`
                 # what actually bounds the kernel: wave-instruction issue (MI355X_MICROARCH.md: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction)
                 valu_per_frame, salu_per_frame = k["SQ_INSTS_VALU"] / frames_profiled, k["SQ_INSTS_SALU"] / frames_profiled

@@ -35,6 +35,13 @@ def main():
         if "TCC_EA0_RDREQ_sum" in k:
             d["hbm_read_bytes_TCC_EA0_RDREQ_x64"] = k["TCC_EA0_RDREQ_sum"] * 64
             d["hbm_write_bytes_TCC_EA0_WRREQ_x64_upper_bound"] = k.get("TCC_EA0_WRREQ_sum", 0) * 64
+            # by request width (tools/tcc_calibrate.py: reads 64 / 128 bytes, writes 64 bytes for a full line and 32 for a partial one): the bytes that cross the fabric
+            if "TCC_EA0_RDREQ_128B_sum" in k:
+                r32, r64, r128 = k.get("TCC_EA0_RDREQ_32B_sum", 0), k.get("TCC_EA0_RDREQ_64B_sum", 0), k["TCC_EA0_RDREQ_128B_sum"]
+                d["hbm_read_bytes"] = 32 * r32 + 64 * r64 + 128 * r128 + 64 * max(k["TCC_EA0_RDREQ_sum"] - r32 - r64 - r128, 0)
+            if "TCC_EA0_WRREQ_64B_sum" in k:
+                d["hbm_write_bytes"] = 64 * k["TCC_EA0_WRREQ_64B_sum"] + 32 * (k.get("TCC_EA0_WRREQ_sum", 0) - k["TCC_EA0_WRREQ_64B_sum"])
+                d["write_requests_full_line_share"] = round(k["TCC_EA0_WRREQ_64B_sum"] / max(k.get("TCC_EA0_WRREQ_sum", 0), 1), 3)
             tot = k.get("TCC_HIT_sum", 0) + k.get("TCC_MISS_sum", 0)
             if tot:
                 d["l2_hit_rate"] = round(k["TCC_HIT_sum"] / tot, 4)
