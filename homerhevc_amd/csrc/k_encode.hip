@@ -33,6 +33,10 @@
 
 using namespace henc;
 
+// k_subpel.hip: the phase planes of a reference picture, queued on `stream`
+int hmr_subpel_planes_on(hipStream_t stream, const int16_t *pic_y, const int16_t *pic_u, const int16_t *pic_v, int stride_y, int rows_y, int stride_c, int rows_c, uint8_t *out_y,
+			 uint8_t *out_u, uint8_t *out_v);
+
 struct EncDev {
 	const Seq *seq;
 	const FrameCtx *frame;
@@ -674,16 +678,15 @@ __device__ void sao_decide_one(const SaoDecideArgs &a, int r, int c, SaoContexts
 // sharing a wavefront (lane = row, the first version) executed the union of each other's paths.  Rows advance as the WPP wavefront: CTU (r, c) needs the
 // parameters of (r - 1, c) for the merge-up candidate and row r starts from the contexts row r - 1 had after its second CTU - row r waits until row r - 1 has
 // published c + 2 CTUs (or all of them).  Workgroups are dispatched in row order, so the row a workgroup waits for is always running or done.
-__global__ __launch_bounds__(64) void k_sao_decide(SaoDecideArgs a, int *progress)
+__device__ __forceinline__ void sao_decide_rows(const SaoDecideArgs &a, int *progress, int r)
 {
-	if (threadIdx.x != 0) return;
 	SaoContexts cur = {(uint8_t)a.st_merge, (uint8_t)a.st_type, a.next_lps};
 	if (!a.wpp) {
-		if (blockIdx.x == 0)
+		if (r == 0)
 			for (int n = 0; n < a.W * a.H; n++) sao_decide_one(a, n / a.W, n % a.W, cur);
 		return;
 	}
-	const int r = (int)blockIdx.x;
+	if (r >= a.H) return;
 	for (int c = 0; c < a.W; c++) {
 		if (r > 0) {
 			const int need = c + 2 < a.W ? c + 2 : a.W;
@@ -695,6 +698,43 @@ __global__ __launch_bounds__(64) void k_sao_decide(SaoDecideArgs a, int *progres
 		if (c == 1 || a.W == 1) { a.saved[2 * r] = cur.st_merge; a.saved[2 * r + 1] = cur.st_type; }
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 		__hip_atomic_store(&progress[r], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+__global__ __launch_bounds__(64) void k_sao_decide(SaoDecideArgs a, int *progress)
+{
+	if (threadIdx.x != 0) return;
+	sao_decide_rows(a, progress, (int)blockIdx.x);
+}
+// The pictures of a batch in one launch: a workgroup per picture, a THREAD per CTU row, the rows advancing in lockstep as the WPP wavefront (row r decides CTU
+// t - 2 r at step t, a barrier between the steps).  The threads of a wavefront execute the union of their rows' branches, which makes a picture take about as long
+// as with a workgroup per row (3.6 ms against 2.5 at 1080p) - but a workgroup per row and picture, 3060 of them spinning on each other's progress with an
+// agent-scope fence per CTU, took 20 ms for the 180 pictures of a batch, and as a launch per picture the sequences queued up eleven deep on the hardware queues.
+struct SaoDecideJob {
+	SaoDecideArgs a;
+	int *progress;
+	int enabled, pad_;
+};
+__global__ __launch_bounds__(1024) void k_sao_decide_batch(const SaoDecideJob *jobs)
+{
+	const SaoDecideJob &j = jobs[blockIdx.x];
+	if (!j.enabled) return;
+	const SaoDecideArgs &a = j.a;
+	const int r = (int)threadIdx.x;
+	SaoContexts cur = {(uint8_t)a.st_merge, (uint8_t)a.st_type, a.next_lps};
+	if (!a.wpp) {
+		if (r == 0)
+			for (int n = 0; n < a.W * a.H; n++) sao_decide_one(a, n / a.W, n % a.W, cur);
+		return;
+	}
+	for (int t = 0; t < a.W + 2 * (a.H - 1); t++) {
+		const int c = t - 2 * r;
+		if (r < a.H && c >= 0 && c < a.W) {
+			if (c == 0 && r > 0) { cur.st_merge = a.saved[2 * (r - 1)]; cur.st_type = a.saved[2 * (r - 1) + 1]; }
+			sao_decide_one(a, r, c, cur);
+			if (c == 1 || a.W == 1) { a.saved[2 * r] = cur.st_merge; a.saved[2 * r + 1] = cur.st_type; }
+		}
+		__threadfence_block();
+		__syncthreads();   // the rows' results of this step are in memory before the next step reads them
 	}
 }
 
@@ -788,7 +828,7 @@ struct hmr_gpu_enc {
 	size_t stage_bytes = 0;
 	void *d_batch = nullptr;                             // hmr_gpu_enc_encode_batch (lead encoder): the sequences' EncDev records and first rows
 	// pipelined batch (lead encoder): the step whose access units are still to be delivered
-	bool pending = false;
+	bool pending = false, download_queued = false;
 	std::vector<hmr_gpu_enc *> pend_encs;
 	std::vector<size_t> pend_pub, pend_coeff;
 	size_t pend_total = 0;
@@ -800,6 +840,10 @@ struct hmr_gpu_enc {
 	FrameCtx f_pending;                                  // that frame's parameters (e->f moves on with the next set_frame)
 	double acc_pending = 0;
 	hipEvent_t ev_packed = nullptr;                      // its records and levels are in the staging buffer
+	hipEvent_t ev_decided = nullptr;                     // (lead) the batch's SAO decisions are made
+	void *d_sao_jobs = nullptr;                          // (lead) k_sao_decide_batch's job array
+	FrameCtx *d_frames = nullptr, *h_frames = nullptr;   // (lead) the frame parameters of a batch's pictures, on the device and page-locked on the host
+	EncDev *h_devs = nullptr;                            // (lead) their EncDev records, page-locked
 	int *d_pool_state = nullptr;                         // k_encode_pool: per picture of the launch the open step and the steps' ticket / done counters, then the finished-pictures counter
 	WorkSlow *d_pool_slow = nullptr;                     // the pool workers' transform / decoded windows
 	int pool_workers = 0;
@@ -858,16 +902,22 @@ int load_planes(hmr_gpu_enc *e, const uint8_t *y, const uint8_t *u, const uint8_
 
 
 // what a frame's CTU stage needs on the stream before its first launch
-int ctu_stage_prepare(hmr_gpu_enc *e)
+// the reference picture, interpolated once at every sub-sample phase: what motion search and compensation read (k_subpel.hip)
+int reference_planes(hmr_gpu_enc *e, hipStream_t st)
+{
+	const Seq &s = e->seq;
+	if (e->f.slice_type == SLICE_I) return HMR_GPU_OK;
+	return hmr_subpel_planes_on(st, e->d_pic[e->cur ^ 1][0], e->d_pic[e->cur ^ 1][1], e->d_pic[e->cur ^ 1][2], s.stride_y, s.height + 2 * s.margin_y, s.stride_c,
+				    s.height / 2 + 2 * s.margin_c, e->planes.y, e->planes.c[0], e->planes.c[1]);
+}
+int ctu_stage_prepare(hmr_gpu_enc *e, bool planes_elsewhere = false)
 {
 	const Seq &s = e->seq;
 	hipStream_t st = e->ctx->stream;
 	if (!e->lockstep)   // (the frame-start state CTUs are re-encoded from in the single-thread order)
 		HIP_TRY(hipMemcpyAsync(e->d.ctus_start, e->d.ctus, sizeof(CtuInfo) * s.nctu, hipMemcpyDeviceToDevice, st));
-	if (e->f.slice_type != SLICE_I) {
-		// the reference picture, interpolated once at every sub-sample phase: what motion search and compensation read (k_subpel.hip)
-		const int rc = hmr_gpu_subpel_planes(e->ctx, e->d_pic[e->cur ^ 1][0], e->d_pic[e->cur ^ 1][1], e->d_pic[e->cur ^ 1][2], s.stride_y, s.height + 2 * s.margin_y, s.stride_c,
-						     s.height / 2 + 2 * s.margin_c, e->planes.y, e->planes.c[0], e->planes.c[1]);
+	if (!planes_elsewhere) {
+		const int rc = reference_planes(e, st);
 		if (rc) return rc;
 	}
 	{
@@ -980,7 +1030,7 @@ int run_ctu_passes(hmr_gpu_enc *e)
 	return HMR_GPU_OK;
 }
 
-int set_frame(hmr_gpu_enc *e, int slot, int image_type, double avg_dist)
+int set_frame(hmr_gpu_enc *e, int slot, int image_type, double avg_dist, bool upload = true)
 {
 	const Seq &s = e->seq;
 	e->cur ^= 1;
@@ -1007,7 +1057,7 @@ int set_frame(hmr_gpu_enc *e, int slot, int image_type, double avg_dist)
 		e->f.sub_c[0] = e->planes.c[0] + (size_t)s.margin_c * 64 * s.stride_c + s.margin_c;
 		e->f.sub_c[1] = e->planes.c[1] + (size_t)s.margin_c * 64 * s.stride_c + s.margin_c;
 	}
-	HIP_TRY(hipMemcpyAsync(e->d_frame, &e->f, sizeof(FrameCtx), hipMemcpyHostToDevice, e->ctx->stream));
+	if (upload) HIP_TRY(hipMemcpyAsync(e->d_frame, &e->f, sizeof(FrameCtx), hipMemcpyHostToDevice, e->ctx->stream));      // (a batch uploads its frames' parameters in one copy)
 	return HMR_GPU_OK;
 }
 
@@ -1097,6 +1147,7 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 	HIP_TRY(hipEventCreate(&e->ev_batch0));
 	HIP_TRY(hipEventCreate(&e->ev_batch1));
 	HIP_TRY(hipEventCreateWithFlags(&e->ev_packed, hipEventDisableTiming));
+	HIP_TRY(hipEventCreateWithFlags(&e->ev_decided, hipEventDisableTiming));
 	DEV_ALLOC(e->d.coeff, (size_t)6144 * s.nctu);
 	DEV_ALLOC(e->d.progress, s.hctu);
 	DEV_ALLOC(e->d.prefix, (size_t)s.hctu * (s.wctu + 1));
@@ -1223,6 +1274,11 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	if (e->ev_batch0) (void)hipEventDestroy(e->ev_batch0);
 	if (e->ev_batch1) (void)hipEventDestroy(e->ev_batch1);
 	if (e->ev_packed) (void)hipEventDestroy(e->ev_packed);
+	if (e->ev_decided) (void)hipEventDestroy(e->ev_decided);
+	if (e->d_sao_jobs) (void)hipFree(e->d_sao_jobs);
+	if (e->d_frames) (void)hipFree(e->d_frames);
+	if (e->h_frames) (void)hipHostFree(e->h_frames);
+	if (e->h_devs) (void)hipHostFree(e->h_devs);
 	if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
 	if (e->d_gather) (void)hipFree(e->d_gather);
 	if (e->h_gather) (void)hipHostFree(e->h_gather);
@@ -1373,9 +1429,12 @@ extern "C" int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *e, const uint8_t *y, const ui
 // border padding on the device; entropy coding on the host.  The access unit is written to stream.
 namespace {
 // the frame behind its CTU stage: in-loop filters and SAO on the device, side-info and levels to the host, entropy coding, the access unit into `stream`
-// the frame behind its CTU stage, device part: in-loop filters, SAO statistics / decision / offsets, padding - queued on the encoder's stream
-int frame_device_part(hmr_gpu_enc *e, int slot)
+// the frame behind its CTU stage, device part, queued on the encoder's stream: deblocking, SAO statistics and candidate offsets, and the arguments of the SAO decision ...
+int frame_device_before_decision(hmr_gpu_enc *e, int slot, SaoDecideJob *job)
 {
+	job->enabled = 0;
+	job->progress = nullptr;
+	job->pad_ = 0;
 	const Seq &s = e->seq;
 	hipStream_t st = e->ctx->stream;
 	int rc;
@@ -1407,8 +1466,20 @@ int frame_device_part(hmr_gpu_enc *e, int slot)
 		a.W = s.wctu; a.H = s.hctu; a.wpp = s.wpp; a.st_merge = first.ctx[CTX_SAO_MERGE]; a.st_type = first.ctx[CTX_SAO_TYPE];
 		a.entropy_bits = e->d_sao_bits; a.next_lps = e->d_sao_lps; a.params = e->d_params; a.saved = e->d_sao_saved;
 		HIP_TRY(hipMemsetAsync(e->d_sao_progress, 0, sizeof(int) * s.hctu, st));
-		hipLaunchKernelGGL(k_sao_decide, dim3(s.wpp ? s.hctu : 1), dim3(64), 0, st, a, e->d_sao_progress);
-		HIP_TRY(hipGetLastError());
+		job->a = a;
+		job->progress = e->d_sao_progress;
+		job->enabled = 1;
+	}
+	return HMR_GPU_OK;
+}
+// ... and behind the SAO decision: the offsets applied to a copy of the deblocked picture, border padding
+int frame_device_after_decision(hmr_gpu_enc *e)
+{
+	const Seq &s = e->seq;
+	hipStream_t st = e->ctx->stream;
+	int rc;
+	hmr_gpu_frame pic = {s.width, s.height, plane0(e, e->cur, 0), plane0(e, e->cur, 1), plane0(e, e->cur, 2), s.stride_y, s.stride_c};
+	if (s.sao) {
 		for (int c = 0; c < 3; c++) HIP_TRY(hipMemcpyAsync(e->d_pre[c], e->d_pic[e->cur][c], e->pic_elems[c] * 2, hipMemcpyDeviceToDevice, st));
 		const size_t oy = (size_t)s.margin_y * s.stride_y + s.margin_y, oc = (size_t)s.margin_c * s.stride_c + s.margin_c;
 		hmr_gpu_frame pre = {s.width, s.height, e->d_pre[0] + oy, e->d_pre[1] + oc, e->d_pre[2] + oc, s.stride_y, s.stride_c};
@@ -1416,6 +1487,18 @@ int frame_device_part(hmr_gpu_enc *e, int slot)
 	}
 	if ((rc = hmr_gpu_pad_frame(e->ctx, &pic, s.margin_y, s.margin_y))) return rc;
 	return HMR_GPU_OK;
+}
+// one sequence: the three parts in a row
+int frame_device_part(hmr_gpu_enc *e, int slot)
+{
+	SaoDecideJob job;
+	int rc = frame_device_before_decision(e, slot, &job);
+	if (rc) return rc;
+	if (job.enabled) {
+		hipLaunchKernelGGL(k_sao_decide, dim3(e->seq.wpp ? e->seq.hctu : 1), dim3(64), 0, e->ctx->stream, job.a, job.progress);
+		HIP_TRY(hipGetLastError());
+	}
+	return frame_device_after_decision(e);
 }
 // host part: entropy coding of the frame `f` from the downloaded side-info records and levels, the access unit into `stream`
 int frame_entropy_part(hmr_gpu_enc *e, const FrameCtx &f, const uint8_t *h_public, const int16_t *h_coeff, uint8_t *stream, long cap, long *stream_bytes)
@@ -1509,10 +1592,41 @@ __global__ void k_gather_results(const EncDev *devs, uint32_t *out, int pitch)
 	for (int c = threadIdx.x; c < nctu; c += blockDim.x) o[4 + c] = d.ctus[c].distortion;
 }
 
+// The batch's pictures: their EncDev records and frame parameters come from page-locked host memory (read by the kernel itself: a host-to-device copy queued here
+// waited behind the previous step's 2 GB download on the copy engines - rocprofv3 trace, 35 ms), and what ctu_stage_prepare does for one picture is done for all.
+__global__ void k_batch_stage(const EncDev *h_devs, const FrameCtx *h_frames, EncDev *d_devs, FrameCtx *d_frames)
+{
+	const int i = blockIdx.x, t = threadIdx.x;
+	for (int k = t; k < (int)(sizeof(EncDev) / 4); k += blockDim.x) ((uint32_t *)(d_devs + i))[k] = ((const uint32_t *)(h_devs + i))[k];
+	for (int k = t; k < (int)(sizeof(FrameCtx) / 4); k += blockDim.x) ((uint32_t *)(d_frames + i))[k] = ((const uint32_t *)(h_frames + i))[k];
+	const EncDev d = h_devs[i];
+	const int H = d.seq->hctu, W = d.seq->wctu;
+	if (t < 3) d.counters[t] = t == 2 ? -1 : 0;
+	if (t == 3) *d.row0_checked = 0;
+	for (int k = t; k < H; k += blockDim.x) d.progress[k] = 0;
+	for (int k = t; k < H * (W + 1); k += blockDim.x) d.prefix[k] = 0;
+}
+
 struct BatchTimes {
 	std::chrono::steady_clock::time_point t[8];
 	double ms(int a, int b) const { return std::chrono::duration<double, std::milli>(t[b] - t[a]).count(); }
 };
+
+// fn(i) for i in [0, n) on up to `threads` host threads (sequence i goes to thread i mod threads).  A thread per sequence cost more in thread start-up than the
+// few dozen stream calls a sequence needs; a dozen threads keep the runtime's submission path busy just as well.
+template <class F>
+void parallel_for(int n, int threads, F fn)
+{
+	const int T = n < threads ? n : threads;
+	std::vector<std::thread> th;
+	for (int t = 0; t < T; t++)
+		th.emplace_back([=]() {
+			for (int i = t; i < n; i += T) fn(i);
+		});
+	for (auto &x : th) x.join();
+}
+constexpr int QUEUE_THREADS = 16;       // for queueing device work
+constexpr int CODING_THREADS = 256;     // for entropy coding: as many as there are sequences (the host's cores share them)
 
 int batch_check(hmr_gpu_enc **encs, int n, const int *slots, uint8_t **streams, const long *caps, long *stream_bytes)
 {
@@ -1529,23 +1643,40 @@ int batch_check(hmr_gpu_enc **encs, int n, const int *slots, uint8_t **streams, 
 	return HMR_GPU_OK;
 }
 
+int batch_queue_download(hmr_gpu_enc *lead);
+
 // LAUNCH: the frames' CTU stages as one pool launch on the lead encoder's stream, their counters and distortions gathered behind it
 int batch_launch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_types, int *pitch_out)
 {
 	hmr_gpu_enc *lead = encs[0];
 	hipStream_t bst = lead->ctx->stream;
-	std::vector<EncDev> devs(n);
 	int rc, rows_total = 0, max_ctus = 0;
+	// frame set-up on the host; nothing is queued on the sequences' streams: the launch's stream waits for what each of them still has in flight (the filter
+	// chain and packing of its previous frame) and takes the rest - the frames' parameters in one upload, the phase planes, the per-frame state in one kernel
+	if (!lead->d_frames) {
+		HIP_TRY(hipMalloc((void **)&lead->d_frames, 256 * sizeof(FrameCtx)));
+		HIP_TRY(hipHostMalloc((void **)&lead->h_frames, 256 * sizeof(FrameCtx), hipHostMallocDefault));
+		HIP_TRY(hipHostMalloc((void **)&lead->h_devs, 256 * sizeof(EncDev), hipHostMallocDefault));
+	}
 	for (int i = 0; i < n; i++) {
 		hmr_gpu_enc *e = encs[i];
-		HIP_TRY(hipEventRecord(e->ev_frame, e->ctx->stream));
-		if ((rc = set_frame(e, slots[i], image_types ? image_types[i] : 0, -1.0))) return rc;
-		if ((rc = ctu_stage_prepare(e))) return rc;
+		if ((rc = set_frame(e, slots[i], image_types ? image_types[i] : 0, -1.0, false))) return rc;
 		HIP_TRY(hipEventRecord(e->ev_ready, e->ctx->stream));
 		if (i) HIP_TRY(hipStreamWaitEvent(bst, e->ev_ready, 0));
-		devs[i] = e->d;
+		lead->h_frames[i] = e->f;
+		lead->h_devs[i] = e->d;
+		lead->h_devs[i].frame = lead->d_frames + i;
 		rows_total += e->seq.hctu;
 		if (e->seq.nctu > max_ctus) max_ctus = e->seq.nctu;
+	}
+	// The phase planes of all the reference pictures one after the other on the launch's stream: a picture's three kernels fill the GPU (2500 workgroups, 1.9 TB/s);
+	// run side by side on the sequences' streams, sixteen at a time, they reached a quarter of that between them (rocprofv3 trace: 52 ms for 180 pictures).
+	for (int i = 0; i < n; i++)
+		if ((rc = reference_planes(encs[i], bst))) return rc;
+	if (lead->pending && !lead->download_queued) {
+		HIP_TRY(hipEventRecord(lead->ev_decided, bst));
+		HIP_TRY(hipStreamWaitEvent(lead->copy_stream, lead->ev_decided, 0));
+		if ((rc = batch_queue_download(lead))) return rc;
 	}
 	if (!lead->d_batch) {
 		HIP_TRY(hipMalloc((void **)&lead->d_batch, 256 * sizeof(EncDev)));
@@ -1561,7 +1692,8 @@ int batch_launch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_t
 		HIP_TRY(hipHostMalloc((void **)&lead->h_gather, (size_t)pitch * 256 * 4, hipHostMallocDefault));
 		lead->gather_words = (size_t)pitch * 256;
 	}
-	HIP_TRY(hipMemcpyAsync(lead->d_batch, devs.data(), n * sizeof(EncDev), hipMemcpyHostToDevice, bst));
+	hipLaunchKernelGGL(k_batch_stage, dim3(n), dim3(256), 0, bst, (const EncDev *)lead->h_devs, (const FrameCtx *)lead->h_frames, (EncDev *)lead->d_batch, lead->d_frames);
+	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(lead->ev_batch0, bst));
 	if ((rc = launch_pool(lead, n, rows_total, bst))) return rc;
 	(void)hipEventRecord(lead->ev_batch1, bst);
@@ -1573,7 +1705,19 @@ int batch_launch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_t
 }
 
 // FINISH: wait for the launch; frame bookkeeping; every sequence's filter chain, records and levels queued; the download queued behind them
-int batch_finish(hmr_gpu_enc **encs, int n, const int *slots, int pitch, BatchTimes &bt)
+// the outstanding step's records and levels to the host, behind the sequences' packing (and behind whatever the copy stream has been told to wait for).  The
+// download is a copy kernel that holds wavefront slots for 35 ms: queued right behind the filter chains it kept the next step's phase planes from starting
+// (rocprofv3 trace), queued behind them it runs beside the next CTU launch, whose workers are resident before it.
+int batch_queue_download(hmr_gpu_enc *lead)
+{
+	if (!lead->pending || lead->download_queued) return HMR_GPU_OK;
+	for (hmr_gpu_enc *e : lead->pend_encs) HIP_TRY(hipStreamWaitEvent(lead->copy_stream, e->ev_packed, 0));
+	HIP_TRY(hipMemcpyAsync(lead->h_stage, lead->d_stage, lead->pend_total, hipMemcpyDeviceToHost, lead->copy_stream));
+	lead->download_queued = true;
+	return HMR_GPU_OK;
+}
+
+int batch_finish(hmr_gpu_enc **encs, int n, const int *slots, int pitch, BatchTimes &bt, bool defer_download)
 {
 	hmr_gpu_enc *lead = encs[0];
 	hipStream_t bst = lead->ctx->stream;
@@ -1605,13 +1749,24 @@ int batch_finish(hmr_gpu_enc **encs, int n, const int *slots, int pitch, BatchTi
 		HIP_TRY(hipHostMalloc((void **)&lead->h_stage, total, hipHostMallocDefault));
 		lead->stage_bytes = total;
 	}
-	if (!lead->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&lead->copy_stream, hipStreamNonBlocking));
+	if (!lead->copy_stream) {
+		// its own priority class: the download is a copy kernel that lasts 35 ms, and a stream of the default class may share its hardware queue with the stream
+		// the next launch is queued on (seen in the rocprofv3 trace: the next step's phase planes started when the download ended)
+		int least = 0, greatest = 0;
+		HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+		HIP_TRY(hipStreamCreateWithPriority(&lead->copy_stream, hipStreamNonBlocking, least));
+	}
 	std::vector<int> rcs(n, 0);
 	std::vector<std::string> errs(n);       // (the error text is per thread: bring the workers' back to the caller's)
-	{
-		std::vector<std::thread> th;
+	std::vector<SaoDecideJob> jobs(n);
+	auto failed = [&]() {
 		for (int i = 0; i < n; i++)
-			th.emplace_back([&, i]() {
+			if (rcs[i] < 0) { hmr_set_error("hmr_gpu_enc_encode_batch: sequence %d: %s", i, errs[i].c_str()); return rcs[i]; }
+		return 0;
+	};
+	// every sequence on its own stream, a host thread each: deblocking, SAO statistics, candidate offsets ...
+	{
+		parallel_for(n, QUEUE_THREADS, [&](int i) {
 				hmr_gpu_enc *e = encs[i];
 				if (hipSetDevice(e->ctx->device) != hipSuccess) { rcs[i] = HMR_GPU_ERR_HIP; errs[i] = "hipSetDevice failed"; return; }
 				const uint32_t *g = lead->h_gather + (size_t)i * pitch;
@@ -1620,9 +1775,39 @@ int batch_finish(hmr_gpu_enc **encs, int n, const int *slots, int pitch, BatchTi
 				e->f.scene_cut_ctu = (int)g[2];
 				e->last_passes = 1;
 				release_planes(e);
-				int r = frame_device_part(e, slots[i]);
+				int r = frame_device_before_decision(e, slots[i], &jobs[i]);
+				if (!r && hipEventRecord(e->ev_ready, e->ctx->stream) != hipSuccess) r = HMR_GPU_ERR_HIP;
+				rcs[i] = r;
+				if (r < 0) errs[i] = hmr_gpu_last_error();
+			});
+	}
+	if (failed()) return failed();
+	// ... the SAO decisions of all the pictures as ONE launch (k_sao_decide_batch) ...
+	{
+		int max_rows = 1, any = 0;
+		for (int i = 0; i < n; i++) {
+			HIP_TRY(hipStreamWaitEvent(bst, encs[i]->ev_ready, 0));
+			if (jobs[i].enabled) { any = 1; if (jobs[i].a.wpp && jobs[i].a.H > max_rows) max_rows = jobs[i].a.H; }
+		}
+		if (any) {
+			if (!lead->d_sao_jobs) HIP_TRY(hipMalloc((void **)&lead->d_sao_jobs, 256 * sizeof(SaoDecideJob)));
+			HIP_TRY(hipMemcpyAsync(lead->d_sao_jobs, jobs.data(), n * sizeof(SaoDecideJob), hipMemcpyHostToDevice, bst));
+			if (max_rows > 1024) { hmr_set_error("hmr_gpu_enc_encode_batch: more than 1024 CTU rows"); return HMR_GPU_ERR_ARG; }
+			hipLaunchKernelGGL(k_sao_decide_batch, dim3(n), dim3((max_rows + 63) / 64 * 64), 0, bst, (const SaoDecideJob *)lead->d_sao_jobs);
+			HIP_TRY(hipGetLastError());
+		}
+		HIP_TRY(hipEventRecord(lead->ev_decided, bst));
+	}
+	// ... and behind it, per sequence again: SAO offsets, padding, the records and levels into the staging buffer
+	{
+		parallel_for(n, QUEUE_THREADS, [&](int i) {
+				hmr_gpu_enc *e = encs[i];
+				if (hipSetDevice(e->ctx->device) != hipSuccess) { rcs[i] = HMR_GPU_ERR_HIP; errs[i] = "hipSetDevice failed"; return; }
+				const uint32_t *g = lead->h_gather + (size_t)i * pitch;
+				hipStream_t st = e->ctx->stream;
+				int r = hipStreamWaitEvent(st, lead->ev_decided, 0) == hipSuccess ? 0 : HMR_GPU_ERR_HIP;
+				if (!r) r = frame_device_after_decision(e);
 				if (!r) {
-					hipStream_t st = e->ctx->stream;
 					hipLaunchKernelGGL(k_pack_public, dim3(e->seq.nctu), dim3(256), 0, st, e->d.ctus, (uint32_t *)(lead->d_stage + lead->pend_pub[i]));
 					if (hipGetLastError() != hipSuccess ||
 					    hipMemcpyAsync(lead->d_stage + lead->pend_coeff[i], e->d.coeff, (size_t)12288 * e->seq.nctu, hipMemcpyDeviceToDevice, st) != hipSuccess ||
@@ -1638,17 +1823,15 @@ int batch_finish(hmr_gpu_enc **encs, int n, const int *slots, int pitch, BatchTi
 				rcs[i] = r;
 				if (r < 0) errs[i] = hmr_gpu_last_error();
 			});
-		for (auto &t : th) t.join();
 	}
-	for (int i = 0; i < n; i++)
-		if (rcs[i] < 0) { hmr_set_error("hmr_gpu_enc_encode_batch: sequence %d: %s", i, errs[i].c_str()); return rcs[i]; }
+	if (failed()) return failed();
 	bt.t[3] = std::chrono::steady_clock::now();
-	for (int i = 0; i < n; i++) HIP_TRY(hipStreamWaitEvent(lead->copy_stream, encs[i]->ev_packed, 0));
-	HIP_TRY(hipMemcpyAsync(lead->h_stage, lead->d_stage, total, hipMemcpyDeviceToHost, lead->copy_stream));
 	lead->pend_encs.assign(encs, encs + n);
 	lead->pend_total = total;
 	lead->pending = true;
-	return HMR_GPU_OK;
+	lead->download_queued = false;
+	// (the pipelined call queues the download behind the next step's phase planes, batch_launch; everybody else right away)
+	return defer_download ? HMR_GPU_OK : batch_queue_download(lead);
 }
 
 // DELIVER: the outstanding step's access units
@@ -1656,23 +1839,21 @@ int batch_deliver(hmr_gpu_enc *lead, uint8_t **streams, const long *caps, long *
 {
 	const int n = (int)lead->pend_encs.size();
 	bt.t[4] = std::chrono::steady_clock::now();
+	{
+		const int rc = batch_queue_download(lead);      // (a flush: there was no next step to queue it behind)
+		if (rc) return rc;
+	}
 	lead->pending = false;
 	for (int i = 0; i < n; i++) lead->pend_encs[i]->awaiting_delivery = false;
 	HIP_TRY(hipStreamSynchronize(lead->copy_stream));
 	bt.t[5] = std::chrono::steady_clock::now();
 	std::vector<int> rcs(n, 0);
 	std::vector<std::string> errs(n);
-	{
-		std::vector<std::thread> th;
-		for (int i = 0; i < n; i++)
-			th.emplace_back([&, i]() {
-				hmr_gpu_enc *e = lead->pend_encs[i];
-				rcs[i] = frame_entropy_part(e, e->f_pending, lead->h_stage + lead->pend_pub[i], (const int16_t *)(lead->h_stage + lead->pend_coeff[i]), streams[i], caps[i],
-							    &stream_bytes[i]);
-				if (rcs[i] < 0) errs[i] = hmr_gpu_last_error();
-			});
-		for (auto &t : th) t.join();
-	}
+	parallel_for(n, CODING_THREADS, [&](int i) {
+		hmr_gpu_enc *e = lead->pend_encs[i];
+		rcs[i] = frame_entropy_part(e, e->f_pending, lead->h_stage + lead->pend_pub[i], (const int16_t *)(lead->h_stage + lead->pend_coeff[i]), streams[i], caps[i], &stream_bytes[i]);
+		if (rcs[i] < 0) errs[i] = hmr_gpu_last_error();
+	});
 	bt.t[6] = std::chrono::steady_clock::now();
 	for (int i = 0; i < n; i++)
 		if (rcs[i] < 0) { hmr_set_error("hmr_gpu_enc_encode_batch: sequence %d: %s", i, errs[i].c_str()); return rcs[i]; }
@@ -1682,8 +1863,12 @@ int batch_deliver(hmr_gpu_enc *lead, uint8_t **streams, const long *caps, long *
 void batch_report(const BatchTimes &bt, hmr_gpu_enc *lead, bool pipelined)
 {
 	if (!getenv("HENC_BATCH_TIMING")) return;
-	fprintf(stderr, "batch step%s: launch %.1f ms, wait for the pool %.1f, queue device parts %.1f, download wait %.1f (%.0f MB), entropy coding %.1f\n", pipelined ? " (pipelined)" : "",
-		bt.ms(0, 1), pipelined ? bt.ms(6, 2) : bt.ms(1, 2), bt.ms(2, 3), bt.ms(4, 5), lead->pend_total / 1e6, bt.ms(5, 6));
+	static std::chrono::steady_clock::time_point last_end;
+	const auto now = std::chrono::steady_clock::now();
+	fprintf(stderr, "batch step%s: launch %.1f ms, wait for the pool %.1f, queue device parts %.1f, download wait %.1f (%.0f MB), entropy coding %.1f; the call %.1f, since the last call %.1f\n",
+		pipelined ? " (pipelined)" : "", bt.ms(0, 1), pipelined ? bt.ms(6, 2) : bt.ms(1, 2), bt.ms(2, 3), bt.ms(4, 5), lead->pend_total / 1e6, bt.ms(5, 6),
+		std::chrono::duration<double, std::milli>(now - bt.t[0]).count(), std::chrono::duration<double, std::milli>(bt.t[0] - last_end).count());
+	last_end = now;
 }
 }  // namespace
 
@@ -1704,7 +1889,7 @@ extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *sl
 	bt.t[0] = std::chrono::steady_clock::now();
 	if ((rc = batch_launch(encs, n, slots, image_types, &pitch))) return rc;
 	bt.t[1] = std::chrono::steady_clock::now();
-	if ((rc = batch_finish(encs, n, slots, pitch, bt))) return rc;
+	if ((rc = batch_finish(encs, n, slots, pitch, bt, false))) return rc;
 	if ((rc = batch_deliver(lead, streams, caps, stream_bytes, bt))) return rc;
 	batch_report(bt, lead, false);
 	return HMR_GPU_OK;
@@ -1741,7 +1926,7 @@ extern "C" int hmr_gpu_enc_encode_batch_pipelined(hmr_gpu_enc **encs, int n, con
 		for (int i = 0; i < n; i++) stream_bytes[i] = 0;
 		bt.t[6] = bt.t[1];
 	}
-	if (slots && (rc = batch_finish(encs, n, slots, pitch, bt))) return rc;
+	if (slots && (rc = batch_finish(encs, n, slots, pitch, bt, true))) return rc;
 	if (slots) batch_report(bt, lead, true);
 	return HMR_GPU_OK;
 }

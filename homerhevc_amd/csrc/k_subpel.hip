@@ -181,17 +181,23 @@ __global__ __launch_bounds__(256) void k_subpel_chroma(const int16_t *__restrict
 }  // namespace
 
 // device pointers; pic_* = start of the padded allocations (stride x rows elements), out_y = [rows][16][stride], out_u / out_v = [rows][64][stride]
-extern "C" int hmr_gpu_subpel_planes(hmr_gpu_ctx *ctx, const int16_t *pic_y, const int16_t *pic_u, const int16_t *pic_v, int stride_y, int rows_y, int stride_c, int rows_c,
-				     uint8_t *out_y, uint8_t *out_u, uint8_t *out_v)
+int hmr_subpel_planes_on(hipStream_t stream, const int16_t *pic_y, const int16_t *pic_u, const int16_t *pic_v, int stride_y, int rows_y, int stride_c, int rows_c, uint8_t *out_y,
+			 uint8_t *out_u, uint8_t *out_v)
 {
-	if (!ctx || !pic_y || !out_y || (stride_y & 3) || (stride_c & 3) || stride_y <= 0 || rows_y <= 0) return HMR_GPU_ERR_ARG;
+	if (!pic_y || !out_y || (stride_y & 3) || (stride_c & 3) || stride_y <= 0 || rows_y <= 0) return HMR_GPU_ERR_ARG;
 	const int gy = ((stride_y + TW - 1) / TW) * ((rows_y + TH - 1) / TH);
-	hipLaunchKernelGGL(k_subpel_luma, dim3(gy), dim3(256), 0, ctx->stream, pic_y, stride_y, rows_y, out_y);
+	hipLaunchKernelGGL(k_subpel_luma, dim3(gy), dim3(256), 0, stream, pic_y, stride_y, rows_y, out_y);
 	if (pic_u && pic_v && out_u && out_v) {
 		const int gc = ((stride_c + TW - 1) / TW) * ((rows_c + TH - 1) / TH);
-		hipLaunchKernelGGL(k_subpel_chroma, dim3(gc), dim3(256), 0, ctx->stream, pic_u, stride_c, rows_c, out_u);
-		hipLaunchKernelGGL(k_subpel_chroma, dim3(gc), dim3(256), 0, ctx->stream, pic_v, stride_c, rows_c, out_v);
+		hipLaunchKernelGGL(k_subpel_chroma, dim3(gc), dim3(256), 0, stream, pic_u, stride_c, rows_c, out_u);
+		hipLaunchKernelGGL(k_subpel_chroma, dim3(gc), dim3(256), 0, stream, pic_v, stride_c, rows_c, out_v);
 	}
 	HIP_TRY(hipGetLastError());
 	return HMR_GPU_OK;
+}
+extern "C" int hmr_gpu_subpel_planes(hmr_gpu_ctx *ctx, const int16_t *pic_y, const int16_t *pic_u, const int16_t *pic_v, int stride_y, int rows_y, int stride_c, int rows_c,
+				     uint8_t *out_y, uint8_t *out_u, uint8_t *out_v)
+{
+	if (!ctx) return HMR_GPU_ERR_ARG;
+	return hmr_subpel_planes_on(ctx->stream, pic_y, pic_u, pic_v, stride_y, rows_y, stride_c, rows_c, out_y, out_u, out_v);
 }
