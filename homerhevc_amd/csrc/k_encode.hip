@@ -1068,6 +1068,16 @@ void release_planes(hmr_gpu_enc *e)
 	e->planes = PlaneSet();
 }
 
+// the three planes of a picture to their copies in one launch (three device-to-device copies are three copy kernels on the stream)
+__global__ __launch_bounds__(256) void k_copy_planes(const int16_t *s0, const int16_t *s1, const int16_t *s2, int16_t *d0, int16_t *d1, int16_t *d2, size_t n0, size_t n12)
+{
+	const int c = (int)blockIdx.y;
+	const uint4 *s = (const uint4 *)(c == 0 ? s0 : (c == 1 ? s1 : s2));
+	uint4 *d = (uint4 *)(c == 0 ? d0 : (c == 1 ? d1 : d2));
+	const size_t n = (c == 0 ? n0 : n12) / 8;      // eight samples per thread and step (the planes' sizes are multiples of eight)
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
 // the side-info records lie 68 KB apart inside the CTU records: packed on the device, then one linear copy to the host
 __global__ void k_pack_public(const CtuInfo *ctus, uint32_t *out)
 {
@@ -1465,7 +1475,6 @@ int frame_device_before_decision(hmr_gpu_enc *e, int slot, SaoDecideJob *job)
 		a.ctus = e->d.ctus; a.stats = e->d_stats; a.offsets = e->d_sao_offsets; a.aux = e->d_sao_aux; a.dist = e->d_sao_dist;
 		a.W = s.wctu; a.H = s.hctu; a.wpp = s.wpp; a.st_merge = first.ctx[CTX_SAO_MERGE]; a.st_type = first.ctx[CTX_SAO_TYPE];
 		a.entropy_bits = e->d_sao_bits; a.next_lps = e->d_sao_lps; a.params = e->d_params; a.saved = e->d_sao_saved;
-		HIP_TRY(hipMemsetAsync(e->d_sao_progress, 0, sizeof(int) * s.hctu, st));
 		job->a = a;
 		job->progress = e->d_sao_progress;
 		job->enabled = 1;
@@ -1480,7 +1489,13 @@ int frame_device_after_decision(hmr_gpu_enc *e)
 	int rc;
 	hmr_gpu_frame pic = {s.width, s.height, plane0(e, e->cur, 0), plane0(e, e->cur, 1), plane0(e, e->cur, 2), s.stride_y, s.stride_c};
 	if (s.sao) {
-		for (int c = 0; c < 3; c++) HIP_TRY(hipMemcpyAsync(e->d_pre[c], e->d_pic[e->cur][c], e->pic_elems[c] * 2, hipMemcpyDeviceToDevice, st));
+		if ((e->pic_elems[0] | e->pic_elems[1]) % 8 == 0 && e->pic_elems[1] == e->pic_elems[2]) {
+			hipLaunchKernelGGL(k_copy_planes, dim3(512, 3), dim3(256), 0, st, e->d_pic[e->cur][0], e->d_pic[e->cur][1], e->d_pic[e->cur][2], e->d_pre[0], e->d_pre[1], e->d_pre[2],
+					   e->pic_elems[0], e->pic_elems[1]);
+			HIP_TRY(hipGetLastError());
+		} else {
+			for (int c = 0; c < 3; c++) HIP_TRY(hipMemcpyAsync(e->d_pre[c], e->d_pic[e->cur][c], e->pic_elems[c] * 2, hipMemcpyDeviceToDevice, st));
+		}
 		const size_t oy = (size_t)s.margin_y * s.stride_y + s.margin_y, oc = (size_t)s.margin_c * s.stride_c + s.margin_c;
 		hmr_gpu_frame pre = {s.width, s.height, e->d_pre[0] + oy, e->d_pre[1] + oc, e->d_pre[2] + oc, s.stride_y, s.stride_c};
 		if ((rc = hmr_gpu_sao_apply_frame(e->ctx, &pre, &pic, e->d_params))) return rc;
@@ -1495,6 +1510,7 @@ int frame_device_part(hmr_gpu_enc *e, int slot)
 	int rc = frame_device_before_decision(e, slot, &job);
 	if (rc) return rc;
 	if (job.enabled) {
+		HIP_TRY(hipMemsetAsync(e->d_sao_progress, 0, sizeof(int) * e->seq.hctu, e->ctx->stream));
 		hipLaunchKernelGGL(k_sao_decide, dim3(e->seq.wpp ? e->seq.hctu : 1), dim3(64), 0, e->ctx->stream, job.a, job.progress);
 		HIP_TRY(hipGetLastError());
 	}

@@ -505,16 +505,26 @@ extern "C" int hmr_gpu_sao_apply_ctu(hmr_gpu_ctx *ctx, const hmr_gpu_frame *src,
 	return HMR_GPU_OK;
 }
 
+// the three planes of a 4:2:0 picture in one launch (blockIdx.y = plane; the grid is the luma plane's)
+__global__ __launch_bounds__(HMR_BLOCK) void k_pad420(int16_t *y, int16_t *u, int16_t *v, int stride_y, int stride_c, int width, int height, int pad_x, int pad_y)
+{
+	const int c = (int)blockIdx.y;
+	int16_t *pic = c == 0 ? y : (c == 1 ? u : v);
+	const int stride = c ? stride_c : stride_y, w = c ? width / 2 : width, h = c ? height / 2 : height, px = c ? pad_x / 2 : pad_x, py = c ? pad_y / 2 : pad_y;
+	const int pw = w + 2 * px;
+	const long i = (long)blockIdx.x * HMR_BLOCK + threadIdx.x;
+	if (i >= (long)pw * (h + 2 * py)) return;
+	const int yy = (int)(i / pw) - py, xx = (int)(i % pw) - px;
+	if (xx >= 0 && xx < w && yy >= 0 && yy < h) return;
+	pic[(ptrdiff_t)yy * stride + xx] = pic[(ptrdiff_t)clip3i(yy, 0, h - 1) * stride + clip3i(xx, 0, w - 1)];
+}
+
 extern "C" int hmr_gpu_pad_frame(hmr_gpu_ctx *ctx, const hmr_gpu_frame *f, int pad_x, int pad_y)
 {
 	if (!f) return HMR_GPU_ERR_ARG;
-	int16_t *pl[3] = {f->y, f->u, f->v};
-	for (int c = 0; c < 3; c++) {
-		const int w = c ? f->width / 2 : f->width, h = c ? f->height / 2 : f->height, px = c ? pad_x / 2 : pad_x, py = c ? pad_y / 2 : pad_y;
-		const long n = (long)(w + 2 * px) * (h + 2 * py);
-		hipLaunchKernelGGL(k_pad, dim3((unsigned)((n + HMR_BLOCK - 1) / HMR_BLOCK)), dim3(HMR_BLOCK), 0, ctx->stream, pl[c], c ? f->stride_c : f->stride_y, w, h,
-				   px, py);
-	}
+	const long n = (long)(f->width + 2 * pad_x) * (f->height + 2 * pad_y);
+	hipLaunchKernelGGL(k_pad420, dim3((unsigned)((n + HMR_BLOCK - 1) / HMR_BLOCK), 3), dim3(HMR_BLOCK), 0, ctx->stream, f->y, f->u, f->v, f->stride_y, f->stride_c, f->width, f->height,
+			   pad_x, pad_y);
 	HIP_TRY(hipGetLastError());
 	return HMR_GPU_OK;
 }
