@@ -514,6 +514,12 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
                          "valu_issue_peak_per_s": 614.4e9, "valu_issue_frac": round(valu_per_frame * fps_kernel / 614.4e9, 4),
                          "wait_share_of_wave_cycles": k["derived"].get("wait_share_of_wave_cycles"), "issue_share_of_wave_cycles": k["derived"].get("issue_share_of_wave_cycles"),
                          "wavefronts_per_simd": round(3 * 2 / 4, 2), "workgroups_per_cu": 2,
+                         # a wavefront issues one instruction per four cycles whatever its kind (SQ_ACTIVE_INST_x / SQ_INSTS_x = 1.0 quad-cycles in the counter passes): all
+                         # the kernel's wave-instructions x 4 cycles against the cycles its 512 workers had - an upper bound of the workers' issue share (the helpers'
+                         # instructions, mailbox polling included, are in the count)
+                         "wave_instructions_per_frame": int(sum(k.get(c, 0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_FLAT", "SQ_INSTS_SMEM")) / frames_profiled),
+                         "issue_cycles_over_worker_cycles": round(4 * sum(k.get(c, 0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_FLAT", "SQ_INSTS_SMEM")) / frames_profiled
+                                                                  / (512 * 2.4e9 / fps_kernel), 3),
                          "source": "profiles/r03_pmc_kernels.json (rocprofv3 --pmc passes of this command), instruction counts per encoded frame x this run's frames/s of the kernel"}
         digest = md5.hexdigest()
         matches, checked = check_against_reference(workload, cumulative)
