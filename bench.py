@@ -343,12 +343,12 @@ def main():
             other = run_workload(lib, a, "cfg2-1080p-encode-single-thread-order", world, rank, local, torch)
             out["single_thread_order"] = {k: other[k] for k in ("value", "unit", "ms_per_step", "stream_md5", "stream_matches_reference", "frames_checked_against_reference", "schedule")}
             out["single_thread_order"]["note"] = "the same encode with wfpp_num_threads = 1: output identical to the reference's single-thread run (md5 2f0c3447...), which costs guesses, verification and re-encode passes"
-            # the metric's other picture size: 2160p, 34 CTU rows on the reference's maximum of 32 WPP threads, I + P + P (the two P frames timed):
-            # a batch of 42 sequences (7 groups of 34 row workers, six sequences each) and one sequence alone
+            # the metric's other picture size: 2160p, 34 CTU rows on the reference's maximum of 32 WPP threads, I + P and four timed P frames:
+            # a batch of 64 sequences (2176 CTU rows for the 512 workers of the pool) and one sequence alone
             import copy
             b = copy.copy(a)
-            b.warmup, b.steps = 1, 2
-            big = run_workload(lib, b, "cfg2-2160p-encode", world, rank, local, torch, sequences=42 if a.sequences > 1 else 1)
+            b.warmup, b.steps = 2, 4
+            big = run_workload(lib, b, "cfg2-2160p-encode", world, rank, local, torch, sequences=64 if a.sequences > 1 else 1)
             out["at_2160p"] = {k: big[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "stream_md5", "stream_matches_reference", "frames_checked_against_reference", "all_streams_identical")}
             out["at_2160p"]["config"] = big["config"]
             if a.sequences > 1:
