@@ -33,6 +33,32 @@ __device__ __forceinline__ uint32_t clip255(int v)
 	return (uint32_t)v & 255u;
 }
 
+// Workgroups go to the eight XCDs in turn (blockIdx mod 8), each with an L2 of its own.  A tile row is 64 bytes of a plane row, half a 128-byte line: with
+// neighbouring tiles on different XCDs every line leaves two L2s half written.  This gives XCD k the k-th eighth of the tiles instead, so that the tiles that share
+// lines (and the rows of the picture that neighbouring tiles both read) meet in one L2.  The grid is rounded up to a multiple of eight; -1: no tile.
+__device__ __forceinline__ int xcd_contiguous(unsigned block, unsigned blocks)
+{
+	const unsigned per_xcd = blocks / 8, tile = (block % 8) * per_xcd + block / 8;
+	return (int)tile;
+}
+
+typedef short short2_t __attribute__((ext_vector_type(2)));
+// four results (each inside the 16-bit range) clipped to 0..255 and packed into a dword: two v_perm_b32 to pair them up as 16-bit halves, a packed max and a packed
+// min per pair, one v_perm_b32 to pick the four low bytes - 7 instructions instead of a median, a mask, a shift and an or per byte
+__device__ __forceinline__ uint32_t pack4_clip(int r0, int r1, int r2, int r3)
+{
+	const short2_t lo = {0, 0}, hi = {255, 255};
+	uint32_t a = __builtin_amdgcn_perm((uint32_t)r1, (uint32_t)r0, 0x05040100u), b = __builtin_amdgcn_perm((uint32_t)r3, (uint32_t)r2, 0x05040100u);
+	short2_t va, vb;
+	__builtin_memcpy(&va, &a, 4);
+	__builtin_memcpy(&vb, &b, 4);
+	va = __builtin_elementwise_min(__builtin_elementwise_max(va, lo), hi);
+	vb = __builtin_elementwise_min(__builtin_elementwise_max(vb, lo), hi);
+	__builtin_memcpy(&a, &va, 4);
+	__builtin_memcpy(&b, &vb, 4);
+	return __builtin_amdgcn_perm(b, a, 0x06040200u);
+}
+
 typedef short short4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ short4_t lds4(const int16_t *p) { return *(const short4_t *)p; }      // four samples with one 8-byte LDS read (p 8-byte aligned)
 
@@ -45,7 +71,9 @@ __global__ __launch_bounds__(256) void k_subpel_luma(const int16_t *__restrict__
 	__shared__ __attribute__((aligned(16))) int16_t in[TH + 7][TW + 8];          // rows y0-3 .. y0+TH+3, columns x0-4 .. x0+TW+3
 	__shared__ __attribute__((aligned(16))) int16_t hs[3][TH + 7][TW];           // horizontal stage (sum - 8192) for fx = 1, 2, 3
 	const int tiles_x = (stride + TW - 1) / TW;
-	const int x0 = (int)(blockIdx.x % tiles_x) * TW, y0 = (int)(blockIdx.x / tiles_x) * TH;
+	const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
+	const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
+	if (y0 >= rows) return;
 	const long elems = (long)stride * rows;
 	const int t = (int)threadIdx.x;
 	for (int i = t; i < (TH + 7) * (TW + 8); i += 256) {
@@ -78,30 +106,32 @@ __global__ __launch_bounds__(256) void k_subpel_luma(const int16_t *__restrict__
 	const int y = y0 + ty, x = x0 + tx;
 	if (y >= rows || x >= stride) return;
 	uint32_t pk[16];
-#pragma unroll
-	for (int f = 0; f < 16; f++) pk[f] = 0;
 	short4_t v0[8], v1[8], v2[8], v3[8];
 #pragma unroll
 	for (int k = 0; k < 8; k++) { v0[k] = lds4(&in[ty + k][tx + 4]); v1[k] = lds4(&hs[0][ty + k][tx]); v2[k] = lds4(&hs[1][ty + k][tx]); v3[k] = lds4(&hs[2][ty + k][tx]); }
+	// fy = 0: the integer sample and the three horizontal phases (single stage: (sum + 32) >> 6)
+	pk[0] = pack4_clip(v0[3][0], v0[3][1], v0[3][2], v0[3][3]);
+	pk[1] = pack4_clip((v1[3][0] + 8192 + 32) >> 6, (v1[3][1] + 8192 + 32) >> 6, (v1[3][2] + 8192 + 32) >> 6, (v1[3][3] + 8192 + 32) >> 6);
+	pk[2] = pack4_clip((v2[3][0] + 8192 + 32) >> 6, (v2[3][1] + 8192 + 32) >> 6, (v2[3][2] + 8192 + 32) >> 6, (v2[3][3] + 8192 + 32) >> 6);
+	pk[3] = pack4_clip((v3[3][0] + 8192 + 32) >> 6, (v3[3][1] + 8192 + 32) >> 6, (v3[3][2] + 8192 + 32) >> 6, (v3[3][3] + 8192 + 32) >> 6);
+	// fy = 1..3: vertical filter over the integer column (single stage) and over the horizontal intermediates (second stage: >> 12; its results lie within
+	// -168 .. 434, so the reference's saturation to 16 bits never acts and the clip to 8 bits is all there is)
 #pragma unroll
-	for (int j = 0; j < 4; j++) {
-		// fy = 0: the integer sample and the three horizontal phases (single stage: (sum + 32) >> 6)
-		pk[0] |= clip255(v0[3][j]) << (8 * j);
-		pk[1] |= clip255((v1[3][j] + 8192 + 32) >> 6) << (8 * j);
-		pk[2] |= clip255((v2[3][j] + 8192 + 32) >> 6) << (8 * j);
-		pk[3] |= clip255((v3[3][j] + 8192 + 32) >> 6) << (8 * j);
-		// fy = 1..3: vertical filter over the integer column (single stage) and over the horizontal intermediates (second stage: >> 12)
+	for (int fy = 1; fy < 4; fy++) {
+		const int *cf = fy == 1 ? c1 : (fy == 2 ? c2 : c3);
+		int r[4][4];
 #pragma unroll
-		for (int fy = 1; fy < 4; fy++) {
-			const int *cf = fy == 1 ? c1 : (fy == 2 ? c2 : c3);
+		for (int j = 0; j < 4; j++) {
 			int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
 			for (int k = 0; k < 8; k++) { s0 += v0[k][j] * cf[k]; s1 += v1[k][j] * cf[k]; s2 += v2[k][j] * cf[k]; s3 += v3[k][j] * cf[k]; }
-			pk[fy * 4 + 0] |= clip255((s0 + 32) >> 6) << (8 * j);
-			pk[fy * 4 + 1] |= clip255(sat16i((s1 + 2048 + (8192 << 6)) >> 12)) << (8 * j);
-			pk[fy * 4 + 2] |= clip255(sat16i((s2 + 2048 + (8192 << 6)) >> 12)) << (8 * j);
-			pk[fy * 4 + 3] |= clip255(sat16i((s3 + 2048 + (8192 << 6)) >> 12)) << (8 * j);
+			r[0][j] = (s0 + 32) >> 6;
+			r[1][j] = (s1 + 2048 + (8192 << 6)) >> 12;
+			r[2][j] = (s2 + 2048 + (8192 << 6)) >> 12;
+			r[3][j] = (s3 + 2048 + (8192 << 6)) >> 12;
 		}
+#pragma unroll
+		for (int fx = 0; fx < 4; fx++) pk[fy * 4 + fx] = pack4_clip(r[fx][0], r[fx][1], r[fx][2], r[fx][3]);
 	}
 	uint8_t *o = out + ((size_t)y * 16 * stride + x);      // row y of phase f starts at (y * 16 + f) * stride: the phases of a row lie side by side
 #pragma unroll
@@ -114,7 +144,9 @@ __global__ __launch_bounds__(256) void k_subpel_chroma(const int16_t *__restrict
 	__shared__ __attribute__((aligned(16))) int16_t in[TH + 3][TW + 8];          // rows y0-1 .. y0+TH+1, columns x0-4 .. x0+TW+3
 	__shared__ __attribute__((aligned(16))) int16_t hs[7][TH + 3][TW];           // horizontal stage (sum - 8192) for fx = 1 .. 7
 	const int tiles_x = (stride + TW - 1) / TW;
-	const int x0 = (int)(blockIdx.x % tiles_x) * TW, y0 = (int)(blockIdx.x / tiles_x) * TH;
+	const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
+	const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
+	if (y0 >= rows) return;
 	const long elems = (long)stride * rows;
 	const int t = (int)threadIdx.x;
 	for (int i = t; i < (TH + 3) * (TW + 8); i += 256) {
@@ -148,15 +180,11 @@ __global__ __launch_bounds__(256) void k_subpel_chroma(const int16_t *__restrict
 	{
 		uint32_t pk[8];
 #pragma unroll
-		for (int f = 0; f < 8; f++) pk[f] = 0;
-#pragma unroll
 		for (int fx = 1; fx < 8; fx++) {
 			const short4_t h = lds4(&hs[fx - 1][ty + 1][tx]);
-#pragma unroll
-			for (int j = 0; j < 4; j++) pk[fx] |= clip255((h[j] + 8192 + 32) >> 6) << (8 * j);
+			pk[fx] = pack4_clip((h[0] + 8192 + 32) >> 6, (h[1] + 8192 + 32) >> 6, (h[2] + 8192 + 32) >> 6, (h[3] + 8192 + 32) >> 6);
 		}
-#pragma unroll
-		for (int j = 0; j < 4; j++) pk[0] |= clip255(in4[1][j]) << (8 * j);
+		pk[0] = pack4_clip(in4[1][0], in4[1][1], in4[1][2], in4[1][3]);
 #pragma unroll
 		for (int f = 0; f < 8; f++) *(uint32_t *)(o + (size_t)f * stride) = pk[f];
 	}
@@ -167,13 +195,13 @@ __global__ __launch_bounds__(256) void k_subpel_chroma(const int16_t *__restrict
 		for (int k = 0; k < 4; k++) h[k] = fx ? lds4(&hs[fx - 1][ty + k][tx]) : in4[k];
 #pragma unroll
 		for (int fy = 1; fy < 8; fy++) {
-			uint32_t pk = 0;
+			int r[4];
 #pragma unroll
 			for (int j = 0; j < 4; j++) {
 				const int sum = h[0][j] * cf[fy][0] + h[1][j] * cf[fy][1] + h[2][j] * cf[fy][2] + h[3][j] * cf[fy][3];
-				pk |= (fx ? clip255(sat16i((sum + 2048 + (8192 << 6)) >> 12)) : clip255((sum + 32) >> 6)) << (8 * j);
+				r[j] = fx ? (sum + 2048 + (8192 << 6)) >> 12 : (sum + 32) >> 6;      // (second stage: within -130 .. 390, the saturation to 16 bits never acts)
 			}
-			*(uint32_t *)(o + (size_t)(fy * 8 + fx) * stride) = pk;
+			*(uint32_t *)(o + (size_t)(fy * 8 + fx) * stride) = pack4_clip(r[0], r[1], r[2], r[3]);
 		}
 	}
 }
@@ -185,10 +213,10 @@ int hmr_subpel_planes_on(hipStream_t stream, const int16_t *pic_y, const int16_t
 			 uint8_t *out_u, uint8_t *out_v)
 {
 	if (!pic_y || !out_y || (stride_y & 3) || (stride_c & 3) || stride_y <= 0 || rows_y <= 0) return HMR_GPU_ERR_ARG;
-	const int gy = ((stride_y + TW - 1) / TW) * ((rows_y + TH - 1) / TH);
+	const int gy = (((stride_y + TW - 1) / TW) * ((rows_y + TH - 1) / TH) + 7) / 8 * 8;      // (a multiple of eight: xcd_contiguous)
 	hipLaunchKernelGGL(k_subpel_luma, dim3(gy), dim3(256), 0, stream, pic_y, stride_y, rows_y, out_y);
 	if (pic_u && pic_v && out_u && out_v) {
-		const int gc = ((stride_c + TW - 1) / TW) * ((rows_c + TH - 1) / TH);
+		const int gc = (((stride_c + TW - 1) / TW) * ((rows_c + TH - 1) / TH) + 7) / 8 * 8;
 		hipLaunchKernelGGL(k_subpel_chroma, dim3(gc), dim3(256), 0, stream, pic_u, stride_c, rows_c, out_u);
 		hipLaunchKernelGGL(k_subpel_chroma, dim3(gc), dim3(256), 0, stream, pic_v, stride_c, rows_c, out_v);
 	}
