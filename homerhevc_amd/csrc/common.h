@@ -24,11 +24,12 @@ struct hmr_gpu_ctx {
 	// staging for the host-pointer (drop-in) entries
 	uint8_t *h_stage;               // pinned
 	uint8_t *d_stage;
-	size_t stage_bytes;
+	size_t stage_bytes;             // (h_stage / d_stage: allocated by hmr_ctx_need_stage when a drop-in entry first runs)
 	int num_cus;
 };
 
 void hmr_set_error(const char *fmt, ...);
+int hmr_ctx_need_stage(hmr_gpu_ctx *c);      // context.cpp: the drop-in layer's staging buffers, on first use
 const DevTables *hmr_host_tables();      // host copy (tables.cpp)
 
 #define HIP_TRY(expr)                                                                          \

@@ -24,8 +24,16 @@ static int ctx_init(hmr_gpu_ctx *c, void *stream)
 	HIP_TRY(hipMalloc((void **)&c->tables, sizeof(DevTables)));
 	HIP_TRY(hipMemcpy(c->tables, hmr_host_tables(), sizeof(DevTables), hipMemcpyHostToDevice));
 	c->stage_bytes = 64u << 20;   // largest drop-in operand: a whole 2160p picture going through sse_copy_8_16 (8 MB in, 17 MB out)
-	HIP_TRY(hipHostMalloc((void **)&c->h_stage, c->stage_bytes, hipHostMallocDefault));
-	HIP_TRY(hipMalloc((void **)&c->d_stage, c->stage_bytes));
+	return HMR_GPU_OK;
+}
+
+// The staging buffers of the drop-in layer, allocated when a drop-in entry first needs them: a frame encoder has a context per sequence (its stream), and an engine
+// ring keeps hundreds of them per GPU - 64 MB of page-locked host memory and of HBM each would be most of the host's memory for nothing.
+int hmr_ctx_need_stage(hmr_gpu_ctx *c)
+{
+	if (c->h_stage && c->d_stage) return HMR_GPU_OK;
+	if (!c->h_stage) HIP_TRY(hipHostMalloc((void **)&c->h_stage, c->stage_bytes, hipHostMallocDefault));
+	if (!c->d_stage) HIP_TRY(hipMalloc((void **)&c->d_stage, c->stage_bytes));
 	return HMR_GPU_OK;
 }
 

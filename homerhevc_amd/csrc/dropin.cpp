@@ -23,6 +23,10 @@ struct Stager {
 	{
 		// the reference's WPP / engine threads have device 0 current; the context may live on another GPU (one engine per GPU)
 		(void)hipSetDevice(c->device);
+		if (hmr_ctx_need_stage(c) != HMR_GPU_OK) {
+			fprintf(stderr, "homer_gpu: no memory for the drop-in staging buffers: %s\n", hmr_gpu_last_error());
+			abort();      // (the table's entries have no error channel)
+		}
 		in_end = align(sizeof(hmr_gpu_job));
 	}
 	static size_t align(size_t v) { return (v + 63) & ~(size_t)63; }

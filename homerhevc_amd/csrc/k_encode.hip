@@ -1149,7 +1149,7 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 			HIP_TRY(hipMemcpy(e->d_ctus_eng[k], init.data(), sizeof(CtuInfo) * s.nctu, hipMemcpyHostToDevice));
 		}
 	}
-	DEV_ALLOC(e->d.work_slow, s.hctu);
+	if (e->cfg.wfpp_num_threads <= 1) DEV_ALLOC(e->d.work_slow, s.hctu);      // (the pool has its workers' windows: lead->d_pool_slow)
 	HIP_TRY(hipFuncSetAttribute((const void *)k_encode_ctus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
 	HIP_TRY(hipFuncSetAttribute((const void *)k_encode_pool, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipEventCreate(&e->ev_frame));
