@@ -45,6 +45,8 @@ class EngineRing:
         per_step = (n_sequences + world - 1) // world
         self.send_buf = adapter.new_buffer(per_step)
         self.recv_buf = adapter.new_buffer(per_step)
+        self.outstanding = {}       # late-delivering adapters: (sequences of a call) -> the frame whose access units the next call with them returns
+        self.delivered = None
 
     def sequences_at(self, frame, rank=None):
         r = self.rank if rank is None else rank
@@ -58,12 +60,23 @@ class EngineRing:
                     self.a.load_source(h, t, planes)
 
     def step(self, frame, last=False):
-        """encode frame `frame` of this rank's sequences; returns {sequence: access unit}.  Unless `last`, the reconstructions go round the ring afterwards."""
+        """encode frame `frame` of this rank's sequences; returns {sequence: access unit}.  Unless `last`, the reconstructions go round the ring afterwards.
+        An adapter that delivers late (`GpuEngines(pipelined=True)`: a call returns the access units of the same sequences' previous call, `world` frames earlier,
+        whose download and entropy coding ran under this call's CTU launch) makes this {sequence: unit of frame - world} ({} for the first `world` frames); `delivered`
+        says which frame the units belong to, `flush()` fetches what is outstanding."""
         mine = self.sequences_at(frame)
         if frame > 0 and self.world > 1:
             for i, s in enumerate(mine):
                 self.a.import_(self.enc[s], self.recv_buf[i])
         aus = self.a.encode([self.enc[s] for s in mine], frame)
+        if getattr(self.a, "pipelined", False):
+            key = tuple(mine)
+            self.delivered = self.outstanding.get(key)
+            self.outstanding[key] = frame
+            if self.delivered is None:
+                aus = []
+        else:
+            self.delivered = frame
         if not last and self.world > 1:
             for i, s in enumerate(mine):
                 self.a.export(self.enc[s], self.send_buf[i])
@@ -79,18 +92,28 @@ class EngineRing:
                 r.wait()
         return dict(zip(mine, aus))
 
+    def flush(self):
+        """late-delivering adapters: [(frame, {sequence: access unit})] for everything outstanding"""
+        out = []
+        for key, frame in sorted(self.outstanding.items(), key=lambda kv: kv[1]):
+            aus = self.a.encode([self.enc[s] for s in key], None)
+            out.append((frame, dict(zip(key, aus))))
+        self.outstanding = {}
+        return out
+
 
 class GpuEngines:
     """adapter over libhomer_gpu.so (no fallback: without the HIP library there is nothing to run)"""
 
-    def __init__(self, cfg_of, device):
+    def __init__(self, cfg_of, device, pipelined=False):
         self.lib = C.CDLL(os.path.join(ROOT, "homerhevc_amd", "libhomer_gpu.so"))
-        self.cfg_of, self.device = cfg_of, device
+        self.cfg_of, self.device, self.pipelined = cfg_of, device, pipelined
         lib = self.lib
         lib.hmr_gpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
         lib.hmr_gpu_enc_create_engine.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         lib.hmr_gpu_enc_load_source.argtypes = [C.c_void_p, C.c_int] + [C.c_char_p] * 3
         lib.hmr_gpu_enc_encode_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        lib.hmr_gpu_enc_encode_batch_pipelined.argtypes = lib.hmr_gpu_enc_encode_batch.argtypes
         lib.hmr_gpu_enc_reference_elems.restype = C.c_long
         lib.hmr_gpu_enc_reference_elems.argtypes = [C.c_void_p, C.c_int]
         lib.hmr_gpu_enc_export_reference.argtypes = [C.c_void_p] * 5
@@ -131,11 +154,12 @@ class GpuEngines:
         if n == 0:
             return []
         e_arr = (C.c_void_p * n)(*handles)
-        slots = (C.c_int * n)(*[self.slots[h.value][frame] for h in handles])
+        slots = None if frame is None else (C.c_int * n)(*[self.slots[h.value][frame] for h in handles])      # (None: a pipelined flush)
         ptrs = (C.c_char_p * n)(*[C.cast(self.bufs[h.value], C.c_char_p) for h in handles])
         caps = (C.c_long * n)(*[len(self.bufs[h.value]) for h in handles])
         got = (C.c_long * n)()
-        assert self.lib.hmr_gpu_enc_encode_batch(e_arr, n, slots, None, ptrs, caps, got) == 0, self.lib.hmr_gpu_last_error()
+        call = self.lib.hmr_gpu_enc_encode_batch_pipelined if self.pipelined else self.lib.hmr_gpu_enc_encode_batch
+        assert call(e_arr, n, slots, None, ptrs, caps, got) == 0, self.lib.hmr_gpu_last_error()
         return [C.string_at(self.bufs[h.value], got[i]) for i, h in enumerate(handles)]
 
     def _split(self, row):
