@@ -60,6 +60,7 @@ struct Enc {
 	int16_t *coeff;        // the CTU's coefficient output: 4096 luma + 2 x 1024 chroma, linear per TU in z-order
 	// speculative inputs of a P-frame CTU (enc_ctu.h)
 	uint32_t total_intra_partitions, total_partitions;
+	uint32_t nb_ctus;         // which neighbour CTUs exist (bit 0 left, 1 top, 2 top right, 3 top left): CtuPublic::has_*, kept here because the record lives in HBM
 	unsigned long long *timeline;   // profiling build: the CTU's timestamps
 	int n_spec_reads, n_ratio_cmp, last_slog;
 	FastPtr<Node> nodes;      // the CTU's partition nodes: ctu->nodes, or the worker's fast copy of them (nodes_fast != nullptr) while the CTU is encoded
@@ -139,10 +140,10 @@ HENC_INLINE int node_at(const Enc &__restrict__ e, int depth, int position) { re
 
 // ---- neighbour partitions (hmr_arithmetic_encoding.c:229-355).  Return the CTU that holds the neighbour (nullptr when not
 // available) and its z-order unit index. -------------------------------------------------------------------------------
-HENC_INLINE CtuPublic *ctu_left_of(Enc &__restrict__ e) { return e.ctu->has_left ? e.ctu_g - 1 : nullptr; }
-HENC_INLINE CtuPublic *ctu_top_of(Enc &__restrict__ e) { return e.ctu->has_top ? e.ctu_g - e.seq->wctu : nullptr; }
-HENC_INLINE CtuPublic *ctu_top_right_of(Enc &__restrict__ e) { return e.ctu->has_top_right ? e.ctu_g - e.seq->wctu + 1 : nullptr; }
-HENC_INLINE CtuPublic *ctu_top_left_of(Enc &__restrict__ e) { return e.ctu->has_top_left ? e.ctu_g - e.seq->wctu - 1 : nullptr; }
+HENC_INLINE CtuPublic *ctu_left_of(Enc &__restrict__ e) { return (e.nb_ctus & 1) ? e.ctu_g - 1 : nullptr; }
+HENC_INLINE CtuPublic *ctu_top_of(Enc &__restrict__ e) { return (e.nb_ctus & 2) ? e.ctu_g - e.seq->wctu : nullptr; }
+HENC_INLINE CtuPublic *ctu_top_right_of(Enc &__restrict__ e) { return (e.nb_ctus & 4) ? e.ctu_g - e.seq->wctu + 1 : nullptr; }
+HENC_INLINE CtuPublic *ctu_top_left_of(Enc &__restrict__ e) { return (e.nb_ctus & 8) ? e.ctu_g - e.seq->wctu - 1 : nullptr; }
 
 HENC_INLINE CtuPublic *pu_left(Enc &__restrict__ e, int ni, uint32_t *idx)
 {

@@ -648,6 +648,7 @@ HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 	c.has_top = cy > 0;
 	c.has_top_left = cx > 0 && cy > 0;
 	c.has_top_right = cy > 0 && cx != S.wctu - 1;
+	e.nb_ctus = (uint32_t)((cx > 0) | ((cy > 0) << 1) | ((cy > 0 && cx != S.wctu - 1) << 2) | ((cx > 0 && cy > 0) << 3));
 	e.n_spec_reads = e.n_ratio_cmp = 0;
 	// the worker's mode buffers start as "inherited" everywhere (see read_mode_buff, enc_intra.h)
 	for (int i = g.tid; i < 2 * NDEPTH * NPART; i += g.n) (&w.intra_mode_buffs[0][0][0])[i] = (uint8_t)(MODE_TOKEN | ((i / NPART) % NDEPTH));
