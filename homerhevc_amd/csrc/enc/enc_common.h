@@ -60,6 +60,8 @@ struct Enc {
 	int16_t *coeff;        // the CTU's coefficient output: 4096 luma + 2 x 1024 chroma, linear per TU in z-order
 	// speculative inputs of a P-frame CTU (enc_ctu.h)
 	uint32_t total_intra_partitions, total_partitions;
+	uint32_t inter_ssq[3];    // encode_inter: the squared residual of the CU per component (the no-residual distortion), when inter_ssq_valid
+	int inter_ssq_valid;
 	uint32_t nb_ctus;         // which neighbour CTUs exist (bit 0 left, 1 top, 2 top right, 3 top left): CtuPublic::has_*, kept here because the record lives in HBM
 	unsigned long long *timeline;   // profiling build: the CTU's timestamps
 	int n_spec_reads, n_ratio_cmp, last_slog;

@@ -215,6 +215,7 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth,
 			}
 			continue;
 		}
+		int coded_ran = 0, have_residual = 0;
 		for (int no_res = 0; no_res < 2; no_res++) {
 			if (no_res == 1 && merge_cand_buffer[cand] == 1) continue;
 			if (best_is_skip && no_res == 0) continue;
@@ -222,13 +223,24 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth,
 				const MV mv = w.merge_cands.mv[cand];
 				const int xlow = -S.margin_y, xhigh = S.width + S.margin_y, ylow = -S.margin_y, yhigh = S.height + S.margin_y;
 				const int spx = gx + mv.x / 4, spy = gy + mv.y / 4;
-				if (!(spx < xlow || spx + n > xhigh || spy < ylow || spy + n > yhigh)) motion_compensate_cu(g, e, ni, mv);
+				// (the coded evaluation wants the residual too: written on the way where the device's copy path can)
+				if (!(spx < xlow || spx + n > xhigh || spy < ylow || spy + n > yhigh)) have_residual = motion_compensate_cu(g, e, ni, mv, no_res == 0);
 				mc_done = 1;
 			}
 			if (no_res == 0) {
-				predict_all_comps(g, e, ni);
+				if (!have_residual) predict_all_comps(g, e, ni);
 				cost = dist = encode_inter(g, e, curr_depth, position, PART_2Nx2N);
 				cost = (uint32_t)((double)cost + cost_rd(e.f->avg_dist, nd.sum));
+				coded_ran = e.inter_ssq_valid;
+			} else if (coded_ran) {
+				// SSD(source, prediction) of the three blocks is the squared residual the coded evaluation of this same prediction has just summed up
+				dist = e.inter_ssq[0];
+				dist += (uint32_t)(weight * e.inter_ssq[1]);
+				dist += (uint32_t)(weight * e.inter_ssq[2]);
+				nd.inter_cbf[0] = nd.inter_cbf[1] = nd.inter_cbf[2] = 0;
+				nd.inter_tr_idx = 0;
+				nd.sum = 0;
+				cost = dist;
 			} else {
 				if (e.box) {
 					helper_post(g, e, 0, HJOB_SSD, ni, COMP_U);

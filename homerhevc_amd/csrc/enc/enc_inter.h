@@ -43,8 +43,11 @@ HENC_HD void mc_chroma_interp(const G &g, Enc &__restrict__ e, const int16_t *re
 #endif
 
 // prediction of the node's three blocks for the vector mv (hmr_motion_compensation_luma / _chroma :1779-1907, uni-directional)
+// with_residual: the caller wants the residual source - prediction of the three blocks too (blk_predict, predict_all_comps); true is returned when it has been
+// written on the way (the device's copy path up to 32 x 32: the source samples are at hand in LDS while the prediction bytes are in registers), false when the
+// caller still has to call predict_all_comps.
 template <class G>
-HENC_HD void motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv)
+HENC_HD bool motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv, bool with_residual = false)
 {
 	Work &w = *e.w;
 	const Geo &q = e.geo[ni];
@@ -69,20 +72,36 @@ HENC_HD void motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv
 			const int i = g.tid + 64 * k;
 			if (i < ychunks) vy[k] = ld32u(py + (i >> lw) * sy + ((i & ((1 << lw) - 1)) << 2));
 		}
+		// four samples: prediction bytes -> 16-bit halves; the residual beside them: source bytes (LDS) - prediction, 16 bits each (v_pk_sub_i16)
+		auto put = [&](uint32_t pv, int16_t *dst, const src_t *src, int16_t *res) {
+			const uint32_t o[2] = {__builtin_amdgcn_perm(0u, pv, 0x0c010c00u), __builtin_amdgcn_perm(0u, pv, 0x0c030c02u)};
+			__builtin_memcpy(dst, o, 8);
+			if (with_residual) {
+				const uint32_t sv = ld32u((const uint8_t *)src);
+				typedef short short2_t __attribute__((ext_vector_type(2)));
+				short2_t s0, s1, p0, p1;
+				const uint32_t so[2] = {__builtin_amdgcn_perm(0u, sv, 0x0c010c00u), __builtin_amdgcn_perm(0u, sv, 0x0c030c02u)};
+				__builtin_memcpy(&s0, &so[0], 4); __builtin_memcpy(&s1, &so[1], 4);
+				__builtin_memcpy(&p0, &o[0], 4); __builtin_memcpy(&p1, &o[1], 4);
+				const short2_t r[2] = {s0 - p0, s1 - p1};
+				__builtin_memcpy(res, r, 8);
+			}
+		};
 		if (ic < cchunks) {
-			const uint32_t ou[2] = {__builtin_amdgcn_perm(0u, vu, 0x0c010c00u), __builtin_amdgcn_perm(0u, vu, 0x0c030c02u)};
-			const uint32_t ov[2] = {__builtin_amdgcn_perm(0u, vv, 0x0c010c00u), __builtin_amdgcn_perm(0u, vv, 0x0c030c02u)};
-			__builtin_memcpy(du + rc * 32 + cc, ou, 8);
-			__builtin_memcpy(dv + rc * 32 + cc, ov, 8);
+			put(vu, du + rc * 32 + cc, w.curr_c[0] + q.yc * 32 + q.xc + rc * 32 + cc, w.resid_c[0] + q.yc * 32 + q.xc + rc * 32 + cc);
+			put(vv, dv + rc * 32 + cc, w.curr_c[1] + q.yc * 32 + q.xc + rc * 32 + cc, w.resid_c[1] + q.yc * 32 + q.xc + rc * 32 + cc);
 		}
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
 			const int i = g.tid + 64 * k;
 			if (i < ychunks) {
-				const uint32_t o[2] = {__builtin_amdgcn_perm(0u, vy[k], 0x0c010c00u), __builtin_amdgcn_perm(0u, vy[k], 0x0c030c02u)};
-				__builtin_memcpy(dy + (i >> lw) * 64 + ((i & ((1 << lw) - 1)) << 2), o, 8);
+				const int o = (i >> lw) * 64 + ((i & ((1 << lw) - 1)) << 2);
+				put(vy[k], dy + o, w.curr_y + q.y * 64 + q.x + o, w.resid_y + q.y * 64 + q.x + o);
 			}
 		}
+		g.sync();
+		PRIM_END(PP_INTERP);
+		return with_residual;
 	} else {
 		blk_from_u8(g, e.f->sub_c[0] + oc, sc, w.pred_c[0] + q.yc * 32 + q.xc, 32, q.size_chroma);
 		blk_from_u8(g, e.f->sub_c[1] + oc, sc, w.pred_c[1] + q.yc * 32 + q.xc, 32, q.size_chroma);
@@ -90,10 +109,13 @@ HENC_HD void motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv
 	}
 	g.sync();
 	PRIM_END(PP_INTERP);
+	return false;
 #else
 	mc_luma_interp(g, e, e.f->ref[0] + gy * S.stride_y + gx, S.stride_y, w.pred_y + q.y * 64 + q.x, 64, q.size, mv.x, mv.y);
 	mc_chroma_interp(g, e, e.f->ref[1] + gyc * S.stride_c + gxc, S.stride_c, w.pred_c[0] + q.yc * 32 + q.xc, 32, q.size_chroma, mv.x, mv.y);
 	mc_chroma_interp(g, e, e.f->ref[2] + gyc * S.stride_c + gxc, S.stride_c, w.pred_c[1] + q.yc * 32 + q.xc, 32, q.size_chroma, mv.x, mv.y);
+	(void)with_residual;
+	return false;
 #endif
 }
 
@@ -514,7 +536,7 @@ HENC_INLINE void get_merge_candidates(Enc &__restrict__ e, int ni, MvCandList &l
 // ---- inter TUs ---------------------------------------------------------------------------------------------------------
 // encode_inter_cu :40 (comp 0) / encode_inter_cu_chroma :133: DCT + quant, keep-or-drop decision in the residual domain, reconstruction
 template <class G>
-HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int comp, int depth, int part_size_type, int *curr_sum)
+HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int comp, int depth, int part_size_type, int *curr_sum, uint32_t *raw_ssq = nullptr)
 {
 	Work &w = *e.w;
 	Node &nd = node_of(e, ni);
@@ -545,6 +567,7 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 	if (sum > 0) {
 		lin_copy_nosync(g, iquant, quant, n * n);
 		const uint32_t raw_zero = blk_ssq(g, resid, cs, n);
+		if (raw_ssq) *raw_ssq = raw_zero;
 		dequantize(g, e.ft, e.T, iquant, iquant, curr_depth, comp, 0, n, per, rem);
 		tr_inverse(g, e.ft, e.T, rdec, n, iquant, e.scratch_a, n, 0);
 		const uint32_t raw = blk_ssd(g, resid, cs, rdec, n, n);
@@ -563,6 +586,7 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 	} else {
 		lin_zero_nosync(g, quant, n * n);
 		const uint32_t raw = blk_ssq(g, resid, cs, n);
+		if (raw_ssq) *raw_ssq = raw;
 		ssd = is_y ? raw : (uint32_t)(weight * raw);
 		blk_reconst(g, pred, cs, (const int16_t *)nullptr, 0, dec, ds, n);
 	}
@@ -645,6 +669,11 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 	depth_state[curr_depth] = initial_state;
 	curr_depth = e.geo[curr].depth;
 	int curr_sum_y = 0, curr_sum_u = 0, curr_sum_v = 0;
+	// the squared residual of every component over the CU's TUs - the distortion of coding nothing, which the TU decisions compute anyway and the merge evaluation's
+	// no-residual pass would compute again as SSD(source, prediction) (check_rd_cost_merge): valid only when every TU went through the branches below that set it
+	e.inter_ssq[0] = e.inter_ssq[1] = e.inter_ssq[2] = 0;
+	e.inter_ssq_valid = 1;
+	int luma_covered = 0;      // (a tree that visits a parent AND its children would count samples twice: checked at the end)
 	while (curr_depth != depth || depth_state[curr_depth] != end_state) {
 		curr = parent < 0 ? curr : e.geo[parent].child[depth_state[curr_depth]];
 		Node &cn = node_of(e, curr);
@@ -664,30 +693,38 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 			dist_u = d3[1]; dist_v = d3[2];
 			if (has_chroma) { curr_sum_u = s3[1]; curr_sum_v = s3[2]; }
 			done_wide = true;
+			e.inter_ssq_valid = 0;
 		}
 #endif
 		if (done_wide) {
 		} else if (has_chroma && e.box) {
 			// the three components of a TU are independent: the helpers take U and V
+			uint32_t raw = 0;
 			helper_post(g, e, 0, HJOB_INTER_TU, curr, COMP_U, depth, part_size_type);
 			helper_post(g, e, 1, HJOB_INTER_TU, curr, COMP_V, depth, part_size_type);
-			dist_y = encode_inter_tu(g, e, curr, COMP_Y, depth, part_size_type, &curr_sum_y);
+			dist_y = encode_inter_tu(g, e, curr, COMP_Y, depth, part_size_type, &curr_sum_y, &raw);
 			helper_wait(g, e, 0);
 			helper_wait(g, e, 1);
 			dist_u = e.box->r[0][0]; curr_sum_u = (int)e.box->r[0][1];
 			dist_v = e.box->r[1][0]; curr_sum_v = (int)e.box->r[1][1];
+			e.inter_ssq[0] += raw; e.inter_ssq[1] += e.box->r[0][2]; e.inter_ssq[2] += e.box->r[1][2];
 		} else {
-			dist_y = encode_inter_tu(g, e, curr, COMP_Y, depth, part_size_type, &curr_sum_y);
+			uint32_t raw = 0;
+			dist_y = encode_inter_tu(g, e, curr, COMP_Y, depth, part_size_type, &curr_sum_y, &raw);
+			e.inter_ssq[0] += raw;
 			dist_u = dist_v = 0;
 		}
 		if (has_chroma && !e.box) {
-			dist_u = encode_inter_tu(g, e, curr, COMP_U, depth, part_size_type, &curr_sum_u);
-			dist_v = encode_inter_tu(g, e, curr, COMP_V, depth, part_size_type, &curr_sum_v);
+			uint32_t raw_u = 0, raw_v = 0;
+			dist_u = encode_inter_tu(g, e, curr, COMP_U, depth, part_size_type, &curr_sum_u, &raw_u);
+			dist_v = encode_inter_tu(g, e, curr, COMP_V, depth, part_size_type, &curr_sum_v, &raw_v);
+			e.inter_ssq[1] += raw_u; e.inter_ssq[2] += raw_v;
 		} else if (!has_chroma) {
 			dist_u = dist_v = 0;
 			cn.inter_cbf[COMP_U] = node_of(e, curr - 1).inter_cbf[COMP_U];
 			cn.inter_cbf[COMP_V] = node_of(e, curr - 1).inter_cbf[COMP_V];
 		}
+		luma_covered += e.geo[curr].size * e.geo[curr].size;
 		cn.distortion = dist_y + dist_u + dist_v;
 		cn.cost = cn.distortion;
 		cn.sum = (uint32_t)(curr_sum_y + curr_sum_u + curr_sum_v);
@@ -743,6 +780,7 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 		}
 	}
 	const int top = node_at(e, depth, part_position);
+	if (luma_covered != e.geo[top].size * e.geo[top].size) e.inter_ssq_valid = 0;
 	if (depth == max_tr_processing_depth) set_enc_info_buffs(g, e, top, depth + nxn);
 	{
 		const Geo &tq = e.geo[top];
@@ -812,8 +850,13 @@ HENC_HD int predict_inter(const G &g, Enc &__restrict__ e, int depth, int part_p
 		nd.best_dif_mv.x = mv.x - e.w->amvp.mv[nd.best_candidate_idx].x;
 		nd.best_dif_mv.y = mv.y - e.w->amvp.mv[nd.best_candidate_idx].y;
 		set_inter_mv_buffs(g, e, curr);
+		bool have_residual = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+		have_residual = motion_compensate_cu(g, e, curr, mv, !use_wide(e, e.geo[curr].size));
+#else
 		motion_compensate_cu(g, e, curr, mv);
-		predict_cu_residual(g, e, curr);
+#endif
+		if (!have_residual) predict_cu_residual(g, e, curr);
 	}
 	return mv_cost;
 }

@@ -113,7 +113,7 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 			e.prof = nullptr;
 		}
 		const int *a = box->a[h];
-		uint32_t r0 = 0, r1 = 0;
+		uint32_t r0 = 0, r1 = 0, r2 = 0;
 		switch (job) {
 		case HJOB_WIDE_INTER_TU: {
 			uint32_t dist[3];
@@ -143,8 +143,10 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 		}
 		case HJOB_INTER_TU: {
 			int sum = 0;
-			r0 = encode_inter_tu(g, e, a[0], a[1], a[2], a[3], &sum);
+			uint32_t raw = 0;
+			r0 = encode_inter_tu(g, e, a[0], a[1], a[2], a[3], &sum, &raw);
 			r1 = (uint32_t)sum;
+			r2 = raw;
 			break;
 		}
 		case HJOB_SYNC_CU: sync_cu_comp(g, e, a[0], a[2], a[3], a[4], a[5], a[1]); break;
@@ -178,7 +180,7 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 		}
 		g.sync();
 		if (g.tid == 0) {
-			if (job != HJOB_CHROMA_SEARCH) { box->r[h][0] = r0; box->r[h][1] = r1; }
+			if (job != HJOB_CHROMA_SEARCH) { box->r[h][0] = r0; box->r[h][1] = r1; box->r[h][2] = r2; }
 			__hip_atomic_store(&box->done[h], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 	}
