@@ -62,6 +62,8 @@ struct Enc {
 	uint32_t total_intra_partitions, total_partitions;
 	uint32_t inter_ssq[3];    // encode_inter: the squared residual of the CU per component (the no-residual distortion), when inter_ssq_valid
 	int inter_ssq_valid;
+	int ctu_x, ctu_y;         // CtuPublic::x / y of the CTU being encoded (here for the same reason as nb_ctus: a read of the record is a trip to HBM, and motion compensation,
+	                          // the motion search and the intra reference fill started with one before they could form their first address)
 	uint32_t nb_ctus;         // which neighbour CTUs exist (bit 0 left, 1 top, 2 top right, 3 top left): CtuPublic::has_*, kept here because the record lives in HBM
 	unsigned long long *timeline;   // profiling build: the CTU's timestamps
 	int n_spec_reads, n_ratio_cmp, last_slog;

@@ -186,7 +186,7 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth,
 	Node &nd = node_of(e, ni);
 	CtuPublic &c = *e.ctu;
 	const int abs_index = q.abs_index, curr_depth = q.depth, n = q.size, nc = q.size_chroma;
-	const int gx = c.x + q.x, gy = c.y + q.y;
+	const int gx = e.ctu_x + q.x, gy = e.ctu_y + q.y;
 	int merge_cand_buffer[5] = {0, 0, 0, 0, 0};
 	int best_is_skip = 0, best_candidate = 0;
 	uint32_t dist, best_dist = MAX_COST, cost, best_cost = MAX_COST, best_sum = 0;
@@ -653,6 +653,8 @@ HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 	c.ctu_number = ctu_num;
 	c.x = cx * 64;
 	c.y = cy * 64;
+	e.ctu_x = cx * 64;
+	e.ctu_y = cy * 64;
 	const int ctu_w = (c.x + 64) < S.width ? 64 : S.width - c.x, ctu_h = (c.y + 64) < S.height ? 64 : S.height - c.y;
 	if (ctu_w != 64 || ctu_h != 64) c.last_valid_partition = raster2abs(((ctu_h >> 2) - 1) * 16 + (ctu_w >> 2) - 1);
 	else c.last_valid_partition = NPART - 1;

@@ -52,7 +52,7 @@ HENC_HD bool motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv
 	Work &w = *e.w;
 	const Geo &q = e.geo[ni];
 	const Seq &S = *e.seq;
-	const int gx = e.ctu->x + q.x, gy = e.ctu->y + q.y, gxc = (e.ctu->x >> 1) + q.xc, gyc = (e.ctu->y >> 1) + q.yc;
+	const int gx = e.ctu_x + q.x, gy = e.ctu_y + q.y, gxc = (e.ctu_x >> 1) + q.xc, gyc = (e.ctu_y >> 1) + q.yc;
 #if defined(__HIPCC__)
 	PRIM_T0();
 	// (row-interleaved planes, k_subpel.hip: row y of phase f starts at (y * phases + f) * stride)
@@ -876,7 +876,7 @@ HENC_HD int cu_motion_estimation(const G &g, Enc &__restrict__ e, int depth, int
 	for (int np = 0; np < num_partitions; np++, curr++) {
 		const Geo &q = e.geo[curr];
 		Node &nd = node_of(e, curr);
-		const int gx = e.ctu->x + q.x, gy = e.ctu->y + q.y;
+		const int gx = e.ctu_x + q.x, gy = e.ctu_y + q.y;
 		MvCandList amvp;
 		{ PRIM_T0(); get_amvp_candidates(e, curr, amvp); PRIM_END(PP_CAND); }
 		w.search_cands.num = 0;

@@ -23,7 +23,7 @@ HENC_HD void node_fill_refs(const G &g, Enc &__restrict__ e, int ni, int wnd, in
 	const int is_y = comp == COMP_Y;
 	const int n = is_y ? q.size : q.size_chroma, x = is_y ? q.x : q.xc, y = is_y ? q.y : q.yc;
 	const int pw = is_y ? e.seq->width : e.seq->width >> 1, ph = is_y ? e.seq->height : e.seq->height >> 1;
-	const int cx = is_y ? e.ctu->x : e.ctu->x >> 1, cy = is_y ? e.ctu->y : e.ctu->y >> 1;
+	const int cx = is_y ? e.ctu_x : e.ctu_x >> 1, cy = is_y ? e.ctu_y : e.ctu_y >> 1;
 	const int bl_size = hmin(n, ph - (cy + y + n)), tr_size = hmin(n, pw - (cx + x + n));
 	const int st = dec_stride(comp);
 	const int16_t *corner = dec_ptr(*e.w, wnd, comp) + (y - 1) * st + (x - 1);
