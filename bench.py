@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """bench.py - encoded frames/sec of the device encoder on BASELINE.json configs[1].
 
-Workload ("cfg2-1080p-encode"): the real encode of a 1920x1080 IPPP sequence (gop_size=1, fixed QP 32, quarter-pel ME, SAO on; the
-synthetic clip of SURVEY.md 8-d) through the C ABI (hmr_gpu_enc_encode_source, include/homer_gpu.h section 12).  One step = one
-frame = everything HOMER_enc_encode does for it: the CTU decisions (persistent row-parallel kernel with the guess / verify / re-encode
-schedule that keeps the output identical to the single-thread reference), deblocking, SAO statistics, SAO decision + CABAC + NAL
-writer (host), SAO offsets and border padding; the access unit is produced inside the timed region.  The source pictures are resident
-in HBM before the timed region starts.  Warm-up frames are the first frames of the sequence (the I frame and the first P frames), the
-timed frames the P frames that follow - every frame depends on the reconstruction of the one before, nothing is replayed or cached.
-The stream produced during the run is hashed; for the default workload and --steps + --warmup == 8 it must be the reference's
-2f0c3447dabb6fbd87cac9821bb479fd (reported as `stream_md5`, `stream_matches_reference`).
+Workload ("cfg2-1080p-encode"): the real encode of 1920x1080 IPPP sequences (gop_size=1, fixed QP 32, quarter-pel ME, SAO on, one WPP thread per CTU row; the
+synthetic clip of SURVEY.md 8-d) through the C ABI (include/homer_gpu.h section 12) - a batch of --sequences independent sequences per GPU, one frame of each per
+step (hmr_gpu_enc_encode_batch_pipelined).  One step = everything HOMER_enc_encode does for those frames: the phase planes of the reference pictures, the CTU
+decisions (k_encode_pool: the CTUs of all the pictures as a pool of tasks on two row workers per CU), deblocking, SAO statistics / decision / offsets, border
+padding on the device, the download of side-info and levels, CABAC + NAL writer on the host; the access units are delivered inside the timed region (the
+pipelined call delivers a step's units with the next call: the pipeline is empty when the region starts and flushed before it ends).  The source pictures are
+resident in HBM before the timed region starts.  Warm-up frames are the first frames of the sequences (the I frame and the first P frames), the timed frames
+the P frames that follow - every frame depends on the reconstruction of the one before, nothing is replayed or cached.  Every access unit of every sequence is
+checked against the reference's per-frame digests (tests/golden/bench_md5.json: `stream_matches_reference`, `frames_checked_against_reference`) for any
+--steps / --warmup the fixture covers (40 frames).  Beside the headline: `single_sequence` (one sequence alone), `single_thread_order` (wfpp_num_threads = 1,
+the reference's deterministic single-thread stream 2f0c3447...), `at_2160p`.
 
 Multi-GPU (--gpus N under torch.distributed.run): one engine per GPU, as BASELINE.json's north_star and configs[3] say - the reference's
 num_enc_engines = N frame pipeline (encoder_engine_thread, hmr_encoder_lib.c:3043) with engine k on rank k.  Every rank keeps one engine object of every
@@ -18,10 +20,10 @@ the frame-to-frame scalars round the ring in ONE packed RCCL send / recv per ran
 every rank encodes --sequences frames per step whatever N is (weak scaling); the exchange is inside the timed region.  Every access unit is checked against
 the reference's num_enc_engines = N stream (oracle/ref_ctudump.c's engine turnstile; tests/golden/bench_md5.json).
 
-Extra objects: `roofline` for k_encode_ctus (the launch that takes > 95 % of the frame): algorithmic bytes per SURVEY.md 8-d
-against the 8 TB/s HBM peak - the kernel is bound by dependent-instruction latency of a few wavefronts, not by bandwidth, and the
-fraction says so; `cpu_baseline`: the compiled reference (oracle/_ref/ref_lockstep, one thread) timed on this host on the same
-configuration.
+Extra objects: `roofline` for k_encode_pool (93 % of a step): algorithmic bytes per SURVEY.md 8-d against the 8 TB/s HBM peak, the fabric traffic from the
+calibrated counter passes, and `issue_bound` - what actually binds the kernel (wave-instruction issue and the latency of dependent chains, not bandwidth);
+`roofline.subpel_planes`: the bandwidth-bound phase-plane kernels measured live; `cpu_baseline`: the compiled reference (oracle/_ref/ref_lockstep) timed on
+this host on the same configuration - one thread, one thread per CTU row, and K processes side by side.
 """
 import argparse
 import ctypes as C
@@ -424,9 +426,9 @@ def run_engine_ring(a, world, rank, local, torch):
 
 
 def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
-    """`sequences` independent sequences of the workload per GPU: 1 = hmr_gpu_enc_encode_source frame by frame; more = one hmr_gpu_enc_encode_batch call per step
-    (ONE launch for the CTU stages of all of them - a row worker takes a whole CU, so the launch is 15 groups of 17 workgroups at 1080p and a group encodes its
-    sequences one after the other, which fills the bubbles of the WPP wavefront), every stream hashed."""
+    """`sequences` independent sequences of the workload per GPU: 1 = hmr_gpu_enc_encode_source frame by frame; more = one batch call per step (ONE launch for the
+    CTU stages of all of them: a pool of CTU tasks on two row workers per CU; the pipelined call by default, whose access units come with the next call), every
+    access unit kept and checked against the reference's digests after the timed region."""
     import encoder_cases as ec
     width, height, keys = WORKLOADS[workload]
     nframes = a.warmup + a.steps
