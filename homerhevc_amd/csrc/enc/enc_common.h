@@ -82,17 +82,13 @@ struct Enc {
 // Two helper wavefronts per row worker take the chroma components of a step whose three components are independent (motion compensation, the
 // transform chain of a TU) and single candidates of the intra mode search, while the worker itself does luma / the first candidate.  The worker
 // posts a job in LDS and goes on; a helper runs the same SPMD code on its own 64 lanes with its own scratch and reports back.
-// Wide jobs (HJOB_WIDE_*): all helpers AND the worker run one block's chain together as a 256-lane group (WideGrp, enc_platform.h) - posted to every helper,
-// then the worker enters the same function; the chain's own barriers keep them together, nothing is waited for afterwards.
-enum { HJOB_NONE = 0, HJOB_NEW_CTU, HJOB_INTER_TU, HJOB_INTRA_SAD, HJOB_SYNC_CU, HJOB_SSD, HJOB_CHROMA_SEARCH, HJOB_CHROMA_TU, HJOB_WIDE_INTER_TU, HJOB_WIDE_INTRA_TU,
-       HJOB_WIDE_CHROMA_TU, HJOB_WIDE_PREDICT, HJOB_QUIT };
+enum { HJOB_NONE = 0, HJOB_NEW_CTU, HJOB_INTER_TU, HJOB_INTRA_SAD, HJOB_SYNC_CU, HJOB_SSD, HJOB_CHROMA_SEARCH, HJOB_CHROMA_TU, HJOB_QUIT };
 constexpr int NHELP = 2;   // (a third helper was measured: 3 % slower - one more wavefront polling its mailbox, nothing for it to do most of the time)
 struct HelperBox {
 	int cmd[NHELP], done[NHELP];   // sequence numbers: helper h runs its next job when cmd[h] moves on, and sets done[h] = cmd[h] when finished
 	int job[NHELP];
 	int a[NHELP][8];
 	uint32_t r[NHELP][8];
-	uint32_t xch[2][4];            // WideGrp's reduction exchange ([2][WIDE_WAVES] used)
 	Enc enc;                       // the worker's context, refreshed at every CTU start
 };
 
@@ -124,20 +120,6 @@ HENC_HD void helper_wait(const G &g, Enc &__restrict__ e, int h)
 	(void)g; (void)e; (void)h;
 #endif
 }
-
-// the same job to every helper (wide jobs)
-template <class G>
-HENC_HD void wide_post(const G &g, Enc &__restrict__ e, int job, int a0 = 0, int a1 = 0, int a2 = 0, int a3 = 0, int a4 = 0, int a5 = 0)
-{
-	for (int h = 0; h < NHELP; h++) helper_post(g, e, h, job, a0, a1, a2, a3, a4, a5);
-}
-#if defined(__HIP_DEVICE_COMPILE__)
-// blocks of at least this many samples a side are worked on by the whole workgroup (Seq::wide_min_n; 0 = never)
-HENC_INLINE bool use_wide(const Enc &__restrict__ e, int n) { return e.box && e.seq->wide_min_n > 0 && n >= e.seq->wide_min_n; }
-__device__ __forceinline__ WideGrp wide_group(Enc &__restrict__ e) { return WideGrp{(int)threadIdx.x, &e.box->xch[0][0], 0}; }
-#else
-HENC_INLINE bool use_wide(const Enc &, int) { return false; }
-#endif
 
 HENC_INLINE Node &node_of(Enc &__restrict__ e, int idx) { return e.nodes[idx]; }
 HENC_INLINE int node_at(const Enc &__restrict__ e, int depth, int position) { return e.seq->depth_start[depth] + position; }

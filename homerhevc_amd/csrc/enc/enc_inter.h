@@ -594,7 +594,7 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 	return ssd;
 }
 
-// the three components of one TU, one after the other, by whatever group runs it (the whole workgroup in a wide job, enc_common.h)
+// the three components of one TU, one after the other
 template <class G>
 HENC_HD void inter_tu_all_comps(const G &g, Enc &__restrict__ e, int curr, int depth, int part_size_type, int has_chroma, uint32_t *dist, int *sums)
 {
@@ -670,7 +670,7 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 	curr_depth = e.geo[curr].depth;
 	int curr_sum_y = 0, curr_sum_u = 0, curr_sum_v = 0;
 	// the squared residual of every component over the CU's TUs - the distortion of coding nothing, which the TU decisions compute anyway and the merge evaluation's
-	// no-residual pass would compute again as SSD(source, prediction) (check_rd_cost_merge): valid only when every TU went through the branches below that set it
+	// no-residual pass would compute again as SSD(source, prediction) (check_rd_cost_merge)
 	e.inter_ssq[0] = e.inter_ssq[1] = e.inter_ssq[2] = 0;
 	e.inter_ssq_valid = 1;
 	int luma_covered = 0;      // (a tree that visits a parent AND its children would count samples twice: checked at the end)
@@ -681,23 +681,7 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 		curr_depth = e.geo[curr].depth;
 		uint32_t dist_y, dist_u, dist_v;
 		const bool has_chroma = e.geo[curr].size_chroma != 2 || depth_state[curr_depth] == 0;
-		bool done_wide = false;
-#if defined(__HIP_DEVICE_COMPILE__)
-		if (use_wide(e, e.geo[curr].size)) {
-			// the whole workgroup on this TU: luma, then the chroma planes
-			uint32_t d3[3];
-			int s3[3];
-			wide_post(g, e, HJOB_WIDE_INTER_TU, curr, depth, part_size_type, has_chroma);
-			inter_tu_all_comps(wide_group(e), e, curr, depth, part_size_type, has_chroma, d3, s3);
-			dist_y = d3[0]; curr_sum_y = s3[0];
-			dist_u = d3[1]; dist_v = d3[2];
-			if (has_chroma) { curr_sum_u = s3[1]; curr_sum_v = s3[2]; }
-			done_wide = true;
-			e.inter_ssq_valid = 0;
-		}
-#endif
-		if (done_wide) {
-		} else if (has_chroma && e.box) {
+		if (has_chroma && e.box) {
 			// the three components of a TU are independent: the helpers take U and V
 			uint32_t raw = 0;
 			helper_post(g, e, 0, HJOB_INTER_TU, curr, COMP_U, depth, part_size_type);
@@ -814,21 +798,7 @@ HENC_HD void predict_all_comps(const G &g, Enc &__restrict__ e, int ni)
 		blk_predict(g, w.curr_c[c] + q.yc * 32 + q.xc, 32, w.pred_c[c] + q.yc * 32 + q.xc, 32, w.resid_c[c] + q.yc * 32 + q.xc, 32, q.size_chroma);
 }
 
-// the residual of a CU's three blocks, by the whole workgroup when the CU is large
-template <class G>
-HENC_HD void predict_cu_residual(const G &g, Enc &__restrict__ e, int ni)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-	if (use_wide(e, e.geo[ni].size)) {
-		wide_post(g, e, HJOB_WIDE_PREDICT, ni);
-		const WideGrp wg = wide_group(e);
-		predict_all_comps(wg, e, ni);
-		wg.sync();
-		return;
-	}
-#endif
-	predict_all_comps(g, e, ni);
-}
+
 
 // predict_inter :2924 (uni-directional): vector predictor choice, motion compensation, residual.  Returns the vector cost.
 template <class G>
@@ -850,13 +820,7 @@ HENC_HD int predict_inter(const G &g, Enc &__restrict__ e, int depth, int part_p
 		nd.best_dif_mv.x = mv.x - e.w->amvp.mv[nd.best_candidate_idx].x;
 		nd.best_dif_mv.y = mv.y - e.w->amvp.mv[nd.best_candidate_idx].y;
 		set_inter_mv_buffs(g, e, curr);
-		bool have_residual = false;
-#if defined(__HIP_DEVICE_COMPILE__)
-		have_residual = motion_compensate_cu(g, e, curr, mv, !use_wide(e, e.geo[curr].size));
-#else
-		motion_compensate_cu(g, e, curr, mv);
-#endif
-		if (!have_residual) predict_cu_residual(g, e, curr);
+		if (!motion_compensate_cu(g, e, curr, mv, true)) predict_all_comps(g, e, curr);
 	}
 	return mv_cost;
 }

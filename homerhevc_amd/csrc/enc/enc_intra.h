@@ -289,17 +289,7 @@ HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, i
 		cn.qp = qp;
 		curr_depth = e.geo[curr].depth;
 		int curr_sum = 0;
-		bool done_wide = false;
-#if defined(__HIP_DEVICE_COMPILE__)
-		if (use_wide(e, e.geo[curr].size)) {
-			wide_post(g, e, HJOB_WIDE_INTRA_TU, curr, depth, cu_mode, part_size_type);
-			const WideGrp wg = wide_group(e);
-			cn.distortion = encode_intra_tu(wg, e, curr, depth, cu_mode, part_size_type, &curr_sum);
-			wg.sync();
-			done_wide = true;
-		}
-#endif
-		if (!done_wide) cn.distortion = encode_intra_tu(g, e, curr, depth, cu_mode, part_size_type, &curr_sum);
+		cn.distortion = encode_intra_tu(g, e, curr, depth, cu_mode, part_size_type, &curr_sum);
 		cn.sum = (uint32_t)curr_sum;
 		cn.cost = cn.distortion;
 		depth_state[curr_depth]++;
@@ -430,7 +420,7 @@ HENC_HD int chroma_tu_comp(const G &g, Enc &__restrict__ e, int curr, int c, int
 	return (int)(e.f->chroma_weight * raw);
 }
 
-// both chroma planes of a TU, one after the other, by whatever group runs it (a wide job: the whole workgroup)
+// both chroma planes of a TU, one after the other
 template <class G>
 HENC_HD void chroma_tu_both(const G &g, Enc &__restrict__ e, int curr, int cu_mode, int scan_mode, int shifts, int per, int rem, int *pc, int *cs)
 {
@@ -545,16 +535,7 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth,
 			{
 				int cs[2], pc[2];
 				const int shifts = (original_depth - depth + nxn) | ((curr_depth - depth + nxn) << 8);
-				bool done_wide = false;
-#if defined(__HIP_DEVICE_COMPILE__)
-				if (use_wide(e, 2 * n)) {
-					wide_post(g, e, HJOB_WIDE_CHROMA_TU, curr, cu_mode, scan_mode, shifts, per | (rem << 8));
-					chroma_tu_both(wide_group(e), e, curr, cu_mode, scan_mode, shifts, per, rem, pc, cs);
-					done_wide = true;
-				}
-#endif
-				if (done_wide) {
-				} else if (e.box) {
+				if (e.box) {
 					helper_post(g, e, 0, HJOB_CHROMA_TU, curr, COMP_U, cu_mode, scan_mode, shifts, per | (rem << 8));
 					pc[1] = chroma_tu_comp(g, e, curr, COMP_V, cu_mode, scan_mode, shifts, per, rem, &cs[1]);
 					helper_wait(g, e, 0);

@@ -67,38 +67,6 @@ struct WaveGrp {
 	}
 };
 
-// The row worker and its helper wavefronts working on ONE block together (k_encode.hip, enc_common.h: wide jobs).  The decision walk is a serial chain, but
-// at 32 x 32 a block primitive is bound by what one wavefront can issue (sixteen samples per lane and pass); spread over the workgroup's wavefronts (one per SIMD) it is that many times fewer.
-// Same SPMD code: tid runs over the whole workgroup, sync() is the workgroup barrier, reductions combine the wavefronts' totals through a small exchange
-// buffer in LDS (two slots, used alternately: one barrier per reduction).
-constexpr int WIDE_WAVES = 3;   // = 1 + NHELP (enc_common.h)
-struct WideGrp {
-	int tid;
-	uint32_t *xch;              // [2][WIDE_WAVES] in LDS (HelperBox)
-	mutable int par;
-	static constexpr int n = 64 * WIDE_WAVES;
-	__device__ __forceinline__ void sync() const
-	{
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_s_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-	}
-	__device__ __forceinline__ uint32_t sum(uint32_t v) const
-	{
-		const WaveGrp w{tid & 63};
-		const uint32_t mine = w.sum(v);
-		uint32_t *slot = xch + par * WIDE_WAVES;
-		par ^= 1;
-		if ((tid & 63) == 0) slot[tid >> 6] = mine;
-		sync();
-		uint32_t t = 0;
-#pragma unroll
-		for (int k = 0; k < WIDE_WAVES; k++) t += slot[k];
-		return t;
-	}
-	// (per wavefront: the one user, the sign-hiding pass, keeps all its coefficient groups on the first wavefront)
-	__device__ __forceinline__ uint64_t ballot(bool p) const { return __ballot(p); }
-};
 #endif
 
 // The row worker's state - its Work, the CTU's nodes and record, the geometry, the sequence / frame parameters, the helper mailbox and scratch - lives in

@@ -132,7 +132,7 @@ struct Seq {
 	int32_t src_stride_y, src_stride_c;
 	// elements of one padded plane (stride x (rows + 2 margins)): the phase planes of the reference (FrameCtx::sub_y / sub_c) take 16 / 64 of them
 	int32_t plane_elems_y, plane_elems_c;
-	int32_t wide_min_n;                    // device: smallest block side the row worker and its helpers work on together (enc_common.h: wide jobs)
+	int32_t wide_min_n;                    // (unused: round 3's experiment with 192 lanes on one TU chain, profiles/r03_history.md)
 	int32_t pad_;
 };
 

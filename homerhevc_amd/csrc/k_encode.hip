@@ -88,7 +88,6 @@ constexpr size_t LDS_BYTES = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU 
 constexpr size_t LDS_FT_OFFSET = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH;
 #endif
 constexpr int ENC_THREADS = 64 * (1 + NHELP);   // the row worker + its helper wavefronts: one wavefront per SIMD of the CU
-static_assert(ENC_THREADS == WideGrp::n, "a wide job is the whole workgroup");
 static_assert(LDS_BYTES <= 160 * 1024, "a workgroup has 160 KiB of LDS on gfx950");
 constexpr int WORKERS_PER_CU = LDS_BYTES <= 80 * 1024 ? 2 : 1;
 
@@ -97,15 +96,12 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 {
 	WaveGrp g{(int)(threadIdx.x & 63)};
 	Enc e = {};   // (a context struct shared in LDS instead of one per lane in private memory was tried: the kernel hangs, cause not found)
-	Enc ew = {};  // the worker's own context (its scratch, not this helper's): what a wide job runs on
 	for (int seq = 1;; seq++) {
 		while (__hip_atomic_load(&box->cmd[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) __builtin_amdgcn_s_sleep(1);   // (two workgroups share a CU now: a helper that spins takes issue cycles from the other workgroup's worker on its SIMD)
 		const int job = box->job[h];
 		if (job == HJOB_QUIT) return;
 		if (job == HJOB_NEW_CTU) {
 			e = box->enc;
-			ew = e;
-			ew.box = nullptr;
 			e.box = nullptr;
 			e.scratch_a = scratch;
 			e.scratch_b = scratch + 1024;
@@ -115,32 +111,6 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 		const int *a = box->a[h];
 		uint32_t r0 = 0, r1 = 0, r2 = 0;
 		switch (job) {
-		case HJOB_WIDE_INTER_TU: {
-			uint32_t dist[3];
-			int sums[3];
-			const WideGrp wg{(int)threadIdx.x, &box->xch[0][0], 0};
-			inter_tu_all_comps(wg, ew, a[0], a[1], a[2], a[3], dist, sums);
-			break;
-		}
-		case HJOB_WIDE_PREDICT: {
-			const WideGrp wg{(int)threadIdx.x, &box->xch[0][0], 0};
-			predict_all_comps(wg, ew, a[0]);
-			wg.sync();
-			break;
-		}
-		case HJOB_WIDE_INTRA_TU: {
-			int cs = 0;
-			const WideGrp wg{(int)threadIdx.x, &box->xch[0][0], 0};
-			(void)encode_intra_tu(wg, ew, a[0], a[1], a[2], a[3], &cs);
-			wg.sync();
-			break;
-		}
-		case HJOB_WIDE_CHROMA_TU: {
-			int cs[2], pc[2];
-			const WideGrp wg{(int)threadIdx.x, &box->xch[0][0], 0};
-			chroma_tu_both(wg, ew, a[0], a[1], a[2], a[3], a[4] & 255, a[4] >> 8, pc, cs);
-			break;
-		}
 		case HJOB_INTER_TU: {
 			int sum = 0;
 			uint32_t raw = 0;
@@ -1127,7 +1097,7 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 		bool ok = false;
 		~Guard() { if (!ok) hmr_gpu_enc_destroy(e); }
 	} guard{e};
-	e->seq.wide_min_n = getenv("HENC_WIDE_MIN") ? atoi(getenv("HENC_WIDE_MIN")) : 0;   // blocks from this size on are worked on by the whole workgroup; measured on MI355X (1080p, one sequence): 32 -> no gain, 16 -> 8 % slower, so off by default (profiles/r03_history.md)
+	e->seq.wide_min_n = 0;
 	const Seq &s = e->seq;
 	HIP_TRY(hipSetDevice(ctx->device));
 	e->geo.resize(NNODES);
