@@ -121,6 +121,15 @@ HENC_HD void helper_wait(const G &g, Enc &__restrict__ e, int h)
 #endif
 }
 
+// Does the group that runs the decision walk have helper wavefronts?  On the device always (every worker of k_encode_pool / k_encode_ctus has its two helpers;
+// the helpers themselves only run leaf jobs: a TU chain, a SAD, a copy), on the CPU never - a constant, so that each build carries one of the two paths (as a
+// run-time test of Enc::box both were compiled into the worker's code, and the decision code is several times the instruction cache).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HENC_HELPERS(e) true
+#else
+#define HENC_HELPERS(e) false
+#endif
+
 HENC_INLINE Node &node_of(Enc &__restrict__ e, int idx) { return e.nodes[idx]; }
 HENC_INLINE int node_at(const Enc &__restrict__ e, int depth, int position) { return e.seq->depth_start[depth] + position; }
 
@@ -247,7 +256,7 @@ HENC_HD void sync_motion_buffers_chroma(const G &g, Enc &__restrict__ e, int ni,
 template <class G>
 HENC_HD void sync_motion_buffers(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
 {
-	if (e.box) {
+	if (HENC_HELPERS(e)) {
 		helper_post(g, e, 0, HJOB_SYNC_CU, ni, COMP_U, q_src, q_dst, d_src, d_dst);
 		helper_post(g, e, 1, HJOB_SYNC_CU, ni, COMP_V, q_src, q_dst, d_src, d_dst);
 		sync_cu_comp(g, e, ni, q_src, q_dst, d_src, d_dst, COMP_Y);

@@ -242,12 +242,12 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth,
 				nd.sum = 0;
 				cost = dist;
 			} else {
-				if (e.box) {
+				if (HENC_HELPERS(e)) {
 					helper_post(g, e, 0, HJOB_SSD, ni, COMP_U);
 					helper_post(g, e, 1, HJOB_SSD, ni, COMP_V);
 				}
 				dist = blk_ssd(g, w.curr_y + q.y * 64 + q.x, 64, w.pred_y + q.y * 64 + q.x, 64, n);
-				if (e.box) {
+				if (HENC_HELPERS(e)) {
 					helper_wait(g, e, 0);
 					helper_wait(g, e, 1);
 					dist += (uint32_t)(weight * e.box->r[0][0]);
@@ -703,7 +703,7 @@ HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 		g.sync();
 	}
 	create_partition_neighbours(g, e);
-	if (e.box) {               // the helpers work on this CTU from now on
+	if (HENC_HELPERS(e)) {     // the helpers work on this CTU from now on
 		g.sync();
 		if (g.tid == 0) e.box->enc = e;
 		for (int h = 0; h < NHELP; h++) helper_post(g, e, h, HJOB_NEW_CTU);

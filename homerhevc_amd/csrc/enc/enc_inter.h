@@ -681,7 +681,7 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 		curr_depth = e.geo[curr].depth;
 		uint32_t dist_y, dist_u, dist_v;
 		const bool has_chroma = e.geo[curr].size_chroma != 2 || depth_state[curr_depth] == 0;
-		if (has_chroma && e.box) {
+		if (has_chroma && HENC_HELPERS(e)) {
 			// the three components of a TU are independent: the helpers take U and V
 			uint32_t raw = 0;
 			helper_post(g, e, 0, HJOB_INTER_TU, curr, COMP_U, depth, part_size_type);
@@ -698,7 +698,7 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 			e.inter_ssq[0] += raw;
 			dist_u = dist_v = 0;
 		}
-		if (has_chroma && !e.box) {
+		if (has_chroma && !HENC_HELPERS(e)) {
 			uint32_t raw_u = 0, raw_v = 0;
 			dist_u = encode_inter_tu(g, e, curr, COMP_U, depth, part_size_type, &curr_sum_u, &raw_u);
 			dist_v = encode_inter_tu(g, e, curr, COMP_V, depth, part_size_type, &curr_sum_v, &raw_v);

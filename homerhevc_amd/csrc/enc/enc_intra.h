@@ -168,7 +168,7 @@ HENC_HD int intra_mode_search(const G &g, Enc &__restrict__ e, int ni, int depth
 		// with helper wavefronts: rounds of 1 + NHELP candidates, the worker always taking the last one of the round (so that the prediction
 		// left in the window is the one the serial order leaves there); the helpers only return the SAD
 		for (int k0 = 0; k0 < cnt;) {
-			const int take = e.box ? hmin(1 + NHELP, cnt - k0) : 1, mine = k0 + take - 1;
+			const int take = HENC_HELPERS(e) ? hmin(1 + NHELP, cnt - k0) : 1, mine = k0 + take - 1;
 			for (int j = 0; j < take - 1; j++) helper_post(g, e, j, HJOB_INTRA_SAD, ni, n, modes[k0 + j], intra_is_filtered(modes[k0 + j], inv_depth));
 			{
 				const int mode = modes[mine], filt = intra_is_filtered(mode, inv_depth);
@@ -466,7 +466,7 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth,
 		uint32_t sad_u[5], sad_v[5];
 		int cand[5];
 		for (int mi = 0; mi < 5; mi++) cand[mi] = mode_list[mi] == DM_CHROMA_IDX ? luma_mode : mode_list[mi];
-		if (e.box) {
+		if (HENC_HELPERS(e)) {
 			helper_post(g, e, 0, HJOB_CHROMA_SEARCH, curr, COMP_U, cand[0] | (cand[1] << 8) | (cand[2] << 16) | (cand[3] << 24), cand[4]);
 			chroma_search_comp(g, e, curr, COMP_V, cand, sad_v);
 			helper_wait(g, e, 0);
@@ -535,7 +535,7 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth,
 			{
 				int cs[2], pc[2];
 				const int shifts = (original_depth - depth + nxn) | ((curr_depth - depth + nxn) << 8);
-				if (e.box) {
+				if (HENC_HELPERS(e)) {
 					helper_post(g, e, 0, HJOB_CHROMA_TU, curr, COMP_U, cu_mode, scan_mode, shifts, per | (rem << 8));
 					pc[1] = chroma_tu_comp(g, e, curr, COMP_V, cu_mode, scan_mode, shifts, per, rem, &cs[1]);
 					helper_wait(g, e, 0);
