@@ -131,7 +131,7 @@ HENC_HD void helper_wait(const G &g, Enc &__restrict__ e, int h)
 #endif
 
 HENC_INLINE Node &node_of(Enc &__restrict__ e, int idx) { return e.nodes[idx]; }
-HENC_INLINE int node_at(const Enc &__restrict__ e, int depth, int position) { return e.seq->depth_start[depth] + position; }
+HENC_INLINE int node_at(const Enc &__restrict__ e, int depth, int position) { return cfg_depth_start(depth) + position; }
 
 // ---- neighbour partitions (hmr_arithmetic_encoding.c:229-355).  Return the CTU that holds the neighbour (nullptr when not
 // available) and its z-order unit index. -------------------------------------------------------------------------------

@@ -100,7 +100,7 @@ HENC_HD void consolidate_prediction_info(const G &g, Enc &__restrict__ e, int pi
 	if (pq.child[0] >= 0)
 		children_sum = node_of(e, pq.child[0]).sum + node_of(e, pq.child[1]).sum + node_of(e, pq.child[2]).sum + node_of(e, pq.child[3]).sum;
 	if (children_cost < parent_cost || !(pn.b_inside && pn.r_inside)) {
-		const int part2 = curr_depth < e.seq->max_pred_depth ? PART_2Nx2N : PART_NxN;
+		const int part2 = curr_depth < CFG_MAX_PRED_DEPTH ? PART_2Nx2N : PART_NxN;
 		if (cost_sum) {
 			cost_sum[pq.depth] -= parent_cost;
 			cost_sum[pq.depth] += children_cost;
@@ -125,7 +125,7 @@ HENC_HD void consolidate_prediction_info(const G &g, Enc &__restrict__ e, int pi
 			g.sync();
 		}
 	} else {
-		const int part2 = pq.depth < e.seq->max_pred_depth ? PART_2Nx2N : PART_NxN;
+		const int part2 = pq.depth < CFG_MAX_PRED_DEPTH ? PART_2Nx2N : PART_NxN;
 		const int parent_depth = pq.depth;
 		sync_motion_buffers(g, e, pi, parent_depth + 1, 0, parent_depth + 1, 0);
 		info_buffs_copy(g, e, parent_depth, abs_index, num, 1);
@@ -145,7 +145,7 @@ HENC_HD void consolidate_prediction_info(const G &g, Enc &__restrict__ e, int pi
 template <class G>
 HENC_HD void refresh_deeper_windows(const G &g, Enc &__restrict__ e, int aux_ni, int from_depth, int with_info)
 {
-	const int max_processing_depth = hmin(e.seq->max_pred_depth + e.seq->max_intra_tr_depth - 1, NDEPTH - 1);
+	const int max_processing_depth = hmin(CFG_MAX_PRED_DEPTH + e.seq->max_intra_tr_depth - 1, NDEPTH - 1);
 	if (from_depth > max_processing_depth) return;
 	const Geo &q = e.geo[aux_ni];
 	for (int aux_depth = from_depth; aux_depth <= max_processing_depth; aux_depth++) {
@@ -195,7 +195,7 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth,
 	uint8_t inter_modes[5] = {255, 255, 255, 255, 255};
 	const double weight = e.f->chroma_weight;
 	{ PRIM_T0(); get_merge_candidates(e, ni, w.merge_cands, inter_modes); PRIM_END(PP_CAND); }
-	for (int cand = 0; cand < S.num_merge_cand; cand++) {
+	for (int cand = 0; cand < CFG_NUM_MERGE_CAND; cand++) {
 		int mc_done = 0;
 		// A candidate that repeats the one before it (same vector, same reference - the usual case under coherent motion, and always for the zero candidates that
 		// fill the list: with one reference picture they are all alike) cannot win: its two evaluations recompute what its predecessor's did, bit for bit, into
@@ -344,9 +344,9 @@ HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &__restrict__ e)
 		const Geo &q = e.geo[curr];
 		Node &nd = node_of(e, curr);
 		curr_depth = q.depth;
-		const int part_size_type = curr_depth < S.max_pred_depth ? PART_2Nx2N : PART_NxN;
+		const int part_size_type = curr_depth < CFG_MAX_PRED_DEPTH ? PART_2Nx2N : PART_NxN;
 		const int num_part_in_cu = q.num_part;
-		const int position = q.list_index - S.depth_start[curr_depth];
+		const int position = q.list_index - cfg_depth_start(curr_depth);
 		nd.qp = (uint32_t)e.f->qp;   // hmr_rc_get_cu_qp, fixed QP (hmr_rate_control.c:366)
 		if (nd.b_inside && nd.r_inside) {
 			int mv_cost = 0;
@@ -464,12 +464,12 @@ HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &__restrict__ e)
 		}
 		cost_sum[curr_depth] += nd.cost;
 		depth_state[curr_depth]++;
-		if (curr_depth < S.max_pred_depth && nd.tl_inside && !stop_recursion) {
+		if (curr_depth < CFG_MAX_PRED_DEPTH && nd.tl_inside && !stop_recursion) {
 			curr_depth++;
 			parent = curr;
 		} else if (depth_state[curr_depth] == 4) {
 			while (depth_state[curr_depth] == 4 && curr_depth > 0) {
-				const int is_max_depth = curr_depth == S.max_pred_depth;
+				const int is_max_depth = curr_depth == CFG_MAX_PRED_DEPTH;
 				const Geo &pq = e.geo[parent];
 				const uint32_t ccost = node_of(e, pq.child[0]).cost + node_of(e, pq.child[1]).cost + node_of(e, pq.child[2]).cost + node_of(e, pq.child[3]).cost;
 				cost = ccost;
@@ -507,8 +507,8 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 		const Geo &q = e.geo[curr];
 		Node *nd = &node_of(e, curr);
 		curr_depth = q.depth;
-		const int part_size_type = curr_depth < S.max_pred_depth ? PART_2Nx2N : PART_NxN;
-		int position = q.list_index - S.depth_start[curr_depth];
+		const int part_size_type = curr_depth < CFG_MAX_PRED_DEPTH ? PART_2Nx2N : PART_NxN;
+		int position = q.list_index - cfg_depth_start(curr_depth);
 		double cost_luma = 0, cost_chroma = 0;
 		nd->qp = (uint32_t)e.f->qp;
 		if (nd->b_inside && nd->r_inside) {
@@ -530,7 +530,7 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 					sn.prediction_mode = PM_INTRA;
 				}
 				if (cost_luma < node_of(e, parent).cost && (nd->b_inside && nd->r_inside)) {
-					position = e.geo[e.geo[parent].child[0]].list_index - S.depth_start[curr_depth];
+					position = e.geo[e.geo[parent].child[0]].list_index - cfg_depth_start(curr_depth);
 					cost_chroma = encode_intra_chroma(g, e, curr_depth, position, part_size_type);
 					nd->cost += (uint32_t)cost_chroma;
 					cost_sum[curr_depth] += (uint32_t)cost_chroma;
@@ -540,7 +540,7 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 			}
 		}
 		depth_state[curr_depth]++;
-		if (curr_depth < S.max_pred_depth && nd->tl_inside) {
+		if (curr_depth < CFG_MAX_PRED_DEPTH && nd->tl_inside) {
 			curr_depth++;
 			parent = curr;
 		} else if (depth_state[curr_depth] == 4) {
@@ -550,11 +550,11 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 				const double cost = ccost;
 				depth_state[curr_depth] = 0;
 				const double best_cost = node_of(e, parent).cost;
-				consolidate_prediction_info(g, e, parent, (uint32_t)best_cost, (uint32_t)cost, curr_depth == S.max_pred_depth, cost_sum);
+				consolidate_prediction_info(g, e, parent, (uint32_t)best_cost, (uint32_t)cost, curr_depth == CFG_MAX_PRED_DEPTH, cost_sum);
 				cost_sum[curr_depth] = 0;
 				curr_depth--;
 				parent = e.geo[parent].parent;
-				if (S.perf_mode <= 2 && curr_depth > 0 && curr_depth < S.max_pred_depth && depth_state[curr_depth] < 4 && node_of(e, 0).b_inside && node_of(e, 0).r_inside) {
+				if (S.perf_mode <= 2 && curr_depth > 0 && curr_depth < CFG_MAX_PRED_DEPTH && depth_state[curr_depth] < 4 && node_of(e, 0).b_inside && node_of(e, 0).r_inside) {
 					double totalcost = 0;
 					for (int h = 0; h < depth_state[curr_depth]; h++) totalcost += node_of(e, e.geo[parent].child[h]).cost;
 					if (totalcost > node_of(e, parent).cost) depth_state[curr_depth] = 4;
@@ -583,12 +583,12 @@ HENC_HD void create_partition_neighbours(const G &g, Enc &__restrict__ e)
 {
 	const Seq &S = *e.seq;
 	CtuPublic &c = *e.ctu;
-	const int cu_min_tu_size_shift = hmax(S.max_cu_size_shift - (S.max_pred_depth + hmax(S.max_intra_tr_depth, S.max_inter_tr_depth) - 1), 2);
-	const int max_processing_depth = S.max_cu_size_shift - cu_min_tu_size_shift;
+	const int cu_min_tu_size_shift = hmax(CFG_MAX_CU_SHIFT - (CFG_MAX_PRED_DEPTH + hmax(S.max_intra_tr_depth, S.max_inter_tr_depth) - 1), 2);
+	const int max_processing_depth = CFG_MAX_CU_SHIFT - cu_min_tu_size_shift;
 	const int valid_lines = (c.y + 64) > S.height ? S.height - c.y : 64, valid_cols = (c.x + 64) > S.width ? S.width - c.x : 64;
 	const int cx = c.x, cy = c.y, has_left = c.has_left, has_top = c.has_top, has_top_right = c.has_top_right;
 	for (int depth = 0; depth <= max_processing_depth && depth < NDEPTH; depth++) {
-		const int first = S.depth_start[depth], count = 1 << (2 * depth);
+		const int first = cfg_depth_start(depth), count = 1 << (2 * depth);
 		for (int k = g.tid; k < count; k += g.n) {
 			const int curr = first + k;
 			const Geo &q = e.geo.lane(curr);

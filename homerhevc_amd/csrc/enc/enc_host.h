@@ -91,6 +91,8 @@ inline bool make_seq(HostCfg cfg, Seq &s, const char **why)
 	s.rd_mode = clampi(cfg.rd_mode, 0, 2);
 	s.me_precision = cfg.motion_estimation_precision == 0 ? ME_PEL : (cfg.motion_estimation_precision == 1 ? ME_HALF : ME_QUARTER);
 	s.num_merge_cand = 2;
+	static_assert(CFG_MAX_CU_SIZE == 64 && CFG_MAX_CU_SHIFT == 6 && CFG_MAX_PRED_DEPTH == 4 && CFG_NUM_MERGE_CAND == 2, "the decision code's constants (enc_types.h)");
+	if (s.max_cu_depth != CFG_MAX_CU_DEPTH || s.max_pred_depth != CFG_MAX_PRED_DEPTH) { *why = "partition depths other than the built ones"; return false; }
 	s.sign_hiding = cfg.sign_hiding;
 	s.strong_intra = 1;
 	s.chroma_qp_offset = cfg.chroma_qp_offset;

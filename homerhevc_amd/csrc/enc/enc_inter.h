@@ -368,7 +368,7 @@ struct CornerNodes { int lb, tl, tr; };
 HENC_INLINE CornerNodes corner_nodes(Enc &__restrict__ e, int ni)
 {
 	const Geo &q = e.geo[ni];
-	const int np = q.size >> 2, base = e.seq->depth_start[e.seq->max_cu_depth];
+	const int np = q.size >> 2, base = cfg_depth_start(CFG_MAX_CU_DEPTH);
 	CornerNodes c;
 	c.lb = base + raster2abs(q.raster_index + 16 * (np - 1));
 	c.tl = base + raster2abs(q.raster_index);
@@ -465,7 +465,7 @@ HENC_INLINE int equal_motion(const CtuPublic *a, uint32_t ia, const CtuPublic *b
 // get_merge_mvp_candidates :1937, P slice.  inter_modes[k] = inter_mode of candidate k's source unit.
 HENC_INLINE void get_merge_candidates(Enc &__restrict__ e, int ni, MvCandList &l, uint8_t *inter_modes)
 {
-	const int max_cand = e.seq->num_merge_cand;
+	const int max_cand = CFG_NUM_MERGE_CAND;
 	const CornerNodes cn = corner_nodes(e, ni);
 	uint32_t i_l = 0, i_t = 0, i_tr = 0, i_lb = 0, i_tl = 0;
 	int cnt = 0;
@@ -633,8 +633,8 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 	const int nxn = part_size_type != PART_2Nx2N;
 	int parent, curr, initial_state, end_state;
 	uint32_t qp;
-	if (depth == 0 && S.max_cu_size == 64) {
-		parent = S.depth_start[0];
+	if (depth == 0 && CFG_MAX_CU_SIZE == 64) {
+		parent = cfg_depth_start(0);
 		curr = e.geo[parent].child[0];
 		node_of(e, parent).cost = 0x7fffffff;
 		initial_state = part_position & 3;
@@ -648,7 +648,7 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 		qp = node_of(e, curr).qp;
 	}
 	int curr_depth = e.geo[curr].depth;
-	const int log2cu_size = S.max_cu_size_shift - depth;
+	const int log2cu_size = CFG_MAX_CU_SHIFT - depth;
 	const int one_level_nxn = (S.max_inter_tr_depth == 1 && nxn);
 	int cu_min_tu_size_shift;
 	if (log2cu_size < S.min_tu_size_shift + S.max_inter_tr_depth - 1 + one_level_nxn) cu_min_tu_size_shift = S.min_tu_size_shift;
@@ -656,7 +656,7 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 		cu_min_tu_size_shift = log2cu_size - (S.max_inter_tr_depth - 1 + one_level_nxn);
 		if (cu_min_tu_size_shift > S.max_tu_size_shift) cu_min_tu_size_shift = S.max_tu_size_shift;
 	}
-	int max_tr_processing_depth = S.max_cu_size_shift - cu_min_tu_size_shift;
+	int max_tr_processing_depth = CFG_MAX_CU_SHIFT - cu_min_tu_size_shift;
 	if (S.perf_mode >= 1) max_tr_processing_depth = depth == 0 ? 1 : (depth + (nxn ? 1 : 0));
 	if (S.max_inter_tr_depth == 1 && nxn && curr_depth == depth && log2cu_size > max_tr_processing_depth) {
 		parent = curr;

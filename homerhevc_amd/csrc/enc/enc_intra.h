@@ -140,7 +140,7 @@ HENC_HD int intra_mode_search(const G &g, Enc &__restrict__ e, int ni, int depth
 {
 	const Geo &q = e.geo[ni];
 	Work &w = *e.w;
-	const int n = q.size, curr_depth = q.depth, inv_depth = e.seq->max_cu_size_shift - curr_depth;
+	const int n = q.size, curr_depth = q.depth, inv_depth = CFG_MAX_CU_SHIFT - curr_depth;
 	node_fill_refs(g, e, ni, depth + 1, COMP_Y, 1);
 	int preds[3], dirs[2];
 	uint16_t src[2];
@@ -205,7 +205,7 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 	const src_t *orig = w.curr_y + q.y * CTU_STRIDE_Y + q.x;
 	int16_t *quant = tq_ptr(w, wnd, COMP_Y) + (q.abs_index << 4), *iquant = iq_slot(w, COMP_Y, q.abs_index << 4);
 	int16_t *dec = dec_ptr(w, wnd, COMP_Y) + q.y * DEC_STRIDE_Y + q.x;
-	const int inv_depth = e.seq->max_cu_size_shift - curr_depth;
+	const int inv_depth = CFG_MAX_CU_SHIFT - curr_depth;
 	const int filt = intra_is_filtered(cu_mode, inv_depth);
 	node_fill_refs(g, e, ni, wnd, COMP_Y, filt);
 	intra_predict(g, pred, CTU_STRIDE_Y, filt ? w.adi_f : w.adi, n, cu_mode, 1);
@@ -257,8 +257,8 @@ HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, i
 	{ HENC_PROF_T0(); bitcost_cu_mode = intra_mode_search(g, e, top_ni, depth, &cu_mode, &search_cost); HENC_PROF_ADD(e, PF_INTRA_SEARCH); }
 
 	int parent, curr, initial_state, end_state;
-	if (depth == 0 && S.max_cu_size == 64) {
-		parent = S.depth_start[0];
+	if (depth == 0 && CFG_MAX_CU_SIZE == 64) {
+		parent = cfg_depth_start(0);
 		curr = e.geo[parent].child[0];
 		node_of(e, parent).cost = 0x7fffffff;
 		initial_state = part_position & 3;
@@ -270,14 +270,14 @@ HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, i
 		end_state = initial_state + 1;
 	}
 	int curr_depth = e.geo[curr].depth;
-	const int log2cu_size = S.max_cu_size_shift - (depth - (part_size_type == PART_NxN));
+	const int log2cu_size = CFG_MAX_CU_SHIFT - (depth - (part_size_type == PART_NxN));
 	int cu_min_tu_size_shift;
 	if (log2cu_size < S.min_tu_size_shift + S.max_intra_tr_depth - 1 + (part_size_type == PART_NxN)) cu_min_tu_size_shift = S.min_tu_size_shift;
 	else {
 		cu_min_tu_size_shift = log2cu_size - (S.max_intra_tr_depth - 1 + (part_size_type == PART_NxN));
 		if (cu_min_tu_size_shift > 5) cu_min_tu_size_shift = 5;
 	}
-	int max_tr_processing_depth = S.max_cu_size_shift - cu_min_tu_size_shift;
+	int max_tr_processing_depth = CFG_MAX_CU_SHIFT - cu_min_tu_size_shift;
 	if (S.perf_mode >= 1)
 		max_tr_processing_depth = (depth + 2 <= max_tr_processing_depth) ? depth + 2 : ((depth + 1 <= max_tr_processing_depth) ? depth + 1 : max_tr_processing_depth);
 
@@ -440,8 +440,8 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth,
 	const double weight = e.f->chroma_weight;
 	const int qp_chroma = chroma_qp_table((int)node_of(e, curr).qp + S.chroma_qp_offset);
 	const int per = qp_chroma / 6, rem = qp_chroma % 6;
-	if (depth == 0 && S.max_cu_size == 64) {
-		parent = S.depth_start[0];
+	if (depth == 0 && CFG_MAX_CU_SIZE == 64) {
+		parent = cfg_depth_start(0);
 		curr = e.geo[parent].child[0];
 	} else parent = e.geo[curr].parent;
 	const int luma_mode = w.intra_mode_buffs[COMP_Y][depth][e.geo[curr].abs_index];   // written by the luma pass just before: never a token
@@ -503,8 +503,8 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth,
 		int cbf_split[2][NDEPTH] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
 		int partition_cost[4];
 		if (cu_mode == DM_CHROMA_IDX) cu_mode = luma_mode;
-		if (depth == 0 && S.max_cu_size == 64) {
-			parent = S.depth_start[0];
+		if (depth == 0 && CFG_MAX_CU_SIZE == 64) {
+			parent = cfg_depth_start(0);
 			curr = e.geo[parent].child[0];
 		} else {
 			curr = node_at(e, depth, part_position);
@@ -580,7 +580,7 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth,
 			}
 		}
 		(void)broke;
-		if (depth == 0) top = S.depth_start[0];
+		if (depth == 0) top = cfg_depth_start(0);
 		else {
 			top = node_at(e, depth, part_position);
 			if (nxn) top = e.geo[top].parent;

@@ -115,6 +115,11 @@ struct CtuInfo : CtuPublic {
 	Node nodes[NNODES];
 };
 
+// What make_seq (enc_host.h) fixes for every configuration it accepts: the decision code uses the constants (a read of Seq is a trip to LDS and keeps the
+// compiler from folding the arithmetic around it); Seq keeps the fields for the host stages and as the record of what was checked.
+constexpr int CFG_MAX_CU_SIZE = 64, CFG_MAX_CU_SHIFT = 6, CFG_MAX_PRED_DEPTH = 4, CFG_MAX_CU_DEPTH = 4, CFG_NUM_MERGE_CAND = 2;
+HENC_INLINE constexpr int cfg_depth_start(int depth) { return ((1 << (2 * depth)) - 1) / 3; }      // 0, 1, 5, 21, 85: the first node of a depth
+
 struct Seq {
 	int32_t width, height;                 // luma picture size (multiple of the minimum CU)
 	int32_t wctu, hctu, nctu;
