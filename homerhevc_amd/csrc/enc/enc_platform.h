@@ -33,9 +33,9 @@ struct WaveGrp {
 	// helper wavefronts that are doing something else, see HelperBox in enc_common.h)
 	__device__ __forceinline__ void sync() const
 	{
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	}
 	// wave-wide sum without LDS traffic: row shifts (DPP) inside the 16-lane rows, then the four row totals through readlane
 	__device__ __forceinline__ uint32_t sum(uint32_t v) const
