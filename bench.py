@@ -290,7 +290,7 @@ def measure(step, warmup, nframes, world, device_sync, device, flush=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2-1080p-encode", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
