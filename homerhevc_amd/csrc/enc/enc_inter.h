@@ -559,8 +559,8 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 	// dequantised-coefficient buffer (dequantised in place afterwards), the reconstructed residual in scratch_b (the reference's separate window, which
 	// nothing else reads); only the final levels and the reconstruction go to the windows in HBM.
 	int16_t *rdec = e.scratch_b;
-	tr_forward(g, e.ft, e.T, resid, cs, e.scratch_a, e.scratch_b, n, 0);
-	int sum = quantize(g, e.ft, e.T, e.scratch_a, iquant, e.scratch_b, SCAN_DIAG, curr_depth, comp, 0, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
+	tr_forward(g, HENC_FT(e), e.T, resid, cs, e.scratch_a, e.scratch_b, n, 0);
+	int sum = quantize(g, HENC_FT(e), e.T, e.scratch_a, iquant, e.scratch_b, SCAN_DIAG, curr_depth, comp, 0, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
 	nd.inter_cbf[comp] = (sum ? 1 : 0) << (original_depth - depth);
 	if (is_y) nd.inter_tr_idx = original_depth - depth;
 	uint32_t ssd;
@@ -568,8 +568,8 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 		lin_copy_nosync(g, iquant, quant, n * n);
 		const uint32_t raw_zero = blk_ssq(g, resid, cs, n);
 		if (raw_ssq) *raw_ssq = raw_zero;
-		dequantize(g, e.ft, e.T, iquant, iquant, curr_depth, comp, 0, n, per, rem);
-		tr_inverse(g, e.ft, e.T, rdec, n, iquant, e.scratch_a, n, 0);
+		dequantize(g, HENC_FT(e), e.T, iquant, iquant, curr_depth, comp, 0, n, per, rem);
+		tr_inverse(g, HENC_FT(e), e.T, rdec, n, iquant, e.scratch_a, n, 0);
 		const uint32_t raw = blk_ssd(g, resid, cs, rdec, n, n);
 		uint32_t ssd_zero;
 		if (is_y) { ssd_zero = raw_zero; ssd = raw; }

@@ -211,8 +211,8 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 	intra_predict(g, pred, CTU_STRIDE_Y, filt ? w.adi_f : w.adi, n, cu_mode, 1);
 	blk_predict(g, orig, CTU_STRIDE_Y, pred, CTU_STRIDE_Y, resid, CTU_STRIDE_Y, n);
 	// transform chain in fast memory (see encode_inter_tu): levels in the block's slot of the dequantised-coefficient buffer, to the window in HBM when final
-	tr_forward(g, e.ft, e.T, resid, CTU_STRIDE_Y, w.pred_aux, w.delta_u, n, cu_mode != REG_DCT);
-	const int sum = quantize(g, e.ft, e.T, w.pred_aux, iquant, w.delta_u, scan_mode, curr_depth, COMP_Y, 1, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
+	tr_forward(g, HENC_FT(e), e.T, resid, CTU_STRIDE_Y, w.pred_aux, w.delta_u, n, cu_mode != REG_DCT);
+	const int sum = quantize(g, HENC_FT(e), e.T, w.pred_aux, iquant, w.delta_u, scan_mode, curr_depth, COMP_Y, 1, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
 	*curr_sum = sum;
 	const int tr = curr_depth - depth + (part_size_type == PART_NxN);
 	nd.sum = (uint32_t)sum;
@@ -221,8 +221,8 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 	nd.intra_mode[COMP_Y] = cu_mode;
 	if (sum) {
 		lin_copy_nosync(g, iquant, quant, n * n);
-		dequantize(g, e.ft, e.T, iquant, iquant, curr_depth, COMP_Y, 1, n, per, rem);
-		tr_inverse(g, e.ft, e.T, resid, CTU_STRIDE_Y, iquant, w.pred_aux, n, cu_mode != REG_DCT);
+		dequantize(g, HENC_FT(e), e.T, iquant, iquant, curr_depth, COMP_Y, 1, n, per, rem);
+		tr_inverse(g, HENC_FT(e), e.T, resid, CTU_STRIDE_Y, iquant, w.pred_aux, n, cu_mode != REG_DCT);
 		return blk_reconst_ssd(g, pred, CTU_STRIDE_Y, resid, CTU_STRIDE_Y, orig, CTU_STRIDE_Y, dec, DEC_STRIDE_Y, n);
 	}
 	lin_zero_nosync(g, quant, n * n);
@@ -402,15 +402,15 @@ HENC_HD int chroma_tu_comp(const G &g, Enc &__restrict__ e, int curr, int c, int
 	node_fill_refs(g, e, curr, dwnd, c, 0);
 	intra_predict(g, pred, CTU_STRIDE_C, e.adi_c, n, cu_mode, 0);
 	blk_predict(g, orig, CTU_STRIDE_C, pred, CTU_STRIDE_C, resid, CTU_STRIDE_C, n);
-	tr_forward(g, e.ft, e.T, resid, CTU_STRIDE_C, e.scratch_a, e.scratch_b, n, 0);
-	const int curr_sum = quantize(g, e.ft, e.T, e.scratch_a, iquant, e.scratch_b, scan_mode, curr_depth, c, 1, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
+	tr_forward(g, HENC_FT(e), e.T, resid, CTU_STRIDE_C, e.scratch_a, e.scratch_b, n, 0);
+	const int curr_sum = quantize(g, HENC_FT(e), e.T, e.scratch_a, iquant, e.scratch_b, scan_mode, curr_depth, c, 1, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
 	const int cbfv = ((curr_sum ? 1 : 0) << (shifts & 255)) | ((curr_sum ? 1 : 0) << (shifts >> 8));
 	bytes_set(g, &w.cbf_chroma[c - 1][q.abs_index], cbfv, q.num_part);
 	uint32_t raw;
 	if (curr_sum) {
 		lin_copy_nosync(g, iquant, quant, n * n);
-		dequantize(g, e.ft, e.T, iquant, iquant, curr_depth, c, 1, n, per, rem);
-		tr_inverse(g, e.ft, e.T, resid, CTU_STRIDE_C, iquant, e.scratch_a, n, 0);
+		dequantize(g, HENC_FT(e), e.T, iquant, iquant, curr_depth, c, 1, n, per, rem);
+		tr_inverse(g, HENC_FT(e), e.T, resid, CTU_STRIDE_C, iquant, e.scratch_a, n, 0);
 		raw = blk_reconst_ssd(g, pred, CTU_STRIDE_C, resid, CTU_STRIDE_C, orig, CTU_STRIDE_C, dec, DEC_STRIDE_C, n);
 	} else {
 		lin_zero_nosync(g, quant, n * n);

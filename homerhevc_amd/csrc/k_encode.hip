@@ -75,6 +75,7 @@ namespace henc { __constant__ Geo henc_geo_table[NNODES]; }
 // it in HBM: measured in round 2 to make no difference) and the TU tables (FastTables: transform bases, scans, quantiser cells - from DevTables through L2
 // instead: 1-2 % per worker, against twice the workers).  Set to true to get them back (one worker per CU).
 constexpr bool LDS_KEEPS_CTU_RECORD = false, LDS_KEEPS_TU_TABLES = false;
+static_assert(LDS_KEEPS_TU_TABLES == (HENC_TU_TABLES_IN_LDS != 0), "enc_platform.h: HENC_FT");
 constexpr size_t LDS_SEQ = (sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15, LDS_CTU = LDS_KEEPS_CTU_RECORD ? (sizeof(CtuPublic) + 15) & ~(size_t)15 : 0,
 		 LDS_FT = LDS_KEEPS_TU_TABLES ? (sizeof(FastTables) + 15) & ~(size_t)15 : 0;
 #if defined(HENC_PROFILE)
