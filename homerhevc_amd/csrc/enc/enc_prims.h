@@ -739,14 +739,15 @@ HENC_INLINE uint32_t ft_list_value(const uint16_t *cells, uint32_t flat, int i, 
 	return cells[((y >> s) << 3) | (x >> s)];
 }
 // the same for the four elements i0 .. i0 + 3 of a row (i0 a multiple of 4): one, two or four cells
-HENC_INLINE void ft_list_value4(const uint16_t *cells, uint32_t flat, int i0, int log2n, uint32_t *v)
+template <class CellT>      // uint16_t: the cells cached in FastTables; int32_t: the 8 x 8 lists of DevTables themselves
+HENC_INLINE void ft_list_value4(const CellT *cells, uint32_t flat, int i0, int log2n, uint32_t *v)
 {
 	if (log2n == 2) { v[0] = v[1] = v[2] = v[3] = flat; return; }
 	const int s = log2n - 3, y = i0 >> log2n, x = i0 & ((1 << log2n) - 1);
-	const uint16_t *c = cells + (((y >> s) << 3) | (x >> s));
-	if (s == 0) { v[0] = c[0]; v[1] = c[1]; v[2] = c[2]; v[3] = c[3]; }
-	else if (s == 1) { v[0] = v[1] = c[0]; v[2] = v[3] = c[1]; }
-	else v[0] = v[1] = v[2] = v[3] = c[0];
+	const CellT *c = cells + (((y >> s) << 3) | (x >> s));
+	if (s == 0) { v[0] = (uint32_t)c[0]; v[1] = (uint32_t)c[1]; v[2] = (uint32_t)c[2]; v[3] = (uint32_t)c[3]; }
+	else if (s == 1) { v[0] = v[1] = (uint32_t)c[0]; v[2] = v[3] = (uint32_t)c[1]; }
+	else v[0] = v[1] = v[2] = v[3] = (uint32_t)c[0];
 	if (i0 == 0 && log2n > 3) v[0] = flat;
 }
 template <class G>
@@ -1017,11 +1018,9 @@ HENC_PRIM int quantize(const G &g, const FastTables *F, const DevTables *T, cons
 	const int32_t add = (int32_t)((uint32_t)(slice_is_intra ? 171 : 85) << (qbits - 9));
 	const int total = n * n;
 	uint32_t sum = 0;
-	const int32_t *q = T->quant[inv_depth - 2][list][rem];
-	const uint16_t *cells = fast ? F->q8[rc][ft_list_kind(inv_depth, list)] : nullptr;
-	const uint32_t flat = fast ? F->q_flat[rc] : 0;
-	if (fast) {
-		// four coefficients per lane and step; the list values from the 8 x 8 cells in fast memory
+	// four coefficients per lane and step; a list value is its 8 x 8 cell (DC of the replicated sizes and every 4 x 4 entry: the flat value) - from the cells cached
+	// in fast memory when F holds this QP remainder, else from the 8 x 8 lists of T themselves (the per-position lists of the larger sizes are never read)
+	auto run = [&](const auto *cells, uint32_t flat) {
 #pragma unroll 2
 		for (int i = g.tid * 4; i < total; i += g.n * 4) {
 			const S4 sv4 = ld4(src + i);
@@ -1043,21 +1042,10 @@ HENC_PRIM int quantize(const G &g, const FastTables *F, const DevTables *T, cons
 			st4(dst + i, lv);
 			st4(delta_u + i, du);
 		}
-	} else {
-	#pragma unroll 4
-	for (int i = g.tid; i < total; i += g.n) {
-		const int sv = src[i];
-		const uint32_t a = (uint16_t)(sv < 0 ? -sv : sv);
-		const uint32_t qv = (uint32_t)q[i];
-		const int32_t aux = (int32_t)(a * qv);
-		const int32_t c = (int32_t)((uint32_t)aux + (uint32_t)add) >> qbits;
-		const int32_t d = (int32_t)((uint32_t)aux - ((uint32_t)c << qbits)) >> qbits8;
-		const int sgn = sv > 0 ? 1 : (sv < 0 ? -1 : 0);
-		sum += (uint32_t)c;
-		dst[i] = (int16_t)(sgn * sat16(c));
-		delta_u[i] = sat16(d);
-	}
-	}
+	};
+	const int kind = ft_list_kind(inv_depth, list);
+	if (fast) run(F->q8[rc][kind], (uint32_t)F->q_flat[rc]);
+	else run(T->quant[1][kind ? 3 : 0][rem], (uint32_t)(uint16_t)T->quant[0][0][rem][0]);
 	const int ac_sum = (int)g.sum(sum);
 	g.sync();
 	if (sign_hiding && ac_sum >= 2) {
@@ -1075,13 +1063,10 @@ HENC_PRIM void dequantize(const G &g, const FastTables *F, const DevTables *T, c
 	const int inv_depth = 6 - (depth + (comp != 0));
 	const int list = is_intra ? 0 : 3 + comp, rc = comp != 0;      // (the reference's expression: intra blocks of every component use list 0)
 	const bool fast = F && F->valid && F->rem[rc] == rem;
-	const int32_t *iq = T->dequant[inv_depth - 2][list][rem];
-	const uint16_t *cells = fast ? F->iq8[rc][ft_list_kind(inv_depth, list)] : nullptr;
-	const uint32_t flat = fast ? F->iq_flat[rc] : 0;
 	const int iq_shift = 20 - 14 - (15 - 8 - inv_depth) + 4, total = n * n;
-	if (fast) {
-		const int32_t add = iq_shift > per ? 1 << (iq_shift - per - 1) : 0;
-		const int sh = iq_shift > per ? iq_shift - per : per - iq_shift;
+	const int32_t add = iq_shift > per ? 1 << (iq_shift - per - 1) : 0;
+	const int sh = iq_shift > per ? iq_shift - per : per - iq_shift;
+	auto run = [&](const auto *cells, uint32_t flat) {      // (as in quantize: the 8 x 8 cells, cached or from T)
 		for (int i = g.tid * 4; i < total; i += g.n * 4) {
 			const S4 lv = ld4(src + i);
 			uint32_t v[4];
@@ -1092,14 +1077,10 @@ HENC_PRIM void dequantize(const G &g, const FastTables *F, const DevTables *T, c
 				o.v[k] = iq_shift > per ? sat16((int32_t)((uint32_t)(int32_t)lv.v[k] * v[k] + (uint32_t)add) >> sh) : sat16((int32_t)(((uint32_t)(int32_t)lv.v[k] * v[k]) << sh));
 			st4(dst + i, o);
 		}
-	} else if (iq_shift > per) {
-		const int32_t add = 1 << (iq_shift - per - 1);
-		const int sh = iq_shift - per;
-		for (int i = g.tid; i < total; i += g.n) dst[i] = sat16((int32_t)((uint32_t)(int32_t)src[i] * (uint32_t)iq[i] + (uint32_t)add) >> sh);
-	} else {
-		const int sh = per - iq_shift;
-		for (int i = g.tid; i < total; i += g.n) dst[i] = sat16((int32_t)(((uint32_t)(int32_t)src[i] * (uint32_t)iq[i]) << sh));
-	}
+	};
+	const int kind = ft_list_kind(inv_depth, list);
+	if (fast) run(F->iq8[rc][kind], (uint32_t)F->iq_flat[rc]);
+	else run(T->dequant[1][kind ? 3 : 0][rem], (uint32_t)(uint16_t)T->dequant[0][0][rem][0]);
 	g.sync();
 	PRIM_END(PP_DEQUANT);
 }
