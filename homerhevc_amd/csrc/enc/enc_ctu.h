@@ -188,8 +188,8 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth,
 	const int abs_index = q.abs_index, curr_depth = q.depth, n = q.size, nc = q.size_chroma;
 	const int gx = e.ctu_x + q.x, gy = e.ctu_y + q.y;
 	int merge_cand_buffer[5] = {0, 0, 0, 0, 0};
-	int best_is_skip = 0, best_candidate = 0;
-	uint32_t dist, best_dist = MAX_COST, cost, best_cost = MAX_COST, best_sum = 0;
+	int best_is_skip = 0, best_candidate = 0, have_ctu_cbf = 0;
+	uint32_t dist, best_dist = MAX_COST, cost, best_cost = MAX_COST, best_sum = 0, ctu_cbf = 0;      // ctu_cbf: cbf[0] | cbf[1] | cbf[2] of the CTU record at this CU's first unit
 	MV best_mv = {0, 0};
 	int best_ref_idx = 0;
 	uint8_t inter_modes[5] = {255, 255, 255, 255, 255};
@@ -279,10 +279,16 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth,
 					set_enc_info_buffs(g, e, ni, curr_depth);
 				}
 				put_consolidated_info(g, e, ni, curr_depth);
-				best_is_skip = (((c.cbf[0][abs_index]) | (c.cbf[1][abs_index]) | (c.cbf[2][abs_index])) & 1) == 0;
+				// (the CTU record's cbf of this CU is what put_consolidated_info has just copied there from the worker's buffers of this depth: read from
+				// those - the record lives in HBM, and a store followed by a load of it is a round trip to L2)
+				ctu_cbf = (uint32_t)w.cbf_buffs[0][curr_depth][abs_index] | w.cbf_buffs[1][curr_depth][abs_index] | w.cbf_buffs[2][curr_depth][abs_index];
+				have_ctu_cbf = 1;
+				best_is_skip = (ctu_cbf & 1) == 0;
 			}
-			if (no_res == 0 && ((((c.cbf[0][abs_index] >> curr_depth) | (c.cbf[1][abs_index] >> curr_depth) | (c.cbf[2][abs_index] >> curr_depth)) & 1) == 0))
-				merge_cand_buffer[cand] = 1;
+			if (no_res == 0) {
+				if (!have_ctu_cbf) { ctu_cbf = (uint32_t)c.cbf[0][abs_index] | c.cbf[1][abs_index] | c.cbf[2][abs_index]; have_ctu_cbf = 1; }
+				if (((ctu_cbf >> curr_depth) & 1) == 0) merge_cand_buffer[cand] = 1;
+			}
 		}
 	}
 	nd.skipped = best_is_skip;
