@@ -44,10 +44,19 @@ struct GeoTable {
 #endif
 
 constexpr int NHELP_MAX = 3;
+// the fixed part of a worker's LDS (k_encode.hip checks that its layout agrees)
+constexpr int LDS_OFF_WORK = 0, LDS_OFF_NODES = (int)((sizeof(Work) + 15) & ~(size_t)15), LDS_OFF_SEQ = LDS_OFF_NODES + (int)((sizeof(Node) * NNODES + 15) & ~(size_t)15),
+	      LDS_OFF_FRAME = LDS_OFF_SEQ + (int)((sizeof(Seq) + 15) & ~(size_t)15), LDS_OFF_BOX = LDS_OFF_SEQ + (int)((sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15);
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HENC_AT(T, OFFSET) LdsAt<T, OFFSET>
+#else
+#define HENC_AT(T, OFFSET) FastPtr<T>
+#endif
+
 struct Enc {
 	unsigned long long *prof;   // PF_COUNT accumulators of this worker (profiling build), else unused
-	FastPtr<const Seq> seq;
-	FastPtr<const FrameCtx> f;
+	HENC_AT(const Seq, LDS_OFF_SEQ) seq;
+	HENC_AT(const FrameCtx, LDS_OFF_FRAME) f;
 	const DevTables *T;
 	FastPtr<const FastTables> ft;   // the tables a TU reads, in the worker's fast memory (enc_prims.h)
 	GeoTable geo;
@@ -56,7 +65,7 @@ struct Enc {
 	                          // a plain pointer: FastPtr promises the compiler LDS, which is only true for the copy
 	CtuInfo *ctu_g;        // its home in the picture array (logs, nodes; neighbours are ctu_g - 1, ctu_g - wctu ...)
 	CtuPublic *ctu_fast;
-	FastPtr<Work> w;
+	HENC_AT(Work, LDS_OFF_WORK) w;
 	int16_t *coeff;        // the CTU's coefficient output: 4096 luma + 2 x 1024 chroma, linear per TU in z-order
 	// speculative inputs of a P-frame CTU (enc_ctu.h)
 	uint32_t total_intra_partitions, total_partitions;
@@ -67,10 +76,10 @@ struct Enc {
 	uint32_t nb_ctus;         // which neighbour CTUs exist (bit 0 left, 1 top, 2 top right, 3 top left): CtuPublic::has_*, kept here because the record lives in HBM
 	unsigned long long *timeline;   // profiling build: the CTU's timestamps
 	int n_spec_reads, n_ratio_cmp, last_slog;
-	FastPtr<Node> nodes;      // the CTU's partition nodes: ctu->nodes, or the worker's fast copy of them (nodes_fast != nullptr) while the CTU is encoded
+	HENC_AT(Node, LDS_OFF_NODES) nodes;      // the CTU's partition nodes: ctu->nodes, or the worker's fast copy of them (nodes_fast != nullptr) while the CTU is encoded
 	Node *nodes_fast;
 	// helper wavefronts of the worker (device only; nullptr = everything runs on the group itself)
-	FastPtr<struct HelperBox> box;
+	HENC_AT(struct HelperBox, LDS_OFF_BOX) box;
 	FastPtr<int16_t> adi_c;              // neighbour array of a chroma block: Work::adi, or a helper's own
 	FastPtr<int16_t> mc_tmp_y;           // first-stage buffer of a two-stage luma interpolation (and its row pitch): Work::sub_tmp / 72, or a helper's own
 	int mc_tmp_y_stride;

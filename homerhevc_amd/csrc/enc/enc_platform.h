@@ -102,6 +102,24 @@ struct FastPtr {
 	HENC_INLINE FastPtr &operator=(T *q) { p = q; return *this; }
 };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// A member that IS a fixed place in the workgroup's LDS (the worker's Work, the CTU's nodes, the sequence / frame parameters, the helper mailbox: k_encode.hip lays
+// them out at constant offsets).  As FastPtr members of Enc these pointers were data - and Enc, whose address goes to every out-of-line function of the walk, lives
+// in private memory: each `e.w->` began with a scratch load.  An LdsAt holds nothing; assignments to it are accepted and ignored (the kernels still "set" them).
+extern __shared__ __align__(16) unsigned char henc_lds_base[];
+template <class T, int OFFSET>
+struct LdsAt {
+	HENC_INLINE T *get() const { return (T *)(henc_lds_base + OFFSET); }
+	HENC_INLINE T *operator->() const { return get(); }
+	HENC_INLINE T &operator*() const { return *get(); }
+	HENC_INLINE T &operator[](int i) const { return get()[i]; }
+	HENC_INLINE operator T *() const { return get(); }
+	HENC_INLINE explicit operator bool() const { return true; }
+	HENC_INLINE LdsAt &operator=(T *) { return *this; }
+	HENC_INLINE LdsAt &operator=(decltype(nullptr)) { return *this; }
+};
+#endif
+
 struct CpuGrp {
 	static constexpr int tid = 0;
 	static constexpr int n = 1;

@@ -88,6 +88,8 @@ constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH 
 constexpr size_t LDS_BYTES = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH + LDS_FT;
 constexpr size_t LDS_FT_OFFSET = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH;
 #endif
+static_assert(LDS_OFF_NODES == (int)LDS_WORK && LDS_OFF_SEQ == (int)(LDS_WORK + LDS_NODES + LDS_GEO) && LDS_OFF_BOX == (int)(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU),
+	      "enc_common.h: the fixed places of Enc's LDS members");
 constexpr int ENC_THREADS = 64 * (1 + NHELP);   // the row worker + its helper wavefronts: one wavefront per SIMD of the CU
 static_assert(LDS_BYTES <= 160 * 1024, "a workgroup has 160 KiB of LDS on gfx950");
 constexpr int WORKERS_PER_CU = LDS_BYTES <= 80 * 1024 ? 2 : 1;
@@ -687,7 +689,7 @@ struct SaoDecideJob {
 	int *progress;
 	int enabled, pad_;
 };
-__global__ __launch_bounds__(1024) void k_sao_decide_batch(const SaoDecideJob *jobs)
+__global__ __launch_bounds__(256) void k_sao_decide_batch(const SaoDecideJob *jobs)      // (256 threads = 256 CTU rows = 16384 lines; 1024 would cap the decision at 128 registers: 2000 spills)
 {
 	const SaoDecideJob &j = jobs[blockIdx.x];
 	if (!j.enabled) return;
@@ -1781,7 +1783,7 @@ int batch_finish(hmr_gpu_enc **encs, int n, const int *slots, int pitch, BatchTi
 		if (any) {
 			if (!lead->d_sao_jobs) HIP_TRY(hipMalloc((void **)&lead->d_sao_jobs, 256 * sizeof(SaoDecideJob)));
 			HIP_TRY(hipMemcpyAsync(lead->d_sao_jobs, jobs.data(), n * sizeof(SaoDecideJob), hipMemcpyHostToDevice, bst));
-			if (max_rows > 1024) { hmr_set_error("hmr_gpu_enc_encode_batch: more than 1024 CTU rows"); return HMR_GPU_ERR_ARG; }
+			if (max_rows > 256) { hmr_set_error("hmr_gpu_enc_encode_batch: more than 256 CTU rows"); return HMR_GPU_ERR_ARG; }
 			hipLaunchKernelGGL(k_sao_decide_batch, dim3(n), dim3((max_rows + 63) / 64 * 64), 0, bst, (const SaoDecideJob *)lead->d_sao_jobs);
 			HIP_TRY(hipGetLastError());
 		}
