@@ -88,9 +88,26 @@ HENC_HD void put_consolidated_info(const G &g, Enc &__restrict__ e, int ni, int 
 	sync_motion_buffers(g, e, ni, depth + 1, 0, depth + 1, 0);
 }
 
-// consolidate_prediction_info :3372
+// The walks below keep a state (0 .. 4: which child is next) and a running cost per depth and address both with the current depth.  Registers cannot be
+// indexed with a run-time value: as arrays they lived in private memory, a trip to scratch per access (seen in the ISA).  DepthState packs the five states into
+// one word; DepthCosts keeps five scalars and selects with compares.  Both are plain values (nothing takes their address).
+struct DepthState {
+	uint32_t bits = 0;
+	HENC_INLINE int get(int d) const { return (int)((bits >> (4 * d)) & 15u); }
+	HENC_INLINE void set(int d, int v) { bits = (bits & ~(15u << (4 * d))) | ((uint32_t)v << (4 * d)); }
+	HENC_INLINE void inc(int d) { bits += 1u << (4 * d); }
+};
+struct DepthCosts {
+	uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+	HENC_INLINE uint32_t get(int d) const { return d == 0 ? v0 : (d == 1 ? v1 : (d == 2 ? v2 : (d == 3 ? v3 : v4))); }
+	HENC_INLINE void set(int d, uint32_t x) { v0 = d == 0 ? x : v0; v1 = d == 1 ? x : v1; v2 = d == 2 ? x : v2; v3 = d == 3 ? x : v3; v4 = d == 4 ? x : v4; }
+	HENC_INLINE void add(int d, uint32_t x) { set(d, get(d) + x); }
+};
+
+// consolidate_prediction_info :3372.  Returns true when the children were taken (the caller's running cost of the parent's depth then changes by
+// children_cost - parent_cost, as the reference does inside).
 template <class G>
-HENC_HD void consolidate_prediction_info(const G &g, Enc &__restrict__ e, int pi, uint32_t parent_cost, uint32_t children_cost, int is_max_depth, uint32_t *cost_sum)
+HENC_HD bool consolidate_prediction_info(const G &g, Enc &__restrict__ e, int pi, uint32_t parent_cost, uint32_t children_cost, int is_max_depth)
 {
 	const Geo &pq = e.geo[pi];
 	Node &pn = node_of(e, pi);
@@ -101,10 +118,6 @@ HENC_HD void consolidate_prediction_info(const G &g, Enc &__restrict__ e, int pi
 		children_sum = node_of(e, pq.child[0]).sum + node_of(e, pq.child[1]).sum + node_of(e, pq.child[2]).sum + node_of(e, pq.child[3]).sum;
 	if (children_cost < parent_cost || !(pn.b_inside && pn.r_inside)) {
 		const int part2 = curr_depth < CFG_MAX_PRED_DEPTH ? PART_2Nx2N : PART_NxN;
-		if (cost_sum) {
-			cost_sum[pq.depth] -= parent_cost;
-			cost_sum[pq.depth] += children_cost;
-		}
 		pn.cost = children_cost;
 		pn.distortion = node_of(e, pq.child[0]).distortion + node_of(e, pq.child[1]).distortion + node_of(e, pq.child[2]).distortion + node_of(e, pq.child[3]).distortion;
 		pn.sum = children_sum;
@@ -124,6 +137,7 @@ HENC_HD void consolidate_prediction_info(const G &g, Enc &__restrict__ e, int pi
 			}
 			g.sync();
 		}
+		return true;
 	} else {
 		const int part2 = pq.depth < CFG_MAX_PRED_DEPTH ? PART_2Nx2N : PART_NxN;
 		const int parent_depth = pq.depth;
@@ -138,6 +152,7 @@ HENC_HD void consolidate_prediction_info(const G &g, Enc &__restrict__ e, int pi
 		}
 		g.sync();
 	}
+	return false;
 }
 
 // the reference-sample refresh after a CU (sub)tree is final: bottom row / right column of the consolidated reconstruction
@@ -339,12 +354,12 @@ HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &__restrict__ e)
 	CtuPublic &c = *e.ctu;
 	const double avg_distortion = e.f->avg_dist;
 	const int perf_min_depth = S.perf_min_depth, perf_fast_skip = S.perf_fast_skip;
-	int depth_state[NDEPTH] = {0, 0, 0, 0, 0};
-	uint32_t cost_sum[NDEPTH] = {0, 0, 0, 0, 0};
+	DepthState depth_state;
+	DepthCosts cost_sum;
 	int curr_depth = 0, parent = -1, curr = 0;
 	double dist = 0, best_cost;
 	const int root = 0;
-	while (curr_depth != 0 || depth_state[curr_depth] != 1) {
+	while (curr_depth != 0 || depth_state.get(curr_depth) != 1) {
 		double cost = 0, intra_cost = 0;
 		int stop_recursion = 0, is_skipped = 0;
 		const Geo &q = e.geo[curr];
@@ -419,7 +434,7 @@ HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &__restrict__ e)
 						       (nd.sum == 0 && dist < avg_distortion * num_part_in_cu))) {
 					if (nd.merge_flag) get_back_consolidated_info(g, e, curr, curr_depth);
 					stop_recursion = 1;
-					consolidate_prediction_info(g, e, curr, nd.cost, MAX_COST, 0, (uint32_t *)nullptr);
+					(void)consolidate_prediction_info(g, e, curr, nd.cost, MAX_COST, 0);
 					refresh_deeper_windows(g, e, curr, curr_depth, 1);
 				}
 				if (perf_fast_skip && (curr_depth >= perf_min_depth && !stop_recursion && !is_skipped && (q.size < 32 || sad > 400u * num_part_in_cu))) {
@@ -463,36 +478,36 @@ HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &__restrict__ e)
 			} else {
 				// NxN level.  Inter NxN needs a parent larger than 8x8 (:4061), which the 8x8 minimum CU of the built configurations excludes.
 				cost = dist = nd.cost = nd.distortion = MAX_COST;
-				depth_state[curr_depth] = 3;
+				depth_state.set(curr_depth, 3);
 			}
 		} else {
 			nd.cost = MAX_COST;
 		}
-		cost_sum[curr_depth] += nd.cost;
-		depth_state[curr_depth]++;
+		cost_sum.add(curr_depth, nd.cost);
+		depth_state.inc(curr_depth);
 		if (curr_depth < CFG_MAX_PRED_DEPTH && nd.tl_inside && !stop_recursion) {
 			curr_depth++;
 			parent = curr;
-		} else if (depth_state[curr_depth] == 4) {
-			while (depth_state[curr_depth] == 4 && curr_depth > 0) {
+		} else if (depth_state.get(curr_depth) == 4) {
+			while (depth_state.get(curr_depth) == 4 && curr_depth > 0) {
 				const int is_max_depth = curr_depth == CFG_MAX_PRED_DEPTH;
 				const Geo &pq = e.geo[parent];
 				const uint32_t ccost = node_of(e, pq.child[0]).cost + node_of(e, pq.child[1]).cost + node_of(e, pq.child[2]).cost + node_of(e, pq.child[3]).cost;
 				cost = ccost;
-				depth_state[curr_depth] = 0;
+				depth_state.set(curr_depth, 0);
 				best_cost = node_of(e, parent).cost;
-				consolidate_prediction_info(g, e, parent, (uint32_t)best_cost, (uint32_t)cost, is_max_depth, cost_sum);
-				cost_sum[curr_depth] = 0;
+				if (consolidate_prediction_info(g, e, parent, (uint32_t)best_cost, (uint32_t)cost, is_max_depth)) cost_sum.add(e.geo[parent].depth, (uint32_t)cost - (uint32_t)best_cost);
+				cost_sum.set(curr_depth, 0);
 				curr_depth--;
 				parent = e.geo[parent].parent;
-				if (curr_depth > perf_min_depth && cost_sum[curr_depth] > node_of(e, parent).cost && depth_state[curr_depth] < 4 && node_of(e, root).b_inside &&
+				if (curr_depth > perf_min_depth && cost_sum.get(curr_depth) > node_of(e, parent).cost && depth_state.get(curr_depth) < 4 && node_of(e, root).b_inside &&
 				    node_of(e, root).r_inside)
-					depth_state[curr_depth] = 4;
+					depth_state.set(curr_depth, 4);
 			}
-			const int aux = parent >= 0 ? e.geo[parent].child[(depth_state[curr_depth] + 3) & 3] : root;
+			const int aux = parent >= 0 ? e.geo[parent].child[(depth_state.get(curr_depth) + 3) & 3] : root;
 			refresh_deeper_windows(g, e, aux, curr_depth, 0);
 		}
-		if (parent >= 0) curr = e.geo[parent].child[depth_state[curr_depth]];
+		if (parent >= 0) curr = e.geo[parent].child[depth_state.get(curr_depth)];
 	}
 	return node_of(e, root).cost;
 }
@@ -503,13 +518,13 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 {
 	const Seq &S = *e.seq;
 	CtuPublic &c = *e.ctu;
-	int depth_state[NDEPTH] = {0, 0, 0, 0, 0};
-	uint32_t cost_sum[NDEPTH] = {0, 0, 0, 0, 0};
+	DepthState depth_state;
+	DepthCosts cost_sum;
 	int curr_depth = 0, parent = 0, curr = 0;
 	const int initial_depth = 0, initial_position = 0;
-	depth_state[0] = initial_position;
+	depth_state.set(0, initial_position);
 	e.w->thread_seen_intra = 1;   // (every lane stores the same value) hmr_motion_intra.c:1783: from now on this thread's shadow CTU reads "intra"
-	while (curr_depth != initial_depth || depth_state[curr_depth] != initial_position + 1) {
+	while (curr_depth != initial_depth || depth_state.get(curr_depth) != initial_position + 1) {
 		const Geo &q = e.geo[curr];
 		Node *nd = &node_of(e, curr);
 		curr_depth = q.depth;
@@ -522,7 +537,7 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 				{ HENC_PROF_T0(); cost_luma = encode_intra_luma(g, e, curr_depth, position, part_size_type); HENC_PROF_ADD(e, PF_INTRA_TU); }
 				{ HENC_PROF_T0(); cost_chroma = encode_intra_chroma(g, e, curr_depth, position, part_size_type); HENC_PROF_ADD(e, PF_INTRA_CHROMA); }
 				nd->cost = (uint32_t)(cost_luma + cost_chroma);
-				cost_sum[curr_depth] += nd->cost;
+				cost_sum.add(curr_depth, nd->cost);
 				nd->prediction_mode = PM_INTRA;
 				HENC_TRACE("ICU ctu=%d d=%d abs=%d cost=%u (l %.0f c %.0f) mode=%d\n", c.ctu_number, curr_depth, q.abs_index, nd->cost, cost_luma, cost_chroma, nd->intra_mode[0]);
 			} else {
@@ -532,44 +547,44 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 					sn.qp = (uint32_t)e.f->qp;
 					sn.cost = encode_intra_luma(g, e, curr_depth, position + n, part_size_type);
 					cost_luma += sn.cost;
-					cost_sum[curr_depth] += sn.cost;
+					cost_sum.add(curr_depth, sn.cost);
 					sn.prediction_mode = PM_INTRA;
 				}
 				if (cost_luma < node_of(e, parent).cost && (nd->b_inside && nd->r_inside)) {
 					position = e.geo[e.geo[parent].child[0]].list_index - cfg_depth_start(curr_depth);
 					cost_chroma = encode_intra_chroma(g, e, curr_depth, position, part_size_type);
 					nd->cost += (uint32_t)cost_chroma;
-					cost_sum[curr_depth] += (uint32_t)cost_chroma;
+					cost_sum.add(curr_depth, (uint32_t)cost_chroma);
 				}
 				HENC_TRACE("ICU ctu=%d d=%d abs=%d NxN luma=%.0f chroma=%.0f\n", c.ctu_number, curr_depth, q.abs_index, cost_luma, cost_chroma);
-				depth_state[curr_depth] = 3;
+				depth_state.set(curr_depth, 3);
 			}
 		}
-		depth_state[curr_depth]++;
+		depth_state.inc(curr_depth);
 		if (curr_depth < CFG_MAX_PRED_DEPTH && nd->tl_inside) {
 			curr_depth++;
 			parent = curr;
-		} else if (depth_state[curr_depth] == 4) {
-			while (depth_state[curr_depth] == 4 && curr_depth > initial_depth) {
+		} else if (depth_state.get(curr_depth) == 4) {
+			while (depth_state.get(curr_depth) == 4 && curr_depth > initial_depth) {
 				const Geo &pq = e.geo[parent];
 				const uint32_t ccost = node_of(e, pq.child[0]).cost + node_of(e, pq.child[1]).cost + node_of(e, pq.child[2]).cost + node_of(e, pq.child[3]).cost;
 				const double cost = ccost;
-				depth_state[curr_depth] = 0;
+				depth_state.set(curr_depth, 0);
 				const double best_cost = node_of(e, parent).cost;
-				consolidate_prediction_info(g, e, parent, (uint32_t)best_cost, (uint32_t)cost, curr_depth == CFG_MAX_PRED_DEPTH, cost_sum);
-				cost_sum[curr_depth] = 0;
+				if (consolidate_prediction_info(g, e, parent, (uint32_t)best_cost, (uint32_t)cost, curr_depth == CFG_MAX_PRED_DEPTH)) cost_sum.add(e.geo[parent].depth, (uint32_t)cost - (uint32_t)best_cost);
+				cost_sum.set(curr_depth, 0);
 				curr_depth--;
 				parent = e.geo[parent].parent;
-				if (S.perf_mode <= 2 && curr_depth > 0 && curr_depth < CFG_MAX_PRED_DEPTH && depth_state[curr_depth] < 4 && node_of(e, 0).b_inside && node_of(e, 0).r_inside) {
+				if (S.perf_mode <= 2 && curr_depth > 0 && curr_depth < CFG_MAX_PRED_DEPTH && depth_state.get(curr_depth) < 4 && node_of(e, 0).b_inside && node_of(e, 0).r_inside) {
 					double totalcost = 0;
-					for (int h = 0; h < depth_state[curr_depth]; h++) totalcost += node_of(e, e.geo[parent].child[h]).cost;
-					if (totalcost > node_of(e, parent).cost) depth_state[curr_depth] = 4;
+					for (int h = 0; h < depth_state.get(curr_depth); h++) totalcost += node_of(e, e.geo[parent].child[h]).cost;
+					if (totalcost > node_of(e, parent).cost) depth_state.set(curr_depth, 4);
 				}
 			}
-			const int aux = parent >= 0 ? e.geo[parent].child[(depth_state[curr_depth] + 3) & 3] : 0;
+			const int aux = parent >= 0 ? e.geo[parent].child[(depth_state.get(curr_depth) + 3) & 3] : 0;
 			refresh_deeper_windows(g, e, aux, curr_depth, 1);
 		}
-		if (parent >= 0) curr = e.geo[parent].child[depth_state[curr_depth]];
+		if (parent >= 0) curr = e.geo[parent].child[depth_state.get(curr_depth)];
 	}
 	for (int i = g.tid; i < NPART; i += g.n) {
 		c.mv_ref_idx[i] = -1;
