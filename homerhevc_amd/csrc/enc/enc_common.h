@@ -139,6 +139,29 @@ HENC_HD void helper_wait(const G &g, Enc &__restrict__ e, int h)
 #define HENC_HELPERS(e) false
 #endif
 
+// The quadtree walks (enc_ctu.h, enc_inter.h, enc_intra.h) keep a state (0 .. 4: which child is next) and a running cost per depth and address both with the current depth.  Registers cannot be
+// indexed with a run-time value: as arrays they lived in private memory, a trip to scratch per access (seen in the ISA).  DepthState packs the five states into
+// one word; DepthCosts keeps five scalars and selects with compares.  Both are plain values (nothing takes their address).
+struct DepthState {
+	uint32_t bits = 0;
+	HENC_INLINE int get(int d) const { return (int)((bits >> (4 * d)) & 15u); }
+	HENC_INLINE void set(int d, int v) { bits = (bits & ~(15u << (4 * d))) | ((uint32_t)v << (4 * d)); }
+	HENC_INLINE void inc(int d) { bits += 1u << (4 * d); }
+};
+struct DepthCosts {
+	uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+	HENC_INLINE uint32_t get(int d) const { return d == 0 ? v0 : (d == 1 ? v1 : (d == 2 ? v2 : (d == 3 ? v3 : v4))); }
+	HENC_INLINE void set(int d, uint32_t x) { v0 = d == 0 ? x : v0; v1 = d == 1 ? x : v1; v2 = d == 2 ? x : v2; v3 = d == 3 ? x : v3; v4 = d == 4 ? x : v4; }
+	HENC_INLINE void add(int d, uint32_t x) { set(d, get(d) + x); }
+};
+
+struct DepthInts4 {      // four ints addressed by a run-time index (a chroma CU's per-partition costs)
+	int v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+	HENC_INLINE int get(int i) const { return i == 0 ? v0 : (i == 1 ? v1 : (i == 2 ? v2 : v3)); }
+	HENC_INLINE void set(int i, int x) { v0 = i == 0 ? x : v0; v1 = i == 1 ? x : v1; v2 = i == 2 ? x : v2; v3 = i == 3 ? x : v3; }
+	HENC_INLINE void add(int i, int x) { set(i, get(i) + x); }
+};
+
 HENC_INLINE Node &node_of(Enc &__restrict__ e, int idx) { return e.nodes[idx]; }
 HENC_INLINE int node_at(const Enc &__restrict__ e, int depth, int position) { return cfg_depth_start(depth) + position; }
 

@@ -665,8 +665,8 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 		initial_state = part_position & 3;
 		end_state = initial_state;
 	}
-	int depth_state[NDEPTH] = {0, 0, 0, 0, 0};
-	depth_state[curr_depth] = initial_state;
+	DepthState depth_state;
+	depth_state.set(curr_depth, initial_state);
 	curr_depth = e.geo[curr].depth;
 	int curr_sum_y = 0, curr_sum_u = 0, curr_sum_v = 0;
 	// the squared residual of every component over the CU's TUs - the distortion of coding nothing, which the TU decisions compute anyway and the merge evaluation's
@@ -674,13 +674,13 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 	e.inter_ssq[0] = e.inter_ssq[1] = e.inter_ssq[2] = 0;
 	e.inter_ssq_valid = 1;
 	int luma_covered = 0;      // (a tree that visits a parent AND its children would count samples twice: checked at the end)
-	while (curr_depth != depth || depth_state[curr_depth] != end_state) {
-		curr = parent < 0 ? curr : e.geo[parent].child[depth_state[curr_depth]];
+	while (curr_depth != depth || depth_state.get(curr_depth) != end_state) {
+		curr = parent < 0 ? curr : e.geo[parent].child[depth_state.get(curr_depth)];
 		Node &cn = node_of(e, curr);
 		cn.qp = qp;
 		curr_depth = e.geo[curr].depth;
 		uint32_t dist_y, dist_u, dist_v;
-		const bool has_chroma = e.geo[curr].size_chroma != 2 || depth_state[curr_depth] == 0;
+		const bool has_chroma = e.geo[curr].size_chroma != 2 || depth_state.get(curr_depth) == 0;
 		if (has_chroma && HENC_HELPERS(e)) {
 			// the three components of a TU are independent: the helpers take U and V
 			uint32_t raw = 0;
@@ -712,12 +712,12 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 		cn.distortion = dist_y + dist_u + dist_v;
 		cn.cost = cn.distortion;
 		cn.sum = (uint32_t)(curr_sum_y + curr_sum_u + curr_sum_v);
-		depth_state[curr_depth]++;
+		depth_state.inc(curr_depth);
 		if (curr_depth < max_tr_processing_depth) {
 			curr_depth++;
 			parent = curr;
-		} else if (depth_state[curr_depth] == 4) {
-			while (depth_state[curr_depth] == 4 && curr_depth > depth) {
+		} else if (depth_state.get(curr_depth) == 4) {
+			while (depth_state.get(curr_depth) == 4 && curr_depth > depth) {
 				const Geo &pq = e.geo[parent];
 				Node &pn = node_of(e, parent);
 				Node &c0 = node_of(e, pq.child[0]), &c1 = node_of(e, pq.child[1]), &c2 = node_of(e, pq.child[2]), &c3 = node_of(e, pq.child[3]);
@@ -725,7 +725,7 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 				const uint32_t sum = c0.sum + c1.sum + c2.sum + c3.sum;
 				const double cost = distortion;
 				const int buff_depth = depth + nxn;
-				depth_state[curr_depth] = 0;
+				depth_state.set(curr_depth, 0);
 				if (cost < pn.cost) {
 					pn.cost = (uint32_t)cost;
 					pn.distortion = (uint32_t)distortion;

@@ -281,10 +281,10 @@ HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, i
 	if (S.perf_mode >= 1)
 		max_tr_processing_depth = (depth + 2 <= max_tr_processing_depth) ? depth + 2 : ((depth + 1 <= max_tr_processing_depth) ? depth + 1 : max_tr_processing_depth);
 
-	int depth_state[NDEPTH] = {0, 0, 0, 0, 0};
-	depth_state[curr_depth] = initial_state;
-	while (curr_depth != depth || depth_state[curr_depth] != end_state) {
-		curr = parent < 0 ? curr : e.geo[parent].child[depth_state[curr_depth]];
+	DepthState depth_state;
+	depth_state.set(curr_depth, initial_state);
+	while (curr_depth != depth || depth_state.get(curr_depth) != end_state) {
+		curr = parent < 0 ? curr : e.geo[parent].child[depth_state.get(curr_depth)];
 		Node &cn = node_of(e, curr);
 		cn.qp = qp;
 		curr_depth = e.geo[curr].depth;
@@ -292,19 +292,19 @@ HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, i
 		cn.distortion = encode_intra_tu(g, e, curr, depth, cu_mode, part_size_type, &curr_sum);
 		cn.sum = (uint32_t)curr_sum;
 		cn.cost = cn.distortion;
-		depth_state[curr_depth]++;
+		depth_state.inc(curr_depth);
 		if (curr_depth < max_tr_processing_depth) {
 			curr_depth++;
 			parent = curr;
-		} else if (depth_state[curr_depth] == 4) {
-			while (depth_state[curr_depth] == 4 && curr_depth > depth) {
+		} else if (depth_state.get(curr_depth) == 4) {
+			while (depth_state.get(curr_depth) == 4 && curr_depth > depth) {
 				const Geo &pq = e.geo[parent];
 				Node &pn = node_of(e, parent);
 				Node &c0 = node_of(e, pq.child[0]), &c1 = node_of(e, pq.child[1]), &c2 = node_of(e, pq.child[2]), &c3 = node_of(e, pq.child[3]);
 				const uint32_t sum = c0.sum + c1.sum + c2.sum + c3.sum;
 				const double distortion = (double)c0.distortion + c1.distortion + c2.distortion + c3.distortion;
 				const double cost = distortion;
-				depth_state[curr_depth] = 0;
+				depth_state.set(curr_depth, 0);
 				bool take_children;
 				if (S.rd_mode != RDM_FAST) take_children = cost < pn.cost;
 				else take_children = 1.25 * (cost + (double)(uint32_t)(45u * sum)) < (double)(uint32_t)(pn.cost + 45u * pn.sum);
@@ -339,7 +339,7 @@ HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, i
 				parent = e.geo[parent].parent;
 			}
 			if (curr_depth + 2 <= max_tr_processing_depth) {
-				const int aux = parent >= 0 ? e.geo[parent].child[(depth_state[curr_depth] + 3) & 3] : 0;
+				const int aux = parent >= 0 ? e.geo[parent].child[(depth_state.get(curr_depth) + 3) & 3] : 0;
 				for (int aux_depth = curr_depth + 2; aux_depth <= max_tr_processing_depth; aux_depth++)
 					sync_reference_buffs(g, e, aux, curr_depth + 1, aux_depth + 1);
 			}
@@ -499,9 +499,9 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth,
 	{
 		int cu_mode = best_modes[0];
 		const uint32_t bit_cost = best_bits[0];
-		int depth_state[NDEPTH] = {0, 0, 0, 0, 0};
-		int cbf_split[2][NDEPTH] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
-		int partition_cost[4];
+		DepthState depth_state;
+		DepthState cbf_split0, cbf_split1;      // (0 / 1 per depth, one word per chroma component)
+		DepthInts4 partition_cost;
 		if (cu_mode == DM_CHROMA_IDX) cu_mode = luma_mode;
 		if (depth == 0 && CFG_MAX_CU_SIZE == 64) {
 			parent = cfg_depth_start(0);
@@ -511,16 +511,16 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth,
 			parent = e.geo[curr].parent;
 		}
 		int curr_depth = e.geo[curr].depth;
-		depth_state[curr_depth] = part_position & 3;
+		depth_state.set(curr_depth, part_position & 3);
 		const int qwnd = NWND - 1, dwnd = NWND - 1;
 		bool broke = false;
-		while (!(curr_depth == (depth - nxn) && depth_state[curr_depth] == (part_position & 3) + 1)) {
-			curr = parent < 0 ? curr : e.geo[parent].child[depth_state[curr_depth]];
+		while (!(curr_depth == (depth - nxn) && depth_state.get(curr_depth) == (part_position & 3) + 1)) {
+			curr = parent < 0 ? curr : e.geo[parent].child[depth_state.get(curr_depth)];
 			const int tr_depth_luma = w.tr_idx_buffs[depth][e.geo[curr].abs_index] + depth - nxn;
 			while (curr_depth < tr_depth_luma) {
 				parent = curr;
 				curr_depth++;
-				curr = e.geo[parent].child[depth_state[curr_depth]];
+				curr = e.geo[parent].child[depth_state.get(curr_depth)];
 			}
 			const int scan_mode = find_scan_mode(1, 0, e.geo[curr].size_chroma, cu_mode, 0);
 			const int original_depth = e.geo[curr].depth;
@@ -531,7 +531,7 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth,
 			const Geo &q = e.geo[curr];
 			curr_depth = q.depth;
 			const int n = q.size_chroma;
-			partition_cost[depth_state[curr_depth]] = 0;
+			partition_cost.set(depth_state.get(curr_depth), 0);
 			{
 				int cs[2], pc[2];
 				const int shifts = (original_depth - depth + nxn) | ((curr_depth - depth + nxn) << 8);
@@ -547,34 +547,35 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth,
 				}
 				for (int k = 0; k < 2; k++) {
 					sum += (uint32_t)cs[k];
-					cbf_split[k][curr_depth] |= (cs[k] ? 1 : 0);
-					partition_cost[depth_state[curr_depth]] += pc[k];
+					if (cs[k]) { if (k == 0) cbf_split0.set(curr_depth, 1); else cbf_split1.set(curr_depth, 1); }
+					partition_cost.add(depth_state.get(curr_depth), pc[k]);
 				}
 			}
 			node_of(e, curr).sum += sum;
-			distortion += (uint32_t)partition_cost[depth_state[curr_depth]];
+			distortion += (uint32_t)partition_cost.get(depth_state.get(curr_depth));
 			if (distortion > best_cost) {
 				distortion = best_cost + 1;
 				broke = true;
 				break;
 			}
-			depth_state[curr_depth]++;
-			if (depth_state[curr_depth] == 4) {
-				while (depth_state[curr_depth] == 4 && curr_depth > (depth - nxn)) {
+			depth_state.inc(curr_depth);
+			if (depth_state.get(curr_depth) == 4) {
+				while (depth_state.get(curr_depth) == 4 && curr_depth > (depth - nxn)) {
 					const Geo &pq = e.geo[parent];
 					const int sh = curr_depth - 1 - depth + nxn;
 					g.sync();
 					for (int i = g.tid; i < pq.num_part; i += g.n) {
-						w.cbf_chroma[0][pq.abs_index + i] |= (uint8_t)(cbf_split[0][curr_depth] << sh);
-						w.cbf_chroma[1][pq.abs_index + i] |= (uint8_t)(cbf_split[1][curr_depth] << sh);
+						w.cbf_chroma[0][pq.abs_index + i] |= (uint8_t)(cbf_split0.get(curr_depth) << sh);
+						w.cbf_chroma[1][pq.abs_index + i] |= (uint8_t)(cbf_split1.get(curr_depth) << sh);
 					}
 					g.sync();
-					cbf_split[0][curr_depth - 1] |= cbf_split[0][curr_depth];
-					cbf_split[1][curr_depth - 1] |= cbf_split[1][curr_depth];
-					cbf_split[0][curr_depth] = cbf_split[1][curr_depth] = 0;
-					depth_state[curr_depth] = 0;
+					cbf_split0.set(curr_depth - 1, cbf_split0.get(curr_depth - 1) | cbf_split0.get(curr_depth));
+					cbf_split1.set(curr_depth - 1, cbf_split1.get(curr_depth - 1) | cbf_split1.get(curr_depth));
+					cbf_split0.set(curr_depth, 0);
+					cbf_split1.set(curr_depth, 0);
+					depth_state.set(curr_depth, 0);
 					curr_depth--;
-					depth_state[curr_depth]++;
+					depth_state.inc(curr_depth);
 					if (curr_depth != 0) parent = e.geo[parent].parent;
 				}
 			}
