@@ -205,10 +205,10 @@ template <class G>
 HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, int ox, int oy, int gx, int gy, int size, const MvCandList &amvp, const MvCandList &search, double corr,
 				   int action, MV *mv_io, MV *subpix_out)
 {
-	const int ds[4][2] = {{-1, 0}, {0, -1}, {1, 0}, {0, 1}};
-	const int db[8][2] = {{-2, 0}, {-1, -1}, {0, -2}, {1, -1}, {2, 0}, {1, 1}, {0, 2}, {-1, 1}};
-	const int ref_h[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
-	const int ref_q[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
+	static constexpr int ds[4][2] = {{-1, 0}, {0, -1}, {1, 0}, {0, 1}};
+	static constexpr int db[8][2] = {{-2, 0}, {-1, -1}, {0, -2}, {1, -1}, {2, 0}, {1, 1}, {0, 2}, {-1, 1}};
+	static constexpr int ref_h[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
+	static constexpr int ref_q[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
 	const int fw = e.seq->width, fh = e.seq->height;
 	const int xlow = (gx - SEARCH_RANGE_X) < 0 ? -gx : -SEARCH_RANGE_X, xhigh = (gx + SEARCH_RANGE_X) > (fw - size) ? fw - gx - size : SEARCH_RANGE_X;
 	const int ylow = (gy - SEARCH_RANGE_Y) < 0 ? -gy : -SEARCH_RANGE_Y, yhigh = (gy + SEARCH_RANGE_Y) > (fh - size) ? fh - gy - size : SEARCH_RANGE_Y;

@@ -9,7 +9,7 @@ namespace henc {
 
 HENC_INLINE int intra_is_filtered(int mode, int inv_depth)
 {
-	const int intra_filter[5] = {10, 7, 1, 0, 10};   // hmr_motion_intra.c:148
+	static constexpr int intra_filter[5] = {10, 7, 1, 0, 10};   // hmr_motion_intra.c:148
 	const int diff = hmin(habs(mode - HOR_IDX), habs(mode - VER_IDX));
 	return (mode != DC_IDX) && (diff > intra_filter[inv_depth - 2]);
 }
@@ -88,8 +88,8 @@ HENC_INLINE void intra_neighbour_dirs(Enc &__restrict__ e, int ni, int depth, in
 template <class SadsFn>
 HENC_INLINE int intra_search_walk_batched(const int *preds, int rd_fast, double sqrt_lambda, SadsFn &&sads_of, int *best_mode_out, double *best_cost_out)
 {
-	const int search_points[4][5] = {{0, 1, 0, 8, 16}, {2, 10, 16, 22, 30}, {-4, -2, 2, 4, 0}, {-1, 1, 0, 0, 0}};
-	const int num_search_points[4] = {2, 5, 4, 2};
+	static constexpr int search_points[4][5] = {{0, 1, 0, 8, 16}, {2, 10, 16, 22, 30}, {-4, -2, 2, 4, 0}, {-1, 1, 0, 0, 0}};
+	static constexpr int num_search_points[4] = {2, 5, 4, 2};
 	int best_cu_mode = 0, new_best = 0, min_mode = 0, max_mode = 1, best_bit_cost = 0;
 	double best_cost = MAX_COST;
 	for (int loop = 0; loop < 4; loop++) {

@@ -492,8 +492,8 @@ HENC_INLINE IntraPredictor intra_setup(const int16_t *adi, int n, int mode, int 
 		p.edge_filter = n <= 16 && is_luma;
 	} else {
 		p.kind = 2;
-		const int ang_table[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};
-		const int inv_ang_table[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};
+		static constexpr int ang_table[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};
+		static constexpr int inv_ang_table[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};
 		const int is_hor = mode < 18;
 		p.is_ver = !is_hor;
 		int pa = p.is_ver ? mode - 26 : -(mode - 10);
@@ -1087,7 +1087,7 @@ HENC_PRIM void dequantize(const G &g, const FastTables *F, const DevTables *T, c
 
 HENC_INLINE int chroma_qp_table(int qpi)   // chroma_scale_conversion_table, hmr_encoder_lib.c:2245
 {
-	const uint8_t mid[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37};
+	static constexpr uint8_t mid[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37};
 	qpi = hclip(qpi, 0, 57);
 	return qpi < 30 ? qpi : (qpi < 44 ? mid[qpi - 30] : qpi - 6);
 }
