@@ -33,7 +33,8 @@
 
 using namespace henc;
 
-// k_subpel.hip: the phase planes of a reference picture, queued on `stream`
+// k_subpel.hip: the phase planes of a reference picture, queued on `stream` (all of them / one component's)
+int hmr_subpel_plane_on(hipStream_t stream, int comp, const int16_t *pic, int stride, int rows, uint8_t *out);
 int hmr_subpel_planes_on(hipStream_t stream, const int16_t *pic_y, const int16_t *pic_u, const int16_t *pic_v, int stride_y, int rows_y, int stride_c, int rows_c, uint8_t *out_y,
 			 uint8_t *out_u, uint8_t *out_v);
 
@@ -819,6 +820,8 @@ struct hmr_gpu_enc {
 	void *d_sao_jobs = nullptr;                          // (lead) k_sao_decide_batch's job array
 	FrameCtx *d_frames = nullptr, *h_frames = nullptr;   // (lead) the frame parameters of a batch's pictures, on the device and page-locked on the host
 	EncDev *h_devs = nullptr;                            // (lead) their EncDev records, page-locked
+	hipStream_t plane_stream[2] = {nullptr, nullptr};    // (lead) side streams for the chroma phase planes of a batch
+	hipEvent_t ev_plane[3] = {nullptr, nullptr, nullptr};
 	int *d_pool_state = nullptr;                         // k_encode_pool: per picture of the launch the open step and the steps' ticket / done counters, then the finished-pictures counter
 	WorkSlow *d_pool_slow = nullptr;                     // the pool workers' transform / decoded windows
 	int pool_workers = 0;
@@ -1264,6 +1267,8 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	if (e->d_frames) (void)hipFree(e->d_frames);
 	if (e->h_frames) (void)hipHostFree(e->h_frames);
 	if (e->h_devs) (void)hipHostFree(e->h_devs);
+	for (int k = 0; k < 2; k++) if (e->plane_stream[k]) { (void)hipStreamSynchronize(e->plane_stream[k]); (void)hipStreamDestroy(e->plane_stream[k]); }
+	for (int k = 0; k < 3; k++) if (e->ev_plane[k]) (void)hipEventDestroy(e->ev_plane[k]);
 	if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
 	if (e->d_gather) (void)hipFree(e->d_gather);
 	if (e->h_gather) (void)hipHostFree(e->h_gather);
@@ -1662,8 +1667,29 @@ int batch_launch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_t
 	}
 	// The phase planes of all the reference pictures one after the other on the launch's stream: a picture's three kernels fill the GPU (2500 workgroups, 1.9 TB/s);
 	// run side by side on the sequences' streams, sixteen at a time, they reached a quarter of that between them (rocprofv3 trace: 52 ms for 180 pictures).
-	for (int i = 0; i < n; i++)
-		if ((rc = reference_planes(encs[i], bst))) return rc;
+	// ... luma on the launch's stream, U and V on two side streams: a picture's kernels are 33 + 2 x 20 us of a GPU they do not fill at their ends, three in
+	// flight overlap those ends (sixteen thrash, one leaves them exposed)
+	if (!lead->plane_stream[0]) {
+		for (int k = 0; k < 2; k++) {
+			HIP_TRY(hipStreamCreateWithFlags(&lead->plane_stream[k], hipStreamNonBlocking));
+			HIP_TRY(hipEventCreateWithFlags(&lead->ev_plane[k], hipEventDisableTiming));
+		}
+		HIP_TRY(hipEventCreateWithFlags(&lead->ev_plane[2], hipEventDisableTiming));
+	}
+	HIP_TRY(hipEventRecord(lead->ev_plane[2], bst));
+	for (int k = 0; k < 2; k++) HIP_TRY(hipStreamWaitEvent(lead->plane_stream[k], lead->ev_plane[2], 0));
+	for (int i = 0; i < n; i++) {
+		hmr_gpu_enc *e = encs[i];
+		const Seq &s = e->seq;
+		if (e->f.slice_type == SLICE_I) continue;
+		if ((rc = hmr_subpel_plane_on(bst, 0, e->d_pic[e->cur ^ 1][0], s.stride_y, s.height + 2 * s.margin_y, e->planes.y))) return rc;
+		for (int k = 0; k < 2; k++)
+			if ((rc = hmr_subpel_plane_on(lead->plane_stream[k], 1 + k, e->d_pic[e->cur ^ 1][1 + k], s.stride_c, s.height / 2 + 2 * s.margin_c, e->planes.c[k]))) return rc;
+	}
+	for (int k = 0; k < 2; k++) {
+		HIP_TRY(hipEventRecord(lead->ev_plane[k], lead->plane_stream[k]));
+		HIP_TRY(hipStreamWaitEvent(bst, lead->ev_plane[k], 0));
+	}
 	if (lead->pending && !lead->download_queued) {
 		HIP_TRY(hipEventRecord(lead->ev_decided, bst));
 		HIP_TRY(hipStreamWaitEvent(lead->copy_stream, lead->ev_decided, 0));

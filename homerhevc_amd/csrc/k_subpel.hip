@@ -223,6 +223,16 @@ int hmr_subpel_planes_on(hipStream_t stream, const int16_t *pic_y, const int16_t
 	HIP_TRY(hipGetLastError());
 	return HMR_GPU_OK;
 }
+// one component's planes on `stream` (comp 0: luma, 16 planes; 1 / 2: a chroma component, 64 planes)
+int hmr_subpel_plane_on(hipStream_t stream, int comp, const int16_t *pic, int stride, int rows, uint8_t *out)
+{
+	if (!pic || !out || (stride & 3) || stride <= 0 || rows <= 0) return HMR_GPU_ERR_ARG;
+	const int grid = (((stride + TW - 1) / TW) * ((rows + TH - 1) / TH) + 7) / 8 * 8;
+	if (comp == 0) hipLaunchKernelGGL(k_subpel_luma, dim3(grid), dim3(256), 0, stream, pic, stride, rows, out);
+	else hipLaunchKernelGGL(k_subpel_chroma, dim3(grid), dim3(256), 0, stream, pic, stride, rows, out);
+	HIP_TRY(hipGetLastError());
+	return HMR_GPU_OK;
+}
 extern "C" int hmr_gpu_subpel_planes(hmr_gpu_ctx *ctx, const int16_t *pic_y, const int16_t *pic_u, const int16_t *pic_v, int stride_y, int rows_y, int stride_c, int rows_c,
 				     uint8_t *out_y, uint8_t *out_u, uint8_t *out_v)
 {
