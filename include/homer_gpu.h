@@ -613,7 +613,8 @@ int hmr_gpu_enc_encode_source(hmr_gpu_enc *enc, int slot, int image_type, uint8_
  * into streams[i] (capacity caps[i], size stream_bytes[i]).  The encoders use the row-per-thread schedule (wfpp_num_threads > 1) and the same device; the access
  * units are those hmr_gpu_enc_encode_source gives one by one.  The launch is a pool of persistent row workers (two per CU) that claim CTUs of any of the n
  * pictures whose wavefront step is open (k_encode_pool); n is at most 256, a few hundred pictures' worth of CTU rows saturate the pool (120 at 1080p).  A worker
- * never waits for a CTU that is not already running, so the launch does not depend on all its workgroups being resident. */
+ * never waits for a CTU that is not already running, so the launch does not depend on all its workgroups being resident.  Pictures of more than 256 CTU rows
+ * (16384 lines) are refused by the batch calls (the SAO decisions of a batch run a thread per CTU row in one workgroup per picture). */
 int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes);
 /* the same, pipelined: call k launches the frames slots[] and delivers the access units of call k - 1's frames (stream_bytes[i] = 0 on the first call), whose download
  * and entropy coding run while the device is busy with call k's CTU stage - a frame's successor needs its reconstruction and its distortion statistic, not its bytes
