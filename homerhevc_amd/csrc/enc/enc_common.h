@@ -69,6 +69,7 @@ struct Enc {
 	int16_t *coeff;        // the CTU's coefficient output: 4096 luma + 2 x 1024 chroma, linear per TU in z-order
 	// speculative inputs of a P-frame CTU (enc_ctu.h)
 	uint32_t total_intra_partitions, total_partitions;
+	int ctu_qp;               // the QP of the CTU being decided: the frame's, or what the rate control gives it (hmr_rc_get_cu_qp with qp_depth 0: computed at the CTU's root, inherited below)
 	uint32_t inter_ssq[3];    // encode_inter: the squared residual of the CU per component (the no-residual distortion), when inter_ssq_valid
 	int inter_ssq_valid;
 	int ctu_x, ctu_y;         // CtuPublic::x / y of the CTU being encoded (here for the same reason as nb_ctus: a read of the record is a trip to HBM, and motion compensation,
@@ -162,6 +163,22 @@ struct DepthInts4 {      // four ints addressed by a run-time index (a chroma CU
 	HENC_INLINE void add(int i, int x) { set(i, get(i) + x); }
 };
 
+HENC_INLINE int raster2abs(int r)   // raster2abs_table for the 16 x 16 unit grid (hmr_encoder_lib.c:95-100)
+{
+	const int x = r & 15, y = r >> 4;
+	int a = 0;
+	for (int b = 0; b < 4; b++) a |= (((x >> b) & 1) << (2 * b)) | (((y >> b) & 1) << (2 * b + 1));
+	return a;
+}
+HENC_INLINE int abs2raster(int a)   // abs2raster_table: the Morton de-interleave of the unit index
+{
+	int x = 0, y = 0;
+	for (int b = 0; b < 4; b++) {
+		x |= ((a >> (2 * b)) & 1) << b;
+		y |= ((a >> (2 * b + 1)) & 1) << b;
+	}
+	return y * 16 + x;
+}
 HENC_INLINE Node &node_of(Enc &__restrict__ e, int idx) { return e.nodes[idx]; }
 HENC_INLINE int node_at(const Enc &__restrict__ e, int depth, int position) { return cfg_depth_start(depth) + position; }
 

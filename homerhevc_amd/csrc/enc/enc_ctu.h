@@ -166,7 +166,7 @@ HENC_HD uint32_t encode_intra(const G &g, Enc &__restrict__ e, int curr_depth, i
 		cost = cl + cc;
 	} else {
 		for (int n = 0; n < 4; n++) {
-			node_of(e, node_at(e, curr_depth, position) + n).qp = (uint32_t)e.f->qp;
+			node_of(e, node_at(e, curr_depth, position) + n).qp = (uint32_t)e.ctu_qp;
 			cost += encode_intra_luma(g, e, curr_depth, position + n, part_size_type);
 		}
 		cost += encode_intra_chroma(g, e, curr_depth, position, part_size_type);
@@ -352,7 +352,7 @@ HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &__restrict__ e)
 		const int part_size_type = curr_depth < CFG_MAX_PRED_DEPTH ? PART_2Nx2N : PART_NxN;
 		const int num_part_in_cu = q.num_part;
 		const int position = q.list_index - cfg_depth_start(curr_depth);
-		nd.qp = (uint32_t)e.f->qp;   // hmr_rc_get_cu_qp, fixed QP (hmr_rate_control.c:366)
+		nd.qp = (uint32_t)e.ctu_qp;   // hmr_rc_get_cu_qp (hmr_rate_control.c:337): the slice QP, or under rate control the CTU's (qp_depth 0: a deeper CU takes its parent's)
 		if (nd.b_inside && nd.r_inside) {
 			int mv_cost = 0;
 			if (part_size_type == PART_2Nx2N) {
@@ -515,7 +515,7 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 		const int part_size_type = curr_depth < CFG_MAX_PRED_DEPTH ? PART_2Nx2N : PART_NxN;
 		int position = q.list_index - cfg_depth_start(curr_depth);
 		double cost_luma = 0, cost_chroma = 0;
-		nd->qp = (uint32_t)e.f->qp;
+		nd->qp = (uint32_t)e.ctu_qp;
 		if (nd->b_inside && nd->r_inside) {
 			if (part_size_type == PART_2Nx2N) {
 				{ HENC_PROF_T0(); cost_luma = encode_intra_luma(g, e, curr_depth, position, part_size_type); HENC_PROF_ADD(e, PF_INTRA_TU); }
@@ -528,7 +528,7 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 				cost_luma = 0;
 				for (int n = 0; n < 4; n++) {
 					Node &sn = node_of(e, curr + n);
-					sn.qp = (uint32_t)e.f->qp;
+					sn.qp = (uint32_t)e.ctu_qp;
 					sn.cost = encode_intra_luma(g, e, curr_depth, position + n, part_size_type);
 					cost_luma += sn.cost;
 					cost_sum.add(curr_depth, sn.cost);

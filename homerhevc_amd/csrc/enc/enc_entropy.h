@@ -1,55 +1,95 @@
 // Entropy coding and bitstream of a frame: the serial consumer of the CTU decisions.
 // Restates the reference's L1: the bit writer and NAL escaping (hmr_bitstream.c:63-145), the CABAC engine
 // and its counting twin (hmr_binary_encoding.c:57-358, 553-576), context set-up (hmr_arithmetic_encoding.c:128-204), the CTU syntax
-// (:358-1367, 1561-1832, 2039-2134), the SAO syntax (:1839-2036) and its rate terms (:2377-2429), the SAO mode decision
-// (hmr_sao.c:363-955, 1295-1441), the parameter sets and slice header (hmr_headers.c) and the access-unit assembly of
-// encoder_engine_thread (hmr_encoder_lib.c:3287-3330) + HOMER_enc_write_annex_b_output (:2196).
-// Host code: one pass over the CTUs in raster order, the order the reference's single WPP thread codes them in.
+// (:358-1367, 1561-1832, 2039-2134) with the delta-QP syntax of the rate-controlled modes (:1371-1530), the SAO syntax (:1839-2036) and its rate terms
+// (:2377-2429), the parameter sets and slice header (hmr_headers.c) and the access-unit assembly of encoder_engine_thread (hmr_encoder_lib.c:3287-3330) +
+// HOMER_enc_write_annex_b_output (:2196).
+// The CABAC engine and the CTU syntax are SPMD code like the decision core (one 64-lane group codes a CTU: the syntax walk is group-uniform, the coefficient
+// scans are lane-parallel): on the device they run inside the CTU kernel as the last stage of a CTU's post-decision task (enc_post.h), one sub-stream per CTU
+// row; the host writes parameter sets and slice headers and assembles the access unit.
 #pragma once
 #include <math.h>
 #include <string.h>
 #include <vector>
 #include "enc_cabac_tables.h"
-#include "enc_prims.h"
+#include "enc_common.h"
 #include "enc_sao.h"
+
+#if defined(__HIPCC__)
+#define HENC_HDX __host__ __device__
+#define HENC_FI __host__ __device__ __forceinline__      // the entropy coder's state (engine registers, bit writer) must stay in registers: everything on its path is inlined
+#else
+#define HENC_HDX
+#define HENC_FI inline __attribute__((always_inline))
+#endif
 
 namespace henc {
 
-// ---- bit writer (MSB first; hmr_bitstream_write_bits ORs into a zeroed buffer) ---------------------------------------------
+// ---- bit writer (MSB first) over a caller-owned buffer -----------------------------------------------------------------------
+// A partially filled byte is kept in `cur`; `overflow` is set instead of writing past `cap`.
 struct BitWriter {
-	std::vector<uint8_t> buf;
-	int bytecnt = 0, bitcnt = 0;
-	void init() { buf.assign(buf.size(), 0); bytecnt = bitcnt = 0; }
-	void need(size_t n) { if (buf.size() < n) buf.resize(n * 2 + 64, 0); }
-	void write(uint32_t val, int n)
+	uint8_t *buf = nullptr;
+	int cap = 0, bytecnt = 0, bitcnt = 0;
+	uint32_t cur = 0;
+	int overflow = 0;
+	void (*grow)(BitWriter *) = nullptr;   // host owners (HostBits) enlarge the buffer here
+	HENC_FI void attach(uint8_t *p, int capacity) { buf = p; cap = capacity; bytecnt = bitcnt = 0; cur = 0; overflow = 0; }
+	HENC_FI void init() { bytecnt = bitcnt = 0; cur = 0; overflow = 0; }
+	HENC_FI void put_byte(uint32_t b)
+	{
+		if (bytecnt >= cap) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+			if (grow) grow(this);
+#endif
+			if (bytecnt >= cap) { overflow = 1; return; }
+		}
+		buf[bytecnt++] = (uint8_t)b;
+	}
+	HENC_FI void write(uint32_t val, int n)
 	{
 		if (n <= 0) return;
-		need((size_t)bytecnt + 16);
-		uint64_t v = n >= 32 ? val : (val & ((1u << n) - 1));
-		v <<= (64 - n - bitcnt);
-		for (int k = 0; k < 8 && (k * 8 < bitcnt + n); k++) buf[bytecnt + k] |= (uint8_t)(v >> (56 - 8 * k));
-		bitcnt += n;
-		bytecnt += bitcnt >> 3;
-		bitcnt &= 7;
+		if (n == 8 && bitcnt == 0) { put_byte(val & 255u); return; }
+		const uint64_t acc = ((uint64_t)cur << n) | (n >= 32 ? (uint64_t)val : (uint64_t)(val & ((1u << n) - 1)));
+		int total = bitcnt + n;
+		while (total >= 8) {
+			put_byte((uint32_t)(acc >> (total - 8)) & 255u);
+			total -= 8;
+		}
+		cur = (uint32_t)(acc & ((1u << total) - 1));
+		bitcnt = total;
 	}
-	void uvlc(uint32_t val)
+	HENC_FI void uvlc(uint32_t val)
 	{
 		uint32_t length = 1, temp = ++val;
 		while (temp != 1) { temp >>= 1; length += 2; }
 		write(0, length >> 1);
 		write(val, (length + 1) >> 1);
 	}
-	void svlc(int val) { uvlc(val <= 0 ? (uint32_t)(-val) << 1 : ((uint32_t)val << 1) - 1); }
-	void align0() { if (bitcnt) write(0, 8 - bitcnt); }
-	void trailing_bits() { write(1, 1); align0(); }
-	int bitcount() const { return (bytecnt << 3) + bitcnt; }
+	HENC_FI void svlc(int val) { uvlc(val <= 0 ? (uint32_t)(-val) << 1 : ((uint32_t)val << 1) - 1); }
+	HENC_FI void align0() { if (bitcnt) write(0, 8 - bitcnt); }
+	HENC_FI void trailing_bits() { write(1, 1); align0(); }
+	HENC_FI int bitcount() const { return (bytecnt << 3) + bitcnt; }
+};
+
+// a BitWriter that owns its (growing) buffer: host side
+struct HostBits : BitWriter {
+	std::vector<uint8_t> store;
+	void bind() { buf = store.data(); cap = (int)store.size(); grow = &HostBits::enlarge; }
+	HostBits() { store.assign(256, 0); bind(); }
+	HostBits(const HostBits &o) : BitWriter(o), store(o.store) { bind(); }
+	HostBits &operator=(const HostBits &o) { BitWriter::operator=(o); store = o.store; bind(); return *this; }
+	static void enlarge(BitWriter *b)
+	{
+		HostBits *h = static_cast<HostBits *>(b);
+		h->store.resize(h->store.size() * 2 + 64, 0);
+		h->bind();
+	}
 };
 
 // hmr_bitstream_nalu_ebsp :123 - the reference's escaping loop taken literally (it looks two bytes past the end, which are zero)
-inline void nalu_ebsp(const BitWriter &in, std::vector<uint8_t> &out)
+inline void nalu_ebsp(const uint8_t *data, int size, std::vector<uint8_t> &out)
 {
-	const int size = in.bytecnt;
-	std::vector<uint8_t> p(in.buf.begin(), in.buf.begin() + size);
+	std::vector<uint8_t> p(data, data + size);
 	p.resize(size + 8, 0);
 	int i = 0;
 	while (i < size) {
@@ -63,34 +103,37 @@ inline void nalu_ebsp(const BitWriter &in, std::vector<uint8_t> &out)
 		if (p[++i] <= 3) out.push_back(3);
 	}
 }
+inline void nalu_ebsp(const BitWriter &in, std::vector<uint8_t> &out) { nalu_ebsp(in.buf, in.bytecnt, out); }
 
 // ---- CABAC --------------------------------------------------------------------------------------------------------------
+// The engine registers are plain members (group-uniform values); the context states live where `ctx` points (the worker's fast memory on the device).
 struct Cabac {
 	uint32_t low = 0, range = 510, buffered_byte = 0xff;
 	int num_buffered = 0, bits_left = 23;
 	uint64_t frac_bits = 0;
-	uint8_t ctx[CTX_TOTAL];
+	uint8_t *ctx = nullptr;          // [CTX_TOTAL]
+	const uint8_t *t_range = &kRangeLps[0][0], *t_next = kNextStateLps;      // the LPS range and transition tables (the device keeps copies in the worker's fast memory)
 	bool counter = false;
-	BitWriter *bs = nullptr;
+	BitWriter bw;                    // the sub-stream being written
 
-	static int next_mps(int s) { return s < 124 ? s + 2 : (s < 126 ? s : s); }
-	static int next_lps(int s) { return kNextStateLps[s]; }
-	static int mps_next(int s) { return s >= 124 && s < 126 ? s : (s >= 126 ? s : s + 2); }
-
-	void start() { low = 0; bits_left = 23; num_buffered = 0; buffered_byte = 0xff; range = 510; }
-	void reset_bits() { low = 0; bits_left = 23; num_buffered = 0; buffered_byte = 0xff; frac_bits &= 32767; }
-	void init_contexts(int slice_type, int qp)
+	HENC_FI void start() { low = 0; bits_left = 23; num_buffered = 0; buffered_byte = 0xff; range = 510; }
+	HENC_FI void reset_bits() { low = 0; bits_left = 23; num_buffered = 0; buffered_byte = 0xff; frac_bits &= 32767; }
+	HENC_FI static uint8_t init_state(int slice_type, int qp, int i)
 	{
-		for (int i = 0; i < CTX_TOTAL; i++) {
-			const int init_value = kCtxInit[slice_type][i];
-			const int slope = (init_value >> 4) * 5 - 45, offset = ((init_value & 15) << 3) - 16;
-			int init_state = ((slope * qp) >> 4) + offset;
-			init_state = init_state < 1 ? 1 : (init_state > 126 ? 126 : init_state);
-			const int mp = init_state >= 64;
-			ctx[i] = (uint8_t)(((mp ? init_state - 64 : 63 - init_state) << 1) + mp);
-		}
+		const int init_value = kCtxInit[slice_type][i];
+		const int slope = (init_value >> 4) * 5 - 45, offset = ((init_value & 15) << 3) - 16;
+		int st = ((slope * qp) >> 4) + offset;
+		st = st < 1 ? 1 : (st > 126 ? 126 : st);
+		const int mp = st >= 64;
+		return (uint8_t)(((mp ? st - 64 : 63 - st) << 1) + mp);
 	}
-	void write_out()
+	template <class G>
+	HENC_FI void init_contexts(const G &g, int slice_type, int qp)
+	{
+		for (int i = g.tid; i < CTX_TOTAL; i += g.n) ctx[i] = init_state(slice_type, qp, i);
+		g.sync();
+	}
+	HENC_FI void write_out()
 	{
 		const uint32_t lead = low >> (24 - bits_left);
 		bits_left += 8;
@@ -100,34 +143,35 @@ struct Cabac {
 			const uint32_t carry = lead >> 8;
 			uint32_t byte = buffered_byte + carry;
 			buffered_byte = lead & 0xff;
-			bs->write(byte, 8);
+			bw.write(byte, 8);
 			byte = (0xff + carry) & 0xff;
-			while (num_buffered > 1) { bs->write(byte, 8); num_buffered--; }
+			while (num_buffered > 1) { bw.write(byte, 8); num_buffered--; }
 		} else {
 			num_buffered = 1;
 			buffered_byte = lead;
 		}
 	}
-	void encode_bin(int ci, uint32_t bin)
+	HENC_FI static int mps_tab(int s) { return s < 124 ? s + 2 : s; }   // g_bc_next_state_MPS: saturates at 124 / 125; 126 / 127 stay
+	HENC_FI void encode_bin(int ci, uint32_t bin)
 	{
-		uint8_t &st = ctx[ci];
+		uint8_t st = ctx[ci];
 		if (counter) {
 			frac_bits += (uint64_t)kEntropyBits[st ^ bin];
 			// the counting coder's transition table (g_bc_next_state, hmr_binary_encoding.c:305) is filled by bc_init_next_state_table(),
 			// which nothing calls: it stays all zero, so every context the counter touches falls to state 0
-			st = 0;
+			ctx[ci] = 0;
 			return;
 		}
-		const uint32_t lps = kRangeLps[st >> 1][(range >> 6) & 3];
+		const uint32_t lps = t_range[((st >> 1) << 2) + ((range >> 6) & 3)];
 		range -= lps;
 		if (bin != (uint32_t)(st & 1)) {
-			const int nb = kRenorm[lps >> 3];
+			const int nb = __builtin_clz(lps) - 23;      // kRenorm[lps >> 3]: the shift that brings the LPS range (6 .. 240) back to nine bits
 			low = (low + range) << nb;
 			range = lps << nb;
-			st = (uint8_t)next_lps(st);
+			ctx[ci] = t_next[st];
 			bits_left -= nb;
 		} else {
-			st = (uint8_t)mps_tab(st);
+			ctx[ci] = (uint8_t)mps_tab(st);
 			if (range >= 256) return;
 			low <<= 1;
 			range <<= 1;
@@ -135,8 +179,7 @@ struct Cabac {
 		}
 		if (bits_left < 12) write_out();
 	}
-	static int mps_tab(int s) { return s < 124 ? s + 2 : s; }   // g_bc_next_state_MPS: saturates at 124 / 125; 126 / 127 stay
-	void encode_ep(uint32_t bin)
+	HENC_FI void encode_ep(uint32_t bin)
 	{
 		if (counter) { frac_bits += 32768; return; }
 		low <<= 1;
@@ -144,7 +187,7 @@ struct Cabac {
 		bits_left--;
 		if (bits_left < 12) write_out();
 	}
-	void encode_bins_ep(uint32_t bins, int n)
+	HENC_FI void encode_bins_ep(uint32_t bins, int n)
 	{
 		if (counter) { frac_bits += (uint64_t)32768 * n; return; }
 		while (n > 8) {
@@ -161,7 +204,7 @@ struct Cabac {
 		bits_left -= n;
 		if (bits_left < 12) write_out();
 	}
-	void encode_trm(uint32_t bin)
+	HENC_FI void encode_trm(uint32_t bin)
 	{
 		if (counter) { frac_bits += (uint64_t)kEntropyBits[126 ^ bin]; return; }
 		range -= 2;
@@ -177,69 +220,83 @@ struct Cabac {
 		}
 		if (bits_left < 12) write_out();
 	}
-	void finish()
+	HENC_FI void finish()
 	{
 		if (low >> (32 - bits_left)) {
-			bs->write(buffered_byte + 1, 8);
-			while (num_buffered > 1) { bs->write(0x00, 8); num_buffered--; }
+			bw.write(buffered_byte + 1, 8);
+			while (num_buffered > 1) { bw.write(0x00, 8); num_buffered--; }
 			low -= 1u << (32 - bits_left);
 		} else {
-			if (num_buffered > 0) bs->write(buffered_byte, 8);
-			while (num_buffered > 1) { bs->write(0xff, 8); num_buffered--; }
+			if (num_buffered > 0) bw.write(buffered_byte, 8);
+			while (num_buffered > 1) { bw.write(0xff, 8); num_buffered--; }
 		}
-		bs->write(low >> 8, 24 - bits_left);
+		bw.write(low >> 8, 24 - bits_left);
 	}
-	uint32_t bitcnt() const { return (uint32_t)(frac_bits >> 15); }
-	// bm_copy_binary_model + ee_copy_entropy_model
-	void load(const Cabac &src)
-	{
-		low = src.low; range = src.range; bits_left = src.bits_left; buffered_byte = src.buffered_byte; num_buffered = src.num_buffered; frac_bits = src.frac_bits;
-		if (&src != this) memcpy(ctx, src.ctx, sizeof ctx);
-	}
+	HENC_FI uint32_t bitcnt() const { return (uint32_t)(frac_bits >> 15); }
 };
 
-// ---- frame view the entropy stage works on ---------------------------------------------------------------------------------
-struct EntropyFrame {
+// ---- what the CTU syntax reads ---------------------------------------------------------------------------------------------------
+// The CTU's own side-info record (on the device: a copy in the worker's fast memory, written back where the delta-QP rules change it), the records of the
+// left and above CTUs where they exist, the CTU's levels, and the QP predictor that crosses the CTU boundary.
+struct EntView {
 	const Seq *seq;
 	const FrameCtx *f;
 	const DevTables *T;
-	const Geo *geo;
-	const uint8_t *ctu_base;      // CtuPublic records, `ctu_pitch` bytes apart
-	size_t ctu_pitch;
-	const int16_t *coeff;         // [nctu][6144]
-	const CtuPublic &ctu(int n) const { return *(const CtuPublic *)(ctu_base + (size_t)n * ctu_pitch); }
-	CtuPublic &ctu_rw(int n) const { return *(CtuPublic *)(ctu_base + (size_t)n * ctu_pitch); }
+	GeoTable geo;
+	CtuPublic *c;                 // this CTU
+	const CtuPublic *left, *top;  // neighbours or nullptr
+	const int16_t *coeff;         // this CTU's levels: 4096 luma + 2 x 1024 chroma, linear per TU in z-order
+	int n;                        // CTU index
+	int prev_last_qp;             // QP of the last unit of the previous CTU of the sub-stream (get_last_coded_qp :1382), or -1: the slice QP
+};
+// scratch of the residual coder in the worker's fast memory: the TU's levels and their positions in scan order, the coefficient-group scan and flags
+struct EntScratch {
+	uint16_t cg[64];
+	uint8_t cg_flag[64];
+};
+// Position (y << shift | x) of the i-th coefficient of a (1 << shift)^2 block in coding order: the coefficient groups in the order `cg` gives (their raster
+// index in the grid of groups), the sixteen coefficients of a group in the 4 x 4 scan of the mode - horizontal: rows; vertical: columns; diagonal: up-right
+// anti-diagonals from the bottom left (scan_pyramid, hmr_tables.c:62-160; the tables themselves are compared with this in tests/test_encoder_cpu.py).
+HENC_INLINE int scan4x4_raster(int scan_mode, int k)      // raster index (y * 4 + x) of element k of the 4 x 4 scan
+{
+	if (scan_mode == SCAN_HOR) return k;
+	if (scan_mode == SCAN_VER) return ((k & 3) << 2) | (k >> 2);
+	return (int)((0xfbe7ad369c258140ull >> (4 * k)) & 15u);      // 0 4 1 8 5 2 12 9 6 3 13 10 7 14 11 15
+}
+HENC_INLINE uint32_t scan_position(int scan_mode, int shift, int i, const uint16_t *cg)
+{
+	const int r = scan4x4_raster(scan_mode, i & 15), sx = r & 3, sy = r >> 2;
+	if (shift == 2) return (uint32_t)((sy << 2) | sx);
+	const int cgp = cg[i >> 4], lb = shift - 2, cgx = cgp & ((1 << lb) - 1), cgy = cgp >> lb;
+	return (uint32_t)((((cgy << 2) + sy) << shift) | ((cgx << 2) + sx));
+}
+// state of the delta-QP syntax across the CUs of a CTU (henc_thread_t write_qp_flag / curr_ref_qp / found_zero_cbf, hmr_private.h:1224-1226)
+struct DqpState {
+	int enabled, write_qp, ref_qp, found_coded;
 };
 
-struct CuView {
-	const EntropyFrame *fr;
-	int n;                        // CTU index
-	const CtuPublic *c;
-	const CtuPublic *left() const { return c->has_left ? &fr->ctu(n - 1) : nullptr; }
-	const CtuPublic *top() const { return c->has_top ? &fr->ctu(n - fr->seq->wctu) : nullptr; }
-};
-inline const CtuPublic *ent_pu_left(const CuView &v, int ni, uint32_t *idx)
+HENC_INLINE const CtuPublic *ent_pu_left(const EntView &v, int ni, uint32_t *idx)
 {
-	const Geo &q = v.fr->geo[ni];
+	const Geo &q = v.geo[ni];
 	*idx = q.abs_left;
-	return (q.raster_index & 15) == 0 ? v.left() : v.c;
+	return (q.raster_index & 15) == 0 ? v.left : v.c;
 }
-inline const CtuPublic *ent_pu_top(const CuView &v, int ni, uint32_t *idx, int planar)
+HENC_INLINE const CtuPublic *ent_pu_top(const EntView &v, int ni, uint32_t *idx, int planar)
 {
-	const Geo &q = v.fr->geo[ni];
+	const Geo &q = v.geo[ni];
 	*idx = q.abs_top;
-	if (q.raster_index < 16) return planar ? nullptr : v.top();
+	if (q.raster_index < 16) return planar ? nullptr : v.top;
 	return v.c;
 }
-inline bool node_inside(const CuView &v, int ni)
+HENC_INLINE bool node_inside(const EntView &v, int ni)
 {
-	const Geo &q = v.fr->geo[ni];
-	return v.c->y + q.y + q.size <= v.fr->seq->height && v.c->x + q.x + q.size <= v.fr->seq->width;
+	const Geo &q = v.geo[ni];
+	return v.c->y + q.y + q.size <= v.seq->height && v.c->x + q.x + q.size <= v.seq->width;
 }
 #define HENC_CBF(c, idx, comp, trd) ((((c)->cbf[comp][idx]) >> (trd)) & 1)
 
 // get_intra_dir_luma_predictor :545 on the final arrays
-inline void ent_intra_preds(const CuView &v, int ni, int *p)
+HENC_INLINE void ent_intra_preds(const EntView &v, int ni, int *p)
 {
 	uint32_t idx = 0;
 	const CtuPublic *l = ent_pu_left(v, ni, &idx);
@@ -257,11 +314,13 @@ inline void ent_intra_preds(const CuView &v, int ni, int *p)
 }
 
 // ---- residual coding (encode_residual :1087, encode_last_significant_XY :954, get_sig_ctx_inc :1027) ---------------------------
-inline int sig_ctx_inc(int pattern, int scan_mode, int px, int py, int shift, int comp)
+HENC_INLINE int sig_ctx_inc(int pattern, int scan_mode, int px, int py, int shift, int comp)
 {
-	static const int map4[16] = {0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8};
 	if (px + py == 0) return 0;
-	if (shift == 2) return map4[4 * py + px];
+	if (shift == 2) {
+		// {0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8}[4 * py + px], four bits each
+		return (int)((0x8877886654325410ull >> (4 * (4 * py + px))) & 15u);
+	}
 	const int offset = shift == 3 ? (scan_mode == SCAN_DIAG ? 9 : 15) : (comp == COMP_Y ? 21 : 12);
 	const int xs = px & 3, ys = py & 3;
 	int cnt;
@@ -272,24 +331,25 @@ inline int sig_ctx_inc(int pattern, int scan_mode, int px, int py, int shift, in
 	return ((comp == COMP_Y && ((px >> 2) + (py >> 2)) > 0) ? 3 : 0) + offset + cnt;
 }
 
-inline void encode_last_xy(Cabac &ee, int x, int y, int shift, int comp, int scan_mode)
+HENC_INLINE int last_group_idx(int v) { return v < 4 ? v : (v < 6 ? 4 : (v < 8 ? 5 : (v < 12 ? 6 : (v < 16 ? 7 : (v < 24 ? 8 : 9))))); }
+HENC_INLINE int last_min_in_group(int g) { return g < 4 ? g : (g == 4 ? 4 : (g == 5 ? 6 : (g == 6 ? 8 : (g == 7 ? 12 : (g == 8 ? 16 : 24))))); }
+
+HENC_FI void encode_last_xy(Cabac &ee, int x, int y, int shift, int comp, int scan_mode)
 {
-	static const int group_idx[32] = {0, 1, 2, 3, 4, 4, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 9};
-	static const int min_in_group[10] = {0, 1, 2, 3, 4, 6, 8, 12, 16, 24};
 	const int size = 1 << shift;
 	const int cx = CTX_LAST_X + (comp ? 15 : 0), cy = CTX_LAST_Y + (comp ? 15 : 0);
 	if (scan_mode == SCAN_VER) { const int t = x; x = y; y = t; }
-	const int gx = group_idx[x], gy = group_idx[y];
+	const int gx = last_group_idx(x), gy = last_group_idx(y);
 	const int off = comp ? 0 : ((shift - 2) * 3 + (((shift - 2) + 1) >> 2));
 	const int sh = comp ? (shift - 2) : (((shift - 2) + 3) >> 2);
 	int k;
 	for (k = 0; k < gx; k++) ee.encode_bin(cx + off + (k >> sh), 1);
-	if (gx < group_idx[size - 1]) ee.encode_bin(cx + off + (k >> sh), 0);
+	if (gx < last_group_idx(size - 1)) ee.encode_bin(cx + off + (k >> sh), 0);
 	for (k = 0; k < gy; k++) ee.encode_bin(cy + off + (k >> sh), 1);
-	if (gy < group_idx[size - 1]) ee.encode_bin(cy + off + (k >> sh), 0);
+	if (gy < last_group_idx(size - 1)) ee.encode_bin(cy + off + (k >> sh), 0);
 	if (gx > 3) {
 		const int count = (gx - 2) >> 1;
-		x -= min_in_group[gx];
+		x -= last_min_in_group(gx);
 		for (int i = count - 1; i >= 0; i--) ee.encode_ep((x >> i) & 1);
 	}
 	if (gy > 3) {
@@ -298,93 +358,116 @@ inline void encode_last_xy(Cabac &ee, int x, int y, int shift, int comp, int sca
 	}
 }
 
-inline void encode_residual(Cabac &ee, const CuView &v, int ni, int comp)
+// The TU's levels are first gathered in scan order into the scratch (lane-parallel: on the device the levels and the scan table are in HBM, and the serial
+// walk below would pay a trip to memory per coefficient), together with the last significant position and the coefficient-group flags; the syntax walk then
+// reads the scratch only.
+template <class G>
+HENC_FI void encode_residual(const G &g, Cabac &ee, const EntView &v, EntScratch &sc, int ni, int comp)
 {
-	const EntropyFrame &fr = *v.fr;
-	const Seq &S = *fr.seq;
+	const Seq &S = *v.seq;
 	const int is_luma = comp == COMP_Y;
-	const int abs_index = fr.geo[ni].abs_index;
-	const int pi = is_luma ? ni : (fr.geo[ni].size_chroma > 2 ? ni : fr.geo[ni].parent);
-	const Geo &q = fr.geo[pi];
+	const int abs_index = v.geo[ni].abs_index;
+	const int pi = is_luma ? ni : (v.geo[ni].size_chroma > 2 ? ni : v.geo[ni].parent);
+	const Geo &q = v.geo[pi];
 	const int size = is_luma ? q.size : q.size_chroma;
-	const int shift = is_luma ? S.max_cu_size_shift - q.depth : S.max_cu_size_shift - 1 - q.depth;
-	const int16_t *coeff = fr.coeff + (size_t)v.n * 6144 + (comp == 0 ? 0 : (comp == 1 ? 4096 : 5120)) + (q.abs_index << (4 - (is_luma ? 0 : 2)));
+	const int shift = is_luma ? CFG_MAX_CU_SHIFT - q.depth : CFG_MAX_CU_SHIFT - 1 - q.depth;
+	const int16_t *coeff = v.coeff + (comp == 0 ? 0 : (comp == 1 ? 4096 : 5120)) + (q.abs_index << (4 - (is_luma ? 0 : 2)));
 	const CtuPublic *c = v.c;
 	const int num_part_in_pred_cu = NPART >> (c->pred_depth[abs_index] * 2);
 	const int scan_mode = find_scan_mode(c->pred_mode[q.abs_index] == PM_INTRA, is_luma, size, c->intra_mode[is_luma ? 0 : 1][q.abs_index],
 					     c->intra_mode[0][(abs_index / num_part_in_pred_cu) * num_part_in_pred_cu]);
-	const uint32_t *scan = fr.T->scan[scan_mode][shift];
-	uint32_t cg_tmp[64];
-	const uint32_t *scan_cg;
-	const int blk = size >> 2;
-	if (shift == 3) {
-		static const uint32_t s8[4][4] = {{0, 1, 2, 3}, {0, 1, 2, 3}, {0, 2, 1, 3}, {0, 2, 1, 3}};
-		scan_cg = s8[scan_mode];
-	} else if (shift == 5) {
-		// g_sigLastScanCG32x32 (hmr_tables.c:71-95): the plain up-right diagonal scan of the 8 x 8 grid of coefficient groups
-		int k = 0;
-		for (int d = 0; d < 15; d++)
-			for (int row = d < 8 ? d : 7, col = d - row; row >= 0 && col < 8; row--, col++) cg_tmp[k++] = (uint32_t)(row * 8 + col);
-		scan_cg = cg_tmp;
-	} else scan_cg = fr.T->scan[scan_mode][shift > 3 ? shift - 2 : 0];
-	uint8_t cg_flag[64];
-	memset(cg_flag, 0, sizeof cg_flag);
-	int num_nz = 0, raster_pos_last = 0, scan_pos_last = 0, last_x = 0, last_y = 0;
-	for (int i = 0; i < size * size; i++) {
-		const int sp = scan[i];
-		if (coeff[sp] != 0) {
-			raster_pos_last = i;
-			scan_pos_last = sp;
-			num_nz++;
-			last_y = sp >> shift;
-			last_x = sp - (last_y << shift);
-			cg_flag[blk * (last_y >> 2) + (last_x >> 2)] = 1;
-		}
+	const int blk = size >> 2, ncoef = size * size, ncg = blk * blk;
+	// the coefficient-group scan: {0, 1, 2, 3} / {0, 2, 1, 3} for 8 x 8 (:1147-1150), the plain up-right diagonal of the 8 x 8 grid of groups for 32 x 32
+	// (g_sigLastScanCG32x32, hmr_tables.c:71-95), the 4 x 4 scan of the mode for 16 x 16
+	for (int i = g.tid; i < ncg; i += g.n) {
+		uint32_t cgp;
+		if (shift == 3) cgp = (scan_mode == SCAN_VER || scan_mode == SCAN_DIAG) ? ((uint32_t)((i & 1) << 1) | (uint32_t)(i >> 1)) : (uint32_t)i;
+		else if (shift == 5) {
+			// i-th element of the up-right diagonal scan of an 8 x 8 grid (rows from the bottom of each anti-diagonal)
+			int d = 0, k = i;
+			for (;; d++) {
+				const int len = d < 8 ? d + 1 : 15 - d;
+				if (k < len) break;
+				k -= len;
+			}
+			const int row = (d < 8 ? d : 7) - k, col = d - row;
+			cgp = (uint32_t)(row * 8 + col);
+		} else cgp = shift > 3 ? (uint32_t)scan4x4_raster(scan_mode, i) : 0u;
+		sc.cg[i] = (uint16_t)cgp;
+		sc.cg_flag[i] = 0;
 	}
-	if (num_nz == 0) return;
+	g.sync();
+	// lane-parallel: the last significant coefficient in coding order and the groups that hold one
+	int raster_pos_last = -1;
+	for (int base = 0; base < ncoef; base += g.n) {
+		const int i = base + g.tid;
+		int16_t val = 0;
+		if (i < ncoef) {
+			const uint32_t sp = scan_position(scan_mode, shift, i, sc.cg);
+			val = coeff[sp];
+			if (val != 0) sc.cg_flag[sc.cg[i >> 4]] = 1;
+		}
+		const uint64_t m = g.ballot(val != 0);
+		if (m) raster_pos_last = base + 63 - __builtin_clzll(m);
+	}
+	g.sync();
+	if (raster_pos_last < 0) return;
+	const int scan_pos_last = (int)scan_position(scan_mode, shift, raster_pos_last, sc.cg);
+	const int last_y = scan_pos_last >> shift, last_x = scan_pos_last - (last_y << shift);
 	const int valid = S.sign_hiding;
 	encode_last_xy(ee, last_x, last_y, shift, comp, scan_mode);
 	const int last_scan_set = raster_pos_last >> 4;
 	uint32_t c1 = 1, go_rice;
 	int scan_pos_sig = raster_pos_last;
 	const int base_cg = CTX_SIG_CG + (is_luma ? 0 : 2), base_sig = CTX_SIG + (is_luma ? 0 : 27);
-	int abs_coeff[16];
 	for (int subset = last_scan_set; subset >= 0; subset--) {
 		int num_non_zero = 0;
 		const int sub_pos = subset << 4;
 		uint32_t coeff_signs = 0;
 		int last_nz = -1, first_nz = 16;
+		// the absolute levels of the subset in coding order, four bits short of what a register holds: kept as two 64-bit words of 16-bit fields + the rest
+		uint64_t abs_lo = 0, abs_mid = 0, abs_hi = 0, abs_top = 0;      // abs_coeff[0..3], [4..7], [8..11], [12..15]
+		auto put_abs = [&](int k, int a) {
+			const uint64_t x = (uint64_t)(uint16_t)a << (16 * (k & 3));
+			if (k < 4) abs_lo |= x; else if (k < 8) abs_mid |= x; else if (k < 12) abs_hi |= x; else abs_top |= x;
+		};
+		auto get_abs = [&](int k) -> int {
+			const uint64_t w = k < 4 ? abs_lo : (k < 8 ? abs_mid : (k < 12 ? abs_hi : abs_top));
+			return (int)((w >> (16 * (k & 3))) & 0xffffu);
+		};
 		go_rice = 0;
 		if (scan_pos_sig == raster_pos_last) {
-			abs_coeff[0] = habs(coeff[scan_pos_last]);
-			coeff_signs = coeff[scan_pos_last] < 0;
+			const int lv = coeff[scan_pos_last];
+			put_abs(0, habs(lv));
+			coeff_signs = lv < 0;
 			num_non_zero = 1;
 			last_nz = first_nz = scan_pos_sig;
 			scan_pos_sig--;
 		}
-		const int cg_block_pos = scan_cg[subset];
+		const int cg_block_pos = sc.cg[subset];
 		const int cg_y = cg_block_pos / blk, cg_x = cg_block_pos - cg_y * blk;
-		if (subset == last_scan_set || subset == 0) cg_flag[cg_block_pos] = 1;
+		if (subset == last_scan_set || subset == 0) sc.cg_flag[cg_block_pos] = 1;
 		else {
-			const uint32_t sig_cg = cg_flag[cg_block_pos] != 0;
+			const uint32_t sig_cg = sc.cg_flag[cg_block_pos] != 0;
 			int right = 0, lower = 0;
-			if (cg_x < blk - 1) right = cg_flag[cg_y * blk + cg_x + 1] != 0;
-			if (cg_y < blk - 1) lower = cg_flag[(cg_y + 1) * blk + cg_x] != 0;
+			if (cg_x < blk - 1) right = sc.cg_flag[cg_y * blk + cg_x + 1] != 0;
+			if (cg_y < blk - 1) lower = sc.cg_flag[(cg_y + 1) * blk + cg_x] != 0;
 			ee.encode_bin(base_cg + (right || lower), sig_cg);
 		}
-		if (cg_flag[cg_block_pos]) {
+		if (sc.cg_flag[cg_block_pos]) {
 			uint32_t right = 0, lower = 0;
-			if (cg_x < blk - 1) right = cg_flag[cg_y * blk + cg_x + 1] != 0;
-			if (cg_y < blk - 1) lower = cg_flag[(cg_y + 1) * blk + cg_x] != 0;
+			if (cg_x < blk - 1) right = sc.cg_flag[cg_y * blk + cg_x + 1] != 0;
+			if (cg_y < blk - 1) lower = sc.cg_flag[(cg_y + 1) * blk + cg_x] != 0;
 			const int pattern = right + (lower << 1);
 			for (; scan_pos_sig >= sub_pos; scan_pos_sig--) {
-				const uint32_t bp = scan[scan_pos_sig];
+				const uint32_t bp = scan_position(scan_mode, shift, scan_pos_sig, sc.cg);
 				const uint32_t py = bp >> shift, px = bp - (py << shift);
-				const uint32_t sig = coeff[bp] != 0;
+				const int lv = coeff[bp];
+				const uint32_t sig = lv != 0;
 				if (scan_pos_sig > sub_pos || subset == 0 || num_non_zero) ee.encode_bin(base_sig + sig_ctx_inc(pattern, scan_mode, px, py, shift, comp), sig);
 				if (sig) {
-					abs_coeff[num_non_zero] = habs(coeff[bp]);
-					coeff_signs = 2 * coeff_signs + (coeff[bp] < 0);
+					put_abs(num_non_zero, habs(lv));
+					coeff_signs = 2 * coeff_signs + (lv < 0);
 					num_non_zero++;
 					if (last_nz == -1) last_nz = scan_pos_sig;
 					first_nz = scan_pos_sig;
@@ -400,7 +483,7 @@ inline void encode_residual(Cabac &ee, const CuView &v, int ni, int comp)
 			const int num_c1 = num_non_zero < 8 ? num_non_zero : 8;
 			int first_c2 = -1;
 			for (int idx = 0; idx < num_c1; idx++) {
-				const uint32_t sym = abs_coeff[idx] > 1;
+				const uint32_t sym = get_abs(idx) > 1;
 				ee.encode_bin(base + c1, sym);
 				if (sym) {
 					c1 = 0;
@@ -409,7 +492,7 @@ inline void encode_residual(Cabac &ee, const CuView &v, int ni, int comp)
 			}
 			if (c1 == 0) {
 				base = CTX_ABS + ctx_set + (is_luma ? 0 : 4);
-				if (first_c2 != -1) ee.encode_bin(base, abs_coeff[first_c2] > 2);
+				if (first_c2 != -1) ee.encode_bin(base, get_abs(first_c2) > 2);
 			}
 			if (valid && sign_hidden) ee.encode_bins_ep(coeff_signs >> 1, num_non_zero - 1);
 			else ee.encode_bins_ep(coeff_signs, num_non_zero);
@@ -417,8 +500,9 @@ inline void encode_residual(Cabac &ee, const CuView &v, int ni, int comp)
 				int first_coeff2 = 1;
 				for (int idx = 0; idx < num_non_zero; idx++) {
 					const int base_level = idx < 8 ? (2 + first_coeff2) : 1;
-					if (abs_coeff[idx] >= base_level) {
-						int code = abs_coeff[idx] - base_level;
+					const int a = get_abs(idx);
+					if (a >= base_level) {
+						int code = a - base_level;
 						const uint32_t r = go_rice;
 						if (code < (3 << r)) {
 							const uint32_t length = code >> r;
@@ -431,9 +515,9 @@ inline void encode_residual(Cabac &ee, const CuView &v, int ni, int comp)
 							ee.encode_bins_ep((1u << (3 + length + 1 - r)) - 2, 3 + length + 1 - r);
 							ee.encode_bins_ep(code, length);
 						}
-						if (abs_coeff[idx] > 3 * (1 << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4;
+						if (a > 3 * (1 << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4;
 					}
-					if (abs_coeff[idx] >= 2) first_coeff2 = 0;
+					if (a >= 2) first_coeff2 = 0;
 				}
 			}
 		}
@@ -441,39 +525,67 @@ inline void encode_residual(Cabac &ee, const CuView &v, int ni, int comp)
 }
 
 // ---- CU syntax -----------------------------------------------------------------------------------------------------------------
-inline void encode_qt_cbf(Cabac &ee, int comp, int tr_depth, int cbf)
+HENC_FI void encode_qt_cbf(Cabac &ee, int comp, int tr_depth, int cbf)
 {
 	const int ctx = comp ? tr_depth : (tr_depth == 0 ? 1 : 0);
 	ee.encode_bin(CTX_QT_CBF + (comp ? 4 : 0) + ctx, cbf);
 }
 
-// transform_tree :1561 (fixed QP: no delta-QP syntax)
-inline void encode_transform_tree(Cabac &ee, const CuView &v, int top_ni)
+// encode_delta_qp :1502 (TEncSbac::codeDeltaQP) for the CU at `abs_index`; the predictor is DqpState::ref_qp: with diff_cu_qp_delta_depth = 0 (the only
+// value the reference sets under rate control, hmr_encoder_lib.c:983) a quantisation group is a CTU, it has no left / above group inside the CTU
+// (get_qp_min_cu_left / _top :1432 / :1459 return NULL at the CTU boundary), so get_ref_qp :1487 is the last coded QP
+HENC_FI void encode_delta_qp(Cabac &ee, const EntView &v, const DqpState &dq, int abs_index)
 {
-	const EntropyFrame &fr = *v.fr;
-	const Seq &S = *fr.seq;
+	int diff_qp = (int)v.c->qp[abs_index] - dq.ref_qp;
+	diff_qp = (diff_qp + 78) % 52 - 26;
+	const uint32_t a = (uint32_t)habs(diff_qp), tu = a < 5 ? a : 5;      // CU_DQP_TU_CMAX 5, CU_DQP_EG_k 0
+	// write_unary_max_simbol :358 (offset 1, max 5)
+	ee.encode_bin(CTX_DQP, tu ? 1 : 0);
+	if (tu) {
+		for (uint32_t k = 1; k < tu; k++) ee.encode_bin(CTX_DQP + 1, 1);
+		if (5 > tu) ee.encode_bin(CTX_DQP + 1, 0);
+	}
+	if (a >= 5) {
+		// write_ep_ex_golomb :703
+		uint32_t symbol = a - 5, count = 0, bins = 0;
+		int nb = 0;
+		while (symbol >= (1u << count)) { bins = 2 * bins + 1; nb++; symbol -= 1u << count; count++; }
+		bins = 2 * bins;
+		nb++;
+		bins = (bins << count) | symbol;
+		nb += (int)count;
+		ee.encode_bins_ep(bins, nb);
+	}
+	if (a > 0) ee.encode_ep(diff_qp > 0 ? 0 : 1);
+}
+
+// transform_tree :1561
+template <class G>
+HENC_FI void encode_transform_tree(const G &g, Cabac &ee, const EntView &v, EntScratch &sc, DqpState &dq, int top_ni)
+{
+	const Seq &S = *v.seq;
 	const CtuPublic *c = v.c;
-	const int depth = fr.geo[top_ni].depth;
-	int abs_index = fr.geo[top_ni].abs_index;
+	const int depth = v.geo[top_ni].depth, top_abs = v.geo[top_ni].abs_index;
+	int abs_index = top_abs;
 	int is_intra = c->pred_mode[abs_index] == PM_INTRA;
 	if (!is_intra) {
 		const uint32_t qtroot = HENC_CBF(c, abs_index, 0, 0) || HENC_CBF(c, abs_index, 1, 0) || HENC_CBF(c, abs_index, 2, 0);
 		if (!(c->merge[abs_index] && c->part_size_type[abs_index] == PART_2Nx2N)) ee.encode_bin(CTX_QT_ROOT_CBF, qtroot);
 		if (!qtroot) return;
 	}
-	int depth_state[NDEPTH] = {0, 0, 0, 0, 0};
+	DepthState depth_state;
 	int curr = top_ni, parent = top_ni, curr_depth = depth;
-	while (curr_depth != depth || depth_state[curr_depth] != 1) {
-		const Geo &q = fr.geo[curr];
+	while (curr_depth != depth || depth_state.get(curr_depth) != 1) {
+		const Geo &q = v.geo[curr];
 		curr_depth = q.depth;
 		abs_index = q.abs_index;
-		const int shift = S.max_cu_size_shift - curr_depth;
+		const int shift = CFG_MAX_CU_SHIFT - curr_depth;
 		const int pred_depth = c->pred_depth[abs_index], tr_depth = curr_depth - pred_depth, first = tr_depth == 0;
 		const int tr_idx = c->tr_idx[abs_index];
 		is_intra = c->pred_mode[abs_index] == PM_INTRA;
 		const int part = c->part_size_type[abs_index];
 		const int split_flag = (tr_idx + pred_depth) > curr_depth;
-		const int log2_tr = S.max_cu_size_shift - curr_depth, log2_cu = S.max_cu_size_shift - pred_depth;
+		const int log2_tr = CFG_MAX_CU_SHIFT - curr_depth, log2_cu = CFG_MAX_CU_SHIFT - pred_depth;
 		const int intra_split = is_intra && part == PART_NxN, inter_split = !is_intra && S.max_inter_tr_depth == 1 && part != PART_2Nx2N;
 		const int max_tr = is_intra ? S.max_intra_tr_depth : S.max_inter_tr_depth;
 		int tu_min_in_cu;
@@ -489,34 +601,36 @@ inline void encode_transform_tree(Cabac &ee, const CuView &v, int top_ni)
 			if (first || HENC_CBF(c, abs_index, 1, tr_depth - 1)) encode_qt_cbf(ee, 1, tr_depth, HENC_CBF(c, abs_index, 1, tr_depth));
 			if (first || HENC_CBF(c, abs_index, 2, tr_depth - 1)) encode_qt_cbf(ee, 2, tr_depth, HENC_CBF(c, abs_index, 2, tr_depth));
 		}
-		depth_state[curr_depth]++;
+		depth_state.inc(curr_depth);
 		if (split_flag) {
 			parent = curr;
 			curr_depth++;
 		} else {
 			const uint32_t cbf_y = HENC_CBF(c, abs_index, 0, tr_depth), cbf_u = HENC_CBF(c, abs_index, 1, tr_depth), cbf_v = HENC_CBF(c, abs_index, 2, tr_depth);
 			if (c->pred_mode[abs_index] == PM_INTRA || tr_depth != 0 || cbf_u || cbf_v) encode_qt_cbf(ee, 0, tr_depth, cbf_y);
-			if (cbf_y) encode_residual(ee, v, curr, COMP_Y);
-			if (shift > 2) {
-				if (cbf_u) encode_residual(ee, v, curr, COMP_U);
-				if (cbf_v) encode_residual(ee, v, curr, COMP_V);
-			} else if (q.list_index == fr.geo[fr.geo[q.parent].child[0]].list_index + 3) {
-				if (cbf_u) encode_residual(ee, v, curr, COMP_U);
-				if (cbf_v) encode_residual(ee, v, curr, COMP_V);
+			if ((cbf_y || cbf_u || cbf_v) && dq.enabled && dq.write_qp) {      // the delta QP: once per quantisation group, with the first coded TU (:1660-1674)
+				encode_delta_qp(ee, v, dq, top_abs);
+				dq.write_qp = 0;
 			}
-			while (depth_state[curr_depth] == 4) {
-				depth_state[curr_depth] = 0;
-				parent = fr.geo[parent].parent;
+			// luma, then chroma - of a 4 x 4 luma block's quadruple with the last of the four (:1690-1712).  (One call site: the coder is inlined.)
+			const bool chroma_here = shift > 2 || q.list_index == v.geo[v.geo[q.parent].child[0]].list_index + 3;
+			for (int comp = 0; comp < 3; comp++) {
+				const bool coded = comp == 0 ? cbf_y != 0 : (chroma_here && (comp == 1 ? cbf_u : cbf_v) != 0);
+				if (coded) encode_residual(g, ee, v, sc, curr, comp);
+			}
+			while (depth_state.get(curr_depth) == 4) {
+				depth_state.set(curr_depth, 0);
+				parent = v.geo[parent].parent;
 				curr_depth--;
 			}
-			if (curr_depth == 0 && depth_state[curr_depth] == 1) break;
+			if (curr_depth == 0 && depth_state.get(curr_depth) == 1) break;
 		}
-		if (curr_depth == depth && depth_state[curr_depth] == 1) break;
-		curr = fr.geo[parent].child[depth_state[curr_depth]];
+		if (curr_depth == depth && depth_state.get(curr_depth) == 1) break;
+		curr = v.geo[parent].child[depth_state.get(curr_depth)];
 	}
 }
 
-inline void encode_mvd(Cabac &ee, const CtuPublic *c, int idx)
+HENC_FI void encode_mvd(Cabac &ee, const CtuPublic *c, int idx)
 {
 	const int h = c->mv_diff[idx].x, ver = c->mv_diff[idx].y;
 	const int h0 = h != 0, v0 = ver != 0, ha = habs(h), va = habs(ver);
@@ -539,11 +653,10 @@ inline void encode_mvd(Cabac &ee, const CtuPublic *c, int idx)
 }
 
 // encode_end_of_cu :1723
-inline void encode_end_of_cu(Cabac &ee, const CuView &v, int ni)
+HENC_FI void encode_end_of_cu(Cabac &ee, const EntView &v, int ni)
 {
-	const EntropyFrame &fr = *v.fr;
-	const Seq &S = *fr.seq;
-	const Geo &q = fr.geo[ni];
+	const Seq &S = *v.seq;
+	const Geo &q = v.geo[ni];
 	const uint32_t cu_addr = (uint32_t)v.n * NPART + q.abs_index;
 	const int width = S.width, height = S.height;
 	uint32_t real_end;
@@ -561,14 +674,14 @@ inline void encode_end_of_cu(Cabac &ee, const CuView &v, int ni)
 }
 
 // ee_encode_coding_unit :1787
-inline void encode_coding_unit(Cabac &ee, const CuView &v, int ni)
+template <class G>
+HENC_FI void encode_coding_unit(const G &g, Cabac &ee, const EntView &v, EntScratch &sc, DqpState &dq, int ni)
 {
-	const EntropyFrame &fr = *v.fr;
-	const Seq &S = *fr.seq;
+	const Seq &S = *v.seq;
 	const CtuPublic *c = v.c;
-	const Geo &q = fr.geo[ni];
+	const Geo &q = v.geo[ni];
 	const int abs_index = q.abs_index, is_intra = c->pred_mode[abs_index] == PM_INTRA, part = c->part_size_type[abs_index];
-	const int p_slice = fr.f->slice_type != SLICE_I;
+	const int p_slice = v.f->slice_type != SLICE_I;
 	uint32_t idx = 0;
 	if (p_slice) {
 		const CtuPublic *l = ent_pu_left(v, ni, &idx);
@@ -579,14 +692,12 @@ inline void encode_coding_unit(Cabac &ee, const CuView &v, int ni)
 	}
 	auto merge_index = [&](int a) {
 		// encode_merge_index :613 with two candidates: one context-coded bin
-		if (S.num_merge_cand > 1) {
-			const uint32_t unary = c->merge_idx[a];
-			for (int ui = 0; ui < S.num_merge_cand - 1; ui++) {
-				const uint32_t sym = ui == (int)unary ? 0 : 1;
-				if (ui == 0) ee.encode_bin(CTX_MERGE_IDX, sym);
-				else ee.encode_ep(sym);
-				if (sym == 0) break;
-			}
+		const uint32_t unary = c->merge_idx[a];
+		for (int ui = 0; ui < CFG_NUM_MERGE_CAND - 1; ui++) {
+			const uint32_t sym = ui == (int)unary ? 0 : 1;
+			if (ui == 0) ee.encode_bin(CTX_MERGE_IDX, sym);
+			else ee.encode_ep(sym);
+			if (sym == 0) break;
 		}
 	};
 	if (c->skipped[abs_index]) {
@@ -613,7 +724,7 @@ inline void encode_coding_unit(Cabac &ee, const CuView &v, int ni)
 		int dir[4], preds[4][3], pred_idx[4] = {-1, -1, -1, -1};
 		for (int j = 0; j < part_num; j++) {
 			const int pn = part_num == 4 ? q.child[j] : ni;
-			dir[j] = c->intra_mode[0][fr.geo[pn].abs_index];
+			dir[j] = c->intra_mode[0][v.geo[pn].abs_index];
 			ent_intra_preds(v, pn, preds[j]);
 			for (int i = 0; i < 3; i++)
 				if (dir[j] == preds[j][i]) pred_idx[j] = i;
@@ -649,8 +760,8 @@ inline void encode_coding_unit(Cabac &ee, const CuView &v, int ni)
 	} else {
 		// encode_inter_motion_info :777, P slice with one reference picture
 		const int num_pu = part == PART_2Nx2N ? 1 : (part == PART_NxN ? 4 : 2);
-		static const uint32_t pu_off[8] = {0, 8, 4, 4, 2, 10, 1, 5};
-		const uint32_t pu_offset = (pu_off[part] << ((S.max_cu_depth - c->pred_depth[abs_index]) << 1)) >> 4;
+		const uint32_t pu_off_part = part == PART_2Nx2N ? 0u : (part == 1 ? 8u : (part == 2 ? 4u : (part == 3 ? 4u : (part == 4 ? 2u : (part == 5 ? 10u : (part == 6 ? 1u : 5u))))));   // {0, 8, 4, 4, 2, 10, 1, 5}
+		const uint32_t pu_offset = (pu_off_part << ((S.max_cu_depth - c->pred_depth[abs_index]) << 1)) >> 4;
 		for (int p = 0, sub = abs_index; p < num_pu; p++, sub += pu_offset) {
 			ee.encode_bin(CTX_MERGE_FLAG, c->merge[sub]);
 			if (c->merge[sub]) merge_index(sub);
@@ -660,20 +771,23 @@ inline void encode_coding_unit(Cabac &ee, const CuView &v, int ni)
 			}
 		}
 	}
-	encode_transform_tree(ee, v, ni);
+	encode_transform_tree(g, ee, v, sc, dq, ni);
 	encode_end_of_cu(ee, v, ni);
 }
 
-// ee_encode_ctu :2039
-inline void encode_ctu_syntax(Cabac &ee, const EntropyFrame &fr, int n)
+// ee_encode_ctu :2039.  Under rate control the walk also applies the reference's QP rule for uncoded CUs: a CU without levels that comes before the first
+// coded CU of its quantisation group (the CTU) takes the predictor as its QP (:2091-2104) - written into the record, where the next CTU's predictor and the
+// delta-QP of this one read it.
+template <class G>
+HENC_FI void encode_ctu_syntax(const G &g, Cabac &ee, const EntView &v, EntScratch &sc)
 {
-	const Seq &S = *fr.seq;
-	CuView v{&fr, n, &fr.ctu(n)};
-	int depth_state[NDEPTH] = {0, 0, 0, 0, 0};
+	const Seq &S = *v.seq;
+	DepthState depth_state;
 	int curr = 0, curr_depth = 0;
 	const int min_cu_depth = S.max_cu_depth - S.mincu_mintr_shift_diff;
-	while (curr_depth != 0 || depth_state[curr_depth] != 1) {
-		const Geo &q = fr.geo[curr];
+	DqpState dq = {S.bitrate_mode != 0, 1, 0, 0};
+	while (curr_depth != 0 || depth_state.get(curr_depth) != 1) {
+		const Geo &q = v.geo[curr];
 		const bool inside = node_inside(v, curr);
 		if (inside && q.depth != min_cu_depth) {
 			// encode_split_flag :391
@@ -685,124 +799,43 @@ inline void encode_ctu_syntax(Cabac &ee, const EntropyFrame &fr, int n)
 			ctx += t ? (t->pred_depth[idx] > q.depth ? 1 : 0) : 0;
 			ee.encode_bin(CTX_SPLIT_FLAG + ctx, split);
 		}
+		if (dq.enabled && q.depth == 0) {      // a new quantisation group (diff_cu_qp_delta_depth = 0): get_ref_qp :1487 = the last coded QP
+			dq.ref_qp = v.prev_last_qp >= 0 ? v.prev_last_qp : v.f->qp;
+			dq.found_coded = 0;
+		}
 		const int pred_depth = v.c->pred_depth[q.abs_index];
-		depth_state[curr_depth]++;
+		depth_state.inc(curr_depth);
 		if (curr_depth < pred_depth) {
+			if (dq.enabled && depth_state.get(curr_depth) == 1 && curr_depth == 0) dq.write_qp = 1;
 			curr_depth++;
-			curr = q.child[depth_state[curr_depth]];
+			curr = q.child[depth_state.get(curr_depth)];
 		} else {
-			if (inside) encode_coding_unit(ee, v, curr);
-			while (depth_state[curr_depth] == 4) {
-				depth_state[curr_depth] = 0;
-				curr_depth--;
-				curr = fr.geo[curr].parent;
+			if (inside) {
+				if (dq.enabled && !dq.found_coded) {
+					if (v.c->cbf[0][q.abs_index] || v.c->cbf[1][q.abs_index] || v.c->cbf[2][q.abs_index]) {
+						dq.found_coded = 1;
+						if (depth_state.get(curr_depth) > 1) dq.write_qp = 1;
+					} else {
+						for (int i = g.tid; i < q.num_part; i += g.n) v.c->qp[q.abs_index + i] = (uint8_t)dq.ref_qp;
+						g.sync();
+					}
+				}
+				if (dq.enabled && q.depth <= 0) dq.write_qp = 1;
+				encode_coding_unit(g, ee, v, sc, dq, curr);
 			}
-			if (fr.geo[curr].parent >= 0) curr = fr.geo[fr.geo[curr].parent].child[depth_state[curr_depth]];
+			while (depth_state.get(curr_depth) == 4) {
+				depth_state.set(curr_depth, 0);
+				curr_depth--;
+				curr = v.geo[curr].parent;
+			}
+			if (v.geo[curr].parent >= 0) curr = v.geo[v.geo[curr].parent].child[depth_state.get(curr_depth)];
 		}
 	}
 }
 
-// ---- SAO decision: the shared part is enc_sao.h; here the candidate derivation from the statistics as the reference does it on the CPU ------------
-// est_iter_offset :445
-inline int sao_iter_offset(int type_idx, double lambda, int offset_input, int64_t count, int64_t diff, int64_t *best_dist, double *best_cost)
-{
-	int iter = offset_input, out = 0;
-	double min_cost = lambda;
-	while (iter != 0) {
-		int64_t rate = type_idx == SAO_BO ? habs(iter) + 2 : habs(iter) + 1;
-		if (habs(iter) == 7) rate--;
-		const int64_t dist = est_sao_dist(count, iter, diff);
-		const double cost = (double)dist + lambda * (double)rate;
-		if (cost < min_cost) {
-			min_cost = cost;
-			out = iter;
-			*best_dist = dist;
-			*best_cost = cost;
-		}
-		iter = iter > 0 ? iter - 1 : iter + 1;
-	}
-	return out;
-}
-
-// sao_derive_offsets :480
-inline void sao_derive_offsets(const double *lambdas, int comp, int type, const int32_t (*st)[32], int *q, int *aux)
-{
-	memset(q, 0, sizeof(int) * 32);
-	const int num = type == SAO_BO ? 32 : 5;
-	for (int k = 0; k < num; k++) {
-		if (type != SAO_BO && k == 2) continue;
-		if (st[1][k] == 0) continue;
-		const double x = (double)(int64_t)st[0][k] / (double)(int64_t)st[1][k];
-		q[k] = x >= 0 ? (int)(x + 0.5) : (int)(x - 0.5);
-		q[k] = hclip(q[k], -7, 7);
-	}
-	if (type != SAO_BO) {
-		int64_t d;
-		double cst;
-		for (int k = 0; k < 5; k++) {
-			if (k == 0 && q[k] < 0) q[k] = 0;
-			if (k == 1 && q[k] < 0) q[k] = 0;
-			if (k == 3 && q[k] > 0) q[k] = 0;
-			if (k == 4 && q[k] > 0) q[k] = 0;
-			if (q[k] != 0) q[k] = sao_iter_offset(type, lambdas[comp], q[k], st[1][k], st[0][k], &d, &cst);
-		}
-		*aux = 0;
-	} else {
-		int64_t dist[32];
-		double cost[32];
-		memset(dist, 0, sizeof dist);
-		for (int k = 0; k < 32; k++) {
-			cost[k] = lambdas[comp];
-			if (q[k] != 0) q[k] = sao_iter_offset(type, lambdas[comp], q[k], st[1][k], st[0][k], &dist[k], &cost[k]);
-		}
-		double min_cost = MAX_COST;
-		for (int band = 0; band < 32 - 4 + 1; band++) {
-			double cst = cost[band];
-			cst += cost[band + 1];
-			cst += cost[band + 2];
-			cst += cost[band + 3];
-			if (cst < min_cost) { min_cost = cst; *aux = band; }
-		}
-		int clear[32];
-		memset(clear, 0, sizeof clear);
-		for (int i = 0; i < 4; i++) { const int band = (*aux + i) % 32; clear[band] = q[band]; }
-		memcpy(q, clear, sizeof clear);
-	}
-}
-// sao_invert_quant_offsets :592 (8 bit: step 1) - also clears what the type does not use
-inline void sao_invert_quant(int type, int aux, int *dst, const int *src)
-{
-	int coded[32];
-	memcpy(coded, src, sizeof coded);
-	memset(dst, 0, sizeof(int) * 32);
-	if (type == SAO_BO)
-		for (int i = 0; i < 4; i++) dst[(aux + i) % 32] = coded[(aux + i) % 32];
-	else
-		for (int i = 0; i < 5; i++) dst[i] = coded[i];
-}
-// the candidates of SAO_MODE_NEW from the statistics (on the device k_sao_offsets has them ready: k_saooffsets.hip)
-struct SaoCandFromStats {
-	const double *lambdas;
-	const SaoStats *st;
-	int64_t get(int comp, int type, SaoOffset &t) const
-	{
-		int inv[32];
-		sao_derive_offsets(lambdas, comp, type, (*st)[comp][type], t.offset, &t.type_aux);
-		sao_invert_quant(type, t.type_aux, inv, t.offset);
-		return sao_distortion(type, t.type_aux, inv, (*st)[comp][type]);
-	}
+struct EntropyState {
+	int last_idr = 0;
 };
-// sao_decide_blk_params :1295 for CTU n with the real coder `ee` standing before the CTU's SAO syntax
-inline void sao_decide_ctu(const Cabac &ee, const EntropyFrame &fr, int n, const SaoStats &stats, const double *lambdas)
-{
-	const Seq &S = *fr.seq;
-	CtuPublic &c = fr.ctu_rw(n);
-	const int cx = n % S.wctu, cy = n / S.wctu;
-	const SaoTables T = {kEntropyBits, kNextStateLps};
-	const SaoCandFromStats cand = {lambdas, &stats};
-	sao_decide(T, ee.ctx[CTX_SAO_MERGE], ee.ctx[CTX_SAO_TYPE], cand, stats, cx > 0 ? fr.ctu(n - 1).sao_recon : nullptr, cy > 0 ? fr.ctu(n - S.wctu).sao_recon : nullptr, lambdas,
-		   c.sao_coded, c.sao_recon);
-}
 
 // ---- parameter sets, slice header, access unit ------------------------------------------------------------------------------------
 inline void put_nal_header(std::vector<uint8_t> &out, int type)
@@ -821,7 +854,7 @@ inline void put_profile_tier_level(BitWriter &bs, int profile)
 // hmr_put_vps_header :99, hmr_put_seq_header :204, hmr_put_pic_header :312 for one sub-layer
 inline void write_parameter_sets(const Seq &S, int profile, std::vector<uint8_t> &vps, std::vector<uint8_t> &sps, std::vector<uint8_t> &pps)
 {
-	BitWriter bs;
+	HostBits bs;
 	bs.write(0, 4); bs.write(3, 2); bs.write(0, 6); bs.write(0, 3); bs.write(1, 1); bs.write(0xffff, 16);
 	put_profile_tier_level(bs, profile);
 	bs.write(1, 1);
@@ -831,7 +864,7 @@ inline void write_parameter_sets(const Seq &S, int profile, std::vector<uint8_t>
 	put_nal_header(vps, 32);
 	nalu_ebsp(bs, vps);
 
-	bs = BitWriter();
+	bs = HostBits();
 	bs.write(0, 4); bs.write(0, 3); bs.write(1, 1);
 	put_profile_tier_level(bs, profile);
 	bs.uvlc(0); bs.uvlc(1);
@@ -870,7 +903,7 @@ inline void write_parameter_sets(const Seq &S, int profile, std::vector<uint8_t>
 	put_nal_header(sps, 33);
 	nalu_ebsp(bs, sps);
 
-	bs = BitWriter();
+	bs = HostBits();
 	bs.uvlc(0); bs.uvlc(0);
 	bs.write(0, 1); bs.write(0, 1); bs.write(0, 3);
 	bs.write(S.sign_hiding, 1);
@@ -895,11 +928,10 @@ inline void write_parameter_sets(const Seq &S, int profile, std::vector<uint8_t>
 }
 
 // count_needed_start_codes, hmr_headers.c:573
-inline uint32_t count_escapes(const BitWriter &b)
+inline uint32_t count_escapes(const uint8_t *data, int size)
 {
 	uint32_t cnt = 0;
-	const int size = b.bytecnt;
-	std::vector<uint8_t> p(b.buf.begin(), b.buf.begin() + size);
+	std::vector<uint8_t> p(data, data + size);
 	p.resize(size + 8, 0);
 	int i = 0;
 	while (i < size) {
@@ -915,77 +947,12 @@ inline uint32_t count_escapes(const BitWriter &b)
 	return cnt;
 }
 
-struct EntropyState {
-	std::vector<BitWriter> rows;      // one sub-stream per CTU row (aux_bs)
-	Cabac ee, saved;                  // the coding environment and the copy the next row starts from (ee_list pair)
-	int last_idr = 0;
-	bool sets_written = false;
-};
-
-// The entropy stage of one frame: SAO decision + CTU syntax per CTU in raster order, then the access unit in Annex-B form appended to `out`.
-// stats: SAO statistics of every CTU: the SAO parameters are decided here and land in the CTU records (sao_coded / sao_recon); nullptr when SAO is off or when
-// the records already carry the parameters (the device path: k_sao_decide).
-inline void encode_frame_entropy(EntropyState &es, const EntropyFrame &fr, const SaoStats *stats, int profile, std::vector<uint8_t> &out)
+// The access unit of a frame from its CABAC sub-streams (one per CTU row with WPP, else one): parameter sets in front of an IDR picture, slice header with the
+// entry points, the sub-streams, NAL escaping, Annex-B start codes (encoder_engine_thread :3287-3330, HOMER_enc_write_annex_b_output :2196) - appended to `out`.
+// init_qp: the QP the picture parameter set was written with (pic_init_qp_minus26 + 26: the configured QP, hmr_encoder_lib.c:1611).
+inline void assemble_access_unit(EntropyState &es, const Seq &S, const FrameCtx &f, int profile, const uint8_t *const *row_data, const int *row_bytes, std::vector<uint8_t> &out)
 {
-	const Seq &S = *fr.seq;
-	const FrameCtx &f = *fr.f;
-	const int W = S.wctu, H = S.hctu;
-	es.rows.resize(H);
-	double sao_lambda[3];
-	sao_lambdas(S, f, sao_lambda);
-	es.ee.counter = false;
-	for (int n = 0; n < S.nctu; n++) {
-		const int cx = n % W, cy = n / W;
-		// wfpp_encode_select_bitstream :2299
-		if (n == 0) {
-			es.ee.bs = &es.rows[0];
-			es.rows[0].init();
-			es.ee.init_contexts(f.slice_type, f.qp);
-			es.ee.start();
-			es.ee.reset_bits();
-		} else if (S.wpp) {
-			if (cy > 0 && cx == 0) memcpy(es.ee.ctx, es.saved.ctx, sizeof es.ee.ctx);
-			es.ee.bs = &es.rows[cy];
-			if (cx == 0) {
-				es.rows[cy].init();
-				es.ee.start();
-				es.ee.reset_bits();
-			}
-		}
-		if (S.sao) {
-			if (stats) sao_decide_ctu(es.ee, fr, n, stats[n], sao_lambda);   // (no statistics: the records already hold the decision, made on the device)
-#if defined(HENC_SAO_TRACE)
-			if (henc_sao_trace_file && stats) {
-				fprintf(henc_sao_trace_file, "SAO frame=%d ctu=%d", f.num_encoded_frames, n);
-				for (int c3 = 0; c3 < 3; c3++) {
-					const SaoOffset &o = fr.ctu(n).sao_coded[c3];
-					fprintf(henc_sao_trace_file, " | %d", o.mode_idc);
-					if (o.mode_idc != SAO_OFF) {
-						fprintf(henc_sao_trace_file, " %d %d :", o.type_idc, o.type_aux);
-						if (o.mode_idc == SAO_NEW)
-							for (int k = 0; k < (o.type_idc == SAO_BO ? 32 : 5); k++) fprintf(henc_sao_trace_file, " %d", o.offset[k]);
-					}
-				}
-				fprintf(henc_sao_trace_file, " bits=%d\n", es.ee.bs->bitcount());
-				for (int c3 = 0; c3 < 3; c3++)
-					for (int t = 0; t < 5; t++) {
-						fprintf(henc_sao_trace_file, "  ST %d %d :", c3, t);
-						for (int k = 0; k < (t == 4 ? 32 : 5); k++) fprintf(henc_sao_trace_file, " %d/%d", stats[n][c3][t][0][k], stats[n][c3][t][1][k]);
-						fprintf(henc_sao_trace_file, "\n");
-					}
-			}
-#endif
-			code_sao_blk_param(es.ee, fr.ctu(n).sao_coded, cx > 0, cy > 0);
-		}
-		encode_ctu_syntax(es.ee, fr, n);
-		if (cx == 1 && cy + 1 != H && S.wpp) memcpy(es.saved.ctx, es.ee.ctx, sizeof es.saved.ctx);
-		if ((S.wpp && cx + 1 == W) || (!S.wpp && n + 1 == S.nctu)) {
-			es.ee.encode_trm(1);
-			es.ee.finish();
-			es.ee.bs->trailing_bits();
-		}
-	}
-	// ---- access unit (encoder_engine_thread :3287-3330)
+	const int H = S.hctu, nrows = S.wpp ? H : 1;
 	const bool idr = f.slice_type == SLICE_I;
 	if (idr) es.last_idr = f.poc;
 	std::vector<std::vector<uint8_t>> nals;
@@ -994,7 +961,7 @@ inline void encode_frame_entropy(EntropyState &es, const EntropyFrame &fr, const
 		write_parameter_sets(S, profile, vps, sps, pps);
 		nals.push_back(vps); nals.push_back(sps); nals.push_back(pps);
 	}
-	BitWriter sh;
+	HostBits sh;
 	{
 		// hmr_put_slice_header :375
 		sh.write(1, 1);                        // first_slice_in_pic_flag
@@ -1021,7 +988,7 @@ inline void encode_frame_entropy(EntropyState &es, const EntropyFrame &fr, const
 			uint32_t max_offset = 0, len_m1 = 1;
 			std::vector<uint32_t> ep(num > 0 ? num : 0);
 			for (int i = 0; i < num; i++) {
-				ep[i] = es.rows[i].bytecnt + count_escapes(es.rows[i]);
+				ep[i] = row_bytes[i] + count_escapes(row_data[i], row_bytes[i]);
 				if (ep[i] > max_offset) max_offset = ep[i];
 			}
 			while (max_offset >= (1u << (len_m1 + 1))) len_m1++;
@@ -1032,20 +999,18 @@ inline void encode_frame_entropy(EntropyState &es, const EntropyFrame &fr, const
 		sh.trailing_bits();
 	}
 	{
-		BitWriter all;
-		all.need((size_t)sh.bytecnt + 16);
 		size_t total = sh.bytecnt;
-		for (int r = 0; r < (S.wpp ? H : 1); r++) total += es.rows[r].bytecnt;
-		all.buf.assign(total + 16, 0);
-		memcpy(all.buf.data(), sh.buf.data(), sh.bytecnt);
-		all.bytecnt = sh.bytecnt;
-		for (int r = 0; r < (S.wpp ? H : 1); r++) {
-			memcpy(all.buf.data() + all.bytecnt, es.rows[r].buf.data(), es.rows[r].bytecnt);
-			all.bytecnt += es.rows[r].bytecnt;
+		for (int r = 0; r < nrows; r++) total += row_bytes[r];
+		std::vector<uint8_t> all(total);
+		memcpy(all.data(), sh.buf, sh.bytecnt);
+		size_t o = sh.bytecnt;
+		for (int r = 0; r < nrows; r++) {
+			memcpy(all.data() + o, row_data[r], row_bytes[r]);
+			o += row_bytes[r];
 		}
 		std::vector<uint8_t> nal;
 		put_nal_header(nal, idr ? 19 : 1);
-		nalu_ebsp(all, nal);
+		nalu_ebsp(all.data(), (int)all.size(), nal);
 		nals.push_back(nal);
 	}
 	// HOMER_enc_write_annex_b_output :2196

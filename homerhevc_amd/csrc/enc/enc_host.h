@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <vector>
 #include "enc_types.h"
+#include "enc_rc.h"
 
 namespace henc {
 
@@ -51,7 +52,9 @@ inline bool make_seq(HostCfg cfg, Seq &s, const char **why)
 	if (cfg.cu_size != 64) { *why = "cu_size != 64"; return false; }
 	if (cfg.num_b != 0 || cfg.gop_size != 1) { *why = "B frames"; return false; }
 	if (cfg.num_ref_frames != 1) { *why = "num_ref_frames != 1"; return false; }
-	if (cfg.bitrate_mode != 0) { *why = "rate control (fixed QP only)"; return false; }
+	if (cfg.bitrate_mode < 0 || cfg.bitrate_mode > 2) { *why = "bitrate_mode"; return false; }
+	if (cfg.bitrate_mode != 0 && cfg.num_enc_engines > 1) { *why = "rate control with num_enc_engines > 1"; return false; }
+	if (cfg.bitrate_mode != 0 && (cfg.bitrate <= 0 || cfg.vbv_size <= 0 || cfg.frame_rate <= 0)) { *why = "rate control needs bitrate, vbv_size and frame_rate"; return false; }
 	if (cfg.rd_mode == RDM_FULL) { *why = "rd_mode RD_FULL"; return false; }
 	if (cfg.performance_mode > 2) { *why = "performance_mode 3"; return false; }
 	s.max_cu_size = 64;
@@ -72,6 +75,11 @@ inline bool make_seq(HostCfg cfg, Seq &s, const char **why)
 		if (n > 32) { *why = "wfpp_num_threads above the reference's 32"; return false; }
 		if (n > hc) { *why = "more WPP threads than CTU rows"; return false; }
 		if (n > 1 && n < hc && 2 * n < wc) { *why = "wfpp_num_threads between 1 and the number of CTU rows needs 2 x threads >= CTU columns"; return false; }
+	}
+	{
+		const int wc = (cfg.width + 63) / 64, hc = (cfg.height + 63) / 64;
+		if (hc > POST_MAX_ROWS) { *why = "more than 128 CTU rows"; return false; }
+		if (cfg.wfpp_num_threads > 1 && wc + 2 * (hc - 1) > HENC_MAX_STEPS) { *why = "more than 192 wavefront steps (CTU columns + 2 x (CTU rows - 1))"; return false; }
 	}
 	if ((cfg.width + 63) / 64 < 2) { *why = "picture narrower than two CTUs"; return false; }
 	{
@@ -183,7 +191,18 @@ struct HostState {
 	double avg_dist = 0.0;          // hvenc->avg_dist: calloc'ed, so the first frame runs with 0 (hmr_encoder_lib.c:3191)
 	double avg_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // hvenc->avg_dist after each of the last eight frames
 	int engines = 1, pad_ = 0;
+	RcState rc = {};                // rate control (enc_rc.h): hvenc->rc, pict_qp
 };
+// HVENC_Cfg rates -> the rate control's sequence state (HOMER_SETCFG hmr_encoder_lib.c:949-963 + hmr_rc_init)
+inline void host_rc_init(const HostCfg &cfg, const Seq &s, HostState &st)
+{
+	double vbv_size = cfg.vbv_size, vbv_init = cfg.vbv_init;
+	if (cfg.bitrate_mode == BR_VBR) {
+		vbv_size = cfg.vbv_size * 20;
+		vbv_init = ((double)cfg.vbv_init / (double)cfg.vbv_size) * vbv_size;
+	}
+	rc_init(st.rc, (double)cfg.bitrate, vbv_size, vbv_init, cfg.frame_rate, s.nctu, cfg.qp);
+}
 constexpr int MAX_ENGINES = 8;       // hmr_private.h:1232
 
 enum { IMG_AUTO = 0, IMG_B = 1, IMG_P = 2, IMG_I = 3 };
@@ -201,6 +220,13 @@ inline void begin_frame(const Seq &s, HostState &st, int image_type, FrameCtx &f
 	f.slice_type = intra ? SLICE_I : SLICE_P;
 	f.poc = poc;
 	f.qp = s.qp;
+	if (s.bitrate_mode != BR_FIXED_QP) {
+		// hmr_slice_init :1990 (the slice QP is the frame QP the last frame left), hmr_rc_init_pic
+		f.qp = st.rc.pict_qp;
+		rc_init_pic(st.rc, f.slice_type, s.intra_period);
+		rc_frame_view(st.rc, s.nctu, s.bitrate_mode, f.rc);
+		f.rc.sqrt_clipped_intra_period = sqrt((double)rc_clipped_intra_period(s.intra_period));
+	}
 	f.num_encoded_frames = st.num_encoded_frames;
 	f.is_scene_change = 0;
 	f.scene_cut_ctu = -1;
@@ -209,7 +235,7 @@ inline void begin_frame(const Seq &s, HostState &st, int image_type, FrameCtx &f
 	f.scene_cut_allowed = f.slice_type == SLICE_P && st.num_encoded_frames > 1 && 20 < poc - st.last_gop_reinit;
 	f.ref_poc = poc - 1;
 	f.avg_dist = st.num_encoded_frames >= st.engines ? st.avg_hist[(st.num_encoded_frames - st.engines) & 7] : 0.0;   // one engine: the frame before
-	const double qp_temp = (double)s.qp - 12;
+	const double qp_temp = (double)f.qp - 12;      // hmr_rd_init: enc_engine->pict_qp
 	const double lambda_scale = 1.0 - fmin(fmax(0.05 * (double)(s.gop_size - 1), 0.0), 0.5);
 	double qp_factor = 0.4624;
 	if (f.slice_type == SLICE_I) qp_factor = 0.57 * lambda_scale;
@@ -239,8 +265,14 @@ inline double frame_acc_dist(const Seq &s, int threads, DistFn &&dist_of)
 	return total;
 }
 
-// :3217-3238 after the CTUs of a frame: acc_dist = frame_acc_dist
-inline void end_frame(const Seq &s, HostState &st, const FrameCtx &f, double acc_dist)
+// what the rate control takes from a finished frame: the sum of the CTUs' QPs (acc_qp, hmr_encoder_lib.c:2938), the bits of all its CTUs, and the picture target as
+// the frame left it (hmr_rc_change_pic_mode moves it when a scene change is found)
+struct FrameRcOut {
+	int sum_qp;
+	double consumed_bits, target_pict_size;
+};
+// :3217-3262 after the CTUs of a frame: acc_dist = frame_acc_dist
+inline void end_frame(const Seq &s, HostState &st, const FrameCtx &f, double acc_dist, const FrameRcOut *rc = nullptr)
 {
 	const bool scene_change = f.scene_cut_ctu >= 0;     // :3796-3800: the frame was found to be a new scene while it was encoded
 	if (scene_change) {
@@ -255,6 +287,9 @@ inline void end_frame(const Seq &s, HostState &st, const FrameCtx &f, double acc
 		else if (scene_change) a *= 1.375;
 		st.avg_dist = a;
 	}
+	if (s.bitrate_mode != BR_FIXED_QP && rc)
+		rc_end_pic(st.rc, f.slice_type, s.intra_period, s.bitrate_mode, s.nctu, st.num_encoded_frames == 0 || f.slice_type != SLICE_I || s.intra_period == 1, rc->sum_qp, st.avg_dist,
+			   scene_change, rc->consumed_bits, rc->target_pict_size);
 	st.avg_hist[st.num_encoded_frames & 7] = st.avg_dist;    // (an I frame inside the sequence keeps the value pushed by the frame before it, :3268-3279)
 	st.num_encoded_frames++;
 }

@@ -357,13 +357,6 @@ HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, int ox, int 
 }
 
 // ---- candidate derivation ---------------------------------------------------------------------------------------------
-HENC_INLINE int raster2abs(int r)   // raster2abs_table for the 16 x 16 unit grid (hmr_encoder_lib.c:95-100)
-{
-	const int x = r & 15, y = r >> 4;
-	int a = 0;
-	for (int b = 0; b < 4; b++) a |= (((x >> b) & 1) << (2 * b)) | (((y >> b) & 1) << (2 * b + 1));
-	return a;
-}
 struct CornerNodes { int lb, tl, tr; };
 HENC_INLINE CornerNodes corner_nodes(Enc &__restrict__ e, int ni)
 {

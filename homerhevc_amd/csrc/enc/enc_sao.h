@@ -270,4 +270,16 @@ inline void sao_lambdas(const Seq &S, const FrameCtx &f, double *sao_lambda)
 	sao_lambda[1] = sao_lambda[2] = qp_factor * pow(1.4, (qp_temp + S.chroma_qp_offset) / 1.4);
 }
 
+// the same for every QP a CTU can have: tab[qp][0] luma, [qp][1] chroma (under rate control hmr_wpp_sao_ctu takes the QP of the CTU's first unit, :1420)
+inline void sao_lambda_table(const Seq &S, int slice_type, double *tab)
+{
+	const double lambda_scale = 1.0 - hclip(0.05 * (double)(S.gop_size - 1), 0.0, 0.5);
+	const double qp_factor = slice_type == SLICE_I ? 0.57 * lambda_scale : 0.4624;
+	for (int qp = 0; qp < 52; qp++) {
+		const double qp_temp = (double)qp - 12;
+		tab[2 * qp] = qp_factor * pow(1.4, qp_temp / 1.4);
+		tab[2 * qp + 1] = qp_factor * pow(1.4, (qp_temp + S.chroma_qp_offset) / 1.4);
+	}
+}
+
 }  // namespace henc

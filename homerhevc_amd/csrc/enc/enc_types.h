@@ -28,6 +28,8 @@ constexpr int NWND = 7;                    // NUM_QUANT_WNDS / NUM_DECODED_WNDS
 constexpr uint32_t MAX_COST = 0xffffffffu / 8;   // hmr_private.h:55
 
 constexpr int MAX_SEARCH_LOGS = 192, MAX_RATIO_CMP = 96;
+constexpr int POST_MAX_ROWS = 128;            // CTU rows of a picture (8192 lines)
+constexpr int HENC_MAX_STEPS = 192;            // wavefront steps of a picture in the row-per-thread schedule: CTU columns + 2 x (CTU rows - 1)
 constexpr int MODE_TOKEN = 0x80;           // worker mode buffers: MODE_TOKEN | depth = "whatever this unit held at depth `depth` when the CTU started"
 
 constexpr int SEARCH_RANGE_X = 128, SEARCH_RANGE_Y = 64;   // hmr_private.h:76-77
@@ -141,6 +143,14 @@ struct Seq {
 	int32_t pad_;
 };
 
+// what the CTU walk reads of the rate control of its frame (enc_rc.h; rate_control_t, hmr_private.h:977-990)
+struct RcFrame {
+	double vbv_size, vbv_fullness, target_bits_per_ctu, target_pict_size, average_pict_size;
+	double sqrt_clipped_intra_period;      // hmr_rc_change_pic_mode :65 (sqrt() stays on the host)
+	int32_t extra_bits, on;                // on: bitrate_mode != BR_FIXED_QP
+	int32_t qp_min, is_vbr;
+};
+
 struct FrameCtx {
 	int32_t slice_type, poc, qp, num_encoded_frames, is_scene_change, ref_poc;
 	// scene-change detection inside a P frame (hmr_motion_inter.c:3791-3806): when the running intra share passes 70 % the remaining CTUs of the frame
@@ -158,6 +168,7 @@ struct FrameCtx {
 	// interpolated at that quarter-sample phase, chroma plane (mvy & 7) * 8 + (mvx & 7) likewise in eighth samples; the planes are row-interleaved
 	// (row y of plane f starts at (y * 16 + f) * stride_y, chroma (y * 64 + f) * stride_c) and share the reference's row length and margins.  Device only (the checker build interpolates from ref[]).
 	const uint8_t *sub_y, *sub_c[2];
+	RcFrame rc;
 };
 
 struct MvCandList {

@@ -29,7 +29,7 @@
 #include "common.h"
 #include "enc/enc_sched.h"
 #include "enc/enc_host.h"
-#include "enc/enc_entropy.h"
+#include "enc/enc_post.h"
 
 using namespace henc;
 
@@ -59,6 +59,8 @@ struct EncDev {
 	int *row0_checked;            // lockstep schedule: steps for which row 0 has made its scene-change check
 	int *counters;                // [0] CTUs found wrong by the last check, [1] CTU encodes of the frame, [2] the CTU at which a scene change is detected (-1: none)
 	int threads;                  // lockstep schedule: wfpp_num_threads (row r is encoded by thread r % threads)
+	RcFrame *rc_dyn;              // rate control: the frame's parameters after a scene change moved them (hmr_rc_change_pic_mode), [0]; valid once counters[2] >= 0
+	PostPic post;                 // the post-decision stage of the picture (enc_post.h): deblocking, SAO, entropy coding, padding as tasks of the CTU kernel
 };
 
 __device__ __forceinline__ void wave_copy_words(void *dst, const void *src, int bytes, int tid)
@@ -323,7 +325,7 @@ struct PoolSeq {
 	int *ticket;        // [steps] CTUs of the step handed out
 	int *done;          // [steps] CTUs of the step finished
 };
-constexpr int POOL_MAX_STEPS = 192;             // W + 2 (H - 1) for 64 x 34 CTUs and more
+constexpr int POOL_MAX_STEPS = HENC_MAX_STEPS;  // W + 2 (H - 1): enc_host.h refuses pictures with more wavefront steps
 constexpr int POOL_STRIDE = 1 + 2 * POOL_MAX_STEPS;
 
 // rows of step t: r_lo .. r_hi (empty when r_lo > r_hi)
@@ -334,7 +336,7 @@ __device__ __forceinline__ void pool_step_rows(int t, int W, int H, int *r_lo, i
 	*r_hi = (t >> 1) < H - 1 ? (t >> 1) : H - 1;
 }
 
-__device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const WaveGrp &g, Seq *lseq, FrameCtx *lframe, FastTables *lft, int t, int row, int *cached_rem)
+__device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const WaveGrp &g, Seq *lseq, FrameCtx *lframe, FastTables *lft, int t, int row, int *cached_rem, const int *abort_flag)
 {
 	const Seq &S = *lseq;
 	const int W = S.wctu, H = S.hctu;
@@ -358,18 +360,41 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 	}
 	g.sync();
 	const int hrow = t / (2 * T) * T;   // thread 0's row that is inside the picture at this step, if any
+	// rate control: the bits and the number of the CTUs the reference has entropy coded when this step starts
+	uint32_t rc_bits = 0;
+	int rc_ctus = 0;
+	if (lframe->rc.on) rc_consumed(g, d.post, W, H, t, &rc_bits, &rc_ctus);
 	if (row == hrow) {
 		if (g.tid == 0) {
-			if (d.counters[2] < 0 && lframe->slice_type == SLICE_P && scene_cut_fires(S, *lframe, ti, tc * NPART)) d.counters[2] = n;
+			if (d.counters[2] < 0 && lframe->slice_type == SLICE_P && scene_cut_fires(S, *lframe, ti, tc * NPART)) {
+				if (lframe->rc.on) {
+					RcFrame nrc = lframe->rc;
+					rc_change_pic_mode(nrc, S.reinit_gop, S.intra_period, S.nctu, nrc.sqrt_clipped_intra_period, rc_bits, rc_ctus);
+					*d.rc_dyn = nrc;
+				}
+				d.counters[2] = n;
+			}
 			__hip_atomic_store(d.row0_checked, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	} else if (hrow < H && t - 2 * hrow < W) {
-		while (__hip_atomic_load(d.row0_checked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t + 1) __builtin_amdgcn_s_sleep(8);
+		while (__hip_atomic_load(d.row0_checked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t + 1 && !__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) __builtin_amdgcn_s_sleep(8);
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 	}
 	g.sync();
 	if (g.tid == 0) lframe->scene_cut_ctu = __hip_atomic_load(&d.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	g.sync();
+	e.ctu_qp = lframe->qp;
+	if (lframe->rc.on) {
+		// hmr_rc_calc_cu_qp at the CTU's root.  is_scene_change: set by the detecting CTU before its own walk (hmr_motion_inter.c:3795-3796) and seen by everything
+		// from its step on; the picture target it moved comes from d.rc_dyn
+		const int cut = lframe->scene_cut_ctu;
+		const int is_sc = cut >= 0 && t >= cut % W + 2 * (cut / W);
+		if (is_sc) {
+			wave_copy_words(&lframe->rc, d.rc_dyn, (int)sizeof(RcFrame), g.tid);
+			g.sync();
+		}
+		e.ctu_qp = rc_calc_cu_qp(lframe->rc, (double)rc_bits, rc_ctus, lframe->slice_type, is_sc, S.reinit_gop, S.intra_period, lframe->avg_dist, lframe->num_encoded_frames);
+	}
 	wave_copy_words(e.w->mode_in, e.w->intra_mode_buffs, MODE_STATE_BYTES, g.tid);
 	e.total_intra_partitions = ti;
 	e.total_partitions = tc * NPART;
@@ -399,10 +424,35 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 		atomicAdd(&d.counters[1], 1);
 	}
 	g.sync();
+	// the CTU is decided: its post-decision tasks may run (enc_post.h)
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+	if (g.tid == 0) post_st_release(&d.post.rows[row].dec, c + 1);
 }
 
-__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void k_encode_pool(const EncDev *devs, int nseq, int *state, int *finished, WorkSlow *slow)
+// post-decision tasks of picture q that are ready, on this worker (its Work area is scratch between two CTUs); *finished counts the pictures whose last task is done
+__device__ __attribute__((noinline)) int pool_post_drain(const EncDev &d, const WaveGrp &g, const Seq *lseq, const FrameCtx *lframe, Work *lw, WorkSlow *my_slow, int *finished)
 {
+	if (post_finished(*lseq, d.post)) return 0;
+	PostCtx x;
+	x.seq = lseq; x.f = lframe; x.T = d.tables; x.geo.p = nullptr; x.ctus = d.ctus; x.coeff = d.coeff; x.pic = &d.post;
+	PostScratch &sc = *(PostScratch *)in_fast_memory((uint8_t *)lw);
+	const int ran = post_drain(g, x, sc);
+	if (ran) {
+		if (g.tid == 0) lw->slow = my_slow;      // (the scratch overlays the worker's Work)
+		g.sync();
+		// whoever completes the picture's last task says so - exactly one worker sees its own completion of it
+		if (post_finished(*lseq, d.post) && g.tid == 0) {
+			if (atomicCAS(&d.post.errors[1], 0, 1) == 0) atomicAdd(finished, 1);
+		}
+	}
+	return ran;
+}
+
+__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void k_encode_pool(const EncDev *devs, int nseq, int *state, int *finished, WorkSlow *slow, unsigned long long watchdog_ticks)
+{
+	// finished[0]: pictures whose last task is done; finished[1]: abort - a worker has waited longer than the watchdog allows (a faulted or starved peer): everybody
+	// leaves and the host reports an error instead of the launch hanging
+	const unsigned long long t_start = wall_clock64();
 	if (!rows_enter()) return;
 	extern __shared__ __align__(16) uint8_t lds[];
 	WaveGrp g{(int)(threadIdx.x & 63)};
@@ -454,7 +504,15 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(2))
 				}
 			}
 			if (g.any(!all_finished)) all_finished = false;
-			const uint64_t m = g.ballot(open);
+			uint64_t m = g.ballot(open);
+			// rate control: a step opens when the CTUs its decisions read the bits of have been entropy coded (enc_rc.h)
+			while (m) {
+				const int lane0 = __builtin_ctzll(m);
+				const int q0 = __builtin_amdgcn_readlane(cand, lane0), t0 = __builtin_amdgcn_readlane(ct, lane0);
+				const EncDev &d0 = devs[q0];
+				if (!d0.post.rc_need || rc_ready(g, d0.post, d0.seq->hctu, t0)) break;
+				m &= m - 1;
+			}
 			if (m) {
 				const int lane = __builtin_ctzll(m);
 				const int qq = __builtin_amdgcn_readlane(cand, lane), tt = __builtin_amdgcn_readlane(ct, lane);
@@ -469,8 +527,18 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(2))
 			}
 		}
 		if (q < 0) {
-			if (all_finished && __hip_atomic_load(finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nseq) break;
-			__builtin_amdgcn_s_sleep(32);
+			if (__hip_atomic_load(finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nseq) break;
+			if (__hip_atomic_load(finished + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+			if (wall_clock64() - t_start > watchdog_ticks) { if (g.tid == 0) __hip_atomic_store(finished + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+			// no CTU to decide: post-decision tasks of any picture (deblocking, SAO, entropy coding of CTUs whose neighbourhood is decided)
+			int ran = 0;
+			for (int i = 0; i < nseq; i++) {
+				const int cand = (start + i) % nseq;
+				const EncDev dd = devs[cand];
+				ran += pool_post_drain(dd, g, dd.seq, dd.frame, lw, slow + blockIdx.x, finished);
+				if (ran) { start = cand; break; }
+			}
+			if (!ran) __builtin_amdgcn_s_sleep(32);
 			continue;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (the step was opened with a release store after its predecessors' results)
@@ -492,7 +560,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(2))
 		int row;
 		if (hvalid) row = k == 0 ? hrow : (r_lo + k - 1 < hrow ? r_lo + k - 1 : r_lo + k);
 		else row = r_lo + k;
-		pool_encode_ctu(d, e, g, lseq, lframe, lft, t, row, cached_rem);
+		pool_encode_ctu(d, e, g, lseq, lframe, lft, t, row, cached_rem, finished + 1);
 		// close the step when this was its last CTU
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 		if (g.tid == 0) {
@@ -501,9 +569,9 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(2))
 			if (dn == r_hi - r_lo + 1) {
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (the other finishers' results happen before the step is declared closed)
 				__hip_atomic_store(&st[0], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-				if (t + 1 == W + 2 * (H - 1)) atomicAdd(finished, 1);
 			}
 		}
+		pool_post_drain(d, g, lseq, lframe, lw, slow + blockIdx.x, finished);
 		start = (q + 1) % nseq;
 	}
 	int hseq[NHELP];
@@ -607,6 +675,25 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(2))
 	int hseq[NHELP_MAX] = {0, 0, 0};
 	encode_row(d, pass, (int)blockIdx.x, hseq);
 	release_helpers(hseq);
+}
+// The post-decision stage of a picture whose CTU decisions are all final (the single-thread order: CTUs are re-encoded until the schedule's verification
+// passes, so the stage cannot run along with them): one wavefront per workgroup, each runs whatever task is ready until the picture's last task is done.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_post_frame(EncDev d)
+{
+	extern __shared__ __align__(16) uint8_t lds[];
+	WaveGrp g{(int)threadIdx.x};
+	for (int r = (int)blockIdx.x * 64 + g.tid; r < d.seq->hctu; r += (int)gridDim.x * 64) d.post.rows[r].dec = d.seq->wctu;
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+	PostCtx x;
+	x.seq = d.seq; x.f = d.frame; x.T = d.tables; x.geo.p = nullptr; x.ctus = d.ctus; x.coeff = d.coeff; x.pic = &d.post;
+	PostScratch &sc = *(PostScratch *)in_fast_memory((uint8_t *)lds);
+	const unsigned long long t_start = wall_clock64();
+	while (!post_finished(*d.seq, d.post)) {
+		if (!post_drain(g, x, sc)) {
+			if (wall_clock64() - t_start > 3000000000ull) { if (g.tid == 0) d.post.errors[2] = 1; break; }      // 30 s: a peer is gone - report instead of hanging
+			__builtin_amdgcn_s_sleep(16);
+		}
+	}
 }
 // ---- SAO parameter decision on the device (enc/enc_sao.h): what it needs from the entropy coder is the walk of two contexts through the SAO syntax of each
 // sub-stream, so it runs here, behind the statistics and the candidate offsets (k_saooffsets.hip) and in front of the offset pass, with no host in the chain.
@@ -777,7 +864,17 @@ struct hmr_gpu_enc {
 	Geo *d_geo;
 	std::vector<Geo> geo;
 	std::vector<SrcSlot> src;
-	int16_t *d_pic[2][3], *d_pre[3];
+	int16_t *d_pic[2][3], *d_pre[3], *d_rec[3];   // final pictures (current / reference), the deblocked picture, the reconstruction before the loop filters
+	// post-decision stage (enc_post.h)
+	PostRow *d_rows = nullptr;
+	RowEnt *d_ent = nullptr;
+	uint8_t *d_bs = nullptr;
+	uint32_t *d_cumbits = nullptr;
+	double *d_sao_tab = nullptr;         // [2 slice types: P, I][52][2]
+	int *d_post_err = nullptr;
+	int row_cap = 0;
+	std::vector<RowEnt> h_ent;
+	std::vector<uint8_t, PinnedAlloc<uint8_t>> h_bs;
 	PlaneSet planes;                 // phase planes of the reference picture (k_subpel.hip: 16 luma, 2 x 64 chroma), borrowed from g_plane_pool for the CTU stage of a P frame
 	size_t src_elems[3], pic_elems[3];
 	uint8_t *d_bytes;              // staging for 8-bit planes (one 4:2:0 picture)
@@ -806,7 +903,9 @@ struct hmr_gpu_enc {
 	// pipelined batch (lead encoder): the step whose access units are still to be delivered
 	bool pending = false, download_queued = false;
 	std::vector<hmr_gpu_enc *> pend_encs;
-	std::vector<size_t> pend_pub, pend_coeff;
+	std::vector<size_t> pend_off;                        // where each sequence's sub-streams lie in the staging buffer
+	std::vector<std::vector<uint32_t>> pend_rows;        // and the bytes of each of its rows
+	size_t *h_offs = nullptr;                            // (page-locked: k_pack_streams reads it)
 	size_t pend_total = 0;
 	hipStream_t copy_stream = nullptr;
 	uint32_t *d_gather = nullptr, *h_gather = nullptr;   // per picture of a launch: the frame's counters and the CTUs' distortions
@@ -907,19 +1006,26 @@ int ctu_stage_prepare(hmr_gpu_enc *e, bool planes_elsewhere = false)
 		HIP_TRY(hipMemsetAsync(e->d.row0_checked, 0, sizeof(int), st));
 		HIP_TRY(hipMemsetAsync(e->d.prefix, 0, sizeof(uint32_t) * s.hctu * (s.wctu + 1), st));
 	}
+	HIP_TRY(hipMemsetAsync(e->d_rows, 0, sizeof(PostRow) * s.hctu, st));
+	HIP_TRY(hipMemsetAsync(e->d_post_err, 0, sizeof(int) * 4, st));
 	return HMR_GPU_OK;
 }
 // row-per-thread schedule, after the launch: what the frame found
 int lockstep_collect(hmr_gpu_enc *e)
 {
 	hipStream_t st = e->ctx->stream;
-	int counters[3];
+	int counters[3], aborted = 0;
 	HIP_TRY(hipMemcpyAsync(counters, e->d.counters, sizeof counters, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&aborted, e->d_pool_state + 256 * POOL_STRIDE + 1, sizeof(int), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	e->last_encodes = counters[1];
 	e->f.scene_cut_ctu = counters[2];
 	e->last_passes = 1;
 	release_planes(e);
+	if (aborted) {
+		hmr_set_error("k_encode_pool: the launch was abandoned by its watchdog (a worker found nothing to do for too long: HENC_WATCHDOG_S)");
+		return HMR_GPU_ERR_HIP;
+	}
 	return HMR_GPU_OK;
 }
 
@@ -940,8 +1046,10 @@ int launch_pool(hmr_gpu_enc *lead, int n, int rows_total, hipStream_t st)
 	}
 	HIP_TRY(hipMemsetAsync(lead->d_pool_state, 0, sizeof(int) * (256 * POOL_STRIDE + 4), st));
 	const size_t lds_bytes = getenv("HENC_LDS_BYTES") ? (size_t)atoi(getenv("HENC_LDS_BYTES")) : LDS_BYTES;   // (experiment: a larger request keeps a CU to one worker)
+	// the watchdog (100 MHz ticks): a launch is a second or two of work; a worker that finds nothing to do for this long gives up for everybody
+	const unsigned long long watchdog = (unsigned long long)(getenv("HENC_WATCHDOG_S") ? atof(getenv("HENC_WATCHDOG_S")) : 120.0) * 100000000ull;
 	hipLaunchKernelGGL(k_encode_pool, dim3(workers), dim3(ENC_THREADS), lds_bytes, st, (const EncDev *)lead->d_batch, n, lead->d_pool_state, lead->d_pool_state + 256 * POOL_STRIDE,
-			   lead->d_pool_slow);
+			   lead->d_pool_slow, watchdog);
 	const hipError_t launched = hipGetLastError();
 	if (launched != hipSuccess) {
 		hmr_set_error("k_encode_pool: %s", hipGetErrorString(launched));
@@ -1000,6 +1108,10 @@ int run_ctu_passes(hmr_gpu_enc *e)
 	}
 	hipLaunchKernelGGL(k_sched_finish, dim3(s.nctu), dim3(64), 0, st, e->d);
 	HIP_TRY(hipMemcpyAsync(e->d.chain_start, e->d.chain_end, MODE_STATE_BYTES, hipMemcpyDeviceToDevice, st));
+	HIP_TRY(hipMemcpyAsync(e->d_frame, &e->f, sizeof(FrameCtx), hipMemcpyHostToDevice, st));      // (scene_cut_ctu as the passes found it)
+	HIP_TRY(hipFuncSetAttribute((const void *)k_post_frame, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PostScratch)));
+	hipLaunchKernelGGL(k_post_frame, dim3(s.hctu < 32 ? s.hctu : 32), dim3(64), sizeof(PostScratch), st, e->d);
+	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(e->ctx->ev1, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ctx->ev0, e->ctx->ev1));
@@ -1024,8 +1136,10 @@ int set_frame(hmr_gpu_enc *e, int slot, int image_type, double avg_dist, bool up
 	for (int c = 0; c < 3; c++) {
 		e->f.src[c] = e->src[slot].p[c];
 		e->f.ref[c] = plane0(e, e->cur ^ 1, c);
-		e->f.rec[c] = plane0(e, e->cur, c);
+		e->f.rec[c] = e->d_rec[c] + (size_t)(c ? s.margin_c : s.margin_y) * (c ? s.stride_c : s.stride_y) + (c ? s.margin_c : s.margin_y);
+		e->d.post.fin[c] = plane0(e, e->cur, c);
 	}
+	e->d.post.sao_lambda = e->d_sao_tab + (e->f.slice_type == SLICE_I ? 104 : 0);
 	if (e->f.slice_type != SLICE_I) {
 		if (!e->planes.y) {
 			const int rc = g_plane_pool.acquire(e->ctx->device, (size_t)16 * s.plane_elems_y, (size_t)64 * s.plane_elems_c, &e->planes);
@@ -1166,6 +1280,24 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 		e->pic_elems[c] = (size_t)(c ? s.stride_c : s.stride_y) * ((c ? s.height / 2 : s.height) + 2 * (c ? s.margin_c : s.margin_y));
 		for (int k = 0; k < 2; k++) DEV_ALLOC(e->d_pic[k][c], e->pic_elems[c]);
 		DEV_ALLOC(e->d_pre[c], e->pic_elems[c]);
+		DEV_ALLOC(e->d_rec[c], e->pic_elems[c]);
+	}
+	{
+		// the post-decision stage: row progress, the rows' CABAC coders and sub-streams (8 KB per CTU: forty times what QP 32 needs; a sub-stream that runs
+		// out of room is an error return, not a truncated stream), the SAO Lagrange multipliers of both slice types by QP
+		e->row_cap = s.wctu * 8192;
+		DEV_ALLOC(e->d_rows, s.hctu);
+		DEV_ALLOC(e->d_ent, s.hctu);
+		DEV_ALLOC(e->d_bs, (size_t)e->row_cap * s.hctu);
+		DEV_ALLOC(e->d_cumbits, s.nctu);
+		DEV_ALLOC(e->d_sao_tab, 2 * 52 * 2);
+		DEV_ALLOC(e->d_post_err, 4 + 2 * 16);
+		double tab[2][104];
+		sao_lambda_table(s, SLICE_P, tab[0]);
+		sao_lambda_table(s, SLICE_I, tab[1]);
+		HIP_TRY(hipMemcpy(e->d_sao_tab, tab, sizeof tab, hipMemcpyHostToDevice));
+		e->h_ent.resize(s.hctu);
+		e->h_bs.resize((size_t)e->row_cap * s.hctu);
 	}
 	DEV_ALLOC(e->d_bytes, (size_t)s.width * s.height * 3 / 2);
 	e->units_stride = s.wctu * 16;
@@ -1194,6 +1326,17 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 	e->d.frame = e->d_frame;
 	e->d.tables = ctx->tables;
 	e->d.geo = e->d_geo;
+	{
+		const size_t oy = (size_t)s.margin_y * s.stride_y + s.margin_y, oc = (size_t)s.margin_c * s.stride_c + s.margin_c;
+		PostPic &P = e->d.post;
+		memset(&P, 0, sizeof P);
+		P.dbk[0] = e->d_pre[0] + oy; P.dbk[1] = e->d_pre[1] + oc; P.dbk[2] = e->d_pre[2] + oc;
+		P.units_stride = e->units_stride;
+		P.mvx = e->d_mvx; P.mvy = e->d_mvy; P.ref = e->d_ref; P.uqp = e->d_qp; P.flags = e->d_flags;
+		P.rows = e->d_rows; P.ent = e->d_ent; P.bs = e->d_bs; P.row_cap = e->row_cap; P.cumbits = e->d_cumbits;
+		P.sao_lambda = e->d_sao_tab; P.errors = e->d_post_err; P.rc_need = nullptr;
+		P.prof = (unsigned long long *)(e->d_post_err + 4);      // (profiling build)
+	}
 	e->cur = 0;
 	e->lockstep = e->cfg.wfpp_num_threads > 1;
 	e->d.threads = e->cfg.wfpp_num_threads > 1 ? e->cfg.wfpp_num_threads : 1;
@@ -1272,6 +1415,7 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
 	if (e->d_gather) (void)hipFree(e->d_gather);
 	if (e->h_gather) (void)hipHostFree(e->h_gather);
+	if (e->h_offs) (void)hipHostFree(e->h_offs);
 	if (e->d_batch) (void)hipFree(e->d_batch);
 	if (e->d_pool_state) (void)hipFree(e->d_pool_state);
 	if (e->d_pool_slow) (void)hipFree(e->d_pool_slow);
@@ -1286,10 +1430,23 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 		(void)hipFree(e->d_pic[0][c]);
 		(void)hipFree(e->d_pic[1][c]);
 		(void)hipFree(e->d_pre[c]);
+		(void)hipFree(e->d_rec[c]);
+	}
+	{
+		void *pp[] = {e->d_rows, e->d_ent, e->d_bs, e->d_cumbits, e->d_sao_tab, e->d_post_err};
+		for (void *q : pp) (void)hipFree(q);
 	}
 	for (auto &sl : e->src)
 		for (int c = 0; c < 3; c++) (void)hipFree(sl.p[c]);
 	delete e;
+}
+
+// profiling build (-DHENC_POST_PROFILE): s_memtime ticks per part of the post-decision stage since the encoder was created (enc_post.h PostProf), 16 entries
+extern "C" int hmr_gpu_enc_post_profile(hmr_gpu_enc *e, unsigned long long *out)
+{
+	if (!e || !out) return HMR_GPU_ERR_ARG;
+	HIP_TRY(hipMemcpy(out, e->d_post_err + 4, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	return HMR_GPU_OK;
 }
 
 extern "C" float hmr_gpu_enc_last_ctu_ms(hmr_gpu_enc *e) { return e ? e->last_ms : 0.f; }
@@ -1376,7 +1533,7 @@ extern "C" int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *e, const uint8_t *y, const ui
 		}
 		for (int c = 0; c < 3; c++) {
 			rec[c].resize(e->pic_elems[c]);
-			HIP_TRY(hipMemcpy(rec[c].data(), e->d_pic[e->cur][c], e->pic_elems[c] * 2, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(rec[c].data(), e->d_rec[c], e->pic_elems[c] * 2, hipMemcpyDeviceToHost));
 		}
 		memset(records, 0, (size_t)REC_BYTES * s.nctu);
 		for (int n = 0; n < s.nctu; n++) {
@@ -1415,95 +1572,20 @@ extern "C" int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *e, const uint8_t *y, const ui
 	return e->f.slice_type;
 }
 
-// HOMER_enc_encode for one picture already on the device (hmr_gpu_enc_load_source): CTU decisions, deblocking, SAO statistics, SAO decision, SAO offsets and
-// border padding on the device; entropy coding on the host.  The access unit is written to stream.
+// HOMER_enc_encode for one picture already on the device (hmr_gpu_enc_load_source): CTU decisions, deblocking, SAO, entropy coding of the CTU rows' sub-streams and
+// border padding on the device (the CTU kernel and its post-decision tasks, enc_post.h); the host writes the headers and assembles the access unit.
 namespace {
-// the frame behind its CTU stage: in-loop filters and SAO on the device, side-info and levels to the host, entropy coding, the access unit into `stream`
-// the frame behind its CTU stage, device part, queued on the encoder's stream: deblocking, SAO statistics and candidate offsets, and the arguments of the SAO decision ...
-int frame_device_before_decision(hmr_gpu_enc *e, int slot, SaoDecideJob *job)
-{
-	job->enabled = 0;
-	job->progress = nullptr;
-	job->pad_ = 0;
-	const Seq &s = e->seq;
-	hipStream_t st = e->ctx->stream;
-	int rc;
-	// in-loop filters on the picture under reconstruction
-	hmr_gpu_frame pic = {s.width, s.height, plane0(e, e->cur, 0), plane0(e, e->cur, 1), plane0(e, e->cur, 2), s.stride_y, s.stride_c};
-	hmr_gpu_frame org = {s.width, s.height, e->src[slot].p[0], e->src[slot].p[1], e->src[slot].p[2], s.src_stride_y, s.src_stride_c};
-	hmr_gpu_units units = {e->units_stride, e->d_mvx, e->d_mvy, e->d_ref, e->d_qp, e->d_flags};
-	hipLaunchKernelGGL(k_units_from_ctuinfo, dim3(s.nctu), dim3(NPART), 0, st, e->d.ctus, e->d_geo, s.wctu, e->units_stride, e->d_mvx, e->d_mvy, e->d_ref, e->d_qp, e->d_flags, e->d_pd,
-			   e->d_ti);
-	HIP_TRY(hipGetLastError());
-	if ((rc = hmr_gpu_edge_flags_frame(e->ctx, e->d_pd, e->d_ti, s.width, s.height, e->units_stride, e->d_flags))) return rc;
-	if ((rc = hmr_gpu_deblock_frame(e->ctx, &pic, &units, s.chroma_qp_offset, s.chroma_qp_offset, 0, 0, nullptr, nullptr))) return rc;
-	if (s.sao) {
-		// statistics -> candidate offsets -> decision -> offsets applied to a copy of the deblocked picture: one chain on the encoder's stream
-		if ((rc = hmr_gpu_sao_stats_frame(e->ctx, &org, &pic, e->d_stats))) return rc;
-		SaoDecideArgs a;
-		sao_lambdas(s, e->f, a.lambdas);
-		if (e->h_lambdas.empty() || e->h_lambdas[0] != a.lambdas[0] || e->h_lambdas[1] != a.lambdas[1]) {
-			e->h_lambdas.resize((size_t)s.nctu * 3);
-			for (int n = 0; n < s.nctu; n++)
-				for (int k = 0; k < 3; k++) e->h_lambdas[(size_t)n * 3 + k] = a.lambdas[k];
-			HIP_TRY(hipMemcpyAsync(e->d_sao_lambdas, e->h_lambdas.data(), e->h_lambdas.size() * sizeof(double), hipMemcpyHostToDevice, st));
-			HIP_TRY(hipStreamSynchronize(st));
-		}
-		if ((rc = hmr_gpu_sao_offsets_frame(e->ctx, e->d_stats, s.nctu, e->d_sao_lambdas, e->d_sao_offsets, e->d_sao_aux, (int64_t *)e->d_sao_dist))) return rc;
-		Cabac first;
-		first.init_contexts(e->f.slice_type, e->f.qp);
-		a.ctus = e->d.ctus; a.stats = e->d_stats; a.offsets = e->d_sao_offsets; a.aux = e->d_sao_aux; a.dist = e->d_sao_dist;
-		a.W = s.wctu; a.H = s.hctu; a.wpp = s.wpp; a.st_merge = first.ctx[CTX_SAO_MERGE]; a.st_type = first.ctx[CTX_SAO_TYPE];
-		a.entropy_bits = e->d_sao_bits; a.next_lps = e->d_sao_lps; a.params = e->d_params; a.saved = e->d_sao_saved;
-		job->a = a;
-		job->progress = e->d_sao_progress;
-		job->enabled = 1;
-	}
-	return HMR_GPU_OK;
-}
-// ... and behind the SAO decision: the offsets applied to a copy of the deblocked picture, border padding
-int frame_device_after_decision(hmr_gpu_enc *e)
+// the access unit of frame `f` from the rows' sub-streams (`bytes`: the sub-streams one after the other) into `stream`
+int frame_assemble(hmr_gpu_enc *e, const FrameCtx &f, const uint8_t *bytes, const uint32_t *row_bytes, uint8_t *stream, long cap, long *stream_bytes)
 {
 	const Seq &s = e->seq;
-	hipStream_t st = e->ctx->stream;
-	int rc;
-	hmr_gpu_frame pic = {s.width, s.height, plane0(e, e->cur, 0), plane0(e, e->cur, 1), plane0(e, e->cur, 2), s.stride_y, s.stride_c};
-	if (s.sao) {
-		if ((e->pic_elems[0] | e->pic_elems[1]) % 8 == 0 && e->pic_elems[1] == e->pic_elems[2]) {
-			hipLaunchKernelGGL(k_copy_planes, dim3(512, 3), dim3(256), 0, st, e->d_pic[e->cur][0], e->d_pic[e->cur][1], e->d_pic[e->cur][2], e->d_pre[0], e->d_pre[1], e->d_pre[2],
-					   e->pic_elems[0], e->pic_elems[1]);
-			HIP_TRY(hipGetLastError());
-		} else {
-			for (int c = 0; c < 3; c++) HIP_TRY(hipMemcpyAsync(e->d_pre[c], e->d_pic[e->cur][c], e->pic_elems[c] * 2, hipMemcpyDeviceToDevice, st));
-		}
-		const size_t oy = (size_t)s.margin_y * s.stride_y + s.margin_y, oc = (size_t)s.margin_c * s.stride_c + s.margin_c;
-		hmr_gpu_frame pre = {s.width, s.height, e->d_pre[0] + oy, e->d_pre[1] + oc, e->d_pre[2] + oc, s.stride_y, s.stride_c};
-		if ((rc = hmr_gpu_sao_apply_frame(e->ctx, &pre, &pic, e->d_params))) return rc;
-	}
-	if ((rc = hmr_gpu_pad_frame(e->ctx, &pic, s.margin_y, s.margin_y))) return rc;
-	return HMR_GPU_OK;
-}
-// one sequence: the three parts in a row
-int frame_device_part(hmr_gpu_enc *e, int slot)
-{
-	SaoDecideJob job;
-	int rc = frame_device_before_decision(e, slot, &job);
-	if (rc) return rc;
-	if (job.enabled) {
-		HIP_TRY(hipMemsetAsync(e->d_sao_progress, 0, sizeof(int) * e->seq.hctu, e->ctx->stream));
-		hipLaunchKernelGGL(k_sao_decide, dim3(e->seq.wpp ? e->seq.hctu : 1), dim3(64), 0, e->ctx->stream, job.a, job.progress);
-		HIP_TRY(hipGetLastError());
-	}
-	return frame_device_after_decision(e);
-}
-// host part: entropy coding of the frame `f` from the downloaded side-info records and levels, the access unit into `stream`
-int frame_entropy_part(hmr_gpu_enc *e, const FrameCtx &f, const uint8_t *h_public, const int16_t *h_coeff, uint8_t *stream, long cap, long *stream_bytes)
-{
-	EntropyFrame fr;
-	fr.seq = &e->seq; fr.f = &f; fr.T = hmr_host_tables(); fr.geo = e->geo.data();
-	fr.ctu_base = h_public; fr.ctu_pitch = sizeof(CtuPublic); fr.coeff = h_coeff;
+	const int rows = s.wpp ? s.hctu : 1;
+	std::vector<const uint8_t *> data(rows);
+	std::vector<int> nb(rows);
+	size_t o = 0;
+	for (int r = 0; r < rows; r++) { data[r] = bytes + o; nb[r] = (int)row_bytes[r]; o += row_bytes[r]; }
 	std::vector<uint8_t> out;
-	encode_frame_entropy(e->es, fr, nullptr, e->cfg.profile, out);
+	assemble_access_unit(e->es, s, f, e->cfg.profile, data.data(), nb.data(), out);
 	*stream_bytes = (long)out.size();
 	if ((long)out.size() > cap) {
 		hmr_set_error("hmr_gpu_enc_encode: the access unit needs %ld bytes, the buffer holds %ld", (long)out.size(), cap);
@@ -1512,28 +1594,33 @@ int frame_entropy_part(hmr_gpu_enc *e, const FrameCtx &f, const uint8_t *h_publi
 	memcpy(stream, out.data(), out.size());
 	return f.slice_type;
 }
-// host part of one frame: entropy coding, then the frame bookkeeping
-int frame_host_part(hmr_gpu_enc *e, const uint8_t *h_public, const int16_t *h_coeff, uint8_t *stream, long cap, long *stream_bytes)
-{
-	const Seq &s = e->seq;
-	const double acc = frame_acc_dist(s, e->cfg.wfpp_num_threads, [&](int n) { return ((const CtuPublic *)(h_public + sizeof(CtuPublic) * n))->distortion; });
-	// (a buffer that is too small loses the access unit; the sequence state has not moved on, but the device pictures have: the caller has to start over)
-	const int rc = frame_entropy_part(e, e->f, h_public, h_coeff, stream, cap, stream_bytes);
-	if (rc < 0) return rc;
-	end_frame(s, e->st, e->f, acc);
-	return e->f.slice_type;
-}
-// one sequence: device part, download, host part
+// one sequence, behind its CTU stage (which has been waited for): the sub-streams and the CTUs' distortions to the host, the access unit, the frame bookkeeping
 int frame_finish(hmr_gpu_enc *e, int slot, uint8_t *stream, long cap, long *stream_bytes, uint8_t *recon)
 {
+	(void)slot;
 	const Seq &s = e->seq;
 	hipStream_t st = e->ctx->stream;
-	int rc = frame_device_part(e, slot);
-	if (rc) return rc;
-	// side-info (with the SAO parameters) and levels to the host: what the entropy coder reads
+	int rc, err[4];
+	HIP_TRY(hipMemcpyAsync(e->h_ent.data(), e->d_ent, sizeof(RowEnt) * s.hctu, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(err, e->d_post_err, sizeof err, hipMemcpyDeviceToHost, st));
 	if ((rc = download_public(e))) return rc;
-	HIP_TRY(hipMemcpyAsync(e->h_coeff.data(), e->d.coeff, e->h_coeff.size() * 2, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
+	if (err[0]) {
+		hmr_set_error("hmr_gpu_enc_encode: a CTU row's sub-stream outgrew its buffer (%d bytes)", e->row_cap);
+		return HMR_GPU_ERR_HIP;
+	}
+	if (err[2]) {
+		hmr_set_error("hmr_gpu_enc_encode: the post-decision stage was abandoned by its watchdog");
+		return HMR_GPU_ERR_HIP;
+	}
+	const int rows = s.wpp ? s.hctu : 1;
+	std::vector<uint32_t> row_bytes(rows);
+	size_t total = 0;
+	for (int r = 0; r < rows; r++) {
+		row_bytes[r] = (uint32_t)e->h_ent[r].bytecnt;
+		HIP_TRY(hipMemcpyAsync(e->h_bs.data() + total, e->d_bs + (size_t)r * e->row_cap, row_bytes[r], hipMemcpyDeviceToHost, st));
+		total += row_bytes[r];
+	}
 	if (recon) {
 		uint8_t *o = recon;
 		for (int c = 0; c < 3; c++) {
@@ -1544,11 +1631,16 @@ int frame_finish(hmr_gpu_enc *e, int slot, uint8_t *stream, long cap, long *stre
 			o += (size_t)w * h;
 		}
 	}
-	rc = frame_host_part(e, e->h_public.data(), e->h_coeff.data(), stream, cap, stream_bytes);
+	HIP_TRY(hipStreamSynchronize(st));
+	const double acc = frame_acc_dist(s, e->cfg.wfpp_num_threads, [&](int n) { return ((const CtuPublic *)(e->h_public.data() + sizeof(CtuPublic) * n))->distortion; });
+	// (a buffer that is too small loses the access unit; the sequence state has not moved on, but the device pictures have: the caller has to start over)
+	rc = frame_assemble(e, e->f, e->h_bs.data(), row_bytes.data(), stream, cap, stream_bytes);
+	if (rc < 0) return rc;
+	end_frame(s, e->st, e->f, acc);
 	HIP_TRY(hipEventRecord(e->ctx->ev1, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipEventElapsedTime(&e->last_total_ms, e->ev_frame, e->ctx->ev1));
-	return rc;
+	return e->f.slice_type;
 }
 }  // namespace
 
@@ -1579,13 +1671,36 @@ extern "C" int hmr_gpu_enc_encode_source(hmr_gpu_enc *e, int slot, int image_typ
 // LAUNCH, FINISH, DELIVER; the pipelined call runs LAUNCH(k), DELIVER(k - 1), FINISH(k), so that the download and the entropy coding of a step run while the
 // device is busy with the next step's CTU stage (nothing of step k reads what DELIVER(k - 1) reads: the staging buffers are written again only in FINISH(k)).
 namespace {
-__global__ void k_gather_results(const EncDev *devs, uint32_t *out, int pitch)
+__global__ void k_gather_results(const EncDev *devs, uint32_t *out, int pitch, const int *pool_flags)
 {
 	const EncDev &d = devs[blockIdx.x];
 	uint32_t *o = out + (size_t)blockIdx.x * pitch;
 	const int nctu = d.seq->nctu;
 	if (threadIdx.x < 3) o[threadIdx.x] = (uint32_t)d.counters[threadIdx.x];
+	if (threadIdx.x == 3) o[3] = (uint32_t)d.post.errors[0] | ((uint32_t)(pool_flags[1] != 0) << 1);
 	for (int c = threadIdx.x; c < nctu; c += blockDim.x) o[4 + c] = d.ctus[c].distortion;
+	// bytes of the rows' sub-streams, behind the distortions
+	for (int r = threadIdx.x; r < d.seq->hctu; r += blockDim.x) o[pitch - POST_MAX_ROWS + r] = (uint32_t)d.post.ent[r].bytecnt;
+}
+
+// the sub-streams of the pictures of a launch, row after row, into the staging buffer (picture i at out + offs[i]): what the host downloads to assemble the access units
+__global__ __launch_bounds__(256) void k_pack_streams(const EncDev *devs, uint8_t *out, const size_t *offs)
+{
+	__shared__ uint32_t start[POST_MAX_ROWS + 1];
+	const EncDev &d = devs[blockIdx.x];
+	const int rows = d.seq->wpp ? d.seq->hctu : 1;
+	if (threadIdx.x == 0) {
+		uint32_t o = 0;
+		for (int r = 0; r < rows; r++) { start[r] = o; o += (uint32_t)d.post.ent[r].bytecnt; }
+		start[rows] = o;
+	}
+	__syncthreads();
+	uint8_t *dst = out + offs[blockIdx.x];
+	for (int r = 0; r < rows; r++) {
+		const uint8_t *src = d.post.bs + (size_t)r * d.post.row_cap;
+		const uint32_t n = start[r + 1] - start[r];
+		for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[start[r] + i] = src[i];
+	}
 }
 
 // The batch's pictures: their EncDev records and frame parameters come from page-locked host memory (read by the kernel itself: a host-to-device copy queued here
@@ -1599,6 +1714,8 @@ __global__ void k_batch_stage(const EncDev *h_devs, const FrameCtx *h_frames, En
 	const int H = d.seq->hctu, W = d.seq->wctu;
 	if (t < 3) d.counters[t] = t == 2 ? -1 : 0;
 	if (t == 3) *d.row0_checked = 0;
+	if (t >= 4 && t < 8) d.post.errors[t - 4] = 0;
+	for (int k = t; k < H * (int)(sizeof(PostRow) / 4); k += blockDim.x) ((int *)d.post.rows)[k] = 0;
 	for (int k = t; k < H; k += blockDim.x) d.progress[k] = 0;
 	for (int k = t; k < H * (W + 1); k += blockDim.x) d.prefix[k] = 0;
 }
@@ -1622,7 +1739,7 @@ void parallel_for(int n, int threads, F fn)
 	for (auto &x : th) x.join();
 }
 constexpr int QUEUE_THREADS = 16;       // for queueing device work
-constexpr int CODING_THREADS = 256;     // for entropy coding: as many as there are sequences (the host's cores share them)
+constexpr int CODING_THREADS = 32;      // for the access units (headers, entry points, escaping: a few microseconds per kilobyte)
 
 int batch_check(hmr_gpu_enc **encs, int n, const int *slots, uint8_t **streams, const long *caps, long *stream_bytes)
 {
@@ -1638,8 +1755,6 @@ int batch_check(hmr_gpu_enc **encs, int n, const int *slots, uint8_t **streams, 
 	}
 	return HMR_GPU_OK;
 }
-
-int batch_queue_download(hmr_gpu_enc *lead);
 
 // LAUNCH: the frames' CTU stages as one pool launch on the lead encoder's stream, their counters and distortions gathered behind it
 int batch_launch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_types, int *pitch_out)
@@ -1690,16 +1805,11 @@ int batch_launch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_t
 		HIP_TRY(hipEventRecord(lead->ev_plane[k], lead->plane_stream[k]));
 		HIP_TRY(hipStreamWaitEvent(bst, lead->ev_plane[k], 0));
 	}
-	if (lead->pending && !lead->download_queued) {
-		HIP_TRY(hipEventRecord(lead->ev_decided, bst));
-		HIP_TRY(hipStreamWaitEvent(lead->copy_stream, lead->ev_decided, 0));
-		if ((rc = batch_queue_download(lead))) return rc;
-	}
 	if (!lead->d_batch) {
 		HIP_TRY(hipMalloc((void **)&lead->d_batch, 256 * sizeof(EncDev)));
 		HIP_TRY(hipDeviceGetAttribute(&lead->n_cus, hipDeviceAttributeMultiprocessorCount, lead->ctx->device));
 	}
-	const int pitch = 4 + max_ctus;
+	const int pitch = 4 + max_ctus + POST_MAX_ROWS;
 	if ((size_t)pitch * n > lead->gather_words) {
 		if (lead->d_gather) (void)hipFree(lead->d_gather);
 		if (lead->h_gather) (void)hipHostFree(lead->h_gather);
@@ -1714,28 +1824,18 @@ int batch_launch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_t
 	HIP_TRY(hipEventRecord(lead->ev_batch0, bst));
 	if ((rc = launch_pool(lead, n, rows_total, bst))) return rc;
 	(void)hipEventRecord(lead->ev_batch1, bst);
-	hipLaunchKernelGGL(k_gather_results, dim3(n), dim3(256), 0, bst, (const EncDev *)lead->d_batch, lead->d_gather, pitch);
+	hipLaunchKernelGGL(k_gather_results, dim3(n), dim3(256), 0, bst, (const EncDev *)lead->d_batch, lead->d_gather, pitch, (const int *)(lead->d_pool_state + 256 * POOL_STRIDE));
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(lead->h_gather, lead->d_gather, (size_t)pitch * n * 4, hipMemcpyDeviceToHost, bst));
 	*pitch_out = pitch;
 	return HMR_GPU_OK;
 }
 
-// FINISH: wait for the launch; frame bookkeeping; every sequence's filter chain, records and levels queued; the download queued behind them
-// the outstanding step's records and levels to the host, behind the sequences' packing (and behind whatever the copy stream has been told to wait for).  The
-// download is a copy kernel that holds wavefront slots for 35 ms: queued right behind the filter chains it kept the next step's phase planes from starting
-// (rocprofv3 trace), queued behind them it runs beside the next CTU launch, whose workers are resident before it.
-int batch_queue_download(hmr_gpu_enc *lead)
+// FINISH: wait for the launch (CTU decisions, filters and entropy coding of every picture are done when it ends); frame bookkeeping from the gathered counters,
+// distortions and sub-stream sizes; the sub-streams of all pictures packed into one staging buffer by one kernel and their download queued on the copy stream
+int batch_finish(hmr_gpu_enc **encs, int n, const int *slots, int pitch, BatchTimes &bt)
 {
-	if (!lead->pending || lead->download_queued) return HMR_GPU_OK;
-	for (hmr_gpu_enc *e : lead->pend_encs) HIP_TRY(hipStreamWaitEvent(lead->copy_stream, e->ev_packed, 0));
-	HIP_TRY(hipMemcpyAsync(lead->h_stage, lead->d_stage, lead->pend_total, hipMemcpyDeviceToHost, lead->copy_stream));
-	lead->download_queued = true;
-	return HMR_GPU_OK;
-}
-
-int batch_finish(hmr_gpu_enc **encs, int n, const int *slots, int pitch, BatchTimes &bt, bool defer_download)
-{
+	(void)slots;
 	hmr_gpu_enc *lead = encs[0];
 	hipStream_t bst = lead->ctx->stream;
 	const hipError_t waited = hipStreamSynchronize(bst);
@@ -1746,109 +1846,58 @@ int batch_finish(hmr_gpu_enc **encs, int n, const int *slots, int pitch, BatchTi
 	bt.t[2] = std::chrono::steady_clock::now();
 	float ms = 0;
 	HIP_TRY(hipEventElapsedTime(&ms, lead->ev_batch0, lead->ev_batch1));
-	// The side-info records and the levels of ALL sequences are packed into one staging buffer and come to the host as ONE copy (sixty separate 11 MB downloads
-	// reached 9 GB/s between them).
-	lead->pend_pub.resize(n);
-	lead->pend_coeff.resize(n);
+	if (!lead->h_offs) HIP_TRY(hipHostMalloc((void **)&lead->h_offs, 256 * sizeof(size_t), hipHostMallocDefault));
+	lead->pend_off.resize(n);
+	lead->pend_rows.assign(n, std::vector<uint32_t>());
 	size_t total = 0;
 	for (int i = 0; i < n; i++) {
-		lead->pend_pub[i] = total;
-		total += (sizeof(CtuPublic) * encs[i]->seq.nctu + 255) & ~(size_t)255;
-		lead->pend_coeff[i] = total;
-		total += ((size_t)12288 * encs[i]->seq.nctu + 255) & ~(size_t)255;
+		hmr_gpu_enc *e = encs[i];
+		const uint32_t *g = lead->h_gather + (size_t)i * pitch;
+		if (g[3] & 2) {
+			hmr_set_error("k_encode_pool: the launch was abandoned by its watchdog (a worker found nothing to do for too long: HENC_WATCHDOG_S)");
+			return HMR_GPU_ERR_HIP;
+		}
+		if (g[3] & 1) {
+			hmr_set_error("hmr_gpu_enc_encode_batch: sequence %d: a CTU row's sub-stream outgrew its buffer (%d bytes)", i, e->row_cap);
+			return HMR_GPU_ERR_HIP;
+		}
+		const int rows = e->seq.wpp ? e->seq.hctu : 1;
+		lead->pend_off[i] = total;
+		lead->h_offs[i] = total;
+		lead->pend_rows[i].assign(g + pitch - POST_MAX_ROWS, g + pitch - POST_MAX_ROWS + rows);
+		for (int r = 0; r < rows; r++) total += lead->pend_rows[i][r];
+		total = (total + 255) & ~(size_t)255;
+		e->last_ms = e->last_total_ms = ms;
+		e->last_encodes = (int)g[1];
+		e->f.scene_cut_ctu = (int)g[2];
+		e->last_passes = 1;
+		release_planes(e);
+		// the frame's statistics (encoder_engine_thread :3217-3238) need the CTUs' distortions only: the sequence can start its next frame
+		e->f_pending = e->f;
+		e->awaiting_delivery = true;
+		end_frame(e->seq, e->st, e->f, frame_acc_dist(e->seq, e->cfg.wfpp_num_threads, [&](int c) { return g[4 + c]; }));
 	}
 	if (total > lead->stage_bytes) {
 		if (lead->d_stage) (void)hipFree(lead->d_stage);
 		if (lead->h_stage) (void)hipHostFree(lead->h_stage);
 		lead->d_stage = lead->h_stage = nullptr;
 		lead->stage_bytes = 0;
-		HIP_TRY(hipMalloc((void **)&lead->d_stage, total));
-		HIP_TRY(hipHostMalloc((void **)&lead->h_stage, total, hipHostMallocDefault));
-		lead->stage_bytes = total;
+		const size_t want = total * 2 + (1 << 20);
+		HIP_TRY(hipMalloc((void **)&lead->d_stage, want));
+		HIP_TRY(hipHostMalloc((void **)&lead->h_stage, want, hipHostMallocDefault));
+		lead->stage_bytes = want;
 	}
-	if (!lead->copy_stream) {
-		// its own priority class: the download is a copy kernel that lasts 35 ms, and a stream of the default class may share its hardware queue with the stream
-		// the next launch is queued on (seen in the rocprofv3 trace: the next step's phase planes started when the download ended)
-		int least = 0, greatest = 0;
-		HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-		HIP_TRY(hipStreamCreateWithPriority(&lead->copy_stream, hipStreamNonBlocking, least));
-	}
-	std::vector<int> rcs(n, 0);
-	std::vector<std::string> errs(n);       // (the error text is per thread: bring the workers' back to the caller's)
-	std::vector<SaoDecideJob> jobs(n);
-	auto failed = [&]() {
-		for (int i = 0; i < n; i++)
-			if (rcs[i] < 0) { hmr_set_error("hmr_gpu_enc_encode_batch: sequence %d: %s", i, errs[i].c_str()); return rcs[i]; }
-		return 0;
-	};
-	// every sequence on its own stream, a host thread each: deblocking, SAO statistics, candidate offsets ...
-	{
-		parallel_for(n, QUEUE_THREADS, [&](int i) {
-				hmr_gpu_enc *e = encs[i];
-				if (hipSetDevice(e->ctx->device) != hipSuccess) { rcs[i] = HMR_GPU_ERR_HIP; errs[i] = "hipSetDevice failed"; return; }
-				const uint32_t *g = lead->h_gather + (size_t)i * pitch;
-				e->last_ms = e->last_total_ms = ms;
-				e->last_encodes = (int)g[1];
-				e->f.scene_cut_ctu = (int)g[2];
-				e->last_passes = 1;
-				release_planes(e);
-				int r = frame_device_before_decision(e, slots[i], &jobs[i]);
-				if (!r && hipEventRecord(e->ev_ready, e->ctx->stream) != hipSuccess) r = HMR_GPU_ERR_HIP;
-				rcs[i] = r;
-				if (r < 0) errs[i] = hmr_gpu_last_error();
-			});
-	}
-	if (failed()) return failed();
-	// ... the SAO decisions of all the pictures as ONE launch (k_sao_decide_batch) ...
-	{
-		int max_rows = 1, any = 0;
-		for (int i = 0; i < n; i++) {
-			HIP_TRY(hipStreamWaitEvent(bst, encs[i]->ev_ready, 0));
-			if (jobs[i].enabled) { any = 1; if (jobs[i].a.wpp && jobs[i].a.H > max_rows) max_rows = jobs[i].a.H; }
-		}
-		if (any) {
-			if (!lead->d_sao_jobs) HIP_TRY(hipMalloc((void **)&lead->d_sao_jobs, 256 * sizeof(SaoDecideJob)));
-			HIP_TRY(hipMemcpyAsync(lead->d_sao_jobs, jobs.data(), n * sizeof(SaoDecideJob), hipMemcpyHostToDevice, bst));
-			if (max_rows > 256) { hmr_set_error("hmr_gpu_enc_encode_batch: more than 256 CTU rows"); return HMR_GPU_ERR_ARG; }
-			hipLaunchKernelGGL(k_sao_decide_batch, dim3(n), dim3((max_rows + 63) / 64 * 64), 0, bst, (const SaoDecideJob *)lead->d_sao_jobs);
-			HIP_TRY(hipGetLastError());
-		}
-		HIP_TRY(hipEventRecord(lead->ev_decided, bst));
-	}
-	// ... and behind it, per sequence again: SAO offsets, padding, the records and levels into the staging buffer
-	{
-		parallel_for(n, QUEUE_THREADS, [&](int i) {
-				hmr_gpu_enc *e = encs[i];
-				if (hipSetDevice(e->ctx->device) != hipSuccess) { rcs[i] = HMR_GPU_ERR_HIP; errs[i] = "hipSetDevice failed"; return; }
-				const uint32_t *g = lead->h_gather + (size_t)i * pitch;
-				hipStream_t st = e->ctx->stream;
-				int r = hipStreamWaitEvent(st, lead->ev_decided, 0) == hipSuccess ? 0 : HMR_GPU_ERR_HIP;
-				if (!r) r = frame_device_after_decision(e);
-				if (!r) {
-					hipLaunchKernelGGL(k_pack_public, dim3(e->seq.nctu), dim3(256), 0, st, e->d.ctus, (uint32_t *)(lead->d_stage + lead->pend_pub[i]));
-					if (hipGetLastError() != hipSuccess ||
-					    hipMemcpyAsync(lead->d_stage + lead->pend_coeff[i], e->d.coeff, (size_t)12288 * e->seq.nctu, hipMemcpyDeviceToDevice, st) != hipSuccess ||
-					    hipEventRecord(e->ev_packed, st) != hipSuccess)
-						r = HMR_GPU_ERR_HIP;
-				}
-				if (!r) {
-					// the frame's statistics (encoder_engine_thread :3217-3238) need the CTUs' distortions only: the sequence can start its next frame
-					e->f_pending = e->f;
-					e->awaiting_delivery = true;
-					end_frame(e->seq, e->st, e->f, frame_acc_dist(e->seq, e->cfg.wfpp_num_threads, [&](int c) { return g[4 + c]; }));
-				}
-				rcs[i] = r;
-				if (r < 0) errs[i] = hmr_gpu_last_error();
-			});
-	}
-	if (failed()) return failed();
+	if (!lead->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&lead->copy_stream, hipStreamNonBlocking));
+	hipLaunchKernelGGL(k_pack_streams, dim3(n), dim3(256), 0, bst, (const EncDev *)lead->d_batch, lead->d_stage, (const size_t *)lead->h_offs);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(lead->ev_decided, bst));
+	HIP_TRY(hipStreamWaitEvent(lead->copy_stream, lead->ev_decided, 0));
+	if (total) HIP_TRY(hipMemcpyAsync(lead->h_stage, lead->d_stage, total, hipMemcpyDeviceToHost, lead->copy_stream));
 	bt.t[3] = std::chrono::steady_clock::now();
 	lead->pend_encs.assign(encs, encs + n);
 	lead->pend_total = total;
 	lead->pending = true;
-	lead->download_queued = false;
-	// (the pipelined call queues the download behind the next step's phase planes, batch_launch; everybody else right away)
-	return defer_download ? HMR_GPU_OK : batch_queue_download(lead);
+	return HMR_GPU_OK;
 }
 
 // DELIVER: the outstanding step's access units
@@ -1856,10 +1905,6 @@ int batch_deliver(hmr_gpu_enc *lead, uint8_t **streams, const long *caps, long *
 {
 	const int n = (int)lead->pend_encs.size();
 	bt.t[4] = std::chrono::steady_clock::now();
-	{
-		const int rc = batch_queue_download(lead);      // (a flush: there was no next step to queue it behind)
-		if (rc) return rc;
-	}
 	lead->pending = false;
 	for (int i = 0; i < n; i++) lead->pend_encs[i]->awaiting_delivery = false;
 	HIP_TRY(hipStreamSynchronize(lead->copy_stream));
@@ -1868,7 +1913,7 @@ int batch_deliver(hmr_gpu_enc *lead, uint8_t **streams, const long *caps, long *
 	std::vector<std::string> errs(n);
 	parallel_for(n, CODING_THREADS, [&](int i) {
 		hmr_gpu_enc *e = lead->pend_encs[i];
-		rcs[i] = frame_entropy_part(e, e->f_pending, lead->h_stage + lead->pend_pub[i], (const int16_t *)(lead->h_stage + lead->pend_coeff[i]), streams[i], caps[i], &stream_bytes[i]);
+		rcs[i] = frame_assemble(e, e->f_pending, lead->h_stage + lead->pend_off[i], lead->pend_rows[i].data(), streams[i], caps[i], &stream_bytes[i]);
 		if (rcs[i] < 0) errs[i] = hmr_gpu_last_error();
 	});
 	bt.t[6] = std::chrono::steady_clock::now();
@@ -1906,7 +1951,7 @@ extern "C" int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *sl
 	bt.t[0] = std::chrono::steady_clock::now();
 	if ((rc = batch_launch(encs, n, slots, image_types, &pitch))) return rc;
 	bt.t[1] = std::chrono::steady_clock::now();
-	if ((rc = batch_finish(encs, n, slots, pitch, bt, false))) return rc;
+	if ((rc = batch_finish(encs, n, slots, pitch, bt))) return rc;
 	if ((rc = batch_deliver(lead, streams, caps, stream_bytes, bt))) return rc;
 	batch_report(bt, lead, false);
 	return HMR_GPU_OK;
@@ -1943,7 +1988,7 @@ extern "C" int hmr_gpu_enc_encode_batch_pipelined(hmr_gpu_enc **encs, int n, con
 		for (int i = 0; i < n; i++) stream_bytes[i] = 0;
 		bt.t[6] = bt.t[1];
 	}
-	if (slots && (rc = batch_finish(encs, n, slots, pitch, bt, true))) return rc;
+	if (slots && (rc = batch_finish(encs, n, slots, pitch, bt))) return rc;
 	if (slots) batch_report(bt, lead, true);
 	return HMR_GPU_OK;
 }

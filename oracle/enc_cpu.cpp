@@ -22,7 +22,7 @@ static FILE *henc_sao_trace_file = nullptr;
 #include <stddef.h>
 #include "../homerhevc_amd/csrc/enc/enc_sched.h"
 #include "../homerhevc_amd/csrc/enc/enc_host.h"
-#include "../homerhevc_amd/csrc/enc/enc_entropy.h"
+#include "../homerhevc_amd/csrc/enc/enc_post.h"
 #include "hmr_oracle.h"
 
 extern "C" FILE *henc_trace_file = nullptr;
@@ -48,6 +48,17 @@ struct Cpu {
 	struct EngState { std::vector<CtuInfo> ctus; Work *w = nullptr; std::vector<Work *> row_w; } eng[MAX_ENGINES];
 	int active = 0, local_engines = 1;
 	std::vector<int16_t> src[3], pic[2][3], coeff;
+	// post-decision stage (enc_post.h): the reconstruction before the loop filters, the deblocked picture, unit arrays, row state, sub-streams
+	std::vector<int16_t> rec[3], dbk[3], u_mvx, u_mvy;
+	std::vector<int8_t> u_ref;
+	std::vector<uint8_t> u_qp, u_flags, bs;
+	std::vector<PostRow> rows;
+	std::vector<RowEnt> ent;
+	std::vector<uint32_t> cumbits;
+	std::vector<double> sao_lambda;
+	int post_errors[2] = {0, 0};
+	PostPic post;
+	PostScratch *scratch = nullptr;
 	std::vector<uint8_t> records;
 	int cur = 0;        // picture under reconstruction: pic[cur], reference: pic[cur ^ 1]
 	uint32_t acc_dist = 0;
@@ -85,6 +96,58 @@ int16_t *plane0(Cpu &c, int which, int comp)
 	const Seq &s = c.seq;
 	const int st = comp ? s.stride_c : s.stride_y, m = comp ? s.margin_c : s.margin_y;
 	return c.pic[which][comp].data() + (size_t)m * st + m;
+}
+
+int16_t *plane0_of(Cpu &c, std::vector<int16_t> *planes, int comp)
+{
+	const Seq &s = c.seq;
+	const int st = comp ? s.stride_c : s.stride_y, m = comp ? s.margin_c : s.margin_y;
+	return planes[comp].data() + (size_t)m * st + m;
+}
+
+// the post-decision stage of the frame that starts: counters, sub-streams, where its pictures are
+void post_begin_frame(Cpu &c)
+{
+	const Seq &s = c.seq;
+	const int us = s.wctu * 16, uh = s.hctu * 16;
+	if (c.rows.empty()) {
+		for (int k = 0; k < 3; k++) { c.rec[k].assign(c.pic[0][k].size(), 0); c.dbk[k].assign(c.pic[0][k].size(), 0); }
+		c.u_mvx.assign((size_t)us * uh, 0); c.u_mvy.assign((size_t)us * uh, 0); c.u_ref.assign((size_t)us * uh, 0); c.u_qp.assign((size_t)us * uh, 0); c.u_flags.assign((size_t)us * uh, 0);
+		c.rows.resize(s.hctu); c.ent.resize(s.hctu); c.cumbits.assign(s.nctu, 0);
+		c.sao_lambda.assign(52 * 2, 0);
+		c.scratch = (PostScratch *)calloc(1, sizeof(PostScratch));
+	}
+	const int row_cap = s.wctu * 24576;
+	c.bs.assign((size_t)row_cap * s.hctu, 0);
+	memset((void *)c.rows.data(), 0, sizeof(PostRow) * s.hctu);
+	memset((void *)c.ent.data(), 0, sizeof(RowEnt) * s.hctu);
+	sao_lambda_table(s, c.f.slice_type, c.sao_lambda.data());
+	PostPic &P = c.post;
+	for (int k = 0; k < 3; k++) { P.dbk[k] = plane0_of(c, c.dbk, k); P.fin[k] = plane0(c, c.cur, k); }
+	P.units_stride = us;
+	P.mvx = c.u_mvx.data(); P.mvy = c.u_mvy.data(); P.ref = c.u_ref.data(); P.uqp = c.u_qp.data(); P.flags = c.u_flags.data();
+	P.rows = c.rows.data(); P.ent = c.ent.data(); P.bs = c.bs.data(); P.row_cap = row_cap; P.cumbits = c.cumbits.data();
+	P.sao_lambda = c.sao_lambda.data(); P.errors = c.post_errors; P.rc_need = nullptr;
+}
+PostCtx post_ctx(Cpu &c)
+{
+	PostCtx x;
+	x.seq = &c.seq; x.f = &c.f; x.T = hmr_host_tables(); x.geo.p = c.geo; x.ctus = c.ctus.data(); x.coeff = c.coeff.data(); x.pic = &c.post;
+	return x;
+}
+// CTU n has been decided: whatever of the post-decision stage can run now, runs
+void post_after_ctu(Cpu &c, int n)
+{
+	const Seq &s = c.seq;
+	c.rows[n / s.wctu].dec = n % s.wctu + 1;
+	post_drain(CpuGrp(), post_ctx(c), *c.scratch);
+}
+// every CTU has been decided (a schedule that re-encodes CTUs: the stage runs when the decisions are final)
+void post_whole_frame(Cpu &c)
+{
+	const Seq &s = c.seq;
+	for (int r = 0; r < s.hctu; r++) c.rows[r].dec = s.wctu;
+	post_drain(CpuGrp(), post_ctx(c), *c.scratch);
 }
 
 void pad_plane(int16_t *p, int stride, int w, int h, int m)
@@ -154,7 +217,7 @@ void record_from_outputs(Cpu &c, int n, const uint8_t *state_after)
 	for (int comp = 0; comp < 3; comp++) {
 		const int nn = comp ? 32 : 64, px = ci.x >> (comp ? 1 : 0), py = ci.y >> (comp ? 1 : 0);
 		const int pw = comp ? s.width / 2 : s.width, ph = comp ? s.height / 2 : s.height, rs = comp ? s.stride_c : s.stride_y;
-		const int16_t *p = plane0(c, c.cur, comp);
+		const int16_t *p = plane0_of(c, c.rec, comp);
 		for (int yy = 0; yy < nn; yy++) {
 			if (py + yy < ph) memcpy(o, p + (size_t)(py + yy) * rs + px, (px + nn <= pw ? nn : pw - px) * 2);
 			o += nn * 2;
@@ -307,6 +370,7 @@ void frame_ctus_lockstep(Cpu &c, Enc &e)
 			step_intra += c.ctus[n].intra_parts;
 			step_ctus++;
 			c.acc_dist += c.ctus[n].distortion;
+			post_after_ctu(c, n);
 		}
 		done_intra += step_intra;
 		done_ctus += step_ctus;
@@ -347,6 +411,7 @@ void frame_ctus_sched(Cpu &c, Enc &e)
 		c.acc_dist += c.ctus[n].distortion;
 	}
 	memcpy(c.chain_start, c.chain_end, MODE_STATE_BYTES);
+	post_whole_frame(c);
 }
 
 }  // namespace
@@ -477,8 +542,9 @@ int henc_cpu_frame_ctus(void *h, const uint8_t *y, const uint8_t *u, const uint8
 			}
 			c.f.src[comp] = c.src[comp].data();
 			c.f.ref[comp] = plane0(c, c.cur ^ 1, comp);
-			c.f.rec[comp] = plane0(c, c.cur, comp);
 		}
+		post_begin_frame(c);
+		for (int comp = 0; comp < 3; comp++) c.f.rec[comp] = plane0_of(c, c.rec, comp);
 	}
 	Enc e;
 	memset(&e, 0, sizeof e);
@@ -521,6 +587,7 @@ int henc_cpu_frame_ctus(void *h, const uint8_t *y, const uint8_t *u, const uint8
 		c.total_parts += NPART;
 		c.acc_dist += c.ctus[n].distortion;
 		make_record(c, n, e);
+		post_after_ctu(c, n);
 	}
 	if (last_ctu == s.nctu) end_frame(s, c.st, c.f, frame_acc_dist(s, c.cfg.wfpp_num_threads, [&](int n) { return c.ctus[n].distortion; }));
 	return c.f.slice_type;
@@ -599,6 +666,31 @@ int henc_cpu_frame_ctus_wavefront(void *h, const uint8_t *y, const uint8_t *u, c
 	return c.f.slice_type;
 }
 
+// the arithmetic coefficient scans of the entropy coder (enc_entropy.h scan_position) against the scan tables built like the reference's (tables.cpp): mismatches
+int henc_cpu_scan_mismatches(void)
+{
+	const DevTables *T = hmr_host_tables();
+	int bad = 0;
+	for (int mode = SCAN_HOR; mode <= SCAN_DIAG; mode++)
+		for (int shift = 2; shift <= 5; shift++) {
+			if (mode != SCAN_DIAG && shift > 3) continue;      // find_scan_mode: horizontal / vertical only up to 8 x 8
+			const int blk = 1 << (shift - 2), ncg = blk * blk;
+			uint16_t cg[64];
+			for (int i = 0; i < ncg; i++) {
+				if (shift == 3) cg[i] = (mode == SCAN_VER || mode == SCAN_DIAG) ? (uint16_t)(((i & 1) << 1) | (i >> 1)) : (uint16_t)i;
+				else if (shift == 5) {
+					int d = 0, k = i;
+					for (;; d++) { const int len = d < 8 ? d + 1 : 15 - d; if (k < len) break; k -= len; }
+					const int row = (d < 8 ? d : 7) - k, col = d - row;
+					cg[i] = (uint16_t)(row * 8 + col);
+				} else cg[i] = shift > 3 ? (uint16_t)scan4x4_raster(mode, i) : 0;
+			}
+			for (int i = 0; i < (1 << (2 * shift)); i++)
+				if (scan_position(mode, shift, i, cg) != T->scan[mode][shift][i]) bad++;
+		}
+	return bad;
+}
+
 const uint8_t *henc_cpu_records(void *h) { return ((Cpu *)h)->records.data(); }
 double henc_cpu_avg_dist(void *h) { return ((Cpu *)h)->st.avg_dist; }
 
@@ -610,47 +702,13 @@ long henc_cpu_encode_frame(void *h, const uint8_t *y, const uint8_t *u, const ui
 	Cpu &c = *(Cpu *)h;
 	const Seq &s = c.seq;
 	henc_cpu_frame_ctus(h, y, u, v, image_type, nullptr, nullptr, nullptr, -1.0, 0, -1);
-	const int us = s.wctu * 16, uh = s.hctu * 16;
-	std::vector<int16_t> mvx((size_t)us * uh), mvy((size_t)us * uh);
-	std::vector<int8_t> ref((size_t)us * uh);
-	std::vector<uint8_t> qp((size_t)us * uh), flags((size_t)us * uh), pd((size_t)us * uh), ti((size_t)us * uh);
-	for (int n = 0; n < s.nctu; n++) {
-		const CtuInfo &ci = c.ctus[n];
-		for (int a = 0; a < 256; a++) {
-			const int r = host_abs2raster(a);
-			const size_t o = (size_t)((n / s.wctu) * 16 + r / 16) * us + (n % s.wctu) * 16 + r % 16;
-			mvx[o] = (int16_t)ci.mv_ref[a].x; mvy[o] = (int16_t)ci.mv_ref[a].y; ref[o] = ci.mv_ref_idx[a]; qp[o] = ci.qp[a];
-			flags[o] = (uint8_t)((ci.pred_mode[a] == PM_INTRA ? 1 : 0) | (((ci.cbf[0][a] >> ci.tr_idx[a]) & 1) ? 2 : 0));
-			pd[o] = ci.pred_depth[a]; ti[o] = ci.tr_idx[a];
-		}
-	}
-	int16_t *ry = plane0(c, c.cur, 0), *ru = plane0(c, c.cur, 1), *rv = plane0(c, c.cur, 2);
-	ora_make_edge_flags(pd.data(), ti.data(), s.width, s.height, us, flags.data());
-	ora_deblock_frame(ry, s.stride_y, ru, rv, s.stride_c, s.width, s.height, us, mvx.data(), mvy.data(), ref.data(), qp.data(), flags.data(), s.chroma_qp_offset,
-			  s.chroma_qp_offset, 0, 0, nullptr, nullptr);
-	std::vector<int32_t> stats((size_t)s.nctu * 3 * 5 * 2 * 32, 0);
-	if (s.sao) ora_sao_stats_frame(c.src[0].data(), c.src[1].data(), c.src[2].data(), s.src_stride_y, s.src_stride_c, ry, ru, rv, s.stride_y, s.stride_c, s.width, s.height, stats.data());
-	EntropyFrame fr;
-	fr.seq = &c.seq; fr.f = &c.f; fr.T = hmr_host_tables(); fr.geo = c.geo;
-	fr.ctu_base = (const uint8_t *)c.ctus.data(); fr.ctu_pitch = sizeof(CtuInfo); fr.coeff = c.coeff.data();
+	// the post-decision stage has run along with the CTU decisions (enc_post.h): deblocked, SAO-filtered and padded picture in pic[cur], one CABAC sub-stream per CTU row
+	if (!post_finished(s, c.post) || c.post_errors[0]) { fprintf(stderr, "henc_cpu_encode_frame: the post-decision stage did not finish (errors %d)\n", c.post_errors[0]); return -2; }
+	std::vector<const uint8_t *> row_data(s.hctu);
+	std::vector<int> row_bytes(s.hctu);
+	for (int r = 0; r < s.hctu; r++) { row_data[r] = c.bs.data() + (size_t)r * c.post.row_cap; row_bytes[r] = c.ent[r].bytecnt; }
 	std::vector<uint8_t> out;
-	encode_frame_entropy(c.es, fr, (const SaoStats *)stats.data(), c.cfg.profile, out);
-	if (s.sao) {
-		std::vector<int32_t> params((size_t)s.nctu * 3 * 34, 0);
-		for (int n = 0; n < s.nctu; n++)
-			for (int k = 0; k < 3; k++) {
-				const SaoOffset &o = c.ctus[n].sao_recon[k];
-				int32_t *p = params.data() + ((size_t)n * 3 + k) * 34;
-				p[0] = o.mode_idc; p[1] = o.type_idc;
-				memcpy(p + 2, o.offset, sizeof o.offset);
-			}
-		std::vector<int16_t> pre[3] = {c.pic[c.cur][0], c.pic[c.cur][1], c.pic[c.cur][2]};
-		const size_t oy = (size_t)s.margin_y * s.stride_y + s.margin_y, oc = (size_t)s.margin_c * s.stride_c + s.margin_c;
-		ora_sao_apply_frame(pre[0].data() + oy, pre[1].data() + oc, pre[2].data() + oc, ry, ru, rv, s.stride_y, s.stride_c, s.width, s.height, params.data());
-	}
-	ora_pad_plane(ry, s.stride_y, s.width, s.height, s.margin_y, s.margin_y);
-	ora_pad_plane(ru, s.stride_c, s.width / 2, s.height / 2, s.margin_c, s.margin_c);
-	ora_pad_plane(rv, s.stride_c, s.width / 2, s.height / 2, s.margin_c, s.margin_c);
+	assemble_access_unit(c.es, s, c.f, c.cfg.profile, row_data.data(), row_bytes.data(), out);
 	if (recon) {
 		uint8_t *o = recon;
 		for (int k = 0; k < 3; k++) {

@@ -50,6 +50,14 @@ def main():
         lib.hmr_gpu_enc_last_stats(enc, C.byref(p), C.byref(n), C.byref(ms), C.byref(tot))
         print(f"frame {f}: slice {st} {nbytes.value} bytes, {p.value} passes, {n.value} CTU encodes, CTU passes {ms.value:.1f} ms, frame {tot.value:.1f} ms")
     dt = time.time() - t0
+    if hasattr(lib, "hmr_gpu_enc_post_profile"):
+        prof = (C.c_ulonglong * 16)()
+        lib.hmr_gpu_enc_post_profile.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+        lib.hmr_gpu_enc_post_profile(enc, prof)
+        names = ["D task", "P load", "P stats", "P candidates", "P decide+sao syntax", "P ctu syntax", "P apply+pad", "scan", "D count", "P count"]
+        if any(prof):
+            nd, npp = max(prof[8], 1), max(prof[9], 1)
+            print("post-decision stage (100 MHz ticks -> us per task): " + ", ".join(f"{names[k]} {prof[k] / 100.0 / (nd if k == 0 else npp):.1f}" for k in range(8)) + f"; {prof[8]} D, {prof[9]} P tasks")
     print(f"{a.frames} frames in {dt:.2f} s = {a.frames / dt:.2f} fps; stream md5 {md5.hexdigest()}")
 
 
