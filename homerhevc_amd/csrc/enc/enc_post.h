@@ -15,12 +15,21 @@
 //   D(r, c):  CTU (r, c) decided; D(r, c - 1) done; D(r - 1, c) done (its vertical edges: the horizontal edges of row r read the rows above them);
 //   P(r, c):  the horizontal edges of (r, c + 1) and (r + 1, c + 1) done (every deblocked sample of the CTU and of the ring around it is final);
 //             P(r, c - 1) done (sub-stream order, SAO merge-left); P(r - 1, c + 1) done (SAO merge-up; the WPP context hand-over after the row's second CTU).
+// Without SAO the reference codes a CTU right behind its decisions (:2611-2612) and the rate control may read its bits one step later: P(r, c) then waits for the
+// CTU's decisions only, and the copy of the deblocked CTU into the final picture + padding is a task of its own, F(r, c), with P's filter conditions.
 // Progress is kept in per-row counters; any worker may run any task whose conditions hold (claimed with a compare-and-swap on the row's task ticket).
 // Under rate control the CTU decisions of wavefront step t read the bits of the CTUs the reference has coded when step t starts: CodedSchedule replays the
 // reference's lag arithmetic once per picture size and the step does not open before those P tasks are done (enc_rc.h).
 #pragma once
 #include "enc_entropy.h"
 #include "enc_rc.h"
+
+#if defined(__HIPCC__)
+#define HENC_NOINLINE __attribute__((noinline))      // one compiled body for every task that uses the function (and: inlined into k_post_frame's copy of the F task, the
+                                                     // offset pass of ROCm 7.2's compiler stored nothing - seen on the MI355X, profiles/r04_history.md)
+#else
+#define HENC_NOINLINE
+#endif
 
 namespace henc {
 
@@ -84,8 +93,8 @@ HENC_HDX void post_add_fast(const G &g, int32_t *p, int32_t v)      // an accumu
 }
 
 // ---- per-picture state of the stage ----------------------------------------------------------------------------------------------------------------------------
-struct PostRow {               // progress of one CTU row: CTUs decided, D tasks claimed / done, P tasks claimed / done
-	int dec, d_claim, d_done, p_claim, p_done, pad_[3];
+struct PostRow {               // progress of one CTU row: CTUs decided, D tasks claimed / done, P tasks claimed / done, F tasks claimed / done
+	int dec, d_claim, d_done, p_claim, p_done, f_claim, f_done, pad_;
 };
 struct RowEnt {                // the CABAC coder of a CTU row's sub-stream between two CTUs, and the contexts the next row starts from
 	uint32_t low, range, buffered_byte;
@@ -293,7 +302,7 @@ HENC_INLINE int sgn3(int v) { return v > 0 ? 1 : (v < 0 ? -1 : 0); }
 // the three components of the deblocked CTU with a one-sample ring into the scratch tiles (what the statistics and the offset pass read): ring samples outside
 // the picture are never used
 template <class G>
-HENC_HDX void post_stage_tiles(const G &g, const Seq &S, const PostPic &P, PostScratch &sc, int cx, int cy)
+HENC_NOINLINE HENC_HDX void post_stage_tiles(const G &g, const Seq &S, const PostPic &P, PostScratch &sc, int cx, int cy)
 {
 	const int width = S.width, height = S.height;
 	const bool la = cx > 0, ta = cy > 0, ra = cx * 64 + 64 < width, ba = cy * 64 + 64 < height;
@@ -460,7 +469,7 @@ struct SaoCandFromScratch {
 // sao_offset_ctu (hmr_sao.c:1210, offset_block :960) from the deblocked CTU (the scratch tiles) into the final picture, then reference_picture_border_padding_ctu
 // (:1723) of the final one
 template <class G>
-HENC_HDX void post_sao_apply_pad(const G &g, const Seq &S, const PostPic &P, const PostScratch &sc, const SaoOffset *params, int cx, int cy)
+HENC_NOINLINE HENC_HDX void post_sao_apply_pad(const G &g, const Seq &S, const PostPic &P, const PostScratch &sc, const SaoOffset *params, int cx, int cy)
 {
 	const int width = S.width, height = S.height;
 	const bool la = cx > 0, ta = cy > 0, ra = cx * 64 + 64 < width, ba = cy * 64 + 64 < height;
@@ -581,8 +590,8 @@ HENC_HDX void post_task_p(const G &g, const PostCtx &x, PostScratch &sc, int r, 
 	g.sync();
 	PPF_LAP(P, PPF_P_LOAD);
 	const int bits_before = bw.bitcount();
-	post_stage_tiles(g, S, P, sc, c, r);
 	if (S.sao) {
+		post_stage_tiles(g, S, P, sc, c, r);
 		const double *lam2 = P.sao_lambda + 2 * hclip((int)sc.c.qp[0], 0, 51);
 		const double lambdas[3] = {lam2[0], lam2[1], lam2[1]};
 		post_sao_stats(g, S, f, sc, c, r);
@@ -628,10 +637,19 @@ HENC_HDX void post_task_p(const G &g, const PostCtx &x, PostScratch &sc, int r, 
 		if (bw.overflow) P.errors[0] = 1;
 	}
 	PPF_LAP(P, PPF_P_SYNTAX);
-	// the filter output of this CTU: SAO offsets applied to the deblocked samples, margins of border CTUs
-	post_sao_apply_pad(g, S, P, sc, sc.c.sao_recon, c, r);
+	// the filter output of this CTU: SAO offsets applied to the deblocked samples, margins of border CTUs (without SAO: task F)
+	if (S.sao) post_sao_apply_pad(g, S, P, sc, sc.c.sao_recon, c, r);
 	g.sync();
 	PPF_LAP(P, PPF_P_APPLY);
+}
+
+// without SAO: the deblocked CTU into the final picture, margins of border CTUs
+template <class G>
+HENC_HDX void post_task_f(const G &g, const PostCtx &x, PostScratch &sc, int r, int c)
+{
+	post_stage_tiles(g, *x.seq, *x.pic, sc, c, r);
+	post_sao_apply_pad(g, *x.seq, *x.pic, sc, sc.c.sao_recon, c, r);
+	g.sync();
 }
 
 // ---- the scheduler -----------------------------------------------------------------------------------------------------------------------------------------------
@@ -651,21 +669,30 @@ HENC_HDX int post_drain(const G &g, const PostCtx &x, PostScratch &sc)
 		int pick_r = -1, pick_c = 0, pick_kind = 0;
 		for (int base = 0; base < H && pick_r < 0; base += g.n) {
 			const int r = base + g.tid;
-			bool d_ok = false, p_ok = false;
-			int dc = 0, pc = 0;
+			bool d_ok = false, p_ok = false, f_ok = false;
+			int dc = 0, pc = 0, fc = 0;
 			if (r < H) {
 				const PostRow &me = P.rows[r];
 				dc = post_ld(&me.d_done);
 				pc = post_ld(&me.p_done);
+				const int below = r + 1 < H ? post_ld(&P.rows[r + 1].d_done) : W;
 				if (dc < W && post_ld(&me.d_claim) == dc && post_ld(&me.dec) >= dc + 1 && (r == 0 || post_ld(&P.rows[r - 1].d_done) >= post_min(dc + 1, W))) d_ok = true;
+				// rate control without SAO: the reference codes a CTU before anything deblocks it (:2611), and coding rewrites the QP of CUs without levels
+				// (ee_encode_ctu :2091-2104) - the filter must see those
+				if (d_ok && !S.sao && P.rc_need && pc < dc + 1) d_ok = false;
 				if (pc < W && post_ld(&me.p_claim) == pc) {
-					// horizontal edges of (r, c + 1) and (r + 1, c + 1) done: D(., c + 2) has run - or D of the row's last CTU
+					// horizontal edges of (r, c + 1) and (r + 1, c + 1) done: D(., c + 2) has run - or D of the row's last CTU.  Without SAO: the CTU decided
 					const int need = post_min(pc + 3, W);
-					p_ok = dc >= need && (r + 1 >= H || post_ld(&P.rows[r + 1].d_done) >= need) && (r == 0 || post_ld(&P.rows[r - 1].p_done) >= post_min(pc + 2, W));
+					p_ok = (S.sao ? dc >= need && below >= need : post_ld(&me.dec) >= pc + 1) && (r == 0 || post_ld(&P.rows[r - 1].p_done) >= post_min(pc + 2, W));
 					if (p_ok && !S.wpp && r > 0 && pc == 0) p_ok = post_ld(&P.rows[r - 1].p_done) >= W;      // one sub-stream: raster order
 				}
+				if (!S.sao) {
+					fc = post_ld(&me.f_done);
+					const int need = post_min(fc + 3, W);
+					f_ok = fc < W && post_ld(&me.f_claim) == fc && dc >= need && below >= need && (r == 0 || post_ld(&P.rows[r - 1].f_done) >= post_min(fc + 2, W));
+				}
 			}
-			const uint64_t pm = g.ballot(p_ok), dm = g.ballot(d_ok);
+			const uint64_t pm = g.ballot(p_ok), dm = g.ballot(d_ok), fm = g.ballot(f_ok);
 			if (pm) {
 				const int lane = __builtin_ctzll(pm);
 				pick_r = base + lane; pick_kind = 1;
@@ -682,17 +709,26 @@ HENC_HDX int post_drain(const G &g, const PostCtx &x, PostScratch &sc)
 #else
 				pick_c = dc;
 #endif
+			} else if (fm) {
+				const int lane = __builtin_ctzll(fm);
+				pick_r = base + lane; pick_kind = 2;
+#if defined(__HIP_DEVICE_COMPILE__)
+				pick_c = __builtin_amdgcn_readlane(fc, lane);
+#else
+				pick_c = fc;
+#endif
 			}
 		}
 		PPF_LAP(P, PPF_SCAN);
 		if (pick_r < 0) return ran;
 		PostRow &row = P.rows[pick_r];
-		if (!post_claim(g, pick_kind ? &row.p_claim : &row.d_claim, pick_c)) continue;      // somebody else took it: look again
+		if (!post_claim(g, pick_kind == 1 ? &row.p_claim : (pick_kind == 2 ? &row.f_claim : &row.d_claim), pick_c)) continue;      // somebody else took it: look again
 		post_acquire();
-		if (pick_kind) post_task_p(g, x, sc, pick_r, pick_c);
+		if (pick_kind == 1) post_task_p(g, x, sc, pick_r, pick_c);
+		else if (pick_kind == 2) post_task_f(g, x, sc, pick_r, pick_c);
 		else post_task_d(g, x, pick_r, pick_c);
 		post_release();
-		if (g.tid == 0) post_st_release(pick_kind ? &row.p_done : &row.d_done, pick_c + 1);
+		if (g.tid == 0) post_st_release(pick_kind == 1 ? &row.p_done : (pick_kind == 2 ? &row.f_done : &row.d_done), pick_c + 1);
 		g.sync();
 		ran++;
 #if defined(__HIP_DEVICE_COMPILE__) && defined(HENC_POST_PROFILE)
@@ -729,6 +765,9 @@ HENC_HDX bool rc_ready(const G &g, const PostPic &P, int H, int k)
 }
 
 // all P tasks of the picture done?
-HENC_INLINE bool post_finished(const Seq &S, const PostPic &P) { return post_ld(&P.rows[S.hctu - 1].p_done) >= S.wctu; }
+HENC_INLINE bool post_finished(const Seq &S, const PostPic &P)
+{
+	return post_ld(&P.rows[S.hctu - 1].p_done) >= S.wctu && (S.sao || post_ld(&P.rows[S.hctu - 1].f_done) >= S.wctu);
+}
 
 }  // namespace henc

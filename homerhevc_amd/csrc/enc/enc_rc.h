@@ -69,7 +69,6 @@ HENC_INLINE void rc_change_pic_mode(RcFrame &rc, int reinit_gop, int intra_perio
 	rc.extra_bits = (int32_t)(rc.target_pict_size * ((double)consumed_ctus / nctu) - (int)consumed_bits);
 }
 
-#if !defined(__HIP_DEVICE_COMPILE__)
 }  // namespace henc
 #include <math.h>
 #include <vector>
@@ -219,6 +218,5 @@ inline bool rc_need_table(int W, int H, int sao, bool wavefront, std::vector<uin
 	}
 	return prefix;
 }
-#endif
 
 }  // namespace henc

@@ -269,6 +269,7 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 			e.total_intra_partitions = ui;
 			e.total_partitions = up;
 			e.coeff = d.coeff + (size_t)n * 6144;
+			e.ctu_qp = lframe->qp;
 			g.sync();
 			encode_ctu(g, e, n);
 			encodes++;
@@ -872,6 +873,8 @@ struct hmr_gpu_enc {
 	uint32_t *d_cumbits = nullptr;
 	double *d_sao_tab = nullptr;         // [2 slice types: P, I][52][2]
 	int *d_post_err = nullptr;
+	uint16_t *d_rc_need = nullptr;       // rate control: the CTUs of each row that are coded when a wavefront step starts (enc_rc.h rc_need_table)
+	RcFrame *d_rc_dyn = nullptr;
 	int row_cap = 0;
 	std::vector<RowEnt> h_ent;
 	std::vector<uint8_t, PinnedAlloc<uint8_t>> h_bs;
@@ -1212,6 +1215,13 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 		return HMR_GPU_ERR_ARG;
 	}
 	if (engine_index >= e->st.engines) { delete e; return HMR_GPU_ERR_ARG; }
+	if (e->cfg.bitrate_mode != 0 && e->cfg.wfpp_num_threads < 2) {
+		// (the single-thread order re-encodes CTUs until its verification passes; the bits the rate control reads come from entropy coding behind FINAL decisions)
+		hmr_set_error("hmr_gpu_enc_create: configuration outside the built rows: rate control needs the row-per-thread schedule (wfpp_num_threads > 1)");
+		delete e;
+		return HMR_GPU_ERR_ARG;
+	}
+	if (e->cfg.bitrate_mode != 0) host_rc_init(e->cfg, e->seq, e->st);
 	struct Guard {               // a failure further down (HIP_TRY / DEV_ALLOC return) frees what has been allocated so far
 		hmr_gpu_enc *e;
 		bool ok = false;
@@ -1298,6 +1308,16 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 		HIP_TRY(hipMemcpy(e->d_sao_tab, tab, sizeof tab, hipMemcpyHostToDevice));
 		e->h_ent.resize(s.hctu);
 		e->h_bs.resize((size_t)e->row_cap * s.hctu);
+		DEV_ALLOC(e->d_rc_dyn, 1);
+		if (e->cfg.bitrate_mode != 0) {
+			std::vector<uint16_t> need;
+			if (!rc_need_table(s.wctu, s.hctu, s.sao, true, need)) {
+				hmr_set_error("hmr_gpu_enc_create: rate control: the reference's entropy-coding lag is not row-monotone on a %d x %d CTU grid", s.wctu, s.hctu);
+				return HMR_GPU_ERR_ARG;
+			}
+			DEV_ALLOC(e->d_rc_need, need.size());
+			HIP_TRY(hipMemcpy(e->d_rc_need, need.data(), need.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+		}
 	}
 	DEV_ALLOC(e->d_bytes, (size_t)s.width * s.height * 3 / 2);
 	e->units_stride = s.wctu * 16;
@@ -1326,6 +1346,7 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 	e->d.frame = e->d_frame;
 	e->d.tables = ctx->tables;
 	e->d.geo = e->d_geo;
+	e->d.rc_dyn = e->d_rc_dyn;
 	{
 		const size_t oy = (size_t)s.margin_y * s.stride_y + s.margin_y, oc = (size_t)s.margin_c * s.stride_c + s.margin_c;
 		PostPic &P = e->d.post;
@@ -1334,7 +1355,7 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 		P.units_stride = e->units_stride;
 		P.mvx = e->d_mvx; P.mvy = e->d_mvy; P.ref = e->d_ref; P.uqp = e->d_qp; P.flags = e->d_flags;
 		P.rows = e->d_rows; P.ent = e->d_ent; P.bs = e->d_bs; P.row_cap = e->row_cap; P.cumbits = e->d_cumbits;
-		P.sao_lambda = e->d_sao_tab; P.errors = e->d_post_err; P.rc_need = nullptr;
+		P.sao_lambda = e->d_sao_tab; P.errors = e->d_post_err; P.rc_need = e->d_rc_need;
 		P.prof = (unsigned long long *)(e->d_post_err + 4);      // (profiling build)
 	}
 	e->cur = 0;
@@ -1433,7 +1454,7 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 		(void)hipFree(e->d_rec[c]);
 	}
 	{
-		void *pp[] = {e->d_rows, e->d_ent, e->d_bs, e->d_cumbits, e->d_sao_tab, e->d_post_err};
+		void *pp[] = {e->d_rows, e->d_ent, e->d_bs, e->d_cumbits, e->d_sao_tab, e->d_post_err, e->d_rc_need, e->d_rc_dyn};
 		for (void *q : pp) (void)hipFree(q);
 	}
 	for (auto &sl : e->src)
@@ -1572,6 +1593,38 @@ extern "C" int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *e, const uint8_t *y, const ui
 	return e->f.slice_type;
 }
 
+namespace {
+constexpr int GATHER_HEAD = 8;      // words in front of the CTUs' distortions in a picture's gather record
+__global__ void k_gather_results(const EncDev *devs, uint32_t *out, int pitch, const int *pool_flags)
+{
+	const EncDev &d = devs[blockIdx.x];
+	uint32_t *o = out + (size_t)blockIdx.x * pitch;
+	const int nctu = d.seq->nctu;
+	if (threadIdx.x < 3) o[threadIdx.x] = (uint32_t)d.counters[threadIdx.x];
+	if (threadIdx.x == 3) o[3] = (uint32_t)d.post.errors[0] | ((uint32_t)(pool_flags && pool_flags[1] != 0) << 1);
+	// rate control: the sum of the CTUs' QPs (the root nodes': acc_qp, hmr_encoder_lib.c:2938), the bits of all CTUs, the picture target as the frame left it
+	__shared__ uint32_t s_qp, s_bits;
+	if (threadIdx.x == 0) { s_qp = 0; s_bits = 0; }
+	__syncthreads();
+	uint32_t q = 0, b = 0;
+	for (int c = threadIdx.x; c < nctu; c += blockDim.x) q += d.ctus[c].nodes[0].qp;
+	for (int r = threadIdx.x; r < d.seq->hctu; r += blockDim.x) b += d.post.cumbits[r * d.seq->wctu + d.seq->wctu - 1];
+	atomicAdd(&s_qp, q);
+	atomicAdd(&s_bits, b);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		o[4] = s_qp;
+		o[5] = s_bits;
+		const double tp = d.counters[2] >= 0 ? d.rc_dyn->target_pict_size : d.frame->rc.target_pict_size;
+		memcpy(&o[6], &tp, 8);
+	}
+	for (int c = threadIdx.x; c < nctu; c += blockDim.x) o[GATHER_HEAD + c] = d.ctus[c].distortion;
+	// bytes of the rows' sub-streams, behind the distortions
+	for (int r = threadIdx.x; r < d.seq->hctu; r += blockDim.x) o[pitch - POST_MAX_ROWS + r] = (uint32_t)d.post.ent[r].bytecnt;
+}
+
+}  // namespace
+
 // HOMER_enc_encode for one picture already on the device (hmr_gpu_enc_load_source): CTU decisions, deblocking, SAO, entropy coding of the CTU rows' sub-streams and
 // border padding on the device (the CTU kernel and its post-decision tasks, enc_post.h); the host writes the headers and assembles the access unit.
 namespace {
@@ -1603,8 +1656,30 @@ int frame_finish(hmr_gpu_enc *e, int slot, uint8_t *stream, long cap, long *stre
 	int rc, err[4];
 	HIP_TRY(hipMemcpyAsync(e->h_ent.data(), e->d_ent, sizeof(RowEnt) * s.hctu, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(err, e->d_post_err, sizeof err, hipMemcpyDeviceToHost, st));
-	if ((rc = download_public(e))) return rc;
+	const int pitch = GATHER_HEAD + s.nctu + POST_MAX_ROWS;
+	if (e->lockstep) {
+		// the frame's counters, distortions and rate-control sums in one small record (the picture's EncDev is at d_batch: run_ctu_passes)
+		if ((size_t)pitch > e->gather_words) {
+			if (e->d_gather) (void)hipFree(e->d_gather);
+			if (e->h_gather) (void)hipHostFree(e->h_gather);
+			e->d_gather = e->h_gather = nullptr;
+			e->gather_words = 0;
+			HIP_TRY(hipMalloc((void **)&e->d_gather, (size_t)pitch * 4));
+			HIP_TRY(hipHostMalloc((void **)&e->h_gather, (size_t)pitch * 4, hipHostMallocDefault));
+			e->gather_words = (size_t)pitch;
+		}
+		hipLaunchKernelGGL(k_gather_results, dim3(1), dim3(256), 0, st, (const EncDev *)e->d_batch, e->d_gather, pitch, (const int *)nullptr);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(e->h_gather, e->d_gather, (size_t)pitch * 4, hipMemcpyDeviceToHost, st));
+	} else if ((rc = download_public(e))) return rc;
 	HIP_TRY(hipStreamSynchronize(st));
+	if (getenv("HENC_DEBUG_POST")) {
+		std::vector<PostRow> rows(s.hctu);
+		HIP_TRY(hipMemcpy(rows.data(), e->d_rows, sizeof(PostRow) * s.hctu, hipMemcpyDeviceToHost));
+		for (int r = 0; r < s.hctu; r++)
+			fprintf(stderr, "post row %d: dec %d D %d/%d P %d/%d F %d/%d\n", r, rows[r].dec, rows[r].d_claim, rows[r].d_done, rows[r].p_claim, rows[r].p_done, rows[r].f_claim, rows[r].f_done);
+		fprintf(stderr, "post errors %d %d %d %d, sao %d\n", err[0], err[1], err[2], err[3], s.sao);
+	}
 	if (err[0]) {
 		hmr_set_error("hmr_gpu_enc_encode: a CTU row's sub-stream outgrew its buffer (%d bytes)", e->row_cap);
 		return HMR_GPU_ERR_HIP;
@@ -1632,11 +1707,18 @@ int frame_finish(hmr_gpu_enc *e, int slot, uint8_t *stream, long cap, long *stre
 		}
 	}
 	HIP_TRY(hipStreamSynchronize(st));
-	const double acc = frame_acc_dist(s, e->cfg.wfpp_num_threads, [&](int n) { return ((const CtuPublic *)(e->h_public.data() + sizeof(CtuPublic) * n))->distortion; });
+	const uint32_t *gr = e->h_gather;
+	const double acc = e->lockstep ? frame_acc_dist(s, e->cfg.wfpp_num_threads, [&](int n) { return gr[GATHER_HEAD + n]; })
+				       : frame_acc_dist(s, e->cfg.wfpp_num_threads, [&](int n) { return ((const CtuPublic *)(e->h_public.data() + sizeof(CtuPublic) * n))->distortion; });
 	// (a buffer that is too small loses the access unit; the sequence state has not moved on, but the device pictures have: the caller has to start over)
 	rc = frame_assemble(e, e->f, e->h_bs.data(), row_bytes.data(), stream, cap, stream_bytes);
 	if (rc < 0) return rc;
-	end_frame(s, e->st, e->f, acc);
+	FrameRcOut ro = {0, 0.0, 0.0};
+	if (e->lockstep) {
+		ro.sum_qp = (int)gr[4]; ro.consumed_bits = (double)gr[5];
+		memcpy(&ro.target_pict_size, &gr[6], 8);
+	}
+	end_frame(s, e->st, e->f, acc, &ro);
 	HIP_TRY(hipEventRecord(e->ctx->ev1, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipEventElapsedTime(&e->last_total_ms, e->ev_frame, e->ctx->ev1));
@@ -1671,18 +1753,6 @@ extern "C" int hmr_gpu_enc_encode_source(hmr_gpu_enc *e, int slot, int image_typ
 // LAUNCH, FINISH, DELIVER; the pipelined call runs LAUNCH(k), DELIVER(k - 1), FINISH(k), so that the download and the entropy coding of a step run while the
 // device is busy with the next step's CTU stage (nothing of step k reads what DELIVER(k - 1) reads: the staging buffers are written again only in FINISH(k)).
 namespace {
-__global__ void k_gather_results(const EncDev *devs, uint32_t *out, int pitch, const int *pool_flags)
-{
-	const EncDev &d = devs[blockIdx.x];
-	uint32_t *o = out + (size_t)blockIdx.x * pitch;
-	const int nctu = d.seq->nctu;
-	if (threadIdx.x < 3) o[threadIdx.x] = (uint32_t)d.counters[threadIdx.x];
-	if (threadIdx.x == 3) o[3] = (uint32_t)d.post.errors[0] | ((uint32_t)(pool_flags[1] != 0) << 1);
-	for (int c = threadIdx.x; c < nctu; c += blockDim.x) o[4 + c] = d.ctus[c].distortion;
-	// bytes of the rows' sub-streams, behind the distortions
-	for (int r = threadIdx.x; r < d.seq->hctu; r += blockDim.x) o[pitch - POST_MAX_ROWS + r] = (uint32_t)d.post.ent[r].bytecnt;
-}
-
 // the sub-streams of the pictures of a launch, row after row, into the staging buffer (picture i at out + offs[i]): what the host downloads to assemble the access units
 __global__ __launch_bounds__(256) void k_pack_streams(const EncDev *devs, uint8_t *out, const size_t *offs)
 {
@@ -1809,7 +1879,7 @@ int batch_launch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_t
 		HIP_TRY(hipMalloc((void **)&lead->d_batch, 256 * sizeof(EncDev)));
 		HIP_TRY(hipDeviceGetAttribute(&lead->n_cus, hipDeviceAttributeMultiprocessorCount, lead->ctx->device));
 	}
-	const int pitch = 4 + max_ctus + POST_MAX_ROWS;
+	const int pitch = GATHER_HEAD + max_ctus + POST_MAX_ROWS;
 	if ((size_t)pitch * n > lead->gather_words) {
 		if (lead->d_gather) (void)hipFree(lead->d_gather);
 		if (lead->h_gather) (void)hipHostFree(lead->h_gather);
@@ -1875,7 +1945,10 @@ int batch_finish(hmr_gpu_enc **encs, int n, const int *slots, int pitch, BatchTi
 		// the frame's statistics (encoder_engine_thread :3217-3238) need the CTUs' distortions only: the sequence can start its next frame
 		e->f_pending = e->f;
 		e->awaiting_delivery = true;
-		end_frame(e->seq, e->st, e->f, frame_acc_dist(e->seq, e->cfg.wfpp_num_threads, [&](int c) { return g[4 + c]; }));
+		FrameRcOut ro;
+		ro.sum_qp = (int)g[4]; ro.consumed_bits = (double)g[5];
+		memcpy(&ro.target_pict_size, &g[6], 8);
+		end_frame(e->seq, e->st, e->f, frame_acc_dist(e->seq, e->cfg.wfpp_num_threads, [&](int c) { return g[GATHER_HEAD + c]; }), &ro);
 	}
 	if (total > lead->stage_bytes) {
 		if (lead->d_stage) (void)hipFree(lead->d_stage);

@@ -56,6 +56,7 @@ struct Cpu {
 	std::vector<RowEnt> ent;
 	std::vector<uint32_t> cumbits;
 	std::vector<double> sao_lambda;
+	std::vector<uint16_t> rc_need;   // rate control: CTUs of each row coded when a wavefront step (sched 2) / a CTU (raster order) starts
 	int post_errors[2] = {0, 0};
 	PostPic post;
 	PostScratch *scratch = nullptr;
@@ -127,7 +128,7 @@ void post_begin_frame(Cpu &c)
 	P.units_stride = us;
 	P.mvx = c.u_mvx.data(); P.mvy = c.u_mvy.data(); P.ref = c.u_ref.data(); P.uqp = c.u_qp.data(); P.flags = c.u_flags.data();
 	P.rows = c.rows.data(); P.ent = c.ent.data(); P.bs = c.bs.data(); P.row_cap = row_cap; P.cumbits = c.cumbits.data();
-	P.sao_lambda = c.sao_lambda.data(); P.errors = c.post_errors; P.rc_need = nullptr;
+	P.sao_lambda = c.sao_lambda.data(); P.errors = c.post_errors; P.rc_need = c.rc_need.empty() ? nullptr : c.rc_need.data();
 }
 PostCtx post_ctx(Cpu &c)
 {
@@ -142,6 +143,37 @@ void post_after_ctu(Cpu &c, int n)
 	c.rows[n / s.wctu].dec = n % s.wctu + 1;
 	post_drain(CpuGrp(), post_ctx(c), *c.scratch);
 }
+// hmr_rc_get_cu_qp for the CTUs whose decisions have index k (the wavefront step / the CTU in raster order): the slice QP, or what the rate control makes of the
+// CTUs coded so far.  is_sc: the frame has been found to be a new scene by the time the CTU computes its QP
+int ctu_qp_for(Cpu &c, int k, int is_sc)
+{
+	if (!c.f.rc.on) return c.f.qp;
+	const Seq &s = c.seq;
+	if (!rc_ready(CpuGrp(), c.post, s.hctu, k)) { fprintf(stderr, "rate control: decisions %d start before the CTUs they read the bits of are coded\n", k); abort(); }
+	uint32_t bits = 0;
+	int ctus = 0;
+	rc_consumed(CpuGrp(), c.post, s.wctu, s.hctu, k, &bits, &ctus);
+	return rc_calc_cu_qp(c.f.rc, (double)bits, ctus, c.f.slice_type, is_sc, s.reinit_gop, s.intra_period, c.f.avg_dist, c.f.num_encoded_frames);
+}
+// a scene change has just been detected by the decisions with index k: hmr_rc_change_pic_mode
+void rc_scene_change(Cpu &c, int k)
+{
+	if (!c.f.rc.on) return;
+	const Seq &s = c.seq;
+	uint32_t bits = 0;
+	int ctus = 0;
+	rc_consumed(CpuGrp(), c.post, s.wctu, s.hctu, k, &bits, &ctus);
+	rc_change_pic_mode(c.f.rc, s.reinit_gop, s.intra_period, s.nctu, c.f.rc.sqrt_clipped_intra_period, bits, ctus);
+}
+FrameRcOut rc_frame_out(Cpu &c)
+{
+	const Seq &s = c.seq;
+	FrameRcOut ro = {0, 0.0, c.f.rc.target_pict_size};
+	for (int n = 0; n < s.nctu; n++) ro.sum_qp += c.ctus[n].nodes[0].qp;
+	for (int r = 0; r < s.hctu; r++) ro.consumed_bits += c.cumbits[(size_t)r * s.wctu + s.wctu - 1];
+	return ro;
+}
+
 // every CTU has been decided (a schedule that re-encodes CTUs: the stage runs when the decisions are final)
 void post_whole_frame(Cpu &c)
 {
@@ -306,6 +338,7 @@ void sched_pass(Cpu &c, Enc &e, int pass)
 			e.coeff = c.coeff.data() + (size_t)n * 6144;
 			e.total_intra_partitions = c.used_intra[n];
 			e.total_partitions = c.used_parts[n];
+			e.ctu_qp = c.f.qp;
 			encode_ctu(g, e, n);
 			c.stat_encodes++;
 			memcpy(&c.outtok[(size_t)n * MODE_STATE_BYTES], e.w->intra_mode_buffs, MODE_STATE_BYTES);
@@ -361,8 +394,11 @@ void frame_ctus_lockstep(Cpu &c, Enc &e)
 			e.total_intra_partitions = done_intra;
 			e.total_partitions = done_ctus * NPART;
 			if (r % N == 0 && c.f.scene_cut_ctu < 0 && fired < 0 && c.f.slice_type == SLICE_P && !ctu_takes_intra_walk(c.f, n) &&
-			    scene_cut_fires(s, c.f, done_intra, done_ctus * NPART))
+			    scene_cut_fires(s, c.f, done_intra, done_ctus * NPART)) {
 				c.f.scene_cut_ctu = fired = n;     // thread 0 decides first in its step: the other CTUs of the step already take the intra walk
+				rc_scene_change(c, t);
+			}
+			e.ctu_qp = ctu_qp_for(c, t, c.f.scene_cut_ctu >= 0 && t >= c.f.scene_cut_ctu % W + 2 * (c.f.scene_cut_ctu / W));
 			memcpy(e.w->mode_in, e.w->intra_mode_buffs, MODE_STATE_BYTES);
 			encode_ctu(g, e, n);
 			resolve_mode_tokens(g, *e.w, c.ctus[n]);
@@ -432,6 +468,14 @@ void *henc_cpu_create(const HostCfg *cfg)
 	}
 	make_geo(c->geo);
 	if (cfg->wfpp_num_threads > 1) c->sched = 2;   // one worker per CTU row: the synchronous wavefront
+	if (cfg->bitrate_mode != 0) {
+		host_rc_init(*cfg, c->seq, c->st);
+		if (!rc_need_table(c->seq.wctu, c->seq.hctu, c->seq.sao, c->sched == 2, c->rc_need)) {
+			fprintf(stderr, "henc_cpu_create: rate control: the entropy-coding lag is not row-monotone on this CTU grid\n");
+			delete c;
+			return nullptr;
+		}
+	}
 	const Seq &s = c->seq;
 	c->ctus.resize(s.nctu);
 	memset(c->ctus.data(), 0, sizeof(CtuInfo) * s.nctu);
@@ -568,7 +612,11 @@ int henc_cpu_frame_ctus(void *h, const uint8_t *y, const uint8_t *u, const uint8
 		e.coeff = c.coeff.data() + (size_t)n * 6144;
 		e.total_intra_partitions = c.intra_parts;
 		e.total_partitions = c.total_parts;
-		if (c.f.scene_cut_ctu < 0 && c.f.slice_type == SLICE_P && scene_cut_fires(s, c.f, c.intra_parts, c.total_parts)) c.f.scene_cut_ctu = n;   // this CTU still takes the inter walk
+		if (c.f.scene_cut_ctu < 0 && c.f.slice_type == SLICE_P && scene_cut_fires(s, c.f, c.intra_parts, c.total_parts)) {
+			c.f.scene_cut_ctu = n;   // this CTU still takes the inter walk
+			rc_scene_change(c, n);
+		}
+		e.ctu_qp = ctu_qp_for(c, n, c.f.scene_cut_ctu >= 0 && n >= c.f.scene_cut_ctu);
 		memcpy(c.w->mode_in, c.w->intra_mode_buffs, MODE_STATE_BYTES);   // one worker in raster order: what the buffers hold IS the inherited state
 		if (getenv("HENC_WIPE_NODES")) memset(c.ctus[n].nodes, atoi(getenv("HENC_WIPE_NODES")), sizeof c.ctus[n].nodes);
 		if (getenv("HENC_WIPE_PUBLIC")) memset((CtuPublic *)&c.ctus[n], atoi(getenv("HENC_WIPE_PUBLIC")), offsetof(CtuPublic, sao_recon));
@@ -589,7 +637,10 @@ int henc_cpu_frame_ctus(void *h, const uint8_t *y, const uint8_t *u, const uint8
 		make_record(c, n, e);
 		post_after_ctu(c, n);
 	}
-	if (last_ctu == s.nctu) end_frame(s, c.st, c.f, frame_acc_dist(s, c.cfg.wfpp_num_threads, [&](int n) { return c.ctus[n].distortion; }));
+	if (last_ctu == s.nctu) {
+		const FrameRcOut ro = rc_frame_out(c);
+		end_frame(s, c.st, c.f, frame_acc_dist(s, c.cfg.wfpp_num_threads, [&](int n) { return c.ctus[n].distortion; }), &ro);
+	}
 	return c.f.slice_type;
 }
 
@@ -653,6 +704,7 @@ int henc_cpu_frame_ctus_wavefront(void *h, const uint8_t *y, const uint8_t *u, c
 			e.total_intra_partitions = intra_prefix[n];
 			e.total_partitions = (uint32_t)n * NPART;
 			memcpy(e.w->mode_in, e.w->intra_mode_buffs, MODE_STATE_BYTES);
+			e.ctu_qp = c.f.qp;
 			encode_ctu(g, e, n);
 			resolve_mode_tokens(g, *e.w, c.ctus[n]);
 			c.acc_dist += c.ctus[n].distortion;

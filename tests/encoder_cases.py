@@ -41,6 +41,9 @@ def default_cfg(width, height, **kw):
                vbv_init=7000, reinit_gop_on_scene_change=1, rd_mode=2, performance_mode=2)
     for k, v in kw.items():
         setattr(c, KEY_NAMES.get(k, k), int(v))
+    # oracle/ref_lockstep.c: the buffer follows the bit rate
+    c.vbv_size = c.bitrate
+    c.vbv_init = int(c.bitrate * 0.35)
     return c
 
 

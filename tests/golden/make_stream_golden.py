@@ -54,7 +54,16 @@ CASES = [
     ("416x240_scene_cut_eng2_wpp_rows", 416, 240, 27, {"cut_at": 23, "engines": 2, "wpp": 4}),
     ("1920x1080_cfg2_eng2", 1920, 1080, 8, {"engines": 2, "wpp": 17}),
     ("1920x1080_cfg2_eng3", 1920, 1080, 8, {"engines": 3, "wpp": 17}),
-    ("3840x2160_cfg2_eng8", 3840, 2160, 10, {"engines": 8, "wpp": 32}),       # BASELINE.json configs[3]: 2160p, n_enc_engines = 8     # the 2160p picture of the metric with the reference's maximum of 32 WPP threads for 34 CTU rows (I + P + P)
+    ("3840x2160_cfg2_eng8", 3840, 2160, 10, {"engines": 8, "wpp": 32}),
+    # rate control (hmr_rate_control.c): the QP of a CTU follows the bits of the CTUs entropy coded so far - in the single-thread order, and in the synchronous
+    # wavefront (the turnstile serialises the threads' post-decision sections, so every CTU of a step sees the bits as of the end of the step before)
+    ("416x240_cbr400_perf1", 416, 240, 8, {"bitrate_mode": 1, "bitrate": 400, "perf": 1}),
+    ("416x240_cbr400_perf1_wpp_rows", 416, 240, 8, {"bitrate_mode": 1, "bitrate": 400, "perf": 1, "wpp": 4}),
+    ("416x240_vbr400_wpp_rows", 416, 240, 8, {"bitrate_mode": 2, "bitrate": 400, "wpp": 4}),
+    ("832x480_cbr1500_perf1_wpp_rows", 832, 480, 6, {"bitrate_mode": 1, "bitrate": 1500, "perf": 1, "wpp": 8}),
+    ("416x240_cbr300_nosao_wpp_rows", 416, 240, 6, {"bitrate_mode": 1, "bitrate": 300, "sao": 0, "wpp": 4}),
+    ("1920x1080_cbr5000_perf1_wpp_rows", 1920, 1080, 6, {"bitrate_mode": 1, "bitrate": 5000, "perf": 1, "wpp": 17}),
+    ("3840x2160_cbr20000_perf1_wpp32", 3840, 2160, 4, {"bitrate_mode": 1, "bitrate": 20000, "perf": 1, "wpp": 32}),       # BASELINE.json configs[2]: 2160p IPPP, CBR 20000 kbps, performance_mode 1       # BASELINE.json configs[3]: 2160p, n_enc_engines = 8     # the 2160p picture of the metric with the reference's maximum of 32 WPP threads for 34 CTU rows (I + P + P)
 ]
 
 
