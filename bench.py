@@ -380,7 +380,8 @@ def run_engine_ring(a, world, rank, local, torch):
     keys = dict(keys, engines=world)
     nframes = a.warmup + a.steps
     S = a.sequences * world
-    adapter = GpuEngines(lambda seq: ec.default_cfg(width, height, **keys), local, pipelined=not a.no_pipeline)
+    # (HOMER_BENCH_ONE_DEVICE: all ranks on one GPU over gloo - the pictures then cross page-locked host buffers)
+    adapter = GpuEngines(lambda seq: ec.default_cfg(width, height, **keys), local, pipelined=not a.no_pipeline, host_exchange=bool(os.environ.get("HOMER_BENCH_ONE_DEVICE")))
     ring = EngineRing(adapter, S, rank, world)
     ring.load_sources(ec.clip_frames(width, height, nframes))
     gold = REFERENCE_MD5.get(name, {}).get("au_md5", [])
@@ -403,10 +404,10 @@ def run_engine_ring(a, world, rank, local, torch):
             if f < len(gold):
                 checked[0] += 1
                 bad[0] += hashlib.md5(au).hexdigest() != gold[f]
-    t = torch.tensor([bad[0], checked[0], produced[0]], dtype=torch.int64, device="cuda")
+    t = torch.tensor([bad[0], checked[0], produced[0]], dtype=torch.int64, device="cpu" if adapter.host_exchange else "cuda")
     dist.all_reduce(t)
     bad_all, checked_all, produced_all = (int(x) for x in t.tolist())
-    row_bytes = adapter.row_elems * 2
+    row_bytes = adapter.row_bytes
     return {
         "metric": "encoded frames/sec, 1080p & 2160p YUV420 fixed-QP IPPP, 1/2/4/8 MI355X", "value": round(S * a.steps / dt, 4), "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -414,8 +415,8 @@ def run_engine_ring(a, world, rank, local, torch):
         "config": {"workload": name, "sequences_per_gpu": a.sequences, "sequences": S, "frames_per_step": S, "num_enc_engines": world, "wfpp_num_threads": int(keys.get("wpp", 1)),
                    "width": width, "height": height, "frames_in_sequence": nframes, "gop": "IPPP intra_period=100", "qp": 32, "rd_mode": 2, "performance_mode": 2, "sao": 1,
                    "parallelism": f"engine per GPU: frame t of sequence s on rank (s + t) mod {world}; every rank encodes {a.sequences} frames per step in one launch, "
-                                  "then one packed RCCL send / recv of the reconstructed pictures + frame scalars to the next rank",
-                   "timed_region": "per step: import of the previous rank's pictures, CTU decisions + filters + SAO on the device, CABAC / NAL on the host, export + ring exchange",
+                                  "then one packed RCCL send / recv of the reconstructed pictures (8-bit, without margins) + frame scalars to the next rank",
+                   "timed_region": "per step: import of the previous rank's pictures (widen + pad), CTU decisions + filters + SAO + CABAC on the device, headers / NAL on the host, export + ring exchange",
                    "call": "hmr_gpu_enc_encode_batch_pipelined per set of sequences (a rank's sets take turns: a set's access units come with its next call, `world` steps later, "
                            "their download and entropy coding under that call's CTU launch); every pipeline empty when the timed region starts and flushed inside it" if adapter.pipelined
                            else "hmr_gpu_enc_encode_batch"},

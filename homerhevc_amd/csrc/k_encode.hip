@@ -1409,6 +1409,62 @@ extern "C" int hmr_gpu_enc_import_reference(hmr_gpu_enc *e, const int16_t *dy, c
 	return HMR_GPU_OK;
 }
 
+// The same hand-over for the engines of a step at once, with the picture as it travels between GPUs: 8-bit samples without margins (width x height luma, then the
+// two width / 2 x height / 2 chroma planes: hmr_gpu_enc_reference_bytes), picture i at dev_rows + i * pitch; the importer widens it and pads the margins
+// (reference_picture_border_padding_ctu: the margins are a function of the picture).  states: n x hmr_gpu_enc_state_bytes() bytes of host memory.
+extern "C" long hmr_gpu_enc_reference_bytes(hmr_gpu_enc *e) { return e ? (long)e->seq.width * e->seq.height * 3 / 2 : -1; }
+extern "C" int hmr_gpu_enc_export_references8(hmr_gpu_enc **encs, int n, uint8_t *dev_rows, long pitch, void *states)
+{
+	if (!encs || n <= 0 || !dev_rows || !states) return HMR_GPU_ERR_ARG;
+	for (int i = 0; i < n; i++) {
+		hmr_gpu_enc *e = encs[i];
+		if (!e || pitch < hmr_gpu_enc_reference_bytes(e)) return HMR_GPU_ERR_ARG;
+		const Seq &s = e->seq;
+		hipStream_t st = e->ctx->stream;
+		HIP_TRY(hipSetDevice(e->ctx->device));
+		uint8_t *o = dev_rows + (size_t)i * pitch;
+		for (int c = 0; c < 3; c++) {
+			const int w = c ? s.width / 2 : s.width, h = c ? s.height / 2 : s.height;
+			hipLaunchKernelGGL(k_narrow_plane, dim3((w + 255) / 256, h), dim3(256), 0, st, plane0(e, e->cur, c), c ? s.stride_c : s.stride_y, w, h, o);
+			o += (size_t)w * h;
+		}
+		HIP_TRY(hipGetLastError());
+		memcpy((uint8_t *)states + (size_t)i * sizeof(HostState), &e->st, sizeof(HostState));
+	}
+	for (int i = 0; i < n; i++) HIP_TRY(hipStreamSynchronize(encs[i]->ctx->stream));
+	return HMR_GPU_OK;
+}
+extern "C" int hmr_gpu_enc_import_references8(hmr_gpu_enc **encs, int n, const uint8_t *dev_rows, long pitch, const void *states)
+{
+	if (!encs || n <= 0 || !dev_rows || !states) return HMR_GPU_ERR_ARG;
+	for (int i = 0; i < n; i++) {
+		hmr_gpu_enc *e = encs[i];
+		if (!e || pitch < hmr_gpu_enc_reference_bytes(e)) return HMR_GPU_ERR_ARG;
+		HostState in;
+		memcpy(&in, (const uint8_t *)states + (size_t)i * sizeof(HostState), sizeof in);
+		if (in.engines != e->st.engines || (e->engine_index >= 0 && in.num_encoded_frames % e->st.engines != e->engine_index)) {
+			hmr_set_error("hmr_gpu_enc_import_references8: engine %d: state of frame %d does not precede a frame of engine %d of %d", i, in.num_encoded_frames - 1, e->engine_index, e->st.engines);
+			return HMR_GPU_ERR_ARG;
+		}
+		const Seq &s = e->seq;
+		hipStream_t st = e->ctx->stream;
+		HIP_TRY(hipSetDevice(e->ctx->device));
+		const uint8_t *o = dev_rows + (size_t)i * pitch;
+		for (int c = 0; c < 3; c++) {
+			const int w = c ? s.width / 2 : s.width, h = c ? s.height / 2 : s.height;
+			hipLaunchKernelGGL(k_widen_plane, dim3((w + 255) / 256, h), dim3(256), 0, st, o, w, h, plane0(e, e->cur, c), c ? s.stride_c : s.stride_y);
+			o += (size_t)w * h;
+		}
+		HIP_TRY(hipGetLastError());
+		hmr_gpu_frame fr = {s.width, s.height, plane0(e, e->cur, 0), plane0(e, e->cur, 1), plane0(e, e->cur, 2), s.stride_y, s.stride_c};
+		const int rc = hmr_gpu_pad_frame(e->ctx, &fr, s.margin_y, s.margin_y);
+		if (rc) return rc;
+		e->st = in;
+	}
+	for (int i = 0; i < n; i++) HIP_TRY(hipStreamSynchronize(encs[i]->ctx->stream));
+	return HMR_GPU_OK;
+}
+
 extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 {
 	if (!e) return;

@@ -13,11 +13,13 @@ reference (include/homer_gpu.h section 12b, enc/enc_host.h).
 (s + t) mod E - at step t every rank encodes the frames t of the sequences whose turn it is there (one batch launch on the
 GPU), then every rank sends what it produced to the next and receives what the previous produced, in ONE packed transfer.
 
-An `adapter` hides the encoder behind five calls (the product's is `GpuEngines` below: the C ABI of libhomer_gpu.so on torch
+An `adapter` hides the encoder behind a few calls (the product's is `GpuEngines` below: the C ABI of libhomer_gpu.so on torch
 CUDA tensors; the CPU tests bring their own over the checker build):
     create(seq, engine_index) -> handle          load_source(handle, slot, planes)
-    encode(handles, slot) -> [access unit bytes] export(handle, tensor_row)        import_(handle, tensor_row)
-    row_elems                                     new_buffer(rows) -> torch.int16 tensor [rows, row_elems]
+    encode(handles, slot) -> [access unit bytes] new_buffer(rows) -> tensor [rows, row size] that torch.distributed can send
+    export(handle, tensor_row) / import_(handle, tensor_row), or for all engines of a step at once export_many(handles, tensor) / import_many(handles, tensor)
+
+`exchange` (optional) replaces the torch.distributed transfer: exchange(ring, send_rows, recv_rows) - the one-process loop-back of tests/test_gpu_engines.py.
 """
 import ctypes as C
 import os
@@ -39,8 +41,8 @@ def engine_index(seq, rank, world):
 
 
 class EngineRing:
-    def __init__(self, adapter, n_sequences, rank, world):
-        self.a, self.S, self.rank, self.world = adapter, n_sequences, rank, world
+    def __init__(self, adapter, n_sequences, rank, world, exchange=None):
+        self.a, self.S, self.rank, self.world, self.exchange = adapter, n_sequences, rank, world, exchange
         self.enc = {s: adapter.create(s, engine_index(s, rank, world)) for s in range(n_sequences)}
         per_step = (n_sequences + world - 1) // world
         self.send_buf = adapter.new_buffer(per_step)
@@ -59,16 +61,18 @@ class EngineRing:
                 if engine_of(s, t, self.world) == self.rank:
                     self.a.load_source(h, t, planes)
 
-    def step(self, frame, last=False):
-        """encode frame `frame` of this rank's sequences; returns {sequence: access unit}.  Unless `last`, the reconstructions go round the ring afterwards.
-        An adapter that delivers late (`GpuEngines(pipelined=True)`: a call returns the access units of the same sequences' previous call, `world` frames earlier,
-        whose download and entropy coding ran under this call's CTU launch) makes this {sequence: unit of frame - world} ({} for the first `world` frames); `delivered`
-        says which frame the units belong to, `flush()` fetches what is outstanding."""
+    def step_encode(self, frame, last=False):
+        """import what the previous step received, encode frame `frame` of this rank's sequences, export their reconstructions into the send buffer (unless
+        `last`).  Returns {sequence: access unit} (see step())."""
         mine = self.sequences_at(frame)
-        if frame > 0 and self.world > 1:
-            for i, s in enumerate(mine):
-                self.a.import_(self.enc[s], self.recv_buf[i])
-        aus = self.a.encode([self.enc[s] for s in mine], frame)
+        handles = [self.enc[s] for s in mine]
+        if frame > 0 and self.world > 1 and handles:
+            if hasattr(self.a, "import_many"):
+                self.a.import_many(handles, self.recv_buf)
+            else:
+                for i, h in enumerate(handles):
+                    self.a.import_(h, self.recv_buf[i])
+        aus = self.a.encode(handles, frame)
         if getattr(self.a, "pipelined", False):
             key = tuple(mine)
             self.delivered = self.outstanding.get(key)
@@ -77,20 +81,44 @@ class EngineRing:
                 aus = []
         else:
             self.delivered = frame
-        if not last and self.world > 1:
-            for i, s in enumerate(mine):
-                self.a.export(self.enc[s], self.send_buf[i])
-            # rank r's sequences of this step are rank r + 1's of the next, in the same order
-            nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
-            n_out, n_in = len(mine), len(self.sequences_at(frame + 1))
-            ops = []
-            if n_out:
-                ops.append(dist.P2POp(dist.isend, self.send_buf[:n_out], nxt))
-            if n_in:
-                ops.append(dist.P2POp(dist.irecv, self.recv_buf[:n_in], prv))
-            for r in dist.batch_isend_irecv(ops):
-                r.wait()
+        if not last and self.world > 1 and handles:
+            if hasattr(self.a, "export_many"):
+                self.a.export_many(handles, self.send_buf)
+            else:
+                for i, h in enumerate(handles):
+                    self.a.export(h, self.send_buf[i])
         return dict(zip(mine, aus))
+
+    def step_exchange(self, frame):
+        """the reconstructions of frame `frame` go to the next rank, the previous rank's arrive: ONE packed transfer each way"""
+        if self.world < 2:
+            return
+        # rank r's sequences of this step are rank r + 1's of the next, in the same order
+        nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
+        n_out, n_in = len(self.sequences_at(frame)), len(self.sequences_at(frame + 1))
+        if self.exchange is not None:
+            self.exchange(self, self.send_buf[:n_out], self.recv_buf[:n_in])
+            return
+        ops = []
+        if n_out:
+            ops.append(dist.P2POp(dist.isend, self.send_buf[:n_out], nxt))
+        if n_in:
+            ops.append(dist.P2POp(dist.irecv, self.recv_buf[:n_in], prv))
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        # r.wait() orders torch's current stream behind the transfer, not the host: the library reads / writes these buffers on streams of its own
+        if self.recv_buf.is_cuda:
+            torch.cuda.current_stream(self.recv_buf.device).synchronize()
+
+    def step(self, frame, last=False):
+        """encode frame `frame` of this rank's sequences; returns {sequence: access unit}.  Unless `last`, the reconstructions go round the ring afterwards.
+        An adapter that delivers late (`GpuEngines(pipelined=True)`: a call returns the access units of the same sequences' previous call, `world` frames earlier,
+        whose download and entropy coding ran under this call's CTU launch) makes this {sequence: unit of frame - world} ({} for the first `world` frames); `delivered`
+        says which frame the units belong to, `flush()` fetches what is outstanding."""
+        out = self.step_encode(frame, last)
+        if not last:
+            self.step_exchange(frame)
+        return out
 
     def flush(self):
         """late-delivering adapters: [(frame, {sequence: access unit})] for everything outstanding"""
@@ -105,23 +133,24 @@ class EngineRing:
 class GpuEngines:
     """adapter over libhomer_gpu.so (no fallback: without the HIP library there is nothing to run)"""
 
-    def __init__(self, cfg_of, device, pipelined=False):
+    def __init__(self, cfg_of, device, pipelined=False, host_exchange=False):
         self.lib = C.CDLL(os.path.join(ROOT, "homerhevc_amd", "libhomer_gpu.so"))
-        self.cfg_of, self.device, self.pipelined = cfg_of, device, pipelined
+        self.cfg_of, self.device, self.pipelined, self.host_exchange = cfg_of, device, pipelined, host_exchange
+        self.scratch = {}
         lib = self.lib
         lib.hmr_gpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
         lib.hmr_gpu_enc_create_engine.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         lib.hmr_gpu_enc_load_source.argtypes = [C.c_void_p, C.c_int] + [C.c_char_p] * 3
         lib.hmr_gpu_enc_encode_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_long)]
         lib.hmr_gpu_enc_encode_batch_pipelined.argtypes = lib.hmr_gpu_enc_encode_batch.argtypes
-        lib.hmr_gpu_enc_reference_elems.restype = C.c_long
-        lib.hmr_gpu_enc_reference_elems.argtypes = [C.c_void_p, C.c_int]
-        lib.hmr_gpu_enc_export_reference.argtypes = [C.c_void_p] * 5
-        lib.hmr_gpu_enc_import_reference.argtypes = [C.c_void_p] * 5
+        lib.hmr_gpu_enc_reference_bytes.restype = C.c_long
+        lib.hmr_gpu_enc_reference_bytes.argtypes = [C.c_void_p]
+        lib.hmr_gpu_enc_export_references8.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_long, C.c_void_p]
+        lib.hmr_gpu_enc_import_references8.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_long, C.c_char_p]
         lib.hmr_gpu_enc_destroy.argtypes = [C.c_void_p]
         lib.hmr_gpu_last_error.restype = C.c_char_p
         self.state_bytes = lib.hmr_gpu_enc_state_bytes()
-        self.elems = None
+        self.ref_bytes = None
         self.bufs = {}
         self.states = {}
         self.slots = {}
@@ -131,18 +160,31 @@ class GpuEngines:
         assert self.lib.hmr_gpu_create(C.byref(ctx), self.device, None) == 0, self.lib.hmr_gpu_last_error()
         cfg = self.cfg_of(seq)
         assert self.lib.hmr_gpu_enc_create_engine(ctx, C.byref(cfg), index, C.byref(enc)) == 0, self.lib.hmr_gpu_last_error()
-        if self.elems is None:
-            self.elems = [self.lib.hmr_gpu_enc_reference_elems(enc, c) for c in range(3)]
+        if self.ref_bytes is None:
+            self.ref_bytes = self.lib.hmr_gpu_enc_reference_bytes(enc)
         self.bufs[enc.value] = C.create_string_buffer(4 << 20)
         self.slots[enc.value] = {}
         return enc
 
     @property
-    def row_elems(self):
-        return sum(self.elems) + (self.state_bytes + 1) // 2
+    def row_bytes(self):
+        """a picture as it travels (8-bit samples, no margins) + the frame-to-frame scalars, rounded up to 16 bytes"""
+        return (self.ref_bytes + self.state_bytes + 15) // 16 * 16
 
     def new_buffer(self, rows):
-        return torch.zeros((max(rows, 1), self.row_elems), dtype=torch.int16, device=f"cuda:{self.device}")
+        """what torch.distributed sends / receives: on the GPU (RCCL), or page-locked on the host (`host_exchange`: gloo, e.g. several ranks on one GPU)"""
+        shape = (max(rows, 1), self.row_bytes)
+        if self.host_exchange:
+            return torch.zeros(shape, dtype=torch.uint8).pin_memory()
+        return torch.zeros(shape, dtype=torch.uint8, device=f"cuda:{self.device}")
+
+    def _device_rows(self, buf):
+        if buf.is_cuda:
+            return buf
+        key = tuple(buf.shape)
+        if key not in self.scratch:
+            self.scratch[key] = torch.zeros(key, dtype=torch.uint8, device=f"cuda:{self.device}")
+        return self.scratch[key]
 
     def load_source(self, h, frame, planes):
         slot = len(self.slots[h.value])
@@ -162,22 +204,27 @@ class GpuEngines:
         assert call(e_arr, n, slots, None, ptrs, caps, got) == 0, self.lib.hmr_gpu_last_error()
         return [C.string_at(self.bufs[h.value], got[i]) for i, h in enumerate(handles)]
 
-    def _split(self, row):
-        p = row.data_ptr()
-        y, u, v = p, p + 2 * self.elems[0], p + 2 * (self.elems[0] + self.elems[1])
-        return y, u, v, p + 2 * sum(self.elems)
+    def export_many(self, handles, buf):
+        """the reconstructions (8-bit, unpadded) and the scalars of the engines of a step into buf[:n]: one call, one copy of all the scalars"""
+        n = len(handles)
+        dev = self._device_rows(buf)
+        states = C.create_string_buffer(self.state_bytes * n)
+        e_arr = (C.c_void_p * n)(*handles)
+        assert self.lib.hmr_gpu_enc_export_references8(e_arr, n, dev.data_ptr(), self.row_bytes, states) == 0, self.lib.hmr_gpu_last_error()
+        tail = torch.frombuffer(bytearray(states.raw), dtype=torch.uint8).view(n, self.state_bytes)
+        dev[:n, self.ref_bytes:self.ref_bytes + self.state_bytes].copy_(tail)
+        if dev is not buf:
+            buf[:n].copy_(dev[:n])
+        torch.cuda.current_stream(dev.device).synchronize()
 
-    def export(self, h, row):
-        y, u, v, st = self._split(row)
-        state = C.create_string_buffer(self.state_bytes)
-        assert self.lib.hmr_gpu_enc_export_reference(h, y, u, v, state) == 0, self.lib.hmr_gpu_last_error()
-        tail = torch.frombuffer(bytearray(state.raw + b"\0" * (self.state_bytes & 1)), dtype=torch.int16)
-        row[sum(self.elems):].copy_(tail)
-
-    def import_(self, h, row):
-        y, u, v, st = self._split(row)
-        state = bytes(row[sum(self.elems):].cpu().numpy().tobytes()[:self.state_bytes])
-        assert self.lib.hmr_gpu_enc_import_reference(h, y, u, v, state) == 0, self.lib.hmr_gpu_last_error()
+    def import_many(self, handles, buf):
+        n = len(handles)
+        dev = self._device_rows(buf)
+        if dev is not buf:
+            dev[:n].copy_(buf[:n])
+        states = dev[:n, self.ref_bytes:self.ref_bytes + self.state_bytes].cpu().contiguous().numpy().tobytes()      # (one copy for all engines; it also waits for the rows)
+        e_arr = (C.c_void_p * n)(*handles)
+        assert self.lib.hmr_gpu_enc_import_references8(e_arr, n, dev.data_ptr(), self.row_bytes, states) == 0, self.lib.hmr_gpu_last_error()
 
     def destroy(self, h):
         self.lib.hmr_gpu_enc_destroy(h)

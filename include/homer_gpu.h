@@ -645,6 +645,12 @@ int hmr_gpu_enc_state_bytes(void);
 long hmr_gpu_enc_reference_elems(hmr_gpu_enc *enc, int comp);
 int hmr_gpu_enc_export_reference(hmr_gpu_enc *enc, int16_t *dev_y, int16_t *dev_u, int16_t *dev_v, void *state);
 int hmr_gpu_enc_import_reference(hmr_gpu_enc *enc, const int16_t *dev_y, const int16_t *dev_u, const int16_t *dev_v, const void *state);
+/* The hand-over of n engines at once with the picture as it travels between GPUs: 8-bit samples without margins (hmr_gpu_enc_reference_bytes: width x height
+ * luma, then the two chroma planes; 3.1 MB at 1080p against 6.6 MB of padded int16 planes), picture i at dev_rows + i * pitch in DEVICE memory; the importer
+ * widens the samples and rebuilds the margins (reference_picture_border_padding_ctu, hmr_encoder_lib.c:1723).  states: n x hmr_gpu_enc_state_bytes() bytes (host). */
+long hmr_gpu_enc_reference_bytes(hmr_gpu_enc *enc);
+int hmr_gpu_enc_export_references8(hmr_gpu_enc **encs, int n, uint8_t *dev_rows, long pitch, void *states);
+int hmr_gpu_enc_import_references8(hmr_gpu_enc **encs, int n, const uint8_t *dev_rows, long pitch, const void *states);
 
 /* ------------------------------------------------------------------------------------------------
  * 13. Phase planes of a reference picture
