@@ -954,7 +954,7 @@ inline void assemble_access_unit(EntropyState &es, const Seq &S, const FrameCtx 
 {
 	const int H = S.hctu, nrows = S.wpp ? H : 1;
 	const bool idr = f.slice_type == SLICE_I;
-	if (idr) es.last_idr = f.poc;
+	(void)es;
 	std::vector<std::vector<uint8_t>> nals;
 	if (idr) {
 		std::vector<uint8_t> vps, sps, pps;
@@ -969,7 +969,7 @@ inline void assemble_access_unit(EntropyState &es, const Seq &S, const FrameCtx 
 		sh.uvlc(0);                            // pps id
 		sh.uvlc(f.slice_type);
 		if (!idr) {
-			sh.write((f.poc - es.last_idr + 16) % 16, 4);
+			sh.write((f.poc - f.last_idr + 16) % 16, 4);
 			sh.write(1, 1);                    // short_term_ref_pic_set_sps_flag
 			int num_bits = 0;
 			while ((1 << num_bits) < S.gop_size + S.num_ref_frames) num_bits++;

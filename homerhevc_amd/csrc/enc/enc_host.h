@@ -190,7 +190,7 @@ struct HostState {
 	int poc = 0, last_intra = 0, last_gop_reinit = 0, num_encoded_frames = 0;
 	double avg_dist = 0.0;          // hvenc->avg_dist: calloc'ed, so the first frame runs with 0 (hmr_encoder_lib.c:3191)
 	double avg_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // hvenc->avg_dist after each of the last eight frames
-	int engines = 1, pad_ = 0;
+	int engines = 1, last_idr = 0;  // last_idr: picture order count of the last IDR picture
 	RcState rc = {};                // rate control (enc_rc.h): hvenc->rc, pict_qp
 };
 // HVENC_Cfg rates -> the rate control's sequence state (HOMER_SETCFG hmr_encoder_lib.c:949-963 + hmr_rc_init)
@@ -216,9 +216,11 @@ inline void begin_frame(const Seq &s, HostState &st, int image_type, FrameCtx &f
 	if (intra) {
 		st.last_intra = poc;
 		st.last_gop_reinit = poc;
+		st.last_idr = poc;
 	}
 	f.slice_type = intra ? SLICE_I : SLICE_P;
 	f.poc = poc;
+	f.last_idr = st.last_idr;
 	f.qp = s.qp;
 	if (s.bitrate_mode != BR_FIXED_QP) {
 		// hmr_slice_init :1990 (the slice QP is the frame QP the last frame left), hmr_rc_init_pic

@@ -17,12 +17,17 @@
 //             P(r, c - 1) done (sub-stream order, SAO merge-left); P(r - 1, c + 1) done (SAO merge-up; the WPP context hand-over after the row's second CTU).
 // Without SAO the reference codes a CTU right behind its decisions (:2611-2612) and the rate control may read its bits one step later: P(r, c) then waits for the
 // CTU's decisions only, and the copy of the deblocked CTU into the final picture + padding is a task of its own, F(r, c), with P's filter conditions.
+// When the frames of a sequence overlap (hmr_gpu_enc_encode_chain) a fourth task S(r, c) makes the phase planes of the final picture around CTU (r, c) as soon as
+// P (or F) has run on the CTUs around it; the next frame's CTUs wait for the S tasks of the part of this picture their vectors can reach (k_encode.hip).
 // Progress is kept in per-row counters; any worker may run any task whose conditions hold (claimed with a compare-and-swap on the row's task ticket).
 // Under rate control the CTU decisions of wavefront step t read the bits of the CTUs the reference has coded when step t starts: CodedSchedule replays the
 // reference's lag arithmetic once per picture size and the step does not open before those P tasks are done (enc_rc.h).
 #pragma once
 #include "enc_entropy.h"
 #include "enc_rc.h"
+#if defined(__HIPCC__)
+#include "../subpel_task.h"      // (device only) the phase planes of the final picture, CTU by CTU: task S
+#endif
 
 #if defined(__HIPCC__)
 #define HENC_NOINLINE __attribute__((noinline))      // one compiled body for every task that uses the function (and: inlined into k_post_frame's copy of the F task, the
@@ -93,8 +98,8 @@ HENC_HDX void post_add_fast(const G &g, int32_t *p, int32_t v)      // an accumu
 }
 
 // ---- per-picture state of the stage ----------------------------------------------------------------------------------------------------------------------------
-struct PostRow {               // progress of one CTU row: CTUs decided, D tasks claimed / done, P tasks claimed / done, F tasks claimed / done
-	int dec, d_claim, d_done, p_claim, p_done, f_claim, f_done, pad_;
+struct PostRow {               // progress of one CTU row: CTUs decided, D / P / F / S tasks claimed and done
+	int dec, d_claim, d_done, p_claim, p_done, f_claim, f_done, s_claim, s_done, pad_[7];
 };
 struct RowEnt {                // the CABAC coder of a CTU row's sub-stream between two CTUs, and the contexts the next row starts from
 	uint32_t low, range, buffered_byte;
@@ -117,6 +122,8 @@ struct PostPic {
 	int *errors;               // [0] a sub-stream ran out of room
 	const uint16_t *rc_need;   // rate control: [steps + 1][hctu] P tasks of each row the reference has run when the step starts (nullptr: fixed QP)
 	unsigned long long *prof;  // profiling build (-DHENC_POST_PROFILE): ticks per part of the stage (PostProf), else unused
+	uint8_t *planes[3];        // device, overlapping frames of a sequence: the phase planes of the final picture (allocation start: k_subpel.hip's layout), written by
+	                           // task S(r, c) when the final samples around CTU (r, c) are there; nullptr: the planes are made by the frame kernels before the next frame
 };
 enum PostProf { PPF_D = 0, PPF_P_LOAD, PPF_P_STATS, PPF_P_CAND, PPF_P_DECIDE, PPF_P_SYNTAX, PPF_P_APPLY, PPF_SCAN, PPF_D_COUNT, PPF_P_COUNT, PPF_N };
 #if defined(__HIP_DEVICE_COMPILE__) && defined(HENC_POST_PROFILE)
@@ -149,6 +156,7 @@ struct alignas(16) PostScratch {
 };
 #if defined(__HIPCC__)
 static_assert(sizeof(PostScratch) <= sizeof(Work), "the post stage works in the worker's Work area");
+static_assert(sizeof(SubpelScratch) <= sizeof(PostScratch), "task S works in the post stage's scratch");
 #endif
 
 static constexpr uint8_t kDbkTc[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1,
@@ -692,7 +700,20 @@ HENC_HDX int post_drain(const G &g, const PostCtx &x, PostScratch &sc)
 					f_ok = fc < W && post_ld(&me.f_claim) == fc && dc >= need && below >= need && (r == 0 || post_ld(&P.rows[r - 1].f_done) >= post_min(fc + 2, W));
 				}
 			}
-			const uint64_t pm = g.ballot(p_ok), dm = g.ballot(d_ok), fm = g.ballot(f_ok);
+			bool s_ok = false;
+			int sc_ = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (r < H && P.planes[0]) {
+				// S(r, c): the final samples of the CTUs around (r, c) - the filters reach four samples out
+				const PostRow &me = P.rows[r];
+				sc_ = post_ld(&me.s_done);
+				const int need = post_min(sc_ + 2, W);
+				const int *fin_done = S.sao ? &me.p_done : &me.f_done;
+				const ptrdiff_t row_ints = (ptrdiff_t)(sizeof(PostRow) / sizeof(int));
+				s_ok = sc_ < W && post_ld(&me.s_claim) == sc_ && post_ld(fin_done) >= need && (r == 0 || post_ld(fin_done - row_ints) >= need) && (r + 1 >= H || post_ld(fin_done + row_ints) >= need);
+			}
+#endif
+			const uint64_t pm = g.ballot(p_ok), dm = g.ballot(d_ok), fm = g.ballot(f_ok), sm = g.ballot(s_ok);
 			if (pm) {
 				const int lane = __builtin_ctzll(pm);
 				pick_r = base + lane; pick_kind = 1;
@@ -717,18 +738,31 @@ HENC_HDX int post_drain(const G &g, const PostCtx &x, PostScratch &sc)
 #else
 				pick_c = fc;
 #endif
+			} else if (sm) {
+				const int lane = __builtin_ctzll(sm);
+				pick_r = base + lane; pick_kind = 3;
+#if defined(__HIP_DEVICE_COMPILE__)
+				pick_c = __builtin_amdgcn_readlane(sc_, lane);
+#else
+				pick_c = sc_;
+#endif
 			}
 		}
 		PPF_LAP(P, PPF_SCAN);
 		if (pick_r < 0) return ran;
 		PostRow &row = P.rows[pick_r];
-		if (!post_claim(g, pick_kind == 1 ? &row.p_claim : (pick_kind == 2 ? &row.f_claim : &row.d_claim), pick_c)) continue;      // somebody else took it: look again
+		int *claim = pick_kind == 1 ? &row.p_claim : (pick_kind == 2 ? &row.f_claim : (pick_kind == 3 ? &row.s_claim : &row.d_claim));
+		int *done = pick_kind == 1 ? &row.p_done : (pick_kind == 2 ? &row.f_done : (pick_kind == 3 ? &row.s_done : &row.d_done));
+		if (!post_claim(g, claim, pick_c)) continue;      // somebody else took it: look again
 		post_acquire();
 		if (pick_kind == 1) post_task_p(g, x, sc, pick_r, pick_c);
 		else if (pick_kind == 2) post_task_f(g, x, sc, pick_r, pick_c);
+#if defined(__HIP_DEVICE_COMPILE__)
+		else if (pick_kind == 3) subpel_task_ctu(g.tid, *(SubpelScratch *)&sc, S, P.fin, P.planes[0], P.planes[1], P.planes[2], pick_c, pick_r);
+#endif
 		else post_task_d(g, x, pick_r, pick_c);
 		post_release();
-		if (g.tid == 0) post_st_release(pick_kind == 1 ? &row.p_done : (pick_kind == 2 ? &row.f_done : &row.d_done), pick_c + 1);
+		if (g.tid == 0) post_st_release(done, pick_c + 1);
 		g.sync();
 		ran++;
 #if defined(__HIP_DEVICE_COMPILE__) && defined(HENC_POST_PROFILE)
@@ -767,7 +801,11 @@ HENC_HDX bool rc_ready(const G &g, const PostPic &P, int H, int k)
 // all P tasks of the picture done?
 HENC_INLINE bool post_finished(const Seq &S, const PostPic &P)
 {
-	return post_ld(&P.rows[S.hctu - 1].p_done) >= S.wctu && (S.sao || post_ld(&P.rows[S.hctu - 1].f_done) >= S.wctu);
+	if (!(post_ld(&P.rows[S.hctu - 1].p_done) >= S.wctu && (S.sao || post_ld(&P.rows[S.hctu - 1].f_done) >= S.wctu))) return false;
+	if (P.planes[0])      // (S tasks of different rows are not ordered: every row)
+		for (int r = 0; r < S.hctu; r++)
+			if (post_ld(&P.rows[r].s_done) < S.wctu) return false;
+	return true;
 }
 
 }  // namespace henc

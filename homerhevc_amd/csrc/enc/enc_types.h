@@ -159,6 +159,7 @@ struct FrameCtx {
 	int32_t scene_cut_allowed, scene_cut_ctu;
 	// lockstep = 1: the synchronous-wavefront schedule of wfpp_num_threads > 1 (enc_sched.h): "after the cut" then means a later STEP (c + 2r), not a later CTU
 	int32_t lockstep, wctu;
+	int32_t last_idr, pad_idr_;            // picture order count of the last IDR picture (the slice header codes the count relative to it)
 	double avg_dist, lambda, sqrt_lambda, chroma_weight;
 	double sao_lambda[3];
 	const int16_t *src[3];                 // source picture, first sample

@@ -59,6 +59,7 @@ struct EncDev {
 	int *row0_checked;            // lockstep schedule: steps for which row 0 has made its scene-change check
 	int *counters;                // [0] CTUs found wrong by the last check, [1] CTU encodes of the frame, [2] the CTU at which a scene change is detected (-1: none)
 	int threads;                  // lockstep schedule: wfpp_num_threads (row r is encoded by thread r % threads)
+	int dep, dep_full;            // overlapping frames of a sequence (hmr_gpu_enc_encode_chain): the picture of this launch whose final picture this one predicts from, or -1
 	RcFrame *rc_dyn;              // rate control: the frame's parameters after a scene change moved them (hmr_rc_change_pic_mode), [0]; valid once counters[2] >= 0
 	PostPic post;                 // the post-decision stage of the picture (enc_post.h): deblocking, SAO, entropy coding, padding as tasks of the CTU kernel
 };
@@ -511,7 +512,25 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(2))
 				const int lane0 = __builtin_ctzll(m);
 				const int q0 = __builtin_amdgcn_readlane(cand, lane0), t0 = __builtin_amdgcn_readlane(ct, lane0);
 				const EncDev &d0 = devs[q0];
-				if (!d0.post.rc_need || rc_ready(g, d0.post, d0.seq->hctu, t0)) break;
+				bool ready = !d0.post.rc_need || rc_ready(g, d0.post, d0.seq->hctu, t0);
+				// overlapping frames: the phase planes of the part of the reference picture this step's CTUs can reach (rows r - 2 .. r + 2, columns c - 3 .. c + 3:
+				// +-128 x +-64 samples of search, a sample of refinement, four of filter) have been written by the S tasks of the picture it predicts from
+				if (ready && d0.dep >= 0) {
+					const EncDev &dd = devs[d0.dep];
+					const int H0 = dd.seq->hctu, W0 = dd.seq->wctu;
+					for (int base2 = 0; base2 < H0 && ready; base2 += 64) {
+						const int r2 = base2 + g.tid;
+						bool miss = false;
+						if (r2 < H0) {
+							int need = t0 - 2 * r2 + 8;
+							need = need < 0 ? 0 : (need > W0 ? W0 : need);
+							if (d0.dep_full) need = W0;
+							miss = post_ld(&dd.post.rows[r2].s_done) < need;
+						}
+						if (g.any(miss)) ready = false;
+					}
+				}
+				if (ready) break;
 				m &= m - 1;
 			}
 			if (m) {
@@ -878,6 +897,8 @@ struct hmr_gpu_enc {
 	int row_cap = 0;
 	std::vector<RowEnt> h_ent;
 	std::vector<uint8_t, PinnedAlloc<uint8_t>> h_bs;
+	PlaneSet chain_planes2;          // (the set of its frame before: the object that ends a chain holds the planes the chain's first frame predicts from while its own S tasks write the next)
+	PlaneSet chain_planes;           // overlapping frames (hmr_gpu_enc_encode_chain): the phase planes of THIS object's final picture, written by the S tasks of its CTU launch
 	PlaneSet planes;                 // phase planes of the reference picture (k_subpel.hip: 16 luma, 2 x 64 chroma), borrowed from g_plane_pool for the CTU stage of a P frame
 	size_t src_elems[3], pic_elems[3];
 	uint8_t *d_bytes;              // staging for 8-bit planes (one 4:2:0 picture)
@@ -1123,7 +1144,7 @@ int run_ctu_passes(hmr_gpu_enc *e)
 	return HMR_GPU_OK;
 }
 
-int set_frame(hmr_gpu_enc *e, int slot, int image_type, double avg_dist, bool upload = true)
+int set_frame(hmr_gpu_enc *e, int slot, int image_type, double avg_dist, bool upload = true, bool chain = false)
 {
 	const Seq &s = e->seq;
 	e->cur ^= 1;
@@ -1143,7 +1164,10 @@ int set_frame(hmr_gpu_enc *e, int slot, int image_type, double avg_dist, bool up
 		e->d.post.fin[c] = plane0(e, e->cur, c);
 	}
 	e->d.post.sao_lambda = e->d_sao_tab + (e->f.slice_type == SLICE_I ? 104 : 0);
-	if (e->f.slice_type != SLICE_I) {
+	e->d.dep = -1;
+	e->d.dep_full = 0;
+	e->d.post.planes[0] = e->d.post.planes[1] = e->d.post.planes[2] = nullptr;
+	if (e->f.slice_type != SLICE_I && !chain) {
 		if (!e->planes.y) {
 			const int rc = g_plane_pool.acquire(e->ctx->device, (size_t)16 * s.plane_elems_y, (size_t)64 * s.plane_elems_c, &e->planes);
 			if (rc) return rc;
@@ -1471,6 +1495,8 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	(void)hipSetDevice(e->ctx->device);
 	(void)hipStreamSynchronize(e->ctx->stream);
 	release_planes(e);
+	for (PlaneSet *ps : {&e->chain_planes, &e->chain_planes2})
+		if (ps->y) { (void)hipFree(ps->y); (void)hipFree(ps->c[0]); (void)hipFree(ps->c[1]); }
 	e->d.ctus = e->d_ctus_eng[0]; e->d.rowstate = e->d_rowstate_eng[0]; e->d.thread_seen = e->d_seen_eng[0];
 	for (int k = 1; k < MAX_ENGINES; k++) {
 		if (e->d_ctus_eng[k]) (void)hipFree(e->d_ctus_eng[k]);
@@ -2119,6 +2145,163 @@ extern "C" int hmr_gpu_enc_encode_batch_pipelined(hmr_gpu_enc **encs, int n, con
 	}
 	if (slots && (rc = batch_finish(encs, n, slots, pitch, bt))) return rc;
 	if (slots) batch_report(bt, lead, true);
+	return HMR_GPU_OK;
+}
+
+// Consecutive frames of ONE sequence in one CTU launch, overlapping as far as the reference samples allow (the engines' overlap of the reference, encoder_engine_thread
+// hmr_encoder_lib.c:3154-3211 with the row semaphores of :2393-2445, in the interleaving the engine turnstile pins: oracle/ref_ctudump.c:88-108).
+// encs[0 .. n - 1]: the engine objects (hmr_gpu_enc_create_engine) of the frames slots[0 .. n - 1] in coding order, n <= num_enc_engines; prev: the object that encoded
+// the frame before slots[0] (NULL for the sequence's first frame).  Frame j predicts from the final picture of frame j - 1 where it lies - in encs[j - 1], or prev - and
+// from the phase planes the S tasks of that picture's launch have written (enc_post.h); its CTUs of a wavefront step start when the S tasks of the part of the
+// reference they can reach are done.  Frame typing and the frame scalars a frame starts from are those of the sequential order: they depend on frames at least n before
+// it, except when a frame of the chain detects a scene change - if a later frame of the same chain detects one too, the call fails (HMR_GPU_ERR_ARG) and the chain has
+// to be repeated frame by frame.
+extern "C" int hmr_gpu_enc_encode_chain(hmr_gpu_enc **encs, int n, hmr_gpu_enc *prev, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes)
+{
+	if (!encs || n <= 0 || n > MAX_ENGINES || !slots || !streams || !caps || !stream_bytes) return HMR_GPU_ERR_ARG;
+	for (int j = 0; j < n; j++) {
+		hmr_gpu_enc *e = encs[j];
+		if (!e || !e->lockstep || e->ctx->device != encs[0]->ctx->device || slots[j] < 0 || slots[j] >= (int)e->src.size() || !streams[j] || e->awaiting_delivery || e->engine_index < 0 ||
+		    n > e->st.engines || e->seq.width != encs[0]->seq.width || e->seq.height != encs[0]->seq.height) {
+			hmr_set_error("hmr_gpu_enc_encode_chain: frame %d: needs an engine object (hmr_gpu_enc_create_engine) of the chain's sequence on the chain's device with a loaded picture slot, at most num_enc_engines frames", j);
+			return HMR_GPU_ERR_ARG;
+		}
+		for (int i = 0; i < j; i++)
+			if (encs[i] == e) return HMR_GPU_ERR_ARG;
+	}
+	hmr_gpu_enc *lead = encs[0];
+	hipStream_t bst = lead->ctx->stream;
+	HIP_TRY(hipSetDevice(lead->ctx->device));
+	int rc, rows_total = 0;
+	if (!lead->d_frames) {
+		HIP_TRY(hipMalloc((void **)&lead->d_frames, 256 * sizeof(FrameCtx)));
+		HIP_TRY(hipHostMalloc((void **)&lead->h_frames, 256 * sizeof(FrameCtx), hipHostMallocDefault));
+		HIP_TRY(hipHostMalloc((void **)&lead->h_devs, 256 * sizeof(EncDev), hipHostMallocDefault));
+	}
+	if (!lead->d_batch) HIP_TRY(hipMalloc((void **)&lead->d_batch, 256 * sizeof(EncDev)));
+	// the state every frame starts from, as the sequential order would hand it over: what begin_frame reads of it is older than the chain, a scene change excepted
+	HostState st = prev ? prev->st : lead->st;
+	const HostState start_state = st;
+	std::vector<HostState> before(n);
+	for (int j = 0; j < n; j++) {
+		hmr_gpu_enc *e = encs[j];
+		const Seq &s = e->seq;
+		if (st.num_encoded_frames % e->st.engines != e->engine_index) {
+			hmr_set_error("hmr_gpu_enc_encode_chain: frame %d of the sequence belongs to engine %d, not %d", st.num_encoded_frames, st.num_encoded_frames % e->st.engines, e->engine_index);
+			return HMR_GPU_ERR_ARG;
+		}
+		for (int k = 0; k < 2; k++) {
+			PlaneSet &ps = k ? e->chain_planes2 : e->chain_planes;
+			if (ps.y) continue;
+			PlaneSet p;
+			p.device = e->ctx->device; p.bytes_y = (size_t)16 * s.plane_elems_y; p.bytes_c = (size_t)64 * s.plane_elems_c;
+			HIP_TRY(hipMalloc((void **)&p.y, p.bytes_y));
+			HIP_TRY(hipMalloc((void **)&p.c[0], p.bytes_c));
+			HIP_TRY(hipMalloc((void **)&p.c[1], p.bytes_c));
+			ps = p;
+		}
+		before[j] = st;
+		e->st = st;
+		// what the frame predicts from, taken before the object that holds it (prev may be the chain's last object) moves on to its own next frame
+		const hmr_gpu_enc *r = j ? encs[j - 1] : prev;
+		const int16_t *ref_planes[3] = {nullptr, nullptr, nullptr};
+		PlaneSet ref_set;
+		if (r) {
+			for (int c = 0; c < 3; c++) ref_planes[c] = plane0(const_cast<hmr_gpu_enc *>(r), r->cur, c);
+			ref_set = r->chain_planes;
+		}
+		std::swap(e->chain_planes, e->chain_planes2);      // (an object writes its two sets in turn: prev - often the chain's last object - keeps the set the chain's first frame reads)
+		if (j == 0 && e == prev) ref_set = e->chain_planes2;       // (a one-engine sequence: the object predicts from its own last picture)
+		if ((rc = set_frame(e, slots[j], image_types ? image_types[j] : 0, -1.0, false, true))) return rc;
+		st = e->st;
+		st.num_encoded_frames++;                       // (what end_frame will do; the distortion average it will store is not read inside the chain)
+		if (e->f.slice_type != SLICE_I) {
+			if (!r || !ref_set.y) {
+				hmr_set_error("hmr_gpu_enc_encode_chain: frame %d is a P frame and there is no object that holds the picture before it with its phase planes", j);
+				return HMR_GPU_ERR_ARG;
+			}
+			for (int c = 0; c < 3; c++) e->f.ref[c] = ref_planes[c];
+			e->f.sub_y = ref_set.y + (size_t)s.margin_y * 16 * s.stride_y + s.margin_y;
+			e->f.sub_c[0] = ref_set.c[0] + (size_t)s.margin_c * 64 * s.stride_c + s.margin_c;
+			e->f.sub_c[1] = ref_set.c[1] + (size_t)s.margin_c * 64 * s.stride_c + s.margin_c;
+			e->d.dep = j ? j - 1 : -1;
+			e->d.dep_full = getenv("HENC_CHAIN_SERIAL") ? 1 : 0;
+		}
+		e->d.post.planes[0] = e->chain_planes.y; e->d.post.planes[1] = e->chain_planes.c[0]; e->d.post.planes[2] = e->chain_planes.c[1];
+		HIP_TRY(hipEventRecord(e->ev_ready, e->ctx->stream));
+		if (j) HIP_TRY(hipStreamWaitEvent(bst, e->ev_ready, 0));
+		lead->h_frames[j] = e->f;
+		lead->h_devs[j] = e->d;
+		lead->h_devs[j].frame = lead->d_frames + j;
+		rows_total += s.hctu;
+	}
+	const int nctu = lead->seq.nctu, pitch = GATHER_HEAD + nctu + POST_MAX_ROWS;
+	if ((size_t)pitch * n > lead->gather_words) {
+		if (lead->d_gather) (void)hipFree(lead->d_gather);
+		if (lead->h_gather) (void)hipHostFree(lead->h_gather);
+		lead->d_gather = lead->h_gather = nullptr;
+		lead->gather_words = 0;
+		HIP_TRY(hipMalloc((void **)&lead->d_gather, (size_t)pitch * 256 * 4));
+		HIP_TRY(hipHostMalloc((void **)&lead->h_gather, (size_t)pitch * 256 * 4, hipHostMallocDefault));
+		lead->gather_words = (size_t)pitch * 256;
+	}
+	hipLaunchKernelGGL(k_batch_stage, dim3(n), dim3(256), 0, bst, (const EncDev *)lead->h_devs, (const FrameCtx *)lead->h_frames, (EncDev *)lead->d_batch, lead->d_frames);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(lead->ev_batch0, bst));
+	if ((rc = launch_pool(lead, n, rows_total, bst))) return rc;
+	(void)hipEventRecord(lead->ev_batch1, bst);
+	hipLaunchKernelGGL(k_gather_results, dim3(n), dim3(256), 0, bst, (const EncDev *)lead->d_batch, lead->d_gather, pitch, (const int *)(lead->d_pool_state + 256 * POOL_STRIDE));
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(lead->h_gather, lead->d_gather, (size_t)pitch * n * 4, hipMemcpyDeviceToHost, bst));
+	{
+		const hipError_t waited = hipStreamSynchronize(bst);
+		if (waited != hipSuccess) { hmr_set_error("k_encode_pool: %s", hipGetErrorString(waited)); return HMR_GPU_ERR_HIP; }
+	}
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, lead->ev_batch0, lead->ev_batch1));
+	// the frames' bookkeeping in coding order, on the state the sequential order hands from frame to frame
+	HostState seq_state = start_state;
+	bool cut_before = false;
+	for (int j = 0; j < n; j++) {
+		hmr_gpu_enc *e = encs[j];
+		const Seq &s = e->seq;
+		const uint32_t *g = lead->h_gather + (size_t)j * pitch;
+		if (g[3] & 2) { hmr_set_error("k_encode_pool: the launch was abandoned by its watchdog (HENC_WATCHDOG_S)"); return HMR_GPU_ERR_HIP; }
+		if (g[3] & 1) { hmr_set_error("hmr_gpu_enc_encode_chain: frame %d: a CTU row's sub-stream outgrew its buffer (%d bytes)", j, e->row_cap); return HMR_GPU_ERR_HIP; }
+		e->last_ms = e->last_total_ms = ms;
+		e->last_encodes = (int)g[1];
+		e->f.scene_cut_ctu = (int)g[2];
+		e->last_passes = 1;
+		const bool fired = (int)g[2] >= 0;
+		if (fired && cut_before) {
+			hmr_set_error("hmr_gpu_enc_encode_chain: two frames of the chain detected a scene change: in the sequential order the first one switches the detection off for the second; repeat the chain frame by frame");
+			return HMR_GPU_ERR_ARG;
+		}
+		cut_before = cut_before || fired;
+		// the frame's true starting state: what begin_frame made of the predicted one (picture order count, frame typing) on top of what the frames before really left
+		FrameCtx replay;
+		e->st = seq_state;
+		begin_frame(s, e->st, image_types ? image_types[j] : 0, replay);
+		if (replay.slice_type != e->f.slice_type || replay.poc != e->f.poc || replay.avg_dist != e->f.avg_dist) {
+			hmr_set_error("hmr_gpu_enc_encode_chain: frame %d started from a state the frames before it changed", j);
+			return HMR_GPU_ERR_ARG;
+		}
+		FrameRcOut ro;
+		ro.sum_qp = (int)g[4]; ro.consumed_bits = (double)g[5];
+		memcpy(&ro.target_pict_size, &g[6], 8);
+		end_frame(s, e->st, e->f, frame_acc_dist(s, e->cfg.wfpp_num_threads, [&](int c) { return g[GATHER_HEAD + c]; }), &ro);
+		seq_state = e->st;
+		// the access unit
+		const int rows = s.wpp ? s.hctu : 1;
+		std::vector<uint32_t> row_bytes(g + pitch - POST_MAX_ROWS, g + pitch - POST_MAX_ROWS + rows);
+		size_t total = 0;
+		for (int r = 0; r < rows; r++) {
+			HIP_TRY(hipMemcpyAsync(e->h_bs.data() + total, e->d_bs + (size_t)r * e->row_cap, row_bytes[r], hipMemcpyDeviceToHost, bst));
+			total += row_bytes[r];
+		}
+		HIP_TRY(hipStreamSynchronize(bst));
+		if ((rc = frame_assemble(e, e->f, e->h_bs.data(), row_bytes.data(), streams[j], caps[j], &stream_bytes[j])) < 0) return rc;
+	}
 	return HMR_GPU_OK;
 }
 

@@ -649,6 +649,14 @@ int hmr_gpu_enc_import_reference(hmr_gpu_enc *enc, const int16_t *dev_y, const i
  * luma, then the two chroma planes; 3.1 MB at 1080p against 6.6 MB of padded int16 planes), picture i at dev_rows + i * pitch in DEVICE memory; the importer
  * widens the samples and rebuilds the margins (reference_picture_border_padding_ctu, hmr_encoder_lib.c:1723).  states: n x hmr_gpu_enc_state_bytes() bytes (host). */
 long hmr_gpu_enc_reference_bytes(hmr_gpu_enc *enc);
+/* 12c. Overlapping engines on one GPU.  The reference's engine k + 1 follows engine k's frame at the distance of the search window and the filter lag, CTU row by CTU row
+ * (hmr_encoder_lib.c:2393-2403 the lag arithmetic, :2440-2445 the per-CTU SEM_POST of synchro_signal[1], :3154-3211 the frame hand-out).  hmr_gpu_enc_encode_chain encodes
+ * the frames slots[0 .. n - 1] (n <= num_enc_engines) of ONE sequence on its engine objects encs[0 .. n - 1] (in coding order; prev = the object that encoded the frame
+ * before, NULL at the sequence start) in one launch of the CTU kernel: frame j predicts from the final picture of frame j - 1 where it lies (no copy) and from its phase
+ * planes, which the same launch produces CTU by CTU; a wavefront step of frame j starts when the part of that picture its vectors can reach is ready.  Same streams as frame
+ * by frame (the engine turnstile's interleaving, oracle/ref_ctudump.c).  Returns HMR_GPU_ERR_ARG when two frames of the chain both detect a scene change (sequentially the
+ * first switches the detection off for the second): repeat those frames one by one. */
+int hmr_gpu_enc_encode_chain(hmr_gpu_enc **encs, int n, hmr_gpu_enc *prev, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes);
 int hmr_gpu_enc_export_references8(hmr_gpu_enc **encs, int n, uint8_t *dev_rows, long pitch, void *states);
 int hmr_gpu_enc_import_references8(hmr_gpu_enc **encs, int n, const uint8_t *dev_rows, long pitch, const void *states);
 

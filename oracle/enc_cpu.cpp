@@ -58,7 +58,7 @@ struct Cpu {
 	std::vector<double> sao_lambda;
 	std::vector<uint16_t> rc_need;   // rate control: CTUs of each row coded when a wavefront step (sched 2) / a CTU (raster order) starts
 	int post_errors[2] = {0, 0};
-	PostPic post;
+	PostPic post = {};
 	PostScratch *scratch = nullptr;
 	std::vector<uint8_t> records;
 	int cur = 0;        // picture under reconstruction: pic[cur], reference: pic[cur ^ 1]
@@ -128,6 +128,7 @@ void post_begin_frame(Cpu &c)
 	P.units_stride = us;
 	P.mvx = c.u_mvx.data(); P.mvy = c.u_mvy.data(); P.ref = c.u_ref.data(); P.uqp = c.u_qp.data(); P.flags = c.u_flags.data();
 	P.rows = c.rows.data(); P.ent = c.ent.data(); P.bs = c.bs.data(); P.row_cap = row_cap; P.cumbits = c.cumbits.data();
+	P.planes[0] = P.planes[1] = P.planes[2] = nullptr; P.prof = nullptr;
 	P.sao_lambda = c.sao_lambda.data(); P.errors = c.post_errors; P.rc_need = c.rc_need.empty() ? nullptr : c.rc_need.data();
 }
 PostCtx post_ctx(Cpu &c)
