@@ -114,6 +114,9 @@ struct Cabac {
 	uint8_t *ctx = nullptr;          // [CTX_TOTAL]
 	const uint8_t *t_range = &kRangeLps[0][0], *t_next = kNextStateLps;      // the LPS range and transition tables (the device keeps copies in the worker's fast memory)
 	bool counter = false;
+#if defined(HENC_POST_PROFILE)
+	uint32_t nbins = 0;
+#endif
 	BitWriter bw;                    // the sub-stream being written
 
 	HENC_FI void start() { low = 0; bits_left = 23; num_buffered = 0; buffered_byte = 0xff; range = 510; }
@@ -152,8 +155,69 @@ struct Cabac {
 		}
 	}
 	HENC_FI static int mps_tab(int s) { return s < 124 ? s + 2 : s; }   // g_bc_next_state_MPS: saturates at 124 / 125; 126 / 127 stay
+#if defined(__HIP_DEVICE_COMPILE__)
+	// On the device the coder's walk is one wavefront executing group-uniform code: the context states and the two tables live in registers, spread over the
+	// lanes (context i: byte i >> 6 of lane i & 63 of ONE register; kRangeLps[s] as the four bytes of lane s; kNextStateLps[4 l .. 4 l + 3] in lane l), read with
+	// v_readlane and written by the lane that holds them - a bin is arithmetic on scalar registers instead of four dependent trips to the LDS.  load_ctx /
+	// store_ctx move the states between `ctx` (where the rest of the stage reads them) and the register.
+	uint32_t cw = 0, trw = 0, tnw = 0, my_lane = 0;
+	static_assert(CTX_TOTAL <= 192, "three context bytes per lane");
+	template <class G>
+	HENC_FI void load_ctx(const G &g)
+	{
+		my_lane = (uint32_t)g.tid;
+		cw = (uint32_t)ctx[g.tid] | (uint32_t)ctx[64 + g.tid] << 8 | (128 + g.tid < CTX_TOTAL ? (uint32_t)ctx[128 + g.tid] << 16 : 0u);
+		trw = (uint32_t)kRangeLps[g.tid][0] | (uint32_t)kRangeLps[g.tid][1] << 8 | (uint32_t)kRangeLps[g.tid][2] << 16 | (uint32_t)kRangeLps[g.tid][3] << 24;
+		const int l4 = (g.tid & 31) * 4;
+		tnw = (uint32_t)kNextStateLps[l4] | (uint32_t)kNextStateLps[l4 + 1] << 8 | (uint32_t)kNextStateLps[l4 + 2] << 16 | (uint32_t)kNextStateLps[l4 + 3] << 24;
+	}
+	template <class G>
+	HENC_FI void store_ctx(const G &g)
+	{
+		ctx[g.tid] = (uint8_t)cw;
+		ctx[64 + g.tid] = (uint8_t)(cw >> 8);
+		if (128 + g.tid < CTX_TOTAL) ctx[128 + g.tid] = (uint8_t)(cw >> 16);
+		g.sync();
+	}
+	HENC_FI void encode_bin(int ci_, uint32_t bin_)
+	{
+#if defined(HENC_POST_PROFILE)
+		nbins++;
+#endif
+		const int ci = __builtin_amdgcn_readfirstlane(ci_);
+		const uint32_t bin = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin_);
+		const int sh = (ci >> 6) * 8;
+		const uint32_t st = ((uint32_t)__builtin_amdgcn_readlane((int)cw, ci & 63) >> sh) & 255u;
+		const uint32_t lps = ((uint32_t)__builtin_amdgcn_readlane((int)trw, (int)(st >> 1)) >> (((range >> 6) & 3) * 8)) & 255u;
+		uint32_t nst;
+		range -= lps;
+		if (bin != (st & 1)) {
+			const int nb = __builtin_clz(lps) - 23;
+			low = (low + range) << nb;
+			range = lps << nb;
+			nst = ((uint32_t)__builtin_amdgcn_readlane((int)tnw, (int)(st >> 2)) >> ((st & 3) * 8)) & 255u;
+			bits_left -= nb;
+		} else {
+			nst = (uint32_t)mps_tab((int)st);
+			if (range < 256) {
+				low <<= 1;
+				range <<= 1;
+				bits_left--;
+			}
+		}
+		cw = my_lane == (uint32_t)(ci & 63) ? (cw & ~(255u << sh)) | (nst << sh) : cw;
+		if (bits_left < 12) write_out();
+	}
+#else
+	template <class G>
+	HENC_FI void load_ctx(const G &) { }
+	template <class G>
+	HENC_FI void store_ctx(const G &) { }
 	HENC_FI void encode_bin(int ci, uint32_t bin)
 	{
+#if defined(HENC_POST_PROFILE)
+		nbins++;
+#endif
 		uint8_t st = ctx[ci];
 		if (counter) {
 			frac_bits += (uint64_t)kEntropyBits[st ^ bin];
@@ -179,8 +243,10 @@ struct Cabac {
 		}
 		if (bits_left < 12) write_out();
 	}
+#endif
 	HENC_FI void encode_ep(uint32_t bin)
 	{
+		bin = uni(bin);
 		if (counter) { frac_bits += 32768; return; }
 		low <<= 1;
 		if (bin) low += range;
@@ -189,6 +255,8 @@ struct Cabac {
 	}
 	HENC_FI void encode_bins_ep(uint32_t bins, int n)
 	{
+		bins = uni(bins);
+		n = uni(n);
 		if (counter) { frac_bits += (uint64_t)32768 * n; return; }
 		while (n > 8) {
 			n -= 8;
@@ -206,6 +274,7 @@ struct Cabac {
 	}
 	HENC_FI void encode_trm(uint32_t bin)
 	{
+		bin = uni(bin);
 		if (counter) { frac_bits += (uint64_t)kEntropyBits[126 ^ bin]; return; }
 		range -= 2;
 		if (bin) {
@@ -291,18 +360,18 @@ HENC_INLINE const CtuPublic *ent_pu_top(const EntView &v, int ni, uint32_t *idx,
 HENC_INLINE bool node_inside(const EntView &v, int ni)
 {
 	const Geo &q = v.geo[ni];
-	return v.c->y + q.y + q.size <= v.seq->height && v.c->x + q.x + q.size <= v.seq->width;
+	return uni(v.c->y) + q.y + q.size <= uni(v.seq->height) && uni(v.c->x) + q.x + q.size <= uni(v.seq->width);
 }
-#define HENC_CBF(c, idx, comp, trd) ((((c)->cbf[comp][idx]) >> (trd)) & 1)
+#define HENC_CBF(c, idx, comp, trd) (((uni((c)->cbf[comp][idx])) >> (trd)) & 1)
 
 // get_intra_dir_luma_predictor :545 on the final arrays
 HENC_INLINE void ent_intra_preds(const EntView &v, int ni, int *p)
 {
 	uint32_t idx = 0;
 	const CtuPublic *l = ent_pu_left(v, ni, &idx);
-	const int ld = l ? (l->pred_mode[idx] == PM_INTRA ? l->intra_mode[0][idx] : DC_IDX) : DC_IDX;
+	const int ld = l ? (uni(l->pred_mode[idx]) == PM_INTRA ? uni(l->intra_mode[0][idx]) : DC_IDX) : DC_IDX;
 	const CtuPublic *t = ent_pu_top(v, ni, &idx, 1);
-	const int td = t ? (t->pred_mode[idx] == PM_INTRA ? t->intra_mode[0][idx] : DC_IDX) : DC_IDX;
+	const int td = t ? (uni(t->pred_mode[idx]) == PM_INTRA ? uni(t->intra_mode[0][idx]) : DC_IDX) : DC_IDX;
 	if (ld == td) {
 		if (ld > 1) { p[0] = ld; p[1] = ((ld + 29) % 32) + 2; p[2] = ((ld - 1) % 32) + 2; }
 		else { p[0] = PLANAR_IDX; p[1] = DC_IDX; p[2] = VER_IDX; }
@@ -313,6 +382,18 @@ HENC_INLINE void ent_intra_preds(const EntView &v, int ni, int *p)
 	}
 }
 
+#if defined(HENC_POST_PROFILE) && defined(__HIPCC__)
+static __device__ unsigned long long g_ent_prof[6];      // ticks in encode_residual, calls, context-coded bins, ticks of its lane-parallel gather, bypass bins, spare
+#endif
+#if defined(HENC_POST_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define ENT_PROF_T0() const unsigned long long ent_t0_ = __builtin_amdgcn_s_memtime()
+#define ENT_PROF_ADD(k, v) do { if (threadIdx.x % 64 == 0) atomicAdd(&g_ent_prof[k], (unsigned long long)(v)); } while (0)
+#define ENT_PROF_NOW() (__builtin_amdgcn_s_memtime() - ent_t0_)
+#else
+#define ENT_PROF_T0() do { } while (0)
+#define ENT_PROF_ADD(k, v) do { } while (0)
+#define ENT_PROF_NOW() 0
+#endif
 // ---- residual coding (encode_residual :1087, encode_last_significant_XY :954, get_sig_ctx_inc :1027) ---------------------------
 HENC_INLINE int sig_ctx_inc(int pattern, int scan_mode, int px, int py, int shift, int comp)
 {
@@ -365,6 +446,8 @@ template <class G>
 HENC_FI void encode_residual(const G &g, Cabac &ee, const EntView &v, EntScratch &sc, int ni, int comp)
 {
 	const Seq &S = *v.seq;
+	ENT_PROF_T0();
+	ENT_PROF_ADD(1, 1);
 	const int is_luma = comp == COMP_Y;
 	const int abs_index = v.geo[ni].abs_index;
 	const int pi = is_luma ? ni : (v.geo[ni].size_chroma > 2 ? ni : v.geo[ni].parent);
@@ -373,9 +456,9 @@ HENC_FI void encode_residual(const G &g, Cabac &ee, const EntView &v, EntScratch
 	const int shift = is_luma ? CFG_MAX_CU_SHIFT - q.depth : CFG_MAX_CU_SHIFT - 1 - q.depth;
 	const int16_t *coeff = v.coeff + (comp == 0 ? 0 : (comp == 1 ? 4096 : 5120)) + (q.abs_index << (4 - (is_luma ? 0 : 2)));
 	const CtuPublic *c = v.c;
-	const int num_part_in_pred_cu = NPART >> (c->pred_depth[abs_index] * 2);
-	const int scan_mode = find_scan_mode(c->pred_mode[q.abs_index] == PM_INTRA, is_luma, size, c->intra_mode[is_luma ? 0 : 1][q.abs_index],
-					     c->intra_mode[0][(abs_index / num_part_in_pred_cu) * num_part_in_pred_cu]);
+	const int num_part_in_pred_cu = NPART >> (uni(c->pred_depth[abs_index]) * 2);
+	const int scan_mode = find_scan_mode(uni(c->pred_mode[q.abs_index]) == PM_INTRA, is_luma, size, uni(c->intra_mode[is_luma ? 0 : 1][q.abs_index]),
+					     uni(c->intra_mode[0][(abs_index / num_part_in_pred_cu) * num_part_in_pred_cu]));
 	const int blk = size >> 2, ncoef = size * size, ncg = blk * blk;
 	// the coefficient-group scan: {0, 1, 2, 3} / {0, 2, 1, 3} for 8 x 8 (:1147-1150), the plain up-right diagonal of the 8 x 8 grid of groups for 32 x 32
 	// (g_sigLastScanCG32x32, hmr_tables.c:71-95), the 4 x 4 scan of the mode for 16 x 16
@@ -411,10 +494,11 @@ HENC_FI void encode_residual(const G &g, Cabac &ee, const EntView &v, EntScratch
 		if (m) raster_pos_last = base + 63 - __builtin_clzll(m);
 	}
 	g.sync();
+	ENT_PROF_ADD(3, ENT_PROF_NOW());
 	if (raster_pos_last < 0) return;
-	const int scan_pos_last = (int)scan_position(scan_mode, shift, raster_pos_last, sc.cg);
+	const int scan_pos_last = uni((int)scan_position(scan_mode, shift, raster_pos_last, sc.cg));
 	const int last_y = scan_pos_last >> shift, last_x = scan_pos_last - (last_y << shift);
-	const int valid = S.sign_hiding;
+	const int valid = uni(S.sign_hiding);
 	encode_last_xy(ee, last_x, last_y, shift, comp, scan_mode);
 	const int last_scan_set = raster_pos_last >> 4;
 	uint32_t c1 = 1, go_rice;
@@ -437,32 +521,43 @@ HENC_FI void encode_residual(const G &g, Cabac &ee, const EntView &v, EntScratch
 		};
 		go_rice = 0;
 		if (scan_pos_sig == raster_pos_last) {
-			const int lv = coeff[scan_pos_last];
+			const int lv = uni((int)coeff[scan_pos_last]);
 			put_abs(0, habs(lv));
 			coeff_signs = lv < 0;
 			num_non_zero = 1;
 			last_nz = first_nz = scan_pos_sig;
 			scan_pos_sig--;
 		}
-		const int cg_block_pos = sc.cg[subset];
+		const int cg_block_pos = uni((int)sc.cg[subset]);
 		const int cg_y = cg_block_pos / blk, cg_x = cg_block_pos - cg_y * blk;
 		if (subset == last_scan_set || subset == 0) sc.cg_flag[cg_block_pos] = 1;
 		else {
-			const uint32_t sig_cg = sc.cg_flag[cg_block_pos] != 0;
+			const uint32_t sig_cg = uni(sc.cg_flag[cg_block_pos]) != 0;
 			int right = 0, lower = 0;
-			if (cg_x < blk - 1) right = sc.cg_flag[cg_y * blk + cg_x + 1] != 0;
-			if (cg_y < blk - 1) lower = sc.cg_flag[(cg_y + 1) * blk + cg_x] != 0;
+			if (cg_x < blk - 1) right = uni(sc.cg_flag[cg_y * blk + cg_x + 1]) != 0;
+			if (cg_y < blk - 1) lower = uni(sc.cg_flag[(cg_y + 1) * blk + cg_x]) != 0;
 			ee.encode_bin(base_cg + (right || lower), sig_cg);
 		}
-		if (sc.cg_flag[cg_block_pos]) {
+		if (uni(sc.cg_flag[cg_block_pos])) {
 			uint32_t right = 0, lower = 0;
-			if (cg_x < blk - 1) right = sc.cg_flag[cg_y * blk + cg_x + 1] != 0;
-			if (cg_y < blk - 1) lower = sc.cg_flag[(cg_y + 1) * blk + cg_x] != 0;
+			if (cg_x < blk - 1) right = uni(sc.cg_flag[cg_y * blk + cg_x + 1]) != 0;
+			if (cg_y < blk - 1) lower = uni(sc.cg_flag[(cg_y + 1) * blk + cg_x]) != 0;
 			const int pattern = right + (lower << 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+			// the group's sixteen positions and levels by sixteen lanes at once: the serial walk below reads them from the register (two trips to the LDS per
+			// group instead of two per coefficient)
+			const uint32_t bp_lane = scan_position(scan_mode, shift, sub_pos + (g.tid & 15), sc.cg);
+			const int lv_lane = coeff[bp_lane];
+#endif
 			for (; scan_pos_sig >= sub_pos; scan_pos_sig--) {
+#if defined(__HIP_DEVICE_COMPILE__)
+				const uint32_t bp = (uint32_t)__builtin_amdgcn_readlane((int)bp_lane, scan_pos_sig - sub_pos);
+				const int lv = __builtin_amdgcn_readlane(lv_lane, scan_pos_sig - sub_pos);
+#else
 				const uint32_t bp = scan_position(scan_mode, shift, scan_pos_sig, sc.cg);
-				const uint32_t py = bp >> shift, px = bp - (py << shift);
 				const int lv = coeff[bp];
+#endif
+				const uint32_t py = bp >> shift, px = bp - (py << shift);
 				const uint32_t sig = lv != 0;
 				if (scan_pos_sig > sub_pos || subset == 0 || num_non_zero) ee.encode_bin(base_sig + sig_ctx_inc(pattern, scan_mode, px, py, shift, comp), sig);
 				if (sig) {
@@ -522,6 +617,7 @@ HENC_FI void encode_residual(const G &g, Cabac &ee, const EntView &v, EntScratch
 			}
 		}
 	}
+	ENT_PROF_ADD(0, ENT_PROF_NOW());
 }
 
 // ---- CU syntax -----------------------------------------------------------------------------------------------------------------
@@ -536,7 +632,7 @@ HENC_FI void encode_qt_cbf(Cabac &ee, int comp, int tr_depth, int cbf)
 // (get_qp_min_cu_left / _top :1432 / :1459 return NULL at the CTU boundary), so get_ref_qp :1487 is the last coded QP
 HENC_FI void encode_delta_qp(Cabac &ee, const EntView &v, const DqpState &dq, int abs_index)
 {
-	int diff_qp = (int)v.c->qp[abs_index] - dq.ref_qp;
+	int diff_qp = (int)uni(v.c->qp[abs_index]) - dq.ref_qp;
 	diff_qp = (diff_qp + 78) % 52 - 26;
 	const uint32_t a = (uint32_t)habs(diff_qp), tu = a < 5 ? a : 5;      // CU_DQP_TU_CMAX 5, CU_DQP_EG_k 0
 	// write_unary_max_simbol :358 (offset 1, max 5)
@@ -567,10 +663,10 @@ HENC_FI void encode_transform_tree(const G &g, Cabac &ee, const EntView &v, EntS
 	const CtuPublic *c = v.c;
 	const int depth = v.geo[top_ni].depth, top_abs = v.geo[top_ni].abs_index;
 	int abs_index = top_abs;
-	int is_intra = c->pred_mode[abs_index] == PM_INTRA;
+	int is_intra = uni(c->pred_mode[abs_index]) == PM_INTRA;
 	if (!is_intra) {
 		const uint32_t qtroot = HENC_CBF(c, abs_index, 0, 0) || HENC_CBF(c, abs_index, 1, 0) || HENC_CBF(c, abs_index, 2, 0);
-		if (!(c->merge[abs_index] && c->part_size_type[abs_index] == PART_2Nx2N)) ee.encode_bin(CTX_QT_ROOT_CBF, qtroot);
+		if (!(uni(c->merge[abs_index]) && uni(c->part_size_type[abs_index]) == PART_2Nx2N)) ee.encode_bin(CTX_QT_ROOT_CBF, qtroot);
 		if (!qtroot) return;
 	}
 	DepthState depth_state;
@@ -580,22 +676,22 @@ HENC_FI void encode_transform_tree(const G &g, Cabac &ee, const EntView &v, EntS
 		curr_depth = q.depth;
 		abs_index = q.abs_index;
 		const int shift = CFG_MAX_CU_SHIFT - curr_depth;
-		const int pred_depth = c->pred_depth[abs_index], tr_depth = curr_depth - pred_depth, first = tr_depth == 0;
-		const int tr_idx = c->tr_idx[abs_index];
-		is_intra = c->pred_mode[abs_index] == PM_INTRA;
-		const int part = c->part_size_type[abs_index];
+		const int pred_depth = uni(c->pred_depth[abs_index]), tr_depth = curr_depth - pred_depth, first = tr_depth == 0;
+		const int tr_idx = uni(c->tr_idx[abs_index]);
+		is_intra = uni(c->pred_mode[abs_index]) == PM_INTRA;
+		const int part = uni(c->part_size_type[abs_index]);
 		const int split_flag = (tr_idx + pred_depth) > curr_depth;
 		const int log2_tr = CFG_MAX_CU_SHIFT - curr_depth, log2_cu = CFG_MAX_CU_SHIFT - pred_depth;
-		const int intra_split = is_intra && part == PART_NxN, inter_split = !is_intra && S.max_inter_tr_depth == 1 && part != PART_2Nx2N;
-		const int max_tr = is_intra ? S.max_intra_tr_depth : S.max_inter_tr_depth;
+		const int intra_split = is_intra && part == PART_NxN, inter_split = !is_intra && uni(S.max_inter_tr_depth) == 1 && part != PART_2Nx2N;
+		const int max_tr = is_intra ? uni(S.max_intra_tr_depth) : uni(S.max_inter_tr_depth);
 		int tu_min_in_cu;
-		if (log2_cu < S.min_tu_size_shift + max_tr - 1 + inter_split + intra_split) tu_min_in_cu = S.min_tu_size_shift;
+		if (log2_cu < uni(S.min_tu_size_shift) + max_tr - 1 + inter_split + intra_split) tu_min_in_cu = uni(S.min_tu_size_shift);
 		else {
 			tu_min_in_cu = log2_cu - (max_tr - 1 + inter_split + intra_split);
-			if (tu_min_in_cu > S.max_tu_size_shift) tu_min_in_cu = S.max_tu_size_shift;
+			if (tu_min_in_cu > uni(S.max_tu_size_shift)) tu_min_in_cu = uni(S.max_tu_size_shift);
 		}
-		if (!(is_intra && part == PART_NxN && curr_depth == pred_depth) && !(!is_intra && part != PART_2Nx2N && curr_depth == pred_depth && S.max_inter_tr_depth == 1) &&
-		    !(log2_tr > S.max_tu_size_shift) && !(log2_tr == S.min_tu_size_shift) && !(log2_tr == tu_min_in_cu))
+		if (!(is_intra && part == PART_NxN && curr_depth == pred_depth) && !(!is_intra && part != PART_2Nx2N && curr_depth == pred_depth && uni(S.max_inter_tr_depth) == 1) &&
+		    !(log2_tr > uni(S.max_tu_size_shift)) && !(log2_tr == uni(S.min_tu_size_shift)) && !(log2_tr == tu_min_in_cu))
 			ee.encode_bin(CTX_TRANS_SUBDIV + 5 - shift, split_flag);
 		if (first || shift > 2) {
 			if (first || HENC_CBF(c, abs_index, 1, tr_depth - 1)) encode_qt_cbf(ee, 1, tr_depth, HENC_CBF(c, abs_index, 1, tr_depth));
@@ -607,7 +703,7 @@ HENC_FI void encode_transform_tree(const G &g, Cabac &ee, const EntView &v, EntS
 			curr_depth++;
 		} else {
 			const uint32_t cbf_y = HENC_CBF(c, abs_index, 0, tr_depth), cbf_u = HENC_CBF(c, abs_index, 1, tr_depth), cbf_v = HENC_CBF(c, abs_index, 2, tr_depth);
-			if (c->pred_mode[abs_index] == PM_INTRA || tr_depth != 0 || cbf_u || cbf_v) encode_qt_cbf(ee, 0, tr_depth, cbf_y);
+			if (uni(c->pred_mode[abs_index]) == PM_INTRA || tr_depth != 0 || cbf_u || cbf_v) encode_qt_cbf(ee, 0, tr_depth, cbf_y);
 			if ((cbf_y || cbf_u || cbf_v) && dq.enabled && dq.write_qp) {      // the delta QP: once per quantisation group, with the first coded TU (:1660-1674)
 				encode_delta_qp(ee, v, dq, top_abs);
 				dq.write_qp = 0;
@@ -632,7 +728,7 @@ HENC_FI void encode_transform_tree(const G &g, Cabac &ee, const EntView &v, EntS
 
 HENC_FI void encode_mvd(Cabac &ee, const CtuPublic *c, int idx)
 {
-	const int h = c->mv_diff[idx].x, ver = c->mv_diff[idx].y;
+	const int h = uni(c->mv_diff[idx].x), ver = uni(c->mv_diff[idx].y);
 	const int h0 = h != 0, v0 = ver != 0, ha = habs(h), va = habs(ver);
 	ee.encode_bin(CTX_MVD, h0);
 	ee.encode_bin(CTX_MVD, v0);
@@ -658,16 +754,16 @@ HENC_FI void encode_end_of_cu(Cabac &ee, const EntView &v, int ni)
 	const Seq &S = *v.seq;
 	const Geo &q = v.geo[ni];
 	const uint32_t cu_addr = (uint32_t)v.n * NPART + q.abs_index;
-	const int width = S.width, height = S.height;
+	const int width = uni(S.width), height = uni(S.height);
 	uint32_t real_end;
 	if (width % 64 || height % 64) {
 		int wr = (width % 64) >> 2, hr = (height % 64) >> 2;
 		if (hr == 0) hr = 15;
 		else if (wr) hr -= 1;
 		const int aux = hr * 16 + wr;
-		real_end = (uint32_t)S.nctu * NPART - NPART + raster2abs(aux - 1) + 1;
-	} else real_end = (uint32_t)S.nctu * NPART;
-	const int px = v.c->x + q.x, py = v.c->y + q.y;
+		real_end = (uint32_t)uni(S.nctu) * NPART - NPART + raster2abs(aux - 1) + 1;
+	} else real_end = (uint32_t)uni(S.nctu) * NPART;
+	const int px = uni(v.c->x) + q.x, py = uni(v.c->y) + q.y;
 	const int boundary = ((px + q.size) % 64 == 0 || (px + q.size) == width) && ((py + q.size) % 64 == 0 || (py + q.size) == height);
 	const int terminate = cu_addr + q.num_part == real_end;
 	if (boundary && !terminate) ee.encode_trm(0);
@@ -680,19 +776,19 @@ HENC_FI void encode_coding_unit(const G &g, Cabac &ee, const EntView &v, EntScra
 	const Seq &S = *v.seq;
 	const CtuPublic *c = v.c;
 	const Geo &q = v.geo[ni];
-	const int abs_index = q.abs_index, is_intra = c->pred_mode[abs_index] == PM_INTRA, part = c->part_size_type[abs_index];
-	const int p_slice = v.f->slice_type != SLICE_I;
+	const int abs_index = q.abs_index, is_intra = uni(c->pred_mode[abs_index]) == PM_INTRA, part = uni(c->part_size_type[abs_index]);
+	const int p_slice = uni(v.f->slice_type) != SLICE_I;
 	uint32_t idx = 0;
 	if (p_slice) {
 		const CtuPublic *l = ent_pu_left(v, ni, &idx);
-		int ctx = l ? (l->skipped[idx] ? 1 : 0) : 0;
+		int ctx = l ? (uni(l->skipped[idx]) ? 1 : 0) : 0;
 		const CtuPublic *t = ent_pu_top(v, ni, &idx, 0);
-		ctx += t ? (t->skipped[idx] ? 1 : 0) : 0;
-		ee.encode_bin(CTX_SKIP_FLAG + ctx, c->skipped[abs_index]);
+		ctx += t ? (uni(t->skipped[idx]) ? 1 : 0) : 0;
+		ee.encode_bin(CTX_SKIP_FLAG + ctx, uni(c->skipped[abs_index]));
 	}
 	auto merge_index = [&](int a) {
 		// encode_merge_index :613 with two candidates: one context-coded bin
-		const uint32_t unary = c->merge_idx[a];
+		const uint32_t unary = uni(c->merge_idx[a]);
 		for (int ui = 0; ui < CFG_NUM_MERGE_CAND - 1; ui++) {
 			const uint32_t sym = ui == (int)unary ? 0 : 1;
 			if (ui == 0) ee.encode_bin(CTX_MERGE_IDX, sym);
@@ -700,14 +796,14 @@ HENC_FI void encode_coding_unit(const G &g, Cabac &ee, const EntView &v, EntScra
 			if (sym == 0) break;
 		}
 	};
-	if (c->skipped[abs_index]) {
+	if (uni(c->skipped[abs_index])) {
 		merge_index(abs_index);
 		encode_end_of_cu(ee, v, ni);
 		return;
 	}
-	if (p_slice) ee.encode_bin(CTX_PRED_MODE, c->pred_mode[abs_index]);
+	if (p_slice) ee.encode_bin(CTX_PRED_MODE, uni(c->pred_mode[abs_index]));
 	// encode_part_size :436
-	const int min_cu_depth = S.max_cu_depth - S.mincu_mintr_shift_diff;
+	const int min_cu_depth = uni(S.max_cu_depth) - uni(S.mincu_mintr_shift_diff);
 	if (is_intra) {
 		if (q.depth == min_cu_depth) ee.encode_bin(CTX_PART_SIZE, part == PART_2Nx2N ? 1 : 0);
 	} else if (part == PART_2Nx2N) ee.encode_bin(CTX_PART_SIZE, 1);
@@ -724,7 +820,7 @@ HENC_FI void encode_coding_unit(const G &g, Cabac &ee, const EntView &v, EntScra
 		int dir[4], preds[4][3], pred_idx[4] = {-1, -1, -1, -1};
 		for (int j = 0; j < part_num; j++) {
 			const int pn = part_num == 4 ? q.child[j] : ni;
-			dir[j] = c->intra_mode[0][v.geo[pn].abs_index];
+			dir[j] = uni(c->intra_mode[0][v.geo[pn].abs_index]);
 			ent_intra_preds(v, pn, preds[j]);
 			for (int i = 0; i < 3; i++)
 				if (dir[j] == preds[j][i]) pred_idx[j] = i;
@@ -744,11 +840,11 @@ HENC_FI void encode_coding_unit(const G &g, Cabac &ee, const EntView &v, EntScra
 			}
 		}
 		// encode_intra_dir_chroma :907
-		uint32_t chroma = c->intra_mode[1][abs_index];
+		uint32_t chroma = uni(c->intra_mode[1][abs_index]);
 		if (chroma == DM_CHROMA_IDX) ee.encode_bin(CTX_CHROMA_PRED, 0);
 		else {
 			int list[5];
-			const int luma = c->intra_mode[0][abs_index];
+			const int luma = uni(c->intra_mode[0][abs_index]);
 			list[0] = PLANAR_IDX; list[1] = VER_IDX; list[2] = HOR_IDX; list[3] = DC_IDX; list[4] = DM_CHROMA_IDX;
 			for (int i = 0; i < 4; i++)
 				if (luma == list[i]) { list[i] = 34; break; }
@@ -761,13 +857,13 @@ HENC_FI void encode_coding_unit(const G &g, Cabac &ee, const EntView &v, EntScra
 		// encode_inter_motion_info :777, P slice with one reference picture
 		const int num_pu = part == PART_2Nx2N ? 1 : (part == PART_NxN ? 4 : 2);
 		const uint32_t pu_off_part = part == PART_2Nx2N ? 0u : (part == 1 ? 8u : (part == 2 ? 4u : (part == 3 ? 4u : (part == 4 ? 2u : (part == 5 ? 10u : (part == 6 ? 1u : 5u))))));   // {0, 8, 4, 4, 2, 10, 1, 5}
-		const uint32_t pu_offset = (pu_off_part << ((S.max_cu_depth - c->pred_depth[abs_index]) << 1)) >> 4;
+		const uint32_t pu_offset = (pu_off_part << ((uni(S.max_cu_depth) - uni(c->pred_depth[abs_index])) << 1)) >> 4;
 		for (int p = 0, sub = abs_index; p < num_pu; p++, sub += pu_offset) {
-			ee.encode_bin(CTX_MERGE_FLAG, c->merge[sub]);
-			if (c->merge[sub]) merge_index(sub);
-			else if (c->inter_mode[sub] & 1) {
+			ee.encode_bin(CTX_MERGE_FLAG, uni(c->merge[sub]));
+			if (uni(c->merge[sub])) merge_index(sub);
+			else if (uni(c->inter_mode[sub]) & 1) {
 				encode_mvd(ee, c, sub);
-				ee.encode_bin(CTX_MVP_IDX, c->mv_diff_ref_idx[sub] ? 1 : 0);
+				ee.encode_bin(CTX_MVP_IDX, uni(c->mv_diff_ref_idx[sub]) ? 1 : 0);
 			}
 		}
 	}
@@ -784,26 +880,26 @@ HENC_FI void encode_ctu_syntax(const G &g, Cabac &ee, const EntView &v, EntScrat
 	const Seq &S = *v.seq;
 	DepthState depth_state;
 	int curr = 0, curr_depth = 0;
-	const int min_cu_depth = S.max_cu_depth - S.mincu_mintr_shift_diff;
-	DqpState dq = {S.bitrate_mode != 0, 1, 0, 0};
+	const int min_cu_depth = uni(S.max_cu_depth) - uni(S.mincu_mintr_shift_diff);
+	DqpState dq = {uni(S.bitrate_mode) != 0, 1, 0, 0};
 	while (curr_depth != 0 || depth_state.get(curr_depth) != 1) {
 		const Geo &q = v.geo[curr];
 		const bool inside = node_inside(v, curr);
 		if (inside && q.depth != min_cu_depth) {
 			// encode_split_flag :391
 			uint32_t idx = 0;
-			const int split = v.c->pred_depth[q.abs_index] > q.depth;
+			const int split = uni(v.c->pred_depth[q.abs_index]) > q.depth;
 			const CtuPublic *l = ent_pu_left(v, curr, &idx);
-			int ctx = l ? (l->pred_depth[idx] > q.depth ? 1 : 0) : 0;
+			int ctx = l ? (uni(l->pred_depth[idx]) > q.depth ? 1 : 0) : 0;
 			const CtuPublic *t = ent_pu_top(v, curr, &idx, 0);
-			ctx += t ? (t->pred_depth[idx] > q.depth ? 1 : 0) : 0;
+			ctx += t ? (uni(t->pred_depth[idx]) > q.depth ? 1 : 0) : 0;
 			ee.encode_bin(CTX_SPLIT_FLAG + ctx, split);
 		}
 		if (dq.enabled && q.depth == 0) {      // a new quantisation group (diff_cu_qp_delta_depth = 0): get_ref_qp :1487 = the last coded QP
-			dq.ref_qp = v.prev_last_qp >= 0 ? v.prev_last_qp : v.f->qp;
+			dq.ref_qp = v.prev_last_qp >= 0 ? v.prev_last_qp : uni(v.f->qp);
 			dq.found_coded = 0;
 		}
-		const int pred_depth = v.c->pred_depth[q.abs_index];
+		const int pred_depth = uni(v.c->pred_depth[q.abs_index]);
 		depth_state.inc(curr_depth);
 		if (curr_depth < pred_depth) {
 			if (dq.enabled && depth_state.get(curr_depth) == 1 && curr_depth == 0) dq.write_qp = 1;
@@ -812,7 +908,7 @@ HENC_FI void encode_ctu_syntax(const G &g, Cabac &ee, const EntView &v, EntScrat
 		} else {
 			if (inside) {
 				if (dq.enabled && !dq.found_coded) {
-					if (v.c->cbf[0][q.abs_index] || v.c->cbf[1][q.abs_index] || v.c->cbf[2][q.abs_index]) {
+					if (uni(v.c->cbf[0][q.abs_index]) || uni(v.c->cbf[1][q.abs_index]) || uni(v.c->cbf[2][q.abs_index])) {
 						dq.found_coded = 1;
 						if (depth_state.get(curr_depth) > 1) dq.write_qp = 1;
 					} else {

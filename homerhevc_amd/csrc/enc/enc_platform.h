@@ -80,6 +80,19 @@ struct WaveGrp {
 // 64-bit address arithmetic, and a wait on every outstanding store before any load result is used.  FastPtr says where they point (a cast to the LDS address
 // space and back, which address-space inference propagates into everything derived from the pointer), so these accesses become ds_* instructions.
 // On the CPU (checker build, host pass) it is an ordinary pointer.
+// A value every lane of the group holds (it was read at a group-uniform address, or computed from such values): on the device this says so - the value moves to a
+// scalar register, what is computed from it is scalar arithmetic and branches on it are scalar branches instead of execution-mask regions.  The compiler cannot
+// see it by itself where the address is a generic pointer (a flat load is a source of divergence for it).
+template <class T>
+HENC_INLINE T uni(T x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	static_assert(sizeof(T) <= 4, "one scalar register");
+	return (T)__builtin_amdgcn_readfirstlane((int)x);
+#else
+	return x;
+#endif
+}
 template <class T>
 HENC_INLINE T *in_fast_memory(T *p)
 {

@@ -576,12 +576,6 @@ HENC_HDX void post_task_p(const G &g, const PostCtx &x, PostScratch &sc, int r, 
 	Cabac ee;
 	BitWriter &bw = ee.bw;
 	ee.ctx = sc.ctx;
-#if defined(__HIP_DEVICE_COMPILE__)
-	for (int i = g.tid; i < 256; i += g.n) sc.t_range[i] = (&kRangeLps[0][0])[i];
-	for (int i = g.tid; i < 128; i += g.n) sc.t_next[i] = kNextStateLps[i];
-	ee.t_range = sc.t_range;
-	ee.t_next = sc.t_next;
-#endif
 	bw.attach(P.bs + (size_t)row * P.row_cap, P.row_cap);
 	// wfpp_encode_select_bitstream :2299
 	const bool fresh = n == 0 || (S.wpp && c == 0);
@@ -592,8 +586,8 @@ HENC_HDX void post_task_p(const G &g, const PostCtx &x, PostScratch &sc, int r, 
 	}
 	if (fresh) { ee.start(); ee.reset_bits(); }
 	else {
-		ee.low = re.low; ee.range = re.range; ee.buffered_byte = re.buffered_byte; ee.num_buffered = re.num_buffered; ee.bits_left = re.bits_left;
-		bw.bytecnt = re.bytecnt;
+		ee.low = uni(re.low); ee.range = uni(re.range); ee.buffered_byte = uni(re.buffered_byte); ee.num_buffered = uni(re.num_buffered); ee.bits_left = uni(re.bits_left);
+		bw.bytecnt = uni(re.bytecnt);
 	}
 	g.sync();
 	PPF_LAP(P, PPF_P_LOAD);
@@ -613,9 +607,10 @@ HENC_HDX void post_task_p(const G &g, const PostCtx &x, PostScratch &sc, int r, 
 		g.sync();
 		// the neighbours' decisions read the parameters from the record
 		lin_copy_words(g, (const uint32_t *)sc.c.sao_recon, (uint32_t *)home->sao_recon, (int)(2 * 3 * sizeof(SaoOffset) / 4));
+		ee.load_ctx(g);
 		code_sao_blk_param(ee, sc.c.sao_coded, c > 0, r > 0);
 		PPF_LAP(P, PPF_P_DECIDE);
-	}
+	} else ee.load_ctx(g);
 	EntView v;
 	v.seq = x.seq; v.f = x.f; v.T = x.T; v.geo = x.geo;
 	v.c = &sc.c;
@@ -623,8 +618,9 @@ HENC_HDX void post_task_p(const G &g, const PostCtx &x, PostScratch &sc, int r, 
 	v.top = r > 0 ? home - W : nullptr;
 	v.coeff = sc.coef;
 	v.n = n;
-	v.prev_last_qp = (n > 0 && !(S.wpp && c == 0)) ? (int)(home - 1)->qp[(home - 1)->last_valid_partition] : -1;
+	v.prev_last_qp = (n > 0 && !(S.wpp && c == 0)) ? uni((int)(home - 1)->qp[(home - 1)->last_valid_partition]) : -1;
 	encode_ctu_syntax(g, ee, v, sc.ent);
+	ee.store_ctx(g);
 	const uint32_t bits = (uint32_t)(bw.bitcount() - bits_before);
 	if (S.bitrate_mode != 0) {      // the QPs the delta-QP rules rewrote (ee_encode_ctu :2091-2104): the next CTU's predictor reads them
 		g.sync();
@@ -645,6 +641,9 @@ HENC_HDX void post_task_p(const G &g, const PostCtx &x, PostScratch &sc, int r, 
 		if (bw.overflow) P.errors[0] = 1;
 	}
 	PPF_LAP(P, PPF_P_SYNTAX);
+#if defined(HENC_POST_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+	ENT_PROF_ADD(2, ee.nbins);
+#endif
 	// the filter output of this CTU: SAO offsets applied to the deblocked samples, margins of border CTUs (without SAO: task F)
 	if (S.sao) post_sao_apply_pad(g, S, P, sc, sc.c.sao_recon, c, r);
 	g.sync();

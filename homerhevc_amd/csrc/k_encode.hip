@@ -1549,6 +1549,9 @@ extern "C" int hmr_gpu_enc_post_profile(hmr_gpu_enc *e, unsigned long long *out)
 {
 	if (!e || !out) return HMR_GPU_ERR_ARG;
 	HIP_TRY(hipMemcpy(out, e->d_post_err + 4, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+#if defined(HENC_POST_PROFILE)
+	HIP_TRY(hipMemcpyFromSymbol(out + 10, HIP_SYMBOL(g_ent_prof), 6 * sizeof(unsigned long long)));
+#endif
 	return HMR_GPU_OK;
 }
 

@@ -134,6 +134,7 @@ class GpuEngines:
     """adapter over libhomer_gpu.so (no fallback: without the HIP library there is nothing to run)"""
 
     def __init__(self, cfg_of, device, pipelined=False, host_exchange=False):
+        torch.cuda.init()          # torch's HIP runtime first: it ships its own libamdhip64 and finds no GPU once the system one has been initialised by the library
         self.lib = C.CDLL(os.path.join(ROOT, "homerhevc_amd", "libhomer_gpu.so"))
         self.cfg_of, self.device, self.pipelined, self.host_exchange = cfg_of, device, pipelined, host_exchange
         self.scratch = {}

@@ -30,13 +30,14 @@ CASES = {
     "cfg2-416x240-encode": (416, 240, 40, {"wpp": 4}),
     # bench.py --gpus N: the same 1080p encode with one engine per GPU (num_enc_engines = N), the reference pinned by the engine turnstile
     "cfg2-1080p-encode-engines2": (1920, 1080, 40, {"wpp": 17, "engines": 2}),
+    "cfg2-1080p-encode-engines3": (1920, 1080, 40, {"wpp": 17, "engines": 3}),
     "cfg2-1080p-encode-engines4": (1920, 1080, 40, {"wpp": 17, "engines": 4}),
     "cfg2-1080p-encode-engines8": (1920, 1080, 40, {"wpp": 17, "engines": 8}),
     "cfg2-416x240-encode-engines2": (416, 240, 40, {"wpp": 4, "engines": 2}),
     # BASELINE.json configs[3]: 2160p with one engine per GPU
     "cfg2-2160p-encode-engines2": (3840, 2160, 10, {"wpp": 32, "engines": 2}),
     "cfg2-2160p-encode-engines4": (3840, 2160, 10, {"wpp": 32, "engines": 4}),
-    "cfg2-2160p-encode-engines8": (3840, 2160, 10, {"wpp": 32, "engines": 8}),
+    "cfg2-2160p-encode-engines8": (3840, 2160, 34, {"wpp": 32, "engines": 8}),
     # BASELINE.json configs[2]: 2160p IPPP, CBR 20000 kbps, performance_mode 1
     "cfg3-2160p-cbr": (3840, 2160, 10, {"wpp": 32, "bitrate_mode": 1, "bitrate": 20000, "perf": 1}),
     "cfg3-1080p-cbr": (1920, 1080, 24, {"wpp": 17, "bitrate_mode": 1, "bitrate": 5000, "perf": 1}),

@@ -40,5 +40,10 @@ def load_gpu():
     if "gpu" not in _cache:
         if not os.path.exists(GPU_SO):
             raise RuntimeError("homerhevc_amd/libhomer_gpu.so missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        # a process that also uses torch on the GPU (tests/test_gpu_engines.py, bench.py) has to let torch bring up its HIP runtime FIRST: torch ships its own
+        # libamdhip64, and once this library has initialised the system one torch finds "No HIP GPUs" (INTEGRATION.md "torch in the same process")
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
         _cache["gpu"] = ctypes.CDLL(GPU_SO)
     return _cache["gpu"]

@@ -57,6 +57,7 @@ def main():
         names = ["D task", "P load", "P stats", "P candidates", "P decide+sao syntax", "P ctu syntax", "P apply+pad", "scan", "D count", "P count"]
         if any(prof):
             nd, npp = max(prof[8], 1), max(prof[9], 1)
+            print(f"entropy coder: encode_residual {prof[10] / max(prof[11], 1):.0f} ticks per call ({prof[13] / max(prof[11], 1):.0f} of them its gather), {prof[11] / npp:.1f} calls and {prof[12] / npp:.0f} context-coded bins per CTU; residual share of the CTU syntax {prof[10] / max(prof[5], 1):.2f}")
             print("post-decision stage (100 MHz ticks -> us per task): " + ", ".join(f"{names[k]} {prof[k] / 100.0 / (nd if k == 0 else npp):.1f}" for k in range(8)) + f"; {prof[8]} D, {prof[9]} P tasks")
     print(f"{a.frames} frames in {dt:.2f} s = {a.frames / dt:.2f} fps; stream md5 {md5.hexdigest()}")
 
