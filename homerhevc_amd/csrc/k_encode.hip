@@ -60,6 +60,9 @@ struct EncDev {
 	int *counters;                // [0] CTUs found wrong by the last check, [1] CTU encodes of the frame, [2] the CTU at which a scene change is detected (-1: none)
 	int threads;                  // lockstep schedule: wfpp_num_threads (row r is encoded by thread r % threads)
 	int dep, dep_full;            // overlapping frames of a sequence (hmr_gpu_enc_encode_chain): the picture of this launch whose final picture this one predicts from, or -1
+	int after, pad_after_;        // ... the picture of this launch that the same engine encodes before this one (it has to be finished: the engine's persistent state), or -1
+	FrameCtx *next_frame;         // ... the frame parameters of the picture the same engine encodes next in this launch (it starts from this picture's average distortion), or nullptr
+	double *fin;                  // [0] the picture's distortion total (frame_acc_dist, enc_host.h), written by the worker that completes the picture's last task
 	RcFrame *rc_dyn;              // rate control: the frame's parameters after a scene change moved them (hmr_rc_change_pic_mode), [0]; valid once counters[2] >= 0
 	PostPic post;                 // the post-decision stage of the picture (enc_post.h): deblocking, SAO, entropy coding, padding as tasks of the CTU kernel
 };
@@ -442,9 +445,38 @@ __device__ __attribute__((noinline)) int pool_post_drain(const EncDev &d, const 
 	if (ran) {
 		if (g.tid == 0) lw->slow = my_slow;      // (the scratch overlays the worker's Work)
 		g.sync();
-		// whoever completes the picture's last task says so - exactly one worker sees its own completion of it
-		if (post_finished(*lseq, d.post) && g.tid == 0) {
-			if (atomicCAS(&d.post.errors[1], 0, 1) == 0) atomicAdd(finished, 1);
+		// whoever completes the picture's last task says so - exactly one worker wins the claim (errors[1]: 0 -> 2) - after the picture's last duty: its distortion
+		// total (hmr_encoder_lib.c:3217-3228: every WPP thread adds up its rows' CTUs in a uint32 that may wrap, the engine adds the threads in a double), from
+		// which the engine's next picture in this launch takes its average distortion (end_frame, enc_host.h - the same arithmetic)
+		if (post_finished(*lseq, d.post)) {
+			int won = 0;
+			if (g.tid == 0) won = atomicCAS(&d.post.errors[1], 0, 2) == 0;
+			if (__builtin_amdgcn_readfirstlane(won)) {
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+				const int W = lseq->wctu, H = lseq->hctu, T = d.threads < 1 ? 1 : d.threads;
+				int64_t part = 0;
+				for (int t = g.tid; t < T && t < H; t += 64) {
+					uint32_t acc = 0;
+					for (int r = t; r < H; r += T)
+						for (int c = 0; c < W; c++) acc += d.ctus[r * W + c].distortion;
+					part += acc;
+				}
+				const double total = (double)g.sum64(part);
+				if (g.tid == 0) {
+					d.fin[0] = total;
+					if (d.next_frame) {
+						double a = total;
+						a /= lseq->nctu * NPART;
+						a = a < .1 ? .1 : a;
+						if (lframe->slice_type == SLICE_I) a *= 1.5;
+						else if (__hip_atomic_load(&d.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) a *= 1.375;
+						d.next_frame->avg_dist = a;      // (an I frame inside the sequence would hand on the value before it: such chains are refused by the host)
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+					post_st_release(&d.post.errors[1], 1);
+					atomicAdd(finished, 1);
+				}
+			}
 		}
 	}
 	return ran;
@@ -530,6 +562,8 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(2))
 						if (g.any(miss)) ready = false;
 					}
 				}
+				// the engine's previous picture of this launch is finished (the picture continues in the engine's persistent records)
+				if (ready && d0.after >= 0) ready = post_ld(&devs[d0.after].post.errors[1]) == 1;
 				if (ready) break;
 				m &= m - 1;
 			}
@@ -953,6 +987,7 @@ struct hmr_gpu_enc {
 	CtuInfo *d_ctus_eng[MAX_ENGINES] = {nullptr};
 	uint8_t *d_rowstate_eng[MAX_ENGINES] = {nullptr};
 	int *d_seen_eng[MAX_ENGINES] = {nullptr};
+	hmr_gpu_enc *twin_of = nullptr;   // hmr_gpu_enc_create_engine_twin: the object whose persistent engine state this one shares
 	int local_engines = 1, engine_index = -1;     // engine_index >= 0: this object is ONE engine of st.engines (the others live elsewhere, hmr_gpu_enc_create_engine)
 	int cur, lockstep;
 	float last_ms, last_total_ms;
@@ -1166,6 +1201,8 @@ int set_frame(hmr_gpu_enc *e, int slot, int image_type, double avg_dist, bool up
 	e->d.post.sao_lambda = e->d_sao_tab + (e->f.slice_type == SLICE_I ? 104 : 0);
 	e->d.dep = -1;
 	e->d.dep_full = 0;
+	e->d.after = -1;
+	e->d.next_frame = nullptr;
 	e->d.post.planes[0] = e->d.post.planes[1] = e->d.post.planes[2] = nullptr;
 	if (e->f.slice_type != SLICE_I && !chain) {
 		if (!e->planes.y) {
@@ -1325,7 +1362,7 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 		DEV_ALLOC(e->d_bs, (size_t)e->row_cap * s.hctu);
 		DEV_ALLOC(e->d_cumbits, s.nctu);
 		DEV_ALLOC(e->d_sao_tab, 2 * 52 * 2);
-		DEV_ALLOC(e->d_post_err, 4 + 2 * 16);
+		DEV_ALLOC(e->d_post_err, 4 + 2 * 16 + 4);
 		double tab[2][104];
 		sao_lambda_table(s, SLICE_P, tab[0]);
 		sao_lambda_table(s, SLICE_I, tab[1]);
@@ -1381,6 +1418,7 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 		P.rows = e->d_rows; P.ent = e->d_ent; P.bs = e->d_bs; P.row_cap = e->row_cap; P.cumbits = e->d_cumbits;
 		P.sao_lambda = e->d_sao_tab; P.errors = e->d_post_err; P.rc_need = e->d_rc_need;
 		P.prof = (unsigned long long *)(e->d_post_err + 4);      // (profiling build)
+		e->d.fin = (double *)(e->d_post_err + 4 + 2 * 16);
 	}
 	e->cur = 0;
 	e->lockstep = e->cfg.wfpp_num_threads > 1;
@@ -1398,6 +1436,26 @@ extern "C" int hmr_gpu_enc_create_engine(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg
 {
 	if (engine_index < 0) return HMR_GPU_ERR_ARG;
 	return enc_create(ctx, cfg, engine_index, out);
+}
+// A second object for the SAME engine: it shares the engine's persistent state (the CTU records and the WPP threads' mode buffers, which a frame continues from the
+// engine's previous frame) with `of` and has pictures, filter state and sub-stream buffers of its own - so that hmr_gpu_enc_encode_chain can hold the engine's next frame
+// in the same launch (it starts when the one before it is finished, as the reference's engine does).  Destroy the twins before the object they were made from.
+extern "C" int hmr_gpu_enc_create_engine_twin(hmr_gpu_ctx *ctx, hmr_gpu_enc *of, hmr_gpu_enc **out)
+{
+	if (!ctx || !of || !out || of->engine_index < 0 || of->twin_of) return HMR_GPU_ERR_ARG;
+	hmr_gpu_enc *t = nullptr;
+	const int rc = enc_create(ctx, (const hmr_gpu_enc_cfg *)&of->cfg, of->engine_index, &t);
+	if (rc) return rc;
+	(void)hipFree(t->d_ctus_eng[0]);
+	(void)hipFree(t->d_rowstate_eng[0]);
+	(void)hipFree(t->d_seen_eng[0]);
+	t->d_ctus_eng[0] = of->d_ctus_eng[0];
+	t->d_rowstate_eng[0] = of->d_rowstate_eng[0];
+	t->d_seen_eng[0] = of->d_seen_eng[0];
+	t->d.ctus = t->d_ctus_eng[0]; t->d.rowstate = t->d_rowstate_eng[0]; t->d.thread_seen = t->d_seen_eng[0];
+	t->twin_of = of;
+	*out = t;
+	return HMR_GPU_OK;
 }
 extern "C" int hmr_gpu_enc_state_bytes(void) { return (int)sizeof(HostState); }
 extern "C" long hmr_gpu_enc_reference_elems(hmr_gpu_enc *e, int comp) { return e && comp >= 0 && comp < 3 ? (long)e->pic_elems[comp] : -1; }
@@ -1498,6 +1556,7 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	for (PlaneSet *ps : {&e->chain_planes, &e->chain_planes2})
 		if (ps->y) { (void)hipFree(ps->y); (void)hipFree(ps->c[0]); (void)hipFree(ps->c[1]); }
 	e->d.ctus = e->d_ctus_eng[0]; e->d.rowstate = e->d_rowstate_eng[0]; e->d.thread_seen = e->d_seen_eng[0];
+	if (e->twin_of) e->d.ctus = nullptr, e->d.rowstate = nullptr, e->d.thread_seen = nullptr;      // (they belong to the object the twin was made from)
 	for (int k = 1; k < MAX_ENGINES; k++) {
 		if (e->d_ctus_eng[k]) (void)hipFree(e->d_ctus_eng[k]);
 		if (e->d_rowstate_eng[k]) (void)hipFree(e->d_rowstate_eng[k]);
@@ -1679,7 +1738,8 @@ extern "C" int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *e, const uint8_t *y, const ui
 }
 
 namespace {
-constexpr int GATHER_HEAD = 8;      // words in front of the CTUs' distortions in a picture's gather record
+constexpr int GATHER_HEAD = 12;         // words in front of the CTUs' distortions in a picture's gather record
+constexpr int CHAIN_MAX_FRAMES = 32;    // frames of one hmr_gpu_enc_encode_chain call
 __global__ void k_gather_results(const EncDev *devs, uint32_t *out, int pitch, const int *pool_flags)
 {
 	const EncDev &d = devs[blockIdx.x];
@@ -1702,6 +1762,10 @@ __global__ void k_gather_results(const EncDev *devs, uint32_t *out, int pitch, c
 		o[5] = s_bits;
 		const double tp = d.counters[2] >= 0 ? d.rc_dyn->target_pict_size : d.frame->rc.target_pict_size;
 		memcpy(&o[6], &tp, 8);
+		// chains: the distortion total as the launch computed it, and the average distortion the picture started from (the launch sets it for an engine's later pictures)
+		const double fin = d.fin[0], avg = d.frame->avg_dist;
+		memcpy(&o[8], &fin, 8);
+		memcpy(&o[10], &avg, 8);
 	}
 	for (int c = threadIdx.x; c < nctu; c += blockDim.x) o[GATHER_HEAD + c] = d.ctus[c].distortion;
 	// bytes of the rows' sub-streams, behind the distortions
@@ -2161,12 +2225,17 @@ extern "C" int hmr_gpu_enc_encode_batch_pipelined(hmr_gpu_enc **encs, int n, con
 // to be repeated frame by frame.
 extern "C" int hmr_gpu_enc_encode_chain(hmr_gpu_enc **encs, int n, hmr_gpu_enc *prev, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes)
 {
-	if (!encs || n <= 0 || n > MAX_ENGINES || !slots || !streams || !caps || !stream_bytes) return HMR_GPU_ERR_ARG;
+	if (!encs || n <= 0 || n > CHAIN_MAX_FRAMES || !slots || !streams || !caps || !stream_bytes) return HMR_GPU_ERR_ARG;
 	for (int j = 0; j < n; j++) {
 		hmr_gpu_enc *e = encs[j];
 		if (!e || !e->lockstep || e->ctx->device != encs[0]->ctx->device || slots[j] < 0 || slots[j] >= (int)e->src.size() || !streams[j] || e->awaiting_delivery || e->engine_index < 0 ||
-		    n > e->st.engines || e->seq.width != encs[0]->seq.width || e->seq.height != encs[0]->seq.height) {
-			hmr_set_error("hmr_gpu_enc_encode_chain: frame %d: needs an engine object (hmr_gpu_enc_create_engine) of the chain's sequence on the chain's device with a loaded picture slot, at most num_enc_engines frames", j);
+		    e->seq.width != encs[0]->seq.width || e->seq.height != encs[0]->seq.height) {
+			hmr_set_error("hmr_gpu_enc_encode_chain: frame %d: needs an engine object (hmr_gpu_enc_create_engine) of the chain's sequence on the chain's device with a loaded picture slot", j);
+			return HMR_GPU_ERR_ARG;
+		}
+		// more frames than engines: an engine's next frame is encoded by a twin of its object (hmr_gpu_enc_create_engine_twin: the same persistent engine state)
+		if (j >= e->st.engines && e->d_ctus_eng[0] != encs[j - e->st.engines]->d_ctus_eng[0]) {
+			hmr_set_error("hmr_gpu_enc_encode_chain: frame %d: the object has to be a twin (hmr_gpu_enc_create_engine_twin) of the one that encodes frame %d, the engine's frame before it", j, j - e->st.engines);
 			return HMR_GPU_ERR_ARG;
 		}
 		for (int i = 0; i < j; i++)
@@ -2185,7 +2254,6 @@ extern "C" int hmr_gpu_enc_encode_chain(hmr_gpu_enc **encs, int n, hmr_gpu_enc *
 	// the state every frame starts from, as the sequential order would hand it over: what begin_frame reads of it is older than the chain, a scene change excepted
 	HostState st = prev ? prev->st : lead->st;
 	const HostState start_state = st;
-	std::vector<HostState> before(n);
 	for (int j = 0; j < n; j++) {
 		hmr_gpu_enc *e = encs[j];
 		const Seq &s = e->seq;
@@ -2203,7 +2271,6 @@ extern "C" int hmr_gpu_enc_encode_chain(hmr_gpu_enc **encs, int n, hmr_gpu_enc *
 			HIP_TRY(hipMalloc((void **)&p.c[1], p.bytes_c));
 			ps = p;
 		}
-		before[j] = st;
 		e->st = st;
 		// what the frame predicts from, taken before the object that holds it (prev may be the chain's last object) moves on to its own next frame
 		const hmr_gpu_enc *r = j ? encs[j - 1] : prev;
@@ -2229,6 +2296,19 @@ extern "C" int hmr_gpu_enc_encode_chain(hmr_gpu_enc **encs, int n, hmr_gpu_enc *
 			e->f.sub_c[1] = ref_set.c[1] + (size_t)s.margin_c * 64 * s.stride_c + s.margin_c;
 			e->d.dep = j ? j - 1 : -1;
 			e->d.dep_full = getenv("HENC_CHAIN_SERIAL") ? 1 : 0;
+		}
+		if (j >= e->st.engines) {
+			// the engine's second (third ...) frame of the launch: it starts when the one before it is finished, from the average distortion that one leaves
+			// (the launch writes it into this frame's parameters); an I frame inside the sequence hands on the value of the frame BEFORE it (end_frame), which
+			// the launch does not have
+			const hmr_gpu_enc *b = encs[j - e->st.engines];
+			if (b->f.slice_type == SLICE_I && b->f.num_encoded_frames != 0 && s.intra_period != 1) {
+				hmr_set_error("hmr_gpu_enc_encode_chain: frame %d is an I frame inside the sequence and the same engine's next frame is in the chain: end the chain before frame %d", j - e->st.engines, j);
+				return HMR_GPU_ERR_ARG;
+			}
+			e->d.after = j - e->st.engines;
+			e->f.avg_dist = 0.0;
+			lead->h_devs[j - e->st.engines].next_frame = lead->d_frames + j;
 		}
 		e->d.post.planes[0] = e->chain_planes.y; e->d.post.planes[1] = e->chain_planes.c[0]; e->d.post.planes[2] = e->chain_planes.c[1];
 		HIP_TRY(hipEventRecord(e->ev_ready, e->ctx->stream));
@@ -2285,6 +2365,9 @@ extern "C" int hmr_gpu_enc_encode_chain(hmr_gpu_enc **encs, int n, hmr_gpu_enc *
 		FrameCtx replay;
 		e->st = seq_state;
 		begin_frame(s, e->st, image_types ? image_types[j] : 0, replay);
+		double acc_dist;
+		memcpy(&acc_dist, &g[8], 8);
+		memcpy(&e->f.avg_dist, &g[10], 8);      // (what the frame's CTUs read: for an engine's later frames of the launch the launch itself set it)
 		if (replay.slice_type != e->f.slice_type || replay.poc != e->f.poc || replay.avg_dist != e->f.avg_dist) {
 			hmr_set_error("hmr_gpu_enc_encode_chain: frame %d started from a state the frames before it changed", j);
 			return HMR_GPU_ERR_ARG;
@@ -2292,7 +2375,7 @@ extern "C" int hmr_gpu_enc_encode_chain(hmr_gpu_enc **encs, int n, hmr_gpu_enc *
 		FrameRcOut ro;
 		ro.sum_qp = (int)g[4]; ro.consumed_bits = (double)g[5];
 		memcpy(&ro.target_pict_size, &g[6], 8);
-		end_frame(s, e->st, e->f, frame_acc_dist(s, e->cfg.wfpp_num_threads, [&](int c) { return g[GATHER_HEAD + c]; }), &ro);
+		end_frame(s, e->st, e->f, acc_dist, &ro);      // (the total the launch formed when the picture finished: by now a twin's frame may have overwritten the records)
 		seq_state = e->st;
 		// the access unit
 		const int rows = s.wpp ? s.hctu : 1;

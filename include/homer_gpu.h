@@ -651,11 +651,18 @@ int hmr_gpu_enc_import_reference(hmr_gpu_enc *enc, const int16_t *dev_y, const i
 long hmr_gpu_enc_reference_bytes(hmr_gpu_enc *enc);
 /* 12c. Overlapping engines on one GPU.  The reference's engine k + 1 follows engine k's frame at the distance of the search window and the filter lag, CTU row by CTU row
  * (hmr_encoder_lib.c:2393-2403 the lag arithmetic, :2440-2445 the per-CTU SEM_POST of synchro_signal[1], :3154-3211 the frame hand-out).  hmr_gpu_enc_encode_chain encodes
- * the frames slots[0 .. n - 1] (n <= num_enc_engines) of ONE sequence on its engine objects encs[0 .. n - 1] (in coding order; prev = the object that encoded the frame
+ * the frames slots[0 .. n - 1] (n <= num_enc_engines; more with twins, below) of ONE sequence on its engine objects encs[0 .. n - 1] (in coding order; prev = the object that encoded the frame
  * before, NULL at the sequence start) in one launch of the CTU kernel: frame j predicts from the final picture of frame j - 1 where it lies (no copy) and from its phase
  * planes, which the same launch produces CTU by CTU; a wavefront step of frame j starts when the part of that picture its vectors can reach is ready.  Same streams as frame
  * by frame (the engine turnstile's interleaving, oracle/ref_ctudump.c).  Returns HMR_GPU_ERR_ARG when two frames of the chain both detect a scene change (sequentially the
- * first switches the detection off for the second): repeat those frames one by one. */
+ * first switches the detection off for the second): repeat those frames one by one.
+ * More frames than engines (n up to 32): the reference's engine k takes frame t + num_enc_engines when its frame t is finished.  hmr_gpu_enc_create_engine_twin makes
+ * another object for the same engine - it shares the engine's persistent state (CTU records, the WPP threads' mode buffers) with `of` and has its own pictures, filter state
+ * and sub-stream buffers; encs[j] for j >= num_enc_engines has to be a twin of encs[j - num_enc_engines] (or the other way round).  The launch then starts an engine's next
+ * frame when its previous one is finished and hands on the average distortion it leaves (hmr_encoder_lib.c:3217-3262) inside the launch; the engines never idle between the
+ * frames of a call.  An I frame inside the sequence must be among the last num_enc_engines frames of its call (it hands on the value of the frame before it).  Destroy the
+ * twins before the object they were made from. */
+int hmr_gpu_enc_create_engine_twin(hmr_gpu_ctx *ctx, hmr_gpu_enc *of, hmr_gpu_enc **out);
 int hmr_gpu_enc_encode_chain(hmr_gpu_enc **encs, int n, hmr_gpu_enc *prev, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes);
 int hmr_gpu_enc_export_references8(hmr_gpu_enc **encs, int n, uint8_t *dev_rows, long pitch, void *states);
 int hmr_gpu_enc_import_references8(hmr_gpu_enc **encs, int n, const uint8_t *dev_rows, long pitch, const void *states);
