@@ -52,7 +52,16 @@ WORKLOADS = {                  # name -> (width, height, configuration keys of t
     "cfg2-1080p-encode-single-thread-order": (1920, 1080, {}),
     "cfg2-2160p-encode": (3840, 2160, {"wpp": 32}),                          # the same encode at 2160p (configs[3] per engine): 34 CTU rows on the reference's maximum of 32 threads
     "cfg2-416x240-encode": (416, 240, {"wpp": 4}),                           # quick look
+    # BASELINE.json configs[2]: 2160p IPPP, CBR 20000 kbps (vbv = 1 s, 35 % initial fullness), performance_mode 1 - the rate control runs in the CTU kernel
+    "cfg3-2160p-cbr": (3840, 2160, {"wpp": 32, "bitrate_mode": 1, "bitrate": 20000, "perf": 1}),
+    "cfg3-1080p-cbr": (1920, 1080, {"wpp": 17, "bitrate_mode": 1, "bitrate": 5000, "perf": 1}),
 }
+# the sequences of a batch encode eight different clips (tools/gen_yuv.py: 1234 is the published clip); the reference's digests of each are in bench_md5.json
+CLIP_SEEDS = [1234, 1, 2, 3, 4, 5, 6, 7]
+
+
+def seed_workload(workload, seed):
+    return workload if seed == 1234 else f"{workload}-seed{seed}"
 # md5 of the reference's stream after every access unit, per workload (tests/golden/bench_md5.json, minted by tests/golden/make_bench_golden.py from the compiled
 # reference: ref_lockstep for one thread, ref_ctudump under HOMER_TURNSTILE for one thread per row): whatever --steps / --warmup, the digest after frame k is checked
 REFERENCE_MD5 = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_md5.json")))
@@ -81,41 +90,78 @@ def load_lib():
 
 
 def cpu_baseline(width, height, keys, frames):
-    """The compiled reference, one thread (wpp = 1, engines = 1: the configuration the device output is identical to), on this host."""
+    """The compiled reference, one thread (wpp = 1, engines = 1: the configuration the device output is identical to), on this host: one process, one process with a
+    thread per CTU row, and K = host cores processes side by side (one sequence each, `frames` frames).  The times are the harness's own (oracle/ref_lockstep.c prints
+    the seconds between the first HOMER_enc_encode and the last access unit): process start, HOMER_enc_init and the library's table set-up are NOT in them."""
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_lockstep")
     if not os.path.exists(exe):
         return None
     import gen_yuv
+
+    def seconds(stdout):
+        for line in reversed(stdout.decode("latin1").splitlines()):
+            if line.startswith("LOCKSTEP"):
+                f = dict(kv.split("=") for kv in line.split()[1:])
+                return float(f["seconds"]), int(f["frames"])
+        raise RuntimeError("no LOCKSTEP line from the reference harness")
+
+    ncores = os.cpu_count() or 1
+    try:
+        avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        avail = 64 << 30
+    # one process per PHYSICAL core (the siblings of a core share its SSE units and caches: 256 processes on 128 cores were slower in total than 128)
+    physical = set()
+    for cpu in range(ncores):
+        try:
+            base = f"/sys/devices/system/cpu/cpu{cpu}/topology/"
+            physical.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        except OSError:
+            physical.add(("?", str(cpu)))
+    K = max(1, min(len(physical), int(avail * 0.5 / (400 << 20))))      # (a 1080p reference process holds well under 400 MB)
     with tempfile.TemporaryDirectory() as tmp:
         yuv = os.path.join(tmp, "in.yuv")
         gen_yuv.write_clip(yuv, width, height, frames)
-        cmd = [exe, yuv, os.path.join(tmp, "out.265"), str(width), str(height), str(frames)] + [f"{k}={v}" for k, v in keys.items()]
-        t0 = time.time()
-        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
-        dt = time.time() - t0
+        cmd = [exe, yuv, "-", str(width), str(height), str(frames)] + [f"{k}={v}" for k, v in keys.items()]
+        dt, n1 = seconds(subprocess.run(cmd, check=True, capture_output=True).stdout)
         rows = (height + 63) // 64
+        dt_rows, _ = seconds(subprocess.run(cmd + [f"wpp={rows}"], check=True, capture_output=True).stdout)
+        # the same shape as the batch: K independent sequences at once, one single-thread reference process per host core
         t0 = time.time()
-        subprocess.run(cmd + [f"wpp={rows}"], check=True, stdout=subprocess.DEVNULL)
-        dt_rows = time.time() - t0
-    # the same shape as the batch: K independent sequences at once, one single-thread reference process per host core
-    ncores = os.cpu_count() or 1
-    K = max(1, min(ncores, 64))
-    with tempfile.TemporaryDirectory() as tmp:
-        yuv = os.path.join(tmp, "in.yuv")
-        tf = max(4, frames // 3)
-        gen_yuv.write_clip(yuv, width, height, tf)
-        cmd = [exe, yuv, "-", str(width), str(height), str(tf)] + [f"{k}={v}" for k, v in keys.items()]
-        t0 = time.time()
-        procs = [subprocess.Popen(cmd, stdout=subprocess.DEVNULL) for _ in range(K)]
-        for p in procs:
-            p.wait()
-        dt_k = time.time() - t0
-    throughput = {"value": round(K * tf / dt_k, 3), "unit": "frames/s aggregate", "processes": K, "cores": K, "host_cores": ncores, "frames_per_process": tf,
-                  "note": "K single-thread reference processes side by side, one sequence each: the host's answer to a batch of independent sequences"}
-    return {"value": round(frames / dt, 3), "unit": "frames/s", "cores": 1, "kind": "reference", "throughput": throughput,
-            "sample": f"{frames} frames {width}x{height} IPPP QP32 through oracle/_ref/ref_lockstep (SSE4.2 table, wpp=1, engines=1), wall time incl. init and file I/O",
-            "one_thread_per_ctu_row": {"value": round(frames / dt_rows, 3), "threads": rows, "host_cores": os.cpu_count(),
+        procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(K)]
+        secs = [seconds(p.communicate()[0])[0] for p in procs]
+        wall_k = time.time() - t0
+    throughput = {"value": round(K * frames / max(secs), 3), "unit": "frames/s aggregate", "processes": K, "cores": K, "host_cores": ncores, "host_physical_cores": len(physical), "frames_per_process": frames,
+                  "slowest_process_s": round(max(secs), 2), "fastest_process_s": round(min(secs), 2), "wall_s_incl_process_start": round(wall_k, 2),
+                  "note": "K single-thread reference processes side by side, one sequence each: the host's answer to a batch of independent sequences; K x frames / the slowest "
+                          "process's encode time (start-up and HOMER_enc_init excluded)"}
+    # the headline of the baseline is the host's best answer to the bench's workload (a batch of independent sequences): all cores, one reference process each
+    return {"value": throughput["value"], "unit": "frames/s", "cores": K, "kind": "reference",
+            "sample": f"{K} processes x {frames} frames {width}x{height} IPPP QP32 through oracle/_ref/ref_lockstep (SSE4.2 table, wpp=1, engines=1), one per physical host core; the harness's own "
+                      "clock from the first HOMER_enc_encode to the last access unit of the slowest process (no process start, no HOMER_enc_init)",
+            "throughput": throughput,
+            "one_process": {"value": round(n1 / dt, 3), "unit": "frames/s", "cores": 1, "frames": n1},
+            "one_thread_per_ctu_row": {"value": round(n1 / dt_rows, 3), "threads": rows, "host_cores": ncores,
                                        "note": "the same reference run free with wfpp_num_threads = CTU rows (its multi-thread mode; output depends on timing)"}}
+
+
+def valu_issue_probe(lib, device):
+    """hmr_gpu_probe_valu_issue (include/homer_gpu.h section 14): plain vector instructions per second of this device - all SIMDs busy with independent instructions
+    (the ceiling the guide's 1024 SIMDs x clock / 4 cycles describes) and with ONE dependent chain per wavefront (what a row worker's decision chain is made of)."""
+    lib.hmr_gpu_probe_valu_issue.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.hmr_gpu_destroy.argtypes = [C.c_void_p]
+    ctx = C.c_void_p()
+    assert lib.hmr_gpu_create(C.byref(ctx), device, None) == 0
+    rows = []
+    for waves, dep in ((1, 0), (2, 0), (4, 0), (1, 1), (2, 1)):
+        rate, ms = C.c_double(), C.c_double()
+        assert lib.hmr_gpu_probe_valu_issue(ctx, waves, dep, C.byref(rate), C.byref(ms)) == 0, lib.hmr_gpu_last_error()
+        rows.append({"waves_per_simd": waves, "dependent_chain": bool(dep), "wave_instructions_per_s": round(rate.value / 1e9, 2), "unit": "G/s", "ms": round(ms.value, 2),
+                     "cycles_per_instruction_and_simd_at_2p4GHz": round(2.4e9 * 1024 / rate.value, 3)})
+    lib.hmr_gpu_destroy(ctx)
+    return {"kernel": "k_probe_valu (v_mad_u32_u24, no memory access in the loop)", "rows": rows,
+            "note": "independent instructions reach the guide's ceiling from one wavefront per SIMD on; a dependent chain issues one instruction per the ALU's latency - "
+                    "k_encode_pool's workers are such chains, 1.5 wavefronts per SIMD"}
 
 
 def subpel_planes_roofline(lib, torch, width, height, reps=20):
@@ -351,13 +397,39 @@ def main():
             b = copy.copy(a)
             b.warmup, b.steps = 2, 4
             big = run_workload(lib, b, "cfg2-2160p-encode", world, rank, local, torch, sequences=64 if a.sequences > 1 else 1)
-            out["at_2160p"] = {k: big[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "stream_md5", "stream_matches_reference", "frames_checked_against_reference", "all_streams_identical")}
+            out["at_2160p"] = {k: big[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "stream_md5", "stream_matches_reference", "frames_checked_against_reference", "clips")}
             out["at_2160p"]["config"] = big["config"]
             if a.sequences > 1:
                 big1 = run_workload(lib, b, "cfg2-2160p-encode", world, rank, local, torch)
                 out["at_2160p"]["single_sequence"] = {k: big1[k] for k in ("value", "ms_per_step", "stream_matches_reference")}
+        if world == 1 and a.workload == "cfg2-1080p-encode" and not a.no_single_thread_order:
+            # ONE sequence with its engines overlapped on this GPU (hmr_gpu_enc_encode_chain: the frames of a chain in one launch of the CTU kernel, every engine
+            # starting its next frame when its last is finished; tools/chain_bench.py): the reference's num_enc_engines pipeline, streams checked against its digests
+            import chain_bench
+            lanes = []
+            for wl, sets in (("cfg2-1080p-encode-engines3", 4), ("cfg2-1080p-encode-engines8", 2), ("cfg2-2160p-encode-engines8", 2)):
+                if wl in REFERENCE_MD5:
+                    r = chain_bench.run(lib, wl, sets=sets, quiet=True)
+                    lanes.append({k: r[k] for k in ("workload", "engines", "objects_per_engine", "chain", "frames", "frames_per_s_full_chains", "frames_per_s_after_first_chain", "stream_matches_reference",
+                                                   "ctu_launch_ms_per_chain")})
+            out.setdefault("single_sequence", {})["engines_overlapped"] = lanes
+            # BASELINE.json configs[2]: 2160p CBR 20000 kbps, performance_mode 1 - a batch of 32 sequences and one sequence alone (the fixture covers ten frames)
+            import copy
+            c3 = copy.copy(a)
+            c3.warmup, c3.steps = 2, 6
+            r3 = run_workload(lib, c3, "cfg3-2160p-cbr", world, rank, local, torch, sequences=32 if a.sequences > 1 else 1)
+            out["cfg3_2160p_cbr"] = {k: r3[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "stream_md5", "stream_matches_reference", "frames_checked_against_reference", "clips")}
+            out["cfg3_2160p_cbr"]["config"] = dict(r3["config"], bitrate_mode="CBR", bitrate_kbps=20000, vbv_size_kbit=20000, performance_mode=1)
+            if a.sequences > 1:
+                r31 = run_workload(lib, c3, "cfg3-2160p-cbr", world, rank, local, torch)
+                out["cfg3_2160p_cbr"]["single_sequence"] = {k: r31[k] for k in ("value", "ms_per_step", "stream_matches_reference")}
         if world == 1:
             out["roofline"]["subpel_planes"] = subpel_planes_roofline(lib, torch, width, height)
+            probe = valu_issue_probe(lib, local)
+            if out["roofline"].get("issue_bound") is not None:
+                out["roofline"]["issue_bound"]["probe"] = probe
+            else:
+                out["roofline"]["issue_probe"] = probe
         if world == 1 and a.streams > 1:
             out["multi_stream"] = multi_stream_child(local, a.workload, a.streams)
         if world == 1 and a.batch > 1:
@@ -434,15 +506,19 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
     width, height, keys = WORKLOADS[workload]
     nframes = a.warmup + a.steps
     S = sequences if int(keys.get("wpp", 1)) > 1 else 1
-    frames = ec.clip_frames(width, height, nframes)
+    # sequence i encodes clip i mod 8 where the reference's digests of that clip cover the run (else the published clip)
+    seeds = [sd for sd in CLIP_SEEDS if REFERENCE_MD5.get(seed_workload(workload, sd), {}).get("frames", 0) >= nframes] if S > 1 else []
+    if not seeds or os.environ.get("HOMER_BENCH_ONE_CLIP"):
+        seeds = [1234]
+    clips = {sd: ec.clip_frames(width, height, nframes, seed=sd) for sd in seeds}
     encs, bufs, ctxs = [], [], []
     lib.hmr_gpu_destroy.argtypes = [C.c_void_p]
-    for _ in range(S):
+    for i in range(S):
         ctx, enc = C.c_void_p(), C.c_void_p()
         assert lib.hmr_gpu_create(C.byref(ctx), local, None) == 0, lib.hmr_gpu_last_error()
         cfg = ec.default_cfg(width, height, **keys)
         assert lib.hmr_gpu_enc_create(ctx, C.byref(cfg), C.byref(enc)) == 0, lib.hmr_gpu_last_error()
-        for f, planes in enumerate(frames):
+        for f, planes in enumerate(clips[seeds[i % len(seeds)]]):
             assert lib.hmr_gpu_enc_load_source(enc, f, *planes) == 0, lib.hmr_gpu_last_error()
         encs.append(enc)
         ctxs.append(ctx)
@@ -450,8 +526,10 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
     enc, buf = encs[0], bufs[0]
     nbytes = C.c_long()
     md5s = [hashlib.md5() for _ in range(S)]
-    cumulative = []                # digest of sequence 0's stream after every access unit
+    nrep = min(S, len(seeds))      # sequences 0 .. nrep - 1: the first of each clip, whose stream is checked access unit by access unit
+    cumulative = [[] for _ in range(nrep)]      # digest of their streams after every access unit
     stats = []
+    step_wall = []
     lib.hmr_gpu_enc_encode_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_long)]
     lib.hmr_gpu_enc_encode_batch_pipelined.argtypes = lib.hmr_gpu_enc_encode_batch.argtypes
     pipelined = S > 1 and not a.no_pipeline
@@ -474,6 +552,7 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
         take_units()
 
     def step(f):
+        t_step = time.perf_counter()
         if S == 1:
             st = lib.hmr_gpu_enc_encode_source(enc, f, 0, buf, len(buf), C.byref(nbytes), None)
             assert st in (1, 2), lib.hmr_gpu_last_error()
@@ -484,22 +563,25 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
             take_units()
             st, nbytes.value = 0, got[0]
         if S == 1:
-            cumulative.append(md5s[0].hexdigest())
+            cumulative[0].append(md5s[0].hexdigest())
         p, n, ms, tot = C.c_int(), C.c_int(), C.c_float(), C.c_float()
         lib.hmr_gpu_enc_last_stats(enc, C.byref(p), C.byref(n), C.byref(ms), C.byref(tot))
         stats.append((f, st, nbytes.value, p.value, n.value, ms.value, tot.value))
+        step_wall.append(time.perf_counter() - t_step)
 
     dt = measure(step, a.warmup, nframes, world, torch.cuda.synchronize, "cuda", flush if pipelined else None)
     for units in kept:              # every access unit of every sequence, in the order delivered
         for i in range(S):
             md5s[i].update(units[i])
-        cumulative.append(md5s[0].hexdigest())
+        for i in range(nrep):
+            cumulative[i].append(md5s[i].hexdigest())
     for x in encs:
         lib.hmr_gpu_enc_destroy(x)
     for x in ctxs:
         lib.hmr_gpu_destroy(x)          # (a context holds pinned host memory, HBM staging and a stream)
     md5 = md5s[0]
-    all_same = len({m.hexdigest() for m in md5s}) == 1
+    # every sequence of a clip must have produced the stream of the clip's first sequence, and that one the reference's, access unit by access unit
+    all_same = all(md5s[i].hexdigest() == md5s[i % nrep].hexdigest() for i in range(S))
 
     if True:
         timed = stats[a.warmup:]
@@ -537,17 +619,28 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
                                                                   / (512 * 2.4e9 / fps_kernel), 3),
                          "source": "profiles/r03_pmc_kernels.json (rocprofv3 --pmc passes of this command), instruction counts per encoded frame x this run's frames/s of the kernel"}
         digest = md5.hexdigest()
-        matches, checked = check_against_reference(workload, cumulative)
+        per_clip = {}
+        matches, checked = True, None
+        for i in range(nrep):
+            ok_i, n_i = check_against_reference(seed_workload(workload, seeds[i]), cumulative[i])
+            per_clip[str(seeds[i])] = {"stream_md5": md5s[i].hexdigest(), "matches_reference": bool(ok_i), "frames_checked": n_i, "sequences": len(range(i, S, nrep))}
+            matches = matches and ok_i
+            checked = n_i if checked is None else min(checked, n_i)
         out = {
             "metric": "encoded frames/sec, 1080p & 2160p YUV420 fixed-QP IPPP, 1/2/4/8 MI355X", "value": round(world * S * a.steps / dt, 4), "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": workload, "sequences_per_gpu": S, "frames_per_step": S, "wfpp_num_threads": int(keys.get("wpp", 1)), "width": width, "height": height, "frames_in_sequence": nframes, "gop": "IPPP intra_period=100", "qp": 32,
-                       "rd_mode": 2, "performance_mode": 2, "sao": 1, "parallelism": (f"{S} independent sequences per GPU, one launch per step for their CTU stages (a pool of CTU tasks on two row workers per CU)" if S > 1 else "one sequence"),
-                       "timed_region": "CTU decisions + deblock + SAO statistics / decision / offsets + padding on the device, CABAC / NAL on the host, per frame; source in HBM",
+                       "rd_mode": 2, "performance_mode": int(keys.get("perf", 2)), "sao": 1, "parallelism": (f"{S} independent sequences per GPU, one launch per step for their CTU stages (a pool of CTU tasks on two row workers per CU)" if S > 1 else "one sequence"),
+                       "timed_region": "per frame: phase planes of the reference, CTU decisions, deblocking, SAO statistics / decision / syntax, CABAC of the CTU rows' sub-streams, SAO offsets and border padding on the device "
+                                       "(one launch of k_encode_pool: the decisions and the post-decision tasks of enc_post.h), download of the sub-streams, slice header / entry points / NAL escaping on the host; source in HBM; "
+                                       "the first warm-up step is the I frames (warmup_ms_per_step[0])",
                        "call": ("hmr_gpu_enc_encode_batch_pipelined: a step's download and entropy coding run under the next step's CTU launch; the pipeline is empty when the timed "
                                 "region starts and flushed inside it" if pipelined else "hmr_gpu_enc_encode_batch" if S > 1 else "hmr_gpu_enc_encode_source")},
-            "stream_md5": digest, "stream_matches_reference": bool(matches and all_same), "frames_checked_against_reference": checked, "all_streams_identical": all_same,
+            "stream_md5": digest, "stream_matches_reference": bool(matches and all_same), "frames_checked_against_reference": checked,
+            "clips": {"distinct": nrep, "by_seed": per_clip, "sequences_of_a_clip_identical": all_same,
+                      "note": "sequence i encodes clip i mod distinct (tools/gen_yuv.py seeds: own texture, pan, pattern, box path); each clip's stream is checked against the compiled reference's digests of that clip"},
+            "warmup_ms_per_step": [round(x * 1e3, 1) for x in step_wall[:a.warmup]],
             "schedule": {"ctus_per_frame": nctu, "passes_per_frame": [s[3] for s in timed], "ctu_encodes_per_frame": [s[4] for s in timed],
                          "ctu_stage_ms_per_frame": [round(s[5], 1) for s in timed], "device_ms_per_frame": [round(s[6], 1) for s in timed]},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 7),

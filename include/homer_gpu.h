@@ -684,6 +684,15 @@ int hmr_gpu_enc_import_references8(hmr_gpu_enc **encs, int n, const uint8_t *dev
 int hmr_gpu_subpel_planes(hmr_gpu_ctx *ctx, const int16_t *pic_y, const int16_t *pic_u, const int16_t *pic_v, int stride_y, int rows_y, int stride_c, int rows_c,
 			  uint8_t *out_y, uint8_t *out_u, uint8_t *out_v);
 
+/* ------------------------------------------------------------------------------------------------
+ * 14. Measurement aid (no counterpart in the reference): the vector-instruction issue rate of the device
+ *     k_encode_pool is bound by the instruction issue of a few wavefronts per CU and by the latency of its dependent chains, not by HBM bandwidth; bench.py prices it
+ *     against wave-instructions per second.  This measures that ceiling on the device at hand: every CU runs waves_per_simd (1 .. 4) wavefronts per SIMD, each a
+ *     loop of 64 integer multiply-adds without memory accesses - on eight independent accumulators, or (dependent != 0) as ONE chain, the rate a single dependent
+ *     instruction stream reaches.  *wave_instr_per_s: vector instructions per second of all wavefronts together; *ms (may be NULL): the launch's duration.
+ * ------------------------------------------------------------------------------------------------ */
+int hmr_gpu_probe_valu_issue(hmr_gpu_ctx *ctx, int waves_per_simd, int dependent, double *wave_instr_per_s, double *ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,9 +105,9 @@ def load_fixture(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
 
-def clip_frames(width, height, frames, cut_at=None):
+def clip_frames(width, height, frames, cut_at=None, seed=1234):
     import gen_yuv
-    return [tuple(p.tobytes() for p in planes) for planes in gen_yuv.gen_frames(width, height, frames, cut_at=cut_at)]
+    return [tuple(p.tobytes() for p in planes) for planes in gen_yuv.gen_frames(width, height, frames, seed=seed, cut_at=cut_at)]
 
 
 def check_frame_against_fixture(fx, f, records, width, height):

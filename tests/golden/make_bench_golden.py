@@ -42,6 +42,11 @@ CASES = {
     "cfg3-2160p-cbr": (3840, 2160, 10, {"wpp": 32, "bitrate_mode": 1, "bitrate": 20000, "perf": 1}),
     "cfg3-1080p-cbr": (1920, 1080, 24, {"wpp": 17, "bitrate_mode": 1, "bitrate": 5000, "perf": 1}),
 }
+# bench.py's batch encodes eight DIFFERENT clips side by side (tools/gen_yuv.py: seed 1234 is the published clip, the others differ in texture, pan, pattern and box path)
+CLIP_SEEDS = [1234, 1, 2, 3, 4, 5, 6, 7]
+for _seed in CLIP_SEEDS[1:]:
+    CASES[f"cfg2-1080p-encode-seed{_seed}"] = (1920, 1080, 24, {"wpp": 17}, _seed)
+    CASES[f"cfg2-2160p-encode-seed{_seed}"] = (3840, 2160, 6, {"wpp": 32}, _seed)
 
 
 def access_unit_ends(stream):
@@ -60,10 +65,10 @@ def access_unit_ends(stream):
     return ends
 
 
-def run(width, height, frames, keys):
+def run(width, height, frames, keys, seed=1234):
     with tempfile.TemporaryDirectory() as tmp:
         yuv = os.path.join(tmp, "in.yuv")
-        gen_yuv.write_clip(yuv, width, height, frames)
+        gen_yuv.write_clip(yuv, width, height, frames, seed)
         turnstile = int(keys.get("wpp", 1)) > 1 or int(keys.get("engines", 1)) > 1
         cmd = [os.path.join(ROOT, "oracle", "_ref", "ref_ctudump" if turnstile else "ref_lockstep"), yuv, os.path.join(tmp, "out.265"), str(width), str(height), str(frames)]
         cmd += [f"{k}={v}" for k, v in keys.items()]
@@ -77,16 +82,35 @@ def run(width, height, frames, keys):
         each.append(hashlib.md5(stream[pos:e]).hexdigest())
         pos = e
         out.append(h.copy().hexdigest())
-    return {"width": width, "height": height, "frames": frames, "keys": keys, "cumulative_md5": out, "au_md5": each}
+    rec = {"width": width, "height": height, "frames": frames, "keys": keys, "cumulative_md5": out, "au_md5": each}
+    if seed != 1234:
+        rec["clip_seed"] = seed
+    return rec
 
 
 if __name__ == "__main__":
+    # usage: make_bench_golden.py [-jN] [workload or prefix* ...]: N reference runs side by side (a 2160p run holds a few hundred MB)
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
     path = os.path.join(HERE, "bench_md5.json")
-    only = set(sys.argv[1:])
+    args = sys.argv[1:]
+    jobs = 1
+    for a in list(args):
+        if a.startswith("-j"):
+            jobs = int(a[2:])
+            args.remove(a)
     out = json.load(open(path)) if os.path.exists(path) else {}
-    for name, (w, h, f, keys) in CASES.items():
-        if only and name not in only:
-            continue
-        out[name] = run(w, h, f, keys)
-        print(name, f, out[name]["cumulative_md5"][-1], flush=True)
-        json.dump(out, open(path, "w"), indent=1)
+    lock = threading.Lock()
+
+    def wanted(name):
+        return not args or any(name == a or (a.endswith("*") and name.startswith(a[:-1])) for a in args)
+
+    def one(name):
+        rec = run(*CASES[name])
+        with lock:
+            out[name] = rec
+            print(name, rec["frames"], rec["cumulative_md5"][-1], flush=True)
+            json.dump(out, open(path, "w"), indent=1)
+
+    with ThreadPoolExecutor(jobs) as ex:
+        list(ex.map(one, [n for n in CASES if wanted(n)]))

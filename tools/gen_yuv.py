@@ -18,20 +18,29 @@ def gen_frames(width, height, frames, seed=1234, cut_at=None):
     re-scaled base) - what the encoder's scene-change detection reacts to; None (the published clips) = no cut."""
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:height, 0:width]
-    base = (128 + 60 * np.sin(xx / 53.0) * np.cos(yy / 41.0) + 40 * np.sin((xx + yy) / 17.0)).astype(np.float32)
+    # seed 1234 is the published clip; any other seed is a different clip of the same kind: its own texture, pan, base pattern and box path (bench.py encodes
+    # several of them side by side so that the sequences of a batch do not all walk the same decisions)
+    pan_x, pan_y, f1, f2, f3, box_x, box_y, box_dx, box_dy = 3, 2, 53.0, 41.0, 17.0, 200, 300, 11, 7
+    if seed != 1234:
+        prm = np.random.default_rng(seed ^ 0x5EED)
+        pan_x, pan_y = int(prm.integers(1, 6)), int(prm.integers(0, 4))
+        f1, f2, f3 = 53.0 * float(prm.uniform(0.6, 1.5)), 41.0 * float(prm.uniform(0.6, 1.5)), 17.0 * float(prm.uniform(0.7, 1.6))
+        box_x, box_y = int(prm.integers(0, max(width - 240, 1))), int(prm.integers(0, max(height - 160, 1)))
+        box_dx, box_dy = int(prm.integers(-9, 13)), int(prm.integers(-5, 9))
+    base = (128 + 60 * np.sin(xx / f1) * np.cos(yy / f2) + 40 * np.sin((xx + yy) / f3)).astype(np.float32)
     tex = rng.integers(-12, 13, size=(height + 64, width + 64)).astype(np.float32)
     base2 = tex2 = None
     if cut_at is not None:
         base2 = (120 + 70 * np.cos(xx[:, ::-1] / 23.0) * np.sin(yy / 19.0) + 30 * np.sin((2 * xx - yy) / 11.0)).astype(np.float32)
         tex2 = np.random.default_rng(seed + 1).integers(-40, 41, size=(height + 64, width + 64)).astype(np.float32)
     for n in range(frames):
-        dx, dy = 3 * n, 2 * n
+        dx, dy = pan_x * n, pan_y * n
         if cut_at is not None and n >= cut_at:
             base, tex = base2, tex2
         tx, ty = dx % 64, dy % 64      # the texture window wraps after 21 frames (identical to the published definition before that)
         Y = np.roll(np.roll(base, dx, axis=1), dy, axis=0) + tex[ty:ty + height, tx:tx + width]
-        bx, by = 200 + 11 * n, 300 + 7 * n
-        if by < height and bx < width:
+        bx, by = box_x + box_dx * n, box_y + box_dy * n
+        if 0 <= by < height and 0 <= bx < width:
             bh, bw = min(160, height - by), min(240, width - bx)
             Y[by:by + bh, bx:bx + bw] = (200 - 0.2 * np.arange(240))[None, :bw]
         Y = np.clip(Y, 0, 255).astype(np.uint8)
