@@ -593,10 +593,10 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
         algo_bytes_frame = 1.5 * width * height * 3 + 2 * 1.5 * width * height
         achieved = S * algo_bytes_frame * len(timed) / (ctu_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed counter passes of this same command: TCC_EA0 requests by their width (64 / 128-byte reads, 64-byte full-line and 32-byte
-        # partial-line writes; calibrated on known byte counts, profiles/r03_tcc_calibration.json, as MI355X_MICROARCH.md "HBM" asks for narrow accesses)
+        # partial-line writes; calibrated on known byte counts, profiles/r04_tcc_calibration.json, as MI355X_MICROARCH.md "HBM" asks for narrow accesses)
         traffic, issue = None, None
         kernel_name = "k_encode_pool"
-        tpath = os.path.join(ROOT, "profiles", "r03_pmc_kernels.json")
+        tpath = os.path.join(ROOT, "profiles", "r04_pmc_kernels.json")
         if os.path.exists(tpath) and workload == "cfg2-1080p-encode":
             pm = json.load(open(tpath))
             k, frames_profiled = pm.get(kernel_name), pm.get("frames_encoded_by_k_encode_pool")
@@ -617,7 +617,7 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
                          "wave_instructions_per_frame": int(sum(k.get(c, 0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_FLAT", "SQ_INSTS_SMEM")) / frames_profiled),
                          "issue_cycles_over_worker_cycles": round(4 * sum(k.get(c, 0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_FLAT", "SQ_INSTS_SMEM")) / frames_profiled
                                                                   / (512 * 2.4e9 / fps_kernel), 3),
-                         "source": "profiles/r03_pmc_kernels.json (rocprofv3 --pmc passes of this command), instruction counts per encoded frame x this run's frames/s of the kernel"}
+                         "source": f"profiles/r04_pmc_kernels.json (rocprofv3 --pmc passes of this command on the build of commit {pm.get('build_commit')}), instruction counts per encoded frame x this run's frames/s of the kernel"}
         digest = md5.hexdigest()
         per_clip = {}
         matches, checked = True, None

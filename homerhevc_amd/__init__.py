@@ -1,9 +1,8 @@
 """homerhevc_amd - MI355X (gfx950) backend for HomerHEVC's per-block encode hot path.
 
 The product is `libhomer_gpu.so` (hand-written HIP kernels behind the C ABI of include/homer_gpu.h);
-this package is the thin Python host side: the build recipe (build.py), the engine-per-GPU ring bench.py --gpus N runs
-(engines.py), a ctypes mirror of the reference's `low_level_funcs_t` table (lowlevel.py) and the batched / frame-level
-kernel driver the round-1 kernel tests and tools/bench_callmix.py use (gpu.py).
+this package is the thin Python host side: the build recipe (build.py) and the engine-per-GPU ring bench.py --gpus N runs
+(engines.py).  (The ctypes mirror of the batched kernel ABI that the kernel tests use is test infrastructure: tests/gpu_abi.py.)
 There is no CPU fallback: importing works anywhere, calling a kernel without the native library or
 without a GPU raises.
 """

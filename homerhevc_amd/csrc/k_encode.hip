@@ -105,7 +105,7 @@ constexpr int WORKERS_PER_CU = LDS_BYTES <= 80 * 1024 ? 2 : 1;
 __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 {
 	WaveGrp g{(int)(threadIdx.x & 63)};
-	Enc e = {};   // (a context struct shared in LDS instead of one per lane in private memory was tried: the kernel hangs, cause not found)
+	Enc e = {};
 	for (int seq = 1;; seq++) {
 		while (__hip_atomic_load(&box->cmd[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) __builtin_amdgcn_s_sleep(1);   // (two workgroups share a CU now: a helper that spins takes issue cycles from the other workgroup's worker on its SIMD)
 		const int job = box->job[h];
@@ -690,23 +690,6 @@ __global__ __launch_bounds__(64) void k_sched_finish(EncDev d)
 	}
 }
 
-// side-info of the CTUs (z-order per CTU) -> the raster unit arrays the frame filters read (hmr_gpu_units, homer_gpu.h section 4)
-__global__ __launch_bounds__(256) void k_units_from_ctuinfo(const CtuInfo *ctus, const Geo *geo, int wctu, int units_stride, int16_t *mvx, int16_t *mvy, int8_t *ref, uint8_t *qp,
-							      uint8_t *flags, uint8_t *pred_depth, uint8_t *tr_idx)
-{
-	const int n = blockIdx.x, a = threadIdx.x;
-	const CtuInfo &c = ctus[n];
-	const int r = geo[NNODES - NPART + a].raster_index;   // the 256 depth-4 nodes are the units in z-order
-	const size_t o = (size_t)((n / wctu) * 16 + r / 16) * units_stride + (n % wctu) * 16 + r % 16;
-	mvx[o] = (int16_t)c.mv_ref[a].x;
-	mvy[o] = (int16_t)c.mv_ref[a].y;
-	ref[o] = c.mv_ref_idx[a];
-	qp[o] = c.qp[a];
-	flags[o] = (uint8_t)((c.pred_mode[a] == PM_INTRA ? HMR_GPU_UNIT_INTRA : 0) | (((c.cbf[0][a] >> c.tr_idx[a]) & 1) ? HMR_GPU_UNIT_CBF_Y : 0));
-	pred_depth[o] = c.pred_depth[a];
-	tr_idx[o] = c.tr_idx[a];
-}
-
 // host 8-bit planes -> int16 device planes (sse_copy_8_16 at frame entry, hmr_encoder_lib.c:295-305)
 __global__ void k_widen_plane(const uint8_t *src, int w, int h, int16_t *dst, int stride)
 {
@@ -749,111 +732,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
 		}
 	}
 }
-// ---- SAO parameter decision on the device (enc/enc_sao.h): what it needs from the entropy coder is the walk of two contexts through the SAO syntax of each
-// sub-stream, so it runs here, behind the statistics and the candidate offsets (k_saooffsets.hip) and in front of the offset pass, with no host in the chain.
-// One wavefront; lane r owns CTU row r and the rows advance as the WPP wavefront (CTU (r, c) at step c + 2 r): a CTU needs the parameters of its left and
-// above neighbours, and a row starts from the contexts the row above had after its second CTU (hmr_encoder_lib.c:2368-2373).  Without WPP lane 0 walks alone.
-struct SaoCandFromDevice {
-	const int32_t *offsets, *aux;   // [3][5][32], [3][5] of the CTU (hmr_gpu_sao_offsets_frame)
-	const long long *dist;          // [3][5]
-	__device__ int64_t get(int comp, int type, SaoOffset &t) const
-	{
-		const int32_t *o = offsets + (comp * 5 + type) * 32;
-		for (int k = 0; k < 32; k++) t.offset[k] = o[k];
-		t.type_aux = aux[comp * 5 + type];
-		return dist[comp * 5 + type];
-	}
-};
-struct SaoDecideArgs {
-	CtuInfo *ctus;
-	const int32_t *stats, *offsets, *aux;
-	const long long *dist;
-	double lambdas[3];
-	int W, H, wpp, st_merge, st_type;
-	const int32_t *entropy_bits;
-	const uint8_t *next_lps;
-	int32_t *params;                // [ctu][3][34] for the offset pass: mode, type, 32 offsets
-	uint8_t *saved;                 // [H][2] scratch: the two contexts after the second CTU of each row
-};
-__device__ void sao_decide_one(const SaoDecideArgs &a, int r, int c, SaoContexts &cur)
-{
-	const int n = r * a.W + c;
-	CtuPublic &ci = a.ctus[n];
-	const SaoTables T = {a.entropy_bits, a.next_lps};
-	const SaoCandFromDevice cand = {a.offsets + (size_t)n * 480, a.aux + (size_t)n * 15, a.dist + (size_t)n * 15};
-	sao_decide(T, cur.st_merge, cur.st_type, cand, *(const SaoStats *)(a.stats + (size_t)n * 960), c > 0 ? a.ctus[n - 1].sao_recon : nullptr,
-		   r > 0 ? a.ctus[n - a.W].sao_recon : nullptr, a.lambdas, ci.sao_coded, ci.sao_recon);
-	code_sao_blk_param(cur, ci.sao_coded, c > 0, r > 0);   // the real coder's two contexts move on through this CTU's SAO syntax
-	for (int k = 0; k < 3; k++) {
-		int32_t *p = a.params + ((size_t)n * 3 + k) * 34;
-		p[0] = ci.sao_recon[k].mode_idc;
-		p[1] = ci.sao_recon[k].type_idc;
-		for (int j = 0; j < 32; j++) p[2 + j] = ci.sao_recon[k].offset[j];
-	}
-}
-// One workgroup (one wavefront, its first lane working) per CTU row: the decision of a CTU is a long scalar computation with data-dependent branches, and rows
-// sharing a wavefront (lane = row, the first version) executed the union of each other's paths.  Rows advance as the WPP wavefront: CTU (r, c) needs the
-// parameters of (r - 1, c) for the merge-up candidate and row r starts from the contexts row r - 1 had after its second CTU - row r waits until row r - 1 has
-// published c + 2 CTUs (or all of them).  Workgroups are dispatched in row order, so the row a workgroup waits for is always running or done.
-__device__ __forceinline__ void sao_decide_rows(const SaoDecideArgs &a, int *progress, int r)
-{
-	SaoContexts cur = {(uint8_t)a.st_merge, (uint8_t)a.st_type, a.next_lps};
-	if (!a.wpp) {
-		if (r == 0)
-			for (int n = 0; n < a.W * a.H; n++) sao_decide_one(a, n / a.W, n % a.W, cur);
-		return;
-	}
-	if (r >= a.H) return;
-	for (int c = 0; c < a.W; c++) {
-		if (r > 0) {
-			const int need = c + 2 < a.W ? c + 2 : a.W;
-			while (__hip_atomic_load(&progress[r - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(4);
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-			if (c == 0) { cur.st_merge = a.saved[2 * (r - 1)]; cur.st_type = a.saved[2 * (r - 1) + 1]; }
-		}
-		sao_decide_one(a, r, c, cur);
-		if (c == 1 || a.W == 1) { a.saved[2 * r] = cur.st_merge; a.saved[2 * r + 1] = cur.st_type; }
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-		__hip_atomic_store(&progress[r], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	}
-}
-__global__ __launch_bounds__(64) void k_sao_decide(SaoDecideArgs a, int *progress)
-{
-	if (threadIdx.x != 0) return;
-	sao_decide_rows(a, progress, (int)blockIdx.x);
-}
-// The pictures of a batch in one launch: a workgroup per picture, a THREAD per CTU row, the rows advancing in lockstep as the WPP wavefront (row r decides CTU
-// t - 2 r at step t, a barrier between the steps).  The threads of a wavefront execute the union of their rows' branches, which makes a picture take about as long
-// as with a workgroup per row (3.6 ms against 2.5 at 1080p) - but a workgroup per row and picture, 3060 of them spinning on each other's progress with an
-// agent-scope fence per CTU, took 20 ms for the 180 pictures of a batch, and as a launch per picture the sequences queued up eleven deep on the hardware queues.
-struct SaoDecideJob {
-	SaoDecideArgs a;
-	int *progress;
-	int enabled, pad_;
-};
-__global__ __launch_bounds__(256) void k_sao_decide_batch(const SaoDecideJob *jobs)      // (256 threads = 256 CTU rows = 16384 lines; 1024 would cap the decision at 128 registers: 2000 spills)
-{
-	const SaoDecideJob &j = jobs[blockIdx.x];
-	if (!j.enabled) return;
-	const SaoDecideArgs &a = j.a;
-	const int r = (int)threadIdx.x;
-	SaoContexts cur = {(uint8_t)a.st_merge, (uint8_t)a.st_type, a.next_lps};
-	if (!a.wpp) {
-		if (r == 0)
-			for (int n = 0; n < a.W * a.H; n++) sao_decide_one(a, n / a.W, n % a.W, cur);
-		return;
-	}
-	for (int t = 0; t < a.W + 2 * (a.H - 1); t++) {
-		const int c = t - 2 * r;
-		if (r < a.H && c >= 0 && c < a.W) {
-			if (c == 0 && r > 0) { cur.st_merge = a.saved[2 * (r - 1)]; cur.st_type = a.saved[2 * (r - 1) + 1]; }
-			sao_decide_one(a, r, c, cur);
-			if (c == 1 || a.W == 1) { a.saved[2 * r] = cur.st_merge; a.saved[2 * r + 1] = cur.st_type; }
-		}
-		__threadfence_block();
-		__syncthreads();   // the rows' results of this step are in memory before the next step reads them
-	}
-}
 
 // page-locked host memory for what comes back from the device every frame (records and levels: 11 MB per 1080p frame; a pageable target is copied through a
 // staging buffer at a fraction of the link's rate)
@@ -893,9 +771,14 @@ struct PlanePool {
 		}
 		PlaneSet p;
 		p.device = device; p.bytes_y = by; p.bytes_c = bc;
-		HIP_TRY(hipMalloc((void **)&p.y, by));
-		HIP_TRY(hipMalloc((void **)&p.c[0], bc));
-		HIP_TRY(hipMalloc((void **)&p.c[1], bc));
+		if (hipMalloc((void **)&p.y, by) != hipSuccess || hipMalloc((void **)&p.c[0], bc) != hipSuccess || hipMalloc((void **)&p.c[1], bc) != hipSuccess) {
+			(void)hipGetLastError();
+			if (p.y) (void)hipFree(p.y);
+			if (p.c[0]) (void)hipFree(p.c[0]);
+			if (p.c[1]) (void)hipFree(p.c[1]);
+			hmr_set_error("phase planes: out of device memory (%zu bytes per picture)", by + 2 * bc);
+			return HMR_GPU_ERR_HIP;
+		}
 		*out = p;
 		return HMR_GPU_OK;
 	}
@@ -903,6 +786,20 @@ struct PlanePool {
 	{
 		std::lock_guard<std::mutex> lk(m);
 		free_sets.push_back(p);
+	}
+	// the pool keeps the sets of destroyed encoders for the next ones (a batch of 180 sequences allocates 38 GB of them once); when the last encoder is gone they
+	// go back to the device
+	int live = 0;
+	void encoder_created() { std::lock_guard<std::mutex> lk(m); live++; }
+	void encoder_destroyed()
+	{
+		std::lock_guard<std::mutex> lk(m);
+		if (--live > 0) return;
+		for (PlaneSet &p : free_sets) {
+			(void)hipSetDevice(p.device);
+			(void)hipFree(p.y); (void)hipFree(p.c[0]); (void)hipFree(p.c[1]);
+		}
+		free_sets.clear();
 	}
 };
 PlanePool g_plane_pool;
@@ -940,14 +837,8 @@ struct hmr_gpu_enc {
 	int units_stride, units_rows;
 	int16_t *d_mvx, *d_mvy;
 	int8_t *d_ref;
-	uint8_t *d_qp, *d_flags, *d_pd, *d_ti;
-	int32_t *d_stats, *d_params;
+	uint8_t *d_qp, *d_flags;
 	uint8_t *d_public;                                 // the CTUs' side-info records, packed for the download
-	int32_t *d_sao_offsets, *d_sao_aux, *d_sao_bits;   // candidate offsets [ctu][3][5][32], band positions [ctu][3][5]; kEntropyBits
-	long long *d_sao_dist;                             // [ctu][3][5]
-	double *d_sao_lambdas;                             // [ctu][3]
-	uint8_t *d_sao_lps, *d_sao_saved;                  // kNextStateLps; [ctu rows][2]
-	int *d_sao_progress = nullptr;                     // [ctu rows] CTUs decided per row (k_sao_decide)
 	// host side of the entropy stage
 	std::vector<uint8_t, PinnedAlloc<uint8_t>> h_public;
 	std::vector<int16_t, PinnedAlloc<int16_t>> h_coeff;
@@ -974,7 +865,6 @@ struct hmr_gpu_enc {
 	double acc_pending = 0;
 	hipEvent_t ev_packed = nullptr;                      // its records and levels are in the staging buffer
 	hipEvent_t ev_decided = nullptr;                     // (lead) the batch's SAO decisions are made
-	void *d_sao_jobs = nullptr;                          // (lead) k_sao_decide_batch's job array
 	FrameCtx *d_frames = nullptr, *h_frames = nullptr;   // (lead) the frame parameters of a batch's pictures, on the device and page-locked on the host
 	EncDev *h_devs = nullptr;                            // (lead) their EncDev records, page-locked
 	hipStream_t plane_stream[2] = {nullptr, nullptr};    // (lead) side streams for the chroma phase planes of a batch
@@ -1283,6 +1173,7 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 		return HMR_GPU_ERR_ARG;
 	}
 	if (e->cfg.bitrate_mode != 0) host_rc_init(e->cfg, e->seq, e->st);
+	g_plane_pool.encoder_created();      // (hmr_gpu_enc_destroy - also the guard's - takes it back)
 	struct Guard {               // a failure further down (HIP_TRY / DEV_ALLOC return) frees what has been allocated so far
 		hmr_gpu_enc *e;
 		bool ok = false;
@@ -1385,20 +1276,8 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 	e->units_rows = s.hctu * 16;
 	const size_t nu = (size_t)e->units_stride * e->units_rows;
 	DEV_ALLOC(e->d_mvx, nu); DEV_ALLOC(e->d_mvy, nu); DEV_ALLOC(e->d_ref, nu); DEV_ALLOC(e->d_qp, nu);
-	DEV_ALLOC(e->d_flags, nu); DEV_ALLOC(e->d_pd, nu); DEV_ALLOC(e->d_ti, nu);
-	DEV_ALLOC(e->d_stats, (size_t)s.nctu * 3 * 5 * 2 * 32);
-	DEV_ALLOC(e->d_params, (size_t)s.nctu * 3 * 34);
+	DEV_ALLOC(e->d_flags, nu);
 	DEV_ALLOC(e->d_public, sizeof(CtuPublic) * s.nctu);
-	DEV_ALLOC(e->d_sao_offsets, (size_t)s.nctu * 480);
-	DEV_ALLOC(e->d_sao_aux, (size_t)s.nctu * 15);
-	DEV_ALLOC(e->d_sao_dist, (size_t)s.nctu * 15);
-	DEV_ALLOC(e->d_sao_lambdas, (size_t)s.nctu * 3);
-	DEV_ALLOC(e->d_sao_bits, 128);
-	DEV_ALLOC(e->d_sao_lps, 128);
-	DEV_ALLOC(e->d_sao_saved, (size_t)s.hctu * 2);
-	DEV_ALLOC(e->d_sao_progress, s.hctu);
-	HIP_TRY(hipMemcpy(e->d_sao_bits, kEntropyBits, sizeof kEntropyBits, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(e->d_sao_lps, kNextStateLps, sizeof kNextStateLps, hipMemcpyHostToDevice));
 	e->h_public.resize(sizeof(CtuPublic) * s.nctu);
 	e->h_coeff.resize((size_t)6144 * s.nctu);
 	e->h_stats.resize((size_t)s.nctu * 3 * 5 * 2 * 32);
@@ -1568,7 +1447,6 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	if (e->ev_batch1) (void)hipEventDestroy(e->ev_batch1);
 	if (e->ev_packed) (void)hipEventDestroy(e->ev_packed);
 	if (e->ev_decided) (void)hipEventDestroy(e->ev_decided);
-	if (e->d_sao_jobs) (void)hipFree(e->d_sao_jobs);
 	if (e->d_frames) (void)hipFree(e->d_frames);
 	if (e->h_frames) (void)hipHostFree(e->h_frames);
 	if (e->h_devs) (void)hipHostFree(e->h_devs);
@@ -1585,8 +1463,7 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	if (e->h_stage) (void)hipHostFree(e->h_stage);
 	void *p[] = {e->d_seq, e->d_frame, e->d_geo, e->d.ctus, e->d.ctus_start, e->d.work_slow, e->d.coeff, e->d.progress, e->d.prefix, e->d.prof, e->d.guess, e->d.truth, e->d.outtok,
 		     e->d.chain_start, e->d.chain_end, e->d.valid, e->d.dirty, e->d.hash, e->d.intra_before, e->d.used_intra, e->d.used_parts, e->d.counters, e->d.rowstate, e->d.thread_seen, e->d.row0_checked, e->d_bytes, e->d_mvx,
-		     e->d_mvy, e->d_ref, e->d_qp, e->d_flags, e->d_pd, e->d_ti, e->d_stats, e->d_params, e->d_sao_offsets, e->d_sao_aux, e->d_sao_dist, e->d_sao_lambdas, e->d_sao_bits,
-		     e->d_sao_lps, e->d_sao_saved, e->d_sao_progress, e->d_public};
+		     e->d_mvy, e->d_ref, e->d_qp, e->d_flags, e->d_public};
 	for (void *q : p) (void)hipFree(q);
 	for (int c = 0; c < 3; c++) {
 		(void)hipFree(e->d_pic[0][c]);
@@ -1601,6 +1478,7 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 	for (auto &sl : e->src)
 		for (int c = 0; c < 3; c++) (void)hipFree(sl.p[c]);
 	delete e;
+	g_plane_pool.encoder_destroyed();
 }
 
 // profiling build (-DHENC_POST_PROFILE): s_memtime ticks per part of the post-decision stage since the encoder was created (enc_post.h PostProf), 16 entries

@@ -1,4 +1,5 @@
-"""Host-side driver over the batched / frame-level C ABI (include/homer_gpu.h layers 1, 3, 4).
+"""Test-side ctypes mirror of the batched / frame-level C ABI (include/homer_gpu.h layers 1, 3, 4): descriptor layouts and a thin driver for the kernel tests and
+the legacy tools (tools/legacy).  Not part of the product package.
 
 Device memory is owned by the caller (torch tensors in bench.py, hmr_gpu_malloc in tests); this module only
 marshals pointers.  Everything here fails loudly when the native library or the GPU is missing.
@@ -7,7 +8,12 @@ import ctypes as C
 
 import numpy as np
 
-from .lowlevel import load_library
+import libs
+
+
+def load_library():
+    return libs.load_gpu()
+
 
 JOB_DTYPE = np.dtype([("a_off", "<u4"), ("a_stride", "<u4"), ("b_off", "<u4"), ("b_stride", "<u4"), ("c_off", "<u4"), ("c_stride", "<u4"),
                       ("w", "<u2"), ("h", "<u2"), ("p0", "<u4"), ("p1", "<u4")])

@@ -12,7 +12,7 @@ import libs
 from kernel_cases import quant_depth
 
 sys.path.insert(0, libs.ROOT)
-from homerhevc_amd import gpu as gpu_host  # noqa: E402  (descriptor layouts of include/homer_gpu.h)
+import gpu_abi as gpu_host  # noqa: E402  (descriptor layouts of include/homer_gpu.h)
 
 pytestmark = pytest.mark.gpu
 

@@ -10,7 +10,7 @@ import libs
 import trace_cases as tc
 
 sys.path.insert(0, libs.ROOT)
-from homerhevc_amd import gpu as gh  # noqa: E402
+import gpu_abi as gh  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 VP = C.c_void_p

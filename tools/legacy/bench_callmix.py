@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/bench_callmix.py - round 1's call-mix replay, kept as a KERNEL-LEVEL measurement tool (per-launch algorithmic rates of the batched
+"""tools/legacy/bench_callmix.py - round 1's call-mix replay, kept as a KERNEL-LEVEL measurement tool (per-launch algorithmic rates of the batched
 table kernels).  It is not the bench: a replay has no data dependencies between launches, the real encode does.  bench.py at the repo
 root times the real cfg-2 encode through hmr_gpu_enc_encode.
 
@@ -44,8 +44,9 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))      # gpu_abi.py: the ctypes mirror of the batched ABI
 
 W, H = 1920, 1080
 HA = 1088                      # CTU-aligned height
@@ -93,13 +94,13 @@ class Arena:
         return off
 
 
-from homerhevc_amd.gpu import (CHROMA_JOB_DTYPE, INTER_TU_JOB_DTYPE, INTRA_JOB_DTYPE, ITU_JOB_DTYPE, ITU_MODE_FROM_SEARCH, ME_JOB_DTYPE, TREE_JOB_DTYPE, TREE_NO_PARENT,  # noqa: E402
+from gpu_abi import (CHROMA_JOB_DTYPE, INTER_TU_JOB_DTYPE, INTRA_JOB_DTYPE, ITU_JOB_DTYPE, ITU_MODE_FROM_SEARCH, ME_JOB_DTYPE, TREE_JOB_DTYPE, TREE_NO_PARENT,  # noqa: E402
                                TU_JOB_DTYPE)
 
 
 def build_groups(calls, rng, arena, fused=True, cu_driver=False, cu_rounds=True, chroma_driver=True, inter_source=True):
     """Turn the recorded call mix into batched launches.  Returns list of dict(name, fn, size, jobs, args, bytes)."""
-    from homerhevc_amd.gpu import JOB_DTYPE
+    from gpu_abi import JOB_DTYPE
 
     # Data layout follows the reference (SURVEY.md §8 header, hmr_encoder_lib.c:1343-1395): per-CTU working windows - source CTU
     # (curr_mbs_wnd), prediction, residual, reconstruction at pitch 64, sub-pel / intermediate windows at pitch 80 - plus the
@@ -864,7 +865,7 @@ def main():
     import torch
     import torch.distributed as dist
     from homerhevc_amd.engines import exchange_reference
-    from homerhevc_amd.gpu import Context, Frame, Units
+    from gpu_abi import Context, Frame, Units
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

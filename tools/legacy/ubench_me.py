@@ -3,10 +3,11 @@
 import ctypes as C
 import sys, os
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))      # gpu_abi.py: the ctypes mirror of the batched ABI
 import bench_callmix as bench
-from homerhevc_amd.gpu import Context
+from gpu_abi import Context
 import torch
 
 def main():
