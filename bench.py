@@ -458,6 +458,7 @@ def run_engine_ring(a, world, rank, local, torch):
     ring.load_sources(ec.clip_frames(width, height, nframes))
     gold = REFERENCE_MD5.get(name, {}).get("au_md5", [])
     bad, checked, produced = [0], [0], [0]
+    first_bad = []
 
     kept = []
 
@@ -475,7 +476,13 @@ def run_engine_ring(a, world, rank, local, torch):
             produced[0] += 1
             if f < len(gold):
                 checked[0] += 1
-                bad[0] += hashlib.md5(au).hexdigest() != gold[f]
+                if os.environ.get("HOMER_BENCH_DUMP_UNITS") and f in (1, 2, 3, 4):      # (debugging aid: the access units of a few frames, all sequences, every rank)
+                    os.makedirs(os.environ["HOMER_BENCH_DUMP_UNITS"], exist_ok=True)
+                    open(os.path.join(os.environ["HOMER_BENCH_DUMP_UNITS"], f"au_f{f}_s{s}_{'ok' if hashlib.md5(au).hexdigest() == gold[f] else 'BAD'}.bin"), "wb").write(au)
+                if hashlib.md5(au).hexdigest() != gold[f]:
+                    bad[0] += 1
+                    if len(first_bad) < 6:
+                        first_bad.append({"rank": rank, "sequence": s, "frame": f, "bytes": len(au)})
     t = torch.tensor([bad[0], checked[0], produced[0]], dtype=torch.int64, device="cpu" if adapter.host_exchange else "cuda")
     dist.all_reduce(t)
     bad_all, checked_all, produced_all = (int(x) for x in t.tolist())
@@ -493,6 +500,7 @@ def run_engine_ring(a, world, rank, local, torch):
                            "their download and entropy coding under that call's CTU launch); every pipeline empty when the timed region starts and flushed inside it" if adapter.pipelined
                            else "hmr_gpu_enc_encode_batch"},
         "stream_matches_reference": bool(checked_all > 0 and bad_all == 0), "access_units_checked_against_reference": checked_all, "access_units_produced": produced_all,
+        "access_units_differing": bad_all, "first_differences_on_rank_0": first_bad,
         "exchange": {"bytes_per_sequence_and_step": row_bytes, "bytes_per_rank_and_step": row_bytes * a.sequences, "collective": "ring of point-to-point transfers (batch_isend_irecv), no reduction"},
         "roofline": None, "cpu_baseline": None,
     }

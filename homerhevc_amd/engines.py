@@ -106,6 +106,17 @@ class EngineRing:
             ops.append(dist.P2POp(dist.irecv, self.recv_buf[:n_in], prv))
         for r in dist.batch_isend_irecv(ops):
             r.wait()
+        if os.environ.get("HOMER_RING_TRACE") and not self.recv_buf.is_cuda:      # debugging aid: checksums of what left and what arrived (host buffers only)
+            import zlib
+            with open(os.path.join(os.environ["HOMER_RING_TRACE"], f"ring_rank{self.rank}.txt"), "a") as f:
+                for i in range(n_out):
+                    row = self.send_buf[i].numpy().tobytes()
+                    rb = self.a.ref_bytes
+                    y, c = rb * 2 // 3, rb // 6
+                    f.write(f"sent frame {frame} row {i} to {nxt} crc {zlib.crc32(row):08x} y {zlib.crc32(row[:y]):08x} u {zlib.crc32(row[y:y + c]):08x} v {zlib.crc32(row[y + c:rb]):08x} "
+                            f"state {row[rb:rb + self.a.state_bytes].hex()[:400]}\n")
+                for i in range(n_in):
+                    f.write(f"recv frame {frame} row {i} from {prv} crc {zlib.crc32(self.recv_buf[i].numpy().tobytes()):08x}\n")
         # r.wait() orders torch's current stream behind the transfer, not the host: the library reads / writes these buffers on streams of its own
         if self.recv_buf.is_cuda:
             torch.cuda.current_stream(self.recv_buf.device).synchronize()
@@ -177,14 +188,21 @@ class GpuEngines:
         shape = (max(rows, 1), self.row_bytes)
         if self.host_exchange:
             return torch.zeros(shape, dtype=torch.uint8).pin_memory()
-        return torch.zeros(shape, dtype=torch.uint8, device=f"cuda:{self.device}")
+        return self._zeros_on_device(shape)
+
+    def _zeros_on_device(self, shape):
+        """a zeroed device buffer the LIBRARY will write through its raw pointer: torch fills it on its own stream, which the library's (non-blocking) streams do
+        not wait for - the fill has to be over before the pointer is handed out, or it can land on top of the first pictures written there"""
+        t = torch.zeros(shape, dtype=torch.uint8, device=f"cuda:{self.device}")
+        torch.cuda.current_stream(t.device).synchronize()
+        return t
 
     def _device_rows(self, buf):
         if buf.is_cuda:
             return buf
         key = tuple(buf.shape)
         if key not in self.scratch:
-            self.scratch[key] = torch.zeros(key, dtype=torch.uint8, device=f"cuda:{self.device}")
+            self.scratch[key] = self._zeros_on_device(key)
         return self.scratch[key]
 
     def load_source(self, h, frame, planes):

@@ -51,6 +51,7 @@ CASES = [
     ("416x240_eng2", 416, 240, 10, {"engines": 2}),
     ("416x240_eng3_wpp_rows", 416, 240, 10, {"engines": 3, "wpp": 4}),
     ("832x480_eng2_wpp_rows", 832, 480, 6, {"engines": 2, "wpp": 8}),
+    ("416x240_eng4_wpp_rows", 416, 240, 14, {"engines": 4, "wpp": 4}),
     ("416x240_scene_cut_eng2_wpp_rows", 416, 240, 27, {"cut_at": 23, "engines": 2, "wpp": 4}),
     ("1920x1080_cfg2_eng2", 1920, 1080, 8, {"engines": 2, "wpp": 17}),
     ("1920x1080_cfg2_eng3", 1920, 1080, 8, {"engines": 3, "wpp": 17}),

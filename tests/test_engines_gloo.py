@@ -1,4 +1,4 @@
-"""Engine per rank on CPU: world_size 2 and 3 over gloo.  homerhevc_amd.engines.EngineRing - the code bench.py --gpus N runs over RCCL - deals the frames
+"""Engine per rank on CPU: world_size 2, 3 and 4 over gloo.  homerhevc_amd.engines.EngineRing - the code bench.py --gpus N runs over RCCL - deals the frames
 of several sequences to the ranks (frame t of sequence s on rank (s + t) mod E), every rank encodes its frames with an engine object of its own and hands the
 reconstructed picture and the frame-to-frame scalars to the next rank.  Here the engine behind the adapter is the one-lane checker build
 (oracle/libenc_cpu.so, test infrastructure); the streams that come out must be the ones the compiled reference produces with num_enc_engines = E under
@@ -86,7 +86,7 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("case,world,sequences,port", [("416x240_eng2", 2, 3, 29641), ("416x240_eng3_wpp_rows", 3, 2, 29643)])
+@pytest.mark.parametrize("case,world,sequences,port", [("416x240_eng2", 2, 3, 29641), ("416x240_eng3_wpp_rows", 3, 2, 29643), ("416x240_eng4_wpp_rows", 4, 5, 29647)])
 def test_engine_ring_reproduces_the_reference_engine_stream(tmp_path, case, world, sequences, port):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "libenc_cpu.so")])
     script = tmp_path / "worker.py"

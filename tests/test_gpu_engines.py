@@ -14,9 +14,12 @@ import encoder_cases as ec
 
 pytestmark = pytest.mark.gpu
 GOLD = json.load(open(os.path.join(ec.GOLDEN, "streams.json")))
+# bench.py's fixtures hold the digest after every access unit: the first frames of its 1080p four-engine stream as one more case
+_B = json.load(open(os.path.join(ec.GOLDEN, "bench_md5.json")))["cfg2-1080p-encode-engines4"]
+GOLD["1920x1080_cfg2_eng4"] = {"width": 1920, "height": 1080, "frames": 9, "keys": _B["keys"], "stream_md5": _B["cumulative_md5"][8]}
 
 
-def run_ring(case, sequences, pipelined):
+def run_ring(case, sequences, pipelined, flush_after=None):
     from homerhevc_amd.engines import EngineRing, GpuEngines, engine_of
     g = GOLD[case]
     w, h, frames, keys = g["width"], g["height"], g["frames"], dict(g["keys"])
@@ -46,6 +49,11 @@ def run_ring(case, sequences, pipelined):
             for ring in rings:
                 ring.step_exchange(t)
             torch.cuda.synchronize()
+        if flush_after is not None and t == flush_after:      # (bench.py empties the pipelines between its warm-up and its timed steps)
+            for ring in rings:
+                for f, units in ring.flush():
+                    for s, au in units.items():
+                        aus[(s, f)] = au
     for ring in rings:
         for f, units in ring.flush():
             for s, au in units.items():
@@ -57,7 +65,14 @@ def run_ring(case, sequences, pipelined):
     return [hashlib.md5(b"".join(aus[(s, t)] for t in range(frames))).hexdigest() for s in range(sequences)], g["stream_md5"]
 
 
-@pytest.mark.parametrize("case,sequences,pipelined", [("832x480_eng2_wpp_rows", 3, False), ("416x240_eng3_wpp_rows", 4, True), ("1920x1080_cfg2_eng2", 2, True), ("1920x1080_cfg2_eng3", 3, False)])
+@pytest.mark.parametrize("case,sequences,pipelined", [("832x480_eng2_wpp_rows", 3, False), ("416x240_eng3_wpp_rows", 4, True), ("416x240_eng4_wpp_rows", 5, True), ("416x240_eng4_wpp_rows", 8, False), ("1920x1080_cfg2_eng2", 2, True), ("1920x1080_cfg2_eng3", 3, False), ("1920x1080_cfg2_eng4", 8, True)])
 def test_engine_ring_on_one_gpu_reproduces_the_reference_engine_stream(case, sequences, pipelined):
     md5s, gold = run_ring(case, sequences, pipelined)
+    assert md5s == [gold] * sequences
+
+
+@pytest.mark.parametrize("case,sequences,flush_after", [("416x240_eng4_wpp_rows", 8, 2), ("416x240_eng3_wpp_rows", 4, 3), ("832x480_eng2_wpp_rows", 3, 2)])
+def test_pipelines_emptied_in_the_middle_of_a_run(case, sequences, flush_after):
+    """bench.py flushes every rank's pipelines after the warm-up steps: the frames after that must not notice"""
+    md5s, gold = run_ring(case, sequences, True, flush_after)
     assert md5s == [gold] * sequences
