@@ -77,6 +77,11 @@ struct Enc {
 	uint32_t nb_ctus;         // which neighbour CTUs exist (bit 0 left, 1 top, 2 top right, 3 top left): CtuPublic::has_*, kept here because the record lives in HBM
 	unsigned long long *timeline;   // profiling build: the CTU's timestamps
 	int n_spec_reads, n_ratio_cmp, last_slog;
+	// RD_FULL (enc_rdo.h): the context states the bit estimates of this CTU copy (what the reference's et->ee holds when the CTU is decided), where the last luma
+	// estimate left the shadow CTU's luma-direction pointer (-1: at the CTU's own array), the counter's chroma direction context
+	const uint8_t *rd_ctx;
+	int rd_luma_depth;
+	uint32_t rd_chroma_state;
 	HENC_AT(Node, LDS_OFF_NODES) nodes;      // the CTU's partition nodes: ctu->nodes, or the worker's fast copy of them (nodes_fast != nullptr) while the CTU is encoded
 	Node *nodes_fast;
 	// helper wavefronts of the worker (device only; nullptr = everything runs on the group itself)

@@ -508,6 +508,11 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 	const int initial_depth = 0, initial_position = 0;
 	depth_state.set(0, initial_position);
 	e.w->thread_seen_intra = 1;   // (every lane stores the same value) hmr_motion_intra.c:1783: from now on this thread's shadow CTU reads "intra"
+	if (S.rd_mode == RDM_FULL) {      // motion_intra :1993: the shadow CTU starts as a copy of the CTU's descriptor (its side-info pointers at the CTU's arrays), all INTRA
+		bytes_set(g, e.w->rd_pred_mode, PM_INTRA, NPART);
+		e.rd_luma_depth = -1;
+		e.rd_chroma_state = 0;
+	}
 	while (curr_depth != initial_depth || depth_state.get(curr_depth) != initial_position + 1) {
 		const Geo &q = e.geo[curr];
 		Node *nd = &node_of(e, curr);

@@ -188,6 +188,11 @@ struct Cabac {
 		const uint32_t bin = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin_);
 		const int sh = (ci >> 6) * 8;
 		const uint32_t st = ((uint32_t)__builtin_amdgcn_readlane((int)cw, ci & 63) >> sh) & 255u;
+		if (counter) {      // (the counting coder: see the host version below)
+			frac_bits += (uint64_t)kEntropyBits[st ^ bin];
+			cw = my_lane == (uint32_t)(ci & 63) ? (cw & ~(255u << sh)) : cw;
+			return;
+		}
 		const uint32_t lps = ((uint32_t)__builtin_amdgcn_readlane((int)trw, (int)(st >> 1)) >> (((range >> 6) & 3) * 8)) & 255u;
 		uint32_t nst;
 		range -= lps;
@@ -307,21 +312,37 @@ struct Cabac {
 // ---- what the CTU syntax reads ---------------------------------------------------------------------------------------------------
 // The CTU's own side-info record (on the device: a copy in the worker's fast memory, written back where the delta-QP rules change it), the records of the
 // left and above CTUs where they exist, the CTU's levels, and the QP predictor that crosses the CTU boundary.
+// A CTU's side-info as the syntax functions read it: pointers to the arrays (a CTU record's own, or - for the bit estimates of the decision stage, enc_rdo.h -
+// the per-depth buffers of the CU under evaluation, which is what the reference's shadow CTU `ctu_rd` points at)
+struct CtuView {
+	const uint8_t *cbf[3], *intra_mode[2];
+	const uint8_t *inter_mode, *tr_idx, *pred_depth, *part_size_type, *pred_mode, *skipped, *merge, *merge_idx, *mv_diff_ref_idx;
+	uint8_t *qp;
+	const MV *mv_diff;
+	int x, y;
+};
+HENC_FI CtuView view_of(CtuPublic &c)
+{
+	CtuView v;
+	for (int k = 0; k < 3; k++) v.cbf[k] = c.cbf[k];
+	v.intra_mode[0] = c.intra_mode[0]; v.intra_mode[1] = c.intra_mode[1];
+	v.inter_mode = c.inter_mode; v.tr_idx = c.tr_idx; v.pred_depth = c.pred_depth; v.part_size_type = c.part_size_type; v.pred_mode = c.pred_mode;
+	v.skipped = c.skipped; v.merge = c.merge; v.merge_idx = c.merge_idx; v.mv_diff_ref_idx = c.mv_diff_ref_idx;
+	v.qp = c.qp;
+	v.mv_diff = c.mv_diff;
+	v.x = c.x; v.y = c.y;
+	return v;
+}
 struct EntView {
 	const Seq *seq;
 	const FrameCtx *f;
 	const DevTables *T;
 	GeoTable geo;
-	CtuPublic *c;                 // this CTU
-	const CtuPublic *left, *top;  // neighbours or nullptr
-	const int16_t *coeff;         // this CTU's levels: 4096 luma + 2 x 1024 chroma, linear per TU in z-order
+	const CtuView *c;             // this CTU
+	const CtuView *left, *top;    // neighbours or nullptr
+	const int16_t *coeff[3];      // the levels per component, linear per TU in z-order (a CTU's final levels: 4096 luma + 2 x 1024 chroma in one buffer)
 	int n;                        // CTU index
 	int prev_last_qp;             // QP of the last unit of the previous CTU of the sub-stream (get_last_coded_qp :1382), or -1: the slice QP
-};
-// scratch of the residual coder in the worker's fast memory: the TU's levels and their positions in scan order, the coefficient-group scan and flags
-struct EntScratch {
-	uint16_t cg[64];
-	uint8_t cg_flag[64];
 };
 // Position (y << shift | x) of the i-th coefficient of a (1 << shift)^2 block in coding order: the coefficient groups in the order `cg` gives (their raster
 // index in the grid of groups), the sixteen coefficients of a group in the 4 x 4 scan of the mode - horizontal: rows; vertical: columns; diagonal: up-right
@@ -344,13 +365,13 @@ struct DqpState {
 	int enabled, write_qp, ref_qp, found_coded;
 };
 
-HENC_INLINE const CtuPublic *ent_pu_left(const EntView &v, int ni, uint32_t *idx)
+HENC_INLINE const CtuView *ent_pu_left(const EntView &v, int ni, uint32_t *idx)
 {
 	const Geo &q = v.geo[ni];
 	*idx = q.abs_left;
 	return (q.raster_index & 15) == 0 ? v.left : v.c;
 }
-HENC_INLINE const CtuPublic *ent_pu_top(const EntView &v, int ni, uint32_t *idx, int planar)
+HENC_INLINE const CtuView *ent_pu_top(const EntView &v, int ni, uint32_t *idx, int planar)
 {
 	const Geo &q = v.geo[ni];
 	*idx = q.abs_top;
@@ -368,9 +389,9 @@ HENC_INLINE bool node_inside(const EntView &v, int ni)
 HENC_INLINE void ent_intra_preds(const EntView &v, int ni, int *p)
 {
 	uint32_t idx = 0;
-	const CtuPublic *l = ent_pu_left(v, ni, &idx);
+	const CtuView *l = ent_pu_left(v, ni, &idx);
 	const int ld = l ? (uni(l->pred_mode[idx]) == PM_INTRA ? uni(l->intra_mode[0][idx]) : DC_IDX) : DC_IDX;
-	const CtuPublic *t = ent_pu_top(v, ni, &idx, 1);
+	const CtuView *t = ent_pu_top(v, ni, &idx, 1);
 	const int td = t ? (uni(t->pred_mode[idx]) == PM_INTRA ? uni(t->intra_mode[0][idx]) : DC_IDX) : DC_IDX;
 	if (ld == td) {
 		if (ld > 1) { p[0] = ld; p[1] = ((ld + 29) % 32) + 2; p[2] = ((ld - 1) % 32) + 2; }
@@ -454,8 +475,8 @@ HENC_FI void encode_residual(const G &g, Cabac &ee, const EntView &v, EntScratch
 	const Geo &q = v.geo[pi];
 	const int size = is_luma ? q.size : q.size_chroma;
 	const int shift = is_luma ? CFG_MAX_CU_SHIFT - q.depth : CFG_MAX_CU_SHIFT - 1 - q.depth;
-	const int16_t *coeff = v.coeff + (comp == 0 ? 0 : (comp == 1 ? 4096 : 5120)) + (q.abs_index << (4 - (is_luma ? 0 : 2)));
-	const CtuPublic *c = v.c;
+	const int16_t *coeff = v.coeff[comp] + (q.abs_index << (4 - (is_luma ? 0 : 2)));
+	const CtuView *c = v.c;
 	const int num_part_in_pred_cu = NPART >> (uni(c->pred_depth[abs_index]) * 2);
 	const int scan_mode = find_scan_mode(uni(c->pred_mode[q.abs_index]) == PM_INTRA, is_luma, size, uni(c->intra_mode[is_luma ? 0 : 1][q.abs_index]),
 					     uni(c->intra_mode[0][(abs_index / num_part_in_pred_cu) * num_part_in_pred_cu]));
@@ -660,7 +681,7 @@ template <class G>
 HENC_FI void encode_transform_tree(const G &g, Cabac &ee, const EntView &v, EntScratch &sc, DqpState &dq, int top_ni)
 {
 	const Seq &S = *v.seq;
-	const CtuPublic *c = v.c;
+	const CtuView *c = v.c;
 	const int depth = v.geo[top_ni].depth, top_abs = v.geo[top_ni].abs_index;
 	int abs_index = top_abs;
 	int is_intra = uni(c->pred_mode[abs_index]) == PM_INTRA;
@@ -726,7 +747,7 @@ HENC_FI void encode_transform_tree(const G &g, Cabac &ee, const EntView &v, EntS
 	}
 }
 
-HENC_FI void encode_mvd(Cabac &ee, const CtuPublic *c, int idx)
+HENC_FI void encode_mvd(Cabac &ee, const CtuView *c, int idx)
 {
 	const int h = uni(c->mv_diff[idx].x), ver = uni(c->mv_diff[idx].y);
 	const int h0 = h != 0, v0 = ver != 0, ha = habs(h), va = habs(ver);
@@ -774,15 +795,15 @@ template <class G>
 HENC_FI void encode_coding_unit(const G &g, Cabac &ee, const EntView &v, EntScratch &sc, DqpState &dq, int ni)
 {
 	const Seq &S = *v.seq;
-	const CtuPublic *c = v.c;
+	const CtuView *c = v.c;
 	const Geo &q = v.geo[ni];
 	const int abs_index = q.abs_index, is_intra = uni(c->pred_mode[abs_index]) == PM_INTRA, part = uni(c->part_size_type[abs_index]);
 	const int p_slice = uni(v.f->slice_type) != SLICE_I;
 	uint32_t idx = 0;
 	if (p_slice) {
-		const CtuPublic *l = ent_pu_left(v, ni, &idx);
+		const CtuView *l = ent_pu_left(v, ni, &idx);
 		int ctx = l ? (uni(l->skipped[idx]) ? 1 : 0) : 0;
-		const CtuPublic *t = ent_pu_top(v, ni, &idx, 0);
+		const CtuView *t = ent_pu_top(v, ni, &idx, 0);
 		ctx += t ? (uni(t->skipped[idx]) ? 1 : 0) : 0;
 		ee.encode_bin(CTX_SKIP_FLAG + ctx, uni(c->skipped[abs_index]));
 	}
@@ -889,9 +910,9 @@ HENC_FI void encode_ctu_syntax(const G &g, Cabac &ee, const EntView &v, EntScrat
 			// encode_split_flag :391
 			uint32_t idx = 0;
 			const int split = uni(v.c->pred_depth[q.abs_index]) > q.depth;
-			const CtuPublic *l = ent_pu_left(v, curr, &idx);
+			const CtuView *l = ent_pu_left(v, curr, &idx);
 			int ctx = l ? (uni(l->pred_depth[idx]) > q.depth ? 1 : 0) : 0;
-			const CtuPublic *t = ent_pu_top(v, curr, &idx, 0);
+			const CtuView *t = ent_pu_top(v, curr, &idx, 0);
 			ctx += t ? (uni(t->pred_depth[idx]) > q.depth ? 1 : 0) : 0;
 			ee.encode_bin(CTX_SPLIT_FLAG + ctx, split);
 		}

@@ -4,6 +4,7 @@
 // for rd_mode != RD_FULL (BASELINE configs 1-4; the full-RDO bit estimators are a later row).
 #pragma once
 #include "enc_common.h"
+#include "enc_rdo.h"
 
 namespace henc {
 
@@ -85,8 +86,8 @@ HENC_INLINE void intra_neighbour_dirs(Enc &__restrict__ e, int ni, int depth, in
 // The walk of homer_loop1_motion_intra (hmr_motion_intra.c:1084-1180) over the prediction directions: planar / DC, five coarse
 // angles, +-2 / +-4 around the best, +-1 around that.  sad_of(mode) returns the SAD of a direction or a negative value when it is not
 // available (only the replay in enc_sched.h can fail).  Returns the bit cost of the winner, or -1.
-template <class SadsFn>
-HENC_INLINE int intra_search_walk_batched(const int *preds, int rd_fast, double sqrt_lambda, SadsFn &&sads_of, int *best_mode_out, double *best_cost_out)
+template <class SadsFn, class BitsFn>
+HENC_INLINE int intra_search_walk_batched(const int *preds, int rd_fast, double sqrt_lambda, SadsFn &&sads_of, int *best_mode_out, double *best_cost_out, BitsFn &&full_bits_of)
 {
 	static constexpr int search_points[4][5] = {{0, 1, 0, 8, 16}, {2, 10, 16, 22, 30}, {-4, -2, 2, 4, 0}, {-1, 1, 0, 0, 0}};
 	static constexpr int num_search_points[4] = {2, 5, 4, 2};
@@ -107,8 +108,11 @@ HENC_INLINE int intra_search_walk_batched(const int *preds, int rd_fast, double 
 			const int mode = modes[k];
 			double cost = (double)(uint32_t)sads[k];
 			int bit_cost = 0;
-			if (rd_fast) {
+			if (rd_fast == 1) {
 				bit_cost = (preds[0] == mode || preds[1] == mode || preds[2] == mode) ? 1 : 12;
+				cost += bit_cost * sqrt_lambda;
+			} else if (rd_fast == 2) {      // RD_FULL :1140: the counter's bits for a candidate direction, 6 for any other ("introduces some error but gives good results")
+				bit_cost = (preds[0] == mode || preds[1] == mode || preds[2] == mode) ? (int)full_bits_of(mode) : 6;
 				cost += bit_cost * sqrt_lambda;
 			}
 			if (cost < best_cost) { best_cost = cost; new_best = mode; best_bit_cost = bit_cost; }
@@ -128,7 +132,7 @@ HENC_INLINE int intra_search_walk(const int *preds, int rd_fast, double sqrt_lam
 			if (sads[k] < 0) return false;
 		}
 		return true;
-	}, best_mode_out, best_cost_out);
+	}, best_mode_out, best_cost_out, [](int) { return 0u; });
 }
 
 // what encode_intra_luma returns for rd_mode != RD_FULL: the transform tree's cost plus the mode bits (hmr_motion_intra.c:1625)
@@ -144,13 +148,14 @@ HENC_HD int intra_mode_search(const G &g, Enc &__restrict__ e, int ni, int depth
 	node_fill_refs(g, e, ni, depth + 1, COMP_Y, 1);
 	int preds[3], dirs[2];
 	uint16_t src[2];
+	e.rd_luma_depth = curr_depth;      // (homer_loop1_motion_intra :1103 aims the shadow CTU's luma directions at this depth's buffer "for rd")
 	intra_neighbour_dirs(e, ni, curr_depth, dirs, src);
 	mpm_from_dirs(dirs[0], dirs[1], preds);
-	const int rd_fast = e.seq->rd_mode == RDM_FAST;
+	const int rd_fast = e.seq->rd_mode == RDM_FAST ? 1 : (e.seq->rd_mode == RDM_FULL ? 2 : 0);      // (how the walk prices a direction)
 	// a search whose candidate list rests on a guess is logged (every lane writes the same values)
 	SearchLog *lg = nullptr;
 	e.last_slog = -1;
-	if (rd_fast && ((src[0] | src[1]) & 0x8000)) {
+	if (rd_fast == 1 && ((src[0] | src[1]) & 0x8000)) {
 		if (e.n_spec_reads < MAX_SEARCH_LOGS) {
 			lg = e.ctu_g->slog + e.n_spec_reads;
 			lg->src[0] = src[0]; lg->src[1] = src[1];
@@ -187,7 +192,21 @@ HENC_HD int intra_mode_search(const G &g, Enc &__restrict__ e, int ni, int depth
 				lg->n++;
 			}
 		return true;
-	}, best_mode_out, best_cost_out);
+	}, best_mode_out, best_cost_out, [&](int mode) { return rd_bits_luma_mode_in_preds(e, mode, preds); });
+}
+
+template <class G>
+HENC_HD void set_intra_info_buffs(const G &g, Enc &__restrict__ e, int depth, int ni)
+{
+	const Geo &q = e.geo[ni];
+	const Node &nd = node_of(e, ni);
+	Work &w = *e.w;
+	for (int i = g.tid; i < q.num_part; i += g.n) {
+		w.cbf_buffs[COMP_Y][depth][q.abs_index + i] = (uint8_t)nd.intra_cbf[COMP_Y];
+		w.tr_idx_buffs[depth][q.abs_index + i] = (uint8_t)nd.intra_tr_idx;
+		w.intra_mode_buffs[COMP_Y][depth][q.abs_index + i] = (uint8_t)nd.intra_mode[COMP_Y];
+	}
+	g.sync();
 }
 
 // encode_intra_cu, hmr_motion_intra.c:973-1071: one luma TU.  depth = prediction depth.  Returns the SSD, *curr_sum the level sum.
@@ -219,6 +238,7 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 	nd.intra_cbf[COMP_Y] = (sum ? 1 : 0) << tr;
 	nd.intra_tr_idx = tr;
 	nd.intra_mode[COMP_Y] = cu_mode;
+	if (e.seq->rd_mode == RDM_FULL) set_intra_info_buffs(g, e, curr_depth, ni);      // :1041: what the bit estimate of this node reads
 	if (sum) {
 		lin_copy_nosync(g, iquant, quant, n * n);
 		dequantize(g, HENC_FT(e), e.T, iquant, iquant, curr_depth, COMP_Y, 1, n, per, rem);
@@ -227,20 +247,6 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 	}
 	lin_zero_nosync(g, quant, n * n);
 	return blk_reconst_ssd(g, pred, CTU_STRIDE_Y, (const int16_t *)nullptr, 0, orig, CTU_STRIDE_Y, dec, DEC_STRIDE_Y, n);
-}
-
-template <class G>
-HENC_HD void set_intra_info_buffs(const G &g, Enc &__restrict__ e, int depth, int ni)
-{
-	const Geo &q = e.geo[ni];
-	const Node &nd = node_of(e, ni);
-	Work &w = *e.w;
-	for (int i = g.tid; i < q.num_part; i += g.n) {
-		w.cbf_buffs[COMP_Y][depth][q.abs_index + i] = (uint8_t)nd.intra_cbf[COMP_Y];
-		w.tr_idx_buffs[depth][q.abs_index + i] = (uint8_t)nd.intra_tr_idx;
-		w.intra_mode_buffs[COMP_Y][depth][q.abs_index + i] = (uint8_t)nd.intra_mode[COMP_Y];
-	}
-	g.sync();
 }
 
 // encode_intra_luma, hmr_motion_intra.c:1229-1630 (non-HM path): search, then the transform tree of the winner.
@@ -254,6 +260,12 @@ HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, i
 	int cu_mode;
 	double search_cost;
 	int bitcost_cu_mode;
+	const bool rd_full = S.rd_mode == RDM_FULL;
+	if (rd_full) {      // :1287: the shadow CTU's partition size and prediction depth of this CU
+		const Geo &tq = e.geo[top_ni];
+		bytes_set(g, &w.rd_part_size[tq.abs_index], part_size_type, tq.num_part);
+		bytes_set(g, &w.rd_pred_depth[tq.abs_index], depth - (part_size_type == PART_NxN), tq.num_part);
+	}
 	{ HENC_PROF_T0(); bitcost_cu_mode = intra_mode_search(g, e, top_ni, depth, &cu_mode, &search_cost); HENC_PROF_ADD(e, PF_INTRA_SEARCH); }
 
 	int parent, curr, initial_state, end_state;
@@ -292,6 +304,13 @@ HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, i
 		cn.distortion = encode_intra_tu(g, e, curr, depth, cu_mode, part_size_type, &curr_sum);
 		cn.sum = (uint32_t)curr_sum;
 		cn.cost = cn.distortion;
+		if (rd_full && (curr_depth < max_tr_processing_depth || curr_depth == depth)) {      // :1457: the node's syntax priced by the bit counter
+			RdViews rv;
+			e.rd_luma_depth = curr_depth;
+			rd_make_views(g, e, rv, curr_depth, curr_depth, nullptr, nullptr, 0, tq_ptr(w, curr_depth + 1, COMP_Y), nullptr, nullptr);
+			const uint32_t bit_cost = rd_get_intra_bits_qt(g, e, rv, curr, 1);
+			cn.cost += (uint32_t)(bit_cost * e.f->lambda + .5);
+		}
 		depth_state.inc(curr_depth);
 		if (curr_depth < max_tr_processing_depth) {
 			curr_depth++;
@@ -303,8 +322,14 @@ HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, i
 				Node &c0 = node_of(e, pq.child[0]), &c1 = node_of(e, pq.child[1]), &c2 = node_of(e, pq.child[2]), &c3 = node_of(e, pq.child[3]);
 				const uint32_t sum = c0.sum + c1.sum + c2.sum + c3.sum;
 				const double distortion = (double)c0.distortion + c1.distortion + c2.distortion + c3.distortion;
-				const double cost = distortion;
+				double cost = distortion;
 				depth_state.set(curr_depth, 0);
+				if (rd_full) {      // :1486: the parent's syntax with its four children as the transform split
+					RdViews rv;
+					rd_make_views(g, e, rv, curr_depth, curr_depth, nullptr, nullptr, 0, tq_ptr(w, curr_depth + 1, COMP_Y), nullptr, nullptr);
+					const uint32_t bit_cost = rd_get_intra_bits_qt(g, e, rv, parent, 1);
+					cost += (uint32_t)(bit_cost * e.f->lambda + .5);
+				}
 				bool take_children;
 				if (S.rd_mode != RDM_FAST) take_children = cost < pn.cost;
 				else take_children = 1.25 * (cost + (double)(uint32_t)(45u * sum)) < (double)(uint32_t)(pn.cost + 45u * pn.sum);
@@ -340,8 +365,15 @@ HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, i
 			}
 			if (curr_depth + 2 <= max_tr_processing_depth) {
 				const int aux = parent >= 0 ? e.geo[parent].child[(depth_state.get(curr_depth) + 3) & 3] : 0;
-				for (int aux_depth = curr_depth + 2; aux_depth <= max_tr_processing_depth; aux_depth++)
+				for (int aux_depth = curr_depth + 2; aux_depth <= max_tr_processing_depth; aux_depth++) {
 					sync_reference_buffs(g, e, aux, curr_depth + 1, aux_depth + 1);
+					if (rd_full) {      // :1577
+						const Geo &aq = e.geo[aux];
+						bytes_copy(g, &w.intra_mode_buffs[COMP_Y][depth][aq.abs_index], &w.intra_mode_buffs[COMP_Y][aux_depth][aq.abs_index], aq.num_part);
+						bytes_copy(g, &w.cbf_buffs[COMP_Y][depth][aq.abs_index], &w.cbf_buffs[COMP_Y][aux_depth][aq.abs_index], aq.num_part);
+						bytes_copy(g, &w.tr_idx_buffs[depth][aq.abs_index], &w.tr_idx_buffs[aux_depth][aq.abs_index], aq.num_part);
+					}
+				}
 			}
 		}
 	}
@@ -480,6 +512,13 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth,
 			distortion += sad_v[mi];
 			cost += distortion;
 			uint32_t bit_cost = mode_list[mi] == DM_CHROMA_IDX ? 1 : 12;
+			if (S.rd_mode == RDM_FULL) {      // hmr_motion_intra_chroma.c:228: the candidate goes into the depth's direction buffer and is priced by the counter
+				const Geo &sq = e.geo[curr];
+				bytes_set(g, &w.intra_mode_buffs[COMP_CHR][depth][sq.abs_index], mode_list[mi], sq.num_part);
+				RdViews rv;
+				rd_make_views(g, e, rv, depth, depth, nullptr, nullptr, depth, nullptr, nullptr, nullptr);
+				bit_cost = rd_bits_chroma_mode(e, rv.v, curr);
+			}
 			cost += (uint32_t)(bit_cost * e.f->sqrt_lambda + .5);
 			// homer_update_cand_list, hmr_motion_intra.c:893
 			int um = mode_list[mi];
@@ -587,7 +626,14 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth,
 			if (nxn) top = e.geo[top].parent;
 		}
 		cost = distortion;
-		if (cost < best_cost) {
+		if (S.rd_mode == RDM_FULL && cost < best_cost) {      // :417: the chroma syntax of the CU with the winner of the search
+			const Geo &tq = e.geo[top];
+			bytes_set(g, &w.intra_mode_buffs[COMP_CHR][depth][tq.abs_index], best_modes[0], tq.num_part);
+			RdViews rv;
+			rd_make_views(g, e, rv, depth, depth, w.cbf_chroma[0], w.cbf_chroma[1], depth, nullptr, tq_ptr(w, qwnd, COMP_U), tq_ptr(w, qwnd, COMP_V));
+			const uint32_t bits = rd_get_intra_bits_qt(g, e, rv, top, 0);
+			cost += (uint32_t)(bits * e.f->lambda + .5);
+		} else if (S.rd_mode != RDM_FULL && cost < best_cost) {
 			const double correction = calc_mv_correction(node_of(e, top).qp, e.f->avg_dist);
 			cost += (uint32_t)(bit_cost * correction + .5);
 		}

@@ -120,7 +120,8 @@ struct PostPic {
 	uint32_t *cumbits;         // [nctu] bits of the CTU's sub-stream up to and including the CTU (what hmr_bitstream_bitcount has grown by, :2366)
 	const double *sao_lambda;  // [52][2] the SAO Lagrange multipliers by the CTU's QP: luma, chroma (hmr_wpp_sao_ctu :1415-1430; pow() stays on the host)
 	int *errors;               // [0] a sub-stream ran out of room
-	const uint16_t *rc_need;   // rate control: [steps + 1][hctu] P tasks of each row the reference has run when the step starts (nullptr: fixed QP)
+	const uint16_t *rc_need;   // rate control / RD_FULL: [steps + 1][hctu] P tasks of each row the reference has run when the step starts (nullptr: neither)
+	uint8_t *ctx_after;        // RD_FULL: [nctu][RD_CTX_BYTES] the context states of the CTU's sub-stream after the CTU (what later decisions' bit estimates copy), or nullptr
 	unsigned long long *prof;  // profiling build (-DHENC_POST_PROFILE): ticks per part of the stage (PostProf), else unused
 	uint8_t *planes[3];        // device, overlapping frames of a sequence: the phase planes of the final picture (allocation start: k_subpel.hip's layout), written by
 	                           // task S(r, c) when the final samples around CTU (r, c) are there; nullptr: the planes are made by the frame kernels before the next frame
@@ -613,14 +614,17 @@ HENC_HDX void post_task_p(const G &g, const PostCtx &x, PostScratch &sc, int r, 
 	} else ee.load_ctx(g);
 	EntView v;
 	v.seq = x.seq; v.f = x.f; v.T = x.T; v.geo = x.geo;
-	v.c = &sc.c;
-	v.left = c > 0 ? home - 1 : nullptr;
-	v.top = r > 0 ? home - W : nullptr;
-	v.coeff = sc.coef;
+	const CtuView cv = view_of(sc.c), lv = view_of(*(c > 0 ? home - 1 : home)), tv = view_of(*(r > 0 ? home - W : home));
+	v.c = &cv;
+	v.left = c > 0 ? &lv : nullptr;
+	v.top = r > 0 ? &tv : nullptr;
+	v.coeff[0] = sc.coef; v.coeff[1] = sc.coef + 4096; v.coeff[2] = sc.coef + 5120;
 	v.n = n;
 	v.prev_last_qp = (n > 0 && !(S.wpp && c == 0)) ? uni((int)(home - 1)->qp[(home - 1)->last_valid_partition]) : -1;
 	encode_ctu_syntax(g, ee, v, sc.ent);
 	ee.store_ctx(g);
+	if (P.ctx_after)
+		for (int i = g.tid; i < CTX_TOTAL; i += g.n) P.ctx_after[(size_t)n * RD_CTX_BYTES + i] = sc.ctx[i];
 	const uint32_t bits = (uint32_t)(bw.bitcount() - bits_before);
 	if (S.bitrate_mode != 0) {      // the QPs the delta-QP rules rewrote (ee_encode_ctu :2091-2104): the next CTU's predictor reads them
 		g.sync();

@@ -192,6 +192,78 @@ inline void rc_coded_by(int W, int H, int sao, std::vector<int> &coded_by)
 		}
 	}
 }
+// ---- RD_FULL: which contexts a CTU's bit estimates copy (enc_rdo.h) -------------------------------------------------------------------------------------------
+// The estimates copy from et->ee, the coder object the WPP thread selected last (wfpp_encode_select_bitstream, hmr_encoder_lib.c:2299-2344): there are 2 T objects
+// in ee_list (T threads; :1096, created with all-zero states :1116-1121), thread i starts with ee_list[2 i] (:1439) and keeps its pointer across frames.  Selecting
+// CTU m of row R for coding: at the row's first CTU (R > 0) the slots 2 (R mod T) and 2 (R mod T) - 1 swap their objects - the second one holds the states the
+// row above saved after ITS second CTU (wfpp_encode_ctu :2368-2373, into slot 2 ((R - 1) mod T) + 1) - then the thread's pointer is the object in slot 2 (R mod T);
+// CTU 0 resets the object to the slice's initial states.  Coding CTU (R, x) leaves the object with the sub-stream's states after x + 1 CTUs.  So the content of any
+// object is "the states of sub-stream R of frame f after k CTUs" (or all-zero) - a version.  RdCtxSim replays a frame's sections in the synchronous-wavefront order
+// (decisions of a step, then the steps' sections by rows) and says which version every CTU's decisions see.
+struct RdCtxVersion {
+	int frame, row, k;      // frame < 0: the all-zero states the objects are created with; else sub-stream `row` of `frame` after `k` CTUs; k = 0: the slice's initial states
+};
+struct RdCtxSim {
+	int T = 0, W = 0, H = 0, sao = 0;
+	std::vector<int> slot, thread_ee;
+	std::vector<RdCtxVersion> obj;
+	void init(int threads, int wctu, int hctu, int sao_on)
+	{
+		T = threads; W = wctu; H = hctu; sao = sao_on;
+		slot.resize(2 * T);
+		thread_ee.resize(T);
+		obj.assign(2 * T, RdCtxVersion{-1, 0, 0});
+		for (int i = 0; i < 2 * T; i++) slot[i] = i;
+		for (int i = 0; i < T; i++) thread_ee[i] = 2 * i;
+	}
+	// src[n]: what CTU n's decisions copy in frame f
+	void frame(int f, std::vector<RdCtxVersion> &src)
+	{
+		const int total = W * H, num_ee = 2 * T, last = W + 2 * (H - 1);
+		src.assign(total, RdCtxVersion{-1, 0, 0});
+		std::vector<char> coded(total, 0);
+		// wfpp_encoder_thread :2865-2877: every frame, thread 0 takes the object in slot 0 and resets it to the slice's initial states before its first CTU
+		thread_ee[0] = slot[0];
+		obj[slot[0]] = RdCtxVersion{f, 0, 0};
+		auto code = [&](int th, int m) {
+			if (m < 0 || m >= total || coded[m]) return;
+			coded[m] = 1;
+			const int R = m / W, x = m % W, idx = R % T;
+			if (m != 0 && R > 0 && x == 0) std::swap(slot[2 * idx], slot[(2 * idx + num_ee - 1) % num_ee]);
+			thread_ee[th] = slot[2 * idx];
+			obj[thread_ee[th]] = RdCtxVersion{f, R, x + 1};
+			if (x == 1 && R + 1 != H) obj[slot[(2 * idx + 1) % num_ee]] = RdCtxVersion{f, R, 2};
+		};
+		for (int t = 0; t < last; t++) {
+			for (int r = 0; r < H; r++) {
+				const int c = t - 2 * r;
+				if (c >= 0 && c < W) src[r * W + c] = obj[thread_ee[r % T]];
+			}
+			for (int r = 0; r < H; r++) {
+				const int c = t - 2 * r;
+				if (c < 0 || c >= W) continue;
+				// the entropy coding calls of the section behind CTU n (hmr_deblock_sao_pad_sync_ctu; the same lag arithmetic as rc_coded_by)
+				const int n = r * W + c, th = r % T, idx = c;
+				if (!sao) { code(th, n); continue; }
+				const int v = n - (W + 1), vi = v % W, h = v - 1;
+				int s = h - (W + 1);
+				if (v >= 0 && idx >= 1 && h >= 0 && idx >= 2 && s >= 0 && idx >= 3) code(th, s);
+				if ((vi + 1) == W - 1 && (n + 1) != total) {
+					int max_filter = ((v / W) + 1) * W;
+					if (s > 0) {
+						max_filter -= W;
+						for (int a = s + 1; a < max_filter; a++) code(th, a);
+					}
+				}
+				if ((n + 1) == total) {
+					if (s < 0) s = -1;
+					for (int a = s + 1; a < total; a++) code(th, a);
+				}
+			}
+		}
+	}
+};
+
 // need[k * H + r] = the CTUs of row r that are coded when the decisions with index k start - synchronous wavefront: k = the step, 0 .. steps (the last entry is
 // the whole picture); raster order (one thread): k = the CTU, 0 .. nctu.  False when a row's coded CTUs are not a prefix of the row (no picture grid the encoder
 // accepts does that).

@@ -196,6 +196,13 @@ typedef int16_t src_t;
 constexpr int TU_SCRATCH = 64 * 64;        // (the checker's motion search also interpolates candidate blocks of up to 64 x 64 into pred_aux)
 #endif
 
+// scratch of the residual coder (enc_entropy.h) in the worker's fast memory: the coefficient-group scan and flags of the TU being coded
+struct EntScratch {
+	uint16_t cg[64];
+	uint8_t cg_flag[64];
+};
+constexpr int RD_CTX_BYTES = 192;      // CTX_TOTAL (enc_cabac_tables.h: 179) rounded up
+
 struct Work {
 	src_t curr_y[64 * 64], curr_c[2][32 * 32];
 	int16_t pred_y[64 * 64], pred_c[2][32 * 32];
@@ -223,6 +230,10 @@ struct Work {
 	// it (homer_loop1_motion_intra :1102-1104).  With one engine every thread has been through the first (intra) frame; the threads of a second engine start
 	// on a P frame and see "not intra" -> DC for neighbours inside the CTU until an intra frame or a scene change comes their way.
 	int32_t thread_seen_intra;
+	// RD_FULL (enc_rdo.h): the shadow CTU's own arrays, the counter's working copy of the contexts, the residual coder's scratch
+	uint8_t rd_pred_depth[NPART], rd_part_size[NPART], rd_pred_mode[NPART], rd_luma_modes[NPART];
+	uint8_t rd_ctx_work[RD_CTX_BYTES];
+	EntScratch rd_ent;
 };
 
 HENC_INLINE int16_t *wnd_y(int16_t *base) { return base; }

@@ -75,6 +75,19 @@ static void ts_leave_decision(int n)
 	while (ts_returned[t] < ts_count(t)) pthread_cond_wait(&ts_c, &ts_m);
 	pthread_mutex_unlock(&ts_m);
 }
+/* RD_FULL: the bit estimates of a decision run on the counter object et->ec = ec_list[row of the CTU the thread coded last mod threads] (wfpp_encode_select_bitstream,
+ * hmr_encoder_lib.c:2311, :2332), which the thread two rows up owns too - two decisions of one step that estimate at the same time add into each other's bit
+ * count and the stream changes from run to run (seen from eight CTU columns on).  Under the turnstile the decisions of a step therefore run one after the other,
+ * rows top down, when rd_mode is RD_FULL: every estimate starts from its own copy of the contexts, so one at a time they do not see each other. */
+static void ts_decide_in_turn(int n)
+{
+	const int r = n / ts_W, t = n % ts_W + 2 * r;
+	int pos = 0, rr;
+	for (rr = 0; rr < r; rr++) { const int c = t - 2 * rr; if (c >= 0 && c < ts_W) pos++; }
+	pthread_mutex_lock(&ts_m);
+	while (ts_returned[t] < pos) pthread_cond_wait(&ts_c, &ts_m);
+	pthread_mutex_unlock(&ts_m);
+}
 static void ts_post_begin(int n)
 {
 	const int r = n / ts_W, t = n % ts_W + 2 * r;
@@ -155,6 +168,7 @@ uint32_t motion_inter(henc_thread_t *et, ctu_info_t *ctu)
 	uint32_t r;
 	if (!real) real = next("motion_inter");
 	if (!ts_enabled() || et->wfpp_num_threads < 2) return real(et, ctu);
+	if (et->rd_mode == RD_FULL) ts_decide_in_turn(ctu->ctu_number);
 	r = real(et, ctu);
 	ts_leave_decision(ctu->ctu_number);
 	return r;
@@ -165,6 +179,7 @@ uint32_t motion_intra(henc_thread_t *et, ctu_info_t *ctu, int gcnt)
 	uint32_t r;
 	if (!real) real = next("motion_intra");
 	if (!ts_enabled() || et->wfpp_num_threads < 2) return real(et, ctu, gcnt);
+	if (et->rd_mode == RD_FULL) ts_decide_in_turn(ctu->ctu_number);
 	r = real(et, ctu, gcnt);
 	ts_leave_decision(ctu->ctu_number);
 	return r;
@@ -327,6 +342,64 @@ uint32_t encode_intra_luma(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int dep
 		cu_partition_info_t *cu = &ctu->partition_list[et->partition_depth_start[depth]] + part_position;
 		fprintf(g_trace, "ILUMA ctu=%d d=%d abs=%d ret=%u mode=%d sum=%u cost=%u\n", ctu->ctu_number, depth, cu->abs_index, r, cu->intra_mode[0], cu->sum, cu->cost);
 	}
+	return r;
+}
+
+/* (the pieces of an estimate, with HOMER_RDTRACE_CTX: what the counter has accumulated after each) */
+void encode_residual(henc_thread_t *et, enc_env_t *ee, ctu_info_t *ctu, cu_partition_info_t *pi, int component, int gcnt)
+{
+	static void (*real)(henc_thread_t *, enc_env_t *, ctu_info_t *, cu_partition_info_t *, int, int);
+	if (!real) real = next("encode_residual");
+	real(et, ee, ctu, pi, component, gcnt);
+	if (trace() && ee->type == EE_COUNTER && getenv("HOMER_RDTRACE_CTX")) fprintf(g_trace, "  RES d=%d abs=%d comp=%d frac=%llu ec=%p\n", pi->depth, pi->abs_index, component, (unsigned long long)ee->b_ctx->m_fracBits, (void *)ee);
+}
+void encode_qt_cbf(enc_env_t *ee, cu_partition_info_t *pi, int component, int tr_depth, int cbf)
+{
+	static void (*real)(enc_env_t *, cu_partition_info_t *, int, int, int);
+	if (!real) real = next("encode_qt_cbf");
+	real(ee, pi, component, tr_depth, cbf);
+	if (trace() && ee->type == EE_COUNTER && getenv("HOMER_RDTRACE_CTX")) fprintf(g_trace, "  CBF d=%d abs=%d comp=%d trd=%d cbf=%d frac=%llu ec=%p\n", pi->depth, pi->abs_index, component, tr_depth, cbf, (unsigned long long)ee->b_ctx->m_fracBits, (void *)ee);
+}
+void encode_intra_dir_luma_ang(enc_env_t *ee, ctu_info_t *ctu, cu_partition_info_t *pi, int is_multiple)
+{
+	static void (*real)(enc_env_t *, ctu_info_t *, cu_partition_info_t *, int);
+	if (!real) real = next("encode_intra_dir_luma_ang");
+	real(ee, ctu, pi, is_multiple);
+	if (trace() && ee->type == EE_COUNTER && getenv("HOMER_RDTRACE_CTX")) fprintf(g_trace, "  DIR d=%d abs=%d dir=%d frac=%llu ec=%p\n", pi->depth, pi->abs_index, ctu->intra_mode[0][pi->abs_index], (unsigned long long)ee->b_ctx->m_fracBits, (void *)ee);
+}
+
+/* RD_FULL: the counter's estimates (hmr_arithmetic_encoding.c:2186, :2198, :2362), for tools/ctu_diff.py --trace */
+uint rd_get_intra_bits_qt(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *pi, uint pred_depth, int is_luma, int gcnt)
+{
+	static uint (*real)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, uint, int, int);
+	if (!real) real = next("rd_get_intra_bits_qt");
+	uint r = real(et, ctu, pi, pred_depth, is_luma, gcnt);
+	if (trace()) {
+		char line[1024];      /* (one write per line: the threads of a step trace side by side) */
+		int o = snprintf(line, sizeof line, "RDQT ctu=%d d=%d abs=%d pd=%u luma=%d bits=%u", ctu->ctu_number, pi->depth, pi->abs_index, pred_depth, is_luma, r);
+		if (getenv("HOMER_RDTRACE_CTX")) {
+			int i;
+			o += snprintf(line + o, sizeof line - o, " ctx ");
+			for (i = 0; i < NUM_CTXs; i++) o += snprintf(line + o, sizeof line - o, "%02x", et->ee->contexts[i].state);
+		}
+		fprintf(g_trace, "%s ec=%p\n", line, (void *)et->ec);
+	}
+	return r;
+}
+uint fast_rd_estimate_bits_intra_luma_mode(henc_thread_t *et, cu_partition_info_t *pi, uint pred_depth, int dir, int *preds, int num_preds)
+{
+	static uint (*real)(henc_thread_t *, cu_partition_info_t *, uint, int, int *, int);
+	if (!real) real = next("fast_rd_estimate_bits_intra_luma_mode");
+	uint r = real(et, pi, pred_depth, dir, preds, num_preds);
+	if (trace()) fprintf(g_trace, "RDLM d=%d abs=%d dir=%d bits=%u\n", pi->depth, pi->abs_index, dir, r);
+	return r;
+}
+uint rd_estimate_bits_intra_mode(henc_thread_t *et, ctu_info_t *ctu, cu_partition_info_t *pi, uint pred_depth, int is_luma)
+{
+	static uint (*real)(henc_thread_t *, ctu_info_t *, cu_partition_info_t *, uint, int);
+	if (!real) real = next("rd_estimate_bits_intra_mode");
+	uint r = real(et, ctu, pi, pred_depth, is_luma);
+	if (trace()) fprintf(g_trace, "RDCM ctu=%d d=%d abs=%d luma=%d bits=%u\n", ctu->ctu_number, pi->depth, pi->abs_index, is_luma, r);
 	return r;
 }
 
