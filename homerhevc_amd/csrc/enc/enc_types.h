@@ -202,6 +202,7 @@ struct EntScratch {
 	uint8_t cg_flag[64];
 };
 constexpr int RD_CTX_BYTES = 192;      // CTX_TOTAL (enc_cabac_tables.h: 179) rounded up
+constexpr int RD_RING = 8;             // RD_FULL: frames whose coder states are kept (a coder object nobody selects keeps its states: enc_rc.h RdCtxSim)
 
 struct Work {
 	src_t curr_y[64 * 64], curr_c[2][32 * 32];

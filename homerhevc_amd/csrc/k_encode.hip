@@ -64,10 +64,10 @@ struct EncDev {
 	FrameCtx *next_frame;         // ... the frame parameters of the picture the same engine encodes next in this launch (it starts from this picture's average distortion), or nullptr
 	double *fin;                  // [0] the picture's distortion total (frame_acc_dist, enc_host.h), written by the worker that completes the picture's last task
 	RcFrame *rc_dyn;              // rate control: the frame's parameters after a scene change moved them (hmr_rc_change_pic_mode), [0]; valid once counters[2] >= 0
-	// RD_FULL (enc_rdo.h): what every CTU's bit estimates copy - rd_src[n] = kind << 28 | index; kind 0: all-zero states, 1 / 2: the slice's initial states of this
-	// frame / the one before (rd_init + 0 / RD_CTX_BYTES), 3 / 4: the states after coded CTU `index` of this frame (post.ctx_after) / the one before (rd_prev)
+	// RD_FULL (enc_rdo.h): what every CTU's bit estimates copy - rd_src[n] = kind << 28 | slot << 24 | index; kind 0: all-zero states (rd_init), 1: the initial
+	// states of the slice of the frame in ring slot `slot` (rd_init + (1 + slot) x RD_CTX_BYTES), 3: the states after coded CTU `index` of that frame (rd_ring)
 	const int *rd_src;
-	const uint8_t *rd_init, *rd_prev;
+	const uint8_t *rd_init, *rd_ring;
 	PostPic post;                 // the post-decision stage of the picture (enc_post.h): deblocking, SAO, entropy coding, padding as tasks of the CTU kernel
 };
 
@@ -362,6 +362,12 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 	// the mode buffers of the thread that owns this row, as the CTU before left them (this row's, or the last one of row - T)
 	wave_copy_words(&e.w->intra_mode_buffs[0][0][0], d.rowstate + (size_t)me * MODE_STATE_BYTES, MODE_STATE_BYTES, g.tid);
 	if (g.tid == 0) e.w->thread_seen_intra = d.thread_seen[me];
+	if (S.rd_mode == RDM_FULL) {
+		// RD_FULL: the thread's shadow CTU keeps its prediction modes from CTU to CTU - all INTRA once the thread has taken the intra walk (motion_intra :2003),
+		// the zeroes it was created with before (the worker's fast memory is not the thread's: enc_rdo.h)
+		const int seen = d.thread_seen[me];
+		for (int i = g.tid; i < NPART; i += 64) e.w->rd_pred_mode[i] = seen ? PM_INTRA : PM_INTER;
+	}
 	const int rem_y = lframe->qp % 6, rem_c = chroma_qp_table(lframe->qp + S.chroma_qp_offset) % 6;
 	if (lft && (cached_rem[0] != rem_y || cached_rem[1] != rem_c)) {
 		fast_tables_fill(g, *lft, d.tables, rem_y, rem_c);
@@ -373,9 +379,9 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 	uint32_t rc_bits = 0;
 	int rc_ctus = 0;
 	if (S.rd_mode == RDM_FULL) {
-		const int code = d.rd_src[n], kind = code >> 28;
-		const size_t off = (size_t)(code & 0x0fffffff) * RD_CTX_BYTES;
-		e.rd_ctx = kind == 3 ? d.post.ctx_after + off : (kind == 4 ? d.rd_prev + off : d.rd_init + (size_t)kind * RD_CTX_BYTES);
+		const int code = d.rd_src[n], kind = code >> 28, slot = (code >> 24) & 15;
+		const size_t off = (size_t)(code & 0x00ffffff) * RD_CTX_BYTES;
+		e.rd_ctx = kind == 3 ? d.rd_ring + ((size_t)slot * S.nctu) * RD_CTX_BYTES + off : d.rd_init + (size_t)(kind ? 1 + slot : 0) * RD_CTX_BYTES;
 	}
 	if (lframe->rc.on) rc_consumed(g, d.post, W, H, t, &rc_bits, &rc_ctus);
 	if (row == hrow) {
@@ -834,10 +840,9 @@ struct hmr_gpu_enc {
 	int *d_post_err = nullptr;
 	// RD_FULL: the replay of the reference's coder objects (enc_rc.h), the states after every coded CTU of this frame and the one before, the table of the frame
 	RdCtxSim rdsim;
-	uint8_t *d_ctx_after[2] = {nullptr, nullptr}, *d_rd_init = nullptr;      // (d_rd_init: [all-zero | initial states of this frame | of the one before] x RD_CTX_BYTES)
+	uint8_t *d_ctx_ring = nullptr, *d_rd_init = nullptr;      // (ring: frame f in slot f mod RD_RING; d_rd_init: [all-zero | the slices' initial states per slot] x RD_CTX_BYTES)
 	int *d_rd_src = nullptr;
-	int ctx_cur = 0;
-	uint8_t h_rd_init[3 * RD_CTX_BYTES] = {0};
+	uint8_t h_rd_init[(1 + RD_RING) * RD_CTX_BYTES] = {0};
 	uint16_t *d_rc_need = nullptr;       // rate control: the CTUs of each row that are coded when a wavefront step starts (enc_rc.h rc_need_table)
 	RcFrame *d_rc_dyn = nullptr;
 	int row_cap = 0;
@@ -1112,22 +1117,21 @@ int set_frame(hmr_gpu_enc *e, int slot, int image_type, double avg_dist, bool up
 		std::vector<int> codes(s.nctu);
 		for (int n = 0; n < s.nctu; n++) {
 			const RdCtxVersion v = src[n];
-			if (v.frame >= 0 && v.frame != e->f.num_encoded_frames && v.frame != e->f.num_encoded_frames - 1) {
-				hmr_set_error("RD_FULL: CTU %d copies coder states of frame %d in frame %d", n, v.frame, e->f.num_encoded_frames);
+			if (v.frame > e->f.num_encoded_frames || (v.frame >= 0 && v.frame <= e->f.num_encoded_frames - RD_RING)) {
+				hmr_set_error("RD_FULL: CTU %d copies coder states of frame %d in frame %d (the states of %d frames are kept)", n, v.frame, e->f.num_encoded_frames, RD_RING);
 				return HMR_GPU_ERR_ARG;
 			}
-			const int now = v.frame == e->f.num_encoded_frames;
-			codes[n] = v.frame < 0 ? 0 : (v.k == 0 ? (now ? 1 : 2) << 28 : ((now ? 3 : 4) << 28) | (v.row * s.wctu + v.k - 1));
+			const int slot = v.frame < 0 ? 0 : v.frame % RD_RING;
+			codes[n] = v.frame < 0 ? 0 : (v.k == 0 ? (1 << 28) | (slot << 24) : (3 << 28) | (slot << 24) | (v.row * s.wctu + v.k - 1));
 		}
-		e->ctx_cur ^= 1;
-		memcpy(e->h_rd_init + 2 * RD_CTX_BYTES, e->h_rd_init + RD_CTX_BYTES, RD_CTX_BYTES);
-		for (int i = 0; i < CTX_TOTAL; i++) e->h_rd_init[RD_CTX_BYTES + i] = Cabac::init_state(e->f.slice_type, e->f.qp, i);
+		const int slot_now = e->f.num_encoded_frames % RD_RING;
+		for (int i = 0; i < CTX_TOTAL; i++) e->h_rd_init[(1 + slot_now) * RD_CTX_BYTES + i] = Cabac::init_state(e->f.slice_type, e->f.qp, i);
 		HIP_TRY(hipMemcpyAsync(e->d_rd_src, codes.data(), sizeof(int) * s.nctu, hipMemcpyHostToDevice, e->ctx->stream));      // (pageable sources: copied before the call returns)
 		HIP_TRY(hipMemcpyAsync(e->d_rd_init, e->h_rd_init, sizeof e->h_rd_init, hipMemcpyHostToDevice, e->ctx->stream));
-		e->d.post.ctx_after = e->d_ctx_after[e->ctx_cur];
+		e->d.post.ctx_after = e->d_ctx_ring + (size_t)slot_now * s.nctu * RD_CTX_BYTES;
 		e->d.rd_src = e->d_rd_src;
 		e->d.rd_init = e->d_rd_init;
-		e->d.rd_prev = e->d_ctx_after[e->ctx_cur ^ 1];
+		e->d.rd_ring = e->d_ctx_ring;
 	}
 	e->d.dep = -1;
 	e->d.dep_full = 0;
@@ -1303,11 +1307,9 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 		DEV_ALLOC(e->d_rc_dyn, 1);
 		if (s.rd_mode == RDM_FULL) {
 			e->rdsim.init(e->cfg.wfpp_num_threads, s.wctu, s.hctu, s.sao);
-			for (int k = 0; k < 2; k++) {
-				DEV_ALLOC(e->d_ctx_after[k], (size_t)s.nctu * RD_CTX_BYTES);
-				HIP_TRY(hipMemset(e->d_ctx_after[k], 0, (size_t)s.nctu * RD_CTX_BYTES));
-			}
-			DEV_ALLOC(e->d_rd_init, 3 * RD_CTX_BYTES);
+			DEV_ALLOC(e->d_ctx_ring, (size_t)RD_RING * s.nctu * RD_CTX_BYTES);
+			HIP_TRY(hipMemset(e->d_ctx_ring, 0, (size_t)RD_RING * s.nctu * RD_CTX_BYTES));
+			DEV_ALLOC(e->d_rd_init, (1 + RD_RING) * RD_CTX_BYTES);
 			DEV_ALLOC(e->d_rd_src, s.nctu);
 		}
 		if (e->cfg.bitrate_mode != 0 || s.rd_mode == RDM_FULL) {      // (RD_FULL: a step's estimates copy coder states the steps before must have produced)
@@ -1521,7 +1523,7 @@ extern "C" void hmr_gpu_enc_destroy(hmr_gpu_enc *e)
 		(void)hipFree(e->d_rec[c]);
 	}
 	{
-		void *pp[] = {e->d_rows, e->d_ent, e->d_bs, e->d_cumbits, e->d_sao_tab, e->d_post_err, e->d_rc_need, e->d_rc_dyn, e->d_ctx_after[0], e->d_ctx_after[1], e->d_rd_init, e->d_rd_src};
+		void *pp[] = {e->d_rows, e->d_ent, e->d_bs, e->d_cumbits, e->d_sao_tab, e->d_post_err, e->d_rc_need, e->d_rc_dyn, e->d_ctx_ring, e->d_rd_init, e->d_rd_src};
 		for (void *q : pp) (void)hipFree(q);
 	}
 	for (auto &sl : e->src)

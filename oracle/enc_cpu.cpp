@@ -61,9 +61,8 @@ struct Cpu {
 	// RD_FULL: which coder states each CTU's bit estimates copy (enc_rc.h RdCtxSim), the states after every coded CTU of this frame and of the one before
 	RdCtxSim rdsim;
 	std::vector<RdCtxVersion> rdsrc;
-	std::vector<uint8_t> ctx_after[2];
-	int ctx_cur = 0;
-	uint8_t zero_ctx[RD_CTX_BYTES] = {0}, init_ctx[2][RD_CTX_BYTES] = {{0}, {0}};      // (init_ctx: the slice's initial states of this frame and of the one before)
+	std::vector<uint8_t> ctx_after[RD_RING];      // (frame f in slot f mod RD_RING)
+	uint8_t zero_ctx[RD_CTX_BYTES] = {0}, init_ctx[RD_RING][RD_CTX_BYTES] = {{0}};      // (init_ctx: the slice's initial states of the frames)
 	PostPic post = {};
 	PostScratch *scratch = nullptr;
 	std::vector<uint8_t> records;
@@ -138,11 +137,11 @@ void post_begin_frame(Cpu &c)
 	P.sao_lambda = c.sao_lambda.data(); P.errors = c.post_errors; P.rc_need = c.rc_need.empty() ? nullptr : c.rc_need.data();
 	P.ctx_after = nullptr;
 	if (s.rd_mode == RDM_FULL) {
-		c.ctx_cur ^= 1;
-		c.ctx_after[c.ctx_cur].assign((size_t)s.nctu * RD_CTX_BYTES, 0);
-		P.ctx_after = c.ctx_after[c.ctx_cur].data();
+		const int slot = c.f.num_encoded_frames % RD_RING;
+		c.ctx_after[slot].assign((size_t)s.nctu * RD_CTX_BYTES, 0);
+		P.ctx_after = c.ctx_after[slot].data();
 		c.rdsim.frame(c.f.num_encoded_frames, c.rdsrc);
-		for (int i = 0; i < CTX_TOTAL; i++) c.init_ctx[c.ctx_cur][i] = Cabac::init_state(c.f.slice_type, c.f.qp, i);
+		for (int i = 0; i < CTX_TOTAL; i++) c.init_ctx[slot][i] = Cabac::init_state(c.f.slice_type, c.f.qp, i);
 	}
 }
 // RD_FULL: the states CTU n's bit estimates copy
@@ -152,11 +151,11 @@ const uint8_t *rd_ctx_for(Cpu &c, int n)
 	if (s.rd_mode != RDM_FULL) return nullptr;
 	const RdCtxVersion v = c.rdsrc[n];
 	if (v.frame < 0) return c.zero_ctx;
-	if (v.frame != c.f.num_encoded_frames && v.frame != c.f.num_encoded_frames - 1) { fprintf(stderr, "RD_FULL: CTU %d copies coder states of frame %d in frame %d\n", n, v.frame, c.f.num_encoded_frames); abort(); }
-	if (v.k == 0) return c.init_ctx[v.frame == c.f.num_encoded_frames ? c.ctx_cur : c.ctx_cur ^ 1];
+	if (v.frame > c.f.num_encoded_frames || v.frame <= c.f.num_encoded_frames - RD_RING) { fprintf(stderr, "RD_FULL: CTU %d copies coder states of frame %d in frame %d\n", n, v.frame, c.f.num_encoded_frames); abort(); }
+	if (v.k == 0) return c.init_ctx[v.frame % RD_RING];
 	const int idx = v.row * s.wctu + v.k - 1;
 	if (v.frame == c.f.num_encoded_frames && c.rows[v.row].p_done < v.k) { fprintf(stderr, "RD_FULL: CTU %d starts before CTU (%d, %d) is coded\n", n, v.row, v.k - 1); abort(); }
-	return c.ctx_after[v.frame == c.f.num_encoded_frames ? c.ctx_cur : c.ctx_cur ^ 1].data() + (size_t)idx * RD_CTX_BYTES;
+	return c.ctx_after[v.frame % RD_RING].data() + (size_t)idx * RD_CTX_BYTES;
 }
 PostCtx post_ctx(Cpu &c)
 {
@@ -499,8 +498,7 @@ void *henc_cpu_create(const HostCfg *cfg)
 	if (cfg->wfpp_num_threads > 1) c->sched = 2;   // one worker per CTU row: the synchronous wavefront
 	if (c->seq.rd_mode == RDM_FULL) {
 		c->rdsim.init(cfg->wfpp_num_threads, c->seq.wctu, c->seq.hctu, c->seq.sao);
-		c->ctx_after[0].assign((size_t)c->seq.nctu * RD_CTX_BYTES, 0);
-		c->ctx_after[1] = c->ctx_after[0];
+		for (auto &v : c->ctx_after) v.assign((size_t)c->seq.nctu * RD_CTX_BYTES, 0);
 	}
 	if (cfg->bitrate_mode != 0) {
 		host_rc_init(*cfg, c->seq, c->st);

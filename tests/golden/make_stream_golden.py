@@ -36,6 +36,8 @@ CASES = [
     ("416x240_force_intra_rdfull_wpp_rows", 416, 240, 2, {"force_intra": 1, "rd": 1, "wpp": 4}),
     ("328x264_force_intra_rdfull_tr3_perf0_wpp_rows", 328, 264, 2, {"force_intra": 1, "rd": 1, "intra_tr": 3, "perf": 0, "wpp": 5}),
     ("3840x2160_force_intra_rdfull_tr4", 3840, 2160, 2, {"force_intra": 1, "rd": 1, "intra_tr": 4, "wpp": 32}),
+    ("416x240_rdfull_wpp_rows", 416, 240, 5, {"rd": 1, "wpp": 4}),      # IPPP with RD_FULL: the intra CUs of P frames price their syntax too
+    ("832x480_rdfull_tr3_wpp_rows", 832, 480, 4, {"rd": 1, "intra_tr": 3, "wpp": 8}),
     ("3840x2160_cfg2", 3840, 2160, 2, {}),       # configs[3], one engine's share: the cfg-2 encode at 2160p (I + P)
     ("200x136_scene_cut", 200, 136, 27, {"cut_at": 24}),     # new scene at frame 24: in-frame scene-change detection (hmr_motion_inter.c:3791), frames 25-26 after it
     ("416x240_scene_cut", 416, 240, 25, {"cut_at": 23}),
