@@ -55,6 +55,9 @@ WORKLOADS = {                  # name -> (width, height, configuration keys of t
     # BASELINE.json configs[2]: 2160p IPPP, CBR 20000 kbps (vbv = 1 s, 35 % initial fullness), performance_mode 1 - the rate control runs in the CTU kernel
     "cfg3-2160p-cbr": (3840, 2160, {"wpp": 32, "bitrate_mode": 1, "bitrate": 20000, "perf": 1}),
     "cfg3-1080p-cbr": (1920, 1080, {"wpp": 17, "bitrate_mode": 1, "bitrate": 5000, "perf": 1}),
+    # BASELINE.json configs[4]: 2160p all-intra (every picture an I picture), rd_mode 1 = full RDO (the CABAC bit counter prices every intra decision), intra TU depth 4
+    "cfg5-2160p-intra-rdfull": (3840, 2160, {"wpp": 32, "force_intra": 1, "rd": 1, "intra_tr": 4}),
+    "cfg5-1080p-intra-rdfull": (1920, 1080, {"wpp": 17, "force_intra": 1, "rd": 1, "intra_tr": 4}),
 }
 # the sequences of a batch encode eight different clips (tools/gen_yuv.py: 1234 is the published clip); the reference's digests of each are in bench_md5.json
 CLIP_SEEDS = [1234, 1, 2, 3, 4, 5, 6, 7]
@@ -148,18 +151,19 @@ def cpu_baseline(width, height, keys, frames):
 def valu_issue_probe(lib, device):
     """hmr_gpu_probe_valu_issue (include/homer_gpu.h section 14): plain vector instructions per second of this device - all SIMDs busy with independent instructions
     (the ceiling the guide's 1024 SIMDs x clock / 4 cycles describes) and with ONE dependent chain per wavefront (what a row worker's decision chain is made of)."""
-    lib.hmr_gpu_probe_valu_issue.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.hmr_gpu_probe_issue.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.hmr_gpu_destroy.argtypes = [C.c_void_p]
     ctx = C.c_void_p()
     assert lib.hmr_gpu_create(C.byref(ctx), device, None) == 0
     rows = []
-    for waves, dep in ((1, 0), (2, 0), (4, 0), (1, 1), (2, 1)):
+    names = ["v_mad_u32_u24", "v_add_u32", "v_mov_b32", "v_perm_b32", "s_add_u32"]
+    for op, waves, dep in ((0, 1, 0), (0, 2, 0), (0, 4, 0), (1, 1, 0), (1, 2, 0), (2, 2, 0), (3, 2, 0), (4, 1, 0), (4, 2, 0), (0, 1, 1), (1, 1, 1), (1, 2, 1), (4, 1, 1)):
         rate, ms = C.c_double(), C.c_double()
-        assert lib.hmr_gpu_probe_valu_issue(ctx, waves, dep, C.byref(rate), C.byref(ms)) == 0, lib.hmr_gpu_last_error()
-        rows.append({"waves_per_simd": waves, "dependent_chain": bool(dep), "wave_instructions_per_s": round(rate.value / 1e9, 2), "unit": "G/s", "ms": round(ms.value, 2),
+        assert lib.hmr_gpu_probe_issue(ctx, op, waves, dep, C.byref(rate), C.byref(ms)) == 0, lib.hmr_gpu_last_error()
+        rows.append({"instruction": names[op], "waves_per_simd": waves, "dependent_chain": bool(dep), "wave_instructions_per_s": round(rate.value / 1e9, 2), "unit": "G/s", "ms": round(ms.value, 2),
                      "cycles_per_instruction_and_simd_at_2p4GHz": round(2.4e9 * 1024 / rate.value, 3)})
     lib.hmr_gpu_destroy(ctx)
-    return {"kernel": "k_probe_valu (v_mad_u32_u24, no memory access in the loop)", "rows": rows,
+    return {"kernel": "k_probe_valu (64 instructions of one kind per round, no memory access in the loop)", "rows": rows,
             "note": "independent instructions reach the guide's ceiling from one wavefront per SIMD on; a dependent chain issues one instruction per the ALU's latency - "
                     "k_encode_pool's workers are such chains, 1.5 wavefronts per SIMD"}
 
@@ -423,6 +427,16 @@ def main():
             if a.sequences > 1:
                 r31 = run_workload(lib, c3, "cfg3-2160p-cbr", world, rank, local, torch)
                 out["cfg3_2160p_cbr"]["single_sequence"] = {k: r31[k] for k in ("value", "ms_per_step", "stream_matches_reference")}
+            # BASELINE.json configs[4]: 2160p all-intra, full RDO, intra TU depth 4 - a batch of 32 sequences and one sequence alone (the fixture covers eight frames)
+            if "cfg5-2160p-intra-rdfull" in REFERENCE_MD5:
+                c5 = copy.copy(a)
+                c5.warmup, c5.steps = 2, 4
+                r5 = run_workload(lib, c5, "cfg5-2160p-intra-rdfull", world, rank, local, torch, sequences=32 if a.sequences > 1 else 1)
+                out["cfg5_2160p_intra_rdfull"] = {k: r5[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "stream_md5", "stream_matches_reference", "frames_checked_against_reference", "clips")}
+                out["cfg5_2160p_intra_rdfull"]["config"] = r5["config"]
+                if a.sequences > 1:
+                    r51 = run_workload(lib, c5, "cfg5-2160p-intra-rdfull", world, rank, local, torch)
+                    out["cfg5_2160p_intra_rdfull"]["single_sequence"] = {k: r51[k] for k in ("value", "ms_per_step", "stream_matches_reference")}
         if world == 1:
             out["roofline"]["subpel_planes"] = subpel_planes_roofline(lib, torch, width, height)
             probe = valu_issue_probe(lib, local)
@@ -512,6 +526,8 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
     access unit kept and checked against the reference's digests after the timed region."""
     import encoder_cases as ec
     width, height, keys = WORKLOADS[workload]
+    keys = dict(keys)
+    image_type = 3 if keys.pop("force_intra", 0) else 0      # (encoder_in_out_t.image_type: IMAGE_I on every picture)
     nframes = a.warmup + a.steps
     S = sequences if int(keys.get("wpp", 1)) > 1 else 1
     # sequence i encodes clip i mod 8 where the reference's digests of that clip cover the run (else the published clip)
@@ -562,12 +578,12 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
     def step(f):
         t_step = time.perf_counter()
         if S == 1:
-            st = lib.hmr_gpu_enc_encode_source(enc, f, 0, buf, len(buf), C.byref(nbytes), None)
+            st = lib.hmr_gpu_enc_encode_source(enc, f, image_type, buf, len(buf), C.byref(nbytes), None)
             assert st in (1, 2), lib.hmr_gpu_last_error()
             md5s[0].update(C.string_at(buf, nbytes.value))
         else:
             call = lib.hmr_gpu_enc_encode_batch_pipelined if pipelined else lib.hmr_gpu_enc_encode_batch
-            assert call(e_arr, S, (C.c_int * S)(*([f] * S)), None, ptrs, caps, got) == 0, lib.hmr_gpu_last_error()
+            assert call(e_arr, S, (C.c_int * S)(*([f] * S)), (C.c_int * S)(*([image_type] * S)) if image_type else None, ptrs, caps, got) == 0, lib.hmr_gpu_last_error()
             take_units()
             st, nbytes.value = 0, got[0]
         if S == 1:
@@ -638,8 +654,8 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
             "metric": "encoded frames/sec, 1080p & 2160p YUV420 fixed-QP IPPP, 1/2/4/8 MI355X", "value": round(world * S * a.steps / dt, 4), "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
-            "config": {"workload": workload, "sequences_per_gpu": S, "frames_per_step": S, "wfpp_num_threads": int(keys.get("wpp", 1)), "width": width, "height": height, "frames_in_sequence": nframes, "gop": "IPPP intra_period=100", "qp": 32,
-                       "rd_mode": 2, "performance_mode": int(keys.get("perf", 2)), "sao": 1, "parallelism": (f"{S} independent sequences per GPU, one launch per step for their CTU stages (a pool of CTU tasks on two row workers per CU)" if S > 1 else "one sequence"),
+            "config": {"workload": workload, "sequences_per_gpu": S, "frames_per_step": S, "wfpp_num_threads": int(keys.get("wpp", 1)), "width": width, "height": height, "frames_in_sequence": nframes, "gop": "all intra (IMAGE_I forced)" if image_type else "IPPP intra_period=100", "qp": 32,
+                       "rd_mode": int(keys.get("rd", 2)), "max_intra_tr_depth": int(keys.get("intra_tr", 2)), "performance_mode": int(keys.get("perf", 2)), "sao": 1, "parallelism": (f"{S} independent sequences per GPU, one launch per step for their CTU stages (a pool of CTU tasks on two row workers per CU)" if S > 1 else "one sequence"),
                        "timed_region": "per frame: phase planes of the reference, CTU decisions, deblocking, SAO statistics / decision / syntax, CABAC of the CTU rows' sub-streams, SAO offsets and border padding on the device "
                                        "(one launch of k_encode_pool: the decisions and the post-decision tasks of enc_post.h), download of the sub-streams, slice header / entry points / NAL escaping on the host; source in HBM; "
                                        "the first warm-up step is the I frames (warmup_ms_per_step[0])",

@@ -692,6 +692,8 @@ int hmr_gpu_subpel_planes(hmr_gpu_ctx *ctx, const int16_t *pic_y, const int16_t 
  *     instruction stream reaches.  *wave_instr_per_s: vector instructions per second of all wavefronts together; *ms (may be NULL): the launch's duration.
  * ------------------------------------------------------------------------------------------------ */
 int hmr_gpu_probe_valu_issue(hmr_gpu_ctx *ctx, int waves_per_simd, int dependent, double *wave_instr_per_s, double *ms);
+/* the same for one instruction kind: op 0 v_mad_u32_u24, 1 v_add_u32, 2 v_mov_b32, 3 v_perm_b32, 4 s_add_u32 (scalar unit) */
+int hmr_gpu_probe_issue(hmr_gpu_ctx *ctx, int op, int waves_per_simd, int dependent, double *wave_instr_per_s, double *ms);
 
 #ifdef __cplusplus
 }
