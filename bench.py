@@ -157,7 +157,7 @@ def valu_issue_probe(lib, device):
     assert lib.hmr_gpu_create(C.byref(ctx), device, None) == 0
     rows = []
     names = ["v_mad_u32_u24", "v_add_u32", "v_mov_b32", "v_perm_b32", "s_add_u32"]
-    for op, waves, dep in ((0, 1, 0), (0, 2, 0), (0, 4, 0), (1, 1, 0), (1, 2, 0), (2, 2, 0), (3, 2, 0), (4, 1, 0), (4, 2, 0), (0, 1, 1), (1, 1, 1), (1, 2, 1), (4, 1, 1)):
+    for op, waves, dep in ((1, 1, 0), (1, 2, 0), (1, 4, 0), (2, 2, 0), (0, 1, 0), (0, 2, 0), (0, 4, 0), (3, 2, 0), (1, 1, 1), (1, 2, 1), (0, 1, 1)):
         rate, ms = C.c_double(), C.c_double()
         assert lib.hmr_gpu_probe_issue(ctx, op, waves, dep, C.byref(rate), C.byref(ms)) == 0, lib.hmr_gpu_last_error()
         rows.append({"instruction": names[op], "waves_per_simd": waves, "dependent_chain": bool(dep), "wave_instructions_per_s": round(rate.value / 1e9, 2), "unit": "G/s", "ms": round(ms.value, 2),
@@ -441,7 +441,22 @@ def main():
             out["roofline"]["subpel_planes"] = subpel_planes_roofline(lib, torch, width, height)
             probe = valu_issue_probe(lib, local)
             if out["roofline"].get("issue_bound") is not None:
-                out["roofline"]["issue_bound"]["probe"] = probe
+                ib = out["roofline"]["issue_bound"]
+                ib["probe"] = probe
+                # the ceiling a plain vector instruction meets on THIS device (v_add_u32, two wavefronts per SIMD) instead of the guide's four cycles per instruction,
+                # and what ONE wavefront per SIMD reaches (k_encode_pool has 1.5 per SIMD, each a dependent chain most of the time)
+                plain = max(r["wave_instructions_per_s"] for r in probe["rows"] if r["instruction"] == "v_add_u32" and not r["dependent_chain"]) * 1e9
+                one = [r["wave_instructions_per_s"] for r in probe["rows"] if r["instruction"] == "v_add_u32" and r["waves_per_simd"] == 1 and not r["dependent_chain"]][0] * 1e9
+                dep = [r["wave_instructions_per_s"] for r in probe["rows"] if r["instruction"] == "v_add_u32" and r["waves_per_simd"] == 1 and r["dependent_chain"]][0] * 1e9
+                fps_kernel = ib["valu_issue_frac"] * ib["valu_issue_peak_per_s"] / ib["valu_wave_instructions_per_frame"]
+                ib["guide_four_cycle_peak_per_s"] = ib["valu_issue_peak_per_s"]
+                ib["valu_issue_peak_per_s"] = plain
+                ib["valu_issue_frac"] = round(ib["valu_wave_instructions_per_frame"] * fps_kernel / plain, 4)
+                ib["one_wavefront_per_simd_peak_per_s"] = one
+                ib["one_dependent_chain_per_simd_per_s"] = dep
+                ib["verdict"] = ("plain vector instructions (v_add_u32, v_mov_b32) issue every 2.5 cycles per SIMD with two wavefronts on it, v_mad_u32_u24 / v_perm_b32 every 5; ONE wavefront gets an "
+                                 "instruction every 5 cycles and a dependent chain one every 8.3: at 1.5 wavefronts per SIMD the workers are bound by their own issue latency and the memory "
+                                 "trips between instructions, not by the SIMDs' throughput")
             else:
                 out["roofline"]["issue_probe"] = probe
         if world == 1 and a.streams > 1:
