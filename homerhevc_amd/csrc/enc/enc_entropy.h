@@ -501,6 +501,12 @@ HENC_FI void encode_residual(const G &g, Cabac &ee, const EntView &v, EntScratch
 		sc.cg_flag[i] = 0;
 	}
 	g.sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+	// on the device the groups' positions also sit in a register (lane i: group i of the scan; at most 64 groups) and the "group holds a level" flags in a 64-bit
+	// mask indexed by the group's raster position: the serial walk below reads neither from memory (a 32 x 32 TU walks up to 64 groups, most of them empty)
+	const int cgv = g.tid < ncg ? (int)sc.cg[g.tid] : 0;
+	uint64_t cgmask = 0;
+#endif
 	// lane-parallel: the last significant coefficient in coding order and the groups that hold one
 	int raster_pos_last = -1;
 	for (int base = 0; base < ncoef; base += g.n) {
@@ -509,10 +515,16 @@ HENC_FI void encode_residual(const G &g, Cabac &ee, const EntView &v, EntScratch
 		if (i < ncoef) {
 			const uint32_t sp = scan_position(scan_mode, shift, i, sc.cg);
 			val = coeff[sp];
+#if !defined(__HIP_DEVICE_COMPILE__)
 			if (val != 0) sc.cg_flag[sc.cg[i >> 4]] = 1;
+#endif
 		}
 		const uint64_t m = g.ballot(val != 0);
 		if (m) raster_pos_last = base + 63 - __builtin_clzll(m);
+#if defined(__HIP_DEVICE_COMPILE__)
+		for (int j = 0; j < 4; j++)
+			if ((m >> (16 * j)) & 0xffffu) cgmask |= 1ull << __builtin_amdgcn_readlane(cgv, (base >> 4) + j);
+#endif
 	}
 	g.sync();
 	ENT_PROF_ADD(3, ENT_PROF_NOW());
@@ -549,20 +561,28 @@ HENC_FI void encode_residual(const G &g, Cabac &ee, const EntView &v, EntScratch
 			last_nz = first_nz = scan_pos_sig;
 			scan_pos_sig--;
 		}
-		const int cg_block_pos = uni((int)sc.cg[subset]);
+#if defined(__HIP_DEVICE_COMPILE__)
+		const int cg_block_pos = __builtin_amdgcn_readlane(cgv, subset);
+#define HENC_CG_FLAG(pos) ((uint32_t)((cgmask >> (pos)) & 1ull))
+#define HENC_CG_SET(pos) (cgmask |= 1ull << (pos))
+#else
+		const int cg_block_pos = sc.cg[subset];
+#define HENC_CG_FLAG(pos) ((uint32_t)(sc.cg_flag[pos] != 0))
+#define HENC_CG_SET(pos) (sc.cg_flag[pos] = 1)
+#endif
 		const int cg_y = cg_block_pos / blk, cg_x = cg_block_pos - cg_y * blk;
-		if (subset == last_scan_set || subset == 0) sc.cg_flag[cg_block_pos] = 1;
+		if (subset == last_scan_set || subset == 0) HENC_CG_SET(cg_block_pos);
 		else {
-			const uint32_t sig_cg = uni(sc.cg_flag[cg_block_pos]) != 0;
+			const uint32_t sig_cg = HENC_CG_FLAG(cg_block_pos);
 			int right = 0, lower = 0;
-			if (cg_x < blk - 1) right = uni(sc.cg_flag[cg_y * blk + cg_x + 1]) != 0;
-			if (cg_y < blk - 1) lower = uni(sc.cg_flag[(cg_y + 1) * blk + cg_x]) != 0;
+			if (cg_x < blk - 1) right = HENC_CG_FLAG(cg_y * blk + cg_x + 1);
+			if (cg_y < blk - 1) lower = HENC_CG_FLAG((cg_y + 1) * blk + cg_x);
 			ee.encode_bin(base_cg + (right || lower), sig_cg);
 		}
-		if (uni(sc.cg_flag[cg_block_pos])) {
+		if (HENC_CG_FLAG(cg_block_pos)) {
 			uint32_t right = 0, lower = 0;
-			if (cg_x < blk - 1) right = uni(sc.cg_flag[cg_y * blk + cg_x + 1]) != 0;
-			if (cg_y < blk - 1) lower = uni(sc.cg_flag[(cg_y + 1) * blk + cg_x]) != 0;
+			if (cg_x < blk - 1) right = HENC_CG_FLAG(cg_y * blk + cg_x + 1);
+			if (cg_y < blk - 1) lower = HENC_CG_FLAG((cg_y + 1) * blk + cg_x);
 			const int pattern = right + (lower << 1);
 #if defined(__HIP_DEVICE_COMPILE__)
 			// the group's sixteen positions and levels by sixteen lanes at once: the serial walk below reads them from the register (two trips to the LDS per
@@ -640,6 +660,8 @@ HENC_FI void encode_residual(const G &g, Cabac &ee, const EntView &v, EntScratch
 	}
 	ENT_PROF_ADD(0, ENT_PROF_NOW());
 }
+#undef HENC_CG_FLAG
+#undef HENC_CG_SET
 
 // ---- CU syntax -----------------------------------------------------------------------------------------------------------------
 HENC_FI void encode_qt_cbf(Cabac &ee, int comp, int tr_depth, int cbf)
