@@ -346,7 +346,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=24)
     ap.add_argument("--no-single-thread-order", action="store_true", help="skip the second measurement (wfpp_num_threads = 1)")
-    ap.add_argument("--sequences", type=int, default=180, help="independent sequences per GPU, encoded with one launch per step (hmr_gpu_enc_encode_batch: their CTUs are a pool of tasks for "
+    ap.add_argument("--sequences", type=int, default=256, help="independent sequences per GPU, encoded with one launch per step (hmr_gpu_enc_encode_batch: their CTUs are a pool of tasks for "
                     "two row workers per CU); 1 = a single sequence")
     ap.add_argument("--no-pipeline", action="store_true", help="batch steps through hmr_gpu_enc_encode_batch (access units inside the call) instead of the pipelined call")
     ap.add_argument("--streams", type=int, default=0, help="concurrent sequences of the extra multi_stream measurement (0 = skip)")
@@ -396,11 +396,11 @@ def main():
             out["single_thread_order"] = {k: other[k] for k in ("value", "unit", "ms_per_step", "stream_md5", "stream_matches_reference", "frames_checked_against_reference", "schedule")}
             out["single_thread_order"]["note"] = "the same encode with wfpp_num_threads = 1: output identical to the reference's single-thread run (md5 2f0c3447...), which costs guesses, verification and re-encode passes"
             # the metric's other picture size: 2160p, 34 CTU rows on the reference's maximum of 32 WPP threads, I + P and four timed P frames:
-            # a batch of 64 sequences (2176 CTU rows for the 512 workers of the pool) and one sequence alone
+            # a batch of 96 sequences (3264 CTU rows for the 512 workers of the pool) and one sequence alone
             import copy
             b = copy.copy(a)
             b.warmup, b.steps = 2, 4
-            big = run_workload(lib, b, "cfg2-2160p-encode", world, rank, local, torch, sequences=64 if a.sequences > 1 else 1)
+            big = run_workload(lib, b, "cfg2-2160p-encode", world, rank, local, torch, sequences=96 if a.sequences > 1 else 1)
             out["at_2160p"] = {k: big[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "stream_md5", "stream_matches_reference", "frames_checked_against_reference", "clips")}
             out["at_2160p"]["config"] = big["config"]
             if a.sequences > 1:
@@ -480,6 +480,9 @@ def run_engine_ring(a, world, rank, local, torch):
     name = f"{base}-engines{world}"
     keys = dict(keys, engines=world)
     nframes = a.warmup + a.steps
+    # every rank keeps an engine object of EVERY sequence (about 105 MB at 1080p: three pictures, the CTU records, the levels) beside the phase planes of the
+    # sequences it encodes in a step: 160 sequences per GPU keep an 8-GPU ring (1280 objects per rank) under 200 GB of the 288
+    a.sequences = min(a.sequences, 160)
     S = a.sequences * world
     # (HOMER_BENCH_ONE_DEVICE: all ranks on one GPU over gloo - the pictures then cross page-locked host buffers)
     adapter = GpuEngines(lambda seq: ec.default_cfg(width, height, **keys), local, pipelined=not a.no_pipeline, host_exchange=bool(os.environ.get("HOMER_BENCH_ONE_DEVICE")))
