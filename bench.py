@@ -411,7 +411,7 @@ def main():
             # starting its next frame when its last is finished; tools/chain_bench.py): the reference's num_enc_engines pipeline, streams checked against its digests
             import chain_bench
             lanes = []
-            for wl, sets in (("cfg2-1080p-encode-engines3", 4), ("cfg2-1080p-encode-engines8", 2), ("cfg2-2160p-encode-engines8", 2)):
+            for wl, sets in (("cfg2-1080p-encode-engines3", 5), ("cfg2-1080p-encode-engines8", 2), ("cfg2-2160p-encode-engines8", 2)):
                 if wl in REFERENCE_MD5:
                     r = chain_bench.run(lib, wl, sets=sets, quiet=True)
                     lanes.append({k: r[k] for k in ("workload", "engines", "objects_per_engine", "chain", "frames", "frames_per_s_full_chains", "frames_per_s_after_first_chain", "stream_matches_reference",
