@@ -13,9 +13,10 @@
 // (the true chains, one thread per 4x4 unit column), k_sched_check (one wavefront per CTU replays its logs against the truth), repeated until
 // nothing is wrong, then k_sched_finish.
 //
-// Before the CTU stage of a P frame k_subpel.hip writes the reference picture at every sub-sample phase (planes borrowed from g_plane_pool);
-// after it the in-loop filters are the frame kernels of round 1 (k_deblock.hip, k_sao.hip, k_pad.hip) and k_sao_decide (the SAO parameter decision,
-// one workgroup per CTU row); the entropy stage (enc/enc_entropy.h) is host code fed with the side-info records and the levels.
+// Before the CTU stage of a P frame k_subpel.hip writes the reference picture at every sub-sample phase (planes borrowed from g_plane_pool; overlapped
+// frames of a sequence - hmr_gpu_enc_encode_chain - get them from S tasks of the launch instead).  Behind a CTU's decisions everything else of the frame is
+// post-decision TASKS of the same launch (enc/enc_post.h: deblocking, SAO, CABAC of the CTU rows' sub-streams, padding); the single-thread order, whose
+// decisions are final only after its verification passes, runs them as one more launch (k_post_frame).  The host assembles the access unit.
 #include <stddef.h>
 #include <stdlib.h>
 #include <chrono>

@@ -566,12 +566,16 @@ void hmr_gpu_sao_offsets_ctu(const int32_t *stats, const double *lambdas, int32_
  *     per CTU row, row r+1 two CTUs behind row r (:2885-2898); planes, side-info and levels stay resident in HBM.
  *     hmr_gpu_enc_cfg has the layout and field names of HVENC_Cfg (homer_hevc_enc_api.h:138-167), so a caller passes
  *     the struct it already fills for HOMER_enc_control(HOMER_SETCFG).
- *     Built rows: 8-bit 4:2:0, 64x64 CTUs, I / P slices with one reference picture, fixed QP, rd_mode 0 / 2,
- *     performance_mode 0-2 (BASELINE configs 1, 2, 4); anything else makes hmr_gpu_enc_create return HMR_GPU_ERR_ARG.
+ *     Built rows: 8-bit 4:2:0, 64x64 CTUs, I / P slices with one reference picture, performance_mode 0-2, max_intra_tr_depth / max_inter_tr_depth up to 4,
+ *     rd_mode 0 / 2 and - with wfpp_num_threads > 1, one engine, fixed QP - rd_mode 1 (RD_FULL: the CABAC bit counter prices the intra decisions);
+ *     fixed QP and - with wfpp_num_threads > 1 and one engine - bitrate_mode 1 / 2 (CBR / VBR: bitrate, vbv_size, vbv_init, frame_rate) - BASELINE configs
+ *     0 .. 4; anything else, pictures of more than 128 CTU rows and pictures of more than 192 wavefront steps (CTU columns + 2 x (CTU rows - 1)) make
+ *     hmr_gpu_enc_create return HMR_GPU_ERR_ARG (hmr_gpu_last_error says why).
  *     wfpp_num_threads = 1: the stream of the reference's single worker thread.  wfpp_num_threads = CTU rows: the stream of its
  *     multi-thread mode with the threads advancing as a synchronous wavefront (pinned by oracle/ref_ctudump.c, HOMER_TURNSTILE);
  *     fewer threads than rows are accepted when 2 x threads >= CTU columns (2160p: 32 threads, the reference's maximum, for 34 rows), others are refused.
- *     The SAO parameter decision runs on the device too (k_sao_decide); entropy coding is the host stage.
+ *     Deblocking, SAO (statistics, decision, syntax, offsets), the CABAC coding of the CTU rows' sub-streams and border padding are tasks of the same launch
+ *     (enc/enc_post.h); the host writes parameter sets, slice header, entry points and the NAL escaping.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct hmr_gpu_enc_cfg {
 	int32_t size, profile, width, height;
@@ -599,9 +603,9 @@ int hmr_gpu_enc_frame_ctus(hmr_gpu_enc *enc, const uint8_t *y, const uint8_t *u,
 float hmr_gpu_enc_last_ctu_ms(hmr_gpu_enc *enc);
 
 /* HOMER_enc_encode (homer_hevc_enc_api.h:173, hmr_encoder_lib.c:1655 + encoder_engine_thread :3043-3260): one picture in, one access unit out.
- * CTU decisions, deblocking, SAO statistics, the SAO parameter decision (hmr_sao.c:663-1410), SAO offsets and border padding run on the
- * device; the CABAC / NAL writer (hmr_arithmetic_encoding.c, hmr_binary_encoding.c, hmr_bitstream.c) runs on the host from the side-info
- * records and the levels.  y / u / v: host 8-bit planes; image_type as encoder_in_out_t.image_type (0 auto, 3 forced intra).  stream receives the
+ * CTU decisions, rate control, deblocking, SAO statistics / parameter decision (hmr_sao.c:663-1410) / offsets, the CABAC coding of the CTU rows' sub-streams
+ * (hmr_arithmetic_encoding.c, hmr_binary_encoding.c) and border padding run on the device; the host assembles the access unit (hmr_headers.c, hmr_bitstream.c)
+ * from the sub-streams.  y / u / v: host 8-bit planes; image_type as encoder_in_out_t.image_type (0 auto, 3 forced intra).  stream receives the
  * Annex-B bytes of the access unit (VPS / SPS / PPS in front of an IDR), *stream_bytes their count; recon (optional) the final picture,
  * 8-bit planar.  Returns the slice type (1 P, 2 I) or a negative status. */
 int hmr_gpu_enc_encode(hmr_gpu_enc *enc, const uint8_t *y, const uint8_t *u, const uint8_t *v, int image_type, uint8_t *stream, long cap, long *stream_bytes,
@@ -613,8 +617,8 @@ int hmr_gpu_enc_encode_source(hmr_gpu_enc *enc, int slot, int image_type, uint8_
  * into streams[i] (capacity caps[i], size stream_bytes[i]).  The encoders use the row-per-thread schedule (wfpp_num_threads > 1) and the same device; the access
  * units are those hmr_gpu_enc_encode_source gives one by one.  The launch is a pool of persistent row workers (two per CU) that claim CTUs of any of the n
  * pictures whose wavefront step is open (k_encode_pool); n is at most 256, a few hundred pictures' worth of CTU rows saturate the pool (120 at 1080p).  A worker
- * never waits for a CTU that is not already running, so the launch does not depend on all its workgroups being resident.  Pictures of more than 256 CTU rows
- * (16384 lines) are refused by the batch calls (the SAO decisions of a batch run a thread per CTU row in one workgroup per picture). */
+ * never waits for a CTU that is not already running, so the launch does not depend on all its workgroups being resident; a watchdog (HENC_WATCHDOG_S, 120 s by
+ * default) makes a launch that finds nothing to do for that long return HMR_GPU_ERR_HIP instead of hanging. */
 int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes);
 /* the same, pipelined: call k launches the frames slots[] and delivers the access units of call k - 1's frames (stream_bytes[i] = 0 on the first call), whose download
  * and entropy coding run while the device is busy with call k's CTU stage - a frame's successor needs its reconstruction and its distortion statistic, not its bytes
