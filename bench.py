@@ -1,29 +1,32 @@
 #!/usr/bin/env python3
 """bench.py - encoded frames/sec of the device encoder on BASELINE.json configs[1].
 
-Workload ("cfg2-1080p-encode"): the real encode of 1920x1080 IPPP sequences (gop_size=1, fixed QP 32, quarter-pel ME, SAO on, one WPP thread per CTU row; the
-synthetic clip of SURVEY.md 8-d) through the C ABI (include/homer_gpu.h section 12) - a batch of --sequences independent sequences per GPU, one frame of each per
-step (hmr_gpu_enc_encode_batch_pipelined).  One step = everything HOMER_enc_encode does for those frames: the phase planes of the reference pictures, the CTU
-decisions (k_encode_pool: the CTUs of all the pictures as a pool of tasks on two row workers per CU), deblocking, SAO statistics / decision / offsets, border
-padding on the device, the download of side-info and levels, CABAC + NAL writer on the host; the access units are delivered inside the timed region (the
-pipelined call delivers a step's units with the next call: the pipeline is empty when the region starts and flushed before it ends).  The source pictures are
-resident in HBM before the timed region starts.  Warm-up frames are the first frames of the sequences (the I frame and the first P frames), the timed frames
-the P frames that follow - every frame depends on the reconstruction of the one before, nothing is replayed or cached.  Every access unit of every sequence is
-checked against the reference's per-frame digests (tests/golden/bench_md5.json: `stream_matches_reference`, `frames_checked_against_reference`) for any
---steps / --warmup the fixture covers (40 frames).  Beside the headline: `single_sequence` (one sequence alone), `single_thread_order` (wfpp_num_threads = 1,
-the reference's deterministic single-thread stream 2f0c3447...), `at_2160p`.
+Workload ("cfg2-1080p-encode"): the real encode of 1920x1080 IPPP sequences (gop_size=1, fixed QP 32, quarter-pel ME, SAO on, one WPP thread per CTU row) through the
+C ABI (include/homer_gpu.h section 12) - a batch of --sequences independent sequences per GPU (256; eight different synthetic clips, tools/gen_yuv.py), one frame of
+each per step (hmr_gpu_enc_encode_batch_pipelined).  One step = everything HOMER_enc_encode does for those frames: the phase planes of the reference pictures, then ONE
+launch of k_encode_pool - the CTU decisions of all the pictures as a pool of tasks on two row workers per CU and, behind each CTU, its post-decision tasks: deblocking,
+SAO statistics / decision / syntax / offsets, CABAC of the CTU row's sub-stream, border padding - then the download of the sub-streams and headers / entry points / NAL
+escaping on the host; the access units are delivered inside the timed region (the pipelined call delivers a step's units with the next call: the pipeline is empty when
+the region starts and flushed before it ends).  The source pictures are resident in HBM before the timed region starts.  Warm-up frames are the first frames of the
+sequences (the I frame and the first P frames), the timed frames the P frames that follow - every frame depends on the reconstruction of the one before, nothing is
+replayed or cached.  Every access unit of every sequence is checked against the compiled reference's per-frame digests of its clip (tests/golden/bench_md5.json:
+`stream_matches_reference`, `frames_checked_against_reference`, `clips`) for any --steps / --warmup the fixtures cover (24-40 frames).  Beside the headline:
+`single_sequence` (one sequence alone, frame by frame and with its engines overlapped in one launch: hmr_gpu_enc_encode_chain), `single_thread_order`
+(wfpp_num_threads = 1, the reference's deterministic single-thread stream 2f0c3447...), `at_2160p`, `cfg3_2160p_cbr` (BASELINE configs[2]: rate control in the CTU
+kernel), `cfg5_2160p_intra_rdfull` (configs[4]: all-intra, full RDO, intra TU depth 4).
 
 Multi-GPU (--gpus N under torch.distributed.run): one engine per GPU, as BASELINE.json's north_star and configs[3] say - the reference's
 num_enc_engines = N frame pipeline (encoder_engine_thread, hmr_encoder_lib.c:3043) with engine k on rank k.  Every rank keeps one engine object of every
-sequence; frame t of sequence s is encoded on rank (s + t) mod N, and after each step the ranks pass the reconstructed pictures (padded int16 planes) and
-the frame-to-frame scalars round the ring in ONE packed RCCL send / recv per rank (homerhevc_amd/engines.py).  N x --sequences sequences are in flight, so
-every rank encodes --sequences frames per step whatever N is (weak scaling); the exchange is inside the timed region.  Every access unit is checked against
+sequence; frame t of sequence s is encoded on rank (s + t) mod N, and after each step the ranks pass the final pictures (8-bit, without margins) and
+the frame-to-frame scalars round the ring in ONE packed RCCL send / recv per rank (homerhevc_amd/engines.py).  N x min(--sequences, 160) sequences are in flight, so
+every rank encodes that many frames per step whatever N is (weak scaling); the exchange is inside the timed region.  Every access unit is checked against
 the reference's num_enc_engines = N stream (oracle/ref_ctudump.c's engine turnstile; tests/golden/bench_md5.json).
 
-Extra objects: `roofline` for k_encode_pool (93 % of a step): algorithmic bytes per SURVEY.md 8-d against the 8 TB/s HBM peak, the fabric traffic from the
-calibrated counter passes, and `issue_bound` - what actually binds the kernel (wave-instruction issue and the latency of dependent chains, not bandwidth);
-`roofline.subpel_planes`: the bandwidth-bound phase-plane kernels measured live; `cpu_baseline`: the compiled reference (oracle/_ref/ref_lockstep) timed on
-this host on the same configuration - one thread, one thread per CTU row, and K processes side by side.
+Extra objects: `roofline` for k_encode_pool (98 % of a step): algorithmic bytes per SURVEY.md 8-d against the 8 TB/s HBM peak, the fabric traffic from the
+calibrated counter passes of this build, and `issue_bound` - what actually binds the kernel (the issue latency of 1.5 wavefronts per SIMD and the memory trips of
+their dependent chains), with the ceiling measured live by an issue-rate probe; `roofline.subpel_planes`: the bandwidth-bound phase-plane kernels measured live;
+`cpu_baseline`: the compiled reference (oracle/_ref/ref_lockstep) timed on this host on the same configuration by its own clock - one process per physical core
+side by side (the headline of the baseline), one process, and one process with a thread per CTU row.
 """
 import argparse
 import ctypes as C
