@@ -87,9 +87,21 @@ inline bool make_seq(HostCfg cfg, Seq &s, const char **why)
 		if (cfg.wfpp_num_threads > 1 && wc + 2 * (hc - 1) > HENC_MAX_STEPS) { *why = "more than 192 wavefront steps (CTU columns + 2 x (CTU rows - 1))"; return false; }
 	}
 	if ((cfg.width + 63) / 64 < 2) { *why = "picture narrower than two CTUs"; return false; }
+	// (two CTU columns and more than one CTU row: the compiled reference crashes - 120x88, 128x128, 128x192, any configuration; 128x64 runs - so no stream exists to pin one on)
+	if ((cfg.width + 63) / 64 < 3 && (cfg.height + 63) / 64 > 1) { *why = "picture of two CTU columns and more than one CTU row (the reference crashes there)"; return false; }
+	// Several engines on a narrow picture: the reference hands a reference row on to the next engine from the in-row stage of its lagged filter pipeline only
+	// from column index 5 + 2 (the search window) on (hmr_deblock_sao_pad_sync_ctu, hmr_encoder_lib.c:2437); on pictures of fewer than nine CTU columns the
+	// semaphore counts then do not add up once there are more than four CTU rows and its engines wait for each other for ever (observed with ref_lockstep: 3 ... 8
+	// columns x 5, 6 or 9 rows, SAO on or off, any thread count; with two columns it crashes).  There is nothing to pin a stream on there: refused.
+	{
+		const int wc = (cfg.width + 63) / 64, hc = (cfg.height + 63) / 64;
+		if (cfg.num_enc_engines > 1 && (wc < 3 || (wc < 9 && hc > 4))) { *why = "num_enc_engines > 1 on a picture of fewer than nine CTU columns and more than four CTU rows (the reference's engines deadlock there)"; return false; }
+	}
 	{
 		const int wc = (cfg.width + 63) / 64, hc = (cfg.height + 63) / 64;
 		if (cfg.sample_adaptive_offset && wc <= 5 && hc >= (wc > 4 ? wc : 4)) { *why = "SAO on a picture of at most five CTU columns that has at least as many CTU rows"; return false; }
+		// (three columns: the same corner without SAO too - 3x4 ... 3x9 differ, 3x3 and every 4 ... 7 column grid up to 9 rows are identical; tools/encoder_fuzz.py)
+		if (wc == 3 && hc >= 4) { *why = "picture of three CTU columns and four or more CTU rows"; return false; }
 	}
 	s.max_intra_tr_depth = cfg.max_intra_tr_depth > 5 ? 5 : cfg.max_intra_tr_depth;
 	s.max_inter_tr_depth = cfg.max_inter_tr_depth > 5 ? 5 : cfg.max_inter_tr_depth;

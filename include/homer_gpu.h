@@ -574,6 +574,10 @@ void hmr_gpu_sao_offsets_ctu(const int32_t *stats, const double *lambdas, int32_
  *     wfpp_num_threads = 1: the stream of the reference's single worker thread.  wfpp_num_threads = CTU rows: the stream of its
  *     multi-thread mode with the threads advancing as a synchronous wavefront (pinned by oracle/ref_ctudump.c, HOMER_TURNSTILE);
  *     fewer threads than rows are accepted when 2 x threads >= CTU columns (2160p: 32 threads, the reference's maximum, for 34 rows), others are refused.
+ *     Picture grids the compiled reference cannot run are refused too (no stream exists to compare with): two CTU columns x several rows (it crashes),
+ *     num_enc_engines > 1 on fewer than nine CTU columns with more than four CTU rows (its engines deadlock), and the two small-grid corners of its
+ *     lagged filter pipeline that the frame passes here do not reproduce (enc/enc_host.h make_seq: one CTU column; three columns with four or more rows;
+ *     SAO on at most five columns with at least as many rows).
  *     Deblocking, SAO (statistics, decision, syntax, offsets), the CABAC coding of the CTU rows' sub-streams and border padding are tasks of the same launch
  *     (enc/enc_post.h); the host writes parameter sets, slice header, entry points and the NAL escaping.
  * ------------------------------------------------------------------------------------------------ */

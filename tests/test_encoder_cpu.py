@@ -56,15 +56,23 @@ def test_core_matches_reference_fixture(cpu, name):
 
 
 def test_unsupported_configurations_are_refused(cpu):
-    for kw in ({"rd": 1}, {"rd": 1, "wpp": 4, "bitrate_mode": 1, "bitrate": 400}, {"bitrate_mode": 3},      # (RD_FULL: one thread per CTU row, fixed QP) {"bitrate_mode": 1, "engines": 2, "wpp": 4}, {"num_b": 1, "gop_size": 2}, {"perf": 3}, {"cu_size": 32},
+    for kw in ({"rd": 1}, {"rd": 1, "wpp": 4, "bitrate_mode": 1, "bitrate": 400}, {"bitrate_mode": 3},      # (RD_FULL: one thread per CTU row, fixed QP)
+               {"bitrate_mode": 1, "bitrate": 400, "engines": 2, "wpp": 4}, {"num_b": 1, "gop_size": 2}, {"perf": 3}, {"cu_size": 32},
                {"wpp": 2},      # 7 CTU columns: two threads would have to be in rows 0 and 2 at once under the synchronous wavefront
                {"wpp": 5}):     # more threads than the 4 CTU rows
         cfg = ec.default_cfg(416, 240, **kw)
         assert not cpu.henc_cpu_create(C.byref(cfg)), kw
+    cfg = ec.default_cfg(136, 456, sao=0)      # three CTU columns x four or more rows: refused with SAO off as well
+    assert not cpu.henc_cpu_create(C.byref(cfg))
     for size in ((64, 256), (192, 256), (320, 320)):      # one CTU wide; SAO on grids of at most five columns with at least as many rows
         cfg = ec.default_cfg(*size)
         assert not cpu.henc_cpu_create(C.byref(cfg)), size
-    for size, kw in (((416, 240), {"wpp": 4}), ((328, 264), {"wpp": 3}), ((320, 320), {"sao": 0}), ((416, 240), {"bitrate_mode": 1, "bitrate": 400}), ((416, 240), {"bitrate_mode": 2, "bitrate": 400, "wpp": 4}), ((416, 240), {"rd": 1, "wpp": 4, "intra_tr": 4})):
+    # grids the compiled reference itself cannot run: two CTU columns x several rows (crash); several engines on fewer than nine columns with more than four rows (deadlock)
+    for size, kw in (((128, 128), {}), ((120, 88), {"sao": 0}), ((320, 320), {"sao": 0, "engines": 2}), ((512, 384), {"engines": 2}), ((448, 576), {"engines": 3, "wpp": 9})):
+        cfg = ec.default_cfg(*size, **kw)
+        assert not cpu.henc_cpu_create(C.byref(cfg)), (size, kw)
+    for size, kw in (((128, 64), {}), ((576, 384), {"engines": 2}), ((512, 256), {"engines": 4}),
+                     ((416, 240), {"wpp": 4}), ((328, 264), {"wpp": 3}), ((320, 320), {"sao": 0}), ((416, 240), {"bitrate_mode": 1, "bitrate": 400}), ((416, 240), {"bitrate_mode": 2, "bitrate": 400, "wpp": 4}), ((416, 240), {"rd": 1, "wpp": 4, "intra_tr": 4})):
         cfg = ec.default_cfg(*size, **kw)
         assert cpu.henc_cpu_create(C.byref(cfg)), (size, kw)
 

@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Build-container tool: random configurations of the frame encoder - checker build (oracle/libenc_cpu.so: the device's source compiled for one lane) against the
+compiled reference (oracle/_ref/ref_lockstep, or ref_ctudump under HOMER_TURNSTILE for several WPP threads / engines) - beyond the fixed cases of
+tests/golden/streams.json: other picture sizes, clip seeds, QPs, rate-control targets, RD modes, transform depths, thread and engine counts.
+
+usage: tools/encoder_fuzz.py [--cases N] [--seed S] [--max-ctus M]        (prints one line per case; exit code = number of differing cases)
+       tools/encoder_fuzz.py WxHxFRAMES:clipseed[:key=value,...] ...      (explicit cases)"""
+import argparse
+import ctypes as C
+import hashlib
+import os
+import random
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import encoder_cases as ec  # noqa: E402
+import gen_yuv  # noqa: E402
+
+CPU_SO = os.path.join(ROOT, "oracle", "libenc_cpu.so")
+
+
+def reference(width, height, frames, clip_seed, keys):
+    with tempfile.TemporaryDirectory() as tmp:
+        yuv = os.path.join(tmp, "in.yuv")
+        gen_yuv.write_clip(yuv, width, height, frames, clip_seed)
+        turnstile = int(keys.get("wpp", 1)) > 1 or int(keys.get("engines", 1)) > 1
+        cmd = [os.path.join(ROOT, "oracle", "_ref", "ref_ctudump" if turnstile else "ref_lockstep"), yuv, os.path.join(tmp, "out.265"), str(width), str(height), str(frames)]
+        cmd += [f"{k}={v}" for k, v in keys.items()]
+        try:
+            subprocess.run(cmd, check=True, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, HOMER_TURNSTILE="1") if turnstile else None)
+        except (subprocess.TimeoutExpired, subprocess.CalledProcessError) as e:      # (the reference has configurations it deadlocks or crashes on)
+            return type(e).__name__
+        return open(os.path.join(tmp, "out.265"), "rb").read()
+
+
+def checker(lib, width, height, frames, clip_seed, keys):
+    keys = dict(keys)
+    image_type = 3 if int(keys.pop("force_intra", 0)) else 0
+    cfg = ec.default_cfg(width, height, **keys)
+    enc = lib.henc_cpu_create(C.byref(cfg))
+    if not enc:
+        return None
+    buf = C.create_string_buffer(8 << 20)
+    rec = C.create_string_buffer(width * height * 3 // 2)
+    stream = b""
+    for planes in ec.clip_frames(width, height, frames, seed=clip_seed):
+        n = lib.henc_cpu_encode_frame(enc, *planes, image_type, buf, len(buf), rec)
+        assert n > 0
+        stream += buf.raw[:n]
+    lib.henc_cpu_destroy(enc)
+    return stream
+
+
+def random_case(rng, max_ctus):
+    while True:
+        wc, hc = rng.randint(2, 14), rng.randint(1, 9)
+        if wc * hc > max_ctus:
+            continue
+        # multiples of 8 (the minimum CU); the last CTU column / row partly outside the picture most of the time
+        width = wc * 64 - 8 * rng.randint(0, 7)
+        height = hc * 64 - 8 * rng.randint(0, 7)
+        if width < 72 or height < 16 or (wc == 2 and hc > 1) or (wc == 3 and hc >= 4):        # (two columns x several rows: the reference crashes; 3 x 4 and taller: refused, enc_host.h)
+            continue
+        keys = {}
+        sao = rng.random() < 0.75
+        if sao and wc <= 5 and hc >= max(wc, 4):        # (a refused corner of the lagged filter pipeline, enc_host.h)
+            sao = False
+        if not sao:
+            keys["sao"] = 0
+        mode = rng.choice(["fixed", "fixed", "rc", "rdfull", "engines"])
+        wpp = 1
+        if rng.random() < 0.6 or mode == "rdfull":
+            wpp = hc if hc <= 32 else 32
+            if hc > 2 and rng.random() < 0.25 and mode != "rdfull":
+                n = rng.randint(2, hc - 1)
+                if 2 * n >= wc:
+                    wpp = n
+        if mode == "rdfull" and wpp < 2:
+            continue
+        if wpp > 1:
+            keys["wpp"] = wpp
+        keys["qp"] = rng.choice([22, 27, 30, 32, 32, 35, 38, 42])
+        keys["perf"] = rng.choice([0, 1, 2, 2])
+        if rng.random() < 0.3:
+            keys["sign_hiding"] = 0
+        if rng.random() < 0.4:
+            keys["intra_tr"] = rng.choice([1, 3, 4])
+        frames = rng.randint(2, 5)
+        if mode == "rc":
+            keys["bitrate_mode"] = rng.choice([1, 2])
+            keys["bitrate"] = max(100, int(width * height * rng.choice([1.5, 3, 6, 12]) / 1000))
+            frames = rng.randint(4, 8)
+        elif mode == "rdfull":
+            keys["rd"] = 1
+        elif mode == "engines" and (wc >= 9 or (wc >= 3 and hc <= 4)):      # (narrower: the reference's engines deadlock, enc_host.h)
+            keys["engines"] = rng.choice([2, 3, 4])
+            frames = rng.randint(5, 10)
+        elif rng.random() < 0.25:
+            keys["rd"] = 0
+        if rng.random() < 0.2:
+            keys["force_intra"] = 1
+        if rng.random() < 0.15 and mode != "engines":
+            keys["intra_period"] = rng.choice([2, 3])
+        return width, height, frames, rng.randint(1, 10 ** 6), keys
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-ctus", type=int, default=60)
+    ap.add_argument("specs", nargs="*")
+    a = ap.parse_args()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), CPU_SO])
+    lib = C.CDLL(CPU_SO)
+    lib.henc_cpu_create.restype = C.c_void_p
+    lib.henc_cpu_create.argtypes = [C.POINTER(ec.EncCfg)]
+    lib.henc_cpu_encode_frame.restype = C.c_long
+    lib.henc_cpu_encode_frame.argtypes = [C.c_void_p] + [C.c_char_p] * 3 + [C.c_int, C.c_char_p, C.c_long, C.c_char_p]
+    lib.henc_cpu_destroy.argtypes = [C.c_void_p]
+    cases = []
+    for spec in a.specs:
+        parts = spec.split(":")
+        w, h, frames = (int(v) for v in parts[0].split("x"))
+        keys = dict(kv.split("=") for kv in parts[2].split(",")) if len(parts) > 2 and parts[2] else {}
+        cases.append((w, h, frames, int(parts[1]) if len(parts) > 1 and parts[1] else 1234, {k: int(v) for k, v in keys.items()}))
+    if not cases:
+        rng = random.Random(a.seed)
+        cases = [random_case(rng, a.max_ctus) for _ in range(a.cases)]
+    bad = 0
+    for w, h, frames, clip_seed, keys in cases:
+        spec = f"{w}x{h}x{frames}:{clip_seed}:" + ",".join(f"{k}={v}" for k, v in keys.items())
+        mine = checker(lib, w, h, frames, clip_seed, keys)
+        if mine is None:
+            print(spec, "REFUSED by the encoder", flush=True)
+            continue
+        ref = reference(w, h, frames, clip_seed, keys)
+        if isinstance(ref, str):
+            print(spec, "THE REFERENCE FAILED:", ref, flush=True)
+            bad += 1
+            continue
+        ok = ref == mine
+        bad += not ok
+        print(spec, len(ref), "bytes", hashlib.md5(ref).hexdigest(), "IDENTICAL" if ok else f"DIFFERENT (checker: {len(mine)} bytes)", flush=True)
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(main())
