@@ -187,7 +187,7 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth,
 	const int abs_index = q.abs_index, curr_depth = q.depth, n = q.size, nc = q.size_chroma;
 	const int gx = e.ctu_x + q.x, gy = e.ctu_y + q.y;
 	int merge_cand_buffer[5] = {0, 0, 0, 0, 0};
-	int best_is_skip = 0, best_candidate = 0, have_ctu_cbf = 0;
+	int best_is_skip = 0, best_candidate = 0, have_ctu_cbf = 0, prev_nores_ran = 0;      // prev_nores_ran: has the candidate before this one been through a no-residual evaluation?
 	uint32_t dist, best_dist = MAX_COST, cost, best_cost = MAX_COST, best_sum = 0, ctu_cbf = 0;      // ctu_cbf: cbf[0] | cbf[1] | cbf[2] of the CTU record at this CU's first unit
 	MV best_mv = {0, 0};
 	int best_ref_idx = 0;
@@ -202,22 +202,31 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth,
 		// the no-residual evaluation, where it runs (the candidate's coded evaluation - the predecessor's - had levels, or is itself skipped because the best so
 		// far is a skip), resets the node's cbf / transform index / level sum.  Do exactly that and nothing else.  (best_is_skip only ever goes from 0 to 1, so a
 		// coded evaluation that would run here has run for the predecessor.)
+		// One case is NOT a repeat: the predecessor's coded evaluation came out without levels (so its own no-residual evaluation was left out) and became the best
+		// (so this candidate's coded evaluation is left out and its flag stays 0): the no-residual evaluation of this prediction then runs here for the first time, and
+		// it can win - a transform block whose levels were zeroed by the coded evaluation's rate test is charged the distortion of the levels it dropped
+		// (encode_inter, hmr_motion_inter.c:207-219), not that of the prediction.  Found by tools/encoder_fuzz.py (392x136, clip 931814, QP 22).
 		if (cand >= 1 && w.merge_cands.mv[cand].x == w.merge_cands.mv[cand - 1].x && w.merge_cands.mv[cand].y == w.merge_cands.mv[cand - 1].y &&
 		    w.merge_cands.ref_idx[cand] == w.merge_cands.ref_idx[cand - 1]) {
 			const int coded_runs = !best_is_skip;                                       // (then it rewrites the predecessor's coded result over itself)
 			if (coded_runs) merge_cand_buffer[cand] = merge_cand_buffer[cand - 1];
 			const int nores_runs = !(coded_runs && merge_cand_buffer[cand] == 1);
-			if (nores_runs) {
-				nd.inter_cbf[0] = nd.inter_cbf[1] = nd.inter_cbf[2] = 0;
-				nd.inter_tr_idx = 0;
-				nd.sum = 0;
+			if (!nores_runs || prev_nores_ran) {
+				if (nores_runs) {
+					nd.inter_cbf[0] = nd.inter_cbf[1] = nd.inter_cbf[2] = 0;
+					nd.inter_tr_idx = 0;
+					nd.sum = 0;
+				}
+				prev_nores_ran = nores_runs;
+				continue;
 			}
-			continue;
 		}
 		int coded_ran = 0, have_residual = 0;
+		prev_nores_ran = 0;
 		for (int no_res = 0; no_res < 2; no_res++) {
 			if (no_res == 1 && merge_cand_buffer[cand] == 1) continue;
 			if (best_is_skip && no_res == 0) continue;
+			if (no_res == 1) prev_nores_ran = 1;
 			if (!mc_done) {
 				const MV mv = w.merge_cands.mv[cand];
 				const int xlow = -S.margin_y, xhigh = S.width + S.margin_y, ylow = -S.margin_y, yhigh = S.height + S.margin_y;

@@ -25,6 +25,9 @@ CASES = [
     ("328x264_qp38_nosbh", 328, 264, 3, {"qp": 38, "sign_hiding": 0}),
     ("416x240_intra_period1", 416, 240, 2, {"intra_period": 1}),   # the reference clamps intra_period to gop_size + 1 = 2 (hmr_encoder_lib.c:743): I, P
     ("832x480", 832, 480, 3, {}),
+    # found by tools/encoder_fuzz.py: two identical merge candidates, the first one's coded evaluation without levels and best - the second one's no-residual evaluation
+    # is then the first of that prediction and wins (enc_ctu.h check_rd_cost_merge)
+    ("392x136_qp22_clip931814", 392, 136, 4, {"qp": 22, "clip_seed": 931814}),
     ("1920x1080_cfg2", 1920, 1080, 8, {}),       # BASELINE.json configs[1]
     ("1280x720_intra_period1", 1280, 720, 2, {"intra_period": 1}),   # I, P at 720p (see above)
     # forced intra pictures (encoder_in_out_t.image_type = IMAGE_I on every frame, homer_hevc_enc_api.h:112, honoured hmr_encoder_lib.c:311-313): consecutive I frames
@@ -78,9 +81,10 @@ CASES = [
 def run(width, height, frames, keys):
     keys = dict(keys)
     cut_at = keys.pop("cut_at", None)
+    clip_seed = keys.pop("clip_seed", None)
     with tempfile.TemporaryDirectory() as tmp:
         yuv = os.path.join(tmp, "in.yuv")
-        gen_yuv.write_clip(yuv, width, height, frames, cut_at=cut_at)
+        gen_yuv.write_clip(yuv, width, height, frames, seed=clip_seed or 1234, cut_at=cut_at)
         turnstile = int(keys.get("wpp", 1)) > 1 or int(keys.get("engines", 1)) > 1
         cmd = [os.path.join(ROOT, "oracle", "_ref", "ref_ctudump" if turnstile else "ref_lockstep"), yuv, os.path.join(tmp, "out.265"), str(width), str(height), str(frames),
                "recon=" + os.path.join(tmp, "rec.yuv")] + [f"{k}={v}" for k, v in keys.items()]
@@ -90,6 +94,8 @@ def run(width, height, frames, keys):
     fsz = width * height * 3 // 2
     if cut_at is not None:
         keys["cut_at"] = cut_at
+    if clip_seed is not None:
+        keys["clip_seed"] = clip_seed
     return {"width": width, "height": height, "frames": frames, "keys": keys, "stream_md5": hashlib.md5(stream).hexdigest(), "stream_bytes": len(stream),
             "nal_sizes": [len(x) for x in stream_diff.split_nals(stream)],
             "recon_md5": [hashlib.md5(rec[f * fsz:(f + 1) * fsz]).hexdigest() for f in range(frames)]}

@@ -37,6 +37,7 @@ def encode(lib, case):
     w, h, frames = g["width"], g["height"], g["frames"]
     keys = dict(g["keys"])
     cut_at = keys.pop("cut_at", None)
+    clip_seed = keys.pop("clip_seed", 1234)
     image_type = 3 if keys.pop("force_intra", 0) else 0          # encoder_in_out_t.image_type: IMAGE_I on every frame
     cfg = ec.default_cfg(w, h, **keys)
     enc = C.c_void_p()
@@ -46,7 +47,7 @@ def encode(lib, case):
     rec = C.create_string_buffer(w * h * 3 // 2)
     nbytes = C.c_long()
     stream, recon, log = b"", [], []
-    for f, planes in enumerate(ec.clip_frames(w, h, frames, cut_at)):
+    for f, planes in enumerate(ec.clip_frames(w, h, frames, cut_at, clip_seed)):
         st = lib.hmr_gpu_enc_encode(enc, *planes, image_type, buf, len(buf), C.byref(nbytes), rec)
         assert st in (1, 2), lib.hmr_gpu_last_error()
         stream += buf.raw[:nbytes.value]
@@ -59,7 +60,7 @@ def encode(lib, case):
     return stream, recon
 
 
-@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra_period1", "832x480", "1920x1080_cfg2", "1280x720_intra_period1", "1280x720_force_intra", "416x240_force_intra", "416x240_force_intra_wpp_rows", "416x240_force_intra_rdfull_wpp_rows", "416x240_force_intra_rdfull_tr4_wpp_rows", "328x264_force_intra_rdfull_tr3_perf0_wpp_rows", "416x240_rdfull_wpp_rows", "832x480_rdfull_tr3_wpp_rows", "3840x2160_cfg2", "200x136_scene_cut", "416x240_scene_cut", "416x240_wpp_rows", "416x240_scene_cut_wpp_rows", "1920x1080_cfg2_wpp_rows", "832x480_wpp_rows", "416x240_qp22_perf0_wpp_rows", "416x240_nosao_wpp_rows", "328x264_wpp3", "200x136_wpp2", "416x240_eng3_wpp_rows", "832x480_eng2_wpp_rows", "416x240_scene_cut_eng2_wpp_rows", "1920x1080_cfg2_eng2", "1920x1080_cfg2_eng3", "3840x2160_cfg2_eng8", "3840x2160_cfg2_wpp32", "3840x2160_force_intra_rdfull_tr4",
+@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra_period1", "832x480", "392x136_qp22_clip931814", "1920x1080_cfg2", "1280x720_intra_period1", "1280x720_force_intra", "416x240_force_intra", "416x240_force_intra_wpp_rows", "416x240_force_intra_rdfull_wpp_rows", "416x240_force_intra_rdfull_tr4_wpp_rows", "328x264_force_intra_rdfull_tr3_perf0_wpp_rows", "416x240_rdfull_wpp_rows", "832x480_rdfull_tr3_wpp_rows", "3840x2160_cfg2", "200x136_scene_cut", "416x240_scene_cut", "416x240_wpp_rows", "416x240_scene_cut_wpp_rows", "1920x1080_cfg2_wpp_rows", "832x480_wpp_rows", "416x240_qp22_perf0_wpp_rows", "416x240_nosao_wpp_rows", "328x264_wpp3", "200x136_wpp2", "416x240_eng3_wpp_rows", "832x480_eng2_wpp_rows", "416x240_scene_cut_eng2_wpp_rows", "1920x1080_cfg2_eng2", "1920x1080_cfg2_eng3", "3840x2160_cfg2_eng8", "3840x2160_cfg2_wpp32", "3840x2160_force_intra_rdfull_tr4",
                                   "416x240_cbr400_perf1_wpp_rows", "416x240_vbr400_wpp_rows", "832x480_cbr1500_perf1_wpp_rows", "416x240_cbr300_nosao_wpp_rows", "1920x1080_cbr5000_perf1_wpp_rows",
                                   "3840x2160_cbr20000_perf1_wpp32"])
 def test_device_stream_is_byte_identical_to_the_reference(gpu, case):

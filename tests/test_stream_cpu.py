@@ -36,6 +36,7 @@ def encode(lib, case, sched=0):
     w, h, frames = g["width"], g["height"], g["frames"]
     keys = dict(g["keys"])
     cut_at = keys.pop("cut_at", None)
+    clip_seed = keys.pop("clip_seed", 1234)
     image_type = 3 if keys.pop("force_intra", 0) else 0          # encoder_in_out_t.image_type: IMAGE_I on every frame
     cfg = ec.default_cfg(w, h, **keys)
     enc = lib.henc_cpu_create(C.byref(cfg))
@@ -44,7 +45,7 @@ def encode(lib, case, sched=0):
     buf = C.create_string_buffer(4 << 20)
     rec = C.create_string_buffer(w * h * 3 // 2)
     stream, recon = b"", []
-    for planes in ec.clip_frames(w, h, frames, cut_at):
+    for planes in ec.clip_frames(w, h, frames, cut_at, clip_seed):
         n = lib.henc_cpu_encode_frame(enc, *planes, image_type, buf, len(buf), rec)
         assert n > 0
         stream += buf.raw[:n]
@@ -55,7 +56,7 @@ def encode(lib, case, sched=0):
     return stream, recon, list(st)
 
 
-@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra_period1", "832x480", "1280x720_intra_period1", "1280x720_force_intra", "416x240_force_intra", "416x240_force_intra_wpp_rows", "416x240_force_intra_rdfull_wpp_rows", "416x240_force_intra_rdfull_tr4_wpp_rows", "328x264_force_intra_rdfull_tr3_perf0_wpp_rows", "416x240_rdfull_wpp_rows", "832x480_rdfull_tr3_wpp_rows", "200x136_scene_cut", "416x240_scene_cut", "416x240_wpp_rows", "416x240_scene_cut_wpp_rows", "832x480_wpp_rows", "416x240_qp22_perf0_wpp_rows", "416x240_nosao_wpp_rows", "328x264_wpp3", "200x136_wpp2", "416x240_eng2", "416x240_eng3_wpp_rows", "832x480_eng2_wpp_rows", "416x240_scene_cut_eng2_wpp_rows",
+@pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra_period1", "832x480", "392x136_qp22_clip931814", "1280x720_intra_period1", "1280x720_force_intra", "416x240_force_intra", "416x240_force_intra_wpp_rows", "416x240_force_intra_rdfull_wpp_rows", "416x240_force_intra_rdfull_tr4_wpp_rows", "328x264_force_intra_rdfull_tr3_perf0_wpp_rows", "416x240_rdfull_wpp_rows", "832x480_rdfull_tr3_wpp_rows", "200x136_scene_cut", "416x240_scene_cut", "416x240_wpp_rows", "416x240_scene_cut_wpp_rows", "832x480_wpp_rows", "416x240_qp22_perf0_wpp_rows", "416x240_nosao_wpp_rows", "328x264_wpp3", "200x136_wpp2", "416x240_eng2", "416x240_eng3_wpp_rows", "832x480_eng2_wpp_rows", "416x240_scene_cut_eng2_wpp_rows",
                                   "416x240_cbr400_perf1", "416x240_cbr400_perf1_wpp_rows", "416x240_vbr400_wpp_rows", "832x480_cbr1500_perf1_wpp_rows", "416x240_cbr300_nosao_wpp_rows"])
 def test_stream_is_byte_identical_to_the_reference(cpu, case):
     stream, recon, _ = encode(cpu, case)

@@ -69,9 +69,9 @@ def load_cpu():
     return lib
 
 
-def run_reference(tmp, width, height, frames, keys, force_intra=False, trace=False):
+def run_reference(tmp, width, height, frames, keys, force_intra=False, trace=False, seed=1234):
     yuv = os.path.join(tmp, "in.yuv")
-    gen_yuv.write_clip(yuv, width, height, frames)
+    gen_yuv.write_clip(yuv, width, height, frames, seed)
     env = dict(os.environ, HOMER_CTUDUMP=os.path.join(tmp, "ctus.bin"))
     if int(keys.get("wpp", 1)) > 1 or int(keys.get("engines", 1)) > 1:
         env["HOMER_TURNSTILE"] = "1"      # (the deterministic schedule the streams are pinned on)
@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--height", type=int, default=240)
     ap.add_argument("--frames", type=int, default=3)
     ap.add_argument("--force-intra", action="store_true")
+    ap.add_argument("--seed", type=int, default=1234, help="clip seed (tools/gen_yuv.py)")
     ap.add_argument("--trace", action="store_true", help="write per-CU traces of both sides next to the dumps")
     ap.add_argument("--keep", default=None, help="directory to keep the artefacts in")
     ap.add_argument("--max-report", type=int, default=6)
@@ -99,7 +100,7 @@ def main():
     keys = dict(k.split("=") for k in a.keys)
     tmp = a.keep or tempfile.mkdtemp(prefix="ctudiff_")
     os.makedirs(tmp, exist_ok=True)
-    yuv = run_reference(tmp, a.width, a.height, a.frames, keys, a.force_intra, a.trace)
+    yuv = run_reference(tmp, a.width, a.height, a.frames, keys, a.force_intra, a.trace, a.seed)
     ref = open(os.path.join(tmp, "ctus.bin"), "rb").read()
     rec = open(os.path.join(tmp, "rec.yuv"), "rb").read()
     src = open(yuv, "rb").read()

@@ -4,7 +4,9 @@ compiled reference (oracle/_ref/ref_lockstep, or ref_ctudump under HOMER_TURNSTI
 tests/golden/streams.json: other picture sizes, clip seeds, QPs, rate-control targets, RD modes, transform depths, thread and engine counts.
 
 usage: tools/encoder_fuzz.py [--cases N] [--seed S] [--max-ctus M]        (prints one line per case; exit code = number of differing cases)
-       tools/encoder_fuzz.py WxHxFRAMES:clipseed[:key=value,...] ...      (explicit cases)"""
+       tools/encoder_fuzz.py WxHxFRAMES:clipseed[:key=value,...] ...      (explicit cases)
+       tools/encoder_fuzz.py --gpu ...                                     (GPU box: the device encoder, hmr_gpu_enc_encode, instead of the checker build; the
+                                                                            compiled reference travels there as oracle/_ref/)"""
 import argparse
 import ctypes as C
 import hashlib
@@ -55,7 +57,25 @@ def checker(lib, width, height, frames, clip_seed, keys):
     return stream
 
 
-def random_case(rng, max_ctus):
+def device(lib, ctx, width, height, frames, clip_seed, keys):
+    keys = dict(keys)
+    image_type = 3 if int(keys.pop("force_intra", 0)) else 0
+    cfg = ec.default_cfg(width, height, **keys)
+    enc = C.c_void_p()
+    if lib.hmr_gpu_enc_create(ctx, C.byref(cfg), C.byref(enc)) != 0:
+        return None
+    buf = C.create_string_buffer(8 << 20)
+    nbytes = C.c_long()
+    stream = b""
+    for planes in ec.clip_frames(width, height, frames, seed=clip_seed):
+        st = lib.hmr_gpu_enc_encode(enc, *planes, image_type, buf, len(buf), C.byref(nbytes), None)
+        assert st in (1, 2), lib.hmr_gpu_last_error()
+        stream += buf.raw[:nbytes.value]
+    lib.hmr_gpu_enc_destroy(enc)
+    return stream
+
+
+def random_case(rng, max_ctus, gpu=False):
     while True:
         wc, hc = rng.randint(2, 14), rng.randint(1, 9)
         if wc * hc > max_ctus:
@@ -80,6 +100,8 @@ def random_case(rng, max_ctus):
                 if 2 * n >= wc:
                     wpp = n
         if mode == "rdfull" and wpp < 2:
+            continue
+        if gpu and mode == "rc" and wpp < 2:       # (the device encoder runs rate control with one thread per CTU row only)
             continue
         if wpp > 1:
             keys["wpp"] = wpp
@@ -113,15 +135,28 @@ def main():
     ap.add_argument("--cases", type=int, default=20)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-ctus", type=int, default=60)
+    ap.add_argument("--gpu", action="store_true")
     ap.add_argument("specs", nargs="*")
     a = ap.parse_args()
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), CPU_SO])
-    lib = C.CDLL(CPU_SO)
-    lib.henc_cpu_create.restype = C.c_void_p
-    lib.henc_cpu_create.argtypes = [C.POINTER(ec.EncCfg)]
-    lib.henc_cpu_encode_frame.restype = C.c_long
-    lib.henc_cpu_encode_frame.argtypes = [C.c_void_p] + [C.c_char_p] * 3 + [C.c_int, C.c_char_p, C.c_long, C.c_char_p]
-    lib.henc_cpu_destroy.argtypes = [C.c_void_p]
+    ctx = None
+    if a.gpu:
+        import libs
+        lib = libs.load_gpu()
+        lib.hmr_gpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
+        lib.hmr_gpu_enc_create.argtypes = [C.c_void_p, C.POINTER(ec.EncCfg), C.POINTER(C.c_void_p)]
+        lib.hmr_gpu_enc_encode.argtypes = [C.c_void_p] + [C.c_char_p] * 3 + [C.c_int, C.c_char_p, C.c_long, C.POINTER(C.c_long), C.c_char_p]
+        lib.hmr_gpu_enc_destroy.argtypes = [C.c_void_p]
+        lib.hmr_gpu_last_error.restype = C.c_char_p
+        ctx = C.c_void_p()
+        assert lib.hmr_gpu_create(C.byref(ctx), 0, None) == 0, lib.hmr_gpu_last_error()
+    else:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), CPU_SO])
+        lib = C.CDLL(CPU_SO)
+        lib.henc_cpu_create.restype = C.c_void_p
+        lib.henc_cpu_create.argtypes = [C.POINTER(ec.EncCfg)]
+        lib.henc_cpu_encode_frame.restype = C.c_long
+        lib.henc_cpu_encode_frame.argtypes = [C.c_void_p] + [C.c_char_p] * 3 + [C.c_int, C.c_char_p, C.c_long, C.c_char_p]
+        lib.henc_cpu_destroy.argtypes = [C.c_void_p]
     cases = []
     for spec in a.specs:
         parts = spec.split(":")
@@ -130,13 +165,13 @@ def main():
         cases.append((w, h, frames, int(parts[1]) if len(parts) > 1 and parts[1] else 1234, {k: int(v) for k, v in keys.items()}))
     if not cases:
         rng = random.Random(a.seed)
-        cases = [random_case(rng, a.max_ctus) for _ in range(a.cases)]
+        cases = [random_case(rng, a.max_ctus, a.gpu) for _ in range(a.cases)]
     bad = 0
     for w, h, frames, clip_seed, keys in cases:
         spec = f"{w}x{h}x{frames}:{clip_seed}:" + ",".join(f"{k}={v}" for k, v in keys.items())
-        mine = checker(lib, w, h, frames, clip_seed, keys)
+        mine = device(lib, ctx, w, h, frames, clip_seed, keys) if a.gpu else checker(lib, w, h, frames, clip_seed, keys)
         if mine is None:
-            print(spec, "REFUSED by the encoder", flush=True)
+            print(spec, "REFUSED by the encoder" + (": " + lib.hmr_gpu_last_error().decode() if a.gpu else ""), flush=True)
             continue
         ref = reference(w, h, frames, clip_seed, keys)
         if isinstance(ref, str):
@@ -145,7 +180,7 @@ def main():
             continue
         ok = ref == mine
         bad += not ok
-        print(spec, len(ref), "bytes", hashlib.md5(ref).hexdigest(), "IDENTICAL" if ok else f"DIFFERENT (checker: {len(mine)} bytes)", flush=True)
+        print(spec, len(ref), "bytes", hashlib.md5(ref).hexdigest(), "IDENTICAL" if ok else f"DIFFERENT (mine: {len(mine)} bytes)", flush=True)
     return bad
 
 
