@@ -55,7 +55,7 @@ struct EncDev {
 	int *valid, *dirty;           // [nctu]
 	unsigned long long *hash;     // [nctu] digest of what other CTUs can see of a CTU
 	uint32_t *intra_before, *used_intra, *used_parts;   // [nctu] true intra count before the CTU; the counters it was given
-	uint8_t *rowstate;            // [hctu][MODE_STATE_BYTES] lockstep schedule: the mode buffers of the worker of each CTU row, carried from frame to frame
+	uint8_t *rowstate;            // [hctu][ROW_STATE_BYTES] row-per-thread schedule: what a WPP thread carries from CTU to CTU and from frame to frame - its mode buffers and its prediction window
 	int *thread_seen;             // [threads] lockstep schedule: has the WPP thread ever taken the intra walk (Work::thread_seen_intra)
 	int *row0_checked;            // lockstep schedule: steps for which row 0 has made its scene-change check
 	int *counters;                // [0] CTUs found wrong by the last check, [1] CTU encodes of the frame, [2] the CTU at which a scene change is detected (-1: none)
@@ -78,6 +78,21 @@ __device__ __forceinline__ void wave_copy_words(void *dst, const void *src, int 
 	const uint32_t *s = (const uint32_t *)src;
 	for (int i = tid; i < bytes / 4; i += 64) d[i] = s[i];
 }
+// (16 bytes per lane and step; both sides 16-byte aligned, bytes a multiple of 1024)
+__device__ __forceinline__ void wave_copy_quads(void *dst, const void *src, int bytes, int tid)
+{
+	uint4 *d = (uint4 *)dst;
+	const uint4 *s = (const uint4 *)src;
+#pragma unroll 4
+	for (int i = tid; i < bytes / 16; i += 64) d[i] = s[i];
+}
+// The thread's prediction window (Work::pred_y, pred_c: 64 x 64 + 2 x 32 x 32 samples).  A merge candidate whose vector points outside the padded reference
+// picture is evaluated on whatever the window holds (check_rd_cost_merge_2nx2n leaves out the motion compensation and nothing else,
+// hmr_motion_inter.c:3651) - for the first CUs of a CTU that is what the thread's CTU before left there.  So the window travels with the thread like the mode
+// buffers do (found by tools/encoder_fuzz.py --gpu: 400x104, clip 657909, QP 22, a 122-sample vector next to the right picture edge).
+constexpr int PRED_STATE_BYTES = (64 * 64 + 2 * 32 * 32) * 2, ROW_STATE_BYTES = MODE_STATE_BYTES + PRED_STATE_BYTES;
+static_assert(offsetof(Work, pred_c) == offsetof(Work, pred_y) + 64 * 64 * 2 && sizeof(((Work *)nullptr)->pred_c) == 2 * 32 * 32 * 2, "the prediction windows are one block of Work");
+static_assert(MODE_STATE_BYTES % 16 == 0 && offsetof(Work, pred_y) % 16 == 0, "wave_copy_quads alignment");
 
 constexpr int HSCRATCH_ELEMS = 2048 + 144;   // int16 per helper
 // LDS of a row worker: its Work, a copy of the CTU's partition nodes and of the partition geometry
@@ -327,8 +342,8 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 // orders them.  With one workgroup nailed to each CTU row, a step lasts as long as its slowest CTU and the other rows' CUs wait (46 % of the row workers' time
 // at 1080p, profiles/r03_history.md).  Here the CTUs are tasks instead: a persistent workgroup (row worker + helpers, as before) claims the next CTU of ANY
 // picture of the launch whose step is open, encodes it and closes the step when it was the step's last.  What a CTU needs from "its thread" - the mode buffers
-// the reference's WPP thread carries along its rows - travels through EncDev::rowstate; everything else in Work is scratch (checked by wiping it between CTUs,
-// oracle/enc_cpu.cpp HENC_WIPE_WORK).  No workgroup ever waits for a CTU that is not already running (the one exception - a step's CTUs wait for thread 0's
+// the reference's WPP thread carries along its rows, and its prediction window (Q12 above) - travels through EncDev::rowstate; everything else in Work is scratch
+// (checked by wiping it between CTUs, oracle/enc_cpu.cpp HENC_WIPE_WORK).  No workgroup ever waits for a CTU that is not already running (the one exception - a step's CTUs wait for thread 0's
 // scene-change check - is claimed first in its step), so the launch needs no co-residency: any number of workgroups makes progress.
 struct PoolSeq {
 	int *cur_step;      // the open step of the picture
@@ -361,7 +376,8 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 	ti = g.sum(ti);
 	tc = g.sum(tc);
 	// the mode buffers of the thread that owns this row, as the CTU before left them (this row's, or the last one of row - T)
-	wave_copy_words(&e.w->intra_mode_buffs[0][0][0], d.rowstate + (size_t)me * MODE_STATE_BYTES, MODE_STATE_BYTES, g.tid);
+	wave_copy_words(&e.w->intra_mode_buffs[0][0][0], d.rowstate + (size_t)me * ROW_STATE_BYTES, MODE_STATE_BYTES, g.tid);
+	wave_copy_quads(e.w->pred_y, d.rowstate + (size_t)me * ROW_STATE_BYTES + MODE_STATE_BYTES, PRED_STATE_BYTES, g.tid);
 	if (g.tid == 0) e.w->thread_seen_intra = d.thread_seen[me];
 	if (S.rd_mode == RDM_FULL) {
 		// RD_FULL: the thread's shadow CTU keeps its prediction modes from CTU to CTU - all INTRA once the thread has taken the intra walk (motion_intra :2003),
@@ -437,7 +453,8 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 #endif
 	resolve_mode_tokens(g, *e.w, d.ctus[n]);
 	wave_copy_words(d.outtok + (size_t)n * MODE_STATE_BYTES, e.w->intra_mode_buffs, MODE_STATE_BYTES, g.tid);
-	wave_copy_words(d.rowstate + (size_t)me * MODE_STATE_BYTES, &e.w->intra_mode_buffs[0][0][0], MODE_STATE_BYTES, g.tid);
+	wave_copy_words(d.rowstate + (size_t)me * ROW_STATE_BYTES, &e.w->intra_mode_buffs[0][0][0], MODE_STATE_BYTES, g.tid);
+	wave_copy_quads(d.rowstate + (size_t)me * ROW_STATE_BYTES + MODE_STATE_BYTES, e.w->pred_y, PRED_STATE_BYTES, g.tid);
 	if (g.tid == 0) {
 		d.thread_seen[me] = e.w->thread_seen_intra;
 		uint32_t *my_prefix = d.prefix + (size_t)row * (W + 1);
@@ -1273,12 +1290,12 @@ static int enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, int engine_i
 	DEV_ALLOC(e->d.used_intra, s.nctu);
 	DEV_ALLOC(e->d.used_parts, s.nctu);
 	DEV_ALLOC(e->d.counters, 4);
-	DEV_ALLOC(e->d.rowstate, (size_t)s.hctu * MODE_STATE_BYTES);
+	DEV_ALLOC(e->d.rowstate, (size_t)s.hctu * ROW_STATE_BYTES);
 	DEV_ALLOC(e->d.thread_seen, 64);
 	e->d_rowstate_eng[0] = e->d.rowstate;
 	e->d_seen_eng[0] = e->d.thread_seen;
 	for (int k = 1; k < e->local_engines; k++) {
-		DEV_ALLOC(e->d_rowstate_eng[k], (size_t)s.hctu * MODE_STATE_BYTES);
+		DEV_ALLOC(e->d_rowstate_eng[k], (size_t)s.hctu * ROW_STATE_BYTES);
 		DEV_ALLOC(e->d_seen_eng[k], 64);
 	}
 	DEV_ALLOC(e->d.row0_checked, 1);

@@ -28,6 +28,8 @@ CASES = [
     # found by tools/encoder_fuzz.py: two identical merge candidates, the first one's coded evaluation without levels and best - the second one's no-residual evaluation
     # is then the first of that prediction and wins (enc_ctu.h check_rd_cost_merge)
     ("392x136_qp22_clip931814", 392, 136, 4, {"qp": 22, "clip_seed": 931814}),
+    # found by tools/encoder_fuzz.py --gpu: a merge candidate 122 samples outside the right picture edge is evaluated on what the THREAD's prediction window holds (Q12)
+    ("400x104_qp22_perf0_nosao_wpp_rows_clip657909", 400, 104, 3, {"qp": 22, "perf": 0, "sao": 0, "wpp": 2, "clip_seed": 657909}),
     ("1920x1080_cfg2", 1920, 1080, 8, {}),       # BASELINE.json configs[1]
     ("1280x720_intra_period1", 1280, 720, 2, {"intra_period": 1}),   # I, P at 720p (see above)
     # forced intra pictures (encoder_in_out_t.image_type = IMAGE_I on every frame, homer_hevc_enc_api.h:112, honoured hmr_encoder_lib.c:311-313): consecutive I frames

@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--frames", type=int, default=3)
     ap.add_argument("--force-intra", action="store_true")
     ap.add_argument("--seed", type=int, default=1234, help="clip seed (tools/gen_yuv.py)")
+    ap.add_argument("--gpu", action="store_true", help="GPU box: the device encoder (hmr_gpu_enc_frame_ctus) instead of the checker build")
     ap.add_argument("--trace", action="store_true", help="write per-CU traces of both sides next to the dumps")
     ap.add_argument("--keep", default=None, help="directory to keep the artefacts in")
     ap.add_argument("--max-report", type=int, default=6)
@@ -107,6 +108,20 @@ def main():
     fsz = a.width * a.height * 3 // 2
     nctu = ((a.width + 63) // 64) * ((a.height + 63) // 64)
     assert len(ref) == REC * nctu * a.frames, (len(ref), REC, nctu)
+    gpu = None
+    if a.gpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import libs
+        gpu = libs.load_gpu()
+        gpu.hmr_gpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
+        gpu.hmr_gpu_enc_create.argtypes = [C.c_void_p, C.POINTER(HostCfg), C.POINTER(C.c_void_p)]
+        gpu.hmr_gpu_enc_frame_ctus.argtypes = [C.c_void_p] + [C.c_char_p] * 3 + [C.c_int] + [C.c_char_p] * 3 + [C.c_double, C.c_char_p]
+        gpu.hmr_gpu_last_error.restype = C.c_char_p
+        gctx, genc = C.c_void_p(), C.c_void_p()
+        assert gpu.hmr_gpu_create(C.byref(gctx), 0, None) == 0, gpu.hmr_gpu_last_error()
+        gcfg = default_cfg(a.width, a.height, **keys)
+        assert gpu.hmr_gpu_enc_create(gctx, C.byref(gcfg), C.byref(genc)) == 0, gpu.hmr_gpu_last_error()
+        grecs = C.create_string_buffer(REC * nctu)
     lib = load_cpu()
     cfg = default_cfg(a.width, a.height, **keys)
     h = lib.henc_cpu_create(C.byref(cfg))
@@ -124,21 +139,31 @@ def main():
             refs = [None, None, None]
         st = lib.henc_cpu_frame_ctus(h, *planes, 3 if a.force_intra else 0, *refs, -1.0, 0, -1)
         mine = C.string_at(lib.henc_cpu_records(h), REC * nctu)
+        if gpu:         # (the checker runs alongside: its running state - avg_dist - is what the printout below shows)
+            st = gpu.hmr_gpu_enc_frame_ctus(genc, *planes, 3 if a.force_intra else 0, *refs, -1.0, grecs)
+            assert st > 0, gpu.hmr_gpu_last_error()
+            mine = grecs.raw
         nbad = 0
         # (with several WPP threads the reference dumps its records in the order the CTUs finish: pair them by the CTU number in the header)
         by_num = {}
         for k in range(nctu):
             rr = ref[(f * nctu + k) * REC:(f * nctu + k + 1) * REC]
             by_num[int(np.frombuffer(rr[8:12], dtype=np.int32)[0])] = rr
+        ref_f = b"".join(by_num.get(n, ref[(f * nctu + n) * REC:(f * nctu + n + 1) * REC]) for n in range(nctu))
+        if a.gpu:       # (outside the picture the reference's windows hold what the thread's previous CTU left, the device's hold zeros: compare what is coded)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import encoder_cases as ec
+            nx = (a.width + 63) // 64
+            ref_f, mine = bytes(ec.crop_recon(ref_f, a.width, a.height, nx)), bytes(ec.crop_recon(mine, a.width, a.height, nx))
         for n in range(nctu):
-            r = split(by_num.get(n, ref[(f * nctu + n) * REC:(f * nctu + n + 1) * REC]))
+            r = split(ref_f[n * REC:(n + 1) * REC])
             m = split(mine[n * REC:(n + 1) * REC])
             diffs = [name for name, _, _ in FIELDS if not np.array_equal(r[name], m[name]) and not (name == "mode_buffs" and int(keys.get("wpp", 1)) > 1)]
             if diffs:
                 nbad += 1
                 if nbad <= a.max_report:
                     print(f"frame {f} (slice {st}) ctu {n}: mismatch in {diffs}")
-                    for name in diffs[:4]:
+                    for name in diffs[:4 if not a.gpu else 12]:
                         idx = np.flatnonzero(r[name] != m[name])
                         print(f"   {name}: {len(idx)} entries differ, first at {idx[:6]}: ref {r[name][idx[:6]]} mine {m[name][idx[:6]]}")
         print(f"frame {f}: slice_type {st}, {nctu - nbad}/{nctu} CTUs identical, avg_dist after = {lib.henc_cpu_avg_dist(h):.4f}")

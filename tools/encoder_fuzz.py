@@ -26,9 +26,11 @@ CPU_SO = os.path.join(ROOT, "oracle", "libenc_cpu.so")
 
 
 def reference(width, height, frames, clip_seed, keys):
+    keys = dict(keys)
+    cut_at = keys.pop("cut_at", None)
     with tempfile.TemporaryDirectory() as tmp:
         yuv = os.path.join(tmp, "in.yuv")
-        gen_yuv.write_clip(yuv, width, height, frames, clip_seed)
+        gen_yuv.write_clip(yuv, width, height, frames, clip_seed, cut_at)
         turnstile = int(keys.get("wpp", 1)) > 1 or int(keys.get("engines", 1)) > 1
         cmd = [os.path.join(ROOT, "oracle", "_ref", "ref_ctudump" if turnstile else "ref_lockstep"), yuv, os.path.join(tmp, "out.265"), str(width), str(height), str(frames)]
         cmd += [f"{k}={v}" for k, v in keys.items()]
@@ -41,6 +43,7 @@ def reference(width, height, frames, clip_seed, keys):
 
 def checker(lib, width, height, frames, clip_seed, keys):
     keys = dict(keys)
+    cut_at = keys.pop("cut_at", None)
     image_type = 3 if int(keys.pop("force_intra", 0)) else 0
     cfg = ec.default_cfg(width, height, **keys)
     enc = lib.henc_cpu_create(C.byref(cfg))
@@ -48,17 +51,18 @@ def checker(lib, width, height, frames, clip_seed, keys):
         return None
     buf = C.create_string_buffer(8 << 20)
     rec = C.create_string_buffer(width * height * 3 // 2)
-    stream = b""
-    for planes in ec.clip_frames(width, height, frames, seed=clip_seed):
+    units = []
+    for planes in ec.clip_frames(width, height, frames, cut_at, clip_seed):
         n = lib.henc_cpu_encode_frame(enc, *planes, image_type, buf, len(buf), rec)
         assert n > 0
-        stream += buf.raw[:n]
+        units.append(buf.raw[:n])
     lib.henc_cpu_destroy(enc)
-    return stream
+    return units
 
 
 def device(lib, ctx, width, height, frames, clip_seed, keys):
     keys = dict(keys)
+    cut_at = keys.pop("cut_at", None)
     image_type = 3 if int(keys.pop("force_intra", 0)) else 0
     cfg = ec.default_cfg(width, height, **keys)
     enc = C.c_void_p()
@@ -66,13 +70,23 @@ def device(lib, ctx, width, height, frames, clip_seed, keys):
         return None
     buf = C.create_string_buffer(8 << 20)
     nbytes = C.c_long()
-    stream = b""
-    for planes in ec.clip_frames(width, height, frames, seed=clip_seed):
+    units = []
+    for planes in ec.clip_frames(width, height, frames, cut_at, clip_seed):
         st = lib.hmr_gpu_enc_encode(enc, *planes, image_type, buf, len(buf), C.byref(nbytes), None)
         assert st in (1, 2), lib.hmr_gpu_last_error()
-        stream += buf.raw[:nbytes.value]
+        units.append(buf.raw[:nbytes.value])
     lib.hmr_gpu_enc_destroy(enc)
-    return stream
+    return units
+
+
+def load_checker():
+    lib = C.CDLL(CPU_SO)
+    lib.henc_cpu_create.restype = C.c_void_p
+    lib.henc_cpu_create.argtypes = [C.POINTER(ec.EncCfg)]
+    lib.henc_cpu_encode_frame.restype = C.c_long
+    lib.henc_cpu_encode_frame.argtypes = [C.c_void_p] + [C.c_char_p] * 3 + [C.c_int, C.c_char_p, C.c_long, C.c_char_p]
+    lib.henc_cpu_destroy.argtypes = [C.c_void_p]
+    return lib
 
 
 def random_case(rng, max_ctus, gpu=False):
@@ -101,7 +115,7 @@ def random_case(rng, max_ctus, gpu=False):
                     wpp = n
         if mode == "rdfull" and wpp < 2:
             continue
-        if gpu and mode == "rc" and wpp < 2:       # (the device encoder runs rate control with one thread per CTU row only)
+        if gpu and mode in ("rc", "engines") and wpp < 2:       # (the device encoder runs rate control and several engines with one thread per CTU row only)
             continue
         if wpp > 1:
             keys["wpp"] = wpp
@@ -127,6 +141,9 @@ def random_case(rng, max_ctus, gpu=False):
             keys["force_intra"] = 1
         if rng.random() < 0.15 and mode != "engines":
             keys["intra_period"] = rng.choice([2, 3])
+        elif rng.random() < 0.12 and mode != "rc":         # a new scene inside the clip (the in-frame scene-change detection, hmr_motion_inter.c:3791)
+            frames += rng.randint(2, 4)
+            keys["cut_at"] = rng.randint(2, frames - 2)
         return width, height, frames, rng.randint(1, 10 ** 6), keys
 
 
@@ -151,12 +168,7 @@ def main():
         assert lib.hmr_gpu_create(C.byref(ctx), 0, None) == 0, lib.hmr_gpu_last_error()
     else:
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), CPU_SO])
-        lib = C.CDLL(CPU_SO)
-        lib.henc_cpu_create.restype = C.c_void_p
-        lib.henc_cpu_create.argtypes = [C.POINTER(ec.EncCfg)]
-        lib.henc_cpu_encode_frame.restype = C.c_long
-        lib.henc_cpu_encode_frame.argtypes = [C.c_void_p] + [C.c_char_p] * 3 + [C.c_int, C.c_char_p, C.c_long, C.c_char_p]
-        lib.henc_cpu_destroy.argtypes = [C.c_void_p]
+        lib = load_checker()
     cases = []
     for spec in a.specs:
         parts = spec.split(":")
@@ -178,9 +190,19 @@ def main():
             print(spec, "THE REFERENCE FAILED:", ref, flush=True)
             bad += 1
             continue
+        units, mine = mine, b"".join(mine)
         ok = ref == mine
         bad += not ok
         print(spec, len(ref), "bytes", hashlib.md5(ref).hexdigest(), "IDENTICAL" if ok else f"DIFFERENT (mine: {len(mine)} bytes)", flush=True)
+        if not ok:          # which access unit: the reference's stream cut at the lengths of mine
+            o = 0
+            for f, u in enumerate(units):
+                print(f"    frame {f}: {len(u)} bytes", "same" if ref[o:o + len(u)] == u else "DIFFERS from the reference's bytes at this offset", flush=True)
+                o += len(u)
+            if a.gpu and os.path.exists(CPU_SO):        # the checker build on the same case (it travels to the GPU box as test infrastructure)
+                cl = load_checker()
+                cu = checker(cl, w, h, frames, clip_seed, keys)
+                print("    checker build:", "identical to the reference" if cu is not None and b"".join(cu) == ref else "differs too", [len(u) for u in cu or []], flush=True)
     return bad
 
 
