@@ -1,0 +1,35 @@
+"""Random configurations of the frame encoder against the compiled reference (tools/encoder_fuzz.py): picture sizes, clip seeds, QPs, rate-control targets, RD modes,
+transform depths, thread and engine counts, scene cuts drawn from a fixed seed.  The checker build here, the device encoder under -m gpu (oracle/_ref/ travels to the
+GPU box as built files; where it is missing the tests skip).  Longer runs of the same tool: profiles/r04_encoder_fuzz.md."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import encoder_cases as ec
+import libs
+
+TOOL = os.path.join(ec.ROOT, "tools", "encoder_fuzz.py")
+REF = os.path.join(libs.ORACLE_DIR, "_ref", "ref_ctudump")
+
+
+def run(args, timeout):
+    r = subprocess.run([sys.executable, TOOL] + args, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln and not ln.startswith(" ")]
+    bad = [ln for ln in lines if not ln.endswith("IDENTICAL") and "REFUSED" not in ln]
+    assert r.returncode == 0 and not bad, "\n".join(bad[:5]) + r.stderr[-500:]
+    return lines
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not built (the reference's sources are only in the build container)")
+def test_checker_build_on_random_configurations():
+    lines = run(["--cases", "16", "--seed", "101", "--max-ctus", "40"], 1200)
+    assert sum(ln.endswith("IDENTICAL") for ln in lines) >= 15
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not built")
+def test_device_encoder_on_random_configurations():
+    lines = run(["--gpu", "--cases", "120", "--seed", "102", "--max-ctus", "120"], 900)
+    assert sum(ln.endswith("IDENTICAL") for ln in lines) >= 110

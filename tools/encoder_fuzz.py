@@ -89,9 +89,9 @@ def load_checker():
     return lib
 
 
-def random_case(rng, max_ctus, gpu=False):
+def random_case(rng, max_ctus, gpu=False, max_cols=14, max_rows=9):
     while True:
-        wc, hc = rng.randint(2, 14), rng.randint(1, 9)
+        wc, hc = rng.randint(2, max_cols), rng.randint(1, max_rows)
         if wc * hc > max_ctus:
             continue
         # multiples of 8 (the minimum CU); the last CTU column / row partly outside the picture most of the time
@@ -119,12 +119,14 @@ def random_case(rng, max_ctus, gpu=False):
             continue
         if wpp > 1:
             keys["wpp"] = wpp
-        keys["qp"] = rng.choice([22, 27, 30, 32, 32, 35, 38, 42])
+        keys["qp"] = rng.choice([12, 17, 22, 27, 30, 32, 32, 35, 38, 42, 47, 51])
         keys["perf"] = rng.choice([0, 1, 2, 2])
         if rng.random() < 0.3:
             keys["sign_hiding"] = 0
         if rng.random() < 0.4:
             keys["intra_tr"] = rng.choice([1, 3, 4])
+        if rng.random() < 0.25:
+            keys["inter_tr"] = rng.choice([2, 3, 4])
         frames = rng.randint(2, 5)
         if mode == "rc":
             keys["bitrate_mode"] = rng.choice([1, 2])
@@ -152,6 +154,8 @@ def main():
     ap.add_argument("--cases", type=int, default=20)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-ctus", type=int, default=60)
+    ap.add_argument("--max-cols", type=int, default=14, help="CTU columns of the largest picture")
+    ap.add_argument("--max-rows", type=int, default=9)
     ap.add_argument("--gpu", action="store_true")
     ap.add_argument("specs", nargs="*")
     a = ap.parse_args()
@@ -177,7 +181,7 @@ def main():
         cases.append((w, h, frames, int(parts[1]) if len(parts) > 1 and parts[1] else 1234, {k: int(v) for k, v in keys.items()}))
     if not cases:
         rng = random.Random(a.seed)
-        cases = [random_case(rng, a.max_ctus, a.gpu) for _ in range(a.cases)]
+        cases = [random_case(rng, a.max_ctus, a.gpu, a.max_cols, a.max_rows) for _ in range(a.cases)]
     bad = 0
     for w, h, frames, clip_seed, keys in cases:
         spec = f"{w}x{h}x{frames}:{clip_seed}:" + ",".join(f"{k}={v}" for k, v in keys.items())
