@@ -620,7 +620,13 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
             md5s[i].update(units[i])
         for i in range(nrep):
             cumulative[i].append(md5s[i].hexdigest())
+    # the one documented exception to byte identity, counted by the library (include/homer_gpu.h: hmr_gpu_enc_stale_predictions): 0 = it did not occur in these clips
+    stale_total = 0
+    lib.hmr_gpu_enc_stale_predictions.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
     for x in encs:
+        tot = C.c_long()
+        lib.hmr_gpu_enc_stale_predictions(x, None, C.byref(tot))
+        stale_total += tot.value
         lib.hmr_gpu_enc_destroy(x)
     for x in ctxs:
         lib.hmr_gpu_destroy(x)          # (a context holds pinned host memory, HBM staging and a stream)
@@ -683,6 +689,7 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
                        "call": ("hmr_gpu_enc_encode_batch_pipelined: a step's download and entropy coding run under the next step's CTU launch; the pipeline is empty when the timed "
                                 "region starts and flushed inside it" if pipelined else "hmr_gpu_enc_encode_batch" if S > 1 else "hmr_gpu_enc_encode_source")},
             "stream_md5": digest, "stream_matches_reference": bool(matches and all_same), "frames_checked_against_reference": checked,
+            "evaluations_on_a_stale_prediction_window": stale_total,
             "clips": {"distinct": nrep, "by_seed": per_clip, "sequences_of_a_clip_identical": all_same,
                       "note": "sequence i encodes clip i mod distinct (tools/gen_yuv.py seeds: own texture, pan, pattern, box path); each clip's stream is checked against the compiled reference's digests of that clip"},
             "warmup_ms_per_step": [round(x * 1e3, 1) for x in step_wall[:a.warmup]],

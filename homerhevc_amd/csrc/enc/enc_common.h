@@ -7,8 +7,23 @@
 #include <stdio.h>
 extern "C" FILE *henc_trace_file;
 #define HENC_TRACE(...) do { if (henc_trace_file) fprintf(henc_trace_file, __VA_ARGS__); } while (0)
+// the whole prediction window after a call that writes it (oracle/ref_ctudump.c prints the same sums: what a later evaluation on a stale window - quirk Q12 - would see)
+#define HENC_TRACE_PW(e, tag)                                                                                                                      \
+	do {                                                                                                                                       \
+		if (henc_trace_file) {                                                                                                             \
+			unsigned a_[3] = {0, 0, 0};                                                                                                \
+			for (int c_ = 0; c_ < 3; c_++) {                                                                                           \
+				const int n_ = c_ ? 32 : 64;                                                                                       \
+				const int16_t *p_ = c_ ? (e).w->pred_c[c_ - 1] : (e).w->pred_y;                                                    \
+				for (int y_ = 0; y_ < n_; y_++)                                                                                    \
+					for (int x_ = 0; x_ < n_; x_++) a_[c_] += (unsigned)(p_[y_ * n_ + x_] & 0xffff) * (unsigned)(1 + ((x_ + 3 * y_) & 7)); \
+			}                                                                                                                          \
+			fprintf(henc_trace_file, "PW %s ctu=%d pred=%u,%u,%u\n", tag, (e).ctu->ctu_number, a_[0], a_[1], a_[2]);                   \
+		}                                                                                                                                  \
+	} while (0)
 #else
 #define HENC_TRACE(...) do { } while (0)
+#define HENC_TRACE_PW(e, tag) do { } while (0)
 #endif
 
 // Device-side phase timers (profiling build only, -DHENC_PROFILE): lane 0 accumulates s_memtime ticks per phase into Enc::prof.
@@ -77,6 +92,7 @@ struct Enc {
 	uint32_t nb_ctus;         // which neighbour CTUs exist (bit 0 left, 1 top, 2 top right, 3 top left): CtuPublic::has_*, kept here because the record lives in HBM
 	unsigned long long *timeline;   // profiling build: the CTU's timestamps
 	int n_spec_reads, n_ratio_cmp, last_slog;
+	int n_stale_pred;         // (CtuInfo::n_stale_pred of the CTU being encoded)
 	// RD_FULL (enc_rdo.h): the context states the bit estimates of this CTU copy (what the reference's et->ee holds when the CTU is decided), where the last luma
 	// estimate left the shadow CTU's luma-direction pointer (-1: at the CTU's own array), the counter's chroma direction context
 	const uint8_t *rd_ctx;

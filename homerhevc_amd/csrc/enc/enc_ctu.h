@@ -161,15 +161,15 @@ HENC_HD uint32_t encode_intra(const G &g, Enc &__restrict__ e, int curr_depth, i
 	uint32_t cost = 0;
 	if (part_size_type == PART_2Nx2N) {
 		uint32_t cl, cc;
-		{ HENC_PROF_T0(); cl = encode_intra_luma(g, e, curr_depth, position, part_size_type); HENC_PROF_ADD(e, PF_INTRA_TU); }
-		{ HENC_PROF_T0(); cc = encode_intra_chroma(g, e, curr_depth, position, part_size_type); HENC_PROF_ADD(e, PF_INTRA_CHROMA); }
+		{ HENC_PROF_T0(); cl = encode_intra_luma(g, e, curr_depth, position, part_size_type); HENC_PROF_ADD(e, PF_INTRA_TU); } HENC_TRACE_PW(e, "iluma");
+		{ HENC_PROF_T0(); cc = encode_intra_chroma(g, e, curr_depth, position, part_size_type); HENC_PROF_ADD(e, PF_INTRA_CHROMA); } HENC_TRACE_PW(e, "ichroma");
 		cost = cl + cc;
 	} else {
 		for (int n = 0; n < 4; n++) {
 			node_of(e, node_at(e, curr_depth, position) + n).qp = (uint32_t)e.ctu_qp;
-			cost += encode_intra_luma(g, e, curr_depth, position + n, part_size_type);
+			cost += encode_intra_luma(g, e, curr_depth, position + n, part_size_type); HENC_TRACE_PW(e, "iluma");
 		}
-		cost += encode_intra_chroma(g, e, curr_depth, position, part_size_type);
+		cost += encode_intra_chroma(g, e, curr_depth, position, part_size_type); HENC_TRACE_PW(e, "ichroma");
 	}
 	return cost;
 }
@@ -233,11 +233,12 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth,
 				const int spx = gx + mv.x / 4, spy = gy + mv.y / 4;
 				// (the coded evaluation wants the residual too: written on the way where the device's copy path can)
 				if (!(spx < xlow || spx + n > xhigh || spy < ylow || spy + n > yhigh)) have_residual = motion_compensate_cu(g, e, ni, mv, no_res == 0);
+				else e.n_stale_pred++;      // Q12: the candidate is evaluated on what the prediction window holds (see include/homer_gpu.h, hmr_gpu_enc_stale_predictions)
 				mc_done = 1;
 			}
 			if (no_res == 0) {
 				if (!have_residual) predict_all_comps(g, e, ni);
-				cost = dist = encode_inter(g, e, curr_depth, position, PART_2Nx2N);
+				cost = dist = encode_inter(g, e, curr_depth, position, PART_2Nx2N); HENC_TRACE_PW(e, "einter");
 				cost = (uint32_t)((double)cost + cost_rd(e.f->avg_dist, nd.sum));
 				coded_ran = e.inter_ssq_valid;
 			} else if (coded_ran) {
@@ -395,7 +396,7 @@ HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &__restrict__ e)
 				if (curr_depth >= perf_min_depth) {
 					if (!is_skipped) sad = (uint32_t)cu_motion_estimation(g, e, curr_depth, position, PART_2Nx2N, action);   // timed inside (PF_ME_INT / PF_ME_SUB)
 					if (!is_skipped && (q.size < 64 || sad < 100u * num_part_in_cu)) {
-						{ HENC_PROF_T0(); mv_cost = predict_inter(g, e, curr_depth, position, PART_2Nx2N); HENC_PROF_ADD(e, PF_PRED_INTER); }
+						{ HENC_PROF_T0(); mv_cost = predict_inter(g, e, curr_depth, position, PART_2Nx2N); HENC_PROF_ADD(e, PF_PRED_INTER); } HENC_TRACE_PW(e, "pred");
 						{ HENC_PROF_T0(); dist = (double)(int)encode_inter(g, e, curr_depth, position, PART_2Nx2N); HENC_PROF_ADD(e, PF_ENC_INTER); }
 					} else {
 						mv_cost = 0;
@@ -532,8 +533,8 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 		nd->qp = (uint32_t)e.ctu_qp;
 		if (nd->b_inside && nd->r_inside) {
 			if (part_size_type == PART_2Nx2N) {
-				{ HENC_PROF_T0(); cost_luma = encode_intra_luma(g, e, curr_depth, position, part_size_type); HENC_PROF_ADD(e, PF_INTRA_TU); }
-				{ HENC_PROF_T0(); cost_chroma = encode_intra_chroma(g, e, curr_depth, position, part_size_type); HENC_PROF_ADD(e, PF_INTRA_CHROMA); }
+				{ HENC_PROF_T0(); cost_luma = encode_intra_luma(g, e, curr_depth, position, part_size_type); HENC_PROF_ADD(e, PF_INTRA_TU); } HENC_TRACE_PW(e, "iluma");
+				{ HENC_PROF_T0(); cost_chroma = encode_intra_chroma(g, e, curr_depth, position, part_size_type); HENC_PROF_ADD(e, PF_INTRA_CHROMA); } HENC_TRACE_PW(e, "ichroma");
 				nd->cost = (uint32_t)(cost_luma + cost_chroma);
 				cost_sum.add(curr_depth, nd->cost);
 				nd->prediction_mode = PM_INTRA;
@@ -543,14 +544,14 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 				for (int n = 0; n < 4; n++) {
 					Node &sn = node_of(e, curr + n);
 					sn.qp = (uint32_t)e.ctu_qp;
-					sn.cost = encode_intra_luma(g, e, curr_depth, position + n, part_size_type);
+					sn.cost = encode_intra_luma(g, e, curr_depth, position + n, part_size_type); HENC_TRACE_PW(e, "iluma");
 					cost_luma += sn.cost;
 					cost_sum.add(curr_depth, sn.cost);
 					sn.prediction_mode = PM_INTRA;
 				}
 				if (cost_luma < node_of(e, parent).cost && (nd->b_inside && nd->r_inside)) {
 					position = e.geo[e.geo[parent].child[0]].list_index - cfg_depth_start(curr_depth);
-					cost_chroma = encode_intra_chroma(g, e, curr_depth, position, part_size_type);
+					cost_chroma = encode_intra_chroma(g, e, curr_depth, position, part_size_type); HENC_TRACE_PW(e, "ichroma");
 					nd->cost += (uint32_t)cost_chroma;
 					cost_sum.add(curr_depth, (uint32_t)cost_chroma);
 				}
@@ -683,6 +684,7 @@ HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 	c.has_top_right = cy > 0 && cx != S.wctu - 1;
 	e.nb_ctus = (uint32_t)((cx > 0) | ((cy > 0) << 1) | ((cy > 0 && cx != S.wctu - 1) << 2) | ((cx > 0 && cy > 0) << 3));
 	e.n_spec_reads = e.n_ratio_cmp = 0;
+	e.n_stale_pred = 0;
 	// the worker's mode buffers start as "inherited" everywhere (see read_mode_buff, enc_intra.h)
 	for (int i = g.tid; i < 2 * NDEPTH * NPART; i += g.n) (&w.intra_mode_buffs[0][0][0])[i] = (uint8_t)(MODE_TOKEN | ((i / NPART) % NDEPTH));
 	// source CTU
@@ -755,6 +757,7 @@ HENC_HD void ctu_end(const G &g, Enc &__restrict__ e)
 	c.intra_parts = ctu_takes_intra_walk(*e.f, c.ctu_number) ? NPART : cnt;
 	c.distortion = node_of(e, 0).distortion;
 	e.ctu_g->n_spec_reads = e.n_spec_reads;
+	e.ctu_g->n_stale_pred = e.n_stale_pred;
 	e.ctu_g->n_ratio_cmp = e.n_ratio_cmp;
 	g.sync();
 	if (e.ctu_fast) lin_copy_words(g, (const uint32_t *)e.ctu_fast, (uint32_t *)(CtuPublic *)e.ctu_g, (int)(sizeof(CtuPublic) / 4));

@@ -623,6 +623,18 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 {
 	const Seq &S = *e.seq;
 	Work &w = *e.w;
+#if !defined(__HIPCC__) && defined(HENC_TRACE_ENABLE)
+	if (henc_trace_file) {      // what the prediction window holds for this CU when the evaluation starts (oracle/ref_ctudump.c prints the same sums)
+		const Geo &tq = e.geo[node_at(e, depth, part_position)];
+		unsigned a[3] = {0, 0, 0};
+		for (int c = 0; c < 3; c++) {
+			const int n = c ? tq.size_chroma : tq.size, st = c ? 32 : 64;
+			const int16_t *p = c ? w.pred_c[c - 1] + tq.yc * 32 + tq.xc : w.pred_y + tq.y * 64 + tq.x;
+			for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) a[c] += (unsigned)(p[y * st + x] & 0xffff) * (unsigned)(1 + ((x + 3 * y) & 7));
+		}
+		HENC_TRACE("EIN ctu=%d d=%d abs=%d pred=%u,%u,%u\n", e.ctu->ctu_number, depth, tq.abs_index, a[0], a[1], a[2]);
+	}
+#endif
 	const int nxn = part_size_type != PART_2Nx2N;
 	int parent, curr, initial_state, end_state;
 	uint32_t qp;

@@ -114,6 +114,7 @@ struct CtuInfo : CtuPublic {
 	uint8_t ratio_out[MAX_RATIO_CMP];
 	int16_t ratio_slog[MAX_RATIO_CMP];     // the logged search behind the comparison's intra cost, or -1
 	int32_t walk_intra;                    // the CTU took the intra walk (I slice, or after a scene cut)
+	int32_t n_stale_pred;                  // merge candidates of this CTU that pointed outside the padded reference picture and were evaluated on what the prediction window held (Q12)
 	Node nodes[NNODES];
 };
 

@@ -839,6 +839,9 @@ PlanePool g_plane_pool;
 struct hmr_gpu_enc {
 	hmr_gpu_ctx *ctx;
 	HostCfg cfg;
+	// evaluations on a stale prediction window (quirk Q12, hmr_gpu_enc_stale_predictions): of the last picture (-1: not counted - single-thread order), of all pictures
+	long stale_last = -1, stale_total = 0;
+	void note_stale_predictions(uint32_t n) { stale_last = (long)n; stale_total += (long)n; }
 	Seq seq;
 	HostState st;
 	FrameCtx f;
@@ -1563,6 +1566,14 @@ extern "C" int hmr_gpu_enc_post_profile(hmr_gpu_enc *e, unsigned long long *out)
 
 extern "C" float hmr_gpu_enc_last_ctu_ms(hmr_gpu_enc *e) { return e ? e->last_ms : 0.f; }
 
+extern "C" int hmr_gpu_enc_stale_predictions(hmr_gpu_enc *e, long *last_picture, long *all_pictures)
+{
+	if (!e) return HMR_GPU_ERR_ARG;
+	if (last_picture) *last_picture = e->stale_last;
+	if (all_pictures) *all_pictures = e->stale_total;
+	return HMR_GPU_OK;
+}
+
 extern "C" int hmr_gpu_enc_last_stats(hmr_gpu_enc *e, int *passes, int *ctu_encodes, float *ctu_ms, float *frame_ms)
 {
 	if (!e) return HMR_GPU_ERR_ARG;
@@ -1693,17 +1704,19 @@ __global__ void k_gather_results(const EncDev *devs, uint32_t *out, int pitch, c
 	uint32_t *o = out + (size_t)blockIdx.x * pitch;
 	const int nctu = d.seq->nctu;
 	if (threadIdx.x < 3) o[threadIdx.x] = (uint32_t)d.counters[threadIdx.x];
-	if (threadIdx.x == 3) o[3] = (uint32_t)d.post.errors[0] | ((uint32_t)(pool_flags && pool_flags[1] != 0) << 1);
 	// rate control: the sum of the CTUs' QPs (the root nodes': acc_qp, hmr_encoder_lib.c:2938), the bits of all CTUs, the picture target as the frame left it
-	__shared__ uint32_t s_qp, s_bits;
-	if (threadIdx.x == 0) { s_qp = 0; s_bits = 0; }
+	__shared__ uint32_t s_qp, s_bits, s_stale;
+	if (threadIdx.x == 0) { s_qp = 0; s_bits = 0; s_stale = 0; }
 	__syncthreads();
-	uint32_t q = 0, b = 0;
-	for (int c = threadIdx.x; c < nctu; c += blockDim.x) q += d.ctus[c].nodes[0].qp;
+	uint32_t q = 0, b = 0, stale = 0;
+	for (int c = threadIdx.x; c < nctu; c += blockDim.x) { q += d.ctus[c].nodes[0].qp; stale += (uint32_t)d.ctus[c].n_stale_pred; }
 	for (int r = threadIdx.x; r < d.seq->hctu; r += blockDim.x) b += d.post.cumbits[r * d.seq->wctu + d.seq->wctu - 1];
 	atomicAdd(&s_qp, q);
 	atomicAdd(&s_bits, b);
+	atomicAdd(&s_stale, stale);
 	__syncthreads();
+	// word 3: bit 0 a row's sub-stream outgrew its buffer, bit 1 the launch was abandoned, bits 8 ...: the picture's evaluations on a stale prediction window (Q12)
+	if (threadIdx.x == 0) o[3] = (uint32_t)(d.post.errors[0] != 0) | ((uint32_t)(pool_flags && pool_flags[1] != 0) << 1) | ((s_stale > 0xffffffu ? 0xffffffu : s_stale) << 8);
 	if (threadIdx.x == 0) {
 		o[4] = s_qp;
 		o[5] = s_bits;
@@ -1804,6 +1817,7 @@ int frame_finish(hmr_gpu_enc *e, int slot, uint8_t *stream, long cap, long *stre
 	}
 	HIP_TRY(hipStreamSynchronize(st));
 	const uint32_t *gr = e->h_gather;
+	if (e->lockstep) e->note_stale_predictions(gr[3] >> 8);
 	const double acc = e->lockstep ? frame_acc_dist(s, e->cfg.wfpp_num_threads, [&](int n) { return gr[GATHER_HEAD + n]; })
 				       : frame_acc_dist(s, e->cfg.wfpp_num_threads, [&](int n) { return ((const CtuPublic *)(e->h_public.data() + sizeof(CtuPublic) * n))->distortion; });
 	// (a buffer that is too small loses the access unit; the sequence state has not moved on, but the device pictures have: the caller has to start over)
@@ -2027,6 +2041,7 @@ int batch_finish(hmr_gpu_enc **encs, int n, const int *slots, int pitch, BatchTi
 			hmr_set_error("hmr_gpu_enc_encode_batch: sequence %d: a CTU row's sub-stream outgrew its buffer (%d bytes)", i, e->row_cap);
 			return HMR_GPU_ERR_HIP;
 		}
+		e->note_stale_predictions(g[3] >> 8);
 		const int rows = e->seq.wpp ? e->seq.hctu : 1;
 		lead->pend_off[i] = total;
 		lead->h_offs[i] = total;
@@ -2035,6 +2050,7 @@ int batch_finish(hmr_gpu_enc **encs, int n, const int *slots, int pitch, BatchTi
 		total = (total + 255) & ~(size_t)255;
 		e->last_ms = e->last_total_ms = ms;
 		e->last_encodes = (int)g[1];
+		e->note_stale_predictions(g[3] >> 8);
 		e->f.scene_cut_ctu = (int)g[2];
 		e->last_passes = 1;
 		release_planes(e);

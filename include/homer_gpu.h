@@ -632,6 +632,14 @@ int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *slots, const 
 int hmr_gpu_enc_encode_batch_pipelined(hmr_gpu_enc **encs, int n, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes);
 /* the last frame: passes of the CTU schedule, CTU encodes (>= the number of CTUs), device milliseconds of the CTU passes and of the whole frame */
 int hmr_gpu_enc_last_stats(hmr_gpu_enc *enc, int *passes, int *ctu_encodes, float *ctu_ms, float *frame_ms);
+/* The one place where byte identity with the reference is not guaranteed, counted: a merge candidate whose vector points outside the padded reference picture
+ * (more than 80 samples beyond the frame) is evaluated by the reference on whatever its thread's prediction window holds (check_rd_cost_merge_2nx2n leaves out
+ * the motion compensation and nothing else, hmr_motion_inter.c:3651).  The window travels with the thread here too (the stream is the
+ * reference's when its content came from block writes), but the reference's SSE predictors also leave samples outside the blocks they predict (e.g. 255s right of
+ * a 4 x 4 angular chroma block), which are not reproduced.  *last_picture: such evaluations in the last picture encoded through this object (-1: not counted -
+ * wfpp_num_threads = 1), *all_pictures: since the object was created.  0 = the quirk did not occur (every clip of bench.py; 3 of about 3700 random fuzz cases
+ * had it, profiles/r04_encoder_fuzz.md).  Either pointer may be NULL. */
+int hmr_gpu_enc_stale_predictions(hmr_gpu_enc *enc, long *last_picture, long *all_pictures);
 /* profiling build (-DHENC_PROFILE): per-row phase timers, [ctu rows][12] */
 int hmr_gpu_enc_profile(hmr_gpu_enc *enc, unsigned long long *out, int reset);
 /* profiling build, row-per-thread schedule: per CTU four 100 MHz timestamps {wait start, encode start, first use of the intra share (0: none), end}, [ctus][4] */

@@ -427,6 +427,26 @@ void frame_ctus_lockstep(Cpu &c, Enc &e)
 			}
 			e.ctu_qp = ctu_qp_for(c, t, c.f.scene_cut_ctu >= 0 && t >= c.f.scene_cut_ctu % W + 2 * (c.f.scene_cut_ctu / W));
 			e.rd_ctx = rd_ctx_for(c, n);
+			if (getenv("HENC_WIPE_WORK")) {
+				// experiment: a worker that is not the thread (the device's pool, k_encode.hip pool_encode_ctu) - only what travels through the row state
+				// there survives from one CTU of a thread to the next: the mode buffers, the prediction window (quirk Q12), "has taken the intra walk";
+				// with RD_FULL the shadow CTU's prediction modes are rebuilt from that flag
+				Work &w = *e.w;
+				std::vector<uint8_t> modes(MODE_STATE_BYTES), pred(sizeof w.pred_y + sizeof w.pred_c);
+				memcpy(modes.data(), w.intra_mode_buffs, MODE_STATE_BYTES);
+				memcpy(pred.data(), w.pred_y, sizeof w.pred_y);
+				memcpy(pred.data() + sizeof w.pred_y, w.pred_c, sizeof w.pred_c);
+				const int32_t seen = w.thread_seen_intra;
+				WorkSlow *slow = w.slow;
+				memset(&w, atoi(getenv("HENC_WIPE_WORK")), sizeof(Work));
+				memset(slow, atoi(getenv("HENC_WIPE_WORK")), sizeof(WorkSlow));
+				w.slow = slow;
+				memcpy(w.intra_mode_buffs, modes.data(), MODE_STATE_BYTES);
+				memcpy(w.pred_y, pred.data(), sizeof w.pred_y);
+				memcpy(w.pred_c, pred.data() + sizeof w.pred_y, sizeof w.pred_c);
+				w.thread_seen_intra = seen;
+				if (s.rd_mode == RDM_FULL) memset(w.rd_pred_mode, seen ? PM_INTRA : PM_INTER, sizeof w.rd_pred_mode);
+			}
 			memcpy(e.w->mode_in, e.w->intra_mode_buffs, MODE_STATE_BYTES);
 			encode_ctu(g, e, n);
 			resolve_mode_tokens(g, *e.w, c.ctus[n]);
@@ -563,6 +583,15 @@ void henc_cpu_destroy(void *h)
 	free(c->w->slow);
 	free(c->w);
 	delete c;
+}
+
+// evaluations on a stale prediction window (quirk Q12) over all CTUs of the last frame
+long henc_cpu_stale_predictions(void *h)
+{
+	Cpu &c = *(Cpu *)h;
+	long n = 0;
+	for (int k = 0; k < c.seq.nctu; k++) n += c.ctus[k].n_stale_pred;
+	return n;
 }
 
 void henc_cpu_set_sched(void *h, int sched, int row_guess)

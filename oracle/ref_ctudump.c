@@ -308,6 +308,18 @@ int hmr_cu_motion_estimation(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int d
 	return r;
 }
 
+static void trace_pw(henc_thread_t *et, ctu_info_t *ctu, int gcnt, const char *tag)
+{
+	unsigned a[3] = {0, 0, 0};
+	int c, x, y;
+	for (c = 0; c < 3; c++) {
+		int n = c ? 32 : 64, st = WND_STRIDE_2D(et->prediction_wnd[0], c);
+		int16_t *p = WND_POSITION_2D(int16_t *, et->prediction_wnd[0], c, 0, 0, gcnt, et->ctu_width);
+		for (y = 0; y < n; y++) for (x = 0; x < n; x++) a[c] += (unsigned)(p[y * st + x] & 0xffff) * (unsigned)(1 + ((x + 3 * y) & 7));
+	}
+	fprintf(g_trace, "PW %s ctu=%d pred=%u,%u,%u\n", tag, ctu->ctu_number, a[0], a[1], a[2]);
+}
+
 int predict_inter(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int depth, int part_position, PartSize pst)
 {
 	static int (*real)(henc_thread_t *, ctu_info_t *, int, int, int, PartSize);
@@ -316,6 +328,7 @@ int predict_inter(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int depth, int p
 	if (trace()) {
 		cu_partition_info_t *cu = &ctu->partition_list[et->partition_depth_start[depth]] + part_position;
 		fprintf(g_trace, "PRED ctu=%d d=%d abs=%d mvcost=%d\n", ctu->ctu_number, depth, cu->abs_index, r);
+		trace_pw(et, ctu, gcnt, "pred");
 	}
 	return r;
 }
@@ -324,11 +337,26 @@ int encode_inter(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int depth, int pa
 {
 	static int (*real)(henc_thread_t *, ctu_info_t *, int, int, int, PartSize);
 	if (!real) real = next("encode_inter");
+	if (trace()) {      /* what the prediction window holds for this CU when the evaluation starts (quirk Q12: it may be stale) */
+		cu_partition_info_t *cu = &ctu->partition_list[et->partition_depth_start[depth]] + part_position;
+		unsigned sy = 0, su = 0, sv = 0;
+		int x, y, c;
+		for (c = 0; c < 3; c++) {
+			int n = c ? cu->size_chroma : cu->size, px = c ? cu->x_position_chroma : cu->x_position, py = c ? cu->y_position_chroma : cu->y_position;
+			int st = WND_STRIDE_2D(et->prediction_wnd[0], c);
+			int16_t *p = WND_POSITION_2D(int16_t *, et->prediction_wnd[0], c, px, py, gcnt, et->ctu_width);
+			unsigned a = 0;
+			for (y = 0; y < n; y++) for (x = 0; x < n; x++) a += (unsigned)(p[y * st + x] & 0xffff) * (unsigned)(1 + ((x + 3 * y) & 7));
+			if (c == 0) sy = a; else if (c == 1) su = a; else sv = a;
+		}
+		fprintf(g_trace, "EIN ctu=%d d=%d abs=%d pred=%u,%u,%u\n", ctu->ctu_number, depth, cu->abs_index, sy, su, sv);
+	}
 	int r = real(et, ctu, gcnt, depth, part_position, pst);
 	if (trace()) {
 		cu_partition_info_t *cu = &ctu->partition_list[et->partition_depth_start[depth]] + part_position;
 		fprintf(g_trace, "EINTER ctu=%d d=%d abs=%d ret=%d sum=%u cbf=%d,%d,%d\n", ctu->ctu_number, depth, cu->abs_index, r, cu->sum, cu->inter_cbf[0], cu->inter_cbf[1],
 			cu->inter_cbf[2]);
+		trace_pw(et, ctu, gcnt, "einter");
 	}
 	return r;
 }
@@ -341,6 +369,7 @@ uint32_t encode_intra_luma(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int dep
 	if (trace()) {
 		cu_partition_info_t *cu = &ctu->partition_list[et->partition_depth_start[depth]] + part_position;
 		fprintf(g_trace, "ILUMA ctu=%d d=%d abs=%d ret=%u mode=%d sum=%u cost=%u\n", ctu->ctu_number, depth, cu->abs_index, r, cu->intra_mode[0], cu->sum, cu->cost);
+		trace_pw(et, ctu, gcnt, "iluma");
 	}
 	return r;
 }
@@ -407,11 +436,25 @@ uint32_t encode_intra_chroma(henc_thread_t *et, ctu_info_t *ctu, int gcnt, int d
 {
 	static uint32_t (*real)(henc_thread_t *, ctu_info_t *, int, int, int, int);
 	if (!real) real = next("encode_intra_chroma");
+	int16_t dbg_before[32 * 32];
+	int dbg = trace() && getenv("HOMER_DBG_PW") && ctu->ctu_number == 0 && depth == 3 && part_position == 0 && et->enc_engine->num_encoded_frames == 0;
+	if (dbg) {
+		int st = WND_STRIDE_2D(et->prediction_wnd[0], 1), x, y;
+		int16_t *p = WND_POSITION_2D(int16_t *, et->prediction_wnd[0], 1, 0, 0, gcnt, et->ctu_width);
+		for (y = 0; y < 32; y++) for (x = 0; x < 32; x++) dbg_before[y * 32 + x] = p[y * st + x];
+	}
 	uint32_t r = real(et, ctu, gcnt, depth, part_position, pst);
+	if (dbg) {
+		int st = WND_STRIDE_2D(et->prediction_wnd[0], 1), x, y;
+		int16_t *p = WND_POSITION_2D(int16_t *, et->prediction_wnd[0], 1, 0, 0, gcnt, et->ctu_width);
+		for (y = 0; y < 32; y++) for (x = 0; x < 32; x++)
+			if (dbg_before[y * 32 + x] != p[y * st + x]) fprintf(g_trace, "DBGPW U (%d,%d) %d -> %d\n", x, y, dbg_before[y * 32 + x], p[y * st + x]);
+	}
 	if (trace()) {
 		cu_partition_info_t *cu = &ctu->partition_list[et->partition_depth_start[depth]] + part_position;
 		fprintf(g_trace, "ICHROMA ctu=%d d=%d abs=%d ret=%u mode=%d\n", ctu->ctu_number, depth, cu->abs_index, r,
 			et->intra_mode_buffs[1][depth][depth == 0 ? 0 : (pst == SIZE_NxN ? cu->parent->abs_index : cu->abs_index)]);
+		trace_pw(et, ctu, gcnt, "ichroma");
 	}
 	return r;
 }
