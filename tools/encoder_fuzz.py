@@ -87,6 +87,107 @@ def device(lib, ctx, width, height, frames, clip_seed, keys):
     return units
 
 
+def device_batch(lib, group):
+    """the cases of a group advance together: one hmr_gpu_enc_encode_batch call (ONE launch for all their CTU stages) per frame step"""
+    lib.hmr_gpu_enc_load_source.argtypes = [C.c_void_p, C.c_int] + [C.c_char_p] * 3
+    lib.hmr_gpu_enc_encode_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    lib.hmr_gpu_destroy.argtypes = [C.c_void_p]
+    encs, ctxs, types, nfr = [], [], [], []
+    for w, h, frames, clip_seed, keys in group:
+        keys = dict(keys)
+        cut_at = keys.pop("cut_at", None)
+        types.append(3 if int(keys.pop("force_intra", 0)) else 0)
+        cfg = ec.default_cfg(w, h, **keys)
+        ctx, enc = C.c_void_p(), C.c_void_p()
+        assert lib.hmr_gpu_create(C.byref(ctx), 0, None) == 0, lib.hmr_gpu_last_error()
+        assert lib.hmr_gpu_enc_create(ctx, C.byref(cfg), C.byref(enc)) == 0, lib.hmr_gpu_last_error()
+        for f, planes in enumerate(ec.clip_frames(w, h, frames, cut_at, clip_seed)):
+            assert lib.hmr_gpu_enc_load_source(enc, f, *planes) == 0, lib.hmr_gpu_last_error()
+        encs.append(enc); ctxs.append(ctx); nfr.append(frames)
+    bufs = [C.create_string_buffer(8 << 20) for _ in group]
+    out = [[] for _ in group]
+    for f in range(max(nfr)):
+        live = [i for i in range(len(group)) if f < nfr[i]]
+        n = len(live)
+        e_arr = (C.c_void_p * n)(*[encs[i] for i in live])
+        slots = (C.c_int * n)(*([f] * n))
+        its = (C.c_int * n)(*[types[i] for i in live])
+        ptrs = (C.c_char_p * n)(*[C.cast(bufs[i], C.c_char_p) for i in live])
+        caps = (C.c_long * n)(*[len(bufs[i]) for i in live])
+        got = (C.c_long * n)()
+        assert lib.hmr_gpu_enc_encode_batch(e_arr, n, slots, its, ptrs, caps, got) == 0, lib.hmr_gpu_last_error()
+        for k, i in enumerate(live):
+            out[i].append(bufs[i].raw[:got[k]])
+    stale = []
+    for i in range(len(group)):
+        tot = C.c_long()
+        lib.hmr_gpu_enc_stale_predictions(encs[i], None, C.byref(tot))
+        stale.append(tot.value)
+        lib.hmr_gpu_enc_destroy(encs[i])
+        lib.hmr_gpu_destroy(ctxs[i])
+    return out, stale
+
+
+def device_chain(lib, w, h, frames, clip_seed, keys, sets):
+    """a case with several engines through hmr_gpu_enc_encode_chain: the engine objects (and `sets` - 1 twins of each) encode chains of E x sets overlapping frames"""
+    keys = dict(keys)
+    cut_at = keys.pop("cut_at", None)
+    if int(keys.pop("force_intra", 0)):
+        return None
+    E = int(keys["engines"])
+    chain = E * sets
+    lib.hmr_gpu_enc_create_engine.argtypes = [C.c_void_p, C.POINTER(ec.EncCfg), C.c_int, C.POINTER(C.c_void_p)]
+    lib.hmr_gpu_enc_create_engine_twin.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.hmr_gpu_enc_load_source.argtypes = [C.c_void_p, C.c_int] + [C.c_char_p] * 3
+    lib.hmr_gpu_enc_encode_chain.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    lib.hmr_gpu_destroy.argtypes = [C.c_void_p]
+    cfg = ec.default_cfg(w, h, **keys)
+    ctxs, encs = [], []
+    for k in range(E * sets):
+        ctx, enc = C.c_void_p(), C.c_void_p()
+        assert lib.hmr_gpu_create(C.byref(ctx), 0, None) == 0, lib.hmr_gpu_last_error()
+        rc = lib.hmr_gpu_enc_create_engine(ctx, C.byref(cfg), k, C.byref(enc)) if k < E else lib.hmr_gpu_enc_create_engine_twin(ctx, encs[k % E], C.byref(enc))
+        if rc != 0:
+            for x in reversed(encs):
+                lib.hmr_gpu_enc_destroy(x)
+            return None
+        ctxs.append(ctx); encs.append(enc)
+    obj_of, slot_of, used = {}, {}, [0] * len(encs)
+    for f in range(frames):
+        k = ((f % chain) // E) * E + f % E
+        obj_of[f], slot_of[f] = k, used[k]
+        used[k] += 1
+    for f, planes in enumerate(ec.clip_frames(w, h, frames, cut_at, clip_seed)):
+        assert lib.hmr_gpu_enc_load_source(encs[obj_of[f]], slot_of[f], *planes) == 0, lib.hmr_gpu_last_error()
+    bufs = [C.create_string_buffer(8 << 20) for _ in range(chain)]
+    units = []
+    for first in range(0, frames, chain):
+        fs = list(range(first, min(first + chain, frames)))
+        n = len(fs)
+        e_arr = (C.c_void_p * n)(*[encs[obj_of[f]] for f in fs])
+        slots = (C.c_int * n)(*[slot_of[f] for f in fs])
+        ptrs = (C.c_char_p * n)(*[C.cast(bufs[i], C.c_char_p) for i in range(n)])
+        caps = (C.c_long * n)(*[len(bufs[i]) for i in range(n)])
+        got = (C.c_long * n)()
+        prev = encs[obj_of[first - 1]] if first else None
+        rc = lib.hmr_gpu_enc_encode_chain(e_arr, n, prev, slots, None, ptrs, caps, got)
+        if rc != 0:
+            units = lib.hmr_gpu_last_error().decode()
+            break
+        units += [bufs[i].raw[:got[i]] for i in range(n)]
+    global STALE
+    STALE = 0
+    for x in encs:
+        tot = C.c_long()
+        lib.hmr_gpu_enc_stale_predictions(x, None, C.byref(tot))
+        STALE += tot.value
+    for x in reversed(encs):
+        lib.hmr_gpu_enc_destroy(x)
+    for x in ctxs:
+        lib.hmr_gpu_destroy(x)
+    return units
+
+
 def load_checker():
     lib = C.CDLL(CPU_SO)
     lib.henc_cpu_create.restype = C.c_void_p
@@ -99,7 +200,7 @@ def load_checker():
     return lib
 
 
-def random_case(rng, max_ctus, gpu=False, max_cols=14, max_rows=9, threads_only=False):
+def random_case(rng, max_ctus, gpu=False, max_cols=14, max_rows=9, threads_only=False, engines_only=False):
     while True:
         wc, hc = rng.randint(2, max_cols), rng.randint(1, max_rows)
         if wc * hc > max_ctus:
@@ -115,15 +216,17 @@ def random_case(rng, max_ctus, gpu=False, max_cols=14, max_rows=9, threads_only=
             sao = False
         if not sao:
             keys["sao"] = 0
-        mode = rng.choice(["fixed", "fixed", "rc", "rdfull", "engines"])
+        mode = "engines" if engines_only else rng.choice(["fixed", "fixed", "rc", "rdfull", "engines"])
+        if engines_only and not (wc >= 9 or (wc >= 3 and hc <= 4)):
+            continue
         wpp = 1
-        if rng.random() < 0.6 or mode == "rdfull" or threads_only:
+        if rng.random() < 0.6 or mode == "rdfull" or threads_only or engines_only:
             wpp = hc if hc <= 32 else 32
             if hc > 2 and rng.random() < 0.25 and mode != "rdfull":
                 n = rng.randint(2, hc - 1)
                 if 2 * n >= wc:
                     wpp = n
-        if (mode == "rdfull" or threads_only) and wpp < 2:
+        if (mode == "rdfull" or threads_only or engines_only) and wpp < 2:
             continue
         if gpu and mode in ("rc", "engines") and wpp < 2:       # (the device encoder runs rate control and several engines with one thread per CTU row only)
             continue
@@ -146,7 +249,7 @@ def random_case(rng, max_ctus, gpu=False, max_cols=14, max_rows=9, threads_only=
             keys["rd"] = 1
         elif mode == "engines" and (wc >= 9 or (wc >= 3 and hc <= 4)):      # (narrower: the reference's engines deadlock, enc_host.h)
             keys["engines"] = rng.choice([2, 3, 4])
-            frames = rng.randint(5, 10)
+            frames = rng.randint(5, 14 if engines_only else 10)
         elif rng.random() < 0.25:
             keys["rd"] = 0
         if rng.random() < 0.2:
@@ -169,6 +272,9 @@ def main():
     ap.add_argument("--threads-only", action="store_true", help="only cases with several WPP threads (with HENC_WIPE_WORK=<byte> in the environment the checker build then "
                     "keeps of a thread's working memory only what the device's row state carries: oracle/enc_cpu.cpp frame_ctus_lockstep)")
     ap.add_argument("--gpu", action="store_true")
+    ap.add_argument("--chain-sets", type=int, default=0, help="with --gpu: cases with several engines go through hmr_gpu_enc_encode_chain with this many objects per engine (0: hmr_gpu_enc_encode)")
+    ap.add_argument("--engines-only", action="store_true", help="only cases with several engines and several WPP threads")
+    ap.add_argument("--batch", type=int, default=1, help="with --gpu: this many cases per hmr_gpu_enc_encode_batch call (cases the batch call does not take are left out)")
     ap.add_argument("--tolerate-q12", action="store_true", help="do not count a differing case that had evaluations on a stale prediction window (the documented exception) in the exit code")
     ap.add_argument("specs", nargs="*")
     a = ap.parse_args()
@@ -195,11 +301,30 @@ def main():
         cases.append((w, h, frames, int(parts[1]) if len(parts) > 1 and parts[1] else 1234, {k: int(v) for k, v in keys.items()}))
     if not cases:
         rng = random.Random(a.seed)
-        cases = [random_case(rng, a.max_ctus, a.gpu, a.max_cols, a.max_rows, a.threads_only) for _ in range(a.cases)]
+        cases = [random_case(rng, a.max_ctus, a.gpu, a.max_cols, a.max_rows, a.threads_only, a.engines_only) for _ in range(a.cases)]
     bad = q12_bad = 0
-    for w, h, frames, clip_seed, keys in cases:
+    batched = {}
+    if a.gpu and a.batch > 1:       # groups of cases the batch call takes (one thread per CTU row or the in-between counts, one engine) share their launches
+        ok_cases = [c for c in cases if int(c[4].get("wpp", 1)) > 1 and int(c[4].get("engines", 1)) == 1]
+        for k in range(0, len(ok_cases), a.batch):
+            group = ok_cases[k:k + a.batch]
+            units, stale = device_batch(lib, group)
+            for c, u, st in zip(group, units, stale):
+                batched[id(c)] = (u, st)
+        cases = ok_cases
+    global STALE
+    for case in cases:
+        w, h, frames, clip_seed, keys = case
         spec = f"{w}x{h}x{frames}:{clip_seed}:" + ",".join(f"{k}={v}" for k, v in keys.items())
-        mine = device(lib, ctx, w, h, frames, clip_seed, keys) if a.gpu else checker(lib, w, h, frames, clip_seed, keys)
+        if id(case) in batched:
+            mine, STALE = batched[id(case)]
+        elif a.gpu and a.chain_sets and int(keys.get("engines", 1)) > 1 and int(keys.get("wpp", 1)) > 1 and not int(keys.get("force_intra", 0)):
+            mine = device_chain(lib, w, h, frames, clip_seed, keys, a.chain_sets)
+            if isinstance(mine, str):
+                print(spec if False else f"{w}x{h}x{frames}:{clip_seed}:" + ",".join(f"{k}={v}" for k, v in keys.items()), "CHAIN CALL REFUSED:", mine, flush=True)
+                continue
+        else:
+            mine = device(lib, ctx, w, h, frames, clip_seed, keys) if a.gpu else checker(lib, w, h, frames, clip_seed, keys)
         if mine is None:
             print(spec, "REFUSED by the encoder" + (": " + lib.hmr_gpu_last_error().decode() if a.gpu else ""), flush=True)
             continue
