@@ -14,11 +14,19 @@ TOOL = os.path.join(ec.ROOT, "tools", "encoder_fuzz.py")
 REF = os.path.join(libs.ORACLE_DIR, "_ref", "ref_ctudump")
 
 
-def run(args, timeout):
+def run(args, timeout, retry=True):
     r = subprocess.run([sys.executable, TOOL] + args, capture_output=True, text=True, timeout=timeout)
     lines = [ln for ln in r.stdout.splitlines() if ln and not ln.startswith(" ")]
     # (a differing case that had evaluations on a stale prediction window is the documented exception, include/homer_gpu.h: hmr_gpu_enc_stale_predictions)
     bad = [ln for ln in lines if "IDENTICAL" not in ln and "REFUSED" not in ln and "quirk Q12" not in ln and "differing cases" not in ln]
+    # a differing case gets a second run on its own: the turnstiled reference has been seen to differ from itself once in about 1900 runs with several engines
+    # (profiles/r04_encoder_fuzz.md, finding 7); a real difference repeats
+    if bad and retry:
+        flags = ["--gpu"] if "--gpu" in args else []
+        if "--chain-sets" in args:
+            flags += ["--chain-sets", args[args.index("--chain-sets") + 1]]
+        again = run(flags + [ln.split()[0] for ln in bad], timeout, retry=False)
+        bad = [ln for ln in again if "IDENTICAL" not in ln]
     assert not bad, "\n".join(bad[:5]) + r.stderr[-500:]
     return lines
 
