@@ -321,7 +321,7 @@ def main():
         elif a.gpu and a.chain_sets and int(keys.get("engines", 1)) > 1 and int(keys.get("wpp", 1)) > 1 and not int(keys.get("force_intra", 0)):
             mine = device_chain(lib, w, h, frames, clip_seed, keys, a.chain_sets)
             if isinstance(mine, str):
-                print(spec if False else f"{w}x{h}x{frames}:{clip_seed}:" + ",".join(f"{k}={v}" for k, v in keys.items()), "CHAIN CALL REFUSED:", mine, flush=True)
+                print(spec, "CHAIN CALL REFUSED:", mine, flush=True)
                 continue
         else:
             mine = device(lib, ctx, w, h, frames, clip_seed, keys) if a.gpu else checker(lib, w, h, frames, clip_seed, keys)
