@@ -94,6 +94,8 @@ int main(int argc, char **argv)
 		else if (!strcmp(k, "force_intra")) force_intra = atoi(v);
 		else if (!strcmp(k, "intra_tr")) c.max_intra_tr_depth = atoi(v);
 		else if (!strcmp(k, "inter_tr")) c.max_inter_tr_depth = atoi(v);
+		else if (!strcmp(k, "me")) c.motion_estimation_precision = atoi(v);      /* 0 PEL, 1 HALF_PEL, 2 QUARTER_PEL */
+		else if (!strcmp(k, "cqo")) c.chroma_qp_offset = atoi(v);
 		else if (!strcmp(k, "sign_hiding")) c.sign_hiding = atoi(v);
 		else if (!strcmp(k, "recon")) recpath = v;
 		else { fprintf(stderr, "unknown key %s\n", k); return 2; }

@@ -30,7 +30,8 @@ class EncCfg(C.Structure):
                 ("vbv_init", C.c_int32), ("reinit_gop_on_scene_change", C.c_int32), ("rd_mode", C.c_int32), ("performance_mode", C.c_int32)]
 
 
-KEY_NAMES = {"engines": "num_enc_engines", "wpp": "wfpp_num_threads", "perf": "performance_mode", "rd": "rd_mode", "sao": "sample_adaptive_offset", "intra_tr": "max_intra_tr_depth", "inter_tr": "max_inter_tr_depth"}
+KEY_NAMES = {"engines": "num_enc_engines", "wpp": "wfpp_num_threads", "perf": "performance_mode", "rd": "rd_mode", "sao": "sample_adaptive_offset", "intra_tr": "max_intra_tr_depth", "inter_tr": "max_inter_tr_depth",
+             "me": "motion_estimation_precision", "cqo": "chroma_qp_offset"}
 
 
 def default_cfg(width, height, **kw):

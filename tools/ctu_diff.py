@@ -40,7 +40,7 @@ def default_cfg(width, height, **kw):
                 max_inter_tr_depth=1, intra_period=100, gop_size=1, num_b=0, num_ref_frames=1, motion_estimation_precision=2, qp=32, chroma_qp_offset=2,
                 num_enc_engines=1, wfpp_enable=1, wfpp_num_threads=1, sign_hiding=1, sample_adaptive_offset=1, bitrate_mode=0, bitrate=20000, vbv_size=20000,
                 vbv_init=7000, reinit_gop_on_scene_change=1, rd_mode=2, performance_mode=2)
-    names = {"wpp": "wfpp_num_threads", "engines": "num_enc_engines", "perf": "performance_mode", "rd": "rd_mode", "sao": "sample_adaptive_offset", "intra_tr": "max_intra_tr_depth", "inter_tr": "max_inter_tr_depth"}
+    names = {"wpp": "wfpp_num_threads", "engines": "num_enc_engines", "perf": "performance_mode", "rd": "rd_mode", "sao": "sample_adaptive_offset", "intra_tr": "max_intra_tr_depth", "inter_tr": "max_inter_tr_depth", "me": "motion_estimation_precision", "cqo": "chroma_qp_offset"}
     for k, v in kw.items():
         setattr(c, names.get(k, k), int(v))
     return c

@@ -200,7 +200,7 @@ def load_checker():
     return lib
 
 
-def random_case(rng, max_ctus, gpu=False, max_cols=14, max_rows=9, threads_only=False, engines_only=False):
+def random_case(rng, max_ctus, gpu=False, max_cols=14, max_rows=9, threads_only=False, engines_only=False, extra_keys=False):
     while True:
         wc, hc = rng.randint(2, max_cols), rng.randint(1, max_rows)
         if wc * hc > max_ctus:
@@ -240,6 +240,10 @@ def random_case(rng, max_ctus, gpu=False, max_cols=14, max_rows=9, threads_only=
             keys["intra_tr"] = rng.choice([1, 3, 4])
         if rng.random() < 0.25:
             keys["inter_tr"] = rng.choice([2, 3, 4])
+        if extra_keys and rng.random() < 0.3:
+            keys["me"] = rng.choice([0, 1])              # motion_estimation_precision: whole / half samples
+        if extra_keys and rng.random() < 0.3:
+            keys["cqo"] = rng.choice([-4, -1, 0, 1, 5])  # chroma_qp_offset
         frames = rng.randint(2, 5)
         if mode == "rc":
             keys["bitrate_mode"] = rng.choice([1, 2])
@@ -273,6 +277,7 @@ def main():
                     "keeps of a thread's working memory only what the device's row state carries: oracle/enc_cpu.cpp frame_ctus_lockstep)")
     ap.add_argument("--gpu", action="store_true")
     ap.add_argument("--chain-sets", type=int, default=0, help="with --gpu: cases with several engines go through hmr_gpu_enc_encode_chain with this many objects per engine (0: hmr_gpu_enc_encode)")
+    ap.add_argument("--extra-keys", action="store_true", help="also draw motion_estimation_precision (me) and chroma_qp_offset (cqo)")
     ap.add_argument("--engines-only", action="store_true", help="only cases with several engines and several WPP threads")
     ap.add_argument("--batch", type=int, default=1, help="with --gpu: this many cases per hmr_gpu_enc_encode_batch call (cases the batch call does not take are left out)")
     ap.add_argument("--tolerate-q12", action="store_true", help="do not count a differing case that had evaluations on a stale prediction window (the documented exception) in the exit code")
@@ -301,7 +306,7 @@ def main():
         cases.append((w, h, frames, int(parts[1]) if len(parts) > 1 and parts[1] else 1234, {k: int(v) for k, v in keys.items()}))
     if not cases:
         rng = random.Random(a.seed)
-        cases = [random_case(rng, a.max_ctus, a.gpu, a.max_cols, a.max_rows, a.threads_only, a.engines_only) for _ in range(a.cases)]
+        cases = [random_case(rng, a.max_ctus, a.gpu, a.max_cols, a.max_rows, a.threads_only, a.engines_only, a.extra_keys) for _ in range(a.cases)]
     bad = q12_bad = 0
     batched = {}
     if a.gpu and a.batch > 1:       # groups of cases the batch call takes (one thread per CTU row or the in-between counts, one engine) share their launches
