@@ -272,19 +272,43 @@ HENC_HD void sync_reference_buffs(const G &g, Enc &__restrict__ e, int ni, int s
 	g.sync();
 	PRIM_END(PP_SYNC);
 }
+// the same samples into the windows first_dst .. last_dst: read once (the windows live in HBM: every copy is a trip there and back), written to each
+template <class G>
+HENC_HD void sync_reference_buffs_range(const G &g, Enc &__restrict__ e, int ni, int src_wnd, int first_dst, int last_dst)
+{
+	PRIM_T0();
+	const Geo &q = e.geo[ni];
+	const int16_t *s = dec_ptr(*e.w, src_wnd, COMP_Y) + q.y * DEC_STRIDE_Y + q.x;
+	const int n = q.size, base = q.y * DEC_STRIDE_Y + q.x;
+	for (int i0 = g.tid; i0 < 2 * n - 1; i0 += 2 * g.n) {      // (2 n - 1 <= 127: two samples per lane of a wavefront)
+		const int i1 = i0 + g.n;
+		const int off0 = i0 < n ? (n - 1) * DEC_STRIDE_Y + i0 : (i0 - n) * DEC_STRIDE_Y + n - 1;
+		const int off1 = i1 < n ? (n - 1) * DEC_STRIDE_Y + i1 : (i1 - n) * DEC_STRIDE_Y + n - 1;
+		const bool two = i1 < 2 * n - 1;
+		const int16_t v0 = s[off0], v1 = two ? s[off1] : (int16_t)0;
+		for (int wnd = first_dst; wnd <= last_dst; wnd++) {
+			int16_t *d = dec_ptr(*e.w, wnd, COMP_Y) + base;
+			d[off0] = v0;
+			if (two) d[off1] = v1;
+		}
+	}
+	g.sync();
+	PRIM_END(PP_SYNC);
+}
 template <class G>
 HENC_HD void sync_reference_buffs_chroma(const G &g, Enc &__restrict__ e, int ni, int src_wnd, int dst_wnd)
 {
 	PRIM_T0();
 	const Geo &q = e.geo[ni];
 	const int n = q.size_chroma;
-	for (int c = COMP_U; c <= COMP_V; c++) {
-		const int16_t *s = dec_ptr(*e.w, src_wnd, c) + q.yc * DEC_STRIDE_C + q.xc;
-		int16_t *d = dec_ptr(*e.w, dst_wnd, c) + q.yc * DEC_STRIDE_C + q.xc;
-		for (int i = g.tid; i < 2 * n - 1; i += g.n) {
-			const int off = i < n ? (n - 1) * DEC_STRIDE_C + i : (i - n) * DEC_STRIDE_C + n - 1;
-			d[off] = s[off];
-		}
+	// (both components' samples are read before either is written: one trip to the windows, not two)
+	const int16_t *su = dec_ptr(*e.w, src_wnd, COMP_U) + q.yc * DEC_STRIDE_C + q.xc, *sv = dec_ptr(*e.w, src_wnd, COMP_V) + q.yc * DEC_STRIDE_C + q.xc;
+	int16_t *du = dec_ptr(*e.w, dst_wnd, COMP_U) + q.yc * DEC_STRIDE_C + q.xc, *dv = dec_ptr(*e.w, dst_wnd, COMP_V) + q.yc * DEC_STRIDE_C + q.xc;
+	for (int i = g.tid; i < 2 * n - 1; i += g.n) {
+		const int off = i < n ? (n - 1) * DEC_STRIDE_C + i : (i - n) * DEC_STRIDE_C + n - 1;
+		const int16_t a = su[off], b = sv[off];
+		du[off] = a;
+		dv[off] = b;
 	}
 	g.sync();
 	PRIM_END(PP_SYNC);
@@ -302,10 +326,27 @@ HENC_HD void sync_cu_comp(const G &g, Enc &__restrict__ e, int ni, int q_src, in
 	const int16_t *qs = tq_ptr(*e.w, q_src, comp) + off;
 	int16_t *qd = tq_ptr(*e.w, q_dst, comp) + off;
 	const int ln = ilog2i(n);
-	for (int i = g.tid * 4; i < n * n; i += g.n * 4) {      // four samples per lane and step (enc_prims.h)
-		const int r = i >> ln, c = i & (n - 1);
-		st4(dd + r * st + c, ld4(ds + r * st + c));
-		st4(qd + i, ld4(qs + i));
+	// four samples per lane and step (enc_prims.h), four steps in flight: the windows are in HBM and the compiler cannot move a load above a store it cannot tell
+	// apart, so the loads of a batch are issued together - a 64 x 64 CU is four trips to memory instead of thirty-two
+	constexpr int BATCH = 4;
+	for (int i0 = g.tid * 4; i0 < n * n; i0 += g.n * 4 * BATCH) {
+		S4 a[BATCH], b[BATCH];
+#pragma unroll
+		for (int u = 0; u < BATCH; u++) {
+			const int i = i0 + u * g.n * 4;
+			if (i < n * n) {
+				a[u] = ld4(ds + (i >> ln) * st + (i & (n - 1)));
+				b[u] = ld4(qs + i);
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < BATCH; u++) {
+			const int i = i0 + u * g.n * 4;
+			if (i < n * n) {
+				st4(dd + (i >> ln) * st + (i & (n - 1)), a[u]);
+				st4(qd + i, b[u]);
+			}
+		}
 	}
 	g.sync();
 	PRIM_END(PP_SYNC);

@@ -28,12 +28,14 @@ HENC_HD void info_buffs_copy(const G &g, Enc &__restrict__ e, int depth, int abs
 			c.intra_mode[0][k] = w.intra_mode_buffs[0][depth][k];
 			c.intra_mode[1][k] = w.intra_mode_buffs[1][depth][k];
 		} else {
-			w.cbf_buffs[0][depth][k] = c.cbf[0][k];
-			w.cbf_buffs[1][depth][k] = c.cbf[1][k];
-			w.cbf_buffs[2][depth][k] = c.cbf[2][k];
-			w.tr_idx_buffs[depth][k] = c.tr_idx[k];
-			w.intra_mode_buffs[0][depth][k] = c.intra_mode[0][k];
-			w.intra_mode_buffs[1][depth][k] = c.intra_mode[1][k];
+			// (the record is in HBM behind a pointer the compiler cannot tell from the worker's buffers: read everything first - one trip to memory, not six)
+			const uint8_t v0 = c.cbf[0][k], v1 = c.cbf[1][k], v2 = c.cbf[2][k], v3 = c.tr_idx[k], v4 = c.intra_mode[0][k], v5 = c.intra_mode[1][k];
+			w.cbf_buffs[0][depth][k] = v0;
+			w.cbf_buffs[1][depth][k] = v1;
+			w.cbf_buffs[2][depth][k] = v2;
+			w.tr_idx_buffs[depth][k] = v3;
+			w.intra_mode_buffs[0][depth][k] = v4;
+			w.intra_mode_buffs[1][depth][k] = v5;
 		}
 	}
 	g.sync();
@@ -147,10 +149,10 @@ HENC_HD void refresh_deeper_windows(const G &g, Enc &__restrict__ e, int aux_ni,
 	const int max_processing_depth = hmin(CFG_MAX_PRED_DEPTH + e.seq->max_intra_tr_depth - 1, NDEPTH - 1);
 	if (from_depth > max_processing_depth) return;
 	const Geo &q = e.geo[aux_ni];
-	for (int aux_depth = from_depth; aux_depth <= max_processing_depth; aux_depth++) {
-		sync_reference_buffs(g, e, aux_ni, 0, aux_depth + 1);
-		if (with_info && e.seq->rd_mode != RDM_DIST_ONLY) info_buffs_copy(g, e, aux_depth, q.abs_index, q.num_part, 0);
-	}
+	// (the reference copies window by window, each followed by the depth's side-info copy; source and destinations are distinct buffers, so the order is free)
+	sync_reference_buffs_range(g, e, aux_ni, 0, from_depth + 1, max_processing_depth + 1);
+	if (with_info && e.seq->rd_mode != RDM_DIST_ONLY)
+		for (int aux_depth = from_depth; aux_depth <= max_processing_depth; aux_depth++) info_buffs_copy(g, e, aux_depth, q.abs_index, q.num_part, 0);
 	sync_reference_buffs_chroma(g, e, aux_ni, 0, NWND - 1);
 }
 

@@ -239,10 +239,20 @@ HENC_PRIM void blk_copy(const G &g, const int16_t *s, int ss, int16_t *d, int ds
 	PRIM_T0();
 	if ((w & 3) == 0 && (w & (w - 1)) == 0) {
 		const int lw = ilog2i(w);
-#pragma unroll 2
-		for (int i = g.tid * 4; i < h * w; i += g.n * 4) {
-			const int y = i >> lw, x = i & (w - 1);
-			st4(d + y * ds + x, ld4(s + y * ss + x));
+		// up to four steps in flight: source or destination may be a window in HBM, and a load cannot pass a store the compiler cannot tell apart from it
+		constexpr int BATCH = 4;
+		for (int i0 = g.tid * 4; i0 < h * w; i0 += g.n * 4 * BATCH) {
+			S4 v[BATCH];
+#pragma unroll
+			for (int u = 0; u < BATCH; u++) {
+				const int i = i0 + u * g.n * 4;
+				if (i < h * w) v[u] = ld4(s + (i >> lw) * ss + (i & (w - 1)));
+			}
+#pragma unroll
+			for (int u = 0; u < BATCH; u++) {
+				const int i = i0 + u * g.n * 4;
+				if (i < h * w) st4(d + (i >> lw) * ds + (i & (w - 1)), v[u]);
+			}
 		}
 	} else {
 		const int lw = ilog2i(w);
