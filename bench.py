@@ -696,7 +696,11 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
             "schedule": {"ctus_per_frame": nctu, "passes_per_frame": [s[3] for s in timed], "ctu_encodes_per_frame": [s[4] for s in timed],
                          "ctu_stage_ms_per_frame": [round(s[5], 1) for s in timed], "device_ms_per_frame": [round(s[6], 1) for s in timed]},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 7),
-                         "traffic": traffic, "launches": launches, "algorithmic_bytes_per_launch": int(S * algo_bytes_frame * len(timed) / max(launches, 1)), "ms_per_launch": round(ctu_ms / max(launches, 1), 2),
+                         "traffic": traffic,
+                         "traffic_source": (f"profiles/r04_pmc_kernels.json: TCC_EA0 read / write requests by width, rocprofv3 --pmc passes of this command on the build of commit "
+                                            f"{pm.get('build_commit')} (the commits after it add 24 KB of per-thread row state read and written per CTU, about 1 % more), bytes per "
+                                            "encoded frame x the frames of one launch") if traffic is not None else None,
+                         "launches": launches, "algorithmic_bytes_per_launch": int(S * algo_bytes_frame * len(timed) / max(launches, 1)), "ms_per_launch": round(ctu_ms / max(launches, 1), 2),
                          "algorithmic_bytes_per_frame": int(algo_bytes_frame), "share_of_device_time": round(ctu_ms / frame_ms, 3),
                          # SURVEY 8-d, the whole P frame (CTU stage + the in-loop filters' read / write): 10.5 W H bytes x frames/s against the same peak
                          "frame_level": {"algorithmic_bytes_per_frame": int(10.5 * width * height), "achieved": round(10.5 * width * height * world * S * a.steps / dt / 1e9, 4),
