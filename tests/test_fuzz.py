@@ -40,21 +40,21 @@ def test_checker_build_on_random_configurations():
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not built")
 def test_device_encoder_on_random_configurations():
-    lines = run(["--gpu", "--cases", "120", "--seed", "102", "--max-ctus", "120"], 900)
-    assert sum("IDENTICAL" in ln for ln in lines) >= 110
+    lines = run(["--gpu", "--cases", "90", "--seed", "102", "--max-ctus", "120"], 900)
+    assert sum("IDENTICAL" in ln for ln in lines) >= 80
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not built")
 def test_device_batch_call_on_random_configurations():
     """eight random cases per hmr_gpu_enc_encode_batch call: CTUs of pictures of different sizes and settings share the pool's workers"""
-    lines = run(["--gpu", "--batch", "8", "--cases", "120", "--seed", "103", "--max-ctus", "120"], 900)
-    assert sum("IDENTICAL" in ln for ln in lines) >= 60
+    lines = run(["--gpu", "--batch", "8", "--cases", "90", "--seed", "103", "--max-ctus", "120"], 900)
+    assert sum("IDENTICAL" in ln for ln in lines) >= 45
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not built")
 def test_device_chain_call_on_random_configurations():
     """several engines through hmr_gpu_enc_encode_chain, two objects per engine: overlapped frames of one sequence"""
-    lines = run(["--gpu", "--engines-only", "--chain-sets", "2", "--cases", "40", "--seed", "104", "--max-ctus", "150", "--max-cols", "16"], 900)
-    assert sum("IDENTICAL" in ln for ln in lines) >= 38
+    lines = run(["--gpu", "--engines-only", "--chain-sets", "2", "--cases", "30", "--seed", "104", "--max-ctus", "150", "--max-cols", "16"], 900)
+    assert sum("IDENTICAL" in ln for ln in lines) >= 28
