@@ -6,7 +6,12 @@ tests/golden/streams.json: other picture sizes, clip seeds, QPs, rate-control ta
 usage: tools/encoder_fuzz.py [--cases N] [--seed S] [--max-ctus M]        (prints one line per case; exit code = number of differing cases)
        tools/encoder_fuzz.py WxHxFRAMES:clipseed[:key=value,...] ...      (explicit cases)
        tools/encoder_fuzz.py --gpu ...                                     (GPU box: the device encoder, hmr_gpu_enc_encode, instead of the checker build; the
-                                                                            compiled reference travels there as oracle/_ref/)"""
+                                                                            compiled reference travels there as oracle/_ref/)
+       ... --gpu --batch K                                                  (K cases per hmr_gpu_enc_encode_batch call: one launch for all their CTU stages)
+       ... --gpu --engines-only --chain-sets M                              (several engines through hmr_gpu_enc_encode_chain, M objects per engine)
+       ... --threads-only / --extra-keys / --max-cols C --max-rows R        (several WPP threads only; also draw me= and cqo=; larger CTU grids)
+A case that differs and had evaluations on a stale prediction window (quirk Q12, include/homer_gpu.h: hmr_gpu_enc_stale_predictions) is marked; --tolerate-q12 keeps it out
+of the exit code.  Runs of the round: profiles/r04_encoder_fuzz.md."""
 import argparse
 import ctypes as C
 import hashlib
