@@ -645,7 +645,7 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
         achieved = S * algo_bytes_frame * len(timed) / (ctu_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed counter passes of this same command: TCC_EA0 requests by their width (64 / 128-byte reads, 64-byte full-line and 32-byte
         # partial-line writes; calibrated on known byte counts, profiles/r04_tcc_calibration.json, as MI355X_MICROARCH.md "HBM" asks for narrow accesses)
-        traffic, issue = None, None
+        traffic, issue, traffic_source = None, None, None
         kernel_name = "k_encode_pool"
         tpath = os.path.join(ROOT, "profiles", "r04_pmc_kernels.json")
         if os.path.exists(tpath) and workload == "cfg2-1080p-encode":
@@ -655,6 +655,17 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
                 dv = k["derived"]      # (by request width where the passes have it, tools/tcc_calibrate.py; else requests x 64 B)
                 per_frame = (dv.get("hbm_read_bytes", dv["hbm_read_bytes_TCC_EA0_RDREQ_x64"]) + dv.get("hbm_write_bytes", dv["hbm_write_bytes_TCC_EA0_WRREQ_x64_upper_bound"])) / frames_profiled
                 traffic = int(per_frame * S * len(timed) / max(launches, 1))       # per launch, like `achieved`
+                traffic_source = (f"profiles/r04_pmc_kernels.json: TCC_EA0 read / write requests by width, rocprofv3 --pmc passes of this command on the build of commit "
+                                  f"{pm.get('build_commit')}, bytes per encoded frame x the frames of one launch")
+                # the memory-side passes repeated on the final build (tools/pmc_traffic.sh) take precedence for the byte count
+                fpath = os.path.join(ROOT, "profiles", "r04_final_traffic_pmc_kernels.json")
+                if os.path.exists(fpath):
+                    fm = json.load(open(fpath))
+                    fd = fm["k_encode_pool"]["derived"]
+                    traffic = int((fd["hbm_read_bytes"] + fd["hbm_write_bytes"]) / fm["frames_encoded_by_k_encode_pool"] * S * len(timed) / max(launches, 1))
+                    traffic_source = (f"profiles/r04_final_traffic_pmc_kernels.json: TCC_EA0 read / write requests by width (64 / 128-byte reads, 64-byte full-line and 32-byte "
+                                      f"partial-line writes), rocprofv3 --pmc passes of a 256-sequence run of this command on the build of commit {fm.get('build_commit')}, bytes per "
+                                      "encoded frame x the frames of one launch")
                 # what actually bounds the kernel: wave-instruction issue (MI355X_MICROARCH.md: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction)
                 valu_per_frame, salu_per_frame = k["SQ_INSTS_VALU"] / frames_profiled, k["SQ_INSTS_SALU"] / frames_profiled
                 fps_kernel = S * len(timed) / (ctu_ms * 1e-3)
@@ -696,10 +707,7 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
             "schedule": {"ctus_per_frame": nctu, "passes_per_frame": [s[3] for s in timed], "ctu_encodes_per_frame": [s[4] for s in timed],
                          "ctu_stage_ms_per_frame": [round(s[5], 1) for s in timed], "device_ms_per_frame": [round(s[6], 1) for s in timed]},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 7),
-                         "traffic": traffic,
-                         "traffic_source": (f"profiles/r04_pmc_kernels.json: TCC_EA0 read / write requests by width, rocprofv3 --pmc passes of this command on the build of commit "
-                                            f"{pm.get('build_commit')} (the commits after it add 24 KB of per-thread row state read and written per CTU, about 1 % more), bytes per "
-                                            "encoded frame x the frames of one launch") if traffic is not None else None,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "launches": launches, "algorithmic_bytes_per_launch": int(S * algo_bytes_frame * len(timed) / max(launches, 1)), "ms_per_launch": round(ctu_ms / max(launches, 1), 2),
                          "algorithmic_bytes_per_frame": int(algo_bytes_frame), "share_of_device_time": round(ctu_ms / frame_ms, 3),
                          # SURVEY 8-d, the whole P frame (CTU stage + the in-loop filters' read / write): 10.5 W H bytes x frames/s against the same peak
