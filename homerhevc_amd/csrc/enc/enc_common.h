@@ -2,6 +2,10 @@
 // neighbour lookup over the partition tree and the window consolidation copies.
 #pragma once
 #include "enc_prims.h"
+#if !defined(__HIPCC__)
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 
 #if !defined(__HIPCC__) && defined(HENC_TRACE_ENABLE)
 #include <stdio.h>
@@ -60,7 +64,11 @@ struct GeoTable {
 
 constexpr int NHELP_MAX = 3;
 // the fixed part of a worker's LDS (k_encode.hip checks that its layout agrees)
-constexpr int LDS_OFF_WORK = 0, LDS_OFF_NODES = (int)((sizeof(Work) + 15) & ~(size_t)15), LDS_OFF_SEQ = LDS_OFF_NODES + (int)((sizeof(Node) * NNODES + 15) & ~(size_t)15),
+// Of the CTU's 341 partition nodes a worker keeps the 85 of depths 0 .. 3 and the 64 depth-4 nodes of ONE quadrant (the 32 x 32 area of a depth-1 node) in its
+// fast memory: the walks are depth first, so while a depth-1 node and what hangs below it is evaluated no depth-4 node of another quadrant is touched (the
+// checker build verifies exactly that at every access); the other three quadrants' depth-4 nodes wait in the CTU's record in HBM (nodes_select_quad).
+constexpr int NODES_RESIDENT = 85, NODE_QUAD = 64, NODE_SLOTS = NODES_RESIDENT + NODE_QUAD;
+constexpr int LDS_OFF_WORK = 0, LDS_OFF_NODES = (int)((sizeof(Work) + 15) & ~(size_t)15), LDS_OFF_SEQ = LDS_OFF_NODES + (int)((sizeof(Node) * NODE_SLOTS + 15) & ~(size_t)15),
 	      LDS_OFF_FRAME = LDS_OFF_SEQ + (int)((sizeof(Seq) + 15) & ~(size_t)15), LDS_OFF_BOX = LDS_OFF_SEQ + (int)((sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15);
 #if defined(__HIP_DEVICE_COMPILE__)
 #define HENC_AT(T, OFFSET) LdsAt<T, OFFSET>
@@ -98,8 +106,9 @@ struct Enc {
 	const uint8_t *rd_ctx;
 	int rd_luma_depth;
 	uint32_t rd_chroma_state;
-	HENC_AT(Node, LDS_OFF_NODES) nodes;      // the CTU's partition nodes: ctu->nodes, or the worker's fast copy of them (nodes_fast != nullptr) while the CTU is encoded
+	HENC_AT(Node, LDS_OFF_NODES) nodes;      // the CTU's partition nodes while the CTU is encoded: the worker's fast copy (NODE_SLOTS of them, see node_of)
 	Node *nodes_fast;
+	int node_quad;            // the quadrant whose depth-4 nodes are in the fast copy (-1: none yet)
 	// helper wavefronts of the worker (device only; nullptr = everything runs on the group itself)
 	HENC_AT(struct HelperBox, LDS_OFF_BOX) box;
 	FastPtr<int16_t> adi_c;              // neighbour array of a chroma block: Work::adi, or a helper's own
@@ -114,7 +123,14 @@ struct Enc {
 // transform chain of a TU) and single candidates of the intra mode search, while the worker itself does luma / the first candidate.  The worker
 // posts a job in LDS and goes on; a helper runs the same SPMD code on its own 64 lanes with its own scratch and reports back.
 enum { HJOB_NONE = 0, HJOB_NEW_CTU, HJOB_INTER_TU, HJOB_INTRA_SAD, HJOB_SYNC_CU, HJOB_SSD, HJOB_CHROMA_SEARCH, HJOB_CHROMA_TU, HJOB_QUIT };
-constexpr int NHELP = 2;   // (a third helper was measured: 3 % slower - one more wavefront polling its mailbox, nothing for it to do most of the time)
+// One helper per worker: it takes BOTH chroma planes of a step, one after the other, while the worker does luma (a workgroup of two wavefronts, so that more
+// workers fit a CU: k_encode.hip).  HENC_NHELP=2 builds the round-4 arrangement, a helper per chroma plane (a third was measured then: 3 % slower).
+#if !defined(HENC_NHELP)
+#define HENC_NHELP 1
+#endif
+constexpr int NHELP = HENC_NHELP;
+static_assert(NHELP == 1 || NHELP == 2, "one helper for both chroma planes, or one per plane");
+constexpr int COMP_UV = 3;   // a helper job's component argument: U, then V
 struct HelperBox {
 	int cmd[NHELP], done[NHELP];   // sequence numbers: helper h runs its next job when cmd[h] moves on, and sets done[h] = cmd[h] when finished
 	int job[NHELP];
@@ -200,7 +216,30 @@ HENC_INLINE int abs2raster(int a)   // abs2raster_table: the Morton de-interleav
 	}
 	return y * 16 + x;
 }
-HENC_INLINE Node &node_of(Enc &__restrict__ e, int idx) { return e.nodes[idx]; }
+HENC_INLINE Node &node_of(Enc &__restrict__ e, int idx)
+{
+#if !defined(__HIPCC__)
+	if (idx >= NODES_RESIDENT && ((idx - NODES_RESIDENT) >> 6) != e.node_quad) {
+		fprintf(stderr, "node_of: depth-4 node %d of quadrant %d while quadrant %d is resident\n", idx, (idx - NODES_RESIDENT) >> 6, e.node_quad);
+		abort();
+	}
+#endif
+	return e.nodes[idx < NODES_RESIDENT ? idx : NODES_RESIDENT + ((idx - NODES_RESIDENT) & (NODE_QUAD - 1))];
+}
+// The candidate derivations copy a CU's left-bottom / top-right flag into the depth-4 node of its corner unit (get_amvp_candidates hmr_motion_inter.c:2354-2355,
+// get_merge_mvp_candidates :1990,:2020) - a lasting change of that node.  For the 64 x 64 CU the corners lie in quadrants 1 and 2, which need not be the resident one:
+// the flag then goes to the CTU's record, where the quadrant is loaded from when the walk gets there.
+HENC_INLINE bool node_is_resident(const Enc &__restrict__ e, int idx) { return idx < NODES_RESIDENT || ((idx - NODES_RESIDENT) >> 6) == e.node_quad; }
+HENC_INLINE void corner_set_left_bottom(Enc &__restrict__ e, int idx, uint8_t v)
+{
+	if (node_is_resident(e, idx)) node_of(e, idx).left_bottom_nb = v;
+	else e.ctu_g->nodes[idx].left_bottom_nb = v;
+}
+HENC_INLINE void corner_set_top_right(Enc &__restrict__ e, int idx, uint8_t v)
+{
+	if (node_is_resident(e, idx)) node_of(e, idx).top_right_nb = v;
+	else e.ctu_g->nodes[idx].top_right_nb = v;
+}
 HENC_INLINE int node_at(const Enc &__restrict__ e, int depth, int position) { return cfg_depth_start(depth) + position; }
 
 // ---- neighbour partitions (hmr_arithmetic_encoding.c:229-355).  Return the CTU that holds the neighbour (nullptr when not
@@ -216,10 +255,11 @@ HENC_INLINE CtuPublic *pu_left(Enc &__restrict__ e, int ni, uint32_t *idx)
 	*idx = gq.abs_left;
 	return (gq.raster_index & 15) == 0 ? ctu_left_of(e) : e.ctu;
 }
-HENC_INLINE CtuPublic *pu_left_bottom(Enc &__restrict__ e, int ni, uint32_t *idx)
+// (ni: the 4 x 4 corner unit the candidate derivations ask about; has_nb: its left_bottom_nb / top_right_nb flag, which the caller has just given it)
+HENC_INLINE CtuPublic *pu_left_bottom(Enc &__restrict__ e, int ni, int has_nb, uint32_t *idx)
 {
 	const Geo &gq = e.geo[ni];
-	if (!node_of(e, ni).left_bottom_nb) return nullptr;
+	if (!has_nb) return nullptr;
 	*idx = gq.abs_left_bottom;
 	if (gq.raster_index == NPART - 16) return nullptr;                     // ctu_left_bottom never exists in raster / wavefront order
 	if ((gq.raster_index & 15) == 0) return ctu_left_of(e);
@@ -234,10 +274,10 @@ HENC_INLINE CtuPublic *pu_top(Enc &__restrict__ e, int ni, uint32_t *idx, int pl
 	if (gq.raster_index < 16) return planar_at_ctu_boundary ? nullptr : ctu_top_of(e);
 	return e.ctu;
 }
-HENC_INLINE CtuPublic *pu_top_right(Enc &__restrict__ e, int ni, uint32_t *idx)
+HENC_INLINE CtuPublic *pu_top_right(Enc &__restrict__ e, int ni, int has_nb, uint32_t *idx)
 {
 	const Geo &gq = e.geo[ni];
-	if (!node_of(e, ni).top_right_nb) return nullptr;
+	if (!has_nb) return nullptr;
 	*idx = gq.abs_top_right;
 	if (gq.raster_index == 15) return ctu_top_right_of(e);
 	if (gq.raster_index < 16) return ctu_top_of(e);
@@ -368,15 +408,38 @@ template <class G>
 HENC_HD void sync_motion_buffers(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
 {
 	if (HENC_HELPERS(e)) {
-		helper_post(g, e, 0, HJOB_SYNC_CU, ni, COMP_U, q_src, q_dst, d_src, d_dst);
-		helper_post(g, e, 1, HJOB_SYNC_CU, ni, COMP_V, q_src, q_dst, d_src, d_dst);
+		if (NHELP >= 2) {
+			helper_post(g, e, 0, HJOB_SYNC_CU, ni, COMP_U, q_src, q_dst, d_src, d_dst);
+			helper_post(g, e, NHELP - 1, HJOB_SYNC_CU, ni, COMP_V, q_src, q_dst, d_src, d_dst);
+		} else helper_post(g, e, 0, HJOB_SYNC_CU, ni, COMP_UV, q_src, q_dst, d_src, d_dst);
 		sync_cu_comp(g, e, ni, q_src, q_dst, d_src, d_dst, COMP_Y);
-		helper_wait(g, e, 0);
-		helper_wait(g, e, 1);
+		for (int h = 0; h < NHELP; h++) helper_wait(g, e, h);
 		return;
 	}
 	sync_motion_buffers_luma(g, e, ni, q_src, q_dst, d_src, d_dst);
 	sync_motion_buffers_chroma(g, e, ni, q_src, q_dst, d_src, d_dst);
+}
+
+// the depth-4 nodes of quadrant `quad` into the worker's fast copy (the ones that were there go back to the CTU's record first)
+template <class G>
+HENC_HD void nodes_select_quad(const G &g, Enc &__restrict__ e, int quad)
+{
+	if (quad == e.node_quad) return;
+	constexpr int WORDS = (int)(sizeof(Node) * NODE_QUAD / 4);
+	Node *cache = &e.nodes[NODES_RESIDENT];
+	g.sync();
+	if (e.node_quad >= 0) lin_copy_words(g, (const uint32_t *)cache, (uint32_t *)(e.ctu_g->nodes + NODES_RESIDENT + NODE_QUAD * e.node_quad), WORDS);
+	lin_copy_words(g, (const uint32_t *)(e.ctu_g->nodes + NODES_RESIDENT + NODE_QUAD * quad), (uint32_t *)cache, WORDS);
+	e.node_quad = quad;
+}
+// the fast copy back into the CTU's record
+template <class G>
+HENC_HD void nodes_write_back(const G &g, Enc &__restrict__ e)
+{
+	g.sync();
+	lin_copy_words(g, (const uint32_t *)&e.nodes[0], (uint32_t *)e.ctu_g->nodes, (int)(sizeof(Node) * NODES_RESIDENT / 4));
+	if (e.node_quad >= 0)
+		lin_copy_words(g, (const uint32_t *)&e.nodes[NODES_RESIDENT], (uint32_t *)(e.ctu_g->nodes + NODES_RESIDENT + NODE_QUAD * e.node_quad), (int)(sizeof(Node) * NODE_QUAD / 4));
 }
 
 // cost helpers (hmr_common.h:53-59): the reference's macros with their operand types

@@ -223,7 +223,7 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth,
 				continue;
 			}
 		}
-		int coded_ran = 0, have_residual = 0;
+		int coded_ran = 0;
 		prev_nores_ran = 0;
 		for (int no_res = 0; no_res < 2; no_res++) {
 			if (no_res == 1 && merge_cand_buffer[cand] == 1) continue;
@@ -233,13 +233,11 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth,
 				const MV mv = w.merge_cands.mv[cand];
 				const int xlow = -S.margin_y, xhigh = S.width + S.margin_y, ylow = -S.margin_y, yhigh = S.height + S.margin_y;
 				const int spx = gx + mv.x / 4, spy = gy + mv.y / 4;
-				// (the coded evaluation wants the residual too: written on the way where the device's copy path can)
-				if (!(spx < xlow || spx + n > xhigh || spy < ylow || spy + n > yhigh)) have_residual = motion_compensate_cu(g, e, ni, mv, no_res == 0);
+				if (!(spx < xlow || spx + n > xhigh || spy < ylow || spy + n > yhigh)) motion_compensate_cu(g, e, ni, mv);
 				else e.n_stale_pred++;      // Q12: the candidate is evaluated on what the prediction window holds (see include/homer_gpu.h, hmr_gpu_enc_stale_predictions)
 				mc_done = 1;
 			}
 			if (no_res == 0) {
-				if (!have_residual) predict_all_comps(g, e, ni);
 				cost = dist = encode_inter(g, e, curr_depth, position, PART_2Nx2N); HENC_TRACE_PW(e, "einter");
 				cost = (uint32_t)((double)cost + cost_rd(e.f->avg_dist, nd.sum));
 				coded_ran = e.inter_ssq_valid;
@@ -254,15 +252,16 @@ HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth,
 				cost = dist;
 			} else {
 				if (HENC_HELPERS(e)) {
-					helper_post(g, e, 0, HJOB_SSD, ni, COMP_U);
-					helper_post(g, e, 1, HJOB_SSD, ni, COMP_V);
+					if (NHELP >= 2) {
+						helper_post(g, e, 0, HJOB_SSD, ni, COMP_U);
+						helper_post(g, e, NHELP - 1, HJOB_SSD, ni, COMP_V);
+					} else helper_post(g, e, 0, HJOB_SSD, ni, COMP_UV);
 				}
 				dist = blk_ssd(g, w.curr_y + q.y * 64 + q.x, 64, w.pred_y + q.y * 64 + q.x, 64, n);
 				if (HENC_HELPERS(e)) {
-					helper_wait(g, e, 0);
-					helper_wait(g, e, 1);
+					for (int h = 0; h < NHELP; h++) helper_wait(g, e, h);
 					dist += (uint32_t)(weight * e.box->r[0][0]);
-					dist += (uint32_t)(weight * e.box->r[1][0]);
+					dist += (uint32_t)(weight * (NHELP >= 2 ? e.box->r[NHELP - 1][0] : e.box->r[0][1]));
 				} else {
 					dist += (uint32_t)(weight * blk_ssd(g, w.curr_c[0] + q.yc * 32 + q.xc, 32, w.pred_c[0] + q.yc * 32 + q.xc, 32, nc));
 					dist += (uint32_t)(weight * blk_ssd(g, w.curr_c[1] + q.yc * 32 + q.xc, 32, w.pred_c[1] + q.yc * 32 + q.xc, 32, nc));
@@ -359,6 +358,7 @@ HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &__restrict__ e)
 		double cost = 0, intra_cost = 0;
 		int stop_recursion = 0, is_skipped = 0;
 		const Geo &q = e.geo[curr];
+		if (q.depth >= 1) nodes_select_quad(g, e, q.abs_index >> 6);
 		Node &nd = node_of(e, curr);
 		curr_depth = q.depth;
 		const int part_size_type = curr_depth < CFG_MAX_PRED_DEPTH ? PART_2Nx2N : PART_NxN;
@@ -527,6 +527,7 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 	}
 	while (curr_depth != initial_depth || depth_state.get(curr_depth) != initial_position + 1) {
 		const Geo &q = e.geo[curr];
+		if (q.depth >= 1) nodes_select_quad(g, e, q.abs_index >> 6);
 		Node *nd = &node_of(e, curr);
 		curr_depth = q.depth;
 		const int part_size_type = curr_depth < CFG_MAX_PRED_DEPTH ? PART_2Nx2N : PART_NxN;
@@ -618,7 +619,7 @@ HENC_HD void create_partition_neighbours(const G &g, Enc &__restrict__ e)
 				const Geo &pq = e.geo.lane(q.parent);
 				if (!((cy + pq.y < S.height) && (cx + pq.x < S.width))) continue;
 			}
-			Node &nd = node_of(e, curr);
+			Node &nd = depth < CFG_MAX_PRED_DEPTH ? e.nodes[curr] : e.ctu_g->nodes[curr];      // (depth 4: the record in HBM - no quadrant is resident yet; the parents are)
 			nd.tl_inside = (cy + q.y < S.height) && (cx + q.x < S.width);
 			nd.b_inside = (cy + q.y + q.size <= S.height);
 			nd.r_inside = (cx + q.x + q.size <= S.width);
@@ -630,7 +631,7 @@ HENC_HD void create_partition_neighbours(const G &g, Enc &__restrict__ e)
 					nd.top_right_nb = has_top_right;
 				} else {
 					const Geo &pq = e.geo.lane(q.parent);
-					const Node &pn = node_of(e, q.parent);
+					const Node &pn = e.nodes[q.parent];
 					nd.left_nb = (pn.left_nb || q.x) ? 1 : 0;
 					nd.top_nb = (pn.top_nb || q.y) ? 1 : 0;
 					nd.left_bottom_nb = ((pn.left_bottom_nb && q.x == pq.x) || (pn.left_nb && q.x == pq.x && q.y == pq.y && valid_lines > q.y + q.size)) ? 1 : 0;
@@ -658,10 +659,12 @@ HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 		lin_copy_words(g, (const uint32_t *)(const CtuPublic *)e.ctu_g, (uint32_t *)e.ctu_fast, (int)(sizeof(CtuPublic) / 4));
 		e.ctu = e.ctu_fast;
 	} else e.ctu = e.ctu_g;
-	if (e.nodes_fast) {
-		lin_copy_words(g, (const uint32_t *)e.ctu_g->nodes, (uint32_t *)e.nodes_fast, (int)(sizeof(Node) * NNODES / 4));
-		e.nodes = e.nodes_fast;
-	} else e.nodes = e.ctu_g->nodes;
+#if !defined(__HIPCC__)
+	e.nodes_fast = (Node *)(((uintptr_t)w.nodes_fast_store + 15) & ~(uintptr_t)15);
+#endif
+	lin_copy_words(g, (const uint32_t *)e.ctu_g->nodes, (uint32_t *)e.nodes_fast, (int)(sizeof(Node) * NODES_RESIDENT / 4));
+	e.nodes = e.nodes_fast;
+	e.node_quad = -1;
 	CtuPublic &c = *e.ctu;
 	e.scratch_a = w.pred_aux;
 	e.scratch_b = w.delta_u;
@@ -763,7 +766,7 @@ HENC_HD void ctu_end(const G &g, Enc &__restrict__ e)
 	e.ctu_g->n_ratio_cmp = e.n_ratio_cmp;
 	g.sync();
 	if (e.ctu_fast) lin_copy_words(g, (const uint32_t *)e.ctu_fast, (uint32_t *)(CtuPublic *)e.ctu_g, (int)(sizeof(CtuPublic) / 4));
-	if (e.nodes_fast) lin_copy_words(g, (const uint32_t *)e.nodes_fast, (uint32_t *)e.ctu_g->nodes, (int)(sizeof(Node) * NNODES / 4));
+	nodes_write_back(g, e);
 	PRIM_END(PP_CTU_IO);
 }
 

@@ -43,11 +43,8 @@ HENC_HD void mc_chroma_interp(const G &g, Enc &__restrict__ e, const int16_t *re
 #endif
 
 // prediction of the node's three blocks for the vector mv (hmr_motion_compensation_luma / _chroma :1779-1907, uni-directional)
-// with_residual: the caller wants the residual source - prediction of the three blocks too (blk_predict, predict_all_comps); true is returned when it has been
-// written on the way (the device's copy path up to 32 x 32: the source samples are at hand in LDS while the prediction bytes are in registers), false when the
-// caller still has to call predict_all_comps.
 template <class G>
-HENC_HD bool motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv, bool with_residual = false)
+HENC_HD void motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv)
 {
 	Work &w = *e.w;
 	const Geo &q = e.geo[ni];
@@ -72,36 +69,20 @@ HENC_HD bool motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv
 			const int i = g.tid + 64 * k;
 			if (i < ychunks) vy[k] = ld32u(py + (i >> lw) * sy + ((i & ((1 << lw) - 1)) << 2));
 		}
-		// four samples: prediction bytes -> 16-bit halves; the residual beside them: source bytes (LDS) - prediction, 16 bits each (v_pk_sub_i16)
-		auto put = [&](uint32_t pv, int16_t *dst, const src_t *src, int16_t *res) {
+		// four samples: prediction bytes -> 16-bit halves
+		auto put = [&](uint32_t pv, int16_t *dst) {
 			const uint32_t o[2] = {__builtin_amdgcn_perm(0u, pv, 0x0c010c00u), __builtin_amdgcn_perm(0u, pv, 0x0c030c02u)};
 			__builtin_memcpy(dst, o, 8);
-			if (with_residual) {
-				const uint32_t sv = ld32u((const uint8_t *)src);
-				typedef short short2_t __attribute__((ext_vector_type(2)));
-				short2_t s0, s1, p0, p1;
-				const uint32_t so[2] = {__builtin_amdgcn_perm(0u, sv, 0x0c010c00u), __builtin_amdgcn_perm(0u, sv, 0x0c030c02u)};
-				__builtin_memcpy(&s0, &so[0], 4); __builtin_memcpy(&s1, &so[1], 4);
-				__builtin_memcpy(&p0, &o[0], 4); __builtin_memcpy(&p1, &o[1], 4);
-				const short2_t r[2] = {s0 - p0, s1 - p1};
-				__builtin_memcpy(res, r, 8);
-			}
 		};
 		if (ic < cchunks) {
-			put(vu, du + rc * 32 + cc, w.curr_c[0] + q.yc * 32 + q.xc + rc * 32 + cc, w.resid_c[0] + q.yc * 32 + q.xc + rc * 32 + cc);
-			put(vv, dv + rc * 32 + cc, w.curr_c[1] + q.yc * 32 + q.xc + rc * 32 + cc, w.resid_c[1] + q.yc * 32 + q.xc + rc * 32 + cc);
+			put(vu, du + rc * 32 + cc);
+			put(vv, dv + rc * 32 + cc);
 		}
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
 			const int i = g.tid + 64 * k;
-			if (i < ychunks) {
-				const int o = (i >> lw) * 64 + ((i & ((1 << lw) - 1)) << 2);
-				put(vy[k], dy + o, w.curr_y + q.y * 64 + q.x + o, w.resid_y + q.y * 64 + q.x + o);
-			}
+			if (i < ychunks) put(vy[k], dy + (i >> lw) * 64 + ((i & ((1 << lw) - 1)) << 2));
 		}
-		g.sync();
-		PRIM_END(PP_INTERP);
-		return with_residual;
 	} else {
 		blk_from_u8(g, e.f->sub_c[0] + oc, sc, w.pred_c[0] + q.yc * 32 + q.xc, 32, q.size_chroma);
 		blk_from_u8(g, e.f->sub_c[1] + oc, sc, w.pred_c[1] + q.yc * 32 + q.xc, 32, q.size_chroma);
@@ -109,13 +90,10 @@ HENC_HD bool motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv
 	}
 	g.sync();
 	PRIM_END(PP_INTERP);
-	return false;
 #else
 	mc_luma_interp(g, e, e.f->ref[0] + gy * S.stride_y + gx, S.stride_y, w.pred_y + q.y * 64 + q.x, 64, q.size, mv.x, mv.y);
 	mc_chroma_interp(g, e, e.f->ref[1] + gyc * S.stride_c + gxc, S.stride_c, w.pred_c[0] + q.yc * 32 + q.xc, 32, q.size_chroma, mv.x, mv.y);
 	mc_chroma_interp(g, e, e.f->ref[2] + gyc * S.stride_c + gxc, S.stride_c, w.pred_c[1] + q.yc * 32 + q.xc, 32, q.size_chroma, mv.x, mv.y);
-	(void)with_residual;
-	return false;
 #endif
 }
 
@@ -413,11 +391,12 @@ HENC_INLINE void get_amvp_candidates(Enc &__restrict__ e, int ni, MvCandList &l)
 	const CornerNodes cn = corner_nodes(e, ni);
 	uint32_t idx_lb = 0, idx_l = 0, idx_tr = 0, idx_t = 0, idx_tl = 0;
 	l.num = 0;
-	node_of(e, cn.lb).left_bottom_nb = node_of(e, ni).left_bottom_nb;
-	node_of(e, cn.tr).top_right_nb = node_of(e, ni).top_right_nb;
-	CtuPublic *c_lb = pu_left_bottom(e, cn.lb, &idx_lb);
+	const uint8_t has_lb = node_of(e, ni).left_bottom_nb, has_tr = node_of(e, ni).top_right_nb;
+	corner_set_left_bottom(e, cn.lb, has_lb);
+	corner_set_top_right(e, cn.tr, has_tr);
+	CtuPublic *c_lb = pu_left_bottom(e, cn.lb, has_lb, &idx_lb);
 	CtuPublic *c_l = pu_left(e, cn.lb, &idx_l);
-	CtuPublic *c_tr = pu_top_right(e, cn.tr, &idx_tr);
+	CtuPublic *c_tr = pu_top_right(e, cn.tr, has_tr, &idx_tr);
 	CtuPublic *c_t = pu_top(e, cn.tr, &idx_t, 0);
 	CtuPublic *c_tl = pu_top_left(e, cn.tl, &idx_tl);
 	const NbUnit u_lb = nb_unit(e, c_lb, idx_lb), u_l = nb_unit(e, c_l, idx_l), u_tr = nb_unit(e, c_tr, idx_tr), u_t = nb_unit(e, c_t, idx_t), u_tl = nb_unit(e, c_tl, idx_tl);
@@ -484,8 +463,9 @@ HENC_INLINE void get_merge_candidates(Enc &__restrict__ e, int ni, MvCandList &l
 		cnt++;
 	}
 	if (cnt >= max_cand) { l.num = cnt; return; }
-	node_of(e, cn.tr).top_right_nb = node_of(e, ni).top_right_nb;
-	CtuPublic *c_tr = pu_top_right(e, cn.tr, &i_tr);
+	const uint8_t has_tr = node_of(e, ni).top_right_nb;
+	corner_set_top_right(e, cn.tr, has_tr);
+	CtuPublic *c_tr = pu_top_right(e, cn.tr, has_tr, &i_tr);
 	const int b0 = c_tr && c_tr->pred_mode[i_tr] != PM_INTRA;
 	if (b0 && (!b1 || !equal_motion(c_t, i_t, c_tr, i_tr))) {
 		inter_modes[cnt] = c_tr->inter_mode[i_tr];
@@ -494,8 +474,9 @@ HENC_INLINE void get_merge_candidates(Enc &__restrict__ e, int ni, MvCandList &l
 		cnt++;
 	}
 	if (cnt >= max_cand) { l.num = cnt; return; }
-	node_of(e, cn.lb).left_bottom_nb = node_of(e, ni).left_bottom_nb;
-	CtuPublic *c_lb = pu_left_bottom(e, cn.lb, &i_lb);
+	const uint8_t has_lb = node_of(e, ni).left_bottom_nb;
+	corner_set_left_bottom(e, cn.lb, has_lb);
+	CtuPublic *c_lb = pu_left_bottom(e, cn.lb, has_lb, &i_lb);
 	const int a0 = c_lb && c_lb->pred_mode[i_lb] != PM_INTRA;
 	if (a0 && (!a1 || !equal_motion(c_l, i_l, c_lb, i_lb))) {
 		inter_modes[cnt] = c_lb->inter_mode[i_lb];
@@ -545,25 +526,25 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 	const double weight = is_y ? 1.0 : e.f->chroma_weight;
 	const int off = is_y ? (q.abs_index << 4) : ((q.abs_index << 4) >> 2);
 	const int16_t *pred = pred_ptr(w, comp) + y * cs + x;
-	int16_t *resid = resid_ptr(w, comp) + y * cs + x;
+	const src_t *orig = curr_ptr(w, comp) + y * cs + x;      // (the residual source - prediction is formed where it is read: the worker keeps no residual window)
 	int16_t *quant = tq_ptr(w, wnd, comp) + off, *iquant = iq_slot(w, comp, off);
 	int16_t *dec = dec_ptr(w, wnd, comp) + y * ds + x;
 	// The chain runs in the worker's fast memory: coefficients in scratch_a, rounding remainders in scratch_b, the levels in the block's slot of the
 	// dequantised-coefficient buffer (dequantised in place afterwards), the reconstructed residual in scratch_b (the reference's separate window, which
 	// nothing else reads); only the final levels and the reconstruction go to the windows in HBM.
 	int16_t *rdec = e.scratch_b;
-	tr_forward(g, HENC_FT(e), e.T, resid, cs, e.scratch_a, e.scratch_b, n, 0);
+	tr_forward(g, HENC_FT(e), e.T, orig, cs, pred, cs, e.scratch_a, e.scratch_b, n, 0);
 	int sum = quantize(g, HENC_FT(e), e.T, e.scratch_a, iquant, e.scratch_b, SCAN_DIAG, curr_depth, comp, 0, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
 	nd.inter_cbf[comp] = (sum ? 1 : 0) << (original_depth - depth);
 	if (is_y) nd.inter_tr_idx = original_depth - depth;
 	uint32_t ssd;
 	if (sum > 0) {
 		lin_copy_nosync(g, iquant, quant, n * n);
-		const uint32_t raw_zero = blk_ssq(g, resid, cs, n);
+		const uint32_t raw_zero = blk_ssd(g, orig, cs, pred, cs, n);
 		if (raw_ssq) *raw_ssq = raw_zero;
 		dequantize(g, HENC_FT(e), e.T, iquant, iquant, curr_depth, comp, 0, n, per, rem);
 		tr_inverse(g, HENC_FT(e), e.T, rdec, n, iquant, e.scratch_a, n, 0);
-		const uint32_t raw = blk_ssd(g, resid, cs, rdec, n, n);
+		const uint32_t raw = blk_ssd_diff(g, orig, cs, pred, cs, rdec, n, n);
 		uint32_t ssd_zero;
 		if (is_y) { ssd_zero = raw_zero; ssd = raw; }
 		else { ssd_zero = (uint32_t)(weight * raw_zero); ssd = (uint32_t)(weight * raw); }
@@ -578,7 +559,7 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 		}
 	} else {
 		lin_zero_nosync(g, quant, n * n);
-		const uint32_t raw = blk_ssq(g, resid, cs, n);
+		const uint32_t raw = blk_ssd(g, orig, cs, pred, cs, n);
 		if (raw_ssq) *raw_ssq = raw;
 		ssd = is_y ? raw : (uint32_t)(weight * raw);
 		blk_reconst(g, pred, cs, (const int16_t *)nullptr, 0, dec, ds, n);
@@ -689,14 +670,16 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 		if (has_chroma && HENC_HELPERS(e)) {
 			// the three components of a TU are independent: the helpers take U and V
 			uint32_t raw = 0;
-			helper_post(g, e, 0, HJOB_INTER_TU, curr, COMP_U, depth, part_size_type);
-			helper_post(g, e, 1, HJOB_INTER_TU, curr, COMP_V, depth, part_size_type);
+			if (NHELP >= 2) {
+				helper_post(g, e, 0, HJOB_INTER_TU, curr, COMP_U, depth, part_size_type);
+				helper_post(g, e, NHELP - 1, HJOB_INTER_TU, curr, COMP_V, depth, part_size_type);
+			} else helper_post(g, e, 0, HJOB_INTER_TU, curr, COMP_UV, depth, part_size_type);
 			dist_y = encode_inter_tu(g, e, curr, COMP_Y, depth, part_size_type, &curr_sum_y, &raw);
-			helper_wait(g, e, 0);
-			helper_wait(g, e, 1);
-			dist_u = e.box->r[0][0]; curr_sum_u = (int)e.box->r[0][1];
-			dist_v = e.box->r[1][0]; curr_sum_v = (int)e.box->r[1][1];
-			e.inter_ssq[0] += raw; e.inter_ssq[1] += e.box->r[0][2]; e.inter_ssq[2] += e.box->r[1][2];
+			for (int h = 0; h < NHELP; h++) helper_wait(g, e, h);
+			const uint32_t *ru = e.box->r[0], *rv = NHELP >= 2 ? e.box->r[NHELP - 1] : e.box->r[0] + 3;
+			dist_u = ru[0]; curr_sum_u = (int)ru[1];
+			dist_v = rv[0]; curr_sum_v = (int)rv[1];
+			e.inter_ssq[0] += raw; e.inter_ssq[1] += ru[2]; e.inter_ssq[2] += rv[2];
 		} else {
 			uint32_t raw = 0;
 			dist_y = encode_inter_tu(g, e, curr, COMP_Y, depth, part_size_type, &curr_sum_y, &raw);
@@ -793,18 +776,6 @@ HENC_HD void set_inter_mv_buffs(const G &g, Enc &__restrict__ e, int ni)
 	g.sync();
 }
 
-template <class G>
-HENC_HD void predict_all_comps(const G &g, Enc &__restrict__ e, int ni)
-{
-	Work &w = *e.w;
-	const Geo &q = e.geo[ni];
-	blk_predict(g, w.curr_y + q.y * 64 + q.x, 64, w.pred_y + q.y * 64 + q.x, 64, w.resid_y + q.y * 64 + q.x, 64, q.size);
-	for (int c = 0; c < 2; c++)
-		blk_predict(g, w.curr_c[c] + q.yc * 32 + q.xc, 32, w.pred_c[c] + q.yc * 32 + q.xc, 32, w.resid_c[c] + q.yc * 32 + q.xc, 32, q.size_chroma);
-}
-
-
-
 // predict_inter :2924 (uni-directional): vector predictor choice, motion compensation, residual.  Returns the vector cost.
 template <class G>
 HENC_HD int predict_inter(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
@@ -825,7 +796,7 @@ HENC_HD int predict_inter(const G &g, Enc &__restrict__ e, int depth, int part_p
 		nd.best_dif_mv.x = mv.x - e.w->amvp.mv[nd.best_candidate_idx].x;
 		nd.best_dif_mv.y = mv.y - e.w->amvp.mv[nd.best_candidate_idx].y;
 		set_inter_mv_buffs(g, e, curr);
-		if (!motion_compensate_cu(g, e, curr, mv, true)) predict_all_comps(g, e, curr);
+		motion_compensate_cu(g, e, curr, mv);      // (the residual the reference writes here, :3046-3055, is formed by the TUs that read it)
 	}
 	return mv_cost;
 }

@@ -220,7 +220,7 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 	const int scan_mode = find_scan_mode(1, 1, n, cu_mode, 0);
 	const int per = nd.qp / 6, rem = nd.qp % 6;
 	const int wnd = curr_depth + 1;
-	int16_t *pred = w.pred_y + q.y * CTU_STRIDE_Y + q.x, *resid = w.resid_y + q.y * CTU_STRIDE_Y + q.x;
+	int16_t *pred = w.pred_y + q.y * CTU_STRIDE_Y + q.x;
 	const src_t *orig = w.curr_y + q.y * CTU_STRIDE_Y + q.x;
 	int16_t *quant = tq_ptr(w, wnd, COMP_Y) + (q.abs_index << 4), *iquant = iq_slot(w, COMP_Y, q.abs_index << 4);
 	int16_t *dec = dec_ptr(w, wnd, COMP_Y) + q.y * DEC_STRIDE_Y + q.x;
@@ -228,9 +228,9 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 	const int filt = intra_is_filtered(cu_mode, inv_depth);
 	node_fill_refs(g, e, ni, wnd, COMP_Y, filt);
 	intra_predict(g, pred, CTU_STRIDE_Y, filt ? w.adi_f : w.adi, n, cu_mode, 1);
-	blk_predict(g, orig, CTU_STRIDE_Y, pred, CTU_STRIDE_Y, resid, CTU_STRIDE_Y, n);
-	// transform chain in fast memory (see encode_inter_tu): levels in the block's slot of the dequantised-coefficient buffer, to the window in HBM when final
-	tr_forward(g, HENC_FT(e), e.T, resid, CTU_STRIDE_Y, w.pred_aux, w.delta_u, n, cu_mode != REG_DCT);
+	// transform chain in fast memory (see encode_inter_tu): the residual source - prediction formed by the transform's first stage, levels in the block's slot of
+	// the dequantised-coefficient buffer (to the window in HBM when final), the reconstructed residual where the rounding remainders were
+	tr_forward(g, HENC_FT(e), e.T, orig, CTU_STRIDE_Y, pred, CTU_STRIDE_Y, w.pred_aux, w.delta_u, n, cu_mode != REG_DCT);
 	const int sum = quantize(g, HENC_FT(e), e.T, w.pred_aux, iquant, w.delta_u, scan_mode, curr_depth, COMP_Y, 1, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
 	*curr_sum = sum;
 	const int tr = curr_depth - depth + (part_size_type == PART_NxN);
@@ -242,8 +242,8 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 	if (sum) {
 		lin_copy_nosync(g, iquant, quant, n * n);
 		dequantize(g, HENC_FT(e), e.T, iquant, iquant, curr_depth, COMP_Y, 1, n, per, rem);
-		tr_inverse(g, HENC_FT(e), e.T, resid, CTU_STRIDE_Y, iquant, w.pred_aux, n, cu_mode != REG_DCT);
-		return blk_reconst_ssd(g, pred, CTU_STRIDE_Y, resid, CTU_STRIDE_Y, orig, CTU_STRIDE_Y, dec, DEC_STRIDE_Y, n);
+		tr_inverse(g, HENC_FT(e), e.T, w.delta_u, n, iquant, w.pred_aux, n, cu_mode != REG_DCT);
+		return blk_reconst_ssd(g, pred, CTU_STRIDE_Y, w.delta_u, n, orig, CTU_STRIDE_Y, dec, DEC_STRIDE_Y, n);
 	}
 	lin_zero_nosync(g, quant, n * n);
 	return blk_reconst_ssd(g, pred, CTU_STRIDE_Y, (const int16_t *)nullptr, 0, orig, CTU_STRIDE_Y, dec, DEC_STRIDE_Y, n);
@@ -427,14 +427,13 @@ HENC_HD int chroma_tu_comp(const G &g, Enc &__restrict__ e, int curr, int c, int
 	Work &w = *e.w;
 	const Geo &q = e.geo[curr];
 	const int n = q.size_chroma, curr_depth = q.depth, qwnd = NWND - 1, dwnd = NWND - 1;
-	int16_t *pred = pred_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc, *resid = resid_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
+	int16_t *pred = pred_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
 	const src_t *orig = curr_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
 	int16_t *quant = tq_ptr(w, qwnd, c) + ((q.abs_index << 4) >> 2), *iquant = iq_slot(w, c, (q.abs_index << 4) >> 2);
 	int16_t *dec = dec_ptr(w, dwnd, c) + q.yc * DEC_STRIDE_C + q.xc;
 	node_fill_refs(g, e, curr, dwnd, c, 0);
 	intra_predict(g, pred, CTU_STRIDE_C, e.adi_c, n, cu_mode, 0);
-	blk_predict(g, orig, CTU_STRIDE_C, pred, CTU_STRIDE_C, resid, CTU_STRIDE_C, n);
-	tr_forward(g, HENC_FT(e), e.T, resid, CTU_STRIDE_C, e.scratch_a, e.scratch_b, n, 0);
+	tr_forward(g, HENC_FT(e), e.T, orig, CTU_STRIDE_C, pred, CTU_STRIDE_C, e.scratch_a, e.scratch_b, n, 0);
 	const int curr_sum = quantize(g, HENC_FT(e), e.T, e.scratch_a, iquant, e.scratch_b, scan_mode, curr_depth, c, 1, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
 	const int cbfv = ((curr_sum ? 1 : 0) << (shifts & 255)) | ((curr_sum ? 1 : 0) << (shifts >> 8));
 	bytes_set(g, &w.cbf_chroma[c - 1][q.abs_index], cbfv, q.num_part);
@@ -442,8 +441,8 @@ HENC_HD int chroma_tu_comp(const G &g, Enc &__restrict__ e, int curr, int c, int
 	if (curr_sum) {
 		lin_copy_nosync(g, iquant, quant, n * n);
 		dequantize(g, HENC_FT(e), e.T, iquant, iquant, curr_depth, c, 1, n, per, rem);
-		tr_inverse(g, HENC_FT(e), e.T, resid, CTU_STRIDE_C, iquant, e.scratch_a, n, 0);
-		raw = blk_reconst_ssd(g, pred, CTU_STRIDE_C, resid, CTU_STRIDE_C, orig, CTU_STRIDE_C, dec, DEC_STRIDE_C, n);
+		tr_inverse(g, HENC_FT(e), e.T, e.scratch_b, n, iquant, e.scratch_a, n, 0);
+		raw = blk_reconst_ssd(g, pred, CTU_STRIDE_C, e.scratch_b, n, orig, CTU_STRIDE_C, dec, DEC_STRIDE_C, n);
 	} else {
 		lin_zero_nosync(g, quant, n * n);
 		raw = blk_reconst_ssd(g, pred, CTU_STRIDE_C, (const int16_t *)nullptr, 0, orig, CTU_STRIDE_C, dec, DEC_STRIDE_C, n);

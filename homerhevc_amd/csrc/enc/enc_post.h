@@ -156,7 +156,7 @@ struct alignas(16) PostScratch {
 	int64_t dist[64];
 };
 #if defined(__HIPCC__)
-static_assert(sizeof(PostScratch) <= sizeof(Work), "the post stage works in the worker's Work area");
+// (k_encode.hip checks that the scratch fits the part of a worker's fast memory that is idle between two CTUs: its Work and the CTU's partition nodes)
 static_assert(sizeof(SubpelScratch) <= sizeof(PostScratch), "task S works in the post stage's scratch");
 #endif
 

@@ -153,6 +153,28 @@ HENC_PRIM uint32_t blk_ssd(const G &g, const S *a, int as, const int16_t *b, int
 	{ const auto prim_ret_ = g.sum(acc); PRIM_END(PP_SSD); return prim_ret_; }
 }
 
+// SSD of the residual source - prediction against a reconstructed residual, the residual formed on the way (16-bit wrap like the reference's predict kernel
+// writes it): what ssd16b(residual window, reconstructed residual) gives, without the window
+template <class G, class S>
+HENC_PRIM uint32_t blk_ssd_diff(const G &g, const S *o, int os, const int16_t *p, int ps, const int16_t *r, int rs, int n)
+{
+	PRIM_T0();
+	const int l = ilog2i(n);
+	uint32_t acc = 0;
+#pragma unroll 2
+	for (int i = g.tid * 4; i < n * n; i += g.n * 4) {
+		const int y = i >> l, x = i & (n - 1);
+		const S4 vo = ld4(o + y * os + x), vp = ld4(p + y * ps + x), vr = ld4(r + y * rs + x);
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const int16_t res = (int16_t)(vo.v[k] - vp.v[k]);
+			const int32_t d = (int16_t)(res - vr.v[k]);
+			acc += (uint32_t)(d * d);
+		}
+	}
+	{ const auto prim_ret_ = g.sum(acc); PRIM_END(PP_SSD); return prim_ret_; }
+}
+
 // sum of squares of a block (ssd16b against the reference's zero row, hmr_motion_inter.c:94)
 template <class G>
 HENC_PRIM uint32_t blk_ssq(const G &g, const int16_t *a, int as, int n)
@@ -812,16 +834,44 @@ HENC_INLINE void load_pairs(const int16_t *p, int32_t (&r)[N / 2])
 	__builtin_memcpy(r, __builtin_assume_aligned(p, N >= 8 ? 16 : 8), N * 2);
 }
 
-// one stage with the input row held by the lane: in[j][0..N) contiguous at in + j * is
-template <int N, class G>
-HENC_HD void tr_stage_rows(const G &g, const int16_t *B, const int16_t *in, int is, int16_t *out, int os_k, int os_j, int shift)
+// where a stage's input rows come from: a 16-bit block, or the residual source - prediction formed on the way (what the reference's predict kernel writes into
+// its residual window - 16-bit wrap included - before the forward transform reads it; the worker keeps no such window)
+template <int N>
+struct RowPlain {
+	const int16_t *in;
+	int is;
+	HENC_INLINE void load(int j, int32_t (&row)[N / 2]) const { load_pairs<N>(in + j * is, row); }
+};
+template <int N, class S>
+struct RowDiff {
+	const S *o;
+	int os;
+	const int16_t *p;
+	int ps;
+	HENC_INLINE void load(int j, int32_t (&row)[N / 2]) const
+	{
+		int32_t pr[N / 2];
+		load_pairs<N>(p + j * ps, pr);
+		S ov[N];
+		__builtin_memcpy(ov, __builtin_assume_aligned(o + j * os, (N * sizeof(S)) >= 16 ? 16 : N * sizeof(S)), N * sizeof(S));
+#pragma unroll
+		for (int h = 0; h < N / 2; h++) {
+			const int16_t lo = (int16_t)((int)ov[2 * h] - (int)(int16_t)(pr[h] & 0xffff)), hi = (int16_t)((int)ov[2 * h + 1] - (int)(int16_t)(pr[h] >> 16));
+			row[h] = pack_pair(lo, hi);
+		}
+	}
+};
+
+// one stage with the input row held by the lane: row j of the source `in`
+template <int N, class G, class Rows>
+HENC_HD void tr_stage_rows_from(const G &g, const int16_t *B, const Rows &in, int16_t *out, int os_k, int os_j, int shift)
 {
 	constexpr int H = N / 2;
 	const int rnd = shift > 0 ? 1 << (shift - 1) : 0;
 	if (G::n % N == 0) {
 		const int j = g.tid % N;
 		int32_t row[H], m[H];
-		load_pairs<N>(in + j * is, row);
+		in.load(j, row);
 #pragma unroll 4
 		for (int k = g.tid / N; k < N; k += (G::n / N ? G::n / N : 1)) {
 			load_pairs<N>(B + k * N, m);
@@ -834,13 +884,19 @@ HENC_HD void tr_stage_rows(const G &g, const int16_t *B, const int16_t *in, int 
 		for (int o = g.tid; o < N * N; o += G::n) {
 			const int j = o % N, k = o / N;
 			int32_t row[H], m[H];
-			load_pairs<N>(in + j * is, row);
+			in.load(j, row);
 			load_pairs<N>(B + k * N, m);
 			int32_t s = 0;
 			for (int h = 0; h < H; h++) s = dot2_acc(m[h], row[h], s);
 			out[k * os_k + j * os_j] = sat16((s + rnd) >> shift);
 		}
 	}
+}
+// ... in[j][0..N) contiguous at in + j * is
+template <int N, class G>
+HENC_HD void tr_stage_rows(const G &g, const int16_t *B, const int16_t *in, int is, int16_t *out, int os_k, int os_j, int shift)
+{
+	tr_stage_rows_from<N>(g, B, RowPlain<N>{in, is}, out, os_k, os_j, shift);
 }
 // the same with the input COLUMN j of a linear N x N array (first inverse stage: the levels come row-major)
 template <int N, class G>
@@ -866,11 +922,11 @@ HENC_HD void tr_stage_cols(const G &g, const int16_t *B, const int16_t *in, int1
 	}
 }
 
-template <int N, class G>
-HENC_HD void tr_forward_n(const G &g, const int16_t *M, const int16_t *block, int bs, int16_t *coeff, int16_t *tmp)
+template <int N, class G, class Rows>
+HENC_HD void tr_forward_n(const G &g, const int16_t *M, const Rows &block, int16_t *coeff, int16_t *tmp)
 {
 	constexpr int L = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
-	tr_stage_rows<N>(g, M, block, bs, tmp, N, 1, L - 1);     // tmp[k][j] = sum_i M[k][i] * block[j][i]
+	tr_stage_rows_from<N>(g, M, block, tmp, N, 1, L - 1);    // tmp[k][j] = sum_i M[k][i] * block[j][i]
 	g.sync();
 	tr_stage_rows<N>(g, M, tmp, N, coeff, N, 1, L + 6);      // coeff[k][j] = sum_i M[k][i] * tmp[j][i]
 	g.sync();
@@ -884,25 +940,26 @@ HENC_HD void tr_inverse_n(const G &g, const int16_t *Mt, int16_t *block, int bs,
 	g.sync();
 }
 
-template <class G>
-HENC_PRIM void tr_forward(const G &g, const FastTables *F, const DevTables *T, const int16_t *block, int bs, int16_t *coeff, int16_t *tmp, int n, int is_dst)
+// forward transform of the residual source - prediction (hmr_motion_intra.c:1036-1040 / hmr_motion_inter.c:57-60: predict, then transform of the residual window)
+template <class G, class S>
+HENC_PRIM void tr_forward(const G &g, const FastTables *F, const DevTables *T, const S *orig, int os, const int16_t *pred, int ps, int16_t *coeff, int16_t *tmp, int n, int is_dst)
 {
 	PRIM_T0();
 	if (!F) {
 		switch (n) {
-		case 4: tr_forward_n<4>(g, is_dst ? T->dst4 : T->dct[0], block, bs, coeff, tmp); break;
-		case 8: tr_forward_n<8>(g, T->dct[1], block, bs, coeff, tmp); break;
-		case 16: tr_forward_n<16>(g, T->dct[2], block, bs, coeff, tmp); break;
-		default: tr_forward_n<32>(g, T->dct[3], block, bs, coeff, tmp); break;
+		case 4: tr_forward_n<4>(g, is_dst ? T->dst4 : T->dct[0], RowDiff<4, S>{orig, os, pred, ps}, coeff, tmp); break;
+		case 8: tr_forward_n<8>(g, T->dct[1], RowDiff<8, S>{orig, os, pred, ps}, coeff, tmp); break;
+		case 16: tr_forward_n<16>(g, T->dct[2], RowDiff<16, S>{orig, os, pred, ps}, coeff, tmp); break;
+		default: tr_forward_n<32>(g, T->dct[3], RowDiff<32, S>{orig, os, pred, ps}, coeff, tmp); break;
 		}
 		PRIM_END(PP_TRF);
 		return;
 	}
 	switch (n) {
-	case 4: tr_forward_n<4>(g, is_dst ? F->dst4 : F->dct, block, bs, coeff, tmp); break;
-	case 8: tr_forward_n<8>(g, F->dct + 16, block, bs, coeff, tmp); break;
-	case 16: tr_forward_n<16>(g, F->dct + 80, block, bs, coeff, tmp); break;
-	default: tr_forward_n<32>(g, F->dct + 336, block, bs, coeff, tmp); break;
+	case 4: tr_forward_n<4>(g, is_dst ? F->dst4 : F->dct, RowDiff<4, S>{orig, os, pred, ps}, coeff, tmp); break;
+	case 8: tr_forward_n<8>(g, F->dct + 16, RowDiff<8, S>{orig, os, pred, ps}, coeff, tmp); break;
+	case 16: tr_forward_n<16>(g, F->dct + 80, RowDiff<16, S>{orig, os, pred, ps}, coeff, tmp); break;
+	default: tr_forward_n<32>(g, F->dct + 336, RowDiff<32, S>{orig, os, pred, ps}, coeff, tmp); break;
 	}
 	PRIM_END(PP_TRF);
 }

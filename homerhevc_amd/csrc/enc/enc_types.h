@@ -208,7 +208,6 @@ constexpr int RD_RING = 8;             // RD_FULL: frames whose coder states are
 struct Work {
 	src_t curr_y[64 * 64], curr_c[2][32 * 32];
 	int16_t pred_y[64 * 64], pred_c[2][32 * 32];
-	int16_t resid_y[64 * 64], resid_c[2][32 * 32];
 #if defined(__HIPCC__)
 	int16_t iq_y[32 * 32], iq_c[2][32 * 32];   // levels, then dequantised coefficients, of the TU in flight (one slot per component: the helpers run chroma beside luma)
 #else
@@ -216,7 +215,12 @@ struct Work {
 #endif
 	uint8_t cbf_buffs[3][NDEPTH][NPART];
 	uint8_t intra_mode_buffs[2][NDEPTH][NPART];
+#if defined(__HIPCC__)
+	const uint8_t (*mode_in)[NDEPTH][NPART];   // what intra_mode_buffs held when the CTU started (the values behind the tokens): on the device the thread's row state in HBM itself,
+	                                           // which the worker rewrites only after the CTU (k_encode.hip) - a token look-up is rare, 2.5 KB of LDS per worker are not
+#else
 	uint8_t mode_in[2][NDEPTH][NPART];     // what intra_mode_buffs held when the CTU started (the values behind the tokens)
+#endif
 	uint8_t tr_idx_buffs[NDEPTH][NPART];
 	uint8_t cbf_chroma[2][NPART];
 	int16_t adi[264], adi_f[264];
@@ -226,6 +230,9 @@ struct Work {
 	int16_t sub_tmp[(64 + 8) * 72];        // checker build: first interpolation stage of a sub-pel candidate / two-stage motion compensation
 #endif
 	MvCandList amvp, merge_cands, search_cands;
+#if !defined(__HIPCC__)
+	uint8_t nodes_fast_store[52 * (85 + 64) + 16];      // checker build: the worker's fast copy of the CTU's partition nodes (enc_common.h NODE_SLOTS; on the device a place in LDS)
+#endif
 	WorkSlow *slow;
 	// Part of the WPP thread's state next to the mode buffers: has this thread ever taken the intra walk?  The reference's thread keeps a shadow CTU whose
 	// pred_mode array is set to INTRA by motion_intra_cu (hmr_motion_intra.c:1783) and never cleared; the most-probable-mode look-up of the mode search reads
@@ -250,7 +257,6 @@ HENC_INLINE int ctu_stride(int comp) { return comp == COMP_Y ? CTU_STRIDE_Y : CT
 HENC_INLINE int16_t *tq_ptr(Work &w, int wnd, int comp) { return comp == COMP_Y ? w.slow->tq_y[wnd] : w.slow->tq_c[wnd][comp - 1]; }
 HENC_INLINE src_t *curr_ptr(Work &w, int comp) { return comp == COMP_Y ? w.curr_y : w.curr_c[comp - 1]; }
 HENC_INLINE int16_t *pred_ptr(Work &w, int comp) { return comp == COMP_Y ? w.pred_y : w.pred_c[comp - 1]; }
-HENC_INLINE int16_t *resid_ptr(Work &w, int comp) { return comp == COMP_Y ? w.resid_y : w.resid_c[comp - 1]; }
 HENC_INLINE int16_t *rdec_ptr(Work &w, int comp) { return comp == COMP_Y ? w.slow->rdec_y : w.slow->rdec_c[comp - 1]; }
 // the TU's slot of the level / dequantised-coefficient buffer (`off`: its place in a CTU-sized buffer, which only the checker build keeps)
 HENC_INLINE int16_t *iq_slot(Work &w, int comp, int off)

@@ -96,7 +96,7 @@ static_assert(MODE_STATE_BYTES % 16 == 0 && offsetof(Work, pred_y) % 16 == 0, "w
 
 constexpr int HSCRATCH_ELEMS = 2048 + 144;   // int16 per helper
 // LDS of a row worker: its Work, a copy of the CTU's partition nodes and of the partition geometry
-constexpr size_t LDS_WORK = (sizeof(Work) + 15) & ~(size_t)15, LDS_NODES = (sizeof(Node) * NNODES + 15) & ~(size_t)15, LDS_GEO = 0;   // (the geometry is in constant memory: enc_common.h GeoTable)
+constexpr size_t LDS_WORK = (sizeof(Work) + 15) & ~(size_t)15, LDS_NODES = (sizeof(Node) * NODE_SLOTS + 15) & ~(size_t)15, LDS_GEO = 0;   // (the geometry is in constant memory: enc_common.h GeoTable)
 namespace henc { __constant__ Geo henc_geo_table[NNODES]; }
 // Two things that used to sit in LDS do not any more, so that TWO row workers fit a CU (80 KB each): the CTU's side-info record (the worker reads and writes
 // it in HBM: measured in round 2 to make no difference) and the TU tables (FastTables: transform bases, scans, quantiser cells - from DevTables through L2
@@ -115,11 +115,20 @@ constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH 
 constexpr size_t LDS_BYTES = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH + LDS_FT;
 constexpr size_t LDS_FT_OFFSET = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH;
 #endif
+static_assert(sizeof(PostScratch) <= LDS_WORK + LDS_NODES, "the post stage works in what is idle between two CTUs: the worker's Work area and the CTU's partition nodes");
 static_assert(LDS_OFF_NODES == (int)LDS_WORK && LDS_OFF_SEQ == (int)(LDS_WORK + LDS_NODES + LDS_GEO) && LDS_OFF_BOX == (int)(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU),
 	      "enc_common.h: the fixed places of Enc's LDS members");
+#if !defined(HENC_WAVES_PER_EU)
+#define HENC_WAVES_PER_EU 2      // wavefronts per SIMD the pool kernel's register budget allows (512 / this registers per lane)
+#endif
 constexpr int ENC_THREADS = 64 * (1 + NHELP);   // the row worker + its helper wavefronts: one wavefront per SIMD of the CU
 static_assert(LDS_BYTES <= 160 * 1024, "a workgroup has 160 KiB of LDS on gfx950");
-constexpr int WORKERS_PER_CU = LDS_BYTES <= 80 * 1024 ? 2 : 1;
+// workers a CU holds: by LDS (160 KiB, allocated in 1280-byte granules is assumed: the tighter of the granule sizes seen on this family) and by wavefront slots
+constexpr int WORKERS_PER_CU_LDS = (int)((160 * 1024) / ((LDS_BYTES + 1279) / 1280 * 1280)), WORKERS_PER_CU_WAVES = 4 * HENC_WAVES_PER_EU / (1 + NHELP);
+constexpr int WORKERS_PER_CU = WORKERS_PER_CU_LDS < WORKERS_PER_CU_WAVES ? WORKERS_PER_CU_LDS : WORKERS_PER_CU_WAVES;
+#if defined(HENC_PRINT_LDS)
+static_assert(LDS_BYTES == 0 && LDS_WORK == 0 && LDS_NODES == 0 && LDS_BOX == 0 && sizeof(PostScratch) == 0 && WORKERS_PER_CU == 0, "sizes");
+#endif
 
 // a helper wavefront: run the jobs the worker posts (HelperBox, enc_common.h) until it says quit
 __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
@@ -139,21 +148,34 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 			e.prof = nullptr;
 		}
 		const int *a = box->a[h];
-		uint32_t r0 = 0, r1 = 0, r2 = 0;
+		uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0;      // (a job for both chroma planes reports U in r0 .. r2, V in r3 .. r5 - the SSD job: r0, r1)
 		switch (job) {
 		case HJOB_INTER_TU: {
 			int sum = 0;
 			uint32_t raw = 0;
-			r0 = encode_inter_tu(g, e, a[0], a[1], a[2], a[3], &sum, &raw);
+			r0 = encode_inter_tu(g, e, a[0], a[1] == COMP_UV ? COMP_U : a[1], a[2], a[3], &sum, &raw);
 			r1 = (uint32_t)sum;
 			r2 = raw;
+			if (a[1] == COMP_UV) {
+				r3 = encode_inter_tu(g, e, a[0], COMP_V, a[2], a[3], &sum, &raw);
+				r4 = (uint32_t)sum;
+				r5 = raw;
+			}
 			break;
 		}
-		case HJOB_SYNC_CU: sync_cu_comp(g, e, a[0], a[2], a[3], a[4], a[5], a[1]); break;
+		case HJOB_SYNC_CU:
+			if (a[1] == COMP_UV) { sync_cu_comp(g, e, a[0], a[2], a[3], a[4], a[5], COMP_U); sync_cu_comp(g, e, a[0], a[2], a[3], a[4], a[5], COMP_V); }
+			else sync_cu_comp(g, e, a[0], a[2], a[3], a[4], a[5], a[1]);
+			break;
 		case HJOB_SSD: {
 			const Geo &q = e.geo[a[0]];
-			const int c = a[1] - 1;
-			r0 = blk_ssd(g, e.w->curr_c[c] + q.yc * 32 + q.xc, 32, e.w->pred_c[c] + q.yc * 32 + q.xc, 32, q.size_chroma);
+			if (a[1] == COMP_UV) {
+				r0 = blk_ssd(g, e.w->curr_c[0] + q.yc * 32 + q.xc, 32, e.w->pred_c[0] + q.yc * 32 + q.xc, 32, q.size_chroma);
+				r1 = blk_ssd(g, e.w->curr_c[1] + q.yc * 32 + q.xc, 32, e.w->pred_c[1] + q.yc * 32 + q.xc, 32, q.size_chroma);
+			} else {
+				const int c = a[1] - 1;
+				r0 = blk_ssd(g, e.w->curr_c[c] + q.yc * 32 + q.xc, 32, e.w->pred_c[c] + q.yc * 32 + q.xc, 32, q.size_chroma);
+			}
 			break;
 		}
 		case HJOB_CHROMA_SEARCH: {
@@ -180,7 +202,7 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 		}
 		g.sync();
 		if (g.tid == 0) {
-			if (job != HJOB_CHROMA_SEARCH) { box->r[h][0] = r0; box->r[h][1] = r1; box->r[h][2] = r2; }
+			if (job != HJOB_CHROMA_SEARCH) { box->r[h][0] = r0; box->r[h][1] = r1; box->r[h][2] = r2; box->r[h][3] = r3; box->r[h][4] = r4; box->r[h][5] = r5; }
 			__hip_atomic_store(&box->done[h], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 	}
@@ -287,7 +309,7 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 				sched_known_intra(d.prefix, W, row, c, &ui, &up);
 			}
 			g.sync();
-			wave_copy_words(e.w->mode_in, gs, MODE_STATE_BYTES, g.tid);
+			if (g.tid == 0) e.w->mode_in = (const uint8_t (*)[NDEPTH][NPART])gs;      // (the guess is not written while the CTU is encoded)
 			if (g.tid == 0) { d.used_intra[n] = ui; d.used_parts[n] = up; }
 			const unsigned long long old_hash = d.hash[n];
 			e.total_intra_partitions = ui;
@@ -432,7 +454,7 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 		}
 		e.ctu_qp = rc_calc_cu_qp(lframe->rc, (double)rc_bits, rc_ctus, lframe->slice_type, is_sc, S.reinit_gop, S.intra_period, lframe->avg_dist, lframe->num_encoded_frames);
 	}
-	wave_copy_words(e.w->mode_in, e.w->intra_mode_buffs, MODE_STATE_BYTES, g.tid);
+	if (g.tid == 0) e.w->mode_in = (const uint8_t (*)[NDEPTH][NPART])(d.rowstate + (size_t)me * ROW_STATE_BYTES);      // (rewritten below, after the tokens are resolved)
 	e.total_intra_partitions = ti;
 	e.total_partitions = tc * NPART;
 	e.coeff = d.coeff + (size_t)n * 6144;
@@ -515,7 +537,7 @@ __device__ __attribute__((noinline)) int pool_post_drain(const EncDev &d, const 
 	return ran;
 }
 
-__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void k_encode_pool(const EncDev *devs, int nseq, int *state, int *finished, WorkSlow *slow, unsigned long long watchdog_ticks)
+__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HENC_WAVES_PER_EU))) void k_encode_pool(const EncDev *devs, int nseq, int *state, int *finished, WorkSlow *slow, unsigned long long watchdog_ticks)
 {
 	// finished[0]: pictures whose last task is done; finished[1]: abort - a worker has waited longer than the watchdog allows (a faulted or starved peer): everybody
 	// leaves and the host reports an error instead of the launch hanging
