@@ -1,5 +1,6 @@
 // Context: device selection, stream, constant-table upload, device memory helpers, HIP-event timer.
 #include <mutex>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -16,7 +17,13 @@ static int ctx_init(hmr_gpu_ctx *c, void *stream)
 		c->stream = (hipStream_t)stream;
 		c->owns_stream = false;
 	} else {
-		HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+		const int every = getenv("HENC_CU_MASK_EVERY") ? atoi(getenv("HENC_CU_MASK_EVERY")) : 0;      // (experiment: the stream's kernels on every k-th CU only - how workers that share a CU slow each other, tools/cu_sharing.sh)
+		if (every > 1) {
+			uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+			for (int i = 0; i < c->num_cus && i < 256; i++)
+				if (i % every == 0) mask[i >> 5] |= 1u << (i & 31);
+			HIP_TRY(hipExtStreamCreateWithCUMask(&c->stream, 8, mask));
+		} else HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 		c->owns_stream = true;
 	}
 	HIP_TRY(hipEventCreate(&c->ev0));

@@ -18,7 +18,7 @@ extern "C" FILE *henc_trace_file;
 			unsigned a_[3] = {0, 0, 0};                                                                                                \
 			for (int c_ = 0; c_ < 3; c_++) {                                                                                           \
 				const int n_ = c_ ? 32 : 64;                                                                                       \
-				const int16_t *p_ = c_ ? (e).w->pred_c[c_ - 1] : (e).w->pred_y;                                                    \
+				const pred_t *p_ = c_ ? (e).w->pred_c[c_ - 1] : (e).w->pred_y;                                                     \
 				for (int y_ = 0; y_ < n_; y_++)                                                                                    \
 					for (int x_ = 0; x_ < n_; x_++) a_[c_] += (unsigned)(p_[y_ * n_ + x_] & 0xffff) * (unsigned)(1 + ((x_ + 3 * y_) & 7)); \
 			}                                                                                                                          \
@@ -68,7 +68,13 @@ constexpr int NHELP_MAX = 3;
 // fast memory: the walks are depth first, so while a depth-1 node and what hangs below it is evaluated no depth-4 node of another quadrant is touched (the
 // checker build verifies exactly that at every access); the other three quadrants' depth-4 nodes wait in the CTU's record in HBM (nodes_select_quad).
 constexpr int NODES_RESIDENT = 85, NODE_QUAD = 64, NODE_SLOTS = NODES_RESIDENT + NODE_QUAD;
-constexpr int LDS_OFF_WORK = 0, LDS_OFF_NODES = (int)((sizeof(Work) + 15) & ~(size_t)15), LDS_OFF_SEQ = LDS_OFF_NODES + (int)((sizeof(Node) * NODE_SLOTS + 15) & ~(size_t)15),
+constexpr int NHELP_ = 1
+#if defined(HENC_NHELP)
+	+ (HENC_NHELP) - 1
+#endif
+	;
+constexpr int HSCRATCH_ELEMS = 2048 + 144;   // int16 per helper wavefront (its scratch sits between the nodes and the sequence parameters: k_encode.hip)
+constexpr int LDS_OFF_WORK = 0, LDS_OFF_NODES = (int)((sizeof(Work) + 15) & ~(size_t)15), LDS_OFF_SEQ = LDS_OFF_NODES + (int)((sizeof(Node) * NODE_SLOTS + 15) & ~(size_t)15) + NHELP_ * HSCRATCH_ELEMS * 2,
 	      LDS_OFF_FRAME = LDS_OFF_SEQ + (int)((sizeof(Seq) + 15) & ~(size_t)15), LDS_OFF_BOX = LDS_OFF_SEQ + (int)((sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15);
 #if defined(__HIP_DEVICE_COMPILE__)
 #define HENC_AT(T, OFFSET) LdsAt<T, OFFSET>
@@ -129,7 +135,7 @@ enum { HJOB_NONE = 0, HJOB_NEW_CTU, HJOB_INTER_TU, HJOB_INTRA_SAD, HJOB_SYNC_CU,
 #define HENC_NHELP 1
 #endif
 constexpr int NHELP = HENC_NHELP;
-static_assert(NHELP == 1 || NHELP == 2, "one helper for both chroma planes, or one per plane");
+static_assert(NHELP == NHELP_ && (NHELP == 1 || NHELP == 2), "one helper for both chroma planes, or one per plane");
 constexpr int COMP_UV = 3;   // a helper job's component argument: U, then V
 struct HelperBox {
 	int cmd[NHELP], done[NHELP];   // sequence numbers: helper h runs its next job when cmd[h] moves on, and sets done[h] = cmd[h] when finished

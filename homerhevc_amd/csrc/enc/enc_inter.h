@@ -60,7 +60,7 @@ HENC_HD void motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv
 		// every load of the three blocks is issued before the first store waits for one: the copy costs one trip to the planes, not three
 		const int n = q.size, nc = q.size_chroma, lw = ilog2i(n) - 2, lc = ilog2i(nc) - 2, ychunks = (n * n) >> 2, cchunks = (nc * nc) >> 2;
 		const uint8_t *pu = e.f->sub_c[0] + oc, *pv = e.f->sub_c[1] + oc;
-		int16_t *dy = w.pred_y + q.y * 64 + q.x, *du = w.pred_c[0] + q.yc * 32 + q.xc, *dv = w.pred_c[1] + q.yc * 32 + q.xc;
+		pred_t *dy = w.pred_y + q.y * 64 + q.x, *du = w.pred_c[0] + q.yc * 32 + q.xc, *dv = w.pred_c[1] + q.yc * 32 + q.xc;
 		uint32_t vy[4] = {0, 0, 0, 0}, vu = 0, vv = 0;
 		const int ic = g.tid, rc = ic >> lc, cc = (ic & ((1 << lc) - 1)) << 2;
 		if (ic < cchunks) { vu = ld32u(pu + rc * sc + cc); vv = ld32u(pv + rc * sc + cc); }
@@ -69,19 +69,15 @@ HENC_HD void motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv
 			const int i = g.tid + 64 * k;
 			if (i < ychunks) vy[k] = ld32u(py + (i >> lw) * sy + ((i & ((1 << lw) - 1)) << 2));
 		}
-		// four samples: prediction bytes -> 16-bit halves
-		auto put = [&](uint32_t pv, int16_t *dst) {
-			const uint32_t o[2] = {__builtin_amdgcn_perm(0u, pv, 0x0c010c00u), __builtin_amdgcn_perm(0u, pv, 0x0c030c02u)};
-			__builtin_memcpy(dst, o, 8);
-		};
+		// four prediction bytes per lane and step, as they are
 		if (ic < cchunks) {
-			put(vu, du + rc * 32 + cc);
-			put(vv, dv + rc * 32 + cc);
+			*(uint32_t *)(du + rc * 32 + cc) = vu;
+			*(uint32_t *)(dv + rc * 32 + cc) = vv;
 		}
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
 			const int i = g.tid + 64 * k;
-			if (i < ychunks) put(vy[k], dy + (i >> lw) * 64 + ((i & ((1 << lw) - 1)) << 2));
+			if (i < ychunks) *(uint32_t *)(dy + (i >> lw) * 64 + ((i & ((1 << lw) - 1)) << 2)) = vy[k];
 		}
 	} else {
 		blk_from_u8(g, e.f->sub_c[0] + oc, sc, w.pred_c[0] + q.yc * 32 + q.xc, 32, q.size_chroma);
@@ -525,7 +521,7 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 	const int per = qp / 6, rem = qp % 6;
 	const double weight = is_y ? 1.0 : e.f->chroma_weight;
 	const int off = is_y ? (q.abs_index << 4) : ((q.abs_index << 4) >> 2);
-	const int16_t *pred = pred_ptr(w, comp) + y * cs + x;
+	const pred_t *pred = pred_ptr(w, comp) + y * cs + x;
 	const src_t *orig = curr_ptr(w, comp) + y * cs + x;      // (the residual source - prediction is formed where it is read: the worker keeps no residual window)
 	int16_t *quant = tq_ptr(w, wnd, comp) + off, *iquant = iq_slot(w, comp, off);
 	int16_t *dec = dec_ptr(w, wnd, comp) + y * ds + x;
@@ -610,7 +606,7 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 		unsigned a[3] = {0, 0, 0};
 		for (int c = 0; c < 3; c++) {
 			const int n = c ? tq.size_chroma : tq.size, st = c ? 32 : 64;
-			const int16_t *p = c ? w.pred_c[c - 1] + tq.yc * 32 + tq.xc : w.pred_y + tq.y * 64 + tq.x;
+			const pred_t *p = c ? w.pred_c[c - 1] + tq.yc * 32 + tq.xc : w.pred_y + tq.y * 64 + tq.x;
 			for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) a[c] += (unsigned)(p[y * st + x] & 0xffff) * (unsigned)(1 + ((x + 3 * y) & 7));
 		}
 		HENC_TRACE("EIN ctu=%d d=%d abs=%d pred=%u,%u,%u\n", e.ctu->ctu_number, depth, tq.abs_index, a[0], a[1], a[2]);

@@ -167,7 +167,7 @@ HENC_HD int intra_mode_search(const G &g, Enc &__restrict__ e, int ni, int depth
 		}
 		e.n_spec_reads++;
 	}
-	int16_t *pred = w.pred_y + q.y * CTU_STRIDE_Y + q.x;
+	pred_t *pred = w.pred_y + q.y * CTU_STRIDE_Y + q.x;
 	const src_t *orig = w.curr_y + q.y * CTU_STRIDE_Y + q.x;
 	return intra_search_walk_batched(preds, rd_fast, e.f->sqrt_lambda, [&](const int *modes, int cnt, int64_t *sads) -> bool {
 		// with helper wavefronts: rounds of 1 + NHELP candidates, the worker always taking the last one of the round (so that the prediction
@@ -220,7 +220,7 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 	const int scan_mode = find_scan_mode(1, 1, n, cu_mode, 0);
 	const int per = nd.qp / 6, rem = nd.qp % 6;
 	const int wnd = curr_depth + 1;
-	int16_t *pred = w.pred_y + q.y * CTU_STRIDE_Y + q.x;
+	pred_t *pred = w.pred_y + q.y * CTU_STRIDE_Y + q.x;
 	const src_t *orig = w.curr_y + q.y * CTU_STRIDE_Y + q.x;
 	int16_t *quant = tq_ptr(w, wnd, COMP_Y) + (q.abs_index << 4), *iquant = iq_slot(w, COMP_Y, q.abs_index << 4);
 	int16_t *dec = dec_ptr(w, wnd, COMP_Y) + q.y * DEC_STRIDE_Y + q.x;
@@ -413,7 +413,7 @@ HENC_HD void chroma_search_comp(const G &g, Enc &__restrict__ e, int curr, int c
 	Work &w = *e.w;
 	const Geo &q = e.geo[curr];
 	const int n = q.size_chroma;
-	int16_t *pred = pred_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
+	pred_t *pred = pred_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
 	const src_t *orig = curr_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
 	for (int mi = 0; mi < 5; mi++) {
 		node_fill_refs(g, e, curr, NWND - 1, c, 0);
@@ -427,7 +427,7 @@ HENC_HD int chroma_tu_comp(const G &g, Enc &__restrict__ e, int curr, int c, int
 	Work &w = *e.w;
 	const Geo &q = e.geo[curr];
 	const int n = q.size_chroma, curr_depth = q.depth, qwnd = NWND - 1, dwnd = NWND - 1;
-	int16_t *pred = pred_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
+	pred_t *pred = pred_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
 	const src_t *orig = curr_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
 	int16_t *quant = tq_ptr(w, qwnd, c) + ((q.abs_index << 4) >> 2), *iquant = iq_slot(w, c, (q.abs_index << 4) >> 2);
 	int16_t *dec = dec_ptr(w, dwnd, c) + q.yc * DEC_STRIDE_C + q.xc;

@@ -13,7 +13,11 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define HENC_HD __device__
+#if defined(HENC_PRIM_NOINLINE)
+#define HENC_PRIM __device__ __attribute__((noinline))
+#else
 #define HENC_PRIM __device__   // block primitives: the compiler decides (forcing them out of line does not pay: all of them +3 %, only the large ones - intra prediction, SSD, reference fill - +2 %)
+#endif
 #define HENC_INLINE __host__ __device__ __forceinline__   // the small helpers are also used by the host entropy stage
 // Are the TU tables (FastTables, enc_prims.h) kept in the worker's fast memory?  Not on the device since two workers share a CU's LDS (k_encode.hip:
 // LDS_KEEPS_TU_TABLES must agree) - a constant, so that the transform / quantiser primitives carry one table source instead of a run-time choice of two.

@@ -11,7 +11,7 @@
 enum { PP_SAD = 0, PP_SSD, PP_BLK, PP_FILLREF, PP_ADIFILT, PP_INTRAPRED, PP_INTERP, PP_TRF, PP_TRI, PP_QUANT, PP_DEQUANT, PP_CAND, PP_SYNC, PP_INFO, PP_CTU_IO, PP_HWAIT, PP_COUNT };
 #if defined(__HIPCC__) && defined(HENC_PROFILE)
 extern __shared__ __align__(16) unsigned char henc_lds[];
-#define HENC_LDS_PROF_OFFSET (159 * 1024)
+#define HENC_LDS_PROF_OFFSET 52736      // (behind the worker state, so that the profiling build keeps the product's workers per CU: k_encode.hip checks the place)
 #define PRIM_T0() const unsigned long long prim_t0_ = __builtin_amdgcn_s_memtime()
 #define PRIM_END(cat) do { if (threadIdx.x == 0) { unsigned long long *pp_ = (unsigned long long *)(henc_lds + HENC_LDS_PROF_OFFSET); pp_[cat] += __builtin_amdgcn_s_memtime() - prim_t0_; pp_[PP_COUNT + (cat)]++; } } while (0)
 #else
@@ -47,6 +47,13 @@ HENC_INLINE S4 ld4(const uint8_t *p)
 	S4 r;
 	r.v[0] = (int16_t)(v & 255); r.v[1] = (int16_t)((v >> 8) & 255); r.v[2] = (int16_t)((v >> 16) & 255); r.v[3] = (int16_t)(v >> 24);
 	return r;
+}
+
+// four 16-bit sample values (0 .. 255) into a byte window
+HENC_INLINE void st4(uint8_t *p, const S4 &v)
+{
+	const uint32_t o = (uint32_t)(v.v[0] & 255) | ((uint32_t)(v.v[1] & 255) << 8) | ((uint32_t)(v.v[2] & 255) << 16) | ((uint32_t)(v.v[3] & 255) << 24);
+	__builtin_memcpy(p, &o, 4);
 }
 
 template <class G, class S>
@@ -119,23 +126,20 @@ __device__ __forceinline__ void multi_sad_u8(const WaveGrp &g, const uint8_t *or
 	PRIM_END(PP_SAD);
 }
 
-// n x n samples of an 8-bit plane into a 16-bit block (motion compensation from the phase planes); the caller syncs
-__device__ __forceinline__ void blk_from_u8(const WaveGrp &g, const uint8_t *s, int ss, int16_t *d, int ds, int n)
+// n x n samples of an 8-bit plane into the (8-bit) prediction window (motion compensation from the phase planes); the caller syncs
+__device__ __forceinline__ void blk_from_u8(const WaveGrp &g, const uint8_t *s, int ss, uint8_t *d, int ds, int n)
 {
 	const int lw = ilog2i(n) - 2, chunks = (n * n) >> 2;
 #pragma unroll 4
 	for (int i = g.tid; i < chunks; i += 64) {
 		const int r = i >> lw, c = (i & ((1 << lw) - 1)) << 2;
-		const uint32_t v = ld32u(s + r * ss + c);
-		// bytes -> zero-extended 16-bit samples, two per dword (v_perm_b32; selector 0x0c = the constant 0)
-		const uint32_t o[2] = {__builtin_amdgcn_perm(0u, v, 0x0c010c00u), __builtin_amdgcn_perm(0u, v, 0x0c030c02u)};
-		__builtin_memcpy(d + r * ds + c, o, 8);
+		*(uint32_t *)(d + r * ds + c) = ld32u(s + r * ss + c);
 	}
 }
 #endif
 
-template <class G, class S>
-HENC_PRIM uint32_t blk_ssd(const G &g, const S *a, int as, const int16_t *b, int bs, int n)
+template <class G, class S, class P>
+HENC_PRIM uint32_t blk_ssd(const G &g, const S *a, int as, const P *b, int bs, int n)
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
@@ -155,8 +159,8 @@ HENC_PRIM uint32_t blk_ssd(const G &g, const S *a, int as, const int16_t *b, int
 
 // SSD of the residual source - prediction against a reconstructed residual, the residual formed on the way (16-bit wrap like the reference's predict kernel
 // writes it): what ssd16b(residual window, reconstructed residual) gives, without the window
-template <class G, class S>
-HENC_PRIM uint32_t blk_ssd_diff(const G &g, const S *o, int os, const int16_t *p, int ps, const int16_t *r, int rs, int n)
+template <class G, class S, class P>
+HENC_PRIM uint32_t blk_ssd_diff(const G &g, const S *o, int os, const P *p, int ps, const int16_t *r, int rs, int n)
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
@@ -191,8 +195,8 @@ HENC_PRIM uint32_t blk_ssq(const G &g, const int16_t *a, int as, int n)
 	{ const auto prim_ret_ = g.sum(acc); PRIM_END(PP_SSD); return prim_ret_; }
 }
 
-template <class G, class S>
-HENC_PRIM void blk_predict(const G &g, const S *o, int os, const int16_t *p, int ps, int16_t *r, int rs, int n)
+template <class G, class S, class P>
+HENC_PRIM void blk_predict(const G &g, const S *o, int os, const P *p, int ps, int16_t *r, int rs, int n)
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
@@ -210,8 +214,8 @@ HENC_PRIM void blk_predict(const G &g, const S *o, int os, const int16_t *p, int
 }
 
 // res == nullptr: the all-zero residual (the reference passes a zeroed row with stride 0, hmr_motion_intra.c:1065)
-template <class G>
-HENC_PRIM void blk_reconst(const G &g, const int16_t *p, int ps, const int16_t *res, int rs, int16_t *d, int ds, int n)
+template <class G, class P>
+HENC_PRIM void blk_reconst(const G &g, const P *p, int ps, const int16_t *res, int rs, int16_t *d, int ds, int n)
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
@@ -230,8 +234,8 @@ HENC_PRIM void blk_reconst(const G &g, const int16_t *p, int ps, const int16_t *
 }
 
 // reconstruction and its distance from the source in one pass (the reference reconstructs, then reads the window back for ssd16b, hmr_motion_intra.c:1061-1068)
-template <class G, class S>
-HENC_PRIM uint32_t blk_reconst_ssd(const G &g, const int16_t *p, int ps, const int16_t *res, int rs, const S *o, int os, int16_t *d, int ds, int n)
+template <class G, class S, class P>
+HENC_PRIM uint32_t blk_reconst_ssd(const G &g, const P *p, int ps, const int16_t *res, int rs, const S *o, int os, int16_t *d, int ds, int n)
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
@@ -255,8 +259,8 @@ HENC_PRIM uint32_t blk_reconst_ssd(const G &g, const int16_t *p, int ps, const i
 	{ const auto prim_ret_ = s; PRIM_END(PP_BLK); return prim_ret_; }
 }
 
-template <class G>
-HENC_PRIM void blk_copy(const G &g, const int16_t *s, int ss, int16_t *d, int ds, int h, int w)
+template <class G, class P>
+HENC_PRIM void blk_copy(const G &g, const P *s, int ss, int16_t *d, int ds, int h, int w)
 {
 	PRIM_T0();
 	if ((w & 3) == 0 && (w & (w - 1)) == 0) {
@@ -577,8 +581,8 @@ HENC_INLINE int intra_sample(const IntraPredictor &p, int j, int i)
 	return (uint8_t)intra_ref_main(p, idx);
 }
 
-template <class G>
-HENC_PRIM void intra_predict(const G &g, int16_t *pred, int ps, const int16_t *adi, int n, int mode, int is_luma)
+template <class G, class P>
+HENC_PRIM void intra_predict(const G &g, P *pred, int ps, const int16_t *adi, int n, int mode, int is_luma)
 {
 	PRIM_T0();
 	const IntraPredictor p = intra_setup(adi, n, mode, is_luma);
@@ -586,15 +590,15 @@ HENC_PRIM void intra_predict(const G &g, int16_t *pred, int ps, const int16_t *a
 	#pragma unroll 4
 	for (int k = g.tid; k < n * n; k += g.n) {
 		const int j = k >> l, i = k & (n - 1);
-		pred[j * ps + i] = (int16_t)intra_sample(p, j, i);
+		pred[j * ps + i] = (P)intra_sample(p, j, i);
 	}
 	g.sync();
 	PRIM_END(PP_INTRAPRED);
 }
 
 // prediction + SAD against the source in one pass; the prediction is also stored (later stages of the reference read it)
-template <class G, class S>
-HENC_PRIM uint32_t intra_predict_sad(const G &g, int16_t *pred, int ps, const S *orig, int os, const int16_t *adi, int n, int mode, int is_luma)
+template <class G, class S, class P>
+HENC_PRIM uint32_t intra_predict_sad(const G &g, P *pred, int ps, const S *orig, int os, const int16_t *adi, int n, int mode, int is_luma)
 {
 	PRIM_T0();
 	const IntraPredictor p = intra_setup(adi, n, mode, is_luma);
@@ -604,7 +608,7 @@ HENC_PRIM uint32_t intra_predict_sad(const G &g, int16_t *pred, int ps, const S 
 	for (int k = g.tid; k < n * n; k += g.n) {
 		const int j = k >> l, i = k & (n - 1);
 		const int v = intra_sample(p, j, i);
-		if (pred) pred[j * ps + i] = (int16_t)v;          // pred == nullptr: the SAD alone (a helper wavefront's candidate)
+		if (pred) pred[j * ps + i] = (P)v;                // pred == nullptr: the SAD alone (a helper wavefront's candidate)
 		acc += (uint32_t)habs((int16_t)(orig[j * os + i] - (int16_t)v));
 	}
 	const uint32_t s = g.sum(acc);
@@ -842,21 +846,21 @@ struct RowPlain {
 	int is;
 	HENC_INLINE void load(int j, int32_t (&row)[N / 2]) const { load_pairs<N>(in + j * is, row); }
 };
-template <int N, class S>
+template <int N, class S, class P>
 struct RowDiff {
 	const S *o;
 	int os;
-	const int16_t *p;
+	const P *p;
 	int ps;
 	HENC_INLINE void load(int j, int32_t (&row)[N / 2]) const
 	{
-		int32_t pr[N / 2];
-		load_pairs<N>(p + j * ps, pr);
 		S ov[N];
+		P pv[N];
 		__builtin_memcpy(ov, __builtin_assume_aligned(o + j * os, (N * sizeof(S)) >= 16 ? 16 : N * sizeof(S)), N * sizeof(S));
+		__builtin_memcpy(pv, __builtin_assume_aligned(p + j * ps, (N * sizeof(P)) >= 16 ? 16 : N * sizeof(P)), N * sizeof(P));
 #pragma unroll
 		for (int h = 0; h < N / 2; h++) {
-			const int16_t lo = (int16_t)((int)ov[2 * h] - (int)(int16_t)(pr[h] & 0xffff)), hi = (int16_t)((int)ov[2 * h + 1] - (int)(int16_t)(pr[h] >> 16));
+			const int16_t lo = (int16_t)((int)ov[2 * h] - (int)pv[2 * h]), hi = (int16_t)((int)ov[2 * h + 1] - (int)pv[2 * h + 1]);
 			row[h] = pack_pair(lo, hi);
 		}
 	}
@@ -941,25 +945,25 @@ HENC_HD void tr_inverse_n(const G &g, const int16_t *Mt, int16_t *block, int bs,
 }
 
 // forward transform of the residual source - prediction (hmr_motion_intra.c:1036-1040 / hmr_motion_inter.c:57-60: predict, then transform of the residual window)
-template <class G, class S>
-HENC_PRIM void tr_forward(const G &g, const FastTables *F, const DevTables *T, const S *orig, int os, const int16_t *pred, int ps, int16_t *coeff, int16_t *tmp, int n, int is_dst)
+template <class G, class S, class P>
+HENC_PRIM void tr_forward(const G &g, const FastTables *F, const DevTables *T, const S *orig, int os, const P *pred, int ps, int16_t *coeff, int16_t *tmp, int n, int is_dst)
 {
 	PRIM_T0();
 	if (!F) {
 		switch (n) {
-		case 4: tr_forward_n<4>(g, is_dst ? T->dst4 : T->dct[0], RowDiff<4, S>{orig, os, pred, ps}, coeff, tmp); break;
-		case 8: tr_forward_n<8>(g, T->dct[1], RowDiff<8, S>{orig, os, pred, ps}, coeff, tmp); break;
-		case 16: tr_forward_n<16>(g, T->dct[2], RowDiff<16, S>{orig, os, pred, ps}, coeff, tmp); break;
-		default: tr_forward_n<32>(g, T->dct[3], RowDiff<32, S>{orig, os, pred, ps}, coeff, tmp); break;
+		case 4: tr_forward_n<4>(g, is_dst ? T->dst4 : T->dct[0], RowDiff<4, S, P>{orig, os, pred, ps}, coeff, tmp); break;
+		case 8: tr_forward_n<8>(g, T->dct[1], RowDiff<8, S, P>{orig, os, pred, ps}, coeff, tmp); break;
+		case 16: tr_forward_n<16>(g, T->dct[2], RowDiff<16, S, P>{orig, os, pred, ps}, coeff, tmp); break;
+		default: tr_forward_n<32>(g, T->dct[3], RowDiff<32, S, P>{orig, os, pred, ps}, coeff, tmp); break;
 		}
 		PRIM_END(PP_TRF);
 		return;
 	}
 	switch (n) {
-	case 4: tr_forward_n<4>(g, is_dst ? F->dst4 : F->dct, RowDiff<4, S>{orig, os, pred, ps}, coeff, tmp); break;
-	case 8: tr_forward_n<8>(g, F->dct + 16, RowDiff<8, S>{orig, os, pred, ps}, coeff, tmp); break;
-	case 16: tr_forward_n<16>(g, F->dct + 80, RowDiff<16, S>{orig, os, pred, ps}, coeff, tmp); break;
-	default: tr_forward_n<32>(g, F->dct + 336, RowDiff<32, S>{orig, os, pred, ps}, coeff, tmp); break;
+	case 4: tr_forward_n<4>(g, is_dst ? F->dst4 : F->dct, RowDiff<4, S, P>{orig, os, pred, ps}, coeff, tmp); break;
+	case 8: tr_forward_n<8>(g, F->dct + 16, RowDiff<8, S, P>{orig, os, pred, ps}, coeff, tmp); break;
+	case 16: tr_forward_n<16>(g, F->dct + 80, RowDiff<16, S, P>{orig, os, pred, ps}, coeff, tmp); break;
+	default: tr_forward_n<32>(g, F->dct + 336, RowDiff<32, S, P>{orig, os, pred, ps}, coeff, tmp); break;
 	}
 	PRIM_END(PP_TRF);
 }

@@ -189,6 +189,12 @@ struct WorkSlow {
 
 // Source samples of the CTU: bytes on the device (LDS is what limits how many row workers a CU holds: two fit when a worker's state stays under 80 KB),
 // the reference's 16-bit width in the checker build.  Block primitives take the source operand as a template parameter.
+// The prediction window likewise: what intra prediction and motion compensation write is always a sample value (0 .. 255).
+#if defined(__HIPCC__)
+typedef uint8_t pred_t;
+#else
+typedef int16_t pred_t;
+#endif
 #if defined(__HIPCC__)
 typedef uint8_t src_t;
 constexpr int TU_SCRATCH = 32 * 32;        // coefficients / remainders / levels of the TU in flight: a TU is at most 32 x 32
@@ -207,7 +213,7 @@ constexpr int RD_RING = 8;             // RD_FULL: frames whose coder states are
 
 struct Work {
 	src_t curr_y[64 * 64], curr_c[2][32 * 32];
-	int16_t pred_y[64 * 64], pred_c[2][32 * 32];
+	pred_t pred_y[64 * 64], pred_c[2][32 * 32];
 #if defined(__HIPCC__)
 	int16_t iq_y[32 * 32], iq_c[2][32 * 32];   // levels, then dequantised coefficients, of the TU in flight (one slot per component: the helpers run chroma beside luma)
 #else
@@ -256,7 +262,7 @@ HENC_INLINE int dec_stride(int comp) { return comp == COMP_Y ? DEC_STRIDE_Y : DE
 HENC_INLINE int ctu_stride(int comp) { return comp == COMP_Y ? CTU_STRIDE_Y : CTU_STRIDE_C; }
 HENC_INLINE int16_t *tq_ptr(Work &w, int wnd, int comp) { return comp == COMP_Y ? w.slow->tq_y[wnd] : w.slow->tq_c[wnd][comp - 1]; }
 HENC_INLINE src_t *curr_ptr(Work &w, int comp) { return comp == COMP_Y ? w.curr_y : w.curr_c[comp - 1]; }
-HENC_INLINE int16_t *pred_ptr(Work &w, int comp) { return comp == COMP_Y ? w.pred_y : w.pred_c[comp - 1]; }
+HENC_INLINE pred_t *pred_ptr(Work &w, int comp) { return comp == COMP_Y ? w.pred_y : w.pred_c[comp - 1]; }
 HENC_INLINE int16_t *rdec_ptr(Work &w, int comp) { return comp == COMP_Y ? w.slow->rdec_y : w.slow->rdec_c[comp - 1]; }
 // the TU's slot of the level / dequantised-coefficient buffer (`off`: its place in a CTU-sized buffer, which only the checker build keeps)
 HENC_INLINE int16_t *iq_slot(Work &w, int comp, int off)

@@ -90,13 +90,15 @@ __device__ __forceinline__ void wave_copy_quads(void *dst, const void *src, int 
 // picture is evaluated on whatever the window holds (check_rd_cost_merge_2nx2n leaves out the motion compensation and nothing else,
 // hmr_motion_inter.c:3651) - for the first CUs of a CTU that is what the thread's CTU before left there.  So the window travels with the thread like the mode
 // buffers do (found by tools/encoder_fuzz.py --gpu: 400x104, clip 657909, QP 22, a 122-sample vector next to the right picture edge).
-constexpr int PRED_STATE_BYTES = (64 * 64 + 2 * 32 * 32) * 2, ROW_STATE_BYTES = MODE_STATE_BYTES + PRED_STATE_BYTES;
-static_assert(offsetof(Work, pred_c) == offsetof(Work, pred_y) + 64 * 64 * 2 && sizeof(((Work *)nullptr)->pred_c) == 2 * 32 * 32 * 2, "the prediction windows are one block of Work");
+constexpr int PRED_STATE_BYTES = (64 * 64 + 2 * 32 * 32) * (int)sizeof(pred_t), ROW_STATE_BYTES = MODE_STATE_BYTES + PRED_STATE_BYTES;
+static_assert(offsetof(Work, pred_c) == offsetof(Work, pred_y) + 64 * 64 * sizeof(pred_t) && sizeof(((Work *)nullptr)->pred_c) == 2 * 32 * 32 * sizeof(pred_t), "the prediction windows are one block of Work");
 static_assert(MODE_STATE_BYTES % 16 == 0 && offsetof(Work, pred_y) % 16 == 0, "wave_copy_quads alignment");
 
-constexpr int HSCRATCH_ELEMS = 2048 + 144;   // int16 per helper
 // LDS of a row worker: its Work, a copy of the CTU's partition nodes and of the partition geometry
-constexpr size_t LDS_WORK = (sizeof(Work) + 15) & ~(size_t)15, LDS_NODES = (sizeof(Node) * NODE_SLOTS + 15) & ~(size_t)15, LDS_GEO = 0;   // (the geometry is in constant memory: enc_common.h GeoTable)
+constexpr size_t LDS_WORK = (sizeof(Work) + 15) & ~(size_t)15, LDS_NODES = (sizeof(Node) * NODE_SLOTS + 15) & ~(size_t)15,
+		 LDS_GEO = NHELP * HSCRATCH_ELEMS * 2;   // the helpers' scratch (per helper: 2 x 1024 coefficients - a 32 x 32 chroma TU - and a chroma neighbour array): behind Work and the nodes, so
+		                                         // that the post-decision stage, which runs between two CTUs when the helpers have no job, can use the three as one scratch area.
+		                                         // (The partition geometry, whose place this was, is in constant memory: enc_common.h GeoTable.)
 namespace henc { __constant__ Geo henc_geo_table[NNODES]; }
 // Two things that used to sit in LDS do not any more, so that TWO row workers fit a CU (80 KB each): the CTU's side-info record (the worker reads and writes
 // it in HBM: measured in round 2 to make no difference) and the TU tables (FastTables: transform bases, scans, quantiser cells - from DevTables through L2
@@ -106,16 +108,16 @@ static_assert(LDS_KEEPS_TU_TABLES == (HENC_TU_TABLES_IN_LDS != 0), "enc_platform
 constexpr size_t LDS_SEQ = (sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15, LDS_CTU = LDS_KEEPS_CTU_RECORD ? (sizeof(CtuPublic) + 15) & ~(size_t)15 : 0,
 		 LDS_FT = LDS_KEEPS_TU_TABLES ? (sizeof(FastTables) + 15) & ~(size_t)15 : 0;
 #if defined(HENC_PROFILE)
-constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = NHELP * HSCRATCH_ELEMS * 2;
-constexpr size_t LDS_BYTES = 160 * 1024;   // the primitive timers sit at HENC_LDS_PROF_OFFSET
+constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = 0;
+constexpr size_t LDS_BYTES = HENC_LDS_PROF_OFFSET + 2 * PP_COUNT * 8;   // the primitive timers sit at HENC_LDS_PROF_OFFSET
 constexpr size_t LDS_FT_OFFSET = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH;
 static_assert(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH + LDS_FT <= HENC_LDS_PROF_OFFSET, "profile table overlaps the worker state");
 #else
-constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = NHELP * HSCRATCH_ELEMS * 2;   // per helper: 2 x 1024 coefficients (a 32 x 32 chroma TU) + a chroma neighbour array
+constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = 0;
 constexpr size_t LDS_BYTES = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH + LDS_FT;
 constexpr size_t LDS_FT_OFFSET = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH;
 #endif
-static_assert(sizeof(PostScratch) <= LDS_WORK + LDS_NODES, "the post stage works in what is idle between two CTUs: the worker's Work area and the CTU's partition nodes");
+static_assert(sizeof(PostScratch) <= LDS_WORK + LDS_NODES + LDS_GEO, "the post stage works in what is idle between two CTUs: the worker's Work area, the CTU's partition nodes, the helpers' scratch");
 static_assert(LDS_OFF_NODES == (int)LDS_WORK && LDS_OFF_SEQ == (int)(LDS_WORK + LDS_NODES + LDS_GEO) && LDS_OFF_BOX == (int)(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU),
 	      "enc_common.h: the fixed places of Enc's LDS members");
 #if !defined(HENC_WAVES_PER_EU)
@@ -195,7 +197,7 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 		}
 		case HJOB_INTRA_SAD: {
 			const Geo &q = e.geo[a[0]];
-			r0 = intra_predict_sad(g, (int16_t *)nullptr, 0, e.w->curr_y + q.y * CTU_STRIDE_Y + q.x, CTU_STRIDE_Y, a[3] ? e.w->adi_f : e.w->adi, a[1], a[2], 1);
+			r0 = intra_predict_sad(g, (pred_t *)nullptr, 0, e.w->curr_y + q.y * CTU_STRIDE_Y + q.x, CTU_STRIDE_Y, a[3] ? e.w->adi_f : e.w->adi, a[1], a[2], 1);
 			break;
 		}
 		default: break;
@@ -219,7 +221,7 @@ __device__ __forceinline__ bool rows_enter()
 	for (int i = (int)threadIdx.x; i < (int)(LDS_BYTES / 4); i += ENC_THREADS) ((uint32_t *)lds)[i] = 0;
 	__syncthreads();
 	if (wave > 0) {
-		helper_loop(box, wave - 1, (int16_t *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX) + (wave - 1) * HSCRATCH_ELEMS);
+		helper_loop(box, wave - 1, (int16_t *)(lds + LDS_WORK + LDS_NODES) + (wave - 1) * HSCRATCH_ELEMS);
 		return false;
 	}
 	return true;
@@ -1046,7 +1048,8 @@ int launch_pool(hmr_gpu_enc *lead, int n, int rows_total, hipStream_t st)
 {
 	if (!lead->n_cus) HIP_TRY(hipDeviceGetAttribute(&lead->n_cus, hipDeviceAttributeMultiprocessorCount, lead->ctx->device));
 	const int cap = lead->n_cus * WORKERS_PER_CU;                             // what the LDS lets be resident; more would only queue behind
-	const int workers = rows_total < cap ? rows_total : cap;                  // (a picture never has more CTUs in flight than rows)
+	int workers = rows_total < cap ? rows_total : cap;                        // (a picture never has more CTUs in flight than rows)
+	if (getenv("HENC_POOL_WORKERS") && atoi(getenv("HENC_POOL_WORKERS")) > 0 && atoi(getenv("HENC_POOL_WORKERS")) < workers) workers = atoi(getenv("HENC_POOL_WORKERS"));      // (experiment)
 	if (!lead->d_pool_state) HIP_TRY(hipMalloc((void **)&lead->d_pool_state, sizeof(int) * (256 * POOL_STRIDE + 4)));
 	if (lead->pool_workers < workers) {
 		if (lead->d_pool_slow) (void)hipFree(lead->d_pool_slow);
