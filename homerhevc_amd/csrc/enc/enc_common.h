@@ -64,10 +64,16 @@ struct GeoTable {
 
 constexpr int NHELP_MAX = 3;
 // the fixed part of a worker's LDS (k_encode.hip checks that its layout agrees)
-// Of the CTU's 341 partition nodes a worker keeps the 85 of depths 0 .. 3 and the 64 depth-4 nodes of ONE quadrant (the 32 x 32 area of a depth-1 node) in its
-// fast memory: the walks are depth first, so while a depth-1 node and what hangs below it is evaluated no depth-4 node of another quadrant is touched (the
-// checker build verifies exactly that at every access); the other three quadrants' depth-4 nodes wait in the CTU's record in HBM (nodes_select_quad).
-constexpr int NODES_RESIDENT = 85, NODE_QUAD = 64, NODE_SLOTS = NODES_RESIDENT + NODE_QUAD;
+// Of the CTU's 341 partition nodes a worker keeps the 21 of depths 0 .. 2 and the depth-3 and depth-4 nodes (16 + 64) of ONE quadrant (the 32 x 32 area of a
+// depth-1 node) in its fast memory: the walks are depth first, so while a depth-1 node and what hangs below it is evaluated no deeper node of another quadrant is
+// touched (the checker build verifies exactly that at every access; the one exception, the corner units of the 64 x 64 CU, is handled where it occurs); the other
+// three quadrants' nodes wait in the CTU's record in HBM (nodes_select_quad).
+constexpr int NODES_RESIDENT = 21, NODES_D3 = 85, NODE_QUAD_D3 = 16, NODE_QUAD_D4 = 64, NODE_SLOTS = NODES_RESIDENT + NODE_QUAD_D3 + NODE_QUAD_D4;
+HENC_INLINE int node_quadrant(int idx) { return idx < NODES_D3 ? (idx - NODES_RESIDENT) >> 4 : (idx - NODES_D3) >> 6; }      // of a node of depth 3 or 4
+HENC_INLINE int node_slot(int idx)
+{
+	return idx < NODES_RESIDENT ? idx : (idx < NODES_D3 ? NODES_RESIDENT + ((idx - NODES_RESIDENT) & (NODE_QUAD_D3 - 1)) : NODES_RESIDENT + NODE_QUAD_D3 + ((idx - NODES_D3) & (NODE_QUAD_D4 - 1)));
+}
 constexpr int NHELP_ = 1
 #if defined(HENC_NHELP)
 	+ (HENC_NHELP) - 1
@@ -76,12 +82,15 @@ constexpr int NHELP_ = 1
 constexpr int HSCRATCH_ELEMS = 2048 + 144;   // int16 per helper wavefront (its scratch sits between the nodes and the sequence parameters: k_encode.hip)
 constexpr int LDS_OFF_WORK = 0, LDS_OFF_NODES = (int)((sizeof(Work) + 15) & ~(size_t)15), LDS_OFF_SEQ = LDS_OFF_NODES + (int)((sizeof(Node) * NODE_SLOTS + 15) & ~(size_t)15) + NHELP_ * HSCRATCH_ELEMS * 2,
 	      LDS_OFF_FRAME = LDS_OFF_SEQ + (int)((sizeof(Seq) + 15) & ~(size_t)15), LDS_OFF_BOX = LDS_OFF_SEQ + (int)((sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15);
+// (LDS_OFF_RD, the RD_FULL arrays behind the mailbox: below HelperBox)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define HENC_AT(T, OFFSET) LdsAt<T, OFFSET>
 #else
 #define HENC_AT(T, OFFSET) FastPtr<T>
 #endif
 
+constexpr int LDS_BOX_BYTES = 512;      // what the mailbox may take (checked behind HelperBox)
+constexpr int LDS_OFF_RD = LDS_OFF_BOX + LDS_BOX_BYTES;
 struct Enc {
 	unsigned long long *prof;   // PF_COUNT accumulators of this worker (profiling build), else unused
 	HENC_AT(const Seq, LDS_OFF_SEQ) seq;
@@ -95,6 +104,8 @@ struct Enc {
 	CtuInfo *ctu_g;        // its home in the picture array (logs, nodes; neighbours are ctu_g - 1, ctu_g - wctu ...)
 	CtuPublic *ctu_fast;
 	HENC_AT(Work, LDS_OFF_WORK) w;
+	HENC_AT(WorkRd, LDS_OFF_RD) wrd;      // RD_FULL only
+	int on_helper;            // this context is a helper wavefront's copy (which slot of the level buffer a TU takes: enc_types.h iq_slot)
 	int16_t *coeff;        // the CTU's coefficient output: 4096 luma + 2 x 1024 chroma, linear per TU in z-order
 	// speculative inputs of a P-frame CTU (enc_ctu.h)
 	uint32_t total_intra_partitions, total_partitions;
@@ -144,6 +155,7 @@ struct HelperBox {
 	uint32_t r[NHELP][8];
 	Enc enc;                       // the worker's context, refreshed at every CTU start
 };
+static_assert(sizeof(HelperBox) <= LDS_BOX_BYTES, "the mailbox's place in a worker's LDS");
 
 template <class G>
 HENC_HD void helper_post(const G &g, Enc &__restrict__ e, int h, int job, int a0 = 0, int a1 = 0, int a2 = 0, int a3 = 0, int a4 = 0, int a5 = 0)
@@ -225,17 +237,17 @@ HENC_INLINE int abs2raster(int a)   // abs2raster_table: the Morton de-interleav
 HENC_INLINE Node &node_of(Enc &__restrict__ e, int idx)
 {
 #if !defined(__HIPCC__)
-	if (idx >= NODES_RESIDENT && ((idx - NODES_RESIDENT) >> 6) != e.node_quad) {
-		fprintf(stderr, "node_of: depth-4 node %d of quadrant %d while quadrant %d is resident\n", idx, (idx - NODES_RESIDENT) >> 6, e.node_quad);
+	if (idx >= NODES_RESIDENT && node_quadrant(idx) != e.node_quad) {
+		fprintf(stderr, "node_of: node %d of quadrant %d while quadrant %d is resident\n", idx, node_quadrant(idx), e.node_quad);
 		abort();
 	}
 #endif
-	return e.nodes[idx < NODES_RESIDENT ? idx : NODES_RESIDENT + ((idx - NODES_RESIDENT) & (NODE_QUAD - 1))];
+	return e.nodes[node_slot(idx)];
 }
 // The candidate derivations copy a CU's left-bottom / top-right flag into the depth-4 node of its corner unit (get_amvp_candidates hmr_motion_inter.c:2354-2355,
 // get_merge_mvp_candidates :1990,:2020) - a lasting change of that node.  For the 64 x 64 CU the corners lie in quadrants 1 and 2, which need not be the resident one:
 // the flag then goes to the CTU's record, where the quadrant is loaded from when the walk gets there.
-HENC_INLINE bool node_is_resident(const Enc &__restrict__ e, int idx) { return idx < NODES_RESIDENT || ((idx - NODES_RESIDENT) >> 6) == e.node_quad; }
+HENC_INLINE bool node_is_resident(const Enc &__restrict__ e, int idx) { return idx < NODES_RESIDENT || node_quadrant(idx) == e.node_quad; }
 HENC_INLINE void corner_set_left_bottom(Enc &__restrict__ e, int idx, uint8_t v)
 {
 	if (node_is_resident(e, idx)) node_of(e, idx).left_bottom_nb = v;
@@ -426,16 +438,27 @@ HENC_HD void sync_motion_buffers(const G &g, Enc &__restrict__ e, int ni, int q_
 	sync_motion_buffers_chroma(g, e, ni, q_src, q_dst, d_src, d_dst);
 }
 
-// the depth-4 nodes of quadrant `quad` into the worker's fast copy (the ones that were there go back to the CTU's record first)
+// the depth-3 and depth-4 nodes of quadrant `quad` into the worker's fast copy (the ones that were there go back to the CTU's record first)
+template <class G>
+HENC_HD void nodes_quad_move(const G &g, Enc &__restrict__ e, int quad, int to_record)
+{
+	constexpr int W3 = (int)(sizeof(Node) * NODE_QUAD_D3 / 4), W4 = (int)(sizeof(Node) * NODE_QUAD_D4 / 4);
+	uint32_t *f3 = (uint32_t *)&e.nodes[NODES_RESIDENT], *f4 = (uint32_t *)&e.nodes[NODES_RESIDENT + NODE_QUAD_D3];
+	uint32_t *r3 = (uint32_t *)(e.ctu_g->nodes + NODES_RESIDENT + NODE_QUAD_D3 * quad), *r4 = (uint32_t *)(e.ctu_g->nodes + NODES_D3 + NODE_QUAD_D4 * quad);
+	// (both pieces are read before either is written: one trip to the record)
+	for (int i = g.tid; i < W3 + W4; i += g.n) {
+		if (to_record) { if (i < W3) r3[i] = f3[i]; else r4[i - W3] = f4[i - W3]; }
+		else { if (i < W3) f3[i] = r3[i]; else f4[i - W3] = r4[i - W3]; }
+	}
+	g.sync();
+}
 template <class G>
 HENC_HD void nodes_select_quad(const G &g, Enc &__restrict__ e, int quad)
 {
 	if (quad == e.node_quad) return;
-	constexpr int WORDS = (int)(sizeof(Node) * NODE_QUAD / 4);
-	Node *cache = &e.nodes[NODES_RESIDENT];
 	g.sync();
-	if (e.node_quad >= 0) lin_copy_words(g, (const uint32_t *)cache, (uint32_t *)(e.ctu_g->nodes + NODES_RESIDENT + NODE_QUAD * e.node_quad), WORDS);
-	lin_copy_words(g, (const uint32_t *)(e.ctu_g->nodes + NODES_RESIDENT + NODE_QUAD * quad), (uint32_t *)cache, WORDS);
+	if (e.node_quad >= 0) nodes_quad_move(g, e, e.node_quad, 1);
+	nodes_quad_move(g, e, quad, 0);
 	e.node_quad = quad;
 }
 // the fast copy back into the CTU's record
@@ -444,8 +467,7 @@ HENC_HD void nodes_write_back(const G &g, Enc &__restrict__ e)
 {
 	g.sync();
 	lin_copy_words(g, (const uint32_t *)&e.nodes[0], (uint32_t *)e.ctu_g->nodes, (int)(sizeof(Node) * NODES_RESIDENT / 4));
-	if (e.node_quad >= 0)
-		lin_copy_words(g, (const uint32_t *)&e.nodes[NODES_RESIDENT], (uint32_t *)(e.ctu_g->nodes + NODES_RESIDENT + NODE_QUAD * e.node_quad), (int)(sizeof(Node) * NODE_QUAD / 4));
+	if (e.node_quad >= 0) nodes_quad_move(g, e, e.node_quad, 1);
 }
 
 // cost helpers (hmr_common.h:53-59): the reference's macros with their operand types

@@ -521,7 +521,7 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 	depth_state.set(0, initial_position);
 	e.w->thread_seen_intra = 1;   // (every lane stores the same value) hmr_motion_intra.c:1783: from now on this thread's shadow CTU reads "intra"
 	if (S.rd_mode == RDM_FULL) {      // motion_intra :1993: the shadow CTU starts as a copy of the CTU's descriptor (its side-info pointers at the CTU's arrays), all INTRA
-		bytes_set(g, e.w->rd_pred_mode, PM_INTRA, NPART);
+		bytes_set(g, e.wrd->rd_pred_mode, PM_INTRA, NPART);
 		e.rd_luma_depth = -1;
 		e.rd_chroma_state = 0;
 	}
@@ -619,7 +619,7 @@ HENC_HD void create_partition_neighbours(const G &g, Enc &__restrict__ e)
 				const Geo &pq = e.geo.lane(q.parent);
 				if (!((cy + pq.y < S.height) && (cx + pq.x < S.width))) continue;
 			}
-			Node &nd = depth < CFG_MAX_PRED_DEPTH ? e.nodes[curr] : e.ctu_g->nodes[curr];      // (depth 4: the record in HBM - no quadrant is resident yet; the parents are)
+			Node &nd = depth < 3 ? e.nodes[curr] : e.ctu_g->nodes[curr];      // (depths 3 and 4: the record in HBM - no quadrant is resident yet)
 			nd.tl_inside = (cy + q.y < S.height) && (cx + q.x < S.width);
 			nd.b_inside = (cy + q.y + q.size <= S.height);
 			nd.r_inside = (cx + q.x + q.size <= S.width);
@@ -631,7 +631,7 @@ HENC_HD void create_partition_neighbours(const G &g, Enc &__restrict__ e)
 					nd.top_right_nb = has_top_right;
 				} else {
 					const Geo &pq = e.geo.lane(q.parent);
-					const Node &pn = e.nodes[q.parent];
+					const Node &pn = depth < 4 ? e.nodes[q.parent] : e.ctu_g->nodes[q.parent];      // (the parent of a depth-4 node was written to the record by the pass before)
 					nd.left_nb = (pn.left_nb || q.x) ? 1 : 0;
 					nd.top_nb = (pn.top_nb || q.y) ? 1 : 0;
 					nd.left_bottom_nb = ((pn.left_bottom_nb && q.x == pq.x) || (pn.left_nb && q.x == pq.x && q.y == pq.y && valid_lines > q.y + q.size)) ? 1 : 0;
@@ -661,6 +661,7 @@ HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 	} else e.ctu = e.ctu_g;
 #if !defined(__HIPCC__)
 	e.nodes_fast = (Node *)(((uintptr_t)w.nodes_fast_store + 15) & ~(uintptr_t)15);
+	e.wrd = w.rd_store;
 #endif
 	lin_copy_words(g, (const uint32_t *)e.ctu_g->nodes, (uint32_t *)e.nodes_fast, (int)(sizeof(Node) * NODES_RESIDENT / 4));
 	e.nodes = e.nodes_fast;

@@ -523,7 +523,7 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 	const int off = is_y ? (q.abs_index << 4) : ((q.abs_index << 4) >> 2);
 	const pred_t *pred = pred_ptr(w, comp) + y * cs + x;
 	const src_t *orig = curr_ptr(w, comp) + y * cs + x;      // (the residual source - prediction is formed where it is read: the worker keeps no residual window)
-	int16_t *quant = tq_ptr(w, wnd, comp) + off, *iquant = iq_slot(w, comp, off);
+	int16_t *quant = tq_ptr(w, wnd, comp) + off, *iquant = iq_slot(w, comp, off, e.on_helper);
 	int16_t *dec = dec_ptr(w, wnd, comp) + y * ds + x;
 	// The chain runs in the worker's fast memory: coefficients in scratch_a, rounding remainders in scratch_b, the levels in the block's slot of the
 	// dequantised-coefficient buffer (dequantised in place afterwards), the reconstructed residual in scratch_b (the reference's separate window, which

@@ -222,7 +222,7 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 	const int wnd = curr_depth + 1;
 	pred_t *pred = w.pred_y + q.y * CTU_STRIDE_Y + q.x;
 	const src_t *orig = w.curr_y + q.y * CTU_STRIDE_Y + q.x;
-	int16_t *quant = tq_ptr(w, wnd, COMP_Y) + (q.abs_index << 4), *iquant = iq_slot(w, COMP_Y, q.abs_index << 4);
+	int16_t *quant = tq_ptr(w, wnd, COMP_Y) + (q.abs_index << 4), *iquant = iq_slot(w, COMP_Y, q.abs_index << 4, e.on_helper);
 	int16_t *dec = dec_ptr(w, wnd, COMP_Y) + q.y * DEC_STRIDE_Y + q.x;
 	const int inv_depth = CFG_MAX_CU_SHIFT - curr_depth;
 	const int filt = intra_is_filtered(cu_mode, inv_depth);
@@ -263,8 +263,8 @@ HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, i
 	const bool rd_full = S.rd_mode == RDM_FULL;
 	if (rd_full) {      // :1287: the shadow CTU's partition size and prediction depth of this CU
 		const Geo &tq = e.geo[top_ni];
-		bytes_set(g, &w.rd_part_size[tq.abs_index], part_size_type, tq.num_part);
-		bytes_set(g, &w.rd_pred_depth[tq.abs_index], depth - (part_size_type == PART_NxN), tq.num_part);
+		bytes_set(g, &e.wrd->rd_part_size[tq.abs_index], part_size_type, tq.num_part);
+		bytes_set(g, &e.wrd->rd_pred_depth[tq.abs_index], depth - (part_size_type == PART_NxN), tq.num_part);
 	}
 	{ HENC_PROF_T0(); bitcost_cu_mode = intra_mode_search(g, e, top_ni, depth, &cu_mode, &search_cost); HENC_PROF_ADD(e, PF_INTRA_SEARCH); }
 
@@ -429,7 +429,7 @@ HENC_HD int chroma_tu_comp(const G &g, Enc &__restrict__ e, int curr, int c, int
 	const int n = q.size_chroma, curr_depth = q.depth, qwnd = NWND - 1, dwnd = NWND - 1;
 	pred_t *pred = pred_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
 	const src_t *orig = curr_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
-	int16_t *quant = tq_ptr(w, qwnd, c) + ((q.abs_index << 4) >> 2), *iquant = iq_slot(w, c, (q.abs_index << 4) >> 2);
+	int16_t *quant = tq_ptr(w, qwnd, c) + ((q.abs_index << 4) >> 2), *iquant = iq_slot(w, c, (q.abs_index << 4) >> 2, e.on_helper);
 	int16_t *dec = dec_ptr(w, dwnd, c) + q.yc * DEC_STRIDE_C + q.xc;
 	node_fill_refs(g, e, curr, dwnd, c, 0);
 	intra_predict(g, pred, CTU_STRIDE_C, e.adi_c, n, cu_mode, 0);

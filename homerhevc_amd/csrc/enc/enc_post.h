@@ -139,6 +139,12 @@ enum PostProf { PPF_D = 0, PPF_P_LOAD, PPF_P_STATS, PPF_P_CAND, PPF_P_DECIDE, PP
 
 constexpr int UF_INTRA = 1, UF_CBF = 2, UF_EDGE_VER = 4, UF_EDGE_HOR = 8;      // unit flags (the frame-level kernels' bits, k_loop.hip)
 
+// samples of the deblocked CTU in the scratch tiles: bytes on the device (the scratch has to fit what a worker's fast memory leaves idle between two CTUs)
+#if defined(__HIPCC__)
+typedef uint8_t tile_t;
+#else
+typedef int16_t tile_t;
+#endif
 constexpr int POST_TS_Y = 72, POST_TS_C = 40;      // row pitches of the tiles: the CTU's first column is 8-byte aligned behind the ring column
 // scratch of a task in the worker's fast memory (on the device the worker's Work area, idle between two CTUs)
 struct alignas(16) PostScratch {
@@ -147,7 +153,7 @@ struct alignas(16) PostScratch {
 	uint8_t ctx[CTX_TOTAL + 5];
 	uint8_t t_range[256], t_next[128];   // the coder's tables next to it
 	alignas(16) int16_t coef[6144];    // the CTU's levels
-	alignas(16) int16_t tile_y[66 * POST_TS_Y], tile_c[2][34 * POST_TS_C];   // the deblocked CTU with a one-sample ring, per component (sample (x, y) at (y + 1) * pitch + x + 4)
+	alignas(16) tile_t tile_y[66 * POST_TS_Y], tile_c[2][34 * POST_TS_C];   // the deblocked CTU with a one-sample ring, per component (sample (x, y) at (y + 1) * pitch + x + 4)
 	int32_t acc[5][2][32];             // statistics of the component being counted
 	SaoStats stats;
 	int32_t cand_off[3][5][32], cand_aux[3][5];
@@ -157,7 +163,7 @@ struct alignas(16) PostScratch {
 };
 #if defined(__HIPCC__)
 // (k_encode.hip checks that the scratch fits the part of a worker's fast memory that is idle between two CTUs: its Work and the CTU's partition nodes)
-static_assert(sizeof(SubpelScratch) <= sizeof(PostScratch), "task S works in the post stage's scratch");
+// (task S works in the same place: k_encode.hip checks SubpelScratch against it too)
 #endif
 
 static constexpr uint8_t kDbkTc[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1,
@@ -320,7 +326,7 @@ HENC_NOINLINE HENC_HDX void post_stage_tiles(const G &g, const Seq &S, const Pos
 		const int sh = comp ? 1 : 0, h = hl >> sh, w = wl >> sh, w4 = w >> 2;
 		const int rs = comp ? S.stride_c : S.stride_y, ts = comp ? POST_TS_C : POST_TS_Y;
 		const int16_t *r0 = P.dbk[comp] + (size_t)((cy * 64) >> sh) * rs + ((cx * 64) >> sh);
-		int16_t *t0 = (comp ? sc.tile_c[comp - 1] : sc.tile_y) + ts + 4;
+		tile_t *t0 = (comp ? sc.tile_c[comp - 1] : sc.tile_y) + ts + 4;
 		const int y0 = ta ? -1 : 0, y1 = ba ? h + 1 : h;
 		// rows (with the ring rows above / below), four samples per lane
 		for (int i = g.tid; i < w4 * (y1 - y0); i += g.n) {
@@ -330,7 +336,7 @@ HENC_NOINLINE HENC_HDX void post_stage_tiles(const G &g, const Seq &S, const Pos
 		// ring columns
 		for (int i = g.tid; i < 2 * (y1 - y0); i += g.n) {
 			const int y = y0 + (i >> 1), right = i & 1;
-			if (right ? ra : la) t0[y * ts + (right ? w : -1)] = r0[(ptrdiff_t)y * rs + (right ? w : -1)];
+			if (right ? ra : la) t0[y * ts + (right ? w : -1)] = (tile_t)r0[(ptrdiff_t)y * rs + (right ? w : -1)];
 		}
 	}
 	g.sync();
@@ -348,7 +354,7 @@ HENC_HDX void post_sao_stats(const G &g, const Seq &S, const FrameCtx &f, PostSc
 		const int sh = comp ? 1 : 0, h = hl >> sh, w = wl >> sh, w4 = w >> 2;
 		const int os = comp ? S.src_stride_c : S.src_stride_y, ts = comp ? POST_TS_C : POST_TS_Y;
 		const int16_t *o0 = f.src[comp] + (size_t)((cy * 64) >> sh) * os + ((cx * 64) >> sh);
-		const int16_t *t0 = (comp ? sc.tile_c[comp - 1] : sc.tile_y) + ts + 4;
+		const tile_t *t0 = (comp ? sc.tile_c[comp - 1] : sc.tile_y) + ts + 4;
 		for (int i = g.tid; i < 5 * 2 * 32; i += g.n) (&sc.acc[0][0][0])[i] = 0;
 		g.sync();
 		const int skr = comp ? 3 : 5, skb = comp ? 2 : 4;
@@ -365,11 +371,11 @@ HENC_HDX void post_sao_stats(const G &g, const Seq &S, const FrameCtx &f, PostSc
 			if (i < total) {
 				const int y = i / w4, x0 = (i - y * w4) << 2;
 				const S4 org = ld4(o0 + (size_t)y * os + x0);
-				const int16_t *c = t0 + y * ts + x0;
+				const tile_t *c = t0 + y * ts + x0;
 				const bool in_y_eo = y >= sy_eo && y < ey_eo;
 				for (int j = 0; j < 4; j++) {
 					const int x = x0 + j;
-					const int16_t *cc = c + j;
+					const tile_t *cc = c + j;
 					const int v = cc[0], d = org.v[j] - v;
 					const int sl = sgn3(v - cc[-1]), sr = sgn3(v - cc[1]), su = sgn3(v - cc[-ts]), sd = sgn3(v - cc[ts]);
 					const int sul = sgn3(v - cc[-ts - 1]), sdr = sgn3(v - cc[ts + 1]), sur = sgn3(v - cc[-ts + 1]), sdl = sgn3(v - cc[ts - 1]);
@@ -486,7 +492,7 @@ HENC_NOINLINE HENC_HDX void post_sao_apply_pad(const G &g, const Seq &S, const P
 	for (int comp = 0; comp < 3; comp++) {
 		const int sh = comp ? 1 : 0, h = hl >> sh, w = wl >> sh, w4 = w >> 2, st = comp ? S.stride_c : S.stride_y, ts = comp ? POST_TS_C : POST_TS_Y;
 		const size_t base = (size_t)((cy * 64) >> sh) * st + ((cx * 64) >> sh);
-		const int16_t *t0 = (comp ? sc.tile_c[comp - 1] : sc.tile_y) + ts + 4;
+		const tile_t *t0 = (comp ? sc.tile_c[comp - 1] : sc.tile_y) + ts + 4;
 		int16_t *d0 = P.fin[comp] + base;
 		const SaoOffset &p = params[comp];
 		const int on = S.sao && p.mode_idc != SAO_OFF, type = p.type_idc;
@@ -494,7 +500,7 @@ HENC_NOINLINE HENC_HDX void post_sao_apply_pad(const G &g, const Seq &S, const P
 		const int nb = dy0 * ts + dx0;
 		for (int i = g.tid; i < w4 * h; i += g.n) {
 			const int y = i / w4, x0 = (i - y * w4) << 2;
-			const int16_t *c = t0 + y * ts + x0;
+			const tile_t *c = t0 + y * ts + x0;
 			S4 out = ld4(c);
 			if (on) {
 				const bool row_ok = !(type != 0 && ((y == 0 && !ta) || (y == h - 1 && !ba)));

@@ -46,16 +46,16 @@ HENC_FI void rd_make_views(const G &g, Enc &__restrict__ e, RdViews &r, int y_de
 	if (e.rd_luma_depth >= 0) {
 		for (int i = g.tid; i < NPART; i += g.n) {
 			const int m = w.intra_mode_buffs[COMP_Y][e.rd_luma_depth][i];
-			w.rd_luma_modes[i] = (uint8_t)((m & MODE_TOKEN) ? w.mode_in[COMP_Y][m & 7][i] : m);
+			e.wrd->rd_luma_modes[i] = (uint8_t)((m & MODE_TOKEN) ? w.mode_in[COMP_Y][m & 7][i] : m);
 		}
 		g.sync();
-		c.intra_mode[0] = w.rd_luma_modes;
+		c.intra_mode[0] = e.wrd->rd_luma_modes;
 	} else c.intra_mode[0] = e.ctu->intra_mode[0];
 	c.intra_mode[1] = w.intra_mode_buffs[COMP_CHR][chroma_mode_depth];
 	c.tr_idx = w.tr_idx_buffs[tr_depth_buf];
-	c.pred_depth = w.rd_pred_depth;
-	c.part_size_type = w.rd_part_size;
-	c.pred_mode = w.rd_pred_mode;
+	c.pred_depth = e.wrd->rd_pred_depth;
+	c.part_size_type = e.wrd->rd_part_size;
+	c.pred_mode = e.wrd->rd_pred_mode;
 	c.inter_mode = c.skipped = c.merge = c.merge_idx = c.mv_diff_ref_idx = nullptr;
 	c.qp = nullptr;
 	c.mv_diff = nullptr;
@@ -188,8 +188,8 @@ HENC_RD_NOINLINE HENC_HD uint32_t rd_get_intra_bits_qt(const G &g, Enc &__restri
 {
 	Cabac ec;
 	ec.counter = true;
-	ec.ctx = e.w->rd_ctx_work;
-	for (int i = g.tid; i < CTX_TOTAL; i += g.n) e.w->rd_ctx_work[i] = e.rd_ctx[i];
+	ec.ctx = e.wrd->rd_ctx_work;
+	for (int i = g.tid; i < CTX_TOTAL; i += g.n) e.wrd->rd_ctx_work[i] = e.rd_ctx[i];
 	g.sync();
 	ec.load_ctx(g);
 	e.rd_chroma_state = e.rd_ctx[CTX_CHROMA_PRED];      // (a full copy: the counter's chroma direction context is et->ee's again)
@@ -206,7 +206,7 @@ HENC_RD_NOINLINE HENC_HD uint32_t rd_get_intra_bits_qt(const G &g, Enc &__restri
 		rd_code_chroma_dir(ec, v, ni);
 		e.rd_chroma_state = 0;
 	}
-	rd_transform_tree(g, ec, v, e.w->rd_ent, ni, is_luma);
+	rd_transform_tree(g, ec, v, e.wrd->rd_ent, ni, is_luma);
 	HENC_TRACE("RDQT ctu=%d d=%d abs=%d pd=%d luma=%d bits=%u", e.ctu->ctu_number, v.geo[ni].depth, v.geo[ni].abs_index, (int)v.c->pred_depth[v.geo[ni].abs_index], is_luma, ec.bitcnt());
 #if !defined(__HIPCC__) && defined(HENC_TRACE_ENABLE)
 	if (getenv("HOMER_RDTRACE_CTX")) {

@@ -215,7 +215,9 @@ struct Work {
 	src_t curr_y[64 * 64], curr_c[2][32 * 32];
 	pred_t pred_y[64 * 64], pred_c[2][32 * 32];
 #if defined(__HIPCC__)
-	int16_t iq_y[32 * 32], iq_c[2][32 * 32];   // levels, then dequantised coefficients, of the TU in flight (one slot per component: the helpers run chroma beside luma)
+	// levels, then dequantised coefficients, of the TU in flight: a slot for the worker (luma; V of an intra chroma TU, while its helper does U) and one for the helper
+	// (U, then V of an inter TU; U of an intra chroma TU) - iq_slot below
+	int16_t iq_y[32 * 32], iq_c[1][32 * 32];
 #else
 	int16_t iq_y[64 * 64], iq_c[2][32 * 32];
 #endif
@@ -237,7 +239,7 @@ struct Work {
 #endif
 	MvCandList amvp, merge_cands, search_cands;
 #if !defined(__HIPCC__)
-	uint8_t nodes_fast_store[52 * (85 + 64) + 16];      // checker build: the worker's fast copy of the CTU's partition nodes (enc_common.h NODE_SLOTS; on the device a place in LDS)
+	uint8_t nodes_fast_store[52 * (21 + 16 + 64) + 16];      // checker build: the worker's fast copy of the CTU's partition nodes (enc_common.h NODE_SLOTS; on the device a place in LDS)
 #endif
 	WorkSlow *slow;
 	// Part of the WPP thread's state next to the mode buffers: has this thread ever taken the intra walk?  The reference's thread keeps a shadow CTU whose
@@ -245,7 +247,12 @@ struct Work {
 	// it (homer_loop1_motion_intra :1102-1104).  With one engine every thread has been through the first (intra) frame; the threads of a second engine start
 	// on a P frame and see "not intra" -> DC for neighbours inside the CTU until an intra frame or a scene change comes their way.
 	int32_t thread_seen_intra;
-	// RD_FULL (enc_rdo.h): the shadow CTU's own arrays, the counter's working copy of the contexts, the residual coder's scratch
+#if !defined(__HIPCC__)
+	struct WorkRd *rd_store;               // checker build: the RD_FULL arrays (on the device a place at the end of the worker's LDS, allocated only for launches that need it)
+#endif
+};
+// RD_FULL (enc_rdo.h): the shadow CTU's own arrays, the counter's working copy of the contexts, the residual coder's scratch
+struct WorkRd {
 	uint8_t rd_pred_depth[NPART], rd_part_size[NPART], rd_pred_mode[NPART], rd_luma_modes[NPART];
 	uint8_t rd_ctx_work[RD_CTX_BYTES];
 	EntScratch rd_ent;
@@ -265,12 +272,13 @@ HENC_INLINE src_t *curr_ptr(Work &w, int comp) { return comp == COMP_Y ? w.curr_
 HENC_INLINE pred_t *pred_ptr(Work &w, int comp) { return comp == COMP_Y ? w.pred_y : w.pred_c[comp - 1]; }
 HENC_INLINE int16_t *rdec_ptr(Work &w, int comp) { return comp == COMP_Y ? w.slow->rdec_y : w.slow->rdec_c[comp - 1]; }
 // the TU's slot of the level / dequantised-coefficient buffer (`off`: its place in a CTU-sized buffer, which only the checker build keeps)
-HENC_INLINE int16_t *iq_slot(Work &w, int comp, int off)
+HENC_INLINE int16_t *iq_slot(Work &w, int comp, int off, int on_helper)
 {
 #if defined(__HIPCC__)
-	(void)off;
-	return comp == COMP_Y ? w.iq_y : w.iq_c[comp - 1];
+	(void)off; (void)comp;
+	return on_helper ? w.iq_c[0] : w.iq_y;
 #else
+	(void)on_helper;
 	return (comp == COMP_Y ? w.iq_y : w.iq_c[comp - 1]) + off;
 #endif
 }

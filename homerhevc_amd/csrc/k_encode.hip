@@ -108,16 +108,18 @@ static_assert(LDS_KEEPS_TU_TABLES == (HENC_TU_TABLES_IN_LDS != 0), "enc_platform
 constexpr size_t LDS_SEQ = (sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15, LDS_CTU = LDS_KEEPS_CTU_RECORD ? (sizeof(CtuPublic) + 15) & ~(size_t)15 : 0,
 		 LDS_FT = LDS_KEEPS_TU_TABLES ? (sizeof(FastTables) + 15) & ~(size_t)15 : 0;
 #if defined(HENC_PROFILE)
-constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = 0;
+constexpr size_t LDS_BOX = LDS_BOX_BYTES, LDS_HSCRATCH = 0, LDS_RD = (sizeof(WorkRd) + 15) & ~(size_t)15;
 constexpr size_t LDS_BYTES = HENC_LDS_PROF_OFFSET + 2 * PP_COUNT * 8;   // the primitive timers sit at HENC_LDS_PROF_OFFSET
 constexpr size_t LDS_FT_OFFSET = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH;
-static_assert(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH + LDS_FT <= HENC_LDS_PROF_OFFSET, "profile table overlaps the worker state");
+static_assert(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH + LDS_FT + LDS_RD <= HENC_LDS_PROF_OFFSET, "profile table overlaps the worker state");
 #else
-constexpr size_t LDS_BOX = (sizeof(HelperBox) + 15) & ~(size_t)15, LDS_HSCRATCH = 0;
-constexpr size_t LDS_BYTES = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH + LDS_FT;
+constexpr size_t LDS_BOX = LDS_BOX_BYTES, LDS_HSCRATCH = 0, LDS_RD = (sizeof(WorkRd) + 15) & ~(size_t)15;
+constexpr size_t LDS_BYTES = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH + LDS_FT + LDS_RD;
 constexpr size_t LDS_FT_OFFSET = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH;
 #endif
+static_assert(sizeof(SubpelScratch) <= LDS_WORK + LDS_NODES + LDS_GEO, "task S works where the post stage does");
 static_assert(sizeof(PostScratch) <= LDS_WORK + LDS_NODES + LDS_GEO, "the post stage works in what is idle between two CTUs: the worker's Work area, the CTU's partition nodes, the helpers' scratch");
+static_assert(LDS_OFF_RD == (int)(LDS_BYTES - LDS_RD) || LDS_FT != 0 || LDS_CTU != 0, "the RD_FULL arrays are the tail of a worker's LDS: launches without RD_FULL pictures leave them out");
 static_assert(LDS_OFF_NODES == (int)LDS_WORK && LDS_OFF_SEQ == (int)(LDS_WORK + LDS_NODES + LDS_GEO) && LDS_OFF_BOX == (int)(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU),
 	      "enc_common.h: the fixed places of Enc's LDS members");
 #if !defined(HENC_WAVES_PER_EU)
@@ -125,11 +127,15 @@ static_assert(LDS_OFF_NODES == (int)LDS_WORK && LDS_OFF_SEQ == (int)(LDS_WORK + 
 #endif
 constexpr int ENC_THREADS = 64 * (1 + NHELP);   // the row worker + its helper wavefronts: one wavefront per SIMD of the CU
 static_assert(LDS_BYTES <= 160 * 1024, "a workgroup has 160 KiB of LDS on gfx950");
-// workers a CU holds: by LDS (160 KiB, allocated in 1280-byte granules is assumed: the tighter of the granule sizes seen on this family) and by wavefront slots
-constexpr int WORKERS_PER_CU_LDS = (int)((160 * 1024) / ((LDS_BYTES + 1279) / 1280 * 1280)), WORKERS_PER_CU_WAVES = 4 * HENC_WAVES_PER_EU / (1 + NHELP);
-constexpr int WORKERS_PER_CU = WORKERS_PER_CU_LDS < WORKERS_PER_CU_WAVES ? WORKERS_PER_CU_LDS : WORKERS_PER_CU_WAVES;
+// workers a CU holds: by LDS (160 KiB in 1280-byte granules on gfx950) and by wavefront slots; a launch without RD_FULL pictures asks for LDS_BYTES - LDS_RD
+constexpr int workers_per_cu(size_t lds_bytes)
+{
+	const int by_lds = (int)((160 * 1024) / ((lds_bytes + 1279) / 1280 * 1280)), by_waves = 4 * HENC_WAVES_PER_EU / (1 + NHELP);
+	return by_lds < by_waves ? by_lds : by_waves;
+}
+constexpr int WORKERS_PER_CU = workers_per_cu(LDS_BYTES - LDS_RD);
 #if defined(HENC_PRINT_LDS)
-static_assert(LDS_BYTES == 0 && LDS_WORK == 0 && LDS_NODES == 0 && LDS_BOX == 0 && sizeof(PostScratch) == 0 && WORKERS_PER_CU == 0, "sizes");
+static_assert(LDS_BYTES - LDS_RD == 0 && LDS_WORK == 0 && LDS_NODES == 0 && LDS_BOX == 0 && sizeof(PostScratch) == 0 && WORKERS_PER_CU == 0, "sizes");
 #endif
 
 // a helper wavefront: run the jobs the worker posts (HelperBox, enc_common.h) until it says quit
@@ -144,6 +150,7 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 		if (job == HJOB_NEW_CTU) {
 			e = box->enc;
 			e.box = nullptr;
+			e.on_helper = 1;
 			e.scratch_a = scratch;
 			e.scratch_b = scratch + 1024;
 			e.adi_c = scratch + 2048;
@@ -212,13 +219,13 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 
 // A workgroup is a row worker (wavefront 0) and its two helpers.  rows_enter sets the mailbox up and sends the helper wavefronts into their service loop; it
 // returns true on the worker only.  release_helpers lets them go (without it the workgroup never ends).
-__device__ __forceinline__ bool rows_enter()
+__device__ __forceinline__ bool rows_enter(unsigned lds_bytes)
 {
 	extern __shared__ __align__(16) uint8_t lds[];
 	HelperBox *box = (HelperBox *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU);
 	const int wave = (int)(threadIdx.x >> 6);
 	// LDS keeps what the last workgroup on this CU left in it: everything starts from zero (the helpers' scratch included), whatever ran here before
-	for (int i = (int)threadIdx.x; i < (int)(LDS_BYTES / 4); i += ENC_THREADS) ((uint32_t *)lds)[i] = 0;
+	for (int i = (int)threadIdx.x; i < (int)(lds_bytes / 4); i += ENC_THREADS) ((uint32_t *)lds)[i] = 0;
 	__syncthreads();
 	if (wave > 0) {
 		helper_loop(box, wave - 1, (int16_t *)(lds + LDS_WORK + LDS_NODES) + (wave - 1) * HSCRATCH_ELEMS);
@@ -273,6 +280,8 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 	e.w = lw;
 	e.nodes = nullptr;
 	e.nodes_fast = (Node *)(lds + LDS_WORK);
+	e.node_quad = -1;
+	e.on_helper = 0;
 	e.ctu_g = nullptr;
 	e.ctu_fast = LDS_KEEPS_CTU_RECORD ? (CtuPublic *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ) : nullptr;
 	e.box = box;
@@ -407,7 +416,7 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 		// RD_FULL: the thread's shadow CTU keeps its prediction modes from CTU to CTU - all INTRA once the thread has taken the intra walk (motion_intra :2003),
 		// the zeroes it was created with before (the worker's fast memory is not the thread's: enc_rdo.h)
 		const int seen = d.thread_seen[me];
-		for (int i = g.tid; i < NPART; i += 64) e.w->rd_pred_mode[i] = seen ? PM_INTRA : PM_INTER;
+		for (int i = g.tid; i < NPART; i += 64) e.wrd->rd_pred_mode[i] = seen ? PM_INTRA : PM_INTER;
 	}
 	const int rem_y = lframe->qp % 6, rem_c = chroma_qp_table(lframe->qp + S.chroma_qp_offset) % 6;
 	if (lft && (cached_rem[0] != rem_y || cached_rem[1] != rem_c)) {
@@ -539,12 +548,12 @@ __device__ __attribute__((noinline)) int pool_post_drain(const EncDev &d, const 
 	return ran;
 }
 
-__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HENC_WAVES_PER_EU))) void k_encode_pool(const EncDev *devs, int nseq, int *state, int *finished, WorkSlow *slow, unsigned long long watchdog_ticks)
+__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HENC_WAVES_PER_EU))) void k_encode_pool(const EncDev *devs, int nseq, int *state, int *finished, WorkSlow *slow, unsigned long long watchdog_ticks, unsigned lds_bytes)
 {
 	// finished[0]: pictures whose last task is done; finished[1]: abort - a worker has waited longer than the watchdog allows (a faulted or starved peer): everybody
 	// leaves and the host reports an error instead of the launch hanging
 	const unsigned long long t_start = wall_clock64();
-	if (!rows_enter()) return;
+	if (!rows_enter(lds_bytes)) return;
 	extern __shared__ __align__(16) uint8_t lds[];
 	WaveGrp g{(int)(threadIdx.x & 63)};
 	Work *lw = (Work *)lds;
@@ -566,6 +575,8 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HEN
 	e.w = lw;
 	e.nodes = nullptr;
 	e.nodes_fast = (Node *)(lds + LDS_WORK);
+	e.node_quad = -1;
+	e.on_helper = 0;
 	e.ctu_g = nullptr;
 	e.ctu_fast = LDS_KEEPS_CTU_RECORD ? (CtuPublic *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ) : nullptr;
 	e.box = box;
@@ -765,7 +776,7 @@ struct SrcSlot {
 
 __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void k_encode_ctus(EncDev d, int pass)
 {
-	if (!rows_enter()) return;
+	if (!rows_enter((unsigned)LDS_BYTES)) return;
 	int hseq[NHELP_MAX] = {0, 0, 0};
 	encode_row(d, pass, (int)blockIdx.x, hseq);
 	release_helpers(hseq);
@@ -1044,10 +1055,13 @@ int lockstep_collect(hmr_gpu_enc *e)
 }
 
 // the row-per-thread schedule of n pictures (their EncDev records already at lead->d_batch) as ONE pool launch on `st`
-int launch_pool(hmr_gpu_enc *lead, int n, int rows_total, hipStream_t st)
+int launch_pool(hmr_gpu_enc *lead, int n, int rows_total, bool needs_rd, hipStream_t st)
 {
 	if (!lead->n_cus) HIP_TRY(hipDeviceGetAttribute(&lead->n_cus, hipDeviceAttributeMultiprocessorCount, lead->ctx->device));
-	const int cap = lead->n_cus * WORKERS_PER_CU;                             // what the LDS lets be resident; more would only queue behind
+	// a worker's LDS: without RD_FULL pictures in the launch the RD arrays at its end are left out (a fourth worker then fits a CU)
+	const size_t lds_default = needs_rd ? LDS_BYTES : LDS_BYTES - LDS_RD;
+	const size_t lds_bytes = getenv("HENC_LDS_BYTES") && (size_t)atoi(getenv("HENC_LDS_BYTES")) > lds_default ? (size_t)atoi(getenv("HENC_LDS_BYTES")) : lds_default;   // (experiment: a larger request keeps a CU to fewer workers)
+	const int cap = lead->n_cus * workers_per_cu(lds_bytes);                  // what the LDS lets be resident; more would only queue behind
 	int workers = rows_total < cap ? rows_total : cap;                        // (a picture never has more CTUs in flight than rows)
 	if (getenv("HENC_POOL_WORKERS") && atoi(getenv("HENC_POOL_WORKERS")) > 0 && atoi(getenv("HENC_POOL_WORKERS")) < workers) workers = atoi(getenv("HENC_POOL_WORKERS"));      // (experiment)
 	if (!lead->d_pool_state) HIP_TRY(hipMalloc((void **)&lead->d_pool_state, sizeof(int) * (256 * POOL_STRIDE + 4)));
@@ -1060,11 +1074,10 @@ int launch_pool(hmr_gpu_enc *lead, int n, int rows_total, hipStream_t st)
 		lead->pool_workers = workers;
 	}
 	HIP_TRY(hipMemsetAsync(lead->d_pool_state, 0, sizeof(int) * (256 * POOL_STRIDE + 4), st));
-	const size_t lds_bytes = getenv("HENC_LDS_BYTES") ? (size_t)atoi(getenv("HENC_LDS_BYTES")) : LDS_BYTES;   // (experiment: a larger request keeps a CU to one worker)
 	// the watchdog (100 MHz ticks): a launch is a second or two of work; a worker that finds nothing to do for this long gives up for everybody
 	const unsigned long long watchdog = (unsigned long long)(getenv("HENC_WATCHDOG_S") ? atof(getenv("HENC_WATCHDOG_S")) : 120.0) * 100000000ull;
 	hipLaunchKernelGGL(k_encode_pool, dim3(workers), dim3(ENC_THREADS), lds_bytes, st, (const EncDev *)lead->d_batch, n, lead->d_pool_state, lead->d_pool_state + 256 * POOL_STRIDE,
-			   lead->d_pool_slow, watchdog);
+			   lead->d_pool_slow, watchdog, (unsigned)lds_default);
 	const hipError_t launched = hipGetLastError();
 	if (launched != hipSuccess) {
 		hmr_set_error("k_encode_pool: %s", hipGetErrorString(launched));
@@ -1085,7 +1098,7 @@ int run_ctu_passes(hmr_gpu_enc *e)
 		// wfpp_num_threads > 1: the synchronous wavefront, one launch, nothing to verify - the picture's CTUs as a pool of tasks (k_encode_pool)
 		if (!e->d_batch) HIP_TRY(hipMalloc((void **)&e->d_batch, 256 * sizeof(EncDev)));
 		HIP_TRY(hipMemcpyAsync(e->d_batch, &e->d, sizeof(EncDev), hipMemcpyHostToDevice, st));
-		if ((rc = launch_pool(e, 1, s.hctu, st))) return rc;
+		if ((rc = launch_pool(e, 1, s.hctu, s.rd_mode == RDM_FULL, st))) return rc;
 		HIP_TRY(hipEventRecord(e->ctx->ev1, st));
 		if ((rc = lockstep_collect(e))) return rc;      // (waits for the launch)
 		HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ctx->ev0, e->ctx->ev1));
@@ -1967,6 +1980,7 @@ int batch_launch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_t
 	hmr_gpu_enc *lead = encs[0];
 	hipStream_t bst = lead->ctx->stream;
 	int rc, rows_total = 0, max_ctus = 0;
+	bool needs_rd = false;
 	// frame set-up on the host; nothing is queued on the sequences' streams: the launch's stream waits for what each of them still has in flight (the filter
 	// chain and packing of its previous frame) and takes the rest - the frames' parameters in one upload, the phase planes, the per-frame state in one kernel
 	if (!lead->d_frames) {
@@ -1983,6 +1997,7 @@ int batch_launch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_t
 		lead->h_devs[i] = e->d;
 		lead->h_devs[i].frame = lead->d_frames + i;
 		rows_total += e->seq.hctu;
+		needs_rd = needs_rd || e->seq.rd_mode == RDM_FULL;
 		if (e->seq.nctu > max_ctus) max_ctus = e->seq.nctu;
 	}
 	// The phase planes of all the reference pictures one after the other on the launch's stream: a picture's three kernels fill the GPU (2500 workgroups, 1.9 TB/s);
@@ -2027,7 +2042,7 @@ int batch_launch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_t
 	hipLaunchKernelGGL(k_batch_stage, dim3(n), dim3(256), 0, bst, (const EncDev *)lead->h_devs, (const FrameCtx *)lead->h_frames, (EncDev *)lead->d_batch, lead->d_frames);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(lead->ev_batch0, bst));
-	if ((rc = launch_pool(lead, n, rows_total, bst))) return rc;
+	if ((rc = launch_pool(lead, n, rows_total, needs_rd, bst))) return rc;
 	(void)hipEventRecord(lead->ev_batch1, bst);
 	hipLaunchKernelGGL(k_gather_results, dim3(n), dim3(256), 0, bst, (const EncDev *)lead->d_batch, lead->d_gather, pitch, (const int *)(lead->d_pool_state + 256 * POOL_STRIDE));
 	HIP_TRY(hipGetLastError());
@@ -2233,6 +2248,7 @@ extern "C" int hmr_gpu_enc_encode_chain(hmr_gpu_enc **encs, int n, hmr_gpu_enc *
 	hipStream_t bst = lead->ctx->stream;
 	HIP_TRY(hipSetDevice(lead->ctx->device));
 	int rc, rows_total = 0;
+	bool needs_rd = false;
 	if (!lead->d_frames) {
 		HIP_TRY(hipMalloc((void **)&lead->d_frames, 256 * sizeof(FrameCtx)));
 		HIP_TRY(hipHostMalloc((void **)&lead->h_frames, 256 * sizeof(FrameCtx), hipHostMallocDefault));
@@ -2305,6 +2321,7 @@ extern "C" int hmr_gpu_enc_encode_chain(hmr_gpu_enc **encs, int n, hmr_gpu_enc *
 		lead->h_devs[j] = e->d;
 		lead->h_devs[j].frame = lead->d_frames + j;
 		rows_total += s.hctu;
+		needs_rd = needs_rd || s.rd_mode == RDM_FULL;
 	}
 	const int nctu = lead->seq.nctu, pitch = GATHER_HEAD + nctu + POST_MAX_ROWS;
 	if ((size_t)pitch * n > lead->gather_words) {
@@ -2319,7 +2336,7 @@ extern "C" int hmr_gpu_enc_encode_chain(hmr_gpu_enc **encs, int n, hmr_gpu_enc *
 	hipLaunchKernelGGL(k_batch_stage, dim3(n), dim3(256), 0, bst, (const EncDev *)lead->h_devs, (const FrameCtx *)lead->h_frames, (EncDev *)lead->d_batch, lead->d_frames);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(lead->ev_batch0, bst));
-	if ((rc = launch_pool(lead, n, rows_total, bst))) return rc;
+	if ((rc = launch_pool(lead, n, rows_total, needs_rd, bst))) return rc;
 	(void)hipEventRecord(lead->ev_batch1, bst);
 	hipLaunchKernelGGL(k_gather_results, dim3(n), dim3(256), 0, bst, (const EncDev *)lead->d_batch, lead->d_gather, pitch, (const int *)(lead->d_pool_state + 256 * POOL_STRIDE));
 	HIP_TRY(hipGetLastError());

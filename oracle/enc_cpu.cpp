@@ -84,6 +84,7 @@ struct Cpu {
 Work *new_work()
 {
 	Work *w = (Work *)calloc(1, sizeof(Work));
+	w->rd_store = (WorkRd *)calloc(1, sizeof(WorkRd));
 	w->slow = (WorkSlow *)calloc(1, sizeof(WorkSlow));
 	return w;
 }
@@ -438,14 +439,17 @@ void frame_ctus_lockstep(Cpu &c, Enc &e)
 				memcpy(pred.data() + sizeof w.pred_y, w.pred_c, sizeof w.pred_c);
 				const int32_t seen = w.thread_seen_intra;
 				WorkSlow *slow = w.slow;
+				WorkRd *rd = w.rd_store;
 				memset(&w, atoi(getenv("HENC_WIPE_WORK")), sizeof(Work));
 				memset(slow, atoi(getenv("HENC_WIPE_WORK")), sizeof(WorkSlow));
+				memset(rd, atoi(getenv("HENC_WIPE_WORK")), sizeof(WorkRd));
 				w.slow = slow;
+				w.rd_store = rd;
 				memcpy(w.intra_mode_buffs, modes.data(), MODE_STATE_BYTES);
 				memcpy(w.pred_y, pred.data(), sizeof w.pred_y);
 				memcpy(w.pred_c, pred.data() + sizeof w.pred_y, sizeof w.pred_c);
 				w.thread_seen_intra = seen;
-				if (s.rd_mode == RDM_FULL) memset(w.rd_pred_mode, seen ? PM_INTRA : PM_INTER, sizeof w.rd_pred_mode);
+				if (s.rd_mode == RDM_FULL) memset(w.rd_store->rd_pred_mode, seen ? PM_INTRA : PM_INTER, sizeof w.rd_store->rd_pred_mode);
 			}
 			memcpy(e.w->mode_in, e.w->intra_mode_buffs, MODE_STATE_BYTES);
 			encode_ctu(g, e, n);
