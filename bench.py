@@ -4,7 +4,7 @@
 Workload ("cfg2-1080p-encode"): the real encode of 1920x1080 IPPP sequences (gop_size=1, fixed QP 32, quarter-pel ME, SAO on, one WPP thread per CTU row) through the
 C ABI (include/homer_gpu.h section 12) - a batch of --sequences independent sequences per GPU (256; eight different synthetic clips, tools/gen_yuv.py), one frame of
 each per step (hmr_gpu_enc_encode_batch_pipelined).  One step = everything HOMER_enc_encode does for those frames: the phase planes of the reference pictures, then ONE
-launch of k_encode_pool - the CTU decisions of all the pictures as a pool of tasks on two row workers per CU and, behind each CTU, its post-decision tasks: deblocking,
+launch of k_encode_pool - the CTU decisions of all the pictures as a pool of tasks on four row workers per CU and, behind each CTU, its post-decision tasks: deblocking,
 SAO statistics / decision / syntax / offsets, CABAC of the CTU row's sub-stream, border padding - then the download of the sub-streams and headers / entry points / NAL
 escaping on the host; the access units are delivered inside the timed region (the pipelined call delivers a step's units with the next call: the pipeline is empty when
 the region starts and flushed before it ends).  The source pictures are resident in HBM before the timed region starts.  Warm-up frames are the first frames of the
@@ -23,7 +23,7 @@ every rank encodes that many frames per step whatever N is (weak scaling); the e
 the reference's num_enc_engines = N stream (oracle/ref_ctudump.c's engine turnstile; tests/golden/bench_md5.json).
 
 Extra objects: `roofline` for k_encode_pool (98 % of a step): algorithmic bytes per SURVEY.md 8-d against the 8 TB/s HBM peak, the fabric traffic from the
-calibrated counter passes of this build, and `issue_bound` - what actually binds the kernel (the issue latency of 1.5 wavefronts per SIMD and the memory trips of
+calibrated counter passes of this build, and `issue_bound` - what actually binds the kernel (the issue latency of two wavefronts per SIMD and the memory trips of
 their dependent chains), with the ceiling measured live by an issue-rate probe; `roofline.subpel_planes`: the bandwidth-bound phase-plane kernels measured live;
 `cpu_baseline`: the compiled reference (oracle/_ref/ref_lockstep) timed on this host on the same configuration by its own clock - one process per physical core
 side by side (the headline of the baseline), one process, and one process with a thread per CTU row.
@@ -48,6 +48,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s
+WORKERS_PER_CU = 4             # k_encode_pool: row workers (a wavefront + its helper, 40.6 KB of LDS) a CU holds (k_encode.hip workers_per_cu)
 WORKLOADS = {                  # name -> (width, height, configuration keys of tests/encoder_cases.default_cfg)
     # BASELINE.json configs[1] "WPP CTU rows on-GPU": one WPP thread per CTU row (wfpp_num_threads = 17), the reference's synchronous-wavefront schedule
     "cfg2-1080p-encode": (1920, 1080, {"wpp": 17}),
@@ -116,37 +117,77 @@ def cpu_baseline(width, height, keys, frames):
         avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
     except (ValueError, OSError):
         avail = 64 << 30
-    # one process per PHYSICAL core (the siblings of a core share its SSE units and caches: 256 processes on 128 cores were slower in total than 128)
-    physical = set()
-    for cpu in range(ncores):
+    # what this process may actually use of the host: its affinity mask and its cgroup's CPU quota
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = list(range(ncores))
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            quota = open(path).read().strip()
+            break
+        except OSError:
+            pass
+    quota_cpus = None
+    if quota and quota.split()[0] not in ("max", "-1"):
+        f = quota.split()
+        quota_cpus = round(int(f[0]) / (int(f[1]) if len(f) > 1 else 100000), 2)
+    # one process per PHYSICAL core, pinned to it (the siblings of a core share its SSE units and caches: 256 processes on 128 cores were slower in total than 128)
+    first_cpu_of_core = {}
+    for cpu in allowed:
         try:
             base = f"/sys/devices/system/cpu/cpu{cpu}/topology/"
-            physical.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+            key = (open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip())
         except OSError:
-            physical.add(("?", str(cpu)))
-    K = max(1, min(len(physical), int(avail * 0.5 / (400 << 20))))      # (a 1080p reference process holds well under 400 MB)
+            key = ("?", str(cpu))
+        first_cpu_of_core.setdefault(key, cpu)
+    pins = sorted(first_cpu_of_core.values())
+    K = max(1, min(len(pins), int(avail * 0.5 / (400 << 20))))      # (a 1080p reference process holds well under 400 MB)
+    if quota_cpus:
+        K = max(1, min(K, int(quota_cpus)))
     with tempfile.TemporaryDirectory() as tmp:
         yuv = os.path.join(tmp, "in.yuv")
         gen_yuv.write_clip(yuv, width, height, frames)
         cmd = [exe, yuv, "-", str(width), str(height), str(frames)] + [f"{k}={v}" for k, v in keys.items()]
-        dt, n1 = seconds(subprocess.run(cmd, check=True, capture_output=True).stdout)
+
+        def pinned(cpu):
+            return lambda: os.sched_setaffinity(0, {cpu})
+
+        dt, n1 = seconds(subprocess.run(cmd, check=True, capture_output=True, preexec_fn=pinned(pins[0])).stdout)
         rows = (height + 63) // 64
         dt_rows, _ = seconds(subprocess.run(cmd + [f"wpp={rows}"], check=True, capture_output=True).stdout)
-        # the same shape as the batch: K independent sequences at once, one single-thread reference process per host core
+        # the same shape as the batch: K independent sequences at once, one single-thread reference process per physical host core
         t0 = time.time()
-        procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(K)]
-        secs = [seconds(p.communicate()[0])[0] for p in procs]
+        procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, preexec_fn=pinned(pins[k])) for k in range(K)]
+        secs, cpu_s = [], []
+        for p in procs:
+            out = p.stdout.read()
+            _, status, ru = os.wait4(p.pid, 0)
+            p.returncode = os.waitstatus_to_exitcode(status)
+            secs.append(seconds(out)[0])
+            cpu_s.append(ru.ru_utime + ru.ru_stime)
         wall_k = time.time() - t0
-    throughput = {"value": round(K * frames / max(secs), 3), "unit": "frames/s aggregate", "processes": K, "cores": K, "host_cores": ncores, "host_physical_cores": len(physical), "frames_per_process": frames,
+    one = n1 / dt
+    aggregate = K * frames / max(secs)
+    effective = aggregate / one
+    throughput = {"value": round(aggregate, 3), "unit": "frames/s aggregate", "processes": K, "cores": round(effective, 1), "host_cores": ncores, "host_physical_cores_allowed": len(pins),
+                  "affinity_cpus": len(allowed), "cgroup_cpu_max": quota, "frames_per_process": frames,
                   "slowest_process_s": round(max(secs), 2), "fastest_process_s": round(min(secs), 2), "wall_s_incl_process_start": round(wall_k, 2),
-                  "note": "K single-thread reference processes side by side, one sequence each: the host's answer to a batch of independent sequences; K x frames / the slowest "
-                          "process's encode time (start-up and HOMER_enc_init excluded)"}
+                  "cpu_seconds_per_process_mean": round(sum(cpu_s) / len(cpu_s), 2), "cpu_seconds_per_process_max": round(max(cpu_s), 2),
+                  "one_process_encode_s": round(dt, 2),
+                  "parallel_efficiency": round(effective / K, 3),
+                  "note": "K single-thread reference processes side by side, each pinned to its own physical core, one sequence each: the host's answer to a batch of independent sequences; "
+                          "K x frames / the slowest process's encode time (start-up and HOMER_enc_init excluded).  `cores` is the EFFECTIVE parallelism (aggregate rate / the rate of one "
+                          "process alone): cpu_seconds_per_process against one_process_encode_s says whether the processes got their cores (equal: they did, and the loss is the memory "
+                          "system's; larger wall than CPU time: they were descheduled - a quota or other tenants)"}
     # the headline of the baseline is the host's best answer to the bench's workload (a batch of independent sequences): all cores, one reference process each
-    return {"value": throughput["value"], "unit": "frames/s", "cores": K, "kind": "reference",
-            "sample": f"{K} processes x {frames} frames {width}x{height} IPPP QP32 through oracle/_ref/ref_lockstep (SSE4.2 table, wpp=1, engines=1), one per physical host core; the harness's own "
-                      "clock from the first HOMER_enc_encode to the last access unit of the slowest process (no process start, no HOMER_enc_init)",
+    return {"value": throughput["value"], "unit": "frames/s", "cores": throughput["cores"], "kind": "reference",
+            "sample": f"{K} processes x {frames} frames {width}x{height} IPPP QP32 through oracle/_ref/ref_lockstep (SSE4.2 table, wpp=1, engines=1), one pinned to each physical host core this "
+                      f"process may use; the harness's own clock from the first HOMER_enc_encode to the last access unit of the slowest process (no process start, no HOMER_enc_init); `cores` = "
+                      f"effective parallelism {round(effective, 1)} of {K} processes",
             "throughput": throughput,
-            "one_process": {"value": round(n1 / dt, 3), "unit": "frames/s", "cores": 1, "frames": n1},
+            "one_process": {"value": round(one, 3), "unit": "frames/s", "cores": 1, "frames": n1},
             "one_thread_per_ctu_row": {"value": round(n1 / dt_rows, 3), "threads": rows, "host_cores": ncores,
                                        "note": "the same reference run free with wfpp_num_threads = CTU rows (its multi-thread mode; output depends on timing)"}}
 
@@ -340,6 +381,20 @@ def measure(step, warmup, nframes, world, device_sync, device, flush=None):
     return dt
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, 127.0.0.1), rank 0's
+    stdout passed through.  Returns the worst exit code."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    return max(abs(p.wait()) for p in procs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -350,7 +405,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=24)
     ap.add_argument("--no-single-thread-order", action="store_true", help="skip the second measurement (wfpp_num_threads = 1)")
     ap.add_argument("--sequences", type=int, default=256, help="independent sequences per GPU, encoded with one launch per step (hmr_gpu_enc_encode_batch: their CTUs are a pool of tasks for "
-                    "two row workers per CU); 1 = a single sequence")
+                    "four row workers per CU); 1 = a single sequence")
     ap.add_argument("--no-pipeline", action="store_true", help="batch steps through hmr_gpu_enc_encode_batch (access units inside the call) instead of the pipelined call")
     ap.add_argument("--streams", type=int, default=0, help="concurrent sequences of the extra multi_stream measurement (0 = skip)")
     ap.add_argument("--multi-stream-child", type=int, default=0, help=argparse.SUPPRESS)
@@ -363,6 +418,15 @@ def main():
         fn = multi_stream_batched if a.batched else multi_stream
         print(json.dumps(fn(load_lib(), a.device, width, height, keys, a.multi_stream_child, 2, 3)))
         return
+
+    # --gpus N: under a launcher (torch.distributed.run sets WORLD_SIZE) the flag must agree with it; without one this process starts the N ranks itself - plain child
+    # processes, started before anything here has touched the GPU (never an exec of a process that has) - and passes on rank 0's line and the worst exit code
+    if "WORLD_SIZE" in os.environ:
+        if int(os.environ["WORLD_SIZE"]) != a.gpus:
+            print(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={os.environ['WORLD_SIZE']}", file=sys.stderr)
+            sys.exit(2)
+    elif a.gpus > 1:
+        sys.exit(spawn_ranks(a.gpus))
 
     import torch
     import torch.distributed as dist
@@ -384,8 +448,14 @@ def main():
     if world > 1:
         out = run_engine_ring(a, world, rank, local, torch)
         if rank == 0:
+            if not a.no_cpu_baseline:
+                width, height, keys = WORKLOADS[a.workload]
+                out["cpu_baseline"] = cpu_baseline(width, height, {k: v for k, v in keys.items() if k != "wpp"}, a.cpu_frames)
             print(json.dumps(out))
         dist.destroy_process_group()
+        if not out["stream_matches_reference"]:
+            print("bench.py: access units differ from the reference's", file=sys.stderr)
+            sys.exit(3)
         return
     out = run_workload(lib, a, a.workload, world, rank, local, torch, sequences=a.sequences)
     if rank == 0:
@@ -469,12 +539,19 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(width, height, {k: v for k, v in keys.items() if k != "wpp"}, a.cpu_frames)
         print(json.dumps(out))
+        # a run whose output differs from the reference's is a failed run, whatever it measured: every section that checked its stream must have matched
+        bad = [name for name, sec in [("headline", out)] + [(k, v) for k, v in out.items() if isinstance(v, dict)] if sec.get("stream_matches_reference") is False]
+        bad += [f"single_sequence.engines_overlapped[{i}]" for i, lane in enumerate(out.get("single_sequence", {}).get("engines_overlapped", [])) if lane.get("stream_matches_reference") is False]
+        if bad:
+            print("bench.py: output differs from the reference in: " + ", ".join(bad), file=sys.stderr)
+            sys.exit(3)
     if world > 1:
         dist.destroy_process_group()
 
 
-def run_engine_ring(a, world, rank, local, torch):
-    """--gpus N > 1: the engine ring (module docstring)."""
+def run_engine_ring(a, world, rank, local, torch, adapter=None):
+    """--gpus N > 1: the engine ring (module docstring).  `adapter`: the encoder behind homerhevc_amd.engines.EngineRing - the product's GpuEngines unless a test brings its
+    own (tests/test_bench_gloo.py runs this function at world 2 over gloo with the one-lane checker build behind it, `adapter.on_cpu`)."""
     import torch.distributed as dist
     import encoder_cases as ec
     from homerhevc_amd.engines import EngineRing, GpuEngines
@@ -483,29 +560,51 @@ def run_engine_ring(a, world, rank, local, torch):
     name = f"{base}-engines{world}"
     keys = dict(keys, engines=world)
     nframes = a.warmup + a.steps
-    # every rank keeps an engine object of EVERY sequence (about 105 MB at 1080p: three pictures, the CTU records, the levels) beside the phase planes of the
-    # sequences it encodes in a step: 160 sequences per GPU keep an 8-GPU ring (1280 objects per rank) under 200 GB of the 288
-    a.sequences = min(a.sequences, 160)
-    S = a.sequences * world
-    # (HOMER_BENCH_ONE_DEVICE: all ranks on one GPU over gloo - the pictures then cross page-locked host buffers)
-    adapter = GpuEngines(lambda seq: ec.default_cfg(width, height, **keys), local, pipelined=not a.no_pipeline, host_exchange=bool(os.environ.get("HOMER_BENCH_ONE_DEVICE")))
+    on_cpu = adapter is not None and getattr(adapter, "on_cpu", False)
+    if adapter is None:
+        # (HOMER_BENCH_ONE_DEVICE: all ranks on one GPU over gloo - the pictures then cross page-locked host buffers)
+        adapter = GpuEngines(lambda seq: ec.default_cfg(width, height, **keys), local, pipelined=not a.no_pipeline, host_exchange=bool(os.environ.get("HOMER_BENCH_ONE_DEVICE")))
+    host_tensors = on_cpu or getattr(adapter, "host_exchange", False)
+    # Every rank keeps an engine object of EVERY sequence in flight (the engine of that sequence that lives on this rank: its pictures, CTU records, levels) beside the
+    # phase planes of the sequences it encodes in a step.  The per-GPU load is the N = 1 line's (--sequences, 256) wherever that fits the GPU's memory; where it does not
+    # (eight ranks: 2048 objects) it is what fits, the same on every rank - `sequences_per_gpu` says which.
+    per_gpu = a.sequences
+    if not on_cpu:
+        free0, _ = torch.cuda.mem_get_info()
+        probe = adapter.create(0, 0)
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        adapter.destroy(probe)
+        obj = max(free0 - free1, 1)
+        sy, ry, sc, rc = width + 160, height + 160, width // 2 + 80, height // 2 + 80
+        planes = 16 * sy * ry + 2 * 64 * sc * rc + 8 * width * height       # phase planes of a picture being encoded + its share of staging
+        fit = int(0.85 * free1 // (world * obj + planes))
+        if os.environ.get("HOMER_BENCH_ONE_DEVICE"):
+            fit //= world
+        t = torch.tensor([max(1, min(per_gpu, fit))], dtype=torch.int64, device="cpu" if host_tensors else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        per_gpu = int(t.item())
+    S = per_gpu * world
     ring = EngineRing(adapter, S, rank, world)
     ring.load_sources(ec.clip_frames(width, height, nframes))
     gold = REFERENCE_MD5.get(name, {}).get("au_md5", [])
     bad, checked, produced = [0], [0], [0]
     first_bad = []
-
+    pipelined = getattr(adapter, "pipelined", False)
     kept = []
+    launch_ms = []
 
     def step(f):
         units = ring.step(f, last=f + 1 == nframes)                 # (pipelined: the units of frame f - world of the same sequences)
+        if f >= a.warmup and getattr(adapter, "last_ctu_ms", None) is not None:
+            launch_ms.append(adapter.last_ctu_ms)
         if units:
             kept.append((ring.delivered, units))                    # (hashed after the timed region: checking the output is the harness's work)
 
     def flush():
         kept.extend(ring.flush())
 
-    dt = measure(step, a.warmup, nframes, world, torch.cuda.synchronize, "cuda", flush if adapter.pipelined else None)
+    dt = measure(step, a.warmup, nframes, world, (lambda: None) if on_cpu else torch.cuda.synchronize, "cpu" if host_tensors else "cuda", flush if pipelined else None)
     for f, units in kept:
         for s, au in units.items():
             produced[0] += 1
@@ -518,32 +617,42 @@ def run_engine_ring(a, world, rank, local, torch):
                     bad[0] += 1
                     if len(first_bad) < 6:
                         first_bad.append({"rank": rank, "sequence": s, "frame": f, "bytes": len(au)})
-    t = torch.tensor([bad[0], checked[0], produced[0]], dtype=torch.int64, device="cpu" if adapter.host_exchange else "cuda")
+    t = torch.tensor([bad[0], checked[0], produced[0]], dtype=torch.int64, device="cpu" if host_tensors else "cuda")
     dist.all_reduce(t)
     bad_all, checked_all, produced_all = (int(x) for x in t.tolist())
-    row_bytes = adapter.row_bytes
+    row_bytes = getattr(adapter, "row_bytes", None)
+    matches = bool(checked_all > 0 and bad_all == 0)
+    # the dominant kernel on this rank, as on one GPU: k_encode_pool, one launch per step for this rank's `per_gpu` pictures (HIP events on the lead encoder's stream)
+    roofline = None
+    if launch_ms:
+        algo = 10.5 * width * height * per_gpu
+        ms = sum(launch_ms) / len(launch_ms)
+        roofline = {"bound": "hbm", "kernel": "k_encode_pool", "achieved": round(algo / (ms * 1e-3) / 1e9, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 7),
+                    "traffic": None, "launches": len(launch_ms), "algorithmic_bytes_per_launch": int(algo), "ms_per_launch": round(ms, 2), "rank": rank,
+                    "note": "rank 0's launches; the kernel and its limits are the N = 1 line's (roofline.issue_bound there)"}
     return {
         "metric": "encoded frames/sec, 1080p & 2160p YUV420 fixed-QP IPPP, 1/2/4/8 MI355X", "value": round(S * a.steps / dt, 4), "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int16", "data": "synthetic",
-        "config": {"workload": name, "sequences_per_gpu": a.sequences, "sequences": S, "frames_per_step": S, "num_enc_engines": world, "wfpp_num_threads": int(keys.get("wpp", 1)),
+        "config": {"workload": name, "sequences_per_gpu": per_gpu, "sequences_per_gpu_asked": a.sequences, "sequences": S, "frames_per_step": S, "num_enc_engines": world, "wfpp_num_threads": int(keys.get("wpp", 1)),
                    "width": width, "height": height, "frames_in_sequence": nframes, "gop": "IPPP intra_period=100", "qp": 32, "rd_mode": 2, "performance_mode": 2, "sao": 1,
-                   "parallelism": f"engine per GPU: frame t of sequence s on rank (s + t) mod {world}; every rank encodes {a.sequences} frames per step in one launch, "
+                   "parallelism": f"engine per GPU: frame t of sequence s on rank (s + t) mod {world}; every rank encodes {per_gpu} frames per step in one launch, "
                                   "then one packed RCCL send / recv of the reconstructed pictures (8-bit, without margins) + frame scalars to the next rank",
                    "timed_region": "per step: import of the previous rank's pictures (widen + pad), CTU decisions + filters + SAO + CABAC on the device, headers / NAL on the host, export + ring exchange",
                    "call": "hmr_gpu_enc_encode_batch_pipelined per set of sequences (a rank's sets take turns: a set's access units come with its next call, `world` steps later, "
-                           "their download and entropy coding under that call's CTU launch); every pipeline empty when the timed region starts and flushed inside it" if adapter.pipelined
-                           else "hmr_gpu_enc_encode_batch"},
-        "stream_matches_reference": bool(checked_all > 0 and bad_all == 0), "access_units_checked_against_reference": checked_all, "access_units_produced": produced_all,
+                           "their download and entropy coding under that call's CTU launch); every pipeline empty when the timed region starts and flushed inside it" if pipelined
+                           else "hmr_gpu_enc_encode_batch",
+                   "stream_matches_reference": matches, "access_units_checked_against_reference": checked_all},
+        "stream_matches_reference": matches, "access_units_checked_against_reference": checked_all, "access_units_produced": produced_all,
         "access_units_differing": bad_all, "first_differences_on_rank_0": first_bad,
-        "exchange": {"bytes_per_sequence_and_step": row_bytes, "bytes_per_rank_and_step": row_bytes * a.sequences, "collective": "ring of point-to-point transfers (batch_isend_irecv), no reduction"},
-        "roofline": None, "cpu_baseline": None,
+        "exchange": {"bytes_per_sequence_and_step": row_bytes, "bytes_per_rank_and_step": row_bytes * per_gpu if row_bytes else None, "collective": "ring of point-to-point transfers (batch_isend_irecv), no reduction"},
+        "roofline": roofline, "cpu_baseline": None,
     }
 
 
 def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
     """`sequences` independent sequences of the workload per GPU: 1 = hmr_gpu_enc_encode_source frame by frame; more = one batch call per step (ONE launch for the
-    CTU stages of all of them: a pool of CTU tasks on two row workers per CU; the pipelined call by default, whose access units come with the next call), every
+    CTU stages of all of them: a pool of CTU tasks on four row workers per CU; the pipelined call by default, whose access units come with the next call), every
     access unit kept and checked against the reference's digests after the timed region."""
     import encoder_cases as ec
     width, height, keys = WORKLOADS[workload]
@@ -641,13 +750,14 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
         ctu_ms = sum(s[5] for s in timed)                         # HIP events around the passes of each frame, on the encoder's stream
         frame_ms = sum(s[6] for s in timed)
         # SURVEY.md 8-d, the CTU stage's share of the frame-level compulsory traffic: source + reference + reconstruction (1 byte samples) + levels (2 bytes)
-        algo_bytes_frame = 1.5 * width * height * 3 + 2 * 1.5 * width * height
+        # ... plus the in-loop filters' read and write of the picture, which are tasks of the same kernel: 10.5 W H bytes per P frame ("whole P frame")
+        algo_bytes_frame = 10.5 * width * height
         achieved = S * algo_bytes_frame * len(timed) / (ctu_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed counter passes of this same command: TCC_EA0 requests by their width (64 / 128-byte reads, 64-byte full-line and 32-byte
         # partial-line writes; calibrated on known byte counts, profiles/r04_tcc_calibration.json, as MI355X_MICROARCH.md "HBM" asks for narrow accesses)
         traffic, issue, traffic_source = None, None, None
         kernel_name = "k_encode_pool"
-        tpath = os.path.join(ROOT, "profiles", "r04_pmc_kernels.json")
+        tpath = os.path.join(ROOT, "profiles", "r05_pmc_kernels.json")
         if os.path.exists(tpath) and workload == "cfg2-1080p-encode":
             pm = json.load(open(tpath))
             k, frames_profiled = pm.get(kernel_name), pm.get("frames_encoded_by_k_encode_pool")
@@ -655,15 +765,15 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
                 dv = k["derived"]      # (by request width where the passes have it, tools/tcc_calibrate.py; else requests x 64 B)
                 per_frame = (dv.get("hbm_read_bytes", dv["hbm_read_bytes_TCC_EA0_RDREQ_x64"]) + dv.get("hbm_write_bytes", dv["hbm_write_bytes_TCC_EA0_WRREQ_x64_upper_bound"])) / frames_profiled
                 traffic = int(per_frame * S * len(timed) / max(launches, 1))       # per launch, like `achieved`
-                traffic_source = (f"profiles/r04_pmc_kernels.json: TCC_EA0 read / write requests by width, rocprofv3 --pmc passes of this command on the build of commit "
+                traffic_source = (f"profiles/r05_pmc_kernels.json: TCC_EA0 read / write requests by width, rocprofv3 --pmc passes of this command on the build of commit "
                                   f"{pm.get('build_commit')}, bytes per encoded frame x the frames of one launch")
                 # the memory-side passes repeated on the final build (tools/pmc_traffic.sh) take precedence for the byte count
-                fpath = os.path.join(ROOT, "profiles", "r04_final_traffic_pmc_kernels.json")
+                fpath = os.path.join(ROOT, "profiles", "r05_final_traffic_pmc_kernels.json")
                 if os.path.exists(fpath):
                     fm = json.load(open(fpath))
                     fd = fm["k_encode_pool"]["derived"]
                     traffic = int((fd["hbm_read_bytes"] + fd["hbm_write_bytes"]) / fm["frames_encoded_by_k_encode_pool"] * S * len(timed) / max(launches, 1))
-                    traffic_source = (f"profiles/r04_final_traffic_pmc_kernels.json: TCC_EA0 read / write requests by width (64 / 128-byte reads, 64-byte full-line and 32-byte "
+                    traffic_source = (f"profiles/r05_final_traffic_pmc_kernels.json: TCC_EA0 read / write requests by width (64 / 128-byte reads, 64-byte full-line and 32-byte "
                                       f"partial-line writes), rocprofv3 --pmc passes of a 256-sequence run of this command on the build of commit {fm.get('build_commit')}, bytes per "
                                       "encoded frame x the frames of one launch")
                 # what actually bounds the kernel: wave-instruction issue (MI355X_MICROARCH.md: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction)
@@ -672,14 +782,14 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
                 issue = {"valu_wave_instructions_per_frame": int(valu_per_frame), "salu_wave_instructions_per_frame": int(salu_per_frame),
                          "valu_issue_peak_per_s": 614.4e9, "valu_issue_frac": round(valu_per_frame * fps_kernel / 614.4e9, 4),
                          "wait_share_of_wave_cycles": k["derived"].get("wait_share_of_wave_cycles"), "issue_share_of_wave_cycles": k["derived"].get("issue_share_of_wave_cycles"),
-                         "wavefronts_per_simd": round(3 * 2 / 4, 2), "workgroups_per_cu": 2,
+                         "wavefronts_per_simd": round(2 * WORKERS_PER_CU / 4, 2), "workgroups_per_cu": WORKERS_PER_CU,
                          # a wavefront issues one instruction per four cycles whatever its kind (SQ_ACTIVE_INST_x / SQ_INSTS_x = 1.0 quad-cycles in the counter passes): all
                          # the kernel's wave-instructions x 4 cycles against the cycles its 512 workers had - an upper bound of the workers' issue share (the helpers'
                          # instructions, mailbox polling included, are in the count)
                          "wave_instructions_per_frame": int(sum(k.get(c, 0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_FLAT", "SQ_INSTS_SMEM")) / frames_profiled),
                          "issue_cycles_over_worker_cycles": round(4 * sum(k.get(c, 0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_FLAT", "SQ_INSTS_SMEM")) / frames_profiled
-                                                                  / (512 * 2.4e9 / fps_kernel), 3),
-                         "source": f"profiles/r04_pmc_kernels.json (rocprofv3 --pmc passes of this command on the build of commit {pm.get('build_commit')}), instruction counts per encoded frame x this run's frames/s of the kernel"}
+                                                                  / (256 * WORKERS_PER_CU * 2.4e9 / fps_kernel), 3),
+                         "source": f"profiles/r05_pmc_kernels.json (rocprofv3 --pmc passes of this command on the build of commit {pm.get('build_commit')}), instruction counts per encoded frame x this run's frames/s of the kernel"}
         digest = md5.hexdigest()
         per_clip = {}
         matches, checked = True, None
@@ -693,7 +803,9 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": workload, "sequences_per_gpu": S, "frames_per_step": S, "wfpp_num_threads": int(keys.get("wpp", 1)), "width": width, "height": height, "frames_in_sequence": nframes, "gop": "all intra (IMAGE_I forced)" if image_type else "IPPP intra_period=100", "qp": 32,
-                       "rd_mode": int(keys.get("rd", 2)), "max_intra_tr_depth": int(keys.get("intra_tr", 2)), "performance_mode": int(keys.get("perf", 2)), "sao": 1, "parallelism": (f"{S} independent sequences per GPU, one launch per step for their CTU stages (a pool of CTU tasks on two row workers per CU)" if S > 1 else "one sequence"),
+                       "rd_mode": int(keys.get("rd", 2)), "max_intra_tr_depth": int(keys.get("intra_tr", 2)), "performance_mode": int(keys.get("perf", 2)), "sao": 1, "parallelism": (f"{S} independent sequences per GPU, one launch per step for their CTU stages (a pool of CTU tasks on {WORKERS_PER_CU} row workers per CU)" if S > 1 else "one sequence"),
+                       # (the driver keeps `config` verbatim: the run's own verdict on its output sits here too)
+                       "stream_matches_reference": bool(matches and all_same), "frames_checked_against_reference": checked,
                        "timed_region": "per frame: phase planes of the reference, CTU decisions, deblocking, SAO statistics / decision / syntax, CABAC of the CTU rows' sub-streams, SAO offsets and border padding on the device "
                                        "(one launch of k_encode_pool: the decisions and the post-decision tasks of enc_post.h), download of the sub-streams, slice header / entry points / NAL escaping on the host; source in HBM; "
                                        "the first warm-up step is the I frames (warmup_ms_per_step[0])",
@@ -714,8 +826,12 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
                          "frame_level": {"algorithmic_bytes_per_frame": int(10.5 * width * height), "achieved": round(10.5 * width * height * world * S * a.steps / dt / 1e9, 4),
                                          "frac": round(10.5 * width * height * world * S * a.steps / dt / 1e9 / HBM_PEAK_GBS, 7)},
                          "issue_bound": issue,
-                         "note": "a pool of CTU tasks on 2 x 256 row workers (one wavefront + two helpers each) walking dependent decision chains: bound by instruction "
-                                 "issue of the workers' wavefronts (issue_bound) and memory latency, not by HBM bandwidth; frac is the honest distance from the bandwidth roof"},
+                         "note": f"a pool of CTU tasks on {WORKERS_PER_CU} x 256 row workers (one wavefront + one helper each) walking dependent decision chains: bound by the issue "
+                                 "latency of the workers' wavefronts (issue_bound) and by memory latency (the workers of an XCD share 4 MB of L2), not by HBM bandwidth; frac is the honest "
+                                 "distance from the bandwidth roof"},
+            "note": (f"the headline is a BATCH rate: {S} independent sequences share the GPU's {WORKERS_PER_CU * 256} row workers (a 1080p picture has at most 15 CTUs in flight - its wavefront "
+                     "steps - so about 120 concurrent sequences are needed to keep the workers busy at all, 256 to keep them busy through the pictures' ramps); ONE sequence alone is "
+                     "`single_sequence` (a few frames/s frame by frame, about 10 with its engines overlapped)") if S > 1 else "one sequence alone",
         }
         return out
 

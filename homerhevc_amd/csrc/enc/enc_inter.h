@@ -658,6 +658,7 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 	int luma_covered = 0;      // (a tree that visits a parent AND its children would count samples twice: checked at the end)
 	while (curr_depth != depth || depth_state.get(curr_depth) != end_state) {
 		curr = parent < 0 ? curr : e.geo[parent].child[depth_state.get(curr_depth)];
+		if (e.geo[curr].depth >= 1) nodes_select_quad(g, e, e.geo[curr].abs_index >> 6);      // (the transform tree of the 64 x 64 CU goes through all four quadrants)
 		Node &cn = node_of(e, curr);
 		cn.qp = qp;
 		curr_depth = e.geo[curr].depth;

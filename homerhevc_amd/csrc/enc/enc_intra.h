@@ -297,6 +297,7 @@ HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, i
 	depth_state.set(curr_depth, initial_state);
 	while (curr_depth != depth || depth_state.get(curr_depth) != end_state) {
 		curr = parent < 0 ? curr : e.geo[parent].child[depth_state.get(curr_depth)];
+		if (e.geo[curr].depth >= 1) nodes_select_quad(g, e, e.geo[curr].abs_index >> 6);      // (the transform tree of the 64 x 64 CU goes through all four quadrants)
 		Node &cn = node_of(e, curr);
 		cn.qp = qp;
 		curr_depth = e.geo[curr].depth;
@@ -560,6 +561,7 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth,
 				curr_depth++;
 				curr = e.geo[parent].child[depth_state.get(curr_depth)];
 			}
+			if (e.geo[curr].depth >= 1) nodes_select_quad(g, e, e.geo[curr].abs_index >> 6);
 			const int scan_mode = find_scan_mode(1, 0, e.geo[curr].size_chroma, cu_mode, 0);
 			const int original_depth = e.geo[curr].depth;
 			if (e.geo[curr].size_chroma == 2) {

@@ -160,7 +160,9 @@ class GpuEngines:
         lib.hmr_gpu_enc_export_references8.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_long, C.c_void_p]
         lib.hmr_gpu_enc_import_references8.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_long, C.c_char_p]
         lib.hmr_gpu_enc_destroy.argtypes = [C.c_void_p]
+        lib.hmr_gpu_enc_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         lib.hmr_gpu_last_error.restype = C.c_char_p
+        self.last_ctu_ms = None
         self.state_bytes = lib.hmr_gpu_enc_state_bytes()
         self.ref_bytes = None
         self.bufs = {}
@@ -221,6 +223,11 @@ class GpuEngines:
         got = (C.c_long * n)()
         call = self.lib.hmr_gpu_enc_encode_batch_pipelined if self.pipelined else self.lib.hmr_gpu_enc_encode_batch
         assert call(e_arr, n, slots, None, ptrs, caps, got) == 0, self.lib.hmr_gpu_last_error()
+        if frame is not None:
+            # the CTU launch of this call, by HIP events on the lead encoder's stream (what bench.py's roofline divides by)
+            p, k, ms, tot = C.c_int(), C.c_int(), C.c_float(), C.c_float()
+            self.lib.hmr_gpu_enc_last_stats(handles[0], C.byref(p), C.byref(k), C.byref(ms), C.byref(tot))
+            self.last_ctu_ms = ms.value
         return [C.string_at(self.bufs[h.value], got[i]) for i, h in enumerate(handles)]
 
     def export_many(self, handles, buf):
@@ -246,4 +253,6 @@ class GpuEngines:
         assert self.lib.hmr_gpu_enc_import_references8(e_arr, n, dev.data_ptr(), self.row_bytes, states) == 0, self.lib.hmr_gpu_last_error()
 
     def destroy(self, h):
+        self.bufs.pop(h.value, None)
+        self.slots.pop(h.value, None)
         self.lib.hmr_gpu_enc_destroy(h)
