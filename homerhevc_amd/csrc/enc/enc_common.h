@@ -409,6 +409,46 @@ HENC_HD void sync_cu_comp(const G &g, Enc &__restrict__ e, int ni, int q_src, in
 	g.sync();
 	PRIM_END(PP_SYNC);
 }
+// both chroma components of a CU in one pass: the reads of U and V are issued together (one trip to the windows instead of two; what a helper that takes both planes does)
+template <class G>
+HENC_HD void sync_cu_chroma_both(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
+{
+	PRIM_T0();
+	const Geo &q = e.geo[ni];
+	const int n = q.size_chroma, st = DEC_STRIDE_C, off = (q.abs_index << 4) >> 2, ln = ilog2i(n);
+	const int16_t *ds[2], *qs[2];
+	int16_t *dd[2], *qd[2];
+	for (int c = 0; c < 2; c++) {
+		ds[c] = dec_ptr(*e.w, d_src, COMP_U + c) + q.yc * st + q.xc;
+		dd[c] = dec_ptr(*e.w, d_dst, COMP_U + c) + q.yc * st + q.xc;
+		qs[c] = tq_ptr(*e.w, q_src, COMP_U + c) + off;
+		qd[c] = tq_ptr(*e.w, q_dst, COMP_U + c) + off;
+	}
+	constexpr int BATCH = 2;
+	for (int i0 = g.tid * 4; i0 < n * n; i0 += g.n * 4 * BATCH) {
+		S4 a[2][BATCH], b[2][BATCH];
+#pragma unroll
+		for (int u = 0; u < BATCH; u++) {
+			const int i = i0 + u * g.n * 4;
+			if (i < n * n)
+				for (int c = 0; c < 2; c++) {
+					a[c][u] = ld4(ds[c] + (i >> ln) * st + (i & (n - 1)));
+					b[c][u] = ld4(qs[c] + i);
+				}
+		}
+#pragma unroll
+		for (int u = 0; u < BATCH; u++) {
+			const int i = i0 + u * g.n * 4;
+			if (i < n * n)
+				for (int c = 0; c < 2; c++) {
+					st4(dd[c] + (i >> ln) * st + (i & (n - 1)), a[c][u]);
+					st4(qd[c] + i, b[c][u]);
+				}
+		}
+	}
+	g.sync();
+	PRIM_END(PP_SYNC);
+}
 template <class G>
 HENC_HD void sync_motion_buffers_luma(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
 {

@@ -583,7 +583,7 @@ HENC_HDX void post_task_p(const G &g, const PostCtx &x, PostScratch &sc, int r, 
 	Cabac ee;
 	BitWriter &bw = ee.bw;
 	ee.ctx = sc.ctx;
-	bw.attach(P.bs + (size_t)row * P.row_cap, P.row_cap);
+	bw.attach(P.bs + (size_t)row * P.row_cap, S.wpp ? P.row_cap : P.row_cap * S.hctu);      // (without WPP the picture is ONE sub-stream: it has the whole allocation, hctu x row_cap)
 	// wfpp_encode_select_bitstream :2299
 	const bool fresh = n == 0 || (S.wpp && c == 0);
 	if (n == 0) ee.init_contexts(g, f.slice_type, f.qp);

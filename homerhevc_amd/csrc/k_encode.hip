@@ -173,14 +173,26 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 			break;
 		}
 		case HJOB_SYNC_CU:
-			if (a[1] == COMP_UV) { sync_cu_comp(g, e, a[0], a[2], a[3], a[4], a[5], COMP_U); sync_cu_comp(g, e, a[0], a[2], a[3], a[4], a[5], COMP_V); }
+			if (a[1] == COMP_UV) sync_cu_chroma_both(g, e, a[0], a[2], a[3], a[4], a[5]);
 			else sync_cu_comp(g, e, a[0], a[2], a[3], a[4], a[5], a[1]);
 			break;
 		case HJOB_SSD: {
 			const Geo &q = e.geo[a[0]];
 			if (a[1] == COMP_UV) {
-				r0 = blk_ssd(g, e.w->curr_c[0] + q.yc * 32 + q.xc, 32, e.w->pred_c[0] + q.yc * 32 + q.xc, 32, q.size_chroma);
-				r1 = blk_ssd(g, e.w->curr_c[1] + q.yc * 32 + q.xc, 32, e.w->pred_c[1] + q.yc * 32 + q.xc, 32, q.size_chroma);
+				// both planes in one pass (curr_c[1] / pred_c[1] lie 32 x 32 samples behind curr_c[0] / pred_c[0])
+				const int n = q.size_chroma, l = ilog2i(n);
+				uint32_t acc[2] = {0, 0};
+				for (int i = g.tid * 4; i < n * n; i += 64 * 4) {
+					const int o = q.yc * 32 + q.xc + (i >> l) * 32 + (i & (n - 1));
+#pragma unroll
+					for (int c = 0; c < 2; c++) {
+						const S4 va = ld4(e.w->curr_c[c] + o), vb = ld4(e.w->pred_c[c] + o);
+#pragma unroll
+						for (int k = 0; k < 4; k++) { const int32_t dd = (int16_t)(va.v[k] - vb.v[k]); acc[c] += (uint32_t)(dd * dd); }
+					}
+				}
+				r0 = g.sum(acc[0]);
+				r1 = g.sum(acc[1]);
 			} else {
 				const int c = a[1] - 1;
 				r0 = blk_ssd(g, e.w->curr_c[c] + q.yc * 32 + q.xc, 32, e.w->pred_c[c] + q.yc * 32 + q.xc, 32, q.size_chroma);
@@ -552,7 +564,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HEN
 {
 	// finished[0]: pictures whose last task is done; finished[1]: abort - a worker has waited longer than the watchdog allows (a faulted or starved peer): everybody
 	// leaves and the host reports an error instead of the launch hanging
-	const unsigned long long t_start = wall_clock64();
+	unsigned long long t_start = wall_clock64();      // when this worker last had something to do (the watchdog's clock)
 	if (!rows_enter(lds_bytes)) return;
 	extern __shared__ __align__(16) uint8_t lds[];
 	WaveGrp g{(int)(threadIdx.x & 63)};
@@ -583,7 +595,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HEN
 	for (int h = 0; h < NHELP; h++) e.hseq[h] = 0;
 	e.prof = nullptr;
 	e.timeline = nullptr;
-	int cached_rem[2] = {-1, -1}, cached_q = -1;
+	int cached_rem[2] = {-1, -1}, cached_q = -1, idle_rounds = 0;
 	int start = (int)(blockIdx.x % (unsigned)nseq);
 	for (;;) {
 		// look for a picture with an open step that still has CTUs to hand out: 64 pictures at a time, one per lane
@@ -660,7 +672,16 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HEN
 				ran += pool_post_drain(dd, g, dd.seq, dd.frame, lw, slow + blockIdx.x, finished);
 				if (ran) { start = cand; break; }
 			}
-			if (!ran) __builtin_amdgcn_s_sleep(32);
+			if (!ran) {
+				// nothing to decide, nothing to filter or code: back off - a worker that rescans at once keeps 64 x nseq atomic loads and the rows' counters of every
+				// picture in flight on the L2 of an XCD whose other workers are deciding CTUs (rate control gates steps on the coder's progress: most of a
+				// 2160p CBR batch's 1024 workers are idle at any time, and with a fixed 1 us pause the batch ran at 30 frames/s on 1024 workers, 44 on 512)
+				idle_rounds = idle_rounds < 16 ? idle_rounds + 1 : 16;
+				for (int i = 0; i < idle_rounds; i++) __builtin_amdgcn_s_sleep(127);
+			} else {
+				idle_rounds = 0;
+				t_start = wall_clock64();
+			}
 			continue;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (the step was opened with a release store after its predecessors' results)
@@ -694,6 +715,8 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HEN
 			}
 		}
 		pool_post_drain(d, g, lseq, lframe, lw, slow + blockIdx.x, finished);
+		idle_rounds = 0;
+		t_start = wall_clock64();
 		start = (q + 1) % nseq;
 	}
 	int hseq[NHELP];
@@ -1054,7 +1077,15 @@ int lockstep_collect(hmr_gpu_enc *e)
 	return HMR_GPU_OK;
 }
 
-// the row-per-thread schedule of n pictures (their EncDev records already at lead->d_batch) as ONE pool launch on `st`
+// CTUs of a picture that can be decided at the same time: a wavefront step holds one CTU of every second column, so at most min(rows, (columns + 1) / 2); under rate
+// control a step also waits for the entropy coder's progress (enc_rc.h), which about halves it.  Workers beyond what a launch can keep busy are not merely idle: every
+// active worker runs slower the more of them share the chip's caches (a 2160p CBR batch of 32: 45 frames/s on 512 workers, 43 on 640, 30 on 1024)
+static int pool_inflight(const Seq &s)
+{
+	const int by_step = s.hctu < (s.wctu + 1) / 2 ? s.hctu : (s.wctu + 1) / 2;
+	return s.bitrate_mode != 0 ? (by_step + 1) / 2 : by_step;
+}
+// the row-per-thread schedule of n pictures (their EncDev records already at lead->d_batch) as ONE pool launch on `st`; rows_total: the sum of their pool_inflight()
 int launch_pool(hmr_gpu_enc *lead, int n, int rows_total, bool needs_rd, hipStream_t st)
 {
 	if (!lead->n_cus) HIP_TRY(hipDeviceGetAttribute(&lead->n_cus, hipDeviceAttributeMultiprocessorCount, lead->ctx->device));
@@ -1075,7 +1106,9 @@ int launch_pool(hmr_gpu_enc *lead, int n, int rows_total, bool needs_rd, hipStre
 	}
 	HIP_TRY(hipMemsetAsync(lead->d_pool_state, 0, sizeof(int) * (256 * POOL_STRIDE + 4), st));
 	// the watchdog (100 MHz ticks): a launch is a second or two of work; a worker that finds nothing to do for this long gives up for everybody
-	const unsigned long long watchdog = (unsigned long long)(getenv("HENC_WATCHDOG_S") ? atof(getenv("HENC_WATCHDOG_S")) : 120.0) * 100000000ull;
+	double watchdog_s = getenv("HENC_WATCHDOG_S") ? atof(getenv("HENC_WATCHDOG_S")) : 120.0;
+	if (!(watchdog_s > 0)) watchdog_s = 120.0;
+	const unsigned long long watchdog = (unsigned long long)(watchdog_s * 1e8);
 	hipLaunchKernelGGL(k_encode_pool, dim3(workers), dim3(ENC_THREADS), lds_bytes, st, (const EncDev *)lead->d_batch, n, lead->d_pool_state, lead->d_pool_state + 256 * POOL_STRIDE,
 			   lead->d_pool_slow, watchdog, (unsigned)lds_default);
 	const hipError_t launched = hipGetLastError();
@@ -1098,7 +1131,7 @@ int run_ctu_passes(hmr_gpu_enc *e)
 		// wfpp_num_threads > 1: the synchronous wavefront, one launch, nothing to verify - the picture's CTUs as a pool of tasks (k_encode_pool)
 		if (!e->d_batch) HIP_TRY(hipMalloc((void **)&e->d_batch, 256 * sizeof(EncDev)));
 		HIP_TRY(hipMemcpyAsync(e->d_batch, &e->d, sizeof(EncDev), hipMemcpyHostToDevice, st));
-		if ((rc = launch_pool(e, 1, s.hctu, s.rd_mode == RDM_FULL, st))) return rc;
+		if ((rc = launch_pool(e, 1, s.hctu, s.rd_mode == RDM_FULL, st))) return rc;      // (one picture: a worker per row, each on a CU of its own)
 		HIP_TRY(hipEventRecord(e->ctx->ev1, st));
 		if ((rc = lockstep_collect(e))) return rc;      // (waits for the launch)
 		HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ctx->ev0, e->ctx->ev1));
@@ -1996,7 +2029,7 @@ int batch_launch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_t
 		lead->h_frames[i] = e->f;
 		lead->h_devs[i] = e->d;
 		lead->h_devs[i].frame = lead->d_frames + i;
-		rows_total += e->seq.hctu;
+		rows_total += pool_inflight(e->seq);
 		needs_rd = needs_rd || e->seq.rd_mode == RDM_FULL;
 		if (e->seq.nctu > max_ctus) max_ctus = e->seq.nctu;
 	}
@@ -2090,7 +2123,6 @@ int batch_finish(hmr_gpu_enc **encs, int n, const int *slots, int pitch, BatchTi
 		total = (total + 255) & ~(size_t)255;
 		e->last_ms = e->last_total_ms = ms;
 		e->last_encodes = (int)g[1];
-		e->note_stale_predictions(g[3] >> 8);
 		e->f.scene_cut_ctu = (int)g[2];
 		e->last_passes = 1;
 		release_planes(e);
@@ -2236,6 +2268,13 @@ extern "C" int hmr_gpu_enc_encode_chain(hmr_gpu_enc **encs, int n, hmr_gpu_enc *
 			hmr_set_error("hmr_gpu_enc_encode_chain: frame %d: needs an engine object (hmr_gpu_enc_create_engine) of the chain's sequence on the chain's device with a loaded picture slot", j);
 			return HMR_GPU_ERR_ARG;
 		}
+		// rate control and RD_FULL read entropy-coder state of the frame before (rc_end_pic's VBV / QP carry, the context ring of the coder objects): a chain's frames
+		// start from a PREDICTED host state, in which neither exists, and the replay check behind the launch would not see a wrong QP - refused, as make_seq refuses
+		// them for num_enc_engines > 1 (hmr_rate_control.c:266-282, hmr_encoder_lib.c:3268-3279 are per-frame, in order)
+		if (n > 1 && (e->seq.bitrate_mode != 0 || e->seq.rd_mode == RDM_FULL)) {
+			hmr_set_error("hmr_gpu_enc_encode_chain: frame %d: rate control and RD_FULL need the frames one at a time (a chain of %d frames starts them from a predicted state)", j, n);
+			return HMR_GPU_ERR_ARG;
+		}
 		// more frames than engines: an engine's next frame is encoded by a twin of its object (hmr_gpu_enc_create_engine_twin: the same persistent engine state)
 		if (j >= e->st.engines && e->d_ctus_eng[0] != encs[j - e->st.engines]->d_ctus_eng[0]) {
 			hmr_set_error("hmr_gpu_enc_encode_chain: frame %d: the object has to be a twin (hmr_gpu_enc_create_engine_twin) of the one that encodes frame %d, the engine's frame before it", j, j - e->st.engines);
@@ -2356,6 +2395,7 @@ extern "C" int hmr_gpu_enc_encode_chain(hmr_gpu_enc **encs, int n, hmr_gpu_enc *
 		const uint32_t *g = lead->h_gather + (size_t)j * pitch;
 		if (g[3] & 2) { hmr_set_error("k_encode_pool: the launch was abandoned by its watchdog (HENC_WATCHDOG_S)"); return HMR_GPU_ERR_HIP; }
 		if (g[3] & 1) { hmr_set_error("hmr_gpu_enc_encode_chain: frame %d: a CTU row's sub-stream outgrew its buffer (%d bytes)", j, e->row_cap); return HMR_GPU_ERR_HIP; }
+		e->note_stale_predictions(g[3] >> 8);
 		e->last_ms = e->last_total_ms = ms;
 		e->last_encodes = (int)g[1];
 		e->f.scene_cut_ctu = (int)g[2];

@@ -1,5 +1,5 @@
-"""Test-side ctypes mirror of the batched / frame-level C ABI (include/homer_gpu.h layers 1, 3, 4): descriptor layouts and a thin driver for the kernel tests and
-the legacy tools (tools/legacy).  Not part of the product package.
+"""Test-side ctypes mirror of the batched / frame-level C ABI (include/homer_gpu.h layers 1, 3, 4): descriptor layouts and a thin driver for the kernel tests.
+Not part of the product package.
 
 Device memory is owned by the caller (torch tensors in bench.py, hmr_gpu_malloc in tests); this module only
 marshals pointers.  Everything here fails loudly when the native library or the GPU is missing.

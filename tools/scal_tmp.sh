@@ -1,7 +1,9 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/bprof
-export HOMER_GPU_LIB=build/variants/prof/libhomer_gpu.so
-HENC_LDS_BYTES=100000 python3 tools/batch_profile.py --sequences 128 --frames 3 --out gpurun_out/bprof/w1.json > gpurun_out/bprof/w1.log 2>&1
-HENC_LDS_BYTES=70000 python3 tools/batch_profile.py --sequences 128 --frames 3 --out gpurun_out/bprof/w2.json > gpurun_out/bprof/w2.log 2>&1
-python3 tools/batch_profile.py --sequences 128 --frames 3 --out gpurun_out/bprof/w3.json > gpurun_out/bprof/w3.log 2>&1
-tail -2 gpurun_out/bprof/w3.log | cut -c1-300
+cp homerhevc_amd/libhomer_gpu.so /tmp/prod.so; cp build/variants/${1:-fu}/libhomer_gpu.so homerhevc_amd/libhomer_gpu.so
+python3 bench.py --sequences 256 --steps 5 --warmup 3 --no-cpu-baseline --no-single-thread-order 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg2 fps', d['value'], 'kernel ms', d['roofline']['ms_per_launch'], d['stream_matches_reference'], 'single', d.get('single_sequence',{}).get('value'))"
+python3 bench.py --workload cfg3-2160p-cbr --sequences 32 --steps 6 --warmup 2 --no-cpu-baseline --no-single-thread-order 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cbr fps', d['value'], 'kernel ms', d['roofline']['ms_per_launch'], d['stream_matches_reference'], 'single', d.get('single_sequence',{}).get('value'))"
+cp /tmp/prod.so homerhevc_amd/libhomer_gpu.so
