@@ -89,8 +89,9 @@ constexpr int LDS_OFF_WORK = 0, LDS_OFF_NODES = (int)((sizeof(Work) + 15) & ~(si
 #define HENC_AT(T, OFFSET) FastPtr<T>
 #endif
 
-constexpr int LDS_BOX_BYTES = 512;      // what the mailbox may take (checked behind HelperBox)
-constexpr int LDS_OFF_RD = LDS_OFF_BOX + LDS_BOX_BYTES;
+constexpr int LDS_BOX_BYTES = 160, LDS_ENC_BYTES = 256;      // what the mailbox and a context may take (checked behind HelperBox / Enc)
+constexpr int LDS_OFF_ENC = LDS_OFF_BOX + LDS_BOX_BYTES;      // the worker's context, then one per helper
+constexpr int LDS_OFF_RD = LDS_OFF_ENC + (1 + NHELP_) * LDS_ENC_BYTES;
 struct Enc {
 	unsigned long long *prof;   // PF_COUNT accumulators of this worker (profiling build), else unused
 	HENC_AT(const Seq, LDS_OFF_SEQ) seq;
@@ -153,13 +154,15 @@ struct HelperBox {
 	int job[NHELP];
 	int a[NHELP][8];
 	uint32_t r[NHELP][8];
-	Enc enc;                       // the worker's context, refreshed at every CTU start
 };
-static_assert(sizeof(HelperBox) <= LDS_BOX_BYTES, "the mailbox's place in a worker's LDS");
+#if defined(__HIP_DEVICE_COMPILE__)
+static_assert(sizeof(HelperBox) <= LDS_BOX_BYTES && sizeof(Enc) <= LDS_ENC_BYTES, "the places of the mailbox and of the contexts in a worker's LDS");
+#endif
 
 template <class G>
 HENC_HD void helper_post(const G &g, Enc &__restrict__ e, int h, int job, int a0 = 0, int a1 = 0, int a2 = 0, int a3 = 0, int a4 = 0, int a5 = 0)
 {
+	HENC_ENC_IN_LDS(e);
 #if defined(__HIP_DEVICE_COMPILE__)
 	HelperBox *b = e.box;
 	e.hseq[h]++;               // (the release store below orders everything this wavefront has written before it)
@@ -175,6 +178,7 @@ HENC_HD void helper_post(const G &g, Enc &__restrict__ e, int h, int job, int a0
 template <class G>
 HENC_HD void helper_wait(const G &g, Enc &__restrict__ e, int h)
 {
+	HENC_ENC_IN_LDS(e);
 #if defined(__HIP_DEVICE_COMPILE__)
 	PRIM_T0();
 	HelperBox *b = e.box;
@@ -236,6 +240,7 @@ HENC_INLINE int abs2raster(int a)   // abs2raster_table: the Morton de-interleav
 }
 HENC_INLINE Node &node_of(Enc &__restrict__ e, int idx)
 {
+	HENC_ENC_IN_LDS(e);
 #if !defined(__HIPCC__)
 	if (idx >= NODES_RESIDENT && node_quadrant(idx) != e.node_quad) {
 		fprintf(stderr, "node_of: node %d of quadrant %d while quadrant %d is resident\n", idx, node_quadrant(idx), e.node_quad);
@@ -250,11 +255,13 @@ HENC_INLINE Node &node_of(Enc &__restrict__ e, int idx)
 HENC_INLINE bool node_is_resident(const Enc &__restrict__ e, int idx) { return idx < NODES_RESIDENT || node_quadrant(idx) == e.node_quad; }
 HENC_INLINE void corner_set_left_bottom(Enc &__restrict__ e, int idx, uint8_t v)
 {
+	HENC_ENC_IN_LDS(e);
 	if (node_is_resident(e, idx)) node_of(e, idx).left_bottom_nb = v;
 	else e.ctu_g->nodes[idx].left_bottom_nb = v;
 }
 HENC_INLINE void corner_set_top_right(Enc &__restrict__ e, int idx, uint8_t v)
 {
+	HENC_ENC_IN_LDS(e);
 	if (node_is_resident(e, idx)) node_of(e, idx).top_right_nb = v;
 	else e.ctu_g->nodes[idx].top_right_nb = v;
 }
@@ -269,6 +276,7 @@ HENC_INLINE CtuPublic *ctu_top_left_of(Enc &__restrict__ e) { return (e.nb_ctus 
 
 HENC_INLINE CtuPublic *pu_left(Enc &__restrict__ e, int ni, uint32_t *idx)
 {
+	HENC_ENC_IN_LDS(e);
 	const Geo &gq = e.geo[ni];
 	*idx = gq.abs_left;
 	return (gq.raster_index & 15) == 0 ? ctu_left_of(e) : e.ctu;
@@ -276,6 +284,7 @@ HENC_INLINE CtuPublic *pu_left(Enc &__restrict__ e, int ni, uint32_t *idx)
 // (ni: the 4 x 4 corner unit the candidate derivations ask about; has_nb: its left_bottom_nb / top_right_nb flag, which the caller has just given it)
 HENC_INLINE CtuPublic *pu_left_bottom(Enc &__restrict__ e, int ni, int has_nb, uint32_t *idx)
 {
+	HENC_ENC_IN_LDS(e);
 	const Geo &gq = e.geo[ni];
 	if (!has_nb) return nullptr;
 	*idx = gq.abs_left_bottom;
@@ -287,6 +296,7 @@ HENC_INLINE CtuPublic *pu_left_bottom(Enc &__restrict__ e, int ni, int has_nb, u
 }
 HENC_INLINE CtuPublic *pu_top(Enc &__restrict__ e, int ni, uint32_t *idx, int planar_at_ctu_boundary)
 {
+	HENC_ENC_IN_LDS(e);
 	const Geo &gq = e.geo[ni];
 	*idx = gq.abs_top;
 	if (gq.raster_index < 16) return planar_at_ctu_boundary ? nullptr : ctu_top_of(e);
@@ -294,6 +304,7 @@ HENC_INLINE CtuPublic *pu_top(Enc &__restrict__ e, int ni, uint32_t *idx, int pl
 }
 HENC_INLINE CtuPublic *pu_top_right(Enc &__restrict__ e, int ni, int has_nb, uint32_t *idx)
 {
+	HENC_ENC_IN_LDS(e);
 	const Geo &gq = e.geo[ni];
 	if (!has_nb) return nullptr;
 	*idx = gq.abs_top_right;
@@ -305,6 +316,7 @@ HENC_INLINE CtuPublic *pu_top_right(Enc &__restrict__ e, int ni, int has_nb, uin
 }
 HENC_INLINE CtuPublic *pu_top_left(Enc &__restrict__ e, int ni, uint32_t *idx)
 {
+	HENC_ENC_IN_LDS(e);
 	const Geo &gq = e.geo[ni];
 	*idx = gq.abs_top_left;
 	if (gq.raster_index == 0) return ctu_top_left_of(e);
@@ -318,6 +330,7 @@ HENC_INLINE CtuPublic *pu_top_left(Enc &__restrict__ e, int ni, uint32_t *idx)
 template <class G>
 HENC_HD void sync_reference_buffs(const G &g, Enc &__restrict__ e, int ni, int src_wnd, int dst_wnd)
 {
+	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
 	const Geo &q = e.geo[ni];
 	const int16_t *s = dec_ptr(*e.w, src_wnd, COMP_Y) + q.y * DEC_STRIDE_Y + q.x;
@@ -334,6 +347,7 @@ HENC_HD void sync_reference_buffs(const G &g, Enc &__restrict__ e, int ni, int s
 template <class G>
 HENC_HD void sync_reference_buffs_range(const G &g, Enc &__restrict__ e, int ni, int src_wnd, int first_dst, int last_dst)
 {
+	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
 	const Geo &q = e.geo[ni];
 	const int16_t *s = dec_ptr(*e.w, src_wnd, COMP_Y) + q.y * DEC_STRIDE_Y + q.x;
@@ -356,6 +370,7 @@ HENC_HD void sync_reference_buffs_range(const G &g, Enc &__restrict__ e, int ni,
 template <class G>
 HENC_HD void sync_reference_buffs_chroma(const G &g, Enc &__restrict__ e, int ni, int src_wnd, int dst_wnd)
 {
+	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
 	const Geo &q = e.geo[ni];
 	const int n = q.size_chroma;
@@ -375,6 +390,7 @@ HENC_HD void sync_reference_buffs_chroma(const G &g, Enc &__restrict__ e, int ni
 template <class G>
 HENC_HD void sync_cu_comp(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst, int comp)
 {
+	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
 	const Geo &q = e.geo[ni];
 	const int n = comp == COMP_Y ? q.size : q.size_chroma, x = comp == COMP_Y ? q.x : q.xc, y = comp == COMP_Y ? q.y : q.yc;
@@ -413,6 +429,7 @@ HENC_HD void sync_cu_comp(const G &g, Enc &__restrict__ e, int ni, int q_src, in
 template <class G>
 HENC_HD void sync_cu_chroma_both(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
 {
+	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
 	const Geo &q = e.geo[ni];
 	const int n = q.size_chroma, st = DEC_STRIDE_C, off = (q.abs_index << 4) >> 2, ln = ilog2i(n);
@@ -452,11 +469,13 @@ HENC_HD void sync_cu_chroma_both(const G &g, Enc &__restrict__ e, int ni, int q_
 template <class G>
 HENC_HD void sync_motion_buffers_luma(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
 {
+	HENC_ENC_IN_LDS(e);
 	sync_cu_comp(g, e, ni, q_src, q_dst, d_src, d_dst, COMP_Y);
 }
 template <class G>
 HENC_HD void sync_motion_buffers_chroma(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
 {
+	HENC_ENC_IN_LDS(e);
 	sync_cu_comp(g, e, ni, q_src, q_dst, d_src, d_dst, COMP_U);
 	sync_cu_comp(g, e, ni, q_src, q_dst, d_src, d_dst, COMP_V);
 }
@@ -465,6 +484,7 @@ HENC_HD void sync_motion_buffers_chroma(const G &g, Enc &__restrict__ e, int ni,
 template <class G>
 HENC_HD void sync_motion_buffers(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
 {
+	HENC_ENC_IN_LDS(e);
 	if (HENC_HELPERS(e)) {
 		if (NHELP >= 2) {
 			helper_post(g, e, 0, HJOB_SYNC_CU, ni, COMP_U, q_src, q_dst, d_src, d_dst);
@@ -482,6 +502,7 @@ HENC_HD void sync_motion_buffers(const G &g, Enc &__restrict__ e, int ni, int q_
 template <class G>
 HENC_HD void nodes_quad_move(const G &g, Enc &__restrict__ e, int quad, int to_record)
 {
+	HENC_ENC_IN_LDS(e);
 	constexpr int W3 = (int)(sizeof(Node) * NODE_QUAD_D3 / 4), W4 = (int)(sizeof(Node) * NODE_QUAD_D4 / 4);
 	uint32_t *f3 = (uint32_t *)&e.nodes[NODES_RESIDENT], *f4 = (uint32_t *)&e.nodes[NODES_RESIDENT + NODE_QUAD_D3];
 	uint32_t *r3 = (uint32_t *)(e.ctu_g->nodes + NODES_RESIDENT + NODE_QUAD_D3 * quad), *r4 = (uint32_t *)(e.ctu_g->nodes + NODES_D3 + NODE_QUAD_D4 * quad);
@@ -495,6 +516,7 @@ HENC_HD void nodes_quad_move(const G &g, Enc &__restrict__ e, int quad, int to_r
 template <class G>
 HENC_HD void nodes_select_quad(const G &g, Enc &__restrict__ e, int quad)
 {
+	HENC_ENC_IN_LDS(e);
 	if (quad == e.node_quad) return;
 	g.sync();
 	if (e.node_quad >= 0) nodes_quad_move(g, e, e.node_quad, 1);
@@ -505,6 +527,7 @@ HENC_HD void nodes_select_quad(const G &g, Enc &__restrict__ e, int quad)
 template <class G>
 HENC_HD void nodes_write_back(const G &g, Enc &__restrict__ e)
 {
+	HENC_ENC_IN_LDS(e);
 	g.sync();
 	lin_copy_words(g, (const uint32_t *)&e.nodes[0], (uint32_t *)e.ctu_g->nodes, (int)(sizeof(Node) * NODES_RESIDENT / 4));
 	if (e.node_quad >= 0) nodes_quad_move(g, e, e.node_quad, 1);

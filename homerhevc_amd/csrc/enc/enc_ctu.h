@@ -15,6 +15,7 @@ namespace henc {
 template <class G>
 HENC_HD void info_buffs_copy(const G &g, Enc &__restrict__ e, int depth, int abs_idx, int num, int to_ctu)
 {
+	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
 	Work &w = *e.w;
 	CtuPublic &c = *e.ctu;
@@ -46,6 +47,7 @@ HENC_HD void info_buffs_copy(const G &g, Enc &__restrict__ e, int depth, int abs
 template <class G>
 HENC_HD void set_inter_info_buffs(const G &g, Enc &__restrict__ e, int ni)
 {
+	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
 	const Geo &q = e.geo[ni];
 	const Node &nd = node_of(e, ni);
@@ -80,12 +82,14 @@ HENC_HD void set_inter_info_buffs(const G &g, Enc &__restrict__ e, int ni)
 template <class G>
 HENC_HD void get_back_consolidated_info(const G &g, Enc &__restrict__ e, int ni, int depth)
 {
+	HENC_ENC_IN_LDS(e);
 	info_buffs_copy(g, e, depth, e.geo[ni].abs_index, e.geo[ni].num_part, 0);
 	sync_motion_buffers(g, e, ni, 0, depth + 1, 0, depth + 1);
 }
 template <class G>
 HENC_HD void put_consolidated_info(const G &g, Enc &__restrict__ e, int ni, int depth)
 {
+	HENC_ENC_IN_LDS(e);
 	info_buffs_copy(g, e, depth, e.geo[ni].abs_index, e.geo[ni].num_part, 1);
 	sync_motion_buffers(g, e, ni, depth + 1, 0, depth + 1, 0);
 }
@@ -95,6 +99,7 @@ HENC_HD void put_consolidated_info(const G &g, Enc &__restrict__ e, int ni, int 
 template <class G>
 HENC_HD bool consolidate_prediction_info(const G &g, Enc &__restrict__ e, int pi, uint32_t parent_cost, uint32_t children_cost, int is_max_depth)
 {
+	HENC_ENC_IN_LDS(e);
 	const Geo &pq = e.geo[pi];
 	Node &pn = node_of(e, pi);
 	CtuPublic &c = *e.ctu;
@@ -146,6 +151,7 @@ HENC_HD bool consolidate_prediction_info(const G &g, Enc &__restrict__ e, int pi
 template <class G>
 HENC_HD void refresh_deeper_windows(const G &g, Enc &__restrict__ e, int aux_ni, int from_depth, int with_info)
 {
+	HENC_ENC_IN_LDS(e);
 	const int max_processing_depth = hmin(CFG_MAX_PRED_DEPTH + e.seq->max_intra_tr_depth - 1, NDEPTH - 1);
 	if (from_depth > max_processing_depth) return;
 	const Geo &q = e.geo[aux_ni];
@@ -160,6 +166,7 @@ HENC_HD void refresh_deeper_windows(const G &g, Enc &__restrict__ e, int aux_ni,
 template <class G>
 HENC_HD uint32_t encode_intra(const G &g, Enc &__restrict__ e, int curr_depth, int position, int part_size_type)
 {
+	HENC_ENC_IN_LDS(e);
 	uint32_t cost = 0;
 	if (part_size_type == PART_2Nx2N) {
 		uint32_t cl, cc;
@@ -180,6 +187,7 @@ HENC_HD uint32_t encode_intra(const G &g, Enc &__restrict__ e, int curr_depth, i
 template <class G>
 HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth, int position)
 {
+	HENC_ENC_IN_LDS(e);
 	Work &w = *e.w;
 	const Seq &S = *e.seq;
 	const int ni = node_at(e, depth, position);
@@ -345,6 +353,7 @@ HENC_INLINE int scene_cut_fires(const Seq &S, const FrameCtx &f, uint32_t intra_
 template <class G>
 HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &__restrict__ e)
 {
+	HENC_ENC_IN_LDS(e);
 	const Seq &S = *e.seq;
 	CtuPublic &c = *e.ctu;
 	const double avg_distortion = e.f->avg_dist;
@@ -512,6 +521,7 @@ HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &__restrict__ e)
 template <class G>
 HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 {
+	HENC_ENC_IN_LDS(e);
 	const Seq &S = *e.seq;
 	CtuPublic &c = *e.ctu;
 	DepthState depth_state;
@@ -604,6 +614,7 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 template <class G>
 HENC_HD void create_partition_neighbours(const G &g, Enc &__restrict__ e)
 {
+	HENC_ENC_IN_LDS(e);
 	const Seq &S = *e.seq;
 	CtuPublic &c = *e.ctu;
 	const int cu_min_tu_size_shift = hmax(CFG_MAX_CU_SHIFT - (CFG_MAX_PRED_DEPTH + hmax(S.max_intra_tr_depth, S.max_inter_tr_depth) - 1), 2);
@@ -650,6 +661,7 @@ HENC_HD void create_partition_neighbours(const G &g, Enc &__restrict__ e)
 template <class G>
 HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 {
+	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
 	const Seq &S = *e.seq;
 	Work &w = *e.w;
@@ -731,8 +743,7 @@ HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 	}
 	create_partition_neighbours(g, e);
 	if (HENC_HELPERS(e)) {     // the helpers work on this CTU from now on
-		g.sync();
-		if (g.tid == 0) e.box->enc = e;
+		g.sync();      // (the helpers copy this context - the worker's, at its fixed place in LDS - when they take the job)
 		for (int h = 0; h < NHELP; h++) helper_post(g, e, h, HJOB_NEW_CTU);
 		for (int h = 0; h < NHELP; h++) helper_wait(g, e, h);
 	}
@@ -743,6 +754,7 @@ HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 template <class G>
 HENC_HD void ctu_end(const G &g, Enc &__restrict__ e)
 {
+	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
 	const Seq &S = *e.seq;
 	Work &w = *e.w;
@@ -792,6 +804,7 @@ __attribute__((noinline))   // one compiled body for every kernel that encodes C
 #endif
 HENC_HD void encode_ctu(const G &g, Enc &__restrict__ e, int ctu_num)
 {
+	HENC_ENC_IN_LDS(e);
 	{ HENC_PROF_T0(); ctu_begin(g, e, ctu_num); HENC_PROF_ADD(e, PF_SETUP); }
 	const int intra_walk = ctu_takes_intra_walk(*e.f, ctu_num);
 	e.ctu_g->walk_intra = intra_walk;

@@ -16,6 +16,7 @@ namespace henc {
 template <class G>
 HENC_HD void mc_luma_interp(const G &g, Enc &__restrict__ e, const int16_t *ref, int rs, int16_t *pred, int ps, int n, int mvx, int mvy)
 {
+	HENC_ENC_IN_LDS(e);
 	const int xf = mvx & 3, yf = mvy & 3;
 	const int16_t *src = ref + (mvy >> 2) * rs + (mvx >> 2);
 	if (xf == 0) interp_stage<8>(g, src, rs, pred, ps, yf, n, n, 1, 1, 1);
@@ -30,6 +31,7 @@ HENC_HD void mc_luma_interp(const G &g, Enc &__restrict__ e, const int16_t *ref,
 template <class G>
 HENC_HD void mc_chroma_interp(const G &g, Enc &__restrict__ e, const int16_t *ref, int rs, int16_t *pred, int ps, int n, int mvx, int mvy)
 {
+	HENC_ENC_IN_LDS(e);
 	const int xf = mvx & 7, yf = mvy & 7;
 	const int16_t *src = ref + (mvy >> 3) * rs + (mvx >> 3);
 	if (xf == 0) interp_stage<4>(g, src, rs, pred, ps, yf, n, n, 1, 1, 1);
@@ -46,6 +48,7 @@ HENC_HD void mc_chroma_interp(const G &g, Enc &__restrict__ e, const int16_t *re
 template <class G>
 HENC_HD void motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv)
 {
+	HENC_ENC_IN_LDS(e);
 	Work &w = *e.w;
 	const Geo &q = e.geo[ni];
 	const Seq &S = *e.seq;
@@ -99,6 +102,7 @@ template <int MAXC, class G>
 HENC_HD void cand_sads(const G &g, Enc &__restrict__ e, int ox, int oy, int gx, int gy, int size, const int (&qx)[MAXC], const int (&qy)[MAXC], const bool (&ok)[MAXC],
 		       uint32_t (&out)[MAXC])
 {
+	HENC_ENC_IN_LDS(e);
 	const Seq &S = *e.seq;
 #if defined(__HIPCC__)
 	const int sy = 16 * S.stride_y;      // (row-interleaved planes)
@@ -179,6 +183,7 @@ template <class G>
 HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, int ox, int oy, int gx, int gy, int size, const MvCandList &amvp, const MvCandList &search, double corr,
 				   int action, MV *mv_io, MV *subpix_out)
 {
+	HENC_ENC_IN_LDS(e);
 	static constexpr int ds[4][2] = {{-1, 0}, {0, -1}, {1, 0}, {0, 1}};
 	static constexpr int db[8][2] = {{-2, 0}, {-1, -1}, {0, -2}, {1, -1}, {2, 0}, {1, 1}, {0, 2}, {-1, 1}};
 	static constexpr int ref_h[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
@@ -334,6 +339,7 @@ HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, int ox, int 
 struct CornerNodes { int lb, tl, tr; };
 HENC_INLINE CornerNodes corner_nodes(Enc &__restrict__ e, int ni)
 {
+	HENC_ENC_IN_LDS(e);
 	const Geo &q = e.geo[ni];
 	const int np = q.size >> 2, base = cfg_depth_start(CFG_MAX_CU_DEPTH);
 	CornerNodes c;
@@ -351,6 +357,7 @@ struct NbUnit {
 };
 HENC_INLINE NbUnit nb_unit(Enc &__restrict__ e, const CtuPublic *c, uint32_t idx)
 {
+	HENC_ENC_IN_LDS(e);
 	const CtuPublic *p = c ? c : e.ctu;
 	const uint32_t i = c ? idx : 0;
 	NbUnit u;
@@ -384,6 +391,7 @@ HENC_INLINE int add_amvp_cand(MvCandList &l, const NbUnit &u)
 // reference too, and nothing in between reads them), then the reference's order of questions runs on the fetched values.
 HENC_INLINE void get_amvp_candidates(Enc &__restrict__ e, int ni, MvCandList &l)
 {
+	HENC_ENC_IN_LDS(e);
 	const CornerNodes cn = corner_nodes(e, ni);
 	uint32_t idx_lb = 0, idx_l = 0, idx_tr = 0, idx_t = 0, idx_tl = 0;
 	l.num = 0;
@@ -433,6 +441,7 @@ HENC_INLINE int equal_motion(const CtuPublic *a, uint32_t ia, const CtuPublic *b
 // get_merge_mvp_candidates :1937, P slice.  inter_modes[k] = inter_mode of candidate k's source unit.
 HENC_INLINE void get_merge_candidates(Enc &__restrict__ e, int ni, MvCandList &l, uint8_t *inter_modes)
 {
+	HENC_ENC_IN_LDS(e);
 	const int max_cand = CFG_NUM_MERGE_CAND;
 	const CornerNodes cn = corner_nodes(e, ni);
 	uint32_t i_l = 0, i_t = 0, i_tr = 0, i_lb = 0, i_tl = 0;
@@ -508,6 +517,7 @@ HENC_INLINE void get_merge_candidates(Enc &__restrict__ e, int ni, MvCandList &l
 template <class G>
 HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int comp, int depth, int part_size_type, int *curr_sum, uint32_t *raw_ssq = nullptr)
 {
+	HENC_ENC_IN_LDS(e);
 	Work &w = *e.w;
 	Node &nd = node_of(e, ni);
 	const int original_depth = e.geo[ni].depth;
@@ -568,6 +578,7 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 template <class G>
 HENC_HD void inter_tu_all_comps(const G &g, Enc &__restrict__ e, int curr, int depth, int part_size_type, int has_chroma, uint32_t *dist, int *sums)
 {
+	HENC_ENC_IN_LDS(e);
 	dist[0] = encode_inter_tu(g, e, curr, COMP_Y, depth, part_size_type, &sums[0]);
 	dist[1] = dist[2] = 0;
 	sums[1] = sums[2] = 0;
@@ -582,6 +593,7 @@ HENC_HD void inter_tu_all_comps(const G &g, Enc &__restrict__ e, int curr, int d
 template <class G>
 HENC_HD void set_enc_info_buffs(const G &g, Enc &__restrict__ e, int ni, int depth)
 {
+	HENC_ENC_IN_LDS(e);
 	const Geo &q = e.geo[ni];
 	const Node &nd = node_of(e, ni);
 	Work &w = *e.w;
@@ -596,8 +608,9 @@ HENC_HD void set_enc_info_buffs(const G &g, Enc &__restrict__ e, int ni, int dep
 
 // encode_inter :3071 - the transform tree of an inter CU; referenced by the prediction depth
 template <class G>
-HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
+HENC_WALK_FN HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
 {
+	HENC_ENC_IN_LDS(e);
 	const Seq &S = *e.seq;
 	Work &w = *e.w;
 #if !defined(__HIPCC__) && defined(HENC_TRACE_ENABLE)
@@ -764,6 +777,7 @@ HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int pa
 template <class G>
 HENC_HD void set_inter_mv_buffs(const G &g, Enc &__restrict__ e, int ni)
 {
+	HENC_ENC_IN_LDS(e);
 	const Geo &q = e.geo[ni];
 	const Node &nd = node_of(e, ni);
 	for (int i = g.tid; i < q.num_part; i += g.n) {
@@ -777,6 +791,7 @@ HENC_HD void set_inter_mv_buffs(const G &g, Enc &__restrict__ e, int ni)
 template <class G>
 HENC_HD int predict_inter(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
 {
+	HENC_ENC_IN_LDS(e);
 	int curr = node_at(e, depth, part_position), num_partitions = 1;
 	if (part_size_type == PART_NxN) {
 		curr = e.geo[e.geo[curr].parent].child[0];
@@ -802,6 +817,7 @@ HENC_HD int predict_inter(const G &g, Enc &__restrict__ e, int depth, int part_p
 template <class G>
 HENC_HD int cu_motion_estimation(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type, int action)
 {
+	HENC_ENC_IN_LDS(e);
 	Work &w = *e.w;
 	const Seq &S = *e.seq;
 	int curr = node_at(e, depth, part_position), num_partitions = 1;
@@ -814,7 +830,7 @@ HENC_HD int cu_motion_estimation(const G &g, Enc &__restrict__ e, int depth, int
 		const Geo &q = e.geo[curr];
 		Node &nd = node_of(e, curr);
 		const int gx = e.ctu_x + q.x, gy = e.ctu_y + q.y;
-		MvCandList amvp;
+		MvCandList &amvp = w.amvp;      // (built where predict_inter will read it: as a local its dynamically indexed lists lived in private memory)
 		{ PRIM_T0(); get_amvp_candidates(e, curr, amvp); PRIM_END(PP_CAND); }
 		w.search_cands.num = 0;
 		for (int i = 0; i < amvp.num; i++)
@@ -837,7 +853,6 @@ HENC_HD int cu_motion_estimation(const G &g, Enc &__restrict__ e, int depth, int
 		nd.inter_mv = mv;
 		nd.inter_ref_index = 0;
 		nd.inter_mode = 1;
-		w.amvp = amvp;
 		nd.best_candidate_idx = mvp_idx;
 		nd.best_dif_mv.x = mv.x - amvp.mv[mvp_idx].x;
 		nd.best_dif_mv.y = mv.y - amvp.mv[mvp_idx].y;

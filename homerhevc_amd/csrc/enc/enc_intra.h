@@ -19,6 +19,7 @@ HENC_INLINE int intra_is_filtered(int mode, int inv_depth)
 template <class G>
 HENC_HD void node_fill_refs(const G &g, Enc &__restrict__ e, int ni, int wnd, int comp, int want_filtered)
 {
+	HENC_ENC_IN_LDS(e);
 	const Geo &q = e.geo[ni];
 	const Node &nd = node_of(e, ni);
 	const int is_y = comp == COMP_Y;
@@ -46,6 +47,7 @@ HENC_HD void node_fill_refs(const G &g, Enc &__restrict__ e, int ni, int wnd, in
 // the winner, its cost or its bit cost would have been different.
 HENC_INLINE int read_mode_buff(Enc &__restrict__ e, int depth, uint32_t idx, uint16_t *src)
 {
+	HENC_ENC_IN_LDS(e);
 	const int v = e.w->intra_mode_buffs[COMP_Y][depth][idx];
 	if (!(v & MODE_TOKEN)) { *src = (uint16_t)v; return v; }
 	const int d = v & 7;
@@ -72,6 +74,7 @@ HENC_INLINE void mpm_from_dirs(int left_dir, int top_dir, int *preds)
 }
 HENC_INLINE void intra_neighbour_dirs(Enc &__restrict__ e, int ni, int depth, int *dirs, uint16_t *src)
 {
+	HENC_ENC_IN_LDS(e);
 	uint32_t idx = 0;
 	CtuPublic *cl = pu_left(e, ni, &idx);
 	dirs[0] = dirs[1] = DC_IDX;
@@ -87,7 +90,8 @@ HENC_INLINE void intra_neighbour_dirs(Enc &__restrict__ e, int ni, int depth, in
 // angles, +-2 / +-4 around the best, +-1 around that.  sad_of(mode) returns the SAD of a direction or a negative value when it is not
 // available (only the replay in enc_sched.h can fail).  Returns the bit cost of the winner, or -1.
 template <class SadsFn, class BitsFn>
-HENC_INLINE int intra_search_walk_batched(const int *preds, int rd_fast, double sqrt_lambda, SadsFn &&sads_of, int *best_mode_out, double *best_cost_out, BitsFn &&full_bits_of)
+HENC_INLINE int intra_search_walk_batched(const int *preds, int rd_fast, double sqrt_lambda, SadsFn &&sads_of, int *best_mode_out, double *best_cost_out, BitsFn &&full_bits_of,
+					  int *modes_buf = nullptr, int64_t *sads_buf = nullptr)
 {
 	static constexpr int search_points[4][5] = {{0, 1, 0, 8, 16}, {2, 10, 16, 22, 30}, {-4, -2, 2, 4, 0}, {-1, 1, 0, 0, 0}};
 	static constexpr int num_search_points[4] = {2, 5, 4, 2};
@@ -96,8 +100,10 @@ HENC_INLINE int intra_search_walk_batched(const int *preds, int rd_fast, double 
 	for (int loop = 0; loop < 4; loop++) {
 		if (loop == 1) { best_cu_mode = 2; min_mode = 2; max_mode = 34; }
 		// the candidates of a round do not depend on each other: their SADs may be computed side by side, the comparison below keeps the reference's order
-		int modes[5], cnt = 0;
-		int64_t sads[5];
+		int modes_local[5], cnt = 0;
+		int64_t sads_local[5];
+		int *modes = modes_buf ? modes_buf : modes_local;      // (the worker passes a place in its fast memory: the lists are indexed at run time)
+		int64_t *sads = sads_buf ? sads_buf : sads_local;
 		for (int k = 0; k < num_search_points[loop]; k++) {
 			const int mode = best_cu_mode + search_points[loop][k];
 			if (mode < min_mode || mode > max_mode) continue;
@@ -142,6 +148,7 @@ HENC_INLINE uint32_t intra_luma_cost(uint32_t tu_cost, int mode_bits, double cor
 template <class G>
 HENC_HD int intra_mode_search(const G &g, Enc &__restrict__ e, int ni, int depth, int *best_mode_out, double *best_cost_out)
 {
+	HENC_ENC_IN_LDS(e);
 	const Geo &q = e.geo[ni];
 	Work &w = *e.w;
 	const int n = q.size, curr_depth = q.depth, inv_depth = CFG_MAX_CU_SHIFT - curr_depth;
@@ -192,12 +199,13 @@ HENC_HD int intra_mode_search(const G &g, Enc &__restrict__ e, int ni, int depth
 				lg->n++;
 			}
 		return true;
-	}, best_mode_out, best_cost_out, [&](int mode) { return rd_bits_luma_mode_in_preds(e, mode, preds); });
+	}, best_mode_out, best_cost_out, [&](int mode) { return rd_bits_luma_mode_in_preds(e, mode, preds); }, w.srch_modes, w.srch_sads);
 }
 
 template <class G>
 HENC_HD void set_intra_info_buffs(const G &g, Enc &__restrict__ e, int depth, int ni)
 {
+	HENC_ENC_IN_LDS(e);
 	const Geo &q = e.geo[ni];
 	const Node &nd = node_of(e, ni);
 	Work &w = *e.w;
@@ -213,6 +221,7 @@ HENC_HD void set_intra_info_buffs(const G &g, Enc &__restrict__ e, int depth, in
 template <class G>
 HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int depth, int cu_mode, int part_size_type, int *curr_sum)
 {
+	HENC_ENC_IN_LDS(e);
 	const Geo &q = e.geo[ni];
 	Node &nd = node_of(e, ni);
 	Work &w = *e.w;
@@ -251,8 +260,9 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 
 // encode_intra_luma, hmr_motion_intra.c:1229-1630 (non-HM path): search, then the transform tree of the winner.
 template <class G>
-HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
+HENC_WALK_FN HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
 {
+	HENC_ENC_IN_LDS(e);
 	const Seq &S = *e.seq;
 	Work &w = *e.w;
 	const int top_ni = node_at(e, depth, part_position);
@@ -403,14 +413,17 @@ HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, i
 HENC_INLINE void chroma_dir_list(int *list, int luma_mode)
 {
 	list[0] = PLANAR_IDX; list[1] = VER_IDX; list[2] = HOR_IDX; list[3] = DC_IDX; list[4] = DM_CHROMA_IDX;
+	// (the first match only - the four entries differ, so at most one matches; no break, so that the loop unrolls and the list stays in registers)
+#pragma unroll
 	for (int i = 0; i < 4; i++)
-		if (luma_mode == list[i]) { list[i] = 34; break; }
+		if (luma_mode == list[i]) list[i] = 34;
 }
 
 // one chroma plane of the candidate search of encode_intra_chroma: SAD of the five candidates on the unfiltered neighbours of the auxiliary window
 template <class G>
 HENC_HD void chroma_search_comp(const G &g, Enc &__restrict__ e, int curr, int c, const int *cand, uint32_t *sads)
 {
+	HENC_ENC_IN_LDS(e);
 	Work &w = *e.w;
 	const Geo &q = e.geo[curr];
 	const int n = q.size_chroma;
@@ -425,6 +438,7 @@ HENC_HD void chroma_search_comp(const G &g, Enc &__restrict__ e, int curr, int c
 template <class G>
 HENC_HD int chroma_tu_comp(const G &g, Enc &__restrict__ e, int curr, int c, int cu_mode, int scan_mode, int shifts, int per, int rem, int *curr_sum_out)
 {
+	HENC_ENC_IN_LDS(e);
 	Work &w = *e.w;
 	const Geo &q = e.geo[curr];
 	const int n = q.size_chroma, curr_depth = q.depth, qwnd = NWND - 1, dwnd = NWND - 1;
@@ -456,6 +470,7 @@ HENC_HD int chroma_tu_comp(const G &g, Enc &__restrict__ e, int curr, int c, int
 template <class G>
 HENC_HD void chroma_tu_both(const G &g, Enc &__restrict__ e, int curr, int cu_mode, int scan_mode, int shifts, int per, int rem, int *pc, int *cs)
 {
+	HENC_ENC_IN_LDS(e);
 	pc[0] = chroma_tu_comp(g, e, curr, COMP_U, cu_mode, scan_mode, shifts, per, rem, &cs[0]);
 	pc[1] = chroma_tu_comp(g, e, curr, COMP_V, cu_mode, scan_mode, shifts, per, rem, &cs[1]);
 	g.sync();
@@ -463,8 +478,9 @@ HENC_HD void chroma_tu_both(const G &g, Enc &__restrict__ e, int curr, int cu_mo
 
 // encode_intra_chroma, hmr_motion_intra_chroma.c:114-469 (non-HM path, rd_mode != RD_FULL)
 template <class G>
-HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
+HENC_WALK_FN HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
 {
+	HENC_ENC_IN_LDS(e);
 	const Seq &S = *e.seq;
 	Work &w = *e.w;
 	const int nxn = part_size_type == PART_NxN;
@@ -497,16 +513,19 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth,
 		// the neighbour arrays do not change during the search, so the grouping does not matter)
 		uint32_t sad_u[5], sad_v[5];
 		int cand[5];
+#pragma unroll
 		for (int mi = 0; mi < 5; mi++) cand[mi] = mode_list[mi] == DM_CHROMA_IDX ? luma_mode : mode_list[mi];
 		if (HENC_HELPERS(e)) {
 			helper_post(g, e, 0, HJOB_CHROMA_SEARCH, curr, COMP_U, cand[0] | (cand[1] << 8) | (cand[2] << 16) | (cand[3] << 24), cand[4]);
 			chroma_search_comp(g, e, curr, COMP_V, cand, sad_v);
 			helper_wait(g, e, 0);
+#pragma unroll
 			for (int mi = 0; mi < 5; mi++) sad_u[mi] = e.box->r[0][mi];
 		} else {
 			chroma_search_comp(g, e, curr, COMP_U, cand, sad_u);
 			chroma_search_comp(g, e, curr, COMP_V, cand, sad_v);
 		}
+#pragma unroll
 		for (int mi = 0; mi < 5; mi++) {
 			uint32_t distortion = sad_u[mi], cost = distortion;
 			distortion += sad_v[mi];
@@ -524,6 +543,7 @@ HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth,
 			int um = mode_list[mi];
 			double uc = cost;
 			uint32_t ub = bit_cost;
+#pragma unroll
 			for (int i = 0; i < 3; i++)
 				if (best_costs[i] > uc) {
 					const int am = best_modes[i]; const double ac = best_costs[i]; const uint32_t ab = best_bits[i];

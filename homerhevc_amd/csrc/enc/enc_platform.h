@@ -31,6 +31,14 @@
 #define HENC_FT(e) ((e).ft)
 #endif
 
+// The three CU-level evaluations (encode_inter, encode_intra_luma, encode_intra_chroma): left to the compiler (it keeps them out of line), or forced into their callers
+// (the default; -DHENC_WALK_OUTLINE leaves them to the compiler: no call frames - a call saves and restores up to a hundred callee-saved registers through private memory - against a larger body)
+#if defined(__HIPCC__) && !defined(HENC_WALK_OUTLINE)
+#define HENC_WALK_FN __attribute__((always_inline))
+#else
+#define HENC_WALK_FN
+#endif
+
 namespace henc {
 
 #if defined(__HIPCC__)
@@ -107,6 +115,14 @@ HENC_INLINE T *in_fast_memory(T *p)
 	return p;
 #endif
 }
+// The worker's context (Enc, enc_common.h) is ONE object per wavefront at a fixed place in LDS; it reaches the functions of the walk as a reference, which the compiler
+// can only take for a generic pointer (flat_* accesses, and - when the object was a local of the kernel - private memory behind it).  Every function that gets it says
+// where it is: its members then are ds_* accesses at an address the lanes share.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HENC_ENC_IN_LDS(e) __builtin_assume(__builtin_amdgcn_is_shared((const void *)&(e)))
+#else
+#define HENC_ENC_IN_LDS(e) do { } while (0)
+#endif
 template <class T>
 struct FastPtr {
 	T *p;

@@ -36,6 +36,7 @@ template <class G>
 HENC_FI void rd_make_views(const G &g, Enc &__restrict__ e, RdViews &r, int y_depth, int tr_depth_buf, const uint8_t *cbf_u, const uint8_t *cbf_v, int chroma_mode_depth,
 			   const int16_t *coef_y, const int16_t *coef_u, const int16_t *coef_v)
 {
+	HENC_ENC_IN_LDS(e);
 	Work &w = *e.w;
 	CtuView &c = r.c;
 	c.cbf[0] = w.cbf_buffs[COMP_Y][y_depth];
@@ -186,6 +187,7 @@ HENC_FI void rd_transform_tree(const G &g, Cabac &ec, const EntView &v, EntScrat
 template <class G>
 HENC_RD_NOINLINE HENC_HD uint32_t rd_get_intra_bits_qt(const G &g, Enc &__restrict__ e, const RdViews &r, int ni, int is_luma)
 {
+	HENC_ENC_IN_LDS(e);
 	Cabac ec;
 	ec.counter = true;
 	ec.ctx = e.wrd->rd_ctx_work;
@@ -222,6 +224,7 @@ HENC_RD_NOINLINE HENC_HD uint32_t rd_get_intra_bits_qt(const G &g, Enc &__restri
 // holds (Enc::rd_chroma_state), which then falls to state 0
 HENC_FI uint32_t rd_bits_chroma_mode(Enc &__restrict__ e, const EntView &v, int ni)
 {
+	HENC_ENC_IN_LDS(e);
 	const int abs_index = v.geo[ni].abs_index;
 	const uint32_t chroma = uni(v.c->intra_mode[1][abs_index]);
 	uint64_t frac = kEntropyBits[e.rd_chroma_state ^ (chroma == DM_CHROMA_IDX ? 0u : 1u)];

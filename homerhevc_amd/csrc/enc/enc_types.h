@@ -238,6 +238,8 @@ struct Work {
 	int16_t sub_tmp[(64 + 8) * 72];        // checker build: first interpolation stage of a sub-pel candidate / two-stage motion compensation
 #endif
 	MvCandList amvp, merge_cands, search_cands;
+	alignas(8) int64_t srch_sads[5];       // a round of the intra mode search: its candidates and their SADs (indexed at run time: as locals they lived in private memory)
+	int32_t srch_modes[6];
 #if !defined(__HIPCC__)
 	uint8_t nodes_fast_store[52 * (21 + 16 + 64) + 16];      // checker build: the worker's fast copy of the CTU's partition nodes (enc_common.h NODE_SLOTS; on the device a place in LDS)
 #endif

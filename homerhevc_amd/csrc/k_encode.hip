@@ -108,18 +108,18 @@ static_assert(LDS_KEEPS_TU_TABLES == (HENC_TU_TABLES_IN_LDS != 0), "enc_platform
 constexpr size_t LDS_SEQ = (sizeof(Seq) + sizeof(FrameCtx) + 31) & ~(size_t)15, LDS_CTU = LDS_KEEPS_CTU_RECORD ? (sizeof(CtuPublic) + 15) & ~(size_t)15 : 0,
 		 LDS_FT = LDS_KEEPS_TU_TABLES ? (sizeof(FastTables) + 15) & ~(size_t)15 : 0;
 #if defined(HENC_PROFILE)
-constexpr size_t LDS_BOX = LDS_BOX_BYTES, LDS_HSCRATCH = 0, LDS_RD = (sizeof(WorkRd) + 15) & ~(size_t)15;
+constexpr size_t LDS_BOX = LDS_BOX_BYTES + (1 + NHELP) * LDS_ENC_BYTES, LDS_HSCRATCH = 0, LDS_RD = (sizeof(WorkRd) + 15) & ~(size_t)15;
 constexpr size_t LDS_BYTES = HENC_LDS_PROF_OFFSET + 2 * PP_COUNT * 8;   // the primitive timers sit at HENC_LDS_PROF_OFFSET
 constexpr size_t LDS_FT_OFFSET = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH;
 static_assert(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH + LDS_FT + LDS_RD <= HENC_LDS_PROF_OFFSET, "profile table overlaps the worker state");
 #else
-constexpr size_t LDS_BOX = LDS_BOX_BYTES, LDS_HSCRATCH = 0, LDS_RD = (sizeof(WorkRd) + 15) & ~(size_t)15;
+constexpr size_t LDS_BOX = LDS_BOX_BYTES + (1 + NHELP) * LDS_ENC_BYTES, LDS_HSCRATCH = 0, LDS_RD = (sizeof(WorkRd) + 15) & ~(size_t)15;
 constexpr size_t LDS_BYTES = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH + LDS_FT + LDS_RD;
 constexpr size_t LDS_FT_OFFSET = LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX + LDS_HSCRATCH;
 #endif
 static_assert(sizeof(SubpelScratch) <= LDS_WORK + LDS_NODES + LDS_GEO, "task S works where the post stage does");
 static_assert(sizeof(PostScratch) <= LDS_WORK + LDS_NODES + LDS_GEO, "the post stage works in what is idle between two CTUs: the worker's Work area, the CTU's partition nodes, the helpers' scratch");
-static_assert(LDS_OFF_RD == (int)(LDS_BYTES - LDS_RD) || LDS_FT != 0 || LDS_CTU != 0, "the RD_FULL arrays are the tail of a worker's LDS: launches without RD_FULL pictures leave them out");
+static_assert(LDS_OFF_RD == (int)(LDS_BYTES - LDS_RD) && LDS_OFF_ENC == (int)(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU + LDS_BOX_BYTES) || LDS_FT != 0 || LDS_CTU != 0, "the RD_FULL arrays are the tail of a worker's LDS: launches without RD_FULL pictures leave them out");
 static_assert(LDS_OFF_NODES == (int)LDS_WORK && LDS_OFF_SEQ == (int)(LDS_WORK + LDS_NODES + LDS_GEO) && LDS_OFF_BOX == (int)(LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU),
 	      "enc_common.h: the fixed places of Enc's LDS members");
 #if !defined(HENC_WAVES_PER_EU)
@@ -142,13 +142,17 @@ static_assert(LDS_BYTES - LDS_RD == 0 && LDS_WORK == 0 && LDS_NODES == 0 && LDS_
 __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 {
 	WaveGrp g{(int)(threadIdx.x & 63)};
-	Enc e = {};
+	extern __shared__ __align__(16) uint8_t lds[];
+	Enc &e = *(Enc *)(lds + LDS_OFF_ENC + (1 + h) * LDS_ENC_BYTES);      // (this helper's own context; LDS starts zeroed)
+	HENC_ENC_IN_LDS(e);
+	const Enc &worker = *(const Enc *)(lds + LDS_OFF_ENC);
 	for (int seq = 1;; seq++) {
 		while (__hip_atomic_load(&box->cmd[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) __builtin_amdgcn_s_sleep(1);   // (two workgroups share a CU now: a helper that spins takes issue cycles from the other workgroup's worker on its SIMD)
 		const int job = box->job[h];
 		if (job == HJOB_QUIT) return;
 		if (job == HJOB_NEW_CTU) {
-			e = box->enc;
+			wave_copy_words(&e, &worker, (int)sizeof(Enc), g.tid);
+			g.sync();
 			e.box = nullptr;
 			e.on_helper = 1;
 			e.scratch_a = scratch;
@@ -281,7 +285,8 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 	if (g.tid < 2 * PP_COUNT) ((unsigned long long *)(lds + HENC_LDS_PROF_OFFSET))[g.tid] = 0;
 #endif
 	g.sync();
-	Enc e;
+	Enc &e = *(Enc *)(lds + LDS_OFF_ENC);      // (the context lives in LDS: enc_platform.h HENC_ENC_IN_LDS)
+	HENC_ENC_IN_LDS(e);
 	e.seq = lseq;
 	e.f = lframe;
 	e.T = d.tables;
@@ -408,6 +413,7 @@ __device__ __forceinline__ void pool_step_rows(int t, int W, int H, int *r_lo, i
 
 __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const WaveGrp &g, Seq *lseq, FrameCtx *lframe, FastTables *lft, int t, int row, int *cached_rem, const int *abort_flag)
 {
+	HENC_ENC_IN_LDS(e);
 	const Seq &S = *lseq;
 	const int W = S.wctu, H = S.hctu;
 	const int T = d.threads, me = row % T, c = t - 2 * row, n = row * W + c;
@@ -578,7 +584,8 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HEN
 	if (g.tid < 2 * PP_COUNT) ((unsigned long long *)(lds + HENC_LDS_PROF_OFFSET))[g.tid] = 0;
 #endif
 	g.sync();
-	Enc e;
+	Enc &e = *(Enc *)(lds + LDS_OFF_ENC);      // (the context lives in LDS: enc_platform.h HENC_ENC_IN_LDS)
+	HENC_ENC_IN_LDS(e);
 	e.seq = lseq;
 	e.f = lframe;
 	e.ft = lft;
