@@ -123,6 +123,13 @@ HENC_INLINE T *in_fast_memory(T *p)
 #else
 #define HENC_ENC_IN_LDS(e) do { } while (0)
 #endif
+// ... and a pointer into HBM (the worker's slow windows): kept as a pointer of the global address space, what is derived from it are global_* accesses instead of
+// flat_* ones (which wait for LDS and memory operations alike and decide per lane where they go)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HENC_GLOBAL_PTR(T) __attribute__((address_space(1))) T *
+#else
+#define HENC_GLOBAL_PTR(T) T *
+#endif
 template <class T>
 struct FastPtr {
 	T *p;

@@ -243,7 +243,7 @@ struct Work {
 #if !defined(__HIPCC__)
 	uint8_t nodes_fast_store[52 * (21 + 16 + 64) + 16];      // checker build: the worker's fast copy of the CTU's partition nodes (enc_common.h NODE_SLOTS; on the device a place in LDS)
 #endif
-	WorkSlow *slow;
+	HENC_GLOBAL_PTR(WorkSlow) slow;
 	// Part of the WPP thread's state next to the mode buffers: has this thread ever taken the intra walk?  The reference's thread keeps a shadow CTU whose
 	// pred_mode array is set to INTRA by motion_intra_cu (hmr_motion_intra.c:1783) and never cleared; the most-probable-mode look-up of the mode search reads
 	// it (homer_loop1_motion_intra :1102-1104).  With one engine every thread has been through the first (intra) frame; the threads of a second engine start
@@ -265,14 +265,14 @@ HENC_INLINE int16_t *wnd_y(int16_t *base) { return base; }
 // accessors ------------------------------------------------------------------------------------------------------
 HENC_INLINE int16_t *dec_ptr(Work &w, int wnd, int comp)
 {
-	return comp == COMP_Y ? w.slow->dec_y[wnd] + DEC_ORG_Y : w.slow->dec_c[wnd][comp - 1] + DEC_ORG_C;
+	return (int16_t *)(comp == COMP_Y ? w.slow->dec_y[wnd] + DEC_ORG_Y : w.slow->dec_c[wnd][comp - 1] + DEC_ORG_C);
 }
 HENC_INLINE int dec_stride(int comp) { return comp == COMP_Y ? DEC_STRIDE_Y : DEC_STRIDE_C; }
 HENC_INLINE int ctu_stride(int comp) { return comp == COMP_Y ? CTU_STRIDE_Y : CTU_STRIDE_C; }
-HENC_INLINE int16_t *tq_ptr(Work &w, int wnd, int comp) { return comp == COMP_Y ? w.slow->tq_y[wnd] : w.slow->tq_c[wnd][comp - 1]; }
+HENC_INLINE int16_t *tq_ptr(Work &w, int wnd, int comp) { return (int16_t *)(comp == COMP_Y ? w.slow->tq_y[wnd] : w.slow->tq_c[wnd][comp - 1]); }
 HENC_INLINE src_t *curr_ptr(Work &w, int comp) { return comp == COMP_Y ? w.curr_y : w.curr_c[comp - 1]; }
 HENC_INLINE pred_t *pred_ptr(Work &w, int comp) { return comp == COMP_Y ? w.pred_y : w.pred_c[comp - 1]; }
-HENC_INLINE int16_t *rdec_ptr(Work &w, int comp) { return comp == COMP_Y ? w.slow->rdec_y : w.slow->rdec_c[comp - 1]; }
+HENC_INLINE int16_t *rdec_ptr(Work &w, int comp) { return (int16_t *)(comp == COMP_Y ? w.slow->rdec_y : w.slow->rdec_c[comp - 1]); }
 // the TU's slot of the level / dequantised-coefficient buffer (`off`: its place in a CTU-sized buffer, which only the checker build keeps)
 HENC_INLINE int16_t *iq_slot(Work &w, int comp, int off, int on_helper)
 {

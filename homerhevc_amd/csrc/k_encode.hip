@@ -275,7 +275,7 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 	FrameCtx *lframe = (FrameCtx *)((uint8_t *)lseq + ((sizeof(Seq) + 15) & ~(size_t)15));
 	for (int i = g.tid; i < (int)(sizeof(Seq) / 4); i += 64) ((uint32_t *)lseq)[i] = ((const uint32_t *)d.seq)[i];
 	for (int i = g.tid; i < (int)(sizeof(FrameCtx) / 4); i += 64) ((uint32_t *)lframe)[i] = ((const uint32_t *)d.frame)[i];
-	if (g.tid == 0) lw->slow = d.work_slow + row;
+	if (g.tid == 0) lw->slow = (HENC_GLOBAL_PTR(WorkSlow))(d.work_slow + row);
 	g.sync();
 	if (g.tid == 0) lframe->scene_cut_ctu = d.counters[2];
 	// the transform bases, scans and this frame's quantiser lists next to the worker (enc_prims.h: FastTables)
@@ -527,7 +527,7 @@ __device__ __attribute__((noinline)) int pool_post_drain(const EncDev &d, const 
 	PostScratch &sc = *(PostScratch *)in_fast_memory((uint8_t *)lw);
 	const int ran = post_drain(g, x, sc);
 	if (ran) {
-		if (g.tid == 0) lw->slow = my_slow;      // (the scratch overlays the worker's Work)
+		if (g.tid == 0) lw->slow = (HENC_GLOBAL_PTR(WorkSlow))my_slow;      // (the scratch overlays the worker's Work)
 		g.sync();
 		// whoever completes the picture's last task says so - exactly one worker wins the claim (errors[1]: 0 -> 2) - after the picture's last duty: its distortion
 		// total (hmr_encoder_lib.c:3217-3228: every WPP thread adds up its rows' CTUs in a uint32 that may wrap, the engine adds the threads in a double), from
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HEN
 	Seq *lseq = (Seq *)(lds + LDS_WORK + LDS_NODES + LDS_GEO);
 	FrameCtx *lframe = (FrameCtx *)((uint8_t *)lseq + ((sizeof(Seq) + 15) & ~(size_t)15));
 	FastTables *lft = LDS_KEEPS_TU_TABLES ? (FastTables *)(lds + LDS_FT_OFFSET) : nullptr;
-	if (g.tid == 0) lw->slow = slow + blockIdx.x;
+	if (g.tid == 0) lw->slow = (HENC_GLOBAL_PTR(WorkSlow))(slow + blockIdx.x);
 #if defined(HENC_PROFILE)
 	if (g.tid < 2 * PP_COUNT) ((unsigned long long *)(lds + HENC_LDS_PROF_OFFSET))[g.tid] = 0;
 #endif
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HEN
 			int ran = 0;
 			for (int i = 0; i < nseq; i++) {
 				const int cand = (start + i) % nseq;
-				const EncDev dd = devs[cand];
+				const EncDev &dd = devs[cand];      // (by reference: an idle scan does not copy every picture's descriptor into private memory)
 				ran += pool_post_drain(dd, g, dd.seq, dd.frame, lw, slow + blockIdx.x, finished);
 				if (ran) { start = cand; break; }
 			}
