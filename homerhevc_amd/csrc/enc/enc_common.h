@@ -89,7 +89,7 @@ constexpr int LDS_OFF_WORK = 0, LDS_OFF_NODES = (int)((sizeof(Work) + 15) & ~(si
 #define HENC_AT(T, OFFSET) FastPtr<T>
 #endif
 
-constexpr int LDS_BOX_BYTES = 160, LDS_ENC_BYTES = 256;      // what the mailbox and a context may take (checked behind HelperBox / Enc)
+constexpr int LDS_BOX_BYTES = 160, LDS_ENC_BYTES = 272;      // what the mailbox and a context may take (checked behind HelperBox / Enc)
 constexpr int LDS_OFF_ENC = LDS_OFF_BOX + LDS_BOX_BYTES;      // the worker's context, then one per helper
 constexpr int LDS_OFF_RD = LDS_OFF_ENC + (1 + NHELP_) * LDS_ENC_BYTES;
 struct Enc {
@@ -106,6 +106,7 @@ struct Enc {
 	CtuPublic *ctu_fast;
 	HENC_AT(Work, LDS_OFF_WORK) w;
 	HENC_AT(WorkRd, LDS_OFF_RD) wrd;      // RD_FULL only
+	int amvp_node;            // the node whose vector predictor list w.amvp holds, straight from motion estimation (-1: none)
 	int on_helper;            // this context is a helper wavefront's copy (which slot of the level buffer a TU takes: enc_types.h iq_slot)
 	int16_t *coeff;        // the CTU's coefficient output: 4096 luma + 2 x 1024 chroma, linear per TU in z-order
 	// speculative inputs of a P-frame CTU (enc_ctu.h)

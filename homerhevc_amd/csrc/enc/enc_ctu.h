@@ -703,6 +703,7 @@ HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 	e.nb_ctus = (uint32_t)((cx > 0) | ((cy > 0) << 1) | ((cy > 0 && cx != S.wctu - 1) << 2) | ((cx > 0 && cy > 0) << 3));
 	e.n_spec_reads = e.n_ratio_cmp = 0;
 	e.n_stale_pred = 0;
+	e.amvp_node = -1;
 	// the worker's mode buffers start as "inherited" everywhere (see read_mode_buff, enc_intra.h)
 	for (int i = g.tid; i < 2 * NDEPTH * NPART; i += g.n) (&w.intra_mode_buffs[0][0][0])[i] = (uint8_t)(MODE_TOKEN | ((i / NPART) % NDEPTH));
 	// source CTU

@@ -801,7 +801,9 @@ HENC_HD int predict_inter(const G &g, Enc &__restrict__ e, int depth, int part_p
 	for (int np = 0; np < num_partitions; np++, curr++) {
 		Node &nd = node_of(e, curr);
 		const MV mv = nd.inter_mv;
-		{ PRIM_T0(); get_amvp_candidates(e, curr, e.w->amvp); PRIM_END(PP_CAND); }
+		// (the list motion estimation has just derived for this node is still in place: nothing in between changes what it is derived from)
+		if (e.amvp_node != curr) { PRIM_T0(); get_amvp_candidates(e, curr, e.w->amvp); PRIM_END(PP_CAND); }
+		e.amvp_node = -1;
 		int best_idx = 0;
 		mv_cost += (int)mv_cost_sqrt(e.w->amvp, nd.qp, mv.x, mv.y, &best_idx);
 		nd.best_candidate_idx = (int8_t)best_idx;
@@ -853,6 +855,7 @@ HENC_HD int cu_motion_estimation(const G &g, Enc &__restrict__ e, int depth, int
 		nd.inter_mv = mv;
 		nd.inter_ref_index = 0;
 		nd.inter_mode = 1;
+		e.amvp_node = curr;      // (predict_inter, if it follows for this node, finds the list in w.amvp)
 		nd.best_candidate_idx = mvp_idx;
 		nd.best_dif_mv.x = mv.x - amvp.mv[mvp_idx].x;
 		nd.best_dif_mv.y = mv.y - amvp.mv[mvp_idx].y;

@@ -429,10 +429,9 @@ HENC_HD void chroma_search_comp(const G &g, Enc &__restrict__ e, int curr, int c
 	const int n = q.size_chroma;
 	pred_t *pred = pred_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
 	const src_t *orig = curr_ptr(w, c) + q.yc * CTU_STRIDE_C + q.xc;
-	for (int mi = 0; mi < 5; mi++) {
-		node_fill_refs(g, e, curr, NWND - 1, c, 0);
-		sads[mi] = intra_predict_sad(g, pred, CTU_STRIDE_C, orig, CTU_STRIDE_C, e.adi_c, n, cand[mi], 0);
-	}
+	// (the reference fills the neighbour array before every candidate, hmr_motion_intra_chroma.c:196; nothing between two candidates changes what it is filled from)
+	node_fill_refs(g, e, curr, NWND - 1, c, 0);
+	for (int mi = 0; mi < 5; mi++) sads[mi] = intra_predict_sad(g, pred, CTU_STRIDE_C, orig, CTU_STRIDE_C, e.adi_c, n, cand[mi], 0);
 }
 // one chroma TU of the winner: neighbours, prediction, residual, transform chain, reconstruction into the auxiliary window.  Returns the weighted SSD.
 template <class G>
