@@ -517,7 +517,63 @@ HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &__restrict__ e)
 	return node_of(e, root).cost;
 }
 
-// motion_intra_cu, hmr_motion_intra.c:1759 (performance_mode <= 2: no variance pre-analysis)
+// analyse_recursive_info_cu + calc_variance_cu, hmr_motion_intra.c:1645-1727 (performance_mode 3, called on the CTU's root: :1788): the variance of every partition
+// (luma + 1.25 x both chroma components, per sample) and, bottom up, "recursive_split": a partition whose variance exceeds one of its children's by the reference's
+// measure - or one of whose children is itself split, or which reaches outside the picture - is not evaluated as a whole, one that is not split ends the recursion.
+// The reference walks the tree depth first; what it computes depends on a partition and its children only, so the variances are taken partition by partition and the
+// flags level by level, the partitions of a level side by side.  Variances sit in the TU scratch (free before the walk), the flags as a bit per node in Work::rsplit.
+HENC_INLINE bool rsplit_of(const Work &w, int ni) { return (w.rsplit[ni >> 5] >> (ni & 31)) & 1u; }
+template <class G>
+HENC_HD void analyse_recursive_info(const G &g, Enc &__restrict__ e)
+{
+	HENC_ENC_IN_LDS(e);
+	const Seq &S = *e.seq;
+	Work &w = *e.w;
+	uint32_t *var = (uint32_t *)(int16_t *)w.pred_aux;       // [NNODES]
+	uint8_t *split = (uint8_t *)(int16_t *)w.delta_u;         // [NNODES]
+	static_assert(NNODES * 4 <= TU_SCRATCH * 2 && NNODES <= TU_SCRATCH * 2, "the analysis works in the TU scratch");
+	for (int ni = 0; ni < NNODES; ni++) {
+		const Geo &q = e.geo[ni];
+		const bool inside = (e.ctu_y + q.y + q.size <= S.height) && (e.ctu_x + q.x + q.size <= S.width);
+		uint32_t v = 0;
+		if (inside) {
+			const int nc = q.size_chroma;
+			const uint32_t vy = blk_modified_variance(g, w.curr_y + q.y * CTU_STRIDE_Y + q.x, CTU_STRIDE_Y, q.size, 1) / (uint32_t)(q.size * q.size);
+			uint32_t vc = (uint32_t)(1.25 * blk_modified_variance(g, w.curr_c[0] + q.yc * CTU_STRIDE_C + q.xc, CTU_STRIDE_C, nc, 2) / (nc * nc));
+			vc += (uint32_t)(1.25 * blk_modified_variance(g, w.curr_c[1] + q.yc * CTU_STRIDE_C + q.xc, CTU_STRIDE_C, nc, 2) / (nc * nc));
+			v = vy + vc;
+		}
+		if (g.tid == 0) { var[ni] = v; split[ni] = inside ? 0 : 1; }
+	}
+	g.sync();
+	for (int depth = CFG_MAX_PRED_DEPTH - 1; depth >= 0; depth--) {
+		const int first = cfg_depth_start(depth), count = 1 << (2 * depth);
+		for (int k = g.tid; k < count; k += g.n) {
+			const int pi = first + k;
+			const Geo &pq = e.geo.lane(pi);
+			const uint32_t parent_variance = (uint32_t)(.5 + hsqrt((double)var[pi]));
+			for (int l = 0; l < 4; l++) {
+				const int ci = pq.child[l];
+				const uint32_t child_variance = (uint32_t)(.5 + ((double)(depth + 1) / 4.) * hsqrt((double)var[ci]) + 3 * (depth + 1));
+				if (parent_variance > child_variance || split[ci]) { split[pi] = 1; break; }
+			}
+		}
+		g.sync();
+	}
+	for (int base = 0; base < 11 * 32; base += g.n) {
+		const int ni = base + g.tid;
+		if (G::n >= 64) {
+			const uint64_t m = g.ballot(ni < NNODES && split[ni]);
+			if (g.tid == 0) { w.rsplit[base >> 5] = (uint32_t)m; if ((base >> 5) + 1 < 11) w.rsplit[(base >> 5) + 1] = (uint32_t)(m >> 32); }
+		} else {
+			if ((ni & 31) == 0) w.rsplit[ni >> 5] = 0;
+			if (ni < NNODES && split[ni]) w.rsplit[ni >> 5] |= 1u << (ni & 31);
+		}
+	}
+	g.sync();
+}
+
+// motion_intra_cu, hmr_motion_intra.c:1759
 template <class G>
 HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 {
@@ -535,6 +591,8 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 		e.rd_luma_depth = -1;
 		e.rd_chroma_state = 0;
 	}
+	const bool fastest = S.perf_mode > 2;      // PERF_FASTEST_COMPUTATION: the variance pre-analysis steers the recursion (:1788, :1824, :1891)
+	if (fastest) analyse_recursive_info(g, e);
 	while (curr_depth != initial_depth || depth_state.get(curr_depth) != initial_position + 1) {
 		const Geo &q = e.geo[curr];
 		if (q.depth >= 1) nodes_select_quad(g, e, q.abs_index >> 6);
@@ -543,9 +601,12 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 		const int part_size_type = curr_depth < CFG_MAX_PRED_DEPTH ? PART_2Nx2N : PART_NxN;
 		int position = q.list_index - cfg_depth_start(curr_depth);
 		double cost_luma = 0, cost_chroma = 0;
+		int stop_recursion = 0;
 		nd->qp = (uint32_t)e.ctu_qp;
 		if (nd->b_inside && nd->r_inside) {
-			if (part_size_type == PART_2Nx2N) {
+			if (fastest && rsplit_of(*e.w, curr)) {
+				nd->cost = MAX_COST;      // (:1826-1828: not evaluated as a whole; nothing goes into the depth's running cost)
+			} else if (part_size_type == PART_2Nx2N) {
 				{ HENC_PROF_T0(); cost_luma = encode_intra_luma(g, e, curr_depth, position, part_size_type); HENC_PROF_ADD(e, PF_INTRA_TU); } HENC_TRACE_PW(e, "iluma");
 				{ HENC_PROF_T0(); cost_chroma = encode_intra_chroma(g, e, curr_depth, position, part_size_type); HENC_PROF_ADD(e, PF_INTRA_CHROMA); } HENC_TRACE_PW(e, "ichroma");
 				nd->cost = (uint32_t)(cost_luma + cost_chroma);
@@ -573,7 +634,14 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 			}
 		}
 		depth_state.inc(curr_depth);
-		if (curr_depth < CFG_MAX_PRED_DEPTH && nd->tl_inside) {
+		// :1891: a partition the analysis does not split (or that cost nothing) ends the recursion here
+		if (fastest && (!rsplit_of(*e.w, curr) || nd->cost == 0) && part_size_type != PART_NxN && nd->b_inside && nd->r_inside) {
+			(void)consolidate_prediction_info(g, e, curr, nd->cost, MAX_COST, 0);
+			stop_recursion = 1;
+			const int aux = parent >= 0 ? e.geo[parent].child[(depth_state.get(curr_depth) + 3) & 3] : 0;
+			refresh_deeper_windows(g, e, aux, curr_depth, 1);
+		}
+		if (!stop_recursion && curr_depth < CFG_MAX_PRED_DEPTH && nd->tl_inside) {
 			curr_depth++;
 			parent = curr;
 		} else if (depth_state.get(curr_depth) == 4) {

@@ -61,7 +61,6 @@ inline bool make_seq(HostCfg cfg, Seq &s, const char **why)
 		*why = "rd_mode RD_FULL needs wfpp_num_threads > 1, one engine and fixed QP";
 		return false;
 	}
-	if (cfg.performance_mode > 2) { *why = "performance_mode 3"; return false; }
 	s.max_cu_size = 64;
 	s.max_cu_size_shift = 6;
 	s.max_pred_depth = cfg.max_pred_partition_depth > 4 ? 4 : cfg.max_pred_partition_depth;

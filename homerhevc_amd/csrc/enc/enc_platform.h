@@ -9,6 +9,7 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include <math.h>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -175,6 +176,7 @@ template <class T> HENC_INLINE T hmin(T a, T b) { return a < b ? a : b; }
 template <class T> HENC_INLINE T hmax(T a, T b) { return a > b ? a : b; }
 template <class T> HENC_INLINE T hclip(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
 HENC_INLINE int habs(int v) { return v < 0 ? -v : v; }
+HENC_INLINE double hsqrt(double v) { return ::sqrt(v); }      // (correctly rounded on both sides: libm here, __ocml_sqrt_f64 on the device)
 HENC_INLINE int16_t sat16(int v) { return (int16_t)hclip(v, -32768, 32767); }
 
 }  // namespace henc

@@ -179,6 +179,32 @@ HENC_PRIM uint32_t blk_ssd_diff(const G &g, const S *o, int os, const P *p, int 
 	{ const auto prim_ret_ = g.sum(acc); PRIM_END(PP_SSD); return prim_ret_; }
 }
 
+// modified_variance (sse_modified_variance, hmr_sse42_functions_pixel.c:1123; quirk Q2 of SURVEY.md: the SSE code loads 16-bit rows and zero-extends their BYTES - per
+// row it consumes `size` bytes: the low and high bytes of half of the samples, for size >= 16 bytes [32 g, 32 g + 8) and [32 g + 16, 32 g + 24) of every
+// 16-sample group g; oracle/hmr_oracle.c ora_modified_variance).  The source window holds the samples themselves: byte b of a row is sample b / 2 for even b, 0 for odd b
+// (a sample's high byte).
+template <class G, class S>
+HENC_PRIM uint32_t blk_modified_variance(const G &g, const S *p, int stride, int size, int modif)
+{
+	PRIM_T0();
+	const int l = ilog2i(size), total = size * size;
+	auto byte_at = [&](int i) -> int {
+		const int j = i >> l, k = i & (size - 1);
+		const int off = size < 16 ? k : (k >> 4) * 32 + ((k >> 3) & 1) * 16 + (k & 7);
+		const int v = (int)p[j * stride + (off >> 1)];
+		return (off & 1) ? ((v >> 8) & 255) : (v & 255);
+	};
+	uint32_t acc = 0;
+	for (int i = g.tid; i < total; i += g.n) acc += (uint32_t)byte_at(i);
+	const int avg = (int)(g.sum(acc) / (uint32_t)total);
+	acc = 0;
+	for (int i = g.tid; i < total; i += g.n) {
+		const int16_t d = (int16_t)(1 + (int16_t)((int16_t)(byte_at(i) - avg) * (int16_t)modif));
+		acc += (uint32_t)((int32_t)d * d);
+	}
+	{ const auto prim_ret_ = g.sum(acc); PRIM_END(PP_SSD); return prim_ret_; }
+}
+
 // sum of squares of a block (ssd16b against the reference's zero row, hmr_motion_inter.c:94)
 template <class G>
 HENC_PRIM uint32_t blk_ssq(const G &g, const int16_t *a, int as, int n)

@@ -238,6 +238,8 @@ struct Work {
 	int16_t sub_tmp[(64 + 8) * 72];        // checker build: first interpolation stage of a sub-pel candidate / two-stage motion compensation
 #endif
 	MvCandList amvp, merge_cands, search_cands;
+	uint32_t rsplit[11];                   // performance_mode 3: cu_partition_info_t::recursive_split of the CTU's 341 nodes, one bit each (analyse_recursive_info, enc_ctu.h)
+	uint32_t pad_rsplit_;
 	alignas(8) int64_t srch_sads[5];       // a round of the intra mode search: its candidates and their SADs (indexed at run time: as locals they lived in private memory)
 	int32_t srch_modes[6];
 #if !defined(__HIPCC__)

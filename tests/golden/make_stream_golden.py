@@ -76,6 +76,13 @@ CASES = [
     ("832x480_cbr1500_perf1_wpp_rows", 832, 480, 6, {"bitrate_mode": 1, "bitrate": 1500, "perf": 1, "wpp": 8}),
     ("416x240_cbr300_nosao_wpp_rows", 416, 240, 6, {"bitrate_mode": 1, "bitrate": 300, "sao": 0, "wpp": 4}),
     ("1920x1080_cbr5000_perf1_wpp_rows", 1920, 1080, 6, {"bitrate_mode": 1, "bitrate": 5000, "perf": 1, "wpp": 17}),
+    # performance_mode 3 (PERF_FASTEST_COMPUTATION): inter CUs from depth 2 on, and in the intra walk (I pictures, the CTUs after a scene cut) the variance
+    # pre-analysis (analyse_recursive_info_cu, hmr_motion_intra.c:1660) decides which partitions are evaluated as a whole and where the recursion ends
+    ("416x240_perf3", 416, 240, 5, {"perf": 3}),
+    ("416x240_perf3_wpp_rows", 416, 240, 5, {"perf": 3, "wpp": 4}),
+    ("416x240_force_intra_perf3_wpp_rows", 416, 240, 3, {"perf": 3, "force_intra": 1, "wpp": 4}),
+    ("416x240_scene_cut_perf3_wpp_rows", 416, 240, 26, {"perf": 3, "cut_at": 23, "wpp": 4}),
+    ("832x480_qp26_perf3_rdfull_wpp_rows", 832, 480, 3, {"perf": 3, "qp": 26, "rd": 1, "wpp": 8}),
     ("3840x2160_cbr20000_perf1_wpp32", 3840, 2160, 4, {"bitrate_mode": 1, "bitrate": 20000, "perf": 1, "wpp": 32}),       # BASELINE.json configs[2]: 2160p IPPP, CBR 20000 kbps, performance_mode 1       # BASELINE.json configs[3]: 2160p, n_enc_engines = 8     # the 2160p picture of the metric with the reference's maximum of 32 WPP threads for 34 CTU rows (I + P + P)
 ]
 

@@ -238,7 +238,7 @@ def random_case(rng, max_ctus, gpu=False, max_cols=14, max_rows=9, threads_only=
         if wpp > 1:
             keys["wpp"] = wpp
         keys["qp"] = rng.choice([12, 17, 22, 27, 30, 32, 32, 35, 38, 42, 47, 51])
-        keys["perf"] = rng.choice([0, 1, 2, 2])
+        keys["perf"] = rng.choice([0, 1, 2, 2, 3])
         if rng.random() < 0.3:
             keys["sign_hiding"] = 0
         if rng.random() < 0.4:

@@ -46,13 +46,18 @@ def main():
             if tot:
                 d["l2_hit_rate"] = round(k["TCC_HIT_sum"] / tot, 4)
         if name.startswith("k_encode_ctus") or name.startswith("k_encode_pool"):
-            d["note"] = (f"rocprofv3 --pmc passes of `{cmd}`; sums over all launches of the kernel (three wavefronts per workgroup: the row worker and two "
-                         "helpers, whose polling counts as waiting); SQ cycle counters in quad-cycles")
+            d["note"] = (f"rocprofv3 --pmc passes of `{cmd}`; sums over all launches of the kernel (two wavefronts per workgroup: the row worker and its "
+                         "helper, whose polling counts as waiting); SQ cycle counters in quad-cycles")
             if k.get("SQ_WAVE_CYCLES"):
                 d["valu_share_of_issue"] = round(k.get("SQ_INSTS_VALU", 0) / max(k.get("SQ_INSTS_VALU", 0) + k.get("SQ_INSTS_SALU", 0), 1), 3)
         k["derived"] = d
     if frames:
         kernels["frames_encoded_by_k_encode_pool"] = frames
+    try:      # the build the passes ran on (the tree the GPU box was given: HEAD when the working tree is clean)
+        import subprocess
+        kernels["build_commit"] = subprocess.run(["git", "-C", os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        kernels["build_commit"] = None
     json.dump(kernels, sys.stdout, indent=1)
     print()
 
