@@ -6,7 +6,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libhomer_gpu.so")
-SOURCES = ["tables.cpp", "context.cpp", "dropin.cpp", "cmdlist.cpp", "k_pixel.hip", "k_transform.hip", "k_intra.hip", "k_interp.hip", "k_loop.hip", "k_motion.hip", "k_tuchain.hip", "k_intrasearch.hip", "k_tree.hip", "k_chromasearch.hip", "k_saooffsets.hip", "k_subpel.hip", "k_probe.hip", "k_encode.hip"]
+SOURCES = ["tables.cpp", "context.cpp", "dropin.cpp", "cmdlist.cpp", "k_pixel.hip", "k_transform.hip", "k_intra.hip", "k_interp.hip", "k_loop.hip", "k_motion.hip", "k_tuchain.hip", "k_intrasearch.hip", "k_tree.hip", "k_chromasearch.hip", "k_saooffsets.hip", "k_subpel.hip", "k_probe.hip", "k_primtest.hip", "k_encode.hip"]
 # -ffp-contract=off: the few double-precision cost terms must round exactly like the reference's x87-free SSE2 code
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip"] + (["-DHENC_PROFILE"] if os.environ.get("HENC_PROFILE") else []) + os.environ.get("HENC_EXTRA_FLAGS", "").split()
 

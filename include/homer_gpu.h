@@ -711,6 +711,30 @@ int hmr_gpu_probe_valu_issue(hmr_gpu_ctx *ctx, int waves_per_simd, int dependent
 /* the same for one instruction kind: op 0 v_mad_u32_u24, 1 v_add_u32, 2 v_mov_b32, 3 v_perm_b32, 4 s_add_u32 (scalar unit) */
 int hmr_gpu_probe_issue(hmr_gpu_ctx *ctx, int op, int waves_per_simd, int dependent, double *wave_instr_per_s, double *ms);
 
+/* ------------------------------------------------------------------------------------------------
+ * 15. Test aid: the block primitives the frame encoder's CTU walk runs (homerhevc_amd/csrc/enc/enc_prims.h), one call at a time
+ *     k_encode_pool does not go through the table kernels of sections 1 - 7: its worker wavefront runs SPMD primitives of its own on data in LDS.  These entries run exactly
+ *     those primitives - one wavefront, as in the walk - behind the flat signatures of the table functions they restate (hmr_private.h:1063-1092; the same argument meaning as
+ *     hmr_gpu_sad ... hmr_gpu_inv_quant above), so that the parity sweep of the table kernels also holds the walk's primitives to the oracle (tests/test_gpu_prims.py).
+ *     hmr_gpu_prim_bytes(1): sample operands the worker keeps as bytes (source block, prediction window) are narrowed first, i.e. the byte instantiations run - for
+ *     calls whose samples are 0 .. 255; hmr_gpu_prim_sad then is the motion search's multi-candidate byte SAD.  Host pointers, synchronous, default context.
+ * ------------------------------------------------------------------------------------------------ */
+void hmr_gpu_prim_bytes(int on);
+uint32_t hmr_gpu_prim_sad(int16_t *src, uint32_t src_stride, int16_t *pred, uint32_t pred_stride, int size);
+uint32_t hmr_gpu_prim_ssd16b(int16_t *src, uint32_t src_stride, int16_t *pred, uint32_t pred_stride, int size);
+void hmr_gpu_prim_predict(int16_t *orig, int orig_stride, int16_t *pred, int pred_stride, int16_t *residual, int residual_stride, int size);
+void hmr_gpu_prim_reconst(int16_t *pred, int pred_stride, int16_t *residual, int residual_stride, int16_t *decoded, int decoded_stride, int size);
+uint32_t hmr_gpu_prim_modified_variance(int16_t *p, int size, int stride, int modif);
+void hmr_gpu_prim_intra_planar(int16_t *prediction, int pred_stride, int16_t *adi_pred_buff, int adi_size, int cu_size);
+void hmr_gpu_prim_intra_angular(int16_t *prediction, int pred_stride, int16_t *adi_pred_buff, int adi_size, int cu_size, int cu_mode, int is_luma);
+void hmr_gpu_prim_fill_reference_samples(int16_t *decoded_corner, int stride, int n, int left, int top, int bottom_left, int top_right, int bl_size, int tr_size, int16_t *adi);
+void hmr_gpu_prim_adi_filter(int16_t *adi, int16_t *out, int adi_size, int n, int strong_enabled);
+void hmr_gpu_prim_transform(int16_t *block, int16_t *coeff, int block_stride, int n, int is_dst);
+void hmr_gpu_prim_itransform(int16_t *block, int16_t *coeff, int block_stride, int n, int is_dst);
+void hmr_gpu_prim_quant(int16_t *src, int16_t *dst, int16_t *delta_u, int scan_mode, int depth, int comp, int is_intra, int slice_is_intra, int sign_hiding, int *ac_sum,
+			int cu_size, int per, int rem);
+void hmr_gpu_prim_inv_quant(int16_t *src, int16_t *dst, int depth, int comp, int is_intra, int cu_size, int per, int rem);
+
 #ifdef __cplusplus
 }
 #endif
