@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Build container: copy the summaries a profiling call left in gpurun_out/ into profiles/ (tracked) and stamp them with the commit they were measured on - the GPU box
+gets a snapshot of the tree without .git, so the tools there cannot know it.     usage: tools/keep_profiles.py r05 [commit]"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+kept = []
+for name in sorted(os.listdir(src)):
+    if not name.startswith(tag + "_") or not name.endswith((".json", ".csv", ".md")):
+        continue
+    path = os.path.join(src, name)
+    if name.endswith(".json"):
+        try:
+            text = open(path).read().strip()
+            d = json.loads(text.splitlines()[-1] if name.endswith(("bench.json", "under_rocprof.json")) else text)
+        except (ValueError, IndexError):
+            continue
+        if isinstance(d, dict):
+            d["build_commit"] = commit
+        json.dump(d, open(os.path.join(dst, name), "w"), indent=1)
+    else:
+        shutil.copy(path, os.path.join(dst, name))
+    kept.append(name)
+print("\n".join(kept))
