@@ -209,7 +209,7 @@ def valu_issue_probe(lib, device):
     lib.hmr_gpu_destroy(ctx)
     return {"kernel": "k_probe_valu (64 instructions of one kind per round, no memory access in the loop)", "rows": rows,
             "note": "independent instructions reach the guide's ceiling from one wavefront per SIMD on; a dependent chain issues one instruction per the ALU's latency - "
-                    "k_encode_pool's workers are such chains, 1.5 wavefronts per SIMD"}
+                    "k_encode_pool's workers are such chains, two wavefronts per SIMD (a worker and a helper, or two workers' wavefronts)"}
 
 
 def subpel_planes_roofline(lib, torch, width, height, reps=20):
@@ -528,7 +528,7 @@ def main():
                 ib["one_wavefront_per_simd_peak_per_s"] = one
                 ib["one_dependent_chain_per_simd_per_s"] = dep
                 ib["verdict"] = ("plain vector instructions (v_add_u32, v_mov_b32) issue every 2.5 cycles per SIMD with two wavefronts on it, v_mad_u32_u24 / v_perm_b32 every 5; ONE wavefront gets an "
-                                 "instruction every 5 cycles and a dependent chain one every 8.3: at 1.5 wavefronts per SIMD the workers are bound by their own issue latency and the memory "
+                                 "instruction every 5 cycles and a dependent chain one every 8.3: at two wavefronts per SIMD (eight per CU: four workers and their helpers) the workers are bound by their own issue latency and the memory "
                                  "trips between instructions, not by the SIMDs' throughput")
             else:
                 out["roofline"]["issue_probe"] = probe

@@ -19,7 +19,10 @@ for name in sorted(os.listdir(src)):
     if name.endswith(".json"):
         try:
             text = open(path).read().strip()
-            d = json.loads(text.splitlines()[-1] if name.endswith(("bench.json", "under_rocprof.json")) else text)
+            try:
+                d = json.loads(text)
+            except ValueError:
+                d = json.loads(text.splitlines()[-1])      # (a bench line behind other output)
         except (ValueError, IndexError):
             continue
         if isinstance(d, dict):
