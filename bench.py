@@ -538,6 +538,12 @@ def main():
             out["multi_stream_batched"] = multi_stream_child(local, a.workload, a.batch, batched=True)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(width, height, {k: v for k, v in keys.items() if k != "wpp"}, a.cpu_frames)
+            # the host's figures beside the other sections too: the same three measurements (one process, one thread per CTU row, a process per usable core) of the
+            # compiled reference on that section's configuration, on a few frames (2160p: 6; all-intra RD_FULL: 3)
+            for section, wl, frames in (("at_2160p", "cfg2-2160p-encode", 6), ("cfg3_2160p_cbr", "cfg3-2160p-cbr", 6), ("cfg5_2160p_intra_rdfull", "cfg5-2160p-intra-rdfull", 3)):
+                if section in out:
+                    w2, h2, k2 = WORKLOADS[wl]
+                    out[section]["cpu_baseline"] = cpu_baseline(w2, h2, {k: v for k, v in k2.items() if k != "wpp"}, frames)
         print(json.dumps(out))
         # a run whose output differs from the reference's is a failed run, whatever it measured: every section that checked its stream must have matched
         bad = [name for name, sec in [("headline", out)] + [(k, v) for k, v in out.items() if isinstance(v, dict)] if sec.get("stream_matches_reference") is False]

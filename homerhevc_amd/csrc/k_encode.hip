@@ -137,6 +137,9 @@ constexpr int workers_per_cu(size_t lds_bytes)
 	return by_lds < by_waves ? by_lds : by_waves;
 }
 constexpr int WORKERS_PER_CU = workers_per_cu(LDS_BYTES - LDS_RD);
+#if !defined(HENC_PROFILE) && HENC_WAVES_PER_EU == 2 && HENC_NHELP == 1
+static_assert(WORKERS_PER_CU == 4, "a worker's LDS (without the RD_FULL arrays) has to stay within a quarter of the CU's: 32 granules of 1280 bytes");
+#endif
 #if defined(HENC_PRINT_LDS)
 static_assert(LDS_BYTES - LDS_RD == 0 && LDS_WORK == 0 && LDS_NODES == 0 && LDS_BOX == 0 && sizeof(PostScratch) == 0 && WORKERS_PER_CU == 0, "sizes");
 #endif
