@@ -515,7 +515,7 @@ HENC_INLINE void get_merge_candidates(Enc &__restrict__ e, int ni, MvCandList &l
 // ---- inter TUs ---------------------------------------------------------------------------------------------------------
 // encode_inter_cu :40 (comp 0) / encode_inter_cu_chroma :133: DCT + quant, keep-or-drop decision in the residual domain, reconstruction
 template <class G>
-HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int comp, int depth, int part_size_type, int *curr_sum, uint32_t *raw_ssq = nullptr)
+HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int comp, int depth, int part_size_type, int *curr_sum, uint32_t *raw_ssq = nullptr, int scratch_off = 0)
 {
 	HENC_ENC_IN_LDS(e);
 	Work &w = *e.w;
@@ -533,14 +533,16 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 	const int off = is_y ? (q.abs_index << 4) : ((q.abs_index << 4) >> 2);
 	const pred_t *pred = pred_ptr(w, comp) + y * cs + x;
 	const src_t *orig = curr_ptr(w, comp) + y * cs + x;      // (the residual source - prediction is formed where it is read: the worker keeps no residual window)
-	int16_t *quant = tq_ptr(w, wnd, comp) + off, *iquant = iq_slot(w, comp, off, e.on_helper);
+	// (scratch_off: the group's share of the scratch buffers when two groups of a wavefront run a TU each - PairGrp, both chroma planes of a small TU on the helper)
+	int16_t *quant = tq_ptr(w, wnd, comp) + off, *iquant = iq_slot(w, comp, off, e.on_helper) + scratch_off;
+	int16_t *const scratch_a = e.scratch_a + scratch_off, *const scratch_b = e.scratch_b + scratch_off;
 	int16_t *dec = dec_ptr(w, wnd, comp) + y * ds + x;
 	// The chain runs in the worker's fast memory: coefficients in scratch_a, rounding remainders in scratch_b, the levels in the block's slot of the
 	// dequantised-coefficient buffer (dequantised in place afterwards), the reconstructed residual in scratch_b (the reference's separate window, which
 	// nothing else reads); only the final levels and the reconstruction go to the windows in HBM.
-	int16_t *rdec = e.scratch_b;
-	tr_forward(g, HENC_FT(e), e.T, orig, cs, pred, cs, e.scratch_a, e.scratch_b, n, 0);
-	int sum = quantize(g, HENC_FT(e), e.T, e.scratch_a, iquant, e.scratch_b, SCAN_DIAG, curr_depth, comp, 0, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
+	int16_t *rdec = scratch_b;
+	tr_forward(g, HENC_FT(e), e.T, orig, cs, pred, cs, scratch_a, scratch_b, n, 0);
+	int sum = quantize(g, HENC_FT(e), e.T, scratch_a, iquant, scratch_b, SCAN_DIAG, curr_depth, comp, 0, e.f->slice_type == SLICE_I, e.seq->sign_hiding, n, per, rem);
 	nd.inter_cbf[comp] = (sum ? 1 : 0) << (original_depth - depth);
 	if (is_y) nd.inter_tr_idx = original_depth - depth;
 	uint32_t ssd;
@@ -549,7 +551,7 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 		const uint32_t raw_zero = blk_ssd(g, orig, cs, pred, cs, n);
 		if (raw_ssq) *raw_ssq = raw_zero;
 		dequantize(g, HENC_FT(e), e.T, iquant, iquant, curr_depth, comp, 0, n, per, rem);
-		tr_inverse(g, HENC_FT(e), e.T, rdec, n, iquant, e.scratch_a, n, 0);
+		tr_inverse(g, HENC_FT(e), e.T, rdec, n, iquant, scratch_a, n, 0);
 		const uint32_t raw = blk_ssd_diff(g, orig, cs, pred, cs, rdec, n, n);
 		uint32_t ssd_zero;
 		if (is_y) { ssd_zero = raw_zero; ssd = raw; }

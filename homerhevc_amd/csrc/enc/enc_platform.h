@@ -86,6 +86,33 @@ struct WaveGrp {
 	}
 };
 
+// Two groups of 32 lanes in one wavefront, each with a block of its own (the helper's two chroma planes of a small TU: a 4 x 4 or 8 x 8 chain keeps 4 - 16 lanes busy,
+// and two of them one after the other made the helper the slower side of a small CU).  The halves run the same code on different operands; where their control flow
+// parts (one plane has levels, the other has not) the hardware masks the lanes, and nothing in the group operations crosses the halves: sums add up a half's two
+// 16-lane rows, the ballot is the half's 32 bits.
+struct PairGrp {
+	int tid, half;           // lane within the half, the half (0 / 1)
+	static constexpr int n = 32;
+	__device__ __forceinline__ void sync() const
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+	__device__ __forceinline__ uint32_t sum(uint32_t v) const
+	{
+		int x = (int)v;
+		x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+		x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+		x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+		x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // lane 15 of every 16-lane row: the row total
+		const int lo = __builtin_amdgcn_readlane(x, 15) + __builtin_amdgcn_readlane(x, 31), hi = __builtin_amdgcn_readlane(x, 47) + __builtin_amdgcn_readlane(x, 63);
+		return (uint32_t)(half ? hi : lo);
+	}
+	__device__ __forceinline__ uint64_t ballot(bool p) const { const uint64_t m = __ballot(p); return half ? m >> 32 : m & 0xffffffffull; }
+	__device__ __forceinline__ uint32_t any(bool p) const { return ballot(p) != 0; }
+};
+
 #endif
 
 // The row worker's state - its Work, the CTU's nodes and record, the geometry, the sequence / frame parameters, the helper mailbox and scratch - lives in

@@ -1082,7 +1082,7 @@ HENC_HD void sbh_pass(const G &g, const int16_t *src, int16_t *dst, const int16_
 {
 	const int ngroups = total >> 4;
 	// the last group holding a level (in scan order) starts its walk at its last level
-	if (G::n >= 64) {
+	if (G::n >= 32) {      // (a wavefront, or a half of one with a block of at most 16 x 16: a coefficient group per lane)
 		// one group per lane: gather once, find the last non-empty group with a ballot, apply where there is anything to hide a sign in
 		SbhGroup q;
 		const int cg = g.tid;

@@ -172,6 +172,15 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 		case HJOB_INTER_TU: {
 			int sum = 0;
 			uint32_t raw = 0;
+			if (NHELP == 1 && a[1] == COMP_UV && e.geo[a[0]].size_chroma <= 8) {
+				// both planes of a small TU side by side, a half of the wavefront each (enc_platform.h PairGrp): one after the other they made the helper the
+				// slower side of every 8 x 8 and 16 x 16 CU (two chains against the worker's one)
+				const PairGrp pg{g.tid & 31, g.tid >> 5};
+				const uint32_t d = encode_inter_tu(pg, e, a[0], COMP_U + pg.half, a[2], a[3], &sum, &raw, pg.half * 512);
+				r0 = (uint32_t)__builtin_amdgcn_readlane((int)d, 0); r1 = (uint32_t)__builtin_amdgcn_readlane(sum, 0); r2 = (uint32_t)__builtin_amdgcn_readlane((int)raw, 0);
+				r3 = (uint32_t)__builtin_amdgcn_readlane((int)d, 32); r4 = (uint32_t)__builtin_amdgcn_readlane(sum, 32); r5 = (uint32_t)__builtin_amdgcn_readlane((int)raw, 32);
+				break;
+			}
 			r0 = encode_inter_tu(g, e, a[0], a[1] == COMP_UV ? COMP_U : a[1], a[2], a[3], &sum, &raw);
 			r1 = (uint32_t)sum;
 			r2 = raw;

@@ -76,6 +76,8 @@ CASES = [
     ("832x480_cbr1500_perf1_wpp_rows", 832, 480, 6, {"bitrate_mode": 1, "bitrate": 1500, "perf": 1, "wpp": 8}),
     ("416x240_cbr300_nosao_wpp_rows", 416, 240, 6, {"bitrate_mode": 1, "bitrate": 300, "sao": 0, "wpp": 4}),
     ("1920x1080_cbr5000_perf1_wpp_rows", 1920, 1080, 6, {"bitrate_mode": 1, "bitrate": 5000, "perf": 1, "wpp": 17}),
+    # a very low QP without WPP: the picture is ONE sub-stream of several hundred bytes per CTU (the device's entropy stage writes it into the whole allocation, not a row's share)
+    ("416x240_qp4", 416, 240, 2, {"qp": 4}),
     # performance_mode 3 (PERF_FASTEST_COMPUTATION): inter CUs from depth 2 on, and in the intra walk (I pictures, the CTUs after a scene cut) the variance
     # pre-analysis (analyse_recursive_info_cu, hmr_motion_intra.c:1660) decides which partitions are evaluated as a whole and where the recursion ends
     ("416x240_perf3", 416, 240, 5, {"perf": 3}),

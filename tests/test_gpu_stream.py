@@ -61,7 +61,7 @@ def encode(lib, case):
 
 
 @pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra_period1", "832x480", "392x136_qp22_clip931814", "400x104_qp22_perf0_nosao_wpp_rows_clip657909", "1920x1080_cfg2", "1280x720_intra_period1", "1280x720_force_intra", "416x240_force_intra", "416x240_force_intra_wpp_rows", "416x240_force_intra_rdfull_wpp_rows", "416x240_force_intra_rdfull_tr4_wpp_rows", "328x264_force_intra_rdfull_tr3_perf0_wpp_rows", "416x240_rdfull_wpp_rows", "832x480_rdfull_tr3_wpp_rows", "3840x2160_cfg2", "200x136_scene_cut", "416x240_scene_cut", "416x240_wpp_rows", "416x240_scene_cut_wpp_rows", "1920x1080_cfg2_wpp_rows", "832x480_wpp_rows", "416x240_qp22_perf0_wpp_rows", "416x240_nosao_wpp_rows", "328x264_wpp3", "200x136_wpp2", "416x240_eng3_wpp_rows", "832x480_eng2_wpp_rows", "416x240_scene_cut_eng2_wpp_rows", "1920x1080_cfg2_eng2", "1920x1080_cfg2_eng3", "3840x2160_cfg2_eng8", "3840x2160_cfg2_wpp32", "3840x2160_force_intra_rdfull_tr4",
-                                  "416x240_cbr400_perf1_wpp_rows", "416x240_vbr400_wpp_rows", "832x480_cbr1500_perf1_wpp_rows", "416x240_cbr300_nosao_wpp_rows", "416x240_perf3", "416x240_perf3_wpp_rows", "416x240_force_intra_perf3_wpp_rows", "416x240_scene_cut_perf3_wpp_rows", "832x480_qp26_perf3_rdfull_wpp_rows", "1920x1080_cbr5000_perf1_wpp_rows",
+                                  "416x240_cbr400_perf1_wpp_rows", "416x240_vbr400_wpp_rows", "832x480_cbr1500_perf1_wpp_rows", "416x240_cbr300_nosao_wpp_rows", "416x240_qp4", "416x240_perf3", "416x240_perf3_wpp_rows", "416x240_force_intra_perf3_wpp_rows", "416x240_scene_cut_perf3_wpp_rows", "832x480_qp26_perf3_rdfull_wpp_rows", "1920x1080_cbr5000_perf1_wpp_rows",
                                   "3840x2160_cbr20000_perf1_wpp32"])
 def test_device_stream_is_byte_identical_to_the_reference(gpu, case):
     stream, recon = encode(gpu, case)
@@ -117,3 +117,39 @@ def test_batch_of_sequences_in_one_launch(gpu):
     e_arr, slots, ptrs, caps, got = (C.c_void_p * 1)(enc), (C.c_int * 1)(0), (C.c_char_p * 1)(C.cast(bufs[0], C.c_char_p)), (C.c_long * 1)(len(bufs[0])), (C.c_long * 1)()
     assert lib.hmr_gpu_enc_encode_batch(e_arr, 1, slots, None, ptrs, caps, got) == -3
     lib.hmr_gpu_enc_destroy(enc)
+
+
+def test_stale_window_count_is_the_same_frame_by_frame_and_in_a_batch(gpu):
+    """hmr_gpu_enc_stale_predictions (quirk Q12: merge candidates evaluated on what the thread's prediction window held) is the API's only indicator that byte identity may
+    not hold: the batch call must count a picture once (it used to count it twice) and agree with the frame-by-frame count of the same clip - which has such evaluations."""
+    lib = gpu
+    lib.hmr_gpu_enc_load_source.argtypes = [C.c_void_p, C.c_int] + [C.c_char_p] * 3
+    lib.hmr_gpu_enc_encode_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    lib.hmr_gpu_enc_stale_predictions.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    case = "400x104_qp22_perf0_nosao_wpp_rows_clip657909"
+    g = GOLD[case]
+    keys = dict(g["keys"])
+    seed = keys.pop("clip_seed")
+    clip = list(ec.clip_frames(g["width"], g["height"], g["frames"], None, seed))
+    totals = []
+    for batch in (False, True):
+        enc = C.c_void_p()
+        cfg = ec.default_cfg(g["width"], g["height"], **keys)
+        assert lib.hmr_gpu_enc_create(lib._ctx, C.byref(cfg), C.byref(enc)) == 0, lib.hmr_gpu_last_error()
+        buf, n = C.create_string_buffer(1 << 20), C.c_long()
+        stream = b""
+        for f, planes in enumerate(clip):
+            if batch:
+                assert lib.hmr_gpu_enc_load_source(enc, f, *planes) == 0
+                got = (C.c_long * 1)()
+                assert lib.hmr_gpu_enc_encode_batch((C.c_void_p * 1)(enc), 1, (C.c_int * 1)(f), None, (C.c_char_p * 1)(C.cast(buf, C.c_char_p)), (C.c_long * 1)(len(buf)), got) == 0, lib.hmr_gpu_last_error()
+                stream += buf.raw[:got[0]]
+            else:
+                assert lib.hmr_gpu_enc_encode(enc, *planes, 0, buf, len(buf), C.byref(n), None) in (1, 2), lib.hmr_gpu_last_error()
+                stream += buf.raw[:n.value]
+        last, tot = C.c_long(), C.c_long()
+        assert lib.hmr_gpu_enc_stale_predictions(enc, C.byref(last), C.byref(tot)) == 0
+        totals.append(tot.value)
+        assert hashlib.md5(stream).hexdigest() == g["stream_md5"]
+        lib.hmr_gpu_enc_destroy(enc)
+    assert totals[0] == totals[1] and totals[0] > 0, totals
