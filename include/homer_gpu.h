@@ -619,10 +619,11 @@ int hmr_gpu_enc_load_source(hmr_gpu_enc *enc, int slot, const uint8_t *y, const 
 int hmr_gpu_enc_encode_source(hmr_gpu_enc *enc, int slot, int image_type, uint8_t *stream, long cap, long *stream_bytes, uint8_t *recon);
 /* one frame of each of n sequences with ONE launch for all their CTU stages: encs[i] encodes its resident picture slots[i] (image_types may be NULL: automatic)
  * into streams[i] (capacity caps[i], size stream_bytes[i]).  The encoders use the row-per-thread schedule (wfpp_num_threads > 1) and the same device; the access
- * units are those hmr_gpu_enc_encode_source gives one by one.  The launch is a pool of persistent row workers (two per CU) that claim CTUs of any of the n
- * pictures whose wavefront step is open (k_encode_pool); n is at most 256, a few hundred pictures' worth of CTU rows saturate the pool (120 at 1080p).  A worker
- * never waits for a CTU that is not already running, so the launch does not depend on all its workgroups being resident; a watchdog (HENC_WATCHDOG_S, 120 s by
- * default) makes a launch that finds nothing to do for that long return HMR_GPU_ERR_HIP instead of hanging. */
+ * units are those hmr_gpu_enc_encode_source gives one by one.  The launch is a pool of persistent row workers (four per CU; as many as the pictures can keep busy)
+ * that claim CTUs of any of the n pictures whose wavefront step is open (k_encode_pool); n is at most 256, a few hundred pictures' worth of CTU rows saturate the pool
+ * (120 at 1080p, 256 keep it busy through the pictures' ramps).  A worker never waits for a CTU that is not already running, so the launch does not depend on all its
+ * workgroups being resident; a watchdog (HENC_WATCHDOG_S seconds, fractions allowed, 120 by default) makes a launch in which a worker has found nothing to do - no CTU
+ * to decide, no post-decision task - for that long SINCE IT LAST DID return HMR_GPU_ERR_HIP instead of hanging. */
 int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes);
 /* the same, pipelined: call k launches the frames slots[] and delivers the access units of call k - 1's frames (stream_bytes[i] = 0 on the first call), whose download
  * and entropy coding run while the device is busy with call k's CTU stage - a frame's successor needs its reconstruction and its distortion statistic, not its bytes
@@ -671,7 +672,10 @@ long hmr_gpu_enc_reference_bytes(hmr_gpu_enc *enc);
  * before, NULL at the sequence start) in one launch of the CTU kernel: frame j predicts from the final picture of frame j - 1 where it lies (no copy) and from its phase
  * planes, which the same launch produces CTU by CTU; a wavefront step of frame j starts when the part of that picture its vectors can reach is ready.  Same streams as frame
  * by frame (the engine turnstile's interleaving, oracle/ref_ctudump.c).  Returns HMR_GPU_ERR_ARG when two frames of the chain both detect a scene change (sequentially the
- * first switches the detection off for the second): repeat those frames one by one.
+ * first switches the detection off for the second): repeat those frames one by one.  A call that is refused while its frames are being set up (wrong engine for a frame, a P
+ * frame without the object that holds the picture before it, an I frame too early in the chain) leaves every object as it found it.  Chains of more than one frame are refused
+ * under rate control and with rd_mode RD_FULL: both read entropy-coder state of the frame before (hmr_rate_control.c:266-282, the coder objects' context states), which a
+ * chain's frames, started from a predicted state, do not have - encode those sequences frame by frame.
  * More frames than engines (n up to 32): the reference's engine k takes frame t + num_enc_engines when its frame t is finished.  hmr_gpu_enc_create_engine_twin makes
  * another object for the same engine - it shares the engine's persistent state (CTU records, the WPP threads' mode buffers) with `of` and has its own pictures, filter state
  * and sub-stream buffers; encs[j] for j >= num_enc_engines has to be a twin of encs[j - num_enc_engines] (or the other way round).  The launch then starts an engine's next
