@@ -637,8 +637,8 @@ int hmr_gpu_enc_last_stats(hmr_gpu_enc *enc, int *passes, int *ctu_encodes, floa
  * (more than 80 samples beyond the frame) is evaluated by the reference on whatever its thread's prediction window holds (check_rd_cost_merge_2nx2n leaves out
  * the motion compensation and nothing else, hmr_motion_inter.c:3651).  The window travels with the thread here too (the stream is the
  * reference's when its content came from block writes), but the reference's SSE predictors also leave samples outside the blocks they predict (e.g. 255s right of
- * a 4 x 4 angular chroma block), which are not reproduced.  *last_picture: such evaluations in the last picture encoded through this object (-1: not counted -
- * wfpp_num_threads = 1), *all_pictures: since the object was created.  0 = the quirk did not occur (every clip of bench.py; 12 of about 3000 random fuzz cases
+ * a 4 x 4 angular chroma block), which are not reproduced.  *last_picture: such evaluations in the last picture encoded through this object (-1: none encoded
+ * yet; counted in both thread orders), *all_pictures: since the object was created.  0 = the quirk did not occur (every clip of bench.py; 12 of about 3000 random fuzz cases
  * had it, one of them differs: profiles/r04_encoder_fuzz.md).  Either pointer may be NULL. */
 int hmr_gpu_enc_stale_predictions(hmr_gpu_enc *enc, long *last_picture, long *all_pictures);
 /* profiling build (-DHENC_PROFILE): per-row phase timers, [ctu rows][12] */

@@ -153,3 +153,28 @@ def test_stale_window_count_is_the_same_frame_by_frame_and_in_a_batch(gpu):
         assert hashlib.md5(stream).hexdigest() == g["stream_md5"]
         lib.hmr_gpu_enc_destroy(enc)
     assert totals[0] == totals[1] and totals[0] > 0, totals
+
+
+def test_stale_window_count_is_kept_in_the_single_thread_order_too(gpu):
+    """wfpp_num_threads = 1 goes through the other CTU kernel (k_encode_ctus); the counter is read there as well: -1 only before the first picture, then the picture's count
+    (0 for this clip, whose stream is the reference's), and the total is the sum of the pictures' counts."""
+    lib = gpu
+    lib.hmr_gpu_enc_stale_predictions.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    g = GOLD["392x136_qp22_clip931814"]
+    keys = dict(g["keys"])
+    seed = keys.pop("clip_seed")
+    enc = C.c_void_p()
+    cfg = ec.default_cfg(g["width"], g["height"], **keys)
+    assert cfg.wfpp_num_threads == 1
+    assert lib.hmr_gpu_enc_create(lib._ctx, C.byref(cfg), C.byref(enc)) == 0, lib.hmr_gpu_last_error()
+    last, tot = C.c_long(7), C.c_long(7)
+    assert lib.hmr_gpu_enc_stale_predictions(enc, C.byref(last), C.byref(tot)) == 0 and (last.value, tot.value) == (-1, 0)
+    buf, n, stream, counts = C.create_string_buffer(1 << 20), C.c_long(), b"", []
+    for planes in ec.clip_frames(g["width"], g["height"], g["frames"], None, seed):
+        assert lib.hmr_gpu_enc_encode(enc, *planes, 0, buf, len(buf), C.byref(n), None) in (1, 2), lib.hmr_gpu_last_error()
+        stream += buf.raw[:n.value]
+        assert lib.hmr_gpu_enc_stale_predictions(enc, C.byref(last), C.byref(tot)) == 0
+        counts.append(last.value)
+        assert last.value >= 0 and tot.value == sum(counts)
+    assert hashlib.md5(stream).hexdigest() == g["stream_md5"]
+    lib.hmr_gpu_enc_destroy(enc)
