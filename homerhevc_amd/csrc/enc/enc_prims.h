@@ -970,11 +970,181 @@ HENC_HD void tr_inverse_n(const G &g, const int16_t *Mt, int16_t *block, int bs,
 	g.sync();
 }
 
+#if defined(__HIPCC__) && !defined(HENC_NO_MFMA_TRANSFORM)
+// ---- the transforms on the matrix cores (device, one whole wavefront) -------------------------------------------------------------------------------
+// A stage is a matrix product, and the product of two matrices of small integers is exact in the matrix cores' binary16 x binary16 -> binary32 arithmetic
+// as long as every partial sum stays below 2^24: the bases are integers of at most 90, a residual is within +-255, and a 16-bit stage input is split
+// into its high byte (-128 .. 127) and low byte (0 .. 255), each with an accumulator of its own (at most 32 x 255 x 90 < 2^20), put together as integers.
+// The rounding, shift and 16-bit saturation between the stages are the reference's, on integers.  v_mfma_f32_16x16x16_f16 holds A[lane % 16][4 (lane / 16) + e],
+// B[4 (lane / 16) + e][lane % 16] and D[4 (lane / 16) + r][lane % 16]: a stage's result IS the next stage's operand (as B, or - read as the transposed
+// matrix - as A), so the intermediate never leaves the registers, and the last result has four consecutive outputs of one row per lane (one 8-byte store).
+// Sizes 4 and 8 (and the DST) run in a 16 x 16 tile padded with zeros; 32 x 32 uses v_mfma_f32_32x32x8_f16 over four K-steps (D rows 8 (v / 4) + 4 (lane / 32) + v % 4).
+// The bases come as ready fragments (DevTables::frag16 / frag32).  ALL 64 lanes must be active: the caller is the whole wavefront in uniform control flow.
+typedef _Float16 mf_h4 __attribute__((ext_vector_type(4)));
+typedef float mf_f4 __attribute__((ext_vector_type(4)));
+typedef float mf_f16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ mf_h4 mf_frag(const uint16_t *frag, int lane) { mf_h4 r; __builtin_memcpy(&r, __builtin_assume_aligned(frag + lane * 4, 8), 8); return r; }
+__device__ __forceinline__ int mf_stage(float d_hi, float d_lo, int rnd, int shift) { return (int)sat16(((((int)d_hi) << 8) + (int)d_lo + rnd) >> shift); }
+__device__ __forceinline__ void mf_split(const int (&t)[4], mf_h4 &hi, mf_h4 &lo)
+{
+#pragma unroll
+	for (int r = 0; r < 4; r++) { hi[r] = (_Float16)(short)(t[r] >> 8); lo[r] = (_Float16)(short)(t[r] & 255); }
+}
+template <int N, class S, class P>
+__device__ __forceinline__ void tr_forward_mfma(int lane, const DevTables *T, int basis, const S *orig, int os, const P *pred, int ps, int16_t *coeff)
+{
+	constexpr int L = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+	constexpr int sh1 = L - 1, sh2 = L + 6, rnd1 = sh1 > 0 ? 1 << (sh1 - 1) : 0, rnd2 = 1 << (sh2 - 1);
+	if constexpr (N <= 16) {
+		const int row = lane & 15, k0 = (lane >> 4) * 4;
+		const bool in = row < N && k0 < N;
+		const mf_h4 m = mf_frag(T->frag16[0][basis], lane);                 // M[row][k0 + e]
+		mf_h4 x = {0, 0, 0, 0};
+		if (in) {
+			S ov[4]; P pv[4];
+			__builtin_memcpy(ov, __builtin_assume_aligned(orig + row * os + k0, 4 * sizeof(S)), 4 * sizeof(S));
+			__builtin_memcpy(pv, __builtin_assume_aligned(pred + row * ps + k0, 4 * sizeof(P)), 4 * sizeof(P));
+#pragma unroll
+			for (int e = 0; e < 4; e++) x[e] = (_Float16)(short)((int)ov[e] - (int)pv[e]);
+		}
+		const mf_f4 z = {0, 0, 0, 0};
+		const mf_f4 d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(x, m, z, 0, 0, 0);      // T[j = k0 + r][k1 = row]
+		int t[4];
+#pragma unroll
+		for (int r = 0; r < 4; r++) t[r] = (int)sat16(((int)d1[r] + rnd1) >> sh1);
+		mf_h4 hi, lo;
+		mf_split(t, hi, lo);
+		const mf_f4 dh = __builtin_amdgcn_mfma_f32_16x16x16f16(hi, m, z, 0, 0, 0);     // (as A: the transposed intermediate) -> Y[k2 = row][k1 = k0 + r]
+		const mf_f4 dl = __builtin_amdgcn_mfma_f32_16x16x16f16(lo, m, z, 0, 0, 0);
+		if (in) {
+			S4 o;
+#pragma unroll
+			for (int r = 0; r < 4; r++) o.v[r] = (int16_t)mf_stage(dh[r], dl[r], rnd2, sh2);
+			st4(coeff + row * N + k0, o);
+		}
+	} else {
+		const int row = lane & 31, h4 = (lane >> 5) * 4;
+		mf_h4 m[4];
+#pragma unroll
+		for (int s = 0; s < 4; s++) m[s] = mf_frag(T->frag32[0][s], lane);              // M[row][8 s + h4 + e]
+		mf_f16 d1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+		for (int s = 0; s < 4; s++) {
+			S ov[4]; P pv[4];
+			__builtin_memcpy(ov, __builtin_assume_aligned(orig + row * os + 8 * s + h4, 4 * sizeof(S)), 4 * sizeof(S));
+			__builtin_memcpy(pv, __builtin_assume_aligned(pred + row * ps + 8 * s + h4, 4 * sizeof(P)), 4 * sizeof(P));
+			mf_h4 x;
+#pragma unroll
+			for (int e = 0; e < 4; e++) x[e] = (_Float16)(short)((int)ov[e] - (int)pv[e]);
+			d1 = __builtin_amdgcn_mfma_f32_32x32x8f16(x, m[s], d1, 0, 0, 0);           // T[j = 8 q + h4 + r][k1 = row] in d1[4 q + r]
+		}
+		mf_f16 dh = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dl = dh;
+#pragma unroll
+		for (int s = 0; s < 4; s++) {
+			int t[4];
+#pragma unroll
+			for (int r = 0; r < 4; r++) t[r] = (int)sat16(((int)d1[4 * s + r] + rnd1) >> sh1);
+			mf_h4 hi, lo;
+			mf_split(t, hi, lo);
+			dh = __builtin_amdgcn_mfma_f32_32x32x8f16(hi, m[s], dh, 0, 0, 0);
+			dl = __builtin_amdgcn_mfma_f32_32x32x8f16(lo, m[s], dl, 0, 0, 0);
+		}
+#pragma unroll
+		for (int q = 0; q < 4; q++) {                                                   // Y[k2 = row][k1 = 8 q + h4 + r]
+			S4 o;
+#pragma unroll
+			for (int r = 0; r < 4; r++) o.v[r] = (int16_t)mf_stage(dh[4 * q + r], dl[4 * q + r], rnd2, sh2);
+			st4(coeff + row * 32 + 8 * q + h4, o);
+		}
+	}
+}
+// inverse: tmp[a][b] = sat16((sum_i Mt[a][i] coeff[i][b] + 64) >> 7), block[a][k] = sat16((sum_b Mt[k][b] tmp[a][b] + 2048) >> 12)   (tr_inverse_n)
+template <int N>
+__device__ __forceinline__ void tr_inverse_mfma(int lane, const DevTables *T, int basis, int16_t *block, int bs, const int16_t *coeff)
+{
+	if constexpr (N <= 16) {
+		const int row = lane & 15, k0 = (lane >> 4) * 4;
+		const bool in = row < N && k0 < N;
+		const mf_h4 mt = mf_frag(T->frag16[1][basis], lane);                // Mt[row][k0 + e]
+		int c[4] = {0, 0, 0, 0};
+		if (in) {
+#pragma unroll
+			for (int e = 0; e < 4; e++) c[e] = coeff[(k0 + e) * N + row];         // coeff[i = k0 + e][b = row]: the operand's K runs down a column
+		}
+		mf_h4 hi, lo;
+		mf_split(c, hi, lo);
+		const mf_f4 z = {0, 0, 0, 0};
+		mf_f4 dh = __builtin_amdgcn_mfma_f32_16x16x16f16(hi, mt, z, 0, 0, 0);          // tmp[a = row][b = k0 + r]  (D rows b, columns a)
+		mf_f4 dl = __builtin_amdgcn_mfma_f32_16x16x16f16(lo, mt, z, 0, 0, 0);
+		int t[4];
+#pragma unroll
+		for (int r = 0; r < 4; r++) t[r] = mf_stage(dh[r], dl[r], 64, 7);
+		mf_split(t, hi, lo);
+		dh = __builtin_amdgcn_mfma_f32_16x16x16f16(mt, hi, z, 0, 0, 0);                // (as B) -> block[a = row][k = k0 + r]
+		dl = __builtin_amdgcn_mfma_f32_16x16x16f16(mt, lo, z, 0, 0, 0);
+		if (in) {
+			S4 o;
+#pragma unroll
+			for (int r = 0; r < 4; r++) o.v[r] = (int16_t)mf_stage(dh[r], dl[r], 2048, 12);
+			st4(block + row * bs + k0, o);
+		}
+	} else {
+		const int row = lane & 31, h4 = (lane >> 5) * 4;
+		mf_h4 mt[4];
+#pragma unroll
+		for (int s = 0; s < 4; s++) mt[s] = mf_frag(T->frag32[1][s], lane);             // Mt[row][8 s + h4 + e]
+		mf_f16 dh = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dl = dh;
+#pragma unroll
+		for (int s = 0; s < 4; s++) {
+			int c[4];
+#pragma unroll
+			for (int e = 0; e < 4; e++) c[e] = coeff[(8 * s + h4 + e) * 32 + row];
+			mf_h4 hi, lo;
+			mf_split(c, hi, lo);
+			dh = __builtin_amdgcn_mfma_f32_32x32x8f16(hi, mt[s], dh, 0, 0, 0);         // tmp[a = row][b = 8 q + h4 + r] in d[4 q + r]
+			dl = __builtin_amdgcn_mfma_f32_32x32x8f16(lo, mt[s], dl, 0, 0, 0);
+		}
+		mf_f16 eh = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, el = eh;
+#pragma unroll
+		for (int s = 0; s < 4; s++) {
+			int t[4];
+#pragma unroll
+			for (int r = 0; r < 4; r++) t[r] = mf_stage(dh[4 * s + r], dl[4 * s + r], 64, 7);
+			mf_h4 hi, lo;
+			mf_split(t, hi, lo);
+			eh = __builtin_amdgcn_mfma_f32_32x32x8f16(mt[s], hi, eh, 0, 0, 0);
+			el = __builtin_amdgcn_mfma_f32_32x32x8f16(mt[s], lo, el, 0, 0, 0);
+		}
+#pragma unroll
+		for (int q = 0; q < 4; q++) {                                                   // block[a = row][k = 8 q + h4 + r]
+			S4 o;
+#pragma unroll
+			for (int r = 0; r < 4; r++) o.v[r] = (int16_t)mf_stage(eh[4 * q + r], el[4 * q + r], 2048, 12);
+			st4(block + row * bs + 8 * q + h4, o);
+		}
+	}
+}
+#define HENC_MFMA_TRANSFORM 1
+#endif
+
 // forward transform of the residual source - prediction (hmr_motion_intra.c:1036-1040 / hmr_motion_inter.c:57-60: predict, then transform of the residual window)
 template <class G, class S, class P>
 HENC_PRIM void tr_forward(const G &g, const FastTables *F, const DevTables *T, const S *orig, int os, const P *pred, int ps, int16_t *coeff, int16_t *tmp, int n, int is_dst)
 {
 	PRIM_T0();
+#if defined(HENC_MFMA_TRANSFORM)
+	if constexpr (G::n == 64 && sizeof(S) == 1 && sizeof(P) == 1) {      // (bytes: the residual is within +-255)
+		switch (n) {
+		case 4: tr_forward_mfma<4>(g.tid, T, is_dst ? 3 : 0, orig, os, pred, ps, coeff); break;
+		case 8: tr_forward_mfma<8>(g.tid, T, 1, orig, os, pred, ps, coeff); break;
+		case 16: tr_forward_mfma<16>(g.tid, T, 2, orig, os, pred, ps, coeff); break;
+		default: tr_forward_mfma<32>(g.tid, T, 0, orig, os, pred, ps, coeff); break;
+		}
+		g.sync();
+		PRIM_END(PP_TRF);
+		return;
+	}
+#endif
 	if (!F) {
 		switch (n) {
 		case 4: tr_forward_n<4>(g, is_dst ? T->dst4 : T->dct[0], RowDiff<4, S, P>{orig, os, pred, ps}, coeff, tmp); break;
@@ -998,6 +1168,19 @@ template <class G>
 HENC_PRIM void tr_inverse(const G &g, const FastTables *F, const DevTables *T, int16_t *block, int bs, const int16_t *coeff, int16_t *tmp, int n, int is_dst)
 {
 	PRIM_T0();
+#if defined(HENC_MFMA_TRANSFORM)
+	if constexpr (G::n == 64) {
+		switch (n) {
+		case 4: tr_inverse_mfma<4>(g.tid, T, is_dst ? 3 : 0, block, bs, coeff); break;
+		case 8: tr_inverse_mfma<8>(g.tid, T, 1, block, bs, coeff); break;
+		case 16: tr_inverse_mfma<16>(g.tid, T, 2, block, bs, coeff); break;
+		default: tr_inverse_mfma<32>(g.tid, T, 0, block, bs, coeff); break;
+		}
+		g.sync();
+		PRIM_END(PP_TRI);
+		return;
+	}
+#endif
 	if (!F) {
 		switch (n) {
 		case 4: tr_inverse_n<4>(g, is_dst ? T->dst4_t : T->dct_t[0], block, bs, coeff, tmp); break;

@@ -190,6 +190,21 @@ void hmr_gpu_prim_adi_filter(int16_t *adi, int16_t *out, int adi_size, int n, in
 }
 void hmr_gpu_prim_transform(int16_t *block, int16_t *coeff, int block_stride, int n, int is_dst)
 {
+	if (g_bytes) {      // the worker's call: source and prediction windows of bytes (the transforms on the matrix cores) - block = source - prediction, both 0 .. 255
+		const size_t el = span(block_stride, n, n);
+		std::vector<int16_t> o(el, 0), q(el, 0);
+		for (int y = 0; y < n; y++)
+			for (int x = 0; x < n; x++) {
+				const int b = block[(size_t)y * block_stride + x];
+				if (b < -255 || b > 255) { fprintf(stderr, "hmr_gpu_prim_transform: a residual of %d is not the difference of two bytes\n", b); abort(); }
+				o[(size_t)y * block_stride + x] = (int16_t)(b > 0 ? b : 0);
+				q[(size_t)y * block_stride + x] = (int16_t)(b < 0 ? -b : 0);
+			}
+		Operand ops[4] = {{o.data(), nullptr, el}, {nullptr, coeff, (size_t)n * n}, {nullptr, nullptr, (size_t)n * n}, {q.data(), nullptr, el}};
+		const int p[3] = {block_stride, n, is_dst};
+		run(PT_TRANSFORM, p, 3, ops, 4);
+		return;
+	}
 	Operand ops[4] = {{block, nullptr, span(block_stride, n, n)}, {nullptr, coeff, (size_t)n * n}, {nullptr, nullptr, (size_t)n * n}, {nullptr, nullptr, span(block_stride, n, n)}};
 	const int p[3] = {block_stride, n, is_dst};
 	run(PT_TRANSFORM, p, 3, ops, 4);

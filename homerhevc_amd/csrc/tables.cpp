@@ -68,6 +68,33 @@ void build()
 	}
 	for (int k = 0; k < 4; k++)
 		for (int x = 0; x < 4; x++) t->dst4_t[x * 4 + k] = dst[k * 4 + x];
+	// MFMA operand fragments of the bases (tables_layout.h)
+	{
+		auto half_bits = [](int v) -> uint16_t {      // binary16 of an integer, |v| < 2048: exact
+			if (v == 0) return 0;
+			const uint16_t sign = v < 0 ? 0x8000 : 0;
+			unsigned a = (unsigned)(v < 0 ? -v : v);
+			int e = 0;
+			while ((a >> (e + 1)) != 0) e++;              // a = 1.xxx * 2^e
+			const unsigned mant = (a << (10 - e)) & 0x3ff;
+			return (uint16_t)(sign | ((unsigned)(e + 15) << 10) | mant);
+		};
+		for (int dir = 0; dir < 2; dir++) {
+			for (int b = 0; b < 4; b++) {
+				const int n = b == 3 ? 4 : 4 << b;
+				const int16_t *M = b == 3 ? (dir ? t->dst4_t : t->dst4) : (dir ? t->dct_t[b] : t->dct[b]);
+				for (int lane = 0; lane < 64; lane++)
+					for (int e = 0; e < 4; e++) {
+						const int row = lane % 16, col = 4 * (lane / 16) + e;
+						t->frag16[dir][b][lane * 4 + e] = row < n && col < n ? half_bits(M[row * n + col]) : 0;
+					}
+			}
+			const int16_t *M = dir ? t->dct_t[3] : t->dct[3];
+			for (int s2 = 0; s2 < 4; s2++)
+				for (int lane = 0; lane < 64; lane++)
+					for (int e = 0; e < 4; e++) t->frag32[dir][s2][lane * 4 + e] = half_bits(M[(lane % 32) * 32 + 8 * s2 + 4 * (lane / 32) + e]);
+		}
+	}
 	// even / odd split of the inverse DCT: out[k] = E[k] + O[k], out[N-1-k] = E[k] - O[k] with E over the even, O over the odd input indices
 	for (int l = 3; l <= 5; l++) {
 		const int n = 1 << l;

@@ -13,5 +13,11 @@ struct DevTables {
 	int32_t quant[4][6][6][32 * 32];   // [log2N-2][list][qp%6]
 	int32_t dequant[4][6][6][32 * 32];
 	uint8_t blk2cg[4][6][64];       // [scan_mode][log2N][4x4 block in raster order] -> index of its coefficient group in scan order
+	// The transform bases as MFMA operand fragments (enc_prims.h, tr_forward / tr_inverse on the matrix cores): binary16 bit patterns (every entry is an integer of
+	// at most 90 in magnitude, exact in binary16), in the order the lanes of a wavefront hold them.
+	//   frag16[dir][b][lane * 4 + e] = B[lane % 16][4 * (lane / 16) + e] of the basis b (0: DCT 4, 1: DCT 8, 2: DCT 16, 3: DST 4) padded with zeros to 16 x 16,
+	//   frag32[dir][s][lane * 4 + e] = B[lane % 32][8 * s + 4 * (lane / 32) + e] of the 32 x 32 DCT; dir 0: B = M (forward), dir 1: B = M transposed (inverse).
+	uint16_t frag16[2][4][64 * 4];
+	uint16_t frag32[2][4][64 * 4];
 };
 

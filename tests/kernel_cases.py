@@ -583,6 +583,7 @@ def all_cases(level="full"):
             add("transform", n=n, dst=dst, const=-255)
             add("transform", n=n, dst=dst, amp=1)
             add("itransform", n=n, dst=dst, amp=20000, sparse=False)
+            add("itransform", n=n, dst=dst, amp=32767, sparse=False)
             add("itransform", n=n, dst=dst, amp=60)
     for n in (4, 8, 16, 32):
         for comp in ((0, 1, 2) if n < 32 else (0,)):

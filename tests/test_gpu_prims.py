@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 PRIMS = ["sad", "ssd16b", "predict", "reconst", "modified_variance", "intra_planar", "intra_angular", "fill_reference_samples", "adi_filter", "transform", "itransform",
          "quant", "inv_quant"]
-BYTE_PRIMS = {"sad", "ssd16b", "predict", "reconst", "modified_variance", "intra_planar", "intra_angular"}     # source / prediction operands live in byte windows on the device
+BYTE_PRIMS = {"sad", "ssd16b", "predict", "reconst", "modified_variance", "intra_planar", "intra_angular", "transform"}     # source / prediction operands live in byte windows on the device
 CASES = [c for c in kc.all_cases("full") if c[0] in PRIMS]
 
 
