@@ -546,12 +546,23 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 	nd.inter_cbf[comp] = (sum ? 1 : 0) << (original_depth - depth);
 	if (is_y) nd.inter_tr_idx = original_depth - depth;
 	uint32_t ssd;
-	if (sum > 0) {
+	const bool coded = sum > 0;
+	uint32_t raw_zero = 0;
+	if (coded) {
 		lin_copy_nosync(g, iquant, quant, n * n);
-		const uint32_t raw_zero = blk_ssd(g, orig, cs, pred, cs, n);
+		raw_zero = blk_ssd(g, orig, cs, pred, cs, n);
 		if (raw_ssq) *raw_ssq = raw_zero;
 		dequantize(g, HENC_FT(e), e.T, iquant, iquant, curr_depth, comp, 0, n, per, rem);
-		tr_inverse(g, HENC_FT(e), e.T, rdec, n, iquant, scratch_a, n, 0);
+	}
+#if defined(HENC_MFMA_TRANSFORM)
+	// two halves of a wavefront with a block each: their inverse transforms share a matrix-core tile, which all lanes have to run together - outside the halves' own branches
+	if constexpr (G::n == 32) {
+		if (__ballot(coded) != 0 && n <= 8) tr_inverse_pair(g, coded, e.T, rdec, n, iquant, n);
+		else if (coded) tr_inverse(g, HENC_FT(e), e.T, rdec, n, iquant, scratch_a, n, 0);
+	} else
+#endif
+	if (coded) tr_inverse(g, HENC_FT(e), e.T, rdec, n, iquant, scratch_a, n, 0);
+	if (coded) {
 		const uint32_t raw = blk_ssd_diff(g, orig, cs, pred, cs, rdec, n, n);
 		uint32_t ssd_zero;
 		if (is_y) { ssd_zero = raw_zero; ssd = raw; }

@@ -1124,6 +1124,70 @@ __device__ __forceinline__ void tr_inverse_mfma(int lane, const DevTables *T, in
 		}
 	}
 }
+// Two blocks of size 4 or 8 at once, one per half of the wavefront (PairGrp: the helper's two chroma planes of a small TU): block h lies in rows / columns
+// 8 h .. 8 h + N - 1 of the 16 x 16 tile (DevTables::fragp is the block-diagonal basis), its operands come from the lanes of half h whose tile row is the block's,
+// and its results arrive in those lanes.  Both halves run this together (the caller's control flow is uniform here); `live` says whether the half has work.
+template <int N, class S, class P>
+__device__ __forceinline__ void tr_forward_mfma_pair(int lane, const DevTables *T, const S *orig, int os, const P *pred, int ps, int16_t *coeff)
+{
+	constexpr int L = N == 4 ? 2 : 3;
+	constexpr int sh1 = L - 1, sh2 = L + 6, rnd1 = 1 << (sh1 - 1), rnd2 = 1 << (sh2 - 1);
+	const int row = lane & 7, k0 = ((lane >> 4) & 1) * 4;
+	const bool in = ((lane & 15) >> 3) == (lane >> 5) && row < N && k0 < N;
+	const mf_h4 m = mf_frag(T->fragp[0][N == 8], lane);
+	mf_h4 x = {0, 0, 0, 0};
+	if (in) {
+		S ov[4]; P pv[4];
+		__builtin_memcpy(ov, __builtin_assume_aligned(orig + row * os + k0, 4 * sizeof(S)), 4 * sizeof(S));
+		__builtin_memcpy(pv, __builtin_assume_aligned(pred + row * ps + k0, 4 * sizeof(P)), 4 * sizeof(P));
+#pragma unroll
+		for (int e = 0; e < 4; e++) x[e] = (_Float16)(short)((int)ov[e] - (int)pv[e]);
+	}
+	const mf_f4 z = {0, 0, 0, 0};
+	const mf_f4 d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(x, m, z, 0, 0, 0);
+	int t[4];
+#pragma unroll
+	for (int r = 0; r < 4; r++) t[r] = (int)sat16(((int)d1[r] + rnd1) >> sh1);
+	mf_h4 hi, lo;
+	mf_split(t, hi, lo);
+	const mf_f4 dh = __builtin_amdgcn_mfma_f32_16x16x16f16(hi, m, z, 0, 0, 0);
+	const mf_f4 dl = __builtin_amdgcn_mfma_f32_16x16x16f16(lo, m, z, 0, 0, 0);
+	if (in) {
+		S4 o;
+#pragma unroll
+		for (int r = 0; r < 4; r++) o.v[r] = (int16_t)mf_stage(dh[r], dl[r], rnd2, sh2);
+		st4(coeff + row * N + k0, o);
+	}
+}
+template <int N>
+__device__ __forceinline__ void tr_inverse_mfma_pair(int lane, bool live, const DevTables *T, int16_t *block, int bs, const int16_t *coeff)
+{
+	const int row = lane & 7, k0 = ((lane >> 4) & 1) * 4;
+	const bool in = live && ((lane & 15) >> 3) == (lane >> 5) && row < N && k0 < N;
+	const mf_h4 mt = mf_frag(T->fragp[1][N == 8], lane);
+	int c[4] = {0, 0, 0, 0};
+	if (in) {
+#pragma unroll
+		for (int e = 0; e < 4; e++) c[e] = coeff[(k0 + e) * N + row];
+	}
+	mf_h4 hi, lo;
+	mf_split(c, hi, lo);
+	const mf_f4 z = {0, 0, 0, 0};
+	mf_f4 dh = __builtin_amdgcn_mfma_f32_16x16x16f16(hi, mt, z, 0, 0, 0);
+	mf_f4 dl = __builtin_amdgcn_mfma_f32_16x16x16f16(lo, mt, z, 0, 0, 0);
+	int t[4];
+#pragma unroll
+	for (int r = 0; r < 4; r++) t[r] = mf_stage(dh[r], dl[r], 64, 7);
+	mf_split(t, hi, lo);
+	dh = __builtin_amdgcn_mfma_f32_16x16x16f16(mt, hi, z, 0, 0, 0);
+	dl = __builtin_amdgcn_mfma_f32_16x16x16f16(mt, lo, z, 0, 0, 0);
+	if (in) {
+		S4 o;
+#pragma unroll
+		for (int r = 0; r < 4; r++) o.v[r] = (int16_t)mf_stage(dh[r], dl[r], 2048, 12);
+		st4(block + row * bs + k0, o);
+	}
+}
 #define HENC_MFMA_TRANSFORM 1
 #endif
 
@@ -1143,6 +1207,16 @@ HENC_PRIM void tr_forward(const G &g, const FastTables *F, const DevTables *T, c
 		g.sync();
 		PRIM_END(PP_TRF);
 		return;
+	}
+	if constexpr (G::n == 32 && sizeof(S) == 1 && sizeof(P) == 1) {      // two blocks of 4 x 4 or 8 x 8, a half of the wavefront each, in one tile (the caller's flow is uniform)
+		if (n <= 8 && !is_dst) {
+			const int lane = g.half * 32 + g.tid;
+			if (n == 4) tr_forward_mfma_pair<4>(lane, T, orig, os, pred, ps, coeff);
+			else tr_forward_mfma_pair<8>(lane, T, orig, os, pred, ps, coeff);
+			g.sync();
+			PRIM_END(PP_TRF);
+			return;
+		}
 	}
 #endif
 	if (!F) {
@@ -1199,6 +1273,20 @@ HENC_PRIM void tr_inverse(const G &g, const FastTables *F, const DevTables *T, i
 	}
 	PRIM_END(PP_TRI);
 }
+
+#if defined(HENC_MFMA_TRANSFORM)
+// the inverse transform of the two halves' blocks together (see tr_forward_mfma_pair): called by BOTH halves from uniform control flow, `live` = this half has levels
+template <class G>
+__device__ __forceinline__ void tr_inverse_pair(const G &g, bool live, const DevTables *T, int16_t *block, int bs, const int16_t *coeff, int n)
+{
+	PRIM_T0();
+	const int lane = g.half * 32 + g.tid;
+	if (n == 4) tr_inverse_mfma_pair<4>(lane, live, T, block, bs, coeff);
+	else tr_inverse_mfma_pair<8>(lane, live, T, block, bs, coeff);
+	g.sync();
+	PRIM_END(PP_TRI);
+}
+#endif
 
 // ---- quantisation (hmr_sse42_functions_quant.c:34-131 + sign_bit_hidding hmr_quant.c:61-169; inverse :135-246) -------
 // sign hiding of one 16-coefficient group (sign_bit_hidding, hmr_quant.c:61-169).  The group's positions, levels, source coefficients and

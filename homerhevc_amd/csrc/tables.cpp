@@ -89,6 +89,15 @@ void build()
 						t->frag16[dir][b][lane * 4 + e] = row < n && col < n ? half_bits(M[row * n + col]) : 0;
 					}
 			}
+			for (int b = 0; b < 2; b++) {
+				const int n = 4 << b;
+				const int16_t *M = dir ? t->dct_t[b] : t->dct[b];
+				for (int lane = 0; lane < 64; lane++)
+					for (int e = 0; e < 4; e++) {
+						const int row = lane % 8, col = 4 * (lane / 16 % 2) + e;
+						t->fragp[dir][b][lane * 4 + e] = (lane % 16 / 8 == lane / 32 && row < n && col < n) ? half_bits(M[row * n + col]) : 0;
+					}
+			}
 			const int16_t *M = dir ? t->dct_t[3] : t->dct[3];
 			for (int s2 = 0; s2 < 4; s2++)
 				for (int lane = 0; lane < 64; lane++)
