@@ -11,7 +11,7 @@
 enum { PP_SAD = 0, PP_SSD, PP_BLK, PP_FILLREF, PP_ADIFILT, PP_INTRAPRED, PP_INTERP, PP_TRF, PP_TRI, PP_QUANT, PP_DEQUANT, PP_CAND, PP_SYNC, PP_INFO, PP_CTU_IO, PP_HWAIT, PP_COUNT };
 #if defined(__HIPCC__) && defined(HENC_PROFILE)
 extern __shared__ __align__(16) unsigned char henc_lds[];
-#define HENC_LDS_PROF_OFFSET 42240      // (behind the worker state: the profiling build holds three workers per CU where the product holds four; k_encode.hip checks the place)
+#define HENC_LDS_PROF_OFFSET 42304      // (behind the worker state: the profiling build holds three workers per CU where the product holds four; k_encode.hip checks the place)
 #define PRIM_T0() const unsigned long long prim_t0_ = __builtin_amdgcn_s_memtime()
 #define PRIM_END(cat) do { if (threadIdx.x == 0) { unsigned long long *pp_ = (unsigned long long *)(henc_lds + HENC_LDS_PROF_OFFSET); pp_[cat] += __builtin_amdgcn_s_memtime() - prim_t0_; pp_[PP_COUNT + (cat)]++; } } while (0)
 #else
