@@ -554,7 +554,7 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 		if (raw_ssq) *raw_ssq = raw_zero;
 		dequantize(g, HENC_FT(e), e.T, iquant, iquant, curr_depth, comp, 0, n, per, rem);
 	}
-#if defined(HENC_MFMA_TRANSFORM)
+#if defined(HENC_MFMA_TRANSFORM) && !defined(HENC_MFMA_NO_PAIR)
 	// two halves of a wavefront with a block each: their inverse transforms share a matrix-core tile, which all lanes have to run together - outside the halves' own branches
 	if constexpr (G::n == 32) {
 		if (__ballot(coded) != 0 && n <= 8) tr_inverse_pair(g, coded, e.T, rdec, n, iquant, n);

@@ -1089,39 +1089,51 @@ __device__ __forceinline__ void tr_inverse_mfma(int lane, const DevTables *T, in
 			st4(block + row * bs + k0, o);
 		}
 	} else {
-		const int row = lane & 31, h4 = (lane >> 5) * 4;
-		mf_h4 mt[4];
+		// 32 x 32 as 16 x 16 quarter tiles (DevTables::frag32t): the two stages as sixteen small products each, with eight accumulator registers in flight (as one
+		// 32 x 32 x 8 chain the four accumulators took 64 registers, and what they displaced was spilled in the loops around the transform: 17 % more store instructions)
+		const int r16 = lane & 15, g4 = (lane >> 4) * 4;
+		mf_h4 mt[2][2];
 #pragma unroll
-		for (int s = 0; s < 4; s++) mt[s] = mf_frag(T->frag32[1][s], lane);             // Mt[row][8 s + h4 + e]
-		mf_f16 dh = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dl = dh;
+		for (int R = 0; R < 2; R++)
 #pragma unroll
-		for (int s = 0; s < 4; s++) {
-			int c[4];
+			for (int K = 0; K < 2; K++) mt[R][K] = mf_frag(T->frag32t[1][R][K], lane);      // Mt[16 R + r16][16 K + g4 + e]
+		const mf_f4 z = {0, 0, 0, 0};
+		mf_h4 th[2][2], tl[2][2];                                                               // tmp, transposed: tile (B, A) = rows b of block B, columns a of block A
 #pragma unroll
-			for (int e = 0; e < 4; e++) c[e] = coeff[(8 * s + h4 + e) * 32 + row];
-			mf_h4 hi, lo;
-			mf_split(c, hi, lo);
-			dh = __builtin_amdgcn_mfma_f32_32x32x8f16(hi, mt[s], dh, 0, 0, 0);         // tmp[a = row][b = 8 q + h4 + r] in d[4 q + r]
-			dl = __builtin_amdgcn_mfma_f32_32x32x8f16(lo, mt[s], dl, 0, 0, 0);
+		for (int B = 0; B < 2; B++) {
+			mf_h4 ch[2], cl[2];
+#pragma unroll
+			for (int I = 0; I < 2; I++) {
+				int c[4];
+#pragma unroll
+				for (int e = 0; e < 4; e++) c[e] = coeff[(16 * I + g4 + e) * 32 + 16 * B + r16];       // coeff[i][b]
+				mf_split(c, ch[I], cl[I]);
+			}
+#pragma unroll
+			for (int A = 0; A < 2; A++) {
+				mf_f4 dh = __builtin_amdgcn_mfma_f32_16x16x16f16(ch[0], mt[A][0], z, 0, 0, 0);
+				mf_f4 dl = __builtin_amdgcn_mfma_f32_16x16x16f16(cl[0], mt[A][0], z, 0, 0, 0);
+				dh = __builtin_amdgcn_mfma_f32_16x16x16f16(ch[1], mt[A][1], dh, 0, 0, 0);
+				dl = __builtin_amdgcn_mfma_f32_16x16x16f16(cl[1], mt[A][1], dl, 0, 0, 0);
+				int t[4];
+#pragma unroll
+				for (int r = 0; r < 4; r++) t[r] = mf_stage(dh[r], dl[r], 64, 7);                 // tmp[a = 16 A + r16][b = 16 B + g4 + r]
+				mf_split(t, th[B][A], tl[B][A]);
+			}
 		}
-		mf_f16 eh = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, el = eh;
 #pragma unroll
-		for (int s = 0; s < 4; s++) {
-			int t[4];
+		for (int K = 0; K < 2; K++)
 #pragma unroll
-			for (int r = 0; r < 4; r++) t[r] = mf_stage(dh[4 * s + r], dl[4 * s + r], 64, 7);
-			mf_h4 hi, lo;
-			mf_split(t, hi, lo);
-			eh = __builtin_amdgcn_mfma_f32_32x32x8f16(mt[s], hi, eh, 0, 0, 0);
-			el = __builtin_amdgcn_mfma_f32_32x32x8f16(mt[s], lo, el, 0, 0, 0);
-		}
+			for (int A = 0; A < 2; A++) {
+				mf_f4 eh = __builtin_amdgcn_mfma_f32_16x16x16f16(mt[K][0], th[0][A], z, 0, 0, 0);
+				mf_f4 el = __builtin_amdgcn_mfma_f32_16x16x16f16(mt[K][0], tl[0][A], z, 0, 0, 0);
+				eh = __builtin_amdgcn_mfma_f32_16x16x16f16(mt[K][1], th[1][A], eh, 0, 0, 0);
+				el = __builtin_amdgcn_mfma_f32_16x16x16f16(mt[K][1], tl[1][A], el, 0, 0, 0);
+				S4 o;                                                                               // block[a = 16 A + r16][k = 16 K + g4 + r]
 #pragma unroll
-		for (int q = 0; q < 4; q++) {                                                   // block[a = row][k = 8 q + h4 + r]
-			S4 o;
-#pragma unroll
-			for (int r = 0; r < 4; r++) o.v[r] = (int16_t)mf_stage(eh[4 * q + r], el[4 * q + r], 2048, 12);
-			st4(block + row * bs + 8 * q + h4, o);
-		}
+				for (int r = 0; r < 4; r++) o.v[r] = (int16_t)mf_stage(eh[r], el[r], 2048, 12);
+				st4(block + (16 * A + r16) * bs + 16 * K + g4, o);
+			}
 	}
 }
 // Two blocks of size 4 or 8 at once, one per half of the wavefront (PairGrp: the helper's two chroma planes of a small TU): block h lies in rows / columns
@@ -1197,6 +1209,7 @@ HENC_PRIM void tr_forward(const G &g, const FastTables *F, const DevTables *T, c
 {
 	PRIM_T0();
 #if defined(HENC_MFMA_TRANSFORM)
+#if !defined(HENC_MFMA_NO_FWD)
 	if constexpr (G::n == 64 && sizeof(S) == 1 && sizeof(P) == 1) {      // (bytes: the residual is within +-255)
 		switch (n) {
 		case 4: tr_forward_mfma<4>(g.tid, T, is_dst ? 3 : 0, orig, os, pred, ps, coeff); break;
@@ -1208,6 +1221,8 @@ HENC_PRIM void tr_forward(const G &g, const FastTables *F, const DevTables *T, c
 		PRIM_END(PP_TRF);
 		return;
 	}
+#endif
+#if !defined(HENC_MFMA_NO_PAIR)
 	if constexpr (G::n == 32 && sizeof(S) == 1 && sizeof(P) == 1) {      // two blocks of 4 x 4 or 8 x 8, a half of the wavefront each, in one tile (the caller's flow is uniform)
 		if (n <= 8 && !is_dst) {
 			const int lane = g.half * 32 + g.tid;
@@ -1218,6 +1233,7 @@ HENC_PRIM void tr_forward(const G &g, const FastTables *F, const DevTables *T, c
 			return;
 		}
 	}
+#endif
 #endif
 	if (!F) {
 		switch (n) {
@@ -1242,8 +1258,11 @@ template <class G>
 HENC_PRIM void tr_inverse(const G &g, const FastTables *F, const DevTables *T, int16_t *block, int bs, const int16_t *coeff, int16_t *tmp, int n, int is_dst)
 {
 	PRIM_T0();
-#if defined(HENC_MFMA_TRANSFORM)
-	if constexpr (G::n == 64) {
+#if defined(HENC_MFMA_TRANSFORM) && !defined(HENC_MFMA_NO_INV)
+#if !defined(HENC_MFMA_INV_MASK)
+#define HENC_MFMA_INV_MASK 15
+#endif
+	if constexpr (G::n == 64) if ((HENC_MFMA_INV_MASK >> (n == 4 ? 0 : n == 8 ? 1 : n == 16 ? 2 : 3)) & 1) {
 		switch (n) {
 		case 4: tr_inverse_mfma<4>(g.tid, T, is_dst ? 3 : 0, block, bs, coeff); break;
 		case 8: tr_inverse_mfma<8>(g.tid, T, 1, block, bs, coeff); break;

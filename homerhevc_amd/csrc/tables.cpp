@@ -98,6 +98,11 @@ void build()
 						t->fragp[dir][b][lane * 4 + e] = (lane % 16 / 8 == lane / 32 && row < n && col < n) ? half_bits(M[row * n + col]) : 0;
 					}
 			}
+			for (int R = 0; R < 2; R++)
+				for (int K = 0; K < 2; K++)
+					for (int lane = 0; lane < 64; lane++)
+						for (int e = 0; e < 4; e++)
+							t->frag32t[dir][R][K][lane * 4 + e] = half_bits((dir ? t->dct_t[3] : t->dct[3])[(16 * R + lane % 16) * 32 + 16 * K + 4 * (lane / 16) + e]);
 			const int16_t *M = dir ? t->dct_t[3] : t->dct[3];
 			for (int s2 = 0; s2 < 4; s2++)
 				for (int lane = 0; lane < 64; lane++)

@@ -22,5 +22,8 @@ struct DevTables {
 	uint16_t frag16[2][4][64 * 4];
 	uint16_t frag32[2][4][64 * 4];
 	uint16_t fragp[2][2][64 * 4];
+	//   frag32t[dir][R][K][lane * 4 + e] = B[16 R + lane % 16][16 K + 4 * (lane / 16) + e] of the 32 x 32 DCT: its four 16 x 16 quarters as fragments of the 16 x 16 x 16 product
+	//   (the inverse 32 x 32 transform runs as quarter tiles: sixteen accumulator registers in flight instead of sixty-four)
+	uint16_t frag32t[2][2][2][64 * 4];
 };
 
