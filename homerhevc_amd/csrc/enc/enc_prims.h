@@ -978,8 +978,8 @@ HENC_HD void tr_inverse_n(const G &g, const int16_t *Mt, int16_t *block, int bs,
 // The rounding, shift and 16-bit saturation between the stages are the reference's, on integers.  v_mfma_f32_16x16x16_f16 holds A[lane % 16][4 (lane / 16) + e],
 // B[4 (lane / 16) + e][lane % 16] and D[4 (lane / 16) + r][lane % 16]: a stage's result IS the next stage's operand (as B, or - read as the transposed
 // matrix - as A), so the intermediate never leaves the registers, and the last result has four consecutive outputs of one row per lane (one 8-byte store).
-// Sizes 4 and 8 (and the DST) run in a 16 x 16 tile padded with zeros; 32 x 32 uses v_mfma_f32_32x32x8_f16 over four K-steps (D rows 8 (v / 4) + 4 (lane / 32) + v % 4).
-// The bases come as ready fragments (DevTables::frag16 / frag32).  ALL 64 lanes must be active: the caller is the whole wavefront in uniform control flow.
+// Sizes 4 and 8 (and the DST) run in a 16 x 16 tile padded with zeros; 32 x 32 runs as 16 x 16 quarter tiles (as a v_mfma_f32_32x32x8_f16 chain the accumulators
+// held 64 registers, paid for with spills around the transform).  The bases come as ready fragments (DevTables::frag16 / frag32t / fragp).  ALL 64 lanes must be active: the caller is the whole wavefront in uniform control flow.
 typedef _Float16 mf_h4 __attribute__((ext_vector_type(4)));
 typedef float mf_f4 __attribute__((ext_vector_type(4)));
 typedef float mf_f16 __attribute__((ext_vector_type(16)));
@@ -1023,39 +1023,49 @@ __device__ __forceinline__ void tr_forward_mfma(int lane, const DevTables *T, in
 			st4(coeff + row * N + k0, o);
 		}
 	} else {
-		const int row = lane & 31, h4 = (lane >> 5) * 4;
-		mf_h4 m[4];
+		// 32 x 32 as 16 x 16 quarter tiles (see tr_inverse_mfma): eight accumulator registers in flight
+		const int r16 = lane & 15, g4 = (lane >> 4) * 4;
+		mf_h4 m[2][2];
 #pragma unroll
-		for (int s = 0; s < 4; s++) m[s] = mf_frag(T->frag32[0][s], lane);              // M[row][8 s + h4 + e]
-		mf_f16 d1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+		for (int R = 0; R < 2; R++)
 #pragma unroll
-		for (int s = 0; s < 4; s++) {
-			S ov[4]; P pv[4];
-			__builtin_memcpy(ov, __builtin_assume_aligned(orig + row * os + 8 * s + h4, 4 * sizeof(S)), 4 * sizeof(S));
-			__builtin_memcpy(pv, __builtin_assume_aligned(pred + row * ps + 8 * s + h4, 4 * sizeof(P)), 4 * sizeof(P));
-			mf_h4 x;
+			for (int K = 0; K < 2; K++) m[R][K] = mf_frag(T->frag32t[0][R][K], lane);        // M[16 R + r16][16 K + g4 + e]
+		const mf_f4 z = {0, 0, 0, 0};
+		mf_h4 th[2][2], tl[2][2];                                                               // the intermediate: tile (J, K1) = rows j of block J, columns k1 of block K1
 #pragma unroll
-			for (int e = 0; e < 4; e++) x[e] = (_Float16)(short)((int)ov[e] - (int)pv[e]);
-			d1 = __builtin_amdgcn_mfma_f32_32x32x8f16(x, m[s], d1, 0, 0, 0);           // T[j = 8 q + h4 + r][k1 = row] in d1[4 q + r]
+		for (int J = 0; J < 2; J++) {
+			mf_h4 x[2];
+#pragma unroll
+			for (int C = 0; C < 2; C++) {
+				S ov[4]; P pv[4];
+				__builtin_memcpy(ov, __builtin_assume_aligned(orig + (16 * J + r16) * os + 16 * C + g4, 4 * sizeof(S)), 4 * sizeof(S));
+				__builtin_memcpy(pv, __builtin_assume_aligned(pred + (16 * J + r16) * ps + 16 * C + g4, 4 * sizeof(P)), 4 * sizeof(P));
+#pragma unroll
+				for (int e = 0; e < 4; e++) x[C][e] = (_Float16)(short)((int)ov[e] - (int)pv[e]);
+			}
+#pragma unroll
+			for (int K1 = 0; K1 < 2; K1++) {
+				mf_f4 d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(x[0], m[K1][0], z, 0, 0, 0);
+				d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(x[1], m[K1][1], d1, 0, 0, 0);        // T[j = 16 J + g4 + r][k1 = 16 K1 + r16]
+				int t[4];
+#pragma unroll
+				for (int r = 0; r < 4; r++) t[r] = (int)sat16(((int)d1[r] + rnd1) >> sh1);
+				mf_split(t, th[J][K1], tl[J][K1]);
+			}
 		}
-		mf_f16 dh = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dl = dh;
 #pragma unroll
-		for (int s = 0; s < 4; s++) {
-			int t[4];
+		for (int K2 = 0; K2 < 2; K2++)
 #pragma unroll
-			for (int r = 0; r < 4; r++) t[r] = (int)sat16(((int)d1[4 * s + r] + rnd1) >> sh1);
-			mf_h4 hi, lo;
-			mf_split(t, hi, lo);
-			dh = __builtin_amdgcn_mfma_f32_32x32x8f16(hi, m[s], dh, 0, 0, 0);
-			dl = __builtin_amdgcn_mfma_f32_32x32x8f16(lo, m[s], dl, 0, 0, 0);
-		}
+			for (int K1 = 0; K1 < 2; K1++) {
+				mf_f4 dh = __builtin_amdgcn_mfma_f32_16x16x16f16(th[0][K1], m[K2][0], z, 0, 0, 0);
+				mf_f4 dl = __builtin_amdgcn_mfma_f32_16x16x16f16(tl[0][K1], m[K2][0], z, 0, 0, 0);
+				dh = __builtin_amdgcn_mfma_f32_16x16x16f16(th[1][K1], m[K2][1], dh, 0, 0, 0);
+				dl = __builtin_amdgcn_mfma_f32_16x16x16f16(tl[1][K1], m[K2][1], dl, 0, 0, 0);
+				S4 o;                                                                               // Y[k2 = 16 K2 + r16][k1 = 16 K1 + g4 + r]
 #pragma unroll
-		for (int q = 0; q < 4; q++) {                                                   // Y[k2 = row][k1 = 8 q + h4 + r]
-			S4 o;
-#pragma unroll
-			for (int r = 0; r < 4; r++) o.v[r] = (int16_t)mf_stage(dh[4 * q + r], dl[4 * q + r], rnd2, sh2);
-			st4(coeff + row * 32 + 8 * q + h4, o);
-		}
+				for (int r = 0; r < 4; r++) o.v[r] = (int16_t)mf_stage(dh[r], dl[r], rnd2, sh2);
+				st4(coeff + (16 * K2 + r16) * 32 + 16 * K1 + g4, o);
+			}
 	}
 }
 // inverse: tmp[a][b] = sat16((sum_i Mt[a][i] coeff[i][b] + 64) >> 7), block[a][k] = sat16((sum_b Mt[k][b] tmp[a][b] + 2048) >> 12)   (tr_inverse_n)

@@ -103,10 +103,6 @@ void build()
 					for (int lane = 0; lane < 64; lane++)
 						for (int e = 0; e < 4; e++)
 							t->frag32t[dir][R][K][lane * 4 + e] = half_bits((dir ? t->dct_t[3] : t->dct[3])[(16 * R + lane % 16) * 32 + 16 * K + 4 * (lane / 16) + e]);
-			const int16_t *M = dir ? t->dct_t[3] : t->dct[3];
-			for (int s2 = 0; s2 < 4; s2++)
-				for (int lane = 0; lane < 64; lane++)
-					for (int e = 0; e < 4; e++) t->frag32[dir][s2][lane * 4 + e] = half_bits(M[(lane % 32) * 32 + 8 * s2 + 4 * (lane / 32) + e]);
 		}
 	}
 	// even / odd split of the inverse DCT: out[k] = E[k] + O[k], out[N-1-k] = E[k] - O[k] with E over the even, O over the odd input indices

@@ -16,14 +16,13 @@ struct DevTables {
 	// The transform bases as MFMA operand fragments (enc_prims.h, tr_forward / tr_inverse on the matrix cores): binary16 bit patterns (every entry is an integer of
 	// at most 90 in magnitude, exact in binary16), in the order the lanes of a wavefront hold them.
 	//   frag16[dir][b][lane * 4 + e] = B[lane % 16][4 * (lane / 16) + e] of the basis b (0: DCT 4, 1: DCT 8, 2: DCT 16, 3: DST 4) padded with zeros to 16 x 16,
-	//   frag32[dir][s][lane * 4 + e] = B[lane % 32][8 * s + 4 * (lane / 32) + e] of the 32 x 32 DCT; dir 0: B = M (forward), dir 1: B = M transposed (inverse).
+	//   dir 0: B = M (forward), dir 1: B = M transposed (inverse).
 	//   fragp[dir][b][lane * 4 + e]: TWO blocks of size 4 (b = 0) or 8 (b = 1) side by side in one 16 x 16 tile, block h in rows / columns 8 h .. 8 h + 7 (block diagonal):
 	//   B[lane % 8][4 * (lane / 16 % 2) + e] where lane % 16 / 8 == lane / 32, else 0 - the two halves of a wavefront transform a block each (PairGrp).
 	uint16_t frag16[2][4][64 * 4];
-	uint16_t frag32[2][4][64 * 4];
 	uint16_t fragp[2][2][64 * 4];
 	//   frag32t[dir][R][K][lane * 4 + e] = B[16 R + lane % 16][16 K + 4 * (lane / 16) + e] of the 32 x 32 DCT: its four 16 x 16 quarters as fragments of the 16 x 16 x 16 product
-	//   (the inverse 32 x 32 transform runs as quarter tiles: sixteen accumulator registers in flight instead of sixty-four)
+	//   (the 32 x 32 transforms run as quarter tiles: eight accumulator registers in flight; a 32 x 32 x 8 chain held 64)
 	uint16_t frag32t[2][2][2][64 * 4];
 };
 
