@@ -185,7 +185,7 @@ HENC_HD uint32_t encode_intra(const G &g, Enc &__restrict__ e, int curr_depth, i
 
 // check_rd_cost_merge_2nx2n :3493 (P slice)
 template <class G>
-HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth, int position)
+HENC_WALK_FN HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth, int position)
 {
 	HENC_ENC_IN_LDS(e);
 	Work &w = *e.w;

@@ -129,12 +129,21 @@ HENC_HD void cand_sads(const G &g, Enc &__restrict__ e, int ox, int oy, int gx, 
 template <int N>
 HENC_INLINE uint32_t pick(const uint32_t (&a)[N], int idx)
 {
-	uint32_t r = a[0];
-#if defined(__HIPCC__)
+#if defined(__HIP_DEVICE_COMPILE__)
+	// (the elements go through an empty asm: a plain chain of selects is turned back into a[idx], and an array indexed at run time lives in private memory;
+	// the values are a search round's SADs - wavefront sums, uniform - hence scalar registers)
+	uint32_t v[N];
 #pragma unroll
-#endif
+	for (int k = 0; k < N; k++) { v[k] = a[k]; asm("" : "+s"(v[k])); }
+	uint32_t r = v[0];
+#pragma unroll
+	for (int k = 1; k < N; k++) r = idx == k ? v[k] : r;
+	return r;
+#else
+	uint32_t r = a[0];
 	for (int k = 1; k < N; k++) r = idx == k ? a[k] : r;
 	return r;
+#endif
 }
 
 // ---- vector cost ----------------------------------------------------------------------------------------------------

@@ -316,7 +316,7 @@ HENC_WALK_FN HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e,
 		cn.sum = (uint32_t)curr_sum;
 		cn.cost = cn.distortion;
 		if (rd_full && (curr_depth < max_tr_processing_depth || curr_depth == depth)) {      // :1457: the node's syntax priced by the bit counter
-			RdViews rv;
+			RdViews &rv = rd_views_of(e);
 			e.rd_luma_depth = curr_depth;
 			rd_make_views(g, e, rv, curr_depth, curr_depth, nullptr, nullptr, 0, tq_ptr(w, curr_depth + 1, COMP_Y), nullptr, nullptr);
 			const uint32_t bit_cost = rd_get_intra_bits_qt(g, e, rv, curr, 1);
@@ -336,7 +336,7 @@ HENC_WALK_FN HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e,
 				double cost = distortion;
 				depth_state.set(curr_depth, 0);
 				if (rd_full) {      // :1486: the parent's syntax with its four children as the transform split
-					RdViews rv;
+					RdViews &rv = rd_views_of(e);
 					rd_make_views(g, e, rv, curr_depth, curr_depth, nullptr, nullptr, 0, tq_ptr(w, curr_depth + 1, COMP_Y), nullptr, nullptr);
 					const uint32_t bit_cost = rd_get_intra_bits_qt(g, e, rv, parent, 1);
 					cost += (uint32_t)(bit_cost * e.f->lambda + .5);
@@ -533,7 +533,7 @@ HENC_WALK_FN HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ 
 			if (S.rd_mode == RDM_FULL) {      // hmr_motion_intra_chroma.c:228: the candidate goes into the depth's direction buffer and is priced by the counter
 				const Geo &sq = e.geo[curr];
 				bytes_set(g, &w.intra_mode_buffs[COMP_CHR][depth][sq.abs_index], mode_list[mi], sq.num_part);
-				RdViews rv;
+				RdViews &rv = rd_views_of(e);
 				rd_make_views(g, e, rv, depth, depth, nullptr, nullptr, depth, nullptr, nullptr, nullptr);
 				bit_cost = rd_bits_chroma_mode(e, rv.v, curr);
 			}
@@ -649,7 +649,7 @@ HENC_WALK_FN HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ 
 		if (S.rd_mode == RDM_FULL && cost < best_cost) {      // :417: the chroma syntax of the CU with the winner of the search
 			const Geo &tq = e.geo[top];
 			bytes_set(g, &w.intra_mode_buffs[COMP_CHR][depth][tq.abs_index], best_modes[0], tq.num_part);
-			RdViews rv;
+			RdViews &rv = rd_views_of(e);
 			rd_make_views(g, e, rv, depth, depth, w.cbf_chroma[0], w.cbf_chroma[1], depth, nullptr, tq_ptr(w, qwnd, COMP_U), tq_ptr(w, qwnd, COMP_V));
 			const uint32_t bits = rd_get_intra_bits_qt(g, e, rv, top, 0);
 			cost += (uint32_t)(bits * e.f->lambda + .5);

@@ -11,7 +11,7 @@
 enum { PP_SAD = 0, PP_SSD, PP_BLK, PP_FILLREF, PP_ADIFILT, PP_INTRAPRED, PP_INTERP, PP_TRF, PP_TRI, PP_QUANT, PP_DEQUANT, PP_CAND, PP_SYNC, PP_INFO, PP_CTU_IO, PP_HWAIT, PP_COUNT };
 #if defined(__HIPCC__) && defined(HENC_PROFILE)
 extern __shared__ __align__(16) unsigned char henc_lds[];
-#define HENC_LDS_PROF_OFFSET 42304      // (behind the worker state: the profiling build holds three workers per CU where the product holds four; k_encode.hip checks the place)
+#define HENC_LDS_PROF_OFFSET 43008      // (behind the worker state: the profiling build holds three workers per CU where the product holds four; k_encode.hip checks the place)
 #define PRIM_T0() const unsigned long long prim_t0_ = __builtin_amdgcn_s_memtime()
 #define PRIM_END(cat) do { if (threadIdx.x == 0) { unsigned long long *pp_ = (unsigned long long *)(henc_lds + HENC_LDS_PROF_OFFSET); pp_[cat] += __builtin_amdgcn_s_memtime() - prim_t0_; pp_[PP_COUNT + (cat)]++; } } while (0)
 #else
@@ -91,10 +91,19 @@ __device__ __forceinline__ void multi_sad_u8(const WaveGrp &g, const uint8_t *or
 		const uint32_t a = *(const uint32_t *)(orig8 + r * 64 + c);
 #pragma unroll
 		for (int k0 = 0; k0 < MAXC; k0 += 4) {
-			const uint8_t *p = cand[k0];
+			// (each candidate pointer goes through an empty asm: the compiler otherwise turns this chain of selects into ONE load at cand[k0 + sub] - an array
+			// indexed at run time lives in private memory, a store and a dependent load through L2 per round of the search)
+			uint64_t cp[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				cp[j] = k0 + j < MAXC ? (uint64_t)(uintptr_t)cand[k0 + j] : 0;
+				asm("" : "+v"(cp[j]));
+			}
+			uint64_t ps = cp[0];
 #pragma unroll
 			for (int j = 1; j < 4; j++)
-				if (k0 + j < MAXC) p = sub == j ? cand[k0 + j] : p;
+				if (k0 + j < MAXC) ps = sub == j ? cp[j] : ps;
+			const uint8_t *p = (const uint8_t *)(uintptr_t)ps;
 			if (k0 + 4 > MAXC && sub >= MAXC - k0) p = nullptr;
 			int x = p ? (int)__builtin_amdgcn_sad_u8(a, ld32u(p + r * stride + c), 0u) : 0;
 			x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);

@@ -29,6 +29,9 @@ struct RdViews {
 	EntView v;
 	CtuView c, l, t;
 };
+static_assert(sizeof(RdViews) <= sizeof(WorkRd::rd_views), "RdViews outgrew its place in the worker's RD area");
+// the worker's one set of views (in its fast memory): filled by rd_make_views before every estimate
+HENC_INLINE RdViews &rd_views_of(Enc &e) { return *(RdViews *)e.wrd->rd_views; }
 
 // the shadow CTU's view: luma cbf / transform index buffers of `y_depth`, the luma directions where the last luma estimate left the pointer, the chroma cbf and
 // direction buffers given

@@ -260,6 +260,9 @@ struct WorkRd {
 	uint8_t rd_pred_depth[NPART], rd_part_size[NPART], rd_pred_mode[NPART], rd_luma_modes[NPART];
 	uint8_t rd_ctx_work[RD_CTX_BYTES];
 	EntScratch rd_ent;
+	// the views a bit estimate reads its CTU and the neighbours through (enc_rdo.h RdViews: pointers handed on by address, so a local would live in private
+	// memory - every look at a neighbour's flag a trip through L2 for the pointer first); rd_views_of() in enc_rdo.h
+	alignas(8) unsigned char rd_views[512];
 };
 
 HENC_INLINE int16_t *wnd_y(int16_t *base) { return base; }
