@@ -160,6 +160,10 @@ struct alignas(16) PostScratch {
 	int64_t cand_dist[3][5];
 	double cost[32];
 	int64_t dist[64];
+	// what the syntax coder reads the CTU and its neighbours through (handed on by address: as locals they lived in private memory)
+	EntView view;
+	CtuView view_c, view_l, view_t;
+	SaoOffset sao_ws[SAO_DECIDE_WS];   // sao_decide's candidates under test
 };
 #if defined(__HIPCC__)
 // (k_encode.hip checks that the scratch fits the part of a worker's fast memory that is idle between two CTUs: its Work and the CTU's partition nodes)
@@ -610,7 +614,7 @@ HENC_HDX void post_task_p(const G &g, const PostCtx &x, PostScratch &sc, int r, 
 		const SaoTables T = {kEntropyBits, kNextStateLps};
 		const SaoCandFromScratch cand = {&sc};
 		sao_decide(T, sc.ctx[CTX_SAO_MERGE], sc.ctx[CTX_SAO_TYPE], cand, sc.stats, c > 0 ? (home - 1)->sao_recon : nullptr, r > 0 ? (home - W)->sao_recon : nullptr, lambdas,
-			   sc.c.sao_coded, sc.c.sao_recon);
+			   sc.c.sao_coded, sc.c.sao_recon, sc.sao_ws);
 		g.sync();
 		// the neighbours' decisions read the parameters from the record
 		lin_copy_words(g, (const uint32_t *)sc.c.sao_recon, (uint32_t *)home->sao_recon, (int)(2 * 3 * sizeof(SaoOffset) / 4));
@@ -618,15 +622,16 @@ HENC_HDX void post_task_p(const G &g, const PostCtx &x, PostScratch &sc, int r, 
 		code_sao_blk_param(ee, sc.c.sao_coded, c > 0, r > 0);
 		PPF_LAP(P, PPF_P_DECIDE);
 	} else ee.load_ctx(g);
-	EntView v;
+	EntView &v = sc.view;
 	v.seq = x.seq; v.f = x.f; v.T = x.T; v.geo = x.geo;
-	const CtuView cv = view_of(sc.c), lv = view_of(*(c > 0 ? home - 1 : home)), tv = view_of(*(r > 0 ? home - W : home));
-	v.c = &cv;
-	v.left = c > 0 ? &lv : nullptr;
-	v.top = r > 0 ? &tv : nullptr;
+	sc.view_c = view_of(sc.c); sc.view_l = view_of(*(c > 0 ? home - 1 : home)); sc.view_t = view_of(*(r > 0 ? home - W : home));
+	v.c = &sc.view_c;
+	v.left = c > 0 ? &sc.view_l : nullptr;
+	v.top = r > 0 ? &sc.view_t : nullptr;
 	v.coeff[0] = sc.coef; v.coeff[1] = sc.coef + 4096; v.coeff[2] = sc.coef + 5120;
 	v.n = n;
 	v.prev_last_qp = (n > 0 && !(S.wpp && c == 0)) ? uni((int)(home - 1)->qp[(home - 1)->last_valid_partition]) : -1;
+	g.sync();
 	encode_ctu_syntax(g, ee, v, sc.ent);
 	ee.store_ctx(g);
 	if (P.ctx_after)

@@ -137,9 +137,11 @@ HENC_INLINE void sao_clear(SaoOffset &d)
 // sao_derive_offsets :480) and test.type_aux and returns the distortion of their reconstruction (sao_invert_quant_offsets :592 + sao_get_distortion :620).
 // st_merge / st_type: the two contexts in the real coder before this CTU's SAO syntax; left / above: the reconstructed parameters ([3]) of the neighbours or nullptr.
 // Returns in coded[3] what the syntax carries and in recon[3] what the filter applies.
+// ws: nine parameter sets of working space (the candidates under test: in the caller's fast memory, not in locals - their offset arrays are indexed at run time)
+constexpr int SAO_DECIDE_WS = 9;
 template <class Cand>
 HENC_INLINE void sao_decide(const SaoTables &T, uint8_t st_merge, uint8_t st_type, const Cand &cand, const SaoStats &stats, const SaoOffset *left, const SaoOffset *above,
-			    const double *lambdas, SaoOffset *coded, SaoOffset *recon)
+			    const double *lambdas, SaoOffset *coded, SaoOffset *recon, SaoOffset *ws)
 {
 	const SaoOffset *merge_list[2] = {left, above};
 	const int left_avail = left != nullptr, above_avail = above != nullptr;
@@ -158,13 +160,13 @@ HENC_INLINE void sao_decide(const SaoTables &T, uint8_t st_merge, uint8_t st_typ
 		code_sao_blk_param(ec, p, left_avail, above_avail);
 		return ec.bitcnt() - init;
 	};
-	SaoOffset mode_param[3];
+	SaoOffset *const mode_param = ws;
 	for (int k = 0; k < 3; k++) { sao_clear(mode_param[k]); sao_clear(coded[k]); }
 	double min_cost = MAX_COST, mode_cost;
 	// ---- SAO_MODE_NEW
 	{
 		int64_t dist[3], mode_dist[3] = {0, 0, 0};
-		SaoOffset test[3];
+		SaoOffset *const test = ws + 3;
 		double cost, mcost;
 		uint32_t rate;
 		for (int k = 0; k < 3; k++) sao_clear(test[k]);
@@ -219,7 +221,7 @@ HENC_INLINE void sao_decide(const SaoTables &T, uint8_t st_merge, uint8_t st_typ
 	// ---- SAO_MODE_MERGE (the reference's test parameters start from a copy of the candidate; the mode decision only reads what is set here)
 	{
 		mode_cost = MAX_COST;
-		SaoOffset best[3], test[3];
+		SaoOffset *const best = ws + 6, *const test = ws + 3;
 		bool have = false;
 		for (int mt = 0; mt < 2; mt++) {
 			if (!merge_list[mt]) continue;
@@ -251,7 +253,7 @@ HENC_INLINE void sao_decide(const SaoTables &T, uint8_t st_merge, uint8_t st_typ
 		if (o.mode_idc == SAO_OFF) continue;
 		if (o.mode_idc == SAO_NEW) {
 			// sao_invert_quant_offsets :592 (8 bit: step 1) - also clears what the type does not use
-			int32_t keep[32];
+			int32_t *const keep = ws[0].offset;      // (the working sets are free by now)
 			for (int k = 0; k < 32; k++) { keep[k] = o.offset[k]; o.offset[k] = 0; }
 			if (o.type_idc == SAO_BO)
 				for (int i = 0; i < 4; i++) o.offset[(o.type_aux + i) % 32] = keep[(o.type_aux + i) % 32];
