@@ -348,7 +348,7 @@ HENC_PRIM void blk_copy_to_src(const G &g, const int16_t *s, int ss, src_t *d, i
 
 // linear copies: 16 bytes per lane and step where both ends allow it, four steps in flight (the CTU's record, its 40 KB of partition nodes and its levels
 // move between HBM and the worker's fast memory at every CTU start and end)
-struct __attribute__((may_alias, aligned(16))) Q16 { uint32_t v[4]; };
+typedef uint32_t Q16 __attribute__((vector_size(16), may_alias, aligned(16)));      // (a vector, not a struct of four words: struct temporaries of the copy loops ended up in private memory)
 template <class G>
 HENC_HD void lin_copy_bytes(const G &g, const void *s, void *d, int bytes)
 {

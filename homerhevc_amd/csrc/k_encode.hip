@@ -707,7 +707,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HEN
 			continue;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (the step was opened with a release store after its predecessors' results)
-		const EncDev d = devs[q];
+		const EncDev &d = devs[q];      // (by reference: a copy of the 480-byte descriptor is thirty stores to private memory per CTU, and every d.member a load from there)
 		if (q != cached_q) {
 			for (int i = g.tid; i < (int)(sizeof(Seq) / 4); i += 64) ((uint32_t *)lseq)[i] = ((const uint32_t *)d.seq)[i];
 			for (int i = g.tid; i < (int)(sizeof(FrameCtx) / 4); i += 64) ((uint32_t *)lframe)[i] = ((const uint32_t *)d.frame)[i];
