@@ -55,6 +55,15 @@ HENC_INLINE void post_st_release(int *p, int v)
 	*p = v;
 #endif
 }
+// the store after a post_release() of the whole wavefront: the fence has published what the store announces (a release STORE would write the L2 back a second time)
+HENC_INLINE void post_st_fenced(int *p, int v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+	*p = v;
+#endif
+}
 HENC_INLINE void post_acquire()
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -776,7 +785,7 @@ HENC_HDX int post_drain(const G &g, const PostCtx &x, PostScratch &sc)
 #endif
 		else post_task_d(g, x, pick_r, pick_c);
 		post_release();
-		if (g.tid == 0) post_st_release(done, pick_c + 1);
+		if (g.tid == 0) post_st_fenced(done, pick_c + 1);
 		g.sync();
 		ran++;
 #if defined(__HIP_DEVICE_COMPILE__) && defined(HENC_POST_PROFILE)

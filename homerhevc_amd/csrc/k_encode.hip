@@ -530,7 +530,7 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 	g.sync();
 	// the CTU is decided: its post-decision tasks may run (enc_post.h)
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-	if (g.tid == 0) post_st_release(&d.post.rows[row].dec, c + 1);
+	if (g.tid == 0) post_st_fenced(&d.post.rows[row].dec, c + 1);
 }
 
 // post-decision tasks of picture q that are ready, on this worker (its Work area is scratch between two CTUs); *finished counts the pictures whose last task is done
@@ -726,8 +726,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HEN
 		if (hvalid) row = k == 0 ? hrow : (r_lo + k - 1 < hrow ? r_lo + k - 1 : r_lo + k);
 		else row = r_lo + k;
 		pool_encode_ctu(d, e, g, lseq, lframe, lft, t, row, cached_rem, finished + 1);
-		// close the step when this was its last CTU
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		// close the step when this was its last CTU (the CTU's results were published by the release fence at the end of pool_encode_ctu)
 		if (g.tid == 0) {
 			int *st = state + (size_t)q * POOL_STRIDE;
 			const int dn = atomicAdd(&st[1 + POOL_MAX_STEPS + t], 1) + 1;
