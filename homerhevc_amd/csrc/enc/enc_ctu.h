@@ -164,7 +164,7 @@ HENC_HD void refresh_deeper_windows(const G &g, Enc &__restrict__ e, int aux_ni,
 
 // encode_intra, hmr_motion_intra.c:1731
 template <class G>
-HENC_HD uint32_t encode_intra(const G &g, Enc &__restrict__ e, int curr_depth, int position, int part_size_type)
+HENC_WALK_FN HENC_HD uint32_t encode_intra(const G &g, Enc &__restrict__ e, int curr_depth, int position, int part_size_type)
 {
 	HENC_ENC_IN_LDS(e);
 	uint32_t cost = 0;
