@@ -151,6 +151,14 @@ HENC_INLINE T *in_fast_memory(T *p)
 #else
 #define HENC_ENC_IN_LDS(e) do { } while (0)
 #endif
+// The operands of the TU primitives (source / prediction windows, coefficient, level and remainder buffers of the TU in flight) are in the worker's LDS wherever the
+// encoder kernel calls them; the primitives are functions of their own with generic pointer parameters, i.e. flat_* accesses that wait for LDS and memory together.
+// k_encode.hip defines HENC_TU_OPERANDS_IN_LDS and the primitives say so per operand; the test harness (k_primtest.hip: operands in HBM) does not.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(HENC_TU_OPERANDS_IN_LDS)
+#define HENC_OP_IN_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void *)(p)))
+#else
+#define HENC_OP_IN_LDS(p) do { } while (0)
+#endif
 // ... and a pointer into HBM (the worker's slow windows): kept as a pointer of the global address space, what is derived from it are global_* accesses instead of
 // flat_* ones (which wait for LDS and memory operations alike and decide per lane where they go)
 #if defined(__HIP_DEVICE_COMPILE__)

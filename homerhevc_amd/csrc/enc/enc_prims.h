@@ -1227,6 +1227,7 @@ template <class G, class S, class P>
 HENC_PRIM void tr_forward(const G &g, const FastTables *F, const DevTables *T, const S *orig, int os, const P *pred, int ps, int16_t *coeff, int16_t *tmp, int n, int is_dst)
 {
 	PRIM_T0();
+	HENC_OP_IN_LDS(orig); HENC_OP_IN_LDS(pred); HENC_OP_IN_LDS(coeff); HENC_OP_IN_LDS(tmp);
 #if defined(HENC_MFMA_TRANSFORM)
 #if !defined(HENC_MFMA_NO_FWD)
 	if constexpr (G::n == 64 && sizeof(S) == 1 && sizeof(P) == 1) {      // (bytes: the residual is within +-255)
@@ -1277,6 +1278,7 @@ template <class G>
 HENC_PRIM void tr_inverse(const G &g, const FastTables *F, const DevTables *T, int16_t *block, int bs, const int16_t *coeff, int16_t *tmp, int n, int is_dst)
 {
 	PRIM_T0();
+	HENC_OP_IN_LDS(block); HENC_OP_IN_LDS(coeff); HENC_OP_IN_LDS(tmp);
 #if defined(HENC_MFMA_TRANSFORM) && !defined(HENC_MFMA_NO_INV)
 #if !defined(HENC_MFMA_INV_MASK)
 #define HENC_MFMA_INV_MASK 15
@@ -1318,6 +1320,7 @@ template <class G>
 __device__ __forceinline__ void tr_inverse_pair(const G &g, bool live, const DevTables *T, int16_t *block, int bs, const int16_t *coeff, int n)
 {
 	PRIM_T0();
+	HENC_OP_IN_LDS(block); HENC_OP_IN_LDS(coeff);
 	const int lane = g.half * 32 + g.tid;
 	if (n == 4) tr_inverse_mfma_pair<4>(lane, live, T, block, bs, coeff);
 	else tr_inverse_mfma_pair<8>(lane, live, T, block, bs, coeff);
@@ -1417,6 +1420,7 @@ HENC_PRIM int quantize(const G &g, const FastTables *F, const DevTables *T, cons
 		     int is_intra, int slice_is_intra, int sign_hiding, int n, int per, int rem)
 {
 	PRIM_T0();
+	HENC_OP_IN_LDS(src); HENC_OP_IN_LDS(dst); HENC_OP_IN_LDS(delta_u);
 	const int inv_depth = 6 - (depth + (comp != 0));
 	const int list = (is_intra ? 0 : 3) + comp, rc = comp != 0;
 	const bool fast = F && F->valid && F->rem[rc] == rem;
@@ -1466,6 +1470,7 @@ template <class G>
 HENC_PRIM void dequantize(const G &g, const FastTables *F, const DevTables *T, const int16_t *src, int16_t *dst, int depth, int comp, int is_intra, int n, int per, int rem)
 {
 	PRIM_T0();
+	HENC_OP_IN_LDS(src); HENC_OP_IN_LDS(dst);
 	const int inv_depth = 6 - (depth + (comp != 0));
 	const int list = is_intra ? 0 : 3 + comp, rc = comp != 0;      // (the reference's expression: intra blocks of every component use list 0)
 	const bool fast = F && F->valid && F->rem[rc] == rem;

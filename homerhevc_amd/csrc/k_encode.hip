@@ -17,6 +17,7 @@
 // frames of a sequence - hmr_gpu_enc_encode_chain - get them from S tasks of the launch instead).  Behind a CTU's decisions everything else of the frame is
 // post-decision TASKS of the same launch (enc/enc_post.h: deblocking, SAO, CABAC of the CTU rows' sub-streams, padding); the single-thread order, whose
 // decisions are final only after its verification passes, runs them as one more launch (k_post_frame).  The host assembles the access unit.
+#define HENC_TU_OPERANDS_IN_LDS 1      // (enc_platform.h: the TU primitives' operands are in this kernel's LDS)
 #include <stddef.h>
 #include <stdlib.h>
 #include <chrono>
