@@ -474,11 +474,12 @@ def main():
             out["single_thread_order"] = {k: other[k] for k in ("value", "unit", "ms_per_step", "stream_md5", "stream_matches_reference", "frames_checked_against_reference", "schedule")}
             out["single_thread_order"]["note"] = "the same encode with wfpp_num_threads = 1: output identical to the reference's single-thread run (md5 2f0c3447...), which costs guesses, verification and re-encode passes"
             # the metric's other picture size: 2160p, 34 CTU rows on the reference's maximum of 32 WPP threads, I + P and four timed P frames:
-            # a batch of 96 sequences (3264 CTU rows for the 512 workers of the pool) and one sequence alone
+            # a batch of 192 sequences (6528 CTU rows for the 1024 workers of the pool: 96 sequences gave 86.5 frames/s, 128 91.9, 192 95.6 - the head and tail of every
+            # picture's wavefront leave workers idle, more pictures fill them) and one sequence alone
             import copy
             b = copy.copy(a)
             b.warmup, b.steps = 2, 4
-            big = run_workload(lib, b, "cfg2-2160p-encode", world, rank, local, torch, sequences=96 if a.sequences > 1 else 1)
+            big = run_workload(lib, b, "cfg2-2160p-encode", world, rank, local, torch, sequences=192 if a.sequences > 1 else 1)
             out["at_2160p"] = {k: big[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "stream_md5", "stream_matches_reference", "frames_checked_against_reference", "clips")}
             out["at_2160p"]["config"] = big["config"]
             if a.sequences > 1:
@@ -495,21 +496,23 @@ def main():
                     lanes.append({k: r[k] for k in ("workload", "engines", "objects_per_engine", "chain", "frames", "frames_per_s_full_chains", "frames_per_s_after_first_chain", "stream_matches_reference",
                                                    "ctu_launch_ms_per_chain")})
             out.setdefault("single_sequence", {})["engines_overlapped"] = lanes
-            # BASELINE.json configs[2]: 2160p CBR 20000 kbps, performance_mode 1 - a batch of 32 sequences and one sequence alone (the fixture covers ten frames)
+            # BASELINE.json configs[2]: 2160p CBR 20000 kbps, performance_mode 1 - a batch of 128 sequences (32: 56 frames/s, 64: 97, 96: 115, 128: 122 - rate control gates a
+            # picture's wavefront steps on its entropy coder, so a launch needs many pictures) and one sequence alone (the fixture covers ten frames)
             import copy
             c3 = copy.copy(a)
             c3.warmup, c3.steps = 2, 6
-            r3 = run_workload(lib, c3, "cfg3-2160p-cbr", world, rank, local, torch, sequences=32 if a.sequences > 1 else 1)
+            r3 = run_workload(lib, c3, "cfg3-2160p-cbr", world, rank, local, torch, sequences=128 if a.sequences > 1 else 1)
             out["cfg3_2160p_cbr"] = {k: r3[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "stream_md5", "stream_matches_reference", "frames_checked_against_reference", "clips")}
             out["cfg3_2160p_cbr"]["config"] = dict(r3["config"], bitrate_mode="CBR", bitrate_kbps=20000, vbv_size_kbit=20000, performance_mode=1)
             if a.sequences > 1:
                 r31 = run_workload(lib, c3, "cfg3-2160p-cbr", world, rank, local, torch)
                 out["cfg3_2160p_cbr"]["single_sequence"] = {k: r31[k] for k in ("value", "ms_per_step", "stream_matches_reference")}
-            # BASELINE.json configs[4]: 2160p all-intra, full RDO, intra TU depth 4 - a batch of 32 sequences and one sequence alone (the fixture covers eight frames)
+            # BASELINE.json configs[4]: 2160p all-intra, full RDO, intra TU depth 4 - a batch of 96 sequences (32: 10.8 frames/s, 64: 14.8, 96: 15.9) and one sequence alone
+            # (the fixture covers eight frames)
             if "cfg5-2160p-intra-rdfull" in REFERENCE_MD5:
                 c5 = copy.copy(a)
-                c5.warmup, c5.steps = 2, 4
-                r5 = run_workload(lib, c5, "cfg5-2160p-intra-rdfull", world, rank, local, torch, sequences=32 if a.sequences > 1 else 1)
+                c5.warmup, c5.steps = 1, 3
+                r5 = run_workload(lib, c5, "cfg5-2160p-intra-rdfull", world, rank, local, torch, sequences=96 if a.sequences > 1 else 1)
                 out["cfg5_2160p_intra_rdfull"] = {k: r5[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "stream_md5", "stream_matches_reference", "frames_checked_against_reference", "clips")}
                 out["cfg5_2160p_intra_rdfull"]["config"] = r5["config"]
                 if a.sequences > 1:
