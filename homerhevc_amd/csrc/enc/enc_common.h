@@ -161,7 +161,7 @@ static_assert(sizeof(HelperBox) <= LDS_BOX_BYTES && sizeof(Enc) <= LDS_ENC_BYTES
 #endif
 
 template <class G>
-HENC_HD void helper_post(const G &g, Enc &__restrict__ e, int h, int job, int a0 = 0, int a1 = 0, int a2 = 0, int a3 = 0, int a4 = 0, int a5 = 0)
+HENC_HD void helper_post(const G g, Enc &__restrict__ e, int h, int job, int a0 = 0, int a1 = 0, int a2 = 0, int a3 = 0, int a4 = 0, int a5 = 0)
 {
 	HENC_ENC_IN_LDS(e);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -177,7 +177,7 @@ HENC_HD void helper_post(const G &g, Enc &__restrict__ e, int h, int job, int a0
 #endif
 }
 template <class G>
-HENC_HD void helper_wait(const G &g, Enc &__restrict__ e, int h)
+HENC_HD void helper_wait(const G g, Enc &__restrict__ e, int h)
 {
 	HENC_ENC_IN_LDS(e);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -329,7 +329,7 @@ HENC_INLINE CtuPublic *pu_top_left(Enc &__restrict__ e, int ni, uint32_t *idx)
 // ---- window consolidation (hmr_motion_intra.c:844-890, hmr_motion_intra_chroma.c:29-90, hmr_mem_transfer.c:125-176) -------
 // bottom row and right column of a CU, luma: what later blocks of a deeper window need as neighbours
 template <class G>
-HENC_HD void sync_reference_buffs(const G &g, Enc &__restrict__ e, int ni, int src_wnd, int dst_wnd)
+HENC_HD void sync_reference_buffs(const G g, Enc &__restrict__ e, int ni, int src_wnd, int dst_wnd)
 {
 	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
@@ -346,7 +346,7 @@ HENC_HD void sync_reference_buffs(const G &g, Enc &__restrict__ e, int ni, int s
 }
 // the same samples into the windows first_dst .. last_dst: read once (the windows live in HBM: every copy is a trip there and back), written to each
 template <class G>
-HENC_HD void sync_reference_buffs_range(const G &g, Enc &__restrict__ e, int ni, int src_wnd, int first_dst, int last_dst)
+HENC_HD void sync_reference_buffs_range(const G g, Enc &__restrict__ e, int ni, int src_wnd, int first_dst, int last_dst)
 {
 	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
@@ -369,7 +369,7 @@ HENC_HD void sync_reference_buffs_range(const G &g, Enc &__restrict__ e, int ni,
 	PRIM_END(PP_SYNC);
 }
 template <class G>
-HENC_HD void sync_reference_buffs_chroma(const G &g, Enc &__restrict__ e, int ni, int src_wnd, int dst_wnd)
+HENC_HD void sync_reference_buffs_chroma(const G g, Enc &__restrict__ e, int ni, int src_wnd, int dst_wnd)
 {
 	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
@@ -389,7 +389,7 @@ HENC_HD void sync_reference_buffs_chroma(const G &g, Enc &__restrict__ e, int ni
 }
 // whole CU: reconstruction (2-D) and levels (linear), one component
 template <class G>
-HENC_HD void sync_cu_comp(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst, int comp)
+HENC_HD void sync_cu_comp(const G g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst, int comp)
 {
 	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
@@ -428,7 +428,7 @@ HENC_HD void sync_cu_comp(const G &g, Enc &__restrict__ e, int ni, int q_src, in
 }
 // both chroma components of a CU in one pass: the reads of U and V are issued together (one trip to the windows instead of two; what a helper that takes both planes does)
 template <class G>
-HENC_HD void sync_cu_chroma_both(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
+HENC_HD void sync_cu_chroma_both(const G g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
 {
 	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
@@ -468,13 +468,13 @@ HENC_HD void sync_cu_chroma_both(const G &g, Enc &__restrict__ e, int ni, int q_
 	PRIM_END(PP_SYNC);
 }
 template <class G>
-HENC_HD void sync_motion_buffers_luma(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
+HENC_HD void sync_motion_buffers_luma(const G g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
 {
 	HENC_ENC_IN_LDS(e);
 	sync_cu_comp(g, e, ni, q_src, q_dst, d_src, d_dst, COMP_Y);
 }
 template <class G>
-HENC_HD void sync_motion_buffers_chroma(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
+HENC_HD void sync_motion_buffers_chroma(const G g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
 {
 	HENC_ENC_IN_LDS(e);
 	sync_cu_comp(g, e, ni, q_src, q_dst, d_src, d_dst, COMP_U);
@@ -483,7 +483,7 @@ HENC_HD void sync_motion_buffers_chroma(const G &g, Enc &__restrict__ e, int ni,
 
 // both: with helper wavefronts the chroma planes are copied while the worker copies luma
 template <class G>
-HENC_HD void sync_motion_buffers(const G &g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
+HENC_HD void sync_motion_buffers(const G g, Enc &__restrict__ e, int ni, int q_src, int q_dst, int d_src, int d_dst)
 {
 	HENC_ENC_IN_LDS(e);
 	if (HENC_HELPERS(e)) {
@@ -501,7 +501,7 @@ HENC_HD void sync_motion_buffers(const G &g, Enc &__restrict__ e, int ni, int q_
 
 // the depth-3 and depth-4 nodes of quadrant `quad` into the worker's fast copy (the ones that were there go back to the CTU's record first)
 template <class G>
-HENC_HD void nodes_quad_move(const G &g, Enc &__restrict__ e, int quad, int to_record)
+HENC_HD void nodes_quad_move(const G g, Enc &__restrict__ e, int quad, int to_record)
 {
 	HENC_ENC_IN_LDS(e);
 	constexpr int W3 = (int)(sizeof(Node) * NODE_QUAD_D3 / 4), W4 = (int)(sizeof(Node) * NODE_QUAD_D4 / 4);
@@ -515,7 +515,7 @@ HENC_HD void nodes_quad_move(const G &g, Enc &__restrict__ e, int quad, int to_r
 	g.sync();
 }
 template <class G>
-HENC_HD void nodes_select_quad(const G &g, Enc &__restrict__ e, int quad)
+HENC_HD void nodes_select_quad(const G g, Enc &__restrict__ e, int quad)
 {
 	HENC_ENC_IN_LDS(e);
 	if (quad == e.node_quad) return;
@@ -526,7 +526,7 @@ HENC_HD void nodes_select_quad(const G &g, Enc &__restrict__ e, int quad)
 }
 // the fast copy back into the CTU's record
 template <class G>
-HENC_HD void nodes_write_back(const G &g, Enc &__restrict__ e)
+HENC_HD void nodes_write_back(const G g, Enc &__restrict__ e)
 {
 	HENC_ENC_IN_LDS(e);
 	g.sync();

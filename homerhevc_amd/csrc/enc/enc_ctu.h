@@ -13,7 +13,7 @@ namespace henc {
 // CONSOLIDATE_ENC_INFO_BUFFS :3298 (dir = 0: CTU arrays <- worker buffers of `depth`) and its inverse (get_back :3461-3466,
 // consolidate_info_buffers_for_rd hmr_motion_intra.c:1632)
 template <class G>
-HENC_HD void info_buffs_copy(const G &g, Enc &__restrict__ e, int depth, int abs_idx, int num, int to_ctu)
+HENC_HD void info_buffs_copy(const G g, Enc &__restrict__ e, int depth, int abs_idx, int num, int to_ctu)
 {
 	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
@@ -45,7 +45,7 @@ HENC_HD void info_buffs_copy(const G &g, Enc &__restrict__ e, int depth, int abs
 
 // SET_INTER_INFO_BUFFS :3309
 template <class G>
-HENC_HD void set_inter_info_buffs(const G &g, Enc &__restrict__ e, int ni)
+HENC_HD void set_inter_info_buffs(const G g, Enc &__restrict__ e, int ni)
 {
 	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
@@ -80,14 +80,14 @@ HENC_HD void set_inter_info_buffs(const G &g, Enc &__restrict__ e, int ni)
 
 // get_back_consolidated_info :3456 / put_consolidated_info :3472
 template <class G>
-HENC_HD void get_back_consolidated_info(const G &g, Enc &__restrict__ e, int ni, int depth)
+HENC_HD void get_back_consolidated_info(const G g, Enc &__restrict__ e, int ni, int depth)
 {
 	HENC_ENC_IN_LDS(e);
 	info_buffs_copy(g, e, depth, e.geo[ni].abs_index, e.geo[ni].num_part, 0);
 	sync_motion_buffers(g, e, ni, 0, depth + 1, 0, depth + 1);
 }
 template <class G>
-HENC_HD void put_consolidated_info(const G &g, Enc &__restrict__ e, int ni, int depth)
+HENC_HD void put_consolidated_info(const G g, Enc &__restrict__ e, int ni, int depth)
 {
 	HENC_ENC_IN_LDS(e);
 	info_buffs_copy(g, e, depth, e.geo[ni].abs_index, e.geo[ni].num_part, 1);
@@ -97,7 +97,7 @@ HENC_HD void put_consolidated_info(const G &g, Enc &__restrict__ e, int ni, int 
 // consolidate_prediction_info :3372.  Returns true when the children were taken (the caller's running cost of the parent's depth then changes by
 // children_cost - parent_cost, as the reference does inside).
 template <class G>
-HENC_HD bool consolidate_prediction_info(const G &g, Enc &__restrict__ e, int pi, uint32_t parent_cost, uint32_t children_cost, int is_max_depth)
+HENC_HD bool consolidate_prediction_info(const G g, Enc &__restrict__ e, int pi, uint32_t parent_cost, uint32_t children_cost, int is_max_depth)
 {
 	HENC_ENC_IN_LDS(e);
 	const Geo &pq = e.geo[pi];
@@ -149,7 +149,7 @@ HENC_HD bool consolidate_prediction_info(const G &g, Enc &__restrict__ e, int pi
 // the reference-sample refresh after a CU (sub)tree is final: bottom row / right column of the consolidated reconstruction
 // into the deeper windows (hmr_motion_inter.c:3985-4001 and :4222-4230, hmr_motion_intra.c:1899-1916, 1956-1974)
 template <class G>
-HENC_HD void refresh_deeper_windows(const G &g, Enc &__restrict__ e, int aux_ni, int from_depth, int with_info)
+HENC_HD void refresh_deeper_windows(const G g, Enc &__restrict__ e, int aux_ni, int from_depth, int with_info)
 {
 	HENC_ENC_IN_LDS(e);
 	const int max_processing_depth = hmin(CFG_MAX_PRED_DEPTH + e.seq->max_intra_tr_depth - 1, NDEPTH - 1);
@@ -164,7 +164,7 @@ HENC_HD void refresh_deeper_windows(const G &g, Enc &__restrict__ e, int aux_ni,
 
 // encode_intra, hmr_motion_intra.c:1731
 template <class G>
-HENC_WALK_FN HENC_HD uint32_t encode_intra(const G &g, Enc &__restrict__ e, int curr_depth, int position, int part_size_type)
+HENC_WALK_FN HENC_HD uint32_t encode_intra(const G g, Enc &__restrict__ e, int curr_depth, int position, int part_size_type)
 {
 	HENC_ENC_IN_LDS(e);
 	uint32_t cost = 0;
@@ -185,7 +185,7 @@ HENC_WALK_FN HENC_HD uint32_t encode_intra(const G &g, Enc &__restrict__ e, int 
 
 // check_rd_cost_merge_2nx2n :3493 (P slice)
 template <class G>
-HENC_WALK_FN HENC_HD uint32_t check_rd_cost_merge(const G &g, Enc &__restrict__ e, int depth, int position)
+HENC_WALK_FN HENC_HD uint32_t check_rd_cost_merge(const G g, Enc &__restrict__ e, int depth, int position)
 {
 	HENC_ENC_IN_LDS(e);
 	Work &w = *e.w;
@@ -351,7 +351,7 @@ HENC_INLINE int scene_cut_fires(const Seq &S, const FrameCtx &f, uint32_t intra_
 
 // motion_inter_full :3746
 template <class G>
-HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &__restrict__ e)
+HENC_HD uint32_t motion_inter_ctu(const G g, Enc &__restrict__ e)
 {
 	HENC_ENC_IN_LDS(e);
 	const Seq &S = *e.seq;
@@ -524,7 +524,7 @@ HENC_HD uint32_t motion_inter_ctu(const G &g, Enc &__restrict__ e)
 // flags level by level, the partitions of a level side by side.  Variances sit in the TU scratch (free before the walk), the flags as a bit per node in Work::rsplit.
 HENC_INLINE bool rsplit_of(const Work &w, int ni) { return (w.rsplit[ni >> 5] >> (ni & 31)) & 1u; }
 template <class G>
-HENC_HD void analyse_recursive_info(const G &g, Enc &__restrict__ e)
+HENC_HD void analyse_recursive_info(const G g, Enc &__restrict__ e)
 {
 	HENC_ENC_IN_LDS(e);
 	const Seq &S = *e.seq;
@@ -575,7 +575,7 @@ HENC_HD void analyse_recursive_info(const G &g, Enc &__restrict__ e)
 
 // motion_intra_cu, hmr_motion_intra.c:1759
 template <class G>
-HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
+HENC_HD uint32_t motion_intra_ctu(const G g, Enc &__restrict__ e)
 {
 	HENC_ENC_IN_LDS(e);
 	const Seq &S = *e.seq;
@@ -680,7 +680,7 @@ HENC_HD uint32_t motion_intra_ctu(const G &g, Enc &__restrict__ e)
 // The reference walks the tree depth-first; a node only reads its parent, so the levels are done one after the other with the nodes of a level side by side.
 // A node is reached when its parent's top-left corner lies inside the picture (then so do the corners of the parent's ancestors).
 template <class G>
-HENC_HD void create_partition_neighbours(const G &g, Enc &__restrict__ e)
+HENC_HD void create_partition_neighbours(const G g, Enc &__restrict__ e)
 {
 	HENC_ENC_IN_LDS(e);
 	const Seq &S = *e.seq;
@@ -727,7 +727,7 @@ HENC_HD void create_partition_neighbours(const G &g, Enc &__restrict__ e)
 
 // init_ctu :2254 + CuGetNeighbors :2160, mem_transfer_move_curr_ctu_group / mem_transfer_intra_refs (hmr_mem_transfer.c:284,351)
 template <class G>
-HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
+HENC_HD void ctu_begin(const G g, Enc &__restrict__ e, int ctu_num)
 {
 	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
@@ -821,7 +821,7 @@ HENC_HD void ctu_begin(const G &g, Enc &__restrict__ e, int ctu_num)
 
 // mem_transfer_decoded_blocks :312 + the coefficient copy (hmr_encoder_lib.c:2942-2945) + the thread counters (:2924-2940)
 template <class G>
-HENC_HD void ctu_end(const G &g, Enc &__restrict__ e)
+HENC_HD void ctu_end(const G g, Enc &__restrict__ e)
 {
 	HENC_ENC_IN_LDS(e);
 	PRIM_T0();
@@ -854,7 +854,7 @@ HENC_HD void ctu_end(const G &g, Enc &__restrict__ e)
 
 // tokens -> values, for the worker buffers and the CTU's mode arrays, once the values behind the tokens (Work::mode_in) are the true ones
 template <class G>
-HENC_HD void resolve_mode_tokens(const G &g, Work &w, CtuPublic &c)
+HENC_HD void resolve_mode_tokens(const G g, Work &w, CtuPublic &c)
 {
 	for (int i = g.tid; i < 2 * NDEPTH * NPART; i += g.n) {
 		uint8_t &v = (&w.intra_mode_buffs[0][0][0])[i];
@@ -871,7 +871,7 @@ template <class G>
 #if defined(__HIPCC__)
 __attribute__((noinline))   // one compiled body for every kernel that encodes CTUs
 #endif
-HENC_HD void encode_ctu(const G &g, Enc &__restrict__ e, int ctu_num)
+HENC_HD void encode_ctu(const G g, Enc &__restrict__ e, int ctu_num)
 {
 	HENC_ENC_IN_LDS(e);
 	{ HENC_PROF_T0(); ctu_begin(g, e, ctu_num); HENC_PROF_ADD(e, PF_SETUP); }

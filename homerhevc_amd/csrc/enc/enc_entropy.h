@@ -131,7 +131,7 @@ struct Cabac {
 		return (uint8_t)(((mp ? st - 64 : 63 - st) << 1) + mp);
 	}
 	template <class G>
-	HENC_FI void init_contexts(const G &g, int slice_type, int qp)
+	HENC_FI void init_contexts(const G g, int slice_type, int qp)
 	{
 		for (int i = g.tid; i < CTX_TOTAL; i += g.n) ctx[i] = init_state(slice_type, qp, i);
 		g.sync();
@@ -163,7 +163,7 @@ struct Cabac {
 	uint32_t cw = 0, trw = 0, tnw = 0, my_lane = 0;
 	static_assert(CTX_TOTAL <= 192, "three context bytes per lane");
 	template <class G>
-	HENC_FI void load_ctx(const G &g)
+	HENC_FI void load_ctx(const G g)
 	{
 		my_lane = (uint32_t)g.tid;
 		cw = (uint32_t)ctx[g.tid] | (uint32_t)ctx[64 + g.tid] << 8 | (128 + g.tid < CTX_TOTAL ? (uint32_t)ctx[128 + g.tid] << 16 : 0u);
@@ -172,7 +172,7 @@ struct Cabac {
 		tnw = (uint32_t)kNextStateLps[l4] | (uint32_t)kNextStateLps[l4 + 1] << 8 | (uint32_t)kNextStateLps[l4 + 2] << 16 | (uint32_t)kNextStateLps[l4 + 3] << 24;
 	}
 	template <class G>
-	HENC_FI void store_ctx(const G &g)
+	HENC_FI void store_ctx(const G g)
 	{
 		ctx[g.tid] = (uint8_t)cw;
 		ctx[64 + g.tid] = (uint8_t)(cw >> 8);
@@ -464,7 +464,7 @@ HENC_FI void encode_last_xy(Cabac &ee, int x, int y, int shift, int comp, int sc
 // walk below would pay a trip to memory per coefficient), together with the last significant position and the coefficient-group flags; the syntax walk then
 // reads the scratch only.
 template <class G>
-HENC_FI void encode_residual(const G &g, Cabac &ee, const EntView &v, EntScratch &sc, int ni, int comp)
+HENC_FI void encode_residual(const G g, Cabac &ee, const EntView &v, EntScratch &sc, int ni, int comp)
 {
 	const Seq &S = *v.seq;
 	ENT_PROF_T0();
@@ -700,7 +700,7 @@ HENC_FI void encode_delta_qp(Cabac &ee, const EntView &v, const DqpState &dq, in
 
 // transform_tree :1561
 template <class G>
-HENC_FI void encode_transform_tree(const G &g, Cabac &ee, const EntView &v, EntScratch &sc, DqpState &dq, int top_ni)
+HENC_FI void encode_transform_tree(const G g, Cabac &ee, const EntView &v, EntScratch &sc, DqpState &dq, int top_ni)
 {
 	const Seq &S = *v.seq;
 	const CtuView *c = v.c;
@@ -814,7 +814,7 @@ HENC_FI void encode_end_of_cu(Cabac &ee, const EntView &v, int ni)
 
 // ee_encode_coding_unit :1787
 template <class G>
-HENC_FI void encode_coding_unit(const G &g, Cabac &ee, const EntView &v, EntScratch &sc, DqpState &dq, int ni)
+HENC_FI void encode_coding_unit(const G g, Cabac &ee, const EntView &v, EntScratch &sc, DqpState &dq, int ni)
 {
 	const Seq &S = *v.seq;
 	const CtuView *c = v.c;
@@ -918,7 +918,7 @@ HENC_FI void encode_coding_unit(const G &g, Cabac &ee, const EntView &v, EntScra
 // coded CU of its quantisation group (the CTU) takes the predictor as its QP (:2091-2104) - written into the record, where the next CTU's predictor and the
 // delta-QP of this one read it.
 template <class G>
-HENC_FI void encode_ctu_syntax(const G &g, Cabac &ee, const EntView &v, EntScratch &sc)
+HENC_FI void encode_ctu_syntax(const G g, Cabac &ee, const EntView &v, EntScratch &sc)
 {
 	const Seq &S = *v.seq;
 	DepthState depth_state;

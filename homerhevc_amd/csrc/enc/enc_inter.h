@@ -14,7 +14,7 @@ namespace henc {
 #if !defined(__HIPCC__)
 // `ref` points at the co-located block (mv = 0) in the padded reference plane
 template <class G>
-HENC_HD void mc_luma_interp(const G &g, Enc &__restrict__ e, const int16_t *ref, int rs, int16_t *pred, int ps, int n, int mvx, int mvy)
+HENC_HD void mc_luma_interp(const G g, Enc &__restrict__ e, const int16_t *ref, int rs, int16_t *pred, int ps, int n, int mvx, int mvy)
 {
 	HENC_ENC_IN_LDS(e);
 	const int xf = mvx & 3, yf = mvy & 3;
@@ -29,7 +29,7 @@ HENC_HD void mc_luma_interp(const G &g, Enc &__restrict__ e, const int16_t *ref,
 	}
 }
 template <class G>
-HENC_HD void mc_chroma_interp(const G &g, Enc &__restrict__ e, const int16_t *ref, int rs, int16_t *pred, int ps, int n, int mvx, int mvy)
+HENC_HD void mc_chroma_interp(const G g, Enc &__restrict__ e, const int16_t *ref, int rs, int16_t *pred, int ps, int n, int mvx, int mvy)
 {
 	HENC_ENC_IN_LDS(e);
 	const int xf = mvx & 7, yf = mvy & 7;
@@ -46,7 +46,7 @@ HENC_HD void mc_chroma_interp(const G &g, Enc &__restrict__ e, const int16_t *re
 
 // prediction of the node's three blocks for the vector mv (hmr_motion_compensation_luma / _chroma :1779-1907, uni-directional)
 template <class G>
-HENC_HD void motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv)
+HENC_HD void motion_compensate_cu(const G g, Enc &__restrict__ e, int ni, MV mv)
 {
 	HENC_ENC_IN_LDS(e);
 	Work &w = *e.w;
@@ -99,7 +99,7 @@ HENC_HD void motion_compensate_cu(const G &g, Enc &__restrict__ e, int ni, MV mv
 // SADs of the source block at (ox, oy) of the CTU against the reference displaced by (qx[k], qy[k]) quarter samples from the co-located block at picture
 // position (gx, gy), for the candidates with ok[k]: a round of the motion search in one go
 template <int MAXC, class G>
-HENC_HD void cand_sads(const G &g, Enc &__restrict__ e, int ox, int oy, int gx, int gy, int size, const int (&qx)[MAXC], const int (&qy)[MAXC], const bool (&ok)[MAXC],
+HENC_HD void cand_sads(const G g, Enc &__restrict__ e, int ox, int oy, int gx, int gy, int size, const int (&qx)[MAXC], const int (&qy)[MAXC], const bool (&ok)[MAXC],
 		       uint32_t (&out)[MAXC])
 {
 	HENC_ENC_IN_LDS(e);
@@ -189,7 +189,7 @@ HENC_INLINE uint32_t mv_cost_sqrt(const MvCandList &l, uint32_t qp, int mvx, int
 // The candidates of a search round do not depend on each other - only the comparisons do - so every round asks for all its SADs at once (cand_sads) and
 // then walks them in the reference's order, with its loop bounds that move while the loop runs.
 template <class G>
-HENC_HD uint32_t motion_estimation(const G &g, Enc &__restrict__ e, int ox, int oy, int gx, int gy, int size, const MvCandList &amvp, const MvCandList &search, double corr,
+HENC_HD uint32_t motion_estimation(const G g, Enc &__restrict__ e, int ox, int oy, int gx, int gy, int size, const MvCandList &amvp, const MvCandList &search, double corr,
 				   int action, MV *mv_io, MV *subpix_out)
 {
 	HENC_ENC_IN_LDS(e);
@@ -524,7 +524,7 @@ HENC_INLINE void get_merge_candidates(Enc &__restrict__ e, int ni, MvCandList &l
 // ---- inter TUs ---------------------------------------------------------------------------------------------------------
 // encode_inter_cu :40 (comp 0) / encode_inter_cu_chroma :133: DCT + quant, keep-or-drop decision in the residual domain, reconstruction
 template <class G>
-HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int comp, int depth, int part_size_type, int *curr_sum, uint32_t *raw_ssq = nullptr, int scratch_off = 0)
+HENC_HD uint32_t encode_inter_tu(const G g, Enc &__restrict__ e, int ni, int comp, int depth, int part_size_type, int *curr_sum, uint32_t *raw_ssq = nullptr, int scratch_off = 0)
 {
 	HENC_ENC_IN_LDS(e);
 	Work &w = *e.w;
@@ -598,7 +598,7 @@ HENC_HD uint32_t encode_inter_tu(const G &g, Enc &__restrict__ e, int ni, int co
 
 // the three components of one TU, one after the other
 template <class G>
-HENC_HD void inter_tu_all_comps(const G &g, Enc &__restrict__ e, int curr, int depth, int part_size_type, int has_chroma, uint32_t *dist, int *sums)
+HENC_HD void inter_tu_all_comps(const G g, Enc &__restrict__ e, int curr, int depth, int part_size_type, int has_chroma, uint32_t *dist, int *sums)
 {
 	HENC_ENC_IN_LDS(e);
 	dist[0] = encode_inter_tu(g, e, curr, COMP_Y, depth, part_size_type, &sums[0]);
@@ -613,7 +613,7 @@ HENC_HD void inter_tu_all_comps(const G &g, Enc &__restrict__ e, int curr, int d
 
 // SET_ENC_INFO_BUFFS :2451
 template <class G>
-HENC_HD void set_enc_info_buffs(const G &g, Enc &__restrict__ e, int ni, int depth)
+HENC_HD void set_enc_info_buffs(const G g, Enc &__restrict__ e, int ni, int depth)
 {
 	HENC_ENC_IN_LDS(e);
 	const Geo &q = e.geo[ni];
@@ -630,7 +630,7 @@ HENC_HD void set_enc_info_buffs(const G &g, Enc &__restrict__ e, int ni, int dep
 
 // encode_inter :3071 - the transform tree of an inter CU; referenced by the prediction depth
 template <class G>
-HENC_WALK_FN HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
+HENC_WALK_FN HENC_HD uint32_t encode_inter(const G g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
 {
 	HENC_ENC_IN_LDS(e);
 	const Seq &S = *e.seq;
@@ -797,7 +797,7 @@ HENC_WALK_FN HENC_HD uint32_t encode_inter(const G &g, Enc &__restrict__ e, int 
 
 // SET_INTER_MV_BUFFS :2460 + the reference-index memsets that follow it in predict_inter :3042-3044
 template <class G>
-HENC_HD void set_inter_mv_buffs(const G &g, Enc &__restrict__ e, int ni)
+HENC_HD void set_inter_mv_buffs(const G g, Enc &__restrict__ e, int ni)
 {
 	HENC_ENC_IN_LDS(e);
 	const Geo &q = e.geo[ni];
@@ -811,7 +811,7 @@ HENC_HD void set_inter_mv_buffs(const G &g, Enc &__restrict__ e, int ni)
 
 // predict_inter :2924 (uni-directional): vector predictor choice, motion compensation, residual.  Returns the vector cost.
 template <class G>
-HENC_HD int predict_inter(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
+HENC_HD int predict_inter(const G g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
 {
 	HENC_ENC_IN_LDS(e);
 	int curr = node_at(e, depth, part_position), num_partitions = 1;
@@ -839,7 +839,7 @@ HENC_HD int predict_inter(const G &g, Enc &__restrict__ e, int depth, int part_p
 
 // hmr_cu_motion_estimation :2471 (list 0, one reference).  Returns SAD + vector cost.
 template <class G>
-HENC_HD int cu_motion_estimation(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type, int action)
+HENC_HD int cu_motion_estimation(const G g, Enc &__restrict__ e, int depth, int part_position, int part_size_type, int action)
 {
 	HENC_ENC_IN_LDS(e);
 	Work &w = *e.w;

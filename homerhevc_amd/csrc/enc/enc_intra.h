@@ -17,7 +17,7 @@ HENC_INLINE int intra_is_filtered(int mode, int inv_depth)
 
 // fill_reference_samples for the node's block of component class `comp` in decoded window `wnd` (+ smoothing when asked)
 template <class G>
-HENC_HD void node_fill_refs(const G &g, Enc &__restrict__ e, int ni, int wnd, int comp, int want_filtered)
+HENC_HD void node_fill_refs(const G g, Enc &__restrict__ e, int ni, int wnd, int comp, int want_filtered)
 {
 	HENC_ENC_IN_LDS(e);
 	const Geo &q = e.geo[ni];
@@ -146,7 +146,7 @@ HENC_INLINE uint32_t intra_luma_cost(uint32_t tu_cost, int mode_bits, double cor
 
 // homer_loop1_motion_intra, hmr_motion_intra.c:1084-1180.  Returns the bit cost of the winner; *best_mode / *best_cost out.
 template <class G>
-HENC_HD int intra_mode_search(const G &g, Enc &__restrict__ e, int ni, int depth, int *best_mode_out, double *best_cost_out)
+HENC_HD int intra_mode_search(const G g, Enc &__restrict__ e, int ni, int depth, int *best_mode_out, double *best_cost_out)
 {
 	HENC_ENC_IN_LDS(e);
 	const Geo &q = e.geo[ni];
@@ -203,7 +203,7 @@ HENC_HD int intra_mode_search(const G &g, Enc &__restrict__ e, int ni, int depth
 }
 
 template <class G>
-HENC_HD void set_intra_info_buffs(const G &g, Enc &__restrict__ e, int depth, int ni)
+HENC_HD void set_intra_info_buffs(const G g, Enc &__restrict__ e, int depth, int ni)
 {
 	HENC_ENC_IN_LDS(e);
 	const Geo &q = e.geo[ni];
@@ -219,7 +219,7 @@ HENC_HD void set_intra_info_buffs(const G &g, Enc &__restrict__ e, int depth, in
 
 // encode_intra_cu, hmr_motion_intra.c:973-1071: one luma TU.  depth = prediction depth.  Returns the SSD, *curr_sum the level sum.
 template <class G>
-HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int depth, int cu_mode, int part_size_type, int *curr_sum)
+HENC_HD uint32_t encode_intra_tu(const G g, Enc &__restrict__ e, int ni, int depth, int cu_mode, int part_size_type, int *curr_sum)
 {
 	HENC_ENC_IN_LDS(e);
 	const Geo &q = e.geo[ni];
@@ -260,7 +260,7 @@ HENC_HD uint32_t encode_intra_tu(const G &g, Enc &__restrict__ e, int ni, int de
 
 // encode_intra_luma, hmr_motion_intra.c:1229-1630 (non-HM path): search, then the transform tree of the winner.
 template <class G>
-HENC_WALK_FN HENC_HD uint32_t encode_intra_luma(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
+HENC_WALK_FN HENC_HD uint32_t encode_intra_luma(const G g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
 {
 	HENC_ENC_IN_LDS(e);
 	const Seq &S = *e.seq;
@@ -421,7 +421,7 @@ HENC_INLINE void chroma_dir_list(int *list, int luma_mode)
 
 // one chroma plane of the candidate search of encode_intra_chroma: SAD of the five candidates on the unfiltered neighbours of the auxiliary window
 template <class G>
-HENC_HD void chroma_search_comp(const G &g, Enc &__restrict__ e, int curr, int c, const int *cand, uint32_t *sads)
+HENC_HD void chroma_search_comp(const G g, Enc &__restrict__ e, int curr, int c, const int *cand, uint32_t *sads)
 {
 	HENC_ENC_IN_LDS(e);
 	Work &w = *e.w;
@@ -435,7 +435,7 @@ HENC_HD void chroma_search_comp(const G &g, Enc &__restrict__ e, int curr, int c
 }
 // one chroma TU of the winner: neighbours, prediction, residual, transform chain, reconstruction into the auxiliary window.  Returns the weighted SSD.
 template <class G>
-HENC_HD int chroma_tu_comp(const G &g, Enc &__restrict__ e, int curr, int c, int cu_mode, int scan_mode, int shifts, int per, int rem, int *curr_sum_out)
+HENC_HD int chroma_tu_comp(const G g, Enc &__restrict__ e, int curr, int c, int cu_mode, int scan_mode, int shifts, int per, int rem, int *curr_sum_out)
 {
 	HENC_ENC_IN_LDS(e);
 	Work &w = *e.w;
@@ -467,7 +467,7 @@ HENC_HD int chroma_tu_comp(const G &g, Enc &__restrict__ e, int curr, int c, int
 
 // both chroma planes of a TU, one after the other
 template <class G>
-HENC_HD void chroma_tu_both(const G &g, Enc &__restrict__ e, int curr, int cu_mode, int scan_mode, int shifts, int per, int rem, int *pc, int *cs)
+HENC_HD void chroma_tu_both(const G g, Enc &__restrict__ e, int curr, int cu_mode, int scan_mode, int shifts, int per, int rem, int *pc, int *cs)
 {
 	HENC_ENC_IN_LDS(e);
 	pc[0] = chroma_tu_comp(g, e, curr, COMP_U, cu_mode, scan_mode, shifts, per, rem, &cs[0]);
@@ -477,7 +477,7 @@ HENC_HD void chroma_tu_both(const G &g, Enc &__restrict__ e, int curr, int cu_mo
 
 // encode_intra_chroma, hmr_motion_intra_chroma.c:114-469 (non-HM path, rd_mode != RD_FULL)
 template <class G>
-HENC_WALK_FN HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
+HENC_WALK_FN HENC_HD uint32_t encode_intra_chroma(const G g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
 {
 	HENC_ENC_IN_LDS(e);
 	const Seq &S = *e.seq;
@@ -674,6 +674,6 @@ HENC_WALK_FN HENC_HD uint32_t encode_intra_chroma(const G &g, Enc &__restrict__ 
 }
 
 template <class G>
-HENC_HD uint32_t encode_intra(const G &g, Enc &__restrict__ e, int curr_depth, int position, int part_size_type);
+HENC_HD uint32_t encode_intra(const G g, Enc &__restrict__ e, int curr_depth, int position, int part_size_type);
 
 }  // namespace henc

@@ -78,7 +78,7 @@ HENC_INLINE void post_release()
 }
 // one lane tries to move *p from `expect` to expect + 1; every lane learns the outcome
 template <class G>
-HENC_HDX bool post_claim(const G &g, int *p, int expect)
+HENC_HDX bool post_claim(const G g, int *p, int expect)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 	int ok = 0;
@@ -95,7 +95,7 @@ HENC_HDX bool post_claim(const G &g, int *p, int expect)
 #endif
 }
 template <class G>
-HENC_HDX void post_add_fast(const G &g, int32_t *p, int32_t v)      // an accumulator in the worker's fast memory that several lanes add to
+HENC_HDX void post_add_fast(const G g, int32_t *p, int32_t v)      // an accumulator in the worker's fast memory that several lanes add to
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 	(void)g;
@@ -187,7 +187,7 @@ static constexpr uint8_t kDbkBeta[52] = {0,  0,  0,  0,  0,  0,  0,  0,  0,  0, 
 // ---- D task ------------------------------------------------------------------------------------------------------------------------------------------------------
 // the CTU's side-info (z-order) into the raster unit arrays, with the transform / prediction edge flags (k_units_from_ctuinfo + k_edge_flags)
 template <class G>
-HENC_HDX void post_units_ctu(const G &g, const PostPic &P, const CtuPublic &c, int cx, int cy)
+HENC_HDX void post_units_ctu(const G g, const PostPic &P, const CtuPublic &c, int cx, int cy)
 {
 	for (int a = g.tid; a < NPART; a += g.n) {
 		const int r = abs2raster(a), ux = cx * 16 + (r & 15), uy = cy * 16 + (r >> 4);
@@ -207,7 +207,7 @@ HENC_HDX void post_units_ctu(const G &g, const PostPic &P, const CtuPublic &c, i
 
 // the CTU's samples from the reconstruction into the deblocking picture
 template <class G>
-HENC_HDX void post_copy_ctu(const G &g, const Seq &S, const FrameCtx &f, const PostPic &P, int cx, int cy)
+HENC_HDX void post_copy_ctu(const G g, const Seq &S, const FrameCtx &f, const PostPic &P, int cx, int cy)
 {
 	for (int comp = 0; comp < 3; comp++) {
 		const int sz = comp ? 32 : 64, px = cx * sz, py = cy * sz, pw = comp ? S.width >> 1 : S.width, ph = comp ? S.height >> 1 : S.height;
@@ -281,7 +281,7 @@ HENC_INLINE void dbk_chroma_edge(int16_t *e, int s, int t, int tc)
 
 // edges of one direction inside CTU (cx, cy) and on its left / top border (hmr_deblock_filter_cu): a lane owns a four-sample edge segment
 template <class G>
-HENC_HDX void post_deblock_ctu(const G &g, const Seq &S, const PostPic &P, int cx, int cy, int dir)
+HENC_HDX void post_deblock_ctu(const G g, const Seq &S, const PostPic &P, int cx, int cy, int dir)
 {
 	const int w4 = hmin(16, (S.width >> 2) - cx * 16), h4 = hmin(16, (S.height >> 2) - cy * 16);
 	const int ys = S.stride_y, cs = S.stride_c, us = P.units_stride;
@@ -330,7 +330,7 @@ HENC_INLINE int sgn3(int v) { return v > 0 ? 1 : (v < 0 ? -1 : 0); }
 // the three components of the deblocked CTU with a one-sample ring into the scratch tiles (what the statistics and the offset pass read): ring samples outside
 // the picture are never used
 template <class G>
-HENC_NOINLINE HENC_HDX void post_stage_tiles(const G &g, const Seq &S, const PostPic &P, PostScratch &sc, int cx, int cy)
+HENC_NOINLINE HENC_HDX void post_stage_tiles(const G g, const Seq &S, const PostPic &P, PostScratch &sc, int cx, int cy)
 {
 	const int width = S.width, height = S.height;
 	const bool la = cx > 0, ta = cy > 0, ra = cx * 64 + 64 < width, ba = cy * 64 + 64 < height;
@@ -358,7 +358,7 @@ HENC_NOINLINE HENC_HDX void post_stage_tiles(const G &g, const Seq &S, const Pos
 // statistics of CTU (cx, cy) (sse_sao_get_ctu_stats; the scalar form hmr_sao.c:75-348): for the three components the differences and counts of the five edge
 // classes of the four edge types and of the 32 bands, over the CTU minus the margins the reference leaves out because they were not deblocked yet in its pipeline
 template <class G>
-HENC_HDX void post_sao_stats(const G &g, const Seq &S, const FrameCtx &f, PostScratch &sc, int cx, int cy)
+HENC_HDX void post_sao_stats(const G g, const Seq &S, const FrameCtx &f, PostScratch &sc, int cx, int cy)
 {
 	const int width = S.width, height = S.height;
 	const bool la = cx > 0, ta = cy > 0, ra = cx * 64 + 64 < width, ba = cy * 64 + 64 < height;
@@ -429,7 +429,7 @@ HENC_HDX void post_sao_stats(const G &g, const Seq &S, const FrameCtx &f, PostSc
 // candidate offsets of SAO_MODE_NEW for every (component, type) of the CTU: sao_derive_offsets + sao_invert_quant_offsets + sao_get_distortion
 // (hmr_sao.c:480-659, est_iter_offset :445).  "Lane" l owns a class: 0-31 the bands, 32-51 the 4 x 5 edge classes.
 template <class G>
-HENC_HDX void post_sao_candidates(const G &g, PostScratch &sc, const double *lambdas)
+HENC_HDX void post_sao_candidates(const G g, PostScratch &sc, const double *lambdas)
 {
 	for (int comp = 0; comp < 3; comp++) {
 		const double lambda = lambdas[comp];
@@ -497,7 +497,7 @@ struct SaoCandFromScratch {
 // sao_offset_ctu (hmr_sao.c:1210, offset_block :960) from the deblocked CTU (the scratch tiles) into the final picture, then reference_picture_border_padding_ctu
 // (:1723) of the final one
 template <class G>
-HENC_NOINLINE HENC_HDX void post_sao_apply_pad(const G &g, const Seq &S, const PostPic &P, const PostScratch &sc, const SaoOffset *params, int cx, int cy)
+HENC_NOINLINE HENC_HDX void post_sao_apply_pad(const G g, const Seq &S, const PostPic &P, const PostScratch &sc, const SaoOffset *params, int cx, int cy)
 {
 	const int width = S.width, height = S.height;
 	const bool la = cx > 0, ta = cy > 0, ra = cx * 64 + 64 < width, ba = cy * 64 + 64 < height;
@@ -558,7 +558,7 @@ struct PostCtx {               // what a task needs of the picture it belongs to
 };
 
 template <class G>
-HENC_HDX void post_task_d(const G &g, const PostCtx &x, int r, int c)
+HENC_HDX void post_task_d(const G g, const PostCtx &x, int r, int c)
 {
 	const Seq &S = *x.seq;
 	const PostPic &P = *x.pic;
@@ -580,7 +580,7 @@ HENC_HDX void post_task_d(const G &g, const PostCtx &x, int r, int c)
 }
 
 template <class G>
-HENC_HDX void post_task_p(const G &g, const PostCtx &x, PostScratch &sc, int r, int c)
+HENC_HDX void post_task_p(const G g, const PostCtx &x, PostScratch &sc, int r, int c)
 {
 	const Seq &S = *x.seq;
 	const FrameCtx &f = *x.f;
@@ -676,7 +676,7 @@ HENC_HDX void post_task_p(const G &g, const PostCtx &x, PostScratch &sc, int r, 
 
 // without SAO: the deblocked CTU into the final picture, margins of border CTUs
 template <class G>
-HENC_HDX void post_task_f(const G &g, const PostCtx &x, PostScratch &sc, int r, int c)
+HENC_HDX void post_task_f(const G g, const PostCtx &x, PostScratch &sc, int r, int c)
 {
 	post_stage_tiles(g, *x.seq, *x.pic, sc, c, r);
 	post_sao_apply_pad(g, *x.seq, *x.pic, sc, sc.c.sao_recon, c, r);
@@ -688,7 +688,7 @@ HENC_INLINE int post_min(int a, int b) { return a < b ? a : b; }
 
 // Runs tasks of the picture until none is ready (other workers may be running some: whoever finishes a task looks again).  Returns the number of tasks it ran.
 template <class G>
-HENC_HDX int post_drain(const G &g, const PostCtx &x, PostScratch &sc)
+HENC_HDX int post_drain(const G g, const PostCtx &x, PostScratch &sc)
 {
 	const Seq &S = *x.seq;
 	const PostPic &P = *x.pic;
@@ -797,7 +797,7 @@ HENC_HDX int post_drain(const G &g, const PostCtx &x, PostScratch &sc)
 // ---- rate control: what the decisions with index k (the wavefront step; in raster order the CTU) see of the frame so far (enc_rc.h) ---------------------------
 // the bits and the number of the CTUs the reference has entropy coded when they start
 template <class G>
-HENC_HDX void rc_consumed(const G &g, const PostPic &P, int W, int H, int k, uint32_t *bits, int *ctus)
+HENC_HDX void rc_consumed(const G g, const PostPic &P, int W, int H, int k, uint32_t *bits, int *ctus)
 {
 	uint32_t b = 0, n = 0;
 	for (int r = g.tid; r < H; r += g.n) {
@@ -810,7 +810,7 @@ HENC_HDX void rc_consumed(const G &g, const PostPic &P, int W, int H, int k, uin
 }
 // have those CTUs been coded here?
 template <class G>
-HENC_HDX bool rc_ready(const G &g, const PostPic &P, int H, int k)
+HENC_HDX bool rc_ready(const G g, const PostPic &P, int H, int k)
 {
 	bool ok = true;
 	for (int base = 0; base < H; base += g.n) {

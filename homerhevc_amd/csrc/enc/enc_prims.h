@@ -57,7 +57,7 @@ HENC_INLINE void st4(uint8_t *p, const S4 &v)
 }
 
 template <class G, class S>
-HENC_PRIM uint32_t blk_sad(const G &g, const S *a, int as, const int16_t *b, int bs, int n)
+HENC_PRIM uint32_t blk_sad(const G g, const S *a, int as, const int16_t *b, int bs, int n)
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
@@ -82,7 +82,7 @@ HENC_INLINE uint32_t ld32u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, 
 // SADs of up to MAXC candidate blocks (global, 8 bit, row pitch `stride`) against one source block (8 bit, row pitch 64); cand[k] == nullptr: skipped.
 // Every candidate's loads are issued before the first result is needed, so a round of candidates costs one memory latency.
 template <int MAXC>
-__device__ __forceinline__ void multi_sad_u8(const WaveGrp &g, const uint8_t *orig8, int n, const uint8_t *const (&cand)[MAXC], int stride, uint32_t (&out)[MAXC])
+__device__ __forceinline__ void multi_sad_u8(const WaveGrp g, const uint8_t *orig8, int n, const uint8_t *const (&cand)[MAXC], int stride, uint32_t (&out)[MAXC])
 {
 	PRIM_T0();
 	if (n == 8) {
@@ -136,7 +136,7 @@ __device__ __forceinline__ void multi_sad_u8(const WaveGrp &g, const uint8_t *or
 }
 
 // n x n samples of an 8-bit plane into the (8-bit) prediction window (motion compensation from the phase planes); the caller syncs
-__device__ __forceinline__ void blk_from_u8(const WaveGrp &g, const uint8_t *s, int ss, uint8_t *d, int ds, int n)
+__device__ __forceinline__ void blk_from_u8(const WaveGrp g, const uint8_t *s, int ss, uint8_t *d, int ds, int n)
 {
 	const int lw = ilog2i(n) - 2, chunks = (n * n) >> 2;
 #pragma unroll 4
@@ -148,7 +148,7 @@ __device__ __forceinline__ void blk_from_u8(const WaveGrp &g, const uint8_t *s, 
 #endif
 
 template <class G, class S, class P>
-HENC_PRIM uint32_t blk_ssd(const G &g, const S *a, int as, const P *b, int bs, int n)
+HENC_PRIM uint32_t blk_ssd(const G g, const S *a, int as, const P *b, int bs, int n)
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
@@ -169,7 +169,7 @@ HENC_PRIM uint32_t blk_ssd(const G &g, const S *a, int as, const P *b, int bs, i
 // SSD of the residual source - prediction against a reconstructed residual, the residual formed on the way (16-bit wrap like the reference's predict kernel
 // writes it): what ssd16b(residual window, reconstructed residual) gives, without the window
 template <class G, class S, class P>
-HENC_PRIM uint32_t blk_ssd_diff(const G &g, const S *o, int os, const P *p, int ps, const int16_t *r, int rs, int n)
+HENC_PRIM uint32_t blk_ssd_diff(const G g, const S *o, int os, const P *p, int ps, const int16_t *r, int rs, int n)
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
@@ -193,7 +193,7 @@ HENC_PRIM uint32_t blk_ssd_diff(const G &g, const S *o, int os, const P *p, int 
 // 16-sample group g; oracle/hmr_oracle.c ora_modified_variance).  The source window holds the samples themselves: byte b of a row is sample b / 2 for even b, 0 for odd b
 // (a sample's high byte).
 template <class G, class S>
-HENC_PRIM uint32_t blk_modified_variance(const G &g, const S *p, int stride, int size, int modif)
+HENC_PRIM uint32_t blk_modified_variance(const G g, const S *p, int stride, int size, int modif)
 {
 	PRIM_T0();
 	const int l = ilog2i(size), total = size * size;
@@ -216,7 +216,7 @@ HENC_PRIM uint32_t blk_modified_variance(const G &g, const S *p, int stride, int
 
 // sum of squares of a block (ssd16b against the reference's zero row, hmr_motion_inter.c:94)
 template <class G>
-HENC_PRIM uint32_t blk_ssq(const G &g, const int16_t *a, int as, int n)
+HENC_PRIM uint32_t blk_ssq(const G g, const int16_t *a, int as, int n)
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
@@ -231,7 +231,7 @@ HENC_PRIM uint32_t blk_ssq(const G &g, const int16_t *a, int as, int n)
 }
 
 template <class G, class S, class P>
-HENC_PRIM void blk_predict(const G &g, const S *o, int os, const P *p, int ps, int16_t *r, int rs, int n)
+HENC_PRIM void blk_predict(const G g, const S *o, int os, const P *p, int ps, int16_t *r, int rs, int n)
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
@@ -250,7 +250,7 @@ HENC_PRIM void blk_predict(const G &g, const S *o, int os, const P *p, int ps, i
 
 // res == nullptr: the all-zero residual (the reference passes a zeroed row with stride 0, hmr_motion_intra.c:1065)
 template <class G, class P>
-HENC_PRIM void blk_reconst(const G &g, const P *p, int ps, const int16_t *res, int rs, int16_t *d, int ds, int n)
+HENC_PRIM void blk_reconst(const G g, const P *p, int ps, const int16_t *res, int rs, int16_t *d, int ds, int n)
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
@@ -270,7 +270,7 @@ HENC_PRIM void blk_reconst(const G &g, const P *p, int ps, const int16_t *res, i
 
 // reconstruction and its distance from the source in one pass (the reference reconstructs, then reads the window back for ssd16b, hmr_motion_intra.c:1061-1068)
 template <class G, class S, class P>
-HENC_PRIM uint32_t blk_reconst_ssd(const G &g, const P *p, int ps, const int16_t *res, int rs, const S *o, int os, int16_t *d, int ds, int n)
+HENC_PRIM uint32_t blk_reconst_ssd(const G g, const P *p, int ps, const int16_t *res, int rs, const S *o, int os, int16_t *d, int ds, int n)
 {
 	PRIM_T0();
 	const int l = ilog2i(n);
@@ -295,7 +295,7 @@ HENC_PRIM uint32_t blk_reconst_ssd(const G &g, const P *p, int ps, const int16_t
 }
 
 template <class G, class P>
-HENC_PRIM void blk_copy(const G &g, const P *s, int ss, int16_t *d, int ds, int h, int w)
+HENC_PRIM void blk_copy(const G g, const P *s, int ss, int16_t *d, int ds, int h, int w)
 {
 	PRIM_T0();
 	if ((w & 3) == 0 && (w & (w - 1)) == 0) {
@@ -329,7 +329,7 @@ HENC_PRIM void blk_copy(const G &g, const P *s, int ss, int16_t *d, int ds, int 
 
 // a block of a 16-bit picture plane into the CTU's source buffer (bytes on the device); w a multiple of 4
 template <class G>
-HENC_PRIM void blk_copy_to_src(const G &g, const int16_t *s, int ss, src_t *d, int ds, int h, int w)
+HENC_PRIM void blk_copy_to_src(const G g, const int16_t *s, int ss, src_t *d, int ds, int h, int w)
 {
 	PRIM_T0();
 	const int cw = w >> 2;
@@ -350,7 +350,7 @@ HENC_PRIM void blk_copy_to_src(const G &g, const int16_t *s, int ss, src_t *d, i
 // move between HBM and the worker's fast memory at every CTU start and end)
 typedef uint32_t Q16 __attribute__((vector_size(16), may_alias, aligned(16)));      // (a vector, not a struct of four words: struct temporaries of the copy loops ended up in private memory)
 template <class G>
-HENC_HD void lin_copy_bytes(const G &g, const void *s, void *d, int bytes)
+HENC_HD void lin_copy_bytes(const G g, const void *s, void *d, int bytes)
 {
 	const uintptr_t both = (uintptr_t)s | (uintptr_t)d | (uintptr_t)bytes;
 	if ((both & 15) == 0) {
@@ -380,7 +380,7 @@ HENC_HD void lin_copy_bytes(const G &g, const void *s, void *d, int bytes)
 	}
 }
 template <class G>
-HENC_PRIM void lin_copy(const G &g, const int16_t *s, int16_t *d, int count)
+HENC_PRIM void lin_copy(const G g, const int16_t *s, int16_t *d, int count)
 {
 	PRIM_T0();
 	lin_copy_bytes(g, s, d, count * 2);
@@ -390,12 +390,12 @@ HENC_PRIM void lin_copy(const G &g, const int16_t *s, int16_t *d, int count)
 
 // the same without the closing sync: stores to a window nobody reads before the chain's next sync (the levels of a TU on their way to HBM)
 template <class G>
-HENC_PRIM void lin_copy_nosync(const G &g, const int16_t *s, int16_t *d, int count)
+HENC_PRIM void lin_copy_nosync(const G g, const int16_t *s, int16_t *d, int count)
 {
 	lin_copy_bytes(g, s, d, count * 2);
 }
 template <class G>
-HENC_PRIM void lin_zero_nosync(const G &g, int16_t *d, int count)
+HENC_PRIM void lin_zero_nosync(const G g, int16_t *d, int count)
 {
 	if ((((uintptr_t)d | (uintptr_t)(count * 2)) & 7) == 0) {
 		const S4 z = {{0, 0, 0, 0}};
@@ -405,7 +405,7 @@ HENC_PRIM void lin_zero_nosync(const G &g, int16_t *d, int count)
 }
 
 template <class G>
-HENC_PRIM void lin_copy_words(const G &g, const uint32_t *s, uint32_t *d, int count)
+HENC_PRIM void lin_copy_words(const G g, const uint32_t *s, uint32_t *d, int count)
 {
 	PRIM_T0();
 	lin_copy_bytes(g, s, d, count * 4);
@@ -414,7 +414,7 @@ HENC_PRIM void lin_copy_words(const G &g, const uint32_t *s, uint32_t *d, int co
 }
 
 template <class G>
-HENC_PRIM void lin_zero(const G &g, int16_t *d, int count)
+HENC_PRIM void lin_zero(const G g, int16_t *d, int count)
 {
 	PRIM_T0();
 	for (int i = g.tid; i < count; i += g.n) d[i] = 0;
@@ -423,7 +423,7 @@ HENC_PRIM void lin_zero(const G &g, int16_t *d, int count)
 }
 
 template <class G>
-HENC_PRIM void bytes_set(const G &g, uint8_t *d, int v, int count)
+HENC_PRIM void bytes_set(const G g, uint8_t *d, int v, int count)
 {
 	PRIM_T0();
 	for (int i = g.tid; i < count; i += g.n) d[i] = (uint8_t)v;
@@ -432,7 +432,7 @@ HENC_PRIM void bytes_set(const G &g, uint8_t *d, int v, int count)
 }
 
 template <class G>
-HENC_PRIM void bytes_copy(const G &g, const uint8_t *s, uint8_t *d, int count)
+HENC_PRIM void bytes_copy(const G g, const uint8_t *s, uint8_t *d, int count)
 {
 	PRIM_T0();
 	for (int i = g.tid; i < count; i += g.n) d[i] = s[i];
@@ -443,7 +443,7 @@ HENC_PRIM void bytes_copy(const G &g, const uint8_t *s, uint8_t *d, int count)
 // ---- intra reference samples (fill_reference_samples hmr_motion_intra.c:246-404, adi_filter :189-244) --------------
 // `corner` points at sample (-1,-1) of the block in the window under reconstruction.
 template <class G>
-HENC_PRIM void intra_fill_refs(const G &g, const int16_t *corner, int stride, int n, int left, int top, int bottom_left, int top_right,
+HENC_PRIM void intra_fill_refs(const G g, const int16_t *corner, int stride, int n, int left, int top, int bottom_left, int top_right,
 			     int bl_size, int tr_size, int16_t *adi)
 {
 	PRIM_T0();
@@ -506,7 +506,7 @@ HENC_PRIM void intra_fill_refs(const G &g, const int16_t *corner, int stride, in
 }
 
 template <class G>
-HENC_PRIM void intra_adi_filter(const G &g, const int16_t *adi, int16_t *out, int n, int strong_enabled)
+HENC_PRIM void intra_adi_filter(const G g, const int16_t *adi, int16_t *out, int n, int strong_enabled)
 {
 	PRIM_T0();
 	const int adi_size = 4 * n + 1;
@@ -617,7 +617,7 @@ HENC_INLINE int intra_sample(const IntraPredictor &p, int j, int i)
 }
 
 template <class G, class P>
-HENC_PRIM void intra_predict(const G &g, P *pred, int ps, const int16_t *adi, int n, int mode, int is_luma)
+HENC_PRIM void intra_predict(const G g, P *pred, int ps, const int16_t *adi, int n, int mode, int is_luma)
 {
 	PRIM_T0();
 	const IntraPredictor p = intra_setup(adi, n, mode, is_luma);
@@ -633,7 +633,7 @@ HENC_PRIM void intra_predict(const G &g, P *pred, int ps, const int16_t *adi, in
 
 // prediction + SAD against the source in one pass; the prediction is also stored (later stages of the reference read it)
 template <class G, class S, class P>
-HENC_PRIM uint32_t intra_predict_sad(const G &g, P *pred, int ps, const S *orig, int os, const int16_t *adi, int n, int mode, int is_luma)
+HENC_PRIM uint32_t intra_predict_sad(const G g, P *pred, int ps, const S *orig, int os, const int16_t *adi, int n, int mode, int is_luma)
 {
 	PRIM_T0();
 	const IntraPredictor p = intra_setup(adi, n, mode, is_luma);
@@ -667,7 +667,7 @@ HENC_INLINE void chroma_tap_row(int f, int *c)
 // stage reads its 4 + NT - 1 consecutive samples with 8-byte loads (the source may start at any sample: unaligned global access), a vertical one reads
 // NT rows of four.
 template <int NT, class G>
-HENC_PRIM void interp_stage(const G &g, const int16_t *src, int ss, int16_t *dst, int ds, int fraction, int w, int h, int vert, int first, int last)
+HENC_PRIM void interp_stage(const G g, const int16_t *src, int ss, int16_t *dst, int ds, int fraction, int w, int h, int vert, int first, int last)
 {
 	PRIM_T0();
 	if (NT == 4 && w < 4 && fraction == 0) { g.sync(); PRIM_END(PP_INTERP); return; }    // chroma no-op (inter_prediction.c:822-825)
@@ -822,7 +822,7 @@ HENC_INLINE void ft_list_value4(const CellT *cells, uint32_t flat, int i0, int l
 	if (i0 == 0 && log2n > 3) v[0] = flat;
 }
 template <class G>
-HENC_HD void fast_tables_fill(const G &g, FastTables &F, const DevTables *T, int rem_y, int rem_c)
+HENC_HD void fast_tables_fill(const G g, FastTables &F, const DevTables *T, int rem_y, int rem_c)
 {
 	for (int l = 2; l <= 5; l++) {
 		const int n = 1 << l, o = ft_dct_offset(l);
@@ -903,7 +903,7 @@ struct RowDiff {
 
 // one stage with the input row held by the lane: row j of the source `in`
 template <int N, class G, class Rows>
-HENC_HD void tr_stage_rows_from(const G &g, const int16_t *B, const Rows &in, int16_t *out, int os_k, int os_j, int shift)
+HENC_HD void tr_stage_rows_from(const G g, const int16_t *B, const Rows &in, int16_t *out, int os_k, int os_j, int shift)
 {
 	constexpr int H = N / 2;
 	const int rnd = shift > 0 ? 1 << (shift - 1) : 0;
@@ -933,13 +933,13 @@ HENC_HD void tr_stage_rows_from(const G &g, const int16_t *B, const Rows &in, in
 }
 // ... in[j][0..N) contiguous at in + j * is
 template <int N, class G>
-HENC_HD void tr_stage_rows(const G &g, const int16_t *B, const int16_t *in, int is, int16_t *out, int os_k, int os_j, int shift)
+HENC_HD void tr_stage_rows(const G g, const int16_t *B, const int16_t *in, int is, int16_t *out, int os_k, int os_j, int shift)
 {
 	tr_stage_rows_from<N>(g, B, RowPlain<N>{in, is}, out, os_k, os_j, shift);
 }
 // the same with the input COLUMN j of a linear N x N array (first inverse stage: the levels come row-major)
 template <int N, class G>
-HENC_HD void tr_stage_cols(const G &g, const int16_t *B, const int16_t *in, int16_t *out, int shift)
+HENC_HD void tr_stage_cols(const G g, const int16_t *B, const int16_t *in, int16_t *out, int shift)
 {
 	constexpr int H = N / 2;
 	const int rnd = 1 << (shift - 1);
@@ -962,7 +962,7 @@ HENC_HD void tr_stage_cols(const G &g, const int16_t *B, const int16_t *in, int1
 }
 
 template <int N, class G, class Rows>
-HENC_HD void tr_forward_n(const G &g, const int16_t *M, const Rows &block, int16_t *coeff, int16_t *tmp)
+HENC_HD void tr_forward_n(const G g, const int16_t *M, const Rows &block, int16_t *coeff, int16_t *tmp)
 {
 	constexpr int L = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
 	tr_stage_rows_from<N>(g, M, block, tmp, N, 1, L - 1);    // tmp[k][j] = sum_i M[k][i] * block[j][i]
@@ -971,7 +971,7 @@ HENC_HD void tr_forward_n(const G &g, const int16_t *M, const Rows &block, int16
 	g.sync();
 }
 template <int N, class G>
-HENC_HD void tr_inverse_n(const G &g, const int16_t *Mt, int16_t *block, int bs, const int16_t *coeff, int16_t *tmp)
+HENC_HD void tr_inverse_n(const G g, const int16_t *Mt, int16_t *block, int bs, const int16_t *coeff, int16_t *tmp)
 {
 	tr_stage_cols<N>(g, Mt, coeff, tmp, 7);                   // tmp[k][j] = sum_i M[i][k] * coeff[i][j]  (the reference's tmp, transposed)
 	g.sync();
@@ -1224,7 +1224,7 @@ __device__ __forceinline__ void tr_inverse_mfma_pair(int lane, bool live, const 
 
 // forward transform of the residual source - prediction (hmr_motion_intra.c:1036-1040 / hmr_motion_inter.c:57-60: predict, then transform of the residual window)
 template <class G, class S, class P>
-HENC_PRIM void tr_forward(const G &g, const FastTables *F, const DevTables *T, const S *orig, int os, const P *pred, int ps, int16_t *coeff, int16_t *tmp, int n, int is_dst)
+HENC_PRIM void tr_forward(const G g, const FastTables *F, const DevTables *T, const S *orig, int os, const P *pred, int ps, int16_t *coeff, int16_t *tmp, int n, int is_dst)
 {
 	PRIM_T0();
 	HENC_OP_IN_LDS(orig); HENC_OP_IN_LDS(pred); HENC_OP_IN_LDS(coeff); HENC_OP_IN_LDS(tmp);
@@ -1275,7 +1275,7 @@ HENC_PRIM void tr_forward(const G &g, const FastTables *F, const DevTables *T, c
 }
 
 template <class G>
-HENC_PRIM void tr_inverse(const G &g, const FastTables *F, const DevTables *T, int16_t *block, int bs, const int16_t *coeff, int16_t *tmp, int n, int is_dst)
+HENC_PRIM void tr_inverse(const G g, const FastTables *F, const DevTables *T, int16_t *block, int bs, const int16_t *coeff, int16_t *tmp, int n, int is_dst)
 {
 	PRIM_T0();
 	HENC_OP_IN_LDS(block); HENC_OP_IN_LDS(coeff); HENC_OP_IN_LDS(tmp);
@@ -1317,7 +1317,7 @@ HENC_PRIM void tr_inverse(const G &g, const FastTables *F, const DevTables *T, i
 #if defined(HENC_MFMA_TRANSFORM)
 // the inverse transform of the two halves' blocks together (see tr_forward_mfma_pair): called by BOTH halves from uniform control flow, `live` = this half has levels
 template <class G>
-__device__ __forceinline__ void tr_inverse_pair(const G &g, bool live, const DevTables *T, int16_t *block, int bs, const int16_t *coeff, int n)
+__device__ __forceinline__ void tr_inverse_pair(const G g, bool live, const DevTables *T, int16_t *block, int bs, const int16_t *coeff, int n)
 {
 	PRIM_T0();
 	HENC_OP_IN_LDS(block); HENC_OP_IN_LDS(coeff);
@@ -1390,7 +1390,7 @@ HENC_INLINE void sbh_apply(const SbhGroup &q, int16_t *dst, bool is_last_cg)
 
 // the sign-hiding pass over the coefficient groups of a block (after the levels are visible to the group)
 template <class G, class ScanT>
-HENC_HD void sbh_pass(const G &g, const int16_t *src, int16_t *dst, const int16_t *delta_u, const ScanT *scan, int total)
+HENC_HD void sbh_pass(const G g, const int16_t *src, int16_t *dst, const int16_t *delta_u, const ScanT *scan, int total)
 {
 	const int ngroups = total >> 4;
 	// the last group holding a level (in scan order) starts its walk at its last level
@@ -1416,7 +1416,7 @@ HENC_HD void sbh_pass(const G &g, const int16_t *src, int16_t *dst, const int16_
 // returns ac_sum (the sum of the levels BEFORE sign hiding, as the reference reports it).  src / dst / delta_u are the worker's (fast memory); the lists and
 // the scan come from F when it caches this QP remainder, else from T.
 template <class G>
-HENC_PRIM int quantize(const G &g, const FastTables *F, const DevTables *T, const int16_t *src, int16_t *dst, int16_t *delta_u, int scan_mode, int depth, int comp,
+HENC_PRIM int quantize(const G g, const FastTables *F, const DevTables *T, const int16_t *src, int16_t *dst, int16_t *delta_u, int scan_mode, int depth, int comp,
 		     int is_intra, int slice_is_intra, int sign_hiding, int n, int per, int rem)
 {
 	PRIM_T0();
@@ -1467,7 +1467,7 @@ HENC_PRIM int quantize(const G &g, const FastTables *F, const DevTables *T, cons
 
 // src == dst is allowed (element-wise)
 template <class G>
-HENC_PRIM void dequantize(const G &g, const FastTables *F, const DevTables *T, const int16_t *src, int16_t *dst, int depth, int comp, int is_intra, int n, int per, int rem)
+HENC_PRIM void dequantize(const G g, const FastTables *F, const DevTables *T, const int16_t *src, int16_t *dst, int depth, int comp, int is_intra, int n, int per, int rem)
 {
 	PRIM_T0();
 	HENC_OP_IN_LDS(src); HENC_OP_IN_LDS(dst);

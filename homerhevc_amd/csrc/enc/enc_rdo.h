@@ -36,7 +36,7 @@ HENC_INLINE RdViews &rd_views_of(Enc &e) { return *(RdViews *)e.wrd->rd_views; }
 // the shadow CTU's view: luma cbf / transform index buffers of `y_depth`, the luma directions where the last luma estimate left the pointer, the chroma cbf and
 // direction buffers given
 template <class G>
-HENC_FI void rd_make_views(const G &g, Enc &__restrict__ e, RdViews &r, int y_depth, int tr_depth_buf, const uint8_t *cbf_u, const uint8_t *cbf_v, int chroma_mode_depth,
+HENC_FI void rd_make_views(const G g, Enc &__restrict__ e, RdViews &r, int y_depth, int tr_depth_buf, const uint8_t *cbf_u, const uint8_t *cbf_v, int chroma_mode_depth,
 			   const int16_t *coef_y, const int16_t *coef_u, const int16_t *coef_v)
 {
 	HENC_ENC_IN_LDS(e);
@@ -128,7 +128,7 @@ HENC_FI void rd_code_chroma_dir(Cabac &ec, const EntView &v, int ni)
 
 // rd_transform_tree :2239: the luma OR the chroma syntax of the transform tree under `top_ni`
 template <class G>
-HENC_FI void rd_transform_tree(const G &g, Cabac &ec, const EntView &v, EntScratch &sc, int top_ni, int is_luma)
+HENC_FI void rd_transform_tree(const G g, Cabac &ec, const EntView &v, EntScratch &sc, int top_ni, int is_luma)
 {
 	const Seq &S = *v.seq;
 	const CtuView *c = v.c;
@@ -188,7 +188,7 @@ HENC_FI void rd_transform_tree(const G &g, Cabac &ec, const EntView &v, EntScrat
 
 // rd_get_intra_bits_qt :2362: all contexts from et->ee, the header of the partition and the luma or chroma part of its transform tree
 template <class G>
-HENC_RD_NOINLINE HENC_HD uint32_t rd_get_intra_bits_qt(const G &g, Enc &__restrict__ e, const RdViews &r, int ni, int is_luma)
+HENC_RD_NOINLINE HENC_HD uint32_t rd_get_intra_bits_qt(const G g, Enc &__restrict__ e, const RdViews &r, int ni, int is_luma)
 {
 	HENC_ENC_IN_LDS(e);
 	Cabac ec;

@@ -68,7 +68,7 @@ HENC_INLINE int sched_replay_search(const SearchLog &lg, const uint8_t *true_in,
 //     inter candidate wins either way (the intra cost is then discarded; what the evaluation left in the buffers is the winner);
 //   * every comparison must keep its outcome under the true ratio, and where intra wins, the cost it leaves behind.
 template <class G>
-HENC_HD int sched_guesses_hold(const G &g, const CtuInfo &c, const FrameCtx &f, const uint8_t *true_in, const uint8_t *used_in, uint32_t intra_before,
+HENC_HD int sched_guesses_hold(const G g, const CtuInfo &c, const FrameCtx &f, const uint8_t *true_in, const uint8_t *used_in, uint32_t intra_before,
 			       uint32_t parts_before, uint32_t used_intra, uint32_t used_parts, int uses_ratio)
 {
 	int bad = 0;
@@ -113,7 +113,7 @@ HENC_HD int sched_guesses_hold(const G &g, const CtuInfo &c, const FrameCtx &f, 
 
 // what other CTUs can see of a CTU: its side-info arrays and its reconstruction.  Two independent 32-bit sums of products.
 template <class G>
-HENC_HD uint64_t sched_output_hash(const G &g, const Seq &S, const FrameCtx &f, const CtuInfo &c)
+HENC_HD uint64_t sched_output_hash(const G g, const Seq &S, const FrameCtx &f, const CtuInfo &c)
 {
 	uint32_t h1 = 0, h2 = 0;
 	const uint32_t *p = (const uint32_t *)(const CtuPublic *)&c;

@@ -427,7 +427,7 @@ __device__ __forceinline__ void pool_step_rows(int t, int W, int H, int *r_lo, i
 	*r_hi = (t >> 1) < H - 1 ? (t >> 1) : H - 1;
 }
 
-__device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const WaveGrp &g, Seq *lseq, FrameCtx *lframe, FastTables *lft, int t, int row, int *cached_rem, const int *abort_flag)
+__device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const WaveGrp g, Seq *lseq, FrameCtx *lframe, FastTables *lft, int t, int row, int *cached_rem, const int *abort_flag)
 {
 	HENC_ENC_IN_LDS(e);
 	const Seq &S = *lseq;
@@ -535,7 +535,7 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 }
 
 // post-decision tasks of picture q that are ready, on this worker (its Work area is scratch between two CTUs); *finished counts the pictures whose last task is done
-__device__ __attribute__((noinline)) int pool_post_drain(const EncDev &d, const WaveGrp &g, const Seq *lseq, const FrameCtx *lframe, Work *lw, WorkSlow *my_slow, int *finished)
+__device__ __attribute__((noinline)) int pool_post_drain(const EncDev &d, const WaveGrp g, const Seq *lseq, const FrameCtx *lframe, Work *lw, WorkSlow *my_slow, int *finished)
 {
 	if (post_finished(*lseq, d.post)) return 0;
 	PostCtx x;
