@@ -421,7 +421,7 @@ HENC_INLINE void chroma_dir_list(int *list, int luma_mode)
 
 // one chroma plane of the candidate search of encode_intra_chroma: SAD of the five candidates on the unfiltered neighbours of the auxiliary window
 template <class G>
-HENC_HD void chroma_search_comp(const G g, Enc &__restrict__ e, int curr, int c, const int *cand, uint32_t *sads)
+HENC_WALK_FN HENC_HD void chroma_search_comp(const G g, Enc &__restrict__ e, int curr, int c, const int *cand, uint32_t *sads)
 {
 	HENC_ENC_IN_LDS(e);
 	Work &w = *e.w;

@@ -133,6 +133,19 @@ HENC_INLINE T uni(T x)
 	return x;
 #endif
 }
+// ... and a pointer every lane holds (an argument of a function the compiler keeps out of line arrives in vector registers even when the caller had it in scalar ones:
+// uniform again, the address arithmetic behind it is scalar and a switch on a uniform size is a scalar branch instead of execution-mask regions)
+template <class T>
+HENC_INLINE T *uni_ptr(T *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uintptr_t v = (uintptr_t)p;
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+	return (T *)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+#else
+	return p;
+#endif
+}
 template <class T>
 HENC_INLINE T *in_fast_memory(T *p)
 {

@@ -1227,6 +1227,10 @@ template <class G, class S, class P>
 HENC_PRIM void tr_forward(const G g, const FastTables *F, const DevTables *T, const S *orig, int os, const P *pred, int ps, int16_t *coeff, int16_t *tmp, int n, int is_dst)
 {
 	PRIM_T0();
+	if constexpr (G::n == 64) {      // (one block for the whole wavefront: the arguments are uniform; a pair of groups has a block per half)
+		orig = uni_ptr(orig); pred = uni_ptr(pred); coeff = uni_ptr(coeff); tmp = uni_ptr(tmp); os = uni(os); ps = uni(ps);
+	}
+	T = uni_ptr(T); n = uni(n); is_dst = uni(is_dst);
 	HENC_OP_IN_LDS(orig); HENC_OP_IN_LDS(pred); HENC_OP_IN_LDS(coeff); HENC_OP_IN_LDS(tmp);
 #if defined(HENC_MFMA_TRANSFORM)
 #if !defined(HENC_MFMA_NO_FWD)
@@ -1278,6 +1282,8 @@ template <class G>
 HENC_PRIM void tr_inverse(const G g, const FastTables *F, const DevTables *T, int16_t *block, int bs, const int16_t *coeff, int16_t *tmp, int n, int is_dst)
 {
 	PRIM_T0();
+	if constexpr (G::n == 64) { block = uni_ptr(block); coeff = uni_ptr(coeff); tmp = uni_ptr(tmp); bs = uni(bs); }
+	T = uni_ptr(T); n = uni(n); is_dst = uni(is_dst);
 	HENC_OP_IN_LDS(block); HENC_OP_IN_LDS(coeff); HENC_OP_IN_LDS(tmp);
 #if defined(HENC_MFMA_TRANSFORM) && !defined(HENC_MFMA_NO_INV)
 #if !defined(HENC_MFMA_INV_MASK)
@@ -1420,6 +1426,10 @@ HENC_PRIM int quantize(const G g, const FastTables *F, const DevTables *T, const
 		     int is_intra, int slice_is_intra, int sign_hiding, int n, int per, int rem)
 {
 	PRIM_T0();
+	if constexpr (G::n == 64) {
+		src = uni_ptr(src); dst = uni_ptr(dst); delta_u = uni_ptr(delta_u); per = uni(per); rem = uni(rem); comp = uni(comp);
+	}
+	T = uni_ptr(T); n = uni(n); depth = uni(depth); scan_mode = uni(scan_mode); is_intra = uni(is_intra); slice_is_intra = uni(slice_is_intra); sign_hiding = uni(sign_hiding);
 	HENC_OP_IN_LDS(src); HENC_OP_IN_LDS(dst); HENC_OP_IN_LDS(delta_u);
 	const int inv_depth = 6 - (depth + (comp != 0));
 	const int list = (is_intra ? 0 : 3) + comp, rc = comp != 0;
@@ -1470,6 +1480,8 @@ template <class G>
 HENC_PRIM void dequantize(const G g, const FastTables *F, const DevTables *T, const int16_t *src, int16_t *dst, int depth, int comp, int is_intra, int n, int per, int rem)
 {
 	PRIM_T0();
+	if constexpr (G::n == 64) { src = uni_ptr(src); dst = uni_ptr(dst); per = uni(per); rem = uni(rem); comp = uni(comp); }
+	T = uni_ptr(T); n = uni(n); depth = uni(depth); is_intra = uni(is_intra);
 	HENC_OP_IN_LDS(src); HENC_OP_IN_LDS(dst);
 	const int inv_depth = 6 - (depth + (comp != 0));
 	const int list = is_intra ? 0 : 3 + comp, rc = comp != 0;      // (the reference's expression: intra blocks of every component use list 0)
