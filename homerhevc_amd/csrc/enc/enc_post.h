@@ -24,6 +24,13 @@
 // reference's lag arithmetic once per picture size and the step does not open before those P tasks are done (enc_rc.h).
 #pragma once
 #include "enc_entropy.h"
+// The post-decision tasks stay functions of their own on the device: inlined into the pool's drain they made IT save eighty registers to private memory on every call -
+// and an idle worker calls it for every picture of the launch to find out that nothing is ready.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HENC_TASK_FN __attribute__((noinline))
+#else
+#define HENC_TASK_FN
+#endif
 #include "enc_rc.h"
 #if defined(__HIPCC__)
 #include "../subpel_task.h"      // (device only) the phase planes of the final picture, CTU by CTU: task S
@@ -558,7 +565,7 @@ struct PostCtx {               // what a task needs of the picture it belongs to
 };
 
 template <class G>
-HENC_HDX void post_task_d(const G g, const PostCtx &x, int r, int c)
+HENC_TASK_FN HENC_HDX void post_task_d(const G g, const PostCtx &x, int r, int c)
 {
 	const Seq &S = *x.seq;
 	const PostPic &P = *x.pic;
@@ -580,7 +587,7 @@ HENC_HDX void post_task_d(const G g, const PostCtx &x, int r, int c)
 }
 
 template <class G>
-HENC_HDX void post_task_p(const G g, const PostCtx &x, PostScratch &sc, int r, int c)
+HENC_TASK_FN HENC_HDX void post_task_p(const G g, const PostCtx &x, PostScratch &sc, int r, int c)
 {
 	const Seq &S = *x.seq;
 	const FrameCtx &f = *x.f;
@@ -676,7 +683,7 @@ HENC_HDX void post_task_p(const G g, const PostCtx &x, PostScratch &sc, int r, i
 
 // without SAO: the deblocked CTU into the final picture, margins of border CTUs
 template <class G>
-HENC_HDX void post_task_f(const G g, const PostCtx &x, PostScratch &sc, int r, int c)
+HENC_TASK_FN HENC_HDX void post_task_f(const G g, const PostCtx &x, PostScratch &sc, int r, int c)
 {
 	post_stage_tiles(g, *x.seq, *x.pic, sc, c, r);
 	post_sao_apply_pad(g, *x.seq, *x.pic, sc, sc.c.sao_recon, c, r);
@@ -686,18 +693,14 @@ HENC_HDX void post_task_f(const G g, const PostCtx &x, PostScratch &sc, int r, i
 // ---- the scheduler -----------------------------------------------------------------------------------------------------------------------------------------------
 HENC_INLINE int post_min(int a, int b) { return a < b ? a : b; }
 
-// Runs tasks of the picture until none is ready (other workers may be running some: whoever finishes a task looks again).  Returns the number of tasks it ran.
+// which task of the picture could run now: every lane looks at one row (which of its chains could move?), the first row with one wins.  false: nothing is ready
 template <class G>
-HENC_HDX int post_drain(const G g, const PostCtx &x, PostScratch &sc)
+HENC_HDX inline bool post_scan(const G g, const PostCtx &x, int &pick_r, int &pick_c, int &pick_kind)
 {
 	const Seq &S = *x.seq;
 	const PostPic &P = *x.pic;
 	const int W = S.wctu, H = S.hctu;
-	int ran = 0;
-	PPF_T0();
-	for (;;) {
-		// every lane looks at one row: which of its two chains could move?
-		int pick_r = -1, pick_c = 0, pick_kind = 0;
+	pick_r = -1; pick_c = 0; pick_kind = 0;
 		for (int base = 0; base < H && pick_r < 0; base += g.n) {
 			const int r = base + g.tid;
 			bool d_ok = false, p_ok = false, f_ok = false;
@@ -771,6 +774,20 @@ HENC_HDX int post_drain(const G g, const PostCtx &x, PostScratch &sc)
 #endif
 			}
 		}
+	return pick_r >= 0;
+}
+// Runs tasks of the picture until none is ready (other workers may be running some: whoever finishes a task looks again).  Returns the number of tasks it ran.
+template <class G>
+HENC_HDX int post_drain(const G g, const PostCtx &x, PostScratch &sc)
+{
+	const Seq &S = *x.seq;
+	const PostPic &P = *x.pic;
+	int ran = 0;
+	PPF_T0();
+	(void)S;
+	for (;;) {
+		int pick_r, pick_c, pick_kind;
+		post_scan(g, x, pick_r, pick_c, pick_kind);
 		PPF_LAP(P, PPF_SCAN);
 		if (pick_r < 0) return ran;
 		PostRow &row = P.rows[pick_r];

@@ -535,9 +535,20 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 }
 
 // post-decision tasks of picture q that are ready, on this worker (its Work area is scratch between two CTUs); *finished counts the pictures whose last task is done
-__device__ __attribute__((noinline)) int pool_post_drain(const EncDev &d, const WaveGrp g, const Seq *lseq, const FrameCtx *lframe, Work *lw, WorkSlow *my_slow, int *finished)
+__device__ __attribute__((noinline)) int pool_post_drain_run(const EncDev &d, const WaveGrp g, const Seq *lseq, const FrameCtx *lframe, Work *lw, WorkSlow *my_slow, int *finished);
+// ... the look first, in line: the function that runs the tasks saves forty registers to private memory when it is entered, and an idle worker asks every picture of the
+// launch - mostly to learn that nothing is ready
+__device__ __forceinline__ int pool_post_drain(const EncDev &d, const WaveGrp g, const Seq *lseq, const FrameCtx *lframe, Work *lw, WorkSlow *my_slow, int *finished)
 {
 	if (post_finished(*lseq, d.post)) return 0;
+	PostCtx x;
+	x.seq = lseq; x.f = lframe; x.T = d.tables; x.geo.p = nullptr; x.ctus = d.ctus; x.coeff = d.coeff; x.pic = &d.post;
+	int r, c, k;
+	if (!post_scan(g, x, r, c, k)) return 0;
+	return pool_post_drain_run(d, g, lseq, lframe, lw, my_slow, finished);
+}
+__device__ __attribute__((noinline)) int pool_post_drain_run(const EncDev &d, const WaveGrp g, const Seq *lseq, const FrameCtx *lframe, Work *lw, WorkSlow *my_slow, int *finished)
+{
 	PostCtx x;
 	x.seq = lseq; x.f = lframe; x.T = d.tables; x.geo.p = nullptr; x.ctus = d.ctus; x.coeff = d.coeff; x.pic = &d.post;
 	PostScratch &sc = *(PostScratch *)in_fast_memory((uint8_t *)lw);

@@ -184,7 +184,7 @@ __device__ void subpel_chroma_tile(int tid, SubpelScratch &sc, const int16_t *__
 }
 
 // S(r, c): the planes of CTU (cx, cy) of the final picture `fin` (first valid sample of each padded plane) and of the margins beside it on the picture's edges
-__device__ void subpel_task_ctu(int tid, SubpelScratch &sc, const Seq &S, int16_t *const *fin, uint8_t *out_y, uint8_t *out_u, uint8_t *out_v, int cx, int cy)
+__device__ __attribute__((noinline)) void subpel_task_ctu(int tid, SubpelScratch &sc, const Seq &S, int16_t *const *fin, uint8_t *out_y, uint8_t *out_u, uint8_t *out_v, int cx, int cy)
 {
 	for (int comp = 0; comp < 3; comp++) {
 		const int sh = comp ? 1 : 0, m = comp ? S.margin_c : S.margin_y, stride = comp ? S.stride_c : S.stride_y;
