@@ -516,7 +516,8 @@ HENC_HD void nodes_quad_move(const G g, Enc &__restrict__ e, int quad, int to_re
 }
 template <class G>
 HENC_HD void nodes_select_quad(const G g, Enc &__restrict__ e, int quad)
-{
+{	quad = uni(quad);      // (an argument of a function of its own arrives in a vector register: uniform again, what depends on it is scalar)
+
 	HENC_ENC_IN_LDS(e);
 	if (quad == e.node_quad) return;
 	g.sync();

@@ -81,14 +81,16 @@ HENC_HD void set_inter_info_buffs(const G g, Enc &__restrict__ e, int ni)
 // get_back_consolidated_info :3456 / put_consolidated_info :3472
 template <class G>
 HENC_HD void get_back_consolidated_info(const G g, Enc &__restrict__ e, int ni, int depth)
-{
+{	ni = uni(ni); depth = uni(depth);
+
 	HENC_ENC_IN_LDS(e);
 	info_buffs_copy(g, e, depth, e.geo[ni].abs_index, e.geo[ni].num_part, 0);
 	sync_motion_buffers(g, e, ni, 0, depth + 1, 0, depth + 1);
 }
 template <class G>
 HENC_HD void put_consolidated_info(const G g, Enc &__restrict__ e, int ni, int depth)
-{
+{	ni = uni(ni); depth = uni(depth);
+
 	HENC_ENC_IN_LDS(e);
 	info_buffs_copy(g, e, depth, e.geo[ni].abs_index, e.geo[ni].num_part, 1);
 	sync_motion_buffers(g, e, ni, depth + 1, 0, depth + 1, 0);
@@ -98,7 +100,8 @@ HENC_HD void put_consolidated_info(const G g, Enc &__restrict__ e, int ni, int d
 // children_cost - parent_cost, as the reference does inside).
 template <class G>
 HENC_HD bool consolidate_prediction_info(const G g, Enc &__restrict__ e, int pi, uint32_t parent_cost, uint32_t children_cost, int is_max_depth)
-{
+{	pi = uni(pi); parent_cost = uni(parent_cost); children_cost = uni(children_cost); is_max_depth = uni(is_max_depth);
+
 	HENC_ENC_IN_LDS(e);
 	const Geo &pq = e.geo[pi];
 	Node &pn = node_of(e, pi);
@@ -150,7 +153,8 @@ HENC_HD bool consolidate_prediction_info(const G g, Enc &__restrict__ e, int pi,
 // into the deeper windows (hmr_motion_inter.c:3985-4001 and :4222-4230, hmr_motion_intra.c:1899-1916, 1956-1974)
 template <class G>
 HENC_HD void refresh_deeper_windows(const G g, Enc &__restrict__ e, int aux_ni, int from_depth, int with_info)
-{
+{	aux_ni = uni(aux_ni); from_depth = uni(from_depth); with_info = uni(with_info);
+
 	HENC_ENC_IN_LDS(e);
 	const int max_processing_depth = hmin(CFG_MAX_PRED_DEPTH + e.seq->max_intra_tr_depth - 1, NDEPTH - 1);
 	if (from_depth > max_processing_depth) return;

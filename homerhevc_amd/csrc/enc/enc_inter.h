@@ -812,7 +812,8 @@ HENC_HD void set_inter_mv_buffs(const G g, Enc &__restrict__ e, int ni)
 // predict_inter :2924 (uni-directional): vector predictor choice, motion compensation, residual.  Returns the vector cost.
 template <class G>
 HENC_HD int predict_inter(const G g, Enc &__restrict__ e, int depth, int part_position, int part_size_type)
-{
+{	depth = uni(depth); part_position = uni(part_position); part_size_type = uni(part_size_type);
+
 	HENC_ENC_IN_LDS(e);
 	int curr = node_at(e, depth, part_position), num_partitions = 1;
 	if (part_size_type == PART_NxN) {
@@ -840,7 +841,8 @@ HENC_HD int predict_inter(const G g, Enc &__restrict__ e, int depth, int part_po
 // hmr_cu_motion_estimation :2471 (list 0, one reference).  Returns SAD + vector cost.
 template <class G>
 HENC_HD int cu_motion_estimation(const G g, Enc &__restrict__ e, int depth, int part_position, int part_size_type, int action)
-{
+{	depth = uni(depth); part_position = uni(part_position); part_size_type = uni(part_size_type); action = uni(action);
+
 	HENC_ENC_IN_LDS(e);
 	Work &w = *e.w;
 	const Seq &S = *e.seq;
