@@ -289,7 +289,8 @@ HENC_INLINE void dbk_chroma_edge(int16_t *e, int s, int t, int tc)
 // edges of one direction inside CTU (cx, cy) and on its left / top border (hmr_deblock_filter_cu): a lane owns a four-sample edge segment
 template <class G>
 HENC_HDX void post_deblock_ctu(const G g, const Seq &S, const PostPic &P, int cx, int cy, int dir)
-{
+{	cx = uni(cx); cy = uni(cy); dir = uni(dir);      // (arguments of a function of its own arrive in vector registers)
+
 	const int w4 = hmin(16, (S.width >> 2) - cx * 16), h4 = hmin(16, (S.height >> 2) - cy * 16);
 	const int ys = S.stride_y, cs = S.stride_c, us = P.units_stride;
 	const int cb_off = S.chroma_qp_offset, cr_off = S.chroma_qp_offset;
@@ -338,7 +339,8 @@ HENC_INLINE int sgn3(int v) { return v > 0 ? 1 : (v < 0 ? -1 : 0); }
 // the picture are never used
 template <class G>
 HENC_NOINLINE HENC_HDX void post_stage_tiles(const G g, const Seq &S, const PostPic &P, PostScratch &sc, int cx, int cy)
-{
+{	cx = uni(cx); cy = uni(cy);
+
 	const int width = S.width, height = S.height;
 	const bool la = cx > 0, ta = cy > 0, ra = cx * 64 + 64 < width, ba = cy * 64 + 64 < height;
 	const int hl = (cy * 64 + 64 > height) ? height - cy * 64 : 64, wl = (cx * 64 + 64 > width) ? width - cx * 64 : 64;
@@ -366,7 +368,8 @@ HENC_NOINLINE HENC_HDX void post_stage_tiles(const G g, const Seq &S, const Post
 // classes of the four edge types and of the 32 bands, over the CTU minus the margins the reference leaves out because they were not deblocked yet in its pipeline
 template <class G>
 HENC_HDX void post_sao_stats(const G g, const Seq &S, const FrameCtx &f, PostScratch &sc, int cx, int cy)
-{
+{	cx = uni(cx); cy = uni(cy);
+
 	const int width = S.width, height = S.height;
 	const bool la = cx > 0, ta = cy > 0, ra = cx * 64 + 64 < width, ba = cy * 64 + 64 < height;
 	const int hl = (cy * 64 + 64 > height) ? height - cy * 64 : 64, wl = (cx * 64 + 64 > width) ? width - cx * 64 : 64;
@@ -505,7 +508,8 @@ struct SaoCandFromScratch {
 // (:1723) of the final one
 template <class G>
 HENC_NOINLINE HENC_HDX void post_sao_apply_pad(const G g, const Seq &S, const PostPic &P, const PostScratch &sc, const SaoOffset *params, int cx, int cy)
-{
+{	cx = uni(cx); cy = uni(cy);
+
 	const int width = S.width, height = S.height;
 	const bool la = cx > 0, ta = cy > 0, ra = cx * 64 + 64 < width, ba = cy * 64 + 64 < height;
 	const int hl = (cy * 64 + 64 > height) ? height - cy * 64 : 64, wl = (cx * 64 + 64 > width) ? width - cx * 64 : 64;
@@ -566,7 +570,8 @@ struct PostCtx {               // what a task needs of the picture it belongs to
 
 template <class G>
 HENC_TASK_FN HENC_HDX void post_task_d(const G g, const PostCtx &x, int r, int c)
-{
+{	r = uni(r); c = uni(c);
+
 	const Seq &S = *x.seq;
 	const PostPic &P = *x.pic;
 	const int W = S.wctu;
@@ -588,7 +593,8 @@ HENC_TASK_FN HENC_HDX void post_task_d(const G g, const PostCtx &x, int r, int c
 
 template <class G>
 HENC_TASK_FN HENC_HDX void post_task_p(const G g, const PostCtx &x, PostScratch &sc, int r, int c)
-{
+{	r = uni(r); c = uni(c);
+
 	const Seq &S = *x.seq;
 	const FrameCtx &f = *x.f;
 	const PostPic &P = *x.pic;
@@ -684,7 +690,8 @@ HENC_TASK_FN HENC_HDX void post_task_p(const G g, const PostCtx &x, PostScratch 
 // without SAO: the deblocked CTU into the final picture, margins of border CTUs
 template <class G>
 HENC_TASK_FN HENC_HDX void post_task_f(const G g, const PostCtx &x, PostScratch &sc, int r, int c)
-{
+{	r = uni(r); c = uni(c);
+
 	post_stage_tiles(g, *x.seq, *x.pic, sc, c, r);
 	post_sao_apply_pad(g, *x.seq, *x.pic, sc, sc.c.sao_recon, c, r);
 	g.sync();

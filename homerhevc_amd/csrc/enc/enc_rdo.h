@@ -189,7 +189,8 @@ HENC_FI void rd_transform_tree(const G g, Cabac &ec, const EntView &v, EntScratc
 // rd_get_intra_bits_qt :2362: all contexts from et->ee, the header of the partition and the luma or chroma part of its transform tree
 template <class G>
 HENC_RD_NOINLINE HENC_HD uint32_t rd_get_intra_bits_qt(const G g, Enc &__restrict__ e, const RdViews &r, int ni, int is_luma)
-{
+{	ni = uni(ni); is_luma = uni(is_luma);
+
 	HENC_ENC_IN_LDS(e);
 	Cabac ec;
 	ec.counter = true;
