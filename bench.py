@@ -83,6 +83,83 @@ def check_against_reference(workload, cumulative):
     return all(cumulative[k] == gold[k] for k in range(n)), n
 
 
+def latest_profile(suffix):
+    """The newest committed counter-pass summary profiles/rNN_<suffix> (NN = round; the `final` set of a round before its first)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_final_{suffix}")) + glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{suffix}")),
+                   key=lambda q: (os.path.basename(q)[:3], "_final_" in q))
+    return found[-1] if found else None
+
+
+def pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def headline_line(out):
+    """The driver's record: ONE compact JSON line (well under 4 KB) - the contract's keys, `roofline` and `cpu_baseline` as objects of numbers and short strings, and one
+    number per secondary section.  Everything else of `out` goes to earlier lines (emit)."""
+    cfg = out.get("config", {})
+    roof = out.get("roofline") or {}
+    line = pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line["config"] = pick(cfg, "workload", "sequences_per_gpu", "sequences", "num_enc_engines", "width", "height", "wfpp_num_threads", "qp", "gop", "stream_matches_reference")
+    line["config"]["frames_checked"] = cfg.get("frames_checked_against_reference", cfg.get("access_units_checked_against_reference"))
+    r = pick(roof, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_build", "traffic_is_of_this_build", "ms_per_launch", "launches",
+             "algorithmic_bytes_per_launch", "algorithmic_bytes_model")
+    ib = roof.get("issue_bound") or {}
+    if ib:
+        r["issue_bound"] = pick(ib, "wave_instructions_per_frame", "salu_over_valu", "valu_issue_frac", "wait_share_of_wave_cycles", "valu_lane_utilisation", "build")
+    sp = roof.get("subpel_planes") or {}
+    if sp:
+        r["subpel_planes"] = pick(sp, "achieved", "frac", "ms_per_picture")
+    line["roofline"] = r or None
+    cb = out.get("cpu_baseline")
+    if cb:
+        c = pick(cb, "value", "unit", "cores", "kind")
+        c["sample"] = cb.get("sample", "")[:200]
+        c["one_process"] = (cb.get("one_process") or {}).get("value")
+        rows = cb.get("one_thread_per_ctu_row") or {}
+        c["rows_threads"] = {"value": rows.get("value"), "threads": rows.get("threads")}
+        line["cpu_baseline"] = c
+    else:
+        line["cpu_baseline"] = None
+    ss = out.get("single_sequence")
+    if ss:
+        line["single_sequence"] = {"value": ss.get("value"), "stream_matches_reference": ss.get("stream_matches_reference"),
+                                   "engines_overlapped": [pick(lane, "workload", "frames_per_s_full_chains", "stream_matches_reference") for lane in ss.get("engines_overlapped", [])]}
+    for name in ("single_thread_order", "at_2160p", "cfg3_2160p_cbr", "cfg5_2160p_intra_rdfull"):
+        sec = out.get(name)
+        if isinstance(sec, dict):
+            d = pick(sec, "value", "stream_matches_reference")
+            d["sequences"] = (sec.get("config") or {}).get("sequences_per_gpu")
+            d["alone"] = (sec.get("single_sequence") or {}).get("value")
+            d["cpu"] = (sec.get("cpu_baseline") or {}).get("value")
+            d["cpu_one_process"] = ((sec.get("cpu_baseline") or {}).get("one_process") or {}).get("value")
+            line[name] = {k: v for k, v in d.items() if v is not None}
+    line["stream_matches_reference"] = out.get("stream_matches_reference")
+    line.update(pick(out, "access_units_checked_against_reference", "access_units_differing", "access_units_produced"))
+    line["stale_prediction_windows"] = out.get("evaluations_on_a_stale_prediction_window")
+    line["build"] = roof.get("this_build")
+    return line
+
+
+def emit(out):
+    """stdout: the full record section by section on EARLIER lines (`{"detail": name, ...}`, also kept as gpurun_out/bench_detail.json where that directory can be written),
+    then the compact headline as the LAST line."""
+    head = headline_line(out)
+    for name, sec in out.items():
+        if isinstance(sec, (dict, list)):
+            print(json.dumps({"detail": name, "content": sec}))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w"), indent=1)
+    except OSError:
+        pass
+    text = json.dumps(head)
+    assert len(text) < 4096, f"headline line grew to {len(text)} bytes"
+    sys.stdout.flush()
+    print(text, flush=True)
+
+
 def load_lib():
     lib = C.CDLL(os.path.join(ROOT, "homerhevc_amd", "libhomer_gpu.so"))   # no fallback: without the HIP library there is no bench
     import encoder_cases as ec
@@ -94,6 +171,14 @@ def load_lib():
     lib.hmr_gpu_enc_destroy.argtypes = [C.c_void_p]
     lib.hmr_gpu_last_error.restype = C.c_char_p
     return lib
+
+
+def describe_keys(keys):
+    """The configuration a WORKLOADS key set stands for, in the words of BASELINE.json (the `sample` text of a cpu_baseline)."""
+    gop = "all-intra" if keys.get("force_intra") else "IPPP"
+    rate = f"CBR {keys['bitrate']} kbps" if keys.get("bitrate_mode") == 1 else f"VBR {keys['bitrate']} kbps" if keys.get("bitrate_mode") else "QP32"
+    extra = "".join(f" {k}={keys[k]}" for k in ("rd", "intra_tr", "perf") if k in keys)
+    return f"{gop} {rate}{extra}"
 
 
 def cpu_baseline(width, height, keys, frames):
@@ -157,7 +242,7 @@ def cpu_baseline(width, height, keys, frames):
         dt, n1 = seconds(subprocess.run(cmd, check=True, capture_output=True, preexec_fn=pinned(pins[0])).stdout)
         rows = (height + 63) // 64
         try:      # (free-running threads: at 3840x2160 the reference has been seen to die with SIGSEGV in this mode - recorded, not fatal)
-            dt_rows, _ = seconds(subprocess.run(cmd + [f"wpp={rows}"], check=True, capture_output=True, timeout=600).stdout)
+            dt_rows, _ = seconds(subprocess.run(cmd + [f"wpp={min(rows, 32)}"], check=True, capture_output=True, timeout=600).stdout)      # (MAX_NUM_THREADS 32, hmr_private.h:1234)
             rows_failed = None
         except (subprocess.CalledProcessError, subprocess.TimeoutExpired, RuntimeError) as ex:
             dt_rows, rows_failed = None, f"{type(ex).__name__}: returncode {getattr(ex, 'returncode', None)}"
@@ -187,12 +272,12 @@ def cpu_baseline(width, height, keys, frames):
                           "system's; larger wall than CPU time: they were descheduled - a quota or other tenants)"}
     # the headline of the baseline is the host's best answer to the bench's workload (a batch of independent sequences): all cores, one reference process each
     return {"value": throughput["value"], "unit": "frames/s", "cores": throughput["cores"], "kind": "reference",
-            "sample": f"{K} processes x {frames} frames {width}x{height} IPPP QP32 through oracle/_ref/ref_lockstep (SSE4.2 table, wpp=1, engines=1), one pinned to each physical host core this "
+            "sample": f"{K} processes x {frames} frames {width}x{height} {describe_keys(keys)} through oracle/_ref/ref_lockstep (SSE4.2 table, wpp=1, engines=1), one pinned to each physical host core this "
                       f"process may use; the harness's own clock from the first HOMER_enc_encode to the last access unit of the slowest process (no process start, no HOMER_enc_init); `cores` = "
                       f"effective parallelism {round(effective, 1)} of {K} processes",
             "throughput": throughput,
             "one_process": {"value": round(one, 3), "unit": "frames/s", "cores": 1, "frames": n1},
-            "one_thread_per_ctu_row": {"value": round(n1 / dt_rows, 3) if dt_rows else None, "threads": rows, "host_cores": ncores, "failed": rows_failed,
+            "one_thread_per_ctu_row": {"value": round(n1 / dt_rows, 3) if dt_rows else None, "threads": min(rows, 32), "host_cores": ncores, "failed": rows_failed,
                                        "note": "the same reference run free with wfpp_num_threads = CTU rows (its multi-thread mode; output depends on timing; `failed` when the reference "
                                                "process itself died or hung in this mode)"}}
 
@@ -456,7 +541,7 @@ def main():
             if not a.no_cpu_baseline:
                 width, height, keys = WORKLOADS[a.workload]
                 out["cpu_baseline"] = cpu_baseline(width, height, {k: v for k, v in keys.items() if k != "wpp"}, a.cpu_frames)
-            print(json.dumps(out))
+            emit(out)
         dist.destroy_process_group()
         if not out["stream_matches_reference"]:
             print("bench.py: access units differ from the reference's", file=sys.stderr)
@@ -552,7 +637,7 @@ def main():
                 if section in out:
                     w2, h2, k2 = WORKLOADS[wl]
                     out[section]["cpu_baseline"] = cpu_baseline(w2, h2, {k: v for k, v in k2.items() if k != "wpp"}, frames)
-        print(json.dumps(out))
+        emit(out)
         # a run whose output differs from the reference's is a failed run, whatever it measured: every section that checked its stream must have matched
         bad = [name for name, sec in [("headline", out)] + [(k, v) for k, v in out.items() if isinstance(v, dict)] if sec.get("stream_matches_reference") is False]
         bad += [f"single_sequence.engines_overlapped[{i}]" for i, lane in enumerate(out.get("single_sequence", {}).get("engines_overlapped", [])) if lane.get("stream_matches_reference") is False]
@@ -769,41 +854,47 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
         achieved = S * algo_bytes_frame * len(timed) / (ctu_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed counter passes of this same command: TCC_EA0 requests by their width (64 / 128-byte reads, 64-byte full-line and 32-byte
         # partial-line writes; calibrated on known byte counts, profiles/r04_tcc_calibration.json, as MI355X_MICROARCH.md "HBM" asks for narrow accesses)
-        traffic, issue, traffic_source = None, None, None
+        traffic, issue, traffic_source, traffic_build = None, None, None, None
         kernel_name = "k_encode_pool"
-        tpath = os.path.join(ROOT, "profiles", "r05_pmc_kernels.json")
-        if os.path.exists(tpath) and workload == "cfg2-1080p-encode":
-            pm = json.load(open(tpath))
+        from homerhevc_amd.build import source_digest
+        this_build = source_digest()
+        pm_path, fm_path = latest_profile("pmc_kernels.json"), latest_profile("traffic_pmc_kernels.json")
+        if pm_path and workload == "cfg2-1080p-encode":
+            pm = json.load(open(pm_path))
             k, frames_profiled = pm.get(kernel_name), pm.get("frames_encoded_by_k_encode_pool")
             if k and frames_profiled:
                 dv = k["derived"]      # (by request width where the passes have it, tools/tcc_calibrate.py; else requests x 64 B)
-                per_frame = (dv.get("hbm_read_bytes", dv["hbm_read_bytes_TCC_EA0_RDREQ_x64"]) + dv.get("hbm_write_bytes", dv["hbm_write_bytes_TCC_EA0_WRREQ_x64_upper_bound"])) / frames_profiled
-                traffic = int(per_frame * S * len(timed) / max(launches, 1))       # per launch, like `achieved`
-                traffic_source = (f"profiles/r05_pmc_kernels.json: TCC_EA0 read / write requests by width, rocprofv3 --pmc passes of this command on the build of commit "
-                                  f"{pm.get('build_commit')}, bytes per encoded frame x the frames of one launch")
+                if "hbm_read_bytes_TCC_EA0_RDREQ_x64" in dv:
+                    per_frame = (dv.get("hbm_read_bytes", dv["hbm_read_bytes_TCC_EA0_RDREQ_x64"]) + dv.get("hbm_write_bytes", dv["hbm_write_bytes_TCC_EA0_WRREQ_x64_upper_bound"])) / frames_profiled
+                    traffic = int(per_frame * S * len(timed) / max(launches, 1))       # per launch, like `achieved`
+                    traffic_build = pm.get("source_digest") or pm.get("build_commit")
+                    traffic_source = (f"{os.path.relpath(pm_path, ROOT)}: TCC_EA0 read / write requests by width, rocprofv3 --pmc passes of this command, bytes per encoded frame x the frames of one launch")
                 # the memory-side passes repeated on the final build (tools/pmc_traffic.sh) take precedence for the byte count
-                fpath = os.path.join(ROOT, "profiles", "r05_final_traffic_pmc_kernels.json")
-                if os.path.exists(fpath):
-                    fm = json.load(open(fpath))
+                if fm_path:
+                    fm = json.load(open(fm_path))
                     fd = fm["k_encode_pool"]["derived"]
                     traffic = int((fd["hbm_read_bytes"] + fd["hbm_write_bytes"]) / fm["frames_encoded_by_k_encode_pool"] * S * len(timed) / max(launches, 1))
-                    traffic_source = (f"profiles/r05_final_traffic_pmc_kernels.json: TCC_EA0 read / write requests by width (64 / 128-byte reads, 64-byte full-line and 32-byte "
-                                      f"partial-line writes), rocprofv3 --pmc passes of a 256-sequence run of this command on the build of commit {fm.get('build_commit')}, bytes per "
-                                      "encoded frame x the frames of one launch")
+                    traffic_build = fm.get("source_digest") or fm.get("build_commit")
+                    traffic_source = (f"{os.path.relpath(fm_path, ROOT)}: TCC_EA0 read / write requests by width (64 / 128-byte reads, 64-byte full-line and 32-byte "
+                                      "partial-line writes), rocprofv3 --pmc passes of a 256-sequence run of this command, bytes per encoded frame x the frames of one launch")
                 # what actually bounds the kernel: wave-instruction issue (MI355X_MICROARCH.md: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction)
                 valu_per_frame, salu_per_frame = k["SQ_INSTS_VALU"] / frames_profiled, k["SQ_INSTS_SALU"] / frames_profiled
                 fps_kernel = S * len(timed) / (ctu_ms * 1e-3)
+                all_insts = sum(k.get(c, 0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_FLAT", "SQ_INSTS_SMEM")) / frames_profiled
                 issue = {"valu_wave_instructions_per_frame": int(valu_per_frame), "salu_wave_instructions_per_frame": int(salu_per_frame),
+                         "salu_over_valu": round(salu_per_frame / max(valu_per_frame, 1), 3),
                          "valu_issue_peak_per_s": 614.4e9, "valu_issue_frac": round(valu_per_frame * fps_kernel / 614.4e9, 4),
                          "wait_share_of_wave_cycles": k["derived"].get("wait_share_of_wave_cycles"), "issue_share_of_wave_cycles": k["derived"].get("issue_share_of_wave_cycles"),
+                         # lanes a vector instruction keeps busy: SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64) where the passes collected both
+                         "valu_lane_utilisation": k["derived"].get("valu_lane_utilisation"),
                          "wavefronts_per_simd": round(2 * WORKERS_PER_CU / 4, 2), "workgroups_per_cu": WORKERS_PER_CU,
                          # a wavefront issues one instruction per four cycles whatever its kind (SQ_ACTIVE_INST_x / SQ_INSTS_x = 1.0 quad-cycles in the counter passes): all
                          # the kernel's wave-instructions x 4 cycles against the cycles its 512 workers had - an upper bound of the workers' issue share (the helpers'
                          # instructions, mailbox polling included, are in the count)
-                         "wave_instructions_per_frame": int(sum(k.get(c, 0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_FLAT", "SQ_INSTS_SMEM")) / frames_profiled),
-                         "issue_cycles_over_worker_cycles": round(4 * sum(k.get(c, 0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_FLAT", "SQ_INSTS_SMEM")) / frames_profiled
-                                                                  / (256 * WORKERS_PER_CU * 2.4e9 / fps_kernel), 3),
-                         "source": f"profiles/r05_pmc_kernels.json (rocprofv3 --pmc passes of this command on the build of commit {pm.get('build_commit')}), instruction counts per encoded frame x this run's frames/s of the kernel"}
+                         "wave_instructions_per_frame": int(all_insts),
+                         "issue_cycles_over_worker_cycles": round(4 * all_insts / (256 * WORKERS_PER_CU * 2.4e9 / fps_kernel), 3),
+                         "build": pm.get("source_digest") or pm.get("build_commit"),
+                         "source": f"{os.path.relpath(pm_path, ROOT)} (rocprofv3 --pmc passes of this command), instruction counts per encoded frame x this run's frames/s of the kernel"}
         digest = md5.hexdigest()
         per_clip = {}
         matches, checked = True, None
@@ -833,7 +924,10 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
             "schedule": {"ctus_per_frame": nctu, "passes_per_frame": [s[3] for s in timed], "ctu_encodes_per_frame": [s[4] for s in timed],
                          "ctu_stage_ms_per_frame": [round(s[5], 1) for s in timed], "device_ms_per_frame": [round(s[6], 1) for s in timed]},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 7),
-                         "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic": traffic, "traffic_source": traffic_source, "traffic_build": traffic_build, "this_build": this_build,
+                         "traffic_is_of_this_build": bool(traffic_build and traffic_build == this_build),
+                         "algorithmic_bytes_model": "10.5 W H per frame (SURVEY 8-d whole P frame: CTU stage 7.5 W H + the in-loop filters' read and write)",
+                         "achieved_7p5WH_ctu_stage_only": round(achieved * 7.5 / 10.5, 4),
                          "launches": launches, "algorithmic_bytes_per_launch": int(S * algo_bytes_frame * len(timed) / max(launches, 1)), "ms_per_launch": round(ctu_ms / max(launches, 1), 2),
                          "algorithmic_bytes_per_frame": int(algo_bytes_frame), "share_of_device_time": round(ctu_ms / frame_ms, 3),
                          # SURVEY 8-d, the whole P frame (CTU stage + the in-loop filters' read / write): 10.5 W H bytes x frames/s against the same peak

@@ -22,6 +22,18 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_digest():
+    """A short digest of everything the library is built from (csrc/ and the public header): the GPU box gets the tree without .git, so this - not a commit - is how
+    a measurement file says which build it belongs to (bench.py `build`, tools/pmc_kernels.py `source_digest`)."""
+    import hashlib
+    h = hashlib.sha1()
+    paths = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(CSRC) for f in fs if f.endswith((".h", ".hip", ".cpp", ".inc")))
+    for path in paths + [os.path.join(PKG_DIR, "..", "include", "homer_gpu.h")]:
+        h.update(os.path.relpath(path, PKG_DIR).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def build_native(force=False, verbose=False):
     """Compile every HIP source into homerhevc_amd/libhomer_gpu.so (cross-compiles without a GPU)."""
     if not force and not _stale():

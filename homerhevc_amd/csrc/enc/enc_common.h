@@ -107,7 +107,7 @@ struct Enc {
 	HENC_AT(Work, LDS_OFF_WORK) w;
 	HENC_AT(WorkRd, LDS_OFF_RD) wrd;      // RD_FULL only
 	int amvp_node;            // the node whose vector predictor list w.amvp holds, straight from motion estimation (-1: none)
-	int on_helper;            // this context is a helper wavefront's copy (which slot of the level buffer a TU takes: enc_types.h iq_slot)
+	int on_helper;            // 0: the worker's context; 1 + h: helper wavefront h's copy (which slot of the level buffer a TU takes: enc_types.h iq_slot)
 	int16_t *coeff;        // the CTU's coefficient output: 4096 luma + 2 x 1024 chroma, linear per TU in z-order
 	// speculative inputs of a P-frame CTU (enc_ctu.h)
 	uint32_t total_intra_partitions, total_partitions;

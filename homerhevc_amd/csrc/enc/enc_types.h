@@ -211,13 +211,18 @@ struct EntScratch {
 constexpr int RD_CTX_BYTES = 192;      // CTX_TOTAL (enc_cabac_tables.h: 179) rounded up
 constexpr int RD_RING = 8;             // RD_FULL: frames whose coder states are kept (a coder object nobody selects keeps its states: enc_rc.h RdCtxSim)
 
+#if defined(HENC_NHELP)
+#define HENC_IQ_SLOTS (HENC_NHELP)
+#else
+#define HENC_IQ_SLOTS 1
+#endif
 struct Work {
 	src_t curr_y[64 * 64], curr_c[2][32 * 32];
 	pred_t pred_y[64 * 64], pred_c[2][32 * 32];
 #if defined(__HIPCC__)
 	// levels, then dequantised coefficients, of the TU in flight: a slot for the worker (luma; V of an intra chroma TU, while its helper does U) and one for the helper
 	// (U, then V of an inter TU; U of an intra chroma TU) - iq_slot below
-	int16_t iq_y[32 * 32], iq_c[1][32 * 32];
+	int16_t iq_y[32 * 32], iq_c[HENC_IQ_SLOTS][32 * 32];      // (a slot per helper wavefront: two helpers run U and V of a TU at the same time)
 #else
 	int16_t iq_y[64 * 64], iq_c[2][32 * 32];
 #endif
@@ -283,7 +288,7 @@ HENC_INLINE int16_t *iq_slot(Work &w, int comp, int off, int on_helper)
 {
 #if defined(__HIPCC__)
 	(void)off; (void)comp;
-	return on_helper ? w.iq_c[0] : w.iq_y;
+	return on_helper ? w.iq_c[on_helper - 1] : w.iq_y;      // (on_helper: 0 = the worker, 1 + h = helper h)
 #else
 	(void)on_helper;
 	return (comp == COMP_Y ? w.iq_y : w.iq_c[comp - 1]) + off;

@@ -161,7 +161,7 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 			wave_copy_words(&e, &worker, (int)sizeof(Enc), g.tid);
 			g.sync();
 			e.box = nullptr;
-			e.on_helper = 1;
+			e.on_helper = 1 + h;      // (its own slot of the chroma level buffer: enc_types.h iq_slot)
 			e.scratch_a = scratch;
 			e.scratch_b = scratch + 1024;
 			e.adi_c = scratch + 2048;

@@ -8,6 +8,9 @@ import shutil
 import subprocess
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bench_record
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
@@ -24,7 +27,7 @@ for name in sorted(os.listdir(src)):
             try:
                 d = json.loads(text)
             except ValueError:
-                d = json.loads(text.splitlines()[-1])      # (a bench line behind other output)
+                d = bench_record.load(path)      # (a bench record: detail lines, then the headline)
         except (ValueError, IndexError):
             continue
         if isinstance(d, dict):

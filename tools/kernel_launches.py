@@ -5,7 +5,11 @@
 """
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bench_record
 
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_encode_pool" in r["Kernel_Name"]]
 # the bench's headline is the batch of sequences (a launch of as many workgroups as the GPU has CUs); the single-sequence run beside it (17 workgroups) is not listed here
@@ -15,7 +19,7 @@ if gkey:
     rows = [r for r in rows if int(r[gkey]) == big]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ms = [round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, 2) for r in rows]
-b = json.load(open(sys.argv[2]))
+b = bench_record.load(sys.argv[2])
 timed = b["schedule"]["ctu_stage_ms_per_frame"]
 json.dump({"rocprofv3_kernel_trace_ms_per_launch": ms, "warmup_launches": b["warmup"], "timed_launches_rocprofv3_ms": ms[b["warmup"]:],
            "timed_launches_hip_events_ms": timed, "mean_rocprofv3_ms": round(sum(ms[b["warmup"]:]) / max(len(ms[b["warmup"]:]), 1), 2),

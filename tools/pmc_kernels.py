@@ -32,6 +32,9 @@ def main():
         if "SQ_WAVE_CYCLES" in k and k["SQ_WAVE_CYCLES"]:
             d["wait_share_of_wave_cycles"] = round(k.get("SQ_WAIT_ANY", 0) / k["SQ_WAVE_CYCLES"], 3)
             d["issue_share_of_wave_cycles"] = round(k.get("SQ_ACTIVE_INST_ANY", 0) / k["SQ_WAVE_CYCLES"], 3)
+        if k.get("SQ_THREAD_CYCLES_VALU") and k.get("SQ_ACTIVE_INST_VALU"):
+            # lanes a vector instruction keeps busy: thread-cycles over 64 x the cycles vector instructions were executing (both in quad-cycles)
+            d["valu_lane_utilisation"] = round(k["SQ_THREAD_CYCLES_VALU"] / (64.0 * k["SQ_ACTIVE_INST_VALU"]), 4)
         if "TCC_EA0_RDREQ_sum" in k:
             d["hbm_read_bytes_TCC_EA0_RDREQ_x64"] = k["TCC_EA0_RDREQ_sum"] * 64
             d["hbm_write_bytes_TCC_EA0_WRREQ_x64_upper_bound"] = k.get("TCC_EA0_WRREQ_sum", 0) * 64
@@ -58,6 +61,12 @@ def main():
         kernels["build_commit"] = subprocess.run(["git", "-C", os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     except OSError:
         kernels["build_commit"] = None
+    try:      # the digest of the sources in the tree the passes ran on (what the GPU box does have)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from homerhevc_amd.build import source_digest
+        kernels["source_digest"] = source_digest()
+    except Exception:      # noqa: BLE001
+        kernels["source_digest"] = None
     json.dump(kernels, sys.stdout, indent=1)
     print()
 
