@@ -111,7 +111,7 @@ HENC_HD void cand_sads(const G g, Enc &__restrict__ e, int ox, int oy, int gx, i
 #pragma unroll
 	for (int k = 0; k < MAXC; k++)
 		cand[k] = ok[k] ? p0 + (((qy[k] & 3) << 2) | (qx[k] & 3)) * S.stride_y + (ptrdiff_t)(qy[k] >> 2) * sy + (qx[k] >> 2) : nullptr;
-	multi_sad_u8<MAXC>(g, e.w->curr_y + oy * 64 + ox, size, cand, sy, out);
+	{ PRIM_T0(); multi_sad_u8<MAXC>(g, e.w->curr_y + oy * 64 + ox, size, cand, sy, out); PRIM_END(PP_SAD); }
 #else
 	const int16_t *orig = e.w->curr_y + oy * 64 + ox, *ref = e.f->ref[0] + gy * S.stride_y + gx;
 	for (int k = 0; k < MAXC; k++) {

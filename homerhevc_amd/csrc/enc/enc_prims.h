@@ -81,10 +81,10 @@ HENC_INLINE uint32_t ld32u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, 
 
 // SADs of up to MAXC candidate blocks (global, 8 bit, row pitch `stride`) against one source block (8 bit, row pitch 64); cand[k] == nullptr: skipped.
 // Every candidate's loads are issued before the first result is needed, so a round of candidates costs one memory latency.
+// (The profiling build times it at the call, enc_inter.h cand_sads: with the timer in here the compiler fails with "illegal VGPR to SGPR copy".)
 template <int MAXC>
 __device__ __forceinline__ void multi_sad_u8(const WaveGrp g, const uint8_t *orig8, int n, const uint8_t *const (&cand)[MAXC], int stride, uint32_t (&out)[MAXC])
 {
-	PRIM_T0();
 	if (n == 8) {
 		// 16 four-sample chunks per block: four candidates side by side, one per 16-lane row; the row totals are what WaveGrp::sum adds up last
 		const int sub = g.tid >> 4, r = (g.tid & 15) >> 1, c = (g.tid & 1) << 2;
@@ -114,7 +114,6 @@ __device__ __forceinline__ void multi_sad_u8(const WaveGrp g, const uint8_t *ori
 			for (int j = 0; j < 4; j++)
 				if (k0 + j < MAXC) out[k0 + j] = (uint32_t)__builtin_amdgcn_readlane(x, 16 * j + 15);
 		}
-		PRIM_END(PP_SAD);
 		return;
 	}
 	const int lw = ilog2i(n) - 2, chunks = (n * n) >> 2;       // n >= 16: at least one chunk per lane
@@ -132,7 +131,6 @@ __device__ __forceinline__ void multi_sad_u8(const WaveGrp g, const uint8_t *ori
 	}
 #pragma unroll
 	for (int k = 0; k < MAXC; k++) out[k] = g.sum(acc[k]);
-	PRIM_END(PP_SAD);
 }
 
 // n x n samples of an 8-bit plane into the (8-bit) prediction window (motion compensation from the phase planes); the caller syncs
