@@ -141,7 +141,7 @@ struct Enc {
 // Two helper wavefronts per row worker take the chroma components of a step whose three components are independent (motion compensation, the
 // transform chain of a TU) and single candidates of the intra mode search, while the worker itself does luma / the first candidate.  The worker
 // posts a job in LDS and goes on; a helper runs the same SPMD code on its own 64 lanes with its own scratch and reports back.
-enum { HJOB_NONE = 0, HJOB_NEW_CTU, HJOB_INTER_TU, HJOB_INTRA_SAD, HJOB_SYNC_CU, HJOB_SSD, HJOB_CHROMA_SEARCH, HJOB_CHROMA_TU, HJOB_QUIT };
+enum { HJOB_NONE = 0, HJOB_NEW_CTU, HJOB_INTER_TU, HJOB_INTRA_SAD, HJOB_SYNC_CU, HJOB_SSD, HJOB_CHROMA_SEARCH, HJOB_CHROMA_TU, HJOB_QUAD_C, HJOB_QUIT };
 // One helper per worker: it takes BOTH chroma planes of a step, one after the other, while the worker does luma (a workgroup of two wavefronts, so that more
 // workers fit a CU: k_encode.hip).  HENC_NHELP=2 builds the round-4 arrangement, a helper per chroma plane (a third was measured then: 3 % slower).
 #if !defined(HENC_NHELP)

@@ -6,6 +6,7 @@
 #pragma once
 #include "enc_intra.h"
 #include "enc_inter.h"
+#include "enc_quad.h"
 
 namespace henc {
 
@@ -208,6 +209,12 @@ HENC_WALK_FN HENC_HD uint32_t check_rd_cost_merge(const G g, Enc &__restrict__ e
 	uint8_t inter_modes[5] = {255, 255, 255, 255, 255};
 	const double weight = e.f->chroma_weight;
 	{ PRIM_T0(); get_merge_candidates(e, ni, w.merge_cands, inter_modes); PRIM_END(PP_CAND); }
+#if defined(HENC_QUAD)
+	{	// an 8 x 8 CU: the evaluations of all candidates in one pass, then this loop on their results (enc_quad.h); -1: the sequential way
+		const int slots = quad_prepare(g, e, ni);
+		if (slots >= 0) return quad_merge_loop(g, e, ni, slots, inter_modes);
+	}
+#endif
 	for (int cand = 0; cand < CFG_NUM_MERGE_CAND; cand++) {
 		int mc_done = 0;
 		// A candidate that repeats the one before it (same vector, same reference - the usual case under coherent motion, and always for the zero candidates that

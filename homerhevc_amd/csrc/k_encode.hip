@@ -234,6 +234,11 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 			r1 = (uint32_t)cs;
 			break;
 		}
+#if defined(HENC_QUAD)
+		case HJOB_QUAD_C:      // the chroma blocks of all merge candidates of an 8 x 8 CU in one pass (enc_quad.h)
+			quad_chroma_job(g, e, a[0]);
+			break;
+#endif
 		case HJOB_INTRA_SAD: {
 			const Geo &q = e.geo[a[0]];
 			r0 = intra_predict_sad(g, (pred_t *)nullptr, 0, e.w->curr_y + q.y * CTU_STRIDE_Y + q.x, CTU_STRIDE_Y, a[3] ? e.w->adi_f : e.w->adi, a[1], a[2], 1);

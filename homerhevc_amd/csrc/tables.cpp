@@ -98,6 +98,12 @@ void build()
 						t->fragp[dir][b][lane * 4 + e] = (lane % 16 / 8 == lane / 32 && row < n && col < n) ? half_bits(M[row * n + col]) : 0;
 					}
 			}
+			{
+				const int16_t *M = dir ? t->dct_t[0] : t->dct[0];
+				for (int lane = 0; lane < 64; lane++)
+					for (int e = 0; e < 4; e++)
+						t->fragq[dir][lane * 4 + e] = (lane % 16 / 4 == lane / 16) ? half_bits(M[(lane % 4) * 4 + e]) : 0;
+			}
 			for (int R = 0; R < 2; R++)
 				for (int K = 0; K < 2; K++)
 					for (int lane = 0; lane < 64; lane++)

@@ -24,5 +24,8 @@ struct DevTables {
 	//   frag32t[dir][R][K][lane * 4 + e] = B[16 R + lane % 16][16 K + 4 * (lane / 16) + e] of the 32 x 32 DCT: its four 16 x 16 quarters as fragments of the 16 x 16 x 16 product
 	//   (the 32 x 32 transforms run as quarter tiles: eight accumulator registers in flight; a 32 x 32 x 8 chain held 64)
 	uint16_t frag32t[2][2][2][64 * 4];
+	//   fragq[dir][lane * 4 + e]: SIXTEEN 4 x 4 blocks in one 16 x 16 tile (block diagonal, DCT 4): B[lane % 4][e] where lane % 16 / 4 == lane / 16, else 0 -
+	//   the merge evaluation of an 8 x 8 CU transforms the chroma blocks of all its candidates in one product (enc_quad.h); four 8 x 8 blocks use fragp[dir][1]
+	uint16_t fragq[2][64 * 4];
 };
 
