@@ -34,10 +34,26 @@ extern "C" FILE *henc_trace_file;
 enum { PF_SETUP = 0, PF_MERGE, PF_ME_INT, PF_ME_SUB, PF_PRED_INTER, PF_ENC_INTER, PF_INTRA_SEARCH, PF_INTRA_TU, PF_INTRA_CHROMA, PF_CONSOLIDATE, PF_WAIT, PF_TOTAL, PF_PRIM0, PF_COUNT = PF_PRIM0 + 2 * PP_COUNT + 2 };   // PF_PRIM0...: ticks, then calls, per primitive class (enc_prims.h)
 #if defined(__HIPCC__) && defined(HENC_PROFILE)
 #define HENC_PROF_T0() const unsigned long long prof_t0_ = __builtin_amdgcn_s_memtime()
+#if defined(HENC_QPROF)
+// (an experiment build: the phase slots 1 .. 10 are lent to the marks of one code path - HENC_QPROF_MARK adds the time since the last mark to slot `cat` - and the
+// regular phase timers only keep the total)
+#define HENC_PROF_ADD(e, cat) do { if ((cat) == PF_TOTAL && (e).prof && threadIdx.x == 0) (e).prof[cat] += __builtin_amdgcn_s_memtime() - prof_t0_; } while (0)
+#define HENC_QPROF_T0() unsigned long long qprof_t_ = __builtin_amdgcn_s_memtime()
+#define HENC_QPROF_MARK(e, cat) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if ((e).prof && threadIdx.x == 0) (e).prof[cat] += now_ - qprof_t_; qprof_t_ = now_; } while (0)
+#define HENC_QPROF_ARG , unsigned long long &qprof_t_
+#define HENC_QPROF_PASS , qprof_t_
+#else
 #define HENC_PROF_ADD(e, cat) do { if ((e).prof && threadIdx.x == 0) (e).prof[cat] += __builtin_amdgcn_s_memtime() - prof_t0_; } while (0)
+#endif
 #else
 #define HENC_PROF_T0() do { } while (0)
 #define HENC_PROF_ADD(e, cat) do { } while (0)
+#endif
+#if !defined(HENC_QPROF_MARK)
+#define HENC_QPROF_T0() do { } while (0)
+#define HENC_QPROF_MARK(e, cat) do { } while (0)
+#define HENC_QPROF_ARG
+#define HENC_QPROF_PASS
 #endif
 
 namespace henc {

@@ -208,11 +208,19 @@ HENC_WALK_FN HENC_HD uint32_t check_rd_cost_merge(const G g, Enc &__restrict__ e
 	int best_ref_idx = 0;
 	uint8_t inter_modes[5] = {255, 255, 255, 255, 255};
 	const double weight = e.f->chroma_weight;
+	HENC_QPROF_T0();
 	{ PRIM_T0(); get_merge_candidates(e, ni, w.merge_cands, inter_modes); PRIM_END(PP_CAND); }
+	if (q.size == 8) HENC_QPROF_MARK(e, 1);
 #if defined(HENC_QUAD)
 	{	// an 8 x 8 CU: the evaluations of all candidates in one pass, then this loop on their results (enc_quad.h); -1: the sequential way
-		const int slots = quad_prepare(g, e, ni);
-		if (slots >= 0) return quad_merge_loop(g, e, ni, slots, inter_modes);
+		const QuadCands mc = quad_load_cands(e);
+		const int slots = quad_prepare(g, e, ni, mc HENC_QPROF_PASS);
+		if (slots >= 0) {
+			const uint32_t best = quad_merge_loop(g, e, ni, slots, mc, inter_modes HENC_QPROF_PASS);
+			HENC_QPROF_MARK(e, 7);      // (the node's fields)
+			if (g.tid == 0 && e.prof) e.prof[8] += 1;      // (CUs taken this way)
+			return best;
+		}
 	}
 #endif
 	for (int cand = 0; cand < CFG_NUM_MERGE_CAND; cand++) {

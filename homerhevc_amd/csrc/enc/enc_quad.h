@@ -116,6 +116,15 @@ __device__ __forceinline__ void quad_chain(const int lane, Enc &__restrict__ e, 
 #pragma unroll
 		for (int k = 0; k < 4; k++) { qv[k] = qf; iv[k] = ifl; }
 	}
+	// the scan positions of the lane's coefficient group for the sign-hiding walk (lanes below NBLK * GPB: block gb, group cg), fetched with everything else that
+	// comes from memory
+	const int gb = lane / GPB, cg = lane % GPB;
+	SbhGroup sg;
+	if (S.sign_hiding && lane < NBLK * GPB) {
+		const uint32_t *sc = T->scan[SCAN_DIAG][L] + (cg << 4);
+#pragma unroll
+		for (int n = 0; n < 16; n++) sg.pos[n] = sc[n];
+	}
 	// forward transform (tr_forward_mfma with the block-diagonal basis)
 	const mf_f4 z = {0, 0, 0, 0};
 	int y[4];
@@ -157,8 +166,8 @@ __device__ __forceinline__ void quad_chain(const int lane, Enc &__restrict__ e, 
 	}
 	int sum = (int)quad_blk_sum<N>(lsum);                    // (the level sum BEFORE sign hiding, as quantize reports it)
 	const uint32_t raw_zero = quad_blk_sum<N>(lraw);         // blk_ssd(source, prediction)
-	// sign hiding (sbh_pass): a coefficient group per lane, over the blocks' buffers
-	if (S.sign_hiding) {      // (uniform)
+	// sign hiding (sbh_pass): a coefficient group per lane, over the blocks' buffers - when any block has two levels to hide a sign in
+	if (S.sign_hiding && __ballot(active && sum >= 2) != 0) {      // (uniform)
 		if (active) {
 			S4 a, b, c;
 #pragma unroll
@@ -171,9 +180,14 @@ __device__ __forceinline__ void quad_chain(const int lane, Enc &__restrict__ e, 
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		SbhGroup sg;
-		const int gb = lane / GPB, cg = lane % GPB;
-		const bool nz = lane < NBLK * GPB && acs[gb] >= 2 && sbh_gather(sg, wk_lv + gb * NN, wk_cf + gb * NN, wk_du + gb * NN, T->scan[SCAN_DIAG][L], cg);
+		bool nz = false;
+		if (lane < NBLK * GPB && acs[gb] >= 2) {
+			const int16_t *dl = wk_lv + gb * NN, *sl = wk_cf + gb * NN, *ul = wk_du + gb * NN;
+			int any = 0;
+#pragma unroll
+			for (int n = 0; n < 16; n++) { sg.lv[n] = dl[sg.pos[n]]; sg.sv[n] = sl[sg.pos[n]]; sg.du[n] = ul[sg.pos[n]]; any |= sg.lv[n]; }      // (sbh_gather)
+			nz = any != 0;
+		}
 		const uint64_t mask = __ballot(nz);
 		if (nz) {
 			const uint32_t mine = (uint32_t)(mask >> (gb * GPB)) & ((1u << GPB) - 1u);
@@ -189,6 +203,9 @@ __device__ __forceinline__ void quad_chain(const int lane, Enc &__restrict__ e, 
 		}
 	}
 	const bool coded = sum > 0;
+	int rd[4] = {0, 0, 0, 0};
+	uint32_t raw = 0;
+	if (__ballot(active && coded) != 0) {      // (uniform: some block has levels)
 	// dequantisation (dequantize), to the exchange buffer: the inverse transform's operand is the transposed tile
 	{
 		const int iq_shift = 20 - 14 - (15 - 8 - L) + 4;
@@ -204,7 +221,6 @@ __device__ __forceinline__ void quad_chain(const int lane, Enc &__restrict__ e, 
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	// inverse transform (tr_inverse_mfma): operand element e of the lane is tile element (k0 + e, row)
-	int rd[4];
 	{
 		const mf_h4 mt = mf_frag(N == 8 ? T->fragp[1][1] : T->fragq[1], lane);
 		int c[4] = {0, 0, 0, 0};
@@ -235,7 +251,8 @@ __device__ __forceinline__ void quad_chain(const int lane, Enc &__restrict__ e, 
 		const int32_t dd = (int16_t)((int16_t)x[k] - (int16_t)rd[k]);
 		lrec += (uint32_t)(dd * dd);
 	}
-	const uint32_t raw = quad_blk_sum<N>(lrec);
+	raw = quad_blk_sum<N>(lrec);
+	}
 	const double weight = e.f->chroma_weight;
 	uint32_t ssd;
 	bool keep = false;
@@ -288,48 +305,74 @@ __device__ __forceinline__ void quad_chroma_job(const WaveGrp g, Enc &__restrict
 	quad_chain<4>(g.tid, e, uni(ni), quad_scratch(e), s, s + 128, s + 256, (int32_t *)(s + 384));
 }
 
+// the CU's merge candidates in registers (one look at the list for the slot assignment and the candidate loop; indexed with constants only: the loops over
+// the candidates are unrolled)
+struct QuadCands {
+	int x[5], y[5], ref[5];
+};
+__device__ __forceinline__ QuadCands quad_load_cands(Enc &__restrict__ e)
+{
+	HENC_ENC_IN_LDS(e);
+	const MvCandList &l = e.w->merge_cands;
+	QuadCands c;
+#pragma unroll
+	for (int k = 0; k < 5; k++) {
+		if (k < CFG_NUM_MERGE_CAND) { c.x[k] = uni(l.mv[k].x); c.y[k] = uni(l.mv[k].y); c.ref[k] = uni(l.ref_idx[k]); }
+		else c.x[k] = c.y[k] = c.ref[k] = 0;
+	}
+	return c;
+}
+
 // Slots for the CU's merge candidates and the chains of all slots.  Returns -1 when the CU is evaluated the sequential way (see the head of the file), else
 // the slot of candidate cand in bits 4 cand .. 4 cand + 3 (quad_slot).
 HENC_INLINE int quad_slot(int slots, int cand) { return (slots >> (4 * cand)) & 15; }
-__device__ __forceinline__ int quad_prepare(const WaveGrp g, Enc &__restrict__ e, int ni)
+__device__ __forceinline__ int quad_prepare(const WaveGrp g, Enc &__restrict__ e, int ni, const QuadCands &mc HENC_QPROF_ARG)
 {
 	HENC_ENC_IN_LDS(e);
-	Work &w = *e.w;
 	const Seq &S = *e.seq;
 	const Geo &q = e.geo[ni];
 	if (q.size != 8 || S.perf_mode < 1) return -1;
+	static_assert(CFG_NUM_MERGE_CAND <= 5, "at most five merge candidates (QuadCands, the slot bits)");
 	QuadScratch &qs = quad_scratch(e);
 	const int gx = e.ctu_x + q.x, gy = e.ctu_y + q.y, n = 8;
 	const int xlow = -S.margin_y, xhigh = S.width + S.margin_y, ylow = -S.margin_y, yhigh = S.height + S.margin_y;
-	int nslots = 0, slots = 0;
-	MV smv[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-	int sref[4] = {0, 0, 0, 0};
+	int nslots = 0, slots = 0, bad = 0;
+	int sx[4] = {0, 0, 0, 0}, sy[4] = {0, 0, 0, 0}, sr[4] = {0, 0, 0, 0};
+#pragma unroll
 	for (int cand = 0; cand < CFG_NUM_MERGE_CAND; cand++) {
-		const MV mv = w.merge_cands.mv[cand];
-		const int ref = w.merge_cands.ref_idx[cand];
-		const int spx = gx + mv.x / 4, spy = gy + mv.y / 4;
-		if (spx < xlow || spx + n > xhigh || spy < ylow || spy + n > yhigh) return -1;      // Q12: the sequential evaluation reads a stale window
+		const int spx = gx + mc.x[cand] / 4, spy = gy + mc.y[cand] / 4;
+		if (spx < xlow || spx + n > xhigh || spy < ylow || spy + n > yhigh) bad = 1;      // Q12: the sequential evaluation reads a stale window
 		int s = -1;
 #pragma unroll
-		for (int k = 0; k < 4; k++)
-			if (s < 0 && k < nslots && smv[k].x == mv.x && smv[k].y == mv.y && sref[k] == ref) s = k;
+		for (int k = 3; k >= 0; k--)
+			if (k < nslots && sx[k] == mc.x[cand] && sy[k] == mc.y[cand] && sr[k] == mc.ref[cand]) s = k;
 		if (s < 0) {
-			if (nslots == 4) return -1;
-			s = nslots;
+			if (nslots == 4) bad = 1;
+			s = nslots & 3;
 #pragma unroll
 			for (int k = 0; k < 4; k++)
-				if (k == nslots) { smv[k] = mv; sref[k] = ref; }
+				if (k == s && nslots < 4) { sx[k] = mc.x[cand]; sy[k] = mc.y[cand]; sr[k] = mc.ref[cand]; }
 			nslots++;
 		}
 		slots |= s << (4 * cand);
 	}
+	if (bad) return -1;
 	// (slots nobody uses repeat slot 0: every block of the tile then holds valid data)
+	if (g.tid < 4) {
+		int mx = sx[0], my = sy[0];
 #pragma unroll
-	for (int k = 0; k < 4; k++) qs.mv[k] = k < nslots ? smv[k] : smv[0];
+		for (int k = 1; k < 4; k++)
+			if (g.tid == k && k < nslots) { mx = sx[k]; my = sy[k]; }
+		qs.mv[g.tid].x = mx;
+		qs.mv[g.tid].y = my;
+	}
 	g.sync();
+	HENC_QPROF_MARK(e, 2);      // (the slots)
 	helper_post(g, e, 0, HJOB_QUAD_C, ni);
 	quad_chain<8>(g.tid, e, ni, qs, qs.wk_lv, qs.wk_cf, qs.wk_du, qs.acs);
+	HENC_QPROF_MARK(e, 3);      // (the luma chain)
 	helper_wait(g, e, 0);
+	HENC_QPROF_MARK(e, 4);      // (the rest of the helper's chroma chain)
 	return slots;
 }
 
@@ -393,82 +436,88 @@ __device__ __forceinline__ void quad_commit(const WaveGrp g, Enc &__restrict__ e
 }
 
 // check_rd_cost_merge (enc_ctu.h) on the slots' results: the same loop, statement for statement, with every evaluation a look-up and every copy deferred to
-// quad_commit.  `slots` from quad_prepare; inter_modes from get_merge_candidates.
-__device__ __forceinline__ uint32_t quad_merge_loop(const WaveGrp g, Enc &__restrict__ e, int ni, int slots, const uint8_t *inter_modes)
+// quad_commit.  The slots' figures are fetched once (a slot per lane, then scalar registers) and the node's fields are written once at the end: the loop itself
+// touches no memory.  `slots` from quad_prepare; inter_modes from get_merge_candidates.
+__device__ __forceinline__ uint32_t quad_merge_loop(const WaveGrp g, Enc &__restrict__ e, int ni, int slots, const QuadCands &mc, const uint8_t *inter_modes HENC_QPROF_ARG)
 {
 	HENC_ENC_IN_LDS(e);
-	Work &w = *e.w;
 	const Geo &q = e.geo[ni];
 	Node &nd = node_of(e, ni);
 	CtuPublic &c = *e.ctu;
 	QuadScratch &qs = quad_scratch(e);
 	const int abs_index = q.abs_index, curr_depth = q.depth;
+	const double weight = e.f->chroma_weight, avg_dist = e.f->avg_dist;
+	// per slot: the coded evaluation's distortion, level sum, cost and cbf bits, the no-residual evaluation's distortion
+	uint32_t s_dist[4], s_sum[4], s_cost[4], s_cbf[4], s_nores[4];
+	{
+		const QuadRes &r = qs.res[g.tid & 3];
+		const uint32_t d = r.dist[0] + r.dist[1] + r.dist[2], sm = (uint32_t)(r.sum[0] + r.sum[1] + r.sum[2]);
+		const uint32_t cst = (uint32_t)((double)d + cost_rd(avg_dist, sm));
+		uint32_t nr = r.raw[0];
+		nr += (uint32_t)(weight * r.raw[1]);
+		nr += (uint32_t)(weight * r.raw[2]);
+		const uint32_t cb = r.cbf[0] | (r.cbf[1] << 1) | (r.cbf[2] << 2);
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			s_dist[k] = (uint32_t)__builtin_amdgcn_readlane((int)d, k);
+			s_sum[k] = (uint32_t)__builtin_amdgcn_readlane((int)sm, k);
+			s_cost[k] = (uint32_t)__builtin_amdgcn_readlane((int)cst, k);
+			s_cbf[k] = (uint32_t)__builtin_amdgcn_readlane((int)cb, k);
+			s_nores[k] = (uint32_t)__builtin_amdgcn_readlane((int)nr, k);
+		}
+	}
+	auto of_slot = [](const uint32_t (&a)[4], int s) -> uint32_t { return s == 0 ? a[0] : (s == 1 ? a[1] : (s == 2 ? a[2] : a[3])); };
 	uint32_t no_nores_mask = 0;      // merge_cand_buffer: bit cand
 	int best_is_skip = 0, best_candidate = 0, have_ctu_cbf = 0, prev_nores_ran = 0;
 	uint32_t dist, best_dist = MAX_COST, cost, best_cost = MAX_COST, best_sum = 0, ctu_cbf = 0;
-	MV best_mv = {0, 0};
-	int best_ref_idx = 0;
-	int cons_slot = 0, cons_kind = 0, wnd_slot = 0, wnd_kind = 0, last_pred = -1, coded_any = 0;
-	const double weight = e.f->chroma_weight;
+	int best_x = 0, best_y = 0, best_ref_idx = 0;
+	int cons_slot = 0, cons_kind = 0, wnd_slot = 0, wnd_kind = 0, last_pred = -1, coded_slot = -1;
+	uint32_t nd_cbf = 0, nd_sum = 0;      // the node's inter_cbf bits and level sum as the evaluations leave them
+#pragma unroll
 	for (int cand = 0; cand < CFG_NUM_MERGE_CAND; cand++) {
 		const int slot = quad_slot(slots, cand);
 		int mc_done = 0;
-		if (cand >= 1 && w.merge_cands.mv[cand].x == w.merge_cands.mv[cand - 1].x && w.merge_cands.mv[cand].y == w.merge_cands.mv[cand - 1].y &&
-		    w.merge_cands.ref_idx[cand] == w.merge_cands.ref_idx[cand - 1]) {
+		if (cand >= 1 && mc.x[cand] == mc.x[cand >= 1 ? cand - 1 : 0] && mc.y[cand] == mc.y[cand >= 1 ? cand - 1 : 0] && mc.ref[cand] == mc.ref[cand >= 1 ? cand - 1 : 0]) {
 			const int coded_runs = !best_is_skip;
-			if (coded_runs) no_nores_mask = (no_nores_mask & ~(1u << cand)) | (((no_nores_mask >> (cand - 1)) & 1u) << cand);
+			if (coded_runs) no_nores_mask = (no_nores_mask & ~(1u << cand)) | (((no_nores_mask >> (cand >= 1 ? cand - 1 : 0)) & 1u) << cand);
 			const int nores_runs = !(coded_runs && ((no_nores_mask >> cand) & 1u));
 			if (!nores_runs || prev_nores_ran) {
-				if (nores_runs) {
-					nd.inter_cbf[0] = nd.inter_cbf[1] = nd.inter_cbf[2] = 0;
-					nd.inter_tr_idx = 0;
-					nd.sum = 0;
-				}
+				if (nores_runs) { nd_cbf = 0; nd_sum = 0; }
 				prev_nores_ran = nores_runs;
 				continue;
 			}
 		}
 		prev_nores_ran = 0;
-		const QuadRes &qr = qs.res[slot];
+#pragma unroll
 		for (int no_res = 0; no_res < 2; no_res++) {
 			if (no_res == 1 && ((no_nores_mask >> cand) & 1u)) continue;
 			if (best_is_skip && no_res == 0) continue;
 			if (no_res == 1) prev_nores_ran = 1;
 			if (!mc_done) { last_pred = slot; mc_done = 1; }
 			if (no_res == 0) {
-				// encode_inter: the node's fields, the windows and buffers of the CU's depth (deferred: wnd), the squared residuals
-				nd.inter_cbf[0] = (int32_t)qr.cbf[0];
-				nd.inter_cbf[1] = (int32_t)qr.cbf[1];
-				nd.inter_cbf[2] = (int32_t)qr.cbf[2];
-				nd.inter_tr_idx = 0;
-				dist = qr.dist[0] + qr.dist[1] + qr.dist[2];
-				nd.distortion = dist;
-				nd.cost = dist;
-				nd.sum = (uint32_t)(qr.sum[0] + qr.sum[1] + qr.sum[2]);
-				e.inter_ssq[0] = qr.raw[0]; e.inter_ssq[1] = qr.raw[1]; e.inter_ssq[2] = qr.raw[2];
-				e.inter_ssq_valid = 1;
-				wnd_slot = slot; wnd_kind = 1; coded_any = 1;
-				cost = dist;
-				cost = (uint32_t)((double)cost + cost_rd(e.f->avg_dist, nd.sum));
+				// encode_inter: the node's fields, the windows and buffers of the CU's depth (deferred: wnd), the squared residuals (coded_slot)
+				nd_cbf = of_slot(s_cbf, slot);
+				nd_sum = of_slot(s_sum, slot);
+				dist = of_slot(s_dist, slot);
+				wnd_slot = slot; wnd_kind = 1; coded_slot = slot;
+				cost = of_slot(s_cost, slot);
 			} else {
-				dist = qr.raw[0];
-				dist += (uint32_t)(weight * qr.raw[1]);
-				dist += (uint32_t)(weight * qr.raw[2]);
-				nd.inter_cbf[0] = nd.inter_cbf[1] = nd.inter_cbf[2] = 0;
-				nd.inter_tr_idx = 0;
-				nd.sum = 0;
+				dist = of_slot(s_nores, slot);
+				nd_cbf = 0;
+				nd_sum = 0;
 				cost = dist;
 			}
 			if (cost < best_cost) {
-				best_mv = w.merge_cands.mv[cand];
-				best_ref_idx = w.merge_cands.ref_idx[cand];
+				best_x = mc.x[cand]; best_y = mc.y[cand];
+				best_ref_idx = mc.ref[cand];
 				best_candidate = cand;
 				best_dist = dist;
 				best_cost = cost;
-				best_sum = nd.sum;
+				best_sum = nd_sum;
 				if (no_res == 1) { wnd_slot = slot; wnd_kind = 2; }      // the prediction is the reconstruction, the levels are zero
 				cons_slot = wnd_slot; cons_kind = wnd_kind;               // put_consolidated_info
-				ctu_cbf = wnd_kind == 1 ? (qs.res[wnd_slot].cbf[0] | qs.res[wnd_slot].cbf[1] | qs.res[wnd_slot].cbf[2]) : 0u;
+				const uint32_t cb = wnd_kind == 1 ? of_slot(s_cbf, wnd_slot) : 0u;
+				ctu_cbf = (cb | (cb >> 1) | (cb >> 2)) & 1u;               // cbf[0] | cbf[1] | cbf[2] of the per-depth buffers (each 0 or 1)
 				have_ctu_cbf = 1;
 				best_is_skip = (ctu_cbf & 1) == 0;
 			}
@@ -478,9 +527,22 @@ __device__ __forceinline__ uint32_t quad_merge_loop(const WaveGrp g, Enc &__rest
 			}
 		}
 	}
-	quad_commit(g, e, ni, curr_depth, cons_slot, cons_kind, wnd_slot, wnd_kind, last_pred, coded_any);
+	HENC_QPROF_MARK(e, 5);      // (the candidate loop)
+	// what the evaluations left in the node and the context, then the windows, buffers and the record
+	nd.inter_cbf[0] = (int32_t)(nd_cbf & 1u);
+	nd.inter_cbf[1] = (int32_t)((nd_cbf >> 1) & 1u);
+	nd.inter_cbf[2] = (int32_t)((nd_cbf >> 2) & 1u);
+	nd.inter_tr_idx = 0;
+	if (coded_slot >= 0) {
+		const QuadRes &lr = qs.res[coded_slot];
+		e.inter_ssq[0] = lr.raw[0]; e.inter_ssq[1] = lr.raw[1]; e.inter_ssq[2] = lr.raw[2];
+		e.inter_ssq_valid = 1;
+	}
+	quad_commit(g, e, ni, curr_depth, cons_slot, cons_kind, wnd_slot, wnd_kind, last_pred, coded_slot >= 0);
+	HENC_QPROF_MARK(e, 6);      // (the commit)
 	nd.skipped = best_is_skip;
-	nd.inter_mv = best_mv;
+	nd.inter_mv.x = best_x;
+	nd.inter_mv.y = best_y;
 	nd.inter_ref_index = best_ref_idx;
 	nd.cost = nd.distortion = best_dist;
 	nd.merge_flag = 1;
