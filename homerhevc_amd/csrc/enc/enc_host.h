@@ -55,10 +55,10 @@ inline bool make_seq(HostCfg cfg, Seq &s, const char **why)
 	if (cfg.bitrate_mode < 0 || cfg.bitrate_mode > 2) { *why = "bitrate_mode"; return false; }
 	if (cfg.bitrate_mode != 0 && cfg.num_enc_engines > 1) { *why = "rate control with num_enc_engines > 1"; return false; }
 	if (cfg.bitrate_mode != 0 && (cfg.bitrate <= 0 || cfg.vbv_size <= 0 || cfg.frame_rate <= 0)) { *why = "rate control needs bitrate, vbv_size and frame_rate"; return false; }
-	// RD_FULL: the bit estimates copy the real coder's contexts as the synchronous wavefront leaves them (enc_rdo.h, enc_rc.h RdCtxSim) - one thread per CTU row,
-	// one engine, fixed QP
-	if (cfg.rd_mode == RDM_FULL && (cfg.wfpp_num_threads < 2 || cfg.num_enc_engines > 1 || cfg.bitrate_mode != 0)) {
-		*why = "rd_mode RD_FULL needs wfpp_num_threads > 1, one engine and fixed QP";
+	// RD_FULL: the bit estimates copy the real coder's contexts as the schedule leaves them (enc_rdo.h, enc_rc.h RdCtxSim: the synchronous wavefront, or one thread in
+	// raster order) - one engine, fixed QP
+	if (cfg.rd_mode == RDM_FULL && (cfg.num_enc_engines > 1 || cfg.bitrate_mode != 0)) {
+		*why = "rd_mode RD_FULL needs one engine and fixed QP";
 		return false;
 	}
 	s.max_cu_size = 64;

@@ -149,7 +149,10 @@ HENC_INLINE T *uni_ptr(T *p)
 template <class T>
 HENC_INLINE T *in_fast_memory(T *p)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(HENC_CHECK_ADDRSPACE)
+	if (p && !__builtin_amdgcn_is_shared((const void *)p)) __builtin_trap();
+	return p;
+#elif defined(__HIP_DEVICE_COMPILE__)
 	__builtin_assume(__builtin_amdgcn_is_shared((const void *)p));
 	return p;
 #else
@@ -159,7 +162,11 @@ HENC_INLINE T *in_fast_memory(T *p)
 // The worker's context (Enc, enc_common.h) is ONE object per wavefront at a fixed place in LDS; it reaches the functions of the walk as a reference, which the compiler
 // can only take for a generic pointer (flat_* accesses, and - when the object was a local of the kernel - private memory behind it).  Every function that gets it says
 // where it is: its members then are ds_* accesses at an address the lanes share.
-#if defined(__HIP_DEVICE_COMPILE__)
+// -DHENC_CHECK_ADDRSPACE (a debug build, tools/build_variant.sh): the promises become checks - a pointer that is not in LDS traps instead of being read through
+// ds_* instructions at a wrong address (the GPU stream tests run once on such a build per round: profiles/r06_history.md)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(HENC_CHECK_ADDRSPACE)
+#define HENC_ENC_IN_LDS(e) do { if (!__builtin_amdgcn_is_shared((const void *)&(e))) __builtin_trap(); } while (0)
+#elif defined(__HIP_DEVICE_COMPILE__)
 #define HENC_ENC_IN_LDS(e) __builtin_assume(__builtin_amdgcn_is_shared((const void *)&(e)))
 #else
 #define HENC_ENC_IN_LDS(e) do { } while (0)
@@ -167,7 +174,9 @@ HENC_INLINE T *in_fast_memory(T *p)
 // The operands of the TU primitives (source / prediction windows, coefficient, level and remainder buffers of the TU in flight) are in the worker's LDS wherever the
 // encoder kernel calls them; the primitives are functions of their own with generic pointer parameters, i.e. flat_* accesses that wait for LDS and memory together.
 // k_encode.hip defines HENC_TU_OPERANDS_IN_LDS and the primitives say so per operand; the test harness (k_primtest.hip: operands in HBM) does not.
-#if defined(__HIP_DEVICE_COMPILE__) && defined(HENC_TU_OPERANDS_IN_LDS)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(HENC_TU_OPERANDS_IN_LDS) && defined(HENC_CHECK_ADDRSPACE)
+#define HENC_OP_IN_LDS(p) do { if (!__builtin_amdgcn_is_shared((const void *)(p))) __builtin_trap(); } while (0)
+#elif defined(__HIP_DEVICE_COMPILE__) && defined(HENC_TU_OPERANDS_IN_LDS)
 #define HENC_OP_IN_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void *)(p)))
 #else
 #define HENC_OP_IN_LDS(p) do { } while (0)

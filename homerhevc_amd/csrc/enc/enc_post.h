@@ -808,6 +808,7 @@ HENC_HDX int post_drain(const G g, const PostCtx &x, PostScratch &sc)
 		else if (pick_kind == 3) subpel_task_ctu(g.tid, *(SubpelScratch *)&sc, S, P.fin, P.planes[0], P.planes[1], P.planes[2], pick_c, pick_r);
 #endif
 		else post_task_d(g, x, pick_r, pick_c);
+		g.sync();      // (every lane's stores of the task before the fence: on a wavefront the fence is wave-wide, a group of another width has to say so)
 		post_release();
 		if (g.tid == 0) post_st_fenced(done, pick_c + 1);
 		g.sync();

@@ -216,8 +216,9 @@ struct RdCtxSim {
 		for (int i = 0; i < 2 * T; i++) slot[i] = i;
 		for (int i = 0; i < T; i++) thread_ee[i] = 2 * i;
 	}
-	// src[n]: what CTU n's decisions copy in frame f
-	void frame(int f, std::vector<RdCtxVersion> &src)
+	// src[n]: what CTU n's decisions copy in frame f.  raster: one thread in raster order (wfpp_num_threads = 1: T = 1) - a CTU's decisions see what the sections
+	// behind all the CTUs before it have left; else the synchronous wavefront.
+	void frame(int f, std::vector<RdCtxVersion> &src, bool raster = false)
 	{
 		const int total = W * H, num_ee = 2 * T, last = W + 2 * (H - 1);
 		src.assign(total, RdCtxVersion{-1, 0, 0});
@@ -234,6 +235,32 @@ struct RdCtxSim {
 			obj[thread_ee[th]] = RdCtxVersion{f, R, x + 1};
 			if (x == 1 && R + 1 != H) obj[slot[(2 * idx + 1) % num_ee]] = RdCtxVersion{f, R, 2};
 		};
+		// the entropy coding calls of the section behind CTU n = (r, c) (hmr_deblock_sao_pad_sync_ctu; the same lag arithmetic as rc_coded_by)
+		auto section = [&](int r, int c) {
+			const int n = r * W + c, th = r % T, idx = c;
+			if (!sao) { code(th, n); return; }
+			const int v = n - (W + 1), vi = v % W, h = v - 1;
+			int s = h - (W + 1);
+			if (v >= 0 && idx >= 1 && h >= 0 && idx >= 2 && s >= 0 && idx >= 3) code(th, s);
+			if ((vi + 1) == W - 1 && (n + 1) != total) {
+				int max_filter = ((v / W) + 1) * W;
+				if (s > 0) {
+					max_filter -= W;
+					for (int a = s + 1; a < max_filter; a++) code(th, a);
+				}
+			}
+			if ((n + 1) == total) {
+				if (s < 0) s = -1;
+				for (int a = s + 1; a < total; a++) code(th, a);
+			}
+		};
+		if (raster) {
+			for (int n = 0; n < total; n++) {
+				src[n] = obj[thread_ee[(n / W) % T]];
+				section(n / W, n % W);
+			}
+			return;
+		}
 		for (int t = 0; t < last; t++) {
 			for (int r = 0; r < H; r++) {
 				const int c = t - 2 * r;
@@ -242,23 +269,7 @@ struct RdCtxSim {
 			for (int r = 0; r < H; r++) {
 				const int c = t - 2 * r;
 				if (c < 0 || c >= W) continue;
-				// the entropy coding calls of the section behind CTU n (hmr_deblock_sao_pad_sync_ctu; the same lag arithmetic as rc_coded_by)
-				const int n = r * W + c, th = r % T, idx = c;
-				if (!sao) { code(th, n); continue; }
-				const int v = n - (W + 1), vi = v % W, h = v - 1;
-				int s = h - (W + 1);
-				if (v >= 0 && idx >= 1 && h >= 0 && idx >= 2 && s >= 0 && idx >= 3) code(th, s);
-				if ((vi + 1) == W - 1 && (n + 1) != total) {
-					int max_filter = ((v / W) + 1) * W;
-					if (s > 0) {
-						max_filter -= W;
-						for (int a = s + 1; a < max_filter; a++) code(th, a);
-					}
-				}
-				if ((n + 1) == total) {
-					if (s < 0) s = -1;
-					for (int a = s + 1; a < total; a++) code(th, a);
-				}
+				section(r, c);
 			}
 		}
 	}

@@ -62,7 +62,8 @@ struct EncDev {
 	int *counters;                // [0] CTUs found wrong by the last check, [1] CTU encodes of the frame, [2] the CTU at which a scene change is detected (-1: none)
 	int threads;                  // lockstep schedule: wfpp_num_threads (row r is encoded by thread r % threads)
 	int dep, dep_full;            // overlapping frames of a sequence (hmr_gpu_enc_encode_chain): the picture of this launch whose final picture this one predicts from, or -1
-	int after, pad_after_;        // ... the picture of this launch that the same engine encodes before this one (it has to be finished: the engine's persistent state), or -1
+	int after, raster;            // raster = 1: ONE thread in raster order (wfpp_num_threads = 1 under rate control / RD_FULL: a step is one CTU, t = its number) instead of the synchronous wavefront;
+	                              // ... the picture of this launch that the same engine encodes before this one (it has to be finished: the engine's persistent state), or -1
 	FrameCtx *next_frame;         // ... the frame parameters of the picture the same engine encodes next in this launch (it starts from this picture's average distortion), or nullptr
 	double *fin;                  // [0] the picture's distortion total (frame_acc_dist, enc_host.h), written by the worker that completes the picture's last task
 	RcFrame *rc_dyn;              // rate control: the frame's parameters after a scene change moved them (hmr_rc_change_pic_mode), [0]; valid once counters[2] >= 0
@@ -437,11 +438,12 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 	HENC_ENC_IN_LDS(e);
 	const Seq &S = *lseq;
 	const int W = S.wctu, H = S.hctu;
-	const int T = d.threads, me = row % T, c = t - 2 * row, n = row * W + c;
+	const int raster = d.raster;
+	const int T = d.threads, me = row % T, c = raster ? t - row * W : t - 2 * row, n = row * W + c;
 	// counters as of the end of step t - 1
 	uint32_t ti = 0, tc = 0;
 	for (int r2 = g.tid; r2 < H; r2 += 64) {
-		const int have = t - 2 * r2 < 0 ? 0 : (t - 2 * r2 < W ? t - 2 * r2 : W);
+		const int have = raster ? (r2 < row ? W : (r2 == row ? c : 0)) : (t - 2 * r2 < 0 ? 0 : (t - 2 * r2 < W ? t - 2 * r2 : W));      // (raster order: as of CTU n - 1)
 		ti += d.prefix[(size_t)r2 * (W + 1) + have];
 		tc += (uint32_t)have;
 	}
@@ -463,7 +465,7 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 		cached_rem[0] = rem_y; cached_rem[1] = rem_c;
 	}
 	g.sync();
-	const int hrow = t / (2 * T) * T;   // thread 0's row that is inside the picture at this step, if any
+	const int hrow = raster ? row : t / (2 * T) * T;   // thread 0's row that is inside the picture at this step, if any
 	// rate control: the bits and the number of the CTUs the reference has entropy coded when this step starts
 	uint32_t rc_bits = 0;
 	int rc_ctus = 0;
@@ -497,7 +499,7 @@ __device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const Wave
 		// hmr_rc_calc_cu_qp at the CTU's root.  is_scene_change: set by the detecting CTU before its own walk (hmr_motion_inter.c:3795-3796) and seen by everything
 		// from its step on; the picture target it moved comes from d.rc_dyn
 		const int cut = lframe->scene_cut_ctu;
-		const int is_sc = cut >= 0 && t >= cut % W + 2 * (cut / W);
+		const int is_sc = cut >= 0 && (raster ? n >= cut : t >= cut % W + 2 * (cut / W));
 		if (is_sc) {
 			wave_copy_words(&lframe->rc, d.rc_dyn, (int)sizeof(RcFrame), g.tid);
 			g.sync();
@@ -647,13 +649,16 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HEN
 			if (cand >= 0) {
 				const int *st = state + (size_t)cand * POOL_STRIDE;
 				const EncDev &dd = devs[cand];
-				const int W = dd.seq->wctu, H = dd.seq->hctu, steps = W + 2 * (H - 1);
+				const int W = dd.seq->wctu, H = dd.seq->hctu, steps = dd.raster ? W * H : W + 2 * (H - 1);
 				ct = __hip_atomic_load(&st[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				if (ct < steps) {
 					all_finished = false;
-					int r_lo, r_hi;
-					pool_step_rows(ct, W, H, &r_lo, &r_hi);
-					open = __hip_atomic_load(&st[1 + ct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < r_hi - r_lo + 1;
+					if (dd.raster) open = __hip_atomic_load(&st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ct;      // (a step is one CTU: st[1] = CTUs handed out)
+					else {
+						int r_lo, r_hi;
+						pool_step_rows(ct, W, H, &r_lo, &r_hi);
+						open = __hip_atomic_load(&st[1 + ct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < r_hi - r_lo + 1;
+					}
 				}
 			}
 			if (g.any(!all_finished)) all_finished = false;
@@ -690,9 +695,16 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HEN
 				const int lane = __builtin_ctzll(m);
 				const int qq = __builtin_amdgcn_readlane(cand, lane), tt = __builtin_amdgcn_readlane(ct, lane);
 				int kk = 0;
+				const EncDev &dd = devs[qq];
+				if (dd.raster) {
+					if (g.tid == 0) kk = atomicCAS(&state[(size_t)qq * POOL_STRIDE + 1], tt, tt + 1) == tt ? 0 : 1;
+					kk = __builtin_amdgcn_readfirstlane(kk);
+					if (kk == 0) { q = qq; t = tt; k = 0; }
+					else base -= 64;
+					continue;
+				}
 				if (g.tid == 0) kk = atomicAdd(&state[(size_t)qq * POOL_STRIDE + 1 + tt], 1);
 				kk = __builtin_amdgcn_readfirstlane(kk);
-				const EncDev &dd = devs[qq];
 				int r_lo, r_hi;
 				pool_step_rows(tt, dd.seq->wctu, dd.seq->hctu, &r_lo, &r_hi);
 				if (kk < r_hi - r_lo + 1) { q = qq; t = tt; k = kk; }
@@ -740,14 +752,15 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HEN
 		const int hrow = t / (2 * d.threads) * d.threads;
 		const bool hvalid = hrow >= r_lo && hrow <= r_hi;
 		int row;
-		if (hvalid) row = k == 0 ? hrow : (r_lo + k - 1 < hrow ? r_lo + k - 1 : r_lo + k);
+		if (d.raster) row = t / W;
+		else if (hvalid) row = k == 0 ? hrow : (r_lo + k - 1 < hrow ? r_lo + k - 1 : r_lo + k);
 		else row = r_lo + k;
 		pool_encode_ctu(d, e, g, lseq, lframe, lft, t, row, cached_rem, finished + 1);
 		// close the step when this was its last CTU (the CTU's results were published by the release fence at the end of pool_encode_ctu)
 		if (g.tid == 0) {
 			int *st = state + (size_t)q * POOL_STRIDE;
-			const int dn = atomicAdd(&st[1 + POOL_MAX_STEPS + t], 1) + 1;
-			if (dn == r_hi - r_lo + 1) {
+			const int dn = d.raster ? 1 : atomicAdd(&st[1 + POOL_MAX_STEPS + t], 1) + 1;
+			if (dn == (d.raster ? 1 : r_hi - r_lo + 1)) {
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (the other finishers' results happen before the step is declared closed)
 				__hip_atomic_store(&st[0], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 			}

@@ -141,7 +141,7 @@ void post_begin_frame(Cpu &c)
 		const int slot = c.f.num_encoded_frames % RD_RING;
 		c.ctx_after[slot].assign((size_t)s.nctu * RD_CTX_BYTES, 0);
 		P.ctx_after = c.ctx_after[slot].data();
-		c.rdsim.frame(c.f.num_encoded_frames, c.rdsrc);
+		c.rdsim.frame(c.f.num_encoded_frames, c.rdsrc, c.sched != 2);      // (one thread: raster order)
 		for (int i = 0; i < CTX_TOTAL; i++) c.init_ctx[slot][i] = Cabac::init_state(c.f.slice_type, c.f.qp, i);
 	}
 }
@@ -682,6 +682,7 @@ int henc_cpu_frame_ctus(void *h, const uint8_t *y, const uint8_t *u, const uint8
 			rc_scene_change(c, n);
 		}
 		e.ctu_qp = ctu_qp_for(c, n, c.f.scene_cut_ctu >= 0 && n >= c.f.scene_cut_ctu);
+		e.rd_ctx = rd_ctx_for(c, n);
 		memcpy(c.w->mode_in, c.w->intra_mode_buffs, MODE_STATE_BYTES);   // one worker in raster order: what the buffers hold IS the inherited state
 		if (getenv("HENC_WIPE_NODES")) memset(c.ctus[n].nodes, atoi(getenv("HENC_WIPE_NODES")), sizeof c.ctus[n].nodes);
 		if (getenv("HENC_WIPE_PUBLIC")) memset((CtuPublic *)&c.ctus[n], atoi(getenv("HENC_WIPE_PUBLIC")), offsetof(CtuPublic, sao_recon));

@@ -41,9 +41,9 @@ CASES = {
     # BASELINE.json configs[2]: 2160p IPPP, CBR 20000 kbps, performance_mode 1
     "cfg3-2160p-cbr": (3840, 2160, 10, {"wpp": 32, "bitrate_mode": 1, "bitrate": 20000, "perf": 1}),
     "cfg3-1080p-cbr": (1920, 1080, 24, {"wpp": 17, "bitrate_mode": 1, "bitrate": 5000, "perf": 1}),
-    # BASELINE.json configs[4]: 2160p all-intra, rd = 1 (full RDO), max_intra_tr_depth = 4, SAO on
-    "cfg5-2160p-intra-rdfull": (3840, 2160, 8, {"wpp": 32, "force_intra": 1, "rd": 1, "intra_tr": 4}),
-    "cfg5-1080p-intra-rdfull": (1920, 1080, 12, {"wpp": 17, "force_intra": 1, "rd": 1, "intra_tr": 4}),
+    # BASELINE.json configs[4] as BASELINE.md realises it: 2160p all-intra, rd = 1 (full RDO), performance_mode 0, max_intra_tr_depth = 4, SAO on
+    "cfg5-2160p-intra-rdfull": (3840, 2160, 8, {"wpp": 32, "force_intra": 1, "rd": 1, "intra_tr": 4, "perf": 0}),
+    "cfg5-1080p-intra-rdfull": (1920, 1080, 12, {"wpp": 17, "force_intra": 1, "rd": 1, "intra_tr": 4, "perf": 0}),
 }
 # bench.py's batch encodes eight DIFFERENT clips side by side (tools/gen_yuv.py: seed 1234 is the published clip, the others differ in texture, pan, pattern and box path)
 CLIP_SEEDS = [1234, 1, 2, 3, 4, 5, 6, 7]

@@ -71,6 +71,14 @@ CASES = [
     # rate control (hmr_rate_control.c): the QP of a CTU follows the bits of the CTUs entropy coded so far - in the single-thread order, and in the synchronous
     # wavefront (the turnstile serialises the threads' post-decision sections, so every CTU of a step sees the bits as of the end of the step before)
     ("416x240_cbr400_perf1", 416, 240, 8, {"bitrate_mode": 1, "bitrate": 400, "perf": 1}),
+    # ... and the bit estimates of RD_FULL, rate control at 2160p, the all-intra RD_FULL encode of BASELINE.json configs[4] as BASELINE.md states it (performance_mode 0):
+    # the reference's deterministic single-thread mode itself (ref_lockstep, no turnstile) - on the device one CTU at a time, the pool's raster schedule
+    ("416x240_force_intra_rdfull_tr4", 416, 240, 3, {"force_intra": 1, "rd": 1, "intra_tr": 4}),
+    ("416x240_rdfull", 416, 240, 4, {"rd": 1}),
+    ("328x264_force_intra_rdfull_tr3_perf0", 328, 264, 2, {"force_intra": 1, "rd": 1, "intra_tr": 3, "perf": 0}),
+    ("416x240_vbr400", 416, 240, 6, {"bitrate_mode": 2, "bitrate": 400}),
+    ("3840x2160_cbr20000_perf1", 3840, 2160, 2, {"bitrate_mode": 1, "bitrate": 20000, "perf": 1}),
+    ("3840x2160_force_intra_rdfull_tr4_perf0", 3840, 2160, 1, {"force_intra": 1, "rd": 1, "intra_tr": 4, "perf": 0}),
     ("416x240_cbr400_perf1_wpp_rows", 416, 240, 8, {"bitrate_mode": 1, "bitrate": 400, "perf": 1, "wpp": 4}),
     ("416x240_vbr400_wpp_rows", 416, 240, 8, {"bitrate_mode": 2, "bitrate": 400, "wpp": 4}),
     ("832x480_cbr1500_perf1_wpp_rows", 832, 480, 6, {"bitrate_mode": 1, "bitrate": 1500, "perf": 1, "wpp": 8}),

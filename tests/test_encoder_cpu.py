@@ -56,7 +56,7 @@ def test_core_matches_reference_fixture(cpu, name):
 
 
 def test_unsupported_configurations_are_refused(cpu):
-    for kw in ({"rd": 1}, {"rd": 1, "wpp": 4, "bitrate_mode": 1, "bitrate": 400}, {"bitrate_mode": 3},      # (RD_FULL: one thread per CTU row, fixed QP)
+    for kw in ({"rd": 1, "wpp": 4, "bitrate_mode": 1, "bitrate": 400}, {"rd": 1, "bitrate_mode": 1, "bitrate": 400}, {"bitrate_mode": 3},      # (RD_FULL: fixed QP; with one thread or a thread per row since round 6)
                {"bitrate_mode": 1, "bitrate": 400, "engines": 2, "wpp": 4}, {"num_b": 1, "gop_size": 2}, {"cu_size": 32},      # (performance_mode 3 is accepted since round 5)
                {"wpp": 2},      # 7 CTU columns: two threads would have to be in rows 0 and 2 at once under the synchronous wavefront
                {"wpp": 5}):     # more threads than the 4 CTU rows
@@ -72,7 +72,7 @@ def test_unsupported_configurations_are_refused(cpu):
         cfg = ec.default_cfg(*size, **kw)
         assert not cpu.henc_cpu_create(C.byref(cfg)), (size, kw)
     for size, kw in (((128, 64), {}), ((576, 384), {"engines": 2}), ((512, 256), {"engines": 4}),
-                     ((416, 240), {"wpp": 4}), ((328, 264), {"wpp": 3}), ((320, 320), {"sao": 0}), ((416, 240), {"bitrate_mode": 1, "bitrate": 400}), ((416, 240), {"bitrate_mode": 2, "bitrate": 400, "wpp": 4}), ((416, 240), {"rd": 1, "wpp": 4, "intra_tr": 4})):
+                     ((416, 240), {"wpp": 4}), ((328, 264), {"wpp": 3}), ((320, 320), {"sao": 0}), ((416, 240), {"bitrate_mode": 1, "bitrate": 400}), ((416, 240), {"bitrate_mode": 2, "bitrate": 400, "wpp": 4}), ((416, 240), {"rd": 1, "wpp": 4, "intra_tr": 4}), ((416, 240), {"rd": 1}), ((416, 240), {"rd": 1, "intra_tr": 4, "perf": 0})):
         cfg = ec.default_cfg(*size, **kw)
         assert cpu.henc_cpu_create(C.byref(cfg)), (size, kw)
 

@@ -63,6 +63,6 @@ def test_ctu_encoder_matches_reference_fixture(gpu, name):
 
 
 def test_unsupported_configuration_is_refused(gpu):
-    cfg = ec.default_cfg(416, 240, rd=1)
+    cfg = ec.default_cfg(416, 240, rd=1, bitrate_mode=1, bitrate=400)      # (RD_FULL under rate control)
     enc = C.c_void_p()
     assert gpu.hmr_gpu_enc_create(gpu._ctx, C.byref(cfg), C.byref(enc)) == -3
