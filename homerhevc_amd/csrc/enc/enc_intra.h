@@ -305,6 +305,14 @@ HENC_WALK_FN HENC_HD uint32_t encode_intra_luma(const G g, Enc &__restrict__ e, 
 
 	DepthState depth_state;
 	depth_state.set(curr_depth, initial_state);
+	// The four TUs of a split at the tree's last level are compared with their parent only as sums (distortion and level sum, below), and both only grow from child
+	// to child: once the children evaluated so far cannot beat the parent any more the rest of them cannot change the decision.  The reference evaluates them anyway;
+	// what that leaves behind - their nodes' fields, the inside of the deeper window - is overwritten before anything reads it (the losing branch below restores the
+	// window's border from the parent).  Not with RD_FULL: its bit estimates have side effects of their own (enc_rdo.h).
+	const bool split_early_out = !rd_full;
+	double split_cost = 0;
+	uint32_t split_sum = 0;
+	bool split_lost = false;
 	while (curr_depth != depth || depth_state.get(curr_depth) != end_state) {
 		curr = parent < 0 ? curr : e.geo[parent].child[depth_state.get(curr_depth)];
 		if (e.geo[curr].depth >= 1) nodes_select_quad(g, e, e.geo[curr].abs_index >> 6);      // (the transform tree of the 64 x 64 CU goes through all four quadrants)
@@ -315,6 +323,18 @@ HENC_WALK_FN HENC_HD uint32_t encode_intra_luma(const G g, Enc &__restrict__ e, 
 		cn.distortion = encode_intra_tu(g, e, curr, depth, cu_mode, part_size_type, &curr_sum);
 		cn.sum = (uint32_t)curr_sum;
 		cn.cost = cn.distortion;
+		if (split_early_out && curr_depth == max_tr_processing_depth && curr_depth > depth && parent >= 0 && e.geo[parent].depth == curr_depth - 1) {
+			if (depth_state.get(curr_depth) == 0) { split_cost = 0; split_sum = 0; }
+			split_cost += (double)cn.distortion;
+			split_sum += cn.sum;
+			const Node &spn = node_of(e, parent);
+			const bool lost = S.rd_mode != RDM_FAST ? !(split_cost < (double)spn.cost)
+								  : !(1.25 * (split_cost + (double)(uint32_t)(45u * split_sum)) < (double)(uint32_t)(spn.cost + 45u * spn.sum));
+			if (lost && depth_state.get(curr_depth) < 3) {
+				split_lost = true;
+				depth_state.set(curr_depth, 3);      // (the increment below makes it 4: the split is closed)
+			}
+		}
 		if (rd_full && (curr_depth < max_tr_processing_depth || curr_depth == depth)) {      // :1457: the node's syntax priced by the bit counter
 			RdViews &rv = rd_views_of(e);
 			e.rd_luma_depth = curr_depth;
@@ -344,6 +364,7 @@ HENC_WALK_FN HENC_HD uint32_t encode_intra_luma(const G g, Enc &__restrict__ e, 
 				bool take_children;
 				if (S.rd_mode != RDM_FAST) take_children = cost < pn.cost;
 				else take_children = 1.25 * (cost + (double)(uint32_t)(45u * sum)) < (double)(uint32_t)(pn.cost + 45u * pn.sum);
+				if (split_lost) { take_children = false; split_lost = false; }      // (decided above on the children evaluated: the others' fields are not theirs)
 				if (take_children) {
 					pn.cost = (uint32_t)cost;
 					pn.distortion = (uint32_t)distortion;

@@ -1,8 +1,10 @@
-// GPU box tool: cycles per call of the CTU encoder's block primitives as ONE wavefront sees them (the situation inside k_encode_ctus):
-// operands in LDS or in global memory, calls back to back.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off
-// -I homerhevc_amd/csrc tools/ubench/prim_ubench.hip homerhevc_amd/csrc/tables.cpp -o tools/ubench/prim_ubench
+// GPU box tool: cycles per call of the CTU walk's block primitives as ONE wavefront sees them alone on its CU (no timers inside the loop: the profiling build's
+// per-call timers cost several hundred cycles each and inflate exactly the small calls).  Operands in LDS as in k_encode_pool (HENC_TU_OPERANDS_IN_LDS), windows in
+// global memory, tables from DevTables through L2, calls back to back - what a call costs when nothing else hides its latency.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I homerhevc_amd/csrc tools/ubench/prim_ubench.hip homerhevc_amd/csrc/tables.cpp -o tools/ubench/prim_ubench
 #include <stdio.h>
 #include <vector>
+#define HENC_TU_OPERANDS_IN_LDS 1
 #include "common.h"
 #include "enc/enc_prims.h"
 
@@ -10,8 +12,8 @@ using namespace henc;
 
 struct Args {
 	const DevTables *T;
-	int16_t *ga, *gb, *gc;      // global scratch planes (64 x 64 each, stride 64) and a "reference picture" (gc, stride 2080)
-	unsigned long long *out;    // [case] cycles for `reps` calls
+	int16_t *ga, *gb;           // global windows (a decoded window with its margin, a level window)
+	unsigned long long *out;    // [case] ticks for `reps` calls
 	uint32_t *sink;
 	int reps;
 };
@@ -26,50 +28,41 @@ struct Args {
 		if (threadIdx.x == 0) a.out[idx] = t1 - t0;                 \
 	} while (0)
 
-__global__ __launch_bounds__(64) void k_ubench(Args a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_ubench(Args a)
 {
 	extern __shared__ __align__(16) uint8_t lds[];
-	int16_t *la = (int16_t *)lds, *lb = la + 4096, *lc = lb + 4096, *ld = lc + 4096;
+	uint8_t *orig = lds, *pred = lds + 4096;                         // 64 x 64 bytes each
+	int16_t *coef = (int16_t *)(lds + 8192), *du = coef + 1024, *lv = du + 1024, *adi = lv + 1024, *adif = adi + 264, *rd = adif + 264;
 	WaveGrp g{(int)threadIdx.x};
-	for (int i = g.tid; i < 4096; i += 64) { la[i] = (int16_t)((i * 7) & 255); lb[i] = (int16_t)((i * 13) & 255); lc[i] = 0; ld[i] = 0; }
+	for (int i = g.tid; i < 4096; i += 64) { pred[i] = (uint8_t)(100 + ((i * 7) & 31)); orig[i] = (uint8_t)(pred[i] + ((i * 13) % 41) - 20); }
+	for (int i = g.tid; i < 264; i += 64) { adi[i] = (int16_t)(90 + (i & 31)); adif[i] = adi[i]; }
 	__syncthreads();
 	uint32_t acc = 0;
-	int n;
-	// 0-3: SAD LDS/LDS n = 8,16,32,64
-	n = 8;  CASE(0, acc += blk_sad(g, la, 64, lb, 64, n));
-	n = 16; CASE(1, acc += blk_sad(g, la, 64, lb, 64, n));
-	n = 32; CASE(2, acc += blk_sad(g, la, 64, lb, 64, n));
-	n = 64; CASE(3, acc += blk_sad(g, la, 64, lb, 64, n));
-	// 4-5: SAD LDS vs global reference (the motion search)
-	n = 8;  CASE(4, acc += blk_sad(g, la, 64, a.gc + (r & 63) * 2080 + (r & 31), 2080, n));
-	n = 16; CASE(5, acc += blk_sad(g, la, 64, a.gc + (r & 63) * 2080 + (r & 31), 2080, n));
-	// 6-9: forward transform 4, 8, 16, 32 (LDS)
-	n = 4;  CASE(6, tr_forward(g, a.T, la, 64, lc, ld, n, 0));
-	n = 8;  CASE(7, tr_forward(g, a.T, la, 64, lc, ld, n, 0));
-	n = 16; CASE(8, tr_forward(g, a.T, la, 64, lc, ld, n, 0));
-	n = 32; CASE(9, tr_forward(g, a.T, la, 64, lc, ld, n, 0));
-	// 10-11: quantize 8, 32 (LDS in, global out like the tq windows)
-	n = 8;  CASE(10, acc += quantize(g, a.T, lc, a.ga, ld, 3, 3, 0, 0, 0, 1, n, 5, 2));
-	n = 32; CASE(11, acc += quantize(g, a.T, lc, a.ga, ld, 3, 1, 0, 0, 0, 1, n, 5, 2));
-	// 12-13: luma interpolation stage 8x8 and 32x32 horizontal from global, vertical from LDS
-	n = 8;  CASE(12, interp_stage<8>(g, a.gc + 8 * 2080 + 8, 2080, lc, 72, 2, n, n + 7, 0, 1, 0));
-	n = 8;  CASE(13, interp_stage<8>(g, lc + 3 * 72, 72, ld, 64, 2, n, n, 1, 0, 1));
-	n = 32; CASE(14, interp_stage<8>(g, a.gc + 8 * 2080 + 8, 2080, lc, 72, 2, n, n + 7, 0, 1, 0));
-	// 15-16: intra prediction + SAD 8x8 angular / planar
-	n = 8;  CASE(15, acc += intra_predict_sad(g, lc, 64, la, 64, lb, n, 20 + (r & 7), 1));
-	n = 8;  CASE(16, acc += intra_predict_sad(g, lc, 64, la, 64, lb, n, 0, 1));
-	n = 32; CASE(17, acc += intra_predict_sad(g, lc, 64, la, 64, lb, n, 20 + (r & 7), 1));
-	// 18: predict (residual) 8x8; 19: reconst to global; 20: copy 8x8 global->global
-	n = 8;  CASE(18, blk_predict(g, la, 64, lb, 64, lc, 64, n));
-	n = 8;  CASE(19, blk_reconst(g, la, 64, lc, 64, a.ga, 144, n));
-	n = 8;  CASE(20, blk_copy(g, a.ga, 144, a.gb, 144, n, n));
-	// 21: empty sync; 22: wave sum alone
-	CASE(21, g.sync());
-	CASE(22, acc += g.sum(acc));
-	// 23: inverse transform 8; 24: dequantize 8 from global
-	n = 8;  CASE(23, tr_inverse(g, a.T, lc, 64, la, ld, n, 0));
-	n = 8;  CASE(24, dequantize(g, a.T, a.ga, lc, 3, 0, 0, n, 5, 2));
-	if (acc == 0x12345678) a.sink[0] = acc;
+	const FastTables *F = nullptr;
+	int16_t *dec = a.ga + 8 * 144 + 8;
+	int n, c = 0;
+#define SIZES(base, stmt) n = 4; CASE(base, stmt); n = 8; CASE(base + 1, stmt); n = 16; CASE(base + 2, stmt); n = 32; CASE(base + 3, stmt);
+	SIZES(0, tr_forward(g, F, a.T, orig, 64, pred, 64, coef, du, n, 0));
+	SIZES(4, acc += quantize(g, F, a.T, coef, lv, du, 3, 6 - ilog2i(n), 0, 1, 0, 1, n, 5, 2));
+	SIZES(8, dequantize(g, F, a.T, lv, coef, 6 - ilog2i(n), 0, 1, n, 5, 2));
+	SIZES(12, tr_inverse(g, F, a.T, rd, n, coef, du, n, 0));
+	SIZES(16, acc += blk_reconst_ssd(g, pred, 64, rd, n, orig, 64, dec, 144, n));
+	SIZES(20, intra_fill_refs(g, a.ga + 7 * 144 + 7, 144, n, 1, 1, 0, 1, n, n, adi));
+	SIZES(24, intra_adi_filter(g, adi, adif, n, 1));
+	SIZES(28, intra_predict(g, pred, 64, adi, n, 20 + (r & 7), 1));
+	SIZES(32, acc += intra_predict_sad(g, pred, 64, orig, 64, adi, n, 20 + (r & 7), 1));
+	SIZES(36, acc += intra_predict_sad(g, pred, 64, orig, 64, adi, n, r & 1, 1));
+	SIZES(40, acc += blk_ssd(g, orig, 64, pred, 64, n));
+	SIZES(44, lin_copy_nosync(g, lv, a.gb, n * n); g.sync());
+	SIZES(48, blk_copy(g, pred, 64, dec, 144, n, n));
+	// the whole intra TU chain as encode_intra_tu strings it together (enc_intra.h), neighbours from the global window
+	SIZES(52, intra_fill_refs(g, a.ga + 7 * 144 + 7, 144, n, 1, 1, 0, 1, n, n, adi); intra_adi_filter(g, adi, adif, n, 1); intra_predict(g, pred, 64, adif, n, 20 + (r & 7), 1);
+		  tr_forward(g, F, a.T, orig, 64, pred, 64, coef, du, n, 0); c = quantize(g, F, a.T, coef, lv, du, 3, 6 - ilog2i(n), 0, 1, 0, 1, n, 5, 2);
+		  if (c) { lin_copy_nosync(g, lv, a.gb, n * n); dequantize(g, F, a.T, lv, lv, 6 - ilog2i(n), 0, 1, n, 5, 2); tr_inverse(g, F, a.T, du, n, lv, coef, n, 0);
+			   acc += blk_reconst_ssd(g, pred, 64, du, n, orig, 64, dec, 144, n); });
+	CASE(56, g.sync());
+	CASE(57, acc += g.sum(acc));
+	if (acc == 0x12345678) a.sink[0] = acc + (uint32_t)c;
 }
 
 int main()
@@ -79,18 +72,21 @@ int main()
 	hipMalloc((void **)&T, sizeof(DevTables));
 	hipMemcpy(T, hmr_host_tables(), sizeof(DevTables), hipMemcpyHostToDevice);
 	a.T = T;
-	hipMalloc((void **)&a.ga, 144 * 144 * 2); hipMalloc((void **)&a.gb, 144 * 144 * 2); hipMalloc((void **)&a.gc, 2080 * 256 * 2);
-	hipMemset(a.ga, 1, 144 * 144 * 2); hipMemset(a.gb, 2, 144 * 144 * 2); hipMemset(a.gc, 3, 2080 * 256 * 2);
-	hipMalloc((void **)&a.out, 32 * 8); hipMalloc((void **)&a.sink, 4);
+	hipMalloc((void **)&a.ga, 144 * 144 * 2); hipMalloc((void **)&a.gb, 64 * 64 * 2);
+	hipMemset(a.ga, 1, 144 * 144 * 2); hipMemset(a.gb, 2, 64 * 64 * 2);
+	hipMalloc((void **)&a.out, 64 * 8); hipMalloc((void **)&a.sink, 4);
 	a.reps = 200;
 	hipFuncSetAttribute((const void *)k_ubench, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-	for (int it = 0; it < 2; it++) hipLaunchKernelGGL(k_ubench, dim3(1), dim3(64), 4 * 4096 * 2, 0, a);
+	for (int it = 0; it < 2; it++) hipLaunchKernelGGL(k_ubench, dim3(1), dim3(64), 20 * 1024, 0, a);
 	hipDeviceSynchronize();
-	unsigned long long out[32];
+	unsigned long long out[64];
 	hipMemcpy(out, a.out, sizeof out, hipMemcpyDeviceToHost);
-	const char *names[25] = {"sad8 lds", "sad16 lds", "sad32 lds", "sad64 lds", "sad8 lds/global", "sad16 lds/global", "tr_fwd4", "tr_fwd8", "tr_fwd16", "tr_fwd32", "quant8", "quant32",
-				 "interp8 H 8x15 global", "interp8 V 8x8 lds", "interp32 H 32x39 global", "intra_sad8 ang", "intra_sad8 planar", "intra_sad32 ang", "predict8", "reconst8 ->global",
-				 "copy8 global", "sync", "wave sum", "tr_inv8", "dequant8 global"};
-	for (int i = 0; i < 25; i++) printf("%-28s %8.0f cycles/call (s_memtime ticks)\n", names[i], (double)out[i] / a.reps);
+	const char *names[14] = {"tr_forward", "quantize (sbh)", "dequantize", "tr_inverse", "reconst_ssd -> window", "fill_refs <- window", "adi_filter", "intra_predict ang", "intra_predict_sad ang",
+				 "intra_predict_sad planar/dc", "blk_ssd", "levels -> window", "blk_copy -> window", "intra TU chain"};
+	printf("%-30s %9s %9s %9s %9s   (s_memtime ticks per call, one wavefront alone)\n", "primitive", "4x4", "8x8", "16x16", "32x32");
+	for (int i = 0; i < 14; i++) printf("%-30s %9.0f %9.0f %9.0f %9.0f\n", names[i], (double)out[4 * i] / a.reps, (double)out[4 * i + 1] / a.reps, (double)out[4 * i + 2] / a.reps, (double)out[4 * i + 3] / a.reps);
+	printf("%-30s %9.0f\n%-30s %9.0f\n", "sync", (double)out[56] / a.reps, "wave sum", (double)out[57] / a.reps);
+	hipError_t err = hipGetLastError();
+	if (err != hipSuccess) printf("HIP error: %s\n", hipGetErrorString(err));
 	return 0;
 }
