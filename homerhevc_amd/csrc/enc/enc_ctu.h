@@ -465,7 +465,25 @@ HENC_HD uint32_t motion_inter_ctu(const G g, Enc &__restrict__ e)
 					const uint32_t inter_sum = nd.sum;
 					if (!nd.merge_flag) put_consolidated_info(g, e, curr, curr_depth);
 					e.last_slog = -1;
-					const uint32_t intra_dist = encode_intra(g, e, curr_depth, position, PART_2Nx2N);
+					// encode_intra (:1731): luma, then chroma.  The comparison below only grows with what chroma adds - its distortion, and its levels through cost_rd - so when
+					// luma alone already loses against the inter cost for every value the intra ratio can take (it is clipped to 0 .. 0.15, and enc_sched.h re-evaluates
+					// the comparison with the true one), chroma cannot change the outcome: the evaluation is left out.  What it would have left behind - the auxiliary
+					// chroma window, the depth's chroma buffers, the node's level sum - is restored from the consolidated inter result by the losing branch below or
+					// rewritten before it is read.  Not with RD_FULL (its bit estimates have side effects of their own) and not while a CTU is logged for replay by
+					// a schedule that needs the true distortion (lockstep = 0 keeps the full evaluation).
+					uint32_t intra_dist;
+					{
+						uint32_t cl;
+						{ HENC_PROF_T0(); cl = encode_intra_luma(g, e, curr_depth, position, PART_2Nx2N); HENC_PROF_ADD(e, PF_INTRA_TU); } HENC_TRACE_PW(e, "iluma");
+						const double add_lb = hclip(avg_distortion - 400, 40., avg_distortion) / 1.75 * curr_depth;
+						const double lb = intra_cost_with_ratio((double)cl, .15, add_lb, cost_rd(e.f->avg_dist, nd.sum));
+						if (S.rd_mode != RDM_FULL && e.f->lockstep && lb > cost + 1.) intra_dist = cl;
+						else {
+							uint32_t cc;
+							{ HENC_PROF_T0(); cc = encode_intra_chroma(g, e, curr_depth, position, PART_2Nx2N); HENC_PROF_ADD(e, PF_INTRA_CHROMA); } HENC_TRACE_PW(e, "ichroma");
+							intra_dist = cl + cc;
+						}
+					}
 #if defined(__HIPCC__) && defined(HENC_PROFILE)
 					if (g.tid == 0 && e.timeline && e.timeline[2] == 0) e.timeline[2] = wall_clock64();
 #endif
