@@ -53,7 +53,6 @@ inline bool make_seq(HostCfg cfg, Seq &s, const char **why)
 	if (cfg.num_b != 0 || cfg.gop_size != 1) { *why = "B frames"; return false; }
 	if (cfg.num_ref_frames != 1) { *why = "num_ref_frames != 1"; return false; }
 	if (cfg.bitrate_mode < 0 || cfg.bitrate_mode > 2) { *why = "bitrate_mode"; return false; }
-	if (cfg.bitrate_mode != 0 && cfg.num_enc_engines > 1) { *why = "rate control with num_enc_engines > 1"; return false; }
 	if (cfg.bitrate_mode != 0 && (cfg.bitrate <= 0 || cfg.vbv_size <= 0 || cfg.frame_rate <= 0)) { *why = "rate control needs bitrate, vbv_size and frame_rate"; return false; }
 	// RD_FULL: the bit estimates copy the real coder's contexts as the schedule leaves them (enc_rdo.h, enc_rc.h RdCtxSim: the synchronous wavefront, or one thread in
 	// raster order) - one engine, fixed QP
@@ -207,7 +206,13 @@ struct HostState {
 	double avg_dist = 0.0;          // hvenc->avg_dist: calloc'ed, so the first frame runs with 0 (hmr_encoder_lib.c:3191)
 	double avg_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // hvenc->avg_dist after each of the last eight frames
 	int engines = 1, last_idr = 0;  // last_idr: picture order count of the last IDR picture
-	RcState rc = {};                // rate control (enc_rc.h): hvenc->rc, pict_qp
+	RcState rc = {};                // rate control (enc_rc.h): hvenc->rc, pict_qp - with several engines the rc object of the engine whose frame is in flight
+	// Rate control with several engines, as the engine turnstile of oracle/ref_ctudump.c pins it (hmr_encoder_lib.c:3195-3202, :3262-3279, hmr_rate_control.c:89-265):
+	// a frame's engine copies hvenc->rc when the frame is fed - right after the engine's last frame n - E has ended - and makes its CTU decisions with that
+	// (vbv_fullness E frames old, the engine's own pict_qp and avg_qp); the end sections run in frame order, each pushing vbv_fullness / acc_avg / acc_rate into
+	// the engines ahead after their CTU work, so hmr_rc_end_pic(n) continues from what hmr_rc_end_pic(n - 1) left.  rc_hist[k & 7]: the state after frame k's end.
+	RcState rc_hist[8] = {};
+	RcState rc_start = {};          // what hmr_rc_init leaves (the first E frames are fed before any frame has ended)
 };
 // HVENC_Cfg rates -> the rate control's sequence state (HOMER_SETCFG hmr_encoder_lib.c:949-963 + hmr_rc_init)
 inline void host_rc_init(const HostCfg &cfg, const Seq &s, HostState &st)
@@ -218,6 +223,7 @@ inline void host_rc_init(const HostCfg &cfg, const Seq &s, HostState &st)
 		vbv_init = ((double)cfg.vbv_init / (double)cfg.vbv_size) * vbv_size;
 	}
 	rc_init(st.rc, (double)cfg.bitrate, vbv_size, vbv_init, cfg.frame_rate, s.nctu, cfg.qp);
+	st.rc_start = st.rc;
 }
 constexpr int MAX_ENGINES = 8;       // hmr_private.h:1232
 
@@ -239,7 +245,8 @@ inline void begin_frame(const Seq &s, HostState &st, int image_type, FrameCtx &f
 	f.last_idr = st.last_idr;
 	f.qp = s.qp;
 	if (s.bitrate_mode != BR_FIXED_QP) {
-		// hmr_slice_init :1990 (the slice QP is the frame QP the last frame left), hmr_rc_init_pic
+		// hmr_slice_init :1990 (the slice QP is the frame QP the engine's last frame left), hmr_rc_init_pic
+		if (st.engines > 1) st.rc = st.num_encoded_frames >= st.engines ? st.rc_hist[(st.num_encoded_frames - st.engines) & 7] : st.rc_start;
 		f.qp = st.rc.pict_qp;
 		rc_init_pic(st.rc, f.slice_type, s.intra_period);
 		rc_frame_view(st.rc, s.nctu, s.bitrate_mode, f.rc);
@@ -305,9 +312,17 @@ inline void end_frame(const Seq &s, HostState &st, const FrameCtx &f, double acc
 		else if (scene_change) a *= 1.375;
 		st.avg_dist = a;
 	}
-	if (s.bitrate_mode != BR_FIXED_QP && rc)
+	if (s.bitrate_mode != BR_FIXED_QP && rc) {
+		if (st.engines > 1 && st.num_encoded_frames >= 1) {      // (the push of the frames that ended before this one: the last one's counts)
+			const RcState &prev = st.rc_hist[(st.num_encoded_frames - 1) & 7];
+			st.rc.vbv_fullness = prev.vbv_fullness;
+			st.rc.acc_avg = prev.acc_avg;
+			st.rc.acc_rate = prev.acc_rate;
+		}
 		rc_end_pic(st.rc, f.slice_type, s.intra_period, s.bitrate_mode, s.nctu, st.num_encoded_frames == 0 || f.slice_type != SLICE_I || s.intra_period == 1, rc->sum_qp, st.avg_dist,
 			   scene_change, rc->consumed_bits, rc->target_pict_size);
+		st.rc_hist[st.num_encoded_frames & 7] = st.rc;
+	}
 	st.avg_hist[st.num_encoded_frames & 7] = st.avg_dist;    // (an I frame inside the sequence keeps the value pushed by the frame before it, :3268-3279)
 	st.num_encoded_frames++;
 }

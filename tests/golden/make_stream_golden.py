@@ -79,6 +79,11 @@ CASES = [
     ("416x240_vbr400", 416, 240, 6, {"bitrate_mode": 2, "bitrate": 400}),
     ("3840x2160_cbr20000_perf1", 3840, 2160, 2, {"bitrate_mode": 1, "bitrate": 20000, "perf": 1}),
     ("3840x2160_force_intra_rdfull_tr4_perf0", 3840, 2160, 1, {"force_intra": 1, "rd": 1, "intra_tr": 4, "perf": 0}),
+    # rate control with several engines (the engine turnstile: a frame decides with the rate-control state its engine copied when the frame was fed)
+    ("416x240_cbr400_perf1_eng2_wpp_rows", 416, 240, 12, {"bitrate_mode": 1, "bitrate": 400, "perf": 1, "engines": 2, "wpp": 4}),
+    ("416x240_vbr400_eng3_wpp_rows", 416, 240, 12, {"bitrate_mode": 2, "bitrate": 400, "engines": 3, "wpp": 4}),
+    ("416x240_cbr300_eng2", 416, 240, 10, {"bitrate_mode": 1, "bitrate": 300, "engines": 2}),
+    ("832x480_cbr1500_perf1_eng4_wpp_rows", 832, 480, 12, {"bitrate_mode": 1, "bitrate": 1500, "perf": 1, "engines": 4, "wpp": 8}),
     ("416x240_cbr400_perf1_wpp_rows", 416, 240, 8, {"bitrate_mode": 1, "bitrate": 400, "perf": 1, "wpp": 4}),
     ("416x240_vbr400_wpp_rows", 416, 240, 8, {"bitrate_mode": 2, "bitrate": 400, "wpp": 4}),
     ("832x480_cbr1500_perf1_wpp_rows", 832, 480, 6, {"bitrate_mode": 1, "bitrate": 1500, "perf": 1, "wpp": 8}),
