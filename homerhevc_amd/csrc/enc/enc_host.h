@@ -55,9 +55,9 @@ inline bool make_seq(HostCfg cfg, Seq &s, const char **why)
 	if (cfg.bitrate_mode < 0 || cfg.bitrate_mode > 2) { *why = "bitrate_mode"; return false; }
 	if (cfg.bitrate_mode != 0 && (cfg.bitrate <= 0 || cfg.vbv_size <= 0 || cfg.frame_rate <= 0)) { *why = "rate control needs bitrate, vbv_size and frame_rate"; return false; }
 	// RD_FULL: the bit estimates copy the real coder's contexts as the schedule leaves them (enc_rdo.h, enc_rc.h RdCtxSim: the synchronous wavefront, or one thread in
-	// raster order) - one engine, fixed QP
-	if (cfg.rd_mode == RDM_FULL && (cfg.num_enc_engines > 1 || cfg.bitrate_mode != 0)) {
-		*why = "rd_mode RD_FULL needs one engine and fixed QP";
+	// raster order; every engine has coder objects of its own) - fixed QP
+	if (cfg.rd_mode == RDM_FULL && cfg.bitrate_mode != 0) {
+		*why = "rd_mode RD_FULL needs fixed QP";
 		return false;
 	}
 	s.max_cu_size = 64;

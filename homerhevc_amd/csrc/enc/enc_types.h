@@ -209,7 +209,7 @@ struct EntScratch {
 	uint8_t cg_flag[64];
 };
 constexpr int RD_CTX_BYTES = 192;      // CTX_TOTAL (enc_cabac_tables.h: 179) rounded up
-constexpr int RD_RING = 8;             // RD_FULL: frames whose coder states are kept (a coder object nobody selects keeps its states: enc_rc.h RdCtxSim)
+constexpr int RD_RING = 16;            // RD_FULL: frames whose coder states are kept - an engine's objects keep states of its last two frames (enc_rc.h RdCtxSim): 2 x 8 engines (a coder object nobody selects keeps its states: enc_rc.h RdCtxSim)
 
 #if defined(HENC_NHELP)
 #define HENC_IQ_SLOTS (HENC_NHELP)

@@ -59,7 +59,7 @@ struct Cpu {
 	std::vector<uint16_t> rc_need;   // rate control: CTUs of each row coded when a wavefront step (sched 2) / a CTU (raster order) starts
 	int post_errors[2] = {0, 0};
 	// RD_FULL: which coder states each CTU's bit estimates copy (enc_rc.h RdCtxSim), the states after every coded CTU of this frame and of the one before
-	RdCtxSim rdsim;
+	RdCtxSim rdsim[MAX_ENGINES];      // (an engine's coder objects are its own: hmr_encoder_lib.c:1096)
 	std::vector<RdCtxVersion> rdsrc;
 	std::vector<uint8_t> ctx_after[RD_RING];      // (frame f in slot f mod RD_RING)
 	uint8_t zero_ctx[RD_CTX_BYTES] = {0}, init_ctx[RD_RING][RD_CTX_BYTES] = {{0}};      // (init_ctx: the slice's initial states of the frames)
@@ -141,7 +141,7 @@ void post_begin_frame(Cpu &c)
 		const int slot = c.f.num_encoded_frames % RD_RING;
 		c.ctx_after[slot].assign((size_t)s.nctu * RD_CTX_BYTES, 0);
 		P.ctx_after = c.ctx_after[slot].data();
-		c.rdsim.frame(c.f.num_encoded_frames, c.rdsrc, c.sched != 2);      // (one thread: raster order)
+		c.rdsim[c.local_engines > 1 ? c.f.num_encoded_frames % c.local_engines : 0].frame(c.f.num_encoded_frames, c.rdsrc, c.sched != 2);      // (one thread: raster order)
 		for (int i = 0; i < CTX_TOTAL; i++) c.init_ctx[slot][i] = Cabac::init_state(c.f.slice_type, c.f.qp, i);
 	}
 }
@@ -521,7 +521,7 @@ void *henc_cpu_create(const HostCfg *cfg)
 	make_geo(c->geo);
 	if (cfg->wfpp_num_threads > 1) c->sched = 2;   // one worker per CTU row: the synchronous wavefront
 	if (c->seq.rd_mode == RDM_FULL) {
-		c->rdsim.init(cfg->wfpp_num_threads, c->seq.wctu, c->seq.hctu, c->seq.sao);
+		for (auto &sim : c->rdsim) sim.init(cfg->wfpp_num_threads, c->seq.wctu, c->seq.hctu, c->seq.sao);
 		for (auto &v : c->ctx_after) v.assign((size_t)c->seq.nctu * RD_CTX_BYTES, 0);
 	}
 	if (cfg->bitrate_mode != 0) {
