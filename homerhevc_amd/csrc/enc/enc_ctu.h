@@ -214,9 +214,9 @@ HENC_WALK_FN HENC_HD uint32_t check_rd_cost_merge(const G g, Enc &__restrict__ e
 #if defined(HENC_QUAD)
 	{	// an 8 x 8 CU: the evaluations of all candidates in one pass, then this loop on their results (enc_quad.h); -1: the sequential way
 		const QuadCands mc = quad_load_cands(e);
-		const int slots = quad_prepare(g, e, ni, mc HENC_QPROF_PASS);
+		const int slots = q.size == 8 ? quad_prepare<8>(g, e, ni, mc HENC_QPROF_PASS) : (q.size == 16 ? quad_prepare<16>(g, e, ni, mc HENC_QPROF_PASS) : -1);
 		if (slots >= 0) {
-			const uint32_t best = quad_merge_loop(g, e, ni, slots, mc, inter_modes HENC_QPROF_PASS);
+			const uint32_t best = q.size == 8 ? quad_merge_loop<8>(g, e, ni, slots, mc, inter_modes HENC_QPROF_PASS) : quad_merge_loop<16>(g, e, ni, slots, mc, inter_modes HENC_QPROF_PASS);
 			HENC_QPROF_MARK(e, 7);      // (the node's fields)
 			if (g.tid == 0 && e.prof) e.prof[8] += 1;      // (CUs taken this way)
 			return best;

@@ -1,4 +1,4 @@
-// The merge evaluation of an 8 x 8 CU with all its candidates side by side (device only).
+// The merge evaluation of an 8 x 8 or 16 x 16 CU with all its candidates side by side (device only).
 //
 // check_rd_cost_merge_2nx2n (hmr_motion_inter.c:3493-3742) evaluates up to five candidate vectors one after the other: motion compensation, then encode_inter
 // (:3071: forward transform, quantisation + sign hiding, and for blocks with levels dequantisation, inverse transform, the keep-or-drop test of
@@ -15,6 +15,8 @@
 //      the slot's prediction into the prediction window (quad_put_pred), the coded evaluation puts the slot's levels and reconstruction into the windows of the
 //      CU's depth and sets the node's fields (quad_encode_inter) - every side effect of the sequential evaluation, none of its arithmetic.
 //
+// A 16 x 16 CU (round 6, second step) goes the same way with other tile shapes: its luma block IS a tile (the slots' luma chains run one after the other in one
+// piece of code, DevTables::frag16), its four chroma blocks (two slots x two planes, 8 x 8) are the four quadrants of the helper's tile.
 // Not taken (the sequential evaluation runs as before): CUs of another size, performance_mode 0 (the 8 x 8 CU's transform tree then has a 4 x 4 level), more
 // than four distinct candidates, a candidate whose vector points outside the padded reference (quirk Q12: evaluated on a stale window).
 // The arithmetic of a chain is the one of encode_inter_tu (enc_inter.h) and the primitives it calls (enc_prims.h: tr_forward_mfma, quantize, sbh_pass,
@@ -34,88 +36,114 @@ struct QuadRes {
 	uint32_t raw[3];       // its *raw_ssq: SSD(source, prediction), unweighted
 	uint32_t cbf[3];       // the node's inter_cbf after it
 };
-struct QuadScratch {      // in Work::pred_aux + Work::delta_u (the TU scratch: no TU is in flight while the candidate loop runs on the slots' results)
-	uint8_t pred_y[4][64], rec_y[4][64];
-	int16_t lv_y[4][64];
-	uint8_t pred_c[4][2][16], rec_c[4][2][16];
-	int16_t lv_c[4][2][16];
+// in Work::pred_aux + Work::delta_u (the TU scratch: no TU is in flight while the candidate loop runs on the slots' results).  CU 8: up to four slots and the luma
+// chain's exchange buffers; CU 16: up to two slots (the luma chain's exchange buffers are the worker's level slot, Work::iq_y)
+struct QuadScratch {
+	union {
+		struct {
+			uint8_t pred_y[4][64], rec_y[4][64];
+			int16_t lv_y[4][64];
+			uint8_t pred_c[4][2][16], rec_c[4][2][16];
+			int16_t lv_c[4][2][16];
+			int16_t wk_lv[256], wk_cf[256], wk_du[256];      // levels / coefficients / remainders for the sign-hiding walk; the dequantised coefficients for the inverse's operand
+		} s8;
+		struct {
+			uint8_t pred_y[2][256], rec_y[2][256];
+			int16_t lv_y[2][256];
+			uint8_t pred_c[2][2][64], rec_c[2][2][64];
+			int16_t lv_c[2][2][64];
+		} s16;
+	};
 	QuadRes res[4];
 	MV mv[4];
-	int32_t acs[4];                              // level sums of the luma blocks (what the sign-hiding lanes ask for)
-	int16_t wk_lv[256], wk_cf[256], wk_du[256];  // the luma chain's exchange buffers (levels / coefficients / remainders for the sign-hiding walk; the dequantised coefficients for the inverse's operand)
+	int32_t acs[4];      // level sums of the luma blocks (what the sign-hiding lanes ask for)
 };
 static_assert(sizeof(QuadScratch) <= 2 * TU_SCRATCH * sizeof(int16_t), "the slots' results live in the TU scratch");
 static_assert(offsetof(Work, delta_u) == offsetof(Work, pred_aux) + TU_SCRATCH * sizeof(int16_t), "pred_aux and delta_u are one area");
 HENC_INLINE QuadScratch &quad_scratch(Enc &__restrict__ e) { return *(QuadScratch *)(int16_t *)e.w->pred_aux; }
+template <int CU> __device__ __forceinline__ uint8_t *quad_pred_y(QuadScratch &qs, int slot) { if constexpr (CU == 8) return qs.s8.pred_y[slot]; else return qs.s16.pred_y[slot]; }
+template <int CU> __device__ __forceinline__ uint8_t *quad_rec_y(QuadScratch &qs, int slot) { if constexpr (CU == 8) return qs.s8.rec_y[slot]; else return qs.s16.rec_y[slot]; }
+template <int CU> __device__ __forceinline__ int16_t *quad_lv_y(QuadScratch &qs, int slot) { if constexpr (CU == 8) return qs.s8.lv_y[slot]; else return qs.s16.lv_y[slot]; }
+template <int CU> __device__ __forceinline__ uint8_t *quad_pred_c(QuadScratch &qs, int slot, int p) { if constexpr (CU == 8) return qs.s8.pred_c[slot][p]; else return qs.s16.pred_c[slot][p]; }
+template <int CU> __device__ __forceinline__ uint8_t *quad_rec_c(QuadScratch &qs, int slot, int p) { if constexpr (CU == 8) return qs.s8.rec_c[slot][p]; else return qs.s16.rec_c[slot][p]; }
+template <int CU> __device__ __forceinline__ int16_t *quad_lv_c(QuadScratch &qs, int slot, int p) { if constexpr (CU == 8) return qs.s8.lv_c[slot][p]; else return qs.s16.lv_c[slot][p]; }
 
-// sum over the lanes of a block of the tile: N = 4: the block's rows are the four lanes of a quad; N = 8: eight lanes of a half row and the eight 16 lanes on
+// sum over the lanes of a block of the tile: N = 4: the block's rows are the four lanes of a quad; N = 8: eight lanes of a half row and the eight 16 lanes on;
+// N = 16: the whole wavefront
 template <int N>
 __device__ __forceinline__ uint32_t quad_blk_sum(uint32_t v)
 {
 	int x = (int)v;
-	x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);       // quad_perm [1, 0, 3, 2]
-	x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);       // quad_perm [2, 3, 0, 1]
-	if constexpr (N == 8) {
-		x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);   // row_half_mirror: the other quad of the eight
-		x += __builtin_amdgcn_ds_swizzle(x, 0x401F);                      // lane ^ 16
+	if constexpr (N == 16) {
+		x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+		x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+		x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+		x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+		return (uint32_t)(__builtin_amdgcn_readlane(x, 15) + __builtin_amdgcn_readlane(x, 31) + __builtin_amdgcn_readlane(x, 47) + __builtin_amdgcn_readlane(x, 63));
+	} else {
+		x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);       // quad_perm [1, 0, 3, 2]
+		x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);       // quad_perm [2, 3, 0, 1]
+		if constexpr (N == 8) {
+			x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);   // row_half_mirror: the other quad of the eight
+			x += __builtin_amdgcn_ds_swizzle(x, 0x401F);                      // lane ^ 16
+		}
+		return (uint32_t)x;
 	}
-	return (uint32_t)x;
 }
 
-// The chain of all slots for one component class.  N = 8: luma, slot = 2 (tile row / 8) + tile column / 8; N = 4: chroma, slot = tile row / 4, plane = tile
-// column / 4 (columns 8 .. 15 of the tile stay empty).  A lane owns four consecutive elements of one block row all the way: source, prediction, residual,
-// coefficients, levels, reconstruction; memory is only touched for the sign-hiding walk (a coefficient group per lane) and for the inverse transform's
-// operand (the transposed block).  ALL 64 lanes run this in uniform control flow.
-template <int N>
-__device__ __forceinline__ void quad_chain(const int lane, Enc &__restrict__ e, const int ni, QuadScratch &qs, int16_t *wk_lv, int16_t *wk_cf, int16_t *wk_du, int32_t *acs)
+// The chain of the slots' blocks of one component class in ONE matrix-core tile.  Block size N and what the tile holds:
+//   CU 8 luma:    N = 8,  four blocks, slot = 2 (tile row / 8) + tile column / 8            (block-diagonal basis DevTables::fragp)
+//   CU 8 chroma:  N = 4,  eight blocks, slot = tile row / 4, plane = tile column / 4 (columns 8 .. 15 of the tile stay empty; DevTables::fragq)
+//   CU 16 luma:   N = 16, the block of slot `one_slot` (DevTables::frag16)
+//   CU 16 chroma: N = 8,  four blocks, quadrant b = 2 (tile row / 8) + tile column / 8: slot = b / 2, plane = b % 2
+// A lane owns four consecutive elements of one block row all the way: source, prediction, residual, coefficients, levels, reconstruction; memory is only touched
+// for the sign-hiding walk (a coefficient group per lane) and for the inverse transform's operand (the transposed block).  ALL 64 lanes run this in uniform control flow.
+template <int CU, bool CHROMA>
+__device__ __forceinline__ void quad_chain(const int lane, Enc &__restrict__ e, const int ni, QuadScratch &qs, const int one_slot, int16_t *wk_lv, int16_t *wk_cf, int16_t *wk_du, int32_t *acs)
 {
 	HENC_ENC_IN_LDS(e);
-	constexpr int L = N == 8 ? 3 : 2, NN = N * N, GPB = NN / 16, NBLK = N == 8 ? 4 : 8;
+	constexpr int N = CHROMA ? CU / 2 : CU;
+	constexpr int L = N == 16 ? 4 : (N == 8 ? 3 : 2), NN = N * N, GPB = NN / 16, NBLK = N == 16 ? 1 : (N == 8 ? 4 : 8);
 	Work &w = *e.w;
 	const Seq &S = *e.seq;
 	const DevTables *T = e.T;
 	const Geo &q = e.geo[ni];
 	const int row = lane & 15, k0 = (lane >> 4) * 4;
-	const bool is_y = N == 8;
-	const int slot = is_y ? 2 * (row >> 3) + (k0 >> 3) : (row >> 2);
-	const int plane = is_y ? 0 : ((lane >> 4) & 1);
-	const bool active = is_y || lane < 32;
-	const int blk = is_y ? slot : slot * 2 + plane;
+	const int quadrant = 2 * (row >> 3) + (k0 >> 3);
+	const int slot = N == 16 ? one_slot : (N == 8 ? (CHROMA ? quadrant >> 1 : quadrant) : (row >> 2));
+	const int plane = !CHROMA ? 0 : (N == 8 ? quadrant & 1 : ((lane >> 4) & 1));
+	const bool active = N != 4 || lane < 32;
+	const int blk = N == 16 ? 0 : (N == 8 ? quadrant : slot * 2 + plane);      // the block's place in the exchange buffers
 	const int r = row & (N - 1), c0 = k0 & (N - 1), pos0 = r * N + c0;
-	const int comp = is_y ? COMP_Y : COMP_U + plane;
+	const int comp = CHROMA ? COMP_U + plane : COMP_Y;
+	uint8_t *const st_pred = CHROMA ? quad_pred_c<CU>(qs, slot, plane) : quad_pred_y<CU>(qs, slot);
+	uint8_t *const st_rec = CHROMA ? quad_rec_c<CU>(qs, slot, plane) : quad_rec_y<CU>(qs, slot);
+	int16_t *const st_lv = CHROMA ? quad_lv_c<CU>(qs, slot, plane) : quad_lv_y<CU>(qs, slot);
 	// source and prediction (motion compensation from the phase planes: motion_compensate_cu, enc_inter.h)
 	const MV mv = qs.mv[slot];
 	uint32_t o4, p4;
-	if constexpr (N == 8) {
+	if constexpr (!CHROMA) {
 		const int gx = e.ctu_x + q.x, gy = e.ctu_y + q.y, sy = 16 * S.stride_y;
 		const uint8_t *py = e.f->sub_y + (((mv.y & 3) << 2) | (mv.x & 3)) * S.stride_y + (ptrdiff_t)(gy + (mv.y >> 2)) * sy + gx + (mv.x >> 2);
 		p4 = ld32u(py + r * sy + c0);
 		o4 = *(const uint32_t *)(w.curr_y + (q.y + r) * 64 + q.x + c0);
-		*(uint32_t *)(qs.pred_y[slot] + pos0) = p4;
 	} else {
 		const int gxc = (e.ctu_x >> 1) + q.xc, gyc = (e.ctu_y >> 1) + q.yc, sc = 64 * S.stride_c;
 		const ptrdiff_t oc = (((mv.y & 7) << 3) | (mv.x & 7)) * S.stride_c + (ptrdiff_t)(gyc + (mv.y >> 3)) * sc + gxc + (mv.x >> 3);
-		p4 = ld32u(e.f->sub_c[plane] + oc + r * sc);
-		o4 = *(const uint32_t *)(w.curr_c[plane] + (q.yc + r) * 32 + q.xc);
-		if (active) *(uint32_t *)(qs.pred_c[slot][plane] + pos0) = p4;
+		p4 = ld32u(e.f->sub_c[plane] + oc + r * sc + c0);
+		o4 = *(const uint32_t *)(w.curr_c[plane] + (q.yc + r) * 32 + q.xc + c0);
 	}
+	if (active) *(uint32_t *)(st_pred + pos0) = p4;
 	int x[4], pv[4];
 #pragma unroll
 	for (int k = 0; k < 4; k++) { pv[k] = (int)((p4 >> (8 * k)) & 255u); x[k] = active ? (int)((o4 >> (8 * k)) & 255u) - pv[k] : 0; }
-	// quantiser values of the lane's four positions (quantize / dequantize, enc_prims.h: inter lists; 4 x 4: the flat value)
+	// quantiser values of the lane's four positions (quantize / dequantize, enc_prims.h: the inter lists as 8 x 8 cells; 4 x 4: the flat value)
 	const Node &nd = node_of(e, ni);
-	const int qp = is_y ? (int)nd.qp : chroma_qp_table((int)nd.qp + S.chroma_qp_offset);
+	const int qp = !CHROMA ? (int)nd.qp : chroma_qp_table((int)nd.qp + S.chroma_qp_offset);
 	const int per = qp / 6, rem = qp % 6;
 	uint32_t qv[4], iv[4];
-	if constexpr (N == 8) {
-		const int32_t *qc = T->quant[1][3][rem] + pos0, *ic = T->dequant[1][3][rem] + pos0;
-#pragma unroll
-		for (int k = 0; k < 4; k++) { qv[k] = (uint32_t)qc[k]; iv[k] = (uint32_t)ic[k]; }
-	} else {
-		const uint32_t qf = (uint32_t)(uint16_t)T->quant[0][0][rem][0], ifl = (uint32_t)(uint16_t)T->dequant[0][0][rem][0];
-#pragma unroll
-		for (int k = 0; k < 4; k++) { qv[k] = qf; iv[k] = ifl; }
-	}
+	ft_list_value4(T->quant[1][3][rem], (uint32_t)(uint16_t)T->quant[0][0][rem][0], pos0, L, qv);
+	ft_list_value4(T->dequant[1][3][rem], (uint32_t)(uint16_t)T->dequant[0][0][rem][0], pos0, L, iv);
 	// the scan positions of the lane's coefficient group for the sign-hiding walk (lanes below NBLK * GPB: block gb, group cg), fetched with everything else that
 	// comes from memory
 	const int gb = lane / GPB, cg = lane % GPB;
@@ -125,12 +153,14 @@ __device__ __forceinline__ void quad_chain(const int lane, Enc &__restrict__ e, 
 #pragma unroll
 		for (int n = 0; n < 16; n++) sg.pos[n] = sc[n];
 	}
+	const uint16_t *const frag_f = N == 16 ? T->frag16[0][2] : (N == 8 ? T->fragp[0][1] : T->fragq[0]);
+	const uint16_t *const frag_i = N == 16 ? T->frag16[1][2] : (N == 8 ? T->fragp[1][1] : T->fragq[1]);
 	// forward transform (tr_forward_mfma with the block-diagonal basis)
 	const mf_f4 z = {0, 0, 0, 0};
 	int y[4];
 	{
 		constexpr int sh1 = L - 1, sh2 = L + 6, rnd1 = 1 << (sh1 - 1), rnd2 = 1 << (sh2 - 1);
-		const mf_h4 m = mf_frag(N == 8 ? T->fragp[0][1] : T->fragq[0], lane);
+		const mf_h4 m = mf_frag(frag_f, lane);
 		mf_h4 xh;
 #pragma unroll
 		for (int k = 0; k < 4; k++) xh[k] = (_Float16)(short)x[k];
@@ -190,7 +220,7 @@ __device__ __forceinline__ void quad_chain(const int lane, Enc &__restrict__ e, 
 		}
 		const uint64_t mask = __ballot(nz);
 		if (nz) {
-			const uint32_t mine = (uint32_t)(mask >> (gb * GPB)) & ((1u << GPB) - 1u);
+			const uint32_t mine = GPB == 16 ? (uint32_t)mask : ((uint32_t)(mask >> (gb * GPB)) & ((1u << (GPB & 15)) - 1u));
 			sbh_apply(sg, wk_lv + gb * NN, cg == 31 - __builtin_clz(mine));
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -206,66 +236,67 @@ __device__ __forceinline__ void quad_chain(const int lane, Enc &__restrict__ e, 
 	int rd[4] = {0, 0, 0, 0};
 	uint32_t raw = 0;
 	if (__ballot(active && coded) != 0) {      // (uniform: some block has levels)
-	// dequantisation (dequantize), to the exchange buffer: the inverse transform's operand is the transposed tile
-	{
-		const int iq_shift = 20 - 14 - (15 - 8 - L) + 4;
-		const int32_t iadd = iq_shift > per ? 1 << (iq_shift - per - 1) : 0;
-		const int sh = iq_shift > per ? iq_shift - per : per - iq_shift;
-		S4 o;
+		// dequantisation (dequantize), to the exchange buffer: the inverse transform's operand is the transposed tile
+		{
+			const int iq_shift = 20 - 14 - (15 - 8 - L) + 4;
+			const int32_t iadd = iq_shift > per ? 1 << (iq_shift - per - 1) : 0;
+			const int sh = iq_shift > per ? iq_shift - per : per - iq_shift;
+			S4 o;
 #pragma unroll
-		for (int k = 0; k < 4; k++)
-			o.v[k] = iq_shift > per ? sat16((int32_t)((uint32_t)(int32_t)lv[k] * iv[k] + (uint32_t)iadd) >> sh) : sat16((int32_t)(((uint32_t)(int32_t)lv[k] * iv[k]) << sh));
-		if (active) st4(wk_cf + blk * NN + pos0, o);
-	}
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-	// inverse transform (tr_inverse_mfma): operand element e of the lane is tile element (k0 + e, row)
-	{
-		const mf_h4 mt = mf_frag(N == 8 ? T->fragp[1][1] : T->fragq[1], lane);
-		int c[4] = {0, 0, 0, 0};
-		// the block that holds tile rows k0 .. k0 + 3 and tile column `row`
-		const int tb = is_y ? 2 * (k0 >> 3) + (row >> 3) : (k0 >> 2) * 2 + (row >> 2);
-		const bool there = is_y || row < 8;
-		if (there) {
-#pragma unroll
-			for (int k = 0; k < 4; k++) c[k] = wk_cf[tb * NN + (c0 + k) * N + r];
+			for (int k = 0; k < 4; k++)
+				o.v[k] = iq_shift > per ? sat16((int32_t)((uint32_t)(int32_t)lv[k] * iv[k] + (uint32_t)iadd) >> sh) : sat16((int32_t)(((uint32_t)(int32_t)lv[k] * iv[k]) << sh));
+			if (active) st4(wk_cf + blk * NN + pos0, o);
 		}
-		mf_h4 hi, lo;
-		mf_split(c, hi, lo);
-		mf_f4 dh = __builtin_amdgcn_mfma_f32_16x16x16f16(hi, mt, z, 0, 0, 0);
-		mf_f4 dl = __builtin_amdgcn_mfma_f32_16x16x16f16(lo, mt, z, 0, 0, 0);
-		int t[4];
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		// inverse transform (tr_inverse_mfma): operand element e of the lane is tile element (k0 + e, row)
+		{
+			const mf_h4 mt = mf_frag(frag_i, lane);
+			int c[4] = {0, 0, 0, 0};
+			// the block that holds tile rows k0 .. k0 + 3 and tile column `row`
+			const int tb = N == 16 ? 0 : (N == 8 ? 2 * (k0 >> 3) + (row >> 3) : (k0 >> 2) * 2 + (row >> 2));
+			const bool there = N != 4 || row < 8;
+			if (there) {
 #pragma unroll
-		for (int k = 0; k < 4; k++) t[k] = mf_stage(dh[k], dl[k], 64, 7);
-		mf_split(t, hi, lo);
-		dh = __builtin_amdgcn_mfma_f32_16x16x16f16(mt, hi, z, 0, 0, 0);
-		dl = __builtin_amdgcn_mfma_f32_16x16x16f16(mt, lo, z, 0, 0, 0);
+				for (int k = 0; k < 4; k++) c[k] = wk_cf[tb * NN + (c0 + k) * N + r];
+			}
+			mf_h4 hi, lo;
+			mf_split(c, hi, lo);
+			mf_f4 dh = __builtin_amdgcn_mfma_f32_16x16x16f16(hi, mt, z, 0, 0, 0);
+			mf_f4 dl = __builtin_amdgcn_mfma_f32_16x16x16f16(lo, mt, z, 0, 0, 0);
+			int t[4];
 #pragma unroll
-		for (int k = 0; k < 4; k++) rd[k] = mf_stage(dh[k], dl[k], 2048, 12);
-	}
-	// blk_ssd_diff(source, prediction, reconstructed residual), then the keep-or-drop test of encode_inter_tu
-	uint32_t lrec = 0;
+			for (int k = 0; k < 4; k++) t[k] = mf_stage(dh[k], dl[k], 64, 7);
+			mf_split(t, hi, lo);
+			dh = __builtin_amdgcn_mfma_f32_16x16x16f16(mt, hi, z, 0, 0, 0);
+			dl = __builtin_amdgcn_mfma_f32_16x16x16f16(mt, lo, z, 0, 0, 0);
 #pragma unroll
-	for (int k = 0; k < 4; k++) {
-		const int32_t dd = (int16_t)((int16_t)x[k] - (int16_t)rd[k]);
-		lrec += (uint32_t)(dd * dd);
+			for (int k = 0; k < 4; k++) rd[k] = mf_stage(dh[k], dl[k], 2048, 12);
+		}
+		// blk_ssd_diff(source, prediction, reconstructed residual)
+		uint32_t lrec = 0;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const int32_t dd = (int16_t)((int16_t)x[k] - (int16_t)rd[k]);
+			lrec += (uint32_t)(dd * dd);
+		}
+		raw = quad_blk_sum<N>(lrec);
 	}
-	raw = quad_blk_sum<N>(lrec);
-	}
+	// the keep-or-drop test of encode_inter_tu
 	const double weight = e.f->chroma_weight;
 	uint32_t ssd;
 	bool keep = false;
 	if (coded) {
 		uint32_t ssd_zero;
-		if (is_y) { ssd_zero = raw_zero; ssd = raw; }
+		if (!CHROMA) { ssd_zero = raw_zero; ssd = raw; }
 		else { ssd_zero = (uint32_t)(weight * raw_zero); ssd = (uint32_t)(weight * raw); }
 		const double thr = hclip(e.f->avg_dist / 2.5 - 5., 1., 20000.);
-		const bool drop = is_y ? ((double)ssd_zero <= (double)(int)ssd + thr * sum) : ((double)ssd_zero <= (double)ssd + thr * sum);
+		const bool drop = !CHROMA ? ((double)ssd_zero <= (double)(int)ssd + thr * sum) : ((double)ssd_zero <= (double)ssd + thr * sum);
 		keep = !drop;
 		if (drop) sum = 0;
 	} else {
-		ssd = is_y ? raw_zero : (uint32_t)(weight * raw_zero);
+		ssd = !CHROMA ? raw_zero : (uint32_t)(weight * raw_zero);
 	}
 	// reconstruction (blk_reconst) and the block's final levels
 	uint32_t rec4 = 0;
@@ -277,13 +308,8 @@ __device__ __forceinline__ void quad_chain(const int lane, Enc &__restrict__ e, 
 		fl.v[k] = keep ? (int16_t)lv[k] : (int16_t)0;
 	}
 	if (active) {
-		if constexpr (N == 8) {
-			*(uint32_t *)(qs.rec_y[slot] + pos0) = rec4;
-			st4(qs.lv_y[slot] + pos0, fl);
-		} else {
-			*(uint32_t *)(qs.rec_c[slot][plane] + pos0) = rec4;
-			st4(qs.lv_c[slot][plane] + pos0, fl);
-		}
+		*(uint32_t *)(st_rec + pos0) = rec4;
+		st4(st_lv + pos0, fl);
 		if (pos0 == 0) {
 			QuadRes &res = qs.res[slot];
 			res.dist[comp] = ssd;
@@ -297,12 +323,13 @@ __device__ __forceinline__ void quad_chain(const int lane, Enc &__restrict__ e, 
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// the helper's half of quad_prepare: the chroma blocks of all slots (k_encode.hip, HJOB_QUAD_C); its exchange buffers are its own scratch
-__device__ __forceinline__ void quad_chroma_job(const WaveGrp g, Enc &__restrict__ e, int ni)
+// the helper's half of quad_prepare: the chroma blocks of all slots (k_encode.hip, HJOB_QUAD_C; cu: the CU's size); its exchange buffers are its own scratch
+__device__ __forceinline__ void quad_chroma_job(const WaveGrp g, Enc &__restrict__ e, int ni, int cu)
 {
 	HENC_ENC_IN_LDS(e);
 	int16_t *s = e.scratch_a;
-	quad_chain<4>(g.tid, e, uni(ni), quad_scratch(e), s, s + 128, s + 256, (int32_t *)(s + 384));
+	if (uni(cu) == 8) quad_chain<8, true>(g.tid, e, uni(ni), quad_scratch(e), 0, s, s + 128, s + 256, (int32_t *)(s + 384));
+	else quad_chain<16, true>(g.tid, e, uni(ni), quad_scratch(e), 0, s, s + 256, s + 512, (int32_t *)(s + 768));
 }
 
 // the CU's merge candidates in registers (one look at the list for the slot assignment and the candidate loop; indexed with constants only: the loops over
@@ -326,15 +353,17 @@ __device__ __forceinline__ QuadCands quad_load_cands(Enc &__restrict__ e)
 // Slots for the CU's merge candidates and the chains of all slots.  Returns -1 when the CU is evaluated the sequential way (see the head of the file), else
 // the slot of candidate cand in bits 4 cand .. 4 cand + 3 (quad_slot).
 HENC_INLINE int quad_slot(int slots, int cand) { return (slots >> (4 * cand)) & 15; }
+template <int CU>
 __device__ __forceinline__ int quad_prepare(const WaveGrp g, Enc &__restrict__ e, int ni, const QuadCands &mc HENC_QPROF_ARG)
 {
 	HENC_ENC_IN_LDS(e);
 	const Seq &S = *e.seq;
 	const Geo &q = e.geo[ni];
-	if (q.size != 8 || S.perf_mode < 1) return -1;
+	if (S.perf_mode < 1) return -1;
 	static_assert(CFG_NUM_MERGE_CAND <= 5, "at most five merge candidates (QuadCands, the slot bits)");
+	constexpr int MAXS = CU == 8 ? 4 : 2;
 	QuadScratch &qs = quad_scratch(e);
-	const int gx = e.ctu_x + q.x, gy = e.ctu_y + q.y, n = 8;
+	const int gx = e.ctu_x + q.x, gy = e.ctu_y + q.y, n = CU;
 	const int xlow = -S.margin_y, xhigh = S.width + S.margin_y, ylow = -S.margin_y, yhigh = S.height + S.margin_y;
 	int nslots = 0, slots = 0, bad = 0;
 	int sx[4] = {0, 0, 0, 0}, sy[4] = {0, 0, 0, 0}, sr[4] = {0, 0, 0, 0};
@@ -347,11 +376,11 @@ __device__ __forceinline__ int quad_prepare(const WaveGrp g, Enc &__restrict__ e
 		for (int k = 3; k >= 0; k--)
 			if (k < nslots && sx[k] == mc.x[cand] && sy[k] == mc.y[cand] && sr[k] == mc.ref[cand]) s = k;
 		if (s < 0) {
-			if (nslots == 4) bad = 1;
+			if (nslots == MAXS) bad = 1;
 			s = nslots & 3;
 #pragma unroll
 			for (int k = 0; k < 4; k++)
-				if (k == s && nslots < 4) { sx[k] = mc.x[cand]; sy[k] = mc.y[cand]; sr[k] = mc.ref[cand]; }
+				if (k == s && nslots < MAXS) { sx[k] = mc.x[cand]; sy[k] = mc.y[cand]; sr[k] = mc.ref[cand]; }
 			nslots++;
 		}
 		slots |= s << (4 * cand);
@@ -368,8 +397,14 @@ __device__ __forceinline__ int quad_prepare(const WaveGrp g, Enc &__restrict__ e
 	}
 	g.sync();
 	HENC_QPROF_MARK(e, 2);      // (the slots)
-	helper_post(g, e, 0, HJOB_QUAD_C, ni);
-	quad_chain<8>(g.tid, e, ni, qs, qs.wk_lv, qs.wk_cf, qs.wk_du, qs.acs);
+	helper_post(g, e, 0, HJOB_QUAD_C, ni, CU);
+	if constexpr (CU == 8) quad_chain<8, false>(g.tid, e, ni, qs, 0, qs.s8.wk_lv, qs.s8.wk_cf, qs.s8.wk_du, qs.acs);
+	else {
+		// the slots' luma blocks one after the other (a block is a tile); the exchange buffers: the worker's level slot
+		int16_t *x0 = e.w->iq_y;
+		quad_chain<16, false>(g.tid, e, ni, qs, 0, x0, x0 + 256, x0 + 512, qs.acs);
+		if (nslots > 1) quad_chain<16, false>(g.tid, e, ni, qs, 1, x0, x0 + 256, x0 + 512, qs.acs);
+	}
 	HENC_QPROF_MARK(e, 3);      // (the luma chain)
 	helper_wait(g, e, 0);
 	HENC_QPROF_MARK(e, 4);      // (the rest of the helper's chroma chain)
@@ -379,6 +414,7 @@ __device__ __forceinline__ int quad_prepare(const WaveGrp g, Enc &__restrict__ e
 // What the candidate loop leaves behind, written once: `cons` = the evaluation put_consolidated_info saw last (the best: into window 0 and the CTU's record),
 // `wnd` = the evaluation that wrote the windows and per-depth buffers of the CU's depth last, `last_pred` = the slot whose prediction the window holds.
 // An evaluation is a slot and a kind: 1 = coded (the slot's levels and reconstruction), 2 = a winning no-residual evaluation (zero levels, the prediction).
+template <int CU>
 __device__ __forceinline__ void quad_commit(const WaveGrp g, Enc &__restrict__ e, int ni, int depth, int cons_slot, int cons_kind, int wnd_slot, int wnd_kind, int last_pred, int coded_any)
 {
 	HENC_ENC_IN_LDS(e);
@@ -388,32 +424,36 @@ __device__ __forceinline__ void quad_commit(const WaveGrp g, Enc &__restrict__ e
 	CtuPublic &c = *e.ctu;
 	QuadScratch &qs = quad_scratch(e);
 	const S4 zero = {{0, 0, 0, 0}};
-	if (g.tid < 16) {
-		const int r = g.tid >> 1, c0 = (g.tid & 1) * 4;
+	constexpr int NC = CU / 2, YL = CU * CU / 4, CL = 2 * NC * NC / 4;      // lanes (four samples each) of the luma block and of the two chroma blocks
+	// luma: lanes 0 .. YL - 1; chroma: lanes YL .. YL + CL - 1 (CU 8) or, after the luma lanes have had the whole wavefront, lanes 0 .. CL - 1 (CU 16)
+	auto luma = [&](int l) {
+		const int r = l / (CU / 4), c0 = (l % (CU / 4)) * 4;
 		if (cons_kind) {
-			st4(tq_ptr(w, 0, COMP_Y) + (q.abs_index << 4) + g.tid * 4, cons_kind == 1 ? ld4(qs.lv_y[cons_slot] + g.tid * 4) : zero);
-			st4(dec_ptr(w, 0, COMP_Y) + (q.y + r) * DEC_STRIDE_Y + q.x + c0, ld4((cons_kind == 1 ? qs.rec_y[cons_slot] : qs.pred_y[cons_slot]) + r * 8 + c0));
+			st4(tq_ptr(w, 0, COMP_Y) + (q.abs_index << 4) + l * 4, cons_kind == 1 ? ld4(quad_lv_y<CU>(qs, cons_slot) + l * 4) : zero);
+			st4(dec_ptr(w, 0, COMP_Y) + (q.y + r) * DEC_STRIDE_Y + q.x + c0, ld4((cons_kind == 1 ? quad_rec_y<CU>(qs, cons_slot) : quad_pred_y<CU>(qs, cons_slot)) + r * CU + c0));
 		}
 		if (wnd_kind) {
-			st4(tq_ptr(w, depth + 1, COMP_Y) + (q.abs_index << 4) + g.tid * 4, wnd_kind == 1 ? ld4(qs.lv_y[wnd_slot] + g.tid * 4) : zero);
-			st4(dec_ptr(w, depth + 1, COMP_Y) + (q.y + r) * DEC_STRIDE_Y + q.x + c0, ld4((wnd_kind == 1 ? qs.rec_y[wnd_slot] : qs.pred_y[wnd_slot]) + r * 8 + c0));
+			st4(tq_ptr(w, depth + 1, COMP_Y) + (q.abs_index << 4) + l * 4, wnd_kind == 1 ? ld4(quad_lv_y<CU>(qs, wnd_slot) + l * 4) : zero);
+			st4(dec_ptr(w, depth + 1, COMP_Y) + (q.y + r) * DEC_STRIDE_Y + q.x + c0, ld4((wnd_kind == 1 ? quad_rec_y<CU>(qs, wnd_slot) : quad_pred_y<CU>(qs, wnd_slot)) + r * CU + c0));
 		}
-		if (last_pred >= 0) *(uint32_t *)(w.pred_y + (q.y + r) * 64 + q.x + c0) = *(const uint32_t *)(qs.pred_y[last_pred] + r * 8 + c0);
-	} else if (g.tid < 24) {
-		const int p = (g.tid - 16) >> 2, r = g.tid & 3;
+		if (last_pred >= 0) *(uint32_t *)(w.pred_y + (q.y + r) * 64 + q.x + c0) = *(const uint32_t *)(quad_pred_y<CU>(qs, last_pred) + r * CU + c0);
+	};
+	auto chroma = [&](int l) {
+		const int p = l / (NC * NC / 4), j = l % (NC * NC / 4), r = j / (NC / 4), c0 = (j % (NC / 4)) * 4;
 		if (cons_kind) {
-			st4(tq_ptr(w, 0, COMP_U + p) + ((q.abs_index << 4) >> 2) + r * 4, cons_kind == 1 ? ld4(qs.lv_c[cons_slot][p] + r * 4) : zero);
-			st4(dec_ptr(w, 0, COMP_U + p) + (q.yc + r) * DEC_STRIDE_C + q.xc, ld4((cons_kind == 1 ? qs.rec_c[cons_slot][p] : qs.pred_c[cons_slot][p]) + r * 4));
+			st4(tq_ptr(w, 0, COMP_U + p) + ((q.abs_index << 4) >> 2) + j * 4, cons_kind == 1 ? ld4(quad_lv_c<CU>(qs, cons_slot, p) + j * 4) : zero);
+			st4(dec_ptr(w, 0, COMP_U + p) + (q.yc + r) * DEC_STRIDE_C + q.xc + c0, ld4((cons_kind == 1 ? quad_rec_c<CU>(qs, cons_slot, p) : quad_pred_c<CU>(qs, cons_slot, p)) + r * NC + c0));
 		}
 		if (wnd_kind) {
-			st4(tq_ptr(w, depth + 1, COMP_U + p) + ((q.abs_index << 4) >> 2) + r * 4, wnd_kind == 1 ? ld4(qs.lv_c[wnd_slot][p] + r * 4) : zero);
-			st4(dec_ptr(w, depth + 1, COMP_U + p) + (q.yc + r) * DEC_STRIDE_C + q.xc, ld4((wnd_kind == 1 ? qs.rec_c[wnd_slot][p] : qs.pred_c[wnd_slot][p]) + r * 4));
+			st4(tq_ptr(w, depth + 1, COMP_U + p) + ((q.abs_index << 4) >> 2) + j * 4, wnd_kind == 1 ? ld4(quad_lv_c<CU>(qs, wnd_slot, p) + j * 4) : zero);
+			st4(dec_ptr(w, depth + 1, COMP_U + p) + (q.yc + r) * DEC_STRIDE_C + q.xc + c0, ld4((wnd_kind == 1 ? quad_rec_c<CU>(qs, wnd_slot, p) : quad_pred_c<CU>(qs, wnd_slot, p)) + r * NC + c0));
 		}
-		if (last_pred >= 0) *(uint32_t *)(w.pred_c[p] + (q.yc + r) * 32 + q.xc) = *(const uint32_t *)(qs.pred_c[last_pred][p] + r * 4);
-	} else if (g.tid < 24 + 4) {
-		// the side info of the CU's four units: put_consolidated_info's copy of the per-depth buffers into the CTU's record (with what the buffers held for `cons`),
-		// then the buffers as `wnd` left them (set_enc_info_buffs), and encode_inter's reference-index write
-		const int k = q.abs_index + (g.tid - 24);
+		if (last_pred >= 0) *(uint32_t *)(w.pred_c[p] + (q.yc + r) * 32 + q.xc + c0) = *(const uint32_t *)(quad_pred_c<CU>(qs, last_pred, p) + r * NC + c0);
+	};
+	// the side info of the CU's units: put_consolidated_info's copy of the per-depth buffers into the CTU's record (with what the buffers held for `cons`), then the
+	// buffers as `wnd` left them (set_enc_info_buffs), and encode_inter's reference-index write
+	auto info = [&](int u) {
+		const int k = q.abs_index + u;
 		if (cons_kind) {
 			const QuadRes &cr = qs.res[cons_slot];
 			c.cbf[0][k] = cons_kind == 1 ? (uint8_t)cr.cbf[0] : (uint8_t)0;
@@ -431,6 +471,16 @@ __device__ __forceinline__ void quad_commit(const WaveGrp g, Enc &__restrict__ e
 			w.tr_idx_buffs[depth][k] = 0;
 		}
 		if (coded_any) c.mv_ref_idx[k] = (int8_t)nd.inter_ref_index;
+	};
+	constexpr int UNITS = CU * CU / 16;
+	if constexpr (CU == 8) {
+		if (g.tid < YL) luma(g.tid);
+		else if (g.tid < YL + CL) chroma(g.tid - YL);
+		else if (g.tid < YL + CL + UNITS) info(g.tid - YL - CL);
+	} else {
+		luma(g.tid);
+		if (g.tid < CL) chroma(g.tid);
+		else if (g.tid < CL + UNITS) info(g.tid - CL);
 	}
 	g.sync();
 }
@@ -438,6 +488,7 @@ __device__ __forceinline__ void quad_commit(const WaveGrp g, Enc &__restrict__ e
 // check_rd_cost_merge (enc_ctu.h) on the slots' results: the same loop, statement for statement, with every evaluation a look-up and every copy deferred to
 // quad_commit.  The slots' figures are fetched once (a slot per lane, then scalar registers) and the node's fields are written once at the end: the loop itself
 // touches no memory.  `slots` from quad_prepare; inter_modes from get_merge_candidates.
+template <int CU>
 __device__ __forceinline__ uint32_t quad_merge_loop(const WaveGrp g, Enc &__restrict__ e, int ni, int slots, const QuadCands &mc, const uint8_t *inter_modes HENC_QPROF_ARG)
 {
 	HENC_ENC_IN_LDS(e);
@@ -538,7 +589,7 @@ __device__ __forceinline__ uint32_t quad_merge_loop(const WaveGrp g, Enc &__rest
 		e.inter_ssq[0] = lr.raw[0]; e.inter_ssq[1] = lr.raw[1]; e.inter_ssq[2] = lr.raw[2];
 		e.inter_ssq_valid = 1;
 	}
-	quad_commit(g, e, ni, curr_depth, cons_slot, cons_kind, wnd_slot, wnd_kind, last_pred, coded_slot >= 0);
+	quad_commit<CU>(g, e, ni, curr_depth, cons_slot, cons_kind, wnd_slot, wnd_kind, last_pred, coded_slot >= 0);
 	HENC_QPROF_MARK(e, 6);      // (the commit)
 	nd.skipped = best_is_skip;
 	nd.inter_mv.x = best_x;

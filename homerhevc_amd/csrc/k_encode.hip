@@ -236,8 +236,8 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 			break;
 		}
 #if defined(HENC_QUAD)
-		case HJOB_QUAD_C:      // the chroma blocks of all merge candidates of an 8 x 8 CU in one pass (enc_quad.h)
-			quad_chroma_job(g, e, a[0]);
+		case HJOB_QUAD_C:      // the chroma blocks of all merge candidates of an 8 x 8 or 16 x 16 CU in one pass (enc_quad.h)
+			quad_chroma_job(g, e, a[0], a[1]);
 			break;
 #endif
 		case HJOB_INTRA_SAD: {
