@@ -205,7 +205,7 @@ def load_checker():
     return lib
 
 
-def random_case(rng, max_ctus, gpu=False, max_cols=14, max_rows=9, threads_only=False, engines_only=False, extra_keys=False):
+def random_case(rng, max_ctus, gpu=False, max_cols=14, max_rows=9, threads_only=False, engines_only=False, extra_keys=False, combos=False):
     while True:
         wc, hc = rng.randint(2, max_cols), rng.randint(1, max_rows)
         if wc * hc > max_ctus:
@@ -222,6 +222,10 @@ def random_case(rng, max_ctus, gpu=False, max_cols=14, max_rows=9, threads_only=
         if not sao:
             keys["sao"] = 0
         mode = "engines" if engines_only else rng.choice(["fixed", "fixed", "rc", "rdfull", "engines"])
+        # --combos (round 6): rate control / RD_FULL with ONE thread (the pool's raster schedule) and with several engines
+        combo = rng.choice(["rc1", "rd1", "rc_eng", "rd_eng"]) if combos else None
+        if combo:
+            mode = "rc" if combo.startswith("rc") else "rdfull"
         if engines_only and not (wc >= 9 or (wc >= 3 and hc <= 4)):
             continue
         wpp = 1
@@ -231,9 +235,15 @@ def random_case(rng, max_ctus, gpu=False, max_cols=14, max_rows=9, threads_only=
                 n = rng.randint(2, hc - 1)
                 if 2 * n >= wc:
                     wpp = n
-        if (mode == "rdfull" or threads_only or engines_only) and wpp < 2:
+        if combo in ("rc1", "rd1"):
+            wpp = 1
+        elif combo:
+            wpp = hc if hc <= 32 else 32
+            if wpp < 2 or not (wc >= 9 or (wc >= 3 and hc <= 4 and combo == "rc_eng")):      # (RD_FULL with several engines: nine or more CTU columns, enc_host.h)
+                continue
+        if (mode == "rdfull" or threads_only or engines_only) and wpp < 2 and not combo:
             continue
-        if gpu and mode in ("rc", "engines") and wpp < 2:       # (the device encoder runs rate control and several engines with one thread per CTU row only)
+        if gpu and mode in ("rc", "engines") and wpp < 2 and not combo:       # (several engines need a thread per CTU row on the device)
             continue
         if wpp > 1:
             keys["wpp"] = wpp
@@ -256,11 +266,16 @@ def random_case(rng, max_ctus, gpu=False, max_cols=14, max_rows=9, threads_only=
             frames = rng.randint(4, 8)
         elif mode == "rdfull":
             keys["rd"] = 1
+            if combo:
+                frames = rng.randint(3, 6)
         elif mode == "engines" and (wc >= 9 or (wc >= 3 and hc <= 4)):      # (narrower: the reference's engines deadlock, enc_host.h)
             keys["engines"] = rng.choice([2, 3, 4])
             frames = rng.randint(5, 14 if engines_only else 10)
         elif rng.random() < 0.25:
             keys["rd"] = 0
+        if combo in ("rc_eng", "rd_eng"):
+            keys["engines"] = rng.choice([2, 3, 4])
+            frames = rng.randint(6, 12)
         if rng.random() < 0.2:
             keys["force_intra"] = 1
         if rng.random() < 0.15 and mode != "engines":
@@ -283,6 +298,7 @@ def main():
     ap.add_argument("--gpu", action="store_true")
     ap.add_argument("--chain-sets", type=int, default=0, help="with --gpu: cases with several engines go through hmr_gpu_enc_encode_chain with this many objects per engine (0: hmr_gpu_enc_encode)")
     ap.add_argument("--extra-keys", action="store_true", help="also draw motion_estimation_precision (me) and chroma_qp_offset (cqo)")
+    ap.add_argument("--combos", action="store_true", help="only rate control / RD_FULL with one WPP thread or with several engines (accepted since round 6)")
     ap.add_argument("--engines-only", action="store_true", help="only cases with several engines and several WPP threads")
     ap.add_argument("--batch", type=int, default=1, help="with --gpu: this many cases per hmr_gpu_enc_encode_batch call (cases the batch call does not take are left out)")
     ap.add_argument("--tolerate-q12", action="store_true", help="do not count a differing case that had evaluations on a stale prediction window (the documented exception) in the exit code")
@@ -311,7 +327,7 @@ def main():
         cases.append((w, h, frames, int(parts[1]) if len(parts) > 1 and parts[1] else 1234, {k: int(v) for k, v in keys.items()}))
     if not cases:
         rng = random.Random(a.seed)
-        cases = [random_case(rng, a.max_ctus, a.gpu, a.max_cols, a.max_rows, a.threads_only, a.engines_only, a.extra_keys) for _ in range(a.cases)]
+        cases = [random_case(rng, a.max_ctus, a.gpu, a.max_cols, a.max_rows, a.threads_only, a.engines_only, a.extra_keys, a.combos) for _ in range(a.cases)]
     bad = q12_bad = 0
     batched = {}
     if a.gpu and a.batch > 1:       # groups of cases the batch call takes (one thread per CTU row or the in-between counts, one engine) share their launches
