@@ -94,9 +94,10 @@ inline bool make_seq(HostCfg cfg, Seq &s, const char **why)
 	{
 		const int wc = (cfg.width + 63) / 64, hc = (cfg.height + 63) / 64;
 		if (cfg.num_enc_engines > 1 && (wc < 3 || (wc < 9 && hc > 4))) { *why = "num_enc_engines > 1 on a picture of fewer than nine CTU columns and more than four CTU rows (the reference's engines deadlock there)"; return false; }
-		// (RD_FULL with several engines on fewer than nine columns: two of 160 random configurations differed from the compiled reference - 6 and 8 columns x 2 rows, SAO on,
-		// tools/encoder_fuzz.py --combos; thirty with nine or more columns and every one without SAO were identical.  Refused until it is understood)
-		if (cfg.num_enc_engines > 1 && cfg.rd_mode == RDM_FULL && wc < 9) { *why = "rd_mode RD_FULL with num_enc_engines > 1 on a picture of fewer than nine CTU columns"; return false; }
+		// RD_FULL with several engines: every engine has coder objects of its own, and a per-engine replay of them (RdCtxSim) reproduces the compiled reference on the
+		// fixtures tried and on most random configurations - but not all (round 6, tools/encoder_fuzz.py --combos: 4 of about 75 differ, on 6 / 8 / 13 / 14 CTU columns,
+		// checker build and device alike).  Not pinned, so refused.
+		if (cfg.num_enc_engines > 1 && cfg.rd_mode == RDM_FULL) { *why = "rd_mode RD_FULL with num_enc_engines > 1"; return false; }
 	}
 	{
 		const int wc = (cfg.width + 63) / 64, hc = (cfg.height + 63) / 64;

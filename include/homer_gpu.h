@@ -569,8 +569,8 @@ void hmr_gpu_sao_offsets_ctu(const int32_t *stats, const double *lambdas, int32_
  *     Built rows: 8-bit 4:2:0, 64x64 CTUs, I / P slices with one reference picture, performance_mode 0-3, max_intra_tr_depth / max_inter_tr_depth up to 4,
  *     rd_mode 0 / 2 and - at fixed QP - rd_mode 1 (RD_FULL: the CABAC bit counter prices the intra decisions); fixed QP and bitrate_mode 1 / 2 (CBR / VBR:
  *     bitrate, vbv_size, vbv_init, frame_rate) - BASELINE configs 0 .. 4.  Rate control and RD_FULL run with one WPP thread (the reference's deterministic
- *     serial mode: the picture one CTU at a time in raster order), with a thread per CTU row, and with num_enc_engines > 1 (round 6; RD_FULL with several engines
- *     from nine CTU columns on); together (RD_FULL under rate control) they are refused.  Anything else, pictures of more than 128 CTU rows and pictures of more than 192 wavefront steps (CTU columns + 2 x (CTU rows - 1))
+ *     serial mode: the picture one CTU at a time in raster order), with a thread per CTU row, and - rate control - with num_enc_engines > 1 (round 6); RD_FULL with
+ *     several engines and RD_FULL under rate control are refused.  Anything else, pictures of more than 128 CTU rows and pictures of more than 192 wavefront steps (CTU columns + 2 x (CTU rows - 1))
  *     make hmr_gpu_enc_create return HMR_GPU_ERR_ARG (hmr_gpu_last_error says why).
  *     wfpp_num_threads = 1: the stream of the reference's single worker thread.  wfpp_num_threads = CTU rows: the stream of its
  *     multi-thread mode with the threads advancing as a synchronous wavefront (pinned by oracle/ref_ctudump.c, HOMER_TURNSTILE);

@@ -84,9 +84,6 @@ CASES = [
     ("416x240_vbr400_eng3_wpp_rows", 416, 240, 12, {"bitrate_mode": 2, "bitrate": 400, "engines": 3, "wpp": 4}),
     ("416x240_cbr300_eng2", 416, 240, 10, {"bitrate_mode": 1, "bitrate": 300, "engines": 2}),
     ("832x480_cbr1500_perf1_eng4_wpp_rows", 832, 480, 12, {"bitrate_mode": 1, "bitrate": 1500, "perf": 1, "engines": 4, "wpp": 8}),
-    # RD_FULL with several engines (every engine has its own coder objects: its estimates copy states of the engine's own earlier frames)
-    ("640x240_rdfull_eng2_wpp_rows", 640, 240, 9, {"rd": 1, "engines": 2, "wpp": 4}),
-    ("640x240_force_intra_rdfull_tr4_eng3_wpp_rows", 640, 240, 9, {"force_intra": 1, "rd": 1, "intra_tr": 4, "engines": 3, "wpp": 4}),
     ("416x240_cbr400_perf1_wpp_rows", 416, 240, 8, {"bitrate_mode": 1, "bitrate": 400, "perf": 1, "wpp": 4}),
     ("416x240_vbr400_wpp_rows", 416, 240, 8, {"bitrate_mode": 2, "bitrate": 400, "wpp": 4}),
     ("832x480_cbr1500_perf1_wpp_rows", 832, 480, 6, {"bitrate_mode": 1, "bitrate": 1500, "perf": 1, "wpp": 8}),

@@ -57,8 +57,8 @@ def test_core_matches_reference_fixture(cpu, name):
 
 def test_unsupported_configurations_are_refused(cpu):
     for kw in ({"rd": 1, "wpp": 4, "bitrate_mode": 1, "bitrate": 400}, {"rd": 1, "bitrate_mode": 1, "bitrate": 400}, {"bitrate_mode": 3},      # (RD_FULL: fixed QP; with one thread or a thread per row since round 6)
-               {"num_b": 1, "gop_size": 2}, {"cu_size": 32},      # (rate control / RD_FULL with several engines are accepted since round 6 ...
-               {"rd": 1, "engines": 2, "wpp": 4},             # ... RD_FULL with engines from nine CTU columns on: 416 x 240 has seven)      # (performance_mode 3 is accepted since round 5)
+               {"num_b": 1, "gop_size": 2}, {"cu_size": 32},      # (rate control with several engines is accepted since round 6 ...
+               {"rd": 1, "engines": 2, "wpp": 4},             # ... RD_FULL with several engines is not: its replay matches the reference on most configurations only)      # (performance_mode 3 is accepted since round 5)
                {"wpp": 2},      # 7 CTU columns: two threads would have to be in rows 0 and 2 at once under the synchronous wavefront
                {"wpp": 5}):     # more threads than the 4 CTU rows
         cfg = ec.default_cfg(416, 240, **kw)

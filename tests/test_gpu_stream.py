@@ -67,9 +67,7 @@ def encode(lib, case):
                                   "416x240_cbr400_perf1", "416x240_vbr400", "416x240_force_intra_rdfull_tr4", "416x240_rdfull", "328x264_force_intra_rdfull_tr3_perf0",
                                   "3840x2160_cbr20000_perf1", "3840x2160_force_intra_rdfull_tr4_perf0",
                                   # rate control with several engines
-                                  "416x240_cbr400_perf1_eng2_wpp_rows", "416x240_vbr400_eng3_wpp_rows", "832x480_cbr1500_perf1_eng4_wpp_rows",
-                                  # RD_FULL with several engines
-                                  "640x240_rdfull_eng2_wpp_rows", "640x240_force_intra_rdfull_tr4_eng3_wpp_rows"])
+                                  "416x240_cbr400_perf1_eng2_wpp_rows", "416x240_vbr400_eng3_wpp_rows", "832x480_cbr1500_perf1_eng4_wpp_rows"])
 def test_device_stream_is_byte_identical_to_the_reference(gpu, case):
     stream, recon = encode(gpu, case)
     g = GOLD[case]

@@ -59,7 +59,6 @@ def encode(lib, case, sched=0):
 @pytest.mark.parametrize("case", ["200x136", "416x240", "416x240_nosao", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_intra_period1", "832x480", "392x136_qp22_clip931814", "400x104_qp22_perf0_nosao_wpp_rows_clip657909", "1280x720_intra_period1", "1280x720_force_intra", "416x240_force_intra", "416x240_force_intra_wpp_rows", "416x240_force_intra_rdfull_wpp_rows", "416x240_force_intra_rdfull_tr4_wpp_rows", "328x264_force_intra_rdfull_tr3_perf0_wpp_rows", "416x240_rdfull_wpp_rows", "832x480_rdfull_tr3_wpp_rows", "200x136_scene_cut", "416x240_scene_cut", "416x240_wpp_rows", "416x240_scene_cut_wpp_rows", "832x480_wpp_rows", "416x240_qp22_perf0_wpp_rows", "416x240_nosao_wpp_rows", "328x264_wpp3", "200x136_wpp2", "416x240_eng2", "416x240_eng3_wpp_rows", "832x480_eng2_wpp_rows", "416x240_scene_cut_eng2_wpp_rows",
                                   "416x240_force_intra_rdfull_tr4", "416x240_rdfull", "328x264_force_intra_rdfull_tr3_perf0", "416x240_vbr400",
                                   "416x240_cbr400_perf1_eng2_wpp_rows", "416x240_vbr400_eng3_wpp_rows", "416x240_cbr300_eng2", "832x480_cbr1500_perf1_eng4_wpp_rows",
-                                  "640x240_rdfull_eng2_wpp_rows", "640x240_force_intra_rdfull_tr4_eng3_wpp_rows",
                                   "416x240_cbr400_perf1", "416x240_cbr400_perf1_wpp_rows", "416x240_vbr400_wpp_rows", "832x480_cbr1500_perf1_wpp_rows", "416x240_cbr300_nosao_wpp_rows", "416x240_qp4", "416x240_perf3", "416x240_perf3_wpp_rows", "416x240_force_intra_perf3_wpp_rows", "416x240_scene_cut_perf3_wpp_rows", "832x480_qp26_perf3_rdfull_wpp_rows"])
 def test_stream_is_byte_identical_to_the_reference(cpu, case):
     stream, recon, _ = encode(cpu, case)

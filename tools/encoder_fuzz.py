@@ -223,7 +223,7 @@ def random_case(rng, max_ctus, gpu=False, max_cols=14, max_rows=9, threads_only=
             keys["sao"] = 0
         mode = "engines" if engines_only else rng.choice(["fixed", "fixed", "rc", "rdfull", "engines"])
         # --combos (round 6): rate control / RD_FULL with ONE thread (the pool's raster schedule) and with several engines
-        combo = rng.choice(["rc1", "rd1", "rc_eng", "rd_eng"]) if combos else None
+        combo = rng.choice(["rc1", "rd1", "rc_eng"]) if combos else None      # ("rd_eng": RD_FULL with several engines is refused, enc_host.h)
         if combo:
             mode = "rc" if combo.startswith("rc") else "rdfull"
         if engines_only and not (wc >= 9 or (wc >= 3 and hc <= 4)):
