@@ -86,4 +86,4 @@ def test_ring_line_is_compact():
 def test_describe_keys():
     assert bench.describe_keys({}) == "IPPP QP32"
     assert bench.describe_keys(bench.WORKLOADS["cfg3-2160p-cbr"][2]) == "IPPP CBR 20000 kbps perf=1"
-    assert bench.describe_keys(bench.WORKLOADS["cfg5-2160p-intra-rdfull"][2]) == "all-intra QP32 rd=1 intra_tr=4"
+    assert bench.describe_keys(bench.WORKLOADS["cfg5-2160p-intra-rdfull"][2]) == "all-intra QP32 rd=1 intra_tr=4 perf=0"
