@@ -174,7 +174,6 @@ HENC_HD int intra_mode_search(const G g, Enc &__restrict__ e, int ni, int depth,
 		}
 		e.n_spec_reads++;
 	}
-	pred_t *pred = w.pred_y + q.y * CTU_STRIDE_Y + q.x;
 	const src_t *orig = w.curr_y + q.y * CTU_STRIDE_Y + q.x;
 	return intra_search_walk_batched(preds, rd_fast, e.f->sqrt_lambda, [&](const int *modes, int cnt, int64_t *sads) -> bool {
 		// with helper wavefronts: rounds of 1 + NHELP candidates, the worker always taking the last one of the round (so that the prediction
@@ -184,7 +183,8 @@ HENC_HD int intra_mode_search(const G g, Enc &__restrict__ e, int ni, int depth,
 			for (int j = 0; j < take - 1; j++) helper_post(g, e, j, HJOB_INTRA_SAD, ni, n, modes[k0 + j], intra_is_filtered(modes[k0 + j], inv_depth));
 			{
 				const int mode = modes[mine], filt = intra_is_filtered(mode, inv_depth);
-				sads[mine] = (int64_t)intra_predict_sad(g, pred, CTU_STRIDE_Y, orig, CTU_STRIDE_Y, filt ? w.adi_f : w.adi, n, mode, 1);
+				// (the prediction is not stored: the transform tree that follows predicts every sample of this block again before anything reads the window)
+				sads[mine] = (int64_t)intra_predict_sad(g, (pred_t *)nullptr, 0, orig, CTU_STRIDE_Y, filt ? w.adi_f : w.adi, n, mode, 1);
 			}
 			for (int j = 0; j < take - 1; j++) {
 				helper_wait(g, e, j);

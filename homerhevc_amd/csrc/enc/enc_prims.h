@@ -543,7 +543,9 @@ struct IntraPredictor {
 	int is_ver, angle, inv_angle, edge_filter;
 };
 
-HENC_INLINE IntraPredictor intra_setup(const int16_t *adi, int n, int mode, int is_luma)
+// (the DC value: the 2 n samples beside the block, one per lane and a sum over the group - every lane adding all of them itself is 2 n dependent reads)
+template <class G>
+HENC_INLINE IntraPredictor intra_setup(const G g, const int16_t *adi, int n, int mode, int is_luma)
 {
 	IntraPredictor p;
 	p.mid = adi + 2 * n;
@@ -556,7 +558,8 @@ HENC_INLINE IntraPredictor intra_setup(const int16_t *adi, int n, int mode, int 
 	} else if (mode == DC_IDX) {
 		p.kind = 1;
 		int acc = 0;
-		for (int i = 1; i <= n; i++) acc += p.mid[i] + p.mid[-i];
+		for (int i = g.tid; i < 2 * n; i += g.n) acc += i < n ? p.mid[i + 1] : p.mid[-(i - n + 1)];
+		acc = (int)g.sum((uint32_t)acc);
 		p.dc = (uint8_t)(uint16_t)((acc + n) / (2 * n));
 		p.edge_filter = n <= 16 && is_luma;
 	} else {
@@ -618,7 +621,8 @@ template <class G, class P>
 HENC_PRIM void intra_predict(const G g, P *pred, int ps, const int16_t *adi, int n, int mode, int is_luma)
 {
 	PRIM_T0();
-	const IntraPredictor p = intra_setup(adi, n, mode, is_luma);
+	if constexpr (G::n == 64) { mode = uni(mode); n = uni(n); is_luma = uni(is_luma); }      // (a search's winner arrives in a vector register: what depends on it is scalar again)
+	const IntraPredictor p = intra_setup(g, adi, n, mode, is_luma);
 	const int l = p.shift;
 	#pragma unroll 4
 	for (int k = g.tid; k < n * n; k += g.n) {
@@ -634,7 +638,8 @@ template <class G, class S, class P>
 HENC_PRIM uint32_t intra_predict_sad(const G g, P *pred, int ps, const S *orig, int os, const int16_t *adi, int n, int mode, int is_luma)
 {
 	PRIM_T0();
-	const IntraPredictor p = intra_setup(adi, n, mode, is_luma);
+	if constexpr (G::n == 64) { mode = uni(mode); n = uni(n); is_luma = uni(is_luma); }
+	const IntraPredictor p = intra_setup(g, adi, n, mode, is_luma);
 	const int l = p.shift;
 	uint32_t acc = 0;
 	#pragma unroll 4
