@@ -9,6 +9,7 @@ import os
 
 import pytest
 
+import decoder_check
 import encoder_cases as ec
 import libs
 
@@ -32,7 +33,7 @@ def gpu():
     return lib
 
 
-def encode(lib, case):
+def encode(lib, case, raw_recon=None):
     g = GOLD[case]
     w, h, frames = g["width"], g["height"], g["frames"]
     keys = dict(g["keys"])
@@ -52,6 +53,8 @@ def encode(lib, case):
         assert st in (1, 2), lib.hmr_gpu_last_error()
         stream += buf.raw[:nbytes.value]
         recon.append(hashlib.md5(rec.raw).hexdigest())
+        if raw_recon is not None:
+            raw_recon.append(rec.raw)
         p, n, ms, tot = C.c_int(), C.c_int(), C.c_float(), C.c_float()
         lib.hmr_gpu_enc_last_stats(enc, C.byref(p), C.byref(n), C.byref(ms), C.byref(tot))
         log.append(f"f{f}: {p.value} passes {n.value} encodes {ms.value:.1f}/{tot.value:.1f} ms")
@@ -69,12 +72,15 @@ def encode(lib, case):
                                   # rate control with several engines
                                   "416x240_cbr400_perf1_eng2_wpp_rows", "416x240_vbr400_eng3_wpp_rows", "832x480_cbr1500_perf1_eng4_wpp_rows"])
 def test_device_stream_is_byte_identical_to_the_reference(gpu, case):
-    stream, recon = encode(gpu, case)
+    raw = []
+    stream, recon = encode(gpu, case, raw_recon=raw)
     g = GOLD[case]
     first_bad = next((f for f in range(g["frames"]) if recon[f] != g["recon_md5"][f]), None)
     assert first_bad is None, f"reconstructed picture {first_bad} differs"
     assert len(stream) == g["stream_bytes"]
     assert hashlib.md5(stream).hexdigest() == g["stream_md5"]
+    # the decoder-side check: what the device wrote decodes (sub-stream ends, entry points, ranges) to the pictures the device reconstructed (tests/decoder_check.py)
+    decoder_check.check(stream, g, case, raw)
 
 
 def test_batch_of_sequences_in_one_launch(gpu):

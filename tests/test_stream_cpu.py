@@ -10,6 +10,7 @@ import subprocess
 
 import pytest
 
+import decoder_check
 import encoder_cases as ec
 import libs
 
@@ -31,7 +32,7 @@ def cpu():
     return lib
 
 
-def encode(lib, case, sched=0):
+def encode(lib, case, sched=0, raw_recon=None):
     g = GOLD[case]
     w, h, frames = g["width"], g["height"], g["frames"]
     keys = dict(g["keys"])
@@ -50,6 +51,8 @@ def encode(lib, case, sched=0):
         assert n > 0
         stream += buf.raw[:n]
         recon.append(hashlib.md5(rec.raw).hexdigest())
+        if raw_recon is not None:
+            raw_recon.append(rec.raw)
     st = (C.c_int * 3)()
     lib.henc_cpu_sched_stats(enc, st, 0)
     lib.henc_cpu_destroy(enc)
@@ -61,11 +64,13 @@ def encode(lib, case, sched=0):
                                   "416x240_cbr400_perf1_eng2_wpp_rows", "416x240_vbr400_eng3_wpp_rows", "416x240_cbr300_eng2", "832x480_cbr1500_perf1_eng4_wpp_rows",
                                   "416x240_cbr400_perf1", "416x240_cbr400_perf1_wpp_rows", "416x240_vbr400_wpp_rows", "832x480_cbr1500_perf1_wpp_rows", "416x240_cbr300_nosao_wpp_rows", "416x240_qp4", "416x240_perf3", "416x240_perf3_wpp_rows", "416x240_force_intra_perf3_wpp_rows", "416x240_scene_cut_perf3_wpp_rows", "832x480_qp26_perf3_rdfull_wpp_rows"])
 def test_stream_is_byte_identical_to_the_reference(cpu, case):
-    stream, recon, _ = encode(cpu, case)
+    raw = []
+    stream, recon, _ = encode(cpu, case, raw_recon=raw)
     g = GOLD[case]
     assert len(stream) == g["stream_bytes"]
     assert hashlib.md5(stream).hexdigest() == g["stream_md5"]
     assert recon == g["recon_md5"]
+    decoder_check.check(stream, g, case, raw)      # ... and a decoder reconstructs from it what the reference encoder reconstructed (tests/decoder_check.py)
 
 
 def test_stream_matches_the_ctu_fixture_stream(cpu):
