@@ -424,6 +424,7 @@ struct PoolSeq {
 };
 constexpr int POOL_MAX_STEPS = HENC_MAX_STEPS;  // W + 2 (H - 1): enc_host.h refuses pictures with more wavefront steps
 constexpr int POOL_STRIDE = 1 + 2 * POOL_MAX_STEPS;
+constexpr int BATCH_MAX = 512;      // pictures of one launch (hmr_gpu_enc_encode_batch: sequences per call); the pool's state rows and the batch's staging arrays are sized for it
 
 // rows of step t: r_lo .. r_hi (empty when r_lo > r_hi)
 __device__ __forceinline__ void pool_step_rows(int t, int W, int H, int *r_lo, int *r_hi)

@@ -621,8 +621,8 @@ int hmr_gpu_enc_encode_source(hmr_gpu_enc *enc, int slot, int image_type, uint8_
 /* one frame of each of n sequences with ONE launch for all their CTU stages: encs[i] encodes its resident picture slots[i] (image_types may be NULL: automatic)
  * into streams[i] (capacity caps[i], size stream_bytes[i]).  The encoders use the row-per-thread schedule (wfpp_num_threads > 1) and the same device; the access
  * units are those hmr_gpu_enc_encode_source gives one by one.  The launch is a pool of persistent row workers (four per CU; as many as the pictures can keep busy)
- * that claim CTUs of any of the n pictures whose wavefront step is open (k_encode_pool); n is at most 256, a few hundred pictures' worth of CTU rows saturate the pool
- * (120 at 1080p, 256 keep it busy through the pictures' ramps).  A worker never waits for a CTU that is not already running, so the launch does not depend on all its
+ * that claim CTUs of any of the n pictures whose wavefront step is open (k_encode_pool); n is at most 512, a few hundred pictures' worth of CTU rows saturate the pool
+ * (120 at 1080p; a launch costs about 110 ms of ramps on top of 1.7 ms per 1080p picture, so more pictures per launch amortise it: 256 -> 512 is +10 %).  A worker never waits for a CTU that is not already running, so the launch does not depend on all its
  * workgroups being resident; a watchdog (HENC_WATCHDOG_S seconds, fractions allowed, 120 by default) makes a launch in which a worker has found nothing to do - no CTU
  * to decide, no post-decision task - for that long SINCE IT LAST DID return HMR_GPU_ERR_HIP instead of hanging. */
 int hmr_gpu_enc_encode_batch(hmr_gpu_enc **encs, int n, const int *slots, const int *image_types, uint8_t **streams, const long *caps, long *stream_bytes);

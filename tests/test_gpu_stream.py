@@ -130,6 +130,40 @@ def test_batch_of_sequences_in_one_launch(gpu):
     lib.hmr_gpu_enc_destroy(enc)
 
 
+def test_batch_of_300_sequences_in_one_launch(gpu):
+    """more pictures in one launch than round 5's cap of 256 (BATCH_MAX = 512: the pool's state rows, the staging arrays and the gather buffer are sized by it): 300
+    sequences of the 200x136_wpp2 fixture, every stream the fixture's; 513 are refused"""
+    lib = gpu
+    lib.hmr_gpu_enc_load_source.argtypes = [C.c_void_p, C.c_int] + [C.c_char_p] * 3
+    lib.hmr_gpu_enc_encode_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    case, n = "200x136_wpp2", 300
+    g = GOLD[case]
+    clip = list(ec.clip_frames(g["width"], g["height"], g["frames"], None))
+    cfg = ec.default_cfg(g["width"], g["height"], **g["keys"])
+    encs = []
+    for _ in range(n):
+        enc = C.c_void_p()
+        assert lib.hmr_gpu_enc_create(lib._ctx, C.byref(cfg), C.byref(enc)) == 0, lib.hmr_gpu_last_error()
+        for f, planes in enumerate(clip):
+            assert lib.hmr_gpu_enc_load_source(enc, f, *planes) == 0, lib.hmr_gpu_last_error()
+        encs.append(enc)
+    bufs = [C.create_string_buffer(1 << 16) for _ in range(n)]
+    out = [b""] * n
+    e_arr = (C.c_void_p * n)(*encs)
+    ptrs = (C.c_char_p * n)(*[C.cast(b, C.c_char_p) for b in bufs])
+    caps = (C.c_long * n)(*[len(b) for b in bufs])
+    got = (C.c_long * n)()
+    for f in range(g["frames"]):
+        assert lib.hmr_gpu_enc_encode_batch(e_arr, n, (C.c_int * n)(*([f] * n)), None, ptrs, caps, got) == 0, lib.hmr_gpu_last_error()
+        for i in range(n):
+            out[i] += bufs[i].raw[:got[i]]
+    assert {hashlib.md5(o).hexdigest() for o in out} == {g["stream_md5"]}
+    big = (C.c_void_p * 513)(*([encs[0]] * 513))
+    assert lib.hmr_gpu_enc_encode_batch(big, 513, (C.c_int * 513)(), None, (C.c_char_p * 513)(), (C.c_long * 513)(), (C.c_long * 513)()) != 0
+    for enc in encs:
+        lib.hmr_gpu_enc_destroy(enc)
+
+
 def test_stale_window_count_is_the_same_frame_by_frame_and_in_a_batch(gpu):
     """hmr_gpu_enc_stale_predictions (quirk Q12: merge candidates evaluated on what the thread's prediction window held) is the API's only indicator that byte identity may
     not hold: the batch call must count a picture once (it used to count it twice) and agree with the frame-by-frame count of the same clip - which has such evaluations."""

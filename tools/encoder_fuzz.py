@@ -28,6 +28,8 @@ import encoder_cases as ec  # noqa: E402
 import gen_yuv  # noqa: E402
 
 CPU_SO = os.path.join(ROOT, "oracle", "libenc_cpu.so")
+DECODE = False      # --decode: the reference's stream also goes through oracle/hevcdec, decoded pictures against the reference's own reconstruction
+LAST_RECON = None
 STALE = 0      # evaluations on a stale prediction window (quirk Q12) in the case just encoded; -1: not counted
 
 
@@ -40,11 +42,38 @@ def reference(width, height, frames, clip_seed, keys):
         turnstile = int(keys.get("wpp", 1)) > 1 or int(keys.get("engines", 1)) > 1
         cmd = [os.path.join(ROOT, "oracle", "_ref", "ref_ctudump" if turnstile else "ref_lockstep"), yuv, os.path.join(tmp, "out.265"), str(width), str(height), str(frames)]
         cmd += [f"{k}={v}" for k, v in keys.items()]
+        global LAST_RECON
+        LAST_RECON = None
+        if DECODE:
+            cmd.append("recon=" + os.path.join(tmp, "rec.yuv"))
         try:
             subprocess.run(cmd, check=True, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, HOMER_TURNSTILE="1") if turnstile else None)
         except (subprocess.TimeoutExpired, subprocess.CalledProcessError) as e:      # (the reference has configurations it deadlocks or crashes on)
             return type(e).__name__
+        if DECODE:
+            LAST_RECON = open(os.path.join(tmp, "rec.yuv"), "rb").read()
         return open(os.path.join(tmp, "out.265"), "rb").read()
+
+
+def decoder_verdict(stream, recon, width, height, keys, stale):
+    """the reference's stream through oracle/hevcdec (a decoder written from the standard, test infrastructure): 'identical', or which documented drift of the reference
+    explains the difference (R1 rate control, R2 quirk Q12), or 'UNEXPLAINED'"""
+    with tempfile.TemporaryDirectory() as tmp:
+        open(os.path.join(tmp, "in.265"), "wb").write(stream)
+        r = subprocess.run([os.path.join(ROOT, "oracle", "hevcdec"), os.path.join(tmp, "in.265"), os.path.join(tmp, "dec.yuv")], capture_output=True, text=True)
+        if r.returncode:
+            return "UNEXPLAINED: hevcdec " + r.stderr.strip()
+        dec = open(os.path.join(tmp, "dec.yuv"), "rb").read()
+    if dec == recon:
+        return "identical"
+    fsz = width * height * 3 // 2
+    first = next((i for i in range(len(recon) // fsz) if dec[i * fsz:(i + 1) * fsz] != recon[i * fsz:(i + 1) * fsz]), -1)
+    if int(keys.get("bitrate_mode", 0)):
+        return f"R1 (rate control: deblocking QP) from picture {first}"
+    if stale > 0:
+        return f"R2 (quirk Q12) from picture {first}"
+    return f"UNEXPLAINED: pictures differ from {first}"
+
 
 
 def checker(lib, width, height, frames, clip_seed, keys):
@@ -302,8 +331,14 @@ def main():
     ap.add_argument("--engines-only", action="store_true", help="only cases with several engines and several WPP threads")
     ap.add_argument("--batch", type=int, default=1, help="with --gpu: this many cases per hmr_gpu_enc_encode_batch call (cases the batch call does not take are left out)")
     ap.add_argument("--tolerate-q12", action="store_true", help="do not count a differing case that had evaluations on a stale prediction window (the documented exception) in the exit code")
+    ap.add_argument("--decode", action="store_true", help="also decode the reference's stream with oracle/hevcdec and compare the pictures with the reference's own reconstruction")
     ap.add_argument("specs", nargs="*")
     a = ap.parse_args()
+    global DECODE
+    DECODE = a.decode
+    if DECODE:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "hevcdec")])
+    dec_counts = {}
     ctx = None
     if a.gpu:
         import libs
@@ -374,7 +409,13 @@ def main():
         bad += not ok
         stale = STALE
         q12 = f" [{stale} evaluations on a stale prediction window: quirk Q12]" if stale > 0 else ""
-        print(spec, len(ref), "bytes", hashlib.md5(ref).hexdigest(), ("IDENTICAL" + q12) if ok else f"DIFFERENT (mine: {len(mine)} bytes){q12}", flush=True)
+        dv = ""
+        if DECODE and LAST_RECON is not None:
+            verdict = decoder_verdict(ref, LAST_RECON, w, h, keys, stale)
+            dec_counts[verdict.split(" ")[0].rstrip(":")] = dec_counts.get(verdict.split(" ")[0].rstrip(":"), 0) + 1
+            dv = "; decoded: " + verdict
+            bad += verdict.startswith("UNEXPLAINED")
+        print(spec, len(ref), "bytes", hashlib.md5(ref).hexdigest(), (("IDENTICAL" + q12) if ok else f"DIFFERENT (mine: {len(mine)} bytes){q12}") + dv, flush=True)
         if not ok and stale > 0:
             q12_bad += 1
         if not ok:          # which access unit: the reference's stream cut at the lengths of mine
@@ -386,6 +427,8 @@ def main():
                 cl = load_checker()
                 cu = checker(cl, w, h, frames, clip_seed, keys)
                 print("    checker build:", "identical to the reference" if cu is not None and b"".join(cu) == ref else "differs too", [len(u) for u in cu or []], flush=True)
+    if DECODE:
+        print("decoder-side check of the reference's streams:", dec_counts)
     if q12_bad:
         print(f"{q12_bad} of the {bad} differing cases had evaluations on a stale prediction window (include/homer_gpu.h: hmr_gpu_enc_stale_predictions)")
     return bad - q12_bad if a.tolerate_q12 else bad
