@@ -15,13 +15,14 @@
  *   - end_of_slice_segment_flag is 1 exactly after the picture's last CTU and the slice data end with it;
  *   - syntax element ranges (intra modes, merge index, cu_qp_delta, coefficient positions, QP range).
  * The decoded pictures are written as 8-bit planar YUV; tests/test_decoder_check.py compares them with the reconstruction the
- * compiled reference encoder itself dumped (ref_lockstep recon=...), and tests/test_gpu_decoder_check.py with the device's.
+ * compiled reference encoder itself dumped (ref_lockstep recon=...) - for the checker build in tests/test_stream_cpu.py, for the device in tests/test_gpu_stream.py.
  *
  * What it found in the reference encoder: two cases in which the encoder's own reconstruction is NOT what a decoder
- * reconstructs from its stream - (R1) under rate control the encoder deblocks the coding units of a CTU that precede the CTU's first coded
- * cu_qp_delta with the CTU's rate-control QP, a decoder (8.6.1) with the predicted QP; (R2) quirk Q12, a merge candidate far outside the
- * picture predicted from a stale window.  `--ref-deblock-qp` makes this decoder deblock like the reference encoder does in case R1, so that
- * a test can show that this and nothing else is the difference.
+ * reconstructs from its stream - (R1) under rate control the encoder deblocks coding units whose QP the stream does not carry (those of a CTU
+ * that precede its first coded cu_qp_delta, or all of a CTU without one) with its rate-control QP or with the predicted one, depending on
+ * how far its lagged filter / entropy pipeline has got; a decoder (8.6.1) always uses the predicted QP; (R2) quirk Q12, a merge candidate far
+ * outside the picture predicted from a stale window.  `--ref-deblock-qp` deblocks every coding unit of a CTU that has a coded delta with
+ * that CTU's QP: where the stream lets a decoder know the encoder's QP this reproduces the reference (tests/test_decoder_check.py).
  *
  * usage: hevcdec in.265 out.yuv|- [-v] [--ref-deblock-qp]          prints "DECODED pictures=N ..." on success
  */
@@ -861,7 +862,7 @@ static int nb_inter(int xp, int yp, int xn, int yn)
 	return avail_z(xp, yp, xn, yn) && u_pm[U(xn, yn)] == PM_INTER;
 }
 
-static void prediction_unit(CU *cu, int x0, int y0, int w, int h)      /* 7.3.8.6, 8.5.3.2 */
+static int prediction_unit(CU *cu, int x0, int y0, int w, int h)      /* 7.3.8.6, 8.5.3.2; returns merge_flag */
 {
 	int merge = cu->skip, merge_idx = 0, mvx = 0, mvy = 0;
 	if (!cu->skip) merge = ae_ctx(C_MERGE_FLAG);
@@ -932,9 +933,7 @@ static void prediction_unit(CU *cu, int x0, int y0, int w, int h)      /* 7.3.8.
 	inter_predict(0, x0, y0, w, h, mvx, mvy);
 	inter_predict(1, x0 / 2, y0 / 2, w / 2, h / 2, mvx, mvy);
 	inter_predict(2, x0 / 2, y0 / 2, w / 2, h / 2, mvx, mvy);
-	cu->skip = cu->skip;
-	/* a merged 2Nx2N block has no rqt_root_cbf: tell the caller */
-	cu->intra_c = merge;      /* (scratch use: merge flag of the PU, read by coding_unit for inter CUs only) */
+	return merge;      /* (a merged 2Nx2N block has no rqt_root_cbf) */
 }
 
 static void coding_unit(int x0, int y0, int log2cb)      /* 7.3.8.5 */
@@ -957,7 +956,7 @@ static void coding_unit(int x0, int y0, int log2cb)      /* 7.3.8.5 */
 		}
 	if (cu.skip) {
 		for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) u_pm[U(x, y)] = PM_NONE;      /* (not yet available to itself) */
-		prediction_unit(&cu, x0, y0, n, n);
+		(void)prediction_unit(&cu, x0, y0, n, n);
 		rqt_root = 0;
 	} else {
 		if (sl.type != 2) cu.pred_mode = ae_ctx(C_PRED_MODE) ? PM_INTRA : PM_INTER;
@@ -1015,9 +1014,7 @@ static void coding_unit(int x0, int y0, int log2cb)      /* 7.3.8.5 */
 			cu.max_trafo_depth = sps.max_th_intra + cu.intra_split;
 		} else {
 			for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) u_pm[U(x, y)] = PM_NONE;
-			prediction_unit(&cu, x0, y0, n, n);
-			merge2n = cu.intra_c;
-			cu.intra_c = 0;
+			merge2n = prediction_unit(&cu, x0, y0, n, n);
 			if (!merge2n) rqt_root = ae_ctx(C_RQT_ROOT);
 			cu.max_trafo_depth = sps.max_th_inter;
 		}
@@ -1096,7 +1093,7 @@ static void deblock_luma_edge(uint8_t *s, int xs, int ys, int bs, int qp)      /
 #undef P
 #undef Q
 }
-static void deblock_chroma_edge(uint8_t *s, int xs, int ys, int qp_avg, int off)      /* two chroma lines per 4 luma lines are handled by the caller: here 4 chroma lines? no: 2 */
+static void deblock_chroma_edge(uint8_t *s, int xs, int ys, int qp_avg, int off)      /* the two chroma lines that belong to a four-line luma segment */
 {
 	const int qpc = chroma_qp(qp_avg, off), tc = tc_tab[clip3(0, 53, qpc + 2)];
 	for (int k = 0; k < 2; k++) {
