@@ -127,11 +127,11 @@ def headline_line(out):
     if ss:
         line["single_sequence"] = {"value": ss.get("value"), "stream_matches_reference": ss.get("stream_matches_reference"),
                                    "engines_overlapped": [pick(lane, "workload", "frames_per_s_full_chains", "stream_matches_reference") for lane in ss.get("engines_overlapped", [])]}
-    for name in ("single_thread_order", "at_2160p", "cfg3_2160p_cbr", "cfg5_2160p_intra_rdfull"):
+    for name in ("single_thread_order", "serial_order_batch", "at_2160p", "cfg3_2160p_cbr", "cfg5_2160p_intra_rdfull"):
         sec = out.get(name)
         if isinstance(sec, dict):
             d = pick(sec, "value", "stream_matches_reference")
-            d["sequences"] = (sec.get("config") or {}).get("sequences_per_gpu")
+            d["sequences"] = sec.get("sequences") or (sec.get("config") or {}).get("sequences_per_gpu")
             d["alone"] = (sec.get("single_sequence") or {}).get("value")
             d["cpu"] = (sec.get("cpu_baseline") or {}).get("value")
             d["cpu_one_process"] = ((sec.get("cpu_baseline") or {}).get("one_process") or {}).get("value")
@@ -166,6 +166,7 @@ def load_lib():
     import encoder_cases as ec
     lib.hmr_gpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
     lib.hmr_gpu_enc_create.argtypes = [C.c_void_p, C.POINTER(ec.EncCfg), C.POINTER(C.c_void_p)]
+    lib.hmr_gpu_enc_create_serial_pool.argtypes = lib.hmr_gpu_enc_create.argtypes
     lib.hmr_gpu_enc_load_source.argtypes = [C.c_void_p, C.c_int] + [C.c_char_p] * 3
     lib.hmr_gpu_enc_encode_source.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_long, C.POINTER(C.c_long), C.c_char_p]
     lib.hmr_gpu_enc_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -571,6 +572,18 @@ def main():
             if a.sequences > 1:
                 big1 = run_workload(lib, b, "cfg2-2160p-encode", world, rank, local, torch)
                 out["at_2160p"]["single_sequence"] = {k: big1[k] for k in ("value", "ms_per_step", "stream_matches_reference")}
+        if world == 1 and a.workload == "cfg2-1080p-encode" and not a.no_single_thread_order and a.sequences > 1:
+            # the reference's deterministic single-thread order (wfpp_num_threads = 1: BASELINE.md's parity mode, md5 2f0c3447... for the published clip, no pinned
+            # interleaving) as a BATCH: hmr_gpu_enc_create_serial_pool runs a picture CTU by CTU in raster order as tasks of the pool - one decision in flight per
+            # picture, so the launch takes the batch call's maximum of 512 pictures
+            import copy
+            b = copy.copy(a)
+            b.warmup, b.steps = 2, 4
+            ser = run_workload(lib, b, "cfg2-1080p-encode-single-thread-order", world, rank, local, torch, sequences=512, serial_pool=True)
+            out["serial_order_batch"] = {k: ser[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "stream_md5", "stream_matches_reference", "frames_checked_against_reference", "clips")}
+            out["serial_order_batch"]["sequences"] = 512
+            out["serial_order_batch"]["note"] = ("wfpp_num_threads = 1, the reference's single-thread order, 512 sequences (eight clips) per launch: every stream equal to the plain "
+                                                 "reference's (ref_lockstep, no turnstile); one sequence alone in this order: single_thread_order")
         if world == 1 and a.workload == "cfg2-1080p-encode" and not a.no_single_thread_order:
             # ONE sequence with its engines overlapped on this GPU (hmr_gpu_enc_encode_chain: the frames of a chain in one launch of the CTU kernel, every engine
             # starting its next frame when its last is finished; tools/chain_bench.py): the reference's num_enc_engines pipeline, streams checked against its digests
@@ -750,7 +763,7 @@ def run_engine_ring(a, world, rank, local, torch, adapter=None):
     }
 
 
-def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
+def run_workload(lib, a, workload, world, rank, local, torch, sequences=1, serial_pool=False):
     """`sequences` independent sequences of the workload per GPU: 1 = hmr_gpu_enc_encode_source frame by frame; more = one batch call per step (ONE launch for the
     CTU stages of all of them: a pool of CTU tasks on four row workers per CU; the pipelined call by default, whose access units come with the next call), every
     access unit kept and checked against the reference's digests after the timed region."""
@@ -759,7 +772,8 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
     keys = dict(keys)
     image_type = 3 if keys.pop("force_intra", 0) else 0      # (encoder_in_out_t.image_type: IMAGE_I on every picture)
     nframes = a.warmup + a.steps
-    S = sequences if int(keys.get("wpp", 1)) > 1 else 1
+    # (serial_pool: wfpp_num_threads = 1 as a batch - hmr_gpu_enc_create_serial_pool, the pool's raster schedule)
+    S = sequences if int(keys.get("wpp", 1)) > 1 or serial_pool else 1
     # sequence i encodes clip i mod 8 where the reference's digests of that clip cover the run (else the published clip)
     seeds = [sd for sd in CLIP_SEEDS if REFERENCE_MD5.get(seed_workload(workload, sd), {}).get("frames", 0) >= nframes] if S > 1 else []
     if not seeds or os.environ.get("HOMER_BENCH_ONE_CLIP"):
@@ -771,7 +785,7 @@ def run_workload(lib, a, workload, world, rank, local, torch, sequences=1):
         ctx, enc = C.c_void_p(), C.c_void_p()
         assert lib.hmr_gpu_create(C.byref(ctx), local, None) == 0, lib.hmr_gpu_last_error()
         cfg = ec.default_cfg(width, height, **keys)
-        assert lib.hmr_gpu_enc_create(ctx, C.byref(cfg), C.byref(enc)) == 0, lib.hmr_gpu_last_error()
+        assert (lib.hmr_gpu_enc_create_serial_pool if serial_pool else lib.hmr_gpu_enc_create)(ctx, C.byref(cfg), C.byref(enc)) == 0, lib.hmr_gpu_last_error()
         for f, planes in enumerate(clips[seeds[i % len(seeds)]]):
             assert lib.hmr_gpu_enc_load_source(enc, f, *planes) == 0, lib.hmr_gpu_last_error()
         encs.append(enc)

@@ -593,6 +593,11 @@ typedef struct hmr_gpu_enc hmr_gpu_enc;
 
 /* HOMER_enc_init + HOMER_enc_control(HOMER_SETCFG) */
 int hmr_gpu_enc_create(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, hmr_gpu_enc **out);
+/* The same for BATCHES of sequences in the reference's deterministic single-thread order (wfpp_num_threads = 1, num_enc_engines = 1: BASELINE.md's parity mode, the
+ * stream of the plain reference without any pinned interleaving): the object's pictures run CTU by CTU in raster order as tasks of the batch launch (section 12b) - one
+ * decision in flight per picture, the post-decision tasks beside it - so it takes many pictures per launch to fill the device.  An object made by hmr_gpu_enc_create with
+ * one thread, fixed QP and RD_FAST runs the guess / verify / re-encode schedule instead: faster for ONE sequence, not a batch schedule (the batch calls refuse it). */
+int hmr_gpu_enc_create_serial_pool(hmr_gpu_ctx *ctx, const hmr_gpu_enc_cfg *cfg, hmr_gpu_enc **out);
 /* HOMER_enc_close */
 void hmr_gpu_enc_destroy(hmr_gpu_enc *enc);
 /* bytes of one per-CTU record of hmr_gpu_enc_frame_ctus (layout of oracle/ref_ctudump.c) */

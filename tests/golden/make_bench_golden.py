@@ -50,6 +50,8 @@ CLIP_SEEDS = [1234, 1, 2, 3, 4, 5, 6, 7]
 for _seed in CLIP_SEEDS[1:]:
     CASES[f"cfg2-1080p-encode-seed{_seed}"] = (1920, 1080, 24, {"wpp": 17}, _seed)
     CASES[f"cfg2-2160p-encode-seed{_seed}"] = (3840, 2160, 6, {"wpp": 32}, _seed)
+    # ... and in the single-thread order (bench.py's serial_order_batch: hmr_gpu_enc_create_serial_pool), minted by the plain ref_lockstep
+    CASES[f"cfg2-1080p-encode-single-thread-order-seed{_seed}"] = (1920, 1080, 24, {}, _seed)
 
 
 def access_unit_ends(stream):

@@ -164,6 +164,47 @@ def test_batch_of_300_sequences_in_one_launch(gpu):
         lib.hmr_gpu_enc_destroy(enc)
 
 
+def test_serial_order_batch(gpu):
+    """hmr_gpu_enc_create_serial_pool: sequences in the reference's deterministic single-thread order (wfpp_num_threads = 1) as ONE batch - the pool's raster schedule, a CTU
+    at a time per picture.  The fixtures are the plain reference's (ref_lockstep, no pinned interleaving): fixed QP, RD_FAST, incl. a scene cut, forced intra pictures,
+    performance_mode 0 and 3, and the one the merge shortcut of round 3 got wrong."""
+    lib = gpu
+    lib.hmr_gpu_enc_create_serial_pool.argtypes = [C.c_void_p, C.POINTER(ec.EncCfg), C.POINTER(C.c_void_p)]
+    lib.hmr_gpu_enc_load_source.argtypes = [C.c_void_p, C.c_int] + [C.c_char_p] * 3
+    lib.hmr_gpu_enc_encode_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    cases = ["416x240", "200x136_scene_cut", "416x240_qp22_perf0", "328x264_qp38_nosbh", "416x240_nosao", "416x240_force_intra", "392x136_qp22_clip931814", "416x240_perf3", "832x480"]
+    encs, frames, itype = [], [], []
+    for case in cases:
+        g = GOLD[case]
+        keys = dict(g["keys"])
+        assert int(keys.get("wpp", 1)) == 1 and int(keys.get("engines", 1)) == 1
+        cut_at, seed = keys.pop("cut_at", None), keys.pop("clip_seed", 1234)
+        itype.append(3 if keys.pop("force_intra", 0) else 0)
+        cfg = ec.default_cfg(g["width"], g["height"], **keys)
+        enc = C.c_void_p()
+        assert lib.hmr_gpu_enc_create_serial_pool(lib._ctx, C.byref(cfg), C.byref(enc)) == 0, lib.hmr_gpu_last_error()
+        for f, planes in enumerate(ec.clip_frames(g["width"], g["height"], g["frames"], cut_at, seed)):
+            assert lib.hmr_gpu_enc_load_source(enc, f, *planes) == 0, lib.hmr_gpu_last_error()
+        encs.append(enc); frames.append(g["frames"])
+    bufs = [C.create_string_buffer(1 << 20) for _ in cases]
+    out = [b"" for _ in cases]
+    for f in range(max(frames)):
+        live = [i for i in range(len(cases)) if f < frames[i]]
+        n = len(live)
+        got = (C.c_long * n)()
+        assert lib.hmr_gpu_enc_encode_batch((C.c_void_p * n)(*[encs[i] for i in live]), n, (C.c_int * n)(*([f] * n)), (C.c_int * n)(*[itype[i] for i in live]),
+                                            (C.c_char_p * n)(*[C.cast(bufs[i], C.c_char_p) for i in live]), (C.c_long * n)(*[len(bufs[i]) for i in live]), got) == 0, lib.hmr_gpu_last_error()
+        for k, i in enumerate(live):
+            out[i] += bufs[i].raw[:got[k]]
+    for i, case in enumerate(cases):
+        assert hashlib.md5(out[i]).hexdigest() == GOLD[case]["stream_md5"], case
+        decoder_check.check(out[i], GOLD[case], case)
+        lib.hmr_gpu_enc_destroy(encs[i])
+    cfg = ec.default_cfg(416, 240, wpp=4)
+    enc = C.c_void_p()
+    assert lib.hmr_gpu_enc_create_serial_pool(lib._ctx, C.byref(cfg), C.byref(enc)) != 0
+
+
 def test_stale_window_count_is_the_same_frame_by_frame_and_in_a_batch(gpu):
     """hmr_gpu_enc_stale_predictions (quirk Q12: merge candidates evaluated on what the thread's prediction window held) is the API's only indicator that byte identity may
     not hold: the batch call must count a picture once (it used to count it twice) and agree with the frame-by-frame count of the same clip - which has such evaluations."""
