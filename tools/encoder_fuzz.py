@@ -121,6 +121,9 @@ def device(lib, ctx, width, height, frames, clip_seed, keys):
     return units
 
 
+SERIAL_POOL = False      # --serial-batch: one-thread cases as batches through hmr_gpu_enc_create_serial_pool
+
+
 def device_batch(lib, group):
     """the cases of a group advance together: one hmr_gpu_enc_encode_batch call (ONE launch for all their CTU stages) per frame step"""
     lib.hmr_gpu_enc_load_source.argtypes = [C.c_void_p, C.c_int] + [C.c_char_p] * 3
@@ -134,7 +137,7 @@ def device_batch(lib, group):
         cfg = ec.default_cfg(w, h, **keys)
         ctx, enc = C.c_void_p(), C.c_void_p()
         assert lib.hmr_gpu_create(C.byref(ctx), 0, None) == 0, lib.hmr_gpu_last_error()
-        assert lib.hmr_gpu_enc_create(ctx, C.byref(cfg), C.byref(enc)) == 0, lib.hmr_gpu_last_error()
+        assert (lib.hmr_gpu_enc_create_serial_pool if SERIAL_POOL else lib.hmr_gpu_enc_create)(ctx, C.byref(cfg), C.byref(enc)) == 0, lib.hmr_gpu_last_error()
         for f, planes in enumerate(ec.clip_frames(w, h, frames, cut_at, clip_seed)):
             assert lib.hmr_gpu_enc_load_source(enc, f, *planes) == 0, lib.hmr_gpu_last_error()
         encs.append(enc); ctxs.append(ctx); nfr.append(frames)
@@ -331,11 +334,14 @@ def main():
     ap.add_argument("--engines-only", action="store_true", help="only cases with several engines and several WPP threads")
     ap.add_argument("--batch", type=int, default=1, help="with --gpu: this many cases per hmr_gpu_enc_encode_batch call (cases the batch call does not take are left out)")
     ap.add_argument("--tolerate-q12", action="store_true", help="do not count a differing case that had evaluations on a stale prediction window (the documented exception) in the exit code")
+    ap.add_argument("--serial-batch", action="store_true", help="with --gpu --batch N: only cases with one WPP thread and one engine, created with hmr_gpu_enc_create_serial_pool and encoded N per batch call "
+                                                                "(the reference's single-thread order as a batch schedule)")
     ap.add_argument("--decode", action="store_true", help="also decode the reference's stream with oracle/hevcdec and compare the pictures with the reference's own reconstruction")
     ap.add_argument("specs", nargs="*")
     a = ap.parse_args()
-    global DECODE
+    global DECODE, SERIAL_POOL
     DECODE = a.decode
+    SERIAL_POOL = a.serial_batch
     if DECODE:
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "hevcdec")])
     dec_counts = {}
@@ -366,7 +372,13 @@ def main():
     bad = q12_bad = 0
     batched = {}
     if a.gpu and a.batch > 1:       # groups of cases the batch call takes (one thread per CTU row or the in-between counts, one engine) share their launches
-        ok_cases = [c for c in cases if int(c[4].get("wpp", 1)) > 1 and int(c[4].get("engines", 1)) == 1]
+        if a.serial_batch:
+            lib.hmr_gpu_enc_create_serial_pool.argtypes = lib.hmr_gpu_enc_create.argtypes
+            for c in cases:      # (every drawn case becomes a one-thread, one-engine case; RD_FULL under rate control is refused by every entry)
+                c[4].pop("wpp", None); c[4].pop("engines", None)
+                if int(c[4].get("rd", 0)) == 1 and int(c[4].get("bitrate_mode", 0)):
+                    c[4].pop("bitrate_mode"); c[4].pop("bitrate", None)
+        ok_cases = [c for c in cases if a.serial_batch or (int(c[4].get("wpp", 1)) > 1 and int(c[4].get("engines", 1)) == 1)]
         for k in range(0, len(ok_cases), a.batch):
             group = ok_cases[k:k + a.batch]
             units, stale = device_batch(lib, group)
