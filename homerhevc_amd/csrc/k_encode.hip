@@ -147,17 +147,16 @@ static_assert(LDS_BYTES - LDS_RD == 0 && LDS_WORK == 0 && LDS_NODES == 0 && LDS_
 #endif
 
 // a helper wavefront: run the jobs the worker posts (HelperBox, enc_common.h) until it says quit
-__device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
+// one ordinary job of helper h (the one with sequence number seq, which has been posted); false: it was HJOB_QUIT
+__device__ __attribute__((noinline)) bool helper_serve(HelperBox *box, int h, int16_t *scratch, const WaveGrp g, int seq)
 {
-	WaveGrp g{(int)(threadIdx.x & 63)};
 	extern __shared__ __align__(16) uint8_t lds[];
 	Enc &e = *(Enc *)(lds + LDS_OFF_ENC + (1 + h) * LDS_ENC_BYTES);      // (this helper's own context; LDS starts zeroed)
 	HENC_ENC_IN_LDS(e);
 	const Enc &worker = *(const Enc *)(lds + LDS_OFF_ENC);
-	for (int seq = 1;; seq++) {
-		while (__hip_atomic_load(&box->cmd[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) __builtin_amdgcn_s_sleep(1);   // (two workgroups share a CU now: a helper that spins takes issue cycles from the other workgroup's worker on its SIMD)
+	{
 		const int job = box->job[h];
-		if (job == HJOB_QUIT) return;
+		if (job == HJOB_QUIT) return false;
 		if (job == HJOB_NEW_CTU) {
 			wave_copy_words(&e, &worker, (int)sizeof(Enc), g.tid);
 			g.sync();
@@ -253,6 +252,65 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 			__hip_atomic_store(&box->done[h], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 	}
+	return true;
+}
+
+// The background slot (enc_common.h bg_post): the intra mode search of node bg_ni - homer_loop1_motion_intra, as intra_mode_search runs it, without the search log (the
+// pool's schedules do not read it) - every candidate on this wavefront, an ordinary job served before each of them.  false: HJOB_QUIT was among those.
+__device__ __attribute__((noinline)) bool helper_bg_search(HelperBox *box, int h, int16_t *scratch, const WaveGrp g, int &seq, int bgseq)
+{
+	extern __shared__ __align__(16) uint8_t lds[];
+	Enc &e = *(Enc *)(lds + LDS_OFF_ENC + (1 + h) * LDS_ENC_BYTES);
+	HENC_ENC_IN_LDS(e);
+	const int ni = uni(box->bg_ni), depth = uni(box->bg_depth);
+	const Geo &q = e.geo[ni];
+	const int n = q.size, curr_depth = q.depth, inv_depth = CFG_MAX_CU_SHIFT - curr_depth;
+	bool quit = false;
+	int best_mode = 0, bits = -1;
+	double best_cost = 0;
+	if (__hip_atomic_load(&box->bg_cancel, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != bgseq) {
+		node_fill_refs(g, e, ni, depth + 1, COMP_Y, 1);
+		int preds[3], dirs[2];
+		uint16_t src[2];
+		intra_neighbour_dirs(e, ni, curr_depth, dirs, src);
+		mpm_from_dirs(dirs[0], dirs[1], preds);
+		const int rd_fast = e.seq->rd_mode == RDM_FAST ? 1 : 0;
+		const src_t *orig = e.w->curr_y + q.y * CTU_STRIDE_Y + q.x;
+		bits = intra_search_walk(preds, rd_fast, e.f->sqrt_lambda, [&](int mode) -> int64_t {
+			if (__hip_atomic_load(&box->cmd[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == seq) {
+				if (!helper_serve(box, h, scratch, g, seq)) { quit = true; return -1; }
+				seq++;
+			}
+			if (__hip_atomic_load(&box->bg_cancel, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == bgseq) return -1;
+			return (int64_t)intra_predict_sad(g, (pred_t *)nullptr, 0, orig, CTU_STRIDE_Y, intra_is_filtered(mode, inv_depth) ? e.w->adi_f : e.w->adi, n, mode, 1);
+		}, &best_mode, &best_cost);
+	}
+	g.sync();
+	if (g.tid == 0) {
+		box->bg_mode = best_mode;
+		box->bg_bits = bits;
+		__hip_atomic_store(&box->bg_done, bgseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+	return !quit;
+}
+
+__device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
+{
+	WaveGrp g{(int)(threadIdx.x & 63)};
+	int seq = 1, bgseq = 1;
+	for (;;) {
+		if (__hip_atomic_load(&box->cmd[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == seq) {
+			if (!helper_serve(box, h, scratch, g, seq)) return;
+			seq++;
+			continue;
+		}
+		if (NHELP == 1 && __hip_atomic_load(&box->bg_cmd, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == bgseq) {
+			if (!helper_bg_search(box, h, scratch, g, seq, bgseq)) return;
+			bgseq++;
+			continue;
+		}
+		__builtin_amdgcn_s_sleep(1);   // (two workgroups share a CU now: a helper that spins takes issue cycles from the other workgroup's worker on its SIMD)
+	}
 }
 
 // A workgroup is a row worker (wavefront 0) and its two helpers.  rows_enter sets the mailbox up and sends the helper wavefronts into their service loop; it
@@ -325,6 +383,9 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 	e.ctu_fast = LDS_KEEPS_CTU_RECORD ? (CtuPublic *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ) : nullptr;
 	e.box = box;
 	for (int h = 0; h < NHELP; h++) e.hseq[h] = hseq[h];
+	e.bgseq = 0;
+	e.bg_node = -1;
+	e.bg_ok = 0;
 	e.prof = d.prof ? d.prof + (size_t)row * PF_COUNT : nullptr;
 	e.timeline = nullptr;
 	uint32_t *my_prefix = d.prefix + (size_t)row * (W + 1);
@@ -635,6 +696,9 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HEN
 	e.ctu_fast = LDS_KEEPS_CTU_RECORD ? (CtuPublic *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ) : nullptr;
 	e.box = box;
 	for (int h = 0; h < NHELP; h++) e.hseq[h] = 0;
+	e.bgseq = 0;
+	e.bg_node = -1;
+	e.bg_ok = gridDim.x <= 256;      // (a launch of at most one worker per CU - one sequence alone, a short chain: the latency of a CTU counts, the helper's SIMD is otherwise idle)
 	e.prof = nullptr;
 	e.timeline = nullptr;
 	int cached_rem[2] = {-1, -1}, cached_q = -1, idle_rounds = 0;
