@@ -153,7 +153,6 @@ struct Enc {
 	FastPtr<int16_t> scratch_a, scratch_b;   // transform coefficients / rounding remainders of the TU in flight: Work::pred_aux / delta_u, or a helper's own
 	int hseq[NHELP_MAX];
 	int bgseq, bg_node;       // the helper's background intra search (bg_post ... bg_take / bg_quiesce below): jobs posted so far, the node of the one outstanding (-1: none)
-	int bg_ok;                // ... and whether this launch uses it: only where a worker has its CU to itself (k_encode.hip)
 };
 
 // Two helper wavefronts per row worker take the chroma components of a step whose three components are independent (motion compensation, the
@@ -217,7 +216,7 @@ HENC_HD void helper_wait(const G g, Enc &__restrict__ e, int h)
 // looks at its ordinary slot before every candidate); the worker takes mode and bit cost when it gets to the intra evaluation, or cancels.  Device only, one helper.
 // Measured: one sequence alone +5.5 % (a CTU's chain is shorter), a batch of 256 sequences -2 % (the helper runs all thirteen candidates itself, searches are started for CUs
 // that never reach their intra evaluation, and with four workers per CU the helper's instructions are not free) - so a launch uses it only when it has at most one worker
-// per CU (Enc::bg_ok).
+// per CU: the latency kernel k_encode_pool_lat, whose walk is compiled with these hooks (WaveGrpLat, enc_platform.h).
 template <class G>
 HENC_HD void bg_post(const G g, Enc &__restrict__ e, int ni, int depth)
 {

@@ -386,7 +386,7 @@ HENC_HD uint32_t motion_inter_ctu(const G g, Enc &__restrict__ e)
 		double cost = 0, intra_cost = 0;
 		int stop_recursion = 0, is_skipped = 0;
 		const Geo &q = e.geo[curr];
-		if (HENC_HELPERS(e)) bg_quiesce(g, e);      // (a background intra search of the CU before that nobody took: it reads the partition nodes, which the next line may replace)
+		if constexpr (G::bg) bg_quiesce(g, e);      // (a background intra search of the CU before that nobody took: it reads the partition nodes, which the next line may replace)
 		if (q.depth >= 1) nodes_select_quad(g, e, q.abs_index >> 6);
 		Node &nd = node_of(e, curr);
 		curr_depth = q.depth;
@@ -426,8 +426,8 @@ HENC_HD uint32_t motion_inter_ctu(const G g, Enc &__restrict__ e)
 				}
 				// the intra evaluation below starts with a mode search that depends on nothing the motion search and the inter transform tree change: the helper
 				// starts on it now (enc_common.h bg_post), for the CU sizes whose intra evaluation does not depend on the motion search's SAD
-				if (HENC_HELPERS(e) && NHELP == 1 && e.bg_ok && perf_fast_skip && curr_depth >= perf_min_depth && !is_skipped && q.size < 32 && S.rd_mode != RDM_FULL && e.f->lockstep)
-					bg_post(g, e, curr, curr_depth);
+				if constexpr (G::bg)
+					if (NHELP == 1 && perf_fast_skip && curr_depth >= perf_min_depth && !is_skipped && q.size < 32 && S.rd_mode != RDM_FULL && e.f->lockstep) bg_post(g, e, curr, curr_depth);
 				if (curr_depth >= perf_min_depth) {
 					if (!is_skipped) sad = (uint32_t)cu_motion_estimation(g, e, curr_depth, position, PART_2Nx2N, action);   // timed inside (PF_ME_INT / PF_ME_SUB)
 					if (!is_skipped && (q.size < 64 || sad < 100u * num_part_in_cu)) {
@@ -556,7 +556,7 @@ HENC_HD uint32_t motion_inter_ctu(const G g, Enc &__restrict__ e)
 		}
 		if (parent >= 0) curr = e.geo[parent].child[depth_state.get(curr_depth)];
 	}
-	if (HENC_HELPERS(e)) bg_quiesce(g, e);
+	if constexpr (G::bg) bg_quiesce(g, e);
 	return node_of(e, root).cost;
 }
 

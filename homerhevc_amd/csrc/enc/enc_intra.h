@@ -280,7 +280,9 @@ HENC_WALK_FN HENC_HD uint32_t encode_intra_luma(const G g, Enc &__restrict__ e, 
 		HENC_PROF_T0();
 		// (the P-slice walk may have had the helper run this search under the CU's inter evaluation: enc_common.h bg_post; a search of another node is stopped first - the
 		// neighbour arrays it fills are the ones the search here and the TUs below use)
-		if (HENC_HELPERS(e) && bg_take(g, e, top_ni, &cu_mode, &bitcost_cu_mode)) { search_cost = 0; e.last_slog = -1; }
+		bool taken = false;
+		if constexpr (G::bg) taken = bg_take(g, e, top_ni, &cu_mode, &bitcost_cu_mode);
+		if (taken) { search_cost = 0; e.last_slog = -1; }
 		else bitcost_cu_mode = intra_mode_search(g, e, top_ni, depth, &cu_mode, &search_cost);
 		HENC_PROF_ADD(e, PF_INTRA_SEARCH);
 	}

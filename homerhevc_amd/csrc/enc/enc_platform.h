@@ -48,6 +48,7 @@ namespace henc {
 struct WaveGrp {
 	int tid;
 	static constexpr int n = 64;
+	static constexpr bool bg = false;      // (WaveGrpLat: the walk of the latency kernel, whose helper runs background intra searches - enc_common.h bg_post)
 	// the group is ONE wavefront: its lanes run in lockstep, so ordering its own memory operations is all a "barrier" has to do (the workgroup may hold
 	// helper wavefronts that are doing something else, see HelperBox in enc_common.h)
 	__device__ __forceinline__ void sync() const
@@ -85,6 +86,11 @@ struct WaveGrp {
 		return v;
 	}
 };
+// the same wavefront as the group of the latency kernel's walk (k_encode_pool_lat): a type of its own, so that the walk is compiled a second time WITH the background-search
+// hooks and the throughput kernel's code stays exactly what it was (a batch pays for every instruction the hooks add: -1.3 % when both kernels shared the walk)
+struct WaveGrpLat : WaveGrp {
+	static constexpr bool bg = true;
+};
 
 // Two groups of 32 lanes in one wavefront, each with a block of its own (the helper's two chroma planes of a small TU: a 4 x 4 or 8 x 8 chain keeps 4 - 16 lanes busy,
 // and two of them one after the other made the helper the slower side of a small CU).  The halves run the same code on different operands; where their control flow
@@ -93,6 +99,7 @@ struct WaveGrp {
 struct PairGrp {
 	int tid, half;           // lane within the half, the half (0 / 1)
 	static constexpr int n = 32;
+	static constexpr bool bg = false;
 	__device__ __forceinline__ void sync() const
 	{
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -221,6 +228,7 @@ struct LdsAt {
 struct CpuGrp {
 	static constexpr int tid = 0;
 	static constexpr int n = 1;
+	static constexpr bool bg = false;
 	void sync() const {}
 	uint32_t sum(uint32_t v) const { return v; }
 	int64_t sum64(int64_t v) const { return v; }

@@ -28,6 +28,7 @@
 #include <thread>
 #include <vector>
 
+#include <type_traits>
 #include "common.h"
 #include "enc/enc_sched.h"
 #include "enc/enc_host.h"
@@ -148,7 +149,7 @@ static_assert(LDS_BYTES - LDS_RD == 0 && LDS_WORK == 0 && LDS_NODES == 0 && LDS_
 
 // a helper wavefront: run the jobs the worker posts (HelperBox, enc_common.h) until it says quit
 // one ordinary job of helper h (the one with sequence number seq, which has been posted); false: it was HJOB_QUIT
-__device__ __attribute__((noinline)) bool helper_serve(HelperBox *box, int h, int16_t *scratch, const WaveGrp g, int seq)
+__device__ __forceinline__ bool helper_serve(HelperBox *box, int h, int16_t *scratch, const WaveGrp g, int seq)
 {
 	extern __shared__ __align__(16) uint8_t lds[];
 	Enc &e = *(Enc *)(lds + LDS_OFF_ENC + (1 + h) * LDS_ENC_BYTES);      // (this helper's own context; LDS starts zeroed)
@@ -255,6 +256,9 @@ __device__ __attribute__((noinline)) bool helper_serve(HelperBox *box, int h, in
 	return true;
 }
 
+// (the latency kernel's copy, out of line: its loop and its background search both call it)
+__device__ __attribute__((noinline)) bool helper_serve_out(HelperBox *box, int h, int16_t *scratch, const WaveGrp g, int seq) { return helper_serve(box, h, scratch, g, seq); }
+
 // The background slot (enc_common.h bg_post): the intra mode search of node bg_ni - homer_loop1_motion_intra, as intra_mode_search runs it, without the search log (the
 // pool's schedules do not read it) - every candidate on this wavefront, an ordinary job served before each of them.  false: HJOB_QUIT was among those.
 __device__ __attribute__((noinline)) bool helper_bg_search(HelperBox *box, int h, int16_t *scratch, const WaveGrp g, int &seq, int bgseq)
@@ -278,7 +282,7 @@ __device__ __attribute__((noinline)) bool helper_bg_search(HelperBox *box, int h
 		const src_t *orig = e.w->curr_y + q.y * CTU_STRIDE_Y + q.x;
 		bits = intra_search_walk(preds, rd_fast, e.f->sqrt_lambda, [&](int mode) -> int64_t {
 			if (__hip_atomic_load(&box->cmd[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == seq) {
-				if (!helper_serve(box, h, scratch, g, seq)) { quit = true; return -1; }
+				if (!helper_serve_out(box, h, scratch, g, seq)) { quit = true; return -1; }
 				seq++;
 			}
 			if (__hip_atomic_load(&box->bg_cancel, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == bgseq) return -1;
@@ -294,13 +298,23 @@ __device__ __attribute__((noinline)) bool helper_bg_search(HelperBox *box, int h
 	return !quit;
 }
 
-__device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
+// LAT: the kernel of launches with at most one worker per CU (k_encode_pool_lat), whose helpers also run the background search; the throughput kernel keeps the plain
+// loop (the out-of-line dispatch and the second poll cost a batch 8 % when both kernels shared one loop - the code the helper wavefronts run counts: two CUs share an
+// instruction cache)
+template <bool LAT>
+__device__ __attribute__((noinline)) void helper_loop(HelperBox *box, int h, int16_t *scratch)      // (out of line, as it was before it became a template: inlined it costs the kernel 38 spilled registers)
 {
 	WaveGrp g{(int)(threadIdx.x & 63)};
+	if constexpr (!LAT) {
+		for (int seq = 1;; seq++) {
+			while (__hip_atomic_load(&box->cmd[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) __builtin_amdgcn_s_sleep(1);   // (two workgroups share a CU now: a helper that spins takes issue cycles from the other workgroup's worker on its SIMD)
+			if (!helper_serve(box, h, scratch, g, seq)) return;
+		}
+	}
 	int seq = 1, bgseq = 1;
 	for (;;) {
 		if (__hip_atomic_load(&box->cmd[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == seq) {
-			if (!helper_serve(box, h, scratch, g, seq)) return;
+			if (!helper_serve_out(box, h, scratch, g, seq)) return;
 			seq++;
 			continue;
 		}
@@ -315,6 +329,7 @@ __device__ void helper_loop(HelperBox *box, int h, int16_t *scratch)
 
 // A workgroup is a row worker (wavefront 0) and its two helpers.  rows_enter sets the mailbox up and sends the helper wavefronts into their service loop; it
 // returns true on the worker only.  release_helpers lets them go (without it the workgroup never ends).
+template <bool LAT = false>
 __device__ __forceinline__ bool rows_enter(unsigned lds_bytes)
 {
 	extern __shared__ __align__(16) uint8_t lds[];
@@ -324,7 +339,7 @@ __device__ __forceinline__ bool rows_enter(unsigned lds_bytes)
 	for (int i = (int)threadIdx.x; i < (int)(lds_bytes / 4); i += ENC_THREADS) ((uint32_t *)lds)[i] = 0;
 	__syncthreads();
 	if (wave > 0) {
-		helper_loop(box, wave - 1, (int16_t *)(lds + LDS_WORK + LDS_NODES) + (wave - 1) * HSCRATCH_ELEMS);
+		helper_loop<LAT>(box, wave - 1, (int16_t *)(lds + LDS_WORK + LDS_NODES) + (wave - 1) * HSCRATCH_ELEMS);
 		return false;
 	}
 	return true;
@@ -385,7 +400,6 @@ __device__ __forceinline__ void encode_row(const EncDev &d, int pass, int row, i
 	for (int h = 0; h < NHELP; h++) e.hseq[h] = hseq[h];
 	e.bgseq = 0;
 	e.bg_node = -1;
-	e.bg_ok = 0;
 	e.prof = d.prof ? d.prof + (size_t)row * PF_COUNT : nullptr;
 	e.timeline = nullptr;
 	uint32_t *my_prefix = d.prefix + (size_t)row * (W + 1);
@@ -495,7 +509,8 @@ __device__ __forceinline__ void pool_step_rows(int t, int W, int H, int *r_lo, i
 	*r_hi = (t >> 1) < H - 1 ? (t >> 1) : H - 1;
 }
 
-__device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const WaveGrp g, Seq *lseq, FrameCtx *lframe, FastTables *lft, int t, int row, int *cached_rem, const int *abort_flag)
+template <class G>
+__device__ void pool_encode_ctu(const EncDev &d, Enc &__restrict__ e, const G g, Seq *lseq, FrameCtx *lframe, FastTables *lft, int t, int row, int *cached_rem, const int *abort_flag)
 {
 	HENC_ENC_IN_LDS(e);
 	const Seq &S = *lseq;
@@ -662,14 +677,15 @@ __device__ __attribute__((noinline)) int pool_post_drain_run(const EncDev &d, co
 	return ran;
 }
 
-__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HENC_WAVES_PER_EU))) void k_encode_pool(const EncDev *devs, int nseq, int *state, int *finished, WorkSlow *slow, unsigned long long watchdog_ticks, unsigned lds_bytes)
+template <bool LAT>
+__device__ __forceinline__ void encode_pool_body(const EncDev *devs, int nseq, int *state, int *finished, WorkSlow *slow, unsigned long long watchdog_ticks, unsigned lds_bytes)
 {
 	// finished[0]: pictures whose last task is done; finished[1]: abort - a worker has waited longer than the watchdog allows (a faulted or starved peer): everybody
 	// leaves and the host reports an error instead of the launch hanging
 	unsigned long long t_start = wall_clock64();      // when this worker last had something to do (the watchdog's clock)
-	if (!rows_enter(lds_bytes)) return;
+	if (!rows_enter<LAT>(lds_bytes)) return;
 	extern __shared__ __align__(16) uint8_t lds[];
-	WaveGrp g{(int)(threadIdx.x & 63)};
+	typename std::conditional<LAT, WaveGrpLat, WaveGrp>::type g{(int)(threadIdx.x & 63)};      // (the latency kernel's walk is an instantiation of its own: enc_platform.h)
 	Work *lw = (Work *)lds;
 	HelperBox *box = (HelperBox *)(lds + LDS_WORK + LDS_NODES + LDS_GEO + LDS_SEQ + LDS_CTU);
 	Seq *lseq = (Seq *)(lds + LDS_WORK + LDS_NODES + LDS_GEO);
@@ -698,7 +714,6 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HEN
 	for (int h = 0; h < NHELP; h++) e.hseq[h] = 0;
 	e.bgseq = 0;
 	e.bg_node = -1;
-	e.bg_ok = gridDim.x <= 256;      // (a launch of at most one worker per CU - one sequence alone, a short chain: the latency of a CTU counts, the helper's SIMD is otherwise idle)
 	e.prof = nullptr;
 	e.timeline = nullptr;
 	int cached_rem[2] = {-1, -1}, cached_q = -1, idle_rounds = 0;
@@ -838,6 +853,15 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HEN
 	int hseq[NHELP];
 	for (int h = 0; h < NHELP; h++) hseq[h] = e.hseq[h];
 	release_helpers(hseq);
+}
+// the throughput kernel (many pictures, four workers per CU) and the latency kernel (at most one worker per CU: the helpers also run the background intra search)
+__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HENC_WAVES_PER_EU))) void k_encode_pool(const EncDev *devs, int nseq, int *state, int *finished, WorkSlow *slow, unsigned long long watchdog_ticks, unsigned lds_bytes)
+{
+	encode_pool_body<false>(devs, nseq, state, finished, slow, watchdog_ticks, lds_bytes);
+}
+__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(HENC_WAVES_PER_EU))) void k_encode_pool_lat(const EncDev *devs, int nseq, int *state, int *finished, WorkSlow *slow, unsigned long long watchdog_ticks, unsigned lds_bytes)
+{
+	encode_pool_body<true>(devs, nseq, state, finished, slow, watchdog_ticks, lds_bytes);
 }
 
 // the true chains in raster order: threads 0..255 one unit column of the mode buffers each, thread 256 the intra counter

@@ -23,7 +23,9 @@ def test_encoder_kernel_private_memory_budget(tmp_path):
         name = blk.split()[0]
         f = {k: int(v) for k, v in re.findall(r"(ScratchSize \[bytes/lane\]|VGPRs Spill|VGPRs): (\d+)", blk)}
         seen[name] = f
-    pool = next(v for k, v in seen.items() if "k_encode_pool" in k)
+    pools = [v for k, v in seen.items() if "k_encode_pool" in k]      # the throughput kernel and the latency kernel (k_encode_pool_lat)
+    assert len(pools) == 2
+    pool = max(pools, key=lambda v: v["ScratchSize [bytes/lane]"])
     # round 4: 2080 bytes and 53 spilled registers; round 5's last build: 760 and 1
     assert pool["ScratchSize [bytes/lane]"] <= 1024, pool
     assert pool["VGPRs Spill"] <= 8, pool
