@@ -55,7 +55,12 @@ def main():
                 d["valu_share_of_issue"] = round(k.get("SQ_INSTS_VALU", 0) / max(k.get("SQ_INSTS_VALU", 0) + k.get("SQ_INSTS_SALU", 0), 1), 3)
         k["derived"] = d
     if frames:
-        kernels["frames_encoded_by_k_encode_pool"] = frames
+        # (`frames` counts every picture the command encodes; those of launches with at most one worker per CU - one picture each here - go through the latency kernel
+        # k_encode_pool_lat and are not k_encode_pool's)
+        lat = kernels.get("k_encode_pool_lat", {}).get("launches", 0)      # (launches of ONE pass, as every count in this summary)
+        kernels["frames_encoded_by_k_encode_pool"] = frames - lat
+        if lat:
+            kernels["frames_encoded_by_k_encode_pool_lat"] = lat
     try:      # the build the passes ran on (the tree the GPU box was given: HEAD when the working tree is clean)
         import subprocess
         kernels["build_commit"] = subprocess.run(["git", "-C", os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
